@@ -1,0 +1,640 @@
+/* TEST INFRASTRUCTURE ONLY -- see grdma_oracle.h for the rules.
+ *
+ * Plain-C restatement of the reference's CPU algorithms on the RDMA_BP/BPEV
+ * endpoint hot path.  Parity is pinned against the reference-built
+ * oracle/_ref/libref_ring.so and the golden vectors under tests/golden/.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "grdma_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ===================================================================== ring */
+
+uint64_t orc_round_up8(uint64_t v) { /* ring_buffer.h:232-237 */
+  return (v % ORC_ALIGN == 0) ? v : v - v % ORC_ALIGN + ORC_ALIGN;
+}
+
+uint64_t orc_round_down8(uint64_t v) { /* ring_buffer.h:240-245 */
+  return v - v % ORC_ALIGN;
+}
+
+uint64_t orc_encoded_size(uint64_t payload) { /* ring_buffer.h:180-183 */
+  return 2u * ORC_ALIGN + orc_round_up8(payload);
+}
+
+uint64_t orc_calc_writable(uint64_t space) { /* ring_buffer.h:185-189 */
+  int64_t fr = (int64_t)space - (int64_t)ORC_RESERVED;
+  if (fr < 0) fr = 0;
+  return orc_round_down8((uint64_t)fr);
+}
+
+static uint64_t ld64(const uint8_t* p) {
+  uint64_t v;
+  memcpy(&v, p, 8);
+  return v; /* native little-endian, ring_buffer.h:84-87 */
+}
+static void st64(uint8_t* p, uint64_t v) { memcpy(p, &v, 8); }
+
+int orc_ring_init(orc_ring* r, uint8_t* buf, uint64_t cap) {
+  /* ring_buffer.cc:20-25: power of two, larger than the reserved space */
+  if ((cap & (cap - 1)) != 0 || cap <= ORC_RESERVED) return -1;
+  r->buf = buf;
+  r->cap = cap;
+  r->mask = cap - 1;
+  memset(buf, 0, cap); /* Init(), ring_buffer.cc:49-54 */
+  r->head = r->moving_head = r->remain = 0;
+  return 0;
+}
+
+int orc_ring_has_message(const orc_ring* r) { /* ring_buffer.cc:56-65 */
+  if (r->remain > 0) return 1;
+  return ld64(r->buf + r->head) > 0;
+}
+
+uint64_t orc_ring_readable(const orc_ring* r) { /* ring_buffer.cc:67-97 */
+  if (r->remain > 0) return r->remain;
+  uint64_t size = ld64(r->buf + r->head);
+  if (size == 0) return 0;
+  /* The reference spins ("goto retry") on an oversized header, treating it as
+   * a torn read.  A static snapshot cannot change, so report "not ready". */
+  if (size > r->cap - ORC_RESERVED) return 0;
+  uint64_t foot = (r->head + ORC_ALIGN + orc_round_up8(size)) & r->mask;
+  return ld64(r->buf + foot) == ORC_FOOTER ? size : 0;
+}
+
+uint64_t orc_ring_free_size(const orc_ring* r, uint64_t head, uint64_t tail) {
+  uint64_t occupied = (tail + r->cap - head) & r->mask; /* ring_buffer.cc:99-104 */
+  return r->cap - occupied;
+}
+
+uint64_t orc_ring_writable(const orc_ring* r, uint64_t head, uint64_t tail) {
+  uint64_t remaining = orc_ring_free_size(r, head, tail); /* ring_buffer.cc:106-116 */
+  return remaining > ORC_RESERVED ? remaining - ORC_RESERVED : 0;
+}
+
+uint64_t orc_ring_read(orc_ring* r, void* dst, uint64_t cap, uint64_t* internal) {
+  /* ring_buffer.cc:122-191 */
+  uint64_t readable = orc_ring_readable(r);
+  uint64_t copy = readable < cap ? readable : cap;
+  uint64_t prev_moving = r->moving_head;
+  if (copy == 0) {
+    if (internal) *internal = 0;
+    return 0;
+  }
+  if (r->remain == 0) { /* opening a record: :133-146 */
+    r->moving_head = (r->head + ORC_ALIGN) & r->mask;
+    st64(r->buf + r->head, 0); /* clear header */
+    r->head = (r->head + 2u * ORC_ALIGN + orc_round_up8(readable)) & r->mask;
+  }
+  uint64_t end = (r->moving_head + copy) & r->mask;
+  uint64_t seg1, seg2 = 0;
+  if (r->moving_head < end) {
+    seg1 = copy;
+  } else { /* circular case :153-156 */
+    seg2 = end;
+    seg1 = copy - seg2;
+  }
+  memcpy(dst, r->buf + r->moving_head, seg1);
+  memset(r->buf + r->moving_head, 0, seg1);
+  if (seg2 > 0) {
+    memcpy((uint8_t*)dst + seg1, r->buf, seg2);
+    memset(r->buf, 0, seg2);
+  }
+  r->moving_head = (r->moving_head + copy) & r->mask;
+  r->remain = readable - copy;
+  if (r->remain == 0) { /* record finished: :169-182 */
+    for (uint64_t pos = r->moving_head; pos < orc_round_up8(r->moving_head); pos++)
+      r->buf[pos & r->mask] = 0;
+    r->moving_head = orc_round_up8(r->moving_head) & r->mask;
+    st64(r->buf + r->moving_head, 0); /* clear footer */
+    r->moving_head = (r->moving_head + ORC_ALIGN) & r->mask;
+  }
+  if (internal) *internal = (r->moving_head + r->cap - prev_moving) & r->mask;
+  return copy;
+}
+
+uint64_t orc_ring_write(orc_ring* r, uint64_t tail, const void* src, uint64_t n) {
+  /* ring_buffer.cc:193-226 */
+  if (n == 0) return tail;
+  st64(r->buf + tail, n);
+  tail = (tail + ORC_ALIGN) & r->mask;
+  uint64_t end = (tail + n) & r->mask;
+  uint64_t seg1 = (tail < end) ? n : n - end;
+  memcpy(r->buf + tail, src, seg1);
+  if (n - seg1 > 0) memcpy(r->buf, (const uint8_t*)src + seg1, n - seg1);
+  tail = (tail + orc_round_up8(n)) & r->mask;
+  st64(r->buf + tail, ORC_FOOTER);
+  return (tail + ORC_ALIGN) & r->mask;
+}
+
+/* ===================================================================== pair */
+
+uint64_t orc_plan_send(uint64_t ring_cap, uint64_t staging_cap, uint64_t remote_head,
+                       uint64_t remote_tail, int max_sge, const uint64_t* lens,
+                       uint64_t n, uint64_t byte_idx, uint64_t* pays,
+                       uint64_t* sent) {
+  /* pair.cc:671-707, the arithmetic only */
+  uint64_t mask = ring_cap - 1, st = 0, total = 0, k = 0;
+  for (uint64_t i = 0; i < n && (int64_t)k < (int64_t)max_sge; i++) {
+    uint64_t len = lens[i] - byte_idx;
+    byte_idx = 0;
+    uint64_t occupied = (remote_tail + ring_cap - remote_head) & mask;
+    uint64_t recv_free = ring_cap - occupied;
+    uint64_t send_free = staging_cap - st;
+    uint64_t a = orc_calc_writable(send_free), b = orc_calc_writable(recv_free);
+    uint64_t pay = len;
+    if (a < pay) pay = a;
+    if (b < pay) pay = b;
+    if (pay == 0) break;
+    uint64_t enc = orc_encoded_size(pay);
+    pays[k++] = pay;
+    total += pay;
+    st += enc;
+    remote_tail = (remote_tail + enc) & mask;
+  }
+  if (sent) *sent = total;
+  return k;
+}
+
+int orc_pair_init(orc_pair* p, uint64_t ring_cap, int max_sge) {
+  memset(p, 0, sizeof(*p));
+  uint8_t* buf = (uint8_t*)malloc(ring_cap);
+  if (!buf || orc_ring_init(&p->ring, buf, ring_cap) != 0) {
+    free(buf);
+    return -1;
+  }
+  p->staging_cap = ring_cap / 2; /* pair.cc:104 */
+  p->staging = (uint8_t*)calloc(1, p->staging_cap);
+  p->max_sge = max_sge;
+  return p->staging ? 0 : -1;
+}
+
+void orc_pair_destroy(orc_pair* p) {
+  free(p->ring.buf);
+  free(p->staging);
+  memset(p, 0, sizeof(*p));
+}
+
+void orc_pair_connect(orc_pair* a, orc_pair* b) {
+  a->peer = b;
+  b->peer = a;
+}
+
+uint64_t orc_pair_writable(const orc_pair* p) { /* pair.cc:294-301 */
+  return orc_ring_writable(&p->peer->ring, p->status_recv.remote_head, p->remote_tail);
+}
+
+uint64_t orc_pair_send(orc_pair* p, const orc_slice* slices, uint64_t n,
+                       uint64_t byte_idx) {
+  /* pair.cc:645-734 */
+  orc_ring* rr = &p->peer->ring;
+  uint64_t remote_head = p->status_recv.remote_head; /* pair.h:229-233 */
+  uint64_t remote_tail = p->remote_tail;
+  uint64_t st = 0, total = 0, written = 0, k = 0;
+  /* wrap bookkeeping of GetWriteRequests(sg_list), ring_buffer.cc:261-330 */
+  int64_t split = -1;
+  uint64_t seg1 = 0, seg2 = 0, before_split = 0;
+
+  for (uint64_t i = 0; i < n; i++) total += slices[i].len;
+  total -= byte_idx;
+
+  for (uint64_t i = 0; i < n && (int64_t)k < (int64_t)p->max_sge; i++) {
+    const uint8_t* ptr = slices[i].ptr + byte_idx;
+    uint64_t len = slices[i].len - byte_idx;
+    byte_idx = 0;
+    uint64_t recv_free = orc_ring_free_size(rr, remote_head, remote_tail);
+    uint64_t send_free = p->staging_cap - st;
+    uint64_t a = orc_calc_writable(send_free), b = orc_calc_writable(recv_free);
+    uint64_t pay = len;
+    if (a < pay) pay = a;
+    if (b < pay) pay = b;
+    if (pay == 0) break;
+    uint64_t enc = orc_encoded_size(pay);
+    /* AppendHeader / AppendPayload / AppendFooter, ring_buffer.h:84-99: the
+     * padding bytes are skipped, not written. */
+    st64(p->staging + st, pay);
+    memcpy(p->staging + st + ORC_ALIGN, ptr, pay);
+    st64(p->staging + st + ORC_ALIGN + orc_round_up8(pay), ORC_FOOTER);
+    uint64_t next_tail = (remote_tail + enc) & rr->mask;
+    if (remote_tail > next_tail && split < 0) { /* ring_buffer.cc:276-283 */
+      split = (int64_t)k;
+      seg2 = next_tail;
+      seg1 = enc - seg2;
+      before_split = st;
+    }
+    st += enc;
+    written += pay;
+    remote_tail = next_tail;
+    k++;
+  }
+  p->partial_write = written < total; /* pair.cc:709 */
+  p->staging_used = st;
+  p->wr_count = 0;
+  if (k > 0) {
+    /* Execute the (at most two) RDMA WRITE work requests in order. */
+    if (split >= 0) {
+      uint64_t n0 = before_split + seg1, n1 = st - n0;
+      memcpy(rr->buf + p->remote_tail, p->staging, n0);
+      if (n1) memcpy(rr->buf, p->staging + n0, n1);
+      p->wr[0][0] = p->remote_tail; p->wr[0][1] = n0;
+      p->wr[1][0] = 0;              p->wr[1][1] = n1;
+      p->wr_count = 2;
+    } else {
+      memcpy(rr->buf + p->remote_tail, p->staging, st);
+      p->wr[0][0] = p->remote_tail; p->wr[0][1] = st;
+      p->wr_count = 1;
+    }
+    p->remote_tail = remote_tail;
+  }
+  return written;
+}
+
+uint64_t orc_pair_recv(orc_pair* p, void* dst, uint64_t cap) {
+  /* pair.cc:264-286 */
+  uint64_t internal = 0;
+  uint64_t n = orc_ring_read(&p->ring, dst, cap, &internal);
+  p->internal_read_size += internal;
+  if (p->internal_read_size >= p->ring.cap / 2) {
+    p->status_send.remote_head = p->ring.moving_head; /* get_head(), .cc:334 */
+    p->peer->status_recv = p->status_send;            /* updateStatus(), pair.cc:624-641 */
+    p->credit_msgs++;
+    p->internal_read_size = 0;
+  }
+  return n;
+}
+
+uint64_t orc_endpoint_read(orc_pair* p, uint8_t* dst, uint64_t* alloc_out) {
+  /* rdma_bp_posix.cc:306-326: a fresh slice of max(256, readable) is allocated
+   * only when incoming_buffer is empty; otherwise the unfilled tail retained in
+   * last_read_buffer (:283-287, :350-351) is the read target. */
+  uint64_t readable = orc_ring_readable(&p->ring);
+  uint64_t alloc = p->leftover_cap;
+  if (alloc == 0) alloc = readable > 256 ? readable : 256;
+  if (alloc_out) *alloc_out = alloc;
+  uint64_t total = 0;
+  for (;;) { /* rdma_do_read loop :195-277 */
+    uint64_t n = orc_pair_recv(p, dst + total, alloc - total);
+    if (n == 0) break;
+    total += n;
+    if (total == alloc) break;
+  }
+  if (total == 0) { /* would block: the slice stays in incoming_buffer */
+    p->leftover_cap = alloc;
+    return 0;
+  }
+  p->leftover_cap = alloc - total; /* grpc_slice_buffer_trim_end → last_read_buffer */
+  return total;
+}
+
+/* ================================================================ HTTP/2 TX */
+
+void orc_grpc_msg_header(uint8_t out[5], int compressed, uint32_t len) {
+  /* chttp2_transport.cc:1502-1510 */
+  out[0] = compressed ? 1 : 0;
+  out[1] = (uint8_t)(len >> 24);
+  out[2] = (uint8_t)(len >> 16);
+  out[3] = (uint8_t)(len >> 8);
+  out[4] = (uint8_t)len;
+}
+
+void orc_h2_data_header(uint8_t out[9], uint32_t len, int end_stream, uint32_t id) {
+  /* frame_data.cc:73-82 */
+  out[0] = (uint8_t)(len >> 16);
+  out[1] = (uint8_t)(len >> 8);
+  out[2] = (uint8_t)len;
+  out[3] = ORC_H2_FRAME_DATA;
+  out[4] = end_stream ? ORC_H2_FLAG_END_STREAM : 0;
+  out[5] = (uint8_t)(id >> 24);
+  out[6] = (uint8_t)(id >> 16);
+  out[7] = (uint8_t)(id >> 8);
+  out[8] = (uint8_t)id;
+}
+
+/* A slice buffer modelled as (length, inlined?) entries; bytes live in the
+ * flat wire image because concatenation order is all that the ring sees. */
+typedef struct sbuf {
+  uint64_t* lens;
+  uint8_t* inl;
+  uint64_t count, cap;
+  int overflow;
+} sbuf;
+
+static void sb_add_indexed(sbuf* sb, uint64_t len, int inlined) {
+  /* grpc_slice_buffer_add_indexed, slice_buffer.cc:127-134 */
+  if (sb->count >= sb->cap) {
+    sb->overflow = 1;
+    return;
+  }
+  sb->lens[sb->count] = len;
+  sb->inl[sb->count] = (uint8_t)inlined;
+  sb->count++;
+}
+
+static void sb_add(sbuf* sb, uint64_t len, int inlined) {
+  /* grpc_slice_buffer_add, slice_buffer.cc:136-171 */
+  if (inlined && sb->count > 0) {
+    uint64_t b = sb->count - 1;
+    if (sb->inl[b] && sb->lens[b] < ORC_SLICE_INLINED_SIZE) {
+      if (len + sb->lens[b] <= ORC_SLICE_INLINED_SIZE) {
+        sb->lens[b] += len;
+      } else {
+        uint64_t cp1 = ORC_SLICE_INLINED_SIZE - sb->lens[b];
+        sb->lens[b] = ORC_SLICE_INLINED_SIZE;
+        sb_add_indexed(sb, len - cp1, 1);
+      }
+      return;
+    }
+  }
+  sb_add_indexed(sb, len, inlined);
+}
+
+int64_t orc_h2_frame_message(const uint8_t* msg, uint64_t msg_len, int compressed,
+                             uint32_t stream_id, uint32_t max_frame, int end_stream,
+                             uint8_t* wire, uint64_t wire_cap, uint64_t* wire_len,
+                             uint64_t* lens, uint64_t lens_cap) {
+  /* flow_controlled_buffer after perform_stream_op_locked: [inlined 5][msg] */
+  struct { uint64_t len; int inl; } fcb[2];
+  int fcb_n = 0, fcb_i = 0;
+  fcb[fcb_n].len = 5; fcb[fcb_n].inl = 1; fcb_n++;
+  if (msg_len > 0) { fcb[fcb_n].len = msg_len; fcb[fcb_n].inl = 0; fcb_n++; }
+  uint64_t fcb_len = 5 + msg_len;
+
+  uint8_t* inl = (uint8_t*)malloc(lens_cap ? lens_cap : 1);
+  if (!inl) return -1;
+  sbuf out = {lens, inl, 0, lens_cap, 0};
+  uint64_t w = 0, src_off = 0; /* src_off: bytes of [hdr5|msg] already moved */
+  uint8_t hdr5[5];
+  orc_grpc_msg_header(hdr5, compressed, (uint32_t)msg_len);
+
+  while (fcb_len > 0) {
+    /* DataSendContext::FlushUncompressedBytes, writing.cc:344-355 (windows are
+     * assumed open: flow control is out of scope) */
+    uint64_t send = fcb_len < max_frame ? fcb_len : max_frame;
+    int is_last = end_stream && send == fcb_len;
+    if (w + 9 + send > wire_cap) { free(inl); return -1; }
+    orc_h2_data_header(wire + w, (uint32_t)send, is_last, stream_id);
+    w += 9;
+    sb_add(&out, 9, 1); /* GRPC_SLICE_MALLOC(9) is an inlined slice */
+    /* bytes */
+    for (uint64_t i = 0; i < send; i++) {
+      uint64_t o = src_off + i;
+      wire[w + i] = o < 5 ? hdr5[o] : msg[o - 5];
+    }
+    w += send;
+    src_off += send;
+    /* grpc_slice_buffer_move_first_no_ref(inbuf, send, outbuf), slice_buffer.cc:270-313 */
+    uint64_t n = send;
+    if (fcb_len == n) { /* move_into → grpc_slice_buffer_add for each slice */
+      for (; fcb_i < fcb_n; fcb_i++) sb_add(&out, fcb[fcb_i].len, fcb[fcb_i].inl);
+    } else {
+      while (fcb_i < fcb_n) {
+        uint64_t sl = fcb[fcb_i].len;
+        if (n > sl) {
+          sb_add(&out, sl, fcb[fcb_i].inl);
+          n -= sl;
+          fcb_i++;
+        } else if (n == sl) {
+          sb_add(&out, sl, fcb[fcb_i].inl);
+          fcb_i++;
+          break;
+        } else { /* split: head goes in un-merged (add_indexed), tail stays */
+          sb_add_indexed(&out, n, fcb[fcb_i].inl);
+          fcb[fcb_i].len = sl - n;
+          break;
+        }
+      }
+    }
+    fcb_len -= send;
+  }
+  free(inl);
+  if (out.overflow) return -1;
+  *wire_len = w;
+  return (int64_t)out.count;
+}
+
+/* ================================================================ HTTP/2 RX */
+
+static const char kClientPrefix[] = "PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n"; /* internal.h:781 */
+enum { ST_FH0 = 24, ST_FH8 = 32, ST_FRAME = 33 };
+enum { PARSER_SKIP = 0, PARSER_DATA = 1 };
+
+void orc_h2_parser_init(orc_h2_parser* p, int expect_client_prefix, uint32_t max_frame_size) {
+  memset(p, 0, sizeof(*p));
+  p->state = expect_client_prefix ? 0 : ST_FH0; /* chttp2_transport.cc: server starts at PREFIX_0 */
+  p->max_frame_size = max_frame_size;           /* http2_settings.cc:56 default 16384 */
+  p->check_frame_size = 1;
+}
+
+static orc_grpc_deframer* find_stream(orc_h2_parser* p, uint32_t id) {
+  for (int i = 0; i < p->nstreams; i++)
+    if (p->streams[i].stream_id == id) return &p->streams[i];
+  if (id == 0 || p->nstreams >= ORC_H2_MAX_STREAMS) return NULL;
+  orc_grpc_deframer* d = &p->streams[p->nstreams++];
+  memset(d, 0, sizeof(*d));
+  d->stream_id = id;
+  return d;
+}
+
+static int push_ev(orc_h2_event* ev, uint64_t cap, uint64_t* nev, uint32_t kind,
+                   uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  if (*nev >= cap) return ORC_H2_ERR_EVENT_OVERFLOW;
+  ev[*nev].kind = kind; ev[*nev].a = a; ev[*nev].b = b; ev[*nev].c = c; ev[*nev].d = d;
+  (*nev)++;
+  return 0;
+}
+
+/* grpc_deframe_unprocessed_incoming_frames (frame_data.cc:92-276) applied to a
+ * run of DATA payload bytes [beg, beg+len) of the chunk at `base`. */
+static int grpc_deframe(orc_grpc_deframer* d, const uint8_t* base, uint64_t beg,
+                        uint64_t len, orc_h2_event* ev, uint64_t cap, uint64_t* nev) {
+  uint64_t cur = beg, end = beg + len;
+  int rc;
+  while (cur < end) {
+    switch (d->state) {
+      case 6: /* GRPC_CHTTP2_DATA_ERROR: swallow */
+        return 0;
+      case 0: { /* FH_0: compressed flag, :113-141 */
+        uint8_t t = base[cur];
+        if (t > 1) {
+          d->state = 6;
+          return ORC_H2_ERR_GRPC_FRAME_TYPE;
+        }
+        d->compressed = t;
+        d->state = 1; cur++;
+        break;
+      }
+      case 1: d->frame_size = (uint32_t)base[cur] << 24; d->state = 2; cur++; break;
+      case 2: d->frame_size |= (uint32_t)base[cur] << 16; d->state = 3; cur++; break;
+      case 3: d->frame_size |= (uint32_t)base[cur] << 8; d->state = 4; cur++; break;
+      case 4: /* FH_4 :174-203 */
+        d->frame_size |= (uint32_t)base[cur]; cur++;
+        if ((rc = push_ev(ev, cap, nev, ORC_EV_MSG_BEGIN, (uint32_t)d->compressed,
+                          d->frame_size, d->stream_id, 0))) return rc;
+        if (d->frame_size == 0) {
+          if ((rc = push_ev(ev, cap, nev, ORC_EV_MSG_END, 0, 0, d->stream_id, 0))) return rc;
+          d->state = 0;
+        } else {
+          d->state = 5;
+        }
+        break;
+      case 5: { /* FRAME :204-271 */
+        uint64_t remaining = end - cur;
+        uint64_t take = remaining < d->frame_size ? remaining : d->frame_size;
+        if ((rc = push_ev(ev, cap, nev, ORC_EV_MSG_BYTES, (uint32_t)cur, (uint32_t)take,
+                          d->stream_id, 0))) return rc;
+        d->frame_size -= (uint32_t)take;
+        cur += take;
+        if (d->frame_size == 0) {
+          if ((rc = push_ev(ev, cap, nev, ORC_EV_MSG_END, 0, 0, d->stream_id, 0))) return rc;
+          d->state = 0;
+        }
+        break;
+      }
+    }
+  }
+  return 0;
+}
+
+static int begin_frame(orc_h2_parser* p, int* parser_kind, orc_h2_event* ev, uint64_t cap,
+                       uint64_t* nev) {
+  /* init_frame_parser (parsing.cc:255-308), DATA branch init_data_frame_parser
+   * (:340-397) + grpc_chttp2_data_parser_begin_frame (frame_data.cc:43-62). */
+  uint32_t status = 0;
+  *parser_kind = PARSER_SKIP;
+  if (p->incoming_frame_type == ORC_H2_FRAME_DATA) {
+    orc_grpc_deframer* d = find_stream(p, p->incoming_stream_id);
+    if (d != NULL) {
+      if (p->incoming_frame_flags & ~ORC_H2_FLAG_END_STREAM) {
+        status = ORC_H2_ERR_DATA_FLAGS; /* stream error → skip parser */
+      } else {
+        *parser_kind = PARSER_DATA;
+      }
+    }
+  }
+  int rc = push_ev(ev, cap, nev, ORC_EV_FRAME, p->incoming_frame_type,
+                   p->incoming_frame_flags | (status << 8), p->incoming_stream_id,
+                   p->incoming_frame_size);
+  return rc;
+}
+
+int orc_h2_parser_feed(orc_h2_parser* p, const uint8_t* data, uint64_t len,
+                       orc_h2_event* ev, uint64_t cap, uint64_t* nev) {
+  /* grpc_chttp2_perform_read, parsing.cc:56-253 */
+  uint64_t cur = 0;
+  int rc;
+  while (cur < len) {
+    if (p->state < ST_FH0) { /* :70-109 */
+      if (data[cur] != (uint8_t)kClientPrefix[p->state]) return ORC_H2_ERR_PREFIX;
+      cur++; p->state++;
+      continue;
+    }
+    uint8_t c = data[cur];
+    switch (p->state) {
+      case 24: p->incoming_frame_size = (uint32_t)c << 16; p->state++; cur++; break;
+      case 25: p->incoming_frame_size |= (uint32_t)c << 8; p->state++; cur++; break;
+      case 26: p->incoming_frame_size |= c; p->state++; cur++; break;
+      case 27: p->incoming_frame_type = c; p->state++; cur++; break;
+      case 28: p->incoming_frame_flags = c; p->state++; cur++; break;
+      case 29: p->incoming_stream_id = ((uint32_t)c & 0x7f) << 24; p->state++; cur++; break;
+      case 30: p->incoming_stream_id |= (uint32_t)c << 16; p->state++; cur++; break;
+      case 31: p->incoming_stream_id |= (uint32_t)c << 8; p->state++; cur++; break;
+      case 32: { /* FH_8 :177-214 */
+        p->incoming_stream_id |= c;
+        cur++;
+        int kind;
+        if ((rc = begin_frame(p, &kind, ev, cap, nev))) return rc;
+        p->cur_parser = kind; /* must survive across feeds */
+        if (p->incoming_frame_size == 0) {
+          /* parse_frame_slice(empty, is_last=1) */
+          if ((rc = push_ev(ev, cap, nev, ORC_EV_PAYLOAD, (uint32_t)cur, 0, 1, 0))) return rc;
+          p->state = ST_FH0;
+        } else if (p->check_frame_size && p->incoming_frame_size > p->max_frame_size) {
+          return ORC_H2_ERR_FRAME_TOO_LARGE;
+        } else {
+          p->state = ST_FRAME;
+        }
+        break;
+      }
+      case ST_FRAME: { /* :215-250 */
+        uint64_t avail = len - cur;
+        uint64_t take = avail < p->incoming_frame_size ? avail : p->incoming_frame_size;
+        int is_last = take == p->incoming_frame_size;
+        if ((rc = push_ev(ev, cap, nev, ORC_EV_PAYLOAD, (uint32_t)cur, (uint32_t)take,
+                          (uint32_t)is_last, 0))) return rc;
+        if (p->cur_parser == PARSER_DATA) {
+          orc_grpc_deframer* d = find_stream(p, p->incoming_stream_id);
+          rc = grpc_deframe(d, data, cur, take, ev, cap, nev);
+          if (rc == ORC_H2_ERR_GRPC_FRAME_TYPE) {
+            /* stream error: reported, connection keeps parsing */
+            int rc2 = push_ev(ev, cap, nev, ORC_EV_FRAME, 0xff, 0, p->incoming_stream_id,
+                              ORC_H2_ERR_GRPC_FRAME_TYPE);
+            if (rc2) return rc2;
+          } else if (rc) {
+            return rc;
+          }
+        }
+        p->incoming_frame_size -= (uint32_t)take;
+        cur += take;
+        if (is_last) p->state = ST_FH0;
+        break;
+      }
+      default:
+        return -1;
+    }
+  }
+  return ORC_H2_OK;
+}
+
+/* ============================================================ cpu baseline */
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+uint64_t orc_stream_baseline(uint64_t ring_cap, int max_sge, const uint8_t* wire,
+                             const uint64_t* lens, uint64_t nslices, uint64_t n_msgs,
+                             double* seconds, uint64_t* checksum) {
+  orc_pair a, b;
+  if (orc_pair_init(&a, ring_cap, max_sge) || orc_pair_init(&b, ring_cap, max_sge)) return 0;
+  orc_pair_connect(&a, &b);
+  orc_slice* sl = (orc_slice*)malloc(sizeof(orc_slice) * nslices);
+  uint8_t* dst = (uint8_t*)malloc(ring_cap);
+  uint64_t off = 0, delivered = 0, sum = 0;
+  for (uint64_t i = 0; i < nslices; i++) {
+    sl[i].ptr = wire + off;
+    sl[i].len = lens[i];
+    off += lens[i];
+  }
+  double t0 = now_s();
+  for (uint64_t m = 0; m < n_msgs; m++) {
+    uint64_t idx = 0, byte_idx = 0;
+    while (idx < nslices) { /* rdma_write/rdma_flush loop, rdma_bp_posix.cc:470-524 */
+      uint64_t sent = orc_pair_send(&a, sl + idx, nslices - idx, byte_idx);
+      while (sent > 0) {
+        uint64_t sl_len = sl[idx].len - byte_idx;
+        if (sent >= sl_len) { sent -= sl_len; idx++; byte_idx = 0; }
+        else { byte_idx += sent; sent = 0; }
+      }
+      /* receiver drains everything that landed */
+      for (;;) {
+        uint64_t alloc;
+        uint64_t n = orc_endpoint_read(&b, dst, &alloc);
+        if (n == 0) break;
+        delivered += n;
+        sum += dst[0] + dst[n - 1];
+      }
+    }
+  }
+  *seconds = now_s() - t0;
+  if (checksum) *checksum = sum;
+  free(sl);
+  free(dst);
+  orc_pair_destroy(&a);
+  orc_pair_destroy(&b);
+  return delivered;
+}

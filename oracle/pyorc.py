@@ -1,0 +1,368 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes bindings for the two CPU checkers.
+
+* ``Oracle``  -> oracle/_build/liboracle.so   (from-scratch C restatement)
+* ``RefRing`` -> oracle/_ref/libref_ring.so   (the reference's own
+  src/core/lib/ibverbs/ring_buffer.cc, compiled where it lies)
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg may
+import this module.  The product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "_build", "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libref_ring.so")
+
+u8p = C.POINTER(C.c_uint8)
+u64 = C.c_uint64
+u64p = C.POINTER(C.c_uint64)
+
+
+def build(force=False):
+    """Compile the checkers (the reference build only where /root/reference exists)."""
+    if force or not os.path.exists(ORACLE_SO) or (
+            os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(HERE, "grdma_oracle.c"))):
+        subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+    if os.path.isdir("/root/reference/src/core/lib/ibverbs") and (
+            force or not os.path.exists(REF_SO)
+            or os.path.getmtime(REF_SO) < os.path.getmtime(os.path.join(HERE, "ref_driver.cc"))):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+# --------------------------------------------------------------------------- C structs
+class OrcRing(C.Structure):
+    _fields_ = [("buf", C.c_void_p), ("cap", u64), ("mask", u64), ("head", u64),
+                ("moving_head", u64), ("remain", u64)]
+
+
+class OrcSlice(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("len", u64)]
+
+
+class OrcStatus(C.Structure):
+    _fields_ = [("remote_head", u64), ("peer_exit", C.c_int32), ("pad", C.c_int32)]
+
+
+class OrcPair(C.Structure):
+    pass
+
+
+OrcPair._fields_ = [
+    ("ring", OrcRing), ("staging", C.c_void_p), ("staging_cap", u64), ("staging_used", u64),
+    ("status_recv", OrcStatus), ("status_send", OrcStatus), ("remote_tail", u64),
+    ("internal_read_size", u64), ("partial_write", C.c_int), ("max_sge", C.c_int),
+    ("credit_msgs", u64), ("peer", C.POINTER(OrcPair)), ("wr", (u64 * 2) * 2),
+    ("wr_count", C.c_int), ("leftover_cap", u64)]
+
+
+class OrcEvent(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32),
+                ("c", C.c_uint32), ("d", C.c_uint32)]
+
+
+class OrcDeframer(C.Structure):
+    _fields_ = [("stream_id", C.c_uint32), ("state", C.c_int), ("frame_size", C.c_uint32),
+                ("compressed", C.c_int)]
+
+
+class OrcParser(C.Structure):
+    _fields_ = [("state", C.c_int), ("incoming_frame_size", C.c_uint32),
+                ("incoming_frame_type", C.c_uint8), ("incoming_frame_flags", C.c_uint8),
+                ("incoming_stream_id", C.c_uint32), ("max_frame_size", C.c_uint32),
+                ("check_frame_size", C.c_int), ("cur_parser", C.c_int),
+                ("streams", OrcDeframer * 16), ("nstreams", C.c_int)]
+
+
+EV_FRAME, EV_PAYLOAD, EV_MSG_BEGIN, EV_MSG_BYTES, EV_MSG_END = 1, 2, 3, 4, 5
+
+
+def _lib():
+    build()
+    lib = C.CDLL(ORACLE_SO)
+    lib.orc_encoded_size.restype = u64
+    lib.orc_encoded_size.argtypes = [u64]
+    lib.orc_calc_writable.restype = u64
+    lib.orc_calc_writable.argtypes = [u64]
+    lib.orc_plan_send.restype = u64
+    lib.orc_plan_send.argtypes = [u64, u64, u64, u64, C.c_int, u64p, u64, u64, u64p, u64p]
+    lib.orc_pair_init.argtypes = [C.POINTER(OrcPair), u64, C.c_int]
+    lib.orc_pair_destroy.argtypes = [C.POINTER(OrcPair)]
+    lib.orc_pair_connect.argtypes = [C.POINTER(OrcPair), C.POINTER(OrcPair)]
+    lib.orc_pair_send.restype = u64
+    lib.orc_pair_send.argtypes = [C.POINTER(OrcPair), C.POINTER(OrcSlice), u64, u64]
+    lib.orc_pair_recv.restype = u64
+    lib.orc_pair_recv.argtypes = [C.POINTER(OrcPair), C.c_void_p, u64]
+    lib.orc_pair_writable.restype = u64
+    lib.orc_pair_writable.argtypes = [C.POINTER(OrcPair)]
+    lib.orc_endpoint_read.restype = u64
+    lib.orc_endpoint_read.argtypes = [C.POINTER(OrcPair), C.c_void_p, u64p]
+    lib.orc_ring_readable.restype = u64
+    lib.orc_ring_readable.argtypes = [C.POINTER(OrcRing)]
+    lib.orc_ring_has_message.argtypes = [C.POINTER(OrcRing)]
+    lib.orc_h2_frame_message.restype = C.c_int64
+    lib.orc_h2_frame_message.argtypes = [C.c_char_p, u64, C.c_int, C.c_uint32, C.c_uint32,
+                                         C.c_int, C.c_void_p, u64, u64p, u64p, u64]
+    lib.orc_h2_parser_init.argtypes = [C.POINTER(OrcParser), C.c_int, C.c_uint32]
+    lib.orc_h2_parser_feed.argtypes = [C.POINTER(OrcParser), C.c_char_p, u64,
+                                       C.POINTER(OrcEvent), u64, u64p]
+    lib.orc_stream_baseline.restype = u64
+    lib.orc_stream_baseline.argtypes = [u64, C.c_int, C.c_void_p, u64p, u64, u64,
+                                        C.POINTER(C.c_double), u64p]
+    lib.orc_grpc_msg_header.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    lib.orc_h2_data_header.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
+    return lib
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = _lib()
+    return _LIB
+
+
+def _keep(slices):
+    """-> (ctypes array of (ptr,len), keepalive list)"""
+    bufs = [C.create_string_buffer(bytes(s), len(s)) if len(s) else C.create_string_buffer(1)
+            for s in slices]
+    return bufs
+
+
+class OracleLink:
+    """Two connected oracle pairs (a loop-back connection), side 0 and side 1."""
+
+    def __init__(self, ring_size=4 << 20, max_sge=30):
+        self.l = lib()
+        self.p = [OrcPair(), OrcPair()]
+        for q in self.p:
+            assert self.l.orc_pair_init(C.byref(q), ring_size, max_sge) == 0
+        self.l.orc_pair_connect(C.byref(self.p[0]), C.byref(self.p[1]))
+        self.ring_size = ring_size
+
+    def close(self):
+        for q in self.p:
+            self.l.orc_pair_destroy(C.byref(q))
+
+    def send(self, side, slices, byte_idx=0):
+        bufs = _keep(slices)
+        arr = (OrcSlice * max(1, len(slices)))()
+        for i, (b, s) in enumerate(zip(bufs, slices)):
+            arr[i].ptr = C.addressof(b)
+            arr[i].len = len(s)
+        return self.l.orc_pair_send(C.byref(self.p[side]), arr, len(slices), byte_idx)
+
+    def recv(self, side, cap):
+        dst = C.create_string_buffer(max(1, cap))
+        n = self.l.orc_pair_recv(C.byref(self.p[side]), dst, cap)
+        return dst.raw[:n]
+
+    def endpoint_read(self, side):
+        q = self.p[side]
+        cap = max(256, self.readable(side), q.leftover_cap)
+        dst = C.create_string_buffer(cap)
+        alloc = u64(0)
+        n = self.l.orc_endpoint_read(C.byref(q), dst, C.byref(alloc))
+        return dst.raw[:n], alloc.value
+
+    def readable(self, side):
+        return self.l.orc_ring_readable(C.byref(self.p[side].ring))
+
+    def has_message(self, side):
+        return bool(self.l.orc_ring_has_message(C.byref(self.p[side].ring)))
+
+    def writable(self, side):
+        return self.l.orc_pair_writable(C.byref(self.p[side]))
+
+    def ring_mem(self, side):
+        return C.string_at(self.p[side].ring.buf, self.ring_size)
+
+    def staging_mem(self, side):
+        q = self.p[side]
+        return C.string_at(q.staging, q.staging_used)
+
+    def state(self, side):
+        q = self.p[side]
+        return dict(head=q.ring.head, moving_head=q.ring.moving_head, remain=q.ring.remain,
+                    remote_tail=q.remote_tail, remote_head=q.status_recv.remote_head,
+                    internal_read_size=q.internal_read_size, credit_msgs=q.credit_msgs,
+                    partial_write=int(q.partial_write))
+
+    def last_wrs(self, side):
+        q = self.p[side]
+        return [(q.wr[i][0], q.wr[i][1]) for i in range(q.wr_count)]
+
+
+# --------------------------------------------------------------------------- reference build
+def ref_available():
+    build()
+    return os.path.exists(REF_SO)
+
+
+_REF = None
+
+
+def ref():
+    global _REF
+    if _REF is None:
+        build()
+        r = C.CDLL(REF_SO)
+        for name in ("ref_encoded_size", "ref_calc_writable"):
+            getattr(r, name).restype = u64
+            getattr(r, name).argtypes = [u64]
+        for name in ("ref_reserved_space", "ref_sizeof_grpc_slice",
+                     "ref_sizeof_grpc_slice_buffer", "ref_slice_inlined_size"):
+            getattr(r, name).restype = u64
+        r.ref_link_new.restype = C.c_void_p
+        r.ref_link_new.argtypes = [u64, C.c_int]
+        r.ref_link_free.argtypes = [C.c_void_p]
+        r.ref_pair_send.restype = u64
+        r.ref_pair_send.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), u64p, u64, u64,
+                                    C.c_int]
+        r.ref_pair_recv.restype = u64
+        r.ref_pair_recv.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64]
+        r.ref_pair_readable.restype = u64
+        r.ref_pair_readable.argtypes = [C.c_void_p, C.c_int]
+        r.ref_pair_has_message.argtypes = [C.c_void_p, C.c_int]
+        r.ref_pair_writable.restype = u64
+        r.ref_pair_writable.argtypes = [C.c_void_p, C.c_int]
+        r.ref_pair_ring_mem.restype = C.c_void_p
+        r.ref_pair_ring_mem.argtypes = [C.c_void_p, C.c_int]
+        r.ref_pair_staging_mem.restype = C.c_void_p
+        r.ref_pair_staging_mem.argtypes = [C.c_void_p, C.c_int]
+        r.ref_pair_staging_used.restype = u64
+        r.ref_pair_staging_used.argtypes = [C.c_void_p, C.c_int]
+        r.ref_pair_state.argtypes = [C.c_void_p, C.c_int, u64p]
+        r.ref_pair_last_wrs.argtypes = [C.c_void_p, C.c_int, C.POINTER((u64 * 2) * 2)]
+        r.ref_ring_new.restype = C.c_void_p
+        r.ref_ring_new.argtypes = [u64]
+        r.ref_ring_free.argtypes = [C.c_void_p]
+        r.ref_ring_mem.restype = C.c_void_p
+        r.ref_ring_mem.argtypes = [C.c_void_p]
+        r.ref_ring_write.restype = u64
+        r.ref_ring_write.argtypes = [C.c_void_p, u64, C.c_char_p, u64]
+        r.ref_ring_readable.restype = u64
+        r.ref_ring_readable.argtypes = [C.c_void_p]
+        r.ref_ring_read.restype = u64
+        r.ref_ring_read.argtypes = [C.c_void_p, C.c_void_p, u64, u64p]
+        r.ref_ring_free_size.restype = u64
+        r.ref_ring_free_size.argtypes = [C.c_void_p, u64, u64]
+        r.ref_ring_writable.restype = u64
+        r.ref_ring_writable.argtypes = [C.c_void_p, u64, u64]
+        _REF = r
+    return _REF
+
+
+class RefLink:
+    """Same interface as OracleLink, backed by the reference-built ring codec."""
+
+    def __init__(self, ring_size=4 << 20, max_sge=30):
+        self.r = ref()
+        self.h = self.r.ref_link_new(ring_size, max_sge)
+        self.ring_size = ring_size
+        self.leftover = [0, 0]
+
+    def close(self):
+        self.r.ref_link_free(self.h)
+
+    def send(self, side, slices, byte_idx=0, inline_small=0):
+        bufs = _keep(slices)
+        n = len(slices)
+        ptrs = (C.c_void_p * max(1, n))()
+        lens = (u64 * max(1, n))()
+        for i, (b, s) in enumerate(zip(bufs, slices)):
+            ptrs[i] = C.addressof(b)
+            lens[i] = len(s)
+        return self.r.ref_pair_send(self.h, side, ptrs, lens, n, byte_idx, inline_small)
+
+    def recv(self, side, cap):
+        dst = C.create_string_buffer(max(1, cap))
+        n = self.r.ref_pair_recv(self.h, side, dst, cap)
+        return dst.raw[:n]
+
+    def endpoint_read(self, side):
+        """rdma_bp_posix.cc:306-326 + :180-291 driven over the reference ring."""
+        readable = self.readable(side)
+        alloc = self.leftover[side] or max(256, readable)
+        out = b""
+        while len(out) < alloc:
+            got = self.recv(side, alloc - len(out))
+            if not got:
+                break
+            out += got
+        self.leftover[side] = alloc - len(out) if out else alloc
+        return out, alloc
+
+    def readable(self, side):
+        return self.r.ref_pair_readable(self.h, side)
+
+    def has_message(self, side):
+        return bool(self.r.ref_pair_has_message(self.h, side))
+
+    def writable(self, side):
+        return self.r.ref_pair_writable(self.h, side)
+
+    def ring_mem(self, side):
+        return C.string_at(self.r.ref_pair_ring_mem(self.h, side), self.ring_size)
+
+    def staging_mem(self, side):
+        return C.string_at(self.r.ref_pair_staging_mem(self.h, side),
+                           self.r.ref_pair_staging_used(self.h, side))
+
+    def state(self, side):
+        st = (u64 * 8)()
+        self.r.ref_pair_state(self.h, side, st)
+        keys = ["head", "moving_head", "remain", "remote_tail", "remote_head",
+                "internal_read_size", "credit_msgs", "partial_write"]
+        return dict(zip(keys, [int(x) for x in st]))
+
+    def last_wrs(self, side):
+        out = ((u64 * 2) * 2)()
+        n = self.r.ref_pair_last_wrs(self.h, side, C.byref(out))
+        return [(out[i][0], out[i][1]) for i in range(n)]
+
+
+# --------------------------------------------------------------------------- HTTP/2 helpers
+def h2_frame_message(msg, stream_id=1, max_frame=16384, compressed=0, end_stream=0):
+    """-> (wire bytes, slice lengths) for one gRPC message (frame_data.cc:64-90)."""
+    l = lib()
+    n = len(msg)
+    frames = (n + 5 + max_frame - 1) // max_frame + 1
+    wire_cap = n + 5 + 9 * frames + 64
+    wire = C.create_string_buffer(wire_cap)
+    lens = (u64 * (3 * frames + 8))()
+    wl = u64(0)
+    cnt = l.orc_h2_frame_message(bytes(msg), n, compressed, stream_id, max_frame, end_stream,
+                                 wire, wire_cap, C.byref(wl), lens, len(lens))
+    assert cnt >= 0
+    return wire.raw[:wl.value], [int(lens[i]) for i in range(cnt)]
+
+
+class H2Parser:
+    def __init__(self, expect_client_prefix=False, max_frame_size=16384):
+        self.l = lib()
+        self.p = OrcParser()
+        self.l.orc_h2_parser_init(C.byref(self.p), int(expect_client_prefix), max_frame_size)
+
+    def feed(self, data, cap=None):
+        data = bytes(data)
+        cap = cap or (len(data) * 2 + 64)
+        ev = (OrcEvent * cap)()
+        nev = u64(0)
+        rc = self.l.orc_h2_parser_feed(C.byref(self.p), data, len(data), ev, cap, C.byref(nev))
+        return rc, [(e.kind, e.a, e.b, e.c, e.d) for e in ev[:nev.value]]
+
+
+def stream_baseline(ring_size, max_sge, wire, lens, n_msgs):
+    """Single-thread CPU pass of the full pair protocol; -> (payload bytes, seconds)."""
+    l = lib()
+    arr = (u64 * len(lens))(*lens)
+    buf = C.create_string_buffer(bytes(wire), len(wire))
+    sec = C.c_double(0)
+    chk = u64(0)
+    n = l.orc_stream_baseline(ring_size, max_sge, buf, arr, len(lens), n_msgs, C.byref(sec),
+                              C.byref(chk))
+    return n, sec.value
