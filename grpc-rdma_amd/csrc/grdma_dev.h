@@ -1,0 +1,136 @@
+// Device-resident data layout of the MI355X ring-buffer endpoint data plane.
+//
+// Everything a connection needs on the hot path lives in HBM so that the HIP
+// kernels own the protocol state (head/tail credit accounting included) and a
+// NIC (GPUDirect RDMA) or an xGMI peer can write the ring / status words
+// without the host touching them.  Field names follow the reference:
+//   RingBufferPollable  src/core/lib/ibverbs/ring_buffer.h:203-208
+//   PairPollable        src/core/lib/ibverbs/pair.h:100-103,169-171
+//   grpc_rdma           src/core/lib/iomgr/rdma_bp_posix.cc:45-88
+#ifndef GRDMA_DEV_H
+#define GRDMA_DEV_H
+
+#include <stdint.h>
+
+#define GRDMA_ALIGN 8ull            // ring_buffer.h:49
+#define GRDMA_RESERVED 24ull        // ring_buffer.h:52
+#define GRDMA_FOOTER 0xFFFFFFFFFFFFFFFFull  // ring_buffer.h:50
+
+#define GRDMA_MAX_SEGS 4096         // copy segments per plan
+#define GRDMA_MAX_SLICES 4096       // delivered slices per receive plan
+#define GRDMA_TILE_BYTES 4096ull    // bytes one wave copies per tile
+#define GRDMA_MIN_READ_SLICE 256ull // rdma_bp_posix.cc:308
+
+// PairStatus, pair.h:44-51
+enum grdma_pair_status {
+  GRDMA_PAIR_UNINITIALIZED = 0,
+  GRDMA_PAIR_INITIALIZED = 1,
+  GRDMA_PAIR_CONNECTED = 2,
+  GRDMA_PAIR_HALF_CLOSED = 3,
+  GRDMA_PAIR_DISCONNECTED = 4,
+  GRDMA_PAIR_ERROR = 5
+};
+
+// status_report, pair.h:100-103: the 16-byte credit message the receiver
+// RDMA-writes into the sender's status buffer.
+struct grdma_status_report {
+  uint64_t remote_head;
+  int32_t peer_exit;
+  int32_t pad;
+};
+
+// {ptr,len} view of one grpc_slice (GRPC_SLICE_START_PTR / GRPC_SLICE_LENGTH,
+// include/grpc/impl/codegen/slice.h:96-101).  ptr must be device-accessible.
+struct grdma_sge {
+  const uint8_t* ptr;
+  uint64_t len;
+};
+
+// One connection end.  Lives in HBM; 256-byte aligned so that concurrently
+// polled words of different connections never share a cache line pair.
+struct grdma_conn {
+  // ---- receive side: my ring (RingBufferPollable) -------------------------
+  uint8_t* ring;
+  uint64_t cap;                 // power of two
+  uint64_t head;                // head_
+  uint64_t moving_head;         // moving_head_ (what is reported as credit)
+  uint64_t remain;              // remain_
+  uint64_t internal_read_size;  // pair.h:169
+  uint64_t leftover_cap;        // unfilled tail kept in last_read_buffer
+  uint64_t credit_msgs;         // status reports sent so far
+  uint64_t total_read;          // total_read_size_
+  // ---- send side ------------------------------------------------------------
+  uint8_t* staging;             // send_buffers_[kDataBuffer], ring/2 bytes
+  uint64_t staging_cap;
+  uint64_t remote_tail;         // remote_tail_
+  uint64_t partial_write;       // partial_write_
+  uint64_t total_written;       // total_write_size_
+  uint64_t tx_slice_idx;        // rdma_flush cursor: first unsent slice ...
+  uint64_t tx_byte_idx;         // ... and outgoing_byte_idx within it
+  // ---- wire: where my one-sided writes land ---------------------------------
+  uint8_t* peer_ring;                       // remote ring base (same cap)
+  struct grdma_status_report* peer_status;  // peer's status_recv
+  uint32_t max_sge;             // max_sge_num_
+  uint32_t status;              // grdma_pair_status
+  uint32_t wire_direct;         // 1: encode straight into peer_ring (no staging)
+  uint32_t pad0;
+  // ---- credit the peer granted me (written remotely) --------------------------
+  struct grdma_status_report status_recv;   // recv_buffers_[kStatusBuffer]
+  struct grdma_status_report status_send;   // send_buffers_[kStatusBuffer]
+  uint64_t pad1[8];
+};
+
+struct grdma_seg {
+  uint64_t dst;
+  uint64_t src;   // 0 = fill with zero bytes
+  uint64_t len;
+};
+
+struct grdma_slice_out {  // one completed endpoint_read: a single slice
+  uint64_t off;           // offset into the receive arena
+  uint64_t len;
+};
+
+// Result block of one send plan (mirrors what PairPollable::Send and
+// rdma_flush report back, pair.cc:645-734 / rdma_bp_posix.cc:470-524).
+struct grdma_tx_result {
+  uint64_t sent;           // payload bytes consumed from the slice list
+  uint64_t records;        // ring records produced (== SGEs)
+  uint64_t staged;         // encoded bytes (Σ 16 + round_up8(pay))
+  uint64_t partial;        // partial_write_
+  uint64_t new_remote_tail;
+  uint64_t wr_off[2];      // the ≤2 RDMA WRITE work requests:
+  uint64_t wr_len[2];      //   remote ring offset / byte count
+  uint64_t wr_count;
+  uint64_t slice_idx;      // rdma_flush cursor after this send
+  uint64_t byte_idx;
+  uint64_t done;           // 1 when the whole slice list has been sent
+  uint64_t seq;            // bumped last (host polls it)
+};
+
+struct grdma_rx_result {
+  uint64_t nslices;        // endpoint_read completions emulated
+  uint64_t bytes;          // payload bytes delivered
+  uint64_t consumed;       // ring bytes consumed (records incl. tags)
+  uint64_t records;        // ring records fully or partly consumed
+  uint64_t would_block;    // 1: the last read found nothing (re-arm notify_on_read)
+  uint64_t credit_sent;    // status reports posted during this call
+  uint64_t credit_head;    // remote_head value of the last report
+  uint64_t head, moving_head, remain;
+  uint64_t arena_used;     // bytes of the arena handed out
+  uint64_t zero_off[2];    // ring ranges cleared
+  uint64_t zero_len[2];
+  uint64_t seq;            // bumped by k_rx_plan
+  uint64_t commit_seq;     // bumped by k_rx_commit (copy + zero-fill + credit done)
+};
+
+// A list of byte-copy segments plus its decomposition into wave tiles.
+struct grdma_plan {
+  uint32_t nsegs;
+  uint32_t ntiles;
+  uint64_t bytes;
+  struct grdma_seg segs[GRDMA_MAX_SEGS];
+  uint32_t tile_prefix[GRDMA_MAX_SEGS + 1];
+};
+
+#endif  // GRDMA_DEV_H

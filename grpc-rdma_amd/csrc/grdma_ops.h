@@ -1,0 +1,35 @@
+// Operation descriptors consumed by the plan kernels (device-visible memory).
+#ifndef GRDMA_OPS_H
+#define GRDMA_OPS_H
+
+#include <stdint.h>
+
+#include "grdma_dev.h"
+
+// One PairPollable::Send / rdma_flush step for one connection.
+struct grdma_tx_op {
+  struct grdma_conn* conn;
+  const struct grdma_sge* slices;  // the grpc_slice_buffer being written
+  uint64_t nslices;
+  uint64_t byte_idx;               // outgoing_byte_idx when use_cursor == 0
+  struct grdma_plan* plan;         // gather plan (slices -> records)
+  struct grdma_plan* wire_plan;    // loop-back wire plan (staging -> peer ring)
+  struct grdma_tx_result* result;
+  uint32_t use_cursor;             // 0: slice 0 + byte_idx; 1: continue from the conn's
+                                   // rdma_flush cursor; 2: reset that cursor first
+  uint32_t pad;
+};
+
+// One drain of a connection's ring: a run of endpoint_read completions.
+struct grdma_rx_op {
+  struct grdma_conn* conn;
+  struct grdma_plan* plan;         // scatter plan (ring -> arena)
+  struct grdma_rx_result* result;
+  struct grdma_slice_out* slices;  // one entry per completed endpoint_read
+  uint8_t* arena;                  // receive arena (HBM or pinned host)
+  uint64_t arena_cap;
+  uint64_t max_reads;              // stop after this many completions
+  uint64_t raw_cap;                // != 0: one PairPollable::Recv(arena, raw_cap) instead
+};
+
+#endif  // GRDMA_OPS_H

@@ -1,0 +1,608 @@
+// Host side of the data plane: the PairPollable analogue and the C ABI declared
+// in include/grdma_amd.h.  This layer owns HBM allocations and enqueues the
+// kernels of grdma_kernels.hip; it never computes on payload bytes itself and
+// has no CPU fallback -- without a HIP device every entry point fails.
+//
+// Reference counterparts: src/core/lib/ibverbs/pair.{h,cc} (PairPollable),
+// src/core/lib/iomgr/rdma_bp_posix.cc (endpoint read/write loops).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/grdma_amd.h"
+#include "grdma_dev.h"
+#include "grdma_host.h"
+#include "grdma_ops.h"
+
+extern "C" {
+hipError_t grdma_launch_tx_plan(const grdma_tx_op*, uint32_t, hipStream_t);
+hipError_t grdma_launch_copy(const grdma_plan* const*, uint32_t, uint32_t, hipStream_t);
+hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
+hipError_t grdma_launch_zero(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
+hipError_t grdma_launch_rx_commit(const grdma_rx_op*, uint32_t, hipStream_t);
+hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*, uint64_t*,
+                             hipStream_t);
+}
+
+namespace {
+
+struct grdma_ctx {
+  std::mutex mu;
+  bool ready = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  // pinned scratch for k_poll
+  grdma_conn** h_conns = nullptr;
+  uint64_t* h_readable = nullptr;
+  uint64_t* h_masks = nullptr;
+  uint32_t poll_cap = 0;
+};
+
+grdma_ctx g_ctx;
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return -code;
+}
+
+#define HIP_TRY(expr)                                                               \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess)                                                           \
+      return fail(GRDMA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                              \
+  } while (0)
+
+int require_ctx() {
+  if (!g_ctx.ready) return fail(GRDMA_ERR_NO_DEVICE, "grdma_init() has not succeeded: no HIP device");
+  return 0;
+}
+
+uint32_t copy_blocks_for(uint64_t bytes) {
+  uint64_t tiles = (bytes + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
+  uint64_t blocks = (tiles + 3) / 4;  // 4 waves per block, one tile per wave pass
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;  // 256 CUs x 8; the rest is grid-strided
+  return (uint32_t)blocks;
+}
+
+}  // namespace
+
+// Host control block shared with the device (pinned, device-visible).
+struct grdma_hostblk {
+  grdma_tx_op txop;
+  grdma_rx_op rxop;
+  grdma_tx_result txres;
+  grdma_rx_result rxres;
+  const grdma_plan* plan_ptrs[4];  // [0] tx gather, [1] wire, [2] rx scatter
+};
+
+struct grdma_pair {
+  uint64_t ring_size = 0;
+  int max_sge = 0;
+  int flags = 0;
+  grdma_conn* d_conn = nullptr;
+  uint8_t* d_ring = nullptr;
+  uint8_t* d_staging = nullptr;
+  grdma_plan* d_txplan = nullptr;
+  grdma_plan* d_wireplan = nullptr;
+  grdma_plan* d_rxplan = nullptr;
+  uint8_t* d_arena = nullptr;
+  uint64_t arena_cap = 0;
+  grdma_hostblk* h = nullptr;        // pinned
+  grdma_sge* h_sges = nullptr;       // pinned, GRDMA_MAX_SEGS entries
+  grdma_slice_out* h_slices = nullptr;  // pinned, GRDMA_MAX_SLICES entries
+  uint8_t* h_bounce = nullptr;       // pinned, staging-sized, lazily allocated
+  grdma_pair* peer = nullptr;
+  hipStream_t stream = nullptr;
+  // endpoint_write context
+  std::vector<grdma_slice> w_slices;
+  uint64_t w_idx = 0, w_byte = 0;
+  int w_flags = 0;
+  bool w_active = false;
+};
+
+namespace {
+
+int fetch_conn(grdma_pair* p, grdma_conn* out) {
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  HIP_TRY(hipMemcpy(out, p->d_conn, sizeof(grdma_conn), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// Fill the device-visible slice table.  For GRDMA_MEM_HOST the first
+// staging_cap bytes of the list are copied into the pinned bounce buffer (a Send
+// can never consume more than the staging budget, pair.cc:676-685).
+int stage_slices(grdma_pair* p, const grdma_slice* slices, uint64_t count, uint64_t skip_first,
+                 int flags) {
+  if (count > GRDMA_MAX_SEGS - 1)
+    return fail(GRDMA_ERR_CAPACITY, "slice list of %llu entries exceeds %d",
+                (unsigned long long)count, GRDMA_MAX_SEGS - 1);
+  if (flags & GRDMA_MEM_HOST) {
+    const uint64_t cap = p->ring_size / 2;
+    if (!p->h_bounce) HIP_TRY(hipHostMalloc((void**)&p->h_bounce, cap + 64, hipHostMallocDefault));
+    uint64_t off = 0;
+    for (uint64_t i = 0; i < count; i++) {
+      const uint8_t* src = static_cast<const uint8_t*>(slices[i].ptr);
+      uint64_t len = slices[i].len;
+      uint64_t sk = (i == 0) ? skip_first : 0;  // bytes before byte_idx are never read
+      uint64_t room = cap > off ? cap - off : 0;
+      uint64_t n = len > sk ? len - sk : 0;
+      if (n > room) n = room;
+      if (n) memcpy(p->h_bounce + off, src + sk, n);
+      p->h_sges[i].ptr = p->h_bounce + off - sk;  // so that ptr + byte_idx lands on the copy
+      p->h_sges[i].len = len;
+      off += n;
+    }
+  } else {
+    for (uint64_t i = 0; i < count; i++) {
+      p->h_sges[i].ptr = static_cast<const uint8_t*>(slices[i].ptr);
+      p->h_sges[i].len = slices[i].len;
+    }
+  }
+  return 0;
+}
+
+int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_cursor) {
+  grdma_hostblk* h = p->h;
+  h->txop.conn = p->d_conn;
+  h->txop.slices = p->h_sges;
+  h->txop.nslices = count;
+  h->txop.byte_idx = byte_idx;
+  h->txop.plan = p->d_txplan;
+  h->txop.wire_plan = p->d_wireplan;
+  h->txop.result = &h->txres;
+  h->txop.use_cursor = use_cursor;
+  const uint32_t blocks = copy_blocks_for(p->ring_size / 2);
+  HIP_TRY(grdma_launch_tx_plan(&h->txop, 1, p->stream));
+  HIP_TRY(grdma_launch_copy(&h->plan_ptrs[0], 1, blocks, p->stream));
+  if (!(p->flags & GRDMA_WIRE_DIRECT))
+    HIP_TRY(grdma_launch_copy(&h->plan_ptrs[1], 1, blocks, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+int run_recv(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_reads,
+             uint64_t raw_cap) {
+  grdma_hostblk* h = p->h;
+  h->rxop.conn = p->d_conn;
+  h->rxop.plan = p->d_rxplan;
+  h->rxop.result = &h->rxres;
+  h->rxop.slices = p->h_slices;
+  h->rxop.arena = arena;
+  h->rxop.arena_cap = arena_cap;
+  h->rxop.max_reads = max_reads;
+  h->rxop.raw_cap = raw_cap;
+  const uint32_t blocks = copy_blocks_for(p->ring_size);
+  HIP_TRY(grdma_launch_rx_plan(&h->rxop, 1, p->stream));
+  HIP_TRY(grdma_launch_copy(&h->plan_ptrs[2], 1, blocks, p->stream));
+  HIP_TRY(grdma_launch_zero(&h->rxop, 1, blocks, p->stream));
+  HIP_TRY(grdma_launch_rx_commit(&h->rxop, 1, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grdma_abi_version(void) { return GRDMA_ABI_VERSION; }
+
+const char* grdma_last_error(void) { return g_err.c_str(); }
+
+int grdma_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int grdma_init(int hip_device) {
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(GRDMA_ERR_NO_DEVICE, "no HIP device visible (%s); this data plane has no CPU path",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (hip_device < 0 || hip_device >= n)
+    return fail(GRDMA_ERR_INVALID, "hip_device %d out of range [0,%d)", hip_device, n);
+  if (g_ctx.ready && g_ctx.device == hip_device) return 0;
+  HIP_TRY(hipSetDevice(hip_device));
+  if (!g_ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  g_ctx.device = hip_device;
+  g_ctx.ready = true;
+  return 0;
+}
+
+grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
+  if (require_ctx()) return nullptr;
+  // ring_buffer.cc:22-24
+  if (ring_size <= GRDMA_RESERVED || (ring_size & (ring_size - 1)) != 0 || ring_size < 64) {
+    fail(GRDMA_ERR_INVALID, "ring size %llu is not a power of two >= 64",
+         (unsigned long long)ring_size);
+    return nullptr;
+  }
+  if (max_sge <= 0) max_sge = 30;
+  if (max_sge > GRDMA_MAX_SEGS - 1) max_sge = GRDMA_MAX_SEGS - 1;
+  grdma_pair* p = new grdma_pair();
+  p->ring_size = ring_size;
+  p->max_sge = max_sge;
+  p->flags = flags;
+  p->stream = g_ctx.stream;
+  p->arena_cap = 2 * ring_size + 4096;
+  bool ok = hipMalloc((void**)&p->d_conn, sizeof(grdma_conn)) == hipSuccess &&
+            hipMalloc((void**)&p->d_ring, ring_size) == hipSuccess &&
+            hipMalloc((void**)&p->d_staging, ring_size / 2 + 64) == hipSuccess &&
+            hipMalloc((void**)&p->d_txplan, sizeof(grdma_plan)) == hipSuccess &&
+            hipMalloc((void**)&p->d_wireplan, sizeof(grdma_plan)) == hipSuccess &&
+            hipMalloc((void**)&p->d_rxplan, sizeof(grdma_plan)) == hipSuccess &&
+            hipMalloc((void**)&p->d_arena, p->arena_cap) == hipSuccess &&
+            hipHostMalloc((void**)&p->h, sizeof(grdma_hostblk), hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void**)&p->h_sges, sizeof(grdma_sge) * GRDMA_MAX_SEGS,
+                          hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void**)&p->h_slices, sizeof(grdma_slice_out) * GRDMA_MAX_SLICES,
+                          hipHostMallocDefault) == hipSuccess;
+  if (!ok) {
+    fail(GRDMA_ERR_HIP, "device allocation failed for a %llu-byte ring",
+         (unsigned long long)ring_size);
+    grdma_pair_destroy(p);
+    return nullptr;
+  }
+  // Init(): zero the ring (ring_buffer.cc:49-54, pair.cc:117-118) and the state
+  hipMemsetAsync(p->d_ring, 0, ring_size, p->stream);
+  hipMemsetAsync(p->d_staging, 0, ring_size / 2 + 64, p->stream);
+  hipMemsetAsync(p->d_txplan, 0, sizeof(grdma_plan), p->stream);
+  hipMemsetAsync(p->d_wireplan, 0, sizeof(grdma_plan), p->stream);
+  hipMemsetAsync(p->d_rxplan, 0, sizeof(grdma_plan), p->stream);
+  memset(p->h, 0, sizeof(grdma_hostblk));
+  p->h->plan_ptrs[0] = p->d_txplan;
+  p->h->plan_ptrs[1] = p->d_wireplan;
+  p->h->plan_ptrs[2] = p->d_rxplan;
+  grdma_conn c;
+  memset(&c, 0, sizeof(c));
+  c.ring = p->d_ring;
+  c.cap = ring_size;
+  c.staging = p->d_staging;
+  c.staging_cap = ring_size / 2;  // pair.cc:104
+  c.max_sge = (uint32_t)max_sge;
+  c.status = GRDMA_PAIR_INITIALIZED;
+  c.wire_direct = (flags & GRDMA_WIRE_DIRECT) ? 1 : 0;
+  hipMemcpyAsync(p->d_conn, &c, sizeof(c), hipMemcpyHostToDevice, p->stream);
+  if (hipStreamSynchronize(p->stream) != hipSuccess) {
+    fail(GRDMA_ERR_HIP, "pair initialisation failed");
+    grdma_pair_destroy(p);
+    return nullptr;
+  }
+  return p;
+}
+
+void grdma_pair_destroy(grdma_pair* p) {
+  if (!p) return;
+  if (p->stream) hipStreamSynchronize(p->stream);
+  hipFree(p->d_conn);
+  hipFree(p->d_ring);
+  hipFree(p->d_staging);
+  hipFree(p->d_txplan);
+  hipFree(p->d_wireplan);
+  hipFree(p->d_rxplan);
+  hipFree(p->d_arena);
+  if (p->h) hipHostFree(p->h);
+  if (p->h_sges) hipHostFree(p->h_sges);
+  if (p->h_slices) hipHostFree(p->h_slices);
+  if (p->h_bounce) hipHostFree(p->h_bounce);
+  if (p->peer && p->peer->peer == p) p->peer->peer = nullptr;
+  delete p;
+}
+
+int grdma_pair_connect(grdma_pair* a, grdma_pair* b) {
+  if (int rc = require_ctx()) return rc;
+  if (!a || !b) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (a->ring_size != b->ring_size)  // pair.cc:149
+    return fail(GRDMA_ERR_INVALID, "ring sizes differ (%llu vs %llu)",
+                (unsigned long long)a->ring_size, (unsigned long long)b->ring_size);
+  grdma_pair* ends[2] = {a, b};
+  for (int i = 0; i < 2; i++) {
+    grdma_pair* me = ends[i];
+    grdma_pair* other = ends[1 - i];
+    grdma_conn c;
+    if (int rc = fetch_conn(me, &c)) return rc;
+    c.peer_ring = other->d_ring;
+    c.peer_status = reinterpret_cast<grdma_status_report*>(
+        reinterpret_cast<uint8_t*>(other->d_conn) + offsetof(grdma_conn, status_recv));
+    c.status = GRDMA_PAIR_CONNECTED;
+    HIP_TRY(hipMemcpy(me->d_conn, &c, sizeof(c), hipMemcpyHostToDevice));
+    me->peer = other;
+    me->stream = a->stream;  // one in-order queue per loop-back link
+  }
+  return 0;
+}
+
+int grdma_pair_disconnect(grdma_pair* p) {
+  if (int rc = require_ctx()) return rc;
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  grdma_conn c;
+  if (int rc = fetch_conn(p, &c)) return rc;
+  if (c.status == GRDMA_PAIR_CONNECTED && p->peer) {
+    // peer_exit = 1 in the peer's status buffer, pair.cc:332-336
+    int32_t one = 1;
+    uint8_t* dst = reinterpret_cast<uint8_t*>(p->peer->d_conn) +
+                   offsetof(grdma_conn, status_recv) + offsetof(grdma_status_report, peer_exit);
+    HIP_TRY(hipMemcpy(dst, &one, sizeof(one), hipMemcpyHostToDevice));
+  }
+  uint32_t st = GRDMA_PAIR_DISCONNECTED;
+  HIP_TRY(hipMemcpy(reinterpret_cast<uint8_t*>(p->d_conn) + offsetof(grdma_conn, status), &st,
+                    sizeof(st), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int grdma_pair_get_status(grdma_pair* p) {
+  if (int rc = require_ctx()) return rc;
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  grdma_conn c;
+  if (int rc = fetch_conn(p, &c)) return rc;
+  // pair.cc:349-356: a connected pair whose peer announced its exit is half closed
+  if (c.status == GRDMA_PAIR_CONNECTED && c.status_recv.peer_exit == 1) {
+    uint32_t st = GRDMA_PAIR_HALF_CLOSED;
+    HIP_TRY(hipMemcpy(reinterpret_cast<uint8_t*>(p->d_conn) + offsetof(grdma_conn, status), &st,
+                      sizeof(st), hipMemcpyHostToDevice));
+    return GRDMA_PAIR_HALF_CLOSED;
+  }
+  return (int)c.status;
+}
+
+int64_t grdma_pair_send(grdma_pair* p, const grdma_slice* slices, uint64_t count,
+                        uint64_t byte_idx, int flags) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || (!slices && count)) return fail(GRDMA_ERR_INVALID, "null argument");
+  if (count == 0) return 0;
+  if (byte_idx >= slices[0].len && slices[0].len > 0)
+    return fail(GRDMA_ERR_INVALID, "byte_idx %llu beyond the first slice",
+                (unsigned long long)byte_idx);
+  if (int rc = stage_slices(p, slices, count, byte_idx, flags)) return rc;
+  if (int rc = run_send(p, count, byte_idx, 0)) return rc;
+  return (int64_t)p->h->txres.sent;
+}
+
+int64_t grdma_pair_recv(grdma_pair* p, void* dst, uint64_t capacity, int flags) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || !dst) return fail(GRDMA_ERR_INVALID, "null argument");
+  if (capacity == 0) return 0;
+  uint8_t* target = static_cast<uint8_t*>(dst);
+  bool bounce = (flags & GRDMA_MEM_HOST) != 0;
+  if (bounce) {
+    if (capacity > p->arena_cap) capacity = p->arena_cap;
+    target = p->d_arena;
+  }
+  if (int rc = run_recv(p, target, capacity, 1, capacity)) return rc;
+  uint64_t n = p->h->rxres.bytes;
+  if (bounce && n) HIP_TRY(hipMemcpy(dst, p->d_arena, n, hipMemcpyDeviceToHost));
+  return (int64_t)n;
+}
+
+int grdma_poll_pairs(grdma_pair* const* pairs, uint32_t n, uint64_t* readable,
+                     uint8_t* has_message) {
+  if (int rc = require_ctx()) return rc;
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  if (n > g_ctx.poll_cap) {
+    if (g_ctx.h_conns) hipHostFree(g_ctx.h_conns);
+    if (g_ctx.h_readable) hipHostFree(g_ctx.h_readable);
+    if (g_ctx.h_masks) hipHostFree(g_ctx.h_masks);
+    uint32_t cap = (n + 63) & ~63u;
+    HIP_TRY(hipHostMalloc((void**)&g_ctx.h_conns, sizeof(void*) * cap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&g_ctx.h_readable, sizeof(uint64_t) * cap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&g_ctx.h_masks, sizeof(uint64_t) * 2 * (cap / 64),
+                          hipHostMallocDefault));
+    g_ctx.poll_cap = cap;
+  }
+  hipStream_t s = pairs[0]->stream;
+  for (uint32_t i = 0; i < n; i++) {
+    g_ctx.h_conns[i] = pairs[i]->d_conn;
+    if (pairs[i]->stream != s) HIP_TRY(hipStreamSynchronize(pairs[i]->stream));
+  }
+  uint32_t words = (n + 63) / 64;
+  HIP_TRY(grdma_launch_poll(g_ctx.h_conns, n, g_ctx.h_readable, g_ctx.h_masks,
+                            g_ctx.h_masks + words, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (uint32_t i = 0; i < n; i++) {
+    if (readable) readable[i] = g_ctx.h_readable[i];
+    if (has_message) has_message[i] = (g_ctx.h_masks[words + i / 64] >> (i % 64)) & 1;
+  }
+  return 0;
+}
+
+int grdma_pair_has_message(grdma_pair* p) {
+  uint8_t has = 0;
+  grdma_pair* arr[1] = {p};
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  int rc = grdma_poll_pairs(arr, 1, nullptr, &has);
+  return rc < 0 ? rc : has;
+}
+
+int64_t grdma_pair_readable_size(grdma_pair* p) {
+  uint64_t r = 0;
+  grdma_pair* arr[1] = {p};
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  int rc = grdma_poll_pairs(arr, 1, &r, nullptr);
+  if (rc < 0) return rc;
+  grdma_conn c;
+  if (int rc2 = fetch_conn(p, &c)) return rc2;
+  return c.status == GRDMA_PAIR_CONNECTED ? (int64_t)r : 0;  // pair.cc:290-292
+}
+
+int grdma_pair_has_pending_writes(grdma_pair* p) {
+  if (int rc = require_ctx()) return rc;
+  grdma_conn c;
+  if (int rc = fetch_conn(p, &c)) return rc;
+  return c.partial_write ? 1 : 0;
+}
+
+int64_t grdma_pair_writable_size(grdma_pair* p) {
+  if (int rc = require_ctx()) return rc;
+  grdma_conn c;
+  if (int rc = fetch_conn(p, &c)) return rc;
+  return (int64_t)grdma_host_writable(c.cap, c.status_recv.remote_head, c.remote_tail);
+}
+
+int grdma_pair_state_get(grdma_pair* p, grdma_pair_state* out) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || !out) return fail(GRDMA_ERR_INVALID, "null argument");
+  grdma_conn c;
+  if (int rc = fetch_conn(p, &c)) return rc;
+  out->head = c.head;
+  out->moving_head = c.moving_head;
+  out->remain = c.remain;
+  out->remote_tail = c.remote_tail;
+  out->remote_head = c.status_recv.remote_head;
+  out->internal_read_size = c.internal_read_size;
+  out->credit_msgs = c.credit_msgs;
+  out->partial_write = c.partial_write;
+  out->total_read = c.total_read;
+  out->total_written = c.total_written;
+  out->leftover_cap = c.leftover_cap;
+  return 0;
+}
+
+int grdma_pair_peek_ring(grdma_pair* p, uint64_t off, void* host_dst, uint64_t len) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || off + len > p->ring_size) return fail(GRDMA_ERR_INVALID, "range outside the ring");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  HIP_TRY(hipMemcpy(host_dst, p->d_ring + off, len, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int grdma_pair_peek_staging(grdma_pair* p, uint64_t off, void* host_dst, uint64_t len) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || off + len > p->ring_size / 2) return fail(GRDMA_ERR_INVALID, "range outside staging");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  HIP_TRY(hipMemcpy(host_dst, p->d_staging + off, len, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int grdma_pair_last_wrs(grdma_pair* p, uint64_t out[2][2]) {
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  int n = (int)p->h->txres.wr_count;
+  for (int i = 0; i < n && i < 2; i++) {
+    out[i][0] = p->h->txres.wr_off[i];
+    out[i][1] = p->h->txres.wr_len[i];
+  }
+  return n;
+}
+
+void* grdma_pair_ring_device_ptr(grdma_pair* p) { return p ? p->d_ring : nullptr; }
+void* grdma_pair_arena_device_ptr(grdma_pair* p) { return p ? p->d_arena : nullptr; }
+uint64_t grdma_pair_arena_size(grdma_pair* p) { return p ? p->arena_cap : 0; }
+
+int grdma_pair_arena_copy_out(grdma_pair* p, uint64_t off, void* host_dst, uint64_t len) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || off + len > p->arena_cap) return fail(GRDMA_ERR_INVALID, "range outside the arena");
+  HIP_TRY(hipMemcpy(host_dst, p->d_arena + off, len, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- endpoint write: rdma_write / rdma_flush / rdma_handle_write -------------
+int64_t grdma_endpoint_write_begin(grdma_pair* p, const grdma_slice* slices, uint64_t count,
+                                   int flags) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || (!slices && count)) return fail(GRDMA_ERR_INVALID, "null argument");
+  if (p->w_active) return fail(GRDMA_ERR_INVALID, "a write is already outstanding");  // :563
+  if (count > GRDMA_MAX_SEGS - 1)
+    return fail(GRDMA_ERR_CAPACITY, "slice buffer of %llu slices exceeds %d",
+                (unsigned long long)count, GRDMA_MAX_SEGS - 1);
+  p->w_slices.assign(slices, slices + count);
+  p->w_idx = 0;
+  p->w_byte = 0;
+  p->w_flags = flags;
+  p->w_active = count > 0;
+  return 0;
+}
+
+int64_t grdma_endpoint_write_step(grdma_pair* p, int* done) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || !done) return fail(GRDMA_ERR_INVALID, "null argument");
+  if (!p->w_active) {
+    *done = 1;
+    return 0;
+  }
+  // One rdma_flush: Send(slices + idx, count - idx, byte_idx), then walk the
+  // cursor over what was accepted (rdma_bp_posix.cc:476-493).  The walk itself
+  // happens on the device (k_tx_plan); the host mirrors it from the result.
+  const uint64_t n = p->w_slices.size() - p->w_idx;
+  if (int rc = stage_slices(p, p->w_slices.data() + p->w_idx, n, p->w_byte, p->w_flags)) return rc;
+  if (int rc = run_send(p, n, p->w_byte, 0)) return rc;
+  const grdma_tx_result& r = p->h->txres;
+  p->w_idx += r.slice_idx;
+  p->w_byte = r.byte_idx;
+  *done = r.done ? 1 : 0;
+  if (r.done) {
+    p->w_active = false;
+    p->w_slices.clear();
+  }
+  return (int64_t)r.sent;
+}
+
+// ---- endpoint read: rdma_read / rdma_continue_read / rdma_do_read -----------
+int64_t grdma_endpoint_read(grdma_pair* p, uint64_t max_reads, grdma_read_slice* slices,
+                            uint64_t slices_cap, int* would_block) {
+  if (int rc = require_ctx()) return rc;
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (max_reads > slices_cap) max_reads = slices_cap;
+  if (max_reads > GRDMA_MAX_SLICES) max_reads = GRDMA_MAX_SLICES;
+  if (max_reads == 0) return 0;
+  if (int rc = run_recv(p, p->d_arena, p->arena_cap, max_reads, 0)) return rc;
+  const grdma_rx_result& r = p->h->rxres;
+  for (uint64_t i = 0; i < r.nslices; i++) {
+    slices[i].off = p->h_slices[i].off;
+    slices[i].len = p->h_slices[i].len;
+  }
+  if (would_block) *would_block = (int)r.would_block;
+  return (int64_t)r.nslices;
+}
+
+// ---- small device helpers -------------------------------------------------------
+void* grdma_device_alloc(uint64_t bytes) {
+  if (require_ctx()) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    fail(GRDMA_ERR_HIP, "hipMalloc(%llu) failed", (unsigned long long)bytes);
+    return nullptr;
+  }
+  return p;
+}
+void grdma_device_free(void* p) { if (p) hipFree(p); }
+void* grdma_host_alloc_pinned(uint64_t bytes) {
+  if (require_ctx()) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void grdma_host_free_pinned(void* p) { if (p) hipHostFree(p); }
+int grdma_copy_to_device(void* dst, const void* src, uint64_t n) {
+  if (int rc = require_ctx()) return rc;
+  HIP_TRY(hipMemcpy(dst, src, n, hipMemcpyHostToDevice));
+  return 0;
+}
+int grdma_copy_to_host(void* dst, const void* src, uint64_t n) {
+  if (int rc = require_ctx()) return rc;
+  HIP_TRY(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+  return 0;
+}
+int grdma_device_synchronize(void) {
+  if (int rc = require_ctx()) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  return 0;
+}
+
+}  // extern "C"

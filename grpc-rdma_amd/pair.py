@@ -1,0 +1,183 @@
+"""Host-side mirror of PairPollable (src/core/lib/ibverbs/pair.h:106-152) and of
+the endpoint read/write loops (src/core/lib/iomgr/rdma_bp_posix.cc), as thin
+wrappers over the C ABI.  Same method names and argument meaning as the
+reference so the parity tests read like pair-level tests of the reference."""
+import ctypes as C
+
+from . import _lib
+from ._lib import GrdmaError, PairState, ReadSlice, Slice, check, load
+
+MEM_DEVICE, MEM_HOST = 0, 1
+WIRE_STAGED, WIRE_DIRECT = 0, 2
+
+
+class DeviceBuffer:
+    """A byte buffer in HBM (payloads that are already resident on the GPU)."""
+
+    def __init__(self, nbytes=None, data=None, offset=0):
+        lib = load()
+        if data is not None:
+            nbytes = len(data)
+        self.nbytes = nbytes
+        self.offset = offset  # lets tests place payloads at odd alignments
+        self._base = lib.grdma_device_alloc(nbytes + offset + 64)
+        if not self._base:
+            raise GrdmaError(lib.grdma_last_error().decode())
+        self.ptr = self._base + offset
+        if data is not None and nbytes:
+            src = C.create_string_buffer(bytes(data), nbytes)
+            check(lib.grdma_copy_to_device(self.ptr, src, nbytes))
+
+    def read(self, n=None, off=0):
+        n = self.nbytes - off if n is None else n
+        dst = C.create_string_buffer(max(1, n))
+        if n:
+            check(load().grdma_copy_to_host(dst, self.ptr + off, n))
+        return dst.raw[:n]
+
+    def free(self):
+        if self._base:
+            load().grdma_device_free(self._base)
+            self._base = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Pair:
+    def __init__(self, ring_size=4 << 20, max_sge=30, flags=WIRE_STAGED):
+        self.lib = load()
+        self.ring_size = ring_size
+        self.h = self.lib.grdma_pair_create(ring_size, max_sge, flags)
+        if not self.h:
+            raise GrdmaError(self.lib.grdma_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.grdma_pair_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- PairPollable ------------------------------------------------------------
+    @staticmethod
+    def _slices(slices):
+        """slices: list of (ptr, len) or DeviceBuffer or bytes (host memory)."""
+        arr = (Slice * max(1, len(slices)))()
+        keep, host = [], False
+        for i, s in enumerate(slices):
+            if isinstance(s, DeviceBuffer):
+                arr[i].ptr, arr[i].len = s.ptr, s.nbytes
+            elif isinstance(s, (bytes, bytearray)):
+                b = C.create_string_buffer(bytes(s), len(s)) if len(s) else C.create_string_buffer(1)
+                keep.append(b)
+                arr[i].ptr, arr[i].len = C.addressof(b), len(s)
+                host = True
+            else:
+                arr[i].ptr, arr[i].len = s
+        return arr, keep, host
+
+    def Send(self, slices, byte_idx=0, flags=None):
+        arr, keep, host = self._slices(slices)
+        if flags is None:
+            flags = MEM_HOST if host else MEM_DEVICE
+        return check(self.lib.grdma_pair_send(self.h, arr, len(slices), byte_idx, flags))
+
+    def Recv(self, capacity):
+        """-> bytes (copied to the host for inspection)."""
+        dst = C.create_string_buffer(max(1, capacity))
+        n = check(self.lib.grdma_pair_recv(self.h, dst, capacity, MEM_HOST))
+        return dst.raw[:n]
+
+    def HasMessage(self):
+        return bool(check(self.lib.grdma_pair_has_message(self.h)))
+
+    def HasPendingWrites(self):
+        return bool(check(self.lib.grdma_pair_has_pending_writes(self.h)))
+
+    def GetReadableSize(self):
+        return check(self.lib.grdma_pair_readable_size(self.h))
+
+    def GetWritableSize(self):
+        return check(self.lib.grdma_pair_writable_size(self.h))
+
+    def get_status(self):
+        return check(self.lib.grdma_pair_get_status(self.h))
+
+    def Disconnect(self):
+        check(self.lib.grdma_pair_disconnect(self.h))
+
+    # -- endpoint ------------------------------------------------------------------
+    def endpoint_write(self, slices, flags=None):
+        """rdma_write + the rdma_flush retries.  -> list of per-step sent counts;
+        stops early (list ends with 0) when no credit is left."""
+        arr, keep, host = self._slices(slices)
+        if flags is None:
+            flags = MEM_HOST if host else MEM_DEVICE
+        check(self.lib.grdma_endpoint_write_begin(self.h, arr, len(slices), flags))
+        return self.endpoint_write_continue()
+
+    def endpoint_write_continue(self):
+        steps, done = [], C.c_int(0)
+        while not done.value:
+            n = check(self.lib.grdma_endpoint_write_step(self.h, C.byref(done)))
+            steps.append(n)
+            if n == 0:
+                break
+        return steps, bool(done.value)
+
+    def endpoint_read(self, max_reads=1):
+        """-> (list of bytes, one per endpoint_read completion, would_block)."""
+        cap = min(max_reads, 4096)
+        arr = (ReadSlice * cap)()
+        wb = C.c_int(0)
+        n = check(self.lib.grdma_endpoint_read(self.h, max_reads, arr, cap, C.byref(wb)))
+        out = []
+        for i in range(n):
+            dst = C.create_string_buffer(max(1, arr[i].len))
+            check(self.lib.grdma_pair_arena_copy_out(self.h, arr[i].off, dst, arr[i].len))
+            out.append(dst.raw[:arr[i].len])
+        return out, bool(wb.value)
+
+    # -- observability -------------------------------------------------------------
+    def state(self):
+        st = PairState()
+        check(self.lib.grdma_pair_state_get(self.h, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in PairState._fields_}
+
+    def ring_mem(self):
+        dst = C.create_string_buffer(self.ring_size)
+        check(self.lib.grdma_pair_peek_ring(self.h, 0, dst, self.ring_size))
+        return dst.raw
+
+    def staging_mem(self, n):
+        dst = C.create_string_buffer(max(1, n))
+        if n:
+            check(self.lib.grdma_pair_peek_staging(self.h, 0, dst, n))
+        return dst.raw[:n]
+
+    def last_wrs(self):
+        out = ((C.c_uint64 * 2) * 2)()
+        n = check(self.lib.grdma_pair_last_wrs(self.h, C.byref(out)))
+        return [(int(out[i][0]), int(out[i][1])) for i in range(n)]
+
+
+def connect_pairs(a, b):
+    check(load().grdma_pair_connect(a.h, b.h))
+
+
+def poll_pairs(pairs):
+    """Batched HasMessage/GetReadableSize: -> (readable list, has_message list)."""
+    n = len(pairs)
+    hs = (C.c_void_p * n)(*[p.h for p in pairs])
+    rd = (C.c_uint64 * n)()
+    hm = (C.c_uint8 * n)()
+    check(load().grdma_poll_pairs(hs, n, rd, hm))
+    return [int(x) for x in rd], [bool(x) for x in hm]

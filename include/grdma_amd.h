@@ -1,0 +1,173 @@
+/* grdma_amd.h -- C ABI of the MI355X-native RDMA_BP/BPEV endpoint data plane.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch
+ * types.  Each entry point names the reference interface it replaces (paths
+ * relative to the pwrliang/grpc-rdma tree).  INTEGRATION.md shows the C++
+ * adapter that fills the real grpc_endpoint_vtable from these calls.
+ *
+ * Memory model: rings, staging buffers, credit words and the per-connection
+ * protocol state live in device HBM.  `grdma_slice.ptr` may point to device
+ * memory or to host memory that is device-accessible (hipHostMalloc /
+ * hipHostRegister); plain pageable host memory is accepted when the call is
+ * flagged GRDMA_MEM_HOST (the library then stages it through a pinned bounce
+ * buffer).  All functions return <0 (a negated grdma_error) on failure and
+ * never fall back to a CPU implementation: without a usable HIP device
+ * grdma_init() fails and every other call reports GRDMA_ERR_NO_DEVICE.
+ */
+#ifndef GRDMA_AMD_H
+#define GRDMA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRDMA_ABI_VERSION 1
+
+enum grdma_error {
+  GRDMA_OK = 0,
+  GRDMA_ERR_NO_DEVICE = 1,   /* no HIP device / HIP runtime failure at init          */
+  GRDMA_ERR_INVALID = 2,     /* bad argument (ring size not a power of two, ...)     */
+  GRDMA_ERR_HIP = 3,         /* a HIP call failed; see grdma_last_error()            */
+  GRDMA_ERR_NOT_CONNECTED = 4,
+  GRDMA_ERR_CAPACITY = 5,    /* slice list / arena larger than the configured caps   */
+  GRDMA_ERR_CONFIG = 6       /* GRPC_PLATFORM_TYPE / GRPC_RDMA_* value rejected      */
+};
+
+/* ---- platform selection: src/core/lib/iomgr/iomgr_internal.cc:37-62 --------- */
+enum grdma_platform {          /* iomgr_internal.h:45 platform_t */
+  GRDMA_IOMGR_TCP = 0,
+  GRDMA_IOMGR_RDMA_BP = 1,
+  GRDMA_IOMGR_RDMA_BPEV = 2,
+  GRDMA_IOMGR_RDMA_EVENT = 3
+};
+/* Parses a GRPC_PLATFORM_TYPE value: NULL/unset -> TCP, exact strings "TCP",
+ * "RDMA_BP", "RDMA_BPEV", "RDMA_EVENT"; anything else -> -GRDMA_ERR_CONFIG
+ * (the reference calls exit(1) there, iomgr_internal.cc:57-58). */
+int grdma_parse_platform(const char* value);
+/* grpc_determine_iomgr_platform(): reads the environment once. */
+int grdma_determine_platform(void);
+
+/* ---- Config: src/core/lib/ibverbs/config.cc:45-115 --------------------------- */
+typedef struct grdma_config {
+  char device_name[64];              /* GRPC_RDMA_DEVICE_NAME   ("" = first)      */
+  int32_t port_num;                  /* GRPC_RDMA_PORT_NUM      (1)               */
+  int32_t gid_index;                 /* GRPC_RDMA_GID_INDEX     (0)               */
+  int32_t poller_thread_num;         /* GRPC_RDMA_POLLER_THREAD_NUM (1)           */
+  int32_t busy_polling_timeout_us;   /* GRPC_RDMA_BUSY_POLLING_TIMEOUT_US (500)   */
+  int32_t poller_sleep_timeout_ms;   /* GRPC_RDMA_POLLER_SLEEP_TIMEOUT_MS (1000)  */
+  uint32_t ring_buffer_size_kb;      /* GRPC_RDMA_RING_BUFFER_SIZE_KB (4096)      */
+  uint32_t zerocopy_buffer_size_kb;  /* reads the SAME variable (config.cc:100-106), 32768 */
+  uint32_t zerocopy_threshold_kb;    /* GRPC_RDMA_ZEROCOPY_THRESHOLD_KB (UINT32_MAX) */
+  int32_t max_sge;                   /* GRPC_RDMA_MAX_SGE: this build's stand-in for
+                                        the HCA attribute max_sge (pair.cc:53-60); 30 */
+  int32_t hip_device;                /* GRPC_RDMA_HIP_DEVICE (LOCAL_RANK or 0)    */
+} grdma_config;
+int grdma_config_from_env(grdma_config* out);
+
+/* ---- library / device ------------------------------------------------------------ */
+int grdma_init(int hip_device);      /* Device::Get(), device.cc:45-101           */
+int grdma_device_count(void);
+const char* grdma_last_error(void);
+int grdma_abi_version(void);
+
+/* ---- PairPollable: src/core/lib/ibverbs/pair.h:106-152 ---------------------- */
+typedef struct grdma_pair grdma_pair;
+
+typedef struct grdma_slice {         /* GRPC_SLICE_START_PTR / GRPC_SLICE_LENGTH  */
+  const void* ptr;
+  uint64_t len;
+} grdma_slice;
+
+enum grdma_flags {
+  GRDMA_MEM_DEVICE = 0,   /* slice pointers are device-accessible                  */
+  GRDMA_MEM_HOST = 1,     /* pageable host memory: stage through the bounce buffer */
+  GRDMA_WIRE_STAGED = 0,  /* records are built in the staging buffer, then written
+                             to the peer ring by <=2 wire writes (what a NIC needs) */
+  GRDMA_WIRE_DIRECT = 2   /* loop-back / xGMI peer: encode straight into the ring  */
+};
+
+/* PairPollable() + Init(): allocates the HBM ring (ring_size bytes, power of
+ * two > 24, ring_buffer.cc:22-24), the ring/2 staging buffer (pair.cc:104), the
+ * status words and a receive arena.  pair.cc:21-76, 85-141. */
+grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags);
+/* Connect(): the loop-back wire replaces the 48-byte address exchange + QP
+ * bring-up (rdma_bp_posix.cc:767-771, pair.cc:143-168).  Both ends must use the
+ * same ring size (asserted at pair.cc:149). */
+int grdma_pair_connect(grdma_pair* a, grdma_pair* b);
+int grdma_pair_disconnect(grdma_pair* p);          /* Disconnect(), pair.cc:325-347 */
+void grdma_pair_destroy(grdma_pair* p);
+int grdma_pair_get_status(grdma_pair* p);          /* get_status(), pair.cc:349-375 */
+
+/* Send(slices, count, byte_idx), pair.cc:645-734.  Returns payload bytes
+ * accepted (a prefix of the slice list) or <0. */
+int64_t grdma_pair_send(grdma_pair* p, const grdma_slice* slices, uint64_t count,
+                        uint64_t byte_idx, int flags);
+/* Recv(buf, capacity), pair.cc:264-286: one RingBufferPollable::Read.  dst is
+ * device-accessible memory (or host memory with GRDMA_MEM_HOST). */
+int64_t grdma_pair_recv(grdma_pair* p, void* dst, uint64_t capacity, int flags);
+int grdma_pair_has_message(grdma_pair* p);         /* HasMessage(), ring_buffer.cc:56-65   */
+int grdma_pair_has_pending_writes(grdma_pair* p);  /* HasPendingWrites(), pair.cc:303      */
+int64_t grdma_pair_readable_size(grdma_pair* p);   /* GetReadableSize(), ring_buffer.cc:67 */
+int64_t grdma_pair_writable_size(grdma_pair* p);   /* GetWritableSize(), pair.cc:294-301   */
+
+/* Observability used by the parity tests (debug monitor of pair.h:235-270). */
+typedef struct grdma_pair_state {
+  uint64_t head, moving_head, remain;              /* ring_buffer.h:203-205 */
+  uint64_t remote_tail, remote_head;               /* pair.h:170, 229-233   */
+  uint64_t internal_read_size, credit_msgs, partial_write;
+  uint64_t total_read, total_written, leftover_cap;
+} grdma_pair_state;
+int grdma_pair_state_get(grdma_pair* p, grdma_pair_state* out);
+/* Copies `len` bytes of the pair's HBM ring / staging buffer to host memory. */
+int grdma_pair_peek_ring(grdma_pair* p, uint64_t off, void* host_dst, uint64_t len);
+int grdma_pair_peek_staging(grdma_pair* p, uint64_t off, void* host_dst, uint64_t len);
+/* Last Send's work requests {remote ring offset, length}; returns the count
+ * (GetWriteRequests, ring_buffer.cc:261-330). */
+int grdma_pair_last_wrs(grdma_pair* p, uint64_t out[2][2]);
+void* grdma_pair_ring_device_ptr(grdma_pair* p);
+
+/* ---- endpoint read/write on the pair: rdma_bp_posix.cc ----------------------- */
+typedef struct grdma_read_slice { uint64_t off, len; } grdma_read_slice;
+
+/* rdma_write()/rdma_flush() (rdma_bp_posix.cc:470-586): sends as much of the
+ * slice list as credit allows, continuing from the internal cursor
+ * (outgoing_byte_idx).  *done = 1 when the whole buffer went out; otherwise the
+ * caller retries when the pair becomes writable (notify_on_write). */
+int64_t grdma_endpoint_write_begin(grdma_pair* p, const grdma_slice* slices, uint64_t count,
+                                   int flags);
+int64_t grdma_endpoint_write_step(grdma_pair* p, int* done);
+
+/* rdma_read()/rdma_continue_read()/rdma_do_read() (rdma_bp_posix.cc:180-376):
+ * performs up to max_reads endpoint_read completions in ONE device pass; each
+ * completion is one slice in the pair's receive arena.  Returns the number of
+ * completions; slices[i] = {arena offset, length}.  *would_block = 1 when the
+ * last attempt found no complete record (the endpoint re-arms notify_on_read). */
+int64_t grdma_endpoint_read(grdma_pair* p, uint64_t max_reads, grdma_read_slice* slices,
+                            uint64_t slices_cap, int* would_block);
+void* grdma_pair_arena_device_ptr(grdma_pair* p);
+uint64_t grdma_pair_arena_size(grdma_pair* p);
+int grdma_pair_arena_copy_out(grdma_pair* p, uint64_t off, void* host_dst, uint64_t len);
+
+/* ---- K3 batched message-ready detection ------------------------------------------- */
+/* HasMessage()/GetReadableSize() for n pairs in one launch (the busy-poll scan
+ * of ev_epollex_rdma_bpev_linux.cc:1105-1149 / poller.cc:84).  readable[i] = bytes,
+ * has_message[i] = 0/1. */
+int grdma_poll_pairs(grdma_pair* const* pairs, uint32_t n, uint64_t* readable,
+                     uint8_t* has_message);
+
+/* ---- device helpers for callers that keep payloads in HBM ---------------------- */
+void* grdma_device_alloc(uint64_t bytes);
+void grdma_device_free(void* p);
+void* grdma_host_alloc_pinned(uint64_t bytes);
+void grdma_host_free_pinned(void* p);
+int grdma_copy_to_device(void* dst, const void* src, uint64_t n);
+int grdma_copy_to_host(void* dst, const void* src, uint64_t n);
+int grdma_device_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRDMA_AMD_H */

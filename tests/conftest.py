@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def gpu(built):
+    """Initialised HIP data plane; fails loudly when there is no device."""
+    import grpc_rdma_amd as g
+    g.init(0)
+    return g
