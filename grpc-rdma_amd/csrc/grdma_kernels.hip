@@ -598,18 +598,18 @@ __global__ __launch_bounds__(COPY_THREADS) void k_zero(const grdma_rx_op* ops) {
   const uint64_t gsz = (uint64_t)gridDim.x * COPY_THREADS;
 #pragma unroll
   for (int r = 0; r < 2; r++) {
-    uint64_t off = res->zero_off[r], len = res->zero_len[r];  // both multiples of 8
+    // byte-granular: a partial Read (remain_ > 0) leaves moving_head_ unaligned
+    const uint64_t off = res->zero_off[r], len = res->zero_len[r];
     if (len == 0) continue;
-    uint64_t* p = reinterpret_cast<uint64_t*>(ring + off);
-    uint64_t words = len >> 3;
-    // 8-byte lead-in so the bulk is 16-byte aligned
-    uint64_t lead = (off & 8) ? 1 : 0;
-    if (lead > words) lead = words;
-    if (gtid == 0 && lead) p[0] = 0;
+    uint8_t* p = ring + off;
+    uint64_t lead = (16 - ((uint64_t)p & 15)) & 15;
+    if (lead > len) lead = len;
+    if (gtid < lead) p[gtid] = 0;
     u32x4* q = reinterpret_cast<u32x4*>(p + lead);
-    uint64_t units = (words - lead) >> 1;
+    const uint64_t units = (len - lead) >> 4;
     for (uint64_t u = gtid; u < units; u += gsz) q[u] = u32x4{0, 0, 0, 0};
-    if (gtid == 0 && ((words - lead) & 1)) p[words - 1] = 0;
+    const uint64_t tail = (len - lead) & 15;
+    if (gtid < tail) p[lead + (units << 4) + gtid] = 0;
   }
 }
 
