@@ -77,14 +77,25 @@ struct grdma_conn {
   // ---- credit the peer granted me (written remotely) --------------------------
   struct grdma_status_report status_recv;   // recv_buffers_[kStatusBuffer]
   struct grdma_status_report status_send;   // send_buffers_[kStatusBuffer]
-  uint64_t pad1[8];
+  // ---- streaming-job cursors (append mode of the drain) -----------------------
+  uint64_t rx_arena_off;        // next free byte of the caller's destination buffer
+  uint64_t rx_slice_idx;        // next free entry of the caller's slice table
+  uint64_t tx_rounds;           // Send() calls that produced at least one record
+  uint64_t rx_rounds;           // drains that delivered at least one slice
+  uint64_t tx_records;          // ring records produced
+  uint64_t rx_records;          // ring records consumed
+  uint32_t rx_blocks_done;      // k_rx_apply arrival counter (last block commits)
+  uint32_t pad2;
+  uint64_t pad1[1];
 };
 
 struct grdma_seg {
   uint64_t dst;
-  uint64_t src;   // 0 = fill with zero bytes
+  uint64_t src;    // 0 = fill dst with zero bytes
   uint64_t len;
+  uint64_t flags;  // GRDMA_SEG_ZERO_SRC: clear the source bytes after copying them
 };
+#define GRDMA_SEG_ZERO_SRC 1ull
 
 struct grdma_slice_out {  // one completed endpoint_read: a single slice
   uint64_t off;           // offset into the receive arena

@@ -18,12 +18,13 @@
 //               loop-back wire, and ring->slice scatter (RX).
 //   k_rx_plan   one wave per connection: walks the record chain from head_
 //               (header tag + footer tag = message-ready test of
-//               GetReadableSize, ring_buffer.cc:67-97), replays the
-//               endpoint_read loop of rdma_bp_posix.cc:180-326 to decide slice
-//               boundaries, does the credit accounting of Recv()
-//               (pair.cc:264-286) and posts the 16-byte status report.
-//   k_zero      clears the consumed ring bytes (reader zero-fill invariant,
-//               ring_buffer.cc:146,160,164,173-180).
+//               GetReadableSize, ring_buffer.cc:67-97) 64 speculative probes per
+//               memory round trip, replays the endpoint_read loop of
+//               rdma_bp_posix.cc:180-326 to decide slice boundaries, does the
+//               credit accounting of Recv() (pair.cc:264-286), clears the tags.
+//   k_rx_apply  K4: scatters the payload to the slices, clears it behind itself
+//               (reader zero-fill invariant, ring_buffer.cc:146,160,164,173-180);
+//               the last workgroup posts the 16-byte status report.
 //   k_poll      K3 batched: one lane per connection, 64 connections per wave,
 //               __ballot() of the ready set (HasMessage / GetReadableSize).
 //
@@ -234,12 +235,12 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
     uint64_t seg = i + (i > wrap_rec ? 1 : 0);
     if (i == wrap_rec) {
       uint64_t l1 = cap - pay_off;
-      plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, l1};
-      plan->segs[seg + 1] = {(uint64_t)dbase, (uint64_t)(src + l1), p - l1};
+      plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, l1, 0};
+      plan->segs[seg + 1] = {(uint64_t)dbase, (uint64_t)(src + l1), p - l1, 0};
       seg_tiles[k][0] = (l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
       seg_tiles[k][1] = (p - l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
     } else {
-      plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, p};
+      plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, p, 0};
       seg_tiles[k][0] = (p + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
     }
     tiles_chunk += seg_tiles[k][0] + seg_tiles[k][1];
@@ -292,12 +293,12 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
     if (wp != nullptr) {
       uint32_t ns = 0, nt = 0;
       if (!direct && staged > 0) {
-        wp->segs[0] = {(uint64_t)(c->peer_ring + tail0), (uint64_t)c->staging, seg1};
+        wp->segs[0] = {(uint64_t)(c->peer_ring + tail0), (uint64_t)c->staging, seg1, 0};
         wp->tile_prefix[0] = 0;
         nt = (uint32_t)((seg1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
         ns = 1;
         if (staged > seg1) {
-          wp->segs[1] = {(uint64_t)c->peer_ring, (uint64_t)(c->staging + seg1), staged - seg1};
+          wp->segs[1] = {(uint64_t)c->peer_ring, (uint64_t)(c->staging + seg1), staged - seg1, 0};
           wp->tile_prefix[1] = nt;
           nt += (uint32_t)((staged - seg1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
           ns = 2;
@@ -316,6 +317,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
     c->remote_tail = new_tail;
     c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709
     c->total_written += sent;
+    c->tx_records += nrec_total;
+    if (nrec_total) c->tx_rounds++;
     if (op.use_cursor) {
       c->tx_slice_idx = idx;
       c->tx_byte_idx = bidx;
@@ -396,14 +399,24 @@ __device__ __forceinline__ void wave_copy_tile(uint8_t* dst, const uint8_t* src,
   }
 }
 
-__global__ __launch_bounds__(COPY_THREADS) void k_copy(const grdma_plan* const* plans) {
-  const grdma_plan* plan = plans[blockIdx.y];
+// Reader zero-fill (ring_buffer.cc:160,164): clear exactly [p, p+n).
+__device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane) {
+  uint64_t head = (16 - ((uint64_t)p & 15)) & 15;
+  if (head > n) head = n;
+  if ((uint64_t)lane < head) p[lane] = 0;
+  p += head;
+  n -= head;
+  const uint64_t units = n >> 4;
+  u32x4* q = reinterpret_cast<u32x4*>(p);
+  for (uint64_t u = lane; u < units; u += 64) q[u] = u32x4{0, 0, 0, 0};
+  const uint64_t tail = n & 15;
+  if ((uint64_t)lane < tail) p[(units << 4) + lane] = 0;
+}
+
+__device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t wave,
+                                               uint32_t nwaves, int lane) {
   const uint32_t nsegs = plan->nsegs;
   const uint32_t ntiles = plan->ntiles;
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * COPY_THREADS + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * COPY_THREADS) >> 6;
-  if (wave >= ntiles) return;
   // tile -> segment: binary search of the tile prefix (wave-uniform)
   for (uint32_t t = wave; t < ntiles; t += nwaves) {
     uint32_t lo = 0, hi = nsegs;  // invariant: prefix[lo] <= t < prefix[hi]
@@ -415,38 +428,111 @@ __global__ __launch_bounds__(COPY_THREADS) void k_copy(const grdma_plan* const* 
     const uint64_t off = (uint64_t)(t - plan->tile_prefix[lo]) * GRDMA_TILE_BYTES;
     uint64_t n = sg.len - off;
     if (n > GRDMA_TILE_BYTES) n = GRDMA_TILE_BYTES;
-    wave_copy_tile(reinterpret_cast<uint8_t*>(sg.dst + off),
-                   sg.src ? reinterpret_cast<const uint8_t*>(sg.src + off) : nullptr, n, lane);
+    uint8_t* src = sg.src ? reinterpret_cast<uint8_t*>(sg.src + off) : nullptr;
+    wave_copy_tile(reinterpret_cast<uint8_t*>(sg.dst + off), src, n, lane);
+    if ((sg.flags & GRDMA_SEG_ZERO_SRC) && src) {
+      // every load of this tile has returned (its data fed the stores above);
+      // make that explicit before the source bytes are overwritten
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wave_zero_tile(src, n, lane);
+    }
   }
+}
+
+__global__ __launch_bounds__(COPY_THREADS) void k_copy(const grdma_plan* const* plans) {
+  const grdma_plan* plan = plans[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * COPY_THREADS + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * COPY_THREADS) >> 6;
+  run_plan_tiles(plan, wave, nwaves, lane);
 }
 
 // ----------------------------------------------------------------------------
 // k_rx_plan: message-ready test + record chain walk + endpoint_read replay
 // ----------------------------------------------------------------------------
-struct ring_probe {
-  uint64_t n;      // header value at `pos`
-  bool ready;      // header valid and footer tag present
+// The record chain is a linked list (each header gives the next offset), so a
+// naive walk costs one dependent HBM/L2 round trip per record.  Here one wave
+// probes 64 *predicted* positions per round trip: record sizes on a gRPC
+// connection repeat with period 2 (9-byte DATA frame header slice, 16 KiB
+// payload slice), so lane j loads the tag words at the position the chain
+// reaches after j records if the last two sizes keep alternating.  The chain
+// is then verified lane by lane in registers (readlane), stopping at the first
+// misprediction; a round always resolves at least one record.
+#define CHAIN_CAP 128
+
+struct chain_state {
+  uint64_t e_prev1;  // encoded size of the most recent verified record (0 = unknown)
+  uint64_t e_prev2;  // the one before it
 };
 
-__device__ __forceinline__ ring_probe probe_record(const uint8_t* ring, uint64_t cap,
-                                                   uint64_t pos) {
-  // GetReadableSize, ring_buffer.cc:67-97
-  ring_probe r;
-  r.n = ld_tag(ring + pos);
-  r.ready = false;
-  if (r.n == 0 || r.n > cap - GRDMA_RESERVED) return r;  // empty / torn header
-  uint64_t f = (pos + 8 + round_up8(r.n)) & (cap - 1);
-  r.ready = ld_tag(ring + f) == GRDMA_FOOTER;
-  return r;
+// Verifies up to CHAIN_CAP ready records starting at ring offset `pos` and
+// stores their payload sizes in chain[0..count).  Returns count; *exhausted is
+// set when the walk stopped on a position that holds no complete record.
+__device__ __forceinline__ uint32_t chain_refill(const uint8_t* ring, uint64_t cap, uint64_t pos,
+                                                 chain_state* cs, uint64_t* chain,
+                                                 bool* exhausted, int lane) {
+  const uint64_t mask = cap - 1;
+  uint32_t count = 0;
+  *exhausted = false;
+  while (count + 64 <= CHAIN_CAP) {
+    // predicted offsets: pos, pos+ea, pos+ea+eb, ... (ea = two back, eb = one back)
+    uint64_t ea = cs->e_prev2 ? cs->e_prev2 : cs->e_prev1;
+    uint64_t eb = cs->e_prev1;
+    uint64_t rel = (uint64_t)(lane >> 1) * (ea + eb) + ((lane & 1) ? ea : 0);
+    if (ea == 0) rel = 0;  // nothing known yet: only lane 0 is meaningful
+    const uint64_t my_pos = (pos + rel) & mask;
+    const uint64_t hdr = ld_tag(ring + my_pos);
+    const uint64_t prev = ld_tag(ring + ((my_pos + cap - 8) & mask));  // footer of the previous record
+    bool stop = false;
+    uint64_t cur = pos;
+    int s = 0;
+    for (; s < 64; s++) {
+      const uint64_t n = __shfl(hdr, s, 64);
+      if (n == 0 || n > cap - GRDMA_RESERVED) {  // empty or torn header: not ready
+        stop = true;
+        *exhausted = true;
+        break;
+      }
+      const uint64_t enc = 16 + round_up8(n);
+      const uint64_t nxt = (cur + enc) & mask;
+      uint64_t foot;
+      bool predicted = false;
+      if (s < 63) {
+        const uint64_t npos = __shfl(my_pos, s + 1, 64);
+        if (npos == nxt && (ea != 0)) {
+          foot = __shfl(prev, s + 1, 64);
+          predicted = true;
+        }
+      }
+      if (!predicted) foot = ld_tag(ring + ((nxt + cap - 8) & mask));
+      if (foot != GRDMA_FOOTER) {  // header landed, footer not yet: not ready
+        stop = true;
+        *exhausted = true;
+        break;
+      }
+      if (lane == 0) chain[count] = n;
+      count++;
+      cs->e_prev2 = cs->e_prev1;
+      cs->e_prev1 = enc;
+      cur = nxt;
+      if (!predicted) {  // continue from here with the corrected pattern
+        s++;
+        break;
+      }
+    }
+    pos = cur;
+    if (stop) break;
+  }
+  return count;
 }
 
 __global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
   const grdma_rx_op op = ops[blockIdx.x];
-  if (threadIdx.x != 0) return;  // the record chain is a linked list: one lane walks it
+  const int lane = threadIdx.x;
   grdma_conn* c = op.conn;
   grdma_plan* plan = op.plan;
   grdma_rx_result* res = op.result;
-  const uint8_t* ring = c->ring;
+  uint8_t* ring = c->ring;
   const uint64_t cap = c->cap, mask = cap - 1;
   uint64_t head = c->head, mh = c->moving_head, remain = c->remain;
   uint64_t irs = c->internal_read_size, leftover = c->leftover_cap;
@@ -454,39 +540,84 @@ __global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
   uint64_t nslices = 0, nsegs = 0, ntiles = 0, bytes = 0, consumed_total = 0, records = 0;
   uint64_t a_off = 0, would_block = 0, credit = 0, credit_head = 0;
   const bool connected = c->status == GRDMA_PAIR_CONNECTED;
+  grdma_slice_out* out_slices = op.slices;
+  uint64_t max_slices = GRDMA_MAX_SLICES;
+  if (op.append == 2) {  // first round of a streaming job
+    if (lane == 0) {
+      c->rx_arena_off = 0;
+      c->rx_slice_idx = 0;
+    }
+  }
+  if (op.append) {  // streaming job: keep filling the caller's buffer / slice table
+    const uint64_t s_idx = op.append == 2 ? 0 : c->rx_slice_idx;
+    a_off = op.append == 2 ? 0 : c->rx_arena_off;
+    out_slices = op.slices + s_idx;
+    const uint64_t room = op.slices_cap > s_idx ? op.slices_cap - s_idx : 0;
+    if (room < max_slices) max_slices = room;
+  }
+
+  __shared__ uint64_t s_chain[CHAIN_CAP];
+  chain_state cs = {0, 0};
+  uint32_t chain_n = 0, chain_i = 0;
+  bool chain_dry = false;  // the walk hit a position without a complete record
+  uint64_t chain_pos = head;  // ring offset of the next unverified record
+
+  // size of the next unopened record if it is completely there, else 0
+  auto next_ready = [&]() -> uint64_t {
+    if (chain_i == chain_n) {
+      if (chain_dry) return 0;
+      chain_n = chain_refill(ring, cap, chain_pos, &cs, s_chain, &chain_dry, lane);
+      chain_i = 0;
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      // advance chain_pos past the verified records
+      for (uint32_t k = 0; k < chain_n; k++) chain_pos = (chain_pos + 16 + round_up8(s_chain[k])) & mask;
+      if (chain_n == 0) return 0;
+    }
+    return s_chain[chain_i];
+  };
 
   // PairPollable::Recv -> RingBufferPollable::Read(dst, capacity)
   // (pair.cc:264-286, ring_buffer.cc:122-191); returns the bytes copied.
   auto recv_step = [&](uint64_t dst, uint64_t capacity) -> uint64_t {
     uint64_t avail = remain;
-    if (avail == 0) {
-      ring_probe pr = probe_record(ring, cap, head);
-      avail = pr.ready ? pr.n : 0;
-    }
+    if (avail == 0) avail = next_ready();
     const uint64_t cpy = avail < capacity ? avail : capacity;
     if (cpy == 0) return 0;
     const uint64_t prev_mh = mh;
     if (remain == 0) {  // open the record, ring_buffer.cc:133-146
+      if (lane == 0) *reinterpret_cast<uint64_t*>(ring + head) = 0;  // clear header
       mh = (head + 8) & mask;
       head = (head + 16 + round_up8(avail)) & mask;
       records++;
+      chain_i++;
     }
-    // payload bytes [mh, mh+cpy) -> dst, at most two pieces at the wrap
+    // payload bytes [mh, mh+cpy) -> dst, at most two pieces at the wrap; the
+    // copying wave clears them behind itself (ring_buffer.cc:160,164)
     const uint64_t l1 = cpy < cap - mh ? cpy : cap - mh;
-    plan->segs[nsegs] = {dst, (uint64_t)(ring + mh), l1};
-    plan->tile_prefix[nsegs] = (uint32_t)ntiles;
+    if (lane == 0) {
+      plan->segs[nsegs] = {dst, (uint64_t)(ring + mh), l1, GRDMA_SEG_ZERO_SRC};
+      plan->tile_prefix[nsegs] = (uint32_t)ntiles;
+    }
     ntiles += (l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
     nsegs++;
     if (cpy > l1) {
-      plan->segs[nsegs] = {dst + l1, (uint64_t)ring, cpy - l1};
-      plan->tile_prefix[nsegs] = (uint32_t)ntiles;
+      if (lane == 0) {
+        plan->segs[nsegs] = {dst + l1, (uint64_t)ring, cpy - l1, GRDMA_SEG_ZERO_SRC};
+        plan->tile_prefix[nsegs] = (uint32_t)ntiles;
+      }
       ntiles += (cpy - l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
       nsegs++;
     }
     mh = (mh + cpy) & mask;
     remain = avail - cpy;
     if (remain == 0) {  // finish the record, ring_buffer.cc:169-182
-      mh = round_up8(mh) & mask;
+      const uint64_t pad_end = round_up8(mh);
+      if (lane == 0) {
+        for (uint64_t q = mh; q < pad_end; q++) ring[q & mask] = 0;  // clear padded space
+        *reinterpret_cast<uint64_t*>(ring + (pad_end & mask)) = 0;    // clear footer
+      }
+      mh = pad_end & mask;
       mh = (mh + 8) & mask;
     }
     const uint64_t consumed = (mh + cap - prev_mh) & mask;
@@ -504,20 +635,19 @@ __global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
   if (connected && op.raw_cap > 0) {
     // grdma_pair_recv(): exactly one Recv(buf, capacity)
     uint64_t n = recv_step((uint64_t)op.arena, op.raw_cap);
-    op.slices[0].off = 0;
-    op.slices[0].len = n;
+    if (lane == 0) {
+      out_slices[0].off = 0;
+      out_slices[0].len = n;
+    }
     nslices = n ? 1 : 0;
     bytes = n;
     a_off = n;
   } else {
-    while (connected && nslices < op.max_reads && nslices < GRDMA_MAX_SLICES &&
+    while (connected && nslices < op.max_reads && nslices < max_slices &&
            nsegs + 520 <= GRDMA_MAX_SEGS) {
       // rdma_continue_read, rdma_bp_posix.cc:306-317
       uint64_t readable = remain;
-      if (readable == 0) {
-        ring_probe pr = probe_record(ring, cap, head);
-        readable = pr.ready ? pr.n : 0;
-      }
+      if (readable == 0) readable = next_ready();
       const uint64_t alloc =
           leftover ? leftover
                    : (readable > GRDMA_MIN_READ_SLICE ? readable : GRDMA_MIN_READ_SLICE);
@@ -535,14 +665,17 @@ __global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
         break;
       }
       leftover = alloc - total;  // grpc_slice_buffer_trim_end -> last_read_buffer
-      op.slices[nslices].off = a_off;
-      op.slices[nslices].len = total;
+      if (lane == 0) {
+        out_slices[nslices].off = a_off;
+        out_slices[nslices].len = total;
+      }
       nslices++;
       bytes += total;
       a_off = (a_off + total + 15) & ~15ull;
     }
   }
 
+  if (lane != 0) return;
   plan->nsegs = (uint32_t)nsegs;
   plan->ntiles = (uint32_t)ntiles;
   plan->tile_prefix[nsegs] = (uint32_t)ntiles;
@@ -555,9 +688,16 @@ __global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
   c->leftover_cap = leftover;
   c->total_read += bytes;
   c->credit_msgs += credit;
+  c->rx_records += records;
+  if (nslices) c->rx_rounds++;
+  if (op.append) {
+    c->rx_arena_off = a_off;
+    c->rx_slice_idx = (op.append == 2 ? 0 : c->rx_slice_idx) + nslices;
+  }
+  c->rx_blocks_done = 0;
   // updateStatus() (pair.cc:624-641) must not overtake the copy-out and the
-  // zero-fill of the bytes it grants: the 16-byte report is posted by
-  // k_rx_commit, after k_copy and k_zero of this drain have completed.
+  // zero-fill of the bytes it grants: the 16-byte report is posted by the last
+  // workgroup of k_rx_apply.
   if (credit) c->status_send.remote_head = credit_head;
   res->credit_head = credit_head;
   res->nslices = nslices;
@@ -588,47 +728,55 @@ __global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
 }
 
 // ----------------------------------------------------------------------------
-// k_zero: reader zero-fill of the consumed ring range
+// k_rx_apply: K4 in one launch -- copy the payload out, clear it behind, and let
+// the last workgroup post the credit (status report) once every byte is free.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(COPY_THREADS) void k_zero(const grdma_rx_op* ops) {
+__global__ __launch_bounds__(COPY_THREADS) void k_rx_apply(const grdma_rx_op* ops) {
   const grdma_rx_op op = ops[blockIdx.y];
-  const grdma_rx_result* res = op.result;
-  uint8_t* ring = op.conn->ring;
-  const uint64_t gtid = (uint64_t)blockIdx.x * COPY_THREADS + threadIdx.x;
-  const uint64_t gsz = (uint64_t)gridDim.x * COPY_THREADS;
-#pragma unroll
-  for (int r = 0; r < 2; r++) {
-    // byte-granular: a partial Read (remain_ > 0) leaves moving_head_ unaligned
-    const uint64_t off = res->zero_off[r], len = res->zero_len[r];
-    if (len == 0) continue;
-    uint8_t* p = ring + off;
-    uint64_t lead = (16 - ((uint64_t)p & 15)) & 15;
-    if (lead > len) lead = len;
-    if (gtid < lead) p[gtid] = 0;
-    u32x4* q = reinterpret_cast<u32x4*>(p + lead);
-    const uint64_t units = (len - lead) >> 4;
-    for (uint64_t u = gtid; u < units; u += gsz) q[u] = u32x4{0, 0, 0, 0};
-    const uint64_t tail = (len - lead) & 15;
-    if (gtid < tail) p[lead + (units << 4) + gtid] = 0;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * COPY_THREADS + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * COPY_THREADS) >> 6;
+  run_plan_tiles(op.plan, wave, nwaves, lane);
+  // arrival: release my stores, count in, last one publishes
+  __shared__ unsigned int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int prev = __hip_atomic_fetch_add(&op.conn->rx_blocks_done, 1u, __ATOMIC_ACQ_REL,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (prev == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    grdma_rx_result* res = op.result;
+    if (res->credit_sent) {
+      grdma_status_report* ps = op.conn->peer_status;
+      if (ps != nullptr)
+        __hip_atomic_store(&ps->remote_head, res->credit_head, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(&res->commit_seq, res->commit_seq + 1, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
-// ----------------------------------------------------------------------------
-// k_rx_commit: post the credit (status report) once the bytes are really free
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_rx_commit(const grdma_rx_op* ops, uint32_t nops) {
-  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= nops) return;
-  const grdma_rx_op op = ops[i];
-  grdma_rx_result* res = op.result;
-  if (res->credit_sent) {
-    grdma_status_report* ps = op.conn->peer_status;
-    if (ps != nullptr)
-      __hip_atomic_store(&ps->remote_head, res->credit_head, __ATOMIC_RELEASE,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  __hip_atomic_store(&res->commit_seq, res->commit_seq + 1, __ATOMIC_RELEASE,
-                     __HIP_MEMORY_SCOPE_SYSTEM);
+struct ring_probe {
+  uint64_t n;      // header value at `pos`
+  bool ready;      // header valid and footer tag present
+};
+
+__device__ __forceinline__ ring_probe probe_record(const uint8_t* ring, uint64_t cap,
+                                                   uint64_t pos) {
+  // GetReadableSize, ring_buffer.cc:67-97
+  ring_probe r;
+  r.n = ld_tag(ring + pos);
+  r.ready = false;
+  if (r.n == 0 || r.n > cap - GRDMA_RESERVED) return r;  // empty / torn header
+  uint64_t f = (pos + 8 + round_up8(r.n)) & (cap - 1);
+  r.ready = ld_tag(ring + f) == GRDMA_FOOTER;
+  return r;
 }
 
 // ----------------------------------------------------------------------------
@@ -685,16 +833,10 @@ hipError_t grdma_launch_rx_plan(const grdma_rx_op* d_ops, uint32_t nops, hipStre
   return hipGetLastError();
 }
 
-hipError_t grdma_launch_zero(const grdma_rx_op* d_ops, uint32_t nops, uint32_t blocks_per_op,
-                             hipStream_t s) {
+hipError_t grdma_launch_rx_apply(const grdma_rx_op* d_ops, uint32_t nops, uint32_t blocks_per_op,
+                                 hipStream_t s) {
   if (nops == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_zero, dim3(blocks_per_op, nops), dim3(COPY_THREADS), 0, s, d_ops);
-  return hipGetLastError();
-}
-
-hipError_t grdma_launch_rx_commit(const grdma_rx_op* d_ops, uint32_t nops, hipStream_t s) {
-  if (nops == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_rx_commit, dim3((nops + 63) / 64), dim3(64), 0, s, d_ops, nops);
+  hipLaunchKernelGGL(k_rx_apply, dim3(blocks_per_op, nops), dim3(COPY_THREADS), 0, s, d_ops);
   return hipGetLastError();
 }
 

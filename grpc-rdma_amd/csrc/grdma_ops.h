@@ -30,6 +30,8 @@ struct grdma_rx_op {
   uint64_t arena_cap;
   uint64_t max_reads;              // stop after this many completions
   uint64_t raw_cap;                // != 0: one PairPollable::Recv(arena, raw_cap) instead
+  uint64_t append;                 // 1: continue at conn->rx_arena_off / rx_slice_idx
+  uint64_t slices_cap;             // entries in `slices` (append mode)
 };
 
 #endif  // GRDMA_OPS_H

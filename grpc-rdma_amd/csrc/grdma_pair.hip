@@ -25,8 +25,7 @@ extern "C" {
 hipError_t grdma_launch_tx_plan(const grdma_tx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_copy(const grdma_plan* const*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
-hipError_t grdma_launch_zero(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
-hipError_t grdma_launch_rx_commit(const grdma_rx_op*, uint32_t, hipStream_t);
+hipError_t grdma_launch_rx_apply(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*, uint64_t*,
                              hipStream_t);
 }
@@ -186,11 +185,11 @@ int run_recv(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_rea
   h->rxop.arena_cap = arena_cap;
   h->rxop.max_reads = max_reads;
   h->rxop.raw_cap = raw_cap;
+  h->rxop.append = 0;
+  h->rxop.slices_cap = GRDMA_MAX_SLICES;
   const uint32_t blocks = copy_blocks_for(p->ring_size);
   HIP_TRY(grdma_launch_rx_plan(&h->rxop, 1, p->stream));
-  HIP_TRY(grdma_launch_copy(&h->plan_ptrs[2], 1, blocks, p->stream));
-  HIP_TRY(grdma_launch_zero(&h->rxop, 1, blocks, p->stream));
-  HIP_TRY(grdma_launch_rx_commit(&h->rxop, 1, p->stream));
+  HIP_TRY(grdma_launch_rx_apply(&h->rxop, 1, blocks, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return 0;
 }
@@ -603,6 +602,227 @@ int grdma_device_synchronize(void) {
   if (int rc = require_ctx()) return rc;
   HIP_TRY(hipDeviceSynchronize());
   return 0;
+}
+
+}  // extern "C"
+
+// ---- device-resident streaming job -------------------------------------------------
+struct grdma_job_ctl {  // pinned, device-visible
+  grdma_tx_op txop[2];  // [0] first round (cursor reset), [1] later rounds
+  grdma_rx_op rxop[2];
+  grdma_tx_result txres;
+  grdma_rx_result rxres;
+  const grdma_plan* plan_ptrs[4];
+};
+
+struct grdma_stream_job {
+  grdma_pair* tx = nullptr;
+  grdma_pair* rx = nullptr;
+  grdma_sge* d_sges = nullptr;
+  uint64_t count = 0;
+  grdma_slice_out* d_slices = nullptr;
+  uint64_t slices_cap = 0;
+  uint8_t* dst = nullptr;
+  uint64_t dst_cap = 0;
+  uint64_t rounds = 0;
+  grdma_job_ctl* ctl = nullptr;
+  hipGraphExec_t exec = nullptr;
+  uint64_t exec_rounds = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> kev;
+};
+
+namespace {
+
+int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
+  const uint32_t tx_blocks = copy_blocks_for(j->tx->ring_size / 2);
+  const uint32_t rx_blocks = copy_blocks_for(j->rx->ring_size);
+  const bool direct = (j->tx->flags & GRDMA_WIRE_DIRECT) != 0;
+  size_t e = 0;
+  auto mark = [&]() -> int {
+    if (!instrument) return 0;
+    if (e >= j->kev.size()) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreate(&ev));
+      j->kev.push_back(ev);
+    }
+    HIP_TRY(hipEventRecord(j->kev[e++], s));
+    return 0;
+  };
+  if (int rc = mark()) return rc;
+  for (uint64_t r = 0; r < j->rounds; r++) {
+    const int k = r == 0 ? 0 : 1;
+    HIP_TRY(grdma_launch_tx_plan(&j->ctl->txop[k], 1, s));
+    if (int rc = mark()) return rc;
+    HIP_TRY(grdma_launch_copy(&j->ctl->plan_ptrs[0], 1, tx_blocks, s));
+    if (int rc = mark()) return rc;
+    if (!direct) HIP_TRY(grdma_launch_copy(&j->ctl->plan_ptrs[1], 1, tx_blocks, s));
+    if (int rc = mark()) return rc;
+    HIP_TRY(grdma_launch_rx_plan(&j->ctl->rxop[k], 1, s));
+    if (int rc = mark()) return rc;
+    HIP_TRY(grdma_launch_rx_apply(&j->ctl->rxop[k], 1, rx_blocks, s));
+    if (int rc = mark()) return rc;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,
+                                          const grdma_slice* slices, uint64_t count,
+                                          void* rx_dst, uint64_t rx_dst_cap,
+                                          uint64_t slices_cap, uint64_t max_rounds) {
+  if (require_ctx()) return nullptr;
+  if (!tx || !rx || tx->peer != rx || !slices || !count || !rx_dst) {
+    fail(GRDMA_ERR_INVALID, "stream job needs two connected pairs, slices and a destination");
+    return nullptr;
+  }
+  grdma_stream_job* j = new grdma_stream_job();
+  j->tx = tx;
+  j->rx = rx;
+  j->count = count;
+  j->dst = static_cast<uint8_t*>(rx_dst);
+  j->dst_cap = rx_dst_cap;
+  j->slices_cap = slices_cap;
+  j->rounds = max_rounds;
+  bool ok = hipMalloc((void**)&j->d_sges, sizeof(grdma_sge) * count) == hipSuccess &&
+            hipMalloc((void**)&j->d_slices, sizeof(grdma_slice_out) * slices_cap) == hipSuccess &&
+            hipHostMalloc((void**)&j->ctl, sizeof(grdma_job_ctl), hipHostMallocDefault) == hipSuccess &&
+            hipEventCreate(&j->ev0) == hipSuccess && hipEventCreate(&j->ev1) == hipSuccess;
+  if (!ok) {
+    fail(GRDMA_ERR_HIP, "stream job allocation failed");
+    grdma_stream_job_destroy(j);
+    return nullptr;
+  }
+  std::vector<grdma_sge> tmp(count);
+  for (uint64_t i = 0; i < count; i++) {
+    tmp[i].ptr = static_cast<const uint8_t*>(slices[i].ptr);
+    tmp[i].len = slices[i].len;
+  }
+  if (hipMemcpy(j->d_sges, tmp.data(), sizeof(grdma_sge) * count, hipMemcpyHostToDevice) !=
+      hipSuccess) {
+    fail(GRDMA_ERR_HIP, "slice table upload failed");
+    grdma_stream_job_destroy(j);
+    return nullptr;
+  }
+  memset(j->ctl, 0, sizeof(*j->ctl));
+  for (int k = 0; k < 2; k++) {
+    grdma_tx_op& t = j->ctl->txop[k];
+    t.conn = tx->d_conn;
+    t.slices = j->d_sges;
+    t.nslices = count;
+    t.plan = tx->d_txplan;
+    t.wire_plan = tx->d_wireplan;
+    t.result = &j->ctl->txres;
+    t.use_cursor = k == 0 ? 2 : 1;
+    grdma_rx_op& r = j->ctl->rxop[k];
+    r.conn = rx->d_conn;
+    r.plan = rx->d_rxplan;
+    r.result = &j->ctl->rxres;
+    r.slices = j->d_slices;
+    r.arena = j->dst;
+    r.arena_cap = rx_dst_cap;
+    r.max_reads = GRDMA_MAX_SLICES;
+    r.raw_cap = 0;
+    r.append = k == 0 ? 2 : 1;
+    r.slices_cap = slices_cap;
+  }
+  j->ctl->plan_ptrs[0] = tx->d_txplan;
+  j->ctl->plan_ptrs[1] = tx->d_wireplan;
+  j->ctl->plan_ptrs[2] = rx->d_rxplan;
+  return j;
+}
+
+void grdma_stream_job_destroy(grdma_stream_job* j) {
+  if (!j) return;
+  if (j->tx && j->tx->stream) hipStreamSynchronize(j->tx->stream);
+  if (j->exec) hipGraphExecDestroy(j->exec);
+  for (hipEvent_t e : j->kev) hipEventDestroy(e);
+  if (j->ev0) hipEventDestroy(j->ev0);
+  if (j->ev1) hipEventDestroy(j->ev1);
+  hipFree(j->d_sges);
+  hipFree(j->d_slices);
+  if (j->ctl) hipHostFree(j->ctl);
+  delete j;
+}
+
+int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds) {
+  if (!j || rounds == 0) return fail(GRDMA_ERR_INVALID, "bad rounds");
+  j->rounds = rounds;
+  return 0;
+}
+
+int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out) {
+  if (int rc = require_ctx()) return rc;
+  if (!j || !out) return fail(GRDMA_ERR_INVALID, "null argument");
+  hipStream_t s = j->tx->stream;
+  grdma_conn c0t, c0r;
+  if (int rc = fetch_conn(j->tx, &c0t)) return rc;
+  if (int rc = fetch_conn(j->rx, &c0r)) return rc;
+  memset(out, 0, sizeof(*out));
+  if (mode == GRDMA_RUN_GRAPH) {
+    if (!j->exec || j->exec_rounds != j->rounds) {
+      if (j->exec) hipGraphExecDestroy(j->exec);
+      j->exec = nullptr;
+      hipGraph_t graph;
+      HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      int rc = job_enqueue(j, s, false);
+      hipError_t e = hipStreamEndCapture(s, &graph);
+      if (rc) return rc;
+      if (e != hipSuccess) return fail(GRDMA_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
+      HIP_TRY(hipGraphInstantiate(&j->exec, graph, nullptr, nullptr, 0));
+      hipGraphDestroy(graph);
+      j->exec_rounds = j->rounds;
+    }
+    HIP_TRY(hipEventRecord(j->ev0, s));
+    HIP_TRY(hipGraphLaunch(j->exec, s));
+    HIP_TRY(hipEventRecord(j->ev1, s));
+  } else {
+    HIP_TRY(hipEventRecord(j->ev0, s));
+    if (int rc = job_enqueue(j, s, mode == GRDMA_RUN_INSTRUMENTED)) return rc;
+    HIP_TRY(hipEventRecord(j->ev1, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, j->ev0, j->ev1));
+  out->ms_total = ms;
+  if (mode == GRDMA_RUN_INSTRUMENTED) {
+    const bool direct = (j->tx->flags & GRDMA_WIRE_DIRECT) != 0;
+    size_t e = 0;
+    for (uint64_t r = 0; r < j->rounds; r++)
+      for (int cls = 0; cls < 5; cls++, e++) {
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, j->kev[e], j->kev[e + 1]));
+        if (cls == 2 && direct) continue;
+        out->ms_class[cls] += t;
+        out->launches_class[cls]++;
+      }
+  }
+  grdma_conn c1t, c1r;
+  if (int rc = fetch_conn(j->tx, &c1t)) return rc;
+  if (int rc = fetch_conn(j->rx, &c1r)) return rc;
+  out->bytes_sent = c1t.total_written - c0t.total_written;
+  out->bytes_delivered = c1r.total_read - c0r.total_read;
+  out->slices_delivered = c1r.rx_slice_idx;
+  out->tx_rounds = c1t.tx_rounds - c0t.tx_rounds;
+  out->rx_rounds = c1r.rx_rounds - c0r.rx_rounds;
+  out->tx_records = c1t.tx_records - c0t.tx_records;
+  out->rx_records = c1r.rx_records - c0r.rx_records;
+  out->done = (c1t.tx_slice_idx >= j->count && out->bytes_delivered == out->bytes_sent) ? 1 : 0;
+  return 0;
+}
+
+int grdma_stream_job_slices(grdma_stream_job* j, grdma_read_slice* out, uint64_t cap) {
+  if (int rc = require_ctx()) return rc;
+  if (!j || !out) return fail(GRDMA_ERR_INVALID, "null argument");
+  grdma_conn c;
+  if (int rc = fetch_conn(j->rx, &c)) return rc;
+  uint64_t n = c.rx_slice_idx < cap ? c.rx_slice_idx : cap;
+  static_assert(sizeof(grdma_read_slice) == sizeof(grdma_slice_out), "layout");
+  if (n) HIP_TRY(hipMemcpy(out, j->d_slices, sizeof(grdma_slice_out) * n, hipMemcpyDeviceToHost));
+  return (int)n;
 }
 
 }  // extern "C"

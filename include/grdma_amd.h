@@ -158,6 +158,34 @@ int grdma_pair_arena_copy_out(grdma_pair* p, uint64_t off, void* host_dst, uint6
 int grdma_poll_pairs(grdma_pair* const* pairs, uint32_t n, uint64_t* readable,
                      uint8_t* has_message);
 
+/* ---- device-resident streaming job ------------------------------------------------
+ * Pushes a whole slice list (e.g. a batch of framed gRPC messages) through a
+ * connected loop-back link without host round trips: each round is one
+ * rdma_flush step on `tx` (Send from the device-side cursor), the wire write,
+ * and one drain of `rx` (as many endpoint_read completions as are ready),
+ * appended to rx_dst.  This is the reference's write loop
+ * (rdma_bp_posix.cc:470-557) and read loop (:180-376) with the credit
+ * hand-shake of pair.cc:264-301 between them, enqueued back to back. */
+typedef struct grdma_stream_job grdma_stream_job;
+typedef struct grdma_stream_result {
+  uint64_t bytes_sent, bytes_delivered, slices_delivered;
+  uint64_t tx_rounds, rx_rounds, tx_records, rx_records;
+  uint64_t done;               /* 1: every slice was sent and delivered            */
+  double ms_total;             /* HIP-event time of the enqueued rounds            */
+  double ms_class[8];          /* instrumented mode: summed kernel time per class  */
+  uint64_t launches_class[8];  /*   0 tx_plan 1 gather 2 wire 3 rx_plan 4 rx_apply (scatter+zero+credit) */
+} grdma_stream_result;
+enum grdma_stream_mode { GRDMA_RUN_EAGER = 0, GRDMA_RUN_GRAPH = 1, GRDMA_RUN_INSTRUMENTED = 2 };
+
+grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,
+                                          const grdma_slice* slices, uint64_t count,
+                                          void* rx_dst, uint64_t rx_dst_cap,
+                                          uint64_t slices_cap, uint64_t max_rounds);
+void grdma_stream_job_destroy(grdma_stream_job* j);
+int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out);
+int grdma_stream_job_slices(grdma_stream_job* j, grdma_read_slice* out, uint64_t cap);
+int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds);
+
 /* ---- device helpers for callers that keep payloads in HBM ---------------------- */
 void* grdma_device_alloc(uint64_t bytes);
 void grdma_device_free(void* p);
