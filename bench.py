@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- streaming GiB/s @ 1 MiB messages through the HIP ring-buffer endpoint.
+
+One "step" = one pass of the hot path over one batch: `--msgs` gRPC messages of
+1 MiB payload, framed into HTTP/2 DATA frames exactly as chttp2 hands them to
+grpc_endpoint_write (130 slices per message), pushed through ONE connection:
+slice gather + ring-record encode -> wire -> message-ready detection -> record
+decode + scatter + zero-fill, with the head/tail credit protocol running between
+the two ends.  Inputs are resident in HBM before the timed region; the delivered
+slices stay in HBM (the PCIe-inclusive rate is reported separately in DESIGN.md).
+
+Contract: python bench.py --gpus N --steps K --warmup W  (N>1 under torch.distributed.run,
+one rank per GPU, one independent connection per GPU: weak scaling, no collective
+on the data path).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MIB = 1 << 20
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def proto_message(i, payload=MIB):
+    """Serialized SimpleRequest{bytes message = <payload bytes>} (micro_benchmark.proto):
+    tag 0x0a, varint length, bytes.  Content rotates with the message index so a
+    misordered or stale delivery cannot compare equal."""
+    n = payload
+    var = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        var.append(b | (0x80 if n else 0))
+        if not n:
+            break
+    body = bytes(((j + 17 * i) % 251) for j in range(256)) * (payload // 256 + 1)
+    return bytes([0x0A]) + bytes(var) + body[:payload]
+
+
+class Workload:
+    """B framed messages laid out in HBM + the slice list of the endpoint_write."""
+
+    def __init__(self, g, n_msgs, payload=MIB, max_frame=16384, stream_id=1):
+        from grpc_rdma_amd import h2
+        self.g = g
+        self.n_msgs = n_msgs
+        self.msgs = [proto_message(i, payload) for i in range(min(n_msgs, 8))]
+        self.msg_len = len(self.msgs[0])
+        layout = h2.frame_message(self.msg_len, stream_id, max_frame)
+        self.layout = layout
+        self.slices_per_msg = len(layout)
+        # HBM: one buffer per distinct message content, n_msgs copies of the payload
+        self.payload_buf = g.DeviceBuffer(nbytes=n_msgs * self.msg_len)
+        lib = g.load()
+        for i in range(n_msgs):
+            src = self.msgs[i % len(self.msgs)]
+            b = C.create_string_buffer(src, len(src))
+            lib.grdma_copy_to_device(self.payload_buf.ptr + i * self.msg_len, b, len(src))
+        # inlined slices: bytes live at offset 9 of a 32-byte grpc_slice (slice.h:60-75)
+        n_inl = sum(1 for it in layout if it[0] == "inl")
+        hdr_host = bytearray(32 * n_inl * n_msgs)
+        self.slices = []
+        self.wire_per_msg = []
+        k = 0
+        for i in range(n_msgs):
+            for it in layout:
+                if it[0] == "inl":
+                    off = 32 * k + 9
+                    hdr_host[off:off + len(it[1])] = it[1]
+                    self.slices.append(("h", off, len(it[1])))
+                    k += 1
+                else:
+                    self.slices.append(("p", i * self.msg_len + it[1][0], it[1][1]))
+        self.hdr_buf = g.DeviceBuffer(data=bytes(hdr_host))
+        self.sge = [((self.hdr_buf.ptr if kind == "h" else self.payload_buf.ptr) + off, n)
+                    for kind, off, n in self.slices]
+        self.lens = [n for _, _, n in self.slices]
+        self.N = sum(self.lens)                       # endpoint payload bytes per step
+        self.E = h2.ring_bytes_for(self.lens)         # encoded ring bytes per step
+        self.user_bytes = n_msgs * payload            # application payload per step
+
+    def expected_wire(self, i):
+        """Byte stream of message i as it must come out of the endpoint."""
+        m = self.msgs[i % len(self.msgs)]
+        return b"".join(it[1] if it[0] == "inl" else m[it[1][0]:it[1][0] + it[1][1]]
+                        for it in self.layout)
+
+
+def cpu_baseline(wl, ring, max_sge, target_s=12.0):
+    """The CPU port (oracle/) timed on host cores: same slices, same ring size, full
+    pair protocol + endpoint read loop, single thread (the reference is
+    single-reader/single-writer per pair)."""
+    from oracle import pyorc
+    wire = wl.expected_wire(0)
+    lens = wl.lens[:wl.slices_per_msg]
+    n, sec = pyorc.stream_baseline(ring, max_sge, wire, lens, 32)
+    per_msg = sec / 32
+    n_msgs = max(32, min(20000, int(target_s / per_msg)))
+    n, sec = pyorc.stream_baseline(ring, max_sge, wire, lens, n_msgs)
+    gib = (n_msgs * (wl.user_bytes // wl.n_msgs)) / sec / (1 << 30)
+    return {"value": round(gib, 3), "unit": "GiB/s", "cores": 1, "kind": "port",
+            "sample": "%d x 1 MiB messages (%d slices each) through oracle/ pair + endpoint-read "
+                      "loop, %d KiB ring, 1 thread, %.1f s" % (n_msgs, len(lens), ring >> 10, sec)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--msgs", type=int, default=64, help="1 MiB messages per step")
+    ap.add_argument("--ring-kb", type=int, default=int(os.environ.get("GRPC_RDMA_RING_BUFFER_SIZE_KB", 4096)))
+    ap.add_argument("--max-sge", type=int, default=4095)
+    ap.add_argument("--wire", choices=["staged", "direct"], default="staged")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    import grpc_rdma_amd as g
+    from grpc_rdma_amd import stream as gs
+    g.init(local_rank)
+
+    ring = args.ring_kb * 1024
+    flags = 2 if args.wire == "direct" else 0
+    tx, rx = g.Pair(ring, args.max_sge, flags), g.Pair(ring, args.max_sge, flags)
+    g.connect_pairs(tx, rx)
+    wl = Workload(g, args.msgs)
+    dst_cap = wl.N + 16 * (len(wl.lens) * 2 + 64) + 4096
+    dst = g.DeviceBuffer(nbytes=dst_cap)
+    slices_cap = len(wl.lens) * 2 + 64
+    est_rounds = max(8, 4 * (wl.E // (ring // 2) + 2))
+    if args.max_sge < 4095:
+        est_rounds = max(est_rounds, 2 * (len(wl.lens) // args.max_sge + 2))
+    job = gs.StreamJob(tx, rx, wl.sge, dst.ptr, dst_cap, slices_cap, est_rounds)
+    r = job.run(gs.RUN_EAGER)                      # calibration: how many rounds are needed
+    assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
+        r.bytes_delivered, wl.N)
+    rounds = int(max(r.tx_rounds, r.rx_rounds))
+    job.set_rounds(rounds)
+    r = job.run(gs.RUN_GRAPH)                      # capture + first replay
+    assert r.done and r.bytes_delivered == wl.N
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.launch()
+    job.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.launch()
+    job.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    barrier()
+
+    # ---- correctness of what the timed region produced (untimed) ---------------
+    verified = None
+    if not args.no_verify:
+        r = job.run(gs.RUN_GRAPH)
+        assert r.done and r.bytes_delivered == wl.N and r.bytes_sent == wl.N
+        ds = job.delivered_slices()
+        got = dst.read(dst_cap)
+        stream = b"".join(got[o:o + n] for o, n in ds)
+        exp = b"".join(wl.expected_wire(i) for i in range(wl.n_msgs))
+        assert stream == exp, "delivered byte stream differs from the framed messages"
+        assert rx.ring_mem() == bytes(ring), "ring not zero after the drain"
+        verified = True
+
+    # ---- roofline: per-kernel time with HIP events on the launch stream --------
+    inst = None
+    for _ in range(3):
+        inst = job.run(gs.RUN_INSTRUMENTED)
+    classes = {}
+    for i, name in enumerate(gs.CLASS_NAMES):
+        n = int(inst.launches_class[i])
+        if n:
+            classes[name] = {"launches": n, "ms": inst.ms_class[i], "us_per_launch": 1e3 * inst.ms_class[i] / n}
+    # algorithmic bytes per step per kernel class:
+    alg = {"gather": 2 * wl.N,          # K1: N read + N written (tags E-N by tx_plan)
+           "wire": 2 * wl.E,            # loop-back stand-in for the NIC: E read + E written
+           "rx_apply": 3 * wl.N}        # K4: N read + N written + N cleared (tags by rx_plan)
+    dom = max((k for k in classes if k in alg), key=lambda k: classes[k]["ms"])
+    per_launch = alg[dom] / classes[dom]["launches"]
+    achieved = per_launch / (classes[dom]["us_per_launch"] * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_rx_apply" if dom == "rx_apply" else "k_copy(%s)" % dom,
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "bytes_per_launch": int(per_launch),
+                "us_per_launch": round(classes[dom]["us_per_launch"], 2)}
+
+    total_user = wl.user_bytes * args.steps * world
+    value = total_user / elapsed / (1 << 30)
+    out = {
+        "metric": "streaming GiB/s @1 MiB msgs (client-streaming, 1 connection per GPU)",
+        "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "client-streaming 1 MiB payloads, 1 connection on 1xMI355X "
+                               "(BASELINE.json configs[2])",
+                   "msgs_per_step": args.msgs, "slices_per_msg": wl.slices_per_msg,
+                   "ring_kib": args.ring_kb, "max_sge": args.max_sge, "wire": args.wire,
+                   "rounds_per_step": rounds, "connections_per_gpu": 1,
+                   "stages": "gather+encode, wire, ready-detect, decode+scatter+zero, credit"},
+        "roofline": roofline,
+        "kernels": {k: {"launches": v["launches"], "us_per_launch": round(v["us_per_launch"], 2)}
+                    for k, v in classes.items()},
+        "endpoint_bytes_per_step": wl.N, "ring_bytes_per_step": wl.E, "verified": verified,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, ring, min(args.max_sge, 4095))
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

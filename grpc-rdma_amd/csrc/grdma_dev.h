@@ -86,7 +86,7 @@ struct grdma_conn {
   uint64_t rx_records;          // ring records consumed
   uint32_t rx_blocks_done;      // k_rx_apply arrival counter (last block commits)
   uint32_t pad2;
-  uint64_t pad1[1];
+  uint64_t tx_remaining;        // bytes of the current slice list not yet accepted
 };
 
 struct grdma_seg {
@@ -117,6 +117,7 @@ struct grdma_tx_result {
   uint64_t byte_idx;
   uint64_t done;           // 1 when the whole slice list has been sent
   uint64_t seq;            // bumped last (host polls it)
+  uint64_t dbg[16];        // s_memtime stamps of the plan phases (profiling aid)
 };
 
 struct grdma_rx_result {
@@ -133,6 +134,7 @@ struct grdma_rx_result {
   uint64_t zero_len[2];
   uint64_t seq;            // bumped by k_rx_plan
   uint64_t commit_seq;     // bumped by k_rx_commit (copy + zero-fill + credit done)
+  uint64_t dbg[16];        // s_memtime stamps of the plan phases (profiling aid)
 };
 
 // A list of byte-copy segments plus its decomposition into wave tiles.

@@ -36,7 +36,6 @@
 #include "grdma_ops.h"
 
 #define PLAN_THREADS 256
-#define PLAN_ITEMS (GRDMA_MAX_SEGS / PLAN_THREADS)  // 16 slices per thread
 #define COPY_THREADS 256
 
 namespace {
@@ -50,11 +49,13 @@ __device__ __forceinline__ uint64_t writable_of(uint64_t space) {
 }
 __device__ __forceinline__ uint64_t sat_sub(uint64_t a, uint64_t b) { return a > b ? a - b : 0ull; }
 
-// Tag words are polled across agents (a NIC or a peer GPU writes them): use
-// system-scope relaxed atomics so they are never served from a stale L1 line.
+// Tag words are written by another agent (the wire kernel of a peer, a NIC):
+// relaxed agent-scope atomic loads bypass the per-CU L1 (never refreshed by other
+// writers) and are served by L2 / memory.  A ring registered for NIC writes must
+// be allocated uncached (fine-grained), where the same load reaches memory.
 __device__ __forceinline__ uint64_t ld_tag(const uint8_t* p) {
   return __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
+                           __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int lane) {
@@ -63,6 +64,19 @@ __device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int lane) {
     uint64_t t = __shfl_up(v, d, 64);
     if (lane >= d) v += t;
   }
+  return v;
+}
+
+// Inclusive wave64 prefix sum of a 32-bit value on the DPP network (row shifts
+// 1,2,4,8, then row_bcast:15 / row_bcast:31 across the four 16-lane rows): six
+// VALU instructions, no LDS traffic.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31
   return v;
 }
 
@@ -89,15 +103,25 @@ __device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t* wave_s
 // ----------------------------------------------------------------------------
 // k_tx_plan: PairPollable::Send arithmetic + rdma_flush cursor, one block per op
 // ----------------------------------------------------------------------------
+// All records of a Send are priced at once: enc_i = 16 + round_up8(len_i) is
+// prefix-summed across the block (st_i), every record tests its own budget
+// pay_i = min(len_i, W(S - st_i), W(free0 - st_i)) under the assumption that all
+// earlier records went out whole, and an LDS atomic-min finds the first record
+// that comes up short -- which is exactly where the reference's sequential loop
+// stops (pair.cc:671-707).  Global loads/stores are
+// striped over the block (record i -> thread i % 256) so they coalesce.
 __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops) {
   const grdma_tx_op op = ops[blockIdx.x];
   grdma_conn* c = op.conn;
   grdma_plan* plan = op.plan;
   __shared__ uint64_t s_wave[PLAN_THREADS / 64];
-  __shared__ uint64_t s_excl[GRDMA_MAX_SEGS + 1];  // staging offset of record i
+  __shared__ uint64_t s_len[GRDMA_MAX_SEGS];       // len_i, later pay_i
+  __shared__ uint64_t s_excl[GRDMA_MAX_SEGS + 1];  // st_i, later the tile prefix
   __shared__ unsigned int s_first_short;
   __shared__ unsigned int s_wrap_rec;
-  const int tid = threadIdx.x;
+  const unsigned tid = threadIdx.x;
+  uint64_t tdbg[8];
+  tdbg[0] = __builtin_amdgcn_s_memtime();
 
   const uint64_t cap = c->cap, mask = cap - 1;
   const uint64_t S = c->staging_cap;
@@ -107,7 +131,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
                                            __HIP_MEMORY_SCOPE_SYSTEM);
   const bool connected = c->status == GRDMA_PAIR_CONNECTED;
   uint64_t start = op.use_cursor == 1 ? c->tx_slice_idx : 0;
-  uint64_t byte_idx = op.use_cursor == 1 ? c->tx_byte_idx : (op.use_cursor ? 0 : op.byte_idx);
+  const uint64_t byte_idx =
+      op.use_cursor == 1 ? c->tx_byte_idx : (op.use_cursor ? 0 : op.byte_idx);
   if (start > op.nslices) start = op.nslices;
   const uint64_t avail = op.nslices - start;
   const grdma_sge* sl = op.slices + start;
@@ -117,157 +142,176 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
     s_wrap_rec = 0xFFFFFFFFu;
   }
 
-  // total bytes offered (pair.cc:660-663)
-  uint64_t part = 0;
-  for (uint64_t i = tid; i < avail; i += PLAN_THREADS) part += sl[i].len;
+  // total bytes offered (pair.cc:660-663).  A streaming job keeps the running
+  // remainder in the connection instead of re-summing the whole list per round.
   uint64_t offered;
-  block_excl_scan(part, s_wave, &offered);
-  offered = sat_sub(offered, byte_idx);
+  if (op.use_cursor == 1) {
+    offered = c->tx_remaining;
+    __syncthreads();
+  } else {
+    uint64_t part = 0;
+    for (uint64_t i = tid; i < avail; i += PLAN_THREADS) part += sl[i].len;
+    block_excl_scan(part, s_wave, &offered);
+    offered = sat_sub(offered, byte_idx);
+  }
 
   uint64_t m = avail;
   if (m > c->max_sge) m = c->max_sge;
   if (m > GRDMA_MAX_SEGS - 1) m = GRDMA_MAX_SEGS - 1;
   if (!connected) m = 0;
 
-  // per-thread contiguous chunk of PLAN_ITEMS slices
-  uint64_t len[PLAN_ITEMS], enc[PLAN_ITEMS];
-  uint64_t chunk = 0;
-  const uint64_t i0 = (uint64_t)tid * PLAN_ITEMS;
-#pragma unroll
-  for (int k = 0; k < PLAN_ITEMS; k++) {
-    uint64_t i = i0 + k;
-    uint64_t l = 0;
-    if (i < m) {
-      l = sl[i].len;
-      if (i == 0) l = sat_sub(l, byte_idx);
-    }
-    len[k] = l;
-    // clamp so that sums cannot overflow; anything above 2*cap is "too big" anyway
-    uint64_t e = (i < m) ? enc_size(l < (cap << 1) ? l : (cap << 1)) : 0;
-    enc[k] = e;
-    chunk += e;
+  tdbg[1] = __builtin_amdgcn_s_memtime();
+  // lengths, striped
+  for (uint64_t i = tid; i < m; i += PLAN_THREADS) {
+    uint64_t l = sl[i].len;
+    if (i == 0) l = sat_sub(l, byte_idx);
+    s_len[i] = l;
   }
-  uint64_t total_enc;
-  uint64_t excl = block_excl_scan(chunk, s_wave, &total_enc);
+  __syncthreads();
 
-  // Budget test with "every earlier record went out whole" (pair.cc:676-685).
-  // The first record that does not fit whole ends the send (Appendix A.4).
+  // st_i: each thread scans a contiguous run of `per` records out of LDS
+  const uint64_t per = (m + PLAN_THREADS - 1) / PLAN_THREADS;
+  {
+    uint64_t chunk = 0;
+    for (uint64_t k = 0; k < per; k++) {
+      const uint64_t i = tid * per + k;
+      if (i < m) {
+        const uint64_t l = s_len[i];
+        // clamp so that sums cannot overflow; anything above 2*cap cannot fit anyway
+        chunk += enc_size(l < (cap << 1) ? l : (cap << 1));
+      }
+    }
+    uint64_t total_enc;
+    uint64_t st = block_excl_scan(chunk, s_wave, &total_enc);
+    for (uint64_t k = 0; k < per; k++) {
+      const uint64_t i = tid * per + k;
+      if (i < m) {
+        s_excl[i] = st;
+        const uint64_t l = s_len[i];
+        st += enc_size(l < (cap << 1) ? l : (cap << 1));
+      }
+    }
+    if (tid == PLAN_THREADS - 1 || (tid * per < m && (tid + 1) * per >= m)) s_excl[m] = st;
+    if (m == 0 && tid == 0) s_excl[0] = 0;
+  }
+  __syncthreads();
+
+  tdbg[2] = __builtin_amdgcn_s_memtime();
+  // budget test, striped
   const uint64_t occupied0 = (tail0 + cap - rhead) & mask;
   const uint64_t free0 = cap - occupied0;
-  uint64_t pay[PLAN_ITEMS];
-  {
-    uint64_t st = excl;
-#pragma unroll
-    for (int k = 0; k < PLAN_ITEMS; k++) {
-      uint64_t i = i0 + k;
-      if (i <= m) s_excl[i] = st;
-      uint64_t a = writable_of(sat_sub(S, st));
-      uint64_t b = writable_of(sat_sub(free0, st));
-      uint64_t p = len[k];
-      if (a < p) p = a;
-      if (b < p) p = b;
-      pay[k] = p;
-      if (i < m && p < len[k]) atomicMin(&s_first_short, (unsigned int)i);
-      // zero-length slices cannot occur (grpc never queues them); a zero
-      // payload ends the send exactly like the reference's `break`.
-      if (i < m && len[k] == 0) atomicMin(&s_first_short, (unsigned int)i);
-      st += enc[k];
-    }
+  for (uint64_t i = tid; i < m; i += PLAN_THREADS) {
+    const uint64_t st = s_excl[i];
+    const uint64_t a = writable_of(sat_sub(S, st));
+    const uint64_t b = writable_of(sat_sub(free0, st));
+    const uint64_t l = s_len[i];
+    uint64_t p = l;
+    if (a < p) p = a;
+    if (b < p) p = b;
+    // a zero payload ends the send exactly like the reference's `break`.
+    // One LDS atomic per wave: the lowest short lane of a wave holds its lowest i.
+    const bool is_short = p < l || l == 0;
+    const uint64_t bm = __ballot(is_short);
+    if (bm != 0 && (tid & 63) == (unsigned)__builtin_ctzll(bm)) atomicMin(&s_first_short, (unsigned int)i);
   }
   __syncthreads();
   const uint64_t fs = s_first_short;
-  // number of records and the (possibly short) last payload
-  uint64_t nrec = m;
-  if (fs != 0xFFFFFFFFu) nrec = fs;  // records [0, fs) whole; fs itself maybe short
-  __shared__ uint64_t s_last_pay;
-  if (tid == 0) s_last_pay = 0;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < PLAN_ITEMS; k++)
-    if (i0 + k == fs && fs < m) s_last_pay = pay[k];
-  __syncthreads();
-  const uint64_t short_pay = (fs != 0xFFFFFFFFu && fs < m) ? s_last_pay : 0;
+  const uint64_t nrec = (fs != 0xFFFFFFFFu) ? fs : m;  // records [0, nrec) go out whole
+  uint64_t short_pay = 0;
+  if (fs != 0xFFFFFFFFu) {
+    const uint64_t st = s_excl[fs];
+    const uint64_t a = writable_of(sat_sub(S, st));
+    const uint64_t b = writable_of(sat_sub(free0, st));
+    short_pay = s_len[fs];
+    if (a < short_pay) short_pay = a;
+    if (b < short_pay) short_pay = b;
+  }
   const uint64_t nrec_total = nrec + (short_pay > 0 ? 1 : 0);
   // Σ enc over the whole records, plus the short one if any
   const uint64_t staged = s_excl[nrec] + (short_pay > 0 ? enc_size(short_pay) : 0);
+  __syncthreads();
+  if (tid == 0 && short_pay > 0) s_len[nrec] = short_pay;  // s_len[i] is pay_i from here on
+  __syncthreads();
 
   // destination of record i: staging + st_i, or the peer ring itself at
   // (tail0 + st_i) & mask when the wire is direct.
   const bool direct = c->wire_direct != 0;
   uint8_t* const dbase = direct ? c->peer_ring : c->staging;
-
-  // find the single record whose payload crosses the ring end (direct mode)
-  uint64_t my_pay[PLAN_ITEMS];
-#pragma unroll
-  for (int k = 0; k < PLAN_ITEMS; k++) {
-    uint64_t i = i0 + k;
-    uint64_t p = 0;
-    if (i < nrec) p = len[k];
-    else if (i == nrec && short_pay > 0) p = short_pay;
-    my_pay[k] = p;
-    if (direct && p > 0) {
-      uint64_t pstart = (tail0 + s_excl[i] + 8) & mask;
-      if (pstart + p > cap) atomicMin(&s_wrap_rec, (unsigned int)i);
+  if (direct) {
+    for (uint64_t i = tid; i < nrec_total; i += PLAN_THREADS) {
+      const uint64_t pstart = (tail0 + s_excl[i] + 8) & mask;
+      if (pstart + s_len[i] > cap) atomicMin(&s_wrap_rec, (unsigned int)i);
     }
   }
   __syncthreads();
   const uint64_t wrap_rec = s_wrap_rec;
 
-  // tags + segments
-  uint64_t tiles_chunk = 0;
-  uint64_t seg_tiles[PLAN_ITEMS][2];
-#pragma unroll
-  for (int k = 0; k < PLAN_ITEMS; k++) {
-    uint64_t i = i0 + k;
-    seg_tiles[k][0] = seg_tiles[k][1] = 0;
-    uint64_t p = my_pay[k];
-    if (p == 0) continue;
-    uint64_t st = s_excl[i];
-    uint64_t hdr_off = direct ? ((tail0 + st) & mask) : st;
-    uint64_t pay_off = direct ? ((hdr_off + 8) & mask) : st + 8;
-    uint64_t foot_off = direct ? ((hdr_off + 8 + round_up8(p)) & mask) : st + 8 + round_up8(p);
+  tdbg[3] = __builtin_amdgcn_s_memtime();
+  // tags + segments, striped
+  uint64_t sent_part = 0;
+  for (uint64_t i = tid; i < nrec_total; i += PLAN_THREADS) {
+    const uint64_t p = s_len[i];
+    const uint64_t st = s_excl[i];
+    sent_part += p;
+    const uint64_t hdr_off = direct ? ((tail0 + st) & mask) : st;
+    const uint64_t pay_off = direct ? ((hdr_off + 8) & mask) : st + 8;
+    const uint64_t foot_off = direct ? ((hdr_off + 8 + round_up8(p)) & mask) : st + 8 + round_up8(p);
     // AppendHeader / AppendFooter, ring_buffer.h:84-99
     *reinterpret_cast<uint64_t*>(dbase + hdr_off) = p;
     *reinterpret_cast<uint64_t*>(dbase + foot_off) = GRDMA_FOOTER;
     // deterministic zero padding (the reference leaves stale staging bytes there)
-    for (uint64_t q = p; q < round_up8(p); q++) dbase[direct ? ((pay_off + q) & mask) : pay_off + q] = 0;
+    for (uint64_t q = p; q < round_up8(p); q++)
+      dbase[direct ? ((pay_off + q) & mask) : pay_off + q] = 0;
     const uint8_t* src = sl[i].ptr + (i == 0 ? byte_idx : 0);
-    uint64_t seg = i + (i > wrap_rec ? 1 : 0);
+    const uint64_t seg = i + (i > wrap_rec ? 1 : 0);
     if (i == wrap_rec) {
-      uint64_t l1 = cap - pay_off;
+      const uint64_t l1 = cap - pay_off;
       plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, l1, 0};
       plan->segs[seg + 1] = {(uint64_t)dbase, (uint64_t)(src + l1), p - l1, 0};
-      seg_tiles[k][0] = (l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
-      seg_tiles[k][1] = (p - l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
     } else {
       plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, p, 0};
-      seg_tiles[k][0] = (p + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
     }
-    tiles_chunk += seg_tiles[k][0] + seg_tiles[k][1];
   }
+  uint64_t sent;
+  block_excl_scan(sent_part, s_wave, &sent);
+
+  tdbg[4] = __builtin_amdgcn_s_memtime();
+  // tile prefix per segment (contiguous runs again, out of LDS)
   uint64_t ntiles;
-  uint64_t texcl = block_excl_scan(tiles_chunk, s_wave, &ntiles);
-#pragma unroll
-  for (int k = 0; k < PLAN_ITEMS; k++) {
-    uint64_t i = i0 + k;
-    if (my_pay[k] == 0) continue;
-    uint64_t seg = i + (i > wrap_rec ? 1 : 0);
-    plan->tile_prefix[seg] = (uint32_t)texcl;
-    texcl += seg_tiles[k][0];
-    if (i == wrap_rec) {
-      plan->tile_prefix[seg + 1] = (uint32_t)texcl;
-      texcl += seg_tiles[k][1];
+  {
+    const uint64_t per2 = (nrec_total + PLAN_THREADS - 1) / PLAN_THREADS;
+    auto tiles_of = [&](uint64_t i, uint64_t* t1) -> uint64_t {
+      const uint64_t p = s_len[i];
+      if (i == wrap_rec) {
+        const uint64_t pay_off = (tail0 + s_excl[i] + 16) & mask;  // (hdr_off + 8) & mask
+        const uint64_t l1 = cap - ((tail0 + s_excl[i] + 8) & mask);
+        (void)pay_off;
+        *t1 = (l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
+        return *t1 + (p - l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
+      }
+      *t1 = (p + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
+      return *t1;
+    };
+    uint64_t chunk = 0, t1;
+    for (uint64_t k = 0; k < per2; k++) {
+      const uint64_t i = tid * per2 + k;
+      if (i < nrec_total) chunk += tiles_of(i, &t1);
+    }
+    uint64_t x = block_excl_scan(chunk, s_wave, &ntiles);
+    for (uint64_t k = 0; k < per2; k++) {
+      const uint64_t i = tid * per2 + k;
+      if (i < nrec_total) {
+        const uint64_t seg = i + (i > wrap_rec ? 1 : 0);
+        const uint64_t t = tiles_of(i, &t1);
+        plan->tile_prefix[seg] = (uint32_t)x;
+        if (i == wrap_rec) plan->tile_prefix[seg + 1] = (uint32_t)(x + t1);
+        x += t;
+      }
     }
   }
   const uint64_t nsegs = nrec_total + ((wrap_rec != 0xFFFFFFFFu) ? 1 : 0);
 
-  // payload total
-  uint64_t sent_part = 0;
-#pragma unroll
-  for (int k = 0; k < PLAN_ITEMS; k++) sent_part += my_pay[k];
-  uint64_t sent;
-  block_excl_scan(sent_part, s_wave, &sent);
-
+  tdbg[5] = __builtin_amdgcn_s_memtime();
   if (tid == 0) {
     plan->nsegs = (uint32_t)nsegs;
     plan->ntiles = (uint32_t)ntiles;
@@ -322,6 +366,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
     if (op.use_cursor) {
       c->tx_slice_idx = idx;
       c->tx_byte_idx = bidx;
+      c->tx_remaining = offered - sent;
     }
     r->sent = sent;
     r->records = nrec_total;
@@ -331,6 +376,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
     r->slice_idx = idx;
     r->byte_idx = bidx;
     r->done = (idx >= op.nslices) ? 1 : 0;
+    tdbg[6] = __builtin_amdgcn_s_memtime();
+    for (int q = 0; q < 7; q++) r->dbg[q] = tdbg[q];
+    r->dbg[7] = m;
     __threadfence_system();
     __hip_atomic_store(&r->seq, r->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -413,19 +461,30 @@ __device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane)
   if ((uint64_t)lane < tail) p[(units << 4) + lane] = 0;
 }
 
+#define PREFIX_LDS 2048
+
+// Every workgroup stages the tile prefix in LDS (one coalesced load), then each
+// wave maps its tiles to segments with an LDS binary search: no dependent global
+// loads between picking a tile and issuing its first payload load.
 __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t wave,
                                                uint32_t nwaves, int lane) {
+  __shared__ uint32_t s_prefix[PREFIX_LDS + 1];
   const uint32_t nsegs = plan->nsegs;
   const uint32_t ntiles = plan->ntiles;
-  // tile -> segment: binary search of the tile prefix (wave-uniform)
+  const bool in_lds = nsegs <= PREFIX_LDS;
+  if (in_lds)
+    for (uint32_t i = threadIdx.x; i <= nsegs; i += COPY_THREADS) s_prefix[i] = plan->tile_prefix[i];
+  __syncthreads();
   for (uint32_t t = wave; t < ntiles; t += nwaves) {
     uint32_t lo = 0, hi = nsegs;  // invariant: prefix[lo] <= t < prefix[hi]
     while (hi - lo > 1) {
-      uint32_t mid = (lo + hi) >> 1;
-      if (plan->tile_prefix[mid] <= t) lo = mid; else hi = mid;
+      const uint32_t mid = (lo + hi) >> 1;
+      const uint32_t pm = in_lds ? s_prefix[mid] : plan->tile_prefix[mid];
+      if (pm <= t) lo = mid; else hi = mid;
     }
     const grdma_seg sg = plan->segs[lo];
-    const uint64_t off = (uint64_t)(t - plan->tile_prefix[lo]) * GRDMA_TILE_BYTES;
+    const uint32_t p0 = in_lds ? s_prefix[lo] : plan->tile_prefix[lo];
+    const uint64_t off = (uint64_t)(t - p0) * GRDMA_TILE_BYTES;
     uint64_t n = sg.len - off;
     if (n > GRDMA_TILE_BYTES) n = GRDMA_TILE_BYTES;
     uint8_t* src = sg.src ? reinterpret_cast<uint8_t*>(sg.src + off) : nullptr;
@@ -454,85 +513,116 @@ __global__ __launch_bounds__(COPY_THREADS) void k_copy(const grdma_plan* const* 
 // naive walk costs one dependent HBM/L2 round trip per record.  Here one wave
 // probes 64 *predicted* positions per round trip: record sizes on a gRPC
 // connection repeat with period 2 (9-byte DATA frame header slice, 16 KiB
-// payload slice), so lane j loads the tag words at the position the chain
-// reaches after j records if the last two sizes keep alternating.  The chain
-// is then verified lane by lane in registers (readlane), stopping at the first
-// misprediction; a round always resolves at least one record.
+// payload slice), so lane j loads the tag words at the offset the chain reaches
+// after j records if the last two sizes keep alternating.  Every lane then
+// checks its own link (header valid, its size equals the prediction) and the
+// footer word in front of it; two __ballot()s give the verified prefix.  A round
+// always resolves at least one record, and a mispredicted record's size is
+// carried into the next round so its footer probe is exact.
 #define CHAIN_CAP 128
 
-struct chain_state {
-  uint64_t e_prev1;  // encoded size of the most recent verified record (0 = unknown)
-  uint64_t e_prev2;  // the one before it
+struct chain_walker {
+  const uint8_t* ring;
+  uint64_t cap;
+  uint64_t pos;   // ring offset of the first unverified record
+  uint64_t e0;    // encoded size of the record at pos when its header is already known
+  uint64_t h2, h1;  // encoded sizes of the two records before pos (0 = unknown)
+  bool dry;       // pos holds no complete record
 };
 
-// Verifies up to CHAIN_CAP ready records starting at ring offset `pos` and
-// stores their payload sizes in chain[0..count).  Returns count; *exhausted is
-// set when the walk stopped on a position that holds no complete record.
-__device__ __forceinline__ uint32_t chain_refill(const uint8_t* ring, uint64_t cap, uint64_t pos,
-                                                 chain_state* cs, uint64_t* chain,
-                                                 bool* exhausted, int lane) {
-  const uint64_t mask = cap - 1;
-  uint32_t count = 0;
-  *exhausted = false;
-  while (count + 64 <= CHAIN_CAP) {
-    // predicted offsets: pos, pos+ea, pos+ea+eb, ... (ea = two back, eb = one back)
-    uint64_t ea = cs->e_prev2 ? cs->e_prev2 : cs->e_prev1;
-    uint64_t eb = cs->e_prev1;
-    uint64_t rel = (uint64_t)(lane >> 1) * (ea + eb) + ((lane & 1) ? ea : 0);
-    if (ea == 0) rel = 0;  // nothing known yet: only lane 0 is meaningful
-    const uint64_t my_pos = (pos + rel) & mask;
-    const uint64_t hdr = ld_tag(ring + my_pos);
-    const uint64_t prev = ld_tag(ring + ((my_pos + cap - 8) & mask));  // footer of the previous record
-    bool stop = false;
-    uint64_t cur = pos;
-    int s = 0;
-    for (; s < 64; s++) {
-      const uint64_t n = __shfl(hdr, s, 64);
-      if (n == 0 || n > cap - GRDMA_RESERVED) {  // empty or torn header: not ready
-        stop = true;
-        *exhausted = true;
-        break;
-      }
-      const uint64_t enc = 16 + round_up8(n);
-      const uint64_t nxt = (cur + enc) & mask;
-      uint64_t foot;
-      bool predicted = false;
-      if (s < 63) {
-        const uint64_t npos = __shfl(my_pos, s + 1, 64);
-        if (npos == nxt && (ea != 0)) {
-          foot = __shfl(prev, s + 1, 64);
-          predicted = true;
-        }
-      }
-      if (!predicted) foot = ld_tag(ring + ((nxt + cap - 8) & mask));
-      if (foot != GRDMA_FOOTER) {  // header landed, footer not yet: not ready
-        stop = true;
-        *exhausted = true;
-        break;
-      }
-      if (lane == 0) chain[count] = n;
-      count++;
-      cs->e_prev2 = cs->e_prev1;
-      cs->e_prev1 = enc;
-      cur = nxt;
-      if (!predicted) {  // continue from here with the corrected pattern
-        s++;
-        break;
-      }
+// One probe round.  Stores the payload sizes of the verified records in
+// chain[0..v) and returns v.
+__device__ __forceinline__ uint32_t chain_round(chain_walker* w, uint64_t* chain, int lane) {
+  const uint64_t cap = w->cap, mask = cap - 1;
+  // history with the already-known first record folded in
+  const uint64_t H2 = w->e0 ? w->h1 : w->h2;
+  const uint64_t H1 = w->e0 ? w->e0 : w->h1;
+  const uint64_t A = H2 ? H2 : H1, B = H1;  // predicted sizes alternate A, B, A, ...
+  // rel(j): predicted offset of record j from pos; k = index among the predicted ones
+  auto rel_of = [&](uint64_t j) -> uint64_t {
+    uint64_t base = 0, k = j;
+    if (w->e0) {
+      if (j == 0) return 0;
+      base = w->e0;
+      k = j - 1;
     }
-    pos = cur;
-    if (stop) break;
+    return base + (k >> 1) * (A + B) + ((k & 1) ? A : 0);
+  };
+  const bool have_pattern = (A != 0);
+  const uint64_t rel = have_pattern ? rel_of(lane) : 0;
+  const uint64_t rel_next = have_pattern ? rel_of(lane + 1) : 0;
+  // The sender never lets the ring hold more than cap - 8 bytes (W() keeps 24
+  // free before a write), so a record can only exist where it ends by cap - 8,
+  // and the footer in front of lane j only matters if record j-1 ends by then.
+  const bool probe_hdr = (lane == 0) || (have_pattern && rel_next <= cap - 8);
+  const bool probe_prev = lane > 0 && have_pattern && rel <= cap - 8;
+  const uint64_t my_pos = (w->pos + rel) & mask;
+  uint64_t hdr = 0, prev = 0;
+  if (probe_hdr) hdr = ld_tag(w->ring + my_pos);
+  if (probe_prev) prev = ld_tag(w->ring + ((my_pos + cap - 8) & mask));  // footer of record j-1
+  const bool valid = probe_hdr && hdr != 0 && hdr <= cap - GRDMA_RESERVED;
+  const uint64_t enc = 16 + round_up8(hdr);
+  const bool link_ok = valid && have_pattern && lane < 63 && enc == rel_next - rel;
+  const uint64_t m_link = __ballot(link_ok);
+  const uint64_t m_foot = __ballot(probe_prev && prev == GRDMA_FOOTER) >> 1;  // bit j: footer of j
+  const uint64_t m_fprobed = __ballot(probe_prev) >> 1;
+  const uint64_t m_hprobed = __ballot(probe_hdr);
+  const uint64_t good = m_link & m_foot;
+  const uint32_t v = (good == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~good);
+  if ((uint32_t)lane < v) chain[lane] = hdr;
+  // state for the next round: lane v is the first unverified record
+  const uint64_t m_valid = __ballot(valid);
+  const uint64_t rel_v = __shfl(rel, v < 64 ? v : 63, 64);
+  const uint64_t enc_v = __shfl(enc, v < 64 ? v : 63, 64);
+  const uint64_t enc_l1 = __shfl(enc, v >= 1 ? v - 1 : 0, 64);
+  const uint64_t enc_l2 = __shfl(enc, v >= 2 ? v - 2 : 0, 64);
+  if (v >= 2) {
+    w->h2 = enc_l2;
+    w->h1 = enc_l1;
+  } else if (v == 1) {
+    w->h2 = w->e0 ? w->h1 : w->h1;
+    w->h1 = enc_l1;
   }
-  return count;
+  // (v == 1 keeps the older size as h2: the record before lane 0)
+  w->pos = (w->pos + rel_v) & mask;
+  w->e0 = 0;
+  if (v < 64) {
+    const bool v_hprobed = (m_hprobed >> v) & 1;
+    const bool v_valid = (m_valid >> v) & 1;
+    const bool v_link = (m_link >> v) & 1;
+    const bool v_fprobed = (m_fprobed >> v) & 1;
+    if (!v_hprobed) {
+      // not looked at (prediction ran past the ring): probe it as lane 0 next round
+    } else if (!v_valid) {
+      w->dry = true;                 // no (or torn) header: nothing more is ready
+    } else if (!v_link || !v_fprobed) {
+      w->e0 = enc_v;                 // header known, exact footer probe next round
+    } else {
+      w->dry = true;                 // size as predicted but the footer has not landed
+    }
+  }
+  return v;
+}
+
+// transition of the endpoint-read state over one record of n bytes:
+// s = bytes of space left in an open 256-byte read (0 = between reads)
+__device__ __forceinline__ uint64_t read_space_after(uint64_t n, uint64_t s) {
+  if (s == 0) return n >= GRDMA_MIN_READ_SLICE ? 0 : GRDMA_MIN_READ_SLICE - n;
+  if (n < s) return s - n;
+  if (n == s) return 0;
+  const uint64_t r = n - s;
+  return r >= GRDMA_MIN_READ_SLICE ? 0 : GRDMA_MIN_READ_SLICE - r;
 }
 
 __global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
+  const uint64_t t_begin = __builtin_amdgcn_s_memtime();
   const grdma_rx_op op = ops[blockIdx.x];
   const int lane = threadIdx.x;
   grdma_conn* c = op.conn;
   grdma_plan* plan = op.plan;
   grdma_rx_result* res = op.result;
   uint8_t* ring = c->ring;
+  uint64_t n_rounds = 0, n_fast = 0, n_scalar = 0, t_refill = 0, t_fast = 0;
   const uint64_t cap = c->cap, mask = cap - 1;
   uint64_t head = c->head, mh = c->moving_head, remain = c->remain;
   uint64_t irs = c->internal_read_size, leftover = c->leftover_cap;
@@ -542,11 +632,9 @@ __global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
   const bool connected = c->status == GRDMA_PAIR_CONNECTED;
   grdma_slice_out* out_slices = op.slices;
   uint64_t max_slices = GRDMA_MAX_SLICES;
-  if (op.append == 2) {  // first round of a streaming job
-    if (lane == 0) {
-      c->rx_arena_off = 0;
-      c->rx_slice_idx = 0;
-    }
+  if (op.append == 2 && lane == 0) {  // first round of a streaming job
+    c->rx_arena_off = 0;
+    c->rx_slice_idx = 0;
   }
   if (op.append) {  // streaming job: keep filling the caller's buffer / slice table
     const uint64_t s_idx = op.append == 2 ? 0 : c->rx_slice_idx;
@@ -555,26 +643,44 @@ __global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
     const uint64_t room = op.slices_cap > s_idx ? op.slices_cap - s_idx : 0;
     if (room < max_slices) max_slices = room;
   }
+  if (op.max_reads < max_slices) max_slices = op.max_reads;
 
   __shared__ uint64_t s_chain[CHAIN_CAP];
-  chain_state cs = {0, 0};
+  chain_walker w = {ring, cap, head, 0, 0, 0, false};
   uint32_t chain_n = 0, chain_i = 0;
-  bool chain_dry = false;  // the walk hit a position without a complete record
-  uint64_t chain_pos = head;  // ring offset of the next unverified record
 
+  auto refill = [&]() {
+    while (chain_i == chain_n && !w.dry) {
+      const uint64_t t0 = __builtin_amdgcn_s_memtime();
+      __syncthreads();
+      chain_n = chain_round(&w, s_chain, lane);
+      chain_i = 0;
+      __syncthreads();
+      n_rounds++;
+      t_refill += __builtin_amdgcn_s_memtime() - t0;
+    }
+  };
+  // keep at least 64 verified records queued while the ring has more
+  auto top_up = [&]() {
+    while (chain_n - chain_i < 64 && !w.dry) {
+      const uint64_t t0 = __builtin_amdgcn_s_memtime();
+      const uint32_t k = chain_n - chain_i;
+      uint64_t keep = 0;
+      if ((uint32_t)lane < k) keep = s_chain[chain_i + lane];
+      __syncthreads();
+      if ((uint32_t)lane < k) s_chain[lane] = keep;
+      chain_i = 0;
+      chain_n = k;
+      chain_n += chain_round(&w, s_chain + k, lane);
+      __syncthreads();
+      n_rounds++;
+      t_refill += __builtin_amdgcn_s_memtime() - t0;
+    }
+  };
   // size of the next unopened record if it is completely there, else 0
   auto next_ready = [&]() -> uint64_t {
-    if (chain_i == chain_n) {
-      if (chain_dry) return 0;
-      chain_n = chain_refill(ring, cap, chain_pos, &cs, s_chain, &chain_dry, lane);
-      chain_i = 0;
-      __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_wave_barrier();
-      // advance chain_pos past the verified records
-      for (uint32_t k = 0; k < chain_n; k++) chain_pos = (chain_pos + 16 + round_up8(s_chain[k])) & mask;
-      if (chain_n == 0) return 0;
-    }
-    return s_chain[chain_i];
+    refill();
+    return chain_i < chain_n ? s_chain[chain_i] : 0;
   };
 
   // PairPollable::Recv -> RingBufferPollable::Read(dst, capacity)
@@ -632,6 +738,156 @@ __global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
     return cpy;
   };
 
+  // ---- data-parallel replay of whole records, one lane per record -------------
+  // Between reads (remain == 0, no retained slice) the endpoint-read loop is a
+  // tiny state machine over the record sizes: s = space left in an open 256-byte
+  // read.  Any record of >= 511 bytes forces s back to 0 whatever came before, so
+  // every lane finds its own incoming state by looking back to the nearest such
+  // record and replaying the few small records in between.  Offsets, slice and
+  // segment indices then follow from wave prefix sums.  Returns the number of
+  // records consumed (0: fall back to the scalar path).
+  auto fast_chunk = [&]() -> uint32_t {
+    if (cap > (1ull << 31)) return 0;  // 32-bit DPP scans below
+    top_up();
+    uint32_t k = chain_n - chain_i;
+    if (k == 0) return 0;
+    if (k > 64) k = 64;
+    // conservative room checks for up to 64 records
+    if (nslices + 128 > max_slices || nsegs + 256 + 520 > GRDMA_MAX_SEGS) return 0;
+    const bool act0 = (uint32_t)lane < k;
+    const uint64_t n = act0 ? s_chain[chain_i + lane] : 0;
+    // incoming read state
+    const uint64_t resets = __ballot(act0 && n >= 2 * GRDMA_MIN_READ_SLICE - 1);
+    const uint64_t below = resets & ((1ull << lane) - 1ull);
+    const uint32_t from = below ? (64 - __builtin_clzll(below)) : 0;  // first record after the reset
+    uint64_t s_in = 0;
+    for (uint32_t i = from; i < (uint32_t)lane && act0; i++)
+      s_in = read_space_after(s_chain[chain_i + i], s_in);
+    const uint64_t s_out = read_space_after(n, s_in);
+    // stop after the last record that leaves the state clean
+    const uint64_t clean = __ballot(act0 && s_out == 0);
+    if (clean == 0) return 0;
+    const uint32_t cnt = 64 - __builtin_clzll(clean);
+    const bool act = (uint32_t)lane < cnt;
+    const uint32_t enc = act ? (uint32_t)(16 + round_up8(n)) : 0;
+
+    // what this record does to the read sequence
+    uint64_t c1 = 0, c2 = 0;          // bytes of the two Recv steps
+    uint64_t sl_len[2] = {0, 0};      // slices completed here, in order
+    uint32_t sl_cnt = 0;
+    if (act) {
+      if (s_in == 0) {
+        c1 = n;
+        if (n >= GRDMA_MIN_READ_SLICE) sl_len[sl_cnt++] = n;
+      } else if (n <= s_in) {
+        c1 = n;
+        if (n == s_in) sl_len[sl_cnt++] = GRDMA_MIN_READ_SLICE;
+      } else {
+        c1 = s_in;
+        c2 = n - s_in;
+        sl_len[sl_cnt++] = GRDMA_MIN_READ_SLICE;
+        if (c2 >= GRDMA_MIN_READ_SLICE) sl_len[sl_cnt++] = c2;
+      }
+    }
+    const uint32_t done_bytes =
+        (uint32_t)(((sl_len[0] + 15) & ~15ull) + ((sl_len[1] + 15) & ~15ull));
+    const uint32_t i_enc = wave_incl_scan_u32(enc);
+    const uint32_t i_bytes = wave_incl_scan_u32(done_bytes);
+    const uint32_t i_n = wave_incl_scan_u32(act ? (uint32_t)n : 0);
+    const uint64_t tot_n = __shfl(i_n, 63, 64);
+    // arena room: every slice start is 16-byte aligned
+    if (a_off + tot_n + 32ull * cnt + 512 > op.arena_cap) return 0;
+    const uint64_t x_enc = i_enc - enc, x_bytes = i_bytes - done_bytes;
+    const uint64_t pos = (head + x_enc) & mask;           // header of my record
+    const uint64_t pay = (pos + 8) & mask;
+    const uint64_t A = a_off + x_bytes;                   // start of the open / next slice
+    const uint64_t filled = s_in ? GRDMA_MIN_READ_SLICE - s_in : 0;
+    const uint64_t dst1 = (uint64_t)op.arena + A + filled;
+    const uint64_t dst2 = (uint64_t)op.arena + A + GRDMA_MIN_READ_SLICE;
+    // segments: each step is one piece, two when it crosses the ring end
+    uint64_t sg_dst[4], sg_src[4], sg_len[4];
+    uint32_t sg_cnt = 0;
+    auto add_step = [&](uint64_t dst, uint64_t off, uint64_t len) {
+      if (len == 0) return;
+      const uint64_t p0 = (pay + off) & mask;
+      const uint64_t l1 = len < cap - p0 ? len : cap - p0;
+      sg_dst[sg_cnt] = dst; sg_src[sg_cnt] = (uint64_t)(ring + p0); sg_len[sg_cnt] = l1; sg_cnt++;
+      if (len > l1) {
+        sg_dst[sg_cnt] = dst + l1; sg_src[sg_cnt] = (uint64_t)ring; sg_len[sg_cnt] = len - l1; sg_cnt++;
+      }
+    };
+    if (act) {
+      add_step(dst1, 0, c1);
+      add_step(dst2, c1, c2);
+    }
+    uint32_t my_tiles = 0;
+    for (uint32_t q = 0; q < sg_cnt; q++)
+      my_tiles += (uint32_t)((sg_len[q] + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+    const uint32_t packed = sl_cnt | (sg_cnt << 16);
+    const uint32_t i_packed = wave_incl_scan_u32(packed);
+    const uint32_t i_tiles = wave_incl_scan_u32(my_tiles);
+    const uint64_t x_slices = (i_packed & 0xFFFFu) - sl_cnt;
+    const uint64_t x_segs = (i_packed >> 16) - sg_cnt;
+    uint64_t x_tiles = i_tiles - my_tiles;
+    if (act) {
+      for (uint32_t q = 0; q < sg_cnt; q++) {
+        plan->segs[nsegs + x_segs + q] = {sg_dst[q], sg_src[q], sg_len[q], GRDMA_SEG_ZERO_SRC};
+        plan->tile_prefix[nsegs + x_segs + q] = (uint32_t)(ntiles + x_tiles);
+        x_tiles += (sg_len[q] + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
+      }
+      uint64_t so = A;
+      for (uint32_t q = 0; q < sl_cnt; q++) {
+        out_slices[nslices + x_slices + q].off = so;
+        out_slices[nslices + x_slices + q].len = sl_len[q];
+        so += (sl_len[q] + 15) & ~15ull;
+      }
+      // clear header, padding and footer (ring_buffer.cc:146,173-180)
+      *reinterpret_cast<uint64_t*>(ring + pos) = 0;
+      for (uint64_t q = n; q < round_up8(n); q++) ring[(pay + q) & mask] = 0;
+      *reinterpret_cast<uint64_t*>(ring + ((pay + round_up8(n)) & mask)) = 0;
+    }
+    // credit accounting over the Recv steps, in order (pair.cc:276-284): a
+    // record's steps consume enc bytes in total, so the running sum after its
+    // last step is the inclusive enc scan
+    const uint64_t pad_foot = round_up8(n) - n + 8;
+    const uint64_t cons2 = act && c2 ? c2 + pad_foot : 0;
+    const uint64_t mh1 = c2 == 0 ? (pos + enc) & mask : (pay + c1) & mask;
+    const uint64_t mh2 = (pos + enc) & mask;
+    const uint64_t C2 = i_enc;
+    const uint64_t C1 = C2 - cons2;
+    const uint64_t Ctot = __shfl(i_enc, 63, 64);
+    uint64_t base = 0, thr = cap / 2 - irs;
+    bool crossed = false;
+    for (;;) {
+      const uint64_t hit = __ballot(act && C2 >= thr);
+      if (hit == 0) break;
+      const int f = __builtin_ctzll(hit);
+      const uint64_t fC1 = __shfl(C1, f, 64), fC2 = __shfl(C2, f, 64);
+      const uint64_t fmh1 = __shfl(mh1, f, 64), fmh2 = __shfl(mh2, f, 64);
+      const bool first = fC1 >= thr;
+      credit_head = first ? fmh1 : fmh2;
+      base = first ? fC1 : fC2;
+      credit++;
+      crossed = true;
+      thr = base + cap / 2;
+    }
+    irs = crossed ? Ctot - base : irs + Ctot;
+
+    const uint32_t t_packed = __shfl(i_packed, 63, 64);
+    // lanes >= cnt contributed nothing, so lane 63 holds the totals
+    head = (head + Ctot) & mask;
+    mh = head;
+    consumed_total += Ctot;
+    bytes += tot_n;
+    records += cnt;
+    nslices += t_packed & 0xFFFFu;
+    nsegs += t_packed >> 16;
+    ntiles += __shfl(i_tiles, 63, 64);
+    a_off += __shfl(i_bytes, 63, 64);
+    chain_i += cnt;
+    return cnt;
+  };
+
   if (connected && op.raw_cap > 0) {
     // grdma_pair_recv(): exactly one Recv(buf, capacity)
     uint64_t n = recv_step((uint64_t)op.arena, op.raw_cap);
@@ -643,8 +899,14 @@ __global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
     bytes = n;
     a_off = n;
   } else {
-    while (connected && nslices < op.max_reads && nslices < max_slices &&
-           nsegs + 520 <= GRDMA_MAX_SEGS) {
+    while (connected && nslices < max_slices && nsegs + 520 <= GRDMA_MAX_SEGS) {
+      {
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        const bool took = remain == 0 && leftover == 0 && fast_chunk() > 0;
+        t_fast += __builtin_amdgcn_s_memtime() - t0;
+        if (took) { n_fast++; continue; }
+      }
+      n_scalar++;
       // rdma_continue_read, rdma_bp_posix.cc:306-317
       uint64_t readable = remain;
       if (readable == 0) readable = next_ready();
@@ -710,6 +972,13 @@ __global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
   res->moving_head = mh;
   res->remain = remain;
   res->arena_used = a_off;
+  res->dbg[0] = t_begin;
+  res->dbg[1] = __builtin_amdgcn_s_memtime();
+  res->dbg[2] = n_rounds;
+  res->dbg[3] = n_fast;
+  res->dbg[4] = n_scalar;
+  res->dbg[5] = t_refill;
+  res->dbg[6] = t_fast;
   // consumed ring bytes are always the contiguous range [mh0, mh)
   res->zero_off[0] = res->zero_off[1] = res->zero_len[0] = res->zero_len[1] = 0;
   if (consumed_total > 0) {
@@ -737,14 +1006,16 @@ __global__ __launch_bounds__(COPY_THREADS) void k_rx_apply(const grdma_rx_op* op
   const uint32_t wave = (blockIdx.x * COPY_THREADS + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * COPY_THREADS) >> 6;
   run_plan_tiles(op.plan, wave, nwaves, lane);
-  // arrival: release my stores, count in, last one publishes
+  // arrival: my stores have been issued and acknowledged (vmcnt(0)); count in,
+  // the last workgroup publishes.  Consumers on this device run in later
+  // kernels of the stream (a kernel boundary makes the writes visible); a ring
+  // registered for a NIC is uncached memory, where acknowledged stores are
+  // already at their destination -- so no L2 write-back fence is paid here.
   __shared__ unsigned int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned int prev = __hip_atomic_fetch_add(&op.conn->rx_blocks_done, 1u, __ATOMIC_ACQ_REL,
+    unsigned int prev = __hip_atomic_fetch_add(&op.conn->rx_blocks_done, 1u, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
     s_last = (prev == gridDim.x - 1) ? 1u : 0u;
   }

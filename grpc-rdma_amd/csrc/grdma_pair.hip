@@ -625,7 +625,8 @@ struct grdma_stream_job {
   uint8_t* dst = nullptr;
   uint64_t dst_cap = 0;
   uint64_t rounds = 0;
-  grdma_job_ctl* ctl = nullptr;
+  grdma_job_ctl* ctl = nullptr;     // device memory: the kernels read it
+  grdma_job_ctl* h_ctl = nullptr;   // host mirror used to build / read it back
   hipGraphExec_t exec = nullptr;
   uint64_t exec_rounds = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -689,7 +690,7 @@ grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,
   j->rounds = max_rounds;
   bool ok = hipMalloc((void**)&j->d_sges, sizeof(grdma_sge) * count) == hipSuccess &&
             hipMalloc((void**)&j->d_slices, sizeof(grdma_slice_out) * slices_cap) == hipSuccess &&
-            hipHostMalloc((void**)&j->ctl, sizeof(grdma_job_ctl), hipHostMallocDefault) == hipSuccess &&
+            hipMalloc((void**)&j->ctl, sizeof(grdma_job_ctl)) == hipSuccess &&
             hipEventCreate(&j->ev0) == hipSuccess && hipEventCreate(&j->ev1) == hipSuccess;
   if (!ok) {
     fail(GRDMA_ERR_HIP, "stream job allocation failed");
@@ -707,9 +708,10 @@ grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,
     grdma_stream_job_destroy(j);
     return nullptr;
   }
-  memset(j->ctl, 0, sizeof(*j->ctl));
+  j->h_ctl = new grdma_job_ctl();
+  memset(j->h_ctl, 0, sizeof(*j->h_ctl));
   for (int k = 0; k < 2; k++) {
-    grdma_tx_op& t = j->ctl->txop[k];
+    grdma_tx_op& t = j->h_ctl->txop[k];
     t.conn = tx->d_conn;
     t.slices = j->d_sges;
     t.nslices = count;
@@ -717,7 +719,7 @@ grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,
     t.wire_plan = tx->d_wireplan;
     t.result = &j->ctl->txres;
     t.use_cursor = k == 0 ? 2 : 1;
-    grdma_rx_op& r = j->ctl->rxop[k];
+    grdma_rx_op& r = j->h_ctl->rxop[k];
     r.conn = rx->d_conn;
     r.plan = rx->d_rxplan;
     r.result = &j->ctl->rxres;
@@ -729,9 +731,14 @@ grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,
     r.append = k == 0 ? 2 : 1;
     r.slices_cap = slices_cap;
   }
-  j->ctl->plan_ptrs[0] = tx->d_txplan;
-  j->ctl->plan_ptrs[1] = tx->d_wireplan;
-  j->ctl->plan_ptrs[2] = rx->d_rxplan;
+  j->h_ctl->plan_ptrs[0] = tx->d_txplan;
+  j->h_ctl->plan_ptrs[1] = tx->d_wireplan;
+  j->h_ctl->plan_ptrs[2] = rx->d_rxplan;
+  if (hipMemcpy(j->ctl, j->h_ctl, sizeof(grdma_job_ctl), hipMemcpyHostToDevice) != hipSuccess) {
+    fail(GRDMA_ERR_HIP, "job control block upload failed");
+    grdma_stream_job_destroy(j);
+    return nullptr;
+  }
   return j;
 }
 
@@ -744,7 +751,8 @@ void grdma_stream_job_destroy(grdma_stream_job* j) {
   if (j->ev1) hipEventDestroy(j->ev1);
   hipFree(j->d_sges);
   hipFree(j->d_slices);
-  if (j->ctl) hipHostFree(j->ctl);
+  if (j->ctl) hipFree(j->ctl);
+  delete j->h_ctl;
   delete j;
 }
 
@@ -811,6 +819,30 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
   out->tx_records = c1t.tx_records - c0t.tx_records;
   out->rx_records = c1r.rx_records - c0r.rx_records;
   out->done = (c1t.tx_slice_idx >= j->count && out->bytes_delivered == out->bytes_sent) ? 1 : 0;
+  return 0;
+}
+
+int grdma_stream_job_debug(grdma_stream_job* j, uint64_t* tx_dbg, uint64_t* rx_dbg) {
+  if (!j) return -1;
+  hipStreamSynchronize(j->tx->stream);
+  hipMemcpy(tx_dbg, j->ctl->txres.dbg, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost);
+  hipMemcpy(rx_dbg, j->ctl->rxres.dbg, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost);
+  return 0;
+}
+
+int grdma_stream_job_launch(grdma_stream_job* j) {
+  if (int rc = require_ctx()) return rc;
+  if (!j) return fail(GRDMA_ERR_INVALID, "null job");
+  if (!j->exec || j->exec_rounds != j->rounds)
+    return fail(GRDMA_ERR_INVALID, "run the job once in GRDMA_RUN_GRAPH mode before launching it");
+  HIP_TRY(hipGraphLaunch(j->exec, j->tx->stream));
+  return 0;
+}
+
+int grdma_stream_job_sync(grdma_stream_job* j) {
+  if (int rc = require_ctx()) return rc;
+  if (!j) return fail(GRDMA_ERR_INVALID, "null job");
+  HIP_TRY(hipStreamSynchronize(j->tx->stream));
   return 0;
 }
 

@@ -1,0 +1,75 @@
+"""Device-resident streaming job (grdma_stream_job_*): pushes a whole slice
+list through a connected loop-back link with no host round trips."""
+import ctypes as C
+
+from ._lib import GrdmaError, ReadSlice, Slice, check, load
+
+u64 = C.c_uint64
+
+
+class StreamResult(C.Structure):
+    _fields_ = [(n, u64) for n in ("bytes_sent", "bytes_delivered", "slices_delivered",
+                                   "tx_rounds", "rx_rounds", "tx_records", "rx_records", "done")] + \
+               [("ms_total", C.c_double), ("ms_class", C.c_double * 8),
+                ("launches_class", u64 * 8)]
+
+
+RUN_EAGER, RUN_GRAPH, RUN_INSTRUMENTED = 0, 1, 2
+CLASS_NAMES = ["tx_plan", "gather", "wire", "rx_plan", "rx_apply"]
+
+_bound = False
+
+
+def _bind():
+    global _bound
+    lib = load()
+    if not _bound:
+        lib.grdma_stream_job_create.restype = C.c_void_p
+        lib.grdma_stream_job_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Slice), u64,
+                                                C.c_void_p, u64, u64, u64]
+        lib.grdma_stream_job_destroy.argtypes = [C.c_void_p]
+        lib.grdma_stream_job_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(StreamResult)]
+        lib.grdma_stream_job_slices.argtypes = [C.c_void_p, C.POINTER(ReadSlice), u64]
+        lib.grdma_stream_job_set_rounds.argtypes = [C.c_void_p, u64]
+        lib.grdma_stream_job_launch.argtypes = [C.c_void_p]
+        lib.grdma_stream_job_sync.argtypes = [C.c_void_p]
+        _bound = True
+    return lib
+
+
+class StreamJob:
+    def __init__(self, tx, rx, slices, rx_dst_ptr, rx_dst_cap, slices_cap, max_rounds):
+        """slices: list of (device ptr, len)."""
+        self.lib = _bind()
+        arr = (Slice * len(slices))()
+        for i, (p, n) in enumerate(slices):
+            arr[i].ptr, arr[i].len = p, n
+        self.slices_cap = slices_cap
+        self.h = self.lib.grdma_stream_job_create(tx.h, rx.h, arr, len(slices), rx_dst_ptr,
+                                                  rx_dst_cap, slices_cap, max_rounds)
+        if not self.h:
+            raise GrdmaError(self.lib.grdma_last_error().decode())
+
+    def set_rounds(self, n):
+        check(self.lib.grdma_stream_job_set_rounds(self.h, n))
+
+    def run(self, mode=RUN_GRAPH):
+        r = StreamResult()
+        check(self.lib.grdma_stream_job_run(self.h, mode, C.byref(r)))
+        return r
+
+    def launch(self):
+        check(self.lib.grdma_stream_job_launch(self.h))
+
+    def sync(self):
+        check(self.lib.grdma_stream_job_sync(self.h))
+
+    def delivered_slices(self):
+        arr = (ReadSlice * self.slices_cap)()
+        n = check(self.lib.grdma_stream_job_slices(self.h, arr, self.slices_cap))
+        return [(int(arr[i].off), int(arr[i].len)) for i in range(n)]
+
+    def close(self):
+        if self.h:
+            self.lib.grdma_stream_job_destroy(self.h)
+            self.h = None

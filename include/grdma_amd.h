@@ -183,6 +183,10 @@ grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,
                                           uint64_t slices_cap, uint64_t max_rounds);
 void grdma_stream_job_destroy(grdma_stream_job* j);
 int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out);
+/* Asynchronous form for timed loops: enqueue one pass (the captured graph) on
+ * the link's stream without reading any state back; _sync() waits for it. */
+int grdma_stream_job_launch(grdma_stream_job* j);
+int grdma_stream_job_sync(grdma_stream_job* j);
 int grdma_stream_job_slices(grdma_stream_job* j, grdma_read_slice* out, uint64_t cap);
 int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds);
 

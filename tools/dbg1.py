@@ -3,7 +3,8 @@ sys.path.insert(0, '.')
 import grpc_rdma_amd as g
 from oracle import pyorc
 g.init(0)
-seed=0; flags=0
+import os
+seed=int(os.environ.get("SEED","0")); flags=int(os.environ.get("FLAGS","0"))
 rng = random.Random(1000 + seed)
 R = rng.choice([64, 256, 4096, 65536]); sge = rng.choice([1, 3, 30, 200])
 print("R",R,"sge",sge)
@@ -25,7 +26,7 @@ for step in range(40):
         print(step, "recv cap", cap, len(x), len(y), x==y)
     else:
         got,_=b.endpoint_read(1); exp,_al=o.endpoint_read(1)
-        print(step, "epread", [len(x) for x in got], len(exp), (got[0] if got else b"")==exp)
+        print(step, "epread", [len(x) for x in got], len(exp), (got[0] if got else b"")==exp, "alloc", _al)
     x=b.ring_mem(); y=o.ring_mem(1)
     d=[i for i in range(R) if x[i]!=y[i]]
     print("   state g", b.state()); print("   state o", o.state(1))
