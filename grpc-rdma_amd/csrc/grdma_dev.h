@@ -16,8 +16,10 @@
 #define GRDMA_RESERVED 24ull        // ring_buffer.h:52
 #define GRDMA_FOOTER 0xFFFFFFFFFFFFFFFFull  // ring_buffer.h:50
 
-#define GRDMA_MAX_SEGS 4096         // copy segments per plan
-#define GRDMA_MAX_SLICES 4096       // delivered slices per receive plan
+#define GRDMA_MAX_SEGS 8192         // copy segments per plan
+#define GRDMA_MAX_SLICES 8192       // delivered slices per receive plan
+#define GRDMA_TX_MAX_RECORDS 4096   // records priced by one send plan
+#define GRDMA_RX_HIST 256           // record sizes remembered per connection
 #define GRDMA_TILE_BYTES 4096ull    // bytes one wave copies per tile
 #define GRDMA_MIN_READ_SLICE 256ull // rdma_bp_posix.cc:308
 
@@ -87,6 +89,8 @@ struct grdma_conn {
   uint32_t rx_blocks_done;      // k_rx_apply arrival counter (last block commits)
   uint32_t pad2;
   uint64_t tx_remaining;        // bytes of the current slice list not yet accepted
+  uint32_t* rx_hist;            // encoded sizes of the last GRDMA_RX_HIST records read
+  uint64_t rx_hist_count;       // records read so far (ring index = count % HIST)
 };
 
 struct grdma_seg {

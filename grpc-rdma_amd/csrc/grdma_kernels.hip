@@ -33,72 +33,10 @@
 #include <stdint.h>
 
 #include "grdma_dev.h"
+#include "grdma_devfn.h"
 #include "grdma_ops.h"
 
-#define PLAN_THREADS 256
-#define COPY_THREADS 256
-
 namespace {
-
-__device__ __forceinline__ uint64_t round_up8(uint64_t v) { return (v + 7ull) & ~7ull; }
-__device__ __forceinline__ uint64_t round_down8(uint64_t v) { return v & ~7ull; }
-__device__ __forceinline__ uint64_t enc_size(uint64_t pay) { return 16ull + round_up8(pay); }
-// CalculateWritableSize, ring_buffer.h:185-189
-__device__ __forceinline__ uint64_t writable_of(uint64_t space) {
-  return space > GRDMA_RESERVED ? round_down8(space - GRDMA_RESERVED) : 0ull;
-}
-__device__ __forceinline__ uint64_t sat_sub(uint64_t a, uint64_t b) { return a > b ? a - b : 0ull; }
-
-// Tag words are written by another agent (the wire kernel of a peer, a NIC):
-// relaxed agent-scope atomic loads bypass the per-CU L1 (never refreshed by other
-// writers) and are served by L2 / memory.  A ring registered for NIC writes must
-// be allocated uncached (fine-grained), where the same load reaches memory.
-__device__ __forceinline__ uint64_t ld_tag(const uint8_t* p) {
-  return __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint64_t t = __shfl_up(v, d, 64);
-    if (lane >= d) v += t;
-  }
-  return v;
-}
-
-// Inclusive wave64 prefix sum of a 32-bit value on the DPP network (row shifts
-// 1,2,4,8, then row_bcast:15 / row_bcast:31 across the four 16-lane rows): six
-// VALU instructions, no LDS traffic.
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31
-  return v;
-}
-
-// Exclusive scan of one value per thread over a 256-thread block; returns the
-// exclusive prefix and the block total (via *total).
-__device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t* wave_sums,
-                                                    uint64_t* total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint64_t incl = wave_incl_scan(v, lane);
-  if (lane == 63) wave_sums[wave] = incl;
-  __syncthreads();
-  uint64_t base = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < PLAN_THREADS / 64; w++) {
-    uint64_t s = wave_sums[w];
-    if (w < wave) base += s;
-    tot += s;
-  }
-  __syncthreads();
-  *total = tot;
-  return base + incl - v;
-}
 
 // ----------------------------------------------------------------------------
 // k_tx_plan: PairPollable::Send arithmetic + rdma_flush cursor, one block per op
@@ -115,8 +53,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
   grdma_conn* c = op.conn;
   grdma_plan* plan = op.plan;
   __shared__ uint64_t s_wave[PLAN_THREADS / 64];
-  __shared__ uint64_t s_len[GRDMA_MAX_SEGS];       // len_i, later pay_i
-  __shared__ uint64_t s_excl[GRDMA_MAX_SEGS + 1];  // st_i, later the tile prefix
+  __shared__ uint64_t s_len[GRDMA_TX_MAX_RECORDS];       // len_i, later pay_i
+  __shared__ uint64_t s_excl[GRDMA_TX_MAX_RECORDS + 1];  // st_i
   __shared__ unsigned int s_first_short;
   __shared__ unsigned int s_wrap_rec;
   const unsigned tid = threadIdx.x;
@@ -157,7 +95,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
 
   uint64_t m = avail;
   if (m > c->max_sge) m = c->max_sge;
-  if (m > GRDMA_MAX_SEGS - 1) m = GRDMA_MAX_SEGS - 1;
+  if (m > GRDMA_TX_MAX_RECORDS - 1) m = GRDMA_TX_MAX_RECORDS - 1;
   if (!connected) m = 0;
 
   tdbg[1] = __builtin_amdgcn_s_memtime();
@@ -507,496 +445,6 @@ __global__ __launch_bounds__(COPY_THREADS) void k_copy(const grdma_plan* const* 
 }
 
 // ----------------------------------------------------------------------------
-// k_rx_plan: message-ready test + record chain walk + endpoint_read replay
-// ----------------------------------------------------------------------------
-// The record chain is a linked list (each header gives the next offset), so a
-// naive walk costs one dependent HBM/L2 round trip per record.  Here one wave
-// probes 64 *predicted* positions per round trip: record sizes on a gRPC
-// connection repeat with period 2 (9-byte DATA frame header slice, 16 KiB
-// payload slice), so lane j loads the tag words at the offset the chain reaches
-// after j records if the last two sizes keep alternating.  Every lane then
-// checks its own link (header valid, its size equals the prediction) and the
-// footer word in front of it; two __ballot()s give the verified prefix.  A round
-// always resolves at least one record, and a mispredicted record's size is
-// carried into the next round so its footer probe is exact.
-#define CHAIN_CAP 128
-
-struct chain_walker {
-  const uint8_t* ring;
-  uint64_t cap;
-  uint64_t pos;   // ring offset of the first unverified record
-  uint64_t e0;    // encoded size of the record at pos when its header is already known
-  uint64_t h2, h1;  // encoded sizes of the two records before pos (0 = unknown)
-  bool dry;       // pos holds no complete record
-};
-
-// One probe round.  Stores the payload sizes of the verified records in
-// chain[0..v) and returns v.
-__device__ __forceinline__ uint32_t chain_round(chain_walker* w, uint64_t* chain, int lane) {
-  const uint64_t cap = w->cap, mask = cap - 1;
-  // history with the already-known first record folded in
-  const uint64_t H2 = w->e0 ? w->h1 : w->h2;
-  const uint64_t H1 = w->e0 ? w->e0 : w->h1;
-  const uint64_t A = H2 ? H2 : H1, B = H1;  // predicted sizes alternate A, B, A, ...
-  // rel(j): predicted offset of record j from pos; k = index among the predicted ones
-  auto rel_of = [&](uint64_t j) -> uint64_t {
-    uint64_t base = 0, k = j;
-    if (w->e0) {
-      if (j == 0) return 0;
-      base = w->e0;
-      k = j - 1;
-    }
-    return base + (k >> 1) * (A + B) + ((k & 1) ? A : 0);
-  };
-  const bool have_pattern = (A != 0);
-  const uint64_t rel = have_pattern ? rel_of(lane) : 0;
-  const uint64_t rel_next = have_pattern ? rel_of(lane + 1) : 0;
-  // The sender never lets the ring hold more than cap - 8 bytes (W() keeps 24
-  // free before a write), so a record can only exist where it ends by cap - 8,
-  // and the footer in front of lane j only matters if record j-1 ends by then.
-  const bool probe_hdr = (lane == 0) || (have_pattern && rel_next <= cap - 8);
-  const bool probe_prev = lane > 0 && have_pattern && rel <= cap - 8;
-  const uint64_t my_pos = (w->pos + rel) & mask;
-  uint64_t hdr = 0, prev = 0;
-  if (probe_hdr) hdr = ld_tag(w->ring + my_pos);
-  if (probe_prev) prev = ld_tag(w->ring + ((my_pos + cap - 8) & mask));  // footer of record j-1
-  const bool valid = probe_hdr && hdr != 0 && hdr <= cap - GRDMA_RESERVED;
-  const uint64_t enc = 16 + round_up8(hdr);
-  const bool link_ok = valid && have_pattern && lane < 63 && enc == rel_next - rel;
-  const uint64_t m_link = __ballot(link_ok);
-  const uint64_t m_foot = __ballot(probe_prev && prev == GRDMA_FOOTER) >> 1;  // bit j: footer of j
-  const uint64_t m_fprobed = __ballot(probe_prev) >> 1;
-  const uint64_t m_hprobed = __ballot(probe_hdr);
-  const uint64_t good = m_link & m_foot;
-  const uint32_t v = (good == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~good);
-  if ((uint32_t)lane < v) chain[lane] = hdr;
-  // state for the next round: lane v is the first unverified record
-  const uint64_t m_valid = __ballot(valid);
-  const uint64_t rel_v = __shfl(rel, v < 64 ? v : 63, 64);
-  const uint64_t enc_v = __shfl(enc, v < 64 ? v : 63, 64);
-  const uint64_t enc_l1 = __shfl(enc, v >= 1 ? v - 1 : 0, 64);
-  const uint64_t enc_l2 = __shfl(enc, v >= 2 ? v - 2 : 0, 64);
-  if (v >= 2) {
-    w->h2 = enc_l2;
-    w->h1 = enc_l1;
-  } else if (v == 1) {
-    w->h2 = w->e0 ? w->h1 : w->h1;
-    w->h1 = enc_l1;
-  }
-  // (v == 1 keeps the older size as h2: the record before lane 0)
-  w->pos = (w->pos + rel_v) & mask;
-  w->e0 = 0;
-  if (v < 64) {
-    const bool v_hprobed = (m_hprobed >> v) & 1;
-    const bool v_valid = (m_valid >> v) & 1;
-    const bool v_link = (m_link >> v) & 1;
-    const bool v_fprobed = (m_fprobed >> v) & 1;
-    if (!v_hprobed) {
-      // not looked at (prediction ran past the ring): probe it as lane 0 next round
-    } else if (!v_valid) {
-      w->dry = true;                 // no (or torn) header: nothing more is ready
-    } else if (!v_link || !v_fprobed) {
-      w->e0 = enc_v;                 // header known, exact footer probe next round
-    } else {
-      w->dry = true;                 // size as predicted but the footer has not landed
-    }
-  }
-  return v;
-}
-
-// transition of the endpoint-read state over one record of n bytes:
-// s = bytes of space left in an open 256-byte read (0 = between reads)
-__device__ __forceinline__ uint64_t read_space_after(uint64_t n, uint64_t s) {
-  if (s == 0) return n >= GRDMA_MIN_READ_SLICE ? 0 : GRDMA_MIN_READ_SLICE - n;
-  if (n < s) return s - n;
-  if (n == s) return 0;
-  const uint64_t r = n - s;
-  return r >= GRDMA_MIN_READ_SLICE ? 0 : GRDMA_MIN_READ_SLICE - r;
-}
-
-__global__ __launch_bounds__(64) void k_rx_plan(const grdma_rx_op* ops) {
-  const uint64_t t_begin = __builtin_amdgcn_s_memtime();
-  const grdma_rx_op op = ops[blockIdx.x];
-  const int lane = threadIdx.x;
-  grdma_conn* c = op.conn;
-  grdma_plan* plan = op.plan;
-  grdma_rx_result* res = op.result;
-  uint8_t* ring = c->ring;
-  uint64_t n_rounds = 0, n_fast = 0, n_scalar = 0, t_refill = 0, t_fast = 0;
-  const uint64_t cap = c->cap, mask = cap - 1;
-  uint64_t head = c->head, mh = c->moving_head, remain = c->remain;
-  uint64_t irs = c->internal_read_size, leftover = c->leftover_cap;
-  const uint64_t mh0 = mh;
-  uint64_t nslices = 0, nsegs = 0, ntiles = 0, bytes = 0, consumed_total = 0, records = 0;
-  uint64_t a_off = 0, would_block = 0, credit = 0, credit_head = 0;
-  const bool connected = c->status == GRDMA_PAIR_CONNECTED;
-  grdma_slice_out* out_slices = op.slices;
-  uint64_t max_slices = GRDMA_MAX_SLICES;
-  if (op.append == 2 && lane == 0) {  // first round of a streaming job
-    c->rx_arena_off = 0;
-    c->rx_slice_idx = 0;
-  }
-  if (op.append) {  // streaming job: keep filling the caller's buffer / slice table
-    const uint64_t s_idx = op.append == 2 ? 0 : c->rx_slice_idx;
-    a_off = op.append == 2 ? 0 : c->rx_arena_off;
-    out_slices = op.slices + s_idx;
-    const uint64_t room = op.slices_cap > s_idx ? op.slices_cap - s_idx : 0;
-    if (room < max_slices) max_slices = room;
-  }
-  if (op.max_reads < max_slices) max_slices = op.max_reads;
-
-  __shared__ uint64_t s_chain[CHAIN_CAP];
-  chain_walker w = {ring, cap, head, 0, 0, 0, false};
-  uint32_t chain_n = 0, chain_i = 0;
-
-  auto refill = [&]() {
-    while (chain_i == chain_n && !w.dry) {
-      const uint64_t t0 = __builtin_amdgcn_s_memtime();
-      __syncthreads();
-      chain_n = chain_round(&w, s_chain, lane);
-      chain_i = 0;
-      __syncthreads();
-      n_rounds++;
-      t_refill += __builtin_amdgcn_s_memtime() - t0;
-    }
-  };
-  // keep at least 64 verified records queued while the ring has more
-  auto top_up = [&]() {
-    while (chain_n - chain_i < 64 && !w.dry) {
-      const uint64_t t0 = __builtin_amdgcn_s_memtime();
-      const uint32_t k = chain_n - chain_i;
-      uint64_t keep = 0;
-      if ((uint32_t)lane < k) keep = s_chain[chain_i + lane];
-      __syncthreads();
-      if ((uint32_t)lane < k) s_chain[lane] = keep;
-      chain_i = 0;
-      chain_n = k;
-      chain_n += chain_round(&w, s_chain + k, lane);
-      __syncthreads();
-      n_rounds++;
-      t_refill += __builtin_amdgcn_s_memtime() - t0;
-    }
-  };
-  // size of the next unopened record if it is completely there, else 0
-  auto next_ready = [&]() -> uint64_t {
-    refill();
-    return chain_i < chain_n ? s_chain[chain_i] : 0;
-  };
-
-  // PairPollable::Recv -> RingBufferPollable::Read(dst, capacity)
-  // (pair.cc:264-286, ring_buffer.cc:122-191); returns the bytes copied.
-  auto recv_step = [&](uint64_t dst, uint64_t capacity) -> uint64_t {
-    uint64_t avail = remain;
-    if (avail == 0) avail = next_ready();
-    const uint64_t cpy = avail < capacity ? avail : capacity;
-    if (cpy == 0) return 0;
-    const uint64_t prev_mh = mh;
-    if (remain == 0) {  // open the record, ring_buffer.cc:133-146
-      if (lane == 0) *reinterpret_cast<uint64_t*>(ring + head) = 0;  // clear header
-      mh = (head + 8) & mask;
-      head = (head + 16 + round_up8(avail)) & mask;
-      records++;
-      chain_i++;
-    }
-    // payload bytes [mh, mh+cpy) -> dst, at most two pieces at the wrap; the
-    // copying wave clears them behind itself (ring_buffer.cc:160,164)
-    const uint64_t l1 = cpy < cap - mh ? cpy : cap - mh;
-    if (lane == 0) {
-      plan->segs[nsegs] = {dst, (uint64_t)(ring + mh), l1, GRDMA_SEG_ZERO_SRC};
-      plan->tile_prefix[nsegs] = (uint32_t)ntiles;
-    }
-    ntiles += (l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
-    nsegs++;
-    if (cpy > l1) {
-      if (lane == 0) {
-        plan->segs[nsegs] = {dst + l1, (uint64_t)ring, cpy - l1, GRDMA_SEG_ZERO_SRC};
-        plan->tile_prefix[nsegs] = (uint32_t)ntiles;
-      }
-      ntiles += (cpy - l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
-      nsegs++;
-    }
-    mh = (mh + cpy) & mask;
-    remain = avail - cpy;
-    if (remain == 0) {  // finish the record, ring_buffer.cc:169-182
-      const uint64_t pad_end = round_up8(mh);
-      if (lane == 0) {
-        for (uint64_t q = mh; q < pad_end; q++) ring[q & mask] = 0;  // clear padded space
-        *reinterpret_cast<uint64_t*>(ring + (pad_end & mask)) = 0;    // clear footer
-      }
-      mh = pad_end & mask;
-      mh = (mh + 8) & mask;
-    }
-    const uint64_t consumed = (mh + cap - prev_mh) & mask;
-    consumed_total += consumed;
-    // credit return every cap/2 consumed bytes, pair.cc:276-284
-    irs += consumed;
-    if (irs >= cap / 2) {
-      credit_head = mh;
-      credit++;
-      irs = 0;
-    }
-    return cpy;
-  };
-
-  // ---- data-parallel replay of whole records, one lane per record -------------
-  // Between reads (remain == 0, no retained slice) the endpoint-read loop is a
-  // tiny state machine over the record sizes: s = space left in an open 256-byte
-  // read.  Any record of >= 511 bytes forces s back to 0 whatever came before, so
-  // every lane finds its own incoming state by looking back to the nearest such
-  // record and replaying the few small records in between.  Offsets, slice and
-  // segment indices then follow from wave prefix sums.  Returns the number of
-  // records consumed (0: fall back to the scalar path).
-  auto fast_chunk = [&]() -> uint32_t {
-    if (cap > (1ull << 31)) return 0;  // 32-bit DPP scans below
-    top_up();
-    uint32_t k = chain_n - chain_i;
-    if (k == 0) return 0;
-    if (k > 64) k = 64;
-    // conservative room checks for up to 64 records
-    if (nslices + 128 > max_slices || nsegs + 256 + 520 > GRDMA_MAX_SEGS) return 0;
-    const bool act0 = (uint32_t)lane < k;
-    const uint64_t n = act0 ? s_chain[chain_i + lane] : 0;
-    // incoming read state
-    const uint64_t resets = __ballot(act0 && n >= 2 * GRDMA_MIN_READ_SLICE - 1);
-    const uint64_t below = resets & ((1ull << lane) - 1ull);
-    const uint32_t from = below ? (64 - __builtin_clzll(below)) : 0;  // first record after the reset
-    uint64_t s_in = 0;
-    for (uint32_t i = from; i < (uint32_t)lane && act0; i++)
-      s_in = read_space_after(s_chain[chain_i + i], s_in);
-    const uint64_t s_out = read_space_after(n, s_in);
-    // stop after the last record that leaves the state clean
-    const uint64_t clean = __ballot(act0 && s_out == 0);
-    if (clean == 0) return 0;
-    const uint32_t cnt = 64 - __builtin_clzll(clean);
-    const bool act = (uint32_t)lane < cnt;
-    const uint32_t enc = act ? (uint32_t)(16 + round_up8(n)) : 0;
-
-    // what this record does to the read sequence
-    uint64_t c1 = 0, c2 = 0;          // bytes of the two Recv steps
-    uint64_t sl_len[2] = {0, 0};      // slices completed here, in order
-    uint32_t sl_cnt = 0;
-    if (act) {
-      if (s_in == 0) {
-        c1 = n;
-        if (n >= GRDMA_MIN_READ_SLICE) sl_len[sl_cnt++] = n;
-      } else if (n <= s_in) {
-        c1 = n;
-        if (n == s_in) sl_len[sl_cnt++] = GRDMA_MIN_READ_SLICE;
-      } else {
-        c1 = s_in;
-        c2 = n - s_in;
-        sl_len[sl_cnt++] = GRDMA_MIN_READ_SLICE;
-        if (c2 >= GRDMA_MIN_READ_SLICE) sl_len[sl_cnt++] = c2;
-      }
-    }
-    const uint32_t done_bytes =
-        (uint32_t)(((sl_len[0] + 15) & ~15ull) + ((sl_len[1] + 15) & ~15ull));
-    const uint32_t i_enc = wave_incl_scan_u32(enc);
-    const uint32_t i_bytes = wave_incl_scan_u32(done_bytes);
-    const uint32_t i_n = wave_incl_scan_u32(act ? (uint32_t)n : 0);
-    const uint64_t tot_n = __shfl(i_n, 63, 64);
-    // arena room: every slice start is 16-byte aligned
-    if (a_off + tot_n + 32ull * cnt + 512 > op.arena_cap) return 0;
-    const uint64_t x_enc = i_enc - enc, x_bytes = i_bytes - done_bytes;
-    const uint64_t pos = (head + x_enc) & mask;           // header of my record
-    const uint64_t pay = (pos + 8) & mask;
-    const uint64_t A = a_off + x_bytes;                   // start of the open / next slice
-    const uint64_t filled = s_in ? GRDMA_MIN_READ_SLICE - s_in : 0;
-    const uint64_t dst1 = (uint64_t)op.arena + A + filled;
-    const uint64_t dst2 = (uint64_t)op.arena + A + GRDMA_MIN_READ_SLICE;
-    // segments: each step is one piece, two when it crosses the ring end
-    uint64_t sg_dst[4], sg_src[4], sg_len[4];
-    uint32_t sg_cnt = 0;
-    auto add_step = [&](uint64_t dst, uint64_t off, uint64_t len) {
-      if (len == 0) return;
-      const uint64_t p0 = (pay + off) & mask;
-      const uint64_t l1 = len < cap - p0 ? len : cap - p0;
-      sg_dst[sg_cnt] = dst; sg_src[sg_cnt] = (uint64_t)(ring + p0); sg_len[sg_cnt] = l1; sg_cnt++;
-      if (len > l1) {
-        sg_dst[sg_cnt] = dst + l1; sg_src[sg_cnt] = (uint64_t)ring; sg_len[sg_cnt] = len - l1; sg_cnt++;
-      }
-    };
-    if (act) {
-      add_step(dst1, 0, c1);
-      add_step(dst2, c1, c2);
-    }
-    uint32_t my_tiles = 0;
-    for (uint32_t q = 0; q < sg_cnt; q++)
-      my_tiles += (uint32_t)((sg_len[q] + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
-    const uint32_t packed = sl_cnt | (sg_cnt << 16);
-    const uint32_t i_packed = wave_incl_scan_u32(packed);
-    const uint32_t i_tiles = wave_incl_scan_u32(my_tiles);
-    const uint64_t x_slices = (i_packed & 0xFFFFu) - sl_cnt;
-    const uint64_t x_segs = (i_packed >> 16) - sg_cnt;
-    uint64_t x_tiles = i_tiles - my_tiles;
-    if (act) {
-      for (uint32_t q = 0; q < sg_cnt; q++) {
-        plan->segs[nsegs + x_segs + q] = {sg_dst[q], sg_src[q], sg_len[q], GRDMA_SEG_ZERO_SRC};
-        plan->tile_prefix[nsegs + x_segs + q] = (uint32_t)(ntiles + x_tiles);
-        x_tiles += (sg_len[q] + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
-      }
-      uint64_t so = A;
-      for (uint32_t q = 0; q < sl_cnt; q++) {
-        out_slices[nslices + x_slices + q].off = so;
-        out_slices[nslices + x_slices + q].len = sl_len[q];
-        so += (sl_len[q] + 15) & ~15ull;
-      }
-      // clear header, padding and footer (ring_buffer.cc:146,173-180)
-      *reinterpret_cast<uint64_t*>(ring + pos) = 0;
-      for (uint64_t q = n; q < round_up8(n); q++) ring[(pay + q) & mask] = 0;
-      *reinterpret_cast<uint64_t*>(ring + ((pay + round_up8(n)) & mask)) = 0;
-    }
-    // credit accounting over the Recv steps, in order (pair.cc:276-284): a
-    // record's steps consume enc bytes in total, so the running sum after its
-    // last step is the inclusive enc scan
-    const uint64_t pad_foot = round_up8(n) - n + 8;
-    const uint64_t cons2 = act && c2 ? c2 + pad_foot : 0;
-    const uint64_t mh1 = c2 == 0 ? (pos + enc) & mask : (pay + c1) & mask;
-    const uint64_t mh2 = (pos + enc) & mask;
-    const uint64_t C2 = i_enc;
-    const uint64_t C1 = C2 - cons2;
-    const uint64_t Ctot = __shfl(i_enc, 63, 64);
-    uint64_t base = 0, thr = cap / 2 - irs;
-    bool crossed = false;
-    for (;;) {
-      const uint64_t hit = __ballot(act && C2 >= thr);
-      if (hit == 0) break;
-      const int f = __builtin_ctzll(hit);
-      const uint64_t fC1 = __shfl(C1, f, 64), fC2 = __shfl(C2, f, 64);
-      const uint64_t fmh1 = __shfl(mh1, f, 64), fmh2 = __shfl(mh2, f, 64);
-      const bool first = fC1 >= thr;
-      credit_head = first ? fmh1 : fmh2;
-      base = first ? fC1 : fC2;
-      credit++;
-      crossed = true;
-      thr = base + cap / 2;
-    }
-    irs = crossed ? Ctot - base : irs + Ctot;
-
-    const uint32_t t_packed = __shfl(i_packed, 63, 64);
-    // lanes >= cnt contributed nothing, so lane 63 holds the totals
-    head = (head + Ctot) & mask;
-    mh = head;
-    consumed_total += Ctot;
-    bytes += tot_n;
-    records += cnt;
-    nslices += t_packed & 0xFFFFu;
-    nsegs += t_packed >> 16;
-    ntiles += __shfl(i_tiles, 63, 64);
-    a_off += __shfl(i_bytes, 63, 64);
-    chain_i += cnt;
-    return cnt;
-  };
-
-  if (connected && op.raw_cap > 0) {
-    // grdma_pair_recv(): exactly one Recv(buf, capacity)
-    uint64_t n = recv_step((uint64_t)op.arena, op.raw_cap);
-    if (lane == 0) {
-      out_slices[0].off = 0;
-      out_slices[0].len = n;
-    }
-    nslices = n ? 1 : 0;
-    bytes = n;
-    a_off = n;
-  } else {
-    while (connected && nslices < max_slices && nsegs + 520 <= GRDMA_MAX_SEGS) {
-      {
-        const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        const bool took = remain == 0 && leftover == 0 && fast_chunk() > 0;
-        t_fast += __builtin_amdgcn_s_memtime() - t0;
-        if (took) { n_fast++; continue; }
-      }
-      n_scalar++;
-      // rdma_continue_read, rdma_bp_posix.cc:306-317
-      uint64_t readable = remain;
-      if (readable == 0) readable = next_ready();
-      const uint64_t alloc =
-          leftover ? leftover
-                   : (readable > GRDMA_MIN_READ_SLICE ? readable : GRDMA_MIN_READ_SLICE);
-      if (a_off + alloc > op.arena_cap) break;  // receive arena exhausted
-      uint64_t total = 0;
-      // rdma_do_read loop, rdma_bp_posix.cc:195-277
-      while (total < alloc) {
-        uint64_t n = recv_step((uint64_t)(op.arena + a_off + total), alloc - total);
-        if (n == 0) break;
-        total += n;
-      }
-      if (total == 0) {  // nothing ready: notify_on_read, the slice stays allocated
-        leftover = alloc;
-        would_block = 1;
-        break;
-      }
-      leftover = alloc - total;  // grpc_slice_buffer_trim_end -> last_read_buffer
-      if (lane == 0) {
-        out_slices[nslices].off = a_off;
-        out_slices[nslices].len = total;
-      }
-      nslices++;
-      bytes += total;
-      a_off = (a_off + total + 15) & ~15ull;
-    }
-  }
-
-  if (lane != 0) return;
-  plan->nsegs = (uint32_t)nsegs;
-  plan->ntiles = (uint32_t)ntiles;
-  plan->tile_prefix[nsegs] = (uint32_t)ntiles;
-  plan->bytes = bytes;
-
-  c->head = head;
-  c->moving_head = mh;
-  c->remain = remain;
-  c->internal_read_size = irs;
-  c->leftover_cap = leftover;
-  c->total_read += bytes;
-  c->credit_msgs += credit;
-  c->rx_records += records;
-  if (nslices) c->rx_rounds++;
-  if (op.append) {
-    c->rx_arena_off = a_off;
-    c->rx_slice_idx = (op.append == 2 ? 0 : c->rx_slice_idx) + nslices;
-  }
-  c->rx_blocks_done = 0;
-  // updateStatus() (pair.cc:624-641) must not overtake the copy-out and the
-  // zero-fill of the bytes it grants: the 16-byte report is posted by the last
-  // workgroup of k_rx_apply.
-  if (credit) c->status_send.remote_head = credit_head;
-  res->credit_head = credit_head;
-  res->nslices = nslices;
-  res->bytes = bytes;
-  res->consumed = consumed_total;
-  res->records = records;
-  res->would_block = would_block;
-  res->credit_sent = credit;
-  res->head = head;
-  res->moving_head = mh;
-  res->remain = remain;
-  res->arena_used = a_off;
-  res->dbg[0] = t_begin;
-  res->dbg[1] = __builtin_amdgcn_s_memtime();
-  res->dbg[2] = n_rounds;
-  res->dbg[3] = n_fast;
-  res->dbg[4] = n_scalar;
-  res->dbg[5] = t_refill;
-  res->dbg[6] = t_fast;
-  // consumed ring bytes are always the contiguous range [mh0, mh)
-  res->zero_off[0] = res->zero_off[1] = res->zero_len[0] = res->zero_len[1] = 0;
-  if (consumed_total > 0) {
-    if (mh > mh0) {
-      res->zero_off[0] = mh0;
-      res->zero_len[0] = mh - mh0;
-    } else {
-      res->zero_off[0] = mh0;
-      res->zero_len[0] = cap - mh0;
-      res->zero_off[1] = 0;
-      res->zero_len[1] = mh;
-    }
-  }
-  __threadfence_system();
-  __hip_atomic_store(&res->seq, res->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// ----------------------------------------------------------------------------
 // k_rx_apply: K4 in one launch -- copy the payload out, clear it behind, and let
 // the last workgroup post the credit (status report) once every byte is free.
 // ----------------------------------------------------------------------------
@@ -1095,12 +543,6 @@ hipError_t grdma_launch_copy(const grdma_plan* const* d_plans, uint32_t nplans,
                              uint32_t blocks_per_plan, hipStream_t s) {
   if (nplans == 0) return hipSuccess;
   hipLaunchKernelGGL(k_copy, dim3(blocks_per_plan, nplans), dim3(COPY_THREADS), 0, s, d_plans);
-  return hipGetLastError();
-}
-
-hipError_t grdma_launch_rx_plan(const grdma_rx_op* d_ops, uint32_t nops, hipStream_t s) {
-  if (nops == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_rx_plan, dim3(nops), dim3(64), 0, s, d_ops);
   return hipGetLastError();
 }
 

@@ -101,6 +101,7 @@ struct grdma_pair {
   grdma_plan* d_rxplan = nullptr;
   uint8_t* d_arena = nullptr;
   uint64_t arena_cap = 0;
+  uint32_t* d_hist = nullptr;
   grdma_hostblk* h = nullptr;        // pinned
   grdma_sge* h_sges = nullptr;       // pinned, GRDMA_MAX_SEGS entries
   grdma_slice_out* h_slices = nullptr;  // pinned, GRDMA_MAX_SLICES entries
@@ -127,9 +128,9 @@ int fetch_conn(grdma_pair* p, grdma_conn* out) {
 // can never consume more than the staging budget, pair.cc:676-685).
 int stage_slices(grdma_pair* p, const grdma_slice* slices, uint64_t count, uint64_t skip_first,
                  int flags) {
-  if (count > GRDMA_MAX_SEGS - 1)
+  if (count > GRDMA_TX_MAX_RECORDS - 1)
     return fail(GRDMA_ERR_CAPACITY, "slice list of %llu entries exceeds %d",
-                (unsigned long long)count, GRDMA_MAX_SEGS - 1);
+                (unsigned long long)count, GRDMA_TX_MAX_RECORDS - 1);
   if (flags & GRDMA_MEM_HOST) {
     const uint64_t cap = p->ring_size / 2;
     if (!p->h_bounce) HIP_TRY(hipHostMalloc((void**)&p->h_bounce, cap + 64, hipHostMallocDefault));
@@ -234,7 +235,7 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
     return nullptr;
   }
   if (max_sge <= 0) max_sge = 30;
-  if (max_sge > GRDMA_MAX_SEGS - 1) max_sge = GRDMA_MAX_SEGS - 1;
+  if (max_sge > GRDMA_TX_MAX_RECORDS - 1) max_sge = GRDMA_TX_MAX_RECORDS - 1;
   grdma_pair* p = new grdma_pair();
   p->ring_size = ring_size;
   p->max_sge = max_sge;
@@ -248,8 +249,9 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
             hipMalloc((void**)&p->d_wireplan, sizeof(grdma_plan)) == hipSuccess &&
             hipMalloc((void**)&p->d_rxplan, sizeof(grdma_plan)) == hipSuccess &&
             hipMalloc((void**)&p->d_arena, p->arena_cap) == hipSuccess &&
+            hipMalloc((void**)&p->d_hist, sizeof(uint32_t) * GRDMA_RX_HIST) == hipSuccess &&
             hipHostMalloc((void**)&p->h, sizeof(grdma_hostblk), hipHostMallocDefault) == hipSuccess &&
-            hipHostMalloc((void**)&p->h_sges, sizeof(grdma_sge) * GRDMA_MAX_SEGS,
+            hipHostMalloc((void**)&p->h_sges, sizeof(grdma_sge) * GRDMA_TX_MAX_RECORDS,
                           hipHostMallocDefault) == hipSuccess &&
             hipHostMalloc((void**)&p->h_slices, sizeof(grdma_slice_out) * GRDMA_MAX_SLICES,
                           hipHostMallocDefault) == hipSuccess;
@@ -265,6 +267,7 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
   hipMemsetAsync(p->d_txplan, 0, sizeof(grdma_plan), p->stream);
   hipMemsetAsync(p->d_wireplan, 0, sizeof(grdma_plan), p->stream);
   hipMemsetAsync(p->d_rxplan, 0, sizeof(grdma_plan), p->stream);
+  hipMemsetAsync(p->d_hist, 0, sizeof(uint32_t) * GRDMA_RX_HIST, p->stream);
   memset(p->h, 0, sizeof(grdma_hostblk));
   p->h->plan_ptrs[0] = p->d_txplan;
   p->h->plan_ptrs[1] = p->d_wireplan;
@@ -278,6 +281,7 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
   c.max_sge = (uint32_t)max_sge;
   c.status = GRDMA_PAIR_INITIALIZED;
   c.wire_direct = (flags & GRDMA_WIRE_DIRECT) ? 1 : 0;
+  c.rx_hist = p->d_hist;
   hipMemcpyAsync(p->d_conn, &c, sizeof(c), hipMemcpyHostToDevice, p->stream);
   if (hipStreamSynchronize(p->stream) != hipSuccess) {
     fail(GRDMA_ERR_HIP, "pair initialisation failed");
@@ -297,6 +301,7 @@ void grdma_pair_destroy(grdma_pair* p) {
   hipFree(p->d_wireplan);
   hipFree(p->d_rxplan);
   hipFree(p->d_arena);
+  hipFree(p->d_hist);
   if (p->h) hipHostFree(p->h);
   if (p->h_sges) hipHostFree(p->h_sges);
   if (p->h_slices) hipHostFree(p->h_slices);
@@ -517,9 +522,9 @@ int64_t grdma_endpoint_write_begin(grdma_pair* p, const grdma_slice* slices, uin
   if (int rc = require_ctx()) return rc;
   if (!p || (!slices && count)) return fail(GRDMA_ERR_INVALID, "null argument");
   if (p->w_active) return fail(GRDMA_ERR_INVALID, "a write is already outstanding");  // :563
-  if (count > GRDMA_MAX_SEGS - 1)
+  if (count > GRDMA_TX_MAX_RECORDS - 1)
     return fail(GRDMA_ERR_CAPACITY, "slice buffer of %llu slices exceeds %d",
-                (unsigned long long)count, GRDMA_MAX_SEGS - 1);
+                (unsigned long long)count, GRDMA_TX_MAX_RECORDS - 1);
   p->w_slices.assign(slices, slices + count);
   p->w_idx = 0;
   p->w_byte = 0;

@@ -1,0 +1,840 @@
+// k_rx_plan: message-ready detection (K3), record-chain walk, endpoint_read
+// replay and credit accounting (K5) for one drain of a connection's ring.
+//
+// What the reference does one record at a time on a CPU thread
+// (RingBufferPollable::GetReadableSize / Read, src/core/lib/ibverbs/ring_buffer.cc:67-191;
+// PairPollable::Recv, pair.cc:264-286; rdma_continue_read / rdma_do_read,
+// src/core/lib/iomgr/rdma_bp_posix.cc:180-326) is done here in three tiers, all
+// producing exactly the slices, ring state and credit reports the reference
+// would:
+//
+//  bulk    256 threads, up to 4096 records per pass.  The record chain is a
+//          linked list, but on a gRPC connection it is periodic (one message =
+//          a fixed run of frame-header and payload slices), so the sizes of the
+//          last records are kept per connection, the period is detected, every
+//          predicted header/footer pair is probed at once (one memory round trip
+//          for the whole ring instead of one per record) and the first
+//          mismatch bounds the verified prefix.  The endpoint-read state machine
+//          is then replayed data-parallel: a record of >= 511 bytes resets the
+//          state, so each thread recovers its incoming state by looking back
+//          to the nearest such record; offsets come from block prefix sums.
+//  wave    one wavefront, 64 probes per round trip with period-2 prediction and
+//          __ballot() verification, 64 records replayed per step on the DPP
+//          network.  Used while no period is known and around irregularities.
+//  scalar  one endpoint_read at a time (partial reads, retained slices, tails).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "grdma_dev.h"
+#include "grdma_devfn.h"
+#include "grdma_ops.h"
+
+namespace {
+
+#define CHAIN_CAP 128
+#define BULK_MAX 4096
+#define MINRD GRDMA_MIN_READ_SLICE
+
+struct chain_walker {
+  const uint8_t* ring;
+  uint64_t cap;
+  uint64_t pos;     // ring offset of the first unverified record
+  uint64_t e0;      // encoded size of the record at pos when its header is already known
+  uint64_t h2, h1;  // encoded sizes of the two records before pos (0 = unknown)
+  bool dry;         // pos holds no complete record
+};
+
+// One probe round of the wave tier.  Lane j loads the tag words at the offset the
+// chain reaches after j records if the last two sizes keep alternating; every
+// lane checks its own link and the footer in front of it; two ballots give the
+// verified prefix.  Stores the payload sizes in chain[0..v) and returns v.
+__device__ __forceinline__ uint32_t chain_round(chain_walker* w, uint64_t* chain, int lane) {
+  const uint64_t cap = w->cap, mask = cap - 1;
+  // history with the already-known first record folded in
+  const uint64_t H2 = w->e0 ? w->h1 : w->h2;
+  const uint64_t H1 = w->e0 ? w->e0 : w->h1;
+  const uint64_t A = H2 ? H2 : H1, B = H1;  // predicted sizes alternate A, B, A, ...
+  auto rel_of = [&](uint64_t j) -> uint64_t {
+    uint64_t base = 0, k = j;
+    if (w->e0) {
+      if (j == 0) return 0;
+      base = w->e0;
+      k = j - 1;
+    }
+    return base + (k >> 1) * (A + B) + ((k & 1) ? A : 0);
+  };
+  const bool have_pattern = (A != 0);
+  const uint64_t rel = have_pattern ? rel_of(lane) : 0;
+  const uint64_t rel_next = have_pattern ? rel_of(lane + 1) : 0;
+  // The sender never lets the ring hold more than cap - 8 bytes (W() keeps 24
+  // free before a write), so a record can only exist where it ends by cap - 8,
+  // and the footer in front of lane j only matters if record j-1 ends by then.
+  const bool probe_hdr = (lane == 0) || (have_pattern && rel_next <= cap - 8);
+  const bool probe_prev = lane > 0 && have_pattern && rel <= cap - 8;
+  const uint64_t my_pos = (w->pos + rel) & mask;
+  uint64_t hdr = 0, prev = 0;
+  if (probe_hdr) hdr = ld_tag(w->ring + my_pos);
+  if (probe_prev) prev = ld_tag(w->ring + ((my_pos + cap - 8) & mask));  // footer of record j-1
+  const bool valid = probe_hdr && hdr != 0 && hdr <= cap - GRDMA_RESERVED;
+  const uint64_t enc = 16 + round_up8(hdr);
+  const bool link_ok = valid && have_pattern && lane < 63 && enc == rel_next - rel;
+  const uint64_t m_link = __ballot(link_ok);
+  const uint64_t m_foot = __ballot(probe_prev && prev == GRDMA_FOOTER) >> 1;  // bit j: footer of j
+  const uint64_t m_fprobed = __ballot(probe_prev) >> 1;
+  const uint64_t m_hprobed = __ballot(probe_hdr);
+  const uint64_t good = m_link & m_foot;
+  const uint32_t v = (good == ~0ull) ? 64u : (uint32_t)__builtin_ctzll(~good);
+  if ((uint32_t)lane < v) chain[lane] = hdr;
+  // state for the next round: lane v is the first unverified record
+  const uint64_t m_valid = __ballot(valid);
+  const uint64_t rel_v = __shfl(rel, v < 64 ? v : 63, 64);
+  const uint64_t enc_v = __shfl(enc, v < 64 ? v : 63, 64);
+  const uint64_t enc_l1 = __shfl(enc, v >= 1 ? v - 1 : 0, 64);
+  const uint64_t enc_l2 = __shfl(enc, v >= 2 ? v - 2 : 0, 64);
+  if (v >= 2) {
+    w->h2 = enc_l2;
+    w->h1 = enc_l1;
+  } else if (v == 1) {
+    w->h2 = w->h1;
+    w->h1 = enc_l1;
+  }
+  w->pos = (w->pos + (v < 64 ? rel_v : rel_v + enc_v)) & mask;
+  w->e0 = 0;
+  if (v < 64) {
+    const bool v_hprobed = (m_hprobed >> v) & 1;
+    const bool v_valid = (m_valid >> v) & 1;
+    const bool v_link = (m_link >> v) & 1;
+    const bool v_fprobed = (m_fprobed >> v) & 1;
+    if (!v_hprobed) {
+      // not looked at (prediction ran past the ring): probe it as lane 0 next round
+    } else if (!v_valid) {
+      w->dry = true;                 // no (or torn) header: nothing more is ready
+    } else if (!v_link || !v_fprobed) {
+      w->e0 = enc_v;                 // header known, exact footer probe next round
+    } else {
+      w->dry = true;                 // size as predicted but the footer has not landed
+    }
+  }
+  return v;
+}
+
+// Transition of the endpoint-read state over one record of n bytes:
+// s = bytes of space left in an open 256-byte read (0 = between reads).
+__device__ __forceinline__ uint32_t read_space_after(uint64_t n, uint32_t s) {
+  if (s == 0) return n >= MINRD ? 0 : (uint32_t)(MINRD - n);
+  if (n < s) return s - (uint32_t)n;
+  if (n == s) return 0;
+  const uint64_t r = n - s;
+  return r >= MINRD ? 0 : (uint32_t)(MINRD - r);
+}
+
+// What one whole record does to the read sequence, given the incoming state.
+struct rec_plan {
+  uint64_t c1, c2;     // bytes of the (at most) two Recv steps
+  uint64_t sl_len[2];  // slices completed by this record, in order
+  uint32_t sl_cnt;
+};
+
+__device__ __forceinline__ rec_plan replay_record(uint64_t n, uint32_t s_in) {
+  rec_plan r;
+  r.c1 = r.c2 = 0;
+  r.sl_len[0] = r.sl_len[1] = 0;
+  r.sl_cnt = 0;
+  if (s_in == 0) {
+    r.c1 = n;
+    if (n >= MINRD) r.sl_len[r.sl_cnt++] = n;
+  } else if (n <= s_in) {
+    r.c1 = n;
+    if (n == s_in) r.sl_len[r.sl_cnt++] = MINRD;
+  } else {
+    r.c1 = s_in;
+    r.c2 = n - s_in;
+    r.sl_len[r.sl_cnt++] = MINRD;
+    if (r.c2 >= MINRD) r.sl_len[r.sl_cnt++] = r.c2;
+  }
+  return r;
+}
+
+__device__ __forceinline__ uint64_t al16(uint64_t v) { return (v + 15) & ~15ull; }
+__device__ __forceinline__ uint32_t tiles_of(uint64_t len) {
+  return (uint32_t)((len + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+}
+
+// Everything the tiers share, kept in LDS between the phases of the kernel.
+struct rx_state {
+  uint64_t head, mh, remain, irs, leftover;
+  uint64_t nslices, nsegs, ntiles, bytes, consumed_total, records;
+  uint64_t a_off, would_block, credit, credit_head;
+  uint64_t hist_count;
+  uint32_t stop;
+  uint32_t bulk_tries;    // bulk attempts left in this call
+  uint32_t bulk_blocked;  // last bulk attempt verified nothing: let the wave tier move first
+  uint32_t took;
+};
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_rx_plan(const grdma_rx_op* ops) {
+  const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+  const grdma_rx_op op = ops[blockIdx.x];
+  const unsigned tid = threadIdx.x;
+  const int lane = tid & 63;
+  const unsigned wave = tid >> 6;
+  grdma_conn* c = op.conn;
+  grdma_plan* plan = op.plan;
+  grdma_rx_result* res = op.result;
+  uint8_t* ring = c->ring;
+  const uint64_t cap = c->cap, mask = cap - 1;
+  const bool connected = c->status == GRDMA_PAIR_CONNECTED;
+
+  __shared__ rx_state S;
+  __shared__ uint64_t s_chain[CHAIN_CAP];
+  __shared__ uint32_t s_hist[GRDMA_RX_HIST];
+  __shared__ uint32_t s_penc[BULK_MAX];
+  __shared__ uint32_t s_xenc[BULK_MAX + 1];
+  __shared__ uint32_t s_n[BULK_MAX];
+  __shared__ uint16_t s_sin[BULK_MAX];
+  __shared__ uint64_t s_wave[PLAN_THREADS / 64];
+  __shared__ unsigned int s_key, s_fail, s_clean;
+  __shared__ uint64_t s_dbg[16];
+
+  grdma_slice_out* out_slices = op.slices;
+  uint64_t max_slices = GRDMA_MAX_SLICES;
+  uint64_t a_off0 = 0;
+  if (op.append) {  // streaming job: keep filling the caller's buffer / slice table
+    const uint64_t s_idx = op.append == 2 ? 0 : c->rx_slice_idx;
+    a_off0 = op.append == 2 ? 0 : c->rx_arena_off;
+    out_slices = op.slices + s_idx;
+    const uint64_t room = op.slices_cap > s_idx ? op.slices_cap - s_idx : 0;
+    if (room < max_slices) max_slices = room;
+  }
+  if (op.max_reads < max_slices) max_slices = op.max_reads;
+  const uint64_t mh0 = c->moving_head;
+  const uint64_t hist_count0 = c->rx_hist_count;
+
+  for (unsigned i = tid; i < GRDMA_RX_HIST; i += PLAN_THREADS) s_hist[i] = c->rx_hist[i];
+  if (tid == 0) {
+    S.head = c->head; S.mh = c->moving_head; S.remain = c->remain;
+    S.irs = c->internal_read_size; S.leftover = c->leftover_cap;
+    S.nslices = S.nsegs = S.ntiles = S.bytes = S.consumed_total = S.records = 0;
+    S.a_off = a_off0; S.would_block = 0; S.credit = 0; S.credit_head = 0;
+    S.hist_count = hist_count0;
+    S.stop = connected ? 0 : 1;
+    S.bulk_tries = (op.raw_cap == 0 && cap <= (1ull << 31) && max_slices >= 512) ? 6 : 0;
+    S.bulk_blocked = 0;
+    S.took = 0;
+    for (int q = 0; q < 16; q++) s_dbg[q] = 0;
+  }
+  __syncthreads();
+
+  // ===================================================================== bulk tier
+  auto bulk = [&]() -> uint32_t {
+    const uint64_t H = S.hist_count < GRDMA_RX_HIST ? S.hist_count : GRDMA_RX_HIST;
+    if (H < 4) return 0;
+    const uint64_t hbase = S.hist_count - H;  // absolute index of the oldest entry kept
+    auto hist_at = [&](uint64_t i) -> uint32_t {  // i in [0, H): oldest .. newest
+      return s_hist[(hbase + i) % GRDMA_RX_HIST];
+    };
+    // ---- period detection: thread t tests P = t + 1 -------------------------------
+    if (tid == 0) {
+      s_key = 0xFFFFFFFFu;
+      s_fail = 0xFFFFFFFFu;
+      s_clean = 0;
+    }
+    __syncthreads();
+    {
+      const uint64_t P = tid + 1;
+      if (P < H) {
+        const uint64_t L = H - P;  // comparable entries
+        uint64_t score = 0;
+        while (score < L && hist_at(H - 1 - score) == hist_at(H - 1 - score - P)) score++;  // <= 255 LDS steps
+        const bool full = (score == L) && L >= 2;
+        // smallest full-match period wins; otherwise the longest matching suffix
+        const unsigned key = full ? (unsigned)P
+                                  : (0x10000u + ((unsigned)(GRDMA_RX_HIST - score) << 8) + (unsigned)P);
+        atomicMin(&s_key, key);
+      }
+    }
+    __syncthreads();
+    const unsigned key = s_key;
+    // only a period that explains the whole remembered history is worth a bulk pass;
+    // anything else is left to the wave tier (64 probes per round trip)
+    if (key >= 0x10000u) return 0xFFFFFFFFu;  // no period: no more bulk attempts in this call
+    const uint64_t P = key & 0xFFu ? (key & 0xFFu) : 256;  // P <= 255 by construction
+    // ---- predicted sizes and offsets for up to BULK_MAX records ----------------------
+    const uint32_t per = BULK_MAX / PLAN_THREADS;  // 16 contiguous records per thread
+    {
+      uint64_t chunk = 0;
+      uint64_t ph = (uint64_t)tid * per % P;
+      for (uint32_t k = 0; k < per; k++) {
+        const uint32_t e = hist_at(H - P + ph);
+        s_penc[tid * per + k] = e;
+        chunk += e;
+        if (++ph == P) ph = 0;
+      }
+      uint64_t total;
+      uint64_t x = block_excl_scan(chunk, s_wave, &total);
+      for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = tid * per + k;
+        s_xenc[i] = x > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)x;
+        x += s_penc[i];
+      }
+      if (tid == PLAN_THREADS - 1) s_xenc[BULK_MAX] = x > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)x;
+    }
+    __syncthreads();
+    // ---- probe every predicted header / footer pair at once ---------------------------
+    const uint64_t head = S.head;
+    // room: slices <= 2 per record, segments <= 2 per record + 1 wrap, arena by offsets
+    uint64_t vmax = BULK_MAX;
+    {
+      const uint64_t r_sl = (max_slices - S.nslices) / 2;
+      const uint64_t r_sg = (GRDMA_MAX_SEGS - 524 - S.nsegs) / 2;
+      if (r_sl < vmax) vmax = r_sl;
+      if (r_sg < vmax) vmax = r_sg;
+    }
+    const uint64_t arena_room = op.arena_cap > S.a_off + 1024 ? op.arena_cap - S.a_off - 1024 : 0;
+    for (uint32_t i = tid; i < BULK_MAX; i += PLAN_THREADS) {
+      const uint64_t x = s_xenc[i], e = s_penc[i];
+      bool ok = i < vmax && x + e <= cap - 8 && x + e + 32ull * (i + 1) <= arena_room;
+      uint64_t hdr = 0;
+      if (ok) {
+        hdr = ld_tag(ring + ((head + x) & mask));
+        const uint64_t foot = ld_tag(ring + ((head + x + e - 8) & mask));
+        ok = hdr != 0 && hdr <= cap - GRDMA_RESERVED && 16 + round_up8(hdr) == e &&
+             foot == GRDMA_FOOTER;
+      }
+      s_n[i] = (uint32_t)hdr;
+      const uint64_t bm = __ballot(!ok);
+      if (bm != 0 && lane == __builtin_ctzll(bm)) atomicMin(&s_fail, i);
+    }
+    __syncthreads();
+    const uint32_t V = s_fail == 0xFFFFFFFFu ? BULK_MAX : s_fail;
+    if (tid == 0 && s_dbg[6] == 0) {
+      s_dbg[6] = P; s_dbg[7] = H; s_dbg[8] = V; s_dbg[9] = s_penc[0]; s_dbg[10] = s_penc[1];
+      s_dbg[11] = V < BULK_MAX ? s_penc[V] : 0; s_dbg[12] = V < BULK_MAX ? s_n[V] : 0; s_dbg[13] = key; s_dbg[14] = vmax; s_dbg[15] = S.head;
+    }
+    if (V == 0) return 0;
+    // ---- pass 0: incoming read state of every record, last clean record ----------------
+    const uint32_t per0 = (V + PLAN_THREADS - 1) / PLAN_THREADS;
+    const uint32_t k0 = tid * per0;
+    if (k0 < V) {
+      // look back to the nearest record that resets the state
+      uint32_t j = k0;
+      while (j > 0 && s_n[j - 1] < 2 * MINRD - 1) j--;
+      uint32_t s = 0;
+      for (; j < k0; j++) s = read_space_after(s_n[j], s);
+      uint32_t last_clean = 0;
+      for (uint32_t k = k0; k < k0 + per0 && k < V; k++) {
+        s_sin[k] = (uint16_t)s;
+        s = read_space_after(s_n[k], s);
+        if (s == 0) last_clean = k + 1;
+      }
+      if (last_clean) atomicMax(&s_clean, last_clean);
+    }
+    __syncthreads();
+    const uint32_t cnt = s_clean;  // records [0, cnt) are processed; the state ends clean
+    if (cnt == 0) return 0;
+    // ---- pass 1: per-thread totals, block prefix --------------------------------------
+    const uint32_t per1 = (cnt + PLAN_THREADS - 1) / PLAN_THREADS;
+    const uint32_t q0 = tid * per1;
+    uint64_t t_bytes = 0, t_sl = 0, t_sg = 0, t_tiles = 0, t_n = 0;
+    auto steps_of = [&](uint32_t k, uint64_t* st_off, uint64_t* st_len, uint32_t* nst,
+                        rec_plan* rp) {
+      *rp = replay_record(s_n[k], s_sin[k]);
+      const uint64_t pay = (head + s_xenc[k] + 8) & mask;
+      *nst = 0;
+      auto add = [&](uint64_t off, uint64_t len) {
+        if (len == 0) return;
+        const uint64_t p0 = (pay + off) & mask;
+        const uint64_t l1 = len < cap - p0 ? len : cap - p0;
+        st_off[*nst] = p0; st_len[*nst] = l1; (*nst)++;
+        if (len > l1) { st_off[*nst] = 0; st_len[*nst] = len - l1; (*nst)++; }
+      };
+      add(0, rp->c1);
+      add(rp->c1, rp->c2);
+    };
+    for (uint32_t k = q0; k < q0 + per1 && k < cnt; k++) {
+      uint64_t so[4], sl[4];
+      uint32_t ns;
+      rec_plan rp;
+      steps_of(k, so, sl, &ns, &rp);
+      t_bytes += al16(rp.sl_len[0]) + al16(rp.sl_len[1]);
+      t_sl += rp.sl_cnt;
+      t_sg += ns;
+      for (uint32_t q = 0; q < ns; q++) t_tiles += tiles_of(sl[q]);
+      t_n += s_n[k];
+    }
+    uint64_t tot_bytes, tot_sl, tot_sg, tot_tiles, tot_n;
+    uint64_t x_bytes = block_excl_scan(t_bytes, s_wave, &tot_bytes);
+    uint64_t x_sl = block_excl_scan(t_sl, s_wave, &tot_sl);
+    uint64_t x_sg = block_excl_scan(t_sg, s_wave, &tot_sg);
+    uint64_t x_tiles = block_excl_scan(t_tiles, s_wave, &tot_tiles);
+    block_excl_scan(t_n, s_wave, &tot_n);
+    // ---- pass 2: segments, slices, tag clearing -------------------------------------------
+    const uint64_t nsegs0 = S.nsegs, ntiles0 = S.ntiles, nsl0 = S.nslices, a0 = S.a_off;
+    for (uint32_t k = q0; k < q0 + per1 && k < cnt; k++) {
+      uint64_t so[4], sl[4];
+      uint32_t ns;
+      rec_plan rp;
+      steps_of(k, so, sl, &ns, &rp);
+      const uint32_t s_in = s_sin[k];
+      const uint64_t A = a0 + x_bytes;                    // start of the open / next slice
+      const uint64_t filled = s_in ? MINRD - s_in : 0;
+      // the steps of one record are contiguous in the arena: step 1 fills the
+      // open 256-byte slice exactly, step 2 starts the next slice right behind it
+      uint64_t dst = (uint64_t)op.arena + A + filled;
+      for (uint32_t q = 0; q < ns; q++) {
+        plan->segs[nsegs0 + x_sg] = {dst, (uint64_t)(ring + so[q]), sl[q], GRDMA_SEG_ZERO_SRC};
+        plan->tile_prefix[nsegs0 + x_sg] = (uint32_t)(ntiles0 + x_tiles);
+        x_sg++;
+        x_tiles += tiles_of(sl[q]);
+        dst += sl[q];
+      }
+      uint64_t sof = A;
+      for (uint32_t q = 0; q < rp.sl_cnt; q++) {
+        out_slices[nsl0 + x_sl].off = sof;
+        out_slices[nsl0 + x_sl].len = rp.sl_len[q];
+        x_sl++;
+        sof += al16(rp.sl_len[q]);
+      }
+      x_bytes += al16(rp.sl_len[0]) + al16(rp.sl_len[1]);
+      // clear header, padding and footer (ring_buffer.cc:146,173-180)
+      const uint64_t n = s_n[k];
+      const uint64_t pos = (head + s_xenc[k]) & mask, pay = (pos + 8) & mask;
+      *reinterpret_cast<uint64_t*>(ring + pos) = 0;
+      for (uint64_t q = n; q < round_up8(n); q++) ring[(pay + q) & mask] = 0;
+      *reinterpret_cast<uint64_t*>(ring + ((pay + round_up8(n)) & mask)) = 0;
+    }
+    // history: the processed records become the newest entries
+    {
+      const uint64_t hc = S.hist_count;
+      const uint32_t first = cnt > GRDMA_RX_HIST ? cnt - GRDMA_RX_HIST : 0;
+      __syncthreads();  // everyone is done reading s_hist through s_penc
+      for (uint32_t k = first + tid; k < cnt; k += PLAN_THREADS)
+        s_hist[(hc + k) % GRDMA_RX_HIST] = s_penc[k];
+    }
+    // ---- credit accounting over the Recv steps (pair.cc:276-284), thread 0 ----------------
+    if (tid == 0) {
+      const uint64_t T = cap / 2;
+      const uint64_t Ctot = s_xenc[cnt - 1] + s_penc[cnt - 1];
+      uint64_t base = 0, thr = T - S.irs;
+      bool crossed = false;
+      uint64_t credit = S.credit, credit_head = S.credit_head;
+      while (Ctot >= thr) {
+        // first record whose running consumption (after its last step) reaches thr
+        uint32_t lo = 0, hi = cnt - 1;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if ((uint64_t)s_xenc[mid] + s_penc[mid] >= thr) hi = mid; else lo = mid + 1;
+        }
+        const uint64_t n = s_n[lo], e = s_penc[lo];
+        const rec_plan rp = replay_record(n, s_sin[lo]);
+        const uint64_t C2 = (uint64_t)s_xenc[lo] + e;
+        const uint64_t cons2 = rp.c2 ? rp.c2 + (round_up8(n) - n + 8) : 0;
+        const uint64_t C1 = C2 - cons2;
+        const uint64_t pos = (head + s_xenc[lo]) & mask;
+        if (rp.c2 && C1 >= thr) {  // crossed after the first step of a two-step record
+          credit_head = (pos + 8 + rp.c1) & mask;
+          base = C1;
+        } else {
+          credit_head = (pos + e) & mask;
+          base = C2;
+        }
+        credit++;
+        crossed = true;
+        thr = base + T;
+      }
+      S.irs = crossed ? Ctot - base : S.irs + Ctot;
+      S.credit = credit;
+      S.credit_head = credit_head;
+      S.head = (head + Ctot) & mask;
+      S.mh = S.head;
+      S.consumed_total += Ctot;
+      S.bytes += tot_n;
+      S.records += cnt;
+      S.nslices += tot_sl;
+      S.nsegs += tot_sg;
+      S.ntiles += tot_tiles;
+      S.a_off += tot_bytes;
+      S.hist_count += cnt;
+    }
+    return cnt;
+  };
+
+  // ============================================================== wave + scalar tiers
+  // Runs on wave 0 with the state in registers; returns when the call is finished
+  // (S.stop) or when the state is clean and the bulk tier should try again.
+  auto wave_tier = [&]() {
+    uint64_t head = S.head, mh = S.mh, remain = S.remain, irs = S.irs, leftover = S.leftover;
+    uint64_t nslices = S.nslices, nsegs = S.nsegs, ntiles = S.ntiles, bytes = S.bytes;
+    uint64_t consumed_total = S.consumed_total, records = S.records, a_off = S.a_off;
+    uint64_t would_block = S.would_block, credit = S.credit, credit_head = S.credit_head;
+    uint64_t hist_count = S.hist_count;
+    uint32_t stop = 0, progressed = 0;
+    const bool may_bulk = S.bulk_tries > 0;
+    bool blocked = S.bulk_blocked != 0;
+    uint64_t n_rounds = 0, n_fast = 0, n_scalar = 0;
+
+    chain_walker w = {ring, cap, head, 0, 0, 0, false};
+    if (hist_count >= 1) w.h1 = s_hist[(hist_count - 1) % GRDMA_RX_HIST];
+    if (hist_count >= 2) w.h2 = s_hist[(hist_count - 2) % GRDMA_RX_HIST];
+    uint32_t chain_n = 0, chain_i = 0;
+
+    auto hist_push = [&](uint64_t enc) {
+      if (lane == 0) s_hist[hist_count % GRDMA_RX_HIST] = (uint32_t)enc;
+      hist_count++;
+    };
+    auto refill = [&]() {
+      while (chain_i == chain_n && !w.dry) {
+        chain_n = chain_round(&w, s_chain, lane);
+        chain_i = 0;
+        n_rounds++;
+      }
+    };
+    // keep at least 64 verified records queued while the ring has more
+    auto top_up = [&]() {
+      while (chain_n - chain_i < 64 && !w.dry) {
+        const uint32_t k = chain_n - chain_i;
+        uint64_t keep = 0;
+        if ((uint32_t)lane < k) keep = s_chain[chain_i + lane];
+        if ((uint32_t)lane < k) s_chain[lane] = keep;
+        chain_i = 0;
+        chain_n = k;
+        chain_n += chain_round(&w, s_chain + k, lane);
+        n_rounds++;
+      }
+    };
+    auto next_ready = [&]() -> uint64_t {
+      refill();
+      return chain_i < chain_n ? s_chain[chain_i] : 0;
+    };
+
+    // PairPollable::Recv -> RingBufferPollable::Read(dst, capacity)
+    // (pair.cc:264-286, ring_buffer.cc:122-191); returns the bytes copied.
+    auto recv_step = [&](uint64_t dst, uint64_t capacity) -> uint64_t {
+      uint64_t avail = remain;
+      if (avail == 0) avail = next_ready();
+      const uint64_t cpy = avail < capacity ? avail : capacity;
+      if (cpy == 0) return 0;
+      const uint64_t prev_mh = mh;
+      if (remain == 0) {  // open the record, ring_buffer.cc:133-146
+        if (lane == 0) *reinterpret_cast<uint64_t*>(ring + head) = 0;  // clear header
+        mh = (head + 8) & mask;
+        head = (head + 16 + round_up8(avail)) & mask;
+        records++;
+        chain_i++;
+        hist_push(16 + round_up8(avail));
+        progressed = 1;
+      }
+      // payload bytes [mh, mh+cpy) -> dst, at most two pieces at the wrap; the
+      // copying wave clears them behind itself (ring_buffer.cc:160,164)
+      const uint64_t l1 = cpy < cap - mh ? cpy : cap - mh;
+      if (lane == 0) {
+        plan->segs[nsegs] = {dst, (uint64_t)(ring + mh), l1, GRDMA_SEG_ZERO_SRC};
+        plan->tile_prefix[nsegs] = (uint32_t)ntiles;
+      }
+      ntiles += tiles_of(l1);
+      nsegs++;
+      if (cpy > l1) {
+        if (lane == 0) {
+          plan->segs[nsegs] = {dst + l1, (uint64_t)ring, cpy - l1, GRDMA_SEG_ZERO_SRC};
+          plan->tile_prefix[nsegs] = (uint32_t)ntiles;
+        }
+        ntiles += tiles_of(cpy - l1);
+        nsegs++;
+      }
+      mh = (mh + cpy) & mask;
+      remain = avail - cpy;
+      if (remain == 0) {  // finish the record, ring_buffer.cc:169-182
+        const uint64_t pad_end = round_up8(mh);
+        if (lane == 0) {
+          for (uint64_t q = mh; q < pad_end; q++) ring[q & mask] = 0;  // clear padded space
+          *reinterpret_cast<uint64_t*>(ring + (pad_end & mask)) = 0;    // clear footer
+        }
+        mh = pad_end & mask;
+        mh = (mh + 8) & mask;
+      }
+      const uint64_t consumed = (mh + cap - prev_mh) & mask;
+      consumed_total += consumed;
+      // credit return every cap/2 consumed bytes, pair.cc:276-284
+      irs += consumed;
+      if (irs >= cap / 2) {
+        credit_head = mh;
+        credit++;
+        irs = 0;
+      }
+      return cpy;
+    };
+
+    // 64 whole records per step, one lane per record (see the file header)
+    auto fast_chunk = [&]() -> uint32_t {
+      if (cap > (1ull << 31)) return 0;  // 32-bit DPP scans below
+      top_up();
+      uint32_t k = chain_n - chain_i;
+      if (k == 0) return 0;
+      if (k > 64) k = 64;
+      if (nslices + 128 > max_slices || nsegs + 256 + 520 > GRDMA_MAX_SEGS) return 0;
+      const bool act0 = (uint32_t)lane < k;
+      const uint64_t n = act0 ? s_chain[chain_i + lane] : 0;
+      const uint64_t resets = __ballot(act0 && n >= 2 * MINRD - 1);
+      const uint64_t below = resets & ((1ull << lane) - 1ull);
+      const uint32_t from = below ? (64 - __builtin_clzll(below)) : 0;
+      uint32_t s_in = 0;
+      for (uint32_t i = from; i < (uint32_t)lane && act0; i++)
+        s_in = read_space_after(s_chain[chain_i + i], s_in);
+      const uint32_t s_out = read_space_after(n, s_in);
+      const uint64_t clean = __ballot(act0 && s_out == 0);
+      if (clean == 0) return 0;
+      const uint32_t cnt = 64 - __builtin_clzll(clean);
+      const bool act = (uint32_t)lane < cnt;
+      const uint32_t enc = act ? (uint32_t)(16 + round_up8(n)) : 0;
+      rec_plan rp = replay_record(act ? n : 0, act ? s_in : 0);
+      if (!act) { rp.c1 = rp.c2 = 0; rp.sl_cnt = 0; rp.sl_len[0] = rp.sl_len[1] = 0; }
+      const uint32_t done_bytes = (uint32_t)(al16(rp.sl_len[0]) + al16(rp.sl_len[1]));
+      const uint32_t i_enc = wave_incl_scan_u32(enc);
+      const uint32_t i_bytes = wave_incl_scan_u32(done_bytes);
+      const uint32_t i_n = wave_incl_scan_u32(act ? (uint32_t)n : 0);
+      const uint64_t tot_n = __shfl(i_n, 63, 64);
+      if (a_off + tot_n + 32ull * cnt + 512 > op.arena_cap) return 0;
+      const uint64_t x_enc = i_enc - enc, x_bytes = i_bytes - done_bytes;
+      const uint64_t pos = (head + x_enc) & mask;
+      const uint64_t pay = (pos + 8) & mask;
+      const uint64_t A = a_off + x_bytes;
+      const uint64_t filled = s_in ? MINRD - s_in : 0;
+      const uint64_t dst1 = (uint64_t)op.arena + A + filled;
+      const uint64_t dst2 = (uint64_t)op.arena + A + MINRD;
+      uint64_t sg_dst[4], sg_src[4], sg_len[4];
+      uint32_t sg_cnt = 0;
+      auto add_step = [&](uint64_t dst, uint64_t off, uint64_t len) {
+        if (len == 0) return;
+        const uint64_t p0 = (pay + off) & mask;
+        const uint64_t l1 = len < cap - p0 ? len : cap - p0;
+        sg_dst[sg_cnt] = dst; sg_src[sg_cnt] = (uint64_t)(ring + p0); sg_len[sg_cnt] = l1; sg_cnt++;
+        if (len > l1) {
+          sg_dst[sg_cnt] = dst + l1; sg_src[sg_cnt] = (uint64_t)ring; sg_len[sg_cnt] = len - l1; sg_cnt++;
+        }
+      };
+      if (act) {
+        add_step(dst1, 0, rp.c1);
+        add_step(dst2, rp.c1, rp.c2);
+      }
+      uint32_t my_tiles = 0;
+      for (uint32_t q = 0; q < sg_cnt; q++) my_tiles += tiles_of(sg_len[q]);
+      const uint32_t packed = rp.sl_cnt | (sg_cnt << 16);
+      const uint32_t i_packed = wave_incl_scan_u32(packed);
+      const uint32_t i_tiles = wave_incl_scan_u32(my_tiles);
+      const uint64_t x_slices = (i_packed & 0xFFFFu) - rp.sl_cnt;
+      const uint64_t x_segs = (i_packed >> 16) - sg_cnt;
+      uint64_t x_tiles = i_tiles - my_tiles;
+      if (act) {
+        for (uint32_t q = 0; q < sg_cnt; q++) {
+          plan->segs[nsegs + x_segs + q] = {sg_dst[q], sg_src[q], sg_len[q], GRDMA_SEG_ZERO_SRC};
+          plan->tile_prefix[nsegs + x_segs + q] = (uint32_t)(ntiles + x_tiles);
+          x_tiles += tiles_of(sg_len[q]);
+        }
+        uint64_t so = A;
+        for (uint32_t q = 0; q < rp.sl_cnt; q++) {
+          out_slices[nslices + x_slices + q].off = so;
+          out_slices[nslices + x_slices + q].len = rp.sl_len[q];
+          so += al16(rp.sl_len[q]);
+        }
+        *reinterpret_cast<uint64_t*>(ring + pos) = 0;
+        for (uint64_t q = n; q < round_up8(n); q++) ring[(pay + q) & mask] = 0;
+        *reinterpret_cast<uint64_t*>(ring + ((pay + round_up8(n)) & mask)) = 0;
+        s_hist[(hist_count + lane) % GRDMA_RX_HIST] = enc;
+      }
+      const uint64_t pad_foot = round_up8(n) - n + 8;
+      const uint64_t cons2 = act && rp.c2 ? rp.c2 + pad_foot : 0;
+      const uint64_t mh1 = rp.c2 == 0 ? (pos + enc) & mask : (pay + rp.c1) & mask;
+      const uint64_t mh2 = (pos + enc) & mask;
+      const uint64_t C2 = i_enc;
+      const uint64_t C1 = C2 - cons2;
+      const uint64_t Ctot = __shfl(i_enc, 63, 64);
+      uint64_t base = 0, thr = cap / 2 - irs;
+      bool crossed = false;
+      for (;;) {
+        const uint64_t hit = __ballot(act && C2 >= thr);
+        if (hit == 0) break;
+        const int f = __builtin_ctzll(hit);
+        const uint64_t fC1 = __shfl(C1, f, 64), fC2 = __shfl(C2, f, 64);
+        const uint64_t fmh1 = __shfl(mh1, f, 64), fmh2 = __shfl(mh2, f, 64);
+        const bool first = fC1 >= thr;
+        credit_head = first ? fmh1 : fmh2;
+        base = first ? fC1 : fC2;
+        credit++;
+        crossed = true;
+        thr = base + cap / 2;
+      }
+      irs = crossed ? Ctot - base : irs + Ctot;
+      const uint32_t t_packed = __shfl(i_packed, 63, 64);
+      head = (head + Ctot) & mask;
+      mh = head;
+      consumed_total += Ctot;
+      bytes += tot_n;
+      records += cnt;
+      nslices += t_packed & 0xFFFFu;
+      nsegs += t_packed >> 16;
+      ntiles += __shfl(i_tiles, 63, 64);
+      a_off += __shfl(i_bytes, 63, 64);
+      chain_i += cnt;
+      hist_count += cnt;
+      progressed = 1;
+      return cnt;
+    };
+
+    if (op.raw_cap > 0) {
+      // grdma_pair_recv(): exactly one Recv(buf, capacity)
+      uint64_t n = recv_step((uint64_t)op.arena, op.raw_cap);
+      if (lane == 0) {
+        out_slices[0].off = 0;
+        out_slices[0].len = n;
+      }
+      nslices = n ? 1 : 0;
+      bytes = n;
+      a_off = n;
+      stop = 1;
+    } else {
+      for (;;) {
+        if (!(nslices < max_slices && nsegs + 520 <= GRDMA_MAX_SEGS)) { stop = 1; break; }
+        const bool clean = remain == 0 && leftover == 0;
+        // hand back to the bulk tier once something moved since its last miss
+        if (clean && may_bulk && (!blocked || progressed)) break;
+        if (clean && fast_chunk() > 0) { n_fast++; continue; }
+        n_scalar++;
+        // rdma_continue_read, rdma_bp_posix.cc:306-317
+        uint64_t readable = remain;
+        if (readable == 0) readable = next_ready();
+        const uint64_t alloc = leftover ? leftover : (readable > MINRD ? readable : MINRD);
+        if (a_off + alloc > op.arena_cap) { stop = 1; break; }  // receive arena exhausted
+        uint64_t total = 0;
+        // rdma_do_read loop, rdma_bp_posix.cc:195-277
+        while (total < alloc) {
+          uint64_t n = recv_step((uint64_t)(op.arena + a_off + total), alloc - total);
+          if (n == 0) break;
+          total += n;
+        }
+        if (total == 0) {  // nothing ready: notify_on_read, the slice stays allocated
+          leftover = alloc;
+          would_block = 1;
+          stop = 1;
+          break;
+        }
+        leftover = alloc - total;  // grpc_slice_buffer_trim_end -> last_read_buffer
+        if (lane == 0) {
+          out_slices[nslices].off = a_off;
+          out_slices[nslices].len = total;
+        }
+        nslices++;
+        bytes += total;
+        a_off = al16(a_off + total);
+      }
+    }
+    if (lane == 0) {
+      S.head = head; S.mh = mh; S.remain = remain; S.irs = irs; S.leftover = leftover;
+      S.nslices = nslices; S.nsegs = nsegs; S.ntiles = ntiles; S.bytes = bytes;
+      S.consumed_total = consumed_total; S.records = records; S.a_off = a_off;
+      S.would_block = would_block; S.credit = credit; S.credit_head = credit_head;
+      S.hist_count = hist_count;
+      S.stop = stop;
+      if (progressed) S.bulk_blocked = 0;
+      s_dbg[0] += n_rounds; s_dbg[1] += n_fast; s_dbg[2] += n_scalar;
+    }
+  };
+
+  // ==================================================================== driver loop
+  for (;;) {
+    if (S.stop) break;  // uniform: S is only written between barriers
+    const bool clean = S.remain == 0 && S.leftover == 0;
+    uint32_t took = 0;
+    if (S.bulk_tries > 0 && !(S.nslices + 512 <= max_slices && S.nsegs + 1024 <= GRDMA_MAX_SEGS)) {
+      __syncthreads();
+      if (tid == 0) S.bulk_tries = 0;  // no room for a bulk pass: the wave tier finishes
+      __syncthreads();
+    }
+    if (clean && S.bulk_tries > 0 && !S.bulk_blocked) {
+      took = bulk();
+      __syncthreads();
+      if (tid == 0) {
+        if (took == 0xFFFFFFFFu) S.bulk_tries = 0; else S.bulk_tries--;
+        if (took == 0) S.bulk_blocked = 1;
+        if (took != 0xFFFFFFFFu) s_dbg[3] += took;
+      }
+      if (took == 0xFFFFFFFFu) took = 0;
+      __syncthreads();
+      if (took) continue;
+    }
+    if (wave == 0) wave_tier();
+    __syncthreads();
+  }
+
+  // history back to the connection
+  __syncthreads();
+  for (unsigned i = tid; i < GRDMA_RX_HIST; i += PLAN_THREADS) c->rx_hist[i] = s_hist[i];
+  if (tid != 0) return;
+  c->rx_hist_count = S.hist_count;
+
+  const uint64_t head = S.head, mh = S.mh, nsegs = S.nsegs, nslices = S.nslices;
+  plan->nsegs = (uint32_t)nsegs;
+  plan->ntiles = (uint32_t)S.ntiles;
+  plan->tile_prefix[nsegs] = (uint32_t)S.ntiles;
+  plan->bytes = S.bytes;
+
+  c->head = head;
+  c->moving_head = mh;
+  c->remain = S.remain;
+  c->internal_read_size = S.irs;
+  c->leftover_cap = S.leftover;
+  c->total_read += S.bytes;
+  c->credit_msgs += S.credit;
+  c->rx_records += S.records;
+  if (nslices) c->rx_rounds++;
+  if (op.append) {
+    c->rx_arena_off = S.a_off;
+    c->rx_slice_idx = (op.append == 2 ? 0 : c->rx_slice_idx) + nslices;
+  }
+  c->rx_blocks_done = 0;
+  // updateStatus() (pair.cc:624-641) must not overtake the copy-out and the
+  // zero-fill of the bytes it grants: the 16-byte report is posted by the last
+  // workgroup of k_rx_apply.
+  if (S.credit) c->status_send.remote_head = S.credit_head;
+  res->credit_head = S.credit_head;
+  res->nslices = nslices;
+  res->bytes = S.bytes;
+  res->consumed = S.consumed_total;
+  res->records = S.records;
+  res->would_block = S.would_block;
+  res->credit_sent = S.credit;
+  res->head = head;
+  res->moving_head = mh;
+  res->remain = S.remain;
+  res->arena_used = S.a_off;
+  res->dbg[0] = t_begin;
+  res->dbg[1] = __builtin_amdgcn_s_memtime();
+  res->dbg[2] = s_dbg[0];
+  res->dbg[3] = s_dbg[1];
+  res->dbg[4] = s_dbg[2];
+  res->dbg[5] = s_dbg[3];
+  for (int q = 6; q < 16; q++) res->dbg[q] = s_dbg[q];
+  // consumed ring bytes are always the contiguous range [mh0, mh)
+  res->zero_off[0] = res->zero_off[1] = res->zero_len[0] = res->zero_len[1] = 0;
+  if (S.consumed_total > 0) {
+    if (mh > mh0) {
+      res->zero_off[0] = mh0;
+      res->zero_len[0] = mh - mh0;
+    } else {
+      res->zero_off[0] = mh0;
+      res->zero_len[0] = cap - mh0;
+      res->zero_off[1] = 0;
+      res->zero_len[1] = mh;
+    }
+  }
+  __threadfence_system();
+  __hip_atomic_store(&res->seq, res->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace
+
+extern "C" hipError_t grdma_launch_rx_plan(const grdma_rx_op* d_ops, uint32_t nops,
+                                           hipStream_t s) {
+  if (nops == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_rx_plan, dim3(nops), dim3(PLAN_THREADS), 0, s, d_ops);
+  return hipGetLastError();
+}

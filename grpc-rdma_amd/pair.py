@@ -135,7 +135,7 @@ class Pair:
 
     def endpoint_read(self, max_reads=1):
         """-> (list of bytes, one per endpoint_read completion, would_block)."""
-        cap = min(max_reads, 4096)
+        cap = min(max_reads, 8192)
         arr = (ReadSlice * cap)()
         wb = C.c_int(0)
         n = check(self.lib.grdma_endpoint_read(self.h, max_reads, arr, cap, C.byref(wb)))

@@ -230,3 +230,40 @@ def test_drain_many_records(gpu, R, sizes, seed, flags):
         assert _ring_eq(b.ring_mem(), o.ring_mem(1))  # unread records may differ in pad bytes only
         check_state(a, b, o)
     a.close(); b.close(); o.close()
+
+
+@pytest.mark.parametrize("pattern,R", [
+    ([9, 16384], 1 << 20),                 # period 2
+    ([14, 1000, 9, 1000, 9, 200, 9, 9], 1 << 18),  # period 8 with small-record runs
+    ([700], 1 << 16),                      # period 1
+    ([9, 300, 9, 300, 9, 255], 1 << 17),
+])
+def test_periodic_stream_bulk_tier(gpu, pattern, R):
+    """A strictly periodic record stream (what a gRPC stream of equal messages
+    looks like) sent in bursts that never split a record: after the history has
+    seen a few periods the 256-thread bulk tier takes over.  Several ring laps so
+    the wrap and the cap/2 credit rule are crossed inside bulk passes."""
+    g = gpu
+    rng = random.Random(11)
+    a, b = mk_link(g, R, 4095)
+    o = pyorc.OracleLink(R, 4095)
+    period_bytes = sum(16 + ((n + 7) & ~7) for n in pattern)
+    bufs_one = [bytes(rng.getrandbits(8) for _ in range(n)) for n in pattern]
+    dev_one = dev_slices(g, bufs_one, rng)
+    for lap in range(10):
+        reps = max(1, min(4000 // len(pattern), (R // 2 - 64) // period_bytes, o.writable(0) // period_bytes))
+        sl = bufs_one * reps
+        s_g = a.Send(dev_one * reps); s_o = o.send(0, sl)
+        assert s_g == s_o == sum(len(x) for x in sl)
+        got, wb = b.endpoint_read(8192)
+        exp = []
+        while True:
+            s, _al = o.endpoint_read(1)
+            if not s:
+                break
+            exp.append(s)
+        assert [len(x) for x in got] == [len(x) for x in exp]
+        assert got == exp
+        assert _ring_eq(b.ring_mem(), o.ring_mem(1))
+        check_state(a, b, o)
+    a.close(); b.close(); o.close()

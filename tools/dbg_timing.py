@@ -18,4 +18,4 @@ t=(C.c_uint64*16)(); rr=(C.c_uint64*16)()
 lib.grdma_stream_job_debug(job.h,t,rr)
 t=[int(x) for x in t]; rr=[int(x) for x in rr]
 print("tx stamps (memtime ticks, 100MHz => 10ns):", [t[i]-t[0] for i in range(7)], "m=",t[7])
-print("rx: total", rr[1]-rr[0], "rounds", rr[2], "fast", rr[3], "scalar", rr[4], "t_refill", rr[5], "t_fast", rr[6])
+print("rx: total", rr[1]-rr[0], "rounds", rr[2], "fast", rr[3], "scalar", rr[4], "bulk_took", rr[5], "P,H,V,pe0,pe1,pe[V],n[V],key,vmax,head", rr[6:16])
