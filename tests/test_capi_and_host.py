@@ -1,0 +1,122 @@
+"""CPU: the C-ABI library loads and exports every symbol include/grdma_amd.h
+declares; host-only logic (GRPC_PLATFORM_TYPE, GRPC_RDMA_* knobs, scalar ring
+arithmetic).  No compute call is made: there is no GPU here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import grpc_rdma_amd as g
+from grpc_rdma_amd import _lib
+from oracle import pyorc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "grdma_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(grdma_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = C.CDLL(_lib.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), "libgrdma_amd.so does not export %s" % n
+
+
+def test_python_binding_table_covers_the_core_abi(built):
+    names = set(declared_functions())
+    assert set(_lib.SIGNATURES) <= names
+    assert g.load().grdma_abi_version() == 1
+
+
+def test_no_device_fails_loudly(built):
+    lib = g.load()
+    if lib.grdma_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(g.GrdmaError, match="no HIP device"):
+        g.init(0)
+    # nothing silently works without a device
+    assert lib.grdma_pair_create(1 << 20, 30, 0) is None
+    assert b"no HIP device" in lib.grdma_last_error() or b"grdma_init" in lib.grdma_last_error()
+
+
+def test_platform_type_parsing(built):
+    lib = g.load()
+    # src/core/lib/iomgr/iomgr_internal.cc:37-62: exact strings, unset = TCP
+    assert lib.grdma_parse_platform(None) == 0
+    assert lib.grdma_parse_platform(b"TCP") == 0
+    assert lib.grdma_parse_platform(b"RDMA_BP") == 1
+    assert lib.grdma_parse_platform(b"RDMA_BPEV") == 2
+    assert lib.grdma_parse_platform(b"RDMA_EVENT") == 3
+    for bad in (b"rdma_bp", b"RDMA", b"", b"RDMA_BP ", b"TCPX"):
+        assert lib.grdma_parse_platform(bad) == -6  # the reference exit(1)s here
+
+
+def test_determine_platform_reads_env(built, monkeypatch):
+    lib = g.load()
+    monkeypatch.delenv("GRPC_PLATFORM_TYPE", raising=False)
+    assert lib.grdma_determine_platform() == 0
+    monkeypatch.setenv("GRPC_PLATFORM_TYPE", "RDMA_BPEV")
+    assert lib.grdma_determine_platform() == 2
+    monkeypatch.setenv("GRPC_PLATFORM_TYPE", "nope")
+    assert lib.grdma_determine_platform() == -6
+
+
+def test_config_defaults_and_env(built, monkeypatch):
+    lib = g.load()
+    for k in list(os.environ):
+        if k.startswith("GRPC_RDMA_"):
+            monkeypatch.delenv(k)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    cfg = _lib.Config()
+    assert lib.grdma_config_from_env(C.byref(cfg)) == 0
+    # src/core/lib/ibverbs/config.cc:45-115 defaults
+    assert (cfg.port_num, cfg.gid_index, cfg.poller_thread_num) == (1, 0, 1)
+    assert cfg.busy_polling_timeout_us == 500 and cfg.poller_sleep_timeout_ms == 1000
+    assert cfg.ring_buffer_size_kb == 4096 and cfg.zerocopy_buffer_size_kb == 32768
+    assert cfg.zerocopy_threshold_kb == 0xFFFFFFFF and cfg.max_sge == 30
+    monkeypatch.setenv("GRPC_RDMA_RING_BUFFER_SIZE_KB", "2048")
+    monkeypatch.setenv("GRPC_RDMA_BUSY_POLLING_TIMEOUT_US", "0")
+    monkeypatch.setenv("GRPC_RDMA_POLLER_THREAD_NUM", "4")
+    monkeypatch.setenv("GRPC_RDMA_DEVICE_NAME", "mlx5_1")
+    assert lib.grdma_config_from_env(C.byref(cfg)) == 0
+    assert cfg.ring_buffer_size_kb == 2048
+    assert cfg.zerocopy_buffer_size_kb == 2048  # same variable, config.cc:100-106 (Appendix A.10)
+    assert cfg.busy_polling_timeout_us == 0 and cfg.poller_thread_num == 4
+    assert cfg.device_name == b"mlx5_1"
+    monkeypatch.setenv("GRPC_RDMA_RING_BUFFER_SIZE_KB", "3000")  # not a power of two: ring_buffer.cc:22
+    assert lib.grdma_config_from_env(C.byref(cfg)) == -6
+    monkeypatch.setenv("GRPC_RDMA_RING_BUFFER_SIZE_KB", "4096")
+    monkeypatch.setenv("GRPC_RDMA_POLLER_THREAD_NUM", "0")       # GPR_ASSERT(> 0)
+    assert lib.grdma_config_from_env(C.byref(cfg)) == -6
+
+
+def test_host_ring_arithmetic_matches_oracle(built):
+    lib = C.CDLL(_lib.LIB_PATH)
+    for f in ("grdma_host_free_size", "grdma_host_writable"):
+        getattr(lib, f).restype = C.c_uint64
+        getattr(lib, f).argtypes = [C.c_uint64] * 3
+    lib.grdma_host_encoded_size.restype = C.c_uint64
+    lib.grdma_host_encoded_size.argtypes = [C.c_uint64]
+    lib.grdma_host_calc_writable.restype = C.c_uint64
+    lib.grdma_host_calc_writable.argtypes = [C.c_uint64]
+    o = pyorc.lib()
+    for v in list(range(0, 100)) + [1000, 4096, (1 << 22) - 3]:
+        assert lib.grdma_host_calc_writable(v) == o.orc_calc_writable(v)
+        if v:
+            assert lib.grdma_host_encoded_size(v) == o.orc_encoded_size(v)
+    ring = pyorc.OrcRing()
+    ring.cap, ring.mask = 4096, 4095
+    o.orc_ring_free_size.restype = C.c_uint64
+    o.orc_ring_free_size.argtypes = [C.POINTER(pyorc.OrcRing), C.c_uint64, C.c_uint64]
+    o.orc_ring_writable.restype = C.c_uint64
+    o.orc_ring_writable.argtypes = [C.POINTER(pyorc.OrcRing), C.c_uint64, C.c_uint64]
+    for head in range(0, 4096, 264):
+        for tail in range(0, 4096, 312):
+            assert lib.grdma_host_free_size(4096, head, tail) == o.orc_ring_free_size(C.byref(ring), head, tail)
+            assert lib.grdma_host_writable(4096, head, tail) == o.orc_ring_writable(C.byref(ring), head, tail)

@@ -1,0 +1,150 @@
+"""CPU: the HTTP/2 DATA framing / deframing restatement against the reference's
+own byte vectors (tests/golden/h2_bad_client.json, extracted from
+test/core/bad_client/tests/*.cc) and the constructive framing of
+test/cpp/microbenchmarks/bm_chttp2_transport.cc:504-560."""
+import json
+import os
+import random
+
+import pytest
+
+import grpc_rdma_amd  # noqa: F401  (import shim)
+from grpc_rdma_amd import h2
+from oracle import pyorc
+from oracle.pyorc import EV_FRAME, EV_MSG_BEGIN, EV_MSG_BYTES, EV_MSG_END, EV_PAYLOAD
+
+VEC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "h2_bad_client.json")))["vectors"]
+
+
+def feed_chunks(data, cuts, prefix=True):
+    """Feed `data` split at `cuts`; -> (rc, events with absolute stream offsets)."""
+    p = pyorc.H2Parser(expect_client_prefix=prefix)
+    out, base = [], 0
+    bounds = [0] + sorted(cuts) + [len(data)]
+    for a, b in zip(bounds, bounds[1:]):
+        rc, ev = p.feed(data[a:b])
+        if rc:
+            return rc, out
+        for k, x, y, z, w in ev:
+            if k in (EV_PAYLOAD, EV_MSG_BYTES):
+                out.append((k, x + a, y, z, w))
+            else:
+                out.append((k, x, y, z, w))
+    return 0, out
+
+
+def coalesce(events):
+    """Chunking-independent view of a parse: the frame / message events in order,
+    and the byte intervals handed out as frame payload and as message bytes."""
+    def merged(iv):
+        out = []
+        for a, n in sorted(iv):
+            if n == 0:
+                continue
+            if out and out[-1][0] + out[-1][1] == a:
+                out[-1] = (out[-1][0], out[-1][1] + n)
+            else:
+                out.append((a, n))
+        return out
+    control = [e for e in events if e[0] not in (EV_PAYLOAD, EV_MSG_BYTES)]
+    payload = merged([(e[1], e[2]) for e in events if e[0] == EV_PAYLOAD])
+    frame_ends = sorted(e[1] + e[2] for e in events if e[0] == EV_PAYLOAD and e[3] == 1)
+    msg = {}
+    for e in events:
+        if e[0] == EV_MSG_BYTES:
+            msg.setdefault(e[3], []).append((e[1], e[2]))
+    return control, payload, frame_ends, {k: merged(v) for k, v in msg.items()}
+
+
+@pytest.mark.parametrize("vec", VEC, ids=[v["name"] for v in VEC])
+def test_reference_vectors_parse_as_documented(vec):
+    data = bytes.fromhex(vec["hex"])
+    rc, ev = feed_chunks(data, [])
+    assert rc == 0
+    frames = [[a, b & 0xFF, c, d] for k, a, b, c, d in ev if k == EV_FRAME and a != 0xFF]
+    assert frames == vec["frames"]
+    begins = [(c, a, b) for k, a, b, c, d in ev if k == EV_MSG_BEGIN]
+    assert begins == [(m["stream"], m["compressed"], m["length"]) for m in vec["messages"]]
+    ends = [c for k, a, b, c, d in ev if k == EV_MSG_END]
+    assert ends == [m["stream"] for m in vec["messages"] if m["complete"]]
+    for m in vec["messages"]:
+        if m["complete"]:
+            body = b"".join(data[a:a + b] for k, a, b, c, d in ev if k == EV_MSG_BYTES and c == m["stream"])
+            assert body == bytes.fromhex(m["payload_byte"]) * m["length"]
+    err = vec["stream_error"]
+    if err and err["code"] == "bad_grpc_frame_type":
+        assert any(k == EV_FRAME and a == 0xFF and d == 4 and c == err["stream"] for k, a, b, c, d in ev)
+    if err and err["code"] == "data_flags":
+        assert any(k == EV_FRAME and a == 0 and (b >> 8) == 3 for k, a, b, c, d in ev)
+
+
+@pytest.mark.parametrize("vec", VEC, ids=[v["name"] for v in VEC])
+def test_every_split_point_gives_the_same_parse(vec):
+    """h2_sockpair_1byte.cc feeds chttp2 one byte at a time; the state machines
+    must be resumable at any byte (parsing.cc:56-253, frame_data.cc:92-276)."""
+    data = bytes.fromhex(vec["hex"])
+    rc0, whole = feed_chunks(data, [])
+    rc1, single = feed_chunks(data, list(range(1, len(data))))
+    assert rc0 == rc1 == 0
+    assert coalesce(single) == coalesce(whole)
+    rng = random.Random(5)
+    for _ in range(20):
+        cuts = sorted(rng.sample(range(1, len(data)), rng.randint(1, 12)))
+        rc, ev = feed_chunks(data, cuts)
+        assert rc == 0 and coalesce(ev) == coalesce(whole)
+
+
+def create_incoming_data_slice(length, frame_size):
+    """bm_chttp2_transport.cc:504-560: 5-byte message header + 'a' * length cut into
+    DATA frames of frame_size on stream 1 (the last frame holds the rest, > 0 bytes)."""
+    unframed = bytes([0]) + length.to_bytes(4, "big") + b"a" * length
+    out = bytearray()
+    while len(unframed) > frame_size:
+        out += frame_size.to_bytes(3, "big") + bytes([0, 0, 0, 0, 0, 1]) + unframed[:frame_size]
+        unframed = unframed[frame_size:]
+    out += len(unframed).to_bytes(3, "big") + bytes([0, 0, 0, 0, 0, 1]) + unframed
+    return bytes(out)
+
+
+@pytest.mark.parametrize("length", [0, 1, 4, 5, 16378, 16379, 16380, 16384, 100000, 1 << 20])
+def test_tx_framing_equals_the_reference_benchmark_framing(length):
+    msg = b"a" * length
+    wire, lens = pyorc.h2_frame_message(msg, stream_id=1, max_frame=16384)
+    assert wire == create_incoming_data_slice(length, 16384)
+    assert sum(lens) == len(wire)
+    # and it parses back to exactly that message
+    rc, ev = feed_chunks(wire, [], prefix=False)
+    assert rc == 0
+    assert [(a, b) for k, a, b, c, d in ev if k == EV_MSG_BEGIN] == [(0, length)]
+    assert b"".join(wire[a:a + b] for k, a, b, c, d in ev if k == EV_MSG_BYTES) == msg
+
+
+def test_one_mib_message_slice_list_is_the_documented_one():
+    """130 slices, N = 1 049 170, E = 1 051 712."""
+    msg = bytes(1048580)
+    wire, lens = pyorc.h2_frame_message(msg)
+    assert len(lens) == 130 and lens[0] == 14 and lens[1] == 16379 and lens[-2:] == [9, 9]
+    assert sum(lens) == 1049170
+    assert h2.ring_bytes_for(lens) == 1051712
+
+
+@pytest.mark.parametrize("M", [0, 1, 4, 5, 6, 17, 18, 19, 100, 16379, 16380, 16384, 16385, 70000])
+@pytest.mark.parametrize("F", [1, 3, 5, 9, 100, 16384])
+def test_host_layout_matches_oracle(M, F):
+    if M // F > 4000:
+        pytest.skip("too many frames for a unit test")
+    rng = random.Random(M * 31 + F)
+    msg = bytes(rng.getrandbits(8) for _ in range(M))
+    wire, lens = pyorc.h2_frame_message(msg, 7, F)
+    items = h2.frame_message(M, 7, F)
+    assert [len(i[1]) if i[0] == "inl" else i[1][1] for i in items] == lens
+    assert b"".join(i[1] if i[0] == "inl" else msg[i[1][0]:i[1][0] + i[1][1]] for i in items) == wire
+
+
+def test_oversized_frame_and_bad_prefix_are_connection_errors():
+    p = pyorc.H2Parser(expect_client_prefix=True)
+    rc, _ = p.feed(b"PRI * HTTP/2.0\r\n\r\nSM\r\n\r\nX"[:24][:-1] + b"X")
+    assert rc == 1  # connect string mismatch, parsing.cc:91-104
+    p = pyorc.H2Parser(expect_client_prefix=False, max_frame_size=16384)
+    rc, _ = p.feed((16385).to_bytes(3, "big") + bytes([0, 0, 0, 0, 0, 1]))
+    assert rc == 2  # parsing.cc:195-205
