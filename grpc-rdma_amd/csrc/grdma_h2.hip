@@ -1,0 +1,533 @@
+// HTTP/2 DATA framing (K6/K7) and deframing (K8/K9) on the device.
+//
+// TX  k_h2_frame     builds, in HBM, the slice list chttp2 hands to
+//                    grpc_endpoint_write for a batch of gRPC messages:
+//                    5-byte message header (chttp2_transport.cc:1502-1510), 9-byte
+//                    DATA frame headers (grpc_chttp2_encode_data, frame_data.cc:64-90),
+//                    payload sub-slices by reference, with the inlined-slice merge
+//                    rule of grpc_slice_buffer_add (slice_buffer.cc:136-171) and the
+//                    split rule of move_first_no_ref (slice_buffer.cc:270-313).
+//                    No payload byte is copied: K1 (k_copy) gathers straight from
+//                    the message buffers.
+// RX  k_h2_deframe   the resumable frame-header state machine of
+//                    grpc_chttp2_perform_read (parsing.cc:56-253) and the gRPC
+//                    message deframer (frame_data.cc:92-276) over the slices an
+//                    endpoint_read delivered.  Frame headers sit at data-dependent
+//                    offsets (a linked list again); one wave stages the first 32
+//                    bytes of the next 64 slices in registers so the automaton
+//                    never waits on memory for a header that starts a slice -- the
+//                    common case, because the ring preserves slice boundaries.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/grdma_amd.h"
+#include "grdma_dev.h"
+#include "grdma_devfn.h"
+
+struct grdma_h2_msg_dev {
+  const uint8_t* payload;
+  uint64_t len;
+  uint32_t stream_id;
+  uint32_t flags;  // 1 = compressed, 2 = end_stream
+};
+
+struct grdma_h2_frame_result {
+  uint64_t nslices;
+  uint64_t hdr_bytes;   // bytes of the header arena used
+  uint64_t wire_bytes;  // Σ slice lengths
+  uint64_t overflow;
+};
+
+#define H2_INLINED 23u
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+
+// grpc_chttp2_data_parser + the deframe fields of grpc_chttp2_transport, one
+// per connection, resident in HBM between calls.
+struct grdma_h2_stream_dev {
+  uint32_t stream_id;
+  int32_t state;        // 0..4 FH_0..FH_4, 5 FRAME, 6 ERROR
+  uint32_t frame_size;
+  int32_t compressed;
+};
+#define H2_MAX_STREAMS 16
+struct grdma_h2_parser_dev {
+  int32_t state;        // 0..23 client prefix, 24..32 FH_0..FH_8, 33 FRAME
+  uint32_t incoming_frame_size;
+  uint32_t incoming_frame_type;
+  uint32_t incoming_frame_flags;
+  uint32_t incoming_stream_id;
+  uint32_t max_frame_size;
+  int32_t cur_parser;   // 0 skip, 1 data
+  int32_t nstreams;
+  grdma_h2_stream_dev streams[H2_MAX_STREAMS];
+  int32_t error;        // connection error (grdma_h2_error), sticky
+  int32_t pad;
+};
+
+struct grdma_h2_deframe_result {
+  uint64_t nevents;
+  uint64_t overflow;
+  uint64_t slices_done;
+  int64_t error;
+};
+
+namespace {
+
+// ------------------------------------------------------------------ TX framing
+// Sequential layout of ONE message given the state of the slice buffer's back
+// slice (inlined length, 0 = not inlined).  emit(kind, a, b): kind 0 = inlined
+// bytes [a = source selector, b = length] appended as a new slice or merged,
+// handled by the caller through the callbacks below.
+struct frame_walk {
+  // output cursors
+  uint64_t nslices;
+  uint64_t hdr_off;
+  uint64_t wire;
+  uint32_t back_inl;  // length of the back slice if it is inlined, else 0
+};
+
+template <bool EMIT>
+__device__ __forceinline__ void add_inlined(frame_walk* w, const uint8_t* bytes, uint32_t n,
+                                            bool merge, grdma_sge* out, uint8_t* hdr, uint64_t cap,
+                                            uint64_t hdr_cap, uint64_t* overflow) {
+  // grpc_slice_buffer_add (merge) / grpc_slice_buffer_add_indexed (no merge)
+  uint32_t done = 0;
+  if (merge && w->back_inl && w->back_inl < H2_INLINED) {
+    const uint32_t room = H2_INLINED - w->back_inl;
+    const uint32_t cp = n < room ? n : room;
+    if (EMIT) {
+      // the back slice's bytes end at hdr_off (slots are packed per slice start)
+      grdma_sge* back = &out[w->nslices - 1];
+      uint8_t* dst = const_cast<uint8_t*>(back->ptr) + back->len;
+      for (uint32_t i = 0; i < cp; i++) dst[i] = bytes[i];
+      back->len += cp;
+    }
+    w->back_inl += cp;
+    done = cp;
+    w->wire += cp;
+    if (done == n) return;
+  }
+  const uint32_t rest = n - done;
+  if (w->nslices >= cap || w->hdr_off + 32 > hdr_cap) {
+    *overflow = 1;
+    return;
+  }
+  if (EMIT) {
+    uint8_t* dst = hdr + w->hdr_off;
+    for (uint32_t i = 0; i < rest; i++) dst[i] = bytes[done + i];
+    out[w->nslices].ptr = dst;
+    out[w->nslices].len = rest;
+  }
+  w->nslices++;
+  w->hdr_off += 32;  // one 32-byte slot per inlined slice (sizeof(grpc_slice))
+  w->back_inl = rest;
+  w->wire += rest;
+}
+
+template <bool EMIT>
+__device__ __forceinline__ void add_ref(frame_walk* w, const uint8_t* ptr, uint64_t n,
+                                        grdma_sge* out, uint64_t cap, uint64_t* overflow) {
+  if (w->nslices >= cap) {
+    *overflow = 1;
+    return;
+  }
+  if (EMIT) {
+    out[w->nslices].ptr = ptr;
+    out[w->nslices].len = n;
+  }
+  w->nslices++;
+  w->back_inl = 0;
+  w->wire += n;
+}
+
+template <bool EMIT>
+__device__ void walk_message(const grdma_h2_msg_dev& m, uint32_t max_frame, frame_walk* w,
+                             grdma_sge* out, uint8_t* hdr, uint64_t cap, uint64_t hdr_cap,
+                             uint64_t* overflow) {
+  uint8_t h5[5];
+  h5[0] = (m.flags & 1) ? 1 : 0;  // chttp2_transport.cc:1504-1509
+  h5[1] = (uint8_t)(m.len >> 24);
+  h5[2] = (uint8_t)(m.len >> 16);
+  h5[3] = (uint8_t)(m.len >> 8);
+  h5[4] = (uint8_t)m.len;
+  uint64_t h5_left = 5, pay_left = m.len, pay_off = 0;
+  uint64_t fcb = 5 + m.len;
+  while (fcb > 0) {
+    const uint64_t send = fcb < max_frame ? fcb : max_frame;
+    const bool last = (m.flags & 2) && send == fcb;
+    uint8_t fh[9];  // frame_data.cc:73-82
+    fh[0] = (uint8_t)(send >> 16); fh[1] = (uint8_t)(send >> 8); fh[2] = (uint8_t)send;
+    fh[3] = 0; fh[4] = last ? 1 : 0;
+    fh[5] = (uint8_t)(m.stream_id >> 24); fh[6] = (uint8_t)(m.stream_id >> 16);
+    fh[7] = (uint8_t)(m.stream_id >> 8); fh[8] = (uint8_t)m.stream_id;
+    add_inlined<EMIT>(w, fh, 9, true, out, hdr, cap, hdr_cap, overflow);
+    uint64_t n = send;
+    const bool whole = (fcb == n);  // grpc_slice_buffer_move_into: every slice via add()
+    if (h5_left > 0) {
+      const uint64_t take = n < h5_left ? n : h5_left;
+      // n >= slice_len (or the final move_into): merged add; n < slice_len: split,
+      // the head goes in un-merged (add_indexed)
+      const bool merge = whole || n >= h5_left;
+      add_inlined<EMIT>(w, h5 + (5 - h5_left), (uint32_t)take, merge, out, hdr, cap, hdr_cap, overflow);
+      h5_left -= take;
+      n -= take;
+    }
+    if (n > 0) {
+      add_ref<EMIT>(w, m.payload + pay_off, n, out, cap, overflow);
+      pay_off += n;
+      pay_left -= n;
+    }
+    fcb -= send;
+  }
+  (void)pay_left;
+}
+
+// One thread lays out one message.  A message that ends with an inlined slice
+// (only an empty message does) lets the next header merge into it, so a thread
+// first replays the run of empty messages in front of it to learn the state of
+// the back slice.
+__global__ __launch_bounds__(256) void k_h2_frame(const grdma_h2_msg_dev* msgs, uint64_t nmsgs,
+                                                  uint32_t max_frame, grdma_sge* out,
+                                                  uint64_t cap, uint8_t* hdr, uint64_t hdr_cap,
+                                                  uint64_t* counts /* 3*nmsgs scratch */,
+                                                  grdma_h2_frame_result* res) {
+  __shared__ uint64_t s_wave[4];
+  const uint64_t tid = threadIdx.x;
+  uint64_t overflow = 0;
+  // pass 1: sizes (serial over blocks of 256 messages; one block is launched)
+  uint64_t base_sl = 0, base_hdr = 0, base_wire = 0;
+  for (uint64_t m0 = 0; m0 < nmsgs; m0 += 256) {
+    const uint64_t i = m0 + tid;
+    frame_walk w = {0, 0, 0, 0};
+    uint64_t merged_into_prev = 0;
+    if (i < nmsgs) {
+      // incoming back-slice state
+      uint64_t j = i;
+      while (j > 0 && msgs[j - 1].len == 0) j--;
+      frame_walk pre = {0, 0, 0, 0};
+      for (; j < i; j++) walk_message<false>(msgs[j], max_frame, &pre, nullptr, nullptr, ~0ull, ~0ull, &overflow);
+      frame_walk me = {0, 0, 0, pre.back_inl};
+      walk_message<false>(msgs[i], max_frame, &me, nullptr, nullptr, ~0ull, ~0ull, &overflow);
+      w = me;
+      merged_into_prev = pre.back_inl;
+    }
+    uint64_t tot_sl, tot_hdr, tot_wire;
+    const uint64_t x_sl = block_excl_scan(w.nslices, s_wave, &tot_sl);
+    const uint64_t x_hdr = block_excl_scan(w.hdr_off, s_wave, &tot_hdr);
+    block_excl_scan(w.wire, s_wave, &tot_wire);
+    if (i < nmsgs && (i == 0 || msgs[i - 1].len != 0)) {
+      // pass 2: emit at the exact position.  A run of empty messages shares
+      // inlined slices across message boundaries, so the first message of such
+      // a run emits the whole run (sequentially, like the reference would).
+      frame_walk me = {base_sl + x_sl, base_hdr + x_hdr, 0, 0};
+      uint64_t k = i;
+      for (;;) {
+        walk_message<true>(msgs[k], max_frame, &me, out, hdr, cap, hdr_cap, &overflow);
+        if (msgs[k].len != 0 || k + 1 >= nmsgs) break;
+        k++;
+      }
+    }
+    base_sl += tot_sl;
+    base_hdr += tot_hdr;
+    base_wire += tot_wire;
+    __syncthreads();
+  }
+  (void)counts;
+  if (overflow) atomicExch((unsigned long long*)&res->overflow, 1ull);
+  if (tid == 0) {
+    res->nslices = base_sl;
+    res->hdr_bytes = base_hdr;
+    res->wire_bytes = base_wire;
+  }
+}
+
+// ---------------------------------------------------------------- RX deframing
+enum { EV_FRAME = 1, EV_PAYLOAD = 2, EV_MSG_BEGIN = 3, EV_MSG_BYTES = 4, EV_MSG_END = 5 };
+enum { ST_FH0 = 24, ST_FRAME = 33 };
+
+__device__ __forceinline__ grdma_h2_stream_dev* find_stream(grdma_h2_parser_dev* p, uint32_t id) {
+  for (int i = 0; i < p->nstreams; i++)
+    if (p->streams[i].stream_id == id) return &p->streams[i];
+  if (id == 0 || p->nstreams >= H2_MAX_STREAMS) return nullptr;
+  grdma_h2_stream_dev* d = &p->streams[p->nstreams++];
+  d->stream_id = id;
+  d->state = 0;
+  d->frame_size = 0;
+  d->compressed = 0;
+  return d;
+}
+
+__global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, const uint8_t* arena,
+                                                   const grdma_slice_out* slices, uint64_t nslices,
+                                                   grdma_h2_event* ev, uint64_t ev_cap,
+                                                   grdma_h2_deframe_result* res) {
+  const int lane = threadIdx.x;
+  __shared__ grdma_h2_parser_dev P;
+  if (lane == 0) P = *gp;
+  __syncthreads();
+  uint64_t nev = 0, overflow = 0;
+  static const char kPrefix[] = "PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n";  // internal.h:781
+
+  auto push = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t sl) {
+    if (nev >= ev_cap) {
+      overflow = 1;
+      return;
+    }
+    if (lane == 0) {
+      ev[nev].kind = kind; ev[nev].a = a; ev[nev].b = b; ev[nev].c = c; ev[nev].d = d;
+      ev[nev].slice = sl;
+    }
+    nev++;
+  };
+
+  // register cache: the first 32 bytes of slices [cbase, cbase + 64)
+  uint64_t cbase = ~0ull;
+  uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  auto byte_at = [&](uint64_t s, uint64_t off) -> uint32_t {
+    if (off < 32) {
+      if (s < cbase || s >= cbase + 64) {
+        cbase = s;
+        const uint64_t mine = s + lane;
+        c0 = c1 = c2 = c3 = 0;
+        if (mine < nslices) {
+          const uint8_t* p = arena + slices[mine].off;
+          const uint64_t n = slices[mine].len;
+          if (((uint64_t)p & 15) == 0) {
+            // aligned 16-byte words that start inside the slice; the tail of the
+            // last word stays inside its own 16-byte block
+            const u64x2* q = reinterpret_cast<const u64x2*>(p);
+            if (n > 0) { u64x2 v = q[0]; c0 = v.x; c1 = v.y; }
+            if (n > 16) { u64x2 v = q[1]; c2 = v.x; c3 = v.y; }
+          } else {
+            uint8_t tmp[32];
+            for (int i = 0; i < 32; i++) tmp[i] = (uint64_t)i < n ? p[i] : 0;
+            memcpy(&c0, tmp, 8); memcpy(&c1, tmp + 8, 8); memcpy(&c2, tmp + 16, 8); memcpy(&c3, tmp + 24, 8);
+          }
+        }
+      }
+      const int src = (int)(s - cbase);
+      const uint64_t q = off >> 3;
+      const uint64_t word = __shfl(q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3, src, 64);
+      return (uint32_t)((word >> ((off & 7) * 8)) & 0xFF);
+    }
+    return arena[slices[s].off + off];
+  };
+
+  uint64_t s = 0;
+  int err = P.error;
+  for (; s < nslices && !err && !overflow; s++) {
+    const uint64_t len = slices[s].len;
+    uint64_t cur = 0;
+    while (cur < len && !err && !overflow) {
+      if (P.state < ST_FH0) {  // client connection preface, parsing.cc:70-109
+        if (byte_at(s, cur) != (uint8_t)kPrefix[P.state]) { err = 1; break; }
+        cur++; P.state++;
+        continue;
+      }
+      if (P.state < ST_FRAME) {
+        const uint32_t c = byte_at(s, cur);
+        switch (P.state) {
+          case 24: P.incoming_frame_size = c << 16; break;
+          case 25: P.incoming_frame_size |= c << 8; break;
+          case 26: P.incoming_frame_size |= c; break;
+          case 27: P.incoming_frame_type = c; break;
+          case 28: P.incoming_frame_flags = c; break;
+          case 29: P.incoming_stream_id = (c & 0x7f) << 24; break;
+          case 30: P.incoming_stream_id |= c << 16; break;
+          case 31: P.incoming_stream_id |= c << 8; break;
+          case 32: P.incoming_stream_id |= c; break;
+        }
+        cur++;
+        if (P.state < 32) { P.state++; continue; }
+        // FH_8 done: init_frame_parser (parsing.cc:255-308), DATA branch :340-397
+        uint32_t status = 0;
+        P.cur_parser = 0;
+        if (P.incoming_frame_type == 0) {
+          grdma_h2_stream_dev* d = find_stream(&P, P.incoming_stream_id);
+          if (d != nullptr) {
+            if (P.incoming_frame_flags & ~1u) status = 3;  // frame_data.cc:47-52
+            else P.cur_parser = 1;
+          }
+        }
+        push(EV_FRAME, P.incoming_frame_type, P.incoming_frame_flags | (status << 8),
+             P.incoming_stream_id, P.incoming_frame_size, (uint32_t)s);
+        if (P.incoming_frame_size == 0) {
+          push(EV_PAYLOAD, (uint32_t)cur, 0, 1, 0, (uint32_t)s);
+          P.state = ST_FH0;
+        } else if (P.incoming_frame_size > P.max_frame_size) {
+          err = 2;  // parsing.cc:195-205
+        } else {
+          P.state = ST_FRAME;
+        }
+        continue;
+      }
+      // FRAME: parsing.cc:215-250
+      const uint64_t avail = len - cur;
+      const uint64_t take = avail < P.incoming_frame_size ? avail : P.incoming_frame_size;
+      const uint32_t is_last = take == P.incoming_frame_size;
+      push(EV_PAYLOAD, (uint32_t)cur, (uint32_t)take, is_last, 0, (uint32_t)s);
+      if (P.cur_parser == 1) {
+        // grpc_deframe_unprocessed_incoming_frames, frame_data.cc:92-276
+        grdma_h2_stream_dev* d = find_stream(&P, P.incoming_stream_id);
+        uint64_t q = cur;
+        const uint64_t end = cur + take;
+        while (q < end && d->state != 6 && !overflow) {
+          if (d->state < 5) {
+            const uint32_t c = byte_at(s, q);
+            if (d->state == 0) {
+              if (c > 1) {  // "Bad GRPC frame type", frame_data.cc:123-140: stream error
+                d->state = 6;
+                push(EV_FRAME, 0xff, 0, P.incoming_stream_id, 4, (uint32_t)s);
+                break;
+              }
+              d->compressed = (int32_t)c;
+              d->state = 1;
+            } else if (d->state == 1) { d->frame_size = c << 24; d->state = 2; }
+            else if (d->state == 2) { d->frame_size |= c << 16; d->state = 3; }
+            else if (d->state == 3) { d->frame_size |= c << 8; d->state = 4; }
+            else {
+              d->frame_size |= c;
+              push(EV_MSG_BEGIN, (uint32_t)d->compressed, d->frame_size, d->stream_id, 0, (uint32_t)s);
+              if (d->frame_size == 0) {
+                push(EV_MSG_END, 0, 0, d->stream_id, 0, (uint32_t)s);
+                d->state = 0;
+              } else {
+                d->state = 5;
+              }
+            }
+            q++;
+          } else {
+            const uint64_t rem = end - q;
+            const uint64_t tk = rem < d->frame_size ? rem : d->frame_size;
+            push(EV_MSG_BYTES, (uint32_t)q, (uint32_t)tk, d->stream_id, 0, (uint32_t)s);
+            d->frame_size -= (uint32_t)tk;
+            q += tk;
+            if (d->frame_size == 0) {
+              push(EV_MSG_END, 0, 0, d->stream_id, 0, (uint32_t)s);
+              d->state = 0;
+            }
+          }
+        }
+      }
+      P.incoming_frame_size -= (uint32_t)take;
+      cur += take;
+      if (is_last) P.state = ST_FH0;
+    }
+    if (err || overflow) break;
+  }
+  if (lane == 0) {
+    P.error = err;
+    *gp = P;
+    res->nevents = nev;
+    res->overflow = overflow;
+    res->slices_done = s;
+    res->error = err;
+  }
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------- host API
+struct grdma_h2_parser {
+  grdma_h2_parser_dev* d = nullptr;
+};
+
+extern "C" {
+
+const char* grdma_last_error(void);
+
+int64_t grdma_h2_frame_messages(const grdma_h2_msg* msgs, uint64_t n, uint32_t max_frame,
+                                grdma_slice* d_slices_out, uint64_t slices_cap,
+                                void* d_hdr_arena, uint64_t hdr_cap, uint64_t* wire_bytes) {
+  if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
+  if (!msgs || !n || !d_slices_out || !d_hdr_arena || max_frame == 0 || max_frame >= (1u << 24))
+    return -GRDMA_ERR_INVALID;
+  std::vector<grdma_h2_msg_dev> tmp(n);
+  for (uint64_t i = 0; i < n; i++) {
+    tmp[i].payload = static_cast<const uint8_t*>(msgs[i].payload);
+    tmp[i].len = msgs[i].len;
+    tmp[i].stream_id = msgs[i].stream_id;
+    tmp[i].flags = msgs[i].flags;
+    if (msgs[i].len >= (1ull << 32)) return -GRDMA_ERR_INVALID;  // 32-bit message length field
+  }
+  grdma_h2_msg_dev* d_msgs = nullptr;
+  grdma_h2_frame_result* d_res = nullptr;
+  grdma_h2_frame_result h_res;
+  int64_t rc = -GRDMA_ERR_HIP;
+  if (hipMalloc((void**)&d_msgs, sizeof(grdma_h2_msg_dev) * n) == hipSuccess &&
+      hipMalloc((void**)&d_res, sizeof(grdma_h2_frame_result)) == hipSuccess &&
+      hipMemcpy(d_msgs, tmp.data(), sizeof(grdma_h2_msg_dev) * n, hipMemcpyHostToDevice) == hipSuccess &&
+      hipMemset(d_res, 0, sizeof(grdma_h2_frame_result)) == hipSuccess) {
+    hipLaunchKernelGGL(k_h2_frame, dim3(1), dim3(256), 0, 0, d_msgs, n, max_frame,
+                       reinterpret_cast<grdma_sge*>(d_slices_out), slices_cap,
+                       static_cast<uint8_t*>(d_hdr_arena), hdr_cap, (uint64_t*)nullptr, d_res);
+    if (hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(&h_res, d_res, sizeof(h_res), hipMemcpyDeviceToHost) == hipSuccess) {
+      if (h_res.overflow) rc = -GRDMA_ERR_CAPACITY;
+      else {
+        rc = (int64_t)h_res.nslices;
+        if (wire_bytes) *wire_bytes = h_res.wire_bytes;
+      }
+    }
+  }
+  hipFree(d_msgs);
+  hipFree(d_res);
+  return rc;
+}
+
+grdma_h2_parser* grdma_h2_parser_create(int expect_client_prefix, uint32_t max_frame_size) {
+  if (grdma_device_count() <= 0) return nullptr;
+  grdma_h2_parser* p = new grdma_h2_parser();
+  grdma_h2_parser_dev init;
+  memset(&init, 0, sizeof(init));
+  init.state = expect_client_prefix ? 0 : 24;
+  init.max_frame_size = max_frame_size;  // http2_settings.cc:56 default 16384
+  if (hipMalloc((void**)&p->d, sizeof(init)) != hipSuccess ||
+      hipMemcpy(p->d, &init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) {
+    delete p;
+    return nullptr;
+  }
+  return p;
+}
+
+void grdma_h2_parser_destroy(grdma_h2_parser* p) {
+  if (!p) return;
+  hipFree(p->d);
+  delete p;
+}
+
+int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_read_slice* slices,
+                         uint64_t n, grdma_h2_event* events_out, uint64_t cap, int* h2_error) {
+  if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
+  if (!p || !d_arena || (!slices && n) || !events_out) return -GRDMA_ERR_INVALID;
+  grdma_slice_out* d_sl = nullptr;
+  grdma_h2_event* d_ev = nullptr;
+  grdma_h2_deframe_result* d_res = nullptr;
+  grdma_h2_deframe_result h_res;
+  memset(&h_res, 0, sizeof(h_res));
+  int64_t rc = -GRDMA_ERR_HIP;
+  static_assert(sizeof(grdma_read_slice) == sizeof(grdma_slice_out), "layout");
+  if (hipMalloc((void**)&d_sl, sizeof(grdma_slice_out) * (n ? n : 1)) == hipSuccess &&
+      hipMalloc((void**)&d_ev, sizeof(grdma_h2_event) * (cap ? cap : 1)) == hipSuccess &&
+      hipMalloc((void**)&d_res, sizeof(h_res)) == hipSuccess &&
+      (n == 0 || hipMemcpy(d_sl, slices, sizeof(grdma_slice_out) * n, hipMemcpyHostToDevice) == hipSuccess)) {
+    hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(64), 0, 0, p->d,
+                       static_cast<const uint8_t*>(d_arena), d_sl, n, d_ev, cap, d_res);
+    if (hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(&h_res, d_res, sizeof(h_res), hipMemcpyDeviceToHost) == hipSuccess) {
+      const uint64_t m = h_res.nevents < cap ? h_res.nevents : cap;
+      if (m == 0 || hipMemcpy(events_out, d_ev, sizeof(grdma_h2_event) * m, hipMemcpyDeviceToHost) == hipSuccess)
+        rc = h_res.overflow ? -GRDMA_ERR_CAPACITY : (int64_t)m;
+      if (h2_error) *h2_error = (int)h_res.error;
+    }
+  }
+  hipFree(d_sl);
+  hipFree(d_ev);
+  hipFree(d_res);
+  return rc;
+}
+
+}  // extern "C"

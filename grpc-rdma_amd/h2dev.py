@@ -1,0 +1,73 @@
+"""Device-side HTTP/2 DATA framing / deframing (grdma_h2_*), thin ctypes wrappers."""
+import ctypes as C
+
+from ._lib import GrdmaError, ReadSlice, Slice, check, load
+
+u64 = C.c_uint64
+
+
+class H2Msg(C.Structure):
+    _fields_ = [("payload", C.c_void_p), ("len", u64), ("stream_id", C.c_uint32),
+                ("flags", C.c_uint32)]
+
+
+class H2Event(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("kind", "a", "b", "c", "d", "slice")]
+
+
+_bound = False
+
+
+def _bind():
+    global _bound
+    lib = load()
+    if not _bound:
+        lib.grdma_h2_frame_messages.restype = C.c_int64
+        lib.grdma_h2_frame_messages.argtypes = [C.POINTER(H2Msg), u64, C.c_uint32, C.c_void_p, u64,
+                                                C.c_void_p, u64, C.POINTER(u64)]
+        lib.grdma_h2_parser_create.restype = C.c_void_p
+        lib.grdma_h2_parser_create.argtypes = [C.c_int, C.c_uint32]
+        lib.grdma_h2_parser_destroy.argtypes = [C.c_void_p]
+        lib.grdma_h2_deframe.restype = C.c_int64
+        lib.grdma_h2_deframe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ReadSlice), u64,
+                                         C.POINTER(H2Event), u64, C.POINTER(C.c_int)]
+        _bound = True
+    return lib
+
+
+def frame_messages(msgs, max_frame, slices_dev_ptr, slices_cap, hdr_dev_ptr, hdr_cap):
+    """msgs: list of (payload device ptr, len, stream_id, flags). -> (nslices, wire_bytes)."""
+    lib = _bind()
+    arr = (H2Msg * len(msgs))()
+    for i, (p, n, sid, fl) in enumerate(msgs):
+        arr[i].payload, arr[i].len, arr[i].stream_id, arr[i].flags = p, n, sid, fl
+    wire = u64(0)
+    n = check(lib.grdma_h2_frame_messages(arr, len(msgs), max_frame, slices_dev_ptr, slices_cap,
+                                          hdr_dev_ptr, hdr_cap, C.byref(wire)))
+    return n, wire.value
+
+
+class Parser:
+    def __init__(self, expect_client_prefix=False, max_frame_size=16384):
+        self.lib = _bind()
+        self.h = self.lib.grdma_h2_parser_create(int(expect_client_prefix), max_frame_size)
+        if not self.h:
+            raise GrdmaError("h2 parser allocation failed")
+
+    def deframe(self, arena_dev_ptr, slices, cap=None):
+        """slices: list of (offset, len) in the arena. -> (h2 error, events)"""
+        n = len(slices)
+        arr = (ReadSlice * max(1, n))()
+        for i, (o, l) in enumerate(slices):
+            arr[i].off, arr[i].len = o, l
+        cap = cap or (sum(l for _, l in slices) * 2 + 64 if n else 64)
+        cap = min(cap, 1 << 20)
+        ev = (H2Event * cap)()
+        err = C.c_int(0)
+        m = check(self.lib.grdma_h2_deframe(self.h, arena_dev_ptr, arr, n, ev, cap, C.byref(err)))
+        return err.value, [(e.kind, e.a, e.b, e.c, e.d, e.slice) for e in ev[:m]]
+
+    def close(self):
+        if self.h:
+            self.lib.grdma_h2_parser_destroy(self.h)
+            self.h = None

@@ -190,6 +190,43 @@ int grdma_stream_job_sync(grdma_stream_job* j);
 int grdma_stream_job_slices(grdma_stream_job* j, grdma_read_slice* out, uint64_t cap);
 int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds);
 
+/* ---- HTTP/2 DATA framing / deframing on the device --------------------------------- */
+typedef struct grdma_h2_msg {     /* one gRPC message queued on a stream              */
+  const void* payload;            /* serialized message bytes (device-accessible)     */
+  uint64_t len;
+  uint32_t stream_id;
+  uint32_t flags;                 /* 1 = compressed (GRPC_WRITE_INTERNAL_COMPRESS), 2 = END_STREAM */
+} grdma_h2_msg;
+/* The 5-byte message header (chttp2_transport.cc:1502-1510) + grpc_chttp2_encode_data
+ * (frame_data.cc:64-90) for a batch of messages, each sent alone on its stream with
+ * open flow-control windows: writes into device memory the slice list
+ * grpc_endpoint_write would receive (9-byte frame headers and the 5-byte message
+ * header as inlined slices in d_hdr_arena, 32 bytes per slice; payload by
+ * reference).  Returns the slice count. */
+int64_t grdma_h2_frame_messages(const grdma_h2_msg* msgs, uint64_t n, uint32_t max_frame,
+                                grdma_slice* d_slices_out, uint64_t slices_cap,
+                                void* d_hdr_arena, uint64_t hdr_cap, uint64_t* wire_bytes);
+
+typedef struct grdma_h2_event {   /* what the deframer saw, in order                  */
+  uint32_t kind;                  /* 1 FRAME 2 PAYLOAD 3 MSG_BEGIN 4 MSG_BYTES 5 MSG_END */
+  uint32_t a, b, c, d;            /* FRAME: type, flags|status<<8, stream, size         */
+                                  /* PAYLOAD: offset in slice, length, is_last          */
+                                  /* MSG_BEGIN: compressed, length, stream              */
+                                  /* MSG_BYTES: offset in slice, length, stream         */
+  uint32_t slice;                 /* index of the delivered slice                       */
+} grdma_h2_event;
+enum grdma_h2_error { GRDMA_H2_OK = 0, GRDMA_H2_ERR_PREFIX = 1, GRDMA_H2_ERR_FRAME_TOO_LARGE = 2 };
+typedef struct grdma_h2_parser grdma_h2_parser;
+/* deframe state of one transport (grpc_chttp2_transport deframe_state & co.,
+ * internal.h; per-stream grpc_chttp2_data_parser), kept in device memory */
+grdma_h2_parser* grdma_h2_parser_create(int expect_client_prefix, uint32_t max_frame_size);
+void grdma_h2_parser_destroy(grdma_h2_parser* p);
+/* grpc_chttp2_perform_read (parsing.cc:56-253) + grpc_deframe_unprocessed_incoming_frames
+ * (frame_data.cc:92-276) over n delivered slices {offset, length} of d_arena.
+ * Returns the number of events; *h2_error = connection error, if any. */
+int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_read_slice* slices,
+                         uint64_t n, grdma_h2_event* events_out, uint64_t cap, int* h2_error);
+
 /* ---- device helpers for callers that keep payloads in HBM ---------------------- */
 void* grdma_device_alloc(uint64_t bytes);
 void grdma_device_free(void* p);

@@ -351,21 +351,17 @@ static void sb_add(sbuf* sb, uint64_t len, int inlined) {
   sb_add_indexed(sb, len, inlined);
 }
 
-int64_t orc_h2_frame_message(const uint8_t* msg, uint64_t msg_len, int compressed,
-                             uint32_t stream_id, uint32_t max_frame, int end_stream,
-                             uint8_t* wire, uint64_t wire_cap, uint64_t* wire_len,
-                             uint64_t* lens, uint64_t lens_cap) {
+/* One message appended to an existing slice buffer `out` / wire image. */
+static int frame_one(sbuf* out, const uint8_t* msg, uint64_t msg_len, int compressed,
+                     uint32_t stream_id, uint32_t max_frame, int end_stream, uint8_t* wire,
+                     uint64_t wire_cap, uint64_t* wpos) {
   /* flow_controlled_buffer after perform_stream_op_locked: [inlined 5][msg] */
   struct { uint64_t len; int inl; } fcb[2];
   int fcb_n = 0, fcb_i = 0;
   fcb[fcb_n].len = 5; fcb[fcb_n].inl = 1; fcb_n++;
   if (msg_len > 0) { fcb[fcb_n].len = msg_len; fcb[fcb_n].inl = 0; fcb_n++; }
   uint64_t fcb_len = 5 + msg_len;
-
-  uint8_t* inl = (uint8_t*)malloc(lens_cap ? lens_cap : 1);
-  if (!inl) return -1;
-  sbuf out = {lens, inl, 0, lens_cap, 0};
-  uint64_t w = 0, src_off = 0; /* src_off: bytes of [hdr5|msg] already moved */
+  uint64_t w = *wpos, src_off = 0; /* src_off: bytes of [hdr5|msg] already moved */
   uint8_t hdr5[5];
   orc_grpc_msg_header(hdr5, compressed, (uint32_t)msg_len);
 
@@ -374,11 +370,10 @@ int64_t orc_h2_frame_message(const uint8_t* msg, uint64_t msg_len, int compresse
      * assumed open: flow control is out of scope) */
     uint64_t send = fcb_len < max_frame ? fcb_len : max_frame;
     int is_last = end_stream && send == fcb_len;
-    if (w + 9 + send > wire_cap) { free(inl); return -1; }
+    if (w + 9 + send > wire_cap) return -1;
     orc_h2_data_header(wire + w, (uint32_t)send, is_last, stream_id);
     w += 9;
-    sb_add(&out, 9, 1); /* GRPC_SLICE_MALLOC(9) is an inlined slice */
-    /* bytes */
+    sb_add(out, 9, 1); /* GRPC_SLICE_MALLOC(9) is an inlined slice */
     for (uint64_t i = 0; i < send; i++) {
       uint64_t o = src_off + i;
       wire[w + i] = o < 5 ? hdr5[o] : msg[o - 5];
@@ -387,21 +382,21 @@ int64_t orc_h2_frame_message(const uint8_t* msg, uint64_t msg_len, int compresse
     src_off += send;
     /* grpc_slice_buffer_move_first_no_ref(inbuf, send, outbuf), slice_buffer.cc:270-313 */
     uint64_t n = send;
-    if (fcb_len == n) { /* move_into → grpc_slice_buffer_add for each slice */
-      for (; fcb_i < fcb_n; fcb_i++) sb_add(&out, fcb[fcb_i].len, fcb[fcb_i].inl);
+    if (fcb_len == n) { /* move_into -> grpc_slice_buffer_add for each slice */
+      for (; fcb_i < fcb_n; fcb_i++) sb_add(out, fcb[fcb_i].len, fcb[fcb_i].inl);
     } else {
       while (fcb_i < fcb_n) {
         uint64_t sl = fcb[fcb_i].len;
         if (n > sl) {
-          sb_add(&out, sl, fcb[fcb_i].inl);
+          sb_add(out, sl, fcb[fcb_i].inl);
           n -= sl;
           fcb_i++;
         } else if (n == sl) {
-          sb_add(&out, sl, fcb[fcb_i].inl);
+          sb_add(out, sl, fcb[fcb_i].inl);
           fcb_i++;
           break;
         } else { /* split: head goes in un-merged (add_indexed), tail stays */
-          sb_add_indexed(&out, n, fcb[fcb_i].inl);
+          sb_add_indexed(out, n, fcb[fcb_i].inl);
           fcb[fcb_i].len = sl - n;
           break;
         }
@@ -409,8 +404,44 @@ int64_t orc_h2_frame_message(const uint8_t* msg, uint64_t msg_len, int compresse
     }
     fcb_len -= send;
   }
+  *wpos = w;
+  return out->overflow ? -1 : 0;
+}
+
+int64_t orc_h2_frame_message(const uint8_t* msg, uint64_t msg_len, int compressed,
+                             uint32_t stream_id, uint32_t max_frame, int end_stream,
+                             uint8_t* wire, uint64_t wire_cap, uint64_t* wire_len,
+                             uint64_t* lens, uint64_t lens_cap) {
+  uint8_t* inl = (uint8_t*)malloc(lens_cap ? lens_cap : 1);
+  if (!inl) return -1;
+  sbuf out = {lens, inl, 0, lens_cap, 0};
+  uint64_t w = 0;
+  int rc = frame_one(&out, msg, msg_len, compressed, stream_id, max_frame, end_stream, wire,
+                     wire_cap, &w);
   free(inl);
-  if (out.overflow) return -1;
+  if (rc) return -1;
+  *wire_len = w;
+  return (int64_t)out.count;
+}
+
+int64_t orc_h2_frame_batch(const uint8_t* const* msgs, const uint64_t* msg_lens,
+                           const uint32_t* stream_ids, const uint32_t* flags, uint64_t n,
+                           uint32_t max_frame, uint8_t* wire, uint64_t wire_cap,
+                           uint64_t* wire_len, uint64_t* lens, uint64_t lens_cap) {
+  /* several messages queued on one t->outbuf: the inlined-slice merge rule of
+   * grpc_slice_buffer_add applies across message boundaries too */
+  uint8_t* inl = (uint8_t*)malloc(lens_cap ? lens_cap : 1);
+  if (!inl) return -1;
+  sbuf out = {lens, inl, 0, lens_cap, 0};
+  uint64_t w = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    if (frame_one(&out, msgs[i], msg_lens[i], flags[i] & 1, stream_ids[i], max_frame,
+                  (flags[i] >> 1) & 1, wire, wire_cap, &w)) {
+      free(inl);
+      return -1;
+    }
+  }
+  free(inl);
   *wire_len = w;
   return (int64_t)out.count;
 }

@@ -133,6 +133,13 @@ int64_t orc_h2_frame_message(const uint8_t* msg, uint64_t msg_len, int compresse
                              uint8_t* wire, uint64_t wire_cap, uint64_t* wire_len,
                              uint64_t* lens, uint64_t lens_cap);
 
+/* Same for n messages queued back to back on one outbuf (flags: 1 compressed,
+ * 2 END_STREAM). */
+int64_t orc_h2_frame_batch(const uint8_t* const* msgs, const uint64_t* msg_lens,
+                           const uint32_t* stream_ids, const uint32_t* flags, uint64_t n,
+                           uint32_t max_frame, uint8_t* wire, uint64_t wire_cap,
+                           uint64_t* wire_len, uint64_t* lens, uint64_t lens_cap);
+
 /* ------------------------------------------------------------ HTTP/2 RX -- */
 enum {
   ORC_EV_FRAME = 1,     /* a = type, b = flags, c = stream id, d = frame size      */

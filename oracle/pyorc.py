@@ -104,6 +104,10 @@ def _lib():
     lib.orc_h2_frame_message.restype = C.c_int64
     lib.orc_h2_frame_message.argtypes = [C.c_char_p, u64, C.c_int, C.c_uint32, C.c_uint32,
                                          C.c_int, C.c_void_p, u64, u64p, u64p, u64]
+    lib.orc_h2_frame_batch.restype = C.c_int64
+    lib.orc_h2_frame_batch.argtypes = [C.POINTER(C.c_char_p), u64p, C.POINTER(C.c_uint32),
+                                       C.POINTER(C.c_uint32), u64, C.c_uint32, C.c_void_p, u64,
+                                       u64p, u64p, u64]
     lib.orc_h2_parser_init.argtypes = [C.POINTER(OrcParser), C.c_int, C.c_uint32]
     lib.orc_h2_parser_feed.argtypes = [C.POINTER(OrcParser), C.c_char_p, u64,
                                        C.POINTER(OrcEvent), u64, u64p]
@@ -337,6 +341,26 @@ def h2_frame_message(msg, stream_id=1, max_frame=16384, compressed=0, end_stream
     wl = u64(0)
     cnt = l.orc_h2_frame_message(bytes(msg), n, compressed, stream_id, max_frame, end_stream,
                                  wire, wire_cap, C.byref(wl), lens, len(lens))
+    assert cnt >= 0
+    return wire.raw[:wl.value], [int(lens[i]) for i in range(cnt)]
+
+
+def h2_frame_batch(msgs, stream_ids, flags, max_frame=16384):
+    """-> (wire bytes, slice lengths) for messages queued back to back on one outbuf."""
+    l = lib()
+    n = len(msgs)
+    ptrs = (C.c_char_p * n)(*[bytes(m) for m in msgs])
+    lens_in = (u64 * n)(*[len(m) for m in msgs])
+    sids = (C.c_uint32 * n)(*stream_ids)
+    fl = (C.c_uint32 * n)(*flags)
+    total = sum(len(m) for m in msgs)
+    frames = sum((len(m) + 5 + max_frame - 1) // max_frame + 1 for m in msgs)
+    wire_cap = total + 5 * n + 9 * frames + 64
+    wire = C.create_string_buffer(wire_cap)
+    lens = (u64 * (3 * frames + 8))()
+    wl = u64(0)
+    cnt = l.orc_h2_frame_batch(ptrs, lens_in, sids, fl, n, max_frame, wire, wire_cap, C.byref(wl),
+                               lens, len(lens))
     assert cnt >= 0
     return wire.raw[:wl.value], [int(lens[i]) for i in range(cnt)]
 
