@@ -101,7 +101,7 @@ def cpu_baseline(wl, ring, max_sge, target_s=12.0):
     lens = wl.lens[:wl.slices_per_msg]
     n, sec = pyorc.stream_baseline(ring, max_sge, wire, lens, 32)
     per_msg = sec / 32
-    n_msgs = max(32, min(20000, int(target_s / per_msg)))
+    n_msgs = max(32, min(400000, int(target_s / per_msg)))
     n, sec = pyorc.stream_baseline(ring, max_sge, wire, lens, n_msgs)
     gib = (n_msgs * (wl.user_bytes // wl.n_msgs)) / sec / (1 << 30)
     return {"value": round(gib, 3), "unit": "GiB/s", "cores": 1, "kind": "port",
@@ -114,52 +114,34 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--msgs", type=int, default=64, help="1 MiB messages per step")
-    ap.add_argument("--ring-kb", type=int, default=int(os.environ.get("GRPC_RDMA_RING_BUFFER_SIZE_KB", 4096)))
+    ap.add_argument("--msgs", type=int, default=256, help="1 MiB messages per step")
+    ap.add_argument("--ring-kb", type=int,
+                    default=int(os.environ.get("GRPC_RDMA_RING_BUFFER_SIZE_KB", 65536)),
+                    help="ring size (GRPC_RDMA_RING_BUFFER_SIZE_KB); the reference default is 4096")
     ap.add_argument("--max-sge", type=int, default=4095)
     ap.add_argument("--wire", choices=["staged", "direct"], default="staged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-small-ring", action="store_true", help="skip the extra 4 MiB-ring run")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-
+    from_env = (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+                int(os.environ.get("WORLD_SIZE", "1")))
+    rank, local_rank, world = from_env
+    torch.cuda.set_device(local_rank)
     import __graft_entry__ as ge
     if not os.path.exists(ge.LIB):
         ge.build()
     import grpc_rdma_amd as g
     from grpc_rdma_amd import stream as gs
     g.init(local_rank)
+    from grpc_rdma_amd import shard
+    grp = shard.RankGroup(backend="nccl", device=torch.device("cuda", local_rank))
+    dist = grp.dist
 
-    ring = args.ring_kb * 1024
     flags = 2 if args.wire == "direct" else 0
-    tx, rx = g.Pair(ring, args.max_sge, flags), g.Pair(ring, args.max_sge, flags)
-    g.connect_pairs(tx, rx)
     wl = Workload(g, args.msgs)
-    dst_cap = wl.N + 16 * (len(wl.lens) * 2 + 64) + 4096
-    dst = g.DeviceBuffer(nbytes=dst_cap)
-    slices_cap = len(wl.lens) * 2 + 64
-    est_rounds = max(8, 4 * (wl.E // (ring // 2) + 2))
-    if args.max_sge < 4095:
-        est_rounds = max(est_rounds, 2 * (len(wl.lens) // args.max_sge + 2))
-    job = gs.StreamJob(tx, rx, wl.sge, dst.ptr, dst_cap, slices_cap, est_rounds)
-    r = job.run(gs.RUN_EAGER)                      # calibration: how many rounds are needed
-    assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
-        r.bytes_delivered, wl.N)
-    rounds = int(max(r.tx_rounds, r.rx_rounds))
-    job.set_rounds(rounds)
-    r = job.run(gs.RUN_GRAPH)                      # capture + first replay
-    assert r.done and r.bytes_delivered == wl.N
 
     def barrier():
         torch.cuda.synchronize()
@@ -167,44 +149,69 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        job.launch()
-    job.sync()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.launch()
-    job.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    barrier()
+    def measure(ring_kb, steps, warmup, verify, instrument):
+        """One connection with a ring of ring_kb KiB: calibrate the number of rounds,
+        capture the graph, time `steps` passes, verify, optionally instrument."""
+        ring = ring_kb * 1024
+        tx, rx = g.Pair(ring, args.max_sge, flags), g.Pair(ring, args.max_sge, flags)
+        g.connect_pairs(tx, rx)
+        dst_cap = wl.N + 16 * (len(wl.lens) * 2 + 64) + 4096
+        dst = g.DeviceBuffer(nbytes=dst_cap)
+        slices_cap = len(wl.lens) * 2 + 64
+        est_rounds = max(8, 4 * (wl.E // (ring // 2) + 2), 2 * (len(wl.lens) // min(args.max_sge, 4095) + 2))
+        job = gs.StreamJob(tx, rx, wl.sge, dst.ptr, dst_cap, slices_cap, est_rounds)
+        r = job.run(gs.RUN_EAGER)                  # calibration: how many rounds are needed
+        assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
+            r.bytes_delivered, wl.N)
+        rounds = int(max(r.tx_rounds, r.rx_rounds))
+        job.set_rounds(rounds)
+        r = job.run(gs.RUN_GRAPH)                  # capture + first replay
+        assert r.done and r.bytes_delivered == wl.N
+        for _ in range(warmup):
+            job.launch()
+        job.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            job.launch()
+        job.sync()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        elapsed = grp.max(elapsed)
+        barrier()
+        out = {"elapsed": elapsed, "rounds": rounds, "verified": None, "classes": None}
+        if verify:  # correctness of what the timed region produced (untimed)
+            r = job.run(gs.RUN_GRAPH)
+            assert r.done and r.bytes_delivered == wl.N and r.bytes_sent == wl.N
+            ds = job.delivered_slices()
+            got = dst.read(dst_cap)
+            stream = b"".join(got[o:o + n] for o, n in ds)
+            exp = b"".join(wl.expected_wire(i) for i in range(wl.n_msgs))
+            assert stream == exp, "delivered byte stream differs from the framed messages"
+            assert rx.ring_mem() == bytes(ring), "ring not zero after the drain"
+            out["verified"] = True
+        if instrument:  # per-kernel time, HIP events on the launch stream
+            inst = None
+            for _ in range(3):
+                inst = job.run(gs.RUN_INSTRUMENTED)
+            classes = {}
+            for i, name in enumerate(gs.CLASS_NAMES):
+                n = int(inst.launches_class[i])
+                if n:
+                    classes[name] = {"launches": n, "ms": inst.ms_class[i],
+                                     "us_per_launch": 1e3 * inst.ms_class[i] / n}
+            out["classes"] = classes
+        job.close()
+        tx.close(); rx.close(); dst.free()
+        return out
 
-    # ---- correctness of what the timed region produced (untimed) ---------------
-    verified = None
-    if not args.no_verify:
-        r = job.run(gs.RUN_GRAPH)
-        assert r.done and r.bytes_delivered == wl.N and r.bytes_sent == wl.N
-        ds = job.delivered_slices()
-        got = dst.read(dst_cap)
-        stream = b"".join(got[o:o + n] for o, n in ds)
-        exp = b"".join(wl.expected_wire(i) for i in range(wl.n_msgs))
-        assert stream == exp, "delivered byte stream differs from the framed messages"
-        assert rx.ring_mem() == bytes(ring), "ring not zero after the drain"
-        verified = True
+    head = measure(args.ring_kb, args.steps, args.warmup, not args.no_verify, True)
+    elapsed, rounds, classes, verified = head["elapsed"], head["rounds"], head["classes"], head["verified"]
+    ring = args.ring_kb * 1024
+    small = None
+    if args.ring_kb != 4096 and not args.no_small_ring:
+        small = measure(4096, max(2, args.steps // 2), 1, not args.no_verify, False)
 
-    # ---- roofline: per-kernel time with HIP events on the launch stream --------
-    inst = None
-    for _ in range(3):
-        inst = job.run(gs.RUN_INSTRUMENTED)
-    classes = {}
-    for i, name in enumerate(gs.CLASS_NAMES):
-        n = int(inst.launches_class[i])
-        if n:
-            classes[name] = {"launches": n, "ms": inst.ms_class[i], "us_per_launch": 1e3 * inst.ms_class[i] / n}
     # algorithmic bytes per step per kernel class (DESIGN.md section 4):
     alg = {"gather": 2 * wl.N,          # K1: N read + N written (tags E-N by tx_plan)
            "wire": 2 * wl.E,            # loop-back stand-in for the NIC: E read + E written
@@ -212,9 +219,17 @@ def main():
     dom = max((k for k in classes if k in alg), key=lambda k: classes[k]["ms"])
     per_launch = alg[dom] / classes[dom]["launches"]
     achieved = per_launch / (classes[dom]["us_per_launch"] * 1e-6) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_rx_apply" if dom == "rx_apply" else "k_copy(%s)" % dom,
+    kname = "k_rx_apply" if dom == "rx_apply" else "k_copy"
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_ring%dm_summary.json" % (args.ring_kb // 1024))
+    if os.path.exists(pmc) and args.msgs == 256 and args.wire == "staged":
+        try:
+            traffic = json.load(open(pmc))["kernels"][kname]["hbm_traffic_bytes"]
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "%s (%s)" % (kname, dom),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "bytes_per_launch": int(per_launch),
                 "us_per_launch": round(classes[dom]["us_per_launch"], 2)}
 
@@ -237,14 +252,17 @@ def main():
                     for k, v in classes.items()},
         "endpoint_bytes_per_step": wl.N, "ring_bytes_per_step": wl.E, "verified": verified,
     }
+    if small is not None:
+        sm_steps = max(2, args.steps // 2)
+        out["value_ring4096"] = round(wl.user_bytes * sm_steps * world / small["elapsed"] / (1 << 30), 3)
+        out["rounds_per_step_ring4096"] = small["rounds"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, ring, min(args.max_sge, 4095))
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 import sys, random, os
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import grpc_rdma_amd as g
 from oracle import pyorc
 g.init(0)

@@ -1,5 +1,5 @@
 import sys, ctypes as C
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, grpc_rdma_amd as g
 from grpc_rdma_amd import stream as gs
 g.init(0)
