@@ -109,6 +109,35 @@ def cpu_baseline(wl, ring, max_sge, target_s=12.0):
                       "loop, %d KiB ring, 1 thread, %.1f s" % (n_msgs, len(lens), ring >> 10, sec)}
 
 
+def measure_rtt(g, iters=3000, warmup=300):
+    """Unary ping-pong, 64-byte payload both ways, 1 connection, 4 MiB rings in HBM, host
+    in the loop where gRPC's consumer is (host slices in, host-visible slices out),
+    commands through the resident latency engine.  p50/p95/p99 from the sorted samples."""
+    from grpc_rdma_amd import h2
+    lib = g.load()
+    msg = bytes([0x0A, 64]) + bytes(range(64))           # SimpleRequest{bytes message = 64 B}
+    items = h2.frame_message(len(msg), 1)
+    slices = [i[1] if i[0] == "inl" else msg[i[1][0]:i[1][0] + i[1][1]] for i in items]
+    a, b = g.Pair(4 << 20, 30), g.Pair(4 << 20, 30)
+    g.connect_pairs(a, b)
+    a.set_latency_mode(True)
+    b.set_latency_mode(True)
+    g._lib.check(lib.grdma_engine_start())
+    try:
+        rtt, ph = g.pingpong(a, b, slices, slices, iters=iters, warmup=warmup)
+    finally:
+        lib.grdma_engine_stop()
+    a.close()
+    b.close()
+    rtt.sort()
+    return {"rtt_p50_us": round(rtt[iters // 2] / 1e3, 2), "rtt_p95_us": round(rtt[int(iters * .95)] / 1e3, 2),
+            "rtt_p99_us": round(rtt[int(iters * .99)] / 1e3, 2),
+            "rtt_config": "unary ping-pong 64 B, 1 connection, 4 MiB ring in HBM, slices [14 B][66 B] "
+                          "each way, resident latency engine, host slices in / pinned slices out",
+            "rtt_breakdown_us": {k: round(v / iters / 1e3, 2) for k, v in zip(
+                ["client_write", "server_read", "server_write", "client_read"], ph)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +152,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-small-ring", action="store_true", help="skip the extra 4 MiB-ring run")
+    ap.add_argument("--no-rtt", action="store_true", help="skip the 64 B ping-pong leg")
     args = ap.parse_args()
 
     import torch
@@ -252,6 +282,12 @@ def main():
                     for k, v in classes.items()},
         "endpoint_bytes_per_step": wl.N, "ring_bytes_per_step": wl.E, "verified": verified,
     }
+    # ---- unary 64 B ping-pong (BASELINE.json configs[1]): second half of the metric -------
+    if not args.no_rtt:
+        try:
+            out.update(measure_rtt(g))
+        except Exception as e:  # never lose the throughput line to the latency leg
+            out["rtt_error"] = str(e)
     if small is not None:
         sm_steps = max(2, args.steps // 2)
         out["value_ring4096"] = round(wl.user_bytes * sm_steps * world / small["elapsed"] / (1 << 30), 3)

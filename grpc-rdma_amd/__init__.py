@@ -6,4 +6,4 @@ The directory is named `grpc-rdma_amd`; import it as `grpc_rdma_amd`
 (see grpc_rdma_amd.py at the repository root).
 """
 from ._lib import GrdmaError, init, load  # noqa: F401
-from .pair import Pair, DeviceBuffer, connect_pairs, poll_pairs  # noqa: F401
+from .pair import Pair, DeviceBuffer, connect_pairs, poll_pairs, pingpong  # noqa: F401

@@ -9,6 +9,13 @@
 #define PLAN_THREADS 256
 #define COPY_THREADS 256
 
+// progress word of the resident engine (pinned host memory), null elsewhere
+__device__ uint64_t* g_engine_trace = nullptr;
+__device__ __forceinline__ void engine_trace(uint64_t code) {
+  if (g_engine_trace != nullptr && threadIdx.x == 0)
+    __hip_atomic_store(g_engine_trace, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ uint64_t round_up8(uint64_t v) { return (v + 7ull) & ~7ull; }
 __device__ __forceinline__ uint64_t round_down8(uint64_t v) { return v & ~7ull; }
 __device__ __forceinline__ uint64_t enc_size(uint64_t pay) { return 16ull + round_up8(pay); }
@@ -67,6 +74,118 @@ __device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t* wave_s
   __syncthreads();
   *total = tot;
   return base + incl - v;
+}
+
+// ---- segment-list byte mover: tiles, funnel-shift realignment, zero-behind ----
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 funnel16(u32x4 a, u32x4 b, unsigned shift) {
+  // bytes [shift, shift+16) of the 32-byte little-endian concatenation a|b
+  uint64_t q0 = (uint64_t)a.x | ((uint64_t)a.y << 32);
+  uint64_t q1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
+  uint64_t q2 = (uint64_t)b.x | ((uint64_t)b.y << 32);
+  uint64_t q3 = (uint64_t)b.z | ((uint64_t)b.w << 32);
+  if (shift & 8) {
+    q0 = q1;
+    q1 = q2;
+    q2 = q3;
+  }
+  unsigned s = (shift & 7) * 8;
+  uint64_t o0 = q0, o1 = q1;
+  if (s) {
+    o0 = (q0 >> s) | (q1 << (64 - s));
+    o1 = (q1 >> s) | (q2 << (64 - s));
+  }
+  u32x4 o;
+  o.x = (uint32_t)o0;
+  o.y = (uint32_t)(o0 >> 32);
+  o.z = (uint32_t)o1;
+  o.w = (uint32_t)(o1 >> 32);
+  return o;
+}
+
+// One wave moves n (<= GRDMA_TILE_BYTES) bytes src -> dst, any alignment.
+__device__ __forceinline__ void wave_copy_tile(uint8_t* dst, const uint8_t* src, uint64_t n,
+                                               int lane) {
+  uint64_t head = (16 - ((uint64_t)dst & 15)) & 15;
+  if (head > n) head = n;
+  if ((uint64_t)lane < head) dst[lane] = src ? src[lane] : 0;
+  dst += head;
+  if (src) src += head;
+  n -= head;
+  const uint64_t units = n >> 4;
+  const unsigned shift = (unsigned)((uint64_t)src & 15);
+  const u32x4* sa = reinterpret_cast<const u32x4*>((uint64_t)src & ~15ull);
+  u32x4* da = reinterpret_cast<u32x4*>(dst);
+  if (src == nullptr) {
+    for (uint64_t u = lane; u < units; u += 64) da[u] = u32x4{0, 0, 0, 0};
+  } else if (shift == 0) {
+#pragma unroll 4
+    for (uint64_t u = lane; u < units; u += 64) da[u] = __builtin_nontemporal_load(sa + u);
+  } else {
+#pragma unroll 4
+    for (uint64_t u = lane; u < units; u += 64) {
+      u32x4 a = __builtin_nontemporal_load(sa + u);
+      u32x4 b = __builtin_nontemporal_load(sa + u + 1);
+      da[u] = funnel16(a, b, shift);
+    }
+  }
+  const uint64_t tail = n & 15;
+  if ((uint64_t)lane < tail) {
+    uint64_t o = (units << 4) + lane;
+    dst[o] = src ? src[o] : 0;
+  }
+}
+
+// Reader zero-fill (ring_buffer.cc:160,164): clear exactly [p, p+n).
+__device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane) {
+  uint64_t head = (16 - ((uint64_t)p & 15)) & 15;
+  if (head > n) head = n;
+  if ((uint64_t)lane < head) p[lane] = 0;
+  p += head;
+  n -= head;
+  const uint64_t units = n >> 4;
+  u32x4* q = reinterpret_cast<u32x4*>(p);
+  for (uint64_t u = lane; u < units; u += 64) q[u] = u32x4{0, 0, 0, 0};
+  const uint64_t tail = n & 15;
+  if ((uint64_t)lane < tail) p[(units << 4) + lane] = 0;
+}
+
+#define PREFIX_LDS 2048
+
+// Every workgroup stages the tile prefix in LDS (one coalesced load), then each
+// wave maps its tiles to segments with an LDS binary search: no dependent global
+// loads between picking a tile and issuing its first payload load.
+__device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t wave,
+                                               uint32_t nwaves, int lane) {
+  __shared__ uint32_t s_prefix[PREFIX_LDS + 1];
+  const uint32_t nsegs = plan->nsegs;
+  const uint32_t ntiles = plan->ntiles;
+  const bool in_lds = nsegs <= PREFIX_LDS;
+  if (in_lds)
+    for (uint32_t i = threadIdx.x; i <= nsegs; i += COPY_THREADS) s_prefix[i] = plan->tile_prefix[i];
+  __syncthreads();
+  for (uint32_t t = wave; t < ntiles; t += nwaves) {
+    uint32_t lo = 0, hi = nsegs;  // invariant: prefix[lo] <= t < prefix[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      const uint32_t pm = in_lds ? s_prefix[mid] : plan->tile_prefix[mid];
+      if (pm <= t) lo = mid; else hi = mid;
+    }
+    const grdma_seg sg = plan->segs[lo];
+    const uint32_t p0 = in_lds ? s_prefix[lo] : plan->tile_prefix[lo];
+    const uint64_t off = (uint64_t)(t - p0) * GRDMA_TILE_BYTES;
+    uint64_t n = sg.len - off;
+    if (n > GRDMA_TILE_BYTES) n = GRDMA_TILE_BYTES;
+    uint8_t* src = sg.src ? reinterpret_cast<uint8_t*>(sg.src + off) : nullptr;
+    wave_copy_tile(reinterpret_cast<uint8_t*>(sg.dst + off), src, n, lane);
+    if ((sg.flags & GRDMA_SEG_ZERO_SRC) && src) {
+      // every load of this tile has returned (its data fed the stores above);
+      // make that explicit before the source bytes are overwritten
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wave_zero_tile(src, n, lane);
+    }
+  }
 }
 
 

@@ -17,7 +17,8 @@ struct grdma_tx_op {
   struct grdma_tx_result* result;
   uint32_t use_cursor;             // 0: slice 0 + byte_idx; 1: continue from the conn's
                                    // rdma_flush cursor; 2: reset that cursor first
-  uint32_t pad;
+  uint32_t inline_copy;            // 1: this workgroup also runs the gather (and wire) tiles --
+                                   // one launch per Send for small messages
 };
 
 // One drain of a connection's ring: a run of endpoint_read completions.
@@ -32,6 +33,20 @@ struct grdma_rx_op {
   uint64_t raw_cap;                // != 0: one PairPollable::Recv(arena, raw_cap) instead
   uint64_t append;                 // 1: continue at conn->rx_arena_off / rx_slice_idx
   uint64_t slices_cap;             // entries in `slices` (append mode)
+  uint64_t inline_apply;           // 1: this workgroup also scatters, zero-fills and posts credit
+};
+
+// Mailbox of the persistent latency engine (pinned host memory).
+enum { GRDMA_ENGINE_SEND = 1, GRDMA_ENGINE_DRAIN = 2 };
+struct grdma_engine_mbox {
+  uint64_t cmd_seq;    // host: bumped last, after cmd_type/op are written
+  uint64_t cmd_type;
+  const void* op;      // grdma_tx_op* / grdma_rx_op* (device-visible)
+  uint64_t pad0[5];
+  uint64_t ack_seq;    // engine: last command completed
+  uint64_t alive;      // engine: 1 while resident
+  uint64_t exit_flag;  // host: ask the engine to leave
+  uint64_t pad1[5];
 };
 
 #endif  // GRDMA_OPS_H

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +29,7 @@ hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_apply(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*, uint64_t*,
                              hipStream_t);
+hipError_t grdma_launch_engine(grdma_engine_mbox*, hipStream_t);
 }
 
 namespace {
@@ -46,6 +48,15 @@ struct grdma_ctx {
 
 grdma_ctx g_ctx;
 thread_local std::string g_err;
+
+// persistent latency engine (k_engine): mailbox in pinned host memory
+struct grdma_engine {
+  grdma_engine_mbox* mb = nullptr;
+  hipStream_t stream = nullptr;
+  bool wanted = false;   // grdma_engine_start() was called
+  uint64_t seq = 0;
+};
+grdma_engine g_engine;
 
 int fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -102,6 +113,9 @@ struct grdma_pair {
   uint8_t* d_arena = nullptr;
   uint64_t arena_cap = 0;
   uint32_t* d_hist = nullptr;
+  bool latency = false;              // fused single-launch kernels + spin on pinned seq words
+  uint8_t* h_arena = nullptr;        // pinned receive arena used in latency mode
+  uint64_t h_arena_cap = 0;
   grdma_hostblk* h = nullptr;        // pinned
   grdma_sge* h_sges = nullptr;       // pinned, GRDMA_MAX_SEGS entries
   grdma_slice_out* h_slices = nullptr;  // pinned, GRDMA_MAX_SLICES entries
@@ -133,7 +147,7 @@ int stage_slices(grdma_pair* p, const grdma_slice* slices, uint64_t count, uint6
                 (unsigned long long)count, GRDMA_TX_MAX_RECORDS - 1);
   if (flags & GRDMA_MEM_HOST) {
     const uint64_t cap = p->ring_size / 2;
-    if (!p->h_bounce) HIP_TRY(hipHostMalloc((void**)&p->h_bounce, cap + 64, hipHostMallocDefault));
+    if (!p->h_bounce) HIP_TRY(hipHostMalloc((void**)&p->h_bounce, cap + 64, hipHostMallocCoherent | hipHostMallocMapped));
     uint64_t off = 0;
     for (uint64_t i = 0; i < count; i++) {
       const uint8_t* src = static_cast<const uint8_t*>(slices[i].ptr);
@@ -156,6 +170,85 @@ int stage_slices(grdma_pair* p, const grdma_slice* slices, uint64_t count, uint6
   return 0;
 }
 
+int engine_launch() {
+  grdma_engine& e = g_engine;
+  if (!e.mb) {
+    HIP_TRY(hipHostMalloc((void**)&e.mb, sizeof(grdma_engine_mbox), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(e.mb, 0, sizeof(*e.mb));
+    HIP_TRY(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+  }
+  volatile uint64_t* alive = &e.mb->alive;
+  if (*alive) return 0;
+  e.mb->exit_flag = 0;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  HIP_TRY(grdma_launch_engine(e.mb, e.stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  while (!*alive) {
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5))
+      return fail(GRDMA_ERR_HIP, "latency engine did not come up");
+  }
+  return 0;
+}
+
+// Hand one command to the resident engine and wait for it.
+int engine_submit(uint64_t type, const void* op) {
+  grdma_engine& e = g_engine;
+  if (int rc = engine_launch()) return rc;
+  e.mb->cmd_type = type;
+  e.mb->op = op;
+  std::atomic_thread_fence(std::memory_order_release);
+  const uint64_t seq = ++e.seq;
+  *(volatile uint64_t*)&e.mb->cmd_seq = seq;
+  volatile uint64_t* ack = &e.mb->ack_seq;
+  volatile uint64_t* alive = &e.mb->alive;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spins = 0;; spins++) {
+    if (*ack == seq) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return 0;
+    }
+    if ((spins & 0x3FF) == 0x3FF) {
+      if (!*alive && *ack != seq) {  // the engine timed out just before the doorbell
+        if (int rc = engine_launch()) return rc;
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) {
+        *(volatile uint64_t*)&e.mb->exit_flag = 1;
+        return fail(GRDMA_ERR_HIP, "latency engine did not answer: alive=%llu ack=%llu seq=%llu polls=%llu seen=%llu stage=0x%llx trace=%llu",
+                    (unsigned long long)*alive, (unsigned long long)*ack, (unsigned long long)seq,
+                    (unsigned long long)e.mb->pad1[0], (unsigned long long)e.mb->pad1[1],
+                    (unsigned long long)e.mb->pad1[2], (unsigned long long)e.mb->pad1[3]);
+      }
+    }
+  }
+}
+
+int engine_stop() {
+  grdma_engine& e = g_engine;
+  e.wanted = false;
+  if (!e.mb) return 0;
+  *(volatile uint64_t*)&e.mb->exit_flag = 1;
+  HIP_TRY(hipStreamSynchronize(e.stream));
+  return 0;
+}
+
+// Wait for a plan kernel by watching its sequence word in pinned host memory
+// (the kernel bumps it last, with a system-scope release); falls back to a
+// stream synchronize so that a failed launch is still reported.
+int wait_seq(grdma_pair* p, volatile uint64_t* seq, uint64_t old) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spins = 0;; spins++) {
+    if (*seq != old) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return 0;
+    }
+    if ((spins & 0xFFF) == 0xFFF &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
+      break;
+  }
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return *seq != old ? 0 : fail(GRDMA_ERR_HIP, "plan kernel did not complete");
+}
+
 int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_cursor) {
   grdma_hostblk* h = p->h;
   h->txop.conn = p->d_conn;
@@ -166,7 +259,14 @@ int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_curs
   h->txop.wire_plan = p->d_wireplan;
   h->txop.result = &h->txres;
   h->txop.use_cursor = use_cursor;
+  h->txop.inline_copy = p->latency ? 1 : 0;
   const uint32_t blocks = copy_blocks_for(p->ring_size / 2);
+  if (p->latency) {
+    if (g_engine.wanted) return engine_submit(GRDMA_ENGINE_SEND, &h->txop);
+    const uint64_t old = h->txres.seq;
+    HIP_TRY(grdma_launch_tx_plan(&h->txop, 1, p->stream));
+    return wait_seq(p, &h->txres.seq, old);
+  }
   HIP_TRY(grdma_launch_tx_plan(&h->txop, 1, p->stream));
   HIP_TRY(grdma_launch_copy(&h->plan_ptrs[0], 1, blocks, p->stream));
   if (!(p->flags & GRDMA_WIRE_DIRECT))
@@ -188,7 +288,14 @@ int run_recv(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_rea
   h->rxop.raw_cap = raw_cap;
   h->rxop.append = 0;
   h->rxop.slices_cap = GRDMA_MAX_SLICES;
+  h->rxop.inline_apply = p->latency ? 1 : 0;
   const uint32_t blocks = copy_blocks_for(p->ring_size);
+  if (p->latency) {
+    if (g_engine.wanted) return engine_submit(GRDMA_ENGINE_DRAIN, &h->rxop);
+    const uint64_t old = h->rxres.seq;
+    HIP_TRY(grdma_launch_rx_plan(&h->rxop, 1, p->stream));
+    return wait_seq(p, &h->rxres.seq, old);
+  }
   HIP_TRY(grdma_launch_rx_plan(&h->rxop, 1, p->stream));
   HIP_TRY(grdma_launch_rx_apply(&h->rxop, 1, blocks, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -250,11 +357,11 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
             hipMalloc((void**)&p->d_rxplan, sizeof(grdma_plan)) == hipSuccess &&
             hipMalloc((void**)&p->d_arena, p->arena_cap) == hipSuccess &&
             hipMalloc((void**)&p->d_hist, sizeof(uint32_t) * GRDMA_RX_HIST) == hipSuccess &&
-            hipHostMalloc((void**)&p->h, sizeof(grdma_hostblk), hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void**)&p->h, sizeof(grdma_hostblk), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess &&
             hipHostMalloc((void**)&p->h_sges, sizeof(grdma_sge) * GRDMA_TX_MAX_RECORDS,
-                          hipHostMallocDefault) == hipSuccess &&
+                          hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess &&
             hipHostMalloc((void**)&p->h_slices, sizeof(grdma_slice_out) * GRDMA_MAX_SLICES,
-                          hipHostMallocDefault) == hipSuccess;
+                          hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
   if (!ok) {
     fail(GRDMA_ERR_HIP, "device allocation failed for a %llu-byte ring",
          (unsigned long long)ring_size);
@@ -306,6 +413,7 @@ void grdma_pair_destroy(grdma_pair* p) {
   if (p->h_sges) hipHostFree(p->h_sges);
   if (p->h_slices) hipHostFree(p->h_slices);
   if (p->h_bounce) hipHostFree(p->h_bounce);
+  if (p->h_arena) hipHostFree(p->h_arena);
   if (p->peer && p->peer->peer == p) p->peer->peer = nullptr;
   delete p;
 }
@@ -405,10 +513,10 @@ int grdma_poll_pairs(grdma_pair* const* pairs, uint32_t n, uint64_t* readable,
     if (g_ctx.h_readable) hipHostFree(g_ctx.h_readable);
     if (g_ctx.h_masks) hipHostFree(g_ctx.h_masks);
     uint32_t cap = (n + 63) & ~63u;
-    HIP_TRY(hipHostMalloc((void**)&g_ctx.h_conns, sizeof(void*) * cap, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&g_ctx.h_readable, sizeof(uint64_t) * cap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&g_ctx.h_conns, sizeof(void*) * cap, hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void**)&g_ctx.h_readable, sizeof(uint64_t) * cap, hipHostMallocCoherent | hipHostMallocMapped));
     HIP_TRY(hipHostMalloc((void**)&g_ctx.h_masks, sizeof(uint64_t) * 2 * (cap / 64),
-                          hipHostMallocDefault));
+                          hipHostMallocCoherent | hipHostMallocMapped));
     g_ctx.poll_cap = cap;
   }
   hipStream_t s = pairs[0]->stream;
@@ -506,13 +614,104 @@ int grdma_pair_last_wrs(grdma_pair* p, uint64_t out[2][2]) {
 }
 
 void* grdma_pair_ring_device_ptr(grdma_pair* p) { return p ? p->d_ring : nullptr; }
-void* grdma_pair_arena_device_ptr(grdma_pair* p) { return p ? p->d_arena : nullptr; }
+void* grdma_pair_arena_device_ptr(grdma_pair* p) {
+  return p ? (p->latency ? p->h_arena : p->d_arena) : nullptr;
+}
 uint64_t grdma_pair_arena_size(grdma_pair* p) { return p ? p->arena_cap : 0; }
 
 int grdma_pair_arena_copy_out(grdma_pair* p, uint64_t off, void* host_dst, uint64_t len) {
   if (int rc = require_ctx()) return rc;
-  if (!p || off + len > p->arena_cap) return fail(GRDMA_ERR_INVALID, "range outside the arena");
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (p->latency) {  // the arena is pinned host memory: the kernel already wrote it there
+    if (off + len > p->h_arena_cap) return fail(GRDMA_ERR_INVALID, "range outside the arena");
+    memcpy(host_dst, p->h_arena + off, len);
+    return 0;
+  }
+  if (off + len > p->arena_cap) return fail(GRDMA_ERR_INVALID, "range outside the arena");
   HIP_TRY(hipMemcpy(host_dst, p->d_arena + off, len, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int grdma_engine_start(void) {
+  if (int rc = require_ctx()) return rc;
+  g_engine.wanted = true;
+  return engine_launch();
+}
+
+int grdma_engine_stop(void) {
+  if (int rc = require_ctx()) return rc;
+  return engine_stop();
+}
+
+int grdma_pair_set_latency_mode(grdma_pair* p, int on) {
+  if (int rc = require_ctx()) return rc;
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (on && !p->h_arena) {
+    p->h_arena_cap = 2 * p->ring_size + 4096;
+    if (p->h_arena_cap > (64ull << 20)) p->h_arena_cap = 64ull << 20;
+    HIP_TRY(hipHostMalloc((void**)&p->h_arena, p->h_arena_cap, hipHostMallocCoherent | hipHostMallocMapped));
+  }
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->latency = on != 0;
+  return 0;
+}
+
+// Unary ping-pong over a connected loop-back link, host in the loop exactly
+// where gRPC's consumer is: a = client end, b = server end.  Per iteration:
+// client endpoint_write(req) -> server endpoint_read -> server
+// endpoint_write(resp) -> client endpoint_read.  rtt_ns[i] = wall time of
+// iteration i; phase_ns[0..4) = summed time of the four phases.
+int grdma_pingpong(grdma_pair* a, grdma_pair* b, const grdma_slice* req, uint64_t nreq,
+                   const grdma_slice* resp, uint64_t nresp, int mem_flags, uint64_t iters,
+                   uint64_t warmup, uint64_t* rtt_ns, uint64_t phase_ns[4]) {
+  if (int rc = require_ctx()) return rc;
+  if (!a || !b || a->peer != b || !req || !resp || !rtt_ns) return fail(GRDMA_ERR_INVALID, "bad argument");
+  uint64_t req_bytes = 0, resp_bytes = 0;
+  for (uint64_t i = 0; i < nreq; i++) req_bytes += req[i].len;
+  for (uint64_t i = 0; i < nresp; i++) resp_bytes += resp[i].len;
+  grdma_read_slice sl[64];
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ns = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(y - x).count();
+  };
+  auto write_all = [&](grdma_pair* p, const grdma_slice* s, uint64_t n) -> int {
+    if (int64_t rc = grdma_endpoint_write_begin(p, s, n, mem_flags); rc < 0) return (int)rc;
+    int done = 0;
+    for (int tries = 0; !done && tries < 1000; tries++) {
+      int64_t rc = grdma_endpoint_write_step(p, &done);
+      if (rc < 0) return (int)rc;
+    }
+    return done ? 0 : fail(GRDMA_ERR_HIP, "write did not complete");
+  };
+  auto read_all = [&](grdma_pair* p, uint64_t want) -> int {
+    uint64_t got = 0;
+    for (int tries = 0; got < want && tries < 100000; tries++) {
+      int wb = 0;
+      int64_t n = grdma_endpoint_read(p, 64, sl, 64, &wb);
+      if (n < 0) return (int)n;
+      for (int64_t i = 0; i < n; i++) got += sl[i].len;
+    }
+    return got == want ? 0 : fail(GRDMA_ERR_HIP, "short read in ping-pong");
+  };
+  if (phase_ns) phase_ns[0] = phase_ns[1] = phase_ns[2] = phase_ns[3] = 0;
+  for (uint64_t it = 0; it < warmup + iters; it++) {
+    const auto t0 = now();
+    if (int rc = write_all(a, req, nreq)) return rc;
+    const auto t1 = now();
+    if (int rc = read_all(b, req_bytes)) return rc;
+    const auto t2 = now();
+    if (int rc = write_all(b, resp, nresp)) return rc;
+    const auto t3 = now();
+    if (int rc = read_all(a, resp_bytes)) return rc;
+    const auto t4 = now();
+    if (it >= warmup) {
+      rtt_ns[it - warmup] = ns(t0, t4);
+      if (phase_ns) {
+        phase_ns[0] += ns(t0, t1); phase_ns[1] += ns(t1, t2);
+        phase_ns[2] += ns(t2, t3); phase_ns[3] += ns(t3, t4);
+      }
+    }
+  }
   return 0;
 }
 
@@ -565,7 +764,9 @@ int64_t grdma_endpoint_read(grdma_pair* p, uint64_t max_reads, grdma_read_slice*
   if (max_reads > slices_cap) max_reads = slices_cap;
   if (max_reads > GRDMA_MAX_SLICES) max_reads = GRDMA_MAX_SLICES;
   if (max_reads == 0) return 0;
-  if (int rc = run_recv(p, p->d_arena, p->arena_cap, max_reads, 0)) return rc;
+  uint8_t* arena = p->latency ? p->h_arena : p->d_arena;
+  const uint64_t acap = p->latency ? p->h_arena_cap : p->arena_cap;
+  if (int rc = run_recv(p, arena, acap, max_reads, 0)) return rc;
   const grdma_rx_result& r = p->h->rxres;
   for (uint64_t i = 0; i < r.nslices; i++) {
     slices[i].off = p->h_slices[i].off;
@@ -589,7 +790,7 @@ void grdma_device_free(void* p) { if (p) hipFree(p); }
 void* grdma_host_alloc_pinned(uint64_t bytes) {
   if (require_ctx()) return nullptr;
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return nullptr;
   return p;
 }
 void grdma_host_free_pinned(void* p) { if (p) hipHostFree(p); }
@@ -605,6 +806,7 @@ int grdma_copy_to_host(void* dst, const void* src, uint64_t n) {
 }
 int grdma_device_synchronize(void) {
   if (int rc = require_ctx()) return rc;
+  if (int rc = engine_stop()) return rc;  // a resident engine would never let this return
   HIP_TRY(hipDeviceSynchronize());
   return 0;
 }

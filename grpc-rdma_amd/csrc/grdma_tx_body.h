@@ -1,0 +1,322 @@
+// Body of the send plan (PairPollable::Send arithmetic + rdma_flush cursor), shared by
+// the k_tx_plan kernel and the persistent latency engine.  One 256-thread workgroup.
+#ifndef GRDMA_TX_BODY_H
+#define GRDMA_TX_BODY_H
+#include "grdma_devfn.h"
+#include "grdma_ops.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// k_tx_plan: PairPollable::Send arithmetic + rdma_flush cursor, one block per op
+// ----------------------------------------------------------------------------
+// All records of a Send are priced at once: enc_i = 16 + round_up8(len_i) is
+// prefix-summed across the block (st_i), every record tests its own budget
+// pay_i = min(len_i, W(S - st_i), W(free0 - st_i)) under the assumption that all
+// earlier records went out whole, and an LDS atomic-min finds the first record
+// that comes up short -- which is exactly where the reference's sequential loop
+// stops (pair.cc:671-707).  Global loads/stores are
+// striped over the block (record i -> thread i % 256) so they coalesce.
+__device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
+  grdma_conn* c = op.conn;
+  grdma_plan* plan = op.plan;
+  __shared__ uint64_t s_wave[PLAN_THREADS / 64];
+  __shared__ uint64_t s_len[GRDMA_TX_MAX_RECORDS];       // len_i, later pay_i
+  __shared__ uint64_t s_excl[GRDMA_TX_MAX_RECORDS + 1];  // st_i
+  __shared__ unsigned int s_first_short;
+  __shared__ unsigned int s_wrap_rec;
+  const unsigned tid = threadIdx.x;
+  uint64_t tdbg[8];
+  tdbg[0] = __builtin_amdgcn_s_memtime();
+
+  const uint64_t cap = c->cap, mask = cap - 1;
+  const uint64_t S = c->staging_cap;
+  const uint64_t tail0 = c->remote_tail;
+  // get_remote_head(), pair.h:229-233
+  const uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool connected = c->status == GRDMA_PAIR_CONNECTED;
+  uint64_t start = op.use_cursor == 1 ? c->tx_slice_idx : 0;
+  const uint64_t byte_idx =
+      op.use_cursor == 1 ? c->tx_byte_idx : (op.use_cursor ? 0 : op.byte_idx);
+  if (start > op.nslices) start = op.nslices;
+  const uint64_t avail = op.nslices - start;
+  const grdma_sge* sl = op.slices + start;
+
+  if (tid == 0) {
+    s_first_short = 0xFFFFFFFFu;
+    s_wrap_rec = 0xFFFFFFFFu;
+  }
+
+  // total bytes offered (pair.cc:660-663).  A streaming job keeps the running
+  // remainder in the connection instead of re-summing the whole list per round.
+  uint64_t offered;
+  if (op.use_cursor == 1) {
+    offered = c->tx_remaining;
+    __syncthreads();
+  } else {
+    uint64_t part = 0;
+    for (uint64_t i = tid; i < avail; i += PLAN_THREADS) part += sl[i].len;
+    block_excl_scan(part, s_wave, &offered);
+    offered = sat_sub(offered, byte_idx);
+  }
+
+  uint64_t m = avail;
+  if (m > c->max_sge) m = c->max_sge;
+  if (m > GRDMA_TX_MAX_RECORDS - 1) m = GRDMA_TX_MAX_RECORDS - 1;
+  if (!connected) m = 0;
+
+  tdbg[1] = __builtin_amdgcn_s_memtime();
+  engine_trace(11);
+  // lengths, striped
+  for (uint64_t i = tid; i < m; i += PLAN_THREADS) {
+    uint64_t l = sl[i].len;
+    if (i == 0) l = sat_sub(l, byte_idx);
+    s_len[i] = l;
+  }
+  __syncthreads();
+
+  // st_i: each thread scans a contiguous run of `per` records out of LDS
+  const uint64_t per = (m + PLAN_THREADS - 1) / PLAN_THREADS;
+  {
+    uint64_t chunk = 0;
+    for (uint64_t k = 0; k < per; k++) {
+      const uint64_t i = tid * per + k;
+      if (i < m) {
+        const uint64_t l = s_len[i];
+        // clamp so that sums cannot overflow; anything above 2*cap cannot fit anyway
+        chunk += enc_size(l < (cap << 1) ? l : (cap << 1));
+      }
+    }
+    uint64_t total_enc;
+    uint64_t st = block_excl_scan(chunk, s_wave, &total_enc);
+    for (uint64_t k = 0; k < per; k++) {
+      const uint64_t i = tid * per + k;
+      if (i < m) {
+        s_excl[i] = st;
+        const uint64_t l = s_len[i];
+        st += enc_size(l < (cap << 1) ? l : (cap << 1));
+      }
+    }
+    if (tid == PLAN_THREADS - 1 || (tid * per < m && (tid + 1) * per >= m)) s_excl[m] = st;
+    if (m == 0 && tid == 0) s_excl[0] = 0;
+  }
+  __syncthreads();
+
+  tdbg[2] = __builtin_amdgcn_s_memtime();
+  engine_trace(12);
+  // budget test, striped
+  const uint64_t occupied0 = (tail0 + cap - rhead) & mask;
+  const uint64_t free0 = cap - occupied0;
+  for (uint64_t i = tid; i < m; i += PLAN_THREADS) {
+    const uint64_t st = s_excl[i];
+    const uint64_t a = writable_of(sat_sub(S, st));
+    const uint64_t b = writable_of(sat_sub(free0, st));
+    const uint64_t l = s_len[i];
+    uint64_t p = l;
+    if (a < p) p = a;
+    if (b < p) p = b;
+    // a zero payload ends the send exactly like the reference's `break`.
+    // One LDS atomic per wave: the lowest short lane of a wave holds its lowest i.
+    const bool is_short = p < l || l == 0;
+    const uint64_t bm = __ballot(is_short);
+    if (bm != 0 && (tid & 63) == (unsigned)__builtin_ctzll(bm)) atomicMin(&s_first_short, (unsigned int)i);
+  }
+  __syncthreads();
+  const uint64_t fs = s_first_short;
+  const uint64_t nrec = (fs != 0xFFFFFFFFu) ? fs : m;  // records [0, nrec) go out whole
+  uint64_t short_pay = 0;
+  if (fs != 0xFFFFFFFFu) {
+    const uint64_t st = s_excl[fs];
+    const uint64_t a = writable_of(sat_sub(S, st));
+    const uint64_t b = writable_of(sat_sub(free0, st));
+    short_pay = s_len[fs];
+    if (a < short_pay) short_pay = a;
+    if (b < short_pay) short_pay = b;
+  }
+  const uint64_t nrec_total = nrec + (short_pay > 0 ? 1 : 0);
+  // Σ enc over the whole records, plus the short one if any
+  const uint64_t staged = s_excl[nrec] + (short_pay > 0 ? enc_size(short_pay) : 0);
+  __syncthreads();
+  if (tid == 0 && short_pay > 0) s_len[nrec] = short_pay;  // s_len[i] is pay_i from here on
+  __syncthreads();
+
+  // destination of record i: staging + st_i, or the peer ring itself at
+  // (tail0 + st_i) & mask when the wire is direct.
+  const bool direct = c->wire_direct != 0;
+  uint8_t* const dbase = direct ? c->peer_ring : c->staging;
+  if (direct) {
+    for (uint64_t i = tid; i < nrec_total; i += PLAN_THREADS) {
+      const uint64_t pstart = (tail0 + s_excl[i] + 8) & mask;
+      if (pstart + s_len[i] > cap) atomicMin(&s_wrap_rec, (unsigned int)i);
+    }
+  }
+  __syncthreads();
+  const uint64_t wrap_rec = s_wrap_rec;
+
+  tdbg[3] = __builtin_amdgcn_s_memtime();
+  engine_trace(13);
+  // tags + segments, striped
+  uint64_t sent_part = 0;
+  for (uint64_t i = tid; i < nrec_total; i += PLAN_THREADS) {
+    const uint64_t p = s_len[i];
+    const uint64_t st = s_excl[i];
+    sent_part += p;
+    const uint64_t hdr_off = direct ? ((tail0 + st) & mask) : st;
+    const uint64_t pay_off = direct ? ((hdr_off + 8) & mask) : st + 8;
+    const uint64_t foot_off = direct ? ((hdr_off + 8 + round_up8(p)) & mask) : st + 8 + round_up8(p);
+    // AppendHeader / AppendFooter, ring_buffer.h:84-99
+    *reinterpret_cast<uint64_t*>(dbase + hdr_off) = p;
+    *reinterpret_cast<uint64_t*>(dbase + foot_off) = GRDMA_FOOTER;
+    // deterministic zero padding (the reference leaves stale staging bytes there)
+    for (uint64_t q = p; q < round_up8(p); q++)
+      dbase[direct ? ((pay_off + q) & mask) : pay_off + q] = 0;
+    const uint8_t* src = sl[i].ptr + (i == 0 ? byte_idx : 0);
+    const uint64_t seg = i + (i > wrap_rec ? 1 : 0);
+    if (i == wrap_rec) {
+      const uint64_t l1 = cap - pay_off;
+      plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, l1, 0};
+      plan->segs[seg + 1] = {(uint64_t)dbase, (uint64_t)(src + l1), p - l1, 0};
+    } else {
+      plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, p, 0};
+    }
+  }
+  uint64_t sent;
+  block_excl_scan(sent_part, s_wave, &sent);
+
+  tdbg[4] = __builtin_amdgcn_s_memtime();
+  engine_trace(14);
+  // tile prefix per segment (contiguous runs again, out of LDS)
+  uint64_t ntiles;
+  {
+    const uint64_t per2 = (nrec_total + PLAN_THREADS - 1) / PLAN_THREADS;
+    auto tiles_of = [&](uint64_t i, uint64_t* t1) -> uint64_t {
+      const uint64_t p = s_len[i];
+      if (i == wrap_rec) {
+        const uint64_t pay_off = (tail0 + s_excl[i] + 16) & mask;  // (hdr_off + 8) & mask
+        const uint64_t l1 = cap - ((tail0 + s_excl[i] + 8) & mask);
+        (void)pay_off;
+        *t1 = (l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
+        return *t1 + (p - l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
+      }
+      *t1 = (p + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
+      return *t1;
+    };
+    uint64_t chunk = 0, t1;
+    for (uint64_t k = 0; k < per2; k++) {
+      const uint64_t i = tid * per2 + k;
+      if (i < nrec_total) chunk += tiles_of(i, &t1);
+    }
+    uint64_t x = block_excl_scan(chunk, s_wave, &ntiles);
+    for (uint64_t k = 0; k < per2; k++) {
+      const uint64_t i = tid * per2 + k;
+      if (i < nrec_total) {
+        const uint64_t seg = i + (i > wrap_rec ? 1 : 0);
+        const uint64_t t = tiles_of(i, &t1);
+        plan->tile_prefix[seg] = (uint32_t)x;
+        if (i == wrap_rec) plan->tile_prefix[seg + 1] = (uint32_t)(x + t1);
+        x += t;
+      }
+    }
+  }
+  const uint64_t nsegs = nrec_total + ((wrap_rec != 0xFFFFFFFFu) ? 1 : 0);
+
+  tdbg[5] = __builtin_amdgcn_s_memtime();
+  engine_trace(15);
+  if (tid == 0) {
+    plan->nsegs = (uint32_t)nsegs;
+    plan->ntiles = (uint32_t)ntiles;
+    plan->tile_prefix[nsegs] = (uint32_t)ntiles;
+    plan->bytes = sent;
+    const uint64_t new_tail = (tail0 + staged) & mask;
+    // the ≤2 RDMA WRITEs of GetWriteRequests(sg_list), ring_buffer.cc:261-330
+    uint64_t seg1 = staged < cap - tail0 ? staged : cap - tail0;
+    grdma_tx_result* r = op.result;
+    r->wr_count = 0;
+    r->wr_off[0] = r->wr_off[1] = r->wr_len[0] = r->wr_len[1] = 0;
+    if (staged > 0) {
+      r->wr_off[0] = tail0;
+      r->wr_len[0] = seg1;
+      r->wr_count = 1;
+      if (tail0 + staged >= cap) {  // a record reached (or crossed) the ring end
+        r->wr_off[1] = 0;
+        r->wr_len[1] = staged - seg1;
+        r->wr_count = 2;
+      }
+    }
+    grdma_plan* wp = op.wire_plan;
+    if (wp != nullptr) {
+      uint32_t ns = 0, nt = 0;
+      if (!direct && staged > 0) {
+        wp->segs[0] = {(uint64_t)(c->peer_ring + tail0), (uint64_t)c->staging, seg1, 0};
+        wp->tile_prefix[0] = 0;
+        nt = (uint32_t)((seg1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+        ns = 1;
+        if (staged > seg1) {
+          wp->segs[1] = {(uint64_t)c->peer_ring, (uint64_t)(c->staging + seg1), staged - seg1, 0};
+          wp->tile_prefix[1] = nt;
+          nt += (uint32_t)((staged - seg1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+          ns = 2;
+        }
+      }
+      wp->nsegs = ns;
+      wp->ntiles = nt;
+      wp->tile_prefix[ns] = nt;
+      wp->bytes = direct ? 0 : staged;
+    }
+    // rdma_flush cursor walk, rdma_bp_posix.cc:480-493
+    uint64_t idx = start + nrec;
+    uint64_t bidx = 0;
+    if (short_pay > 0) bidx = (nrec == 0 ? byte_idx : 0) + short_pay;
+    else if (nrec == 0) bidx = byte_idx;
+    c->remote_tail = new_tail;
+    c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709
+    c->total_written += sent;
+    c->tx_records += nrec_total;
+    if (nrec_total) c->tx_rounds++;
+    if (op.use_cursor) {
+      c->tx_slice_idx = idx;
+      c->tx_byte_idx = bidx;
+      c->tx_remaining = offered - sent;
+    }
+    r->sent = sent;
+    r->records = nrec_total;
+    r->staged = staged;
+    r->partial = sent < offered ? 1 : 0;
+    r->new_remote_tail = new_tail;
+    r->slice_idx = idx;
+    r->byte_idx = bidx;
+    r->done = (idx >= op.nslices) ? 1 : 0;
+    tdbg[6] = __builtin_amdgcn_s_memtime();
+    for (int q = 0; q < 7; q++) r->dbg[q] = tdbg[q];
+    r->dbg[7] = m;
+  }
+  engine_trace(16);
+  if (op.inline_copy) {
+    // small-message path: the planning workgroup moves the bytes itself (its
+    // own plan stores are visible to its waves after the barrier)
+    __syncthreads();
+    run_plan_tiles(plan, tid >> 6, PLAN_THREADS / 64, tid & 63);
+    if (op.wire_plan != nullptr && !direct) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      run_plan_tiles(op.wire_plan, tid >> 6, PLAN_THREADS / 64, tid & 63);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  engine_trace(17);
+  if (tid == 0) {
+    grdma_tx_result* r = op.result;
+    __threadfence_system();
+    engine_trace(18);
+    const uint64_t nxt = r->seq + 1;
+    engine_trace(19);
+    __hip_atomic_store(&r->seq, nxt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    engine_trace(20);
+  }
+}
+
+
+}  // namespace
+#endif  // GRDMA_TX_BODY_H

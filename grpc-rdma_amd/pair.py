@@ -146,6 +146,10 @@ class Pair:
             out.append(dst.raw[:arr[i].len])
         return out, bool(wb.value)
 
+    def set_latency_mode(self, on=True):
+        self.lib.grdma_pair_set_latency_mode.argtypes = [C.c_void_p, C.c_int]
+        check(self.lib.grdma_pair_set_latency_mode(self.h, int(on)))
+
     # -- observability -------------------------------------------------------------
     def state(self):
         st = PairState()
@@ -181,3 +185,19 @@ def poll_pairs(pairs):
     hm = (C.c_uint8 * n)()
     check(load().grdma_poll_pairs(hs, n, rd, hm))
     return [int(x) for x in rd], [bool(x) for x in hm]
+
+
+def pingpong(a, b, req_slices, resp_slices, iters=1000, warmup=100):
+    """Unary ping-pong a -> b -> a (grdma_pingpong).  Slices are host bytes.
+    -> (list of RTT in ns, [phase ns sums: client write, server read, server write, client read])"""
+    lib = load()
+    lib.grdma_pingpong.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Slice), C.c_uint64,
+                                   C.POINTER(Slice), C.c_uint64, C.c_int, C.c_uint64, C.c_uint64,
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    ra, ka, _ = Pair._slices(req_slices)
+    rb, kb, _ = Pair._slices(resp_slices)
+    rtt = (C.c_uint64 * iters)()
+    ph = (C.c_uint64 * 4)()
+    check(lib.grdma_pingpong(a.h, b.h, ra, len(req_slices), rb, len(resp_slices), MEM_HOST, iters,
+                             warmup, rtt, ph))
+    return [int(x) for x in rtt], [int(x) for x in ph]

@@ -151,6 +151,24 @@ void* grdma_pair_arena_device_ptr(grdma_pair* p);
 uint64_t grdma_pair_arena_size(grdma_pair* p);
 int grdma_pair_arena_copy_out(grdma_pair* p, uint64_t off, void* host_dst, uint64_t len);
 
+/* ---- latency path ------------------------------------------------------------------------
+ * Latency mode: every blocking call becomes ONE fused kernel launch (the planning
+ * workgroup also moves the bytes), the host waits on a sequence word in pinned
+ * memory instead of a stream synchronize, and delivered slices are written
+ * straight into a pinned host arena. */
+int grdma_pair_set_latency_mode(grdma_pair* p, int on);
+/* Persistent latency engine: one resident workgroup takes the fused Send / drain
+ * commands of latency-mode pairs from a mailbox in pinned host memory (a PCIe
+ * doorbell read instead of a kernel launch per call).  It retires by itself after
+ * ~1 s without commands; stop it before any device-wide synchronize. */
+int grdma_engine_start(void);
+int grdma_engine_stop(void);
+/* Unary ping-pong (the reference's micro-bench loop, examples/cpp/micro-bench/mb_client.cc):
+ * a = client end, b = server end of a connected link.  rtt_ns has `iters` entries. */
+int grdma_pingpong(grdma_pair* a, grdma_pair* b, const grdma_slice* req, uint64_t nreq,
+                   const grdma_slice* resp, uint64_t nresp, int mem_flags, uint64_t iters,
+                   uint64_t warmup, uint64_t* rtt_ns, uint64_t phase_ns[4]);
+
 /* ---- K3 batched message-ready detection ------------------------------------------- */
 /* HasMessage()/GetReadableSize() for n pairs in one launch (the busy-poll scan
  * of ev_epollex_rdma_bpev_linux.cc:1105-1149 / poller.cc:84).  readable[i] = bytes,

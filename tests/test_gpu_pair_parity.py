@@ -325,3 +325,60 @@ def test_golden_reference_traces_on_gpu(gpu):
         link = _GpuLinkAdapter(gpu, doc["ring_size"], doc["max_sge"])
         replay(doc, link, ring_exact=False, mask=_ring_eq)
         link.a.close(); link.b.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_latency_mode_matches_oracle(gpu, seed):
+    """Latency mode (one fused launch per call, pinned arena, host bytes through the
+    bounce buffer) must be byte-identical to the batched path and the oracle."""
+    g = gpu
+    rng = random.Random(500 + seed)
+    R = rng.choice([4096, 65536, 4 << 20])
+    a, b = mk_link(g, R, 30)
+    a.set_latency_mode(True); b.set_latency_mode(True)
+    o = pyorc.OracleLink(R, 30)
+    sizes = [1, 9, 14, 64, 66, 255, 256, 300, 1000, 5000]
+    for step in range(40):
+        if rng.random() < 0.55:
+            sl = [bytes(rng.getrandbits(8) for _ in range(rng.choice(sizes))) for _ in range(rng.randint(1, 6))]
+            assert a.Send(sl) == o.send(0, sl)           # host bytes
+        else:
+            got, _ = b.endpoint_read(rng.choice([1, 3, 64]))
+            exp = []
+            while len(exp) < len(got) or (not got and not exp):
+                s_, _al = o.endpoint_read(1)
+                if not s_:
+                    break
+                exp.append(s_)
+            assert got == exp
+        assert _ring_eq(b.ring_mem(), o.ring_mem(1))
+        check_state(a, b, o)
+    a.close(); b.close(); o.close()
+
+
+def test_pingpong_unary_64b(gpu):
+    """Config 2 shape: 64-byte unary ping-pong, request and response each framed as
+    chttp2 would ([14-byte inlined header slice][66-byte proto])."""
+    g = gpu
+    from grpc_rdma_amd import h2
+    msg = bytes([0x0A, 64]) + bytes(range(64))
+    items = h2.frame_message(len(msg), 1)
+    slices = [i[1] if i[0] == "inl" else msg[i[1][0]:i[1][0] + i[1][1]] for i in items]
+    assert [len(s) for s in slices] == [14, 66]
+    a, b = mk_link(g, 4 << 20, 30)
+    a.set_latency_mode(True); b.set_latency_mode(True)
+    rtt, ph = g.pingpong(a, b, slices, slices, iters=200, warmup=20)
+    assert len(rtt) == 200 and min(rtt) > 0
+    # state after 220 round trips equals the oracle's
+    o = pyorc.OracleLink(4 << 20, 30)
+    for _ in range(220):
+        for src, dst in ((0, 1), (1, 0)):
+            assert o.send(src, slices) == 80
+            while True:
+                s_, _al = o.endpoint_read(dst)
+                if not s_:
+                    break
+    sa, sb = a.state(), b.state()
+    for k in STATE_KEYS:
+        assert sa[k] == o.state(0)[k] and sb[k] == o.state(1)[k], k
+    assert a.ring_mem() == o.ring_mem(0) and b.ring_mem() == o.ring_mem(1)

@@ -1,0 +1,24 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import grpc_rdma_amd as g
+from grpc_rdma_amd import h2
+g.init(0)
+msg = bytes([0x0A, 64]) + bytes(range(64))
+items = h2.frame_message(len(msg), 1)
+slices = [i[1] if i[0] == "inl" else msg[i[1][0]:i[1][0] + i[1][1]] for i in items]
+import ctypes as C
+lib=g.load()
+for mode in ('engine', True, False):
+    a, b = g.Pair(4 << 20, 30), g.Pair(4 << 20, 30); g.connect_pairs(a, b)
+    a.set_latency_mode(bool(mode)); b.set_latency_mode(bool(mode))
+    if mode == 'engine': assert lib.grdma_engine_start() == 0, lib.grdma_last_error()
+    n = 2000 if mode else 300
+    try:
+        rtt, ph = g.pingpong(a, b, slices, slices, iters=n, warmup=100)
+    except Exception as e:
+        print('FAILED', e); sys.stdout.flush(); os._exit(1)
+    rtt.sort()
+    print("latency_mode=%s p50 %.1f us p95 %.1f p99 %.1f min %.1f | phases us: %s" % (
+        mode, rtt[n // 2] / 1e3, rtt[int(n * .95)] / 1e3, rtt[int(n * .99)] / 1e3, rtt[0] / 1e3,
+        [round(x / n / 1e3, 1) for x in ph]))
+    if mode == 'engine': lib.grdma_engine_stop()
