@@ -1,0 +1,253 @@
+// Endpoint conformance harness for the HIP RDMA_BP endpoint, in the shape of the
+// reference's pluggable endpoint test (test/core/iomgr/endpoint_tests.cc:341-355:
+// multiple_shutdown_test, read_and_write_test with a byte pattern i % 256 checked by
+// the reader, the write = slice = i sweep).  Sizes are scaled to what the blocking
+// C ABI moves in seconds; every case is also byte-checked.
+//
+// Usage: endpoint_conformance <num_bytes> <write_size> <slice_size> <shutdown 0|1>
+//        endpoint_conformance sweep <lo> <hi>
+//        endpoint_conformance multiple_shutdown
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "grdma_endpoint.hpp"
+
+using namespace grdma_core;
+
+#define CHECK(x)                                                          \
+  do {                                                                    \
+    if (!(x)) {                                                           \
+      fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #x, __FILE__, __LINE__); \
+      exit(2);                                                            \
+    }                                                                     \
+  } while (0)
+
+// A miniature ExecCtx: closures scheduled from handlers run from the main loop, so
+// long read/write chains do not recurse (endpoint_tests.cc:147-150).
+static std::deque<std::pair<grpc_closure*, grpc_error_handle>> g_exec_queue;
+static void exec_ctx_run(grpc_closure* c, grpc_error_handle e) { g_exec_queue.emplace_back(c, e); }
+static bool exec_ctx_flush() {
+  bool did = false;
+  while (!g_exec_queue.empty()) {
+    auto item = g_exec_queue.front();
+    g_exec_queue.pop_front();
+    item.first->cb(item.first->cb_arg, item.second);
+    did = true;
+  }
+  return did;
+}
+
+struct fixture {
+  grpc_endpoint* client_ep;
+  grpc_endpoint* server_ep;
+};
+
+static fixture create_fixture() {
+  setenv("GRPC_PLATFORM_TYPE", "RDMA_BP", 1);
+  fixture f;
+  f.client_ep = grpc_endpoint_create(3, "ipv4:127.0.0.1:1", false);
+  f.server_ep = grpc_endpoint_create(4, "ipv4:127.0.0.1:2", true);
+  CHECK(f.client_ep != nullptr && f.server_ep != nullptr);
+  CHECK(grpc_rdma_bp_connect_loopback(f.client_ep, f.server_ep));
+  return f;
+}
+
+// bytes 0,1,2,...,255,0,... across all slices of the stream
+static size_t count_slices(grpc_slice* slices, size_t nslices, int* current_data) {
+  size_t num_bytes = 0;
+  for (size_t i = 0; i < nslices; ++i) {
+    unsigned char* buf = GRPC_SLICE_START_PTR(slices[i]);
+    for (size_t j = 0; j < GRPC_SLICE_LENGTH(slices[i]); ++j) {
+      CHECK(buf[j] == *current_data);
+      *current_data = (*current_data + 1) % 256;
+    }
+    num_bytes += GRPC_SLICE_LENGTH(slices[i]);
+  }
+  return num_bytes;
+}
+
+static void fill_buffer(grpc_slice_buffer* out, size_t num_bytes, size_t slice_size, uint8_t* current) {
+  grpc_slice_buffer_reset_and_unref(out);
+  while (num_bytes > 0) {
+    const size_t n = num_bytes < slice_size ? num_bytes : slice_size;
+    grpc_slice s = grpc_slice_malloc(n);
+    unsigned char* buf = GRPC_SLICE_START_PTR(s);
+    for (size_t j = 0; j < n; ++j) buf[j] = (*current)++;
+    grpc_slice_buffer_add_indexed(out, s);
+    num_bytes -= n;
+  }
+}
+
+struct read_and_write_test_state {
+  grpc_endpoint* read_ep;
+  grpc_endpoint* write_ep;
+  size_t target_bytes, bytes_read, current_write_size, bytes_written, slice_size;
+  int current_read_data;
+  uint8_t current_write_data;
+  int read_done, write_done;
+  grpc_slice_buffer incoming, outgoing;
+  grpc_closure done_read, done_write, read_scheduler, write_scheduler;
+};
+
+static void read_scheduler(void* data, grpc_error_handle) {
+  auto* st = static_cast<read_and_write_test_state*>(data);
+  grpc_endpoint_read(st->read_ep, &st->incoming, &st->done_read, /*urgent=*/false);
+}
+
+static void read_handler(void* data, grpc_error_handle error) {
+  auto* st = static_cast<read_and_write_test_state*>(data);
+  st->bytes_read += count_slices(st->incoming.slices, st->incoming.count, &st->current_read_data);
+  if (st->bytes_read == st->target_bytes || error != GRPC_ERROR_NONE) {
+    st->read_done = 1 + (error == GRPC_ERROR_NONE);
+  } else {
+    exec_ctx_run(&st->read_scheduler, GRPC_ERROR_NONE);
+  }
+}
+
+static void write_scheduler(void* data, grpc_error_handle) {
+  auto* st = static_cast<read_and_write_test_state*>(data);
+  grpc_endpoint_write(st->write_ep, &st->outgoing, &st->done_write, nullptr);
+}
+
+static void write_handler(void* data, grpc_error_handle error) {
+  auto* st = static_cast<read_and_write_test_state*>(data);
+  if (error == GRPC_ERROR_NONE) {
+    st->bytes_written += st->current_write_size;
+    if (st->target_bytes - st->bytes_written < st->current_write_size)
+      st->current_write_size = st->target_bytes - st->bytes_written;
+    if (st->current_write_size != 0) {
+      fill_buffer(&st->outgoing, st->current_write_size, st->slice_size, &st->current_write_data);
+      exec_ctx_run(&st->write_scheduler, GRPC_ERROR_NONE);
+      return;
+    }
+  }
+  st->write_done = 1 + (error == GRPC_ERROR_NONE);
+}
+
+static void read_and_write_test(size_t num_bytes, size_t write_size, size_t slice_size, bool shutdown) {
+  fixture f = create_fixture();
+  read_and_write_test_state st;
+  st.read_ep = f.client_ep;
+  st.write_ep = f.server_ep;
+  st.target_bytes = num_bytes;
+  st.bytes_read = 0;
+  st.current_write_size = write_size;
+  st.bytes_written = 0;
+  st.slice_size = slice_size;
+  st.read_done = st.write_done = 0;
+  st.current_read_data = 0;
+  st.current_write_data = 0;
+  GRPC_CLOSURE_INIT(&st.read_scheduler, read_scheduler, &st, nullptr);
+  GRPC_CLOSURE_INIT(&st.done_read, read_handler, &st, nullptr);
+  GRPC_CLOSURE_INIT(&st.write_scheduler, write_scheduler, &st, nullptr);
+  GRPC_CLOSURE_INIT(&st.done_write, write_handler, &st, nullptr);
+  grpc_slice_buffer_init(&st.outgoing);
+  grpc_slice_buffer_init(&st.incoming);
+
+  // start by pretending an initial write completed (same handler for every iteration)
+  st.bytes_written -= st.current_write_size;
+  write_handler(&st, GRPC_ERROR_NONE);
+  exec_ctx_flush();
+  grpc_endpoint_read(st.read_ep, &st.incoming, &st.done_read, /*urgent=*/false);
+  if (shutdown) {
+    grpc_endpoint_shutdown(st.read_ep, GRPC_ERROR_CREATE_FROM_STATIC_STRING("Test Shutdown"));
+    grpc_endpoint_shutdown(st.write_ep, GRPC_ERROR_CREATE_FROM_STATIC_STRING("Test Shutdown"));
+  }
+  exec_ctx_flush();
+  long spins = 0;
+  while (!st.read_done || !st.write_done) {  // the pollset_work loop
+    int ran = grdma_endpoint_poll(st.read_ep) + grdma_endpoint_poll(st.write_ep);
+    if (exec_ctx_flush()) ran++;
+    if (!ran && ++spins > 2000000) CHECK(!"endpoint made no progress");
+    if (ran) spins = 0;
+  }
+  if (!shutdown) {
+    CHECK(st.read_done == 2 && st.write_done == 2);
+    CHECK(st.bytes_read == num_bytes && st.bytes_written == num_bytes);
+  } else {
+    CHECK(st.read_done >= 1 && st.write_done >= 1);
+  }
+  grpc_endpoint_shutdown(st.read_ep, GRPC_ERROR_CREATE_FROM_STATIC_STRING("test done"));
+  grpc_endpoint_shutdown(st.write_ep, GRPC_ERROR_CREATE_FROM_STATIC_STRING("test done"));
+  grpc_endpoint_destroy(st.read_ep);
+  grpc_endpoint_destroy(st.write_ep);
+  grpc_slice_buffer_destroy(&st.outgoing);
+  grpc_slice_buffer_destroy(&st.incoming);
+  printf("read_and_write_test num_bytes=%zu write_size=%zu slice_size=%zu shutdown=%d: ok\n", num_bytes,
+         write_size, slice_size, (int)shutdown);
+}
+
+static int g_fail_count = 0;
+static void inc_on_failure(void*, grpc_error_handle error) { g_fail_count += (error != GRPC_ERROR_NONE); }
+
+// endpoint_tests.cc multiple_shutdown_test: a pending read fails once on shutdown;
+// reads and writes after shutdown fail immediately; shutting down twice is harmless.
+static void multiple_shutdown_test() {
+  fixture f = create_fixture();
+  grpc_slice_buffer slice_buffer;
+  grpc_slice_buffer_init(&slice_buffer);
+  grpc_closure cb;
+  GRPC_CLOSURE_INIT(&cb, inc_on_failure, nullptr, nullptr);
+  grpc_endpoint_read(f.client_ep, &slice_buffer, &cb, false);
+  CHECK(g_fail_count == 0);
+  grpc_endpoint_shutdown(f.client_ep, GRPC_ERROR_CREATE_FROM_STATIC_STRING("Test Shutdown"));
+  CHECK(g_fail_count == 1);
+  grpc_endpoint_read(f.client_ep, &slice_buffer, &cb, false);
+  CHECK(g_fail_count == 2);
+  grpc_slice_buffer_add(&slice_buffer, grpc_slice_from_copied_buffer("a", 1));
+  grpc_endpoint_write(f.client_ep, &slice_buffer, &cb, nullptr);
+  CHECK(g_fail_count == 3);
+  grpc_endpoint_shutdown(f.client_ep, GRPC_ERROR_CREATE_FROM_STATIC_STRING("Test Shutdown"));
+  CHECK(g_fail_count == 3);
+  grpc_slice_buffer_destroy(&slice_buffer);
+  grpc_endpoint_destroy(f.client_ep);
+  grpc_endpoint_destroy(f.server_ep);
+  printf("multiple_shutdown_test: ok\n");
+}
+
+// half-close: the peer disconnects, a pending read completes with "Pair closed" /
+// UNAVAILABLE (rdma_bp_posix.cc:220-228, 86-96)
+static int g_status = -1;
+static std::string g_desc;
+static void record_error(void*, grpc_error_handle e) {
+  if (e) { g_status = e->grpc_status; g_desc = e->description; }
+}
+static void half_close_test() {
+  fixture f = create_fixture();
+  grpc_slice_buffer in;
+  grpc_slice_buffer_init(&in);
+  grpc_closure cb;
+  GRPC_CLOSURE_INIT(&cb, record_error, nullptr, nullptr);
+  grpc_endpoint_read(f.client_ep, &in, &cb, false);
+  CHECK(grdma_endpoint_poll(f.client_ep) == 0);
+  grpc_endpoint_destroy(f.server_ep);  // Disconnect(): peer_exit = 1 in my status buffer
+  int ran = 0;
+  for (int i = 0; i < 100 && !ran; i++) ran = grdma_endpoint_poll(f.client_ep);
+  CHECK(ran == 1 && g_status == GRPC_STATUS_UNAVAILABLE && g_desc == "Pair closed");
+  grpc_slice_buffer_destroy(&in);
+  grpc_endpoint_destroy(f.client_ep);
+  printf("half_close_test: ok\n");
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "multiple_shutdown")) {
+    multiple_shutdown_test();
+    half_close_test();
+    return 0;
+  }
+  if (argc >= 4 && !strcmp(argv[1], "sweep")) {  // endpoint_tests.cc:350-352
+    for (size_t i = (size_t)atol(argv[2]); i < (size_t)atol(argv[3]); i = (i < 5 ? i + 1 : i * 5 / 4))
+      read_and_write_test(40320, i, i, false);
+    return 0;
+  }
+  if (argc >= 5) {
+    read_and_write_test((size_t)atol(argv[1]), (size_t)atol(argv[2]), (size_t)atol(argv[3]), atoi(argv[4]) != 0);
+    return 0;
+  }
+  fprintf(stderr, "usage: see the file header\n");
+  return 64;
+}
