@@ -47,6 +47,7 @@ class Workload:
     """B framed messages laid out in HBM + the slice list of the endpoint_write."""
 
     def __init__(self, g, n_msgs, payload=MIB, max_frame=16384, stream_id=1):
+        self.payload = payload
         from grpc_rdma_amd import h2
         self.g = g
         self.n_msgs = n_msgs
@@ -153,6 +154,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-small-ring", action="store_true", help="skip the extra 4 MiB-ring run")
     ap.add_argument("--no-rtt", action="store_true", help="skip the 64 B ping-pong leg")
+    ap.add_argument("--conns", type=int, default=32,
+                    help="connections per GPU in the multi-connection leg (BASELINE configs[3]: 32); 1 = skip")
     args = ap.parse_args()
 
     import torch
@@ -172,6 +175,14 @@ def main():
 
     flags = 2 if args.wire == "direct" else 0
     wl = Workload(g, args.msgs)
+    workloads = {(args.msgs, MIB): [wl]}
+
+    def get_workloads(n_links, msgs_per_link, payload):
+        key = (msgs_per_link, payload)
+        lst = workloads.setdefault(key, [])
+        while len(lst) < n_links:
+            lst.append(Workload(g, msgs_per_link, payload))
+        return lst[:n_links]
 
     def barrier():
         torch.cuda.synchronize()
@@ -179,24 +190,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(ring_kb, steps, warmup, verify, instrument):
-        """One connection with a ring of ring_kb KiB: calibrate the number of rounds,
+    def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB):
+        """n_links connections with rings of ring_kb KiB: calibrate the number of rounds,
         capture the graph, time `steps` passes, verify, optionally instrument."""
         ring = ring_kb * 1024
-        tx, rx = g.Pair(ring, args.max_sge, flags), g.Pair(ring, args.max_sge, flags)
-        g.connect_pairs(tx, rx)
-        dst_cap = wl.N + 16 * (len(wl.lens) * 2 + 64) + 4096
-        dst = g.DeviceBuffer(nbytes=dst_cap)
-        slices_cap = len(wl.lens) * 2 + 64
-        est_rounds = max(8, 4 * (wl.E // (ring // 2) + 2), 2 * (len(wl.lens) // min(args.max_sge, 4095) + 2))
-        job = gs.StreamJob(tx, rx, wl.sge, dst.ptr, dst_cap, slices_cap, est_rounds)
+        wls = get_workloads(n_links, msgs_per_link or args.msgs, payload)
+        links, keep = [], []
+        for w in wls:
+            tx, rx = g.Pair(ring, args.max_sge, flags), g.Pair(ring, args.max_sge, flags)
+            g.connect_pairs(tx, rx)
+            dst_cap = w.N + 16 * (len(w.lens) * 2 + 64) + 4096
+            dst = g.DeviceBuffer(nbytes=dst_cap)
+            links.append((tx, rx, w.sge, dst.ptr, dst_cap, len(w.lens) * 2 + 64))
+            keep.append((tx, rx, dst, dst_cap, w))
+        w0 = wls[0]
+        est_rounds = max(8, 4 * (w0.E // (ring // 2) + 2), 2 * (len(w0.lens) // min(args.max_sge, 4095) + 2))
+        job = gs.MultiStreamJob(links, est_rounds)
         r = job.run(gs.RUN_EAGER)                  # calibration: how many rounds are needed
+        total_n = sum(w.N for w in wls)
         assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
-            r.bytes_delivered, wl.N)
+            r.bytes_delivered, total_n)
         rounds = int(max(r.tx_rounds, r.rx_rounds))
         job.set_rounds(rounds)
         r = job.run(gs.RUN_GRAPH)                  # capture + first replay
-        assert r.done and r.bytes_delivered == wl.N
+        assert r.done and r.bytes_delivered == total_n
         for _ in range(warmup):
             job.launch()
         job.sync()
@@ -209,16 +226,21 @@ def main():
         elapsed = time.perf_counter() - t0
         elapsed = grp.max(elapsed)
         barrier()
-        out = {"elapsed": elapsed, "rounds": rounds, "verified": None, "classes": None}
+        out = {"elapsed": elapsed, "rounds": rounds, "verified": None, "classes": None,
+               "user_bytes": sum(w.user_bytes for w in wls), "N": total_n,
+               "E": sum(w.E for w in wls)}
         if verify:  # correctness of what the timed region produced (untimed)
             r = job.run(gs.RUN_GRAPH)
-            assert r.done and r.bytes_delivered == wl.N and r.bytes_sent == wl.N
-            ds = job.delivered_slices()
-            got = dst.read(dst_cap)
-            stream = b"".join(got[o:o + n] for o, n in ds)
-            exp = b"".join(wl.expected_wire(i) for i in range(wl.n_msgs))
-            assert stream == exp, "delivered byte stream differs from the framed messages"
-            assert rx.ring_mem() == bytes(ring), "ring not zero after the drain"
+            assert r.done and r.bytes_delivered == total_n and r.bytes_sent == total_n
+            for li, (tx, rx, dst, dst_cap, w) in enumerate(keep):
+                if li not in (0, len(keep) - 1):
+                    continue                       # first and last link, byte for byte
+                ds = job.delivered_slices(li)
+                got = dst.read(dst_cap)
+                stream = b"".join(got[o:o + n] for o, n in ds)
+                exp = b"".join(w.expected_wire(i) for i in range(w.n_msgs))
+                assert stream == exp, "delivered byte stream differs from the framed messages"
+                assert rx.ring_mem() == bytes(ring), "ring not zero after the drain"
             out["verified"] = True
         if instrument:  # per-kernel time, HIP events on the launch stream
             inst = None
@@ -232,7 +254,8 @@ def main():
                                      "us_per_launch": 1e3 * inst.ms_class[i] / n}
             out["classes"] = classes
         job.close()
-        tx.close(); rx.close(); dst.free()
+        for tx, rx, dst, _c, _w in keep:
+            tx.close(); rx.close(); dst.free()
         return out
 
     head = measure(args.ring_kb, args.steps, args.warmup, not args.no_verify, True)
@@ -292,6 +315,16 @@ def main():
         sm_steps = max(2, args.steps // 2)
         out["value_ring4096"] = round(wl.user_bytes * sm_steps * world / small["elapsed"] / (1 << 30), 3)
         out["rounds_per_step_ring4096"] = small["rounds"]
+    if args.conns > 1:
+        # BASELINE.json configs[3] shape: many connections per GPU, 64 KiB messages, reference-default
+        # 4 MiB rings; one op per connection in every launch
+        per = max(8, 2048 // args.conns)
+        mc = measure(4096, max(2, args.steps // 2), 1, not args.no_verify, False, n_links=args.conns,
+                     msgs_per_link=per, payload=64 * 1024)
+        out["value_conns%d_64KiB_ring4096" % args.conns] = round(
+            mc["user_bytes"] * max(2, args.steps // 2) * world / mc["elapsed"] / (1 << 30), 3)
+        out["config"]["multi_connection_leg"] = "%d connections x %d x 64 KiB messages per step, 4 MiB rings, %d rounds" % (
+            args.conns, per, mc["rounds"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, ring, min(args.max_sge, 4095))
     elif rank == 0:

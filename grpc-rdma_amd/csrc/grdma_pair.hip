@@ -7,6 +7,7 @@
 // src/core/lib/iomgr/rdma_bp_posix.cc (endpoint read/write loops).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -814,15 +815,10 @@ int grdma_device_synchronize(void) {
 }  // extern "C"
 
 // ---- device-resident streaming job -------------------------------------------------
-struct grdma_job_ctl {  // pinned, device-visible
-  grdma_tx_op txop[2];  // [0] first round (cursor reset), [1] later rounds
-  grdma_rx_op rxop[2];
-  grdma_tx_result txres;
-  grdma_rx_result rxres;
-  const grdma_plan* plan_ptrs[4];
-};
-
-struct grdma_stream_job {
+// n independent links (connections) advance in lock step: every launch carries one
+// op per link (grid.y = n), so 32 connections with 4 MiB rings fill the chip the way
+// one connection with a 128 MiB ring would.
+struct grdma_job_link {
   grdma_pair* tx = nullptr;
   grdma_pair* rx = nullptr;
   grdma_sge* d_sges = nullptr;
@@ -831,21 +827,36 @@ struct grdma_stream_job {
   uint64_t slices_cap = 0;
   uint8_t* dst = nullptr;
   uint64_t dst_cap = 0;
+};
+
+struct grdma_stream_job {
+  std::vector<grdma_job_link> links;
   uint64_t rounds = 0;
-  grdma_job_ctl* ctl = nullptr;     // device memory: the kernels read it
-  grdma_job_ctl* h_ctl = nullptr;   // host mirror used to build / read it back
+  // device control block: txop[2][n], rxop[2][n], results[n], plan pointer arrays
+  uint8_t* d_ctl = nullptr;
+  grdma_tx_op* d_txop = nullptr;      // [2 * n]
+  grdma_rx_op* d_rxop = nullptr;      // [2 * n]
+  grdma_tx_result* d_txres = nullptr; // [n]
+  grdma_rx_result* d_rxres = nullptr; // [n]
+  const grdma_plan** d_plans = nullptr;  // [3 * n]: gather, wire, scatter
   hipGraphExec_t exec = nullptr;
   uint64_t exec_rounds = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> kev;
+  hipStream_t stream = nullptr;
+  bool direct = false;
+  uint64_t max_ring = 0;
 };
 
 namespace {
 
 int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
-  const uint32_t tx_blocks = copy_blocks_for(j->tx->ring_size / 2);
-  const uint32_t rx_blocks = copy_blocks_for(j->rx->ring_size);
-  const bool direct = (j->tx->flags & GRDMA_WIRE_DIRECT) != 0;
+  const uint32_t n = (uint32_t)j->links.size();
+  const uint32_t tx_blocks = copy_blocks_for(j->max_ring / 2);
+  const uint32_t rx_blocks = copy_blocks_for(j->max_ring);
+  // keep the grid around 2048 workgroups in total
+  const uint32_t txb = std::max<uint32_t>(1, std::min<uint32_t>(tx_blocks, 2048 / n + 1));
+  const uint32_t rxb = std::max<uint32_t>(1, std::min<uint32_t>(rx_blocks, 2048 / n + 1));
   size_t e = 0;
   auto mark = [&]() -> int {
     if (!instrument) return 0;
@@ -860,15 +871,15 @@ int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
   if (int rc = mark()) return rc;
   for (uint64_t r = 0; r < j->rounds; r++) {
     const int k = r == 0 ? 0 : 1;
-    HIP_TRY(grdma_launch_tx_plan(&j->ctl->txop[k], 1, s));
+    HIP_TRY(grdma_launch_tx_plan(j->d_txop + k * n, n, s));
     if (int rc = mark()) return rc;
-    HIP_TRY(grdma_launch_copy(&j->ctl->plan_ptrs[0], 1, tx_blocks, s));
+    HIP_TRY(grdma_launch_copy(j->d_plans, n, txb, s));
     if (int rc = mark()) return rc;
-    if (!direct) HIP_TRY(grdma_launch_copy(&j->ctl->plan_ptrs[1], 1, tx_blocks, s));
+    if (!j->direct) HIP_TRY(grdma_launch_copy(j->d_plans + n, n, txb, s));
     if (int rc = mark()) return rc;
-    HIP_TRY(grdma_launch_rx_plan(&j->ctl->rxop[k], 1, s));
+    HIP_TRY(grdma_launch_rx_plan(j->d_rxop + k * n, n, s));
     if (int rc = mark()) return rc;
-    HIP_TRY(grdma_launch_rx_apply(&j->ctl->rxop[k], 1, rx_blocks, s));
+    HIP_TRY(grdma_launch_rx_apply(j->d_rxop + k * n, n, rxb, s));
     if (int rc = mark()) return rc;
   }
   return 0;
@@ -878,70 +889,97 @@ int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
 
 extern "C" {
 
-grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,
-                                          const grdma_slice* slices, uint64_t count,
-                                          void* rx_dst, uint64_t rx_dst_cap,
-                                          uint64_t slices_cap, uint64_t max_rounds) {
+grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* tx,
+                                                grdma_pair* const* rx, const grdma_slice* slices,
+                                                const uint64_t* counts, void* const* rx_dsts,
+                                                const uint64_t* rx_dst_caps,
+                                                const uint64_t* slices_caps, uint64_t max_rounds) {
   if (require_ctx()) return nullptr;
-  if (!tx || !rx || tx->peer != rx || !slices || !count || !rx_dst) {
-    fail(GRDMA_ERR_INVALID, "stream job needs two connected pairs, slices and a destination");
+  if (!n || !tx || !rx || !slices || !counts || !rx_dsts || !rx_dst_caps || !slices_caps) {
+    fail(GRDMA_ERR_INVALID, "stream job: null argument");
     return nullptr;
   }
   grdma_stream_job* j = new grdma_stream_job();
-  j->tx = tx;
-  j->rx = rx;
-  j->count = count;
-  j->dst = static_cast<uint8_t*>(rx_dst);
-  j->dst_cap = rx_dst_cap;
-  j->slices_cap = slices_cap;
   j->rounds = max_rounds;
-  bool ok = hipMalloc((void**)&j->d_sges, sizeof(grdma_sge) * count) == hipSuccess &&
-            hipMalloc((void**)&j->d_slices, sizeof(grdma_slice_out) * slices_cap) == hipSuccess &&
-            hipMalloc((void**)&j->ctl, sizeof(grdma_job_ctl)) == hipSuccess &&
-            hipEventCreate(&j->ev0) == hipSuccess && hipEventCreate(&j->ev1) == hipSuccess;
+  j->stream = tx[0]->stream;
+  j->direct = (tx[0]->flags & GRDMA_WIRE_DIRECT) != 0;
+  j->links.resize(n);
+  bool ok = hipEventCreate(&j->ev0) == hipSuccess && hipEventCreate(&j->ev1) == hipSuccess;
+  uint64_t off = 0;
+  for (uint32_t i = 0; i < n && ok; i++) {
+    grdma_job_link& l = j->links[i];
+    if (!tx[i] || !rx[i] || tx[i]->peer != rx[i] || !counts[i] || !rx_dsts[i] ||
+        tx[i]->stream != j->stream || ((tx[i]->flags & GRDMA_WIRE_DIRECT) != 0) != j->direct) {
+      fail(GRDMA_ERR_INVALID, "stream job link %u: needs two connected pairs on the shared stream", i);
+      ok = false;
+      break;
+    }
+    l.tx = tx[i];
+    l.rx = rx[i];
+    l.count = counts[i];
+    l.dst = static_cast<uint8_t*>(rx_dsts[i]);
+    l.dst_cap = rx_dst_caps[i];
+    l.slices_cap = slices_caps[i];
+    if (tx[i]->ring_size > j->max_ring) j->max_ring = tx[i]->ring_size;
+    ok = hipMalloc((void**)&l.d_sges, sizeof(grdma_sge) * l.count) == hipSuccess &&
+         hipMalloc((void**)&l.d_slices, sizeof(grdma_slice_out) * l.slices_cap) == hipSuccess;
+    if (!ok) break;
+    std::vector<grdma_sge> tmp(l.count);
+    for (uint64_t q = 0; q < l.count; q++) {
+      tmp[q].ptr = static_cast<const uint8_t*>(slices[off + q].ptr);
+      tmp[q].len = slices[off + q].len;
+    }
+    off += l.count;
+    ok = hipMemcpy(l.d_sges, tmp.data(), sizeof(grdma_sge) * l.count, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  const size_t sz_tx = sizeof(grdma_tx_op) * 2 * n, sz_rx = sizeof(grdma_rx_op) * 2 * n;
+  const size_t sz_txr = sizeof(grdma_tx_result) * n, sz_rxr = sizeof(grdma_rx_result) * n;
+  const size_t sz_pl = sizeof(grdma_plan*) * 3 * n;
+  if (ok) ok = hipMalloc((void**)&j->d_ctl, sz_tx + sz_rx + sz_txr + sz_rxr + sz_pl) == hipSuccess;
   if (!ok) {
-    fail(GRDMA_ERR_HIP, "stream job allocation failed");
+    if (g_err.empty()) fail(GRDMA_ERR_HIP, "stream job allocation failed");
     grdma_stream_job_destroy(j);
     return nullptr;
   }
-  std::vector<grdma_sge> tmp(count);
-  for (uint64_t i = 0; i < count; i++) {
-    tmp[i].ptr = static_cast<const uint8_t*>(slices[i].ptr);
-    tmp[i].len = slices[i].len;
+  j->d_txop = reinterpret_cast<grdma_tx_op*>(j->d_ctl);
+  j->d_rxop = reinterpret_cast<grdma_rx_op*>(j->d_ctl + sz_tx);
+  j->d_txres = reinterpret_cast<grdma_tx_result*>(j->d_ctl + sz_tx + sz_rx);
+  j->d_rxres = reinterpret_cast<grdma_rx_result*>(j->d_ctl + sz_tx + sz_rx + sz_txr);
+  j->d_plans = reinterpret_cast<const grdma_plan**>(j->d_ctl + sz_tx + sz_rx + sz_txr + sz_rxr);
+  std::vector<uint8_t> host(sz_tx + sz_rx + sz_txr + sz_rxr + sz_pl, 0);
+  auto* h_tx = reinterpret_cast<grdma_tx_op*>(host.data());
+  auto* h_rx = reinterpret_cast<grdma_rx_op*>(host.data() + sz_tx);
+  auto** h_pl = reinterpret_cast<const grdma_plan**>(host.data() + sz_tx + sz_rx + sz_txr + sz_rxr);
+  for (int k = 0; k < 2; k++)
+    for (uint32_t i = 0; i < n; i++) {
+      const grdma_job_link& l = j->links[i];
+      grdma_tx_op& t = h_tx[k * n + i];
+      t.conn = l.tx->d_conn;
+      t.slices = l.d_sges;
+      t.nslices = l.count;
+      t.plan = l.tx->d_txplan;
+      t.wire_plan = l.tx->d_wireplan;
+      t.result = &j->d_txres[i];
+      t.use_cursor = k == 0 ? 2 : 1;
+      grdma_rx_op& r = h_rx[k * n + i];
+      r.conn = l.rx->d_conn;
+      r.plan = l.rx->d_rxplan;
+      r.result = &j->d_rxres[i];
+      r.slices = l.d_slices;
+      r.arena = l.dst;
+      r.arena_cap = l.dst_cap;
+      r.max_reads = GRDMA_MAX_SLICES;
+      r.raw_cap = 0;
+      r.append = k == 0 ? 2 : 1;
+      r.slices_cap = l.slices_cap;
+    }
+  for (uint32_t i = 0; i < n; i++) {
+    h_pl[i] = j->links[i].tx->d_txplan;
+    h_pl[n + i] = j->links[i].tx->d_wireplan;
+    h_pl[2 * n + i] = j->links[i].rx->d_rxplan;
   }
-  if (hipMemcpy(j->d_sges, tmp.data(), sizeof(grdma_sge) * count, hipMemcpyHostToDevice) !=
-      hipSuccess) {
-    fail(GRDMA_ERR_HIP, "slice table upload failed");
-    grdma_stream_job_destroy(j);
-    return nullptr;
-  }
-  j->h_ctl = new grdma_job_ctl();
-  memset(j->h_ctl, 0, sizeof(*j->h_ctl));
-  for (int k = 0; k < 2; k++) {
-    grdma_tx_op& t = j->h_ctl->txop[k];
-    t.conn = tx->d_conn;
-    t.slices = j->d_sges;
-    t.nslices = count;
-    t.plan = tx->d_txplan;
-    t.wire_plan = tx->d_wireplan;
-    t.result = &j->ctl->txres;
-    t.use_cursor = k == 0 ? 2 : 1;
-    grdma_rx_op& r = j->h_ctl->rxop[k];
-    r.conn = rx->d_conn;
-    r.plan = rx->d_rxplan;
-    r.result = &j->ctl->rxres;
-    r.slices = j->d_slices;
-    r.arena = j->dst;
-    r.arena_cap = rx_dst_cap;
-    r.max_reads = GRDMA_MAX_SLICES;
-    r.raw_cap = 0;
-    r.append = k == 0 ? 2 : 1;
-    r.slices_cap = slices_cap;
-  }
-  j->h_ctl->plan_ptrs[0] = tx->d_txplan;
-  j->h_ctl->plan_ptrs[1] = tx->d_wireplan;
-  j->h_ctl->plan_ptrs[2] = rx->d_rxplan;
-  if (hipMemcpy(j->ctl, j->h_ctl, sizeof(grdma_job_ctl), hipMemcpyHostToDevice) != hipSuccess) {
+  // the scatter plans are addressed through the rx ops; the plan pointer array is for k_copy
+  if (hipMemcpy(j->d_ctl, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) {
     fail(GRDMA_ERR_HIP, "job control block upload failed");
     grdma_stream_job_destroy(j);
     return nullptr;
@@ -949,17 +987,26 @@ grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,
   return j;
 }
 
+grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,
+                                          const grdma_slice* slices, uint64_t count,
+                                          void* rx_dst, uint64_t rx_dst_cap,
+                                          uint64_t slices_cap, uint64_t max_rounds) {
+  return grdma_stream_job_create_multi(1, &tx, &rx, slices, &count, &rx_dst, &rx_dst_cap,
+                                       &slices_cap, max_rounds);
+}
+
 void grdma_stream_job_destroy(grdma_stream_job* j) {
   if (!j) return;
-  if (j->tx && j->tx->stream) hipStreamSynchronize(j->tx->stream);
+  if (j->stream) hipStreamSynchronize(j->stream);
   if (j->exec) hipGraphExecDestroy(j->exec);
   for (hipEvent_t e : j->kev) hipEventDestroy(e);
   if (j->ev0) hipEventDestroy(j->ev0);
   if (j->ev1) hipEventDestroy(j->ev1);
-  hipFree(j->d_sges);
-  hipFree(j->d_slices);
-  if (j->ctl) hipFree(j->ctl);
-  delete j->h_ctl;
+  for (auto& l : j->links) {
+    hipFree(l.d_sges);
+    hipFree(l.d_slices);
+  }
+  hipFree(j->d_ctl);
   delete j;
 }
 
@@ -972,10 +1019,13 @@ int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds) {
 int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out) {
   if (int rc = require_ctx()) return rc;
   if (!j || !out) return fail(GRDMA_ERR_INVALID, "null argument");
-  hipStream_t s = j->tx->stream;
-  grdma_conn c0t, c0r;
-  if (int rc = fetch_conn(j->tx, &c0t)) return rc;
-  if (int rc = fetch_conn(j->rx, &c0r)) return rc;
+  hipStream_t s = j->stream;
+  const size_t n = j->links.size();
+  std::vector<grdma_conn> c0t(n), c0r(n), c1t(n), c1r(n);
+  for (size_t i = 0; i < n; i++) {
+    if (int rc = fetch_conn(j->links[i].tx, &c0t[i])) return rc;
+    if (int rc = fetch_conn(j->links[i].rx, &c0r[i])) return rc;
+  }
   memset(out, 0, sizeof(*out));
   if (mode == GRDMA_RUN_GRAPH) {
     if (!j->exec || j->exec_rounds != j->rounds) {
@@ -1004,36 +1054,39 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
   HIP_TRY(hipEventElapsedTime(&ms, j->ev0, j->ev1));
   out->ms_total = ms;
   if (mode == GRDMA_RUN_INSTRUMENTED) {
-    const bool direct = (j->tx->flags & GRDMA_WIRE_DIRECT) != 0;
     size_t e = 0;
     for (uint64_t r = 0; r < j->rounds; r++)
       for (int cls = 0; cls < 5; cls++, e++) {
         float t = 0;
         HIP_TRY(hipEventElapsedTime(&t, j->kev[e], j->kev[e + 1]));
-        if (cls == 2 && direct) continue;
+        if (cls == 2 && j->direct) continue;
         out->ms_class[cls] += t;
         out->launches_class[cls]++;
       }
   }
-  grdma_conn c1t, c1r;
-  if (int rc = fetch_conn(j->tx, &c1t)) return rc;
-  if (int rc = fetch_conn(j->rx, &c1r)) return rc;
-  out->bytes_sent = c1t.total_written - c0t.total_written;
-  out->bytes_delivered = c1r.total_read - c0r.total_read;
-  out->slices_delivered = c1r.rx_slice_idx;
-  out->tx_rounds = c1t.tx_rounds - c0t.tx_rounds;
-  out->rx_rounds = c1r.rx_rounds - c0r.rx_rounds;
-  out->tx_records = c1t.tx_records - c0t.tx_records;
-  out->rx_records = c1r.rx_records - c0r.rx_records;
-  out->done = (c1t.tx_slice_idx >= j->count && out->bytes_delivered == out->bytes_sent) ? 1 : 0;
+  out->done = 1;
+  for (size_t i = 0; i < n; i++) {
+    if (int rc = fetch_conn(j->links[i].tx, &c1t[i])) return rc;
+    if (int rc = fetch_conn(j->links[i].rx, &c1r[i])) return rc;
+    const uint64_t sent = c1t[i].total_written - c0t[i].total_written;
+    const uint64_t deliv = c1r[i].total_read - c0r[i].total_read;
+    out->bytes_sent += sent;
+    out->bytes_delivered += deliv;
+    out->slices_delivered += c1r[i].rx_slice_idx;
+    out->tx_rounds = std::max<uint64_t>(out->tx_rounds, c1t[i].tx_rounds - c0t[i].tx_rounds);
+    out->rx_rounds = std::max<uint64_t>(out->rx_rounds, c1r[i].rx_rounds - c0r[i].rx_rounds);
+    out->tx_records += c1t[i].tx_records - c0t[i].tx_records;
+    out->rx_records += c1r[i].rx_records - c0r[i].rx_records;
+    if (!(c1t[i].tx_slice_idx >= j->links[i].count && deliv == sent)) out->done = 0;
+  }
   return 0;
 }
 
 int grdma_stream_job_debug(grdma_stream_job* j, uint64_t* tx_dbg, uint64_t* rx_dbg) {
   if (!j) return -1;
-  hipStreamSynchronize(j->tx->stream);
-  hipMemcpy(tx_dbg, j->ctl->txres.dbg, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost);
-  hipMemcpy(rx_dbg, j->ctl->rxres.dbg, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost);
+  hipStreamSynchronize(j->stream);
+  hipMemcpy(tx_dbg, j->d_txres[0].dbg, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost);
+  hipMemcpy(rx_dbg, j->d_rxres[0].dbg, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost);
   return 0;
 }
 
@@ -1042,26 +1095,31 @@ int grdma_stream_job_launch(grdma_stream_job* j) {
   if (!j) return fail(GRDMA_ERR_INVALID, "null job");
   if (!j->exec || j->exec_rounds != j->rounds)
     return fail(GRDMA_ERR_INVALID, "run the job once in GRDMA_RUN_GRAPH mode before launching it");
-  HIP_TRY(hipGraphLaunch(j->exec, j->tx->stream));
+  HIP_TRY(hipGraphLaunch(j->exec, j->stream));
   return 0;
 }
 
 int grdma_stream_job_sync(grdma_stream_job* j) {
   if (int rc = require_ctx()) return rc;
   if (!j) return fail(GRDMA_ERR_INVALID, "null job");
-  HIP_TRY(hipStreamSynchronize(j->tx->stream));
+  HIP_TRY(hipStreamSynchronize(j->stream));
   return 0;
 }
 
-int grdma_stream_job_slices(grdma_stream_job* j, grdma_read_slice* out, uint64_t cap) {
+// Delivered slices {offset into the link's destination, length} of link `link`.
+int grdma_stream_job_slices_of(grdma_stream_job* j, uint32_t link, grdma_read_slice* out, uint64_t cap) {
   if (int rc = require_ctx()) return rc;
-  if (!j || !out) return fail(GRDMA_ERR_INVALID, "null argument");
+  if (!j || !out || link >= j->links.size()) return fail(GRDMA_ERR_INVALID, "bad argument");
   grdma_conn c;
-  if (int rc = fetch_conn(j->rx, &c)) return rc;
+  if (int rc = fetch_conn(j->links[link].rx, &c)) return rc;
   uint64_t n = c.rx_slice_idx < cap ? c.rx_slice_idx : cap;
   static_assert(sizeof(grdma_read_slice) == sizeof(grdma_slice_out), "layout");
-  if (n) HIP_TRY(hipMemcpy(out, j->d_slices, sizeof(grdma_slice_out) * n, hipMemcpyDeviceToHost));
+  if (n) HIP_TRY(hipMemcpy(out, j->links[link].d_slices, sizeof(grdma_slice_out) * n, hipMemcpyDeviceToHost));
   return (int)n;
+}
+
+int grdma_stream_job_slices(grdma_stream_job* j, grdma_read_slice* out, uint64_t cap) {
+  return grdma_stream_job_slices_of(j, 0, out, cap);
 }
 
 }  // extern "C"

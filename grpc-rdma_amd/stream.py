@@ -32,6 +32,11 @@ def _bind():
         lib.grdma_stream_job_slices.argtypes = [C.c_void_p, C.POINTER(ReadSlice), u64]
         lib.grdma_stream_job_set_rounds.argtypes = [C.c_void_p, u64]
         lib.grdma_stream_job_launch.argtypes = [C.c_void_p]
+        lib.grdma_stream_job_create_multi.restype = C.c_void_p
+        lib.grdma_stream_job_create_multi.argtypes = [C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                      C.POINTER(Slice), C.POINTER(u64), C.POINTER(C.c_void_p),
+                                                      C.POINTER(u64), C.POINTER(u64), u64]
+        lib.grdma_stream_job_slices_of.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(ReadSlice), u64]
         lib.grdma_stream_job_sync.argtypes = [C.c_void_p]
         _bound = True
     return lib
@@ -64,12 +69,39 @@ class StreamJob:
     def sync(self):
         check(self.lib.grdma_stream_job_sync(self.h))
 
-    def delivered_slices(self):
+    def delivered_slices(self, link=0):
         arr = (ReadSlice * self.slices_cap)()
-        n = check(self.lib.grdma_stream_job_slices(self.h, arr, self.slices_cap))
+        n = check(self.lib.grdma_stream_job_slices_of(self.h, link, arr, self.slices_cap))
         return [(int(arr[i].off), int(arr[i].len)) for i in range(n)]
 
     def close(self):
         if self.h:
             self.lib.grdma_stream_job_destroy(self.h)
             self.h = None
+
+
+class MultiStreamJob(StreamJob):
+    """n links advancing in lock step, one op per link in every launch."""
+
+    def __init__(self, links, max_rounds):
+        """links: list of (tx Pair, rx Pair, slices [(ptr,len)...], dst ptr, dst cap, slices cap)."""
+        self.lib = _bind()
+        n = len(links)
+        txs = (C.c_void_p * n)(*[l[0].h for l in links])
+        rxs = (C.c_void_p * n)(*[l[1].h for l in links])
+        total = sum(len(l[2]) for l in links)
+        arr = (Slice * total)()
+        k = 0
+        for l in links:
+            for p, ln in l[2]:
+                arr[k].ptr, arr[k].len = p, ln
+                k += 1
+        counts = (u64 * n)(*[len(l[2]) for l in links])
+        dsts = (C.c_void_p * n)(*[l[3] for l in links])
+        dcaps = (u64 * n)(*[l[4] for l in links])
+        scaps = (u64 * n)(*[l[5] for l in links])
+        self.slices_cap = max(l[5] for l in links)
+        self.h = self.lib.grdma_stream_job_create_multi(n, txs, rxs, arr, counts, dsts, dcaps, scaps,
+                                                        max_rounds)
+        if not self.h:
+            raise GrdmaError(self.lib.grdma_last_error().decode())

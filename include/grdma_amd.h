@@ -199,6 +199,16 @@ grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,
                                           const grdma_slice* slices, uint64_t count,
                                           void* rx_dst, uint64_t rx_dst_cap,
                                           uint64_t slices_cap, uint64_t max_rounds);
+/* n independent links advancing in lock step: every kernel launch carries one op
+ * per link (connections are the data-parallel axis; config 4 =
+ * 32 connections per GPU).  slices holds the links' slice lists back to back,
+ * counts[i] entries each. */
+grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* tx,
+                                                grdma_pair* const* rx, const grdma_slice* slices,
+                                                const uint64_t* counts, void* const* rx_dsts,
+                                                const uint64_t* rx_dst_caps,
+                                                const uint64_t* slices_caps, uint64_t max_rounds);
+int grdma_stream_job_slices_of(grdma_stream_job* j, uint32_t link, grdma_read_slice* out, uint64_t cap);
 void grdma_stream_job_destroy(grdma_stream_job* j);
 int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out);
 /* Asynchronous form for timed loops: enqueue one pass (the captured graph) on
