@@ -19,7 +19,7 @@
 #define GRDMA_MAX_SEGS 8192         // copy segments per plan
 #define GRDMA_MAX_SLICES 8192       // delivered slices per receive plan
 #define GRDMA_TX_MAX_RECORDS 4096   // records priced by one send plan
-#define GRDMA_RX_HIST 256           // record sizes remembered per connection
+#define GRDMA_RX_HIST 1024          // record sizes remembered per connection
 #define GRDMA_TILE_BYTES 4096ull    // bytes one wave copies per tile
 #define GRDMA_MIN_READ_SLICE 256ull // rdma_bp_posix.cc:308
 
@@ -91,6 +91,9 @@ struct grdma_conn {
   uint64_t tx_remaining;        // bytes of the current slice list not yet accepted
   uint32_t* rx_hist;            // encoded sizes of the last GRDMA_RX_HIST records read
   uint64_t rx_hist_count;       // records read so far (ring index = count % HIST)
+  uint32_t rx_period;           // detected period of the record sizes (0 = none)
+  uint32_t pad3;
+  uint64_t rx_period_retry_at;  // no new period search before this many records were read
 };
 
 struct grdma_seg {

@@ -1082,6 +1082,16 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
   return 0;
 }
 
+int grdma_pair_debug_hist(grdma_pair* p, uint32_t* hist_out, uint64_t* count, uint32_t* period) {
+  if (!p) return -1;
+  grdma_conn c;
+  if (int rc = fetch_conn(p, &c)) return rc;
+  hipMemcpy(hist_out, p->d_hist, sizeof(uint32_t) * GRDMA_RX_HIST, hipMemcpyDeviceToHost);
+  *count = c.rx_hist_count;
+  *period = c.rx_period;
+  return 0;
+}
+
 int grdma_stream_job_debug(grdma_stream_job* j, uint64_t* tx_dbg, uint64_t* rx_dbg) {
   if (!j) return -1;
   hipStreamSynchronize(j->stream);

@@ -130,30 +130,45 @@ __device__ __forceinline__ uint32_t read_space_after(uint64_t n, uint32_t s) {
 }
 
 // What one whole record does to the read sequence, given the incoming state.
+// (Plain scalars only: arrays indexed at run time would live in scratch memory.)
 struct rec_plan {
-  uint64_t c1, c2;     // bytes of the (at most) two Recv steps
-  uint64_t sl_len[2];  // slices completed by this record, in order
+  uint64_t c1, c2;    // bytes of the (at most) two Recv steps
+  uint64_t sl0, sl1;  // lengths of the slices completed by this record, in order (0 = none)
   uint32_t sl_cnt;
 };
 
 __device__ __forceinline__ rec_plan replay_record(uint64_t n, uint32_t s_in) {
   rec_plan r;
-  r.c1 = r.c2 = 0;
-  r.sl_len[0] = r.sl_len[1] = 0;
-  r.sl_cnt = 0;
+  r.c1 = n;
+  r.c2 = 0;
+  r.sl0 = r.sl1 = 0;
   if (s_in == 0) {
-    r.c1 = n;
-    if (n >= MINRD) r.sl_len[r.sl_cnt++] = n;
+    if (n >= MINRD) r.sl0 = n;
   } else if (n <= s_in) {
-    r.c1 = n;
-    if (n == s_in) r.sl_len[r.sl_cnt++] = MINRD;
+    if (n == s_in) r.sl0 = MINRD;
   } else {
     r.c1 = s_in;
     r.c2 = n - s_in;
-    r.sl_len[r.sl_cnt++] = MINRD;
-    if (r.c2 >= MINRD) r.sl_len[r.sl_cnt++] = r.c2;
+    r.sl0 = MINRD;
+    if (r.c2 >= MINRD) r.sl1 = r.c2;
   }
+  r.sl_cnt = (r.sl0 ? 1u : 0u) + (r.sl1 ? 1u : 0u);
   return r;
+}
+
+// The ring pieces of one record's steps: step 1 = pieces 0,1; step 2 = pieces 2,3
+// (the second piece of a step exists only when the step crosses the ring end).
+struct rec_pieces {
+  uint64_t off[4], len[4];
+};
+__device__ __forceinline__ void split_step(uint64_t pay, uint64_t off, uint64_t len, uint64_t cap,
+                                           uint64_t* o0, uint64_t* l0, uint64_t* o1, uint64_t* l1) {
+  const uint64_t p0 = (pay + off) & (cap - 1);
+  const uint64_t first = len < cap - p0 ? len : cap - p0;
+  *o0 = p0;
+  *l0 = first;
+  *o1 = 0;
+  *l1 = len - first;
 }
 
 __device__ __forceinline__ uint64_t al16(uint64_t v) { return (v + 15) & ~15ull; }
@@ -170,6 +185,12 @@ struct rx_state {
   uint32_t stop;
   uint32_t bulk_tries;    // bulk attempts left in this call
   uint32_t bulk_blocked;  // last bulk attempt verified nothing: let the wave tier move first
+  uint32_t period;        // record-size period of this connection (0 = unknown)
+  uint32_t period_searched;  // the full period search already ran in this call
+  uint64_t period_retry_at;  // hist_count before which no new search is made
+  uint32_t period_strikes;   // consecutive drains whose first bulk pass mispredicted
+  uint32_t bulk_first;       // no bulk pass has run in this call yet
+  uint32_t period_backoff;   // log2 of the cool-down after a retired / missing period
   uint32_t took;
 };
 
@@ -221,6 +242,12 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     S.bulk_tries = (op.raw_cap == 0 && cap <= (1ull << 31) && max_slices >= 512) ? 6 : 0;
     S.bulk_blocked = 0;
     S.took = 0;
+    S.period = c->rx_period;
+    S.period_searched = 0;
+    S.period_retry_at = c->rx_period_retry_at;
+    S.period_strikes = c->pad3 & 0xFFFFu;
+    S.period_backoff = c->pad3 >> 16;
+    S.bulk_first = 1;
     for (int q = 0; q < 16; q++) s_dbg[q] = 0;
   }
   __syncthreads();
@@ -228,47 +255,130 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
   // ===================================================================== bulk tier
   auto bulk = [&]() -> uint32_t {
     const uint64_t H = S.hist_count < GRDMA_RX_HIST ? S.hist_count : GRDMA_RX_HIST;
-    if (H < 4) return 0;
     const uint64_t hbase = S.hist_count - H;  // absolute index of the oldest entry kept
     auto hist_at = [&](uint64_t i) -> uint32_t {  // i in [0, H): oldest .. newest
       return s_hist[(hbase + i) % GRDMA_RX_HIST];
     };
-    // ---- period detection: thread t tests P = t + 1 -------------------------------
+    // ---- period detection -------------------------------------------------------------------
+    // The newest TAIL entries are set aside: a Send that stops on the staging budget
+    // splits one record in two pieces (the last record of one drain, the first of
+    // the next), which would break an otherwise exact period.  The period is found
+    // on the older entries and the tail is then replayed against it.
+    const uint64_t TAIL = 3;
+    if (H < TAIL + 6) return 0xFFFFFFFFu;
+    const uint64_t Hp = H - TAIL;
     if (tid == 0) {
       s_key = 0xFFFFFFFFu;
       s_fail = 0xFFFFFFFFu;
       s_clean = 0;
     }
     __syncthreads();
+    // The period found earlier is remembered in the connection and only re-validated
+    // (256 threads compare up to WIN recent entries in one step); a full search runs
+    // when it stops matching, at most once per call.
+    const uint32_t WIN = 64;
+    const uint64_t tb0 = __builtin_amdgcn_s_memtime();
+    const uint32_t hp1 = (uint32_t)((hbase + Hp - 1) % GRDMA_RX_HIST);  // newest clean entry
+    auto entry_back = [&](uint32_t back) -> uint32_t {   // back = 0: newest clean entry
+      return s_hist[(hp1 + GRDMA_RX_HIST - back) % GRDMA_RX_HIST];
+    };
+    // Evidence for a period P: the newest min(L, P) clean records equal the ones P
+    // earlier (a whole period of them always straddles the message boundary, which
+    // is what separates the true period from the frame-header / payload alternation
+    // inside one message), with at least 3P/4 records to compare.
+    uint64_t P = S.period;
+    if (P != 0 && P + (3 * P) / 4 <= Hp) {
+      const uint32_t L = (uint32_t)(Hp - P);
+      const uint32_t W = L < P ? L : (uint32_t)P;
+      bool bad = false;
+      for (uint32_t jj = tid; jj < W; jj += PLAN_THREADS)
+        bad |= entry_back(jj) != entry_back(jj + (uint32_t)P);
+      if (bad) atomicMin(&s_key, 0u);
+      __syncthreads();
+      if (s_key == 0u) P = 0;
+      __syncthreads();
+      if (tid == 0) s_key = 0xFFFFFFFFu;
+      __syncthreads();
+    } else {
+      P = 0;
+    }
+    if (P == 0) {
+      // a failed search is not repeated until a fresh window of records has been seen
+      if (S.period_searched || S.hist_count < S.period_retry_at) return 0xFFFFFFFFu;
+      // full search: the largest period up to 512 records with that evidence
+      for (uint32_t Pc = tid + 1; Pc <= 512 && Pc + (3 * Pc) / 4 <= Hp; Pc += PLAN_THREADS) {
+        const uint32_t L = (uint32_t)Hp - Pc;
+        const uint32_t W = L < Pc ? L : Pc;
+        uint32_t score = 0;
+        while (score < W && entry_back(score) == entry_back(score + Pc)) score++;
+        if (score == W) atomicMin(&s_key, 0xFFFFu - Pc);
+      }
+      __syncthreads();
+      const unsigned key = s_key;
+      __syncthreads();
+      P = key == 0xFFFFFFFFu ? 0xFFFFFFFFull : (uint64_t)(0xFFFFu - key);
+      if (tid == 0) {
+        S.period_searched = 1;
+        S.period = P == 0xFFFFFFFFull ? 0 : (uint32_t)P;
+        if (P == 0xFFFFFFFFull) {
+          if (S.period_backoff < 10) S.period_backoff++;
+          S.period_retry_at = S.hist_count + ((uint64_t)GRDMA_RX_HIST << S.period_backoff) / 4;
+        }
+      }
+      // no period: leave the drain to the wave tier (64 probes per round trip)
+      if (P == 0xFFFFFFFFull) return 0xFFFFFFFFu;
+    }
     {
-      const uint64_t P = tid + 1;
-      if (P < H) {
-        const uint64_t L = H - P;  // comparable entries
-        uint64_t score = 0;
-        while (score < L && hist_at(H - 1 - score) == hist_at(H - 1 - score - P)) score++;  // <= 255 LDS steps
-        const bool full = (score == L) && L >= 2;
-        // smallest full-match period wins; otherwise the longest matching suffix
-        const unsigned key = full ? (unsigned)P
-                                  : (0x10000u + ((unsigned)(GRDMA_RX_HIST - score) << 8) + (unsigned)P);
-        atomicMin(&s_key, key);
+      // A Send that stops on the staging budget (cap / 2) splits a record and shifts
+      // the phase; when fewer than three periods fit between two such splits the
+      // history never holds enough clean records to keep the period validated, and
+      // the wave tier is the better walker.
+      uint64_t part = 0;
+      for (uint64_t i = tid; i < P; i += PLAN_THREADS) part += entry_back((uint32_t)i);
+      uint64_t period_bytes;
+      block_excl_scan(part, s_wave, &period_bytes);
+      if (3 * period_bytes > cap / 2) {
+        if (tid == 0) {
+          S.period = 0;
+          S.period_retry_at = S.hist_count + 4 * GRDMA_RX_HIST;
+        }
+        return 0xFFFFFFFFu;
       }
     }
-    __syncthreads();
-    const unsigned key = s_key;
-    // only a period that explains the whole remembered history is worth a bulk pass;
-    // anything else is left to the wave tier (64 probes per round trip)
-    if (key >= 0x10000u) return 0xFFFFFFFFu;  // no period: no more bulk attempts in this call
-    const uint64_t P = key & 0xFFu ? (key & 0xFFu) : 256;  // P <= 255 by construction
+    if (tid == 0) s_dbg[8] += __builtin_amdgcn_s_memtime() - tb0;
+    auto pattern = [&](uint64_t i) -> uint32_t {  // slot i after the clean prefix
+      return hist_at(Hp - P + (i % P));
+    };
+    // replay the tail: whole slots advance q, pieces of a split slot accumulate
+    uint64_t q = 0, acc = 0, pieces = 0;
+    bool tail_ok = true;
+    for (uint64_t a = 0; a < TAIL; a++) {
+      const uint64_t x = hist_at(Hp + a);
+      if (acc == 0 && x == pattern(q)) { q++; continue; }
+      acc += x;
+      pieces++;
+      const uint64_t whole = (uint64_t)pattern(q) + 16 * (pieces - 1);
+      if (acc == whole) { q++; acc = 0; pieces = 0; }
+      else if (acc > whole) tail_ok = false;
+    }
+    uint64_t rem = 0;  // encoded size of the piece that completes a split slot
+    if (acc > 0) {
+      rem = (uint64_t)pattern(q) + 16 * pieces - acc;
+      if (rem < 24 || (rem & 7)) tail_ok = false;
+      q++;
+    }
+    if (!tail_ok) return 0xFFFFFFFFu;
     // ---- predicted sizes and offsets for up to BULK_MAX records ----------------------
     const uint32_t per = BULK_MAX / PLAN_THREADS;  // 16 contiguous records per thread
     {
       uint64_t chunk = 0;
-      uint64_t ph = (uint64_t)tid * per % P;
       for (uint32_t k = 0; k < per; k++) {
-        const uint32_t e = hist_at(H - P + ph);
-        s_penc[tid * per + k] = e;
+        const uint64_t i = (uint64_t)tid * per + k;
+        uint32_t e;
+        if (rem) e = i == 0 ? (uint32_t)rem : pattern(q + i - 1);
+        else e = pattern(q + i);
+        s_penc[i] = e;
         chunk += e;
-        if (++ph == P) ph = 0;
       }
       uint64_t total;
       uint64_t x = block_excl_scan(chunk, s_wave, &total);
@@ -280,6 +390,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
       if (tid == PLAN_THREADS - 1) s_xenc[BULK_MAX] = x > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)x;
     }
     __syncthreads();
+    const uint64_t tb1 = __builtin_amdgcn_s_memtime();
     // ---- probe every predicted header / footer pair at once ---------------------------
     const uint64_t head = S.head;
     // room: slices <= 2 per record, segments <= 2 per record + 1 wrap, arena by offsets
@@ -291,25 +402,70 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
       if (r_sg < vmax) vmax = r_sg;
     }
     const uint64_t arena_room = op.arena_cap > S.a_off + 1024 ? op.arena_cap - S.a_off - 1024 : 0;
-    for (uint32_t i = tid; i < BULK_MAX; i += PLAN_THREADS) {
-      const uint64_t x = s_xenc[i], e = s_penc[i];
-      bool ok = i < vmax && x + e <= cap - 8 && x + e + 32ull * (i + 1) <= arena_room;
-      uint64_t hdr = 0;
-      if (ok) {
-        hdr = ld_tag(ring + ((head + x) & mask));
-        const uint64_t foot = ld_tag(ring + ((head + x + e - 8) & mask));
-        ok = hdr != 0 && hdr <= cap - GRDMA_RESERVED && 16 + round_up8(hdr) == e &&
-             foot == GRDMA_FOOTER;
+    {
+      // all 2 x 16 tag loads of a thread are in flight before the first is looked at
+      constexpr int NP = BULK_MAX / PLAN_THREADS;
+      uint64_t hdrs[NP], foots[NP];
+      bool want[NP];
+#pragma unroll
+      for (int r = 0; r < NP; r++) {
+        const uint32_t i = tid + r * PLAN_THREADS;
+        const uint64_t x = s_xenc[i], e = s_penc[i];
+        want[r] = i < vmax && x + e <= cap - 8 && x + e + 32ull * (i + 1) <= arena_room;
+        hdrs[r] = foots[r] = 0;
+        if (want[r]) {
+          hdrs[r] = ld_tag(ring + ((head + x) & mask));
+          foots[r] = ld_tag(ring + ((head + x + e - 8) & mask));
+        }
       }
-      s_n[i] = (uint32_t)hdr;
-      const uint64_t bm = __ballot(!ok);
-      if (bm != 0 && lane == __builtin_ctzll(bm)) atomicMin(&s_fail, i);
+      uint32_t first_bad = 0xFFFFFFFFu;
+#pragma unroll
+      for (int r = 0; r < NP; r++) {
+        const uint32_t i = tid + r * PLAN_THREADS;
+        const uint64_t hdr = hdrs[r];
+        const bool ok = want[r] && hdr != 0 && hdr <= cap - GRDMA_RESERVED &&
+                        16 + round_up8(hdr) == s_penc[i] && foots[r] == GRDMA_FOOTER;
+        s_n[i] = (uint32_t)hdr;
+        if (!ok && i < first_bad) first_bad = i;
+      }
+      // one LDS atomic per wave
+      const uint64_t bm = __ballot(first_bad != 0xFFFFFFFFu);
+      if (bm != 0) {
+        uint32_t m = first_bad;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+          const uint32_t o = __shfl_xor(m, d, 64);
+          m = o < m ? o : m;
+        }
+        if (lane == 0) atomicMin(&s_fail, m);
+      }
     }
     __syncthreads();
     const uint32_t V = s_fail == 0xFFFFFFFFu ? BULK_MAX : s_fail;
-    if (tid == 0 && s_dbg[6] == 0) {
-      s_dbg[6] = P; s_dbg[7] = H; s_dbg[8] = V; s_dbg[9] = s_penc[0]; s_dbg[10] = s_penc[1];
-      s_dbg[11] = V < BULK_MAX ? s_penc[V] : 0; s_dbg[12] = V < BULK_MAX ? s_n[V] : 0; s_dbg[13] = key; s_dbg[14] = vmax; s_dbg[15] = S.head;
+    const uint64_t tb2 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) s_dbg[9] += tb2 - tb1;
+    if (tid == 0) { s_dbg[6] = P; s_dbg[7] = V; }
+    if (V < BULK_MAX && tid == 0) {
+      // Was the first unverified record a misprediction (a complete record of another
+      // size) or simply the end of what has arrived?  Three mispredicted drain starts
+      // in a row retire the remembered period.
+      const uint64_t hv = s_n[V];
+      const bool mispredicted = hv != 0 && hv <= cap - GRDMA_RESERVED &&
+                                16 + round_up8(hv) != s_penc[V];
+      if (S.bulk_first) {
+        if (V < 16 && mispredicted) {
+          if (++S.period_strikes >= 3) {
+            S.period = 0;
+            S.period_strikes = 0;
+            if (S.period_backoff < 10) S.period_backoff++;  // up to 1024 x HIST records
+            S.period_retry_at = S.hist_count + ((uint64_t)GRDMA_RX_HIST << S.period_backoff);
+          }
+        } else if (V >= 16) {
+          S.period_strikes = 0;
+          if (V >= 256) S.period_backoff = 0;
+        }
+      }
+      S.bulk_first = 0;
     }
     if (V == 0) return 0;
     // ---- pass 0: incoming read state of every record, last clean record ----------------
@@ -331,35 +487,23 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     }
     __syncthreads();
     const uint32_t cnt = s_clean;  // records [0, cnt) are processed; the state ends clean
+    const uint64_t tb3 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) s_dbg[10] += tb3 - tb2;
     if (cnt == 0) return 0;
     // ---- pass 1: per-thread totals, block prefix --------------------------------------
     const uint32_t per1 = (cnt + PLAN_THREADS - 1) / PLAN_THREADS;
     const uint32_t q0 = tid * per1;
     uint64_t t_bytes = 0, t_sl = 0, t_sg = 0, t_tiles = 0, t_n = 0;
-    auto steps_of = [&](uint32_t k, uint64_t* st_off, uint64_t* st_len, uint32_t* nst,
-                        rec_plan* rp) {
-      *rp = replay_record(s_n[k], s_sin[k]);
-      const uint64_t pay = (head + s_xenc[k] + 8) & mask;
-      *nst = 0;
-      auto add = [&](uint64_t off, uint64_t len) {
-        if (len == 0) return;
-        const uint64_t p0 = (pay + off) & mask;
-        const uint64_t l1 = len < cap - p0 ? len : cap - p0;
-        st_off[*nst] = p0; st_len[*nst] = l1; (*nst)++;
-        if (len > l1) { st_off[*nst] = 0; st_len[*nst] = len - l1; (*nst)++; }
-      };
-      add(0, rp->c1);
-      add(rp->c1, rp->c2);
-    };
     for (uint32_t k = q0; k < q0 + per1 && k < cnt; k++) {
-      uint64_t so[4], sl[4];
-      uint32_t ns;
-      rec_plan rp;
-      steps_of(k, so, sl, &ns, &rp);
-      t_bytes += al16(rp.sl_len[0]) + al16(rp.sl_len[1]);
+      const rec_plan rp = replay_record(s_n[k], s_sin[k]);
+      const uint64_t pay = (head + s_xenc[k] + 8) & mask;
+      uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
+      split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
+      split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
+      t_bytes += al16(rp.sl0) + al16(rp.sl1);
       t_sl += rp.sl_cnt;
-      t_sg += ns;
-      for (uint32_t q = 0; q < ns; q++) t_tiles += tiles_of(sl[q]);
+      t_sg += (l0 ? 1 : 0) + (l1 ? 1 : 0) + (l2 ? 1 : 0) + (l3 ? 1 : 0);
+      t_tiles += tiles_of(l0) + tiles_of(l1) + tiles_of(l2) + tiles_of(l3);
       t_n += s_n[k];
     }
     uint64_t tot_bytes, tot_sl, tot_sg, tot_tiles, tot_n;
@@ -368,41 +512,55 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     uint64_t x_sg = block_excl_scan(t_sg, s_wave, &tot_sg);
     uint64_t x_tiles = block_excl_scan(t_tiles, s_wave, &tot_tiles);
     block_excl_scan(t_n, s_wave, &tot_n);
+    const uint64_t tb4 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) s_dbg[11] += tb4 - tb3;
     // ---- pass 2: segments, slices, tag clearing -------------------------------------------
     const uint64_t nsegs0 = S.nsegs, ntiles0 = S.ntiles, nsl0 = S.nslices, a0 = S.a_off;
     for (uint32_t k = q0; k < q0 + per1 && k < cnt; k++) {
-      uint64_t so[4], sl[4];
-      uint32_t ns;
-      rec_plan rp;
-      steps_of(k, so, sl, &ns, &rp);
+      const uint64_t n = s_n[k];
       const uint32_t s_in = s_sin[k];
+      const rec_plan rp = replay_record(n, s_in);
+      const uint64_t pos = (head + s_xenc[k]) & mask, pay = (pos + 8) & mask;
+      uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
+      split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
+      split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
       const uint64_t A = a0 + x_bytes;                    // start of the open / next slice
       const uint64_t filled = s_in ? MINRD - s_in : 0;
       // the steps of one record are contiguous in the arena: step 1 fills the
       // open 256-byte slice exactly, step 2 starts the next slice right behind it
       uint64_t dst = (uint64_t)op.arena + A + filled;
-      for (uint32_t q = 0; q < ns; q++) {
-        plan->segs[nsegs0 + x_sg] = {dst, (uint64_t)(ring + so[q]), sl[q], GRDMA_SEG_ZERO_SRC};
+      auto emit = [&](uint64_t off, uint64_t len) {
+        if (len == 0) return;
+        plan->segs[nsegs0 + x_sg] = {dst, (uint64_t)(ring + off), len, GRDMA_SEG_ZERO_SRC};
         plan->tile_prefix[nsegs0 + x_sg] = (uint32_t)(ntiles0 + x_tiles);
         x_sg++;
-        x_tiles += tiles_of(sl[q]);
-        dst += sl[q];
-      }
+        x_tiles += tiles_of(len);
+        dst += len;
+      };
+      emit(o0, l0);
+      emit(o1, l1);
+      emit(o2, l2);
+      emit(o3, l3);
       uint64_t sof = A;
-      for (uint32_t q = 0; q < rp.sl_cnt; q++) {
+      if (rp.sl0) {
         out_slices[nsl0 + x_sl].off = sof;
-        out_slices[nsl0 + x_sl].len = rp.sl_len[q];
+        out_slices[nsl0 + x_sl].len = rp.sl0;
         x_sl++;
-        sof += al16(rp.sl_len[q]);
+        sof += al16(rp.sl0);
       }
-      x_bytes += al16(rp.sl_len[0]) + al16(rp.sl_len[1]);
+      if (rp.sl1) {
+        out_slices[nsl0 + x_sl].off = sof;
+        out_slices[nsl0 + x_sl].len = rp.sl1;
+        x_sl++;
+      }
+      x_bytes += al16(rp.sl0) + al16(rp.sl1);
       // clear header, padding and footer (ring_buffer.cc:146,173-180)
-      const uint64_t n = s_n[k];
-      const uint64_t pos = (head + s_xenc[k]) & mask, pay = (pos + 8) & mask;
       *reinterpret_cast<uint64_t*>(ring + pos) = 0;
       for (uint64_t q = n; q < round_up8(n); q++) ring[(pay + q) & mask] = 0;
       *reinterpret_cast<uint64_t*>(ring + ((pay + round_up8(n)) & mask)) = 0;
     }
+    const uint64_t tb5 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) s_dbg[12] += tb5 - tb4;
     // history: the processed records become the newest entries
     {
       const uint64_t hc = S.hist_count;
@@ -587,8 +745,8 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
       const bool act = (uint32_t)lane < cnt;
       const uint32_t enc = act ? (uint32_t)(16 + round_up8(n)) : 0;
       rec_plan rp = replay_record(act ? n : 0, act ? s_in : 0);
-      if (!act) { rp.c1 = rp.c2 = 0; rp.sl_cnt = 0; rp.sl_len[0] = rp.sl_len[1] = 0; }
-      const uint32_t done_bytes = (uint32_t)(al16(rp.sl_len[0]) + al16(rp.sl_len[1]));
+      if (!act) { rp.c1 = rp.c2 = 0; rp.sl_cnt = 0; rp.sl0 = rp.sl1 = 0; }
+      const uint32_t done_bytes = (uint32_t)(al16(rp.sl0) + al16(rp.sl1));
       const uint32_t i_enc = wave_incl_scan_u32(enc);
       const uint32_t i_bytes = wave_incl_scan_u32(done_bytes);
       const uint32_t i_n = wave_incl_scan_u32(act ? (uint32_t)n : 0);
@@ -599,42 +757,42 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
       const uint64_t pay = (pos + 8) & mask;
       const uint64_t A = a_off + x_bytes;
       const uint64_t filled = s_in ? MINRD - s_in : 0;
-      const uint64_t dst1 = (uint64_t)op.arena + A + filled;
-      const uint64_t dst2 = (uint64_t)op.arena + A + MINRD;
-      uint64_t sg_dst[4], sg_src[4], sg_len[4];
-      uint32_t sg_cnt = 0;
-      auto add_step = [&](uint64_t dst, uint64_t off, uint64_t len) {
-        if (len == 0) return;
-        const uint64_t p0 = (pay + off) & mask;
-        const uint64_t l1 = len < cap - p0 ? len : cap - p0;
-        sg_dst[sg_cnt] = dst; sg_src[sg_cnt] = (uint64_t)(ring + p0); sg_len[sg_cnt] = l1; sg_cnt++;
-        if (len > l1) {
-          sg_dst[sg_cnt] = dst + l1; sg_src[sg_cnt] = (uint64_t)ring; sg_len[sg_cnt] = len - l1; sg_cnt++;
-        }
-      };
-      if (act) {
-        add_step(dst1, 0, rp.c1);
-        add_step(dst2, rp.c1, rp.c2);
-      }
-      uint32_t my_tiles = 0;
-      for (uint32_t q = 0; q < sg_cnt; q++) my_tiles += tiles_of(sg_len[q]);
+      uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
+      split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
+      split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
+      const uint32_t sg_cnt = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
+      const uint32_t my_tiles = tiles_of(l0) + tiles_of(l1) + tiles_of(l2) + tiles_of(l3);
       const uint32_t packed = rp.sl_cnt | (sg_cnt << 16);
       const uint32_t i_packed = wave_incl_scan_u32(packed);
       const uint32_t i_tiles = wave_incl_scan_u32(my_tiles);
       const uint64_t x_slices = (i_packed & 0xFFFFu) - rp.sl_cnt;
-      const uint64_t x_segs = (i_packed >> 16) - sg_cnt;
+      uint64_t x_segs = (i_packed >> 16) - sg_cnt;
       uint64_t x_tiles = i_tiles - my_tiles;
       if (act) {
-        for (uint32_t q = 0; q < sg_cnt; q++) {
-          plan->segs[nsegs + x_segs + q] = {sg_dst[q], sg_src[q], sg_len[q], GRDMA_SEG_ZERO_SRC};
-          plan->tile_prefix[nsegs + x_segs + q] = (uint32_t)(ntiles + x_tiles);
-          x_tiles += tiles_of(sg_len[q]);
-        }
+        uint64_t dst = (uint64_t)op.arena + A + filled;  // steps are contiguous in the arena
+        auto emit = [&](uint64_t off, uint64_t len) {
+          if (len == 0) return;
+          plan->segs[nsegs + x_segs] = {dst, (uint64_t)(ring + off), len, GRDMA_SEG_ZERO_SRC};
+          plan->tile_prefix[nsegs + x_segs] = (uint32_t)(ntiles + x_tiles);
+          x_segs++;
+          x_tiles += tiles_of(len);
+          dst += len;
+        };
+        emit(o0, l0);
+        emit(o1, l1);
+        emit(o2, l2);
+        emit(o3, l3);
         uint64_t so = A;
-        for (uint32_t q = 0; q < rp.sl_cnt; q++) {
-          out_slices[nslices + x_slices + q].off = so;
-          out_slices[nslices + x_slices + q].len = rp.sl_len[q];
-          so += al16(rp.sl_len[q]);
+        uint64_t xs = nslices + x_slices;
+        if (rp.sl0) {
+          out_slices[xs].off = so;
+          out_slices[xs].len = rp.sl0;
+          xs++;
+          so += al16(rp.sl0);
+        }
+        if (rp.sl1) {
+          out_slices[xs].off = so;
+          out_slices[xs].len = rp.sl1;
         }
         *reinterpret_cast<uint64_t*>(ring + pos) = 0;
         for (uint64_t q = n; q < round_up8(n); q++) ring[(pay + q) & mask] = 0;
@@ -785,6 +943,9 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
   // barriers, so every thread must fall out of the function together)
   if (tid == 0) {
     c->rx_hist_count = S.hist_count;
+    c->rx_period = S.period;
+    c->rx_period_retry_at = S.period_retry_at;
+    c->pad3 = (S.period_strikes & 0xFFFFu) | (S.period_backoff << 16);
 
     const uint64_t head = S.head, mh = S.mh, nsegs = S.nsegs, nslices = S.nslices;
     plan->nsegs = (uint32_t)nsegs;
@@ -857,7 +1018,9 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
   }
 }
 
-__global__ __launch_bounds__(PLAN_THREADS) void k_rx_plan(const grdma_rx_op* ops) {
+// one wave per SIMD: the whole 512-register file is available, no spills
+__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_rx_plan(const grdma_rx_op* ops) {
   rx_plan_body(ops[blockIdx.x]);
 }
 
@@ -876,7 +1039,8 @@ __device__ __attribute__((noinline)) void rx_plan_call(const grdma_rx_op* op) { 
 // the batched path.  The engine leaves by itself when idle for ~1 s or when the
 // host sets exit_flag.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(PLAN_THREADS) void k_engine(grdma_engine_mbox* mb) {
+__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_engine(grdma_engine_mbox* mb) {
   __shared__ uint64_t s_cmd[4];
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // resume after the last command a previous incarnation completed
