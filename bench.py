@@ -139,6 +139,49 @@ def measure_rtt(g, iters=3000, warmup=300):
                 ["client_write", "server_read", "server_write", "client_read"], ph)}}
 
 
+def fanout_leg(g, gs, grp, torch, args, flags, n_msgs=128):
+    """One 128 MiB stream (128 x 1 MiB messages) ingested on rank 0, decoded into a torch
+    tensor, then rebalanced to all ranks with one RCCL scatter (grpc_rdma_amd.fanout)."""
+    from grpc_rdma_amd import fanout
+    dev = torch.device("cuda", grp.local_rank)
+    ring = args.ring_kb * 1024
+    arena, slices = torch.zeros(16, dtype=torch.uint8, device=dev), []
+    t_ingest = 0.0
+    if grp.rank == 0:
+        wl = Workload(g, n_msgs)
+        tx, rx = g.Pair(ring, args.max_sge, flags), g.Pair(ring, args.max_sge, flags)
+        g.connect_pairs(tx, rx)
+        dst_cap = wl.N + 16 * (len(wl.lens) * 2 + 64) + 4096
+        arena = torch.empty(dst_cap, dtype=torch.uint8, device=dev)
+        job = gs.StreamJob(tx, rx, wl.sge, arena.data_ptr(), dst_cap, len(wl.lens) * 2 + 64,
+                           max(8, 4 * (wl.E // (ring // 2) + 2)))
+        r = job.run(gs.RUN_EAGER)
+        assert r.done
+        job.set_rounds(int(max(r.tx_rounds, r.rx_rounds)))
+        job.run(gs.RUN_GRAPH)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        job.launch()
+        job.sync()
+        t_ingest = time.perf_counter() - t0
+        slices = job.delivered_slices()
+    torch.cuda.synchronize()
+    grp.barrier()
+    t0 = time.perf_counter()
+    mine, my_slices = fanout.scatter_arena(grp, arena, slices, src=0)
+    torch.cuda.synchronize()
+    t_scatter = grp.max(time.perf_counter() - t0)
+    got = grp.sum(sum(n for _, n in my_slices))
+    out = {}
+    if grp.rank == 0:
+        total = sum(n for _, n in slices)
+        out = {"fanout_config": "%d MiB stream ingested on GPU 0, one RCCL scatter to %d GPUs" % (n_msgs, grp.world),
+               "fanout_ingest_ms": round(1e3 * t_ingest, 3), "fanout_scatter_ms": round(1e3 * t_scatter, 3),
+               "fanout_GiBps": round(n_msgs * MIB / (t_ingest + t_scatter) / (1 << 30), 3),
+               "fanout_bytes_ok": bool(got == total)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +197,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-small-ring", action="store_true", help="skip the extra 4 MiB-ring run")
     ap.add_argument("--no-rtt", action="store_true", help="skip the 64 B ping-pong leg")
+    ap.add_argument("--no-fanout", action="store_true", help="skip the RCCL fan-out leg (N>1 only)")
     ap.add_argument("--conns", type=int, default=32,
                     help="connections per GPU in the multi-connection leg (BASELINE configs[3]: 32); 1 = skip")
     args = ap.parse_args()
@@ -305,6 +349,14 @@ def main():
                     for k, v in classes.items()},
         "endpoint_bytes_per_step": wl.N, "ring_bytes_per_step": wl.E, "verified": verified,
     }
+    # ---- single-stream fan-out (BASELINE.json configs[4]): the one collective of the path ---
+    if world > 1 and not args.no_fanout:
+        try:
+            fo = fanout_leg(g, gs, grp, torch, args, flags)
+            if rank == 0:
+                out.update(fo)
+        except Exception as e:
+            out["fanout_error"] = str(e)
     # ---- unary 64 B ping-pong (BASELINE.json configs[1]): second half of the metric -------
     if not args.no_rtt:
         try:

@@ -9,12 +9,6 @@
 #define PLAN_THREADS 256
 #define COPY_THREADS 256
 
-// progress word of the resident engine (pinned host memory), null elsewhere
-__device__ uint64_t* g_engine_trace = nullptr;
-__device__ __forceinline__ void engine_trace(uint64_t code) {
-  if (g_engine_trace != nullptr && threadIdx.x == 0)
-    __hip_atomic_store(g_engine_trace, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 __device__ __forceinline__ uint64_t round_up8(uint64_t v) { return (v + 7ull) & ~7ull; }
 __device__ __forceinline__ uint64_t round_down8(uint64_t v) { return v & ~7ull; }

@@ -214,10 +214,9 @@ int engine_submit(uint64_t type, const void* op) {
       }
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) {
         *(volatile uint64_t*)&e.mb->exit_flag = 1;
-        return fail(GRDMA_ERR_HIP, "latency engine did not answer: alive=%llu ack=%llu seq=%llu polls=%llu seen=%llu stage=0x%llx trace=%llu",
+        return fail(GRDMA_ERR_HIP, "latency engine did not answer: alive=%llu ack=%llu seq=%llu polls=%llu",
                     (unsigned long long)*alive, (unsigned long long)*ack, (unsigned long long)seq,
-                    (unsigned long long)e.mb->pad1[0], (unsigned long long)e.mb->pad1[1],
-                    (unsigned long long)e.mb->pad1[2], (unsigned long long)e.mb->pad1[3]);
+                    (unsigned long long)e.mb->pad1[0]);
       }
     }
   }

@@ -209,10 +209,12 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
   __shared__ rx_state S;
   __shared__ uint64_t s_chain[CHAIN_CAP];
   __shared__ uint32_t s_hist[GRDMA_RX_HIST];
-  __shared__ uint32_t s_penc[BULK_MAX];
-  __shared__ uint32_t s_xenc[BULK_MAX + 1];
-  __shared__ uint32_t s_n[BULK_MAX];
-  __shared__ uint16_t s_sin[BULK_MAX];
+  // padded like the send plan's arrays: contiguous 16-record runs per thread
+#define RXP(i) ((i) + ((i) >> 4))
+  __shared__ uint32_t s_penc[RXP(BULK_MAX) + 1];
+  __shared__ uint32_t s_xenc[RXP(BULK_MAX + 1) + 1];
+  __shared__ uint32_t s_n[RXP(BULK_MAX) + 1];
+  __shared__ uint16_t s_sin[RXP(BULK_MAX) + 1];
   __shared__ uint64_t s_wave[PLAN_THREADS / 64];
   __shared__ unsigned int s_key, s_fail, s_clean;
   __shared__ uint64_t s_dbg[16];
@@ -377,17 +379,17 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
         uint32_t e;
         if (rem) e = i == 0 ? (uint32_t)rem : pattern(q + i - 1);
         else e = pattern(q + i);
-        s_penc[i] = e;
+        s_penc[RXP(i)] = e;
         chunk += e;
       }
       uint64_t total;
       uint64_t x = block_excl_scan(chunk, s_wave, &total);
       for (uint32_t k = 0; k < per; k++) {
         const uint32_t i = tid * per + k;
-        s_xenc[i] = x > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)x;
-        x += s_penc[i];
+        s_xenc[RXP(i)] = x > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)x;
+        x += s_penc[RXP(i)];
       }
-      if (tid == PLAN_THREADS - 1) s_xenc[BULK_MAX] = x > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)x;
+      if (tid == PLAN_THREADS - 1) s_xenc[RXP(BULK_MAX)] = x > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)x;
     }
     __syncthreads();
     const uint64_t tb1 = __builtin_amdgcn_s_memtime();
@@ -410,7 +412,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
 #pragma unroll
       for (int r = 0; r < NP; r++) {
         const uint32_t i = tid + r * PLAN_THREADS;
-        const uint64_t x = s_xenc[i], e = s_penc[i];
+        const uint64_t x = s_xenc[RXP(i)], e = s_penc[RXP(i)];
         want[r] = i < vmax && x + e <= cap - 8 && x + e + 32ull * (i + 1) <= arena_room;
         hdrs[r] = foots[r] = 0;
         if (want[r]) {
@@ -424,8 +426,8 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
         const uint32_t i = tid + r * PLAN_THREADS;
         const uint64_t hdr = hdrs[r];
         const bool ok = want[r] && hdr != 0 && hdr <= cap - GRDMA_RESERVED &&
-                        16 + round_up8(hdr) == s_penc[i] && foots[r] == GRDMA_FOOTER;
-        s_n[i] = (uint32_t)hdr;
+                        16 + round_up8(hdr) == s_penc[RXP(i)] && foots[r] == GRDMA_FOOTER;
+        s_n[RXP(i)] = (uint32_t)hdr;
         if (!ok && i < first_bad) first_bad = i;
       }
       // one LDS atomic per wave
@@ -449,9 +451,9 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
       // Was the first unverified record a misprediction (a complete record of another
       // size) or simply the end of what has arrived?  Three mispredicted drain starts
       // in a row retire the remembered period.
-      const uint64_t hv = s_n[V];
+      const uint64_t hv = s_n[RXP(V)];
       const bool mispredicted = hv != 0 && hv <= cap - GRDMA_RESERVED &&
-                                16 + round_up8(hv) != s_penc[V];
+                                16 + round_up8(hv) != s_penc[RXP(V)];
       if (S.bulk_first) {
         if (V < 16 && mispredicted) {
           if (++S.period_strikes >= 3) {
@@ -474,13 +476,13 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     if (k0 < V) {
       // look back to the nearest record that resets the state
       uint32_t j = k0;
-      while (j > 0 && s_n[j - 1] < 2 * MINRD - 1) j--;
+      while (j > 0 && s_n[RXP(j - 1)] < 2 * MINRD - 1) j--;
       uint32_t s = 0;
-      for (; j < k0; j++) s = read_space_after(s_n[j], s);
+      for (; j < k0; j++) s = read_space_after(s_n[RXP(j)], s);
       uint32_t last_clean = 0;
       for (uint32_t k = k0; k < k0 + per0 && k < V; k++) {
-        s_sin[k] = (uint16_t)s;
-        s = read_space_after(s_n[k], s);
+        s_sin[RXP(k)] = (uint16_t)s;
+        s = read_space_after(s_n[RXP(k)], s);
         if (s == 0) last_clean = k + 1;
       }
       if (last_clean) atomicMax(&s_clean, last_clean);
@@ -495,8 +497,8 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     const uint32_t q0 = tid * per1;
     uint64_t t_bytes = 0, t_sl = 0, t_sg = 0, t_tiles = 0, t_n = 0;
     for (uint32_t k = q0; k < q0 + per1 && k < cnt; k++) {
-      const rec_plan rp = replay_record(s_n[k], s_sin[k]);
-      const uint64_t pay = (head + s_xenc[k] + 8) & mask;
+      const rec_plan rp = replay_record(s_n[RXP(k)], s_sin[RXP(k)]);
+      const uint64_t pay = (head + s_xenc[RXP(k)] + 8) & mask;
       uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
       split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
       split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
@@ -504,7 +506,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
       t_sl += rp.sl_cnt;
       t_sg += (l0 ? 1 : 0) + (l1 ? 1 : 0) + (l2 ? 1 : 0) + (l3 ? 1 : 0);
       t_tiles += tiles_of(l0) + tiles_of(l1) + tiles_of(l2) + tiles_of(l3);
-      t_n += s_n[k];
+      t_n += s_n[RXP(k)];
     }
     uint64_t tot_bytes, tot_sl, tot_sg, tot_tiles, tot_n;
     uint64_t x_bytes = block_excl_scan(t_bytes, s_wave, &tot_bytes);
@@ -517,10 +519,10 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     // ---- pass 2: segments, slices, tag clearing -------------------------------------------
     const uint64_t nsegs0 = S.nsegs, ntiles0 = S.ntiles, nsl0 = S.nslices, a0 = S.a_off;
     for (uint32_t k = q0; k < q0 + per1 && k < cnt; k++) {
-      const uint64_t n = s_n[k];
-      const uint32_t s_in = s_sin[k];
+      const uint64_t n = s_n[RXP(k)];
+      const uint32_t s_in = s_sin[RXP(k)];
       const rec_plan rp = replay_record(n, s_in);
-      const uint64_t pos = (head + s_xenc[k]) & mask, pay = (pos + 8) & mask;
+      const uint64_t pos = (head + s_xenc[RXP(k)]) & mask, pay = (pos + 8) & mask;
       uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
       split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
       split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
@@ -567,12 +569,12 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
       const uint32_t first = cnt > GRDMA_RX_HIST ? cnt - GRDMA_RX_HIST : 0;
       __syncthreads();  // everyone is done reading s_hist through s_penc
       for (uint32_t k = first + tid; k < cnt; k += PLAN_THREADS)
-        s_hist[(hc + k) % GRDMA_RX_HIST] = s_penc[k];
+        s_hist[(hc + k) % GRDMA_RX_HIST] = s_penc[RXP(k)];
     }
     // ---- credit accounting over the Recv steps (pair.cc:276-284), thread 0 ----------------
     if (tid == 0) {
       const uint64_t T = cap / 2;
-      const uint64_t Ctot = s_xenc[cnt - 1] + s_penc[cnt - 1];
+      const uint64_t Ctot = s_xenc[RXP(cnt - 1)] + s_penc[RXP(cnt - 1)];
       uint64_t base = 0, thr = T - S.irs;
       bool crossed = false;
       uint64_t credit = S.credit, credit_head = S.credit_head;
@@ -581,14 +583,14 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
         uint32_t lo = 0, hi = cnt - 1;
         while (lo < hi) {
           const uint32_t mid = (lo + hi) >> 1;
-          if ((uint64_t)s_xenc[mid] + s_penc[mid] >= thr) hi = mid; else lo = mid + 1;
+          if ((uint64_t)s_xenc[RXP(mid)] + s_penc[RXP(mid)] >= thr) hi = mid; else lo = mid + 1;
         }
-        const uint64_t n = s_n[lo], e = s_penc[lo];
-        const rec_plan rp = replay_record(n, s_sin[lo]);
-        const uint64_t C2 = (uint64_t)s_xenc[lo] + e;
+        const uint64_t n = s_n[RXP(lo)], e = s_penc[RXP(lo)];
+        const rec_plan rp = replay_record(n, s_sin[RXP(lo)]);
+        const uint64_t C2 = (uint64_t)s_xenc[RXP(lo)] + e;
         const uint64_t cons2 = rp.c2 ? rp.c2 + (round_up8(n) - n + 8) : 0;
         const uint64_t C1 = C2 - cons2;
-        const uint64_t pos = (head + s_xenc[lo]) & mask;
+        const uint64_t pos = (head + s_xenc[RXP(lo)]) & mask;
         if (rp.c2 && C1 >= thr) {  // crossed after the first step of a two-step record
           credit_head = (pos + 8 + rp.c1) & mask;
           base = C1;
@@ -1046,7 +1048,6 @@ void k_engine(grdma_engine_mbox* mb) {
   // resume after the last command a previous incarnation completed
   uint64_t last = __hip_atomic_load(&mb->ack_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (threadIdx.x == 0) {
-    g_engine_trace = &mb->pad1[3];
     __hip_atomic_store(&mb->alive, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();

@@ -21,8 +21,11 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
   grdma_conn* c = op.conn;
   grdma_plan* plan = op.plan;
   __shared__ uint64_t s_wave[PLAN_THREADS / 64];
-  __shared__ uint64_t s_len[GRDMA_TX_MAX_RECORDS];       // len_i, later pay_i
-  __shared__ uint64_t s_excl[GRDMA_TX_MAX_RECORDS + 1];  // st_i
+  // LDS index padding: threads walk contiguous runs of up to 16 records, a 128-byte
+  // stride that would put all 64 lanes on the same banks; one extra slot per 16 breaks it
+#define TXP(i) ((i) + ((i) >> 4))
+  __shared__ uint64_t s_len[TXP(GRDMA_TX_MAX_RECORDS) + 1];       // len_i, later pay_i
+  __shared__ uint64_t s_excl[TXP(GRDMA_TX_MAX_RECORDS + 1) + 1];  // st_i
   __shared__ unsigned int s_first_short;
   __shared__ unsigned int s_wrap_rec;
   const unsigned tid = threadIdx.x;
@@ -67,12 +70,11 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
   if (!connected) m = 0;
 
   tdbg[1] = __builtin_amdgcn_s_memtime();
-  engine_trace(11);
   // lengths, striped
   for (uint64_t i = tid; i < m; i += PLAN_THREADS) {
     uint64_t l = sl[i].len;
     if (i == 0) l = sat_sub(l, byte_idx);
-    s_len[i] = l;
+    s_len[TXP(i)] = l;
   }
   __syncthreads();
 
@@ -83,7 +85,7 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
     for (uint64_t k = 0; k < per; k++) {
       const uint64_t i = tid * per + k;
       if (i < m) {
-        const uint64_t l = s_len[i];
+        const uint64_t l = s_len[TXP(i)];
         // clamp so that sums cannot overflow; anything above 2*cap cannot fit anyway
         chunk += enc_size(l < (cap << 1) ? l : (cap << 1));
       }
@@ -93,26 +95,25 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
     for (uint64_t k = 0; k < per; k++) {
       const uint64_t i = tid * per + k;
       if (i < m) {
-        s_excl[i] = st;
-        const uint64_t l = s_len[i];
+        s_excl[TXP(i)] = st;
+        const uint64_t l = s_len[TXP(i)];
         st += enc_size(l < (cap << 1) ? l : (cap << 1));
       }
     }
-    if (tid == PLAN_THREADS - 1 || (tid * per < m && (tid + 1) * per >= m)) s_excl[m] = st;
-    if (m == 0 && tid == 0) s_excl[0] = 0;
+    if (tid == PLAN_THREADS - 1 || (tid * per < m && (tid + 1) * per >= m)) s_excl[TXP(m)] = st;
+    if (m == 0 && tid == 0) s_excl[TXP(0)] = 0;
   }
   __syncthreads();
 
   tdbg[2] = __builtin_amdgcn_s_memtime();
-  engine_trace(12);
   // budget test, striped
   const uint64_t occupied0 = (tail0 + cap - rhead) & mask;
   const uint64_t free0 = cap - occupied0;
   for (uint64_t i = tid; i < m; i += PLAN_THREADS) {
-    const uint64_t st = s_excl[i];
+    const uint64_t st = s_excl[TXP(i)];
     const uint64_t a = writable_of(sat_sub(S, st));
     const uint64_t b = writable_of(sat_sub(free0, st));
-    const uint64_t l = s_len[i];
+    const uint64_t l = s_len[TXP(i)];
     uint64_t p = l;
     if (a < p) p = a;
     if (b < p) p = b;
@@ -127,18 +128,18 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
   const uint64_t nrec = (fs != 0xFFFFFFFFu) ? fs : m;  // records [0, nrec) go out whole
   uint64_t short_pay = 0;
   if (fs != 0xFFFFFFFFu) {
-    const uint64_t st = s_excl[fs];
+    const uint64_t st = s_excl[TXP(fs)];
     const uint64_t a = writable_of(sat_sub(S, st));
     const uint64_t b = writable_of(sat_sub(free0, st));
-    short_pay = s_len[fs];
+    short_pay = s_len[TXP(fs)];
     if (a < short_pay) short_pay = a;
     if (b < short_pay) short_pay = b;
   }
   const uint64_t nrec_total = nrec + (short_pay > 0 ? 1 : 0);
   // Σ enc over the whole records, plus the short one if any
-  const uint64_t staged = s_excl[nrec] + (short_pay > 0 ? enc_size(short_pay) : 0);
+  const uint64_t staged = s_excl[TXP(nrec)] + (short_pay > 0 ? enc_size(short_pay) : 0);
   __syncthreads();
-  if (tid == 0 && short_pay > 0) s_len[nrec] = short_pay;  // s_len[i] is pay_i from here on
+  if (tid == 0 && short_pay > 0) s_len[TXP(nrec)] = short_pay;  // s_len[TXP(i)] is pay_i from here on
   __syncthreads();
 
   // destination of record i: staging + st_i, or the peer ring itself at
@@ -147,20 +148,19 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
   uint8_t* const dbase = direct ? c->peer_ring : c->staging;
   if (direct) {
     for (uint64_t i = tid; i < nrec_total; i += PLAN_THREADS) {
-      const uint64_t pstart = (tail0 + s_excl[i] + 8) & mask;
-      if (pstart + s_len[i] > cap) atomicMin(&s_wrap_rec, (unsigned int)i);
+      const uint64_t pstart = (tail0 + s_excl[TXP(i)] + 8) & mask;
+      if (pstart + s_len[TXP(i)] > cap) atomicMin(&s_wrap_rec, (unsigned int)i);
     }
   }
   __syncthreads();
   const uint64_t wrap_rec = s_wrap_rec;
 
   tdbg[3] = __builtin_amdgcn_s_memtime();
-  engine_trace(13);
   // tags + segments, striped
   uint64_t sent_part = 0;
   for (uint64_t i = tid; i < nrec_total; i += PLAN_THREADS) {
-    const uint64_t p = s_len[i];
-    const uint64_t st = s_excl[i];
+    const uint64_t p = s_len[TXP(i)];
+    const uint64_t st = s_excl[TXP(i)];
     sent_part += p;
     const uint64_t hdr_off = direct ? ((tail0 + st) & mask) : st;
     const uint64_t pay_off = direct ? ((hdr_off + 8) & mask) : st + 8;
@@ -185,16 +185,15 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
   block_excl_scan(sent_part, s_wave, &sent);
 
   tdbg[4] = __builtin_amdgcn_s_memtime();
-  engine_trace(14);
   // tile prefix per segment (contiguous runs again, out of LDS)
   uint64_t ntiles;
   {
     const uint64_t per2 = (nrec_total + PLAN_THREADS - 1) / PLAN_THREADS;
     auto tiles_of = [&](uint64_t i, uint64_t* t1) -> uint64_t {
-      const uint64_t p = s_len[i];
+      const uint64_t p = s_len[TXP(i)];
       if (i == wrap_rec) {
-        const uint64_t pay_off = (tail0 + s_excl[i] + 16) & mask;  // (hdr_off + 8) & mask
-        const uint64_t l1 = cap - ((tail0 + s_excl[i] + 8) & mask);
+        const uint64_t pay_off = (tail0 + s_excl[TXP(i)] + 16) & mask;  // (hdr_off + 8) & mask
+        const uint64_t l1 = cap - ((tail0 + s_excl[TXP(i)] + 8) & mask);
         (void)pay_off;
         *t1 = (l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
         return *t1 + (p - l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
@@ -222,7 +221,6 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
   const uint64_t nsegs = nrec_total + ((wrap_rec != 0xFFFFFFFFu) ? 1 : 0);
 
   tdbg[5] = __builtin_amdgcn_s_memtime();
-  engine_trace(15);
   if (tid == 0) {
     plan->nsegs = (uint32_t)nsegs;
     plan->ntiles = (uint32_t)ntiles;
@@ -291,7 +289,6 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
     for (int q = 0; q < 7; q++) r->dbg[q] = tdbg[q];
     r->dbg[7] = m;
   }
-  engine_trace(16);
   if (op.inline_copy) {
     // small-message path: the planning workgroup moves the bytes itself (its
     // own plan stores are visible to its waves after the barrier)
@@ -305,15 +302,11 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  engine_trace(17);
   if (tid == 0) {
     grdma_tx_result* r = op.result;
     __threadfence_system();
-    engine_trace(18);
     const uint64_t nxt = r->seq + 1;
-    engine_trace(19);
     __hip_atomic_store(&r->seq, nxt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    engine_trace(20);
   }
 }
 
