@@ -37,7 +37,19 @@ struct grdma_rx_op {
 };
 
 // Mailbox of the persistent latency engine (pinned host memory).
-enum { GRDMA_ENGINE_SEND = 1, GRDMA_ENGINE_DRAIN = 2 };
+enum { GRDMA_ENGINE_SEND = 1, GRDMA_ENGINE_DRAIN = 2, GRDMA_ENGINE_SEND_INLINE = 3, GRDMA_ENGINE_DRAIN_BLOCK = 4 };
+
+// Self-contained command block for small messages: the op, its slice table and the
+// payload bytes travel in ONE contiguous pinned block that the engine pulls into LDS
+// with a single wide read, instead of chasing op -> slices -> payload over PCIe.
+#define GRDMA_CMD_MAX_SGES 16
+#define GRDMA_CMD_INLINE_BYTES 1024
+struct grdma_engine_cmd {
+  struct grdma_tx_op tx;
+  struct grdma_rx_op rx;
+  struct grdma_sge sges[GRDMA_CMD_MAX_SGES];  // ptr = offset into inline_data
+  uint8_t inline_data[GRDMA_CMD_INLINE_BYTES];
+};
 struct grdma_engine_mbox {
   uint64_t cmd_seq;    // host: bumped last, after cmd_type/op are written
   uint64_t cmd_type;

@@ -115,7 +115,9 @@ struct grdma_pair {
   uint64_t arena_cap = 0;
   uint32_t* d_hist = nullptr;
   bool latency = false;              // fused single-launch kernels + spin on pinned seq words
+  bool cmd_inline = false;           // the current slice list lives in h_cmd (small host message)
   uint8_t* h_arena = nullptr;        // pinned receive arena used in latency mode
+  grdma_engine_cmd* h_cmd = nullptr; // pinned self-contained command block (latency engine)
   uint64_t h_arena_cap = 0;
   grdma_hostblk* h = nullptr;        // pinned
   grdma_sge* h_sges = nullptr;       // pinned, GRDMA_MAX_SEGS entries
@@ -146,6 +148,25 @@ int stage_slices(grdma_pair* p, const grdma_slice* slices, uint64_t count, uint6
   if (count > GRDMA_TX_MAX_RECORDS - 1)
     return fail(GRDMA_ERR_CAPACITY, "slice list of %llu entries exceeds %d",
                 (unsigned long long)count, GRDMA_TX_MAX_RECORDS - 1);
+  p->cmd_inline = false;
+  if ((flags & GRDMA_MEM_HOST) && p->latency && p->h_cmd && count <= GRDMA_CMD_MAX_SGES) {
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < count; i++) total += slices[i].len;
+    if (total <= GRDMA_CMD_INLINE_BYTES) {
+      uint64_t off = 0;
+      for (uint64_t i = 0; i < count; i++) {
+        if (slices[i].len) memcpy(p->h_cmd->inline_data + off, slices[i].ptr, slices[i].len);
+        p->h_cmd->sges[i].ptr = reinterpret_cast<const uint8_t*>(off);  // rebased by the engine
+        p->h_cmd->sges[i].len = slices[i].len;
+        // keep the ordinary table valid too (byte_idx handling reads lengths from it)
+        p->h_sges[i].ptr = p->h_cmd->inline_data + off;
+        p->h_sges[i].len = slices[i].len;
+        off += slices[i].len;
+      }
+      p->cmd_inline = true;
+      return 0;
+    }
+  }
   if (flags & GRDMA_MEM_HOST) {
     const uint64_t cap = p->ring_size / 2;
     if (!p->h_bounce) HIP_TRY(hipHostMalloc((void**)&p->h_bounce, cap + 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -262,6 +283,11 @@ int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_curs
   h->txop.inline_copy = p->latency ? 1 : 0;
   const uint32_t blocks = copy_blocks_for(p->ring_size / 2);
   if (p->latency) {
+    if (g_engine.wanted && p->h_cmd && p->cmd_inline) {
+      // the slice table and payload were staged into the command block (stage_slices)
+      p->h_cmd->tx = h->txop;
+      return engine_submit(GRDMA_ENGINE_SEND_INLINE, p->h_cmd);
+    }
     if (g_engine.wanted) return engine_submit(GRDMA_ENGINE_SEND, &h->txop);
     const uint64_t old = h->txres.seq;
     HIP_TRY(grdma_launch_tx_plan(&h->txop, 1, p->stream));
@@ -291,6 +317,10 @@ int run_recv(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_rea
   h->rxop.inline_apply = p->latency ? 1 : 0;
   const uint32_t blocks = copy_blocks_for(p->ring_size);
   if (p->latency) {
+    if (g_engine.wanted && p->h_cmd) {
+      p->h_cmd->rx = h->rxop;
+      return engine_submit(GRDMA_ENGINE_DRAIN_BLOCK, p->h_cmd);
+    }
     if (g_engine.wanted) return engine_submit(GRDMA_ENGINE_DRAIN, &h->rxop);
     const uint64_t old = h->rxres.seq;
     HIP_TRY(grdma_launch_rx_plan(&h->rxop, 1, p->stream));
@@ -414,6 +444,7 @@ void grdma_pair_destroy(grdma_pair* p) {
   if (p->h_slices) hipHostFree(p->h_slices);
   if (p->h_bounce) hipHostFree(p->h_bounce);
   if (p->h_arena) hipHostFree(p->h_arena);
+  if (p->h_cmd) hipHostFree(p->h_cmd);
   if (p->peer && p->peer->peer == p) p->peer->peer = nullptr;
   delete p;
 }
@@ -638,6 +669,19 @@ int grdma_engine_start(void) {
   return engine_launch();
 }
 
+int grdma_pair_last_dbg(grdma_pair* p, uint64_t* tx_dbg, uint64_t* rx_dbg) {
+  if (!p) return -1;
+  memcpy(tx_dbg, p->h->txres.dbg, sizeof(uint64_t) * 16);
+  memcpy(rx_dbg, p->h->rxres.dbg, sizeof(uint64_t) * 16);
+  return 0;
+}
+
+int grdma_engine_debug(uint64_t out[5]) {
+  if (!g_engine.mb) return -1;
+  for (int i = 0; i < 5; i++) out[i] = g_engine.mb->pad1[i];
+  return 0;
+}
+
 int grdma_engine_stop(void) {
   if (int rc = require_ctx()) return rc;
   return engine_stop();
@@ -646,6 +690,10 @@ int grdma_engine_stop(void) {
 int grdma_pair_set_latency_mode(grdma_pair* p, int on) {
   if (int rc = require_ctx()) return rc;
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (on && !p->h_cmd) {
+    HIP_TRY(hipHostMalloc((void**)&p->h_cmd, sizeof(grdma_engine_cmd), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(p->h_cmd, 0, sizeof(grdma_engine_cmd));
+  }
   if (on && !p->h_arena) {
     p->h_arena_cap = 2 * p->ring_size + 4096;
     if (p->h_arena_cap > (64ull << 20)) p->h_arena_cap = 64ull << 20;

@@ -925,6 +925,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     __syncthreads();
   }
 
+  const uint64_t t_loop_end = __builtin_amdgcn_s_memtime();
   // history back to the connection
   __syncthreads();
   for (unsigned i = tid; i < GRDMA_RX_HIST; i += PLAN_THREADS) c->rx_hist[i] = s_hist[i];
@@ -984,6 +985,8 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     res->moving_head = mh;
     res->remain = S.remain;
     res->arena_used = S.a_off;
+    res->dbg[13] = t_loop_end;
+    res->dbg[14] = __builtin_amdgcn_s_memtime();
     res->dbg[0] = t_begin;
     res->dbg[1] = __builtin_amdgcn_s_memtime();
     res->dbg[2] = s_dbg[0];
@@ -1005,17 +1008,17 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
       }
     }
     if (op.inline_apply) {
+      // (relaxed stores: the single system-scope release on `seq` below publishes them;
+      // every release is an L2 write-back, and this is the latency path)
       if (S.credit) {
         grdma_status_report* ps = c->peer_status;
         if (ps != nullptr)
-          __hip_atomic_store(&ps->remote_head, S.credit_head, __ATOMIC_RELEASE,
+          __hip_atomic_store(&ps->remote_head, S.credit_head, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      __threadfence_system();
-      __hip_atomic_store(&res->commit_seq, res->commit_seq + 1, __ATOMIC_RELEASE,
+      __hip_atomic_store(&res->commit_seq, res->commit_seq + 1, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
     __hip_atomic_store(&res->seq, res->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -1044,6 +1047,7 @@ __device__ __attribute__((noinline)) void rx_plan_call(const grdma_rx_op* op) { 
 __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_engine(grdma_engine_mbox* mb) {
   __shared__ uint64_t s_cmd[4];
+  __shared__ __attribute__((aligned(16))) grdma_engine_cmd s_blk;
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // resume after the last command a previous incarnation completed
   uint64_t last = __hip_atomic_load(&mb->ack_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1083,16 +1087,43 @@ void k_engine(grdma_engine_mbox* mb) {
     __syncthreads();
     if (quit) break;
     last = seq;
+    const uint64_t te0 = __builtin_amdgcn_s_memtime();
+    uint64_t te1 = te0;
     if (opp == 0) {
       // malformed doorbell: acknowledge and keep serving
     } else if (type == GRDMA_ENGINE_SEND) {
       tx_plan_call(reinterpret_cast<const grdma_tx_op*>(opp));
     } else if (type == GRDMA_ENGINE_DRAIN) {
       rx_plan_call(reinterpret_cast<const grdma_rx_op*>(opp));
+    } else if (type == GRDMA_ENGINE_SEND_INLINE || type == GRDMA_ENGINE_DRAIN_BLOCK) {
+      // one wide read of the whole command block into LDS, then everything the body
+      // touches (op, slice table, payload) is local
+      {
+        const u32x4* src = reinterpret_cast<const u32x4*>(opp);
+        u32x4* dst = reinterpret_cast<u32x4*>(&s_blk);
+        for (unsigned i = threadIdx.x; i < sizeof(grdma_engine_cmd) / 16; i += PLAN_THREADS)
+          dst[i] = __builtin_nontemporal_load(src + i);
+      }
+      __syncthreads();
+      te1 = __builtin_amdgcn_s_memtime();
+      if (type == GRDMA_ENGINE_SEND_INLINE) {
+        if (threadIdx.x < GRDMA_CMD_MAX_SGES)
+          s_blk.sges[threadIdx.x].ptr = s_blk.inline_data + (uint64_t)s_blk.sges[threadIdx.x].ptr;
+        if (threadIdx.x == 0) s_blk.tx.slices = s_blk.sges;
+        __syncthreads();
+        tx_plan_call(&s_blk.tx);
+      } else {
+        rx_plan_call(&s_blk.rx);
+      }
     }
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
+      const uint64_t te2 = __builtin_amdgcn_s_memtime();
+      // profiling aid: cycles spent loading the command block / running the body, per type
+      mb->pad1[(type & 1) ? 0 : 2] += te1 - te0;
+      mb->pad1[(type & 1) ? 1 : 3] += te2 - te1;
       __hip_atomic_store(&mb->ack_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0)

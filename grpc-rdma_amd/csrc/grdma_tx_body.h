@@ -8,6 +8,165 @@
 namespace {
 
 // ----------------------------------------------------------------------------
+// Small sends (<= 64 slices, <= 64 KiB): the whole of PairPollable::Send on ONE
+// wavefront, lane i = slice i.  Same arithmetic as the block-wide plan below
+// (pay_i = min(len_i, W(S - st_i), W(free0 - st_i)), first short record ends the
+// send), with the prefix sum on the DPP network and the first short record from a
+// single __ballot; no LDS, no barriers.  The wave then writes the tags, moves
+// the payload and performs the wire write itself.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t start,
+                                              uint64_t byte_idx, uint64_t avail, int lane) {
+  grdma_conn* c = op.conn;
+  const uint64_t cap = c->cap, mask = cap - 1, S = c->staging_cap, tail0 = c->remote_tail;
+  const uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool connected = c->status == GRDMA_PAIR_CONNECTED;
+  const grdma_sge* sl = op.slices + start;
+  const bool direct = c->wire_direct != 0;
+  uint8_t* const dbase = direct ? c->peer_ring : c->staging;
+
+  uint64_t len = 0;
+  const uint8_t* src = nullptr;
+  if ((uint64_t)lane < avail) {
+    len = sl[lane].len;
+    src = sl[lane].ptr;
+    if (lane == 0) {
+      len = sat_sub(len, byte_idx);
+      src += byte_idx;
+    }
+  }
+  // total offered (pair.cc:660-663)
+  uint64_t offered = len;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) offered += __shfl_xor(offered, d, 64);
+  if (op.use_cursor == 1) offered = c->tx_remaining;
+
+  uint64_t m = avail < c->max_sge ? avail : c->max_sge;
+  if (!connected) m = 0;
+  const bool in_m = (uint64_t)lane < m;
+  const uint32_t enc = in_m ? (uint32_t)enc_size(len < (cap << 1) ? len : (cap << 1)) : 0;
+  const uint32_t incl = wave_incl_scan_u32(enc);
+  const uint64_t st = incl - enc;
+  const uint64_t occupied0 = (tail0 + cap - rhead) & mask;
+  const uint64_t free0 = cap - occupied0;
+  uint64_t pay = len;
+  {
+    const uint64_t a = writable_of(sat_sub(S, st)), b = writable_of(sat_sub(free0, st));
+    if (a < pay) pay = a;
+    if (b < pay) pay = b;
+  }
+  const uint64_t shorts = __ballot(in_m && (pay < len || len == 0));
+  const uint64_t nrec = shorts ? (uint64_t)__builtin_ctzll(shorts) : m;
+  const uint64_t short_pay = shorts ? __shfl(pay, (int)nrec, 64) : 0;
+  const uint64_t nrec_total = nrec + (short_pay > 0 ? 1 : 0);
+  const uint64_t my_pay = (uint64_t)lane < nrec ? len : ((uint64_t)lane == nrec ? short_pay : 0);
+  // Σ enc over the whole records, plus the short one if any
+  const uint64_t whole = nrec ? (uint64_t)__shfl(incl, (int)nrec - 1, 64) : 0;
+  const uint64_t staged = whole + (short_pay > 0 ? enc_size(short_pay) : 0);
+  uint64_t sent = my_pay;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sent += __shfl_xor(sent, d, 64);
+
+  // tags (AppendHeader / AppendFooter, ring_buffer.h:84-99) and zero padding
+  uint64_t pay_off = 0;
+  if (my_pay > 0) {
+    const uint64_t hdr_off = direct ? ((tail0 + st) & mask) : st;
+    pay_off = direct ? ((hdr_off + 8) & mask) : st + 8;
+    const uint64_t foot_off = direct ? ((hdr_off + 8 + round_up8(my_pay)) & mask) : st + 8 + round_up8(my_pay);
+    *reinterpret_cast<uint64_t*>(dbase + hdr_off) = my_pay;
+    *reinterpret_cast<uint64_t*>(dbase + foot_off) = GRDMA_FOOTER;
+    for (uint64_t q = my_pay; q < round_up8(my_pay); q++)
+      dbase[direct ? ((pay_off + q) & mask) : pay_off + q] = 0;
+  }
+  // payload: the wave walks the records (K1)
+  for (uint64_t r = 0; r < nrec_total; r++) {
+    const uint64_t p = __shfl(my_pay, (int)r, 64);
+    const uint64_t po = __shfl(pay_off, (int)r, 64);
+    const uint8_t* sp = reinterpret_cast<const uint8_t*>(__shfl((uint64_t)src, (int)r, 64));
+    uint64_t done = 0;
+    while (done < p) {
+      const uint64_t at = direct ? ((po + done) & mask) : po + done;
+      uint64_t n = p - done;
+      if (n > GRDMA_TILE_BYTES) n = GRDMA_TILE_BYTES;
+      if (direct && at + n > cap) n = cap - at;  // ring end: continue at offset 0
+      wave_copy_tile(dbase + at, sp + done, n, lane);
+      done += n;
+    }
+  }
+  // wire: the <= 2 RDMA WRITEs of GetWriteRequests (ring_buffer.cc:261-330)
+  const uint64_t seg1 = staged < cap - tail0 ? staged : cap - tail0;
+  if (!direct && staged > 0 && c->peer_ring != nullptr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // staging complete before it is read back
+    for (uint64_t done = 0; done < staged;) {
+      uint64_t n = staged - done;
+      if (n > GRDMA_TILE_BYTES) n = GRDMA_TILE_BYTES;
+      uint8_t* dst;
+      if (done < seg1) {
+        if (n > seg1 - done) n = seg1 - done;
+        dst = c->peer_ring + tail0 + done;
+      } else {
+        dst = c->peer_ring + (done - seg1);
+      }
+      wave_copy_tile(dst, c->staging + done, n, lane);
+      done += n;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) {
+    grdma_plan* plan = op.plan;
+    plan->nsegs = 0;
+    plan->ntiles = 0;
+    plan->tile_prefix[0] = 0;
+    plan->bytes = sent;
+    if (op.wire_plan != nullptr) {
+      op.wire_plan->nsegs = 0;
+      op.wire_plan->ntiles = 0;
+      op.wire_plan->tile_prefix[0] = 0;
+      op.wire_plan->bytes = direct ? 0 : staged;
+    }
+    const uint64_t new_tail = (tail0 + staged) & mask;
+    grdma_tx_result* r = op.result;
+    r->wr_count = 0;
+    r->wr_off[0] = r->wr_off[1] = r->wr_len[0] = r->wr_len[1] = 0;
+    if (staged > 0) {
+      r->wr_off[0] = tail0;
+      r->wr_len[0] = seg1;
+      r->wr_count = 1;
+      if (tail0 + staged >= cap) {
+        r->wr_off[1] = 0;
+        r->wr_len[1] = staged - seg1;
+        r->wr_count = 2;
+      }
+    }
+    uint64_t idx = start + nrec, bidx = 0;
+    if (short_pay > 0) bidx = (nrec == 0 ? byte_idx : 0) + short_pay;
+    else if (nrec == 0) bidx = byte_idx;
+    c->remote_tail = new_tail;
+    c->partial_write = sent < offered ? 1 : 0;
+    c->total_written += sent;
+    c->tx_records += nrec_total;
+    if (nrec_total) c->tx_rounds++;
+    if (op.use_cursor) {
+      c->tx_slice_idx = idx;
+      c->tx_byte_idx = bidx;
+      c->tx_remaining = offered - sent;
+    }
+    r->sent = sent;
+    r->records = nrec_total;
+    r->staged = staged;
+    r->partial = sent < offered ? 1 : 0;
+    r->new_remote_tail = new_tail;
+    r->slice_idx = idx;
+    r->byte_idx = bidx;
+    r->done = (idx >= op.nslices) ? 1 : 0;
+    // the peer reads the ring in a later command / kernel; the host needs the result
+    // block (pinned memory): a system-scope release on the sequence word covers it
+    __hip_atomic_store(&r->seq, r->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ----------------------------------------------------------------------------
 // k_tx_plan: PairPollable::Send arithmetic + rdma_flush cursor, one block per op
 // ----------------------------------------------------------------------------
 // All records of a Send are priced at once: enc_i = 16 + round_up8(len_i) is
@@ -46,6 +205,23 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
   const uint64_t avail = op.nslices - start;
   const grdma_sge* sl = op.slices + start;
 
+  // latency path: small sends run on one wavefront without LDS or barriers
+  if (op.inline_copy && avail <= 64 && cap <= (1ull << 31)) {
+    uint64_t small_bytes = 0;
+    if (tid < avail) small_bytes = sl[tid].len;
+    // (uniform decision: every thread sums the same <= 64 lengths through wave 0's lanes)
+    __shared__ uint64_t s_small_total;
+    if (tid < 64) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) small_bytes += __shfl_xor(small_bytes, d, 64);
+      if (tid == 0) s_small_total = small_bytes;
+    }
+    __syncthreads();
+    if (s_small_total <= (64ull << 10)) {
+      if (tid < 64) tx_small_wave(op, start, byte_idx, avail, (int)tid);
+      return;
+    }
+  }
   if (tid == 0) {
     s_first_short = 0xFFFFFFFFu;
     s_wrap_rec = 0xFFFFFFFFu;
@@ -304,7 +480,6 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
   }
   if (tid == 0) {
     grdma_tx_result* r = op.result;
-    __threadfence_system();
     const uint64_t nxt = r->seq + 1;
     __hip_atomic_store(&r->seq, nxt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }

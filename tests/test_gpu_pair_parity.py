@@ -327,14 +327,15 @@ def test_golden_reference_traces_on_gpu(gpu):
         link.a.close(); link.b.close()
 
 
+@pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
 @pytest.mark.parametrize("seed", range(4))
-def test_latency_mode_matches_oracle(gpu, seed):
+def test_latency_mode_matches_oracle(gpu, seed, flags):
     """Latency mode (one fused launch per call, pinned arena, host bytes through the
     bounce buffer) must be byte-identical to the batched path and the oracle."""
     g = gpu
     rng = random.Random(500 + seed)
     R = rng.choice([4096, 65536, 4 << 20])
-    a, b = mk_link(g, R, 30)
+    a, b = mk_link(g, R, 30, flags)
     a.set_latency_mode(True); b.set_latency_mode(True)
     o = pyorc.OracleLink(R, 30)
     sizes = [1, 9, 14, 64, 66, 255, 256, 300, 1000, 5000]
