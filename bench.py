@@ -192,6 +192,10 @@ def main():
                     default=int(os.environ.get("GRPC_RDMA_RING_BUFFER_SIZE_KB", 65536)),
                     help="ring size (GRPC_RDMA_RING_BUFFER_SIZE_KB); the reference default is 4096")
     ap.add_argument("--max-sge", type=int, default=4095)
+    ap.add_argument("--launch", choices=["graph", "streams"], default="graph",
+                    help="replay a step as one HIP graph, or issue its kernels on the job's streams")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="1: run the rounds of a step as a software pipeline (side streams)")
     ap.add_argument("--wire", choices=["staged", "direct"], default="staged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -234,22 +238,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB):
+    def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB,
+                pipeline=False, max_sge=None):
         """n_links connections with rings of ring_kb KiB: calibrate the number of rounds,
         capture the graph, time `steps` passes, verify, optionally instrument."""
         ring = ring_kb * 1024
+        max_sge = max_sge or args.max_sge
         wls = get_workloads(n_links, msgs_per_link or args.msgs, payload)
         links, keep = [], []
         for w in wls:
-            tx, rx = g.Pair(ring, args.max_sge, flags), g.Pair(ring, args.max_sge, flags)
+            tx, rx = g.Pair(ring, max_sge, flags), g.Pair(ring, max_sge, flags)
             g.connect_pairs(tx, rx)
             dst_cap = w.N + 16 * (len(w.lens) * 2 + 64) + 4096
             dst = g.DeviceBuffer(nbytes=dst_cap)
             links.append((tx, rx, w.sge, dst.ptr, dst_cap, len(w.lens) * 2 + 64))
             keep.append((tx, rx, dst, dst_cap, w))
         w0 = wls[0]
-        est_rounds = max(8, 4 * (w0.E // (ring // 2) + 2), 2 * (len(w0.lens) // min(args.max_sge, 4095) + 2))
+        est_rounds = max(8, 4 * (w0.E // (ring // 2) + 2), 2 * (len(w0.lens) // min(max_sge, 4095) + 2))
         job = gs.MultiStreamJob(links, est_rounds)
+        job.set_pipeline(pipeline)
         r = job.run(gs.RUN_EAGER)                  # calibration: how many rounds are needed
         total_n = sum(w.N for w in wls)
         assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
@@ -258,13 +265,14 @@ def main():
         job.set_rounds(rounds)
         r = job.run(gs.RUN_GRAPH)                  # capture + first replay
         assert r.done and r.bytes_delivered == total_n
+        use_streams = args.launch == "streams"
         for _ in range(warmup):
-            job.launch()
+            job.launch(use_streams)
         job.sync()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            job.launch()
+            job.launch(use_streams)
         job.sync()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -302,7 +310,8 @@ def main():
             tx.close(); rx.close(); dst.free()
         return out
 
-    head = measure(args.ring_kb, args.steps, args.warmup, not args.no_verify, True)
+    head = measure(args.ring_kb, args.steps, args.warmup, not args.no_verify, True,
+                   pipeline=bool(args.pipeline))
     elapsed, rounds, classes, verified = head["elapsed"], head["rounds"], head["classes"], head["verified"]
     ring = args.ring_kb * 1024
     small = None

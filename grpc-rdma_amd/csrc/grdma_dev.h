@@ -16,7 +16,8 @@
 #define GRDMA_RESERVED 24ull        // ring_buffer.h:52
 #define GRDMA_FOOTER 0xFFFFFFFFFFFFFFFFull  // ring_buffer.h:50
 
-#define GRDMA_MAX_SEGS 8192         // copy segments per plan
+#define GRDMA_MAX_SEGS 16384        // copy segments per plan (<= 2 per record of a 4096-record
+                                    // bulk pass, plus wrap splits)
 #define GRDMA_MAX_SLICES 8192       // delivered slices per receive plan
 #define GRDMA_TX_MAX_RECORDS 4096   // records priced by one send plan
 #define GRDMA_RX_HIST 1024          // record sizes remembered per connection
@@ -103,6 +104,22 @@ struct grdma_seg {
   uint64_t flags;  // GRDMA_SEG_ZERO_SRC: clear the source bytes after copying them
 };
 #define GRDMA_SEG_ZERO_SRC 1ull
+// Record tags ride on the segments instead of being stored one by one by the plan
+// workgroup (thousands of scattered 8-byte stores from a single CU were the longest
+// phase of both plans): the wave that copies the first / last tile of a record also
+// handles its header / its padding + footer.
+//   GRDMA_SEG_TAG_HDR   this segment starts a record
+//   GRDMA_SEG_TAG_FTR   this segment ends a record
+//   GRDMA_SEG_TAG_WRITE sender: header = flags >> 8 (payload bytes) in front of dst, zero
+//                       padding and the 0xFF.. footer behind dst + len (AppendHeader /
+//                       AppendFooter, ring_buffer.h:84-99); without it, receiver: clear the
+//                       same places around src (ring_buffer.cc:146,173-180)
+// Tag addresses wrap inside the plan's [tag_base, tag_base + tag_mask] window (the ring);
+// a linear staging buffer uses tag_mask = ~0.
+#define GRDMA_SEG_TAG_HDR 2ull
+#define GRDMA_SEG_TAG_FTR 4ull
+#define GRDMA_SEG_TAG_WRITE 8ull
+#define GRDMA_SEG_TAG_LEN_SHIFT 8
 
 struct grdma_slice_out {  // one completed endpoint_read: a single slice
   uint64_t off;           // offset into the receive arena
@@ -141,6 +158,8 @@ struct grdma_rx_result {
   uint64_t zero_len[2];
   uint64_t seq;            // bumped by k_rx_plan
   uint64_t commit_seq;     // bumped by k_rx_commit (copy + zero-fill + credit done)
+  uint32_t blocks_done;    // k_rx_apply arrival counter (the last workgroup commits); lives
+  uint32_t pad0;           // here, not in the connection, so that drains can be pipelined
   uint64_t dbg[16];        // s_memtime stamps of the plan phases (profiling aid)
 };
 
@@ -149,6 +168,8 @@ struct grdma_plan {
   uint32_t nsegs;
   uint32_t ntiles;
   uint64_t bytes;
+  uint64_t tag_base;   // window for the record tags of GRDMA_SEG_TAG_* segments
+  uint64_t tag_mask;
   struct grdma_seg segs[GRDMA_MAX_SEGS];
   uint32_t tile_prefix[GRDMA_MAX_SEGS + 1];
 };

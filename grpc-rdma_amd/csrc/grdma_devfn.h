@@ -131,6 +131,88 @@ __device__ __forceinline__ void wave_copy_tile(uint8_t* dst, const uint8_t* src,
   }
 }
 
+// Global-memory pointers: loads and stores through these are global_* instructions the
+// compiler may reorder freely against LDS traffic (a generic pointer could point into LDS).
+typedef const __attribute__((address_space(1))) u32x4* g_u32x4_c;
+typedef __attribute__((address_space(1))) u32x4* g_u32x4;
+
+// wave_copy_tile for tiles whose source and destination are known to be global memory
+// (HBM or mapped host memory), n <= GRDMA_TILE_BYTES.  All loads of the tile -- at most
+// four 16-byte units per lane -- are issued before the first store: a load -> wait ->
+// store -> load chain costs one memory round trip per unit.
+__device__ __forceinline__ void wave_copy_tile_g(uint8_t* dst, const uint8_t* src, uint64_t n,
+                                                 int lane) {
+  if (n > GRDMA_TILE_BYTES) {  // (not produced by the planners: tiles are cut at GRDMA_TILE_BYTES)
+    wave_copy_tile(dst, src, n, lane);
+    return;
+  }
+  uint64_t head = (16 - ((uint64_t)dst & 15)) & 15;
+  if (head > n) head = n;
+  const uint64_t n2 = n - head;
+  const uint64_t units = n2 >> 4;
+  const uint64_t tail = n2 & 15;
+  // edge bytes first (their loads join the batch below)
+  uint8_t hb = 0, tb = 0;
+  if (src) {
+    if ((uint64_t)lane < head) hb = src[lane];
+    if ((uint64_t)lane < tail) tb = src[head + (units << 4) + lane];
+  }
+  uint8_t* d2 = dst + head;
+  g_u32x4 da = (g_u32x4)(uint64_t)d2;
+  if (src == nullptr) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint64_t u = (uint64_t)lane + 64u * k;
+      if (u < units) da[u] = u32x4{0, 0, 0, 0};
+    }
+  } else if (units) {
+    const uint8_t* s2 = src + head;
+    const unsigned shift = (unsigned)((uint64_t)s2 & 15);
+    g_u32x4_c sa = (g_u32x4_c)((uint64_t)s2 & ~15ull);
+    u32x4 a[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint64_t u = (uint64_t)lane + 64u * k;
+      a[k] = __builtin_nontemporal_load(sa + (u < units ? u : units - 1));
+    }
+    if (shift == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint64_t u = (uint64_t)lane + 64u * k;
+        if (u < units) da[u] = a[k];
+      }
+    } else {
+      // unaligned source: unit u needs blocks u and u + 1.  Block u + 1 is what the next
+      // lane holds, so it comes over the DPP network (wave_shl:1); lane 63 fetches its own.
+      u32x4 e[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint64_t u = (uint64_t)lane + 64u * k + 1;
+        e[k] = a[k];
+        if (lane == 63) e[k] = __builtin_nontemporal_load(sa + (u < units ? u : units));
+      }
+      // the last active lane of the tile needs block `units` too
+      const uint64_t lastu = units - 1;
+      u32x4 last_b = u32x4{0, 0, 0, 0};
+      if ((uint64_t)lane == (lastu & 63)) last_b = __builtin_nontemporal_load(sa + units);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint64_t u = (uint64_t)lane + 64u * k;
+        u32x4 b;
+        b.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[k].x, 0x130, 0xf, 0xf, false);
+        b.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[k].y, 0x130, 0xf, 0xf, false);
+        b.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[k].z, 0x130, 0xf, 0xf, false);
+        b.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[k].w, 0x130, 0xf, 0xf, false);
+        if (lane == 63) b = e[k];
+        if (u == lastu) b = last_b;
+        if (u < units) da[u] = funnel16(a[k], b, shift);
+      }
+    }
+  }
+  if ((uint64_t)lane < head) dst[lane] = hb;
+  if ((uint64_t)lane < tail) d2[(units << 4) + lane] = tb;
+}
+
 // Reader zero-fill (ring_buffer.cc:160,164): clear exactly [p, p+n).
 __device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane) {
   uint64_t head = (16 - ((uint64_t)p & 15)) & 15;
@@ -145,34 +227,64 @@ __device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane)
   if ((uint64_t)lane < tail) p[(units << 4) + lane] = 0;
 }
 
-#define PREFIX_LDS 2048
+#define PREFIX_LDS 4096
 
-// Every workgroup stages the tile prefix in LDS (one coalesced load), then each
-// wave maps its tiles to segments with an LDS binary search: no dependent global
-// loads between picking a tile and issuing its first payload load.
+// Every workgroup stages the tile prefix in LDS (one coalesced load), then each wave
+// maps its tiles to segments with an LDS binary search.  Plans with more segments than
+// LDS slots are staged SAMPLED (every 2nd / 4th entry, the stride a power of two): the
+// LDS search then lands on a window of `stride` entries, which the wave fetches with one
+// global load (lane k takes entry k of the window) and resolves with a ballot.  Either
+// way there is no chain of dependent global loads between picking a tile and issuing
+// its first payload load.
 __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t wave,
                                                uint32_t nwaves, int lane) {
   __shared__ uint32_t s_prefix[PREFIX_LDS + 1];
   const uint32_t nsegs = plan->nsegs;
   const uint32_t ntiles = plan->ntiles;
-  const bool in_lds = nsegs <= PREFIX_LDS;
-  if (in_lds)
-    for (uint32_t i = threadIdx.x; i <= nsegs; i += COPY_THREADS) s_prefix[i] = plan->tile_prefix[i];
+  uint32_t shift = 0;  // entry k of s_prefix is tile_prefix[k << shift]
+  while (((nsegs >> shift) + 1) > PREFIX_LDS) shift++;
+  const uint32_t nsamp = (nsegs >> shift) + 1;  // samples 0 .. nsegs >> shift
+  for (uint32_t i = threadIdx.x; i < nsamp; i += blockDim.x) s_prefix[i] = plan->tile_prefix[i << shift];
   __syncthreads();
   for (uint32_t t = wave; t < ntiles; t += nwaves) {
-    uint32_t lo = 0, hi = nsegs;  // invariant: prefix[lo] <= t < prefix[hi]
+    uint32_t lo = 0, hi = nsamp;  // invariant: sample[lo] <= t, (hi == nsamp or sample[hi] > t)
     while (hi - lo > 1) {
       const uint32_t mid = (lo + hi) >> 1;
-      const uint32_t pm = in_lds ? s_prefix[mid] : plan->tile_prefix[mid];
-      if (pm <= t) lo = mid; else hi = mid;
+      if (s_prefix[mid] <= t) lo = mid; else hi = mid;
     }
-    const grdma_seg sg = plan->segs[lo];
-    const uint32_t p0 = in_lds ? s_prefix[lo] : plan->tile_prefix[lo];
+    uint32_t seg = lo << shift;
+    uint32_t p0 = s_prefix[lo];
+    if (shift) {
+      // entries seg .. seg + stride - 1 (those that exist): the last one that is <= t
+      const uint32_t k = seg + (uint32_t)lane;
+      const bool in = (uint32_t)lane < (1u << shift) && k < nsegs;
+      const uint32_t pk = in ? plan->tile_prefix[k] : 0xFFFFFFFFu;
+      const uint64_t le = __ballot(in && pk <= t);
+      const int last = 63 - __builtin_clzll(le);  // lane 0 always qualifies (pk == p0 <= t)
+      seg += (uint32_t)last;
+      p0 = __shfl(pk, last, 64);
+    }
+    const grdma_seg sg = plan->segs[seg];
     const uint64_t off = (uint64_t)(t - p0) * GRDMA_TILE_BYTES;
     uint64_t n = sg.len - off;
     if (n > GRDMA_TILE_BYTES) n = GRDMA_TILE_BYTES;
     uint8_t* src = sg.src ? reinterpret_cast<uint8_t*>(sg.src + off) : nullptr;
-    wave_copy_tile(reinterpret_cast<uint8_t*>(sg.dst + off), src, n, lane);
+    wave_copy_tile_g(reinterpret_cast<uint8_t*>(sg.dst + off), src, n, lane);
+    if (sg.flags & (GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR)) {
+      const bool wr = (sg.flags & GRDMA_SEG_TAG_WRITE) != 0;
+      const uint64_t side = wr ? sg.dst : sg.src;
+      uint8_t* const tb = reinterpret_cast<uint8_t*>(plan->tag_base);
+      const uint64_t tm = plan->tag_mask;
+      if ((sg.flags & GRDMA_SEG_TAG_HDR) && off == 0 && lane == 0)
+        *reinterpret_cast<uint64_t*>(tb + ((side - 8 - plan->tag_base) & tm)) =
+            wr ? (sg.flags >> GRDMA_SEG_TAG_LEN_SHIFT) : 0;
+      if ((sg.flags & GRDMA_SEG_TAG_FTR) && off + n == sg.len) {
+        const uint64_t e = (side + sg.len - plan->tag_base) & tm;  // first byte behind the payload
+        const uint64_t pad = (0 - e) & 7;
+        if ((uint64_t)lane < pad) tb[e + lane] = 0;
+        if (lane == 8) *reinterpret_cast<uint64_t*>(tb + ((e + pad) & tm)) = wr ? GRDMA_FOOTER : 0;
+      }
+    }
     if ((sg.flags & GRDMA_SEG_ZERO_SRC) && src) {
       // every load of this tile has returned (its data fed the stores above);
       // make that explicit before the source bytes are overwritten

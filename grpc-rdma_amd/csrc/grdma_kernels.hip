@@ -77,7 +77,7 @@ __global__ __launch_bounds__(COPY_THREADS) void k_rx_apply(const grdma_rx_op* op
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned int prev = __hip_atomic_fetch_add(&op.conn->rx_blocks_done, 1u, __ATOMIC_RELAXED,
+    unsigned int prev = __hip_atomic_fetch_add(&op.result->blocks_done, 1u, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
     s_last = (prev == gridDim.x - 1) ? 1u : 0u;
   }
@@ -166,6 +166,32 @@ hipError_t grdma_launch_rx_apply(const grdma_rx_op* d_ops, uint32_t nops, uint32
   hipLaunchKernelGGL(k_rx_apply, dim3(blocks_per_op, nops), dim3(COPY_THREADS), 0, s, d_ops);
   return hipGetLastError();
 }
+
+// Kernel entry points for explicitly built HIP graphs (hipGraphAddKernelNode): the job
+// graph is assembled node by node instead of being recorded from streams.
+const void* grdma_kernel_fn(int which) {
+  switch (which) {
+    case 0: return reinterpret_cast<const void*>(&k_tx_plan);
+    case 1: return reinterpret_cast<const void*>(&k_copy);
+    case 3: return reinterpret_cast<const void*>(&k_rx_apply);
+    default: return nullptr;
+  }
+}
+// Workgroups of the copy kernels that are resident at once on the current device: the
+// grid is capped there (the tile loop is grid-strided), so that no second, partial wave
+// of workgroups trails the first.
+uint32_t grdma_copy_resident_blocks(void) {
+  int dev = 0, cus = 0, a = 0, b = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 1024;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return 1024;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_copy, COPY_THREADS, 0) != hipSuccess) a = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_rx_apply, COPY_THREADS, 0) != hipSuccess) b = 4;
+  const int per_cu = a < b ? a : b;
+  return (uint32_t)((per_cu > 0 ? per_cu : 1) * cus);
+}
+
+uint32_t grdma_kernel_threads(int which) { return (which == 0 || which == 2) ? PLAN_THREADS : COPY_THREADS; }
 
 hipError_t grdma_launch_poll(grdma_conn* const* d_conns, uint32_t nconns, uint64_t* d_readable,
                              uint64_t* d_ready_mask, uint64_t* d_has_mask, hipStream_t s) {

@@ -31,6 +31,10 @@ hipError_t grdma_launch_rx_apply(const grdma_rx_op*, uint32_t, uint32_t, hipStre
 hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*, uint64_t*,
                              hipStream_t);
 hipError_t grdma_launch_engine(grdma_engine_mbox*, hipStream_t);
+const void* grdma_kernel_fn(int which);          // 0 tx_plan, 1 copy, 3 rx_apply
+const void* grdma_kernel_fn_rx_plan(void);
+uint32_t grdma_kernel_threads(int which);
+uint32_t grdma_copy_resident_blocks(void);
 }
 
 namespace {
@@ -86,7 +90,12 @@ uint32_t copy_blocks_for(uint64_t bytes) {
   uint64_t tiles = (bytes + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
   uint64_t blocks = (tiles + 3) / 4;  // 4 waves per block, one tile per wave pass
   if (blocks < 1) blocks = 1;
-  if (blocks > 2048) blocks = 2048;  // 256 CUs x 8; the rest is grid-strided
+  static const uint64_t cap_blocks = [] {
+    const char* e = getenv("GRDMA_COPY_BLOCKS");  // tuning knob, tools/ experiments
+    const long v = e ? atol(e) : 0;
+    return (uint64_t)(v > 0 ? v : grdma_copy_resident_blocks());  // the rest is grid-strided
+  }();
+  if (blocks > cap_blocks) blocks = cap_blocks;
   return (uint32_t)blocks;
 }
 
@@ -865,6 +874,8 @@ int grdma_device_synchronize(void) {
 // n independent links (connections) advance in lock step: every launch carries one
 // op per link (grid.y = n), so 32 connections with 4 MiB rings fill the chip the way
 // one connection with a 128 MiB ring would.
+static uint64_t g_debug_flags = 0;  // copied into job ops; tools/ timing experiments only
+
 struct grdma_job_link {
   grdma_pair* tx = nullptr;
   grdma_pair* rx = nullptr;
@@ -874,20 +885,32 @@ struct grdma_job_link {
   uint64_t slices_cap = 0;
   uint8_t* dst = nullptr;
   uint64_t dst_cap = 0;
+  // second copies of what two rounds in flight would otherwise share (pipelined mode)
+  grdma_plan* d_wireplan2 = nullptr;
+  grdma_plan* d_rxplan2 = nullptr;
+  uint8_t* d_staging2 = nullptr;
 };
 
 struct grdma_stream_job {
   std::vector<grdma_job_link> links;
   uint64_t rounds = 0;
-  // device control block: txop[2][n], rxop[2][n], results[n], plan pointer arrays
+  // device control block: txop[3][n], rxop[3][n], results, plan pointer arrays.
+  // Op set 0 is the first round (resets the cursors), sets 1 / 2 are odd / even rounds:
+  // they differ in which of the doubled buffers (wire plan, staging, scatter plan,
+  // drain result) they use, so that two rounds can be in flight.
   uint8_t* d_ctl = nullptr;
-  grdma_tx_op* d_txop = nullptr;      // [2 * n]
-  grdma_rx_op* d_rxop = nullptr;      // [2 * n]
+  grdma_tx_op* d_txop = nullptr;      // [3 * n]
+  grdma_rx_op* d_rxop = nullptr;      // [3 * n]
   grdma_tx_result* d_txres = nullptr; // [n]
-  grdma_rx_result* d_rxres = nullptr; // [n]
-  const grdma_plan** d_plans = nullptr;  // [3 * n]: gather, wire, scatter
+  grdma_rx_result* d_rxres = nullptr; // [2 * n]
+  const grdma_plan** d_plans = nullptr;  // [3 * n]: gather, wire (even), wire (odd)
   hipGraphExec_t exec = nullptr;
   uint64_t exec_rounds = 0;
+  int exec_pipeline = -1;
+  int pipeline = 0;                   // 1: overlap the send plan / gather / scatter of
+                                      // neighbouring rounds on side streams
+  hipStream_t s_wire = nullptr, s_rxplan = nullptr, s_apply = nullptr;
+  std::vector<hipEvent_t> pev;        // dependency events of the pipelined schedule
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> kev;
   hipStream_t stream = nullptr;
@@ -897,13 +920,16 @@ struct grdma_stream_job {
 
 namespace {
 
+inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 : 2); }
+
 int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
   const uint32_t n = (uint32_t)j->links.size();
   const uint32_t tx_blocks = copy_blocks_for(j->max_ring / 2);
   const uint32_t rx_blocks = copy_blocks_for(j->max_ring);
   // keep the grid around 2048 workgroups in total
-  const uint32_t txb = std::max<uint32_t>(1, std::min<uint32_t>(tx_blocks, 2048 / n + 1));
-  const uint32_t rxb = std::max<uint32_t>(1, std::min<uint32_t>(rx_blocks, 2048 / n + 1));
+  const uint32_t grid_cap = copy_blocks_for(~0ull >> 8);
+  const uint32_t txb = std::max<uint32_t>(1, std::min<uint32_t>(tx_blocks, grid_cap / n + 1));
+  const uint32_t rxb = std::max<uint32_t>(1, std::min<uint32_t>(rx_blocks, grid_cap / n + 1));
   size_t e = 0;
   auto mark = [&]() -> int {
     if (!instrument) return 0;
@@ -917,18 +943,180 @@ int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
   };
   if (int rc = mark()) return rc;
   for (uint64_t r = 0; r < j->rounds; r++) {
-    const int k = r == 0 ? 0 : 1;
+    const int k = job_opset(r);
     HIP_TRY(grdma_launch_tx_plan(j->d_txop + k * n, n, s));
     if (int rc = mark()) return rc;
     HIP_TRY(grdma_launch_copy(j->d_plans, n, txb, s));
     if (int rc = mark()) return rc;
-    if (!j->direct) HIP_TRY(grdma_launch_copy(j->d_plans + n, n, txb, s));
+    if (!j->direct) HIP_TRY(grdma_launch_copy(j->d_plans + n * (1 + (r & 1)), n, txb, s));
     if (int rc = mark()) return rc;
     HIP_TRY(grdma_launch_rx_plan(j->d_rxop + k * n, n, s));
     if (int rc = mark()) return rc;
     HIP_TRY(grdma_launch_rx_apply(j->d_rxop + k * n, n, rxb, s));
     if (int rc = mark()) return rc;
   }
+  return 0;
+}
+
+// The same five kernels per round, scheduled as a software pipeline over four streams.
+// What has to stay ordered (t = round):
+//   plan_t -> gather_t -> wire_t -> rx_plan_t -> rx_apply_t      the data path of one round
+//   wire_{t-2} -> plan_t      two staging buffers (and wire plans) alternate; the one of
+//       this parity comes free when the round before last has left it
+//   rx_plan_{t-1} -> wire_t   the loop-back wire is a parallel copy: it does not deliver
+//       the footer of a record after its payload the way an RC queue pair does, so the
+//       receiver must not be walking the chain while new records land behind it
+//   rx_apply_{t-2} -> rx_plan_t   the scatter plan and result block of that parity are free
+//   rx_apply_{t-2} -> plan_t      the sender sees every credit but (possibly) the last one
+// Everything else overlaps: the send plan and gather of round t+1 run while round t is on
+// the wire and being walked, and the scatter of round t runs under round t+1.  The
+// sender may see the credit of a scatter one round later than in the sequential
+// schedule; with rounds of at most ring/6 that never limits a Send.
+int job_enqueue_pipelined(grdma_stream_job* j, hipStream_t s) {
+  const uint32_t n = (uint32_t)j->links.size();
+  const uint32_t tx_blocks = copy_blocks_for(j->max_ring / 2);
+  const uint32_t rx_blocks = copy_blocks_for(j->max_ring);
+  const uint32_t grid_cap = copy_blocks_for(~0ull >> 8);
+  const uint32_t txb = std::max<uint32_t>(1, std::min<uint32_t>(tx_blocks, grid_cap / n + 1));
+  const uint32_t rxb = std::max<uint32_t>(1, std::min<uint32_t>(rx_blocks, grid_cap / n + 1));
+  const uint64_t R = j->rounds;
+  if (!j->s_wire) {
+    HIP_TRY(hipStreamCreateWithFlags(&j->s_wire, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&j->s_rxplan, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&j->s_apply, hipStreamNonBlocking));
+  }
+  while (j->pev.size() < 4 * R + 1) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    j->pev.push_back(ev);
+  }
+  auto evG = [&](uint64_t t) { return j->pev[4 * t]; };      // gather_t done
+  auto evW = [&](uint64_t t) { return j->pev[4 * t + 1]; };  // round t is in the ring
+  auto evX = [&](uint64_t t) { return j->pev[4 * t + 2]; };  // rx_plan_t done
+  auto evA = [&](uint64_t t) { return j->pev[4 * t + 3]; };  // rx_apply_t done
+  hipStream_t sW = j->direct ? s : j->s_wire, sX = j->s_rxplan, sA = j->s_apply;
+  hipEvent_t fork = j->pev[4 * R];
+  HIP_TRY(hipEventRecord(fork, s));
+  if (!j->direct) HIP_TRY(hipStreamWaitEvent(sW, fork, 0));
+  HIP_TRY(hipStreamWaitEvent(sX, fork, 0));
+  HIP_TRY(hipStreamWaitEvent(sA, fork, 0));
+  for (uint64_t t = 0; t < R; t++) {
+    const int k = job_opset(t);
+    if (j->direct) {
+      // the plan itself writes the tags into the peer ring: no part of round t may start
+      // before the receiver has finished walking round t-1
+      if (t >= 1) HIP_TRY(hipStreamWaitEvent(s, evX(t - 1), 0));
+      HIP_TRY(grdma_launch_tx_plan(j->d_txop + k * n, n, s));
+      HIP_TRY(grdma_launch_copy(j->d_plans, n, txb, s));
+      HIP_TRY(hipEventRecord(evW(t), s));
+    } else {
+      if (t >= 2) {
+        HIP_TRY(hipStreamWaitEvent(s, evW(t - 2), 0));
+        HIP_TRY(hipStreamWaitEvent(s, evA(t - 2), 0));  // bounds the credit lag to one round
+      }
+      HIP_TRY(grdma_launch_tx_plan(j->d_txop + k * n, n, s));
+      HIP_TRY(grdma_launch_copy(j->d_plans, n, txb, s));
+      HIP_TRY(hipEventRecord(evG(t), s));
+      HIP_TRY(hipStreamWaitEvent(sW, evG(t), 0));
+      if (t >= 1) HIP_TRY(hipStreamWaitEvent(sW, evX(t - 1), 0));
+      HIP_TRY(grdma_launch_copy(j->d_plans + n * (1 + (t & 1)), n, txb, sW));
+      HIP_TRY(hipEventRecord(evW(t), sW));
+    }
+    HIP_TRY(hipStreamWaitEvent(sX, evW(t), 0));
+    if (t >= 2) HIP_TRY(hipStreamWaitEvent(sX, evA(t - 2), 0));
+    HIP_TRY(grdma_launch_rx_plan(j->d_rxop + k * n, n, sX));
+    HIP_TRY(hipEventRecord(evX(t), sX));
+    HIP_TRY(hipStreamWaitEvent(sA, evX(t), 0));
+    HIP_TRY(grdma_launch_rx_apply(j->d_rxop + k * n, n, rxb, sA));
+    HIP_TRY(hipEventRecord(evA(t), sA));
+  }
+  // join the side streams back into the launch stream
+  if (R > 0) {
+    if (!j->direct) HIP_TRY(hipStreamWaitEvent(s, evW(R - 1), 0));
+    HIP_TRY(hipStreamWaitEvent(s, evX(R - 1), 0));
+    HIP_TRY(hipStreamWaitEvent(s, evA(R - 1), 0));
+  }
+  return 0;
+}
+
+
+// The job as an explicitly built HIP graph: 5 kernel nodes per round, edges exactly as
+// listed above (pipelined) or a plain chain (sequential).  Built node by node rather
+// than recorded from the streams: the dependency structure is known here, and it keeps
+// the replay independent of how a runtime records cross-stream joins.
+int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
+  const uint32_t n = (uint32_t)j->links.size();
+  const uint32_t tx_blocks = copy_blocks_for(j->max_ring / 2);
+  const uint32_t rx_blocks = copy_blocks_for(j->max_ring);
+  const uint32_t grid_cap = copy_blocks_for(~0ull >> 8);
+  const uint32_t txb = std::max<uint32_t>(1, std::min<uint32_t>(tx_blocks, grid_cap / n + 1));
+  const uint32_t rxb = std::max<uint32_t>(1, std::min<uint32_t>(rx_blocks, grid_cap / n + 1));
+  const uint64_t R = j->rounds;
+  hipGraph_t g;
+  HIP_TRY(hipGraphCreate(&g, 0));
+  std::vector<hipGraphNode_t> P(R), G(R), W(R), X(R), A(R);
+  auto add = [&](hipGraphNode_t* node, const void* fn, dim3 grid, uint32_t threads, const void* arg,
+                 std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
+    std::vector<hipGraphNode_t> d;
+    for (hipGraphNode_t x : deps)
+      if (x) d.push_back(x);
+    void* args[1] = {const_cast<void*>(static_cast<const void*>(&arg))};
+    hipKernelNodeParams np;
+    memset(&np, 0, sizeof(np));
+    np.func = const_cast<void*>(fn);
+    np.gridDim = grid;
+    np.blockDim = dim3(threads);
+    np.sharedMemBytes = 0;
+    np.kernelParams = args;
+    np.extra = nullptr;
+    return hipGraphAddKernelNode(node, g, d.empty() ? nullptr : d.data(), d.size(), &np);
+  };
+  const void* f_txp = grdma_kernel_fn(0);
+  const void* f_cpy = grdma_kernel_fn(1);
+  const void* f_rxp = grdma_kernel_fn_rx_plan();
+  const void* f_rxa = grdma_kernel_fn(3);
+  const uint32_t pt = grdma_kernel_threads(0), ct = grdma_kernel_threads(1);
+  auto at = [](std::vector<hipGraphNode_t>& v, uint64_t t, uint64_t back) -> hipGraphNode_t {
+    return t >= back ? v[t - back] : nullptr;
+  };
+  hipError_t e = hipSuccess;
+  for (uint64_t t = 0; t < R && e == hipSuccess; t++) {
+    const int k = job_opset(t);
+    const void* txop = j->d_txop + k * n;
+    const void* rxop = j->d_rxop + k * n;
+    const void* gplans = j->d_plans;
+    const void* wplans = j->d_plans + n * (1 + (t & 1));
+    if (!j->pipeline) {
+      hipGraphNode_t prev = at(A, t, 1);
+      e = add(&P[t], f_txp, dim3(n), pt, txop, {prev});
+      if (e == hipSuccess) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t]});
+      hipGraphNode_t last = G[t];
+      W[t] = nullptr;
+      if (!j->direct && e == hipSuccess) {
+        e = add(&W[t], f_cpy, dim3(txb, n), ct, wplans, {G[t]});
+        last = W[t];
+      }
+      if (e == hipSuccess) e = add(&X[t], f_rxp, dim3(n), pt, rxop, {last});
+      if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t]});
+    } else if (j->direct) {
+      e = add(&P[t], f_txp, dim3(n), pt, txop, {at(G, t, 1), at(X, t, 1)});
+      if (e == hipSuccess) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t]});
+      W[t] = nullptr;
+      if (e == hipSuccess) e = add(&X[t], f_rxp, dim3(n), pt, rxop, {G[t], at(A, t, 2)});
+      if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t], at(A, t, 1)});
+    } else {
+      e = add(&P[t], f_txp, dim3(n), pt, txop, {at(G, t, 1), at(W, t, 2), at(A, t, 2)});
+      if (e == hipSuccess) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t]});
+      if (e == hipSuccess) e = add(&W[t], f_cpy, dim3(txb, n), ct, wplans, {G[t], at(X, t, 1)});
+      if (e == hipSuccess) e = add(&X[t], f_rxp, dim3(n), pt, rxop, {W[t], at(A, t, 2)});
+      if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t], at(A, t, 1)});
+    }
+  }
+  if (e != hipSuccess) {
+    hipGraphDestroy(g);
+    return fail(GRDMA_ERR_HIP, "graph construction failed: %s", hipGetErrorString(e));
+  }
+  *out = g;
   return 0;
 }
 
@@ -969,8 +1157,14 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
     l.slices_cap = slices_caps[i];
     if (tx[i]->ring_size > j->max_ring) j->max_ring = tx[i]->ring_size;
     ok = hipMalloc((void**)&l.d_sges, sizeof(grdma_sge) * l.count) == hipSuccess &&
-         hipMalloc((void**)&l.d_slices, sizeof(grdma_slice_out) * l.slices_cap) == hipSuccess;
+         hipMalloc((void**)&l.d_slices, sizeof(grdma_slice_out) * l.slices_cap) == hipSuccess &&
+         hipMalloc((void**)&l.d_wireplan2, sizeof(grdma_plan)) == hipSuccess &&
+         hipMalloc((void**)&l.d_rxplan2, sizeof(grdma_plan)) == hipSuccess &&
+         (j->direct || hipMalloc((void**)&l.d_staging2, tx[i]->ring_size / 2 + 64) == hipSuccess);
     if (!ok) break;
+    hipMemset(l.d_wireplan2, 0, sizeof(grdma_plan));
+    hipMemset(l.d_rxplan2, 0, sizeof(grdma_plan));
+    if (l.d_staging2) hipMemset(l.d_staging2, 0, tx[i]->ring_size / 2 + 64);
     std::vector<grdma_sge> tmp(l.count);
     for (uint64_t q = 0; q < l.count; q++) {
       tmp[q].ptr = static_cast<const uint8_t*>(slices[off + q].ptr);
@@ -979,8 +1173,8 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
     off += l.count;
     ok = hipMemcpy(l.d_sges, tmp.data(), sizeof(grdma_sge) * l.count, hipMemcpyHostToDevice) == hipSuccess;
   }
-  const size_t sz_tx = sizeof(grdma_tx_op) * 2 * n, sz_rx = sizeof(grdma_rx_op) * 2 * n;
-  const size_t sz_txr = sizeof(grdma_tx_result) * n, sz_rxr = sizeof(grdma_rx_result) * n;
+  const size_t sz_tx = sizeof(grdma_tx_op) * 3 * n, sz_rx = sizeof(grdma_rx_op) * 3 * n;
+  const size_t sz_txr = sizeof(grdma_tx_result) * n, sz_rxr = sizeof(grdma_rx_result) * 2 * n;
   const size_t sz_pl = sizeof(grdma_plan*) * 3 * n;
   if (ok) ok = hipMalloc((void**)&j->d_ctl, sz_tx + sz_rx + sz_txr + sz_rxr + sz_pl) == hipSuccess;
   if (!ok) {
@@ -997,21 +1191,25 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
   auto* h_tx = reinterpret_cast<grdma_tx_op*>(host.data());
   auto* h_rx = reinterpret_cast<grdma_rx_op*>(host.data() + sz_tx);
   auto** h_pl = reinterpret_cast<const grdma_plan**>(host.data() + sz_tx + sz_rx + sz_txr + sz_rxr);
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < 3; k++)
     for (uint32_t i = 0; i < n; i++) {
       const grdma_job_link& l = j->links[i];
+      const bool odd = k == 1;
       grdma_tx_op& t = h_tx[k * n + i];
       t.conn = l.tx->d_conn;
       t.slices = l.d_sges;
       t.nslices = l.count;
       t.plan = l.tx->d_txplan;
-      t.wire_plan = l.tx->d_wireplan;
+      t.wire_plan = odd ? l.d_wireplan2 : l.tx->d_wireplan;
+      t.staging_alt = odd ? l.d_staging2 : nullptr;
       t.result = &j->d_txres[i];
       t.use_cursor = k == 0 ? 2 : 1;
+      t.debug_flags = g_debug_flags;
       grdma_rx_op& r = h_rx[k * n + i];
+      r.debug_flags = g_debug_flags;
       r.conn = l.rx->d_conn;
-      r.plan = l.rx->d_rxplan;
-      r.result = &j->d_rxres[i];
+      r.plan = odd ? l.d_rxplan2 : l.rx->d_rxplan;
+      r.result = &j->d_rxres[(odd ? n : 0) + i];
       r.slices = l.d_slices;
       r.arena = l.dst;
       r.arena_cap = l.dst_cap;
@@ -1022,8 +1220,8 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
     }
   for (uint32_t i = 0; i < n; i++) {
     h_pl[i] = j->links[i].tx->d_txplan;
-    h_pl[n + i] = j->links[i].tx->d_wireplan;
-    h_pl[2 * n + i] = j->links[i].rx->d_rxplan;
+    h_pl[n + i] = j->links[i].tx->d_wireplan;   // even rounds
+    h_pl[2 * n + i] = j->links[i].d_wireplan2;  // odd rounds
   }
   // the scatter plans are addressed through the rx ops; the plan pointer array is for k_copy
   if (hipMemcpy(j->d_ctl, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -1046,12 +1244,21 @@ void grdma_stream_job_destroy(grdma_stream_job* j) {
   if (!j) return;
   if (j->stream) hipStreamSynchronize(j->stream);
   if (j->exec) hipGraphExecDestroy(j->exec);
+  for (hipStream_t st : {j->s_wire, j->s_rxplan, j->s_apply})
+    if (st) {
+      hipStreamSynchronize(st);
+      hipStreamDestroy(st);
+    }
   for (hipEvent_t e : j->kev) hipEventDestroy(e);
+  for (hipEvent_t e : j->pev) hipEventDestroy(e);
   if (j->ev0) hipEventDestroy(j->ev0);
   if (j->ev1) hipEventDestroy(j->ev1);
   for (auto& l : j->links) {
     hipFree(l.d_sges);
     hipFree(l.d_slices);
+    hipFree(l.d_wireplan2);
+    hipFree(l.d_rxplan2);
+    hipFree(l.d_staging2);
   }
   hipFree(j->d_ctl);
   delete j;
@@ -1060,6 +1267,14 @@ void grdma_stream_job_destroy(grdma_stream_job* j) {
 int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds) {
   if (!j || rounds == 0) return fail(GRDMA_ERR_INVALID, "bad rounds");
   j->rounds = rounds;
+  return 0;
+}
+
+void grdma_debug_set_flags(uint64_t f) { g_debug_flags = f; }  // tools/ timing experiments
+
+int grdma_stream_job_set_pipeline(grdma_stream_job* j, int on) {
+  if (!j) return fail(GRDMA_ERR_INVALID, "null job");
+  j->pipeline = on ? 1 : 0;
   return 0;
 }
 
@@ -1075,25 +1290,26 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
   }
   memset(out, 0, sizeof(*out));
   if (mode == GRDMA_RUN_GRAPH) {
-    if (!j->exec || j->exec_rounds != j->rounds) {
+    if (!j->exec || j->exec_rounds != j->rounds || j->exec_pipeline != j->pipeline) {
       if (j->exec) hipGraphExecDestroy(j->exec);
       j->exec = nullptr;
       hipGraph_t graph;
-      HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      int rc = job_enqueue(j, s, false);
-      hipError_t e = hipStreamEndCapture(s, &graph);
-      if (rc) return rc;
-      if (e != hipSuccess) return fail(GRDMA_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
+      if (int rc = job_build_graph(j, &graph)) return rc;
       HIP_TRY(hipGraphInstantiate(&j->exec, graph, nullptr, nullptr, 0));
       hipGraphDestroy(graph);
       j->exec_rounds = j->rounds;
+      j->exec_pipeline = j->pipeline;
     }
     HIP_TRY(hipEventRecord(j->ev0, s));
     HIP_TRY(hipGraphLaunch(j->exec, s));
     HIP_TRY(hipEventRecord(j->ev1, s));
   } else {
     HIP_TRY(hipEventRecord(j->ev0, s));
-    if (int rc = job_enqueue(j, s, mode == GRDMA_RUN_INSTRUMENTED)) return rc;
+    if (j->pipeline && mode == GRDMA_RUN_EAGER) {
+      if (int rc = job_enqueue_pipelined(j, s)) return rc;
+    } else {
+      if (int rc = job_enqueue(j, s, mode == GRDMA_RUN_INSTRUMENTED)) return rc;
+    }
     HIP_TRY(hipEventRecord(j->ev1, s));
   }
   HIP_TRY(hipStreamSynchronize(s));
@@ -1150,10 +1366,16 @@ int grdma_stream_job_debug(grdma_stream_job* j, uint64_t* tx_dbg, uint64_t* rx_d
 int grdma_stream_job_launch(grdma_stream_job* j) {
   if (int rc = require_ctx()) return rc;
   if (!j) return fail(GRDMA_ERR_INVALID, "null job");
-  if (!j->exec || j->exec_rounds != j->rounds)
+  if (!j->exec || j->exec_rounds != j->rounds || j->exec_pipeline != j->pipeline)
     return fail(GRDMA_ERR_INVALID, "run the job once in GRDMA_RUN_GRAPH mode before launching it");
   HIP_TRY(hipGraphLaunch(j->exec, j->stream));
   return 0;
+}
+
+int grdma_stream_job_launch_streams(grdma_stream_job* j) {
+  if (int rc = require_ctx()) return rc;
+  if (!j) return fail(GRDMA_ERR_INVALID, "null job");
+  return j->pipeline ? job_enqueue_pipelined(j, j->stream) : job_enqueue(j, j->stream, false);
 }
 
 int grdma_stream_job_sync(grdma_stream_job* j) {

@@ -194,7 +194,10 @@ struct rx_state {
   uint32_t took;
 };
 
-__device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
+__device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
+  // (a private copy: fields read through the reference would be re-fetched from memory
+  // after every store the compiler cannot prove unrelated)
+  const grdma_rx_op op = op_in;
   const uint64_t t_begin = __builtin_amdgcn_s_memtime();
   const unsigned tid = threadIdx.x;
   const int lane = tid & 63;
@@ -216,6 +219,8 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
   __shared__ uint32_t s_n[RXP(BULK_MAX) + 1];
   __shared__ uint16_t s_sin[RXP(BULK_MAX) + 1];
   __shared__ uint64_t s_wave[PLAN_THREADS / 64];
+  __shared__ uint64_t s_wbytes[PLAN_THREADS / 64], s_wn[PLAN_THREADS / 64];
+  __shared__ uint32_t s_wpk[PLAN_THREADS / 64], s_wtiles[PLAN_THREADS / 64];
   __shared__ unsigned int s_key, s_fail, s_clean;
   __shared__ uint64_t s_dbg[16];
 
@@ -253,6 +258,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     for (int q = 0; q < 16; q++) s_dbg[q] = 0;
   }
   __syncthreads();
+  if (tid == 0) s_dbg[14] = __builtin_amdgcn_s_memtime() - t_begin;  // prologue
 
   // ===================================================================== bulk tier
   auto bulk = [&]() -> uint32_t {
@@ -393,6 +399,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     }
     __syncthreads();
     const uint64_t tb1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) s_dbg[15] += tb1 - tb0;
     // ---- probe every predicted header / footer pair at once ---------------------------
     const uint64_t head = S.head;
     // room: slices <= 2 per record, segments <= 2 per record + 1 wrap, arena by offsets
@@ -414,11 +421,10 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
         const uint32_t i = tid + r * PLAN_THREADS;
         const uint64_t x = s_xenc[RXP(i)], e = s_penc[RXP(i)];
         want[r] = i < vmax && x + e <= cap - 8 && x + e + 32ull * (i + 1) <= arena_room;
-        hdrs[r] = foots[r] = 0;
-        if (want[r]) {
-          hdrs[r] = ld_tag(ring + ((head + x) & mask));
-          foots[r] = ld_tag(ring + ((head + x + e - 8) & mask));
-        }
+        // (unconditional: a masked offset is always inside the ring, and straight-line
+        // loads are all issued before the first wait)
+        hdrs[r] = ld_tag(ring + ((head + x) & mask & ~7ull));
+        foots[r] = ld_tag(ring + ((head + x + e - 8) & mask & ~7ull));
       }
       uint32_t first_bad = 0xFFFFFFFFu;
 #pragma unroll
@@ -448,6 +454,10 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     if (tid == 0) s_dbg[9] += tb2 - tb1;
     if (tid == 0) { s_dbg[6] = P; s_dbg[7] = V; }
     if (V < BULK_MAX && tid == 0) {
+      // The verified run ended before the prediction did: either the data ends here or
+      // the pattern changed.  Another bulk pass would probe thousands of predicted
+      // positions to learn the same thing, so the wave tier finishes this call.
+      S.bulk_tries = 1;
       // Was the first unverified record a misprediction (a complete record of another
       // size) or simply the end of what has arrived?  Three mispredicted drain starts
       // in a row retire the remembered period.
@@ -492,74 +502,117 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     const uint64_t tb3 = __builtin_amdgcn_s_memtime();
     if (tid == 0) s_dbg[10] += tb3 - tb2;
     if (cnt == 0) return 0;
-    // ---- pass 1: per-thread totals, block prefix --------------------------------------
-    const uint32_t per1 = (cnt + PLAN_THREADS - 1) / PLAN_THREADS;
-    const uint32_t q0 = tid * per1;
-    uint64_t t_bytes = 0, t_sl = 0, t_sg = 0, t_tiles = 0, t_n = 0;
-    for (uint32_t k = q0; k < q0 + per1 && k < cnt; k++) {
-      const rec_plan rp = replay_record(s_n[RXP(k)], s_sin[RXP(k)]);
-      const uint64_t pay = (head + s_xenc[RXP(k)] + 8) & mask;
-      uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
-      split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
-      split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
-      t_bytes += al16(rp.sl0) + al16(rp.sl1);
-      t_sl += rp.sl_cnt;
-      t_sg += (l0 ? 1 : 0) + (l1 ? 1 : 0) + (l2 ? 1 : 0) + (l3 ? 1 : 0);
-      t_tiles += tiles_of(l0) + tiles_of(l1) + tiles_of(l2) + tiles_of(l3);
-      t_n += s_n[RXP(k)];
+    // ---- pass 1: totals per wave --------------------------------------------------------
+    // The cnt records are dealt to the four waves in contiguous quarters and, inside a
+    // wave, to lanes round-robin: neighbouring lanes then write neighbouring plan and
+    // slice-table entries in pass 2 (coalesced 32-byte / 16-byte stores).
+    constexpr uint32_t NW = PLAN_THREADS / 64;
+    const uint32_t wchunk = (((cnt + NW - 1) / NW) + 63u) & ~63u;
+    const uint32_t wbeg = wave * wchunk < cnt ? wave * wchunk : cnt;
+    const uint32_t wend = wbeg + wchunk < cnt ? wbeg + wchunk : cnt;
+    {
+      uint64_t t_bytes = 0, t_n = 0;
+      uint32_t t_pk = 0, t_tiles = 0;  // t_pk: slices | segments << 16 (<= 2 and 4 per record)
+      for (uint32_t k = wbeg + lane; k < wend; k += 64) {
+        const rec_plan rp = replay_record(s_n[RXP(k)], s_sin[RXP(k)]);
+        const uint64_t pay = (head + s_xenc[RXP(k)] + 8) & mask;
+        uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
+        split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
+        split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
+        t_bytes += al16(rp.sl0) + al16(rp.sl1);
+        t_pk += rp.sl_cnt + (((l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u)) << 16);
+        t_tiles += tiles_of(l0) + tiles_of(l1) + tiles_of(l2) + tiles_of(l3);
+        t_n += s_n[RXP(k)];
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        t_bytes += __shfl_xor(t_bytes, d, 64);
+        t_n += __shfl_xor(t_n, d, 64);
+        t_pk += __shfl_xor(t_pk, d, 64);
+        t_tiles += __shfl_xor(t_tiles, d, 64);
+      }
+      if (lane == 0) {
+        s_wbytes[wave] = t_bytes;
+        s_wn[wave] = t_n;
+        s_wpk[wave] = t_pk;
+        s_wtiles[wave] = t_tiles;
+      }
     }
-    uint64_t tot_bytes, tot_sl, tot_sg, tot_tiles, tot_n;
-    uint64_t x_bytes = block_excl_scan(t_bytes, s_wave, &tot_bytes);
-    uint64_t x_sl = block_excl_scan(t_sl, s_wave, &tot_sl);
-    uint64_t x_sg = block_excl_scan(t_sg, s_wave, &tot_sg);
-    uint64_t x_tiles = block_excl_scan(t_tiles, s_wave, &tot_tiles);
-    block_excl_scan(t_n, s_wave, &tot_n);
+    __syncthreads();
+    uint64_t tot_bytes = 0, tot_sl = 0, tot_sg = 0, tot_tiles = 0, tot_n = 0;
+    uint64_t c_bytes = 0, c_sl = 0, c_sg = 0, c_tiles = 0;  // running prefix of this wave
+#pragma unroll
+    for (uint32_t w = 0; w < NW; w++) {
+      const uint64_t b = s_wbytes[w], sl = s_wpk[w] & 0xFFFFu, sg = s_wpk[w] >> 16, tl = s_wtiles[w];
+      if (w < wave) { c_bytes += b; c_sl += sl; c_sg += sg; c_tiles += tl; }
+      tot_bytes += b; tot_sl += sl; tot_sg += sg; tot_tiles += tl; tot_n += s_wn[w];
+    }
     const uint64_t tb4 = __builtin_amdgcn_s_memtime();
     if (tid == 0) s_dbg[11] += tb4 - tb3;
     // ---- pass 2: segments, slices, tag clearing -------------------------------------------
     const uint64_t nsegs0 = S.nsegs, ntiles0 = S.ntiles, nsl0 = S.nslices, a0 = S.a_off;
-    for (uint32_t k = q0; k < q0 + per1 && k < cnt; k++) {
-      const uint64_t n = s_n[RXP(k)];
-      const uint32_t s_in = s_sin[RXP(k)];
-      const rec_plan rp = replay_record(n, s_in);
-      const uint64_t pos = (head + s_xenc[RXP(k)]) & mask, pay = (pos + 8) & mask;
+    for (uint32_t base = wbeg; base < wend; base += 64) {
+      const uint32_t k = base + lane;
+      const bool act = k < wend;
+      const uint64_t n = act ? s_n[RXP(k)] : 0;
+      const uint32_t s_in = act ? s_sin[RXP(k)] : 0;
+      rec_plan rp = replay_record(n, s_in);
+      if (!act) { rp.c1 = rp.c2 = 0; rp.sl_cnt = 0; rp.sl0 = rp.sl1 = 0; }
+      const uint64_t pos = (head + (act ? s_xenc[RXP(k)] : 0)) & mask, pay = (pos + 8) & mask;
       uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
       split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
       split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
-      const uint64_t A = a0 + x_bytes;                    // start of the open / next slice
-      const uint64_t filled = s_in ? MINRD - s_in : 0;
-      // the steps of one record are contiguous in the arena: step 1 fills the
-      // open 256-byte slice exactly, step 2 starts the next slice right behind it
-      uint64_t dst = (uint64_t)op.arena + A + filled;
-      auto emit = [&](uint64_t off, uint64_t len) {
-        if (len == 0) return;
-        plan->segs[nsegs0 + x_sg] = {dst, (uint64_t)(ring + off), len, GRDMA_SEG_ZERO_SRC};
-        plan->tile_prefix[nsegs0 + x_sg] = (uint32_t)(ntiles0 + x_tiles);
-        x_sg++;
-        x_tiles += tiles_of(len);
-        dst += len;
-      };
-      emit(o0, l0);
-      emit(o1, l1);
-      emit(o2, l2);
-      emit(o3, l3);
-      uint64_t sof = A;
-      if (rp.sl0) {
-        out_slices[nsl0 + x_sl].off = sof;
-        out_slices[nsl0 + x_sl].len = rp.sl0;
-        x_sl++;
-        sof += al16(rp.sl0);
+      const uint32_t my_sg = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
+      const uint32_t my_pk = rp.sl_cnt | (my_sg << 16);
+      const uint32_t my_tiles = tiles_of(l0) + tiles_of(l1) + tiles_of(l2) + tiles_of(l3);
+      // (the ring holds < 2^31 bytes in a bulk pass, so 32-bit scans of one step's bytes are exact)
+      const uint32_t my_bytes = (uint32_t)(al16(rp.sl0) + al16(rp.sl1));
+      const uint32_t i_pk = wave_incl_scan_u32(my_pk);
+      const uint32_t i_tiles = wave_incl_scan_u32(my_tiles);
+      const uint32_t i_bytes = wave_incl_scan_u32(my_bytes);
+      if (act) {
+        uint64_t x_sl = c_sl + (i_pk & 0xFFFFu) - rp.sl_cnt;
+        uint64_t x_sg = c_sg + (i_pk >> 16) - my_sg;
+        uint64_t x_tiles = c_tiles + i_tiles - my_tiles;
+        const uint64_t A = a0 + c_bytes + i_bytes - my_bytes;  // start of the open / next slice
+        const uint64_t filled = s_in ? MINRD - s_in : 0;
+        // the steps of one record are contiguous in the arena: step 1 fills the
+        // open 256-byte slice exactly, step 2 starts the next slice right behind it
+        uint64_t dst = (uint64_t)op.arena + A + filled;
+        // header, padding and footer (ring_buffer.cc:146,173-180) are cleared by the
+        // scatter waves of the record's first / last piece: GRDMA_SEG_TAG_* in grdma_dev.h
+        const int last_piece = l3 ? 3 : (l2 ? 2 : (l1 ? 1 : 0));
+        auto emit = [&](uint64_t off, uint64_t len, int piece) {
+          if (len == 0) return;
+          const uint64_t fl = GRDMA_SEG_ZERO_SRC | (piece == 0 ? GRDMA_SEG_TAG_HDR : 0) |
+                              (piece == last_piece ? GRDMA_SEG_TAG_FTR : 0);
+          plan->segs[nsegs0 + x_sg] = {dst, (uint64_t)(ring + off), len, fl};
+          plan->tile_prefix[nsegs0 + x_sg] = (uint32_t)(ntiles0 + x_tiles);
+          x_sg++;
+          x_tiles += tiles_of(len);
+          dst += len;
+        };
+        emit(o0, l0, 0);
+        emit(o1, l1, 1);
+        emit(o2, l2, 2);
+        emit(o3, l3, 3);
+        uint64_t sof = A;
+        if (rp.sl0) {
+          out_slices[nsl0 + x_sl].off = sof;
+          out_slices[nsl0 + x_sl].len = rp.sl0;
+          x_sl++;
+          sof += al16(rp.sl0);
+        }
+        if (rp.sl1) {
+          out_slices[nsl0 + x_sl].off = sof;
+          out_slices[nsl0 + x_sl].len = rp.sl1;
+        }
       }
-      if (rp.sl1) {
-        out_slices[nsl0 + x_sl].off = sof;
-        out_slices[nsl0 + x_sl].len = rp.sl1;
-        x_sl++;
-      }
-      x_bytes += al16(rp.sl0) + al16(rp.sl1);
-      // clear header, padding and footer (ring_buffer.cc:146,173-180)
-      *reinterpret_cast<uint64_t*>(ring + pos) = 0;
-      for (uint64_t q = n; q < round_up8(n); q++) ring[(pay + q) & mask] = 0;
-      *reinterpret_cast<uint64_t*>(ring + ((pay + round_up8(n)) & mask)) = 0;
+      const uint32_t w_pk = __shfl(i_pk, 63, 64);
+      c_sl += w_pk & 0xFFFFu;
+      c_sg += w_pk >> 16;
+      c_tiles += __shfl(i_tiles, 63, 64);
+      c_bytes += __shfl(i_bytes, 63, 64);
     }
     const uint64_t tb5 = __builtin_amdgcn_s_memtime();
     if (tid == 0) s_dbg[12] += tb5 - tb4;
@@ -772,18 +825,21 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
       uint64_t x_tiles = i_tiles - my_tiles;
       if (act) {
         uint64_t dst = (uint64_t)op.arena + A + filled;  // steps are contiguous in the arena
-        auto emit = [&](uint64_t off, uint64_t len) {
+        const int last_piece = l3 ? 3 : (l2 ? 2 : (l1 ? 1 : 0));
+        auto emit = [&](uint64_t off, uint64_t len, int piece) {
           if (len == 0) return;
-          plan->segs[nsegs + x_segs] = {dst, (uint64_t)(ring + off), len, GRDMA_SEG_ZERO_SRC};
+          const uint64_t fl = GRDMA_SEG_ZERO_SRC | (piece == 0 ? GRDMA_SEG_TAG_HDR : 0) |
+                              (piece == last_piece ? GRDMA_SEG_TAG_FTR : 0);
+          plan->segs[nsegs + x_segs] = {dst, (uint64_t)(ring + off), len, fl};
           plan->tile_prefix[nsegs + x_segs] = (uint32_t)(ntiles + x_tiles);
           x_segs++;
           x_tiles += tiles_of(len);
           dst += len;
         };
-        emit(o0, l0);
-        emit(o1, l1);
-        emit(o2, l2);
-        emit(o3, l3);
+        emit(o0, l0, 0);
+        emit(o1, l1, 1);
+        emit(o2, l2, 2);
+        emit(o3, l3, 3);
         uint64_t so = A;
         uint64_t xs = nslices + x_slices;
         if (rp.sl0) {
@@ -796,9 +852,6 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
           out_slices[xs].off = so;
           out_slices[xs].len = rp.sl1;
         }
-        *reinterpret_cast<uint64_t*>(ring + pos) = 0;
-        for (uint64_t q = n; q < round_up8(n); q++) ring[(pay + q) & mask] = 0;
-        *reinterpret_cast<uint64_t*>(ring + ((pay + round_up8(n)) & mask)) = 0;
         s_hist[(hist_count + lane) % GRDMA_RX_HIST] = enc;
       }
       const uint64_t pad_foot = round_up8(n) - n + 8;
@@ -936,6 +989,8 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
       plan->nsegs = (uint32_t)S.nsegs;
       plan->ntiles = (uint32_t)S.ntiles;
       plan->tile_prefix[S.nsegs] = (uint32_t)S.ntiles;
+      plan->tag_base = (uint64_t)ring;
+      plan->tag_mask = mask;
     }
     __syncthreads();
     run_plan_tiles(plan, wave, PLAN_THREADS / 64, lane);
@@ -955,6 +1010,8 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     plan->ntiles = (uint32_t)S.ntiles;
     plan->tile_prefix[nsegs] = (uint32_t)S.ntiles;
     plan->bytes = S.bytes;
+    plan->tag_base = (uint64_t)ring;
+    plan->tag_mask = mask;
 
     c->head = head;
     c->moving_head = mh;
@@ -969,7 +1026,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
       c->rx_arena_off = S.a_off;
       c->rx_slice_idx = (op.append == 2 ? 0 : c->rx_slice_idx) + nslices;
     }
-    c->rx_blocks_done = 0;
+    res->blocks_done = 0;
     // updateStatus() (pair.cc:624-641) must not overtake the copy-out and the
     // zero-fill of the bytes it grants: the 16-byte report is posted by the last
     // workgroup of k_rx_apply.
@@ -985,15 +1042,16 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op) {
     res->moving_head = mh;
     res->remain = S.remain;
     res->arena_used = S.a_off;
-    res->dbg[13] = t_loop_end;
-    res->dbg[14] = __builtin_amdgcn_s_memtime();
     res->dbg[0] = t_begin;
     res->dbg[1] = __builtin_amdgcn_s_memtime();
     res->dbg[2] = s_dbg[0];
     res->dbg[3] = s_dbg[1];
     res->dbg[4] = s_dbg[2];
     res->dbg[5] = s_dbg[3];
-    for (int q = 6; q < 16; q++) res->dbg[q] = s_dbg[q];
+    for (int q = 6; q < 13; q++) res->dbg[q] = s_dbg[q];
+    res->dbg[13] = t_loop_end - t_begin;
+    res->dbg[14] = s_dbg[14];
+    res->dbg[15] = s_dbg[15];
     // consumed ring bytes are always the contiguous range [mh0, mh)
     res->zero_off[0] = res->zero_off[1] = res->zero_len[0] = res->zero_len[1] = 0;
     if (S.consumed_total > 0) {
@@ -1136,6 +1194,8 @@ extern "C" hipError_t grdma_launch_engine(grdma_engine_mbox* mb, hipStream_t s) 
   hipLaunchKernelGGL(k_engine, dim3(1), dim3(PLAN_THREADS), 0, s, mb);
   return hipGetLastError();
 }
+
+extern "C" const void* grdma_kernel_fn_rx_plan(void) { return reinterpret_cast<const void*>(&k_rx_plan); }
 
 extern "C" hipError_t grdma_launch_rx_plan(const grdma_rx_op* d_ops, uint32_t nops,
                                            hipStream_t s) {

@@ -176,7 +176,8 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
 // that comes up short -- which is exactly where the reference's sequential loop
 // stops (pair.cc:671-707).  Global loads/stores are
 // striped over the block (record i -> thread i % 256) so they coalesce.
-__device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
+__device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
+  const grdma_tx_op op = op_in;  // private copy: no re-fetch through the reference after stores
   grdma_conn* c = op.conn;
   grdma_plan* plan = op.plan;
   __shared__ uint64_t s_wave[PLAN_THREADS / 64];
@@ -246,13 +247,31 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
   if (!connected) m = 0;
 
   tdbg[1] = __builtin_amdgcn_s_memtime();
-  // lengths, striped
-  for (uint64_t i = tid; i < m; i += PLAN_THREADS) {
-    uint64_t l = sl[i].len;
-    if (i == 0) l = sat_sub(l, byte_idx);
-    s_len[TXP(i)] = l;
+  // slice table, striped: thread `tid` owns records tid, tid + 256, ...; all of its
+  // 16-byte {ptr, len} loads are in flight together and stay in registers for the
+  // segment pass below (no second trip to the table)
+  constexpr int NPT = GRDMA_TX_MAX_RECORDS / PLAN_THREADS;
+  uint64_t r_ptr[NPT], r_len[NPT];
+#pragma unroll
+  for (int r = 0; r < NPT; r++) r_ptr[r] = r_len[r] = 0;
+  if (m) {
+    // (clamped, unconditional, and no LDS store in between: the table pointer is a
+    // generic pointer, so every store to LDS would otherwise fence the loads behind it)
+#pragma unroll
+    for (int r = 0; r < NPT; r++) {
+      const uint64_t i = tid + (uint64_t)r * PLAN_THREADS;
+      const grdma_sge g = sl[i < m ? i : m - 1];
+      r_ptr[r] = reinterpret_cast<uint64_t>(g.ptr);
+      r_len[r] = g.len;
+    }
+#pragma unroll
+    for (int r = 0; r < NPT; r++) {
+      const uint64_t i = tid + (uint64_t)r * PLAN_THREADS;
+      if (i < m) s_len[TXP(i)] = i == 0 ? sat_sub(r_len[r], byte_idx) : r_len[r];
+    }
   }
   __syncthreads();
+  const uint64_t t_loaded = __builtin_amdgcn_s_memtime();
 
   // st_i: each thread scans a contiguous run of `per` records out of LDS
   const uint64_t per = (m + PLAN_THREADS - 1) / PLAN_THREADS;
@@ -321,7 +340,10 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
   // destination of record i: staging + st_i, or the peer ring itself at
   // (tail0 + st_i) & mask when the wire is direct.
   const bool direct = c->wire_direct != 0;
-  uint8_t* const dbase = direct ? c->peer_ring : c->staging;
+  // (a pipelined job alternates between two staging buffers so that the plan of the next
+  // Send can be laid out while the wire still reads the previous one)
+  uint8_t* const staging = op.staging_alt ? op.staging_alt : c->staging;
+  uint8_t* const dbase = direct ? c->peer_ring : staging;
   if (direct) {
     for (uint64_t i = tid; i < nrec_total; i += PLAN_THREADS) {
       const uint64_t pstart = (tail0 + s_excl[TXP(i)] + 8) & mask;
@@ -332,29 +354,30 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
   const uint64_t wrap_rec = s_wrap_rec;
 
   tdbg[3] = __builtin_amdgcn_s_memtime();
-  // tags + segments, striped
+  // segments, striped.  AppendHeader / AppendFooter (ring_buffer.h:84-99) and the
+  // deterministic zero padding (the reference leaves stale staging bytes there) are
+  // written by the gather waves that move the first / last tile of each record: see
+  // GRDMA_SEG_TAG_* in grdma_dev.h
   uint64_t sent_part = 0;
-  for (uint64_t i = tid; i < nrec_total; i += PLAN_THREADS) {
+#pragma unroll
+  for (int r = 0; r < NPT; r++) {
+    const uint64_t i = tid + (uint64_t)r * PLAN_THREADS;
+    if (i >= nrec_total) break;
     const uint64_t p = s_len[TXP(i)];
     const uint64_t st = s_excl[TXP(i)];
     sent_part += p;
     const uint64_t hdr_off = direct ? ((tail0 + st) & mask) : st;
     const uint64_t pay_off = direct ? ((hdr_off + 8) & mask) : st + 8;
-    const uint64_t foot_off = direct ? ((hdr_off + 8 + round_up8(p)) & mask) : st + 8 + round_up8(p);
-    // AppendHeader / AppendFooter, ring_buffer.h:84-99
-    *reinterpret_cast<uint64_t*>(dbase + hdr_off) = p;
-    *reinterpret_cast<uint64_t*>(dbase + foot_off) = GRDMA_FOOTER;
-    // deterministic zero padding (the reference leaves stale staging bytes there)
-    for (uint64_t q = p; q < round_up8(p); q++)
-      dbase[direct ? ((pay_off + q) & mask) : pay_off + q] = 0;
-    const uint8_t* src = sl[i].ptr + (i == 0 ? byte_idx : 0);
+    const uint64_t tagw = GRDMA_SEG_TAG_WRITE | (p << GRDMA_SEG_TAG_LEN_SHIFT);
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(r_ptr[r]) + (i == 0 ? byte_idx : 0);
     const uint64_t seg = i + (i > wrap_rec ? 1 : 0);
     if (i == wrap_rec) {
       const uint64_t l1 = cap - pay_off;
-      plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, l1, 0};
-      plan->segs[seg + 1] = {(uint64_t)dbase, (uint64_t)(src + l1), p - l1, 0};
+      plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, l1, tagw | GRDMA_SEG_TAG_HDR};
+      plan->segs[seg + 1] = {(uint64_t)dbase, (uint64_t)(src + l1), p - l1, tagw | GRDMA_SEG_TAG_FTR};
     } else {
-      plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, p, 0};
+      plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, p,
+                         tagw | GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR};
     }
   }
   uint64_t sent;
@@ -402,6 +425,8 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
     plan->ntiles = (uint32_t)ntiles;
     plan->tile_prefix[nsegs] = (uint32_t)ntiles;
     plan->bytes = sent;
+    plan->tag_base = (uint64_t)dbase;
+    plan->tag_mask = direct ? mask : ~0ull;
     const uint64_t new_tail = (tail0 + staged) & mask;
     // the ≤2 RDMA WRITEs of GetWriteRequests(sg_list), ring_buffer.cc:261-330
     uint64_t seg1 = staged < cap - tail0 ? staged : cap - tail0;
@@ -422,12 +447,12 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
     if (wp != nullptr) {
       uint32_t ns = 0, nt = 0;
       if (!direct && staged > 0) {
-        wp->segs[0] = {(uint64_t)(c->peer_ring + tail0), (uint64_t)c->staging, seg1, 0};
+        wp->segs[0] = {(uint64_t)(c->peer_ring + tail0), (uint64_t)staging, seg1, 0};
         wp->tile_prefix[0] = 0;
         nt = (uint32_t)((seg1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
         ns = 1;
         if (staged > seg1) {
-          wp->segs[1] = {(uint64_t)c->peer_ring, (uint64_t)(c->staging + seg1), staged - seg1, 0};
+          wp->segs[1] = {(uint64_t)c->peer_ring, (uint64_t)(staging + seg1), staged - seg1, 0};
           wp->tile_prefix[1] = nt;
           nt += (uint32_t)((staged - seg1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
           ns = 2;
@@ -463,6 +488,7 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op) {
     r->done = (idx >= op.nslices) ? 1 : 0;
     tdbg[6] = __builtin_amdgcn_s_memtime();
     for (int q = 0; q < 7; q++) r->dbg[q] = tdbg[q];
+    r->dbg[8] = t_loaded;
     r->dbg[7] = m;
   }
   if (op.inline_copy) {

@@ -31,7 +31,9 @@ def _bind():
         lib.grdma_stream_job_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(StreamResult)]
         lib.grdma_stream_job_slices.argtypes = [C.c_void_p, C.POINTER(ReadSlice), u64]
         lib.grdma_stream_job_set_rounds.argtypes = [C.c_void_p, u64]
+        lib.grdma_stream_job_set_pipeline.argtypes = [C.c_void_p, C.c_int]
         lib.grdma_stream_job_launch.argtypes = [C.c_void_p]
+        lib.grdma_stream_job_launch_streams.argtypes = [C.c_void_p]
         lib.grdma_stream_job_create_multi.restype = C.c_void_p
         lib.grdma_stream_job_create_multi.argtypes = [C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                       C.POINTER(Slice), C.POINTER(u64), C.POINTER(C.c_void_p),
@@ -58,13 +60,19 @@ class StreamJob:
     def set_rounds(self, n):
         check(self.lib.grdma_stream_job_set_rounds(self.h, n))
 
+    def set_pipeline(self, on):
+        check(self.lib.grdma_stream_job_set_pipeline(self.h, 1 if on else 0))
+
     def run(self, mode=RUN_GRAPH):
         r = StreamResult()
         check(self.lib.grdma_stream_job_run(self.h, mode, C.byref(r)))
         return r
 
-    def launch(self):
-        check(self.lib.grdma_stream_job_launch(self.h))
+    def launch(self, streams=False):
+        if streams:
+            check(self.lib.grdma_stream_job_launch_streams(self.h))
+        else:
+            check(self.lib.grdma_stream_job_launch(self.h))
 
     def sync(self):
         check(self.lib.grdma_stream_job_sync(self.h))

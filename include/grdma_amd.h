@@ -214,9 +214,15 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
 /* Asynchronous form for timed loops: enqueue one pass (the captured graph) on
  * the link's stream without reading any state back; _sync() waits for it. */
 int grdma_stream_job_launch(grdma_stream_job* j);
+/* Same work as _launch, issued kernel by kernel on the job's streams (no graph). */
+int grdma_stream_job_launch_streams(grdma_stream_job* j);
 int grdma_stream_job_sync(grdma_stream_job* j);
 int grdma_stream_job_slices(grdma_stream_job* j, grdma_read_slice* out, uint64_t cap);
 int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds);
+/* on != 0: run the rounds as a software pipeline (the send plan and gather of round t+1
+ * and the scatter of round t overlap the wire and ring walk of neighbouring rounds, as
+ * two hosts do over a NIC).  Same bytes delivered; affects GRDMA_RUN_GRAPH and _EAGER. */
+int grdma_stream_job_set_pipeline(grdma_stream_job* j, int on);
 
 /* ---- HTTP/2 DATA framing / deframing on the device --------------------------------- */
 typedef struct grdma_h2_msg {     /* one gRPC message queued on a stream              */

@@ -3,6 +3,7 @@ import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__
 import bench, grpc_rdma_amd as g
 from grpc_rdma_amd import stream as gs
 g.init(0)
+g.load().grdma_debug_set_flags(C.c_uint64(int(os.environ.get('DBGF','0'))))
 ring=int(os.environ.get('RING_KB','4096'))<<10
 tx,rx=g.Pair(ring,4095,0),g.Pair(ring,4095,0); g.connect_pairs(tx,rx)
 wl=bench.Workload(g,int(os.environ.get('MSGS','16')))
@@ -17,8 +18,8 @@ lib.grdma_stream_job_debug.argtypes=[C.c_void_p,C.POINTER(C.c_uint64),C.POINTER(
 t=(C.c_uint64*16)(); rr=(C.c_uint64*16)()
 lib.grdma_stream_job_debug(job.h,t,rr)
 t=[int(x) for x in t]; rr=[int(x) for x in rr]
-print("tx stamps (memtime ticks, 100MHz => 10ns):", [t[i]-t[0] for i in range(7)], "m=",t[7])
-print("rx: total", rr[1]-rr[0], "rounds", rr[2], "fast", rr[3], "scalar", rr[4], "bulk_took", rr[5], "P", rr[6], "V", rr[7], "cycles: period", rr[8], "probe", rr[9], "pass0", rr[10], "pass1", rr[11], "pass2", rr[12])
+print("tx stamps (memtime ticks, 100MHz => 10ns):", [t[i]-t[0] for i in range(7)], "m=",t[7], "loaded", t[8]-t[0])
+print("rx: total", rr[1]-rr[0], "rounds", rr[2], "fast", rr[3], "scalar", rr[4], "bulk_took", rr[5], "P", rr[6], "V", rr[7], "cycles: period", rr[8], "probe", rr[9], "pass0", rr[10], "pass1", rr[11], "pass2", rr[12], "loop_total", rr[13], "prologue", rr[14], "period+predict", rr[15])
 
 hist=(C.c_uint32*1024)(); cnt=C.c_uint64(0); per=C.c_uint32(0)
 lib.grdma_pair_debug_hist.argtypes=[C.c_void_p,C.POINTER(C.c_uint32),C.POINTER(C.c_uint64),C.POINTER(C.c_uint32)]
