@@ -76,7 +76,7 @@ struct grdma_conn {
   uint32_t max_sge;             // max_sge_num_
   uint32_t status;              // grdma_pair_status
   uint32_t wire_direct;         // 1: encode straight into peer_ring (no staging)
-  uint32_t pad0;
+  uint32_t tx_last_records;     // records the previous Send produced (sizes the next pricing window)
   // ---- credit the peer granted me (written remotely) --------------------------
   struct grdma_status_report status_recv;   // recv_buffers_[kStatusBuffer]
   struct grdma_status_report status_send;   // send_buffers_[kStatusBuffer]
@@ -87,7 +87,7 @@ struct grdma_conn {
   uint64_t rx_rounds;           // drains that delivered at least one slice
   uint64_t tx_records;          // ring records produced
   uint64_t rx_records;          // ring records consumed
-  uint32_t rx_blocks_done;      // k_rx_apply arrival counter (last block commits)
+  uint32_t pad1;
   uint32_t pad2;
   uint64_t tx_remaining;        // bytes of the current slice list not yet accepted
   uint32_t* rx_hist;            // encoded sizes of the last GRDMA_RX_HIST records read

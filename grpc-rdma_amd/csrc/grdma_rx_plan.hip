@@ -156,6 +156,34 @@ __device__ __forceinline__ rec_plan replay_record(uint64_t n, uint32_t s_in) {
   return r;
 }
 
+// The same in 32-bit arithmetic, for the bulk tier (ring <= 2 GiB there): half the
+// VALU work of the 64-bit form on the pass that is instruction-issue bound.
+struct rec_plan32 {
+  uint32_t c1, c2, sl0, sl1, sl_cnt;
+};
+__device__ __forceinline__ rec_plan32 replay_record32(uint32_t n, uint32_t s_in) {
+  rec_plan32 r;
+  r.c1 = n;
+  r.c2 = 0;
+  r.sl0 = r.sl1 = 0;
+  if (s_in == 0) {
+    if (n >= MINRD) r.sl0 = n;
+  } else if (n <= s_in) {
+    if (n == s_in) r.sl0 = MINRD;
+  } else {
+    r.c1 = s_in;
+    r.c2 = n - s_in;
+    r.sl0 = MINRD;
+    if (r.c2 >= MINRD) r.sl1 = r.c2;
+  }
+  r.sl_cnt = (r.sl0 ? 1u : 0u) + (r.sl1 ? 1u : 0u);
+  return r;
+}
+__device__ __forceinline__ uint32_t al16_32(uint32_t v) { return (v + 15u) & ~15u; }
+__device__ __forceinline__ uint32_t tiles_of32(uint32_t len) {
+  return (len + (uint32_t)GRDMA_TILE_BYTES - 1u) / (uint32_t)GRDMA_TILE_BYTES;
+}
+
 // The ring pieces of one record's steps: step 1 = pieces 0,1; step 2 = pieces 2,3
 // (the second piece of a step exists only when the step crosses the ring end).
 struct rec_pieces {
@@ -510,19 +538,29 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     const uint32_t wchunk = (((cnt + NW - 1) / NW) + 63u) & ~63u;
     const uint32_t wbeg = wave * wchunk < cnt ? wave * wchunk : cnt;
     const uint32_t wend = wbeg + wchunk < cnt ? wbeg + wchunk : cnt;
+    // (32-bit arithmetic: the ring is at most 2 GiB in a bulk pass.  At most one record of
+    // the pass straddles the ring end; only that lane takes the 4-piece path.)
+    const uint32_t cap32 = (uint32_t)cap, mask32 = (uint32_t)mask, head32 = (uint32_t)head;
     {
       uint64_t t_bytes = 0, t_n = 0;
       uint32_t t_pk = 0, t_tiles = 0;  // t_pk: slices | segments << 16 (<= 2 and 4 per record)
       for (uint32_t k = wbeg + lane; k < wend; k += 64) {
-        const rec_plan rp = replay_record(s_n[RXP(k)], s_sin[RXP(k)]);
-        const uint64_t pay = (head + s_xenc[RXP(k)] + 8) & mask;
-        uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
-        split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
-        split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
-        t_bytes += al16(rp.sl0) + al16(rp.sl1);
-        t_pk += rp.sl_cnt + (((l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u)) << 16);
-        t_tiles += tiles_of(l0) + tiles_of(l1) + tiles_of(l2) + tiles_of(l3);
-        t_n += s_n[RXP(k)];
+        const uint32_t n = s_n[RXP(k)];
+        const rec_plan32 rp = replay_record32(n, s_sin[RXP(k)]);
+        const uint32_t pay = (head32 + s_xenc[RXP(k)] + 8u) & mask32;
+        uint32_t sg = 1u + (rp.c2 ? 1u : 0u);
+        uint32_t tl = tiles_of32(rp.c1) + tiles_of32(rp.c2);
+        if (pay + n > cap32 || pay + n < pay) {  // crosses the ring end: split the step(s) it cuts
+          uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
+          split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
+          split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
+          sg = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
+          tl = tiles_of(l0) + tiles_of(l1) + tiles_of(l2) + tiles_of(l3);
+        }
+        t_bytes += al16_32(rp.sl0) + al16_32(rp.sl1);
+        t_pk += rp.sl_cnt + (sg << 16);
+        t_tiles += tl;
+        t_n += n;
       }
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) {
@@ -554,42 +592,50 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     for (uint32_t base = wbeg; base < wend; base += 64) {
       const uint32_t k = base + lane;
       const bool act = k < wend;
-      const uint64_t n = act ? s_n[RXP(k)] : 0;
+      const uint32_t n = act ? s_n[RXP(k)] : 0;
       const uint32_t s_in = act ? s_sin[RXP(k)] : 0;
-      rec_plan rp = replay_record(n, s_in);
+      rec_plan32 rp = replay_record32(n, s_in);
       if (!act) { rp.c1 = rp.c2 = 0; rp.sl_cnt = 0; rp.sl0 = rp.sl1 = 0; }
-      const uint64_t pos = (head + (act ? s_xenc[RXP(k)] : 0)) & mask, pay = (pos + 8) & mask;
-      uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
-      split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
-      split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
+      const uint32_t pos = (head32 + (act ? s_xenc[RXP(k)] : 0)) & mask32, pay = (pos + 8u) & mask32;
+      // pieces of the record in the ring: step 1 = pieces 0,1; step 2 = pieces 2,3 (the
+      // second piece of a step exists only for the one record that crosses the ring end)
+      uint32_t o0 = pay, l0 = rp.c1, o1 = 0, l1 = 0, o2 = pay + rp.c1, l2 = rp.c2, o3 = 0, l3 = 0;
+      if (act && (pay + n > cap32 || pay + n < pay)) {
+        uint64_t a0, b0, a1, b1, a2, b2, a3, b3;
+        split_step(pay, 0, rp.c1, cap, &a0, &b0, &a1, &b1);
+        split_step(pay, rp.c1, rp.c2, cap, &a2, &b2, &a3, &b3);
+        o0 = (uint32_t)a0; l0 = (uint32_t)b0; o1 = (uint32_t)a1; l1 = (uint32_t)b1;
+        o2 = (uint32_t)a2; l2 = (uint32_t)b2; o3 = (uint32_t)a3; l3 = (uint32_t)b3;
+      }
+      if (!act) l0 = 0;
       const uint32_t my_sg = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
       const uint32_t my_pk = rp.sl_cnt | (my_sg << 16);
-      const uint32_t my_tiles = tiles_of(l0) + tiles_of(l1) + tiles_of(l2) + tiles_of(l3);
+      const uint32_t my_tiles = tiles_of32(l0) + tiles_of32(l1) + tiles_of32(l2) + tiles_of32(l3);
       // (the ring holds < 2^31 bytes in a bulk pass, so 32-bit scans of one step's bytes are exact)
-      const uint32_t my_bytes = (uint32_t)(al16(rp.sl0) + al16(rp.sl1));
+      const uint32_t my_bytes = al16_32(rp.sl0) + al16_32(rp.sl1);
       const uint32_t i_pk = wave_incl_scan_u32(my_pk);
       const uint32_t i_tiles = wave_incl_scan_u32(my_tiles);
       const uint32_t i_bytes = wave_incl_scan_u32(my_bytes);
       if (act) {
         uint64_t x_sl = c_sl + (i_pk & 0xFFFFu) - rp.sl_cnt;
         uint64_t x_sg = c_sg + (i_pk >> 16) - my_sg;
-        uint64_t x_tiles = c_tiles + i_tiles - my_tiles;
+        uint32_t x_tiles = (uint32_t)(ntiles0 + c_tiles) + i_tiles - my_tiles;
         const uint64_t A = a0 + c_bytes + i_bytes - my_bytes;  // start of the open / next slice
-        const uint64_t filled = s_in ? MINRD - s_in : 0;
+        const uint32_t filled = s_in ? MINRD - s_in : 0;
         // the steps of one record are contiguous in the arena: step 1 fills the
         // open 256-byte slice exactly, step 2 starts the next slice right behind it
         uint64_t dst = (uint64_t)op.arena + A + filled;
         // header, padding and footer (ring_buffer.cc:146,173-180) are cleared by the
         // scatter waves of the record's first / last piece: GRDMA_SEG_TAG_* in grdma_dev.h
         const int last_piece = l3 ? 3 : (l2 ? 2 : (l1 ? 1 : 0));
-        auto emit = [&](uint64_t off, uint64_t len, int piece) {
+        auto emit = [&](uint32_t off, uint32_t len, int piece) {
           if (len == 0) return;
           const uint64_t fl = GRDMA_SEG_ZERO_SRC | (piece == 0 ? GRDMA_SEG_TAG_HDR : 0) |
                               (piece == last_piece ? GRDMA_SEG_TAG_FTR : 0);
-          plan->segs[nsegs0 + x_sg] = {dst, (uint64_t)(ring + off), len, fl};
-          plan->tile_prefix[nsegs0 + x_sg] = (uint32_t)(ntiles0 + x_tiles);
+          plan->segs[nsegs0 + x_sg] = {dst, (uint64_t)(ring + off), (uint64_t)len, fl};
+          plan->tile_prefix[nsegs0 + x_sg] = x_tiles;
           x_sg++;
-          x_tiles += tiles_of(len);
+          x_tiles += tiles_of32(len);
           dst += len;
         };
         emit(o0, l0, 0);
@@ -601,7 +647,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
           out_slices[nsl0 + x_sl].off = sof;
           out_slices[nsl0 + x_sl].len = rp.sl0;
           x_sl++;
-          sof += al16(rp.sl0);
+          sof += al16_32(rp.sl0);
         }
         if (rp.sl1) {
           out_slices[nsl0 + x_sl].off = sof;

@@ -146,6 +146,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     c->partial_write = sent < offered ? 1 : 0;
     c->total_written += sent;
     c->tx_records += nrec_total;
+    c->tx_last_records = (uint32_t)nrec_total;
     if (nrec_total) c->tx_rounds++;
     if (op.use_cursor) {
       c->tx_slice_idx = idx;
@@ -245,13 +246,25 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
   if (m > c->max_sge) m = c->max_sge;
   if (m > GRDMA_TX_MAX_RECORDS - 1) m = GRDMA_TX_MAX_RECORDS - 1;
   if (!connected) m = 0;
+  // Pricing window.  A Send takes the records that fit the staging / credit budget, usually
+  // far fewer than the slices offered (a 4 MiB ring takes ~150 of 4095).  The first
+  // attempt prices only a window sized from what the previous Send took; if the budget
+  // is not exhausted inside the window, the whole list is priced.  Same result either
+  // way: records behind the first short one never matter.
+  const uint64_t m_full = m;
+  {
+    const uint64_t guess = (uint64_t)c->tx_last_records + (c->tx_last_records >> 2) + 64;
+    if (guess < m) m = guess;
+  }
 
   tdbg[1] = __builtin_amdgcn_s_memtime();
+  uint64_t t_loaded = 0, per = 0, room0 = 0, free0 = 0;
+  constexpr int NPT = GRDMA_TX_MAX_RECORDS / PLAN_THREADS;
+  uint64_t r_ptr[NPT], r_len[NPT];
+  for (;;) {
   // slice table, striped: thread `tid` owns records tid, tid + 256, ...; all of its
   // 16-byte {ptr, len} loads are in flight together and stay in registers for the
   // segment pass below (no second trip to the table)
-  constexpr int NPT = GRDMA_TX_MAX_RECORDS / PLAN_THREADS;
-  uint64_t r_ptr[NPT], r_len[NPT];
 #pragma unroll
   for (int r = 0; r < NPT; r++) r_ptr[r] = r_len[r] = 0;
   if (m) {
@@ -271,10 +284,15 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
     }
   }
   __syncthreads();
-  const uint64_t t_loaded = __builtin_amdgcn_s_memtime();
+  t_loaded = __builtin_amdgcn_s_memtime();
 
-  // st_i: each thread scans a contiguous run of `per` records out of LDS
-  const uint64_t per = (m + PLAN_THREADS - 1) / PLAN_THREADS;
+  // st_i: each thread scans a contiguous run of `per` records out of LDS, and tests the
+  // budget of each record in the same sweep (pay_i = min(len_i, W(S - st_i), W(free - st_i)):
+  // the record is short exactly when len_i > W(min(S, free) - st_i), W being monotone)
+  per = (m + PLAN_THREADS - 1) / PLAN_THREADS;
+  const uint64_t occupied0 = (tail0 + cap - rhead) & mask;
+  free0 = cap - occupied0;
+  room0 = S < free0 ? S : free0;
   {
     uint64_t chunk = 0;
     for (uint64_t k = 0; k < per; k++) {
@@ -287,38 +305,30 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
     }
     uint64_t total_enc;
     uint64_t st = block_excl_scan(chunk, s_wave, &total_enc);
+    unsigned int my_short = 0xFFFFFFFFu;
     for (uint64_t k = 0; k < per; k++) {
       const uint64_t i = tid * per + k;
       if (i < m) {
         s_excl[TXP(i)] = st;
         const uint64_t l = s_len[TXP(i)];
+        // a zero payload ends the send exactly like the reference's `break`
+        if (my_short == 0xFFFFFFFFu && (l == 0 || l > writable_of(sat_sub(room0, st))))
+          my_short = (unsigned int)i;
         st += enc_size(l < (cap << 1) ? l : (cap << 1));
       }
     }
     if (tid == PLAN_THREADS - 1 || (tid * per < m && (tid + 1) * per >= m)) s_excl[TXP(m)] = st;
     if (m == 0 && tid == 0) s_excl[TXP(0)] = 0;
+    // one LDS atomic per wave: runs are in thread order, so the lowest short lane of a
+    // wave holds the wave's lowest short record
+    const uint64_t bm = __ballot(my_short != 0xFFFFFFFFu);
+    if (bm != 0 && (tid & 63) == (unsigned)__builtin_ctzll(bm)) atomicMin(&s_first_short, my_short);
   }
-  __syncthreads();
-
   tdbg[2] = __builtin_amdgcn_s_memtime();
-  // budget test, striped
-  const uint64_t occupied0 = (tail0 + cap - rhead) & mask;
-  const uint64_t free0 = cap - occupied0;
-  for (uint64_t i = tid; i < m; i += PLAN_THREADS) {
-    const uint64_t st = s_excl[TXP(i)];
-    const uint64_t a = writable_of(sat_sub(S, st));
-    const uint64_t b = writable_of(sat_sub(free0, st));
-    const uint64_t l = s_len[TXP(i)];
-    uint64_t p = l;
-    if (a < p) p = a;
-    if (b < p) p = b;
-    // a zero payload ends the send exactly like the reference's `break`.
-    // One LDS atomic per wave: the lowest short lane of a wave holds its lowest i.
-    const bool is_short = p < l || l == 0;
-    const uint64_t bm = __ballot(is_short);
-    if (bm != 0 && (tid & 63) == (unsigned)__builtin_ctzll(bm)) atomicMin(&s_first_short, (unsigned int)i);
-  }
   __syncthreads();
+  if (s_first_short != 0xFFFFFFFFu || m == m_full) break;  // uniform
+  m = m_full;  // the window did not reach the end of the budget
+  }
   const uint64_t fs = s_first_short;
   const uint64_t nrec = (fs != 0xFFFFFFFFu) ? fs : m;  // records [0, nrec) go out whole
   uint64_t short_pay = 0;
@@ -472,6 +482,7 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
     c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709
     c->total_written += sent;
     c->tx_records += nrec_total;
+    c->tx_last_records = (uint32_t)nrec_total;
     if (nrec_total) c->tx_rounds++;
     if (op.use_cursor) {
       c->tx_slice_idx = idx;
