@@ -189,13 +189,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--msgs", type=int, default=256, help="1 MiB messages per step")
     ap.add_argument("--ring-kb", type=int,
-                    default=int(os.environ.get("GRPC_RDMA_RING_BUFFER_SIZE_KB", 65536)),
+                    default=int(os.environ.get("GRPC_RDMA_RING_BUFFER_SIZE_KB", 131072)),
                     help="ring size (GRPC_RDMA_RING_BUFFER_SIZE_KB); the reference default is 4096")
     ap.add_argument("--max-sge", type=int, default=4095)
     ap.add_argument("--launch", choices=["graph", "streams"], default="graph",
                     help="replay a step as one HIP graph, or issue its kernels on the job's streams")
-    ap.add_argument("--pipeline", type=int, default=0,
-                    help="1: run the rounds of a step as a software pipeline (side streams)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="1: the rounds of a step overlap (plan/gather of round t+1 and scatter of "
+                         "round t beside the wire + ring walk); 0: five kernels per round in order")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the sequential-schedule and direct-wire comparison runs")
     ap.add_argument("--wire", choices=["staged", "direct"], default="staged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -239,15 +242,16 @@ def main():
         torch.cuda.synchronize()
 
     def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB,
-                pipeline=False, max_sge=None):
+                pipeline=False, max_sge=None, wire_flags=None):
         """n_links connections with rings of ring_kb KiB: calibrate the number of rounds,
         capture the graph, time `steps` passes, verify, optionally instrument."""
         ring = ring_kb * 1024
         max_sge = max_sge or args.max_sge
+        wf = flags if wire_flags is None else wire_flags
         wls = get_workloads(n_links, msgs_per_link or args.msgs, payload)
         links, keep = [], []
         for w in wls:
-            tx, rx = g.Pair(ring, max_sge, flags), g.Pair(ring, max_sge, flags)
+            tx, rx = g.Pair(ring, max_sge, wf), g.Pair(ring, max_sge, wf)
             g.connect_pairs(tx, rx)
             dst_cap = w.N + 16 * (len(w.lens) * 2 + 64) + 4096
             dst = g.DeviceBuffer(nbytes=dst_cap)
@@ -310,8 +314,19 @@ def main():
             tx.close(); rx.close(); dst.free()
         return out
 
-    head = measure(args.ring_kb, args.steps, args.warmup, not args.no_verify, True,
-                   pipeline=bool(args.pipeline))
+    schedule = "pipelined" if args.pipeline else "sequential"
+    head = None
+    if args.pipeline:
+        try:
+            head = measure(args.ring_kb, args.steps, args.warmup, not args.no_verify, True, pipeline=True)
+        except Exception as e:  # keep the line: fall back to the plain schedule and say so
+            schedule = "sequential (pipelined run failed: %s)" % str(e)[:120]
+    seq = None
+    if head is None or not args.no_extra_legs:
+        seq = measure(args.ring_kb, args.steps if head is None else max(2, args.steps // 2),
+                      args.warmup if head is None else 1, not args.no_verify, head is None, pipeline=False)
+    if head is None:
+        head, seq = seq, None
     elapsed, rounds, classes, verified = head["elapsed"], head["rounds"], head["classes"], head["verified"]
     ring = args.ring_kb * 1024
     small = None
@@ -351,6 +366,7 @@ def main():
                                "(BASELINE.json configs[2])",
                    "msgs_per_step": args.msgs, "slices_per_msg": wl.slices_per_msg,
                    "ring_kib": args.ring_kb, "max_sge": args.max_sge, "wire": args.wire,
+                   "schedule": schedule,
                    "rounds_per_step": rounds, "connections_per_gpu": 1,
                    "stages": "gather+encode, wire, ready-detect, decode+scatter+zero, credit"},
         "roofline": roofline,
@@ -372,6 +388,19 @@ def main():
             out.update(measure_rtt(g))
         except Exception as e:  # never lose the throughput line to the latency leg
             out["rtt_error"] = str(e)
+    if seq is not None:  # same workload and ring, five kernels per round strictly in order
+        out["value_sequential"] = round(
+            wl.user_bytes * max(2, args.steps // 2) * world / seq["elapsed"] / (1 << 30), 3)
+    if not args.no_extra_legs and args.wire == "staged":
+        # GRDMA_WIRE_DIRECT: the gather writes the records straight into the peer ring
+        # (HBM / xGMI peer memory), no staging copy and no wire kernel
+        try:
+            dr = measure(args.ring_kb, max(2, args.steps // 2), 1, not args.no_verify, False,
+                         pipeline=False, wire_flags=2)
+            out["value_wire_direct"] = round(
+                wl.user_bytes * max(2, args.steps // 2) * world / dr["elapsed"] / (1 << 30), 3)
+        except Exception as e:
+            out["wire_direct_error"] = str(e)[:200]
     if small is not None:
         sm_steps = max(2, args.steps // 2)
         out["value_ring4096"] = round(wl.user_bytes * sm_steps * world / small["elapsed"] / (1 << 30), 3)

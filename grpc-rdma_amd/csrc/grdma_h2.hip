@@ -271,6 +271,46 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
   uint64_t nev = 0, overflow = 0;
   static const char kPrefix[] = "PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n";  // internal.h:781
 
+  // The automaton state lives in (wave-uniform) registers for the whole call; the copy in
+  // LDS is only the stream table, touched when a frame changes the current stream.
+  int32_t st = P.state;
+  uint32_t fsz = P.incoming_frame_size, ftype = P.incoming_frame_type;
+  uint32_t fflags = P.incoming_frame_flags, sid = P.incoming_stream_id;
+  int32_t cur_parser = P.cur_parser;
+  const uint32_t max_frame = P.max_frame_size;
+  // the data parser of the current stream (grpc_chttp2_data_parser), cached the same way
+  int d_idx = -1;
+  uint32_t d_id = 0, d_fsz = 0;
+  int32_t d_state = 0, d_comp = 0;
+  auto flush_stream = [&]() {
+    if (d_idx >= 0 && lane == 0) {
+      P.streams[d_idx].state = d_state;
+      P.streams[d_idx].frame_size = d_fsz;
+      P.streams[d_idx].compressed = d_comp;
+    }
+    __syncthreads();
+  };
+  auto select_stream = [&](uint32_t id) -> bool {  // false: unknown stream and no room / id 0
+    if (d_idx >= 0 && d_id == id) return true;
+    flush_stream();
+    d_idx = -1;
+    __shared__ int s_idx;
+    if (lane == 0) {
+      grdma_h2_stream_dev* d = find_stream(&P, id);
+      s_idx = d ? (int)(d - P.streams) : -1;
+    }
+    __syncthreads();
+    const int idx = s_idx;
+    __syncthreads();
+    if (idx < 0) return false;
+    d_idx = idx;
+    d_id = id;
+    d_state = P.streams[idx].state;
+    d_fsz = P.streams[idx].frame_size;
+    d_comp = P.streams[idx].compressed;
+    return true;
+  };
+
   auto push = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t sl) {
     if (nev >= ev_cap) {
       overflow = 1;
@@ -283,142 +323,153 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
     nev++;
   };
 
-  // register cache: the first 32 bytes of slices [cbase, cbase + 64)
+  // register cache of slices [cbase, cbase + 64): lane i holds the descriptor and the
+  // first 32 bytes of slice cbase + i (one memory round trip per 64 slices)
   uint64_t cbase = ~0ull;
-  uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  auto byte_at = [&](uint64_t s, uint64_t off) -> uint32_t {
-    if (off < 32) {
-      if (s < cbase || s >= cbase + 64) {
-        cbase = s;
-        const uint64_t mine = s + lane;
-        c0 = c1 = c2 = c3 = 0;
-        if (mine < nslices) {
-          const uint8_t* p = arena + slices[mine].off;
-          const uint64_t n = slices[mine].len;
-          if (((uint64_t)p & 15) == 0) {
-            // aligned 16-byte words that start inside the slice; the tail of the
-            // last word stays inside its own 16-byte block
-            const u64x2* q = reinterpret_cast<const u64x2*>(p);
-            if (n > 0) { u64x2 v = q[0]; c0 = v.x; c1 = v.y; }
-            if (n > 16) { u64x2 v = q[1]; c2 = v.x; c3 = v.y; }
-          } else {
-            uint8_t tmp[32];
-            for (int i = 0; i < 32; i++) tmp[i] = (uint64_t)i < n ? p[i] : 0;
-            memcpy(&c0, tmp, 8); memcpy(&c1, tmp + 8, 8); memcpy(&c2, tmp + 16, 8); memcpy(&c3, tmp + 24, 8);
-          }
-        }
+  uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c_off = 0, c_len = 0;
+  auto ensure = [&](uint64_t s) {
+    if (s >= cbase && s < cbase + 64) return;
+    cbase = s;
+    const uint64_t mine = s + lane;
+    c0 = c1 = c2 = c3 = 0;
+    c_off = c_len = 0;
+    if (mine < nslices) {
+      c_off = slices[mine].off;
+      c_len = slices[mine].len;
+      const uint8_t* p = arena + c_off;
+      const uint64_t n = c_len;
+      if (((uint64_t)p & 15) == 0) {
+        // aligned 16-byte words that start inside the slice; the tail of the
+        // last word stays inside its own 16-byte block
+        const u64x2* q = reinterpret_cast<const u64x2*>(p);
+        if (n > 0) { u64x2 v = q[0]; c0 = v.x; c1 = v.y; }
+        if (n > 16) { u64x2 v = q[1]; c2 = v.x; c3 = v.y; }
+      } else {
+        uint8_t tmp[32];
+        for (int i = 0; i < 32; i++) tmp[i] = (uint64_t)i < n ? p[i] : 0;
+        memcpy(&c0, tmp, 8); memcpy(&c1, tmp + 8, 8); memcpy(&c2, tmp + 16, 8); memcpy(&c3, tmp + 24, 8);
       }
-      const int src = (int)(s - cbase);
+    }
+  };
+  auto byte_at = [&](uint64_t s, uint64_t off) -> uint32_t {
+    ensure(s);
+    const int src = (int)(s - cbase);
+    if (off < 32) {
       const uint64_t q = off >> 3;
       const uint64_t word = __shfl(q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3, src, 64);
       return (uint32_t)((word >> ((off & 7) * 8)) & 0xFF);
     }
-    return arena[slices[s].off + off];
+    return arena[__shfl(c_off, src, 64) + off];
   };
 
   uint64_t s = 0;
   int err = P.error;
   for (; s < nslices && !err && !overflow; s++) {
-    const uint64_t len = slices[s].len;
+    ensure(s);
+    const uint64_t len = __shfl(c_len, (int)(s - cbase), 64);
     uint64_t cur = 0;
     while (cur < len && !err && !overflow) {
-      if (P.state < ST_FH0) {  // client connection preface, parsing.cc:70-109
-        if (byte_at(s, cur) != (uint8_t)kPrefix[P.state]) { err = 1; break; }
-        cur++; P.state++;
+      if (st < ST_FH0) {  // client connection preface, parsing.cc:70-109
+        if (byte_at(s, cur) != (uint8_t)kPrefix[st]) { err = 1; break; }
+        cur++; st++;
         continue;
       }
-      if (P.state < ST_FRAME) {
+      if (st < ST_FRAME) {
         const uint32_t c = byte_at(s, cur);
-        switch (P.state) {
-          case 24: P.incoming_frame_size = c << 16; break;
-          case 25: P.incoming_frame_size |= c << 8; break;
-          case 26: P.incoming_frame_size |= c; break;
-          case 27: P.incoming_frame_type = c; break;
-          case 28: P.incoming_frame_flags = c; break;
-          case 29: P.incoming_stream_id = (c & 0x7f) << 24; break;
-          case 30: P.incoming_stream_id |= c << 16; break;
-          case 31: P.incoming_stream_id |= c << 8; break;
-          case 32: P.incoming_stream_id |= c; break;
+        switch (st) {
+          case 24: fsz = c << 16; break;
+          case 25: fsz |= c << 8; break;
+          case 26: fsz |= c; break;
+          case 27: ftype = c; break;
+          case 28: fflags = c; break;
+          case 29: sid = (c & 0x7f) << 24; break;
+          case 30: sid |= c << 16; break;
+          case 31: sid |= c << 8; break;
+          case 32: sid |= c; break;
         }
         cur++;
-        if (P.state < 32) { P.state++; continue; }
+        if (st < 32) { st++; continue; }
         // FH_8 done: init_frame_parser (parsing.cc:255-308), DATA branch :340-397
         uint32_t status = 0;
-        P.cur_parser = 0;
-        if (P.incoming_frame_type == 0) {
-          grdma_h2_stream_dev* d = find_stream(&P, P.incoming_stream_id);
-          if (d != nullptr) {
-            if (P.incoming_frame_flags & ~1u) status = 3;  // frame_data.cc:47-52
-            else P.cur_parser = 1;
+        cur_parser = 0;
+        if (ftype == 0) {
+          if (select_stream(sid)) {
+            if (fflags & ~1u) status = 3;  // frame_data.cc:47-52
+            else cur_parser = 1;
           }
         }
-        push(EV_FRAME, P.incoming_frame_type, P.incoming_frame_flags | (status << 8),
-             P.incoming_stream_id, P.incoming_frame_size, (uint32_t)s);
-        if (P.incoming_frame_size == 0) {
+        push(EV_FRAME, ftype, fflags | (status << 8), sid, fsz, (uint32_t)s);
+        if (fsz == 0) {
           push(EV_PAYLOAD, (uint32_t)cur, 0, 1, 0, (uint32_t)s);
-          P.state = ST_FH0;
-        } else if (P.incoming_frame_size > P.max_frame_size) {
+          st = ST_FH0;
+        } else if (fsz > max_frame) {
           err = 2;  // parsing.cc:195-205
         } else {
-          P.state = ST_FRAME;
+          st = ST_FRAME;
         }
         continue;
       }
       // FRAME: parsing.cc:215-250
       const uint64_t avail = len - cur;
-      const uint64_t take = avail < P.incoming_frame_size ? avail : P.incoming_frame_size;
-      const uint32_t is_last = take == P.incoming_frame_size;
+      const uint64_t take = avail < fsz ? avail : fsz;
+      const uint32_t is_last = take == fsz;
       push(EV_PAYLOAD, (uint32_t)cur, (uint32_t)take, is_last, 0, (uint32_t)s);
-      if (P.cur_parser == 1) {
+      if (cur_parser == 1 && select_stream(sid)) {
         // grpc_deframe_unprocessed_incoming_frames, frame_data.cc:92-276
-        grdma_h2_stream_dev* d = find_stream(&P, P.incoming_stream_id);
         uint64_t q = cur;
         const uint64_t end = cur + take;
-        while (q < end && d->state != 6 && !overflow) {
-          if (d->state < 5) {
+        while (q < end && d_state != 6 && !overflow) {
+          if (d_state < 5) {
             const uint32_t c = byte_at(s, q);
-            if (d->state == 0) {
+            if (d_state == 0) {
               if (c > 1) {  // "Bad GRPC frame type", frame_data.cc:123-140: stream error
-                d->state = 6;
-                push(EV_FRAME, 0xff, 0, P.incoming_stream_id, 4, (uint32_t)s);
+                d_state = 6;
+                push(EV_FRAME, 0xff, 0, sid, 4, (uint32_t)s);
                 break;
               }
-              d->compressed = (int32_t)c;
-              d->state = 1;
-            } else if (d->state == 1) { d->frame_size = c << 24; d->state = 2; }
-            else if (d->state == 2) { d->frame_size |= c << 16; d->state = 3; }
-            else if (d->state == 3) { d->frame_size |= c << 8; d->state = 4; }
+              d_comp = (int32_t)c;
+              d_state = 1;
+            } else if (d_state == 1) { d_fsz = c << 24; d_state = 2; }
+            else if (d_state == 2) { d_fsz |= c << 16; d_state = 3; }
+            else if (d_state == 3) { d_fsz |= c << 8; d_state = 4; }
             else {
-              d->frame_size |= c;
-              push(EV_MSG_BEGIN, (uint32_t)d->compressed, d->frame_size, d->stream_id, 0, (uint32_t)s);
-              if (d->frame_size == 0) {
-                push(EV_MSG_END, 0, 0, d->stream_id, 0, (uint32_t)s);
-                d->state = 0;
+              d_fsz |= c;
+              push(EV_MSG_BEGIN, (uint32_t)d_comp, d_fsz, d_id, 0, (uint32_t)s);
+              if (d_fsz == 0) {
+                push(EV_MSG_END, 0, 0, d_id, 0, (uint32_t)s);
+                d_state = 0;
               } else {
-                d->state = 5;
+                d_state = 5;
               }
             }
             q++;
           } else {
             const uint64_t rem = end - q;
-            const uint64_t tk = rem < d->frame_size ? rem : d->frame_size;
-            push(EV_MSG_BYTES, (uint32_t)q, (uint32_t)tk, d->stream_id, 0, (uint32_t)s);
-            d->frame_size -= (uint32_t)tk;
+            const uint64_t tk = rem < d_fsz ? rem : d_fsz;
+            push(EV_MSG_BYTES, (uint32_t)q, (uint32_t)tk, d_id, 0, (uint32_t)s);
+            d_fsz -= (uint32_t)tk;
             q += tk;
-            if (d->frame_size == 0) {
-              push(EV_MSG_END, 0, 0, d->stream_id, 0, (uint32_t)s);
-              d->state = 0;
+            if (d_fsz == 0) {
+              push(EV_MSG_END, 0, 0, d_id, 0, (uint32_t)s);
+              d_state = 0;
             }
           }
         }
       }
-      P.incoming_frame_size -= (uint32_t)take;
+      fsz -= (uint32_t)take;
       cur += take;
-      if (is_last) P.state = ST_FH0;
+      if (is_last) st = ST_FH0;
     }
     if (err || overflow) break;
   }
+  flush_stream();
   if (lane == 0) {
+    P.state = st;
+    P.incoming_frame_size = fsz;
+    P.incoming_frame_type = ftype;
+    P.incoming_frame_flags = fflags;
+    P.incoming_stream_id = sid;
+    P.cur_parser = cur_parser;
     P.error = err;
     *gp = P;
     res->nevents = nev;
@@ -435,9 +486,13 @@ struct grdma_h2_parser {
   grdma_h2_parser_dev* d = nullptr;
 };
 
+static double g_h2_last_kernel_us = 0;
+
 extern "C" {
 
 const char* grdma_last_error(void);
+// duration of the framing / deframing kernel of the last call (HIP events), microseconds
+double grdma_h2_last_kernel_us(void) { return g_h2_last_kernel_us; }
 
 int64_t grdma_h2_frame_messages(const grdma_h2_msg* msgs, uint64_t n, uint32_t max_frame,
                                 grdma_slice* d_slices_out, uint64_t slices_cap,
@@ -461,10 +516,20 @@ int64_t grdma_h2_frame_messages(const grdma_h2_msg* msgs, uint64_t n, uint32_t m
       hipMalloc((void**)&d_res, sizeof(grdma_h2_frame_result)) == hipSuccess &&
       hipMemcpy(d_msgs, tmp.data(), sizeof(grdma_h2_msg_dev) * n, hipMemcpyHostToDevice) == hipSuccess &&
       hipMemset(d_res, 0, sizeof(grdma_h2_frame_result)) == hipSuccess) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k_h2_frame, dim3(1), dim3(256), 0, 0, d_msgs, n, max_frame,
                        reinterpret_cast<grdma_sge*>(d_slices_out), slices_cap,
                        static_cast<uint8_t*>(d_hdr_arena), hdr_cap, (uint64_t*)nullptr, d_res);
-    if (hipDeviceSynchronize() == hipSuccess &&
+    hipEventRecord(e1, 0);
+    const bool synced = hipDeviceSynchronize() == hipSuccess;
+    float ms = 0;
+    if (synced && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) g_h2_last_kernel_us = 1e3 * ms;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (synced &&
         hipMemcpy(&h_res, d_res, sizeof(h_res), hipMemcpyDeviceToHost) == hipSuccess) {
       if (h_res.overflow) rc = -GRDMA_ERR_CAPACITY;
       else {
@@ -514,9 +579,19 @@ int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_re
       hipMalloc((void**)&d_ev, sizeof(grdma_h2_event) * (cap ? cap : 1)) == hipSuccess &&
       hipMalloc((void**)&d_res, sizeof(h_res)) == hipSuccess &&
       (n == 0 || hipMemcpy(d_sl, slices, sizeof(grdma_slice_out) * n, hipMemcpyHostToDevice) == hipSuccess)) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(64), 0, 0, p->d,
                        static_cast<const uint8_t*>(d_arena), d_sl, n, d_ev, cap, d_res);
-    if (hipDeviceSynchronize() == hipSuccess &&
+    hipEventRecord(e1, 0);
+    const bool synced = hipDeviceSynchronize() == hipSuccess;
+    float ms = 0;
+    if (synced && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) g_h2_last_kernel_us = 1e3 * ms;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (synced &&
         hipMemcpy(&h_res, d_res, sizeof(h_res), hipMemcpyDeviceToHost) == hipSuccess) {
       const uint64_t m = h_res.nevents < cap ? h_res.nevents : cap;
       if (m == 0 || hipMemcpy(events_out, d_ev, sizeof(grdma_h2_event) * m, hipMemcpyDeviceToHost) == hipSuccess)

@@ -266,7 +266,17 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
   const uint64_t mh0 = c->moving_head;
   const uint64_t hist_count0 = c->rx_hist_count;
 
-  for (unsigned i = tid; i < GRDMA_RX_HIST; i += PLAN_THREADS) s_hist[i] = c->rx_hist[i];
+  {
+    // (all loads first: `c->rx_hist` is a generic pointer, so a store to LDS between two
+    // of them would serialise the round trips)
+    constexpr int NH = GRDMA_RX_HIST / PLAN_THREADS;
+    const uint32_t* gh = c->rx_hist;
+    uint32_t hv[NH];
+#pragma unroll
+    for (int r = 0; r < NH; r++) hv[r] = gh[tid + r * PLAN_THREADS];
+#pragma unroll
+    for (int r = 0; r < NH; r++) s_hist[tid + r * PLAN_THREADS] = hv[r];
+  }
   if (tid == 0) {
     S.head = c->head; S.mh = c->moving_head; S.remain = c->remain;
     S.irs = c->internal_read_size; S.leftover = c->leftover_cap;
@@ -408,11 +418,21 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     const uint32_t per = BULK_MAX / PLAN_THREADS;  // 16 contiguous records per thread
     {
       uint64_t chunk = 0;
+      // record i takes pattern slot q + i (one earlier when a split slot is being completed
+      // by `rem`); the slot index modulo P is carried along instead of divided out per record
+      const uint32_t P32 = (uint32_t)P, r1 = rem ? 1u : 0u;
+      const uint32_t i0 = tid * per;
+      uint32_t jm = (uint32_t)((q + (i0 > r1 ? i0 - r1 : 0)) % P);
+      const uint32_t hoff = (uint32_t)((hbase + Hp - P) % GRDMA_RX_HIST);
       for (uint32_t k = 0; k < per; k++) {
-        const uint64_t i = (uint64_t)tid * per + k;
+        const uint32_t i = i0 + k;
         uint32_t e;
-        if (rem) e = i == 0 ? (uint32_t)rem : pattern(q + i - 1);
-        else e = pattern(q + i);
+        if (r1 && i == 0) {
+          e = (uint32_t)rem;
+        } else {
+          e = s_hist[(hoff + jm) % GRDMA_RX_HIST];
+          if (++jm == P32) jm = 0;
+        }
         s_penc[RXP(i)] = e;
         chunk += e;
       }

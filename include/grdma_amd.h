@@ -258,6 +258,8 @@ void grdma_h2_parser_destroy(grdma_h2_parser* p);
 /* grpc_chttp2_perform_read (parsing.cc:56-253) + grpc_deframe_unprocessed_incoming_frames
  * (frame_data.cc:92-276) over n delivered slices {offset, length} of d_arena.
  * Returns the number of events; *h2_error = connection error, if any. */
+/* Duration of the framing / deframing kernel of the last call (HIP events), microseconds. */
+double grdma_h2_last_kernel_us(void);
 int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_read_slice* slices,
                          uint64_t n, grdma_h2_event* events_out, uint64_t cap, int* h2_error);
 

@@ -5,10 +5,14 @@ import sys, json
 l = sys.stdin.read().strip()
 try:
     d = json.loads(l)
-    print(d['value'], d['config']['rounds_per_step'], d['verified'], {k: v['us_per_launch'] for k, v in d['kernels'].items()})
+    print(d['value'], d['config']['rounds_per_step'], d['verified'])
 except Exception as e:
     print('ERR', l[-600:])
 "; }
-ENVX="X=1" run --ring-kb 65536
-ENVX="X=1" run --ring-kb 65536
-ENVX="X=1" run --ring-kb 4096
+for r in 131072 524288; do
+ENVX="X=1" run --ring-kb $r
+ENVX="GRDMA_PIPE_VARIANT=0" run --ring-kb $r --pipeline 1
+ENVX="GRDMA_PIPE_VARIANT=1" run --ring-kb $r --pipeline 1
+ENVX="GRDMA_PIPE_VARIANT=2" run --ring-kb $r --pipeline 1
+done
+ENVX="X=1" run --ring-kb 65536 --wire direct

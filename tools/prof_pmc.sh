@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $out
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$ctr -o pmc -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-verify --no-small-ring --no-rtt --conns 1 "$@" > $out/$ctr.stdout.log 2>&1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$ctr -o pmc -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-verify --no-small-ring --no-rtt --no-extra-legs --conns 1 "$@" > $out/$ctr.stdout.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
