@@ -48,6 +48,13 @@ SIGNATURES = {
     "grdma_determine_platform": (C.c_int, []),
     "grdma_config_from_env": (C.c_int, [C.POINTER(Config)]),
     "grdma_init": (C.c_int, [C.c_int]),
+    "grdma_poller_create": (C.c_void_p, [C.c_int, C.c_int]),
+    "grdma_poller_destroy": (None, [C.c_void_p]),
+    "grdma_poller_add": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "grdma_poller_remove": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "grdma_poller_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "grdma_pair_get_wakeup_fd": (C.c_int, [C.c_void_p]),
+    "grdma_pair_consume_wakeup": (C.c_int, [C.c_void_p]),
     "grdma_device_count": (C.c_int, []),
     "grdma_last_error": (C.c_char_p, []),
     "grdma_pair_create": (C.c_void_p, [u64, C.c_int, C.c_int]),

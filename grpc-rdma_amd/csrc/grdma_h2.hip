@@ -260,13 +260,152 @@ __device__ __forceinline__ grdma_h2_stream_dev* find_stream(grdma_h2_parser_dev*
   return d;
 }
 
+// Register cache of slices [cbase, cbase + 64): lane i holds the descriptor and the first
+// 32 bytes of slice cbase + i (one memory round trip per 64 slices).  Plain functions over a
+// plain struct (no capturing lambdas): everything stays in registers.
+struct h2_slice_cache {
+  uint64_t cbase, c0, c1, c2, c3, c_off, c_len;
+};
+
+__device__ __forceinline__ uint64_t h2_keep(uint64_t v, uint64_t first, uint64_t n) {
+  // bytes at and beyond the slice end read as zero
+  if (n >= first + 8) return v;
+  if (n <= first) return 0;
+  return v & ((1ull << ((n - first) * 8)) - 1);
+}
+
+__device__ __forceinline__ void h2_ensure(h2_slice_cache& C, uint64_t s, const uint8_t* arena,
+                                          const grdma_slice_out* slices, uint64_t nslices, int lane) {
+  if (s >= C.cbase && s < C.cbase + 64) return;
+  C.cbase = s;
+  const uint64_t mine = s + lane;
+  C.c0 = C.c1 = C.c2 = C.c3 = 0;
+  C.c_off = C.c_len = 0;
+  if (mine < nslices) {
+    C.c_off = slices[mine].off;
+    C.c_len = slices[mine].len;
+    const uint8_t* p = arena + C.c_off;
+    const uint64_t n = C.c_len;
+    // the aligned 16-byte blocks that hold the first 32 bytes of the slice (two when the
+    // slice starts on a 16-byte boundary, three otherwise); a block is only fetched when
+    // it overlaps the slice, so nothing outside the blocks the slice touches is read
+    const uint64_t sh = (uint64_t)p & 15;
+    const u64x2* q = reinterpret_cast<const u64x2*>((uint64_t)p & ~15ull);
+    const uint64_t need = (n < 32 ? n : 32) + sh;
+    u64x2 v0 = {0, 0}, v1 = {0, 0}, v2 = {0, 0};
+    if (need > 0) v0 = q[0];
+    if (need > 16) v1 = q[1];
+    if (need > 32) v2 = q[2];
+    // 48-byte window w0..w5, shifted right by sh bytes
+    uint64_t w0 = v0.x, w1 = v0.y, w2 = v1.x, w3 = v1.y, w4 = v2.x, w5 = v2.y;
+    if (sh & 8) { w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; }
+    const unsigned bs = (unsigned)(sh & 7) * 8;
+    uint64_t o0 = w0, o1 = w1, o2 = w2, o3 = w3;
+    if (bs) {
+      o0 = (w0 >> bs) | (w1 << (64 - bs));
+      o1 = (w1 >> bs) | (w2 << (64 - bs));
+      o2 = (w2 >> bs) | (w3 << (64 - bs));
+      o3 = (w3 >> bs) | (w4 << (64 - bs));
+    }
+    C.c0 = h2_keep(o0, 0, n);
+    C.c1 = h2_keep(o1, 8, n);
+    C.c2 = h2_keep(o2, 16, n);
+    C.c3 = h2_keep(o3, 24, n);
+  }
+}
+
+__device__ __forceinline__ uint32_t h2_byte_at(h2_slice_cache& C, uint64_t s, uint64_t off,
+                                               const uint8_t* arena, const grdma_slice_out* slices,
+                                               uint64_t nslices, int lane) {
+  h2_ensure(C, s, arena, slices, nslices, lane);
+  const int src = (int)(s - C.cbase);
+  if (off < 32) {
+    const uint64_t q = off >> 3;
+    const uint64_t word = __shfl(q == 0 ? C.c0 : q == 1 ? C.c1 : q == 2 ? C.c2 : C.c3, src, 64);
+    return (uint32_t)((word >> ((off & 7) * 8)) & 0xFF);
+  }
+  return arena[__shfl(C.c_off, src, 64) + off];
+}
+
+// bytes [off, off + 8) of slice s as a little-endian word; needs off + 8 <= 32 (inside the
+// cached look-ahead).  Two shuffles instead of eight byte fetches.
+__device__ __forceinline__ uint64_t h2_bytes8(h2_slice_cache& C, uint64_t s, uint64_t off,
+                                              const uint8_t* arena, const grdma_slice_out* slices,
+                                              uint64_t nslices, int lane) {
+  h2_ensure(C, s, arena, slices, nslices, lane);
+  const int src = (int)(s - C.cbase);
+  const uint64_t q = off >> 3;
+  const uint64_t lo = __shfl(q == 0 ? C.c0 : q == 1 ? C.c1 : q == 2 ? C.c2 : C.c3, src, 64);
+  const uint64_t hi = __shfl(q == 0 ? C.c1 : q == 1 ? C.c2 : C.c3, src, 64);  // q == 3: unused
+  const unsigned bs = (unsigned)(off & 7) * 8;
+  return bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+}
+
+__device__ __forceinline__ void h2_push(grdma_h2_event* ev, uint64_t ev_cap, uint64_t& nev,
+                                        uint64_t& overflow, int lane, uint32_t kind, uint32_t a,
+                                        uint32_t b, uint32_t c, uint32_t d, uint32_t sl) {
+  if (nev >= ev_cap) {
+    overflow = 1;
+    return;
+  }
+  if (lane == 0) {
+    // (global address space: a generic store would also count against the LDS counter
+    // and stall the next shuffle of the slice cache)
+    auto* e = (__attribute__((address_space(1))) grdma_h2_event*)(uint64_t)(ev + nev);
+    e->kind = kind; e->a = a; e->b = b; e->c = c; e->d = d;
+    e->slice = sl;
+  }
+  nev++;
+}
+
+// the data parser of the current stream (grpc_chttp2_data_parser), cached in registers
+struct h2_cur_stream {
+  int idx;
+  uint32_t id, fsz;
+  int32_t state, comp;
+};
+
+__device__ __forceinline__ void h2_flush_stream(grdma_h2_parser_dev* P, const h2_cur_stream& D, int lane) {
+  if (D.idx >= 0 && lane == 0) {
+    P->streams[D.idx].state = D.state;
+    P->streams[D.idx].frame_size = D.fsz;
+    P->streams[D.idx].compressed = D.comp;
+  }
+  __syncthreads();
+}
+
+// false: unknown stream and no room in the table / stream id 0
+__device__ __forceinline__ bool h2_select_stream(grdma_h2_parser_dev* P, h2_cur_stream& D, uint32_t id,
+                                                 int* s_idx, int lane) {
+  if (D.idx >= 0 && D.id == id) return true;
+  h2_flush_stream(P, D, lane);
+  D.idx = -1;
+  if (lane == 0) {
+    grdma_h2_stream_dev* d = find_stream(P, id);
+    *s_idx = d ? (int)(d - P->streams) : -1;
+  }
+  __syncthreads();
+  const int idx = *s_idx;
+  __syncthreads();
+  if (idx < 0) return false;
+  D.idx = idx;
+  D.id = id;
+  D.state = P->streams[idx].state;
+  D.fsz = P->streams[idx].frame_size;
+  D.comp = P->streams[idx].compressed;
+  return true;
+}
+
 __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, const uint8_t* arena,
                                                    const grdma_slice_out* slices, uint64_t nslices,
                                                    grdma_h2_event* ev, uint64_t ev_cap,
                                                    grdma_h2_deframe_result* res) {
   const int lane = threadIdx.x;
   __shared__ grdma_h2_parser_dev P;
-  if (lane == 0) P = *gp;
+  __shared__ int s_idx;
+  static_assert(sizeof(grdma_h2_parser_dev) % 4 == 0, "word copy");
+  for (unsigned i = lane; i < sizeof(grdma_h2_parser_dev) / 4; i += 64)
+    reinterpret_cast<uint32_t*>(&P)[i] = reinterpret_cast<const uint32_t*>(gp)[i];
   __syncthreads();
   uint64_t nev = 0, overflow = 0;
   static const char kPrefix[] = "PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n";  // internal.h:781
@@ -278,104 +417,38 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
   uint32_t fflags = P.incoming_frame_flags, sid = P.incoming_stream_id;
   int32_t cur_parser = P.cur_parser;
   const uint32_t max_frame = P.max_frame_size;
-  // the data parser of the current stream (grpc_chttp2_data_parser), cached the same way
-  int d_idx = -1;
-  uint32_t d_id = 0, d_fsz = 0;
-  int32_t d_state = 0, d_comp = 0;
-  auto flush_stream = [&]() {
-    if (d_idx >= 0 && lane == 0) {
-      P.streams[d_idx].state = d_state;
-      P.streams[d_idx].frame_size = d_fsz;
-      P.streams[d_idx].compressed = d_comp;
-    }
-    __syncthreads();
-  };
-  auto select_stream = [&](uint32_t id) -> bool {  // false: unknown stream and no room / id 0
-    if (d_idx >= 0 && d_id == id) return true;
-    flush_stream();
-    d_idx = -1;
-    __shared__ int s_idx;
-    if (lane == 0) {
-      grdma_h2_stream_dev* d = find_stream(&P, id);
-      s_idx = d ? (int)(d - P.streams) : -1;
-    }
-    __syncthreads();
-    const int idx = s_idx;
-    __syncthreads();
-    if (idx < 0) return false;
-    d_idx = idx;
-    d_id = id;
-    d_state = P.streams[idx].state;
-    d_fsz = P.streams[idx].frame_size;
-    d_comp = P.streams[idx].compressed;
-    return true;
-  };
-
-  auto push = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t sl) {
-    if (nev >= ev_cap) {
-      overflow = 1;
-      return;
-    }
-    if (lane == 0) {
-      ev[nev].kind = kind; ev[nev].a = a; ev[nev].b = b; ev[nev].c = c; ev[nev].d = d;
-      ev[nev].slice = sl;
-    }
-    nev++;
-  };
-
-  // register cache of slices [cbase, cbase + 64): lane i holds the descriptor and the
-  // first 32 bytes of slice cbase + i (one memory round trip per 64 slices)
-  uint64_t cbase = ~0ull;
-  uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c_off = 0, c_len = 0;
-  auto ensure = [&](uint64_t s) {
-    if (s >= cbase && s < cbase + 64) return;
-    cbase = s;
-    const uint64_t mine = s + lane;
-    c0 = c1 = c2 = c3 = 0;
-    c_off = c_len = 0;
-    if (mine < nslices) {
-      c_off = slices[mine].off;
-      c_len = slices[mine].len;
-      const uint8_t* p = arena + c_off;
-      const uint64_t n = c_len;
-      if (((uint64_t)p & 15) == 0) {
-        // aligned 16-byte words that start inside the slice; the tail of the
-        // last word stays inside its own 16-byte block
-        const u64x2* q = reinterpret_cast<const u64x2*>(p);
-        if (n > 0) { u64x2 v = q[0]; c0 = v.x; c1 = v.y; }
-        if (n > 16) { u64x2 v = q[1]; c2 = v.x; c3 = v.y; }
-      } else {
-        uint8_t tmp[32];
-        for (int i = 0; i < 32; i++) tmp[i] = (uint64_t)i < n ? p[i] : 0;
-        memcpy(&c0, tmp, 8); memcpy(&c1, tmp + 8, 8); memcpy(&c2, tmp + 16, 8); memcpy(&c3, tmp + 24, 8);
-      }
-    }
-  };
-  auto byte_at = [&](uint64_t s, uint64_t off) -> uint32_t {
-    ensure(s);
-    const int src = (int)(s - cbase);
-    if (off < 32) {
-      const uint64_t q = off >> 3;
-      const uint64_t word = __shfl(q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3, src, 64);
-      return (uint32_t)((word >> ((off & 7) * 8)) & 0xFF);
-    }
-    return arena[__shfl(c_off, src, 64) + off];
-  };
+  h2_cur_stream D = {-1, 0, 0, 0, 0};
+  h2_slice_cache C = {~0ull, 0, 0, 0, 0, 0, 0};
+#define H2_PUSH(kind, a, b, c, d, sl) h2_push(ev, ev_cap, nev, overflow, lane, kind, a, b, c, d, sl)
+#define H2_BYTE(s_, off_) h2_byte_at(C, s_, off_, arena, slices, nslices, lane)
 
   uint64_t s = 0;
   int err = P.error;
   for (; s < nslices && !err && !overflow; s++) {
-    ensure(s);
-    const uint64_t len = __shfl(c_len, (int)(s - cbase), 64);
+    h2_ensure(C, s, arena, slices, nslices, lane);
+    const uint64_t len = __shfl(C.c_len, (int)(s - C.cbase), 64);
     uint64_t cur = 0;
     while (cur < len && !err && !overflow) {
       if (st < ST_FH0) {  // client connection preface, parsing.cc:70-109
-        if (byte_at(s, cur) != (uint8_t)kPrefix[st]) { err = 1; break; }
+        if (H2_BYTE(s, cur) != (uint8_t)kPrefix[st]) { err = 1; break; }
         cur++; st++;
         continue;
       }
       if (st < ST_FRAME) {
-        const uint32_t c = byte_at(s, cur);
+        if (st == ST_FH0 && len - cur >= 9 && cur + 9 <= 32) {
+          // the whole 9-byte frame header sits in the cached look-ahead: same fields as
+          // the byte-wise FH_0..FH_8 walk below (parsing.cc:111-193), taken in one step
+          const uint64_t b8 = h2_bytes8(C, s, cur, arena, slices, nslices, lane);
+          const uint32_t b9 = H2_BYTE(s, cur + 8);
+          fsz = (uint32_t)(((b8 & 0xFF) << 16) | (((b8 >> 8) & 0xFF) << 8) | ((b8 >> 16) & 0xFF));
+          ftype = (uint32_t)((b8 >> 24) & 0xFF);
+          fflags = (uint32_t)((b8 >> 32) & 0xFF);
+          sid = (uint32_t)((((b8 >> 40) & 0x7F) << 24) | (((b8 >> 48) & 0xFF) << 16) |
+                           (((b8 >> 56) & 0xFF) << 8)) | b9;
+          cur += 9;
+          st = 32;
+        } else {
+        const uint32_t c = H2_BYTE(s, cur);
         switch (st) {
           case 24: fsz = c << 16; break;
           case 25: fsz |= c << 8; break;
@@ -389,18 +462,19 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
         }
         cur++;
         if (st < 32) { st++; continue; }
+        }
         // FH_8 done: init_frame_parser (parsing.cc:255-308), DATA branch :340-397
         uint32_t status = 0;
         cur_parser = 0;
         if (ftype == 0) {
-          if (select_stream(sid)) {
+          if (h2_select_stream(&P, D, sid, &s_idx, lane)) {
             if (fflags & ~1u) status = 3;  // frame_data.cc:47-52
             else cur_parser = 1;
           }
         }
-        push(EV_FRAME, ftype, fflags | (status << 8), sid, fsz, (uint32_t)s);
+        H2_PUSH(EV_FRAME, ftype, fflags | (status << 8), sid, fsz, (uint32_t)s);
         if (fsz == 0) {
-          push(EV_PAYLOAD, (uint32_t)cur, 0, 1, 0, (uint32_t)s);
+          H2_PUSH(EV_PAYLOAD, (uint32_t)cur, 0, 1, 0, (uint32_t)s);
           st = ST_FH0;
         } else if (fsz > max_frame) {
           err = 2;  // parsing.cc:195-205
@@ -413,45 +487,60 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
       const uint64_t avail = len - cur;
       const uint64_t take = avail < fsz ? avail : fsz;
       const uint32_t is_last = take == fsz;
-      push(EV_PAYLOAD, (uint32_t)cur, (uint32_t)take, is_last, 0, (uint32_t)s);
-      if (cur_parser == 1 && select_stream(sid)) {
+      H2_PUSH(EV_PAYLOAD, (uint32_t)cur, (uint32_t)take, is_last, 0, (uint32_t)s);
+      if (cur_parser == 1 && h2_select_stream(&P, D, sid, &s_idx, lane)) {
         // grpc_deframe_unprocessed_incoming_frames, frame_data.cc:92-276
         uint64_t q = cur;
         const uint64_t end = cur + take;
-        while (q < end && d_state != 6 && !overflow) {
-          if (d_state < 5) {
-            const uint32_t c = byte_at(s, q);
-            if (d_state == 0) {
+        while (q < end && D.state != 6 && !overflow) {
+          if (D.state == 0 && end - q >= 5 && q + 8 <= 32 &&
+              (h2_bytes8(C, s, q, arena, slices, nslices, lane) & 0xFF) <= 1) {
+            // the 5-byte message header in one step (frame_data.cc:112-176)
+            const uint64_t b8 = h2_bytes8(C, s, q, arena, slices, nslices, lane);
+            D.comp = (int32_t)(b8 & 0xFF);
+            D.fsz = (uint32_t)((((b8 >> 8) & 0xFF) << 24) | (((b8 >> 16) & 0xFF) << 16) |
+                               (((b8 >> 24) & 0xFF) << 8) | ((b8 >> 32) & 0xFF));
+            H2_PUSH(EV_MSG_BEGIN, (uint32_t)D.comp, D.fsz, D.id, 0, (uint32_t)s);
+            if (D.fsz == 0) {
+              H2_PUSH(EV_MSG_END, 0, 0, D.id, 0, (uint32_t)s);
+              D.state = 0;
+            } else {
+              D.state = 5;
+            }
+            q += 5;
+          } else if (D.state < 5) {
+            const uint32_t c = H2_BYTE(s, q);
+            if (D.state == 0) {
               if (c > 1) {  // "Bad GRPC frame type", frame_data.cc:123-140: stream error
-                d_state = 6;
-                push(EV_FRAME, 0xff, 0, sid, 4, (uint32_t)s);
+                D.state = 6;
+                H2_PUSH(EV_FRAME, 0xff, 0, sid, 4, (uint32_t)s);
                 break;
               }
-              d_comp = (int32_t)c;
-              d_state = 1;
-            } else if (d_state == 1) { d_fsz = c << 24; d_state = 2; }
-            else if (d_state == 2) { d_fsz |= c << 16; d_state = 3; }
-            else if (d_state == 3) { d_fsz |= c << 8; d_state = 4; }
+              D.comp = (int32_t)c;
+              D.state = 1;
+            } else if (D.state == 1) { D.fsz = c << 24; D.state = 2; }
+            else if (D.state == 2) { D.fsz |= c << 16; D.state = 3; }
+            else if (D.state == 3) { D.fsz |= c << 8; D.state = 4; }
             else {
-              d_fsz |= c;
-              push(EV_MSG_BEGIN, (uint32_t)d_comp, d_fsz, d_id, 0, (uint32_t)s);
-              if (d_fsz == 0) {
-                push(EV_MSG_END, 0, 0, d_id, 0, (uint32_t)s);
-                d_state = 0;
+              D.fsz |= c;
+              H2_PUSH(EV_MSG_BEGIN, (uint32_t)D.comp, D.fsz, D.id, 0, (uint32_t)s);
+              if (D.fsz == 0) {
+                H2_PUSH(EV_MSG_END, 0, 0, D.id, 0, (uint32_t)s);
+                D.state = 0;
               } else {
-                d_state = 5;
+                D.state = 5;
               }
             }
             q++;
           } else {
             const uint64_t rem = end - q;
-            const uint64_t tk = rem < d_fsz ? rem : d_fsz;
-            push(EV_MSG_BYTES, (uint32_t)q, (uint32_t)tk, d_id, 0, (uint32_t)s);
-            d_fsz -= (uint32_t)tk;
+            const uint64_t tk = rem < D.fsz ? rem : D.fsz;
+            H2_PUSH(EV_MSG_BYTES, (uint32_t)q, (uint32_t)tk, D.id, 0, (uint32_t)s);
+            D.fsz -= (uint32_t)tk;
             q += tk;
-            if (d_fsz == 0) {
-              push(EV_MSG_END, 0, 0, d_id, 0, (uint32_t)s);
-              d_state = 0;
+            if (D.fsz == 0) {
+              H2_PUSH(EV_MSG_END, 0, 0, D.id, 0, (uint32_t)s);
+              D.state = 0;
             }
           }
         }
@@ -462,7 +551,9 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
     }
     if (err || overflow) break;
   }
-  flush_stream();
+#undef H2_PUSH
+#undef H2_BYTE
+  h2_flush_stream(&P, D, lane);
   if (lane == 0) {
     P.state = st;
     P.incoming_frame_size = fsz;
@@ -471,12 +562,14 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
     P.incoming_stream_id = sid;
     P.cur_parser = cur_parser;
     P.error = err;
-    *gp = P;
     res->nevents = nev;
     res->overflow = overflow;
     res->slices_done = s;
     res->error = err;
   }
+  __syncthreads();
+  for (unsigned i = lane; i < sizeof(grdma_h2_parser_dev) / 4; i += 64)
+    reinterpret_cast<uint32_t*>(gp)[i] = reinterpret_cast<const uint32_t*>(&P)[i];
 }
 
 }  // namespace

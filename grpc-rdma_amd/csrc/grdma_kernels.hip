@@ -117,10 +117,10 @@ __device__ __forceinline__ ring_probe probe_record(const uint8_t* ring, uint64_t
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_poll(grdma_conn* const* conns, uint32_t nconns,
                                              uint64_t* readable_out, uint64_t* ready_mask,
-                                             uint64_t* has_msg_mask) {
+                                             uint64_t* has_msg_mask, uint64_t* trigger_mask) {
   const uint32_t i = blockIdx.x * 64 + threadIdx.x;
   uint64_t readable = 0;
-  bool has = false;
+  bool has = false, trigger = false;
   if (i < nconns) {
     const grdma_conn* c = conns[i];
     if (c->remain > 0) {  // HasMessage / GetReadableSize fast path
@@ -132,13 +132,21 @@ __global__ __launch_bounds__(64) void k_poll(grdma_conn* const* conns, uint32_t 
       readable = pr.ready ? pr.n : 0;
     }
     readable_out[i] = readable;
+    // what makes Poller::begin_polling kick the pair's wakeup fd, poller.cc:80-98
+    uint32_t st = c->status;
+    // get_status(), pair.cc:349-356: a connected pair whose peer announced its exit is half closed
+    if (st == GRDMA_PAIR_CONNECTED && c->status_recv.peer_exit == 1) st = GRDMA_PAIR_HALF_CLOSED;
+    trigger = st == GRDMA_PAIR_CONNECTED ? (has || c->partial_write != 0)
+                                         : (st == GRDMA_PAIR_HALF_CLOSED || st == GRDMA_PAIR_ERROR);
   }
-  // wavefront ballots: 64 connections -> two 64-bit words
+  // wavefront ballots: 64 connections -> 64-bit words
   const uint64_t m_ready = __ballot(readable > 0);
   const uint64_t m_has = __ballot(has);
+  const uint64_t m_trig = __ballot(trigger);
   if (threadIdx.x == 0) {
     ready_mask[blockIdx.x] = m_ready;
     has_msg_mask[blockIdx.x] = m_has;
+    if (trigger_mask) trigger_mask[blockIdx.x] = m_trig;
   }
 }
 
@@ -194,10 +202,11 @@ uint32_t grdma_copy_resident_blocks(void) {
 uint32_t grdma_kernel_threads(int which) { return (which == 0 || which == 2) ? PLAN_THREADS : COPY_THREADS; }
 
 hipError_t grdma_launch_poll(grdma_conn* const* d_conns, uint32_t nconns, uint64_t* d_readable,
-                             uint64_t* d_ready_mask, uint64_t* d_has_mask, hipStream_t s) {
+                             uint64_t* d_ready_mask, uint64_t* d_has_mask, uint64_t* d_trigger_mask,
+                             hipStream_t s) {
   if (nconns == 0) return hipSuccess;
   hipLaunchKernelGGL(k_poll, dim3((nconns + 63) / 64), dim3(64), 0, s, d_conns, nconns,
-                     d_readable, d_ready_mask, d_has_mask);
+                     d_readable, d_ready_mask, d_has_mask, d_trigger_mask);
   return hipGetLastError();
 }
 

@@ -14,7 +14,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
+#include <poll.h>
+#include <sys/eventfd.h>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -28,7 +33,7 @@ hipError_t grdma_launch_tx_plan(const grdma_tx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_copy(const grdma_plan* const*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_apply(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
-hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*, uint64_t*,
+hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*, uint64_t*, uint64_t*,
                              hipStream_t);
 hipError_t grdma_launch_engine(grdma_engine_mbox*, hipStream_t);
 const void* grdma_kernel_fn(int which);          // 0 tx_plan, 1 copy, 3 rx_apply
@@ -134,6 +139,7 @@ struct grdma_pair {
   uint8_t* h_bounce = nullptr;       // pinned, staging-sized, lazily allocated
   grdma_pair* peer = nullptr;
   hipStream_t stream = nullptr;
+  int wakeup_fd = -1;                // grpc_wakeup_fd of the pair (pair.h:187): an eventfd
   // endpoint_write context
   std::vector<grdma_slice> w_slices;
   uint64_t w_idx = 0, w_byte = 0;
@@ -452,6 +458,7 @@ void grdma_pair_destroy(grdma_pair* p) {
   if (p->h_sges) hipHostFree(p->h_sges);
   if (p->h_slices) hipHostFree(p->h_slices);
   if (p->h_bounce) hipHostFree(p->h_bounce);
+  if (p->wakeup_fd >= 0) close(p->wakeup_fd);
   if (p->h_arena) hipHostFree(p->h_arena);
   if (p->h_cmd) hipHostFree(p->h_cmd);
   if (p->peer && p->peer->peer == p) p->peer->peer = nullptr;
@@ -566,13 +573,182 @@ int grdma_poll_pairs(grdma_pair* const* pairs, uint32_t n, uint64_t* readable,
   }
   uint32_t words = (n + 63) / 64;
   HIP_TRY(grdma_launch_poll(g_ctx.h_conns, n, g_ctx.h_readable, g_ctx.h_masks,
-                            g_ctx.h_masks + words, s));
+                            g_ctx.h_masks + words, nullptr, s));
   HIP_TRY(hipStreamSynchronize(s));
   for (uint32_t i = 0; i < n; i++) {
     if (readable) readable[i] = g_ctx.h_readable[i];
     if (has_message) has_message[i] = (g_ctx.h_masks[words + i / 64] >> (i % 64)) & 1;
   }
   return 0;
+}
+
+// ---- background poller (RDMA_BPEV): src/core/lib/ibverbs/poller.{h,cc} ---------------------
+// The reference runs GRPC_RDMA_POLLER_THREAD_NUM threads that visit the registered pairs
+// one by one and kick a pair's wakeup fd when it has a message, pending writes or a dead
+// peer (poller.cc:52-106).  Here ONE thread covers every registered pair with one k_poll
+// launch per pass (64 connections per wavefront, the tests done on the device where the
+// rings live), on a stream of its own so that it never queues behind the data path.
+}  // extern "C"
+
+struct grdma_poller {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<grdma_pair*> pairs;  // slot == nullptr: free (RemovePollable leaves a hole, poller.cc:45-54)
+  std::atomic<bool> running{true};
+  std::atomic<uint64_t> wakeups{0}, passes{0};
+  uint64_t pass_started = 0;               // under mu: passes whose snapshot has been taken
+  std::atomic<uint64_t> pass_finished{0};  // passes that no longer touch their snapshot
+  std::thread th;
+  int sleep_ms = 1000;
+  int device = 0;
+};
+
+namespace {
+
+void poller_loop(grdma_poller* pl) {
+  if (hipSetDevice(pl->device) != hipSuccess) return;
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
+  grdma_conn** h_conns = nullptr;
+  uint64_t* h_words = nullptr;  // readable[cap] | ready[cap/64] | has[cap/64] | trigger[cap/64]
+  uint32_t cap = 0;
+  std::vector<grdma_pair*> snap;
+  while (pl->running.load(std::memory_order_acquire)) {
+    {
+      std::unique_lock<std::mutex> lk(pl->mu);
+      snap.clear();
+      for (grdma_pair* p : pl->pairs)
+        if (p) snap.push_back(p);
+      if (snap.empty()) {  // poller.cc:58-63
+        pl->cv.wait_for(lk, std::chrono::milliseconds(pl->sleep_ms));
+        continue;
+      }
+      pl->pass_started++;
+    }
+    struct pass_guard {  // whatever way the pass ends, RemovePollable may stop waiting for it
+      grdma_poller* pl;
+      ~pass_guard() { pl->pass_finished.fetch_add(1, std::memory_order_release); }
+    } guard{pl};
+    const uint32_t n = (uint32_t)snap.size();
+    if (n > cap) {
+      if (h_conns) hipHostFree(h_conns);
+      if (h_words) hipHostFree(h_words);
+      cap = (n + 63) & ~63u;
+      if (hipHostMalloc((void**)&h_conns, sizeof(void*) * cap, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+          hipHostMalloc((void**)&h_words, sizeof(uint64_t) * (cap + 3 * (cap / 64)),
+                        hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+        break;
+    }
+    for (uint32_t i = 0; i < n; i++) h_conns[i] = snap[i]->d_conn;
+    uint64_t* ready = h_words + cap;
+    uint64_t* has = ready + cap / 64;
+    uint64_t* trig = has + cap / 64;
+    if (grdma_launch_poll(h_conns, n, h_words, ready, has, trig, s) != hipSuccess) break;
+    if (hipStreamSynchronize(s) != hipSuccess) break;
+    pl->passes.fetch_add(1, std::memory_order_relaxed);
+    for (uint32_t i = 0; i < n; i++) {
+      if (!((trig[i / 64] >> (i % 64)) & 1)) continue;
+      const int fd = snap[i]->wakeup_fd;
+      if (fd < 0) continue;
+      struct pollfd pfd = {fd, POLLIN, 0};
+      if (poll(&pfd, 1, 0) > 0) continue;  // already signalled and not consumed yet (poller.cc:76-78)
+      const uint64_t one = 1;
+      if (write(fd, &one, sizeof(one)) == (ssize_t)sizeof(one)) pl->wakeups.fetch_add(1, std::memory_order_relaxed);
+    }
+  }
+  if (h_conns) hipHostFree(h_conns);
+  if (h_words) hipHostFree(h_words);
+  hipStreamDestroy(s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int grdma_pair_get_wakeup_fd(grdma_pair* p) {
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (p->wakeup_fd < 0) {
+    p->wakeup_fd = eventfd(0, EFD_NONBLOCK | EFD_CLOEXEC);  // grpc_wakeup_fd_init, pair.cc:74
+    if (p->wakeup_fd < 0) return fail(GRDMA_ERR_INVALID, "eventfd failed");
+  }
+  return p->wakeup_fd;
+}
+
+int grdma_pair_consume_wakeup(grdma_pair* p) {  // grpc_wakeup_fd_consume_wakeup
+  if (!p || p->wakeup_fd < 0) return fail(GRDMA_ERR_INVALID, "pair has no wakeup fd");
+  uint64_t v = 0;
+  const ssize_t r = read(p->wakeup_fd, &v, sizeof(v));
+  return r == (ssize_t)sizeof(v) ? 1 : 0;
+}
+
+grdma_poller* grdma_poller_create(int n_threads, int sleep_timeout_ms) {
+  if (require_ctx()) return nullptr;
+  if (n_threads <= 0) {  // GPR_ASSERT(poller_thread_num_ > 0), config.cc
+    fail(GRDMA_ERR_CONFIG, "poller thread count must be positive");
+    return nullptr;
+  }
+  grdma_poller* pl = new grdma_poller();
+  pl->sleep_ms = sleep_timeout_ms > 0 ? sleep_timeout_ms : 1000;
+  pl->device = g_ctx.device;
+  pl->th = std::thread(poller_loop, pl);
+  return pl;
+}
+
+int grdma_poller_add(grdma_poller* pl, grdma_pair* p) {  // Poller::AddPollable, poller.cc:12-43
+  if (!pl || !p) return fail(GRDMA_ERR_INVALID, "null argument");
+  const int fd = grdma_pair_get_wakeup_fd(p);
+  if (fd < 0) return fd;
+  {
+    std::lock_guard<std::mutex> lk(pl->mu);
+    size_t slot = 0;
+    for (; slot < pl->pairs.size(); slot++)
+      if (pl->pairs[slot] == nullptr) break;
+    if (slot == pl->pairs.size()) {
+      if (pl->pairs.size() >= 4096) return fail(GRDMA_ERR_CAPACITY, "poller is full");
+      pl->pairs.push_back(p);
+    } else {
+      pl->pairs[slot] = p;
+    }
+  }
+  pl->cv.notify_one();
+  return fd;
+}
+
+int grdma_poller_remove(grdma_poller* pl, grdma_pair* p) {  // Poller::RemovePollable, poller.cc:45-54
+  if (!pl || !p) return fail(GRDMA_ERR_INVALID, "null argument");
+  uint64_t started = 0;
+  bool found = false;
+  {
+    std::lock_guard<std::mutex> lk(pl->mu);
+    for (auto& q : pl->pairs)
+      if (q == p) {
+        q = nullptr;
+        found = true;
+        break;
+      }
+    started = pl->pass_started;
+  }
+  if (!found) return fail(GRDMA_ERR_INVALID, "pair is not registered with this poller");
+  // a pass that took its snapshot before the removal may still be looking at the pair:
+  // it is safe to destroy the pair once every such pass has finished
+  while (pl->pass_finished.load(std::memory_order_acquire) < started && pl->running.load())
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  return 0;
+}
+
+int grdma_poller_stats(grdma_poller* pl, uint64_t* passes, uint64_t* wakeups) {
+  if (!pl) return fail(GRDMA_ERR_INVALID, "null poller");
+  if (passes) *passes = pl->passes.load();
+  if (wakeups) *wakeups = pl->wakeups.load();
+  return 0;
+}
+
+void grdma_poller_destroy(grdma_poller* pl) {  // Poller::Shutdown, poller.h:37-50
+  if (!pl) return;
+  pl->running.store(false, std::memory_order_release);
+  pl->cv.notify_all();
+  if (pl->th.joinable()) pl->th.join();
+  delete pl;
 }
 
 int grdma_pair_has_message(grdma_pair* p) {

@@ -1,0 +1,37 @@
+"""Background poller of the RDMA_BPEV platform (src/core/lib/ibverbs/poller.{h,cc}):
+registered pairs get their wakeup fd kicked when they have something for the event
+engine.  Thin wrapper over grdma_poller_* (one host thread, one k_poll launch per pass)."""
+import ctypes as C
+
+from ._lib import GrdmaError, check, load
+
+
+class Poller:
+    def __init__(self, n_threads=1, sleep_timeout_ms=1000):
+        self.lib = load()
+        self.h = self.lib.grdma_poller_create(n_threads, sleep_timeout_ms)
+        if not self.h:
+            raise GrdmaError(self.lib.grdma_last_error().decode())
+
+    def add(self, pair):
+        """AddPollable -> the pair's wakeup fd (add it to an epoll set / poll on it)."""
+        return check(self.lib.grdma_poller_add(self.h, pair.h))
+
+    def remove(self, pair):
+        check(self.lib.grdma_poller_remove(self.h, pair.h))
+
+    def stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(self.lib.grdma_poller_stats(self.h, C.byref(a), C.byref(b)))
+        return {"passes": a.value, "wakeups": b.value}
+
+    def close(self):
+        if self.h:
+            self.lib.grdma_poller_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

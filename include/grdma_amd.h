@@ -129,6 +129,25 @@ int grdma_pair_peek_staging(grdma_pair* p, uint64_t off, void* host_dst, uint64_
 int grdma_pair_last_wrs(grdma_pair* p, uint64_t out[2][2]);
 void* grdma_pair_ring_device_ptr(grdma_pair* p);
 
+/* ---- background poller (RDMA_BPEV): src/core/lib/ibverbs/poller.h:16-71, poller.cc:12-106 ----
+ * One host thread, one k_poll launch per pass over every registered pair (64 connections
+ * per wavefront) on a stream of its own.  A pair's wakeup fd (an eventfd; the reference's
+ * grpc_wakeup_fd, pair.h:150,187) becomes readable when the pair is connected and has a
+ * message or pending writes, or when it is half-closed / in error (poller.cc:80-98); it is
+ * not signalled again until the consumer has read it (poller.cc:76-78).  The event engine
+ * adds the fd to its epoll set exactly as ev_epollex_rdma_bpev_linux.cc does.
+ * n_threads mirrors GRPC_RDMA_POLLER_THREAD_NUM (must be > 0; one thread serves any number
+ * of pairs here), sleep_timeout_ms mirrors GRPC_RDMA_POLLER_SLEEP_TIMEOUT_MS. */
+typedef struct grdma_poller grdma_poller;
+grdma_poller* grdma_poller_create(int n_threads, int sleep_timeout_ms);
+void grdma_poller_destroy(grdma_poller* pl);                 /* Poller::Shutdown          */
+int grdma_poller_add(grdma_poller* pl, grdma_pair* p);       /* AddPollable; returns the fd */
+int grdma_poller_remove(grdma_poller* pl, grdma_pair* p);    /* RemovePollable; afterwards the
+                                                              * poller no longer touches p   */
+int grdma_poller_stats(grdma_poller* pl, uint64_t* passes, uint64_t* wakeups);
+int grdma_pair_get_wakeup_fd(grdma_pair* p);                 /* PairPollable::get_wakeup_fd */
+int grdma_pair_consume_wakeup(grdma_pair* p);                /* grpc_wakeup_fd_consume_wakeup: 1 if one was pending */
+
 /* ---- endpoint read/write on the pair: rdma_bp_posix.cc ----------------------- */
 typedef struct grdma_read_slice { uint64_t off, len; } grdma_read_slice;
 

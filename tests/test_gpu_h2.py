@@ -73,18 +73,39 @@ def oracle_events(slices_bytes, prefix, max_frame=16384):
     return 0, out
 
 
-def gpu_events(g, slices_bytes, prefix, max_frame=16384):
+def gpu_events(g, slices_bytes, prefix, max_frame=16384, gap_rng=None):
     from grpc_rdma_amd import h2dev
     arena, table, off = bytearray(), [], 0
     for s in slices_bytes:
+        if gap_rng is not None:  # slices at arbitrary byte offsets, 0xEE filler between them
+            arena += b"\xee" * gap_rng.randrange(1, 16)
+            off = len(arena)
         table.append((off, len(s)))
-        arena += s + bytes((-len(s)) % 16)
+        arena += s + (b"" if gap_rng is not None else bytes((-len(s)) % 16))
         off = len(arena)
     buf = g.DeviceBuffer(data=bytes(arena) + bytes(64))
     p = h2dev.Parser(prefix, max_frame)
     err, ev = p.deframe(buf.ptr, table)
     p.close()
     return err, ev
+
+
+@pytest.mark.parametrize("vec", VEC, ids=[v["name"] for v in VEC])
+def test_deframe_unaligned_slices(gpu, vec):
+    """Same vectors, the slices packed at arbitrary byte offsets of the arena (what a
+    caller-owned buffer looks like): the 32-byte look-ahead of every slice is assembled
+    from the aligned blocks around it and must not pick up the neighbouring bytes."""
+    data = bytes.fromhex(vec["hex"])
+    rng = random.Random(17)
+    for trial in range(6):
+        k = min(len(data) - 1, rng.choice([1, 3, 8, 20, 40]))
+        cuts = sorted(rng.sample(range(1, len(data)), k))
+        bounds = [0] + cuts + [len(data)]
+        chunks = [data[a:b] for a, b in zip(bounds, bounds[1:])]
+        rc_o, ev_o = oracle_events(chunks, True)
+        rc_g, ev_g = gpu_events(gpu, chunks, True, gap_rng=rng)
+        assert rc_g == rc_o == 0
+        assert ev_g == ev_o
 
 
 @pytest.mark.parametrize("vec", VEC, ids=[v["name"] for v in VEC])
