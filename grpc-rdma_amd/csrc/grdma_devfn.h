@@ -286,9 +286,9 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
       }
     }
     if ((sg.flags & GRDMA_SEG_ZERO_SRC) && src) {
-      // every load of this tile has returned (its data fed the stores above);
-      // make that explicit before the source bytes are overwritten
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // Every load of this tile has returned: its data fed the stores issued above, and
+      // a store cannot issue before its operands have arrived.  So the source may be
+      // overwritten right away, without waiting for those stores to complete.
       wave_zero_tile(src, n, lane);
     }
   }
