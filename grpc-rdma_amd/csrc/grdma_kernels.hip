@@ -155,20 +155,20 @@ __global__ __launch_bounds__(64) void k_poll(grdma_conn* const* conns, uint32_t 
 // ------------------------------------------------------------------ launchers
 extern "C" {
 
-hipError_t grdma_launch_tx_plan(const grdma_tx_op* d_ops, uint32_t nops, hipStream_t s) {
+__attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_plan(const grdma_tx_op* d_ops, uint32_t nops, hipStream_t s) {
   if (nops == 0) return hipSuccess;
   hipLaunchKernelGGL(k_tx_plan, dim3(nops), dim3(PLAN_THREADS), 0, s, d_ops);
   return hipGetLastError();
 }
 
-hipError_t grdma_launch_copy(const grdma_plan* const* d_plans, uint32_t nplans,
+__attribute__((visibility("hidden"))) hipError_t grdma_launch_copy(const grdma_plan* const* d_plans, uint32_t nplans,
                              uint32_t blocks_per_plan, hipStream_t s) {
   if (nplans == 0) return hipSuccess;
   hipLaunchKernelGGL(k_copy, dim3(blocks_per_plan, nplans), dim3(COPY_THREADS), 0, s, d_plans);
   return hipGetLastError();
 }
 
-hipError_t grdma_launch_rx_apply(const grdma_rx_op* d_ops, uint32_t nops, uint32_t blocks_per_op,
+__attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_apply(const grdma_rx_op* d_ops, uint32_t nops, uint32_t blocks_per_op,
                                  hipStream_t s) {
   if (nops == 0) return hipSuccess;
   hipLaunchKernelGGL(k_rx_apply, dim3(blocks_per_op, nops), dim3(COPY_THREADS), 0, s, d_ops);
@@ -177,7 +177,7 @@ hipError_t grdma_launch_rx_apply(const grdma_rx_op* d_ops, uint32_t nops, uint32
 
 // Kernel entry points for explicitly built HIP graphs (hipGraphAddKernelNode): the job
 // graph is assembled node by node instead of being recorded from streams.
-const void* grdma_kernel_fn(int which) {
+__attribute__((visibility("hidden"))) const void* grdma_kernel_fn(int which) {
   switch (which) {
     case 0: return reinterpret_cast<const void*>(&k_tx_plan);
     case 1: return reinterpret_cast<const void*>(&k_copy);
@@ -188,7 +188,7 @@ const void* grdma_kernel_fn(int which) {
 // Workgroups of the copy kernels that are resident at once on the current device: the
 // grid is capped there (the tile loop is grid-strided), so that no second, partial wave
 // of workgroups trails the first.
-uint32_t grdma_copy_resident_blocks(void) {
+__attribute__((visibility("hidden"))) uint32_t grdma_copy_resident_blocks(void) {
   int dev = 0, cus = 0, a = 0, b = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 1024;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
@@ -199,9 +199,9 @@ uint32_t grdma_copy_resident_blocks(void) {
   return (uint32_t)((per_cu > 0 ? per_cu : 1) * cus);
 }
 
-uint32_t grdma_kernel_threads(int which) { return (which == 0 || which == 2) ? PLAN_THREADS : COPY_THREADS; }
+__attribute__((visibility("hidden"))) uint32_t grdma_kernel_threads(int which) { return (which == 0 || which == 2) ? PLAN_THREADS : COPY_THREADS; }
 
-hipError_t grdma_launch_poll(grdma_conn* const* d_conns, uint32_t nconns, uint64_t* d_readable,
+__attribute__((visibility("hidden"))) hipError_t grdma_launch_poll(grdma_conn* const* d_conns, uint32_t nconns, uint64_t* d_readable,
                              uint64_t* d_ready_mask, uint64_t* d_has_mask, uint64_t* d_trigger_mask,
                              hipStream_t s) {
   if (nconns == 0) return hipSuccess;

@@ -1050,8 +1050,6 @@ int grdma_device_synchronize(void) {
 // n independent links (connections) advance in lock step: every launch carries one
 // op per link (grid.y = n), so 32 connections with 4 MiB rings fill the chip the way
 // one connection with a 128 MiB ring would.
-static uint64_t g_debug_flags = 0;  // copied into job ops; tools/ timing experiments only
-
 struct grdma_job_link {
   grdma_pair* tx = nullptr;
   grdma_pair* rx = nullptr;
@@ -1380,9 +1378,7 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
       t.staging_alt = odd ? l.d_staging2 : nullptr;
       t.result = &j->d_txres[i];
       t.use_cursor = k == 0 ? 2 : 1;
-      t.debug_flags = g_debug_flags;
       grdma_rx_op& r = h_rx[k * n + i];
-      r.debug_flags = g_debug_flags;
       r.conn = l.rx->d_conn;
       r.plan = odd ? l.d_rxplan2 : l.rx->d_rxplan;
       r.result = &j->d_rxres[(odd ? n : 0) + i];
@@ -1445,8 +1441,6 @@ int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds) {
   j->rounds = rounds;
   return 0;
 }
-
-void grdma_debug_set_flags(uint64_t f) { g_debug_flags = f; }  // tools/ timing experiments
 
 int grdma_stream_job_set_pipeline(grdma_stream_job* j, int on) {
   if (!j) return fail(GRDMA_ERR_INVALID, "null job");

@@ -1256,14 +1256,14 @@ void k_engine(grdma_engine_mbox* mb) {
 
 }  // namespace
 
-extern "C" hipError_t grdma_launch_engine(grdma_engine_mbox* mb, hipStream_t s) {
+extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_engine(grdma_engine_mbox* mb, hipStream_t s) {
   hipLaunchKernelGGL(k_engine, dim3(1), dim3(PLAN_THREADS), 0, s, mb);
   return hipGetLastError();
 }
 
-extern "C" const void* grdma_kernel_fn_rx_plan(void) { return reinterpret_cast<const void*>(&k_rx_plan); }
+extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rx_plan(void) { return reinterpret_cast<const void*>(&k_rx_plan); }
 
-extern "C" hipError_t grdma_launch_rx_plan(const grdma_rx_op* d_ops, uint32_t nops,
+extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan(const grdma_rx_op* d_ops, uint32_t nops,
                                            hipStream_t s) {
   if (nops == 0) return hipSuccess;
   hipLaunchKernelGGL(k_rx_plan, dim3(nops), dim3(PLAN_THREADS), 0, s, d_ops);

@@ -243,6 +243,21 @@ int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds);
  * two hosts do over a NIC).  Same bytes delivered; affects GRDMA_RUN_GRAPH and _EAGER. */
 int grdma_stream_job_set_pipeline(grdma_stream_job* j, int on);
 
+/* ---- diagnostics (profiling aids used by tools/; not needed by an integration) ------------
+ * s_memtime stamps / counters the plan kernels leave in their result blocks, the
+ * record-size history of a pair, per-command cycle counts of the latency engine. */
+int grdma_pair_last_dbg(grdma_pair* p, uint64_t tx_dbg[16], uint64_t rx_dbg[16]);
+int grdma_stream_job_debug(grdma_stream_job* j, uint64_t tx_dbg[16], uint64_t rx_dbg[16]);
+int grdma_pair_debug_hist(grdma_pair* p, uint32_t* hist_out /* 1024 entries */, uint64_t* count,
+                          uint32_t* period);
+int grdma_engine_debug(uint64_t out[5]);
+/* Scalar ring arithmetic of the host layer (ring_buffer.h:101-143), exported so that the
+ * CPU tests can pin it against the oracle without a device. */
+uint64_t grdma_host_free_size(uint64_t cap, uint64_t head, uint64_t tail);
+uint64_t grdma_host_writable(uint64_t cap, uint64_t head, uint64_t tail);
+uint64_t grdma_host_encoded_size(uint64_t payload);
+uint64_t grdma_host_calc_writable(uint64_t space);
+
 /* ---- HTTP/2 DATA framing / deframing on the device --------------------------------- */
 typedef struct grdma_h2_msg {     /* one gRPC message queued on a stream              */
   const void* payload;            /* serialized message bytes (device-accessible)     */

@@ -3,7 +3,6 @@ import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__
 import bench, grpc_rdma_amd as g
 from grpc_rdma_amd import stream as gs
 g.init(0)
-g.load().grdma_debug_set_flags(C.c_uint64(int(os.environ.get('DBGF','0'))))
 ring=int(os.environ.get('RING_KB','4096'))<<10
 tx,rx=g.Pair(ring,4095,0),g.Pair(ring,4095,0); g.connect_pairs(tx,rx)
 wl=bench.Workload(g,int(os.environ.get('MSGS','16')))
