@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgrdma_amd.so")
+LIB_PATH = os.environ.get("GRDMA_LIB_PATH") or os.path.join(HERE, "libgrdma_amd.so")  # (override: A/B builds in tools/)
 
 u64 = C.c_uint64
 u64p = C.POINTER(C.c_uint64)

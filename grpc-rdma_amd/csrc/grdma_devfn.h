@@ -227,33 +227,43 @@ __device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane)
   if ((uint64_t)lane < tail) p[(units << 4) + lane] = 0;
 }
 
-#define PREFIX_LDS 4096
-
-// Every workgroup stages the tile prefix in LDS (one coalesced load), then each wave
-// maps its tiles to segments with an LDS binary search.  Plans with more segments than
-// LDS slots are staged SAMPLED (every 2nd / 4th entry, the stride a power of two): the
-// LDS search then lands on a window of `stride` entries, which the wave fetches with one
-// global load (lane k takes entry k of the window) and resolves with a ballot.  Either
-// way there is no chain of dependent global loads between picking a tile and issuing
-// its first payload load.
+// Every workgroup stages the tile prefix in LDS (one coalesced load).  A wave takes a
+// CONTIGUOUS run of tiles: one LDS binary search finds the segment of its first tile, the
+// following tiles walk forward through the staged prefix (a 16 KiB record is four tiles
+// of the same segment: one search and one descriptor fetch instead of four).  Plans with
+// more segments than LDS slots are staged SAMPLED (every 2nd / 4th entry, the stride a
+// power of two): the search then lands on a window of `stride` entries, which the wave
+// fetches with one global load (lane k takes entry k of the window) and resolves with a
+// ballot, and the walk reads the next prefix entry from memory.
+// LDS_N: slots of the staged prefix -- 8192 in the copy kernels (32 KB, occupancy is
+// bound by registers there), 1024 where a plan workgroup runs its own small plan inline.
+template <uint32_t LDS_N, bool CONTIG = true>
 __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t wave,
                                                uint32_t nwaves, int lane) {
-  __shared__ uint32_t s_prefix[PREFIX_LDS + 1];
+  __shared__ uint32_t s_prefix[LDS_N + 1];
   const uint32_t nsegs = plan->nsegs;
   const uint32_t ntiles = plan->ntiles;
   uint32_t shift = 0;  // entry k of s_prefix is tile_prefix[k << shift]
-  while (((nsegs >> shift) + 1) > PREFIX_LDS) shift++;
+  while (((nsegs >> shift) + 1) > LDS_N) shift++;
   const uint32_t nsamp = (nsegs >> shift) + 1;  // samples 0 .. nsegs >> shift
   for (uint32_t i = threadIdx.x; i < nsamp; i += blockDim.x) s_prefix[i] = plan->tile_prefix[i << shift];
   __syncthreads();
-  for (uint32_t t = wave; t < ntiles; t += nwaves) {
+  // CONTIG: tiles [wave * per, (wave + 1) * per); otherwise wave, wave + nwaves, ... (each
+  // located by its own search)
+  const uint32_t per = CONTIG ? (ntiles + nwaves - 1) / nwaves : 1;
+  uint32_t t = CONTIG ? wave * per : wave;
+  uint32_t tend = t + per < ntiles ? t + per : ntiles;
+  if (t >= tend) return;
+ next_run:
+  uint32_t seg, p0, pnext;
+  {
     uint32_t lo = 0, hi = nsamp;  // invariant: sample[lo] <= t, (hi == nsamp or sample[hi] > t)
     while (hi - lo > 1) {
       const uint32_t mid = (lo + hi) >> 1;
       if (s_prefix[mid] <= t) lo = mid; else hi = mid;
     }
-    uint32_t seg = lo << shift;
-    uint32_t p0 = s_prefix[lo];
+    seg = lo << shift;
+    p0 = s_prefix[lo];
     if (shift) {
       // entries seg .. seg + stride - 1 (those that exist): the last one that is <= t
       const uint32_t k = seg + (uint32_t)lane;
@@ -264,7 +274,10 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
       seg += (uint32_t)last;
       p0 = __shfl(pk, last, 64);
     }
-    const grdma_seg sg = plan->segs[seg];
+    pnext = shift ? plan->tile_prefix[seg + 1] : s_prefix[seg + 1];
+  }
+  grdma_seg sg = plan->segs[seg];
+  for (;; ) {
     const uint64_t off = (uint64_t)(t - p0) * GRDMA_TILE_BYTES;
     uint64_t n = sg.len - off;
     if (n > GRDMA_TILE_BYTES) n = GRDMA_TILE_BYTES;
@@ -290,6 +303,22 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
       // a store cannot issue before its operands have arrived.  So the source may be
       // overwritten right away, without waiting for those stores to complete.
       wave_zero_tile(src, n, lane);
+    }
+    if (++t >= tend) {
+      if (CONTIG) break;
+      t += nwaves - 1;
+      if (t >= ntiles) break;
+      tend = t + 1;
+      goto next_run;
+    }
+    if (t >= pnext) {
+      // next segment that owns a tile (t < ntiles = prefix[nsegs], so the walk ends inside the plan)
+      do {
+        seg++;
+        p0 = pnext;
+        pnext = shift ? plan->tile_prefix[seg + 1] : s_prefix[seg + 1];
+      } while (t >= pnext);
+      sg = plan->segs[seg];
     }
   }
 }

@@ -1059,7 +1059,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
       plan->tag_mask = mask;
     }
     __syncthreads();
-    run_plan_tiles(plan, wave, PLAN_THREADS / 64, lane);
+    run_plan_tiles<1024>(plan, wave, PLAN_THREADS / 64, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }

@@ -506,11 +506,11 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
     // small-message path: the planning workgroup moves the bytes itself (its
     // own plan stores are visible to its waves after the barrier)
     __syncthreads();
-    run_plan_tiles(plan, tid >> 6, PLAN_THREADS / 64, tid & 63);
+    run_plan_tiles<1024>(plan, tid >> 6, PLAN_THREADS / 64, tid & 63);
     if (op.wire_plan != nullptr && !direct) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      run_plan_tiles(op.wire_plan, tid >> 6, PLAN_THREADS / 64, tid & 63);
+      run_plan_tiles<1024>(op.wire_plan, tid >> 6, PLAN_THREADS / 64, tid & 63);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

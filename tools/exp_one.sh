@@ -1,18 +1,13 @@
 #!/bin/bash
-B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-rtt --no-small-ring --conns 1"
+B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-rtt --no-small-ring --no-extra-legs --conns 1"
 run() { echo "== $ENVX $*"; timeout 300 env $ENVX $B "$@" 2>&1 | tail -1 | python -c "
 import sys, json
 l = sys.stdin.read().strip()
 try:
     d = json.loads(l)
-    print(d['value'], d['config']['rounds_per_step'], d['verified'])
+    print(d['value'], d['config']['rounds_per_step'], d['verified'], {k: v['us_per_launch'] for k, v in d['kernels'].items()})
 except Exception as e:
     print('ERR', l[-600:])
 "; }
-for r in 131072 524288; do
-ENVX="X=1" run --ring-kb $r
-ENVX="GRDMA_PIPE_VARIANT=0" run --ring-kb $r --pipeline 1
-ENVX="GRDMA_PIPE_VARIANT=1" run --ring-kb $r --pipeline 1
-ENVX="GRDMA_PIPE_VARIANT=2" run --ring-kb $r --pipeline 1
-done
-ENVX="X=1" run --ring-kb 65536 --wire direct
+ENVX="X=1" run
+ENVX="X=1" run --pipeline 0
