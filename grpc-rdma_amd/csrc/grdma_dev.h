@@ -87,8 +87,8 @@ struct grdma_conn {
   uint64_t rx_rounds;           // drains that delivered at least one slice
   uint64_t tx_records;          // ring records produced
   uint64_t rx_records;          // ring records consumed
-  uint32_t pad1;
-  uint32_t pad2;
+  uint32_t rx_h1;               // encoded sizes of the last / last-but-one record read (0 = none yet):
+  uint32_t rx_h2;               // the chain walker's size prediction without a trip to the history ring
   uint64_t tx_remaining;        // bytes of the current slice list not yet accepted
   uint32_t* rx_hist;            // encoded sizes of the last GRDMA_RX_HIST records read
   uint64_t rx_hist_count;       // records read so far (ring index = count % HIST)

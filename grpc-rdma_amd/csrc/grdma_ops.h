@@ -20,6 +20,9 @@ struct grdma_tx_op {
   uint32_t inline_copy;            // 1: this workgroup also runs the gather (and wire) tiles --
                                    // one launch per Send for small messages
   uint8_t* staging_alt;            // != NULL: stage this Send here instead of conn->staging
+  uint64_t seq_next;               // != 0: the value to publish in result->seq (latency mode: the
+                                   // result block is host memory, reading the old value back
+                                   // would be a PCIe round trip in front of the release)
 };
 
 // One drain of a connection's ring: a run of endpoint_read completions.
@@ -35,6 +38,7 @@ struct grdma_rx_op {
   uint64_t append;                 // 1: continue at conn->rx_arena_off / rx_slice_idx
   uint64_t slices_cap;             // entries in `slices` (append mode)
   uint64_t inline_apply;           // 1: this workgroup also scatters, zero-fills and posts credit
+  uint64_t seq_next;               // != 0: the value to publish in result->seq / commit_seq
 };
 
 // Mailbox of the persistent latency engine (pinned host memory).

@@ -296,6 +296,7 @@ int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_curs
   h->txop.result = &h->txres;
   h->txop.use_cursor = use_cursor;
   h->txop.inline_copy = p->latency ? 1 : 0;
+  h->txop.seq_next = p->latency ? h->txres.seq + 1 : 0;
   const uint32_t blocks = copy_blocks_for(p->ring_size / 2);
   if (p->latency) {
     if (g_engine.wanted && p->h_cmd && p->cmd_inline) {
@@ -330,6 +331,7 @@ int run_recv(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_rea
   h->rxop.append = 0;
   h->rxop.slices_cap = GRDMA_MAX_SLICES;
   h->rxop.inline_apply = p->latency ? 1 : 0;
+  h->rxop.seq_next = p->latency ? h->rxres.seq + 1 : 0;
   const uint32_t blocks = copy_blocks_for(p->ring_size);
   if (p->latency) {
     if (g_engine.wanted && p->h_cmd) {

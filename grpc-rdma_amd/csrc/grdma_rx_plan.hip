@@ -36,6 +36,8 @@ namespace {
 #define BULK_MAX 4096
 #define MINRD GRDMA_MIN_READ_SLICE
 
+__device__ unsigned long long g_express_drains = 0;  // diagnostics: drains served by the express path
+
 struct chain_walker {
   const uint8_t* ring;
   uint64_t cap;
@@ -266,7 +268,123 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
   const uint64_t mh0 = c->moving_head;
   const uint64_t hist_count0 = c->rx_hist_count;
 
-  {
+  // ===================================================================== express drain
+  // The unary small-message case (latency mode): nothing is half-read, at most EXPRESS_MAX
+  // tiny records are ready and they fit the read that is open (or the 256-byte read a fresh
+  // rdma_continue_read allocates).  One wavefront then does the whole drain in three
+  // memory round trips -- connection state, one probe round, the payload bytes -- with no
+  // plan in memory, no LDS tables and no history load: lane i owns record i for the
+  // arithmetic, every lane moves eight bytes of the delivered slice.  Anything else
+  // (a record cut by the read, more records than lanes looked at, a pattern the probe round
+  // could not follow) falls through to the general tiers below, which produce the same
+  // result for these cases too.
+  __shared__ unsigned int s_express;
+  constexpr uint32_t EXPRESS_MAX = 8, EXPRESS_BYTES = 512;
+  if (tid == 0) s_express = 0;
+  __syncthreads();
+  if (op.inline_apply && op.raw_cap == 0 && !op.append && connected && wave == 0 && c->remain == 0 &&
+      max_slices >= 1) {
+    const uint64_t head0 = c->head, leftover0 = c->leftover_cap, irs0 = c->internal_read_size;
+    chain_walker w = {ring, cap, head0, 0, c->rx_h2, c->rx_h1, false};
+    const uint32_t v = chain_round(&w, s_chain, lane);
+    const bool all_seen = w.dry && v <= EXPRESS_MAX;
+    const uint32_t n = ((uint32_t)lane < v && all_seen) ? (uint32_t)s_chain[lane] : 0;
+    const uint32_t enc = ((uint32_t)lane < v && all_seen) ? 16u + (uint32_t)round_up8(n) : 0;
+    const uint32_t i_n = wave_incl_scan_u32(n), i_enc = wave_incl_scan_u32(enc);
+    const uint32_t T = __shfl(i_n, 63, 64), E = __shfl(i_enc, 63, 64);
+    const uint32_t n0 = __shfl(n, 0, 64);
+    // rdma_continue_read, rdma_bp_posix.cc:306-317: the open read, or a new one of max(256, readable)
+    const uint64_t alloc = leftover0 ? leftover0 : (n0 > MINRD ? n0 : MINRD);
+    // (the arena must also hold the read that follows and finds nothing, like the loop below checks)
+    const uint64_t next_alloc = (alloc - (T <= alloc ? T : 0)) ? alloc - T : MINRD;
+    if (all_seen && T <= alloc && T <= EXPRESS_BYTES && a_off0 + alloc <= op.arena_cap &&
+        ((a_off0 + T + 15) & ~15ull) + next_alloc <= op.arena_cap) {
+      // payload: output byte b of the slice lives in record r(b) at offset b - x_n(r)
+      const uint32_t x_n = i_n - n, x_enc = i_enc - enc;
+      uint8_t* dst = op.arena + a_off0;
+      uint32_t src_off[8];  // ring offset of output byte 8 * lane + q, relative to head0
+#pragma unroll
+      for (int q = 0; q < 8; q++) src_off[q] = 0;
+#pragma unroll
+      for (uint32_t r = 0; r < EXPRESS_MAX; r++) {
+        const uint32_t rx = __shfl(x_n, (int)r, 64), rn = __shfl(n, (int)r, 64), re = __shfl(x_enc, (int)r, 64);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t b = (uint32_t)lane * 8 + q;
+          if (b >= rx && b < rx + rn) src_off[q] = re + 8 + (b - rx);
+        }
+      }
+      // all byte loads first (global address space: no LDS counter involved), then the stores
+      auto* gring = (const __attribute__((address_space(1))) uint8_t*)(uint64_t)ring;
+      uint8_t bytes[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t b = (uint32_t)lane * 8 + q;
+        bytes[q] = b < T ? gring[(head0 + src_off[q]) & mask] : (uint8_t)0;
+      }
+      // one 8-byte store per lane (the slice buffer is 16-byte aligned and `alloc` bytes long;
+      // the bytes behind the slice end inside the last word are written as zero)
+      if ((uint32_t)lane * 8 < T) {
+        uint64_t word = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) word |= (uint64_t)bytes[q] << (8 * q);
+        *reinterpret_cast<uint64_t*>(dst + (uint32_t)lane * 8) = word;
+      }
+      // clear what was consumed: records are 8-byte granular, [head0, head0 + E) with wrap
+      for (uint32_t o = (uint32_t)lane * 8; o < E; o += 64 * 8)
+        *reinterpret_cast<uint64_t*>(ring + ((head0 + o) & mask)) = 0;
+      // history ring and the credit rule of Recv (pair.cc:276-284), record by record
+      uint32_t* gh = c->rx_hist;
+      if ((uint32_t)lane < v) gh[(hist_count0 + lane) % GRDMA_RX_HIST] = enc;
+      uint64_t irs = irs0, credit = 0, credit_head = 0;
+      for (uint32_t r = 0; r < v; r++) {
+        irs += __shfl(enc, (int)r, 64);
+        if (irs >= cap / 2) {
+          credit_head = (head0 + __shfl(i_enc, (int)r, 64)) & mask;
+          credit++;
+          irs = 0;
+        }
+      }
+      if (lane == 0) {
+        const uint64_t nh = (head0 + E) & mask;
+        S.head = nh; S.mh = v ? nh : c->moving_head; S.remain = 0; S.irs = irs;
+        S.nsegs = S.ntiles = 0;
+        S.consumed_total = E; S.records = v; S.bytes = T;
+        S.credit = credit; S.credit_head = credit_head;
+        S.hist_count = hist_count0 + v;
+        if (v) {
+          // one completed read of T bytes; a second read finds nothing and keeps its buffer
+          out_slices[0].off = a_off0;
+          out_slices[0].len = T;
+          S.nslices = 1;
+          S.a_off = (a_off0 + T + 15) & ~15ull;
+          const uint64_t rest = alloc - T;
+          S.would_block = max_slices >= 2 ? 1 : 0;
+          S.leftover = max_slices >= 2 ? (rest ? rest : MINRD) : rest;
+        } else {
+          // nothing ready: notify_on_read, the slice stays allocated (rdma_bp_posix.cc:241-243)
+          S.nslices = 0; S.a_off = a_off0; S.would_block = 1; S.leftover = alloc;
+        }
+        S.stop = 1;
+        S.bulk_tries = 0; S.bulk_blocked = 0; S.took = 0;
+        S.period = c->rx_period; S.period_searched = 0; S.period_retry_at = c->rx_period_retry_at;
+        S.period_strikes = c->pad3 & 0xFFFFu; S.period_backoff = c->pad3 >> 16; S.bulk_first = 1;
+        for (int q = 0; q < 16; q++) s_dbg[q] = 0;
+        s_dbg[0] = 1;
+        // sizes of the two newest records, for the next call's probe round
+        const uint32_t e_last = v >= 1 ? (uint32_t)s_chain[v - 1] : 0, e_prev = v >= 2 ? (uint32_t)s_chain[v - 2] : 0;
+        if (v >= 2) { c->rx_h1 = 16u + (uint32_t)round_up8(e_last); c->rx_h2 = 16u + (uint32_t)round_up8(e_prev); }
+        else if (v == 1) { c->rx_h2 = c->rx_h1; c->rx_h1 = 16u + (uint32_t)round_up8(e_last); }
+        s_express = 1;
+        atomicAdd(&g_express_drains, 1ull);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  const bool express = s_express != 0;
+
+  if (!express) {
     // (all loads first: `c->rx_hist` is a generic pointer, so a store to LDS between two
     // of them would serialise the round trips)
     constexpr int NH = GRDMA_RX_HIST / PLAN_THREADS;
@@ -277,7 +395,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
 #pragma unroll
     for (int r = 0; r < NH; r++) s_hist[tid + r * PLAN_THREADS] = hv[r];
   }
-  if (tid == 0) {
+  if (tid == 0 && !express) {
     S.head = c->head; S.mh = c->moving_head; S.remain = c->remain;
     S.irs = c->internal_read_size; S.leftover = c->leftover_cap;
     S.nslices = S.nsegs = S.ntiles = S.bytes = S.consumed_total = S.records = 0;
@@ -1047,8 +1165,14 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
   const uint64_t t_loop_end = __builtin_amdgcn_s_memtime();
   // history back to the connection
   __syncthreads();
-  for (unsigned i = tid; i < GRDMA_RX_HIST; i += PLAN_THREADS) c->rx_hist[i] = s_hist[i];
-  if (op.inline_apply) {
+  if (!express) {
+    for (unsigned i = tid; i < GRDMA_RX_HIST; i += PLAN_THREADS) c->rx_hist[i] = s_hist[i];
+    if (tid == 0 && S.hist_count >= 1) {
+      c->rx_h1 = s_hist[(S.hist_count - 1) % GRDMA_RX_HIST];
+      c->rx_h2 = S.hist_count >= 2 ? s_hist[(S.hist_count - 2) % GRDMA_RX_HIST] : 0;
+    }
+  }
+  if (op.inline_apply && !express) {
     // small-message path: this workgroup also scatters the payload, clears it
     // behind itself and (below, thread 0) posts the credit -- one launch per drain
     if (tid == 0) {
@@ -1079,18 +1203,22 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     plan->tag_base = (uint64_t)ring;
     plan->tag_mask = mask;
 
+    // (counters: all loads before the first store to the connection, one round trip)
+    const uint64_t o_total_read = c->total_read, o_credit_msgs = c->credit_msgs;
+    const uint64_t o_rx_records = c->rx_records, o_rx_rounds = c->rx_rounds;
+    const uint64_t o_slice_idx = op.append == 1 ? c->rx_slice_idx : 0;
     c->head = head;
     c->moving_head = mh;
     c->remain = S.remain;
     c->internal_read_size = S.irs;
     c->leftover_cap = S.leftover;
-    c->total_read += S.bytes;
-    c->credit_msgs += S.credit;
-    c->rx_records += S.records;
-    if (nslices) c->rx_rounds++;
+    c->total_read = o_total_read + S.bytes;
+    c->credit_msgs = o_credit_msgs + S.credit;
+    c->rx_records = o_rx_records + S.records;
+    if (nslices) c->rx_rounds = o_rx_rounds + 1;
     if (op.append) {
       c->rx_arena_off = S.a_off;
-      c->rx_slice_idx = (op.append == 2 ? 0 : c->rx_slice_idx) + nslices;
+      c->rx_slice_idx = o_slice_idx + nslices;
     }
     res->blocks_done = 0;
     // updateStatus() (pair.cc:624-641) must not overtake the copy-out and the
@@ -1108,6 +1236,9 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     res->moving_head = mh;
     res->remain = S.remain;
     res->arena_used = S.a_off;
+    // (profiling stamps: not in latency mode, where the result block lives in host memory and
+    // every word of it is a PCIe write in front of the release below)
+    if (!op.inline_apply) {
     res->dbg[0] = t_begin;
     res->dbg[1] = __builtin_amdgcn_s_memtime();
     res->dbg[2] = s_dbg[0];
@@ -1118,6 +1249,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     res->dbg[13] = t_loop_end - t_begin;
     res->dbg[14] = s_dbg[14];
     res->dbg[15] = s_dbg[15];
+    }
     // consumed ring bytes are always the contiguous range [mh0, mh)
     res->zero_off[0] = res->zero_off[1] = res->zero_len[0] = res->zero_len[1] = 0;
     if (S.consumed_total > 0) {
@@ -1140,10 +1272,11 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
           __hip_atomic_store(&ps->remote_head, S.credit_head, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      __hip_atomic_store(&res->commit_seq, res->commit_seq + 1, __ATOMIC_RELAXED,
+      __hip_atomic_store(&res->commit_seq, op.seq_next ? op.seq_next : res->commit_seq + 1, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __hip_atomic_store(&res->seq, res->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&res->seq, op.seq_next ? op.seq_next : res->seq + 1, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1259,6 +1392,12 @@ void k_engine(grdma_engine_mbox* mb) {
 extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_engine(grdma_engine_mbox* mb, hipStream_t s) {
   hipLaunchKernelGGL(k_engine, dim3(1), dim3(PLAN_THREADS), 0, s, mb);
   return hipGetLastError();
+}
+
+extern "C" uint64_t grdma_express_drains(void) {
+  unsigned long long v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_express_drains), sizeof(v)) != hipSuccess) return 0;
+  return (uint64_t)v;
 }
 
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rx_plan(void) { return reinterpret_cast<const void*>(&k_rx_plan); }

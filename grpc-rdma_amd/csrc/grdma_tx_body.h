@@ -142,12 +142,14 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     uint64_t idx = start + nrec, bidx = 0;
     if (short_pay > 0) bidx = (nrec == 0 ? byte_idx : 0) + short_pay;
     else if (nrec == 0) bidx = byte_idx;
+    // (counters: loads before the first store to the connection, one round trip)
+    const uint64_t o_written = c->total_written, o_records = c->tx_records, o_rounds = c->tx_rounds;
     c->remote_tail = new_tail;
-    c->partial_write = sent < offered ? 1 : 0;
-    c->total_written += sent;
-    c->tx_records += nrec_total;
+    c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709
+    c->total_written = o_written + sent;
+    c->tx_records = o_records + nrec_total;
     c->tx_last_records = (uint32_t)nrec_total;
-    if (nrec_total) c->tx_rounds++;
+    if (nrec_total) c->tx_rounds = o_rounds + 1;
     if (op.use_cursor) {
       c->tx_slice_idx = idx;
       c->tx_byte_idx = bidx;
@@ -163,7 +165,8 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     r->done = (idx >= op.nslices) ? 1 : 0;
     // the peer reads the ring in a later command / kernel; the host needs the result
     // block (pinned memory): a system-scope release on the sequence word covers it
-    __hip_atomic_store(&r->seq, r->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&r->seq, op.seq_next ? op.seq_next : r->seq + 1, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -478,12 +481,14 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
     uint64_t bidx = 0;
     if (short_pay > 0) bidx = (nrec == 0 ? byte_idx : 0) + short_pay;
     else if (nrec == 0) bidx = byte_idx;
+    // (counters: loads before the first store to the connection, one round trip)
+    const uint64_t o_written = c->total_written, o_records = c->tx_records, o_rounds = c->tx_rounds;
     c->remote_tail = new_tail;
     c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709
-    c->total_written += sent;
-    c->tx_records += nrec_total;
+    c->total_written = o_written + sent;
+    c->tx_records = o_records + nrec_total;
     c->tx_last_records = (uint32_t)nrec_total;
-    if (nrec_total) c->tx_rounds++;
+    if (nrec_total) c->tx_rounds = o_rounds + 1;
     if (op.use_cursor) {
       c->tx_slice_idx = idx;
       c->tx_byte_idx = bidx;
@@ -498,9 +503,11 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
     r->byte_idx = bidx;
     r->done = (idx >= op.nslices) ? 1 : 0;
     tdbg[6] = __builtin_amdgcn_s_memtime();
-    for (int q = 0; q < 7; q++) r->dbg[q] = tdbg[q];
-    r->dbg[8] = t_loaded;
-    r->dbg[7] = m;
+    if (!op.inline_copy) {  // profiling stamps; not in latency mode (PCIe writes in front of the release)
+      for (int q = 0; q < 7; q++) r->dbg[q] = tdbg[q];
+      r->dbg[8] = t_loaded;
+      r->dbg[7] = m;
+    }
   }
   if (op.inline_copy) {
     // small-message path: the planning workgroup moves the bytes itself (its
@@ -517,7 +524,7 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
   }
   if (tid == 0) {
     grdma_tx_result* r = op.result;
-    const uint64_t nxt = r->seq + 1;
+    const uint64_t nxt = op.seq_next ? op.seq_next : r->seq + 1;
     __hip_atomic_store(&r->seq, nxt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }

@@ -251,6 +251,7 @@ int grdma_stream_job_debug(grdma_stream_job* j, uint64_t tx_dbg[16], uint64_t rx
 int grdma_pair_debug_hist(grdma_pair* p, uint32_t* hist_out /* 1024 entries */, uint64_t* count,
                           uint32_t* period);
 int grdma_engine_debug(uint64_t out[5]);
+uint64_t grdma_express_drains(void);  /* drains served by the single-wave express path so far */
 /* Scalar ring arithmetic of the host layer (ring_buffer.h:101-143), exported so that the
  * CPU tests can pin it against the oracle without a device. */
 uint64_t grdma_host_free_size(uint64_t cap, uint64_t head, uint64_t tail);

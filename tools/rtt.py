@@ -25,6 +25,8 @@ for mode in ('engine',):
         d=(C.c_uint64*5)(); lib.grdma_engine_debug(d); ops=2*(n+100)
         print('engine cycles per op: send load %d body %d | drain load %d body %d' % (d[0]//ops, d[1]//ops, d[2]//ops, d[3]//ops))
         lib.grdma_engine_stop()
+        lib.grdma_express_drains.restype=C.c_uint64
+        print('express drains:', lib.grdma_express_drains(), 'of', ops, 'drains')
         td=(C.c_uint64*16)(); rd=(C.c_uint64*16)(); lib.grdma_pair_last_dbg.argtypes=[C.c_void_p,C.POINTER(C.c_uint64),C.POINTER(C.c_uint64)]
         lib.grdma_pair_last_dbg(a.h,td,rd)
         print('tx stamps', [int(td[i])-int(td[0]) for i in range(10)])
