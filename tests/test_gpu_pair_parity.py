@@ -424,6 +424,8 @@ def test_express_drain_matches_oracle(gpu, sizes):
             assert got == [] and not s_ and wb
             check_state(a, b, o)
             assert b.state()["leftover_cap"] == o.p[1].leftover_cap, it
-    if len(sizes) <= 2:  # (the probe round predicts sizes that alternate; longer patterns take the general tiers)
+    # (the probe round predicts sizes that alternate, and a message only takes the express path
+    # while it still fits the shrinking open read: small two-record messages do most of the time)
+    if len(sizes) <= 2 and sum(sizes) <= 128:
         assert lib.grdma_express_drains() - before >= 60, "the express path was not exercised"
     a.close(); b.close(); o.close()
