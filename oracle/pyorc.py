@@ -380,8 +380,22 @@ class H2Parser:
         return rc, [(e.kind, e.a, e.b, e.c, e.d) for e in ev[:nev.value]]
 
 
-def stream_baseline(ring_size, max_sge, wire, lens, n_msgs):
-    """Single-thread CPU pass of the full pair protocol; -> (payload bytes, seconds)."""
+def ref_stream_baseline(ring_size, max_sge, wire, lens, n_msgs):
+    """The same pass over the reference-built ring codec (oracle/_ref); -> (payload bytes,
+    seconds, checksum).  Raises if oracle/_ref is not there."""
+    r = ref()
+    r.ref_stream_baseline.restype = u64
+    r.ref_stream_baseline.argtypes = [u64, C.c_int, C.c_char_p, C.POINTER(u64), u64, u64,
+                                      C.POINTER(C.c_double), C.POINTER(u64)]
+    arr = (u64 * len(lens))(*lens)
+    buf = C.create_string_buffer(bytes(wire), len(wire))
+    sec, chk = C.c_double(0), u64(0)
+    n = r.ref_stream_baseline(ring_size, max_sge, buf, arr, len(lens), n_msgs, C.byref(sec), C.byref(chk))
+    return n, sec.value, chk.value
+
+
+def stream_baseline(ring_size, max_sge, wire, lens, n_msgs, with_checksum=False):
+    """Single-thread CPU pass of the full pair protocol; -> (payload bytes, seconds[, checksum])."""
     l = lib()
     arr = (u64 * len(lens))(*lens)
     buf = C.create_string_buffer(bytes(wire), len(wire))
@@ -389,4 +403,6 @@ def stream_baseline(ring_size, max_sge, wire, lens, n_msgs):
     chk = u64(0)
     n = l.orc_stream_baseline(ring_size, max_sge, buf, arr, len(lens), n_msgs, C.byref(sec),
                               C.byref(chk))
+    if with_checksum:
+        return n, sec.value, chk.value
     return n, sec.value

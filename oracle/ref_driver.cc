@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <time.h>
 #include <vector>
 
 #include <grpc/support/log.h>
@@ -335,6 +336,59 @@ void ref_pair_state(void* h, int s, uint64_t state[8]) {
   state[6] = p->credit_msgs_;
   state[7] = p->partial_write_ ? 1 : 0;
 }
+// Single-thread streaming pass over the reference-built ring codec: the same loop as
+// orc_stream_baseline (oracle/grdma_oracle.c) -- rdma_write/rdma_flush on one side
+// (rdma_bp_posix.cc:470-524), rdma_continue_read/rdma_do_read on the other (:180-326) --
+// with every byte encoded and decoded by the reference's own ring_buffer.cc.  bench.py
+// times it as the CPU baseline (kind "reference") when oracle/_ref is present.
+uint64_t ref_stream_baseline(uint64_t ring_size, int max_sge, const uint8_t* wire,
+                             const uint64_t* lens, uint64_t nslices, uint64_t n_msgs,
+                             double* seconds, uint64_t* checksum) {
+  PairPollable a(ring_size, max_sge), b(ring_size, max_sge);
+  a.Connect(&b);
+  b.Connect(&a);
+  std::vector<const uint8_t*> ptrs(nslices);
+  uint64_t off = 0;
+  for (uint64_t i = 0; i < nslices; i++) {
+    ptrs[i] = wire + off;
+    off += lens[i];
+  }
+  std::vector<grpc_slice> sl = make_slices(ptrs.data(), lens, nslices, 0);
+  std::vector<uint8_t> dst(ring_size);
+  uint64_t delivered = 0, sum = 0, leftover = 0;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (uint64_t m = 0; m < n_msgs; m++) {
+    uint64_t idx = 0, byte_idx = 0;
+    while (idx < nslices) {
+      uint64_t sent = a.Send(sl.data() + idx, nslices - idx, byte_idx);
+      while (sent > 0) {
+        const uint64_t sl_len = lens[idx] - byte_idx;
+        if (sent >= sl_len) { sent -= sl_len; idx++; byte_idx = 0; }
+        else { byte_idx += sent; sent = 0; }
+      }
+      for (;;) {  // one endpoint read per iteration
+        const uint64_t readable = b.ring().GetReadableSize();
+        const uint64_t alloc = leftover ? leftover : (readable > 256 ? readable : 256);
+        uint64_t total = 0;
+        while (total < alloc) {
+          const uint64_t n = b.Recv(dst.data() + total, alloc - total);
+          if (n == 0) break;
+          total += n;
+        }
+        leftover = total ? alloc - total : alloc;
+        if (total == 0) break;
+        delivered += total;
+        sum += dst[0] + dst[total - 1];
+      }
+    }
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  if (checksum) *checksum = sum;
+  return delivered;
+}
+
 // Work requests of the last Send: out[k] = {remote ring offset, length}.
 int ref_pair_last_wrs(void* h, int s, uint64_t out[2][2]) {
   PairPollable* p = side(h, s);

@@ -89,3 +89,19 @@ def test_inlined_slices_are_read_through_the_accessor_macros():
     assert b1.send(0, sl, 0, inline_small=0) == b2.send(0, sl, 0, inline_small=1)
     assert b1.ring_mem(1) == b2.ring_mem(1)
     b1.close(); b2.close()
+
+
+@pytest.mark.parametrize("ring", [1 << 14, 1 << 18, 4 << 20])
+@pytest.mark.parametrize("msg_len", [1, 300, 70000, 1 << 20])
+def test_stream_baseline_port_equals_reference_codec(ring, msg_len):
+    """The streaming loop bench.py times as the CPU baseline: the plain-C port and the same
+    loop over the reference-built ring codec deliver the same bytes (count and the
+    first/last-byte checksum of every endpoint read)."""
+    if not pyorc.ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    msg = bytes((i * 37 + 11) & 0xFF for i in range(msg_len))
+    wire, lens = pyorc.h2_frame_message(msg, 1)
+    n_port, _s, chk_port = pyorc.stream_baseline(ring, 30, wire, lens, 5, with_checksum=True)
+    n_ref, _s2, chk_ref = pyorc.ref_stream_baseline(ring, 30, wire, lens, 5)
+    assert n_port == n_ref == 5 * len(wire)
+    assert chk_port == chk_ref
