@@ -22,6 +22,13 @@
 //          __ballot() verification, 64 records replayed per step on the DPP
 //          network.  Used while no period is known and around irregularities.
 //  scalar  one endpoint_read at a time (partial reads, retained slices, tails).
+//
+// In front of the tiers, in latency mode only: the EXPRESS drain -- a small unary message
+// (<= 8 tiny records that fit the open read) handled by one wavefront in three memory
+// round trips, no plan, no LDS tables (see "express drain" in rx_plan_body).
+//
+// Record tags (header / padding / footer words) are not cleared here: the segments carry
+// GRDMA_SEG_TAG_* flags and the scatter waves of k_rx_apply do it (grdma_dev.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
