@@ -44,15 +44,20 @@ struct grdma_h2_frame_result {
 #define H2_INLINED 23u
 typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
-// grpc_chttp2_data_parser + the deframe fields of grpc_chttp2_transport, one
-// per connection, resident in HBM between calls.
+// One entry of the transport's stream map (grpc_chttp2_stream_map, internal.h) with what
+// the deframe path reads: the per-stream grpc_chttp2_data_parser (frame_data.h),
+// read_closed / write_closed (chttp2_transport.cc:2194-2244), header_frames_received.
+// The map is an open-addressing table in HBM (linear probing from (id >> 1) & mask --
+// stream ids of one side are consecutive odd numbers -- with backward-shift deletion, so
+// it never fills with tombstones however many RPCs a connection has carried).
 struct grdma_h2_stream_dev {
-  uint32_t stream_id;
+  uint32_t stream_id;   // 0 = empty slot
   int32_t state;        // 0..4 FH_0..FH_4, 5 FRAME, 6 ERROR
   uint32_t frame_size;
-  int32_t compressed;
+  uint8_t compressed, read_closed, write_closed, hdr_frames;
 };
-#define H2_MAX_STREAMS 16
+// The deframe fields of grpc_chttp2_transport (internal.h), one per connection, resident
+// in HBM between calls.
 struct grdma_h2_parser_dev {
   int32_t state;        // 0..23 client prefix, 24..32 FH_0..FH_8, 33 FRAME
   uint32_t incoming_frame_size;
@@ -60,11 +65,17 @@ struct grdma_h2_parser_dev {
   uint32_t incoming_frame_flags;
   uint32_t incoming_stream_id;
   uint32_t max_frame_size;
-  int32_t cur_parser;   // 0 skip, 1 data
-  int32_t nstreams;
-  grdma_h2_stream_dev streams[H2_MAX_STREAMS];
+  int32_t cur_parser;   // 0 skip, 1 data, 2 header, 3 rst_stream
+  int32_t is_server;
+  int32_t is_first_frame;
+  uint32_t expect_continuation;
+  uint32_t header_eof, header_boundary, received_last_frame;
+  uint32_t last_new_stream_id;
+  uint32_t max_concurrent;
+  uint32_t live_streams;
+  uint32_t tab_mask;
   int32_t error;        // connection error (grdma_h2_error), sticky
-  int32_t pad;
+  grdma_h2_stream_dev* tab;
 };
 
 struct grdma_h2_deframe_result {
@@ -245,19 +256,54 @@ __global__ __launch_bounds__(256) void k_h2_frame(const grdma_h2_msg_dev* msgs, 
 }
 
 // ---------------------------------------------------------------- RX deframing
-enum { EV_FRAME = 1, EV_PAYLOAD = 2, EV_MSG_BEGIN = 3, EV_MSG_BYTES = 4, EV_MSG_END = 5 };
+enum { EV_FRAME = 1, EV_PAYLOAD = 2, EV_MSG_BEGIN = 3, EV_MSG_BYTES = 4, EV_MSG_END = 5,
+       EV_STREAM_OPEN = 6, EV_STREAM_CLOSED = 7 };
 enum { ST_FH0 = 24, ST_FRAME = 33 };
+enum { PARSER_SKIP = 0, PARSER_DATA = 1, PARSER_HEADER = 2, PARSER_RST = 3 };
+enum { FT_DATA = 0, FT_HEADERS = 1, FT_RST_STREAM = 3, FT_SETTINGS = 4, FT_CONTINUATION = 9 };
 
-__device__ __forceinline__ grdma_h2_stream_dev* find_stream(grdma_h2_parser_dev* p, uint32_t id) {
-  for (int i = 0; i < p->nstreams; i++)
-    if (p->streams[i].stream_id == id) return &p->streams[i];
-  if (id == 0 || p->nstreams >= H2_MAX_STREAMS) return nullptr;
-  grdma_h2_stream_dev* d = &p->streams[p->nstreams++];
-  d->stream_id = id;
-  d->state = 0;
-  d->frame_size = 0;
-  d->compressed = 0;
-  return d;
+// ---- stream map (single-lane code; callers broadcast the result) ----
+__device__ __forceinline__ uint32_t tab_home(uint32_t id, uint32_t mask) { return (id >> 1) & mask; }
+
+// grpc_chttp2_parsing_lookup_stream: plain lookup, never creates
+__device__ int tab_find(const grdma_h2_stream_dev* tab, uint32_t mask, uint32_t id) {
+  if (id == 0) return -1;
+  uint32_t i = tab_home(id, mask);
+  for (uint32_t n = 0; n <= mask; n++, i = (i + 1) & mask) {
+    const uint32_t k = tab[i].stream_id;
+    if (k == id) return (int)i;
+    if (k == 0) return -1;
+  }
+  return -1;
+}
+
+// the caller keeps the table at most half full, so a free slot always exists
+__device__ int tab_insert(grdma_h2_stream_dev* tab, uint32_t mask, uint32_t id) {
+  uint32_t i = tab_home(id, mask);
+  while (tab[i].stream_id != 0) i = (i + 1) & mask;
+  grdma_h2_stream_dev e;
+  e.stream_id = id; e.state = 0; e.frame_size = 0;
+  e.compressed = e.read_closed = e.write_closed = e.hdr_frames = 0;
+  tab[i] = e;
+  return (int)i;
+}
+
+// backward-shift deletion: entries behind the hole move up while that keeps them
+// reachable from their home slot
+__device__ void tab_remove(grdma_h2_stream_dev* tab, uint32_t mask, uint32_t i) {
+  uint32_t j = i;
+  for (;;) {
+    j = (j + 1) & mask;
+    const grdma_h2_stream_dev e = tab[j];
+    if (e.stream_id == 0) break;
+    const uint32_t k = tab_home(e.stream_id, mask);
+    // keep e where it is if its home k lies cyclically in (i, j]
+    const bool stays = (i <= j) ? (i < k && k <= j) : (i < k || k <= j);
+    if (stays) continue;
+    tab[i] = e;
+    i = j;
+  }
+  tab[i].stream_id = 0;
 }
 
 // Register cache of slices [cbase, cbase + 64): lane i holds the descriptor and the first
@@ -358,42 +404,61 @@ __device__ __forceinline__ void h2_push(grdma_h2_event* ev, uint64_t ev_cap, uin
   nev++;
 }
 
-// the data parser of the current stream (grpc_chttp2_data_parser), cached in registers
+// the map entry of the current stream, cached in (wave-uniform) registers
 struct h2_cur_stream {
   int idx;
   uint32_t id, fsz;
   int32_t state, comp;
+  uint32_t read_closed, write_closed, hdr_frames;
 };
 
-__device__ __forceinline__ void h2_flush_stream(grdma_h2_parser_dev* P, const h2_cur_stream& D, int lane) {
+__device__ __forceinline__ void h2_flush_stream(grdma_h2_stream_dev* tab, const h2_cur_stream& D, int lane) {
   if (D.idx >= 0 && lane == 0) {
-    P->streams[D.idx].state = D.state;
-    P->streams[D.idx].frame_size = D.fsz;
-    P->streams[D.idx].compressed = D.comp;
+    grdma_h2_stream_dev e;
+    e.stream_id = D.id; e.state = D.state; e.frame_size = D.fsz;
+    e.compressed = (uint8_t)D.comp; e.read_closed = (uint8_t)D.read_closed;
+    e.write_closed = (uint8_t)D.write_closed; e.hdr_frames = (uint8_t)D.hdr_frames;
+    tab[D.idx] = e;
   }
-  __syncthreads();
 }
 
-// false: unknown stream and no room in the table / stream id 0
-__device__ __forceinline__ bool h2_select_stream(grdma_h2_parser_dev* P, h2_cur_stream& D, uint32_t id,
-                                                 int* s_idx, int lane) {
+// lookup (never creates): false = not in the map
+__device__ __forceinline__ bool h2_select_stream(grdma_h2_stream_dev* tab, uint32_t mask, h2_cur_stream& D,
+                                                 uint32_t id, int lane) {
   if (D.idx >= 0 && D.id == id) return true;
-  h2_flush_stream(P, D, lane);
+  h2_flush_stream(tab, D, lane);
   D.idx = -1;
-  if (lane == 0) {
-    grdma_h2_stream_dev* d = find_stream(P, id);
-    *s_idx = d ? (int)(d - P->streams) : -1;
-  }
-  __syncthreads();
-  const int idx = *s_idx;
-  __syncthreads();
+  int idx = -1;
+  if (lane == 0) idx = tab_find(tab, mask, id);
+  idx = __builtin_amdgcn_readfirstlane(idx);
   if (idx < 0) return false;
+  const grdma_h2_stream_dev e = tab[idx];  // (uniform address: one load, broadcast)
   D.idx = idx;
   D.id = id;
-  D.state = P->streams[idx].state;
-  D.fsz = P->streams[idx].frame_size;
-  D.comp = P->streams[idx].compressed;
+  D.state = e.state;
+  D.fsz = e.frame_size;
+  D.comp = e.compressed;
+  D.read_closed = e.read_closed;
+  D.write_closed = e.write_closed;
+  D.hdr_frames = e.hdr_frames;
   return true;
+}
+
+// grpc_chttp2_mark_stream_closed(t, s, close_reads, close_writes), chttp2_transport.cc:2194-2244:
+// the stream leaves the map once both sides are closed.  Returns 1 if it left.
+__device__ __forceinline__ uint32_t h2_mark_closed(grdma_h2_stream_dev* tab, uint32_t mask, h2_cur_stream& D,
+                                                   uint32_t& live, bool close_writes, int lane) {
+  // D is the stream being closed
+  D.read_closed = 1;
+  if (close_writes) D.write_closed = 1;
+  const uint32_t gone = D.write_closed ? 1u : 0u;
+  h2_flush_stream(tab, D, lane);
+  if (gone) {
+    if (lane == 0) tab_remove(tab, mask, (uint32_t)D.idx);
+    live--;
+    D.idx = -1;  // entries may have moved
+  }
+  return gone;
 }
 
 __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, const uint8_t* arena,
@@ -401,26 +466,49 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
                                                    grdma_h2_event* ev, uint64_t ev_cap,
                                                    grdma_h2_deframe_result* res) {
   const int lane = threadIdx.x;
-  __shared__ grdma_h2_parser_dev P;
-  __shared__ int s_idx;
-  static_assert(sizeof(grdma_h2_parser_dev) % 4 == 0, "word copy");
-  for (unsigned i = lane; i < sizeof(grdma_h2_parser_dev) / 4; i += 64)
-    reinterpret_cast<uint32_t*>(&P)[i] = reinterpret_cast<const uint32_t*>(gp)[i];
-  __syncthreads();
+  const grdma_h2_parser_dev P = *gp;  // uniform loads: the whole block sits in scalar registers
   uint64_t nev = 0, overflow = 0;
   static const char kPrefix[] = "PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n";  // internal.h:781
 
-  // The automaton state lives in (wave-uniform) registers for the whole call; the copy in
-  // LDS is only the stream table, touched when a frame changes the current stream.
+  // The automaton state lives in (wave-uniform) registers for the whole call.
   int32_t st = P.state;
   uint32_t fsz = P.incoming_frame_size, ftype = P.incoming_frame_type;
   uint32_t fflags = P.incoming_frame_flags, sid = P.incoming_stream_id;
   int32_t cur_parser = P.cur_parser;
-  const uint32_t max_frame = P.max_frame_size;
-  h2_cur_stream D = {-1, 0, 0, 0, 0};
+  int32_t is_first_frame = P.is_first_frame;
+  uint32_t expect_cont = P.expect_continuation, header_eof = P.header_eof, header_boundary = P.header_boundary;
+  uint32_t received_last = P.received_last_frame, last_new = P.last_new_stream_id, live = P.live_streams;
+  const uint32_t max_frame = P.max_frame_size, mask = P.tab_mask, max_conc = P.max_concurrent;
+  const bool is_server = P.is_server != 0;
+  grdma_h2_stream_dev* const tab = P.tab;
+  h2_cur_stream D = {-1, 0, 0, 0, 0, 0, 0, 0};
   h2_slice_cache C = {~0ull, 0, 0, 0, 0, 0, 0};
 #define H2_PUSH(kind, a, b, c, d, sl) h2_push(ev, ev_cap, nev, overflow, lane, kind, a, b, c, d, sl)
 #define H2_BYTE(s_, off_) h2_byte_at(C, s_, off_, arena, slices, nslices, lane)
+  // what the payload parser does with the last piece of a frame (frame_data.cc:299-305,
+  // hpack_parser.cc:1746-1782, frame_rst_stream.cc:99-119)
+#define H2_END_FRAME(sl)                                                                          \
+  do {                                                                                            \
+    if (cur_parser == PARSER_DATA) {                                                              \
+      if (received_last && h2_select_stream(tab, mask, D, sid, lane)) {                           \
+        const uint32_t gone = h2_mark_closed(tab, mask, D, live, false, lane);                    \
+        H2_PUSH(EV_STREAM_CLOSED, gone, 0, sid, 0, (uint32_t)(sl));                               \
+      }                                                                                           \
+    } else if (cur_parser == PARSER_HEADER) {                                                     \
+      if (header_boundary && h2_select_stream(tab, mask, D, sid, lane)) {                         \
+        D.hdr_frames++;                                                                           \
+        if (header_eof) {                                                                         \
+          const uint32_t gone = h2_mark_closed(tab, mask, D, live, false, lane);                  \
+          H2_PUSH(EV_STREAM_CLOSED, gone, 0, sid, 0, (uint32_t)(sl));                             \
+        }                                                                                         \
+      }                                                                                           \
+    } else if (cur_parser == PARSER_RST) {                                                        \
+      if (h2_select_stream(tab, mask, D, sid, lane)) {                                            \
+        const uint32_t gone = h2_mark_closed(tab, mask, D, live, true, lane);                     \
+        H2_PUSH(EV_STREAM_CLOSED, gone, 0, sid, 0, (uint32_t)(sl));                               \
+      }                                                                                           \
+    }                                                                                             \
+  } while (0)
 
   uint64_t s = 0;
   int err = P.error;
@@ -463,18 +551,62 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
         cur++;
         if (st < 32) { st++; continue; }
         }
-        // FH_8 done: init_frame_parser (parsing.cc:255-308), DATA branch :340-397
+        // FH_8 done: init_frame_parser (parsing.cc:255-306)
         uint32_t status = 0;
-        cur_parser = 0;
-        if (ftype == 0) {
-          if (h2_select_stream(&P, D, sid, &s_idx, lane)) {
-            if (fflags & ~1u) status = 3;  // frame_data.cc:47-52
-            else cur_parser = 1;
+        bool opened = false, hdr_frame = false, is_cont = false;
+        cur_parser = PARSER_SKIP;
+        if (is_first_frame && ftype != FT_SETTINGS) { err = 8; break; }  // :256-263
+        is_first_frame = 0;
+        if (expect_cont != 0) {                                          // :265-283
+          if (ftype != FT_CONTINUATION) { err = 5; break; }
+          if (expect_cont != sid) { err = 6; break; }
+          hdr_frame = is_cont = true;
+        } else if (ftype == FT_DATA) {
+          // init_data_frame_parser (:341-397) + grpc_chttp2_data_parser_begin_frame (frame_data.cc:43-62)
+          if (h2_select_stream(tab, mask, D, sid, lane) && !D.read_closed) {
+            if (fflags & ~1u) status = 3;  // frame_data.cc:47-52: stream error
+            else {
+              received_last = fflags & 1u;
+              cur_parser = PARSER_DATA;
+            }
           }
+        } else if (ftype == FT_HEADERS) {
+          hdr_frame = true;
+        } else if (ftype == FT_CONTINUATION) {
+          err = 7;                                                       // :287-289
+          break;
+        } else if (ftype == FT_RST_STREAM) {
+          if (fsz != 4) { err = 10; break; }                             // frame_rst_stream.cc:73-79
+          if (h2_select_stream(tab, mask, D, sid, lane)) cur_parser = PARSER_RST;
+        }  // SETTINGS, WINDOW_UPDATE, PING, GOAWAY: control plane, payload skipped
+        if (hdr_frame) {
+          // init_header_frame_parser (parsing.cc:566-680): stream lookup / acceptance; the
+          // HPACK bytes themselves are control plane and are skipped
+          header_boundary = (fflags & 4u) ? 1u : 0u;
+          expect_cont = header_boundary ? 0u : sid;
+          if (!is_cont) header_eof = fflags & 1u;
+          bool have = h2_select_stream(tab, mask, D, sid, lane);
+          if (!have && !is_cont && is_server && last_new < sid && (sid & 1u)) {
+            if (live >= max_conc || 2 * (live + 1) > mask + 1) { err = 9; break; }  // :623-627
+            last_new = sid;                                              // :629-631 accept_stream
+            h2_flush_stream(tab, D, lane);
+            D.idx = -1;
+            if (lane == 0) tab_insert(tab, mask, sid);
+            live++;
+            opened = true;
+            have = h2_select_stream(tab, mask, D, sid, lane);
+          }
+          if (have && !D.read_closed && D.hdr_frames < 2) cur_parser = PARSER_HEADER;
         }
         H2_PUSH(EV_FRAME, ftype, fflags | (status << 8), sid, fsz, (uint32_t)s);
+        if (opened) H2_PUSH(EV_STREAM_OPEN, 0, 0, sid, 0, (uint32_t)s);
+        if (status == 3) {  // parsing.cc:388-391: the stream is closed for reads
+          const uint32_t gone = h2_mark_closed(tab, mask, D, live, false, lane);
+          H2_PUSH(EV_STREAM_CLOSED, gone, 0, sid, 0, (uint32_t)s);
+        }
         if (fsz == 0) {
           H2_PUSH(EV_PAYLOAD, (uint32_t)cur, 0, 1, 0, (uint32_t)s);
+          H2_END_FRAME(s);
           st = ST_FH0;
         } else if (fsz > max_frame) {
           err = 2;  // parsing.cc:195-205
@@ -488,7 +620,7 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
       const uint64_t take = avail < fsz ? avail : fsz;
       const uint32_t is_last = take == fsz;
       H2_PUSH(EV_PAYLOAD, (uint32_t)cur, (uint32_t)take, is_last, 0, (uint32_t)s);
-      if (cur_parser == 1 && h2_select_stream(&P, D, sid, &s_idx, lane)) {
+      if (cur_parser == PARSER_DATA && h2_select_stream(tab, mask, D, sid, lane)) {
         // grpc_deframe_unprocessed_incoming_frames, frame_data.cc:92-276
         uint64_t q = cur;
         const uint64_t end = cur + take;
@@ -547,39 +679,118 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
       }
       fsz -= (uint32_t)take;
       cur += take;
-      if (is_last) st = ST_FH0;
+      if (is_last) {
+        H2_END_FRAME(s);
+        st = ST_FH0;
+      }
     }
     if (err || overflow) break;
   }
 #undef H2_PUSH
 #undef H2_BYTE
-  h2_flush_stream(&P, D, lane);
+#undef H2_END_FRAME
+  h2_flush_stream(tab, D, lane);
   if (lane == 0) {
-    P.state = st;
-    P.incoming_frame_size = fsz;
-    P.incoming_frame_type = ftype;
-    P.incoming_frame_flags = fflags;
-    P.incoming_stream_id = sid;
-    P.cur_parser = cur_parser;
-    P.error = err;
+    gp->state = st;
+    gp->incoming_frame_size = fsz;
+    gp->incoming_frame_type = ftype;
+    gp->incoming_frame_flags = fflags;
+    gp->incoming_stream_id = sid;
+    gp->cur_parser = cur_parser;
+    gp->is_first_frame = is_first_frame;
+    gp->expect_continuation = expect_cont;
+    gp->header_eof = header_eof;
+    gp->header_boundary = header_boundary;
+    gp->received_last_frame = received_last;
+    gp->last_new_stream_id = last_new;
+    gp->live_streams = live;
+    gp->error = err;
     res->nevents = nev;
     res->overflow = overflow;
     res->slices_done = s;
     res->error = err;
   }
-  __syncthreads();
-  for (unsigned i = lane; i < sizeof(grdma_h2_parser_dev) / 4; i += 64)
-    reinterpret_cast<uint32_t*>(gp)[i] = reinterpret_cast<const uint32_t*>(&P)[i];
+}
+
+// What the surface does to the stream map outside the read path, batched: op 1 = a client starts
+// a call on stream id (grpc_chttp2_stream_map_add), op 2 = the write side of a stream closes
+// (grpc_chttp2_mark_stream_closed(close_writes)); a stream already read-closed then leaves the map.
+struct grdma_h2_table_op { uint32_t op, id; int32_t rc, pad; };
+__global__ void k_h2_table_ops(grdma_h2_parser_dev* gp, grdma_h2_table_op* ops, uint32_t n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  grdma_h2_stream_dev* tab = gp->tab;
+  const uint32_t mask = gp->tab_mask;
+  uint32_t live = gp->live_streams;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t id = ops[i].id;
+    int rc = -1;
+    const int idx = tab_find(tab, mask, id);
+    if (ops[i].op == 1) {
+      if (id != 0 && idx < 0 && 2 * (live + 1) <= mask + 1) {
+        tab_insert(tab, mask, id);
+        live++;
+        rc = 0;
+      }
+    } else if (ops[i].op == 2) {
+      if (idx >= 0) {
+        tab[idx].write_closed = 1;
+        if (tab[idx].read_closed) {
+          tab_remove(tab, mask, (uint32_t)idx);
+          live--;
+        }
+        rc = 0;
+      }
+    }
+    ops[i].rc = rc;
+  }
+  gp->live_streams = live;
 }
 
 }  // namespace
 
 // --------------------------------------------------------------------- host API
+// Everything here runs on one non-blocking stream of its own and waits with
+// hipStreamSynchronize: a device-wide synchronize would sit behind the resident latency
+// engine until that idles out.  Scratch buffers and events are kept per parser / per process.
 struct grdma_h2_parser {
   grdma_h2_parser_dev* d = nullptr;
+  grdma_h2_stream_dev* d_tab = nullptr;
+  grdma_slice_out* d_sl = nullptr;
+  uint64_t sl_cap = 0;
+  grdma_h2_event* d_ev = nullptr;
+  uint64_t ev_cap = 0;
+  grdma_h2_deframe_result* d_res = nullptr;
+  grdma_h2_table_op* d_ops = nullptr;
+  uint32_t ops_cap = 0;
 };
 
 static double g_h2_last_kernel_us = 0;
+
+namespace {
+struct h2_host_ctx {
+  hipStream_t stream = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+h2_host_ctx* h2_ctx() {
+  static h2_host_ctx c;
+  if (!c.stream) {
+    if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreate(&c.e0) != hipSuccess || hipEventCreate(&c.e1) != hipSuccess) return nullptr;
+  }
+  return &c;
+}
+template <typename T>
+bool h2_grow(T** buf, uint64_t* cap, uint64_t need) {
+  if (need <= *cap && *buf) return true;
+  if (*buf) hipFree(*buf);
+  *buf = nullptr;
+  uint64_t n = *cap ? *cap : 64;
+  while (n < need) n *= 2;
+  if (hipMalloc((void**)buf, sizeof(T) * n) != hipSuccess) { *cap = 0; return false; }
+  *cap = n;
+  return true;
+}
+}  // namespace
 
 extern "C" {
 
@@ -593,6 +804,8 @@ int64_t grdma_h2_frame_messages(const grdma_h2_msg* msgs, uint64_t n, uint32_t m
   if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
   if (!msgs || !n || !d_slices_out || !d_hdr_arena || max_frame == 0 || max_frame >= (1u << 24))
     return -GRDMA_ERR_INVALID;
+  h2_host_ctx* hc = h2_ctx();
+  if (!hc) return -GRDMA_ERR_HIP;
   std::vector<grdma_h2_msg_dev> tmp(n);
   for (uint64_t i = 0; i < n; i++) {
     tmp[i].payload = static_cast<const uint8_t*>(msgs[i].payload);
@@ -601,101 +814,146 @@ int64_t grdma_h2_frame_messages(const grdma_h2_msg* msgs, uint64_t n, uint32_t m
     tmp[i].flags = msgs[i].flags;
     if (msgs[i].len >= (1ull << 32)) return -GRDMA_ERR_INVALID;  // 32-bit message length field
   }
-  grdma_h2_msg_dev* d_msgs = nullptr;
-  grdma_h2_frame_result* d_res = nullptr;
+  static grdma_h2_msg_dev* d_msgs = nullptr;
+  static uint64_t msgs_cap = 0;
+  static grdma_h2_frame_result* d_res = nullptr;
   grdma_h2_frame_result h_res;
-  int64_t rc = -GRDMA_ERR_HIP;
-  if (hipMalloc((void**)&d_msgs, sizeof(grdma_h2_msg_dev) * n) == hipSuccess &&
-      hipMalloc((void**)&d_res, sizeof(grdma_h2_frame_result)) == hipSuccess &&
-      hipMemcpy(d_msgs, tmp.data(), sizeof(grdma_h2_msg_dev) * n, hipMemcpyHostToDevice) == hipSuccess &&
-      hipMemset(d_res, 0, sizeof(grdma_h2_frame_result)) == hipSuccess) {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_h2_frame, dim3(1), dim3(256), 0, 0, d_msgs, n, max_frame,
-                       reinterpret_cast<grdma_sge*>(d_slices_out), slices_cap,
-                       static_cast<uint8_t*>(d_hdr_arena), hdr_cap, (uint64_t*)nullptr, d_res);
-    hipEventRecord(e1, 0);
-    const bool synced = hipDeviceSynchronize() == hipSuccess;
-    float ms = 0;
-    if (synced && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) g_h2_last_kernel_us = 1e3 * ms;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    if (synced &&
-        hipMemcpy(&h_res, d_res, sizeof(h_res), hipMemcpyDeviceToHost) == hipSuccess) {
-      if (h_res.overflow) rc = -GRDMA_ERR_CAPACITY;
-      else {
-        rc = (int64_t)h_res.nslices;
-        if (wire_bytes) *wire_bytes = h_res.wire_bytes;
-      }
-    }
-  }
-  hipFree(d_msgs);
-  hipFree(d_res);
-  return rc;
+  if (!h2_grow(&d_msgs, &msgs_cap, n)) return -GRDMA_ERR_HIP;
+  if (!d_res && hipMalloc((void**)&d_res, sizeof(grdma_h2_frame_result)) != hipSuccess) return -GRDMA_ERR_HIP;
+  hipStream_t st = hc->stream;
+  if (hipMemcpyAsync(d_msgs, tmp.data(), sizeof(grdma_h2_msg_dev) * n, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemsetAsync(d_res, 0, sizeof(grdma_h2_frame_result), st) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  hipEventRecord(hc->e0, st);
+  hipLaunchKernelGGL(k_h2_frame, dim3(1), dim3(256), 0, st, d_msgs, n, max_frame,
+                     reinterpret_cast<grdma_sge*>(d_slices_out), slices_cap,
+                     static_cast<uint8_t*>(d_hdr_arena), hdr_cap, (uint64_t*)nullptr, d_res);
+  hipEventRecord(hc->e1, st);
+  if (hipMemcpyAsync(&h_res, d_res, sizeof(h_res), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, hc->e0, hc->e1) == hipSuccess) g_h2_last_kernel_us = 1e3 * ms;
+  if (h_res.overflow) return -GRDMA_ERR_CAPACITY;
+  if (wire_bytes) *wire_bytes = h_res.wire_bytes;
+  return (int64_t)h_res.nslices;
 }
 
-grdma_h2_parser* grdma_h2_parser_create(int expect_client_prefix, uint32_t max_frame_size) {
+grdma_h2_parser* grdma_h2_parser_create_ex(int flags, uint32_t max_frame_size,
+                                           uint32_t max_concurrent_streams, uint32_t table_slots) {
   if (grdma_device_count() <= 0) return nullptr;
+  if (table_slots == 0) table_slots = 4096;
+  if (table_slots < 16 || (table_slots & (table_slots - 1)) != 0) return nullptr;
   grdma_h2_parser* p = new grdma_h2_parser();
   grdma_h2_parser_dev init;
   memset(&init, 0, sizeof(init));
-  init.state = expect_client_prefix ? 0 : 24;
-  init.max_frame_size = max_frame_size;  // http2_settings.cc:56 default 16384
+  init.is_server = (flags & GRDMA_H2_SERVER) ? 1 : 0;
+  init.is_first_frame = (flags & GRDMA_H2_FIRST_FRAME) ? 1 : 0;  // chttp2_transport.cc: t->is_first_frame
+  init.state = init.is_server ? 0 : 24;        // a server starts at GRPC_DTS_CLIENT_PREFIX_0
+  init.max_frame_size = max_frame_size;        // http2_settings.cc:56 default 16384
+  init.max_concurrent = max_concurrent_streams;  // http2_settings.cc:46 default 0xffffffff
+  init.tab_mask = table_slots - 1;
   if (hipMalloc((void**)&p->d, sizeof(init)) != hipSuccess ||
-      hipMemcpy(p->d, &init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) {
-    delete p;
+      hipMalloc((void**)&p->d_tab, sizeof(grdma_h2_stream_dev) * table_slots) != hipSuccess ||
+      hipMalloc((void**)&p->d_res, sizeof(grdma_h2_deframe_result)) != hipSuccess ||
+      hipMemset(p->d_tab, 0, sizeof(grdma_h2_stream_dev) * table_slots) != hipSuccess) {
+    grdma_h2_parser_destroy(p);
+    return nullptr;
+  }
+  init.tab = p->d_tab;
+  if (hipMemcpy(p->d, &init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) {
+    grdma_h2_parser_destroy(p);
     return nullptr;
   }
   return p;
 }
 
+grdma_h2_parser* grdma_h2_parser_create(int expect_client_prefix, uint32_t max_frame_size) {
+  return grdma_h2_parser_create_ex(expect_client_prefix ? (GRDMA_H2_SERVER | GRDMA_H2_FIRST_FRAME) : 0,
+                                   max_frame_size, 0xffffffffu, 0);
+}
+
 void grdma_h2_parser_destroy(grdma_h2_parser* p) {
   if (!p) return;
   hipFree(p->d);
+  hipFree(p->d_tab);
+  hipFree(p->d_sl);
+  hipFree(p->d_ev);
+  hipFree(p->d_res);
+  hipFree(p->d_ops);
   delete p;
+}
+
+static int h2_table_ops(grdma_h2_parser* p, uint32_t op, const uint32_t* ids, uint32_t n) {
+  if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
+  if (!p || (!ids && n)) return -GRDMA_ERR_INVALID;
+  if (n == 0) return 0;
+  h2_host_ctx* hc = h2_ctx();
+  if (!hc) return -GRDMA_ERR_HIP;
+  uint64_t cap = p->ops_cap;
+  if (!h2_grow(&p->d_ops, &cap, n)) return -GRDMA_ERR_HIP;
+  p->ops_cap = (uint32_t)cap;
+  std::vector<grdma_h2_table_op> h(n);
+  for (uint32_t i = 0; i < n; i++) h[i] = {op, ids[i], 0, 0};
+  hipStream_t st = hc->stream;
+  if (hipMemcpyAsync(p->d_ops, h.data(), sizeof(grdma_h2_table_op) * n, hipMemcpyHostToDevice, st) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  hipLaunchKernelGGL(k_h2_table_ops, dim3(1), dim3(1), 0, st, p->d, p->d_ops, n);
+  if (hipMemcpyAsync(h.data(), p->d_ops, sizeof(grdma_h2_table_op) * n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  int failed = 0;
+  for (uint32_t i = 0; i < n; i++) failed += h[i].rc != 0;
+  return failed;
+}
+
+int grdma_h2_parser_open_streams(grdma_h2_parser* p, const uint32_t* ids, uint32_t n) {
+  return h2_table_ops(p, 1, ids, n);
+}
+int grdma_h2_parser_close_writes(grdma_h2_parser* p, const uint32_t* ids, uint32_t n) {
+  return h2_table_ops(p, 2, ids, n);
+}
+int64_t grdma_h2_parser_live_streams(grdma_h2_parser* p) {
+  if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
+  if (!p) return -GRDMA_ERR_INVALID;
+  h2_host_ctx* hc = h2_ctx();
+  if (!hc) return -GRDMA_ERR_HIP;
+  grdma_h2_parser_dev h;
+  if (hipMemcpyAsync(&h, p->d, sizeof(h), hipMemcpyDeviceToHost, hc->stream) != hipSuccess ||
+      hipStreamSynchronize(hc->stream) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  return (int64_t)h.live_streams;
 }
 
 int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_read_slice* slices,
                          uint64_t n, grdma_h2_event* events_out, uint64_t cap, int* h2_error) {
   if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
   if (!p || !d_arena || (!slices && n) || !events_out) return -GRDMA_ERR_INVALID;
-  grdma_slice_out* d_sl = nullptr;
-  grdma_h2_event* d_ev = nullptr;
-  grdma_h2_deframe_result* d_res = nullptr;
+  h2_host_ctx* hc = h2_ctx();
+  if (!hc) return -GRDMA_ERR_HIP;
   grdma_h2_deframe_result h_res;
   memset(&h_res, 0, sizeof(h_res));
-  int64_t rc = -GRDMA_ERR_HIP;
   static_assert(sizeof(grdma_read_slice) == sizeof(grdma_slice_out), "layout");
-  if (hipMalloc((void**)&d_sl, sizeof(grdma_slice_out) * (n ? n : 1)) == hipSuccess &&
-      hipMalloc((void**)&d_ev, sizeof(grdma_h2_event) * (cap ? cap : 1)) == hipSuccess &&
-      hipMalloc((void**)&d_res, sizeof(h_res)) == hipSuccess &&
-      (n == 0 || hipMemcpy(d_sl, slices, sizeof(grdma_slice_out) * n, hipMemcpyHostToDevice) == hipSuccess)) {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(64), 0, 0, p->d,
-                       static_cast<const uint8_t*>(d_arena), d_sl, n, d_ev, cap, d_res);
-    hipEventRecord(e1, 0);
-    const bool synced = hipDeviceSynchronize() == hipSuccess;
-    float ms = 0;
-    if (synced && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) g_h2_last_kernel_us = 1e3 * ms;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    if (synced &&
-        hipMemcpy(&h_res, d_res, sizeof(h_res), hipMemcpyDeviceToHost) == hipSuccess) {
-      const uint64_t m = h_res.nevents < cap ? h_res.nevents : cap;
-      if (m == 0 || hipMemcpy(events_out, d_ev, sizeof(grdma_h2_event) * m, hipMemcpyDeviceToHost) == hipSuccess)
-        rc = h_res.overflow ? -GRDMA_ERR_CAPACITY : (int64_t)m;
-      if (h2_error) *h2_error = (int)h_res.error;
-    }
-  }
-  hipFree(d_sl);
-  hipFree(d_ev);
-  hipFree(d_res);
-  return rc;
+  if (!h2_grow(&p->d_sl, &p->sl_cap, n ? n : 1) || !h2_grow(&p->d_ev, &p->ev_cap, cap ? cap : 1))
+    return -GRDMA_ERR_HIP;
+  hipStream_t st = hc->stream;
+  if (n && hipMemcpyAsync(p->d_sl, slices, sizeof(grdma_slice_out) * n, hipMemcpyHostToDevice, st) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  hipEventRecord(hc->e0, st);
+  hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(64), 0, st, p->d, static_cast<const uint8_t*>(d_arena),
+                     p->d_sl, n, p->d_ev, cap, p->d_res);
+  hipEventRecord(hc->e1, st);
+  if (hipMemcpyAsync(&h_res, p->d_res, sizeof(h_res), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, hc->e0, hc->e1) == hipSuccess) g_h2_last_kernel_us = 1e3 * ms;
+  const uint64_t m = h_res.nevents < cap ? h_res.nevents : cap;
+  if (m && (hipMemcpyAsync(events_out, p->d_ev, sizeof(grdma_h2_event) * m, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess))
+    return -GRDMA_ERR_HIP;
+  if (h2_error) *h2_error = (int)h_res.error;
+  return h_res.overflow ? -GRDMA_ERR_CAPACITY : (int64_t)m;
 }
 
 }  // extern "C"

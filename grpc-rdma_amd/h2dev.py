@@ -28,6 +28,13 @@ def _bind():
         lib.grdma_h2_parser_create.restype = C.c_void_p
         lib.grdma_h2_parser_create.argtypes = [C.c_int, C.c_uint32]
         lib.grdma_h2_parser_destroy.argtypes = [C.c_void_p]
+        lib.grdma_h2_parser_create_ex.restype = C.c_void_p
+        lib.grdma_h2_parser_create_ex.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]
+        for fn in (lib.grdma_h2_parser_open_streams, lib.grdma_h2_parser_close_writes):
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+        lib.grdma_h2_parser_live_streams.restype = C.c_int64
+        lib.grdma_h2_parser_live_streams.argtypes = [C.c_void_p]
         lib.grdma_h2_deframe.restype = C.c_int64
         lib.grdma_h2_deframe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ReadSlice), u64,
                                          C.POINTER(H2Event), u64, C.POINTER(C.c_int)]
@@ -47,12 +54,37 @@ def frame_messages(msgs, max_frame, slices_dev_ptr, slices_cap, hdr_dev_ptr, hdr
     return n, wire.value
 
 
+H2_SERVER, H2_FIRST_FRAME = 1, 2
+
+
 class Parser:
-    def __init__(self, expect_client_prefix=False, max_frame_size=16384):
+    """Deframe state + stream map of one transport in device memory (grdma_h2_parser).
+    expect_client_prefix=True: a fresh server connection (streams accepted from HEADERS);
+    False: a client / mid-connection parser whose streams the caller opens."""
+
+    def __init__(self, expect_client_prefix=False, max_frame_size=16384, flags=None,
+                 max_concurrent_streams=0xFFFFFFFF, table_slots=0):
         self.lib = _bind()
-        self.h = self.lib.grdma_h2_parser_create(int(expect_client_prefix), max_frame_size)
+        if flags is None:
+            flags = (H2_SERVER | H2_FIRST_FRAME) if expect_client_prefix else 0
+        self.h = self.lib.grdma_h2_parser_create_ex(flags, max_frame_size, max_concurrent_streams, table_slots)
         if not self.h:
             raise GrdmaError("h2 parser allocation failed")
+
+    def _ids(self, ids):
+        ids = list(ids)
+        return (C.c_uint32 * max(1, len(ids)))(*ids), len(ids)
+
+    def open_streams(self, ids):
+        arr, n = self._ids(ids)
+        return check(self.lib.grdma_h2_parser_open_streams(self.h, arr, n))
+
+    def close_writes(self, ids):
+        arr, n = self._ids(ids)
+        return check(self.lib.grdma_h2_parser_close_writes(self.h, arr, n))
+
+    def live_streams(self):
+        return check(self.lib.grdma_h2_parser_live_streams(self.h))
 
     def deframe(self, arena_dev_ptr, slices, cap=None):
         """slices: list of (offset, len) in the arena. -> (h2 error, events)"""

@@ -277,24 +277,60 @@ int64_t grdma_h2_frame_messages(const grdma_h2_msg* msgs, uint64_t n, uint32_t m
                                 void* d_hdr_arena, uint64_t hdr_cap, uint64_t* wire_bytes);
 
 typedef struct grdma_h2_event {   /* what the deframer saw, in order                  */
-  uint32_t kind;                  /* 1 FRAME 2 PAYLOAD 3 MSG_BEGIN 4 MSG_BYTES 5 MSG_END */
+  uint32_t kind;                  /* 1 FRAME 2 PAYLOAD 3 MSG_BEGIN 4 MSG_BYTES 5 MSG_END
+                                     6 STREAM_OPEN 7 STREAM_CLOSED                       */
   uint32_t a, b, c, d;            /* FRAME: type, flags|status<<8, stream, size         */
                                   /* PAYLOAD: offset in slice, length, is_last          */
                                   /* MSG_BEGIN: compressed, length, stream              */
                                   /* MSG_BYTES: offset in slice, length, stream         */
+                                  /* STREAM_OPEN: -, -, stream (accepted from HEADERS)  */
+                                  /* STREAM_CLOSED: 1 = left the map / 0 = reads closed, -, stream */
   uint32_t slice;                 /* index of the delivered slice                       */
 } grdma_h2_event;
-enum grdma_h2_error { GRDMA_H2_OK = 0, GRDMA_H2_ERR_PREFIX = 1, GRDMA_H2_ERR_FRAME_TOO_LARGE = 2 };
+/* connection errors of grpc_chttp2_perform_read (sticky; *h2_error of grdma_h2_deframe) */
+enum grdma_h2_error {
+  GRDMA_H2_OK = 0,
+  GRDMA_H2_ERR_PREFIX = 1,                 /* parsing.cc:91-104  connect string mismatch    */
+  GRDMA_H2_ERR_FRAME_TOO_LARGE = 2,        /* parsing.cc:195-205                            */
+  GRDMA_H2_ERR_EXPECTED_CONTINUATION = 5,  /* parsing.cc:266-272                            */
+  GRDMA_H2_ERR_CONTINUATION_STREAM = 6,    /* parsing.cc:273-281                            */
+  GRDMA_H2_ERR_UNEXPECTED_CONTINUATION = 7,/* parsing.cc:287-289                            */
+  GRDMA_H2_ERR_FIRST_FRAME = 8,            /* parsing.cc:256-263 first frame must be SETTINGS */
+  GRDMA_H2_ERR_MAX_STREAMS = 9,            /* parsing.cc:623-627 (or the stream table is half full) */
+  GRDMA_H2_ERR_RST_LENGTH = 10             /* frame_rst_stream.cc:73-79                     */
+};
+enum grdma_h2_parser_flags {
+  GRDMA_H2_SERVER = 1,       /* expects the client preface; accepts streams from HEADERS frames
+                                (init_header_frame_parser, parsing.cc:596-631)               */
+  GRDMA_H2_FIRST_FRAME = 2   /* fresh connection: the first frame must be SETTINGS           */
+};
 typedef struct grdma_h2_parser grdma_h2_parser;
-/* deframe state of one transport (grpc_chttp2_transport deframe_state & co.,
- * internal.h; per-stream grpc_chttp2_data_parser), kept in device memory */
+/* Deframe state of one transport (grpc_chttp2_transport deframe_state & co., internal.h) and
+ * its stream map (grpc_chttp2_stream_map) with each stream's grpc_chttp2_data_parser, kept in
+ * device memory.  DATA frames are looked up in the map and never create a stream
+ * (init_data_frame_parser, parsing.cc:352-374): unknown and read-closed streams are skipped.
+ * A server learns its streams from HEADERS frames; a client's streams are opened by the caller
+ * when it starts a call.  END_STREAM (on DATA, or on the header block) closes the read side;
+ * RST_STREAM closes both; a stream leaves the map once both sides are closed
+ * (grpc_chttp2_mark_stream_closed, chttp2_transport.cc:2194-2244) -- the caller reports the write
+ * side with grdma_h2_parser_close_writes.  HPACK, SETTINGS, PING, GOAWAY and WINDOW_UPDATE payloads
+ * are control plane and are skipped here.
+ * grdma_h2_parser_create(prefix, max) = create_ex(prefix ? SERVER | FIRST_FRAME : 0, max, 0xffffffff, 0).
+ * table_slots: power of two >= 16 (0 = 4096); at most table_slots / 2 streams are live at once. */
 grdma_h2_parser* grdma_h2_parser_create(int expect_client_prefix, uint32_t max_frame_size);
+grdma_h2_parser* grdma_h2_parser_create_ex(int flags, uint32_t max_frame_size,
+                                           uint32_t max_concurrent_streams, uint32_t table_slots);
 void grdma_h2_parser_destroy(grdma_h2_parser* p);
+/* Batched stream-map updates from the surface; return the number of ids that failed
+ * (duplicate / unknown / table full), or <0. */
+int grdma_h2_parser_open_streams(grdma_h2_parser* p, const uint32_t* ids, uint32_t n);
+int grdma_h2_parser_close_writes(grdma_h2_parser* p, const uint32_t* ids, uint32_t n);
+int64_t grdma_h2_parser_live_streams(grdma_h2_parser* p);
+/* Duration of the framing / deframing kernel of the last call (HIP events), microseconds. */
+double grdma_h2_last_kernel_us(void);
 /* grpc_chttp2_perform_read (parsing.cc:56-253) + grpc_deframe_unprocessed_incoming_frames
  * (frame_data.cc:92-276) over n delivered slices {offset, length} of d_arena.
  * Returns the number of events; *h2_error = connection error, if any. */
-/* Duration of the framing / deframing kernel of the last call (HIP events), microseconds. */
-double grdma_h2_last_kernel_us(void);
 int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_read_slice* slices,
                          uint64_t n, grdma_h2_event* events_out, uint64_t cap, int* h2_error);
 

@@ -450,23 +450,71 @@ int64_t orc_h2_frame_batch(const uint8_t* const* msgs, const uint64_t* msg_lens,
 
 static const char kClientPrefix[] = "PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n"; /* internal.h:781 */
 enum { ST_FH0 = 24, ST_FH8 = 32, ST_FRAME = 33 };
-enum { PARSER_SKIP = 0, PARSER_DATA = 1 };
+enum { PARSER_SKIP = 0, PARSER_DATA = 1, PARSER_HEADER = 2, PARSER_RST = 3 };
+enum { FT_DATA = 0, FT_HEADERS = 1, FT_RST_STREAM = 3, FT_SETTINGS = 4, FT_CONTINUATION = 9 };
+enum { FL_END_STREAM = 1, FL_END_HEADERS = 4 };
 
-void orc_h2_parser_init(orc_h2_parser* p, int expect_client_prefix, uint32_t max_frame_size) {
+void orc_h2_parser_init_ex(orc_h2_parser* p, int flags, uint32_t max_frame_size,
+                           uint32_t max_concurrent_streams) {
   memset(p, 0, sizeof(*p));
-  p->state = expect_client_prefix ? 0 : ST_FH0; /* chttp2_transport.cc: server starts at PREFIX_0 */
-  p->max_frame_size = max_frame_size;           /* http2_settings.cc:56 default 16384 */
+  p->is_server = (flags & ORC_H2_SERVER) != 0;
+  p->is_first_frame = (flags & ORC_H2_FIRST_FRAME) != 0; /* chttp2_transport.cc: t->is_first_frame = true */
+  p->state = p->is_server ? 0 : ST_FH0;   /* a server starts at GRPC_DTS_CLIENT_PREFIX_0 */
+  p->max_frame_size = max_frame_size;     /* http2_settings.cc:56 default 16384 */
   p->check_frame_size = 1;
+  p->max_concurrent_streams = max_concurrent_streams; /* http2_settings.cc:46 default 0xffffffff */
 }
 
-static orc_grpc_deframer* find_stream(orc_h2_parser* p, uint32_t id) {
-  for (int i = 0; i < p->nstreams; i++)
+void orc_h2_parser_init(orc_h2_parser* p, int expect_client_prefix, uint32_t max_frame_size) {
+  orc_h2_parser_init_ex(p, expect_client_prefix ? (ORC_H2_SERVER | ORC_H2_FIRST_FRAME) : 0,
+                        max_frame_size, 0xffffffffu);
+}
+
+void orc_h2_parser_free(orc_h2_parser* p) {
+  free(p->streams);
+  p->streams = NULL;
+  p->nstreams = p->streams_cap = 0;
+}
+
+uint64_t orc_h2_parser_live_streams(const orc_h2_parser* p) { return p->nstreams; }
+
+/* grpc_chttp2_parsing_lookup_stream (chttp2_transport.cc): plain map lookup, no creation */
+static orc_h2_stream* lookup_stream(orc_h2_parser* p, uint32_t id) {
+  if (id == 0) return NULL;
+  for (uint64_t i = 0; i < p->nstreams; i++)
     if (p->streams[i].stream_id == id) return &p->streams[i];
-  if (id == 0 || p->nstreams >= ORC_H2_MAX_STREAMS) return NULL;
-  orc_grpc_deframer* d = &p->streams[p->nstreams++];
-  memset(d, 0, sizeof(*d));
-  d->stream_id = id;
-  return d;
+  return NULL;
+}
+
+static orc_h2_stream* add_stream(orc_h2_parser* p, uint32_t id) {
+  if (p->nstreams == p->streams_cap) {
+    uint64_t nc = p->streams_cap ? 2 * p->streams_cap : 16;
+    orc_h2_stream* ns = (orc_h2_stream*)realloc(p->streams, nc * sizeof(orc_h2_stream));
+    if (!ns) return NULL;
+    p->streams = ns;
+    p->streams_cap = nc;
+  }
+  orc_h2_stream* s = &p->streams[p->nstreams++];
+  memset(s, 0, sizeof(*s));
+  s->stream_id = id;
+  return s;
+}
+
+static void remove_stream(orc_h2_parser* p, orc_h2_stream* s) {
+  *s = p->streams[--p->nstreams];
+}
+
+int orc_h2_parser_open_stream(orc_h2_parser* p, uint32_t id) {
+  if (id == 0 || lookup_stream(p, id)) return -1;
+  return add_stream(p, id) ? 0 : -1;
+}
+
+int orc_h2_parser_close_writes(orc_h2_parser* p, uint32_t id) {
+  orc_h2_stream* s = lookup_stream(p, id);
+  if (!s) return -1;
+  s->write_closed = 1;
+  if (s->read_closed) remove_stream(p, s); /* chttp2_transport.cc:2218-2223 */
+  return 0;
 }
 
 static int push_ev(orc_h2_event* ev, uint64_t cap, uint64_t* nev, uint32_t kind,
@@ -477,9 +525,21 @@ static int push_ev(orc_h2_event* ev, uint64_t cap, uint64_t* nev, uint32_t kind,
   return 0;
 }
 
+/* grpc_chttp2_mark_stream_closed(t, s, close_reads, close_writes), chttp2_transport.cc:2194-2244 */
+static int mark_closed(orc_h2_parser* p, uint32_t id, int close_reads, int close_writes,
+                       orc_h2_event* ev, uint64_t cap, uint64_t* nev) {
+  orc_h2_stream* s = lookup_stream(p, id);
+  if (!s) return 0;
+  if (close_reads) s->read_closed = 1;
+  if (close_writes) s->write_closed = 1;
+  int gone = s->read_closed && s->write_closed;
+  if (gone) remove_stream(p, s);
+  return push_ev(ev, cap, nev, ORC_EV_STREAM_CLOSED, (uint32_t)gone, 0, id, 0);
+}
+
 /* grpc_deframe_unprocessed_incoming_frames (frame_data.cc:92-276) applied to a
  * run of DATA payload bytes [beg, beg+len) of the chunk at `base`. */
-static int grpc_deframe(orc_grpc_deframer* d, const uint8_t* base, uint64_t beg,
+static int grpc_deframe(orc_h2_stream* d, const uint8_t* base, uint64_t beg,
                         uint64_t len, orc_h2_event* ev, uint64_t cap, uint64_t* nev) {
   uint64_t cur = beg, end = beg + len;
   int rc;
@@ -529,26 +589,90 @@ static int grpc_deframe(orc_grpc_deframer* d, const uint8_t* base, uint64_t beg,
   return 0;
 }
 
-static int begin_frame(orc_h2_parser* p, int* parser_kind, orc_h2_event* ev, uint64_t cap,
-                       uint64_t* nev) {
-  /* init_frame_parser (parsing.cc:255-308), DATA branch init_data_frame_parser
-   * (:340-397) + grpc_chttp2_data_parser_begin_frame (frame_data.cc:43-62). */
-  uint32_t status = 0;
+/* init_header_frame_parser (parsing.cc:566-680): which stream the header block belongs to,
+ * stream acceptance on a server.  The HPACK bytes themselves are control plane (skipped). */
+static int begin_header_frame(orc_h2_parser* p, int is_continuation, int* parser_kind,
+                              int* opened) {
+  const uint32_t id = p->incoming_stream_id;
+  p->header_boundary = (p->incoming_frame_flags & FL_END_HEADERS) != 0;
+  p->expect_continuation_stream_id = p->header_boundary ? 0 : id;          /* :574-578 */
+  if (!is_continuation) p->header_eof = (p->incoming_frame_flags & FL_END_STREAM) != 0; /* :580-583 */
   *parser_kind = PARSER_SKIP;
-  if (p->incoming_frame_type == ORC_H2_FRAME_DATA) {
-    orc_grpc_deframer* d = find_stream(p, p->incoming_stream_id);
-    if (d != NULL) {
-      if (p->incoming_frame_flags & ~ORC_H2_FLAG_END_STREAM) {
-        status = ORC_H2_ERR_DATA_FLAGS; /* stream error → skip parser */
+  orc_h2_stream* s = lookup_stream(p, id);
+  if (s == NULL) {
+    if (is_continuation) return 0;                      /* :590-595 */
+    if (!p->is_server) return 0;                        /* :596-608 */
+    if (p->last_new_stream_id >= id) return 0;          /* :609-616 */
+    if ((id & 1) == 0) return 0;                        /* :617-622 */
+    if (p->nstreams >= p->max_concurrent_streams) return ORC_H2_ERR_MAX_STREAMS; /* :623-627 */
+    p->last_new_stream_id = id;                         /* :629-631 grpc_chttp2_parsing_accept_stream */
+    s = add_stream(p, id);
+    if (s == NULL) return 0;
+    *opened = 1;
+  }
+  if (s->read_closed) return 0;                         /* :645-650 */
+  if (s->header_frames_received >= 2) return 0;         /* :673-675 too many header frames */
+  *parser_kind = PARSER_HEADER;
+  return 0;
+}
+
+static int begin_frame(orc_h2_parser* p, orc_h2_event* ev, uint64_t cap, uint64_t* nev) {
+  /* init_frame_parser (parsing.cc:255-306) */
+  uint32_t status = 0;
+  int kind = PARSER_SKIP, opened = 0, rc;
+  const uint32_t id = p->incoming_stream_id;
+  if (p->is_first_frame && p->incoming_frame_type != FT_SETTINGS) return ORC_H2_ERR_FIRST_FRAME;
+  p->is_first_frame = 0;
+  if (p->expect_continuation_stream_id != 0) {
+    if (p->incoming_frame_type != FT_CONTINUATION) return ORC_H2_ERR_EXPECTED_CONTINUATION;
+    if (p->expect_continuation_stream_id != id) return ORC_H2_ERR_CONTINUATION_STREAM;
+    if ((rc = begin_header_frame(p, 1, &kind, &opened))) return rc;
+  } else if (p->incoming_frame_type == FT_DATA) {
+    /* init_data_frame_parser (:341-397) + grpc_chttp2_data_parser_begin_frame (frame_data.cc:43-62) */
+    orc_h2_stream* s = lookup_stream(p, id);
+    if (s != NULL && !s->read_closed) {
+      if (p->incoming_frame_flags & ~FL_END_STREAM) {
+        status = ORC_H2_ERR_DATA_FLAGS; /* stream error: the stream is closed for reads, RST_STREAM queued */
       } else {
-        *parser_kind = PARSER_DATA;
+        p->received_last_frame = (p->incoming_frame_flags & FL_END_STREAM) != 0;
+        kind = PARSER_DATA;
       }
     }
+  } else if (p->incoming_frame_type == FT_HEADERS) {
+    if ((rc = begin_header_frame(p, 0, &kind, &opened))) return rc;
+  } else if (p->incoming_frame_type == FT_CONTINUATION) {
+    return ORC_H2_ERR_UNEXPECTED_CONTINUATION;
+  } else if (p->incoming_frame_type == FT_RST_STREAM) {
+    if (p->incoming_frame_size != 4) return ORC_H2_ERR_RST_LENGTH;
+    if (lookup_stream(p, id)) kind = PARSER_RST;
+  } /* SETTINGS, WINDOW_UPDATE, PING, GOAWAY: their payload parsers are control plane -> skipped */
+  p->cur_parser = kind; /* must survive across feeds */
+  if ((rc = push_ev(ev, cap, nev, ORC_EV_FRAME, p->incoming_frame_type,
+                    p->incoming_frame_flags | (status << 8), id, p->incoming_frame_size)))
+    return rc;
+  if (opened && (rc = push_ev(ev, cap, nev, ORC_EV_STREAM_OPEN, 0, 0, id, 0))) return rc;
+  if (status == ORC_H2_ERR_DATA_FLAGS) return mark_closed(p, id, 1, 0, ev, cap, nev); /* parsing.cc:388-391 */
+  return 0;
+}
+
+/* what the payload parser does when it is handed the last piece of a frame */
+static int end_frame(orc_h2_parser* p, orc_h2_event* ev, uint64_t cap, uint64_t* nev) {
+  const uint32_t id = p->incoming_stream_id;
+  if (p->cur_parser == PARSER_DATA) {
+    /* grpc_chttp2_data_parser_parse, frame_data.cc:299-305 */
+    if (p->received_last_frame) return mark_closed(p, id, 1, 0, ev, cap, nev);
+  } else if (p->cur_parser == PARSER_HEADER) {
+    /* grpc_chttp2_header_parser_parse, hpack_parser.cc:1746-1782 */
+    orc_h2_stream* s = lookup_stream(p, id);
+    if (s != NULL && p->header_boundary) {
+      s->header_frames_received++;
+      if (p->header_eof) return mark_closed(p, id, 1, 0, ev, cap, nev);
+    }
+  } else if (p->cur_parser == PARSER_RST) {
+    /* grpc_chttp2_rst_stream_parser_parse, frame_rst_stream.cc:99-119 */
+    return mark_closed(p, id, 1, 1, ev, cap, nev);
   }
-  int rc = push_ev(ev, cap, nev, ORC_EV_FRAME, p->incoming_frame_type,
-                   p->incoming_frame_flags | (status << 8), p->incoming_stream_id,
-                   p->incoming_frame_size);
-  return rc;
+  return 0;
 }
 
 int orc_h2_parser_feed(orc_h2_parser* p, const uint8_t* data, uint64_t len,
@@ -575,12 +699,11 @@ int orc_h2_parser_feed(orc_h2_parser* p, const uint8_t* data, uint64_t len,
       case 32: { /* FH_8 :177-214 */
         p->incoming_stream_id |= c;
         cur++;
-        int kind;
-        if ((rc = begin_frame(p, &kind, ev, cap, nev))) return rc;
-        p->cur_parser = kind; /* must survive across feeds */
+        if ((rc = begin_frame(p, ev, cap, nev))) return rc;
         if (p->incoming_frame_size == 0) {
           /* parse_frame_slice(empty, is_last=1) */
           if ((rc = push_ev(ev, cap, nev, ORC_EV_PAYLOAD, (uint32_t)cur, 0, 1, 0))) return rc;
+          if ((rc = end_frame(p, ev, cap, nev))) return rc;
           p->state = ST_FH0;
         } else if (p->check_frame_size && p->incoming_frame_size > p->max_frame_size) {
           return ORC_H2_ERR_FRAME_TOO_LARGE;
@@ -596,8 +719,8 @@ int orc_h2_parser_feed(orc_h2_parser* p, const uint8_t* data, uint64_t len,
         if ((rc = push_ev(ev, cap, nev, ORC_EV_PAYLOAD, (uint32_t)cur, (uint32_t)take,
                           (uint32_t)is_last, 0))) return rc;
         if (p->cur_parser == PARSER_DATA) {
-          orc_grpc_deframer* d = find_stream(p, p->incoming_stream_id);
-          rc = grpc_deframe(d, data, cur, take, ev, cap, nev);
+          orc_h2_stream* d = lookup_stream(p, p->incoming_stream_id);
+          rc = d ? grpc_deframe(d, data, cur, take, ev, cap, nev) : 0;
           if (rc == ORC_H2_ERR_GRPC_FRAME_TYPE) {
             /* stream error: reported, connection keeps parsing */
             int rc2 = push_ev(ev, cap, nev, ORC_EV_FRAME, 0xff, 0, p->incoming_stream_id,
@@ -609,7 +732,10 @@ int orc_h2_parser_feed(orc_h2_parser* p, const uint8_t* data, uint64_t len,
         }
         p->incoming_frame_size -= (uint32_t)take;
         cur += take;
-        if (is_last) p->state = ST_FH0;
+        if (is_last) {
+          if ((rc = end_frame(p, ev, cap, nev))) return rc;
+          p->state = ST_FH0;
+        }
         break;
       }
       default:

@@ -142,33 +142,46 @@ int64_t orc_h2_frame_batch(const uint8_t* const* msgs, const uint64_t* msg_lens,
 
 /* ------------------------------------------------------------ HTTP/2 RX -- */
 enum {
-  ORC_EV_FRAME = 1,     /* a = type, b = flags, c = stream id, d = frame size      */
+  ORC_EV_FRAME = 1,     /* a = type, b = flags | status << 8, c = stream id, d = frame size */
   ORC_EV_PAYLOAD = 2,   /* a = offset in the fed chunk, b = length, c = is_last    */
   ORC_EV_MSG_BEGIN = 3, /* a = compressed flag, b = message length, c = stream id  */
   ORC_EV_MSG_BYTES = 4, /* a = offset in the fed chunk, b = length, c = stream id  */
-  ORC_EV_MSG_END = 5    /* c = stream id                                            */
+  ORC_EV_MSG_END = 5,   /* c = stream id                                            */
+  ORC_EV_STREAM_OPEN = 6,   /* c = stream id: accepted from a HEADERS frame (server) */
+  ORC_EV_STREAM_CLOSED = 7  /* a = 1 if the stream left the map (read and write side closed),
+                               0 if only the read side closed; c = stream id */
 };
 enum {
   ORC_H2_OK = 0,
   ORC_H2_ERR_PREFIX = 1,        /* parsing.cc:91-104 connect string mismatch */
   ORC_H2_ERR_FRAME_TOO_LARGE = 2, /* parsing.cc:195-205 */
-  ORC_H2_ERR_DATA_FLAGS = 3,    /* frame_data.cc:47-52 */
-  ORC_H2_ERR_GRPC_FRAME_TYPE = 4, /* frame_data.cc:123-140 */
+  ORC_H2_ERR_DATA_FLAGS = 3,    /* frame_data.cc:47-52 (stream error, reported in EV_FRAME) */
+  ORC_H2_ERR_GRPC_FRAME_TYPE = 4, /* frame_data.cc:123-140 (stream error) */
+  ORC_H2_ERR_EXPECTED_CONTINUATION = 5, /* parsing.cc:266-272 */
+  ORC_H2_ERR_CONTINUATION_STREAM = 6,   /* parsing.cc:273-281 */
+  ORC_H2_ERR_UNEXPECTED_CONTINUATION = 7, /* parsing.cc:287-289 */
+  ORC_H2_ERR_FIRST_FRAME = 8,   /* parsing.cc:256-263 */
+  ORC_H2_ERR_MAX_STREAMS = 9,   /* parsing.cc:623-627 */
+  ORC_H2_ERR_RST_LENGTH = 10,   /* frame_rst_stream.cc:73-79 */
   ORC_H2_ERR_EVENT_OVERFLOW = 100
 };
+enum { ORC_H2_SERVER = 1, ORC_H2_FIRST_FRAME = 2 };
 
 typedef struct orc_h2_event {
   uint32_t kind;
   uint32_t a, b, c, d;
 } orc_h2_event;
 
-#define ORC_H2_MAX_STREAMS 16
-typedef struct orc_grpc_deframer { /* frame_data.h grpc_chttp2_data_parser */
+/* One entry of the transport's stream map (grpc_chttp2_stream_map, internal.h) with the
+ * fields the deframe path reads: the per-stream grpc_chttp2_data_parser (frame_data.h),
+ * read_closed / write_closed (chttp2_transport.cc:2194-2244), header_frames_received. */
+typedef struct orc_h2_stream {
   uint32_t stream_id;
-  int state;            /* 0..4 = FH_0..FH_4, 5 = FRAME, 6 = ERROR */
+  int state;            /* data parser: 0..4 = FH_0..FH_4, 5 = FRAME, 6 = ERROR */
   uint32_t frame_size;  /* remaining bytes of the current message  */
   int compressed;
-} orc_grpc_deframer;
+  int read_closed, write_closed, header_frames_received;
+} orc_h2_stream;
 
 typedef struct orc_h2_parser { /* internal.h grpc_chttp2_transport deframe fields */
   int state;            /* 0..23 prefix, 24..32 FH_0..FH_8, 33 FRAME */
@@ -178,12 +191,26 @@ typedef struct orc_h2_parser { /* internal.h grpc_chttp2_transport deframe field
   uint32_t incoming_stream_id;
   uint32_t max_frame_size;
   int check_frame_size;
-  int cur_parser;       /* which payload parser the frame in flight uses */
-  orc_grpc_deframer streams[ORC_H2_MAX_STREAMS];
-  int nstreams;
+  int cur_parser;       /* which payload parser the frame in flight uses: 0 skip 1 data 2 header 3 rst */
+  int is_server, is_first_frame;
+  uint32_t expect_continuation_stream_id;
+  int header_eof, header_boundary, received_last_frame;
+  uint32_t last_new_stream_id, max_concurrent_streams;
+  orc_h2_stream* streams; /* the stream map: unordered, grows on demand */
+  uint64_t nstreams, streams_cap;
 } orc_h2_parser;
 
 void orc_h2_parser_init(orc_h2_parser* p, int expect_client_prefix, uint32_t max_frame_size);
+void orc_h2_parser_init_ex(orc_h2_parser* p, int flags, uint32_t max_frame_size,
+                           uint32_t max_concurrent_streams);
+void orc_h2_parser_free(orc_h2_parser* p);
+/* What the surface does outside the read path: a client starts a call on stream `id`
+ * (grpc_chttp2_stream_map_add, chttp2_transport.cc maybe_start_some_streams); the write side
+ * of a stream closes (grpc_chttp2_mark_stream_closed(close_writes)); a stream already read-closed
+ * then leaves the map.  Return 0, or -1 for an unknown / duplicate id. */
+int orc_h2_parser_open_stream(orc_h2_parser* p, uint32_t id);
+int orc_h2_parser_close_writes(orc_h2_parser* p, uint32_t id);
+uint64_t orc_h2_parser_live_streams(const orc_h2_parser* p);
 /* Feed one slice (parsing.cc:56-253 grpc_chttp2_perform_read).  DATA frame
  * payload is additionally run through the per-stream gRPC message deframer
  * (frame_data.cc:92-276).  Events are appended to ev[*nev..cap). */

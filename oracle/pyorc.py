@@ -62,9 +62,10 @@ class OrcEvent(C.Structure):
                 ("c", C.c_uint32), ("d", C.c_uint32)]
 
 
-class OrcDeframer(C.Structure):
+class OrcStream(C.Structure):
     _fields_ = [("stream_id", C.c_uint32), ("state", C.c_int), ("frame_size", C.c_uint32),
-                ("compressed", C.c_int)]
+                ("compressed", C.c_int), ("read_closed", C.c_int), ("write_closed", C.c_int),
+                ("header_frames_received", C.c_int)]
 
 
 class OrcParser(C.Structure):
@@ -72,10 +73,16 @@ class OrcParser(C.Structure):
                 ("incoming_frame_type", C.c_uint8), ("incoming_frame_flags", C.c_uint8),
                 ("incoming_stream_id", C.c_uint32), ("max_frame_size", C.c_uint32),
                 ("check_frame_size", C.c_int), ("cur_parser", C.c_int),
-                ("streams", OrcDeframer * 16), ("nstreams", C.c_int)]
+                ("is_server", C.c_int), ("is_first_frame", C.c_int),
+                ("expect_continuation_stream_id", C.c_uint32),
+                ("header_eof", C.c_int), ("header_boundary", C.c_int),
+                ("received_last_frame", C.c_int),
+                ("last_new_stream_id", C.c_uint32), ("max_concurrent_streams", C.c_uint32),
+                ("streams", C.POINTER(OrcStream)), ("nstreams", u64), ("streams_cap", u64)]
 
 
-EV_FRAME, EV_PAYLOAD, EV_MSG_BEGIN, EV_MSG_BYTES, EV_MSG_END = 1, 2, 3, 4, 5
+EV_FRAME, EV_PAYLOAD, EV_MSG_BEGIN, EV_MSG_BYTES, EV_MSG_END, EV_STREAM_OPEN, EV_STREAM_CLOSED = 1, 2, 3, 4, 5, 6, 7
+H2_SERVER, H2_FIRST_FRAME = 1, 2
 
 
 def _lib():
@@ -111,6 +118,12 @@ def _lib():
     lib.orc_h2_parser_init.argtypes = [C.POINTER(OrcParser), C.c_int, C.c_uint32]
     lib.orc_h2_parser_feed.argtypes = [C.POINTER(OrcParser), C.c_char_p, u64,
                                        C.POINTER(OrcEvent), u64, u64p]
+    lib.orc_h2_parser_init_ex.argtypes = [C.POINTER(OrcParser), C.c_int, C.c_uint32, C.c_uint32]
+    lib.orc_h2_parser_free.argtypes = [C.POINTER(OrcParser)]
+    lib.orc_h2_parser_open_stream.argtypes = [C.POINTER(OrcParser), C.c_uint32]
+    lib.orc_h2_parser_close_writes.argtypes = [C.POINTER(OrcParser), C.c_uint32]
+    lib.orc_h2_parser_live_streams.restype = u64
+    lib.orc_h2_parser_live_streams.argtypes = [C.POINTER(OrcParser)]
     lib.orc_stream_baseline.restype = u64
     lib.orc_stream_baseline.argtypes = [u64, C.c_int, C.c_void_p, u64p, u64, u64,
                                         C.POINTER(C.c_double), u64p]
@@ -366,10 +379,32 @@ def h2_frame_batch(msgs, stream_ids, flags, max_frame=16384):
 
 
 class H2Parser:
-    def __init__(self, expect_client_prefix=False, max_frame_size=16384):
+    """The deframe side of one chttp2 transport.  expect_client_prefix=True is a fresh server
+    connection (preface, SETTINGS first, streams accepted from HEADERS frames); False is a
+    client / mid-connection parser whose streams the caller opens (open_stream)."""
+
+    def __init__(self, expect_client_prefix=False, max_frame_size=16384, flags=None,
+                 max_concurrent_streams=0xFFFFFFFF):
         self.l = lib()
         self.p = OrcParser()
-        self.l.orc_h2_parser_init(C.byref(self.p), int(expect_client_prefix), max_frame_size)
+        if flags is None:
+            flags = (H2_SERVER | H2_FIRST_FRAME) if expect_client_prefix else 0
+        self.l.orc_h2_parser_init_ex(C.byref(self.p), flags, max_frame_size, max_concurrent_streams)
+
+    def __del__(self):
+        try:
+            self.l.orc_h2_parser_free(C.byref(self.p))
+        except Exception:
+            pass
+
+    def open_stream(self, sid):
+        return self.l.orc_h2_parser_open_stream(C.byref(self.p), sid)
+
+    def close_writes(self, sid):
+        return self.l.orc_h2_parser_close_writes(C.byref(self.p), sid)
+
+    def live_streams(self):
+        return int(self.l.orc_h2_parser_live_streams(C.byref(self.p)))
 
     def feed(self, data, cap=None):
         data = bytes(data)

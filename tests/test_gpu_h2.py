@@ -62,8 +62,10 @@ def test_frame_messages_matches_oracle(gpu, lens, max_frame):
     assert wire == exp_wire and wire_bytes == len(exp_wire)
 
 
-def oracle_events(slices_bytes, prefix, max_frame=16384):
+def oracle_events(slices_bytes, prefix, max_frame=16384, streams=()):
     p = pyorc.H2Parser(expect_client_prefix=prefix, max_frame_size=max_frame)
+    for sid in streams:
+        assert p.open_stream(sid) == 0
     out = []
     for i, s in enumerate(slices_bytes):
         rc, ev = p.feed(s)
@@ -73,7 +75,7 @@ def oracle_events(slices_bytes, prefix, max_frame=16384):
     return 0, out
 
 
-def gpu_events(g, slices_bytes, prefix, max_frame=16384, gap_rng=None):
+def gpu_events(g, slices_bytes, prefix, max_frame=16384, gap_rng=None, streams=()):
     from grpc_rdma_amd import h2dev
     arena, table, off = bytearray(), [], 0
     for s in slices_bytes:
@@ -85,6 +87,8 @@ def gpu_events(g, slices_bytes, prefix, max_frame=16384, gap_rng=None):
         off = len(arena)
     buf = g.DeviceBuffer(data=bytes(arena) + bytes(64))
     p = h2dev.Parser(prefix, max_frame)
+    if streams:
+        assert p.open_streams(streams) == 0
     err, ev = p.deframe(buf.ptr, table)
     p.close()
     return err, ev
@@ -149,8 +153,8 @@ def test_deframe_streamed_messages_through_the_ring(gpu):
         if not done:
             steps, done = a.endpoint_write_continue()
     assert sum(len(x) for x in delivered) == wire_bytes
-    rc_o, ev_o = oracle_events(delivered, False)
-    rc_g, ev_g = gpu_events(g, delivered, False)
+    rc_o, ev_o = oracle_events(delivered, False, streams=(1,))
+    rc_g, ev_g = gpu_events(g, delivered, False, streams=(1,))
     assert rc_o == rc_g == 0 and ev_g == ev_o
     # reassemble the messages from the GPU events
     out, cur = [], bytearray()
@@ -169,3 +173,108 @@ def test_deframe_connection_errors(gpu):
     assert rc == 1
     rc, _ = gpu_events(gpu, [(16385).to_bytes(3, "big") + bytes([0, 0, 0, 0, 0, 1])], False)
     assert rc == 2
+
+
+# ---- the stream map: every RPC is a new stream (parsing.cc:341-397, 566-680) ---------------------
+from h2_helpers import PREFACE, frame, grpc_msg, messages_of, unary_call  # noqa: E402
+
+
+def _chunk(data, rng, mean):
+    out, pos = [], 0
+    while pos < len(data):
+        n = max(1, int(rng.expovariate(1.0 / mean)))
+        out.append(data[pos:pos + n])
+        pos += n
+    return out
+
+
+def test_many_streams_on_one_connection_match_the_oracle(gpu):
+    """>= 200 sequential unary streams, then 40 concurrent ones with interleaved DATA frames, on ONE
+    server connection; the write side of finished calls is closed in batches as a server
+    would after responding.  Events (incl. stream open / close), delivered messages and the
+    number of live streams equal the oracle's at every step."""
+    g = gpu
+    from grpc_rdma_amd import h2dev
+    rng = random.Random(23)
+    data = bytearray(PREFACE + frame(4, 0, 0))
+    sid = 1
+    for i in range(220):
+        data += unary_call(sid, bytes(rng.getrandbits(8) for _ in range(rng.randrange(0, 400))))
+        sid += 2
+    ids = list(range(sid, sid + 80, 2))
+    for s_ in ids:
+        data += frame(1, 4, s_, b"\x82")
+    pieces = {s_: grpc_msg(bytes(rng.getrandbits(8) for _ in range(rng.randrange(10, 3000)))) for s_ in ids}
+    for part in range(3):
+        order = ids[:]
+        rng.shuffle(order)
+        for s_ in order:
+            m = pieces[s_]
+            cut = [0, len(m) // 3, 2 * len(m) // 3, len(m)]
+            data += frame(0, 1 if part == 2 else 0, s_, m[cut[part]:cut[part + 1]])
+    data += frame(0, 0, 1, grpc_msg(b"late"))        # stream 1 left the map long ago: skipped
+    data += frame(0, 0, 999999, grpc_msg(b"never"))  # never opened: skipped
+    data = bytes(data)
+    chunks = _chunk(data, rng, 700)
+    po = pyorc.H2Parser(expect_client_prefix=True, max_concurrent_streams=64)
+    pg = h2dev.Parser(True, 16384, max_concurrent_streams=64, table_slots=128)
+    got_msgs, exp_msgs = [], []
+    for b0 in range(0, len(chunks), 37):             # one deframe call per batch of delivered slices
+        batch = chunks[b0:b0 + 37]
+        ev_o = []
+        for i, c in enumerate(batch):
+            rc, ev = po.feed(c)
+            assert rc == 0
+            ev_o += [(k, a, b, c_, d, i) for k, a, b, c_, d in ev]
+        arena, table = bytearray(), []
+        for c in batch:
+            table.append((len(arena), len(c)))
+            arena += c + bytes((-len(c)) % 16)
+        buf = g.DeviceBuffer(data=bytes(arena) + bytes(64))
+        err, ev_g = pg.deframe(buf.ptr, table)
+        assert err == 0 and ev_g == ev_o
+        closed = [c_ for k, a, b, c_, d, i in ev_g if k == 7 and a == 0]
+        for c_ in closed:
+            assert po.close_writes(c_) == 0
+        assert pg.close_writes(closed) == 0
+        assert pg.live_streams() == po.live_streams() <= 41
+        buf.free()
+    assert po.live_streams() == 0
+    pg.close()
+
+
+def test_stream_map_rules_match_the_oracle(gpu):
+    body = b"x" * 40
+    cases = []
+    d = PREFACE + frame(4, 0, 0)
+    d += frame(0, 0, 5, grpc_msg(body)) + unary_call(7, body) + frame(0, 0, 7, grpc_msg(body))
+    d += frame(1, 4, 3, b"\x82") + frame(0, 1, 3, grpc_msg(body))
+    d += frame(1, 4, 8, b"\x82") + frame(0, 1, 8, grpc_msg(body))
+    d += frame(1, 4, 9, b"\x82") + frame(3, 0, 9, b"\0\0\0\x08") + frame(0, 1, 9, grpc_msg(body))
+    d += frame(1, 1, 11, b"\x82") + frame(9, 4, 11, b"\x86") + frame(0, 9, 13, b"")
+    d += frame(1, 4, 13, b"") + frame(0, 9, 13, b"abc") + frame(0, 0, 13, grpc_msg(body))
+    cases.append((True, d, ()))
+    cases.append((False, frame(0, 0, 1, grpc_msg(body)) + frame(1, 5, 1, b"\x88"), ()))
+    cases.append((False, frame(0, 0, 1, grpc_msg(body)) + frame(1, 5, 1, b"\x88") + frame(0, 0, 1, b"zz"), (1, 3)))
+    ok = PREFACE + frame(4, 0, 0)
+    for bad in (PREFACE + frame(0, 0, 1, b"abc"), ok + frame(1, 0, 1, b"\x82") + frame(0, 0, 1, b""),
+                ok + frame(1, 0, 1, b"\x82") + frame(9, 4, 3, b""), ok + frame(9, 4, 1, b""),
+                ok + frame(3, 0, 1, b"\0\0\0")):
+        cases.append((True, bad, ()))
+    rng = random.Random(4)
+    for prefix, data, streams in cases:
+        for mean in (10000, 5, 1):
+            chunks = _chunk(data, rng, mean)
+            rc_o, ev_o = oracle_events(chunks, prefix, streams=streams)
+            rc_g, ev_g = gpu_events(gpu, chunks, prefix, streams=streams)
+            assert rc_g == rc_o
+            assert ev_g == ev_o
+    # Max stream count exceeded (parsing.cc:623-627)
+    from grpc_rdma_amd import h2dev
+    d = ok + frame(1, 4, 1, b"") + frame(1, 4, 3, b"") + frame(1, 4, 5, b"")
+    po = pyorc.H2Parser(expect_client_prefix=True, max_concurrent_streams=2)
+    assert po.feed(d)[0] == 9
+    pg = h2dev.Parser(True, 16384, max_concurrent_streams=2)
+    buf = gpu.DeviceBuffer(data=d + bytes(64))
+    assert pg.deframe(buf.ptr, [(0, len(d))])[0] == 9
+    pg.close()

@@ -16,9 +16,12 @@ from oracle.pyorc import EV_FRAME, EV_MSG_BEGIN, EV_MSG_BYTES, EV_MSG_END, EV_PA
 VEC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "h2_bad_client.json")))["vectors"]
 
 
-def feed_chunks(data, cuts, prefix=True):
-    """Feed `data` split at `cuts`; -> (rc, events with absolute stream offsets)."""
+def feed_chunks(data, cuts, prefix=True, streams=()):
+    """Feed `data` split at `cuts`; -> (rc, events with absolute stream offsets).  `streams`:
+    ids the caller opened (a client's calls; a server learns its streams from HEADERS)."""
     p = pyorc.H2Parser(expect_client_prefix=prefix)
+    for sid in streams:
+        assert p.open_stream(sid) == 0
     out, base = [], 0
     bounds = [0] + sorted(cuts) + [len(data)]
     for a, b in zip(bounds, bounds[1:]):
@@ -113,7 +116,7 @@ def test_tx_framing_equals_the_reference_benchmark_framing(length):
     assert wire == create_incoming_data_slice(length, 16384)
     assert sum(lens) == len(wire)
     # and it parses back to exactly that message
-    rc, ev = feed_chunks(wire, [], prefix=False)
+    rc, ev = feed_chunks(wire, [], prefix=False, streams=(1,))
     assert rc == 0
     assert [(a, b) for k, a, b, c, d in ev if k == EV_MSG_BEGIN] == [(0, length)]
     assert b"".join(wire[a:a + b] for k, a, b, c, d in ev if k == EV_MSG_BYTES) == msg
@@ -148,3 +151,117 @@ def test_oversized_frame_and_bad_prefix_are_connection_errors():
     p = pyorc.H2Parser(expect_client_prefix=False, max_frame_size=16384)
     rc, _ = p.feed((16385).to_bytes(3, "big") + bytes([0, 0, 0, 0, 0, 1]))
     assert rc == 2  # parsing.cc:195-205
+
+
+# ---------------------------------------------------------------------------------------------
+# The stream map the DATA path reads (parsing.cc init_data_frame_parser / init_header_frame_parser,
+# chttp2_transport.cc grpc_chttp2_mark_stream_closed): lookup only, streams accepted from HEADERS on a
+# server, read-closed by END_STREAM, removed once both sides are closed.
+from h2_helpers import PREFACE, frame, grpc_msg, messages_of, unary_call  # noqa: E402
+
+
+def test_two_hundred_sequential_unary_streams_and_forty_interleaved():
+    """Every RPC is a new stream: a connection must keep deframing after any number of them
+    (the reference looks the stream up in the transport's map, parsing.cc:352-370)."""
+    rng = random.Random(11)
+    data = bytearray(PREFACE + frame(4, 0, 0))
+    expect = []
+    sid = 1
+    for i in range(200):
+        body = bytes(rng.getrandbits(8) for _ in range(rng.randrange(0, 300)))
+        data += unary_call(sid, body)
+        expect.append((sid, body))
+        sid += 2
+    # 40 concurrent streams, each message cut into three DATA frames, frames interleaved
+    ids = list(range(sid, sid + 80, 2))
+    bodies = {s_: bytes(rng.getrandbits(8) for _ in range(rng.randrange(10, 2000))) for s_ in ids}
+    for s_ in ids:
+        data += frame(1, 4, s_, b"\x82")
+    pieces = {s_: grpc_msg(bodies[s_]) for s_ in ids}
+    for part in range(3):
+        order = ids[:]
+        rng.shuffle(order)
+        for s_ in order:
+            m = pieces[s_]
+            cut = [0, len(m) // 3, 2 * len(m) // 3, len(m)]
+            data += frame(0, 1 if part == 2 else 0, s_, m[cut[part]:cut[part + 1]])
+    data = bytes(data)
+    p = pyorc.H2Parser(expect_client_prefix=True)
+    rc, ev = p.feed(data, cap=200000)
+    assert rc == 0
+    got = messages_of(ev, data)
+    assert got[:200] == expect
+    assert sorted(got[200:]) == sorted(bodies.items())
+    opened = [c for k, a, b, c, d in ev if k == pyorc.EV_STREAM_OPEN]
+    closed = [c for k, a, b, c, d in ev if k == pyorc.EV_STREAM_CLOSED]
+    assert opened == list(range(1, sid + 80, 2)) and sorted(closed) == opened
+    # read-closed streams stay in the map until their write side closes too
+    assert p.live_streams() == 240
+    for s_ in opened:
+        assert p.close_writes(s_) == 0
+    assert p.live_streams() == 0
+    # and the same bytes, with the write side of every finished call closed as it completes
+    p = pyorc.H2Parser(expect_client_prefix=True, max_concurrent_streams=64)
+    pos, peak = 0, 0
+    for n in [len(PREFACE) + 9] + [7] * ((len(data) - len(PREFACE) - 9) // 7 + 1):
+        chunk = data[pos:pos + n]
+        pos += n
+        rc, e2 = p.feed(chunk)
+        assert rc == 0
+        for k, a, b, c, d in e2:
+            if k == pyorc.EV_STREAM_CLOSED and a == 0:
+                p.close_writes(c)
+        peak = max(peak, p.live_streams())
+    assert p.live_streams() == 0 and peak <= 41
+
+
+def test_data_for_unknown_closed_or_refused_streams_is_skipped():
+    body = b"x" * 40
+    p = pyorc.H2Parser(expect_client_prefix=True)
+    data = PREFACE + frame(4, 0, 0)
+    data += frame(0, 0, 5, grpc_msg(body))              # no HEADERS seen: unknown stream -> skip
+    data += unary_call(7, body)                         # accepted, read-closed by END_STREAM
+    data += frame(0, 0, 7, grpc_msg(body))              # DATA after END_STREAM -> skip (parsing.cc:372-374)
+    data += frame(1, 4, 3, b"\x82") + frame(0, 1, 3, grpc_msg(body))  # id below last_new_stream_id -> ignored
+    data += frame(1, 4, 8, b"\x82") + frame(0, 1, 8, grpc_msg(body))  # even id -> ignored
+    data += frame(1, 4, 9, b"\x82") + frame(3, 0, 9, b"\0\0\0\x08")  # RST_STREAM removes stream 9
+    data += frame(0, 1, 9, grpc_msg(body))              # -> unknown again
+    rc, ev = p.feed(data)
+    assert rc == 0
+    assert messages_of(ev, data) == [(7, body)]
+    assert [c for k, a, b, c, d in ev if k == pyorc.EV_STREAM_OPEN] == [7, 9]
+    assert [(c, a) for k, a, b, c, d in ev if k == pyorc.EV_STREAM_CLOSED] == [(7, 0), (9, 1)]
+    assert p.live_streams() == 1
+
+
+def test_client_side_streams_are_opened_by_the_caller():
+    body = b"y" * 100
+    data = frame(0, 0, 1, grpc_msg(body)) + frame(1, 5, 1, b"\x88")  # DATA, then trailers with END_STREAM
+    p = pyorc.H2Parser(expect_client_prefix=False)
+    rc, ev = p.feed(data)
+    assert rc == 0 and messages_of(ev, data) == []      # the call was never started here
+    p = pyorc.H2Parser(expect_client_prefix=False)
+    assert p.open_stream(1) == 0 and p.open_stream(1) == -1
+    rc, ev = p.feed(data)
+    assert rc == 0 and messages_of(ev, data) == [(1, body)]
+    assert [(c, a) for k, a, b, c, d in ev if k == pyorc.EV_STREAM_CLOSED] == [(1, 0)]
+    assert p.close_writes(1) == 0 and p.live_streams() == 0
+
+
+def test_continuation_and_first_frame_rules():
+    H = lambda rc_expected, data, **kw: (pyorc.H2Parser(**kw).feed(data)[0] == rc_expected)
+    srv = dict(expect_client_prefix=True)
+    assert H(8, PREFACE + frame(0, 0, 1, b"abc"), **srv)                  # first frame must be SETTINGS
+    ok = PREFACE + frame(4, 0, 0)
+    assert H(0, ok + frame(1, 0, 1, b"\x82") + frame(9, 4, 1, b"\x86") + frame(0, 1, 1, grpc_msg(b"z")), **srv)
+    assert H(5, ok + frame(1, 0, 1, b"\x82") + frame(0, 0, 1, b""), **srv)  # expected CONTINUATION
+    assert H(6, ok + frame(1, 0, 1, b"\x82") + frame(9, 4, 3, b""), **srv)  # CONTINUATION for another stream
+    assert H(7, ok + frame(9, 4, 1, b""), **srv)                          # unexpected CONTINUATION
+    assert H(10, ok + frame(3, 0, 1, b"\0\0\0"), **srv)                  # RST_STREAM length != 4
+    p = pyorc.H2Parser(expect_client_prefix=True, max_concurrent_streams=2)
+    rc, _ = p.feed(ok + frame(1, 4, 1, b"") + frame(1, 4, 3, b"") + frame(1, 4, 5, b""))
+    assert rc == 9                                                        # Max stream count exceeded
+    # END_STREAM on HEADERS closes reads once the header block ends (END_HEADERS on the CONTINUATION)
+    p = pyorc.H2Parser(expect_client_prefix=True)
+    rc, ev = p.feed(ok + frame(1, 1, 1, b"\x82") + frame(9, 4, 1, b"\x86"))
+    assert rc == 0 and [(c, a) for k, a, b, c, d in ev if k == pyorc.EV_STREAM_CLOSED] == [(1, 0)]
