@@ -158,6 +158,7 @@ struct grpc_rdma {  // rdma_bp_posix.cc:45-88
   grpc_slice_buffer* outgoing_buffer;
   std::vector<grdma_slice> out_views;  // {ptr,len} of outgoing_buffer, windowed to the ABI cap
   size_t out_next;                     // first slice not yet handed to the pair
+  bool window_active;                  // the pair holds a window that has not gone out whole yet
   grpc_closure* read_cb;
   grpc_closure* write_cb;
   bool read_armed;   // notify_on_read pending
@@ -249,35 +250,48 @@ void rdma_read(grpc_endpoint* ep, grpc_slice_buffer* incoming_buffer, grpc_closu
   }
 }
 
-// rdma_flush (:470-524): hand the next window of slices to the pair and step it.
-// Returns true when the whole buffer has been written (or an error is set).
+// rdma_flush (:470-524): ONE Send from the cursor, then the status switch of :499-518.
+// The pair's write context holds one window of the buffer at a time (the ABI takes at most
+// 4095 slices); a window that went out whole is followed by the next one right away, as the
+// single Send of the reference would have carried on into those slices.
+// Returns true when the whole buffer has been written or an error is set.
 bool rdma_flush(grpc_rdma* rdma, grpc_error_handle* error) {
   *error = GRPC_ERROR_NONE;
+  auto fail_with = [&](const char* what) {
+    *error = rdma_annotate_error(GRPC_ERROR_CREATE_FROM_STATIC_STRING(what), rdma);
+    grdma_endpoint_write_abort(rdma->pair);  // the pair must not keep views of slices about to be unreffed
+    rdma->window_active = false;
+    rdma->out_views.clear();
+    rdma->out_next = 0;
+    grpc_slice_buffer_reset_and_unref(rdma->outgoing_buffer);
+    return true;
+  };
   for (;;) {
+    if (!rdma->window_active) {
+      if (rdma->out_next >= rdma->out_views.size()) break;
+      size_t cnt = rdma->out_views.size() - rdma->out_next;
+      if (cnt > kWindow) cnt = kWindow;
+      if (grdma_endpoint_write_begin(rdma->pair, rdma->out_views.data() + rdma->out_next, cnt,
+                                     GRDMA_MEM_HOST) < 0)
+        return fail_with("RDMA Pair has an internal error");
+      rdma->out_next += cnt;
+      rdma->window_active = true;
+    }
     int done = 0;
-    int64_t n = grdma_endpoint_write_step(rdma->pair, &done);
-    if (n < 0) {
-      *error = rdma_annotate_error(
-          GRPC_ERROR_CREATE_FROM_STATIC_STRING("RDMA Pair has an internal error"), rdma);  // :511-517
-      grpc_slice_buffer_reset_and_unref(rdma->outgoing_buffer);
-      return true;
+    const int64_t n = grdma_endpoint_write_step(rdma->pair, &done);
+    if (n < 0) return fail_with("RDMA Pair has an internal error");  // :511-517
+    if (done) {
+      rdma->window_active = false;
+      continue;
     }
-    if (!done) {
-      const int status = grdma_pair_get_status(rdma->pair);
-      if (status == 3) {  // kHalfClosed :505-510
-        *error = rdma_annotate_error(GRPC_ERROR_CREATE_FROM_STATIC_STRING("Peer has been exited"), rdma);
-        grpc_slice_buffer_reset_and_unref(rdma->outgoing_buffer);
-        return true;
-      }
-      if (n == 0) return false;  // no credit: wait for the writable edge
-      continue;                  // progress was made: try again, like the event loop would
-    }
-    if (rdma->out_next >= rdma->out_views.size()) break;
-    size_t cnt = rdma->out_views.size() - rdma->out_next;
-    if (cnt > kWindow) cnt = kWindow;
-    grdma_endpoint_write_begin(rdma->pair, rdma->out_views.data() + rdma->out_next, cnt, GRDMA_MEM_HOST);
-    rdma->out_next += cnt;
+    // partial send, :499-518
+    const int status = grdma_pair_get_status(rdma->pair);
+    if (status == 2 /* kConnected */) return false;  // wait for the writable edge
+    if (status == 3 /* kHalfClosed */) return fail_with("Peer has been exited");
+    return fail_with("RDMA Pair has an internal error");
   }
+  rdma->out_views.clear();
+  rdma->out_next = 0;
   grpc_slice_buffer_reset_and_unref(rdma->outgoing_buffer);  // :519-523
   return true;
 }
@@ -319,6 +333,7 @@ void rdma_write(grpc_endpoint* ep, grpc_slice_buffer* buf, grpc_closure* cb, voi
   for (size_t i = 0; i < buf->count; i++)
     rdma->out_views.push_back({GRPC_SLICE_START_PTR(buf->slices[i]), GRPC_SLICE_LENGTH(buf->slices[i])});
   rdma->out_next = 0;
+  rdma->window_active = false;
   grpc_error_handle error;
   if (!rdma_flush(rdma, &error)) {  // :577-583
     rdma->refcount.fetch_add(1);
@@ -401,6 +416,7 @@ grpc_endpoint* grpc_rdma_bp_create(int fd, const char* peer_string, bool enable_
   rdma->incoming_buffer = nullptr;
   rdma->outgoing_buffer = nullptr;
   rdma->out_next = 0;
+  rdma->window_active = false;
   rdma->read_cb = rdma->write_cb = nullptr;
   rdma->read_armed = rdma->write_armed = false;
   rdma->inq = 1;  // :745

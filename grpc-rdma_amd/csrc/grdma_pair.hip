@@ -61,6 +61,7 @@ thread_local std::string g_err;
 
 // persistent latency engine (k_engine): mailbox in pinned host memory
 struct grdma_engine {
+  std::mutex mu;         // one command in the mailbox at a time: callers on different threads queue here
   grdma_engine_mbox* mb = nullptr;
   hipStream_t stream = nullptr;
   bool wanted = false;   // grdma_engine_start() was called
@@ -140,6 +141,7 @@ struct grdma_pair {
   grdma_pair* peer = nullptr;
   hipStream_t stream = nullptr;
   int wakeup_fd = -1;                // grpc_wakeup_fd of the pair (pair.h:187): an eventfd
+  std::mutex fd_mu;                  // creation of wakeup_fd
   // endpoint_write context
   std::vector<grdma_slice> w_slices;
   uint64_t w_idx = 0, w_byte = 0;
@@ -230,6 +232,7 @@ int engine_launch() {
 // Hand one command to the resident engine and wait for it.
 int engine_submit(uint64_t type, const void* op) {
   grdma_engine& e = g_engine;
+  std::lock_guard<std::mutex> lk(e.mu);
   if (int rc = engine_launch()) return rc;
   e.mb->cmd_type = type;
   e.mb->op = op;
@@ -260,6 +263,7 @@ int engine_submit(uint64_t type, const void* op) {
 
 int engine_stop() {
   grdma_engine& e = g_engine;
+  std::lock_guard<std::mutex> lk(e.mu);
   e.wanted = false;
   if (!e.mb) return 0;
   *(volatile uint64_t*)&e.mb->exit_flag = 1;
@@ -603,14 +607,31 @@ struct grdma_poller {
   std::thread th;
   int sleep_ms = 1000;
   int device = 0;
+  std::atomic<bool> failed{false};  // the polling thread hit a HIP error and stopped
+  std::string failure;              // what it was (set before `failed`)
 };
 
 namespace {
 
+// A poller whose thread died must not look healthy: remember why, and kick every registered
+// wakeup fd once so that blocked readers come back and find the failure in poller_stats / add.
+void poller_fail(grdma_poller* pl, const char* what, hipError_t e) {
+  pl->failure = std::string(what) + ": " + hipGetErrorString(e);
+  pl->failed.store(true, std::memory_order_release);
+  std::lock_guard<std::mutex> lk(pl->mu);
+  for (grdma_pair* p : pl->pairs) {
+    if (!p || p->wakeup_fd < 0) continue;
+    const uint64_t one = 1;
+    (void)!write(p->wakeup_fd, &one, sizeof(one));
+  }
+}
+
 void poller_loop(grdma_poller* pl) {
-  if (hipSetDevice(pl->device) != hipSuccess) return;
+  hipError_t he;
+  if ((he = hipSetDevice(pl->device)) != hipSuccess) return poller_fail(pl, "hipSetDevice", he);
   hipStream_t s = nullptr;
-  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
+  if ((he = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess)
+    return poller_fail(pl, "hipStreamCreate", he);
   grdma_conn** h_conns = nullptr;
   uint64_t* h_words = nullptr;  // readable[cap] | ready[cap/64] | has[cap/64] | trigger[cap/64]
   uint32_t cap = 0;
@@ -636,17 +657,25 @@ void poller_loop(grdma_poller* pl) {
       if (h_conns) hipHostFree(h_conns);
       if (h_words) hipHostFree(h_words);
       cap = (n + 63) & ~63u;
-      if (hipHostMalloc((void**)&h_conns, sizeof(void*) * cap, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
-          hipHostMalloc((void**)&h_words, sizeof(uint64_t) * (cap + 3 * (cap / 64)),
-                        hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+      if ((he = hipHostMalloc((void**)&h_conns, sizeof(void*) * cap, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess ||
+          (he = hipHostMalloc((void**)&h_words, sizeof(uint64_t) * (cap + 3 * (cap / 64)),
+                              hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess) {
+        poller_fail(pl, "hipHostMalloc", he);
         break;
+      }
     }
     for (uint32_t i = 0; i < n; i++) h_conns[i] = snap[i]->d_conn;
     uint64_t* ready = h_words + cap;
     uint64_t* has = ready + cap / 64;
     uint64_t* trig = has + cap / 64;
-    if (grdma_launch_poll(h_conns, n, h_words, ready, has, trig, s) != hipSuccess) break;
-    if (hipStreamSynchronize(s) != hipSuccess) break;
+    if ((he = grdma_launch_poll(h_conns, n, h_words, ready, has, trig, s)) != hipSuccess) {
+      poller_fail(pl, "k_poll launch", he);
+      break;
+    }
+    if ((he = hipStreamSynchronize(s)) != hipSuccess) {
+      poller_fail(pl, "k_poll", he);
+      break;
+    }
     pl->passes.fetch_add(1, std::memory_order_relaxed);
     for (uint32_t i = 0; i < n; i++) {
       if (!((trig[i / 64] >> (i % 64)) & 1)) continue;
@@ -669,6 +698,7 @@ extern "C" {
 
 int grdma_pair_get_wakeup_fd(grdma_pair* p) {
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  std::lock_guard<std::mutex> lk(p->fd_mu);
   if (p->wakeup_fd < 0) {
     p->wakeup_fd = eventfd(0, EFD_NONBLOCK | EFD_CLOEXEC);  // grpc_wakeup_fd_init, pair.cc:74
     if (p->wakeup_fd < 0) return fail(GRDMA_ERR_INVALID, "eventfd failed");
@@ -698,6 +728,8 @@ grdma_poller* grdma_poller_create(int n_threads, int sleep_timeout_ms) {
 
 int grdma_poller_add(grdma_poller* pl, grdma_pair* p) {  // Poller::AddPollable, poller.cc:12-43
   if (!pl || !p) return fail(GRDMA_ERR_INVALID, "null argument");
+  if (pl->failed.load(std::memory_order_acquire))
+    return fail(GRDMA_ERR_HIP, "the poller thread has stopped: %s", pl->failure.c_str());
   const int fd = grdma_pair_get_wakeup_fd(p);
   if (fd < 0) return fd;
   {
@@ -742,6 +774,8 @@ int grdma_poller_stats(grdma_poller* pl, uint64_t* passes, uint64_t* wakeups) {
   if (!pl) return fail(GRDMA_ERR_INVALID, "null poller");
   if (passes) *passes = pl->passes.load();
   if (wakeups) *wakeups = pl->wakeups.load();
+  if (pl->failed.load(std::memory_order_acquire))
+    return fail(GRDMA_ERR_HIP, "the poller thread has stopped: %s", pl->failure.c_str());
   return 0;
 }
 
@@ -852,6 +886,7 @@ int grdma_pair_arena_copy_out(grdma_pair* p, uint64_t off, void* host_dst, uint6
 
 int grdma_engine_start(void) {
   if (int rc = require_ctx()) return rc;
+  std::lock_guard<std::mutex> lk(g_engine.mu);
   g_engine.wanted = true;
   return engine_launch();
 }
@@ -964,6 +999,16 @@ int64_t grdma_endpoint_write_begin(grdma_pair* p, const grdma_slice* slices, uin
   p->w_byte = 0;
   p->w_flags = flags;
   p->w_active = count > 0;
+  return 0;
+}
+
+// Drops the write context (error exits of rdma_flush, rdma_bp_posix.cc:505-517: the slice
+// buffer is unreffed there, so no view of it may survive in the pair).
+int grdma_endpoint_write_abort(grdma_pair* p) {
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  p->w_active = false;
+  p->w_slices.clear();
+  p->w_idx = p->w_byte = 0;
   return 0;
 }
 

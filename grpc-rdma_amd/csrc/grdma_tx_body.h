@@ -145,7 +145,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     // (counters: loads before the first store to the connection, one round trip)
     const uint64_t o_written = c->total_written, o_records = c->tx_records, o_rounds = c->tx_rounds;
     c->remote_tail = new_tail;
-    c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709
+    if (connected) c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709 (Send returns at :652-655 when not connected)
     c->total_written = o_written + sent;
     c->tx_records = o_records + nrec_total;
     c->tx_last_records = (uint32_t)nrec_total;
@@ -158,7 +158,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     r->sent = sent;
     r->records = nrec_total;
     r->staged = staged;
-    r->partial = sent < offered ? 1 : 0;
+    r->partial = connected ? (sent < offered ? 1 : 0) : c->partial_write;
     r->new_remote_tail = new_tail;
     r->slice_idx = idx;
     r->byte_idx = bidx;
@@ -484,7 +484,7 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
     // (counters: loads before the first store to the connection, one round trip)
     const uint64_t o_written = c->total_written, o_records = c->tx_records, o_rounds = c->tx_rounds;
     c->remote_tail = new_tail;
-    c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709
+    if (connected) c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709 (Send returns at :652-655 when not connected)
     c->total_written = o_written + sent;
     c->tx_records = o_records + nrec_total;
     c->tx_last_records = (uint32_t)nrec_total;
@@ -497,7 +497,7 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
     r->sent = sent;
     r->records = nrec_total;
     r->staged = staged;
-    r->partial = sent < offered ? 1 : 0;
+    r->partial = connected ? (sent < offered ? 1 : 0) : c->partial_write;
     r->new_remote_tail = new_tail;
     r->slice_idx = idx;
     r->byte_idx = bidx;

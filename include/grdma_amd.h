@@ -13,6 +13,13 @@
  * buffer).  All functions return <0 (a negated grdma_error) on failure and
  * never fall back to a CPU implementation: without a usable HIP device
  * grdma_init() fails and every other call reports GRDMA_ERR_NO_DEVICE.
+ *
+ * Threading (the contract of PairPollable, pair.h:64-81): different pairs may be driven from
+ * different threads at the same time; on ONE pair at most one thread sends / writes and at most
+ * one thread receives / reads at any moment (never two readers or two writers).  The read-only
+ * queries (has_message, has_pending_writes, get_status, readable/writable size, poll_pairs) may
+ * run beside them from any thread.  The latency engine's mailbox is serialised inside the
+ * library.  grdma_last_error() is per thread.
  */
 #ifndef GRDMA_AMD_H
 #define GRDMA_AMD_H
@@ -158,6 +165,9 @@ typedef struct grdma_read_slice { uint64_t off, len; } grdma_read_slice;
 int64_t grdma_endpoint_write_begin(grdma_pair* p, const grdma_slice* slices, uint64_t count,
                                    int flags);
 int64_t grdma_endpoint_write_step(grdma_pair* p, int* done);
+/* Forget the outstanding write (the error exits of rdma_flush, :505-517, unref the slice
+ * buffer; afterwards a new grdma_endpoint_write_begin is accepted). */
+int grdma_endpoint_write_abort(grdma_pair* p);
 
 /* rdma_read()/rdma_continue_read()/rdma_do_read() (rdma_bp_posix.cc:180-376):
  * performs up to max_reads endpoint_read completions in ONE device pass; each

@@ -233,10 +233,48 @@ static void half_close_test() {
   printf("half_close_test: ok\n");
 }
 
+// A write that cannot complete because the peer exited fails with "Peer has been exited"
+// (rdma_bp_posix.cc:505-510), the endpoint forgets the slices it unreffed, and the NEXT write
+// is taken normally and fails the same way instead of touching freed memory or spinning.
+static int g_write_cbs = 0;
+static void record_write(void* p, grpc_error_handle e) {
+  g_write_cbs++;
+  record_error(p, e);
+}
+static void write_after_peer_exit_test() {
+  setenv("GRPC_RDMA_RING_BUFFER_SIZE_KB", "64", 1);
+  fixture f = create_fixture();
+  unsetenv("GRPC_RDMA_RING_BUFFER_SIZE_KB");
+  grpc_slice_buffer out;
+  grpc_slice_buffer_init(&out);
+  uint8_t cur = 0;
+  fill_buffer(&out, 300000, 8192, &cur);  // more than the 64 KiB ring takes: the write parks
+  grpc_closure cb;
+  GRPC_CLOSURE_INIT(&cb, record_write, nullptr, nullptr);
+  g_write_cbs = 0; g_status = -1; g_desc.clear();
+  grpc_endpoint_write(f.client_ep, &out, &cb, nullptr);
+  CHECK(g_write_cbs == 0);
+  grpc_endpoint_destroy(f.server_ep);  // peer_exit = 1: the client end is half closed
+  int ran = 0;
+  for (int i = 0; i < 100 && !g_write_cbs; i++) ran += grdma_endpoint_poll(f.client_ep);
+  CHECK(g_write_cbs == 1 && g_status == GRPC_STATUS_UNAVAILABLE && g_desc == "Peer has been exited");
+  CHECK(out.count == 0);  // reset_and_unref
+  // a second write: accepted, and reported through its own closure
+  fill_buffer(&out, 300000, 8192, &cur);
+  g_status = -1; g_desc.clear();
+  grpc_endpoint_write(f.client_ep, &out, &cb, nullptr);
+  for (int i = 0; i < 100 && g_write_cbs < 2; i++) grdma_endpoint_poll(f.client_ep);
+  CHECK(g_write_cbs == 2 && g_status == GRPC_STATUS_UNAVAILABLE && g_desc == "Peer has been exited");
+  grpc_slice_buffer_destroy(&out);
+  grpc_endpoint_destroy(f.client_ep);
+  printf("write_after_peer_exit_test: ok\n");
+}
+
 int main(int argc, char** argv) {
   if (argc >= 2 && !strcmp(argv[1], "multiple_shutdown")) {
     multiple_shutdown_test();
     half_close_test();
+    write_after_peer_exit_test();
     return 0;
   }
   if (argc >= 4 && !strcmp(argv[1], "sweep")) {  // endpoint_tests.cc:350-352

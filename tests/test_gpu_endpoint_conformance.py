@@ -23,6 +23,7 @@ def run(*args, env=None):
 def test_multiple_shutdown_and_half_close(gpu):
     out = run("multiple_shutdown")
     assert "multiple_shutdown_test: ok" in out and "half_close_test: ok" in out
+    assert "write_after_peer_exit_test: ok" in out
 
 
 @pytest.mark.parametrize("num_bytes,write_size,slice_size,shutdown", [
