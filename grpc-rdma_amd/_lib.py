@@ -60,6 +60,9 @@ SIGNATURES = {
     "grdma_pair_create": (C.c_void_p, [u64, C.c_int, C.c_int]),
     "grdma_pair_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "grdma_pair_disconnect": (C.c_int, [C.c_void_p]),
+    "grdma_pair_export_address": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "grdma_pair_connect_remote": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "grdma_pair_bootstrap_fd": (C.c_int, [C.c_void_p, C.c_int]),
     "grdma_pair_destroy": (None, [C.c_void_p]),
     "grdma_pair_get_status": (C.c_int, [C.c_void_p]),
     "grdma_pair_send": (C.c_int64, [C.c_void_p, C.POINTER(Slice), u64, u64, C.c_int]),

@@ -18,6 +18,8 @@
 #include <mutex>
 #include <thread>
 #include <poll.h>
+#include <sys/socket.h>
+#include <errno.h>
 #include <sys/eventfd.h>
 #include <unistd.h>
 #include <string>
@@ -27,8 +29,11 @@
 #include "grdma_dev.h"
 #include "grdma_host.h"
 #include "grdma_ops.h"
+#include "grdma_link.h"
 
 extern "C" {
+hipError_t grdma_launch_link(lk_ctl* const*, uint32_t, uint32_t, uint64_t, hipStream_t);
+uint32_t grdma_link_resident_blocks(void);
 hipError_t grdma_launch_tx_plan(const grdma_tx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_copy(const grdma_plan* const*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
@@ -139,6 +144,13 @@ struct grdma_pair {
   grdma_slice_out* h_slices = nullptr;  // pinned, GRDMA_MAX_SLICES entries
   uint8_t* h_bounce = nullptr;       // pinned, staging-sized, lazily allocated
   grdma_pair* peer = nullptr;
+  // a peer in another process (or on another GPU): its ring and its connection block are
+  // mapped here through HIP IPC handles exchanged at bootstrap (grdma_pair_connect_remote)
+  bool remote = false;
+  void* ipc_ring = nullptr;             // base of the peer's ring mapping
+  void* ipc_conn = nullptr;             // base of the peer's grdma_conn mapping
+  grdma_status_report* remote_status = nullptr;  // peer's status_recv inside ipc_conn
+  uint32_t serial = 0;                  // "queue pair number" of this pair in its process
   hipStream_t stream = nullptr;
   int wakeup_fd = -1;                // grpc_wakeup_fd of the pair (pair.h:187): an eventfd
   std::mutex fd_mu;                  // creation of wakeup_fd
@@ -452,6 +464,8 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
 void grdma_pair_destroy(grdma_pair* p) {
   if (!p) return;
   if (p->stream) hipStreamSynchronize(p->stream);
+  if (p->ipc_ring) hipIpcCloseMemHandle(p->ipc_ring);
+  if (p->ipc_conn) hipIpcCloseMemHandle(p->ipc_conn);
   hipFree(p->d_conn);
   hipFree(p->d_ring);
   hipFree(p->d_staging);
@@ -494,17 +508,135 @@ int grdma_pair_connect(grdma_pair* a, grdma_pair* b) {
   return 0;
 }
 
+// ---- bootstrap across processes / GPUs ------------------------------------------------------
+// The reference exchanges a 48-byte Address over the TCP fd (exchange_data,
+// rdma_bp_posix.cc:640-692, 767-771), brings the queue pair up (pair.cc:143-168, 413-457) and then
+// swaps memory-region descriptors {addr, rkey} of the ring and of the status buffer over the
+// new QP (syncMemoryRegion).  Here the "memory region" of a ring in HBM is a HIP IPC handle: the
+// peer maps it and its one-sided writes (the wire kernel, or a NIC given the dma-buf of the same
+// allocation) land in my ring.  Both travel in one blob whose first 48 bytes are the reference's
+// Address, so the tag / ring-size checks of Connect() read the same fields.
+namespace {
+std::atomic<uint32_t> g_pair_serial{1};
+const uint32_t kBlobMagic = 0x4d445247u;  // "GRDM"
+static_assert(sizeof(grdma_address) == 48, "Address layout (address.h:24-31)");
+static_assert(sizeof(grdma_bootstrap_blob) == 208, "bootstrap blob layout");
+}  // namespace
+
+int grdma_pair_export_address(grdma_pair* p, grdma_bootstrap_blob* out) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || !out) return fail(GRDMA_ERR_INVALID, "null argument");
+  memset(out, 0, sizeof(*out));
+  if (p->serial == 0) p->serial = g_pair_serial.fetch_add(1);
+  out->addr.lid = (uint32_t)g_ctx.device;          // "local id": the HIP device ordinal
+  out->addr.qpn = p->serial;
+  out->addr.psn = (uint32_t)(((uint64_t)getpid() * 2654435761u) ^ p->serial) & 0xffffffu;  // 24 bits, like lrand48() & 0xffffff
+  char bus[32] = {0};
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), g_ctx.device) == hipSuccess) memcpy(out->addr.gid, bus, 16);
+  out->addr.tag = 0xa0;                            // IBVERBS_PAIR_TAG_POLLABLE, pair.h:26, pair.cc:72
+  out->addr.ring_buffer_size = p->ring_size;       // pair.cc:107
+  out->magic = kBlobMagic;
+  out->version = GRDMA_ABI_VERSION;
+  out->hip_device = g_ctx.device;
+  out->pid = (uint64_t)getpid();
+  out->status_off = offsetof(grdma_conn, status_recv);
+  static_assert(sizeof(hipIpcMemHandle_t) == sizeof(out->ring_handle), "HIP IPC handle size");
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, p->d_ring));
+  memcpy(out->ring_handle, &h, sizeof(h));
+  HIP_TRY(hipIpcGetMemHandle(&h, p->d_conn));
+  memcpy(out->conn_handle, &h, sizeof(h));
+  return 0;
+}
+
+int grdma_pair_connect_remote(grdma_pair* p, const grdma_bootstrap_blob* peer) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || !peer) return fail(GRDMA_ERR_INVALID, "null argument");
+  grdma_conn c;
+  if (int rc = fetch_conn(p, &c)) return rc;
+  if (c.status != GRDMA_PAIR_INITIALIZED)  // Connect() only acts on kInitialized, pair.cc:144
+    return fail(GRDMA_ERR_INVALID, "pair is not in the initialized state (status %u)", c.status);
+  // GPR_ASSERT(peer_.addr_.tag == self_.addr_.tag), pair.cc:146
+  if (peer->addr.tag != 0xa0) return fail(GRDMA_ERR_INVALID, "peer address tag 0x%x, expected 0xa0", peer->addr.tag);
+  // GPR_ASSERT(peer_.addr_.ring_buffer_size == self_.addr_.ring_buffer_size), pair.cc:147-149
+  if (peer->addr.ring_buffer_size != p->ring_size)
+    return fail(GRDMA_ERR_INVALID, "ring sizes differ (mine %llu, peer %llu)", (unsigned long long)p->ring_size,
+                (unsigned long long)peer->addr.ring_buffer_size);
+  if (peer->magic != kBlobMagic || peer->version != GRDMA_ABI_VERSION)
+    return fail(GRDMA_ERR_INVALID, "peer is not a HIP data-plane endpoint of this ABI version");
+  if (peer->pid == (uint64_t)getpid())
+    return fail(GRDMA_ERR_INVALID, "peer lives in this process: use grdma_pair_connect (an IPC handle cannot be opened where it was made)");
+  hipIpcMemHandle_t h;
+  void* ring = nullptr;
+  void* conn = nullptr;
+  memcpy(&h, peer->ring_handle, sizeof(h));
+  HIP_TRY(hipIpcOpenMemHandle(&ring, h, hipIpcMemLazyEnablePeerAccess));
+  memcpy(&h, peer->conn_handle, sizeof(h));
+  hipError_t e = hipIpcOpenMemHandle(&conn, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) {
+    hipIpcCloseMemHandle(ring);
+    return fail(GRDMA_ERR_HIP, "hipIpcOpenMemHandle(peer connection block) failed: %s", hipGetErrorString(e));
+  }
+  p->ipc_ring = ring;
+  p->ipc_conn = conn;
+  p->remote = true;
+  p->remote_status = reinterpret_cast<grdma_status_report*>(static_cast<uint8_t*>(conn) + peer->status_off);
+  c.peer_ring = static_cast<uint8_t*>(ring);
+  c.peer_status = p->remote_status;
+  c.status = GRDMA_PAIR_CONNECTED;
+  HIP_TRY(hipMemcpy(p->d_conn, &c, sizeof(c), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// exchange_data (rdma_bp_posix.cc:640-692): full-duplex swap of sz bytes over a connected socket
+static int exchange_blob(int fd, const char* buf_in, char* buf_out, size_t sz) {
+  size_t sent = 0, got = 0;
+  if (fd < 0) return -1;
+  struct pollfd pfd = {fd, 0, 0};
+  while (got < sz || sent < sz) {
+    pfd.events = (short)((got < sz ? POLLIN : 0) | (sent < sz ? POLLOUT : 0));
+    const int r = poll(&pfd, 1, 30000);
+    if (r == 0) return -2;  // the peer never answered
+    if (r < 0) {
+      if (errno == EINTR) continue;
+      return -1;
+    }
+    if (sent < sz && (pfd.revents & POLLOUT)) {
+      const ssize_t n = ::send(fd, buf_in + sent, sz - sent, MSG_NOSIGNAL);
+      if (n < 0 && errno != EINTR && errno != EAGAIN) return -1;
+      if (n > 0) sent += (size_t)n;
+    }
+    if (got < sz && (pfd.revents & (POLLIN | POLLHUP))) {
+      const ssize_t n = ::recv(fd, buf_out + got, sz - got, 0);
+      if (n == 0) return -3;  // closed before the whole address arrived
+      if (n < 0 && errno != EINTR && errno != EAGAIN) return -1;
+      if (n > 0) got += (size_t)n;
+    }
+  }
+  return 0;
+}
+
+int grdma_pair_bootstrap_fd(grdma_pair* p, int fd) {
+  grdma_bootstrap_blob mine, theirs;
+  if (int rc = grdma_pair_export_address(p, &mine)) return rc;
+  const int x = exchange_blob(fd, reinterpret_cast<const char*>(&mine), reinterpret_cast<char*>(&theirs), sizeof(mine));
+  if (x != 0)
+    return fail(GRDMA_ERR_NOT_CONNECTED, "address exchange over fd %d failed (%s)", fd,
+                x == -2 ? "timeout" : x == -3 ? "peer closed" : strerror(errno));
+  return grdma_pair_connect_remote(p, &theirs);
+}
+
 int grdma_pair_disconnect(grdma_pair* p) {
   if (int rc = require_ctx()) return rc;
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
   grdma_conn c;
   if (int rc = fetch_conn(p, &c)) return rc;
-  if (c.status == GRDMA_PAIR_CONNECTED && p->peer) {
+  if (c.status == GRDMA_PAIR_CONNECTED && (p->peer || p->remote_status)) {
     // peer_exit = 1 in the peer's status buffer, pair.cc:332-336
     int32_t one = 1;
-    uint8_t* dst = reinterpret_cast<uint8_t*>(p->peer->d_conn) +
-                   offsetof(grdma_conn, status_recv) + offsetof(grdma_status_report, peer_exit);
-    HIP_TRY(hipMemcpy(dst, &one, sizeof(one), hipMemcpyHostToDevice));
+    uint8_t* dst = p->peer ? reinterpret_cast<uint8_t*>(p->peer->d_conn) + offsetof(grdma_conn, status_recv)
+                           : reinterpret_cast<uint8_t*>(p->remote_status);
+    HIP_TRY(hipMemcpy(dst + offsetof(grdma_status_report, peer_exit), &one, sizeof(one), hipMemcpyHostToDevice));
   }
   uint32_t st = GRDMA_PAIR_DISCONNECTED;
   HIP_TRY(hipMemcpy(reinterpret_cast<uint8_t*>(p->d_conn) + offsetof(grdma_conn, status), &st,
@@ -1110,6 +1242,10 @@ struct grdma_job_link {
   grdma_plan* d_wireplan2 = nullptr;
   grdma_plan* d_rxplan2 = nullptr;
   uint8_t* d_staging2 = nullptr;
+  // persistent link engine (k_link): control block, the three entry tables, extra staging buffers
+  lk_ctl* d_lk = nullptr;
+  lk_entry* d_tab[3] = {nullptr, nullptr, nullptr};
+  std::vector<uint8_t*> d_staging_more;
 };
 
 struct grdma_stream_job {
@@ -1137,6 +1273,10 @@ struct grdma_stream_job {
   hipStream_t stream = nullptr;
   bool direct = false;
   uint64_t max_ring = 0;
+  // link engine
+  lk_ctl** d_lk_ptrs = nullptr;
+  uint32_t lk_team = 0;
+  uint64_t lk_timeout_ticks = 0;
 };
 
 namespace {
@@ -1341,6 +1481,130 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
   return 0;
 }
 
+// ---- persistent link engine -------------------------------------------------------------------
+// One launch of k_link runs the whole job: per link a team of workgroups (sender's leader,
+// receiver's leader, gather / wire / scatter worker waves) that stay resident until every slice
+// has been delivered.  See grdma_link.h.
+int job_engine_prepare(grdma_stream_job* j) {
+  if (j->d_lk_ptrs) return 0;
+  const uint32_t n = (uint32_t)j->links.size();
+  const uint32_t resident = grdma_link_resident_blocks();
+  if (resident == 0) return fail(GRDMA_ERR_HIP, "occupancy query for the link engine failed");
+  uint32_t cap_blocks = resident;
+  if (const char* e = getenv("GRDMA_LINK_BLOCKS")) {  // tuning knob (tools/, bench legs)
+    const long v = atol(e);
+    if (v > 0 && (uint32_t)v < cap_blocks) cap_blocks = (uint32_t)v;
+  }
+  uint32_t team = cap_blocks / n;
+  if (team < 3) return fail(GRDMA_ERR_CAPACITY, "%u links do not fit the %u resident workgroups of the link engine", n, resident);
+  if (team > 1024) team = 1024;
+  // worker waves per stage: gather : wire : scatter by the bytes they move per payload byte
+  // (2 : 2 : 3; no wire stage when records are built in the peer ring)
+  int mix[3] = {2, j->direct ? 0 : 2, j->direct ? 3 : 3};
+  if (const char* e = getenv("GRDMA_LINK_MIX")) {
+    int a = 0, b = 0, c2 = 0;
+    if (sscanf(e, "%d,%d,%d", &a, &b, &c2) == 3 && a > 0 && c2 > 0 && b >= 0) {
+      mix[0] = a;
+      mix[1] = j->direct ? 0 : (b > 0 ? b : 1);
+      mix[2] = c2;
+    }
+  }
+  const uint32_t waves = (team - 2) * (LK_THREADS / 64);
+  const uint32_t stages = j->direct ? 2 : 3;
+  if (waves < stages) return fail(GRDMA_ERR_CAPACITY, "link engine team of %u workgroups is too small", team);
+  const uint32_t msum = (uint32_t)(mix[0] + mix[1] + mix[2]);
+  uint32_t nw[3];
+  nw[0] = std::max<uint32_t>(1, waves * mix[0] / msum);
+  nw[1] = j->direct ? 0 : std::max<uint32_t>(1, waves * mix[1] / msum);
+  nw[2] = waves - nw[0] - nw[1];
+  if (nw[2] < 1) { nw[2] = 1; if (nw[0] > 1) nw[0]--; }
+  int rate_khz = 0;
+  if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, g_ctx.device) != hipSuccess || rate_khz <= 0)
+    rate_khz = 100000;  // 100 MHz
+  long tmo_ms = 4000;
+  if (const char* e = getenv("GRDMA_LINK_TIMEOUT_MS")) tmo_ms = std::max<long>(10, atol(e));
+  j->lk_timeout_ticks = (uint64_t)rate_khz * (uint64_t)tmo_ms;
+  std::vector<lk_ctl*> ptrs(n);
+  for (uint32_t i = 0; i < n; i++) {
+    grdma_job_link& l = j->links[i];
+    const uint64_t ring = l.tx->ring_size;
+    if (ring > (256ull << 20))
+      return fail(GRDMA_ERR_CAPACITY, "link engine: ring of %llu bytes exceeds 256 MiB", (unsigned long long)ring);
+    HIP_TRY(hipMalloc((void**)&l.d_lk, sizeof(lk_ctl)));
+    for (int t = 0; t < 3; t++) HIP_TRY(hipMalloc((void**)&l.d_tab[t], sizeof(lk_entry) * LK_TABLE_CAP));
+    lk_ctl h;
+    memset(&h, 0, sizeof(h));
+    h.tx = l.tx->d_conn;
+    h.rx = l.rx->d_conn;
+    h.slices = l.d_sges;
+    h.nslices = l.count;
+    {
+      std::vector<grdma_sge> tmp(l.count);
+      HIP_TRY(hipMemcpy(tmp.data(), l.d_sges, sizeof(grdma_sge) * l.count, hipMemcpyDeviceToHost));
+      for (auto& g : tmp) h.total_bytes += g.len;
+    }
+    h.arena = l.dst;
+    h.arena_cap = l.dst_cap;
+    h.out_slices = l.d_slices;
+    h.slices_cap = l.slices_cap;
+    h.direct = j->direct ? 1 : 0;
+    // staging buffers: the sender may run this many Sends ahead of the wire (each Send prices
+    // its records against a whole staging buffer of ring / 2, pair.cc:104)
+    uint32_t nst = 0;
+    if (!j->direct) {
+      uint64_t want = (64ull << 20) / (ring / 2);
+      if (const char* e = getenv("GRDMA_LINK_STAGING")) want = (uint64_t)std::max<long>(1, atol(e));
+      want = std::min<uint64_t>(std::max<uint64_t>(want, 2), LK_MAX_STAGING);
+      h.staging[nst++] = l.tx->d_staging;
+      h.staging[nst++] = l.d_staging2;
+      while (nst < want) {
+        uint8_t* sb = nullptr;
+        HIP_TRY(hipMalloc((void**)&sb, ring / 2 + 64));
+        HIP_TRY(hipMemset(sb, 0, ring / 2 + 64));
+        l.d_staging_more.push_back(sb);
+        h.staging[nst++] = sb;
+      }
+    }
+    h.n_staging = nst ? nst : 1;
+    for (int t = 0; t < 3; t++) {
+      h.tab[t] = l.d_tab[t];
+      h.nwaves[t] = nw[t];
+    }
+    h.timeout_ms = (uint32_t)tmo_ms;
+    HIP_TRY(hipMemcpy(l.d_lk, &h, sizeof(h), hipMemcpyHostToDevice));
+    ptrs[i] = l.d_lk;
+  }
+  HIP_TRY(hipMalloc((void**)&j->d_lk_ptrs, sizeof(lk_ctl*) * n));
+  HIP_TRY(hipMemcpy(j->d_lk_ptrs, ptrs.data(), sizeof(lk_ctl*) * n, hipMemcpyHostToDevice));
+  j->lk_team = team;
+  return 0;
+}
+
+int job_engine_enqueue(grdma_stream_job* j, hipStream_t s) {
+  if (int rc = job_engine_prepare(j)) return rc;
+  // every polled word starts at zero in every launch
+  for (auto& l : j->links)
+    HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t*>(l.d_lk) + LK_DYNAMIC_OFFSET, 0, sizeof(lk_ctl) - LK_DYNAMIC_OFFSET, s));
+  HIP_TRY(grdma_launch_link(j->d_lk_ptrs, (uint32_t)j->links.size(), j->lk_team, j->lk_timeout_ticks, s));
+  return 0;
+}
+
+// after a synchronize: did every link finish cleanly?
+int job_engine_check(grdma_stream_job* j) {
+  for (size_t i = 0; i < j->links.size(); i++) {
+    uint64_t ab = 0;
+    HIP_TRY(hipMemcpy(&ab, reinterpret_cast<uint8_t*>(j->links[i].d_lk) + offsetof(lk_ctl, abort), sizeof(ab), hipMemcpyDeviceToHost));
+    if (ab != 0) {
+      static const char* what[] = {"", "a role timed out waiting", "no progress (zero-length slice at the cursor)",
+                                   "destination buffer too small", "slice table too small",
+                                   "the ring does not hold the records the sender published"};
+      return fail(GRDMA_ERR_HIP, "link engine aborted on link %zu: %s (code %llu)", i, ab <= 5 ? what[ab] : "?",
+                  (unsigned long long)ab);
+    }
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1478,7 +1742,11 @@ void grdma_stream_job_destroy(grdma_stream_job* j) {
     hipFree(l.d_wireplan2);
     hipFree(l.d_rxplan2);
     hipFree(l.d_staging2);
+    hipFree(l.d_lk);
+    for (auto* t : l.d_tab) hipFree(t);
+    for (auto* sb : l.d_staging_more) hipFree(sb);
   }
+  hipFree(j->d_lk_ptrs);
   hipFree(j->d_ctl);
   delete j;
 }
@@ -1520,6 +1788,11 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
     HIP_TRY(hipEventRecord(j->ev0, s));
     HIP_TRY(hipGraphLaunch(j->exec, s));
     HIP_TRY(hipEventRecord(j->ev1, s));
+  } else if (mode == GRDMA_RUN_ENGINE) {
+    if (int rc = job_engine_prepare(j)) return rc;
+    HIP_TRY(hipEventRecord(j->ev0, s));
+    if (int rc = job_engine_enqueue(j, s)) return rc;
+    HIP_TRY(hipEventRecord(j->ev1, s));
   } else {
     HIP_TRY(hipEventRecord(j->ev0, s));
     if (j->pipeline && mode == GRDMA_RUN_EAGER) {
@@ -1530,6 +1803,8 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
     HIP_TRY(hipEventRecord(j->ev1, s));
   }
   HIP_TRY(hipStreamSynchronize(s));
+  if (mode == GRDMA_RUN_ENGINE)
+    if (int rc = job_engine_check(j)) return rc;
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, j->ev0, j->ev1));
   out->ms_total = ms;
@@ -1589,6 +1864,30 @@ int grdma_stream_job_launch(grdma_stream_job* j) {
   return 0;
 }
 
+int grdma_stream_job_launch_engine(grdma_stream_job* j) {
+  if (int rc = require_ctx()) return rc;
+  if (!j) return fail(GRDMA_ERR_INVALID, "null job");
+  return job_engine_enqueue(j, j->stream);
+}
+
+// profiling aid: {Sends, receive chunks, gather / wire / scatter entries, leader wait ticks x 4
+// (sender: staging + slots, credit; receiver: data, scatter), abort code, team, waves x 3}
+int grdma_stream_job_engine_stats(grdma_stream_job* j, uint32_t link, uint64_t out[16]) {
+  if (int rc = require_ctx()) return rc;
+  if (!j || !out || link >= j->links.size() || !j->links[link].d_lk) return fail(GRDMA_ERR_INVALID, "bad argument");
+  HIP_TRY(hipStreamSynchronize(j->stream));
+  lk_ctl h;
+  HIP_TRY(hipMemcpy(&h, j->links[link].d_lk, sizeof(h), hipMemcpyDeviceToHost));
+  memset(out, 0, sizeof(uint64_t) * 16);
+  out[0] = h.res_sends; out[1] = h.res_chunks;
+  for (int t = 0; t < 3; t++) out[2 + t] = h.res_entries[t];
+  for (int t = 0; t < 4; t++) out[5 + t] = h.res_wait_ticks[t];
+  out[9] = h.abort.v; out[10] = j->lk_team;
+  for (int t = 0; t < 3; t++) out[11 + t] = h.nwaves[t];
+  out[14] = h.n_staging;
+  return 0;
+}
+
 int grdma_stream_job_launch_streams(grdma_stream_job* j) {
   if (int rc = require_ctx()) return rc;
   if (!j) return fail(GRDMA_ERR_INVALID, "null job");
@@ -1599,6 +1898,7 @@ int grdma_stream_job_sync(grdma_stream_job* j) {
   if (int rc = require_ctx()) return rc;
   if (!j) return fail(GRDMA_ERR_INVALID, "null job");
   HIP_TRY(hipStreamSynchronize(j->stream));
+  if (j->d_lk_ptrs) return job_engine_check(j);
   return 0;
 }
 

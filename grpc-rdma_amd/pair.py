@@ -111,6 +111,23 @@ class Pair:
     def get_status(self):
         return check(self.lib.grdma_pair_get_status(self.h))
 
+    # -- bootstrap with a peer in another process (rdma_bp_posix.cc:763-784) ------------------
+    BLOB_BYTES = 48 + 32 + 128
+
+    def export_address(self):
+        """-> the bootstrap blob (first 48 bytes = the reference's Address, address.h:24-31)."""
+        buf = C.create_string_buffer(self.BLOB_BYTES)
+        check(self.lib.grdma_pair_export_address(self.h, buf))
+        return buf.raw
+
+    def connect_remote(self, blob):
+        buf = C.create_string_buffer(bytes(blob), self.BLOB_BYTES)
+        check(self.lib.grdma_pair_connect_remote(self.h, buf))
+
+    def bootstrap_fd(self, fd):
+        """exchange_data over a connected socket + Connect()."""
+        check(self.lib.grdma_pair_bootstrap_fd(self.h, fd))
+
     def Disconnect(self):
         check(self.lib.grdma_pair_disconnect(self.h))
 

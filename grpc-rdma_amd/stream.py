@@ -14,7 +14,7 @@ class StreamResult(C.Structure):
                 ("launches_class", u64 * 8)]
 
 
-RUN_EAGER, RUN_GRAPH, RUN_INSTRUMENTED = 0, 1, 2
+RUN_EAGER, RUN_GRAPH, RUN_INSTRUMENTED, RUN_ENGINE = 0, 1, 2, 3
 CLASS_NAMES = ["tx_plan", "gather", "wire", "rx_plan", "rx_apply"]
 
 _bound = False
@@ -40,6 +40,8 @@ def _bind():
                                                       C.POINTER(u64), C.POINTER(u64), u64]
         lib.grdma_stream_job_slices_of.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(ReadSlice), u64]
         lib.grdma_stream_job_sync.argtypes = [C.c_void_p]
+        lib.grdma_stream_job_launch_engine.argtypes = [C.c_void_p]
+        lib.grdma_stream_job_engine_stats.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(u64)]
         _bound = True
     return lib
 
@@ -76,6 +78,17 @@ class StreamJob:
 
     def sync(self):
         check(self.lib.grdma_stream_job_sync(self.h))
+
+    def launch_engine(self):
+        check(self.lib.grdma_stream_job_launch_engine(self.h))
+
+    def engine_stats(self, link=0):
+        out = (u64 * 16)()
+        check(self.lib.grdma_stream_job_engine_stats(self.h, link, out))
+        names = ["sends", "chunks", "gather_entries", "wire_entries", "scatter_entries", "tx_wait_slots",
+                 "tx_wait_credit", "rx_wait_data", "rx_wait_scatter", "abort", "team", "gather_waves",
+                 "wire_waves", "scatter_waves", "staging_buffers"]
+        return {k: int(out[i]) for i, k in enumerate(names)}
 
     def delivered_slices(self, link=0):
         arr = (ReadSlice * self.slices_cap)()

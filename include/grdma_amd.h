@@ -104,6 +104,33 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags);
  * bring-up (rdma_bp_posix.cc:767-771, pair.cc:143-168).  Both ends must use the
  * same ring size (asserted at pair.cc:149). */
 int grdma_pair_connect(grdma_pair* a, grdma_pair* b);
+/* Bootstrap between processes / GPUs.  The reference swaps a 48-byte Address over the TCP fd
+ * (exchange_data, rdma_bp_posix.cc:640-692,767-771; layout address.h:24-31), checks tag and ring
+ * size in Connect() (pair.cc:143-149), brings the QP up and swaps the memory regions of ring and
+ * status buffer (syncMemoryRegion).  Here the memory region of an HBM ring is a HIP IPC handle
+ * (the same allocation exports as a dma-buf for a NIC); both travel in one blob whose first 48
+ * bytes are the reference's Address.  export -> send/recv over any byte channel -> connect_remote,
+ * or grdma_pair_bootstrap_fd() which does all three over a connected socket like
+ * grpc_rdma_bp_create does (rdma_bp_posix.cc:763-784). */
+typedef struct grdma_address {          /* address.h:24-31 (48 bytes, natural alignment)          */
+  uint32_t lid, qpn, psn, pad0;
+  uint8_t gid[16];                      /* union ibv_gid; here: PCI bus id of the HIP device      */
+  uint32_t tag, pad1;                   /* 0xa0: peers must agree (pair.cc:72,146)                */
+  uint64_t ring_buffer_size;            /* peers must agree (pair.cc:107,147-149)                 */
+} grdma_address;
+typedef struct grdma_bootstrap_blob {
+  grdma_address addr;
+  uint32_t magic, version;              /* "GRDM", GRDMA_ABI_VERSION                              */
+  int32_t hip_device;
+  uint32_t pad;
+  uint64_t pid;
+  uint64_t status_off;                  /* offset of the 16-byte status_report in the conn block  */
+  uint8_t ring_handle[64];              /* hipIpcMemHandle_t of the ring                          */
+  uint8_t conn_handle[64];              /* hipIpcMemHandle_t of the connection block              */
+} grdma_bootstrap_blob;
+int grdma_pair_export_address(grdma_pair* p, grdma_bootstrap_blob* out);
+int grdma_pair_connect_remote(grdma_pair* p, const grdma_bootstrap_blob* peer);
+int grdma_pair_bootstrap_fd(grdma_pair* p, int fd);
 int grdma_pair_disconnect(grdma_pair* p);          /* Disconnect(), pair.cc:325-347 */
 void grdma_pair_destroy(grdma_pair* p);
 int grdma_pair_get_status(grdma_pair* p);          /* get_status(), pair.cc:349-375 */
@@ -222,7 +249,13 @@ typedef struct grdma_stream_result {
   double ms_class[8];          /* instrumented mode: summed kernel time per class  */
   uint64_t launches_class[8];  /*   0 tx_plan 1 gather 2 wire 3 rx_plan 4 rx_apply (scatter+zero+credit) */
 } grdma_stream_result;
-enum grdma_stream_mode { GRDMA_RUN_EAGER = 0, GRDMA_RUN_GRAPH = 1, GRDMA_RUN_INSTRUMENTED = 2 };
+enum grdma_stream_mode {
+  GRDMA_RUN_EAGER = 0, GRDMA_RUN_GRAPH = 1, GRDMA_RUN_INSTRUMENTED = 2,
+  /* ONE launch of the persistent link engine (k_link): sender, wire and receiver of every link
+   * run concurrently as resident workgroups that hand work to each other through memory, like
+   * two hosts and a NIC; deterministic, equal to the sequential rounds (see csrc/grdma_link.h) */
+  GRDMA_RUN_ENGINE = 3
+};
 
 grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,
                                           const grdma_slice* slices, uint64_t count,
@@ -243,6 +276,9 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
 /* Asynchronous form for timed loops: enqueue one pass (the captured graph) on
  * the link's stream without reading any state back; _sync() waits for it. */
 int grdma_stream_job_launch(grdma_stream_job* j);
+/* Same work as one GRDMA_RUN_ENGINE pass, enqueued without waiting (timed loops). */
+int grdma_stream_job_launch_engine(grdma_stream_job* j);
+int grdma_stream_job_engine_stats(grdma_stream_job* j, uint32_t link, uint64_t out[16]);
 /* Same work as _launch, issued kernel by kernel on the job's streams (no graph). */
 int grdma_stream_job_launch_streams(grdma_stream_job* j);
 int grdma_stream_job_sync(grdma_stream_job* j);

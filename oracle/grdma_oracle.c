@@ -795,3 +795,72 @@ uint64_t orc_stream_baseline(uint64_t ring_cap, int max_sge, const uint8_t* wire
   orc_pair_destroy(&b);
   return delivered;
 }
+
+/* The sequential schedule the device-resident jobs are checked against, entirely in C so that
+ * the bench-sized configurations (tens of thousands of slices) take milliseconds: per pass, one
+ * Send from the rdma_flush cursor (rdma_bp_posix.cc:470-524), then endpoint reads until one
+ * would block (:180-291); `passes` passes over the same link.  Reports the delivered slice
+ * lengths of the LAST pass, the Sends of the FIRST pass that produced a record, whether every
+ * delivered byte equals the input stream, whether the receiver's ring ended all zero, and the
+ * state words {remote_tail, remote_head, partial_write, head, moving_head, remain,
+ * internal_read_size, credit_msgs(rx), leftover_cap}. */
+int orc_stream_rounds(uint64_t ring_cap, int max_sge, const uint8_t* wire, const uint64_t* lens,
+                      uint64_t nslices, int passes, uint64_t* out_lens, uint64_t out_cap,
+                      uint64_t* n_out, uint64_t* first_rounds, uint64_t state[9], int* stream_ok,
+                      int* ring_zero) {
+  orc_pair a, b;
+  if (orc_pair_init(&a, ring_cap, max_sge) || orc_pair_init(&b, ring_cap, max_sge)) return -1;
+  orc_pair_connect(&a, &b);
+  orc_slice* sl = (orc_slice*)malloc(sizeof(orc_slice) * (nslices ? nslices : 1));
+  uint8_t* dst = (uint8_t*)malloc(ring_cap);
+  uint64_t off = 0;
+  for (uint64_t i = 0; i < nslices; i++) {
+    sl[i].ptr = wire + off;
+    sl[i].len = lens[i];
+    off += lens[i];
+  }
+  int ok = 1, rc = 0;
+  *first_rounds = 0;
+  for (int p = 0; p < passes && rc == 0; p++) {
+    uint64_t idx = 0, byte_idx = 0, rounds = 0, n = 0, pos = 0;
+    while (idx < nslices) {
+      uint64_t sent = orc_pair_send(&a, sl + idx, nslices - idx, byte_idx);
+      if (sent) rounds++;
+      while (sent > 0) {
+        uint64_t sl_len = sl[idx].len - byte_idx;
+        if (sent >= sl_len) { sent -= sl_len; idx++; byte_idx = 0; }
+        else { byte_idx += sent; sent = 0; }
+      }
+      for (;;) {
+        uint64_t alloc;
+        uint64_t got = orc_endpoint_read(&b, dst, &alloc);
+        if (got == 0) break;
+        if (memcmp(dst, wire + pos, got) != 0) ok = 0;
+        pos += got;
+        if (p == passes - 1) {
+          if (n >= out_cap) { rc = -2; break; }
+          out_lens[n] = got;
+        }
+        n++;
+      }
+      if (rc) break;
+      if (rounds > (1ull << 24)) { rc = -3; break; }
+    }
+    if (pos != off) ok = 0;
+    if (p == 0) *first_rounds = rounds;
+    *n_out = n;
+  }
+  state[0] = a.remote_tail; state[1] = a.status_recv.remote_head; state[2] = (uint64_t)a.partial_write;
+  state[3] = b.ring.head; state[4] = b.ring.moving_head; state[5] = b.ring.remain;
+  state[6] = b.internal_read_size; state[7] = b.credit_msgs; state[8] = b.leftover_cap;
+  int zero = 1;
+  for (uint64_t i = 0; i < ring_cap; i++)
+    if (b.ring.buf[i]) { zero = 0; break; }
+  *stream_ok = ok;
+  *ring_zero = zero;
+  free(sl);
+  free(dst);
+  orc_pair_destroy(&a);
+  orc_pair_destroy(&b);
+  return rc;
+}

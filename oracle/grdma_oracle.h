@@ -225,6 +225,13 @@ uint64_t orc_stream_baseline(uint64_t ring_cap, int max_sge, const uint8_t* wire
                              const uint64_t* lens, uint64_t nslices, uint64_t n_msgs,
                              double* seconds, uint64_t* checksum);
 
+/* The sequential schedule (one Send from the cursor, endpoint reads until one would block),
+ * `passes` times over one link; see the definition for what is reported. */
+int orc_stream_rounds(uint64_t ring_cap, int max_sge, const uint8_t* wire, const uint64_t* lens,
+                      uint64_t nslices, int passes, uint64_t* out_lens, uint64_t out_cap,
+                      uint64_t* n_out, uint64_t* first_rounds, uint64_t state[9], int* stream_ok,
+                      int* ring_zero);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,81 @@
+"""GPU: a client PROCESS and a server PROCESS connected the way grpc_rdma_bp_create connects
+them (48-byte Address + memory-region exchange over a socket, rdma_bp_posix.cc:640-692,763-784;
+pair.cc:143-168), then the endpoint conformance grid of the reference
+(test/core/iomgr/endpoint_tests.cc:341-355) echoed byte-identically across the process
+boundary.  The rings live in HBM; each end's one-sided writes land in the other process's ring
+through the HIP IPC mapping of that allocation."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PEER = os.path.join(ROOT, "tests", "two_proc_peer.py")
+
+
+def run_pair(ring_kib, num_bytes, write_size, slice_size, devs=(0, 0)):
+    a, b = socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM)
+    procs = []
+    for role, sock, dev in (("server", a, devs[0]), ("client", b, devs[1])):
+        os.set_inheritable(sock.fileno(), True)
+        procs.append(subprocess.Popen(
+            [sys.executable, PEER, role, str(sock.fileno()), str(dev), str(ring_kib), str(num_bytes),
+             str(write_size), str(slice_size)],
+            pass_fds=[sock.fileno()], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    a.close()
+    b.close()
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        assert rc == 0, "peer failed:\n" + o + e[-3000:]
+    return outs
+
+
+@pytest.mark.parametrize("ring_kib,num_bytes,write_size,slice_size", [
+    (4096, 2000000, 100000, 8192),    # endpoint_tests.cc:345 scaled 5x down, reference-default 4 MiB ring
+    (4096, 20160, 10000, 1),          # :346 scaled: 1-byte slices, one ring record each
+    (64, 500000, 100000, 8192),       # small ring: every write parks on credit several times
+    (4096, 40320, 777, 777),          # one point of the write = slice sweep (:350-352)
+])
+def test_echo_between_two_processes(gpu, ring_kib, num_bytes, write_size, slice_size):
+    outs = run_pair(ring_kib, num_bytes, write_size, slice_size)
+    assert "ok server" in outs[0][1] and "ok client" in outs[1][1]
+
+
+def test_echo_between_two_gpus(gpu):
+    lib = gpu.load()
+    if lib.grdma_device_count() < 2:
+        pytest.skip("one GPU visible: the cross-GPU (xGMI) case needs two")
+    outs = run_pair(4096, 2000000, 100000, 8192, devs=(0, 1))
+    assert "ok server" in outs[0][1] and "ok client" in outs[1][1]
+
+
+def test_connect_checks_of_the_reference(gpu):
+    """Connect() asserts equal tag and equal ring size (pair.cc:146-149); a handle cannot be
+    opened in the process that made it."""
+    g = gpu
+    a, b = g.Pair(1 << 20, 30), g.Pair(2 << 20, 30)
+    blob = bytearray(b.export_address())
+    assert len(blob) == 208 and blob[32] == 0xA0
+    assert int.from_bytes(blob[40:48], "little") == 2 << 20
+    with pytest.raises(g.GrdmaError, match="ring sizes differ"):
+        a.connect_remote(bytes(blob))
+    c = g.Pair(1 << 20, 30)
+    blob = bytearray(c.export_address())
+    with pytest.raises(g.GrdmaError, match="this process"):
+        a.connect_remote(bytes(blob))
+    blob[32] = 0xA1
+    with pytest.raises(g.GrdmaError, match="tag"):
+        a.connect_remote(bytes(blob))
+    assert a.get_status() == 1  # still kInitialized

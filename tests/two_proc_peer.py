@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""One end of a two-PROCESS connection (helper of tests/test_gpu_two_process.py).
+
+usage: two_proc_peer.py <client|server> <fd> <hip_device> <ring_kib> <num_bytes> <write_size> <slice_size>
+
+Bootstraps a pair over the inherited socket fd exactly like grpc_rdma_bp_create does
+(exchange_data + Connect, rdma_bp_posix.cc:763-784), then runs the reference's endpoint
+conformance shape (test/core/iomgr/endpoint_tests.cc:341-355: a stream of bytes i % 256 written
+in `write_size` pieces of `slice_size` slices) client -> server, echoed back server -> client and
+byte-checked on return.  Prints one line 'ok ...' and exits 0, or exits non-zero."""
+import ctypes as C
+import os
+import sys
+import time
+from collections import deque
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import grpc_rdma_amd as g  # noqa: E402
+from grpc_rdma_amd._lib import ReadSlice, Slice, check  # noqa: E402
+
+
+class Writer:
+    """rdma_write + rdma_flush retries, non-blocking: one Send per step()."""
+
+    def __init__(self, pair):
+        self.pair, self.lib, self.active, self.keep = pair, pair.lib, False, None
+
+    def begin(self, slices):
+        arr, keep, _ = g.Pair._slices(slices)
+        self.keep = (arr, keep)          # the pair reads these buffers until the write is done
+        check(self.lib.grdma_endpoint_write_begin(self.pair.h, arr, len(slices), 1))
+        self.active = True
+
+    def step(self):
+        done = C.c_int(0)
+        n = check(self.lib.grdma_endpoint_write_step(self.pair.h, C.byref(done)))
+        if done.value:
+            self.active, self.keep = False, None
+        return n
+
+
+def main():
+    role, fd, dev, ring_kib, num_bytes, write_size, slice_size = sys.argv[1], *map(int, sys.argv[2:8])
+    g.init(dev)
+    pair = g.Pair(ring_kib * 1024, 30)
+    pair.bootstrap_fd(fd)
+    assert pair.get_status() == 2
+    w = Writer(pair)
+    deadline = time.time() + 240
+    if role == "client":
+        writes, pos = deque(), 0
+        while pos < num_bytes:
+            n = min(write_size, num_bytes - pos)
+            data = bytes((pos + i) & 0xFF for i in range(n))
+            sl = [data[o:o + slice_size] for o in range(0, n, slice_size)]
+            for o in range(0, len(sl), 4000):   # the ABI takes at most 4095 slices per write context
+                writes.append(sl[o:o + 4000])   # (grdma_endpoint.cc windows a slice buffer the same way)
+            pos += n
+        got, nslices = bytearray(), 0
+        while len(got) < num_bytes:
+            assert time.time() < deadline, "client timed out at %d/%d" % (len(got), num_bytes)
+            if not w.active and writes:
+                w.begin(writes.popleft())
+            if w.active:
+                w.step()
+            sl, _ = pair.endpoint_read(256)
+            nslices += len(sl)
+            for s in sl:
+                got += s
+        assert len(got) == num_bytes
+        bad = next((i for i in range(num_bytes) if got[i] != (i & 0xFF)), None)
+        assert bad is None, "echo differs at byte %d" % bad
+        assert pair.ring_mem() == bytes(ring_kib * 1024), "client ring not zero after the echo"
+        pair.Disconnect()
+        print("ok client %d bytes echoed in %d slices" % (num_bytes, nslices))
+    else:
+        pending, echoed, seen = deque(), 0, 0
+        while echoed < num_bytes:
+            assert time.time() < deadline, "server timed out at %d/%d" % (echoed, num_bytes)
+            sl, _ = pair.endpoint_read(256)
+            for s in sl:
+                # (records are the client's slices; small ones share a 256-byte read, rdma_bp_posix.cc:306-317)
+                assert all(b == ((seen + i) & 0xFF) for i, b in enumerate(s))
+                seen += len(s)
+                pending.append(s)
+            if not w.active and pending:
+                batch = [pending.popleft() for _ in range(min(len(pending), 2000))]
+                w.batch_bytes = sum(len(b) for b in batch)
+                w.begin(batch)
+            if w.active:
+                w.step()
+                if not w.active:
+                    echoed += w.batch_bytes
+        # the client disconnects when it has everything: this end turns half closed (pair.cc:349-356)
+        for _ in range(2000):
+            if pair.get_status() == 3:
+                break
+            time.sleep(0.005)
+        assert pair.get_status() == 3, "server never saw the peer exit"
+        print("ok server %d bytes echoed" % num_bytes)
+    pair.close()
+
+
+if __name__ == "__main__":
+    main()
