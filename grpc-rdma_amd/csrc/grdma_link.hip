@@ -242,6 +242,13 @@ __device__ __forceinline__ void lk_worker(lk_ctl* L, int stage, uint32_t w, uint
 // entry emission: every lane brings up to NP pieces {dst, src, len, flags, aux}; pieces longer
 // than LK_ENTRY_MAX are cut.  lk_count() first (table space), then lk_emit().
 // ---------------------------------------------------------------------------------------------
+// 16-byte write-through (sc1) store to a global address: the buffer builtins need a descriptor, so
+// this one is inline asm; the trailing s_nop keeps the data registers intact until the store
+// has read them (the compiler does not model the instruction)
+__device__ __forceinline__ void lk_st16(__attribute__((address_space(1))) u32x4* p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 struct lk_piece {
   uint64_t dst, src;
   uint64_t len;
@@ -255,11 +262,14 @@ __device__ __forceinline__ uint32_t lk_sub_entries(uint64_t len) {
 
 __device__ __forceinline__ void lk_store_entry(lk_entry* tab, uint64_t idx, uint64_t dst, uint64_t src,
                                                uint32_t len, uint32_t flags, uint64_t aux) {
-  uint64_t* q = reinterpret_cast<uint64_t*>(tab + (idx & (LK_TABLE_CAP - 1)));
-  stw(q, dst);
-  stw(q + 1, src);
-  stw(q + 2, (uint64_t)len | ((uint64_t)flags << 32));
-  stw(q + 3, aux);  // (8-byte write-through stores; a reader takes the entry only after the published count covers it)
+  // two 16-byte write-through stores (8-byte sc1 stores cost 2.7x per byte and one fabric
+  // write each); a reader takes the entry only after the published count covers it
+  typedef __attribute__((address_space(1))) u32x4 g_q;
+  g_q* q = (g_q*)(uint64_t)(tab + (idx & (LK_TABLE_CAP - 1)));
+  const u32x4 a = {(uint32_t)dst, (uint32_t)(dst >> 32), (uint32_t)src, (uint32_t)(src >> 32)};
+  const u32x4 b = {len, flags, (uint32_t)aux, (uint32_t)(aux >> 32)};
+  lk_st16(q, a);
+  lk_st16(q + 1, b);
 }
 
 template <int NP>
@@ -324,14 +334,43 @@ __device__ __forceinline__ void lk_emit(lk_entry* tab, uint64_t base, const lk_p
 }
 
 // ---------------------------------------------------------------------------------------------
-// TX leader: PairPollable::Send (pair.cc:645-734) + the rdma_flush cursor
-// (rdma_bp_posix.cc:476-493), one Send per iteration, 64 records priced per step:
-// enc_i = 16 + round_up8(len_i) prefix-summed on the DPP network, every record tests its own
-// budget pay_i = min(len_i, W(S - st_i), W(free0 - st_i)) assuming the earlier ones went out
-// whole, a ballot finds the first short record -- where the reference's loop stops
-// (SURVEY.md Appendix A.4).
+// Leaders.  Both run on ONE wavefront (no cross-wave barriers inside a resident kernel), but
+// every lane owns a contiguous RUN of up to 16 records per step, kept in LDS: the per-record
+// work is a short serial loop in registers, and the wave-wide steps (DPP prefix sums, ballots)
+// are paid once per 1024 records instead of once per 64.
 // ---------------------------------------------------------------------------------------------
-__device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, int lane) {
+#define LK_RUN 16                  // records per lane per step
+#define LK_STEP (64 * LK_RUN)      // records per step
+#define LKP(i) ((i) + ((i) >> 4))  // LDS index padding: runs of 16 would otherwise share banks
+#define LK_QCAP 2560               // verified-record queue of the receiver (>= LK_STEP + one probe round)
+#define LK_PROBE_GROUPS 8          // x 64 speculative probes per memory round trip
+
+struct lk_tx_lds {
+  uint32_t len[LKP(LK_STEP) + 2];  // priced length of each slice of the step (clamped)
+  uint64_t ptr[LKP(LK_STEP) + 2];
+};
+struct lk_rx_lds {
+  uint32_t q[LKP(LK_QCAP) + 2];      // payload sizes of verified records, [q_head, q_tail)
+  uint32_t xenc[LKP(LK_STEP) + 2];   // ring offset of each record of the step behind `head`
+  uint16_t sin[LKP(LK_STEP) + 2];    // space left in the open 256-byte read when the record starts
+};
+union lk_lds {
+  lk_tx_lds tx;
+  lk_rx_lds rx;
+};
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
+}
+
+// ---------------------------------------------------------------------------------------------
+// TX leader: PairPollable::Send (pair.cc:645-734) + the rdma_flush cursor
+// (rdma_bp_posix.cc:476-493), one Send per iteration.  All records of a step are priced at once:
+// enc_i = 16 + round_up8(len_i) prefix-summed, every record tests its own budget
+// pay_i = min(len_i, W(S - st_i), W(free0 - st_i)) assuming the earlier ones went out whole, a
+// ballot finds the first short record -- where the reference's loop stops.
+// ---------------------------------------------------------------------------------------------
+__device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) {
   grdma_conn* c = L->tx;
   const uint64_t cap = c->cap, mask = cap - 1, S = c->staging_cap;
   uint32_t max_sge = c->max_sge;
@@ -351,23 +390,11 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, int lane) {
   uint32_t partial = (uint32_t)c->partial_write, last_records = 0;
   // in-flight Sends, one per lane: lane j keeps what the Send in slot j published
   uint32_t my_ng = 0, my_nw = 0;
-  uint64_t wait_slot = 0, wait_credit = 0;
+  uint64_t wait_slot = 0, wait_credit = 0, t_price = 0, t_pub = 0;
+  uint64_t tph[4] = {0, 0, 0, 0};  // profiling aid: load, price, count, emit
+  const uint64_t t_begin = wall_clock64();
+  const bool eager = L->eager_credit != 0;
   bool failed = false;
-
-  // the slice table is read one 64-record chunk ahead of the pricing: the loads are issued as
-  // soon as the next cursor is known and have landed by the time the chunk is priced
-  uint64_t pf_base = ~0ull, pf_len = 0, pf_ptr = 0;
-  auto prefetch = [&](uint64_t base) {
-    const uint64_t i = base + lane;
-    pf_len = 0;
-    pf_ptr = 0;
-    if (i < nslices) {
-      const grdma_sge g = slices[i];
-      pf_len = g.len;
-      pf_ptr = (uint64_t)g.ptr;
-    }
-    pf_base = base;
-  };
 
   auto retire_oldest = [&]() -> bool {
     // the oldest Send in flight has left its staging buffer: gathered and on the wire
@@ -398,9 +425,9 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, int lane) {
         if (!lk_spin(L, ticks, [&]() { return ldw(&L->rx_sends_seen.v) >= need; })) { failed = true; break; }
       }
       uint8_t* const sbuf = direct ? nullptr : L->staging[k % B];
-      uint64_t st_base, nrec, sent, whole_records;
-      uint32_t ents;
-      uint64_t short_pay_total;
+      uint64_t st_base = 0, nrec = 0, sent = 0, whole_records = 0, short_pay_total = 0;
+      uint32_t ents = 0;
+      const uint64_t tp0 = wall_clock64();
       for (;;) {  // pricing attempts of Send k
         // how far the receiver is, then the credit it granted (get_remote_head(), pair.h:229-233):
         // in this order, so that "caught up" implies every credit report is in
@@ -408,81 +435,156 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, int lane) {
         const uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const uint64_t free0 = cap - ((tail + cap - rhead) & mask);
         const uint64_t room0 = S < free0 ? S : free0;
+        // lengths are clamped for pricing: whatever exceeds the budget is short anyway
+        const uint32_t clampv = (uint32_t)(room0 + 64);
         st_base = 0; nrec = 0; sent = 0; whole_records = 0; ents = 0; short_pay_total = 0;
         bool shorted = false;
-        for (bool stop = false; !stop;) {
-          const uint64_t i = idx + nrec + lane, rec_no = nrec + lane;
-          const bool valid = i < nslices && rec_no < max_sge;
-          if (pf_base != idx + nrec) prefetch(idx + nrec);
-          uint64_t len = 0, src = 0;
-          if (valid) {
-            len = pf_len;
-            src = pf_ptr;
-            if (rec_no == 0) {  // the first slice continues at outgoing_byte_idx
-              len = sat_sub(len, bidx);
-              src += bidx;
+        for (bool stop = false; !stop && !failed;) {
+          // ---- this step's slices -> LDS (striped loads, all in flight together)
+          const uint64_t first = idx + nrec;
+          uint64_t m64 = nslices - first;
+          if (m64 > max_sge - nrec) m64 = max_sge - nrec;
+          if (m64 > LK_STEP) m64 = LK_STEP;
+          const uint32_t m = (uint32_t)m64;
+          const uint64_t tq0 = wall_clock64();
+          {
+            grdma_sge g[LK_RUN];
+#pragma unroll
+            for (int r = 0; r < LK_RUN; r++) {
+              const uint32_t i = r * 64 + lane;
+              g[r] = slices[first + (i < m ? i : m - 1)];
+            }
+#pragma unroll
+            for (int r = 0; r < LK_RUN; r++) {
+              const uint32_t i = r * 64 + lane;
+              uint64_t len = g[r].len, ptr = (uint64_t)g[r].ptr;
+              if (nrec == 0 && i == 0) {  // the first slice continues at outgoing_byte_idx
+                len = sat_sub(len, bidx);
+                ptr += bidx;
+              }
+              if (i < m) {
+                D->len[LKP(i)] = len < clampv ? (uint32_t)len : clampv;
+                D->ptr[LKP(i)] = ptr;
+              }
             }
           }
-          // (clamped so that sums cannot overflow; anything above 2 * cap cannot fit anyway)
-          const uint32_t enc = valid ? (uint32_t)enc_size(len < (cap << 1) ? len : (cap << 1)) : 0;
-          // rings in the engine are at most 256 MiB, 64 records of at most 2 * cap: 32 bits do
-          const uint32_t incl = wave_incl_scan_u32(enc);
-          const uint64_t st = st_base + incl - enc;
-          const bool shortf = valid && (len == 0 || len > writable_of(sat_sub(room0, st)));
-          const uint64_t bm = __ballot(shortf);
-          const uint32_t nv = (uint32_t)__builtin_popcountll(__ballot(valid));
-          const uint32_t take = bm ? (uint32_t)__builtin_ctzll(bm) : nv;
+          const uint32_t per = (m + 63) / 64;
+          const uint32_t k0 = lane * per, k1 = k0 + per < m ? k0 + per : m;
+          const uint64_t tq1 = wall_clock64();
+          // ---- where each run starts in the staging buffer (units of 8 bytes, saturating:
+          // a run that alone exceeds the budget ends the Send inside it)
+          uint64_t chunk = 0;
+          for (uint32_t q = k0; q < k1; q++) chunk += enc_size(D->len[LKP(q)]);
+          const uint32_t chunk8 = (uint32_t)((chunk < (uint64_t)clampv + 64 ? chunk : (uint64_t)clampv + 64) >> 3);
+          const uint32_t incl8 = wave_incl_scan_u32(chunk8);
+          const uint64_t st_run = st_base + ((uint64_t)(incl8 - chunk8) << 3);
+          // ---- first short record of my run
+          uint32_t my_short = 0xFFFFFFFFu;
+          uint64_t st_short = 0;
+          {
+            uint64_t st = st_run;
+            for (uint32_t q = k0; q < k1; q++) {
+              const uint32_t l = D->len[LKP(q)];
+              // a zero payload ends the send exactly like the reference's `break`
+              if (l == 0 || l > writable_of(sat_sub(room0, st))) {
+                my_short = q;
+                st_short = st;
+                break;
+              }
+              st += enc_size(l);
+            }
+          }
+          const uint64_t bm = __ballot(my_short != 0xFFFFFFFFu);
+          uint32_t take = m;
           uint64_t short_pay = 0;
           if (bm) {
             const int f = __builtin_ctzll(bm);
-            const uint64_t lf = __shfl(len, f, 64), stf = __shfl(st, f, 64);
+            take = __shfl(my_short, f, 64);
+            const uint64_t stf = __shfl(st_short, f, 64);
+            const uint64_t lf = D->len[LKP(take)];
             const uint64_t a = writable_of(sat_sub(S, stf)), b = writable_of(sat_sub(free0, stf));
             short_pay = lf;
             if (a < short_pay) short_pay = a;
             if (b < short_pay) short_pay = b;
             shorted = true;
           }
-          const uint64_t my_pay = (uint32_t)lane < take ? len : ((bm && (uint32_t)lane == take) ? short_pay : 0);
-          // the record of this lane as copy pieces: the payload goes behind the 8-byte header at
-          // staging + st (or straight into the peer ring, where it may cross the ring end)
-          lk_piece pc[2];
-          pc[0] = {0, 0, 0, 0, 0};
-          pc[1] = {0, 0, 0, 0, 0};
-          if (my_pay) {
-            const uint32_t tagw = (uint32_t)GRDMA_SEG_TAG_WRITE;
-            if (direct) {
-              const uint64_t pay_off = (tail + st + 8) & mask;
-              if (pay_off + my_pay > cap) {
-                const uint64_t l1 = cap - pay_off;
-                pc[0] = {(uint64_t)(peer_ring + pay_off), src, l1, tagw | (uint32_t)GRDMA_SEG_TAG_HDR, my_pay};
-                pc[1] = {(uint64_t)peer_ring, src + l1, my_pay - l1, tagw | (uint32_t)GRDMA_SEG_TAG_FTR, my_pay};
-              } else {
-                pc[0] = {(uint64_t)(peer_ring + pay_off), src, my_pay,
-                         tagw | (uint32_t)(GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR), my_pay};
-              }
-            } else {
-              pc[0] = {(uint64_t)(sbuf + st + 8), src, my_pay, tagw | (uint32_t)(GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR), my_pay};
+          const uint32_t nr = take + (short_pay ? 1u : 0u);  // records of this step
+          const uint64_t tq2 = wall_clock64();
+          // ---- entries: count, make room, emit
+          uint32_t my_cnt = 0, my_sent = 0, my_enc = 0;
+          for (uint32_t q = k0; q < k1 && q < nr; q++) {
+            const uint32_t pay = q < take ? D->len[LKP(q)] : (uint32_t)short_pay;
+            my_cnt += lk_sub_entries(pay);
+            my_sent += pay;
+            my_enc += (uint32_t)enc_size(pay);
+          }
+          if (direct) {
+            // a record that crosses the ring end is cut there: one more entry (at most one record per Send)
+            uint64_t st = st_run;
+            for (uint32_t q = k0; q < k1 && q < nr; q++) {
+              const uint32_t pay = q < take ? D->len[LKP(q)] : (uint32_t)short_pay;
+              const uint64_t po = (tail + st + 8) & mask;
+              if (po + pay > cap) my_cnt += lk_sub_entries(cap - po) + lk_sub_entries(pay - (cap - po)) - lk_sub_entries(pay);
+              st += enc_size(pay);
             }
           }
-          const uint32_t n_new = lk_count<2>(pc);
+          const uint32_t i_cnt = wave_incl_scan_u32(my_cnt);
+          const uint32_t n_new = (uint32_t)__builtin_amdgcn_readlane((int)i_cnt, 63);
           while (gpub + ents + n_new - gfloor > LK_TABLE_CAP)
             if (!retire_oldest()) { failed = true; break; }
           if (failed) break;
-          lk_emit<2>(gtab, gpub + ents, pc, slot, lane);
+          const uint64_t tq3 = wall_clock64();
+          {
+            uint64_t st = st_run;
+            uint64_t at = gpub + ents + i_cnt - my_cnt;
+            const uint32_t tagw = (uint32_t)GRDMA_SEG_TAG_WRITE | (slot << 8);
+            for (uint32_t q = k0; q < k1 && q < nr; q++) {
+              const uint32_t pay = q < take ? D->len[LKP(q)] : (uint32_t)short_pay;
+              const uint64_t src = D->ptr[LKP(q)];
+              // the payload goes behind the 8-byte header at staging + st (or straight into the
+              // peer ring, where it may cross the ring end)
+              uint64_t dst0;
+              uint32_t l0 = pay, l1 = 0;
+              if (direct) {
+                const uint64_t po = (tail + st + 8) & mask;
+                dst0 = (uint64_t)(peer_ring + po);
+                if (po + pay > cap) {
+                  l0 = (uint32_t)(cap - po);
+                  l1 = pay - l0;
+                }
+              } else {
+                dst0 = (uint64_t)(sbuf + st + 8);
+              }
+              // piece 0 (and piece 1 behind the ring end), each cut into entries
+              for (int pi = 0; pi < 2; pi++) {
+                const uint32_t pl = pi ? l1 : l0;
+                if (pl == 0) continue;
+                const uint64_t pd = pi ? (uint64_t)peer_ring : dst0, ps = pi ? src + l0 : src;
+                const uint32_t nsub = lk_sub_entries(pl);
+                for (uint32_t j = 0; j < nsub; j++) {
+                  const uint32_t o = j * LK_ENTRY_MAX;
+                  const uint32_t len = pl - o < LK_ENTRY_MAX ? pl - o : LK_ENTRY_MAX;
+                  uint32_t fl = tagw;
+                  if (pi == 0 && j == 0) fl |= (uint32_t)GRDMA_SEG_TAG_HDR;
+                  if ((pi == 1 || l1 == 0) && j == nsub - 1) fl |= (uint32_t)GRDMA_SEG_TAG_FTR;
+                  lk_store_entry(gtab, at, pd + o, ps + o, len, fl, pay);
+                  at++;
+                }
+              }
+              st += enc_size(pay);
+            }
+          }
           ents += n_new;
-          const uint64_t whole_enc = take ? (uint64_t)__shfl(incl, (int)take - 1, 64) : 0;
-          st_base += whole_enc + (short_pay ? enc_size(short_pay) : 0);
-          nrec += take + (short_pay ? 1u : 0u);
+          {
+            const uint64_t tq4 = wall_clock64();
+            tph[0] += tq1 - tq0; tph[1] += tq2 - tq1; tph[2] += tq3 - tq2; tph[3] += tq4 - tq3;
+          }
+          st_base += wave_sum_u32(my_enc);
+          sent += wave_sum_u32(my_sent);
+          nrec += nr;
           whole_records += take;
           short_pay_total = short_pay;
-          uint64_t s = my_pay;
-#pragma unroll
-          for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-          sent += s;
-          stop = bm != 0 || nv < 64 || nrec >= max_sge;
-          // next chunk of this Send, or the first chunk of the next one (a Send that is priced
-          // again starts where this one did: the synchronous path above covers that)
-          prefetch(stop ? idx + whole_records : idx + nrec);
+          stop = bm != 0 || nrec >= max_sge || idx + nrec >= nslices;
         }
         if (failed) break;
         // A Send the peer's credit cut short (or left empty) is only final when the receiver
@@ -490,6 +592,7 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, int lane) {
         // sequential loop would have priced it in.  Otherwise wait for the receiver and price again.
         const bool credit_limited = (shorted && free0 < S) || nrec == 0;
         if (!credit_limited || rounds_done >= k) break;
+        if (eager && nrec != 0) break;  // concurrent mode: send what fits now
         const uint64_t t0 = wall_clock64();
         if (!lk_spin(L, ticks, [&]() {
               return ldw(&L->rx_rounds_done.v) != rounds_done ||
@@ -504,6 +607,8 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, int lane) {
         break;
       }
       const uint64_t staged = st_base;
+      const uint64_t tp1 = wall_clock64();
+      t_price += tp1 - tp0;
       // the wire: the <= 2 RDMA WRITEs of GetWriteRequests (ring_buffer.cc:261-330), cut into entries
       uint32_t nw = 0;
       if (!direct) {
@@ -558,6 +663,7 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, int lane) {
       else if (whole_records != 0) bidx = 0;
       idx += whole_records;
       k++;
+      t_pub += wall_clock64() - tp1;
     }
   }
   // no more entries: let the workers run dry and leave
@@ -580,17 +686,21 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, int lane) {
     L->res_entries[LK_WIRE] = wpub;
     L->res_wait_ticks[0] = wait_slot;
     L->res_wait_ticks[1] = wait_credit;
+    L->res_prof[0] = t_price;
+    L->res_prof[1] = t_pub;
+    L->res_prof[2] = wall_clock64() - t_begin;
+    for (int q = 0; q < 4; q++) L->res_err_detail[q] = tph[q];
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// RX leader: see the file header.  The wave tier of k_rx_plan (grdma_rx_plan.hip) made
-// incremental: 64 speculative probes of the record chain per memory round trip, 64 whole records
-// replayed through the endpoint-read state machine per step on the DPP network, scalar reads for
-// partial records and tails -- bounded by what the wire has completely delivered.
+// RX leader: see the file header.  Speculative probes of the record chain (LK_PROBE_GROUPS x 64
+// per memory round trip) fill a queue of verified record sizes; up to 1024 whole records per
+// step are replayed through the endpoint-read state machine (a record of >= 511 bytes resets the
+// state, so every lane recovers the incoming state of its run by looking back to the nearest
+// such record); partial records and tails take scalar reads.  Everything is bounded by what the
+// wire has completely delivered.
 // ---------------------------------------------------------------------------------------------
-#define LK_CHAIN_CAP 384
-
 struct lk_walker {
   const uint8_t* ring;
   uint64_t cap;
@@ -600,61 +710,61 @@ struct lk_walker {
   uint64_t limit;   // bytes behind pos that have completely landed
 };
 
-// One probe round: LK_PROBE_GROUPS x 64 speculative probes per memory round trip.  Lane j of
-// group g loads the tag words at the offset the chain reaches after 64 g + j records if the
-// last two sizes keep alternating; every probe checks its own link and the footer in front of
-// it; ballots give the verified prefix.  Stores the payload sizes in chain[0..v), returns v.
-#define LK_PROBE_GROUPS 4
-__device__ __forceinline__ uint32_t lk_chain_round(lk_walker* w, uint64_t* chain, int lane) {
+// One probe round.  Probe i = 64 g + lane loads the tag words at the offset the chain reaches
+// after i records if the last two sizes keep alternating; every probe checks its own link and
+// the footer in front of it; ballots give the verified prefix.  Appends the payload sizes to
+// q[LKP(qt + 0 .. v)), returns v.
+__device__ __forceinline__ uint32_t lk_chain_round(lk_walker* w, uint32_t* q, uint32_t qt, int lane) {
   constexpr int K = LK_PROBE_GROUPS;
   const uint64_t cap = w->cap, mask = cap - 1;
   const uint64_t lim = w->limit;
   if (lim == 0) return 0;
-  const uint64_t H2 = w->e0 ? w->h1 : w->h2;
-  const uint64_t H1 = w->e0 ? w->e0 : w->h1;
-  const uint64_t A = H2 ? H2 : H1, B = H1;  // predicted sizes alternate A, B, A, ...
   const uint64_t e0 = w->e0;
-  auto rel_of = [&](uint64_t j) -> uint64_t {
-    uint64_t base = 0, k = j;
-    if (e0) {
-      if (j == 0) return 0;
-      base = e0;
-      k = j - 1;
-    }
-    return base + (k >> 1) * (A + B) + ((k & 1) ? A : 0);
-  };
+  const uint32_t H2 = (uint32_t)(e0 ? w->h1 : w->h2);
+  const uint32_t H1 = (uint32_t)(e0 ? e0 : w->h1);
+  const uint32_t A = H2 ? H2 : H1, Bv = H1;  // predicted sizes alternate A, B, A, ...
   const bool have_pattern = (A != 0);
+  // offset of probe i behind pos (the ring is at most 256 MiB and a probe beyond the limit is
+  // not used: saturate)
+  auto rel_of = [&](uint32_t i) -> uint64_t {
+    uint64_t base = 0;
+    uint32_t kk = i;
+    if (e0) {
+      if (i == 0) return 0;
+      base = e0;
+      kk = i - 1;
+    }
+    return base + (uint64_t)(kk >> 1) * ((uint64_t)A + Bv) + ((kk & 1) ? A : 0);
+  };
   uint64_t hdr[K], prev[K], rel[K], reln[K];
-  bool ph[K], pp[K];
 #pragma unroll
   for (int g = 0; g < K; g++) {
-    const uint64_t idx = (uint64_t)(64 * g + lane);
-    rel[g] = have_pattern ? rel_of(idx) : 0;
-    reln[g] = have_pattern ? rel_of(idx + 1) : 0;
-    // only records that end inside what has landed are looked at
-    ph[g] = (idx == 0) || (have_pattern && reln[g] <= lim);
-    pp[g] = idx > 0 && have_pattern && rel[g] <= lim;
+    const uint32_t i = 64 * g + lane;
+    rel[g] = have_pattern ? rel_of(i) : 0;
+    reln[g] = have_pattern ? rel_of(i + 1) : 0;
   }
-  // all 2 K tag loads of a lane are in flight together
+  // all 2 K tag loads of a lane are in flight together: unconditional (a masked offset is always
+  // inside the ring), the conditions are applied to what comes back
 #pragma unroll
   for (int g = 0; g < K; g++) {
-    const uint64_t my_pos = (w->pos + rel[g]) & mask;
-    hdr[g] = ph[g] ? ld_tag(w->ring + my_pos) : 0;
-    prev[g] = pp[g] ? ld_tag(w->ring + ((my_pos + cap - 8) & mask)) : 0;  // footer of the record before
+    const uint64_t my_pos = (w->pos + rel[g]) & mask & ~7ull;
+    hdr[g] = ld_tag(w->ring + my_pos);
+    prev[g] = ld_tag(w->ring + ((my_pos + cap - 8) & mask));  // footer of the record before
   }
-  uint32_t v = 64 * K;
-  uint64_t enc_v = 0, rel_v = 0, enc_l1 = 0, enc_l2 = 0;
-  bool v_valid = false;
-  uint64_t foot_next0 = 0;  // bit 0 of the NEXT group's footer ballot = footer of this group's record 63
-  // (groups are examined from the last to the first so that each knows its successor's first footer)
+  uint32_t v = 64 * K - 1;
+  uint64_t foot_next0 = 0;  // footer of this group's record 63 = first footer bit of the next group
   uint64_t m_good[K], m_valid[K];
 #pragma unroll
   for (int g = K - 1; g >= 0; g--) {
-    const bool valid = ph[g] && hdr[g] != 0 && hdr[g] <= cap - GRDMA_RESERVED;
+    const uint32_t i = 64 * g + lane;
+    // only records that end inside what has landed are looked at
+    const bool ph = (i == 0) || (have_pattern && reln[g] <= lim);
+    const bool pp = i > 0 && have_pattern && rel[g] <= lim;
+    const bool valid = ph && hdr[g] != 0 && hdr[g] <= cap - GRDMA_RESERVED;
     const uint64_t enc = 16 + round_up8(hdr[g]);
     const bool link_ok = valid && have_pattern && !(g == K - 1 && lane == 63) && enc == reln[g] - rel[g];
     const uint64_t m_link = __ballot(link_ok);
-    const uint64_t m_fp = __ballot(pp[g] && prev[g] == GRDMA_FOOTER);
+    const uint64_t m_fp = __ballot(pp && prev[g] == GRDMA_FOOTER);
     const uint64_t m_foot = (m_fp >> 1) | (foot_next0 << 63);  // bit j: footer of record 64 g + j
     foot_next0 = m_fp & 1;
     m_good[g] = m_link & m_foot;
@@ -664,22 +774,21 @@ __device__ __forceinline__ uint32_t lk_chain_round(lk_walker* w, uint64_t* chain
   for (int g = K - 1; g >= 0; g--)
     if (m_good[g] != ~0ull) v = 64 * g + (uint32_t)__builtin_ctzll(~m_good[g]);
   // sizes of the verified records; what the walker needs from records v - 2, v - 1 and v
+  uint64_t enc_v = 0, rel_v = 0, enc_l1 = 0, enc_l2 = 0;
+  bool v_valid = false;
 #pragma unroll
   for (int g = 0; g < K; g++) {
-    const uint32_t idx = 64 * g + lane;
-    if (idx < v) chain[idx] = hdr[g];
-    const uint64_t enc = 16 + round_up8(hdr[g]);
+    const uint32_t i = 64 * g + lane;
+    if (i < v) q[LKP(qt + i)] = (uint32_t)hdr[g];
+    const uint32_t enc = 16 + (uint32_t)round_up8(hdr[g] & 0xFFFFFFFFull);
     const uint32_t lo = 64 * g;
-    if (v >= lo && v < lo + 64) {
-      enc_v = __shfl(enc, (int)(v - lo), 64);
-      rel_v = __shfl(rel[g], (int)(v - lo), 64);
+    if (v >= lo && v < lo + 64) {  // uniform
+      enc_v = (uint32_t)__builtin_amdgcn_readlane((int)enc, (int)(v - lo));
+      rel_v = rel_of(v);
       v_valid = (m_valid[g] >> (v - lo)) & 1;
     }
-    if (v >= 1 && v - 1 >= lo && v - 1 < lo + 64) enc_l1 = __shfl(enc, (int)(v - 1 - lo), 64);
-    if (v >= 2 && v - 2 >= lo && v - 2 < lo + 64) enc_l2 = __shfl(enc, (int)(v - 2 - lo), 64);
-  }
-  if (v == 64 * K) {  // (cannot happen: the last probe never links; kept for the arithmetic below)
-    v = 64 * K - 1;
+    if (v >= 1 && v - 1 >= lo && v - 1 < lo + 64) enc_l1 = (uint32_t)__builtin_amdgcn_readlane((int)enc, (int)(v - 1 - lo));
+    if (v >= 2 && v - 2 >= lo && v - 2 < lo + 64) enc_l2 = (uint32_t)__builtin_amdgcn_readlane((int)enc, (int)(v - 2 - lo));
   }
   if (v >= 2) {
     w->h2 = enc_l2;
@@ -705,12 +814,12 @@ __device__ __forceinline__ uint32_t lk_read_space_after(uint64_t n, uint32_t s) 
 }
 
 struct lk_rec_plan {
-  uint64_t c1, c2;    // bytes of the (at most) two Recv steps
-  uint64_t sl0, sl1;  // lengths of the slices completed by this record, in order (0 = none)
+  uint32_t c1, c2;    // bytes of the (at most) two Recv steps
+  uint32_t sl0, sl1;  // lengths of the slices completed by this record, in order (0 = none)
   uint32_t sl_cnt;
 };
 
-__device__ __forceinline__ lk_rec_plan lk_replay_record(uint64_t n, uint32_t s_in) {
+__device__ __forceinline__ lk_rec_plan lk_replay_record(uint32_t n, uint32_t s_in) {
   lk_rec_plan r;
   r.c1 = n;
   r.c2 = 0;
@@ -729,44 +838,46 @@ __device__ __forceinline__ lk_rec_plan lk_replay_record(uint64_t n, uint32_t s_i
   return r;
 }
 
-__device__ __forceinline__ void lk_split_step(uint64_t pay, uint64_t off, uint64_t len, uint64_t cap,
-                                              uint64_t* o0, uint64_t* l0, uint64_t* o1, uint64_t* l1) {
-  const uint64_t p0 = (pay + off) & (cap - 1);
-  const uint64_t first = len < cap - p0 ? len : cap - p0;
-  *o0 = p0;
-  *l0 = first;
-  *o1 = 0;
-  *l1 = len - first;
+__device__ __forceinline__ uint64_t lk_al16(uint64_t v) { return (v + 15) & ~15ull; }
+__device__ __forceinline__ uint32_t lk_al16_32(uint32_t v) { return (v + 15u) & ~15u; }
+
+// the ring pieces of one Recv step of `len` bytes at payload offset `off`: (o0, l0) and, when the
+// step crosses the ring end, (0, l1); then cut into entries
+__device__ __forceinline__ uint32_t lk_step_entries(uint32_t pay, uint32_t off, uint32_t len, uint32_t cap) {
+  if (len == 0) return 0;
+  const uint32_t p0 = (pay + off) & (cap - 1);
+  const uint32_t first = len < cap - p0 ? len : cap - p0;
+  return lk_sub_entries(first) + lk_sub_entries(len - first);
 }
 
-__device__ __forceinline__ uint64_t lk_al16(uint64_t v) { return (v + 15) & ~15ull; }
-
-__device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, uint64_t* s_chain, int lane) {
+__device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) {
   grdma_conn* c = L->rx;
   uint8_t* const ring = c->ring;
   const uint64_t cap = c->cap, mask = cap - 1;
+  const uint32_t cap32 = (uint32_t)cap, mask32 = (uint32_t)mask;  // (rings in the engine are at most 256 MiB)
   const bool direct = L->direct != 0;
   lk_entry* const tab = L->tab[LK_SCATTER];
   uint8_t* const arena = L->arena;
   const uint64_t arena_cap = L->arena_cap;
   grdma_slice_out* const out_slices = L->out_slices;
-  const uint64_t max_slices = L->slices_cap < (uint64_t)GRDMA_MAX_SLICES << 20 ? L->slices_cap : (uint64_t)GRDMA_MAX_SLICES << 20;
+  const uint64_t max_slices = L->slices_cap;
 
   // reader state (ring_buffer.h:203-205, pair.h:169, rdma_bp_posix.cc:63)
   uint64_t head = c->head, mh = c->moving_head, remain = c->remain, irs = c->internal_read_size;
   uint64_t leftover = c->leftover_cap;
   uint64_t nslices = 0, a_off = 0, bytes = 0, records = 0, credit_msgs = 0, credit_head = 0, rounds_with_data = 0;
   // chunks: emission batches with a completion counter each.  Lane j keeps the chunk in slot j.
-  uint64_t spub = 0, sfloor = 0;            // scatter entries published / known complete
+  uint64_t spub = 0, sfloor = 0;            // scatter entries sealed / known complete
   uint64_t chunks = 0, chunks_retired = 0;
   uint32_t my_n = 0, my_flags = 0;          // flags: 1 = post a credit report after it, 2 = ends a round
   uint64_t my_credit = 0;
   uint64_t rounds_done = 0;                 // Sends drained with zero-fill complete and credits posted
-  uint64_t wait_data = 0, wait_table = 0;
+  uint64_t wait_data = 0, wait_table = 0, t_walk = 0, t_fast = 0, t_scalar = 0, t_emit = 0;
+  const uint64_t t_begin = wall_clock64();
   bool failed = false;
 
   lk_walker w = {ring, cap, head, 0, c->rx_h2, c->rx_h1, 0};
-  uint32_t chain_n = 0, chain_i = 0;
+  uint32_t q_head = 0, q_tail = 0;  // verified records not yet consumed: D->q[LKP(q_head .. q_tail))
 
   // Publication is lazy: a sealed chunk's entries become visible to the scatter waves at the
   // next point where this wave has waited for memory anyway (its probe loads: everything issued
@@ -813,8 +924,8 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, uint64_t* s_chain, int l
 
   // seal the entries emitted since the last chunk (possibly none) as one chunk
   uint32_t pend_entries = 0;
-  auto close_chunk = [&](uint32_t flags, uint64_t credit_value) -> bool {
-    if (pend_entries == 0 && flags == 0) return true;
+  auto close_chunk = [&](uint32_t flags, uint64_t credit_value) {
+    if (pend_entries == 0 && flags == 0) return;
     const int s = (int)(chunks % LK_RSLOTS);
     if (lane == s) {
       my_n = pend_entries;
@@ -824,7 +935,6 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, uint64_t* s_chain, int l
     spub += pend_entries;
     chunks++;
     pend_entries = 0;
-    return true;
   };
   // a chunk slot's counter must be zero before its first entry is published (the store is
   // ordered before the publication by the drain in flush_publish)
@@ -838,7 +948,8 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, uint64_t* s_chain, int l
     while (spub + pend_entries + need - sfloor > LK_TABLE_CAP) {
       // my own unsealed entries cannot complete: seal them first
       if (pend_entries && chunks_retired == chunks) {
-        if (!close_chunk(0, 0) || !open_chunk()) return false;
+        close_chunk(0, 0);
+        if (!open_chunk()) return false;
         continue;
       }
       if (!service(true)) return false;
@@ -848,41 +959,36 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, uint64_t* s_chain, int l
 
   uint64_t credit_seen = 0;  // credit_msgs at the last chunk boundary
 
+  // keep at least `want` verified records queued while more have landed
   uint32_t stall = 0;  // consecutive probe rounds that verified nothing (two are normal: header, then footer)
-  auto refill = [&]() {
-    while (chain_i == chain_n && w.limit > 0) {
-      chain_n = lk_chain_round(&w, s_chain, lane);
-      chain_i = 0;
-      flush_publish();
-      stall = chain_n ? 0 : stall + 1;
-      if ((chain_n == 0 && w.e0 == 0) || stall > 3) {  // the ring does not hold what the descriptor promised
-        stw(&L->abort.v, LK_ERR_CORRUPT);
-        failed = true;
-        return;
+  auto fill = [&](uint32_t want) {
+    while (q_tail - q_head < want && w.limit > 0 && !failed) {
+      if (q_tail + 64 * LK_PROBE_GROUPS > LK_QCAP) {
+        // move the queued records to the front (lane-parallel, through registers)
+        const uint32_t nq = q_tail - q_head;
+        for (uint32_t b0 = 0; b0 < nq; b0 += 64) {
+          const uint32_t i = b0 + lane;
+          const uint32_t v = i < nq ? D->q[LKP(q_head + i)] : 0;
+          if (i < nq) D->q[LKP(i)] = v;  // (b0 + lane < q_head + b0 + lane: never overwrites an unread slot of a later pass)
+        }
+        q_head = 0;
+        q_tail = nq;
       }
-    }
-  };
-  auto top_up = [&]() {
-    while (chain_n - chain_i < 64 && w.limit > 0 && !failed) {
-      const uint32_t kq = chain_n - chain_i;
-      uint64_t keep = 0;
-      if ((uint32_t)lane < kq) keep = s_chain[chain_i + lane];
-      if ((uint32_t)lane < kq) s_chain[lane] = keep;
-      chain_i = 0;
-      chain_n = kq;
-      const uint32_t got = lk_chain_round(&w, s_chain + kq, lane);
-      chain_n += got;
+      const uint64_t tw0 = wall_clock64();
+      const uint32_t got = lk_chain_round(&w, D->q, q_tail, lane);
+      t_walk += wall_clock64() - tw0;
+      q_tail += got;
       flush_publish();
       stall = got ? 0 : stall + 1;
-      if ((got == 0 && w.e0 == 0) || stall > 3) {
+      if ((got == 0 && w.e0 == 0) || stall > 3) {  // the ring does not hold what the descriptor promised
         stw(&L->abort.v, LK_ERR_CORRUPT);
         failed = true;
       }
     }
   };
   auto next_ready = [&]() -> uint64_t {
-    refill();
-    return chain_i < chain_n ? s_chain[chain_i] : 0;
+    fill(1);
+    return q_head < q_tail ? D->q[LKP(q_head)] : 0;
   };
 
   // PairPollable::Recv -> RingBufferPollable::Read(dst, capacity) (pair.cc:264-286,
@@ -898,7 +1004,7 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, uint64_t* s_chain, int l
       mh = (head + 8) & mask;
       head = (head + 16 + round_up8(avail)) & mask;
       records++;
-      chain_i++;
+      q_head++;
     }
     const uint64_t l1 = cpy < cap - mh ? cpy : cap - mh;
     lk_piece pc[2];
@@ -932,110 +1038,169 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, uint64_t* s_chain, int l
     return cpy;
   };
 
-  // 64 whole records per step, one lane per record
-  auto fast_chunk = [&]() -> uint32_t {
-    top_up();
+  // Up to 1024 whole records per step.  Lane l owns records [l * per, (l + 1) * per) of the step.
+  auto bulk_step = [&]() -> uint32_t {
+    fill(LK_STEP);
     if (failed) return 0;
-    uint32_t kq = chain_n - chain_i;
-    if (kq == 0) return 0;
-    if (kq > 64) kq = 64;
-    if (nslices + 128 > max_slices) return 0;
-    const bool act0 = (uint32_t)lane < kq;
-    const uint64_t n = act0 ? s_chain[chain_i + lane] : 0;
-    const uint64_t resets = __ballot(act0 && n >= 2 * MINRD - 1);
-    const uint64_t below = resets & ((1ull << lane) - 1ull);
-    const uint32_t from = below ? (64 - __builtin_clzll(below)) : 0;
-    uint32_t s_in = 0;
-    for (uint32_t i = from; i < (uint32_t)lane && act0; i++) s_in = lk_read_space_after(s_chain[chain_i + i], s_in);
-    const uint32_t s_out = lk_read_space_after(n, s_in);
-    const uint64_t clean = __ballot(act0 && s_out == 0);
-    if (clean == 0) return 0;
-    const uint32_t cnt = 64 - __builtin_clzll(clean);
-    const bool act = (uint32_t)lane < cnt;
-    const uint32_t enc = act ? (uint32_t)(16 + round_up8(n)) : 0;
-    lk_rec_plan rp = lk_replay_record(act ? n : 0, act ? s_in : 0);
-    if (!act) { rp.c1 = rp.c2 = 0; rp.sl_cnt = 0; rp.sl0 = rp.sl1 = 0; }
-    const uint32_t done_bytes = (uint32_t)(lk_al16(rp.sl0) + lk_al16(rp.sl1));
-    const uint32_t i_enc = wave_incl_scan_u32(enc);
-    const uint32_t i_bytes = wave_incl_scan_u32(done_bytes);
-    const uint32_t i_n = wave_incl_scan_u32(act ? (uint32_t)n : 0);
-    const uint64_t tot_n = __shfl(i_n, 63, 64);
-    if (a_off + tot_n + 32ull * cnt + 512 > arena_cap) return 0;
-    const uint64_t x_enc = i_enc - enc, x_bytes = i_bytes - done_bytes;
-    const uint64_t pos = (head + x_enc) & mask;
-    const uint64_t pay = (pos + 8) & mask;
-    const uint64_t A = a_off + x_bytes;
-    const uint64_t filled = s_in ? MINRD - s_in : 0;
-    uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
-    lk_split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
-    lk_split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
-    const uint32_t packed = rp.sl_cnt;
-    const uint32_t i_packed = wave_incl_scan_u32(packed);
-    const uint64_t x_slices = i_packed - rp.sl_cnt;
-    // header, padding and footer (ring_buffer.cc:146,173-180) are cleared by the scatter waves of
-    // the record's first / last piece
-    lk_piece pc[4];
+    uint32_t m = q_tail - q_head;
+    if (m == 0) return 0;
+    if (m > LK_STEP) m = LK_STEP;
+    const uint32_t per = (m + 63) / 64;
+    const uint32_t k0 = lane * per < m ? lane * per : m, k1 = k0 + per < m ? k0 + per : m;
+    // ---- incoming read state of my run: look back to the nearest record that resets it
+    uint32_t last_clean = 0;
     {
-      uint64_t dst = (uint64_t)arena + A + filled;  // the steps of one record are contiguous in the arena
-      const int last_piece = l3 ? 3 : (l2 ? 2 : (l1 ? 1 : 0));
-      const uint64_t offs[4] = {o0, o1, o2, o3}, lens[4] = {l0, l1, l2, l3};
+      uint32_t j = k0;
+      while (j > 0 && D->q[LKP(q_head + j - 1)] < 2 * MINRD - 1) j--;
+      uint32_t sp = 0;
+      for (; j < k0; j++) sp = lk_read_space_after(D->q[LKP(q_head + j)], sp);
+      for (uint32_t q = k0; q < k1; q++) {
+        D->sin[LKP(q)] = (uint16_t)sp;
+        sp = lk_read_space_after(D->q[LKP(q_head + q)], sp);
+        if (sp == 0) last_clean = q + 1;
+      }
+    }
+    // records [0, cnt) are processed; the state ends clean
+    uint32_t cnt = last_clean;
 #pragma unroll
-      for (int p = 0; p < 4; p++) {
-        const uint32_t fl = (uint32_t)GRDMA_SEG_ZERO_SRC | (p == 0 ? (uint32_t)GRDMA_SEG_TAG_HDR : 0u) |
-                            (p == last_piece ? (uint32_t)GRDMA_SEG_TAG_FTR : 0u);
-        pc[p] = {dst, (uint64_t)(ring + offs[p]), act ? lens[p] : 0, fl, 0};
-        dst += lens[p];
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t o = __shfl_xor(cnt, d, 64);
+      cnt = o > cnt ? o : cnt;
+    }
+    if (cnt == 0) return 0;
+    const uint32_t e1 = k1 < cnt ? k1 : cnt;  // my run, cut at cnt
+    const uint32_t head32 = (uint32_t)head;
+    // ---- totals of my run
+    uint32_t t_enc = 0, t_bytes = 0, t_sl = 0, t_ent = 0, t_n = 0;
+    for (uint32_t q = k0; q < e1; q++) {
+      const uint32_t n = D->q[LKP(q_head + q)];
+      t_enc += 16u + (uint32_t)round_up8(n);
+    }
+    const uint32_t i_enc = wave_incl_scan_u32(t_enc);
+    {
+      uint32_t x = i_enc - t_enc;
+      for (uint32_t q = k0; q < e1; q++) {
+        const uint32_t n = D->q[LKP(q_head + q)];
+        D->xenc[LKP(q)] = x;
+        const lk_rec_plan rp = lk_replay_record(n, D->sin[LKP(q)]);
+        const uint32_t pay = (head32 + x + 8u) & mask32;
+        t_ent += lk_step_entries(pay, 0, rp.c1, cap32) + lk_step_entries(pay, rp.c1, rp.c2, cap32);
+        t_bytes += lk_al16_32(rp.sl0) + lk_al16_32(rp.sl1);
+        t_sl += rp.sl_cnt;
+        t_n += n;
+        x += 16u + (uint32_t)round_up8(n);
       }
     }
-    const uint32_t need = lk_count<4>(pc);
-    if (!table_room(need)) { failed = true; return 0; }
-    lk_emit<4>(tab, spub + pend_entries, pc, (uint32_t)(chunks % LK_RSLOTS), lane);
-    pend_entries += need;
-    if (act) {
-      uint64_t so = A;
-      uint64_t xs = nslices + x_slices;
-      if (rp.sl0) {
-        out_slices[xs].off = so;
-        out_slices[xs].len = rp.sl0;
-        xs++;
-        so += lk_al16(rp.sl0);
-      }
-      if (rp.sl1) {
-        out_slices[xs].off = so;
-        out_slices[xs].len = rp.sl1;
+    const uint32_t i_bytes = wave_incl_scan_u32(t_bytes), i_sl = wave_incl_scan_u32(t_sl);
+    const uint32_t i_ent = wave_incl_scan_u32(t_ent), i_n = wave_incl_scan_u32(t_n);
+    const uint32_t tot_ent = (uint32_t)__builtin_amdgcn_readlane((int)i_ent, 63);
+    const uint32_t tot_sl = (uint32_t)__builtin_amdgcn_readlane((int)i_sl, 63);
+    const uint32_t tot_bytes = (uint32_t)__builtin_amdgcn_readlane((int)i_bytes, 63);
+    const uint32_t tot_n = (uint32_t)__builtin_amdgcn_readlane((int)i_n, 63);
+    const uint32_t Ctot = (uint32_t)__builtin_amdgcn_readlane((int)i_enc, 63);
+    if (nslices + tot_sl > max_slices) { stw(&L->abort.v, LK_ERR_SLICES); failed = true; return 0; }
+    if (a_off + tot_bytes + 512 > arena_cap) { stw(&L->abort.v, LK_ERR_ARENA); failed = true; return 0; }
+    if (!table_room(tot_ent)) { failed = true; return 0; }
+    const uint64_t te0 = wall_clock64();
+    // ---- entries and slices of my run
+    {
+      uint64_t at = spub + pend_entries + i_ent - t_ent;
+      uint64_t xs = nslices + i_sl - t_sl;
+      uint64_t A = a_off + i_bytes - t_bytes;  // start of the open / next slice
+      const uint32_t slot = ((uint32_t)(chunks % LK_RSLOTS)) << 8;
+      for (uint32_t q = k0; q < e1; q++) {
+        const uint32_t n = D->q[LKP(q_head + q)];
+        const uint32_t s_in = D->sin[LKP(q)];
+        const lk_rec_plan rp = lk_replay_record(n, s_in);
+        const uint32_t pay = (head32 + D->xenc[LKP(q)] + 8u) & mask32;
+        const uint32_t filled = s_in ? MINRD - s_in : 0;
+        // the steps of one record are contiguous in the arena: step 1 fills the open 256-byte
+        // slice exactly, step 2 starts the next slice right behind it.  Header, padding and
+        // footer (ring_buffer.cc:146,173-180) are cleared by the scatter waves of the record's
+        // first / last entry.
+        uint64_t dst = (uint64_t)arena + A + filled;
+        const uint32_t total_ent = lk_step_entries(pay, 0, rp.c1, cap32) + lk_step_entries(pay, rp.c1, rp.c2, cap32);
+        uint32_t emitted = 0;
+        for (int stp = 0; stp < 2; stp++) {
+          const uint32_t off = stp ? rp.c1 : 0, len = stp ? rp.c2 : rp.c1;
+          if (len == 0) continue;
+          const uint32_t p0 = (pay + off) & mask32;
+          const uint32_t first = len < cap32 - p0 ? len : cap32 - p0;
+          for (int pi = 0; pi < 2; pi++) {
+            const uint32_t pl = pi ? len - first : first;
+            if (pl == 0) continue;
+            const uint64_t src = (uint64_t)ring + (pi ? 0u : p0);
+            const uint32_t nsub = lk_sub_entries(pl);
+            for (uint32_t j = 0; j < nsub; j++) {
+              const uint32_t o = j * LK_ENTRY_MAX;
+              const uint32_t l = pl - o < LK_ENTRY_MAX ? pl - o : LK_ENTRY_MAX;
+              uint32_t fl = (uint32_t)GRDMA_SEG_ZERO_SRC | slot;
+              if (emitted == 0) fl |= (uint32_t)GRDMA_SEG_TAG_HDR;
+              if (emitted == total_ent - 1) fl |= (uint32_t)GRDMA_SEG_TAG_FTR;
+              lk_store_entry(tab, at, dst + o, src + o, l, fl, 0);
+              at++;
+              emitted++;
+            }
+            dst += pl;
+          }
+        }
+        uint64_t sof = A;
+        if (rp.sl0) {
+          out_slices[xs].off = sof;
+          out_slices[xs].len = rp.sl0;
+          xs++;
+          sof += lk_al16_32(rp.sl0);
+        }
+        if (rp.sl1) {
+          out_slices[xs].off = sof;
+          out_slices[xs].len = rp.sl1;
+          xs++;
+        }
+        A += lk_al16_32(rp.sl0) + lk_al16_32(rp.sl1);
       }
     }
-    // credit accounting over the Recv steps (pair.cc:276-284)
-    const uint64_t pad_foot = round_up8(n) - n + 8;
-    const uint64_t cons2 = act && rp.c2 ? rp.c2 + pad_foot : 0;
-    const uint64_t mh1 = rp.c2 == 0 ? (pos + enc) & mask : (pay + rp.c1) & mask;
-    const uint64_t mh2 = (pos + enc) & mask;
-    const uint64_t C2 = i_enc;
-    const uint64_t C1 = C2 - cons2;
-    const uint64_t Ctot = __shfl(i_enc, 63, 64);
-    uint64_t base = 0, thr = cap / 2 - irs;
-    bool crossed = false;
-    for (;;) {
-      const uint64_t hit = __ballot(act && C2 >= thr);
-      if (hit == 0) break;
-      const int f = __builtin_ctzll(hit);
-      const uint64_t fC1 = __shfl(C1, f, 64), fC2 = __shfl(C2, f, 64);
-      const uint64_t fmh1 = __shfl(mh1, f, 64), fmh2 = __shfl(mh2, f, 64);
-      const bool first = fC1 >= thr;
-      credit_head = first ? fmh1 : fmh2;
-      base = first ? fC1 : fC2;
-      credit_msgs++;
-      crossed = true;
-      thr = base + cap / 2;
+    pend_entries += tot_ent;
+    t_emit += wall_clock64() - te0;
+    // ---- credit accounting over the Recv steps (pair.cc:276-284): the records whose running
+    // consumption reaches cap / 2 (uniform search over the offsets in LDS)
+    {
+      const uint64_t T = cap / 2;
+      uint64_t base = 0, thr = T - irs;
+      bool crossed = false;
+      while ((uint64_t)Ctot >= thr) {
+        uint32_t lo = 0, hi = cnt - 1;  // first record whose consumption after its last step reaches thr
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          const uint32_t nm = D->q[LKP(q_head + mid)];
+          if ((uint64_t)D->xenc[LKP(mid)] + 16u + round_up8(nm) >= thr) hi = mid; else lo = mid + 1;
+        }
+        const uint32_t n = D->q[LKP(q_head + lo)];
+        const uint32_t e = 16u + (uint32_t)round_up8(n);
+        const lk_rec_plan rp = lk_replay_record(n, D->sin[LKP(lo)]);
+        const uint64_t C2 = (uint64_t)D->xenc[LKP(lo)] + e;
+        const uint64_t cons2 = rp.c2 ? rp.c2 + (round_up8(n) - n + 8) : 0;
+        const uint64_t C1 = C2 - cons2;
+        const uint64_t pos = (head + D->xenc[LKP(lo)]) & mask;
+        if (rp.c2 && C1 >= thr) {  // crossed after the first step of a two-step record
+          credit_head = (pos + 8 + rp.c1) & mask;
+          base = C1;
+        } else {
+          credit_head = (pos + e) & mask;
+          base = C2;
+        }
+        credit_msgs++;
+        crossed = true;
+        thr = base + T;
+      }
+      irs = crossed ? (uint64_t)Ctot - base : irs + Ctot;
     }
-    irs = crossed ? Ctot - base : irs + Ctot;
     head = (head + Ctot) & mask;
     mh = head;
     bytes += tot_n;
     records += cnt;
-    nslices += __shfl(i_packed, 63, 64);
-    a_off += __shfl(i_bytes, 63, 64);
-    chain_i += cnt;
+    nslices += tot_sl;
+    a_off += tot_bytes;
+    q_head += cnt;
     return cnt;
   };
 
@@ -1086,11 +1251,14 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, uint64_t* s_chain, int l
       if (failed) break;
       if (nslices >= max_slices) { stw(&L->abort.v, LK_ERR_SLICES); failed = true; break; }
       const bool clean = remain == 0 && leftover == 0;
-      if (clean && fast_chunk() > 0) {
-        // one chunk per step: its scatter starts while the next 64 records are being walked
+      const uint64_t ts0 = wall_clock64();
+      if (clean && bulk_step() > 0) {
+        t_fast += wall_clock64() - ts0;
+        // one chunk per step: its scatter starts while the next records are being walked
         const bool cr = credit_msgs != credit_seen;
         credit_seen = credit_msgs;
-        if (!close_chunk(cr ? 1u : 0u, credit_head) || !open_chunk()) { failed = true; break; }
+        close_chunk(cr ? 1u : 0u, credit_head);
+        if (!open_chunk()) { failed = true; break; }
         continue;
       }
       if (failed) break;
@@ -1119,13 +1287,14 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, uint64_t* s_chain, int l
       nslices++;
       bytes += total;
       a_off = lk_al16(a_off + total);
+      t_scalar += wall_clock64() - ts0;
     }
     if (failed) break;
     if (nslices != nslices0) rounds_with_data++;
     {
       const bool cr = credit_msgs != credit_seen;
       credit_seen = credit_msgs;
-      if (!close_chunk((cr ? 1u : 0u) | 2u, credit_head)) { failed = true; break; }
+      close_chunk((cr ? 1u : 0u) | 2u, credit_head);
     }
   }
   // everything sealed: publish, wait for the scatter waves, post the last reports
@@ -1153,6 +1322,11 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, uint64_t* s_chain, int l
     L->res_entries[LK_SCATTER] = spub;
     L->res_wait_ticks[2] = wait_data;
     L->res_wait_ticks[3] = wait_table;
+    L->res_prof[3] = t_walk;
+    L->res_prof[4] = t_fast;
+    L->res_prof[5] = t_scalar;
+    L->res_prof[6] = wall_clock64() - t_begin;
+    L->res_prof[7] = t_emit;
   }
 }
 
@@ -1164,13 +1338,13 @@ __global__ __launch_bounds__(LK_THREADS) void k_link(lk_ctl* const* ctls, uint64
   lk_ctl* L = ctls[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6;
-  __shared__ uint64_t s_chain[LK_CHAIN_CAP];
+  __shared__ lk_lds s_lds;  // the leaders' tables (workers use no LDS)
   if (blockIdx.x == 0) {
-    if (wave == 0) lk_tx_leader(L, timeout_ticks, lane);
+    if (wave == 0) lk_tx_leader(L, timeout_ticks, &s_lds.tx, lane);
     return;
   }
   if (blockIdx.x == 1) {
-    if (wave == 0) lk_rx_leader(L, timeout_ticks, s_chain, lane);
+    if (wave == 0) lk_rx_leader(L, timeout_ticks, &s_lds.rx, lane);
     return;
   }
   const uint32_t ww = (blockIdx.x - 2) * (LK_THREADS / 64) + wave;

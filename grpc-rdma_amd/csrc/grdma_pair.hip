@@ -1275,6 +1275,7 @@ struct grdma_stream_job {
   uint64_t max_ring = 0;
   // link engine
   lk_ctl** d_lk_ptrs = nullptr;
+  bool lk_eager = false;
   uint32_t lk_team = 0;
   uint64_t lk_timeout_ticks = 0;
 };
@@ -1487,6 +1488,7 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
 // has been delivered.  See grdma_link.h.
 int job_engine_prepare(grdma_stream_job* j) {
   if (j->d_lk_ptrs) return 0;
+  if (const char* e = getenv("GRDMA_LINK_EAGER_CREDIT")) j->lk_eager = atoi(e) != 0;
   const uint32_t n = (uint32_t)j->links.size();
   const uint32_t resident = grdma_link_resident_blocks();
   if (resident == 0) return fail(GRDMA_ERR_HIP, "occupancy query for the link engine failed");
@@ -1571,6 +1573,7 @@ int job_engine_prepare(grdma_stream_job* j) {
       h.nwaves[t] = nw[t];
     }
     h.timeout_ms = (uint32_t)tmo_ms;
+    h.eager_credit = j->lk_eager ? 1 : 0;
     HIP_TRY(hipMemcpy(l.d_lk, &h, sizeof(h), hipMemcpyHostToDevice));
     ptrs[i] = l.d_lk;
   }
@@ -1872,6 +1875,16 @@ int grdma_stream_job_launch_engine(grdma_stream_job* j) {
 
 // profiling aid: {Sends, receive chunks, gather / wire / scatter entries, leader wait ticks x 4
 // (sender: staging + slots, credit; receiver: data, scatter), abort code, team, waves x 3}
+int grdma_stream_job_engine_prof(grdma_stream_job* j, uint32_t link, uint64_t out[12]) {
+  if (int rc = require_ctx()) return rc;
+  if (!j || !out || link >= j->links.size() || !j->links[link].d_lk) return fail(GRDMA_ERR_INVALID, "bad argument");
+  HIP_TRY(hipStreamSynchronize(j->stream));
+  static_assert(offsetof(lk_ctl, res_err_detail) == offsetof(lk_ctl, res_prof) + 8 * sizeof(uint64_t), "layout");
+  HIP_TRY(hipMemcpy(out, reinterpret_cast<uint8_t*>(j->links[link].d_lk) + offsetof(lk_ctl, res_prof), sizeof(uint64_t) * 12,
+                    hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int grdma_stream_job_engine_stats(grdma_stream_job* j, uint32_t link, uint64_t out[16]) {
   if (int rc = require_ctx()) return rc;
   if (!j || !out || link >= j->links.size() || !j->links[link].d_lk) return fail(GRDMA_ERR_INVALID, "bad argument");
@@ -1885,6 +1898,7 @@ int grdma_stream_job_engine_stats(grdma_stream_job* j, uint32_t link, uint64_t o
   out[9] = h.abort.v; out[10] = j->lk_team;
   for (int t = 0; t < 3; t++) out[11 + t] = h.nwaves[t];
   out[14] = h.n_staging;
+  out[15] = h.eager_credit;
   return 0;
 }
 

@@ -88,7 +88,15 @@ class StreamJob:
         names = ["sends", "chunks", "gather_entries", "wire_entries", "scatter_entries", "tx_wait_slots",
                  "tx_wait_credit", "rx_wait_data", "rx_wait_scatter", "abort", "team", "gather_waves",
                  "wire_waves", "scatter_waves", "staging_buffers"]
-        return {k: int(out[i]) for i, k in enumerate(names)}
+        d = {k: int(out[i]) for i, k in enumerate(names)}
+        d["eager_credit"] = int(out[15])
+        pr = (u64 * 12)()
+        self.lib.grdma_stream_job_engine_prof.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(u64)]
+        check(self.lib.grdma_stream_job_engine_prof(self.h, link, pr))
+        for i, k in enumerate(["tx_price", "tx_publish", "tx_total", "rx_walk", "rx_fast", "rx_scalar", "rx_total",
+                               "rx_emit", "tx_ph_load", "tx_ph_price", "tx_ph_count", "tx_ph_emit"]):
+            d[k] = int(pr[i])
+        return d
 
     def delivered_slices(self, link=0):
         arr = (ReadSlice * self.slices_cap)()

@@ -1,0 +1,10 @@
+#pragma once
+#include <cstdint>
+namespace absl {
+class Duration { public: int64_t ns = 0; };
+class Time { public: int64_t ns = 0; };
+inline Time InfiniteFuture() { return Time{INT64_MAX}; }
+inline Duration Milliseconds(int64_t n) { return Duration{n * 1000000}; }
+inline Duration Seconds(int64_t n) { return Duration{n * 1000000000}; }
+inline Time Now() { return Time{}; }
+}  // namespace absl

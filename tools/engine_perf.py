@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Throughput of the persistent link engine at the bench configurations, with the leaders' wait
+split (tools; bench.py carries the official legs).  usage: engine_perf.py [config ...]
+configs: big (128 MiB ring, sge 4095), r4m (4 MiB ring, sge 4095), ref (4 MiB ring, sge 30),
+         conns (32 links x 64 KiB, 4 MiB rings), mixed (sizes 1 B..4 MiB, 4 MiB ring, sge 30)"""
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def run(g, gs, name, ring_kb, max_sge, n_links, msgs, payload, steps=10, flags=0, wls=None):
+    ring = ring_kb * 1024
+    wls = wls or [bench.Workload(g, msgs, payload) for _ in range(n_links)]
+    links, keep = [], []
+    for w in wls:
+        tx, rx = g.Pair(ring, max_sge, flags), g.Pair(ring, max_sge, flags)
+        g.connect_pairs(tx, rx)
+        scap = len(w.lens) * 2 + 64 + w.N // 256
+        dst_cap = w.N + 32 * scap + 4096
+        dst = g.DeviceBuffer(nbytes=dst_cap)
+        links.append((tx, rx, w.sge, dst.ptr, dst_cap, scap))
+        keep.append((tx, rx, dst))
+    job = gs.MultiStreamJob(links, 8)
+    r = job.run(gs.RUN_ENGINE)
+    assert r.done
+    for _ in range(2):
+        job.launch_engine()
+    job.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.launch_engine()
+    job.sync()
+    dt = time.perf_counter() - t0
+    user = sum(w.user_bytes for w in wls)
+    st = job.engine_stats(0)
+    r = job.run(gs.RUN_ENGINE)
+    out = {"config": name, "GiBps": round(user * steps / dt / (1 << 30), 2), "ms_per_step": round(1e3 * dt / steps, 4),
+           "ms_single": round(r.ms_total, 4), "sends": st["sends"], "chunks": st["chunks"],
+           "entries": [st["gather_entries"], st["wire_entries"], st["scatter_entries"]],
+           "waves": [st["gather_waves"], st["wire_waves"], st["scatter_waves"]], "team": st["team"],
+           "staging": st["staging_buffers"],
+           "ms": {k: round(st[k] / 1e5, 3) for k in ("tx_wait_slots", "tx_wait_credit", "tx_price", "tx_publish", "tx_total",
+                                                     "rx_wait_data", "rx_wait_scatter", "rx_walk", "rx_fast", "rx_scalar", "rx_total", "rx_emit",
+                                                     "tx_ph_load", "tx_ph_price", "tx_ph_count", "tx_ph_emit")}}
+    print(json.dumps(out), flush=True)
+    job.close()
+    for tx, rx, dst in keep:
+        tx.close(); rx.close(); dst.free()
+    return out
+
+
+class MixedWorkload(bench.Workload):
+    """Sizes drawn like examples/cpp/test/common.h:4-31 (uniform in [1, 4 MiB - 1 KiB]), seed 0."""
+
+    def __init__(self, g, n_msgs, seed=0):
+        from grpc_rdma_amd import h2
+        import ctypes as C
+        rng = random.Random(seed)
+        sizes = [rng.randint(1, (4 << 20) - 1024) for _ in range(n_msgs)]
+        self.g, self.n_msgs = g, n_msgs
+        total = sum(sizes)
+        self.payload_buf = g.DeviceBuffer(nbytes=total + 64)
+        block = bytes((i * 7 + 1) % 251 for i in range(1 << 20))
+        lib = g.load()
+        off = 0
+        for n in sizes:
+            for o in range(0, n, len(block)):
+                k = min(len(block), n - o)
+                lib.grdma_copy_to_device(self.payload_buf.ptr + off + o, block, k)
+            off += n
+        hdr, self.slices, k, base = bytearray(), [], 0, 0
+        for i, n in enumerate(sizes):
+            for it in h2.frame_message(n, 2 * i + 1, 16384):
+                if it[0] == "inl":
+                    o = 32 * k + 9
+                    hdr += bytes(32)
+                    hdr[o:o + len(it[1])] = it[1]
+                    self.slices.append(("h", o, len(it[1])))
+                    k += 1
+                else:
+                    self.slices.append(("p", base + it[1][0], it[1][1]))
+            base += n
+        self.hdr_buf = g.DeviceBuffer(data=bytes(hdr) + bytes(64))
+        self.sge = [((self.hdr_buf.ptr if kind == "h" else self.payload_buf.ptr) + o, n) for kind, o, n in self.slices]
+        self.lens = [n for _, _, n in self.slices]
+        self.N = sum(self.lens)
+        self.E = h2.ring_bytes_for(self.lens)
+        self.user_bytes = total
+
+
+def main():
+    import torch  # noqa: F401  (device context like bench.py)
+    import grpc_rdma_amd as g
+    from grpc_rdma_amd import stream as gs
+    g.init(0)
+    which = sys.argv[1:] or ["big", "r4m", "ref", "conns", "mixed"]
+    for w in which:
+        if w == "big":
+            run(g, gs, "ring128m_sge4095", 131072, 4095, 1, 256, bench.MIB)
+        elif w == "bigd":
+            run(g, gs, "ring128m_sge4095_direct", 131072, 4095, 1, 256, bench.MIB, flags=2)
+        elif w == "r4m":
+            run(g, gs, "ring4m_sge4095", 4096, 4095, 1, 256, bench.MIB)
+        elif w == "ref":
+            run(g, gs, "ring4m_sge30", 4096, 30, 1, 256, bench.MIB)
+        elif w == "conns":
+            run(g, gs, "conns32_64k", 4096, 4095, 32, 64, 64 * 1024)
+        elif w == "mixed":
+            run(g, gs, "mixed_ring4m_sge30", 4096, 30, 1, 0, 0, wls=[MixedWorkload(g, 64)])
+        elif w == "mixedbig":
+            run(g, gs, "mixed_ring128m_sge4095", 131072, 4095, 1, 0, 0, wls=[MixedWorkload(g, 64)])
+
+
+if __name__ == "__main__":
+    main()
