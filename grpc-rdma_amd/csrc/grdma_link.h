@@ -74,9 +74,7 @@ struct lk_ctl {
   struct lk_entry* tab[3];
   uint32_t nwaves[3];              // worker waves per stage
   uint32_t timeout_ms;
-  uint32_t eager_credit;           // 1: a Send cut by the peer's credit goes out as it is (what the reference
-                                   // does when it runs concurrently); 0: priced again once the receiver caught up
-  uint32_t pad_cfg32;
+  uint32_t pad_cfg32[2];
   uint64_t pad_cfg[5];
   // ---- dynamic state, zeroed before every launch --------------------------------------------
   // (each polled word on its own 128-byte line: a poller must not share a line with a word
@@ -95,7 +93,8 @@ struct lk_ctl {
   uint64_t res_sends, res_chunks, res_entries[3];
   uint64_t res_wait_ticks[4];      // profiling aid: leader wait time (tx: slots, credit; rx: data, table)
   uint64_t res_prof[8];            // profiling aid: leader busy time (tx: pricing, wire+publish, total; rx: walk, fast steps, scalar steps, total)
-  uint64_t res_err_detail[4];
+  uint64_t res_err_detail[4];      // (profiling aid: sender step phases)
+  uint64_t res_dbg[8];             // what the first aborting role saw: {code, site, a, b, c, d}
 };
 
 #define LK_DYNAMIC_OFFSET offsetof(struct lk_ctl, published)

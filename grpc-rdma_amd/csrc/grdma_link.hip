@@ -5,11 +5,13 @@
 // until one would block (the schedule tests/test_gpu_stream_job.py drives the CPU oracle with):
 //  * the receiver drains Send by Send, each drain ending in the read that finds nothing and
 //    keeps its slice (rdma_bp_posix.cc:241-243);
-//  * the sender runs ahead of the receiver only while that cannot change a record: a Send that
-//    would be cut by the peer's credit (free space < staging budget) is priced again once the
-//    receiver has caught up and every credit report of the earlier rounds is in.
+//  * in that schedule the receiver has drained everything before the next Send is priced, so the
+//    peer's free space is cap - (bytes consumed since the last credit report) > cap / 2 = the
+//    staging budget: the credit NEVER cuts a record there.  The sender therefore prices every
+//    Send against the staging budget alone -- no waiting, any number of Sends ahead -- and only
+//    holds a Send's WIRE back until the credit that has physically arrived covers its bytes.
 // So records, delivered slices, credit reports and final state equal the sequential execution,
-// while gather, wire and scatter of neighbouring Sends overlap in time.
+// while pricing, gather, wire, ring walk and scatter of neighbouring Sends overlap in time.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -43,6 +45,24 @@ __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__built
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(uint64_t base, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// Lanes of one wave that hand data to each other through memory (LDS tables, a word one lane
+// stores and all lanes read) execute in lockstep, but the COMPILER reasons per thread: a load may
+// be hoisted above another lane's store.  A wavefront-scope fence is a no-op in hardware and
+// keeps the program order of the memory operations around it.
+__device__ __forceinline__ void lk_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// first abort wins: remember where and with what
+__device__ __forceinline__ void lk_abort(lk_ctl* L, uint64_t code, uint64_t site, uint64_t a, uint64_t b, uint64_t c2,
+                                         uint64_t d) {
+  if (__hip_atomic_load((const gu64*)(uint64_t)&L->abort.v, RLX_AGENT) == 0) {
+    L->res_dbg[0] = code; L->res_dbg[1] = site; L->res_dbg[2] = a; L->res_dbg[3] = b; L->res_dbg[4] = c2; L->res_dbg[5] = d;
+  }
+  stw(&L->abort.v, code);
 }
 
 // Bounded spin: polls cond() (relaxed loads), leaves on the abort word or on the wall clock.
@@ -342,17 +362,38 @@ __device__ __forceinline__ void lk_emit(lk_entry* tab, uint64_t base, const lk_p
 #define LK_RUN 16                  // records per lane per step
 #define LK_STEP (64 * LK_RUN)      // records per step
 #define LKP(i) ((i) + ((i) >> 4))  // LDS index padding: runs of 16 would otherwise share banks
-#define LK_QCAP 2560               // verified-record queue of the receiver (>= LK_STEP + one probe round)
+#define LK_RX_STEP 4096            // records per step of the receiver (16 per thread of its leader block)
+#define LK_QCAP 5120               // verified-record queue of the receiver (>= LK_RX_STEP + one probe round)
 #define LK_PROBE_GROUPS 8          // x 64 speculative probes per memory round trip
 
 struct lk_tx_lds {
   uint32_t len[LKP(LK_STEP) + 2];  // priced length of each slice of the step (clamped)
+  uint32_t st[LKP(LK_STEP) + 2];   // where its record starts in the staging buffer
   uint64_t ptr[LKP(LK_STEP) + 2];
 };
+// The receiver's leader block works as one wave that drives and three that help: the driver posts
+// a command in LDS, all four waves do their quarter of the records, each helper drains its stores
+// and counts itself done.  (LDS words with workgroup-scope atomics; no s_barrier: the driver's
+// control flow is far from uniform across the block.)
+enum { LK_CMD_EXIT = 1, LK_CMD_STATE = 2, LK_CMD_TOTALS = 3, LK_CMD_EMIT = 4, LK_CMD_COUNT = 5 };
+struct lk_rx_cmd {
+  uint32_t seq;        // bumped last by the driver
+  uint32_t type;
+  uint32_t done;       // helpers that finished the current command
+  uint32_t m, per, cnt, q_head, slot, head32;
+  uint32_t clean_max;  // LK_CMD_STATE: max over threads of "records up to here end clean"
+  uint64_t at0, xs0, a0;
+  // LK_CMD_TOTALS: what each wave's quarter of the records makes (then, for LK_CMD_EMIT, the
+  // exclusive prefixes over the waves)
+  uint32_t w_bytes[4], w_sl[4], w_ent[4], w_n[4];
+};
 struct lk_rx_lds {
+  lk_rx_cmd cmd;
+  uint32_t t_enc[256], t_bytes[256], t_sl[256], t_ent[256], t_n[256];  // per-thread totals, then exclusive prefixes
+  uint32_t hist[1024];               // LK_HCAP encoded sizes, the walker's history ring
   uint32_t q[LKP(LK_QCAP) + 2];      // payload sizes of verified records, [q_head, q_tail)
-  uint32_t xenc[LKP(LK_STEP) + 2];   // ring offset of each record of the step behind `head`
-  uint16_t sin[LKP(LK_STEP) + 2];    // space left in the open 256-byte read when the record starts
+  uint32_t xenc[LKP(LK_RX_STEP) + 2];  // ring offset of each record of the step behind `head`
+  uint16_t sin[LKP(LK_RX_STEP) + 2];   // space left in the open 256-byte read when the record starts
 };
 union lk_lds {
   lk_tx_lds tx;
@@ -371,6 +412,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // ballot finds the first short record -- where the reference's loop stops.
 // ---------------------------------------------------------------------------------------------
 __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) {
+  __builtin_amdgcn_s_setprio(3);  // the copy wave that shares this SIMD takes the slots I leave
   grdma_conn* c = L->tx;
   const uint64_t cap = c->cap, mask = cap - 1, S = c->staging_cap;
   uint32_t max_sge = c->max_sge;
@@ -390,11 +432,35 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
   uint32_t partial = (uint32_t)c->partial_write, last_records = 0;
   // in-flight Sends, one per lane: lane j keeps what the Send in slot j published
   uint32_t my_ng = 0, my_nw = 0;
+  uint64_t my_staged = 0;            // encoded bytes of that Send (what its wire puts into the ring)
+  // credit gate: Sends [gated, k) are priced (and gathered) but their ring writes are still held
+  // back; rel_tail = ring offset behind everything released so far
+  uint64_t gated = 0, rel_tail = c->remote_tail, rel_pub = 0;
   uint64_t wait_slot = 0, wait_credit = 0, t_price = 0, t_pub = 0;
   uint64_t tph[4] = {0, 0, 0, 0};  // profiling aid: load, price, count, emit
   const uint64_t t_begin = wall_clock64();
-  const bool eager = L->eager_credit != 0;
   bool failed = false;
+
+  // release the ring writes of priced Sends, in order, as far as the credit that has ARRIVED
+  // covers them (the ring never fills up completely, so head == tail always means empty).
+  // What is released: the wire entries -- or, when records are built in the peer ring itself,
+  // the gather entries.
+  const int gate_stage = L->direct ? LK_GATHER : LK_WIRE;
+  auto release_ring_writes = [&]() {
+    bool any = false;
+    while (gated < k) {
+      const int s = (int)(gated % LK_SLOTS);
+      const uint64_t need = __shfl(my_staged, s, 64);
+      const uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const uint64_t freeb = cap - ((rel_tail + cap - rhead) & mask);
+      if (freeb < need + 8) break;  // (every record of the Send passed W(free - st) >= pay against an even larger free space)
+      rel_pub += direct ? __shfl(my_ng, s, 64) : __shfl(my_nw, s, 64);
+      rel_tail = (rel_tail + need) & mask;
+      gated++;
+      any = true;
+    }
+    if (any) stw(&L->published[gate_stage].v, rel_pub);
+  };
 
   auto retire_oldest = [&]() -> bool {
     // the oldest Send in flight has left its staging buffer: gathered and on the wire
@@ -403,7 +469,10 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
     const uint32_t* dg = &L->done_tx[LK_GATHER][rs].v;
     const uint32_t* dw = &L->done_tx[LK_WIRE][rs].v;
     const uint64_t t0 = wall_clock64();
-    if (!lk_spin(L, ticks, [&]() { return ldw32(dg) >= ng && ldw32(dw) >= nw; })) return false;
+    if (!lk_spin(L, ticks, [&]() {
+          release_ring_writes();
+          return ldw32(dg) >= ng && ldw32(dw) >= nw;
+        })) return false;
     wait_slot += wall_clock64() - t0;
     retired++;
     gfloor += ng;
@@ -422,23 +491,22 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
       if (failed) break;
       if (k >= LK_SLOTS) {
         const uint64_t need = k - LK_SLOTS + 1;
-        if (!lk_spin(L, ticks, [&]() { return ldw(&L->rx_sends_seen.v) >= need; })) { failed = true; break; }
+        if (!lk_spin(L, ticks, [&]() {
+              release_ring_writes();
+              return ldw(&L->rx_sends_seen.v) >= need;
+            })) { failed = true; break; }
       }
       uint8_t* const sbuf = direct ? nullptr : L->staging[k % B];
       uint64_t st_base = 0, nrec = 0, sent = 0, whole_records = 0, short_pay_total = 0;
       uint32_t ents = 0;
       const uint64_t tp0 = wall_clock64();
-      for (;;) {  // pricing attempts of Send k
-        // how far the receiver is, then the credit it granted (get_remote_head(), pair.h:229-233):
-        // in this order, so that "caught up" implies every credit report is in
-        const uint64_t rounds_done = ldw(&L->rx_rounds_done.v);
-        const uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const uint64_t free0 = cap - ((tail + cap - rhead) & mask);
-        const uint64_t room0 = S < free0 ? S : free0;
+      release_ring_writes();
+      {
+        // priced against the staging budget alone (see the file header): free0 > S in the
+        // sequential schedule, so min(S, free0) = S and W(free0 - st) >= W(S - st)
+        const uint64_t room0 = S;
         // lengths are clamped for pricing: whatever exceeds the budget is short anyway
         const uint32_t clampv = (uint32_t)(room0 + 64);
-        st_base = 0; nrec = 0; sent = 0; whole_records = 0; ents = 0; short_pay_total = 0;
-        bool shorted = false;
         for (bool stop = false; !stop && !failed;) {
           // ---- this step's slices -> LDS (striped loads, all in flight together)
           const uint64_t first = idx + nrec;
@@ -468,6 +536,7 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
               }
             }
           }
+          lk_wave_sync();  // the table is written striped and read in runs
           const uint32_t per = (m + 63) / 64;
           const uint32_t k0 = lane * per, k1 = k0 + per < m ? k0 + per : m;
           const uint64_t tq1 = wall_clock64();
@@ -502,11 +571,8 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
             take = __shfl(my_short, f, 64);
             const uint64_t stf = __shfl(st_short, f, 64);
             const uint64_t lf = D->len[LKP(take)];
-            const uint64_t a = writable_of(sat_sub(S, stf)), b = writable_of(sat_sub(free0, stf));
-            short_pay = lf;
-            if (a < short_pay) short_pay = a;
-            if (b < short_pay) short_pay = b;
-            shorted = true;
+            const uint64_t a = writable_of(sat_sub(S, stf));
+            short_pay = lf < a ? lf : a;
           }
           const uint32_t nr = take + (short_pay ? 1u : 0u);  // records of this step
           const uint64_t tq2 = wall_clock64();
@@ -514,6 +580,7 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
           uint32_t my_cnt = 0, my_sent = 0, my_enc = 0;
           for (uint32_t q = k0; q < k1 && q < nr; q++) {
             const uint32_t pay = q < take ? D->len[LKP(q)] : (uint32_t)short_pay;
+            D->st[LKP(q)] = (uint32_t)st_run + my_enc;
             my_cnt += lk_sub_entries(pay);
             my_sent += pay;
             my_enc += (uint32_t)enc_size(pay);
@@ -534,7 +601,17 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
             if (!retire_oldest()) { failed = true; break; }
           if (failed) break;
           const uint64_t tq3 = wall_clock64();
-          {
+          if (n_new == nr && !direct) {
+            // the common case, one entry per record: dealt to the lanes round-robin, so that
+            // neighbouring lanes write neighbouring table entries (coalesced 16-byte stores)
+            lk_wave_sync();
+            const uint32_t fl = (uint32_t)(GRDMA_SEG_TAG_WRITE | GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR) | (slot << 8);
+#pragma unroll 4
+            for (uint32_t q = lane; q < nr; q += 64) {
+              const uint32_t pay = q < take ? D->len[LKP(q)] : (uint32_t)short_pay;
+              lk_store_entry(gtab, gpub + ents + q, (uint64_t)(sbuf + D->st[LKP(q)] + 8), D->ptr[LKP(q)], pay, fl, pay);
+            }
+          } else {
             uint64_t st = st_run;
             uint64_t at = gpub + ents + i_cnt - my_cnt;
             const uint32_t tagw = (uint32_t)GRDMA_SEG_TAG_WRITE | (slot << 8);
@@ -575,6 +652,7 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
             }
           }
           ents += n_new;
+          lk_wave_sync();  // (the next step overwrites the table)
           {
             const uint64_t tq4 = wall_clock64();
             tph[0] += tq1 - tq0; tph[1] += tq2 - tq1; tph[2] += tq3 - tq2; tph[3] += tq4 - tq3;
@@ -586,22 +664,9 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
           short_pay_total = short_pay;
           stop = bm != 0 || nrec >= max_sge || idx + nrec >= nslices;
         }
-        if (failed) break;
-        // A Send the peer's credit cut short (or left empty) is only final when the receiver
-        // has drained every earlier round and posted its credit reports -- the state the
-        // sequential loop would have priced it in.  Otherwise wait for the receiver and price again.
-        const bool credit_limited = (shorted && free0 < S) || nrec == 0;
-        if (!credit_limited || rounds_done >= k) break;
-        if (eager && nrec != 0) break;  // concurrent mode: send what fits now
-        const uint64_t t0 = wall_clock64();
-        if (!lk_spin(L, ticks, [&]() {
-              return ldw(&L->rx_rounds_done.v) != rounds_done ||
-                     __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != rhead;
-            })) { failed = true; break; }
-        wait_credit += wall_clock64() - t0;
       }
       if (failed) break;
-      if (nrec == 0) {  // nothing in flight, all credit in, and still nothing fits: a zero-length slice
+      if (nrec == 0) {  // nothing fits an empty staging buffer: a zero-length slice at the cursor
         stw(&L->abort.v, LK_ERR_NO_PROGRESS);
         failed = true;
         break;
@@ -643,13 +708,13 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
       drain();
       gpub += ents;
       wpub += nw;
-      stw(&L->published[LK_GATHER].v, gpub);
-      if (!direct) stw(&L->published[LK_WIRE].v, wpub);
-      stw(&L->sends_pub.v, k + 1);
       if (lane == (int)slot) {
         my_ng = ents;
         my_nw = nw;
+        my_staged = staged;
       }
+      if (!direct) stw(&L->published[LK_GATHER].v, gpub);  // staging is mine: gather right away
+      stw(&L->sends_pub.v, k + 1);
       // bookkeeping of Send() and the rdma_flush cursor walk (rdma_bp_posix.cc:480-493)
       tail = (tail + staged) & mask;
       const uint64_t offered = remaining;
@@ -663,7 +728,17 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
       else if (whole_records != 0) bidx = 0;
       idx += whole_records;
       k++;
+      release_ring_writes();
       t_pub += wall_clock64() - tp1;
+    }
+    // every Send is priced: release the rest as the credit comes in
+    if (!failed && gated < k) {
+      const uint64_t t0 = wall_clock64();
+      if (!lk_spin(L, ticks, [&]() {
+            release_ring_writes();
+            return gated >= k;
+          })) failed = true;
+      wait_credit += wall_clock64() - t0;
     }
   }
   // no more entries: let the workers run dry and leave
@@ -701,48 +776,82 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
 // such record); partial records and tails take scalar reads.  Everything is bounded by what the
 // wire has completely delivered.
 // ---------------------------------------------------------------------------------------------
+#define LK_HCAP 1024  // encoded sizes of the last verified records (the predictor's history)
+
 struct lk_walker {
   const uint8_t* ring;
   uint64_t cap;
-  uint64_t pos;     // ring offset of the first unverified record
-  uint64_t e0;      // encoded size of the record at pos when its header is already known
-  uint64_t h2, h1;  // encoded sizes of the two records before pos (0 = unknown)
-  uint64_t limit;   // bytes behind pos that have completely landed
+  uint64_t pos;       // ring offset of the first unverified record
+  uint64_t e0;        // encoded size of the record at pos when its header is already known
+  uint64_t limit;     // bytes behind pos that have completely landed
+  uint64_t hcount;    // records verified so far (history index of the record at pos)
+  uint32_t period;    // detected period of the record sizes (0: none, the last two sizes alternate)
+  uint64_t retry_at;  // no new period search before this many records were verified
 };
 
+// The record chain is a linked list, but on a gRPC connection the sizes repeat: inside a message
+// a 9-byte frame header alternates with a 16 KiB payload, and messages of one size repeat the
+// whole run.  Finds the smallest period P <= 510 for which the newest P + 4 sizes (the header
+// just read at pos included) equal the ones P earlier; lane-parallel over the candidates.
+__device__ __forceinline__ uint32_t lk_find_period(const uint32_t* hist, uint64_t tt, int lane) {
+  const uint64_t have = tt < LK_HCAP ? tt : LK_HCAP;
+  uint32_t best = 0xFFFFFFFFu;
+  for (uint32_t c = 0; c < 8; c++) {
+    const uint32_t P = c * 64 + lane + 1;
+    if (2ull * P + 4 > have) continue;
+    bool ok = true;
+    for (uint32_t j = 0; j < P + 4 && ok; j++)
+      ok = hist[(tt - 1 - j) % LK_HCAP] == hist[(tt - 1 - j - P) % LK_HCAP];
+    if (ok && P < best) best = P;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = __shfl_xor(best, d, 64);
+    best = o < best ? o : best;
+  }
+  return best == 0xFFFFFFFFu ? 0 : best;
+}
+
 // One probe round.  Probe i = 64 g + lane loads the tag words at the offset the chain reaches
-// after i records if the last two sizes keep alternating; every probe checks its own link and
-// the footer in front of it; ballots give the verified prefix.  Appends the payload sizes to
-// q[LKP(qt + 0 .. v)), returns v.
-__device__ __forceinline__ uint32_t lk_chain_round(lk_walker* w, uint32_t* q, uint32_t qt, int lane) {
+// after i records if the sizes keep repeating with the known period; every probe checks its own
+// link and the footer in front of it; ballots give the verified prefix.  Appends the payload
+// sizes to q[LKP(qt + 0 .. v)), returns v.
+__device__ __forceinline__ uint32_t lk_chain_round(lk_walker* w, uint32_t* q, uint32_t qt, uint32_t* hist, int lane) {
   constexpr int K = LK_PROBE_GROUPS;
   const uint64_t cap = w->cap, mask = cap - 1;
   const uint64_t lim = w->limit;
   if (lim == 0) return 0;
   const uint64_t e0 = w->e0;
-  const uint32_t H2 = (uint32_t)(e0 ? w->h1 : w->h2);
-  const uint32_t H1 = (uint32_t)(e0 ? e0 : w->h1);
-  const uint32_t A = H2 ? H2 : H1, Bv = H1;  // predicted sizes alternate A, B, A, ...
-  const bool have_pattern = (A != 0);
-  // offset of probe i behind pos (the ring is at most 256 MiB and a probe beyond the limit is
-  // not used: saturate)
-  auto rel_of = [&](uint32_t i) -> uint64_t {
-    uint64_t base = 0;
-    uint32_t kk = i;
-    if (e0) {
-      if (i == 0) return 0;
-      base = e0;
-      kk = i - 1;
-    }
-    return base + (uint64_t)(kk >> 1) * ((uint64_t)A + Bv) + ((kk & 1) ? A : 0);
-  };
-  uint64_t hdr[K], prev[K], rel[K], reln[K];
+  const uint64_t t = w->hcount;
+  // a header already read counts as the newest history entry
+  if (e0 && lane == 0) hist[t % LK_HCAP] = (uint32_t)e0;
+  lk_wave_sync();
+  const uint64_t tt = t + (e0 ? 1 : 0);
+  const uint32_t i0 = e0 ? 1u : 0u;
+  uint32_t P = w->period;
+  if (P == 0 || P > tt) P = tt >= 2 ? 2u : (uint32_t)tt;
+  const bool have_pattern = P != 0;
+  // predicted encoded size of probe i, then its offset behind pos: prefix sums over the 8 groups
+  // (in units of 8 bytes, saturated just above the limit: a probe beyond the limit is not used)
+  const uint32_t sat8 = (uint32_t)((lim >> 3) + 2);
+  uint64_t rel[K], reln[K];
+  {
+    uint64_t carry = 0;
 #pragma unroll
-  for (int g = 0; g < K; g++) {
-    const uint32_t i = 64 * g + lane;
-    rel[g] = have_pattern ? rel_of(i) : 0;
-    reln[g] = have_pattern ? rel_of(i + 1) : 0;
+    for (int g = 0; g < K; g++) {
+      const uint32_t i = 64 * g + lane;
+      uint32_t pe = 0;
+      if (i < i0) pe = (uint32_t)e0;
+      else if (have_pattern) pe = hist[(tt - P + ((i - i0) % P)) % LK_HCAP];
+      uint32_t p8 = pe >> 3;
+      if (p8 > sat8) p8 = sat8;
+      const uint32_t incl = wave_incl_scan_u32(p8);
+      rel[g] = (carry + incl - p8) << 3;
+      reln[g] = (carry + incl) << 3;
+      carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
   }
+  uint64_t hdr[K], prev[K];
   // all 2 K tag loads of a lane are in flight together: unconditional (a masked offset is always
   // inside the ring), the conditions are applied to what comes back
 #pragma unroll
@@ -757,12 +866,13 @@ __device__ __forceinline__ uint32_t lk_chain_round(lk_walker* w, uint32_t* q, ui
 #pragma unroll
   for (int g = K - 1; g >= 0; g--) {
     const uint32_t i = 64 * g + lane;
+    const bool known = i < i0 || have_pattern;  // this probe's size is predicted (or known)
     // only records that end inside what has landed are looked at
-    const bool ph = (i == 0) || (have_pattern && reln[g] <= lim);
-    const bool pp = i > 0 && have_pattern && rel[g] <= lim;
+    const bool ph = (i == 0) || (known && reln[g] <= lim);
+    const bool pp = i > 0 && rel[g] <= lim && (i - 1 < i0 || have_pattern);
     const bool valid = ph && hdr[g] != 0 && hdr[g] <= cap - GRDMA_RESERVED;
     const uint64_t enc = 16 + round_up8(hdr[g]);
-    const bool link_ok = valid && have_pattern && !(g == K - 1 && lane == 63) && enc == reln[g] - rel[g];
+    const bool link_ok = valid && known && !(g == K - 1 && lane == 63) && enc == reln[g] - rel[g] && reln[g] <= lim;
     const uint64_t m_link = __ballot(link_ok);
     const uint64_t m_fp = __ballot(pp && prev[g] == GRDMA_FOOTER);
     const uint64_t m_foot = (m_fp >> 1) | (foot_next0 << 63);  // bit j: footer of record 64 g + j
@@ -773,35 +883,41 @@ __device__ __forceinline__ uint32_t lk_chain_round(lk_walker* w, uint32_t* q, ui
 #pragma unroll
   for (int g = K - 1; g >= 0; g--)
     if (m_good[g] != ~0ull) v = 64 * g + (uint32_t)__builtin_ctzll(~m_good[g]);
-  // sizes of the verified records; what the walker needs from records v - 2, v - 1 and v
-  uint64_t enc_v = 0, rel_v = 0, enc_l1 = 0, enc_l2 = 0;
+  // sizes of the verified records; what the walker needs from record v
+  uint64_t enc_v = 0, rel_v = 0;
   bool v_valid = false;
 #pragma unroll
   for (int g = 0; g < K; g++) {
     const uint32_t i = 64 * g + lane;
-    if (i < v) q[LKP(qt + i)] = (uint32_t)hdr[g];
     const uint32_t enc = 16 + (uint32_t)round_up8(hdr[g] & 0xFFFFFFFFull);
+    if (i < v) {
+      q[LKP(qt + i)] = (uint32_t)hdr[g];
+      hist[(t + i) % LK_HCAP] = enc;
+    }
     const uint32_t lo = 64 * g;
     if (v >= lo && v < lo + 64) {  // uniform
       enc_v = (uint32_t)__builtin_amdgcn_readlane((int)enc, (int)(v - lo));
-      rel_v = rel_of(v);
+      rel_v = (uint64_t)__builtin_amdgcn_readlane((int)(uint32_t)(rel[g] >> 3), (int)(v - lo)) << 3;
       v_valid = (m_valid[g] >> (v - lo)) & 1;
     }
-    if (v >= 1 && v - 1 >= lo && v - 1 < lo + 64) enc_l1 = (uint32_t)__builtin_amdgcn_readlane((int)enc, (int)(v - 1 - lo));
-    if (v >= 2 && v - 2 >= lo && v - 2 < lo + 64) enc_l2 = (uint32_t)__builtin_amdgcn_readlane((int)enc, (int)(v - 2 - lo));
   }
-  if (v >= 2) {
-    w->h2 = enc_l2;
-    w->h1 = enc_l1;
-  } else if (v == 1) {
-    w->h2 = w->h1;
-    w->h1 = enc_l1;
-  }
+  lk_wave_sync();
   w->pos = (w->pos + rel_v) & mask;
   w->limit = lim - rel_v;
+  w->hcount = t + v;
   // record v is the first unverified one: when its header was read and is a record header, its
   // exact footer position is probed next round (as probe 0)
   w->e0 = v_valid ? enc_v : 0;
+  // a round that stopped on a size it did not predict, with more data behind it: look for a
+  // (longer) period, unless a search failed recently
+  if (w->e0 && v < 64 * K - 1 && w->limit > 0 && w->hcount >= w->retry_at) {
+    lk_wave_sync();
+    if (lane == 0) hist[w->hcount % LK_HCAP] = (uint32_t)w->e0;
+    lk_wave_sync();
+    const uint32_t np = lk_find_period(hist, w->hcount + 1, lane);
+    w->period = np;
+    if (np == 0) w->retry_at = w->hcount + 256;
+  }
   return v;
 }
 
@@ -850,7 +966,194 @@ __device__ __forceinline__ uint32_t lk_step_entries(uint32_t pay, uint32_t off, 
   return lk_sub_entries(first) + lk_sub_entries(len - first);
 }
 
+// ---- the block-wide parts of a bulk step (the command's arguments come by value: the driver
+// passes what it posted, a helper what it read behind its acquire of the sequence word).
+//
+// STATE: thread T of 256 owns the contiguous run [T * per, (T + 1) * per) of the m queued records:
+// incoming read state of every record (look back to the nearest record that resets it, >= 511
+// bytes), the last record after which the state is clean, and the encoded bytes of the run.
+__device__ __forceinline__ void lk_rx_part_state(lk_rx_lds* D, const lk_rx_cmd& cm, uint32_t T) {
+  const uint32_t m = cm.m, per = cm.per, qh = cm.q_head;
+  const uint32_t k0 = T * per < m ? T * per : m, k1 = k0 + per < m ? k0 + per : m;
+  uint32_t t_enc = 0, last_clean = 0;
+  if (k0 < k1) {
+    uint32_t j = k0;
+    while (j > 0 && D->q[LKP(qh + j - 1)] < 2 * MINRD - 1) j--;
+    uint32_t sp = 0;
+    for (; j < k0; j++) sp = lk_read_space_after(D->q[LKP(qh + j)], sp);
+    for (uint32_t q = k0; q < k1; q++) {
+      const uint32_t n = D->q[LKP(qh + q)];
+      D->sin[LKP(q)] = (uint16_t)sp;
+      sp = lk_read_space_after(n, sp);
+      if (sp == 0) last_clean = q + 1;
+      t_enc += 16u + (uint32_t)round_up8(n);
+    }
+  }
+  D->t_enc[T] = t_enc;
+  if (last_clean) __hip_atomic_fetch_max(&D->cmd.clean_max, last_clean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// XENC: ring offset of every record behind `head`, from the exclusive prefix of the runs in t_enc
+__device__ __forceinline__ void lk_rx_part_xenc(lk_rx_lds* D, const lk_rx_cmd& cm, uint32_t T) {
+  const uint32_t m = cm.m, per = cm.per, qh = cm.q_head;
+  const uint32_t k0 = T * per < m ? T * per : m, k1 = k0 + per < m ? k0 + per : m;
+  uint32_t x = D->t_enc[T];
+  for (uint32_t q = k0; q < k1; q++) {
+    D->xenc[LKP(q)] = x;
+    x += 16u + (uint32_t)round_up8(D->q[LKP(qh + q)]);
+  }
+  if (k1 == m && k0 < k1) D->xenc[LKP(m)] = x;
+}
+
+// the range of the cnt processed records that wave w works on, lane per record: contiguous
+// quarters, multiples of 64 (neighbouring lanes then write neighbouring table entries)
+__device__ __forceinline__ void lk_rx_wave_range(uint32_t cnt, uint32_t w, uint32_t* beg, uint32_t* end) {
+  const uint32_t wchunk = (((cnt + 3) / 4) + 63u) & ~63u;
+  *beg = w * wchunk < cnt ? w * wchunk : cnt;
+  *end = *beg + wchunk < cnt ? *beg + wchunk : cnt;
+}
+
+// what one record makes: entries (pieces of at most LK_ENTRY_MAX bytes, cut at the ring end)
+__device__ __forceinline__ uint32_t lk_rec_entries(const lk_rec_plan& rp, uint32_t pay, uint32_t cap32) {
+  return lk_step_entries(pay, 0, rp.c1, cap32) + lk_step_entries(pay, rp.c1, rp.c2, cap32);
+}
+
+// TOTALS: per wave, over its range
+__device__ __forceinline__ void lk_rx_part_totals(lk_rx_lds* D, const lk_rx_cmd& cm, uint32_t w, int lane, uint32_t cap32) {
+  uint32_t wbeg, wend;
+  lk_rx_wave_range(cm.cnt, w, &wbeg, &wend);
+  const uint32_t qh = cm.q_head, head32 = cm.head32, mask32 = cap32 - 1;
+  uint32_t t_bytes = 0, t_pk = 0, t_n = 0;  // t_pk: slices | entries << 12 (per lane: <= 16 records of a 4096-record step per wave... summed below in 32 bits)
+  uint32_t t_sl = 0, t_ent = 0;
+  for (uint32_t k = wbeg + lane; k < wend; k += 64) {
+    const uint32_t n = D->q[LKP(qh + k)];
+    const lk_rec_plan rp = lk_replay_record(n, D->sin[LKP(k)]);
+    const uint32_t pay = (head32 + D->xenc[LKP(k)] + 8u) & mask32;
+    t_ent += lk_rec_entries(rp, pay, cap32);
+    t_sl += rp.sl_cnt;
+    t_bytes += lk_al16_32(rp.sl0) + lk_al16_32(rp.sl1);
+    t_n += n;
+  }
+  (void)t_pk;
+  t_bytes = wave_sum_u32(t_bytes);
+  t_sl = wave_sum_u32(t_sl);
+  t_ent = wave_sum_u32(t_ent);
+  t_n = wave_sum_u32(t_n);
+  if (lane == 0) {
+    D->cmd.w_bytes[w] = t_bytes;
+    D->cmd.w_sl[w] = t_sl;
+    D->cmd.w_ent[w] = t_ent;
+    D->cmd.w_n[w] = t_n;
+  }
+}
+
+// EMIT: entries and slices, 64 records per iteration, one lane per record; the running offsets
+// come from three DPP prefix sums per iteration
+__device__ __forceinline__ void lk_rx_part_emit(lk_rx_lds* D, const lk_rx_cmd& cm, uint32_t w, int lane, lk_entry* tab,
+                                                uint8_t* ring, uint8_t* arena, grdma_slice_out* out_slices, uint32_t cap32) {
+  uint32_t wbeg, wend;
+  lk_rx_wave_range(cm.cnt, w, &wbeg, &wend);
+  const uint32_t qh = cm.q_head, head32 = cm.head32, mask32 = cap32 - 1;
+  uint64_t c_ent = cm.at0 + cm.w_ent[w];    // running prefixes of this wave
+  uint64_t c_sl = cm.xs0 + cm.w_sl[w];
+  uint64_t c_bytes = cm.a0 + cm.w_bytes[w];
+  const uint32_t slot = cm.slot << 8;
+  for (uint32_t base = wbeg; base < wend; base += 64) {
+    const uint32_t k = base + lane;
+    const bool act = k < wend;
+    const uint32_t n = act ? D->q[LKP(qh + k)] : 0;
+    const uint32_t s_in = act ? D->sin[LKP(k)] : 0;
+    lk_rec_plan rp = lk_replay_record(n, s_in);
+    if (!act) { rp.c1 = rp.c2 = 0; rp.sl_cnt = 0; rp.sl0 = rp.sl1 = 0; }
+    const uint32_t pay = (head32 + (act ? D->xenc[LKP(k)] : 0) + 8u) & mask32;
+    const uint32_t my_ent = act ? lk_rec_entries(rp, pay, cap32) : 0;
+    const uint32_t my_bytes = lk_al16_32(rp.sl0) + lk_al16_32(rp.sl1);
+    const uint32_t i_ent = wave_incl_scan_u32(my_ent);
+    const uint32_t i_sl = wave_incl_scan_u32(rp.sl_cnt);
+    const uint32_t i_bytes = wave_incl_scan_u32(my_bytes);
+    if (act) {
+      uint64_t at = c_ent + i_ent - my_ent;
+      uint64_t xs = c_sl + i_sl - rp.sl_cnt;
+      const uint64_t A = c_bytes + i_bytes - my_bytes;  // start of the open / next slice
+      const uint32_t filled = s_in ? MINRD - s_in : 0;
+      // the steps of one record are contiguous in the arena: step 1 fills the open 256-byte
+      // slice exactly, step 2 starts the next slice right behind it.  Header, padding and
+      // footer (ring_buffer.cc:146,173-180) are cleared by the scatter waves of the record's
+      // first / last entry.
+      uint64_t dst = (uint64_t)arena + A + filled;
+      uint32_t emitted = 0;
+      for (int stp = 0; stp < 2; stp++) {
+        const uint32_t off = stp ? rp.c1 : 0, len = stp ? rp.c2 : rp.c1;
+        if (len == 0) continue;
+        const uint32_t p0 = (pay + off) & mask32;
+        const uint32_t first = len < cap32 - p0 ? len : cap32 - p0;
+        for (int pi = 0; pi < 2; pi++) {
+          const uint32_t pl = pi ? len - first : first;
+          if (pl == 0) continue;
+          const uint64_t src = (uint64_t)ring + (pi ? 0u : p0);
+          const uint32_t nsub = lk_sub_entries(pl);
+          for (uint32_t j = 0; j < nsub; j++) {
+            const uint32_t o = j * LK_ENTRY_MAX;
+            const uint32_t l = pl - o < LK_ENTRY_MAX ? pl - o : LK_ENTRY_MAX;
+            uint32_t fl = (uint32_t)GRDMA_SEG_ZERO_SRC | slot;
+            if (emitted == 0) fl |= (uint32_t)GRDMA_SEG_TAG_HDR;
+            if (emitted == my_ent - 1) fl |= (uint32_t)GRDMA_SEG_TAG_FTR;
+            lk_store_entry(tab, at, dst + o, src + o, l, fl, 0);
+            at++;
+            emitted++;
+          }
+          dst += pl;
+        }
+      }
+      uint64_t sof = A;
+      if (rp.sl0) {
+        out_slices[xs].off = sof;
+        out_slices[xs].len = rp.sl0;
+        xs++;
+        sof += lk_al16_32(rp.sl0);
+      }
+      if (rp.sl1) {
+        out_slices[xs].off = sof;
+        out_slices[xs].len = rp.sl1;
+      }
+    }
+    c_ent += (uint32_t)__builtin_amdgcn_readlane((int)i_ent, 63);
+    c_sl += (uint32_t)__builtin_amdgcn_readlane((int)i_sl, 63);
+    c_bytes += (uint32_t)__builtin_amdgcn_readlane((int)i_bytes, 63);
+  }
+}
+
+#define LK_WG_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
+
+// waves 1..3 of the receiver's leader block
+__device__ void lk_rx_helper(lk_ctl* L, lk_rx_lds* D, uint32_t wave, int lane) {
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t T = wave * 64 + lane;
+  uint8_t* const ring = L->rx->ring;
+  const uint32_t cap32 = (uint32_t)L->rx->cap;
+  uint32_t seen = 0;
+  for (;;) {
+    uint32_t sq;
+    uint32_t spins = 0;
+    while ((sq = __hip_atomic_load(&D->cmd.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == seen) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 0xFFFFu) == 0 && ldw(&L->abort.v) != 0) return;
+    }
+    seen = sq;
+    const lk_rx_cmd cm = D->cmd;  // (behind the acquire)
+    const uint32_t type = cm.type;
+    if (type == LK_CMD_EXIT) return;
+    if (type == LK_CMD_STATE) lk_rx_part_state(D, cm, T);
+    else if (type == LK_CMD_COUNT) lk_rx_part_xenc(D, cm, T);
+    else if (type == LK_CMD_TOTALS) lk_rx_part_totals(D, cm, wave, lane, cap32);
+    else if (type == LK_CMD_EMIT) lk_rx_part_emit(D, cm, wave, lane, L->tab[LK_SCATTER], ring, L->arena, L->out_slices, cap32);
+    drain();  // my stores (entries, slice table) are acknowledged before I count as done
+    if (lane == 0) __hip_atomic_fetch_add(&D->cmd.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
 __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) {
+  __builtin_amdgcn_s_setprio(3);
   grdma_conn* c = L->rx;
   uint8_t* const ring = c->ring;
   const uint64_t cap = c->cap, mask = cap - 1;
@@ -876,7 +1179,16 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
   const uint64_t t_begin = wall_clock64();
   bool failed = false;
 
-  lk_walker w = {ring, cap, head, 0, c->rx_h2, c->rx_h1, 0};
+  lk_walker w = {ring, cap, head, 0, 0, 0, 0, 0};
+  // (the sizes of the two newest records of an earlier call seed the history)
+  if (c->rx_h1) {
+    if (lane == 0) {
+      D->hist[0] = c->rx_h2 ? c->rx_h2 : c->rx_h1;
+      D->hist[1] = c->rx_h1;
+    }
+    lk_wave_sync();
+    w.hcount = 2;
+  }
   uint32_t q_head = 0, q_tail = 0;  // verified records not yet consumed: D->q[LKP(q_head .. q_tail))
 
   // Publication is lazy: a sealed chunk's entries become visible to the scatter waves at the
@@ -973,9 +1285,10 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
         }
         q_head = 0;
         q_tail = nq;
+        lk_wave_sync();
       }
       const uint64_t tw0 = wall_clock64();
-      const uint32_t got = lk_chain_round(&w, D->q, q_tail, lane);
+      const uint32_t got = lk_chain_round(&w, D->q, q_tail, D->hist, lane);
       t_walk += wall_clock64() - tw0;
       q_tail += got;
       flush_publish();
@@ -1038,127 +1351,103 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
     return cpy;
   };
 
-  // Up to 1024 whole records per step.  Lane l owns records [l * per, (l + 1) * per) of the step.
+  // post a command to the helper waves, do my own quarter, wait for theirs.  The command lives
+  // in (uniform) registers; lane 0 copies it to LDS for the helpers.
+  lk_rx_cmd cm;
+  cm.seq = 0; cm.type = 0; cm.done = 0; cm.m = cm.per = cm.cnt = cm.q_head = cm.slot = cm.head32 = cm.clean_max = 0;
+  cm.at0 = cm.xs0 = cm.a0 = 0;
+  for (int q = 0; q < 4; q++) cm.w_bytes[q] = cm.w_sl[q] = cm.w_ent[q] = cm.w_n[q] = 0;
+  auto run_cmd = [&](uint32_t type) {
+    cm.type = type;
+    cm.seq++;
+    lk_wave_sync();  // the tables the helpers are about to read were written by all my lanes
+    if (lane == 0) {
+      D->cmd.type = type;
+      D->cmd.m = cm.m; D->cmd.per = cm.per; D->cmd.cnt = cm.cnt; D->cmd.q_head = cm.q_head;
+      D->cmd.slot = cm.slot; D->cmd.head32 = cm.head32;
+      D->cmd.at0 = cm.at0; D->cmd.xs0 = cm.xs0; D->cmd.a0 = cm.a0;
+      if (type == LK_CMD_EMIT)
+        for (int q = 0; q < 4; q++) {
+          D->cmd.w_bytes[q] = cm.w_bytes[q]; D->cmd.w_sl[q] = cm.w_sl[q]; D->cmd.w_ent[q] = cm.w_ent[q];
+        }
+      if (type == LK_CMD_STATE) D->cmd.clean_max = 0;
+      __hip_atomic_store(&D->cmd.done, 0u, LK_WG_RLX);
+      __hip_atomic_store(&D->cmd.seq, cm.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    const uint32_t T = lane;
+    if (type == LK_CMD_STATE) lk_rx_part_state(D, cm, T);
+    else if (type == LK_CMD_COUNT) lk_rx_part_xenc(D, cm, T);
+    else if (type == LK_CMD_TOTALS) lk_rx_part_totals(D, cm, 0, lane, cap32);
+    else if (type == LK_CMD_EMIT) lk_rx_part_emit(D, cm, 0, lane, tab, ring, arena, out_slices, cap32);
+    uint32_t spins = 0;
+    while (__hip_atomic_load(&D->cmd.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 3u) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 0xFFFFu) == 0 && ldw(&L->abort.v) != 0) {  // a helper left on the abort word
+        failed = true;
+        break;
+      }
+    }
+    lk_wave_sync();  // what my own lanes wrote is read across lanes next
+  };
+  // exclusive prefix over the 256 per-thread values of one array (lane l holds threads 4 l .. 4 l + 3);
+  // returns the total
+  auto scan256 = [&](uint32_t* arr) -> uint32_t {
+    // (thread T's value sits at arr[T]; the order of the threads is the order of the records)
+    lk_wave_sync();
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      v[r] = arr[4 * lane + r];
+      sum += v[r];
+    }
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    uint32_t x = incl - sum;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      arr[4 * lane + r] = x;
+      x += v[r];
+    }
+    lk_wave_sync();
+    return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  };
+
+  // Up to 4096 whole records per step, worked on by the four waves of this block: thread T of 256
+  // owns records [T * per, (T + 1) * per).
   auto bulk_step = [&]() -> uint32_t {
-    fill(LK_STEP);
+    fill(LK_RX_STEP);
     if (failed) return 0;
     uint32_t m = q_tail - q_head;
     if (m == 0) return 0;
-    if (m > LK_STEP) m = LK_STEP;
-    const uint32_t per = (m + 63) / 64;
-    const uint32_t k0 = lane * per < m ? lane * per : m, k1 = k0 + per < m ? k0 + per : m;
-    // ---- incoming read state of my run: look back to the nearest record that resets it
-    uint32_t last_clean = 0;
-    {
-      uint32_t j = k0;
-      while (j > 0 && D->q[LKP(q_head + j - 1)] < 2 * MINRD - 1) j--;
-      uint32_t sp = 0;
-      for (; j < k0; j++) sp = lk_read_space_after(D->q[LKP(q_head + j)], sp);
-      for (uint32_t q = k0; q < k1; q++) {
-        D->sin[LKP(q)] = (uint16_t)sp;
-        sp = lk_read_space_after(D->q[LKP(q_head + q)], sp);
-        if (sp == 0) last_clean = q + 1;
-      }
-    }
+    if (m > LK_RX_STEP) m = LK_RX_STEP;
+    cm.m = m;
+    cm.per = (m + 255) / 256;
+    cm.q_head = q_head;
+    cm.head32 = (uint32_t)head;
+    run_cmd(LK_CMD_STATE);
     // records [0, cnt) are processed; the state ends clean
-    uint32_t cnt = last_clean;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const uint32_t o = __shfl_xor(cnt, d, 64);
-      cnt = o > cnt ? o : cnt;
-    }
+    const uint32_t cnt = __hip_atomic_load(&D->cmd.clean_max, LK_WG_RLX);
     if (cnt == 0) return 0;
-    const uint32_t e1 = k1 < cnt ? k1 : cnt;  // my run, cut at cnt
-    const uint32_t head32 = (uint32_t)head;
-    // ---- totals of my run
-    uint32_t t_enc = 0, t_bytes = 0, t_sl = 0, t_ent = 0, t_n = 0;
-    for (uint32_t q = k0; q < e1; q++) {
-      const uint32_t n = D->q[LKP(q_head + q)];
-      t_enc += 16u + (uint32_t)round_up8(n);
+    cm.cnt = cnt;
+    scan256(D->t_enc);
+    run_cmd(LK_CMD_COUNT);   // ring offsets of all m records
+    run_cmd(LK_CMD_TOTALS);  // per wave: arena bytes, slices, entries, payload
+    lk_wave_sync();
+    const uint32_t Ctot = D->xenc[LKP(cnt)];
+    uint32_t tot_bytes = 0, tot_sl = 0, tot_ent = 0, tot_n = 0;
+    for (int q = 0; q < 4; q++) {
+      const uint32_t wb = D->cmd.w_bytes[q], ws = D->cmd.w_sl[q], we = D->cmd.w_ent[q];
+      cm.w_bytes[q] = tot_bytes; cm.w_sl[q] = tot_sl; cm.w_ent[q] = tot_ent;  // exclusive over the waves
+      tot_bytes += wb; tot_sl += ws; tot_ent += we; tot_n += D->cmd.w_n[q];
     }
-    const uint32_t i_enc = wave_incl_scan_u32(t_enc);
-    {
-      uint32_t x = i_enc - t_enc;
-      for (uint32_t q = k0; q < e1; q++) {
-        const uint32_t n = D->q[LKP(q_head + q)];
-        D->xenc[LKP(q)] = x;
-        const lk_rec_plan rp = lk_replay_record(n, D->sin[LKP(q)]);
-        const uint32_t pay = (head32 + x + 8u) & mask32;
-        t_ent += lk_step_entries(pay, 0, rp.c1, cap32) + lk_step_entries(pay, rp.c1, rp.c2, cap32);
-        t_bytes += lk_al16_32(rp.sl0) + lk_al16_32(rp.sl1);
-        t_sl += rp.sl_cnt;
-        t_n += n;
-        x += 16u + (uint32_t)round_up8(n);
-      }
-    }
-    const uint32_t i_bytes = wave_incl_scan_u32(t_bytes), i_sl = wave_incl_scan_u32(t_sl);
-    const uint32_t i_ent = wave_incl_scan_u32(t_ent), i_n = wave_incl_scan_u32(t_n);
-    const uint32_t tot_ent = (uint32_t)__builtin_amdgcn_readlane((int)i_ent, 63);
-    const uint32_t tot_sl = (uint32_t)__builtin_amdgcn_readlane((int)i_sl, 63);
-    const uint32_t tot_bytes = (uint32_t)__builtin_amdgcn_readlane((int)i_bytes, 63);
-    const uint32_t tot_n = (uint32_t)__builtin_amdgcn_readlane((int)i_n, 63);
-    const uint32_t Ctot = (uint32_t)__builtin_amdgcn_readlane((int)i_enc, 63);
-    if (nslices + tot_sl > max_slices) { stw(&L->abort.v, LK_ERR_SLICES); failed = true; return 0; }
-    if (a_off + tot_bytes + 512 > arena_cap) { stw(&L->abort.v, LK_ERR_ARENA); failed = true; return 0; }
+    if (nslices + tot_sl > max_slices) { lk_abort(L, LK_ERR_SLICES, 1, nslices, tot_sl, max_slices, cnt); failed = true; return 0; }
+    if (a_off + tot_bytes + 512 > arena_cap) { lk_abort(L, LK_ERR_ARENA, 2, a_off, tot_bytes, cnt, m); failed = true; return 0; }
     if (!table_room(tot_ent)) { failed = true; return 0; }
     const uint64_t te0 = wall_clock64();
-    // ---- entries and slices of my run
-    {
-      uint64_t at = spub + pend_entries + i_ent - t_ent;
-      uint64_t xs = nslices + i_sl - t_sl;
-      uint64_t A = a_off + i_bytes - t_bytes;  // start of the open / next slice
-      const uint32_t slot = ((uint32_t)(chunks % LK_RSLOTS)) << 8;
-      for (uint32_t q = k0; q < e1; q++) {
-        const uint32_t n = D->q[LKP(q_head + q)];
-        const uint32_t s_in = D->sin[LKP(q)];
-        const lk_rec_plan rp = lk_replay_record(n, s_in);
-        const uint32_t pay = (head32 + D->xenc[LKP(q)] + 8u) & mask32;
-        const uint32_t filled = s_in ? MINRD - s_in : 0;
-        // the steps of one record are contiguous in the arena: step 1 fills the open 256-byte
-        // slice exactly, step 2 starts the next slice right behind it.  Header, padding and
-        // footer (ring_buffer.cc:146,173-180) are cleared by the scatter waves of the record's
-        // first / last entry.
-        uint64_t dst = (uint64_t)arena + A + filled;
-        const uint32_t total_ent = lk_step_entries(pay, 0, rp.c1, cap32) + lk_step_entries(pay, rp.c1, rp.c2, cap32);
-        uint32_t emitted = 0;
-        for (int stp = 0; stp < 2; stp++) {
-          const uint32_t off = stp ? rp.c1 : 0, len = stp ? rp.c2 : rp.c1;
-          if (len == 0) continue;
-          const uint32_t p0 = (pay + off) & mask32;
-          const uint32_t first = len < cap32 - p0 ? len : cap32 - p0;
-          for (int pi = 0; pi < 2; pi++) {
-            const uint32_t pl = pi ? len - first : first;
-            if (pl == 0) continue;
-            const uint64_t src = (uint64_t)ring + (pi ? 0u : p0);
-            const uint32_t nsub = lk_sub_entries(pl);
-            for (uint32_t j = 0; j < nsub; j++) {
-              const uint32_t o = j * LK_ENTRY_MAX;
-              const uint32_t l = pl - o < LK_ENTRY_MAX ? pl - o : LK_ENTRY_MAX;
-              uint32_t fl = (uint32_t)GRDMA_SEG_ZERO_SRC | slot;
-              if (emitted == 0) fl |= (uint32_t)GRDMA_SEG_TAG_HDR;
-              if (emitted == total_ent - 1) fl |= (uint32_t)GRDMA_SEG_TAG_FTR;
-              lk_store_entry(tab, at, dst + o, src + o, l, fl, 0);
-              at++;
-              emitted++;
-            }
-            dst += pl;
-          }
-        }
-        uint64_t sof = A;
-        if (rp.sl0) {
-          out_slices[xs].off = sof;
-          out_slices[xs].len = rp.sl0;
-          xs++;
-          sof += lk_al16_32(rp.sl0);
-        }
-        if (rp.sl1) {
-          out_slices[xs].off = sof;
-          out_slices[xs].len = rp.sl1;
-          xs++;
-        }
-        A += lk_al16_32(rp.sl0) + lk_al16_32(rp.sl1);
-      }
-    }
+    cm.at0 = spub + pend_entries;
+    cm.xs0 = nslices;
+    cm.a0 = a_off;
+    cm.slot = (uint32_t)(chunks % LK_RSLOTS);
+    run_cmd(LK_CMD_EMIT);
     pend_entries += tot_ent;
     t_emit += wall_clock64() - te0;
     // ---- credit accounting over the Recv steps (pair.cc:276-284): the records whose running
@@ -1267,7 +1556,7 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
       if (readable == 0) readable = next_ready();
       if (failed) break;
       const uint64_t alloc = leftover ? leftover : (readable > MINRD ? readable : MINRD);
-      if (a_off + alloc > arena_cap) { stw(&L->abort.v, LK_ERR_ARENA); failed = true; break; }
+      if (a_off + alloc > arena_cap) { lk_abort(L, LK_ERR_ARENA, 3, a_off, alloc, readable, leftover); failed = true; break; }
       uint64_t total = 0;
       while (total < alloc) {  // rdma_do_read loop, rdma_bp_posix.cc:195-277
         const uint64_t n = recv_step((uint64_t)(arena + a_off + total), alloc - total);
@@ -1297,6 +1586,12 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
       close_chunk((cr ? 1u : 0u) | 2u, credit_head);
     }
   }
+  // the helper waves may leave
+  cm.seq++;
+  if (lane == 0) {
+    D->cmd.type = LK_CMD_EXIT;
+    __hip_atomic_store(&D->cmd.seq, cm.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   // everything sealed: publish, wait for the scatter waves, post the last reports
   flush_publish();
   while (!failed && chunks_retired < chunks)
@@ -1316,8 +1611,8 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
     c->rx_arena_off = a_off;
     c->rx_slice_idx = nslices;
     if (credit_msgs) c->status_send.remote_head = credit_head;
-    c->rx_h1 = (uint32_t)w.h1;
-    c->rx_h2 = (uint32_t)w.h2;
+    c->rx_h1 = w.hcount >= 1 ? D->hist[(w.hcount - 1) % LK_HCAP] : 0;
+    c->rx_h2 = w.hcount >= 2 ? D->hist[(w.hcount - 2) % LK_HCAP] : 0;
     L->res_chunks = chunks;
     L->res_entries[LK_SCATTER] = spub;
     L->res_wait_ticks[2] = wait_data;
@@ -1334,7 +1629,7 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
 // k_link: grid (team, links).  Block 0 of a team is the sender's leader, block 1 the receiver's;
 // the waves of the other blocks are workers, dealt to the three stages by position.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LK_THREADS) void k_link(lk_ctl* const* ctls, uint64_t timeout_ticks) {
+__global__ __launch_bounds__(LK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_link(lk_ctl* const* ctls, uint64_t timeout_ticks) {
   lk_ctl* L = ctls[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6;
@@ -1344,7 +1639,13 @@ __global__ __launch_bounds__(LK_THREADS) void k_link(lk_ctl* const* ctls, uint64
     return;
   }
   if (blockIdx.x == 1) {
+    if (threadIdx.x == 0) {
+      s_lds.rx.cmd.seq = 0;
+      s_lds.rx.cmd.done = 0;
+    }
+    __syncthreads();  // (the only barrier of the block: before the roles part ways)
     if (wave == 0) lk_rx_leader(L, timeout_ticks, &s_lds.rx, lane);
+    else lk_rx_helper(L, &s_lds.rx, wave, lane);
     return;
   }
   const uint32_t ww = (blockIdx.x - 2) * (LK_THREADS / 64) + wave;

@@ -1275,7 +1275,6 @@ struct grdma_stream_job {
   uint64_t max_ring = 0;
   // link engine
   lk_ctl** d_lk_ptrs = nullptr;
-  bool lk_eager = false;
   uint32_t lk_team = 0;
   uint64_t lk_timeout_ticks = 0;
 };
@@ -1488,7 +1487,6 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
 // has been delivered.  See grdma_link.h.
 int job_engine_prepare(grdma_stream_job* j) {
   if (j->d_lk_ptrs) return 0;
-  if (const char* e = getenv("GRDMA_LINK_EAGER_CREDIT")) j->lk_eager = atoi(e) != 0;
   const uint32_t n = (uint32_t)j->links.size();
   const uint32_t resident = grdma_link_resident_blocks();
   if (resident == 0) return fail(GRDMA_ERR_HIP, "occupancy query for the link engine failed");
@@ -1573,7 +1571,6 @@ int job_engine_prepare(grdma_stream_job* j) {
       h.nwaves[t] = nw[t];
     }
     h.timeout_ms = (uint32_t)tmo_ms;
-    h.eager_credit = j->lk_eager ? 1 : 0;
     HIP_TRY(hipMemcpy(l.d_lk, &h, sizeof(h), hipMemcpyHostToDevice));
     ptrs[i] = l.d_lk;
   }
@@ -1601,8 +1598,11 @@ int job_engine_check(grdma_stream_job* j) {
       static const char* what[] = {"", "a role timed out waiting", "no progress (zero-length slice at the cursor)",
                                    "destination buffer too small", "slice table too small",
                                    "the ring does not hold the records the sender published"};
-      return fail(GRDMA_ERR_HIP, "link engine aborted on link %zu: %s (code %llu)", i, ab <= 5 ? what[ab] : "?",
-                  (unsigned long long)ab);
+      uint64_t dbg[8] = {0};
+      hipMemcpy(dbg, reinterpret_cast<uint8_t*>(j->links[i].d_lk) + offsetof(lk_ctl, res_dbg), sizeof(dbg), hipMemcpyDeviceToHost);
+      return fail(GRDMA_ERR_HIP, "link engine aborted on link %zu: %s (code %llu; site %llu: %llu %llu %llu %llu)", i,
+                  ab <= 5 ? what[ab] : "?", (unsigned long long)ab, (unsigned long long)dbg[1], (unsigned long long)dbg[2],
+                  (unsigned long long)dbg[3], (unsigned long long)dbg[4], (unsigned long long)dbg[5]);
     }
   }
   return 0;
@@ -1898,7 +1898,6 @@ int grdma_stream_job_engine_stats(grdma_stream_job* j, uint32_t link, uint64_t o
   out[9] = h.abort.v; out[10] = j->lk_team;
   for (int t = 0; t < 3; t++) out[11 + t] = h.nwaves[t];
   out[14] = h.n_staging;
-  out[15] = h.eager_credit;
   return 0;
 }
 

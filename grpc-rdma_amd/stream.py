@@ -89,7 +89,6 @@ class StreamJob:
                  "tx_wait_credit", "rx_wait_data", "rx_wait_scatter", "abort", "team", "gather_waves",
                  "wire_waves", "scatter_waves", "staging_buffers"]
         d = {k: int(out[i]) for i, k in enumerate(names)}
-        d["eager_credit"] = int(out[15])
         pr = (u64 * 12)()
         self.lib.grdma_stream_job_engine_prof.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(u64)]
         check(self.lib.grdma_stream_job_engine_prof(self.h, link, pr))
