@@ -213,6 +213,98 @@ __device__ __forceinline__ void wave_copy_tile_g(uint8_t* dst, const uint8_t* sr
   if ((uint64_t)lane < tail) d2[(units << 4) + lane] = tb;
 }
 
+// wave-uniform copy of a 64-bit value, provably uniform to the compiler (descriptor inputs)
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(uint64_t base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// One wave moves n <= GRDMA_TILE_BYTES bytes src -> dst, any alignment, optionally clearing the source
+// behind itself (reader zero-fill, ring_buffer.cc:160,164).  Destination-aligned 16-byte units;
+// an unaligned source is realigned in registers (unit u needs source blocks u and u + 1; block
+// u + 1 is what the next lane holds: wave_rol over the DPP network).  All loads -- up to nine
+// 16-byte blocks per lane plus the edge bytes -- are in flight before the first store.  Loads
+// and stores go through buffer descriptors sized to the tile: lanes beyond the tile read zero
+// and their stores are dropped by the bounds check, so there is no per-lane branching.  AUX_LD /
+// AUX_ST are the cache policies of the buffer instructions: 16 = sc1 (write-through stores, L1-
+// bypassing loads: what a hand-off inside a resident kernel needs), 2 = nt (streaming), 0 = default.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32x4 dpp_rol1(u32x4 v) {
+  u32x4 r;
+  r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x134, 0xf, 0xf, false);  // wave_rol:1
+  r.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x134, 0xf, 0xf, false);
+  r.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x134, 0xf, 0xf, false);
+  r.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x134, 0xf, 0xf, false);
+  return r;
+}
+
+// U: 16-byte units per lane = loads in flight (a tile is U KiB: n <= U * 1024)
+template <int AUX_LD, int AUX_ST, bool ZERO, int U = GRDMA_TILE_BYTES / 1024>
+__device__ __forceinline__ void wave_move_tile(uint64_t dst, uint64_t src, uint32_t n, int lane) {
+  uint32_t head = (uint32_t)((16 - (dst & 15)) & 15);
+  if (head > n) head = n;
+  const uint32_t n2 = n - head;
+  const uint32_t units = n2 >> 4, tail = n2 & 15;
+  const uint64_t d2 = dst + head, s2 = src + head;
+  const uint32_t shift = (uint32_t)(s2 & 15);
+  const uint32_t nblk = units ? units + (shift ? 1u : 0u) : 0u;
+  // (descriptor inputs must be provably wave-uniform: readfirstlane them)
+  const __amdgpu_buffer_rsrc_t rs = mk_rsrc(uni64(s2 & ~15ull), uni32(nblk * 16));
+  const __amdgpu_buffer_rsrc_t rd = mk_rsrc(uni64(d2), uni32(units * 16));
+  const __amdgpu_buffer_rsrc_t rsb = mk_rsrc(uni64(src), uni32(n));
+  const __amdgpu_buffer_rsrc_t rdb = mk_rsrc(uni64(dst), uni32(n));
+  const uint32_t tail_off = head + (units << 4);
+  u32x4 a[U + 1];
+#pragma unroll
+  for (int k = 0; k < U; k++) a[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * k) * 16, 0, AUX_LD);
+  a[U] = __builtin_amdgcn_raw_buffer_load_b128(rs, 64 * U * 16, 0, AUX_LD);  // block 64 U: same for every lane
+  // edge bytes (out-of-range lanes read 0 and store nothing)
+  const uint8_t hb = __builtin_amdgcn_raw_buffer_load_b8(rsb, (uint32_t)lane < head ? lane : n, 0, AUX_LD);
+  const uint8_t tb = __builtin_amdgcn_raw_buffer_load_b8(rsb, (uint32_t)lane < tail ? tail_off + lane : n, 0, AUX_LD);
+  if (shift == 0) {
+#pragma unroll
+    for (int k = 0; k < U; k++) __builtin_amdgcn_raw_buffer_store_b128(a[k], rd, (lane + 64 * k) * 16, 0, AUX_ST);
+  } else {
+    // unit u needs blocks u and u + 1: block u + 1 sits in the next lane (lane 63: in lane 0's
+    // next register)
+    u32x4 r_cur = dpp_rol1(a[0]);
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      const u32x4 r_next = dpp_rol1(a[k + 1]);
+      const u32x4 b = lane == 63 ? r_next : r_cur;
+      __builtin_amdgcn_raw_buffer_store_b128(funnel16(a[k], b, shift), rd, (lane + 64 * k) * 16, 0, AUX_ST);
+      r_cur = r_next;
+    }
+  }
+  __builtin_amdgcn_raw_buffer_store_b8(hb, rdb, (uint32_t)lane < head ? lane : n, 0, AUX_ST);
+  __builtin_amdgcn_raw_buffer_store_b8(tb, rdb, (uint32_t)lane < tail ? tail_off + lane : n, 0, AUX_ST);
+  if (ZERO) {
+    // Every load of the tile has returned: its data fed the stores above, and a store cannot
+    // issue before its operands arrived.  So the source may be overwritten right away.
+    const uint64_t zs = (src + 15) & ~15ull, ze = (src + n) & ~15ull;
+    if (ze > zs) {
+      const uint32_t zu = (uint32_t)((ze - zs) >> 4);
+      const __amdgpu_buffer_rsrc_t rz = mk_rsrc(uni64(zs), uni32(zu * 16));
+#pragma unroll
+      for (int k = 0; k < U; k++) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0, 0, 0, 0}, rz, (lane + 64 * k) * 16, 0, AUX_ST);
+      const uint32_t e0 = (uint32_t)(zs - src), e1 = (uint32_t)(src + n - ze);  // < 16 each
+      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, rsb, (uint32_t)lane < e0 ? lane : n, 0, AUX_ST);
+      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, rsb, (uint32_t)lane < e1 ? (uint32_t)(ze - src) + lane : n, 0, AUX_ST);
+    } else {
+      // fewer than 31 bytes, no whole aligned block inside: bytes only
+      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, rsb, lane, 0, AUX_ST);
+    }
+  }
+}
+
+
 // Reader zero-fill (ring_buffer.cc:160,164): clear exactly [p, p+n).
 __device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane) {
   uint64_t head = (16 - ((uint64_t)p & 15)) & 15;
@@ -282,7 +374,11 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
     uint64_t n = sg.len - off;
     if (n > GRDMA_TILE_BYTES) n = GRDMA_TILE_BYTES;
     uint8_t* src = sg.src ? reinterpret_cast<uint8_t*>(sg.src + off) : nullptr;
-    wave_copy_tile_g(reinterpret_cast<uint8_t*>(sg.dst + off), src, n, lane);
+    // (nontemporal loads: payload streams through once; plain stores: the next kernel of the
+    // round reads what this one wrote out of the Infinity Cache)
+    if (src == nullptr) wave_zero_tile(reinterpret_cast<uint8_t*>(sg.dst + off), n, lane);
+    else if (sg.flags & GRDMA_SEG_ZERO_SRC) wave_move_tile<2, 0, true>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
+    else wave_move_tile<2, 0, false>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
     if (sg.flags & (GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR)) {
       const bool wr = (sg.flags & GRDMA_SEG_TAG_WRITE) != 0;
       const uint64_t side = wr ? sg.dst : sg.src;
@@ -297,12 +393,6 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
         if ((uint64_t)lane < pad) tb[e + lane] = 0;
         if (lane == 8) *reinterpret_cast<uint64_t*>(tb + ((e + pad) & tm)) = wr ? GRDMA_FOOTER : 0;
       }
-    }
-    if ((sg.flags & GRDMA_SEG_ZERO_SRC) && src) {
-      // Every load of this tile has returned: its data fed the stores issued above, and
-      // a store cannot issue before its operands have arrived.  So the source may be
-      // overwritten right away, without waiting for those stores to complete.
-      wave_zero_tile(src, n, lane);
     }
     if (++t >= tend) {
       if (CONTIG) break;

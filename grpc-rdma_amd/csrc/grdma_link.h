@@ -28,13 +28,14 @@
 
 #include "grdma_dev.h"
 
-#define LK_ENTRY_MAX 16384u   // bytes one table entry moves (two 8 KiB wave tiles)
-#define LK_TILE 8192u         // bytes one wave moves per step: 64 lanes x 16 B x 8 in flight
+#define LK_ENTRY_MAX 16384u   // bytes one table entry moves: one wave tile
+#define LK_TILE 16384u        // bytes one wave moves per step: 64 lanes x 16 B x 16 in flight
 #define LK_TABLE_CAP 32768u   // entries per table (a ring; power of two)
 #define LK_SLOTS 16u          // Sends in flight (completion counters per stage)
 #define LK_RSLOTS 64u         // receive chunks in flight
 #define LK_MAX_STAGING 8u     // staging buffers a sender rotates through
 #define LK_THREADS 256
+#define LK_REPL 8u            // copies of a word that hundreds of waves poll (one per memory channel group)
 
 enum { LK_GATHER = 0, LK_WIRE = 1, LK_SCATTER = 2 };
 
@@ -79,7 +80,10 @@ struct lk_ctl {
   // ---- dynamic state, zeroed before every launch --------------------------------------------
   // (each polled word on its own 128-byte line: a poller must not share a line with a word
   //  somebody else is storing to)
-  struct { uint64_t v; uint64_t pad[15]; } published[3];   // entries published per stage
+  // entries published per stage.  Every idle worker wave polls this word, and a polled word is
+  // re-fetched from the memory side each time (sc1): the copies sit 4 KiB + 128 B apart so the polls
+  // of a stage spread over several memory channels instead of queueing the copy traffic of one
+  struct { uint64_t v; uint64_t pad[527]; } published[3][LK_REPL];
   struct { uint64_t v; uint64_t pad[15]; } closed[3];      // no further entry will be published
   struct { uint64_t v; uint64_t pad[15]; } sends_pub;      // Sends published
   struct { uint64_t v; uint64_t pad[15]; } tx_done;        // the sender has nothing more to send
@@ -95,6 +99,14 @@ struct lk_ctl {
   uint64_t res_prof[8];            // profiling aid: leader busy time (tx: pricing, wire+publish, total; rx: walk, fast steps, scalar steps, total)
   uint64_t res_err_detail[4];      // (profiling aid: sender step phases)
   uint64_t res_dbg[8];             // what the first aborting role saw: {code, site, a, b, c, d}
+  // profiling aid: event trace of the two leaders {tag << 56 | wall-clock tick}, tags:
+  // 1 Send priced, 2 Send published, 3 ring writes released (arg = Sends released so far),
+  // 4 receiver starts waiting for round r, 5 round r has landed, 6 round r walked and planned,
+  // 7 credit report posted, 8 round r complete (scatter done)
+  // rows 2..4: worker wave 0 of the gather / wire / scatter stage: 9 entry taken (arg = entry),
+  // 10 its dependency is met, 11 entry counted done
+  uint32_t trace_n[6];
+  uint64_t trace[5][192];
 };
 
 #define LK_DYNAMIC_OFFSET offsetof(struct lk_ctl, published)

@@ -36,17 +36,6 @@ __device__ __forceinline__ uint32_t ldw32(const uint32_t* p) { return __hip_atom
 __device__ __forceinline__ void stw32(uint32_t* p, uint32_t v) { __hip_atomic_store((gu32*)(uint64_t)p, v, RLX_AGENT); }
 __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// wave-uniform copy of a 64-bit value, provably uniform to the compiler (descriptor inputs)
-__device__ __forceinline__ uint64_t uni64(uint64_t v) {
-  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
-         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-}
-__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(uint64_t base, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-
 // Lanes of one wave that hand data to each other through memory (LDS tables, a word one lane
 // stores and all lanes read) execute in lockstep, but the COMPILER reasons per thread: a load may
 // be hoisted above another lane's store.  A wavefront-scope fence is a no-op in hardware and
@@ -65,6 +54,16 @@ __device__ __forceinline__ void lk_abort(lk_ctl* L, uint64_t code, uint64_t site
   stw(&L->abort.v, code);
 }
 
+__device__ __forceinline__ void lk_trace(lk_ctl* L, int who, uint32_t& n, uint64_t tag, uint64_t arg, int lane) {
+  if (lane == 0 && n < 192) L->trace[who][n] = (tag << 56) | ((arg & 0xFFFFull) << 40) | (wall_clock64() & 0xFFFFFFFFFFull);
+  n++;
+}
+
+__device__ __forceinline__ void lk_publish(lk_ctl* L, int stage, uint64_t v) {
+#pragma unroll
+  for (uint32_t r = 0; r < LK_REPL; r++) stw(&L->published[stage][r].v, v);
+}
+
 // Bounded spin: polls cond() (relaxed loads), leaves on the abort word or on the wall clock.
 template <typename F>
 __device__ __forceinline__ bool lk_spin(lk_ctl* L, uint64_t limit_ticks, F cond) {
@@ -72,94 +71,19 @@ __device__ __forceinline__ bool lk_spin(lk_ctl* L, uint64_t limit_ticks, F cond)
   uint64_t t0 = 0;
   for (;;) {
     if (cond()) return true;
-    if (ldw(&L->abort.v) != 0) return false;
-    if ((++n & 127u) == 0) {
-      const uint64_t now = wall_clock64();
-      if (t0 == 0) t0 = now;
-      else if (now - t0 > limit_ticks) {
-        stw(&L->abort.v, LK_ERR_TIMEOUT);
-        return false;
+    if ((++n & 15u) == 0) {
+      if (ldw(&L->abort.v) != 0) return false;
+      if ((n & 127u) == 0) {
+        const uint64_t now = wall_clock64();
+        if (t0 == 0) t0 = now;
+        else if (now - t0 > limit_ticks) {
+          stw(&L->abort.v, LK_ERR_TIMEOUT);
+          return false;
+        }
       }
     }
-    __builtin_amdgcn_s_sleep(4);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// One wave moves n <= LK_TILE bytes src -> dst, any alignment, optionally clearing the source
-// behind itself (reader zero-fill, ring_buffer.cc:160,164).  Destination-aligned 16-byte units;
-// an unaligned source is realigned in registers (unit u needs source blocks u and u + 1; block
-// u + 1 is what the next lane holds: wave_rol over the DPP network).  All loads -- up to nine
-// 16-byte blocks per lane plus the edge bytes -- are in flight before the first store.  Loads
-// and stores go through buffer descriptors sized to the tile: lanes beyond the tile read zero
-// and their stores are dropped by the bounds check, so there is no per-lane branching, and the
-// sc1 policy makes every store a write-through one (visible to other CUs once acknowledged).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32x4 dpp_rol1(u32x4 v) {
-  u32x4 r;
-  r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x134, 0xf, 0xf, false);  // wave_rol:1
-  r.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x134, 0xf, 0xf, false);
-  r.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x134, 0xf, 0xf, false);
-  r.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x134, 0xf, 0xf, false);
-  return r;
-}
-
-template <bool ZERO>
-__device__ __forceinline__ void lk_move_tile(uint64_t dst, uint64_t src, uint32_t n, int lane) {
-  constexpr int U = LK_TILE / 1024;  // 16-byte units per lane
-  uint32_t head = (uint32_t)((16 - (dst & 15)) & 15);
-  if (head > n) head = n;
-  const uint32_t n2 = n - head;
-  const uint32_t units = n2 >> 4, tail = n2 & 15;
-  const uint64_t d2 = dst + head, s2 = src + head;
-  const uint32_t shift = (uint32_t)(s2 & 15);
-  const uint32_t nblk = units ? units + (shift ? 1u : 0u) : 0u;
-  // (descriptor inputs must be provably wave-uniform: readfirstlane them)
-  const __amdgpu_buffer_rsrc_t rs = mk_rsrc(uni64(s2 & ~15ull), uni32(nblk * 16));
-  const __amdgpu_buffer_rsrc_t rd = mk_rsrc(uni64(d2), uni32(units * 16));
-  const __amdgpu_buffer_rsrc_t rsb = mk_rsrc(uni64(src), uni32(n));
-  const __amdgpu_buffer_rsrc_t rdb = mk_rsrc(uni64(dst), uni32(n));
-  const uint32_t tail_off = head + (units << 4);
-  u32x4 a[U + 1];
-#pragma unroll
-  for (int k = 0; k < U; k++) a[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * k) * 16, 0, LK_AUX_SC1);
-  a[U] = __builtin_amdgcn_raw_buffer_load_b128(rs, 64 * U * 16, 0, LK_AUX_SC1);  // block 64 U: same for every lane
-  // edge bytes (out-of-range lanes read 0 and store nothing)
-  const uint8_t hb = __builtin_amdgcn_raw_buffer_load_b8(rsb, (uint32_t)lane < head ? lane : n, 0, LK_AUX_SC1);
-  const uint8_t tb = __builtin_amdgcn_raw_buffer_load_b8(rsb, (uint32_t)lane < tail ? tail_off + lane : n, 0, LK_AUX_SC1);
-  if (shift == 0) {
-#pragma unroll
-    for (int k = 0; k < U; k++) __builtin_amdgcn_raw_buffer_store_b128(a[k], rd, (lane + 64 * k) * 16, 0, LK_AUX_SC1);
-  } else {
-    // unit u needs blocks u and u + 1: block u + 1 sits in the next lane (lane 63: in lane 0's
-    // next register)
-    u32x4 r_cur = dpp_rol1(a[0]);
-#pragma unroll
-    for (int k = 0; k < U; k++) {
-      const u32x4 r_next = dpp_rol1(a[k + 1]);
-      const u32x4 b = lane == 63 ? r_next : r_cur;
-      __builtin_amdgcn_raw_buffer_store_b128(funnel16(a[k], b, shift), rd, (lane + 64 * k) * 16, 0, LK_AUX_SC1);
-      r_cur = r_next;
-    }
-  }
-  __builtin_amdgcn_raw_buffer_store_b8(hb, rdb, (uint32_t)lane < head ? lane : n, 0, LK_AUX_SC1);
-  __builtin_amdgcn_raw_buffer_store_b8(tb, rdb, (uint32_t)lane < tail ? tail_off + lane : n, 0, LK_AUX_SC1);
-  if (ZERO) {
-    // Every load of the tile has returned: its data fed the stores above, and a store cannot
-    // issue before its operands arrived.  So the source may be overwritten right away.
-    const uint64_t zs = (src + 15) & ~15ull, ze = (src + n) & ~15ull;
-    if (ze > zs) {
-      const uint32_t zu = (uint32_t)((ze - zs) >> 4);
-      const __amdgpu_buffer_rsrc_t rz = mk_rsrc(uni64(zs), uni32(zu * 16));
-#pragma unroll
-      for (int k = 0; k < U; k++) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0, 0, 0, 0}, rz, (lane + 64 * k) * 16, 0, LK_AUX_SC1);
-      const uint32_t e0 = (uint32_t)(zs - src), e1 = (uint32_t)(src + n - ze);  // < 16 each
-      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, rsb, (uint32_t)lane < e0 ? lane : n, 0, LK_AUX_SC1);
-      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, rsb, (uint32_t)lane < e1 ? (uint32_t)(ze - src) + lane : n, 0, LK_AUX_SC1);
-    } else {
-      // fewer than 31 bytes, no whole aligned block inside: bytes only
-      __builtin_amdgcn_raw_buffer_store_b8((uint8_t)0, rsb, lane, 0, LK_AUX_SC1);
-    }
+    if (n < 16u) __builtin_amdgcn_s_sleep(4);
+    else __builtin_amdgcn_s_sleep(20);
   }
 }
 
@@ -172,7 +96,7 @@ __device__ __forceinline__ void lk_run_entry(uint64_t e_dst, uint64_t e_src, uin
 #pragma unroll 1
   for (uint32_t off = 0; off < e_len; off += LK_TILE) {
     const uint32_t n = e_len - off < LK_TILE ? e_len - off : LK_TILE;
-    lk_move_tile<ZERO>(e_dst + off, e_src + off, n, lane);
+    wave_move_tile<LK_AUX_SC1, LK_AUX_SC1, ZERO, (int)(LK_TILE / 1024)>(e_dst + off, e_src + off, n, lane);
   }
   if (e_flags & (GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR)) {
     const bool wr = (e_flags & GRDMA_SEG_TAG_WRITE) != 0;
@@ -202,11 +126,15 @@ __device__ __forceinline__ void lk_worker(lk_ctl* L, int stage, uint32_t w, uint
     tag_base = (uint64_t)L->tx->peer_ring;
     tag_mask = L->tx->cap - 1;
   }
-  const uint64_t* const pub = &L->published[stage].v;
+  const uint64_t* const pub = &L->published[stage][w % LK_REPL].v;
   const uint64_t* const closed = &L->closed[stage].v;
   const uint64_t* const abort_w = &L->abort.v;
   const __amdgpu_buffer_rsrc_t rtab = mk_rsrc(uni64((uint64_t)L->tab[stage]), (uint32_t)(sizeof(lk_entry) * LK_TABLE_CAP));
   uint64_t pub_seen = 0;  // published count read last (entries below it need no new poll)
+  uint32_t trn = 0;
+  const bool tracing = w == 0;
+  bool pre = false;
+  u32x4 p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
   for (uint64_t lap = 0;; lap++) {
     // Entry ownership rotates by one wave per lap: a periodic mix of small and large entries (a
     // 9-byte frame header in front of every 16 KiB payload) is spread over all waves whatever W is.
@@ -217,37 +145,53 @@ __device__ __forceinline__ void lk_worker(lk_ctl* L, int stage, uint32_t w, uint
       for (;;) {
         pub_seen = ldw(pub);
         if (pub_seen > e) break;
-        if (ldw(closed) != 0) {  // published is final once closed is set: read it again
-          pub_seen = ldw(pub);
-          if (pub_seen > e) break;
-          return;
-        }
-        if (ldw(abort_w) != 0) return;
-        if ((++n & 127u) == 0) {
-          const uint64_t now = wall_clock64();
-          if (t0 == 0) t0 = now;
-          else if (now - t0 > ticks) {
-            stw(&L->abort.v, LK_ERR_TIMEOUT);
+        if ((++n & 7u) == 0) {   // the rare words are looked at every 8th poll only
+          if (ldw(closed) != 0) {  // published is final once closed is set: read it again
+            pub_seen = ldw(pub);
+            if (pub_seen > e) break;
+            if (tracing && lane == 0) L->trace_n[2 + stage] = trn < 192 ? trn : 192;
             return;
           }
+          if (ldw(abort_w) != 0) return;
+          if ((n & 127u) == 0) {
+            const uint64_t now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > ticks) {
+              stw(&L->abort.v, LK_ERR_TIMEOUT);
+              return;
+            }
+          }
         }
-        __builtin_amdgcn_s_sleep(8);
+        if (n < 8u) __builtin_amdgcn_s_sleep(6);
+        else __builtin_amdgcn_s_sleep(24);
       }
     }
-    // the whole 32-byte entry in one round trip (same address in every lane)
-    const uint32_t eoff = (uint32_t)(e & (LK_TABLE_CAP - 1)) * (uint32_t)sizeof(lk_entry);
-    const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rtab, eoff, 0, LK_AUX_SC1);
-    const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rtab, eoff + 16, 0, LK_AUX_SC1);
+    // the whole 32-byte entry in one round trip (same address in every lane) -- unless it came
+    // with the previous entry's data already
+    u32x4 q0, q1;
+    if (pre) {
+      q0 = p0;
+      q1 = p1;
+    } else {
+      const uint32_t eoff = (uint32_t)(e & (LK_TABLE_CAP - 1)) * (uint32_t)sizeof(lk_entry);
+      q0 = __builtin_amdgcn_raw_buffer_load_b128(rtab, eoff, 0, LK_AUX_SC1);
+      q1 = __builtin_amdgcn_raw_buffer_load_b128(rtab, eoff + 16, 0, LK_AUX_SC1);
+    }
+    {
+      // my next entry, if it is published already: fetched under this entry's copy
+      const uint64_t e2 = (lap + 1) * W + (w + W - (uint32_t)((lap + 1) % W)) % W;
+      pre = pub_seen > e2;
+      if (pre) {
+        const uint32_t eoff2 = (uint32_t)(e2 & (LK_TABLE_CAP - 1)) * (uint32_t)sizeof(lk_entry);
+        p0 = __builtin_amdgcn_raw_buffer_load_b128(rtab, eoff2, 0, LK_AUX_SC1);
+        p1 = __builtin_amdgcn_raw_buffer_load_b128(rtab, eoff2 + 16, 0, LK_AUX_SC1);
+      }
+    }
     const uint64_t e_dst = (uint64_t)q0.x | ((uint64_t)q0.y << 32), e_src = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
     const uint32_t e_len = q1.x, e_flags = q1.y;
     const uint64_t e_aux = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
     const uint32_t slot = (e_flags >> 8) & 0xFFu;
-    if (stage == LK_WIRE) {
-      // staging is complete when every gather entry of this Send has been counted in
-      const uint32_t* g = &L->done_tx[LK_GATHER][slot].v;
-      const uint32_t need = (uint32_t)e_aux;
-      if (!lk_spin(L, ticks, [&]() { return ldw32(g) >= need; })) return;
-    }
+    if (tracing) lk_trace(L, 2 + stage, trn, 9, e, lane);
     if (stage == LK_SCATTER) lk_run_entry<true>(e_dst, e_src, e_len, e_flags, e_aux, tag_base, tag_mask, lane);
     else lk_run_entry<false>(e_dst, e_src, e_len, e_flags, e_aux, tag_base, tag_mask, lane);
     drain();  // my write-through stores are acknowledged: the entry may be counted
@@ -255,6 +199,7 @@ __device__ __forceinline__ void lk_worker(lk_ctl* L, int stage, uint32_t w, uint
       uint32_t* d = stage == LK_SCATTER ? &L->done_rx[slot].v : &L->done_tx[stage][slot].v;
       __hip_atomic_fetch_add((gu32*)(uint64_t)d, 1u, RLX_AGENT);
     }
+    if (tracing) lk_trace(L, 2 + stage, trn, 11, e, lane);
   }
 }
 
@@ -438,6 +383,7 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
   uint64_t gated = 0, rel_tail = c->remote_tail, rel_pub = 0;
   uint64_t wait_slot = 0, wait_credit = 0, t_price = 0, t_pub = 0;
   uint64_t tph[4] = {0, 0, 0, 0};  // profiling aid: load, price, count, emit
+  uint32_t trn = 0;
   const uint64_t t_begin = wall_clock64();
   bool failed = false;
 
@@ -454,12 +400,19 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
       const uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       const uint64_t freeb = cap - ((rel_tail + cap - rhead) & mask);
       if (freeb < need + 8) break;  // (every record of the Send passed W(free - st) >= pay against an even larger free space)
+      // the wire reads staging: every gather entry of the Send must have been counted in.  (Checked
+      // here by one wave, not by the wire waves: hundreds of pollers on a word that is also the
+      // target of the gather waves' atomic adds starve those adds for tens of microseconds.)
+      if (!direct && ldw32(&L->done_tx[LK_GATHER][s].v) < __shfl(my_ng, s, 64)) break;
       rel_pub += direct ? __shfl(my_ng, s, 64) : __shfl(my_nw, s, 64);
       rel_tail = (rel_tail + need) & mask;
       gated++;
       any = true;
     }
-    if (any) stw(&L->published[gate_stage].v, rel_pub);
+    if (any) {
+      lk_publish(L, gate_stage, rel_pub);
+      lk_trace(L, 0, trn, 3, gated, lane);
+    }
   };
 
   auto retire_oldest = [&]() -> bool {
@@ -508,6 +461,7 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
         // lengths are clamped for pricing: whatever exceeds the budget is short anyway
         const uint32_t clampv = (uint32_t)(room0 + 64);
         for (bool stop = false; !stop && !failed;) {
+          if (nrec != 0) release_ring_writes();  // (a Send whose gather has finished meanwhile goes onto the wire)
           // ---- this step's slices -> LDS (striped loads, all in flight together)
           const uint64_t first = idx + nrec;
           uint64_t m64 = nslices - first;
@@ -674,6 +628,7 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
       const uint64_t staged = st_base;
       const uint64_t tp1 = wall_clock64();
       t_price += tp1 - tp0;
+      lk_trace(L, 0, trn, 1, k, lane);
       // the wire: the <= 2 RDMA WRITEs of GetWriteRequests (ring_buffer.cc:261-330), cut into entries
       uint32_t nw = 0;
       if (!direct) {
@@ -713,8 +668,9 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
         my_nw = nw;
         my_staged = staged;
       }
-      if (!direct) stw(&L->published[LK_GATHER].v, gpub);  // staging is mine: gather right away
+      if (!direct) lk_publish(L, LK_GATHER, gpub);  // staging is mine: gather right away
       stw(&L->sends_pub.v, k + 1);
+      lk_trace(L, 0, trn, 2, k, lane);
       // bookkeeping of Send() and the rdma_flush cursor walk (rdma_bp_posix.cc:480-493)
       tail = (tail + staged) & mask;
       const uint64_t offered = remaining;
@@ -765,6 +721,7 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
     L->res_prof[1] = t_pub;
     L->res_prof[2] = wall_clock64() - t_begin;
     for (int q = 0; q < 4; q++) L->res_err_detail[q] = tph[q];
+    L->trace_n[0] = trn < 192 ? trn : 192;
   }
 }
 
@@ -1176,6 +1133,7 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
   uint64_t my_credit = 0;
   uint64_t rounds_done = 0;                 // Sends drained with zero-fill complete and credits posted
   uint64_t wait_data = 0, wait_table = 0, t_walk = 0, t_fast = 0, t_scalar = 0, t_emit = 0;
+  uint32_t trn = 0;
   const uint64_t t_begin = wall_clock64();
   bool failed = false;
 
@@ -1198,7 +1156,7 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
   auto flush_publish = [&]() {
     if (spub_visible != spub) {
       drain();  // entries, slice table and my own tag clears are acknowledged
-      stw(&L->published[LK_SCATTER].v, spub);
+      lk_publish(L, LK_SCATTER, spub);
       spub_visible = spub;
     }
   };
@@ -1221,11 +1179,13 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
       if (fl & 1u) {
         grdma_status_report* ps = c->peer_status;
         if (ps != nullptr) __hip_atomic_store(&ps->remote_head, ch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        lk_trace(L, 1, trn, 7, chunks_retired, lane);
       }
       if (fl & 2u) {
         rounds_done++;
         drain();
         stw(&L->rx_rounds_done.v, rounds_done);
+        lk_trace(L, 1, trn, 8, rounds_done, lane);
       }
       sfloor += n;
       chunks_retired++;
@@ -1499,6 +1459,7 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
     // wait for Send r (or the end of the job)
     bool have = false;
     flush_publish();
+    lk_trace(L, 1, trn, 4, r, lane);
     {
       const uint64_t t0 = wall_clock64();
       const bool ok = lk_spin(L, ticks, [&]() {
@@ -1532,6 +1493,7 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
     }
     stw(&L->rx_sends_seen.v, r + 1);
     w.limit += staged;
+    lk_trace(L, 1, trn, 5, r, lane);
 
     // drain: endpoint reads until one would block
     const uint64_t nslices0 = nslices;
@@ -1580,6 +1542,7 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
     }
     if (failed) break;
     if (nslices != nslices0) rounds_with_data++;
+    lk_trace(L, 1, trn, 6, r, lane);
     {
       const bool cr = credit_msgs != credit_seen;
       credit_seen = credit_msgs;
@@ -1622,6 +1585,7 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
     L->res_prof[5] = t_scalar;
     L->res_prof[6] = wall_clock64() - t_begin;
     L->res_prof[7] = t_emit;
+    L->trace_n[1] = trn < 192 ? trn : 192;
   }
 }
 

@@ -1885,6 +1885,21 @@ int grdma_stream_job_engine_prof(grdma_stream_job* j, uint32_t link, uint64_t ou
   return 0;
 }
 
+// profiling aid: the leaders' event traces (see lk_ctl::trace); out[who][0] = count
+int grdma_stream_job_engine_trace(grdma_stream_job* j, uint32_t link, uint64_t out[5][193]) {
+  if (int rc = require_ctx()) return rc;
+  if (!j || !out || link >= j->links.size() || !j->links[link].d_lk) return fail(GRDMA_ERR_INVALID, "bad argument");
+  HIP_TRY(hipStreamSynchronize(j->stream));
+  std::vector<uint8_t> h(sizeof(lk_ctl));
+  HIP_TRY(hipMemcpy(h.data(), j->links[link].d_lk, sizeof(lk_ctl), hipMemcpyDeviceToHost));
+  const lk_ctl* c = reinterpret_cast<const lk_ctl*>(h.data());
+  for (int w = 0; w < 5; w++) {
+    out[w][0] = c->trace_n[w];
+    for (int i = 0; i < 192; i++) out[w][1 + i] = c->trace[w][i];
+  }
+  return 0;
+}
+
 int grdma_stream_job_engine_stats(grdma_stream_job* j, uint32_t link, uint64_t out[16]) {
   if (int rc = require_ctx()) return rc;
   if (!j || !out || link >= j->links.size() || !j->links[link].d_lk) return fail(GRDMA_ERR_INVALID, "bad argument");

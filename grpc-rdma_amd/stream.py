@@ -102,6 +102,21 @@ class StreamJob:
         n = check(self.lib.grdma_stream_job_slices_of(self.h, link, arr, self.slices_cap))
         return [(int(arr[i].off), int(arr[i].len)) for i in range(n)]
 
+    def engine_trace(self, link=0):
+        """-> sorted [(us since the first event, who, tag, arg)] of the last engine pass."""
+        out = ((u64 * 193) * 5)()
+        self.lib.grdma_stream_job_engine_trace.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        check(self.lib.grdma_stream_job_engine_trace(self.h, link, out))
+        ev = []
+        for who in range(5):
+            for i in range(int(out[who][0])):
+                v = int(out[who][1 + i])
+                ev.append((v & 0xFFFFFFFFFF, who, v >> 56, (v >> 40) & 0xFFFF))
+        if not ev:
+            return []
+        t0 = min(e[0] for e in ev)
+        return sorted(((t - t0) / 100.0, who, tag, arg) for t, who, tag, arg in ev)
+
     def close(self):
         if self.h:
             self.lib.grdma_stream_job_destroy(self.h)

@@ -280,6 +280,7 @@ int grdma_stream_job_launch(grdma_stream_job* j);
 int grdma_stream_job_launch_engine(grdma_stream_job* j);
 int grdma_stream_job_engine_stats(grdma_stream_job* j, uint32_t link, uint64_t out[16]);
 int grdma_stream_job_engine_prof(grdma_stream_job* j, uint32_t link, uint64_t out[12]);
+int grdma_stream_job_engine_trace(grdma_stream_job* j, uint32_t link, uint64_t out[5][193]);
 /* Same work as _launch, issued kernel by kernel on the job's streams (no graph). */
 int grdma_stream_job_launch_streams(grdma_stream_job* j);
 int grdma_stream_job_sync(grdma_stream_job* j);

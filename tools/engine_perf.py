@@ -49,6 +49,11 @@ def run(g, gs, name, ring_kb, max_sge, n_links, msgs, payload, steps=10, flags=0
                                                      "rx_wait_data", "rx_wait_scatter", "rx_walk", "rx_fast", "rx_scalar", "rx_total", "rx_emit",
                                                      "tx_ph_load", "tx_ph_price", "tx_ph_count", "tx_ph_emit")}}
     print(json.dumps(out), flush=True)
+    if os.environ.get("ENGINE_TRACE"):
+        names = {1: "tx priced", 2: "tx published", 3: "tx released up to", 4: "rx waits for", 5: "rx landed",
+                 6: "rx planned", 7: "rx credit after chunk", 8: "rx round complete", 9: "takes entry", 10: "dependency met", 11: "done entry"}
+        for t, who, tag, arg in job.engine_trace(0):
+            print("  %9.1f us  %s %s %d" % (t, ["TX", "RX", "  g0", "    w0", "      s0"][who], names.get(tag, tag), arg))
     job.close()
     for tx, rx, dst in keep:
         tx.close(); rx.close(); dst.free()
