@@ -93,6 +93,114 @@ class Workload:
                         for it in self.layout)
 
 
+class MixedWorkload(Workload):
+    """Message sizes drawn like the reference's random-size test (examples/cpp/test/common.h:4-31:
+    uniform in [1, 4 MiB - 1 KiB]), fixed seed; every message framed on its own stream id."""
+
+    def __init__(self, g, n_msgs, seed=0):
+        import random
+        from grpc_rdma_amd import h2
+        rng = random.Random(seed)
+        self.sizes = [rng.randint(1, (4 << 20) - 1024) for _ in range(n_msgs)]
+        self.g, self.n_msgs, self.payload = g, n_msgs, None
+        total = sum(self.sizes)
+        self.payload_buf = g.DeviceBuffer(nbytes=total + 64)
+        self.block = bytes((i * 7 + 1) % 251 for i in range(1 << 20))
+        lib = g.load()
+        off = 0
+        for n in self.sizes:
+            for o in range(0, n, len(self.block)):
+                k = min(len(self.block), n - o)
+                lib.grdma_copy_to_device(self.payload_buf.ptr + off + o, self.block, k)
+            off += n
+        hdr, self.slices, k, base = bytearray(), [], 0, 0
+        self.layouts = []
+        for i, n in enumerate(self.sizes):
+            lay = h2.frame_message(n, 2 * i + 1, 16384)
+            self.layouts.append(lay)
+            for it in lay:
+                if it[0] == "inl":
+                    o = 32 * k + 9
+                    hdr += bytes(32)
+                    hdr[o:o + len(it[1])] = it[1]
+                    self.slices.append(("h", o, len(it[1])))
+                    k += 1
+                else:
+                    self.slices.append(("p", base + it[1][0], it[1][1]))
+            base += n
+        self.hdr_buf = g.DeviceBuffer(data=bytes(hdr) + bytes(64))
+        self.sge = [((self.hdr_buf.ptr if kind == "h" else self.payload_buf.ptr) + o, n) for kind, o, n in self.slices]
+        self.lens = [n for _, _, n in self.slices]
+        self.N = sum(self.lens)
+        self.E = h2.ring_bytes_for(self.lens)
+        self.user_bytes = total
+        self.slices_per_msg = len(self.lens) // n_msgs
+
+    def expected_wire(self, i):
+        n = self.sizes[i]
+        # every message restarts the block pattern at each 1 MiB boundary of its own payload
+        m = b"".join(self.block[:min(len(self.block), n - o)] for o in range(0, n, len(self.block)))
+        return b"".join(it[1] if it[0] == "inl" else m[it[1][0]:it[1][0] + it[1][1]] for it in self.layouts[i])
+
+
+def run_json(cmd, timeout, env=None):
+    """Run a helper process that prints one JSON line; None (with the reason) if it cannot."""
+    import subprocess
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        if r.returncode != 0:
+            return {"error": ("rc %d: " % r.returncode) + (r.stderr or r.stdout)[-200:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # missing binary, timeout, no loop-back networking ...
+        return {"error": str(e)[:200]}
+
+
+def tcp_baseline():
+    """What the reference's TCP platform can reach on these host cores (BASELINE.md quotes the
+    RDMA modes relative to TCP): a real gRPC stack over loop-back TCP (the grpcio wheel: gRPC C-core,
+    Python binding on top) and the raw sendmsg/recvmsg floor under any TCP transport
+    (oracle/tcp_floor.c), in the two shapes of the metric."""
+    floor = os.path.join(ROOT, "oracle", "_build", "tcp_floor")
+    gl = os.path.join(ROOT, "oracle", "grpcio_loopback.py")
+    fs = run_json([floor, "stream", "4000", str(MIB)], 60)
+    fp = run_json([floor, "pingpong", "100000", "80"], 60)
+    gs_ = run_json([sys.executable, gl, "stream", "4", str(MIB)], 90)
+    gu = run_json([sys.executable, gl, "unary", "4", "66"], 90)
+    return {"nproc": os.cpu_count(),
+            "sendmsg_floor": {"stream_GiBps": fs.get("GiBps"), "rtt_p50_us": fp.get("p50_us"), "cores": 2,
+                              "what": "raw sendmsg (130 iovecs per 1 MiB message) / recvmsg over loop-back TCP, "
+                                      "writer + reader thread; 80-byte ping-pong, 100k round trips",
+                              "error": fs.get("error") or fp.get("error")},
+            "grpcio_loopback": {"stream_GiBps": gs_.get("GiBps"), "unary_p50_us": gu.get("p50_us"),
+                                "cores": "client thread + C-core poller + 2 server workers (not pinned)",
+                                "what": "grpcio %s client-streaming 1 MiB messages for 4 s / unary 66-byte echo for 4 s, "
+                                        "one insecure channel on 127.0.0.1, identity serializers" % gs_.get("grpcio"),
+                                "error": gs_.get("error") or gu.get("error")}}
+
+
+def measured_copy_ceiling(torch, dev, nbytes=256 * MIB, reps=20):
+    """What this GPU's own copy engines / fill kernels reach on a buffer of the step's size:
+    the practical ceiling to read roofline.frac against (the 8 TB/s peak is the spec figure)."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    a.zero_(); b.zero_()
+    out = {}
+    for name, fn, traffic in (("hipMemcpyDtoD", lambda: b.copy_(a), 2 * nbytes), ("hipMemset", lambda: b.zero_(), nbytes)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3 / reps
+        out[name + "_traffic_GBps"] = round(traffic / sec / 1e9, 1)
+    out["bytes"] = nbytes
+    return out
+
+
 def cpu_baseline(wl, ring, max_sge, target_s=12.0):
     """The CPU port (oracle/) timed on host cores: same slices, same ring size, full
     pair protocol + endpoint read loop, single thread (the reference is
@@ -106,9 +214,9 @@ def cpu_baseline(wl, ring, max_sge, target_s=12.0):
     if pyorc.ref_available():
         kind, what = "reference", "the reference-built ring codec (oracle/_ref) in the pair + endpoint-read loop"
         run = lambda *a: pyorc.ref_stream_baseline(*a)[:2]
-    n, sec = run(ring, max_sge, wire, lens, 32)
-    per_msg = sec / 32
-    n_msgs = max(32, min(400000, int(target_s / per_msg)))
+    n, sec = run(ring, max_sge, wire, lens, 16)
+    per_msg = sec / 16
+    n_msgs = max(16, min(400000, int(target_s / per_msg)))
     n, sec = run(ring, max_sge, wire, lens, n_msgs)
     gib = (n_msgs * (wl.user_bytes // wl.n_msgs)) / sec / (1 << 30)
     return {"value": round(gib, 3), "unit": "GiB/s", "cores": 1, "kind": kind,
@@ -116,7 +224,7 @@ def cpu_baseline(wl, ring, max_sge, target_s=12.0):
                 n_msgs, len(lens), what, ring >> 10, sec)}
 
 
-def measure_rtt(g, iters=3000, warmup=300):
+def measure_rtt(g, iters=100000, warmup=2000):
     """Unary ping-pong, 64-byte payload both ways, 1 connection, 4 MiB rings in HBM, host
     in the loop where gRPC's consumer is (host slices in, host-visible slices out),
     commands through the resident latency engine.  p50/p95/p99 from the sorted samples."""
@@ -131,7 +239,9 @@ def measure_rtt(g, iters=3000, warmup=300):
     b.set_latency_mode(True)
     g._lib.check(lib.grdma_engine_start())
     try:
+        t0 = time.perf_counter()
         rtt, ph = g.pingpong(a, b, slices, slices, iters=iters, warmup=warmup)
+        wall = time.perf_counter() - t0
     finally:
         lib.grdma_engine_stop()
     a.close()
@@ -139,6 +249,7 @@ def measure_rtt(g, iters=3000, warmup=300):
     rtt.sort()
     return {"rtt_p50_us": round(rtt[iters // 2] / 1e3, 2), "rtt_p95_us": round(rtt[int(iters * .95)] / 1e3, 2),
             "rtt_p99_us": round(rtt[int(iters * .99)] / 1e3, 2),
+            "rtt_iters": iters, "rtt_seconds": round(wall, 2),
             "rtt_config": "unary ping-pong 64 B, 1 connection, 4 MiB ring in HBM, slices [14 B][66 B] "
                           "each way, resident latency engine, host slices in / pinned slices out",
             "rtt_breakdown_us": {k: round(v / iters / 1e3, 2) for k, v in zip(
@@ -213,6 +324,11 @@ def main():
     ap.add_argument("--no-fanout", action="store_true", help="skip the RCCL fan-out leg (N>1 only)")
     ap.add_argument("--conns", type=int, default=32,
                     help="connections per GPU in the multi-connection leg (BASELINE configs[3]: 32); 1 = skip")
+    ap.add_argument("--schedule", choices=["graph", "engine"], default="graph",
+                    help="how the timed step is launched: the round-by-round kernels of a HIP graph, or ONE launch of "
+                         "the persistent link engine (k_link); the other one is reported as a comparison leg")
+    ap.add_argument("--no-tcp-baseline", action="store_true", help="skip the loop-back TCP baselines")
+    ap.add_argument("--rtt-iters", type=int, default=100000)
     args = ap.parse_args()
 
     import torch
@@ -248,41 +364,51 @@ def main():
         torch.cuda.synchronize()
 
     def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB,
-                pipeline=False, max_sge=None, wire_flags=None):
-        """n_links connections with rings of ring_kb KiB: calibrate the number of rounds,
-        capture the graph, time `steps` passes, verify, optionally instrument."""
+                pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None):
+        """n_links connections with rings of ring_kb KiB.  Graph schedule: calibrate the number of
+        rounds, capture the graph, time `steps` replays.  Engine schedule: every step is ONE launch of
+        the persistent link engine.  Then verify, optionally instrument."""
         ring = ring_kb * 1024
         max_sge = max_sge or args.max_sge
         wf = flags if wire_flags is None else wire_flags
-        wls = get_workloads(n_links, msgs_per_link or args.msgs, payload)
+        wls = wls or get_workloads(n_links, msgs_per_link or args.msgs, payload)
         links, keep = [], []
         for w in wls:
             tx, rx = g.Pair(ring, max_sge, wf), g.Pair(ring, max_sge, wf)
             g.connect_pairs(tx, rx)
-            dst_cap = w.N + 16 * (len(w.lens) * 2 + 64) + 4096
+            scap = len(w.lens) * 2 + 64 + w.N // 256
+            dst_cap = w.N + 16 * scap + 4096
             dst = g.DeviceBuffer(nbytes=dst_cap)
-            links.append((tx, rx, w.sge, dst.ptr, dst_cap, len(w.lens) * 2 + 64))
+            links.append((tx, rx, w.sge, dst.ptr, dst_cap, scap))
             keep.append((tx, rx, dst, dst_cap, w))
         w0 = wls[0]
         est_rounds = max(8, 4 * (w0.E // (ring // 2) + 2), 2 * (len(w0.lens) // min(max_sge, 4095) + 2))
         job = gs.MultiStreamJob(links, est_rounds)
-        job.set_pipeline(pipeline)
-        r = job.run(gs.RUN_EAGER)                  # calibration: how many rounds are needed
         total_n = sum(w.N for w in wls)
-        assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
-            r.bytes_delivered, total_n)
-        rounds = int(max(r.tx_rounds, r.rx_rounds))
-        job.set_rounds(rounds)
-        r = job.run(gs.RUN_GRAPH)                  # capture + first replay
-        assert r.done and r.bytes_delivered == total_n
-        use_streams = args.launch == "streams"
+        if engine:
+            r = job.run(gs.RUN_ENGINE)
+            assert r.done and r.bytes_delivered == total_n, "engine pass did not deliver everything (%d/%d bytes)" % (
+                r.bytes_delivered, total_n)
+            rounds = int(max(r.tx_rounds, r.rx_rounds))
+            launch = job.launch_engine
+        else:
+            job.set_pipeline(pipeline)
+            r = job.run(gs.RUN_EAGER)                  # calibration: how many rounds are needed
+            assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
+                r.bytes_delivered, total_n)
+            rounds = int(max(r.tx_rounds, r.rx_rounds))
+            job.set_rounds(rounds)
+            r = job.run(gs.RUN_GRAPH)                  # capture + first replay
+            assert r.done and r.bytes_delivered == total_n
+            use_streams = args.launch == "streams"
+            launch = lambda: job.launch(use_streams)  # noqa: E731
         for _ in range(warmup):
-            job.launch(use_streams)
+            launch()
         job.sync()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            job.launch(use_streams)
+            launch()
         job.sync()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -292,7 +418,7 @@ def main():
                "user_bytes": sum(w.user_bytes for w in wls), "N": total_n,
                "E": sum(w.E for w in wls)}
         if verify:  # correctness of what the timed region produced (untimed)
-            r = job.run(gs.RUN_GRAPH)
+            r = job.run(gs.RUN_ENGINE if engine else gs.RUN_GRAPH)
             assert r.done and r.bytes_delivered == total_n and r.bytes_sent == total_n
             for li, (tx, rx, dst, dst_cap, w) in enumerate(keep):
                 if li not in (0, len(keep) - 1):
@@ -304,7 +430,9 @@ def main():
                 assert stream == exp, "delivered byte stream differs from the framed messages"
                 assert rx.ring_mem() == bytes(ring), "ring not zero after the drain"
             out["verified"] = True
-        if instrument:  # per-kernel time, HIP events on the launch stream
+        if engine:
+            out["engine"] = job.engine_stats(0)
+        if instrument and not engine:  # per-kernel time, HIP events on the launch stream
             inst = None
             for _ in range(3):
                 inst = job.run(gs.RUN_INSTRUMENTED)
@@ -333,6 +461,19 @@ def main():
                       args.warmup if head is None else 1, not args.no_verify, head is None, pipeline=False)
     if head is None:
         head, seq = seq, None
+    graph_head = head
+    eng = None
+    if args.schedule == "engine" or not args.no_extra_legs:
+        try:
+            eng = measure(args.ring_kb, args.steps if args.schedule == "engine" else max(2, args.steps // 2),
+                          args.warmup if args.schedule == "engine" else 1, not args.no_verify, False, engine=True)
+        except Exception as e:
+            eng = None
+            if args.schedule == "engine":
+                schedule += " (engine run failed: %s)" % str(e)[:120]
+    if args.schedule == "engine" and eng is not None:
+        head = dict(eng, classes=graph_head["classes"])
+        schedule = "engine (one k_link launch per step)"
     elapsed, rounds, classes, verified = head["elapsed"], head["rounds"], head["classes"], head["verified"]
     ring = args.ring_kb * 1024
     small = None
@@ -348,7 +489,7 @@ def main():
     achieved = per_launch / (classes[dom]["us_per_launch"] * 1e-6) / 1e9
     kname = "k_rx_apply" if dom == "rx_apply" else "k_copy"
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_ring%dm_summary.json" % (args.ring_kb // 1024))
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_ring%dm_summary.json" % (args.ring_kb // 1024))
     if os.path.exists(pmc) and args.msgs == 256 and args.wire == "staged":
         try:
             traffic = json.load(open(pmc))["kernels"][kname]["hbm_traffic_bytes"]
@@ -359,6 +500,17 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "bytes_per_launch": int(per_launch),
                 "us_per_launch": round(classes[dom]["us_per_launch"], 2)}
+    if args.schedule == "engine" and eng is not None:
+        # one kernel does the whole step: N read + N written (gather), E + E (wire), N + N + N (scatter + clear)
+        per_launch = 5 * wl.N + 2 * wl.E
+        us = 1e6 * elapsed / args.steps
+        roofline = {"bound": "hbm", "kernel": "k_link (whole step)", "achieved": round(per_launch / us / 1e3, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(per_launch / us / 1e3 / HBM_PEAK_GBPS, 4),
+                    "traffic": None, "bytes_per_launch": int(per_launch), "us_per_launch": round(us, 2)}
+    try:
+        roofline["measured_ceiling"] = measured_copy_ceiling(torch, torch.device("cuda", local_rank))
+    except Exception as e:
+        roofline["measured_ceiling"] = {"error": str(e)[:120]}
 
     total_user = wl.user_bytes * args.steps * world
     value = total_user / elapsed / (1 << 30)
@@ -368,6 +520,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic",
+        "value_is": "device-resident: slices in HBM before the timed region, delivered slices left in HBM "
+                    "(host-slice rate through the endpoint vtable: value_endpoint_vtable)",
         "config": {"workload": "client-streaming 1 MiB payloads, 1 connection on 1xMI355X "
                                "(BASELINE.json configs[2])",
                    "msgs_per_step": args.msgs, "slices_per_msg": wl.slices_per_msg,
@@ -391,7 +545,7 @@ def main():
     # ---- unary 64 B ping-pong (BASELINE.json configs[1]): second half of the metric -------
     if not args.no_rtt:
         try:
-            out.update(measure_rtt(g))
+            out.update(measure_rtt(g, iters=args.rtt_iters, warmup=min(2000, max(10, args.rtt_iters // 10))))
         except Exception as e:  # never lose the throughput line to the latency leg
             out["rtt_error"] = str(e)
     if seq is not None:  # same workload and ring, five kernels per round strictly in order
@@ -407,6 +561,44 @@ def main():
                 wl.user_bytes * max(2, args.steps // 2) * world / dr["elapsed"] / (1 << 30), 3)
         except Exception as e:
             out["wire_direct_error"] = str(e)[:200]
+    half = max(2, args.steps // 2)
+    if args.schedule == "engine":
+        out["value_graph"] = round(wl.user_bytes * args.steps * world / graph_head["elapsed"] / (1 << 30), 3)
+    elif eng is not None:
+        out["value_engine"] = round(wl.user_bytes * half * world / eng["elapsed"] / (1 << 30), 3)
+    if eng is not None:
+        st = eng["engine"]
+        out["engine"] = {"launches_per_step": 1, "sends": st["sends"], "receive_chunks": st["chunks"],
+                         "table_entries": [st["gather_entries"], st["wire_entries"], st["scatter_entries"]],
+                         "worker_waves": [st["gather_waves"], st["wire_waves"], st["scatter_waves"]],
+                         "workgroups": st["team"], "staging_buffers": st["staging_buffers"], "verified": eng["verified"]}
+    if not args.no_extra_legs:
+        # the reference's default knobs (4 MiB ring, max_sge 30: rdma_utils.h / config.cc), same workload,
+        # with the CPU codec timed at the SAME knobs beside it
+        try:
+            rk = measure(4096, half, 1, not args.no_verify, False, max_sge=30)
+            out["value_ring4096_sge30"] = round(wl.user_bytes * half * world / rk["elapsed"] / (1 << 30), 3)
+            out["rounds_per_step_ring4096_sge30"] = rk["rounds"]
+        except Exception as e:
+            out["ring4096_sge30_error"] = str(e)[:200]
+        # mixed message sizes (examples/cpp/test/common.h: uniform in [1, 4 MiB - 1 KiB]), 64 messages per step
+        try:
+            mw = MixedWorkload(g, 64)
+            mx = measure(args.ring_kb, half, 1, not args.no_verify, False, wls=[mw])
+            out["value_mixed_sizes"] = round(mw.user_bytes * half * world / mx["elapsed"] / (1 << 30), 3)
+            mx2 = measure(4096, half, 1, not args.no_verify, False, max_sge=30, wls=[mw])
+            out["value_mixed_sizes_ring4096_sge30"] = round(mw.user_bytes * half * world / mx2["elapsed"] / (1 << 30), 3)
+            out["config"]["mixed_sizes_leg"] = "64 messages, sizes uniform in [1, 4 MiB - 1 KiB] (seed 0), %d MiB per step, %d slices" % (
+                mw.user_bytes >> 20, len(mw.lens))
+        except Exception as e:
+            out["mixed_sizes_error"] = str(e)[:200]
+    if rank == 0 and world == 1 and not args.no_extra_legs:
+        # host slices through the endpoint vtable (grpc_endpoint_write / _read, include/grdma_endpoint.hpp):
+        # what a gRPC maintainer's process sees, PCIe both ways included
+        env = dict(os.environ, GRPC_RDMA_RING_BUFFER_SIZE_KB=str(args.ring_kb), GRPC_PLATFORM_TYPE="RDMA_BP")
+        ev = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "256", str(MIB), "1"], 120, env)
+        out["value_endpoint_vtable"] = ev.get("GiBps")
+        out["endpoint_vtable"] = ev
     if small is not None:
         sm_steps = max(2, args.steps // 2)
         out["value_ring4096"] = round(wl.user_bytes * sm_steps * world / small["elapsed"] / (1 << 30), 3)
@@ -423,8 +615,12 @@ def main():
             args.conns, per, mc["rounds"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, ring, min(args.max_sge, 4095))
+        if not args.no_extra_legs:
+            out["cpu_baseline_ring4096_sge30"] = cpu_baseline(wl, 4096 * 1024, 30, target_s=6.0)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not args.no_tcp_baseline:
+        out["tcp_baseline"] = tcp_baseline()
     if rank == 0:
         print(json.dumps(out))
     grp.close()

@@ -158,8 +158,8 @@ struct grdma_rx_result {
   uint64_t zero_len[2];
   uint64_t seq;            // bumped by k_rx_plan
   uint64_t commit_seq;     // bumped by k_rx_commit (copy + zero-fill + credit done)
-  uint32_t blocks_done;    // k_rx_apply arrival counter (the last workgroup commits); lives
-  uint32_t pad0;           // here, not in the connection, so that drains can be pipelined
+  uint32_t pad1;           // (the k_rx_apply arrival counter moved into the plan: device memory)
+  uint32_t pad0;
   uint64_t dbg[16];        // s_memtime stamps of the plan phases (profiling aid)
 };
 
@@ -170,6 +170,11 @@ struct grdma_plan {
   uint64_t bytes;
   uint64_t tag_base;   // window for the record tags of GRDMA_SEG_TAG_* segments
   uint64_t tag_mask;
+  // k_rx_apply arrival counter (the last workgroup commits).  It lives in the plan -- always
+  // device memory, one per drain in flight -- and not in the result block, which is pinned HOST
+  // memory for a stand-alone pair: a thousand workgroups counting in over PCIe took a millisecond.
+  uint32_t blocks_done;
+  uint32_t pad_bd;
   struct grdma_seg segs[GRDMA_MAX_SEGS];
   uint32_t tile_prefix[GRDMA_MAX_SEGS + 1];
 };

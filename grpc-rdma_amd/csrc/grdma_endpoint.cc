@@ -165,9 +165,20 @@ struct grpc_rdma {  // rdma_bp_posix.cc:45-88
   bool write_armed;  // notify_on_write pending
   std::string peer_string;
   std::string local_address;
+  // Read-ahead: ONE device pass performs many endpoint reads (grdma_endpoint_read, max_reads);
+  // their slices wait here, copied to the host in one transfer, and the following
+  // grpc_endpoint_read calls are served without touching the device.  Every completion handed
+  // out this way filled its slice, so what it holds cannot depend on records that arrive later --
+  // the chain of reads stops at the first one that would block (rdma_do_read :180-291).
+  std::vector<grdma_read_slice> ahead;
+  size_t ahead_next;
+  uint8_t* ahead_bytes;  // pinned host memory (one device-to-host transfer per pass)
+  uint64_t ahead_cap;
+  uint64_t ahead_base;   // arena offset of ahead_bytes[0]
 };
 
-const size_t kWindow = 4000;  // slices handed to one grdma_endpoint_write_begin (ABI cap 4095)
+const size_t kWindow = 4000;   // slices handed to one grdma_endpoint_write_begin (ABI cap 4095)
+const size_t kReadAhead = 1024;  // endpoint reads performed per device pass  // slices handed to one grdma_endpoint_write_begin (ABI cap 4095)
 
 void run_closure(grpc_closure* c, grpc_error_handle err) {  // grpc_core::Closure::Run
   c->cb(c->cb_arg, err);
@@ -199,12 +210,37 @@ void rdma_handle_read(grpc_rdma* rdma, grpc_error_handle error) {
     rdma_unref(rdma);
     return;
   }
-  grdma_read_slice s;
   int would_block = 0;
-  int64_t n = grdma_endpoint_read(rdma->pair, 1, &s, 1, &would_block);
-  if (n == 1) {
+  int64_t n = 0;
+  if (rdma->ahead_next >= rdma->ahead.size()) {
+    rdma->ahead.resize(kReadAhead);
+    rdma->ahead_next = 0;
+    n = grdma_endpoint_read(rdma->pair, kReadAhead, rdma->ahead.data(), kReadAhead, &would_block);
+    rdma->ahead.resize(n > 0 ? (size_t)n : 0);
+    if (n > 0) {
+      uint64_t lo = ~0ull, hi = 0;
+      for (const grdma_read_slice& a : rdma->ahead) {
+        if (a.off < lo) lo = a.off;
+        if (a.off + a.len > hi) hi = a.off + a.len;
+      }
+      if (hi - lo > rdma->ahead_cap) {
+        grdma_host_free_pinned(rdma->ahead_bytes);
+        rdma->ahead_cap = (hi - lo) * 2;
+        rdma->ahead_bytes = static_cast<uint8_t*>(grdma_host_alloc_pinned(rdma->ahead_cap));
+        if (rdma->ahead_bytes == nullptr) rdma->ahead_cap = 0;
+      }
+      rdma->ahead_base = lo;
+      if (rdma->ahead_bytes == nullptr ||
+          grdma_pair_arena_copy_out(rdma->pair, lo, rdma->ahead_bytes, hi - lo) != 0) {
+        rdma->ahead.clear();
+        n = -1;
+      }
+    }
+  }
+  if (rdma->ahead_next < rdma->ahead.size()) {
+    const grdma_read_slice s = rdma->ahead[rdma->ahead_next++];
     grpc_slice out = grpc_slice_malloc(s.len);
-    grdma_pair_arena_copy_out(rdma->pair, s.off, GRPC_SLICE_START_PTR(out), s.len);
+    memcpy(GRPC_SLICE_START_PTR(out), rdma->ahead_bytes + (s.off - rdma->ahead_base), s.len);
     grpc_slice_buffer_add_indexed(rdma->incoming_buffer, out);
     rdma->inq = 1;
     call_read_cb(rdma, GRPC_ERROR_NONE);
@@ -370,6 +406,7 @@ void rdma_free(grpc_rdma* rdma) {  // :112-132
     rdma->pair = nullptr;
   }
   GRPC_ERROR_UNREF(rdma->shutdown_error);
+  grdma_host_free_pinned(rdma->ahead_bytes);
   delete rdma;
 }
 

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(COPY_THREADS) void k_rx_apply(const grdma_rx_op* op
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned int prev = __hip_atomic_fetch_add(&op.result->blocks_done, 1u, __ATOMIC_RELAXED,
+    // acq_rel: the last arriver must see what the others wrote before it posts the credit
+    unsigned int prev = __hip_atomic_fetch_add(&op.plan->blocks_done, 1u, __ATOMIC_ACQ_REL,
                                                __HIP_MEMORY_SCOPE_AGENT);
     s_last = (prev == gridDim.x - 1) ? 1u : 0u;
   }

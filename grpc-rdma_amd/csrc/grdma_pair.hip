@@ -1552,7 +1552,7 @@ int job_engine_prepare(grdma_stream_job* j) {
     // its records against a whole staging buffer of ring / 2, pair.cc:104)
     uint32_t nst = 0;
     if (!j->direct) {
-      uint64_t want = (64ull << 20) / (ring / 2);
+      uint64_t want = (384ull << 20) / (ring / 2);  // up to 384 MiB of staging per link: the sender runs ahead of the credit loop
       if (const char* e = getenv("GRDMA_LINK_STAGING")) want = (uint64_t)std::max<long>(1, atol(e));
       want = std::min<uint64_t>(std::max<uint64_t>(want, 2), LK_MAX_STAGING);
       h.staging[nst++] = l.tx->d_staging;

@@ -1227,7 +1227,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
       c->rx_arena_off = S.a_off;
       c->rx_slice_idx = o_slice_idx + nslices;
     }
-    res->blocks_done = 0;
+    op.plan->blocks_done = 0;
     // updateStatus() (pair.cc:624-641) must not overtake the copy-out and the
     // zero-fill of the bytes it grants: the 16-byte report is posted by the last
     // workgroup of k_rx_apply.

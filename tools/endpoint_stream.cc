@@ -1,0 +1,162 @@
+// Client-streaming throughput THROUGH THE ENDPOINT VTABLE (grpc_endpoint_write / grpc_endpoint_read,
+// include/grdma_endpoint.hpp), the way chttp2 drives rdma_bp_posix.cc: every message of
+// <payload> bytes is one grpc_endpoint_write of HTTP/2 DATA frames -- a 9-byte frame header slice
+// (inlined) in front of every <= 16384-byte payload slice (refcounted, host memory), the first
+// payload prefixed by the 5-byte gRPC message header -- and the reader re-arms grpc_endpoint_read
+// from its callback.  Host slices in, host slices out: this is the PCIe-inclusive rate of the
+// boundary, reported next to the device-resident figure of bench.py (never instead of it).
+//
+// usage: endpoint_stream <n_msgs> <payload_bytes> [check 0|1]     prints one JSON line
+// env:   GRPC_RDMA_RING_BUFFER_SIZE_KB, GRPC_RDMA_MAX_SGE ... as the reference reads them
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <vector>
+
+#include "grdma_endpoint.hpp"
+
+using namespace grdma_core;
+
+#define CHECK(x)                                                             \
+  do {                                                                       \
+    if (!(x)) {                                                              \
+      fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #x, __FILE__, __LINE__); \
+      exit(2);                                                               \
+    }                                                                        \
+  } while (0)
+
+static std::deque<grpc_closure*> g_queue;  // a miniature ExecCtx
+
+struct state {
+  grpc_endpoint *tx, *rx;
+  grpc_slice_buffer outgoing, incoming;
+  grpc_closure done_write, done_read, next_write, next_read;
+  std::vector<grpc_slice> frames;  // the slices of one message, re-referenced for every write
+  size_t msgs_target, msgs_written, bytes_per_msg, bytes_read, bytes_target;
+  bool check, failed, write_done, read_done;
+  uint64_t sum_read, sum_per_msg;
+};
+
+static void do_write(void* p, grpc_error_handle) {
+  auto* st = static_cast<state*>(p);
+  for (grpc_slice& s : st->frames) {
+    if (s.refcount) s.refcount->refs.fetch_add(1);
+    grpc_slice_buffer_add_indexed(&st->outgoing, s);  // (indexed: no merging, like chttp2's frame slices)
+  }
+  grpc_endpoint_write(st->tx, &st->outgoing, &st->done_write, nullptr);
+}
+static void on_write(void* p, grpc_error_handle e) {
+  auto* st = static_cast<state*>(p);
+  if (e != GRPC_ERROR_NONE) { st->failed = st->write_done = true; return; }
+  grpc_slice_buffer_reset_and_unref(&st->outgoing);  // (chttp2 resets its outbuf in write_action_end)
+  if (++st->msgs_written == st->msgs_target) { st->write_done = true; return; }
+  g_queue.push_back(&st->next_write);
+}
+static void do_read(void* p, grpc_error_handle) {
+  auto* st = static_cast<state*>(p);
+  grpc_endpoint_read(st->rx, &st->incoming, &st->done_read, false);
+}
+static void on_read(void* p, grpc_error_handle e) {
+  auto* st = static_cast<state*>(p);
+  if (e != GRPC_ERROR_NONE) { st->failed = st->read_done = true; return; }
+  for (size_t i = 0; i < st->incoming.count; i++) {
+    const grpc_slice& s = st->incoming.slices[i];
+    const size_t n = GRPC_SLICE_LENGTH(s);
+    if (st->check) {
+      const uint8_t* b = GRPC_SLICE_START_PTR(s);
+      uint64_t a = 0;
+      for (size_t k = 0; k < n; k++) a += b[k];
+      st->sum_read += a;
+    }
+    st->bytes_read += n;
+  }
+  if (st->bytes_read >= st->bytes_target) { st->read_done = true; return; }
+  g_queue.push_back(&st->next_read);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    fprintf(stderr, "usage: %s <n_msgs> <payload_bytes> [check]\n", argv[0]);
+    return 1;
+  }
+  state st{};
+  st.msgs_target = strtoull(argv[1], nullptr, 10);
+  const size_t payload = strtoull(argv[2], nullptr, 10);
+  st.check = argc > 3 && atoi(argv[3]) != 0;
+  setenv("GRPC_PLATFORM_TYPE", "RDMA_BP", 0);
+  st.tx = grpc_endpoint_create(3, "ipv4:127.0.0.1:1", false);
+  st.rx = grpc_endpoint_create(4, "ipv4:127.0.0.1:2", true);
+  CHECK(st.tx && st.rx && grpc_rdma_bp_connect_loopback(st.tx, st.rx));
+
+  // one serialized message: [5-byte gRPC header][0x0a varint(len)][payload], cut into DATA frames
+  std::vector<uint8_t> msg;
+  {
+    std::vector<uint8_t> body;
+    body.push_back(0x0a);
+    for (size_t n = payload;;) {
+      uint8_t b = n & 0x7f;
+      n >>= 7;
+      body.push_back(b | (n ? 0x80 : 0));
+      if (!n) break;
+    }
+    for (size_t i = 0; i < payload; i++) body.push_back((uint8_t)((i * 7 + 3) % 251));
+    const uint32_t L = (uint32_t)body.size();
+    msg = {0, (uint8_t)(L >> 24), (uint8_t)(L >> 16), (uint8_t)(L >> 8), (uint8_t)L};
+    msg.insert(msg.end(), body.begin(), body.end());
+  }
+  for (size_t off = 0; off < msg.size();) {
+    const size_t n = msg.size() - off < 16384 ? msg.size() - off : 16384;
+    const uint8_t hdr[9] = {(uint8_t)(n >> 16), (uint8_t)(n >> 8), (uint8_t)n, 0, 0, 0, 0, 0, 1};
+    st.frames.push_back(grpc_slice_from_copied_buffer(reinterpret_cast<const char*>(hdr), 9));  // inlined (< 24 B)
+    grpc_slice s = grpc_slice_malloc(n);
+    memcpy(GRPC_SLICE_START_PTR(s), msg.data() + off, n);
+    st.frames.push_back(s);
+    off += n;
+  }
+  st.bytes_per_msg = 0;
+  for (grpc_slice& s : st.frames) {
+    st.bytes_per_msg += GRPC_SLICE_LENGTH(s);
+    const uint8_t* b = GRPC_SLICE_START_PTR(s);
+    for (size_t k = 0; k < GRPC_SLICE_LENGTH(s); k++) st.sum_per_msg += b[k];
+  }
+  st.bytes_target = st.bytes_per_msg * st.msgs_target;
+  grpc_slice_buffer_init(&st.outgoing);
+  grpc_slice_buffer_init(&st.incoming);
+  GRPC_CLOSURE_INIT(&st.done_write, on_write, &st, nullptr);
+  GRPC_CLOSURE_INIT(&st.done_read, on_read, &st, nullptr);
+  GRPC_CLOSURE_INIT(&st.next_write, do_write, &st, nullptr);
+  GRPC_CLOSURE_INIT(&st.next_read, do_read, &st, nullptr);
+
+  const auto t0 = std::chrono::steady_clock::now();
+  do_read(&st, GRPC_ERROR_NONE);
+  do_write(&st, GRPC_ERROR_NONE);
+  long idle = 0;
+  while (!st.read_done || !st.write_done) {  // the pollset_work loop
+    int ran = grdma_endpoint_poll(st.rx) + grdma_endpoint_poll(st.tx);
+    while (!g_queue.empty()) {
+      grpc_closure* c = g_queue.front();
+      g_queue.pop_front();
+      c->cb(c->cb_arg, GRPC_ERROR_NONE);
+      ran++;
+    }
+    if (ran) idle = 0;
+    else if (++idle > 20000000) CHECK(!"endpoint made no progress");
+  }
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  CHECK(!st.failed && st.bytes_read == st.bytes_target);
+  if (st.check) CHECK(st.sum_read == st.sum_per_msg * st.msgs_target);
+  printf("{\"msgs\": %zu, \"payload\": %zu, \"slices_per_write\": %zu, \"endpoint_bytes\": %zu, \"seconds\": %.6f, "
+         "\"GiBps\": %.4f, \"checked\": %s}\n",
+         st.msgs_target, payload, st.frames.size(), st.bytes_target, sec,
+         (double)(payload * st.msgs_target) / sec / (double)(1ull << 30), st.check ? "true" : "false");
+  grpc_endpoint_shutdown(st.tx, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
+  grpc_endpoint_shutdown(st.rx, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
+  grpc_endpoint_destroy(st.tx);
+  grpc_endpoint_destroy(st.rx);
+  for (grpc_slice& s : st.frames) grpc_slice_unref(s);
+  grpc_slice_buffer_destroy(&st.outgoing);
+  grpc_slice_buffer_destroy(&st.incoming);
+  return 0;
+}

@@ -60,43 +60,7 @@ def run(g, gs, name, ring_kb, max_sge, n_links, msgs, payload, steps=10, flags=0
     return out
 
 
-class MixedWorkload(bench.Workload):
-    """Sizes drawn like examples/cpp/test/common.h:4-31 (uniform in [1, 4 MiB - 1 KiB]), seed 0."""
-
-    def __init__(self, g, n_msgs, seed=0):
-        from grpc_rdma_amd import h2
-        import ctypes as C
-        rng = random.Random(seed)
-        sizes = [rng.randint(1, (4 << 20) - 1024) for _ in range(n_msgs)]
-        self.g, self.n_msgs = g, n_msgs
-        total = sum(sizes)
-        self.payload_buf = g.DeviceBuffer(nbytes=total + 64)
-        block = bytes((i * 7 + 1) % 251 for i in range(1 << 20))
-        lib = g.load()
-        off = 0
-        for n in sizes:
-            for o in range(0, n, len(block)):
-                k = min(len(block), n - o)
-                lib.grdma_copy_to_device(self.payload_buf.ptr + off + o, block, k)
-            off += n
-        hdr, self.slices, k, base = bytearray(), [], 0, 0
-        for i, n in enumerate(sizes):
-            for it in h2.frame_message(n, 2 * i + 1, 16384):
-                if it[0] == "inl":
-                    o = 32 * k + 9
-                    hdr += bytes(32)
-                    hdr[o:o + len(it[1])] = it[1]
-                    self.slices.append(("h", o, len(it[1])))
-                    k += 1
-                else:
-                    self.slices.append(("p", base + it[1][0], it[1][1]))
-            base += n
-        self.hdr_buf = g.DeviceBuffer(data=bytes(hdr) + bytes(64))
-        self.sge = [((self.hdr_buf.ptr if kind == "h" else self.payload_buf.ptr) + o, n) for kind, o, n in self.slices]
-        self.lens = [n for _, _, n in self.slices]
-        self.N = sum(self.lens)
-        self.E = h2.ring_bytes_for(self.lens)
-        self.user_bytes = total
+MixedWorkload = bench.MixedWorkload
 
 
 def main():
