@@ -24,7 +24,9 @@
 #define GRDMA_TILE_BYTES 8192ull    // bytes one wave copies per tile: 64 lanes x 16 B x 8 loads in flight
 #define GRDMA_MIN_READ_SLICE 256ull // rdma_bp_posix.cc:308
 
-// PairStatus, pair.h:44-51
+// PairStatus, pair.h:44-51 (also in the public header: what grdma_pair_get_status returns)
+#ifndef GRDMA_PAIR_STATUS_DEFINED
+#define GRDMA_PAIR_STATUS_DEFINED
 enum grdma_pair_status {
   GRDMA_PAIR_UNINITIALIZED = 0,
   GRDMA_PAIR_INITIALIZED = 1,
@@ -33,6 +35,7 @@ enum grdma_pair_status {
   GRDMA_PAIR_DISCONNECTED = 4,
   GRDMA_PAIR_ERROR = 5
 };
+#endif
 
 // status_report, pair.h:100-103: the 16-byte credit message the receiver
 // RDMA-writes into the sender's status buffer.

@@ -133,6 +133,18 @@ int grdma_pair_connect_remote(grdma_pair* p, const grdma_bootstrap_blob* peer);
 int grdma_pair_bootstrap_fd(grdma_pair* p, int fd);
 int grdma_pair_disconnect(grdma_pair* p);          /* Disconnect(), pair.cc:325-347 */
 void grdma_pair_destroy(grdma_pair* p);
+/* PairStatus, pair.h:44-51: the values grdma_pair_get_status returns */
+#ifndef GRDMA_PAIR_STATUS_DEFINED
+#define GRDMA_PAIR_STATUS_DEFINED
+enum grdma_pair_status {
+  GRDMA_PAIR_UNINITIALIZED = 0,
+  GRDMA_PAIR_INITIALIZED = 1,
+  GRDMA_PAIR_CONNECTED = 2,
+  GRDMA_PAIR_HALF_CLOSED = 3,
+  GRDMA_PAIR_DISCONNECTED = 4,
+  GRDMA_PAIR_ERROR = 5
+};
+#endif
 int grdma_pair_get_status(grdma_pair* p);          /* get_status(), pair.cc:349-375 */
 
 /* Send(slices, count, byte_idx), pair.cc:645-734.  Returns payload bytes

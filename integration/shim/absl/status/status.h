@@ -1,6 +1,9 @@
 #pragma once
+#include <cstring>
 #include <string>
+#include <vector>
 #include "absl/strings/string_view.h"
+#include "absl/types/optional.h"
 namespace absl {
 enum class StatusCode : int { kOk = 0, kCancelled = 1, kUnknown = 2, kInvalidArgument = 3, kDeadlineExceeded = 4,
   kNotFound = 5, kAlreadyExists = 6, kPermissionDenied = 7, kResourceExhausted = 8, kFailedPrecondition = 9,

@@ -2,6 +2,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include "absl/base/thread_annotations.h"
 #include "absl/time/time.h"
 namespace absl {
 class Mutex {
