@@ -3,6 +3,13 @@
 // happens in the HIP kernels behind grdma_endpoint_write_* / grdma_endpoint_read.
 #include "../../include/grdma_endpoint.hpp"
 
+#include <sys/epoll.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <chrono>
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -144,6 +151,23 @@ void GRPC_ERROR_UNREF(grpc_error_handle e) {
 // ----------------------------------------------------------------------- endpoint
 namespace {
 
+struct grpc_rdma;
+}  // namespace
+
+// `pollable` of the RDMA event engines (ev_epollex_rdma_bpev_linux.cc:208-246): the fds of the
+// set, the epoll fd their wakeup fds are registered with, the busy-polling budget
+struct grpc_pollset {
+  bool bpev;
+  int polling_timeout_us;
+  int epfd;
+  std::vector<grpc_rdma*> rdma_fds;
+  std::vector<grdma_pair*> pairs;      // scratch of one pass
+  std::vector<uint64_t> readable;
+  std::vector<uint8_t> has_message;
+  grdma_pollset_stats stats;
+};
+
+namespace {
 struct grpc_rdma {  // rdma_bp_posix.cc:45-88
   grpc_endpoint base;  // must be first (endpoint.h:112-114)
   int fd;
@@ -165,6 +189,7 @@ struct grpc_rdma {  // rdma_bp_posix.cc:45-88
   bool write_armed;  // notify_on_write pending
   std::string peer_string;
   std::string local_address;
+  grpc_pollset* pollset;  // the set this endpoint was added to (grpc_pollset_add_fd)
   // Read-ahead: ONE device pass performs many endpoint reads (grdma_endpoint_read, max_reads);
   // their slices wait here, copied to the host in one transfer, and the following
   // grpc_endpoint_read calls are served without touching the device.  Every completion handed
@@ -176,6 +201,8 @@ struct grpc_rdma {  // rdma_bp_posix.cc:45-88
   uint64_t ahead_cap;
   uint64_t ahead_base;   // arena offset of ahead_bytes[0]
 };
+
+grdma_poller* g_poller = nullptr;  // Poller::Get(): one per process, created with the first BPEV endpoint
 
 const size_t kWindow = 4000;   // slices handed to one grdma_endpoint_write_begin (ABI cap 4095)
 const size_t kReadAhead = 1024;  // endpoint reads performed per device pass  // slices handed to one grdma_endpoint_write_begin (ABI cap 4095)
@@ -193,6 +220,7 @@ grpc_error_handle rdma_annotate_error(grpc_error_handle src, grpc_rdma* rdma) { 
 }
 
 void rdma_unref(grpc_rdma* rdma);
+void pollset_del_fd(grpc_pollset* ps, grpc_rdma* rdma);
 
 void call_read_cb(grpc_rdma* rdma, grpc_error_handle error) {  // :161-176
   grpc_closure* cb = rdma->read_cb;
@@ -400,7 +428,9 @@ void rdma_shutdown(grpc_endpoint* ep, grpc_error_handle why) {  // :106-110
 }
 
 void rdma_free(grpc_rdma* rdma) {  // :112-132
+  if (rdma->pollset != nullptr) pollset_del_fd(rdma->pollset, rdma);  // grpc_fd_orphan
   if (rdma->pair != nullptr) {
+    if (rdma->enable_poller && g_poller != nullptr) grdma_poller_remove(g_poller, rdma->pair);
     grdma_pair_disconnect(rdma->pair);
     grdma_pair_destroy(rdma->pair);  // PairPool::Putback in the reference
     rdma->pair = nullptr;
@@ -415,7 +445,36 @@ void rdma_unref(grpc_rdma* rdma) {
 }
 
 void rdma_destroy(grpc_endpoint* ep) { rdma_unref(reinterpret_cast<grpc_rdma*>(ep)); }  // :134-139
-void rdma_add_to_pollset(grpc_endpoint*, grpc_pollset*) {}
+void pollset_del_fd(grpc_pollset* ps, grpc_rdma* rdma) {
+  auto it = std::find(ps->rdma_fds.begin(), ps->rdma_fds.end(), rdma);
+  if (it == ps->rdma_fds.end()) return;
+  ps->rdma_fds.erase(it);
+  if (ps->bpev && rdma->pair != nullptr) {
+    const int wfd = grdma_pair_get_wakeup_fd(rdma->pair);
+    if (wfd >= 0) epoll_ctl(ps->epfd, EPOLL_CTL_DEL, wfd, nullptr);
+  }
+}
+
+// grpc_pollset_add_fd -> pollable_add_fd (ev_epollex_rdma_bpev_linux.cc:705-745): the fd joins
+// p->rdma_fds; in BPEV mode the pair's wakeup fd joins the epoll set, its data pointer tagged
+// with bit 1 so that process_events can tell it from a socket (:725-741)
+void rdma_add_to_pollset(grpc_endpoint* ep, grpc_pollset* ps) {
+  grpc_rdma* rdma = reinterpret_cast<grpc_rdma*>(ep);
+  if (ps == nullptr || rdma->pollset == ps) return;
+  if (rdma->pollset != nullptr) pollset_del_fd(rdma->pollset, rdma);
+  rdma->pollset = ps;
+  ps->rdma_fds.push_back(rdma);
+  if (ps->bpev) {
+    const int wfd = grdma_pair_get_wakeup_fd(rdma->pair);
+    if (wfd >= 0) {
+      struct epoll_event ev;
+      memset(&ev, 0, sizeof ev);
+      ev.events = EPOLLIN | EPOLLET;
+      ev.data.ptr = reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(rdma) | 2);
+      epoll_ctl(ps->epfd, EPOLL_CTL_ADD, wfd, &ev);
+    }
+  }
+}
 void rdma_add_to_pollset_set(grpc_endpoint*, grpc_pollset_set*) {}
 void rdma_delete_from_pollset_set(grpc_endpoint*, grpc_pollset_set*) {}
 grpc_resource_user* rdma_get_resource_user(grpc_endpoint*) { return nullptr; }
@@ -457,6 +516,11 @@ grpc_endpoint* grpc_rdma_bp_create(int fd, const char* peer_string, bool enable_
   rdma->read_cb = rdma->write_cb = nullptr;
   rdma->read_armed = rdma->write_armed = false;
   rdma->inq = 1;  // :745
+  rdma->pollset = nullptr;
+  if (enable_poller) {  // RDMA_BPEV: Poller::Get().AddPollable(pair), :789-791
+    if (g_poller == nullptr) g_poller = grdma_poller_create(cfg.poller_thread_num, cfg.poller_sleep_timeout_ms);
+    if (g_poller != nullptr) grdma_poller_add(g_poller, pair);
+  }
   return &rdma->base;
 }
 
@@ -498,6 +562,130 @@ int grdma_endpoint_poll(grpc_endpoint* ep) {
       ran++;
     }
   }
+  return ran;
+}
+
+grpc_pollset* grdma_pollset_create(bool bpev, int busy_polling_timeout_us) {
+  grpc_pollset* ps = new grpc_pollset();
+  ps->bpev = bpev;
+  ps->polling_timeout_us = busy_polling_timeout_us;
+  ps->epfd = -1;
+  memset(&ps->stats, 0, sizeof ps->stats);
+  if (bpev) {
+    ps->epfd = epoll_create1(EPOLL_CLOEXEC);
+    if (ps->epfd < 0) {
+      delete ps;
+      return nullptr;
+    }
+  }
+  return ps;
+}
+
+void grdma_pollset_destroy(grpc_pollset* ps) {
+  if (ps == nullptr) return;
+  for (grpc_rdma* r : ps->rdma_fds) r->pollset = nullptr;
+  if (ps->epfd >= 0) close(ps->epfd);
+  delete ps;
+}
+
+size_t grdma_pollset_size(const grpc_pollset* ps) { return ps->rdma_fds.size(); }
+void grdma_pollset_get_stats(const grpc_pollset* ps, grdma_pollset_stats* out) { *out = ps->stats; }
+
+// fd_become_readable / fd_become_writable for one endpoint of the set.  `in` / `out`: the
+// synthesised EPOLLIN / EPOLLOUT of pollable_epoll (:1105-1149).
+static int pollset_deliver(grpc_rdma* rdma, bool in, bool out) {
+  int ran = 0;
+  rdma->refcount.fetch_add(1);  // a closure may destroy the endpoint
+  if (in && rdma->read_armed) {
+    rdma->read_armed = false;
+    rdma_handle_read(rdma, GRPC_ERROR_NONE);
+    ran++;
+  }
+  if (out && rdma->write_armed) {
+    rdma->write_armed = false;
+    rdma_handle_write(rdma, GRPC_ERROR_NONE);
+    ran++;
+  }
+  rdma_unref(rdma);
+  return ran;
+}
+
+int grdma_pollset_work(grpc_pollset* ps, int timeout_ms) {
+  using clock = std::chrono::steady_clock;
+  ps->stats.passes++;
+  const auto t_begin = clock::now();
+  // the busy-polling budget: RDMA_BP polls for the whole timeout, RDMA_BPEV for at most
+  // polling_timeout_us (:1093-1099)
+  int64_t budget_us = ps->bpev ? ps->polling_timeout_us : INT64_MAX;
+  if (timeout_ms >= 0) budget_us = std::min<int64_t>(budget_us, (int64_t)timeout_ms * 1000);
+  int ran = 0;
+  int64_t elapsed_us = 0;
+  do {
+    const std::vector<grpc_rdma*> fds = ps->rdma_fds;  // closures may add / remove endpoints
+    const size_t n = fds.size();
+    if (n == 0) break;
+    ps->pairs.resize(n);
+    ps->readable.resize(n);
+    ps->has_message.resize(n);
+    bool any_armed = false;
+    for (size_t i = 0; i < n; i++) {
+      ps->pairs[i] = fds[i]->pair;
+      any_armed |= fds[i]->read_armed || fds[i]->write_armed;
+    }
+    if (any_armed) {
+      // HasMessage() of every fd of the set: one launch
+      if (grdma_poll_pairs(ps->pairs.data(), (uint32_t)n, ps->readable.data(), ps->has_message.data()) < 0) return -1;
+      ps->stats.device_polls++;
+      for (size_t i = 0; i < n; i++) {
+        grpc_rdma* r = fds[i];
+        if (std::find(ps->rdma_fds.begin(), ps->rdma_fds.end(), r) == ps->rdma_fds.end()) continue;  // destroyed by a closure
+        if (!r->read_armed && !r->write_armed) continue;
+        const int status = grdma_pair_get_status(r->pair);
+        bool in = false, out = false;
+        if (status == GRDMA_PAIR_CONNECTED) {
+          in = ps->has_message[i] != 0;
+          // HasPendingWrites(): the last Send came up short and there is room again
+          out = r->write_armed && grdma_pair_writable_size(r->pair) > 0;
+        } else if (status == GRDMA_PAIR_HALF_CLOSED || status == GRDMA_PAIR_ERROR) {
+          in = true;  // "Generate an event, so do_read will handle connection close"
+          out = r->write_armed;
+        }
+        if (in || out) ran += pollset_deliver(r, in, out);
+      }
+    }
+    elapsed_us = std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - t_begin).count();
+  } while (ran == 0 && elapsed_us < budget_us);
+  if (ran == 0 && ps->bpev && !ps->rdma_fds.empty()) {
+    // busy-polling timed out: switch to epoll on the wakeup fds (:1155-1170)
+    int left_ms = timeout_ms;
+    if (timeout_ms > 0) left_ms = (int)std::max<int64_t>(0, timeout_ms - elapsed_us / 1000);
+    struct epoll_event evs[100];  // MAX_EPOLL_EVENTS
+    int r;
+    do {
+      r = epoll_wait(ps->epfd, evs, 100, left_ms);
+    } while (r < 0 && errno == EINTR);
+    ps->stats.epoll_waits++;
+    if (r < 0) return -1;
+    for (int k = 0; k < r; k++) {
+      const uintptr_t tagged = reinterpret_cast<uintptr_t>(evs[k].data.ptr);
+      if (!(tagged & 2)) continue;
+      grpc_rdma* rdma = reinterpret_cast<grpc_rdma*>(tagged & ~(uintptr_t)2);
+      if (std::find(ps->rdma_fds.begin(), ps->rdma_fds.end(), rdma) == ps->rdma_fds.end()) continue;
+      // pollable_process_events for a wakeup fd (:1010-1037): consume, then look at the pair
+      if (grdma_pair_consume_wakeup(rdma->pair) > 0) ps->stats.wakeups_consumed++;
+      const int status = grdma_pair_get_status(rdma->pair);
+      bool in, out;
+      if (status == GRDMA_PAIR_CONNECTED) {
+        in = grdma_pair_has_message(rdma->pair) > 0;
+        out = rdma->write_armed && grdma_pair_writable_size(rdma->pair) > 0;
+      } else {
+        in = true;
+        out = rdma->write_armed;
+      }
+      if (in || out) ran += pollset_deliver(rdma, in, out);
+    }
+  }
+  ps->stats.closures_run += (uint64_t)ran;
   return ran;
 }
 

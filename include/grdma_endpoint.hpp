@@ -152,5 +152,27 @@ int grdma_endpoint_poll(grpc_endpoint* ep);
 
 grdma_pair* grdma_endpoint_pair(grpc_endpoint* ep);  // the PairPollable handed to grpc_fd_set_arg
 
+// ---- the pollset of the RDMA event engines --------------------------------------------------
+// Mirror of `pollable` + pollable_epoll + pollable_process_events of
+// ev_epollex_rdma_bp_linux.cc / ev_epollex_rdma_bpev_linux.cc (:1079-1172, :977-1075): endpoints
+// join through the vtable's add_to_pollset; one grdma_pollset_work() call is one pollset_work pass:
+//   * busy-poll: ONE k_poll launch (grdma_poll_pairs) reads HasMessage / readable size of EVERY
+//     endpoint of the set per pass (the reference walks p->rdma_fds calling get_status /
+//     HasMessage / HasPendingWrites one by one), synthesises EPOLLIN / EPOLLOUT and runs the armed
+//     closures; a half-closed or failed pair yields EPOLLIN so that do_read reports the close;
+//   * RDMA_BP (bpev = false): keeps busy-polling until an event or the timeout;
+//   * RDMA_BPEV (bpev = true): busy-polls for at most busy_polling_timeout_us
+//     (GRPC_RDMA_BUSY_POLLING_TIMEOUT_US), then sleeps in epoll_wait on the wakeup fds of its pairs
+//     -- signalled by the background poller (grdma_poller, poller.cc:52-106) -- and consumes the
+//     wakeup (:1010-1037) before it looks at the pair again.
+// Returns the number of closures run, < 0 on error.  Not thread safe against itself (the
+// reference serialises passes with p->rdma_mu); endpoints may be added / destroyed between passes.
+grpc_pollset* grdma_pollset_create(bool bpev, int busy_polling_timeout_us);
+void grdma_pollset_destroy(grpc_pollset* ps);
+int grdma_pollset_work(grpc_pollset* ps, int timeout_ms);
+size_t grdma_pollset_size(const grpc_pollset* ps);
+struct grdma_pollset_stats { uint64_t passes, device_polls, epoll_waits, wakeups_consumed, closures_run; };
+void grdma_pollset_get_stats(const grpc_pollset* ps, grdma_pollset_stats* out);
+
 }  // namespace grdma_core
 #endif  // GRDMA_ENDPOINT_HPP

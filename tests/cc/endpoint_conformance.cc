@@ -7,11 +7,14 @@
 // Usage: endpoint_conformance <num_bytes> <write_size> <slice_size> <shutdown 0|1>
 //        endpoint_conformance sweep <lo> <hi>
 //        endpoint_conformance multiple_shutdown
+//        endpoint_conformance pollset <connections> <rounds> <bpev 0|1>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "grdma_endpoint.hpp"
@@ -270,7 +273,155 @@ static void write_after_peer_exit_test() {
   printf("write_after_peer_exit_test: ok\n");
 }
 
+// ---- many endpoints in ONE pollset (the shape of a server's pollset: every accepted
+// connection's fd lands in the same pollable, ev_epollex_rdma_bpev_linux.cc:705-745) --------
+// n connections, each client writes `rounds` messages of a seeded size, each server echoes what it
+// reads; everything is driven by grdma_pollset_work() alone.  bpev = 1: RDMA_BPEV -- the
+// endpoints register with the background poller and the pollset falls back to epoll_wait on
+// their wakeup fds after the busy-polling budget.
+struct echo_conn {
+  grpc_endpoint *client, *server;
+  grpc_slice_buffer c_out, c_in, s_out, s_in;
+  grpc_closure c_wrote, c_read, s_wrote, s_read;
+  size_t rounds_left, msg_len, c_got, s_pending;
+  uint32_t seed;
+  int pattern_w, pattern_r;
+  bool c_writing, s_writing, done, failed;
+};
+static size_t g_conns_done = 0;
+
+static void echo_client_send(echo_conn* c) {
+  c->seed = c->seed * 1664525u + 1013904223u;
+  c->msg_len = 1 + (c->seed >> 8) % 40000;
+  uint8_t cur = (uint8_t)c->pattern_w;
+  fill_buffer(&c->c_out, c->msg_len, 8192, &cur);
+  c->pattern_w = cur;
+  c->c_got = 0;
+  c->c_writing = true;
+  grpc_endpoint_write(c->client, &c->c_out, &c->c_wrote, nullptr);
+}
+static void echo_c_wrote(void* p, grpc_error_handle e) {
+  auto* c = static_cast<echo_conn*>(p);
+  c->c_writing = false;
+  if (e != GRPC_ERROR_NONE) c->failed = true;
+}
+static void echo_c_read(void* p, grpc_error_handle e) {
+  auto* c = static_cast<echo_conn*>(p);
+  if (e != GRPC_ERROR_NONE) { c->failed = true; return; }
+  c->c_got += count_slices(c->c_in.slices, c->c_in.count, &c->pattern_r);
+  if (c->c_got >= c->msg_len) {
+    CHECK(c->c_got == c->msg_len);
+    if (--c->rounds_left == 0) {
+      c->done = true;
+      g_conns_done++;
+      return;
+    }
+    echo_client_send(c);
+  }
+  grpc_endpoint_read(c->client, &c->c_in, &c->c_read, false);
+}
+static void echo_s_wrote(void* p, grpc_error_handle e) {
+  auto* c = static_cast<echo_conn*>(p);
+  c->s_writing = false;
+  if (e != GRPC_ERROR_NONE) { c->failed = true; return; }
+  grpc_endpoint_read(c->server, &c->s_in, &c->s_read, false);
+}
+static void echo_s_read(void* p, grpc_error_handle e) {
+  auto* c = static_cast<echo_conn*>(p);
+  if (e != GRPC_ERROR_NONE) { c->failed = true; return; }
+  // echo: the read slices become the write buffer (one write outstanding, then read again)
+  grpc_slice_buffer_swap(&c->s_in, &c->s_out);
+  c->s_writing = true;
+  grpc_endpoint_write(c->server, &c->s_out, &c->s_wrote, nullptr);
+}
+
+static void pollset_echo_test(size_t n_conns, size_t rounds, bool bpev) {
+  setenv("GRPC_PLATFORM_TYPE", bpev ? "RDMA_BPEV" : "RDMA_BP", 1);
+  grpc_pollset* ps = grdma_pollset_create(bpev, /*busy_polling_timeout_us=*/200);
+  CHECK(ps != nullptr);
+  std::vector<echo_conn*> conns;
+  for (size_t i = 0; i < n_conns; i++) {
+    auto* c = new echo_conn();
+    c->client = grpc_endpoint_create(100 + 2 * (int)i, "ipv4:127.0.0.1:1", false);
+    c->server = grpc_endpoint_create(101 + 2 * (int)i, "ipv4:127.0.0.1:2", true);
+    CHECK(c->client && c->server && grpc_rdma_bp_connect_loopback(c->client, c->server));
+    grpc_slice_buffer_init(&c->c_out); grpc_slice_buffer_init(&c->c_in);
+    grpc_slice_buffer_init(&c->s_out); grpc_slice_buffer_init(&c->s_in);
+    GRPC_CLOSURE_INIT(&c->c_wrote, echo_c_wrote, c, nullptr);
+    GRPC_CLOSURE_INIT(&c->c_read, echo_c_read, c, nullptr);
+    GRPC_CLOSURE_INIT(&c->s_wrote, echo_s_wrote, c, nullptr);
+    GRPC_CLOSURE_INIT(&c->s_read, echo_s_read, c, nullptr);
+    c->rounds_left = rounds;
+    c->seed = 12345u + 977u * (uint32_t)i;
+    c->pattern_w = c->pattern_r = 0;
+    c->client->vtable->add_to_pollset(c->client, ps);
+    c->server->vtable->add_to_pollset(c->server, ps);
+    conns.push_back(c);
+  }
+  CHECK(grdma_pollset_size(ps) == 2 * n_conns);
+  g_conns_done = 0;
+  for (auto* c : conns) {
+    grpc_endpoint_read(c->server, &c->s_in, &c->s_read, false);  // first read: arms notify_on_read
+    grpc_endpoint_read(c->client, &c->c_in, &c->c_read, false);
+  }
+  size_t first = 0;
+  if (bpev) {
+    // nothing to do yet: the pass burns its busy-polling budget, then sleeps in epoll_wait
+    CHECK(grdma_pollset_work(ps, 30) == 0);
+    grdma_pollset_stats st0;
+    grdma_pollset_get_stats(ps, &st0);
+    CHECK(st0.epoll_waits == 1);
+    // connection 0 starts from ANOTHER thread while this one sleeps in epoll_wait: the background
+    // poller sees the message and signals the pair's wakeup fd (poller.cc:84-100), the pollset
+    // wakes up, consumes the wakeup and delivers the read
+    std::thread late([&]() {
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+      echo_client_send(conns[0]);
+    });
+    const auto t0 = std::chrono::steady_clock::now();
+    int ran = 0;
+    while (ran == 0 && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5)) ran = grdma_pollset_work(ps, 2000);
+    late.join();
+    CHECK(ran > 0);
+    grdma_pollset_get_stats(ps, &st0);
+    CHECK(st0.wakeups_consumed >= 1);
+    first = 1;
+  }
+  for (size_t i = first; i < conns.size(); i++) echo_client_send(conns[i]);
+  long idle = 0;
+  while (g_conns_done < n_conns) {
+    const int ran = grdma_pollset_work(ps, /*timeout_ms=*/20);
+    CHECK(ran >= 0);
+    for (auto* c : conns) CHECK(!c->failed);
+    if (ran) idle = 0;
+    else if (++idle > 3000) CHECK(!"pollset made no progress");
+  }
+  grdma_pollset_stats st;
+  grdma_pollset_get_stats(ps, &st);
+  if (bpev) CHECK(st.epoll_waits > 0 && st.wakeups_consumed > 0);
+  for (auto* c : conns) {
+    grpc_endpoint_shutdown(c->client, GRPC_ERROR_CREATE_FROM_STATIC_STRING("test done"));
+    grpc_endpoint_shutdown(c->server, GRPC_ERROR_CREATE_FROM_STATIC_STRING("test done"));
+    grpc_endpoint_destroy(c->client);
+    grpc_endpoint_destroy(c->server);
+    grpc_slice_buffer_destroy(&c->c_out); grpc_slice_buffer_destroy(&c->c_in);
+    grpc_slice_buffer_destroy(&c->s_out); grpc_slice_buffer_destroy(&c->s_in);
+    delete c;
+  }
+  CHECK(grdma_pollset_size(ps) == 0);  // grpc_fd_orphan took every fd out of the set
+  grdma_pollset_destroy(ps);
+  printf("pollset_echo_test conns=%zu rounds=%zu bpev=%d: ok (passes %llu, device polls %llu, epoll waits %llu, "
+         "wakeups %llu, closures %llu)\n",
+         n_conns, rounds, (int)bpev, (unsigned long long)st.passes, (unsigned long long)st.device_polls,
+         (unsigned long long)st.epoll_waits, (unsigned long long)st.wakeups_consumed,
+         (unsigned long long)st.closures_run);
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 5 && !strcmp(argv[1], "pollset")) {
+    pollset_echo_test((size_t)atol(argv[2]), (size_t)atol(argv[3]), atoi(argv[4]) != 0);
+    return 0;
+  }
   if (argc >= 2 && !strcmp(argv[1], "multiple_shutdown")) {
     multiple_shutdown_test();
     half_close_test();

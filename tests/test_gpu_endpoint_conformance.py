@@ -44,3 +44,14 @@ def test_small_ring_forces_partial_writes(gpu):
     """64 KiB ring: every 100 kB write needs several rdma_flush retries through the
     writable edge (notify_on_write), and the credit protocol keeps cycling."""
     assert ": ok" in run(2000000, 100000, 8192, 0, env={"GRPC_RDMA_RING_BUFFER_SIZE_KB": "64"})
+
+
+@pytest.mark.parametrize("bpev", [0, 1], ids=["RDMA_BP", "RDMA_BPEV"])
+def test_pollset_with_64_connections(gpu, bpev):
+    """128 endpoints (64 client / server pairs) in ONE pollset, driven only by
+    grdma_pollset_work(): seeded message sizes, server echoes, clients check the i % 256
+    pattern.  RDMA_BP busy-polls (one k_poll launch per pass over all 128 fds); RDMA_BPEV
+    busy-polls 200 us, then sleeps in epoll_wait on the pairs' wakeup fds, which the background
+    poller thread signals."""
+    out = run("pollset", 64, 3, bpev, env={"GRPC_RDMA_RING_BUFFER_SIZE_KB": "256"})
+    assert ": ok" in out
