@@ -55,6 +55,16 @@ struct grdma_engine_cmd {
   struct grdma_sge sges[GRDMA_CMD_MAX_SGES];  // ptr = offset into inline_data
   uint8_t inline_data[GRDMA_CMD_INLINE_BYTES];
 };
+// Fast lane: a small command travels INSIDE the mailbox.  Eight 64-byte lines, each seven
+// payload words + the command's sequence number in its last word.  The host fills a line's
+// payload before it stamps the line (stores to one cache line become visible in program order),
+// and a PCIe read returns a line as a unit: a line that shows the expected stamp holds that
+// command's words.  Wave 0 of the engine reads all eight lines with ONE load per poll (lane l =
+// word l), so a 64-byte RPC costs one PCIe round trip from doorbell to payload-in-LDS instead of
+// three dependent ones (doorbell -> type/op -> command block).
+// Payload: [type | nsges << 8 | data bytes << 16] [the op struct] [nsges x {offset, len}] [data].
+#define GRDMA_FAST_LINES 8
+#define GRDMA_FAST_WORDS (GRDMA_FAST_LINES * 7)  // payload words
 struct grdma_engine_mbox {
   uint64_t cmd_seq;    // host: bumped last, after cmd_type/op are written
   uint64_t cmd_type;
@@ -64,6 +74,7 @@ struct grdma_engine_mbox {
   uint64_t alive;      // engine: 1 while resident
   uint64_t exit_flag;  // host: ask the engine to leave
   uint64_t pad1[5];
+  uint64_t fast[GRDMA_FAST_LINES * 8];
 };
 
 #endif  // GRDMA_OPS_H

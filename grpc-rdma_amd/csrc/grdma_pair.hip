@@ -241,16 +241,60 @@ int engine_launch() {
   return 0;
 }
 
+// Pack a small command for the mailbox's fast lane (see grdma_engine_mbox); 0 = does not fit.
+size_t pack_fast(uint64_t type, const grdma_engine_cmd* blk, uint64_t* words) {
+  size_t nsges = 0, dbytes = 0, nw = 1;
+  if (type == GRDMA_ENGINE_SEND_INLINE) {
+    nsges = (size_t)blk->tx.nslices;
+    if (nsges > GRDMA_CMD_MAX_SGES) return 0;
+    for (size_t i = 0; i < nsges; i++) dbytes += (size_t)blk->sges[i].len;
+    const size_t total = 1 + sizeof(grdma_tx_op) / 8 + 2 * nsges + (dbytes + 7) / 8;
+    if (total > GRDMA_FAST_WORDS || dbytes > GRDMA_CMD_INLINE_BYTES) return 0;
+    memcpy(words + nw, &blk->tx, sizeof(grdma_tx_op));
+    nw += sizeof(grdma_tx_op) / 8;
+    for (size_t i = 0; i < nsges; i++) {
+      words[nw++] = (uint64_t)blk->sges[i].ptr;  // offset into the data
+      words[nw++] = blk->sges[i].len;
+    }
+    if (dbytes) {
+      words[nw + (dbytes - 1) / 8] = 0;
+      memcpy(words + nw, blk->inline_data, dbytes);
+      nw += (dbytes + 7) / 8;
+    }
+  } else if (type == GRDMA_ENGINE_DRAIN_BLOCK) {
+    memcpy(words + nw, &blk->rx, sizeof(grdma_rx_op));
+    nw += sizeof(grdma_rx_op) / 8;
+  } else {
+    return 0;
+  }
+  words[0] = type | ((uint64_t)nsges << 8) | ((uint64_t)dbytes << 16);
+  return nw;
+}
+static_assert(sizeof(grdma_tx_op) % 8 == 0 && sizeof(grdma_rx_op) % 8 == 0, "ops are packed as 8-byte words");
+
 // Hand one command to the resident engine and wait for it.
 int engine_submit(uint64_t type, const void* op) {
   grdma_engine& e = g_engine;
   std::lock_guard<std::mutex> lk(e.mu);
   if (int rc = engine_launch()) return rc;
-  e.mb->cmd_type = type;
-  e.mb->op = op;
-  std::atomic_thread_fence(std::memory_order_release);
+  uint64_t words[GRDMA_FAST_WORDS];
+  const size_t nw = (type == GRDMA_ENGINE_SEND_INLINE || type == GRDMA_ENGINE_DRAIN_BLOCK)
+                        ? pack_fast(type, static_cast<const grdma_engine_cmd*>(op), words) : 0;
   const uint64_t seq = ++e.seq;
-  *(volatile uint64_t*)&e.mb->cmd_seq = seq;
+  if (nw) {
+    volatile uint64_t* f = e.mb->fast;
+    const size_t lines = (nw + 6) / 7;
+    for (size_t j = lines; j-- > 0;) {  // line 0 -- the one that announces the command -- last
+      for (size_t k = 0; k < 7 && 7 * j + k < nw; k++) f[8 * j + k] = words[7 * j + k];
+      std::atomic_thread_fence(std::memory_order_release);
+      f[8 * j + 7] = seq;
+    }
+  } else {
+    e.mb->cmd_type = type;
+    e.mb->op = op;
+    std::atomic_thread_fence(std::memory_order_release);
+    *(volatile uint64_t*)&e.mb->cmd_seq = seq;
+  }
   volatile uint64_t* ack = &e.mb->ack_seq;
   volatile uint64_t* alive = &e.mb->alive;
   const auto t0 = std::chrono::steady_clock::now();

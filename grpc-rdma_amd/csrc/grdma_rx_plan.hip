@@ -1311,6 +1311,7 @@ __device__ __attribute__((noinline)) void rx_plan_call(const grdma_rx_op* op) { 
 __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_engine(grdma_engine_mbox* mb) {
   __shared__ uint64_t s_cmd[4];
+  __shared__ uint64_t s_fast[GRDMA_FAST_WORDS];
   __shared__ __attribute__((aligned(16))) grdma_engine_cmd s_blk;
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // resume after the last command a previous incarnation completed
@@ -1324,11 +1325,33 @@ void k_engine(grdma_engine_mbox* mb) {
     // same word): a single-lane spin loop would be a divergent loop around the
     // barriers below, which the compiler may legally serialise into a deadlock.
     if (wave == 0) {
-      uint64_t seq, idle = 0, quit = 0;
+      uint64_t seq, idle = 0, quit = 0, fast_words = 0, fast_type = 0;
       for (;;) {
+        // one poll = two loads in flight together: the eight fast-lane lines (lane l = word l)
+        // and the doorbell of the pointer path
+        const uint64_t fw = __hip_atomic_load(&mb->fast[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         seq = __hip_atomic_load(&mb->cmd_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         seq = __shfl(seq, 0, 64);
-        if (seq != last) break;
+        const uint64_t stamp0 = __shfl(fw, 7, 64);
+        if (stamp0 == last + 1) {
+          // a fast command: every line it spans must carry its stamp
+          const uint64_t hdr = __shfl(fw, 0, 64);
+          const uint64_t ftype = hdr & 0xFF, nsg = (hdr >> 8) & 0xFF, db = (hdr >> 16) & 0xFFFF;
+          const uint64_t nw = 1 + (ftype == GRDMA_ENGINE_SEND_INLINE ? sizeof(grdma_tx_op) / 8 : sizeof(grdma_rx_op) / 8) +
+                              2 * nsg + (db + 7) / 8;
+          const uint64_t lines = (nw + 6) / 7;
+          const bool mine_ok = (lane & 7) != 7 || (uint64_t)(lane >> 3) >= lines || fw == stamp0;
+          if (nw <= GRDMA_FAST_WORDS && __all(mine_ok)) {
+            if ((lane & 7) != 7) s_fast[(lane >> 3) * 7 + (lane & 7)] = fw;
+            seq = stamp0;
+            fast_words = nw;
+            fast_type = ftype;
+            break;
+          }
+          // (a line is still on its way: poll again)
+        } else if (seq == last + 1) {
+          break;
+        }
         if ((idle & 63) == 63) {
           quit = __hip_atomic_load(&mb->exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           quit = __shfl(quit, 0, 64);
@@ -1337,8 +1360,14 @@ void k_engine(grdma_engine_mbox* mb) {
         idle++;
         __builtin_amdgcn_s_sleep(8);
       }
-      const uint64_t type = quit ? 0 : mb->cmd_type;
-      const uint64_t opp = quit ? 0 : (uint64_t)mb->op;
+      uint64_t type, opp;
+      if (fast_words) {
+        type = fast_type;
+        opp = 1;  // "the command came through the fast lane": the block is rebuilt from s_fast below
+      } else {
+        type = quit ? 0 : mb->cmd_type;
+        opp = quit ? 0 : (uint64_t)mb->op;
+      }
       if (lane == 0) {
         s_cmd[0] = seq;
         s_cmd[1] = type;
@@ -1362,7 +1391,20 @@ void k_engine(grdma_engine_mbox* mb) {
     } else if (type == GRDMA_ENGINE_SEND_INLINE || type == GRDMA_ENGINE_DRAIN_BLOCK) {
       // one wide read of the whole command block into LDS, then everything the body
       // touches (op, slice table, payload) is local
-      {
+      if (opp == 1) {
+        // fast lane: the words are in LDS already (the barrier after the doorbell published them)
+        const uint64_t hdr = s_fast[0];
+        const unsigned nsg = (unsigned)((hdr >> 8) & 0xFF), dw = (unsigned)((((hdr >> 16) & 0xFFFF) + 7) / 8);
+        const bool is_tx = type == GRDMA_ENGINE_SEND_INLINE;
+        const unsigned opw = is_tx ? sizeof(grdma_tx_op) / 8 : sizeof(grdma_rx_op) / 8;
+        uint64_t* dop = is_tx ? reinterpret_cast<uint64_t*>(&s_blk.tx) : reinterpret_cast<uint64_t*>(&s_blk.rx);
+        if (threadIdx.x < opw) dop[threadIdx.x] = s_fast[1 + threadIdx.x];
+        if (is_tx) {
+          if (threadIdx.x < 2 * nsg) reinterpret_cast<uint64_t*>(s_blk.sges)[threadIdx.x] = s_fast[1 + opw + threadIdx.x];
+          if (threadIdx.x < dw)
+            reinterpret_cast<uint64_t*>(s_blk.inline_data)[threadIdx.x] = s_fast[1 + opw + 2 * nsg + threadIdx.x];
+        }
+      } else {
         const u32x4* src = reinterpret_cast<const u32x4*>(opp);
         u32x4* dst = reinterpret_cast<u32x4*>(&s_blk);
         for (unsigned i = threadIdx.x; i < sizeof(grdma_engine_cmd) / 16; i += PLAN_THREADS)
