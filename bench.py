@@ -448,6 +448,68 @@ def main():
             tx.close(); rx.close(); dst.free()
         return out
 
+    def measure_with_h2(ring_kb, steps, warmup, engine=False):
+        """The same step with the HTTP/2 stages INSIDE the timed device pipeline: k_h2_frame rebuilds
+        the slice list from the message table, the job carries it through the connection, k_h2_deframe
+        parses what was delivered (events: frames, message boundaries, payload pieces).  Two jobs over
+        the one connection alternate, so framing / deframing of neighbouring steps run beside a job."""
+        from grpc_rdma_amd import h2dev
+        ring = ring_kb * 1024
+        w = wl
+        tx, rx = g.Pair(ring, args.max_sge, flags), g.Pair(ring, args.max_sge, flags)
+        g.connect_pairs(tx, rx)
+        scap = len(w.lens) * 2 + 64 + w.N // 256
+        dst_cap = w.N + 16 * scap + 4096
+        msgs = [(w.payload_buf.ptr + i * w.msg_len, w.msg_len, 1, 0) for i in range(w.n_msgs)]
+        parser = h2dev.Parser(False)
+        assert parser.open_streams([1]) == 0      # a client-side parser: the call runs on stream 1
+        jobs, pipes, dsts = [], [], []
+        for _ in range(2):
+            dst = g.DeviceBuffer(nbytes=dst_cap)
+            est = max(8, 4 * (w.E // (ring // 2) + 2), 2 * (len(w.lens) // min(args.max_sge, 4095) + 2))
+            job = gs.MultiStreamJob([(tx, rx, w.sge, dst.ptr, dst_cap, scap)], est)
+            if engine:
+                r = job.run(gs.RUN_ENGINE)
+            else:
+                job.set_pipeline(bool(args.pipeline))
+                r = job.run(gs.RUN_EAGER)
+                job.set_rounds(int(max(r.tx_rounds, r.rx_rounds)))
+                r = job.run(gs.RUN_GRAPH)
+            assert r.done and r.bytes_delivered == w.N
+            delivered = len(job.delivered_slices(0))
+            pipes.append(h2dev.Pipe(job, msgs, parser, delivered, 4 * len(w.lens) + 1024))
+            jobs.append(job)
+            dsts.append(dst)
+        for i in range(max(2, warmup)):
+            pipes[i % 2].enqueue(engine)
+        for p_ in pipes:
+            p_.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            pipes[i % 2].enqueue(engine)
+        for p_ in pipes:
+            p_.sync()
+        torch.cuda.synchronize()
+        elapsed = grp.max(time.perf_counter() - t0)
+        barrier()
+        ok = True
+        for p_ in pipes:  # what the last step of each pipe produced
+            r = p_.sync(want_events=True)
+            evs = r["event_list"]
+            ok = ok and r["h2_error"] == 0 and not r["frame_overflow"] and not r["deframe_overflow"] and \
+                r["framed"] == len(w.lens) and r["parsed"] == p_.delivered and \
+                sum(1 for e in evs if e[0] == 5) == w.n_msgs and sum(e[2] for e in evs if e[0] == 4) == w.n_msgs * w.msg_len
+        for p_ in pipes:
+            p_.close()
+        for j_ in jobs:
+            j_.close()
+        parser.close()
+        tx.close(); rx.close()
+        for d_ in dsts:
+            d_.free()
+        return {"elapsed": elapsed, "verified": ok}
+
     schedule = "pipelined" if args.pipeline else "sequential"
     head = None
     if args.pipeline:
@@ -572,6 +634,14 @@ def main():
                          "table_entries": [st["gather_entries"], st["wire_entries"], st["scatter_entries"]],
                          "worker_waves": [st["gather_waves"], st["wire_waves"], st["scatter_waves"]],
                          "workgroups": st["team"], "staging_buffers": st["staging_buffers"], "verified": eng["verified"]}
+    if not args.no_extra_legs or os.environ.get("BENCH_H2"):
+        # frame -> endpoint -> deframe, all three inside the timed device pipeline
+        try:
+            hh = measure_with_h2(args.ring_kb, args.steps, max(2, args.warmup), engine=(args.schedule == "engine"))
+            out["value_with_h2"] = round(wl.user_bytes * args.steps * world / hh["elapsed"] / (1 << 30), 3)
+            out["with_h2_verified"] = hh["verified"]
+        except Exception as e:
+            out["with_h2_error"] = str(e)[:200]
     if not args.no_extra_legs:
         # the reference's default knobs (4 MiB ring, max_sge 30: rdma_utils.h / config.cc), same workload,
         # with the CPU codec timed at the SAME knobs beside it

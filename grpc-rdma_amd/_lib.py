@@ -76,6 +76,7 @@ SIGNATURES = {
     "grdma_pair_peek_staging": (C.c_int, [C.c_void_p, u64, C.c_void_p, u64]),
     "grdma_pair_last_wrs": (C.c_int, [C.c_void_p, C.POINTER((u64 * 2) * 2)]),
     "grdma_pair_ring_device_ptr": (C.c_void_p, [C.c_void_p]),
+    "grdma_pair_export_ring_dmabuf": (C.c_int, [C.c_void_p]),
     "grdma_endpoint_write_begin": (C.c_int64, [C.c_void_p, C.POINTER(Slice), u64, C.c_int]),
     "grdma_endpoint_write_step": (C.c_int64, [C.c_void_p, C.POINTER(C.c_int)]),
     "grdma_endpoint_write_abort": (C.c_int, [C.c_void_p]),

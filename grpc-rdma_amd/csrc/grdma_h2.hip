@@ -307,10 +307,17 @@ __device__ void tab_remove(grdma_h2_stream_dev* tab, uint32_t mask, uint32_t i) 
 }
 
 // Register cache of slices [cbase, cbase + 64): lane i holds the descriptor and the first
-// 32 bytes of slice cbase + i (one memory round trip per 64 slices).  Plain functions over a
-// plain struct (no capturing lambdas): everything stays in registers.
+// 32 bytes of slice cbase + i.  Filling a window costs two DEPENDENT memory round trips
+// (descriptor, then the bytes it points to) -- more than it takes to parse the window -- so the
+// cache runs two windows ahead: n1 = the next window, descriptors arrived and bytes requested one
+// window ago; n2 = the window after that, descriptors requested.  A switch to the next window
+// moves n1 in, asks for n1's bytes (its descriptors have long arrived) and for the following
+// window's descriptors, and parsing goes on while those are in flight.
+// Plain functions over a plain struct (no capturing lambdas): everything stays in registers.
 struct h2_slice_cache {
   uint64_t cbase, c0, c1, c2, c3, c_off, c_len;
+  uint64_t n1_base, n1_0, n1_1, n1_2, n1_3, n1_off, n1_len;
+  uint64_t n2_base, n2_off, n2_len;
 };
 
 __device__ __forceinline__ uint64_t h2_keep(uint64_t v, uint64_t first, uint64_t n) {
@@ -320,44 +327,75 @@ __device__ __forceinline__ uint64_t h2_keep(uint64_t v, uint64_t first, uint64_t
   return v & ((1ull << ((n - first) * 8)) - 1);
 }
 
+__device__ __forceinline__ void h2_load_desc(uint64_t base, const grdma_slice_out* slices, uint64_t nslices, int lane,
+                                             uint64_t& off, uint64_t& len) {
+  // (an unconditional load from a clamped index: a load under a branch is followed by a full
+  //  s_waitcnt, which would turn the look-ahead back into one round trip per load)
+  const uint64_t mine = base + (uint64_t)lane;
+  const uint64_t idx = mine < nslices ? mine : nslices - 1;  // nslices >= 1 whenever the kernel parses anything
+  const u64x2 d = *reinterpret_cast<const u64x2*>(&slices[idx]);
+  const bool have = mine < nslices;
+  off = have ? d.x : 0;
+  len = have ? d.y : 0;
+}
+
+// the first 32 bytes of the slice {off, n} (zero beyond its end)
+__device__ __forceinline__ void h2_load_bytes(const uint8_t* arena, uint64_t off, uint64_t n, uint64_t& r0, uint64_t& r1,
+                                              uint64_t& r2, uint64_t& r3) {
+  const uint8_t* p = arena + off;
+  // the aligned 16-byte blocks that hold the first 32 bytes of the slice (two when the
+  // slice starts on a 16-byte boundary, three otherwise).  Nothing outside the blocks the
+  // slice touches is read: a block beyond them is replaced by block 0 (an empty slice reads
+  // the arena's first block) -- the three loads stay unconditional and go out together.
+  const uint64_t sh = (uint64_t)p & 15;
+  const u64x2* q = n ? reinterpret_cast<const u64x2*>((uint64_t)p & ~15ull)
+                     : reinterpret_cast<const u64x2*>((uint64_t)arena & ~15ull);
+  const uint64_t need = n ? (n < 32 ? n : 32) + sh : 0;
+  const u64x2 v0 = q[0];
+  const u64x2 v1 = q[need > 16 ? 1 : 0];
+  const u64x2 v2 = q[need > 32 ? 2 : 0];
+  // 48-byte window w0..w5, shifted right by sh bytes
+  uint64_t w0 = v0.x, w1 = v0.y, w2 = v1.x, w3 = v1.y, w4 = v2.x, w5 = v2.y;
+  if (sh & 8) { w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; }
+  const unsigned bs = (unsigned)(sh & 7) * 8;
+  uint64_t o0 = w0, o1 = w1, o2 = w2, o3 = w3;
+  if (bs) {
+    o0 = (w0 >> bs) | (w1 << (64 - bs));
+    o1 = (w1 >> bs) | (w2 << (64 - bs));
+    o2 = (w2 >> bs) | (w3 << (64 - bs));
+    o3 = (w3 >> bs) | (w4 << (64 - bs));
+  }
+  r0 = h2_keep(o0, 0, n);
+  r1 = h2_keep(o1, 8, n);
+  r2 = h2_keep(o2, 16, n);
+  r3 = h2_keep(o3, 24, n);
+}
+
 __device__ __forceinline__ void h2_ensure(h2_slice_cache& C, uint64_t s, const uint8_t* arena,
                                           const grdma_slice_out* slices, uint64_t nslices, int lane) {
   if (s >= C.cbase && s < C.cbase + 64) return;
-  C.cbase = s;
-  const uint64_t mine = s + lane;
-  C.c0 = C.c1 = C.c2 = C.c3 = 0;
-  C.c_off = C.c_len = 0;
-  if (mine < nslices) {
-    C.c_off = slices[mine].off;
-    C.c_len = slices[mine].len;
-    const uint8_t* p = arena + C.c_off;
-    const uint64_t n = C.c_len;
-    // the aligned 16-byte blocks that hold the first 32 bytes of the slice (two when the
-    // slice starts on a 16-byte boundary, three otherwise); a block is only fetched when
-    // it overlaps the slice, so nothing outside the blocks the slice touches is read
-    const uint64_t sh = (uint64_t)p & 15;
-    const u64x2* q = reinterpret_cast<const u64x2*>((uint64_t)p & ~15ull);
-    const uint64_t need = (n < 32 ? n : 32) + sh;
-    u64x2 v0 = {0, 0}, v1 = {0, 0}, v2 = {0, 0};
-    if (need > 0) v0 = q[0];
-    if (need > 16) v1 = q[1];
-    if (need > 32) v2 = q[2];
-    // 48-byte window w0..w5, shifted right by sh bytes
-    uint64_t w0 = v0.x, w1 = v0.y, w2 = v1.x, w3 = v1.y, w4 = v2.x, w5 = v2.y;
-    if (sh & 8) { w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; }
-    const unsigned bs = (unsigned)(sh & 7) * 8;
-    uint64_t o0 = w0, o1 = w1, o2 = w2, o3 = w3;
-    if (bs) {
-      o0 = (w0 >> bs) | (w1 << (64 - bs));
-      o1 = (w1 >> bs) | (w2 << (64 - bs));
-      o2 = (w2 >> bs) | (w3 << (64 - bs));
-      o3 = (w3 >> bs) | (w4 << (64 - bs));
-    }
-    C.c0 = h2_keep(o0, 0, n);
-    C.c1 = h2_keep(o1, 8, n);
-    C.c2 = h2_keep(o2, 16, n);
-    C.c3 = h2_keep(o3, 24, n);
+  if (C.cbase != ~0ull && s >= C.n1_base && s < C.n1_base + 64) {
+    // the next window moves in; its successor's bytes and the descriptors of the one after are requested
+    C.cbase = C.n1_base;
+    C.c0 = C.n1_0; C.c1 = C.n1_1; C.c2 = C.n1_2; C.c3 = C.n1_3;
+    C.c_off = C.n1_off; C.c_len = C.n1_len;
+    C.n1_base = C.n2_base;
+    C.n1_off = C.n2_off;
+    C.n1_len = C.n2_len;
+    h2_load_bytes(arena, C.n1_off, C.n1_len, C.n1_0, C.n1_1, C.n1_2, C.n1_3);
+    C.n2_base = C.n1_base + 64;
+    h2_load_desc(C.n2_base, slices, nslices, lane, C.n2_off, C.n2_len);
+    return;
   }
+  // cold start (or a jump): three windows of descriptors in one round trip, two of bytes in the next
+  C.cbase = s;
+  C.n1_base = s + 64;
+  C.n2_base = s + 128;
+  h2_load_desc(C.cbase, slices, nslices, lane, C.c_off, C.c_len);
+  h2_load_desc(C.n1_base, slices, nslices, lane, C.n1_off, C.n1_len);
+  h2_load_desc(C.n2_base, slices, nslices, lane, C.n2_off, C.n2_len);
+  h2_load_bytes(arena, C.c_off, C.c_len, C.c0, C.c1, C.c2, C.c3);
+  h2_load_bytes(arena, C.n1_off, C.n1_len, C.n1_0, C.n1_1, C.n1_2, C.n1_3);
 }
 
 __device__ __forceinline__ uint32_t h2_byte_at(h2_slice_cache& C, uint64_t s, uint64_t off,
@@ -482,7 +520,7 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
   const bool is_server = P.is_server != 0;
   grdma_h2_stream_dev* const tab = P.tab;
   h2_cur_stream D = {-1, 0, 0, 0, 0, 0, 0, 0};
-  h2_slice_cache C = {~0ull, 0, 0, 0, 0, 0, 0};
+  h2_slice_cache C = {~0ull, 0, 0, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0, 0, 0, ~0ull, 0, 0};
 #define H2_PUSH(kind, a, b, c, d, sl) h2_push(ev, ev_cap, nev, overflow, lane, kind, a, b, c, d, sl)
 #define H2_BYTE(s_, off_) h2_byte_at(C, s_, off_, arena, slices, nslices, lane)
   // what the payload parser does with the last piece of a frame (frame_data.cc:299-305,
@@ -514,6 +552,82 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
   int err = P.error;
   for (; s < nslices && !err && !overflow; s++) {
     h2_ensure(C, s, arena, slices, nslices, lane);
+    // ---- bulk step: the streaming steady state, many frames at once ---------------------
+    // Between a message's first and last frame every DATA frame of a stream spans exactly TWO
+    // slices: on the sending side a 9-byte header slice and one payload slice
+    // (frame_data.cc:64-90); on the receiving side -- where the endpoint sized its read to the
+    // 9-byte record, max(256, 9) (rdma_bp_posix.cc:308) -- a 256-byte slice holding the header
+    // and the first 247 payload bytes, then one slice with the rest.  In general: slice a = 9
+    // header bytes + p0 >= 0 payload bytes, slice a + 1 = the remaining p1 > 0 bytes.
+    // The slice cache holds descriptor + first bytes of the next 64 slices, one per lane: every
+    // even lane (counted from s) checks "my slice starts such a frame, for the stream that is
+    // mid-message, and the next slice ends it"; a ballot finds the verified prefix, a prefix
+    // sum cuts it where the message ends, and each verified lane writes the events the byte-wise
+    // automaton below would have produced for its frame.
+    if (st == ST_FH0 && expect_cont == 0 && !is_first_frame && D.idx >= 0 && !D.read_closed && D.state == 5 &&
+        D.fsz != 0) {
+      const int rel = lane - (int)(s - C.cbase);  // my slice is s + rel
+      const bool hdr_lane = rel >= 0 && (rel & 1) == 0;
+      const uint64_t b8 = C.c0;
+      const uint32_t fs = (uint32_t)(((b8 & 0xFF) << 16) | (((b8 >> 8) & 0xFF) << 8) | ((b8 >> 16) & 0xFF));
+      const uint32_t sd = (uint32_t)((((b8 >> 40) & 0x7F) << 24) | (((b8 >> 48) & 0xFF) << 16) |
+                                     (((b8 >> 56) & 0xFF) << 8) | (C.c1 & 0xFF));
+      const uint64_t next_len = __shfl(C.c_len, (lane + 1) & 63, 64);
+      const uint32_t p0 = (uint32_t)(C.c_len - 9);  // (only looked at when c_len >= 9)
+      // type DATA, flags 0 (an END_STREAM frame closes the stream: left to the automaton)
+      const bool ok = hdr_lane && lane < 63 && C.c_len >= 9 && C.c_len < 9ull + fs && ((b8 >> 24) & 0xFFFF) == 0 &&
+                      sd == D.id && fs <= max_frame && next_len == (uint64_t)fs - p0;
+      const uint64_t bad = __ballot(hdr_lane && !ok);
+      const int first_bad = bad ? __builtin_ctzll(bad) : 64;
+      const bool cand = ok && lane < first_bad;
+      uint32_t cum = cand ? fs : 0u;                     // payload bytes up to and including my frame
+      uint32_t epos = cand ? (p0 ? 5u : 3u) : 0u;        // events up to and including my frame
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(cum, d, 64), ue = __shfl_up(epos, d, 64);
+        if (lane >= d) {
+          cum += up;
+          epos += ue;
+        }
+      }
+      const bool within = cand && cum <= D.fsz;  // (cum is monotone: the lanes within form a prefix)
+      const uint64_t wmask = __ballot(within);
+      if (wmask != 0) {
+        const int last_lane = 63 - __builtin_clzll(wmask);
+        const uint32_t total = __shfl(cum, last_lane, 64), nevs = __shfl(epos, last_lane, 64);
+        const bool ends = total == D.fsz;
+        if (nev + nevs + 1 <= ev_cap) {
+          if (within) {
+            auto* e = (__attribute__((address_space(1))) grdma_h2_event*)(uint64_t)(ev + nev + epos - (p0 ? 5u : 3u));
+            const uint32_t sl = (uint32_t)(s + (uint64_t)rel);
+            e[0].kind = EV_FRAME; e[0].a = FT_DATA; e[0].b = 0; e[0].c = sd; e[0].d = fs; e[0].slice = sl;
+            if (p0) {
+              e[1].kind = EV_PAYLOAD; e[1].a = 9; e[1].b = p0; e[1].c = 0; e[1].d = 0; e[1].slice = sl;
+              e[2].kind = EV_MSG_BYTES; e[2].a = 9; e[2].b = p0; e[2].c = sd; e[2].d = 0; e[2].slice = sl;
+              e += 2;
+            }
+            const uint32_t p1 = fs - p0;
+            e[1].kind = EV_PAYLOAD; e[1].a = 0; e[1].b = p1; e[1].c = 1; e[1].d = 0; e[1].slice = sl + 1;
+            e[2].kind = EV_MSG_BYTES; e[2].a = 0; e[2].b = p1; e[2].c = sd; e[2].d = 0; e[2].slice = sl + 1;
+            if (ends && lane == last_lane) {
+              e[3].kind = EV_MSG_END; e[3].a = 0; e[3].b = 0; e[3].c = sd; e[3].d = 0; e[3].slice = sl + 1;
+            }
+          }
+          nev += nevs + (ends ? 1 : 0);
+          D.fsz -= total;
+          if (ends) D.state = 0;
+          // what the automaton's registers hold after the last of these frames
+          fsz = 0;
+          ftype = FT_DATA;
+          fflags = 0;
+          sid = D.id;
+          cur_parser = PARSER_DATA;
+          received_last = 0;
+          s += 2ull * (uint64_t)__builtin_popcountll(wmask) - 1;  // (the loop adds the last one)
+          continue;
+        }
+      }
+    }
     const uint64_t len = __shfl(C.c_len, (int)(s - C.cbase), 64);
     uint64_t cur = 0;
     while (cur < len && !err && !overflow) {
@@ -954,6 +1068,152 @@ int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_re
     return -GRDMA_ERR_HIP;
   if (h2_error) *h2_error = (int)h_res.error;
   return h_res.overflow ? -GRDMA_ERR_CAPACITY : (int64_t)m;
+}
+
+// ---- HTTP/2 inside the device pipeline ------------------------------------------------------
+// frame (k_h2_frame rebuilds the job's slice list from the message table) -> the streaming job
+// -> deframe (k_h2_deframe over the slices the job delivered), all enqueued, each stage on its
+// own stream, ordered by events.  Two pipes over two jobs of the same connection alternate so
+// that the deframing of step k and the framing of step k + 1 run beside the job of step k + 1.
+struct grdma_stream_job;
+int grdma_job_link_view(grdma_stream_job* j, uint32_t link, grdma_sge** d_sges, uint64_t* count,
+                        grdma_slice_out** d_slices, uint8_t** dst, hipStream_t* stream);
+int grdma_stream_job_launch(grdma_stream_job* j);
+int grdma_stream_job_launch_engine(grdma_stream_job* j);
+
+struct grdma_h2_pipe {
+  grdma_stream_job* job = nullptr;
+  grdma_h2_parser* parser = nullptr;
+  grdma_sge* d_sges = nullptr;
+  uint64_t count = 0;
+  grdma_slice_out* d_slices = nullptr;
+  uint8_t* dst = nullptr;
+  hipStream_t job_stream = nullptr, frame_stream = nullptr, deframe_stream = nullptr;
+  hipEvent_t framed = nullptr, job_done = nullptr, deframed = nullptr;
+  grdma_h2_msg_dev* d_msgs = nullptr;
+  uint64_t nmsgs = 0;
+  uint32_t max_frame = 16384;
+  uint8_t* d_hdr = nullptr;
+  uint64_t hdr_cap = 0;
+  grdma_h2_frame_result* d_fres = nullptr;
+  grdma_h2_deframe_result* d_dres = nullptr;
+  grdma_h2_event* d_ev = nullptr;
+  uint64_t ev_cap = 0, delivered = 0;
+  bool launched = false;
+};
+
+namespace {
+hipStream_t g_pipe_frame_stream = nullptr, g_pipe_deframe_stream = nullptr;
+}
+
+grdma_h2_pipe* grdma_h2_pipe_create(grdma_stream_job* job, uint32_t link, const grdma_h2_msg* msgs, uint64_t nmsgs,
+                                    uint32_t max_frame, grdma_h2_parser* parser, uint64_t delivered_slices,
+                                    uint64_t events_cap) {
+  if (grdma_device_count() <= 0 || !job || !msgs || !nmsgs || !parser || max_frame == 0 || max_frame >= (1u << 24))
+    return nullptr;
+  if (!g_pipe_frame_stream &&
+      (hipStreamCreateWithFlags(&g_pipe_frame_stream, hipStreamNonBlocking) != hipSuccess ||
+       hipStreamCreateWithFlags(&g_pipe_deframe_stream, hipStreamNonBlocking) != hipSuccess))
+    return nullptr;
+  grdma_h2_pipe* p = new grdma_h2_pipe();
+  p->job = job;
+  p->parser = parser;
+  p->nmsgs = nmsgs;
+  p->max_frame = max_frame;
+  p->delivered = delivered_slices;
+  p->ev_cap = events_cap;
+  p->frame_stream = g_pipe_frame_stream;      // shared by all pipes: framings are ordered among themselves
+  p->deframe_stream = g_pipe_deframe_stream;  // shared: the parser state is handed from one deframing to the next
+  std::vector<grdma_h2_msg_dev> tmp(nmsgs);
+  for (uint64_t i = 0; i < nmsgs; i++) {
+    tmp[i].payload = static_cast<const uint8_t*>(msgs[i].payload);
+    tmp[i].len = msgs[i].len;
+    tmp[i].stream_id = msgs[i].stream_id;
+    tmp[i].flags = msgs[i].flags;
+  }
+  bool ok = grdma_job_link_view(job, link, &p->d_sges, &p->count, &p->d_slices, &p->dst, &p->job_stream) == 0;
+  p->hdr_cap = 32 * (p->count + 64);
+  ok = ok && hipMalloc((void**)&p->d_msgs, sizeof(grdma_h2_msg_dev) * nmsgs) == hipSuccess &&
+       hipMalloc((void**)&p->d_hdr, p->hdr_cap) == hipSuccess &&
+       hipMalloc((void**)&p->d_fres, sizeof(grdma_h2_frame_result)) == hipSuccess &&
+       hipMalloc((void**)&p->d_dres, sizeof(grdma_h2_deframe_result)) == hipSuccess &&
+       hipMalloc((void**)&p->d_ev, sizeof(grdma_h2_event) * (events_cap ? events_cap : 1)) == hipSuccess &&
+       hipMemcpy(p->d_msgs, tmp.data(), sizeof(grdma_h2_msg_dev) * nmsgs, hipMemcpyHostToDevice) == hipSuccess &&
+       hipEventCreateWithFlags(&p->framed, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&p->job_done, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&p->deframed, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    grdma_h2_pipe_destroy(p);
+    return nullptr;
+  }
+  return p;
+}
+
+void grdma_h2_pipe_destroy(grdma_h2_pipe* p) {
+  if (!p) return;
+  if (p->launched) {
+    hipStreamSynchronize(p->frame_stream);
+    hipStreamSynchronize(p->job_stream);
+    hipStreamSynchronize(p->deframe_stream);
+  }
+  hipFree(p->d_msgs);
+  hipFree(p->d_hdr);
+  hipFree(p->d_fres);
+  hipFree(p->d_dres);
+  hipFree(p->d_ev);
+  if (p->framed) hipEventDestroy(p->framed);
+  if (p->job_done) hipEventDestroy(p->job_done);
+  if (p->deframed) hipEventDestroy(p->deframed);
+  delete p;
+}
+
+// One step: schedule 0 = the job's captured graph, 1 = the persistent link engine.
+int grdma_h2_pipe_enqueue(grdma_h2_pipe* p, int schedule) {
+  if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
+  if (!p) return -GRDMA_ERR_INVALID;
+  // framing overwrites the slice table the job's previous step read
+  if (p->launched && hipStreamWaitEvent(p->frame_stream, p->job_done, 0) != hipSuccess) return -GRDMA_ERR_HIP;
+  if (hipMemsetAsync(p->d_fres, 0, sizeof(grdma_h2_frame_result), p->frame_stream) != hipSuccess) return -GRDMA_ERR_HIP;
+  hipLaunchKernelGGL(k_h2_frame, dim3(1), dim3(256), 0, p->frame_stream, p->d_msgs, p->nmsgs, p->max_frame, p->d_sges,
+                     p->count, p->d_hdr, p->hdr_cap, (uint64_t*)nullptr, p->d_fres);
+  if (hipEventRecord(p->framed, p->frame_stream) != hipSuccess) return -GRDMA_ERR_HIP;
+  // the job reads the slice table and overwrites what the previous deframing parsed
+  if (hipStreamWaitEvent(p->job_stream, p->framed, 0) != hipSuccess) return -GRDMA_ERR_HIP;
+  if (p->launched && hipStreamWaitEvent(p->job_stream, p->deframed, 0) != hipSuccess) return -GRDMA_ERR_HIP;
+  const int rc = schedule == 1 ? grdma_stream_job_launch_engine(p->job) : grdma_stream_job_launch(p->job);
+  if (rc < 0) return rc;
+  if (hipEventRecord(p->job_done, p->job_stream) != hipSuccess) return -GRDMA_ERR_HIP;
+  if (hipStreamWaitEvent(p->deframe_stream, p->job_done, 0) != hipSuccess) return -GRDMA_ERR_HIP;
+  hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(64), 0, p->deframe_stream, p->parser->d, p->dst, p->d_slices, p->delivered,
+                     p->d_ev, p->ev_cap, p->d_dres);
+  if (hipEventRecord(p->deframed, p->deframe_stream) != hipSuccess) return -GRDMA_ERR_HIP;
+  p->launched = true;
+  return 0;
+}
+
+// Wait for the last step and report it: out = {slices framed, frame overflow, events, deframe
+// overflow, slices parsed, h2 error}; events_out (may be NULL) receives up to cap events.
+int grdma_h2_pipe_sync(grdma_h2_pipe* p, uint64_t out[6], grdma_h2_event* events_out, uint64_t cap) {
+  if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
+  if (!p || !out) return -GRDMA_ERR_INVALID;
+  if (hipStreamSynchronize(p->frame_stream) != hipSuccess || hipStreamSynchronize(p->job_stream) != hipSuccess ||
+      hipStreamSynchronize(p->deframe_stream) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  grdma_h2_frame_result fr;
+  grdma_h2_deframe_result dr;
+  if (hipMemcpy(&fr, p->d_fres, sizeof(fr), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(&dr, p->d_dres, sizeof(dr), hipMemcpyDeviceToHost) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  out[0] = fr.nslices;
+  out[1] = fr.overflow;
+  out[2] = dr.nevents;
+  out[3] = dr.overflow;
+  out[4] = dr.slices_done;
+  out[5] = (uint64_t)dr.error;
+  const uint64_t m = std::min<uint64_t>(std::min<uint64_t>(dr.nevents, cap), p->ev_cap);
+  if (events_out && m && hipMemcpy(events_out, p->d_ev, sizeof(grdma_h2_event) * m, hipMemcpyDeviceToHost) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  return 0;
 }
 
 }  // extern "C"

@@ -456,8 +456,13 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
   p->flags = flags;
   p->stream = g_ctx.stream;
   p->arena_cap = 2 * ring_size + 4096;
-  bool ok = hipMalloc((void**)&p->d_conn, sizeof(grdma_conn)) == hipSuccess &&
-            hipMalloc((void**)&p->d_ring, ring_size) == hipSuccess &&
+  // the two things a REMOTE writer touches: the ring and the connection block (status report)
+  const bool fine = (flags & GRDMA_RING_FINE_GRAINED) != 0;
+  auto remote_alloc = [&](void** ptr, size_t n) {
+    return fine ? hipExtMallocWithFlags(ptr, n, hipDeviceMallocFinegrained) : hipMalloc(ptr, n);
+  };
+  bool ok = remote_alloc((void**)&p->d_conn, sizeof(grdma_conn)) == hipSuccess &&
+            remote_alloc((void**)&p->d_ring, ring_size) == hipSuccess &&
             hipMalloc((void**)&p->d_staging, ring_size / 2 + 64) == hipSuccess &&
             hipMalloc((void**)&p->d_txplan, sizeof(grdma_plan)) == hipSuccess &&
             hipMalloc((void**)&p->d_wireplan, sizeof(grdma_plan)) == hipSuccess &&
@@ -1042,6 +1047,16 @@ int grdma_pair_last_wrs(grdma_pair* p, uint64_t out[2][2]) {
 }
 
 void* grdma_pair_ring_device_ptr(grdma_pair* p) { return p ? p->d_ring : nullptr; }
+
+int grdma_pair_export_ring_dmabuf(grdma_pair* p) {
+  if (int rc = require_ctx()) return rc;
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  int fd = -1;
+  const hipError_t e = hipMemGetHandleForAddressRange(&fd, (hipDeviceptr_t)p->d_ring, p->ring_size,
+                                                      hipMemRangeHandleTypeDmaBufFd, 0);
+  if (e != hipSuccess || fd < 0) return fail(GRDMA_ERR_HIP, "dma-buf export of the ring failed: %s", hipGetErrorString(e));
+  return fd;
+}
 void* grdma_pair_arena_device_ptr(grdma_pair* p) {
   return p ? (p->latency ? p->h_arena : p->d_arena) : nullptr;
 }
@@ -1908,6 +1923,21 @@ int grdma_stream_job_launch(grdma_stream_job* j) {
   if (!j->exec || j->exec_rounds != j->rounds || j->exec_pipeline != j->pipeline)
     return fail(GRDMA_ERR_INVALID, "run the job once in GRDMA_RUN_GRAPH mode before launching it");
   HIP_TRY(hipGraphLaunch(j->exec, j->stream));
+  return 0;
+}
+
+// What the HTTP/2 pipe (grdma_h2.hip) needs from a job: the device tables of one link and the
+// stream the job's launches go to.
+extern "C" __attribute__((visibility("hidden"))) int grdma_job_link_view(grdma_stream_job* j, uint32_t link, grdma_sge** d_sges,
+                                                                         uint64_t* count, grdma_slice_out** d_slices,
+                                                                         uint8_t** dst, hipStream_t* stream) {
+  if (!j || link >= j->links.size()) return -1;
+  grdma_job_link& l = j->links[link];
+  *d_sges = l.d_sges;
+  *count = l.count;
+  *d_slices = l.d_slices;
+  *dst = l.dst;
+  *stream = j->stream;
   return 0;
 }
 

@@ -103,3 +103,44 @@ class Parser:
         if self.h:
             self.lib.grdma_h2_parser_destroy(self.h)
             self.h = None
+
+
+class Pipe:
+    """frame -> streaming job -> deframe as one enqueued device pipeline (grdma_h2_pipe).
+    msgs: list of (payload device ptr, len, stream_id, flags); the job must have been run once."""
+
+    def __init__(self, job, msgs, parser, delivered_slices, events_cap, link=0, max_frame=16384):
+        self.lib = _bind()
+        lib = self.lib
+        lib.grdma_h2_pipe_create.restype = C.c_void_p
+        lib.grdma_h2_pipe_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(H2Msg), u64, C.c_uint32, C.c_void_p, u64, u64]
+        lib.grdma_h2_pipe_enqueue.argtypes = [C.c_void_p, C.c_int]
+        lib.grdma_h2_pipe_sync.argtypes = [C.c_void_p, C.POINTER(u64), C.POINTER(H2Event), u64]
+        lib.grdma_h2_pipe_destroy.argtypes = [C.c_void_p]
+        arr = (H2Msg * len(msgs))()
+        for i, (p, n, sid, fl) in enumerate(msgs):
+            arr[i].payload, arr[i].len, arr[i].stream_id, arr[i].flags = p, n, sid, fl
+        self.events_cap = events_cap
+        self.delivered = delivered_slices
+        self.parser = parser  # (kept alive)
+        self.h = lib.grdma_h2_pipe_create(job.h, link, arr, len(msgs), max_frame, parser.h, delivered_slices, events_cap)
+        if not self.h:
+            raise GrdmaError("h2 pipe allocation failed")
+
+    def enqueue(self, engine=False):
+        check(self.lib.grdma_h2_pipe_enqueue(self.h, 1 if engine else 0))
+
+    def sync(self, want_events=False):
+        """-> dict(framed, frame_overflow, events, deframe_overflow, parsed, h2_error[, event list])"""
+        out = (u64 * 6)()
+        ev = (H2Event * self.events_cap)() if want_events else None
+        check(self.lib.grdma_h2_pipe_sync(self.h, out, ev, self.events_cap if want_events else 0))
+        r = dict(zip(("framed", "frame_overflow", "events", "deframe_overflow", "parsed", "h2_error"), [int(x) for x in out]))
+        if want_events:
+            r["event_list"] = [(e.kind, e.a, e.b, e.c, e.d, e.slice) for e in ev[:min(r["events"], self.events_cap)]]
+        return r
+
+    def close(self):
+        if self.h:
+            self.lib.grdma_h2_pipe_destroy(self.h)
+            self.h = None

@@ -93,7 +93,13 @@ enum grdma_flags {
   GRDMA_MEM_HOST = 1,     /* pageable host memory: stage through the bounce buffer */
   GRDMA_WIRE_STAGED = 0,  /* records are built in the staging buffer, then written
                              to the peer ring by <=2 wire writes (what a NIC needs) */
-  GRDMA_WIRE_DIRECT = 2   /* loop-back / xGMI peer: encode straight into the ring  */
+  GRDMA_WIRE_DIRECT = 2,  /* loop-back / xGMI peer: encode straight into the ring  */
+  GRDMA_RING_FINE_GRAINED = 4  /* allocate the ring (and the connection block holding the 16-byte
+                             status report) as fine-grained device memory
+                             (hipExtMallocWithFlags, hipDeviceMallocFinegrained): stores are
+                             write-through and visible to a peer device / process / NIC once
+                             acknowledged, with no cache maintenance at kernel boundaries --
+                             what a ring registered for remote writes needs */
 };
 
 /* PairPollable() + Init(): allocates the HBM ring (ring_size bytes, power of
@@ -215,6 +221,11 @@ int grdma_endpoint_write_abort(grdma_pair* p);
  * last attempt found no complete record (the endpoint re-arms notify_on_read). */
 int64_t grdma_endpoint_read(grdma_pair* p, uint64_t max_reads, grdma_read_slice* slices,
                             uint64_t slices_cap, int* would_block);
+/* Export the ring as a dma-buf file descriptor (hipMemGetHandleForAddressRange,
+ * hipMemRangeHandleTypeDmaBufFd): what ibv_reg_dmabuf_mr() takes to register the HBM ring with an
+ * RDMA NIC -- the place of ibv_reg_mr() in the reference (rdma_utils.h:108-160, pair.cc:107-119).
+ * Returns the fd (owned by the caller: close() it) or < 0. */
+int grdma_pair_export_ring_dmabuf(grdma_pair* p);
 void* grdma_pair_arena_device_ptr(grdma_pair* p);
 uint64_t grdma_pair_arena_size(grdma_pair* p);
 int grdma_pair_arena_copy_out(grdma_pair* p, uint64_t off, void* host_dst, uint64_t len);
@@ -393,6 +404,23 @@ double grdma_h2_last_kernel_us(void);
  * Returns the number of events; *h2_error = connection error, if any. */
 int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_read_slice* slices,
                          uint64_t n, grdma_h2_event* events_out, uint64_t cap, int* h2_error);
+
+/* HTTP/2 inside the device pipeline: per step, k_h2_frame rebuilds the slice list of the job's
+ * link from the message table (grpc_chttp2_encode_data, frame_data.cc:64-90), the streaming job
+ * carries it through the connection, and k_h2_deframe parses the slices the job delivered
+ * (grpc_chttp2_perform_read + grpc_deframe_unprocessed_incoming_frames) -- three stages on three
+ * streams ordered by events, nothing returns to the host in between.  The job must have been run
+ * once (graph captured / engine prepared); delivered_slices is what that run delivered.  Two pipes
+ * over two jobs of one connection may alternate: framing and deframing then run beside the other
+ * job's step.  schedule: 0 = the job's graph, 1 = the link engine. */
+typedef struct grdma_h2_pipe grdma_h2_pipe;
+grdma_h2_pipe* grdma_h2_pipe_create(grdma_stream_job* job, uint32_t link, const grdma_h2_msg* msgs, uint64_t nmsgs,
+                                    uint32_t max_frame, grdma_h2_parser* parser, uint64_t delivered_slices,
+                                    uint64_t events_cap);
+int grdma_h2_pipe_enqueue(grdma_h2_pipe* p, int schedule);
+/* out = {slices framed, frame overflow, events, deframe overflow, slices parsed, h2 error} */
+int grdma_h2_pipe_sync(grdma_h2_pipe* p, uint64_t out[6], grdma_h2_event* events_out, uint64_t cap);
+void grdma_h2_pipe_destroy(grdma_h2_pipe* p);
 
 /* ---- device helpers for callers that keep payloads in HBM ---------------------- */
 void* grdma_device_alloc(uint64_t bytes);

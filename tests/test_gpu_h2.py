@@ -278,3 +278,122 @@ def test_stream_map_rules_match_the_oracle(gpu):
     buf = gpu.DeviceBuffer(data=d + bytes(64))
     assert pg.deframe(buf.ptr, [(0, len(d))])[0] == 9
     pg.close()
+
+
+@pytest.mark.parametrize("gaps", [False, True], ids=["aligned", "unaligned"])
+def test_deframe_streaming_shape_bulk_step(gpu, gaps):
+    """The steady state of a client-streaming call -- per DATA frame a 9-byte header slice and
+    one payload slice (what chttp2 hands the endpoint, frame_data.cc:64-90) -- goes through the
+    deframer's bulk step (32 frames per look-ahead window, verified with a ballot).  Message
+    sizes are chosen so that messages end exactly on a frame boundary, inside a frame that also
+    starts the next message, after a single frame, and in a window's last lane; END_STREAM closes
+    the call.  Events equal the oracle's one for one."""
+    rng = random.Random(5)
+    sizes = [1 << 20, 16384 * 3 - 5, 40000, 16384 - 5, 7, 16384 * 70 + 123, 1, 300000]
+    slices = []
+    for i, n in enumerate(sizes):
+        msg = bytes((j * 13 + i) % 251 for j in range(n))
+        body = grpc_msg(msg)
+        # frames exactly as grpc_chttp2_encode_data cuts them: 9-byte header + <= 16384 payload
+        off = 0
+        while off < len(body):
+            k = min(16384, len(body) - off)
+            last = i == len(sizes) - 1 and off + k == len(body)
+            slices.append(k.to_bytes(3, "big") + bytes([0, 1 if last else 0]) + (1).to_bytes(4, "big"))
+            slices.append(body[off:off + k])
+            off += k
+    pre = [PREFACE + frame(4, 0, 0), frame(1, 4, 1, b"\x82")]
+    chunks = pre + slices
+    rc_o, ev_o = oracle_events(chunks, True)
+    rc_g, ev_g = gpu_events(gpu, chunks, True, gap_rng=rng if gaps else None)
+    assert rc_o == 0 and rc_g == 0
+    assert len(ev_g) == len(ev_o)
+    assert ev_g == ev_o
+    # and the same stream with some payload slices cut in two (the bulk step must stop there)
+    cut = list(pre)
+    for j, s_ in enumerate(slices):
+        if len(s_) > 100 and j % 14 == 5:
+            cut += [s_[:77], s_[77:]]
+        else:
+            cut.append(s_)
+    rc_o, ev_o = oracle_events(cut, True)
+    rc_g, ev_g = gpu_events(gpu, cut, True, gap_rng=rng if gaps else None)
+    assert rc_o == 0 and rc_g == 0 and ev_g == ev_o
+    # the shape on the RECEIVING side: the endpoint sizes a read to the 9-byte header record,
+    # max(256, 9) (rdma_bp_posix.cc:308), so a slice holds the header and the first 247 payload
+    # bytes and the next one the rest of the frame
+    rx = list(pre)
+    for h_, p_ in zip(slices[0::2], slices[1::2]):
+        if len(p_) > 247:
+            rx += [h_ + p_[:247], p_[247:]]
+        else:
+            rx += [h_, p_]
+    rc_o, ev_o = oracle_events(rx, True)
+    rc_g, ev_g = gpu_events(gpu, rx, True, gap_rng=rng if gaps else None)
+    assert rc_o == 0 and rc_g == 0 and ev_g == ev_o
+
+
+@pytest.mark.parametrize("engine", [False, True], ids=["graph", "engine"])
+def test_h2_pipe_frame_job_deframe_matches_the_oracle(gpu, engine):
+    """frame -> connection -> deframe as ONE enqueued device pipeline (grdma_h2_pipe): the framing
+    kernel writes the job's slice list, the job delivers it through a 256 KiB ring, the deframing
+    kernel parses the delivered slices.  Three steps back to back; the events of the last one equal
+    the oracle's for the same delivered slices (the parser state carries over between steps)."""
+    g = gpu
+    from grpc_rdma_amd import h2 as h2host, h2dev, stream as gs
+    sizes = [70000, 1, 16379, 200000, 16384 * 2 - 5, 5000]
+    bufs = [g.DeviceBuffer(data=bytes((j * 7 + i) % 251 for j in range(n))) for i, n in enumerate(sizes)]
+    msgs = [(b.ptr, n, 1, 0) for b, n in zip(bufs, sizes)]
+    # the host mirror of the framing lays out the same slice list (count and lengths)
+    lens = []
+    for n in sizes:
+        lens += [len(it[1]) if it[0] == "inl" else it[1][1] for it in h2host.frame_message(n, 1, 16384)]
+    scratch = g.DeviceBuffer(nbytes=max(lens) + 64)
+    sge = [(scratch.ptr, n) for n in lens]          # placeholders: k_h2_frame overwrites the table
+    R = 1 << 18
+    tx, rx = g.Pair(R, 30), g.Pair(R, 30)
+    g.connect_pairs(tx, rx)
+    N = sum(lens)
+    scap = 2 * len(lens) + 64 + N // 256
+    dst_cap = N + 16 * scap + 4096
+    dst = g.DeviceBuffer(nbytes=dst_cap)
+    job = gs.StreamJob(tx, rx, sge, dst.ptr, dst_cap, scap, 64)
+    if engine:
+        r = job.run(gs.RUN_ENGINE)
+    else:
+        r = job.run(gs.RUN_EAGER)
+        job.set_rounds(int(max(r.tx_rounds, r.rx_rounds)))
+        r = job.run(gs.RUN_GRAPH)
+    assert r.done and r.bytes_delivered == N
+    delivered = job.delivered_slices(0)
+    parser = h2dev.Parser(False)
+    assert parser.open_streams([1]) == 0
+    pipe = h2dev.Pipe(job, msgs, parser, len(delivered), 4 * len(lens) + 256)
+    po = pyorc.H2Parser(expect_client_prefix=False)
+    assert po.open_stream(1) == 0
+    for step in range(3):
+        pipe.enqueue(engine)
+        res = pipe.sync(want_events=True)
+        assert res["h2_error"] == 0 and res["framed"] == len(lens) and res["parsed"] == len(delivered)
+        ds = job.delivered_slices(0)
+        got = dst.read(dst_cap)
+        ev_o = []
+        for i, (o, n) in enumerate(ds):
+            rc, ev = po.feed(got[o:o + n])
+            assert rc == 0
+            ev_o += [(k, a, b, c, d, i) for k, a, b, c, d in ev]
+        assert res["event_list"] == ev_o, "step %d" % step
+        # the bytes are the framed messages themselves
+        stream = b"".join(got[o:o + n] for o, n in ds)
+        exp = b"".join(frame(0, 0, 1, b"")[:0] for _ in ())  # (built below)
+        exp = bytearray()
+        for i, n in enumerate(sizes):
+            body = grpc_msg(bytes((j * 7 + i) % 251 for j in range(n)))
+            for off in range(0, len(body), 16384):
+                exp += frame(0, 0, 1, body[off:off + 16384])
+        assert stream == bytes(exp)
+    pipe.close()
+    job.close()
+    parser.close()
+    tx.close()
+    rx.close()

@@ -36,7 +36,7 @@ def check_state(a, b, o):
         assert sb[k] == ob[k], ("side1", k, sb, ob)
 
 
-@pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
+@pytest.mark.parametrize("flags", [0, 2, 4, 6], ids=["staged", "direct", "staged-finegrained", "direct-finegrained"])
 @pytest.mark.parametrize("seed", range(6))
 def test_random_ops_match_oracle(gpu, seed, flags):
     g = gpu
@@ -429,3 +429,25 @@ def test_express_drain_matches_oracle(gpu, sizes):
     if len(sizes) <= 2 and sum(sizes) <= 128:
         assert lib.grdma_express_drains() - before >= 60, "the express path was not exercised"
     a.close(); b.close(); o.close()
+
+
+def test_ring_exports_as_dmabuf(gpu):
+    """The HBM ring exported as a dma-buf fd (what ibv_reg_dmabuf_mr takes, where the reference
+    registers host memory with ibv_reg_mr, pair.cc:107-119): a valid, closable descriptor; two
+    exports give two descriptors."""
+    import os
+    g = gpu
+    lib = g.load()
+    a = g.Pair(1 << 20, 30, 4)
+    fd = lib.grdma_pair_export_ring_dmabuf(a.h)
+    if fd < 0:
+        msg = lib.grdma_last_error().decode()
+        a.close()
+        pytest.skip("dma-buf export not available on this kernel / driver: " + msg)
+    fd2 = lib.grdma_pair_export_ring_dmabuf(a.h)
+    assert fd >= 3 and fd2 >= 3 and fd2 != fd
+    st = os.fstat(fd)
+    assert st.st_size in (0, 1 << 20) or st.st_size >= (1 << 20)
+    os.close(fd)
+    os.close(fd2)
+    a.close()

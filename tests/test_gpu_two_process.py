@@ -17,15 +17,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PEER = os.path.join(ROOT, "tests", "two_proc_peer.py")
 
 
-def run_pair(ring_kib, num_bytes, write_size, slice_size, devs=(0, 0)):
+def run_pair(ring_kib, num_bytes, write_size, slice_size, devs=(0, 0), pair_flags=0):
     a, b = socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM)
     procs = []
+    env = dict(os.environ, GRDMA_TEST_PAIR_FLAGS=str(pair_flags))
     for role, sock, dev in (("server", a, devs[0]), ("client", b, devs[1])):
         os.set_inheritable(sock.fileno(), True)
         procs.append(subprocess.Popen(
             [sys.executable, PEER, role, str(sock.fileno()), str(dev), str(ring_kib), str(num_bytes),
              str(write_size), str(slice_size)],
-            pass_fds=[sock.fileno()], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+            pass_fds=[sock.fileno()], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     a.close()
     b.close()
     outs = []
@@ -50,6 +51,14 @@ def run_pair(ring_kib, num_bytes, write_size, slice_size, devs=(0, 0)):
 ])
 def test_echo_between_two_processes(gpu, ring_kib, num_bytes, write_size, slice_size):
     outs = run_pair(ring_kib, num_bytes, write_size, slice_size)
+    assert "ok server" in outs[0][1] and "ok client" in outs[1][1]
+
+
+def test_echo_between_two_processes_fine_grained_rings(gpu):
+    """GRDMA_RING_FINE_GRAINED: ring and status block are fine-grained device memory -- what a
+    remote writer (peer process, peer GPU, NIC) needs to see acknowledged stores without cache
+    maintenance.  Same echo, same bytes."""
+    outs = run_pair(256, 600000, 100000, 8192, pair_flags=4)
     assert "ok server" in outs[0][1] and "ok client" in outs[1][1]
 
 

@@ -44,7 +44,7 @@ class Writer:
 def main():
     role, fd, dev, ring_kib, num_bytes, write_size, slice_size = sys.argv[1], *map(int, sys.argv[2:8])
     g.init(dev)
-    pair = g.Pair(ring_kib * 1024, 30)
+    pair = g.Pair(ring_kib * 1024, 30, int(os.environ.get("GRDMA_TEST_PAIR_FLAGS", "0")))
     pair.bootstrap_fd(fd)
     assert pair.get_status() == 2
     w = Writer(pair)

@@ -25,6 +25,7 @@ for m in range(8):
         table.append((len(arena),L)); arena+=one[off0:off0+L]+bytes((-L)%16); off0+=L
 ab=g.DeviceBuffer(data=bytes(arena)+bytes(64))
 p=h2dev.Parser(False)
+assert p.open_streams([1]) == 0   # (a client parser: the call was started on stream 1)
 for it in range(3):
     t0=time.perf_counter(); err,ev=p.deframe(ab.ptr,table,cap=len(table)*4+64); t1=time.perf_counter()
     print("deframe: %d slices -> %d events err=%d, %.1f us, kernel %.1f us"%(len(table),len(ev),err,(t1-t0)*1e6, kus()))
