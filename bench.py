@@ -494,8 +494,13 @@ def main():
         elapsed = grp.max(time.perf_counter() - t0)
         barrier()
         ok = True
+        stage_us = {}
         for p_ in pipes:  # what the last step of each pipe produced
             r = p_.sync(want_events=True)
+            stage_us = {"frame_us": r["frame_us"], "deframe_us": r["deframe_us"], "delivered_slices": p_.delivered,
+                        "events": r["events"], "bulk_steps": r["bulk_steps"], "bulk_frames": r["bulk_frames"],
+                        "deframe_ticks": {"wait_for_windows": r["t_wait"], "bulk_steps": r["t_bulk"],
+                                          "bytewise_path": r["t_serial"], "total": r["t_total"]}}
             evs = r["event_list"]
             ok = ok and r["h2_error"] == 0 and not r["frame_overflow"] and not r["deframe_overflow"] and \
                 r["framed"] == len(w.lens) and r["parsed"] == p_.delivered and \
@@ -508,7 +513,7 @@ def main():
         tx.close(); rx.close()
         for d_ in dsts:
             d_.free()
-        return {"elapsed": elapsed, "verified": ok}
+        return {"elapsed": elapsed, "verified": ok, "stages": stage_us}
 
     schedule = "pipelined" if args.pipeline else "sequential"
     head = None
@@ -640,6 +645,7 @@ def main():
             hh = measure_with_h2(args.ring_kb, args.steps, max(2, args.warmup), engine=(args.schedule == "engine"))
             out["value_with_h2"] = round(wl.user_bytes * args.steps * world / hh["elapsed"] / (1 << 30), 3)
             out["with_h2_verified"] = hh["verified"]
+            out["with_h2_stages"] = hh["stages"]
         except Exception as e:
             out["with_h2_error"] = str(e)[:200]
     if not args.no_extra_legs:

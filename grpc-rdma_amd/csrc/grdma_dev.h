@@ -173,13 +173,16 @@ struct grdma_plan {
   uint64_t bytes;
   uint64_t tag_base;   // window for the record tags of GRDMA_SEG_TAG_* segments
   uint64_t tag_mask;
+  struct grdma_seg segs[GRDMA_MAX_SEGS];
+  uint32_t tile_prefix[GRDMA_MAX_SEGS + 1];
   // k_rx_apply arrival counter (the last workgroup commits).  It lives in the plan -- always
   // device memory, one per drain in flight -- and not in the result block, which is pinned HOST
   // memory for a stand-alone pair: a thousand workgroups counting in over PCIe took a millisecond.
+  // On a line of its own: every workgroup reads the plan header when it starts, and a counter in
+  // that line made the early finishers' atomics fight the late starters' loads (2.4x the kernel time).
+  uint32_t pad_line0[31];
   uint32_t blocks_done;
-  uint32_t pad_bd;
-  struct grdma_seg segs[GRDMA_MAX_SEGS];
-  uint32_t tile_prefix[GRDMA_MAX_SEGS + 1];
+  uint32_t pad_line1[31];
 };
 
 #endif  // GRDMA_DEV_H

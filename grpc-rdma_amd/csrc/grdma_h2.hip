@@ -83,6 +83,8 @@ struct grdma_h2_deframe_result {
   uint64_t overflow;
   uint64_t slices_done;
   int64_t error;
+  uint64_t bulk_steps, bulk_frames;  // how much of the call went through the bulk step
+  uint64_t t_wait, t_bulk, t_total, t_serial;  // profiling aid (s_memtime ticks): waiting for staged windows, inside bulk steps, whole parse, byte-wise path
 };
 
 namespace {
@@ -306,19 +308,28 @@ __device__ void tab_remove(grdma_h2_stream_dev* tab, uint32_t mask, uint32_t i) 
   tab[i].stream_id = 0;
 }
 
-// Register cache of slices [cbase, cbase + 64): lane i holds the descriptor and the first
-// 32 bytes of slice cbase + i.  Filling a window costs two DEPENDENT memory round trips
-// (descriptor, then the bytes it points to) -- more than it takes to parse the window -- so the
-// cache runs two windows ahead: n1 = the next window, descriptors arrived and bytes requested one
-// window ago; n2 = the window after that, descriptors requested.  A switch to the next window
-// moves n1 in, asks for n1's bytes (its descriptors have long arrived) and for the following
-// window's descriptors, and parsing goes on while those are in flight.
-// Plain functions over a plain struct (no capturing lambdas): everything stays in registers.
-struct h2_slice_cache {
-  uint64_t cbase, c0, c1, c2, c3, c_off, c_len;
-  uint64_t n1_base, n1_0, n1_1, n1_2, n1_3, n1_off, n1_len;
-  uint64_t n2_base, n2_off, n2_len;
+// Look-ahead ring in LDS.  Parsing a slice needs its descriptor and its first bytes -- two
+// DEPENDENT memory round trips, far more than the few hundred cycles the parse takes.  So the
+// kernel is a small pipeline: seven helper waves run ahead of the parsing wave and stage, window
+// by window (64 slices, one per lane), {offset, length, first 32 bytes} of every slice in an LDS
+// ring of sixteen windows; the parser finds whatever it looks at in LDS.  Hand-off per window:
+// seq[slot] = window + 1 (release / acquire at workgroup scope); `consumed` (the window the parser
+// is in) lets the helpers reuse slots.
+#define H2_RING 16
+struct h2_win_ent {
+  uint64_t off, len, c0, c1, c2, c3;
 };
+struct h2_lds {
+  h2_win_ent win[H2_RING][64];
+  uint32_t seq[H2_RING];
+  uint32_t consumed;
+  uint32_t stop;
+};
+// File-scope LDS object, always named directly: an access through a generic pointer is a FLAT
+// load, and a flat load's result can only be waited for with vmcnt(0) -- behind every event
+// store still in flight, a memory round trip per look at the ring (measured: 3.7 us per slice
+// of the byte-wise path).
+__shared__ h2_lds g_h2;
 
 __device__ __forceinline__ uint64_t h2_keep(uint64_t v, uint64_t first, uint64_t n) {
   // bytes at and beyond the slice end read as zero
@@ -327,103 +338,115 @@ __device__ __forceinline__ uint64_t h2_keep(uint64_t v, uint64_t first, uint64_t
   return v & ((1ull << ((n - first) * 8)) - 1);
 }
 
-__device__ __forceinline__ void h2_load_desc(uint64_t base, const grdma_slice_out* slices, uint64_t nslices, int lane,
-                                             uint64_t& off, uint64_t& len) {
-  // (an unconditional load from a clamped index: a load under a branch is followed by a full
-  //  s_waitcnt, which would turn the look-ahead back into one round trip per load)
-  const uint64_t mine = base + (uint64_t)lane;
-  const uint64_t idx = mine < nslices ? mine : nslices - 1;  // nslices >= 1 whenever the kernel parses anything
-  const u64x2 d = *reinterpret_cast<const u64x2*>(&slices[idx]);
-  const bool have = mine < nslices;
-  off = have ? d.x : 0;
-  len = have ? d.y : 0;
-}
-
-// the first 32 bytes of the slice {off, n} (zero beyond its end)
-__device__ __forceinline__ void h2_load_bytes(const uint8_t* arena, uint64_t off, uint64_t n, uint64_t& r0, uint64_t& r1,
-                                              uint64_t& r2, uint64_t& r3) {
-  const uint8_t* p = arena + off;
-  // the aligned 16-byte blocks that hold the first 32 bytes of the slice (two when the
-  // slice starts on a 16-byte boundary, three otherwise).  Nothing outside the blocks the
-  // slice touches is read: a block beyond them is replaced by block 0 (an empty slice reads
-  // the arena's first block) -- the three loads stay unconditional and go out together.
-  const uint64_t sh = (uint64_t)p & 15;
-  const u64x2* q = n ? reinterpret_cast<const u64x2*>((uint64_t)p & ~15ull)
-                     : reinterpret_cast<const u64x2*>((uint64_t)arena & ~15ull);
-  const uint64_t need = n ? (n < 32 ? n : 32) + sh : 0;
-  const u64x2 v0 = q[0];
-  const u64x2 v1 = q[need > 16 ? 1 : 0];
-  const u64x2 v2 = q[need > 32 ? 2 : 0];
-  // 48-byte window w0..w5, shifted right by sh bytes
-  uint64_t w0 = v0.x, w1 = v0.y, w2 = v1.x, w3 = v1.y, w4 = v2.x, w5 = v2.y;
-  if (sh & 8) { w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; }
-  const unsigned bs = (unsigned)(sh & 7) * 8;
-  uint64_t o0 = w0, o1 = w1, o2 = w2, o3 = w3;
-  if (bs) {
-    o0 = (w0 >> bs) | (w1 << (64 - bs));
-    o1 = (w1 >> bs) | (w2 << (64 - bs));
-    o2 = (w2 >> bs) | (w3 << (64 - bs));
-    o3 = (w3 >> bs) | (w4 << (64 - bs));
+// A helper wave: stages windows h, h + nh, h + 2 nh, ... of the slice list.
+__device__ void h2_stage_windows(uint32_t h, uint32_t nh, const uint8_t* arena,
+                                 const grdma_slice_out* slices, uint64_t nslices, int lane) {
+  h2_lds* const L = &g_h2;
+  for (uint64_t k = h; k * 64 < nslices; k += nh) {
+    // the slot is free once the parser has left window k - H2_RING
+    for (uint32_t spins = 0;; spins++) {
+      const uint32_t cons = __hip_atomic_load(&L->consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t stop = __hip_atomic_load(&L->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (stop) return;
+      if (k < (uint64_t)cons + H2_RING) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const uint64_t mine = k * 64 + (uint64_t)lane;
+    const bool have = mine < nslices;
+    // (unconditional loads from clamped addresses: a load under a branch is followed by a full wait)
+    const u64x2 d = *reinterpret_cast<const u64x2*>(&slices[have ? mine : nslices - 1]);
+    const uint64_t off = have ? d.x : 0, n = have ? d.y : 0;
+    // the aligned 16-byte blocks that hold the first 32 bytes of the slice (two when the slice
+    // starts on a 16-byte boundary, three otherwise).  Nothing outside the blocks the slice
+    // touches is read: a block beyond them is replaced by block 0 (an empty slice reads the
+    // arena's first block).
+    const uint8_t* p = arena + off;
+    const uint64_t sh = n ? (uint64_t)p & 15 : 0;
+    const u64x2* q = n ? reinterpret_cast<const u64x2*>((uint64_t)p & ~15ull)
+                       : reinterpret_cast<const u64x2*>((uint64_t)arena & ~15ull);
+    const uint64_t need = n ? (n < 32 ? n : 32) + sh : 0;
+    const u64x2 v0 = q[0];
+    const u64x2 v1 = q[need > 16 ? 1 : 0];
+    const u64x2 v2 = q[need > 32 ? 2 : 0];
+    // 48-byte window w0..w5, shifted right by sh bytes
+    uint64_t w0 = v0.x, w1 = v0.y, w2 = v1.x, w3 = v1.y, w4 = v2.x, w5 = v2.y;
+    if (sh & 8) { w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; }
+    const unsigned bs = (unsigned)(sh & 7) * 8;
+    uint64_t o0 = w0, o1 = w1, o2 = w2, o3 = w3;
+    if (bs) {
+      o0 = (w0 >> bs) | (w1 << (64 - bs));
+      o1 = (w1 >> bs) | (w2 << (64 - bs));
+      o2 = (w2 >> bs) | (w3 << (64 - bs));
+      o3 = (w3 >> bs) | (w4 << (64 - bs));
+    }
+    h2_win_ent e;
+    e.off = off;
+    e.len = n;
+    e.c0 = h2_keep(o0, 0, n);
+    e.c1 = h2_keep(o1, 8, n);
+    e.c2 = h2_keep(o2, 16, n);
+    e.c3 = h2_keep(o3, 24, n);
+    L->win[k % H2_RING][lane] = e;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every lane's entry before the flag
+    if (lane == 0) __hip_atomic_store(&L->seq[k % H2_RING], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  r0 = h2_keep(o0, 0, n);
-  r1 = h2_keep(o1, 8, n);
-  r2 = h2_keep(o2, 16, n);
-  r3 = h2_keep(o3, 24, n);
 }
 
-__device__ __forceinline__ void h2_ensure(h2_slice_cache& C, uint64_t s, const uint8_t* arena,
-                                          const grdma_slice_out* slices, uint64_t nslices, int lane) {
-  if (s >= C.cbase && s < C.cbase + 64) return;
-  if (C.cbase != ~0ull && s >= C.n1_base && s < C.n1_base + 64) {
-    // the next window moves in; its successor's bytes and the descriptors of the one after are requested
-    C.cbase = C.n1_base;
-    C.c0 = C.n1_0; C.c1 = C.n1_1; C.c2 = C.n1_2; C.c3 = C.n1_3;
-    C.c_off = C.n1_off; C.c_len = C.n1_len;
-    C.n1_base = C.n2_base;
-    C.n1_off = C.n2_off;
-    C.n1_len = C.n2_len;
-    h2_load_bytes(arena, C.n1_off, C.n1_len, C.n1_0, C.n1_1, C.n1_2, C.n1_3);
-    C.n2_base = C.n1_base + 64;
-    h2_load_desc(C.n2_base, slices, nslices, lane, C.n2_off, C.n2_len);
-    return;
+// The parser's view: which windows it has seen arrive.
+struct h2_view {
+  uint64_t have_upto;  // windows [.., have_upto) are known to be staged (and not yet released)
+  uint64_t t_wait;     // profiling aid
+};
+
+// make sure the window of slice s is staged (wave-uniform spin)
+__device__ __forceinline__ void h2_need(h2_view& V, uint64_t s) {
+  const uint64_t k = s >> 6;
+  if (k < V.have_upto) return;
+  const uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (;;) {
+    const uint32_t q = __hip_atomic_load(&g_h2.seq[k % H2_RING], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (q == (uint32_t)(k + 1)) break;
+    __builtin_amdgcn_s_sleep(1);
   }
-  // cold start (or a jump): three windows of descriptors in one round trip, two of bytes in the next
-  C.cbase = s;
-  C.n1_base = s + 64;
-  C.n2_base = s + 128;
-  h2_load_desc(C.cbase, slices, nslices, lane, C.c_off, C.c_len);
-  h2_load_desc(C.n1_base, slices, nslices, lane, C.n1_off, C.n1_len);
-  h2_load_desc(C.n2_base, slices, nslices, lane, C.n2_off, C.n2_len);
-  h2_load_bytes(arena, C.c_off, C.c_len, C.c0, C.c1, C.c2, C.c3);
-  h2_load_bytes(arena, C.n1_off, C.n1_len, C.n1_0, C.n1_1, C.n1_2, C.n1_3);
+  V.t_wait += __builtin_amdgcn_s_memtime() - t0;
+  V.have_upto = k + 1;
+}
+__device__ __forceinline__ const h2_win_ent* h2_ent(h2_view&, uint64_t s) {
+  return &g_h2.win[(s >> 6) % H2_RING][s & 63];
 }
 
-__device__ __forceinline__ uint32_t h2_byte_at(h2_slice_cache& C, uint64_t s, uint64_t off,
-                                               const uint8_t* arena, const grdma_slice_out* slices,
-                                               uint64_t nslices, int lane) {
-  h2_ensure(C, s, arena, slices, nslices, lane);
-  const int src = (int)(s - C.cbase);
+__device__ __forceinline__ uint32_t h2_byte_at(h2_view& V, uint64_t s, uint64_t off, const uint8_t* arena) {
+  h2_need(V, s);
+  const h2_win_ent* e = h2_ent(V, s);
   if (off < 32) {
     const uint64_t q = off >> 3;
-    const uint64_t word = __shfl(q == 0 ? C.c0 : q == 1 ? C.c1 : q == 2 ? C.c2 : C.c3, src, 64);
+    const uint64_t word = q == 0 ? e->c0 : q == 1 ? e->c1 : q == 2 ? e->c2 : e->c3;
     return (uint32_t)((word >> ((off & 7) * 8)) & 0xFF);
   }
-  return arena[__shfl(C.c_off, src, 64) + off];
+  return arena[e->off + off];
 }
 
 // bytes [off, off + 8) of slice s as a little-endian word; needs off + 8 <= 32 (inside the
-// cached look-ahead).  Two shuffles instead of eight byte fetches.
-__device__ __forceinline__ uint64_t h2_bytes8(h2_slice_cache& C, uint64_t s, uint64_t off,
-                                              const uint8_t* arena, const grdma_slice_out* slices,
-                                              uint64_t nslices, int lane) {
-  h2_ensure(C, s, arena, slices, nslices, lane);
-  const int src = (int)(s - C.cbase);
+// staged look-ahead)
+__device__ __forceinline__ uint64_t h2_bytes8(h2_view& V, uint64_t s, uint64_t off) {
+  h2_need(V, s);
+  const h2_win_ent* e = h2_ent(V, s);
   const uint64_t q = off >> 3;
-  const uint64_t lo = __shfl(q == 0 ? C.c0 : q == 1 ? C.c1 : q == 2 ? C.c2 : C.c3, src, 64);
-  const uint64_t hi = __shfl(q == 0 ? C.c1 : q == 1 ? C.c2 : C.c3, src, 64);  // q == 3: unused
+  const uint64_t lo = q == 0 ? e->c0 : q == 1 ? e->c1 : q == 2 ? e->c2 : e->c3;
+  const uint64_t hi = q == 0 ? e->c1 : q == 1 ? e->c2 : e->c3;  // q == 3: unused
   const unsigned bs = (unsigned)(off & 7) * 8;
   return bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
 }
+
+// one event = three 8-byte stores (the array is 8-byte aligned, 24 bytes per event)
+__device__ __forceinline__ void h2_store_event(grdma_h2_event* at, uint32_t kind, uint32_t a, uint32_t b, uint32_t c,
+                                               uint32_t d, uint32_t sl) {
+  auto* w = (__attribute__((address_space(1))) uint64_t*)(uint64_t)at;
+  w[0] = (uint64_t)kind | ((uint64_t)a << 32);
+  w[1] = (uint64_t)b | ((uint64_t)c << 32);
+  w[2] = (uint64_t)d | ((uint64_t)sl << 32);
+}
+static_assert(sizeof(grdma_h2_event) == 24, "event layout");
 
 __device__ __forceinline__ void h2_push(grdma_h2_event* ev, uint64_t ev_cap, uint64_t& nev,
                                         uint64_t& overflow, int lane, uint32_t kind, uint32_t a,
@@ -435,9 +458,7 @@ __device__ __forceinline__ void h2_push(grdma_h2_event* ev, uint64_t ev_cap, uin
   if (lane == 0) {
     // (global address space: a generic store would also count against the LDS counter
     // and stall the next shuffle of the slice cache)
-    auto* e = (__attribute__((address_space(1))) grdma_h2_event*)(uint64_t)(ev + nev);
-    e->kind = kind; e->a = a; e->b = b; e->c = c; e->d = d;
-    e->slice = sl;
+    h2_store_event(ev + nev, kind, a, b, c, d, sl);
   }
   nev++;
 }
@@ -499,11 +520,26 @@ __device__ __forceinline__ uint32_t h2_mark_closed(grdma_h2_stream_dev* tab, uin
   return gone;
 }
 
-__global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, const uint8_t* arena,
-                                                   const grdma_slice_out* slices, uint64_t nslices,
-                                                   grdma_h2_event* ev, uint64_t ev_cap,
-                                                   grdma_h2_deframe_result* res) {
-  const int lane = threadIdx.x;
+#define H2_DEFRAME_THREADS 512
+__global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_parser_dev* gp, const uint8_t* arena,
+                                                                  const grdma_slice_out* slices, uint64_t nslices,
+                                                                  grdma_h2_event* ev, uint64_t ev_cap,
+                                                                  grdma_h2_deframe_result* res) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6;
+  if (threadIdx.x < H2_RING) g_h2.seq[threadIdx.x] = 0;
+  if (threadIdx.x == 0) g_h2.consumed = g_h2.stop = 0;
+  __syncthreads();  // (the only barrier: before the roles part ways)
+  if (wave != 0) {
+    h2_stage_windows(wave - 1, H2_DEFRAME_THREADS / 64 - 1, arena, slices, nslices, lane);
+    return;
+  }
+  __builtin_amdgcn_s_setprio(3);  // the one serial wave of the kernel: it gets the issue slots it asks for
+  h2_view V = {0, 0};
+  const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+  uint64_t t_bulk = 0, t_serial = 0;
+  uint32_t consumed_pub = 0;
+  uint64_t bulk_steps = 0, bulk_frames = 0;
   const grdma_h2_parser_dev P = *gp;  // uniform loads: the whole block sits in scalar registers
   uint64_t nev = 0, overflow = 0;
   static const char kPrefix[] = "PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n";  // internal.h:781
@@ -520,9 +556,8 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
   const bool is_server = P.is_server != 0;
   grdma_h2_stream_dev* const tab = P.tab;
   h2_cur_stream D = {-1, 0, 0, 0, 0, 0, 0, 0};
-  h2_slice_cache C = {~0ull, 0, 0, 0, 0, 0, 0, ~0ull, 0, 0, 0, 0, 0, 0, ~0ull, 0, 0};
 #define H2_PUSH(kind, a, b, c, d, sl) h2_push(ev, ev_cap, nev, overflow, lane, kind, a, b, c, d, sl)
-#define H2_BYTE(s_, off_) h2_byte_at(C, s_, off_, arena, slices, nslices, lane)
+#define H2_BYTE(s_, off_) h2_byte_at(V, s_, off_, arena)
   // what the payload parser does with the last piece of a frame (frame_data.cc:299-305,
   // hpack_parser.cc:1746-1782, frame_rst_stream.cc:99-119)
 #define H2_END_FRAME(sl)                                                                          \
@@ -551,7 +586,15 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
   uint64_t s = 0;
   int err = P.error;
   for (; s < nslices && !err && !overflow; s++) {
-    h2_ensure(C, s, arena, slices, nslices, lane);
+    if ((uint32_t)(s >> 6) != consumed_pub) {  // the parser left a window: its slot may be refilled
+      consumed_pub = (uint32_t)(s >> 6);
+      // Relaxed + a compiler barrier: LDS operations of one wave execute in order, so the reads of
+      // the window left behind are done when this store lands.  (A release store would also wait
+      // for every event store still in flight -- a memory round trip per window.)
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&g_h2.consumed, consumed_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    h2_need(V, s);
     // ---- bulk step: the streaming steady state, many frames at once ---------------------
     // Between a message's first and last frame every DATA frame of a stream spans exactly TWO
     // slices: on the sending side a 9-byte header slice and one payload slice
@@ -566,16 +609,25 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
     // automaton below would have produced for its frame.
     if (st == ST_FH0 && expect_cont == 0 && !is_first_frame && D.idx >= 0 && !D.read_closed && D.state == 5 &&
         D.fsz != 0) {
-      const int rel = lane - (int)(s - C.cbase);  // my slice is s + rel
-      const bool hdr_lane = rel >= 0 && (rel & 1) == 0;
-      const uint64_t b8 = C.c0;
+      const uint64_t tb0 = __builtin_amdgcn_s_memtime();
+      // lane i looks at slice s + i (the windows it needs: the current one and, when s is not
+      // window aligned, the next one -- staged, or beyond the end of the list)
+      const int rel = lane;
+      const uint64_t last_ix = s + 63 < nslices ? s + 63 : nslices - 1;
+      h2_need(V, last_ix);
+      const uint64_t my_ix = s + (uint64_t)lane < nslices ? s + (uint64_t)lane : nslices - 1;
+      const uint64_t nx_ix = my_ix + 1 < nslices ? my_ix + 1 : nslices - 1;
+      const h2_win_ent me = *h2_ent(V, my_ix);
+      const bool hdr_lane = (lane & 1) == 0 && s + (uint64_t)lane + 1 < nslices;
+      const uint64_t my_len = me.len;
+      const uint64_t b8 = me.c0;
       const uint32_t fs = (uint32_t)(((b8 & 0xFF) << 16) | (((b8 >> 8) & 0xFF) << 8) | ((b8 >> 16) & 0xFF));
       const uint32_t sd = (uint32_t)((((b8 >> 40) & 0x7F) << 24) | (((b8 >> 48) & 0xFF) << 16) |
-                                     (((b8 >> 56) & 0xFF) << 8) | (C.c1 & 0xFF));
-      const uint64_t next_len = __shfl(C.c_len, (lane + 1) & 63, 64);
-      const uint32_t p0 = (uint32_t)(C.c_len - 9);  // (only looked at when c_len >= 9)
+                                     (((b8 >> 56) & 0xFF) << 8) | (me.c1 & 0xFF));
+      const uint64_t next_len = h2_ent(V, nx_ix)->len;
+      const uint32_t p0 = (uint32_t)(my_len - 9);  // (only looked at when my_len >= 9)
       // type DATA, flags 0 (an END_STREAM frame closes the stream: left to the automaton)
-      const bool ok = hdr_lane && lane < 63 && C.c_len >= 9 && C.c_len < 9ull + fs && ((b8 >> 24) & 0xFFFF) == 0 &&
+      const bool ok = hdr_lane && my_len >= 9 && my_len < 9ull + fs && ((b8 >> 24) & 0xFFFF) == 0 &&
                       sd == D.id && fs <= max_frame && next_len == (uint64_t)fs - p0;
       const uint64_t bad = __ballot(hdr_lane && !ok);
       const int first_bad = bad ? __builtin_ctzll(bad) : 64;
@@ -598,20 +650,18 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
         const bool ends = total == D.fsz;
         if (nev + nevs + 1 <= ev_cap) {
           if (within) {
-            auto* e = (__attribute__((address_space(1))) grdma_h2_event*)(uint64_t)(ev + nev + epos - (p0 ? 5u : 3u));
+            grdma_h2_event* e = ev + nev + epos - (p0 ? 5u : 3u);
             const uint32_t sl = (uint32_t)(s + (uint64_t)rel);
-            e[0].kind = EV_FRAME; e[0].a = FT_DATA; e[0].b = 0; e[0].c = sd; e[0].d = fs; e[0].slice = sl;
+            h2_store_event(e, EV_FRAME, FT_DATA, 0, sd, fs, sl);
             if (p0) {
-              e[1].kind = EV_PAYLOAD; e[1].a = 9; e[1].b = p0; e[1].c = 0; e[1].d = 0; e[1].slice = sl;
-              e[2].kind = EV_MSG_BYTES; e[2].a = 9; e[2].b = p0; e[2].c = sd; e[2].d = 0; e[2].slice = sl;
+              h2_store_event(e + 1, EV_PAYLOAD, 9, p0, 0, 0, sl);
+              h2_store_event(e + 2, EV_MSG_BYTES, 9, p0, sd, 0, sl);
               e += 2;
             }
             const uint32_t p1 = fs - p0;
-            e[1].kind = EV_PAYLOAD; e[1].a = 0; e[1].b = p1; e[1].c = 1; e[1].d = 0; e[1].slice = sl + 1;
-            e[2].kind = EV_MSG_BYTES; e[2].a = 0; e[2].b = p1; e[2].c = sd; e[2].d = 0; e[2].slice = sl + 1;
-            if (ends && lane == last_lane) {
-              e[3].kind = EV_MSG_END; e[3].a = 0; e[3].b = 0; e[3].c = sd; e[3].d = 0; e[3].slice = sl + 1;
-            }
+            h2_store_event(e + 1, EV_PAYLOAD, 0, p1, 1, 0, sl + 1);
+            h2_store_event(e + 2, EV_MSG_BYTES, 0, p1, sd, 0, sl + 1);
+            if (ends && lane == last_lane) h2_store_event(e + 3, EV_MSG_END, 0, 0, sd, 0, sl + 1);
           }
           nev += nevs + (ends ? 1 : 0);
           D.fsz -= total;
@@ -623,12 +673,16 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
           sid = D.id;
           cur_parser = PARSER_DATA;
           received_last = 0;
+          bulk_steps++;
+          bulk_frames += (uint64_t)__builtin_popcountll(wmask);
+          t_bulk += __builtin_amdgcn_s_memtime() - tb0;
           s += 2ull * (uint64_t)__builtin_popcountll(wmask) - 1;  // (the loop adds the last one)
           continue;
         }
       }
     }
-    const uint64_t len = __shfl(C.c_len, (int)(s - C.cbase), 64);
+    const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+    const uint64_t len = h2_ent(V, s)->len;
     uint64_t cur = 0;
     while (cur < len && !err && !overflow) {
       if (st < ST_FH0) {  // client connection preface, parsing.cc:70-109
@@ -640,7 +694,7 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
         if (st == ST_FH0 && len - cur >= 9 && cur + 9 <= 32) {
           // the whole 9-byte frame header sits in the cached look-ahead: same fields as
           // the byte-wise FH_0..FH_8 walk below (parsing.cc:111-193), taken in one step
-          const uint64_t b8 = h2_bytes8(C, s, cur, arena, slices, nslices, lane);
+          const uint64_t b8 = h2_bytes8(V, s, cur);
           const uint32_t b9 = H2_BYTE(s, cur + 8);
           fsz = (uint32_t)(((b8 & 0xFF) << 16) | (((b8 >> 8) & 0xFF) << 8) | ((b8 >> 16) & 0xFF));
           ftype = (uint32_t)((b8 >> 24) & 0xFF);
@@ -740,9 +794,9 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
         const uint64_t end = cur + take;
         while (q < end && D.state != 6 && !overflow) {
           if (D.state == 0 && end - q >= 5 && q + 8 <= 32 &&
-              (h2_bytes8(C, s, q, arena, slices, nslices, lane) & 0xFF) <= 1) {
+              (h2_bytes8(V, s, q) & 0xFF) <= 1) {
             // the 5-byte message header in one step (frame_data.cc:112-176)
-            const uint64_t b8 = h2_bytes8(C, s, q, arena, slices, nslices, lane);
+            const uint64_t b8 = h2_bytes8(V, s, q);
             D.comp = (int32_t)(b8 & 0xFF);
             D.fsz = (uint32_t)((((b8 >> 8) & 0xFF) << 24) | (((b8 >> 16) & 0xFF) << 16) |
                                (((b8 >> 24) & 0xFF) << 8) | ((b8 >> 32) & 0xFF));
@@ -798,11 +852,13 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
         st = ST_FH0;
       }
     }
+    t_serial += __builtin_amdgcn_s_memtime() - ts0;
     if (err || overflow) break;
   }
 #undef H2_PUSH
 #undef H2_BYTE
 #undef H2_END_FRAME
+  if (lane == 0) __hip_atomic_store(&g_h2.stop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // helpers leave
   h2_flush_stream(tab, D, lane);
   if (lane == 0) {
     gp->state = st;
@@ -823,6 +879,12 @@ __global__ __launch_bounds__(64) void k_h2_deframe(grdma_h2_parser_dev* gp, cons
     res->overflow = overflow;
     res->slices_done = s;
     res->error = err;
+    res->bulk_steps = bulk_steps;
+    res->bulk_frames = bulk_frames;
+    res->t_wait = V.t_wait;
+    res->t_bulk = t_bulk;
+    res->t_total = __builtin_amdgcn_s_memtime() - t_begin;
+    res->t_serial = t_serial;
   }
 }
 
@@ -1054,7 +1116,7 @@ int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_re
   if (n && hipMemcpyAsync(p->d_sl, slices, sizeof(grdma_slice_out) * n, hipMemcpyHostToDevice, st) != hipSuccess)
     return -GRDMA_ERR_HIP;
   hipEventRecord(hc->e0, st);
-  hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(64), 0, st, p->d, static_cast<const uint8_t*>(d_arena),
+  hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(H2_DEFRAME_THREADS), 0, st, p->d, static_cast<const uint8_t*>(d_arena),
                      p->d_sl, n, p->d_ev, cap, p->d_res);
   hipEventRecord(hc->e1, st);
   if (hipMemcpyAsync(&h_res, p->d_res, sizeof(h_res), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -1090,6 +1152,7 @@ struct grdma_h2_pipe {
   uint8_t* dst = nullptr;
   hipStream_t job_stream = nullptr, frame_stream = nullptr, deframe_stream = nullptr;
   hipEvent_t framed = nullptr, job_done = nullptr, deframed = nullptr;
+  hipEvent_t t_f0 = nullptr, t_d0 = nullptr, t_f1 = nullptr, t_d1 = nullptr;  // kernel start / end stamps of the last step
   grdma_h2_msg_dev* d_msgs = nullptr;
   uint64_t nmsgs = 0;
   uint32_t max_frame = 16384;
@@ -1141,7 +1204,9 @@ grdma_h2_pipe* grdma_h2_pipe_create(grdma_stream_job* job, uint32_t link, const 
        hipMemcpy(p->d_msgs, tmp.data(), sizeof(grdma_h2_msg_dev) * nmsgs, hipMemcpyHostToDevice) == hipSuccess &&
        hipEventCreateWithFlags(&p->framed, hipEventDisableTiming) == hipSuccess &&
        hipEventCreateWithFlags(&p->job_done, hipEventDisableTiming) == hipSuccess &&
-       hipEventCreateWithFlags(&p->deframed, hipEventDisableTiming) == hipSuccess;
+       hipEventCreateWithFlags(&p->deframed, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreate(&p->t_f0) == hipSuccess && hipEventCreate(&p->t_f1) == hipSuccess &&
+       hipEventCreate(&p->t_d0) == hipSuccess && hipEventCreate(&p->t_d1) == hipSuccess;
   if (!ok) {
     grdma_h2_pipe_destroy(p);
     return nullptr;
@@ -1164,6 +1229,8 @@ void grdma_h2_pipe_destroy(grdma_h2_pipe* p) {
   if (p->framed) hipEventDestroy(p->framed);
   if (p->job_done) hipEventDestroy(p->job_done);
   if (p->deframed) hipEventDestroy(p->deframed);
+  for (hipEvent_t e : {p->t_f0, p->t_f1, p->t_d0, p->t_d1})
+    if (e) hipEventDestroy(e);
   delete p;
 }
 
@@ -1174,8 +1241,10 @@ int grdma_h2_pipe_enqueue(grdma_h2_pipe* p, int schedule) {
   // framing overwrites the slice table the job's previous step read
   if (p->launched && hipStreamWaitEvent(p->frame_stream, p->job_done, 0) != hipSuccess) return -GRDMA_ERR_HIP;
   if (hipMemsetAsync(p->d_fres, 0, sizeof(grdma_h2_frame_result), p->frame_stream) != hipSuccess) return -GRDMA_ERR_HIP;
+  hipEventRecord(p->t_f0, p->frame_stream);
   hipLaunchKernelGGL(k_h2_frame, dim3(1), dim3(256), 0, p->frame_stream, p->d_msgs, p->nmsgs, p->max_frame, p->d_sges,
                      p->count, p->d_hdr, p->hdr_cap, (uint64_t*)nullptr, p->d_fres);
+  hipEventRecord(p->t_f1, p->frame_stream);
   if (hipEventRecord(p->framed, p->frame_stream) != hipSuccess) return -GRDMA_ERR_HIP;
   // the job reads the slice table and overwrites what the previous deframing parsed
   if (hipStreamWaitEvent(p->job_stream, p->framed, 0) != hipSuccess) return -GRDMA_ERR_HIP;
@@ -1184,16 +1253,18 @@ int grdma_h2_pipe_enqueue(grdma_h2_pipe* p, int schedule) {
   if (rc < 0) return rc;
   if (hipEventRecord(p->job_done, p->job_stream) != hipSuccess) return -GRDMA_ERR_HIP;
   if (hipStreamWaitEvent(p->deframe_stream, p->job_done, 0) != hipSuccess) return -GRDMA_ERR_HIP;
-  hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(64), 0, p->deframe_stream, p->parser->d, p->dst, p->d_slices, p->delivered,
+  hipEventRecord(p->t_d0, p->deframe_stream);
+  hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(H2_DEFRAME_THREADS), 0, p->deframe_stream, p->parser->d, p->dst, p->d_slices, p->delivered,
                      p->d_ev, p->ev_cap, p->d_dres);
+  hipEventRecord(p->t_d1, p->deframe_stream);
   if (hipEventRecord(p->deframed, p->deframe_stream) != hipSuccess) return -GRDMA_ERR_HIP;
   p->launched = true;
   return 0;
 }
 
 // Wait for the last step and report it: out = {slices framed, frame overflow, events, deframe
-// overflow, slices parsed, h2 error}; events_out (may be NULL) receives up to cap events.
-int grdma_h2_pipe_sync(grdma_h2_pipe* p, uint64_t out[6], grdma_h2_event* events_out, uint64_t cap) {
+// overflow, slices parsed, h2 error, framing kernel us, deframing kernel us, bulk steps, frames parsed by bulk steps}; events_out (may be NULL) receives up to cap events.
+int grdma_h2_pipe_sync(grdma_h2_pipe* p, uint64_t out[14], grdma_h2_event* events_out, uint64_t cap) {
   if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
   if (!p || !out) return -GRDMA_ERR_INVALID;
   if (hipStreamSynchronize(p->frame_stream) != hipSuccess || hipStreamSynchronize(p->job_stream) != hipSuccess ||
@@ -1210,6 +1281,16 @@ int grdma_h2_pipe_sync(grdma_h2_pipe* p, uint64_t out[6], grdma_h2_event* events
   out[3] = dr.overflow;
   out[4] = dr.slices_done;
   out[5] = (uint64_t)dr.error;
+  out[8] = dr.bulk_steps;
+  out[9] = dr.bulk_frames;
+  out[10] = dr.t_wait;
+  out[11] = dr.t_bulk;
+  out[12] = dr.t_total;
+  out[13] = dr.t_serial;
+  float fms = 0, dms = 0;
+  out[6] = out[7] = 0;
+  if (p->launched && hipEventElapsedTime(&fms, p->t_f0, p->t_f1) == hipSuccess) out[6] = (uint64_t)(fms * 1e3f);
+  if (p->launched && hipEventElapsedTime(&dms, p->t_d0, p->t_d1) == hipSuccess) out[7] = (uint64_t)(dms * 1e3f);
   const uint64_t m = std::min<uint64_t>(std::min<uint64_t>(dr.nevents, cap), p->ev_cap);
   if (events_out && m && hipMemcpy(events_out, p->d_ev, sizeof(grdma_h2_event) * m, hipMemcpyDeviceToHost) != hipSuccess)
     return -GRDMA_ERR_HIP;

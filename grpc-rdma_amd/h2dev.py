@@ -132,10 +132,11 @@ class Pipe:
 
     def sync(self, want_events=False):
         """-> dict(framed, frame_overflow, events, deframe_overflow, parsed, h2_error[, event list])"""
-        out = (u64 * 6)()
+        out = (u64 * 14)()
         ev = (H2Event * self.events_cap)() if want_events else None
         check(self.lib.grdma_h2_pipe_sync(self.h, out, ev, self.events_cap if want_events else 0))
-        r = dict(zip(("framed", "frame_overflow", "events", "deframe_overflow", "parsed", "h2_error"), [int(x) for x in out]))
+        r = dict(zip(("framed", "frame_overflow", "events", "deframe_overflow", "parsed", "h2_error", "frame_us", "deframe_us", "bulk_steps", "bulk_frames", "t_wait", "t_bulk", "t_total", "t_serial"),
+                     [int(x) for x in out]))
         if want_events:
             r["event_list"] = [(e.kind, e.a, e.b, e.c, e.d, e.slice) for e in ev[:min(r["events"], self.events_cap)]]
         return r

@@ -418,8 +418,11 @@ grdma_h2_pipe* grdma_h2_pipe_create(grdma_stream_job* job, uint32_t link, const 
                                     uint32_t max_frame, grdma_h2_parser* parser, uint64_t delivered_slices,
                                     uint64_t events_cap);
 int grdma_h2_pipe_enqueue(grdma_h2_pipe* p, int schedule);
-/* out = {slices framed, frame overflow, events, deframe overflow, slices parsed, h2 error} */
-int grdma_h2_pipe_sync(grdma_h2_pipe* p, uint64_t out[6], grdma_h2_event* events_out, uint64_t cap);
+/* out = {slices framed, frame overflow, events, deframe overflow, slices parsed, h2 error,
+ *        framing kernel us, deframing kernel us (of the last step), bulk steps of the deframer,
+ *        frames it parsed in bulk steps, and four profiling tick counts of the deframer: waiting for
+ *        staged windows, inside bulk steps, total, inside the byte-wise path} */
+int grdma_h2_pipe_sync(grdma_h2_pipe* p, uint64_t out[14], grdma_h2_event* events_out, uint64_t cap);
 void grdma_h2_pipe_destroy(grdma_h2_pipe* p);
 
 /* ---- device helpers for callers that keep payloads in HBM ---------------------- */
