@@ -139,6 +139,9 @@ class Pair:
         if flags is None:
             flags = MEM_HOST if host else MEM_DEVICE
         check(self.lib.grdma_endpoint_write_begin(self.h, arr, len(slices), flags))
+        # the pair reads the caller's buffers until the write is done (the contract of
+        # grpc_endpoint_write, endpoint.h:78-91): keep them alive across the continuation calls
+        self._w_keep = (arr, keep)
         return self.endpoint_write_continue()
 
     def endpoint_write_continue(self):
@@ -148,6 +151,8 @@ class Pair:
             steps.append(n)
             if n == 0:
                 break
+        if done.value:
+            self._w_keep = None
         return steps, bool(done.value)
 
     def endpoint_read(self, max_reads=1):
