@@ -397,3 +397,33 @@ def test_h2_pipe_frame_job_deframe_matches_the_oracle(gpu, engine):
     parser.close()
     tx.close()
     rx.close()
+
+
+def test_deframe_real_grpc_client_bytes(gpu):
+    """The capture of a stock gRPC client (tests/golden/h2_grpcio_capture.json, see
+    tests/test_h2_oracle.py): k_h2_deframe, fed the bytes whole, in 16 KiB reads and cut at random
+    points (aligned and unaligned), produces the oracle's events one for one and hands back the
+    payloads that went into the calls."""
+    from test_h2_oracle import _grpcio_capture
+    data, exp = _grpcio_capture()
+    for seed in range(5):
+        rng = random.Random(seed)
+        if seed == 0:
+            cuts = []
+        elif seed == 1:
+            cuts = list(range(16384, len(data), 16384))
+        else:
+            cuts = sorted(rng.sample(range(1, len(data)), rng.choice([5, 50, 900])))
+        bounds = [0] + cuts + [len(data)]
+        chunks = [data[a:b] for a, b in zip(bounds, bounds[1:])]
+        rc_o, ev_o = oracle_events(chunks, True)
+        rc_g, ev_g = gpu_events(gpu, chunks, True, gap_rng=rng if seed >= 3 else None)
+        assert rc_o == 0 and rc_g == 0
+        assert ev_g == ev_o
+        # message bytes out of the GPU's events
+        starts, acc = [], 0
+        for c in chunks:
+            starts.append(acc)
+            acc += len(c)
+        flat = [(k, a + starts[sl] if k == pyorc.EV_MSG_BYTES else a, b, c, d) for k, a, b, c, d, sl in ev_g]
+        assert [m for _, m in messages_of(flat, data)] == exp

@@ -265,3 +265,42 @@ def test_continuation_and_first_frame_rules():
     p = pyorc.H2Parser(expect_client_prefix=True)
     rc, ev = p.feed(ok + frame(1, 1, 1, b"\x82") + frame(9, 4, 1, b"\x86"))
     assert rc == 0 and [(c, a) for k, a, b, c, d in ev if k == pyorc.EV_STREAM_CLOSED] == [(1, 0)]
+
+
+def _grpcio_capture():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "h2_grpcio_capture.json")
+    d = json.load(open(path))
+    data = bytes.fromhex(d["client_bytes_hex"])
+    from oracle import gen_h2_grpcio_capture
+    unary, stream = gen_h2_grpcio_capture.payloads()   # the payloads that went into the capture
+    assert [len(p) for p in unary + stream] == d["payload_lengths"]
+    return data, unary + stream
+
+
+def test_oracle_deframes_what_a_real_grpc_client_sends():
+    """tests/golden/h2_grpcio_capture.json holds every byte a stock gRPC C-core client (grpcio) put
+    on the wire for four unary calls and one client-streaming call with known payloads
+    (oracle/gen_h2_grpcio_capture.py): preface, SETTINGS, HPACK HEADERS, WINDOW_UPDATE, PING,
+    RST_STREAM and 29 DATA frames.  The oracle's server-side parser, fed the bytes whole and cut at
+    arbitrary points, must hand back exactly those payloads in order -- K8/K9 pinned against bytes
+    produced by real chttp2 code, not by hand."""
+    import random
+    data, exp = _grpcio_capture()
+    assert data.startswith(PREFACE)
+    for seed in range(6):
+        rng = random.Random(seed)
+        cuts = [] if seed == 0 else sorted(rng.sample(range(1, len(data)), rng.choice([1, 7, 60, 400])))
+        bounds = [0] + cuts + [len(data)]
+        p = pyorc.H2Parser(expect_client_prefix=True)
+        events, base = [], 0
+        for a, b in zip(bounds, bounds[1:]):
+            rc, ev = p.feed(data[a:b])
+            assert rc == 0
+            events += [(k, x + base if k == pyorc.EV_MSG_BYTES else x, y, z, w) for k, x, y, z, w in ev]
+            base = b
+        msgs = messages_of(events, data)
+        assert [m for _, m in msgs] == exp
+        # four unary calls on streams 1,3,5,7 and the streaming call on 9
+        assert [sid for sid, _ in msgs] == [1, 3, 5, 7, 9, 9, 9, 9, 9]
