@@ -258,7 +258,8 @@ def measure_rtt(g, iters=100000, warmup=2000):
 
 def fanout_leg(g, gs, grp, torch, args, flags, n_msgs=128):
     """One 128 MiB stream (128 x 1 MiB messages) ingested on rank 0, decoded into a torch
-    tensor, then rebalanced to all ranks with one RCCL scatter (grpc_rdma_amd.fanout)."""
+    tensor, then rebalanced to all ranks with one grouped RCCL send/recv step over views of the arena
+    (grpc_rdma_amd.fanout: no padded copies on the source)."""
     from grpc_rdma_amd import fanout
     dev = torch.device("cuda", grp.local_rank)
     ring = args.ring_kb * 1024
@@ -292,7 +293,7 @@ def fanout_leg(g, gs, grp, torch, args, flags, n_msgs=128):
     out = {}
     if grp.rank == 0:
         total = sum(n for _, n in slices)
-        out = {"fanout_config": "%d MiB stream ingested on GPU 0, one RCCL scatter to %d GPUs" % (n_msgs, grp.world),
+        out = {"fanout_config": "%d MiB stream ingested on GPU 0, one grouped RCCL send/recv step to %d GPUs" % (n_msgs, grp.world),
                "fanout_ingest_ms": round(1e3 * t_ingest, 3), "fanout_scatter_ms": round(1e3 * t_scatter, 3),
                "fanout_GiBps": round(n_msgs * MIB / (t_ingest + t_scatter) / (1 << 30), 3),
                "fanout_bytes_ok": bool(got == total)}

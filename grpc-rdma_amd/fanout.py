@@ -2,10 +2,13 @@
 
 One stream is inherently serial at ingest (one ring, one head).  After the ingest GPU
 has decoded it into its receive arena, the arena is cut into `world` contiguous byte
-ranges (on delivered-slice boundaries) and rebalanced with ONE scatter step:
-torch.distributed.scatter over RCCL, i.e. grouped ncclSend/ncclRecv, one xGMI link
-per destination GPU (7 links x ~153 GB/s in parallel; not a ring collective, which
-would be bound by a single link).  This is the only collective on the data path."""
+ranges (on delivered-slice boundaries) and rebalanced with ONE grouped point-to-point
+step: torch.distributed.batch_isend_irecv over RCCL = ncclGroupStart / ncclSend x (world-1)
+/ ncclGroupEnd on the ingest rank, one ncclRecv on every other rank -- one xGMI link per
+destination GPU (7 links x ~153 GB/s in parallel; not a ring collective, which would be
+bound by a single link).  The sends are VIEWS of the arena with their exact lengths: nothing
+is copied or padded on the source (a scatter needs equal-sized chunks, which cost
+2 x stream bytes of extra HBM traffic in round 1).  This is the only collective on the data path."""
 import torch
 
 
@@ -52,19 +55,20 @@ def scatter_arena(group, arena, slices, src=0):
         meta = torch.empty((world, 2), dtype=torch.int64, device=device)
     dist.broadcast(meta, src=src)
     ranges = [(int(a), int(b)) for a, b in meta.tolist()]
-    width = max(b - a for a, b in ranges)
-    width = max(1, (width + 15) // 16 * 16)
-    mine = torch.empty(width, dtype=torch.uint8, device=device)
-    if rank == src:
-        chunks = []
-        for a, b in ranges:
-            c = torch.zeros(width, dtype=torch.uint8, device=device)
-            c[:b - a] = arena[a:b]
-            chunks.append(c)
-        dist.scatter(mine, scatter_list=chunks, src=src)
-    else:
-        dist.scatter(mine, scatter_list=None, src=src)
     a, b = ranges[rank]
+    ops = []
+    if rank == src:
+        mine = arena[a:b]  # the ingest rank keeps its share in place
+        for r, (ra, rb) in enumerate(ranges):
+            if r != src and rb > ra:
+                ops.append(dist.P2POp(dist.isend, arena[ra:rb], r))
+    else:
+        mine = torch.empty(max(0, b - a), dtype=torch.uint8, device=device)
+        if b > a:
+            ops.append(dist.P2POp(dist.irecv, mine, src))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     # slice tables travel as one small broadcast of (offset, length) rows per rank
     if rank == src:
         counts = torch.tensor([len(p) for p in parts], dtype=torch.int64, device=device)
@@ -72,11 +76,11 @@ def scatter_arena(group, arena, slices, src=0):
         counts = torch.empty(world, dtype=torch.int64, device=device)
     dist.broadcast(counts, src=src)
     nmax = int(counts.max().item())
-    table = torch.zeros((world, max(1, nmax), 2), dtype=torch.int64, device=device)
-    if rank == src:
-        for r, p in enumerate(parts):
-            for k, (o, n) in enumerate(p):
-                table[r, k, 0], table[r, k, 1] = o - ranges[r][0], n
+    if rank == src:  # built on the host in one go (thousands of rows), then one broadcast
+        rows = [[[o - ranges[r][0], n] for o, n in p] + [[0, 0]] * (max(1, nmax) - len(p)) for r, p in enumerate(parts)]
+        table = torch.tensor(rows, dtype=torch.int64, device=device).reshape(world, max(1, nmax), 2)
+    else:
+        table = torch.zeros((world, max(1, nmax), 2), dtype=torch.int64, device=device)
     dist.broadcast(table, src=src)
     my_slices = [(int(o), int(n)) for o, n in table[rank, :int(counts[rank].item())].tolist()]
-    return mine[:b - a], my_slices
+    return mine, my_slices
