@@ -97,7 +97,7 @@ struct lk_ctl {
   uint64_t res_sends, res_chunks, res_entries[3];
   uint64_t res_wait_ticks[4];      // profiling aid: leader wait time (tx: slots, credit; rx: data, table)
   uint64_t res_prof[8];            // profiling aid: leader busy time (tx: pricing, wire+publish, total; rx: walk, fast steps, scalar steps, total)
-  uint64_t res_err_detail[4];      // (profiling aid: sender step phases)
+  uint64_t res_tx_phases[4];       // profiling aid: sender step phases (slice loads, pricing, counting, emission), ticks
   uint64_t res_dbg[8];             // what the first aborting role saw: {code, site, a, b, c, d}
   // profiling aid: event trace of the two leaders {tag << 56 | wall-clock tick}, tags:
   // 1 Send priced, 2 Send published, 3 ring writes released (arg = Sends released so far),

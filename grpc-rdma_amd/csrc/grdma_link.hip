@@ -720,7 +720,7 @@ __device__ void lk_tx_leader(lk_ctl* L, uint64_t ticks, lk_tx_lds* D, int lane) 
     L->res_prof[0] = t_price;
     L->res_prof[1] = t_pub;
     L->res_prof[2] = wall_clock64() - t_begin;
-    for (int q = 0; q < 4; q++) L->res_err_detail[q] = tph[q];
+    for (int q = 0; q < 4; q++) L->res_tx_phases[q] = tph[q];
     L->trace_n[0] = trn < 192 ? trn : 192;
   }
 }

@@ -1912,8 +1912,11 @@ int grdma_pair_debug_hist(grdma_pair* p, uint32_t* hist_out, uint64_t* count, ui
 int grdma_stream_job_debug(grdma_stream_job* j, uint64_t* tx_dbg, uint64_t* rx_dbg) {
   if (!j) return -1;
   hipStreamSynchronize(j->stream);
-  hipMemcpy(tx_dbg, j->d_txres[0].dbg, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost);
-  hipMemcpy(rx_dbg, j->d_rxres[0].dbg, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost);
+  // result blocks alternate between even and odd rounds: GRDMA_DBG_ODD=1 shows the last odd round
+  // (with 9 rounds per step the last even round is the short ninth one)
+  const size_t slot = getenv("GRDMA_DBG_ODD") ? j->links.size() : 0;
+  hipMemcpy(tx_dbg, j->d_txres[slot].dbg, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost);
+  hipMemcpy(rx_dbg, j->d_rxres[slot].dbg, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost);
   return 0;
 }
 
@@ -1953,7 +1956,7 @@ int grdma_stream_job_engine_prof(grdma_stream_job* j, uint32_t link, uint64_t ou
   if (int rc = require_ctx()) return rc;
   if (!j || !out || link >= j->links.size() || !j->links[link].d_lk) return fail(GRDMA_ERR_INVALID, "bad argument");
   HIP_TRY(hipStreamSynchronize(j->stream));
-  static_assert(offsetof(lk_ctl, res_err_detail) == offsetof(lk_ctl, res_prof) + 8 * sizeof(uint64_t), "layout");
+  static_assert(offsetof(lk_ctl, res_tx_phases) == offsetof(lk_ctl, res_prof) + 8 * sizeof(uint64_t), "layout");
   HIP_TRY(hipMemcpy(out, reinterpret_cast<uint8_t*>(j->links[link].d_lk) + offsetof(lk_ctl, res_prof), sizeof(uint64_t) * 12,
                     hipMemcpyDeviceToHost));
   return 0;
