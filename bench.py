@@ -365,7 +365,7 @@ def main():
         torch.cuda.synchronize()
 
     def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB,
-                pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None):
+                pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None, burst=1):
         """n_links connections with rings of ring_kb KiB.  Graph schedule: calibrate the number of
         rounds, capture the graph, time `steps` replays.  Engine schedule: every step is ONE launch of
         the persistent link engine.  Then verify, optionally instrument."""
@@ -394,10 +394,12 @@ def main():
             launch = job.launch_engine
         else:
             job.set_pipeline(pipeline)
+            if burst > 1:
+                job.set_burst(burst)                   # `burst` Sends per round, then one drain
             r = job.run(gs.RUN_EAGER)                  # calibration: how many rounds are needed
             assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
                 r.bytes_delivered, total_n)
-            rounds = int(max(r.tx_rounds, r.rx_rounds))
+            rounds = int(max(r.tx_rounds, r.rx_rounds)) if burst == 1 else int(r.rx_rounds) + 1
             job.set_rounds(rounds)
             r = job.run(gs.RUN_GRAPH)                  # capture + first replay
             assert r.done and r.bytes_delivered == total_n
@@ -653,9 +655,13 @@ def main():
         # the reference's default knobs (4 MiB ring, max_sge 30: rdma_utils.h / config.cc), same workload,
         # with the CPU codec timed at the SAME knobs beside it
         try:
-            rk = measure(4096, half, 1, not args.no_verify, False, max_sge=30)
+            rk = measure(4096, half, 1, not args.no_verify, False, max_sge=30, burst=16)
             out["value_ring4096_sge30"] = round(wl.user_bytes * half * world / rk["elapsed"] / (1 << 30), 3)
             out["rounds_per_step_ring4096_sge30"] = rk["rounds"]
+            out["config"]["ring4096_sge30_leg"] = ("4 MiB ring, max_sge 30 (the reference's defaults), up to 16 Sends per round "
+                                                   "before the peer drains (grdma_stream_job_set_burst), %d rounds" % rk["rounds"])
+            rk1 = measure(4096, 2, 1, False, False, max_sge=30)
+            out["value_ring4096_sge30_one_send_per_round"] = round(wl.user_bytes * 2 * world / rk1["elapsed"] / (1 << 30), 3)
         except Exception as e:
             out["ring4096_sge30_error"] = str(e)[:200]
         # mixed message sizes (examples/cpp/test/common.h: uniform in [1, 4 MiB - 1 KiB]), 64 messages per step
@@ -663,7 +669,7 @@ def main():
             mw = MixedWorkload(g, 64)
             mx = measure(args.ring_kb, half, 1, not args.no_verify, False, wls=[mw])
             out["value_mixed_sizes"] = round(mw.user_bytes * half * world / mx["elapsed"] / (1 << 30), 3)
-            mx2 = measure(4096, half, 1, not args.no_verify, False, max_sge=30, wls=[mw])
+            mx2 = measure(4096, half, 1, not args.no_verify, False, max_sge=30, wls=[mw], burst=16)
             out["value_mixed_sizes_ring4096_sge30"] = round(mw.user_bytes * half * world / mx2["elapsed"] / (1 << 30), 3)
             out["config"]["mixed_sizes_leg"] = "64 messages, sizes uniform in [1, 4 MiB - 1 KiB] (seed 0), %d MiB per step, %d slices" % (
                 mw.user_bytes >> 20, len(mw.lens))

@@ -53,6 +53,40 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
   tx_plan_body(ops[blockIdx.x]);
 }
 
+// k_tx_plan_seq: gridDim.y Sends of the SAME connection back to back in one launch (a sender that
+// runs ahead of its reader: rdma_flush retried before the peer has read).  ops[k * gridDim.x + link]
+// is Send k of connection `link`; every Send has its own plans, staging buffer and result block and
+// continues from the cursor and ring tail the one before left in the connection block.  Between two
+// Sends the workgroup makes its own stores visible to itself (agent-scope fence around a barrier:
+// the next body reads the connection block the last one wrote).
+__device__ __attribute__((noinline)) void tx_plan_seq_call(const grdma_tx_op* op) { tx_plan_body(*op); }
+__global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan_seq(const grdma_tx_op* ops) {
+  if (blockIdx.y != 0) return;  // (the grid's y extent only carries the burst length)
+  const uint32_t n = gridDim.x, burst = gridDim.y;
+  const grdma_tx_op* mine = ops + blockIdx.x;
+  const grdma_conn* c = mine[0].conn;
+  uint32_t k0 = 0;
+  if (c->max_sge <= 64 && c->cap <= (1ull << 30)) {
+    // the Sends are small: one wavefront prices the whole burst (tx_burst_wave).  A first Send that
+    // resets the cursor (it sums the whole slice list) still takes the block-wide plan.
+    if (mine[0].use_cursor != 1) {
+      tx_plan_seq_call(&mine[0]);
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+      __syncthreads();
+      k0 = 1;
+    }
+    if (threadIdx.x < 64 && k0 < burst) tx_burst_wave(mine + (size_t)k0 * n, n, burst - k0, (int)threadIdx.x);
+    return;
+  }
+  for (uint32_t k = 0; k < burst; k++) {
+    tx_plan_seq_call(&mine[(size_t)k * n]);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    __syncthreads();
+  }
+}
+
 // ----------------------------------------------------------------------------
 // k_copy: segment-list byte mover (slice gather, wire, ring scatter); the tile
 // machinery lives in grdma_devfn.h so the fused small-message paths share it
@@ -174,6 +208,12 @@ __attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_plan(const grdm
   return hipGetLastError();
 }
 
+__attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_plan_seq(const grdma_tx_op* d_ops, uint32_t nlinks, uint32_t burst, hipStream_t s) {
+  if (nlinks == 0 || burst == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tx_plan_seq, dim3(nlinks, burst), dim3(PLAN_THREADS), 0, s, d_ops);
+  return hipGetLastError();
+}
+
 __attribute__((visibility("hidden"))) hipError_t grdma_launch_copy(const grdma_plan* const* d_plans, uint32_t nplans,
                              uint32_t blocks_per_plan, hipStream_t s) {
   if (nplans == 0) return hipSuccess;
@@ -195,6 +235,7 @@ __attribute__((visibility("hidden"))) const void* grdma_kernel_fn(int which) {
     case 0: return reinterpret_cast<const void*>(&k_tx_plan);
     case 1: return reinterpret_cast<const void*>(&k_copy);
     case 3: return reinterpret_cast<const void*>(&k_rx_apply);
+    case 4: return reinterpret_cast<const void*>(&k_tx_plan_seq);
     default: return nullptr;
   }
 }
@@ -212,7 +253,7 @@ __attribute__((visibility("hidden"))) uint32_t grdma_copy_resident_blocks(void) 
   return (uint32_t)((per_cu > 0 ? per_cu : 1) * cus);
 }
 
-__attribute__((visibility("hidden"))) uint32_t grdma_kernel_threads(int which) { return (which == 0 || which == 2) ? PLAN_THREADS : COPY_THREADS; }
+__attribute__((visibility("hidden"))) uint32_t grdma_kernel_threads(int which) { return (which == 0 || which == 2 || which == 4) ? PLAN_THREADS : COPY_THREADS; }
 
 __attribute__((visibility("hidden"))) hipError_t grdma_launch_poll(grdma_conn* const* d_conns, uint32_t nconns, uint64_t* d_readable,
                              uint64_t* d_ready_mask, uint64_t* d_has_mask, uint64_t* d_trigger_mask,

@@ -35,13 +35,14 @@ extern "C" {
 hipError_t grdma_launch_link(lk_ctl* const*, uint32_t, uint32_t, uint64_t, hipStream_t);
 uint32_t grdma_link_resident_blocks(void);
 hipError_t grdma_launch_tx_plan(const grdma_tx_op*, uint32_t, hipStream_t);
+hipError_t grdma_launch_tx_plan_seq(const grdma_tx_op*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_copy(const grdma_plan* const*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_apply(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*, uint64_t*, uint64_t*,
                              hipStream_t);
 hipError_t grdma_launch_engine(grdma_engine_mbox*, hipStream_t);
-const void* grdma_kernel_fn(int which);          // 0 tx_plan, 1 copy, 3 rx_apply
+const void* grdma_kernel_fn(int which);          // 0 tx_plan, 1 copy, 3 rx_apply, 4 tx_plan_seq
 const void* grdma_kernel_fn_rx_plan(void);
 uint32_t grdma_kernel_threads(int which);
 uint32_t grdma_copy_resident_blocks(void);
@@ -1301,6 +1302,9 @@ struct grdma_job_link {
   grdma_plan* d_wireplan2 = nullptr;
   grdma_plan* d_rxplan2 = nullptr;
   uint8_t* d_staging2 = nullptr;
+  // burst mode (several Sends per round): plans, staging buffers of Sends 1 .. burst-1
+  std::vector<grdma_plan*> b_gplan, b_wplan;
+  std::vector<uint8_t*> b_staging;
   // persistent link engine (k_link): control block, the three entry tables, extra staging buffers
   lk_ctl* d_lk = nullptr;
   lk_entry* d_tab[3] = {nullptr, nullptr, nullptr};
@@ -1332,6 +1336,12 @@ struct grdma_stream_job {
   hipStream_t stream = nullptr;
   bool direct = false;
   uint64_t max_ring = 0;
+  // burst mode: `burst` Sends per round, planned back to back by one k_tx_plan_seq launch, gathered
+  // and put on the wire by one k_copy launch each (burst x n plans), drained by ONE receive pass
+  uint32_t burst = 1;
+  uint8_t* d_bctl = nullptr;
+  grdma_tx_op* d_btxop = nullptr;          // [2 sets][burst][n]: set 0 = first round (resets the cursor)
+  const grdma_plan** d_bplans = nullptr;   // [burst * n] gather plans, then [burst * n] wire plans
   // link engine
   lk_ctl** d_lk_ptrs = nullptr;
   uint32_t lk_team = 0;
@@ -1362,14 +1372,25 @@ int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
     return 0;
   };
   if (int rc = mark()) return rc;
+  const uint32_t B = j->burst;
+  const uint32_t txb_b = std::max<uint32_t>(1, std::min<uint32_t>(tx_blocks, grid_cap / (n * B) + 1));
   for (uint64_t r = 0; r < j->rounds; r++) {
     const int k = job_opset(r);
+    if (B > 1) {
+      HIP_TRY(grdma_launch_tx_plan_seq(j->d_btxop + (r == 0 ? 0 : (size_t)B * n), n, B, s));
+      if (int rc = mark()) return rc;
+      HIP_TRY(grdma_launch_copy(j->d_bplans, B * n, txb_b, s));
+      if (int rc = mark()) return rc;
+      if (!j->direct) HIP_TRY(grdma_launch_copy(j->d_bplans + (size_t)B * n, B * n, txb_b, s));
+      if (int rc = mark()) return rc;
+    } else {
     HIP_TRY(grdma_launch_tx_plan(j->d_txop + k * n, n, s));
     if (int rc = mark()) return rc;
     HIP_TRY(grdma_launch_copy(j->d_plans, n, txb, s));
     if (int rc = mark()) return rc;
     if (!j->direct) HIP_TRY(grdma_launch_copy(j->d_plans + n * (1 + (r & 1)), n, txb, s));
     if (int rc = mark()) return rc;
+    }
     HIP_TRY(grdma_launch_rx_plan(j->d_rxop + k * n, n, s));
     if (int rc = mark()) return rc;
     HIP_TRY(grdma_launch_rx_apply(j->d_rxop + k * n, n, rxb, s));
@@ -1506,7 +1527,25 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
     const void* rxop = j->d_rxop + k * n;
     const void* gplans = j->d_plans;
     const void* wplans = j->d_plans + n * (1 + (t & 1));
-    if (!j->pipeline) {
+    if (j->burst > 1) {
+      // burst rounds: strictly in order (one connection state, one receive pass per round)
+      const uint32_t B = j->burst;
+      const uint32_t txb_b = std::max<uint32_t>(1, std::min<uint32_t>(tx_blocks, grid_cap / (n * B) + 1));
+      const void* btx = j->d_btxop + (t == 0 ? 0 : (size_t)B * n);
+      const void* bg = j->d_bplans;
+      const void* bw = j->d_bplans + (size_t)B * n;
+      hipGraphNode_t prev = at(A, t, 1);
+      e = add(&P[t], grdma_kernel_fn(4), dim3(n, B), pt, btx, {prev});
+      if (e == hipSuccess) e = add(&G[t], f_cpy, dim3(txb_b, B * n), ct, bg, {P[t]});
+      hipGraphNode_t last = G[t];
+      W[t] = nullptr;
+      if (!j->direct && e == hipSuccess) {
+        e = add(&W[t], f_cpy, dim3(txb_b, B * n), ct, bw, {G[t]});
+        last = W[t];
+      }
+      if (e == hipSuccess) e = add(&X[t], f_rxp, dim3(n), pt, rxop, {last});
+      if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t]});
+    } else if (!j->pipeline) {
       hipGraphNode_t prev = at(A, t, 1);
       e = add(&P[t], f_txp, dim3(n), pt, txop, {prev});
       if (e == hipSuccess) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t]});
@@ -1807,8 +1846,12 @@ void grdma_stream_job_destroy(grdma_stream_job* j) {
     hipFree(l.d_lk);
     for (auto* t : l.d_tab) hipFree(t);
     for (auto* sb : l.d_staging_more) hipFree(sb);
+    for (auto* q : l.b_gplan) hipFree(q);
+    for (auto* q : l.b_wplan) hipFree(q);
+    for (auto* q : l.b_staging) hipFree(q);
   }
   hipFree(j->d_lk_ptrs);
+  hipFree(j->d_bctl);
   hipFree(j->d_ctl);
   delete j;
 }
@@ -1822,6 +1865,70 @@ int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds) {
 int grdma_stream_job_set_pipeline(grdma_stream_job* j, int on) {
   if (!j) return fail(GRDMA_ERR_INVALID, "null job");
   j->pipeline = on ? 1 : 0;
+  return 0;
+}
+
+// `burst` Sends per round (1 = the plain schedule).  Every Send of a burst gets its own gather plan,
+// wire plan and staging buffer (the reference reuses its one staging buffer after waitDataWrites();
+// here the wire of all Sends of a round runs after all of them were planned).
+int grdma_stream_job_set_burst(grdma_stream_job* j, uint32_t burst) {
+  if (int rc = require_ctx()) return rc;
+  if (!j || burst == 0 || burst > 64) return fail(GRDMA_ERR_INVALID, "burst must be 1..64");
+  if (burst == j->burst) return 0;
+  HIP_TRY(hipStreamSynchronize(j->stream));
+  if (j->exec) hipGraphExecDestroy(j->exec);  // the graph is rebuilt for the new schedule
+  j->exec = nullptr;
+  const uint32_t n = (uint32_t)j->links.size();
+  for (grdma_job_link& l : j->links) {
+    while (l.b_gplan.size() < burst) {
+      grdma_plan *g = nullptr, *w = nullptr;
+      uint8_t* st = nullptr;
+      HIP_TRY(hipMalloc((void**)&g, sizeof(grdma_plan)));
+      l.b_gplan.push_back(g);
+      HIP_TRY(hipMemset(g, 0, sizeof(grdma_plan)));
+      HIP_TRY(hipMalloc((void**)&w, sizeof(grdma_plan)));
+      l.b_wplan.push_back(w);
+      HIP_TRY(hipMemset(w, 0, sizeof(grdma_plan)));
+      if (!j->direct) {
+        HIP_TRY(hipMalloc((void**)&st, l.tx->ring_size / 2 + 64));
+        HIP_TRY(hipMemset(st, 0, l.tx->ring_size / 2 + 64));
+      }
+      l.b_staging.push_back(st);
+    }
+  }
+  if (j->d_bctl) hipFree(j->d_bctl);
+  j->d_bctl = nullptr;
+  j->burst = burst;
+  if (burst == 1) return 0;
+  const size_t sz_tx = sizeof(grdma_tx_op) * 2 * burst * n, sz_pl = sizeof(grdma_plan*) * 2 * burst * n;
+  const size_t sz_res = sizeof(grdma_tx_result) * n;  // scratch results of the Sends before the last
+  HIP_TRY(hipMalloc((void**)&j->d_bctl, sz_tx + sz_pl + sz_res));
+  j->d_btxop = reinterpret_cast<grdma_tx_op*>(j->d_bctl);
+  j->d_bplans = reinterpret_cast<const grdma_plan**>(j->d_bctl + sz_tx);
+  grdma_tx_result* scratch = reinterpret_cast<grdma_tx_result*>(j->d_bctl + sz_tx + sz_pl);
+  std::vector<uint8_t> host(sz_tx + sz_pl + sz_res, 0);
+  auto* h_tx = reinterpret_cast<grdma_tx_op*>(host.data());
+  auto** h_pl = reinterpret_cast<const grdma_plan**>(host.data() + sz_tx);
+  for (int set = 0; set < 2; set++)
+    for (uint32_t k = 0; k < burst; k++)
+      for (uint32_t i = 0; i < n; i++) {
+        const grdma_job_link& l = j->links[i];
+        grdma_tx_op& t = h_tx[((size_t)set * burst + k) * n + i];
+        t.conn = l.tx->d_conn;
+        t.slices = l.d_sges;
+        t.nslices = l.count;
+        t.plan = l.b_gplan[k];
+        t.wire_plan = l.b_wplan[k];
+        t.staging_alt = l.b_staging[k];
+        t.result = k + 1 == burst ? &j->d_txres[i] : &scratch[i];
+        t.use_cursor = (set == 0 && k == 0) ? 2 : 1;
+      }
+  for (uint32_t k = 0; k < burst; k++)
+    for (uint32_t i = 0; i < n; i++) {
+      h_pl[(size_t)k * n + i] = j->links[i].b_gplan[k];
+      h_pl[(size_t)(burst + k) * n + i] = j->links[i].b_wplan[k];
+    }
+  HIP_TRY(hipMemcpy(j->d_bctl, host.data(), host.size(), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -1857,7 +1964,7 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
     HIP_TRY(hipEventRecord(j->ev1, s));
   } else {
     HIP_TRY(hipEventRecord(j->ev0, s));
-    if (j->pipeline && mode == GRDMA_RUN_EAGER) {
+    if (j->pipeline && j->burst == 1 && mode == GRDMA_RUN_EAGER) {
       if (int rc = job_enqueue_pipelined(j, s)) return rc;
     } else {
       if (int rc = job_enqueue(j, s, mode == GRDMA_RUN_INSTRUMENTED)) return rc;

@@ -530,5 +530,216 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
 }
 
 
+// ----------------------------------------------------------------------------
+// A BURST of Sends of one connection on ONE wavefront (k_tx_plan_seq, max_sge <= 64 -- the
+// reference's default is 30): lane i = record i of the current Send.  The connection state
+// (tail, cursor, remaining bytes, counters) lives in registers across the burst and is written back
+// once; per Send: one coalesced load of <= 64 slice descriptors, the same pricing as the block-wide
+// plan (pay_i = min(len_i, W(S - st_i), W(free0 - st_i)), the first short record ends the Send),
+// one segment + tile-prefix entry per lane, the <= 2 wire requests, the result block.  No LDS, no
+// barriers, no wait between Sends except for the descriptors.
+// ops[k * stride] is Send k.  Preconditions checked by the caller: cap <= 2^30, max_sge <= 64,
+// every op has use_cursor == 1.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t stride, uint32_t burst, int lane) {
+  const grdma_tx_op op0 = ops[0];
+  grdma_conn* c = op0.conn;
+  const uint64_t cap = c->cap, mask = cap - 1, S = c->staging_cap;
+  const uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool connected = c->status == GRDMA_PAIR_CONNECTED;
+  const bool direct = c->wire_direct != 0;
+  const uint64_t max_sge = c->max_sge;
+  uint8_t* const peer_ring = c->peer_ring;
+  uint8_t* const conn_staging = c->staging;
+  const grdma_sge* const sl = op0.slices;
+  const uint64_t nslices = op0.nslices;
+  // running state
+  uint64_t tail = c->remote_tail, idx = c->tx_slice_idx, bidx = c->tx_byte_idx, remaining = c->tx_remaining;
+  uint64_t total_written = c->total_written, records = c->tx_records, rounds = c->tx_rounds;
+  uint32_t last_records = c->tx_last_records, partial = (uint32_t)c->partial_write;
+  if (idx > nslices) idx = nslices;
+
+  bool dry = false;  // a Send accepted nothing: nothing changes until the peer reads, the rest accept nothing either
+  for (uint32_t k = 0; k < burst; k++) {
+    const grdma_tx_op op = ops[(size_t)k * stride];
+    grdma_plan* const plan = op.plan;
+    if (dry) {
+      // the same outcome as pricing it: empty plans, nothing sent, state untouched
+      // (partial_write was set by the Send that came up empty, pair.cc:709)
+      if (lane == 0) {
+        plan->nsegs = 0;
+        plan->ntiles = 0;
+        plan->tile_prefix[0] = 0;
+        plan->bytes = 0;
+        if (op.wire_plan != nullptr) {
+          op.wire_plan->nsegs = 0;
+          op.wire_plan->ntiles = 0;
+          op.wire_plan->tile_prefix[0] = 0;
+          op.wire_plan->bytes = 0;
+        }
+        grdma_tx_result* r = op.result;
+        r->wr_count = 0;
+        r->wr_off[0] = r->wr_off[1] = r->wr_len[0] = r->wr_len[1] = 0;
+        r->sent = 0;
+        r->records = 0;
+        r->staged = 0;
+        r->partial = partial;
+        r->new_remote_tail = tail;
+        r->slice_idx = idx;
+        r->byte_idx = bidx;
+        r->done = idx >= nslices ? 1 : 0;
+      }
+      last_records = 0;
+      continue;
+    }
+    const uint64_t avail = nslices - idx;
+    uint64_t m = avail < max_sge ? avail : max_sge;
+    if (!connected) m = 0;
+    const bool in_m = (uint64_t)lane < m;
+    // (unconditional load from a clamped index)
+    const uint64_t li = idx + (uint64_t)lane < nslices ? idx + (uint64_t)lane : (nslices ? nslices - 1 : 0);
+    grdma_sge g = {nullptr, 0};
+    if (nslices) g = sl[li];
+    uint64_t len = in_m ? g.len : 0;
+    const uint8_t* src = g.ptr;
+    if (lane == 0 && in_m) {
+      len = sat_sub(len, bidx);
+      src += bidx;
+    }
+    const uint64_t offered = remaining;
+    const uint32_t enc = in_m ? (uint32_t)enc_size(len < (cap << 1) ? len : (cap << 1)) : 0;
+    const uint32_t incl = wave_incl_scan_u32(enc);
+    const uint64_t st = incl - enc;
+    const uint64_t free0 = cap - ((tail + cap - rhead) & mask);
+    uint64_t pay = len;
+    {
+      const uint64_t a = writable_of(sat_sub(S, st)), b = writable_of(sat_sub(free0, st));
+      if (a < pay) pay = a;
+      if (b < pay) pay = b;
+    }
+    const uint64_t shorts = __ballot(in_m && (pay < len || len == 0));
+    const uint64_t nrec = shorts ? (uint64_t)__builtin_ctzll(shorts) : m;
+    const uint64_t short_pay = shorts ? __shfl(pay, (int)nrec, 64) : 0;
+    const uint64_t nrec_total = nrec + (short_pay > 0 ? 1 : 0);
+    const uint64_t my_pay = (uint64_t)lane < nrec ? len : ((uint64_t)lane == nrec ? short_pay : 0);
+    const uint64_t whole = nrec ? (uint64_t)__shfl(incl, (int)nrec - 1, 64) : 0;
+    const uint64_t staged = whole + (short_pay > 0 ? enc_size(short_pay) : 0);
+    uint64_t sent = my_pay;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sent += __shfl_xor(sent, d, 64);
+
+    // segments (see the block-wide plan: tags ride on the segments, GRDMA_SEG_TAG_*)
+    uint8_t* const staging = op.staging_alt ? op.staging_alt : conn_staging;
+    uint8_t* const dbase = direct ? peer_ring : staging;
+    const bool mine = (uint64_t)lane < nrec_total;
+    const uint64_t hdr_off = direct ? ((tail + st) & mask) : st;
+    const uint64_t pay_off = direct ? ((hdr_off + 8) & mask) : st + 8;
+    const uint64_t wraps = __ballot(mine && direct && pay_off + my_pay > cap);
+    const uint32_t wrap_rec = wraps ? (uint32_t)__builtin_ctzll(wraps) : 0xFFFFFFFFu;
+    const uint64_t l1 = cap - pay_off;  // (only meaningful for the wrapping record)
+    uint32_t t1 = (uint32_t)((my_pay + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES), tiles = t1;
+    if ((uint32_t)lane == wrap_rec) {
+      t1 = (uint32_t)((l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+      tiles = t1 + (uint32_t)((my_pay - l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+    }
+    if (!mine) tiles = 0;
+    const uint32_t tincl = wave_incl_scan_u32(tiles);
+    const uint32_t tx0 = tincl - tiles;
+    const uint32_t ntiles = (uint32_t)__shfl(tincl, 63, 64);
+    if (mine) {
+      const uint64_t tagw = GRDMA_SEG_TAG_WRITE | (my_pay << GRDMA_SEG_TAG_LEN_SHIFT);
+      const uint64_t seg = (uint64_t)lane + ((uint32_t)lane > wrap_rec ? 1 : 0);
+      if ((uint32_t)lane == wrap_rec) {
+        plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, l1, tagw | GRDMA_SEG_TAG_HDR};
+        plan->segs[seg + 1] = {(uint64_t)dbase, (uint64_t)(src + l1), my_pay - l1, tagw | GRDMA_SEG_TAG_FTR};
+        plan->tile_prefix[seg] = tx0;
+        plan->tile_prefix[seg + 1] = tx0 + t1;
+      } else {
+        plan->segs[seg] = {(uint64_t)(dbase + pay_off), (uint64_t)src, my_pay, tagw | GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR};
+        plan->tile_prefix[seg] = tx0;
+      }
+    }
+    const uint64_t new_tail = (tail + staged) & mask;
+    uint64_t nidx = idx + nrec, nbidx = 0;
+    if (short_pay > 0) nbidx = (nrec == 0 ? bidx : 0) + short_pay;
+    else if (nrec == 0) nbidx = bidx;
+    const uint32_t npartial = connected ? (sent < offered ? 1u : 0u) : partial;
+    if (lane == 0) {
+      const uint32_t nsegs = (uint32_t)nrec_total + (wrap_rec != 0xFFFFFFFFu ? 1u : 0u);
+      plan->nsegs = nsegs;
+      plan->ntiles = ntiles;
+      plan->tile_prefix[nsegs] = ntiles;
+      plan->bytes = sent;
+      plan->tag_base = (uint64_t)dbase;
+      plan->tag_mask = direct ? mask : ~0ull;
+      // the <= 2 RDMA WRITEs of GetWriteRequests(sg_list), ring_buffer.cc:261-330
+      const uint64_t seg1 = staged < cap - tail ? staged : cap - tail;
+      grdma_tx_result* r = op.result;
+      r->wr_count = 0;
+      r->wr_off[0] = r->wr_off[1] = r->wr_len[0] = r->wr_len[1] = 0;
+      if (staged > 0) {
+        r->wr_off[0] = tail;
+        r->wr_len[0] = seg1;
+        r->wr_count = 1;
+        if (tail + staged >= cap) {
+          r->wr_off[1] = 0;
+          r->wr_len[1] = staged - seg1;
+          r->wr_count = 2;
+        }
+      }
+      grdma_plan* wp = op.wire_plan;
+      if (wp != nullptr) {
+        uint32_t ns = 0, nt = 0;
+        if (!direct && staged > 0) {
+          wp->segs[0] = {(uint64_t)(peer_ring + tail), (uint64_t)staging, seg1, 0};
+          wp->tile_prefix[0] = 0;
+          nt = (uint32_t)((seg1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+          ns = 1;
+          if (staged > seg1) {
+            wp->segs[1] = {(uint64_t)peer_ring, (uint64_t)(staging + seg1), staged - seg1, 0};
+            wp->tile_prefix[1] = nt;
+            nt += (uint32_t)((staged - seg1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+            ns = 2;
+          }
+        }
+        wp->nsegs = ns;
+        wp->ntiles = nt;
+        wp->tile_prefix[ns] = nt;
+        wp->bytes = direct ? 0 : staged;
+      }
+      r->sent = sent;
+      r->records = nrec_total;
+      r->staged = staged;
+      r->partial = npartial;
+      r->new_remote_tail = new_tail;
+      r->slice_idx = nidx;
+      r->byte_idx = nbidx;
+      r->done = nidx >= nslices ? 1 : 0;
+    }
+    // the state the next Send starts from (PairPollable members + the rdma_flush cursor)
+    tail = new_tail;
+    idx = nidx;
+    bidx = nbidx;
+    remaining = offered - sent;
+    partial = npartial;
+    total_written += sent;
+    records += nrec_total;
+    last_records = (uint32_t)nrec_total;
+    if (nrec_total) rounds++;
+    else dry = true;
+  }
+  if (lane == 0) {
+    c->remote_tail = tail;
+    c->partial_write = partial;
+    c->total_written = total_written;
+    c->tx_records = records;
+    c->tx_last_records = last_records;
+    c->tx_rounds = rounds;
+    c->tx_slice_idx = idx;
+    c->tx_byte_idx = bidx;
+    c->tx_remaining = remaining;
+  }
+}
+
 }  // namespace
 #endif  // GRDMA_TX_BODY_H

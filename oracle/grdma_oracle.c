@@ -808,7 +808,20 @@ int orc_stream_rounds(uint64_t ring_cap, int max_sge, const uint8_t* wire, const
                       uint64_t nslices, int passes, uint64_t* out_lens, uint64_t out_cap,
                       uint64_t* n_out, uint64_t* first_rounds, uint64_t state[9], int* stream_ok,
                       int* ring_zero) {
+  return orc_stream_rounds_burst(ring_cap, max_sge, 1, wire, lens, nslices, passes, out_lens, out_cap, n_out,
+                                 first_rounds, state, stream_ok, ring_zero);
+}
+
+/* The same with `burst` Sends back to back per round before the reader runs (a sender that is
+ * ahead of its reader: rdma_write -> rdma_flush retried on every writable edge while the peer
+ * has not read yet).  A Send that finds no credit accepts nothing and changes nothing but
+ * partial_write.  *first_rounds counts the Sends that accepted at least one byte. */
+int orc_stream_rounds_burst(uint64_t ring_cap, int max_sge, int burst, const uint8_t* wire, const uint64_t* lens,
+                            uint64_t nslices, int passes, uint64_t* out_lens, uint64_t out_cap,
+                            uint64_t* n_out, uint64_t* first_rounds, uint64_t state[9], int* stream_ok,
+                            int* ring_zero) {
   orc_pair a, b;
+  if (burst < 1) burst = 1;
   if (orc_pair_init(&a, ring_cap, max_sge) || orc_pair_init(&b, ring_cap, max_sge)) return -1;
   orc_pair_connect(&a, &b);
   orc_slice* sl = (orc_slice*)malloc(sizeof(orc_slice) * (nslices ? nslices : 1));
@@ -824,12 +837,14 @@ int orc_stream_rounds(uint64_t ring_cap, int max_sge, const uint8_t* wire, const
   for (int p = 0; p < passes && rc == 0; p++) {
     uint64_t idx = 0, byte_idx = 0, rounds = 0, n = 0, pos = 0;
     while (idx < nslices) {
-      uint64_t sent = orc_pair_send(&a, sl + idx, nslices - idx, byte_idx);
-      if (sent) rounds++;
-      while (sent > 0) {
-        uint64_t sl_len = sl[idx].len - byte_idx;
-        if (sent >= sl_len) { sent -= sl_len; idx++; byte_idx = 0; }
-        else { byte_idx += sent; sent = 0; }
+      for (int k = 0; k < burst && idx < nslices; k++) {
+        uint64_t sent = orc_pair_send(&a, sl + idx, nslices - idx, byte_idx);
+        if (sent) rounds++;
+        while (sent > 0) {
+          uint64_t sl_len = sl[idx].len - byte_idx;
+          if (sent >= sl_len) { sent -= sl_len; idx++; byte_idx = 0; }
+          else { byte_idx += sent; sent = 0; }
+        }
       }
       for (;;) {
         uint64_t alloc;

@@ -231,6 +231,10 @@ int orc_stream_rounds(uint64_t ring_cap, int max_sge, const uint8_t* wire, const
                       uint64_t nslices, int passes, uint64_t* out_lens, uint64_t out_cap,
                       uint64_t* n_out, uint64_t* first_rounds, uint64_t state[9], int* stream_ok,
                       int* ring_zero);
+int orc_stream_rounds_burst(uint64_t ring_cap, int max_sge, int burst, const uint8_t* wire, const uint64_t* lens,
+                            uint64_t nslices, int passes, uint64_t* out_lens, uint64_t out_cap,
+                            uint64_t* n_out, uint64_t* first_rounds, uint64_t state[9], int* stream_ok,
+                            int* ring_zero);
 
 #ifdef __cplusplus
 }

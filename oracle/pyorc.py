@@ -429,20 +429,21 @@ def ref_stream_baseline(ring_size, max_sge, wire, lens, n_msgs):
     return n, sec.value, chk.value
 
 
-def stream_rounds(ring_size, max_sge, wire, lens, passes=1):
-    """The sequential schedule in C (orc_stream_rounds): -> dict(lens=delivered slice lengths of the
-    last pass, rounds=Sends of the first pass, state={...}, stream_ok, ring_zero)."""
+def stream_rounds(ring_size, max_sge, wire, lens, passes=1, burst=1):
+    """The sequential schedule in C (orc_stream_rounds_burst): `burst` Sends back to back, then the
+    reader drains until a read would block, repeat.  -> dict(lens=delivered slice lengths of the last
+    pass, rounds=Sends of the first pass that accepted bytes, state={...}, stream_ok, ring_zero)."""
     l = lib()
-    l.orc_stream_rounds.argtypes = [u64, C.c_int, C.c_char_p, u64p, u64, C.c_int, u64p, u64, u64p, u64p,
-                                    u64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    l.orc_stream_rounds_burst.argtypes = [u64, C.c_int, C.c_int, C.c_char_p, u64p, u64, C.c_int, u64p, u64, u64p, u64p,
+                                          u64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     arr = (u64 * max(1, len(lens)))(*lens)
     cap = 2 * len(lens) + 64 + sum(lens) // 256
     out = (u64 * cap)()
     n_out, rounds = u64(0), u64(0)
     st = (u64 * 9)()
     ok, zero = C.c_int(0), C.c_int(0)
-    rc = l.orc_stream_rounds(ring_size, max_sge, bytes(wire), arr, len(lens), passes, out, cap, C.byref(n_out),
-                             C.byref(rounds), st, C.byref(ok), C.byref(zero))
+    rc = l.orc_stream_rounds_burst(ring_size, max_sge, burst, bytes(wire), arr, len(lens), passes, out, cap,
+                                   C.byref(n_out), C.byref(rounds), st, C.byref(ok), C.byref(zero))
     assert rc == 0, rc
     names = ["remote_tail", "remote_head", "partial_write", "head", "moving_head", "remain",
              "internal_read_size", "credit_msgs", "leftover_cap"]

@@ -63,6 +63,39 @@ def run(g, gs, name, ring_kb, max_sge, n_links, msgs, payload, steps=10, flags=0
 MixedWorkload = bench.MixedWorkload
 
 
+def run_burst(g, gs, name, ring_kb, max_sge, msgs, burst, steps=6):
+    """graph schedule with `burst` Sends per round"""
+    ring = ring_kb * 1024
+    w = bench.Workload(g, msgs, bench.MIB)
+    tx, rx = g.Pair(ring, max_sge), g.Pair(ring, max_sge)
+    g.connect_pairs(tx, rx)
+    scap = len(w.lens) * 2 + 64 + w.N // 256
+    dst_cap = w.N + 32 * scap + 4096
+    dst = g.DeviceBuffer(nbytes=dst_cap)
+    job = gs.MultiStreamJob([(tx, rx, w.sge, dst.ptr, dst_cap, scap)], 2 * (len(w.lens) // max(1, max_sge * burst) + 8) + w.E // (ring // 2) * 4)
+    job.set_burst(burst)
+    r = job.run(gs.RUN_EAGER)
+    assert r.done, (r.bytes_delivered, w.N)
+    rounds = int(r.rx_rounds) + 1
+    job.set_rounds(rounds)
+    r = job.run(gs.RUN_GRAPH)
+    assert r.done
+    for _ in range(2):
+        job.launch()
+    job.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.launch()
+    job.sync()
+    dt = time.perf_counter() - t0
+    inst = job.run(gs.RUN_INSTRUMENTED)
+    us = {gs.CLASS_NAMES[i]: round(1e3 * inst.ms_class[i] / max(1, int(inst.launches_class[i])), 1) for i in range(len(gs.CLASS_NAMES))}
+    print(json.dumps({"config": name, "burst": burst, "GiBps": round(w.user_bytes * steps / dt / (1 << 30), 2),
+                      "ms_per_step": round(1e3 * dt / steps, 3), "rounds": rounds, "us_per_launch": us}), flush=True)
+    job.close()
+    tx.close(); rx.close(); dst.free()
+
+
 def main():
     import torch  # noqa: F401  (device context like bench.py)
     import grpc_rdma_amd as g
@@ -82,6 +115,8 @@ def main():
             run(g, gs, "conns32_64k", 4096, 4095, 32, 64, 64 * 1024)
         elif w == "mixed":
             run(g, gs, "mixed_ring4m_sge30", 4096, 30, 1, 0, 0, wls=[MixedWorkload(g, 64)])
+        elif w.startswith("burst"):
+            run_burst(g, gs, "ring4m_sge30", 4096, 30, 256, int(w[5:] or 16))
         elif w == "mixedbig":
             run(g, gs, "mixed_ring128m_sge4095", 131072, 4095, 1, 0, 0, wls=[MixedWorkload(g, 64)])
 
