@@ -331,6 +331,13 @@ def main():
     ap.add_argument("--no-tcp-baseline", action="store_true", help="skip the loop-back TCP baselines")
     ap.add_argument("--rtt-iters", type=int, default=100000)
     args = ap.parse_args()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # Multi-GPU runs measure the headline (and the fan-out leg) only: the comparison legs are
+        # single-GPU questions, and a leg that failed on one rank alone would leave the others waiting
+        # in its barrier.
+        args.no_extra_legs = True
+        args.no_small_ring = True
+        args.conns = 1
 
     import torch
     from_env = (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
