@@ -326,3 +326,44 @@ def test_burst_rounds_equal_the_oracle(gpu, case, graph):
     link.check(job, 0, exp, exact=True)
     job.close()
     link.close()
+
+
+@pytest.mark.parametrize("case", [(1 << 22, 30, 8, 1 << 20, 16), (1 << 16, 30, 40, 20000, 3), (1 << 18, 64, 30, 9000, 5)],
+                         ids=["r4m_sge30_b16", "r64k_b3", "r256k_sge64_b5"])
+def test_burst_rounds_direct_wire(gpu, case):
+    """Burst rounds with GRDMA_WIRE_DIRECT: the Sends of a round build their records in the peer
+    ring itself (no staging, no wire launch); a record that crosses the ring end is two segments."""
+    from grpc_rdma_amd import stream as gs
+    R, sge, n_msgs, msg_len, burst = case
+    wire, lens = framed(n_msgs, msg_len, seed=R + burst)
+    exp = pyorc.stream_rounds(R, sge, wire, lens, passes=PASSES, burst=burst)
+    link = Link(gpu, R, sge, wire, lens, flags=2)
+    job = gs.MultiStreamJob([link.spec()], 4 * (exp["rounds"] + 8))
+    job.set_burst(burst)
+    for _ in range(PASSES):
+        r = job.run(gs.RUN_EAGER)
+        assert r.done and r.bytes_delivered == link.N == r.bytes_sent
+    link.check(job, 0, exp, exact=True)
+    job.close()
+    link.close()
+
+
+def test_burst_rounds_three_links(gpu):
+    """Three connections of different shapes advance in lock step, 6 Sends per round each."""
+    from grpc_rdma_amd import stream as gs
+    shapes = [(1 << 20, 30, 12, 50000), (1 << 18, 30, 20, 7000), (1 << 22, 30, 3, 1 << 20)]
+    links, exps = [], []
+    for i, (R, sge, n_msgs, msg_len) in enumerate(shapes):
+        wire, lens = framed(n_msgs, msg_len, seed=70 + i)
+        exps.append(pyorc.stream_rounds(R, sge, wire, lens, passes=2, burst=6))
+        links.append(Link(gpu, R, sge, wire, lens, seed=i))
+    job = gs.MultiStreamJob([l.spec() for l in links], 4 * (max(e["rounds"] for e in exps) + 8))
+    job.set_burst(6)
+    for _ in range(2):
+        r = job.run(gs.RUN_EAGER)
+        assert r.done and r.bytes_delivered == sum(l.N for l in links)
+    for i, l in enumerate(links):
+        l.check(job, i, exps[i], exact=True)
+    job.close()
+    for l in links:
+        l.close()
