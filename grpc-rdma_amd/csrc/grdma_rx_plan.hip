@@ -1443,6 +1443,15 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_engine(
   return hipGetLastError();
 }
 
+// profiling aid: phase ticks of the small-send wave inside the latency engine
+// {slice loads, pricing, copies issued, copies acknowledged, bookkeeping stores, release, count}
+extern "C" int grdma_tx_small_ticks(uint64_t out[8]) {
+  unsigned long long v[8];
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_tx_small_ticks), sizeof(v)) != hipSuccess) return -1;
+  for (int i = 0; i < 8; i++) out[i] = v[i];
+  return 0;
+}
+
 extern "C" uint64_t grdma_express_drains(void) {
   unsigned long long v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_express_drains), sizeof(v)) != hipSuccess) return 0;

@@ -15,8 +15,13 @@ namespace {
 // single __ballot; no LDS, no barriers.  The wave then writes the tags, moves
 // the payload and performs the wire write itself.
 // ----------------------------------------------------------------------------
+// profiling aid: ticks spent in the phases of tx_small_wave (per translation unit; the latency
+// engine's copy is read by grdma_tx_small_ticks)
+static __device__ unsigned long long g_tx_small_ticks[8];
+
 __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t start,
                                               uint64_t byte_idx, uint64_t avail, int lane) {
+  const uint64_t tk0 = __builtin_amdgcn_s_memtime();
   grdma_conn* c = op.conn;
   const uint64_t cap = c->cap, mask = cap - 1, S = c->staging_cap, tail0 = c->remote_tail;
   const uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED,
@@ -36,6 +41,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
       src += byte_idx;
     }
   }
+  const uint64_t tk1 = __builtin_amdgcn_s_memtime() + (len & 0);  // (after the slice loads)
   // total offered (pair.cc:660-663)
   uint64_t offered = len;
 #pragma unroll
@@ -68,6 +74,56 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) sent += __shfl_xor(sent, d, 64);
 
+  const uint64_t tk2 = __builtin_amdgcn_s_memtime() + (sent & 0);  // (after pricing)
+  const uint64_t seg1 = staged < cap - tail0 ? staged : cap - tail0;
+  uint8_t* const peer_ring = c->peer_ring;
+  if (nrec_total >= 1 && nrec_total <= 4 && __ballot(my_pay > 256) == 0 && peer_ring != nullptr) {
+    // ---- unary-sized Sends: at most four records of at most 256 bytes ------------------------
+    // Every payload byte is loaded BEFORE the first store (a load that is waited for behind a
+    // store waits for the store: the memory counter is in order), from clamped addresses (no load
+    // under a branch); then the records go to staging AND to the peer ring from registers -- the
+    // <= 2 RDMA WRITEs of GetWriteRequests (ring_buffer.cc:261-330) without reading staging back.
+    // The ring's footers are stored last, once everything in front of them is acknowledged
+    // (a record becomes visible to the peer with its footer, ring_buffer.cc:67-97).
+    uint8_t b[4][4];
+    uint32_t rp[4], rst[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int rr = (uint64_t)r < nrec_total ? r : 0;
+      rp[r] = (uint32_t)__shfl(my_pay, rr, 64);
+      rst[r] = (uint32_t)__shfl((uint32_t)st, rr, 64);
+      const uint8_t* sp = reinterpret_cast<const uint8_t*>(__shfl((uint64_t)src, rr, 64));
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t o = (uint32_t)lane + 64u * k;
+        b[r][k] = sp[o < rp[r] ? o : rp[r] - 1];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if ((uint64_t)r >= nrec_total) break;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t o = (uint32_t)lane + 64u * k;
+        if (o < rp[r]) {
+          if (!direct) c->staging[rst[r] + 8 + o] = b[r][k];
+          peer_ring[(tail0 + rst[r] + 8 + o) & mask] = b[r][k];
+        }
+      }
+    }
+    if (my_pay > 0) {  // lane i owns the tags of record i
+      const uint64_t pad_end = round_up8(my_pay);
+      if (!direct) {
+        *reinterpret_cast<uint64_t*>(c->staging + st) = my_pay;
+        *reinterpret_cast<uint64_t*>(c->staging + st + 8 + pad_end) = GRDMA_FOOTER;
+        for (uint64_t q = my_pay; q < pad_end; q++) c->staging[st + 8 + q] = 0;
+      }
+      *reinterpret_cast<uint64_t*>(peer_ring + ((tail0 + st) & mask)) = my_pay;
+      for (uint64_t q = my_pay; q < pad_end; q++) peer_ring[(tail0 + st + 8 + q) & mask] = 0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *reinterpret_cast<uint64_t*>(peer_ring + ((tail0 + st + 8 + pad_end) & mask)) = GRDMA_FOOTER;
+    }
+  } else {
   // tags (AppendHeader / AppendFooter, ring_buffer.h:84-99) and zero padding
   uint64_t pay_off = 0;
   if (my_pay > 0) {
@@ -95,7 +151,6 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     }
   }
   // wire: the <= 2 RDMA WRITEs of GetWriteRequests (ring_buffer.cc:261-330)
-  const uint64_t seg1 = staged < cap - tail0 ? staged : cap - tail0;
   if (!direct && staged > 0 && c->peer_ring != nullptr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // staging complete before it is read back
     for (uint64_t done = 0; done < staged;) {
@@ -112,7 +167,10 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
       done += n;
     }
   }
+  }
+  const uint64_t tk3 = __builtin_amdgcn_s_memtime();  // (copies issued)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint64_t tk4 = __builtin_amdgcn_s_memtime();  // (copies acknowledged)
   if (lane == 0) {
     grdma_plan* plan = op.plan;
     plan->nsegs = 0;
@@ -163,10 +221,19 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     r->slice_idx = idx;
     r->byte_idx = bidx;
     r->done = (idx >= op.nslices) ? 1 : 0;
+    const uint64_t tk5 = __builtin_amdgcn_s_memtime();  // (bookkeeping stores issued)
     // the peer reads the ring in a later command / kernel; the host needs the result
     // block (pinned memory): a system-scope release on the sequence word covers it
     __hip_atomic_store(&r->seq, op.seq_next ? op.seq_next : r->seq + 1, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t tk6 = __builtin_amdgcn_s_memtime();
+    g_tx_small_ticks[0] += tk1 - tk0;
+    g_tx_small_ticks[1] += tk2 - tk1;
+    g_tx_small_ticks[2] += tk3 - tk2;
+    g_tx_small_ticks[3] += tk4 - tk3;
+    g_tx_small_ticks[4] += tk5 - tk4;
+    g_tx_small_ticks[5] += tk6 - tk5;
+    g_tx_small_ticks[6] += 1;
   }
 }
 

@@ -330,6 +330,7 @@ int grdma_pair_debug_hist(grdma_pair* p, uint32_t* hist_out /* 1024 entries */, 
                           uint32_t* period);
 int grdma_engine_debug(uint64_t out[5]);
 uint64_t grdma_express_drains(void);  /* drains served by the single-wave express path so far */
+int grdma_tx_small_ticks(uint64_t out[8]);  /* profiling aid: phase ticks of the latency engine's small Sends */
 /* Scalar ring arithmetic of the host layer (ring_buffer.h:101-143), exported so that the
  * CPU tests can pin it against the oracle without a device. */
 uint64_t grdma_host_free_size(uint64_t cap, uint64_t head, uint64_t tail);

@@ -24,6 +24,8 @@ for mode in ('engine',):
     if mode == 'engine':
         d=(C.c_uint64*5)(); lib.grdma_engine_debug(d); ops=2*(n+100)
         print('engine cycles per op: send load %d body %d | drain load %d body %d' % (d[0]//ops, d[1]//ops, d[2]//ops, d[3]//ops))
+        tk=(C.c_uint64*8)(); lib.grdma_tx_small_ticks(tk); cnt=max(1,int(tk[6]))
+        print('small-send phases (cycles per send): loads %d pricing %d copies-issue %d copies-ack %d bookkeeping %d release %d' % tuple(int(tk[i])//cnt for i in range(6)))
         lib.grdma_engine_stop()
         lib.grdma_express_drains.restype=C.c_uint64
         print('express drains:', lib.grdma_express_drains(), 'of', ops, 'drains')
