@@ -354,13 +354,21 @@ int hip_get_fd(grpc_endpoint* ep) { return reinterpret_cast<grpc_rdma_hip*>(ep)-
 grpc_resource_user* hip_get_resource_user(grpc_endpoint* ep) {
   return reinterpret_cast<grpc_rdma_hip*>(ep)->resource_user;
 }
-bool hip_can_track_err(grpc_endpoint* ep) {  // :621-633
-  grpc_rdma_hip* rdma = reinterpret_cast<grpc_rdma_hip*>(ep);
+bool hip_can_track_err(grpc_endpoint* ep) {  // :621-633: only IP sockets on an engine that tracks errors
   if (!grpc_event_engine_can_track_errors()) return false;
-  struct sockaddr addr;
-  socklen_t len = sizeof(addr);
-  if (getsockname(rdma->fd, &addr, &len) < 0) return false;
-  return addr.sa_family == AF_INET || addr.sa_family == AF_INET6;
+  struct sockaddr sa;
+  socklen_t sa_len = sizeof sa;
+  const int fd = reinterpret_cast<grpc_rdma_hip*>(ep)->fd;
+  return getsockname(fd, &sa, &sa_len) == 0 && (sa.sa_family == AF_INET || sa.sa_family == AF_INET6);
+}
+
+// the URI of the bootstrap socket's local end ("" when the fd has no name), :716-726
+std::string local_uri_of(int fd) {
+  grpc_resolved_address a;
+  memset(&a, 0, sizeof a);
+  a.len = sizeof a.addr;
+  if (getsockname(fd, reinterpret_cast<sockaddr*>(a.addr), &a.len) < 0) return std::string();
+  return grpc_sockaddr_to_uri(&a);
 }
 
 const grpc_endpoint_vtable vtable = {hip_read,
@@ -392,14 +400,7 @@ grpc_endpoint* grpc_rdma_bp_create(grpc_fd* em_fd, const grpc_channel_args* /*ch
   rdma->base.vtable = &vtable;
   rdma->peer_string = peer_string;
   rdma->fd = grpc_fd_wrapped_fd(em_fd);
-  grpc_resolved_address resolved_local_addr;
-  memset(&resolved_local_addr, 0, sizeof(resolved_local_addr));
-  resolved_local_addr.len = sizeof(resolved_local_addr.addr);
-  if (getsockname(rdma->fd, reinterpret_cast<sockaddr*>(resolved_local_addr.addr), &resolved_local_addr.len) < 0) {
-    rdma->local_address = "";
-  } else {
-    rdma->local_address = grpc_sockaddr_to_uri(&resolved_local_addr);
-  }
+  rdma->local_address = local_uri_of(rdma->fd);
   rdma->read_cb = nullptr;
   rdma->write_cb = nullptr;
   rdma->incoming_buffer = nullptr;
