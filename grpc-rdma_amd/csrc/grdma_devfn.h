@@ -329,7 +329,7 @@ __device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane)
 // ballot, and the walk reads the next prefix entry from memory.
 // LDS_N: slots of the staged prefix -- 8192 in the copy kernels (32 KB, occupancy is
 // bound by registers there), 1024 where a plan workgroup runs its own small plan inline.
-template <uint32_t LDS_N, bool CONTIG = true>
+template <uint32_t LDS_N, bool CONTIG = true, uint32_t TILE = GRDMA_TILE_BYTES>
 __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t wave,
                                                uint32_t nwaves, int lane) {
   __shared__ uint32_t s_prefix[LDS_N + 1];
@@ -370,15 +370,15 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
   }
   grdma_seg sg = plan->segs[seg];
   for (;; ) {
-    const uint64_t off = (uint64_t)(t - p0) * GRDMA_TILE_BYTES;
+    const uint64_t off = (uint64_t)(t - p0) * TILE;
     uint64_t n = sg.len - off;
-    if (n > GRDMA_TILE_BYTES) n = GRDMA_TILE_BYTES;
+    if (n > TILE) n = TILE;
     uint8_t* src = sg.src ? reinterpret_cast<uint8_t*>(sg.src + off) : nullptr;
     // (nontemporal loads: payload streams through once; plain stores: the next kernel of the
     // round reads what this one wrote out of the Infinity Cache)
     if (src == nullptr) wave_zero_tile(reinterpret_cast<uint8_t*>(sg.dst + off), n, lane);
-    else if (sg.flags & GRDMA_SEG_ZERO_SRC) wave_move_tile<2, 0, true>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
-    else wave_move_tile<2, 0, false>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
+    else if (sg.flags & GRDMA_SEG_ZERO_SRC) wave_move_tile<2, 0, true, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
+    else wave_move_tile<2, 0, false, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
     if (sg.flags & (GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR)) {
       const bool wr = (sg.flags & GRDMA_SEG_TAG_WRITE) != 0;
       const uint64_t side = wr ? sg.dst : sg.src;

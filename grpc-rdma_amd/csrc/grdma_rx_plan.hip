@@ -190,7 +190,7 @@ __device__ __forceinline__ rec_plan32 replay_record32(uint32_t n, uint32_t s_in)
 }
 __device__ __forceinline__ uint32_t al16_32(uint32_t v) { return (v + 15u) & ~15u; }
 __device__ __forceinline__ uint32_t tiles_of32(uint32_t len) {
-  return (len + (uint32_t)GRDMA_TILE_BYTES - 1u) / (uint32_t)GRDMA_TILE_BYTES;
+  return (len + (uint32_t)GRDMA_RX_TILE_BYTES - 1u) / (uint32_t)GRDMA_RX_TILE_BYTES;
 }
 
 // The ring pieces of one record's steps: step 1 = pieces 0,1; step 2 = pieces 2,3
@@ -210,7 +210,7 @@ __device__ __forceinline__ void split_step(uint64_t pay, uint64_t off, uint64_t 
 
 __device__ __forceinline__ uint64_t al16(uint64_t v) { return (v + 15) & ~15ull; }
 __device__ __forceinline__ uint32_t tiles_of(uint64_t len) {
-  return (uint32_t)((len + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+  return (uint32_t)((len + GRDMA_RX_TILE_BYTES - 1) / GRDMA_RX_TILE_BYTES);
 }
 
 // Everything the tiers share, kept in LDS between the phases of the kernel.
@@ -1190,7 +1190,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
       plan->tag_mask = mask;
     }
     __syncthreads();
-    run_plan_tiles<1024>(plan, wave, PLAN_THREADS / 64, lane);
+    run_plan_tiles<1024, true, (uint32_t)GRDMA_RX_TILE_BYTES>(plan, wave, PLAN_THREADS / 64, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
