@@ -693,8 +693,11 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
         const uint32_t n = s_n[RXP(k)];
         const rec_plan32 rp = replay_record32(n, s_sin[RXP(k)]);
         const uint32_t pay = (head32 + s_xenc[RXP(k)] + 8u) & mask32;
-        uint32_t sg = 1u + (rp.c2 ? 1u : 0u);
-        uint32_t tl = tiles_of32(rp.c1) + tiles_of32(rp.c2);
+        // (the two steps of a record are contiguous in the ring AND in the arena -- step 1 fills
+        // the open slice exactly, step 2 starts the next one right behind it -- so they travel
+        // as ONE segment unless the record crosses the ring end)
+        uint32_t sg = 1u;
+        uint32_t tl = tiles_of32(rp.c1 + rp.c2);
         if (pay + n > cap32 || pay + n < pay) {  // crosses the ring end: split the step(s) it cuts
           uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
           split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
@@ -753,6 +756,10 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
         o2 = (uint32_t)a2; l2 = (uint32_t)b2; o3 = (uint32_t)a3; l3 = (uint32_t)b3;
       }
       if (!act) l0 = 0;
+      else if (l1 == 0 && l3 == 0) {  // no ring wrap: one segment for both steps (see pass 1)
+        l0 += l2;
+        l2 = 0;
+      }
       const uint32_t my_sg = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
       const uint32_t my_pk = rp.sl_cnt | (my_sg << 16);
       const uint32_t my_tiles = tiles_of32(l0) + tiles_of32(l1) + tiles_of32(l2) + tiles_of32(l3);
