@@ -21,8 +21,14 @@
 #define GRDMA_MAX_SLICES 8192       // delivered slices per receive plan
 #define GRDMA_TX_MAX_RECORDS 4096   // records priced by one send plan
 #define GRDMA_RX_HIST 1024          // record sizes remembered per connection
-#define GRDMA_TILE_BYTES 8192ull    // bytes one wave copies per tile of a SEND-side plan (gather, wire): 64 lanes x 16 B x 8 loads in flight
-#define GRDMA_RX_TILE_BYTES 16384ull  // ... of a scatter plan: 16 loads in flight (a 16137-byte slice is one tile; measured 26.5 vs 29.6 us)
+#define GRDMA_TILE_BYTES 8192ull    // chunk of the single-wave inline copies (latency paths)
+// Bytes one wave copies per tile of a plan: 16 KiB (64 lanes x 16 B x 16 loads in flight) for
+// connections with rings of 32 MiB and more -- a 16 KiB payload is then ONE tile and most plans
+// hold one tile per segment, which the copy kernels run without any search (measured at the bench
+// configuration: k_rx_apply 29.6 -> 23.4 us, gather 18.9 -> 17.9 us) --, 8 KiB below that, where a
+// launch moves a few hundred KB to 2 MB and the smaller tile keeps more waves busy.  The planner
+// writes its choice into the plan (grdma_plan::tile_bytes); the copy kernels follow it.
+#define GRDMA_PLAN_TILE_SHIFT(ring_cap) ((ring_cap) >= (32ull << 20) ? 14u : 13u)
 #define GRDMA_MIN_READ_SLICE 256ull // rdma_bp_posix.cc:308
 
 // PairStatus, pair.h:44-51 (also in the public header: what grdma_pair_get_status returns)
@@ -174,6 +180,8 @@ struct grdma_plan {
   uint64_t bytes;
   uint64_t tag_base;   // window for the record tags of GRDMA_SEG_TAG_* segments
   uint64_t tag_mask;
+  uint32_t tile_bytes; // 8192 or 16384: what tile_prefix counts in (GRDMA_PLAN_TILE_SHIFT)
+  uint32_t pad_tile;
   struct grdma_seg segs[GRDMA_MAX_SEGS];
   uint32_t tile_prefix[GRDMA_MAX_SEGS + 1];
   // k_rx_apply arrival counter (the last workgroup commits).  It lives in the plan -- always

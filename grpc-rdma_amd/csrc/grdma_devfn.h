@@ -329,12 +329,47 @@ __device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane)
 // ballot, and the walk reads the next prefix entry from memory.
 // LDS_N: slots of the staged prefix -- 8192 in the copy kernels (32 KB, occupancy is
 // bound by registers there), 1024 where a plan workgroup runs its own small plan inline.
-template <uint32_t LDS_N, bool CONTIG = true, uint32_t TILE = GRDMA_TILE_BYTES>
+// One tile of segment sg (bytes [off, off + n)), plus the record tags the segment carries.
+template <uint32_t TILE>
+__device__ __forceinline__ void plan_tile(const grdma_seg& sg, uint64_t off, uint64_t n, uint64_t tag_base, uint64_t tm, int lane) {
+  // (nontemporal loads: payload streams through once; plain stores: the next kernel of the
+  // round reads what this one wrote out of the Infinity Cache)
+  if (sg.src == 0) wave_zero_tile(reinterpret_cast<uint8_t*>(sg.dst + off), n, lane);
+  else if (sg.flags & GRDMA_SEG_ZERO_SRC) wave_move_tile<2, 0, true, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
+  else wave_move_tile<2, 0, false, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
+  if (sg.flags & (GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR)) {
+    const bool wr = (sg.flags & GRDMA_SEG_TAG_WRITE) != 0;
+    const uint64_t side = wr ? sg.dst : sg.src;
+    uint8_t* const tb = reinterpret_cast<uint8_t*>(tag_base);
+    if ((sg.flags & GRDMA_SEG_TAG_HDR) && off == 0 && lane == 0)
+      *reinterpret_cast<uint64_t*>(tb + ((side - 8 - tag_base) & tm)) = wr ? (sg.flags >> GRDMA_SEG_TAG_LEN_SHIFT) : 0;
+    if ((sg.flags & GRDMA_SEG_TAG_FTR) && off + n == sg.len) {
+      const uint64_t e = (side + sg.len - tag_base) & tm;  // first byte behind the payload
+      const uint64_t pad = (0 - e) & 7;
+      if ((uint64_t)lane < pad) tb[e + lane] = 0;
+      if (lane == 8) *reinterpret_cast<uint64_t*>(tb + ((e + pad) & tm)) = wr ? GRDMA_FOOTER : 0;
+    }
+  }
+}
+
+template <uint32_t LDS_N, bool CONTIG, uint32_t TILE>
 __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t wave,
                                                uint32_t nwaves, int lane) {
   __shared__ uint32_t s_prefix[LDS_N + 1];
   const uint32_t nsegs = plan->nsegs;
   const uint32_t ntiles = plan->ntiles;
+  const uint64_t tag_base = plan->tag_base, tm = plan->tag_mask;
+  // In flight together with the header: the segment of tile `wave`, should the plan turn out to
+  // hold one tile per segment (the steady state of both the gather and the scatter: tile t then IS
+  // segment t -- no prefix staging, no search, no barrier, one memory round trip less).
+  const grdma_seg spec = plan->segs[wave < GRDMA_MAX_SEGS ? wave : 0];
+  if (ntiles == nsegs) {  // (uniform over the workgroup; every segment has at least one tile)
+    for (uint32_t t = wave; t < ntiles; t += nwaves) {
+      const grdma_seg sg = t == wave ? spec : plan->segs[t];
+      plan_tile<TILE>(sg, 0, sg.len, tag_base, tm, lane);
+    }
+    return;
+  }
   uint32_t shift = 0;  // entry k of s_prefix is tile_prefix[k << shift]
   while (((nsegs >> shift) + 1) > LDS_N) shift++;
   const uint32_t nsamp = (nsegs >> shift) + 1;  // samples 0 .. nsegs >> shift
@@ -373,27 +408,7 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
     const uint64_t off = (uint64_t)(t - p0) * TILE;
     uint64_t n = sg.len - off;
     if (n > TILE) n = TILE;
-    uint8_t* src = sg.src ? reinterpret_cast<uint8_t*>(sg.src + off) : nullptr;
-    // (nontemporal loads: payload streams through once; plain stores: the next kernel of the
-    // round reads what this one wrote out of the Infinity Cache)
-    if (src == nullptr) wave_zero_tile(reinterpret_cast<uint8_t*>(sg.dst + off), n, lane);
-    else if (sg.flags & GRDMA_SEG_ZERO_SRC) wave_move_tile<2, 0, true, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
-    else wave_move_tile<2, 0, false, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
-    if (sg.flags & (GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR)) {
-      const bool wr = (sg.flags & GRDMA_SEG_TAG_WRITE) != 0;
-      const uint64_t side = wr ? sg.dst : sg.src;
-      uint8_t* const tb = reinterpret_cast<uint8_t*>(plan->tag_base);
-      const uint64_t tm = plan->tag_mask;
-      if ((sg.flags & GRDMA_SEG_TAG_HDR) && off == 0 && lane == 0)
-        *reinterpret_cast<uint64_t*>(tb + ((side - 8 - plan->tag_base) & tm)) =
-            wr ? (sg.flags >> GRDMA_SEG_TAG_LEN_SHIFT) : 0;
-      if ((sg.flags & GRDMA_SEG_TAG_FTR) && off + n == sg.len) {
-        const uint64_t e = (side + sg.len - plan->tag_base) & tm;  // first byte behind the payload
-        const uint64_t pad = (0 - e) & 7;
-        if ((uint64_t)lane < pad) tb[e + lane] = 0;
-        if (lane == 8) *reinterpret_cast<uint64_t*>(tb + ((e + pad) & tm)) = wr ? GRDMA_FOOTER : 0;
-      }
-    }
+    plan_tile<TILE>(sg, off, n, tag_base, tm, lane);
     if (++t >= tend) {
       if (CONTIG) break;
       t += nwaves - 1;
@@ -413,5 +428,12 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
   }
 }
 
+
+// The plan says which tile size it was laid out for.
+template <uint32_t LDS_N, bool CONTIG = true>
+__device__ __forceinline__ void run_plan(const grdma_plan* plan, uint32_t wave, uint32_t nwaves, int lane) {
+  if (plan->tile_bytes == 16384u) run_plan_tiles<LDS_N, CONTIG, 16384u>(plan, wave, nwaves, lane);
+  else run_plan_tiles<LDS_N, CONTIG, 8192u>(plan, wave, nwaves, lane);
+}
 
 #endif  // GRDMA_DEVFN_H

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(COPY_THREADS) void k_copy(const grdma_plan* const* 
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * COPY_THREADS + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * COPY_THREADS) >> 6;
-  run_plan_tiles<256, GRDMA_COPY_CONTIG>(plan, wave, nwaves, lane);
+  run_plan<256, GRDMA_COPY_CONTIG>(plan, wave, nwaves, lane);
 }
 
 // ----------------------------------------------------------------------------
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(COPY_THREADS) void k_rx_apply(const grdma_rx_op* op
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * COPY_THREADS + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * COPY_THREADS) >> 6;
-  run_plan_tiles<256, GRDMA_APPLY_CONTIG, (uint32_t)GRDMA_RX_TILE_BYTES>(op.plan, wave, nwaves, lane);
+  run_plan<256, GRDMA_APPLY_CONTIG>(op.plan, wave, nwaves, lane);
   // arrival: my stores have been issued and acknowledged (vmcnt(0)); count in,
   // the last workgroup publishes.  Consumers on this device run in later
   // kernels of the stream (a kernel boundary makes the writes visible); a ring

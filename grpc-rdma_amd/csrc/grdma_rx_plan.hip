@@ -189,9 +189,7 @@ __device__ __forceinline__ rec_plan32 replay_record32(uint32_t n, uint32_t s_in)
   return r;
 }
 __device__ __forceinline__ uint32_t al16_32(uint32_t v) { return (v + 15u) & ~15u; }
-__device__ __forceinline__ uint32_t tiles_of32(uint32_t len) {
-  return (len + (uint32_t)GRDMA_RX_TILE_BYTES - 1u) / (uint32_t)GRDMA_RX_TILE_BYTES;
-}
+__device__ __forceinline__ uint32_t tiles_of32(uint32_t len, uint32_t ts) { return (len + (1u << ts) - 1u) >> ts; }
 
 // The ring pieces of one record's steps: step 1 = pieces 0,1; step 2 = pieces 2,3
 // (the second piece of a step exists only when the step crosses the ring end).
@@ -209,9 +207,7 @@ __device__ __forceinline__ void split_step(uint64_t pay, uint64_t off, uint64_t 
 }
 
 __device__ __forceinline__ uint64_t al16(uint64_t v) { return (v + 15) & ~15ull; }
-__device__ __forceinline__ uint32_t tiles_of(uint64_t len) {
-  return (uint32_t)((len + GRDMA_RX_TILE_BYTES - 1) / GRDMA_RX_TILE_BYTES);
-}
+__device__ __forceinline__ uint32_t tiles_of(uint64_t len, uint32_t ts) { return (uint32_t)((len + (1ull << ts) - 1) >> ts); }
 
 // Everything the tiers share, kept in LDS between the phases of the kernel.
 struct rx_state {
@@ -244,6 +240,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
   grdma_rx_result* res = op.result;
   uint8_t* ring = c->ring;
   const uint64_t cap = c->cap, mask = cap - 1;
+  const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap);  // tile size of this connection's plans
   const bool connected = c->status == GRDMA_PAIR_CONNECTED;
 
   __shared__ rx_state S;
@@ -697,13 +694,13 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
         // the open slice exactly, step 2 starts the next one right behind it -- so they travel
         // as ONE segment unless the record crosses the ring end)
         uint32_t sg = 1u;
-        uint32_t tl = tiles_of32(rp.c1 + rp.c2);
+        uint32_t tl = tiles_of32(rp.c1 + rp.c2, ts);
         if (pay + n > cap32 || pay + n < pay) {  // crosses the ring end: split the step(s) it cuts
           uint64_t o0, l0, o1, l1, o2, l2, o3, l3;
           split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
           split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
           sg = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
-          tl = tiles_of(l0) + tiles_of(l1) + tiles_of(l2) + tiles_of(l3);
+          tl = tiles_of(l0, ts) + tiles_of(l1, ts) + tiles_of(l2, ts) + tiles_of(l3, ts);
         }
         t_bytes += al16_32(rp.sl0) + al16_32(rp.sl1);
         t_pk += rp.sl_cnt + (sg << 16);
@@ -762,7 +759,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
       }
       const uint32_t my_sg = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
       const uint32_t my_pk = rp.sl_cnt | (my_sg << 16);
-      const uint32_t my_tiles = tiles_of32(l0) + tiles_of32(l1) + tiles_of32(l2) + tiles_of32(l3);
+      const uint32_t my_tiles = tiles_of32(l0, ts) + tiles_of32(l1, ts) + tiles_of32(l2, ts) + tiles_of32(l3, ts);
       // (the ring holds < 2^31 bytes in a bulk pass, so 32-bit scans of one step's bytes are exact)
       const uint32_t my_bytes = al16_32(rp.sl0) + al16_32(rp.sl1);
       const uint32_t i_pk = wave_incl_scan_u32(my_pk);
@@ -787,7 +784,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
           plan->segs[nsegs0 + x_sg] = {dst, (uint64_t)(ring + off), (uint64_t)len, fl};
           plan->tile_prefix[nsegs0 + x_sg] = x_tiles;
           x_sg++;
-          x_tiles += tiles_of32(len);
+          x_tiles += tiles_of32(len, ts);
           dst += len;
         };
         emit(o0, l0, 0);
@@ -942,14 +939,14 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
         plan->segs[nsegs] = {dst, (uint64_t)(ring + mh), l1, GRDMA_SEG_ZERO_SRC};
         plan->tile_prefix[nsegs] = (uint32_t)ntiles;
       }
-      ntiles += tiles_of(l1);
+      ntiles += tiles_of(l1, ts);
       nsegs++;
       if (cpy > l1) {
         if (lane == 0) {
           plan->segs[nsegs] = {dst + l1, (uint64_t)ring, cpy - l1, GRDMA_SEG_ZERO_SRC};
           plan->tile_prefix[nsegs] = (uint32_t)ntiles;
         }
-        ntiles += tiles_of(cpy - l1);
+        ntiles += tiles_of(cpy - l1, ts);
         nsegs++;
       }
       mh = (mh + cpy) & mask;
@@ -1014,7 +1011,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
       split_step(pay, 0, rp.c1, cap, &o0, &l0, &o1, &l1);
       split_step(pay, rp.c1, rp.c2, cap, &o2, &l2, &o3, &l3);
       const uint32_t sg_cnt = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
-      const uint32_t my_tiles = tiles_of(l0) + tiles_of(l1) + tiles_of(l2) + tiles_of(l3);
+      const uint32_t my_tiles = tiles_of(l0, ts) + tiles_of(l1, ts) + tiles_of(l2, ts) + tiles_of(l3, ts);
       const uint32_t packed = rp.sl_cnt | (sg_cnt << 16);
       const uint32_t i_packed = wave_incl_scan_u32(packed);
       const uint32_t i_tiles = wave_incl_scan_u32(my_tiles);
@@ -1031,7 +1028,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
           plan->segs[nsegs + x_segs] = {dst, (uint64_t)(ring + off), len, fl};
           plan->tile_prefix[nsegs + x_segs] = (uint32_t)(ntiles + x_tiles);
           x_segs++;
-          x_tiles += tiles_of(len);
+          x_tiles += tiles_of(len, ts);
           dst += len;
         };
         emit(o0, l0, 0);
@@ -1192,12 +1189,13 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     if (tid == 0) {
       plan->nsegs = (uint32_t)S.nsegs;
       plan->ntiles = (uint32_t)S.ntiles;
+      plan->tile_bytes = 1u << ts;
       plan->tile_prefix[S.nsegs] = (uint32_t)S.ntiles;
       plan->tag_base = (uint64_t)ring;
       plan->tag_mask = mask;
     }
     __syncthreads();
-    run_plan_tiles<1024, true, (uint32_t)GRDMA_RX_TILE_BYTES>(plan, wave, PLAN_THREADS / 64, lane);
+    run_plan<1024, true>(plan, wave, PLAN_THREADS / 64, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -1212,6 +1210,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     const uint64_t head = S.head, mh = S.mh, nsegs = S.nsegs, nslices = S.nslices;
     plan->nsegs = (uint32_t)nsegs;
     plan->ntiles = (uint32_t)S.ntiles;
+    plan->tile_bytes = 1u << ts;
     plan->tile_prefix[nsegs] = (uint32_t)S.ntiles;
     plan->bytes = S.bytes;
     plan->tag_base = (uint64_t)ring;

@@ -175,11 +175,13 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     grdma_plan* plan = op.plan;
     plan->nsegs = 0;
     plan->ntiles = 0;
+    plan->tile_bytes = 1u << GRDMA_PLAN_TILE_SHIFT(cap);
     plan->tile_prefix[0] = 0;
     plan->bytes = sent;
     if (op.wire_plan != nullptr) {
       op.wire_plan->nsegs = 0;
       op.wire_plan->ntiles = 0;
+      op.wire_plan->tile_bytes = 1u << GRDMA_PLAN_TILE_SHIFT(cap);
       op.wire_plan->tile_prefix[0] = 0;
       op.wire_plan->bytes = direct ? 0 : staged;
     }
@@ -465,6 +467,8 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
 
   tdbg[4] = __builtin_amdgcn_s_memtime();
   // tile prefix per segment (contiguous runs again, out of LDS)
+  const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap);
+  const uint64_t TB = 1ull << ts;
   uint64_t ntiles;
   {
     const uint64_t per2 = (nrec_total + PLAN_THREADS - 1) / PLAN_THREADS;
@@ -474,10 +478,10 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
         const uint64_t pay_off = (tail0 + s_excl[TXP(i)] + 16) & mask;  // (hdr_off + 8) & mask
         const uint64_t l1 = cap - ((tail0 + s_excl[TXP(i)] + 8) & mask);
         (void)pay_off;
-        *t1 = (l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
-        return *t1 + (p - l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
+        *t1 = (l1 + TB - 1) >> ts;
+        return *t1 + ((p - l1 + TB - 1) >> ts);
       }
-      *t1 = (p + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
+      *t1 = (p + TB - 1) >> ts;
       return *t1;
     };
     uint64_t chunk = 0, t1;
@@ -503,6 +507,7 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
   if (tid == 0) {
     plan->nsegs = (uint32_t)nsegs;
     plan->ntiles = (uint32_t)ntiles;
+    plan->tile_bytes = (uint32_t)TB;
     plan->tile_prefix[nsegs] = (uint32_t)ntiles;
     plan->bytes = sent;
     plan->tag_base = (uint64_t)dbase;
@@ -529,17 +534,18 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
       if (!direct && staged > 0) {
         wp->segs[0] = {(uint64_t)(c->peer_ring + tail0), (uint64_t)staging, seg1, 0};
         wp->tile_prefix[0] = 0;
-        nt = (uint32_t)((seg1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+        nt = (uint32_t)((seg1 + TB - 1) >> ts);
         ns = 1;
         if (staged > seg1) {
           wp->segs[1] = {(uint64_t)c->peer_ring, (uint64_t)(staging + seg1), staged - seg1, 0};
           wp->tile_prefix[1] = nt;
-          nt += (uint32_t)((staged - seg1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+          nt += (uint32_t)((staged - seg1 + TB - 1) >> ts);
           ns = 2;
         }
       }
       wp->nsegs = ns;
       wp->ntiles = nt;
+      wp->tile_bytes = (uint32_t)TB;
       wp->tile_prefix[ns] = nt;
       wp->bytes = direct ? 0 : staged;
     }
@@ -580,11 +586,11 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
     // small-message path: the planning workgroup moves the bytes itself (its
     // own plan stores are visible to its waves after the barrier)
     __syncthreads();
-    run_plan_tiles<1024>(plan, tid >> 6, PLAN_THREADS / 64, tid & 63);
+    run_plan<1024>(plan, tid >> 6, PLAN_THREADS / 64, tid & 63);
     if (op.wire_plan != nullptr && !direct) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      run_plan_tiles<1024>(op.wire_plan, tid >> 6, PLAN_THREADS / 64, tid & 63);
+      run_plan<1024>(op.wire_plan, tid >> 6, PLAN_THREADS / 64, tid & 63);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -625,6 +631,8 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
   uint64_t total_written = c->total_written, records = c->tx_records, rounds = c->tx_rounds;
   uint32_t last_records = c->tx_last_records, partial = (uint32_t)c->partial_write;
   if (idx > nslices) idx = nslices;
+  const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap);
+  const uint64_t TB = 1ull << ts;
 
   bool dry = false;  // a Send accepted nothing: nothing changes until the peer reads, the rest accept nothing either
   for (uint32_t k = 0; k < burst; k++) {
@@ -636,11 +644,13 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
       if (lane == 0) {
         plan->nsegs = 0;
         plan->ntiles = 0;
+        plan->tile_bytes = (uint32_t)TB;
         plan->tile_prefix[0] = 0;
         plan->bytes = 0;
         if (op.wire_plan != nullptr) {
           op.wire_plan->nsegs = 0;
           op.wire_plan->ntiles = 0;
+          op.wire_plan->tile_bytes = (uint32_t)TB;
           op.wire_plan->tile_prefix[0] = 0;
           op.wire_plan->bytes = 0;
         }
@@ -704,10 +714,10 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
     const uint64_t wraps = __ballot(mine && direct && pay_off + my_pay > cap);
     const uint32_t wrap_rec = wraps ? (uint32_t)__builtin_ctzll(wraps) : 0xFFFFFFFFu;
     const uint64_t l1 = cap - pay_off;  // (only meaningful for the wrapping record)
-    uint32_t t1 = (uint32_t)((my_pay + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES), tiles = t1;
+    uint32_t t1 = (uint32_t)((my_pay + TB - 1) >> ts), tiles = t1;
     if ((uint32_t)lane == wrap_rec) {
-      t1 = (uint32_t)((l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
-      tiles = t1 + (uint32_t)((my_pay - l1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+      t1 = (uint32_t)((l1 + TB - 1) >> ts);
+      tiles = t1 + (uint32_t)((my_pay - l1 + TB - 1) >> ts);
     }
     if (!mine) tiles = 0;
     const uint32_t tincl = wave_incl_scan_u32(tiles);
@@ -735,6 +745,7 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
       const uint32_t nsegs = (uint32_t)nrec_total + (wrap_rec != 0xFFFFFFFFu ? 1u : 0u);
       plan->nsegs = nsegs;
       plan->ntiles = ntiles;
+      plan->tile_bytes = (uint32_t)TB;
       plan->tile_prefix[nsegs] = ntiles;
       plan->bytes = sent;
       plan->tag_base = (uint64_t)dbase;
@@ -760,17 +771,18 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
         if (!direct && staged > 0) {
           wp->segs[0] = {(uint64_t)(peer_ring + tail), (uint64_t)staging, seg1, 0};
           wp->tile_prefix[0] = 0;
-          nt = (uint32_t)((seg1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+          nt = (uint32_t)((seg1 + TB - 1) >> ts);
           ns = 1;
           if (staged > seg1) {
             wp->segs[1] = {(uint64_t)peer_ring, (uint64_t)(staging + seg1), staged - seg1, 0};
             wp->tile_prefix[1] = nt;
-            nt += (uint32_t)((staged - seg1 + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES);
+            nt += (uint32_t)((staged - seg1 + TB - 1) >> ts);
             ns = 2;
           }
         }
         wp->nsegs = ns;
         wp->ntiles = nt;
+        wp->tile_bytes = (uint32_t)TB;
         wp->tile_prefix[ns] = nt;
         wp->bytes = direct ? 0 : staged;
       }
