@@ -44,6 +44,7 @@ hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*,
 hipError_t grdma_launch_engine(grdma_engine_mbox*, hipStream_t);
 const void* grdma_kernel_fn(int which);          // 0 tx_plan, 1 copy, 3 rx_apply, 4 tx_plan_seq
 const void* grdma_kernel_fn_rx_plan(void);
+const void* grdma_kernel_fn_plan_pair(void);
 uint32_t grdma_kernel_threads(int which);
 uint32_t grdma_copy_resident_blocks(void);
 }
@@ -1496,12 +1497,12 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
   hipGraph_t g;
   HIP_TRY(hipGraphCreate(&g, 0));
   std::vector<hipGraphNode_t> P(R), G(R), W(R), X(R), A(R);
-  auto add = [&](hipGraphNode_t* node, const void* fn, dim3 grid, uint32_t threads, const void* arg,
-                 std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
+  auto add2 = [&](hipGraphNode_t* node, const void* fn, dim3 grid, uint32_t threads, const void* arg, const void* arg2,
+                  std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
     std::vector<hipGraphNode_t> d;
     for (hipGraphNode_t x : deps)
       if (x) d.push_back(x);
-    void* args[1] = {const_cast<void*>(static_cast<const void*>(&arg))};
+    void* args[2] = {const_cast<void*>(static_cast<const void*>(&arg)), const_cast<void*>(static_cast<const void*>(&arg2))};
     hipKernelNodeParams np;
     memset(&np, 0, sizeof(np));
     np.func = const_cast<void*>(fn);
@@ -1512,6 +1513,11 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
     np.extra = nullptr;
     return hipGraphAddKernelNode(node, g, d.empty() ? nullptr : d.data(), d.size(), &np);
   };
+  auto add = [&](hipGraphNode_t* node, const void* fn, dim3 grid, uint32_t threads, const void* arg,
+                 std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
+    return add2(node, fn, grid, threads, arg, nullptr, deps);
+  };
+  const void* f_pair = grdma_kernel_fn_plan_pair();
   const void* f_txp = grdma_kernel_fn(0);
   const void* f_cpy = grdma_kernel_fn(1);
   const void* f_rxp = grdma_kernel_fn_rx_plan();
@@ -1564,10 +1570,19 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
       if (e == hipSuccess) e = add(&X[t], f_rxp, dim3(n), pt, rxop, {G[t], at(A, t, 2)});
       if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t], at(A, t, 1)});
     } else {
-      e = add(&P[t], f_txp, dim3(n), pt, txop, {at(G, t, 1), at(W, t, 2), at(A, t, 2)});
-      if (e == hipSuccess) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t]});
+      // The send plan of round t + 1 shares a launch with the receive plan of round t
+      // (k_plan_pair): P[t + 1] and X[t] are the same node.  Its dependencies are the union of
+      // both kernels': the wire of round t (which implies gather t and everything of round
+      // t - 1 but its scatter) and the scatter of round t - 1 (the credit the next Send may use).
+      if (t == 0) e = add(&P[0], f_txp, dim3(n), pt, txop, {});
+      if (e == hipSuccess) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t], at(A, t, 2)});
       if (e == hipSuccess) e = add(&W[t], f_cpy, dim3(txb, n), ct, wplans, {G[t], at(X, t, 1)});
-      if (e == hipSuccess) e = add(&X[t], f_rxp, dim3(n), pt, rxop, {W[t], at(A, t, 2)});
+      if (e == hipSuccess) {
+        const bool more = t + 1 < R;
+        const void* txop_next = j->d_txop + job_opset(t + 1) * n;
+        e = add2(&X[t], f_pair, dim3(n, more ? 2 : 1), pt, rxop, more ? txop_next : nullptr, {W[t], at(A, t, 1)});
+        if (more) P[t + 1] = X[t];
+      }
       if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t], at(A, t, 1)});
     }
   }

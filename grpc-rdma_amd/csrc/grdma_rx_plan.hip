@@ -1306,6 +1306,22 @@ __device__ __attribute__((noinline)) void tx_plan_call(const grdma_tx_op* op) { 
 __device__ __attribute__((noinline)) void rx_plan_call(const grdma_rx_op* op) { rx_plan_body(*op); }
 
 // ----------------------------------------------------------------------------
+// k_plan_pair: the two planners of a pipelined round in ONE launch.  The send plan of round t + 1
+// depends on the gather of round t and on the credit of round t - 1, not on the receive plan of
+// round t; both are single-workgroup, latency-bound kernels, and a queue runs kernels one after
+// the other -- so they share a launch: workgroup (link, 0) walks and plans the drain of round t,
+// workgroup (link, 1) prices the Send of round t + 1 on another CU at the same time.  They touch
+// different connection blocks (the receiving and the sending end).  gridDim.y == 1: the receive
+// plan alone (last round).
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_plan_pair(const grdma_rx_op* rxops, const grdma_tx_op* txops) {
+  // (both bodies inline: the out-of-line copies used by the resident engine spill)
+  if (blockIdx.y == 0) rx_plan_body(rxops[blockIdx.x]);
+  else tx_plan_body(txops[blockIdx.x]);
+}
+
+// ----------------------------------------------------------------------------
 // k_engine: persistent latency engine.  One workgroup stays resident and takes
 // Send / drain commands from a mailbox in pinned host memory, so a 64-byte RPC
 // pays a PCIe doorbell read instead of a kernel launch.  The command bodies are
@@ -1465,6 +1481,7 @@ extern "C" uint64_t grdma_express_drains(void) {
 }
 
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rx_plan(void) { return reinterpret_cast<const void*>(&k_rx_plan); }
+extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair(void) { return reinterpret_cast<const void*>(&k_plan_pair); }
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan(const grdma_rx_op* d_ops, uint32_t nops,
                                            hipStream_t s) {
