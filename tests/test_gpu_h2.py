@@ -427,3 +427,67 @@ def test_deframe_real_grpc_client_bytes(gpu):
             acc += len(c)
         flat = [(k, a + starts[sl] if k == pyorc.EV_MSG_BYTES else a, b, c, d) for k, a, b, c, d, sl in ev_g]
         assert [m for _, m in messages_of(flat, data)] == exp
+
+
+def test_two_alternating_h2_pipes_share_one_parser(gpu):
+    """What bench.py's value_with_h2 leg runs: two jobs over ONE connection take turns, each with its own
+    pipe (frame -> job -> deframe), the deframing of step k running beside the job of step k + 1, the
+    parser state handed from one deframing to the next.  Six steps back to back; every step's events
+    equal the oracle's over the slices that step delivered."""
+    g = gpu
+    from grpc_rdma_amd import h2 as h2host, h2dev, stream as gs
+    sizes = [50000, 16379, 3, 120000, 16384 * 4 - 5]
+    bufs = [g.DeviceBuffer(data=bytes((j * 11 + i) % 251 for j in range(n))) for i, n in enumerate(sizes)]
+    msgs = [(b.ptr, n, 1, 0) for b, n in zip(bufs, sizes)]
+    lens = []
+    for n in sizes:
+        lens += [len(it[1]) if it[0] == "inl" else it[1][1] for it in h2host.frame_message(n, 1, 16384)]
+    scratch = g.DeviceBuffer(nbytes=max(lens) + 64)
+    sge = [(scratch.ptr, n) for n in lens]
+    R = 1 << 20
+    tx, rx = g.Pair(R, 512), g.Pair(R, 512)
+    g.connect_pairs(tx, rx)
+    N = sum(lens)
+    scap = 2 * len(lens) + 64 + N // 256
+    dst_cap = N + 16 * scap + 4096
+    parser = h2dev.Parser(False)
+    assert parser.open_streams([1]) == 0
+    jobs, pipes, dsts = [], [], []
+    for _ in range(2):
+        dst = g.DeviceBuffer(nbytes=dst_cap)
+        job = gs.StreamJob(tx, rx, sge, dst.ptr, dst_cap, scap, 64)
+        r = job.run(gs.RUN_EAGER)
+        job.set_rounds(int(max(r.tx_rounds, r.rx_rounds)))
+        r = job.run(gs.RUN_GRAPH)
+        assert r.done and r.bytes_delivered == N
+        pipes.append(h2dev.Pipe(job, msgs, parser, len(job.delivered_slices(0)), 4 * len(lens) + 256))
+        jobs.append(job)
+        dsts.append(dst)
+    po = pyorc.H2Parser(expect_client_prefix=False)
+    assert po.open_stream(1) == 0
+    # enqueue all six steps first (nothing returns to the host in between), then look at the last two
+    # steps' results -- and replay the oracle over all six to get there
+    for step in range(6):
+        pipes[step % 2].enqueue()
+    res = [p.sync(want_events=True) for p in pipes]
+    assert all(r["h2_error"] == 0 and r["framed"] == len(lens) for r in res)
+    per_step_events = []
+    for step in range(6):
+        job, dst = jobs[step % 2], dsts[step % 2]
+        ds = job.delivered_slices(0)     # (every step of a job delivers the same slices)
+        got = dst.read(dst_cap)
+        ev_o = []
+        for i, (o, n) in enumerate(ds):
+            rc, ev = po.feed(got[o:o + n])
+            assert rc == 0
+            ev_o += [(k, a, b, c, d, i) for k, a, b, c, d in ev]
+        per_step_events.append(ev_o)
+    assert res[0]["event_list"] == per_step_events[4]   # pipe 0 ran steps 0, 2, 4
+    assert res[1]["event_list"] == per_step_events[5]   # pipe 1 ran steps 1, 3, 5
+    for p in pipes:
+        p.close()
+    for j_ in jobs:
+        j_.close()
+    parser.close()
+    tx.close()
+    rx.close()
