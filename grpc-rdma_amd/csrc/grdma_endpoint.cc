@@ -205,7 +205,7 @@ struct grpc_rdma {  // rdma_bp_posix.cc:45-88
 grdma_poller* g_poller = nullptr;  // Poller::Get(): one per process, created with the first BPEV endpoint
 
 const size_t kWindow = 4000;   // slices handed to one grdma_endpoint_write_begin (ABI cap 4095)
-const size_t kReadAhead = 1024;  // endpoint reads performed per device pass  // slices handed to one grdma_endpoint_write_begin (ABI cap 4095)
+const size_t kReadAhead = 1024;  // endpoint reads performed per device pass
 
 void run_closure(grpc_closure* c, grpc_error_handle err) {  // grpc_core::Closure::Run
   c->cb(c->cb_arg, err);
@@ -632,6 +632,9 @@ int grdma_pollset_work(grpc_pollset* ps, int timeout_ms) {
       ps->pairs[i] = fds[i]->pair;
       any_armed |= fds[i]->read_armed || fds[i]->write_armed;
     }
+    // nothing is armed and passes are serialised by the caller: nothing can become ready in
+    // this pass, so an unbounded busy-poll would never return
+    if (!any_armed && !ps->bpev && timeout_ms < 0) break;
     if (any_armed) {
       // HasMessage() of every fd of the set: one launch
       if (grdma_poll_pairs(ps->pairs.data(), (uint32_t)n, ps->readable.data(), ps->has_message.data()) < 0) return -1;

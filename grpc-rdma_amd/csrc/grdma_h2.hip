@@ -1263,7 +1263,9 @@ int grdma_h2_pipe_enqueue(grdma_h2_pipe* p, int schedule) {
 }
 
 // Wait for the last step and report it: out = {slices framed, frame overflow, events, deframe
-// overflow, slices parsed, h2 error, framing kernel us, deframing kernel us, bulk steps, frames parsed by bulk steps}; events_out (may be NULL) receives up to cap events.
+// overflow, slices parsed, h2 error, framing kernel us, deframing kernel us, bulk steps, frames
+// parsed by bulk steps, then the deframer's device-clock ticks: waiting for the look-ahead ring,
+// in bulk steps, total, in the byte-wise path}; events_out (may be NULL) receives up to cap events.
 int grdma_h2_pipe_sync(grdma_h2_pipe* p, uint64_t out[14], grdma_h2_event* events_out, uint64_t cap) {
   if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
   if (!p || !out) return -GRDMA_ERR_INVALID;

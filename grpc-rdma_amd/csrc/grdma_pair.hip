@@ -1896,24 +1896,30 @@ int grdma_stream_job_set_burst(grdma_stream_job* j, uint32_t burst) {
   const uint32_t n = (uint32_t)j->links.size();
   for (grdma_job_link& l : j->links) {
     while (l.b_gplan.size() < burst) {
+      // all three or none: a failure leaves the vectors the same length
       grdma_plan *g = nullptr, *w = nullptr;
       uint8_t* st = nullptr;
-      HIP_TRY(hipMalloc((void**)&g, sizeof(grdma_plan)));
-      l.b_gplan.push_back(g);
-      HIP_TRY(hipMemset(g, 0, sizeof(grdma_plan)));
-      HIP_TRY(hipMalloc((void**)&w, sizeof(grdma_plan)));
-      l.b_wplan.push_back(w);
-      HIP_TRY(hipMemset(w, 0, sizeof(grdma_plan)));
-      if (!j->direct) {
-        HIP_TRY(hipMalloc((void**)&st, l.tx->ring_size / 2 + 64));
-        HIP_TRY(hipMemset(st, 0, l.tx->ring_size / 2 + 64));
+      const size_t st_bytes = l.tx->ring_size / 2 + 64;
+      hipError_t e = hipMalloc((void**)&g, sizeof(grdma_plan));
+      if (e == hipSuccess) e = hipMemset(g, 0, sizeof(grdma_plan));
+      if (e == hipSuccess) e = hipMalloc((void**)&w, sizeof(grdma_plan));
+      if (e == hipSuccess) e = hipMemset(w, 0, sizeof(grdma_plan));
+      if (e == hipSuccess && !j->direct) e = hipMalloc((void**)&st, st_bytes);
+      if (e == hipSuccess && !j->direct) e = hipMemset(st, 0, st_bytes);
+      if (e != hipSuccess) {
+        hipFree(g);
+        hipFree(w);
+        hipFree(st);
+        return fail(GRDMA_ERR_HIP, "burst buffers: %s", hipGetErrorString(e));
       }
+      l.b_gplan.push_back(g);
+      l.b_wplan.push_back(w);
       l.b_staging.push_back(st);
     }
   }
   if (j->d_bctl) hipFree(j->d_bctl);
   j->d_bctl = nullptr;
-  j->burst = burst;
+  j->burst = 1;  // the plain schedule until the burst tables below are in place
   if (burst == 1) return 0;
   const size_t sz_tx = sizeof(grdma_tx_op) * 2 * burst * n, sz_pl = sizeof(grdma_plan*) * 2 * burst * n;
   const size_t sz_res = sizeof(grdma_tx_result) * n;  // scratch results of the Sends before the last
@@ -1944,6 +1950,7 @@ int grdma_stream_job_set_burst(grdma_stream_job* j, uint32_t burst) {
       h_pl[(size_t)(burst + k) * n + i] = j->links[i].b_wplan[k];
     }
   HIP_TRY(hipMemcpy(j->d_bctl, host.data(), host.size(), hipMemcpyHostToDevice));
+  j->burst = burst;
   return 0;
 }
 
