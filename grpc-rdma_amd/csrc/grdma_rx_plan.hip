@@ -23,6 +23,11 @@
 //          network.  Used while no period is known and around irregularities.
 //  scalar  one endpoint_read at a time (partial reads, retained slices, tails).
 //
+// A bulk pass that stops short of its prediction hands what it already knows to the wave
+// tier (rx_state::hand_*): the records it verified but could not take (they end inside an
+// open read) are queued in s_chain, and a zero header at the first unverified position is
+// the would-block -- the wave tier does not walk those records a second time.
+//
 // In front of the tiers, in latency mode only: the EXPRESS drain -- a small unary message
 // (<= 8 tiny records that fit the open read) handled by one wavefront in three memory
 // round trips, no plan, no LDS tables (see "express drain" in rx_plan_body).
@@ -225,6 +230,11 @@ struct rx_state {
   uint32_t bulk_first;       // no bulk pass has run in this call yet
   uint32_t period_backoff;   // log2 of the cool-down after a retired / missing period
   uint32_t took;
+  // Hand-over from a bulk pass that stopped short of its prediction to the wave tier: the
+  // records it verified but did not consume (they do not end between two reads) wait in
+  // s_chain, and what it saw at the first unverified position is not probed a second time.
+  uint32_t hand_on, hand_n, hand_v, hand_dry;
+  uint64_t hand_pos;
 };
 
 __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
@@ -370,7 +380,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
           S.nslices = 0; S.a_off = a_off0; S.would_block = 1; S.leftover = alloc;
         }
         S.stop = 1;
-        S.bulk_tries = 0; S.bulk_blocked = 0; S.took = 0;
+        S.bulk_tries = 0; S.bulk_blocked = 0; S.took = 0; S.hand_on = 0;
         S.period = c->rx_period; S.period_searched = 0; S.period_retry_at = c->rx_period_retry_at;
         S.period_strikes = c->pad3 & 0xFFFFu; S.period_backoff = c->pad3 >> 16; S.bulk_first = 1;
         for (int q = 0; q < 16; q++) s_dbg[q] = 0;
@@ -409,6 +419,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     S.bulk_tries = (op.raw_cap == 0 && cap <= (1ull << 31) && max_slices >= 512) ? 6 : 0;
     S.bulk_blocked = 0;
     S.took = 0;
+    S.hand_on = 0;
     S.period = c->rx_period;
     S.period_searched = 0;
     S.period_retry_at = c->rx_period_retry_at;
@@ -649,7 +660,26 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
       }
       S.bulk_first = 0;
     }
-    if (V == 0) return 0;
+    // Records [first, V) passed the probe (header, predicted size, footer) but stay unconsumed;
+    // position V is where the chain continues.  A zero header there (low word: a value with
+    // only high bits set is no header either) means nothing more had arrived when this call
+    // looked -- the wave tier takes that as its would-block instead of loading it again.
+    auto hand_over = [&](uint32_t first) {
+      const uint32_t k = V - first;
+      if (V >= BULK_MAX || k > 64) return;  // (uniform)
+      if (tid < k) s_chain[tid] = s_n[RXP(first + tid)];
+      if (tid == 0) {
+        S.hand_on = 1;
+        S.hand_n = k;
+        S.hand_v = V;
+        S.hand_dry = s_n[RXP(V)] == 0 ? 1u : 0u;
+        S.hand_pos = (head + s_xenc[RXP(V)]) & mask;
+      }
+    };
+    if (V == 0) {
+      hand_over(0);
+      return 0;
+    }
     // ---- pass 0: incoming read state of every record, last clean record ----------------
     const uint32_t per0 = (V + PLAN_THREADS - 1) / PLAN_THREADS;
     const uint32_t k0 = tid * per0;
@@ -671,7 +701,10 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     const uint32_t cnt = s_clean;  // records [0, cnt) are processed; the state ends clean
     const uint64_t tb3 = __builtin_amdgcn_s_memtime();
     if (tid == 0) s_dbg[10] += tb3 - tb2;
-    if (cnt == 0) return 0;
+    if (cnt == 0) {
+      hand_over(0);
+      return 0;
+    }
     // ---- pass 1: totals per wave --------------------------------------------------------
     // The cnt records are dealt to the four waves in contiguous quarters and, inside a
     // wave, to lanes round-robin: neighbouring lanes then write neighbouring plan and
@@ -864,6 +897,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
       S.a_off += tot_bytes;
       S.hist_count += cnt;
     }
+    hand_over(cnt);
     return cnt;
   };
 
@@ -885,6 +919,19 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     if (hist_count >= 1) w.h1 = s_hist[(hist_count - 1) % GRDMA_RX_HIST];
     if (hist_count >= 2) w.h2 = s_hist[(hist_count - 2) % GRDMA_RX_HIST];
     uint32_t chain_n = 0, chain_i = 0;
+    if (S.hand_on) {  // what the last bulk pass verified beyond the records it took
+      chain_n = S.hand_n;
+      w.pos = S.hand_pos;
+      w.dry = S.hand_dry != 0;
+      const uint32_t V = S.hand_v;  // sizes of the two records in front of w.pos
+      if (V >= 2) {
+        w.h1 = s_penc[RXP(V - 1)];
+        w.h2 = s_penc[RXP(V - 2)];
+      } else if (V == 1) {
+        w.h2 = w.h1;
+        w.h1 = s_penc[RXP(0)];
+      }
+    }
 
     auto hist_push = [&](uint64_t enc) {
       if (lane == 0) s_hist[hist_count % GRDMA_RX_HIST] = (uint32_t)enc;
@@ -1142,6 +1189,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
       S.would_block = would_block; S.credit = credit; S.credit_head = credit_head;
       S.hist_count = hist_count;
       S.stop = stop;
+      S.hand_on = 0;
       if (progressed) S.bulk_blocked = 0;
       s_dbg[0] += n_rounds; s_dbg[1] += n_fast; s_dbg[2] += n_scalar;
     }
