@@ -593,29 +593,62 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     }
     const uint64_t arena_room = op.arena_cap > S.a_off + 1024 ? op.arena_cap - S.a_off - 1024 : 0;
     {
-      // all 2 x 16 tag loads of a thread are in flight before the first is looked at
+      // One 16-byte load per record: the footer of record i and the header of record i + 1
+      // are neighbouring words of the ring, so thread i fetches both at once and checks the
+      // footer of its own record and the header of the next one (two 8-byte loads per record
+      // were twice the requests from this one CU, and the probe is bound by how many of them
+      // it can keep in flight).  All 16 loads of a thread are issued before the first is
+      // looked at; sc1 as in ld_tag (served by L2 / memory, not by this CU's L1).
       constexpr int NP = BULK_MAX / PLAN_THREADS;
-      uint64_t hdrs[NP], foots[NP];
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      // (readfirstlane returns int: widen through uint32_t, or a set bit 31 smears into the high word)
+      const uint32_t ring_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)ring);
+      const uint32_t ring_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)ring >> 32));
+      const uint64_t ring_u = ((uint64_t)ring_hi << 32) | (uint64_t)ring_lo;
+      const uint32_t cap_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cap);  // <= 2 GiB in a bulk pass
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ring_u, 0, cap_u, 0x00020000);
+      u32x4 pairs[NP];
       bool want[NP];
+      // the header of record 0, and the first word of the ring for the one record whose
+      // footer is the last word of the ring (the same line for every lane)
+      // (through the buffer as well: a FLAT load would also count on LGKM_CNT, and the LDS
+      // reads between the loads below would wait for it)
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 hf = __builtin_amdgcn_raw_buffer_load_b64(rs, (uint32_t)(head & mask & ~7ull), 0, 16);
+      const u32x2 wz = __builtin_amdgcn_raw_buffer_load_b64(rs, 0u, 0, 16);
 #pragma unroll
       for (int r = 0; r < NP; r++) {
         const uint32_t i = tid + r * PLAN_THREADS;
         const uint64_t x = s_xenc[RXP(i)], e = s_penc[RXP(i)];
         want[r] = i < vmax && x + e <= cap - 8 && x + e + 32ull * (i + 1) <= arena_room;
         // (unconditional: a masked offset is always inside the ring, and straight-line
-        // loads are all issued before the first wait)
-        hdrs[r] = ld_tag(ring + ((head + x) & mask & ~7ull));
-        foots[r] = ld_tag(ring + ((head + x + e - 8) & mask & ~7ull));
+        // loads are all issued before the first wait; a footer in the last word of the
+        // ring is read as the second half of the pair one word earlier)
+        const uint32_t f = (uint32_t)((head + x + e - 8) & mask & ~7ull);
+        pairs[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, f <= cap_u - 16u ? f : cap_u - 16u, 0, 16 /* sc1 */);
       }
       uint32_t first_bad = 0xFFFFFFFFu;
+      const uint64_t hdr_first = ((uint64_t)hf.y << 32) | hf.x, word_zero = ((uint64_t)wz.y << 32) | wz.x;
+      if (tid == 0) {
+        const bool ok = hdr_first != 0 && hdr_first <= cap - GRDMA_RESERVED && 16 + round_up8(hdr_first) == s_penc[RXP(0)];
+        s_n[RXP(0)] = (uint32_t)hdr_first;
+        if (!ok) first_bad = 0;
+      }
 #pragma unroll
       for (int r = 0; r < NP; r++) {
         const uint32_t i = tid + r * PLAN_THREADS;
-        const uint64_t hdr = hdrs[r];
-        const bool ok = want[r] && hdr != 0 && hdr <= cap - GRDMA_RESERVED &&
-                        16 + round_up8(hdr) == s_penc[RXP(i)] && foots[r] == GRDMA_FOOTER;
-        s_n[RXP(i)] = (uint32_t)hdr;
-        if (!ok && i < first_bad) first_bad = i;
+        const uint64_t x = s_xenc[RXP(i)], e = s_penc[RXP(i)];
+        const uint32_t f = (uint32_t)((head + x + e - 8) & mask & ~7ull);
+        const bool last_word = f > cap_u - 16u;
+        const uint64_t lo = ((uint64_t)pairs[r].y << 32) | pairs[r].x, hi = ((uint64_t)pairs[r].w << 32) | pairs[r].z;
+        const uint64_t foot = last_word ? hi : lo;
+        const uint64_t next = last_word ? word_zero : hi;  // header of record i + 1
+        if (!(want[r] && foot == GRDMA_FOOTER) && i < first_bad) first_bad = i;
+        if (i + 1 < BULK_MAX) {
+          const bool ok = next != 0 && next <= cap - GRDMA_RESERVED && 16 + round_up8(next) == s_penc[RXP(i + 1)];
+          s_n[RXP(i + 1)] = (uint32_t)next;
+          if (!ok && i + 1 < first_bad) first_bad = i + 1;
+        }
       }
       // one LDS atomic per wave
       const uint64_t bm = __ballot(first_bad != 0xFFFFFFFFu);
