@@ -458,7 +458,7 @@ def main():
             tx.close(); rx.close(); dst.free()
         return out
 
-    def measure_with_h2(ring_kb, steps, warmup, engine=False):
+    def measure_with_h2(ring_kb, steps, warmup, engine=False, boundary_step=None):
         """The same step with the HTTP/2 stages INSIDE the timed device pipeline: k_h2_frame rebuilds
         the slice list from the message table, the job carries it through the connection, k_h2_deframe
         parses what was delivered (events: frames, message boundaries, payload pieces).  Two jobs over
@@ -471,7 +471,7 @@ def main():
         scap = len(w.lens) * 2 + 64 + w.N // 256
         dst_cap = w.N + 16 * scap + 4096
         msgs = [(w.payload_buf.ptr + i * w.msg_len, w.msg_len, 1, 0) for i in range(w.n_msgs)]
-        parser = h2dev.Parser(False)
+        parser = h2dev.Parser(False, boundary_step=boundary_step)
         assert parser.open_streams([1]) == 0      # a client-side parser: the call runs on stream 1
         jobs, pipes, dsts = [], [], []
         for _ in range(2):
@@ -509,7 +509,9 @@ def main():
             r = p_.sync(want_events=True)
             stage_us = {"frame_us": r["frame_us"], "deframe_us": r["deframe_us"], "delivered_slices": p_.delivered,
                         "events": r["events"], "bulk_steps": r["bulk_steps"], "bulk_frames": r["bulk_frames"],
+                        "boundary_steps": r["boundary_steps"],
                         "deframe_ticks": {"wait_for_windows": r["t_wait"], "bulk_steps": r["t_bulk"],
+                                          "boundary_steps": r["t_boundary"],
                                           "bytewise_path": r["t_serial"], "total": r["t_total"]}}
             evs = r["event_list"]
             ok = ok and r["h2_error"] == 0 and not r["frame_overflow"] and not r["deframe_overflow"] and \
@@ -658,6 +660,14 @@ def main():
             out["with_h2_stages"] = hh["stages"]
         except Exception as e:
             out["with_h2_error"] = str(e)[:200]
+        try:  # the same leg with message starts left to the byte-wise automaton
+            h0 = measure_with_h2(args.ring_kb, max(2, args.steps // 4), 2, engine=(args.schedule == "engine"),
+                                 boundary_step=False)
+            out["value_with_h2_no_boundary_step"] = round(
+                wl.user_bytes * max(2, args.steps // 4) * world / h0["elapsed"] / (1 << 30), 3)
+            out["with_h2_no_boundary_step_deframe_us"] = h0["stages"]["deframe_us"]
+        except Exception as e:
+            out["with_h2_no_boundary_step_error"] = str(e)[:200]
     if not args.no_extra_legs:
         # the reference's default knobs (4 MiB ring, max_sge 30: rdma_utils.h / config.cc), same workload,
         # with the CPU codec timed at the SAME knobs beside it

@@ -20,12 +20,14 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "../../include/grdma_amd.h"
 #include "grdma_dev.h"
 #include "grdma_devfn.h"
+#include "grdma_h2_fast.h"
 
 struct grdma_h2_msg_dev {
   const uint8_t* payload;
@@ -75,6 +77,7 @@ struct grdma_h2_parser_dev {
   uint32_t live_streams;
   uint32_t tab_mask;
   int32_t error;        // connection error (grdma_h2_error), sticky
+  int32_t boundary_step;  // 1 = message starts go through h2_boundary_match (grdma_h2_fast.h)
   grdma_h2_stream_dev* tab;
 };
 
@@ -85,6 +88,7 @@ struct grdma_h2_deframe_result {
   int64_t error;
   uint64_t bulk_steps, bulk_frames;  // how much of the call went through the bulk step
   uint64_t t_wait, t_bulk, t_total, t_serial;  // profiling aid (s_memtime ticks): waiting for staged windows, inside bulk steps, whole parse, byte-wise path
+  uint64_t boundary_steps, t_boundary;         // message starts taken by the boundary step, ticks inside it
 };
 
 namespace {
@@ -463,6 +467,12 @@ __device__ __forceinline__ void h2_push(grdma_h2_event* ev, uint64_t ev_cap, uin
   nev++;
 }
 
+// a wave-uniform value, moved to scalar registers
+__device__ __forceinline__ uint32_t h2_uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t h2_uni64(uint64_t v) {
+  return ((uint64_t)h2_uni32((uint32_t)(v >> 32)) << 32) | (uint64_t)h2_uni32((uint32_t)v);
+}
+
 // the map entry of the current stream, cached in (wave-uniform) registers
 struct h2_cur_stream {
   int idx;
@@ -537,9 +547,9 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
   __builtin_amdgcn_s_setprio(3);  // the one serial wave of the kernel: it gets the issue slots it asks for
   h2_view V = {0, 0};
   const uint64_t t_begin = __builtin_amdgcn_s_memtime();
-  uint64_t t_bulk = 0, t_serial = 0;
+  uint64_t t_bulk = 0, t_serial = 0, t_boundary = 0;
   uint32_t consumed_pub = 0;
-  uint64_t bulk_steps = 0, bulk_frames = 0;
+  uint64_t bulk_steps = 0, bulk_frames = 0, boundary_steps = 0;
   const grdma_h2_parser_dev P = *gp;  // uniform loads: the whole block sits in scalar registers
   uint64_t nev = 0, overflow = 0;
   static const char kPrefix[] = "PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n";  // internal.h:781
@@ -595,6 +605,46 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
       if (lane == 0) __hip_atomic_store(&g_h2.consumed, consumed_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     h2_need(V, s);
+    // ---- boundary step: the slice in which a message starts (grdma_h2_fast.h) -------------
+    // Wave-uniform: the staged entry of slice s and the length of slice s + 1 are pulled into
+    // scalar registers, the match runs on the scalar unit, and lane k stores event k.
+    if (P.boundary_step && st == ST_FH0 && expect_cont == 0 && !is_first_frame && D.idx >= 0 && !D.read_closed &&
+        (D.state == 0 || (D.state == 5 && D.fsz - 1u < 9u))) {
+      const uint64_t tq0 = __builtin_amdgcn_s_memtime();
+      const h2_win_ent me = *h2_ent(V, s);
+      uint64_t next_len = ~0ull;
+      if (s + 1 < nslices) {
+        h2_need(V, s + 1);
+        next_len = h2_ent(V, s + 1)->len;
+      }
+      const uint32_t d_id = h2_uni32(D.id);
+      const h2_bstep B = h2_boundary_match(h2_uni64(me.c0), h2_uni64(me.c1), h2_uni64(me.c2), h2_uni64(me.c3),
+                                           h2_uni64(me.len), h2_uni64(next_len), (int32_t)h2_uni32((uint32_t)D.state),
+                                           h2_uni32(D.fsz), d_id, max_frame);
+      if (B.ok && nev + B.nev <= ev_cap) {
+        if ((uint32_t)lane < B.nev) {
+          uint32_t e[6];
+          h2_boundary_event(B, d_id, (uint32_t)s, (uint32_t)lane, e);
+          h2_store_event(ev + nev + (uint64_t)lane, e[0], e[1], e[2], e[3], e[4], e[5]);
+        }
+        nev += B.nev;
+        D.state = B.rem ? 5 : 0;
+        D.fsz = B.rem;
+        D.comp = (int32_t)B.comp;
+        // what the automaton's registers hold after frame B
+        fsz = 0;
+        ftype = FT_DATA;
+        fflags = 0;
+        sid = d_id;
+        cur_parser = PARSER_DATA;
+        received_last = 0;
+        boundary_steps++;
+        t_boundary += __builtin_amdgcn_s_memtime() - tq0;
+        s += (uint64_t)B.nslices - 1;  // (the loop adds the last one)
+        continue;
+      }
+      t_boundary += __builtin_amdgcn_s_memtime() - tq0;
+    }
     // ---- bulk step: the streaming steady state, many frames at once ---------------------
     // Between a message's first and last frame every DATA frame of a stream spans exactly TWO
     // slices: on the sending side a 9-byte header slice and one payload slice
@@ -885,6 +935,8 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
     res->t_bulk = t_bulk;
     res->t_total = __builtin_amdgcn_s_memtime() - t_begin;
     res->t_serial = t_serial;
+    res->boundary_steps = boundary_steps;
+    res->t_boundary = t_boundary;
   }
 }
 
@@ -941,6 +993,18 @@ struct grdma_h2_parser {
 };
 
 static double g_h2_last_kernel_us = 0;
+static uint64_t g_h2_last_boundary_steps = 0;
+
+// What a parser created without either flag does: the boundary step is on unless the environment
+// says GRDMA_H2_BOUNDARY_STEP=0.
+static int h2_boundary_default() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GRDMA_H2_BOUNDARY_STEP");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
 
 namespace {
 struct h2_host_ctx {
@@ -973,6 +1037,8 @@ extern "C" {
 const char* grdma_last_error(void);
 // duration of the framing / deframing kernel of the last call (HIP events), microseconds
 double grdma_h2_last_kernel_us(void) { return g_h2_last_kernel_us; }
+// message starts the last grdma_h2_deframe call took through the boundary step
+uint64_t grdma_h2_last_boundary_steps(void) { return g_h2_last_boundary_steps; }
 
 int64_t grdma_h2_frame_messages(const grdma_h2_msg* msgs, uint64_t n, uint32_t max_frame,
                                 grdma_slice* d_slices_out, uint64_t slices_cap,
@@ -1029,6 +1095,7 @@ grdma_h2_parser* grdma_h2_parser_create_ex(int flags, uint32_t max_frame_size,
   init.max_frame_size = max_frame_size;        // http2_settings.cc:56 default 16384
   init.max_concurrent = max_concurrent_streams;  // http2_settings.cc:46 default 0xffffffff
   init.tab_mask = table_slots - 1;
+  init.boundary_step = (flags & GRDMA_H2_BOUNDARY_STEP) ? 1 : (flags & GRDMA_H2_NO_BOUNDARY_STEP) ? 0 : h2_boundary_default();
   if (hipMalloc((void**)&p->d, sizeof(init)) != hipSuccess ||
       hipMalloc((void**)&p->d_tab, sizeof(grdma_h2_stream_dev) * table_slots) != hipSuccess ||
       hipMalloc((void**)&p->d_res, sizeof(grdma_h2_deframe_result)) != hipSuccess ||
@@ -1124,6 +1191,7 @@ int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_re
     return -GRDMA_ERR_HIP;
   float ms = 0;
   if (hipEventElapsedTime(&ms, hc->e0, hc->e1) == hipSuccess) g_h2_last_kernel_us = 1e3 * ms;
+  g_h2_last_boundary_steps = h_res.boundary_steps;
   const uint64_t m = h_res.nevents < cap ? h_res.nevents : cap;
   if (m && (hipMemcpyAsync(events_out, p->d_ev, sizeof(grdma_h2_event) * m, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess))
@@ -1162,6 +1230,7 @@ struct grdma_h2_pipe {
   grdma_h2_deframe_result* d_dres = nullptr;
   grdma_h2_event* d_ev = nullptr;
   uint64_t ev_cap = 0, delivered = 0;
+  uint64_t boundary_steps = 0, t_boundary = 0;  // of the last synced step
   bool launched = false;
 };
 
@@ -1289,6 +1358,8 @@ int grdma_h2_pipe_sync(grdma_h2_pipe* p, uint64_t out[14], grdma_h2_event* event
   out[11] = dr.t_bulk;
   out[12] = dr.t_total;
   out[13] = dr.t_serial;
+  p->boundary_steps = dr.boundary_steps;
+  p->t_boundary = dr.t_boundary;
   float fms = 0, dms = 0;
   out[6] = out[7] = 0;
   if (p->launched && hipEventElapsedTime(&fms, p->t_f0, p->t_f1) == hipSuccess) out[6] = (uint64_t)(fms * 1e3f);
@@ -1296,6 +1367,15 @@ int grdma_h2_pipe_sync(grdma_h2_pipe* p, uint64_t out[14], grdma_h2_event* event
   const uint64_t m = std::min<uint64_t>(std::min<uint64_t>(dr.nevents, cap), p->ev_cap);
   if (events_out && m && hipMemcpy(events_out, p->d_ev, sizeof(grdma_h2_event) * m, hipMemcpyDeviceToHost) != hipSuccess)
     return -GRDMA_ERR_HIP;
+  return 0;
+}
+
+
+// {message starts taken by the boundary step, device-clock ticks inside it} of the last synced step
+int grdma_h2_pipe_boundary_stats(grdma_h2_pipe* p, uint64_t out[2]) {
+  if (!p || !out) return -GRDMA_ERR_INVALID;
+  out[0] = p->boundary_steps;
+  out[1] = p->t_boundary;
   return 0;
 }
 

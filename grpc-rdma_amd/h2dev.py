@@ -35,6 +35,8 @@ def _bind():
             fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
         lib.grdma_h2_parser_live_streams.restype = C.c_int64
         lib.grdma_h2_parser_live_streams.argtypes = [C.c_void_p]
+        lib.grdma_h2_last_boundary_steps.restype = C.c_uint64
+        lib.grdma_h2_last_boundary_steps.argtypes = []
         lib.grdma_h2_deframe.restype = C.c_int64
         lib.grdma_h2_deframe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ReadSlice), u64,
                                          C.POINTER(H2Event), u64, C.POINTER(C.c_int)]
@@ -54,7 +56,7 @@ def frame_messages(msgs, max_frame, slices_dev_ptr, slices_cap, hdr_dev_ptr, hdr
     return n, wire.value
 
 
-H2_SERVER, H2_FIRST_FRAME = 1, 2
+H2_SERVER, H2_FIRST_FRAME, H2_BOUNDARY_STEP, H2_NO_BOUNDARY_STEP = 1, 2, 4, 8
 
 
 class Parser:
@@ -63,10 +65,12 @@ class Parser:
     False: a client / mid-connection parser whose streams the caller opens."""
 
     def __init__(self, expect_client_prefix=False, max_frame_size=16384, flags=None,
-                 max_concurrent_streams=0xFFFFFFFF, table_slots=0):
+                 max_concurrent_streams=0xFFFFFFFF, table_slots=0, boundary_step=None):
         self.lib = _bind()
         if flags is None:
             flags = (H2_SERVER | H2_FIRST_FRAME) if expect_client_prefix else 0
+        if boundary_step is not None:  # None: GRDMA_H2_BOUNDARY_STEP in the environment decides
+            flags |= H2_BOUNDARY_STEP if boundary_step else H2_NO_BOUNDARY_STEP
         self.h = self.lib.grdma_h2_parser_create_ex(flags, max_frame_size, max_concurrent_streams, table_slots)
         if not self.h:
             raise GrdmaError("h2 parser allocation failed")
@@ -97,6 +101,7 @@ class Parser:
         ev = (H2Event * cap)()
         err = C.c_int(0)
         m = check(self.lib.grdma_h2_deframe(self.h, arena_dev_ptr, arr, n, ev, cap, C.byref(err)))
+        self.last_boundary_steps = int(self.lib.grdma_h2_last_boundary_steps())
         return err.value, [(e.kind, e.a, e.b, e.c, e.d, e.slice) for e in ev[:m]]
 
     def close(self):
@@ -117,6 +122,7 @@ class Pipe:
         lib.grdma_h2_pipe_enqueue.argtypes = [C.c_void_p, C.c_int]
         lib.grdma_h2_pipe_sync.argtypes = [C.c_void_p, C.POINTER(u64), C.POINTER(H2Event), u64]
         lib.grdma_h2_pipe_destroy.argtypes = [C.c_void_p]
+        lib.grdma_h2_pipe_boundary_stats.argtypes = [C.c_void_p, C.POINTER(u64)]
         arr = (H2Msg * len(msgs))()
         for i, (p, n, sid, fl) in enumerate(msgs):
             arr[i].payload, arr[i].len, arr[i].stream_id, arr[i].flags = p, n, sid, fl
@@ -137,6 +143,9 @@ class Pipe:
         check(self.lib.grdma_h2_pipe_sync(self.h, out, ev, self.events_cap if want_events else 0))
         r = dict(zip(("framed", "frame_overflow", "events", "deframe_overflow", "parsed", "h2_error", "frame_us", "deframe_us", "bulk_steps", "bulk_frames", "t_wait", "t_bulk", "t_total", "t_serial"),
                      [int(x) for x in out]))
+        bs = (u64 * 2)()
+        check(self.lib.grdma_h2_pipe_boundary_stats(self.h, bs))
+        r["boundary_steps"], r["t_boundary"] = int(bs[0]), int(bs[1])
         if want_events:
             r["event_list"] = [(e.kind, e.a, e.b, e.c, e.d, e.slice) for e in ev[:min(r["events"], self.events_cap)]]
         return r

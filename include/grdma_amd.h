@@ -381,7 +381,12 @@ enum grdma_h2_error {
 enum grdma_h2_parser_flags {
   GRDMA_H2_SERVER = 1,       /* expects the client preface; accepts streams from HEADERS frames
                                 (init_header_frame_parser, parsing.cc:596-631)               */
-  GRDMA_H2_FIRST_FRAME = 2   /* fresh connection: the first frame must be SETTINGS           */
+  GRDMA_H2_FIRST_FRAME = 2,  /* fresh connection: the first frame must be SETTINGS           */
+  GRDMA_H2_BOUNDARY_STEP = 4,    /* the slice in which a message starts (closing frame of the previous
+                                    message + first frame + 5-byte message header, all inside the staged
+                                    32 bytes) is parsed in one wave-uniform step instead of byte-wise   */
+  GRDMA_H2_NO_BOUNDARY_STEP = 8  /* never; with neither flag the step is on unless the environment
+                                    says GRDMA_H2_BOUNDARY_STEP=0                                    */
 };
 typedef struct grdma_h2_parser grdma_h2_parser;
 /* Deframe state of one transport (grpc_chttp2_transport deframe_state & co., internal.h) and
@@ -407,6 +412,8 @@ int grdma_h2_parser_close_writes(grdma_h2_parser* p, const uint32_t* ids, uint32
 int64_t grdma_h2_parser_live_streams(grdma_h2_parser* p);
 /* Duration of the framing / deframing kernel of the last call (HIP events), microseconds. */
 double grdma_h2_last_kernel_us(void);
+/* Message starts the last grdma_h2_deframe call parsed with the boundary step. */
+uint64_t grdma_h2_last_boundary_steps(void);
 /* grpc_chttp2_perform_read (parsing.cc:56-253) + grpc_deframe_unprocessed_incoming_frames
  * (frame_data.cc:92-276) over n delivered slices {offset, length} of d_arena.
  * Returns the number of events; *h2_error = connection error, if any. */
@@ -432,6 +439,8 @@ int grdma_h2_pipe_enqueue(grdma_h2_pipe* p, int schedule);
  *        staged windows, inside bulk steps, total, inside the byte-wise path} */
 int grdma_h2_pipe_sync(grdma_h2_pipe* p, uint64_t out[14], grdma_h2_event* events_out, uint64_t cap);
 void grdma_h2_pipe_destroy(grdma_h2_pipe* p);
+/* out = {message starts the last synced step parsed with the boundary step, device-clock ticks inside it} */
+int grdma_h2_pipe_boundary_stats(grdma_h2_pipe* p, uint64_t out[2]);
 
 /* ---- device helpers for callers that keep payloads in HBM ---------------------- */
 void* grdma_device_alloc(uint64_t bytes);
