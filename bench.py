@@ -238,10 +238,29 @@ def measure_rtt(g, iters=100000, warmup=2000):
     a.set_latency_mode(True)
     b.set_latency_mode(True)
     g._lib.check(lib.grdma_engine_start())
+    prof = {}
     try:
         t0 = time.perf_counter()
         rtt, ph = g.pingpong(a, b, slices, slices, iters=iters, warmup=warmup)
         wall = time.perf_counter() - t0
+        # a second, short pass with the GRPCProfiler mirror on (slot 0): the same round trips under the
+        # reference's op names (include/grpcpp/stats_time.h:11-44)
+        import ctypes as C
+        lib.grdma_stats_time_get.restype = C.c_uint64
+        lib.grdma_stats_time_get.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
+        lib.grdma_stats_time_op_name.restype = C.c_char_p
+        lib.grdma_stats_time_init(0)
+        lib.grdma_stats_time_enable()
+        g.pingpong(a, b, slices, slices, iters=max(100, iters // 10), warmup=10)
+        lib.grdma_stats_time_disable()
+        for op in range(31):
+            st = (C.c_double * 5)()
+            n = lib.grdma_stats_time_get(0, op, st)
+            if n:
+                prof[lib.grdma_stats_time_op_name(op).decode()] = {
+                    "count": int(n), "mean": round(st[0] / 1e3, 2), "p50": round(st[1] / 1e3, 2),
+                    "p95": round(st[2] / 1e3, 2), "p99": round(st[3] / 1e3, 2)}
+        lib.grdma_stats_time_shutdown()
     finally:
         lib.grdma_engine_stop()
     a.close()
@@ -253,7 +272,8 @@ def measure_rtt(g, iters=100000, warmup=2000):
             "rtt_config": "unary ping-pong 64 B, 1 connection, 4 MiB ring in HBM, slices [14 B][66 B] "
                           "each way, resident latency engine, host slices in / pinned slices out",
             "rtt_breakdown_us": {k: round(v / iters / 1e3, 2) for k, v in zip(
-                ["client_write", "server_read", "server_write", "client_read"], ph)}}
+                ["client_write", "server_read", "server_write", "client_read"], ph)},
+            "rtt_profile_us": prof}
 
 
 def fanout_leg(g, gs, grp, torch, args, flags, n_msgs=128):

@@ -232,12 +232,17 @@ void call_read_cb(grpc_rdma* rdma, grpc_error_handle error) {  // :161-176
 // rdma_continue_read + rdma_do_read (:306-326, :180-291): the device performs the read
 // (slice sizing, Recv loop, credit return); here the slice is materialised.
 void rdma_handle_read(grpc_rdma* rdma, grpc_error_handle error) {
+  grdma_profiler profiler(GRDMA_STATS_TIME_TRANSPORT_HANDLE_READ);  // :330
   if (error != GRPC_ERROR_NONE) {  // :333-338
     grpc_slice_buffer_reset_and_unref(rdma->incoming_buffer);
     call_read_cb(rdma, GRPC_ERROR_REF(error));
     rdma_unref(rdma);
     return;
   }
+  // rdma_continue_read (:307) sizes the slice and calls rdma_do_read (:181); here both are the
+  // device pass below, recorded under the two names the reference uses
+  grdma_profiler cont(GRDMA_STATS_TIME_TRANSPORT_CONTINUE_READ);
+  grdma_profiler do_read(GRDMA_STATS_TIME_TRANSPORT_DO_READ);
   int would_block = 0;
   int64_t n = 0;
   if (rdma->ahead_next >= rdma->ahead.size()) {
@@ -296,6 +301,7 @@ void rdma_handle_read(grpc_rdma* rdma, grpc_error_handle error) {
 }
 
 void rdma_read(grpc_endpoint* ep, grpc_slice_buffer* incoming_buffer, grpc_closure* cb, bool urgent) {
+  grdma_profiler profiler(GRDMA_STATS_TIME_TRANSPORT_READ);  // :345
   grpc_rdma* rdma = reinterpret_cast<grpc_rdma*>(ep);
   if (rdma->read_cb != nullptr) abort();  // GPR_ASSERT(rdma->read_cb == nullptr) :347
   rdma->read_cb = cb;
@@ -320,6 +326,7 @@ void rdma_read(grpc_endpoint* ep, grpc_slice_buffer* incoming_buffer, grpc_closu
 // single Send of the reference would have carried on into those slices.
 // Returns true when the whole buffer has been written or an error is set.
 bool rdma_flush(grpc_rdma* rdma, grpc_error_handle* error) {
+  grdma_profiler profiler(GRDMA_STATS_TIME_TRANSPORT_FLUSH);  // :471
   *error = GRPC_ERROR_NONE;
   auto fail_with = [&](const char* what) {
     *error = rdma_annotate_error(GRPC_ERROR_CREATE_FROM_STATIC_STRING(what), rdma);
@@ -361,6 +368,7 @@ bool rdma_flush(grpc_rdma* rdma, grpc_error_handle* error) {
 }
 
 void rdma_handle_write(grpc_rdma* rdma, grpc_error_handle error) {  // :527-557
+  grdma_profiler profiler(GRDMA_STATS_TIME_TRANSPORT_HANDLE_WRITE);  // :529
   if (error != GRPC_ERROR_NONE) {
     grpc_closure* cb = rdma->write_cb;
     rdma->write_cb = nullptr;
@@ -380,6 +388,7 @@ void rdma_handle_write(grpc_rdma* rdma, grpc_error_handle error) {  // :527-557
 }
 
 void rdma_write(grpc_endpoint* ep, grpc_slice_buffer* buf, grpc_closure* cb, void* /*arg*/) {
+  grdma_profiler profiler(GRDMA_STATS_TIME_TRANSPORT_WRITE);  // :561
   grpc_rdma* rdma = reinterpret_cast<grpc_rdma*>(ep);
   if (rdma->write_cb != nullptr) abort();  // GPR_ASSERT :563
   if (buf->length == 0) {  // :565-574
@@ -611,6 +620,7 @@ static int pollset_deliver(grpc_rdma* rdma, bool in, bool out) {
 }
 
 int grdma_pollset_work(grpc_pollset* ps, int timeout_ms) {
+  grdma_profiler profiler(GRDMA_STATS_TIME_POLLSET_WORK);  // ev_epollex_rdma_bp_linux.cc pollset_work
   using clock = std::chrono::steady_clock;
   ps->stats.passes++;
   const auto t_begin = clock::now();

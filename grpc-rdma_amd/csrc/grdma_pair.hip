@@ -348,6 +348,7 @@ int wait_seq(grdma_pair* p, volatile uint64_t* seq, uint64_t old) {
 }
 
 int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_cursor) {
+  grdma_profiler profiler(GRDMA_STATS_TIME_PAIR_SEND);  // pair.cc:647
   grdma_hostblk* h = p->h;
   h->txop.conn = p->d_conn;
   h->txop.slices = p->h_sges;
@@ -381,6 +382,7 @@ int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_curs
 
 int run_recv(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_reads,
              uint64_t raw_cap) {
+  grdma_profiler profiler(GRDMA_STATS_TIME_PAIR_RECV);  // pair.cc:265
   grdma_hostblk* h = p->h;
   h->rxop.conn = p->d_conn;
   h->rxop.plan = p->d_rxplan;
@@ -1138,6 +1140,7 @@ int grdma_pingpong(grdma_pair* a, grdma_pair* b, const grdma_slice* req, uint64_
     return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(y - x).count();
   };
   auto write_all = [&](grdma_pair* p, const grdma_slice* s, uint64_t n) -> int {
+    grdma_profiler profiler(GRDMA_STATS_TIME_TRANSPORT_WRITE);  // rdma_write, rdma_bp_posix.cc:561
     if (int64_t rc = grdma_endpoint_write_begin(p, s, n, mem_flags); rc < 0) return (int)rc;
     int done = 0;
     for (int tries = 0; !done && tries < 1000; tries++) {
@@ -1147,6 +1150,7 @@ int grdma_pingpong(grdma_pair* a, grdma_pair* b, const grdma_slice* req, uint64_
     return done ? 0 : fail(GRDMA_ERR_HIP, "write did not complete");
   };
   auto read_all = [&](grdma_pair* p, uint64_t want) -> int {
+    grdma_profiler profiler(GRDMA_STATS_TIME_TRANSPORT_READ);  // rdma_read, rdma_bp_posix.cc:345
     uint64_t got = 0;
     for (int tries = 0; got < want && tries < 100000; tries++) {
       int wb = 0;

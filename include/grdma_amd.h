@@ -442,6 +442,61 @@ void grdma_h2_pipe_destroy(grdma_h2_pipe* p);
 /* out = {message starts the last synced step parsed with the boundary step, device-clock ticks inside it} */
 int grdma_h2_pipe_boundary_stats(grdma_h2_pipe* p, uint64_t out[2]);
 
+/* ---- GRPCProfiler: include/grpcpp/stats_time.h:11-44,111-122, src/core/lib/debug/stats_time.cc ----
+ * The reference's scope profiler with its op names in its order: nanoseconds per op per thread slot,
+ * opt-in per thread (init(slot) + enable()), the table {Name, Count, Mean, P50, P95, P99, MAX} per slot
+ * in the unit GRPC_PROFILING_UNIT names (micro / milli / s).  The host layer records
+ * TRANSPORT_{READ,HANDLE_READ,CONTINUE_READ,DO_READ,FLUSH,HANDLE_WRITE,WRITE} in the endpoint mirror
+ * and PAIR_SEND / PAIR_RECV around Send / Recv, where rdma_bp_posix.cc and pair.cc place their
+ * GRPCProfiler objects.  Host only (no device needed). */
+typedef enum grdma_stats_time {
+  GRDMA_STATS_TIME_POLLABLE_EPOLL,
+  GRDMA_STATS_TIME_POLLSET_WORK,
+  GRDMA_STATS_TIME_TRANSPORT_DO_READ,
+  GRDMA_STATS_TIME_TRANSPORT_CONTINUE_READ,
+  GRDMA_STATS_TIME_TRANSPORT_READ_ALLOCATION_DONE,
+  GRDMA_STATS_TIME_TRANSPORT_HANDLE_READ,
+  GRDMA_STATS_TIME_TRANSPORT_READ,
+  GRDMA_STATS_TIME_TRANSPORT_FLUSH,
+  GRDMA_STATS_TIME_TRANSPORT_HANDLE_WRITE,
+  GRDMA_STATS_TIME_TRANSPORT_WRITE,
+  GRDMA_STATS_TIME_PAIR_SEND,
+  GRDMA_STATS_TIME_PAIR_RECV,
+  GRDMA_STATS_TIME_CLIENT_PREPARE,
+  GRDMA_STATS_TIME_CLIENT_CQ_NEXT,
+  GRDMA_STATS_TIME_SERVER_RPC_REQUEST,
+  GRDMA_STATS_TIME_SERVER_RPC_FINISH,
+  GRDMA_STATS_TIME_SERVER_CQ_NEXT,
+  GRDMA_STATS_TIME_BEGIN_WORKER,
+  GRDMA_STATS_TIME_ASYNC_NEXT_INTERNAL,
+  GRDMA_STATS_TIME_FINALIZE_RESULT,
+  GRDMA_STATS_TIME_DESERIALIZE,
+  GRDMA_STATS_TIME_ADHOC_1,
+  GRDMA_STATS_TIME_ADHOC_2,
+  GRDMA_STATS_TIME_ADHOC_3,
+  GRDMA_STATS_TIME_ADHOC_4,
+  GRDMA_STATS_TIME_ADHOC_5,
+  GRDMA_STATS_TIME_ADHOC_6,
+  GRDMA_STATS_TIME_ADHOC_7,
+  GRDMA_STATS_TIME_ADHOC_8,
+  GRDMA_STATS_TIME_ADHOC_9,
+  GRDMA_STATS_TIME_ADHOC_10,
+  GRDMA_STATS_TIME_MAX_OP_SIZE
+} grdma_stats_time;
+void grdma_stats_time_init(int slot);          /* grpc_stats_time_init: the calling thread records into `slot` */
+void grdma_stats_time_enable(void);
+void grdma_stats_time_disable(void);
+int grdma_stats_time_enabled(void);            /* enabled AND the calling thread has a slot */
+void grdma_stats_time_shutdown(void);
+void grdma_stats_time_add(int op, int64_t ns);          /* grpc_stats_time_add */
+void grdma_stats_time_add_custom(int op, int64_t val);  /* grpc_stats_time_add_custom: printed unscaled */
+const char* grdma_stats_time_op_name(int op);           /* grpc_stats_time_op_to_str */
+int64_t grdma_stats_time_now_ns(void);
+/* {mean, p50, p95, p99, max} in ns of one op of one slot; returns the count */
+uint64_t grdma_stats_time_get(int slot, int op, double out[5]);
+/* grpc_stats_time_print into buf (NUL-terminated, truncated to cap); returns the full length */
+int64_t grdma_stats_time_print(char* buf, uint64_t cap);
+
 /* ---- device helpers for callers that keep payloads in HBM ---------------------- */
 void* grdma_device_alloc(uint64_t bytes);
 void grdma_device_free(void* p);
@@ -453,5 +508,19 @@ int grdma_device_synchronize(void);
 
 #ifdef __cplusplus
 }
+/* GRPCProfiler (stats_time.h:111-122): records the lifetime of the object under `op` */
+class grdma_profiler {
+ public:
+  explicit grdma_profiler(int op) : op_(op), begin_(grdma_stats_time_enabled() ? grdma_stats_time_now_ns() : -1) {}
+  ~grdma_profiler() {
+    if (begin_ >= 0) grdma_stats_time_add(op_, grdma_stats_time_now_ns() - begin_);
+  }
+  grdma_profiler(const grdma_profiler&) = delete;
+  grdma_profiler& operator=(const grdma_profiler&) = delete;
+
+ private:
+  int op_;
+  int64_t begin_;
+};
 #endif
 #endif /* GRDMA_AMD_H */

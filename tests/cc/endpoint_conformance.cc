@@ -417,7 +417,20 @@ static void pollset_echo_test(size_t n_conns, size_t rounds, bool bpev) {
          (unsigned long long)st.closures_run);
 }
 
+// GRDMA_PROFILE=1: the run records into profiler slot 0 and prints the reference's table at exit
+// (grpc_stats_time_init / _enable / _print, the way examples/cpp/helloworld.benchmark does)
+static void print_profile() {
+  static char buf[16384];
+  grdma_stats_time_print(buf, sizeof(buf));
+  fputs(buf, stdout);
+}
+
 int main(int argc, char** argv) {
+  if (getenv("GRDMA_PROFILE") && getenv("GRDMA_PROFILE")[0] == '1') {
+    grdma_stats_time_init(0);
+    grdma_stats_time_enable();
+    atexit(print_profile);
+  }
   if (argc >= 5 && !strcmp(argv[1], "pollset")) {
     pollset_echo_test((size_t)atol(argv[2]), (size_t)atol(argv[3]), atoi(argv[4]) != 0);
     return 0;
