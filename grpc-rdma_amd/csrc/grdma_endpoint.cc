@@ -2,6 +2,7 @@
 // Mirrors src/core/lib/iomgr/rdma_bp_posix.cc function by function; the byte work
 // happens in the HIP kernels behind grdma_endpoint_write_* / grdma_endpoint_read.
 #include "../../include/grdma_endpoint.hpp"
+#include "../../include/grdma_profiler.hpp"
 
 #include <sys/epoll.h>
 #include <unistd.h>

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/grdma_amd.h"
+#include "../../include/grdma_profiler.hpp"
 #include "grdma_dev.h"
 #include "grdma_host.h"
 #include "grdma_ops.h"

@@ -508,19 +508,5 @@ int grdma_device_synchronize(void);
 
 #ifdef __cplusplus
 }
-/* GRPCProfiler (stats_time.h:111-122): records the lifetime of the object under `op` */
-class grdma_profiler {
- public:
-  explicit grdma_profiler(int op) : op_(op), begin_(grdma_stats_time_enabled() ? grdma_stats_time_now_ns() : -1) {}
-  ~grdma_profiler() {
-    if (begin_ >= 0) grdma_stats_time_add(op_, grdma_stats_time_now_ns() - begin_);
-  }
-  grdma_profiler(const grdma_profiler&) = delete;
-  grdma_profiler& operator=(const grdma_profiler&) = delete;
-
- private:
-  int op_;
-  int64_t begin_;
-};
 #endif
 #endif /* GRDMA_AMD_H */
