@@ -994,6 +994,7 @@ struct grdma_h2_parser {
 
 static double g_h2_last_kernel_us = 0;
 static uint64_t g_h2_last_boundary_steps = 0;
+static uint64_t g_h2_last_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 // What a parser created without either flag does: the boundary step is on unless the environment
 // says GRDMA_H2_BOUNDARY_STEP=0.
@@ -1039,6 +1040,12 @@ const char* grdma_last_error(void);
 double grdma_h2_last_kernel_us(void) { return g_h2_last_kernel_us; }
 // message starts the last grdma_h2_deframe call took through the boundary step
 uint64_t grdma_h2_last_boundary_steps(void) { return g_h2_last_boundary_steps; }
+// counters of the last grdma_h2_deframe call: {bulk steps, frames parsed in bulk steps, boundary steps,
+// then device-clock ticks: waiting for staged windows, in bulk steps, in boundary steps, in the
+// byte-wise path, total}
+void grdma_h2_last_deframe_stats(uint64_t out[8]) {
+  for (int i = 0; i < 8; i++) out[i] = g_h2_last_stats[i];
+}
 
 int64_t grdma_h2_frame_messages(const grdma_h2_msg* msgs, uint64_t n, uint32_t max_frame,
                                 grdma_slice* d_slices_out, uint64_t slices_cap,
@@ -1192,6 +1199,11 @@ int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_re
   float ms = 0;
   if (hipEventElapsedTime(&ms, hc->e0, hc->e1) == hipSuccess) g_h2_last_kernel_us = 1e3 * ms;
   g_h2_last_boundary_steps = h_res.boundary_steps;
+  {
+    const uint64_t st[8] = {h_res.bulk_steps, h_res.bulk_frames, h_res.boundary_steps, h_res.t_wait,
+                            h_res.t_bulk, h_res.t_boundary, h_res.t_serial, h_res.t_total};
+    for (int i = 0; i < 8; i++) g_h2_last_stats[i] = st[i];
+  }
   const uint64_t m = h_res.nevents < cap ? h_res.nevents : cap;
   if (m && (hipMemcpyAsync(events_out, p->d_ev, sizeof(grdma_h2_event) * m, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess))

@@ -414,6 +414,10 @@ int64_t grdma_h2_parser_live_streams(grdma_h2_parser* p);
 double grdma_h2_last_kernel_us(void);
 /* Message starts the last grdma_h2_deframe call parsed with the boundary step. */
 uint64_t grdma_h2_last_boundary_steps(void);
+/* Counters of the last grdma_h2_deframe call: {bulk steps, frames parsed in bulk steps, boundary steps,
+ * then device-clock ticks: waiting for staged windows, in bulk steps, in boundary steps, in the
+ * byte-wise path, total}. */
+void grdma_h2_last_deframe_stats(uint64_t out[8]);
 /* grpc_chttp2_perform_read (parsing.cc:56-253) + grpc_deframe_unprocessed_incoming_frames
  * (frame_data.cc:92-276) over n delivered slices {offset, length} of d_arena.
  * Returns the number of events; *h2_error = connection error, if any. */

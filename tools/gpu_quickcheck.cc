@@ -105,6 +105,7 @@ struct run_result {
   int64_t n = 0;
   double us = 0;
   uint64_t steps = 0;
+  uint64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 static run_result deframe(const std::vector<bytes>& chunks, bool odd_offsets, int flags) {
@@ -133,6 +134,7 @@ static run_result deframe(const std::vector<bytes>& chunks, bool odd_offsets, in
   R.n = grdma_h2_deframe(p, d, table.data(), table.size(), R.ev.data(), cap, &R.err);
   R.us = grdma_h2_last_kernel_us();
   R.steps = grdma_h2_last_boundary_steps();
+  grdma_h2_last_deframe_stats(R.st);
   if (R.n >= 0) R.ev.resize((size_t)R.n);
   grdma_h2_parser_destroy(p);
   grdma_device_free(d);
@@ -156,6 +158,12 @@ static void check_h2(const char* name, const std::vector<bytes>& body, bool odd,
   SAY("h2_boundary %-28s %s  slices %zu events %lld/%lld err %d/%d steps %llu  kernel_us off %.1f on %.1f\n", name,
       ok ? "PASS" : "FAIL", chunks.size(), (long long)a.n, (long long)b.n, a.err, b.err,
       (unsigned long long)b.steps, a.us, b.us);
+  SAY("  ticks on:  bulk steps %llu (%llu frames) boundary %llu | wait %llu bulk %llu boundary %llu bytewise %llu total %llu\n",
+      (unsigned long long)b.st[0], (unsigned long long)b.st[1], (unsigned long long)b.st[2], (unsigned long long)b.st[3],
+      (unsigned long long)b.st[4], (unsigned long long)b.st[5], (unsigned long long)b.st[6], (unsigned long long)b.st[7]);
+  SAY("  ticks off: bulk steps %llu (%llu frames) | wait %llu bulk %llu bytewise %llu total %llu\n",
+      (unsigned long long)a.st[0], (unsigned long long)a.st[1], (unsigned long long)a.st[3], (unsigned long long)a.st[4],
+      (unsigned long long)a.st[6], (unsigned long long)a.st[7]);
   if (!ok) {
     g_fail++;
     if (a.n > 0 && b.n > 0 && first_diff < a.ev.size() && first_diff < b.ev.size()) {
