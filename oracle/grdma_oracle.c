@@ -175,6 +175,7 @@ int orc_pair_init(orc_pair* p, uint64_t ring_cap, int max_sge) {
 void orc_pair_destroy(orc_pair* p) {
   free(p->ring.buf);
   free(p->staging);
+  free(p->zc_buf);
   memset(p, 0, sizeof(*p));
 }
 
@@ -249,6 +250,121 @@ uint64_t orc_pair_send(orc_pair* p, const orc_slice* slices, uint64_t n,
     }
     p->remote_tail = remote_tail;
   }
+  return written;
+}
+
+int orc_pair_enable_zerocopy(orc_pair* p, uint64_t zc_cap) { /* pair.cc:103,113,120 */
+  free(p->zc_buf);
+  p->zc_buf = (uint8_t*)calloc(1, zc_cap ? zc_cap : 1);
+  p->zc_cap = p->zc_buf ? zc_cap : 0;
+  p->zc_tail = 0;
+  return p->zc_buf ? 0 : -1;
+}
+
+uint8_t* orc_pair_allocate_send_buffer(orc_pair* p, uint64_t size) { /* pair.cc:305-323 */
+  if (size == 0) return NULL;
+  if (p->zc_tail != 0 || p->zc_tail + size > p->zc_cap) return NULL;
+  uint64_t tail = p->zc_tail;
+  p->zc_tail = tail + size;
+  return p->zc_buf + tail;
+}
+
+uint64_t orc_pair_send_zerocopy(orc_pair* p, const orc_slice* slices, uint64_t n,
+                                uint64_t byte_idx) {
+  /* pair.cc:793-941 */
+  orc_ring* rr = &p->peer->ring;
+  uint64_t remote_head = p->status_recv.remote_head;
+  uint64_t remote_tail = p->remote_tail;
+  uint64_t st = 0, total = 0, written = 0;
+  /* the scatter-gather list: {source, length}; at most max_sge entries (+1 after the wrap split) */
+  uint64_t cap_sge = (uint64_t)(p->max_sge > 0 ? p->max_sge : 0) + 4;
+  const uint8_t** sg_ptr = (const uint8_t**)malloc(sizeof(uint8_t*) * cap_sge);
+  uint64_t* sg_len = (uint64_t*)malloc(sizeof(uint64_t) * cap_sge);
+  uint64_t nsge = 0;
+
+  for (uint64_t i = 0; i < n; i++) total += slices[i].len;
+  total -= byte_idx;
+
+  for (uint64_t i = 0; i < n && (int64_t)nsge < (int64_t)p->max_sge; i++) {
+    const uint8_t* ptr = slices[i].ptr + byte_idx;
+    uint64_t len = slices[i].len - byte_idx;
+    uint64_t recv_free = orc_ring_free_size(rr, remote_head, remote_tail);
+    uint64_t send_free = p->staging_cap - st;
+    byte_idx = 0;
+    if (p->zc_buf != NULL && ptr >= p->zc_buf && ptr + len <= p->zc_buf + p->zc_cap) { /* :825-826 */
+      uint64_t pay = len, b = orc_calc_writable(recv_free);
+      if (b < pay) pay = b;
+      /* header, footer and padding are staged; four entries are needed (:830-834) */
+      if (pay == 0 || send_free < 3ull * ORC_ALIGN || (int64_t)(nsge + 4) > (int64_t)p->max_sge) break;
+      uint64_t enc = orc_encoded_size(pay);
+      st64(p->staging + st, pay);                               /* AppendHeader into the staging buffer */
+      sg_ptr[nsge] = p->staging + st; sg_len[nsge] = 8; nsge++;
+      st += 8;
+      sg_ptr[nsge] = ptr; sg_len[nsge] = pay; nsge++;           /* the payload where it lies */
+      uint64_t pad = orc_round_up8(pay) - pay;
+      if (pad > 0) {                                            /* whatever the staging buffer holds there */
+        sg_ptr[nsge] = p->staging + st; sg_len[nsge] = pad; nsge++;
+        st += pad;
+      }
+      st64(p->staging + st, ORC_FOOTER);                        /* AppendFooter */
+      sg_ptr[nsge] = p->staging + st; sg_len[nsge] = 8; nsge++;
+      st += 8;
+      p->zc_tail = (uint32_t)(p->zc_tail - pay);                /* :876, std::atomic_uint32_t */
+      written += pay;
+      remote_tail = (remote_tail + enc) & rr->mask;
+      p->zc_bytes += pay;
+    } else {
+      uint64_t a = orc_calc_writable(send_free), b = orc_calc_writable(recv_free);
+      uint64_t pay = len;
+      if (a < pay) pay = a;
+      if (b < pay) pay = b;
+      if (pay == 0) break;
+      uint64_t enc = orc_encoded_size(pay);
+      st64(p->staging + st, pay);
+      memcpy(p->staging + st + ORC_ALIGN, ptr, pay);
+      st64(p->staging + st + ORC_ALIGN + orc_round_up8(pay), ORC_FOOTER);
+      sg_ptr[nsge] = p->staging + st; sg_len[nsge] = enc; nsge++;
+      written += pay;
+      st += enc;
+      remote_tail = (remote_tail + enc) & rr->mask;
+      p->copy_bytes += pay;
+    }
+  }
+  p->partial_write = written < total; /* :908 */
+  p->staging_used = st;
+  p->wr_count = 0;
+  p->sge_count = nsge;
+  if (nsge > 0) {
+    /* GetWriteRequests(sg_list) + ibv_post_send: the entries land back to back at remote_tail; the
+     * entry that crosses the ring end is split and the rest goes out as a second request at offset 0
+     * (ring_buffer.cc:261-330). */
+    uint64_t at = p->remote_tail, first = 0, second = 0;
+    int wrapped = 0;
+    for (uint64_t k = 0; k < nsge; k++) {
+      const uint8_t* src = sg_ptr[k];
+      uint64_t left = sg_len[k];
+      while (left > 0) {
+        uint64_t room = rr->cap - at, m = left < room ? left : room;
+        memcpy(rr->buf + at, src, m);
+        if (wrapped) second += m; else first += m;
+        src += m; left -= m;
+        at = (at + m) & rr->mask;
+        if (at == 0 && !wrapped) {
+          wrapped = 1;
+          if (left > 0) p->sge_count++;  /* the split entry becomes two (:296-303) */
+        }
+      }
+    }
+    p->wr[0][0] = p->remote_tail; p->wr[0][1] = first;
+    p->wr_count = 1;
+    if (wrapped) {
+      p->wr[1][0] = 0; p->wr[1][1] = second;
+      p->wr_count = 2;
+    }
+    p->remote_tail = remote_tail;
+  }
+  free(sg_ptr);
+  free(sg_len);
   return written;
 }
 

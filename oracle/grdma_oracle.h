@@ -85,6 +85,13 @@ typedef struct orc_pair {
   int wr_count;
   /* endpoint-level state (rdma_bp_posix.cc:45-88) */
   uint64_t leftover_cap;    /* bytes of last_read_buffer retained   */
+  /* zero-copy send buffer (pair.h:96,178,195; pair.cc:103,113,120) */
+  uint8_t* zc_buf;          /* send_buffers_[kZeroCopyBuffer]       */
+  uint64_t zc_cap;
+  uint64_t zc_tail;         /* zerocopy_buffer_tail_                */
+  uint64_t zc_bytes;        /* zerocopy_bytes_                      */
+  uint64_t copy_bytes;      /* copy_bytes_                          */
+  uint64_t sge_count;       /* scatter-gather entries of the last SendZerocopy, after the wrap split */
 } orc_pair;
 
 /* Plan of one PairPollable::Send (pair.cc:671-707): payload bytes taken from
@@ -100,6 +107,20 @@ void orc_pair_connect(orc_pair* a, orc_pair* b);
 uint64_t orc_pair_send(orc_pair* p, const orc_slice* slices, uint64_t n,
                        uint64_t byte_idx);                 /* pair.cc:645-734 */
 uint64_t orc_pair_recv(orc_pair* p, void* dst, uint64_t cap); /* pair.cc:264-286 */
+/* Zero-copy send buffer.  enable: initSendBuffer(kZeroCopyBuffer, size), pair.cc:103,113 (the
+ * reference sizes it from GRPC_RDMA_ZEROCOPY_BUFFER_SIZE_KB ... config.cc:100-106).
+ * allocate: PairPollable::AllocateSendBuffer, pair.cc:305-323 -- succeeds only while the buffer is
+ * empty (tail == 0) and the size fits; NULL otherwise.
+ * send_zerocopy: PairPollable::SendZerocopy, pair.cc:793-941 -- a slice that lies inside the
+ * zero-copy buffer goes out as header / payload / padding / footer scatter-gather entries (only the
+ * 16 + padding tag bytes are staged; the record is limited by the receiver's credit, not by the
+ * staging buffer; it needs 4 free entries and 24 staging bytes), any other slice is encoded into the
+ * staging buffer as Send does; the wire image is the concatenation of the entries at remote_tail,
+ * wrapping once (GetWriteRequests(sg_list), ring_buffer.cc:261-330). */
+int orc_pair_enable_zerocopy(orc_pair* p, uint64_t zc_cap);
+uint8_t* orc_pair_allocate_send_buffer(orc_pair* p, uint64_t size);
+uint64_t orc_pair_send_zerocopy(orc_pair* p, const orc_slice* slices, uint64_t n,
+                                uint64_t byte_idx);
 uint64_t orc_pair_writable(const orc_pair* p);              /* pair.cc:294-301 */
 
 /* One grpc_endpoint_read completion as rdma_bp_posix.cc performs it

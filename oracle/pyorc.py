@@ -54,7 +54,9 @@ OrcPair._fields_ = [
     ("status_recv", OrcStatus), ("status_send", OrcStatus), ("remote_tail", u64),
     ("internal_read_size", u64), ("partial_write", C.c_int), ("max_sge", C.c_int),
     ("credit_msgs", u64), ("peer", C.POINTER(OrcPair)), ("wr", (u64 * 2) * 2),
-    ("wr_count", C.c_int), ("leftover_cap", u64)]
+    ("wr_count", C.c_int), ("leftover_cap", u64),
+    ("zc_buf", C.c_void_p), ("zc_cap", u64), ("zc_tail", u64), ("zc_bytes", u64), ("copy_bytes", u64),
+    ("sge_count", u64)]
 
 
 class OrcEvent(C.Structure):
@@ -103,6 +105,11 @@ def _lib():
     lib.orc_pair_recv.argtypes = [C.POINTER(OrcPair), C.c_void_p, u64]
     lib.orc_pair_writable.restype = u64
     lib.orc_pair_writable.argtypes = [C.POINTER(OrcPair)]
+    lib.orc_pair_enable_zerocopy.argtypes = [C.POINTER(OrcPair), u64]
+    lib.orc_pair_allocate_send_buffer.restype = C.c_void_p
+    lib.orc_pair_allocate_send_buffer.argtypes = [C.POINTER(OrcPair), u64]
+    lib.orc_pair_send_zerocopy.restype = u64
+    lib.orc_pair_send_zerocopy.argtypes = [C.POINTER(OrcPair), C.POINTER(OrcSlice), u64, u64]
     lib.orc_endpoint_read.restype = u64
     lib.orc_endpoint_read.argtypes = [C.POINTER(OrcPair), C.c_void_p, u64p]
     lib.orc_ring_readable.restype = u64
@@ -171,6 +178,39 @@ class OracleLink:
             arr[i].ptr = C.addressof(b)
             arr[i].len = len(s)
         return self.l.orc_pair_send(C.byref(self.p[side]), arr, len(slices), byte_idx)
+
+    # ---- zero-copy send buffer (pair.cc:305-323, 793-941).  A slice is bytes, or ("zc", offset,
+    # length) for a range of the side's zero-copy buffer.
+    def enable_zerocopy(self, side, size):
+        assert self.l.orc_pair_enable_zerocopy(C.byref(self.p[side]), size) == 0
+
+    def allocate_send_buffer(self, side, size):
+        """-> offset into the zero-copy buffer, or None (AllocateSendBuffer returned nullptr)"""
+        q = self.l.orc_pair_allocate_send_buffer(C.byref(self.p[side]), size)
+        return None if not q else q - self.p[side].zc_buf
+
+    def zerocopy_write(self, side, off, data):
+        C.memmove(self.p[side].zc_buf + off, bytes(data), len(data))
+
+    def send_zerocopy(self, side, slices, byte_idx=0):
+        plain = [s for s in slices if not isinstance(s, tuple)]
+        bufs = iter(_keep(plain))
+        keep = []
+        arr = (OrcSlice * max(1, len(slices)))()
+        for i, s in enumerate(slices):
+            if isinstance(s, tuple):
+                arr[i].ptr = self.p[side].zc_buf + s[1]
+                arr[i].len = s[2]
+            else:
+                b = next(bufs)
+                keep.append(b)
+                arr[i].ptr = C.addressof(b)
+                arr[i].len = len(s)
+        return self.l.orc_pair_send_zerocopy(C.byref(self.p[side]), arr, len(slices), byte_idx)
+
+    def zerocopy_state(self, side):
+        q = self.p[side]
+        return dict(tail=q.zc_tail, zerocopy_bytes=q.zc_bytes, copy_bytes=q.copy_bytes, sges=q.sge_count)
 
     def recv(self, side, cap):
         dst = C.create_string_buffer(max(1, cap))
@@ -254,6 +294,15 @@ def ref():
         r.ref_pair_staging_used.argtypes = [C.c_void_p, C.c_int]
         r.ref_pair_state.argtypes = [C.c_void_p, C.c_int, u64p]
         r.ref_pair_last_wrs.argtypes = [C.c_void_p, C.c_int, C.POINTER((u64 * 2) * 2)]
+        r.ref_pair_enable_zerocopy.argtypes = [C.c_void_p, C.c_int, u64]
+        r.ref_pair_allocate_send_buffer.restype = C.c_int64
+        r.ref_pair_allocate_send_buffer.argtypes = [C.c_void_p, C.c_int, u64]
+        r.ref_pair_zerocopy_mem.restype = C.c_void_p
+        r.ref_pair_zerocopy_mem.argtypes = [C.c_void_p, C.c_int]
+        r.ref_pair_send_zerocopy.restype = u64
+        r.ref_pair_send_zerocopy.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                             u64p, u64, u64]
+        r.ref_pair_zerocopy_state.argtypes = [C.c_void_p, C.c_int, u64p]
         r.ref_ring_new.restype = C.c_void_p
         r.ref_ring_new.argtypes = [u64]
         r.ref_ring_free.argtypes = [C.c_void_p]
@@ -294,6 +343,37 @@ class RefLink:
             ptrs[i] = C.addressof(b)
             lens[i] = len(s)
         return self.r.ref_pair_send(self.h, side, ptrs, lens, n, byte_idx, inline_small)
+
+    def enable_zerocopy(self, side, size):
+        self.r.ref_pair_enable_zerocopy(self.h, side, size)
+
+    def allocate_send_buffer(self, side, size):
+        off = self.r.ref_pair_allocate_send_buffer(self.h, side, size)
+        return None if off < 0 else off
+
+    def zerocopy_write(self, side, off, data):
+        C.memmove(self.r.ref_pair_zerocopy_mem(self.h, side) + off, bytes(data), len(data))
+
+    def send_zerocopy(self, side, slices, byte_idx=0):
+        n = len(slices)
+        bufs = iter(_keep([s for s in slices if not isinstance(s, tuple)]))
+        keep = []
+        ptrs = (C.c_void_p * max(1, n))()
+        offs = (C.c_int64 * max(1, n))()
+        lens = (u64 * max(1, n))()
+        for i, s in enumerate(slices):
+            if isinstance(s, tuple):
+                offs[i], lens[i] = s[1], s[2]
+            else:
+                b = next(bufs)
+                keep.append(b)
+                ptrs[i], offs[i], lens[i] = C.addressof(b), -1, len(s)
+        return self.r.ref_pair_send_zerocopy(self.h, side, ptrs, offs, lens, n, byte_idx)
+
+    def zerocopy_state(self, side):
+        st = (u64 * 4)()
+        self.r.ref_pair_zerocopy_state(self.h, side, st)
+        return dict(tail=st[0], zerocopy_bytes=st[1], copy_bytes=st[2], sges=st[3])
 
     def recv(self, side, cap):
         dst = C.create_string_buffer(max(1, cap))

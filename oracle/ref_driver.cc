@@ -111,6 +111,102 @@ class PairPollable {
     return written;
   }
 
+  // pair.cc:103,113,120: the zero-copy send buffer
+  void EnableZerocopy(uint64_t size) {
+    zerocopy_.assign(size, 0);
+    zerocopy_tail_ = 0;
+  }
+
+  // pair.cc:305-323
+  uint8_t* AllocateSendBuffer(size_t size) {
+    if (size == 0) return nullptr;
+    uint32_t tail = zerocopy_tail_;
+    if (tail != 0 || tail + size > zerocopy_.size()) return nullptr;
+    zerocopy_tail_ = (uint32_t)(tail + size);
+    return zerocopy_.data() + tail;
+  }
+
+  // pair.cc:793-941, with the verbs post replaced by execute_wrs().
+  uint64_t SendZerocopy(grpc_slice* slices, size_t slice_count, size_t byte_idx) {
+    uint64_t remote_head = status_recv_.remote_head;
+    uint64_t remote_tail = remote_tail_;
+    uint64_t send_buf_tail = 0;
+    uint64_t total = 0, written = 0;
+    for (size_t i = 0; i < slice_count; i++) total += GRPC_SLICE_LENGTH(slices[i]);
+    total -= byte_idx;
+    sg_list_.clear();
+    last_wr_count_ = 0;
+    for (size_t i = 0; i < slice_count && (int)sg_list_.size() < max_sge_; i++) {
+      uint8_t* slice_ptr = GRPC_SLICE_START_PTR(slices[i]) + byte_idx;
+      uint64_t slice_len = GRPC_SLICE_LENGTH(slices[i]) - byte_idx;
+      uint64_t recv_buf_free = peer_ring().GetFreeSize(remote_head, remote_tail);
+      uint64_t send_buf_free = staging_.size() - send_buf_tail;
+      byte_idx = 0;
+      if (!zerocopy_.empty() && slice_ptr >= zerocopy_.data() &&
+          slice_ptr + slice_len <= zerocopy_.data() + zerocopy_.size()) {
+        uint64_t pay = std::min(slice_len, RingBufferPollable::CalculateWritableSize(recv_buf_free));
+        if (pay == 0 || send_buf_free < 3ul * RingBufferPollable::alignment ||
+            (int)sg_list_.size() + 4 > max_sge_)
+          break;
+        uint64_t enc = RingBufferPollable::GetEncodedSize(pay);
+        ibv_sge sge;
+        sge.lkey = 0;
+        sge.addr = reinterpret_cast<uint64_t>(staging_.data()) + send_buf_tail;  // header
+        sge.length = sizeof(uint64_t);
+        RingBufferPollable::AppendHeader(reinterpret_cast<uint8_t*>(sge.addr), pay);
+        send_buf_tail += sge.length;
+        sg_list_.push_back(sge);
+        sge.addr = reinterpret_cast<uint64_t>(slice_ptr);  // payload where it lies
+        sge.length = (uint32_t)pay;
+        sg_list_.push_back(sge);
+        uint64_t pad = RingBufferPollable::round_up(pay) - pay;
+        if (pad > 0) {
+          sge.addr = reinterpret_cast<uint64_t>(staging_.data()) + send_buf_tail;
+          sge.length = (uint32_t)pad;
+          send_buf_tail += sge.length;
+          sg_list_.push_back(sge);
+        }
+        sge.addr = reinterpret_cast<uint64_t>(staging_.data()) + send_buf_tail;  // footer
+        sge.length = sizeof(uint64_t);
+        RingBufferPollable::AppendFooter(reinterpret_cast<uint8_t*>(sge.addr));
+        send_buf_tail += sge.length;
+        sg_list_.push_back(sge);
+        zerocopy_tail_ -= (uint32_t)pay;
+        written += pay;
+        remote_tail = peer_ring().NextTail(remote_tail, enc);
+        zerocopy_bytes_ += pay;
+      } else {
+        uint64_t pay = std::min(
+            slice_len, std::min(RingBufferPollable::CalculateWritableSize(send_buf_free),
+                                RingBufferPollable::CalculateWritableSize(recv_buf_free)));
+        if (pay == 0) break;
+        uint64_t enc = RingBufferPollable::GetEncodedSize(pay);
+        uint8_t* q = RingBufferPollable::AppendHeader(staging_.data() + send_buf_tail, pay);
+        q = RingBufferPollable::AppendPayload(q, slice_ptr, pay);
+        q = RingBufferPollable::AppendFooter(q);
+        if ((uint64_t)(q - (staging_.data() + send_buf_tail)) != enc) abort();
+        ibv_sge sge;
+        sge.addr = reinterpret_cast<uint64_t>(staging_.data()) + send_buf_tail;
+        sge.length = (uint32_t)enc;
+        sge.lkey = 0;
+        sg_list_.push_back(sge);
+        written += pay;
+        send_buf_tail += enc;
+        remote_tail = peer_ring().NextTail(remote_tail, enc);
+        copy_bytes_ += pay;
+      }
+    }
+    partial_write_ = written < total;
+    last_staging_used_ = send_buf_tail;
+    if (!sg_list_.empty()) {
+      std::array<ibv_send_wr, 2> wrs;
+      remote_tail_ = peer_ring().GetWriteRequests(
+          remote_tail_, peer_->ring_mem_.data(), 0, sg_list_, wrs);
+      execute_wrs(&wrs[0]);
+    }
+    return written;
+  }
+
   // pair.cc:264-286
   uint64_t Recv(void* buf, uint64_t capacity) {
     uint64_t internal = 0;
@@ -152,6 +248,9 @@ class PairPollable {
   status_report status_recv_;
   status_report status_send_;
   std::vector<ibv_sge> sg_list_;
+  std::vector<uint8_t> zerocopy_;  // send_buffers_[kZeroCopyBuffer]
+  uint32_t zerocopy_tail_ = 0;     // std::atomic_uint32_t zerocopy_buffer_tail_, pair.h:178
+  uint64_t zerocopy_bytes_ = 0, copy_bytes_ = 0;
   // Trace of the last Send's work requests: (remote offset, length) per WR.
   uint64_t last_wr_[2][2] = {{0, 0}, {0, 0}};
   int last_wr_count_ = 0;
@@ -387,6 +486,32 @@ uint64_t ref_stream_baseline(uint64_t ring_size, int max_sge, const uint8_t* wir
   *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
   if (checksum) *checksum = sum;
   return delivered;
+}
+
+// Zero-copy send buffer (pair.cc:103-120, 305-323, 793-941).  A slice is given as an offset into the
+// zero-copy buffer (zc_off[i] >= 0) or as a plain pointer (zc_off[i] < 0, ptrs[i]).
+void ref_pair_enable_zerocopy(void* h, int s, uint64_t size) { side(h, s)->EnableZerocopy(size); }
+int64_t ref_pair_allocate_send_buffer(void* h, int s, uint64_t size) {
+  PairPollable* p = side(h, s);
+  uint8_t* q = p->AllocateSendBuffer(size);
+  return q ? (int64_t)(q - p->zerocopy_.data()) : -1;
+}
+uint8_t* ref_pair_zerocopy_mem(void* h, int s) { return side(h, s)->zerocopy_.data(); }
+uint64_t ref_pair_send_zerocopy(void* h, int s, const uint8_t* const* ptrs, const int64_t* zc_off,
+                                const uint64_t* lens, uint64_t n, uint64_t byte_idx) {
+  PairPollable* p = side(h, s);
+  std::vector<const uint8_t*> real(n);
+  for (uint64_t i = 0; i < n; i++) real[i] = zc_off[i] >= 0 ? p->zerocopy_.data() + zc_off[i] : ptrs[i];
+  auto slices = make_slices(real.data(), lens, n, 0);
+  return p->SendZerocopy(slices.data(), slices.size(), byte_idx);
+}
+// {zerocopy_buffer_tail_, zerocopy_bytes_, copy_bytes_, entries of the last scatter-gather list}
+void ref_pair_zerocopy_state(void* h, int s, uint64_t out[4]) {
+  PairPollable* p = side(h, s);
+  out[0] = p->zerocopy_tail_;
+  out[1] = p->zerocopy_bytes_;
+  out[2] = p->copy_bytes_;
+  out[3] = p->sg_list_.size();
 }
 
 // Work requests of the last Send: out[k] = {remote ring offset, length}.

@@ -105,3 +105,86 @@ def test_stream_baseline_port_equals_reference_codec(ring, msg_len):
     n_ref, _s2, chk_ref = pyorc.ref_stream_baseline(ring, 30, wire, lens, 5)
     assert n_port == n_ref == 5 * len(wire)
     assert chk_port == chk_ref
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_zerocopy_send_matches_reference_driver(seed):
+    """PairPollable::AllocateSendBuffer / SendZerocopy (pair.cc:305-323, 793-941): slices inside the
+    zero-copy buffer travel as header / payload / padding / footer scatter-gather entries, other slices
+    are staged, Send and SendZerocopy interleave.  The oracle's restatement against the driver's
+    transcription over the reference-built ring codec: accepted bytes, ring image (padding bytes
+    included: both read them from identically evolving staging buffers), staged bytes, work requests,
+    scatter-gather entry count, buffer tail, counters, state."""
+    rng = random.Random(1000 + seed)
+    R = rng.choice([64, 128, 256, 1024, 4096, 65536])
+    sge = rng.choice([1, 3, 4, 5, 8, 30, 100])
+    Z = rng.choice([64, 4096, 2 * R])
+    a, b = pyorc.OracleLink(R, sge), pyorc.RefLink(R, sge)
+    a.enable_zerocopy(0, Z)
+    b.enable_zerocopy(0, Z)
+    for step in range(60):
+        op = rng.random()
+        if op < 0.45:
+            sl = []
+            for _ in range(rng.randint(1, 6)):
+                n = rng.choice(SIZES + [R // 3, R, Z // 2])
+                if rng.random() < 0.5:
+                    n = min(n, Z)
+                    off_a, off_b = a.allocate_send_buffer(0, n), b.allocate_send_buffer(0, n)
+                    assert off_a == off_b
+                    if off_a is None:  # the buffer is not empty: AllocateSendBuffer refuses
+                        # an arbitrary range of the buffer still counts as "inside" for SendZerocopy
+                        if rng.random() < 0.5:
+                            off_a = rng.randrange(0, Z - n + 1)
+                        else:
+                            sl.append(bytes(rng.getrandbits(8) for _ in range(n)))
+                            continue
+                    data = bytes(rng.getrandbits(8) for _ in range(n))
+                    a.zerocopy_write(0, off_a, data)
+                    b.zerocopy_write(0, off_a, data)
+                    sl.append(("zc", off_a, n))
+                else:
+                    sl.append(bytes(rng.getrandbits(8) for _ in range(n)))
+            first = sl[0][2] if isinstance(sl[0], tuple) else len(sl[0])
+            bi = rng.randrange(first) if rng.random() < 0.3 else 0
+            assert a.send_zerocopy(0, sl, bi) == b.send_zerocopy(0, sl, bi)
+            assert a.staging_mem(0) == b.staging_mem(0)
+            assert a.last_wrs(0) == b.last_wrs(0)
+            assert a.zerocopy_state(0) == b.zerocopy_state(0)
+        elif op < 0.55:
+            sl = [bytes(rng.getrandbits(8) for _ in range(rng.choice(SIZES + [R // 3]))) for _ in range(rng.randint(1, 4))]
+            assert a.send(0, sl) == b.send(0, sl)
+        elif op < 0.8:
+            cap = rng.choice([1, 8, 64, 256, R])
+            assert a.recv(1, cap) == b.recv(1, cap)
+        else:
+            assert a.endpoint_read(1) == b.endpoint_read(1)
+        same(a, b, (seed, step))
+    a.close(); b.close()
+
+
+def test_zerocopy_rules():
+    """The rules spelled out: the allocator only serves an empty buffer; a zero-copy record is limited
+    by the receiver's credit and not by the staging buffer; it needs four free entries."""
+    R = 4096
+    for L in (pyorc.OracleLink(R, 30), pyorc.RefLink(R, 30)):
+        L.enable_zerocopy(0, 8192)
+        assert L.allocate_send_buffer(0, 0) is None
+        assert L.allocate_send_buffer(0, 8193) is None
+        off = L.allocate_send_buffer(0, 3000)
+        assert off == 0 and L.allocate_send_buffer(0, 16) is None      # tail != 0
+        L.zerocopy_write(0, 0, bytes(range(256)) * 12)
+        # 3000 bytes > W(staging = 2048) = 2024: Send would cut the record, SendZerocopy does not
+        assert L.send_zerocopy(0, [("zc", 0, 3000)]) == 3000
+        st = L.zerocopy_state(0)
+        assert st["tail"] == 0 and st["zerocopy_bytes"] == 3000 and st["sges"] == 3   # 3000 % 8 == 0: no padding entry
+        assert L.allocate_send_buffer(0, 16) == 0                      # empty again
+        got = L.recv(1, 4096)
+        assert got == (bytes(range(256)) * 12)[:3000]
+        L.close()
+    for L in (pyorc.OracleLink(R, 3), pyorc.RefLink(R, 3)):           # three entries: never enough
+        L.enable_zerocopy(0, 64)
+        assert L.allocate_send_buffer(0, 10) == 0
+        assert L.send_zerocopy(0, [("zc", 0, 10)]) == 0
+        assert L.zerocopy_state(0)["tail"] == 10
+        L.close()
