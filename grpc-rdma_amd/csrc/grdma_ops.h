@@ -25,6 +25,19 @@ struct grdma_tx_op {
                                    // would be a PCIe round trip in front of the release)
 };
 
+// One PairPollable::SendZerocopy (pair.cc:793-941) for one connection.
+struct grdma_zc_op {
+  struct grdma_conn* conn;
+  const struct grdma_sge* slices;
+  uint64_t nslices;
+  uint64_t byte_idx;
+  struct grdma_plan* plan;         // gather plan: slices / zero-copy buffer -> records in the peer ring
+  struct grdma_tx_result* result;  // dbg[0..4) = zero-copy payload bytes, staged (copied) payload bytes,
+                                   // scatter-gather entries after the wrap split, zero-copy records
+  const uint8_t* zc_base;          // send_buffers_[kZeroCopyBuffer]
+  uint64_t zc_cap;
+};
+
 // One drain of a connection's ring: a run of endpoint_read completions.
 struct grdma_rx_op {
   struct grdma_conn* conn;

@@ -37,6 +37,7 @@ hipError_t grdma_launch_link(lk_ctl* const*, uint32_t, uint32_t, uint64_t, hipSt
 uint32_t grdma_link_resident_blocks(void);
 hipError_t grdma_launch_tx_plan(const grdma_tx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_tx_plan_seq(const grdma_tx_op*, uint32_t, uint32_t, hipStream_t);
+hipError_t grdma_launch_tx_plan_zc(const grdma_zc_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_copy(const grdma_plan* const*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_apply(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
@@ -122,6 +123,7 @@ struct grdma_hostblk {
   grdma_tx_result txres;
   grdma_rx_result rxres;
   const grdma_plan* plan_ptrs[4];  // [0] tx gather, [1] wire, [2] rx scatter
+  grdma_zc_op zcop;                // SendZerocopy
 };
 
 struct grdma_pair {
@@ -157,6 +159,12 @@ struct grdma_pair {
   hipStream_t stream = nullptr;
   int wakeup_fd = -1;                // grpc_wakeup_fd of the pair (pair.h:187): an eventfd
   std::mutex fd_mu;                  // creation of wakeup_fd
+  // zero-copy send buffer (send_buffers_[kZeroCopyBuffer], pair.h:96,178,195)
+  uint8_t* d_zc = nullptr;
+  uint64_t zc_cap = 0;
+  uint32_t zc_tail = 0;              // zerocopy_buffer_tail_ (std::atomic_uint32_t)
+  uint64_t zc_bytes = 0, zc_copy_bytes = 0, zc_last_sges = 0;
+  std::mutex zc_mu;
   // endpoint_write context
   std::vector<grdma_slice> w_slices;
   uint64_t w_idx = 0, w_byte = 0;
@@ -528,6 +536,7 @@ void grdma_pair_destroy(grdma_pair* p) {
   hipFree(p->d_rxplan);
   hipFree(p->d_arena);
   hipFree(p->d_hist);
+  hipFree(p->d_zc);
   if (p->h) hipHostFree(p->h);
   if (p->h_sges) hipHostFree(p->h_sges);
   if (p->h_slices) hipHostFree(p->h_slices);
@@ -1038,6 +1047,85 @@ int grdma_pair_peek_staging(grdma_pair* p, uint64_t off, void* host_dst, uint64_
   if (!p || off + len > p->ring_size / 2) return fail(GRDMA_ERR_INVALID, "range outside staging");
   HIP_TRY(hipStreamSynchronize(p->stream));
   HIP_TRY(hipMemcpy(host_dst, p->d_staging + off, len, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- zero-copy send buffer: pair.cc:103-120 (initSendBuffer(kZeroCopyBuffer)), :305-323
+// (AllocateSendBuffer), :793-941 (SendZerocopy) ------------------------------------------------
+int grdma_pair_enable_zerocopy(grdma_pair* p, uint64_t bytes) {
+  if (int rc = require_ctx()) return rc;
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (bytes == 0) {  // the reference sizes it from its Config (config.cc:100-106)
+    grdma_config cfg;
+    if (grdma_config_from_env(&cfg) < 0) return fail(GRDMA_ERR_INVALID, "bad configuration");
+    bytes = (uint64_t)cfg.zerocopy_buffer_size_kb * 1024;
+  }
+  if (bytes >= (1ull << 32)) return fail(GRDMA_ERR_INVALID, "zero-copy buffer of %llu bytes: the tail is 32 bits",
+                                         (unsigned long long)bytes);
+  std::lock_guard<std::mutex> lk(p->zc_mu);
+  if (p->d_zc && p->zc_cap == bytes) return 0;
+  if (p->zc_tail != 0) return fail(GRDMA_ERR_INVALID, "zero-copy buffer in use");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->d_zc) hipFree(p->d_zc);
+  p->d_zc = nullptr;
+  p->zc_cap = 0;
+  HIP_TRY(hipMalloc((void**)&p->d_zc, bytes));
+  p->zc_cap = bytes;
+  return 0;
+}
+
+void* grdma_pair_allocate_send_buffer(grdma_pair* p, uint64_t size) {
+  if (require_ctx() != 0 || !p || size == 0) return nullptr;                  // :306-308
+  if (!p->d_zc && grdma_pair_enable_zerocopy(p, 0) != 0) return nullptr;
+  std::lock_guard<std::mutex> lk(p->zc_mu);
+  const uint32_t tail = p->zc_tail;
+  if (tail != 0 || (uint64_t)tail + size > p->zc_cap) return nullptr;        // :315-318: only an empty buffer serves
+  p->zc_tail = (uint32_t)(tail + size);
+  return p->d_zc + tail;
+}
+
+int64_t grdma_pair_send_zerocopy(grdma_pair* p, const grdma_slice* slices, uint64_t count, uint64_t byte_idx,
+                                 int flags) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || (!slices && count)) return fail(GRDMA_ERR_INVALID, "null argument");
+  if (flags & GRDMA_MEM_HOST)
+    return fail(GRDMA_ERR_INVALID, "SendZerocopy takes device-accessible slices (the payload is read where it lies)");
+  if (count == 0) return 0;
+  if (byte_idx >= slices[0].len && slices[0].len > 0)
+    return fail(GRDMA_ERR_INVALID, "byte_idx %llu beyond the first slice", (unsigned long long)byte_idx);
+  grdma_profiler profiler(GRDMA_STATS_TIME_PAIR_SEND);  // pair.cc:795
+  if (int rc = stage_slices(p, slices, count, byte_idx, GRDMA_MEM_DEVICE)) return rc;
+  grdma_hostblk* h = p->h;
+  h->zcop.conn = p->d_conn;
+  h->zcop.slices = p->h_sges;
+  h->zcop.nslices = count;
+  h->zcop.byte_idx = byte_idx;
+  h->zcop.plan = p->d_txplan;
+  h->zcop.result = &h->txres;
+  h->zcop.zc_base = p->d_zc;
+  h->zcop.zc_cap = p->zc_cap;
+  HIP_TRY(grdma_launch_tx_plan_zc(&h->zcop, 1, p->stream));
+  // the records go straight into the peer ring: one gather launch, no wire launch
+  HIP_TRY(grdma_launch_copy(&h->plan_ptrs[0], 1, copy_blocks_for(p->ring_size), p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  {
+    std::lock_guard<std::mutex> lk(p->zc_mu);
+    p->zc_tail = (uint32_t)(p->zc_tail - (uint32_t)h->txres.dbg[0]);  // :876
+    p->zc_bytes += h->txres.dbg[0];
+    p->zc_copy_bytes += h->txres.dbg[1];
+    p->zc_last_sges = h->txres.dbg[2];
+  }
+  return (int64_t)h->txres.sent;
+}
+
+// out = {zerocopy_buffer_tail_, zerocopy_bytes_, copy_bytes_, scatter-gather entries of the last SendZerocopy}
+int grdma_pair_zerocopy_state(grdma_pair* p, uint64_t out[4]) {
+  if (!p || !out) return fail(GRDMA_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(p->zc_mu);
+  out[0] = p->zc_tail;
+  out[1] = p->zc_bytes;
+  out[2] = p->zc_copy_bytes;
+  out[3] = p->zc_last_sges;
   return 0;
 }
 

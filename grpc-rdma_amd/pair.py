@@ -90,6 +90,26 @@ class Pair:
             flags = MEM_HOST if host else MEM_DEVICE
         return check(self.lib.grdma_pair_send(self.h, arr, len(slices), byte_idx, flags))
 
+    # -- zero-copy send buffer (pair.cc:305-323, 793-941) ----------------------------
+    def enable_zerocopy(self, nbytes=0):
+        check(self.lib.grdma_pair_enable_zerocopy(self.h, nbytes))
+
+    def AllocateSendBuffer(self, size):
+        """-> device pointer into the pair's zero-copy buffer, or None (as the reference's nullptr)."""
+        return self.lib.grdma_pair_allocate_send_buffer(self.h, size) or None
+
+    def SendZerocopy(self, slices, byte_idx=0):
+        """slices: DeviceBuffer or (device ptr, len) -- ranges of the zero-copy buffer among them."""
+        arr, keep, host = self._slices(slices)
+        if host:
+            raise GrdmaError("SendZerocopy takes device-accessible slices")
+        return check(self.lib.grdma_pair_send_zerocopy(self.h, arr, len(slices), byte_idx, MEM_DEVICE))
+
+    def zerocopy_state(self):
+        out = (C.c_uint64 * 4)()
+        check(self.lib.grdma_pair_zerocopy_state(self.h, out))
+        return dict(tail=out[0], zerocopy_bytes=out[1], copy_bytes=out[2], sges=out[3])
+
     def Recv(self, capacity):
         """-> bytes (copied to the host for inspection)."""
         dst = C.create_string_buffer(max(1, capacity))

@@ -165,6 +165,31 @@ int grdma_pair_has_pending_writes(grdma_pair* p);  /* HasPendingWrites(), pair.c
 int64_t grdma_pair_readable_size(grdma_pair* p);   /* GetReadableSize(), ring_buffer.cc:67 */
 int64_t grdma_pair_writable_size(grdma_pair* p);   /* GetWritableSize(), pair.cc:294-301   */
 
+/* Zero-copy send buffer (pair.h:96,127,140; pair.cc:103-120, 305-323, 793-941).
+ * grdma_pair_enable_zerocopy   initSendBuffer(kZeroCopyBuffer): `bytes` of device memory owned by the
+ *                              pair (0 = GRPC_RDMA_ZEROCOPY_BUFFER_SIZE_KB as the reference's Config
+ *                              reads it); allocate_send_buffer enables it on first use.
+ * grdma_pair_allocate_send_buffer  AllocateSendBuffer(size): a device pointer into that buffer, or NULL
+ *                              when size == 0, the buffer is not empty (the reference serves one
+ *                              allocation at a time: tail != 0 -> nullptr) or the size does not fit.
+ *                              The caller serialises its message there (device-side).
+ * grdma_pair_send_zerocopy     SendZerocopy(slices, count, byte_idx): a slice that lies inside the
+ *                              zero-copy buffer becomes a record whose payload is read where it lies
+ *                              (limited by the receiver's credit only; the reference stages 16 +
+ *                              padding tag bytes and uses 4 of its max_sge entries for it), any other
+ *                              slice is priced as Send prices it.  Device-accessible slices only.
+ *                              Returns the payload bytes accepted; partial_write, remote_tail and the
+ *                              <= 2 work requests (grdma_pair_last_wrs) as the reference leaves them.
+ *                              On this wire every record of the call goes straight from its source into
+ *                              the peer ring (one gather launch); nothing is written to the staging buffer.
+ * grdma_pair_zerocopy_state    out = {zerocopy_buffer_tail_, zerocopy_bytes_, copy_bytes_, scatter-gather
+ *                              entries the reference's list would hold after the last call}. */
+int grdma_pair_enable_zerocopy(grdma_pair* p, uint64_t bytes);
+void* grdma_pair_allocate_send_buffer(grdma_pair* p, uint64_t size);
+int64_t grdma_pair_send_zerocopy(grdma_pair* p, const grdma_slice* slices, uint64_t count,
+                                 uint64_t byte_idx, int flags);
+int grdma_pair_zerocopy_state(grdma_pair* p, uint64_t out[4]);
+
 /* Observability used by the parity tests (debug monitor of pair.h:235-270). */
 typedef struct grdma_pair_state {
   uint64_t head, moving_head, remain;              /* ring_buffer.h:203-205 */

@@ -1,11 +1,16 @@
-// A few seconds of GPU time: device-side checks of code paths that are switched on by a flag, each
-// against the kernel's own verified path on the same input (no Python, no oracle: the process starts in
-// well under a second, which is what is left of a round's GPU budget when this is needed).
+// TEST INFRASTRUCTURE.  A few seconds of GPU time: device-side checks of new code paths, each against
+// the kernel's own verified path on the same input or against the CPU oracle (oracle/, linked here as
+// the checker).  No Python: the process starts in well under a second, which is what is left of a
+// round's GPU budget when this is needed.
 //
 //   h2 boundary step   k_h2_deframe with GRDMA_H2_BOUNDARY_STEP vs GRDMA_H2_NO_BOUNDARY_STEP: identical
 //                      event lists on the bench shape (1 MiB messages as the receiving side sees them),
 //                      on mixed sizes in sender and receiver shape, with slices at odd arena offsets;
 //                      kernel time of both.
+//   zero-copy send     grdma_pair_allocate_send_buffer / grdma_pair_send_zerocopy (k_tx_plan_zc + k_copy)
+//                      against orc_pair_allocate_send_buffer / orc_pair_send_zerocopy: seeded sequences of
+//                      zero-copy sends (buffer slices, ordinary slices, both), plain Sends and Recvs;
+//                      accepted bytes, work requests, entry counts, ring image, state, delivered bytes.
 //
 // usage: gpu_quickcheck [out_file]      exit code 0 = every check passed
 #include <signal.h>
@@ -18,6 +23,9 @@
 #include <vector>
 
 #include "grdma_amd.h"
+extern "C" {
+#include "oracle/grdma_oracle.h"
+}
 
 typedef std::vector<uint8_t> bytes;
 static FILE* g_out = nullptr;
@@ -174,9 +182,162 @@ static void check_h2(const char* name, const std::vector<bytes>& body, bool odd,
   }
 }
 
+// ---- zero-copy send against the oracle ------------------------------------------------------------
+static uint32_t g_rng = 12345;
+static uint32_t rnd() { g_rng = g_rng * 1664525u + 1013904223u; return g_rng >> 8; }
+
+// every differing byte must be a padding byte (the device writes zeros there, the oracle's come from its
+// staging history): it is zero on the device and the next word is the footer in both images
+static bool ring_eq(const bytes& x, const bytes& y) {
+  const size_t R = x.size();
+  for (size_t i = 0; i < R; i++) {
+    if (x[i] == y[i]) continue;
+    if (x[i] != 0) return false;
+    const size_t nxt = ((i & ~(size_t)7) + 8) % R;
+    for (size_t k = 0; k < 8; k++)
+      if (x[nxt + k] != 0xFF || y[nxt + k] != 0xFF) return false;
+  }
+  return true;
+}
+
+static bool zc_sequence(uint64_t R, int sge, uint64_t Z, uint32_t seed, int steps, std::string* why) {
+  g_rng = seed;
+  grdma_pair* a = grdma_pair_create(R, sge, 0);
+  grdma_pair* b = grdma_pair_create(R, sge, 0);
+  orc_pair oa, ob;
+  if (!a || !b || grdma_pair_connect(a, b) != 0 || grdma_pair_enable_zerocopy(a, Z) != 0 ||
+      orc_pair_init(&oa, R, sge) || orc_pair_init(&ob, R, sge) || orc_pair_enable_zerocopy(&oa, Z)) {
+    *why = "setup failed";
+    return false;
+  }
+  orc_pair_connect(&oa, &ob);
+  uint8_t* zc_dev = nullptr;  // base of the device zero-copy buffer (the first allocation returns it)
+  bool ok = true;
+  const uint64_t sizes[] = {1, 2, 7, 8, 9, 15, 16, 17, 23, 24, 100, 255, 256, 257, R / 3, R, Z / 2};
+  for (int step = 0; step < steps && ok; step++) {
+    const uint32_t op = rnd() % 100;
+    char where[96];
+    snprintf(where, sizeof(where), "R %llu sge %d Z %llu seed %u step %d", (unsigned long long)R, sge,
+             (unsigned long long)Z, seed, step);
+    if (op < 55) {
+      const int n = 1 + rnd() % 5;
+      std::vector<grdma_slice> dsl;
+      std::vector<orc_slice> osl;
+      std::vector<void*> dev_allocs;
+      std::vector<bytes> host_keep;
+      host_keep.reserve(n);
+      for (int i = 0; i < n; i++) {
+        uint64_t len = sizes[rnd() % (sizeof(sizes) / sizeof(sizes[0]))];
+        if (len == 0) len = 1;
+        const bool want_zc = rnd() % 2 == 0;
+        bytes data(len);
+        for (auto& v : data) v = (uint8_t)rnd();
+        if (want_zc && len <= Z) {
+          void* dptr = grdma_pair_allocate_send_buffer(a, len);
+          uint8_t* optr = orc_pair_allocate_send_buffer(&oa, len);
+          if ((dptr == nullptr) != (optr == nullptr)) { ok = false; *why = std::string("allocate disagrees, ") + where; break; }
+          uint64_t off;
+          if (dptr) {
+            if (!zc_dev) zc_dev = static_cast<uint8_t*>(dptr);
+            off = (uint64_t)(static_cast<uint8_t*>(dptr) - zc_dev);
+            if (off != (uint64_t)(optr - oa.zc_buf)) { ok = false; *why = std::string("allocate offset, ") + where; break; }
+          } else if (zc_dev && rnd() % 2) {
+            off = rnd() % (Z - len + 1);  // any range of the buffer counts as inside
+          } else {
+            off = ~0ull;
+          }
+          if (off != ~0ull) {
+            grdma_copy_to_device(zc_dev + off, data.data(), len);
+            memcpy(oa.zc_buf + off, data.data(), len);
+            dsl.push_back({zc_dev + off, len});
+            osl.push_back({oa.zc_buf + off, len});
+            continue;
+          }
+        }
+        const uint64_t shift = rnd() % 16;
+        uint8_t* d = static_cast<uint8_t*>(grdma_device_alloc(len + 16));
+        dev_allocs.push_back(d);
+        grdma_copy_to_device(d + shift, data.data(), len);
+        host_keep.push_back(data);
+        dsl.push_back({d + shift, len});
+        osl.push_back({host_keep.back().data(), len});
+      }
+      if (!ok) break;
+      const uint64_t bi = (rnd() % 10 < 3) ? rnd() % dsl[0].len : 0;
+      const int64_t sd = grdma_pair_send_zerocopy(a, dsl.data(), dsl.size(), bi, 0);
+      const uint64_t so = orc_pair_send_zerocopy(&oa, osl.data(), osl.size(), bi);
+      uint64_t wr[2][2] = {{0, 0}, {0, 0}}, zs[4];
+      const int nwr = grdma_pair_last_wrs(a, wr);
+      grdma_pair_zerocopy_state(a, zs);
+      if (sd != (int64_t)so) { ok = false; *why = std::string("accepted bytes differ, ") + where; }
+      else if (nwr != oa.wr_count) { ok = false; *why = std::string("work request count, ") + where; }
+      else if (zs[0] != oa.zc_tail || zs[1] != oa.zc_bytes || zs[2] != oa.copy_bytes || zs[3] != oa.sge_count) {
+        ok = false;
+        *why = std::string("zero-copy state (tail / bytes / copied / entries), ") + where;
+      }
+      for (int k = 0; ok && k < nwr; k++)
+        if (wr[k][0] != oa.wr[k][0] || wr[k][1] != oa.wr[k][1]) { ok = false; *why = std::string("work requests, ") + where; }
+      for (void* d : dev_allocs) grdma_device_free(d);
+    } else if (op < 65) {
+      const uint64_t len = sizes[rnd() % 14];
+      bytes data(len);
+      for (auto& v : data) v = (uint8_t)rnd();
+      uint8_t* d = static_cast<uint8_t*>(grdma_device_alloc(len + 16));
+      grdma_copy_to_device(d, data.data(), len);
+      grdma_slice ds = {d, len};
+      orc_slice os = {data.data(), len};
+      const int64_t sd = grdma_pair_send(a, &ds, 1, 0, 0);
+      const uint64_t so = orc_pair_send(&oa, &os, 1, 0);
+      if (sd != (int64_t)so) { ok = false; *why = std::string("plain Send differs, ") + where; }
+      grdma_device_free(d);
+    } else {
+      const uint64_t caps[] = {1, 8, 64, 256, R};
+      const uint64_t cap = caps[rnd() % 5];
+      bytes gd(cap), go(cap);
+      const int64_t nd = grdma_pair_recv(b, gd.data(), cap, GRDMA_MEM_HOST);
+      const uint64_t no = orc_pair_recv(&ob, go.data(), cap);
+      if (nd != (int64_t)no || memcmp(gd.data(), go.data(), no) != 0) { ok = false; *why = std::string("Recv differs, ") + where; }
+    }
+    if (!ok) break;
+    bytes ring(R), oring(ob.ring.buf, ob.ring.buf + R);
+    grdma_pair_state sa, sb;
+    if (grdma_pair_peek_ring(b, 0, ring.data(), R) != 0 || grdma_pair_state_get(a, &sa) != 0 ||
+        grdma_pair_state_get(b, &sb) != 0) { ok = false; *why = std::string("peek failed, ") + where; break; }
+    if (!ring_eq(ring, oring)) { ok = false; *why = std::string("ring image differs, ") + where; break; }
+    if (sa.remote_tail != oa.remote_tail || sa.partial_write != (uint64_t)oa.partial_write ||
+        sa.remote_head != oa.status_recv.remote_head || sb.head != ob.ring.head || sb.moving_head != ob.ring.moving_head ||
+        sb.remain != ob.ring.remain || sb.internal_read_size != ob.internal_read_size || sb.credit_msgs != ob.credit_msgs) {
+      ok = false;
+      *why = std::string("state differs, ") + where;
+    }
+  }
+  grdma_pair_destroy(a);
+  grdma_pair_destroy(b);
+  orc_pair_destroy(&oa);
+  orc_pair_destroy(&ob);
+  return ok;
+}
+
+static void check_zerocopy() {
+  const struct { uint64_t R; int sge; uint64_t Z; } cfg[] = {
+      {4096, 30, 8192}, {256, 5, 64}, {65536, 8, 4096}, {1024, 4, 2048}, {64, 100, 128}, {1u << 20, 30, 1u << 21}};
+  int pass = 0, total = 0;
+  for (uint32_t seed = 1; seed <= 3; seed++)
+    for (const auto& c : cfg) {
+      std::string why;
+      total++;
+      if (zc_sequence(c.R, c.sge, c.Z, seed * 7919u, 40, &why)) pass++;
+      else {
+        g_fail++;
+        SAY("zerocopy FAIL: %s\n", why.c_str());
+      }
+    }
+  SAY("zerocopy sequences vs oracle: %d / %d %s\n", pass, total, pass == total ? "PASS" : "FAIL");
+}
+
 int main(int argc, char** argv) {
   signal(SIGALRM, on_alarm);
-  alarm(argc > 2 ? atoi(argv[2]) : 12);
+  alarm(argc > 2 ? atoi(argv[2]) : 20);
   if (argc > 1) g_out = fopen(argv[1], "w");
   if (grdma_init(0) != 0) {
     SAY("gpu_quickcheck: grdma_init failed: %s\n", grdma_last_error());
@@ -208,6 +369,7 @@ int main(int argc, char** argv) {
     }
     check_h2("mixed sizes, cut slices, odd", cut, true, 1);
   }
+  check_zerocopy();
   SAY("gpu_quickcheck: %s\n", g_fail ? "FAILED" : "ALL PASS");
   if (g_out) fclose(g_out);
   return g_fail ? 1 : 0;
