@@ -78,6 +78,7 @@ struct grdma_h2_parser_dev {
   uint32_t tab_mask;
   int32_t error;        // connection error (grdma_h2_error), sticky
   int32_t boundary_step;  // 1 = message starts go through h2_boundary_match (grdma_h2_fast.h)
+  int32_t bulk_pairs;     // 1 = the bulk step gives every lane a frame (64 frames, 128 slices per step)
   grdma_h2_stream_dev* tab;
 };
 
@@ -660,15 +661,20 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
     if (st == ST_FH0 && expect_cont == 0 && !is_first_frame && D.idx >= 0 && !D.read_closed && D.state == 5 &&
         D.fsz != 0) {
       const uint64_t tb0 = __builtin_amdgcn_s_memtime();
-      // lane i looks at slice s + i (the windows it needs: the current one and, when s is not
-      // window aligned, the next one -- staged, or beyond the end of the list)
-      const int rel = lane;
-      const uint64_t last_ix = s + 63 < nslices ? s + 63 : nslices - 1;
+      // lane i looks at slice s + i and every even lane owns a frame (the windows needed: the current
+      // one and, when s is not window aligned, the next one -- staged, or beyond the end of the
+      // list); with bulk_pairs lane i owns the frame in slices s + 2 i and s + 2 i + 1, 64 frames per
+      // step over up to three windows (asked for in order: a window's flag says nothing about the
+      // one before it, which another helper wave stages)
+      const bool pairs = P.bulk_pairs != 0;
+      if (pairs) h2_need(V, s + 64 < nslices ? s + 64 : nslices - 1);
+      const uint64_t last_ix = s + (pairs ? 127 : 63) < nslices ? s + (pairs ? 127 : 63) : nslices - 1;
       h2_need(V, last_ix);
-      const uint64_t my_ix = s + (uint64_t)lane < nslices ? s + (uint64_t)lane : nslices - 1;
+      const uint64_t my_raw = s + (pairs ? 2ull * (uint64_t)lane : (uint64_t)lane);
+      const uint64_t my_ix = my_raw < nslices ? my_raw : nslices - 1;
       const uint64_t nx_ix = my_ix + 1 < nslices ? my_ix + 1 : nslices - 1;
       const h2_win_ent me = *h2_ent(V, my_ix);
-      const bool hdr_lane = (lane & 1) == 0 && s + (uint64_t)lane + 1 < nslices;
+      const bool hdr_lane = (pairs || (lane & 1) == 0) && my_raw + 1 < nslices;
       const uint64_t my_len = me.len;
       const uint64_t b8 = me.c0;
       const uint32_t fs = (uint32_t)(((b8 & 0xFF) << 16) | (((b8 >> 8) & 0xFF) << 8) | ((b8 >> 16) & 0xFF));
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
         if (nev + nevs + 1 <= ev_cap) {
           if (within) {
             grdma_h2_event* e = ev + nev + epos - (p0 ? 5u : 3u);
-            const uint32_t sl = (uint32_t)(s + (uint64_t)rel);
+            const uint32_t sl = (uint32_t)my_raw;
             h2_store_event(e, EV_FRAME, FT_DATA, 0, sd, fs, sl);
             if (p0) {
               h2_store_event(e + 1, EV_PAYLOAD, 9, p0, 0, 0, sl);
@@ -996,6 +1002,15 @@ static double g_h2_last_kernel_us = 0;
 static uint64_t g_h2_last_boundary_steps = 0;
 static uint64_t g_h2_last_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
+// 64 frames per bulk step (GRDMA_H2_BULK_PAIRS): off unless the flag or GRDMA_H2_BULK_PAIRS=1 asks for it
+static int h2_bulk_pairs_default() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GRDMA_H2_BULK_PAIRS");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v;
+}
 // What a parser created without either flag does: the boundary step is on unless the environment
 // says GRDMA_H2_BOUNDARY_STEP=0.
 static int h2_boundary_default() {
@@ -1103,6 +1118,7 @@ grdma_h2_parser* grdma_h2_parser_create_ex(int flags, uint32_t max_frame_size,
   init.max_concurrent = max_concurrent_streams;  // http2_settings.cc:46 default 0xffffffff
   init.tab_mask = table_slots - 1;
   init.boundary_step = (flags & GRDMA_H2_BOUNDARY_STEP) ? 1 : (flags & GRDMA_H2_NO_BOUNDARY_STEP) ? 0 : h2_boundary_default();
+  init.bulk_pairs = (flags & GRDMA_H2_BULK_PAIRS) ? 1 : h2_bulk_pairs_default();
   if (hipMalloc((void**)&p->d, sizeof(init)) != hipSuccess ||
       hipMalloc((void**)&p->d_tab, sizeof(grdma_h2_stream_dev) * table_slots) != hipSuccess ||
       hipMalloc((void**)&p->d_res, sizeof(grdma_h2_deframe_result)) != hipSuccess ||

@@ -157,6 +157,15 @@ static void check_h2(const char* name, const std::vector<bytes>& body, bool odd,
   chunks.insert(chunks.end(), body.begin(), body.end());
   const run_result a = deframe(chunks, odd, GRDMA_H2_NO_BOUNDARY_STEP);
   const run_result b = deframe(chunks, odd, GRDMA_H2_BOUNDARY_STEP);
+  const run_result c = deframe(chunks, odd, GRDMA_H2_BOUNDARY_STEP | GRDMA_H2_BULK_PAIRS);
+  {
+    bool okc = c.n == a.n && c.err == 0;
+    for (size_t i = 0; okc && i < a.ev.size(); i++)
+      if (memcmp(&a.ev[i], &c.ev[i], sizeof(grdma_h2_event)) != 0) okc = false;
+    SAY("h2_bulk_pairs %-26s %s  events %lld/%lld bulk steps %llu (%llu frames)  kernel_us %.1f\n", name, okc ? "PASS" : "FAIL",
+        (long long)a.n, (long long)c.n, (unsigned long long)c.st[0], (unsigned long long)c.st[1], c.us);
+    if (!okc) g_fail++;
+  }
   bool ok = a.n > 0 && b.n == a.n && a.err == 0 && b.err == 0 && a.steps == 0 && b.steps >= min_steps;
   size_t first_diff = 0;
   if (ok) {

@@ -101,3 +101,34 @@ def test_boundary_step_random_streams_and_cuts(gpu):
         exp = oracle_events(chunks, True)
         on, _ = gpu_events(gpu, chunks, True, True, gap_rng=rng if trial % 2 else None)
         assert on == exp, trial
+
+
+@pytest.mark.skipif(__import__("os").environ.get("GRDMA_TEST_NEW") != "1",
+                    reason="GRDMA_H2_BULK_PAIRS has not run on hardware yet (GRDMA_TEST_NEW=1 to run)")
+@pytest.mark.parametrize("shape", ["sender", "receiver"])
+def test_bulk_pairs_matches_the_oracle(gpu, shape):
+    """GRDMA_H2_BULK_PAIRS: every lane of the bulk step owns a frame (64 frames per step).  Same events as
+    the oracle on the streaming shapes, with slices at odd offsets and with some slices cut in two."""
+    from grpc_rdma_amd import h2dev
+    sizes = [1 << 20, 16384 * 3 - 5, 40000, 16384 - 5, 7, 16384 * 70 + 123, 1, 300000, 16384 * 130]
+    tx = sender_slices(sizes)
+    body = tx if shape == "sender" else receiver_slices(tx)
+    cut = []
+    for j, s_ in enumerate(body):
+        if len(s_) > 100 and j % 37 == 5:
+            cut += [s_[:77], s_[77:]]
+        else:
+            cut.append(s_)
+    rng = random.Random(2)
+    for chunks in (PRE + body, PRE + cut):
+        exp = oracle_events(chunks, True)
+        arena, table = bytearray(), []
+        for s_ in chunks:
+            arena += b"\xee" * rng.randrange(1, 16)
+            table.append((len(arena), len(s_)))
+            arena += s_
+        buf = gpu.DeviceBuffer(data=bytes(arena) + bytes(64))
+        p = h2dev.Parser(True, boundary_step=True, bulk_pairs=True)
+        err, ev = p.deframe(buf.ptr, table, cap=8 * len(chunks) + 4096)
+        p.close()
+        assert err == 0 and ev == exp
