@@ -14,12 +14,15 @@
 // One wavefront per op.  Zero-copy sends are few, large slices (the reference's threshold is a
 // message size in KiB), so the pricing loop is the reference's sequential loop as it stands: the
 // slice table is pulled 64 entries at a time (one coalesced load), every lane runs the same scalar
-// arithmetic on values broadcast with readlane, lane 0 stores segments and results.
+// arithmetic on values broadcast with readlane, lane 0 stores segments and results.  The loop body
+// (zc_price, csrc/grdma_zc_core.h) is plain integer code that tests/cc/zc_core_host.cc also compiles
+// for the host and runs against the oracle.
 #include <hip/hip_runtime.h>
 
 #include "grdma_dev.h"
 #include "grdma_devfn.h"
 #include "grdma_ops.h"
+#include "grdma_zc_core.h"
 
 namespace {
 
@@ -45,85 +48,34 @@ __global__ __launch_bounds__(64) void k_tx_plan_zc(const grdma_zc_op* ops) {
   for (int d = 32; d >= 1; d >>= 1) offered += __shfl_xor(offered, d, 64);
   offered = sat_sub(offered, op.byte_idx);
 
-  uint64_t rt = tail0, st = 0, nsge = 0, written = 0, zc_bytes = 0, copy_bytes = 0, zc_records = 0;
-  uint64_t nrec = 0, nseg = 0, ntiles = 0, staged = 0, splits = 0;
-  uint64_t idx = 0, bidx = op.byte_idx;  // cursor behind the last byte accepted
+  zc_params P;
+  P.cap = cap; P.S = S; P.tail0 = tail0; P.rhead = rhead; P.max_sge = max_sge; P.ring = (uint64_t)ring;
+  P.zc_base = (uint64_t)op.zc_base; P.zc_cap = op.zc_cap; P.byte_idx = op.byte_idx; P.ts = ts;
+  zc_state Z;
+  zc_begin(P, Z);
   bool stop = !connected || ring == nullptr || n == 0;
   for (uint64_t base = 0; base < n && !stop; base += 64) {
     const uint64_t mine = base + (uint64_t)lane < n ? base + (uint64_t)lane : n - 1;
     const grdma_sge g = sl[mine];
     for (int j = 0; j < 64 && base + (uint64_t)j < n; j++) {
-      if (nsge >= max_sge) { stop = true; break; }                       // loop condition, pair.cc:818
-      const uint8_t* ptr = reinterpret_cast<const uint8_t*>(__shfl((uint64_t)g.ptr, j, 64));
-      uint64_t len = __shfl(g.len, j, 64);
-      const uint64_t skip = (base + (uint64_t)j == 0) ? op.byte_idx : 0;  // :819-824
-      ptr += skip;
-      len = sat_sub(len, skip);
-      const uint64_t recv_free = cap - ((rt + cap - rhead) & mask);       // GetFreeSize, ring_buffer.cc:99-104
-      const uint64_t send_free = S - st;
-      const bool in_zc = op.zc_base != nullptr && ptr >= op.zc_base && ptr + len <= op.zc_base + op.zc_cap;  // :825-826
-      uint64_t pay = len;
-      {
-        const uint64_t b = writable_of(recv_free);
-        if (b < pay) pay = b;
-      }
-      uint64_t pad = 0;
-      if (in_zc) {
-        if (pay == 0 || send_free < 3ull * GRDMA_ALIGN || nsge + 4 > max_sge) { stop = true; break; }  // :830-834
-        pad = round_up8(pay) - pay;
-      } else {
-        const uint64_t a = writable_of(send_free);
-        if (a < pay) pay = a;
-        if (pay == 0) { stop = true; break; }                               // :885-887
-      }
-      const uint64_t enc = enc_size(pay);
-      // scatter-gather entries and where the ring end falls among them (GetWriteRequests splits the
-      // entry that crosses it, ring_buffer.cc:271-303).  Offsets from tail0, not wrapped.
-      {
-        const uint64_t o = tail0 + staged;  // < 2 * cap
-        if (in_zc) {
-          const uint64_t e0 = o, e1 = o + 8, e2 = e1 + pay, e3 = e2 + pad, e4 = e3 + 8;
-          splits += (e0 < cap && e1 > cap) + (e1 < cap && e2 > cap) + (pad && e2 < cap && e3 > cap) + (e3 < cap && e4 > cap);
-          nsge += pad ? 4 : 3;
-          st += 16 + pad;
-          zc_bytes += pay;
-          zc_records++;
-        } else {
-          splits += (o < cap && o + enc > cap);
-          nsge += 1;
-          st += enc;
-          copy_bytes += pay;
+      const uint64_t ptr = __shfl((uint64_t)g.ptr, j, 64);
+      const uint64_t len = __shfl(g.len, j, 64);
+      const uint64_t seg_at = Z.nseg;
+      const zc_record r = zc_price(P, Z, base + (uint64_t)j, ptr, len);  // (every lane: the same scalar arithmetic)
+      if (r.stop) { stop = true; break; }
+      if (lane == 0) {
+        plan->segs[seg_at] = r.seg[0];
+        plan->tile_prefix[seg_at] = r.tile0[0];
+        if (r.nsegs == 2) {
+          plan->segs[seg_at + 1] = r.seg[1];
+          plan->tile_prefix[seg_at + 1] = r.tile0[1];
         }
       }
-      // the record in the peer ring: header at rt, payload behind it (wrapping), tags by the copy waves
-      const uint64_t pay_off = (rt + 8) & mask;
-      const uint64_t tagw = GRDMA_SEG_TAG_WRITE | (pay << GRDMA_SEG_TAG_LEN_SHIFT);
-      if (pay_off + pay > cap) {
-        const uint64_t l1 = cap - pay_off;
-        if (lane == 0) {
-          plan->segs[nseg] = {(uint64_t)(ring + pay_off), (uint64_t)ptr, l1, tagw | GRDMA_SEG_TAG_HDR};
-          plan->tile_prefix[nseg] = (uint32_t)ntiles;
-          plan->segs[nseg + 1] = {(uint64_t)ring, (uint64_t)(ptr + l1), pay - l1, tagw | GRDMA_SEG_TAG_FTR};
-          plan->tile_prefix[nseg + 1] = (uint32_t)(ntiles + ((l1 + TB - 1) >> ts));
-        }
-        ntiles += ((l1 + TB - 1) >> ts) + ((pay - l1 + TB - 1) >> ts);
-        nseg += 2;
-      } else {
-        if (lane == 0) {
-          plan->segs[nseg] = {(uint64_t)(ring + pay_off), (uint64_t)ptr, pay, tagw | GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR};
-          plan->tile_prefix[nseg] = (uint32_t)ntiles;
-        }
-        ntiles += (pay + TB - 1) >> ts;
-        nseg += 1;
-      }
-      rt = (rt + enc) & mask;  // NextTail
-      staged += enc;
-      written += pay;
-      nrec++;
-      if (pay == len) { idx = base + (uint64_t)j + 1; bidx = 0; }
-      else { idx = base + (uint64_t)j; bidx = skip + pay; }
     }
   }
+  const uint64_t rt = Z.rt, st = Z.st, nsge = Z.nsge, splits = Z.splits, written = Z.written, zc_bytes = Z.zc_bytes,
+                 copy_bytes = Z.copy_bytes, zc_records = Z.zc_records, nrec = Z.nrec, nseg = Z.nseg, ntiles = Z.ntiles,
+                 staged = Z.staged, idx = Z.idx, bidx = Z.bidx;
 
   if (lane == 0) {
     plan->nsegs = (uint32_t)nseg;
