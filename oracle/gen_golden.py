@@ -68,6 +68,66 @@ def trace(name, ring, max_sge, ops):
     return doc
 
 
+def zc_slices(link, zc_cap, spec):
+    """spec: [["zc", seed, n] | [seed, n]] -> slices for send_zerocopy.  A "zc" slice asks the allocator
+    first (AllocateSendBuffer); when that refuses (the buffer is not empty) the bytes go to the range at
+    (seed * 131) % (zc_cap - n + 1), which SendZerocopy still treats as inside the buffer."""
+    out, allocs = [], []
+    for item in spec:
+        if item[0] == "zc":
+            _, seed, n = item
+            off = link.allocate_send_buffer(0, n)
+            allocs.append(off)
+            if off is None:
+                off = (seed * 131) % (zc_cap - n + 1)
+            link.zerocopy_write(0, off, payload(seed, n))
+            out.append(("zc", off, n))
+        else:
+            out.append(payload(item[0], item[1]))
+    return out, allocs
+
+
+def trace_zerocopy(name, ring, max_sge, zc_cap, ops):
+    """Same as trace() with PairPollable::AllocateSendBuffer / SendZerocopy (pair.cc:305-323, 793-941) as
+    transcribed in oracle/ref_driver.cc over the reference-built ring codec.  Files are named zc_*.json (the
+    ring_*.json replays do not know these operations)."""
+    link = pyorc.RefLink(ring, max_sge)
+    link.enable_zerocopy(0, zc_cap)
+    steps = []
+    for op in ops:
+        rec = dict(op)
+        if op["op"] == "zc_send":
+            slices, allocs = zc_slices(link, zc_cap, op["slices"])
+            rec["allocs"] = allocs
+            rec["sent"] = link.send_zerocopy(0, slices, op.get("byte_idx", 0))
+            rec["wrs"] = link.last_wrs(0)
+            rec["zc_state"] = link.zerocopy_state(0)
+            rec["staging_sha256"] = hashlib.sha256(link.staging_mem(0)).hexdigest()
+        elif op["op"] == "send":
+            rec["sent"] = link.send(0, [payload(s, n) for s, n in op["slices"]], 0)
+        elif op["op"] == "recv":
+            got = link.recv(1, op["cap"])
+            rec["got_len"] = len(got)
+            rec["got_sha256"] = hashlib.sha256(got).hexdigest()
+        ring_img = link.ring_mem(1)
+        rec["ring_sha256"] = hashlib.sha256(ring_img).hexdigest()
+        if ring <= 256:
+            rec["ring_hex"] = ring_img.hex()
+        rec["rx_state"] = link.state(1)
+        rec["tx_state"] = link.state(0)
+        steps.append(rec)
+    link.close()
+    doc = {"name": name, "ring_size": ring, "max_sge": max_sge, "zerocopy_buffer": zc_cap,
+           "generator": "oracle/gen_golden.py: PairPollable::SendZerocopy as transcribed in oracle/ref_driver.cc "
+                        "over oracle/_ref/libref_ring.so (reference src/core/lib/ibverbs/ring_buffer.cc)",
+           "payload_rule": "random.Random(seed).getrandbits(8) per byte; slices = [seed, length] or "
+                           "['zc', seed, length] (see zc_slices in oracle/gen_golden.py)",
+           "steps": steps}
+    with open(os.path.join(OUT, "zc_%s.json" % name), "w") as f:
+        json.dump(doc, f, indent=0, separators=(",", ":"))
+    return doc
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     # 1. the probe of SURVEY.md section 8c: "hello ring\0" -> tail 32, readable 11
@@ -114,6 +174,27 @@ def main():
         for _ in range(50):
             ops.append({"op": "endpoint_read"})
     trace("h2_shaped_1m", 1 << 20, 30, ops)
+    # 5. zero-copy send buffer: small ring with every wrap position, and a 4 KiB ring with max_sge 5
+    for name, ring, sge, zc_cap, sizes, n_ops in (("tiny", 128, 8, 96, [1, 2, 7, 8, 9, 15, 16, 17, 24, 40, 90], 70),
+                                                  ("sge5_4k", 4096, 5, 8192, [5, 9, 100, 256, 257, 1000, 1365, 3000, 4096], 50)):
+        zrng = random.Random(77)
+        ops = []
+        for i in range(n_ops):
+            r = zrng.random()
+            if r < 0.55:
+                sl = []
+                for k in range(zrng.randint(1, 4)):
+                    n = zrng.choice(sizes)
+                    seed = 5000 + i * 10 + k
+                    sl.append(["zc", seed, min(n, zc_cap)] if zrng.random() < 0.6 else [seed, n])
+                first = sl[0][2] if sl[0][0] == "zc" else sl[0][1]
+                ops.append({"op": "zc_send", "slices": sl,
+                            "byte_idx": zrng.randrange(first) if zrng.random() < 0.3 else 0})
+            elif r < 0.65:
+                ops.append({"op": "send", "slices": [[6000 + i, zrng.choice(sizes)]]})
+            else:
+                ops.append({"op": "recv", "cap": zrng.choice([1, 8, 64, 256, ring])})
+        trace_zerocopy(name, ring, sge, zc_cap, ops)
     print("wrote", sorted(os.listdir(OUT)))
 
 
