@@ -1,0 +1,350 @@
+// TEST INFRASTRUCTURE.  A small host emulator for wave-level HIP kernels: enough of the CDNA execution
+// model to run the latency-bound planner / parser kernels of this repository on a CPU, lane for lane, and
+// compare their results with the oracle when no GPU is at hand (hipcc cross-compiles here, but nothing runs).
+//
+// Model.  A workgroup is emulated one at a time.  Every wavefront is one OS thread; its 64 lanes are
+// coroutines (ucontext) that the wave thread resumes round-robin.  A cross-lane operation (__shfl*,
+// __ballot, readfirstlane, DPP) completes when every lane of the wave that is still running has arrived at
+// it -- the lanes of a wave must reach cross-lane operations in the same order, which is what wave-uniform
+// control flow means on the hardware too; a lane that arrives early yields until the last one is there.
+// __syncthreads() is the same inside a wave plus a barrier between the wave threads.  __shared__ objects are
+// statics (one workgroup at a time); global memory is host memory; atomics map to the compiler's __atomic
+// builtins (scopes collapse: everything is coherent); s_sleep yields to the other lanes and to the OS.
+// What this checks is the LOGIC of a kernel (index arithmetic, ballots, prefix sums, hand-offs through LDS
+// flags).  It says nothing about timing, cache behaviour or weaker-than-x86 memory ordering.
+//
+// Use: include this header FIRST (it defines __device__, __global__, threadIdx, the intrinsics, and empties
+// <hip/hip_runtime.h>), then the kernel's source, then  emu::launch(grid, block, [&] { kernel(args...); }).
+#pragma once
+#define HIP_INCLUDE_HIP_HIP_RUNTIME_H  // (guards of the real headers, in case an include path finds them)
+#define GRDMA_WAVE_EMU 1
+
+#include <sched.h>
+#include <stdint.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __HIP_MEMORY_SCOPE_AGENT 3
+#define __HIP_MEMORY_SCOPE_SYSTEM 4
+#define address_space(x)  // __attribute__((address_space(1))) -> __attribute__(())
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace emu {
+
+constexpr int kWave = 64;
+constexpr size_t kStack = 256 * 1024;
+
+struct lane_ctx {
+  ucontext_t ctx;
+  std::vector<char> stack;
+  dim3 tid;
+  bool done = false;
+};
+
+struct block_sync {  // barrier between the wave threads of a workgroup
+  std::mutex mu;
+  std::condition_variable cv;
+  int waiting = 0, nwaves = 0;
+  uint64_t gen = 0;
+  void arrive_and_wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t g = gen;
+    if (++waiting == nwaves) {
+      waiting = 0;
+      gen++;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return gen != g; });
+    }
+  }
+  void drop() {  // a wave finished: it no longer takes part
+    std::unique_lock<std::mutex> lk(mu);
+    nwaves--;
+    if (nwaves > 0 && waiting == nwaves) {
+      waiting = 0;
+      gen++;
+      cv.notify_all();
+    }
+  }
+};
+
+struct wave_ctx {
+  ucontext_t sched;
+  lane_ctx lanes[kWave];
+  int nlanes = 0;        // lanes this wave has (the last wave of a block may be partial)
+  int active = 0;        // lanes still running
+  int cur = 0;
+  // cross-lane exchange
+  uint64_t slot[kWave];
+  uint64_t res[kWave];
+  bool res_valid[kWave];
+  int arrived = 0;
+  uint64_t gen = 0;
+  bool in_slot[kWave];
+  block_sync* bs = nullptr;
+  const std::function<void()>* body = nullptr;
+  dim3 bid, bdim, gdim;
+};
+
+inline thread_local wave_ctx* t_wave = nullptr;
+
+inline lane_ctx* cur_lane() { return &t_wave->lanes[t_wave->cur]; }
+inline void yield_lane() {
+  wave_ctx* w = t_wave;
+  swapcontext(&w->lanes[w->cur].ctx, &w->sched);
+}
+
+// All running lanes arrive with a 64-bit value; afterwards res[] holds every lane's value (res_valid marks
+// the lanes that took part).
+inline void exchange(uint64_t v) {
+  wave_ctx* w = t_wave;
+  const int me = w->cur;
+  w->slot[me] = v;
+  w->in_slot[me] = true;
+  const uint64_t g = w->gen;
+  if (++w->arrived == w->active) {
+    for (int i = 0; i < kWave; i++) {
+      w->res[i] = w->slot[i];
+      w->res_valid[i] = w->in_slot[i];
+      w->in_slot[i] = false;
+    }
+    w->arrived = 0;
+    w->gen++;
+  } else {
+    while (w->gen == g) yield_lane();
+  }
+}
+
+// a lane left the kernel: operations the others are waiting in may now be complete
+inline void lane_exit() {
+  wave_ctx* w = t_wave;
+  w->lanes[w->cur].done = true;
+  w->active--;
+  if (w->active > 0 && w->arrived == w->active) {
+    for (int i = 0; i < kWave; i++) {
+      w->res[i] = w->slot[i];
+      w->res_valid[i] = w->in_slot[i];
+      w->in_slot[i] = false;
+    }
+    w->arrived = 0;
+    w->gen++;
+  }
+}
+
+inline void lane_entry() {
+  (*t_wave->body)();
+  lane_exit();
+  yield_lane();  // never resumed
+}
+
+inline void run_wave(wave_ctx* w) {
+  t_wave = w;
+  w->active = w->nlanes;
+  for (int i = 0; i < w->nlanes; i++) {
+    lane_ctx& L = w->lanes[i];
+    L.stack.resize(kStack);
+    getcontext(&L.ctx);
+    L.ctx.uc_stack.ss_sp = L.stack.data();
+    L.ctx.uc_stack.ss_size = L.stack.size();
+    L.ctx.uc_link = &w->sched;
+    makecontext(&L.ctx, (void (*)())lane_entry, 0);
+  }
+  while (w->active > 0) {
+    for (int i = 0; i < w->nlanes; i++) {
+      if (w->lanes[i].done) continue;
+      w->cur = i;
+      swapcontext(&w->sched, &w->lanes[i].ctx);
+    }
+  }
+  w->bs->drop();
+  t_wave = nullptr;
+}
+
+// Runs grid.x * grid.y workgroups of block.x threads, one workgroup after the other.
+inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  for (unsigned by = 0; by < grid.y; by++)
+    for (unsigned bx = 0; bx < grid.x; bx++) {
+      const int nw = (int)((block.x + kWave - 1) / kWave);
+      block_sync bs;
+      bs.nwaves = nw;
+      std::vector<wave_ctx*> waves;
+      for (int wv = 0; wv < nw; wv++) {
+        wave_ctx* w = new wave_ctx();
+        w->bs = &bs;
+        w->body = &body;
+        w->bid = dim3(bx, by, 0);
+        w->bdim = block;
+        w->gdim = grid;
+        w->nlanes = (int)std::min<unsigned>(kWave, block.x - (unsigned)wv * kWave);
+        for (int i = 0; i < w->nlanes; i++) w->lanes[i].tid = dim3((unsigned)(wv * kWave + i), 0, 0);
+        memset(w->in_slot, 0, sizeof(w->in_slot));
+        waves.push_back(w);
+      }
+      std::vector<std::thread> th;
+      for (wave_ctx* w : waves) th.emplace_back(run_wave, w);
+      for (auto& t : th) t.join();
+      for (wave_ctx* w : waves) delete w;
+    }
+}
+
+struct tid_proxy {
+  struct field {
+    int which;
+    operator unsigned() const {
+      const dim3& d = cur_lane()->tid;
+      return which == 0 ? d.x : which == 1 ? d.y : d.z;
+    }
+  };
+  field x{0}, y{1}, z{2};
+};
+struct wave_dim_proxy {
+  int sel;  // 0 blockIdx, 1 blockDim, 2 gridDim
+  struct field {
+    int sel, which;
+    operator unsigned() const {
+      const wave_ctx* w = t_wave;
+      const dim3& d = sel == 0 ? w->bid : sel == 1 ? w->bdim : w->gdim;
+      return which == 0 ? d.x : which == 1 ? d.y : d.z;
+    }
+  };
+  field x, y, z;
+  explicit wave_dim_proxy(int s) : sel(s), x{s, 0}, y{s, 1}, z{s, 2} {}
+};
+
+template <typename T>
+inline uint64_t to_bits(T v) {
+  static_assert(sizeof(T) <= 8, "cross-lane values are at most 64 bits");
+  uint64_t b = 0;
+  memcpy(&b, &v, sizeof(T));
+  return b;
+}
+template <typename T>
+inline T from_bits(uint64_t b) {
+  T v;
+  memcpy(&v, &b, sizeof(T));
+  return v;
+}
+
+}  // namespace emu
+
+static emu::tid_proxy threadIdx;
+static emu::wave_dim_proxy blockIdx(0), blockDim(1), gridDim(2);
+
+// ---- cross-lane intrinsics ----------------------------------------------------------------------------
+template <typename T>
+inline T __shfl(T v, int src, int /*width*/ = 64) {
+  emu::exchange(emu::to_bits(v));
+  const emu::wave_ctx* w = emu::t_wave;
+  src &= 63;
+  return w->res_valid[src] ? emu::from_bits<T>(w->res[src]) : v;
+}
+template <typename T>
+inline T __shfl_up(T v, unsigned d, int /*width*/ = 64) {
+  emu::exchange(emu::to_bits(v));
+  const emu::wave_ctx* w = emu::t_wave;
+  const int me = w->cur, src = me - (int)d;
+  return (src >= 0 && w->res_valid[src]) ? emu::from_bits<T>(w->res[src]) : v;
+}
+template <typename T>
+inline T __shfl_xor(T v, int mask, int /*width*/ = 64) {
+  emu::exchange(emu::to_bits(v));
+  const emu::wave_ctx* w = emu::t_wave;
+  const int src = (w->cur ^ mask) & 63;
+  return w->res_valid[src] ? emu::from_bits<T>(w->res[src]) : v;
+}
+inline uint64_t __ballot(int pred) {
+  emu::exchange(pred ? 1u : 0u);
+  const emu::wave_ctx* w = emu::t_wave;
+  uint64_t m = 0;
+  for (int i = 0; i < 64; i++)
+    if (w->res_valid[i] && w->res[i]) m |= 1ull << i;
+  return m;
+}
+inline int __builtin_amdgcn_readfirstlane(int v) {
+  emu::exchange((uint64_t)(uint32_t)v);
+  const emu::wave_ctx* w = emu::t_wave;
+  for (int i = 0; i < 64; i++)
+    if (w->res_valid[i]) return (int)(uint32_t)w->res[i];
+  return v;
+}
+// DPP: the controls this repository uses (row_shr:1/2/4/8, row_bcast:15, row_bcast:31, wave_shl:1, wave_rol:1)
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  emu::exchange((uint64_t)(uint32_t)src);
+  const emu::wave_ctx* w = emu::t_wave;
+  const int me = w->cur, row = me >> 4, bank = (me & 15) >> 2;
+  if (!((row_mask >> row) & 1) || !((bank_mask >> bank) & 1)) return old;
+  int from = -1;
+  if (ctrl >= 0x111 && ctrl <= 0x11F) {  // row_shr:n
+    const int n = ctrl - 0x110;
+    if ((me & 15) - n >= 0) from = me - n;
+  } else if (ctrl == 0x142) {  // row_bcast:15
+    if (row >= 1) from = (row - 1) * 16 + 15;
+  } else if (ctrl == 0x143) {  // row_bcast:31
+    if (row >= 2) from = 31;
+  } else if (ctrl == 0x130) {  // wave_shl:1
+    if (me + 1 < 64) from = me + 1;
+  } else if (ctrl == 0x134) {  // wave_rol:1
+    from = (me + 1) & 63;
+  } else {
+    __builtin_trap();
+  }
+  if (from < 0 || !w->res_valid[from]) return bound_ctrl ? 0 : old;
+  return (int)(uint32_t)w->res[from];
+}
+
+inline void __syncthreads() {
+  emu::wave_ctx* w = emu::t_wave;
+  const uint64_t g = w->gen;
+  w->in_slot[w->cur] = true;
+  if (++w->arrived == w->active) {
+    w->bs->arrive_and_wait();  // the last lane of the wave waits for the other waves
+    for (int i = 0; i < 64; i++) w->in_slot[i] = false;
+    w->arrived = 0;
+    w->gen++;
+  } else {
+    while (w->gen == g) emu::yield_lane();
+  }
+}
+
+// ---- scalar intrinsics ----------------------------------------------------------------------------------
+inline uint64_t __builtin_amdgcn_s_memtime() {
+  static std::atomic<uint64_t> t{0};
+  return t.fetch_add(1, std::memory_order_relaxed);
+}
+inline void __builtin_amdgcn_s_sleep(int) {
+  emu::yield_lane();
+  sched_yield();
+}
+inline void __builtin_amdgcn_s_setprio(int) {}
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
+template <typename T>
+inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+template <typename T>
+inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <typename T>
+inline T atomicMin(T* p, T v) {
+  T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v < old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
