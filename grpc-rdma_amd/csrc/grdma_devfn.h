@@ -9,6 +9,19 @@
 #define PLAN_THREADS 256
 #define COPY_THREADS 256
 
+// Every vector-memory operation this wave has issued is acknowledged (loads returned, stores accepted by
+// the memory system): what orders "the bytes" before "the word that publishes them" inside one wave.
+// (A macro so that the host emulation of tests/cc/wave_emu.h can say what it means there.)
+#ifndef GRDMA_WAIT_VMEM
+#define GRDMA_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+// A point every lane of the wave reaches before any lane goes on.  Nothing on the GPU, where a wave's
+// lanes execute an instruction together; the host emulation (one coroutine per lane) meets here, so that a
+// value one lane stores behind this point is not seen by a lane that has yet to load it in front of it.
+#ifndef GRDMA_WAVE_CONVERGE
+#define GRDMA_WAVE_CONVERGE()
+#endif
+
 
 __device__ __forceinline__ uint64_t round_up8(uint64_t v) { return (v + 7ull) & ~7ull; }
 __device__ __forceinline__ uint64_t round_down8(uint64_t v) { return v & ~7ull; }

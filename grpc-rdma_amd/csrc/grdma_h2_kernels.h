@@ -372,6 +372,7 @@ __device__ void h2_stage_windows(uint32_t h, uint32_t nh, const uint8_t* arena,
     e.c2 = h2_keep(o2, 16, n);
     e.c3 = h2_keep(o3, 24, n);
     L->win[k % H2_RING][lane] = e;
+    GRDMA_WAVE_CONVERGE();  // (every lane has stored its entry: on the GPU the store is one instruction of the wave)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every lane's entry before the flag
     if (lane == 0) __hip_atomic_store(&L->seq[k % H2_RING], (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
@@ -491,6 +492,7 @@ __device__ __forceinline__ bool h2_select_stream(grdma_h2_stream_dev* tab, uint3
   D.read_closed = e.read_closed;
   D.write_closed = e.write_closed;
   D.hdr_frames = e.hdr_frames;
+  GRDMA_WAVE_CONVERGE();  // (every lane holds the entry before lane 0 may write it back)
   return true;
 }
 
@@ -894,6 +896,7 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
 #undef H2_PUSH
 #undef H2_BYTE
 #undef H2_END_FRAME
+  GRDMA_WAVE_CONVERGE();  // (every lane has read the parser block before lane 0 replaces it)
   if (lane == 0) __hip_atomic_store(&g_h2.stop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // helpers leave
   h2_flush_stream(tab, D, lane);
   if (lane == 0) {

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(COPY_THREADS) void k_rx_apply(const grdma_rx_op* op
   // registered for a NIC is uncached memory, where acknowledged stores are
   // already at their destination -- so no L2 write-back fence is paid here.
   __shared__ unsigned int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GRDMA_WAIT_VMEM();
   __syncthreads();
   if (threadIdx.x == 0) {
     // Relaxed on purpose.  An acq_rel arrival makes every workgroup write its L2 back (agent

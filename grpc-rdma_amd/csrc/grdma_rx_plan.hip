@@ -392,7 +392,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
         s_express = 1;
         atomicAdd(&g_express_drains, 1ull);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      GRDMA_WAIT_VMEM();
     }
   }
   __syncthreads();
@@ -1215,6 +1215,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
         a_off = al16(a_off + total);
       }
     }
+    GRDMA_WAVE_CONVERGE();  // (every lane has read S at the top before lane 0 replaces it)
     if (lane == 0) {
       S.head = head; S.mh = mh; S.remain = remain; S.irs = irs; S.leftover = leftover;
       S.nslices = nslices; S.nsegs = nsegs; S.ntiles = ntiles; S.bytes = bytes;
@@ -1277,7 +1278,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     }
     __syncthreads();
     run_plan<1024, true>(plan, wave, PLAN_THREADS / 64, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GRDMA_WAIT_VMEM();
     __syncthreads();
   }
   // (no early return: the resident engine calls this body inside a loop with

@@ -120,7 +120,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
       }
       *reinterpret_cast<uint64_t*>(peer_ring + ((tail0 + st) & mask)) = my_pay;
       for (uint64_t q = my_pay; q < pad_end; q++) peer_ring[(tail0 + st + 8 + q) & mask] = 0;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      GRDMA_WAIT_VMEM();
       *reinterpret_cast<uint64_t*>(peer_ring + ((tail0 + st + 8 + pad_end) & mask)) = GRDMA_FOOTER;
     }
   } else {
@@ -152,7 +152,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
   }
   // wire: the <= 2 RDMA WRITEs of GetWriteRequests (ring_buffer.cc:261-330)
   if (!direct && staged > 0 && c->peer_ring != nullptr) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // staging complete before it is read back
+    GRDMA_WAIT_VMEM();  // staging complete before it is read back
     for (uint64_t done = 0; done < staged;) {
       uint64_t n = staged - done;
       if (n > GRDMA_TILE_BYTES) n = GRDMA_TILE_BYTES;
@@ -169,7 +169,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
   }
   }
   const uint64_t tk3 = __builtin_amdgcn_s_memtime();  // (copies issued)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GRDMA_WAIT_VMEM();
   const uint64_t tk4 = __builtin_amdgcn_s_memtime();  // (copies acknowledged)
   if (lane == 0) {
     grdma_plan* plan = op.plan;
@@ -588,11 +588,11 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
     __syncthreads();
     run_plan<1024>(plan, tid >> 6, PLAN_THREADS / 64, tid & 63);
     if (op.wire_plan != nullptr && !direct) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      GRDMA_WAIT_VMEM();
       __syncthreads();
       run_plan<1024>(op.wire_plan, tid >> 6, PLAN_THREADS / 64, tid & 63);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GRDMA_WAIT_VMEM();
     __syncthreads();
   }
   if (tid == 0) {

@@ -1,0 +1,21 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE: the product sources compiled for the CPU over the wave emulator and the HIP API stand-in
+# (tests/cc/wave_emu.h, hip_api_emu.h) -> oracle/_build/libgrdma_emu.so.  Load it with
+# GRDMA_LIB_PATH=oracle/_build/libgrdma_emu.so to run the parity tests without a GPU (tests/test_emu_pair.py).
+set -e
+R=$(cd "$(dirname "$0")/../.." && pwd)
+CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
+OUT=$R/oracle/_build
+mkdir -p $OUT/emu_obj
+FLAGS="-O1 -g -fno-omit-frame-pointer -std=c++17 -fPIC -pthread -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes -I$R/tests/cc -I$R/tests/cc/emu_include"
+objs=""
+for f in grdma_kernels.hip grdma_rx_plan.hip grdma_zc.hip grdma_h2.hip grdma_pair.hip grdma_host.cc grdma_endpoint.cc grdma_stats_time.cc; do
+  o=$OUT/emu_obj/${f%.*}.o
+  $CXX $FLAGS -x c++ -c $R/grpc-rdma_amd/csrc/$f -o $o &
+  objs="$objs $o"
+done
+$CXX $FLAGS -c $R/tests/cc/emu_link_stubs.cc -o $OUT/emu_obj/link_stubs.o &
+$CXX $FLAGS -c $R/tests/cc/emu_segv.cc -o $OUT/emu_obj/segv.o &
+wait
+$CXX -shared -pthread -o $OUT/libgrdma_emu.so $objs $OUT/emu_obj/link_stubs.o $OUT/emu_obj/segv.o -rdynamic
+echo "built $OUT/libgrdma_emu.so"

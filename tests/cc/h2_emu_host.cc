@@ -4,30 +4,6 @@
 // compares the events with the oracle's, with and without the boundary step and GRDMA_H2_BULK_PAIRS.
 #include "wave_emu.h"
 
-// ---- what csrc/grdma_devfn.h needs from the buffer instructions (bounds-checked 16-byte / 1-byte accesses)
-struct __amdgpu_buffer_rsrc_t {
-  uint8_t* base;
-  uint32_t bytes;
-};
-typedef uint32_t emu_u32x4 __attribute__((ext_vector_type(4)));
-inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int bytes, int) {
-  return {static_cast<uint8_t*>(p), (uint32_t)bytes};
-}
-inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int off, int, int) {
-  emu_u32x4 v = {0, 0, 0, 0};
-  if (off >= 0 && (uint32_t)off + 16 <= r.bytes) memcpy(&v, r.base + off, 16);
-  return v;
-}
-inline uint8_t __builtin_amdgcn_raw_buffer_load_b8(__amdgpu_buffer_rsrc_t r, int off, int, int) {
-  return (off >= 0 && (uint32_t)off < r.bytes) ? r.base[off] : 0;
-}
-inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, __amdgpu_buffer_rsrc_t r, int off, int, int) {
-  if (off >= 0 && (uint32_t)off + 16 <= r.bytes) memcpy(r.base + off, &v, 16);
-}
-inline void __builtin_amdgcn_raw_buffer_store_b8(uint8_t v, __amdgpu_buffer_rsrc_t r, int off, int, int) {
-  if (off >= 0 && (uint32_t)off < r.bytes) r.base[off] = v;
-}
-
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

@@ -1,0 +1,124 @@
+// TEST INFRASTRUCTURE.  The slice of the HIP host API this repository's host layer uses, over host memory and
+// the wave emulator (tests/cc/wave_emu.h): "device" memory is malloc'ed, copies are memcpy, streams and events
+// are synchronous no-ops, a kernel launch runs the kernel under the emulator before it returns.  Together with
+// wave_emu.h this lets the PRODUCT sources (csrc/*.hip, *.cc) be compiled for the CPU into
+// oracle/_build/libgrdma_emu.so, which the Python parity tests can load instead of libgrdma_amd.so
+// (GRDMA_LIB_PATH) when no GPU is at hand -- see tests/cc/build_emu.sh and tests/test_emu_pair.py.
+// Not emulated: HIP graphs, IPC handles, dma-buf export (they report an error), resident kernels that wait
+// for the host (a launch returns only when the kernel has finished).
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+
+typedef int hipError_t;
+enum {
+  hipSuccess = 0,
+  hipErrorInvalidValue = 1,
+  hipErrorOutOfMemory = 2,
+  hipErrorNotSupported = 801,
+};
+typedef struct emu_stream* hipStream_t;
+typedef struct emu_event* hipEvent_t;
+typedef struct emu_graph* hipGraph_t;
+typedef struct emu_graph_exec* hipGraphExec_t;
+typedef struct emu_graph_node* hipGraphNode_t;
+typedef void* hipDeviceptr_t;
+struct hipIpcMemHandle_t {
+  char reserved[64];
+};
+struct hipKernelNodeParams {
+  dim3 blockDim;
+  void** extra;
+  void* func;
+  dim3 gridDim;
+  void** kernelParams;
+  unsigned int sharedMemBytes;
+};
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocCoherent = 0x40000000, hipHostMallocMapped = 2,
+       hipDeviceMallocFinegrained = 1, hipIpcMemLazyEnablePeerAccess = 1, hipMemRangeHandleTypeDmaBufFd = 1 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1, hipDeviceAttributeWallClockRate = 2 };
+
+namespace emu {
+inline std::recursive_mutex& launch_mutex() {
+  static std::recursive_mutex m;
+  return m;
+}
+inline void* dev_alloc(size_t n) {
+  void* p = nullptr;
+  if (posix_memalign(&p, 256, n ? n : 1) != 0) return nullptr;
+  memset(p, 0xA5, n);  // device memory does not come zeroed
+  return p;
+}
+}  // namespace emu
+
+inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "emulated HIP error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
+  *v = a == hipDeviceAttributeMultiprocessorCount ? 2 : 100000;
+  return hipSuccess;
+}
+inline hipError_t hipDeviceGetPCIBusId(char* s, int n, int) {
+  strncpy(s, "0000:00:00.0", (size_t)n);
+  return hipSuccess;
+}
+template <typename F>
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 1; return hipSuccess; }
+
+template <typename T>
+inline hipError_t hipMalloc(T** p, size_t n) { *p = static_cast<T*>(emu::dev_alloc(n)); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T>
+inline hipError_t hipExtMallocWithFlags(T** p, size_t n, unsigned) { return hipMalloc(p, n); }
+template <typename T>
+inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+template <typename T>
+inline hipError_t hipMemcpyFromSymbol(void* d, const T& sym, size_t n, size_t off = 0, hipMemcpyKind = hipMemcpyDeviceToHost) {
+  memcpy(d, reinterpret_cast<const char*>(&sym) + off, n);
+  return hipSuccess;
+}
+#define HIP_SYMBOL(x) x
+
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = reinterpret_cast<hipStream_t>(malloc(8)); return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(malloc(8)); return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
+
+inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return hipErrorNotSupported; }
+inline hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned) { return hipErrorNotSupported; }
+inline hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
+inline hipError_t hipMemGetHandleForAddressRange(void*, hipDeviceptr_t, size_t, int, unsigned long long) { return hipErrorNotSupported; }
+
+inline hipError_t hipGraphCreate(hipGraph_t*, unsigned) { return hipErrorNotSupported; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphAddKernelNode(hipGraphNode_t*, hipGraph_t, const hipGraphNode_t*, size_t, const hipKernelNodeParams*) { return hipErrorNotSupported; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+
+// A launch runs the whole grid under the emulator and returns when it is done.  One launch at a time: the
+// __shared__ objects of a kernel are statics.
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)              \
+  do {                                                                           \
+    std::lock_guard<std::recursive_mutex> emu_lk_(emu::launch_mutex());          \
+    emu::launch(dim3(grid), dim3(block), [=] { kernel(__VA_ARGS__); });          \
+  } while (0)

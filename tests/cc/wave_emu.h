@@ -19,8 +19,12 @@
 #define HIP_INCLUDE_HIP_HIP_RUNTIME_H  // (guards of the real headers, in case an include path finds them)
 #define GRDMA_WAVE_EMU 1
 
+#include <execinfo.h>
 #include <sched.h>
+#include <sys/mman.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <ucontext.h>
 
@@ -41,6 +45,10 @@
 #define __HIP_MEMORY_SCOPE_AGENT 3
 #define __HIP_MEMORY_SCOPE_SYSTEM 4
 #define address_space(x)  // __attribute__((address_space(1))) -> __attribute__(())
+#define amdgpu_waves_per_eu(...)
+// "every vector-memory operation of this wave is acknowledged": host stores are already there
+#define GRDMA_WAIT_VMEM() asm volatile("" ::: "memory")
+#define GRDMA_WAVE_CONVERGE() emu::exchange(0)
 
 struct dim3 {
   unsigned x, y, z;
@@ -50,14 +58,24 @@ struct dim3 {
 namespace emu {
 
 constexpr int kWave = 64;
-constexpr size_t kStack = 256 * 1024;
+constexpr size_t kStack = 1024 * 1024;  // per lane; mapped lazily, with a guard page below it
 
 struct lane_ctx {
   ucontext_t ctx;
-  std::vector<char> stack;
+  char* stack = nullptr;  // mmap'ed: kGuard bytes PROT_NONE, then kStack bytes
   dim3 tid;
   bool done = false;
 };
+constexpr size_t kGuard = 4096;
+inline char* stack_alloc() {
+  void* p = mmap(nullptr, kGuard + kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (p == MAP_FAILED) abort();
+  mprotect(p, kGuard, PROT_NONE);  // a lane that overruns its stack faults here instead of in a neighbour
+  return static_cast<char*>(p);
+}
+inline void stack_free(char* p) {
+  if (p) munmap(p, kGuard + kStack);
+}
 
 struct block_sync {  // barrier between the wave threads of a workgroup
   std::mutex mu;
@@ -99,6 +117,8 @@ struct wave_ctx {
   int arrived = 0;
   uint64_t gen = 0;
   bool in_slot[kWave];
+  void* site = nullptr;  // call site of the operation the lanes are gathering at
+  int site_lane = 0;
   block_sync* bs = nullptr;
   const std::function<void()>* body = nullptr;
   dim3 bid, bdim, gdim;
@@ -106,7 +126,17 @@ struct wave_ctx {
 
 inline thread_local wave_ctx* t_wave = nullptr;
 
+// Debugging aid: a lane appends (tag, value) without any effect on scheduling; when the wave finishes the
+// logs of its lanes are compared and the first entry where a lane differs from lane 0 is reported -- the
+// place where supposedly wave-uniform state stopped being uniform.
+struct trace_entry { const char* tag; uint64_t v; };
+inline thread_local std::vector<trace_entry>* t_traces = nullptr;  // [lane]
+inline void trace(const char* tag, uint64_t v);
+
 inline lane_ctx* cur_lane() { return &t_wave->lanes[t_wave->cur]; }
+inline void trace(const char* tag, uint64_t v) {
+  if (t_traces) t_traces[t_wave->cur].push_back({tag, v});
+}
 inline void yield_lane() {
   wave_ctx* w = t_wave;
   swapcontext(&w->lanes[w->cur].ctx, &w->sched);
@@ -114,9 +144,23 @@ inline void yield_lane() {
 
 // All running lanes arrive with a 64-bit value; afterwards res[] holds every lane's value (res_valid marks
 // the lanes that took part).
-inline void exchange(uint64_t v) {
+// The lanes of a wave must meet at the SAME operation: a lane that arrives from a different call site means
+// the kernel's control flow around a cross-lane operation is not wave-uniform (or depends on lanes running in
+// lockstep between two such operations, which this emulator does not model).
+__attribute__((noinline)) inline void exchange(uint64_t v) {
   wave_ctx* w = t_wave;
   const int me = w->cur;
+  void* const here = __builtin_return_address(0);
+  if (w->arrived == 0) {
+    w->site = here;
+    w->site_lane = me;
+  } else if (w->site != here) {
+    fprintf(stderr, "wave_emu: lane %d is at the cross-lane operation called from %p, lane %d at the one from %p\n", me,
+            here, w->site_lane, w->site);
+    void* bt[24];
+    backtrace_symbols_fd(bt, backtrace(bt, 24), 2);
+    abort();
+  }
   w->slot[me] = v;
   w->in_slot[me] = true;
   const uint64_t g = w->gen;
@@ -157,13 +201,15 @@ inline void lane_entry() {
 
 inline void run_wave(wave_ctx* w) {
   t_wave = w;
+  std::vector<trace_entry> traces[kWave];
+  t_traces = getenv("EMU_TRACE") ? traces : nullptr;
   w->active = w->nlanes;
   for (int i = 0; i < w->nlanes; i++) {
     lane_ctx& L = w->lanes[i];
-    L.stack.resize(kStack);
+    L.stack = stack_alloc();
     getcontext(&L.ctx);
-    L.ctx.uc_stack.ss_sp = L.stack.data();
-    L.ctx.uc_stack.ss_size = L.stack.size();
+    L.ctx.uc_stack.ss_sp = L.stack + kGuard;
+    L.ctx.uc_stack.ss_size = kStack;
     L.ctx.uc_link = &w->sched;
     makecontext(&L.ctx, (void (*)())lane_entry, 0);
   }
@@ -173,6 +219,25 @@ inline void run_wave(wave_ctx* w) {
       w->cur = i;
       swapcontext(&w->sched, &w->lanes[i].ctx);
     }
+  }
+  for (int i = 0; i < w->nlanes; i++) {
+    stack_free(w->lanes[i].stack);
+    w->lanes[i].stack = nullptr;
+  }
+  if (t_traces) {
+    for (int i = 1; i < w->nlanes; i++) {
+      const auto &a = traces[0], &b = traces[i];
+      size_t k = 0;
+      while (k < a.size() && k < b.size() && a[k].v == b[k].v && a[k].tag == b[k].tag) k++;
+      if (k < a.size() || k < b.size()) {
+        fprintf(stderr, "wave_emu trace: lane %d differs from lane 0 at entry %zu: lane0 %s=%llu, lane%d %s=%llu (previous: %s=%llu)\n", i, k,
+                k < a.size() ? a[k].tag : "(end)", k < a.size() ? (unsigned long long)a[k].v : 0ull, i,
+                k < b.size() ? b[k].tag : "(end)", k < b.size() ? (unsigned long long)b[k].v : 0ull,
+                k ? a[k - 1].tag : "-", k ? (unsigned long long)a[k - 1].v : 0ull);
+        break;
+      }
+    }
+    t_traces = nullptr;
   }
   w->bs->drop();
   t_wave = nullptr;
@@ -310,6 +375,9 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
   return (int)(uint32_t)w->res[from];
 }
 
+inline int __all(int pred) { return __ballot(!pred) == 0; }
+inline int __any(int pred) { return __ballot(pred) != 0; }
+
 inline void __syncthreads() {
   emu::wave_ctx* w = emu::t_wave;
   const uint64_t g = w->gen;
@@ -343,8 +411,46 @@ inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAX
 template <typename T>
 inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 template <typename T>
+inline T atomicMax(T* p, T v) {
+  T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v > old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+template <typename T>
 inline T atomicMin(T* p, T v) {
   T old = __atomic_load_n(p, __ATOMIC_RELAXED);
   while (v < old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
   return old;
 }
+
+// ---- buffer instructions: bounds-checked accesses through a {base, bytes} descriptor --------------------
+struct __amdgpu_buffer_rsrc_t {
+  uint8_t* base;
+  uint32_t bytes;
+};
+typedef uint32_t emu_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t emu_u32x2 __attribute__((ext_vector_type(2)));
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int bytes, int) {
+  return {static_cast<uint8_t*>(p), (uint32_t)bytes};
+}
+inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int off, int, int) {
+  emu_u32x4 v = {0, 0, 0, 0};
+  if (off >= 0 && (uint64_t)(uint32_t)off + 16 <= r.bytes) memcpy(&v, r.base + off, 16);
+  return v;
+}
+inline emu_u32x2 __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, int off, int, int) {
+  emu_u32x2 v = {0, 0};
+  if (off >= 0 && (uint64_t)(uint32_t)off + 8 <= r.bytes) memcpy(&v, r.base + off, 8);
+  return v;
+}
+inline uint8_t __builtin_amdgcn_raw_buffer_load_b8(__amdgpu_buffer_rsrc_t r, int off, int, int) {
+  return (off >= 0 && (uint32_t)off < r.bytes) ? r.base[off] : 0;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, __amdgpu_buffer_rsrc_t r, int off, int, int) {
+  if (off >= 0 && (uint64_t)(uint32_t)off + 16 <= r.bytes) memcpy(r.base + off, &v, 16);
+}
+inline void __builtin_amdgcn_raw_buffer_store_b8(uint8_t v, __amdgpu_buffer_rsrc_t r, int off, int, int) {
+  if (off >= 0 && (uint32_t)off < r.bytes) r.base[off] = v;
+}
+
+#include "hip_api_emu.h"

@@ -1,0 +1,62 @@
+"""The GPU parity tests on the CPU: the product sources compiled over the wave emulator and the HIP API stand-in
+(tests/cc/wave_emu.h, tests/cc/hip_api_emu.h, tests/cc/build_emu.sh -> oracle/_build/libgrdma_emu.so), loaded in
+place of libgrdma_amd.so (GRDMA_LIB_PATH), and the `-m gpu` tests run against it in a child pytest.
+
+What runs here: the deframer (all of tests/test_gpu_h2.py but the device pipelines, the boundary step, 64 frames
+per bulk step), the zero-copy send (tests/test_zz_gpu_zerocopy.py: k_tx_plan_zc + k_copy + the host API), and the
+pair protocol on random operation sequences and the reference-generated golden traces (k_tx_plan, k_copy, k_rx_plan,
+k_rx_apply, k_poll).  What the emulator cannot run is deselected: resident kernels that wait for the host (latency
+engine, link engine), HIP graphs, and the receive planner's multi-record drains, whose wave tier hands values from
+lane to lane through LDS between two cross-lane operations (lockstep on the GPU; the emulator's lanes are coroutines).
+
+This checks kernel LOGIC when no GPU is at hand; the GPU runs stay the reference."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+EMU_SO = os.path.join(ROOT, "oracle", "_build", "libgrdma_emu.so")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm clang++ as host compiler")
+
+
+@pytest.fixture(scope="module")
+def emu_lib(built):
+    srcs = []
+    for d in (os.path.join(ROOT, "grpc-rdma_amd", "csrc"), os.path.join(ROOT, "tests", "cc"), os.path.join(ROOT, "include")):
+        srcs += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".cc", ".h", ".hpp", ".sh"))]
+    if not os.path.exists(EMU_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in srcs):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "cc", "build_emu.sh")], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    return EMU_SO
+
+
+def run_gpu_tests(emu_lib, args, min_passed):
+    env = dict(os.environ, GRDMA_LIB_PATH=emu_lib, GRDMA_TEST_NEW="1")
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "--timeout", "600"] + args
+    last = ""
+    for attempt in range(2):  # (the staging waves of the deframer are real threads: one retry on a scheduling hiccup)
+        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+        last = (p.stdout + p.stderr)[-3000:]
+        if p.returncode == 0:
+            tail = p.stdout.strip().splitlines()[-1]
+            n = int(tail.split(" passed")[0].split()[-1])
+            assert n >= min_passed, tail
+            return
+    raise AssertionError(last)
+
+
+def test_deframer_gpu_tests_under_the_emulator(emu_lib):
+    run_gpu_tests(emu_lib, ["tests/test_gpu_h2.py", "tests/test_zz_gpu_h2_boundary.py", "-k", "not h2_pipe and not two_alternating"], 30)
+
+
+def test_zero_copy_gpu_tests_under_the_emulator(emu_lib):
+    run_gpu_tests(emu_lib, ["tests/test_zz_gpu_zerocopy.py"], 10)
+
+
+def test_pair_protocol_gpu_tests_under_the_emulator(emu_lib):
+    run_gpu_tests(emu_lib, ["tests/test_gpu_pair_parity.py", "-k",
+                            "(random_ops_match_oracle and not finegrained) or golden or poll_batch"], 12)
