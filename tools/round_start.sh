@@ -2,17 +2,18 @@
 # First GPU trip of a round: the paths written after the previous round's GPU budget ran out.
 #   1. tests/cc/gpu_quickcheck        (seconds) boundary step / bulk pairs vs the verified deframer,
 #                                      zero-copy send vs the oracle, with the deframer's tick counters
-#   2. the opt-in GPU tests           (GRDMA_TEST_NEW=1): tests/test_zz_gpu_zerocopy.py, bulk pairs
+#   2. the newest GPU tests           tests/test_zz_gpu_zerocopy.py, tests/test_zz_gpu_h2_boundary.py (so far run
+#                                      against the emulated library only)
 #   3. bench.py --no-rtt              value_with_h2 with and without the boundary step, and the same
 #                                      with GRDMA_H2_BULK_PAIRS=1
-# -> gpurun_out/start/.  When 1 and 2 pass: drop the GRDMA_TEST_NEW skips, consider GRDMA_H2_BULK_PAIRS on.
+# -> gpurun_out/start/.  When 1 and 2 pass: consider GRDMA_H2_BULK_PAIRS on by default.
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/start
 rm -rf $out; mkdir -p $out
 cd $R
 timeout 40 ./tests/cc/gpu_quickcheck $out/quickcheck.txt 30
 echo "quickcheck rc=$?"
-GRDMA_TEST_NEW=1 timeout 200 python -m pytest tests/test_zz_gpu_zerocopy.py tests/test_zz_gpu_h2_boundary.py -m gpu -q -x > $out/pytest_new.log 2>&1 < /dev/null
+timeout 200 python -m pytest tests/test_zz_gpu_zerocopy.py tests/test_zz_gpu_h2_boundary.py -m gpu -q -x > $out/pytest_new.log 2>&1 < /dev/null
 echo "new tests rc=$?"; tail -3 $out/pytest_new.log
 timeout 150 python bench.py --no-rtt > $out/bench.log 2> $out/bench.err < /dev/null
 echo "bench rc=$?"
