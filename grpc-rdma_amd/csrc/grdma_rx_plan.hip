@@ -982,7 +982,9 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
       while (chain_n - chain_i < 64 && !w.dry) {
         const uint32_t k = chain_n - chain_i;
         uint64_t keep = 0;
+        GRDMA_WAVE_CONVERGE();  // (no lane still reads the queue where it is about to be moved)
         if ((uint32_t)lane < k) keep = s_chain[chain_i + lane];
+        GRDMA_WAVE_CONVERGE();  // (every lane holds its entry before the entries are overwritten)
         if ((uint32_t)lane < k) s_chain[lane] = keep;
         chain_i = 0;
         chain_n = k;

@@ -119,6 +119,7 @@ struct wave_ctx {
   bool in_slot[kWave];
   void* site = nullptr;  // call site of the operation the lanes are gathering at
   int site_lane = 0;
+  bool restart = false;  // an operation completed: resume the lanes from lane 0, in ascending order
   block_sync* bs = nullptr;
   const std::function<void()>* body = nullptr;
   dim3 bid, bdim, gdim;
@@ -133,6 +134,22 @@ struct trace_entry { const char* tag; uint64_t v; };
 inline thread_local std::vector<trace_entry>* t_traces = nullptr;  // [lane]
 inline void trace(const char* tag, uint64_t v);
 
+inline void trace_report(int nlanes) {
+  if (!t_traces) return;
+  const std::vector<trace_entry>* traces = t_traces;
+  for (int i = 1; i < nlanes; i++) {
+    const auto &a = traces[0], &b = traces[i];
+    size_t k = 0;
+    while (k < a.size() && k < b.size() && a[k].v == b[k].v && a[k].tag == b[k].tag) k++;
+    if ((k < a.size() && k < b.size())) {
+      fprintf(stderr, "wave_emu trace: lane %d differs from lane 0 at entry %zu: lane0 %s=%llu, lane%d %s=%llu (previous: %s=%llu)\n", i, k,
+              a[k].tag, (unsigned long long)a[k].v, i, b[k].tag, (unsigned long long)b[k].v,
+              k ? a[k - 1].tag : "-", k ? (unsigned long long)a[k - 1].v : 0ull);
+      return;
+    }
+  }
+  fprintf(stderr, "wave_emu trace: the lanes agree on every entry they share\n");
+}
 inline lane_ctx* cur_lane() { return &t_wave->lanes[t_wave->cur]; }
 inline void trace(const char* tag, uint64_t v) {
   if (t_traces) t_traces[t_wave->cur].push_back({tag, v});
@@ -159,6 +176,7 @@ __attribute__((noinline)) inline void exchange(uint64_t v) {
             here, w->site_lane, w->site);
     void* bt[24];
     backtrace_symbols_fd(bt, backtrace(bt, 24), 2);
+    trace_report(w->nlanes);
     abort();
   }
   w->slot[me] = v;
@@ -172,6 +190,10 @@ __attribute__((noinline)) inline void exchange(uint64_t v) {
     }
     w->arrived = 0;
     w->gen++;
+    // the stretch up to the next cross-lane operation runs lane 0 first, then 1, 2, ...: a value lane 0 stores
+    // is there for the others, as it is when the lanes execute together
+    w->restart = true;
+    yield_lane();
   } else {
     while (w->gen == g) yield_lane();
   }
@@ -218,27 +240,18 @@ inline void run_wave(wave_ctx* w) {
       if (w->lanes[i].done) continue;
       w->cur = i;
       swapcontext(&w->sched, &w->lanes[i].ctx);
+      if (w->restart) {
+        w->restart = false;
+        break;
+      }
     }
   }
   for (int i = 0; i < w->nlanes; i++) {
     stack_free(w->lanes[i].stack);
     w->lanes[i].stack = nullptr;
   }
-  if (t_traces) {
-    for (int i = 1; i < w->nlanes; i++) {
-      const auto &a = traces[0], &b = traces[i];
-      size_t k = 0;
-      while (k < a.size() && k < b.size() && a[k].v == b[k].v && a[k].tag == b[k].tag) k++;
-      if (k < a.size() || k < b.size()) {
-        fprintf(stderr, "wave_emu trace: lane %d differs from lane 0 at entry %zu: lane0 %s=%llu, lane%d %s=%llu (previous: %s=%llu)\n", i, k,
-                k < a.size() ? a[k].tag : "(end)", k < a.size() ? (unsigned long long)a[k].v : 0ull, i,
-                k < b.size() ? b[k].tag : "(end)", k < b.size() ? (unsigned long long)b[k].v : 0ull,
-                k ? a[k - 1].tag : "-", k ? (unsigned long long)a[k - 1].v : 0ull);
-        break;
-      }
-    }
-    t_traces = nullptr;
-  }
+  trace_report(w->nlanes);
+  t_traces = nullptr;
   w->bs->drop();
   t_wave = nullptr;
 }
@@ -387,6 +400,8 @@ inline void __syncthreads() {
     for (int i = 0; i < 64; i++) w->in_slot[i] = false;
     w->arrived = 0;
     w->gen++;
+    w->restart = true;
+    emu::yield_lane();
   } else {
     while (w->gen == g) emu::yield_lane();
   }

@@ -5,9 +5,8 @@ place of libgrdma_amd.so (GRDMA_LIB_PATH), and the `-m gpu` tests run against it
 What runs here: the deframer (all of tests/test_gpu_h2.py but the device pipelines, the boundary step, 64 frames
 per bulk step), the zero-copy send (tests/test_zz_gpu_zerocopy.py: k_tx_plan_zc + k_copy + the host API), and the
 pair protocol on random operation sequences and the reference-generated golden traces (k_tx_plan, k_copy, k_rx_plan,
-k_rx_apply, k_poll).  What the emulator cannot run is deselected: resident kernels that wait for the host (latency
-engine, link engine), HIP graphs, and the receive planner's multi-record drains, whose wave tier hands values from
-lane to lane through LDS between two cross-lane operations (lockstep on the GPU; the emulator's lanes are coroutines).
+k_rx_apply, k_poll), and the receive planner's multi-record drains.  What the emulator cannot run is deselected:
+resident kernels that wait for the host (latency engine, link engine) and HIP graphs (the streaming jobs).
 
 This checks kernel LOGIC when no GPU is at hand; the GPU runs stay the reference."""
 import os
@@ -60,3 +59,10 @@ def test_zero_copy_gpu_tests_under_the_emulator(emu_lib):
 def test_pair_protocol_gpu_tests_under_the_emulator(emu_lib):
     run_gpu_tests(emu_lib, ["tests/test_gpu_pair_parity.py", "-k",
                             "(random_ops_match_oracle and not finegrained) or golden or poll_batch"], 12)
+
+
+def test_receive_planner_drains_under_the_emulator(emu_lib):
+    """The multi-record drains of k_rx_plan: the 64-probe chain walker, the one-lane-per-record replay, the bulk tier
+    with its period predictor, ring wrap and the credit rule over several cycles."""
+    run_gpu_tests(emu_lib, ["tests/test_gpu_pair_parity.py", "-k",
+                            "periodic_stream_bulk_tier or (drain_many_records and 4096)"], 6)
