@@ -706,6 +706,11 @@ def main():
             out["value_ring4096_sge30_one_send_per_round"] = round(wl.user_bytes * 2 * world / rk1["elapsed"] / (1 << 30), 3)
         except Exception as e:
             out["ring4096_sge30_error"] = str(e)[:200]
+        try:  # the same knobs with the loop-back / xGMI wire written directly (no staging copy, no wire launch)
+            rkd = measure(4096, half, 1, not args.no_verify, False, max_sge=30, burst=16, wire_flags=2)
+            out["value_ring4096_sge30_wire_direct"] = round(wl.user_bytes * half * world / rkd["elapsed"] / (1 << 30), 3)
+        except Exception as e:
+            out["ring4096_sge30_wire_direct_error"] = str(e)[:200]
         # mixed message sizes (examples/cpp/test/common.h: uniform in [1, 4 MiB - 1 KiB]), 64 messages per step
         try:
             mw = MixedWorkload(g, 64)

@@ -4,14 +4,16 @@
 // wave_emu.h this lets the PRODUCT sources (csrc/*.hip, *.cc) be compiled for the CPU into
 // oracle/_build/libgrdma_emu.so, which the Python parity tests can load instead of libgrdma_amd.so
 // (GRDMA_LIB_PATH) when no GPU is at hand -- see tests/cc/build_emu.sh and tests/test_emu_pair.py.
-// Not emulated: HIP graphs, IPC handles, dma-buf export (they report an error), resident kernels that wait
-// for the host (a launch returns only when the kernel has finished).
+// Graphs of kernel nodes run their nodes in the order they were added.  Not emulated: IPC handles, dma-buf
+// export (they report an error), resident kernels that wait for the host (a launch returns only when the
+// kernel has finished).
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 typedef int hipError_t;
 enum {
@@ -22,9 +24,12 @@ enum {
 };
 typedef struct emu_stream* hipStream_t;
 typedef struct emu_event* hipEvent_t;
-typedef struct emu_graph* hipGraph_t;
-typedef struct emu_graph_exec* hipGraphExec_t;
-typedef struct emu_graph_node* hipGraphNode_t;
+struct emu_graph_node;
+struct emu_graph;
+struct emu_graph_exec;
+typedef emu_graph* hipGraph_t;
+typedef emu_graph_exec* hipGraphExec_t;
+typedef emu_graph_node* hipGraphNode_t;
 typedef void* hipDeviceptr_t;
 struct hipIpcMemHandle_t {
   char reserved[64];
@@ -108,12 +113,53 @@ inline hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned) { ret
 inline hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
 inline hipError_t hipMemGetHandleForAddressRange(void*, hipDeviceptr_t, size_t, int, unsigned long long) { return hipErrorNotSupported; }
 
-inline hipError_t hipGraphCreate(hipGraph_t*, unsigned) { return hipErrorNotSupported; }
-inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
-inline hipError_t hipGraphAddKernelNode(hipGraphNode_t*, hipGraph_t, const hipGraphNode_t*, size_t, const hipKernelNodeParams*) { return hipErrorNotSupported; }
-inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
-inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
-inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+// HIP graphs of kernel nodes (what csrc/grdma_pair.hip builds for a streaming job: every node carries two
+// pointer-sized parameters).  The nodes run in the order they were added, which is a valid order of the graph:
+// a node's dependencies are always nodes added before it.
+struct emu_graph_node {
+  void* func;
+  dim3 grid, block;
+  void* a0;
+  void* a1;
+};
+struct emu_graph {
+  std::vector<emu_graph_node*> nodes;
+};
+struct emu_graph_exec {
+  std::vector<emu_graph_node> nodes;
+};
+inline hipError_t hipGraphCreate(hipGraph_t* g, unsigned) { *g = new emu_graph(); return hipSuccess; }
+inline hipError_t hipGraphDestroy(hipGraph_t g) {
+  if (g) {
+    for (emu_graph_node* n : g->nodes) delete n;
+    delete g;
+  }
+  return hipSuccess;
+}
+inline hipError_t hipGraphAddKernelNode(hipGraphNode_t* node, hipGraph_t g, const hipGraphNode_t*, size_t,
+                                        const hipKernelNodeParams* p) {
+  emu_graph_node* n = new emu_graph_node{p->func, p->gridDim, p->blockDim, *static_cast<void**>(p->kernelParams[0]),
+                                         *static_cast<void**>(p->kernelParams[1])};
+  g->nodes.push_back(n);
+  *node = n;
+  return hipSuccess;
+}
+inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) {
+  emu_graph_exec* x = new emu_graph_exec();
+  for (emu_graph_node* n : g->nodes) x->nodes.push_back(*n);
+  *e = x;
+  return hipSuccess;
+}
+inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+  std::lock_guard<std::recursive_mutex> lk(emu::launch_mutex());
+  for (const emu_graph_node& n : e->nodes) {
+    void (*f)(void*, void*) = reinterpret_cast<void (*)(void*, void*)>(n.func);
+    void *a0 = n.a0, *a1 = n.a1;
+    emu::launch(n.grid, n.block, [=] { f(a0, a1); });
+  }
+  return hipSuccess;
+}
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
 
 // A launch runs the whole grid under the emulator and returns when it is done.  One launch at a time: the
 // __shared__ objects of a kernel are statics.

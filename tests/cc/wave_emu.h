@@ -67,14 +67,32 @@ struct lane_ctx {
   bool done = false;
 };
 constexpr size_t kGuard = 4096;
+struct stack_pool {
+  std::mutex mu;
+  std::vector<char*> free_list;
+};
+inline stack_pool& stacks() {
+  static stack_pool p;
+  return p;
+}
 inline char* stack_alloc() {
+  {
+    std::lock_guard<std::mutex> lk(stacks().mu);
+    if (!stacks().free_list.empty()) {
+      char* q = stacks().free_list.back();
+      stacks().free_list.pop_back();
+      return q;
+    }
+  }
   void* p = mmap(nullptr, kGuard + kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
   if (p == MAP_FAILED) abort();
   mprotect(p, kGuard, PROT_NONE);  // a lane that overruns its stack faults here instead of in a neighbour
   return static_cast<char*>(p);
 }
-inline void stack_free(char* p) {
-  if (p) munmap(p, kGuard + kStack);
+inline void stack_free(char* p) {  // back to the pool: the next launch reuses the mapping (and its touched pages)
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(stacks().mu);
+  stacks().free_list.push_back(p);
 }
 
 struct block_sync {  // barrier between the wave threads of a workgroup
