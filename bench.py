@@ -483,7 +483,7 @@ def main():
             tx.close(); rx.close(); dst.free()
         return out
 
-    def measure_with_h2(ring_kb, steps, warmup, engine=False, boundary_step=None):
+    def measure_with_h2(ring_kb, steps, warmup, engine=False, boundary_step=None, bulk_pairs=False, ticks=False):
         """The same step with the HTTP/2 stages INSIDE the timed device pipeline: k_h2_frame rebuilds
         the slice list from the message table, the job carries it through the connection, k_h2_deframe
         parses what was delivered (events: frames, message boundaries, payload pieces).  Two jobs over
@@ -496,7 +496,7 @@ def main():
         scap = len(w.lens) * 2 + 64 + w.N // 256
         dst_cap = w.N + 16 * scap + 4096
         msgs = [(w.payload_buf.ptr + i * w.msg_len, w.msg_len, 1, 0) for i in range(w.n_msgs)]
-        parser = h2dev.Parser(False, boundary_step=boundary_step)
+        parser = h2dev.Parser(False, boundary_step=boundary_step, bulk_pairs=bulk_pairs, ticks=ticks)
         assert parser.open_streams([1]) == 0      # a client-side parser: the call runs on stream 1
         jobs, pipes, dsts = [], [], []
         for _ in range(2):
@@ -685,14 +685,27 @@ def main():
             out["with_h2_stages"] = hh["stages"]
         except Exception as e:
             out["with_h2_error"] = str(e)[:200]
+        eng_ = (args.schedule == "engine")
+        few = max(2, args.steps // 4)
+        try:  # the phase ticks of the deframing kernel (a short run with the clock samples on)
+            ht = measure_with_h2(args.ring_kb, 2, 2, engine=eng_, ticks=True)
+            out["with_h2_stages"]["deframe_ticks"] = ht["stages"]["deframe_ticks"]
+            out["with_h2_stages"]["deframe_us_with_clock_samples"] = ht["stages"]["deframe_us"]
+        except Exception as e:
+            out["with_h2_ticks_error"] = str(e)[:200]
         try:  # the same leg with message starts left to the byte-wise automaton
-            h0 = measure_with_h2(args.ring_kb, max(2, args.steps // 4), 2, engine=(args.schedule == "engine"),
-                                 boundary_step=False)
-            out["value_with_h2_no_boundary_step"] = round(
-                wl.user_bytes * max(2, args.steps // 4) * world / h0["elapsed"] / (1 << 30), 3)
+            h0 = measure_with_h2(args.ring_kb, few, 2, engine=eng_, boundary_step=False)
+            out["value_with_h2_no_boundary_step"] = round(wl.user_bytes * few * world / h0["elapsed"] / (1 << 30), 3)
             out["with_h2_no_boundary_step_deframe_us"] = h0["stages"]["deframe_us"]
         except Exception as e:
             out["with_h2_no_boundary_step_error"] = str(e)[:200]
+        try:  # ... and with 64 frames per bulk step (GRDMA_H2_BULK_PAIRS: off by default until it has run on hardware)
+            h2_ = measure_with_h2(args.ring_kb, few, 2, engine=eng_, bulk_pairs=True)
+            out["value_with_h2_bulk_pairs"] = round(wl.user_bytes * few * world / h2_["elapsed"] / (1 << 30), 3)
+            out["with_h2_bulk_pairs_deframe_us"] = h2_["stages"]["deframe_us"]
+            out["with_h2_bulk_pairs_verified"] = h2_["verified"]
+        except Exception as e:
+            out["with_h2_bulk_pairs_error"] = str(e)[:200]
     if not args.no_extra_legs:
         # the reference's default knobs (4 MiB ring, max_sge 30: rdma_utils.h / config.cc), same workload,
         # with the CPU codec timed at the SAME knobs beside it

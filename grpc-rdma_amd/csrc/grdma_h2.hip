@@ -163,6 +163,7 @@ grdma_h2_parser* grdma_h2_parser_create_ex(int flags, uint32_t max_frame_size,
   init.tab_mask = table_slots - 1;
   init.boundary_step = (flags & GRDMA_H2_BOUNDARY_STEP) ? 1 : (flags & GRDMA_H2_NO_BOUNDARY_STEP) ? 0 : h2_boundary_default();
   init.bulk_pairs = (flags & GRDMA_H2_BULK_PAIRS) ? 1 : h2_bulk_pairs_default();
+  init.ticks = (flags & GRDMA_H2_TICKS) ? 1 : 0;
   if (hipMalloc((void**)&p->d, sizeof(init)) != hipSuccess ||
       hipMalloc((void**)&p->d_tab, sizeof(grdma_h2_stream_dev) * table_slots) != hipSuccess ||
       hipMalloc((void**)&p->d_res, sizeof(grdma_h2_deframe_result)) != hipSuccess ||

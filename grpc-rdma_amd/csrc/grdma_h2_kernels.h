@@ -59,6 +59,7 @@ struct grdma_h2_parser_dev {
   int32_t error;        // connection error (grdma_h2_error), sticky
   int32_t boundary_step;  // 1 = message starts go through h2_boundary_match (grdma_h2_fast.h)
   int32_t bulk_pairs;     // 1 = the bulk step gives every lane a frame (64 frames, 128 slices per step)
+  int32_t ticks;          // 1 = the parsing wave samples the device clock around its phases (profiling aid)
   grdma_h2_stream_dev* tab;
 };
 
@@ -382,19 +383,23 @@ __device__ void h2_stage_windows(uint32_t h, uint32_t nh, const uint8_t* arena,
 struct h2_view {
   uint64_t have_upto;  // windows [.., have_upto) are known to be staged (and not yet released)
   uint64_t t_wait;     // profiling aid
+  bool ticks;          // sample the clock around waits
 };
+// the device clock, or 0 when the call does not collect phase ticks (a sample is a scalar memory operation
+// the wave waits for: a dozen of them per message show in a loop that runs a few hundred instructions)
+__device__ __forceinline__ uint64_t h2_clock(bool on) { return on ? __builtin_amdgcn_s_memtime() : 0; }
 
 // make sure the window of slice s is staged (wave-uniform spin)
 __device__ __forceinline__ void h2_need(h2_view& V, uint64_t s) {
   const uint64_t k = s >> 6;
   if (k < V.have_upto) return;
-  const uint64_t t0 = __builtin_amdgcn_s_memtime();
+  const uint64_t t0 = h2_clock(V.ticks);
   for (;;) {
     const uint32_t q = __hip_atomic_load(&g_h2.seq[k % H2_RING], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (q == (uint32_t)(k + 1)) break;
     __builtin_amdgcn_s_sleep(1);
   }
-  V.t_wait += __builtin_amdgcn_s_memtime() - t0;
+  V.t_wait += h2_clock(V.ticks) - t0;
   V.have_upto = k + 1;
 }
 __device__ __forceinline__ const h2_win_ent* h2_ent(h2_view&, uint64_t s) {
@@ -528,12 +533,13 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
     return;
   }
   __builtin_amdgcn_s_setprio(3);  // the one serial wave of the kernel: it gets the issue slots it asks for
-  h2_view V = {0, 0};
+  const grdma_h2_parser_dev P = *gp;  // uniform loads: the whole block sits in scalar registers
+  const bool ticks = P.ticks != 0;
+  h2_view V = {0, 0, ticks};
   const uint64_t t_begin = __builtin_amdgcn_s_memtime();
   uint64_t t_bulk = 0, t_serial = 0, t_boundary = 0;
   uint32_t consumed_pub = 0;
   uint64_t bulk_steps = 0, bulk_frames = 0, boundary_steps = 0;
-  const grdma_h2_parser_dev P = *gp;  // uniform loads: the whole block sits in scalar registers
   uint64_t nev = 0, overflow = 0;
   static const char kPrefix[] = "PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n";  // internal.h:781
 
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
     // scalar registers, the match runs on the scalar unit, and lane k stores event k.
     if (P.boundary_step && st == ST_FH0 && expect_cont == 0 && !is_first_frame && D.idx >= 0 && !D.read_closed &&
         (D.state == 0 || (D.state == 5 && D.fsz - 1u < 9u))) {
-      const uint64_t tq0 = __builtin_amdgcn_s_memtime();
+      const uint64_t tq0 = h2_clock(ticks);
       const h2_win_ent me = *h2_ent(V, s);
       uint64_t next_len = ~0ull;
       if (s + 1 < nslices) {
@@ -622,11 +628,11 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
         cur_parser = PARSER_DATA;
         received_last = 0;
         boundary_steps++;
-        t_boundary += __builtin_amdgcn_s_memtime() - tq0;
+        t_boundary += h2_clock(ticks) - tq0;
         s += (uint64_t)B.nslices - 1;  // (the loop adds the last one)
         continue;
       }
-      t_boundary += __builtin_amdgcn_s_memtime() - tq0;
+      t_boundary += h2_clock(ticks) - tq0;
     }
     // ---- bulk step: the streaming steady state, many frames at once ---------------------
     // Between a message's first and last frame every DATA frame of a stream spans exactly TWO
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
     // automaton below would have produced for its frame.
     if (st == ST_FH0 && expect_cont == 0 && !is_first_frame && D.idx >= 0 && !D.read_closed && D.state == 5 &&
         D.fsz != 0) {
-      const uint64_t tb0 = __builtin_amdgcn_s_memtime();
+      const uint64_t tb0 = h2_clock(ticks);
       // lane i looks at slice s + i and every even lane owns a frame (the windows needed: the current
       // one and, when s is not window aligned, the next one -- staged, or beyond the end of the
       // list); with bulk_pairs lane i owns the frame in slices s + 2 i and s + 2 i + 1, 64 frames per
@@ -713,13 +719,13 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
           received_last = 0;
           bulk_steps++;
           bulk_frames += (uint64_t)__builtin_popcountll(wmask);
-          t_bulk += __builtin_amdgcn_s_memtime() - tb0;
+          t_bulk += h2_clock(ticks) - tb0;
           s += 2ull * (uint64_t)__builtin_popcountll(wmask) - 1;  // (the loop adds the last one)
           continue;
         }
       }
     }
-    const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+    const uint64_t ts0 = h2_clock(ticks);
     const uint64_t len = h2_ent(V, s)->len;
     uint64_t cur = 0;
     while (cur < len && !err && !overflow) {
@@ -890,7 +896,7 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
         st = ST_FH0;
       }
     }
-    t_serial += __builtin_amdgcn_s_memtime() - ts0;
+    t_serial += h2_clock(ticks) - ts0;
     if (err || overflow) break;
   }
 #undef H2_PUSH

@@ -56,7 +56,7 @@ def frame_messages(msgs, max_frame, slices_dev_ptr, slices_cap, hdr_dev_ptr, hdr
     return n, wire.value
 
 
-H2_SERVER, H2_FIRST_FRAME, H2_BOUNDARY_STEP, H2_NO_BOUNDARY_STEP, H2_BULK_PAIRS = 1, 2, 4, 8, 16
+H2_SERVER, H2_FIRST_FRAME, H2_BOUNDARY_STEP, H2_NO_BOUNDARY_STEP, H2_BULK_PAIRS, H2_TICKS = 1, 2, 4, 8, 16, 32
 
 
 class Parser:
@@ -65,7 +65,7 @@ class Parser:
     False: a client / mid-connection parser whose streams the caller opens."""
 
     def __init__(self, expect_client_prefix=False, max_frame_size=16384, flags=None,
-                 max_concurrent_streams=0xFFFFFFFF, table_slots=0, boundary_step=None, bulk_pairs=False):
+                 max_concurrent_streams=0xFFFFFFFF, table_slots=0, boundary_step=None, bulk_pairs=False, ticks=False):
         self.lib = _bind()
         if flags is None:
             flags = (H2_SERVER | H2_FIRST_FRAME) if expect_client_prefix else 0
@@ -73,6 +73,8 @@ class Parser:
             flags |= H2_BOUNDARY_STEP if boundary_step else H2_NO_BOUNDARY_STEP
         if bulk_pairs:
             flags |= H2_BULK_PAIRS
+        if ticks:
+            flags |= H2_TICKS
         self.h = self.lib.grdma_h2_parser_create_ex(flags, max_frame_size, max_concurrent_streams, table_slots)
         if not self.h:
             raise GrdmaError("h2 parser allocation failed")

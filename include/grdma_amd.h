@@ -412,10 +412,13 @@ enum grdma_h2_parser_flags {
                                     32 bytes) is parsed in one wave-uniform step instead of byte-wise   */
   GRDMA_H2_NO_BOUNDARY_STEP = 8, /* never; with neither flag the step is on unless the environment
                                     says GRDMA_H2_BOUNDARY_STEP=0                                    */
-  GRDMA_H2_BULK_PAIRS = 16       /* the bulk step gives EVERY lane a frame (lane i: slices s + 2i, s + 2i + 1):
+  GRDMA_H2_BULK_PAIRS = 16,      /* the bulk step gives EVERY lane a frame (lane i: slices s + 2i, s + 2i + 1):
                                     64 frames and 128 slices per step instead of 32 / 64.  Off by default
                                     (GRDMA_H2_BULK_PAIRS=1 in the environment turns it on): written after the
                                     round's GPU budget was spent, first run pending                    */
+  GRDMA_H2_TICKS = 32            /* the parsing wave samples the device clock around its phases (the tick counters
+                                    of grdma_h2_pipe_sync / grdma_h2_last_deframe_stats); off by default: a sample
+                                    is a scalar memory operation the wave waits for                     */
 };
 typedef struct grdma_h2_parser grdma_h2_parser;
 /* Deframe state of one transport (grpc_chttp2_transport deframe_state & co., internal.h) and

@@ -155,9 +155,11 @@ static void check_h2(const char* name, const std::vector<bytes>& body, bool odd,
   h.push_back(0x82);
   chunks.push_back(h);
   chunks.insert(chunks.end(), body.begin(), body.end());
-  const run_result a = deframe(chunks, odd, GRDMA_H2_NO_BOUNDARY_STEP);
-  const run_result b = deframe(chunks, odd, GRDMA_H2_BOUNDARY_STEP);
+  const run_result a = deframe(chunks, odd, GRDMA_H2_NO_BOUNDARY_STEP | GRDMA_H2_TICKS);
+  const run_result b = deframe(chunks, odd, GRDMA_H2_BOUNDARY_STEP | GRDMA_H2_TICKS);
   const run_result c = deframe(chunks, odd, GRDMA_H2_BOUNDARY_STEP | GRDMA_H2_BULK_PAIRS);
+  const run_result d = deframe(chunks, odd, GRDMA_H2_BOUNDARY_STEP);  // (no clock samples: the product's default)
+  SAY("h2 without clock samples %-16s kernel_us %.1f (boundary step), %.1f (+ bulk pairs)\n", name, d.us, c.us);
   {
     bool okc = c.n == a.n && c.err == 0;
     for (size_t i = 0; okc && i < a.ev.size(); i++)

@@ -31,6 +31,7 @@ extern "C" int64_t h2_emu_deframe(int flags, uint32_t max_frame, const uint32_t*
   P.tab_mask = table_slots - 1;
   P.boundary_step = (flags & GRDMA_H2_BOUNDARY_STEP) ? 1 : 0;
   P.bulk_pairs = (flags & GRDMA_H2_BULK_PAIRS) ? 1 : 0;
+  P.ticks = (flags & GRDMA_H2_TICKS) ? 1 : 0;
   P.tab = tab.data();
   if (n_open) {
     std::vector<grdma_h2_table_op> ops(n_open);
