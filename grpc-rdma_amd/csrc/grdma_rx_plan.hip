@@ -1253,6 +1253,11 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
       __syncthreads();
       if (took) continue;
     }
+    // Every wave has evaluated the loop head (S.stop, S.remain, S.bulk_*) before wave 0 goes on to replace S
+    // at the end of the wave tier: without this barrier a wave that is late by the duration of the wave tier
+    // would read the NEXT state, take the other branch and miss the barrier below.  (Found with the host
+    // emulation under CPU load, tests/cc/wave_emu.h: there a wave is an OS thread and can be late by that much.)
+    __syncthreads();
     if (wave == 0) wave_tier();
     __syncthreads();
   }

@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #include <mutex>
 #include <vector>
@@ -52,11 +53,36 @@ inline std::recursive_mutex& launch_mutex() {
   static std::recursive_mutex m;
   return m;
 }
+// Device memory.  With EMU_GUARD_ALLOC=1 every allocation ends right in front of an inaccessible page (the
+// start is 16-byte aligned, so an overrun of 16 bytes or more -- a vector load past the end of a ring, an arena,
+// a plan -- faults at once, with EMU_SEGV_TRACE=1 naming the kernel line); the GPU's coarse page mapping lets
+// such accesses through most of the time.  Guarded blocks are never unmapped before exit (a stale pointer
+// faults too).
+inline bool guard_alloc() {
+  static const bool on = [] { const char* e = getenv("EMU_GUARD_ALLOC"); return e && e[0] == '1'; }();
+  return on;
+}
+struct guard_hdr { size_t map_len; };
 inline void* dev_alloc(size_t n) {
+  if (guard_alloc()) {
+    const size_t page = 4096, need = ((n ? n : 1) + 15) & ~(size_t)15;
+    const size_t body = (need + page - 1) / page * page;
+    char* m = static_cast<char*>(mmap(nullptr, body + page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
+    if (m == MAP_FAILED) return nullptr;
+    mprotect(m + body, page, PROT_NONE);
+    char* p = m + body - need;
+    memset(p, 0xA5, need);
+    return p;
+  }
   void* p = nullptr;
   if (posix_memalign(&p, 256, n ? n : 1) != 0) return nullptr;
   memset(p, 0xA5, n);  // device memory does not come zeroed
   return p;
+}
+inline void dev_free(void* p) {
+  if (!p) return;
+  if (guard_alloc()) return;  // (kept mapped: see above)
+  free(p);
 }
 }  // namespace emu
 
@@ -83,8 +109,8 @@ template <typename T>
 inline hipError_t hipExtMallocWithFlags(T** p, size_t n, unsigned) { return hipMalloc(p, n); }
 template <typename T>
 inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
-inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipFree(void* p) { emu::dev_free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void* p) { emu::dev_free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
