@@ -178,6 +178,14 @@ def tcp_baseline():
                                 "error": gs_.get("error") or gu.get("error")}}
 
 
+def err_text(e):
+    """Exception -> short text that still says where it happened (an assert carries no message)."""
+    import traceback
+    tb = traceback.extract_tb(e.__traceback__)
+    where = "%s:%d" % (os.path.basename(tb[-1].filename), tb[-1].lineno) if tb else "?"
+    return ("%s at %s: %s" % (type(e).__name__, where, e))[:240]
+
+
 def measured_copy_ceiling(torch, dev, nbytes=256 * MIB, reps=20):
     """What this GPU's own copy engines / fill kernels reach on a buffer of the step's size:
     the practical ceiling to read roofline.frac against (the 8 TB/s peak is the spec figure)."""
@@ -684,7 +692,7 @@ def main():
             out["with_h2_verified"] = hh["verified"]
             out["with_h2_stages"] = hh["stages"]
         except Exception as e:
-            out["with_h2_error"] = str(e)[:200]
+            out["with_h2_error"] = err_text(e)
         eng_ = (args.schedule == "engine")
         few = max(2, args.steps // 4)
         try:  # the phase ticks of the deframing kernel (a short run with the clock samples on)
@@ -692,20 +700,20 @@ def main():
             out["with_h2_stages"]["deframe_ticks"] = ht["stages"]["deframe_ticks"]
             out["with_h2_stages"]["deframe_us_with_clock_samples"] = ht["stages"]["deframe_us"]
         except Exception as e:
-            out["with_h2_ticks_error"] = str(e)[:200]
+            out["with_h2_ticks_error"] = err_text(e)
         try:  # the same leg with message starts left to the byte-wise automaton
             h0 = measure_with_h2(args.ring_kb, few, 2, engine=eng_, boundary_step=False)
             out["value_with_h2_no_boundary_step"] = round(wl.user_bytes * few * world / h0["elapsed"] / (1 << 30), 3)
             out["with_h2_no_boundary_step_deframe_us"] = h0["stages"]["deframe_us"]
         except Exception as e:
-            out["with_h2_no_boundary_step_error"] = str(e)[:200]
+            out["with_h2_no_boundary_step_error"] = err_text(e)
         try:  # ... and with 64 frames per bulk step (GRDMA_H2_BULK_PAIRS: off by default until it has run on hardware)
             h2_ = measure_with_h2(args.ring_kb, few, 2, engine=eng_, bulk_pairs=True)
             out["value_with_h2_bulk_pairs"] = round(wl.user_bytes * few * world / h2_["elapsed"] / (1 << 30), 3)
             out["with_h2_bulk_pairs_deframe_us"] = h2_["stages"]["deframe_us"]
             out["with_h2_bulk_pairs_verified"] = h2_["verified"]
         except Exception as e:
-            out["with_h2_bulk_pairs_error"] = str(e)[:200]
+            out["with_h2_bulk_pairs_error"] = err_text(e)
     if not args.no_extra_legs:
         # the reference's default knobs (4 MiB ring, max_sge 30: rdma_utils.h / config.cc), same workload,
         # with the CPU codec timed at the SAME knobs beside it
@@ -718,12 +726,12 @@ def main():
             rk1 = measure(4096, 2, 1, False, False, max_sge=30)
             out["value_ring4096_sge30_one_send_per_round"] = round(wl.user_bytes * 2 * world / rk1["elapsed"] / (1 << 30), 3)
         except Exception as e:
-            out["ring4096_sge30_error"] = str(e)[:200]
+            out["ring4096_sge30_error"] = err_text(e)
         try:  # the same knobs with the loop-back / xGMI wire written directly (no staging copy, no wire launch)
             rkd = measure(4096, half, 1, not args.no_verify, False, max_sge=30, burst=16, wire_flags=2)
             out["value_ring4096_sge30_wire_direct"] = round(wl.user_bytes * half * world / rkd["elapsed"] / (1 << 30), 3)
         except Exception as e:
-            out["ring4096_sge30_wire_direct_error"] = str(e)[:200]
+            out["ring4096_sge30_wire_direct_error"] = err_text(e)
         # mixed message sizes (examples/cpp/test/common.h: uniform in [1, 4 MiB - 1 KiB]), 64 messages per step
         try:
             mw = MixedWorkload(g, 64)
@@ -734,7 +742,7 @@ def main():
             out["config"]["mixed_sizes_leg"] = "64 messages, sizes uniform in [1, 4 MiB - 1 KiB] (seed 0), %d MiB per step, %d slices" % (
                 mw.user_bytes >> 20, len(mw.lens))
         except Exception as e:
-            out["mixed_sizes_error"] = str(e)[:200]
+            out["mixed_sizes_error"] = err_text(e)
     if rank == 0 and world == 1 and not args.no_extra_legs:
         # host slices through the endpoint vtable (grpc_endpoint_write / _read, include/grdma_endpoint.hpp):
         # what a gRPC maintainer's process sees, PCIe both ways included
