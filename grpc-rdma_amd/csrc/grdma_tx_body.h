@@ -153,6 +153,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
   // wire: the <= 2 RDMA WRITEs of GetWriteRequests (ring_buffer.cc:261-330)
   if (!direct && staged > 0 && c->peer_ring != nullptr) {
     GRDMA_WAIT_VMEM();  // staging complete before it is read back
+    GRDMA_WAVE_CONVERGE();  // (by every lane: a lane's wire tile holds bytes its neighbours staged)
     for (uint64_t done = 0; done < staged;) {
       uint64_t n = staged - done;
       if (n > GRDMA_TILE_BYTES) n = GRDMA_TILE_BYTES;

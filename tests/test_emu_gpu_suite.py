@@ -59,12 +59,7 @@ def test_zero_copy_gpu_tests_under_the_emulator(emu_lib):
 
 
 def test_pair_protocol_gpu_tests_under_the_emulator(emu_lib):
-    run_gpu_tests(emu_lib, ["tests/test_gpu_pair_parity.py", "-k",
-                            "(random_ops_match_oracle and not finegrained) or golden or poll_batch"], 12)
-
-
-def test_receive_planner_drains_under_the_emulator(emu_lib):
-    """The multi-record drains of k_rx_plan: the 64-probe chain walker, the one-lane-per-record replay, the bulk tier
-    with its period predictor, ring wrap and the credit rule over several cycles."""
-    run_gpu_tests(emu_lib, ["tests/test_gpu_pair_parity.py", "-k",
-                            "periodic_stream_bulk_tier or (drain_many_records and 4096)"], 6)
+    """All of tests/test_gpu_pair_parity.py: random operation sequences in the four wire / memory modes, the golden
+    traces, batched polling, the multi-record drains of k_rx_plan (chain walker, one-lane-per-record replay, bulk tier
+    with its period predictor), latency mode (single-launch small sends, express drain), the unary ping-pong."""
+    run_gpu_tests(emu_lib, ["tests/test_gpu_pair_parity.py", "-n", "4"], 55)
