@@ -58,6 +58,12 @@ def test_zero_copy_gpu_tests_under_the_emulator(emu_lib):
     run_gpu_tests(emu_lib, ["tests/test_zz_gpu_zerocopy.py"], 10)
 
 
+def test_concurrent_writer_and_poller_gpu_tests_under_the_emulator(emu_lib):
+    """Records landing header-first / footer-last from a second thread while the receiver polls and reads; the
+    background poller thread (one k_poll launch per pass, eventfd wakeups)."""
+    run_gpu_tests(emu_lib, ["tests/test_gpu_concurrent_writer.py", "tests/test_gpu_poller.py"], 5)
+
+
 def test_pair_protocol_gpu_tests_under_the_emulator(emu_lib):
     """All of tests/test_gpu_pair_parity.py: random operation sequences in the four wire / memory modes, the golden
     traces, batched polling, the multi-record drains of k_rx_plan (chain walker, one-lane-per-record replay, bulk tier
