@@ -676,16 +676,10 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
       const uint64_t bad = __ballot(hdr_lane && !ok);
       const int first_bad = bad ? __builtin_ctzll(bad) : 64;
       const bool cand = ok && lane < first_bad;
-      uint32_t cum = cand ? fs : 0u;                     // payload bytes up to and including my frame
-      uint32_t epos = cand ? (p0 ? 5u : 3u) : 0u;        // events up to and including my frame
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(cum, d, 64), ue = __shfl_up(epos, d, 64);
-        if (lane >= d) {
-          cum += up;
-          epos += ue;
-        }
-      }
+      // payload bytes / events up to and including my frame: two inclusive scans on the DPP network (six VALU
+      // instructions each, no LDS; the twelve dependent bpermutes they replace were a good part of the step)
+      const uint32_t cum = wave_incl_scan_u32(cand ? fs : 0u);
+      const uint32_t epos = wave_incl_scan_u32(cand ? (p0 ? 5u : 3u) : 0u);
       const bool within = cand && cum <= D.fsz;  // (cum is monotone: the lanes within form a prefix)
       const uint64_t wmask = __ballot(within);
       if (wmask != 0) {
