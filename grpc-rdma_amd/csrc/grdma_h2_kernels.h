@@ -684,7 +684,9 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
       const uint64_t wmask = __ballot(within);
       if (wmask != 0) {
         const int last_lane = 63 - __builtin_clzll(wmask);
-        const uint32_t total = __shfl(cum, last_lane, 64), nevs = __shfl(epos, last_lane, 64);
+        // (last_lane comes from a ballot, a scalar: v_readlane instead of a trip through the LDS crossbar)
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)cum, last_lane);
+        const uint32_t nevs = (uint32_t)__builtin_amdgcn_readlane((int)epos, last_lane);
         const bool ends = total == D.fsz;
         if (nev + nevs + 1 <= ev_cap) {
           if (within) {

@@ -381,6 +381,12 @@ inline int __builtin_amdgcn_readfirstlane(int v) {
     if (w->res_valid[i]) return (int)(uint32_t)w->res[i];
   return v;
 }
+inline int __builtin_amdgcn_readlane(int v, int src) {
+  emu::exchange((uint64_t)(uint32_t)v);
+  const emu::wave_ctx* w = emu::t_wave;
+  src &= 63;
+  return w->res_valid[src] ? (int)(uint32_t)w->res[src] : v;
+}
 // DPP: the controls this repository uses (row_shr:1/2/4/8, row_bcast:15, row_bcast:31, wave_shl:1, wave_rol:1)
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   emu::exchange((uint64_t)(uint32_t)src);
