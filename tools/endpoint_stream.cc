@@ -29,6 +29,28 @@ using namespace grdma_core;
 
 static std::deque<grpc_closure*> g_queue;  // a miniature ExecCtx
 
+// Sum of the bytes of a slice (the check of the delivered stream; independent of where the slices are cut).
+// Eight bytes per step: the even and the odd bytes of a word are added into four 16-bit lanes each, folded
+// every 128 steps -- the check sits inside the timed loop and should not be what is measured.
+static uint64_t sum_bytes(const uint8_t* b, size_t n) {
+  uint64_t total = 0;
+  size_t k = 0;
+  const uint64_t M = 0x00FF00FF00FF00FFull;
+  while (n - k >= 8) {
+    uint64_t acc = 0;
+    size_t steps = (n - k) / 8;
+    if (steps > 128) steps = 128;  // 128 * 2 * 255 < 65536: the 16-bit lanes cannot overflow
+    for (size_t i = 0; i < steps; i++, k += 8) {
+      uint64_t w;
+      memcpy(&w, b + k, 8);
+      acc += (w & M) + ((w >> 8) & M);
+    }
+    total += (acc & 0xFFFF) + ((acc >> 16) & 0xFFFF) + ((acc >> 32) & 0xFFFF) + (acc >> 48);
+  }
+  for (; k < n; k++) total += b[k];
+  return total;
+}
+
 struct state {
   grpc_endpoint *tx, *rx;
   grpc_slice_buffer outgoing, incoming;
@@ -65,10 +87,7 @@ static void on_read(void* p, grpc_error_handle e) {
     const grpc_slice& s = st->incoming.slices[i];
     const size_t n = GRPC_SLICE_LENGTH(s);
     if (st->check) {
-      const uint8_t* b = GRPC_SLICE_START_PTR(s);
-      uint64_t a = 0;
-      for (size_t k = 0; k < n; k++) a += b[k];
-      st->sum_read += a;
+      st->sum_read += sum_bytes(GRPC_SLICE_START_PTR(s), n);
     }
     st->bytes_read += n;
   }
@@ -118,8 +137,7 @@ int main(int argc, char** argv) {
   st.bytes_per_msg = 0;
   for (grpc_slice& s : st.frames) {
     st.bytes_per_msg += GRPC_SLICE_LENGTH(s);
-    const uint8_t* b = GRPC_SLICE_START_PTR(s);
-    for (size_t k = 0; k < GRPC_SLICE_LENGTH(s); k++) st.sum_per_msg += b[k];
+    st.sum_per_msg += sum_bytes(GRPC_SLICE_START_PTR(s), GRPC_SLICE_LENGTH(s));
   }
   st.bytes_target = st.bytes_per_msg * st.msgs_target;
   grpc_slice_buffer_init(&st.outgoing);
