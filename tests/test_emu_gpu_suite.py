@@ -58,6 +58,12 @@ def test_zero_copy_gpu_tests_under_the_emulator(emu_lib):
     run_gpu_tests(emu_lib, ["tests/test_zz_gpu_zerocopy.py"], 10)
 
 
+def test_burst_round_gpu_tests_under_the_emulator(emu_lib):
+    """Streaming jobs with several Sends per round (k_tx_plan_seq: the single-wave burst planner), eager and as a HIP
+    graph, three links in one launch: the small configurations of tests/test_gpu_link_engine.py."""
+    run_gpu_tests(emu_lib, ["tests/test_gpu_link_engine.py", "-n", "4", "-k", "burst and (r64k or r256k or three_links)"], 7)
+
+
 def test_concurrent_writer_and_poller_gpu_tests_under_the_emulator(emu_lib):
     """Records landing header-first / footer-last from a second thread while the receiver polls and reads; the
     background poller thread (one k_poll launch per pass, eventfd wakeups)."""
