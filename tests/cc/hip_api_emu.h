@@ -4,16 +4,18 @@
 // wave_emu.h this lets the PRODUCT sources (csrc/*.hip, *.cc) be compiled for the CPU into
 // oracle/_build/libgrdma_emu.so, which the Python parity tests can load instead of libgrdma_amd.so
 // (GRDMA_LIB_PATH) when no GPU is at hand -- see tests/cc/build_emu.sh and tests/test_emu_pair.py.
-// Graphs of kernel nodes run their nodes in the order they were added.  Not emulated: IPC handles, dma-buf
-// export (they report an error), resident kernels that wait for the host (a launch returns only when the
-// kernel has finished).
+// Graphs of kernel nodes run their nodes in the order they were added; the resident latency engine runs in a
+// thread of its own.  Not emulated: IPC handles, dma-buf export (they report an error).
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 
+#include <functional>
+#include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 typedef int hipError_t;
@@ -125,7 +127,7 @@ inline hipError_t hipMemcpyFromSymbol(void* d, const T& sym, size_t n, size_t of
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = reinterpret_cast<hipStream_t>(malloc(8)); return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
 inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
-inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t s);  // (defined below: waits for a resident kernel on the stream)
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(malloc(8)); return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
@@ -188,9 +190,51 @@ inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
 inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
 
 // A launch runs the whole grid under the emulator and returns when it is done.  One launch at a time: the
-// __shared__ objects of a kernel are statics.
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)              \
-  do {                                                                           \
-    std::lock_guard<std::recursive_mutex> emu_lk_(emu::launch_mutex());          \
-    emu::launch(dim3(grid), dim3(block), [=] { kernel(__VA_ARGS__); });          \
+// __shared__ objects of a kernel are statics.  The exception is a RESIDENT kernel (the latency engine k_engine,
+// which serves a mailbox until the host tells it to leave): it runs in a thread of its own, outside the launch
+// lock, and hipStreamSynchronize on its stream waits for it.
+namespace emu {
+inline bool resident_kernel(const char* name) { return strcmp(name, "k_engine") == 0; }
+struct async_table {
+  std::mutex mu;
+  std::map<hipStream_t, std::thread> running;
+};
+inline async_table& asyncs() {
+  static async_table t;
+  return t;
+}
+inline void launch_async(hipStream_t s, dim3 grid, dim3 block, std::function<void()> body) {
+  std::lock_guard<std::mutex> lk(asyncs().mu);
+  auto it = asyncs().running.find(s);
+  if (it != asyncs().running.end()) {
+    if (it->second.joinable()) it->second.join();
+    asyncs().running.erase(it);
+  }
+  asyncs().running.emplace(s, std::thread([=] { emu::launch(grid, block, body); }));
+}
+inline void stream_wait(hipStream_t s) {
+  std::thread t;
+  {
+    std::lock_guard<std::mutex> lk(asyncs().mu);
+    auto it = asyncs().running.find(s);
+    if (it == asyncs().running.end()) return;
+    t = std::move(it->second);
+    asyncs().running.erase(it);
+  }
+  if (t.joinable()) t.join();
+}
+}  // namespace emu
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                          \
+  do {                                                                                                       \
+    if (emu::resident_kernel(#kernel)) {                                                                     \
+      emu::launch_async(stream, dim3(grid), dim3(block), [=] { kernel(__VA_ARGS__); });                      \
+    } else {                                                                                                 \
+      std::lock_guard<std::recursive_mutex> emu_lk_(emu::launch_mutex());                                    \
+      emu::launch(dim3(grid), dim3(block), [=] { kernel(__VA_ARGS__); });                                    \
+    }                                                                                                        \
   } while (0)
+
+inline hipError_t hipStreamSynchronize(hipStream_t s) {
+  emu::stream_wait(s);
+  return hipSuccess;
+}

@@ -70,6 +70,12 @@ def test_concurrent_writer_and_poller_gpu_tests_under_the_emulator(emu_lib):
     run_gpu_tests(emu_lib, ["tests/test_gpu_concurrent_writer.py", "tests/test_gpu_poller.py"], 5)
 
 
+def test_latency_engine_gpu_tests_under_the_emulator(emu_lib):
+    """k_engine, the resident kernel behind bench.py's RTT leg: under emulation it runs in a thread of its own and
+    serves the mailbox like on the device."""
+    run_gpu_tests(emu_lib, ["tests/test_zz_gpu_latency_engine.py"], 3)
+
+
 def test_pair_protocol_gpu_tests_under_the_emulator(emu_lib):
     """All of tests/test_gpu_pair_parity.py: random operation sequences in the four wire / memory modes, the golden
     traces, batched polling, the multi-record drains of k_rx_plan (chain walker, one-lane-per-record replay, bulk tier
