@@ -346,27 +346,27 @@ static emu::wave_dim_proxy blockIdx(0), blockDim(1), gridDim(2);
 
 // ---- cross-lane intrinsics ----------------------------------------------------------------------------
 template <typename T>
-inline T __shfl(T v, int src, int /*width*/ = 64) {
+__attribute__((always_inline)) inline T __shfl(T v, int src, int /*width*/ = 64) {
   emu::exchange(emu::to_bits(v));
   const emu::wave_ctx* w = emu::t_wave;
   src &= 63;
   return w->res_valid[src] ? emu::from_bits<T>(w->res[src]) : v;
 }
 template <typename T>
-inline T __shfl_up(T v, unsigned d, int /*width*/ = 64) {
+__attribute__((always_inline)) inline T __shfl_up(T v, unsigned d, int /*width*/ = 64) {
   emu::exchange(emu::to_bits(v));
   const emu::wave_ctx* w = emu::t_wave;
   const int me = w->cur, src = me - (int)d;
   return (src >= 0 && w->res_valid[src]) ? emu::from_bits<T>(w->res[src]) : v;
 }
 template <typename T>
-inline T __shfl_xor(T v, int mask, int /*width*/ = 64) {
+__attribute__((always_inline)) inline T __shfl_xor(T v, int mask, int /*width*/ = 64) {
   emu::exchange(emu::to_bits(v));
   const emu::wave_ctx* w = emu::t_wave;
   const int src = (w->cur ^ mask) & 63;
   return w->res_valid[src] ? emu::from_bits<T>(w->res[src]) : v;
 }
-inline uint64_t __ballot(int pred) {
+__attribute__((always_inline)) inline uint64_t __ballot(int pred) {
   emu::exchange(pred ? 1u : 0u);
   const emu::wave_ctx* w = emu::t_wave;
   uint64_t m = 0;
@@ -374,21 +374,21 @@ inline uint64_t __ballot(int pred) {
     if (w->res_valid[i] && w->res[i]) m |= 1ull << i;
   return m;
 }
-inline int __builtin_amdgcn_readfirstlane(int v) {
+__attribute__((always_inline)) inline int __builtin_amdgcn_readfirstlane(int v) {
   emu::exchange((uint64_t)(uint32_t)v);
   const emu::wave_ctx* w = emu::t_wave;
   for (int i = 0; i < 64; i++)
     if (w->res_valid[i]) return (int)(uint32_t)w->res[i];
   return v;
 }
-inline int __builtin_amdgcn_readlane(int v, int src) {
+__attribute__((always_inline)) inline int __builtin_amdgcn_readlane(int v, int src) {
   emu::exchange((uint64_t)(uint32_t)v);
   const emu::wave_ctx* w = emu::t_wave;
   src &= 63;
   return w->res_valid[src] ? (int)(uint32_t)w->res[src] : v;
 }
 // DPP: the controls this repository uses (row_shr:1/2/4/8, row_bcast:15, row_bcast:31, wave_shl:1, wave_rol:1)
-inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+__attribute__((always_inline)) inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   emu::exchange((uint64_t)(uint32_t)src);
   const emu::wave_ctx* w = emu::t_wave;
   const int me = w->cur, row = me >> 4, bank = (me & 15) >> 2;
@@ -412,8 +412,8 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
   return (int)(uint32_t)w->res[from];
 }
 
-inline int __all(int pred) { return __ballot(!pred) == 0; }
-inline int __any(int pred) { return __ballot(pred) != 0; }
+__attribute__((always_inline)) inline int __all(int pred) { return __ballot(!pred) == 0; }
+__attribute__((always_inline)) inline int __any(int pred) { return __ballot(pred) != 0; }
 
 inline void __syncthreads() {
   emu::wave_ctx* w = emu::t_wave;
