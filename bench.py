@@ -691,6 +691,10 @@ def main():
             out["value_with_h2"] = round(wl.user_bytes * args.steps * world / hh["elapsed"] / (1 << 30), 3)
             out["with_h2_verified"] = hh["verified"]
             out["with_h2_stages"] = hh["stages"]
+            out["config"]["with_h2_leg"] = ("k_h2_frame -> the job -> k_h2_deframe inside the timed pipeline, library defaults "
+                                            "(message-boundary step on, 32 frames per bulk step, no clock samples); "
+                                            "value_with_h2_no_boundary_step: message starts byte-wise; "
+                                            "value_with_h2_bulk_pairs: 64 frames per bulk step (GRDMA_H2_BULK_PAIRS)")
         except Exception as e:
             out["with_h2_error"] = err_text(e)
         eng_ = (args.schedule == "engine")
