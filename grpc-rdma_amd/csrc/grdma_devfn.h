@@ -21,6 +21,13 @@
 #ifndef GRDMA_WAVE_CONVERGE
 #define GRDMA_WAVE_CONVERGE()
 #endif
+// Lane l of a wave loads 64-bit word l of a 512-byte block another agent writes line by line (payload words, then
+// the line's stamp in its last word).  On the GPU the lanes' loads of one 64-byte line are one request and the line
+// arrives as a unit, so a lane that sees the stamp has neighbours that see that line's payload.  (The host emulation
+// loads word by word and reads a line's stamp before its payload to keep that property.)
+#ifndef GRDMA_WAVE_LOAD_LINES
+#define GRDMA_WAVE_LOAD_LINES(base, lane) __hip_atomic_load(&(base)[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#endif
 
 
 __device__ __forceinline__ uint64_t round_up8(uint64_t v) { return (v + 7ull) & ~7ull; }

@@ -1440,7 +1440,7 @@ void k_engine(grdma_engine_mbox* mb) {
       for (;;) {
         // one poll = two loads in flight together: the eight fast-lane lines (lane l = word l)
         // and the doorbell of the pointer path
-        const uint64_t fw = __hip_atomic_load(&mb->fast[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint64_t fw = GRDMA_WAVE_LOAD_LINES(mb->fast, lane);
         seq = __hip_atomic_load(&mb->cmd_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         seq = __shfl(seq, 0, 64);
         const uint64_t stamp0 = __shfl(fw, 7, 64);

@@ -49,6 +49,7 @@
 // "every vector-memory operation of this wave is acknowledged": host stores are already there
 #define GRDMA_WAIT_VMEM() asm volatile("" ::: "memory")
 #define GRDMA_WAVE_CONVERGE() emu::exchange(0)
+#define GRDMA_WAVE_LOAD_LINES(base, lane) emu::wave_load_lines(reinterpret_cast<const uint64_t*>(base))
 
 struct dim3 {
   unsigned x, y, z;
@@ -138,6 +139,8 @@ struct wave_ctx {
   void* site = nullptr;  // call site of the operation the lanes are gathering at
   int site_lane = 0;
   bool restart = false;  // an operation completed: resume the lanes from lane 0, in ascending order
+  uint64_t lines[kWave];      // snapshot of a wave-wide block load (wave_load_lines)
+  uint64_t lines_gen = ~0ull; // the exchange generation it belongs to
   block_sync* bs = nullptr;
   const std::function<void()>* body = nullptr;
   dim3 bid, bdim, gdim;
@@ -215,6 +218,23 @@ __attribute__((noinline)) inline void exchange(uint64_t v) {
   } else {
     while (w->gen == g) yield_lane();
   }
+}
+
+// Lane l gets word l of the 64-word block at base.  The first lane to run after the wave has met takes the
+// snapshot for everyone, reading each 64-byte line's last word (its stamp) BEFORE the line's other words: a writer
+// that fills a line and stamps it last is then never seen with a new stamp over old words -- what one request per
+// line gives on the GPU.
+inline uint64_t wave_load_lines(const uint64_t* base) {
+  exchange(0);
+  wave_ctx* w = t_wave;
+  if (w->lines_gen != w->gen) {
+    for (int line = 0; line < kWave / 8; line++) {
+      w->lines[8 * line + 7] = __atomic_load_n(base + 8 * line + 7, __ATOMIC_ACQUIRE);
+      for (int k = 0; k < 7; k++) w->lines[8 * line + k] = __atomic_load_n(base + 8 * line + k, __ATOMIC_RELAXED);
+    }
+    w->lines_gen = w->gen;
+  }
+  return w->lines[w->cur];
 }
 
 // a lane left the kernel: operations the others are waiting in may now be complete
