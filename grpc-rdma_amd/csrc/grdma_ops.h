@@ -55,7 +55,10 @@ struct grdma_rx_op {
 };
 
 // Mailbox of the persistent latency engine (pinned host memory).
-enum { GRDMA_ENGINE_SEND = 1, GRDMA_ENGINE_DRAIN = 2, GRDMA_ENGINE_SEND_INLINE = 3, GRDMA_ENGINE_DRAIN_BLOCK = 4 };
+enum { GRDMA_ENGINE_SEND = 1, GRDMA_ENGINE_DRAIN = 2, GRDMA_ENGINE_SEND_INLINE = 3, GRDMA_ENGINE_DRAIN_BLOCK = 4,
+       // a small send followed, without a host hop, by the drain the LOCAL peer has armed (grdma_pair_arm_read):
+       // the block carries both ops
+       GRDMA_ENGINE_SEND_INLINE_DRAIN = 5 };
 
 // Self-contained command block for small messages: the op, its slice table and the
 // payload bytes travel in ONE contiguous pinned block that the engine pulls into LDS
@@ -75,7 +78,8 @@ struct grdma_engine_cmd {
 // command's words.  Wave 0 of the engine reads all eight lines with ONE load per poll (lane l =
 // word l), so a 64-byte RPC costs one PCIe round trip from doorbell to payload-in-LDS instead of
 // three dependent ones (doorbell -> type/op -> command block).
-// Payload: [type | nsges << 8 | data bytes << 16] [the op struct] [nsges x {offset, len}] [data].
+// Payload: [type | nsges << 8 | data bytes << 16] [the op struct] [nsges x {offset, len}] [data]
+// [the armed peer's grdma_rx_op, GRDMA_ENGINE_SEND_INLINE_DRAIN only].
 #define GRDMA_FAST_LINES 8
 #define GRDMA_FAST_WORDS (GRDMA_FAST_LINES * 7)  // payload words
 struct grdma_engine_mbox {

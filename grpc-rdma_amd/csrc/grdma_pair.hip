@@ -165,6 +165,11 @@ struct grdma_pair {
   uint32_t zc_tail = 0;              // zerocopy_buffer_tail_ (std::atomic_uint32_t)
   uint64_t zc_bytes = 0, zc_copy_bytes = 0, zc_last_sges = 0;
   std::mutex zc_mu;
+  // armed read (grdma_pair_arm_read): the LOCAL peer's small sends carry this pair's drain in the same
+  // engine command; the next grdma_endpoint_read picks the completion up instead of asking for one
+  uint64_t armed_reads = 0;          // max_reads of the armed drain, 0 = not armed
+  bool armed_done = false;           // a chained drain has completed and nobody has consumed it yet
+  uint64_t armed_hits = 0;
   // endpoint_write context
   std::vector<grdma_slice> w_slices;
   uint64_t w_idx = 0, w_byte = 0;
@@ -255,11 +260,12 @@ int engine_launch() {
 // Pack a small command for the mailbox's fast lane (see grdma_engine_mbox); 0 = does not fit.
 size_t pack_fast(uint64_t type, const grdma_engine_cmd* blk, uint64_t* words) {
   size_t nsges = 0, dbytes = 0, nw = 1;
-  if (type == GRDMA_ENGINE_SEND_INLINE) {
+  if (type == GRDMA_ENGINE_SEND_INLINE || type == GRDMA_ENGINE_SEND_INLINE_DRAIN) {
+    const size_t rxw = type == GRDMA_ENGINE_SEND_INLINE_DRAIN ? sizeof(grdma_rx_op) / 8 : 0;
     nsges = (size_t)blk->tx.nslices;
     if (nsges > GRDMA_CMD_MAX_SGES) return 0;
     for (size_t i = 0; i < nsges; i++) dbytes += (size_t)blk->sges[i].len;
-    const size_t total = 1 + sizeof(grdma_tx_op) / 8 + 2 * nsges + (dbytes + 7) / 8;
+    const size_t total = 1 + sizeof(grdma_tx_op) / 8 + 2 * nsges + (dbytes + 7) / 8 + rxw;
     if (total > GRDMA_FAST_WORDS || dbytes > GRDMA_CMD_INLINE_BYTES) return 0;
     memcpy(words + nw, &blk->tx, sizeof(grdma_tx_op));
     nw += sizeof(grdma_tx_op) / 8;
@@ -271,6 +277,10 @@ size_t pack_fast(uint64_t type, const grdma_engine_cmd* blk, uint64_t* words) {
       words[nw + (dbytes - 1) / 8] = 0;
       memcpy(words + nw, blk->inline_data, dbytes);
       nw += (dbytes + 7) / 8;
+    }
+    if (rxw) {
+      memcpy(words + nw, &blk->rx, sizeof(grdma_rx_op));
+      nw += rxw;
     }
   } else if (type == GRDMA_ENGINE_DRAIN_BLOCK) {
     memcpy(words + nw, &blk->rx, sizeof(grdma_rx_op));
@@ -289,7 +299,8 @@ int engine_submit(uint64_t type, const void* op) {
   std::lock_guard<std::mutex> lk(e.mu);
   if (int rc = engine_launch()) return rc;
   uint64_t words[GRDMA_FAST_WORDS];
-  const size_t nw = (type == GRDMA_ENGINE_SEND_INLINE || type == GRDMA_ENGINE_DRAIN_BLOCK)
+  const size_t nw = (type == GRDMA_ENGINE_SEND_INLINE || type == GRDMA_ENGINE_DRAIN_BLOCK ||
+                     type == GRDMA_ENGINE_SEND_INLINE_DRAIN)
                         ? pack_fast(type, static_cast<const grdma_engine_cmd*>(op), words) : 0;
   const uint64_t seq = ++e.seq;
   if (nw) {
@@ -356,6 +367,8 @@ int wait_seq(grdma_pair* p, volatile uint64_t* seq, uint64_t old) {
   return *seq != old ? 0 : fail(GRDMA_ERR_HIP, "plan kernel did not complete");
 }
 
+void fill_rxop(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_reads, uint64_t raw_cap);
+
 int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_cursor) {
   grdma_profiler profiler(GRDMA_STATS_TIME_PAIR_SEND);  // pair.cc:647
   grdma_hostblk* h = p->h;
@@ -374,6 +387,17 @@ int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_curs
     if (g_engine.wanted && p->h_cmd && p->cmd_inline) {
       // the slice table and payload were staged into the command block (stage_slices)
       p->h_cmd->tx = h->txop;
+      grdma_pair* q = p->peer;
+      if (q && !p->remote && q->armed_reads && !q->armed_done && q->latency && q->h_arena) {
+        // the peer has a read armed: its drain rides in this command (the engine runs it right after
+        // the send, in the same workgroup), and its completion waits in the peer's result block
+        fill_rxop(q, q->h_arena, q->h_arena_cap, q->armed_reads, 0);
+        p->h_cmd->rx = q->h->rxop;
+        if (int rc = engine_submit(GRDMA_ENGINE_SEND_INLINE_DRAIN, p->h_cmd)) return rc;
+        q->armed_done = true;
+        q->armed_hits++;
+        return 0;
+      }
       return engine_submit(GRDMA_ENGINE_SEND_INLINE, p->h_cmd);
     }
     if (g_engine.wanted) return engine_submit(GRDMA_ENGINE_SEND, &h->txop);
@@ -393,18 +417,7 @@ int run_recv(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_rea
              uint64_t raw_cap) {
   grdma_profiler profiler(GRDMA_STATS_TIME_PAIR_RECV);  // pair.cc:265
   grdma_hostblk* h = p->h;
-  h->rxop.conn = p->d_conn;
-  h->rxop.plan = p->d_rxplan;
-  h->rxop.result = &h->rxres;
-  h->rxop.slices = p->h_slices;
-  h->rxop.arena = arena;
-  h->rxop.arena_cap = arena_cap;
-  h->rxop.max_reads = max_reads;
-  h->rxop.raw_cap = raw_cap;
-  h->rxop.append = 0;
-  h->rxop.slices_cap = GRDMA_MAX_SLICES;
-  h->rxop.inline_apply = p->latency ? 1 : 0;
-  h->rxop.seq_next = p->latency ? h->rxres.seq + 1 : 0;
+  fill_rxop(p, arena, arena_cap, max_reads, raw_cap);
   const uint32_t blocks = copy_blocks_for(p->ring_size);
   if (p->latency) {
     if (g_engine.wanted && p->h_cmd) {
@@ -420,6 +433,22 @@ int run_recv(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_rea
   HIP_TRY(grdma_launch_rx_apply(&h->rxop, 1, blocks, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return 0;
+}
+
+void fill_rxop(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_reads, uint64_t raw_cap) {
+  grdma_hostblk* h = p->h;
+  h->rxop.conn = p->d_conn;
+  h->rxop.plan = p->d_rxplan;
+  h->rxop.result = &h->rxres;
+  h->rxop.slices = p->h_slices;
+  h->rxop.arena = arena;
+  h->rxop.arena_cap = arena_cap;
+  h->rxop.max_reads = max_reads;
+  h->rxop.raw_cap = raw_cap;
+  h->rxop.append = 0;
+  h->rxop.slices_cap = GRDMA_MAX_SLICES;
+  h->rxop.inline_apply = p->latency ? 1 : 0;
+  h->rxop.seq_next = p->latency ? h->rxres.seq + 1 : 0;
 }
 
 }  // namespace
@@ -1206,9 +1235,28 @@ int grdma_pair_set_latency_mode(grdma_pair* p, int on) {
     HIP_TRY(hipHostMalloc((void**)&p->h_arena, p->h_arena_cap, hipHostMallocCoherent | hipHostMallocMapped));
   }
   HIP_TRY(hipStreamSynchronize(p->stream));
+  if (!on && p->armed_done) return fail(GRDMA_ERR_INVALID, "an armed read has completed and was not consumed");
+  if (!on) p->armed_reads = 0;
   p->latency = on != 0;
   return 0;
 }
+
+// Armed read.  gRPC keeps an endpoint_read outstanding on every connection (the transport re-arms it
+// from read_action_locked, chttp2_transport.cc:2508-2596), and the reference's busy-polling thread
+// completes it the moment a record lands.  Here, when both ends of a link live in this process and
+// run through the latency engine, a small send from the peer carries this pair's drain in the same
+// engine command, so the completion costs no doorbell round trip of its own; the next
+// grdma_endpoint_read (max_reads >= the armed value) returns it.  Bytes, order and connection state
+// are those of the two separate commands.  max_reads = 0 disarms.  Single-threaded use per link.
+int grdma_pair_arm_read(grdma_pair* p, uint64_t max_reads) {
+  if (int rc = require_ctx()) return rc;
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (max_reads && !p->latency) return fail(GRDMA_ERR_INVALID, "armed reads need latency mode");
+  if (max_reads > GRDMA_MAX_SLICES) max_reads = GRDMA_MAX_SLICES;
+  p->armed_reads = max_reads;
+  return 0;
+}
+int64_t grdma_pair_armed_hits(const grdma_pair* p) { return p ? (int64_t)p->armed_hits : -1; }
 
 // Unary ping-pong over a connected loop-back link, host in the loop exactly
 // where gRPC's consumer is: a = client end, b = server end.  Per iteration:
@@ -1332,7 +1380,15 @@ int64_t grdma_endpoint_read(grdma_pair* p, uint64_t max_reads, grdma_read_slice*
   if (max_reads == 0) return 0;
   uint8_t* arena = p->latency ? p->h_arena : p->d_arena;
   const uint64_t acap = p->latency ? p->h_arena_cap : p->arena_cap;
-  if (int rc = run_recv(p, arena, acap, max_reads, 0)) return rc;
+  if (p->armed_done && p->latency) {
+    // the drain already ran behind the peer's send (grdma_pair_arm_read)
+    p->armed_done = false;
+    if (p->h->rxres.nslices > max_reads)
+      return fail(GRDMA_ERR_INVALID, "the armed read delivered %llu slices, this call takes %llu",
+                  (unsigned long long)p->h->rxres.nslices, (unsigned long long)max_reads);
+  } else if (int rc = run_recv(p, arena, acap, max_reads, 0)) {
+    return rc;
+  }
   const grdma_rx_result& r = p->h->rxres;
   for (uint64_t i = 0; i < r.nslices; i++) {
     slices[i].off = p->h_slices[i].off;

@@ -1448,8 +1448,8 @@ void k_engine(grdma_engine_mbox* mb) {
           // a fast command: every line it spans must carry its stamp
           const uint64_t hdr = __shfl(fw, 0, 64);
           const uint64_t ftype = hdr & 0xFF, nsg = (hdr >> 8) & 0xFF, db = (hdr >> 16) & 0xFFFF;
-          const uint64_t nw = 1 + (ftype == GRDMA_ENGINE_SEND_INLINE ? sizeof(grdma_tx_op) / 8 : sizeof(grdma_rx_op) / 8) +
-                              2 * nsg + (db + 7) / 8;
+          const uint64_t nw = 1 + (ftype == GRDMA_ENGINE_DRAIN_BLOCK ? 0 : sizeof(grdma_tx_op) / 8) +
+                              (ftype == GRDMA_ENGINE_SEND_INLINE ? 0 : sizeof(grdma_rx_op) / 8) + 2 * nsg + (db + 7) / 8;
           const uint64_t lines = (nw + 6) / 7;
           const bool mine_ok = (lane & 7) != 7 || (uint64_t)(lane >> 3) >= lines || fw == stamp0;
           if (nw <= GRDMA_FAST_WORDS && __all(mine_ok)) {
@@ -1499,14 +1499,15 @@ void k_engine(grdma_engine_mbox* mb) {
       tx_plan_call(reinterpret_cast<const grdma_tx_op*>(opp));
     } else if (type == GRDMA_ENGINE_DRAIN) {
       rx_plan_call(reinterpret_cast<const grdma_rx_op*>(opp));
-    } else if (type == GRDMA_ENGINE_SEND_INLINE || type == GRDMA_ENGINE_DRAIN_BLOCK) {
+    } else if (type == GRDMA_ENGINE_SEND_INLINE || type == GRDMA_ENGINE_DRAIN_BLOCK ||
+               type == GRDMA_ENGINE_SEND_INLINE_DRAIN) {
       // one wide read of the whole command block into LDS, then everything the body
       // touches (op, slice table, payload) is local
       if (opp == 1) {
         // fast lane: the words are in LDS already (the barrier after the doorbell published them)
         const uint64_t hdr = s_fast[0];
         const unsigned nsg = (unsigned)((hdr >> 8) & 0xFF), dw = (unsigned)((((hdr >> 16) & 0xFFFF) + 7) / 8);
-        const bool is_tx = type == GRDMA_ENGINE_SEND_INLINE;
+        const bool is_tx = type != GRDMA_ENGINE_DRAIN_BLOCK;
         const unsigned opw = is_tx ? sizeof(grdma_tx_op) / 8 : sizeof(grdma_rx_op) / 8;
         uint64_t* dop = is_tx ? reinterpret_cast<uint64_t*>(&s_blk.tx) : reinterpret_cast<uint64_t*>(&s_blk.rx);
         if (threadIdx.x < opw) dop[threadIdx.x] = s_fast[1 + threadIdx.x];
@@ -1514,6 +1515,8 @@ void k_engine(grdma_engine_mbox* mb) {
           if (threadIdx.x < 2 * nsg) reinterpret_cast<uint64_t*>(s_blk.sges)[threadIdx.x] = s_fast[1 + opw + threadIdx.x];
           if (threadIdx.x < dw)
             reinterpret_cast<uint64_t*>(s_blk.inline_data)[threadIdx.x] = s_fast[1 + opw + 2 * nsg + threadIdx.x];
+          if (type == GRDMA_ENGINE_SEND_INLINE_DRAIN && threadIdx.x < sizeof(grdma_rx_op) / 8)
+            reinterpret_cast<uint64_t*>(&s_blk.rx)[threadIdx.x] = s_fast[1 + opw + 2 * nsg + dw + threadIdx.x];
         }
       } else {
         const u32x4* src = reinterpret_cast<const u32x4*>(opp);
@@ -1523,15 +1526,17 @@ void k_engine(grdma_engine_mbox* mb) {
       }
       __syncthreads();
       te1 = __builtin_amdgcn_s_memtime();
-      if (type == GRDMA_ENGINE_SEND_INLINE) {
+      if (type != GRDMA_ENGINE_DRAIN_BLOCK) {
         if (threadIdx.x < GRDMA_CMD_MAX_SGES)
           s_blk.sges[threadIdx.x].ptr = s_blk.inline_data + (uint64_t)s_blk.sges[threadIdx.x].ptr;
         if (threadIdx.x == 0) s_blk.tx.slices = s_blk.sges;
         __syncthreads();
         tx_plan_call(&s_blk.tx);
-      } else {
-        rx_plan_call(&s_blk.rx);
+        __syncthreads();
       }
+      // (the armed drain of the local peer follows the send in the same command: what the host would
+      // have asked for next, minus its doorbell round trip)
+      if (type != GRDMA_ENGINE_SEND_INLINE) rx_plan_call(&s_blk.rx);
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -192,6 +192,16 @@ class Pair:
         self.lib.grdma_pair_set_latency_mode.argtypes = [C.c_void_p, C.c_int]
         check(self.lib.grdma_pair_set_latency_mode(self.h, int(on)))
 
+    def arm_read(self, max_reads=64):
+        """grdma_pair_arm_read: the local peer's small sends carry this pair's drain (0 disarms)."""
+        self.lib.grdma_pair_arm_read.argtypes = [C.c_void_p, C.c_uint64]
+        check(self.lib.grdma_pair_arm_read(self.h, int(max_reads)))
+
+    def armed_hits(self):
+        self.lib.grdma_pair_armed_hits.argtypes = [C.c_void_p]
+        self.lib.grdma_pair_armed_hits.restype = C.c_int64
+        return int(self.lib.grdma_pair_armed_hits(self.h))
+
     # -- observability -------------------------------------------------------------
     def state(self):
         st = PairState()

@@ -261,6 +261,14 @@ int grdma_pair_arena_copy_out(grdma_pair* p, uint64_t off, void* host_dst, uint6
  * memory instead of a stream synchronize, and delivered slices are written
  * straight into a pinned host arena. */
 int grdma_pair_set_latency_mode(grdma_pair* p, int on);
+/* Armed read: what an outstanding grpc_endpoint_read is to the reference's busy-polling thread
+ * (rdma_bp_posix.cc:345-372 arms it, the poller completes it when a record lands).  With both ends of
+ * a link in this process and on the latency engine, the peer's small sends carry this pair's drain in
+ * the same engine command; the next grdma_endpoint_read (max_reads >= the armed value) returns that
+ * completion without a command of its own.  Same bytes, order and state as the two separate calls.
+ * max_reads = 0 disarms.  One thread per link. */
+int grdma_pair_arm_read(grdma_pair* p, uint64_t max_reads);
+int64_t grdma_pair_armed_hits(const grdma_pair* p);   /* sends that carried the peer's drain */
 /* Persistent latency engine: one resident workgroup takes the fused Send / drain
  * commands of latency-mode pairs from a mailbox in pinned host memory (a PCIe
  * doorbell read instead of a kernel launch per call).  It retires by itself after
