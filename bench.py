@@ -274,30 +274,12 @@ def measure_rtt(g, iters=100000, warmup=2000):
             lib.grdma_stats_time_shutdown()
         except Exception as e:  # the breakdown is an extra: never lose the round-trip numbers over it
             prof = {"error": str(e)[:160]}
-        # last (new code runs after the numbers above are safe): both ends keep a read armed, the way
-        # gRPC's transport does, so the drain rides in the peer's send command (grdma_pair_arm_read)
-        armed = {}
-        try:
-            a.arm_read(64)
-            b.arm_read(64)
-            n2 = max(1000, iters // 5)
-            r2, ph2 = g.pingpong(a, b, slices, slices, iters=n2, warmup=min(warmup, 200))
-            r2.sort()
-            armed = {"rtt_armed_read_p50_us": round(r2[n2 // 2] / 1e3, 2),
-                     "rtt_armed_read_p99_us": round(r2[int(n2 * .99)] / 1e3, 2),
-                     "rtt_armed_read_iters": n2, "rtt_armed_read_hits": a.armed_hits() + b.armed_hits(),
-                     "rtt_armed_read_breakdown_us": {k: round(v / n2 / 1e3, 2) for k, v in zip(
-                         ["client_write+server_drain", "server_read", "server_write+client_drain", "client_read"], ph2)}}
-            a.arm_read(0)
-            b.arm_read(0)
-        except Exception as e:
-            armed = {"rtt_armed_read_error": err_text(e)}
     finally:
         lib.grdma_engine_stop()
     a.close()
     b.close()
     rtt.sort()
-    return {**armed, "rtt_p50_us": round(rtt[iters // 2] / 1e3, 2), "rtt_p95_us": round(rtt[int(iters * .95)] / 1e3, 2),
+    return {"rtt_p50_us": round(rtt[iters // 2] / 1e3, 2), "rtt_p95_us": round(rtt[int(iters * .95)] / 1e3, 2),
             "rtt_p99_us": round(rtt[int(iters * .99)] / 1e3, 2),
             "rtt_iters": iters, "rtt_seconds": round(wall, 2),
             "rtt_config": "unary ping-pong 64 B, 1 connection, 4 MiB ring in HBM, slices [14 B][66 B] "
@@ -305,6 +287,57 @@ def measure_rtt(g, iters=100000, warmup=2000):
             "rtt_breakdown_us": {k: round(v / iters / 1e3, 2) for k, v in zip(
                 ["client_write", "server_read", "server_write", "client_read"], ph)},
             "rtt_profile_us": prof}
+
+
+def measure_rtt_armed(g, iters=20000, warmup=200):
+    """The same ping-pong with a read armed on both ends, the way gRPC's transport keeps one outstanding: the drain
+    rides in the peer's send command (grdma_pair_arm_read, GRDMA_ENGINE_SEND_INLINE_DRAIN), a round trip is 2 engine
+    commands instead of 4.  Runs in a process of its own (armed_rtt_subprocess)."""
+    from grpc_rdma_amd import h2
+    lib = g.load()
+    msg = bytes([0x0A, 64]) + bytes(range(64))
+    items = h2.frame_message(len(msg), 1)
+    slices = [i[1] if i[0] == "inl" else msg[i[1][0]:i[1][0] + i[1][1]] for i in items]
+    a, b = g.Pair(4 << 20, 30), g.Pair(4 << 20, 30)
+    g.connect_pairs(a, b)
+    a.set_latency_mode(True)
+    b.set_latency_mode(True)
+    a.arm_read(64)
+    b.arm_read(64)
+    g._lib.check(lib.grdma_engine_start())
+    try:
+        r2, ph2 = g.pingpong(a, b, slices, slices, iters=iters, warmup=warmup)
+        hits = a.armed_hits() + b.armed_hits()
+        a.arm_read(0)
+        b.arm_read(0)
+    finally:
+        lib.grdma_engine_stop()
+    a.close()
+    b.close()
+    r2.sort()
+    return {"rtt_armed_read_p50_us": round(r2[iters // 2] / 1e3, 2),
+            "rtt_armed_read_p95_us": round(r2[int(iters * .95)] / 1e3, 2),
+            "rtt_armed_read_p99_us": round(r2[int(iters * .99)] / 1e3, 2),
+            "rtt_armed_read_iters": iters, "rtt_armed_read_hits": hits,
+            "rtt_armed_read_breakdown_us": {k: round(v / iters / 1e3, 2) for k, v in zip(
+                ["client_write+server_drain", "server_read", "server_write+client_drain", "client_read"], ph2)}}
+
+
+def armed_rtt_subprocess(iters, timeout_s=150):
+    """New engine command, first hardware run: isolate it.  A resident kernel that wedged would hang every later
+    synchronize of THIS process, so the leg runs in a child that can be killed; the line above it stays safe."""
+    import subprocess
+    try:
+        cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--armed-rtt-only", "--rtt-iters", str(iters)],
+                            capture_output=True, text=True, timeout=timeout_s, stdin=subprocess.DEVNULL)
+        for line in reversed(cp.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"rtt_armed_read_error": ("exit %d: " % cp.returncode) + (cp.stderr or cp.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"rtt_armed_read_error": "timed out after %d s (child killed)" % timeout_s}
+    except Exception as e:
+        return {"rtt_armed_read_error": err_text(e)}
 
 
 def fanout_leg(g, gs, grp, torch, args, flags, n_msgs=128):
@@ -381,6 +414,7 @@ def main():
                          "the persistent link engine (k_link); the other one is reported as a comparison leg")
     ap.add_argument("--no-tcp-baseline", action="store_true", help="skip the loop-back TCP baselines")
     ap.add_argument("--rtt-iters", type=int, default=100000)
+    ap.add_argument("--armed-rtt-only", action="store_true", help="(internal) run only the armed-read ping-pong")
     args = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         # Multi-GPU runs measure the headline (and the fan-out leg) only: the comparison legs are
@@ -389,6 +423,13 @@ def main():
         args.no_extra_legs = True
         args.no_small_ring = True
         args.conns = 1
+
+    if args.armed_rtt_only:  # the child of armed_rtt_subprocess: no torch, one leg, one JSON line
+        import __graft_entry__ as ge
+        import grpc_rdma_amd as g
+        g.init(int(os.environ.get("LOCAL_RANK", "0")))
+        print(json.dumps(measure_rtt_armed(g, iters=args.rtt_iters, warmup=min(200, max(10, args.rtt_iters // 10)))))
+        return
 
     import torch
     from_env = (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
@@ -678,6 +719,8 @@ def main():
             out.update(measure_rtt(g, iters=args.rtt_iters, warmup=min(2000, max(10, args.rtt_iters // 10))))
         except Exception as e:  # never lose the throughput line to the latency leg
             out["rtt_error"] = str(e)
+        if rank == 0 and world == 1:
+            out.update(armed_rtt_subprocess(max(1000, args.rtt_iters // 5)))
     if seq is not None:  # same workload and ring, five kernels per round strictly in order
         out["value_sequential"] = round(
             wl.user_bytes * max(2, args.steps // 2) * world / seq["elapsed"] / (1 << 30), 3)

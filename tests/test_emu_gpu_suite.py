@@ -73,7 +73,7 @@ def test_concurrent_writer_and_poller_gpu_tests_under_the_emulator(emu_lib):
 def test_latency_engine_gpu_tests_under_the_emulator(emu_lib):
     """k_engine, the resident kernel behind bench.py's RTT leg: under emulation it runs in a thread of its own and
     serves the mailbox like on the device."""
-    run_gpu_tests(emu_lib, ["tests/test_zz_gpu_latency_engine.py"], 6)
+    run_gpu_tests(emu_lib, ["tests/test_zz_gpu_latency_engine.py", "tests/test_zzz_gpu_armed_read.py"], 6)
 
 
 def test_pair_protocol_gpu_tests_under_the_emulator(emu_lib):

@@ -13,7 +13,7 @@ rm -rf $out; mkdir -p $out
 cd $R
 timeout 40 ./tests/cc/gpu_quickcheck $out/quickcheck.txt 30
 echo "quickcheck rc=$?"
-timeout 200 python -m pytest tests/test_zz_gpu_zerocopy.py tests/test_zz_gpu_h2_boundary.py -m gpu -q -x > $out/pytest_new.log 2>&1 < /dev/null
+timeout 200 python -m pytest tests/test_zz_gpu_zerocopy.py tests/test_zz_gpu_h2_boundary.py tests/test_zz_gpu_latency_engine.py tests/test_zzz_gpu_armed_read.py -m gpu -q -x > $out/pytest_new.log 2>&1 < /dev/null
 echo "new tests rc=$?"; tail -3 $out/pytest_new.log
 timeout 150 python bench.py --no-rtt > $out/bench.log 2> $out/bench.err < /dev/null
 echo "bench rc=$?"
