@@ -1382,10 +1382,10 @@ int64_t grdma_endpoint_read(grdma_pair* p, uint64_t max_reads, grdma_read_slice*
   const uint64_t acap = p->latency ? p->h_arena_cap : p->arena_cap;
   if (p->armed_done && p->latency) {
     // the drain already ran behind the peer's send (grdma_pair_arm_read)
-    p->armed_done = false;
-    if (p->h->rxres.nslices > max_reads)
+    if (p->h->rxres.nslices > max_reads)   // (the completion stays: a call with room for it still gets it)
       return fail(GRDMA_ERR_INVALID, "the armed read delivered %llu slices, this call takes %llu",
                   (unsigned long long)p->h->rxres.nslices, (unsigned long long)max_reads);
+    p->armed_done = false;
   } else if (int rc = run_recv(p, arena, acap, max_reads, 0)) {
     return rc;
   }
