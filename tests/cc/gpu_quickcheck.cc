@@ -16,6 +16,7 @@
 #include <signal.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -346,6 +347,94 @@ static void check_zerocopy() {
   SAY("zerocopy sequences vs oracle: %d / %d %s\n", pass, total, pass == total ? "PASS" : "FAIL");
 }
 
+// ---- armed read through the latency engine against the oracle ---------------------------------------
+// unary ping-pong, [14 B][66 B] each way; armed = the drain rides in the peer's send command
+// (GRDMA_ENGINE_SEND_INLINE_DRAIN).  State and rings must equal the oracle's after the same traffic, and
+// equal the un-armed run's; prints both p50s.
+static bool pingpong_run(bool armed, uint64_t iters, uint64_t* p50_ns, grdma_pair_state st[2], bytes rings[2],
+                         int64_t* hits) {
+  const uint64_t R = 4u << 20;
+  grdma_pair* a = grdma_pair_create(R, 30, 0);
+  grdma_pair* b = grdma_pair_create(R, 30, 0);
+  if (!a || !b || grdma_pair_connect(a, b) != 0 || grdma_pair_set_latency_mode(a, 1) != 0 ||
+      grdma_pair_set_latency_mode(b, 1) != 0)
+    return false;
+  if (armed && (grdma_pair_arm_read(a, 64) != 0 || grdma_pair_arm_read(b, 64) != 0)) return false;
+  uint8_t m0[14], m1[66];
+  for (int i = 0; i < 14; i++) m0[i] = (uint8_t)(i * 7 + 1);
+  for (int i = 0; i < 66; i++) m1[i] = (uint8_t)(i * 5 + 3);
+  const grdma_slice sl[2] = {{m0, 14}, {m1, 66}};
+  std::vector<uint64_t> rtt(iters);
+  uint64_t ph[4];
+  bool ok = grdma_engine_start() == 0 &&
+            grdma_pingpong(a, b, sl, 2, sl, 2, GRDMA_MEM_HOST, iters, 20, rtt.data(), ph) == 0;
+  if (ok && armed) {
+    *hits = grdma_pair_armed_hits(a) + grdma_pair_armed_hits(b);
+    ok = grdma_pair_arm_read(a, 0) == 0 && grdma_pair_arm_read(b, 0) == 0;
+  }
+  grdma_engine_stop();
+  if (ok) {
+    std::sort(rtt.begin(), rtt.end());
+    *p50_ns = rtt[iters / 2];
+    grdma_pair* pp[2] = {a, b};
+    for (int k = 0; k < 2 && ok; k++) {
+      rings[k].resize(R);
+      ok = grdma_pair_peek_ring(pp[k], 0, rings[k].data(), R) == 0 && grdma_pair_state_get(pp[k], &st[k]) == 0;
+    }
+  }
+  grdma_pair_destroy(a);
+  grdma_pair_destroy(b);
+  return ok;
+}
+
+static void check_armed_read() {
+  const uint64_t iters = 300, R = 4u << 20;
+  uint64_t p50[2] = {0, 0};
+  grdma_pair_state st[2][2];
+  bytes rings[2][2];
+  int64_t hits = 0;
+  for (int armed = 0; armed < 2; armed++)
+    if (!pingpong_run(armed != 0, iters, &p50[armed], st[armed], rings[armed], &hits)) {
+      g_fail++;
+      SAY("armed read FAIL: %s run: %s\n", armed ? "armed" : "plain", grdma_last_error());
+      return;
+    }
+  // the oracle through the same traffic
+  orc_pair o[2];
+  if (orc_pair_init(&o[0], R, 30) || orc_pair_init(&o[1], R, 30)) { g_fail++; SAY("armed read FAIL: oracle setup\n"); return; }
+  orc_pair_connect(&o[0], &o[1]);
+  uint8_t m0[14], m1[66];
+  for (int i = 0; i < 14; i++) m0[i] = (uint8_t)(i * 7 + 1);
+  for (int i = 0; i < 66; i++) m1[i] = (uint8_t)(i * 5 + 3);
+  const orc_slice os[2] = {{m0, 14}, {m1, 66}};
+  bytes buf(4096);
+  bool ok = true;
+  for (uint64_t it = 0; it < iters + 20 && ok; it++)
+    for (int dir = 0; dir < 2 && ok; dir++) {
+      ok = orc_pair_send(&o[dir], os, 2, 0) == 80;
+      uint64_t alloc = 0;
+      while (orc_endpoint_read(&o[1 - dir], buf.data(), &alloc) != 0) {}
+    }
+  for (int armed = 0; armed < 2 && ok; armed++)
+    for (int k = 0; k < 2 && ok; k++) {
+      const grdma_pair_state& s = st[armed][k];
+      const bytes oring(o[k].ring.buf, o[k].ring.buf + R);
+      if (!ring_eq(rings[armed][k], oring)) { ok = false; SAY("armed read FAIL: ring image, armed %d side %d\n", armed, k); }
+      if (s.remote_tail != o[k].remote_tail || s.head != o[k].ring.head || s.moving_head != o[k].ring.moving_head ||
+          s.remain != o[k].ring.remain || s.internal_read_size != o[k].internal_read_size ||
+          s.credit_msgs != o[k].credit_msgs || s.remote_head != o[k].status_recv.remote_head) {
+        ok = false;
+        SAY("armed read FAIL: state, armed %d side %d\n", armed, k);
+      }
+    }
+  if (ok && hits != (int64_t)(2 * (iters + 20))) { ok = false; SAY("armed read FAIL: %lld chained sends\n", (long long)hits); }
+  orc_pair_destroy(&o[0]);
+  orc_pair_destroy(&o[1]);
+  if (!ok) g_fail++;
+  SAY("armed read vs oracle (unary 64 B, %llu round trips): %s; RTT p50 plain %.2f us, armed %.2f us\n",
+      (unsigned long long)iters, ok ? "PASS" : "FAIL", p50[0] / 1e3, p50[1] / 1e3);
+}
+
 int main(int argc, char** argv) {
   signal(SIGALRM, on_alarm);
   alarm(argc > 2 ? atoi(argv[2]) : 20);
@@ -381,6 +470,7 @@ int main(int argc, char** argv) {
     check_h2("mixed sizes, cut slices, odd", cut, true, 1);
   }
   check_zerocopy();
+  check_armed_read();  // last: a resident kernel; the alarm ends the run if it ever wedged
   SAY("gpu_quickcheck: %s\n", g_fail ? "FAILED" : "ALL PASS");
   if (g_out) fclose(g_out);
   return g_fail ? 1 : 0;

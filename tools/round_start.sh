@@ -1,7 +1,8 @@
 #!/bin/bash
 # First GPU trip of a round: the paths written after the previous round's GPU budget ran out.
 #   1. tests/cc/gpu_quickcheck        (seconds) boundary step / bulk pairs vs the verified deframer,
-#                                      zero-copy send vs the oracle, with the deframer's tick counters
+#                                      zero-copy send vs the oracle, with the deframer's tick counters; the armed read
+#                                      through the latency engine vs the oracle (prints plain / armed RTT p50)
 #   2. the newest GPU tests           tests/test_zz_gpu_zerocopy.py, tests/test_zz_gpu_h2_boundary.py (so far run
 #                                      against the emulated library only)
 #   3. bench.py --no-rtt              value_with_h2 with and without the boundary step, and the same
