@@ -815,6 +815,13 @@ def main():
         ev = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "256", str(MIB), "1"], 120, env)
         out["value_endpoint_vtable"] = ev.get("GiBps")
         out["endpoint_vtable"] = ev
+        # the same stream with both pairs in latency mode: commands through the resident engine, the receive arena in
+        # pinned host memory (no launch chain and no device-to-host copy per call); first hardware run of this
+        # combination, in the helper process like the leg above
+        evl = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "256", str(MIB), "1", "1"], 120, env)
+        out["value_endpoint_vtable_latency_mode"] = evl.get("GiBps")
+        if evl.get("GiBps") is None:
+            out["endpoint_vtable_latency_mode"] = evl
     if small is not None:
         sm_steps = max(2, args.steps // 2)
         out["value_ring4096"] = round(wl.user_bytes * sm_steps * world / small["elapsed"] / (1 << 30), 3)

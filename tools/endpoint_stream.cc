@@ -6,7 +6,9 @@
 // from its callback.  Host slices in, host slices out: this is the PCIe-inclusive rate of the
 // boundary, reported next to the device-resident figure of bench.py (never instead of it).
 //
-// usage: endpoint_stream <n_msgs> <payload_bytes> [check 0|1]     prints one JSON line
+// usage: endpoint_stream <n_msgs> <payload_bytes> [check 0|1] [latency 0|1]     prints one JSON line
+//        latency 1: both pairs in latency mode, commands through the resident engine (no kernel launch per
+//        write / read, the receive arena in pinned host memory: no device-to-host copy per pass)
 // env:   GRPC_RDMA_RING_BUFFER_SIZE_KB, GRPC_RDMA_MAX_SGE ... as the reference reads them
 #include <chrono>
 #include <cstdio>
@@ -108,6 +110,12 @@ int main(int argc, char** argv) {
   st.tx = grpc_endpoint_create(3, "ipv4:127.0.0.1:1", false);
   st.rx = grpc_endpoint_create(4, "ipv4:127.0.0.1:2", true);
   CHECK(st.tx && st.rx && grpc_rdma_bp_connect_loopback(st.tx, st.rx));
+  const bool latency = argc > 4 && atoi(argv[4]) != 0;
+  if (latency) {
+    CHECK(grdma_pair_set_latency_mode(grdma_endpoint_pair(st.tx), 1) == 0);
+    CHECK(grdma_pair_set_latency_mode(grdma_endpoint_pair(st.rx), 1) == 0);
+    CHECK(grdma_engine_start() == 0);
+  }
 
   // one serialized message: [5-byte gRPC header][0x0a varint(len)][payload], cut into DATA frames
   std::vector<uint8_t> msg;
@@ -166,9 +174,11 @@ int main(int argc, char** argv) {
   CHECK(!st.failed && st.bytes_read == st.bytes_target);
   if (st.check) CHECK(st.sum_read == st.sum_per_msg * st.msgs_target);
   printf("{\"msgs\": %zu, \"payload\": %zu, \"slices_per_write\": %zu, \"endpoint_bytes\": %zu, \"seconds\": %.6f, "
-         "\"GiBps\": %.4f, \"checked\": %s}\n",
+         "\"GiBps\": %.4f, \"checked\": %s, \"latency_mode\": %s}\n",
          st.msgs_target, payload, st.frames.size(), st.bytes_target, sec,
-         (double)(payload * st.msgs_target) / sec / (double)(1ull << 30), st.check ? "true" : "false");
+         (double)(payload * st.msgs_target) / sec / (double)(1ull << 30), st.check ? "true" : "false",
+         latency ? "true" : "false");
+  if (latency) grdma_engine_stop();
   grpc_endpoint_shutdown(st.tx, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
   grpc_endpoint_shutdown(st.rx, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
   grpc_endpoint_destroy(st.tx);
