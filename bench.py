@@ -822,6 +822,14 @@ def main():
         out["value_endpoint_vtable_latency_mode"] = evl.get("GiBps")
         if evl.get("GiBps") is None:
             out["endpoint_vtable_latency_mode"] = evl
+        # unary 64 B round trips through the same vtable (tools/endpoint_pingpong.cc): the blocking C ABI, both pairs on
+        # the resident engine, and the engine with armed reads (each in a helper process; modes 1-2 are first hardware runs)
+        pp = os.path.join(ROOT, "tools", "endpoint_pingpong")
+        vt = {}
+        for mode, name, n in ((0, "launch_chain", 2000), (1, "engine", 20000), (2, "engine_armed_read", 20000)):
+            r = run_json([pp, str(n), "64", str(mode)], 90, env)
+            vt[name] = {k: r.get(k) for k in ("p50_us", "p95_us", "p99_us", "iters", "armed_hits")} if "p50_us" in r else r
+        out["rtt_endpoint_vtable_us"] = vt
     if small is not None:
         sm_steps = max(2, args.steps // 2)
         out["value_ring4096"] = round(wl.user_bytes * sm_steps * world / small["elapsed"] / (1 << 30), 3)

@@ -557,8 +557,10 @@ int grdma_endpoint_poll(grpc_endpoint* ep) {
   int ran = 0;
   // pollable_epoll busy-poll body, ev_epollex_rdma_bpev_linux.cc:1105-1149
   if (rdma->read_armed) {
-    const int status = grdma_pair_get_status(rdma->pair);
-    if (grdma_pair_has_message(rdma->pair) > 0 || status == 3 || status == 5) {
+    // (an armed read that has completed behind the peer's send is visible in host memory: grdma_pair_arm_read)
+    const bool armed_ready = grdma_pair_armed_ready(rdma->pair) > 0;
+    const int status = armed_ready ? 2 : grdma_pair_get_status(rdma->pair);
+    if (armed_ready || grdma_pair_has_message(rdma->pair) > 0 || status == 3 || status == 5) {
       rdma->read_armed = false;  // fd_become_readable
       rdma_handle_read(rdma, GRPC_ERROR_NONE);
       ran++;

@@ -1257,6 +1257,7 @@ int grdma_pair_arm_read(grdma_pair* p, uint64_t max_reads) {
   return 0;
 }
 int64_t grdma_pair_armed_hits(const grdma_pair* p) { return p ? (int64_t)p->armed_hits : -1; }
+int grdma_pair_armed_ready(const grdma_pair* p) { return p && p->armed_done ? 1 : 0; }
 
 // Unary ping-pong over a connected loop-back link, host in the loop exactly
 // where gRPC's consumer is: a = client end, b = server end.  Per iteration:

@@ -269,6 +269,7 @@ int grdma_pair_set_latency_mode(grdma_pair* p, int on);
  * max_reads = 0 disarms.  One thread per link. */
 int grdma_pair_arm_read(grdma_pair* p, uint64_t max_reads);
 int64_t grdma_pair_armed_hits(const grdma_pair* p);   /* sends that carried the peer's drain */
+int grdma_pair_armed_ready(const grdma_pair* p);      /* 1: a completion is waiting (host memory only: no device work) */
 /* Persistent latency engine: one resident workgroup takes the fused Send / drain
  * commands of latency-mode pairs from a mailbox in pinned host memory (a PCIe
  * doorbell read instead of a kernel launch per call).  It retires by itself after
