@@ -81,3 +81,27 @@ def test_pair_protocol_gpu_tests_under_the_emulator(emu_lib):
     traces, batched polling, the multi-record drains of k_rx_plan (chain walker, one-lane-per-record replay, bulk tier
     with its period predictor), latency mode (single-launch small sends, express drain), the unary ping-pong."""
     run_gpu_tests(emu_lib, ["tests/test_gpu_pair_parity.py", "-n", "4"], 55)
+
+
+def test_endpoint_vtable_tools_under_the_emulator(emu_lib, tmp_path):
+    """tools/endpoint_pingpong (unary round trips through grpc_endpoint_write / _read: the blocking ABI, the resident
+    engine, the engine with armed reads) and tools/endpoint_stream in latency mode, against the emulated library
+    (the binaries link libgrdma_amd.so: a link of that name in front of their run path); both check the bytes."""
+    import json
+    os.symlink(emu_lib, str(tmp_path / "libgrdma_amd.so"))
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
+               GRPC_RDMA_RING_BUFFER_SIZE_KB="4096")
+    pp = os.path.join(ROOT, "tools", "endpoint_pingpong")
+    for mode in (0, 1, 2):
+        p = subprocess.run([pp, "20", "64", str(mode)], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-500:]
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        assert r["checked"] and r["mode"] == mode and r["armed_hits"] == (2 * (20 + 7) if mode == 2 else 0), r
+    # a message larger than the inline command and the fast lane: [14 B][3000 B], the pointer path of the engine
+    p = subprocess.run([pp, "10", "3000", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["armed_hits"] == 0, p.stderr[-500:]
+    es = os.path.join(ROOT, "tools", "endpoint_stream")
+    p = subprocess.run([es, "5", str(1 << 20), "1", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-500:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["checked"] and r["latency_mode"] and r["endpoint_bytes"] > 5 << 20
