@@ -415,6 +415,7 @@ def main():
     ap.add_argument("--no-tcp-baseline", action="store_true", help="skip the loop-back TCP baselines")
     ap.add_argument("--rtt-iters", type=int, default=100000)
     ap.add_argument("--armed-rtt-only", action="store_true", help="(internal) run only the armed-read ping-pong")
+    ap.add_argument("--h2-bulk-pairs-only", action="store_true", help="(internal) run only the 64-frames-per-bulk-step h2 leg")
     args = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         # Multi-GPU runs measure the headline (and the fan-out leg) only: the comparison legs are
@@ -619,6 +620,14 @@ def main():
             d_.free()
         return {"elapsed": elapsed, "verified": ok, "stages": stage_us}
 
+    if args.h2_bulk_pairs_only:  # the child of the value_with_h2_bulk_pairs leg: one leg, one JSON line
+        few = max(2, args.steps // 4)
+        h2_ = measure_with_h2(args.ring_kb, few, 2, engine=(args.schedule == "engine"), bulk_pairs=True)
+        print(json.dumps({"value_with_h2_bulk_pairs": round(wl.user_bytes * few * world / h2_["elapsed"] / (1 << 30), 3),
+                          "with_h2_bulk_pairs_deframe_us": h2_["stages"]["deframe_us"],
+                          "with_h2_bulk_pairs_verified": h2_["verified"]}))
+        return
+
     schedule = "pipelined" if args.pipeline else "sequential"
     head = None
     if args.pipeline:
@@ -773,10 +782,15 @@ def main():
         except Exception as e:
             out["with_h2_no_boundary_step_error"] = err_text(e)
         try:  # ... and with 64 frames per bulk step (GRDMA_H2_BULK_PAIRS: off by default until it has run on hardware)
-            h2_ = measure_with_h2(args.ring_kb, few, 2, engine=eng_, bulk_pairs=True)
-            out["value_with_h2_bulk_pairs"] = round(wl.user_bytes * few * world / h2_["elapsed"] / (1 << 30), 3)
-            out["with_h2_bulk_pairs_deframe_us"] = h2_["stages"]["deframe_us"]
-            out["with_h2_bulk_pairs_verified"] = h2_["verified"]
+            # (this variant of the parsing wave has not run on hardware: a helper process with a timeout, N=1 only)
+            if rank == 0 and world == 1:
+                cmd = [sys.executable, os.path.abspath(__file__), "--h2-bulk-pairs-only", "--steps", str(args.steps),
+                       "--ring-kb", str(args.ring_kb), "--msgs", str(args.msgs), "--schedule", args.schedule]
+                r_ = run_json(cmd, 150)
+                if "value_with_h2_bulk_pairs" in r_:
+                    out.update(r_)
+                else:
+                    out["with_h2_bulk_pairs_error"] = str(r_.get("error"))[:300]
         except Exception as e:
             out["with_h2_bulk_pairs_error"] = err_text(e)
     if not args.no_extra_legs:
