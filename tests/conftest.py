@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # A GPU test never needs minutes.  If a kernel ever wedged, end the run (pytest-timeout's thread method exits the
+    # process, which also releases the device) instead of sitting in a synchronize until the caller's limit.
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def built():
     import __graft_entry__ as ge
