@@ -292,7 +292,7 @@ def measure_rtt(g, iters=100000, warmup=2000):
 def measure_rtt_armed(g, iters=20000, warmup=200):
     """The same ping-pong with a read armed on both ends, the way gRPC's transport keeps one outstanding: the drain
     rides in the peer's send command (grdma_pair_arm_read, GRDMA_ENGINE_SEND_INLINE_DRAIN), a round trip is 2 engine
-    commands instead of 4.  Runs in a process of its own (armed_rtt_subprocess)."""
+    commands instead of 4.  Runs in a process of its own (rtt_subprocess)."""
     from grpc_rdma_amd import h2
     lib = g.load()
     msg = bytes([0x0A, 64]) + bytes(range(64))
@@ -323,21 +323,21 @@ def measure_rtt_armed(g, iters=20000, warmup=200):
                 ["client_write+server_drain", "server_read", "server_write+client_drain", "client_read"], ph2)}}
 
 
-def armed_rtt_subprocess(iters, timeout_s=150):
-    """New engine command, first hardware run: isolate it.  A resident kernel that wedged would hang every later
-    synchronize of THIS process, so the leg runs in a child that can be killed; the line above it stays safe."""
+def rtt_subprocess(flag, iters, timeout_s=150, key="rtt_armed_read_error"):
+    """The ping-pong legs run a RESIDENT kernel (k_engine).  One that wedged would hang every later synchronize of
+    this process and take the whole line with it, so each leg runs in a child that can be killed."""
     import subprocess
     try:
-        cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--armed-rtt-only", "--rtt-iters", str(iters)],
+        cp = subprocess.run([sys.executable, os.path.abspath(__file__), flag, "--rtt-iters", str(iters)],
                             capture_output=True, text=True, timeout=timeout_s, stdin=subprocess.DEVNULL)
         for line in reversed(cp.stdout.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
-        return {"rtt_armed_read_error": ("exit %d: " % cp.returncode) + (cp.stderr or cp.stdout)[-300:]}
+        return {key: ("exit %d: " % cp.returncode) + (cp.stderr or cp.stdout)[-300:]}
     except subprocess.TimeoutExpired:
-        return {"rtt_armed_read_error": "timed out after %d s (child killed)" % timeout_s}
+        return {key: "timed out after %d s (child killed)" % timeout_s}
     except Exception as e:
-        return {"rtt_armed_read_error": err_text(e)}
+        return {key: err_text(e)}
 
 
 def fanout_leg(g, gs, grp, torch, args, flags, n_msgs=128):
@@ -415,6 +415,7 @@ def main():
     ap.add_argument("--no-tcp-baseline", action="store_true", help="skip the loop-back TCP baselines")
     ap.add_argument("--rtt-iters", type=int, default=100000)
     ap.add_argument("--armed-rtt-only", action="store_true", help="(internal) run only the armed-read ping-pong")
+    ap.add_argument("--rtt-only", action="store_true", help="(internal) run only the 64 B ping-pong leg")
     ap.add_argument("--h2-bulk-pairs-only", action="store_true", help="(internal) run only the 64-frames-per-bulk-step h2 leg")
     args = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -425,11 +426,14 @@ def main():
         args.no_small_ring = True
         args.conns = 1
 
-    if args.armed_rtt_only:  # the child of armed_rtt_subprocess: no torch, one leg, one JSON line
+    if args.armed_rtt_only or args.rtt_only:  # a child of rtt_subprocess: no torch, one leg, one JSON line
         import __graft_entry__ as ge
         import grpc_rdma_amd as g
         g.init(int(os.environ.get("LOCAL_RANK", "0")))
-        print(json.dumps(measure_rtt_armed(g, iters=args.rtt_iters, warmup=min(200, max(10, args.rtt_iters // 10)))))
+        if args.rtt_only:
+            print(json.dumps(measure_rtt(g, iters=args.rtt_iters, warmup=min(2000, max(10, args.rtt_iters // 10)))))
+        else:
+            print(json.dumps(measure_rtt_armed(g, iters=args.rtt_iters, warmup=min(200, max(10, args.rtt_iters // 10)))))
         return
 
     import torch
@@ -724,12 +728,10 @@ def main():
             out["fanout_error"] = str(e)
     # ---- unary 64 B ping-pong (BASELINE.json configs[1]): second half of the metric -------
     if not args.no_rtt:
-        try:
-            out.update(measure_rtt(g, iters=args.rtt_iters, warmup=min(2000, max(10, args.rtt_iters // 10))))
-        except Exception as e:  # never lose the throughput line to the latency leg
-            out["rtt_error"] = str(e)
-        if rank == 0 and world == 1:
-            out.update(armed_rtt_subprocess(max(1000, args.rtt_iters // 5)))
+        if rank == 0:  # (one connection on one GPU: rank 0 measures it, in helper processes)
+            out.update(rtt_subprocess("--rtt-only", args.rtt_iters, 240, key="rtt_error"))
+            if world == 1:
+                out.update(rtt_subprocess("--armed-rtt-only", max(1000, args.rtt_iters // 5)))
     if seq is not None:  # same workload and ring, five kernels per round strictly in order
         out["value_sequential"] = round(
             wl.user_bytes * max(2, args.steps // 2) * world / seq["elapsed"] / (1 << 30), 3)
