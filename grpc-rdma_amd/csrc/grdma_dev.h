@@ -52,6 +52,43 @@ struct grdma_status_report {
   int32_t pad;
 };
 
+// Arrival report (this build's addition to the wire: nothing like it exists in the reference, whose NIC
+// places the bytes of an RDMA WRITE in order, footer last).  A HIP wire -- the loop-back copy kernel, a peer
+// process writing through an IPC mapping, an xGMI peer -- is a PARALLEL copy: a record's header and footer
+// can be in place while a tile in the middle is still in flight.  So the sender, once a write has completed
+// as a whole, stores the ring offset its writes have reached into the receiver's connection block (the
+// reverse direction of the credit report), and the receiver never walks the chain past it.
+struct grdma_wire_report {
+  uint64_t wire_tail;   // ring offset behind the last record that has landed completely
+  uint64_t pad;
+};
+
+// Host-visible state line of one connection end: 128 bytes of pinned, coherent host memory that the
+// kernels write THROUGH whenever they change what the event engine polls -- HasMessage, HasPendingWrites,
+// get_status, GetWritableSize are read-only, lock-free and called from N polling threads in the reference
+// (ring_buffer.cc:56-65, pair.cc:294-303,349-375; ev_epollex_rdma_bpev_linux.cc:1103-1145), so here they are
+// plain host loads of this line and never a device call.  One writer per word:
+//   wire_tail                       the PEER's send commit (in-process peer), or the refresh pass of k_poll
+//                                   for a peer in another process (copies conn->wire_recv)
+//   rx_head, rx_remain, rx_seq      my own drains
+//   remote_head                     the PEER's scatter (credit post), or the refresh pass
+//   remote_tail, partial_write, tx_seq   my own sends
+//   peer_exit                       the peer's Disconnect (host store), or the refresh pass
+struct grdma_hostline {
+  uint64_t wire_tail;
+  uint64_t rx_head;
+  uint64_t rx_remain;
+  uint64_t rx_seq;        // drains completed (scatter and credit included)
+  uint64_t remote_head;
+  uint64_t remote_tail;
+  uint64_t partial_write;
+  uint64_t tx_seq;        // sends completed (payload has left the caller's slices, wire write done)
+  int32_t peer_exit;
+  uint32_t pad0;
+  uint64_t refresh_seq;   // refresh passes of k_poll that have written this line
+  uint64_t pad1[6];
+};
+
 // {ptr,len} view of one grpc_slice (GRPC_SLICE_START_PTR / GRPC_SLICE_LENGTH,
 // include/grpc/impl/codegen/slice.h:96-101).  ptr must be device-accessible.
 struct grdma_sge {
@@ -105,6 +142,15 @@ struct grdma_conn {
   uint32_t rx_period;           // detected period of the record sizes (0 = none)
   uint32_t pad3;
   uint64_t rx_period_retry_at;  // no new period search before this many records were read
+  // ---- arrival report and host-visible state (see grdma_wire_report / grdma_hostline) -----------
+  struct grdma_wire_report wire_recv;   // written by the peer: how far its completed writes reach in my ring
+  uint64_t* peer_wire;                  // the peer's wire_recv.wire_tail (device memory, possibly an IPC mapping)
+  struct grdma_hostline* line;          // my state line (pinned host memory), NULL = none
+  struct grdma_hostline* peer_line;     // the peer's line when it lives in this process, else NULL
+  uint32_t wire_limit;                  // 1: never walk past wire_recv.wire_tail (every HIP wire); 0: the wire
+                                        // places bytes in order, footer last (a NIC)
+  uint32_t line_remote;                 // 1: nobody pushes wire_tail / remote_head / peer_exit into my line
+                                        // (the peer is another process): k_poll's refresh pass copies them
 };
 
 struct grdma_seg {

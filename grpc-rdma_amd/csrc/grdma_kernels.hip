@@ -136,10 +136,30 @@ __global__ __launch_bounds__(COPY_THREADS) void k_rx_apply(const grdma_rx_op* op
       if (ps != nullptr)
         __hip_atomic_store(&ps->remote_head, res->credit_head, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
+      // the same report into the sender's host-visible state line (GetWritableSize() there is a host load)
+      grdma_hostline* pl = op.conn->peer_line;
+      if (pl != nullptr)
+        __hip_atomic_store(&pl->remote_head, res->credit_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __hip_atomic_store(&res->commit_seq, res->commit_seq + 1, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// ----------------------------------------------------------------------------
+// k_tx_commit: runs behind the wire kernel of a Send (a kernel boundary: every byte of the Send is in
+// the peer ring) and reports the arrival -- grdma_wire_report into the peer's connection block, the
+// same into the peer's host line when it lives in this process, the sender's own line (remote_tail_,
+// partial_write_, and the sequence number the host waits for: the caller's slices are free).
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_tx_commit(grdma_conn* const* conns, const uint64_t* seqs) {
+  if (threadIdx.x != 0) return;
+  grdma_conn* c = conns[blockIdx.x];
+  tx_publish(c, c->remote_tail, c->partial_write, seqs ? seqs[blockIdx.x] : 0);
+}
+
+__global__ __launch_bounds__(64) void k_tx_commit1(grdma_conn* c, uint64_t seq) {  // one pair, arguments by value
+  if (threadIdx.x == 0) tx_publish(c, c->remote_tail, c->partial_write, seq);
 }
 
 struct ring_probe {
@@ -175,6 +195,11 @@ __global__ __launch_bounds__(64) void k_poll(grdma_conn* const* conns, uint32_t 
       has = true;
     } else {
       ring_probe pr = probe_record(c->ring, c->cap, c->head);
+      if (c->wire_limit) {  // (a record the sender has not reported as landed is not there yet)
+        const uint64_t wt = __hip_atomic_load(&c->wire_recv.wire_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint64_t room = (wt - c->head) & (c->cap - 1);
+        if (pr.n != 0 && 16 + round_up8(pr.n) > room) pr.n = 0, pr.ready = false;
+      }
       has = pr.n > 0;  // HasMessage, ring_buffer.cc:56-65: header only
       readable = pr.ready ? pr.n : 0;
     }
@@ -185,6 +210,22 @@ __global__ __launch_bounds__(64) void k_poll(grdma_conn* const* conns, uint32_t 
     if (st == GRDMA_PAIR_CONNECTED && c->status_recv.peer_exit == 1) st = GRDMA_PAIR_HALF_CLOSED;
     trigger = st == GRDMA_PAIR_CONNECTED ? (has || c->partial_write != 0)
                                          : (st == GRDMA_PAIR_HALF_CLOSED || st == GRDMA_PAIR_ERROR);
+    // refresh pass: a peer in another process cannot reach my host line, so what it wrote into my
+    // connection block (arrival report, credit report, peer_exit) is copied there
+    grdma_hostline* ln = c->line;
+    if (ln != nullptr && (c->line_remote || !c->wire_limit)) {
+      // (an ordered wire sends no arrival report: the probe above stands in for it -- a value that differs
+      // from every head while a header is there, the head itself while none is)
+      const uint64_t wt = c->wire_limit
+                              ? __hip_atomic_load(&c->wire_recv.wire_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                              : (has ? (c->head | (1ull << 63)) : c->head);
+      const uint64_t rh = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const int32_t px = __hip_atomic_load(&c->status_recv.peer_exit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&ln->wire_tail, wt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&ln->remote_head, rh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&ln->peer_exit, px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&ln->refresh_seq, ln->refresh_seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   // wavefront ballots: 64 connections -> 64-bit words
   const uint64_t m_ready = __ballot(readable > 0);
@@ -205,6 +246,17 @@ extern "C" {
 __attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_plan(const grdma_tx_op* d_ops, uint32_t nops, hipStream_t s) {
   if (nops == 0) return hipSuccess;
   hipLaunchKernelGGL(k_tx_plan, dim3(nops), dim3(PLAN_THREADS), 0, s, d_ops);
+  return hipGetLastError();
+}
+
+__attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_commit(grdma_conn* const* d_conns, const uint64_t* d_seqs, uint32_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tx_commit, dim3(n), dim3(64), 0, s, d_conns, d_seqs);
+  return hipGetLastError();
+}
+
+__attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_commit1(grdma_conn* d_conn, uint64_t seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_tx_commit1, dim3(1), dim3(64), 0, s, d_conn, seq);
   return hipGetLastError();
 }
 
@@ -236,6 +288,7 @@ __attribute__((visibility("hidden"))) const void* grdma_kernel_fn(int which) {
     case 1: return reinterpret_cast<const void*>(&k_copy);
     case 3: return reinterpret_cast<const void*>(&k_rx_apply);
     case 4: return reinterpret_cast<const void*>(&k_tx_plan_seq);
+    case 5: return reinterpret_cast<const void*>(&k_tx_commit);
     default: return nullptr;
   }
 }

@@ -1179,6 +1179,8 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
       if (fl & 1u) {
         grdma_status_report* ps = c->peer_status;
         if (ps != nullptr) __hip_atomic_store(&ps->remote_head, ch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (c->peer_line != nullptr && lane == 0)  // the sender's host-visible state line (grdma_hostline)
+          __hip_atomic_store(&c->peer_line->remote_head, ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         lk_trace(L, 1, trn, 7, chunks_retired, lane);
       }
       if (fl & 2u) {
@@ -1565,6 +1567,10 @@ __device__ void lk_rx_leader(lk_ctl* L, uint64_t ticks, lk_rx_lds* D, int lane) 
     c->head = head;
     c->moving_head = mh;
     c->remain = remain;
+    if (c->line != nullptr) {  // what HasMessage() on the host compares with the arrival report
+      c->line->rx_head = head;
+      c->line->rx_remain = remain;
+    }
     c->internal_read_size = irs;
     c->leftover_cap = leftover;
     c->total_read += bytes;

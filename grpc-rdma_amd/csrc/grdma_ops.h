@@ -23,6 +23,8 @@ struct grdma_tx_op {
   uint64_t seq_next;               // != 0: the value to publish in result->seq (latency mode: the
                                    // result block is host memory, reading the old value back
                                    // would be a PCIe round trip in front of the release)
+  uint64_t* tail_out;              // != NULL: remote_tail_ after this Send is also stored here (a streaming
+                                   // job hands it to the drain of the same round: grdma_rx_op::limit_ptr)
 };
 
 // One PairPollable::SendZerocopy (pair.cc:793-941) for one connection.
@@ -52,6 +54,11 @@ struct grdma_rx_op {
   uint64_t slices_cap;             // entries in `slices` (append mode)
   uint64_t inline_apply;           // 1: this workgroup also scatters, zero-fills and posts credit
   uint64_t seq_next;               // != 0: the value to publish in result->seq / commit_seq
+  const uint64_t* limit_ptr;       // != NULL: the ring offset this drain may walk up to, read when the drain
+                                   // starts (a streaming job hands over the tail its Send of the same round
+                                   // computed: the graph edge behind that Send's wire write says those bytes
+                                   // have landed, and a later round may already be landing behind them);
+                                   // NULL: conn->wire_recv.wire_tail when conn->wire_limit is set
 };
 
 // Mailbox of the persistent latency engine (pinned host memory).

@@ -18,6 +18,7 @@
 #include <mutex>
 #include <thread>
 #include <poll.h>
+#include <signal.h>
 #include <sys/socket.h>
 #include <errno.h>
 #include <sys/eventfd.h>
@@ -38,6 +39,8 @@ uint32_t grdma_link_resident_blocks(void);
 hipError_t grdma_launch_tx_plan(const grdma_tx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_tx_plan_seq(const grdma_tx_op*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_tx_plan_zc(const grdma_zc_op*, uint32_t, hipStream_t);
+hipError_t grdma_launch_tx_commit(grdma_conn* const*, const uint64_t*, uint32_t, hipStream_t);
+hipError_t grdma_launch_tx_commit1(grdma_conn*, uint64_t, hipStream_t);
 hipError_t grdma_launch_copy(const grdma_plan* const*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_apply(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
@@ -101,6 +104,36 @@ int require_ctx() {
   return 0;
 }
 
+// Host-visible state lines (grdma_hostline): pinned coherent memory, carved from slabs of 512 lines so that a
+// connection does not cost a hipHostMalloc of its own.
+struct line_slab {
+  std::mutex mu;
+  std::vector<grdma_hostline*> blocks;
+  std::vector<grdma_hostline*> free_list;
+};
+line_slab g_lines;
+static_assert(sizeof(grdma_hostline) == 128, "one state line = two cache lines");
+
+grdma_hostline* line_alloc() {
+  std::lock_guard<std::mutex> lk(g_lines.mu);
+  if (g_lines.free_list.empty()) {
+    grdma_hostline* blk = nullptr;
+    if (hipHostMalloc((void**)&blk, sizeof(grdma_hostline) * 512, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+      return nullptr;
+    g_lines.blocks.push_back(blk);
+    for (int i = 511; i >= 0; i--) g_lines.free_list.push_back(blk + i);
+  }
+  grdma_hostline* l = g_lines.free_list.back();
+  g_lines.free_list.pop_back();
+  memset(l, 0, sizeof(*l));
+  return l;
+}
+void line_free(grdma_hostline* l) {
+  if (!l) return;
+  std::lock_guard<std::mutex> lk(g_lines.mu);
+  g_lines.free_list.push_back(l);
+}
+
 uint32_t copy_blocks_for(uint64_t bytes) {
   uint64_t tiles = (bytes + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
   uint64_t blocks = (tiles + 3) / 4;  // 4 waves per block, one tile per wave pass
@@ -124,6 +157,9 @@ struct grdma_hostblk {
   grdma_rx_result rxres;
   const grdma_plan* plan_ptrs[4];  // [0] tx gather, [1] wire, [2] rx scatter
   grdma_zc_op zcop;                // SendZerocopy
+  // refresh pass of a pair whose peer lives in another process (k_poll over this one connection)
+  grdma_conn* refresh_conn;
+  uint64_t refresh_out[4];         // readable, ready mask, has-message mask, trigger mask
 };
 
 struct grdma_pair {
@@ -145,6 +181,14 @@ struct grdma_pair {
   grdma_engine_cmd* h_cmd = nullptr; // pinned self-contained command block (latency engine)
   uint64_t h_arena_cap = 0;
   grdma_hostblk* h = nullptr;        // pinned
+  grdma_hostline* line = nullptr;    // pinned: what the read-only queries load (grdma_hostline)
+  std::atomic<uint32_t> status{GRDMA_PAIR_UNINITIALIZED};  // status_, pair.h:166 (the device copy gates the kernels)
+  uint64_t tx_seq = 0;               // sends committed so far (k_tx_commit publishes it in line->tx_seq)
+  uint64_t refresh_launched = 0;     // refresh passes launched (remote peers only)
+  hipStream_t refresh_stream = nullptr;
+  uint64_t peer_pid = 0;             // remote peer: its process id (liveness check of get_status)
+  int boot_fd = -1;                  // remote peer: the bootstrap socket (not owned), for the hang-up check
+  std::atomic<int64_t> liveness_checked_ns{0};
   grdma_sge* h_sges = nullptr;       // pinned, GRDMA_MAX_SEGS entries
   grdma_slice_out* h_slices = nullptr;  // pinned, GRDMA_MAX_SLICES entries
   uint8_t* h_bounce = nullptr;       // pinned, staging-sized, lazily allocated
@@ -409,6 +453,8 @@ int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_curs
   HIP_TRY(grdma_launch_copy(&h->plan_ptrs[0], 1, blocks, p->stream));
   if (!(p->flags & GRDMA_WIRE_DIRECT))
     HIP_TRY(grdma_launch_copy(&h->plan_ptrs[1], 1, blocks, p->stream));
+  // behind the wire write, as a kernel of its own: the arrival report (and the state lines)
+  HIP_TRY(grdma_launch_tx_commit1(p->d_conn, ++p->tx_seq, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return 0;
 }
@@ -516,6 +562,7 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
                           hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess &&
             hipHostMalloc((void**)&p->h_slices, sizeof(grdma_slice_out) * GRDMA_MAX_SLICES,
                           hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
+  if (ok) ok = (p->line = line_alloc()) != nullptr;
   if (!ok) {
     fail(GRDMA_ERR_HIP, "device allocation failed for a %llu-byte ring",
          (unsigned long long)ring_size);
@@ -543,6 +590,12 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
   c.status = GRDMA_PAIR_INITIALIZED;
   c.wire_direct = (flags & GRDMA_WIRE_DIRECT) ? 1 : 0;
   c.rx_hist = p->d_hist;
+  c.line = p->line;
+  // every wire of this build is a parallel copy: the receiver honours the arrival report -- unless the
+  // caller says an ordered writer (a NIC) fills this ring
+  c.wire_limit = (flags & GRDMA_WIRE_ORDERED) ? 0 : 1;
+  p->h->refresh_conn = p->d_conn;
+  p->status.store(GRDMA_PAIR_INITIALIZED);
   hipMemcpyAsync(p->d_conn, &c, sizeof(c), hipMemcpyHostToDevice, p->stream);
   if (hipStreamSynchronize(p->stream) != hipSuccess) {
     fail(GRDMA_ERR_HIP, "pair initialisation failed");
@@ -566,7 +619,12 @@ void grdma_pair_destroy(grdma_pair* p) {
   hipFree(p->d_arena);
   hipFree(p->d_hist);
   hipFree(p->d_zc);
+  if (p->refresh_stream) {
+    hipStreamSynchronize(p->refresh_stream);  // a refresh pass in flight writes the line
+    hipStreamDestroy(p->refresh_stream);
+  }
   if (p->h) hipHostFree(p->h);
+  line_free(p->line);
   if (p->h_sges) hipHostFree(p->h_sges);
   if (p->h_slices) hipHostFree(p->h_slices);
   if (p->h_bounce) hipHostFree(p->h_bounce);
@@ -592,8 +650,13 @@ int grdma_pair_connect(grdma_pair* a, grdma_pair* b) {
     c.peer_ring = other->d_ring;
     c.peer_status = reinterpret_cast<grdma_status_report*>(
         reinterpret_cast<uint8_t*>(other->d_conn) + offsetof(grdma_conn, status_recv));
+    c.peer_wire = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(other->d_conn) +
+                                              offsetof(grdma_conn, wire_recv) + offsetof(grdma_wire_report, wire_tail));
+    c.peer_line = other->line;  // both ends in this process: the kernels push into each other's state line
+    c.line_remote = 0;
     c.status = GRDMA_PAIR_CONNECTED;
     HIP_TRY(hipMemcpy(me->d_conn, &c, sizeof(c), hipMemcpyHostToDevice));
+    me->status.store(GRDMA_PAIR_CONNECTED);
     me->peer = other;
     me->stream = a->stream;  // one in-order queue per loop-back link
   }
@@ -632,6 +695,13 @@ int grdma_pair_export_address(grdma_pair* p, grdma_bootstrap_blob* out) {
   out->hip_device = g_ctx.device;
   out->pid = (uint64_t)getpid();
   out->status_off = offsetof(grdma_conn, status_recv);
+  out->wire_off = (uint32_t)offsetof(grdma_conn, wire_recv);
+  // What another process (or a NIC) writes must be fine-grained device memory: its stores are then at
+  // memory once acknowledged, and mine (the reader's zero-fill, the credit word) are write-through --
+  // with a coarse-grained ring the zero-fill of one XCD's L2 could be written back OVER records the peer
+  // has placed since (k_rx_apply counts its workgroups in with a relaxed atomic on that assumption).
+  if (!(p->flags & GRDMA_RING_FINE_GRAINED))
+    return fail(GRDMA_ERR_INVALID, "a pair exported to a remote peer must be created with GRDMA_RING_FINE_GRAINED");
   static_assert(sizeof(hipIpcMemHandle_t) == sizeof(out->ring_handle), "HIP IPC handle size");
   hipIpcMemHandle_t h;
   HIP_TRY(hipIpcGetMemHandle(&h, p->d_ring));
@@ -656,6 +726,12 @@ int grdma_pair_connect_remote(grdma_pair* p, const grdma_bootstrap_blob* peer) {
                 (unsigned long long)peer->addr.ring_buffer_size);
   if (peer->magic != kBlobMagic || peer->version != GRDMA_ABI_VERSION)
     return fail(GRDMA_ERR_INVALID, "peer is not a HIP data-plane endpoint of this ABI version");
+  // the offsets come off a socket: they must be the ones of this build's connection block
+  if (peer->status_off != offsetof(grdma_conn, status_recv) || peer->wire_off != offsetof(grdma_conn, wire_recv))
+    return fail(GRDMA_ERR_INVALID, "peer's connection block layout differs (status %llu, wire %u)",
+                (unsigned long long)peer->status_off, peer->wire_off);
+  if (!(p->flags & GRDMA_RING_FINE_GRAINED))
+    return fail(GRDMA_ERR_INVALID, "a pair connected to a remote peer must be created with GRDMA_RING_FINE_GRAINED");
   if (peer->pid == (uint64_t)getpid())
     return fail(GRDMA_ERR_INVALID, "peer lives in this process: use grdma_pair_connect (an IPC handle cannot be opened where it was made)");
   hipIpcMemHandle_t h;
@@ -675,8 +751,13 @@ int grdma_pair_connect_remote(grdma_pair* p, const grdma_bootstrap_blob* peer) {
   p->remote_status = reinterpret_cast<grdma_status_report*>(static_cast<uint8_t*>(conn) + peer->status_off);
   c.peer_ring = static_cast<uint8_t*>(ring);
   c.peer_status = p->remote_status;
+  c.peer_wire = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(conn) + peer->wire_off + offsetof(grdma_wire_report, wire_tail));
+  c.peer_line = nullptr;  // pinned host memory of another process is out of reach:
+  c.line_remote = 1;      // my line is refreshed from my own connection block (k_poll's refresh pass)
   c.status = GRDMA_PAIR_CONNECTED;
   HIP_TRY(hipMemcpy(p->d_conn, &c, sizeof(c), hipMemcpyHostToDevice));
+  p->peer_pid = peer->pid;
+  p->status.store(GRDMA_PAIR_CONNECTED);
   return 0;
 }
 
@@ -715,40 +796,92 @@ int grdma_pair_bootstrap_fd(grdma_pair* p, int fd) {
   if (x != 0)
     return fail(GRDMA_ERR_NOT_CONNECTED, "address exchange over fd %d failed (%s)", fd,
                 x == -2 ? "timeout" : x == -3 ? "peer closed" : strerror(errno));
-  return grdma_pair_connect_remote(p, &theirs);
+  if (int rc = grdma_pair_connect_remote(p, &theirs)) return rc;
+  p->boot_fd = fd;  // (not owned) a hang-up on it means the peer is gone: get_status()
+  return 0;
 }
 
 int grdma_pair_disconnect(grdma_pair* p) {
   if (int rc = require_ctx()) return rc;
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
-  grdma_conn c;
-  if (int rc = fetch_conn(p, &c)) return rc;
-  if (c.status == GRDMA_PAIR_CONNECTED && (p->peer || p->remote_status)) {
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  const uint32_t st0 = p->status.load();
+  if (st0 == GRDMA_PAIR_CONNECTED && (p->peer || p->remote_status)) {
     // peer_exit = 1 in the peer's status buffer, pair.cc:332-336
     int32_t one = 1;
     uint8_t* dst = p->peer ? reinterpret_cast<uint8_t*>(p->peer->d_conn) + offsetof(grdma_conn, status_recv)
                            : reinterpret_cast<uint8_t*>(p->remote_status);
     HIP_TRY(hipMemcpy(dst + offsetof(grdma_status_report, peer_exit), &one, sizeof(one), hipMemcpyHostToDevice));
+    if (p->peer && p->peer->line)  // an in-process peer sees it in its state line at once
+      __atomic_store_n(&p->peer->line->peer_exit, 1, __ATOMIC_RELEASE);
   }
   uint32_t st = GRDMA_PAIR_DISCONNECTED;
   HIP_TRY(hipMemcpy(reinterpret_cast<uint8_t*>(p->d_conn) + offsetof(grdma_conn, status), &st,
                     sizeof(st), hipMemcpyHostToDevice));
+  p->status.store(st);
   return 0;
 }
 
-int grdma_pair_get_status(grdma_pair* p) {
-  if (int rc = require_ctx()) return rc;
-  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
-  grdma_conn c;
-  if (int rc = fetch_conn(p, &c)) return rc;
-  // pair.cc:349-356: a connected pair whose peer announced its exit is half closed
-  if (c.status == GRDMA_PAIR_CONNECTED && c.status_recv.peer_exit == 1) {
-    uint32_t st = GRDMA_PAIR_HALF_CLOSED;
-    HIP_TRY(hipMemcpy(reinterpret_cast<uint8_t*>(p->d_conn) + offsetof(grdma_conn, status), &st,
-                      sizeof(st), hipMemcpyHostToDevice));
-    return GRDMA_PAIR_HALF_CLOSED;
+namespace {
+int64_t mono_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// A peer in another process writes into my connection block, not into my host line: k_poll's refresh pass
+// copies arrival report, credit report and peer_exit over.  At most one pass is in flight per pair, launched
+// without waiting from whichever read-only query finds the previous one done -- the queries themselves stay
+// plain host loads (they see the line as of the last pass).
+void refresh_async(grdma_pair* p) {
+  if (!(p->remote || (p->flags & GRDMA_WIRE_ORDERED)) || !p->line) return;
+  const uint64_t done = __atomic_load_n(&p->line->refresh_seq, __ATOMIC_ACQUIRE);
+  if (done != p->refresh_launched) return;  // the last pass has not written the line yet
+  std::lock_guard<std::mutex> lk(p->fd_mu);
+  if (__atomic_load_n(&p->line->refresh_seq, __ATOMIC_ACQUIRE) != p->refresh_launched) return;
+  if (!p->refresh_stream && hipStreamCreateWithFlags(&p->refresh_stream, hipStreamNonBlocking) != hipSuccess) return;
+  grdma_hostblk* h = p->h;
+  if (grdma_launch_poll(&h->refresh_conn, 1, &h->refresh_out[0], &h->refresh_out[1], &h->refresh_out[2],
+                        &h->refresh_out[3], p->refresh_stream) == hipSuccess)
+    p->refresh_launched++;
+}
+
+// get_status() (pair.cc:349-375).  The reference asks the queue pair every 500 ms whether it is still in a
+// working state (ibv_query_qp, :358-372) and reports kHalfClosed when it is not; here the peer of a remote pair
+// is a process: it is gone when its pid is, or when the bootstrap socket reports a hang-up.
+uint32_t status_now(grdma_pair* p) {
+  uint32_t st = p->status.load(std::memory_order_acquire);
+  if (st != GRDMA_PAIR_CONNECTED) return st;
+  bool closed = p->line && __atomic_load_n(&p->line->peer_exit, __ATOMIC_ACQUIRE) == 1;
+  if (!closed && p->remote) {
+    refresh_async(p);
+    const int64_t now = mono_ns(), last = p->liveness_checked_ns.load(std::memory_order_relaxed);
+    if (now - last > 100 * 1000 * 1000 &&
+        p->liveness_checked_ns.compare_exchange_strong(const_cast<int64_t&>(last), now)) {
+      if (p->peer_pid && kill((pid_t)p->peer_pid, 0) != 0 && errno == ESRCH) closed = true;
+      if (!closed && p->boot_fd >= 0) {
+        struct pollfd pfd = {p->boot_fd, POLLRDHUP, 0};
+        if (poll(&pfd, 1, 0) > 0 && (pfd.revents & (POLLHUP | POLLRDHUP | POLLERR))) closed = true;
+      }
+    }
   }
-  return (int)c.status;
+  if (closed) {
+    uint32_t expect = GRDMA_PAIR_CONNECTED;
+    if (p->status.compare_exchange_strong(expect, GRDMA_PAIR_HALF_CLOSED)) {
+      // the device copy gates the kernels (a Send on a pair that is not connected takes nothing, pair.cc:652-655)
+      std::lock_guard<std::mutex> lk(p->fd_mu);
+      const uint32_t hc = GRDMA_PAIR_HALF_CLOSED;
+      hipMemcpyAsync(reinterpret_cast<uint8_t*>(p->d_conn) + offsetof(grdma_conn, status), &hc, sizeof(hc),
+                     hipMemcpyHostToDevice, p->refresh_stream ? p->refresh_stream : p->stream);
+      hipStreamSynchronize(p->refresh_stream ? p->refresh_stream : p->stream);
+    }
+    return p->status.load();
+  }
+  return st;
+}
+}  // namespace
+
+int grdma_pair_get_status(grdma_pair* p) {
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  return (int)status_now(p);
 }
 
 int64_t grdma_pair_send(grdma_pair* p, const grdma_slice* slices, uint64_t count,
@@ -1011,37 +1144,41 @@ void grdma_poller_destroy(grdma_poller* pl) {  // Poller::Shutdown, poller.h:37-
   delete pl;
 }
 
+// The read-only queries of PairPollable: plain loads of the pair's host-visible state line, no device
+// call, no lock, any number of threads (the contract of ring_buffer.cc:56-65 and pair.cc:294-303, which the
+// event engines rely on: ev_epollex_rdma_bpev_linux.cc:1103-1145 calls them for every fd on every pass).
 int grdma_pair_has_message(grdma_pair* p) {
-  uint8_t has = 0;
-  grdma_pair* arr[1] = {p};
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
-  int rc = grdma_poll_pairs(arr, 1, nullptr, &has);
-  return rc < 0 ? rc : has;
+  const grdma_hostline* l = p->line;
+  refresh_async(p);  // (remote peers only; never waits)
+  // HasMessage(), ring_buffer.cc:56-65: remain_ > 0, or a record behind head_ -- the sender's arrival
+  // report has moved past the position my drains have opened up to
+  const uint64_t wt = __atomic_load_n(&l->wire_tail, __ATOMIC_ACQUIRE);
+  const uint64_t rh = __atomic_load_n(&l->rx_head, __ATOMIC_RELAXED);
+  const uint64_t rem = __atomic_load_n(&l->rx_remain, __ATOMIC_RELAXED);
+  return (rem > 0 || wt != rh) ? 1 : 0;
 }
 
-int64_t grdma_pair_readable_size(grdma_pair* p) {
+int64_t grdma_pair_readable_size(grdma_pair* p) {  // GetReadableSize(): the header itself is in HBM -> one k_poll launch
   uint64_t r = 0;
   grdma_pair* arr[1] = {p};
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
   int rc = grdma_poll_pairs(arr, 1, &r, nullptr);
   if (rc < 0) return rc;
-  grdma_conn c;
-  if (int rc2 = fetch_conn(p, &c)) return rc2;
-  return c.status == GRDMA_PAIR_CONNECTED ? (int64_t)r : 0;  // pair.cc:290-292
+  return status_now(p) == GRDMA_PAIR_CONNECTED ? (int64_t)r : 0;  // pair.cc:290-292
 }
 
-int grdma_pair_has_pending_writes(grdma_pair* p) {
-  if (int rc = require_ctx()) return rc;
-  grdma_conn c;
-  if (int rc = fetch_conn(p, &c)) return rc;
-  return c.partial_write ? 1 : 0;
+int grdma_pair_has_pending_writes(grdma_pair* p) {  // HasPendingWrites(), pair.cc:303: partial_write_
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  return __atomic_load_n(&p->line->partial_write, __ATOMIC_ACQUIRE) ? 1 : 0;
 }
 
-int64_t grdma_pair_writable_size(grdma_pair* p) {
-  if (int rc = require_ctx()) return rc;
-  grdma_conn c;
-  if (int rc = fetch_conn(p, &c)) return rc;
-  return (int64_t)grdma_host_writable(c.cap, c.status_recv.remote_head, c.remote_tail);
+int64_t grdma_pair_writable_size(grdma_pair* p) {  // GetWritableSize(), pair.cc:294-301
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  refresh_async(p);
+  const grdma_hostline* l = p->line;
+  return (int64_t)grdma_host_writable(p->ring_size, __atomic_load_n(&l->remote_head, __ATOMIC_ACQUIRE),
+                                      __atomic_load_n(&l->remote_tail, __ATOMIC_ACQUIRE));
 }
 
 int grdma_pair_state_get(grdma_pair* p, grdma_pair_state* out) {
@@ -1136,6 +1273,7 @@ int64_t grdma_pair_send_zerocopy(grdma_pair* p, const grdma_slice* slices, uint6
   HIP_TRY(grdma_launch_tx_plan_zc(&h->zcop, 1, p->stream));
   // the records go straight into the peer ring: one gather launch, no wire launch
   HIP_TRY(grdma_launch_copy(&h->plan_ptrs[0], 1, copy_blocks_for(p->ring_size), p->stream));
+  HIP_TRY(grdma_launch_tx_commit1(p->d_conn, ++p->tx_seq, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   {
     std::lock_guard<std::mutex> lk(p->zc_mu);
@@ -1475,6 +1613,9 @@ struct grdma_stream_job {
   grdma_tx_result* d_txres = nullptr; // [n]
   grdma_rx_result* d_rxres = nullptr; // [2 * n]
   const grdma_plan** d_plans = nullptr;  // [3 * n]: gather, wire (even), wire (odd)
+  uint64_t* d_limits = nullptr;       // [3 * n]: remote_tail_ after the Send(s) of a round, per op set: what the
+                                      // drain of the same round may walk up to (grdma_rx_op::limit_ptr)
+  grdma_conn** d_txconns = nullptr;   // [n]: the sending ends, for the arrival report behind the last round
   hipGraphExec_t exec = nullptr;
   uint64_t exec_rounds = 0;
   int exec_pipeline = -1;
@@ -1491,7 +1632,7 @@ struct grdma_stream_job {
   // and put on the wire by one k_copy launch each (burst x n plans), drained by ONE receive pass
   uint32_t burst = 1;
   uint8_t* d_bctl = nullptr;
-  grdma_tx_op* d_btxop = nullptr;          // [2 sets][burst][n]: set 0 = first round (resets the cursor)
+  grdma_tx_op* d_btxop = nullptr;          // [3 sets][burst][n]: the op sets of job_opset() (set 0 resets the cursor)
   const grdma_plan** d_bplans = nullptr;   // [burst * n] gather plans, then [burst * n] wire plans
   // link engine
   lk_ctl** d_lk_ptrs = nullptr;
@@ -1528,7 +1669,7 @@ int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
   for (uint64_t r = 0; r < j->rounds; r++) {
     const int k = job_opset(r);
     if (B > 1) {
-      HIP_TRY(grdma_launch_tx_plan_seq(j->d_btxop + (r == 0 ? 0 : (size_t)B * n), n, B, s));
+      HIP_TRY(grdma_launch_tx_plan_seq(j->d_btxop + (size_t)k * B * n, n, B, s));
       if (int rc = mark()) return rc;
       HIP_TRY(grdma_launch_copy(j->d_bplans, B * n, txb_b, s));
       if (int rc = mark()) return rc;
@@ -1547,6 +1688,9 @@ int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
     HIP_TRY(grdma_launch_rx_apply(j->d_rxop + k * n, n, rxb, s));
     if (int rc = mark()) return rc;
   }
+  // the drains of the job were told how far to walk by their op (limit_ptr); the connection's own arrival
+  // report and the state lines follow once, behind the last round
+  HIP_TRY(grdma_launch_tx_commit(j->d_txconns, nullptr, n, s));
   return 0;
 }
 
@@ -1628,6 +1772,7 @@ int job_enqueue_pipelined(grdma_stream_job* j, hipStream_t s) {
     HIP_TRY(hipStreamWaitEvent(s, evX(R - 1), 0));
     HIP_TRY(hipStreamWaitEvent(s, evA(R - 1), 0));
   }
+  HIP_TRY(grdma_launch_tx_commit(j->d_txconns, nullptr, n, s));
   return 0;
 }
 
@@ -1687,7 +1832,7 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
       // burst rounds: strictly in order (one connection state, one receive pass per round)
       const uint32_t B = j->burst;
       const uint32_t txb_b = std::max<uint32_t>(1, std::min<uint32_t>(tx_blocks, grid_cap / (n * B) + 1));
-      const void* btx = j->d_btxop + (t == 0 ? 0 : (size_t)B * n);
+      const void* btx = j->d_btxop + (size_t)k * B * n;
       const void* bg = j->d_bplans;
       const void* bw = j->d_bplans + (size_t)B * n;
       hipGraphNode_t prev = at(A, t, 1);
@@ -1735,6 +1880,11 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
       }
       if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t], at(A, t, 1)});
     }
+  }
+  if (e == hipSuccess && R > 0) {
+    // behind the last round: the connection's arrival report and the state lines (k_tx_commit)
+    hipGraphNode_t cm;
+    e = add2(&cm, grdma_kernel_fn(5), dim3(n), 64, j->d_txconns, nullptr, {W[R - 1] ? W[R - 1] : G[R - 1], A[R - 1]});
   }
   if (e != hipSuccess) {
     hipGraphDestroy(g);
@@ -1849,6 +1999,7 @@ int job_engine_enqueue(grdma_stream_job* j, hipStream_t s) {
   for (auto& l : j->links)
     HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t*>(l.d_lk) + LK_DYNAMIC_OFFSET, 0, sizeof(lk_ctl) - LK_DYNAMIC_OFFSET, s));
   HIP_TRY(grdma_launch_link(j->d_lk_ptrs, (uint32_t)j->links.size(), j->lk_team, j->lk_timeout_ticks, s));
+  HIP_TRY(grdma_launch_tx_commit(j->d_txconns, nullptr, (uint32_t)j->links.size(), s));
   return 0;
 }
 
@@ -1927,7 +2078,8 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
   const size_t sz_tx = sizeof(grdma_tx_op) * 3 * n, sz_rx = sizeof(grdma_rx_op) * 3 * n;
   const size_t sz_txr = sizeof(grdma_tx_result) * n, sz_rxr = sizeof(grdma_rx_result) * 2 * n;
   const size_t sz_pl = sizeof(grdma_plan*) * 3 * n;
-  if (ok) ok = hipMalloc((void**)&j->d_ctl, sz_tx + sz_rx + sz_txr + sz_rxr + sz_pl) == hipSuccess;
+  const size_t sz_lim = sizeof(uint64_t) * 3 * n, sz_cn = sizeof(grdma_conn*) * n;
+  if (ok) ok = hipMalloc((void**)&j->d_ctl, sz_tx + sz_rx + sz_txr + sz_rxr + sz_pl + sz_lim + sz_cn) == hipSuccess;
   if (!ok) {
     if (g_err.empty()) fail(GRDMA_ERR_HIP, "stream job allocation failed");
     grdma_stream_job_destroy(j);
@@ -1938,7 +2090,9 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
   j->d_txres = reinterpret_cast<grdma_tx_result*>(j->d_ctl + sz_tx + sz_rx);
   j->d_rxres = reinterpret_cast<grdma_rx_result*>(j->d_ctl + sz_tx + sz_rx + sz_txr);
   j->d_plans = reinterpret_cast<const grdma_plan**>(j->d_ctl + sz_tx + sz_rx + sz_txr + sz_rxr);
-  std::vector<uint8_t> host(sz_tx + sz_rx + sz_txr + sz_rxr + sz_pl, 0);
+  j->d_limits = reinterpret_cast<uint64_t*>(j->d_ctl + sz_tx + sz_rx + sz_txr + sz_rxr + sz_pl);
+  j->d_txconns = reinterpret_cast<grdma_conn**>(j->d_ctl + sz_tx + sz_rx + sz_txr + sz_rxr + sz_pl + sz_lim);
+  std::vector<uint8_t> host(sz_tx + sz_rx + sz_txr + sz_rxr + sz_pl + sz_lim + sz_cn, 0);
   auto* h_tx = reinterpret_cast<grdma_tx_op*>(host.data());
   auto* h_rx = reinterpret_cast<grdma_rx_op*>(host.data() + sz_tx);
   auto** h_pl = reinterpret_cast<const grdma_plan**>(host.data() + sz_tx + sz_rx + sz_txr + sz_rxr);
@@ -1955,6 +2109,7 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
       t.staging_alt = odd ? l.d_staging2 : nullptr;
       t.result = &j->d_txres[i];
       t.use_cursor = k == 0 ? 2 : 1;
+      t.tail_out = &j->d_limits[k * n + i];
       grdma_rx_op& r = h_rx[k * n + i];
       r.conn = l.rx->d_conn;
       r.plan = odd ? l.d_rxplan2 : l.rx->d_rxplan;
@@ -1966,7 +2121,10 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
       r.raw_cap = 0;
       r.append = k == 0 ? 2 : 1;
       r.slices_cap = l.slices_cap;
+      r.limit_ptr = &j->d_limits[k * n + i];
     }
+  auto** h_cn = reinterpret_cast<grdma_conn**>(host.data() + sz_tx + sz_rx + sz_txr + sz_rxr + sz_pl + sz_lim);
+  for (uint32_t i = 0; i < n; i++) h_cn[i] = j->links[i].tx->d_conn;
   for (uint32_t i = 0; i < n; i++) {
     h_pl[i] = j->links[i].tx->d_txplan;
     h_pl[n + i] = j->links[i].tx->d_wireplan;   // even rounds
@@ -2071,7 +2229,7 @@ int grdma_stream_job_set_burst(grdma_stream_job* j, uint32_t burst) {
   j->d_bctl = nullptr;
   j->burst = 1;  // the plain schedule until the burst tables below are in place
   if (burst == 1) return 0;
-  const size_t sz_tx = sizeof(grdma_tx_op) * 2 * burst * n, sz_pl = sizeof(grdma_plan*) * 2 * burst * n;
+  const size_t sz_tx = sizeof(grdma_tx_op) * 3 * burst * n, sz_pl = sizeof(grdma_plan*) * 2 * burst * n;
   const size_t sz_res = sizeof(grdma_tx_result) * n;  // scratch results of the Sends before the last
   HIP_TRY(hipMalloc((void**)&j->d_bctl, sz_tx + sz_pl + sz_res));
   j->d_btxop = reinterpret_cast<grdma_tx_op*>(j->d_bctl);
@@ -2080,7 +2238,7 @@ int grdma_stream_job_set_burst(grdma_stream_job* j, uint32_t burst) {
   std::vector<uint8_t> host(sz_tx + sz_pl + sz_res, 0);
   auto* h_tx = reinterpret_cast<grdma_tx_op*>(host.data());
   auto** h_pl = reinterpret_cast<const grdma_plan**>(host.data() + sz_tx);
-  for (int set = 0; set < 2; set++)
+  for (int set = 0; set < 3; set++)
     for (uint32_t k = 0; k < burst; k++)
       for (uint32_t i = 0; i < n; i++) {
         const grdma_job_link& l = j->links[i];
@@ -2093,6 +2251,7 @@ int grdma_stream_job_set_burst(grdma_stream_job* j, uint32_t burst) {
         t.staging_alt = l.b_staging[k];
         t.result = k + 1 == burst ? &j->d_txres[i] : &scratch[i];
         t.use_cursor = (set == 0 && k == 0) ? 2 : 1;
+        t.tail_out = &j->d_limits[set * n + i];  // (the Sends of a burst run in order: the last one's stays)
       }
   for (uint32_t k = 0; k < burst; k++)
     for (uint32_t i = 0; i < n; i++) {

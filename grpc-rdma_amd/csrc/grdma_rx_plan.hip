@@ -57,6 +57,7 @@ struct chain_walker {
   uint64_t e0;      // encoded size of the record at pos when its header is already known
   uint64_t h2, h1;  // encoded sizes of the two records before pos (0 = unknown)
   bool dry;         // pos holds no complete record
+  uint64_t room;    // bytes from pos the sender has reported as landed (grdma_wire_report); 2^62 = no limit
 };
 
 // One probe round of the wave tier.  Lane j loads the tag words at the offset the
@@ -90,8 +91,10 @@ __device__ __forceinline__ uint32_t chain_round(chain_walker* w, uint64_t* chain
   uint64_t hdr = 0, prev = 0;
   if (probe_hdr) hdr = ld_tag(w->ring + my_pos);
   if (probe_prev) prev = ld_tag(w->ring + ((my_pos + cap - 8) & mask));  // footer of record j-1
-  const bool valid = probe_hdr && hdr != 0 && hdr <= cap - GRDMA_RESERVED;
   const uint64_t enc = 16 + round_up8(hdr);
+  // (a record the sender has not reported as complete is not there yet: its tags may be in place while a
+  // tile of its payload is still in flight)
+  const bool valid = probe_hdr && hdr != 0 && hdr <= cap - GRDMA_RESERVED && rel + enc <= w->room;
   const bool link_ok = valid && have_pattern && lane < 63 && enc == rel_next - rel;
   const uint64_t m_link = __ballot(link_ok);
   const uint64_t m_foot = __ballot(probe_prev && prev == GRDMA_FOOTER) >> 1;  // bit j: footer of j
@@ -114,6 +117,7 @@ __device__ __forceinline__ uint32_t chain_round(chain_walker* w, uint64_t* chain
     w->h1 = enc_l1;
   }
   w->pos = (w->pos + (v < 64 ? rel_v : rel_v + enc_v)) & mask;
+  w->room -= (v < 64 ? rel_v : rel_v + enc_v);
   w->e0 = 0;
   if (v < 64) {
     const bool v_hprobed = (m_hprobed >> v) & 1;
@@ -252,6 +256,14 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
   const uint64_t cap = c->cap, mask = cap - 1;
   const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap);  // tile size of this connection's plans
   const bool connected = c->status == GRDMA_PAIR_CONNECTED;
+  // How far the sender's completed writes reach (grdma_wire_report), read once: what lands while this
+  // drain runs belongs to the next one.  room_at(pos) = bytes from ring offset pos that may be walked.
+  const bool limited = op.limit_ptr != nullptr || c->wire_limit != 0;
+  const uint64_t lim_tail = !limited ? 0
+                            : (op.limit_ptr != nullptr
+                                   ? __hip_atomic_load(op.limit_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : __hip_atomic_load(&c->wire_recv.wire_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  auto room_at = [&](uint64_t pos) -> uint64_t { return limited ? ((lim_tail - pos) & mask) : (1ull << 62); };
 
   __shared__ rx_state S;
   __shared__ uint64_t s_chain[CHAIN_CAP];
@@ -299,7 +311,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
   if (op.inline_apply && op.raw_cap == 0 && !op.append && connected && wave == 0 && c->remain == 0 &&
       max_slices >= 1) {
     const uint64_t head0 = c->head, leftover0 = c->leftover_cap, irs0 = c->internal_read_size;
-    chain_walker w = {ring, cap, head0, 0, c->rx_h2, c->rx_h1, false};
+    chain_walker w = {ring, cap, head0, 0, c->rx_h2, c->rx_h1, false, room_at(head0)};
     const uint32_t v = chain_round(&w, s_chain, lane);
     const bool all_seen = w.dry && v <= EXPRESS_MAX;
     const uint32_t n = ((uint32_t)lane < v && all_seen) ? (uint32_t)s_chain[lane] : 0;
@@ -592,6 +604,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
       if (r_sg < vmax) vmax = r_sg;
     }
     const uint64_t arena_room = op.arena_cap > S.a_off + 1024 ? op.arena_cap - S.a_off - 1024 : 0;
+    const uint64_t wire_room = room_at(head);
     {
       // One 16-byte load per record: the footer of record i and the header of record i + 1
       // are neighbouring words of the ring, so thread i fetches both at once and checks the
@@ -620,7 +633,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
       for (int r = 0; r < NP; r++) {
         const uint32_t i = tid + r * PLAN_THREADS;
         const uint64_t x = s_xenc[RXP(i)], e = s_penc[RXP(i)];
-        want[r] = i < vmax && x + e <= cap - 8 && x + e + 32ull * (i + 1) <= arena_room;
+        want[r] = i < vmax && x + e <= cap - 8 && x + e <= wire_room && x + e + 32ull * (i + 1) <= arena_room;
         // (unconditional: a masked offset is always inside the ring, and straight-line
         // loads are all issued before the first wait; a footer in the last word of the
         // ring is read as the second half of the pair one word earlier)
@@ -948,13 +961,14 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     bool blocked = S.bulk_blocked != 0;
     uint64_t n_rounds = 0, n_fast = 0, n_scalar = 0;
 
-    chain_walker w = {ring, cap, head, 0, 0, 0, false};
+    chain_walker w = {ring, cap, head, 0, 0, 0, false, room_at(head)};
     if (hist_count >= 1) w.h1 = s_hist[(hist_count - 1) % GRDMA_RX_HIST];
     if (hist_count >= 2) w.h2 = s_hist[(hist_count - 2) % GRDMA_RX_HIST];
     uint32_t chain_n = 0, chain_i = 0;
     if (S.hand_on) {  // what the last bulk pass verified beyond the records it took
       chain_n = S.hand_n;
       w.pos = S.hand_pos;
+      w.room = room_at(w.pos);
       w.dry = S.hand_dry != 0;
       const uint32_t V = S.hand_v;  // sizes of the two records in front of w.pos
       if (V >= 2) {
@@ -1312,6 +1326,10 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
     c->head = head;
     c->moving_head = mh;
     c->remain = S.remain;
+    if (c->line != nullptr) {  // what HasMessage() on the host compares with the sender's arrival report
+      c->line->rx_head = head;
+      c->line->rx_remain = S.remain;
+    }
     c->internal_read_size = S.irs;
     c->leftover_cap = S.leftover;
     c->total_read = o_total_read + S.bytes;
@@ -1372,6 +1390,9 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
         grdma_status_report* ps = c->peer_status;
         if (ps != nullptr)
           __hip_atomic_store(&ps->remote_head, S.credit_head, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+        if (c->peer_line != nullptr)
+          __hip_atomic_store(&c->peer_line->remote_head, S.credit_head, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_SYSTEM);
       }
       __hip_atomic_store(&res->commit_seq, op.seq_next ? op.seq_next : res->commit_seq + 1, __ATOMIC_RELAXED,

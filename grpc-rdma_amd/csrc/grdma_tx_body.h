@@ -7,6 +7,22 @@
 
 namespace {
 
+// The sender's side of grdma_wire_report / grdma_hostline: called by ONE thread once every byte of a Send
+// has landed in the peer ring (all waves of the caller have waited for their stores and met at a barrier,
+// or the wire kernel in front of k_tx_commit has completed).  tail = remote_tail_ after the Send.
+__device__ __forceinline__ void tx_publish(grdma_conn* c, uint64_t tail, uint64_t partial, uint64_t seq) {
+  uint64_t* pw = c->peer_wire;
+  if (pw != nullptr) __hip_atomic_store(pw, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  grdma_hostline* pl = c->peer_line;
+  if (pl != nullptr) __hip_atomic_store(&pl->wire_tail, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  grdma_hostline* ln = c->line;
+  if (ln != nullptr) {
+    __hip_atomic_store(&ln->remote_tail, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&ln->partial_write, partial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (seq) __hip_atomic_store(&ln->tx_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ----------------------------------------------------------------------------
 // Small sends (<= 64 slices, <= 64 KiB): the whole of PairPollable::Send on ONE
 // wavefront, lane i = slice i.  Same arithmetic as the block-wide plan below
@@ -221,10 +237,13 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     r->staged = staged;
     r->partial = connected ? (sent < offered ? 1 : 0) : c->partial_write;
     r->new_remote_tail = new_tail;
+    if (op.tail_out != nullptr) *op.tail_out = new_tail;
     r->slice_idx = idx;
     r->byte_idx = bidx;
     r->done = (idx >= op.nslices) ? 1 : 0;
     const uint64_t tk5 = __builtin_amdgcn_s_memtime();  // (bookkeeping stores issued)
+    // (the wave has waited for every copy above: the arrival report may go out)
+    tx_publish(c, new_tail, connected ? (sent < offered ? 1 : 0) : c->partial_write, 0);
     // the peer reads the ring in a later command / kernel; the host needs the result
     // block (pinned memory): a system-scope release on the sequence word covers it
     __hip_atomic_store(&r->seq, op.seq_next ? op.seq_next : r->seq + 1, __ATOMIC_RELEASE,
@@ -573,6 +592,7 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
     r->staged = staged;
     r->partial = connected ? (sent < offered ? 1 : 0) : c->partial_write;
     r->new_remote_tail = new_tail;
+    if (op.tail_out != nullptr) *op.tail_out = new_tail;
     r->slice_idx = idx;
     r->byte_idx = bidx;
     r->done = (idx >= op.nslices) ? 1 : 0;
@@ -598,6 +618,9 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
   }
   if (tid == 0) {
     grdma_tx_result* r = op.result;
+    // one launch did it all (gather and wire included, every wave has waited for its stores): the
+    // arrival report goes out here; otherwise k_tx_commit follows the wire kernel
+    if (op.inline_copy) tx_publish(c, c->remote_tail, c->partial_write, 0);
     const uint64_t nxt = op.seq_next ? op.seq_next : r->seq + 1;
     __hip_atomic_store(&r->seq, nxt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -663,6 +686,7 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
         r->staged = 0;
         r->partial = partial;
         r->new_remote_tail = tail;
+        if (op.tail_out != nullptr) *op.tail_out = tail;
         r->slice_idx = idx;
         r->byte_idx = bidx;
         r->done = idx >= nslices ? 1 : 0;
@@ -792,6 +816,7 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
       r->staged = staged;
       r->partial = npartial;
       r->new_remote_tail = new_tail;
+      if (op.tail_out != nullptr) *op.tail_out = new_tail;
       r->slice_idx = nidx;
       r->byte_idx = nbidx;
       r->done = nidx >= nslices ? 1 : 0;

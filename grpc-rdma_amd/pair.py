@@ -9,6 +9,7 @@ from ._lib import GrdmaError, PairState, ReadSlice, Slice, check, load
 
 MEM_DEVICE, MEM_HOST = 0, 1
 WIRE_STAGED, WIRE_DIRECT = 0, 2
+RING_FINE_GRAINED, WIRE_ORDERED = 4, 8
 
 
 class DeviceBuffer:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GRDMA_ABI_VERSION 1
+#define GRDMA_ABI_VERSION 2
 
 enum grdma_error {
   GRDMA_OK = 0,
@@ -94,6 +94,12 @@ enum grdma_flags {
   GRDMA_WIRE_STAGED = 0,  /* records are built in the staging buffer, then written
                              to the peer ring by <=2 wire writes (what a NIC needs) */
   GRDMA_WIRE_DIRECT = 2,  /* loop-back / xGMI peer: encode straight into the ring  */
+  GRDMA_WIRE_ORDERED = 8, /* what writes into THIS pair's ring places the bytes of a write in address order, the
+                             footer last -- an RDMA NIC (the reference's wire): header + footer say "complete",
+                             as ring_buffer.cc:67-97 assumes.  Without the flag the writer is taken to be a HIP
+                             wire (copy kernel, IPC / xGMI peer): a PARALLEL copy, whose sender reports how far
+                             its completed writes reach (csrc/grdma_dev.h: grdma_wire_report) and whose receiver
+                             never walks past that report */
   GRDMA_RING_FINE_GRAINED = 4  /* allocate the ring (and the connection block holding the 16-byte
                              status report) as fine-grained device memory
                              (hipExtMallocWithFlags, hipDeviceMallocFinegrained): stores are
@@ -128,7 +134,7 @@ typedef struct grdma_bootstrap_blob {
   grdma_address addr;
   uint32_t magic, version;              /* "GRDM", GRDMA_ABI_VERSION                              */
   int32_t hip_device;
-  uint32_t pad;
+  uint32_t wire_off;                    /* offset of the arrival report (grdma_wire_report) in the conn block */
   uint64_t pid;
   uint64_t status_off;                  /* offset of the 16-byte status_report in the conn block  */
   uint8_t ring_handle[64];              /* hipIpcMemHandle_t of the ring                          */

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_python_binding_table_covers_the_core_abi(built):
     names = set(declared_functions())
     assert set(_lib.SIGNATURES) <= names
-    assert g.load().grdma_abi_version() == 1
+    assert g.load().grdma_abi_version() == 2
 
 
 def test_no_device_fails_loudly(built):

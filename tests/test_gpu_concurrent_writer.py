@@ -90,7 +90,8 @@ def test_concurrent_writer_never_yields_partial_records(gpu, seed):
     for i in range(90):
         n = rng.choice([1, 7, 8, 9, 200, 255, 256, 257, 1000, 4096, 9000])
         payloads.append(bytes((i * 31 + j) % 251 for j in range(n)))
-    a, b = g.Pair(R, 30), g.Pair(R, 30)
+    # (the second thread plays a NIC: bytes in address order, the footer last, no arrival report -- GRDMA_WIRE_ORDERED)
+    a, b = g.Pair(R, 30, flags=8), g.Pair(R, 30, flags=8)
     g.connect_pairs(a, b)
     consumed = [0]
     w = RingWriter(g, b, R, payloads, consumed, seed)
