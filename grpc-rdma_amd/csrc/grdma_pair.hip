@@ -16,6 +16,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <poll.h>
 #include <signal.h>
@@ -78,6 +79,7 @@ struct grdma_engine {
   hipStream_t stream = nullptr;
   bool wanted = false;   // grdma_engine_start() was called
   uint64_t seq = 0;
+  uint64_t posted = 0;   // last command written into the mailbox (== seq while one may still be running)
 };
 grdma_engine g_engine;
 
@@ -162,6 +164,15 @@ struct grdma_hostblk {
   uint64_t refresh_out[4];         // readable, ready mask, has-message mask, trigger mask
 };
 
+// One receive window of an asynchronous endpoint: the slices of one drain, in pinned host memory the scatter kernel
+// writes over PCIe.  Reference-counted: the pair holds one reference, every slice handed to the transport another
+// (it may outlive the endpoint).
+struct grdma_window {
+  uint8_t* base = nullptr;
+  uint64_t bytes = 0;
+  std::atomic<int> refs{1};
+};
+
 struct grdma_pair {
   uint64_t ring_size = 0;
   int max_sge = 0;
@@ -178,7 +189,8 @@ struct grdma_pair {
   bool latency = false;              // fused single-launch kernels + spin on pinned seq words
   bool cmd_inline = false;           // the current slice list lives in h_cmd (small host message)
   uint8_t* h_arena = nullptr;        // pinned receive arena used in latency mode
-  grdma_engine_cmd* h_cmd = nullptr; // pinned self-contained command block (latency engine)
+  grdma_engine_cmd* h_cmd = nullptr; // pinned self-contained command block (latency engine): sends
+  grdma_engine_cmd* h_cmd_rx = nullptr;  // the same for this pair's own drains (the read side may run on another thread)
   uint64_t h_arena_cap = 0;
   grdma_hostblk* h = nullptr;        // pinned
   grdma_hostline* line = nullptr;    // pinned: what the read-only queries load (grdma_hostline)
@@ -214,6 +226,19 @@ struct grdma_pair {
   uint64_t armed_reads = 0;          // max_reads of the armed drain, 0 = not armed
   bool armed_done = false;           // a chained drain has completed and nobody has consumed it yet
   uint64_t armed_hits = 0;
+  // asynchronous endpoint operations (grdma_endpoint_set_async): the send and the receive direction on streams of
+  // their own, one Send and one drain in flight at most, completions in pinned host memory
+  bool async = false;
+  hipStream_t s_tx = nullptr, s_rx = nullptr;
+  std::vector<grdma_window*> windows;   // receive windows (pinned host memory), one drain each
+  std::atomic<int> rx_inflight{-1};     // window of the drain in flight, -1 = none
+  std::atomic<uint64_t> rx_expect{0};   // rxres.commit_seq that says it has completed
+  std::atomic<int> tx_inflight{0};
+  uint64_t tx_expect = 0;               // line->tx_seq (launch chain) or txres.seq (engine command) of the Send in flight
+  bool tx_by_engine = false;
+  std::mutex rx_mu;                     // receive-side submission state: the armed read lets the PEER's sender post my drain
+  std::atomic<uint64_t> armed_async{0}; // standing order of an asynchronous endpoint: max_reads, 0 = none
+  uint64_t test_calls = 0, test_calls_rx = 0;
   // endpoint_write context
   std::vector<grdma_slice> w_slices;
   uint64_t w_idx = 0, w_byte = 0;
@@ -227,6 +252,62 @@ int fetch_conn(grdma_pair* p, grdma_conn* out) {
   HIP_TRY(hipStreamSynchronize(p->stream));
   HIP_TRY(hipMemcpy(out, p->d_conn, sizeof(grdma_conn), hipMemcpyDeviceToHost));
   return 0;
+}
+
+// Registration cache for large host slices (grdma_set_host_register_min): page ranges registered with the device
+// once, looked up by address afterwards.  Small, MRU-ordered, shared by all pairs of the process.
+struct reg_entry { uintptr_t lo, hi; uint8_t* dev; };
+struct reg_cache {
+  std::mutex mu;
+  std::vector<reg_entry> e;
+  std::atomic<uint64_t> min_bytes{0};
+  bool env_read = false;
+};
+reg_cache g_reg;
+
+uint64_t register_min() {
+  if (!g_reg.env_read) {
+    std::lock_guard<std::mutex> lk(g_reg.mu);
+    if (!g_reg.env_read) {
+      if (const char* v = getenv("GRPC_RDMA_HIP_REGISTER_MIN")) g_reg.min_bytes.store(strtoull(v, nullptr, 10));
+      g_reg.env_read = true;
+    }
+  }
+  return g_reg.min_bytes.load(std::memory_order_relaxed);
+}
+
+// device-visible address of [ptr, ptr + len), registering the pages if need be; nullptr = copy instead
+const uint8_t* registered_view(const void* ptr, uint64_t len) {
+  const uintptr_t a = (uintptr_t)ptr, lo = a & ~(uintptr_t)4095, hi = (a + len + 4095) & ~(uintptr_t)4095;
+  std::lock_guard<std::mutex> lk(g_reg.mu);
+  for (size_t i = 0; i < g_reg.e.size(); i++) {
+    if (g_reg.e[i].lo <= a && a + len <= g_reg.e[i].hi) {
+      const reg_entry hit = g_reg.e[i];
+      if (i) {  // move to front
+        g_reg.e.erase(g_reg.e.begin() + (long)i);
+        g_reg.e.insert(g_reg.e.begin(), hit);
+      }
+      return hit.dev + (a - hit.lo);
+    }
+  }
+  // (a range that overlaps a registered one cannot be registered again: such a slice is copied)
+  for (const reg_entry& r : g_reg.e)
+    if (lo < r.hi && r.lo < hi) return nullptr;
+  if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, (void*)lo, 0) != hipSuccess || !dev) {
+    hipHostUnregister((void*)lo);
+    return nullptr;
+  }
+  if (g_reg.e.size() >= 256) {  // forget the least recently used range
+    hipHostUnregister((void*)g_reg.e.back().lo);
+    g_reg.e.pop_back();
+  }
+  g_reg.e.insert(g_reg.e.begin(), reg_entry{lo, hi, static_cast<uint8_t*>(dev)});
+  return static_cast<uint8_t*>(dev) + (a - lo);
 }
 
 // Fill the device-visible slice table.  For GRDMA_MEM_HOST the first
@@ -259,10 +340,18 @@ int stage_slices(grdma_pair* p, const grdma_slice* slices, uint64_t count, uint6
   if (flags & GRDMA_MEM_HOST) {
     const uint64_t cap = p->ring_size / 2;
     if (!p->h_bounce) HIP_TRY(hipHostMalloc((void**)&p->h_bounce, cap + 64, hipHostMallocCoherent | hipHostMallocMapped));
+    const uint64_t reg_min = register_min();
     uint64_t off = 0;
     for (uint64_t i = 0; i < count; i++) {
       const uint8_t* src = static_cast<const uint8_t*>(slices[i].ptr);
       uint64_t len = slices[i].len;
+      if (reg_min && len >= reg_min) {  // read where it lies: the gather kernel pulls it over PCIe
+        if (const uint8_t* dv = registered_view(src, len)) {
+          p->h_sges[i].ptr = dv;
+          p->h_sges[i].len = len;
+          continue;
+        }
+      }
       uint64_t sk = (i == 0) ? skip_first : 0;  // bytes before byte_idx are never read
       uint64_t room = cap > off ? cap - off : 0;
       uint64_t n = len > sk ? len - sk : 0;
@@ -337,11 +426,46 @@ size_t pack_fast(uint64_t type, const grdma_engine_cmd* blk, uint64_t* words) {
 }
 static_assert(sizeof(grdma_tx_op) % 8 == 0 && sizeof(grdma_rx_op) % 8 == 0, "ops are packed as 8-byte words");
 
-// Hand one command to the resident engine and wait for it.
-int engine_submit(uint64_t type, const void* op) {
+// Wait until the engine has acknowledged command `seq` (engine.mu held).
+int engine_wait_locked(uint64_t seq) {
+  grdma_engine& e = g_engine;
+  volatile uint64_t* ack = &e.mb->ack_seq;
+  volatile uint64_t* alive = &e.mb->alive;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spins = 0;; spins++) {
+    if (*ack == seq) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return 0;
+    }
+    if ((spins & 0x3FF) == 0x3FF) {
+      if (!*alive && *ack != seq) {  // the engine timed out just before the doorbell
+        if (int rc = engine_launch()) return rc;
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) {
+        *(volatile uint64_t*)&e.mb->exit_flag = 1;
+        const uint64_t a = *ack, polls = e.mb->pad1[0];
+        // Every incarnation of the engine resumes behind ack_seq and only takes the command numbered ack_seq + 1:
+        // once it has left, forget the command that was never answered, or every later one would time out too.
+        if (hipStreamSynchronize(e.stream) == hipSuccess) {
+          *(volatile uint64_t*)&e.mb->ack_seq = e.seq;
+          e.posted = e.seq;
+        }
+        return fail(GRDMA_ERR_HIP, "latency engine did not answer: alive=%llu ack=%llu seq=%llu polls=%llu",
+                    (unsigned long long)*alive, (unsigned long long)a, (unsigned long long)seq, (unsigned long long)polls);
+      }
+    }
+  }
+}
+
+// Hand one command to the resident engine WITHOUT waiting for it (the mailbox holds one command: the one posted
+// before must have been acknowledged, which this waits for).  The caller finds the completion in its result block.
+int engine_post(uint64_t type, const void* op) {
   grdma_engine& e = g_engine;
   std::lock_guard<std::mutex> lk(e.mu);
   if (int rc = engine_launch()) return rc;
+  if (e.posted != 0 && e.posted == e.seq) {
+    if (int rc = engine_wait_locked(e.posted)) return rc;
+  }
   uint64_t words[GRDMA_FAST_WORDS];
   const size_t nw = (type == GRDMA_ENGINE_SEND_INLINE || type == GRDMA_ENGINE_DRAIN_BLOCK ||
                      type == GRDMA_ENGINE_SEND_INLINE_DRAIN)
@@ -361,26 +485,16 @@ int engine_submit(uint64_t type, const void* op) {
     std::atomic_thread_fence(std::memory_order_release);
     *(volatile uint64_t*)&e.mb->cmd_seq = seq;
   }
-  volatile uint64_t* ack = &e.mb->ack_seq;
-  volatile uint64_t* alive = &e.mb->alive;
-  const auto t0 = std::chrono::steady_clock::now();
-  for (uint64_t spins = 0;; spins++) {
-    if (*ack == seq) {
-      std::atomic_thread_fence(std::memory_order_acquire);
-      return 0;
-    }
-    if ((spins & 0x3FF) == 0x3FF) {
-      if (!*alive && *ack != seq) {  // the engine timed out just before the doorbell
-        if (int rc = engine_launch()) return rc;
-      }
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) {
-        *(volatile uint64_t*)&e.mb->exit_flag = 1;
-        return fail(GRDMA_ERR_HIP, "latency engine did not answer: alive=%llu ack=%llu seq=%llu polls=%llu",
-                    (unsigned long long)*alive, (unsigned long long)*ack, (unsigned long long)seq,
-                    (unsigned long long)e.mb->pad1[0]);
-      }
-    }
-  }
+  e.posted = seq;
+  return 0;
+}
+
+// Hand one command to the resident engine and wait for it.
+int engine_submit(uint64_t type, const void* op) {
+  if (int rc = engine_post(type, op)) return rc;
+  grdma_engine& e = g_engine;
+  std::lock_guard<std::mutex> lk(e.mu);
+  return engine_wait_locked(e.posted);
 }
 
 int engine_stop() {
@@ -619,6 +733,9 @@ void grdma_pair_destroy(grdma_pair* p) {
   hipFree(p->d_arena);
   hipFree(p->d_hist);
   hipFree(p->d_zc);
+  if (p->s_tx) { hipStreamSynchronize(p->s_tx); hipStreamDestroy(p->s_tx); }
+  if (p->s_rx) { hipStreamSynchronize(p->s_rx); hipStreamDestroy(p->s_rx); }
+  for (grdma_window* w : p->windows) grdma_window_unref(w);  // (slices the transport still holds keep theirs)
   if (p->refresh_stream) {
     hipStreamSynchronize(p->refresh_stream);  // a refresh pass in flight writes the line
     hipStreamDestroy(p->refresh_stream);
@@ -954,99 +1071,66 @@ int grdma_poll_pairs(grdma_pair* const* pairs, uint32_t n, uint64_t* readable,
 }  // extern "C"
 
 struct grdma_poller {
-  std::mutex mu;
+  // the slot table of Poller (poller.h:60-66): a hole is a free slot (RemovePollable leaves one, poller.cc:45-54)
+  std::shared_mutex mu;             // shared: a thread looks at one slot; exclusive: add / remove
+  std::vector<grdma_pair*> pairs;
+  std::atomic<uint32_t> curr{0};    // curr_: the threads share one round-robin cursor (poller.cc:66-69)
+  std::atomic<uint32_t> n_pairs{0};
+  std::mutex cv_mu;
   std::condition_variable cv;
-  std::vector<grdma_pair*> pairs;  // slot == nullptr: free (RemovePollable leaves a hole, poller.cc:45-54)
   std::atomic<bool> running{true};
   std::atomic<uint64_t> wakeups{0}, passes{0};
-  uint64_t pass_started = 0;               // under mu: passes whose snapshot has been taken
-  std::atomic<uint64_t> pass_finished{0};  // passes that no longer touch their snapshot
-  std::thread th;
+  std::vector<std::thread> threads; // GRPC_RDMA_POLLER_THREAD_NUM of them
   int sleep_ms = 1000;
   int device = 0;
-  std::atomic<bool> failed{false};  // the polling thread hit a HIP error and stopped
-  std::string failure;              // what it was (set before `failed`)
 };
 
 namespace {
 
-// A poller whose thread died must not look healthy: remember why, and kick every registered
-// wakeup fd once so that blocked readers come back and find the failure in poller_stats / add.
-void poller_fail(grdma_poller* pl, const char* what, hipError_t e) {
-  pl->failure = std::string(what) + ": " + hipGetErrorString(e);
-  pl->failed.store(true, std::memory_order_release);
-  std::lock_guard<std::mutex> lk(pl->mu);
-  for (grdma_pair* p : pl->pairs) {
-    if (!p || p->wakeup_fd < 0) continue;
-    const uint64_t one = 1;
-    (void)!write(p->wakeup_fd, &one, sizeof(one));
-  }
-}
-
-void poller_loop(grdma_poller* pl) {
-  hipError_t he;
-  if ((he = hipSetDevice(pl->device)) != hipSuccess) return poller_fail(pl, "hipSetDevice", he);
-  hipStream_t s = nullptr;
-  if ((he = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess)
-    return poller_fail(pl, "hipStreamCreate", he);
-  grdma_conn** h_conns = nullptr;
-  uint64_t* h_words = nullptr;  // readable[cap] | ready[cap/64] | has[cap/64] | trigger[cap/64]
-  uint32_t cap = 0;
-  std::vector<grdma_pair*> snap;
+// Poller::begin_polling (poller.cc:52-106): every thread takes the next slot of the shared cursor and kicks the
+// pair's wakeup fd when the pair is connected and readable or writable, or half-closed / in error -- unless the
+// fd is still signalled (the consumer has not read it: poller.cc:76-78).  What it looks at is the pair's host-visible
+// state (grdma_endpoint_readable / _writable / get_status: plain loads), so a pass costs no device work for a pair
+// whose peer lives in this process; for a remote peer the queries keep one refresh pass of k_poll in flight.
+void poller_loop(grdma_poller* pl, int /*poller_id*/) {
+  hipSetDevice(pl->device);  // (the refresh pass of a remote pair is launched from here)
+  uint32_t idle = 0;
   while (pl->running.load(std::memory_order_acquire)) {
+    if (pl->n_pairs.load(std::memory_order_acquire) == 0) {  // poller.cc:58-63
+      std::unique_lock<std::mutex> lk(pl->cv_mu);
+      pl->cv.wait_for(lk, std::chrono::milliseconds(pl->sleep_ms),
+                      [&] { return !pl->running.load() || pl->n_pairs.load() != 0; });
+      continue;
+    }
+    bool kicked = false;
     {
-      std::unique_lock<std::mutex> lk(pl->mu);
-      snap.clear();
-      for (grdma_pair* p : pl->pairs)
-        if (p) snap.push_back(p);
-      if (snap.empty()) {  // poller.cc:58-63
-        pl->cv.wait_for(lk, std::chrono::milliseconds(pl->sleep_ms));
-        continue;
-      }
-      pl->pass_started++;
-    }
-    struct pass_guard {  // whatever way the pass ends, RemovePollable may stop waiting for it
-      grdma_poller* pl;
-      ~pass_guard() { pl->pass_finished.fetch_add(1, std::memory_order_release); }
-    } guard{pl};
-    const uint32_t n = (uint32_t)snap.size();
-    if (n > cap) {
-      if (h_conns) hipHostFree(h_conns);
-      if (h_words) hipHostFree(h_words);
-      cap = (n + 63) & ~63u;
-      if ((he = hipHostMalloc((void**)&h_conns, sizeof(void*) * cap, hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess ||
-          (he = hipHostMalloc((void**)&h_words, sizeof(uint64_t) * (cap + 3 * (cap / 64)),
-                              hipHostMallocCoherent | hipHostMallocMapped)) != hipSuccess) {
-        poller_fail(pl, "hipHostMalloc", he);
-        break;
+      std::shared_lock<std::shared_mutex> lk(pl->mu);
+      const size_t n = pl->pairs.size();
+      if (n == 0) continue;
+      const uint32_t at = pl->curr.fetch_add(1, std::memory_order_relaxed);
+      grdma_pair* p = pl->pairs[at % n];
+      if (at % n == 0) pl->passes.fetch_add(1, std::memory_order_relaxed);
+      if (p != nullptr && p->wakeup_fd >= 0) {
+        const uint32_t st = status_now(p);
+        const bool trigger = st == GRDMA_PAIR_CONNECTED
+                                 ? (grdma_endpoint_readable(p) > 0 || grdma_endpoint_writable(p) > 0)
+                                 : (st == GRDMA_PAIR_HALF_CLOSED || st == GRDMA_PAIR_ERROR);
+        if (trigger) {
+          struct pollfd pfd = {p->wakeup_fd, POLLIN, 0};
+          if (poll(&pfd, 1, 0) <= 0) {  // not signalled yet
+            const uint64_t one = 1;
+            if (write(p->wakeup_fd, &one, sizeof(one)) == (ssize_t)sizeof(one)) {
+              pl->wakeups.fetch_add(1, std::memory_order_relaxed);
+              kicked = true;
+            }
+          }
+        }
       }
     }
-    for (uint32_t i = 0; i < n; i++) h_conns[i] = snap[i]->d_conn;
-    uint64_t* ready = h_words + cap;
-    uint64_t* has = ready + cap / 64;
-    uint64_t* trig = has + cap / 64;
-    if ((he = grdma_launch_poll(h_conns, n, h_words, ready, has, trig, s)) != hipSuccess) {
-      poller_fail(pl, "k_poll launch", he);
-      break;
-    }
-    if ((he = hipStreamSynchronize(s)) != hipSuccess) {
-      poller_fail(pl, "k_poll", he);
-      break;
-    }
-    pl->passes.fetch_add(1, std::memory_order_relaxed);
-    for (uint32_t i = 0; i < n; i++) {
-      if (!((trig[i / 64] >> (i % 64)) & 1)) continue;
-      const int fd = snap[i]->wakeup_fd;
-      if (fd < 0) continue;
-      struct pollfd pfd = {fd, POLLIN, 0};
-      if (poll(&pfd, 1, 0) > 0) continue;  // already signalled and not consumed yet (poller.cc:76-78)
-      const uint64_t one = 1;
-      if (write(fd, &one, sizeof(one)) == (ssize_t)sizeof(one)) pl->wakeups.fetch_add(1, std::memory_order_relaxed);
-    }
+    // (the reference spins at full speed; a poller that has found nothing for a while yields its core)
+    if (kicked) idle = 0;
+    else if (++idle > 4096) std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
-  if (h_conns) hipHostFree(h_conns);
-  if (h_words) hipHostFree(h_words);
-  hipStreamDestroy(s);
 }
 
 }  // namespace
@@ -1076,71 +1160,63 @@ grdma_poller* grdma_poller_create(int n_threads, int sleep_timeout_ms) {
     fail(GRDMA_ERR_CONFIG, "poller thread count must be positive");
     return nullptr;
   }
+  if (n_threads > 64) n_threads = 64;
   grdma_poller* pl = new grdma_poller();
   pl->sleep_ms = sleep_timeout_ms > 0 ? sleep_timeout_ms : 1000;
   pl->device = g_ctx.device;
-  pl->th = std::thread(poller_loop, pl);
+  for (int i = 0; i < n_threads; i++) pl->threads.emplace_back(poller_loop, pl, i);  // poller.h:24-28
   return pl;
 }
 
 int grdma_poller_add(grdma_poller* pl, grdma_pair* p) {  // Poller::AddPollable, poller.cc:12-43
   if (!pl || !p) return fail(GRDMA_ERR_INVALID, "null argument");
-  if (pl->failed.load(std::memory_order_acquire))
-    return fail(GRDMA_ERR_HIP, "the poller thread has stopped: %s", pl->failure.c_str());
   const int fd = grdma_pair_get_wakeup_fd(p);
   if (fd < 0) return fd;
   {
-    std::lock_guard<std::mutex> lk(pl->mu);
+    std::unique_lock<std::shared_mutex> lk(pl->mu);
     size_t slot = 0;
     for (; slot < pl->pairs.size(); slot++)
       if (pl->pairs[slot] == nullptr) break;
     if (slot == pl->pairs.size()) {
-      if (pl->pairs.size() >= 4096) return fail(GRDMA_ERR_CAPACITY, "poller is full");
+      if (pl->pairs.size() >= 4096) return fail(GRDMA_ERR_CAPACITY, "poller is full");  // GRPC_IBVERBS_POLLER_CAPACITY
       pl->pairs.push_back(p);
     } else {
       pl->pairs[slot] = p;
     }
+    pl->n_pairs.fetch_add(1, std::memory_order_release);
   }
-  pl->cv.notify_one();
+  pl->cv.notify_all();
   return fd;
 }
 
 int grdma_poller_remove(grdma_poller* pl, grdma_pair* p) {  // Poller::RemovePollable, poller.cc:45-54
   if (!pl || !p) return fail(GRDMA_ERR_INVALID, "null argument");
-  uint64_t started = 0;
-  bool found = false;
-  {
-    std::lock_guard<std::mutex> lk(pl->mu);
-    for (auto& q : pl->pairs)
-      if (q == p) {
-        q = nullptr;
-        found = true;
-        break;
-      }
-    started = pl->pass_started;
-  }
-  if (!found) return fail(GRDMA_ERR_INVALID, "pair is not registered with this poller");
-  // a pass that took its snapshot before the removal may still be looking at the pair:
-  // it is safe to destroy the pair once every such pass has finished
-  while (pl->pass_finished.load(std::memory_order_acquire) < started && pl->running.load())
-    std::this_thread::sleep_for(std::chrono::microseconds(50));
-  return 0;
+  // exclusive: no thread is looking at the pair when this returns, so it may be destroyed
+  std::unique_lock<std::shared_mutex> lk(pl->mu);
+  for (auto& q : pl->pairs)
+    if (q == p) {
+      q = nullptr;
+      pl->n_pairs.fetch_sub(1, std::memory_order_release);
+      return 0;
+    }
+  return fail(GRDMA_ERR_INVALID, "pair is not registered with this poller");
 }
 
 int grdma_poller_stats(grdma_poller* pl, uint64_t* passes, uint64_t* wakeups) {
   if (!pl) return fail(GRDMA_ERR_INVALID, "null poller");
   if (passes) *passes = pl->passes.load();
   if (wakeups) *wakeups = pl->wakeups.load();
-  if (pl->failed.load(std::memory_order_acquire))
-    return fail(GRDMA_ERR_HIP, "the poller thread has stopped: %s", pl->failure.c_str());
   return 0;
 }
+
+int grdma_poller_threads(grdma_poller* pl) { return pl ? (int)pl->threads.size() : -1; }
 
 void grdma_poller_destroy(grdma_poller* pl) {  // Poller::Shutdown, poller.h:37-50
   if (!pl) return;
   pl->running.store(false, std::memory_order_release);
   pl->cv.notify_all();
-  if (pl->th.joinable()) pl->th.join();
+  for (std::thread& t : pl->threads)
+    if (t.joinable()) t.join();
   delete pl;
 }
 
@@ -1364,8 +1440,9 @@ int grdma_pair_set_latency_mode(grdma_pair* p, int on) {
   if (int rc = require_ctx()) return rc;
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
   if (on && !p->h_cmd) {
-    HIP_TRY(hipHostMalloc((void**)&p->h_cmd, sizeof(grdma_engine_cmd), hipHostMallocCoherent | hipHostMallocMapped));
-    memset(p->h_cmd, 0, sizeof(grdma_engine_cmd));
+    HIP_TRY(hipHostMalloc((void**)&p->h_cmd, 2 * sizeof(grdma_engine_cmd), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(p->h_cmd, 0, 2 * sizeof(grdma_engine_cmd));
+    p->h_cmd_rx = p->h_cmd + 1;
   }
   if (on && !p->h_arena) {
     p->h_arena_cap = 2 * p->ring_size + 4096;
@@ -1391,6 +1468,10 @@ int grdma_pair_arm_read(grdma_pair* p, uint64_t max_reads) {
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
   if (max_reads && !p->latency) return fail(GRDMA_ERR_INVALID, "armed reads need latency mode");
   if (max_reads > GRDMA_MAX_SLICES) max_reads = GRDMA_MAX_SLICES;
+  if (p->async) {  // the standing order of an asynchronous endpoint (submit_send of the peer honours it)
+    p->armed_async.store(max_reads, std::memory_order_release);
+    return 0;
+  }
   p->armed_reads = max_reads;
   return 0;
 }
@@ -1535,6 +1616,263 @@ int64_t grdma_endpoint_read(grdma_pair* p, uint64_t max_reads, grdma_read_slice*
   }
   if (would_block) *would_block = (int)r.would_block;
   return (int64_t)r.nslices;
+}
+
+// ---- asynchronous endpoint operations (see include/grdma_amd.h) ----------------------------------
+const void* grdma_window_base(const grdma_window* w) { return w ? w->base : nullptr; }
+void grdma_window_ref(grdma_window* w) { if (w) w->refs.fetch_add(1, std::memory_order_relaxed); }
+void grdma_window_unref(grdma_window* w) {
+  if (w && w->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+    if (w->base) hipHostFree(w->base);
+    delete w;
+  }
+}
+
+int grdma_set_host_register_min(uint64_t bytes) {
+  register_min();  // (the environment is read first, an explicit call wins)
+  g_reg.min_bytes.store(bytes);
+  return 0;
+}
+int grdma_forget_host_range(const void* ptr, uint64_t len) {
+  const uintptr_t a = (uintptr_t)ptr;
+  std::lock_guard<std::mutex> lk(g_reg.mu);
+  int n = 0;
+  for (size_t i = 0; i < g_reg.e.size();) {
+    if (g_reg.e[i].lo < a + len && a < g_reg.e[i].hi) {
+      hipHostUnregister((void*)g_reg.e[i].lo);
+      g_reg.e.erase(g_reg.e.begin() + (long)i);
+      n++;
+    } else {
+      i++;
+    }
+  }
+  return n;
+}
+
+int grdma_endpoint_set_async(grdma_pair* p, int windows, uint64_t window_bytes) {
+  if (int rc = require_ctx()) return rc;
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (p->async) return 0;
+  if (windows <= 0) windows = 3;
+  if (windows < 2) return fail(GRDMA_ERR_INVALID, "an asynchronous endpoint needs at least two receive windows");
+  if (window_bytes == 0) {
+    // a drain delivers at most what the ring holds (plus the open 256-byte read and 16-byte slice alignment); the
+    // planner stops gracefully where a window ends, so a window only has to hold the largest record (< ring / 2)
+    const uint64_t full = 2 * p->ring_size + 4096, floor_ = p->ring_size / 2 + 4096;
+    window_bytes = std::min<uint64_t>(full, std::max<uint64_t>(floor_, 64ull << 20));
+  }
+  if (window_bytes < p->ring_size / 2 + 4096) return fail(GRDMA_ERR_INVALID, "receive window smaller than the largest record");
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  HIP_TRY(hipStreamCreateWithFlags(&p->s_tx, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&p->s_rx, hipStreamNonBlocking));
+  for (int i = 0; i < windows; i++) {
+    grdma_window* w = new grdma_window();
+    w->bytes = window_bytes;
+    if (hipHostMalloc((void**)&w->base, window_bytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+      delete w;
+      return fail(GRDMA_ERR_HIP, "receive window of %llu bytes: pinned allocation failed", (unsigned long long)window_bytes);
+    }
+    p->windows.push_back(w);
+  }
+  p->async = true;
+  return 0;
+}
+
+namespace {
+// the Send of one rdma_flush step, enqueued on the send stream (or posted to the engine) and not waited for
+int submit_send(grdma_pair* p, uint64_t count, uint64_t byte_idx) {
+  grdma_hostblk* h = p->h;
+  h->txop.conn = p->d_conn;
+  h->txop.slices = p->h_sges;
+  h->txop.nslices = count;
+  h->txop.byte_idx = byte_idx;
+  h->txop.plan = p->d_txplan;
+  h->txop.wire_plan = p->d_wireplan;
+  h->txop.result = &h->txres;
+  h->txop.use_cursor = 0;
+  h->txop.inline_copy = p->latency ? 1 : 0;
+  h->txop.seq_next = p->latency ? h->txres.seq + 1 : 0;
+  if (p->latency && g_engine.wanted) {
+    p->tx_by_engine = true;
+    p->tx_expect = h->txop.seq_next;
+    if (p->h_cmd && p->cmd_inline) {
+      p->h_cmd->tx = h->txop;
+      grdma_pair* q = p->peer;
+      // the in-process peer keeps a read armed: its drain rides in this command (k_engine runs it right behind the
+      // Send), and shows up on the peer's side as a drain in flight that completes by itself
+      if (q && !p->remote && q->async && q->latency && q->armed_async.load(std::memory_order_acquire) &&
+          q->rx_mu.try_lock()) {
+        std::lock_guard<std::mutex> lk(q->rx_mu, std::adopt_lock);
+        int w = -1;
+        if (q->rx_inflight.load(std::memory_order_acquire) < 0)
+          for (size_t i = 0; i < q->windows.size(); i++)
+            if (q->windows[i]->refs.load(std::memory_order_acquire) == 1) { w = (int)i; break; }
+        if (w >= 0) {
+          fill_rxop(q, q->windows[w]->base, q->windows[w]->bytes, q->armed_async.load(), 0);
+          p->h_cmd->rx = q->h->rxop;
+          q->rx_expect.store(q->h->rxop.seq_next, std::memory_order_relaxed);
+          q->rx_inflight.store(w, std::memory_order_release);
+          if (int rc = engine_post(GRDMA_ENGINE_SEND_INLINE_DRAIN, p->h_cmd)) {
+            q->rx_inflight.store(-1);
+            return rc;
+          }
+          q->armed_hits++;
+          return 0;
+        }
+      }
+      return engine_post(GRDMA_ENGINE_SEND_INLINE, p->h_cmd);
+    }
+    return engine_post(GRDMA_ENGINE_SEND, &h->txop);
+  }
+  p->tx_by_engine = false;
+  const uint32_t blocks = copy_blocks_for(p->ring_size / 2);
+  HIP_TRY(grdma_launch_tx_plan(&h->txop, 1, p->s_tx));
+  if (!p->latency) {
+    HIP_TRY(grdma_launch_copy(&h->plan_ptrs[0], 1, blocks, p->s_tx));
+    if (!(p->flags & GRDMA_WIRE_DIRECT)) HIP_TRY(grdma_launch_copy(&h->plan_ptrs[1], 1, blocks, p->s_tx));
+  }
+  HIP_TRY(grdma_launch_tx_commit1(p->d_conn, ++p->tx_seq, p->s_tx));
+  p->tx_expect = p->tx_seq;
+  return 0;
+}
+}  // namespace
+
+int grdma_endpoint_write_submit(grdma_pair* p) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || !p->async) return fail(GRDMA_ERR_INVALID, "not an asynchronous endpoint (grdma_endpoint_set_async)");
+  if (!p->w_active) return fail(GRDMA_ERR_INVALID, "no write has been begun");
+  if (p->tx_inflight.load(std::memory_order_acquire)) return fail(GRDMA_ERR_INVALID, "a Send is still in flight");
+  grdma_profiler profiler(GRDMA_STATS_TIME_PAIR_SEND);
+  const uint64_t n = p->w_slices.size() - p->w_idx;
+  if (int rc = stage_slices(p, p->w_slices.data() + p->w_idx, n, p->w_byte, p->w_flags)) return rc;
+  p->tx_inflight.store(1, std::memory_order_release);
+  if (int rc = submit_send(p, n, p->w_byte)) {
+    p->tx_inflight.store(0);
+    return rc;
+  }
+  return 0;
+}
+
+int grdma_endpoint_write_test(grdma_pair* p, int* done, int64_t* sent) {
+  if (!p || !done) return fail(GRDMA_ERR_INVALID, "null argument");
+  if (!p->tx_inflight.load(std::memory_order_acquire)) return fail(GRDMA_ERR_INVALID, "no Send in flight");
+  const uint64_t seen = p->tx_by_engine ? __atomic_load_n(&p->h->txres.seq, __ATOMIC_ACQUIRE)
+                                        : __atomic_load_n(&p->line->tx_seq, __ATOMIC_ACQUIRE);
+  if (seen < p->tx_expect) {
+    if (!p->tx_by_engine && (++p->test_calls & 0xFFFF) == 0) {  // a failed launch would otherwise never be noticed
+      const hipError_t e = hipStreamQuery(p->s_tx);
+      if (e != hipSuccess && e != hipErrorNotReady) return fail(GRDMA_ERR_HIP, "send stream: %s", hipGetErrorString(e));
+    }
+    return 0;
+  }
+  const grdma_tx_result& r = p->h->txres;
+  p->w_idx += r.slice_idx;
+  p->w_byte = r.byte_idx;
+  *done = r.done ? 1 : 0;
+  if (sent) *sent = (int64_t)r.sent;
+  if (r.done) {
+    p->w_active = false;
+    p->w_slices.clear();
+  }
+  p->tx_inflight.store(0, std::memory_order_release);
+  return 1;
+}
+
+int grdma_endpoint_read_submit(grdma_pair* p, uint64_t max_reads) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || !p->async) return fail(GRDMA_ERR_INVALID, "not an asynchronous endpoint (grdma_endpoint_set_async)");
+  if (max_reads == 0) return fail(GRDMA_ERR_INVALID, "max_reads is zero");
+  if (max_reads > GRDMA_MAX_SLICES) max_reads = GRDMA_MAX_SLICES;
+  std::lock_guard<std::mutex> lk(p->rx_mu);
+  if (p->rx_inflight.load(std::memory_order_acquire) >= 0) return fail(GRDMA_ERR_INVALID, "a drain is still in flight");
+  int w = -1;
+  for (size_t i = 0; i < p->windows.size(); i++)
+    if (p->windows[i]->refs.load(std::memory_order_acquire) == 1) { w = (int)i; break; }
+  if (w < 0) return 1;  // the transport still holds slices of every window
+  grdma_profiler profiler(GRDMA_STATS_TIME_PAIR_RECV);
+  grdma_hostblk* h = p->h;
+  fill_rxop(p, p->windows[w]->base, p->windows[w]->bytes, max_reads, 0);
+  if (p->latency && g_engine.wanted && p->h_cmd_rx) {
+    p->h_cmd_rx->rx = h->rxop;
+    p->rx_expect.store(h->rxop.seq_next, std::memory_order_relaxed);
+    p->rx_inflight.store(w, std::memory_order_release);
+    if (int rc = engine_post(GRDMA_ENGINE_DRAIN_BLOCK, p->h_cmd_rx)) {
+      p->rx_inflight.store(-1);
+      return rc;
+    }
+    return 0;
+  }
+  // (a pair in latency mode without the engine: the plan kernel scatters by itself and publishes commit_seq = seq_next)
+  p->rx_expect.store(p->latency ? h->rxop.seq_next : __atomic_load_n(&h->rxres.commit_seq, __ATOMIC_ACQUIRE) + 1,
+                     std::memory_order_relaxed);
+  p->rx_inflight.store(w, std::memory_order_release);
+  hipError_t e = grdma_launch_rx_plan(&h->rxop, 1, p->s_rx);
+  if (e == hipSuccess && !p->latency) e = grdma_launch_rx_apply(&h->rxop, 1, copy_blocks_for(p->ring_size), p->s_rx);
+  if (e != hipSuccess) {
+    p->rx_inflight.store(-1);
+    return fail(GRDMA_ERR_HIP, "drain launch failed: %s", hipGetErrorString(e));
+  }
+  return 0;
+}
+
+int64_t grdma_endpoint_read_test(grdma_pair* p, grdma_read_slice* slices, uint64_t slices_cap, int* would_block,
+                                 grdma_window** window) {
+  if (!p || !slices || !window) return fail(GRDMA_ERR_INVALID, "null argument");
+  const int w = p->rx_inflight.load(std::memory_order_acquire);
+  if (w < 0) return fail(GRDMA_ERR_INVALID, "no drain in flight");
+  if (__atomic_load_n(&p->h->rxres.commit_seq, __ATOMIC_ACQUIRE) != p->rx_expect.load(std::memory_order_relaxed)) {
+    if ((++p->test_calls_rx & 0xFFFF) == 0 && !(p->latency && g_engine.wanted)) {
+      const hipError_t e = hipStreamQuery(p->s_rx);
+      if (e != hipSuccess && e != hipErrorNotReady) return fail(GRDMA_ERR_HIP, "receive stream: %s", hipGetErrorString(e));
+    }
+    return -(int64_t)GRDMA_ERR_AGAIN;
+  }
+  const grdma_rx_result& r = p->h->rxres;
+  if (r.nslices > slices_cap) return fail(GRDMA_ERR_CAPACITY, "the drain delivered %llu slices, the caller takes %llu",
+                                          (unsigned long long)r.nslices, (unsigned long long)slices_cap);
+  for (uint64_t i = 0; i < r.nslices; i++) {
+    slices[i].off = p->h_slices[i].off;
+    slices[i].len = p->h_slices[i].len;
+  }
+  if (would_block) *would_block = (int)r.would_block;
+  grdma_window* win = p->windows[w];
+  win->refs.fetch_add(1, std::memory_order_relaxed);  // the caller's reference
+  *window = win;
+  const int64_t n = (int64_t)r.nslices;
+  p->rx_inflight.store(-1, std::memory_order_release);
+  return n;
+}
+
+int grdma_endpoint_readable(grdma_pair* p) {
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (p->rx_inflight.load(std::memory_order_acquire) >= 0)  // a drain in flight: readable when it has completed
+    return __atomic_load_n(&p->h->rxres.commit_seq, __ATOMIC_ACQUIRE) == p->rx_expect.load(std::memory_order_relaxed) ? 1 : 0;
+  return grdma_pair_has_message(p);
+}
+
+int grdma_endpoint_drain_state(grdma_pair* p) {
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (p->rx_inflight.load(std::memory_order_acquire) < 0) return 0;
+  return __atomic_load_n(&p->h->rxres.commit_seq, __ATOMIC_ACQUIRE) == p->rx_expect.load(std::memory_order_relaxed) ? 2 : 1;
+}
+
+int grdma_endpoint_free_windows(grdma_pair* p) {
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  int n = 0;
+  for (grdma_window* w : p->windows)
+    if (w->refs.load(std::memory_order_acquire) == 1) n++;
+  return n;
+}
+
+int grdma_endpoint_writable(grdma_pair* p) {
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (p->tx_inflight.load(std::memory_order_acquire)) {
+    const uint64_t seen = p->tx_by_engine ? __atomic_load_n(&p->h->txres.seq, __ATOMIC_ACQUIRE)
+                                          : __atomic_load_n(&p->line->tx_seq, __ATOMIC_ACQUIRE);
+    return seen >= p->tx_expect ? 1 : 0;
+  }
+  // HasPendingWrites(): the last Send came up short -- worth another one as soon as the peer has returned credit
+  return grdma_pair_has_pending_writes(p) > 0 && grdma_pair_writable_size(p) > 0 ? 1 : 0;
 }
 
 // ---- small device helpers -------------------------------------------------------

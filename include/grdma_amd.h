@@ -40,7 +40,8 @@ enum grdma_error {
   GRDMA_ERR_HIP = 3,         /* a HIP call failed; see grdma_last_error()            */
   GRDMA_ERR_NOT_CONNECTED = 4,
   GRDMA_ERR_CAPACITY = 5,    /* slice list / arena larger than the configured caps   */
-  GRDMA_ERR_CONFIG = 6       /* GRPC_PLATFORM_TYPE / GRPC_RDMA_* value rejected      */
+  GRDMA_ERR_CONFIG = 6,      /* GRPC_PLATFORM_TYPE / GRPC_RDMA_* value rejected      */
+  GRDMA_ERR_AGAIN = 7        /* an asynchronous operation has not completed yet       */
 };
 
 /* ---- platform selection: src/core/lib/iomgr/iomgr_internal.cc:37-62 --------- */
@@ -213,14 +214,14 @@ int grdma_pair_last_wrs(grdma_pair* p, uint64_t out[2][2]);
 void* grdma_pair_ring_device_ptr(grdma_pair* p);
 
 /* ---- background poller (RDMA_BPEV): src/core/lib/ibverbs/poller.h:16-71, poller.cc:12-106 ----
- * One host thread, one k_poll launch per pass over every registered pair (64 connections
- * per wavefront) on a stream of its own.  A pair's wakeup fd (an eventfd; the reference's
- * grpc_wakeup_fd, pair.h:150,187) becomes readable when the pair is connected and has a
- * message or pending writes, or when it is half-closed / in error (poller.cc:80-98); it is
- * not signalled again until the consumer has read it (poller.cc:76-78).  The event engine
- * adds the fd to its epoll set exactly as ev_epollex_rdma_bpev_linux.cc does.
- * n_threads mirrors GRPC_RDMA_POLLER_THREAD_NUM (must be > 0; one thread serves any number
- * of pairs here), sleep_timeout_ms mirrors GRPC_RDMA_POLLER_SLEEP_TIMEOUT_MS. */
+ * n_threads host threads (GRPC_RDMA_POLLER_THREAD_NUM, must be > 0) share one round-robin cursor over the
+ * slot table, as the reference's do (poller.cc:66-69).  What a thread looks at is the pair's host-visible
+ * state line -- no device work for a pair whose peer lives in this process.  A pair's wakeup fd (an
+ * eventfd; the reference's grpc_wakeup_fd, pair.h:150,187) becomes readable when the pair is connected
+ * and readable or writable (a message, a completed drain or Send, credit for a parked write), or when it
+ * is half-closed / in error (poller.cc:80-98); it is not signalled again until the consumer has read it
+ * (poller.cc:76-78).  The event engine adds the fd to its epoll set exactly as
+ * ev_epollex_rdma_bpev_linux.cc does.  sleep_timeout_ms mirrors GRPC_RDMA_POLLER_SLEEP_TIMEOUT_MS. */
 typedef struct grdma_poller grdma_poller;
 grdma_poller* grdma_poller_create(int n_threads, int sleep_timeout_ms);
 void grdma_poller_destroy(grdma_poller* pl);                 /* Poller::Shutdown          */
@@ -228,6 +229,7 @@ int grdma_poller_add(grdma_poller* pl, grdma_pair* p);       /* AddPollable; ret
 int grdma_poller_remove(grdma_poller* pl, grdma_pair* p);    /* RemovePollable; afterwards the
                                                               * poller no longer touches p   */
 int grdma_poller_stats(grdma_poller* pl, uint64_t* passes, uint64_t* wakeups);
+int grdma_poller_threads(grdma_poller* pl);                  /* threads running (GRPC_RDMA_POLLER_THREAD_NUM) */
 int grdma_pair_get_wakeup_fd(grdma_pair* p);                 /* PairPollable::get_wakeup_fd */
 int grdma_pair_consume_wakeup(grdma_pair* p);                /* grpc_wakeup_fd_consume_wakeup: 1 if one was pending */
 
@@ -252,6 +254,50 @@ int grdma_endpoint_write_abort(grdma_pair* p);
  * last attempt found no complete record (the endpoint re-arms notify_on_read). */
 int64_t grdma_endpoint_read(grdma_pair* p, uint64_t max_reads, grdma_read_slice* slices,
                             uint64_t slices_cap, int* would_block);
+/* ---- asynchronous endpoint operations ----------------------------------------------------------
+ * What the grpc_endpoint_vtable adapter runs on (include/grdma_endpoint_impl.hpp).  grpc_endpoint_write and
+ * grpc_endpoint_read return once the device work is enqueued -- a launch chain on the pair's send / receive stream,
+ * or one command to the resident latency engine when the pair is in latency mode --; the completion shows up in
+ * pinned host memory and the event engine's poll loop finds it with plain loads (grdma_endpoint_readable /
+ * _writable are what HasMessage() / HasPendingWrites() mean to ev_epollex_rdma_bp{,ev}_linux.cc for such an
+ * endpoint).  Delivered slices lie in receive windows of pinned host memory that the scatter kernel writes over
+ * PCIe: the transport gets slices that POINT into the window (no copy on the host), each holding a reference.
+ * One Send and one drain in flight per pair; the blocking calls above must not be mixed in while one is.
+ *
+ * grdma_endpoint_set_async(p, windows, window_bytes)  windows >= 2 (0 = 3); window_bytes 0 = sized from the ring.
+ * grdma_endpoint_write_submit(p)    one rdma_flush step (a Send from the cursor of the begun write), not waited for.
+ * grdma_endpoint_write_test(p, &done, &sent)   1: the step completed (as grdma_endpoint_write_step reports it),
+ *                                   0: still in flight, < 0: error.
+ * grdma_endpoint_read_submit(p, max_reads)     0: a drain of up to max_reads endpoint reads is on its way,
+ *                                   1: every window still holds slices the transport has not released.
+ * grdma_endpoint_read_test(p, slices, cap, &would_block, &window)   >= 0: completions, slices[i].off relative to
+ *                                   grdma_window_base(window); the caller owns one reference of the window
+ *                                   (grdma_window_unref when the last slice is gone); -GRDMA_ERR_AGAIN: in flight.
+ * grdma_pair_arm_read(p, n) on an asynchronous pair in latency mode: the in-process peer's small sends carry this
+ *                                   pair's drain in the same engine command (it then shows up as a drain in flight). */
+typedef struct grdma_window grdma_window;
+int grdma_endpoint_set_async(grdma_pair* p, int windows, uint64_t window_bytes);
+int grdma_endpoint_write_submit(grdma_pair* p);
+int grdma_endpoint_write_test(grdma_pair* p, int* done, int64_t* sent);
+int grdma_endpoint_read_submit(grdma_pair* p, uint64_t max_reads);
+int64_t grdma_endpoint_read_test(grdma_pair* p, grdma_read_slice* slices, uint64_t slices_cap, int* would_block,
+                                 grdma_window** window);
+int grdma_endpoint_readable(grdma_pair* p);
+int grdma_endpoint_writable(grdma_pair* p);
+int grdma_endpoint_drain_state(grdma_pair* p);    /* 0: no drain in flight, 1: in flight, 2: completed, not collected
+                                                     (a drain may have been posted by the in-process peer's sender
+                                                     on behalf of an armed read) */
+int grdma_endpoint_free_windows(grdma_pair* p);   /* receive windows no slice of the transport points into */
+const void* grdma_window_base(const grdma_window* w);
+void grdma_window_ref(grdma_window* w);
+void grdma_window_unref(grdma_window* w);
+/* GRDMA_MEM_HOST slices of at least this many bytes are read where they lie -- the library registers their pages
+ * with the device once (hipHostRegister) and remembers the registration -- instead of being copied into the
+ * pinned bounce buffer.  0 (default) = always copy.  The caller guarantees that a registered range stays mapped
+ * (memory handed back to the OS must be announced with grdma_forget_host_range first).  Env: GRPC_RDMA_HIP_REGISTER_MIN. */
+int grdma_set_host_register_min(uint64_t bytes);
+int grdma_forget_host_range(const void* ptr, uint64_t len);
+
 /* Export the ring as a dma-buf file descriptor (hipMemGetHandleForAddressRange,
  * hipMemRangeHandleTypeDmaBufFd): what ibv_reg_dmabuf_mr() takes to register the HBM ring with an
  * RDMA NIC -- the place of ibv_reg_mr() in the reference (rdma_utils.h:108-160, pair.cc:107-119).

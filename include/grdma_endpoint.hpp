@@ -141,6 +141,13 @@ grpc_endpoint* grpc_rdma_bp_create(int fd, const char* peer_string, bool enable_
 // Loop-back stand-in for exchange_data + PairPollable::Connect
 // (rdma_bp_posix.cc:767-771): joins two freshly created endpoints.
 bool grpc_rdma_bp_connect_loopback(grpc_endpoint* a, grpc_endpoint* b);
+// exchange_data + PairPollable::Connect over the endpoint's own socket (rdma_bp_posix.cc:763-784): what
+// grpc_rdma_bp_create does with the fd it was given, for a peer in ANOTHER process.
+bool grpc_rdma_bp_connect_fd(grpc_endpoint* ep);
+// Small-message mode of this build (no reference counterpart): every write / read of the endpoint becomes one
+// command to the resident latency engine instead of a launch chain; arm_reads != 0 keeps a read armed with the pair
+// whenever the endpoint waits for the readable edge, so that an in-process peer's small sends carry the drain.
+bool grdma_endpoint_set_latency_mode(grpc_endpoint* ep, bool on, uint64_t arm_reads);
 // grpc_endpoint_create (endpoint.cc:33-54): switches on GRPC_PLATFORM_TYPE.  TCP is
 // out of scope here and yields nullptr.
 grpc_endpoint* grpc_endpoint_create(int fd, const char* peer_string, bool server);
@@ -156,17 +163,17 @@ grdma_pair* grdma_endpoint_pair(grpc_endpoint* ep);  // the PairPollable handed 
 // Mirror of `pollable` + pollable_epoll + pollable_process_events of
 // ev_epollex_rdma_bp_linux.cc / ev_epollex_rdma_bpev_linux.cc (:1079-1172, :977-1075): endpoints
 // join through the vtable's add_to_pollset; one grdma_pollset_work() call is one pollset_work pass:
-//   * busy-poll: ONE k_poll launch (grdma_poll_pairs) reads HasMessage / readable size of EVERY
-//     endpoint of the set per pass (the reference walks p->rdma_fds calling get_status /
-//     HasMessage / HasPendingWrites one by one), synthesises EPOLLIN / EPOLLOUT and runs the armed
-//     closures; a half-closed or failed pair yields EPOLLIN so that do_read reports the close;
+//   * busy-poll: walks the fds of the set calling get_status / readable / writable -- plain loads of each pair's
+//     host-visible state line, no device call (the reference's HasMessage / HasPendingWrites are host loads
+//     too) --, synthesises EPOLLIN / EPOLLOUT and runs the armed closures; a half-closed or failed pair yields
+//     EPOLLIN so that do_read reports the close;
 //   * RDMA_BP (bpev = false): keeps busy-polling until an event or the timeout;
 //   * RDMA_BPEV (bpev = true): busy-polls for at most busy_polling_timeout_us
 //     (GRPC_RDMA_BUSY_POLLING_TIMEOUT_US), then sleeps in epoll_wait on the wakeup fds of its pairs
 //     -- signalled by the background poller (grdma_poller, poller.cc:52-106) -- and consumes the
 //     wakeup (:1010-1037) before it looks at the pair again.
-// Returns the number of closures run, < 0 on error.  Not thread safe against itself (the
-// reference serialises passes with p->rdma_mu); endpoints may be added / destroyed between passes.
+// Returns the number of closures run, < 0 on error.  Any number of threads may call it on one set: the pass over
+// the fds runs under the set's rdma_mu (ev_epollex_rdma_bpev_linux.cc:1103-1145), closures run outside it.
 grpc_pollset* grdma_pollset_create(bool bpev, int busy_polling_timeout_us);
 void grdma_pollset_destroy(grpc_pollset* ps);
 int grdma_pollset_work(grpc_pollset* ps, int timeout_ms);

@@ -14,6 +14,8 @@
 #include <deque>
 #include <chrono>
 #include <string>
+#include <mutex>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -287,8 +289,12 @@ struct echo_conn {
   uint32_t seed;
   int pattern_w, pattern_r;
   bool c_writing, s_writing, done, failed;
+  // (several threads may be inside pollset_work: the client's write callback and its read callback can run on
+  // different threads, and the next message may only be written once the callback of the last write has run)
+  std::mutex mu;
+  bool send_when_written = false;
 };
-static size_t g_conns_done = 0;
+static std::atomic<size_t> g_conns_done{0};
 
 static void echo_client_send(echo_conn* c) {
   c->seed = c->seed * 1664525u + 1013904223u;
@@ -297,13 +303,23 @@ static void echo_client_send(echo_conn* c) {
   fill_buffer(&c->c_out, c->msg_len, 8192, &cur);
   c->pattern_w = cur;
   c->c_got = 0;
-  c->c_writing = true;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->c_writing = true;
+  }
   grpc_endpoint_write(c->client, &c->c_out, &c->c_wrote, nullptr);
 }
 static void echo_c_wrote(void* p, grpc_error_handle e) {
   auto* c = static_cast<echo_conn*>(p);
-  c->c_writing = false;
   if (e != GRPC_ERROR_NONE) c->failed = true;
+  bool send;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->c_writing = false;
+    send = c->send_when_written;
+    c->send_when_written = false;
+  }
+  if (send && !c->failed) echo_client_send(c);
 }
 static void echo_c_read(void* p, grpc_error_handle e) {
   auto* c = static_cast<echo_conn*>(p);
@@ -316,7 +332,13 @@ static void echo_c_read(void* p, grpc_error_handle e) {
       g_conns_done++;
       return;
     }
-    echo_client_send(c);
+    bool send;
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      send = !c->c_writing;
+      if (!send) c->send_when_written = true;
+    }
+    if (send) echo_client_send(c);
   }
   grpc_endpoint_read(c->client, &c->c_in, &c->c_read, false);
 }
@@ -335,7 +357,7 @@ static void echo_s_read(void* p, grpc_error_handle e) {
   grpc_endpoint_write(c->server, &c->s_out, &c->s_wrote, nullptr);
 }
 
-static void pollset_echo_test(size_t n_conns, size_t rounds, bool bpev) {
+static void pollset_echo_test(size_t n_conns, size_t rounds, bool bpev, int threads) {
   setenv("GRPC_PLATFORM_TYPE", bpev ? "RDMA_BPEV" : "RDMA_BP", 1);
   grpc_pollset* ps = grdma_pollset_create(bpev, /*busy_polling_timeout_us=*/200);
   CHECK(ps != nullptr);
@@ -388,14 +410,22 @@ static void pollset_echo_test(size_t n_conns, size_t rounds, bool bpev) {
     first = 1;
   }
   for (size_t i = first; i < conns.size(); i++) echo_client_send(conns[i]);
-  long idle = 0;
-  while (g_conns_done < n_conns) {
-    const int ran = grdma_pollset_work(ps, /*timeout_ms=*/20);
-    CHECK(ran >= 0);
-    for (auto* c : conns) CHECK(!c->failed);
-    if (ran) idle = 0;
-    else if (++idle > 3000) CHECK(!"pollset made no progress");
-  }
+  // `threads` workers inside pollset_work at the same time (the reference serialises their passes over the fds with
+  // p->rdma_mu and runs the closures outside, ev_epollex_rdma_bpev_linux.cc:1103-1145)
+  auto worker = [&]() {
+    long idle = 0;
+    while (g_conns_done < n_conns) {
+      const int ran = grdma_pollset_work(ps, /*timeout_ms=*/20);
+      CHECK(ran >= 0);
+      for (auto* c : conns) CHECK(!c->failed);
+      if (ran) idle = 0;
+      else if (++idle > 3000) CHECK(!"pollset made no progress");
+    }
+  };
+  std::vector<std::thread> extra;
+  for (int t = 1; t < threads; t++) extra.emplace_back(worker);
+  worker();
+  for (std::thread& t : extra) t.join();
   grdma_pollset_stats st;
   grdma_pollset_get_stats(ps, &st);
   if (bpev) CHECK(st.epoll_waits > 0 && st.wakeups_consumed > 0);
@@ -410,9 +440,9 @@ static void pollset_echo_test(size_t n_conns, size_t rounds, bool bpev) {
   }
   CHECK(grdma_pollset_size(ps) == 0);  // grpc_fd_orphan took every fd out of the set
   grdma_pollset_destroy(ps);
-  printf("pollset_echo_test conns=%zu rounds=%zu bpev=%d: ok (passes %llu, device polls %llu, epoll waits %llu, "
+  printf("pollset_echo_test conns=%zu rounds=%zu bpev=%d threads=%d: ok (passes %llu, device polls %llu, epoll waits %llu, "
          "wakeups %llu, closures %llu)\n",
-         n_conns, rounds, (int)bpev, (unsigned long long)st.passes, (unsigned long long)st.device_polls,
+         n_conns, rounds, (int)bpev, threads, (unsigned long long)st.passes, (unsigned long long)st.device_polls,
          (unsigned long long)st.epoll_waits, (unsigned long long)st.wakeups_consumed,
          (unsigned long long)st.closures_run);
 }
@@ -432,7 +462,7 @@ int main(int argc, char** argv) {
     atexit(print_profile);
   }
   if (argc >= 5 && !strcmp(argv[1], "pollset")) {
-    pollset_echo_test((size_t)atol(argv[2]), (size_t)atol(argv[3]), atoi(argv[4]) != 0);
+    pollset_echo_test((size_t)atol(argv[2]), (size_t)atol(argv[3]), atoi(argv[4]) != 0, argc >= 6 ? atoi(argv[5]) : 1);
     return 0;
   }
   if (argc >= 2 && !strcmp(argv[1], "multiple_shutdown")) {

@@ -23,6 +23,7 @@ enum {
   hipSuccess = 0,
   hipErrorInvalidValue = 1,
   hipErrorOutOfMemory = 2,
+  hipErrorNotReady = 600,
   hipErrorNotSupported = 801,
 };
 typedef struct emu_stream* hipStream_t;
@@ -111,6 +112,10 @@ template <typename T>
 inline hipError_t hipExtMallocWithFlags(T** p, size_t n, unsigned) { return hipMalloc(p, n); }
 template <typename T>
 inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+enum { hipHostRegisterMapped = 2 };
+inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }  // host memory IS device memory here
+inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
+inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 inline hipError_t hipFree(void* p) { emu::dev_free(p); return hipSuccess; }
 inline hipError_t hipHostFree(void* p) { emu::dev_free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
@@ -129,6 +134,7 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hi
 inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t s);  // (defined below: waits for a resident kernel on the stream)
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }  // (launches have completed when they return)
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(malloc(8)); return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }

@@ -105,3 +105,27 @@ def test_endpoint_vtable_tools_under_the_emulator(emu_lib, tmp_path):
     assert p.returncode == 0, p.stderr[-500:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["checked"] and r["latency_mode"] and r["endpoint_bytes"] > 5 << 20
+
+
+def test_endpoint_conformance_under_the_emulator(emu_lib, tmp_path):
+    """tests/cc/endpoint_conformance -- the reference's endpoint test shape over the vtable mirror, i.e. over the
+    endpoint logic shared with the drop-in for the gRPC tree (include/grdma_endpoint_impl.hpp): shutdown / half close,
+    a small ring that parks every write on credit, and a pollset of 16 endpoints in both platforms (RDMA_BPEV sleeps
+    in epoll_wait and is woken by the poller threads).  Asynchronous Sends and drains, receive windows, zero-copy
+    slices: all of it runs here, on the emulated device."""
+    os.symlink(emu_lib, str(tmp_path / "libgrdma_amd.so"))
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    h = os.path.join(ROOT, "tests", "cc", "endpoint_conformance")
+
+    def run(args, ring_kb):
+        p = subprocess.run([h] + [str(a) for a in args], env=dict(env, GRPC_RDMA_RING_BUFFER_SIZE_KB=str(ring_kb)),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-1000:]
+        return p.stdout
+    out = run(["multiple_shutdown"], 4096)
+    assert "multiple_shutdown_test: ok" in out and "half_close_test: ok" in out and "write_after_peer_exit_test: ok" in out
+    assert ": ok" in run([300000, 100000, 8192, 0], 64)
+    out = run(["pollset", 8, 2, 0], 256)
+    assert ": ok" in out and "device polls 0" in out   # the busy-poll pass is host loads only
+    out = run(["pollset", 8, 2, 1, 2], 256)             # two threads inside pollset_work
+    assert ": ok" in out and "epoll waits 0" not in out

@@ -17,10 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PEER = os.path.join(ROOT, "tests", "two_proc_peer.py")
 
 
-def run_pair(ring_kib, num_bytes, write_size, slice_size, devs=(0, 0), pair_flags=0):
+def run_pair(ring_kib, num_bytes, write_size, slice_size, devs=(0, 0), pair_flags=4, extra_env=None):
     a, b = socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM)
     procs = []
     env = dict(os.environ, GRDMA_TEST_PAIR_FLAGS=str(pair_flags))
+    env.update(extra_env or {})
     for role, sock, dev in (("server", a, devs[0]), ("client", b, devs[1])):
         os.set_inheritable(sock.fileno(), True)
         procs.append(subprocess.Popen(
@@ -57,9 +58,49 @@ def test_echo_between_two_processes(gpu, ring_kib, num_bytes, write_size, slice_
 def test_echo_between_two_processes_fine_grained_rings(gpu):
     """GRDMA_RING_FINE_GRAINED: ring and status block are fine-grained device memory -- what a
     remote writer (peer process, peer GPU, NIC) needs to see acknowledged stores without cache
-    maintenance.  Same echo, same bytes."""
+    maintenance.  Every pair that is exported to another process must be created this way (the
+    export refuses a coarse-grained ring): all cases of this file run with it."""
     outs = run_pair(256, 600000, 100000, 8192, pair_flags=4)
     assert "ok server" in outs[0][1] and "ok client" in outs[1][1]
+
+
+def test_credit_return_across_processes_for_ten_seconds(gpu):
+    """64 KiB rings: every ~32 KiB consumed the reader zero-fills what it read and posts a credit report into
+    the OTHER process's connection block, and the writer reuses that space at once.  Ten seconds of echo
+    (tens of thousands of credit cycles each way) -- a zero-fill that became visible after the credit, or a
+    record accepted before its payload had landed, shows up as a byte mismatch or as a dirty ring at the end."""
+    outs = run_pair(64, 0, 30000, 4096, pair_flags=4, extra_env={"GRDMA_TEST_SECONDS": "10"})
+    assert "ok server" in outs[0][1] and "ok client" in outs[1][1]
+
+
+def test_killed_peer_turns_the_pair_half_closed(gpu):
+    """kill -9 of the peer process: no Disconnect(), no peer_exit word.  The reference notices through
+    ibv_query_qp every 500 ms (pair.cc:358-372 => kHalfClosed) and the TCP fd's hang-up; here get_status()
+    checks the peer's pid and the bootstrap socket.  The survivor must report kHalfClosed within a second."""
+    import signal
+    import time
+    a, b = socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM)
+    env = dict(os.environ, GRDMA_TEST_PAIR_FLAGS="4")
+    procs = {}
+    for role, sock in (("watcher", a), ("victim", b)):
+        os.set_inheritable(sock.fileno(), True)
+        procs[role] = subprocess.Popen([sys.executable, PEER, role, str(sock.fileno()), "0", "256", "0", "0", "0"],
+                                       pass_fds=[sock.fileno()], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    a.close()
+    b.close()
+    try:
+        line = procs["victim"].stdout.readline()   # "connected": both ends are up
+        assert "connected" in line, line + procs["victim"].stderr.read()[-2000:]
+        line = procs["watcher"].stdout.readline()
+        assert "connected" in line, line
+        time.sleep(0.3)
+        procs["victim"].send_signal(signal.SIGKILL)
+        out, err = procs["watcher"].communicate(timeout=60)
+        assert procs["watcher"].returncode == 0 and "ok watcher" in out, out + err[-3000:]
+    finally:
+        for p in procs.values():
+            if p.poll() is None:
+                p.kill()
 
 
 def test_echo_between_two_gpus(gpu):
@@ -74,17 +115,25 @@ def test_connect_checks_of_the_reference(gpu):
     """Connect() asserts equal tag and equal ring size (pair.cc:146-149); a handle cannot be
     opened in the process that made it."""
     g = gpu
-    a, b = g.Pair(1 << 20, 30), g.Pair(2 << 20, 30)
+    coarse = g.Pair(1 << 20, 30)
+    with pytest.raises(g.GrdmaError, match="FINE_GRAINED"):   # what another process writes must be fine-grained memory
+        coarse.export_address()
+    a, b = g.Pair(1 << 20, 30, flags=4), g.Pair(2 << 20, 30, flags=4)
     blob = bytearray(b.export_address())
     assert len(blob) == 208 and blob[32] == 0xA0
     assert int.from_bytes(blob[40:48], "little") == 2 << 20
     with pytest.raises(g.GrdmaError, match="ring sizes differ"):
         a.connect_remote(bytes(blob))
-    c = g.Pair(1 << 20, 30)
+    c = g.Pair(1 << 20, 30, flags=4)
     blob = bytearray(c.export_address())
     with pytest.raises(g.GrdmaError, match="this process"):
         a.connect_remote(bytes(blob))
     blob[32] = 0xA1
     with pytest.raises(g.GrdmaError, match="tag"):
+        a.connect_remote(bytes(blob))
+    blob[32] = 0xA0
+    blob[64 + 16:64 + 24] = (12345).to_bytes(8, "little")   # status_off comes off a socket: it must be this build's
+    blob[64 + 8:64 + 16] = (os.getpid() + 1).to_bytes(8, "little")
+    with pytest.raises(g.GrdmaError, match="layout"):
         a.connect_remote(bytes(blob))
     assert a.get_status() == 1  # still kInitialized

@@ -41,13 +41,80 @@ class Writer:
         return n
 
 
+def on_the_clock(role, pair, w, seconds, ring_kib, write_size, slice_size):
+    """The same echo for `seconds` of wall time instead of a byte count (small rings: a credit report crosses the
+    process boundary every ring/2 bytes, each way).  The client checks every echoed byte as it arrives."""
+    t_end = time.time() + seconds
+    deadline = t_end + 120
+    if role == "client":
+        pos = got = nslices = 0
+        while True:
+            assert time.time() < deadline, "client timed out at %d/%d" % (got, pos)
+            if not w.active and time.time() < t_end:
+                data = bytes((pos + i) & 0xFF for i in range(write_size))
+                w.begin([data[o:o + slice_size] for o in range(0, write_size, slice_size)])
+                pos += write_size
+            if w.active:
+                w.step()
+            sl, _ = pair.endpoint_read(256)
+            nslices += len(sl)
+            for s_ in sl:
+                assert s_ == bytes((got + i) & 0xFF for i in range(len(s_))), "echo differs near byte %d" % got
+                got += len(s_)
+            if not w.active and time.time() >= t_end and got == pos:
+                break
+        assert pair.ring_mem() == bytes(ring_kib * 1024), "client ring not zero after the echo"
+        st = pair.state()
+        pair.Disconnect()
+        print("ok client %d bytes echoed in %d slices, %d credit reports sent" % (got, nslices, st["credit_msgs"]))
+    else:
+        pending, echoed, seen = deque(), 0, 0
+        while True:
+            assert time.time() < deadline, "server timed out at %d" % echoed
+            sl, _ = pair.endpoint_read(256)
+            for s_ in sl:
+                assert all(b == ((seen + i) & 0xFF) for i, b in enumerate(s_))
+                seen += len(s_)
+                pending.append(s_)
+            if not w.active and pending:
+                batch = [pending.popleft() for _ in range(min(len(pending), 2000))]
+                w.batch_bytes = sum(len(b) for b in batch)
+                w.begin(batch)
+            if w.active:
+                w.step()
+                if not w.active:
+                    echoed += w.batch_bytes
+            elif not pending and not sl and pair.get_status() == 3:
+                break
+        assert pair.ring_mem() == bytes(ring_kib * 1024), "server ring not zero after the echo"
+        print("ok server %d bytes echoed, %d credit reports sent" % (echoed, pair.state()["credit_msgs"]))
+    pair.close()
+
+
 def main():
     role, fd, dev, ring_kib, num_bytes, write_size, slice_size = sys.argv[1], *map(int, sys.argv[2:8])
     g.init(dev)
     pair = g.Pair(ring_kib * 1024, 30, int(os.environ.get("GRDMA_TEST_PAIR_FLAGS", "0")))
     pair.bootstrap_fd(fd)
     assert pair.get_status() == 2
+    if role in ("victim", "watcher"):
+        # peer-death detection: the victim is killed with SIGKILL, the watcher must see kHalfClosed
+        print("connected", flush=True)
+        if role == "victim":
+            time.sleep(600)
+            sys.exit(1)
+        t0 = time.time()
+        while pair.get_status() == 2:
+            assert time.time() - t0 < 30, "the watcher never saw its peer die"
+            time.sleep(0.002)
+        assert pair.get_status() == 3, pair.get_status()
+        print("ok watcher: half closed %.3f s after the connection came up" % (time.time() - t0), flush=True)
+        pair.close()
+        return
     w = Writer(pair)
+    seconds = float(os.environ.get("GRDMA_TEST_SECONDS", "0"))
+    if seconds > 0:
+        return on_the_clock(role, pair, w, seconds, ring_kib, write_size, slice_size)
     deadline = time.time() + 240
     if role == "client":
         writes, pos = deque(), 0

@@ -7,8 +7,8 @@
 // transport boundary, PCIe both ways included; bench.py reports it next to the pair-level RTT, never instead of it.
 //
 // usage: endpoint_pingpong <iters> <payload_bytes> <mode>      prints one JSON line
-//   mode 0: the blocking C ABI (a launch chain + synchronize per write / read / poll)
-//   mode 1: both pairs in latency mode: every write / read is one command to the resident engine
+//   mode 0: launch chains (one Send / one drain enqueued per write / read, completion seen in pinned memory)
+//   mode 1: both pairs in latency mode: every write / read is one command posted to the resident engine
 //   mode 2: mode 1 + armed reads (grdma_pair_arm_read): the drain rides in the peer's send command and the poll
 //           sees the completion in host memory, no device work between the doorbell and the read callback
 #include <algorithm>
@@ -96,13 +96,9 @@ int main(int argc, char** argv) {
   sv.ep = grpc_endpoint_create(4, "ipv4:127.0.0.1:2", true);
   CHECK(cl.ep && sv.ep && grpc_rdma_bp_connect_loopback(cl.ep, sv.ep));
   if (mode >= 1) {
-    CHECK(grdma_pair_set_latency_mode(grdma_endpoint_pair(cl.ep), 1) == 0);
-    CHECK(grdma_pair_set_latency_mode(grdma_endpoint_pair(sv.ep), 1) == 0);
+    CHECK(grdma_endpoint_set_latency_mode(cl.ep, true, mode >= 2 ? 1024 : 0));
+    CHECK(grdma_endpoint_set_latency_mode(sv.ep, true, mode >= 2 ? 1024 : 0));
     CHECK(grdma_engine_start() == 0);
-  }
-  if (mode >= 2) {
-    CHECK(grdma_pair_arm_read(grdma_endpoint_pair(cl.ep), 1024) == 0);
-    CHECK(grdma_pair_arm_read(grdma_endpoint_pair(sv.ep), 1024) == 0);
   }
 
   // one message: [frame header 9 B | message header 5 B] (one inlined slice, as chttp2 merges them) + payload
@@ -178,10 +174,6 @@ int main(int argc, char** argv) {
          "\"seconds\": %.3f, \"armed_hits\": %lld, \"checked\": true}\n",
          iters, payload, mode, rtt[iters / 2] / 1e3, rtt[(size_t)(iters * 0.95)] / 1e3, rtt[(size_t)(iters * 0.99)] / 1e3,
          sec, (long long)hits);
-  if (mode >= 2) {
-    grdma_pair_arm_read(grdma_endpoint_pair(cl.ep), 0);
-    grdma_pair_arm_read(grdma_endpoint_pair(sv.ep), 0);
-  }
   if (mode >= 1) grdma_engine_stop();
   grpc_endpoint_shutdown(cl.ep, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
   grpc_endpoint_shutdown(sv.ep, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));

@@ -112,8 +112,8 @@ int main(int argc, char** argv) {
   CHECK(st.tx && st.rx && grpc_rdma_bp_connect_loopback(st.tx, st.rx));
   const bool latency = argc > 4 && atoi(argv[4]) != 0;
   if (latency) {
-    CHECK(grdma_pair_set_latency_mode(grdma_endpoint_pair(st.tx), 1) == 0);
-    CHECK(grdma_pair_set_latency_mode(grdma_endpoint_pair(st.rx), 1) == 0);
+    CHECK(grdma_endpoint_set_latency_mode(st.tx, true, 0));
+    CHECK(grdma_endpoint_set_latency_mode(st.rx, true, 0));
     CHECK(grdma_engine_start() == 0);
   }
 
