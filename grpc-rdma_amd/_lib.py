@@ -37,7 +37,8 @@ class Config(C.Structure):
                 ("poller_thread_num", C.c_int32), ("busy_polling_timeout_us", C.c_int32),
                 ("poller_sleep_timeout_ms", C.c_int32), ("ring_buffer_size_kb", C.c_uint32),
                 ("zerocopy_buffer_size_kb", C.c_uint32), ("zerocopy_threshold_kb", C.c_uint32),
-                ("max_sge", C.c_int32), ("hip_device", C.c_int32)]
+                ("max_sge", C.c_int32), ("hip_device", C.c_int32), ("hip_wire_direct", C.c_int32),
+                ("hip_register_min", C.c_uint32)]
 
 
 # name -> (restype, argtypes); kept in one table so the "exports every symbol"

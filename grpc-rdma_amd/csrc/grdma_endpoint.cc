@@ -384,7 +384,8 @@ grpc_endpoint* grpc_rdma_bp_create(int fd, const char* peer_string, bool enable_
   if (grdma_init(cfg.hip_device) < 0) return nullptr;
   // (fine-grained: the pair may be handed to a peer in another process through grdma_pair_bootstrap_fd)
   grdma_pair* pair = grdma_pair_create(static_cast<uint64_t>(cfg.ring_buffer_size_kb) * 1024,
-                                       cfg.max_sge, GRDMA_WIRE_STAGED | GRDMA_RING_FINE_GRAINED);
+                                       cfg.max_sge,
+                                       (cfg.hip_wire_direct ? GRDMA_WIRE_DIRECT : GRDMA_WIRE_STAGED) | GRDMA_RING_FINE_GRAINED);
   if (pair == nullptr) return nullptr;  // "Connection failed" path :777-784
   if (grdma_endpoint_set_async(pair, 0, 0) < 0) {
     grdma_pair_destroy(pair);

@@ -87,6 +87,13 @@ int grdma_config_from_env(grdma_config* c) {
     if (v <= 0) return -GRDMA_ERR_CONFIG;
     c->max_sge = (int32_t)v;
   }
+  c->hip_wire_direct = 1;
+  if (const char* w = getenv("GRPC_RDMA_HIP_WIRE")) {
+    if (!strcmp(w, "staged")) c->hip_wire_direct = 0;
+    else if (!strcmp(w, "direct")) c->hip_wire_direct = 1;
+    else return -GRDMA_ERR_CONFIG;
+  }
+  c->hip_register_min = env_int("GRPC_RDMA_HIP_REGISTER_MIN", &v) && v > 0 ? (uint32_t)v : 0;
   c->hip_device = 0;
   if (env_int("GRPC_RDMA_HIP_DEVICE", &v)) c->hip_device = (int32_t)v;
   else if (env_int("LOCAL_RANK", &v)) c->hip_device = (int32_t)v;

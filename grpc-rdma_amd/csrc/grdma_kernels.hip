@@ -162,6 +162,16 @@ __global__ __launch_bounds__(64) void k_tx_commit1(grdma_conn* c, uint64_t seq) 
   if (threadIdx.x == 0) tx_publish(c, c->remote_tail, c->partial_write, seq);
 }
 
+// k_rx_commit1: runs behind k_rx_apply of an asynchronous drain whose slices land in pinned HOST memory.  The
+// scatter's workgroups write over PCIe from eight XCDs; that each of them has seen its stores acknowledged before
+// it counted in does not order those posted writes before the last workgroup's flag as the HOST sees them.  A
+// kernel boundary does (the end-of-kernel release the runtime's own completion signals rely on), so the word the
+// host polls is written by this kernel.
+__global__ __launch_bounds__(64) void k_rx_commit1(grdma_conn* c, uint64_t seq) {
+  if (threadIdx.x == 0 && c->line != nullptr)
+    __hip_atomic_store(&c->line->rx_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct ring_probe {
   uint64_t n;      // header value at `pos`
   bool ready;      // header valid and footer tag present
@@ -257,6 +267,11 @@ __attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_commit(grdma_co
 
 __attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_commit1(grdma_conn* d_conn, uint64_t seq, hipStream_t s) {
   hipLaunchKernelGGL(k_tx_commit1, dim3(1), dim3(64), 0, s, d_conn, seq);
+  return hipGetLastError();
+}
+
+__attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_commit1(grdma_conn* d_conn, uint64_t seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_rx_commit1, dim3(1), dim3(64), 0, s, d_conn, seq);
   return hipGetLastError();
 }
 

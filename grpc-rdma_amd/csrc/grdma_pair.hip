@@ -42,6 +42,7 @@ hipError_t grdma_launch_tx_plan_seq(const grdma_tx_op*, uint32_t, uint32_t, hipS
 hipError_t grdma_launch_tx_plan_zc(const grdma_zc_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_tx_commit(grdma_conn* const*, const uint64_t*, uint32_t, hipStream_t);
 hipError_t grdma_launch_tx_commit1(grdma_conn*, uint64_t, hipStream_t);
+hipError_t grdma_launch_rx_commit1(grdma_conn*, uint64_t, hipStream_t);
 hipError_t grdma_launch_copy(const grdma_plan* const*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_apply(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
@@ -232,13 +233,24 @@ struct grdma_pair {
   hipStream_t s_tx = nullptr, s_rx = nullptr;
   std::vector<grdma_window*> windows;   // receive windows (pinned host memory), one drain each
   std::atomic<int> rx_inflight{-1};     // window of the drain in flight, -1 = none
-  std::atomic<uint64_t> rx_expect{0};   // rxres.commit_seq that says it has completed
+  std::atomic<uint64_t> rx_expect{0};   // the sequence number that says it has completed: line->rx_seq (launch chain,
+                                        // written by k_rx_commit1 behind the scatter) or rxres.seq (engine command)
+  std::atomic<int> rx_by_engine{0};
+  uint64_t rx_seq = 0;                  // drains committed through k_rx_commit1
   std::atomic<int> tx_inflight{0};
   uint64_t tx_expect = 0;               // line->tx_seq (launch chain) or txres.seq (engine command) of the Send in flight
   bool tx_by_engine = false;
   std::mutex rx_mu;                     // receive-side submission state: the armed read lets the PEER's sender post my drain
   std::atomic<uint64_t> armed_async{0}; // standing order of an asynchronous endpoint: max_reads, 0 = none
   uint64_t test_calls = 0, test_calls_rx = 0;
+  // several Sends per submit (a write of more slices than max_sge, wire direct): rdma_flush retried back to back on
+  // the device from the cursor, every Send with a gather plan of its own, ONE planning launch and ONE gather launch
+  std::vector<grdma_plan*> b_plans;
+  grdma_tx_op* h_bops = nullptr;              // pinned, kBurstMax ops
+  grdma_tx_result* h_bres = nullptr;          // pinned, kBurstMax results
+  const grdma_plan** h_bplan_ptrs = nullptr;  // pinned
+  uint32_t tx_burst = 0;                      // Sends of the submit in flight (0 = a single Send through h->txop)
+  uint64_t tx_burst_byte0 = 0;                // byte offset the first slice of that submit was entered at
   // endpoint_write context
   std::vector<grdma_slice> w_slices;
   uint64_t w_idx = 0, w_byte = 0;
@@ -338,7 +350,8 @@ int stage_slices(grdma_pair* p, const grdma_slice* slices, uint64_t count, uint6
     }
   }
   if (flags & GRDMA_MEM_HOST) {
-    const uint64_t cap = p->ring_size / 2;
+    // (a Send takes at most ring / 2; a burst of Sends of an asynchronous endpoint at most what the ring holds)
+    const uint64_t cap = p->async ? p->ring_size : p->ring_size / 2;
     if (!p->h_bounce) HIP_TRY(hipHostMalloc((void**)&p->h_bounce, cap + 64, hipHostMallocCoherent | hipHostMallocMapped));
     const uint64_t reg_min = register_min();
     uint64_t off = 0;
@@ -736,6 +749,10 @@ void grdma_pair_destroy(grdma_pair* p) {
   if (p->s_tx) { hipStreamSynchronize(p->s_tx); hipStreamDestroy(p->s_tx); }
   if (p->s_rx) { hipStreamSynchronize(p->s_rx); hipStreamDestroy(p->s_rx); }
   for (grdma_window* w : p->windows) grdma_window_unref(w);  // (slices the transport still holds keep theirs)
+  for (grdma_plan* pl : p->b_plans) hipFree(pl);
+  if (p->h_bops) hipHostFree(p->h_bops);
+  if (p->h_bres) hipHostFree(p->h_bres);
+  if (p->h_bplan_ptrs) hipHostFree(p->h_bplan_ptrs);
   if (p->refresh_stream) {
     hipStreamSynchronize(p->refresh_stream);  // a refresh pass in flight writes the line
     hipStreamDestroy(p->refresh_stream);
@@ -1711,6 +1728,7 @@ int submit_send(grdma_pair* p, uint64_t count, uint64_t byte_idx) {
           fill_rxop(q, q->windows[w]->base, q->windows[w]->bytes, q->armed_async.load(), 0);
           p->h_cmd->rx = q->h->rxop;
           q->rx_expect.store(q->h->rxop.seq_next, std::memory_order_relaxed);
+          q->rx_by_engine.store(1, std::memory_order_relaxed);
           q->rx_inflight.store(w, std::memory_order_release);
           if (int rc = engine_post(GRDMA_ENGINE_SEND_INLINE_DRAIN, p->h_cmd)) {
             q->rx_inflight.store(-1);
@@ -1725,6 +1743,52 @@ int submit_send(grdma_pair* p, uint64_t count, uint64_t byte_idx) {
     return engine_post(GRDMA_ENGINE_SEND, &h->txop);
   }
   p->tx_by_engine = false;
+  p->tx_burst = 0;
+  if (!p->latency && (p->flags & GRDMA_WIRE_DIRECT) && count > (uint64_t)p->max_sge) {
+    // More slices than one Send takes (max_sge): the reference comes back through the writable edge for every
+    // Send (HasPendingWrites() -> rdma_handle_write -> rdma_flush, rdma_bp_posix.cc:527-557); here up to kBurstMax
+    // of those Sends are planned by one launch (k_tx_plan_seq: the cursor and the ring tail stay on the device) and
+    // gathered by one.  Records go straight into the peer ring, so the Sends need no staging buffers of their own.
+    constexpr uint32_t kBurstMax = 16;
+    uint32_t B = (uint32_t)std::min<uint64_t>(kBurstMax, (count + p->max_sge - 1) / p->max_sge);
+    if (!p->h_bops) {
+      HIP_TRY(hipHostMalloc((void**)&p->h_bops, sizeof(grdma_tx_op) * kBurstMax, hipHostMallocCoherent | hipHostMallocMapped));
+      HIP_TRY(hipHostMalloc((void**)&p->h_bres, sizeof(grdma_tx_result) * kBurstMax, hipHostMallocCoherent | hipHostMallocMapped));
+      HIP_TRY(hipHostMalloc((void**)&p->h_bplan_ptrs, sizeof(grdma_plan*) * kBurstMax, hipHostMallocCoherent | hipHostMallocMapped));
+      memset(p->h_bres, 0, sizeof(grdma_tx_result) * kBurstMax);
+    }
+    while (p->b_plans.size() < B) {
+      grdma_plan* pl = nullptr;
+      HIP_TRY(hipMalloc((void**)&pl, sizeof(grdma_plan)));
+      HIP_TRY(hipMemsetAsync(pl, 0, sizeof(grdma_plan), p->s_tx));
+      p->b_plans.push_back(pl);
+    }
+    // the cursor starts at slice 0 of the table: fold the byte offset into the table's first entry
+    p->tx_burst_byte0 = byte_idx;
+    if (byte_idx) {
+      p->h_sges[0].ptr += byte_idx;
+      p->h_sges[0].len -= byte_idx;
+    }
+    for (uint32_t k = 0; k < B; k++) {
+      grdma_tx_op& t = p->h_bops[k];
+      memset(&t, 0, sizeof(t));
+      t.conn = p->d_conn;
+      t.slices = p->h_sges;
+      t.nslices = count;
+      t.plan = p->b_plans[k];
+      t.wire_plan = nullptr;
+      t.result = &p->h_bres[k];
+      t.use_cursor = k == 0 ? 2 : 1;
+      p->h_bplan_ptrs[k] = p->b_plans[k];
+    }
+    const uint32_t blocks_b = std::max<uint32_t>(1, copy_blocks_for(p->ring_size) / B + 1);
+    HIP_TRY(grdma_launch_tx_plan_seq(p->h_bops, 1, B, p->s_tx));
+    HIP_TRY(grdma_launch_copy(p->h_bplan_ptrs, B, blocks_b, p->s_tx));
+    HIP_TRY(grdma_launch_tx_commit1(p->d_conn, ++p->tx_seq, p->s_tx));
+    p->tx_expect = p->tx_seq;
+    p->tx_burst = B;
+    return 0;
+  }
   const uint32_t blocks = copy_blocks_for(p->ring_size / 2);
   HIP_TRY(grdma_launch_tx_plan(&h->txop, 1, p->s_tx));
   if (!p->latency) {
@@ -1734,6 +1798,15 @@ int submit_send(grdma_pair* p, uint64_t count, uint64_t byte_idx) {
   HIP_TRY(grdma_launch_tx_commit1(p->d_conn, ++p->tx_seq, p->s_tx));
   p->tx_expect = p->tx_seq;
   return 0;
+}
+}  // namespace
+
+namespace {
+inline bool drain_complete(grdma_pair* p) {
+  const uint64_t seen = p->rx_by_engine.load(std::memory_order_acquire)
+                            ? __atomic_load_n(&p->h->rxres.seq, __ATOMIC_ACQUIRE)   // (the release store of the plan body)
+                            : __atomic_load_n(&p->line->rx_seq, __ATOMIC_ACQUIRE);
+  return seen >= p->rx_expect.load(std::memory_order_acquire);
 }
 }  // namespace
 
@@ -1765,7 +1838,14 @@ int grdma_endpoint_write_test(grdma_pair* p, int* done, int64_t* sent) {
     }
     return 0;
   }
-  const grdma_tx_result& r = p->h->txres;
+  grdma_tx_result r = p->h->txres;
+  if (p->tx_burst) {  // the last Send's result holds the cursor; what was sent is the sum over the Sends
+    r = p->h_bres[p->tx_burst - 1];
+    r.sent = 0;
+    for (uint32_t k = 0; k < p->tx_burst; k++) r.sent += p->h_bres[k].sent;
+    if (r.slice_idx == 0) r.byte_idx += p->tx_burst_byte0;  // (still inside the slice the offset was folded into)
+    p->tx_burst = 0;
+  }
   p->w_idx += r.slice_idx;
   p->w_byte = r.byte_idx;
   *done = r.done ? 1 : 0;
@@ -1795,6 +1875,7 @@ int grdma_endpoint_read_submit(grdma_pair* p, uint64_t max_reads) {
   if (p->latency && g_engine.wanted && p->h_cmd_rx) {
     p->h_cmd_rx->rx = h->rxop;
     p->rx_expect.store(h->rxop.seq_next, std::memory_order_relaxed);
+    p->rx_by_engine.store(1, std::memory_order_relaxed);
     p->rx_inflight.store(w, std::memory_order_release);
     if (int rc = engine_post(GRDMA_ENGINE_DRAIN_BLOCK, p->h_cmd_rx)) {
       p->rx_inflight.store(-1);
@@ -1802,12 +1883,14 @@ int grdma_endpoint_read_submit(grdma_pair* p, uint64_t max_reads) {
     }
     return 0;
   }
-  // (a pair in latency mode without the engine: the plan kernel scatters by itself and publishes commit_seq = seq_next)
-  p->rx_expect.store(p->latency ? h->rxop.seq_next : __atomic_load_n(&h->rxres.commit_seq, __ATOMIC_ACQUIRE) + 1,
-                     std::memory_order_relaxed);
+  // the launch chain: plan, scatter (not in latency mode, where the plan kernel scatters by itself), and -- as a
+  // kernel of its own -- the word the host polls
+  p->rx_expect.store(++p->rx_seq, std::memory_order_relaxed);
+  p->rx_by_engine.store(0, std::memory_order_relaxed);
   p->rx_inflight.store(w, std::memory_order_release);
   hipError_t e = grdma_launch_rx_plan(&h->rxop, 1, p->s_rx);
   if (e == hipSuccess && !p->latency) e = grdma_launch_rx_apply(&h->rxop, 1, copy_blocks_for(p->ring_size), p->s_rx);
+  if (e == hipSuccess) e = grdma_launch_rx_commit1(p->d_conn, p->rx_seq, p->s_rx);
   if (e != hipSuccess) {
     p->rx_inflight.store(-1);
     return fail(GRDMA_ERR_HIP, "drain launch failed: %s", hipGetErrorString(e));
@@ -1820,7 +1903,7 @@ int64_t grdma_endpoint_read_test(grdma_pair* p, grdma_read_slice* slices, uint64
   if (!p || !slices || !window) return fail(GRDMA_ERR_INVALID, "null argument");
   const int w = p->rx_inflight.load(std::memory_order_acquire);
   if (w < 0) return fail(GRDMA_ERR_INVALID, "no drain in flight");
-  if (__atomic_load_n(&p->h->rxres.commit_seq, __ATOMIC_ACQUIRE) != p->rx_expect.load(std::memory_order_relaxed)) {
+  if (!drain_complete(p)) {
     if ((++p->test_calls_rx & 0xFFFF) == 0 && !(p->latency && g_engine.wanted)) {
       const hipError_t e = hipStreamQuery(p->s_rx);
       if (e != hipSuccess && e != hipErrorNotReady) return fail(GRDMA_ERR_HIP, "receive stream: %s", hipGetErrorString(e));
@@ -1846,14 +1929,14 @@ int64_t grdma_endpoint_read_test(grdma_pair* p, grdma_read_slice* slices, uint64
 int grdma_endpoint_readable(grdma_pair* p) {
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
   if (p->rx_inflight.load(std::memory_order_acquire) >= 0)  // a drain in flight: readable when it has completed
-    return __atomic_load_n(&p->h->rxres.commit_seq, __ATOMIC_ACQUIRE) == p->rx_expect.load(std::memory_order_relaxed) ? 1 : 0;
+    return drain_complete(p) ? 1 : 0;
   return grdma_pair_has_message(p);
 }
 
 int grdma_endpoint_drain_state(grdma_pair* p) {
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
   if (p->rx_inflight.load(std::memory_order_acquire) < 0) return 0;
-  return __atomic_load_n(&p->h->rxres.commit_seq, __ATOMIC_ACQUIRE) == p->rx_expect.load(std::memory_order_relaxed) ? 2 : 1;
+  return drain_complete(p) ? 2 : 1;
 }
 
 int grdma_endpoint_free_windows(grdma_pair* p) {

@@ -72,6 +72,12 @@ typedef struct grdma_config {
   int32_t max_sge;                   /* GRPC_RDMA_MAX_SGE: this build's stand-in for
                                         the HCA attribute max_sge (pair.cc:53-60); 30 */
   int32_t hip_device;                /* GRPC_RDMA_HIP_DEVICE (LOCAL_RANK or 0)    */
+  int32_t hip_wire_direct;           /* GRPC_RDMA_HIP_WIRE: "direct" (1, default: records are encoded straight into
+                                        the peer ring -- every wire of this build is device memory the sender can
+                                        address) or "staged" (0: through the ring/2 staging buffer and <= 2 wire
+                                        writes, what a NIC posts)                                          */
+  uint32_t hip_register_min;         /* GRPC_RDMA_HIP_REGISTER_MIN: host slices of at least this many bytes are read
+                                        where they lie (pages registered once), 0 = always copied (default) */
 } grdma_config;
 int grdma_config_from_env(grdma_config* out);
 

@@ -155,6 +155,9 @@ struct core {
         if (n > 0) {
           ahead_win = win;
           ahead_copy = !any_window_free();
+          // more has arrived meanwhile?  Then the next drain runs on the device while this one's slices are handed
+          // to the transport (it needs a window of its own; none free = it waits until this one has been released)
+          if (!ahead_copy && grdma_pair_has_message(pair) > 0) grdma_endpoint_read_submit(pair, kReadAhead);
           continue;
         }
         grdma_window_unref(win);

@@ -259,7 +259,7 @@ grpc_endpoint* grpc_rdma_bp_create(grpc_fd* em_fd, const grpc_channel_args* /*ch
   // PairPool::Take + PairPollable::Init (pair.h:288-296, pair.cc:85-141).  Fine-grained: the peer -- another
   // process -- writes this pair's ring and status block through an IPC mapping.
   grdma_pair* pair = grdma_pair_create(static_cast<uint64_t>(g_cfg.ring_buffer_size_kb) * 1024, g_cfg.max_sge,
-                                       GRDMA_WIRE_STAGED | GRDMA_RING_FINE_GRAINED);
+                                       (g_cfg.hip_wire_direct ? GRDMA_WIRE_DIRECT : GRDMA_WIRE_STAGED) | GRDMA_RING_FINE_GRAINED);
   // exchange_data + PairPollable::Connect (:640-692, :767-771; pair.cc:143-168): both ends write
   // their 48-byte Address (plus the memory handles of ring and status block) to the bootstrap
   // socket and read the peer's, full duplex, then map the peer's ring

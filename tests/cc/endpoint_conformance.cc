@@ -221,6 +221,14 @@ static std::string g_desc;
 static void record_error(void*, grpc_error_handle e) {
   if (e) { g_status = e->grpc_status; g_desc = e->description; }
 }
+// polls the endpoint until `cond` holds (asynchronous Sends / drains complete on the device's clock), 5 s at most
+template <class F>
+static int poll_until(grpc_endpoint* ep, F cond) {
+  int ran = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  while (!cond() && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5)) ran += grdma_endpoint_poll(ep);
+  return ran;
+}
 static void half_close_test() {
   fixture f = create_fixture();
   grpc_slice_buffer in;
@@ -230,8 +238,9 @@ static void half_close_test() {
   grpc_endpoint_read(f.client_ep, &in, &cb, false);
   CHECK(grdma_endpoint_poll(f.client_ep) == 0);
   grpc_endpoint_destroy(f.server_ep);  // Disconnect(): peer_exit = 1 in my status buffer
-  int ran = 0;
-  for (int i = 0; i < 100 && !ran; i++) ran = grdma_endpoint_poll(f.client_ep);
+  g_status = -1;
+  g_desc.clear();
+  const int ran = poll_until(f.client_ep, [&] { return g_status != -1; });
   CHECK(ran == 1 && g_status == GRPC_STATUS_UNAVAILABLE && g_desc == "Pair closed");
   grpc_slice_buffer_destroy(&in);
   grpc_endpoint_destroy(f.client_ep);
@@ -261,14 +270,14 @@ static void write_after_peer_exit_test() {
   CHECK(g_write_cbs == 0);
   grpc_endpoint_destroy(f.server_ep);  // peer_exit = 1: the client end is half closed
   int ran = 0;
-  for (int i = 0; i < 100 && !g_write_cbs; i++) ran += grdma_endpoint_poll(f.client_ep);
+  ran += poll_until(f.client_ep, [&] { return g_write_cbs != 0; });
   CHECK(g_write_cbs == 1 && g_status == GRPC_STATUS_UNAVAILABLE && g_desc == "Peer has been exited");
   CHECK(out.count == 0);  // reset_and_unref
   // a second write: accepted, and reported through its own closure
   fill_buffer(&out, 300000, 8192, &cur);
   g_status = -1; g_desc.clear();
   grpc_endpoint_write(f.client_ep, &out, &cb, nullptr);
-  for (int i = 0; i < 100 && g_write_cbs < 2; i++) grdma_endpoint_poll(f.client_ep);
+  poll_until(f.client_ep, [&] { return g_write_cbs >= 2; });
   CHECK(g_write_cbs == 2 && g_status == GRPC_STATUS_UNAVAILABLE && g_desc == "Peer has been exited");
   grpc_slice_buffer_destroy(&out);
   grpc_endpoint_destroy(f.client_ep);

@@ -6,15 +6,19 @@
 // from its callback.  Host slices in, host slices out: this is the PCIe-inclusive rate of the
 // boundary, reported next to the device-resident figure of bench.py (never instead of it).
 //
-// usage: endpoint_stream <n_msgs> <payload_bytes> [check 0|1] [latency 0|1]     prints one JSON line
+// usage: endpoint_stream <n_msgs> <payload_bytes> [check 0|1] [latency 0|1] [threads 1|2]     prints one JSON line
 //        latency 1: both pairs in latency mode, commands through the resident engine (no kernel launch per
-//        write / read, the receive arena in pinned host memory: no device-to-host copy per pass)
+//        write / read)
+//        threads 2 (default): the writing side and the reading side each run their own poll loop on a thread of
+//        their own, the way a gRPC process has the two directions of a connection on different threads
+//        (pair.h:64-81: one writer, one reader per pair); 1: one loop polls both endpoints
 // env:   GRPC_RDMA_RING_BUFFER_SIZE_KB, GRPC_RDMA_MAX_SGE ... as the reference reads them
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <thread>
 #include <vector>
 
 #include "grdma_endpoint.hpp"
@@ -29,7 +33,7 @@ using namespace grdma_core;
     }                                                                        \
   } while (0)
 
-static std::deque<grpc_closure*> g_queue;  // a miniature ExecCtx
+static thread_local std::deque<grpc_closure*> g_queue;  // a miniature ExecCtx (one per polling thread)
 
 // Sum of the bytes of a slice (the check of the delivered stream; independent of where the slices are cut).
 // Eight bytes per step: the even and the odd bytes of a word are added into four 16-bit lanes each, folded
@@ -59,7 +63,8 @@ struct state {
   grpc_closure done_write, done_read, next_write, next_read;
   std::vector<grpc_slice> frames;  // the slices of one message, re-referenced for every write
   size_t msgs_target, msgs_written, bytes_per_msg, bytes_read, bytes_target;
-  bool check, failed, write_done, read_done;
+  bool check, failed;
+  volatile bool write_done, read_done;
   uint64_t sum_read, sum_per_msg;
 };
 
@@ -155,29 +160,50 @@ int main(int argc, char** argv) {
   GRPC_CLOSURE_INIT(&st.next_write, do_write, &st, nullptr);
   GRPC_CLOSURE_INIT(&st.next_read, do_read, &st, nullptr);
 
-  const auto t0 = std::chrono::steady_clock::now();
-  do_read(&st, GRPC_ERROR_NONE);
-  do_write(&st, GRPC_ERROR_NONE);
-  long idle = 0;
-  while (!st.read_done || !st.write_done) {  // the pollset_work loop
-    int ran = grdma_endpoint_poll(st.rx) + grdma_endpoint_poll(st.tx);
-    while (!g_queue.empty()) {
-      grpc_closure* c = g_queue.front();
-      g_queue.pop_front();
-      c->cb(c->cb_arg, GRPC_ERROR_NONE);
-      ran++;
+  const int threads = argc > 5 ? atoi(argv[5]) : 2;
+  // the pollset_work loop of one thread: polls `ep` (and `ep2`, if any) until *flag (and *flag2)
+  auto loop = [&](grpc_endpoint* ep, grpc_endpoint* ep2, volatile bool* flag, volatile bool* flag2) {
+    const auto tl = std::chrono::steady_clock::now();
+    uint64_t spins = 0;
+    while (!*flag || (flag2 && !*flag2)) {
+      int ran = grdma_endpoint_poll(ep) + (ep2 ? grdma_endpoint_poll(ep2) : 0);
+      while (!g_queue.empty()) {
+        grpc_closure* c = g_queue.front();
+        g_queue.pop_front();
+        c->cb(c->cb_arg, GRPC_ERROR_NONE);
+        ran++;
+      }
+      if (!ran && (++spins & 0xFFFFF) == 0)
+        CHECK(std::chrono::steady_clock::now() - tl < std::chrono::seconds(100) && "endpoint made no progress");
     }
-    if (ran) idle = 0;
-    else if (++idle > 20000000) CHECK(!"endpoint made no progress");
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  if (threads >= 2) {
+    std::thread reader([&] {
+      do_read(&st, GRPC_ERROR_NONE);
+      loop(st.rx, nullptr, &st.read_done, nullptr);
+    });
+    do_write(&st, GRPC_ERROR_NONE);
+    loop(st.tx, nullptr, &st.write_done, nullptr);
+    reader.join();
+  } else {
+    do_read(&st, GRPC_ERROR_NONE);
+    do_write(&st, GRPC_ERROR_NONE);
+    loop(st.rx, st.tx, &st.read_done, &st.write_done);
   }
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   CHECK(!st.failed && st.bytes_read == st.bytes_target);
   if (st.check) CHECK(st.sum_read == st.sum_per_msg * st.msgs_target);
   printf("{\"msgs\": %zu, \"payload\": %zu, \"slices_per_write\": %zu, \"endpoint_bytes\": %zu, \"seconds\": %.6f, "
-         "\"GiBps\": %.4f, \"checked\": %s, \"latency_mode\": %s}\n",
+         "\"GiBps\": %.4f, \"checked\": %s, \"latency_mode\": %s, \"threads\": %d, \"ring_kib\": %s, \"max_sge\": %s, "
+         "\"wire\": \"%s\", \"register_min\": %s}\n",
          st.msgs_target, payload, st.frames.size(), st.bytes_target, sec,
          (double)(payload * st.msgs_target) / sec / (double)(1ull << 30), st.check ? "true" : "false",
-         latency ? "true" : "false");
+         latency ? "true" : "false", threads >= 2 ? 2 : 1,
+         getenv("GRPC_RDMA_RING_BUFFER_SIZE_KB") ? getenv("GRPC_RDMA_RING_BUFFER_SIZE_KB") : "4096",
+         getenv("GRPC_RDMA_MAX_SGE") ? getenv("GRPC_RDMA_MAX_SGE") : "30",
+         getenv("GRPC_RDMA_HIP_WIRE") ? getenv("GRPC_RDMA_HIP_WIRE") : "direct",
+         getenv("GRPC_RDMA_HIP_REGISTER_MIN") ? getenv("GRPC_RDMA_HIP_REGISTER_MIN") : "0");
   if (latency) grdma_engine_stop();
   grpc_endpoint_shutdown(st.tx, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
   grpc_endpoint_shutdown(st.rx, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
