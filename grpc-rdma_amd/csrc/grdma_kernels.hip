@@ -53,6 +53,13 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
   tx_plan_body(ops[blockIdx.x]);
 }
 
+// The send plan a streaming job's graph runs BEHIND k_tx_fast (grdma_tx_fast.hip): nothing to do when that kernel
+// planned the Send (grdma_txf_ctl::done), the general planner otherwise.
+__global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan_unless_fast(const grdma_tx_op* ops, const grdma_txf_ctl* ctls) {
+  if (ctls[blockIdx.x].done != 0) return;  // (uniform; written by a kernel that has completed)
+  tx_plan_body(ops[blockIdx.x]);
+}
+
 // k_tx_plan_seq: gridDim.y Sends of the SAME connection back to back in one launch (a sender that
 // runs ahead of its reader: rdma_flush retried before the peer has read).  ops[k * gridDim.x + link]
 // is Send k of connection `link`; every Send has its own plans, staging buffer and result block and
@@ -288,6 +295,13 @@ __attribute__((visibility("hidden"))) hipError_t grdma_launch_copy(const grdma_p
   return hipGetLastError();
 }
 
+__attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_plan_unless_fast(const grdma_tx_op* d_ops, const grdma_txf_ctl* d_ctls, uint32_t nops,
+                                                                           hipStream_t s) {
+  if (nops == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_tx_plan_unless_fast, dim3(nops), dim3(PLAN_THREADS), 0, s, d_ops, d_ctls);
+  return hipGetLastError();
+}
+
 __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_apply(const grdma_rx_op* d_ops, uint32_t nops, uint32_t blocks_per_op,
                                  hipStream_t s) {
   if (nops == 0) return hipSuccess;
@@ -304,6 +318,7 @@ __attribute__((visibility("hidden"))) const void* grdma_kernel_fn(int which) {
     case 3: return reinterpret_cast<const void*>(&k_rx_apply);
     case 4: return reinterpret_cast<const void*>(&k_tx_plan_seq);
     case 5: return reinterpret_cast<const void*>(&k_tx_commit);
+    case 6: return reinterpret_cast<const void*>(&k_tx_plan_unless_fast);
     default: return nullptr;
   }
 }

@@ -27,6 +27,20 @@ struct grdma_tx_op {
                                    // job hands it to the drain of the same round: grdma_rx_op::limit_ptr)
 };
 
+// Index of the slice buffer a streaming job writes (csrc/grdma_tx_fast.hip): prefix sums over ALL its slices, built
+// by k_tx_index at the start of a write; k_tx_fast prices every Send of the write from it.
+struct grdma_txf_ctl {
+  const struct grdma_sge* slices;  // the buffer the index was built for ...
+  uint64_t n;                      // ... and its length
+  uint64_t* enc_pre;               // [n + 1] sum of 16 + round_up8(len_j), j < k
+  uint64_t* len_pre;               // [n + 1] sum of len_j
+  uint32_t* tile_pre;              // [n + 1] sum of ceil(len_j / tile)
+  uint32_t tile_shift;             // GRDMA_PLAN_TILE_SHIFT of the connection
+  uint32_t valid;                  // k_tx_index: 1 = usable (no empty slice, lengths below 2 GiB)
+  uint32_t done;                   // k_tx_fast: 1 = it planned this Send, 0 = k_tx_plan_unless_fast has to
+  uint32_t pad;
+};
+
 // One PairPollable::SendZerocopy (pair.cc:793-941) for one connection.
 struct grdma_zc_op {
   struct grdma_conn* conn;

@@ -6,6 +6,7 @@
 // Reference counterparts: src/core/lib/ibverbs/pair.{h,cc} (PairPollable),
 // src/core/lib/iomgr/rdma_bp_posix.cc (endpoint read/write loops).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -51,6 +52,17 @@ hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*,
 hipError_t grdma_launch_engine(grdma_engine_mbox*, hipStream_t);
 const void* grdma_kernel_fn(int which);          // 0 tx_plan, 1 copy, 3 rx_apply, 4 tx_plan_seq
 const void* grdma_kernel_fn_rx_plan(void);
+const void* grdma_kernel_fn_rx_plan_unless_fast(void);
+const void* grdma_kernel_fn_rx_fast(void);
+uint32_t grdma_rx_fast_threads(void);
+hipError_t grdma_launch_rx_fast(const grdma_rx_op*, uint32_t, hipStream_t);
+hipError_t grdma_launch_rx_plan_unless_fast(const grdma_rx_op*, uint32_t, hipStream_t);
+const void* grdma_kernel_fn_tx_fast(void);
+const void* grdma_kernel_fn_tx_index(void);
+uint32_t grdma_tx_fast_threads(void);
+hipError_t grdma_launch_tx_index(grdma_txf_ctl*, uint32_t, hipStream_t);
+hipError_t grdma_launch_tx_fast(const grdma_tx_op*, grdma_txf_ctl*, uint32_t, hipStream_t);
+hipError_t grdma_launch_tx_plan_unless_fast(const grdma_tx_op*, const grdma_txf_ctl*, uint32_t, hipStream_t);
 const void* grdma_kernel_fn_plan_pair(void);
 uint32_t grdma_kernel_threads(int which);
 uint32_t grdma_copy_resident_blocks(void);
@@ -2009,6 +2021,10 @@ struct grdma_job_link {
   uint8_t* dst = nullptr;
   uint64_t dst_cap = 0;
   // second copies of what two rounds in flight would otherwise share (pipelined mode)
+  // index of the slice buffer (k_tx_index / k_tx_fast, grdma_tx_fast.hip): [count + 1] entries each
+  uint64_t* d_encpre = nullptr;
+  uint64_t* d_lenpre = nullptr;
+  uint32_t* d_tilepre = nullptr;
   grdma_plan* d_wireplan2 = nullptr;
   grdma_plan* d_rxplan2 = nullptr;
   uint8_t* d_staging2 = nullptr;
@@ -2042,7 +2058,20 @@ struct grdma_stream_job {
   int exec_pipeline = -1;
   int pipeline = 0;                   // 1: overlap the send plan / gather / scatter of
                                       // neighbouring rounds on side streams
+  int deep = 1;                       // pipelined graph: 1 = the limit-driven schedule (job_build_graph),
+                                      // 0 = the schedule of rounds 1-2 (GRDMA_JOB_SCHEDULE=pair)
   hipStream_t s_wire = nullptr, s_rxplan = nullptr, s_apply = nullptr;
+  // reserved-CU schedule (job_enqueue_masked): the two planners on streams whose CU mask is a few CUs of
+  // their own, the copy kernels on streams masked to the rest, so a one-workgroup planner never waits for a
+  // machine-filling copy kernel to retire
+  int tx_fast = 1;                    // Sends of one-Send rounds are priced from an index of the slice buffer: k_tx_index at
+                                      // the start of a step, k_tx_fast per Send, the general planner behind it for the rest
+  grdma_txf_ctl* d_txf = nullptr;     // [n]
+  int rx_fast = 1;                    // drains of one-Send rounds go through k_rx_fast first (grdma_rx_fast.hip), the
+                                      // general planner behind it only does what that kernel declined
+  int cumask_bits = 0;                // planner CUs (low bits of the mask); 0 = off
+  hipStream_t m_txplan = nullptr, m_rxplan = nullptr, m_copy = nullptr, m_apply = nullptr;
+  std::vector<hipEvent_t> mev;
   std::vector<hipEvent_t> pev;        // dependency events of the pipelined schedule
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> kev;
@@ -2064,6 +2093,28 @@ struct grdma_stream_job {
 namespace {
 
 inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 : 2); }
+
+// the send plan of round t: priced from the index of the slice buffer (built in front of the first round of a
+// step), the general planner for what k_tx_fast declined
+inline bool job_tx_fast(const grdma_stream_job* j) { return j->tx_fast && j->burst == 1 && !j->direct; }
+hipError_t job_launch_tx_plan(grdma_stream_job* j, int k, uint64_t t, uint32_t n, hipStream_t s) {
+  if (!job_tx_fast(j)) return grdma_launch_tx_plan(j->d_txop + k * n, n, s);
+  hipError_t e = hipSuccess;
+  if (t == 0) e = grdma_launch_tx_index(j->d_txf, n, s);
+  if (e == hipSuccess) e = grdma_launch_tx_fast(j->d_txop + k * n, j->d_txf, n, s);
+  if (e == hipSuccess) e = grdma_launch_tx_plan_unless_fast(j->d_txop + k * n, j->d_txf, n, s);
+  return e;
+}
+
+// the receive plan of a round: the short steady-state kernel first, the general planner for what it declined
+hipError_t job_launch_rx_plan(grdma_stream_job* j, const grdma_rx_op* ops, uint32_t n, hipStream_t s) {
+  if (j->rx_fast && j->burst == 1) {
+    hipError_t e = grdma_launch_rx_fast(ops, n, s);
+    if (e != hipSuccess) return e;
+    return grdma_launch_rx_plan_unless_fast(ops, n, s);
+  }
+  return grdma_launch_rx_plan(ops, n, s);
+}
 
 int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
   const uint32_t n = (uint32_t)j->links.size();
@@ -2097,14 +2148,14 @@ int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
       if (!j->direct) HIP_TRY(grdma_launch_copy(j->d_bplans + (size_t)B * n, B * n, txb_b, s));
       if (int rc = mark()) return rc;
     } else {
-    HIP_TRY(grdma_launch_tx_plan(j->d_txop + k * n, n, s));
+    HIP_TRY(job_launch_tx_plan(j, k, r, n, s));
     if (int rc = mark()) return rc;
     HIP_TRY(grdma_launch_copy(j->d_plans, n, txb, s));
     if (int rc = mark()) return rc;
     if (!j->direct) HIP_TRY(grdma_launch_copy(j->d_plans + n * (1 + (r & 1)), n, txb, s));
     if (int rc = mark()) return rc;
     }
-    HIP_TRY(grdma_launch_rx_plan(j->d_rxop + k * n, n, s));
+    HIP_TRY(job_launch_rx_plan(j, j->d_rxop + k * n, n, s));
     if (int rc = mark()) return rc;
     HIP_TRY(grdma_launch_rx_apply(j->d_rxop + k * n, n, rxb, s));
     if (int rc = mark()) return rc;
@@ -2129,6 +2180,8 @@ int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
 // the wire and being walked, and the scatter of round t runs under round t+1.  The
 // sender may see the credit of a scatter one round later than in the sequential
 // schedule; with rounds of at most ring/6 that never limits a Send.
+// Round 3 (j->deep, the default): every drain of a job walks only up to the tail its own Send computed
+// (grdma_rx_op::limit_ptr), so the third rule is dropped -- see the graph builder below for the edges.
 int job_enqueue_pipelined(grdma_stream_job* j, hipStream_t s) {
   const uint32_t n = (uint32_t)j->links.size();
   const uint32_t tx_blocks = copy_blocks_for(j->max_ring / 2);
@@ -2162,8 +2215,13 @@ int job_enqueue_pipelined(grdma_stream_job* j, hipStream_t s) {
     if (j->direct) {
       // the plan itself writes the tags into the peer ring: no part of round t may start
       // before the receiver has finished walking round t-1
-      if (t >= 1) HIP_TRY(hipStreamWaitEvent(s, evX(t - 1), 0));
-      HIP_TRY(grdma_launch_tx_plan(j->d_txop + k * n, n, s));
+      // (limit-driven schedule: the drain walks up to its round's tail, only the credit lag is bounded)
+      if (j->deep) {
+        if (t >= 2) HIP_TRY(hipStreamWaitEvent(s, evA(t - 2), 0));
+      } else if (t >= 1) {
+        HIP_TRY(hipStreamWaitEvent(s, evX(t - 1), 0));
+      }
+      HIP_TRY(job_launch_tx_plan(j, k, t, n, s));
       HIP_TRY(grdma_launch_copy(j->d_plans, n, txb, s));
       HIP_TRY(hipEventRecord(evW(t), s));
     } else {
@@ -2171,17 +2229,17 @@ int job_enqueue_pipelined(grdma_stream_job* j, hipStream_t s) {
         HIP_TRY(hipStreamWaitEvent(s, evW(t - 2), 0));
         HIP_TRY(hipStreamWaitEvent(s, evA(t - 2), 0));  // bounds the credit lag to one round
       }
-      HIP_TRY(grdma_launch_tx_plan(j->d_txop + k * n, n, s));
+      HIP_TRY(job_launch_tx_plan(j, k, t, n, s));
       HIP_TRY(grdma_launch_copy(j->d_plans, n, txb, s));
       HIP_TRY(hipEventRecord(evG(t), s));
       HIP_TRY(hipStreamWaitEvent(sW, evG(t), 0));
-      if (t >= 1) HIP_TRY(hipStreamWaitEvent(sW, evX(t - 1), 0));
+      if (t >= 1 && !j->deep) HIP_TRY(hipStreamWaitEvent(sW, evX(t - 1), 0));
       HIP_TRY(grdma_launch_copy(j->d_plans + n * (1 + (t & 1)), n, txb, sW));
       HIP_TRY(hipEventRecord(evW(t), sW));
     }
     HIP_TRY(hipStreamWaitEvent(sX, evW(t), 0));
     if (t >= 2) HIP_TRY(hipStreamWaitEvent(sX, evA(t - 2), 0));
-    HIP_TRY(grdma_launch_rx_plan(j->d_rxop + k * n, n, sX));
+    HIP_TRY(job_launch_rx_plan(j, j->d_rxop + k * n, n, sX));
     HIP_TRY(hipEventRecord(evX(t), sX));
     HIP_TRY(hipStreamWaitEvent(sA, evX(t), 0));
     HIP_TRY(grdma_launch_rx_apply(j->d_rxop + k * n, n, rxb, sA));
@@ -2192,6 +2250,85 @@ int job_enqueue_pipelined(grdma_stream_job* j, hipStream_t s) {
     if (!j->direct) HIP_TRY(hipStreamWaitEvent(s, evW(R - 1), 0));
     HIP_TRY(hipStreamWaitEvent(s, evX(R - 1), 0));
     HIP_TRY(hipStreamWaitEvent(s, evA(R - 1), 0));
+  }
+  HIP_TRY(grdma_launch_tx_commit(j->d_txconns, nullptr, n, s));
+  return 0;
+}
+
+
+// The limit-driven schedule on streams with CU masks.  A planner is ONE workgroup that needs most of a
+// CU's register file; the copy kernels are grid-strided over every slot of the machine and give none back
+// before they end, so a planner that becomes ready while a copy kernel is resident starts only behind it --
+// on a shared machine the planners serialise with the copies whatever the dependency edges say (measured:
+// the limit-driven graph is SLOWER than the paired one, 1.14 vs 1.04 ms per step).  Here the planners own
+// `cumask_bits` CUs (hipExtStreamCreateWithCUMask) and the copies run on the rest:
+//   m_txplan: P_t   after W_{t-2}, A_{t-2}, G_{t-1}
+//   m_copy:   G_t after P_t, then W_t                       (in stream order; they fill the machine anyway)
+//   m_rxplan: X_t   after W_t, A_{t-2}
+//   m_apply:  A_t   after X_t
+int job_enqueue_masked(grdma_stream_job* j, hipStream_t s) {
+  const uint32_t n = (uint32_t)j->links.size();
+  const uint32_t tx_blocks = copy_blocks_for(j->max_ring / 2);
+  const uint32_t rx_blocks = copy_blocks_for(j->max_ring);
+  const uint32_t grid_cap = copy_blocks_for(~0ull >> 8);
+  const uint32_t txb = std::max<uint32_t>(1, std::min<uint32_t>(tx_blocks, grid_cap / n + 1));
+  const uint32_t rxb = std::max<uint32_t>(1, std::min<uint32_t>(rx_blocks, grid_cap / n + 1));
+  const uint64_t R = j->rounds;
+  if (!j->m_txplan) {
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int words = (cus + 31) / 32;
+    std::vector<uint32_t> mp(words, 0u), mc(words, 0xFFFFFFFFu);
+    for (int b = 0; b < j->cumask_bits && b < cus; b++) {
+      mp[b / 32] |= 1u << (b % 32);
+      mc[b / 32] &= ~(1u << (b % 32));
+    }
+    HIP_TRY(hipExtStreamCreateWithCUMask(&j->m_txplan, (uint32_t)words, mp.data()));
+    HIP_TRY(hipExtStreamCreateWithCUMask(&j->m_rxplan, (uint32_t)words, mp.data()));
+    HIP_TRY(hipExtStreamCreateWithCUMask(&j->m_copy, (uint32_t)words, mc.data()));
+    HIP_TRY(hipExtStreamCreateWithCUMask(&j->m_apply, (uint32_t)words, mc.data()));
+  }
+  while (j->mev.size() < 5 * R + 1) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    j->mev.push_back(ev);
+  }
+  auto evP = [&](uint64_t t) { return j->mev[5 * t]; };
+  auto evG = [&](uint64_t t) { return j->mev[5 * t + 1]; };
+  auto evW = [&](uint64_t t) { return j->mev[5 * t + 2]; };  // round t is in the ring
+  auto evX = [&](uint64_t t) { return j->mev[5 * t + 3]; };
+  auto evA = [&](uint64_t t) { return j->mev[5 * t + 4]; };
+  hipStream_t sP = j->m_txplan, sC = j->m_copy, sX = j->m_rxplan, sA = j->m_apply;
+  hipEvent_t fork = j->mev[5 * R];
+  HIP_TRY(hipEventRecord(fork, s));
+  for (hipStream_t st : {sP, sC, sX, sA}) HIP_TRY(hipStreamWaitEvent(st, fork, 0));
+  for (uint64_t t = 0; t < R; t++) {
+    const int k = job_opset(t);
+    if (t >= 1) HIP_TRY(hipStreamWaitEvent(sP, evG(t - 1), 0));
+    if (t >= 2) {
+      HIP_TRY(hipStreamWaitEvent(sP, evW(t - 2), 0));
+      HIP_TRY(hipStreamWaitEvent(sP, evA(t - 2), 0));
+    }
+    HIP_TRY(job_launch_tx_plan(j, k, t, n, sP));
+    HIP_TRY(hipEventRecord(evP(t), sP));
+    HIP_TRY(hipStreamWaitEvent(sC, evP(t), 0));
+    HIP_TRY(grdma_launch_copy(j->d_plans, n, txb, sC));
+    HIP_TRY(hipEventRecord(evG(t), sC));
+    if (!j->direct) HIP_TRY(grdma_launch_copy(j->d_plans + n * (1 + (t & 1)), n, txb, sC));
+    HIP_TRY(hipEventRecord(evW(t), sC));
+    HIP_TRY(hipStreamWaitEvent(sX, evW(t), 0));
+    if (t >= 2) HIP_TRY(hipStreamWaitEvent(sX, evA(t - 2), 0));
+    HIP_TRY(job_launch_rx_plan(j, j->d_rxop + k * n, n, sX));
+    HIP_TRY(hipEventRecord(evX(t), sX));
+    HIP_TRY(hipStreamWaitEvent(sA, evX(t), 0));
+    HIP_TRY(grdma_launch_rx_apply(j->d_rxop + k * n, n, rxb, sA));
+    HIP_TRY(hipEventRecord(evA(t), sA));
+  }
+  if (R > 0) {
+    HIP_TRY(hipStreamWaitEvent(s, evW(R - 1), 0));
+    HIP_TRY(hipStreamWaitEvent(s, evA(R - 1), 0));
+    HIP_TRY(hipStreamWaitEvent(s, evP(R - 1), 0));
   }
   HIP_TRY(grdma_launch_tx_commit(j->d_txconns, nullptr, n, s));
   return 0;
@@ -2239,6 +2376,38 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
   const void* f_rxp = grdma_kernel_fn_rx_plan();
   const void* f_rxa = grdma_kernel_fn(3);
   const uint32_t pt = grdma_kernel_threads(0), ct = grdma_kernel_threads(1);
+  const bool fast = j->rx_fast && j->burst == 1;
+  const bool tfast = job_tx_fast(j);
+  const void* f_txf = grdma_kernel_fn_tx_fast();
+  const void* f_txi = grdma_kernel_fn_tx_index();
+  const void* f_txu = grdma_kernel_fn(6);
+  const uint32_t tft = grdma_tx_fast_threads();
+  // P[t] = the send plan of round t: (the index of the slice buffer in front of round 0,) k_tx_fast, then the
+  // general planner for what it declined
+  auto add_tx = [&](uint64_t t, const void* txop, std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
+    if (!tfast) return add(&P[t], f_txp, dim3(n), pt, txop, deps);
+    hipGraphNode_t pf, pi = nullptr;
+    hipError_t e2 = hipSuccess;
+    if (t == 0) {
+      e2 = add(&pi, f_txi, dim3(n), tft, j->d_txf, deps);
+      if (e2 == hipSuccess) e2 = add2(&pf, f_txf, dim3(n), tft, txop, j->d_txf, {pi});
+    } else {
+      e2 = add2(&pf, f_txf, dim3(n), tft, txop, j->d_txf, deps);
+    }
+    if (e2 != hipSuccess) return e2;
+    return add2(&P[t], f_txu, dim3(n), pt, txop, j->d_txf, {pf});
+  };
+  const void* f_rxf = grdma_kernel_fn_rx_fast();
+  const void* f_rxu = grdma_kernel_fn_rx_plan_unless_fast();
+  const uint32_t ft = grdma_rx_fast_threads();
+  // X[t] = the receive plan of round t: k_rx_fast, then the general planner for what it declined
+  auto add_rx = [&](uint64_t t, const void* rxop, std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
+    if (!fast) return add(&X[t], f_rxp, dim3(n), pt, rxop, deps);
+    hipGraphNode_t xf;
+    hipError_t e2 = add(&xf, f_rxf, dim3(n), ft, rxop, deps);
+    if (e2 != hipSuccess) return e2;
+    return add(&X[t], f_rxu, dim3(n), pt, rxop, {xf});
+  };
   auto at = [](std::vector<hipGraphNode_t>& v, uint64_t t, uint64_t back) -> hipGraphNode_t {
     return t >= back ? v[t - back] : nullptr;
   };
@@ -2269,7 +2438,7 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
       if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t]});
     } else if (!j->pipeline) {
       hipGraphNode_t prev = at(A, t, 1);
-      e = add(&P[t], f_txp, dim3(n), pt, txop, {prev});
+      e = add_tx(t, txop, {prev});
       if (e == hipSuccess) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t]});
       hipGraphNode_t last = G[t];
       W[t] = nullptr;
@@ -2277,8 +2446,30 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
         e = add(&W[t], f_cpy, dim3(txb, n), ct, wplans, {G[t]});
         last = W[t];
       }
-      if (e == hipSuccess) e = add(&X[t], f_rxp, dim3(n), pt, rxop, {last});
+      if (e == hipSuccess) e = add_rx(t, rxop, {last});
       if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t]});
+    } else if (j->deep || fast || tfast) {
+      // Limit-driven schedule (default): the drain of round t walks exactly up to the tail its Send
+      // computed (grdma_rx_op::limit_ptr), so round t + 1 may land in the ring while round t is being
+      // walked -- the edge rx_plan_{t-1} -> wire_t of the older schedule is gone and both planners
+      // leave the wire's path.  What is left of the ordering:
+      //   P_t: P_{t-1} (the sender's state), G_{t-1} (one gather plan), W_{t-2} (staging / wire plan of
+      //        this parity), A_{t-2} (credit lag of at most one round; implies X_{t-2}: the limit slot)
+      //   G_t: P_t      W_t: G_t      X_t: W_t, X_{t-1} (the reader's state), A_{t-2} (scatter plan / result
+      //        of this parity)        A_t: X_t, A_{t-1} (credit reports stay in order)
+      // The only cycle that spans rounds is A_{t-2} -> P_t -> G_t -> W_t -> X_t -> A_t: two rounds in
+      // flight, (P + G + W + X + A) / 2 per round.
+      const hipGraphNode_t wprev2 = j->direct ? at(G, t, 2) : at(W, t, 2);
+      e = add_tx(t, txop, {at(P, t, 1), at(G, t, 1), wprev2, at(A, t, 2)});
+      if (e == hipSuccess) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t]});
+      hipGraphNode_t last = G[t];
+      W[t] = nullptr;
+      if (!j->direct && e == hipSuccess) {
+        e = add(&W[t], f_cpy, dim3(txb, n), ct, wplans, {G[t]});
+        last = W[t];
+      }
+      if (e == hipSuccess) e = add_rx(t, rxop, {last, at(X, t, 1), at(A, t, 2)});
+      if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t], at(A, t, 1)});
     } else if (j->direct) {
       e = add(&P[t], f_txp, dim3(n), pt, txop, {at(G, t, 1), at(X, t, 1)});
       if (e == hipSuccess) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t]});
@@ -2458,6 +2649,10 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
     return nullptr;
   }
   grdma_stream_job* j = new grdma_stream_job();
+  if (const char* e = getenv("GRDMA_JOB_SCHEDULE")) j->deep = strcmp(e, "pair") == 0 ? 0 : 1;
+  if (const char* e = getenv("GRDMA_JOB_CUMASK")) j->cumask_bits = atoi(e);
+  if (const char* e = getenv("GRDMA_RX_FAST")) j->rx_fast = atoi(e) != 0;
+  if (const char* e = getenv("GRDMA_TX_FAST")) j->tx_fast = atoi(e) != 0;
   j->rounds = max_rounds;
   j->stream = tx[0]->stream;
   j->direct = (tx[0]->flags & GRDMA_WIRE_DIRECT) != 0;
@@ -2483,7 +2678,10 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
          hipMalloc((void**)&l.d_slices, sizeof(grdma_slice_out) * l.slices_cap) == hipSuccess &&
          hipMalloc((void**)&l.d_wireplan2, sizeof(grdma_plan)) == hipSuccess &&
          hipMalloc((void**)&l.d_rxplan2, sizeof(grdma_plan)) == hipSuccess &&
-         (j->direct || hipMalloc((void**)&l.d_staging2, tx[i]->ring_size / 2 + 64) == hipSuccess);
+         (j->direct || hipMalloc((void**)&l.d_staging2, tx[i]->ring_size / 2 + 64) == hipSuccess) &&
+         hipMalloc((void**)&l.d_encpre, sizeof(uint64_t) * (l.count + 1)) == hipSuccess &&
+         hipMalloc((void**)&l.d_lenpre, sizeof(uint64_t) * (l.count + 1)) == hipSuccess &&
+         hipMalloc((void**)&l.d_tilepre, sizeof(uint32_t) * (l.count + 1)) == hipSuccess;
     if (!ok) break;
     hipMemset(l.d_wireplan2, 0, sizeof(grdma_plan));
     hipMemset(l.d_rxplan2, 0, sizeof(grdma_plan));
@@ -2557,6 +2755,25 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
     grdma_stream_job_destroy(j);
     return nullptr;
   }
+  {
+    std::vector<grdma_txf_ctl> h_txf(n);
+    for (uint32_t i = 0; i < n; i++) {
+      const grdma_job_link& l = j->links[i];
+      memset(&h_txf[i], 0, sizeof(grdma_txf_ctl));
+      h_txf[i].slices = l.d_sges;
+      h_txf[i].n = l.count;
+      h_txf[i].enc_pre = l.d_encpre;
+      h_txf[i].len_pre = l.d_lenpre;
+      h_txf[i].tile_pre = l.d_tilepre;
+      h_txf[i].tile_shift = GRDMA_PLAN_TILE_SHIFT(l.tx->ring_size);
+    }
+    if (hipMalloc((void**)&j->d_txf, sizeof(grdma_txf_ctl) * n) != hipSuccess ||
+        hipMemcpy(j->d_txf, h_txf.data(), sizeof(grdma_txf_ctl) * n, hipMemcpyHostToDevice) != hipSuccess) {
+      fail(GRDMA_ERR_HIP, "job index block allocation failed");
+      grdma_stream_job_destroy(j);
+      return nullptr;
+    }
+  }
   return j;
 }
 
@@ -2572,13 +2789,20 @@ void grdma_stream_job_destroy(grdma_stream_job* j) {
   if (!j) return;
   if (j->stream) hipStreamSynchronize(j->stream);
   if (j->exec) hipGraphExecDestroy(j->exec);
-  for (hipStream_t st : {j->s_wire, j->s_rxplan, j->s_apply})
+  for (hipStream_t st : {j->s_wire, j->s_rxplan, j->s_apply, j->m_txplan, j->m_rxplan, j->m_copy, j->m_apply})
     if (st) {
       hipStreamSynchronize(st);
       hipStreamDestroy(st);
     }
+  if (j->d_txf) hipFree(j->d_txf);
+  for (grdma_job_link& l : j->links) {
+    if (l.d_encpre) hipFree(l.d_encpre);
+    if (l.d_lenpre) hipFree(l.d_lenpre);
+    if (l.d_tilepre) hipFree(l.d_tilepre);
+  }
   for (hipEvent_t e : j->kev) hipEventDestroy(e);
   for (hipEvent_t e : j->pev) hipEventDestroy(e);
+  for (hipEvent_t e : j->mev) hipEventDestroy(e);
   if (j->ev0) hipEventDestroy(j->ev0);
   if (j->ev1) hipEventDestroy(j->ev1);
   for (auto& l : j->links) {
@@ -2717,7 +2941,7 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
   } else {
     HIP_TRY(hipEventRecord(j->ev0, s));
     if (j->pipeline && j->burst == 1 && mode == GRDMA_RUN_EAGER) {
-      if (int rc = job_enqueue_pipelined(j, s)) return rc;
+      if (int rc = (j->cumask_bits > 0 ? job_enqueue_masked(j, s) : job_enqueue_pipelined(j, s))) return rc;
     } else {
       if (int rc = job_enqueue(j, s, mode == GRDMA_RUN_INSTRUMENTED)) return rc;
     }
@@ -2855,6 +3079,7 @@ int grdma_stream_job_engine_stats(grdma_stream_job* j, uint32_t link, uint64_t o
 int grdma_stream_job_launch_streams(grdma_stream_job* j) {
   if (int rc = require_ctx()) return rc;
   if (!j) return fail(GRDMA_ERR_INVALID, "null job");
+  if (j->pipeline && j->cumask_bits > 0 && j->burst == 1) return job_enqueue_masked(j, j->stream);
   return j->pipeline ? job_enqueue_pipelined(j, j->stream) : job_enqueue(j, j->stream, false);
 }
 

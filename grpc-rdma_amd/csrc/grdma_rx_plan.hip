@@ -1409,6 +1409,14 @@ void k_rx_plan(const grdma_rx_op* ops) {
   rx_plan_body(ops[blockIdx.x]);
 }
 
+// The drain a streaming job's graph runs BEHIND k_rx_fast (grdma_rx_fast.hip): nothing to do when that kernel
+// took the drain (it says so in the result block), the general planner otherwise.
+__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_rx_plan_unless_fast(const grdma_rx_op* ops) {
+  if (ops[blockIdx.x].result->pad1 != 0) return;  // (uniform; written by a kernel that has completed)
+  rx_plan_body(ops[blockIdx.x]);
+}
+
 // Out-of-line copies for the resident engine: with both bodies inlined into its
 // command loop the structurizer merges the loop tails and parks lane 0 behind
 // the other lanes' next barrier (a deadlock); real calls keep the loop simple.
@@ -1596,6 +1604,12 @@ extern "C" uint64_t grdma_express_drains(void) {
 }
 
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rx_plan(void) { return reinterpret_cast<const void*>(&k_rx_plan); }
+extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rx_plan_unless_fast(void) { return reinterpret_cast<const void*>(&k_rx_plan_unless_fast); }
+extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan_unless_fast(const grdma_rx_op* d_ops, uint32_t nops, hipStream_t s) {
+  if (nops == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_rx_plan_unless_fast, dim3(nops), dim3(PLAN_THREADS), 0, s, d_ops);
+  return hipGetLastError();
+}
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair(void) { return reinterpret_cast<const void*>(&k_plan_pair); }
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan(const grdma_rx_op* d_ops, uint32_t nops,

@@ -422,6 +422,8 @@ int grdma_pair_debug_hist(grdma_pair* p, uint32_t* hist_out /* 1024 entries */, 
                           uint32_t* period);
 int grdma_engine_debug(uint64_t out[5]);
 uint64_t grdma_express_drains(void);  /* drains served by the single-wave express path so far */
+int grdma_tx_fast_sends(uint64_t out[2]);  /* Sends of streaming jobs planned by k_tx_fast [0], left to the general planner [1] (csrc/grdma_tx_fast.hip) */
+int grdma_rx_fast_drains(uint64_t out[6]);  /* drains of streaming jobs taken by k_rx_fast [0], declined by reason [1..5] (csrc/grdma_rx_fast.hip) */
 int grdma_tx_small_ticks(uint64_t out[8]);  /* profiling aid: phase ticks of the latency engine's small Sends */
 /* Scalar ring arithmetic of the host layer (ring_buffer.h:101-143), exported so that the
  * CPU tests can pin it against the oracle without a device. */

@@ -131,6 +131,7 @@ inline hipError_t hipMemcpyFromSymbol(void* d, const T& sym, size_t n, size_t of
 
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = reinterpret_cast<hipStream_t>(malloc(8)); return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, const unsigned*) { return hipStreamCreate(s); }
 inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t s);  // (defined below: waits for a resident kernel on the stream)
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }

@@ -147,3 +147,51 @@ def test_pipelined_job_delivers_the_same_stream(gpu, case, flags):
         # records, hence the same endpoint reads, as the sequential one
         assert [len(x) for x in pip["slices"]] == [len(x) for x in seq["slices"]]
         assert pip["rx"] == seq["rx"] and pip["tx"]["remote_tail"] == seq["tx"]["remote_tail"]
+
+
+def _fast_counts(g):
+    import ctypes as C
+    lib = g.load()
+    out = (C.c_uint64 * 6)()
+    lib.grdma_rx_fast_drains.argtypes = [C.POINTER(C.c_uint64)]
+    assert lib.grdma_rx_fast_drains(out) == 0
+    tx = (C.c_uint64 * 2)()
+    lib.grdma_tx_fast_sends.argtypes = [C.POINTER(C.c_uint64)]
+    assert lib.grdma_tx_fast_sends(tx) == 0
+    return [int(x) for x in out] + [int(x) for x in tx]
+
+
+# Streams whose record sizes are periodic and whose rounds are cut by max_sge (not by the staging budget): the
+# steady state k_rx_fast (csrc/grdma_rx_fast.hip) takes.  An ODD max_sge makes every other round end behind a
+# frame-header slice (the next round starts with a read of capacity 247 left open); several passes over a ring of a
+# few rounds walk the ring end through the records and cross the credit threshold (ring / 2) inside a drain.
+FAST_CASES = [
+    # (ring, max_sge, n_msgs, msg_len)
+    (1 << 24, 255, 40, 1 << 17),
+    (1 << 25, 511, 36, 1 << 18),
+    (1 << 23, 130, 48, 40000),
+]
+
+
+@pytest.mark.parametrize("pipeline", [False, True], ids=["sequential", "pipelined"])
+@pytest.mark.parametrize("case", FAST_CASES, ids=["r16m_sge255", "r32m_sge511", "r8m_sge130"])
+def test_steady_state_drains_through_the_fast_planner_match_the_oracle(gpu, case, pipeline):
+    R, max_sge, n_msgs, msg_len = case
+    slices = _framed_slices(n_msgs, msg_len, seed=R % 89)
+    exp, exp_rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, slices)
+    before = _fast_counts(gpu)
+    got = _run_job(gpu, R, max_sge, slices, pipeline=pipeline)
+    after = _fast_counts(gpu)
+    assert [len(x) for x in got["slices"]] == [len(x) for x in exp]
+    assert got["slices"] == exp
+    assert got["rounds"] == exp_rounds
+    assert got["ring"] == ring == bytes(R)
+    for k in ("remote_tail", "remote_head", "partial_write"):
+        assert got["tx"][k] == st0[k], k
+    for k in ("head", "moving_head", "remain", "internal_read_size"):
+        assert got["rx"][k] == st1[k], k
+    took = after[0] - before[0]
+    assert took >= exp_rounds, "k_rx_fast took %d drains (declined by reason: %s)" % (
+        took, [a - b for a, b in zip(after[1:6], before[1:6])])
+    # every Send of the three passes is priced from the index of the slice buffer (staged wire, no empty slice)
+    assert after[6] - before[6] >= PASSES * exp_rounds and after[7] == before[7], (after[6:], before[6:])
