@@ -214,8 +214,8 @@ struct grdma_rx_result {
   uint64_t zero_len[2];
   uint64_t seq;            // bumped by k_rx_plan
   uint64_t commit_seq;     // bumped by k_rx_commit (copy + zero-fill + credit done)
-  uint32_t pad1;           // (the k_rx_apply arrival counter moved into the plan: device memory)
-  uint32_t pad0;
+  uint32_t pad1;           // drains of this block taken by the steady-state body (grdma_rx_fast.h) ...
+  uint32_t pad0;           // ... and declined by it with data waiting (what grdma_stream_job_run adapts to)
   uint64_t dbg[16];        // s_memtime stamps of the plan phases (profiling aid)
 };
 

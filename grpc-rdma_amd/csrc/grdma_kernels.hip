@@ -36,6 +36,7 @@
 #include "grdma_devfn.h"
 #include "grdma_ops.h"
 #include "grdma_tx_body.h"
+#include "grdma_tx_fast.h"
 
 #ifndef GRDMA_COPY_CONTIG
 #define GRDMA_COPY_CONTIG true
@@ -53,11 +54,14 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
   tx_plan_body(ops[blockIdx.x]);
 }
 
-// The send plan a streaming job's graph runs BEHIND k_tx_fast (grdma_tx_fast.hip): nothing to do when that kernel
-// planned the Send (grdma_txf_ctl::done), the general planner otherwise.
-__global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan_unless_fast(const grdma_tx_op* ops, const grdma_txf_ctl* ctls) {
-  if (ctls[blockIdx.x].done != 0) return;  // (uniform; written by a kernel that has completed)
+// The send plan of a streaming job's round: priced from the index of the slice buffer first (grdma_tx_fast.h); what
+// that body declines -- nothing has been written then -- goes through the general planner in the same launch.
+// (launched in the index body's shape, 1024 threads; the general planner is a 256-thread body: waves 4-15 leave)
+__global__ __launch_bounds__(TXB_THREADS) void k_tx_plan_job(const grdma_tx_op* ops, const grdma_txf_ctl* ctls) {
+  if (txf_body(ops[blockIdx.x], &ctls[blockIdx.x])) return;  // (uniform)
+  if (threadIdx.x >= PLAN_THREADS) return;
   tx_plan_body(ops[blockIdx.x]);
+  if (threadIdx.x == 0) ops[blockIdx.x].result->dbg[9] = 0;  // (not priced from the index)
 }
 
 // k_tx_plan_seq: gridDim.y Sends of the SAME connection back to back in one launch (a sender that
@@ -295,11 +299,20 @@ __attribute__((visibility("hidden"))) hipError_t grdma_launch_copy(const grdma_p
   return hipGetLastError();
 }
 
-__attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_plan_unless_fast(const grdma_tx_op* d_ops, const grdma_txf_ctl* d_ctls, uint32_t nops,
-                                                                           hipStream_t s) {
+__attribute__((visibility("hidden"))) uint32_t grdma_tx_plan_job_threads(void) { return TXB_THREADS; }
+__attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_plan_job(const grdma_tx_op* d_ops, const grdma_txf_ctl* d_ctls, uint32_t nops,
+                                                                   hipStream_t s) {
   if (nops == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_tx_plan_unless_fast, dim3(nops), dim3(PLAN_THREADS), 0, s, d_ops, d_ctls);
+  hipLaunchKernelGGL(k_tx_plan_job, dim3(nops), dim3(TXB_THREADS), 0, s, d_ops, d_ctls);
   return hipGetLastError();
+}
+// diagnostics: Sends of streaming jobs planned by txf_body [0], left to the general planner [1]
+int grdma_tx_fast_sends(uint64_t out[2]) {
+  unsigned long long v[2] = {0, 0};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_tx_fast_sends), sizeof(v)) != hipSuccess) return -1;
+  out[0] = v[0];
+  out[1] = v[1];
+  return 0;
 }
 
 __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_apply(const grdma_rx_op* d_ops, uint32_t nops, uint32_t blocks_per_op,
@@ -318,7 +331,7 @@ __attribute__((visibility("hidden"))) const void* grdma_kernel_fn(int which) {
     case 3: return reinterpret_cast<const void*>(&k_rx_apply);
     case 4: return reinterpret_cast<const void*>(&k_tx_plan_seq);
     case 5: return reinterpret_cast<const void*>(&k_tx_commit);
-    case 6: return reinterpret_cast<const void*>(&k_tx_plan_unless_fast);
+    case 6: return reinterpret_cast<const void*>(&k_tx_plan_job);
     default: return nullptr;
   }
 }

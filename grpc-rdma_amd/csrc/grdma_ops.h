@@ -37,7 +37,7 @@ struct grdma_txf_ctl {
   uint32_t* tile_pre;              // [n + 1] sum of ceil(len_j / tile)
   uint32_t tile_shift;             // GRDMA_PLAN_TILE_SHIFT of the connection
   uint32_t valid;                  // k_tx_index: 1 = usable (no empty slice, lengths below 2 GiB)
-  uint32_t done;                   // k_tx_fast: 1 = it planned this Send, 0 = k_tx_plan_unless_fast has to
+  uint32_t done;                   // (unused)
   uint32_t pad;
 };
 

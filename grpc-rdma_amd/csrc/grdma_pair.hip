@@ -52,17 +52,14 @@ hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*,
 hipError_t grdma_launch_engine(grdma_engine_mbox*, hipStream_t);
 const void* grdma_kernel_fn(int which);          // 0 tx_plan, 1 copy, 3 rx_apply, 4 tx_plan_seq
 const void* grdma_kernel_fn_rx_plan(void);
-const void* grdma_kernel_fn_rx_plan_unless_fast(void);
-const void* grdma_kernel_fn_rx_fast(void);
-uint32_t grdma_rx_fast_threads(void);
-hipError_t grdma_launch_rx_fast(const grdma_rx_op*, uint32_t, hipStream_t);
-hipError_t grdma_launch_rx_plan_unless_fast(const grdma_rx_op*, uint32_t, hipStream_t);
-const void* grdma_kernel_fn_tx_fast(void);
+const void* grdma_kernel_fn_rx_plan_job(void);
+hipError_t grdma_launch_rx_plan_job(const grdma_rx_op*, uint32_t, hipStream_t);
+uint32_t grdma_rx_plan_job_threads(void);
+uint32_t grdma_tx_plan_job_threads(void);
 const void* grdma_kernel_fn_tx_index(void);
-uint32_t grdma_tx_fast_threads(void);
+uint32_t grdma_tx_index_threads(void);
 hipError_t grdma_launch_tx_index(grdma_txf_ctl*, uint32_t, hipStream_t);
-hipError_t grdma_launch_tx_fast(const grdma_tx_op*, grdma_txf_ctl*, uint32_t, hipStream_t);
-hipError_t grdma_launch_tx_plan_unless_fast(const grdma_tx_op*, const grdma_txf_ctl*, uint32_t, hipStream_t);
+hipError_t grdma_launch_tx_plan_job(const grdma_tx_op*, const grdma_txf_ctl*, uint32_t, hipStream_t);
 const void* grdma_kernel_fn_plan_pair(void);
 uint32_t grdma_kernel_threads(int which);
 uint32_t grdma_copy_resident_blocks(void);
@@ -2056,6 +2053,9 @@ struct grdma_stream_job {
   hipGraphExec_t exec = nullptr;
   uint64_t exec_rounds = 0;
   int exec_pipeline = -1;
+  int exec_fastkey = -1;              // rx_fast | tx_fast << 1 | deep << 2 the graph was built for
+  int rx_miss = 0, tx_miss = 0;       // consecutive runs whose drains / Sends of link 0 mostly went to the general planner
+  uint64_t seen[4] = {0, 0, 0, 0};    // the result blocks' taken / declined counters at the end of the last run
   int pipeline = 0;                   // 1: overlap the send plan / gather / scatter of
                                       // neighbouring rounds on side streams
   int deep = 1;                       // pipelined graph: 1 = the limit-driven schedule (job_build_graph),
@@ -2093,26 +2093,25 @@ struct grdma_stream_job {
 namespace {
 
 inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 : 2); }
+inline int job_fastkey(const grdma_stream_job* j) { return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0); }
+inline bool job_exec_stale(const grdma_stream_job* j) {
+  return !j->exec || j->exec_rounds != j->rounds || j->exec_pipeline != j->pipeline || j->exec_fastkey != job_fastkey(j);
+}
 
 // the send plan of round t: priced from the index of the slice buffer (built in front of the first round of a
-// step), the general planner for what k_tx_fast declined
+// step), the general planner in the same launch for what that declines
 inline bool job_tx_fast(const grdma_stream_job* j) { return j->tx_fast && j->burst == 1 && !j->direct; }
 hipError_t job_launch_tx_plan(grdma_stream_job* j, int k, uint64_t t, uint32_t n, hipStream_t s) {
   if (!job_tx_fast(j)) return grdma_launch_tx_plan(j->d_txop + k * n, n, s);
   hipError_t e = hipSuccess;
   if (t == 0) e = grdma_launch_tx_index(j->d_txf, n, s);
-  if (e == hipSuccess) e = grdma_launch_tx_fast(j->d_txop + k * n, j->d_txf, n, s);
-  if (e == hipSuccess) e = grdma_launch_tx_plan_unless_fast(j->d_txop + k * n, j->d_txf, n, s);
+  if (e == hipSuccess) e = grdma_launch_tx_plan_job(j->d_txop + k * n, j->d_txf, n, s);
   return e;
 }
 
-// the receive plan of a round: the short steady-state kernel first, the general planner for what it declined
+// the receive plan of a round: k_rx_plan_job = the straight-line steady-state body, then the general planner for what it declines
 hipError_t job_launch_rx_plan(grdma_stream_job* j, const grdma_rx_op* ops, uint32_t n, hipStream_t s) {
-  if (j->rx_fast && j->burst == 1) {
-    hipError_t e = grdma_launch_rx_fast(ops, n, s);
-    if (e != hipSuccess) return e;
-    return grdma_launch_rx_plan_unless_fast(ops, n, s);
-  }
+  if (j->rx_fast && j->burst == 1) return grdma_launch_rx_plan_job(ops, n, s);
   return grdma_launch_rx_plan(ops, n, s);
 }
 
@@ -2378,35 +2377,22 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
   const uint32_t pt = grdma_kernel_threads(0), ct = grdma_kernel_threads(1);
   const bool fast = j->rx_fast && j->burst == 1;
   const bool tfast = job_tx_fast(j);
-  const void* f_txf = grdma_kernel_fn_tx_fast();
   const void* f_txi = grdma_kernel_fn_tx_index();
-  const void* f_txu = grdma_kernel_fn(6);
-  const uint32_t tft = grdma_tx_fast_threads();
-  // P[t] = the send plan of round t: (the index of the slice buffer in front of round 0,) k_tx_fast, then the
-  // general planner for what it declined
+  const void* f_txj = grdma_kernel_fn(6);
+  const void* f_rxj = grdma_kernel_fn_rx_plan_job();
+  // P[t] = the send plan of round t: (the index of the slice buffer in front of round 0,) then k_tx_plan_job --
+  // the Send priced from the index, the general planner behind it in the same launch for what that declines
   auto add_tx = [&](uint64_t t, const void* txop, std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
     if (!tfast) return add(&P[t], f_txp, dim3(n), pt, txop, deps);
-    hipGraphNode_t pf, pi = nullptr;
-    hipError_t e2 = hipSuccess;
-    if (t == 0) {
-      e2 = add(&pi, f_txi, dim3(n), tft, j->d_txf, deps);
-      if (e2 == hipSuccess) e2 = add2(&pf, f_txf, dim3(n), tft, txop, j->d_txf, {pi});
-    } else {
-      e2 = add2(&pf, f_txf, dim3(n), tft, txop, j->d_txf, deps);
-    }
+    if (t != 0) return add2(&P[t], f_txj, dim3(n), grdma_tx_plan_job_threads(), txop, j->d_txf, deps);
+    hipGraphNode_t pi = nullptr;
+    hipError_t e2 = add(&pi, f_txi, dim3(n), grdma_tx_index_threads(), j->d_txf, deps);
     if (e2 != hipSuccess) return e2;
-    return add2(&P[t], f_txu, dim3(n), pt, txop, j->d_txf, {pf});
+    return add2(&P[t], f_txj, dim3(n), grdma_tx_plan_job_threads(), txop, j->d_txf, {pi});
   };
-  const void* f_rxf = grdma_kernel_fn_rx_fast();
-  const void* f_rxu = grdma_kernel_fn_rx_plan_unless_fast();
-  const uint32_t ft = grdma_rx_fast_threads();
-  // X[t] = the receive plan of round t: k_rx_fast, then the general planner for what it declined
+  // X[t] = the receive plan of round t: k_rx_plan_job -- the steady-state body, the general planner behind it
   auto add_rx = [&](uint64_t t, const void* rxop, std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
-    if (!fast) return add(&X[t], f_rxp, dim3(n), pt, rxop, deps);
-    hipGraphNode_t xf;
-    hipError_t e2 = add(&xf, f_rxf, dim3(n), ft, rxop, deps);
-    if (e2 != hipSuccess) return e2;
-    return add(&X[t], f_rxu, dim3(n), pt, rxop, {xf});
+    return add(&X[t], fast ? f_rxj : f_rxp, dim3(n), fast ? grdma_rx_plan_job_threads() : pt, rxop, deps);
   };
   auto at = [](std::vector<hipGraphNode_t>& v, uint64_t t, uint64_t back) -> hipGraphNode_t {
     return t >= back ? v[t - back] : nullptr;
@@ -2908,6 +2894,26 @@ int grdma_stream_job_set_burst(grdma_stream_job* j, uint32_t burst) {
   return 0;
 }
 
+namespace {
+// (re)build the executable graph when the job's shape changed: rounds, schedule, which planner kernels it uses
+int job_ensure_exec(grdma_stream_job* j) {
+  if (!job_exec_stale(j)) return 0;
+  if (j->exec) {
+    HIP_TRY(hipStreamSynchronize(j->stream));
+    hipGraphExecDestroy(j->exec);
+  }
+  j->exec = nullptr;
+  hipGraph_t graph;
+  if (int rc = job_build_graph(j, &graph)) return rc;
+  HIP_TRY(hipGraphInstantiate(&j->exec, graph, nullptr, nullptr, 0));
+  hipGraphDestroy(graph);
+  j->exec_rounds = j->rounds;
+  j->exec_pipeline = j->pipeline;
+  j->exec_fastkey = job_fastkey(j);
+  return 0;
+}
+}  // namespace
+
 int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out) {
   if (int rc = require_ctx()) return rc;
   if (!j || !out) return fail(GRDMA_ERR_INVALID, "null argument");
@@ -2920,16 +2926,7 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
   }
   memset(out, 0, sizeof(*out));
   if (mode == GRDMA_RUN_GRAPH) {
-    if (!j->exec || j->exec_rounds != j->rounds || j->exec_pipeline != j->pipeline) {
-      if (j->exec) hipGraphExecDestroy(j->exec);
-      j->exec = nullptr;
-      hipGraph_t graph;
-      if (int rc = job_build_graph(j, &graph)) return rc;
-      HIP_TRY(hipGraphInstantiate(&j->exec, graph, nullptr, nullptr, 0));
-      hipGraphDestroy(graph);
-      j->exec_rounds = j->rounds;
-      j->exec_pipeline = j->pipeline;
-    }
+    if (int rc = job_ensure_exec(j)) return rc;
     HIP_TRY(hipEventRecord(j->ev0, s));
     HIP_TRY(hipGraphLaunch(j->exec, s));
     HIP_TRY(hipEventRecord(j->ev1, s));
@@ -2979,6 +2976,27 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
     out->rx_records += c1r[i].rx_records - c0r[i].rx_records;
     if (!(c1t[i].tx_slice_idx >= j->links[i].count && deliv == sent)) out->done = 0;
   }
+  // The job kernels try the steady-state bodies first and run the general planners (under a quarter of their
+  // register budget) for what those decline.  A job whose last drains / Send keep being declined -- no period in
+  // its record sizes, Sends cut by the staging budget, ... -- goes back to the plain planner kernels.
+  if (j->burst == 1 && mode != GRDMA_RUN_ENGINE && j->rounds >= 2 && (j->rx_fast || job_tx_fast(j))) {
+    uint64_t cnt[3][2];  // {taken, declined with work waiting} of link 0: drains of both parities, Sends
+    uint32_t c32[2][2];  // {pad1 = taken, pad0 = declined}
+    static_assert(offsetof(grdma_rx_result, pad0) == offsetof(grdma_rx_result, pad1) + 4, "layout");
+    HIP_TRY(hipMemcpy(c32[0], &j->d_rxres[0].pad1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c32[1], &j->d_rxres[n].pad1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int q = 0; q < 2; q++) { cnt[q][0] = c32[q][0]; cnt[q][1] = c32[q][1]; }
+    HIP_TRY(hipMemcpy(cnt[2], &j->d_txres[0].dbg[10], 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    const uint64_t rx_took = cnt[0][0] + cnt[1][0], rx_decl = cnt[0][1] + cnt[1][1];
+    const uint64_t d_rx_took = rx_took - j->seen[0], d_rx_decl = rx_decl - j->seen[1];
+    const uint64_t d_tx_took = cnt[2][0] - j->seen[2], d_tx_decl = cnt[2][1] - j->seen[3];
+    j->seen[0] = rx_took; j->seen[1] = rx_decl; j->seen[2] = cnt[2][0]; j->seen[3] = cnt[2][1];
+    // a miss: the run's drains (Sends) with work waiting went to the general planner, more than a start-up's worth
+    if (d_rx_took + d_rx_decl) j->rx_miss = d_rx_decl > 2 + d_rx_took ? j->rx_miss + 1 : 0;
+    if (d_tx_took + d_tx_decl) j->tx_miss = d_tx_decl > 2 + d_tx_took ? j->tx_miss + 1 : 0;
+    if (j->rx_fast && j->rx_miss >= 2) j->rx_fast = 0;
+    if (j->tx_fast && j->tx_miss >= 2) j->tx_fast = 0;
+  }
   return 0;
 }
 
@@ -3006,8 +3024,8 @@ int grdma_stream_job_debug(grdma_stream_job* j, uint64_t* tx_dbg, uint64_t* rx_d
 int grdma_stream_job_launch(grdma_stream_job* j) {
   if (int rc = require_ctx()) return rc;
   if (!j) return fail(GRDMA_ERR_INVALID, "null job");
-  if (!j->exec || j->exec_rounds != j->rounds || j->exec_pipeline != j->pipeline)
-    return fail(GRDMA_ERR_INVALID, "run the job once in GRDMA_RUN_GRAPH mode before launching it");
+  if (!j->exec) return fail(GRDMA_ERR_INVALID, "run the job once in GRDMA_RUN_GRAPH mode before launching it");
+  if (int rc = job_ensure_exec(j)) return rc;  // (the last run may have switched the job to other planner kernels)
   HIP_TRY(hipGraphLaunch(j->exec, j->stream));
   return 0;
 }

@@ -1,4 +1,5 @@
-// k_rx_fast: the drain of a streaming connection in its steady state, as ONE short kernel.
+// rxf_body: the drain of a streaming connection in its steady state, in a straight line (the first thing
+// k_rx_plan_job runs; included by grdma_rx_plan.hip).
 //
 // Same contract as k_rx_plan (grdma_rx_plan.hip): GetReadableSize / Read (ring_buffer.cc:67-191), Recv with
 // its credit rule (pair.cc:264-286) and the endpoint-read loop (rdma_bp_posix.cc:180-326) replayed for every
@@ -15,19 +16,21 @@
 //      sender's arrival limit (grdma_rx_op::limit_ptr): V records must end exactly there.
 //   2. ONE probe round: thread t loads footer(i) | header(i + 1) for its four records (16 bytes each, all in
 //      flight together) and checks them against the prediction.  Anything unexpected -- a size that differs,
-//      a footer that is missing, a limit the pattern does not hit, too many records -- and the kernel leaves
-//      WITHOUT having written a byte; k_rx_plan_unless_fast, the next node, then does the drain.
+//      a footer that is missing, a limit the pattern does not hit, too many records -- and the body returns false
+//      WITHOUT having written a byte; the caller then runs the general planner (rx_plan_body) in the same launch.
 //   3. The endpoint-read state machine data-parallel over all records, from ANY starting state (the read left
 //      open by the last drain's would-block: leftover_cap in [0, 256]) and through to the would-block at the
 //      end (a read cut short is delivered as a short slice, its rest stays open), so no sequential tier runs
 //      in front of or behind the parallel pass.
 //   4. Segments, tile prefix, slices: one record per lane-step, coalesced stores.
 //
-// 1024 threads (16 wavefronts on one CU), four records per thread, <= 4096 records per drain.
+// 1024 threads (16 wavefronts on one CU: a single wave per SIMD issues an instruction every 4-5 cycles and this body is
+// a few thousand instructions per thread at 16 records per thread -- measured 2.2x SLOWER with 256 threads), four
+// records per thread in contiguous runs (LDS index padded), <= 4096 records per drain.  k_rx_plan_job launches this
+// shape; when the body declines, waves 4-15 leave and waves 0-3 run the general planner (a 256-thread body).
 // Everything here is u32 arithmetic: the ring is at most 2 GiB on this path.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
+#ifndef GRDMA_RX_FAST_H
+#define GRDMA_RX_FAST_H
 #include "grdma_dev.h"
 #include "grdma_devfn.h"
 #include "grdma_ops.h"
@@ -42,7 +45,7 @@ namespace {
 #define RXF_PMAX 512u
 #define RXF_LOOKBACK 192u
 
-// diagnostics: [0] drains taken by k_rx_fast; declined: [1] preconditions (state, period unknown), [2] the pattern does not
+// diagnostics: [0] drains taken by rxf_body; declined: [1] preconditions (state, period unknown), [2] the pattern does not
 // end at the limit / too many records, [3] the ring does not hold the predicted records, [4] long run of small records,
 // [5] no room in plan / slice table / arena
 __device__ unsigned long long g_rx_fast_drains[6] = {0, 0, 0, 0, 0, 0};
@@ -152,8 +155,14 @@ __device__ __forceinline__ void rxf_scan3(uint32_t v0, uint32_t v1, uint32_t v2,
   tot[0] = t0; tot[1] = t1; tot[2] = t2;
 }
 
-__global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops) {
-  const grdma_rx_op op = ops[blockIdx.x];
+// LDS index padding: a thread walks a contiguous run of RXF_PER records; one extra slot per run makes the
+// lanes' stride odd (5 words), which spreads them over the banks.
+#define RXFP(i) ((i) + ((i) / RXF_PER))
+
+// Returns true when it took the drain (everything is written), false when the general planner has to
+// (nothing is written).  Every thread of the workgroup returns the same value.
+__device__ __forceinline__ bool rxf_body(const grdma_rx_op& op_in) {
+  const grdma_rx_op op = op_in;
   const uint64_t t_begin = __builtin_amdgcn_s_memtime();
   const uint32_t tid = threadIdx.x;
   grdma_conn* c = op.conn;
@@ -162,8 +171,8 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
 
   __shared__ uint32_t s_hist[GRDMA_RX_HIST];
   __shared__ uint32_t s_pat[RXF_PMAX], s_pre[RXF_PMAX + 1];
-  __shared__ uint32_t s_n[RXF_MAX + RXF_PER];
-  __shared__ uint16_t s_sin[RXF_MAX];
+  __shared__ uint32_t s_n[RXFP(RXF_MAX) + 2];
+  __shared__ uint16_t s_sin[RXFP(RXF_MAX) + 2];
   __shared__ uint32_t s_w[3][RXF_WAVES];
   __shared__ uint32_t s_bad, s_vj, s_first, s_send;
 
@@ -179,8 +188,10 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
   const uint64_t lim = op.limit_ptr ? __hip_atomic_load(op.limit_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
   const uint64_t slice_idx0 = op.append == 1 ? c->rx_slice_idx : 0;
   const uint64_t a_off0 = op.append == 1 ? c->rx_arena_off : 0;
-  const uint32_t hv = gh[tid];  // GRDMA_RX_HIST == RXF_THREADS
-  static_assert(GRDMA_RX_HIST == RXF_THREADS, "one history entry per thread");
+  constexpr int NH = GRDMA_RX_HIST / RXF_THREADS;
+  uint32_t hv[NH];
+#pragma unroll
+  for (int r = 0; r < NH; r++) hv[r] = gh[tid + r * RXF_THREADS];
 
   bool ok = status == GRDMA_PAIR_CONNECTED && op.raw_cap == 0 && op.append != 0 && !op.inline_apply &&
             op.limit_ptr != nullptr && remain0 == 0 && leftover0 <= RXF_MINRD && P != 0 && P <= RXF_PMAX && hc >= P &&
@@ -193,51 +204,65 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
   }
   const uint32_t cap = (uint32_t)cap64, mask = cap - 1u, head = (uint32_t)head64;
   const uint32_t Lr = ((uint32_t)lim - head) & mask;  // ring bytes between my head and the sender's tail
-  ok = ok && Lr != 0;
+  const bool idle = Lr == 0;  // nothing has arrived: the general planner records the would-block
   if (tid == 0) {
     s_bad = 0;
     s_vj = 0xFFFFFFFFu;
     s_first = 0xFFFFFFFFu;
     s_send = 0;
   }
-  s_hist[tid] = hv;
+#pragma unroll
+  for (int r = 0; r < NH; r++) s_hist[tid + r * RXF_THREADS] = hv[r];
   __syncthreads();
-  if (!ok) {  // (uniform)
+  if (!ok || idle) {  // (uniform)
     if (tid == 0) {
-      res->pad1 = 0;
       atomicAdd(&g_rx_fast_drains[1], 1ull);
+      if (!idle) res->pad0++;  // (pad1 / pad0: drains of this result block taken / declined with data waiting)
     }
-    return;
+    return false;
   }
 
   // ---- 1. the pattern: the newest P record sizes, their prefix sums, and where the limit falls in it
-  const uint32_t pv = tid < P ? s_hist[(uint32_t)((hc - P + tid) % GRDMA_RX_HIST)] : 0;
+  //         (thread t holds pattern entries 2t and 2t + 1)
+  static_assert(RXF_PMAX <= 2 * RXF_THREADS, "two pattern entries per thread");
+  const uint32_t j0 = 2 * tid, j1 = j0 + 1;
+  const uint32_t pv0 = j0 < P ? s_hist[(uint32_t)((hc - P + j0) % GRDMA_RX_HIST)] : 0;
+  const uint32_t pv1 = j1 < P ? s_hist[(uint32_t)((hc - P + j1) % GRDMA_RX_HIST)] : 0;
   uint32_t px, dummy1, dummy2, ptot[3];
-  rxf_scan3(pv, 0, 0, s_w, &px, &dummy1, &dummy2, ptot);
+  rxf_scan3(pv0 + pv1, 0, 0, s_w, &px, &dummy1, &dummy2, ptot);
   const uint32_t SP = ptot[0];
-  if (tid < P) {
-    s_pat[tid] = pv;
-    s_pre[tid] = px;
+  if (j0 < P) {
+    s_pat[j0] = pv0;
+    s_pre[j0] = px;
+  }
+  if (j1 < P) {
+    s_pat[j1] = pv1;
+    s_pre[j1] = px + pv0;
   }
   if (tid == 0) s_pre[P] = SP;
   const uint32_t q_full = SP ? Lr / SP : 0, rem = SP ? Lr - q_full * SP : 0;
-  if (SP != 0 && tid < P && px == rem) s_vj = tid;  // (pre[] is strictly increasing: at most one match)
+  if (SP != 0) {  // (pre[] is strictly increasing: at most one match)
+    if (j0 < P && px == rem) s_vj = j0;
+    if (j1 < P && px + pv0 == rem) s_vj = j1;
+  }
   __syncthreads();
   const uint32_t vj = s_vj;
   const uint64_t V64 = (uint64_t)q_full * P + vj;
   if (SP == 0 || vj == 0xFFFFFFFFu || V64 == 0 || V64 > RXF_MAX) {  // (uniform)
     if (tid == 0) {
-      res->pad1 = 0;
       atomicAdd(&g_rx_fast_drains[2], 1ull);
+      res->pad0++;
     }
-    return;
+    return false;
   }
   const uint32_t V = (uint32_t)V64;
   const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap64);
+  const uint64_t t_pattern = __builtin_amdgcn_s_memtime();
 
   // ---- 2. one probe round: footer of record i and header of record i + 1 are neighbouring words
   const uint32_t i0 = tid * RXF_PER;
   uint32_t xe[RXF_PER], ee[RXF_PER];  // exclusive encoded prefix and encoded size of my records
+  uint32_t e_after;                    // size the pattern predicts for the record behind my last one
   {
     uint32_t qi = i0 / P, ri = i0 - qi * P;
 #pragma unroll
@@ -249,6 +274,7 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
         qi++;
       }
     }
+    e_after = s_pat[ri];
   }
   {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -270,15 +296,7 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
     if (tid == 0) {
       const uint64_t h0 = ((uint64_t)hf.y << 32) | hf.x;
       bad |= !(h0 != 0 && h0 <= cap64 - GRDMA_RESERVED && 16u + (uint32_t)round_up8(h0) == ee[0]);
-      s_n[0] = (uint32_t)h0;
-    }
-    // size the pattern predicts for the record behind my last one
-    uint32_t e_next[RXF_PER];
-#pragma unroll
-    for (int r = 0; r < RXF_PER - 1; r++) e_next[r] = ee[r + 1];
-    {
-      const uint32_t in = i0 + RXF_PER, qn = in / P;
-      e_next[RXF_PER - 1] = s_pat[in - qn * P];
+      s_n[RXFP(0)] = (uint32_t)h0;
     }
 #pragma unroll
     for (int r = 0; r < RXF_PER; r++) {
@@ -289,10 +307,11 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
         const uint64_t lo = ((uint64_t)pairs[r].y << 32) | pairs[r].x, hi = ((uint64_t)pairs[r].w << 32) | pairs[r].z;
         const uint64_t foot = last_word ? hi : lo;
         const uint64_t next = last_word ? (((uint64_t)wz.y << 32) | wz.x) : hi;
+        const uint32_t e_next = r + 1 < RXF_PER ? ee[r + 1 < RXF_PER ? r + 1 : 0] : e_after;
         bad |= foot != GRDMA_FOOTER;
         if (i + 1 < V) {
-          bad |= !(next != 0 && next <= cap64 - GRDMA_RESERVED && 16u + (uint32_t)round_up8(next) == e_next[r]);
-          s_n[i + 1] = (uint32_t)next;
+          bad |= !(next != 0 && next <= cap64 - GRDMA_RESERVED && 16u + (uint32_t)round_up8(next) == e_next);
+          s_n[RXFP(i + 1)] = (uint32_t)next;
         }
       }
     }
@@ -301,10 +320,10 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
   __syncthreads();
   if (s_bad) {  // (uniform) the ring does not hold what the pattern says: the general planner takes this drain
     if (tid == 0) {
-      res->pad1 = 0;
       atomicAdd(&g_rx_fast_drains[3], 1ull);
+      res->pad0++;
     }
-    return;
+    return false;
   }
   const uint64_t t_probe = __builtin_amdgcn_s_memtime();
 
@@ -312,19 +331,18 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
   const uint32_t s0 = (uint32_t)leftover0;
   if (i0 < V) {
     uint32_t j = i0, steps = 0;
-    while (j > 0 && s_n[j - 1] < 2 * RXF_MINRD && steps < RXF_LOOKBACK) {
+    while (j > 0 && s_n[RXFP(j - 1)] < 2 * RXF_MINRD && steps < RXF_LOOKBACK) {
       j--;
       steps++;
     }
-    if (j > 0 && s_n[j - 1] < 2 * RXF_MINRD) s_bad = 1;  // a long run of small records: not this kernel's case
+    if (j > 0 && s_n[RXFP(j - 1)] < 2 * RXF_MINRD) s_bad = 1;  // a long run of small records: not this body's case
     uint32_t s = j == 0 ? s0 : 0;
-    for (; j < i0; j++) s = rxf_space_after(s_n[j], s);
-#pragma unroll
-    for (int r = 0; r < RXF_PER; r++) {
+    for (; j < i0; j++) s = rxf_space_after(s_n[RXFP(j)], s);
+    for (uint32_t r = 0; r < RXF_PER; r++) {
       const uint32_t i = i0 + r;
       if (i < V) {
-        s_sin[i] = (uint16_t)s;
-        const uint32_t n = s_n[i];
+        s_sin[RXFP(i)] = (uint16_t)s;
+        const uint32_t n = s_n[RXFP(i)];
         // the first record that completes a slice: it closes the read that was open at the start (if any)
         if (rxf_replay(n, s).sl_cnt != 0) atomicMin(&s_first, i);
         s = rxf_space_after(n, s);
@@ -335,14 +353,15 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
   __syncthreads();
   if (s_bad) {
     if (tid == 0) {
-      res->pad1 = 0;
       atomicAdd(&g_rx_fast_drains[4], 1ull);
+      res->pad0++;
     }
-    return;
+    return false;
   }
   const uint32_t first_done = s_first;  // 0xFFFFFFFF: no slice completes in this drain
   const uint32_t s_end = s_send;
   const bool odd_open = s0 != 0 && s0 != RXF_MINRD;  // the open read's capacity is not a fresh read's 256
+  const uint64_t t_state = __builtin_amdgcn_s_memtime();
 
   // ---- 4. counts, prefix sums, room
   uint32_t my_pk = 0, my_tl = 0, my_by = 0, my_n = 0;
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
   for (int r = 0; r < RXF_PER; r++) {
     const uint32_t i = i0 + r;
     if (i < V) {
-      const uint32_t n = s_n[i], s_in = s_sin[i];
+      const uint32_t n = s_n[RXFP(i)], s_in = s_sin[RXFP(i)];
       const bool in_first = odd_open && i <= first_done;
       const rxf_layout L = rxf_lay(n, s_in, (head + xe[r] + 8u) & mask, cap, in_first ? s0 : RXF_MINRD,
                                    odd_open && i == first_done, ts);
@@ -376,11 +395,12 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
   if (!(nsl_final + 2 <= max_slices && tot_sg + 8 <= GRDMA_MAX_SEGS && a_end + leftover_final + 16 <= op.arena_cap &&
         a_end < (1ull << 32))) {  // (uniform)
     if (tid == 0) {
-      res->pad1 = 0;
       atomicAdd(&g_rx_fast_drains[5], 1ull);
+      res->pad0++;
     }
-    return;
+    return false;
   }
+  const uint64_t t_scan = __builtin_amdgcn_s_memtime();
 
   // ---- 5. segments, tile prefix, slices: the drain is committed from here on
   grdma_slice_out* const out_slices = op.slices + slice_idx0;
@@ -390,7 +410,7 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
     for (int r = 0; r < RXF_PER; r++) {
       const uint32_t i = i0 + r;
       if (i < V) {
-        const uint32_t n = s_n[i], s_in = s_sin[i];
+        const uint32_t n = s_n[RXFP(i)], s_in = s_sin[RXFP(i)];
         const bool in_first = odd_open && i <= first_done;
         const rxf_layout L = rxf_lay(n, s_in, (head + xe[r] + 8u) & mask, cap, in_first ? s0 : RXF_MINRD,
                                      odd_open && i == first_done, ts);
@@ -433,6 +453,7 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
       if (i >= first && i < V) c->rx_hist[(uint32_t)((hc + i) % GRDMA_RX_HIST)] = ee[r];
     }
   }
+  const uint64_t t_emit = __builtin_amdgcn_s_memtime();
 
   // ---- 6. credit (pair.cc:276-284), state, result: thread 0
   if (tid == 0) {
@@ -449,8 +470,8 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
         const uint32_t mid = (lo + hi) >> 1;
         if (enc_end(mid) >= thr) hi = mid; else lo = mid + 1;
       }
-      const uint32_t n = s_n[lo];
-      const rxf_rec rp = rxf_replay(n, s_sin[lo]);
+      const uint32_t n = s_n[RXFP(lo)];
+      const rxf_rec rp = rxf_replay(n, s_sin[RXFP(lo)]);
       const uint64_t C2 = enc_end(lo);
       const uint64_t e = 16u + ((n + 7u) & ~7u);
       const uint64_t cons2 = rp.c2 ? rp.c2 + (((n + 7u) & ~7u) - n + 8u) : 0;
@@ -485,12 +506,14 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
     const uint64_t o_total_read = c->total_read, o_credit_msgs = c->credit_msgs;
     const uint64_t o_rx_records = c->rx_records, o_rx_rounds = c->rx_rounds;
     const uint32_t o_h1 = c->rx_h1;
+    const uint64_t o_seq = res->seq;
+    grdma_hostline* const line = c->line;
     c->head = nh;
     c->moving_head = nh;
     c->remain = 0;
-    if (c->line != nullptr) {
-      c->line->rx_head = nh;
-      c->line->rx_remain = 0;
+    if (line != nullptr) {
+      line->rx_head = nh;
+      line->rx_remain = 0;
     }
     c->internal_read_size = irs;
     c->leftover_cap = leftover_final;
@@ -529,31 +552,23 @@ __global__ __launch_bounds__(RXF_THREADS) void k_rx_fast(const grdma_rx_op* ops)
       res->zero_len[1] = nh;
     }
     res->dbg[0] = t_begin;
+    res->dbg[2] = t_pattern - t_begin;
+    res->dbg[3] = t_probe - t_begin;
+    res->dbg[4] = t_state - t_begin;
+    res->dbg[5] = t_scan - t_begin;
+    res->dbg[6] = t_emit - t_begin;
+    res->dbg[7] = V;
+    res->dbg[8] = P;
+    res->dbg[9] = 0xFA57;  // this stamp set comes from rxf_body
+    res->pad1++;
     res->dbg[1] = __builtin_amdgcn_s_memtime();
-    res->dbg[2] = t_probe - t_begin;
-    res->dbg[3] = V;
-    res->dbg[4] = P;
-    res->pad1 = 1;  // k_rx_plan_unless_fast: nothing left to do
     atomicAdd(&g_rx_fast_drains[0], 1ull);
-    __hip_atomic_store(&res->seq, op.seq_next ? op.seq_next : res->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (relaxed: the consumers of a streaming job's drain are later kernels of the graph; a release at system scope
+    // here would write the XCD's L2 back -- the plan just laid out -- before the kernel may end)
+    __hip_atomic_store(&res->seq, op.seq_next ? op.seq_next : o_seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  return true;
 }
 
 }  // namespace
-
-extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rx_fast(void) {
-  return reinterpret_cast<const void*>(&k_rx_fast);
-}
-// diagnostics: drains k_rx_fast took, and the ones it left to the general planner by reason (g_rx_fast_drains)
-extern "C" int grdma_rx_fast_drains(uint64_t out[6]) {
-  unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
-  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_rx_fast_drains), sizeof(v)) != hipSuccess) return -1;
-  for (int i = 0; i < 6; i++) out[i] = v[i];
-  return 0;
-}
-extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_rx_fast_threads(void) { return RXF_THREADS; }
-extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_fast(const grdma_rx_op* d_ops, uint32_t nops, hipStream_t s) {
-  if (nops == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_rx_fast, dim3(nops), dim3(RXF_THREADS), 0, s, d_ops);
-  return hipGetLastError();
-}
+#endif  // GRDMA_RX_FAST_H

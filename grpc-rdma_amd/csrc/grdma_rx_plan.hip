@@ -41,6 +41,7 @@
 #include "grdma_devfn.h"
 #include "grdma_ops.h"
 #include "grdma_tx_body.h"
+#include "grdma_rx_fast.h"
 
 namespace {
 
@@ -1409,12 +1410,18 @@ void k_rx_plan(const grdma_rx_op* ops) {
   rx_plan_body(ops[blockIdx.x]);
 }
 
-// The drain a streaming job's graph runs BEHIND k_rx_fast (grdma_rx_fast.hip): nothing to do when that kernel
-// took the drain (it says so in the result block), the general planner otherwise.
-__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_rx_plan_unless_fast(const grdma_rx_op* ops) {
-  if (ops[blockIdx.x].result->pad1 != 0) return;  // (uniform; written by a kernel that has completed)
+// The receive plan of a streaming job's round: the straight-line steady-state body first (grdma_rx_fast.h); what it
+// declines -- nothing has been written then -- goes through the general planner in the same launch.
+// Launched in the steady-state body's shape (1024 threads); when that declines, waves 4-15 leave (a barrier only
+// counts the waves that are still there) and waves 0-3 run the general planner, a 256-thread body -- under this
+// kernel's 128-register budget, i.e. with spills: a job whose drains keep being declined is switched to the plain
+// k_rx_plan by the host (grdma_stream_job_run).
+__global__ __launch_bounds__(RXF_THREADS)
+void k_rx_plan_job(const grdma_rx_op* ops) {
+  if (rxf_body(ops[blockIdx.x])) return;  // (uniform)
+  if (threadIdx.x >= PLAN_THREADS) return;
   rx_plan_body(ops[blockIdx.x]);
+  if (threadIdx.x == 0) ops[blockIdx.x].result->dbg[9] = 0;  // (not rxf_body's stamps)
 }
 
 // Out-of-line copies for the resident engine: with both bodies inlined into its
@@ -1604,11 +1611,19 @@ extern "C" uint64_t grdma_express_drains(void) {
 }
 
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rx_plan(void) { return reinterpret_cast<const void*>(&k_rx_plan); }
-extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rx_plan_unless_fast(void) { return reinterpret_cast<const void*>(&k_rx_plan_unless_fast); }
-extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan_unless_fast(const grdma_rx_op* d_ops, uint32_t nops, hipStream_t s) {
+extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rx_plan_job(void) { return reinterpret_cast<const void*>(&k_rx_plan_job); }
+extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_rx_plan_job_threads(void) { return RXF_THREADS; }
+extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan_job(const grdma_rx_op* d_ops, uint32_t nops, hipStream_t s) {
   if (nops == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_rx_plan_unless_fast, dim3(nops), dim3(PLAN_THREADS), 0, s, d_ops);
+  hipLaunchKernelGGL(k_rx_plan_job, dim3(nops), dim3(RXF_THREADS), 0, s, d_ops);
   return hipGetLastError();
+}
+// diagnostics: drains rxf_body took, and the ones it left to the general planner by reason (g_rx_fast_drains)
+extern "C" int grdma_rx_fast_drains(uint64_t out[6]) {
+  unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_rx_fast_drains), sizeof(v)) != hipSuccess) return -1;
+  for (int i = 0; i < 6; i++) out[i] = v[i];
+  return 0;
 }
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair(void) { return reinterpret_cast<const void*>(&k_plan_pair); }
 

@@ -1,4 +1,4 @@
-// k_tx_index / k_tx_fast: the send plan of a streaming job (PairPollable::Send arithmetic, pair.cc:645-734, and
+// k_tx_index / txf_body (grdma_tx_fast.h): the send plan of a streaming job (PairPollable::Send arithmetic, pair.cc:645-734, and
 // the rdma_flush cursor, rdma_bp_posix.cc:470-524) over an INDEX of the slice buffer being written.
 //
 // rdma_write hands one grpc_slice_buffer to a loop of Sends; each Send takes a prefix of what is left.  The
@@ -9,7 +9,7 @@
 //
 //   k_tx_index   once per write (the first node of a job's step): enc_pre[k] = sum of 16 + round_up8(len_j), j < k;
 //                len_pre[k] = sum of len_j; tile_pre[k] = sum of ceil(len_j / tile).
-//   k_tx_fast    per Send, 1024 threads, four records per thread, no scan at all: st_i = enc_pre[start + i] -
+//   txf_body     per Send (one workgroup, sixteen records per thread), no scan at all: st_i = enc_pre[start + i] -
 //                enc_pre[start] (+ a correction for the bytes of the first slice already sent); record i goes out
 //                whole exactly when st_{i+1} + 8 <= min(staging, free) -- CalculateWritableSize
 //                (ring_buffer.h:185-189) is round_down8(space - 24), so "len_i <= W(room - st_i)" is
@@ -19,7 +19,7 @@
 //
 // Same plan, wire requests, cursor, counters and result block as k_tx_plan.  What it does not take (a slice of
 // zero bytes anywhere in the buffer -- it ends a Send like the reference's `break` --, a direct wire, the latency
-// path) is left to k_tx_plan_unless_fast, the next node, through the `done` word of the control block.
+// path) is left to the general planner, which k_tx_plan_job runs in the same launch when the body returns false.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,9 +32,6 @@ namespace {
 #define TXF_THREADS 1024
 #define TXF_PER 4
 #define TXF_WAVES (TXF_THREADS / 64)
-
-// diagnostics: Sends taken by k_tx_fast / left to the general planner
-__device__ unsigned long long g_tx_fast_sends[2] = {0, 0};
 
 // exclusive scan of a u64 per thread over the 1024-thread block
 __device__ __forceinline__ uint64_t txf_scan64(uint64_t v, uint64_t* s_w, uint64_t* total) {
@@ -104,245 +101,14 @@ __global__ __launch_bounds__(TXF_THREADS) void k_tx_index(grdma_txf_ctl* ctls) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// k_tx_fast: one Send over the index.
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TXF_THREADS) void k_tx_fast(const grdma_tx_op* ops, grdma_txf_ctl* ctls) {
-  const grdma_tx_op op = ops[blockIdx.x];
-  grdma_txf_ctl* ctl = &ctls[blockIdx.x];
-  const uint64_t t_begin = __builtin_amdgcn_s_memtime();
-  const uint32_t tid = threadIdx.x;
-  const int lane = tid & 63;
-  grdma_conn* c = op.conn;
-  grdma_plan* plan = op.plan;
-  __shared__ uint32_t s_cnt[TXF_WAVES];
-  __shared__ uint64_t s_rhead;
-
-  // ---- state; what this kernel takes (nothing is stored before the decision)
-  const uint64_t cap = c->cap, mask = cap - 1, S = c->staging_cap, tail0 = c->remote_tail;
-  const bool connected = c->status == GRDMA_PAIR_CONNECTED;
-  const uint64_t n = ctl->n;
-  const uint64_t* const enc_pre = ctl->enc_pre;
-  const uint64_t* const len_pre = ctl->len_pre;
-  const uint32_t* const tile_pre = ctl->tile_pre;
-  const bool ok = ctl->valid != 0 && ctl->slices == op.slices && n == op.nslices && op.use_cursor != 0 && !op.inline_copy &&
-                  connected && c->wire_direct == 0 && op.wire_plan != nullptr && cap <= (1ull << 31) &&
-                  ctl->tile_shift == GRDMA_PLAN_TILE_SHIFT(cap);
-  if (tid == 0)  // get_remote_head(), pair.h:229-233 -- ONE read for the whole Send (the peer's scatter may post meanwhile)
-    s_rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __syncthreads();
-  if (!ok) {  // (uniform)
-    if (tid == 0) {
-      ctl->done = 0;
-      atomicAdd(&g_tx_fast_sends[1], 1ull);
-    }
-    return;
-  }
-  const uint64_t rhead = s_rhead;
-  uint64_t start = op.use_cursor == 1 ? c->tx_slice_idx : 0;
-  const uint64_t byte_idx = op.use_cursor == 1 ? c->tx_byte_idx : 0;
-  if (start > n) start = n;
-  const uint64_t avail = n - start;
-  const uint64_t offered = op.use_cursor == 1 ? c->tx_remaining : len_pre[n];
-  uint64_t m = avail;
-  if (m > c->max_sge) m = c->max_sge;
-  if (m > GRDMA_TX_MAX_RECORDS - 1) m = GRDMA_TX_MAX_RECORDS - 1;
-  const grdma_sge* const sl = op.slices + start;
-  const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap);
-  const uint64_t TB = 1ull << ts;
-  const uint64_t occupied0 = (tail0 + cap - rhead) & mask;
-  const uint64_t free0 = cap - occupied0;
-  const uint64_t room0 = S < free0 ? S : free0;
-  // the first slice may have been sent in part: its record is shorter than the index says
-  uint64_t base_e = 0, base_t = 0, D = 0, Dt = 0;
-  if (m) {
-    const uint64_t len0 = sl[0].len, l0 = sat_sub(len0, byte_idx);
-    base_e = enc_pre[start];
-    base_t = tile_pre[start];
-    D = enc_size(l0) - (enc_pre[start + 1] - base_e);              // (<= 0 as a signed number; modular arithmetic)
-    Dt = ((l0 + TB - 1) >> ts) - (tile_pre[start + 1] - base_t);
-  }
-  // st(k): staging offset of record k of this Send (k >= 1), from the index
-  // ---- my records: striped, all loads in flight together
-  uint64_t r_ptr[TXF_PER], r_len[TXF_PER], r_e0[TXF_PER], r_e1[TXF_PER];
-  uint32_t r_t0[TXF_PER];
-#pragma unroll
-  for (int r = 0; r < TXF_PER; r++) {
-    const uint64_t i = tid + (uint64_t)r * TXF_THREADS;
-    const uint64_t k = i < m ? i : (m ? m - 1 : 0);  // clamped, unconditional
-    const grdma_sge g = m ? sl[k] : grdma_sge{nullptr, 0};
-    r_ptr[r] = reinterpret_cast<uint64_t>(g.ptr);
-    r_len[r] = g.len;
-    r_e0[r] = m ? enc_pre[start + k] : 0;
-    r_e1[r] = m ? enc_pre[start + k + 1] : 0;
-    r_t0[r] = m ? tile_pre[start + k] : 0;
-  }
-  // ---- whole records: a count
-  uint32_t my_whole = 0;
-  uint64_t st_i[TXF_PER], st_n[TXF_PER];
-#pragma unroll
-  for (int r = 0; r < TXF_PER; r++) {
-    const uint64_t i = tid + (uint64_t)r * TXF_THREADS;
-    st_i[r] = i == 0 ? 0 : r_e0[r] - base_e + D;
-    st_n[r] = r_e1[r] - base_e + D;
-    if (i < m && st_n[r] + 8 <= room0) my_whole++;
-  }
-  {
-    uint32_t w = my_whole;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) w += __shfl_xor(w, d, 64);
-    if (lane == 0) s_cnt[tid >> 6] = w;
-  }
-  __syncthreads();
-  uint64_t nrec = 0;
-#pragma unroll
-  for (int w = 0; w < TXF_WAVES; w++) nrec += s_cnt[w];
-  // the short record behind them (pay = min(len, W(S - st), W(free0 - st)) = W(room0 - st): it did not fit whole)
-  __shared__ uint64_t s_short[2];  // {short_pay, st of record nrec}
-  if (tid == 0) s_short[0] = s_short[1] = 0;
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < TXF_PER; r++) {
-    const uint64_t i = tid + (uint64_t)r * TXF_THREADS;
-    if (i == nrec && i < m) {
-      uint64_t p = i == 0 ? sat_sub(r_len[r], byte_idx) : r_len[r];
-      const uint64_t a = writable_of(sat_sub(S, st_i[r])), b = writable_of(sat_sub(free0, st_i[r]));
-      if (a < p) p = a;
-      if (b < p) p = b;
-      s_short[0] = p;
-      s_short[1] = st_i[r];
-    }
-    if (nrec == m && m != 0 && i == m - 1) s_short[1] = st_n[r];  // every record went out whole: st(m)
-  }
-  __syncthreads();
-  const uint64_t short_pay = s_short[0];
-  const uint64_t nrec_total = nrec + (short_pay > 0 ? 1 : 0);
-  uint8_t* const staging = op.staging_alt ? op.staging_alt : c->staging;
-  const uint64_t t_priced = __builtin_amdgcn_s_memtime();
-
-  // ---- segments and tile prefix, one record per thread-step (AppendHeader / AppendFooter ride on the segment)
-#pragma unroll
-  for (int r = 0; r < TXF_PER; r++) {
-    const uint64_t i = tid + (uint64_t)r * TXF_THREADS;
-    if (i >= nrec_total) continue;
-    const uint64_t p = i == nrec ? short_pay : (i == 0 ? sat_sub(r_len[r], byte_idx) : r_len[r]);
-    const uint64_t tagw = GRDMA_SEG_TAG_WRITE | (p << GRDMA_SEG_TAG_LEN_SHIFT);
-    const uint8_t* src = reinterpret_cast<const uint8_t*>(r_ptr[r]) + (i == 0 ? byte_idx : 0);
-    plan->segs[i] = {(uint64_t)(staging + st_i[r] + 8), (uint64_t)src, p, tagw | GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR};
-    plan->tile_prefix[i] = i == 0 ? 0u : (uint32_t)(r_t0[r] - base_t + Dt);
-  }
-
-  if (tid == 0) {
-    // totals behind the whole records (one more trip to the index: three independent loads)
-    uint64_t sent = short_pay, ntiles = (short_pay + TB - 1) >> ts;
-    if (nrec) {
-      sent += len_pre[start + nrec] - len_pre[start] - byte_idx;
-      ntiles += tile_pre[start + nrec] - base_t + Dt;
-    }
-    const uint64_t st_last = s_short[1];  // st(nrec)
-    const uint64_t staged = (nrec || short_pay) ? st_last + (short_pay > 0 ? enc_size(short_pay) : 0) : 0;
-    const uint64_t nsegs = nrec_total;
-    plan->nsegs = (uint32_t)nsegs;
-    plan->ntiles = (uint32_t)ntiles;
-    plan->tile_bytes = (uint32_t)TB;
-    plan->tile_prefix[nsegs] = (uint32_t)ntiles;
-    plan->bytes = sent;
-    plan->tag_base = (uint64_t)staging;
-    plan->tag_mask = ~0ull;
-    const uint64_t new_tail = (tail0 + staged) & mask;
-    // the <= 2 RDMA WRITEs of GetWriteRequests(sg_list), ring_buffer.cc:261-330
-    const uint64_t seg1 = staged < cap - tail0 ? staged : cap - tail0;
-    grdma_tx_result* r = op.result;
-    r->wr_count = 0;
-    r->wr_off[0] = r->wr_off[1] = r->wr_len[0] = r->wr_len[1] = 0;
-    if (staged > 0) {
-      r->wr_off[0] = tail0;
-      r->wr_len[0] = seg1;
-      r->wr_count = 1;
-      if (tail0 + staged >= cap) {  // a record reached (or crossed) the ring end
-        r->wr_off[1] = 0;
-        r->wr_len[1] = staged - seg1;
-        r->wr_count = 2;
-      }
-    }
-    grdma_plan* wp = op.wire_plan;
-    {
-      uint32_t ns = 0, nt = 0;
-      if (staged > 0) {
-        wp->segs[0] = {(uint64_t)(c->peer_ring + tail0), (uint64_t)staging, seg1, 0};
-        wp->tile_prefix[0] = 0;
-        nt = (uint32_t)((seg1 + TB - 1) >> ts);
-        ns = 1;
-        if (staged > seg1) {
-          wp->segs[1] = {(uint64_t)c->peer_ring, (uint64_t)(staging + seg1), staged - seg1, 0};
-          wp->tile_prefix[1] = nt;
-          nt += (uint32_t)((staged - seg1 + TB - 1) >> ts);
-          ns = 2;
-        }
-      }
-      wp->nsegs = ns;
-      wp->ntiles = nt;
-      wp->tile_bytes = (uint32_t)TB;
-      wp->tile_prefix[ns] = nt;
-      wp->bytes = staged;
-    }
-    // rdma_flush cursor walk, rdma_bp_posix.cc:480-493
-    const uint64_t idx = start + nrec;
-    uint64_t bidx = 0;
-    if (short_pay > 0) bidx = (nrec == 0 ? byte_idx : 0) + short_pay;
-    else if (nrec == 0) bidx = byte_idx;
-    const uint64_t o_written = c->total_written, o_records = c->tx_records, o_rounds = c->tx_rounds;
-    c->remote_tail = new_tail;
-    c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709
-    c->total_written = o_written + sent;
-    c->tx_records = o_records + nrec_total;
-    c->tx_last_records = (uint32_t)nrec_total;
-    if (nrec_total) c->tx_rounds = o_rounds + 1;
-    c->tx_slice_idx = idx;
-    c->tx_byte_idx = bidx;
-    c->tx_remaining = offered - sent;
-    r->sent = sent;
-    r->records = nrec_total;
-    r->staged = staged;
-    r->partial = sent < offered ? 1 : 0;
-    r->new_remote_tail = new_tail;
-    if (op.tail_out != nullptr) *op.tail_out = new_tail;
-    r->slice_idx = idx;
-    r->byte_idx = bidx;
-    r->done = (idx >= op.nslices) ? 1 : 0;
-    r->dbg[0] = t_begin;
-    r->dbg[1] = t_priced;
-    r->dbg[6] = __builtin_amdgcn_s_memtime();
-    r->dbg[7] = m;
-    ctl->done = 1;
-    atomicAdd(&g_tx_fast_sends[0], 1ull);
-    const uint64_t nxt = op.seq_next ? op.seq_next : r->seq + 1;
-    __hip_atomic_store(&r->seq, nxt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
 }  // namespace
 
 extern "C" {
-__attribute__((visibility("hidden"))) const void* grdma_kernel_fn_tx_fast(void) { return reinterpret_cast<const void*>(&k_tx_fast); }
 __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_tx_index(void) { return reinterpret_cast<const void*>(&k_tx_index); }
-__attribute__((visibility("hidden"))) uint32_t grdma_tx_fast_threads(void) { return TXF_THREADS; }
+__attribute__((visibility("hidden"))) uint32_t grdma_tx_index_threads(void) { return TXF_THREADS; }
 __attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_index(grdma_txf_ctl* d_ctls, uint32_t n, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_tx_index, dim3(n), dim3(TXF_THREADS), 0, s, d_ctls);
   return hipGetLastError();
-}
-__attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_fast(const grdma_tx_op* d_ops, grdma_txf_ctl* d_ctls, uint32_t n, hipStream_t s) {
-  if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_tx_fast, dim3(n), dim3(TXF_THREADS), 0, s, d_ops, d_ctls);
-  return hipGetLastError();
-}
-// diagnostics: Sends of streaming jobs taken by k_tx_fast [0], left to the general planner [1]
-int grdma_tx_fast_sends(uint64_t out[2]) {
-  unsigned long long v[2] = {0, 0};
-  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_tx_fast_sends), sizeof(v)) != hipSuccess) return -1;
-  out[0] = v[0];
-  out[1] = v[1];
-  return 0;
 }
 }

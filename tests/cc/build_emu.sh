@@ -9,7 +9,7 @@ OUT=$R/oracle/_build
 mkdir -p $OUT/emu_obj
 FLAGS="-O1 -g -fno-omit-frame-pointer -std=c++17 -fPIC -pthread -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes -I$R/tests/cc -I$R/tests/cc/emu_include"
 objs=""
-for f in grdma_kernels.hip grdma_rx_plan.hip grdma_rx_fast.hip grdma_tx_fast.hip grdma_zc.hip grdma_h2.hip grdma_pair.hip grdma_host.cc grdma_endpoint.cc grdma_stats_time.cc; do
+for f in grdma_kernels.hip grdma_rx_plan.hip grdma_tx_fast.hip grdma_zc.hip grdma_h2.hip grdma_pair.hip grdma_host.cc grdma_endpoint.cc grdma_stats_time.cc; do
   o=$OUT/emu_obj/${f%.*}.o
   $CXX $FLAGS -x c++ -c $R/grpc-rdma_amd/csrc/$f -o $o &
   objs="$objs $o"

@@ -42,11 +42,16 @@ def main():
     us = {names[i]: 1e3 * inst.ms_class[i] / max(1, int(inst.launches_class[i])) for i in range(len(names))}
     print("kernel us per launch:", {k: round(v, 1) for k, v in us.items()})
     t = [int(x) for x in td]
-    print("k_tx_plan round 0 stamps (ticks from begin):", [t[i] - t[0] for i in range(1, 7)], "records", t[7], "loaded at", t[8] - t[0])
     r_ = [int(x) for x in rd]
-    tot = r_[1] - r_[0]
-    print("k_rx_plan round 0: total %d ticks; prologue %d, period detection %d, predicted sizes %d, probe %d, pass0 %d, pass1 %d, pass2 %d, loop end at %d; rounds %d fast %d scalar %d took %d; P %d V %d"
-          % (tot, r_[14], r_[8], r_[15], r_[9], r_[10], r_[11], r_[12], r_[13], r_[2], r_[3], r_[4], r_[5], r_[6], r_[7]))
+    print("tx dbg:", [t[i] - t[0] for i in range(1, 9)])
+    if r_[9] == 0xFA57:
+        tot = r_[1] - r_[0]
+        print("rxf_body (last round of a parity): total %d ticks; pattern %d, probe %d, read state %d, scans %d, emit %d; V %d P %d"
+              % (tot, r_[2], r_[3], r_[4], r_[5], r_[6], r_[7], r_[8]))
+    else:
+        tot = r_[1] - r_[0]
+        print("k_rx_plan (general): total %d ticks; prologue %d, period detection %d, predicted sizes %d, probe %d, pass0 %d, pass1 %d, pass2 %d, loop end at %d"
+              % (tot, r_[14], r_[8], r_[15], r_[9], r_[10], r_[11], r_[12], r_[13]))
 
 
 if __name__ == "__main__":

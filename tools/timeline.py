@@ -1,19 +1,24 @@
 """Print the kernel timeline of the last step in a rocprofv3 kernel-trace csv
-(start/end relative to the step start, per kernel) to see what overlaps."""
+(start/end relative to the step start, per kernel, gap to the previous kernel's end) to see what overlaps
+and what a kernel boundary costs."""
 import csv
+import re
 import sys
 
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         name = r["Kernel_Name"]
-        short = [k for k in ("k_tx_plan", "k_copy", "k_rx_plan", "k_rx_apply") if k in name]
-        if not short:
+        m = re.search(r"(k_[a-z0-9_]+)", name)
+        if not m:
             continue
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short[0]))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1)))
 rows.sort()
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 tail = rows[-n:]
 t0 = tail[0][0]
+prev_end = None
 for s, e, k in tail:
-    print("%-11s start %9.1f us  end %9.1f us  dur %7.1f" % (k, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3))
+    gap = "" if prev_end is None else "  gap %6.1f" % ((s - prev_end) / 1e3)
+    print("%-24s start %9.1f us  end %9.1f us  dur %7.1f%s" % (k, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, gap))
+    prev_end = e
