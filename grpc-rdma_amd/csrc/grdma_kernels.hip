@@ -57,11 +57,30 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
 // The send plan of a streaming job's round: priced from the index of the slice buffer first (grdma_tx_fast.h); what
 // that body declines -- nothing has been written then -- goes through the general planner in the same launch.
 // (launched in the index body's shape, 1024 threads; the general planner is a 256-thread body: waves 4-15 leave)
-__global__ __launch_bounds__(TXB_THREADS) void k_tx_plan_job(const grdma_tx_op* ops, const grdma_txf_ctl* ctls) {
+__global__ __launch_bounds__(TXB_THREADS) TXB_KERNEL_ATTR void k_tx_plan_job(const grdma_tx_op* ops, const grdma_txf_ctl* ctls) {
   if (txf_body(ops[blockIdx.x], &ctls[blockIdx.x])) return;  // (uniform)
+#ifdef GRDMA_SLIM_PLANNERS
+  // experiment (tools/gpu_slim.sh): no general planner in this kernel -- a declined Send accepts nothing
+  if (threadIdx.x == 0) {
+    const grdma_tx_op op = ops[blockIdx.x];
+    for (grdma_plan* pl : {op.plan, op.wire_plan}) {
+      if (pl == nullptr) continue;
+      pl->nsegs = 0;
+      pl->ntiles = 0;
+      pl->tile_prefix[0] = 0;
+      pl->bytes = 0;
+    }
+    op.result->sent = 0;
+    op.result->records = 0;
+    op.result->staged = 0;
+    if (op.tail_out != nullptr) *op.tail_out = op.conn->remote_tail;
+    op.result->dbg[9] = 0;
+  }
+#else
   if (threadIdx.x >= PLAN_THREADS) return;
   tx_plan_body(ops[blockIdx.x]);
   if (threadIdx.x == 0) ops[blockIdx.x].result->dbg[9] = 0;  // (not priced from the index)
+#endif
 }
 
 // k_tx_plan_seq: gridDim.y Sends of the SAME connection back to back in one launch (a sender that
@@ -307,11 +326,14 @@ __attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_plan_job(const 
   return hipGetLastError();
 }
 // diagnostics: Sends of streaming jobs planned by txf_body [0], left to the general planner [1]
+int grdma_tx_fast_sends_pair(uint64_t out[2]);  // (grdma_rx_plan.hip: the Sends planned inside k_plan_pair_job)
 int grdma_tx_fast_sends(uint64_t out[2]) {
   unsigned long long v[2] = {0, 0};
+  uint64_t w[2] = {0, 0};
   if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_tx_fast_sends), sizeof(v)) != hipSuccess) return -1;
-  out[0] = v[0];
-  out[1] = v[1];
+  if (grdma_tx_fast_sends_pair(w) != 0) return -1;
+  out[0] = v[0] + w[0];
+  out[1] = v[1] + w[1];
   return 0;
 }
 

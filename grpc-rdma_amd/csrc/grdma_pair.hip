@@ -61,6 +61,7 @@ uint32_t grdma_tx_index_threads(void);
 hipError_t grdma_launch_tx_index(grdma_txf_ctl*, uint32_t, hipStream_t);
 hipError_t grdma_launch_tx_plan_job(const grdma_tx_op*, const grdma_txf_ctl*, uint32_t, hipStream_t);
 const void* grdma_kernel_fn_plan_pair(void);
+const void* grdma_kernel_fn_plan_pair_job(void);
 uint32_t grdma_kernel_threads(int which);
 uint32_t grdma_copy_resident_blocks(void);
 }
@@ -2054,6 +2055,7 @@ struct grdma_stream_job {
   uint64_t exec_rounds = 0;
   int exec_pipeline = -1;
   int exec_fastkey = -1;              // rx_fast | tx_fast << 1 | deep << 2 the graph was built for
+  int slim_after = -1, runs = 0;      // experiment: job kernels only from run `slim_after` on
   int rx_miss = 0, tx_miss = 0;       // consecutive runs whose drains / Sends of link 0 mostly went to the general planner
   uint64_t seen[4] = {0, 0, 0, 0};    // the result blocks' taken / declined counters at the end of the last run
   int pipeline = 0;                   // 1: overlap the send plan / gather / scatter of
@@ -2067,6 +2069,7 @@ struct grdma_stream_job {
   int tx_fast = 1;                    // Sends of one-Send rounds are priced from an index of the slice buffer: k_tx_index at
                                       // the start of a step, k_tx_fast per Send, the general planner behind it for the rest
   grdma_txf_ctl* d_txf = nullptr;     // [n]
+  int pair_job = 1;                   // pipelined graph: drain of round t and Send of round t + 1 in one launch (k_plan_pair_job)
   int rx_fast = 1;                    // drains of one-Send rounds go through k_rx_fast first (grdma_rx_fast.hip), the
                                       // general planner behind it only does what that kernel declined
   int cumask_bits = 0;                // planner CUs (low bits of the mask); 0 = off
@@ -2093,7 +2096,7 @@ struct grdma_stream_job {
 namespace {
 
 inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 : 2); }
-inline int job_fastkey(const grdma_stream_job* j) { return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0); }
+inline int job_fastkey(const grdma_stream_job* j) { return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0) | (j->pair_job ? 8 : 0); }
 inline bool job_exec_stale(const grdma_stream_job* j) {
   return !j->exec || j->exec_rounds != j->rounds || j->exec_pipeline != j->pipeline || j->exec_fastkey != job_fastkey(j);
 }
@@ -2349,21 +2352,25 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
   hipGraph_t g;
   HIP_TRY(hipGraphCreate(&g, 0));
   std::vector<hipGraphNode_t> P(R), G(R), W(R), X(R), A(R);
-  auto add2 = [&](hipGraphNode_t* node, const void* fn, dim3 grid, uint32_t threads, const void* arg, const void* arg2,
-                  std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
+  // (every node hands over three pointer-sized parameters; a kernel with fewer ignores the rest)
+  auto add3 = [&](hipGraphNode_t* node, const void* fn, dim3 grid, uint32_t threads, const void* arg, const void* arg2,
+                  const void* arg3, std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
     std::vector<hipGraphNode_t> d;
     for (hipGraphNode_t x : deps)
       if (x) d.push_back(x);
-    void* args[2] = {const_cast<void*>(static_cast<const void*>(&arg)), const_cast<void*>(static_cast<const void*>(&arg2))};
+    void* args[3] = {const_cast<void*>(static_cast<const void*>(&arg)), const_cast<void*>(static_cast<const void*>(&arg2)),
+                     const_cast<void*>(static_cast<const void*>(&arg3))};
     hipKernelNodeParams np;
     memset(&np, 0, sizeof(np));
     np.func = const_cast<void*>(fn);
     np.gridDim = grid;
     np.blockDim = dim3(threads);
-    np.sharedMemBytes = 0;
     np.kernelParams = args;
-    np.extra = nullptr;
     return hipGraphAddKernelNode(node, g, d.empty() ? nullptr : d.data(), d.size(), &np);
+  };
+  auto add2 = [&](hipGraphNode_t* node, const void* fn, dim3 grid, uint32_t threads, const void* arg, const void* arg2,
+                  std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
+    return add3(node, fn, grid, threads, arg, arg2, nullptr, deps);
   };
   auto add = [&](hipGraphNode_t* node, const void* fn, dim3 grid, uint32_t threads, const void* arg,
                  std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
@@ -2433,6 +2440,22 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
         last = W[t];
       }
       if (e == hipSuccess) e = add_rx(t, rxop, {last});
+      if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t]});
+    } else if (fast && tfast && j->pair_job) {
+      // One launch for the drain of round t and the Send of round t + 1 (k_plan_pair_job): kernels of different
+      // branches of a graph do not overlap on this stack (measured: even planner workgroups small enough to sit
+      // beside the copy kernels' run behind them), so the round is a chain -- and this one has four links:
+      //   G_t: P_t (= X_{t-1})      W_t: G_t      X_t + P_{t+1}: W_t, A_{t-1}      A_t: X_t
+      if (t == 0) e = add_tx(0, txop, {});
+      if (e == hipSuccess) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t], at(A, t, 1)});
+      if (e == hipSuccess) e = add(&W[t], f_cpy, dim3(txb, n), ct, wplans, {G[t]});
+      if (e == hipSuccess) {
+        const bool more = t + 1 < R;
+        const void* txop_next = j->d_txop + job_opset(t + 1) * n;
+        e = add3(&X[t], grdma_kernel_fn_plan_pair_job(), dim3(n, more ? 2 : 1), grdma_rx_plan_job_threads(), rxop,
+                 more ? txop_next : nullptr, j->d_txf, {W[t], at(A, t, 1)});
+        if (more) P[t + 1] = X[t];
+      }
       if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t]});
     } else if (j->deep || fast || tfast) {
       // Limit-driven schedule (default): the drain of round t walks exactly up to the tail its Send
@@ -2638,7 +2661,12 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
   if (const char* e = getenv("GRDMA_JOB_SCHEDULE")) j->deep = strcmp(e, "pair") == 0 ? 0 : 1;
   if (const char* e = getenv("GRDMA_JOB_CUMASK")) j->cumask_bits = atoi(e);
   if (const char* e = getenv("GRDMA_RX_FAST")) j->rx_fast = atoi(e) != 0;
+  if (const char* e = getenv("GRDMA_PAIR_JOB")) j->pair_job = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_TX_FAST")) j->tx_fast = atoi(e) != 0;
+  if (const char* e = getenv("GRDMA_SLIM_AFTER")) {  // experiment (tools/gpu_slim.sh): see grdma_stream_job_run
+    j->slim_after = atoi(e);
+    j->rx_fast = j->tx_fast = 0;
+  }
   j->rounds = max_rounds;
   j->stream = tx[0]->stream;
   j->direct = (tx[0]->flags & GRDMA_WIRE_DIRECT) != 0;
@@ -2979,6 +3007,11 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
   // The job kernels try the steady-state bodies first and run the general planners (under a quarter of their
   // register budget) for what those decline.  A job whose last drains / Send keep being declined -- no period in
   // its record sizes, Sends cut by the staging budget, ... -- goes back to the plain planner kernels.
+  j->runs++;
+  if (j->slim_after >= 0) {
+    if (j->runs >= j->slim_after) j->rx_fast = j->tx_fast = 1;
+    return 0;
+  }
   if (j->burst == 1 && mode != GRDMA_RUN_ENGINE && j->rounds >= 2 && (j->rx_fast || job_tx_fast(j))) {
     uint64_t cnt[3][2];  // {taken, declined with work waiting} of link 0: drains of both parities, Sends
     uint32_t c32[2][2];  // {pad1 = taken, pad0 = declined}

@@ -37,8 +37,15 @@
 
 namespace {
 
+#ifdef GRDMA_SLIM_PLANNERS  // experiment: a planner workgroup small enough to sit beside the copy kernels' workgroups
+#define RXF_THREADS 256
+#define RXF_PER 16
+#define RXF_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
+#else
 #define RXF_THREADS 1024
 #define RXF_PER 4
+#define RXF_KERNEL_ATTR
+#endif
 #define RXF_MAX (RXF_THREADS * RXF_PER)
 #define RXF_WAVES (RXF_THREADS / 64)
 #define RXF_MINRD 256u
@@ -49,6 +56,33 @@ namespace {
 // end at the limit / too many records, [3] the ring does not hold the predicted records, [4] long run of small records,
 // [5] no room in plan / slice table / arena
 __device__ unsigned long long g_rx_fast_drains[6] = {0, 0, 0, 0, 0, 0};
+
+// LDS of the receive planners.  The steady-state body runs first and the general planner (grdma_rx_plan.hip) only
+// after it has declined, so their big arrays share one allocation: that is what lets k_plan_pair_job hold both
+// receive bodies AND both send bodies within the CU's 160 KB.
+#define RXG_BULK 4096                       // BULK_MAX of the general planner
+#define RXG_PAD(i) ((i) + ((i) >> 4))       // its index padding (RXP)
+struct rx_lds_general {
+  uint32_t hist[GRDMA_RX_HIST];
+  uint32_t penc[RXG_PAD(RXG_BULK) + 1];
+  uint32_t xenc[RXG_PAD(RXG_BULK + 1) + 1];
+  uint32_t n[RXG_PAD(RXG_BULK) + 1];
+  uint16_t sin[RXG_PAD(RXG_BULK) + 1];
+};
+struct rx_lds_fast {
+  uint32_t hist[GRDMA_RX_HIST];
+  uint32_t pat[RXF_PMAX], pre[RXF_PMAX + 1];
+  uint32_t n[RXF_MAX + RXF_MAX / RXF_PER + 2];
+  uint16_t sin[RXF_MAX + RXF_MAX / RXF_PER + 2];
+};
+union rx_lds {
+  rx_lds_general g;
+  rx_lds_fast f;
+};
+__device__ __forceinline__ rx_lds* rx_lds_get() {
+  __shared__ rx_lds L;
+  return &L;
+}
 
 // (the three functions below restate read_space_after / replay_record32 of grdma_rx_plan.hip)
 // s = bytes of space left in the open read (0 = between reads) after a record of n bytes
@@ -169,12 +203,15 @@ __device__ __forceinline__ bool rxf_body(const grdma_rx_op& op_in) {
   grdma_plan* plan = op.plan;
   grdma_rx_result* res = op.result;
 
-  __shared__ uint32_t s_hist[GRDMA_RX_HIST];
-  __shared__ uint32_t s_pat[RXF_PMAX], s_pre[RXF_PMAX + 1];
-  __shared__ uint32_t s_n[RXFP(RXF_MAX) + 2];
-  __shared__ uint16_t s_sin[RXFP(RXF_MAX) + 2];
+  rx_lds* const lds = rx_lds_get();
+  auto& s_hist = lds->f.hist;
+  auto& s_pat = lds->f.pat;
+  auto& s_pre = lds->f.pre;
+  auto& s_n = lds->f.n;
+  auto& s_sin = lds->f.sin;
+  static_assert(RXFP(RXF_MAX) + 2 <= sizeof(lds->f.n) / sizeof(uint32_t), "padded record arrays fit");
   __shared__ uint32_t s_w[3][RXF_WAVES];
-  __shared__ uint32_t s_bad, s_vj, s_first, s_send;
+  __shared__ uint32_t s_bad, s_vj, s_first, s_send, s_totn;
 
   // ---- 0. state, preconditions (every thread reads the same words; nothing is stored before the probe passed)
   uint8_t* const ring = c->ring;
@@ -188,6 +225,12 @@ __device__ __forceinline__ bool rxf_body(const grdma_rx_op& op_in) {
   const uint64_t lim = op.limit_ptr ? __hip_atomic_load(op.limit_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
   const uint64_t slice_idx0 = op.append == 1 ? c->rx_slice_idx : 0;
   const uint64_t a_off0 = op.append == 1 ? c->rx_arena_off : 0;
+  // (what thread 0 adds to at the very end: fetched now, in the same round trip as the state above)
+  const uint64_t o_total_read = c->total_read, o_credit_msgs = c->credit_msgs;
+  const uint64_t o_rx_records = c->rx_records, o_rx_rounds = c->rx_rounds;
+  const uint32_t o_h1 = c->rx_h1;
+  const uint64_t o_seq = res->seq;
+  grdma_hostline* const line = c->line;
   constexpr int NH = GRDMA_RX_HIST / RXF_THREADS;
   uint32_t hv[NH];
 #pragma unroll
@@ -210,6 +253,7 @@ __device__ __forceinline__ bool rxf_body(const grdma_rx_op& op_in) {
     s_vj = 0xFFFFFFFFu;
     s_first = 0xFFFFFFFFu;
     s_send = 0;
+    s_totn = 0;
   }
 #pragma unroll
   for (int r = 0; r < NH; r++) s_hist[tid + r * RXF_THREADS] = hv[r];
@@ -336,6 +380,7 @@ __device__ __forceinline__ bool rxf_body(const grdma_rx_op& op_in) {
       steps++;
     }
     if (j > 0 && s_n[RXFP(j - 1)] < 2 * RXF_MINRD) s_bad = 1;  // a long run of small records: not this body's case
+    const bool from_start = j == 0;  // my chain began at the drain's start: it may hold the slice that closes the open read
     uint32_t s = j == 0 ? s0 : 0;
     for (; j < i0; j++) s = rxf_space_after(s_n[RXFP(j)], s);
     for (uint32_t r = 0; r < RXF_PER; r++) {
@@ -344,7 +389,7 @@ __device__ __forceinline__ bool rxf_body(const grdma_rx_op& op_in) {
         s_sin[RXFP(i)] = (uint16_t)s;
         const uint32_t n = s_n[RXFP(i)];
         // the first record that completes a slice: it closes the read that was open at the start (if any)
-        if (rxf_replay(n, s).sl_cnt != 0) atomicMin(&s_first, i);
+        if (from_start && rxf_replay(n, s).sl_cnt != 0) atomicMin(&s_first, i);
         s = rxf_space_after(n, s);
         if (i == V - 1) s_send = s;
       }
@@ -381,10 +426,15 @@ __device__ __forceinline__ bool rxf_body(const grdma_rx_op& op_in) {
   }
   uint32_t x_pk, x_tl, x_by, tot[3];
   rxf_scan3(my_pk, my_tl, my_by, s_w, &x_pk, &x_tl, &x_by, tot);
-  uint32_t x_n, d3, d4, totn[3];
-  rxf_scan3(my_n, 0, 0, s_w, &x_n, &d3, &d4, totn);
-  (void)x_n;
-  const uint32_t tot_sl = tot[0] & 0xFFFFu, tot_sg = tot[0] >> 16, tot_tl = tot[1], tot_by = tot[2], tot_n = totn[0];
+  // (payload total: a plain reduction riding on the scan's barriers would need a fourth lane array; one more
+  // wave reduction + LDS atomic is cheaper than a second scan)
+  {
+    uint32_t wn = my_n;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wn += __shfl_xor(wn, d, 64);
+    if ((tid & 63) == 0 && wn) atomicAdd(&s_totn, wn);
+  }
+  const uint32_t tot_sl = tot[0] & 0xFFFFu, tot_sg = tot[0] >> 16, tot_tl = tot[1], tot_by = tot[2];
   // the would-block at the end (rdma_do_read, rdma_bp_posix.cc:195-277): a read with bytes in it is handed up
   // as it is -- a short slice -- and its rest stays open; a clean state allocates a fresh 256-byte read
   const uint32_t cap_open_end = (odd_open && first_done == 0xFFFFFFFFu) ? s0 : RXF_MINRD;
@@ -456,7 +506,9 @@ __device__ __forceinline__ bool rxf_body(const grdma_rx_op& op_in) {
   const uint64_t t_emit = __builtin_amdgcn_s_memtime();
 
   // ---- 6. credit (pair.cc:276-284), state, result: thread 0
+  __syncthreads();  // (s_totn is complete)
   if (tid == 0) {
+    const uint32_t tot_n = s_totn;
     auto enc_end = [&](uint32_t i) -> uint64_t {  // ring bytes consumed once record i is finished
       const uint32_t qi = i / P, ri = i - qi * P;
       return (uint64_t)qi * SP + s_pre[ri] + s_pat[ri];
@@ -502,12 +554,6 @@ __device__ __forceinline__ bool rxf_body(const grdma_rx_op& op_in) {
     plan->tag_base = (uint64_t)ring;
     plan->tag_mask = cap64 - 1;
     plan->blocks_done = 0;
-    // (counters: all loads before the first store to the connection)
-    const uint64_t o_total_read = c->total_read, o_credit_msgs = c->credit_msgs;
-    const uint64_t o_rx_records = c->rx_records, o_rx_rounds = c->rx_rounds;
-    const uint32_t o_h1 = c->rx_h1;
-    const uint64_t o_seq = res->seq;
-    grdma_hostline* const line = c->line;
     c->head = nh;
     c->moving_head = nh;
     c->remain = 0;

@@ -42,6 +42,7 @@
 #include "grdma_ops.h"
 #include "grdma_tx_body.h"
 #include "grdma_rx_fast.h"
+#include "grdma_tx_fast.h"
 
 namespace {
 
@@ -268,13 +269,16 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
 
   __shared__ rx_state S;
   __shared__ uint64_t s_chain[CHAIN_CAP];
-  __shared__ uint32_t s_hist[GRDMA_RX_HIST];
+  // (the big arrays share their allocation with the steady-state body, which has finished when this one runs)
+  rx_lds* const lds = rx_lds_get();
+  auto& s_hist = lds->g.hist;
   // padded like the send plan's arrays: contiguous 16-record runs per thread
 #define RXP(i) ((i) + ((i) >> 4))
-  __shared__ uint32_t s_penc[RXP(BULK_MAX) + 1];
-  __shared__ uint32_t s_xenc[RXP(BULK_MAX + 1) + 1];
-  __shared__ uint32_t s_n[RXP(BULK_MAX) + 1];
-  __shared__ uint16_t s_sin[RXP(BULK_MAX) + 1];
+  auto& s_penc = lds->g.penc;
+  auto& s_xenc = lds->g.xenc;
+  auto& s_n = lds->g.n;
+  auto& s_sin = lds->g.sin;
+  static_assert(BULK_MAX == RXG_BULK && RXP(BULK_MAX) == RXG_PAD(RXG_BULK), "rx_lds_general mirrors these arrays");
   __shared__ uint64_t s_wave[PLAN_THREADS / 64];
   __shared__ uint64_t s_wbytes[PLAN_THREADS / 64], s_wn[PLAN_THREADS / 64];
   __shared__ uint32_t s_wpk[PLAN_THREADS / 64], s_wtiles[PLAN_THREADS / 64];
@@ -1416,12 +1420,31 @@ void k_rx_plan(const grdma_rx_op* ops) {
 // counts the waves that are still there) and waves 0-3 run the general planner, a 256-thread body -- under this
 // kernel's 128-register budget, i.e. with spills: a job whose drains keep being declined is switched to the plain
 // k_rx_plan by the host (grdma_stream_job_run).
-__global__ __launch_bounds__(RXF_THREADS)
+__global__ __launch_bounds__(RXF_THREADS) RXF_KERNEL_ATTR
 void k_rx_plan_job(const grdma_rx_op* ops) {
   if (rxf_body(ops[blockIdx.x])) return;  // (uniform)
+#ifdef GRDMA_SLIM_PLANNERS
+  // experiment (tools/gpu_slim.sh): no general planner in this kernel -- a declined drain simply does not happen
+  // in this round (empty scatter plan, nothing consumed, no credit); the data stays in the ring
+  if (threadIdx.x == 0) {
+    const grdma_rx_op op = ops[blockIdx.x];
+    op.plan->nsegs = 0;
+    op.plan->ntiles = 0;
+    op.plan->tile_prefix[0] = 0;
+    op.plan->bytes = 0;
+    op.plan->blocks_done = 0;
+    op.result->nslices = 0;
+    op.result->bytes = 0;
+    op.result->consumed = 0;
+    op.result->records = 0;
+    op.result->credit_sent = 0;
+    op.result->dbg[9] = 0;
+  }
+#else
   if (threadIdx.x >= PLAN_THREADS) return;
   rx_plan_body(ops[blockIdx.x]);
   if (threadIdx.x == 0) ops[blockIdx.x].result->dbg[9] = 0;  // (not rxf_body's stamps)
+#endif
 }
 
 // Out-of-line copies for the resident engine: with both bodies inlined into its
@@ -1444,6 +1467,28 @@ void k_plan_pair(const grdma_rx_op* rxops, const grdma_tx_op* txops) {
   // (both bodies inline: the out-of-line copies used by the resident engine spill)
   if (blockIdx.y == 0) rx_plan_body(rxops[blockIdx.x]);
   else tx_plan_body(txops[blockIdx.x]);
+}
+
+// ----------------------------------------------------------------------------
+// k_plan_pair_job: k_plan_pair for a streaming job -- the drain of round t (workgroup y = 0: steady-state body, the
+// general planner if that declines) and the Send of round t + 1 (y = 1: priced from the index, the general planner
+// if that declines) in ONE launch of 1024-thread workgroups.  One kernel boundary and the send plan's whole duration
+// leave the round's chain: gather, wire, THIS, scatter.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(RXF_THREADS)
+void k_plan_pair_job(const grdma_rx_op* rxops, const grdma_tx_op* txops, const grdma_txf_ctl* ctls) {
+  static_assert(RXF_THREADS == TXB_THREADS, "one workgroup shape for both planners");
+  if (blockIdx.y == 0) {
+    if (rxf_body(rxops[blockIdx.x])) return;  // (uniform)
+    if (threadIdx.x >= PLAN_THREADS) return;
+    rx_plan_body(rxops[blockIdx.x]);
+    if (threadIdx.x == 0) rxops[blockIdx.x].result->dbg[9] = 0;
+  } else {
+    if (txf_body(txops[blockIdx.x], &ctls[blockIdx.x])) return;  // (uniform)
+    if (threadIdx.x >= PLAN_THREADS) return;
+    tx_plan_body(txops[blockIdx.x]);
+    if (threadIdx.x == 0) txops[blockIdx.x].result->dbg[9] = 0;
+  }
 }
 
 // ----------------------------------------------------------------------------
@@ -1623,6 +1668,15 @@ extern "C" int grdma_rx_fast_drains(uint64_t out[6]) {
   unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
   if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_rx_fast_drains), sizeof(v)) != hipSuccess) return -1;
   for (int i = 0; i < 6; i++) out[i] = v[i];
+  return 0;
+}
+extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_job(void) { return reinterpret_cast<const void*>(&k_plan_pair_job); }
+// (this translation unit's copy of the index body's counters: the pair kernel's Sends)
+extern "C" __attribute__((visibility("hidden"))) int grdma_tx_fast_sends_pair(uint64_t out[2]) {
+  unsigned long long v[2] = {0, 0};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_tx_fast_sends), sizeof(v)) != hipSuccess) return -1;
+  out[0] = v[0];
+  out[1] = v[1];
   return 0;
 }
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair(void) { return reinterpret_cast<const void*>(&k_plan_pair); }

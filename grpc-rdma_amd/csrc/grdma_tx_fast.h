@@ -9,8 +9,15 @@
 
 namespace {
 
+#ifdef GRDMA_SLIM_PLANNERS  // (see grdma_rx_fast.h)
+#define TXB_THREADS 256
+#define TXB_PER 16
+#define TXB_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
+#else
 #define TXB_THREADS 1024
 #define TXB_PER 4
+#define TXB_KERNEL_ATTR
+#endif
 #define TXB_WAVES (TXB_THREADS / 64)
 static_assert(TXB_THREADS * TXB_PER >= GRDMA_TX_MAX_RECORDS, "one pass covers a Send");
 
@@ -79,7 +86,11 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
   // st(k): staging offset of record k of this Send (k >= 1), from the index
   // ---- my records: striped, all loads in flight together
   uint64_t r_ptr[TXB_PER], r_len[TXB_PER], r_e0[TXB_PER], r_e1[TXB_PER];
-  uint32_t r_t0[TXB_PER];
+  uint32_t r_t0[TXB_PER], r_t1[TXB_PER];
+  uint64_t r_l1[TXB_PER];  // len_pre / tile_pre BEHIND my record: what the totals need from the last whole record's owner
+  // (what thread 0 adds to at the very end: fetched now, in the same round trip)
+  const uint64_t o_written = c->total_written, o_records = c->tx_records, o_rounds = c->tx_rounds;
+  const uint64_t o_seq = op.result->seq, lp_start = m ? len_pre[start] : 0;
 #pragma unroll
   for (int r = 0; r < TXB_PER; r++) {
     const uint64_t i = tid + (uint64_t)r * TXB_THREADS;
@@ -90,6 +101,8 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
     r_e0[r] = m ? enc_pre[start + k] : 0;
     r_e1[r] = m ? enc_pre[start + k + 1] : 0;
     r_t0[r] = m ? tile_pre[start + k] : 0;
+    r_t1[r] = m ? tile_pre[start + k + 1] : 0;
+    r_l1[r] = m ? len_pre[start + k + 1] : 0;
   }
   // ---- whole records: a count
   uint32_t my_whole = 0;
@@ -112,8 +125,8 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
 #pragma unroll
   for (int w = 0; w < TXB_WAVES; w++) nrec += s_cnt[w];
   // the short record behind them (pay = min(len, W(S - st), W(free0 - st)) = W(room0 - st): it did not fit whole)
-  __shared__ uint64_t s_short[2];  // {short_pay, st of record nrec}
-  if (tid == 0) s_short[0] = s_short[1] = 0;
+  __shared__ uint64_t s_short[4];  // {short_pay, st of record nrec, len_pre and tile_pre behind the last whole record}
+  if (tid == 0) s_short[0] = s_short[1] = s_short[2] = s_short[3] = 0;
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < TXB_PER; r++) {
@@ -127,6 +140,10 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
       s_short[1] = st_i[r];
     }
     if (nrec == m && m != 0 && i == m - 1) s_short[1] = st_n[r];  // every record went out whole: st(m)
+    if (nrec != 0 && i == nrec - 1) {
+      s_short[2] = r_l1[r];
+      s_short[3] = r_t1[r];
+    }
   }
   __syncthreads();
   const uint64_t short_pay = s_short[0];
@@ -147,11 +164,11 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
   }
 
   if (tid == 0) {
-    // totals behind the whole records (one more trip to the index: three independent loads)
+    // totals behind the whole records (their owner fetched the index entries with its record)
     uint64_t sent = short_pay, ntiles = (short_pay + TB - 1) >> ts;
     if (nrec) {
-      sent += len_pre[start + nrec] - len_pre[start] - byte_idx;
-      ntiles += tile_pre[start + nrec] - base_t + Dt;
+      sent += s_short[2] - lp_start - byte_idx;
+      ntiles += s_short[3] - base_t + Dt;
     }
     const uint64_t st_last = s_short[1];  // st(nrec)
     const uint64_t staged = (nrec || short_pay) ? st_last + (short_pay > 0 ? enc_size(short_pay) : 0) : 0;
@@ -205,7 +222,6 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
     uint64_t bidx = 0;
     if (short_pay > 0) bidx = (nrec == 0 ? byte_idx : 0) + short_pay;
     else if (nrec == 0) bidx = byte_idx;
-    const uint64_t o_written = c->total_written, o_records = c->tx_records, o_rounds = c->tx_rounds;
     c->remote_tail = new_tail;
     c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709
     c->total_written = o_written + sent;
@@ -231,7 +247,7 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
     r->dbg[9] = 0xFA57;  // this Send was priced from the index
     r->dbg[10]++;
     atomicAdd(&g_tx_fast_sends[0], 1ull);
-    const uint64_t nxt = op.seq_next ? op.seq_next : r->seq + 1;
+    const uint64_t nxt = op.seq_next ? op.seq_next : o_seq + 1;
     // (relaxed: a streaming job's consumers are later kernels of the graph; a system-scope release would write the
     // XCD's L2 back -- the plan just laid out -- before the kernel may end)
     __hip_atomic_store(&r->seq, nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -156,6 +156,7 @@ struct emu_graph_node {
   dim3 grid, block;
   void* a0;
   void* a1;
+  void* a2;
 };
 struct emu_graph {
   std::vector<emu_graph_node*> nodes;
@@ -173,8 +174,9 @@ inline hipError_t hipGraphDestroy(hipGraph_t g) {
 }
 inline hipError_t hipGraphAddKernelNode(hipGraphNode_t* node, hipGraph_t g, const hipGraphNode_t*, size_t,
                                         const hipKernelNodeParams* p) {
+  // (the product always hands over three pointer-sized kernel parameters; kernels with fewer ignore the rest)
   emu_graph_node* n = new emu_graph_node{p->func, p->gridDim, p->blockDim, *static_cast<void**>(p->kernelParams[0]),
-                                         *static_cast<void**>(p->kernelParams[1])};
+                                         *static_cast<void**>(p->kernelParams[1]), *static_cast<void**>(p->kernelParams[2])};
   g->nodes.push_back(n);
   *node = n;
   return hipSuccess;
@@ -188,9 +190,9 @@ inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, vo
 inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
   std::lock_guard<std::recursive_mutex> lk(emu::launch_mutex());
   for (const emu_graph_node& n : e->nodes) {
-    void (*f)(void*, void*) = reinterpret_cast<void (*)(void*, void*)>(n.func);
-    void *a0 = n.a0, *a1 = n.a1;
-    emu::launch(n.grid, n.block, [=] { f(a0, a1); });
+    void (*f)(void*, void*, void*) = reinterpret_cast<void (*)(void*, void*, void*)>(n.func);
+    void *a0 = n.a0, *a1 = n.a1, *a2 = n.a2;
+    emu::launch(n.grid, n.block, [=] { f(a0, a1, a2); });
   }
   return hipSuccess;
 }
