@@ -27,10 +27,11 @@ MIB = 1 << 20
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def proto_message(i, payload=MIB):
+def proto_message(i, payload=MIB, prng_seed=None):
     """Serialized SimpleRequest{bytes message = <payload bytes>} (micro_benchmark.proto):
     tag 0x0a, varint length, bytes.  Content rotates with the message index so a
-    misordered or stale delivery cannot compare equal."""
+    misordered or stale delivery cannot compare equal; with prng_seed the body is PRNG bytes
+    (the reference's second payload kind, examples/cpp/micro-bench: seed 1234)."""
     n = payload
     var = bytearray()
     while True:
@@ -39,19 +40,23 @@ def proto_message(i, payload=MIB):
         var.append(b | (0x80 if n else 0))
         if not n:
             break
-    body = bytes(((j + 17 * i) % 251) for j in range(256)) * (payload // 256 + 1)
+    if prng_seed is not None:
+        import random
+        body = random.Random(prng_seed + i).randbytes(payload)
+    else:
+        body = bytes(((j + 17 * i) % 251) for j in range(256)) * (payload // 256 + 1)
     return bytes([0x0A]) + bytes(var) + body[:payload]
 
 
 class Workload:
     """B framed messages laid out in HBM + the slice list of the endpoint_write."""
 
-    def __init__(self, g, n_msgs, payload=MIB, max_frame=16384, stream_id=1):
+    def __init__(self, g, n_msgs, payload=MIB, max_frame=16384, stream_id=1, prng_seed=None):
         self.payload = payload
         from grpc_rdma_amd import h2
         self.g = g
         self.n_msgs = n_msgs
-        self.msgs = [proto_message(i, payload) for i in range(min(n_msgs, 8))]
+        self.msgs = [proto_message(i, payload, prng_seed) for i in range(min(n_msgs, 8))]
         self.msg_len = len(self.msgs[0])
         layout = h2.frame_message(self.msg_len, stream_id, max_frame)
         self.layout = layout
@@ -176,6 +181,30 @@ def tcp_baseline():
                                 "what": "grpcio %s client-streaming 1 MiB messages for 4 s / unary 66-byte echo for 4 s, "
                                         "one insecure channel on 127.0.0.1, identity serializers" % gs_.get("grpcio"),
                                 "error": gs_.get("error") or gu.get("error")}}
+
+
+def conn_setup_us(g, ring=4 << 20, max_sge=30, n=8):
+    """Connection set-up + tear-down (grdma_pair_create + _destroy of the reference's default shape): every block from
+    the allocator vs from the PairPool (pair.h:273-333; here the pool keeps the memory of closed connections)."""
+    lib = g.load()
+    lib.grdma_pair_pool_trim()
+
+    def lap(k):
+        t0 = time.perf_counter()
+        for _ in range(k):
+            p = lib.grdma_pair_create(ring, max_sge, 0)
+            if not p:
+                raise RuntimeError(lib.grdma_last_error().decode())
+            lib.grdma_pair_destroy(p)
+        return 1e6 * (time.perf_counter() - t0) / k
+
+    lap(2)
+    cold = lap(n)
+    lib.grdma_pair_pool_reserve(1, ring, max_sge, 0, 0)
+    lap(2)
+    pooled = lap(n)
+    lib.grdma_pair_pool_trim()
+    return {"ring_kib": ring >> 10, "allocator": round(cold, 1), "pair_pool": round(pooled, 1)}
 
 
 def err_text(e):
@@ -413,7 +442,11 @@ def main():
                     help="how the timed step is launched: the round-by-round kernels of a HIP graph, or ONE launch of "
                          "the persistent link engine (k_link); the other one is reported as a comparison leg")
     ap.add_argument("--no-tcp-baseline", action="store_true", help="skip the loop-back TCP baselines")
-    ap.add_argument("--rtt-iters", type=int, default=100000)
+    ap.add_argument("--reps", type=int, default=3,
+                    help="timed regions of --steps steps each; the median is reported (reference protocol: 3 repetitions)")
+    ap.add_argument("--rtt-iters", type=int, default=200000,
+                    help="64 B round trips (>= 10 s of them on this part; the reference runs >= 10 s or 1 M RPCs behind "
+                         "10 000 warm-up calls, examples/cpp/micro-bench/mb_client.cc:41-44)")
     ap.add_argument("--armed-rtt-only", action="store_true", help="(internal) run only the armed-read ping-pong")
     ap.add_argument("--rtt-only", action="store_true", help="(internal) run only the 64 B ping-pong leg")
     ap.add_argument("--h2-bulk-pairs-only", action="store_true", help="(internal) run only the 64-frames-per-bulk-step h2 leg")
@@ -431,7 +464,7 @@ def main():
         import grpc_rdma_amd as g
         g.init(int(os.environ.get("LOCAL_RANK", "0")))
         if args.rtt_only:
-            print(json.dumps(measure_rtt(g, iters=args.rtt_iters, warmup=min(2000, max(10, args.rtt_iters // 10)))))
+            print(json.dumps(measure_rtt(g, iters=args.rtt_iters, warmup=min(10000, max(10, args.rtt_iters // 10)))))
         else:
             print(json.dumps(measure_rtt_armed(g, iters=args.rtt_iters, warmup=min(200, max(10, args.rtt_iters // 10)))))
         return
@@ -469,7 +502,7 @@ def main():
         torch.cuda.synchronize()
 
     def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB,
-                pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None, burst=1):
+                pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None, burst=1, reps=1):
         """n_links connections with rings of ring_kb KiB.  Graph schedule: calibrate the number of
         rounds, capture the graph, time `steps` replays.  Engine schedule: every step is ONE launch of
         the persistent link engine.  Then verify, optionally instrument."""
@@ -512,16 +545,21 @@ def main():
         for _ in range(warmup):
             launch()
         job.sync()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            launch()
-        job.sync()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        elapsed = grp.max(elapsed)
-        barrier()
-        out = {"elapsed": elapsed, "rounds": rounds, "verified": None, "classes": None,
+        # `reps` timed regions of exactly `steps` steps each (the reference's protocol: 3 repetitions, the median
+        # counts; examples/cpp/micro-bench); every region is bracketed by barrier + synchronize on both sides
+        all_elapsed = []
+        for _rep in range(max(1, reps)):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                launch()
+            job.sync()
+            torch.cuda.synchronize()
+            e = time.perf_counter() - t0
+            all_elapsed.append(grp.max(e))
+            barrier()
+        elapsed = sorted(all_elapsed)[len(all_elapsed) // 2]
+        out = {"elapsed": elapsed, "all_elapsed": all_elapsed, "rounds": rounds, "verified": None, "classes": None,
                "user_bytes": sum(w.user_bytes for w in wls), "N": total_n,
                "E": sum(w.E for w in wls)}
         if verify:  # correctness of what the timed region produced (untimed)
@@ -636,13 +674,14 @@ def main():
     head = None
     if args.pipeline:
         try:
-            head = measure(args.ring_kb, args.steps, args.warmup, not args.no_verify, True, pipeline=True)
+            head = measure(args.ring_kb, args.steps, args.warmup, not args.no_verify, True, pipeline=True, reps=args.reps)
         except Exception as e:  # keep the line: fall back to the plain schedule and say so
             schedule = "sequential (pipelined run failed: %s)" % str(e)[:120]
     seq = None
     if head is None or not args.no_extra_legs:
         seq = measure(args.ring_kb, args.steps if head is None else max(2, args.steps // 2),
-                      args.warmup if head is None else 1, not args.no_verify, head is None, pipeline=False)
+                      args.warmup if head is None else 1, not args.no_verify, head is None, pipeline=False,
+                      reps=args.reps if head is None else 1)
     if head is None:
         head, seq = seq, None
     graph_head = head
@@ -673,7 +712,9 @@ def main():
     achieved = per_launch / (classes[dom]["us_per_launch"] * 1e-6) / 1e9
     kname = "k_rx_apply" if dom == "rx_apply" else "k_copy"
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_ring%dm_summary.json" % (args.ring_kb // 1024))
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_ring%dm_summary.json" % (args.ring_kb // 1024))
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_ring%dm_summary.json" % (args.ring_kb // 1024))
     if os.path.exists(pmc) and args.msgs == 256 and args.wire == "staged":
         try:
             traffic = json.load(open(pmc))["kernels"][kname]["hbm_traffic_bytes"]
@@ -682,8 +723,24 @@ def main():
     roofline = {"bound": "hbm", "kernel": "%s (%s)" % (kname, dom),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": (os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                   "command, committed; NOT re-measured in this run)") if traffic is not None else None,
                 "bytes_per_launch": int(per_launch),
                 "us_per_launch": round(classes[dom]["us_per_launch"], 2)}
+    # what the roofline of the dominant HBM kernel does not show: the kernel that takes the most TIME (a planner is
+    # latency-bound and moves next to nothing), and the step as a whole against the HBM peak
+    tot_ms = sum(v["ms"] for v in classes.values())
+    top = max(classes, key=lambda k: classes[k]["ms"])
+    step_bytes = 2 * wl.N + 3 * wl.E  # K1 (N read + E written) + K4 (E read + N written + E cleared); the wire is the NIC's
+    step_s = elapsed / args.steps
+    roofline["dominant_by_time"] = {
+        "kernel": top, "us_per_launch": round(classes[top]["us_per_launch"], 2),
+        "share_of_kernel_time": round(classes[top]["ms"] / tot_ms, 3),
+        "planner_share_of_kernel_time": round(sum(classes[k]["ms"] for k in ("tx_plan", "rx_plan") if k in classes) / tot_ms, 3),
+        "note": "per-class HIP-event time of the instrumented in-order pass (a class = the launches between two events)"}
+    roofline["step_level"] = {"bytes": int(step_bytes), "achieved": round(step_bytes / step_s / 1e9, 1), "unit": "GB/s",
+                              "frac": round(step_bytes / step_s / 1e9 / HBM_PEAK_GBPS, 4),
+                              "frac_with_wire": round((step_bytes + 2 * wl.E) / step_s / 1e9 / HBM_PEAK_GBPS, 4)}
     if args.schedule == "engine" and eng is not None:
         # one kernel does the whole step: N read + N written (gather), E + E (wire), N + N + N (scatter + clear)
         per_launch = 5 * wl.N + 2 * wl.E
@@ -702,6 +759,8 @@ def main():
         "metric": "streaming GiB/s @1 MiB msgs (client-streaming, 1 connection per GPU)",
         "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "repetitions": {"n": len(head.get("all_elapsed", [elapsed])), "reported": "median",
+                        "ms_per_step": [round(1e3 * e / args.steps, 4) for e in head.get("all_elapsed", [elapsed])]},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic",
         "value_is": "device-resident: slices in HBM before the timed region, delivered slices left in HBM "
@@ -732,6 +791,20 @@ def main():
             out.update(rtt_subprocess("--rtt-only", args.rtt_iters, 240, key="rtt_error"))
             if world == 1:
                 out.update(rtt_subprocess("--armed-rtt-only", max(1000, args.rtt_iters // 5)))
+    if not args.no_extra_legs and rank == 0:
+        try:
+            out["conn_setup_us"] = conn_setup_us(g)
+        except Exception as e:
+            out["conn_setup_error"] = str(e)[:200]
+    if not args.no_extra_legs:
+        # the same headline step with PRNG payload bytes (seed 1234): the reference's second payload kind
+        try:
+            pw = Workload(g, args.msgs, prng_seed=1234)
+            pr = measure(args.ring_kb, max(2, args.steps // 2), 1, not args.no_verify, False, pipeline=bool(args.pipeline), wls=[pw])
+            out["value_prng_payload"] = round(pw.user_bytes * max(2, args.steps // 2) * world / pr["elapsed"] / (1 << 30), 3)
+            out["prng_payload_verified"] = pr["verified"]
+        except Exception as e:
+            out["prng_payload_error"] = str(e)[:200]
     if seq is not None:  # same workload and ring, five kernels per round strictly in order
         out["value_sequential"] = round(
             wl.user_bytes * max(2, args.steps // 2) * world / seq["elapsed"] / (1 << 30), 3)

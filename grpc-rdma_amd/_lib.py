@@ -38,7 +38,7 @@ class Config(C.Structure):
                 ("poller_sleep_timeout_ms", C.c_int32), ("ring_buffer_size_kb", C.c_uint32),
                 ("zerocopy_buffer_size_kb", C.c_uint32), ("zerocopy_threshold_kb", C.c_uint32),
                 ("max_sge", C.c_int32), ("hip_device", C.c_int32), ("hip_wire_direct", C.c_int32),
-                ("hip_register_min", C.c_uint32)]
+                ("hip_register_min", C.c_uint32), ("hip_pair_pool_mb", C.c_uint32)]
 
 
 # name -> (restype, argtypes); kept in one table so the "exports every symbol"
@@ -99,6 +99,14 @@ SIGNATURES = {
     "grdma_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, u64]),
     "grdma_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, u64]),
     "grdma_device_synchronize": (C.c_int, []),
+    "grdma_pair_pool_reserve": (C.c_int, [C.c_uint32, u64, C.c_int, C.c_int, u64]),
+    "grdma_pair_pool_take": (C.c_void_p, [C.c_char_p, u64, C.c_int, C.c_int]),
+    "grdma_pair_pool_get": (C.c_void_p, [C.c_char_p]),
+    "grdma_pair_pool_putback": (None, [C.c_void_p]),
+    "grdma_pair_pool_stats": (C.c_int, [u64p]),
+    "grdma_pair_pool_trim": (None, []),
+    "grdma_rx_fast_drains": (C.c_int, [u64p]),
+    "grdma_tx_fast_sends": (C.c_int, [u64p]),
 }
 
 _lib = None

@@ -309,7 +309,7 @@ void rdma_free(grpc_rdma* rdma) {  // :112-132
   if (rdma->pair != nullptr) {
     if (rdma->enable_poller && g_poller != nullptr) grdma_poller_remove(g_poller, rdma->pair);
     grdma_pair_disconnect(rdma->pair);
-    grdma_pair_destroy(rdma->pair);  // PairPool::Putback in the reference
+    grdma_pair_pool_putback(rdma->pair);  // PairPool::Putback (rdma_bp_posix.cc:128): its memory goes back to the pool
     rdma->pair = nullptr;
   }
   GRPC_ERROR_UNREF(rdma->shutdown_error);
@@ -383,12 +383,20 @@ grpc_endpoint* grpc_rdma_bp_create(int fd, const char* peer_string, bool enable_
   if (grdma_config_from_env(&cfg) < 0) return nullptr;
   if (grdma_init(cfg.hip_device) < 0) return nullptr;
   // (fine-grained: the pair may be handed to a peer in another process through grdma_pair_bootstrap_fd)
-  grdma_pair* pair = grdma_pair_create(static_cast<uint64_t>(cfg.ring_buffer_size_kb) * 1024,
-                                       cfg.max_sge,
-                                       (cfg.hip_wire_direct ? GRDMA_WIRE_DIRECT : GRDMA_WIRE_STAGED) | GRDMA_RING_FINE_GRAINED);
+  static const int pool_on = grdma_pair_pool_reserve(0, 0, 0, 0, static_cast<uint64_t>(cfg.hip_pair_pool_mb) << 20);
+  (void)pool_on;
+  // PairPool::Take(pair_id), rdma_bp_posix.cc:745-761: the id is what follows the last '/' of the peer string
+  std::string pair_id = peer_string ? peer_string : "";
+  {
+    const size_t pos = pair_id.find_last_of('/');
+    if (pos != std::string::npos) pair_id = pair_id.substr(pos + 1);
+  }
+  grdma_pair* pair = grdma_pair_pool_take(pair_id.c_str(), static_cast<uint64_t>(cfg.ring_buffer_size_kb) * 1024,
+                                          cfg.max_sge,
+                                          (cfg.hip_wire_direct ? GRDMA_WIRE_DIRECT : GRDMA_WIRE_STAGED) | GRDMA_RING_FINE_GRAINED);
   if (pair == nullptr) return nullptr;  // "Connection failed" path :777-784
   if (grdma_endpoint_set_async(pair, 0, 0) < 0) {
-    grdma_pair_destroy(pair);
+    grdma_pair_pool_putback(pair);
     return nullptr;
   }
   grpc_rdma* rdma = new grpc_rdma();

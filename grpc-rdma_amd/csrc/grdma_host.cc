@@ -94,6 +94,7 @@ int grdma_config_from_env(grdma_config* c) {
     else return -GRDMA_ERR_CONFIG;
   }
   c->hip_register_min = env_int("GRPC_RDMA_HIP_REGISTER_MIN", &v) && v > 0 ? (uint32_t)v : 0;
+  c->hip_pair_pool_mb = env_int("GRPC_RDMA_HIP_PAIR_POOL_MB", &v) && v >= 0 ? (uint32_t)v : 4096;
   c->hip_device = 0;
   if (env_int("GRPC_RDMA_HIP_DEVICE", &v)) c->hip_device = (int32_t)v;
   else if (env_int("LOCAL_RANK", &v)) c->hip_device = (int32_t)v;

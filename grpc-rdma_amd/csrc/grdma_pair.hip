@@ -17,6 +17,8 @@
 #include <cstring>
 #include <condition_variable>
 #include <mutex>
+#include <unordered_map>
+#include <map>
 #include <shared_mutex>
 #include <thread>
 #include <poll.h>
@@ -266,6 +268,7 @@ struct grdma_pair {
   uint64_t w_idx = 0, w_byte = 0;
   int w_flags = 0;
   bool w_active = false;
+  int pool_keep_open = 0;
 };
 
 namespace {
@@ -665,6 +668,56 @@ int grdma_init(int hip_device) {
   return 0;
 }
 
+// ---- PairPool (src/core/lib/ibverbs/pair.h:273-333) --------------------------------------------------------
+// The reference keeps 128 pre-built PairPollable objects in a queue and maps connection ids to the pairs handed
+// out (Take(id) / Get(id) / Putback).  What is expensive to build here is not the object but its memory: ring,
+// staging buffer, three plans, arena, pinned blocks -- about a dozen hipMalloc / hipHostMalloc calls per
+// connection.  So the pool keeps the BLOCKS: grdma_pair_destroy hands them back by {size, kind}, grdma_pair_create
+// takes them from there (and zeroes what Init() zeroes, as it always does); the id map sits on top.
+namespace {
+struct block_pool {
+  std::mutex mu;
+  std::multimap<std::pair<size_t, int>, void*> free_blocks;  // kind: 0 device, 1 device fine-grained, 2 pinned host
+  size_t cached_bytes[3] = {0, 0, 0};
+  size_t cap_bytes = 0;  // 0 = pooling off: blocks go back to the runtime
+  uint64_t hits = 0, misses = 0;
+  std::shared_timed_mutex id_mu;
+  std::unordered_map<std::string, grdma_pair*> id_pair;
+  std::unordered_map<grdma_pair*, std::string> pair_id;
+};
+block_pool g_pool;
+
+hipError_t pool_alloc(void** ptr, size_t n, int kind) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.free_blocks.find({n, kind});
+    if (it != g_pool.free_blocks.end()) {
+      *ptr = it->second;
+      g_pool.free_blocks.erase(it);
+      g_pool.cached_bytes[kind] -= n;
+      g_pool.hits++;
+      return hipSuccess;
+    }
+    if (g_pool.cap_bytes) g_pool.misses++;
+  }
+  if (kind == 2) return hipHostMalloc(ptr, n, hipHostMallocCoherent | hipHostMallocMapped);
+  return kind == 1 ? hipExtMallocWithFlags(ptr, n, hipDeviceMallocFinegrained) : hipMalloc(ptr, n);
+}
+void pool_free(void* ptr, size_t n, int kind) {
+  if (!ptr) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    const size_t total = g_pool.cached_bytes[0] + g_pool.cached_bytes[1] + g_pool.cached_bytes[2];
+    if (g_pool.cap_bytes && total + n <= g_pool.cap_bytes) {
+      g_pool.free_blocks.insert({{n, kind}, ptr});
+      g_pool.cached_bytes[kind] += n;
+      return;
+    }
+  }
+  if (kind == 2) hipHostFree(ptr); else hipFree(ptr);
+}
+}  // namespace
+
 grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
   if (require_ctx()) return nullptr;
   // ring_buffer.cc:22-24
@@ -683,22 +736,18 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
   p->arena_cap = 2 * ring_size + 4096;
   // the two things a REMOTE writer touches: the ring and the connection block (status report)
   const bool fine = (flags & GRDMA_RING_FINE_GRAINED) != 0;
-  auto remote_alloc = [&](void** ptr, size_t n) {
-    return fine ? hipExtMallocWithFlags(ptr, n, hipDeviceMallocFinegrained) : hipMalloc(ptr, n);
-  };
-  bool ok = remote_alloc((void**)&p->d_conn, sizeof(grdma_conn)) == hipSuccess &&
-            remote_alloc((void**)&p->d_ring, ring_size) == hipSuccess &&
-            hipMalloc((void**)&p->d_staging, ring_size / 2 + 64) == hipSuccess &&
-            hipMalloc((void**)&p->d_txplan, sizeof(grdma_plan)) == hipSuccess &&
-            hipMalloc((void**)&p->d_wireplan, sizeof(grdma_plan)) == hipSuccess &&
-            hipMalloc((void**)&p->d_rxplan, sizeof(grdma_plan)) == hipSuccess &&
-            hipMalloc((void**)&p->d_arena, p->arena_cap) == hipSuccess &&
-            hipMalloc((void**)&p->d_hist, sizeof(uint32_t) * GRDMA_RX_HIST) == hipSuccess &&
-            hipHostMalloc((void**)&p->h, sizeof(grdma_hostblk), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess &&
-            hipHostMalloc((void**)&p->h_sges, sizeof(grdma_sge) * GRDMA_TX_MAX_RECORDS,
-                          hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess &&
-            hipHostMalloc((void**)&p->h_slices, sizeof(grdma_slice_out) * GRDMA_MAX_SLICES,
-                          hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
+  const int rk = fine ? 1 : 0;  // (blocks come from the pool when it holds one of the size, see block_pool)
+  bool ok = pool_alloc((void**)&p->d_conn, sizeof(grdma_conn), rk) == hipSuccess &&
+            pool_alloc((void**)&p->d_ring, ring_size, rk) == hipSuccess &&
+            pool_alloc((void**)&p->d_staging, ring_size / 2 + 64, 0) == hipSuccess &&
+            pool_alloc((void**)&p->d_txplan, sizeof(grdma_plan), 0) == hipSuccess &&
+            pool_alloc((void**)&p->d_wireplan, sizeof(grdma_plan), 0) == hipSuccess &&
+            pool_alloc((void**)&p->d_rxplan, sizeof(grdma_plan), 0) == hipSuccess &&
+            pool_alloc((void**)&p->d_arena, p->arena_cap, 0) == hipSuccess &&
+            pool_alloc((void**)&p->d_hist, sizeof(uint32_t) * GRDMA_RX_HIST, 0) == hipSuccess &&
+            pool_alloc((void**)&p->h, sizeof(grdma_hostblk), 2) == hipSuccess &&
+            pool_alloc((void**)&p->h_sges, sizeof(grdma_sge) * GRDMA_TX_MAX_RECORDS, 2) == hipSuccess &&
+            pool_alloc((void**)&p->h_slices, sizeof(grdma_slice_out) * GRDMA_MAX_SLICES, 2) == hipSuccess;
   if (ok) ok = (p->line = line_alloc()) != nullptr;
   if (!ok) {
     fail(GRDMA_ERR_HIP, "device allocation failed for a %llu-byte ring",
@@ -747,14 +796,17 @@ void grdma_pair_destroy(grdma_pair* p) {
   if (p->stream) hipStreamSynchronize(p->stream);
   if (p->ipc_ring) hipIpcCloseMemHandle(p->ipc_ring);
   if (p->ipc_conn) hipIpcCloseMemHandle(p->ipc_conn);
-  hipFree(p->d_conn);
-  hipFree(p->d_ring);
-  hipFree(p->d_staging);
-  hipFree(p->d_txplan);
-  hipFree(p->d_wireplan);
-  hipFree(p->d_rxplan);
-  hipFree(p->d_arena);
-  hipFree(p->d_hist);
+  {
+    const int rk = (p->flags & GRDMA_RING_FINE_GRAINED) ? 1 : 0;
+    pool_free(p->d_conn, sizeof(grdma_conn), rk);
+    pool_free(p->d_ring, p->ring_size, rk);
+    pool_free(p->d_staging, p->ring_size / 2 + 64, 0);
+    pool_free(p->d_txplan, sizeof(grdma_plan), 0);
+    pool_free(p->d_wireplan, sizeof(grdma_plan), 0);
+    pool_free(p->d_rxplan, sizeof(grdma_plan), 0);
+    pool_free(p->d_arena, p->arena_cap, 0);
+    pool_free(p->d_hist, sizeof(uint32_t) * GRDMA_RX_HIST, 0);
+  }
   hipFree(p->d_zc);
   if (p->s_tx) { hipStreamSynchronize(p->s_tx); hipStreamDestroy(p->s_tx); }
   if (p->s_rx) { hipStreamSynchronize(p->s_rx); hipStreamDestroy(p->s_rx); }
@@ -767,16 +819,106 @@ void grdma_pair_destroy(grdma_pair* p) {
     hipStreamSynchronize(p->refresh_stream);  // a refresh pass in flight writes the line
     hipStreamDestroy(p->refresh_stream);
   }
-  if (p->h) hipHostFree(p->h);
+  pool_free(p->h, sizeof(grdma_hostblk), 2);
   line_free(p->line);
-  if (p->h_sges) hipHostFree(p->h_sges);
-  if (p->h_slices) hipHostFree(p->h_slices);
+  pool_free(p->h_sges, sizeof(grdma_sge) * GRDMA_TX_MAX_RECORDS, 2);
+  pool_free(p->h_slices, sizeof(grdma_slice_out) * GRDMA_MAX_SLICES, 2);
   if (p->h_bounce) hipHostFree(p->h_bounce);
   if (p->wakeup_fd >= 0) close(p->wakeup_fd);
   if (p->h_arena) hipHostFree(p->h_arena);
   if (p->h_cmd) hipHostFree(p->h_cmd);
   if (p->peer && p->peer->peer == p) p->peer->peer = nullptr;
+  {  // (a pair destroyed without Putback leaves the id map too)
+    std::unique_lock<std::shared_timed_mutex> lk(g_pool.id_mu);
+    auto it = g_pool.pair_id.find(p);
+    if (it != g_pool.pair_id.end()) {
+      g_pool.id_pair.erase(it->second);
+      g_pool.pair_id.erase(it);
+    }
+  }
   delete p;
+}
+
+// PairPool::createPairs (pair.h:323-327): memory for `pairs` connections of this shape is set aside now, so that
+// the Takes that follow do not call into the allocator.  cap_bytes = how much the pool may hold (0: what this
+// call sets aside).
+int grdma_pair_pool_reserve(uint32_t pairs, uint64_t ring_size, int max_sge, int flags, uint64_t cap_bytes) {
+  if (int rc = require_ctx()) return rc;
+  const uint64_t per_pair = ring_size + ring_size / 2 + 64 + 3 * sizeof(grdma_plan) + 2 * ring_size + 4096 + (1 << 20);
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    const uint64_t want = cap_bytes ? cap_bytes : (uint64_t)pairs * per_pair;
+    if (want > g_pool.cap_bytes) g_pool.cap_bytes = want;
+  }
+  std::vector<grdma_pair*> made;
+  for (uint32_t i = 0; i < pairs; i++) {
+    grdma_pair* p = grdma_pair_create(ring_size, max_sge, flags);
+    if (!p) break;
+    made.push_back(p);
+  }
+  const bool all = made.size() == pairs;
+  for (grdma_pair* p : made) grdma_pair_destroy(p);  // (their blocks stay in the pool)
+  return all ? 0 : fail(GRDMA_ERR_HIP, "pair pool: only %zu of %u pairs could be set aside", made.size(), pairs);
+}
+
+// Take(id): a pair of this shape, built from pooled blocks when there are any, registered under `id`.
+grdma_pair* grdma_pair_pool_take(const char* id, uint64_t ring_size, int max_sge, int flags) {
+  if (!id) {
+    fail(GRDMA_ERR_INVALID, "pair pool: null id");
+    return nullptr;
+  }
+  grdma_pair* p = grdma_pair_create(ring_size, max_sge, flags);
+  if (!p) return nullptr;
+  std::unique_lock<std::shared_timed_mutex> lk(g_pool.id_mu);
+  g_pool.id_pair[id] = p;
+  g_pool.pair_id[p] = id;
+  return p;
+}
+
+// Get(id): the pair a connection id was handed (what the zero-copy hook of the reference looks up,
+// src/core/lib/surface/call.cc:663-672); NULL when the id is unknown.
+grdma_pair* grdma_pair_pool_get(const char* id) {
+  if (!id) return nullptr;
+  std::shared_lock<std::shared_timed_mutex> lk(g_pool.id_mu);
+  auto it = g_pool.id_pair.find(id);
+  return it == g_pool.id_pair.end() ? nullptr : it->second;
+}
+
+// Putback(pair): the id is forgotten, the pair's blocks go back to the pool (rdma_bp_posix.cc:128,780).
+void grdma_pair_pool_putback(grdma_pair* p) {
+  if (!p) return;
+  if (p->pool_keep_open == 0 && p->status.load() == GRDMA_PAIR_CONNECTED) grdma_pair_disconnect(p);
+  grdma_pair_destroy(p);
+}
+
+// {blocks held, bytes held, allocations served from the pool, allocations that went to the runtime, ids registered}
+int grdma_pair_pool_stats(uint64_t out[5]) {
+  if (!out) return fail(GRDMA_ERR_INVALID, "null argument");
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    out[0] = g_pool.free_blocks.size();
+    out[1] = g_pool.cached_bytes[0] + g_pool.cached_bytes[1] + g_pool.cached_bytes[2];
+    out[2] = g_pool.hits;
+    out[3] = g_pool.misses;
+  }
+  std::shared_lock<std::shared_timed_mutex> lk(g_pool.id_mu);
+  out[4] = g_pool.id_pair.size();
+  return 0;
+}
+
+// Returns every pooled block to the runtime (process shutdown, tests).
+void grdma_pair_pool_trim(void) {
+  std::vector<std::pair<void*, int>> blocks;
+  {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (auto& kv : g_pool.free_blocks) blocks.push_back({kv.second, kv.first.second});
+    g_pool.free_blocks.clear();
+    g_pool.cached_bytes[0] = g_pool.cached_bytes[1] = g_pool.cached_bytes[2] = 0;
+    g_pool.cap_bytes = 0;
+  }
+  for (auto& b : blocks) {
+    if (b.second == 2) hipHostFree(b.first); else hipFree(b.first);
+  }
 }
 
 int grdma_pair_connect(grdma_pair* a, grdma_pair* b) {

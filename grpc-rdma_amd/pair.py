@@ -49,12 +49,17 @@ class DeviceBuffer:
 
 
 class Pair:
-    def __init__(self, ring_size=4 << 20, max_sge=30, flags=WIRE_STAGED):
+    def __init__(self, ring_size=4 << 20, max_sge=30, flags=WIRE_STAGED, handle=None):
         self.lib = load()
         self.ring_size = ring_size
-        self.h = self.lib.grdma_pair_create(ring_size, max_sge, flags)
+        # handle: wrap a pair somebody else owns (grdma_pair_pool_take); detach() before it goes back
+        self.h = handle if handle is not None else self.lib.grdma_pair_create(ring_size, max_sge, flags)
         if not self.h:
             raise GrdmaError(self.lib.grdma_last_error().decode())
+
+    def detach(self):
+        """Forget the handle without destroying the pair (it belongs to the PairPool)."""
+        self.h = None
 
     def close(self):
         if self.h:

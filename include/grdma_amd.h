@@ -78,6 +78,8 @@ typedef struct grdma_config {
                                         writes, what a NIC posts)                                          */
   uint32_t hip_register_min;         /* GRPC_RDMA_HIP_REGISTER_MIN: host slices of at least this many bytes are read
                                         where they lie (pages registered once), 0 = always copied (default) */
+  uint32_t hip_pair_pool_mb;         /* GRPC_RDMA_HIP_PAIR_POOL_MB: how much memory of closed connections the PairPool
+                                        keeps for the next ones (default 4096; 0 = none)                    */
 } grdma_config;
 int grdma_config_from_env(grdma_config* out);
 
@@ -152,6 +154,16 @@ int grdma_pair_connect_remote(grdma_pair* p, const grdma_bootstrap_blob* peer);
 int grdma_pair_bootstrap_fd(grdma_pair* p, int fd);
 int grdma_pair_disconnect(grdma_pair* p);          /* Disconnect(), pair.cc:325-347 */
 void grdma_pair_destroy(grdma_pair* p);
+
+/* ---- PairPool (src/core/lib/ibverbs/pair.h:273-333: Take(id) / Get(id) / Putback over pre-built pairs) --------
+ * Here the pool keeps the MEMORY of released pairs (ring, staging, plans, arena, pinned blocks) by size and
+ * hands it to the next grdma_pair_create / _take of the same shape, and maps connection ids to pairs. */
+int grdma_pair_pool_reserve(uint32_t pairs, uint64_t ring_size, int max_sge, int flags, uint64_t cap_bytes);
+grdma_pair* grdma_pair_pool_take(const char* id, uint64_t ring_size, int max_sge, int flags);  /* PairPool::Take  */
+grdma_pair* grdma_pair_pool_get(const char* id);                                              /* PairPool::Get   */
+void grdma_pair_pool_putback(grdma_pair* p);                                                  /* PairPool::Putback */
+int grdma_pair_pool_stats(uint64_t out[5]);  /* blocks held, bytes held, pool hits, runtime allocations, ids registered */
+void grdma_pair_pool_trim(void);
 /* PairStatus, pair.h:44-51: the values grdma_pair_get_status returns */
 #ifndef GRDMA_PAIR_STATUS_DEFINED
 #define GRDMA_PAIR_STATUS_DEFINED

@@ -151,7 +151,7 @@ void hip_free(grpc_rdma_hip* rdma) {  // rdma_free, :112-131
     if (rdma->enable_poller) grpc_core::ibverbs::Poller::Get().RemovePollable(rdma->pollable);
     grdma_pair_disconnect(rdma->pair);
     delete rdma->pollable;
-    grdma_pair_destroy(rdma->pair);  // PairPool::Putback
+    grdma_pair_pool_putback(rdma->pair);  // PairPool::Putback (:128)
     rdma->pair = nullptr;
   }
   delete rdma;
@@ -234,7 +234,7 @@ const grpc_endpoint_vtable vtable = {hip_read,
 
 // rdma_bp_posix.h:41-44.  Takes ownership of em_fd; nullptr when the pair cannot be brought up
 // (the caller then closes the fd, tcp_server_posix.cc:269-273 / tcp_client_posix.cc).
-grpc_endpoint* grpc_rdma_bp_create(grpc_fd* em_fd, const grpc_channel_args* /*channel_args*/,
+grpc_endpoint* grpc_rdma_bp_create(grpc_fd* em_fd, const grpc_channel_args* channel_args,
                                    const char* peer_string, bool enable_poller) {
   gpr_once_init(&g_cfg_once, init_process_state);
   if (grdma_init(g_cfg.hip_device) < 0) {  // Device::Get, device.cc:45-101
@@ -258,8 +258,19 @@ grpc_endpoint* grpc_rdma_bp_create(grpc_fd* em_fd, const grpc_channel_args* /*ch
 
   // PairPool::Take + PairPollable::Init (pair.h:288-296, pair.cc:85-141).  Fine-grained: the peer -- another
   // process -- writes this pair's ring and status block through an IPC mapping.
-  grdma_pair* pair = grdma_pair_create(static_cast<uint64_t>(g_cfg.ring_buffer_size_kb) * 1024, g_cfg.max_sge,
-                                       (g_cfg.hip_wire_direct ? GRDMA_WIRE_DIRECT : GRDMA_WIRE_STAGED) | GRDMA_RING_FINE_GRAINED);
+#ifndef GRPC_ARG_SERVER_URI  // src/core/ext/filters/client_channel/client_channel.h:61 (not pulled in: it drags the resolver stack along)
+#define GRPC_ARG_SERVER_URI "grpc.server_uri"
+#endif
+  std::string pair_id(rdma->peer_string);  // :745-759: a client registers its pair under the target of the server URI
+  if (const char* server_uri = grpc_channel_args_find_string(channel_args, GRPC_ARG_SERVER_URI)) {
+    std::string uri(server_uri);
+    const size_t pos = uri.find_last_of('/');  // get rid of prefix "dns:///"
+    if (pos != std::string::npos) pair_id = uri.substr(pos + 1);
+  }
+  static const int pool_on = grdma_pair_pool_reserve(0, 0, 0, 0, static_cast<uint64_t>(g_cfg.hip_pair_pool_mb) << 20);
+  (void)pool_on;
+  grdma_pair* pair = grdma_pair_pool_take(pair_id.c_str(), static_cast<uint64_t>(g_cfg.ring_buffer_size_kb) * 1024, g_cfg.max_sge,
+                                          (g_cfg.hip_wire_direct ? GRDMA_WIRE_DIRECT : GRDMA_WIRE_STAGED) | GRDMA_RING_FINE_GRAINED);
   // exchange_data + PairPollable::Connect (:640-692, :767-771; pair.cc:143-168): both ends write
   // their 48-byte Address (plus the memory handles of ring and status block) to the bootstrap
   // socket and read the peer's, full duplex, then map the peer's ring
@@ -267,7 +278,7 @@ grpc_endpoint* grpc_rdma_bp_create(grpc_fd* em_fd, const grpc_channel_args* /*ch
     gpr_log(GPR_ERROR, "Connection failed: %s", grdma_last_error());
     if (pair != nullptr) {
       grdma_pair_disconnect(pair);
-      grdma_pair_destroy(pair);
+      grdma_pair_pool_putback(pair);  // :780
     }
     grpc_resource_user_unref(rdma->resource_user);
     delete rdma;

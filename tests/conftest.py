@@ -37,4 +37,16 @@ def gpu(built):
     """Initialised HIP data plane; fails loudly when there is no device."""
     import grpc_rdma_amd as g
     g.init(0)
+    # Which library is this suite testing?  The product (grpc-rdma_amd/libgrdma_amd.so, built in-tree) -- unless the
+    # run SAYS it is the emulated one (tests/test_emu_gpu_suite.py, tools/emu_site.sh set GRDMA_TEST_ALLOW_EMU=1 next
+    # to GRDMA_LIB_PATH).  A stray GRDMA_LIB_PATH must not turn the hardware suite into an emulation run.
+    product = os.path.realpath(os.path.join(ROOT, "grpc-rdma_amd", "libgrdma_amd.so"))
+    mapped = set()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            path = line.split()[-1]
+            if "libgrdma" in path:
+                mapped.add(os.path.realpath(path))
+    if os.environ.get("GRDMA_TEST_ALLOW_EMU") != "1":
+        assert mapped == {product}, "the gpu suite must load the in-tree product library only, found %s" % sorted(mapped)
     return g

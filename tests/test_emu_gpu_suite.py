@@ -36,7 +36,7 @@ def emu_lib(built):
 
 
 def run_gpu_tests(emu_lib, args, min_passed):
-    env = dict(os.environ, GRDMA_LIB_PATH=emu_lib, GRDMA_TEST_NEW="1")
+    env = dict(os.environ, GRDMA_LIB_PATH=emu_lib, GRDMA_TEST_NEW="1", GRDMA_TEST_ALLOW_EMU="1")
     cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "--timeout", "600"] + args
     last = ""
     for attempt in range(2):  # (the staging waves of the deframer are real threads: one retry on a scheduling hiccup)

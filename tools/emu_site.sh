@@ -8,7 +8,7 @@
 #   EMU_SEGV_TRACE=1   faulting address + backtrace on SIGSEGV inside the library
 #   EMU_GUARD_ALLOC=1  every device allocation ends in front of an inaccessible page (overruns fault at once)
 cd "$(dirname "$0")/.."
-out=$(GRDMA_LIB_PATH=$PWD/oracle/_build/libgrdma_emu.so EMU_SEGV_TRACE=1 timeout 900 python -m pytest "$1" -m gpu -x -q -s -p no:faulthandler 2>&1)
+out=$(GRDMA_LIB_PATH=$PWD/oracle/_build/libgrdma_emu.so GRDMA_TEST_ALLOW_EMU=1 EMU_SEGV_TRACE=1 timeout 900 python -m pytest "$1" -m gpu -x -q -s -p no:faulthandler 2>&1)
 echo "$out" | grep -E "^wave_emu|passed|failed|^emu: SIGSEGV|^E  " | head -8
 base_line=$(echo "$out" | grep -E "libgrdma_emu.so\(\+0x" | head -4)
 for a in $(echo "$out" | grep -oE "libgrdma_emu.so\(\+0x[0-9a-f]+" | sed 's/.*+//' | head -4); do

@@ -9,7 +9,8 @@ echo "pytest rc=$?"; tail -3 $out/pytest.log
 B="python $R/bench.py --no-cpu-baseline --no-tcp-baseline --no-rtt --no-extra-legs --no-small-ring --conns 1 --steps 20 --warmup 5"
 run() { tag=$1; shift; timeout 120 env "$@" $B $EXTRA > $out/$tag.log 2> $out/$tag.err < /dev/null; echo "$tag rc=$? $(grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"verified": [a-z]*\|"rx_plan": {[^}]*}\|"tx_plan": {[^}]*}' $out/$tag.log | tr '\n' ' ')"; grep -v amdgpu.ids $out/$tag.err | tail -2; }
 EXTRA=""
-run deep X=1
+run pairjob X=1
+run nopair GRDMA_PAIR_JOB=0
 EXTRA="--pipeline 0"
 run sequential X=1
 EXTRA="--wire direct"
