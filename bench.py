@@ -449,7 +449,7 @@ def main():
                          "10 000 warm-up calls, examples/cpp/micro-bench/mb_client.cc:41-44)")
     ap.add_argument("--armed-rtt-only", action="store_true", help="(internal) run only the armed-read ping-pong")
     ap.add_argument("--rtt-only", action="store_true", help="(internal) run only the 64 B ping-pong leg")
-    ap.add_argument("--h2-bulk-pairs-only", action="store_true", help="(internal) run only the 64-frames-per-bulk-step h2 leg")
+    ap.add_argument("--h2-bulk-pairs-only", action="store_true", help="(internal) run only the 32-frames-per-bulk-step h2 leg")
     args = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         # Multi-GPU runs measure the headline (and the fan-out leg) only: the comparison legs are
@@ -593,7 +593,7 @@ def main():
             tx.close(); rx.close(); dst.free()
         return out
 
-    def measure_with_h2(ring_kb, steps, warmup, engine=False, boundary_step=None, bulk_pairs=False, ticks=False):
+    def measure_with_h2(ring_kb, steps, warmup, engine=False, boundary_step=None, bulk_pairs=None, ticks=False):
         """The same step with the HTTP/2 stages INSIDE the timed device pipeline: k_h2_frame rebuilds
         the slice list from the message table, the job carries it through the connection, k_h2_deframe
         parses what was delivered (events: frames, message boundaries, payload pieces).  Two jobs over
@@ -664,10 +664,10 @@ def main():
 
     if args.h2_bulk_pairs_only:  # the child of the value_with_h2_bulk_pairs leg: one leg, one JSON line
         few = max(2, args.steps // 4)
-        h2_ = measure_with_h2(args.ring_kb, few, 2, engine=(args.schedule == "engine"), bulk_pairs=True)
-        print(json.dumps({"value_with_h2_bulk_pairs": round(wl.user_bytes * few * world / h2_["elapsed"] / (1 << 30), 3),
-                          "with_h2_bulk_pairs_deframe_us": h2_["stages"]["deframe_us"],
-                          "with_h2_bulk_pairs_verified": h2_["verified"]}))
+        h2_ = measure_with_h2(args.ring_kb, few, 2, engine=(args.schedule == "engine"), bulk_pairs=False)
+        print(json.dumps({"value_with_h2_bulk32": round(wl.user_bytes * few * world / h2_["elapsed"] / (1 << 30), 3),
+                          "with_h2_bulk32_deframe_us": h2_["stages"]["deframe_us"],
+                          "with_h2_bulk32_verified": h2_["verified"]}))
         return
 
     schedule = "pipelined" if args.pipeline else "sequential"
@@ -837,9 +837,9 @@ def main():
             out["with_h2_verified"] = hh["verified"]
             out["with_h2_stages"] = hh["stages"]
             out["config"]["with_h2_leg"] = ("k_h2_frame -> the job -> k_h2_deframe inside the timed pipeline, library defaults "
-                                            "(message-boundary step on, 32 frames per bulk step, no clock samples); "
+                                            "(message-boundary step on, 64 frames per bulk step, no clock samples); "
                                             "value_with_h2_no_boundary_step: message starts byte-wise; "
-                                            "value_with_h2_bulk_pairs: 64 frames per bulk step (GRDMA_H2_BULK_PAIRS)")
+                                            "value_with_h2_bulk32: 32 frames per bulk step (GRDMA_H2_BULK_PAIRS=0)")
         except Exception as e:
             out["with_h2_error"] = err_text(e)
         eng_ = (args.schedule == "engine")
@@ -856,18 +856,17 @@ def main():
             out["with_h2_no_boundary_step_deframe_us"] = h0["stages"]["deframe_us"]
         except Exception as e:
             out["with_h2_no_boundary_step_error"] = err_text(e)
-        try:  # ... and with 64 frames per bulk step (GRDMA_H2_BULK_PAIRS: off by default until it has run on hardware)
-            # (this variant of the parsing wave has not run on hardware: a helper process with a timeout, N=1 only)
+        try:  # ... and with 32 frames per bulk step (the default until round 3), in a helper process, N=1 only
             if rank == 0 and world == 1:
                 cmd = [sys.executable, os.path.abspath(__file__), "--h2-bulk-pairs-only", "--steps", str(args.steps),
                        "--ring-kb", str(args.ring_kb), "--msgs", str(args.msgs), "--schedule", args.schedule]
                 r_ = run_json(cmd, 150)
-                if "value_with_h2_bulk_pairs" in r_:
+                if "value_with_h2_bulk32" in r_:
                     out.update(r_)
                 else:
-                    out["with_h2_bulk_pairs_error"] = str(r_.get("error"))[:300]
+                    out["with_h2_bulk32_error"] = str(r_.get("error"))[:300]
         except Exception as e:
-            out["with_h2_bulk_pairs_error"] = err_text(e)
+            out["with_h2_bulk32_error"] = err_text(e)
     if not args.no_extra_legs:
         # the reference's default knobs (4 MiB ring, max_sge 30: rdma_utils.h / config.cc), same workload,
         # with the CPU codec timed at the SAME knobs beside it
@@ -901,7 +900,7 @@ def main():
         # host slices through the endpoint vtable (grpc_endpoint_write / _read, include/grdma_endpoint.hpp):
         # what a gRPC maintainer's process sees, PCIe both ways included
         env = dict(os.environ, GRPC_RDMA_RING_BUFFER_SIZE_KB=str(args.ring_kb), GRPC_PLATFORM_TYPE="RDMA_BP")
-        ev = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "256", str(MIB), "1"], 120, env)
+        ev = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "1024", str(MIB), "1", "0", "2"], 120, env)
         out["value_endpoint_vtable"] = ev.get("GiBps")
         out["endpoint_vtable"] = ev
         # the same stream with both pairs in latency mode: commands through the resident engine, the receive arena in

@@ -46,12 +46,12 @@ static double g_h2_last_kernel_us = 0;
 static uint64_t g_h2_last_boundary_steps = 0;
 static uint64_t g_h2_last_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-// 64 frames per bulk step (GRDMA_H2_BULK_PAIRS): off unless the flag or GRDMA_H2_BULK_PAIRS=1 asks for it
+// 64 frames per bulk step (GRDMA_H2_BULK_PAIRS): on unless GRDMA_H2_NO_BULK_PAIRS or GRDMA_H2_BULK_PAIRS=0 says otherwise
 static int h2_bulk_pairs_default() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("GRDMA_H2_BULK_PAIRS");
-    v = (e && e[0] == '1') ? 1 : 0;
+    v = (e && e[0] == '0') ? 0 : 1;
   }
   return v;
 }
@@ -162,7 +162,7 @@ grdma_h2_parser* grdma_h2_parser_create_ex(int flags, uint32_t max_frame_size,
   init.max_concurrent = max_concurrent_streams;  // http2_settings.cc:46 default 0xffffffff
   init.tab_mask = table_slots - 1;
   init.boundary_step = (flags & GRDMA_H2_BOUNDARY_STEP) ? 1 : (flags & GRDMA_H2_NO_BOUNDARY_STEP) ? 0 : h2_boundary_default();
-  init.bulk_pairs = (flags & GRDMA_H2_BULK_PAIRS) ? 1 : h2_bulk_pairs_default();
+  init.bulk_pairs = (flags & GRDMA_H2_BULK_PAIRS) ? 1 : (flags & GRDMA_H2_NO_BULK_PAIRS) ? 0 : h2_bulk_pairs_default();
   init.ticks = (flags & GRDMA_H2_TICKS) ? 1 : 0;
   if (hipMalloc((void**)&p->d, sizeof(init)) != hipSuccess ||
       hipMalloc((void**)&p->d_tab, sizeof(grdma_h2_stream_dev) * table_slots) != hipSuccess ||

@@ -56,7 +56,7 @@ def frame_messages(msgs, max_frame, slices_dev_ptr, slices_cap, hdr_dev_ptr, hdr
     return n, wire.value
 
 
-H2_SERVER, H2_FIRST_FRAME, H2_BOUNDARY_STEP, H2_NO_BOUNDARY_STEP, H2_BULK_PAIRS, H2_TICKS = 1, 2, 4, 8, 16, 32
+H2_SERVER, H2_FIRST_FRAME, H2_BOUNDARY_STEP, H2_NO_BOUNDARY_STEP, H2_BULK_PAIRS, H2_TICKS, H2_NO_BULK_PAIRS = 1, 2, 4, 8, 16, 32, 64
 
 
 class Parser:
@@ -65,14 +65,14 @@ class Parser:
     False: a client / mid-connection parser whose streams the caller opens."""
 
     def __init__(self, expect_client_prefix=False, max_frame_size=16384, flags=None,
-                 max_concurrent_streams=0xFFFFFFFF, table_slots=0, boundary_step=None, bulk_pairs=False, ticks=False):
+                 max_concurrent_streams=0xFFFFFFFF, table_slots=0, boundary_step=None, bulk_pairs=None, ticks=False):
         self.lib = _bind()
         if flags is None:
             flags = (H2_SERVER | H2_FIRST_FRAME) if expect_client_prefix else 0
         if boundary_step is not None:  # None: GRDMA_H2_BOUNDARY_STEP in the environment decides
             flags |= H2_BOUNDARY_STEP if boundary_step else H2_NO_BOUNDARY_STEP
-        if bulk_pairs:
-            flags |= H2_BULK_PAIRS
+        if bulk_pairs is not None:  # None: the library default (64 frames per bulk step unless GRDMA_H2_BULK_PAIRS=0)
+            flags |= H2_BULK_PAIRS if bulk_pairs else H2_NO_BULK_PAIRS
         if ticks:
             flags |= H2_TICKS
         self.h = self.lib.grdma_h2_parser_create_ex(flags, max_frame_size, max_concurrent_streams, table_slots)

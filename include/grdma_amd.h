@@ -494,9 +494,11 @@ enum grdma_h2_parser_flags {
   GRDMA_H2_NO_BOUNDARY_STEP = 8, /* never; with neither flag the step is on unless the environment
                                     says GRDMA_H2_BOUNDARY_STEP=0                                    */
   GRDMA_H2_BULK_PAIRS = 16,      /* the bulk step gives EVERY lane a frame (lane i: slices s + 2i, s + 2i + 1):
-                                    64 frames and 128 slices per step instead of 32 / 64.  Off by default
-                                    (GRDMA_H2_BULK_PAIRS=1 in the environment turns it on): written after the
-                                    round's GPU budget was spent, first run pending                    */
+                                    64 frames and 128 slices per step instead of 32 / 64.  On by default since
+                                    round 3 (two hardware rounds: 155.7 vs 148.5 and 172.9 vs 155.1 GiB/s in the
+                                    with-h2 leg, same events); GRDMA_H2_BULK_PAIRS=0 in the environment or
+                                    GRDMA_H2_NO_BULK_PAIRS turns it off                                 */
+  GRDMA_H2_NO_BULK_PAIRS = 64,   /* 32 frames per bulk step                                             */
   GRDMA_H2_TICKS = 32            /* the parsing wave samples the device clock around its phases (the tick counters
                                     of grdma_h2_pipe_sync / grdma_h2_last_deframe_stats); off by default: a sample
                                     is a scalar memory operation the wave waits for                     */

@@ -64,6 +64,14 @@ def test_burst_round_gpu_tests_under_the_emulator(emu_lib):
     run_gpu_tests(emu_lib, ["tests/test_gpu_link_engine.py", "-n", "4", "-k", "burst and (r64k or r256k or three_links)"], 7)
 
 
+def test_steady_state_planner_and_pair_pool_gpu_tests_under_the_emulator(emu_lib):
+    """Round 3: the job kernels (k_rx_plan_job / k_tx_plan_job / k_plan_pair_job: steady-state bodies with the general
+    planners behind them, csrc/grdma_rx_fast.h, grdma_tx_fast.h) on periodic streams cut by max_sge, sequential and
+    pipelined graphs against the oracle's rounds; the PairPool on recycled memory."""
+    run_gpu_tests(emu_lib, ["tests/test_gpu_stream_job.py", "tests/test_gpu_pair_pool.py", "-n", "4",
+                            "-k", "(fast_planner and sge130) or pool"], 4)
+
+
 def test_concurrent_writer_and_poller_gpu_tests_under_the_emulator(emu_lib):
     """Records landing header-first / footer-last from a second thread while the receiver polls and reads; the
     background poller thread (one k_poll launch per pass, eventfd wakeups)."""

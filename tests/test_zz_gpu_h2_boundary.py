@@ -103,11 +103,12 @@ def test_boundary_step_random_streams_and_cuts(gpu):
         assert on == exp, trial
 
 
+@pytest.mark.parametrize("pairs", [True, False], ids=["bulk64", "bulk32"])
 @pytest.mark.parametrize("shape", ["sender", "receiver"])
-def test_bulk_pairs_matches_the_oracle(gpu, shape):
-    """GRDMA_H2_BULK_PAIRS: every lane of the bulk step owns a frame (64 frames per step).  Same events as
-    the oracle on the streaming shapes, with slices at odd offsets and with some slices cut in two.  (First run on
-    hardware pending: so far checked under the wave emulator, tests/test_h2_emu.py and tests/test_emu_gpu_suite.py.)"""
+def test_bulk_pairs_matches_the_oracle(gpu, shape, pairs):
+    """GRDMA_H2_BULK_PAIRS (the default since round 3): every lane of the bulk step owns a frame (64 frames per step);
+    GRDMA_H2_NO_BULK_PAIRS: 32 frames per step.  Same events as the oracle on the streaming shapes, with slices at
+    odd offsets and with some slices cut in two."""
     from grpc_rdma_amd import h2dev
     sizes = [1 << 20, 16384 * 3 - 5, 40000, 16384 - 5, 7, 16384 * 70 + 123, 1, 300000, 16384 * 130]
     tx = sender_slices(sizes)
@@ -127,7 +128,7 @@ def test_bulk_pairs_matches_the_oracle(gpu, shape):
             table.append((len(arena), len(s_)))
             arena += s_
         buf = gpu.DeviceBuffer(data=bytes(arena) + bytes(64))
-        p = h2dev.Parser(True, boundary_step=True, bulk_pairs=True)
+        p = h2dev.Parser(True, boundary_step=True, bulk_pairs=pairs)
         err, ev = p.deframe(buf.ptr, table, cap=8 * len(chunks) + 4096)
         p.close()
         assert err == 0 and ev == exp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # after the planner micro-optimisations: parity, headline variants, phases, kernel timeline, then the full bench line
 R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/run8
+out=$R/gpurun_out/check3
 rm -rf $out; mkdir -p $out
 cd $R
 timeout 300 python -m pytest tests/test_gpu_stream_job.py tests/test_gpu_link_engine.py -m gpu -q -x > $out/pytest.log 2>&1 < /dev/null
@@ -28,7 +28,7 @@ echo "full bench rc=$?"
 python - <<'PY'
 import json,sys
 try:
-    d=json.loads(open("gpurun_out/run8/bench_full.json").read().strip().splitlines()[-1])
+    d=json.loads(open("gpurun_out/check3/bench_full.json").read().strip().splitlines()[-1])
     keys=[k for k in d if k.startswith("value") or k.startswith("rtt") or k in ("ms_per_step","cpu_baseline","roofline")]
     for k in keys: print(k, json.dumps(d[k])[:300])
 except Exception as e:
