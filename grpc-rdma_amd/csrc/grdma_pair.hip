@@ -60,7 +60,7 @@ uint32_t grdma_rx_plan_job_threads(void);
 uint32_t grdma_tx_plan_job_threads(void);
 const void* grdma_kernel_fn_tx_index(void);
 uint32_t grdma_tx_index_threads(void);
-hipError_t grdma_launch_tx_index(grdma_txf_ctl*, uint32_t, hipStream_t);
+hipError_t grdma_launch_tx_index(grdma_txf_ctl*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_tx_plan_job(const grdma_tx_op*, const grdma_txf_ctl*, uint32_t, hipStream_t);
 const void* grdma_kernel_fn_plan_pair(void);
 const void* grdma_kernel_fn_plan_pair_job(void);
@@ -2246,10 +2246,15 @@ inline bool job_exec_stale(const grdma_stream_job* j) {
 // the send plan of round t: priced from the index of the slice buffer (built in front of the first round of a
 // step), the general planner in the same launch for what that declines
 inline bool job_tx_fast(const grdma_stream_job* j) { return j->tx_fast && j->burst == 1 && !j->direct; }
+inline uint32_t job_index_blocks(const grdma_stream_job* j) {  // k_tx_index: 1024 slices per workgroup
+  uint64_t most = 1;
+  for (const grdma_job_link& l : j->links) most = std::max<uint64_t>(most, l.count);
+  return (uint32_t)((most + 1023) / 1024);
+}
 hipError_t job_launch_tx_plan(grdma_stream_job* j, int k, uint64_t t, uint32_t n, hipStream_t s) {
   if (!job_tx_fast(j)) return grdma_launch_tx_plan(j->d_txop + k * n, n, s);
   hipError_t e = hipSuccess;
-  if (t == 0) e = grdma_launch_tx_index(j->d_txf, n, s);
+  if (t == 0) e = grdma_launch_tx_index(j->d_txf, n, job_index_blocks(j), s);
   if (e == hipSuccess) e = grdma_launch_tx_plan_job(j->d_txop + k * n, j->d_txf, n, s);
   return e;
 }
@@ -2535,7 +2540,7 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
     if (!tfast) return add(&P[t], f_txp, dim3(n), pt, txop, deps);
     if (t != 0) return add2(&P[t], f_txj, dim3(n), grdma_tx_plan_job_threads(), txop, j->d_txf, deps);
     hipGraphNode_t pi = nullptr;
-    hipError_t e2 = add(&pi, f_txi, dim3(n), grdma_tx_index_threads(), j->d_txf, deps);
+    hipError_t e2 = add(&pi, f_txi, dim3(job_index_blocks(j), n), grdma_tx_index_threads(), j->d_txf, deps);
     if (e2 != hipSuccess) return e2;
     return add2(&P[t], f_txj, dim3(n), grdma_tx_plan_job_threads(), txop, j->d_txf, {pi});
   };
