@@ -33,24 +33,6 @@ namespace {
 #define TXF_PER 4
 #define TXF_WAVES (TXF_THREADS / 64)
 
-// exclusive scan of a u64 per thread over the 1024-thread block
-__device__ __forceinline__ uint64_t txf_scan64(uint64_t v, uint64_t* s_w, uint64_t* total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t incl = wave_incl_scan(v, lane);
-  if (lane == 63) s_w[wave] = incl;
-  __syncthreads();
-  uint64_t base = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < TXF_WAVES; w++) {
-    const uint64_t s = s_w[w];
-    if (w < wave) base += s;
-    tot += s;
-  }
-  __syncthreads();
-  *total = tot;
-  return base + incl - v;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // k_tx_index: prefix sums over the slice buffer of a write.  Grid (ceil(n / 1024), connections): workgroup b owns
 // entries [1024 b, 1024 (b + 1)), one per thread, and needs no word from any other workgroup -- it sums the entries IN
@@ -66,9 +48,9 @@ __global__ __launch_bounds__(TXF_THREADS) void k_tx_index(grdma_txf_ctl* ctls) {
   const uint32_t ts = ctl->tile_shift;
   const uint64_t first = (uint64_t)blockIdx.x * TXF_THREADS;
   if (first >= n && !(first == 0 && n == 0)) return;  // (grids are sized for the longest list of the job)
-  __shared__ uint64_t s_w[TXF_WAVES];
   __shared__ uint32_t s_bad;
   if (tid == 0) s_bad = 0;
+  __syncthreads();
   auto tiles_of = [&](uint64_t len) -> uint64_t { return (len + (1ull << ts) - 1) >> ts; };
   // what lies in front of this workgroup's entries (and whether any of it is unusable)
   uint64_t pe = 0, pl = 0, pt = 0;
@@ -84,15 +66,37 @@ __global__ __launch_bounds__(TXF_THREADS) void k_tx_index(grdma_txf_ctl* ctls) {
   const uint64_t len = k < n ? sl[k].len : 0;
   if (k < n) bad |= len == 0 || len >= (1ull << 31);
   const uint64_t e = k < n ? enc_size(len) : 0, l = len, t = k < n ? tiles_of(len) : 0;
-  __syncthreads();
+  // one pass for all six numbers: wave scans of my entry's three values (the other lanes' values in front of mine)
+  // and wave sums of what lies in front of the workgroup, combined across the 16 waves through LDS
+  __shared__ uint64_t s_x[6][TXF_WAVES];
+  const int lane = tid & 63, wave = tid >> 6;
+  const uint64_t ie = wave_incl_scan(e, lane), il = wave_incl_scan(l, lane), it = wave_incl_scan(t, lane);
+  uint64_t re = pe, rl = pl, rt = pt;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    re += __shfl_xor(re, d, 64);
+    rl += __shfl_xor(rl, d, 64);
+    rt += __shfl_xor(rt, d, 64);
+  }
+  if (lane == 63) {
+    s_x[0][wave] = ie;
+    s_x[1][wave] = il;
+    s_x[2][wave] = it;
+    s_x[3][wave] = re;
+    s_x[4][wave] = rl;
+    s_x[5][wave] = rt;
+  }
   if (bad) s_bad = 1;
-  uint64_t be, bl, bt, te, tl, tt;
-  (void)txf_scan64(pe, s_w, &be);
-  (void)txf_scan64(pl, s_w, &bl);
-  (void)txf_scan64(pt, s_w, &bt);
-  const uint64_t xe = be + txf_scan64(e, s_w, &te);
-  const uint64_t xl = bl + txf_scan64(l, s_w, &tl);
-  const uint64_t xt = bt + txf_scan64(t, s_w, &tt);
+  __syncthreads();
+  uint64_t be = 0, bl = 0, bt = 0, te = 0, tl = 0, tt = 0, we = 0, wl = 0, wt = 0;
+#pragma unroll
+  for (int w = 0; w < TXF_WAVES; w++) {
+    const uint64_t a0 = s_x[0][w], a1 = s_x[1][w], a2 = s_x[2][w];
+    if (w < wave) { we += a0; wl += a1; wt += a2; }
+    te += a0; tl += a1; tt += a2;
+    be += s_x[3][w]; bl += s_x[4][w]; bt += s_x[5][w];
+  }
+  const uint64_t xe = be + we + ie - e, xl = bl + wl + il - l, xt = bt + wt + it - t;
   if (k < n) {
     ctl->enc_pre[k] = xe;
     ctl->len_pre[k] = xl;
