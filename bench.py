@@ -449,6 +449,7 @@ def main():
                          "10 000 warm-up calls, examples/cpp/micro-bench/mb_client.cc:41-44)")
     ap.add_argument("--armed-rtt-only", action="store_true", help="(internal) run only the armed-read ping-pong")
     ap.add_argument("--rtt-only", action="store_true", help="(internal) run only the 64 B ping-pong leg")
+    ap.add_argument("--h2-only", action="store_true", help="(internal) run only the with-h2 legs")
     ap.add_argument("--h2-bulk-pairs-only", action="store_true", help="(internal) run only the 32-frames-per-bulk-step h2 leg")
     args = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -593,7 +594,7 @@ def main():
             tx.close(); rx.close(); dst.free()
         return out
 
-    def measure_with_h2(ring_kb, steps, warmup, engine=False, boundary_step=None, bulk_pairs=None, ticks=False):
+    def measure_with_h2(ring_kb, steps, warmup, engine=False, boundary_step=None, bulk_pairs=None, ticks=False, chunks=None):
         """The same step with the HTTP/2 stages INSIDE the timed device pipeline: k_h2_frame rebuilds
         the slice list from the message table, the job carries it through the connection, k_h2_deframe
         parses what was delivered (events: frames, message boundaries, payload pieces).  Two jobs over
@@ -606,7 +607,7 @@ def main():
         scap = len(w.lens) * 2 + 64 + w.N // 256
         dst_cap = w.N + 16 * scap + 4096
         msgs = [(w.payload_buf.ptr + i * w.msg_len, w.msg_len, 1, 0) for i in range(w.n_msgs)]
-        parser = h2dev.Parser(False, boundary_step=boundary_step, bulk_pairs=bulk_pairs, ticks=ticks)
+        parser = h2dev.Parser(False, boundary_step=boundary_step, bulk_pairs=bulk_pairs, ticks=ticks, chunks=chunks)
         assert parser.open_streams([1]) == 0      # a client-side parser: the call runs on stream 1
         jobs, pipes, dsts = [], [], []
         for _ in range(2):
@@ -652,6 +653,10 @@ def main():
             ok = ok and r["h2_error"] == 0 and not r["frame_overflow"] and not r["deframe_overflow"] and \
                 r["framed"] == len(w.lens) and r["parsed"] == p_.delivered and \
                 sum(1 for e in evs if e[0] == 5) == w.n_msgs and sum(e[2] for e in evs if e[0] == 4) == w.n_msgs * w.msg_len
+        planned, merged = parser.chunk_stats()
+        stage_us["deframe_calls"] = max(2, warmup) + steps
+        stage_us["deframe_calls_planned_over_chunks"] = planned
+        stage_us["deframe_calls_merged_from_chunks"] = merged
         for p_ in pipes:
             p_.close()
         for j_ in jobs:
@@ -661,6 +666,16 @@ def main():
         for d_ in dsts:
             d_.free()
         return {"elapsed": elapsed, "verified": ok, "stages": stage_us}
+
+    if args.h2_only:  # (internal) the with-h2 legs alone: chunked deframer (default) and the sequential one
+        o_ = {}
+        for tag, ch in (("value_with_h2", None), ("value_with_h2_sequential_deframer", False)):
+            h2_ = measure_with_h2(args.ring_kb, args.steps, max(2, args.warmup), engine=(args.schedule == "engine"), chunks=ch)
+            o_[tag] = round(wl.user_bytes * args.steps * world / h2_["elapsed"] / (1 << 30), 3)
+            o_[tag + "_verified"] = h2_["verified"]
+            o_[tag + "_stages"] = h2_["stages"]
+        print(json.dumps(o_))
+        return
 
     if args.h2_bulk_pairs_only:  # the child of the value_with_h2_bulk_pairs leg: one leg, one JSON line
         few = max(2, args.steps // 4)
@@ -837,7 +852,9 @@ def main():
             out["with_h2_verified"] = hh["verified"]
             out["with_h2_stages"] = hh["stages"]
             out["config"]["with_h2_leg"] = ("k_h2_frame -> the job -> k_h2_deframe inside the timed pipeline, library defaults "
-                                            "(message-boundary step on, 64 frames per bulk step, no clock samples); "
+                                            "(message-boundary step on, 64 frames per bulk step, the delivered slices parsed as 16 chunks side by side "
+                                            "and merged after the chain of end states verified, no clock samples); "
+                                            "value_with_h2_sequential_deframer: one parsing wave over the whole list; "
                                             "value_with_h2_no_boundary_step: message starts byte-wise; "
                                             "value_with_h2_bulk32: 32 frames per bulk step (GRDMA_H2_BULK_PAIRS=0)")
         except Exception as e:
@@ -856,6 +873,12 @@ def main():
             out["with_h2_no_boundary_step_deframe_us"] = h0["stages"]["deframe_us"]
         except Exception as e:
             out["with_h2_no_boundary_step_error"] = err_text(e)
+        try:  # the same leg with the one-wave sequential deframer (no chunks: the default until the end of round 3)
+            h1 = measure_with_h2(args.ring_kb, few, 2, engine=eng_, chunks=False)
+            out["value_with_h2_sequential_deframer"] = round(wl.user_bytes * few * world / h1["elapsed"] / (1 << 30), 3)
+            out["with_h2_sequential_deframer_deframe_us"] = h1["stages"]["deframe_us"]
+        except Exception as e:
+            out["with_h2_sequential_deframer_error"] = err_text(e)
         try:  # ... and with 32 frames per bulk step (the default until round 3), in a helper process, N=1 only
             if rank == 0 and world == 1:
                 cmd = [sys.executable, os.path.abspath(__file__), "--h2-bulk-pairs-only", "--steps", str(args.steps),

@@ -40,7 +40,71 @@ struct grdma_h2_parser {
   grdma_h2_deframe_result* d_res = nullptr;
   grdma_h2_table_op* d_ops = nullptr;
   uint32_t ops_cap = 0;
+  // the deframer over chunks (grdma_h2_kernels.h: grdma_h2_chunks): control block, private stream maps, event segments
+  uint32_t slots = 0;
+  int chunks_want = 0;                 // 0 = off
+  grdma_h2_chunks* d_chunks = nullptr;
+  grdma_h2_stream_dev* d_tabs = nullptr;
+  grdma_h2_event* d_ev_tmp = nullptr;
+  uint64_t ev_tmp_cap = 0;             // events the segments hold in total
 };
+
+// How many chunks a parser created without saying so cuts a long list into: GRDMA_H2_CHUNKS (default 16, 0 or 1 = the
+// sequential deframer only).
+static int h2_chunks_default() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GRDMA_H2_CHUNKS");
+    v = e ? atoi(e) : H2_KMAX;
+    if (v < 2) v = 0;
+    if (v > H2_KMAX) v = H2_KMAX;
+  }
+  return v;
+}
+
+// (re)size the chunk buffers of a parser for calls that may produce ev_cap events
+static bool h2_chunks_prepare(grdma_h2_parser* p, uint64_t ev_cap, hipStream_t st) {
+  if (p->chunks_want < 2) return false;
+  const uint64_t need = 2 * (ev_cap ? ev_cap : 1) + H2_KMAX * 64;
+  if (p->d_chunks && p->ev_tmp_cap >= need) return true;
+  if (!p->d_chunks) {
+    if (hipMalloc((void**)&p->d_chunks, sizeof(grdma_h2_chunks)) != hipSuccess ||
+        hipMalloc((void**)&p->d_tabs, sizeof(grdma_h2_stream_dev) * (size_t)H2_KMAX * p->slots) != hipSuccess)
+      return false;
+    if (hipMemsetAsync(p->d_chunks, 0, sizeof(grdma_h2_chunks), st) != hipSuccess) return false;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) return false;
+  if (p->d_ev_tmp) hipFree(p->d_ev_tmp);
+  p->d_ev_tmp = nullptr;
+  if (hipMalloc((void**)&p->d_ev_tmp, sizeof(grdma_h2_event) * need) != hipSuccess) return false;
+  p->ev_tmp_cap = need;
+  // the host-owned words of the control block (the counters stay)
+  struct { grdma_h2_stream_dev* tabs; grdma_h2_event* ev_tmp; uint64_t ev_stride; uint32_t slots, pad; } tail =
+      {p->d_tabs, p->d_ev_tmp, need / H2_KMAX, p->slots, 0};
+  static_assert(offsetof(grdma_h2_chunks, pad) + sizeof(uint32_t) - offsetof(grdma_h2_chunks, tabs) == sizeof(tail), "layout");
+  const uint32_t want = (uint32_t)p->chunks_want;
+  return hipMemcpyAsync(reinterpret_cast<uint8_t*>(p->d_chunks) + offsetof(grdma_h2_chunks, tabs), &tail, sizeof(tail),
+                        hipMemcpyHostToDevice, st) == hipSuccess &&
+         hipMemcpyAsync(reinterpret_cast<uint8_t*>(p->d_chunks) + offsetof(grdma_h2_chunks, want), &want, sizeof(want),
+                        hipMemcpyHostToDevice, st) == hipSuccess &&
+         hipStreamSynchronize(st) == hipSuccess;
+}
+
+// The deframing of one list of delivered slices, enqueued on st: over chunks when the parser has the buffers (plan,
+// chunks, merge, then the sequential deframer for whatever did not merge), else the sequential deframer alone.
+static void h2_enqueue_deframe(grdma_h2_parser* p, const uint8_t* arena, const grdma_slice_out* d_slices, uint64_t n,
+                               grdma_h2_event* d_ev, uint64_t ev_cap, grdma_h2_deframe_result* d_res, hipStream_t st,
+                               bool chunked) {
+  if (!chunked || n < H2_CHUNK_MIN_SLICES) {
+    hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(H2_DEFRAME_THREADS), 0, st, p->d, arena, d_slices, n, d_ev, ev_cap, d_res);
+    return;
+  }
+  hipLaunchKernelGGL(k_h2_chunk_plan, dim3(1), dim3(H2_PLAN_THREADS), 0, st, p->d, arena, d_slices, n, p->d_chunks);
+  hipLaunchKernelGGL(k_h2_deframe_chunks, dim3(H2_KMAX), dim3(H2_DEFRAME_THREADS), 0, st, p->d_chunks, arena, d_slices);
+  hipLaunchKernelGGL(k_h2_chunk_merge, dim3(64), dim3(H2_MERGE_THREADS), 0, st, p->d, p->d_chunks, d_ev, ev_cap, d_res);
+  hipLaunchKernelGGL(k_h2_deframe_unless_merged, dim3(1), dim3(H2_DEFRAME_THREADS), 0, st,
+                     (const grdma_h2_chunks*)p->d_chunks, p->d, arena, d_slices, n, d_ev, ev_cap, d_res);
+}
 
 static double g_h2_last_kernel_us = 0;
 static uint64_t g_h2_last_boundary_steps = 0;
@@ -164,6 +228,8 @@ grdma_h2_parser* grdma_h2_parser_create_ex(int flags, uint32_t max_frame_size,
   init.boundary_step = (flags & GRDMA_H2_BOUNDARY_STEP) ? 1 : (flags & GRDMA_H2_NO_BOUNDARY_STEP) ? 0 : h2_boundary_default();
   init.bulk_pairs = (flags & GRDMA_H2_BULK_PAIRS) ? 1 : (flags & GRDMA_H2_NO_BULK_PAIRS) ? 0 : h2_bulk_pairs_default();
   init.ticks = (flags & GRDMA_H2_TICKS) ? 1 : 0;
+  p->slots = table_slots;
+  p->chunks_want = (flags & GRDMA_H2_NO_CHUNKS) ? 0 : h2_chunks_default();
   if (hipMalloc((void**)&p->d, sizeof(init)) != hipSuccess ||
       hipMalloc((void**)&p->d_tab, sizeof(grdma_h2_stream_dev) * table_slots) != hipSuccess ||
       hipMalloc((void**)&p->d_res, sizeof(grdma_h2_deframe_result)) != hipSuccess ||
@@ -192,6 +258,9 @@ void grdma_h2_parser_destroy(grdma_h2_parser* p) {
   hipFree(p->d_ev);
   hipFree(p->d_res);
   hipFree(p->d_ops);
+  hipFree(p->d_chunks);
+  hipFree(p->d_tabs);
+  hipFree(p->d_ev_tmp);
   delete p;
 }
 
@@ -224,6 +293,22 @@ int grdma_h2_parser_open_streams(grdma_h2_parser* p, const uint32_t* ids, uint32
 int grdma_h2_parser_close_writes(grdma_h2_parser* p, const uint32_t* ids, uint32_t n) {
   return h2_table_ops(p, 2, ids, n);
 }
+// {calls the chunked deframer planned, calls whose chunks verified and were merged} since the parser was created
+int grdma_h2_parser_chunk_stats(grdma_h2_parser* p, uint64_t out[2]) {
+  if (!p || !out) return -GRDMA_ERR_INVALID;
+  out[0] = out[1] = 0;
+  if (!p->d_chunks) return 0;
+  h2_host_ctx* hc = h2_ctx();
+  if (!hc) return -GRDMA_ERR_HIP;
+  uint64_t v[2];
+  if (hipMemcpyAsync(v, reinterpret_cast<uint8_t*>(p->d_chunks) + offsetof(grdma_h2_chunks, n_planned), sizeof(v),
+                     hipMemcpyDeviceToHost, hc->stream) != hipSuccess ||
+      hipStreamSynchronize(hc->stream) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  out[0] = v[0];
+  out[1] = v[1];
+  return 0;
+}
 int64_t grdma_h2_parser_live_streams(grdma_h2_parser* p) {
   if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
   if (!p) return -GRDMA_ERR_INVALID;
@@ -250,9 +335,9 @@ int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_re
   hipStream_t st = hc->stream;
   if (n && hipMemcpyAsync(p->d_sl, slices, sizeof(grdma_slice_out) * n, hipMemcpyHostToDevice, st) != hipSuccess)
     return -GRDMA_ERR_HIP;
+  const bool chunked = n >= H2_CHUNK_MIN_SLICES && h2_chunks_prepare(p, cap, st);
   hipEventRecord(hc->e0, st);
-  hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(H2_DEFRAME_THREADS), 0, st, p->d, static_cast<const uint8_t*>(d_arena),
-                     p->d_sl, n, p->d_ev, cap, p->d_res);
+  h2_enqueue_deframe(p, static_cast<const uint8_t*>(d_arena), p->d_sl, n, p->d_ev, cap, p->d_res, st, chunked);
   hipEventRecord(hc->e1, st);
   if (hipMemcpyAsync(&h_res, p->d_res, sizeof(h_res), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
@@ -305,6 +390,7 @@ struct grdma_h2_pipe {
   uint64_t ev_cap = 0, delivered = 0;
   uint64_t boundary_steps = 0, t_boundary = 0;  // of the last synced step
   bool launched = false;
+  bool chunked = false;  // the parser has chunk buffers for this pipe's event capacity
 };
 
 namespace {
@@ -353,6 +439,7 @@ grdma_h2_pipe* grdma_h2_pipe_create(grdma_stream_job* job, uint32_t link, const 
     grdma_h2_pipe_destroy(p);
     return nullptr;
   }
+  p->chunked = delivered_slices >= H2_CHUNK_MIN_SLICES && h2_chunks_prepare(parser, events_cap, p->deframe_stream);
   return p;
 }
 
@@ -396,8 +483,7 @@ int grdma_h2_pipe_enqueue(grdma_h2_pipe* p, int schedule) {
   if (hipEventRecord(p->job_done, p->job_stream) != hipSuccess) return -GRDMA_ERR_HIP;
   if (hipStreamWaitEvent(p->deframe_stream, p->job_done, 0) != hipSuccess) return -GRDMA_ERR_HIP;
   hipEventRecord(p->t_d0, p->deframe_stream);
-  hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(H2_DEFRAME_THREADS), 0, p->deframe_stream, p->parser->d, p->dst, p->d_slices, p->delivered,
-                     p->d_ev, p->ev_cap, p->d_dres);
+  h2_enqueue_deframe(p->parser, p->dst, p->d_slices, p->delivered, p->d_ev, p->ev_cap, p->d_dres, p->deframe_stream, p->chunked);
   hipEventRecord(p->t_d1, p->deframe_stream);
   if (hipEventRecord(p->deframed, p->deframe_stream) != hipSuccess) return -GRDMA_ERR_HIP;
   p->launched = true;

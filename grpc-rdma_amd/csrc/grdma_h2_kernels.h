@@ -60,6 +60,10 @@ struct grdma_h2_parser_dev {
   int32_t boundary_step;  // 1 = message starts go through h2_boundary_match (grdma_h2_fast.h)
   int32_t bulk_pairs;     // 1 = the bulk step gives every lane a frame (64 frames, 128 slices per step)
   int32_t ticks;          // 1 = the parsing wave samples the device clock around its phases (profiling aid)
+  // what the data parser of the current stream held in front of the last slice the boundary step took (a slice in
+  // which a message starts): the state a chunk of the parallel deframer is assumed to start in (h2_chunks below)
+  int32_t hint_valid, hint_state;
+  uint32_t hint_fsz, hint_id;
   grdma_h2_stream_dev* tab;
 };
 
@@ -519,10 +523,12 @@ __device__ __forceinline__ uint32_t h2_mark_closed(grdma_h2_stream_dev* tab, uin
 }
 
 #define H2_DEFRAME_THREADS 512
-__global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_parser_dev* gp, const uint8_t* arena,
-                                                                  const grdma_slice_out* slices, uint64_t nslices,
-                                                                  grdma_h2_event* ev, uint64_t ev_cap,
-                                                                  grdma_h2_deframe_result* res) {
+// The deframer of one run of delivered slices: one parsing wave, seven staging waves (every thread of the
+// 512-thread workgroup calls it; the staging waves return when the parser is done).
+__device__ __forceinline__ void h2_deframe_body(grdma_h2_parser_dev* gp, const uint8_t* arena,
+                                                const grdma_slice_out* slices, uint64_t nslices,
+                                                grdma_h2_event* ev, uint64_t ev_cap,
+                                                grdma_h2_deframe_result* res) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6;
   if (threadIdx.x < H2_RING) g_h2.seq[threadIdx.x] = 0;
@@ -555,6 +561,8 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
   const bool is_server = P.is_server != 0;
   grdma_h2_stream_dev* const tab = P.tab;
   h2_cur_stream D = {-1, 0, 0, 0, 0, 0, 0, 0};
+  int32_t hint_valid = P.hint_valid, hint_state = P.hint_state;
+  uint32_t hint_fsz = P.hint_fsz, hint_id = P.hint_id;
 #define H2_PUSH(kind, a, b, c, d, sl) h2_push(ev, ev_cap, nev, overflow, lane, kind, a, b, c, d, sl)
 #define H2_BYTE(s_, off_) h2_byte_at(V, s_, off_, arena)
   // what the payload parser does with the last piece of a frame (frame_data.cc:299-305,
@@ -591,6 +599,7 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
       // the window left behind are done when this store lands.  (A release store would also wait
       // for every event store still in flight -- a memory round trip per window.)
       asm volatile("" ::: "memory");
+      GRDMA_WAVE_CONVERGE();  // (the emulator's lanes: every lane has done its reads of the window left behind)
       if (lane == 0) __hip_atomic_store(&g_h2.consumed, consumed_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     h2_need(V, s);
@@ -611,6 +620,10 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
                                            h2_uni64(me.len), h2_uni64(next_len), (int32_t)h2_uni32((uint32_t)D.state),
                                            h2_uni32(D.fsz), d_id, max_frame);
       if (B.ok && nev + B.nev <= ev_cap) {
+        hint_valid = 1;
+        hint_state = (int32_t)h2_uni32((uint32_t)D.state);
+        hint_fsz = h2_uni32(D.fsz);
+        hint_id = d_id;
         if ((uint32_t)lane < B.nev) {
           uint32_t e[6];
           h2_boundary_event(B, d_id, (uint32_t)s, (uint32_t)lane, e);
@@ -916,6 +929,10 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
     gp->last_new_stream_id = last_new;
     gp->live_streams = live;
     gp->error = err;
+    gp->hint_valid = hint_valid;
+    gp->hint_state = hint_state;
+    gp->hint_fsz = hint_fsz;
+    gp->hint_id = hint_id;
     res->nevents = nev;
     res->overflow = overflow;
     res->slices_done = s;
@@ -929,6 +946,277 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
     res->boundary_steps = boundary_steps;
     res->t_boundary = t_boundary;
   }
+}
+
+__global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_parser_dev* gp, const uint8_t* arena,
+                                                                  const grdma_slice_out* slices, uint64_t nslices,
+                                                                  grdma_h2_event* ev, uint64_t ev_cap,
+                                                                  grdma_h2_deframe_result* res) {
+  h2_deframe_body(gp, arena, slices, nslices, ev, ev_cap, res);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The deframer over CHUNKS of the delivered slices (round 3).  parsing.cc is a byte automaton: one wave walks
+// 33 000 slices in 0.8 ms however wide the machine is.  In a streaming call, though, the parser is in the SAME
+// state in front of every slice in which a message starts (frame boundary; the stream's data parser either at a
+// message header -- sending side -- or a few bytes short of the message end -- receiving side): the state the
+// boundary step (grdma_h2_fast.h) records as it goes (grdma_h2_parser_dev::hint_*).  So:
+//   k_h2_chunk_plan    picks K - 1 such slices near the K-quantiles of the list (h2_boundary_match on the staged
+//                      bytes of every slice near a quantile, the first hit is the cut), and gives every chunk a
+//                      private copy of the parser block and of the stream map, chunks 1 .. K-1 in the hinted state;
+//   k_h2_deframe_chunks  K workgroups, each the ordinary deframer (h2_deframe_body) over its chunk, events into a
+//                      private segment; afterwards each checks that its stream map is the one it started with;
+//   k_h2_chunk_merge   verifies the CHAIN -- chunk k must have ended, without error, exactly where and in exactly
+//                      the state chunk k + 1 was assumed to start -- and only then concatenates the events (slice
+//                      indices rebased), installs the last chunk's parser block and stream map, and says so;
+//   k_h2_deframe_unless_merged   the ordinary deframer over the whole list when anything did not hold (no hint
+//                      yet, a cut that was no frame boundary, a stream that opened or closed, an error, events
+//                      that did not fit): nothing of the chunks' work was visible, the result is the sequential one.
+// The events, the parser state and the stream map are those of the sequential parse by construction.
+// ------------------------------------------------------------------------------------------------------------
+#define H2_KMAX 16
+#define H2_CHUNK_MIN_SLICES 2048
+struct grdma_h2_chunks {
+  uint32_t K;          // chunks of this call, 0 = no plan
+  uint32_t ok;         // k_h2_chunk_merge: 1 = merged (the sequential pass has nothing to do)
+  uint32_t hint_idx;   // slot of the hinted stream in the stream map
+  uint32_t want;       // chunks the host asks for (<= H2_KMAX)
+  uint64_t s_begin[H2_KMAX + 1];
+  grdma_h2_parser_dev ref;            // the parser block the plan started from
+  grdma_h2_stream_dev ref_entry;      // ... and the hinted stream's entry: what chunks 1.. are assumed to start with
+  grdma_h2_parser_dev gp[H2_KMAX];
+  grdma_h2_deframe_result res[H2_KMAX];
+  grdma_h2_stream_dev end_entry[H2_KMAX];
+  uint32_t clean[H2_KMAX];
+  uint64_t n_planned, n_merged;       // calls that were planned / merged since the parser was created
+  grdma_h2_stream_dev* tabs;          // [H2_KMAX][slots] private stream maps
+  grdma_h2_event* ev_tmp;             // [H2_KMAX][ev_stride] private event segments
+  uint64_t ev_stride;
+  uint32_t slots, pad;
+};
+
+// the first 32 bytes of a slice as four little-endian words (zero beyond the slice): what the staging waves put
+// into the look-ahead ring, for one slice
+__device__ __forceinline__ void h2_first32(const uint8_t* arena, uint64_t off, uint64_t n, uint64_t c[4]) {
+  const uint8_t* p = arena + off;
+  const uint64_t sh = n ? (uint64_t)p & 15 : 0;
+  const u64x2* q = n ? reinterpret_cast<const u64x2*>((uint64_t)p & ~15ull)
+                     : reinterpret_cast<const u64x2*>((uint64_t)arena & ~15ull);
+  const uint64_t need = n ? (n < 32 ? n : 32) + sh : 0;
+  const u64x2 v0 = q[0];
+  const u64x2 v1 = q[need > 16 ? 1 : 0];
+  const u64x2 v2 = q[need > 32 ? 2 : 0];
+  uint64_t w0 = v0.x, w1 = v0.y, w2 = v1.x, w3 = v1.y, w4 = v2.x, w5 = v2.y;
+  if (sh & 8) { w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; }
+  const unsigned bs = (unsigned)(sh & 7) * 8;
+  uint64_t o0 = w0, o1 = w1, o2 = w2, o3 = w3;
+  if (bs) {
+    o0 = (w0 >> bs) | (w1 << (64 - bs));
+    o1 = (w1 >> bs) | (w2 << (64 - bs));
+    o2 = (w2 >> bs) | (w3 << (64 - bs));
+    o3 = (w3 >> bs) | (w4 << (64 - bs));
+  }
+  c[0] = h2_keep(o0, 0, n);
+  c[1] = h2_keep(o1, 8, n);
+  c[2] = h2_keep(o2, 16, n);
+  c[3] = h2_keep(o3, 24, n);
+}
+
+#define H2_PLAN_THREADS 1024
+__global__ __launch_bounds__(H2_PLAN_THREADS) void k_h2_chunk_plan(grdma_h2_parser_dev* gp, const uint8_t* arena,
+                                                                   const grdma_slice_out* slices, uint64_t nslices,
+                                                                   grdma_h2_chunks* ctl) {
+  const uint32_t tid = threadIdx.x;
+  const int lane = tid & 63;
+  const uint32_t wave = tid >> 6;
+  const grdma_h2_parser_dev P = *gp;
+  const uint32_t slots = P.tab_mask + 1;
+  uint32_t K = ctl->want < H2_KMAX ? ctl->want : H2_KMAX;
+  __shared__ uint64_t s_cut[H2_KMAX + 1];
+  __shared__ int s_idx;
+  if (tid == 0) {
+    ctl->K = 0;
+    ctl->ok = 0;
+    s_idx = -1;
+  }
+  const bool can = K >= 2 && P.error == 0 && P.hint_valid && P.boundary_step && P.state == ST_FH0 &&
+                   P.expect_continuation == 0 && !P.is_first_frame && nslices >= H2_CHUNK_MIN_SLICES &&
+                   slots == ctl->slots && nslices < (1ull << 31);
+  if (!can) return;  // (uniform)
+  while (K > 2 && nslices / K < H2_CHUNK_MIN_SLICES / 2) K--;
+  // wave j looks for the first slice at or behind the j-th quantile in which a message starts for the hinted stream
+  if (wave >= 1 && wave < K) {
+    const uint64_t t0 = nslices * wave / K, t1 = nslices * (wave + 1) / K;
+    uint64_t found = ~0ull;
+    for (uint64_t base = t0; base < t1 && found == ~0ull; base += 64) {
+      const uint64_t sx = base + (uint64_t)lane;
+      const bool have = sx < t1;
+      const u64x2 d = *reinterpret_cast<const u64x2*>(&slices[have ? sx : nslices - 1]);
+      const u64x2 dn = *reinterpret_cast<const u64x2*>(&slices[sx + 1 < nslices ? sx + 1 : nslices - 1]);
+      uint64_t c[4];
+      h2_first32(arena, d.x, have ? d.y : 0, c);
+      const h2_bstep B = h2_boundary_match(c[0], c[1], c[2], c[3], have ? d.y : 0, sx + 1 < nslices ? dn.y : ~0ull,
+                                           P.hint_state, P.hint_fsz, P.hint_id, P.max_frame_size);
+      const uint64_t hit = __ballot(have && B.ok);
+      if (hit) found = base + (uint64_t)__builtin_ctzll(hit);
+    }
+    if (lane == 0) s_cut[wave] = found;
+  }
+  if (tid == 0) {
+    s_cut[0] = 0;
+    s_idx = tab_find(P.tab, P.tab_mask, P.hint_id);
+  }
+  __syncthreads();
+  if (tid == 0) s_cut[K] = nslices;
+  __syncthreads();
+  bool good = s_idx >= 0;
+  for (uint32_t j = 1; j < K; j++) good = good && s_cut[j] != ~0ull && s_cut[j] > s_cut[j - 1];
+  if (!good) return;  // (uniform)
+  // private stream maps (chunks 1.. with the hinted stream's data parser in the hinted state), parser blocks
+  const grdma_h2_stream_dev ref_entry = P.tab[s_idx];
+  for (uint32_t i = tid; i < K * slots; i += H2_PLAN_THREADS) {
+    const uint32_t k = i / slots, e = i - k * slots;
+    grdma_h2_stream_dev v = P.tab[e];
+    if (k >= 1 && e == (uint32_t)s_idx) {
+      v.state = P.hint_state;
+      v.frame_size = P.hint_fsz;
+    }
+    ctl->tabs[i] = v;
+  }
+  if (tid < K) {
+    grdma_h2_parser_dev g = P;
+    g.tab = ctl->tabs + (size_t)tid * slots;
+    ctl->gp[tid] = g;  // (chunks 1..: P itself IS at a frame boundary with nothing pending -- see `can`)
+    ctl->s_begin[tid] = s_cut[tid];
+    ctl->clean[tid] = 0;
+  }
+  if (tid == 0) {
+    ctl->s_begin[K] = nslices;
+    ctl->ref = P;
+    ctl->ref_entry = ref_entry;
+    ctl->hint_idx = (uint32_t)s_idx;
+    ctl->n_planned++;
+    ctl->K = K;
+  }
+}
+
+__global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe_chunks(grdma_h2_chunks* ctl, const uint8_t* arena,
+                                                                         const grdma_slice_out* slices) {
+  const uint32_t k = blockIdx.x;
+  if (k >= ctl->K) return;  // (uniform)
+  const uint64_t s0 = ctl->s_begin[k], s1 = ctl->s_begin[k + 1];
+  h2_deframe_body(&ctl->gp[k], arena, slices + s0, s1 - s0, ctl->ev_tmp + (size_t)k * ctl->ev_stride, ctl->ev_stride,
+                  &ctl->res[k]);
+  // every wave is back (the staging waves when the parser said stop); the parser's stores to its map are its own
+  // wave's: make them visible to the comparing threads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __shared__ uint32_t s_dirty;
+  if (threadIdx.x == 0) s_dirty = 0;
+  __syncthreads();
+  const uint32_t slots = ctl->slots, hint = ctl->hint_idx;
+  const grdma_h2_stream_dev* mine = ctl->tabs + (size_t)k * slots;
+  const grdma_h2_stream_dev* orig = ctl->ref.tab;
+  bool dirty = false;
+  for (uint32_t i = threadIdx.x; i < slots; i += H2_DEFRAME_THREADS) {
+    if (i == hint) continue;
+    const u64x2 a = *reinterpret_cast<const u64x2*>(&mine[i]), b = *reinterpret_cast<const u64x2*>(&orig[i]);
+    dirty |= a.x != b.x || a.y != b.y;
+  }
+  static_assert(sizeof(grdma_h2_stream_dev) == 16, "two words per map entry");
+  if (dirty) s_dirty = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ctl->clean[k] = s_dirty ? 0u : 1u;
+    ctl->end_entry[k] = mine[hint];
+  }
+}
+
+// is the end of chunk k the start chunk k + 1 was given?
+__device__ __forceinline__ bool h2_chunk_link_ok(const grdma_h2_chunks* ctl, uint32_t k) {
+  const grdma_h2_deframe_result& r = ctl->res[k];
+  const grdma_h2_parser_dev& g = ctl->gp[k];
+  const grdma_h2_parser_dev& R = ctl->ref;
+  const grdma_h2_stream_dev& e = ctl->end_entry[k];
+  const grdma_h2_stream_dev& re = ctl->ref_entry;
+  if (r.error != 0 || r.overflow != 0 || r.slices_done != ctl->s_begin[k + 1] - ctl->s_begin[k]) return false;
+  if (!ctl->clean[k]) return false;
+  if (g.state != ST_FH0 || g.expect_continuation != 0 || g.is_first_frame != 0 || g.error != 0) return false;
+  if (g.last_new_stream_id != R.last_new_stream_id || g.live_streams != R.live_streams) return false;
+  if (e.stream_id != R.hint_id || e.state != R.hint_state || (e.state == 5 && e.frame_size != R.hint_fsz)) return false;
+  if (e.compressed != re.compressed || e.read_closed != re.read_closed || e.write_closed != re.write_closed ||
+      e.hdr_frames != re.hdr_frames)
+    return false;
+  return true;
+}
+
+#define H2_MERGE_THREADS 256
+__global__ __launch_bounds__(H2_MERGE_THREADS) void k_h2_chunk_merge(grdma_h2_parser_dev* gp, grdma_h2_chunks* ctl,
+                                                                     grdma_h2_event* ev, uint64_t ev_cap,
+                                                                     grdma_h2_deframe_result* res) {
+  const uint32_t K = ctl->K;
+  if (K == 0) return;  // (uniform; the sequential pass does the call)
+  // every workgroup verifies the chain itself (a few hundred bytes of control data): no inter-workgroup wait
+  bool ok = true;
+  uint64_t pre[H2_KMAX + 1];
+  pre[0] = 0;
+  for (uint32_t k = 0; k < K; k++) {
+    if (k + 1 < K) ok = ok && h2_chunk_link_ok(ctl, k);
+    else ok = ok && ctl->res[k].error == 0 && ctl->res[k].overflow == 0 &&
+              ctl->res[k].slices_done == ctl->s_begin[k + 1] - ctl->s_begin[k];
+    pre[k + 1] = pre[k] + ctl->res[k].nevents;
+  }
+  ok = ok && pre[K] <= ev_cap;
+  if (!ok) return;  // (uniform; ctl->ok stays 0)
+  const uint64_t total = pre[K];
+  const uint64_t per = (total + gridDim.x - 1) / gridDim.x;
+  const uint64_t i0 = (uint64_t)blockIdx.x * per, i1 = i0 + per < total ? i0 + per : total;
+  for (uint64_t i = i0 + threadIdx.x; i < i1; i += H2_MERGE_THREADS) {
+    uint32_t k = 0;
+    while (k + 1 < K && i >= pre[k + 1]) k++;
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(ctl->ev_tmp + (size_t)k * ctl->ev_stride + (i - pre[k]));
+    const uint64_t w0 = src[0], w1 = src[1];
+    uint64_t w2 = src[2];
+    w2 += ctl->s_begin[k] << 32;  // the slice index of an event is its high half: rebase it on the chunk's first slice
+    uint64_t* dst = reinterpret_cast<uint64_t*>(ev + i);
+    dst[0] = w0;
+    dst[1] = w1;
+    dst[2] = w2;
+  }
+  if (blockIdx.x == 0) {
+    // the last chunk's parser block and stream map are the connection's
+    const uint32_t slots = ctl->slots;
+    grdma_h2_stream_dev* orig = ctl->ref.tab;
+    const grdma_h2_stream_dev* last = ctl->tabs + (size_t)(K - 1) * slots;
+    for (uint32_t i = threadIdx.x; i < slots; i += H2_MERGE_THREADS) orig[i] = last[i];
+    if (threadIdx.x == 0) {
+      grdma_h2_parser_dev g = ctl->gp[K - 1];
+      g.tab = orig;
+      *gp = g;
+      grdma_h2_deframe_result r = ctl->res[K - 1];
+      r.nevents = total;
+      r.slices_done = ctl->s_begin[K];
+      for (uint32_t k = 0; k + 1 < K; k++) {
+        r.bulk_steps += ctl->res[k].bulk_steps;
+        r.bulk_frames += ctl->res[k].bulk_frames;
+        r.boundary_steps += ctl->res[k].boundary_steps;
+        if (ctl->res[k].t_total > r.t_total) r.t_total = ctl->res[k].t_total;  // (the chunks ran side by side)
+      }
+      *res = r;
+      ctl->n_merged++;
+      ctl->ok = 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe_unless_merged(const grdma_h2_chunks* ctl,
+                                                                                grdma_h2_parser_dev* gp, const uint8_t* arena,
+                                                                                const grdma_slice_out* slices, uint64_t nslices,
+                                                                                grdma_h2_event* ev, uint64_t ev_cap,
+                                                                                grdma_h2_deframe_result* res) {
+  if (ctl->K != 0 && ctl->ok != 0) return;  // (uniform; written by kernels that have completed)
+  h2_deframe_body(gp, arena, slices, nslices, ev, ev_cap, res);
 }
 
 // What the surface does to the stream map outside the read path, batched: op 1 = a client starts

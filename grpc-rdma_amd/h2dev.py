@@ -37,6 +37,8 @@ def _bind():
         lib.grdma_h2_parser_live_streams.argtypes = [C.c_void_p]
         lib.grdma_h2_last_boundary_steps.restype = C.c_uint64
         lib.grdma_h2_last_boundary_steps.argtypes = []
+        lib.grdma_h2_parser_chunk_stats.restype = C.c_int
+        lib.grdma_h2_parser_chunk_stats.argtypes = [C.c_void_p, C.POINTER(u64)]
         lib.grdma_h2_deframe.restype = C.c_int64
         lib.grdma_h2_deframe.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ReadSlice), u64,
                                          C.POINTER(H2Event), u64, C.POINTER(C.c_int)]
@@ -57,6 +59,7 @@ def frame_messages(msgs, max_frame, slices_dev_ptr, slices_cap, hdr_dev_ptr, hdr
 
 
 H2_SERVER, H2_FIRST_FRAME, H2_BOUNDARY_STEP, H2_NO_BOUNDARY_STEP, H2_BULK_PAIRS, H2_TICKS, H2_NO_BULK_PAIRS = 1, 2, 4, 8, 16, 32, 64
+H2_NO_CHUNKS = 128
 
 
 class Parser:
@@ -65,7 +68,7 @@ class Parser:
     False: a client / mid-connection parser whose streams the caller opens."""
 
     def __init__(self, expect_client_prefix=False, max_frame_size=16384, flags=None,
-                 max_concurrent_streams=0xFFFFFFFF, table_slots=0, boundary_step=None, bulk_pairs=None, ticks=False):
+                 max_concurrent_streams=0xFFFFFFFF, table_slots=0, boundary_step=None, bulk_pairs=None, ticks=False, chunks=None):
         self.lib = _bind()
         if flags is None:
             flags = (H2_SERVER | H2_FIRST_FRAME) if expect_client_prefix else 0
@@ -75,6 +78,8 @@ class Parser:
             flags |= H2_BULK_PAIRS if bulk_pairs else H2_NO_BULK_PAIRS
         if ticks:
             flags |= H2_TICKS
+        if chunks is not None and not chunks:  # None / True: the library default (GRDMA_H2_CHUNKS, lists of >= 2048 slices)
+            flags |= H2_NO_CHUNKS
         self.h = self.lib.grdma_h2_parser_create_ex(flags, max_frame_size, max_concurrent_streams, table_slots)
         if not self.h:
             raise GrdmaError("h2 parser allocation failed")
@@ -93,6 +98,12 @@ class Parser:
 
     def live_streams(self):
         return check(self.lib.grdma_h2_parser_live_streams(self.h))
+
+    def chunk_stats(self):
+        """(calls the chunked deframer planned, calls whose chunks verified and were merged)"""
+        out = (u64 * 2)()
+        check(self.lib.grdma_h2_parser_chunk_stats(self.h, out))
+        return int(out[0]), int(out[1])
 
     def deframe(self, arena_dev_ptr, slices, cap=None):
         """slices: list of (offset, len) in the arena. -> (h2 error, events)"""

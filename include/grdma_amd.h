@@ -499,6 +499,10 @@ enum grdma_h2_parser_flags {
                                     with-h2 leg, same events); GRDMA_H2_BULK_PAIRS=0 in the environment or
                                     GRDMA_H2_NO_BULK_PAIRS turns it off                                 */
   GRDMA_H2_NO_BULK_PAIRS = 64,   /* 32 frames per bulk step                                             */
+  GRDMA_H2_NO_CHUNKS = 128,      /* always the sequential deframer.  Without it a list of >= 2048 slices is cut at slices in
+                                    which a message starts (GRDMA_H2_CHUNKS chunks, default 16), the chunks are parsed side
+                                    by side and merged when every chunk ended in the state the next one was assumed to
+                                    start in -- the sequential deframer does the call otherwise (csrc/grdma_h2_kernels.h) */
   GRDMA_H2_TICKS = 32            /* the parsing wave samples the device clock around its phases (the tick counters
                                     of grdma_h2_pipe_sync / grdma_h2_last_deframe_stats); off by default: a sample
                                     is a scalar memory operation the wave waits for                     */
@@ -536,6 +540,7 @@ void grdma_h2_last_deframe_stats(uint64_t out[8]);
 /* grpc_chttp2_perform_read (parsing.cc:56-253) + grpc_deframe_unprocessed_incoming_frames
  * (frame_data.cc:92-276) over n delivered slices {offset, length} of d_arena.
  * Returns the number of events; *h2_error = connection error, if any. */
+int grdma_h2_parser_chunk_stats(grdma_h2_parser* p, uint64_t out[2]);  /* calls planned / merged by the chunked deframer */
 int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_read_slice* slices,
                          uint64_t n, grdma_h2_event* events_out, uint64_t cap, int* h2_error);
 

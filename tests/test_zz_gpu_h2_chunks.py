@@ -1,0 +1,178 @@
+"""The deframer over chunks (csrc/grdma_h2_kernels.h: k_h2_chunk_plan / k_h2_deframe_chunks / k_h2_chunk_merge /
+k_h2_deframe_unless_merged): a list of >= 2048 delivered slices is cut at slices in which a message starts, the chunks
+are parsed side by side from the state the boundary step recorded, and merged only when the chain of end states holds.
+Whatever the list holds, the events, the parser state (checked through the NEXT call's events) and the stream map are
+the sequential parser's, i.e. the oracle's (parsing.cc:111-250 + frame_data.cc:92-276 restated in oracle/)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import pyorc
+from tests.h2_helpers import PREFACE, frame, grpc_msg
+from tests.test_h2_fast_host import receiver_slices
+
+pytestmark = pytest.mark.gpu
+
+
+def fast_sender_slices(sizes, sid=1, seed=0, max_frame=16384):
+    """tests/test_h2_fast_host.py::sender_slices with numpy payloads (thousands of slices)."""
+    out = []
+    for i, n in enumerate(sizes):
+        pay = ((np.arange(n, dtype=np.uint32) * 13 + i + seed) % 251).astype(np.uint8).tobytes()
+        body = b"\x00" + n.to_bytes(4, "big") + pay
+        off = 0
+        while off < len(body):
+            k = min(max_frame, len(body) - off)
+            fh = k.to_bytes(3, "big") + bytes([0, 0]) + sid.to_bytes(4, "big")
+            if off == 0:
+                out.append(fh + body[:5])
+                if k > 5:
+                    out.append(body[5:k])
+            else:
+                out += [fh, body[off:off + k]]
+            off += k
+    return out
+
+
+class Both:
+    """The same calls on a device parser and on the oracle's."""
+
+    def __init__(self, g, prefix, streams=(), chunks=None, gap_seed=None):
+        from grpc_rdma_amd import h2dev
+        self.g = g
+        self.dev = h2dev.Parser(prefix, boundary_step=True, chunks=chunks)
+        self.orc = pyorc.H2Parser(expect_client_prefix=prefix)
+        if streams:
+            assert self.dev.open_streams(streams) == 0
+            for sid in streams:
+                assert self.orc.open_stream(sid) == 0
+        self.rng = random.Random(gap_seed) if gap_seed is not None else None
+
+    def call(self, slices):
+        arena, table = bytearray(), []
+        for s in slices:
+            if self.rng is not None:
+                arena += b"\xee" * self.rng.randrange(1, 16)
+            else:
+                arena += bytes((-len(arena)) % 16)
+            table.append((len(arena), len(s)))
+            arena += s
+        buf = self.g.DeviceBuffer(data=bytes(arena) + bytes(64))
+        err, ev = self.dev.deframe(buf.ptr, table, cap=8 * len(slices) + 4096)
+        exp = []
+        for i, s in enumerate(slices):
+            rc, e = self.orc.feed(s, cap=1024)
+            assert rc == 0
+            exp += [(k, a, b, c, d, i) for k, a, b, c, d in e]
+        assert err == 0
+        assert len(ev) == len(exp)
+        if ev != exp:
+            bad = next(i for i in range(len(ev)) if ev[i] != exp[i])
+            raise AssertionError("event %d: device %r, oracle %r" % (bad, ev[bad], exp[bad]))
+        return len(ev)
+
+    def close(self):
+        self.dev.close()
+
+
+@pytest.mark.parametrize("shape", ["sender", "receiver"])
+@pytest.mark.parametrize("gaps", [False, True], ids=["aligned", "unaligned"])
+def test_chunked_deframer_streaming_shapes(gpu, shape, gaps):
+    """A streaming call of equal messages, as the sending side's slice buffer and as the receiving endpoint's reads:
+    the first call leaves the hint, every later long list is planned, verified and merged."""
+    b = Both(gpu, False, streams=(1,), gap_seed=5 if gaps else None)
+    mk = (lambda tx: tx) if shape == "sender" else receiver_slices
+    warm = mk(fast_sender_slices([100000] * 3))
+    b.call([frame(1, 4, 1, b"\x82")] + warm)
+    assert b.dev.chunk_stats() == (0, 0)  # (too short, and no hint before it)
+    for rep in range(2):
+        body = mk(fast_sender_slices([100000] * 330, seed=rep))
+        assert len(body) >= 4096
+        b.call(body)
+        assert b.dev.chunk_stats() == (rep + 1, rep + 1)
+    # a short list goes the sequential way and finds the state the merge installed
+    b.call(mk(fast_sender_slices([5, 100000, 16379], seed=9)))
+    assert b.dev.chunk_stats() == (2, 2)
+    b.close()
+
+
+def test_chunked_deframer_mixed_sizes_and_control_frames(gpu):
+    """Message sizes that end on and off frame boundaries, PING frames between messages: still one stream in one state
+    at every message start, so the chain holds and the call is merged."""
+    rng = random.Random(3)
+    b = Both(gpu, True)
+    b.call([PREFACE + frame(4, 0, 0), frame(1, 4, 1, b"\x82")] + fast_sender_slices([7, 40000, 16379]))
+    sizes = [rng.choice([1, 9, 300, 16379, 16380, 40000, 65536, 200000]) for _ in range(500)]
+    body = []
+    for i, n in enumerate(sizes):
+        body += fast_sender_slices([n], seed=i)
+        if i % 50 == 17:
+            body.append(frame(6, 0, 0, bytes(8)))
+    assert len(body) >= 2048
+    b.call(body)
+    assert b.dev.chunk_stats() == (1, 1)
+    b.call(receiver_slices(fast_sender_slices([70000] * 400)))
+    assert b.dev.chunk_stats() == (2, 2)
+    b.close()
+
+
+def test_chunked_deframer_declines_what_it_cannot_verify(gpu):
+    """Lists on which the chain of end states does NOT hold are the sequential parser's: a second stream that is
+    mid-message at a cut, a stream that opens in the middle of the list, a stream that closes in it, a connection
+    error.  The events are the oracle's every time and nothing of the chunks' work shows."""
+    b = Both(gpu, True)
+    b.call([PREFACE + frame(4, 0, 0), frame(1, 4, 1, b"\x82"), frame(1, 4, 3, b"\x82")] + fast_sender_slices([50000] * 3))
+    # (a) two streams interleaved, a frame of stream 3 behind every message of stream 1: stream 3 is in the middle of
+    # a message at every cut
+    one = fast_sender_slices([60000] * 300, sid=1)
+    three = fast_sender_slices([6000000], sid=3, seed=4)
+    mix, j = [], 0
+    for i in range(0, len(one), 8):
+        mix += one[i:i + 8]
+        if j < len(three):
+            mix += three[j:j + 2]
+            j += 2
+    mix += three[j:]
+    assert len(mix) >= 2048
+    b.call(mix)
+    planned, merged = b.dev.chunk_stats()
+    assert planned == 1 and merged == 0
+    # (b) a stream opens in the middle of the list (HEADERS of stream 5): live_streams / last_new_stream_id move
+    body = fast_sender_slices([60000] * 150, seed=1) + [frame(1, 4, 5, b"\x82")] + fast_sender_slices([60000] * 150, seed=2)
+    b.call(body)
+    assert b.dev.chunk_stats()[1] == 0
+    # (c) the hinted stream ends in the middle of the list (END_STREAM), stream 3 carries on behind it
+    body = fast_sender_slices([60000] * 150, seed=3) + [frame(0, 1, 1, grpc_msg(bytes(100)))]
+    body += fast_sender_slices([60000] * 150, sid=3, seed=6)
+    assert len(body) >= 2048
+    b.call(body)
+    assert b.dev.chunk_stats()[1] == 0
+    # (d) the hint now names stream 3; what happens inside the LAST chunk is not constrained -- a stream may open
+    # there -- and the merged call leaves the state the next (short, sequential) call continues from
+    b.call(fast_sender_slices([60000] * 300, sid=3, seed=7) + [frame(1, 4, 7, b"\x82")] +
+           fast_sender_slices([60000], sid=7, seed=8) + fast_sender_slices([60000] * 5, sid=3, seed=9))
+    assert b.dev.chunk_stats()[1] == 1
+    b.call(fast_sender_slices([100, 60000], sid=7, seed=10) + fast_sender_slices([60000] * 2, sid=3, seed=11))
+    assert b.dev.live_streams() == b.orc.live_streams()
+    b.close()
+
+
+def test_chunked_and_sequential_deframer_agree_call_by_call(gpu):
+    """The same calls on a parser with chunks and on one without: identical events (both checked against the oracle),
+    through alternating long and short lists, so that each path starts from the state the other left."""
+    rng = random.Random(11)
+    on = Both(gpu, False, streams=(1,), chunks=True)
+    off = Both(gpu, False, streams=(1,), chunks=False)
+    first = [frame(1, 4, 1, b"\x82")]
+    for rep in range(5):
+        n = rng.choice([3, 40, 260])
+        size = rng.choice([16379, 100000, 1 << 20]) if n < 100 else 150000
+        tx = fast_sender_slices([size] * n, seed=rep)
+        body = first + (receiver_slices(tx) if rep % 2 else tx)
+        first = []
+        assert on.call(body) == off.call(body)
+    assert off.dev.chunk_stats() == (0, 0)
+    assert on.dev.chunk_stats()[1] >= 1
+    on.close()
+    off.close()
