@@ -594,8 +594,9 @@ def main():
             tx.close(); rx.close(); dst.free()
         return out
 
-    def measure_with_h2(ring_kb, steps, warmup, engine=False, boundary_step=None, bulk_pairs=None, ticks=False, chunks=None):
-        """The same step with the HTTP/2 stages INSIDE the timed device pipeline: k_h2_frame rebuilds
+    def measure_with_h2(ring_kb, steps, warmup, engine=False, boundary_step=None, bulk_pairs=None, ticks=False, chunks=None,
+                        fused=None):
+        """The same step with the HTTP/2 stages INSIDE the timed device pipeline: k_h2_frame_index + k_h2_frame_emit rebuild
         the slice list from the message table, the job carries it through the connection, k_h2_deframe
         parses what was delivered (events: frames, message boundaries, payload pieces).  Two jobs over
         the one connection alternate, so framing / deframing of neighbouring steps run beside a job."""
@@ -610,6 +611,9 @@ def main():
         parser = h2dev.Parser(False, boundary_step=boundary_step, bulk_pairs=bulk_pairs, ticks=ticks, chunks=chunks)
         assert parser.open_streams([1]) == 0      # a client-side parser: the call runs on stream 1
         jobs, pipes, dsts = [], [], []
+        env_fused = os.environ.get("GRDMA_H2_PIPE_FUSED")
+        if fused is not None:  # (read when a pipe is created) 0: stages enqueued around the job's graph, timed by events
+            os.environ["GRDMA_H2_PIPE_FUSED"] = "1" if fused else "0"
         for _ in range(2):
             dst = g.DeviceBuffer(nbytes=dst_cap)
             est = max(8, 4 * (w.E // (ring // 2) + 2), 2 * (len(w.lens) // min(args.max_sge, 4095) + 2))
@@ -626,6 +630,11 @@ def main():
             pipes.append(h2dev.Pipe(job, msgs, parser, delivered, 4 * len(w.lens) + 1024))
             jobs.append(job)
             dsts.append(dst)
+        if fused is not None:
+            if env_fused is None:
+                os.environ.pop("GRDMA_H2_PIPE_FUSED", None)
+            else:
+                os.environ["GRDMA_H2_PIPE_FUSED"] = env_fused
         for i in range(max(2, warmup)):
             pipes[i % 2].enqueue(engine)
         for p_ in pipes:
@@ -669,8 +678,12 @@ def main():
 
     if args.h2_only:  # (internal) the with-h2 legs alone: chunked deframer (default) and the sequential one
         o_ = {}
-        for tag, ch in (("value_with_h2", None), ("value_with_h2_sequential_deframer", False)):
-            h2_ = measure_with_h2(args.ring_kb, args.steps, max(2, args.warmup), engine=(args.schedule == "engine"), chunks=ch)
+        for tag, ch, fu in (("value_with_h2", None, None), ("value_with_h2_stages_around_the_graph", None, False),
+                            ("value_with_h2_sequential_deframer", False, False)):
+            if tag != "value_with_h2" and os.environ.get("BENCH_H2_DEFAULT_LEG_ONLY"):
+                continue
+            h2_ = measure_with_h2(args.ring_kb, args.steps, max(2, args.warmup), engine=(args.schedule == "engine"), chunks=ch,
+                                  fused=fu)
             o_[tag] = round(wl.user_bytes * args.steps * world / h2_["elapsed"] / (1 << 30), 3)
             o_[tag + "_verified"] = h2_["verified"]
             o_[tag + "_stages"] = h2_["stages"]
@@ -851,9 +864,11 @@ def main():
             out["value_with_h2"] = round(wl.user_bytes * args.steps * world / hh["elapsed"] / (1 << 30), 3)
             out["with_h2_verified"] = hh["verified"]
             out["with_h2_stages"] = hh["stages"]
-            out["config"]["with_h2_leg"] = ("k_h2_frame -> the job -> k_h2_deframe inside the timed pipeline, library defaults "
-                                            "(message-boundary step on, 64 frames per bulk step, the delivered slices parsed as 16 chunks side by side "
-                                            "and merged after the chain of end states verified, no clock samples); "
+            out["config"]["with_h2_leg"] = ("k_h2_frame_index + k_h2_frame_emit -> the job -> k_h2_deframe inside the timed pipeline, library defaults "
+                                            "(framing and deframing are kernel nodes of the job's own graph: one launch per step; "
+                                            "message-boundary step on, 64 frames per bulk step, the delivered slices parsed as up to 128 "
+                                            "chunks side by side and merged after the chain of end states verified, no clock samples); "
+                                            "value_with_h2_stages_around_the_graph: the stages enqueued around the job's graph launch; "
                                             "value_with_h2_sequential_deframer: one parsing wave over the whole list; "
                                             "value_with_h2_no_boundary_step: message starts byte-wise; "
                                             "value_with_h2_bulk32: 32 frames per bulk step (GRDMA_H2_BULK_PAIRS=0)")
@@ -861,8 +876,17 @@ def main():
             out["with_h2_error"] = err_text(e)
         eng_ = (args.schedule == "engine")
         few = max(2, args.steps // 4)
+        try:  # per-stage times: the stages enqueued around the job's graph, each between two events
+            hs = measure_with_h2(args.ring_kb, few, 2, engine=eng_, fused=False)
+            out["value_with_h2_stages_around_the_graph"] = round(wl.user_bytes * few * world / hs["elapsed"] / (1 << 30), 3)
+            for k_ in ("frame_us", "deframe_us"):
+                out["with_h2_stages"][k_] = hs["stages"][k_]
+            out["with_h2_stages"]["stage_times_from"] = ("a run with GRDMA_H2_PIPE_FUSED=0 (stages enqueued around the job's "
+                                                         "graph, event pairs around each; includes the graph boundary)")
+        except Exception as e:
+            out["with_h2_unfused_error"] = err_text(e)
         try:  # the phase ticks of the deframing kernel (a short run with the clock samples on)
-            ht = measure_with_h2(args.ring_kb, 2, 2, engine=eng_, ticks=True)
+            ht = measure_with_h2(args.ring_kb, 2, 2, engine=eng_, ticks=True, fused=False)
             out["with_h2_stages"]["deframe_ticks"] = ht["stages"]["deframe_ticks"]
             out["with_h2_stages"]["deframe_us_with_clock_samples"] = ht["stages"]["deframe_us"]
         except Exception as e:
@@ -874,7 +898,7 @@ def main():
         except Exception as e:
             out["with_h2_no_boundary_step_error"] = err_text(e)
         try:  # the same leg with the one-wave sequential deframer (no chunks: the default until the end of round 3)
-            h1 = measure_with_h2(args.ring_kb, few, 2, engine=eng_, chunks=False)
+            h1 = measure_with_h2(args.ring_kb, few, 2, engine=eng_, chunks=False, fused=False)
             out["value_with_h2_sequential_deframer"] = round(wl.user_bytes * few * world / h1["elapsed"] / (1 << 30), 3)
             out["with_h2_sequential_deframer_deframe_us"] = h1["stages"]["deframe_us"]
         except Exception as e:

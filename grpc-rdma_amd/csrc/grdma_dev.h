@@ -240,4 +240,13 @@ struct grdma_plan {
   uint32_t pad_line1[31];
 };
 
+// A kernel node another stage hangs into a streaming job's graph (grdma_job_set_hooks, csrc/grdma_pair.hip): the
+// kernel, its launch shape and its parameters (each at most 8 bytes, one slot per parameter).
+#define GRDMA_JOB_HOOK_ARGS 10
+struct grdma_job_hook {
+  const void* fn;
+  uint32_t grid, threads;
+  uint64_t args[GRDMA_JOB_HOOK_ARGS];
+};
+
 #endif  // GRDMA_DEV_H

@@ -1,6 +1,6 @@
 // HTTP/2 DATA framing (K6/K7) and deframing (K8/K9) on the device.
 //
-// TX  k_h2_frame     builds, in HBM, the slice list chttp2 hands to
+// TX  k_h2_frame_index + k_h2_frame_emit   build, in HBM, the slice list chttp2 hands to
 //                    grpc_endpoint_write for a batch of gRPC messages:
 //                    5-byte message header (chttp2_transport.cc:1502-1510), 9-byte
 //                    DATA frame headers (grpc_chttp2_encode_data, frame_data.cc:64-90),
@@ -9,6 +9,8 @@
 //                    split rule of move_first_no_ref (slice_buffer.cc:270-313).
 //                    No payload byte is copied: K1 (k_copy) gathers straight from
 //                    the message buffers.
+//                    One wave per message (closed-form layout; sequential only around
+//                    empty messages, whose inlined slices merge across message boundaries).
 // RX  k_h2_deframe   the resumable frame-header state machine of
 //                    grpc_chttp2_perform_read (parsing.cc:56-253) and the gRPC
 //                    message deframer (frame_data.cc:92-276) over the slices an
@@ -47,9 +49,12 @@ struct grdma_h2_parser {
   grdma_h2_stream_dev* d_tabs = nullptr;
   grdma_h2_event* d_ev_tmp = nullptr;
   uint64_t ev_tmp_cap = 0;             // events the segments hold in total
+  // the last deframing a pipe enqueued for this parser: the next one is ordered behind it (same stream, or this event)
+  hipStream_t last_stream = nullptr;
+  hipEvent_t last_deframed = nullptr;
 };
 
-// How many chunks a parser created without saying so cuts a long list into: GRDMA_H2_CHUNKS (default 16, 0 or 1 = the
+// How many chunks a parser created without saying so cuts a long list into: GRDMA_H2_CHUNKS (default and at most 128, 0 or 1 = the
 // sequential deframer only).
 static int h2_chunks_default() {
   static int v = -1;
@@ -65,7 +70,7 @@ static int h2_chunks_default() {
 // (re)size the chunk buffers of a parser for calls that may produce ev_cap events
 static bool h2_chunks_prepare(grdma_h2_parser* p, uint64_t ev_cap, hipStream_t st) {
   if (p->chunks_want < 2) return false;
-  const uint64_t need = 2 * (ev_cap ? ev_cap : 1) + H2_KMAX * 64;
+  const uint64_t need = 4 * (ev_cap ? ev_cap : 1) + H2_KMAX * 64;
   if (p->d_chunks && p->ev_tmp_cap >= need) return true;
   if (!p->d_chunks) {
     if (hipMalloc((void**)&p->d_chunks, sizeof(grdma_h2_chunks)) != hipSuccess ||
@@ -79,8 +84,8 @@ static bool h2_chunks_prepare(grdma_h2_parser* p, uint64_t ev_cap, hipStream_t s
   if (hipMalloc((void**)&p->d_ev_tmp, sizeof(grdma_h2_event) * need) != hipSuccess) return false;
   p->ev_tmp_cap = need;
   // the host-owned words of the control block (the counters stay)
-  struct { grdma_h2_stream_dev* tabs; grdma_h2_event* ev_tmp; uint64_t ev_stride; uint32_t slots, pad; } tail =
-      {p->d_tabs, p->d_ev_tmp, need / H2_KMAX, p->slots, 0};
+  struct { grdma_h2_stream_dev* tabs; grdma_h2_event* ev_tmp; uint64_t ev_total; uint32_t slots, pad; } tail =
+      {p->d_tabs, p->d_ev_tmp, need, p->slots, 0};
   static_assert(offsetof(grdma_h2_chunks, pad) + sizeof(uint32_t) - offsetof(grdma_h2_chunks, tabs) == sizeof(tail), "layout");
   const uint32_t want = (uint32_t)p->chunks_want;
   return hipMemcpyAsync(reinterpret_cast<uint8_t*>(p->d_chunks) + offsetof(grdma_h2_chunks, tabs), &tail, sizeof(tail),
@@ -91,7 +96,7 @@ static bool h2_chunks_prepare(grdma_h2_parser* p, uint64_t ev_cap, hipStream_t s
 }
 
 // The deframing of one list of delivered slices, enqueued on st: over chunks when the parser has the buffers (plan,
-// chunks, merge, then the sequential deframer for whatever did not merge), else the sequential deframer alone.
+// the chunks side by side, then the merge -- or the sequential deframer over the whole list when the chain did not hold), else the sequential deframer alone.
 static void h2_enqueue_deframe(grdma_h2_parser* p, const uint8_t* arena, const grdma_slice_out* d_slices, uint64_t n,
                                grdma_h2_event* d_ev, uint64_t ev_cap, grdma_h2_deframe_result* d_res, hipStream_t st,
                                bool chunked) {
@@ -99,11 +104,20 @@ static void h2_enqueue_deframe(grdma_h2_parser* p, const uint8_t* arena, const g
     hipLaunchKernelGGL(k_h2_deframe, dim3(1), dim3(H2_DEFRAME_THREADS), 0, st, p->d, arena, d_slices, n, d_ev, ev_cap, d_res);
     return;
   }
-  hipLaunchKernelGGL(k_h2_chunk_plan, dim3(1), dim3(H2_PLAN_THREADS), 0, st, p->d, arena, d_slices, n, p->d_chunks);
-  hipLaunchKernelGGL(k_h2_deframe_chunks, dim3(H2_KMAX), dim3(H2_DEFRAME_THREADS), 0, st, p->d_chunks, arena, d_slices);
-  hipLaunchKernelGGL(k_h2_chunk_merge, dim3(64), dim3(H2_MERGE_THREADS), 0, st, p->d, p->d_chunks, d_ev, ev_cap, d_res);
-  hipLaunchKernelGGL(k_h2_deframe_unless_merged, dim3(1), dim3(H2_DEFRAME_THREADS), 0, st,
-                     (const grdma_h2_chunks*)p->d_chunks, p->d, arena, d_slices, n, d_ev, ev_cap, d_res);
+  hipLaunchKernelGGL(k_h2_deframe_chunks, dim3((unsigned)p->chunks_want), dim3(H2_DEFRAME_THREADS), 0, st, p->d, p->d_chunks,
+                     arena, d_slices, n);
+  hipLaunchKernelGGL(k_h2_merge_or_deframe, dim3(H2_MERGE_GRID), dim3(H2_DEFRAME_THREADS), 0, st, p->d, p->d_chunks, arena,
+                     d_slices, n, d_ev, ev_cap, d_res);
+}
+
+// The framing of one message table, enqueued on st: sizes and positions, then one wave per message (grdma_h2_kernels.h).
+static void h2_enqueue_frame(const grdma_h2_msg_dev* d_msgs, uint64_t n, uint32_t max_frame, grdma_sge* out, uint64_t cap,
+                             uint8_t* hdr, uint64_t hdr_cap, grdma_h2_msg_pos* d_pos, grdma_h2_frame_result* d_res,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(k_h2_frame_index, dim3(1), dim3(256), 0, st, d_msgs, n, max_frame, cap, hdr_cap, d_pos, d_res);
+  const uint64_t per = H2_EMIT_THREADS / 64;
+  hipLaunchKernelGGL(k_h2_frame_emit, dim3((unsigned)((n + per - 1) / per)), dim3(H2_EMIT_THREADS), 0, st, d_msgs, n, max_frame,
+                     out, cap, hdr, hdr_cap, (const grdma_h2_msg_pos*)d_pos);
 }
 
 static double g_h2_last_kernel_us = 0;
@@ -189,17 +203,18 @@ int64_t grdma_h2_frame_messages(const grdma_h2_msg* msgs, uint64_t n, uint32_t m
   static grdma_h2_msg_dev* d_msgs = nullptr;
   static uint64_t msgs_cap = 0;
   static grdma_h2_frame_result* d_res = nullptr;
+  static grdma_h2_msg_pos* d_pos = nullptr;
+  static uint64_t pos_cap = 0;
   grdma_h2_frame_result h_res;
-  if (!h2_grow(&d_msgs, &msgs_cap, n)) return -GRDMA_ERR_HIP;
+  if (!h2_grow(&d_msgs, &msgs_cap, n) || !h2_grow(&d_pos, &pos_cap, n)) return -GRDMA_ERR_HIP;
   if (!d_res && hipMalloc((void**)&d_res, sizeof(grdma_h2_frame_result)) != hipSuccess) return -GRDMA_ERR_HIP;
   hipStream_t st = hc->stream;
   if (hipMemcpyAsync(d_msgs, tmp.data(), sizeof(grdma_h2_msg_dev) * n, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemsetAsync(d_res, 0, sizeof(grdma_h2_frame_result), st) != hipSuccess)
     return -GRDMA_ERR_HIP;
   hipEventRecord(hc->e0, st);
-  hipLaunchKernelGGL(k_h2_frame, dim3(1), dim3(256), 0, st, d_msgs, n, max_frame,
-                     reinterpret_cast<grdma_sge*>(d_slices_out), slices_cap,
-                     static_cast<uint8_t*>(d_hdr_arena), hdr_cap, (uint64_t*)nullptr, d_res);
+  h2_enqueue_frame(d_msgs, n, max_frame, reinterpret_cast<grdma_sge*>(d_slices_out), slices_cap,
+                   static_cast<uint8_t*>(d_hdr_arena), hdr_cap, d_pos, d_res, st);
   hipEventRecord(hc->e1, st);
   if (hipMemcpyAsync(&h_res, d_res, sizeof(h_res), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
@@ -359,15 +374,17 @@ int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_re
 }
 
 // ---- HTTP/2 inside the device pipeline ------------------------------------------------------
-// frame (k_h2_frame rebuilds the job's slice list from the message table) -> the streaming job
-// -> deframe (k_h2_deframe over the slices the job delivered), all enqueued, each stage on its
-// own stream, ordered by events.  Two pipes over two jobs of the same connection alternate so
-// that the deframing of step k and the framing of step k + 1 run beside the job of step k + 1.
+// frame (k_h2_frame_index + k_h2_frame_emit rebuild the job's slice list from the message table) -> the streaming job
+// -> deframe (the deframer over the slices the job delivered), all enqueued.  By default the two stages are kernel
+// nodes of the job's own graph (one launch per step); with GRDMA_H2_PIPE_FUSED=0, and under the engine schedule, they
+// are enqueued around the job's launch, ordered by events, with per-stage event timing.
 struct grdma_stream_job;
 int grdma_job_link_view(grdma_stream_job* j, uint32_t link, grdma_sge** d_sges, uint64_t* count,
                         grdma_slice_out** d_slices, uint8_t** dst, hipStream_t* stream);
 int grdma_stream_job_launch(grdma_stream_job* j);
 int grdma_stream_job_launch_engine(grdma_stream_job* j);
+extern "C" int grdma_job_set_hooks(grdma_stream_job* j, const grdma_job_hook* pre, uint32_t n_pre, const grdma_job_hook* post,
+                                   uint32_t n_post);
 
 struct grdma_h2_pipe {
   grdma_stream_job* job = nullptr;
@@ -380,6 +397,7 @@ struct grdma_h2_pipe {
   hipEvent_t framed = nullptr, job_done = nullptr, deframed = nullptr;
   hipEvent_t t_f0 = nullptr, t_d0 = nullptr, t_f1 = nullptr, t_d1 = nullptr;  // kernel start / end stamps of the last step
   grdma_h2_msg_dev* d_msgs = nullptr;
+  grdma_h2_msg_pos* d_pos = nullptr;
   uint64_t nmsgs = 0;
   uint32_t max_frame = 16384;
   uint8_t* d_hdr = nullptr;
@@ -391,6 +409,8 @@ struct grdma_h2_pipe {
   uint64_t boundary_steps = 0, t_boundary = 0;  // of the last synced step
   bool launched = false;
   bool chunked = false;  // the parser has chunk buffers for this pipe's event capacity
+  bool fused = false;    // framing and deframing are nodes of the job's graph (one launch per step)
+  bool timed = false;    // the last step recorded the per-stage timing events
 };
 
 namespace {
@@ -423,9 +443,15 @@ grdma_h2_pipe* grdma_h2_pipe_create(grdma_stream_job* job, uint32_t link, const 
     tmp[i].flags = msgs[i].flags;
   }
   bool ok = grdma_job_link_view(job, link, &p->d_sges, &p->count, &p->d_slices, &p->dst, &p->job_stream) == 0;
+  // The deframing goes behind the job on the JOB's stream unless GRDMA_H2_DEFRAME_STREAM=1 asks for a stream of its
+  // own: the next job does not start before the deframing has ended either way (measured: kernels of the two streams
+  // do not run side by side), and a hand-over between streams costs ~20 us of idle device on each side of it.
+  static const bool own_stream = [] { const char* e = getenv("GRDMA_H2_DEFRAME_STREAM"); return e && atoi(e) != 0; }();
+  if (ok && !own_stream) p->deframe_stream = p->job_stream;
   p->hdr_cap = 32 * (p->count + 64);
   ok = ok && hipMalloc((void**)&p->d_msgs, sizeof(grdma_h2_msg_dev) * nmsgs) == hipSuccess &&
        hipMalloc((void**)&p->d_hdr, p->hdr_cap) == hipSuccess &&
+       hipMalloc((void**)&p->d_pos, sizeof(grdma_h2_msg_pos) * nmsgs) == hipSuccess &&
        hipMalloc((void**)&p->d_fres, sizeof(grdma_h2_frame_result)) == hipSuccess &&
        hipMalloc((void**)&p->d_dres, sizeof(grdma_h2_deframe_result)) == hipSuccess &&
        hipMalloc((void**)&p->d_ev, sizeof(grdma_h2_event) * (events_cap ? events_cap : 1)) == hipSuccess &&
@@ -440,6 +466,43 @@ grdma_h2_pipe* grdma_h2_pipe_create(grdma_stream_job* job, uint32_t link, const 
     return nullptr;
   }
   p->chunked = delivered_slices >= H2_CHUNK_MIN_SLICES && h2_chunks_prepare(parser, events_cap, p->deframe_stream);
+  // Framing and deframing as nodes of the job's own graph (default; GRDMA_H2_PIPE_FUSED=0: stages enqueued around the
+  // graph launch, with per-stage event timing): a graph boundary costs ~15-20 us of idle device on each side.
+  const char* fe = getenv("GRDMA_H2_PIPE_FUSED");
+  if (!fe || atoi(fe) != 0) {
+    auto arg = [](uint64_t v) { return v; };
+    auto ptr = [](const void* q) { return (uint64_t)(uintptr_t)q; };
+    grdma_job_hook pre[2], post[2];
+    memset(pre, 0, sizeof(pre));
+    memset(post, 0, sizeof(post));
+    pre[0] = grdma_job_hook{(const void*)k_h2_frame_index, 1, 256,
+                            {ptr(p->d_msgs), arg(p->nmsgs), arg(p->max_frame), arg(p->count), arg(p->hdr_cap), ptr(p->d_pos),
+                             ptr(p->d_fres)}};
+    const uint64_t per = H2_EMIT_THREADS / 64;
+    pre[1] = grdma_job_hook{(const void*)k_h2_frame_emit, (uint32_t)((p->nmsgs + per - 1) / per), H2_EMIT_THREADS,
+                            {ptr(p->d_msgs), arg(p->nmsgs), arg(p->max_frame), ptr(p->d_sges), arg(p->count), ptr(p->d_hdr),
+                             arg(p->hdr_cap), ptr(p->d_pos)}};
+    uint32_t n_post;
+    if (p->chunked) {
+      post[0] = grdma_job_hook{(const void*)k_h2_deframe_chunks, (uint32_t)parser->chunks_want, H2_DEFRAME_THREADS,
+                               {ptr(parser->d), ptr(parser->d_chunks), ptr(p->dst), ptr(p->d_slices), arg(p->delivered)}};
+      post[1] = grdma_job_hook{(const void*)k_h2_merge_or_deframe, H2_MERGE_GRID, H2_DEFRAME_THREADS,
+                               {ptr(parser->d), ptr(parser->d_chunks), ptr(p->dst), ptr(p->d_slices), arg(p->delivered),
+                                ptr(p->d_ev), arg(p->ev_cap), ptr(p->d_dres)}};
+      n_post = 2;
+    } else {
+      post[0] = grdma_job_hook{(const void*)k_h2_deframe, 1, H2_DEFRAME_THREADS,
+                               {ptr(parser->d), ptr(p->dst), ptr(p->d_slices), arg(p->delivered), ptr(p->d_ev), arg(p->ev_cap),
+                                ptr(p->d_dres)}};
+      n_post = 1;
+    }
+    if (grdma_job_set_hooks(job, pre, 2, post, n_post) != 0) {
+      grdma_h2_pipe_destroy(p);
+      return nullptr;
+    }
+    p->fused = true;
+    p->deframe_stream = p->job_stream;
+  }
   return p;
 }
 
@@ -450,7 +513,10 @@ void grdma_h2_pipe_destroy(grdma_h2_pipe* p) {
     hipStreamSynchronize(p->job_stream);
     hipStreamSynchronize(p->deframe_stream);
   }
+  if (p->parser && p->parser->last_deframed == p->deframed) p->parser->last_deframed = nullptr;  // (synchronised above)
+  if (p->fused && p->job) grdma_job_set_hooks(p->job, nullptr, 0, nullptr, 0);
   hipFree(p->d_msgs);
+  hipFree(p->d_pos);
   hipFree(p->d_hdr);
   hipFree(p->d_fres);
   hipFree(p->d_dres);
@@ -467,25 +533,51 @@ void grdma_h2_pipe_destroy(grdma_h2_pipe* p) {
 int grdma_h2_pipe_enqueue(grdma_h2_pipe* p, int schedule) {
   if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
   if (!p) return -GRDMA_ERR_INVALID;
+  if (p->fused && schedule == 0) {
+    // one graph launch: [k_h2_frame_index, k_h2_frame_emit] -> the job's rounds -> [the deframer]; steps and pipes
+    // of one connection are ordered by the job's stream (a parser last used on another stream: by its event)
+    if (p->parser->last_deframed && p->parser->last_stream != p->job_stream &&
+        hipStreamWaitEvent(p->job_stream, p->parser->last_deframed, 0) != hipSuccess)
+      return -GRDMA_ERR_HIP;
+    const int rc = grdma_stream_job_launch(p->job);
+    if (rc < 0) return rc;
+    if (hipEventRecord(p->deframed, p->job_stream) != hipSuccess) return -GRDMA_ERR_HIP;
+    p->parser->last_stream = p->job_stream;
+    p->parser->last_deframed = p->deframed;
+    p->launched = true;
+    p->timed = false;
+    return 0;
+  }
+  if (p->fused) {  // (the engine schedule runs the stages around k_link: the graph's hooks are not in that path)
+    if (hipStreamWaitEvent(p->frame_stream, p->deframed, 0) != hipSuccess) return -GRDMA_ERR_HIP;
+  }
+  p->timed = true;
   // framing overwrites the slice table the job's previous step read
   if (p->launched && hipStreamWaitEvent(p->frame_stream, p->job_done, 0) != hipSuccess) return -GRDMA_ERR_HIP;
   if (hipMemsetAsync(p->d_fres, 0, sizeof(grdma_h2_frame_result), p->frame_stream) != hipSuccess) return -GRDMA_ERR_HIP;
   hipEventRecord(p->t_f0, p->frame_stream);
-  hipLaunchKernelGGL(k_h2_frame, dim3(1), dim3(256), 0, p->frame_stream, p->d_msgs, p->nmsgs, p->max_frame, p->d_sges,
-                     p->count, p->d_hdr, p->hdr_cap, (uint64_t*)nullptr, p->d_fres);
+  h2_enqueue_frame(p->d_msgs, p->nmsgs, p->max_frame, p->d_sges, p->count, p->d_hdr, p->hdr_cap, p->d_pos, p->d_fres,
+                   p->frame_stream);
   hipEventRecord(p->t_f1, p->frame_stream);
   if (hipEventRecord(p->framed, p->frame_stream) != hipSuccess) return -GRDMA_ERR_HIP;
   // the job reads the slice table and overwrites what the previous deframing parsed
   if (hipStreamWaitEvent(p->job_stream, p->framed, 0) != hipSuccess) return -GRDMA_ERR_HIP;
-  if (p->launched && hipStreamWaitEvent(p->job_stream, p->deframed, 0) != hipSuccess) return -GRDMA_ERR_HIP;
+  if (p->launched && p->deframe_stream != p->job_stream && hipStreamWaitEvent(p->job_stream, p->deframed, 0) != hipSuccess)
+    return -GRDMA_ERR_HIP;
   const int rc = schedule == 1 ? grdma_stream_job_launch_engine(p->job) : grdma_stream_job_launch(p->job);
   if (rc < 0) return rc;
   if (hipEventRecord(p->job_done, p->job_stream) != hipSuccess) return -GRDMA_ERR_HIP;
-  if (hipStreamWaitEvent(p->deframe_stream, p->job_done, 0) != hipSuccess) return -GRDMA_ERR_HIP;
+  if (p->deframe_stream != p->job_stream && hipStreamWaitEvent(p->deframe_stream, p->job_done, 0) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  if (p->parser->last_deframed && p->parser->last_stream != p->deframe_stream &&
+      hipStreamWaitEvent(p->deframe_stream, p->parser->last_deframed, 0) != hipSuccess)
+    return -GRDMA_ERR_HIP;  // (the parser state is handed from one deframing to the next)
   hipEventRecord(p->t_d0, p->deframe_stream);
   h2_enqueue_deframe(p->parser, p->dst, p->d_slices, p->delivered, p->d_ev, p->ev_cap, p->d_dres, p->deframe_stream, p->chunked);
   hipEventRecord(p->t_d1, p->deframe_stream);
   if (hipEventRecord(p->deframed, p->deframe_stream) != hipSuccess) return -GRDMA_ERR_HIP;
+  p->parser->last_stream = p->deframe_stream;
+  p->parser->last_deframed = p->deframed;
   p->launched = true;
   return 0;
 }
@@ -521,8 +613,8 @@ int grdma_h2_pipe_sync(grdma_h2_pipe* p, uint64_t out[14], grdma_h2_event* event
   p->t_boundary = dr.t_boundary;
   float fms = 0, dms = 0;
   out[6] = out[7] = 0;
-  if (p->launched && hipEventElapsedTime(&fms, p->t_f0, p->t_f1) == hipSuccess) out[6] = (uint64_t)(fms * 1e3f);
-  if (p->launched && hipEventElapsedTime(&dms, p->t_d0, p->t_d1) == hipSuccess) out[7] = (uint64_t)(dms * 1e3f);
+  if (p->launched && p->timed && hipEventElapsedTime(&fms, p->t_f0, p->t_f1) == hipSuccess) out[6] = (uint64_t)(fms * 1e3f);
+  if (p->launched && p->timed && hipEventElapsedTime(&dms, p->t_d0, p->t_d1) == hipSuccess) out[7] = (uint64_t)(dms * 1e3f);
   const uint64_t m = std::min<uint64_t>(std::min<uint64_t>(dr.nevents, cap), p->ev_cap);
   if (events_out && m && hipMemcpy(events_out, p->d_ev, sizeof(grdma_h2_event) * m, hipMemcpyDeviceToHost) != hipSuccess)
     return -GRDMA_ERR_HIP;

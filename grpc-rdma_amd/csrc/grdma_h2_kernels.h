@@ -1,5 +1,5 @@
 // Device side of the HTTP/2 DATA framing (K6/K7) and deframing (K8/K9): the structures the kernels keep
-// in HBM and the kernels themselves (k_h2_frame, k_h2_deframe, k_h2_table_ops).  Included by
+// in HBM and the kernels themselves (k_h2_frame_index, k_h2_frame_emit, k_h2_deframe and the chunked deframer, k_h2_table_ops).  Included by
 // csrc/grdma_h2.hip, which holds the host API, and -- under the wave emulator of tests/cc/wave_emu.h -- by
 // tests/cc/h2_emu_host.cc, which runs k_h2_deframe on the CPU against the oracle.
 #ifndef GRDMA_H2_KERNELS_H
@@ -188,62 +188,145 @@ __device__ void walk_message(const grdma_h2_msg_dev& m, uint32_t max_frame, fram
   (void)pay_left;
 }
 
-// One thread lays out one message.  A message that ends with an inlined slice
-// (only an empty message does) lets the next header merge into it, so a thread
-// first replays the run of empty messages in front of it to learn the state of
-// the back slice.
-__global__ __launch_bounds__(256) void k_h2_frame(const grdma_h2_msg_dev* msgs, uint64_t nmsgs,
-                                                  uint32_t max_frame, grdma_sge* out,
-                                                  uint64_t cap, uint8_t* hdr, uint64_t hdr_cap,
-                                                  uint64_t* counts /* 3*nmsgs scratch */,
-                                                  grdma_h2_frame_result* res) {
+// Framing in two launches.  The layout of a message is a closed form unless empty messages are around: a
+// non-empty message whose predecessor is non-empty starts behind a by-reference slice (nothing to merge into), its
+// first frame is one inlined slice [frame header 9 | message header 5] plus the first payload piece, every further
+// frame a 9-byte inlined slice plus a payload piece -- 2 F slices, 32 F header-arena bytes, 9 F + 5 + len wire bytes
+// for F = ceil((5 + len) / max_frame) frames (max_frame > 5).  A message that ends with an inlined slice (only an
+// empty message does) lets the next header merge into it, so a run of empty messages and the message behind it are
+// laid out sequentially by the thread of the run's first message, as the reference would.
+//   k_h2_frame_index   one workgroup: per-message sizes (closed form, or the sequential walk around empty messages),
+//                      block scans -> the first slice slot and header-arena offset of every message, the totals;
+//   k_h2_frame_emit    one WAVE per message: lane j writes frame j, j + 64, ... (two 16-byte slice entries side by
+//                      side, one 16-byte header store) -- 256 messages of 64 frames in a few microseconds where one
+//                      thread per message took 150.
+struct grdma_h2_msg_pos {
+  uint64_t sl;    // first slice slot
+  uint64_t hdr;   // first byte in the header arena
+  uint32_t mode;  // 0 = laid out by the leader of its run, 1 = closed form, 2 = leader: sequential walk of the run
+  uint32_t pad;
+};
+
+__device__ __forceinline__ bool h2_msg_plain(const grdma_h2_msg_dev* msgs, uint64_t i, uint32_t max_frame) {
+  return max_frame > 5 && msgs[i].len != 0 && (i == 0 || msgs[i - 1].len != 0);
+}
+
+__global__ __launch_bounds__(256) void k_h2_frame_index(const grdma_h2_msg_dev* msgs, uint64_t nmsgs,
+                                                        uint32_t max_frame, uint64_t cap, uint64_t hdr_cap,
+                                                        grdma_h2_msg_pos* pos, grdma_h2_frame_result* res) {
   __shared__ uint64_t s_wave[4];
   const uint64_t tid = threadIdx.x;
   uint64_t overflow = 0;
-  // pass 1: sizes (serial over blocks of 256 messages; one block is launched)
   uint64_t base_sl = 0, base_hdr = 0, base_wire = 0;
   for (uint64_t m0 = 0; m0 < nmsgs; m0 += 256) {
     const uint64_t i = m0 + tid;
-    frame_walk w = {0, 0, 0, 0};
-    uint64_t merged_into_prev = 0;
+    uint64_t n_sl = 0, n_hdr = 0, n_wire = 0;
+    uint32_t mode = 0;
     if (i < nmsgs) {
-      // incoming back-slice state
-      uint64_t j = i;
-      while (j > 0 && msgs[j - 1].len == 0) j--;
-      frame_walk pre = {0, 0, 0, 0};
-      for (; j < i; j++) walk_message<false>(msgs[j], max_frame, &pre, nullptr, nullptr, ~0ull, ~0ull, &overflow);
-      frame_walk me = {0, 0, 0, pre.back_inl};
-      walk_message<false>(msgs[i], max_frame, &me, nullptr, nullptr, ~0ull, ~0ull, &overflow);
-      w = me;
-      merged_into_prev = pre.back_inl;
+      if (h2_msg_plain(msgs, i, max_frame)) {
+        const uint64_t fcb = 5 + msgs[i].len;
+        const uint64_t F = (fcb + max_frame - 1) / max_frame;
+        n_sl = 2 * F;
+        n_hdr = 32 * F;
+        n_wire = 9 * F + fcb;
+        mode = 1;
+      } else {
+        // incoming back-slice state: replay the run of empty messages in front
+        uint64_t j = i;
+        while (j > 0 && msgs[j - 1].len == 0) j--;
+        frame_walk pre = {0, 0, 0, 0};
+        for (; j < i; j++) walk_message<false>(msgs[j], max_frame, &pre, nullptr, nullptr, ~0ull, ~0ull, &overflow);
+        frame_walk me = {0, 0, 0, pre.back_inl};
+        walk_message<false>(msgs[i], max_frame, &me, nullptr, nullptr, ~0ull, ~0ull, &overflow);
+        n_sl = me.nslices;
+        n_hdr = me.hdr_off;
+        n_wire = me.wire;
+        mode = (i == 0 || msgs[i - 1].len != 0) ? 2u : 0u;
+      }
     }
     uint64_t tot_sl, tot_hdr, tot_wire;
-    const uint64_t x_sl = block_excl_scan(w.nslices, s_wave, &tot_sl);
-    const uint64_t x_hdr = block_excl_scan(w.hdr_off, s_wave, &tot_hdr);
-    block_excl_scan(w.wire, s_wave, &tot_wire);
-    if (i < nmsgs && (i == 0 || msgs[i - 1].len != 0)) {
-      // pass 2: emit at the exact position.  A run of empty messages shares
-      // inlined slices across message boundaries, so the first message of such
-      // a run emits the whole run (sequentially, like the reference would).
-      frame_walk me = {base_sl + x_sl, base_hdr + x_hdr, 0, 0};
-      uint64_t k = i;
-      for (;;) {
+    const uint64_t x_sl = block_excl_scan(n_sl, s_wave, &tot_sl);
+    const uint64_t x_hdr = block_excl_scan(n_hdr, s_wave, &tot_hdr);
+    block_excl_scan(n_wire, s_wave, &tot_wire);
+    if (i < nmsgs) {
+      grdma_h2_msg_pos q;
+      q.sl = base_sl + x_sl;
+      q.hdr = base_hdr + x_hdr;
+      q.mode = mode;
+      q.pad = 0;
+      pos[i] = q;
+    }
+    base_sl += tot_sl;
+    base_hdr += tot_hdr;
+    base_wire += tot_wire;
+  }
+  if (tid == 0) {
+    res->nslices = base_sl;
+    res->hdr_bytes = base_hdr;
+    res->wire_bytes = base_wire;
+    res->overflow = (base_sl > cap || base_hdr > hdr_cap) ? 1 : 0;
+  }
+}
+
+#define H2_EMIT_THREADS 256
+__global__ __launch_bounds__(H2_EMIT_THREADS) void k_h2_frame_emit(const grdma_h2_msg_dev* msgs, uint64_t nmsgs,
+                                                                  uint32_t max_frame, grdma_sge* out, uint64_t cap,
+                                                                  uint8_t* hdr, uint64_t hdr_cap,
+                                                                  const grdma_h2_msg_pos* pos) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t i = (uint64_t)blockIdx.x * (H2_EMIT_THREADS / 64) + (threadIdx.x >> 6);
+  if (i >= nmsgs) return;  // (wave-uniform)
+  const grdma_h2_msg_pos q = pos[i];
+  if (q.mode == 2) {
+    if (lane == 0) {
+      uint64_t overflow = 0;  // (k_h2_frame_index has reported it; here it only keeps the stores inside the arrays)
+      frame_walk me = {q.sl, q.hdr, 0, 0};
+      for (uint64_t k = i;;) {
         walk_message<true>(msgs[k], max_frame, &me, out, hdr, cap, hdr_cap, &overflow);
         if (msgs[k].len != 0 || k + 1 >= nmsgs) break;
         k++;
       }
     }
-    base_sl += tot_sl;
-    base_hdr += tot_hdr;
-    base_wire += tot_wire;
-    __syncthreads();
+    return;
   }
-  (void)counts;
-  if (overflow) atomicExch((unsigned long long*)&res->overflow, 1ull);
-  if (tid == 0) {
-    res->nslices = base_sl;
-    res->hdr_bytes = base_hdr;
-    res->wire_bytes = base_wire;
+  if (q.mode != 1) return;
+  const grdma_h2_msg_dev m = msgs[i];
+  const uint64_t fcb = 5 + m.len;
+  const uint64_t F = (fcb + max_frame - 1) / max_frame;
+  for (uint64_t j = (uint64_t)lane; j < F; j += 64) {
+    const uint64_t slot = q.sl + 2 * j, hoff = q.hdr + 32 * j;
+    if (slot + 2 > cap || hoff + 32 > hdr_cap) break;  // (reported by k_h2_frame_index)
+    const uint64_t done = j * max_frame;
+    const uint64_t send = fcb - done < max_frame ? fcb - done : max_frame;
+    const uint64_t last = ((m.flags & 2) && done + send == fcb) ? 1 : 0;
+    // frame header, big-endian fields (frame_data.cc:73-82), then -- first frame -- the message header
+    // (chttp2_transport.cc:1504-1509): byte k of the slot is byte k of the two words
+    uint64_t w0 = ((send >> 16) & 0xFF) | (((send >> 8) & 0xFF) << 8) | ((send & 0xFF) << 16) | (last << 32) |
+                  ((uint64_t)((m.stream_id >> 24) & 0xFF) << 40) | ((uint64_t)((m.stream_id >> 16) & 0xFF) << 48) |
+                  ((uint64_t)((m.stream_id >> 8) & 0xFF) << 56);
+    uint64_t w1 = (uint64_t)(m.stream_id & 0xFF);
+    uint64_t hl = 9;
+    if (j == 0) {
+      w1 |= (uint64_t)((m.flags & 1) ? 1 : 0) << 8 | ((m.len >> 24) & 0xFF) << 16 | ((m.len >> 16) & 0xFF) << 24 |
+            ((m.len >> 8) & 0xFF) << 32 | (m.len & 0xFF) << 40;
+      hl = 14;
+    }
+    uint8_t* hp = hdr + hoff;
+    u64x2 hv;
+    hv.x = w0;
+    hv.y = w1;
+    if (((uint64_t)hp & 15) == 0) {
+      *reinterpret_cast<u64x2*>(hp) = hv;  // (the slot is 32 bytes: the bytes behind the header are nobody's)
+    } else {
+      for (uint64_t k = 0; k < hl; k++) hp[k] = (uint8_t)((k < 8 ? w0 >> (8 * k) : w1 >> (8 * (k - 8))) & 0xFF);
+    }
+    u64x2 e0, e1;
+    e0.x = (uint64_t)hp;
+    e0.y = hl;
+    e1.x = (uint64_t)(m.payload + (j == 0 ? 0 : done - 5));
+    e1.y = j == 0 ? send - 5 : send;
+    *reinterpret_cast<u64x2*>(&out[slot]) = e0;
+    *reinterpret_cast<u64x2*>(&out[slot + 1]) = e1;
   }
 }
 
@@ -960,38 +1043,42 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
 // 33 000 slices in 0.8 ms however wide the machine is.  In a streaming call, though, the parser is in the SAME
 // state in front of every slice in which a message starts (frame boundary; the stream's data parser either at a
 // message header -- sending side -- or a few bytes short of the message end -- receiving side): the state the
-// boundary step (grdma_h2_fast.h) records as it goes (grdma_h2_parser_dev::hint_*).  So:
-//   k_h2_chunk_plan    picks K - 1 such slices near the K-quantiles of the list (h2_boundary_match on the staged
-//                      bytes of every slice near a quantile, the first hit is the cut), and gives every chunk a
-//                      private copy of the parser block and of the stream map, chunks 1 .. K-1 in the hinted state;
-//   k_h2_deframe_chunks  K workgroups, each the ordinary deframer (h2_deframe_body) over its chunk, events into a
-//                      private segment; afterwards each checks that its stream map is the one it started with;
-//   k_h2_chunk_merge   verifies the CHAIN -- chunk k must have ended, without error, exactly where and in exactly
-//                      the state chunk k + 1 was assumed to start -- and only then concatenates the events (slice
-//                      indices rebased), installs the last chunk's parser block and stream map, and says so;
-//   k_h2_deframe_unless_merged   the ordinary deframer over the whole list when anything did not hold (no hint
-//                      yet, a cut that was no frame boundary, a stream that opened or closed, an error, events
-//                      that did not fit): nothing of the chunks' work was visible, the result is the sequential one.
+// boundary step (grdma_h2_fast.h) records as it goes (grdma_h2_parser_dev::hint_*).  So, in two launches:
+//   k_h2_deframe_chunks   K workgroups.  Workgroup k finds its own two cuts -- the first slice at or behind the
+//                      k-th and the (k+1)-th K-quantile of the list in which a message starts for the hinted stream
+//                      (h2_boundary_match on the staged bytes; cut 0 = 0, cut K = the end) --, copies the parser
+//                      block and the stream map into private ones (chunks 1.. in the hinted state), runs the
+//                      ordinary deframer (h2_deframe_body) over its chunk into a private event segment, and checks
+//                      that its stream map is the one it started with;
+//   k_h2_merge_or_deframe   every workgroup verifies the CHAIN -- chunk k must have ended, without error, exactly
+//                      where and in exactly the state chunk k + 1 was assumed to start -- and only then the events
+//                      are concatenated (slice indices rebased) and the last chunk's parser block and stream map
+//                      installed; when anything did not hold (no hint yet, a cut that was no frame boundary, a
+//                      stream that opened or closed, an error, events that did not fit) workgroup 0 runs the ordinary
+//                      deframer over the whole list: nothing of the chunks' work was visible, the result is the
+//                      sequential one.
 // The events, the parser state and the stream map are those of the sequential parse by construction.
 // ------------------------------------------------------------------------------------------------------------
-#define H2_KMAX 16
-#define H2_CHUNK_MIN_SLICES 2048
+#define H2_KMAX 128
+#define H2_CHUNK_MIN_SLICES 2048   // lists shorter than this go to the sequential deframer directly
+#define H2_CHUNK_SLICES 256        // a chunk is at least this long (K = min(wanted, nslices / this))
+#define H2_MERGE_GRID 64
 struct grdma_h2_chunks {
   uint32_t K;          // chunks of this call, 0 = no plan
-  uint32_t ok;         // k_h2_chunk_merge: 1 = merged (the sequential pass has nothing to do)
+  uint32_t ok;         // k_h2_merge_or_deframe: 1 = merged
   uint32_t hint_idx;   // slot of the hinted stream in the stream map
   uint32_t want;       // chunks the host asks for (<= H2_KMAX)
   uint64_t s_begin[H2_KMAX + 1];
-  grdma_h2_parser_dev ref;            // the parser block the plan started from
+  grdma_h2_parser_dev ref;            // the parser block the call started from
   grdma_h2_stream_dev ref_entry;      // ... and the hinted stream's entry: what chunks 1.. are assumed to start with
   grdma_h2_parser_dev gp[H2_KMAX];
   grdma_h2_deframe_result res[H2_KMAX];
   grdma_h2_stream_dev end_entry[H2_KMAX];
-  uint32_t clean[H2_KMAX];
+  uint32_t clean[H2_KMAX];            // bit 0 = both cuts found, bit 1 = every other map entry as it was
   uint64_t n_planned, n_merged;       // calls that were planned / merged since the parser was created
   grdma_h2_stream_dev* tabs;          // [H2_KMAX][slots] private stream maps
-  grdma_h2_event* ev_tmp;             // [H2_KMAX][ev_stride] private event segments
-  uint64_t ev_stride;
+  grdma_h2_event* ev_tmp;             // ev_total events: K private segments of ev_total / K
+  uint64_t ev_total;
   uint32_t slots, pad;
 };
 
@@ -1022,126 +1109,144 @@ __device__ __forceinline__ void h2_first32(const uint8_t* arena, uint64_t off, u
   c[3] = h2_keep(o3, 24, n);
 }
 
-#define H2_PLAN_THREADS 1024
-__global__ __launch_bounds__(H2_PLAN_THREADS) void k_h2_chunk_plan(grdma_h2_parser_dev* gp, const uint8_t* arena,
-                                                                   const grdma_slice_out* slices, uint64_t nslices,
-                                                                   grdma_h2_chunks* ctl) {
+// how many chunks a list of nslices is cut into (every workgroup and the merge compute the same number)
+__device__ __forceinline__ uint32_t h2_chunk_count(uint32_t want, uint64_t nslices) {
+  uint64_t K = want < H2_KMAX ? want : H2_KMAX;
+  const uint64_t fit = nslices / H2_CHUNK_SLICES;
+  if (K > fit) K = fit;
+  return K >= 2 ? (uint32_t)K : 0u;
+}
+
+// The first slice at or behind `from` in which a message starts for the hinted stream (one wave; ~0 = none within
+// `span` slices; the end of the list when the list ends first).  The match is the boundary step's own (grdma_h2_fast.h): a slice it would take from the hinted state.
+__device__ __forceinline__ uint64_t h2_find_cut(const grdma_h2_parser_dev& P, const uint8_t* arena,
+                                                const grdma_slice_out* slices, uint64_t nslices, uint64_t from,
+                                                uint64_t span, int lane) {
+  const uint64_t end = from + span < nslices ? from + span : nslices;
+  for (uint64_t base = from; base < end; base += 64) {
+    const uint64_t sx = base + (uint64_t)lane;
+    const bool have = sx < end;
+    const u64x2 d = *reinterpret_cast<const u64x2*>(&slices[have ? sx : nslices - 1]);
+    const u64x2 dn = *reinterpret_cast<const u64x2*>(&slices[sx + 1 < nslices ? sx + 1 : nslices - 1]);
+    uint64_t c[4];
+    h2_first32(arena, d.x, have ? d.y : 0, c);
+    const h2_bstep B = h2_boundary_match(c[0], c[1], c[2], c[3], have ? d.y : 0, sx + 1 < nslices ? dn.y : ~0ull,
+                                         P.hint_state, P.hint_fsz, P.hint_id, P.max_frame_size);
+    const uint64_t hit = __ballot(have && B.ok);
+    if (hit) return base + (uint64_t)__builtin_ctzll(hit);
+  }
+  return end == nslices ? nslices : ~0ull;  // (no message starts behind `from`: the chunk in front runs to the end)
+}
+
+__global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe_chunks(grdma_h2_parser_dev* gp, grdma_h2_chunks* ctl,
+                                                                         const uint8_t* arena, const grdma_slice_out* slices,
+                                                                         uint64_t nslices) {
+  const uint32_t k = blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const int lane = tid & 63;
   const uint32_t wave = tid >> 6;
-  const grdma_h2_parser_dev P = *gp;
+  const grdma_h2_parser_dev P = *gp;  // (nothing writes the connection's block before the merge)
   const uint32_t slots = P.tab_mask + 1;
-  uint32_t K = ctl->want < H2_KMAX ? ctl->want : H2_KMAX;
-  __shared__ uint64_t s_cut[H2_KMAX + 1];
-  __shared__ int s_idx;
-  if (tid == 0) {
-    ctl->K = 0;
-    ctl->ok = 0;
-    s_idx = -1;
-  }
+  const uint32_t K = h2_chunk_count(ctl->want, nslices);
   const bool can = K >= 2 && P.error == 0 && P.hint_valid && P.boundary_step && P.state == ST_FH0 &&
-                   P.expect_continuation == 0 && !P.is_first_frame && nslices >= H2_CHUNK_MIN_SLICES &&
-                   slots == ctl->slots && nslices < (1ull << 31);
-  if (!can) return;  // (uniform)
-  while (K > 2 && nslices / K < H2_CHUNK_MIN_SLICES / 2) K--;
-  // wave j looks for the first slice at or behind the j-th quantile in which a message starts for the hinted stream
-  if (wave >= 1 && wave < K) {
-    const uint64_t t0 = nslices * wave / K, t1 = nslices * (wave + 1) / K;
-    uint64_t found = ~0ull;
-    for (uint64_t base = t0; base < t1 && found == ~0ull; base += 64) {
-      const uint64_t sx = base + (uint64_t)lane;
-      const bool have = sx < t1;
-      const u64x2 d = *reinterpret_cast<const u64x2*>(&slices[have ? sx : nslices - 1]);
-      const u64x2 dn = *reinterpret_cast<const u64x2*>(&slices[sx + 1 < nslices ? sx + 1 : nslices - 1]);
-      uint64_t c[4];
-      h2_first32(arena, d.x, have ? d.y : 0, c);
-      const h2_bstep B = h2_boundary_match(c[0], c[1], c[2], c[3], have ? d.y : 0, sx + 1 < nslices ? dn.y : ~0ull,
-                                           P.hint_state, P.hint_fsz, P.hint_id, P.max_frame_size);
-      const uint64_t hit = __ballot(have && B.ok);
-      if (hit) found = base + (uint64_t)__builtin_ctzll(hit);
+                   P.expect_continuation == 0 && !P.is_first_frame && slots == ctl->slots && nslices < (1ull << 31);
+  if (!can) {  // (uniform over the grid: the merge finds K = 0 and runs the sequential deframer)
+    if (k == 0 && tid == 0) {
+      ctl->K = 0;
+      ctl->ok = 0;
     }
-    if (lane == 0) s_cut[wave] = found;
+    return;
   }
-  if (tid == 0) {
-    s_cut[0] = 0;
-    s_idx = tab_find(P.tab, P.tab_mask, P.hint_id);
-  }
-  __syncthreads();
-  if (tid == 0) s_cut[K] = nslices;
-  __syncthreads();
-  bool good = s_idx >= 0;
-  for (uint32_t j = 1; j < K; j++) good = good && s_cut[j] != ~0ull && s_cut[j] > s_cut[j - 1];
-  if (!good) return;  // (uniform)
-  // private stream maps (chunks 1.. with the hinted stream's data parser in the hinted state), parser blocks
-  const grdma_h2_stream_dev ref_entry = P.tab[s_idx];
-  for (uint32_t i = tid; i < K * slots; i += H2_PLAN_THREADS) {
-    const uint32_t k = i / slots, e = i - k * slots;
-    grdma_h2_stream_dev v = P.tab[e];
-    if (k >= 1 && e == (uint32_t)s_idx) {
-      v.state = P.hint_state;
-      v.frame_size = P.hint_fsz;
-    }
-    ctl->tabs[i] = v;
-  }
-  if (tid < K) {
-    grdma_h2_parser_dev g = P;
-    g.tab = ctl->tabs + (size_t)tid * slots;
-    ctl->gp[tid] = g;  // (chunks 1..: P itself IS at a frame boundary with nothing pending -- see `can`)
-    ctl->s_begin[tid] = s_cut[tid];
-    ctl->clean[tid] = 0;
-  }
-  if (tid == 0) {
-    ctl->s_begin[K] = nslices;
-    ctl->ref = P;
-    ctl->ref_entry = ref_entry;
-    ctl->hint_idx = (uint32_t)s_idx;
-    ctl->n_planned++;
-    ctl->K = K;
-  }
-}
-
-__global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe_chunks(grdma_h2_chunks* ctl, const uint8_t* arena,
-                                                                         const grdma_slice_out* slices) {
-  const uint32_t k = blockIdx.x;
-  if (k >= ctl->K) return;  // (uniform)
-  const uint64_t s0 = ctl->s_begin[k], s1 = ctl->s_begin[k + 1];
-  h2_deframe_body(&ctl->gp[k], arena, slices + s0, s1 - s0, ctl->ev_tmp + (size_t)k * ctl->ev_stride, ctl->ev_stride,
-                  &ctl->res[k]);
-  // every wave is back (the staging waves when the parser said stop); the parser's stores to its map are its own
-  // wave's: make them visible to the comparing threads
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (k >= K) return;
+  __shared__ uint64_t s_cut[2];
+  __shared__ int s_idx;
   __shared__ uint32_t s_dirty;
-  if (threadIdx.x == 0) s_dirty = 0;
+  // my two cuts (wave 0: where I start, wave 1: where the next chunk starts), the hinted stream's slot (wave 2)
+  if (wave < 2) {
+    const uint32_t j = k + wave;
+    const uint64_t span = 8 * (nslices / K);
+    uint64_t cut = j == 0 ? 0 : j == K ? nslices : h2_find_cut(P, arena, slices, nslices, nslices * j / K, span, lane);
+    if (lane == 0) s_cut[wave] = cut;
+  } else if (tid == 128) {
+    s_idx = tab_find(P.tab, P.tab_mask, P.hint_id);
+    s_dirty = 0;
+  }
   __syncthreads();
-  const uint32_t slots = ctl->slots, hint = ctl->hint_idx;
-  const grdma_h2_stream_dev* mine = ctl->tabs + (size_t)k * slots;
-  const grdma_h2_stream_dev* orig = ctl->ref.tab;
+  const uint64_t s0 = s_cut[0], s1 = s_cut[1];
+  const int idx = s_idx;
+  const bool found = s0 != ~0ull && s1 != ~0ull && idx >= 0;  // (s0 <= s1: both are "first at or behind" a quantile)
+  grdma_h2_stream_dev* const mine = ctl->tabs + (size_t)k * slots;
+  if (found) {
+    // private stream map (chunks 1.. with the hinted stream's data parser in the hinted state) and parser block
+    for (uint32_t e = tid; e < slots; e += H2_DEFRAME_THREADS) {
+      grdma_h2_stream_dev v = P.tab[e];
+      if (k >= 1 && e == (uint32_t)idx) {
+        v.state = P.hint_state;
+        v.frame_size = P.hint_fsz;
+      }
+      mine[e] = v;
+    }
+  }
+  if (tid == 0) {
+    grdma_h2_parser_dev g = P;  // (chunks 1..: P itself IS at a frame boundary with nothing pending -- see `can`)
+    g.tab = mine;
+    ctl->gp[k] = g;
+    ctl->s_begin[k] = found ? s0 : 0;
+    ctl->clean[k] = 0;
+    if (k == 0) {
+      ctl->s_begin[K] = nslices;
+      ctl->ref = P;
+      if (idx >= 0) ctl->ref_entry = P.tab[idx];
+      ctl->hint_idx = (uint32_t)(idx >= 0 ? idx : 0);
+      ctl->n_planned++;
+      ctl->ok = 0;
+      ctl->K = K;
+    }
+  }
+  if (!found) return;  // (uniform; clean[k] = 0 fails the chain)
+  // (hand-offs inside one workgroup: the barrier orders them -- an agent-scope release here would write the XCD's
+  // whole L2 back, dirty lines of the copy kernels included, once per workgroup)
+  __syncthreads();
+  if (s1 > s0) {
+    const uint64_t stride = ctl->ev_total / K;
+    h2_deframe_body(&ctl->gp[k], arena, slices + s0, s1 - s0, ctl->ev_tmp + (size_t)k * stride, stride, &ctl->res[k]);
+  } else if (tid == 0) {
+    // an empty chunk (its quantile and the next one's lie in front of the same message start): it ends where and as
+    // it starts, which is what the next chunk assumes
+    grdma_h2_deframe_result r;
+    r.nevents = r.overflow = r.slices_done = 0;
+    r.error = 0;
+    r.bulk_steps = r.bulk_frames = r.t_wait = r.t_bulk = r.t_total = r.t_serial = r.boundary_steps = r.t_boundary = 0;
+    ctl->res[k] = r;
+  }
+  // every wave is back (the staging waves when the parser said stop); the parser's stores to its map are its own
+  // wave's: the barrier makes them visible to the comparing threads
+  __syncthreads();
+  const grdma_h2_stream_dev* orig = P.tab;
   bool dirty = false;
-  for (uint32_t i = threadIdx.x; i < slots; i += H2_DEFRAME_THREADS) {
-    if (i == hint) continue;
+  for (uint32_t i = tid; i < slots; i += H2_DEFRAME_THREADS) {
+    if (i == (uint32_t)idx) continue;
     const u64x2 a = *reinterpret_cast<const u64x2*>(&mine[i]), b = *reinterpret_cast<const u64x2*>(&orig[i]);
     dirty |= a.x != b.x || a.y != b.y;
   }
   static_assert(sizeof(grdma_h2_stream_dev) == 16, "two words per map entry");
   if (dirty) s_dirty = 1;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    ctl->clean[k] = s_dirty ? 0u : 1u;
-    ctl->end_entry[k] = mine[hint];
+  if (tid == 0) {
+    ctl->clean[k] = 1u | (s_dirty ? 0u : 2u);
+    ctl->end_entry[k] = mine[idx];
   }
 }
 
-// is the end of chunk k the start chunk k + 1 was given?
+// is the end of chunk k the start the chunk behind it was given?
 __device__ __forceinline__ bool h2_chunk_link_ok(const grdma_h2_chunks* ctl, uint32_t k) {
   const grdma_h2_deframe_result& r = ctl->res[k];
   const grdma_h2_parser_dev& g = ctl->gp[k];
   const grdma_h2_parser_dev& R = ctl->ref;
   const grdma_h2_stream_dev& e = ctl->end_entry[k];
   const grdma_h2_stream_dev& re = ctl->ref_entry;
+  if (ctl->clean[k] != 3u) return false;
   if (r.error != 0 || r.overflow != 0 || r.slices_done != ctl->s_begin[k + 1] - ctl->s_begin[k]) return false;
-  if (!ctl->clean[k]) return false;
   if (g.state != ST_FH0 || g.expect_continuation != 0 || g.is_first_frame != 0 || g.error != 0) return false;
   if (g.last_new_stream_id != R.last_new_stream_id || g.live_streams != R.live_streams) return false;
   if (e.stream_id != R.hint_id || e.state != R.hint_state || (e.state == 5 && e.frame_size != R.hint_fsz)) return false;
@@ -1151,71 +1256,106 @@ __device__ __forceinline__ bool h2_chunk_link_ok(const grdma_h2_chunks* ctl, uin
   return true;
 }
 
-#define H2_MERGE_THREADS 256
-__global__ __launch_bounds__(H2_MERGE_THREADS) void k_h2_chunk_merge(grdma_h2_parser_dev* gp, grdma_h2_chunks* ctl,
-                                                                     grdma_h2_event* ev, uint64_t ev_cap,
-                                                                     grdma_h2_deframe_result* res) {
+__global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_merge_or_deframe(grdma_h2_parser_dev* gp, grdma_h2_chunks* ctl,
+                                                                           const uint8_t* arena, const grdma_slice_out* slices,
+                                                                           uint64_t nslices, grdma_h2_event* ev, uint64_t ev_cap,
+                                                                           grdma_h2_deframe_result* res) {
+  const uint32_t tid = threadIdx.x;
   const uint32_t K = ctl->K;
-  if (K == 0) return;  // (uniform; the sequential pass does the call)
-  // every workgroup verifies the chain itself (a few hundred bytes of control data): no inter-workgroup wait
-  bool ok = true;
-  uint64_t pre[H2_KMAX + 1];
-  pre[0] = 0;
-  for (uint32_t k = 0; k < K; k++) {
-    if (k + 1 < K) ok = ok && h2_chunk_link_ok(ctl, k);
-    else ok = ok && ctl->res[k].error == 0 && ctl->res[k].overflow == 0 &&
-              ctl->res[k].slices_done == ctl->s_begin[k + 1] - ctl->s_begin[k];
-    pre[k + 1] = pre[k] + ctl->res[k].nevents;
-  }
-  ok = ok && pre[K] <= ev_cap;
-  if (!ok) return;  // (uniform; ctl->ok stays 0)
-  const uint64_t total = pre[K];
-  const uint64_t per = (total + gridDim.x - 1) / gridDim.x;
-  const uint64_t i0 = (uint64_t)blockIdx.x * per, i1 = i0 + per < total ? i0 + per : total;
-  for (uint64_t i = i0 + threadIdx.x; i < i1; i += H2_MERGE_THREADS) {
-    uint32_t k = 0;
-    while (k + 1 < K && i >= pre[k + 1]) k++;
-    const uint64_t* src = reinterpret_cast<const uint64_t*>(ctl->ev_tmp + (size_t)k * ctl->ev_stride + (i - pre[k]));
-    const uint64_t w0 = src[0], w1 = src[1];
-    uint64_t w2 = src[2];
-    w2 += ctl->s_begin[k] << 32;  // the slice index of an event is its high half: rebase it on the chunk's first slice
-    uint64_t* dst = reinterpret_cast<uint64_t*>(ev + i);
-    dst[0] = w0;
-    dst[1] = w1;
-    dst[2] = w2;
-  }
-  if (blockIdx.x == 0) {
-    // the last chunk's parser block and stream map are the connection's
-    const uint32_t slots = ctl->slots;
-    grdma_h2_stream_dev* orig = ctl->ref.tab;
-    const grdma_h2_stream_dev* last = ctl->tabs + (size_t)(K - 1) * slots;
-    for (uint32_t i = threadIdx.x; i < slots; i += H2_MERGE_THREADS) orig[i] = last[i];
-    if (threadIdx.x == 0) {
-      grdma_h2_parser_dev g = ctl->gp[K - 1];
-      g.tab = orig;
-      *gp = g;
-      grdma_h2_deframe_result r = ctl->res[K - 1];
-      r.nevents = total;
-      r.slices_done = ctl->s_begin[K];
-      for (uint32_t k = 0; k + 1 < K; k++) {
-        r.bulk_steps += ctl->res[k].bulk_steps;
-        r.bulk_frames += ctl->res[k].bulk_frames;
-        r.boundary_steps += ctl->res[k].boundary_steps;
-        if (ctl->res[k].t_total > r.t_total) r.t_total = ctl->res[k].t_total;  // (the chunks ran side by side)
+  __shared__ uint64_t s_pre[H2_KMAX + 1];
+  __shared__ uint32_t s_bad;
+  // every workgroup verifies the chain itself (a few KB of control data): no inter-workgroup wait.  The last chunk
+  // that holds slices may end in any state (it is the call's end); the ones in front of it must link.
+  if (tid == 0) s_bad = K == 0 ? 1u : 0u;
+  __syncthreads();
+  if (K != 0) {
+    __shared__ uint32_t s_last;
+    __shared__ unsigned long long s_stat[4];
+    if (tid < 4) s_stat[tid] = 0;
+    if (tid == 64) {  // the last chunk that holds slices (chunk 0 always does)
+      uint32_t last = K - 1;
+      while (last > 0 && ctl->s_begin[last] == ctl->s_begin[last + 1]) last--;
+      s_last = last;
+    }
+    if (tid <= H2_KMAX) s_pre[tid] = 0;
+    __syncthreads();
+    const uint32_t last = s_last;
+    if (tid < K) {
+      bool ok;
+      if (tid < last) ok = h2_chunk_link_ok(ctl, tid);
+      else if (tid == last) ok = (ctl->clean[tid] & 1u) && ctl->res[tid].error == 0 && ctl->res[tid].overflow == 0 &&
+                                ctl->res[tid].slices_done == ctl->s_begin[tid + 1] - ctl->s_begin[tid];
+      else ok = (ctl->clean[tid] & 1u) != 0;  // empty chunks behind the last one
+      if (!ok) s_bad = 1;
+      s_pre[tid + 1] = ok ? ctl->res[tid].nevents : 0;
+    }
+    __syncthreads();
+    if (tid < 64) {  // inclusive prefix sums of the event counts: two wave scans (K <= 128)
+      static_assert(H2_KMAX == 128, "two entries per lane");
+      const uint64_t lo = wave_incl_scan(s_pre[tid + 1], (int)tid);
+      const uint64_t lo_tot = __shfl(lo, 63, 64);
+      const uint64_t hi = wave_incl_scan(s_pre[tid + 65], (int)tid) + lo_tot;
+      s_pre[tid + 1] = lo;
+      s_pre[tid + 65] = hi;
+      if (tid == 63 && hi > ev_cap) s_bad = 1;  // (entries behind K are zero: hi of lane 63 is the total)
+    }
+    __syncthreads();
+    if (!s_bad) {
+      const uint64_t total = s_pre[K];
+      const uint64_t stride = ctl->ev_total / K;
+      const uint64_t per = (total + gridDim.x - 1) / gridDim.x;
+      const uint64_t i0 = (uint64_t)blockIdx.x * per, i1 = i0 + per < total ? i0 + per : total;
+      for (uint64_t i = i0 + tid; i < i1; i += H2_DEFRAME_THREADS) {
+        uint32_t lo = 0, hi = K;  // the chunk with s_pre[k] <= i < s_pre[k + 1]
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_pre[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t k = lo;
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(ctl->ev_tmp + (size_t)k * stride + (i - s_pre[k]));
+        const uint64_t w0 = src[0], w1 = src[1];
+        uint64_t w2 = src[2];
+        w2 += ctl->s_begin[k] << 32;  // the slice index of an event is its high half: rebase it on the chunk's first slice
+        uint64_t* dst = reinterpret_cast<uint64_t*>(ev + i);
+        dst[0] = w0;
+        dst[1] = w1;
+        dst[2] = w2;
       }
-      *res = r;
-      ctl->n_merged++;
-      ctl->ok = 1;
+      if (blockIdx.x == 0) {
+        // the last chunk's parser block and stream map are the connection's
+        const uint32_t slots = ctl->slots;
+        grdma_h2_stream_dev* orig = ctl->ref.tab;
+        const grdma_h2_stream_dev* lastt = ctl->tabs + (size_t)last * slots;
+        for (uint32_t i = tid; i < slots; i += H2_DEFRAME_THREADS) orig[i] = lastt[i];
+        if (tid < K) {  // the call's counters: sums over the chunks, the longest chunk's clock (they ran side by side)
+          const grdma_h2_deframe_result& c = ctl->res[tid];
+          atomicAdd(&s_stat[0], (unsigned long long)c.bulk_steps);
+          atomicAdd(&s_stat[1], (unsigned long long)c.bulk_frames);
+          atomicAdd(&s_stat[2], (unsigned long long)c.boundary_steps);
+          atomicMax(&s_stat[3], (unsigned long long)c.t_total);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          grdma_h2_parser_dev g = ctl->gp[last];
+          g.tab = orig;
+          *gp = g;
+          grdma_h2_deframe_result r = ctl->res[last];
+          r.nevents = total;
+          r.slices_done = ctl->s_begin[K];
+          r.bulk_steps = s_stat[0];
+          r.bulk_frames = s_stat[1];
+          r.boundary_steps = s_stat[2];
+          r.t_total = s_stat[3];
+          *res = r;
+          ctl->n_merged++;
+          ctl->ok = 1;
+        }
+      }
+      return;
     }
   }
-}
-
-__global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe_unless_merged(const grdma_h2_chunks* ctl,
-                                                                                grdma_h2_parser_dev* gp, const uint8_t* arena,
-                                                                                const grdma_slice_out* slices, uint64_t nslices,
-                                                                                grdma_h2_event* ev, uint64_t ev_cap,
-                                                                                grdma_h2_deframe_result* res) {
-  if (ctl->K != 0 && ctl->ok != 0) return;  // (uniform; written by kernels that have completed)
+  // not merged: the ordinary deframer over the whole list, on the connection's own block and map
+  if (blockIdx.x != 0) return;
   h2_deframe_body(gp, arena, slices, nslices, ev, ev_cap, res);
 }
 

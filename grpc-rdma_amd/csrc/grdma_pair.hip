@@ -2194,6 +2194,10 @@ struct grdma_stream_job {
                                       // drain of the same round may walk up to (grdma_rx_op::limit_ptr)
   grdma_conn** d_txconns = nullptr;   // [n]: the sending ends, for the arrival report behind the last round
   hipGraphExec_t exec = nullptr;
+  // kernel nodes another stage hangs in front of / behind the job inside its graph (grdma_job_set_hooks: the HTTP/2
+  // pipe's framing and deframing): a chain in front of the first round, a chain behind k_tx_commit
+  std::vector<grdma_job_hook> pre_hooks, post_hooks;
+  uint64_t hooks_gen = 0, exec_hooks_gen = 0;
   uint64_t exec_rounds = 0;
   int exec_pipeline = -1;
   int exec_fastkey = -1;              // rx_fast | tx_fast << 1 | deep << 2 the graph was built for
@@ -2240,7 +2244,8 @@ namespace {
 inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 : 2); }
 inline int job_fastkey(const grdma_stream_job* j) { return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0) | (j->pair_job ? 8 : 0); }
 inline bool job_exec_stale(const grdma_stream_job* j) {
-  return !j->exec || j->exec_rounds != j->rounds || j->exec_pipeline != j->pipeline || j->exec_fastkey != job_fastkey(j);
+  return !j->exec || j->exec_rounds != j->rounds || j->exec_pipeline != j->pipeline || j->exec_fastkey != job_fastkey(j) ||
+         j->exec_hooks_gen != j->hooks_gen;
 }
 
 // the send plan of round t: priced from the index of the slice buffer (built in front of the first round of a
@@ -2499,14 +2504,43 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
   hipGraph_t g;
   HIP_TRY(hipGraphCreate(&g, 0));
   std::vector<hipGraphNode_t> P(R), G(R), W(R), X(R), A(R);
+  // hook nodes: a chain of kernels; `after` (may be null) is what the first one waits for, the last one is returned
+  hipError_t hook_err = hipSuccess;
+  auto add_hooks = [&](std::vector<grdma_job_hook>& hooks, hipGraphNode_t after) -> hipGraphNode_t {
+    for (grdma_job_hook& h : hooks) {
+      void* args[GRDMA_JOB_HOOK_ARGS];
+      for (uint32_t a = 0; a < GRDMA_JOB_HOOK_ARGS; a++) args[a] = &h.args[a];
+      hipKernelNodeParams np;
+      memset(&np, 0, sizeof(np));
+      np.func = const_cast<void*>(h.fn);
+      np.gridDim = dim3(h.grid);
+      np.blockDim = dim3(h.threads);
+      np.kernelParams = args;
+      hipGraphNode_t node = nullptr;
+      const hipError_t he = hipGraphAddKernelNode(&node, g, after ? &after : nullptr, after ? 1 : 0, &np);
+      if (he != hipSuccess) {
+        hook_err = he;
+        return after;
+      }
+      after = node;
+    }
+    return after;
+  };
+  const hipGraphNode_t pre_last = R > 0 ? add_hooks(j->pre_hooks, nullptr) : nullptr;
   // (every node hands over three pointer-sized parameters; a kernel with fewer ignores the rest)
   auto add3 = [&](hipGraphNode_t* node, const void* fn, dim3 grid, uint32_t threads, const void* arg, const void* arg2,
                   const void* arg3, std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
     std::vector<hipGraphNode_t> d;
     for (hipGraphNode_t x : deps)
       if (x) d.push_back(x);
-    void* args[3] = {const_cast<void*>(static_cast<const void*>(&arg)), const_cast<void*>(static_cast<const void*>(&arg2)),
-                     const_cast<void*>(static_cast<const void*>(&arg3))};
+    if (d.empty() && pre_last) d.push_back(pre_last);  // a root of the job waits for the stage in front of it
+    // (an array of GRDMA_JOB_HOOK_ARGS entries for every node -- the runtime reads as many as the kernel has)
+    static uint64_t none = 0;
+    void* args[GRDMA_JOB_HOOK_ARGS];
+    for (uint32_t a = 0; a < GRDMA_JOB_HOOK_ARGS; a++) args[a] = &none;
+    args[0] = const_cast<void*>(static_cast<const void*>(&arg));
+    args[1] = const_cast<void*>(static_cast<const void*>(&arg2));
+    args[2] = const_cast<void*>(static_cast<const void*>(&arg3));
     hipKernelNodeParams np;
     memset(&np, 0, sizeof(np));
     np.func = const_cast<void*>(fn);
@@ -2651,9 +2685,11 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
   }
   if (e == hipSuccess && R > 0) {
     // behind the last round: the connection's arrival report and the state lines (k_tx_commit)
-    hipGraphNode_t cm;
+    hipGraphNode_t cm = nullptr;
     e = add2(&cm, grdma_kernel_fn(5), dim3(n), 64, j->d_txconns, nullptr, {W[R - 1] ? W[R - 1] : G[R - 1], A[R - 1]});
+    if (e == hipSuccess) add_hooks(j->post_hooks, cm);  // (every node of the job reaches k_tx_commit)
   }
+  if (e == hipSuccess) e = hook_err;
   if (e != hipSuccess) {
     hipGraphDestroy(g);
     return fail(GRDMA_ERR_HIP, "graph construction failed: %s", hipGetErrorString(e));
@@ -3085,6 +3121,7 @@ int job_ensure_exec(grdma_stream_job* j) {
   j->exec_rounds = j->rounds;
   j->exec_pipeline = j->pipeline;
   j->exec_fastkey = job_fastkey(j);
+  j->exec_hooks_gen = j->hooks_gen;
   return 0;
 }
 }  // namespace
@@ -3222,6 +3259,18 @@ extern "C" __attribute__((visibility("hidden"))) int grdma_job_link_view(grdma_s
   *d_slices = l.d_slices;
   *dst = l.dst;
   *stream = j->stream;
+  return 0;
+}
+
+// Kernel nodes in front of and behind the job INSIDE its graph (one launch per step, no graph boundary -- ~15-20 us of
+// idle device each -- between the stages); null / 0 removes them.  The graph is rebuilt at the next launch.
+extern "C" __attribute__((visibility("hidden"))) int grdma_job_set_hooks(grdma_stream_job* j, const grdma_job_hook* pre,
+                                                                         uint32_t n_pre, const grdma_job_hook* post,
+                                                                         uint32_t n_post) {
+  if (!j) return -1;
+  j->pre_hooks.assign(pre, pre + (pre ? n_pre : 0));
+  j->post_hooks.assign(post, post + (post ? n_post : 0));
+  j->hooks_gen++;
   return 0;
 }
 

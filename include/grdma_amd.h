@@ -500,7 +500,7 @@ enum grdma_h2_parser_flags {
                                     GRDMA_H2_NO_BULK_PAIRS turns it off                                 */
   GRDMA_H2_NO_BULK_PAIRS = 64,   /* 32 frames per bulk step                                             */
   GRDMA_H2_NO_CHUNKS = 128,      /* always the sequential deframer.  Without it a list of >= 2048 slices is cut at slices in
-                                    which a message starts (GRDMA_H2_CHUNKS chunks, default 16), the chunks are parsed side
+                                    which a message starts (GRDMA_H2_CHUNKS chunks of >= 256 slices, default 128), the chunks are parsed side
                                     by side and merged when every chunk ended in the state the next one was assumed to
                                     start in -- the sequential deframer does the call otherwise (csrc/grdma_h2_kernels.h) */
   GRDMA_H2_TICKS = 32            /* the parsing wave samples the device clock around its phases (the tick counters
@@ -544,7 +544,7 @@ int grdma_h2_parser_chunk_stats(grdma_h2_parser* p, uint64_t out[2]);  /* calls 
 int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_read_slice* slices,
                          uint64_t n, grdma_h2_event* events_out, uint64_t cap, int* h2_error);
 
-/* HTTP/2 inside the device pipeline: per step, k_h2_frame rebuilds the slice list of the job's
+/* HTTP/2 inside the device pipeline: per step, k_h2_frame_index + k_h2_frame_emit rebuild the slice list of the job's
  * link from the message table (grpc_chttp2_encode_data, frame_data.cc:64-90), the streaming job
  * carries it through the connection, and k_h2_deframe parses the slices the job delivered
  * (grpc_chttp2_perform_read + grpc_deframe_unprocessed_incoming_frames) -- three stages on three

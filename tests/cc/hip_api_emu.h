@@ -151,12 +151,11 @@ inline hipError_t hipMemGetHandleForAddressRange(void*, hipDeviceptr_t, size_t, 
 // HIP graphs of kernel nodes (what csrc/grdma_pair.hip builds for a streaming job: every node carries two
 // pointer-sized parameters).  The nodes run in the order they were added, which is a valid order of the graph:
 // a node's dependencies are always nodes added before it.
+#define EMU_GRAPH_NODE_ARGS 10  // (= GRDMA_JOB_HOOK_ARGS: the product hands over that many parameter slots per node)
 struct emu_graph_node {
   void* func;
   dim3 grid, block;
-  void* a0;
-  void* a1;
-  void* a2;
+  uint64_t a[EMU_GRAPH_NODE_ARGS];
 };
 struct emu_graph {
   std::vector<emu_graph_node*> nodes;
@@ -174,9 +173,9 @@ inline hipError_t hipGraphDestroy(hipGraph_t g) {
 }
 inline hipError_t hipGraphAddKernelNode(hipGraphNode_t* node, hipGraph_t g, const hipGraphNode_t*, size_t,
                                         const hipKernelNodeParams* p) {
-  // (the product always hands over three pointer-sized kernel parameters; kernels with fewer ignore the rest)
-  emu_graph_node* n = new emu_graph_node{p->func, p->gridDim, p->blockDim, *static_cast<void**>(p->kernelParams[0]),
-                                         *static_cast<void**>(p->kernelParams[1]), *static_cast<void**>(p->kernelParams[2])};
+  // (the product always hands over EMU_GRAPH_NODE_ARGS parameter slots of 8 bytes; kernels with fewer ignore the rest)
+  emu_graph_node* n = new emu_graph_node{p->func, p->gridDim, p->blockDim, {}};
+  for (int i = 0; i < EMU_GRAPH_NODE_ARGS; i++) n->a[i] = *static_cast<uint64_t*>(p->kernelParams[i]);
   g->nodes.push_back(n);
   *node = n;
   return hipSuccess;
@@ -190,9 +189,11 @@ inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, vo
 inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
   std::lock_guard<std::recursive_mutex> lk(emu::launch_mutex());
   for (const emu_graph_node& n : e->nodes) {
-    void (*f)(void*, void*, void*) = reinterpret_cast<void (*)(void*, void*, void*)>(n.func);
-    void *a0 = n.a0, *a1 = n.a1, *a2 = n.a2;
-    emu::launch(n.grid, n.block, [=] { f(a0, a1, a2); });
+    // (integer / pointer parameters only: a kernel with fewer parameters ignores the registers and stack slots behind its own)
+    typedef void (*fn_t)(uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t);
+    fn_t f = reinterpret_cast<fn_t>(n.func);
+    const emu_graph_node c = n;
+    emu::launch(n.grid, n.block, [=] { f(c.a[0], c.a[1], c.a[2], c.a[3], c.a[4], c.a[5], c.a[6], c.a[7], c.a[8], c.a[9]); });
   }
   return hipSuccess;
 }

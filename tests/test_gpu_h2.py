@@ -34,10 +34,11 @@ def device_bytes(g, ptr, n):
 @pytest.mark.parametrize("lens,max_frame", [
     ([1 << 20], 16384), ([0], 16384), ([0, 0, 0, 5, 0, 0], 16384), ([3, 70000, 16379, 16380], 16384),
     ([100, 0, 17], 3), ([9, 1, 0, 0], 1), ([5000] * 40, 1000), ([1048580] * 3, 16384),
-    ([0] * 300 + [7] * 10, 16384),
+    ([0] * 300 + [7] * 10, 16384), ([70000] * 300 + [0, 5] + [16379] * 300, 16384), ([7] * 10 + [0] * 3 + [9, 100000, 1], 6),
+    ([20, 0, 21, 22, 0, 0, 23, 24], 5), ([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12], 7),
 ])
 def test_frame_messages_matches_oracle(gpu, lens, max_frame):
-    """k_h2_frame against the oracle's model of chttp2 queueing the same messages on one
+    """k_h2_frame_index + k_h2_frame_emit against the oracle's model of chttp2 queueing the same messages on one
     outbuf: identical wire bytes AND identical slice boundaries (including the
     inlined-slice merging that crosses message boundaries after an empty message)."""
     g = gpu

@@ -117,6 +117,29 @@ def test_chunked_deframer_mixed_sizes_and_control_frames(gpu):
     b.close()
 
 
+@pytest.mark.parametrize("shape", ["sender", "receiver"])
+def test_chunked_deframer_messages_longer_than_a_chunk(gpu, shape):
+    """Messages of ~1200 slices (small frames): several quantiles lie in front of the same message start, so some chunks
+    are EMPTY -- they end where and as they start -- and the chain still holds.  One message far longer than the
+    search span has no cut at all: the call is the sequential deframer's.  (Message lengths are multiples of the frame
+    size: the receiving side then sees the closing 5-byte frame and the next message start in one slice, the shape the
+    boundary step -- and with it the cut search -- knows.)"""
+    mk = (lambda tx: tx) if shape == "sender" else receiver_slices
+    b = Both(gpu, False, streams=(1,))
+    b.call([frame(1, 4, 1, b"\x82")] + mk(fast_sender_slices([3072] * 3, max_frame=1024)))
+    body = mk(fast_sender_slices([600064] * 8, seed=2, max_frame=1024))
+    assert len(body) >= 8 * 1000
+    b.call(body)
+    assert b.dev.chunk_stats() == (1, 1)
+    b.call(mk(fast_sender_slices([300032, 5120, 900096, 70656] * 3, seed=3, max_frame=1024)))
+    assert b.dev.chunk_stats() == (2, 2)
+    b.call(mk(fast_sender_slices([6000640], seed=4, max_frame=1024)))  # ~11 700 slices, one message start
+    assert b.dev.chunk_stats()[1] == 2
+    b.call(mk(fast_sender_slices([100352] * 40, seed=5, max_frame=1024)))
+    assert b.dev.chunk_stats()[1] == 3
+    b.close()
+
+
 def test_chunked_deframer_declines_what_it_cannot_verify(gpu):
     """Lists on which the chain of end states does NOT hold are the sequential parser's: a second stream that is
     mid-message at a cut, a stream that opens in the middle of the list, a stream that closes in it, a connection
@@ -142,17 +165,19 @@ def test_chunked_deframer_declines_what_it_cannot_verify(gpu):
     body = fast_sender_slices([60000] * 150, seed=1) + [frame(1, 4, 5, b"\x82")] + fast_sender_slices([60000] * 150, seed=2)
     b.call(body)
     assert b.dev.chunk_stats()[1] == 0
-    # (c) the hinted stream ends in the middle of the list (END_STREAM), stream 3 carries on behind it
+    # (c) the hinted stream ends in the middle of the list (END_STREAM), stream 3 carries on behind it: no message of
+    # stream 1 starts behind its last one, so the chunk that begins there runs to the end of the list -- and what
+    # happens inside the LAST chunk is not constrained (a stream may close or open there): merged
     body = fast_sender_slices([60000] * 150, seed=3) + [frame(0, 1, 1, grpc_msg(bytes(100)))]
     body += fast_sender_slices([60000] * 150, sid=3, seed=6)
     assert len(body) >= 2048
     b.call(body)
-    assert b.dev.chunk_stats()[1] == 0
-    # (d) the hint now names stream 3; what happens inside the LAST chunk is not constrained -- a stream may open
-    # there -- and the merged call leaves the state the next (short, sequential) call continues from
+    assert b.dev.chunk_stats()[1] == 1
+    # (d) the hint now names stream 3; a stream opens inside the last chunk; the merged call leaves the state the next
+    # (short, sequential) call continues from
     b.call(fast_sender_slices([60000] * 300, sid=3, seed=7) + [frame(1, 4, 7, b"\x82")] +
            fast_sender_slices([60000], sid=7, seed=8) + fast_sender_slices([60000] * 5, sid=3, seed=9))
-    assert b.dev.chunk_stats()[1] == 1
+    assert b.dev.chunk_stats()[1] == 2
     b.call(fast_sender_slices([100, 60000], sid=7, seed=10) + fast_sender_slices([60000] * 2, sid=3, seed=11))
     assert b.dev.live_streams() == b.orc.live_streams()
     b.close()
