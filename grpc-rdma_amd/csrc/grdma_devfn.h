@@ -350,13 +350,20 @@ __device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane)
 // LDS_N: slots of the staged prefix -- 8192 in the copy kernels (32 KB, occupancy is
 // bound by registers there), 1024 where a plan workgroup runs its own small plan inline.
 // One tile of segment sg (bytes [off, off + n)), plus the record tags the segment carries.
+// cache policies of the plan tiles' loads / stores (AUX_LD / AUX_ST of wave_move_tile)
+#ifndef GRDMA_PLAN_LD
+#define GRDMA_PLAN_LD 2
+#endif
+#ifndef GRDMA_PLAN_ST
+#define GRDMA_PLAN_ST 0
+#endif
 template <uint32_t TILE>
 __device__ __forceinline__ void plan_tile(const grdma_seg& sg, uint64_t off, uint64_t n, uint64_t tag_base, uint64_t tm, int lane) {
   // (nontemporal loads: payload streams through once; plain stores: the next kernel of the
   // round reads what this one wrote out of the Infinity Cache)
   if (sg.src == 0) wave_zero_tile(reinterpret_cast<uint8_t*>(sg.dst + off), n, lane);
-  else if (sg.flags & GRDMA_SEG_ZERO_SRC) wave_move_tile<2, 0, true, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
-  else wave_move_tile<2, 0, false, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
+  else if (sg.flags & GRDMA_SEG_ZERO_SRC) wave_move_tile<GRDMA_PLAN_LD, GRDMA_PLAN_ST, true, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
+  else wave_move_tile<GRDMA_PLAN_LD, GRDMA_PLAN_ST, false, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
   if (sg.flags & (GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR)) {
     const bool wr = (sg.flags & GRDMA_SEG_TAG_WRITE) != 0;
     const uint64_t side = wr ? sg.dst : sg.src;

@@ -215,6 +215,7 @@ struct mirror_traits {
   static error none() { return GRPC_ERROR_NONE; }
   static bool is_error(error e) { return e != GRPC_ERROR_NONE; }
   static error ref(error e) { return GRPC_ERROR_REF(e); }
+  static void drop(error e) { GRPC_ERROR_UNREF(e); }
   static error annotate(host* rdma, const char* msg);
   static void run(host*, closure* c, error err) {  // grpc_core::Closure::Run
     c->cb(c->cb_arg, err);
@@ -320,7 +321,13 @@ void rdma_unref(grpc_rdma* rdma) {
   if (rdma->refcount.fetch_sub(1) == 1) rdma_free(rdma);
 }
 
-void rdma_destroy(grpc_endpoint* ep) { rdma_unref(reinterpret_cast<grpc_rdma*>(ep)); }  // :134-139
+void rdma_destroy(grpc_endpoint* ep) {  // :134-139
+  grpc_rdma* rdma = reinterpret_cast<grpc_rdma*>(ep);
+  rdma->refcount.fetch_add(1);
+  rdma->core.abandon_buffered_writes();
+  rdma_unref(rdma);
+  rdma_unref(rdma);
+}
 void pollset_del_fd(grpc_pollset* ps, grpc_rdma* rdma) {
   std::lock_guard<std::mutex> lk(ps->rdma_mu);
   auto it = std::find(ps->rdma_fds.begin(), ps->rdma_fds.end(), rdma);

@@ -97,14 +97,21 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan_seq(const grdma_tx_op*
   const grdma_conn* c = mine[0].conn;
   uint32_t k0 = 0;
   if (c->max_sge <= 64 && c->cap <= (1ull << 30)) {
-    // the Sends are small: one wavefront prices the whole burst (tx_burst_wave).  A first Send that
-    // resets the cursor (it sums the whole slice list) still takes the block-wide plan.
-    if (mine[0].use_cursor != 1) {
+    // the Sends are small: one wavefront prices the whole burst (tx_burst_wave).
+    // A first Send that resets the cursor offers the whole slice table: the wave sums a table of up to 4096 entries
+    // itself (a write of a few hundred slices then costs one short wave instead of the block-wide planner);
+    // anything else that is not a continuation takes the block-wide plan.
+    const bool reset = mine[0].use_cursor == 2 && mine[0].nslices <= 4096;
+    if (mine[0].use_cursor != 1 && !reset) {
       tx_plan_seq_call(&mine[0]);
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
       __syncthreads();
       k0 = 1;
+    }
+    if (reset) {
+      if (threadIdx.x < 64) tx_burst_wave(mine, n, burst, (int)threadIdx.x, true);
+      return;
     }
     if (threadIdx.x < 64 && k0 < burst) tx_burst_wave(mine + (size_t)k0 * n, n, burst - k0, (int)threadIdx.x);
     return;

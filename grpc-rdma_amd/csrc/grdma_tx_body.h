@@ -636,9 +636,12 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
 // one segment + tile-prefix entry per lane, the <= 2 wire requests, the result block.  No LDS, no
 // barriers, no wait between Sends except for the descriptors.
 // ops[k * stride] is Send k.  Preconditions checked by the caller: cap <= 2^30, max_sge <= 64,
-// every op has use_cursor == 1.
+// every op has use_cursor == 1 -- or, with `reset`, the first one has use_cursor == 2: the cursor starts at the
+// head of the slice table and the bytes offered are the table's total, which this wave sums itself (a table of a
+// few thousand entries at most: the caller checks).
 // ----------------------------------------------------------------------------
-__device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t stride, uint32_t burst, int lane) {
+__device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t stride, uint32_t burst, int lane,
+                                              bool reset = false) {
   const grdma_tx_op op0 = ops[0];
   grdma_conn* c = op0.conn;
   const uint64_t cap = c->cap, mask = cap - 1, S = c->staging_cap;
@@ -654,6 +657,15 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
   uint64_t tail = c->remote_tail, idx = c->tx_slice_idx, bidx = c->tx_byte_idx, remaining = c->tx_remaining;
   uint64_t total_written = c->total_written, records = c->tx_records, rounds = c->tx_rounds;
   uint32_t last_records = c->tx_last_records, partial = (uint32_t)c->partial_write;
+  if (reset) {  // (pair.cc:660-663: what a Send is offered is the sum over its whole slice list)
+    uint64_t part = 0;
+    for (uint64_t i = (uint64_t)lane; i < nslices; i += 64) part += sl[i].len;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    idx = 0;
+    bidx = 0;
+    remaining = part;
+  }
   if (idx > nslices) idx = nslices;
   const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap);
   const uint64_t TB = 1ull << ts;

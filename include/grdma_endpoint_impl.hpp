@@ -15,6 +15,13 @@
 //     returns; the write callback runs from the writable edge once the Send has completed -- "may complete
 //     synchronously or later" is what endpoint.h:78-91 allows.  A partial Send (credit, max_sge) is continued from
 //     the same edge, as rdma_handle_write does;
+//   * a write that fits a SEND BUFFER of the endpoint (two pinned, device-visible buffers, GRPC_RDMA_HIP_SEND_BUFFER_KB
+//     each, default 4096, 0 = off) completes as soon as its bytes have been copied there -- what a socket does with
+//     its send buffer, and what rdma_flush does when Send() copies the slices into the registered send buffer: the
+//     caller's slices are free, the bytes are the endpoint's to deliver.  The device chain of write k then runs while
+//     the transport prepares and copies write k + 1; an error of a write that has already completed is reported by the
+//     next write (like a socket's).  Writes that do not fit, or that arrive while both buffers are taken, go the
+//     way described above, behind the buffered ones;
 //   * a read that finds a message enqueues one drain -- up to kReadAhead endpoint reads in ONE device pass, each the
 //     slice rdma_continue_read would have sized (max(256, readable)) and rdma_do_read would have filled -- and
 //     returns; the completions are handed to the transport one read callback each, as slices that point into the
@@ -29,7 +36,7 @@
 //            add_copied(sb, bytes, len)               a fresh slice holding a copy
 //            add_window(sb, bytes, len, window)       a slice pointing at `bytes`, takes a window reference,
 //                                                     grdma_window_unref when the slice is destroyed
-//   errors   none() ref(e) annotate(host*, msg)       rdma_annotate_error(GRPC_ERROR_CREATE...(msg), rdma), :86-96
+//   errors   none() ref(e) drop(e) annotate(host*, msg)   rdma_annotate_error(GRPC_ERROR_CREATE...(msg), rdma), :86-96
 //   closures run(host*, closure*, error)              grpc_core::Closure::Run
 //            run_read_done(host*)                     Closure::Run(&rdma->read_done_closure, NONE), :370-374
 //   fd       notify_on_read(host*) notify_on_write(host*) is_shutdown(host*)
@@ -41,6 +48,8 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -50,6 +59,8 @@ namespace grdma_ep {
 
 constexpr uint64_t kReadAhead = 1024;    // endpoint reads performed per device pass
 constexpr size_t kWriteWindow = 4000;    // slices handed to one grdma_endpoint_write_begin (the ABI takes 4095)
+constexpr size_t kSendBufferMin = 8192;  // shorter writes go to the pair as they are (a unary-sized write rides inline
+                                         // in the latency engine's command: nothing to gain from a copy in front of it)
 constexpr size_t kZeroCopyMin = 512;     // shorter slices are copied out of the window (a 9-byte frame header
                                          // should not keep 64 MiB of pinned memory alive)
 
@@ -73,6 +84,23 @@ struct core {
   size_t out_next = 0;                 // first view not yet handed to the pair
   bool window_active = false;          // the pair holds a window of views that has not gone out whole
   bool send_submitted = false;         // a Send is in flight
+  // send buffers (early completion): a write copied into one completes at once; at most one of them is with the pair
+  // (out_views point into it, outgoing_buffer is null), the other one may wait behind it
+  struct send_buffer {
+    uint8_t* mem = nullptr;
+    std::vector<grdma_slice> views;
+  };
+  send_buffer sbuf[2];
+  size_t sbuf_cap = 0;                 // bytes per buffer, 0 = off
+  int bg_running = -1, bg_waiting = -1;
+  bool deferred = false;               // a write of the ordinary kind (deferred_buf, write_cb) waits behind them
+  sb_t* deferred_buf = nullptr;
+  bool bg_failed = false;
+  std::string bg_error;                // what a buffered write failed with: the next write reports it
+  std::string last_failure;            // the text of the last error flush() made
+  int out_flags = GRDMA_MEM_HOST;      // memory kind of out_views (a send buffer is device-visible: 0)
+  std::recursive_mutex wmu;            // write() and handle_write() may come from different threads once a write
+                                       // has completed before its Send has
   // read side
   std::vector<grdma_read_slice> ahead; // completions of the last drain not yet handed to the transport
   size_t ahead_next = 0;
@@ -84,12 +112,28 @@ struct core {
     h = host;
     pair = p;
     ahead.reserve(kReadAhead);
+    const char* e = getenv("GRPC_RDMA_HIP_SEND_BUFFER_KB");
+    const long kb = e ? atol(e) : 4096;
+    sbuf_cap = kb > 0 ? (size_t)kb * 1024 : 0;
   }
   // rdma_free: nothing of the transport's may be referenced afterwards
   void release() {
     if (ahead_win) grdma_window_unref(ahead_win);
     ahead_win = nullptr;
     ahead.clear();
+    for (send_buffer& b : sbuf) {
+      if (b.mem) grdma_host_free_pinned(b.mem);
+      b.mem = nullptr;
+    }
+  }
+  // rdma_destroy without a shutdown in front of it: buffered writes still on their way are dropped (what closing a
+  // socket with unsent bytes does), and the reference their Send holds on the endpoint goes back
+  void abandon_buffered_writes() {
+    std::lock_guard<std::recursive_mutex> lk(wmu);
+    if (bg_running < 0) return;
+    forget_write();
+    bg_running = bg_waiting = -1;
+    T::unref(h);
   }
 
   // ------------------------------------------------------------------------------------------- read
@@ -224,9 +268,10 @@ struct core {
     typename T::scope profiler(T::OP_FLUSH);
     *error = T::none();
     auto fail_with = [&](const std::string& what) {
+      last_failure = what;
       *error = T::annotate(h, what.c_str());
       forget_write();
-      T::reset_and_unref(outgoing_buffer);
+      if (outgoing_buffer) T::reset_and_unref(outgoing_buffer);
       return true;
     };
     for (;;) {
@@ -251,7 +296,7 @@ struct core {
       if (!window_active) {
         if (out_next >= out_views.size()) break;
         const size_t cnt = out_views.size() - out_next < kWriteWindow ? out_views.size() - out_next : kWriteWindow;
-        if (grdma_endpoint_write_begin(pair, out_views.data() + out_next, cnt, GRDMA_MEM_HOST) < 0)
+        if (grdma_endpoint_write_begin(pair, out_views.data() + out_next, cnt, out_flags) < 0)
           return fail_with(std::string("RDMA Pair has an internal error, ") + grdma_last_error());
         out_next += cnt;
         window_active = true;
@@ -263,45 +308,195 @@ struct core {
     }
     out_views.clear();
     out_next = 0;
-    T::reset_and_unref(outgoing_buffer);  // :519-523
+    if (outgoing_buffer) T::reset_and_unref(outgoing_buffer);  // :519-523
     return true;
   }
 
-  void handle_write(error_t error) {  // :527-557
-    typename T::scope profiler(T::OP_HANDLE_WRITE);
-    if (T::is_error(error)) {
-      closure_t* cb = write_cb;
-      write_cb = nullptr;
-      forget_write();
-      T::run(h, cb, T::ref(error));
-      T::unref(h);
-      return;
-    }
-    error_t err;
-    if (!flush(&err)) {
-      T::notify_on_write(h);
-    } else {
+  // ---- send buffers
+  int free_send_buffer() {
+    for (int i = 0; i < 2; i++)
+      if (i != bg_running && i != bg_waiting) return i;
+    return -1;
+  }
+  // hand send buffer s to the pair; false = on its way (the writable edge continues it), true = finished (*error)
+  bool start_buffered(int s, error_t* error) {
+    bg_running = s;
+    outgoing_buffer = nullptr;
+    out_views = sbuf[s].views;
+    out_next = 0;
+    out_flags = 0;
+    window_active = false;
+    send_submitted = false;
+    T::ref(h);
+    return flush(error);
+  }
+  void start_ordinary() {  // the write held in outgoing_buffer / write_cb
+    const size_t n = T::count(outgoing_buffer);
+    out_views.resize(n);
+    for (size_t i = 0; i < n; i++)
+      out_views[i] = grdma_slice{T::slice_ptr(outgoing_buffer, i), (uint64_t)T::slice_len(outgoing_buffer, i)};
+    out_next = 0;
+    out_flags = GRDMA_MEM_HOST;
+    window_active = false;
+    send_submitted = false;
+  }
+  // the Send(s) of whatever the pair was working on have ended with `err`: account for it and start what waits
+  void after_flush(error_t err) {
+    for (;;) {
+      if (bg_running >= 0) {
+        bg_running = -1;
+        if (T::is_error(err)) {  // a write that has completed long ago failed: remembered for the next one
+          bg_failed = true;
+          bg_error = last_failure.empty() ? std::string("an earlier write failed") : last_failure;
+          bg_waiting = -1;
+          T::drop(err);
+        }
+        const int next = bg_waiting;
+        bg_waiting = -1;
+        if (next >= 0 && !bg_failed) {
+          error_t e2;
+          const bool fin = start_buffered(next, &e2);
+          T::unref(h);  // (the reference of the buffer that has just finished; the next one took its own)
+          if (!fin) {
+            T::notify_on_write(h);
+            return;
+          }
+          err = e2;
+          continue;
+        }
+        if (deferred) {
+          deferred = false;
+          if (bg_failed) {
+            closure_t* cb = write_cb;
+            write_cb = nullptr;
+            T::reset_and_unref(deferred_buf);
+            deferred_buf = nullptr;
+            T::run(h, cb, T::annotate(h, bg_error.c_str()));
+            T::unref(h);  // (the deferred write's)
+            T::unref(h);  // (the finished buffer's)
+            return;
+          }
+          outgoing_buffer = deferred_buf;
+          deferred_buf = nullptr;
+          start_ordinary();
+          error_t e2;
+          const bool fin = flush(&e2);
+          T::unref(h);  // (the finished buffer's; the deferred write holds its own since write())
+          if (!fin) {
+            T::notify_on_write(h);
+            return;
+          }
+          err = e2;
+          continue;  // (bg_running < 0 now: the ordinary completion below)
+        }
+        T::unref(h);
+        return;
+      }
       closure_t* cb = write_cb;
       write_cb = nullptr;
       T::run(h, cb, err);
       T::unref(h);
+      return;
     }
   }
 
+  // (the mutex lives in this object: a reference of its own around everything that runs under it, so that the last
+  // unref inside cannot take the object away from under the lock)
+  void handle_write(error_t error) {  // :527-557
+    T::ref(h);
+    {
+      std::lock_guard<std::recursive_mutex> lk(wmu);
+      handle_write_locked(error);
+    }
+    T::unref(h);
+  }
   void write(sb_t* buf, closure_t* cb) {  // :559-586
+    T::ref(h);
+    {
+      std::lock_guard<std::recursive_mutex> lk(wmu);
+      write_locked(buf, cb);
+    }
+    T::unref(h);
+  }
+
+  void handle_write_locked(error_t error) {
+    typename T::scope profiler(T::OP_HANDLE_WRITE);
+    if (T::is_error(error)) {
+      forget_write();
+      if (bg_running >= 0) {  // buffered writes die with the endpoint (their callbacks have run)
+        bg_running = bg_waiting = -1;
+        bg_failed = true;
+        bg_error = "Endpoint shutdown";
+        T::unref(h);
+      }
+      if (write_cb != nullptr) {
+        closure_t* cb = write_cb;
+        write_cb = nullptr;
+        deferred = false;
+        deferred_buf = nullptr;
+        T::run(h, cb, T::ref(error));
+        T::unref(h);
+      }
+      return;
+    }
+    if (bg_running < 0 && write_cb == nullptr) return;  // (an edge nobody waits for any more)
+    error_t err;
+    if (!flush(&err)) {
+      T::notify_on_write(h);
+    } else {
+      after_flush(err);
+    }
+  }
+
+  void write_locked(sb_t* buf, closure_t* cb) {
     typename T::scope profiler(T::OP_WRITE);
     if (write_cb != nullptr) abort();  // GPR_ASSERT(rdma->write_cb == nullptr)
     if (T::length(buf) == 0) {
       T::run(h, cb, T::is_shutdown(h) ? T::annotate(h, "EOF") : T::none());
       return;
     }
-    outgoing_buffer = buf;
+    if (bg_failed) {  // what a socket reports on the write after the one that failed
+      T::reset_and_unref(buf);
+      T::run(h, cb, T::annotate(h, bg_error.c_str()));
+      return;
+    }
     const size_t n = T::count(buf);
-    out_views.resize(n);
-    for (size_t i = 0; i < n; i++) out_views[i] = grdma_slice{T::slice_ptr(buf, i), (uint64_t)T::slice_len(buf, i)};
-    out_next = 0;
-    window_active = false;
-    send_submitted = false;
+    const size_t len = T::length(buf);
+    const int s = free_send_buffer();
+    if (sbuf_cap != 0 && len >= kSendBufferMin && len <= sbuf_cap && n <= kWriteWindow && s >= 0 && !deferred && !T::is_shutdown(h)) {
+      send_buffer& b = sbuf[s];
+      if (b.mem == nullptr) b.mem = static_cast<uint8_t*>(grdma_host_alloc_pinned(sbuf_cap));
+      if (b.mem != nullptr) {
+        // the slices keep their boundaries (one ring record each), their bytes move into the endpoint's buffer
+        b.views.resize(n);
+        size_t off = 0;
+        for (size_t i = 0; i < n; i++) {
+          const size_t l = T::slice_len(buf, i);
+          if (l) memcpy(b.mem + off, T::slice_ptr(buf, i), l);
+          b.views[i] = grdma_slice{b.mem + off, (uint64_t)l};
+          off += l;
+        }
+        T::reset_and_unref(buf);
+        if (bg_running >= 0) {
+          bg_waiting = s;  // behind the buffer that is on its way; handle_write starts it
+        } else {
+          error_t err;
+          if (!start_buffered(s, &err)) T::notify_on_write(h);
+          else after_flush(err);
+        }
+        T::run(h, cb, T::none());
+        return;
+      }
+    }
+    if (bg_running >= 0) {  // behind the buffered writes
+      T::ref(h);
+      write_cb = cb;
+      deferred = true;
+      deferred_buf = buf;
+      return;
+    }
+    outgoing_buffer = buf;
+    start_ordinary();
     error_t error;
     if (!flush(&error)) {
       T::ref(h);

@@ -87,6 +87,7 @@ struct iomgr_traits {
   static error none() { return GRPC_ERROR_NONE; }
   static bool is_error(error e) { return e != GRPC_ERROR_NONE; }
   static error ref(error e) { return GRPC_ERROR_REF(e); }
+  static void drop(error e) { GRPC_ERROR_UNREF(e); }
   static error annotate(host* rdma, const char* msg);  // rdma_annotate_error, :86-96
   static void run(host*, closure* c, error err) { grpc_core::Closure::Run(DEBUG_LOCATION, c, err); }
   static void run_read_done(host* rdma);
@@ -167,7 +168,11 @@ void hip_shutdown(grpc_endpoint* ep, grpc_error_handle why) {  // :106-110
 }
 
 void hip_destroy(grpc_endpoint* ep) {  // :156-164
-  hip_unref(reinterpret_cast<grpc_rdma_hip*>(ep));
+  grpc_rdma_hip* rdma = reinterpret_cast<grpc_rdma_hip*>(ep);
+  rdma->refcount.Ref();
+  rdma->core.abandon_buffered_writes();  // (writes that completed into the send buffer and have not gone out yet)
+  hip_unref(rdma);
+  hip_unref(rdma);
 }
 
 void hip_handle_read(void* arg, grpc_error_handle error) {  // :328-341

@@ -257,8 +257,10 @@ static void record_write(void* p, grpc_error_handle e) {
 }
 static void write_after_peer_exit_test() {
   setenv("GRPC_RDMA_RING_BUFFER_SIZE_KB", "64", 1);
+  setenv("GRPC_RDMA_HIP_SEND_BUFFER_KB", "0", 1);  // the reference's flow: a write is outstanding until its last Send
   fixture f = create_fixture();
   unsetenv("GRPC_RDMA_RING_BUFFER_SIZE_KB");
+  unsetenv("GRPC_RDMA_HIP_SEND_BUFFER_KB");
   grpc_slice_buffer out;
   grpc_slice_buffer_init(&out);
   uint8_t cur = 0;
@@ -282,6 +284,41 @@ static void write_after_peer_exit_test() {
   grpc_slice_buffer_destroy(&out);
   grpc_endpoint_destroy(f.client_ep);
   printf("write_after_peer_exit_test: ok\n");
+}
+
+// The same with the endpoint's send buffers (the default): a write that fits one completes as soon as its bytes have
+// been copied -- a socket's behaviour -- and goes out behind the callback; when the peer exits before it has, the
+// write AFTER the failure is the one that reports it, with the reference's wording, and nothing spins or leaks.
+static void buffered_write_after_peer_exit_test() {
+  setenv("GRPC_RDMA_RING_BUFFER_SIZE_KB", "64", 1);
+  fixture f = create_fixture();
+  unsetenv("GRPC_RDMA_RING_BUFFER_SIZE_KB");
+  grpc_slice_buffer out;
+  grpc_slice_buffer_init(&out);
+  uint8_t cur = 0;
+  fill_buffer(&out, 300000, 8192, &cur);  // more than the 64 KiB ring takes, less than a send buffer
+  grpc_closure cb;
+  GRPC_CLOSURE_INIT(&cb, record_write, nullptr, nullptr);
+  g_write_cbs = 0; g_status = -1; g_desc.clear();
+  grpc_endpoint_write(f.client_ep, &out, &cb, nullptr);
+  CHECK(g_write_cbs == 1 && g_status == -1);  // completed into the send buffer, no error
+  CHECK(out.count == 0);
+  // a second one takes the other buffer and waits behind the first
+  fill_buffer(&out, 100000, 8192, &cur);
+  grpc_endpoint_write(f.client_ep, &out, &cb, nullptr);
+  CHECK(g_write_cbs == 2 && g_status == -1);
+  grpc_endpoint_destroy(f.server_ep);  // peer_exit = 1: the client end is half closed
+  // the parked Send finds out from the writable edge
+  const auto t0 = std::chrono::steady_clock::now();
+  while (std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200)) grdma_endpoint_poll(f.client_ep);
+  fill_buffer(&out, 20000, 8192, &cur);
+  g_status = -1; g_desc.clear();
+  grpc_endpoint_write(f.client_ep, &out, &cb, nullptr);
+  CHECK(g_write_cbs == 3 && g_status == GRPC_STATUS_UNAVAILABLE && g_desc == "Peer has been exited");
+  CHECK(out.count == 0);
+  grpc_slice_buffer_destroy(&out);
+  grpc_endpoint_destroy(f.client_ep);
+  printf("buffered_write_after_peer_exit_test: ok\n");
 }
 
 // ---- many endpoints in ONE pollset (the shape of a server's pollset: every accepted
@@ -478,6 +515,7 @@ int main(int argc, char** argv) {
     multiple_shutdown_test();
     half_close_test();
     write_after_peer_exit_test();
+    buffered_write_after_peer_exit_test();
     return 0;
   }
   if (argc >= 4 && !strcmp(argv[1], "sweep")) {  // endpoint_tests.cc:350-352

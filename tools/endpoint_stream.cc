@@ -184,7 +184,9 @@ int main(int argc, char** argv) {
       loop(st.rx, nullptr, &st.read_done, nullptr);
     });
     do_write(&st, GRPC_ERROR_NONE);
-    loop(st.tx, nullptr, &st.write_done, nullptr);
+    // (a write completes when its bytes sit in the endpoint's send buffer: like a gRPC poller, this thread keeps
+    // polling the sending endpoint until the stream has arrived, not just until the last write callback)
+    loop(st.tx, nullptr, &st.write_done, &st.read_done);
     reader.join();
   } else {
     do_read(&st, GRPC_ERROR_NONE);
