@@ -662,6 +662,17 @@ def main():
             ok = ok and r["h2_error"] == 0 and not r["frame_overflow"] and not r["deframe_overflow"] and \
                 r["framed"] == len(w.lens) and r["parsed"] == p_.delivered and \
                 sum(1 for e in evs if e[0] == 5) == w.n_msgs and sum(e[2] for e in evs if e[0] == 4) == w.n_msgs * w.msg_len
+        if os.environ.get("BENCH_H2_CHUNK_PHASES"):
+            rows = parser.chunk_phases()
+            live = [r for r in rows[:128] if r[0]]
+            ph = [[(r[i] - r[0]) for i in range(5)] + [r[5]] for r in live]  # (every XCD has a clock of its own)
+            mg = rows[128]
+            import statistics as st_
+            sys.stderr.write("chunk phases, device-clock ticks from each chunk's own start (the deframer's 779 us are 1.87 M ticks):\n")
+            for name, i in (("cuts", 1), ("copied", 2), ("parsed", 3), ("compared", 4), ("slices", 5)):
+                col = [p_[i] for p_ in ph]
+                sys.stderr.write("  %-9s min %7d median %7d max %7d\n" % (name, min(col), int(st_.median(col)), max(col)))
+            sys.stderr.write("  merge (workgroup 0): verified %d copied %d end %d\n" % tuple(m_ - mg[0] for m_ in mg[1:4]))
         planned, merged = parser.chunk_stats()
         stage_us["deframe_calls"] = max(2, warmup) + steps
         stage_us["deframe_calls_planned_over_chunks"] = planned
@@ -950,6 +961,15 @@ def main():
         ev = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "1024", str(MIB), "1", "0", "2"], 120, env)
         out["value_endpoint_vtable"] = ev.get("GiBps")
         out["endpoint_vtable"] = ev
+        # the same at the reference's default ring (GRPC_RDMA_RING_BUFFER_SIZE_KB 4096, config.cc): ring and receive
+        # windows stay cache- and IOMMU-resident
+        ev4 = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "1024", str(MIB), "1", "0", "2"], 120,
+                       dict(env, GRPC_RDMA_RING_BUFFER_SIZE_KB="4096"))
+        out["value_endpoint_vtable_ring4096"] = ev4.get("GiBps")
+        # ... and with the endpoint's send buffers off (every write outstanding until its last Send, the reference's flow)
+        ev0 = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "1024", str(MIB), "1", "0", "2"], 120,
+                       dict(env, GRPC_RDMA_HIP_SEND_BUFFER_KB="0"))
+        out["value_endpoint_vtable_no_send_buffers"] = ev0.get("GiBps")
         # the same stream with both pairs in latency mode: commands through the resident engine, the receive arena in
         # pinned host memory (no launch chain and no device-to-host copy per call); first hardware run of this
         # combination, in the helper process like the leg above

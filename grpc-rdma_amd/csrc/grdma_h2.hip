@@ -324,6 +324,18 @@ int grdma_h2_parser_chunk_stats(grdma_h2_parser* p, uint64_t out[2]) {
   out[1] = v[1];
   return 0;
 }
+// profiling aid: the phase stamps of the last chunked call, (H2_KMAX + 1) rows of 8 (csrc/grdma_h2_kernels.h)
+int grdma_h2_parser_chunk_dbg(grdma_h2_parser* p, uint64_t* out, uint64_t cap_words) {
+  if (!p || !out || !p->d_chunks) return -GRDMA_ERR_INVALID;
+  h2_host_ctx* hc = h2_ctx();
+  if (!hc) return -GRDMA_ERR_HIP;
+  const uint64_t words = std::min<uint64_t>(cap_words, (H2_KMAX + 1) * 8);
+  if (hipMemcpyAsync(out, reinterpret_cast<uint8_t*>(p->d_chunks) + offsetof(grdma_h2_chunks, dbg), words * 8,
+                     hipMemcpyDeviceToHost, hc->stream) != hipSuccess ||
+      hipStreamSynchronize(hc->stream) != hipSuccess)
+    return -GRDMA_ERR_HIP;
+  return (int)words;
+}
 int64_t grdma_h2_parser_live_streams(grdma_h2_parser* p) {
   if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
   if (!p) return -GRDMA_ERR_INVALID;

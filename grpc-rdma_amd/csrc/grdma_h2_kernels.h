@@ -1080,6 +1080,7 @@ struct grdma_h2_chunks {
   grdma_h2_event* ev_tmp;             // ev_total events: K private segments of ev_total / K
   uint64_t ev_total;
   uint32_t slots, pad;
+  uint64_t dbg[H2_KMAX + 1][8];       // s_memtime stamps of the phases (profiling aid; row H2_KMAX: the merge)
 };
 
 // the first 32 bytes of a slice as four little-endian words (zero beyond the slice): what the staging waves put
@@ -1123,19 +1124,81 @@ __device__ __forceinline__ uint64_t h2_find_cut(const grdma_h2_parser_dev& P, co
                                                 const grdma_slice_out* slices, uint64_t nslices, uint64_t from,
                                                 uint64_t span, int lane) {
   const uint64_t end = from + span < nslices ? from + span : nslices;
-  for (uint64_t base = from; base < end; base += 64) {
-    const uint64_t sx = base + (uint64_t)lane;
-    const bool have = sx < end;
-    const u64x2 d = *reinterpret_cast<const u64x2*>(&slices[have ? sx : nslices - 1]);
-    const u64x2 dn = *reinterpret_cast<const u64x2*>(&slices[sx + 1 < nslices ? sx + 1 : nslices - 1]);
-    uint64_t c[4];
-    h2_first32(arena, d.x, have ? d.y : 0, c);
-    const h2_bstep B = h2_boundary_match(c[0], c[1], c[2], c[3], have ? d.y : 0, sx + 1 < nslices ? dn.y : ~0ull,
-                                         P.hint_state, P.hint_fsz, P.hint_id, P.max_frame_size);
-    const uint64_t hit = __ballot(have && B.ok);
-    if (hit) return base + (uint64_t)__builtin_ctzll(hit);
+  // three windows of 64 slices per pass: descriptors, then first bytes -- two memory round trips for 192 slices
+  for (uint64_t base = from; base < end; base += 192) {
+    u64x2 d[3], dn[3];
+    bool have[3];
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+      const uint64_t sx = base + 64u * w + (uint64_t)lane;
+      have[w] = sx < end;
+      d[w] = *reinterpret_cast<const u64x2*>(&slices[have[w] ? sx : nslices - 1]);
+      dn[w] = *reinterpret_cast<const u64x2*>(&slices[sx + 1 < nslices ? sx + 1 : nslices - 1]);
+    }
+    uint64_t c[3][4];
+#pragma unroll
+    for (int w = 0; w < 3; w++) h2_first32(arena, d[w].x, have[w] ? d[w].y : 0, c[w]);
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+      const uint64_t sx = base + 64u * w + (uint64_t)lane;
+      const h2_bstep B = h2_boundary_match(c[w][0], c[w][1], c[w][2], c[w][3], have[w] ? d[w].y : 0,
+                                           sx + 1 < nslices ? dn[w].y : ~0ull, P.hint_state, P.hint_fsz, P.hint_id,
+                                           P.max_frame_size);
+      const uint64_t hit = __ballot(have[w] && B.ok);
+      if (hit) return base + 64u * w + (uint64_t)__builtin_ctzll(hit);
+    }
   }
   return end == nslices ? nslices : ~0ull;  // (no message starts behind `from`: the chunk in front runs to the end)
+}
+
+// Stream-map copies and comparisons of a whole workgroup, eight 16-byte entries per thread in flight (a plain loop is a
+// load -> store chain: the compiler cannot know the two maps do not alias).  patch_idx: the entry that is stored with
+// (state, frame_size) replaced (~0 = none); skip_idx: the entry a comparison leaves out.
+template <uint32_t NT = H2_DEFRAME_THREADS>  // threads taking part (tid < NT)
+__device__ __forceinline__ void h2_tab_copy(grdma_h2_stream_dev* dst, const grdma_h2_stream_dev* src, uint32_t slots,
+                                            uint32_t tid, uint32_t patch_idx, int32_t p_state, uint32_t p_fsz) {
+  static_assert(sizeof(grdma_h2_stream_dev) == 16, "two words per map entry");
+  for (uint32_t base = 0; base < slots; base += 8 * NT) {
+    u64x2 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t e = base + (uint32_t)j * NT + tid;
+      v[j] = *reinterpret_cast<const u64x2*>(&src[e < slots ? e : slots - 1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t e = base + (uint32_t)j * NT + tid;
+      if (e >= slots) continue;
+      if (e == patch_idx) {
+        grdma_h2_stream_dev t = src[e];
+        t.state = p_state;
+        t.frame_size = p_fsz;
+        dst[e] = t;
+      } else {
+        *reinterpret_cast<u64x2*>(&dst[e]) = v[j];
+      }
+    }
+  }
+}
+__device__ __forceinline__ bool h2_tab_differs(const grdma_h2_stream_dev* a, const grdma_h2_stream_dev* b, uint32_t slots,
+                                               uint32_t tid, uint32_t skip_idx) {
+  bool diff = false;
+  for (uint32_t base = 0; base < slots; base += 8 * H2_DEFRAME_THREADS) {
+    u64x2 x[8], y[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t e = base + (uint32_t)j * H2_DEFRAME_THREADS + tid;
+      const uint32_t c = e < slots ? e : slots - 1;
+      x[j] = *reinterpret_cast<const u64x2*>(&a[c]);
+      y[j] = *reinterpret_cast<const u64x2*>(&b[c]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t e = base + (uint32_t)j * H2_DEFRAME_THREADS + tid;
+      if (e < slots && e != skip_idx) diff |= x[j].x != y[j].x || x[j].y != y[j].y;
+    }
+  }
+  return diff;
 }
 
 __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe_chunks(grdma_h2_parser_dev* gp, grdma_h2_chunks* ctl,
@@ -1145,6 +1208,7 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe_chunks(grdma_
   const uint32_t tid = threadIdx.x;
   const int lane = tid & 63;
   const uint32_t wave = tid >> 6;
+  const uint64_t tk0 = __builtin_amdgcn_s_memtime();
   const grdma_h2_parser_dev P = *gp;  // (nothing writes the connection's block before the merge)
   const uint32_t slots = P.tab_mask + 1;
   const uint32_t K = h2_chunk_count(ctl->want, nslices);
@@ -1167,25 +1231,27 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe_chunks(grdma_
     const uint64_t span = 8 * (nslices / K);
     uint64_t cut = j == 0 ? 0 : j == K ? nslices : h2_find_cut(P, arena, slices, nslices, nslices * j / K, span, lane);
     if (lane == 0) s_cut[wave] = cut;
-  } else if (tid == 128) {
-    s_idx = tab_find(P.tab, P.tab_mask, P.hint_id);
-    s_dirty = 0;
+  } else {
+    // waves 2-7 meanwhile: the private stream map (a plain copy; the hinted entry is patched below), and the hinted
+    // stream's slot
+    grdma_h2_stream_dev* const mine0 = ctl->tabs + (size_t)k * slots;
+    h2_tab_copy<H2_DEFRAME_THREADS - 128>(mine0, P.tab, slots, tid - 128, ~0u, 0, 0);
+    if (tid == 128) {
+      s_idx = tab_find(P.tab, P.tab_mask, P.hint_id);
+      s_dirty = 0;
+    }
   }
   __syncthreads();
+  const uint64_t tk1 = __builtin_amdgcn_s_memtime();
   const uint64_t s0 = s_cut[0], s1 = s_cut[1];
   const int idx = s_idx;
   const bool found = s0 != ~0ull && s1 != ~0ull && idx >= 0;  // (s0 <= s1: both are "first at or behind" a quantile)
   grdma_h2_stream_dev* const mine = ctl->tabs + (size_t)k * slots;
-  if (found) {
-    // private stream map (chunks 1.. with the hinted stream's data parser in the hinted state) and parser block
-    for (uint32_t e = tid; e < slots; e += H2_DEFRAME_THREADS) {
-      grdma_h2_stream_dev v = P.tab[e];
-      if (k >= 1 && e == (uint32_t)idx) {
-        v.state = P.hint_state;
-        v.frame_size = P.hint_fsz;
-      }
-      mine[e] = v;
-    }
+  if (found && k >= 1 && tid == 64) {  // chunks 1..: the hinted stream's data parser in the hinted state
+    grdma_h2_stream_dev t = P.tab[idx];
+    t.state = P.hint_state;
+    t.frame_size = P.hint_fsz;
+    mine[idx] = t;
   }
   if (tid == 0) {
     grdma_h2_parser_dev g = P;  // (chunks 1..: P itself IS at a frame boundary with nothing pending -- see `can`)
@@ -1207,6 +1273,7 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe_chunks(grdma_
   // (hand-offs inside one workgroup: the barrier orders them -- an agent-scope release here would write the XCD's
   // whole L2 back, dirty lines of the copy kernels included, once per workgroup)
   __syncthreads();
+  const uint64_t tk2 = __builtin_amdgcn_s_memtime();
   if (s1 > s0) {
     const uint64_t stride = ctl->ev_total / K;
     h2_deframe_body(&ctl->gp[k], arena, slices + s0, s1 - s0, ctl->ev_tmp + (size_t)k * stride, stride, &ctl->res[k]);
@@ -1222,19 +1289,14 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe_chunks(grdma_
   // every wave is back (the staging waves when the parser said stop); the parser's stores to its map are its own
   // wave's: the barrier makes them visible to the comparing threads
   __syncthreads();
-  const grdma_h2_stream_dev* orig = P.tab;
-  bool dirty = false;
-  for (uint32_t i = tid; i < slots; i += H2_DEFRAME_THREADS) {
-    if (i == (uint32_t)idx) continue;
-    const u64x2 a = *reinterpret_cast<const u64x2*>(&mine[i]), b = *reinterpret_cast<const u64x2*>(&orig[i]);
-    dirty |= a.x != b.x || a.y != b.y;
-  }
-  static_assert(sizeof(grdma_h2_stream_dev) == 16, "two words per map entry");
-  if (dirty) s_dirty = 1;
+  const uint64_t tk3 = __builtin_amdgcn_s_memtime();
+  if (h2_tab_differs(mine, P.tab, slots, tid, (uint32_t)idx)) s_dirty = 1;
   __syncthreads();
   if (tid == 0) {
     ctl->clean[k] = 1u | (s_dirty ? 0u : 2u);
     ctl->end_entry[k] = mine[idx];
+    uint64_t* d = ctl->dbg[k];
+    d[0] = tk0; d[1] = tk1; d[2] = tk2; d[3] = tk3; d[4] = __builtin_amdgcn_s_memtime(); d[5] = s1 - s0;
   }
 }
 
@@ -1261,6 +1323,7 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_merge_or_deframe(grdm
                                                                            uint64_t nslices, grdma_h2_event* ev, uint64_t ev_cap,
                                                                            grdma_h2_deframe_result* res) {
   const uint32_t tid = threadIdx.x;
+  const uint64_t tm0 = __builtin_amdgcn_s_memtime();
   const uint32_t K = ctl->K;
   __shared__ uint64_t s_pre[H2_KMAX + 1];
   __shared__ uint32_t s_bad;
@@ -1280,6 +1343,28 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_merge_or_deframe(grdm
     if (tid <= H2_KMAX) s_pre[tid] = 0;
     __syncthreads();
     const uint32_t last = s_last;
+    // what the tail of the merge needs, asked for NOW (registers): the control data was written by the chunk kernel on
+    // other XCDs, every dependent load is a trip to memory -- a chain of five of them behind the event copy was half
+    // of this kernel
+    const bool installer = blockIdx.x == 0 && tid == 0;
+    grdma_h2_parser_dev g_last;
+    grdma_h2_deframe_result r_last;
+    grdma_h2_stream_dev e_last;
+    uint32_t clean_last = 0, hint_slot = 0;
+    uint64_t n_merged0 = 0;
+    grdma_h2_stream_dev* orig = nullptr;
+    uint64_t st_bulk = 0, st_frames = 0, st_bsteps = 0, st_total = 0;
+    if (blockIdx.x == 0) {
+      clean_last = ctl->clean[last];
+      orig = ctl->ref.tab;
+      if (installer) {
+        g_last = ctl->gp[last];
+        r_last = ctl->res[last];
+        e_last = ctl->end_entry[last];
+        hint_slot = ctl->hint_idx;
+        n_merged0 = ctl->n_merged;
+      }
+    }
     if (tid < K) {
       bool ok;
       if (tid < last) ok = h2_chunk_link_ok(ctl, tid);
@@ -1288,6 +1373,13 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_merge_or_deframe(grdm
       else ok = (ctl->clean[tid] & 1u) != 0;  // empty chunks behind the last one
       if (!ok) s_bad = 1;
       s_pre[tid + 1] = ok ? ctl->res[tid].nevents : 0;
+      if (blockIdx.x == 0) {
+        const grdma_h2_deframe_result& c = ctl->res[tid];
+        st_bulk = c.bulk_steps;
+        st_frames = c.bulk_frames;
+        st_bsteps = c.boundary_steps;
+        st_total = c.t_total;
+      }
     }
     __syncthreads();
     if (tid < 64) {  // inclusive prefix sums of the event counts: two wave scans (K <= 128)
@@ -1300,9 +1392,11 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_merge_or_deframe(grdm
       if (tid == 63 && hi > ev_cap) s_bad = 1;  // (entries behind K are zero: hi of lane 63 is the total)
     }
     __syncthreads();
+    const uint64_t tm1 = __builtin_amdgcn_s_memtime();
     if (!s_bad) {
       const uint64_t total = s_pre[K];
       const uint64_t stride = ctl->ev_total / K;
+      const grdma_h2_event* const ev_tmp = ctl->ev_tmp;
       const uint64_t per = (total + gridDim.x - 1) / gridDim.x;
       const uint64_t i0 = (uint64_t)blockIdx.x * per, i1 = i0 + per < total ? i0 + per : total;
       for (uint64_t i = i0 + tid; i < i1; i += H2_DEFRAME_THREADS) {
@@ -1312,7 +1406,7 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_merge_or_deframe(grdm
           if (s_pre[mid] <= i) lo = mid; else hi = mid;
         }
         const uint32_t k = lo;
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(ctl->ev_tmp + (size_t)k * stride + (i - s_pre[k]));
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(ev_tmp + (size_t)k * stride + (i - s_pre[k]));
         const uint64_t w0 = src[0], w1 = src[1];
         uint64_t w2 = src[2];
         w2 += ctl->s_begin[k] << 32;  // the slice index of an event is its high half: rebase it on the chunk's first slice
@@ -1321,34 +1415,36 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_merge_or_deframe(grdm
         dst[1] = w1;
         dst[2] = w2;
       }
+      const uint64_t tm2 = __builtin_amdgcn_s_memtime();
       if (blockIdx.x == 0) {
         // the last chunk's parser block and stream map are the connection's
         const uint32_t slots = ctl->slots;
-        grdma_h2_stream_dev* orig = ctl->ref.tab;
-        const grdma_h2_stream_dev* lastt = ctl->tabs + (size_t)last * slots;
-        for (uint32_t i = tid; i < slots; i += H2_DEFRAME_THREADS) orig[i] = lastt[i];
+        if (clean_last == 3u) {  // nothing but the hinted stream's entry moved in the last chunk either
+          if (installer) orig[hint_slot] = e_last;
+        } else {
+          h2_tab_copy(orig, ctl->tabs + (size_t)last * slots, slots, tid, ~0u, 0, 0);
+        }
         if (tid < K) {  // the call's counters: sums over the chunks, the longest chunk's clock (they ran side by side)
-          const grdma_h2_deframe_result& c = ctl->res[tid];
-          atomicAdd(&s_stat[0], (unsigned long long)c.bulk_steps);
-          atomicAdd(&s_stat[1], (unsigned long long)c.bulk_frames);
-          atomicAdd(&s_stat[2], (unsigned long long)c.boundary_steps);
-          atomicMax(&s_stat[3], (unsigned long long)c.t_total);
+          atomicAdd(&s_stat[0], (unsigned long long)st_bulk);
+          atomicAdd(&s_stat[1], (unsigned long long)st_frames);
+          atomicAdd(&s_stat[2], (unsigned long long)st_bsteps);
+          atomicMax(&s_stat[3], (unsigned long long)st_total);
         }
         __syncthreads();
-        if (tid == 0) {
-          grdma_h2_parser_dev g = ctl->gp[last];
-          g.tab = orig;
-          *gp = g;
-          grdma_h2_deframe_result r = ctl->res[last];
-          r.nevents = total;
-          r.slices_done = ctl->s_begin[K];
-          r.bulk_steps = s_stat[0];
-          r.bulk_frames = s_stat[1];
-          r.boundary_steps = s_stat[2];
-          r.t_total = s_stat[3];
-          *res = r;
-          ctl->n_merged++;
+        if (installer) {
+          g_last.tab = orig;
+          *gp = g_last;
+          r_last.nevents = total;
+          r_last.slices_done = nslices;
+          r_last.bulk_steps = s_stat[0];
+          r_last.bulk_frames = s_stat[1];
+          r_last.boundary_steps = s_stat[2];
+          r_last.t_total = s_stat[3];
+          *res = r_last;
+          ctl->n_merged = n_merged0 + 1;
           ctl->ok = 1;
+          uint64_t* d = ctl->dbg[H2_KMAX];
+          d[0] = tm0; d[1] = tm1; d[2] = tm2; d[3] = __builtin_amdgcn_s_memtime();
         }
       }
       return;

@@ -105,6 +105,16 @@ class Parser:
         check(self.lib.grdma_h2_parser_chunk_stats(self.h, out))
         return int(out[0]), int(out[1])
 
+    def chunk_phases(self, kmax=128):
+        """profiling aid: per chunk (start, cuts found, map copied, parsed, compared, slices) and the merge's stamps, in device-clock ticks relative to the earliest"""
+        n = (kmax + 1) * 8
+        out = (u64 * n)()
+        self.lib.grdma_h2_parser_chunk_dbg.restype = C.c_int
+        self.lib.grdma_h2_parser_chunk_dbg.argtypes = [C.c_void_p, C.POINTER(u64), u64]
+        check(self.lib.grdma_h2_parser_chunk_dbg(self.h, out, n))
+        rows = [[int(out[r * 8 + c]) for c in range(8)] for r in range(kmax + 1)]
+        return rows
+
     def deframe(self, arena_dev_ptr, slices, cap=None):
         """slices: list of (offset, len) in the arena. -> (h2 error, events)"""
         n = len(slices)

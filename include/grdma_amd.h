@@ -540,7 +540,8 @@ void grdma_h2_last_deframe_stats(uint64_t out[8]);
 /* grpc_chttp2_perform_read (parsing.cc:56-253) + grpc_deframe_unprocessed_incoming_frames
  * (frame_data.cc:92-276) over n delivered slices {offset, length} of d_arena.
  * Returns the number of events; *h2_error = connection error, if any. */
-int grdma_h2_parser_chunk_stats(grdma_h2_parser* p, uint64_t out[2]);  /* calls planned / merged by the chunked deframer */
+int grdma_h2_parser_chunk_stats(grdma_h2_parser* p, uint64_t out[2]);
+int grdma_h2_parser_chunk_dbg(grdma_h2_parser* p, uint64_t* out, uint64_t cap_words);  /* profiling aid: phase stamps of the last chunked call */  /* calls planned / merged by the chunked deframer */
 int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_read_slice* slices,
                          uint64_t n, grdma_h2_event* events_out, uint64_t cap, int* h2_error);
 
