@@ -83,6 +83,28 @@ __global__ __launch_bounds__(TXB_THREADS) TXB_KERNEL_ATTR void k_tx_plan_job(con
 #endif
 }
 
+// k_wire_txplan_job: the wire of round t and the send plan of round t + 1 in ONE launch.  A send plan is a one-workgroup,
+// latency-bound kernel; it needs the credit of round t - 1 and the sender's state after round t's plan -- not the wire of
+// round t -- and kernels of different graph branches do not run side by side on this stack, so the planner rides in the
+// copy kernel's grid: workgroup x = 0 of every link prices the next Send (k_tx_plan_job's body), workgroups x >= 1 move
+// the wire plan's tiles, sixteen waves each.  The wire plan is the one the planner of the launch before wrote; this
+// planner writes the other parity's (and the gather plan, whose reader -- the gather of round t -- has completed).
+__global__ __launch_bounds__(TXB_THREADS) void k_wire_txplan_job(const grdma_plan* const* wplans, const grdma_tx_op* txops,
+                                                                 const grdma_txf_ctl* ctls) {
+  if (blockIdx.x == 0) {
+    if (txf_body(txops[blockIdx.y], &ctls[blockIdx.y])) return;  // (uniform)
+    if (threadIdx.x >= PLAN_THREADS) return;
+    tx_plan_body(txops[blockIdx.y]);
+    if (threadIdx.x == 0) txops[blockIdx.y].result->dbg[9] = 0;
+    return;
+  }
+  const grdma_plan* plan = wplans[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = ((blockIdx.x - 1) * TXB_THREADS + threadIdx.x) >> 6;
+  const uint32_t nwaves = ((gridDim.x - 1) * TXB_THREADS) >> 6;
+  run_plan<256, GRDMA_COPY_CONTIG>(plan, wave, nwaves, lane);
+}
+
 // k_tx_plan_seq: gridDim.y Sends of the SAME connection back to back in one launch (a sender that
 // runs ahead of its reader: rdma_flush retried before the peer has read).  ops[k * gridDim.x + link]
 // is Send k of connection `link`; every Send has its own plans, staging buffer and result block and
@@ -361,6 +383,7 @@ __attribute__((visibility("hidden"))) const void* grdma_kernel_fn(int which) {
     case 4: return reinterpret_cast<const void*>(&k_tx_plan_seq);
     case 5: return reinterpret_cast<const void*>(&k_tx_commit);
     case 6: return reinterpret_cast<const void*>(&k_tx_plan_job);
+    case 7: return reinterpret_cast<const void*>(&k_wire_txplan_job);
     default: return nullptr;
   }
 }

@@ -64,6 +64,7 @@ hipError_t grdma_launch_tx_index(grdma_txf_ctl*, uint32_t, uint32_t, hipStream_t
 hipError_t grdma_launch_tx_plan_job(const grdma_tx_op*, const grdma_txf_ctl*, uint32_t, hipStream_t);
 const void* grdma_kernel_fn_plan_pair(void);
 const void* grdma_kernel_fn_plan_pair_job(void);
+const void* grdma_kernel_fn_rxplan_gather_job(void);
 uint32_t grdma_kernel_threads(int which);
 uint32_t grdma_copy_resident_blocks(void);
 }
@@ -2216,6 +2217,10 @@ struct grdma_stream_job {
                                       // the start of a step, k_tx_fast per Send, the general planner behind it for the rest
   grdma_txf_ctl* d_txf = nullptr;     // [n]
   int pair_job = 1;                   // pipelined graph: drain of round t and Send of round t + 1 in one launch (k_plan_pair_job)
+  int fuse = 0;                       // GRDMA_JOB_FUSE=1 (experiment, off): the planners ride in the copy kernels' grids
+                                      // (k_wire_txplan_job, k_rxplan_gather_job), three launches per round.  Measured: no
+                                      // gain -- a planner's dependent loads run ~2.3 x slower beside a copy that saturates
+                                      // the memory system (profiles/r03_fused_schedule_experiment.txt)
   int rx_fast = 1;                    // drains of one-Send rounds go through k_rx_fast first (grdma_rx_fast.hip), the
                                       // general planner behind it only does what that kernel declined
   int cumask_bits = 0;                // planner CUs (low bits of the mask); 0 = off
@@ -2242,7 +2247,22 @@ struct grdma_stream_job {
 namespace {
 
 inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 : 2); }
-inline int job_fastkey(const grdma_stream_job* j) { return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0) | (j->pair_job ? 8 : 0); }
+inline int job_fastkey(const grdma_stream_job* j) {
+  return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0) | (j->pair_job ? 8 : 0) | (j->fuse ? 16 : 0);
+}
+// copy workgroups (1024 threads: one per CU) next to a planner workgroup in a fused launch: every CU but the planner's
+inline uint32_t job_fused_copy_blocks() {
+  static const uint32_t v = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2)
+      return 255u;
+    const char* e = getenv("GRDMA_FUSED_COPY_BLOCKS");
+    const long o = e ? atol(e) : 0;
+    return o > 0 ? (uint32_t)o : (uint32_t)(cus - 1);
+  }();
+  return v;
+}
 inline bool job_exec_stale(const grdma_stream_job* j) {
   return !j->exec || j->exec_rounds != j->rounds || j->exec_pipeline != j->pipeline || j->exec_fastkey != job_fastkey(j) ||
          j->exec_hooks_gen != j->hooks_gen;
@@ -2622,6 +2642,39 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
       }
       if (e == hipSuccess) e = add_rx(t, rxop, {last});
       if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t]});
+    } else if (fast && tfast && j->pair_job && j->fuse && !j->direct) {
+      // Fused schedule: the two planners ride in the grids of copy kernels they do not depend on -- the send plan of
+      // round t + 1 beside the wire of round t (it needs the credit of round t - 1 and the sender's state, both there),
+      // the drain plan of round t beside the gather of round t + 1 (which needs that send plan and a staging buffer
+      // the wire of round t - 1 has left).  Three launches per round, and the chip is not idle behind a one-workgroup
+      // planner any more; what every plan sees -- credit, cursor, ring -- is what it saw in the paired schedule, so
+      // the rounds are the same rounds:
+      //   W_t + P_{t+1}: G_t, A_{t-1}      X_t + G_{t+1}: W_t      A_t: X_t
+      if (t == 0) {
+        e = add_tx(0, txop, {});
+        if (e == hipSuccess) e = add(&G[0], f_cpy, dim3(txb, n), ct, gplans, {P[0]});
+      }
+      const bool more = t + 1 < R;
+      const uint32_t fb = 1 + std::max<uint32_t>(1, std::min<uint32_t>((txb + 3) / 4, job_fused_copy_blocks()));
+      if (e == hipSuccess) {
+        if (more) {
+          const void* txop_next = j->d_txop + job_opset(t + 1) * n;
+          e = add3(&W[t], grdma_kernel_fn(7), dim3(fb, n), grdma_tx_plan_job_threads(), wplans, txop_next, j->d_txf,
+                   {G[t], at(A, t, 1)});
+          P[t + 1] = W[t];
+        } else {
+          e = add(&W[t], f_cpy, dim3(txb, n), ct, wplans, {G[t], at(A, t, 1)});
+        }
+      }
+      if (e == hipSuccess) {
+        if (more) {
+          e = add2(&X[t], grdma_kernel_fn_rxplan_gather_job(), dim3(fb, n), grdma_rx_plan_job_threads(), rxop, gplans, {W[t]});
+          G[t + 1] = X[t];
+        } else {
+          e = add_rx(t, rxop, {W[t]});
+        }
+      }
+      if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t]});
     } else if (fast && tfast && j->pair_job) {
       // One launch for the drain of round t and the Send of round t + 1 (k_plan_pair_job): kernels of different
       // branches of a graph do not overlap on this stack (measured: even planner workgroups small enough to sit
@@ -2845,6 +2898,7 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
   if (const char* e = getenv("GRDMA_JOB_CUMASK")) j->cumask_bits = atoi(e);
   if (const char* e = getenv("GRDMA_RX_FAST")) j->rx_fast = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_PAIR_JOB")) j->pair_job = atoi(e) != 0;
+  if (const char* e = getenv("GRDMA_JOB_FUSE")) j->fuse = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_TX_FAST")) j->tx_fast = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_SLIM_AFTER")) {  // experiment (tools/gpu_slim.sh): see grdma_stream_job_run
     j->slim_after = atoi(e);

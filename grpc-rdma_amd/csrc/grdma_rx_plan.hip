@@ -1492,6 +1492,30 @@ void k_plan_pair_job(const grdma_rx_op* rxops, const grdma_tx_op* txops, const g
 }
 
 // ----------------------------------------------------------------------------
+// k_rxplan_gather_job: the drain plan of round t and the GATHER of round t + 1 in ONE launch (the other half of the
+// fused schedule, see k_wire_txplan_job in grdma_kernels.hip): the receive planner -- one workgroup, 28 us of dependent
+// memory round trips during which the rest of the chip used to idle -- needs the wire of round t; the gather of round
+// t + 1 needs the send plan the launch before produced and a staging buffer the wire of round t - 1 has left.  Neither
+// needs the other: workgroup x = 0 of every link plans the drain (k_rx_plan_job's body), workgroups x >= 1 move the
+// gather plan's tiles.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(RXF_THREADS)
+void k_rxplan_gather_job(const grdma_rx_op* rxops, const grdma_plan* const* gplans) {
+  if (blockIdx.x == 0) {
+    if (rxf_body(rxops[blockIdx.y])) return;  // (uniform)
+    if (threadIdx.x >= PLAN_THREADS) return;
+    rx_plan_body(rxops[blockIdx.y]);
+    if (threadIdx.x == 0) rxops[blockIdx.y].result->dbg[9] = 0;
+    return;
+  }
+  const grdma_plan* plan = gplans[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = ((blockIdx.x - 1) * RXF_THREADS + threadIdx.x) >> 6;
+  const uint32_t nwaves = ((gridDim.x - 1) * RXF_THREADS) >> 6;
+  run_plan<256, true>(plan, wave, nwaves, lane);
+}
+
+// ----------------------------------------------------------------------------
 // k_engine: persistent latency engine.  One workgroup stays resident and takes
 // Send / drain commands from a mailbox in pinned host memory, so a 64-byte RPC
 // pays a PCIe doorbell read instead of a kernel launch.  The command bodies are
@@ -1670,6 +1694,7 @@ extern "C" int grdma_rx_fast_drains(uint64_t out[6]) {
   for (int i = 0; i < 6; i++) out[i] = v[i];
   return 0;
 }
+extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rxplan_gather_job(void) { return reinterpret_cast<const void*>(&k_rxplan_gather_job); }
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_job(void) { return reinterpret_cast<const void*>(&k_plan_pair_job); }
 // (this translation unit's copy of the index body's counters: the pair kernel's Sends)
 extern "C" __attribute__((visibility("hidden"))) int grdma_tx_fast_sends_pair(uint64_t out[2]) {
