@@ -970,6 +970,9 @@ def main():
         ev0 = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "1024", str(MIB), "1", "0", "2"], 120,
                        dict(env, GRPC_RDMA_HIP_SEND_BUFFER_KB="0"))
         out["value_endpoint_vtable_no_send_buffers"] = ev0.get("GiBps")
+        # ... and without the reader's byte-sum check of every delivered slice (~57 us of the reading thread per MiB)
+        evu = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "1024", str(MIB), "0", "0", "2"], 120, env)
+        out["value_endpoint_vtable_unchecked"] = evu.get("GiBps")
         # the same stream with both pairs in latency mode: commands through the resident engine, the receive arena in
         # pinned host memory (no launch chain and no device-to-host copy per call); first hardware run of this
         # combination, in the helper process like the leg above

@@ -201,3 +201,78 @@ def test_chunked_and_sequential_deframer_agree_call_by_call(gpu):
     assert on.dev.chunk_stats()[1] >= 1
     on.close()
     off.close()
+
+
+def test_h2_pipe_at_the_bench_configuration_matches_the_oracle(gpu):
+    """What bench.py's value_with_h2 leg runs, at its size: 256 messages of 1 MiB per step framed on the device
+    (k_h2_frame_index / k_h2_frame_emit), carried through a 128 MiB ring by the streaming job, deframed over chunks --
+    framing and deframing as nodes of the job's graph, two jobs over one connection taking turns.  Every step's events
+    equal the oracle's over the slices that step delivered (33 k slices, 83 k events per step), the delivered bytes are
+    the framed messages, and every step after the first (which leaves the hint) was merged from chunks."""
+    g = gpu
+    from grpc_rdma_amd import h2 as h2host, h2dev, stream as gs
+    n_msgs, msg_len = 256, 1 << 20
+    payload = ((np.arange(n_msgs * msg_len, dtype=np.uint32) * 7 + 3) % 251).astype(np.uint8)
+    pbuf = g.DeviceBuffer(data=payload.tobytes())
+    msgs = [(pbuf.ptr + i * msg_len, msg_len, 1, 0) for i in range(n_msgs)]
+    lens = [len(it[1]) if it[0] == "inl" else it[1][1] for it in h2host.frame_message(msg_len, 1, 16384)] * n_msgs
+    scratch = g.DeviceBuffer(nbytes=max(lens) + 64)
+    sge = [(scratch.ptr, n) for n in lens]  # placeholders: the framing kernels overwrite the table
+    R = 128 << 20
+    tx, rx = g.Pair(R, 4095), g.Pair(R, 4095)
+    g.connect_pairs(tx, rx)
+    N = sum(lens)
+    scap = 2 * len(lens) + 64 + N // 256
+    dst_cap = N + 16 * scap + 4096
+    parser = h2dev.Parser(False)
+    assert parser.open_streams([1]) == 0
+    jobs, pipes, dsts = [], [], []
+    for _ in range(2):
+        dst = g.DeviceBuffer(nbytes=dst_cap)
+        job = gs.StreamJob(tx, rx, sge, dst.ptr, dst_cap, scap, 16)
+        job.set_pipeline(True)
+        r = job.run(gs.RUN_EAGER)
+        job.set_rounds(int(max(r.tx_rounds, r.rx_rounds)))
+        r = job.run(gs.RUN_GRAPH)
+        assert r.done and r.bytes_delivered == N
+        pipes.append(h2dev.Pipe(job, msgs, parser, len(job.delivered_slices(0)), 4 * len(lens) + 1024))
+        jobs.append(job)
+        dsts.append(dst)
+    po = pyorc.H2Parser(expect_client_prefix=False)
+    assert po.open_stream(1) == 0
+    # the framed stream the sender builds: per message 64 frames of 16384 bytes and one of 5
+    hdr = lambda n: n.to_bytes(3, "big") + b"\x00\x00" + (1).to_bytes(4, "big")
+    steps = 3
+    for step in range(steps):
+        p_, job, dst = pipes[step % 2], jobs[step % 2], dsts[step % 2]
+        p_.enqueue()
+        res = p_.sync(want_events=True)
+        assert res["h2_error"] == 0 and res["framed"] == len(lens) and not res["frame_overflow"] and not res["deframe_overflow"]
+        ds = job.delivered_slices(0)
+        assert res["parsed"] == len(ds)
+        got = dst.read(dst_cap)
+        ev_o = []
+        for i, (o, n) in enumerate(ds):
+            rc, ev = po.feed(got[o:o + n], cap=1024)
+            assert rc == 0
+            ev_o += [(k, a, b, c, d, i) for k, a, b, c, d in ev]
+        assert len(res["event_list"]) == len(ev_o)
+        assert res["event_list"] == ev_o, "step %d" % step
+        if step == 0:
+            stream = b"".join(got[o:o + n] for o, n in ds)
+            exp = bytearray()
+            for i in range(n_msgs):
+                body = b"\x00" + msg_len.to_bytes(4, "big") + payload[i * msg_len:(i + 1) * msg_len].tobytes()
+                for off in range(0, len(body), 16384):
+                    piece = body[off:off + 16384]
+                    exp += hdr(len(piece)) + piece
+            assert stream == bytes(exp)
+    planned, merged = parser.chunk_stats()
+    assert merged == steps - 1 and planned >= merged
+    for p_ in pipes:
+        p_.close()
+    for j_ in jobs:
+        j_.close()
+    parser.close()
+    tx.close()
+    rx.close()

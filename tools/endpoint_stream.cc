@@ -13,6 +13,8 @@
 //        their own, the way a gRPC process has the two directions of a connection on different threads
 //        (pair.h:64-81: one writer, one reader per pair); 1: one loop polls both endpoints
 // env:   GRPC_RDMA_RING_BUFFER_SIZE_KB, GRPC_RDMA_MAX_SGE ... as the reference reads them
+#include <emmintrin.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -35,24 +37,22 @@ using namespace grdma_core;
 
 static thread_local std::deque<grpc_closure*> g_queue;  // a miniature ExecCtx (one per polling thread)
 
-// Sum of the bytes of a slice (the check of the delivered stream; independent of where the slices are cut).
-// Eight bytes per step: the even and the odd bytes of a word are added into four 16-bit lanes each, folded
-// every 128 steps -- the check sits inside the timed loop and should not be what is measured.
+// Sum of the bytes of a slice (the check of the delivered stream; independent of where the slices are cut).  The check
+// sits inside the timed loop, on the reading thread, and should not be what is measured: psadbw sums sixteen bytes per
+// instruction (SSE2, the x86-64 baseline), four accumulators -- ~18 GB/s from memory where the word-wise loop it
+// replaces did 12, i.e. 57 instead of 87 us of the reader's time per MiB.
 static uint64_t sum_bytes(const uint8_t* b, size_t n) {
-  uint64_t total = 0;
+  __m128i a0 = _mm_setzero_si128(), a1 = _mm_setzero_si128(), a2 = _mm_setzero_si128(), a3 = _mm_setzero_si128();
+  const __m128i z = _mm_setzero_si128();
   size_t k = 0;
-  const uint64_t M = 0x00FF00FF00FF00FFull;
-  while (n - k >= 8) {
-    uint64_t acc = 0;
-    size_t steps = (n - k) / 8;
-    if (steps > 128) steps = 128;  // 128 * 2 * 255 < 65536: the 16-bit lanes cannot overflow
-    for (size_t i = 0; i < steps; i++, k += 8) {
-      uint64_t w;
-      memcpy(&w, b + k, 8);
-      acc += (w & M) + ((w >> 8) & M);
-    }
-    total += (acc & 0xFFFF) + ((acc >> 16) & 0xFFFF) + ((acc >> 32) & 0xFFFF) + (acc >> 48);
+  for (; k + 64 <= n; k += 64) {
+    a0 = _mm_add_epi64(a0, _mm_sad_epu8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(b + k)), z));
+    a1 = _mm_add_epi64(a1, _mm_sad_epu8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(b + k + 16)), z));
+    a2 = _mm_add_epi64(a2, _mm_sad_epu8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(b + k + 32)), z));
+    a3 = _mm_add_epi64(a3, _mm_sad_epu8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(b + k + 48)), z));
   }
+  a0 = _mm_add_epi64(_mm_add_epi64(a0, a1), _mm_add_epi64(a2, a3));
+  uint64_t total = (uint64_t)_mm_cvtsi128_si64(a0) + (uint64_t)_mm_cvtsi128_si64(_mm_unpackhi_epi64(a0, a0));
   for (; k < n; k++) total += b[k];
   return total;
 }
