@@ -662,6 +662,20 @@ def main():
             ok = ok and r["h2_error"] == 0 and not r["frame_overflow"] and not r["deframe_overflow"] and \
                 r["framed"] == len(w.lens) and r["parsed"] == p_.delivered and \
                 sum(1 for e in evs if e[0] == 5) == w.n_msgs and sum(e[2] for e in evs if e[0] == 4) == w.n_msgs * w.msg_len
+        # the events of the last step once more, through a parser of its own with the one-wave sequential deframer over the
+        # same delivered slices (both are product paths: the chunked deframer must not change a single event)
+        try:
+            if chunks is not False:
+                ps_ = h2dev.Parser(False, boundary_step=boundary_step, bulk_pairs=bulk_pairs, chunks=False)
+                assert ps_.open_streams([1]) == 0
+                last = (max(2, warmup) + steps - 1) % 2 if steps else 1
+                rl = pipes[last].sync(want_events=True)
+                err_, ev_seq = ps_.deframe(dsts[last].ptr, jobs[last].delivered_slices(0), cap=pipes[last].events_cap)
+                ps_.close()
+                stage_us["events_equal_sequential_deframer"] = bool(err_ == 0 and ev_seq == rl["event_list"])
+                ok = ok and stage_us["events_equal_sequential_deframer"]
+        except Exception as e:
+            stage_us["events_equal_sequential_deframer_error"] = err_text(e)
         if os.environ.get("BENCH_H2_CHUNK_PHASES"):
             rows = parser.chunk_phases()
             live = [r for r in rows[:128] if r[0]]
