@@ -238,7 +238,8 @@ struct grdma_pair {
   // armed read (grdma_pair_arm_read): the LOCAL peer's small sends carry this pair's drain in the same
   // engine command; the next grdma_endpoint_read picks the completion up instead of asking for one
   uint64_t armed_reads = 0;          // max_reads of the armed drain, 0 = not armed
-  bool armed_done = false;           // a chained drain has completed and nobody has consumed it yet
+  std::atomic<bool> armed_done{false};  // a chained drain has completed and nobody has consumed it yet (set by the
+                                     // sender's thread, consumed by the receiver's)
   uint64_t armed_hits = 0;
   // asynchronous endpoint operations (grdma_endpoint_set_async): the send and the receive direction on streams of
   // their own, one Send and one drain in flight at most, completions in pinned host memory
@@ -603,6 +604,10 @@ int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_curs
 int run_recv(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_reads,
              uint64_t raw_cap) {
   grdma_profiler profiler(GRDMA_STATS_TIME_PAIR_RECV);  // pair.cc:265
+  // a drain that rode behind the peer's send has delivered into the result block and the slice table: those bytes have
+  // left the ring, their credit is out -- another drain now would overwrite the only record of them
+  if (p->armed_done.load(std::memory_order_acquire))
+    return fail(GRDMA_ERR_INVALID, "an armed read has completed: grdma_endpoint_read takes it before anything else drains");
   grdma_hostblk* h = p->h;
   fill_rxop(p, arena, arena_cap, max_reads, raw_cap);
   const uint32_t blocks = copy_blocks_for(p->ring_size);

@@ -98,7 +98,8 @@ struct slot_data {
 std::atomic<bool> g_enabled{false};
 thread_local int t_slot = -1;
 std::mutex g_mu;
-std::vector<std::unique_ptr<slot_data>> g_slots;  // index = slot number
+std::vector<std::shared_ptr<slot_data>> g_slots;  // index = slot number; users hold a reference of their own while they
+                                                  // work on a slot (shutdown / re-init on another thread only drop the table's)
 
 const char* const kNames[GRDMA_STATS_TIME_MAX_OP_SIZE] = {
     "POLLABLE_EPOLL", "POLLSET_WORK", "TRANSPORT_DO_READ", "TRANSPORT_CONTINUE_READ",
@@ -108,15 +109,15 @@ const char* const kNames[GRDMA_STATS_TIME_MAX_OP_SIZE] = {
     "ASYNC_NEXT_INTERNAL", "FINALIZE_RESULT", "DESERIALIZE", "ADHOC_1", "ADHOC_2", "ADHOC_3", "ADHOC_4",
     "ADHOC_5", "ADHOC_6", "ADHOC_7", "ADHOC_8", "ADHOC_9", "ADHOC_10"};
 
-slot_data* my_slot() {
+std::shared_ptr<slot_data> my_slot() {
   if (t_slot < 0) return nullptr;
   std::lock_guard<std::mutex> lg(g_mu);
-  return (size_t)t_slot < g_slots.size() ? g_slots[(size_t)t_slot].get() : nullptr;
+  return (size_t)t_slot < g_slots.size() ? g_slots[(size_t)t_slot] : nullptr;
 }
 
 void add(int op, int64_t val, bool scale) {
   if (!g_enabled.load(std::memory_order_relaxed) || op < 0 || op >= GRDMA_STATS_TIME_MAX_OP_SIZE) return;
-  slot_data* s = my_slot();
+  const std::shared_ptr<slot_data> s = my_slot();
   if (!s) return;
   if (val >= kMaxValue) val = kMaxValue - 1;  // (the reference asserts)
   std::lock_guard<std::mutex> lg(s->mu);
@@ -173,10 +174,10 @@ int64_t grdma_stats_time_now_ns(void) {
 // {mean, p50, p95, p99, max} of one op of one slot in nanoseconds (unscaled); returns the count
 uint64_t grdma_stats_time_get(int slot, int op, double out[5]) {
   if (slot < 0 || op < 0 || op >= GRDMA_STATS_TIME_MAX_OP_SIZE) return 0;
-  slot_data* s;
+  std::shared_ptr<slot_data> s;
   {
     std::lock_guard<std::mutex> lg(g_mu);
-    s = (size_t)slot < g_slots.size() ? g_slots[(size_t)slot].get() : nullptr;
+    if ((size_t)slot < g_slots.size()) s = g_slots[(size_t)slot];
   }
   if (!s) return 0;
   std::lock_guard<std::mutex> lg(s->mu);
@@ -202,13 +203,13 @@ int64_t grdma_stats_time_print(char* buf, uint64_t cap) {
   out += "=================================Profiling Result=================================\n";
   snprintf(line, sizeof(line), "Unit %s\n", unit);
   out += line;
-  std::vector<slot_data*> slots;
+  std::vector<std::shared_ptr<slot_data>> slots;
   {
     std::lock_guard<std::mutex> lg(g_mu);
     for (auto& s : g_slots)
-      if (s) slots.push_back(s.get());
+      if (s) slots.push_back(s);
   }
-  for (slot_data* s : slots) {
+  for (const std::shared_ptr<slot_data>& s : slots) {
     std::lock_guard<std::mutex> lg(s->mu);
     std::string rows;
     for (int op = 0; op < GRDMA_STATS_TIME_MAX_OP_SIZE; op++) {
