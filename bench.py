@@ -678,9 +678,9 @@ def main():
             stage_us["events_equal_sequential_deframer_error"] = err_text(e)
         if os.environ.get("BENCH_H2_CHUNK_PHASES"):
             rows = parser.chunk_phases()
-            live = [r for r in rows[:128] if r[0]]
+            live = [r for r in rows[:-1] if r[0]]
             ph = [[(r[i] - r[0]) for i in range(5)] + [r[5]] for r in live]  # (every XCD has a clock of its own)
-            mg = rows[128]
+            mg = rows[-1]
             import statistics as st_
             sys.stderr.write("chunk phases, device-clock ticks from each chunk's own start (the deframer's 779 us are 1.87 M ticks):\n")
             for name, i in (("cuts", 1), ("copied", 2), ("parsed", 3), ("compared", 4), ("slices", 5)):
@@ -891,7 +891,7 @@ def main():
             out["with_h2_stages"] = hh["stages"]
             out["config"]["with_h2_leg"] = ("k_h2_frame_index + k_h2_frame_emit -> the job -> k_h2_deframe inside the timed pipeline, library defaults "
                                             "(framing and deframing are kernel nodes of the job's own graph: one launch per step; "
-                                            "message-boundary step on, 64 frames per bulk step, the delivered slices parsed as up to 128 "
+                                            "message-boundary step on, 64 frames per bulk step, the delivered slices parsed as up to 256 "
                                             "chunks side by side and merged after the chain of end states verified, no clock samples); "
                                             "value_with_h2_stages_around_the_graph: the stages enqueued around the job's graph launch; "
                                             "value_with_h2_sequential_deframer: one parsing wave over the whole list; "

@@ -54,7 +54,7 @@ struct grdma_h2_parser {
   hipEvent_t last_deframed = nullptr;
 };
 
-// How many chunks a parser created without saying so cuts a long list into: GRDMA_H2_CHUNKS (default and at most 128, 0 or 1 = the
+// How many chunks a parser created without saying so cuts a long list into: GRDMA_H2_CHUNKS (default and at most 256, 0 or 1 = the
 // sequential deframer only).
 static int h2_chunks_default() {
   static int v = -1;
@@ -114,8 +114,13 @@ static void h2_enqueue_deframe(grdma_h2_parser* p, const uint8_t* arena, const g
 static void h2_enqueue_frame(const grdma_h2_msg_dev* d_msgs, uint64_t n, uint32_t max_frame, grdma_sge* out, uint64_t cap,
                              uint8_t* hdr, uint64_t hdr_cap, grdma_h2_msg_pos* d_pos, grdma_h2_frame_result* d_res,
                              hipStream_t st) {
-  hipLaunchKernelGGL(k_h2_frame_index, dim3(1), dim3(256), 0, st, d_msgs, n, max_frame, cap, hdr_cap, d_pos, d_res);
   const uint64_t per = H2_EMIT_THREADS / 64;
+  if (n <= H2_FRAME_ONE_MAX) {  // one launch: every workgroup sums what lies in front of its messages itself
+    hipLaunchKernelGGL(k_h2_frame_one, dim3((unsigned)((n + per - 1) / per)), dim3(H2_EMIT_THREADS), 0, st, d_msgs, n, max_frame,
+                       out, cap, hdr, hdr_cap, d_res);
+    return;
+  }
+  hipLaunchKernelGGL(k_h2_frame_index, dim3(1), dim3(256), 0, st, d_msgs, n, max_frame, cap, hdr_cap, d_pos, d_res);
   hipLaunchKernelGGL(k_h2_frame_emit, dim3((unsigned)((n + per - 1) / per)), dim3(H2_EMIT_THREADS), 0, st, d_msgs, n, max_frame,
                      out, cap, hdr, hdr_cap, (const grdma_h2_msg_pos*)d_pos);
 }
@@ -487,13 +492,21 @@ grdma_h2_pipe* grdma_h2_pipe_create(grdma_stream_job* job, uint32_t link, const 
     grdma_job_hook pre[2], post[2];
     memset(pre, 0, sizeof(pre));
     memset(post, 0, sizeof(post));
-    pre[0] = grdma_job_hook{(const void*)k_h2_frame_index, 1, 256,
-                            {ptr(p->d_msgs), arg(p->nmsgs), arg(p->max_frame), arg(p->count), arg(p->hdr_cap), ptr(p->d_pos),
-                             ptr(p->d_fres)}};
     const uint64_t per = H2_EMIT_THREADS / 64;
-    pre[1] = grdma_job_hook{(const void*)k_h2_frame_emit, (uint32_t)((p->nmsgs + per - 1) / per), H2_EMIT_THREADS,
-                            {ptr(p->d_msgs), arg(p->nmsgs), arg(p->max_frame), ptr(p->d_sges), arg(p->count), ptr(p->d_hdr),
-                             arg(p->hdr_cap), ptr(p->d_pos)}};
+    uint32_t n_pre = 2;
+    if (p->nmsgs <= H2_FRAME_ONE_MAX) {
+      pre[0] = grdma_job_hook{(const void*)k_h2_frame_one, (uint32_t)((p->nmsgs + per - 1) / per), H2_EMIT_THREADS,
+                              {ptr(p->d_msgs), arg(p->nmsgs), arg(p->max_frame), ptr(p->d_sges), arg(p->count), ptr(p->d_hdr),
+                               arg(p->hdr_cap), ptr(p->d_fres)}};
+      n_pre = 1;
+    } else {
+      pre[0] = grdma_job_hook{(const void*)k_h2_frame_index, 1, 256,
+                              {ptr(p->d_msgs), arg(p->nmsgs), arg(p->max_frame), arg(p->count), arg(p->hdr_cap), ptr(p->d_pos),
+                               ptr(p->d_fres)}};
+      pre[1] = grdma_job_hook{(const void*)k_h2_frame_emit, (uint32_t)((p->nmsgs + per - 1) / per), H2_EMIT_THREADS,
+                              {ptr(p->d_msgs), arg(p->nmsgs), arg(p->max_frame), ptr(p->d_sges), arg(p->count), ptr(p->d_hdr),
+                               arg(p->hdr_cap), ptr(p->d_pos)}};
+    }
     uint32_t n_post;
     if (p->chunked) {
       post[0] = grdma_job_hook{(const void*)k_h2_deframe_chunks, (uint32_t)parser->chunks_want, H2_DEFRAME_THREADS,
@@ -508,7 +521,7 @@ grdma_h2_pipe* grdma_h2_pipe_create(grdma_stream_job* job, uint32_t link, const 
                                 ptr(p->d_dres)}};
       n_post = 1;
     }
-    if (grdma_job_set_hooks(job, pre, 2, post, n_post) != 0) {
+    if (grdma_job_set_hooks(job, pre, n_pre, post, n_post) != 0) {
       grdma_h2_pipe_destroy(p);
       return nullptr;
     }

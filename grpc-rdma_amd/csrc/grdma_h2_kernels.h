@@ -211,39 +211,43 @@ __device__ __forceinline__ bool h2_msg_plain(const grdma_h2_msg_dev* msgs, uint6
   return max_frame > 5 && msgs[i].len != 0 && (i == 0 || msgs[i - 1].len != 0);
 }
 
+// sizes of message i and who lays it out (grdma_h2_msg_pos::mode)
+__device__ __forceinline__ void h2_msg_size(const grdma_h2_msg_dev* msgs, uint64_t i, uint32_t max_frame, uint64_t* n_sl,
+                                            uint64_t* n_hdr, uint64_t* n_wire, uint32_t* mode) {
+  if (h2_msg_plain(msgs, i, max_frame)) {
+    const uint64_t fcb = 5 + msgs[i].len;
+    const uint64_t F = (fcb + max_frame - 1) / max_frame;
+    *n_sl = 2 * F;
+    *n_hdr = 32 * F;
+    *n_wire = 9 * F + fcb;
+    *mode = 1;
+    return;
+  }
+  // incoming back-slice state: replay the run of empty messages in front
+  uint64_t overflow = 0;
+  uint64_t j = i;
+  while (j > 0 && msgs[j - 1].len == 0) j--;
+  frame_walk pre = {0, 0, 0, 0};
+  for (; j < i; j++) walk_message<false>(msgs[j], max_frame, &pre, nullptr, nullptr, ~0ull, ~0ull, &overflow);
+  frame_walk me = {0, 0, 0, pre.back_inl};
+  walk_message<false>(msgs[i], max_frame, &me, nullptr, nullptr, ~0ull, ~0ull, &overflow);
+  *n_sl = me.nslices;
+  *n_hdr = me.hdr_off;
+  *n_wire = me.wire;
+  *mode = (i == 0 || msgs[i - 1].len != 0) ? 2u : 0u;
+}
+
 __global__ __launch_bounds__(256) void k_h2_frame_index(const grdma_h2_msg_dev* msgs, uint64_t nmsgs,
                                                         uint32_t max_frame, uint64_t cap, uint64_t hdr_cap,
                                                         grdma_h2_msg_pos* pos, grdma_h2_frame_result* res) {
   __shared__ uint64_t s_wave[4];
   const uint64_t tid = threadIdx.x;
-  uint64_t overflow = 0;
   uint64_t base_sl = 0, base_hdr = 0, base_wire = 0;
   for (uint64_t m0 = 0; m0 < nmsgs; m0 += 256) {
     const uint64_t i = m0 + tid;
     uint64_t n_sl = 0, n_hdr = 0, n_wire = 0;
     uint32_t mode = 0;
-    if (i < nmsgs) {
-      if (h2_msg_plain(msgs, i, max_frame)) {
-        const uint64_t fcb = 5 + msgs[i].len;
-        const uint64_t F = (fcb + max_frame - 1) / max_frame;
-        n_sl = 2 * F;
-        n_hdr = 32 * F;
-        n_wire = 9 * F + fcb;
-        mode = 1;
-      } else {
-        // incoming back-slice state: replay the run of empty messages in front
-        uint64_t j = i;
-        while (j > 0 && msgs[j - 1].len == 0) j--;
-        frame_walk pre = {0, 0, 0, 0};
-        for (; j < i; j++) walk_message<false>(msgs[j], max_frame, &pre, nullptr, nullptr, ~0ull, ~0ull, &overflow);
-        frame_walk me = {0, 0, 0, pre.back_inl};
-        walk_message<false>(msgs[i], max_frame, &me, nullptr, nullptr, ~0ull, ~0ull, &overflow);
-        n_sl = me.nslices;
-        n_hdr = me.hdr_off;
-        n_wire = me.wire;
-        mode = (i == 0 || msgs[i - 1].len != 0) ? 2u : 0u;
-      }
-    }
+    if (i < nmsgs) h2_msg_size(msgs, i, max_frame, &n_sl, &n_hdr, &n_wire, &mode);
     uint64_t tot_sl, tot_hdr, tot_wire;
     const uint64_t x_sl = block_excl_scan(n_sl, s_wave, &tot_sl);
     const uint64_t x_hdr = block_excl_scan(n_hdr, s_wave, &tot_hdr);
@@ -269,14 +273,10 @@ __global__ __launch_bounds__(256) void k_h2_frame_index(const grdma_h2_msg_dev* 
 }
 
 #define H2_EMIT_THREADS 256
-__global__ __launch_bounds__(H2_EMIT_THREADS) void k_h2_frame_emit(const grdma_h2_msg_dev* msgs, uint64_t nmsgs,
-                                                                  uint32_t max_frame, grdma_sge* out, uint64_t cap,
-                                                                  uint8_t* hdr, uint64_t hdr_cap,
-                                                                  const grdma_h2_msg_pos* pos) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t i = (uint64_t)blockIdx.x * (H2_EMIT_THREADS / 64) + (threadIdx.x >> 6);
-  if (i >= nmsgs) return;  // (wave-uniform)
-  const grdma_h2_msg_pos q = pos[i];
+// one wave lays out message i at position q
+__device__ __forceinline__ void h2_emit_message(const grdma_h2_msg_dev* msgs, uint64_t i, uint64_t nmsgs, uint32_t max_frame,
+                                                grdma_sge* out, uint64_t cap, uint8_t* hdr, uint64_t hdr_cap,
+                                                const grdma_h2_msg_pos q, int lane) {
   if (q.mode == 2) {
     if (lane == 0) {
       uint64_t overflow = 0;  // (k_h2_frame_index has reported it; here it only keeps the stores inside the arrays)
@@ -328,6 +328,89 @@ __global__ __launch_bounds__(H2_EMIT_THREADS) void k_h2_frame_emit(const grdma_h
     *reinterpret_cast<u64x2*>(&out[slot]) = e0;
     *reinterpret_cast<u64x2*>(&out[slot + 1]) = e1;
   }
+}
+
+__global__ __launch_bounds__(H2_EMIT_THREADS) void k_h2_frame_emit(const grdma_h2_msg_dev* msgs, uint64_t nmsgs,
+                                                                  uint32_t max_frame, grdma_sge* out, uint64_t cap,
+                                                                  uint8_t* hdr, uint64_t hdr_cap,
+                                                                  const grdma_h2_msg_pos* pos) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t i = (uint64_t)blockIdx.x * (H2_EMIT_THREADS / 64) + (threadIdx.x >> 6);
+  if (i >= nmsgs) return;  // (wave-uniform)
+  h2_emit_message(msgs, i, nmsgs, max_frame, out, cap, hdr, hdr_cap, pos[i], lane);
+}
+
+// Both steps in ONE launch for tables of up to H2_FRAME_ONE_MAX messages: every workgroup sums the sizes of the messages
+// in front of its own four itself (closed form per message: a few hundred multiply-adds against a kernel boundary and a
+// trip through memory for the positions), then its waves lay their messages out.  The workgroup of the last message
+// reports the totals.
+#define H2_FRAME_ONE_MAX 4096
+__global__ __launch_bounds__(H2_EMIT_THREADS) void k_h2_frame_one(const grdma_h2_msg_dev* msgs, uint64_t nmsgs,
+                                                                 uint32_t max_frame, grdma_sge* out, uint64_t cap,
+                                                                 uint8_t* hdr, uint64_t hdr_cap, grdma_h2_frame_result* res) {
+  __shared__ uint64_t s_part[H2_EMIT_THREADS / 64][3];
+  __shared__ uint64_t s_mine[H2_EMIT_THREADS / 64][3];
+  __shared__ uint32_t s_mode[H2_EMIT_THREADS / 64];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6;
+  constexpr uint32_t PER = H2_EMIT_THREADS / 64;
+  const uint64_t i0 = (uint64_t)blockIdx.x * PER;
+  // sizes of the messages in front of this workgroup's, one per thread per pass
+  uint64_t a_sl = 0, a_hdr = 0, a_wire = 0;
+  for (uint64_t j = threadIdx.x; j < i0; j += H2_EMIT_THREADS) {
+    uint64_t n_sl, n_hdr, n_wire;
+    uint32_t mode;
+    h2_msg_size(msgs, j, max_frame, &n_sl, &n_hdr, &n_wire, &mode);
+    a_sl += n_sl;
+    a_hdr += n_hdr;
+    a_wire += n_wire;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    a_sl += __shfl_xor(a_sl, d, 64);
+    a_hdr += __shfl_xor(a_hdr, d, 64);
+    a_wire += __shfl_xor(a_wire, d, 64);
+  }
+  if (lane == 0) {
+    s_part[wave][0] = a_sl;
+    s_part[wave][1] = a_hdr;
+    s_part[wave][2] = a_wire;
+    // ... and of my own message
+    uint64_t n_sl = 0, n_hdr = 0, n_wire = 0;
+    uint32_t mode = 0;
+    if (i0 + wave < nmsgs) h2_msg_size(msgs, i0 + wave, max_frame, &n_sl, &n_hdr, &n_wire, &mode);
+    s_mine[wave][0] = n_sl;
+    s_mine[wave][1] = n_hdr;
+    s_mine[wave][2] = n_wire;
+    s_mode[wave] = mode;
+  }
+  __syncthreads();
+  uint64_t b_sl = 0, b_hdr = 0, b_wire = 0;
+  for (uint32_t w = 0; w < PER; w++) {
+    b_sl += s_part[w][0];
+    b_hdr += s_part[w][1];
+    b_wire += s_part[w][2];
+  }
+  for (uint32_t w = 0; w < wave; w++) {
+    b_sl += s_mine[w][0];
+    b_hdr += s_mine[w][1];
+    b_wire += s_mine[w][2];
+  }
+  const uint64_t i = i0 + wave;
+  if (i + 1 == nmsgs && lane == 0) {  // the last message's wave knows the totals
+    const uint64_t t_sl = b_sl + s_mine[wave][0], t_hdr = b_hdr + s_mine[wave][1];
+    res->nslices = t_sl;
+    res->hdr_bytes = t_hdr;
+    res->wire_bytes = b_wire + s_mine[wave][2];
+    res->overflow = (t_sl > cap || t_hdr > hdr_cap) ? 1 : 0;
+  }
+  if (i >= nmsgs) return;  // (wave-uniform)
+  grdma_h2_msg_pos q;
+  q.sl = b_sl;
+  q.hdr = b_hdr;
+  q.mode = s_mode[wave];
+  q.pad = 0;
+  h2_emit_message(msgs, i, nmsgs, max_frame, out, cap, hdr, hdr_cap, q, lane);
 }
 
 // ---------------------------------------------------------------- RX deframing
@@ -1059,10 +1142,10 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe(grdma_h2_pars
 //                      sequential one.
 // The events, the parser state and the stream map are those of the sequential parse by construction.
 // ------------------------------------------------------------------------------------------------------------
-#define H2_KMAX 128
+#define H2_KMAX 256
 #define H2_CHUNK_MIN_SLICES 2048   // lists shorter than this go to the sequential deframer directly
-#define H2_CHUNK_SLICES 256        // a chunk is at least this long (K = min(wanted, nslices / this))
-#define H2_MERGE_GRID 64
+#define H2_CHUNK_SLICES 128        // a chunk is at least this long (K = min(wanted, nslices / this)): one 1 MiB message
+#define H2_MERGE_GRID 192
 struct grdma_h2_chunks {
   uint32_t K;          // chunks of this call, 0 = no plan
   uint32_t ok;         // k_h2_merge_or_deframe: 1 = merged
@@ -1228,7 +1311,7 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_deframe_chunks(grdma_
   // my two cuts (wave 0: where I start, wave 1: where the next chunk starts), the hinted stream's slot (wave 2)
   if (wave < 2) {
     const uint32_t j = k + wave;
-    const uint64_t span = 8 * (nslices / K);
+    const uint64_t span = 8 * (nslices / K) > 2048 ? 8 * (nslices / K) : 2048;  // (messages of up to ~16 MiB at 16 KiB frames)
     uint64_t cut = j == 0 ? 0 : j == K ? nslices : h2_find_cut(P, arena, slices, nslices, nslices * j / K, span, lane);
     if (lane == 0) s_cut[wave] = cut;
   } else {
@@ -1382,14 +1465,16 @@ __global__ __launch_bounds__(H2_DEFRAME_THREADS) void k_h2_merge_or_deframe(grdm
       }
     }
     __syncthreads();
-    if (tid < 64) {  // inclusive prefix sums of the event counts: two wave scans (K <= 128)
-      static_assert(H2_KMAX == 128, "two entries per lane");
-      const uint64_t lo = wave_incl_scan(s_pre[tid + 1], (int)tid);
-      const uint64_t lo_tot = __shfl(lo, 63, 64);
-      const uint64_t hi = wave_incl_scan(s_pre[tid + 65], (int)tid) + lo_tot;
-      s_pre[tid + 1] = lo;
-      s_pre[tid + 65] = hi;
-      if (tid == 63 && hi > ev_cap) s_bad = 1;  // (entries behind K are zero: hi of lane 63 is the total)
+    if (tid < 64) {  // inclusive prefix sums of the event counts: H2_KMAX / 64 wave scans with a carry
+      static_assert(H2_KMAX % 64 == 0, "whole waves");
+      uint64_t carry = 0;
+#pragma unroll
+      for (uint32_t c = 0; c < H2_KMAX / 64; c++) {
+        const uint64_t inc = wave_incl_scan(s_pre[c * 64 + tid + 1], (int)tid) + carry;
+        s_pre[c * 64 + tid + 1] = inc;
+        carry = __shfl(inc, 63, 64);
+      }
+      if (tid == 63 && carry > ev_cap) s_bad = 1;  // (entries behind K are zero: the last carry is the total)
     }
     __syncthreads();
     const uint64_t tm1 = __builtin_amdgcn_s_memtime();

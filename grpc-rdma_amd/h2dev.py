@@ -105,7 +105,7 @@ class Parser:
         check(self.lib.grdma_h2_parser_chunk_stats(self.h, out))
         return int(out[0]), int(out[1])
 
-    def chunk_phases(self, kmax=128):
+    def chunk_phases(self, kmax=256):
         """profiling aid: per chunk (start, cuts found, map copied, parsed, compared, slices) and the merge's stamps, in device-clock ticks relative to the earliest"""
         n = (kmax + 1) * 8
         out = (u64 * n)()

@@ -500,7 +500,7 @@ enum grdma_h2_parser_flags {
                                     GRDMA_H2_NO_BULK_PAIRS turns it off                                 */
   GRDMA_H2_NO_BULK_PAIRS = 64,   /* 32 frames per bulk step                                             */
   GRDMA_H2_NO_CHUNKS = 128,      /* always the sequential deframer.  Without it a list of >= 2048 slices is cut at slices in
-                                    which a message starts (GRDMA_H2_CHUNKS chunks of >= 256 slices, default 128), the chunks are parsed side
+                                    which a message starts (GRDMA_H2_CHUNKS chunks of >= 128 slices, default 256), the chunks are parsed side
                                     by side and merged when every chunk ended in the state the next one was assumed to
                                     start in -- the sequential deframer does the call otherwise (csrc/grdma_h2_kernels.h) */
   GRDMA_H2_TICKS = 32            /* the parsing wave samples the device clock around its phases (the tick counters

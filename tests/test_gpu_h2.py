@@ -35,7 +35,7 @@ def device_bytes(g, ptr, n):
     ([1 << 20], 16384), ([0], 16384), ([0, 0, 0, 5, 0, 0], 16384), ([3, 70000, 16379, 16380], 16384),
     ([100, 0, 17], 3), ([9, 1, 0, 0], 1), ([5000] * 40, 1000), ([1048580] * 3, 16384),
     ([0] * 300 + [7] * 10, 16384), ([70000] * 300 + [0, 5] + [16379] * 300, 16384), ([7] * 10 + [0] * 3 + [9, 100000, 1], 6),
-    ([20, 0, 21, 22, 0, 0, 23, 24], 5), ([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12], 7),
+    ([20, 0, 21, 22, 0, 0, 23, 24], 5), ([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12], 7), ([7] * 4200 + [0, 9, 0, 0, 40000], 16384),
 ])
 def test_frame_messages_matches_oracle(gpu, lens, max_frame):
     """k_h2_frame_index + k_h2_frame_emit against the oracle's model of chttp2 queueing the same messages on one
@@ -350,7 +350,7 @@ def test_h2_pipe_frame_job_deframe_matches_the_oracle(gpu, engine):
     for n in sizes:
         lens += [len(it[1]) if it[0] == "inl" else it[1][1] for it in h2host.frame_message(n, 1, 16384)]
     scratch = g.DeviceBuffer(nbytes=max(lens) + 64)
-    sge = [(scratch.ptr, n) for n in lens]          # placeholders: k_h2_frame overwrites the table
+    sge = [(scratch.ptr, n) for n in lens]          # placeholders: the framing kernels overwrite the table
     R = 1 << 18
     tx, rx = g.Pair(R, 30), g.Pair(R, 30)
     g.connect_pairs(tx, rx)

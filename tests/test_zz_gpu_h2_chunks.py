@@ -1,5 +1,5 @@
-"""The deframer over chunks (csrc/grdma_h2_kernels.h: k_h2_chunk_plan / k_h2_deframe_chunks / k_h2_chunk_merge /
-k_h2_deframe_unless_merged): a list of >= 2048 delivered slices is cut at slices in which a message starts, the chunks
+"""The deframer over chunks (csrc/grdma_h2_kernels.h: k_h2_deframe_chunks / k_h2_merge_or_deframe): a list of >= 2048
+delivered slices is cut at slices in which a message starts, the chunks
 are parsed side by side from the state the boundary step recorded, and merged only when the chain of end states holds.
 Whatever the list holds, the events, the parser state (checked through the NEXT call's events) and the stream map are
 the sequential parser's, i.e. the oracle's (parsing.cc:111-250 + frame_data.cc:92-276 restated in oracle/)."""
