@@ -132,6 +132,29 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan_seq(const grdma_tx_op*
       k0 = 1;
     }
     if (reset) {
+      // The ops and the slice table of an asynchronous endpoint's write live in pinned HOST memory: the wave below
+      // would fetch them Send by Send, two dependent PCIe round trips each.  The whole workgroup pulls them into LDS
+      // in ONE round trip instead (every load in flight together), and the wave prices the burst from there.
+      constexpr uint32_t kOps = 64, kSl = 1024, kWords = sizeof(grdma_tx_op) / 8;
+      static_assert(sizeof(grdma_tx_op) % 8 == 0 && offsetof(grdma_tx_op, slices) == 8, "op layout");
+      __shared__ __attribute__((aligned(16))) uint64_t s_ops[kOps * kWords];
+      __shared__ __attribute__((aligned(16))) grdma_sge s_sl[kSl];
+      const uint64_t ns = mine[0].nslices;
+      if (burst <= kOps && ns <= kSl) {
+        const grdma_sge* const gsl = mine[0].slices;
+        for (uint32_t w = threadIdx.x; w < burst * kWords; w += PLAN_THREADS) {
+          const uint32_t k = w / kWords, f = w - k * kWords;
+          s_ops[w] = reinterpret_cast<const uint64_t*>(&mine[(size_t)k * n])[f];
+        }
+        for (uint64_t i = threadIdx.x; i < ns; i += PLAN_THREADS) s_sl[i] = gsl[i];
+        __syncthreads();
+        // (every Send of a write walks the same table)
+        if (threadIdx.x < burst) s_ops[threadIdx.x * kWords + 1] = (uint64_t)(uintptr_t)&s_sl[0];
+        __syncthreads();
+        if (threadIdx.x < 64)
+          tx_burst_wave(reinterpret_cast<const grdma_tx_op*>(s_ops), 1, burst, (int)threadIdx.x, true);
+        return;
+      }
       if (threadIdx.x < 64) tx_burst_wave(mine, n, burst, (int)threadIdx.x, true);
       return;
     }
