@@ -57,7 +57,7 @@ def test_deframer_gpu_tests_under_the_emulator(emu_lib):
 def test_chunked_deframer_gpu_tests_under_the_emulator(emu_lib):
     """The deframer over chunks (k_h2_deframe_chunks / k_h2_merge_or_deframe): merged lists, empty chunks, lists the
     chain verification declines; all of tests/test_zz_gpu_h2_chunks.py but the bench-sized pipe (256 MiB per step)."""
-    run_gpu_tests(emu_lib, ["tests/test_zz_gpu_h2_chunks.py", "-n", "4", "-k", "not bench_configuration"], 9)
+    run_gpu_tests(emu_lib, ["tests/test_zz_gpu_h2_chunks.py", "-n", "4", "-k", "not bench_configuration"], 10)
 
 
 def test_zero_copy_gpu_tests_under_the_emulator(emu_lib):

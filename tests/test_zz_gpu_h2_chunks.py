@@ -276,3 +276,53 @@ def test_h2_pipe_at_the_bench_configuration_matches_the_oracle(gpu):
     parser.close()
     tx.close()
     rx.close()
+
+
+def test_chunked_deframer_random_streams(gpu):
+    """Seeded random calls: message sizes from one byte to a few hundred KiB, frames smaller than the maximum, control
+    frames between messages, now and then a message of a second stream, the receiving side's reads, slices cut in
+    two at random.  Whatever the chunked deframer decides -- merge or decline -- every call's events are the oracle's
+    (a merge that should not have happened shows here as a wrong event list), and over the seeds it does merge."""
+    merges = []
+    for seed in range(8):
+        merges.append(_random_stream_calls(gpu, seed))
+    assert sum(merges) >= 4, merges
+
+
+def _random_stream_calls(gpu, seed):
+    rng = random.Random(1000 + seed)
+    b = Both(gpu, True, gap_seed=seed if seed % 2 else None)
+    b.call([PREFACE + frame(4, 0, 0), frame(1, 4, 1, b"\x82"), frame(1, 4, 3, b"\x82")] +
+           fast_sender_slices([rng.randrange(1, 50000) for _ in range(3)], seed=seed))
+    for call in range(3):
+        max_frame = rng.choice([16384, 16384, 4096, 1000])
+        sizes_pool = rng.choice([[1, 9, 300, 16379, 16380, 40000, 65536, 200000], [70000], [5, 16384 * 3 - 5, 16384 - 5],
+                                 [max_frame * 8, max_frame * 40]])
+        second_stream = rng.random() < 0.3
+        body = []
+        while len(body) < 2600:
+            body += fast_sender_slices([rng.choice(sizes_pool)], seed=len(body), max_frame=max_frame)
+            r = rng.random()
+            if r < 0.05:
+                body.append(frame(6, 0, 0, bytes(8)))            # PING
+            elif r < 0.08:
+                body.append(frame(8, 0, 0, (1000).to_bytes(4, "big")))  # WINDOW_UPDATE on the connection
+            elif second_stream and r < 0.15:
+                body += fast_sender_slices([rng.randrange(1, 3000)], sid=3, seed=len(body), max_frame=max_frame)
+        if rng.random() < 0.5:
+            body = receiver_slices(body)
+        if rng.random() < 0.3:
+            cut = []
+            for s_ in body:
+                if len(s_) > 2 and rng.random() < 0.02:
+                    k = rng.randrange(1, len(s_))
+                    cut += [s_[:k], s_[k:]]
+                else:
+                    cut.append(s_)
+            body = cut
+        b.call(body)
+    planned, merged = b.dev.chunk_stats()
+    assert merged <= planned
+    b.close()
+    return merged
+
