@@ -123,7 +123,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan_seq(const grdma_tx_op*
     // A first Send that resets the cursor offers the whole slice table: the wave sums a table of up to 4096 entries
     // itself (a write of a few hundred slices then costs one short wave instead of the block-wide planner);
     // anything else that is not a continuation takes the block-wide plan.
-    const bool reset = mine[0].use_cursor == 2 && mine[0].nslices <= 4096;
+    const uint32_t uc0 = mine[0].use_cursor;
+    const bool reset = (uc0 == 2 || uc0 == 3) && mine[0].nslices <= 4096;
     if (mine[0].use_cursor != 1 && !reset) {
       tx_plan_seq_call(&mine[0]);
       __syncthreads();
@@ -140,6 +141,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan_seq(const grdma_tx_op*
       __shared__ __attribute__((aligned(16))) uint64_t s_ops[kOps * kWords];
       __shared__ __attribute__((aligned(16))) grdma_sge s_sl[kSl];
       const uint64_t ns = mine[0].nslices;
+      // a burst queued behind another write runs only if that write's last Send took everything it was offered
+      __shared__ uint32_t s_gate;
+      if (threadIdx.x == 0)
+        s_gate = uc0 == 3 ? (reinterpret_cast<const grdma_tx_result*>(mine[0].byte_idx)->done == 1 ? 1u : 0u) : 1u;
       if (burst <= kOps && ns <= kSl) {
         const grdma_sge* const gsl = mine[0].slices;
         for (uint32_t w = threadIdx.x; w < burst * kWords; w += PLAN_THREADS) {
@@ -151,11 +156,17 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan_seq(const grdma_tx_op*
         // (every Send of a write walks the same table)
         if (threadIdx.x < burst) s_ops[threadIdx.x * kWords + 1] = (uint64_t)(uintptr_t)&s_sl[0];
         __syncthreads();
-        if (threadIdx.x < 64)
-          tx_burst_wave(reinterpret_cast<const grdma_tx_op*>(s_ops), 1, burst, (int)threadIdx.x, true);
+        if (threadIdx.x < 64) {
+          if (s_gate) tx_burst_wave(reinterpret_cast<const grdma_tx_op*>(s_ops), 1, burst, (int)threadIdx.x, true);
+          else tx_burst_skip(reinterpret_cast<const grdma_tx_op*>(s_ops), 1, burst, (int)threadIdx.x);
+        }
         return;
       }
-      if (threadIdx.x < 64) tx_burst_wave(mine, n, burst, (int)threadIdx.x, true);
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        if (s_gate) tx_burst_wave(mine, n, burst, (int)threadIdx.x, true);
+        else tx_burst_skip(mine, n, burst, (int)threadIdx.x);
+      }
       return;
     }
     if (threadIdx.x < 64 && k0 < burst) tx_burst_wave(mine + (size_t)k0 * n, n, burst - k0, (int)threadIdx.x);

@@ -16,7 +16,9 @@ struct grdma_tx_op {
   struct grdma_plan* wire_plan;    // loop-back wire plan (staging -> peer ring)
   struct grdma_tx_result* result;
   uint32_t use_cursor;             // 0: slice 0 + byte_idx; 1: continue from the conn's
-                                   // rdma_flush cursor; 2: reset that cursor first
+                                   // rdma_flush cursor; 2: reset that cursor first; 3: like 2, but only if the
+                                   // grdma_tx_result byte_idx points at says done == 1 (a write queued behind another:
+                                   // k_tx_plan_seq skips the whole burst otherwise, results done = 2)
   uint32_t inline_copy;            // 1: this workgroup also runs the gather (and wire) tiles --
                                    // one launch per Send for small messages
   uint8_t* staging_alt;            // != NULL: stage this Send here instead of conn->staging

@@ -265,6 +265,23 @@ struct grdma_pair {
   const grdma_plan** h_bplan_ptrs = nullptr;  // pinned
   uint32_t tx_burst = 0;                      // Sends of the submit in flight (0 = a single Send through h->txop)
   uint64_t tx_burst_byte0 = 0;                // byte offset the first slice of that submit was entered at
+  // A write QUEUED behind the burst in flight (grdma_endpoint_write_queue): its chain is already in the send stream,
+  // reading a second set of pinned ops / results / slice table, and its first Send is gated on the device -- it runs
+  // only if the last Send of the write in front took everything (grdma_tx_op::use_cursor 3); otherwise the whole
+  // chain is skipped and the host continues the write in front first.  Set 0 is {h_bops, h_bres, h_bplan_ptrs, h_sges}.
+  grdma_tx_op* q_ops = nullptr;
+  grdma_tx_result* q_res = nullptr;
+  const grdma_plan** q_plan_ptrs = nullptr;
+  grdma_sge* q_sges = nullptr;
+  int inflight_set = 0;                       // which set the burst in flight reads
+  bool inflight_covers_all = false;           // ... and whether it offers every remaining slice of its write
+  int q_state = 0;                            // 1 = a write is queued
+  int q_set = 0;
+  uint32_t q_burst = 0;
+  uint64_t q_expect = 0;                      // tx_seq of the queued chain's commit
+  uint64_t q_pending_seq = 0;                 // a skipped chain still in the stream commits this sequence number
+  std::vector<grdma_slice> q_slices;
+  uint64_t q_queued = 0, q_promoted = 0, q_skipped = 0;  // counters (grdma_endpoint_write_queue_stats)
   // endpoint_write context
   std::vector<grdma_slice> w_slices;
   uint64_t w_idx = 0, w_byte = 0;
@@ -821,6 +838,10 @@ void grdma_pair_destroy(grdma_pair* p) {
   if (p->h_bops) hipHostFree(p->h_bops);
   if (p->h_bres) hipHostFree(p->h_bres);
   if (p->h_bplan_ptrs) hipHostFree(p->h_bplan_ptrs);
+  if (p->q_ops) hipHostFree(p->q_ops);
+  if (p->q_res) hipHostFree(p->q_res);
+  if (p->q_plan_ptrs) hipHostFree(p->q_plan_ptrs);
+  if (p->q_sges) hipHostFree(p->q_sges);
   if (p->refresh_stream) {
     hipStreamSynchronize(p->refresh_stream);  // a refresh pass in flight writes the line
     hipStreamDestroy(p->refresh_stream);
@@ -1738,6 +1759,11 @@ int grdma_endpoint_write_abort(grdma_pair* p) {
   p->w_active = false;
   p->w_slices.clear();
   p->w_idx = p->w_byte = 0;
+  if (p->q_state != 0) {  // (a queued chain may still run: the connection is being given up)
+    p->q_pending_seq = p->q_expect;
+    p->q_state = 0;
+    p->q_slices.clear();
+  }
   return 0;
 }
 
@@ -1909,6 +1935,14 @@ int submit_send(grdma_pair* p, uint64_t count, uint64_t byte_idx) {
     // gathered by one.  Records go straight into the peer ring, so the Sends need no staging buffers of their own.
     constexpr uint32_t kBurstMax = 16;
     uint32_t B = (uint32_t)std::min<uint64_t>(kBurstMax, (count + p->max_sge - 1) / p->max_sge);
+    // (a queued chain that was skipped may still sit in the stream and will read set 0's tables when it runs: it is
+    // right behind the chain whose completion brought us here -- a few tens of microseconds, a rare path)
+    while (__atomic_load_n(&p->line->tx_seq, __ATOMIC_ACQUIRE) < p->q_pending_seq) {
+      const hipError_t qe = hipStreamQuery(p->s_tx);
+      if (qe != hipSuccess && qe != hipErrorNotReady) return fail(GRDMA_ERR_HIP, "send stream: %s", hipGetErrorString(qe));
+    }
+    p->inflight_set = 0;
+    p->inflight_covers_all = (uint64_t)B * (uint64_t)p->max_sge >= count;
     if (!p->h_bops) {
       HIP_TRY(hipHostMalloc((void**)&p->h_bops, sizeof(grdma_tx_op) * kBurstMax, hipHostMallocCoherent | hipHostMallocMapped));
       HIP_TRY(hipHostMalloc((void**)&p->h_bres, sizeof(grdma_tx_result) * kBurstMax, hipHostMallocCoherent | hipHostMallocMapped));
@@ -1947,6 +1981,7 @@ int submit_send(grdma_pair* p, uint64_t count, uint64_t byte_idx) {
     p->tx_burst = B;
     return 0;
   }
+  p->inflight_covers_all = false;
   const uint32_t blocks = copy_blocks_for(p->ring_size / 2);
   HIP_TRY(grdma_launch_tx_plan(&h->txop, 1, p->s_tx));
   if (!p->latency) {
@@ -1957,7 +1992,106 @@ int submit_send(grdma_pair* p, uint64_t count, uint64_t byte_idx) {
   p->tx_expect = p->tx_seq;
   return 0;
 }
+
+struct burst_set {
+  grdma_tx_op* ops;
+  grdma_tx_result* res;
+  const grdma_plan** plan_ptrs;
+  grdma_sge* sges;
+};
+inline burst_set bset(grdma_pair* p, int i) {
+  return i == 0 ? burst_set{p->h_bops, p->h_bres, p->h_bplan_ptrs, p->h_sges}
+                : burst_set{p->q_ops, p->q_res, p->q_plan_ptrs, p->q_sges};
+}
 }  // namespace
+
+// A write behind the burst in flight, submitted NOW: 0 = its chain is in the send stream (the caller treats it as
+// submitted once grdma_endpoint_write_adopt says it was promoted), 1 = not possible at the moment (the caller keeps it
+// and submits it the ordinary way later).  slices must be device-visible memory that stays valid until the write has
+// completed (the endpoint's send buffers).  See the field comments of grdma_pair.
+int grdma_endpoint_write_queue(grdma_pair* p, const grdma_slice* slices, uint64_t count) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || !slices) return fail(GRDMA_ERR_INVALID, "null argument");
+  constexpr uint32_t kBurstMax = 16;
+  if (!p->async || p->latency || !(p->flags & GRDMA_WIRE_DIRECT) || p->remote) return 1;
+  if (!p->tx_inflight.load(std::memory_order_acquire) || p->tx_by_engine || p->tx_burst == 0 || !p->inflight_covers_all)
+    return 1;
+  if (p->q_state != 0 || count <= (uint64_t)p->max_sge || count > (uint64_t)kBurstMax * (uint64_t)p->max_sge ||
+      count > GRDMA_TX_MAX_RECORDS - 1)
+    return 1;
+  if (__atomic_load_n(&p->line->tx_seq, __ATOMIC_ACQUIRE) < p->q_pending_seq) return 1;  // a skipped chain has yet to drain
+  {
+    // Will the write in front go out whole, and this one behind it?  A queued chain that is skipped costs three empty
+    // launches, so it is only queued when the ring -- as the state line showed it at the last commit, minus what is in
+    // flight -- has room for both (a guess: the device decides, the gate keeps the order either way).
+    uint64_t front = 0, mine = 0;
+    for (uint64_t i = p->w_idx; i < p->w_slices.size(); i++) front += 24 + p->w_slices[i].len;
+    for (uint64_t i = 0; i < count; i++) mine += 24 + slices[i].len;
+    const uint64_t tail = __atomic_load_n(&p->line->remote_tail, __ATOMIC_RELAXED);
+    const uint64_t head = __atomic_load_n(&p->line->remote_head, __ATOMIC_RELAXED);
+    const uint64_t used = (tail - head) & (p->ring_size - 1);
+    static const bool always = [] { const char* e = getenv("GRDMA_WRITE_QUEUE_ALWAYS"); return e && atoi(e) != 0; }();  // (tests: the skip path)
+    if (!always && used + front + mine + 4096 > p->ring_size) return 1;
+  }
+  const int set = 1 - p->inflight_set;
+  if (!p->q_ops) {
+    HIP_TRY(hipHostMalloc((void**)&p->q_ops, sizeof(grdma_tx_op) * kBurstMax, hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void**)&p->q_res, sizeof(grdma_tx_result) * kBurstMax, hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void**)&p->q_plan_ptrs, sizeof(grdma_plan*) * kBurstMax, hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void**)&p->q_sges, sizeof(grdma_sge) * GRDMA_TX_MAX_RECORDS, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(p->q_res, 0, sizeof(grdma_tx_result) * kBurstMax);
+  }
+  const uint32_t B = (uint32_t)((count + p->max_sge - 1) / p->max_sge);
+  if (p->b_plans.size() < B) return 1;  // (the plans of a burst are allocated by the ordinary path: no allocation here,
+                                        // it would wait for the stream)
+  const burst_set S = bset(p, set), F = bset(p, p->inflight_set);
+  for (uint64_t i = 0; i < count; i++) {
+    S.sges[i].ptr = static_cast<const uint8_t*>(slices[i].ptr);
+    S.sges[i].len = slices[i].len;
+  }
+  for (uint32_t k = 0; k < B; k++) {
+    grdma_tx_op& t = S.ops[k];
+    memset(&t, 0, sizeof(t));
+    t.conn = p->d_conn;
+    t.slices = S.sges;
+    t.nslices = count;
+    t.plan = p->b_plans[k];
+    t.wire_plan = nullptr;
+    t.result = &S.res[k];
+    t.use_cursor = k == 0 ? 3 : 1;
+    if (k == 0) t.byte_idx = (uint64_t)(uintptr_t)&F.res[p->tx_burst - 1];  // the gate: the last Send in front
+    S.plan_ptrs[k] = p->b_plans[k];
+  }
+  const uint32_t blocks_b = std::max<uint32_t>(1, copy_blocks_for(p->ring_size) / B + 1);
+  HIP_TRY(grdma_launch_tx_plan_seq(S.ops, 1, B, p->s_tx));
+  HIP_TRY(grdma_launch_copy(S.plan_ptrs, B, blocks_b, p->s_tx));
+  HIP_TRY(grdma_launch_tx_commit1(p->d_conn, ++p->tx_seq, p->s_tx));
+  p->q_expect = p->tx_seq;
+  p->q_burst = B;
+  p->q_set = set;
+  p->q_slices.assign(slices, slices + count);
+  p->q_state = 1;
+  p->q_queued++;
+  return 0;
+}
+
+// After grdma_endpoint_write_test reported the write in front complete: 1 = the queued write was promoted -- it is the
+// write outstanding now, its burst in flight (grdma_endpoint_write_test / _writable as usual) --, 0 = there is none
+// (never queued, or skipped on the device: submit it the ordinary way).
+int grdma_endpoint_write_adopt(grdma_pair* p) {
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (p->q_state != 2 || !p->w_active || !p->tx_inflight.load(std::memory_order_acquire)) return 0;
+  p->q_state = 0;
+  return 1;
+}
+
+int grdma_endpoint_write_queue_stats(grdma_pair* p, uint64_t out[3]) {
+  if (!p || !out) return fail(GRDMA_ERR_INVALID, "null argument");
+  out[0] = p->q_queued;
+  out[1] = p->q_promoted;
+  out[2] = p->q_skipped;
+  return 0;
+}
 
 namespace {
 inline bool drain_complete(grdma_pair* p) {
@@ -1974,6 +2108,12 @@ int grdma_endpoint_write_submit(grdma_pair* p) {
   if (!p->w_active) return fail(GRDMA_ERR_INVALID, "no write has been begun");
   if (p->tx_inflight.load(std::memory_order_acquire)) return fail(GRDMA_ERR_INVALID, "a Send is still in flight");
   grdma_profiler profiler(GRDMA_STATS_TIME_PAIR_SEND);
+  // (a queued chain that was skipped may still sit in the stream and will look at the tables this submit rewrites: it
+  // is right behind the chain whose completion brought us here -- a few tens of microseconds, a rare path)
+  while (!p->tx_by_engine && p->q_pending_seq && __atomic_load_n(&p->line->tx_seq, __ATOMIC_ACQUIRE) < p->q_pending_seq) {
+    const hipError_t qe = hipStreamQuery(p->s_tx);
+    if (qe != hipSuccess && qe != hipErrorNotReady) return fail(GRDMA_ERR_HIP, "send stream: %s", hipGetErrorString(qe));
+  }
   const uint64_t n = p->w_slices.size() - p->w_idx;
   if (int rc = stage_slices(p, p->w_slices.data() + p->w_idx, n, p->w_byte, p->w_flags)) return rc;
   p->tx_inflight.store(1, std::memory_order_release);
@@ -1998,19 +2138,44 @@ int grdma_endpoint_write_test(grdma_pair* p, int* done, int64_t* sent) {
   }
   grdma_tx_result r = p->h->txres;
   if (p->tx_burst) {  // the last Send's result holds the cursor; what was sent is the sum over the Sends
-    r = p->h_bres[p->tx_burst - 1];
+    const grdma_tx_result* res = bset(p, p->inflight_set).res;
+    r = res[p->tx_burst - 1];
     r.sent = 0;
-    for (uint32_t k = 0; k < p->tx_burst; k++) r.sent += p->h_bres[k].sent;
+    for (uint32_t k = 0; k < p->tx_burst; k++) r.sent += res[k].sent;
     if (r.slice_idx == 0) r.byte_idx += p->tx_burst_byte0;  // (still inside the slice the offset was folded into)
     p->tx_burst = 0;
   }
   p->w_idx += r.slice_idx;
   p->w_byte = r.byte_idx;
-  *done = r.done ? 1 : 0;
+  *done = r.done == 1 ? 1 : 0;
   if (sent) *sent = (int64_t)r.sent;
-  if (r.done) {
+  if (r.done == 1) {
     p->w_active = false;
     p->w_slices.clear();
+  }
+  if (p->q_state == 1) {
+    if (r.done == 1) {
+      // the write queued behind this one ran (its gate saw the same `done`): it is the write outstanding now
+      p->w_slices.swap(p->q_slices);
+      p->q_slices.clear();
+      p->w_idx = 0;
+      p->w_byte = 0;
+      p->w_flags = 0;
+      p->w_active = true;
+      p->tx_expect = p->q_expect;
+      p->tx_burst = p->q_burst;
+      p->tx_burst_byte0 = 0;
+      p->inflight_set = p->q_set;
+      p->inflight_covers_all = true;
+      p->q_state = 2;  // promoted, not yet adopted by the caller
+      p->q_promoted++;
+      return 1;        // (tx_inflight stays up: the promoted burst is in flight)
+    }
+    // the write in front came up short: the queued chain skips itself on the device; it is submitted again later
+    p->q_state = 0;
+    p->q_slices.clear();
+    p->q_pending_seq = p->q_expect;
+    p->q_skipped++;
   }
   p->tx_inflight.store(0, std::memory_order_release);
   return 1;

@@ -858,5 +858,38 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
   }
 }
 
+// A burst that must not run: it was queued behind a write whose last Send turned out to be partial (grdma_tx_op::
+// use_cursor == 3, grdma_endpoint_write_queue).  Empty plans, results that say so (done = 2), and NOTHING of the
+// connection's state is touched -- the cursor still belongs to the write in front, which the host continues first.
+__device__ __forceinline__ void tx_burst_skip(const grdma_tx_op* ops, uint32_t stride, uint32_t burst, int lane) {
+  if (lane != 0) return;
+  const grdma_conn* c = ops[0].conn;
+  const uint64_t tail = c->remote_tail;
+  const uint32_t TB = 1u << GRDMA_PLAN_TILE_SHIFT(c->cap);
+  for (uint32_t k = 0; k < burst; k++) {
+    const grdma_tx_op op = ops[(size_t)k * stride];
+    for (grdma_plan* pl : {op.plan, op.wire_plan}) {
+      if (pl == nullptr) continue;
+      pl->nsegs = 0;
+      pl->ntiles = 0;
+      pl->tile_bytes = TB;
+      pl->tile_prefix[0] = 0;
+      pl->bytes = 0;
+    }
+    grdma_tx_result* r = op.result;
+    r->wr_count = 0;
+    r->wr_off[0] = r->wr_off[1] = r->wr_len[0] = r->wr_len[1] = 0;
+    r->sent = 0;
+    r->records = 0;
+    r->staged = 0;
+    r->partial = (uint32_t)c->partial_write;
+    r->new_remote_tail = tail;
+    if (op.tail_out != nullptr) *op.tail_out = tail;
+    r->slice_idx = 0;
+    r->byte_idx = 0;
+    r->done = 2;
+  }
+}
+
 }  // namespace
 #endif  // GRDMA_TX_BODY_H

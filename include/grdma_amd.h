@@ -297,6 +297,15 @@ typedef struct grdma_window grdma_window;
 int grdma_endpoint_set_async(grdma_pair* p, int windows, uint64_t window_bytes);
 int grdma_endpoint_write_submit(grdma_pair* p);
 int grdma_endpoint_write_test(grdma_pair* p, int* done, int64_t* sent);
+/* A write submitted BEHIND the burst in flight (asynchronous endpoint, direct wire, a write of more slices than
+ * max_sge and at most 16 x max_sge): its chain goes into the send stream now and runs only if the write in front
+ * turns out to have gone out whole (gated on the device); slices must be device-visible and stay valid.
+ * _queue: 0 = queued, 1 = not possible now.  _adopt, after grdma_endpoint_write_test reported the write in front
+ * complete: 1 = the queued write is the outstanding one now, its burst in flight; 0 = it has to be submitted the
+ * ordinary way (never queued, or skipped because the write in front came up short). */
+int grdma_endpoint_write_queue(grdma_pair* p, const grdma_slice* slices, uint64_t count);
+int grdma_endpoint_write_adopt(grdma_pair* p);
+int grdma_endpoint_write_queue_stats(grdma_pair* p, uint64_t out[3]);  /* queued, promoted, skipped */
 int grdma_endpoint_read_submit(grdma_pair* p, uint64_t max_reads);
 int64_t grdma_endpoint_read_test(grdma_pair* p, grdma_read_slice* slices, uint64_t slices_cap, int* would_block,
                                  grdma_window** window);

@@ -93,6 +93,8 @@ struct core {
   send_buffer sbuf[2];
   size_t sbuf_cap = 0;                 // bytes per buffer, 0 = off
   int bg_running = -1, bg_waiting = -1;
+  bool bg_queued = false;              // the waiting buffer's chain is already in the pair's send stream
+                                       // (grdma_endpoint_write_queue): adopted, not submitted, when its turn comes
   bool deferred = false;               // a write of the ordinary kind (deferred_buf, write_cb) waits behind them
   sb_t* deferred_buf = nullptr;
   bool bg_failed = false;
@@ -256,6 +258,7 @@ struct core {
   // ------------------------------------------------------------------------------------------ write
   void forget_write() {  // the pair must not keep views of slices that are about to be unreffed
     grdma_endpoint_write_abort(pair);
+    bg_queued = false;
     window_active = false;
     send_submitted = false;
     out_views.clear();
@@ -328,7 +331,57 @@ struct core {
     window_active = false;
     send_submitted = false;
     T::ref(h);
+    if (bg_queued) {
+      bg_queued = false;
+      if (grdma_endpoint_write_adopt(pair) == 1) {  // its Sends went into the stream behind the buffer in front
+        out_next = out_views.size();
+        window_active = true;
+        send_submitted = true;
+      }
+    }
     return flush(error);
+  }
+  // copies buf's slices into send buffer s (boundaries kept: one ring record each); false = no pinned memory
+  bool fill_send_buffer(int s, sb_t* buf) {
+    send_buffer& b = sbuf[s];
+    if (b.mem == nullptr) b.mem = static_cast<uint8_t*>(grdma_host_alloc_pinned(sbuf_cap));
+    if (b.mem == nullptr) return false;
+    const size_t n = T::count(buf);
+    b.views.resize(n);
+    size_t off = 0;
+    for (size_t i = 0; i < n; i++) {
+      const size_t l = T::slice_len(buf, i);
+      if (l) memcpy(b.mem + off, T::slice_ptr(buf, i), l);
+      b.views[i] = grdma_slice{b.mem + off, (uint64_t)l};
+      off += l;
+    }
+    return true;
+  }
+  bool fits_send_buffer(sb_t* buf) {
+    const size_t len = T::length(buf);
+    return sbuf_cap != 0 && len >= kSendBufferMin && len <= sbuf_cap && T::count(buf) <= kWriteWindow;
+  }
+  // A write that found both buffers taken waits as an ordinary one (deferred).  When a buffer comes free while the
+  // other one is on its way, it moves into the free one after all: copied, completed, queued behind the Sends in flight.
+  void buffer_the_deferred_write() {
+    if (!deferred || bg_failed || bg_running < 0 || bg_waiting >= 0 || !fits_send_buffer(deferred_buf)) return;
+    const int s = free_send_buffer();
+    if (s < 0 || !fill_send_buffer(s, deferred_buf)) return;
+    T::reset_and_unref(deferred_buf);
+    deferred_buf = nullptr;
+    deferred = false;
+    closure_t* cb = write_cb;
+    write_cb = nullptr;
+    bg_waiting = s;
+    try_queue_waiting();
+    T::run(h, cb, T::none());
+    T::unref(h);  // (the reference the deferred write took in write())
+  }
+  // the buffer that waits, into the pair's send stream right away when the pair can take it behind the Send in flight
+  void try_queue_waiting() {
+    if (bg_waiting < 0 || bg_queued || bg_running < 0 || !send_submitted || out_next < out_views.size()) return;
+    const send_buffer& b = sbuf[bg_waiting];
+    if (grdma_endpoint_write_queue(pair, b.views.data(), b.views.size()) == 0) bg_queued = true;
   }
   void start_ordinary() {  // the write held in outgoing_buffer / write_cb
     const size_t n = T::count(outgoing_buffer);
@@ -349,6 +402,7 @@ struct core {
           bg_failed = true;
           bg_error = last_failure.empty() ? std::string("an earlier write failed") : last_failure;
           bg_waiting = -1;
+          bg_queued = false;
           T::drop(err);
         }
         const int next = bg_waiting;
@@ -359,6 +413,7 @@ struct core {
           T::unref(h);  // (the reference of the buffer that has just finished; the next one took its own)
           if (!fin) {
             T::notify_on_write(h);
+            buffer_the_deferred_write();
             return;
           }
           err = e2;
@@ -425,6 +480,7 @@ struct core {
       forget_write();
       if (bg_running >= 0) {  // buffered writes die with the endpoint (their callbacks have run)
         bg_running = bg_waiting = -1;
+        bg_queued = false;
         bg_failed = true;
         bg_error = "Endpoint shutdown";
         T::unref(h);
@@ -460,33 +516,20 @@ struct core {
       T::run(h, cb, T::annotate(h, bg_error.c_str()));
       return;
     }
-    const size_t n = T::count(buf);
-    const size_t len = T::length(buf);
     const int s = free_send_buffer();
-    if (sbuf_cap != 0 && len >= kSendBufferMin && len <= sbuf_cap && n <= kWriteWindow && s >= 0 && !deferred && !T::is_shutdown(h)) {
-      send_buffer& b = sbuf[s];
-      if (b.mem == nullptr) b.mem = static_cast<uint8_t*>(grdma_host_alloc_pinned(sbuf_cap));
-      if (b.mem != nullptr) {
-        // the slices keep their boundaries (one ring record each), their bytes move into the endpoint's buffer
-        b.views.resize(n);
-        size_t off = 0;
-        for (size_t i = 0; i < n; i++) {
-          const size_t l = T::slice_len(buf, i);
-          if (l) memcpy(b.mem + off, T::slice_ptr(buf, i), l);
-          b.views[i] = grdma_slice{b.mem + off, (uint64_t)l};
-          off += l;
-        }
-        T::reset_and_unref(buf);
-        if (bg_running >= 0) {
-          bg_waiting = s;  // behind the buffer that is on its way; handle_write starts it
-        } else {
-          error_t err;
-          if (!start_buffered(s, &err)) T::notify_on_write(h);
-          else after_flush(err);
-        }
-        T::run(h, cb, T::none());
-        return;
+    if (fits_send_buffer(buf) && s >= 0 && !deferred && !T::is_shutdown(h) && fill_send_buffer(s, buf)) {
+      // the slices keep their boundaries, their bytes are the endpoint's now
+      T::reset_and_unref(buf);
+      if (bg_running >= 0) {
+        bg_waiting = s;  // behind the buffer that is on its way; handle_write starts it
+        try_queue_waiting();
+      } else {
+        error_t err;
+        if (!start_buffered(s, &err)) T::notify_on_write(h);
+        else after_flush(err);
       }
+      T::run(h, cb, T::none());
+      return;
     }
     if (bg_running >= 0) {  // behind the buffered writes
       T::ref(h);

@@ -119,6 +119,19 @@ def test_endpoint_vtable_tools_under_the_emulator(emu_lib, tmp_path):
     assert p.returncode == 0, p.stderr[-500:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["checked"] and r["latency_mode"] and r["endpoint_bytes"] > 5 << 20
+    # the launch-chain path with the endpoint's send buffers: write k + 1 is queued behind the Sends of write k
+    # (grdma_endpoint_write_queue) and promoted when write k has gone out whole; a 256 KiB ring makes some writes come up
+    # short, which skips the queued chain on the device and submits it again the ordinary way -- same bytes either way
+    for ring_kb, want in (("4096", "promoted"), ("256", "skipped")):
+        # (GRDMA_WRITE_QUEUE_ALWAYS: queue even when the state line says the ring has no room for both writes)
+        p = subprocess.run([es, "12", str(1 << 20), "1", "0", "2"],
+                           env=dict(env, GRPC_RDMA_RING_BUFFER_SIZE_KB=ring_kb, GRDMA_WRITE_QUEUE_ALWAYS="1"),
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-500:]
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        queued, promoted, skipped = r["writes_queued"]
+        assert r["checked"] and not r["latency_mode"] and queued >= 1 and promoted + skipped <= queued, r
+        assert (promoted if want == "promoted" else skipped) >= 1, r
 
 
 def test_endpoint_conformance_under_the_emulator(emu_lib, tmp_path):

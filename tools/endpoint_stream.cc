@@ -196,16 +196,19 @@ int main(int argc, char** argv) {
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   CHECK(!st.failed && st.bytes_read == st.bytes_target);
   if (st.check) CHECK(st.sum_read == st.sum_per_msg * st.msgs_target);
+  uint64_t wq[3] = {0, 0, 0};  // writes queued behind the Send in flight / promoted / skipped on the device
+  grdma_endpoint_write_queue_stats(grdma_endpoint_pair(st.tx), wq);
   printf("{\"msgs\": %zu, \"payload\": %zu, \"slices_per_write\": %zu, \"endpoint_bytes\": %zu, \"seconds\": %.6f, "
          "\"GiBps\": %.4f, \"checked\": %s, \"latency_mode\": %s, \"threads\": %d, \"ring_kib\": %s, \"max_sge\": %s, "
-         "\"wire\": \"%s\", \"register_min\": %s}\n",
+         "\"wire\": \"%s\", \"register_min\": %s, \"writes_queued\": [%llu, %llu, %llu]}\n",
          st.msgs_target, payload, st.frames.size(), st.bytes_target, sec,
          (double)(payload * st.msgs_target) / sec / (double)(1ull << 30), st.check ? "true" : "false",
          latency ? "true" : "false", threads >= 2 ? 2 : 1,
          getenv("GRPC_RDMA_RING_BUFFER_SIZE_KB") ? getenv("GRPC_RDMA_RING_BUFFER_SIZE_KB") : "4096",
          getenv("GRPC_RDMA_MAX_SGE") ? getenv("GRPC_RDMA_MAX_SGE") : "30",
          getenv("GRPC_RDMA_HIP_WIRE") ? getenv("GRPC_RDMA_HIP_WIRE") : "direct",
-         getenv("GRPC_RDMA_HIP_REGISTER_MIN") ? getenv("GRPC_RDMA_HIP_REGISTER_MIN") : "0");
+         getenv("GRPC_RDMA_HIP_REGISTER_MIN") ? getenv("GRPC_RDMA_HIP_REGISTER_MIN") : "0",
+         (unsigned long long)wq[0], (unsigned long long)wq[1], (unsigned long long)wq[2]);
   if (latency) grdma_engine_stop();
   grpc_endpoint_shutdown(st.tx, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
   grpc_endpoint_shutdown(st.rx, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
