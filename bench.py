@@ -464,6 +464,8 @@ def main():
         import __graft_entry__ as ge
         import grpc_rdma_amd as g
         g.init(int(os.environ.get("LOCAL_RANK", "0")))
+        if not os.environ.get("GRDMA_NO_NUMA_PIN"):  # like `numactl --cpunodebind` on the GPU's NUMA node
+            g.load().grdma_host_pin_to_device_node()
         if args.rtt_only:
             print(json.dumps(measure_rtt(g, iters=args.rtt_iters, warmup=min(10000, max(10, args.rtt_iters // 10)))))
         else:

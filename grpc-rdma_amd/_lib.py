@@ -95,6 +95,7 @@ SIGNATURES = {
     "grdma_device_alloc": (C.c_void_p, [u64]),
     "grdma_device_free": (None, [C.c_void_p]),
     "grdma_host_alloc_pinned": (C.c_void_p, [u64]),
+    "grdma_host_pin_to_device_node": (C.c_int, []),
     "grdma_host_free_pinned": (None, [C.c_void_p]),
     "grdma_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, u64]),
     "grdma_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, u64]),

@@ -9,7 +9,10 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <sched.h>
+
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -2292,6 +2295,44 @@ void* grdma_device_alloc(uint64_t bytes) {
   return p;
 }
 void grdma_device_free(void* p) { if (p) hipFree(p); }
+int grdma_host_pin_to_device_node(void) {
+  // (no context needed: the calling thread's current HIP device -- device 0 in a process that has not chosen one, or the
+  // one grdma_init selected)
+  int dev = 0;
+  char bus[64] = {0};
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, sizeof(bus), dev) != hipSuccess) return -1;
+  for (char* c = bus; *c; c++) *c = (char)tolower(*c);
+  char path[256];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  if (node < 0) return -1;
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  f = fopen(path, "r");
+  if (!f) return -1;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int a = 0, b = 0, n = 0;
+  while (fscanf(f, "%d", &a) == 1) {  // "0-63,128-191"
+    b = a;
+    int ch = fgetc(f);
+    if (ch == '-') {
+      if (fscanf(f, "%d", &b) != 1) break;
+      ch = fgetc(f);
+    }
+    for (int c = a; c <= b && c < CPU_SETSIZE; c++) {
+      CPU_SET(c, &set);
+      n++;
+    }
+    if (ch != ',') break;
+  }
+  fclose(f);
+  if (n == 0 || sched_setaffinity(0, sizeof(set), &set) != 0) return -1;
+  return node;
+}
 void* grdma_host_alloc_pinned(uint64_t bytes) {
   if (require_ctx()) return nullptr;
   void* p = nullptr;

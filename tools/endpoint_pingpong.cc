@@ -91,6 +91,8 @@ int main(int argc, char** argv) {
   const int mode = atoi(argv[3]);
   const size_t warmup = iters / 10 + 5;
   setenv("GRPC_PLATFORM_TYPE", "RDMA_BP", 0);
+  // (like `numactl --cpunodebind` on the GPU's node: the mailbox and the result lines then sit next to its PCIe root)
+  if (!getenv("GRDMA_NO_NUMA_PIN")) grdma_host_pin_to_device_node();
   side cl, sv;
   cl.ep = grpc_endpoint_create(3, "ipv4:127.0.0.1:1", false);
   sv.ep = grpc_endpoint_create(4, "ipv4:127.0.0.1:2", true);
