@@ -1,5 +1,7 @@
 #!/bin/bash
-# Headline leg under every library variant in grpc-rdma_amd/variants (built with other -D settings): value, ms per step,
+# Headline leg under every library variant in grpc-rdma_amd/variants (built with other -D settings, e.g.
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DGRDMA_PLAN_LD=0 -DGRDMA_PLAN_ST=16 -o grpc-rdma_amd/variants/lib_ld0_st16.so grpc-rdma_amd/csrc/*.hip grpc-rdma_amd/csrc/*.cc
+# the cache policies of the plan tiles' loads / stores, csrc/grdma_devfn.h): value, ms per step,
 # kernel times.  usage (on the GPU box): bash tools/variant_sweep.sh [extra bench args]
 R=$GRAFT_REPO_ROOT
 cd $R
