@@ -820,6 +820,9 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
 void grdma_pair_destroy(grdma_pair* p) {
   if (!p) return;
   if (p->stream) hipStreamSynchronize(p->stream);
+  // (a queued or skipped write chain, a drain in flight: nothing of this pair's may still run when its memory goes back)
+  if (p->s_tx) hipStreamSynchronize(p->s_tx);
+  if (p->s_rx) hipStreamSynchronize(p->s_rx);
   if (p->ipc_ring) hipIpcCloseMemHandle(p->ipc_ring);
   if (p->ipc_conn) hipIpcCloseMemHandle(p->ipc_conn);
   {
@@ -2086,6 +2089,14 @@ int grdma_endpoint_write_adopt(grdma_pair* p) {
   if (p->q_state != 2 || !p->w_active || !p->tx_inflight.load(std::memory_order_acquire)) return 0;
   p->q_state = 0;
   return 1;
+}
+
+// Waits until nothing of this pair's is left in its send stream (a queued chain, a chain that skipped itself): the
+// memory its Sends gather from may be released afterwards.
+int grdma_endpoint_write_quiesce(grdma_pair* p) {
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (p->s_tx) HIP_TRY(hipStreamSynchronize(p->s_tx));
+  return 0;
 }
 
 int grdma_endpoint_write_queue_stats(grdma_pair* p, uint64_t out[3]) {

@@ -123,6 +123,7 @@ struct core {
     if (ahead_win) grdma_window_unref(ahead_win);
     ahead_win = nullptr;
     ahead.clear();
+    if (pair != nullptr && (sbuf[0].mem || sbuf[1].mem)) grdma_endpoint_write_quiesce(pair);  // (a chain may still gather from them)
     for (send_buffer& b : sbuf) {
       if (b.mem) grdma_host_free_pinned(b.mem);
       b.mem = nullptr;
