@@ -616,7 +616,8 @@ def main():
         env_fused = os.environ.get("GRDMA_H2_PIPE_FUSED")
         if fused is not None:  # (read when a pipe is created) 0: stages enqueued around the job's graph, timed by events
             os.environ["GRDMA_H2_PIPE_FUSED"] = "1" if fused else "0"
-        for _ in range(2):
+        n_pipes = int(os.environ.get("BENCH_H2_PIPES", "2"))
+        for _ in range(n_pipes):
             dst = g.DeviceBuffer(nbytes=dst_cap)
             est = max(8, 4 * (w.E // (ring // 2) + 2), 2 * (len(w.lens) // min(args.max_sge, 4095) + 2))
             job = gs.MultiStreamJob([(tx, rx, w.sge, dst.ptr, dst_cap, scap)], est)
@@ -638,13 +639,13 @@ def main():
             else:
                 os.environ["GRDMA_H2_PIPE_FUSED"] = env_fused
         for i in range(max(2, warmup)):
-            pipes[i % 2].enqueue(engine)
+            pipes[i % n_pipes].enqueue(engine)
         for p_ in pipes:
             p_.sync()
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            pipes[i % 2].enqueue(engine)
+            pipes[i % n_pipes].enqueue(engine)
         for p_ in pipes:
             p_.sync()
         torch.cuda.synchronize()
@@ -670,7 +671,7 @@ def main():
             if chunks is not False:
                 ps_ = h2dev.Parser(False, boundary_step=boundary_step, bulk_pairs=bulk_pairs, chunks=False)
                 assert ps_.open_streams([1]) == 0
-                last = (max(2, warmup) + steps - 1) % 2 if steps else 1
+                last = (steps - 1) % n_pipes if steps else n_pipes - 1
                 rl = pipes[last].sync(want_events=True)
                 err_, ev_seq = ps_.deframe(dsts[last].ptr, jobs[last].delivered_slices(0), cap=pipes[last].events_cap)
                 ps_.close()
