@@ -55,12 +55,25 @@ __global__ __launch_bounds__(TXF_THREADS) void k_tx_index(grdma_txf_ctl* ctls) {
   // what lies in front of this workgroup's entries (and whether any of it is unusable)
   uint64_t pe = 0, pl = 0, pt = 0;
   bool bad = false;
-  for (uint64_t k = tid; k < first; k += TXF_THREADS) {
-    const uint64_t len = sl[k].len;
-    bad |= len == 0 || len >= (1ull << 31);
-    pe += enc_size(len);
-    pl += len;
-    pt += tiles_of(len);
+  // (eight loads in flight per pass -- thirty-two were slower, most of them clamped duplicates for the front workgroups: a plain loop is a chain of load -> add, one L2 round trip per entry -- 16 us for
+  // the workgroup that has 32 of them in front)
+  for (uint64_t k0 = tid; k0 < first; k0 += 8 * TXF_THREADS) {
+    uint64_t lens[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint64_t k = k0 + (uint64_t)j * TXF_THREADS;
+      lens[j] = sl[k < first ? k : 0].len;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint64_t k = k0 + (uint64_t)j * TXF_THREADS;
+      if (k >= first) continue;
+      const uint64_t len = lens[j];
+      bad |= len == 0 || len >= (1ull << 31);
+      pe += enc_size(len);
+      pl += len;
+      pt += tiles_of(len);
+    }
   }
   const uint64_t k = first + tid;
   const uint64_t len = k < n ? sl[k].len : 0;
