@@ -196,8 +196,7 @@ __global__ __launch_bounds__(COPY_THREADS) void k_copy(const grdma_plan* const* 
 // k_rx_apply: K4 in one launch -- copy the payload out, clear it behind, and let
 // the last workgroup post the credit (status report) once every byte is free.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(COPY_THREADS) void k_rx_apply(const grdma_rx_op* ops) {
-  const grdma_rx_op op = ops[blockIdx.y];
+__device__ __forceinline__ void rx_apply_body(const grdma_rx_op op) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * COPY_THREADS + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * COPY_THREADS) >> 6;
@@ -237,6 +236,26 @@ __global__ __launch_bounds__(COPY_THREADS) void k_rx_apply(const grdma_rx_op* op
     __hip_atomic_store(&res->commit_seq, res->commit_seq + 1, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+__global__ __launch_bounds__(COPY_THREADS) void k_rx_apply(const grdma_rx_op* ops) { rx_apply_body(ops[blockIdx.y]); }
+
+// k_rx_apply_gather: the scatter of round t and the GATHER of round t + 1 in one launch (gridDim.y = 2 x links: y < links
+// scatters link y, y >= links moves the gather plan of link y - links).  Both are ready when the planner pair of round t
+// has run -- the drain plan for the scatter, the next send plan for the gather, whose staging buffer the wire of round
+// t - 1 has left -- and neither touches what the other does; two copy kernels back to back pay a kernel boundary and a
+// ramp each, and the tail of the first leaves most of the chip idle.  One launch less per round.
+__global__ __launch_bounds__(COPY_THREADS) void k_rx_apply_gather(const grdma_rx_op* ops, const grdma_plan* const* gplans) {
+  const uint32_t links = gridDim.y >> 1;
+  if (blockIdx.y < links) {
+    rx_apply_body(ops[blockIdx.y]);
+    return;
+  }
+  const grdma_plan* plan = gplans[blockIdx.y - links];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * COPY_THREADS + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * COPY_THREADS) >> 6;
+  run_plan<256, GRDMA_COPY_CONTIG>(plan, wave, nwaves, lane);
 }
 
 // ----------------------------------------------------------------------------
@@ -418,6 +437,7 @@ __attribute__((visibility("hidden"))) const void* grdma_kernel_fn(int which) {
     case 5: return reinterpret_cast<const void*>(&k_tx_commit);
     case 6: return reinterpret_cast<const void*>(&k_tx_plan_job);
     case 7: return reinterpret_cast<const void*>(&k_wire_txplan_job);
+    case 8: return reinterpret_cast<const void*>(&k_rx_apply_gather);
     default: return nullptr;
   }
 }

@@ -2439,6 +2439,8 @@ struct grdma_stream_job {
                                       // the start of a step, k_tx_fast per Send, the general planner behind it for the rest
   grdma_txf_ctl* d_txf = nullptr;     // [n]
   int pair_job = 1;                   // pipelined graph: drain of round t and Send of round t + 1 in one launch (k_plan_pair_job)
+  int fuse_ag = 1;                    // paired schedule: the scatter of round t and the gather of round t + 1 in one launch
+                                      // (k_rx_apply_gather); GRDMA_JOB_FUSE_AG=0: two launches
   int fuse = 0;                       // GRDMA_JOB_FUSE=1 (experiment, off): the planners ride in the copy kernels' grids
                                       // (k_wire_txplan_job, k_rxplan_gather_job), three launches per round.  Measured: no
                                       // gain -- a planner's dependent loads run ~2.3 x slower beside a copy that saturates
@@ -2470,7 +2472,8 @@ namespace {
 
 inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 : 2); }
 inline int job_fastkey(const grdma_stream_job* j) {
-  return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0) | (j->pair_job ? 8 : 0) | (j->fuse ? 16 : 0);
+  return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0) | (j->pair_job ? 8 : 0) | (j->fuse ? 16 : 0) |
+         (j->fuse_ag ? 32 : 0);
 }
 // copy workgroups (1024 threads: one per CU) next to a planner workgroup in a fused launch: every CU but the planner's
 inline uint32_t job_fused_copy_blocks() {
@@ -2902,17 +2905,26 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
       // branches of a graph do not overlap on this stack (measured: even planner workgroups small enough to sit
       // beside the copy kernels' run behind them), so the round is a chain -- and this one has four links:
       //   G_t: P_t (= X_{t-1})      W_t: G_t      X_t + P_{t+1}: W_t, A_{t-1}      A_t: X_t
+      // (j->fuse_ag, default: the scatter of round t and the gather of round t + 1 share a launch -- both are ready
+      // behind the planner pair, neither touches the other's bytes: G_{t+1} = A_t, three launches per round)
       if (t == 0) e = add_tx(0, txop, {});
-      if (e == hipSuccess) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t], at(A, t, 1)});
+      if (e == hipSuccess && (t == 0 || !j->fuse_ag)) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t], at(A, t, 1)});
       if (e == hipSuccess) e = add(&W[t], f_cpy, dim3(txb, n), ct, wplans, {G[t]});
+      const bool more = t + 1 < R;
       if (e == hipSuccess) {
-        const bool more = t + 1 < R;
         const void* txop_next = j->d_txop + job_opset(t + 1) * n;
         e = add3(&X[t], grdma_kernel_fn_plan_pair_job(), dim3(n, more ? 2 : 1), grdma_rx_plan_job_threads(), rxop,
                  more ? txop_next : nullptr, j->d_txf, {W[t], at(A, t, 1)});
         if (more) P[t + 1] = X[t];
       }
-      if (e == hipSuccess) e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t]});
+      if (e == hipSuccess) {
+        if (more && j->fuse_ag) {
+          e = add2(&A[t], grdma_kernel_fn(8), dim3(std::max(rxb, txb), 2 * n), ct, rxop, gplans, {X[t]});
+          G[t + 1] = A[t];
+        } else {
+          e = add(&A[t], f_rxa, dim3(rxb, n), ct, rxop, {X[t]});
+        }
+      }
     } else if (j->deep || fast || tfast) {
       // Limit-driven schedule (default): the drain of round t walks exactly up to the tail its Send
       // computed (grdma_rx_op::limit_ptr), so round t + 1 may land in the ring while round t is being
@@ -3121,6 +3133,7 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
   if (const char* e = getenv("GRDMA_RX_FAST")) j->rx_fast = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_PAIR_JOB")) j->pair_job = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_JOB_FUSE")) j->fuse = atoi(e) != 0;
+  if (const char* e = getenv("GRDMA_JOB_FUSE_AG")) j->fuse_ag = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_TX_FAST")) j->tx_fast = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_SLIM_AFTER")) {  // experiment (tools/gpu_slim.sh): see grdma_stream_job_run
     j->slim_after = atoi(e);
