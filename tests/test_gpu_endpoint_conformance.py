@@ -56,3 +56,26 @@ def test_pollset_with_64_connections(gpu, bpev):
     out = run("pollset", 64, 3, bpev, env={"GRPC_RDMA_RING_BUFFER_SIZE_KB": "256"})
     assert ": ok" in out
 
+
+
+@pytest.mark.parametrize("ring_kb,always,want", [("16384", "0", "promoted"), ("256", "1", "skipped"), ("4096", "0", None)],
+                         ids=["r16m_promoted", "r256k_skipped", "r4m_mixed"])
+def test_streamed_writes_queue_behind_the_sends_in_flight(gpu, ring_kb, always, want):
+    """tools/endpoint_stream: 1 MiB writes of 130 slices through grpc_endpoint_write / _read, byte-checked on the reading
+    side.  The endpoint's send buffers complete a write once it is copied, and the buffer that waits is queued into the
+    pair's send stream behind the Sends in flight (grdma_endpoint_write_queue): promoted when the write in front went out
+    whole -- decided on the device --, skipped and submitted again the ordinary way when it did not (a 256 KiB ring,
+    GRDMA_WRITE_QUEUE_ALWAYS: every queued chain finds the write in front short).  The delivered bytes are the written
+    bytes either way."""
+    import json
+    es = os.path.join(ROOT, "tools", "endpoint_stream")
+    env = dict(os.environ, GRPC_PLATFORM_TYPE="RDMA_BP", GRPC_RDMA_RING_BUFFER_SIZE_KB=ring_kb, GRDMA_WRITE_QUEUE_ALWAYS=always)
+    p = subprocess.run([es, "96", str(1 << 20), "1", "0", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    queued, promoted, skipped = r["writes_queued"]
+    assert r["checked"] and r["endpoint_bytes"] > 96 << 20 and promoted + skipped <= queued, r
+    if want == "promoted":
+        assert promoted >= 32 and skipped == 0, r
+    elif want == "skipped":
+        assert skipped >= 8 and promoted == 0, r
