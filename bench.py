@@ -868,10 +868,13 @@ def main():
         # GRDMA_WIRE_DIRECT: the gather writes the records straight into the peer ring
         # (HBM / xGMI peer memory), no staging copy and no wire kernel
         try:
-            dr = measure(args.ring_kb, max(2, args.steps // 2), 1, not args.no_verify, False,
-                         pipeline=False, wire_flags=2)
-            out["value_wire_direct"] = round(
-                wl.user_bytes * max(2, args.steps // 2) * world / dr["elapsed"] / (1 << 30), 3)
+            dr = measure(args.ring_kb, args.steps, max(2, args.warmup), not args.no_verify, False,
+                         pipeline=bool(args.pipeline), wire_flags=2)
+            out["value_wire_direct"] = round(wl.user_bytes * args.steps * world / dr["elapsed"] / (1 << 30), 3)
+            out["wire_direct_verified"] = dr.get("verified")
+            out["config"]["wire_direct_leg"] = ("the same step with GRDMA_WIRE_DIRECT pairs: the gather writes the records straight into the peer "
+                                                "ring (HBM / xGMI peer memory), no staging copy, no wire kernel -- two launches per round "
+                                                "(planner pair; scatter + next gather), same schedule and verification as the headline")
         except Exception as e:
             out["wire_direct_error"] = str(e)[:200]
     half = max(2, args.steps // 2)

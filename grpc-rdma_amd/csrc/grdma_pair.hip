@@ -2495,7 +2495,7 @@ inline bool job_exec_stale(const grdma_stream_job* j) {
 
 // the send plan of round t: priced from the index of the slice buffer (built in front of the first round of a
 // step), the general planner in the same launch for what that declines
-inline bool job_tx_fast(const grdma_stream_job* j) { return j->tx_fast && j->burst == 1 && !j->direct; }
+inline bool job_tx_fast(const grdma_stream_job* j) { return j->tx_fast && j->burst == 1; }
 inline uint32_t job_index_blocks(const grdma_stream_job* j) {  // k_tx_index: 1024 slices per workgroup
   uint64_t most = 1;
   for (const grdma_job_link& l : j->links) most = std::max<uint64_t>(most, l.count);
@@ -2777,7 +2777,7 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
                   const void* arg3, std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
     std::vector<hipGraphNode_t> d;
     for (hipGraphNode_t x : deps)
-      if (x) d.push_back(x);
+      if (x && std::find(d.begin(), d.end(), x) == d.end()) d.push_back(x);  // (a node twice is an invalid argument)
     if (d.empty() && pre_last) d.push_back(pre_last);  // a root of the job waits for the stage in front of it
     // (an array of GRDMA_JOB_HOOK_ARGS entries for every node -- the runtime reads as many as the kernel has)
     static uint64_t none = 0;
@@ -2909,12 +2909,14 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
       // behind the planner pair, neither touches the other's bytes: G_{t+1} = A_t, three launches per round)
       if (t == 0) e = add_tx(0, txop, {});
       if (e == hipSuccess && (t == 0 || !j->fuse_ag)) e = add(&G[t], f_cpy, dim3(txb, n), ct, gplans, {P[t], at(A, t, 1)});
-      if (e == hipSuccess) e = add(&W[t], f_cpy, dim3(txb, n), ct, wplans, {G[t]});
+      // (a direct wire has no wire kernel: the gather writes the records into the peer ring, two launches per round)
+      W[t] = nullptr;
+      if (e == hipSuccess && !j->direct) e = add(&W[t], f_cpy, dim3(txb, n), ct, wplans, {G[t]});
       const bool more = t + 1 < R;
       if (e == hipSuccess) {
         const void* txop_next = j->d_txop + job_opset(t + 1) * n;
         e = add3(&X[t], grdma_kernel_fn_plan_pair_job(), dim3(n, more ? 2 : 1), grdma_rx_plan_job_threads(), rxop,
-                 more ? txop_next : nullptr, j->d_txf, {W[t], at(A, t, 1)});
+                 more ? txop_next : nullptr, j->d_txf, {j->direct ? G[t] : W[t], at(A, t, 1)});
         if (more) P[t + 1] = X[t];
       }
       if (e == hipSuccess) {

@@ -46,8 +46,9 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
   const uint64_t* const enc_pre = ctl->enc_pre;
   const uint64_t* const len_pre = ctl->len_pre;
   const uint32_t* const tile_pre = ctl->tile_pre;
+  const bool direct = c->wire_direct != 0;  // records straight into the peer ring (no staging copy, no wire plan)
   const bool ok = ctl->valid != 0 && ctl->slices == op.slices && n == op.nslices && op.use_cursor != 0 && !op.inline_copy &&
-                  connected && c->wire_direct == 0 && op.wire_plan != nullptr && cap <= (1ull << 31) &&
+                  connected && (direct || op.wire_plan != nullptr) && cap <= (1ull << 31) &&
                   ctl->tile_shift == GRDMA_PLAN_TILE_SHIFT(cap);
   if (tid == 0)  // get_remote_head(), pair.h:229-233 -- ONE read for the whole Send (the peer's scatter may post meanwhile)
     s_rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -151,6 +152,31 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
   uint8_t* const staging = op.staging_alt ? op.staging_alt : c->staging;
   const uint64_t t_priced = __builtin_amdgcn_s_memtime();
 
+  // ---- direct wire: the one record whose payload crosses the ring end becomes two segments (a Send stages at most
+  //      ring / 2 bytes: one wrap at most); the records behind it sit one segment further, their tiles `extra` further
+  __shared__ uint32_t s_wrap[2];  // {record that wraps (0xFFFFFFFF = none), extra tiles of the split}
+  if (tid == 0) {
+    s_wrap[0] = 0xFFFFFFFFu;
+    s_wrap[1] = 0;
+  }
+  __syncthreads();
+  if (direct) {
+#pragma unroll
+    for (int r = 0; r < TXB_PER; r++) {
+      const uint64_t i = tid + (uint64_t)r * TXB_THREADS;
+      if (i >= nrec_total) continue;
+      const uint64_t p = i == nrec ? short_pay : (i == 0 ? sat_sub(r_len[r], byte_idx) : r_len[r]);
+      const uint64_t pay_off = (tail0 + st_i[r] + 8) & mask;
+      if (pay_off + p > cap) {
+        const uint64_t l1 = cap - pay_off;
+        s_wrap[0] = (uint32_t)i;
+        s_wrap[1] = (uint32_t)(((l1 + TB - 1) >> ts) + ((p - l1 + TB - 1) >> ts) - ((p + TB - 1) >> ts));
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t wrap_rec = s_wrap[0], wrap_extra = s_wrap[1];
+
   // ---- segments and tile prefix, one record per thread-step (AppendHeader / AppendFooter ride on the segment)
 #pragma unroll
   for (int r = 0; r < TXB_PER; r++) {
@@ -159,8 +185,26 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
     const uint64_t p = i == nrec ? short_pay : (i == 0 ? sat_sub(r_len[r], byte_idx) : r_len[r]);
     const uint64_t tagw = GRDMA_SEG_TAG_WRITE | (p << GRDMA_SEG_TAG_LEN_SHIFT);
     const uint8_t* src = reinterpret_cast<const uint8_t*>(r_ptr[r]) + (i == 0 ? byte_idx : 0);
-    plan->segs[i] = {(uint64_t)(staging + st_i[r] + 8), (uint64_t)src, p, tagw | GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR};
-    plan->tile_prefix[i] = i == 0 ? 0u : (uint32_t)(r_t0[r] - base_t + Dt);
+    const uint32_t t0 = i == 0 ? 0u : (uint32_t)(r_t0[r] - base_t + Dt);
+    if (!direct) {
+      plan->segs[i] = {(uint64_t)(staging + st_i[r] + 8), (uint64_t)src, p, tagw | GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR};
+      plan->tile_prefix[i] = t0;
+      continue;
+    }
+    uint8_t* const ring = c->peer_ring;
+    const uint64_t pay_off = (tail0 + st_i[r] + 8) & mask;
+    const uint64_t seg = i + ((uint32_t)i > wrap_rec ? 1 : 0);
+    const uint32_t tx0 = t0 + ((uint32_t)i > wrap_rec ? wrap_extra : 0u);
+    if ((uint32_t)i == wrap_rec) {
+      const uint64_t l1 = cap - pay_off;
+      plan->segs[seg] = {(uint64_t)(ring + pay_off), (uint64_t)src, l1, tagw | GRDMA_SEG_TAG_HDR};
+      plan->segs[seg + 1] = {(uint64_t)ring, (uint64_t)(src + l1), p - l1, tagw | GRDMA_SEG_TAG_FTR};
+      plan->tile_prefix[seg] = tx0;
+      plan->tile_prefix[seg + 1] = tx0 + (uint32_t)((l1 + TB - 1) >> ts);
+    } else {
+      plan->segs[seg] = {(uint64_t)(ring + pay_off), (uint64_t)src, p, tagw | GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR};
+      plan->tile_prefix[seg] = tx0;
+    }
   }
 
   if (tid == 0) {
@@ -172,14 +216,15 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
     }
     const uint64_t st_last = s_short[1];  // st(nrec)
     const uint64_t staged = (nrec || short_pay) ? st_last + (short_pay > 0 ? enc_size(short_pay) : 0) : 0;
-    const uint64_t nsegs = nrec_total;
+    const uint64_t nsegs = nrec_total + (wrap_rec != 0xFFFFFFFFu ? 1 : 0);
+    ntiles += wrap_extra;
     plan->nsegs = (uint32_t)nsegs;
     plan->ntiles = (uint32_t)ntiles;
     plan->tile_bytes = (uint32_t)TB;
     plan->tile_prefix[nsegs] = (uint32_t)ntiles;
     plan->bytes = sent;
-    plan->tag_base = (uint64_t)staging;
-    plan->tag_mask = ~0ull;
+    plan->tag_base = direct ? (uint64_t)c->peer_ring : (uint64_t)staging;
+    plan->tag_mask = direct ? mask : ~0ull;
     const uint64_t new_tail = (tail0 + staged) & mask;
     // the <= 2 RDMA WRITEs of GetWriteRequests(sg_list), ring_buffer.cc:261-330
     const uint64_t seg1 = staged < cap - tail0 ? staged : cap - tail0;
@@ -197,9 +242,9 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
       }
     }
     grdma_plan* wp = op.wire_plan;
-    {
+    if (wp != nullptr) {
       uint32_t ns = 0, nt = 0;
-      if (staged > 0) {
+      if (staged > 0 && !direct) {
         wp->segs[0] = {(uint64_t)(c->peer_ring + tail0), (uint64_t)staging, seg1, 0};
         wp->tile_prefix[0] = 0;
         nt = (uint32_t)((seg1 + TB - 1) >> ts);
@@ -215,7 +260,7 @@ __device__ __forceinline__ bool txf_body(const grdma_tx_op& op_in, const grdma_t
       wp->ntiles = nt;
       wp->tile_bytes = (uint32_t)TB;
       wp->tile_prefix[ns] = nt;
-      wp->bytes = staged;
+      wp->bytes = direct ? 0 : staged;
     }
     // rdma_flush cursor walk, rdma_bp_posix.cc:480-493
     const uint64_t idx = start + nrec;

@@ -18,7 +18,7 @@
 //                segment and tile-prefix entry straight from the index.
 //
 // Same plan, wire requests, cursor, counters and result block as k_tx_plan.  What it does not take (a slice of
-// zero bytes anywhere in the buffer -- it ends a Send like the reference's `break` --, a direct wire, the latency
+// zero bytes anywhere in the buffer -- it ends a Send like the reference's `break` --, the latency
 // path) is left to the general planner, which k_tx_plan_job runs in the same launch when the body returns false.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -75,7 +75,7 @@ def test_steady_state_planner_and_pair_pool_gpu_tests_under_the_emulator(emu_lib
     planners behind them, csrc/grdma_rx_fast.h, grdma_tx_fast.h) on periodic streams cut by max_sge, sequential and
     pipelined graphs against the oracle's rounds; the PairPool on recycled memory."""
     run_gpu_tests(emu_lib, ["tests/test_gpu_stream_job.py", "tests/test_gpu_pair_pool.py", "-n", "4",
-                            "-k", "(fast_planner and sge130) or pool"], 4)
+                            "-k", "(fast_planner and sge130) or pool"], 6)
 
 
 def test_concurrent_writer_and_poller_gpu_tests_under_the_emulator(emu_lib):

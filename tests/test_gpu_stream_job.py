@@ -173,14 +173,15 @@ FAST_CASES = [
 ]
 
 
+@pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
 @pytest.mark.parametrize("pipeline", [False, True], ids=["sequential", "pipelined"])
 @pytest.mark.parametrize("case", FAST_CASES, ids=["r16m_sge255", "r32m_sge511", "r8m_sge130"])
-def test_steady_state_drains_through_the_fast_planner_match_the_oracle(gpu, case, pipeline):
+def test_steady_state_drains_through_the_fast_planner_match_the_oracle(gpu, case, pipeline, flags):
     R, max_sge, n_msgs, msg_len = case
     slices = _framed_slices(n_msgs, msg_len, seed=R % 89)
     exp, exp_rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, slices)
     before = _fast_counts(gpu)
-    got = _run_job(gpu, R, max_sge, slices, pipeline=pipeline)
+    got = _run_job(gpu, R, max_sge, slices, pipeline=pipeline, flags=flags)
     after = _fast_counts(gpu)
     assert [len(x) for x in got["slices"]] == [len(x) for x in exp]
     assert got["slices"] == exp
@@ -193,5 +194,5 @@ def test_steady_state_drains_through_the_fast_planner_match_the_oracle(gpu, case
     took = after[0] - before[0]
     assert took >= exp_rounds, "k_rx_fast took %d drains (declined by reason: %s)" % (
         took, [a - b for a, b in zip(after[1:6], before[1:6])])
-    # every Send of the three passes is priced from the index of the slice buffer (staged wire, no empty slice)
+    # every Send of the three passes is priced from the index of the slice buffer (either wire, no empty slice)
     assert after[6] - before[6] >= PASSES * exp_rounds and after[7] == before[7], (after[6:], before[6:])
