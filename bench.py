@@ -773,7 +773,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r02_pmc_ring%dm_summary.json" % (args.ring_kb // 1024))
     if os.path.exists(pmc) and args.msgs == 256 and args.wire == "staged":
         try:
-            traffic = json.load(open(pmc))["kernels"][kname]["hbm_traffic_bytes"]
+            k = json.load(open(pmc))["kernels"][kname]
+            # one FULL launch against the algorithmic bytes of one full launch (the plain mean also counts the
+            # short last round of a step and the warm-ups)
+            traffic = k.get("hbm_traffic_bytes_full_size_launch", k["hbm_traffic_bytes"])
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": "%s (%s)" % (kname, dom),

@@ -12,6 +12,7 @@ import sys
 
 root, out_path, command = sys.argv[1], sys.argv[2], sys.argv[3]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         m = re.search(r"k_\w+|__amd_rocclr_\w+", row["Kernel_Name"])
@@ -19,6 +20,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         a = agg[name][row["Counter_Name"]]
         a[0] += 1
         a[1] += float(row["Counter_Value"])
+        vals[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 kernels = {}
 for name, ctrs in sorted(agg.items()):
     k = {}
@@ -29,6 +31,19 @@ for name, ctrs in sorted(agg.items()):
         rd = 2 * 1024 * ctrs["FETCH_SIZE"][1] / ctrs["FETCH_SIZE"][0]
         wr = 1024 * ctrs["WRITE_SIZE"][1] / ctrs["WRITE_SIZE"][0]
         k["hbm_read_bytes"], k["hbm_write_bytes"], k["hbm_traffic_bytes"] = int(rd), int(wr), int(rd + wr)
+        # The launches of a kernel differ in size (warm-ups, the short last round of a step, the
+        # connection set-up): the figure to set against the algorithmic bytes of ONE full launch is
+        # the mean over the launches within 10 % of the largest one, per counter.
+        full = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            top = max(vals[name][c])
+            sel = [v for v in vals[name][c] if v >= 0.9 * top]
+            full[c] = (len(sel), sum(sel) / len(sel))
+        k["launches_full_size"] = {"FETCH_SIZE": full["FETCH_SIZE"][0], "WRITE_SIZE": full["WRITE_SIZE"][0]}
+        k["hbm_read_bytes_full_size_launch"] = int(2 * 1024 * full["FETCH_SIZE"][1])
+        k["hbm_write_bytes_full_size_launch"] = int(1024 * full["WRITE_SIZE"][1])
+        k["hbm_traffic_bytes_full_size_launch"] = (k["hbm_read_bytes_full_size_launch"]
+                                                   + k["hbm_write_bytes_full_size_launch"])
     for a, b, label in (("SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "frac_wave_time_parked"),
                         ("SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "frac_wave_time_issuing"),
                         ("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "frac_wave_time_issue_stalled")):
@@ -37,9 +52,10 @@ for name, ctrs in sorted(agg.items()):
     kernels[name] = k
 json.dump({"command": command,
            "units": "FETCH_SIZE / WRITE_SIZE: KiB per dispatch; SQ_*: quad-cycles summed over waves; "
-                    "averages per launch over the whole run",
+                    "averages per launch over the whole run; *_full_size_launch: over the launches within 10 % "
+                    "of the kernel's largest (what one full drain / gather moves)",
            "gfx950_correction": "FETCH_SIZE reports 1/2 of a wide coalesced streaming read -> doubled in "
                                 "hbm_read_bytes; WRITE_SIZE uncalibrated on gfx950, taken as reported",
            "kernels": kernels}, open(out_path, "w"), indent=1)
-print(json.dumps({k: {a: b for a, b in v.items() if a.startswith(("hbm_traffic", "frac_"))} for k, v in kernels.items()
+print(json.dumps({k: {a: b for a, b in v.items() if a.startswith(("hbm_traffic", "frac_", "launches_full"))} for k, v in kernels.items()
                   if k.startswith("k_")}))
