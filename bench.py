@@ -591,6 +591,20 @@ def main():
                     classes[name] = {"launches": n, "ms": inst.ms_class[i],
                                      "us_per_launch": 1e3 * inst.ms_class[i] / n}
             out["classes"] = classes
+            # the launches of the schedule that was TIMED (pipelined: planner pair; scatter + next gather; wire), each
+            # by itself between two events -- same work, same order as the graph, which is a chain
+            if pipeline:
+                try:
+                    inst = None
+                    for _ in range(3):
+                        inst = job.run(gs.RUN_INSTRUMENTED_SCHEDULE)
+                    assert inst.done and inst.bytes_delivered == total_n
+                    out["schedule_classes"] = {
+                        name: {"launches": int(inst.launches_class[i]), "ms": inst.ms_class[i],
+                               "us_per_launch": 1e3 * inst.ms_class[i] / int(inst.launches_class[i])}
+                        for i, name in enumerate(gs.CLASS_NAMES) if int(inst.launches_class[i])}
+                except Exception as e:  # (a job that is not on the paired schedule: the in-order classes stand alone)
+                    out["schedule_classes_error"] = str(e)[:160]
         job.close()
         for tx, rx, dst, _c, _w in keep:
             tx.close(); rx.close(); dst.free()
@@ -786,6 +800,49 @@ def main():
                                    "command, committed; NOT re-measured in this run)") if traffic is not None else None,
                 "bytes_per_launch": int(per_launch),
                 "us_per_launch": round(classes[dom]["us_per_launch"], 2)}
+    # The default schedule runs the scatter of round t and the gather of round t + 1 as ONE launch (k_rx_apply_gather):
+    # that launch is the dominant HBM kernel of the timed region.  Its algorithmic bytes: 3 x the payload of the
+    # rounds it scatters (read + written + cleared) + 2 x the payload of the rounds it gathers (read + written); the
+    # rounds are the slice list in chunks of max_sge slices (no Send is cut by credit at this ring size).
+    sched = head.get("schedule_classes") or {}
+    if "scatter_gather" in sched and args.schedule != "engine":
+        sge = min(args.max_sge, 4095)
+        chunks = [sum(wl.lens[i:i + sge]) for i in range(0, len(wl.lens), sge)]
+        sg = sched["scatter_gather"]
+        if len(chunks) == rounds and sg["launches"] == rounds - 1:
+            fused_bytes = 3 * sum(chunks[:-1]) + 2 * sum(chunks[1:])
+        else:
+            fused_bytes = 5 * wl.N * sg["launches"] / max(1, rounds)
+        per_launch_sg = fused_bytes / sg["launches"]
+        ach = per_launch_sg / (sg["us_per_launch"] * 1e-6) / 1e9
+        traffic_sg = None
+        if os.path.exists(pmc) and args.msgs == 256 and args.wire == "staged":
+            try:
+                k = json.load(open(pmc))["kernels"]["k_rx_apply_gather"]
+                traffic_sg = k.get("hbm_traffic_bytes_full_size_launch")
+            except Exception:
+                traffic_sg = None
+        alone = {"kernel": roofline["kernel"], "achieved": roofline["achieved"], "frac": roofline["frac"],
+                 "bytes_per_launch": roofline["bytes_per_launch"], "us_per_launch": roofline["us_per_launch"],
+                 "traffic": roofline["traffic"],
+                 "note": "the scatter as a launch of its own (in-order instrumented pass; what rounds 1 and 2 reported)"}
+        roofline = {"bound": "hbm",
+                    "kernel": "k_rx_apply_gather (scatter of round t + gather of round t + 1: one launch of the timed schedule)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic_sg,
+                    "traffic_source": (os.path.relpath(pmc, ROOT) + " (hbm_traffic_bytes_full_size_launch: rocprofv3 --pmc "
+                                       "FETCH_SIZE / WRITE_SIZE passes of this command, mean over the full-size launches "
+                                       "-- %d B algorithmic for one of those; committed, NOT re-measured in this run)"
+                                       % (5 * max(chunks))) if traffic_sg is not None else None,
+                    "bytes_per_launch": int(per_launch_sg), "us_per_launch": round(sg["us_per_launch"], 2),
+                    "launches_per_step": sg["launches"],
+                    "measured": "HIP events around every launch of the timed schedule, enqueued in the graph's order on "
+                                "one stream (GRDMA_RUN_INSTRUMENTED_SCHEDULE); mean over the %d fused launches of a step, "
+                                "the last of which gathers the short last round" % sg["launches"],
+                    "scatter_alone": alone}
+        tot_s = sum(v["ms"] for v in sched.values())
+        roofline["schedule_kernels"] = {k: {"launches": v["launches"], "us_per_launch": round(v["us_per_launch"], 2),
+                                            "share_of_kernel_time": round(v["ms"] / tot_s, 3)} for k, v in sched.items()}
     # what the roofline of the dominant HBM kernel does not show: the kernel that takes the most TIME (a planner is
     # latency-bound and moves next to nothing), and the step as a whole against the HBM peak
     tot_ms = sum(v["ms"] for v in classes.values())
@@ -797,6 +854,18 @@ def main():
         "share_of_kernel_time": round(classes[top]["ms"] / tot_ms, 3),
         "planner_share_of_kernel_time": round(sum(classes[k]["ms"] for k in ("tx_plan", "rx_plan") if k in classes) / tot_ms, 3),
         "note": "per-class HIP-event time of the instrumented in-order pass (a class = the launches between two events)"}
+    if roofline.get("schedule_kernels"):
+        # the same question for the schedule that was timed: its launches are the planner pair (drain plan of round t +
+        # send plan of round t + 1), the fused scatter + gather and the wire
+        sk = roofline["schedule_kernels"]
+        top_s = max(sk, key=lambda k: sk[k]["share_of_kernel_time"])
+        roofline["dominant_by_time_in_order_pass"] = roofline["dominant_by_time"]
+        roofline["dominant_by_time"] = {
+            "kernel": top_s + {"plan_pair": " (k_plan_pair_job)", "scatter_gather": " (k_rx_apply_gather)"}.get(top_s, ""),
+            "us_per_launch": sk[top_s]["us_per_launch"], "share_of_kernel_time": sk[top_s]["share_of_kernel_time"],
+            "planner_share_of_kernel_time": round(sum(sk[k]["share_of_kernel_time"] for k in ("tx_plan", "plan_pair", "rx_plan")
+                                                      if k in sk), 3),
+            "note": "per-launch HIP-event time of the timed schedule's launches (GRDMA_RUN_INSTRUMENTED_SCHEDULE)"}
     roofline["step_level"] = {"bytes": int(step_bytes), "achieved": round(step_bytes / step_s / 1e9, 1), "unit": "GB/s",
                               "frac": round(step_bytes / step_s / 1e9 / HBM_PEAK_GBPS, 4),
                               "frac_with_wire": round((step_bytes + 2 * wl.E) / step_s / 1e9 / HBM_PEAK_GBPS, 4)}

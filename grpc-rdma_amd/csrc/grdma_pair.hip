@@ -2453,6 +2453,7 @@ struct grdma_stream_job {
   std::vector<hipEvent_t> pev;        // dependency events of the pipelined schedule
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> kev;
+  std::vector<int> kev_cls;                   // GRDMA_RUN_INSTRUMENTED_SCHEDULE: the class of the launch behind mark i
   hipStream_t stream = nullptr;
   bool direct = false;
   uint64_t max_ring = 0;
@@ -2561,6 +2562,81 @@ int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
   }
   // the drains of the job were told how far to walk by their op (limit_ptr); the connection's own arrival
   // report and the state lines follow once, behind the last round
+  HIP_TRY(grdma_launch_tx_commit(j->d_txconns, nullptr, n, s));
+  return 0;
+}
+
+// GRDMA_RUN_INSTRUMENTED_SCHEDULE: the launches of the DEFAULT schedule of a streaming job -- the chain the graph
+// builder below makes of a paired job (planner pair; scatter + next gather; wire) -- one after the other on one
+// stream with an event between every two of them.  The graph's order is a chain already, so this is the same
+// work in the same order; what the events add is the time of each launch by itself (classes 5 = k_plan_pair_job,
+// 6 = k_rx_apply_gather beside the five of the in-order pass).
+bool job_is_paired(const grdma_stream_job* j) {
+  return j->pipeline && j->burst == 1 && j->rx_fast && job_tx_fast(j) && j->pair_job && !j->fuse && j->rounds >= 1;
+}
+int job_enqueue_schedule_instrumented(grdma_stream_job* j, hipStream_t s) {
+  if (!job_is_paired(j))
+    return fail(GRDMA_ERR_INVALID, "GRDMA_RUN_INSTRUMENTED_SCHEDULE times the paired schedule (pipelined job, steady-state planners)");
+  const uint32_t n = (uint32_t)j->links.size();
+  const uint32_t tx_blocks = copy_blocks_for(j->max_ring / 2);
+  const uint32_t rx_blocks = copy_blocks_for(j->max_ring);
+  const uint32_t grid_cap = copy_blocks_for(~0ull >> 8);
+  const uint32_t txb = std::max<uint32_t>(1, std::min<uint32_t>(tx_blocks, grid_cap / n + 1));
+  const uint32_t rxb = std::max<uint32_t>(1, std::min<uint32_t>(rx_blocks, grid_cap / n + 1));
+  const uint32_t ct = grdma_kernel_threads(1);
+  const uint64_t R = j->rounds;
+  size_t e = 0;
+  j->kev_cls.clear();
+  auto mark = [&](int cls) -> int {
+    if (e >= j->kev.size()) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreate(&ev));
+      j->kev.push_back(ev);
+    }
+    HIP_TRY(hipEventRecord(j->kev[e++], s));
+    if (cls >= 0) j->kev_cls.push_back(cls);
+    return 0;
+  };
+  auto launch = [&](const void* fn, dim3 grid, uint32_t threads, const void* a0, const void* a1, const void* a2) -> hipError_t {
+    static uint64_t none = 0;
+    void* args[GRDMA_JOB_HOOK_ARGS];
+    for (uint32_t a = 0; a < GRDMA_JOB_HOOK_ARGS; a++) args[a] = &none;
+    args[0] = const_cast<void*>(static_cast<const void*>(&a0));
+    args[1] = const_cast<void*>(static_cast<const void*>(&a1));
+    args[2] = const_cast<void*>(static_cast<const void*>(&a2));
+    return hipLaunchKernel(fn, grid, dim3(threads), args, 0, s);
+  };
+  if (int rc = mark(-1)) return rc;
+  for (uint64_t t = 0; t < R; t++) {
+    const int k = job_opset(t);
+    const void* rxop = j->d_rxop + k * n;
+    const void* gplans = j->d_plans;
+    const void* wplans = j->d_plans + n * (1 + (t & 1));
+    if (t == 0) {
+      HIP_TRY(job_launch_tx_plan(j, k, 0, n, s));  // k_tx_index + k_tx_plan_job
+      if (int rc = mark(0)) return rc;
+    }
+    if (t == 0 || !j->fuse_ag) {
+      HIP_TRY(launch(grdma_kernel_fn(1), dim3(txb, n), ct, gplans, nullptr, nullptr));
+      if (int rc = mark(1)) return rc;
+    }
+    if (!j->direct) {
+      HIP_TRY(launch(grdma_kernel_fn(1), dim3(txb, n), ct, wplans, nullptr, nullptr));
+      if (int rc = mark(2)) return rc;
+    }
+    const bool more = t + 1 < R;
+    const void* txop_next = j->d_txop + job_opset(t + 1) * n;
+    HIP_TRY(launch(grdma_kernel_fn_plan_pair_job(), dim3(n, more ? 2 : 1), grdma_rx_plan_job_threads(), rxop,
+                   more ? txop_next : nullptr, j->d_txf));
+    if (int rc = mark(5)) return rc;
+    if (more && j->fuse_ag) {
+      HIP_TRY(launch(grdma_kernel_fn(8), dim3(std::max(rxb, txb), 2 * n), ct, rxop, gplans, nullptr));
+      if (int rc = mark(6)) return rc;
+    } else {
+      HIP_TRY(launch(grdma_kernel_fn(3), dim3(rxb, n), ct, rxop, nullptr, nullptr));
+      if (int rc = mark(4)) return rc;
+    }
+  }
   HIP_TRY(grdma_launch_tx_commit(j->d_txconns, nullptr, n, s));
   return 0;
 }
@@ -3440,7 +3516,9 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
     HIP_TRY(hipEventRecord(j->ev1, s));
   } else {
     HIP_TRY(hipEventRecord(j->ev0, s));
-    if (j->pipeline && j->burst == 1 && mode == GRDMA_RUN_EAGER) {
+    if (mode == GRDMA_RUN_INSTRUMENTED_SCHEDULE) {
+      if (int rc = job_enqueue_schedule_instrumented(j, s)) return rc;
+    } else if (j->pipeline && j->burst == 1 && mode == GRDMA_RUN_EAGER) {
       if (int rc = (j->cumask_bits > 0 ? job_enqueue_masked(j, s) : job_enqueue_pipelined(j, s))) return rc;
     } else {
       if (int rc = job_enqueue(j, s, mode == GRDMA_RUN_INSTRUMENTED)) return rc;
@@ -3453,6 +3531,14 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, j->ev0, j->ev1));
   out->ms_total = ms;
+  if (mode == GRDMA_RUN_INSTRUMENTED_SCHEDULE) {
+    for (size_t e = 0; e < j->kev_cls.size(); e++) {
+      float t = 0;
+      HIP_TRY(hipEventElapsedTime(&t, j->kev[e], j->kev[e + 1]));
+      out->ms_class[j->kev_cls[e]] += t;
+      out->launches_class[j->kev_cls[e]]++;
+    }
+  }
   if (mode == GRDMA_RUN_INSTRUMENTED) {
     size_t e = 0;
     for (uint64_t r = 0; r < j->rounds; r++)

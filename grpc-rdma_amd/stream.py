@@ -14,8 +14,9 @@ class StreamResult(C.Structure):
                 ("launches_class", u64 * 8)]
 
 
-RUN_EAGER, RUN_GRAPH, RUN_INSTRUMENTED, RUN_ENGINE = 0, 1, 2, 3
-CLASS_NAMES = ["tx_plan", "gather", "wire", "rx_plan", "rx_apply"]
+RUN_EAGER, RUN_GRAPH, RUN_INSTRUMENTED, RUN_ENGINE, RUN_INSTRUMENTED_SCHEDULE = 0, 1, 2, 3, 4
+# classes 5 and 6 exist in RUN_INSTRUMENTED_SCHEDULE only: the launches two stages of neighbouring rounds share
+CLASS_NAMES = ["tx_plan", "gather", "wire", "rx_plan", "rx_apply", "plan_pair", "scatter_gather"]
 
 _bound = False
 

@@ -383,15 +383,21 @@ typedef struct grdma_stream_result {
   uint64_t tx_rounds, rx_rounds, tx_records, rx_records;
   uint64_t done;               /* 1: every slice was sent and delivered            */
   double ms_total;             /* HIP-event time of the enqueued rounds            */
-  double ms_class[8];          /* instrumented mode: summed kernel time per class  */
-  uint64_t launches_class[8];  /*   0 tx_plan 1 gather 2 wire 3 rx_plan 4 rx_apply (scatter+zero+credit) */
+  double ms_class[8];          /* instrumented modes: summed kernel time per class */
+  uint64_t launches_class[8];  /*   0 tx_plan 1 gather 2 wire 3 rx_plan 4 rx_apply (scatter+zero+credit)
+                                *   _INSTRUMENTED_SCHEDULE also: 5 plan_pair (drain plan of round t + send plan of
+                                *   round t + 1, one launch) 6 scatter_gather (scatter of round t + gather of t + 1) */
 } grdma_stream_result;
 enum grdma_stream_mode {
   GRDMA_RUN_EAGER = 0, GRDMA_RUN_GRAPH = 1, GRDMA_RUN_INSTRUMENTED = 2,
   /* ONE launch of the persistent link engine (k_link): sender, wire and receiver of every link
    * run concurrently as resident workgroups that hand work to each other through memory, like
    * two hosts and a NIC; deterministic, equal to the sequential rounds (see csrc/grdma_link.h) */
-  GRDMA_RUN_ENGINE = 3
+  GRDMA_RUN_ENGINE = 3,
+  /* The launches of the default (pipelined, paired) schedule one after the other on one stream with a HIP event
+   * between every two: the graph's order is a chain already, so the work and its order are the graph's; the
+   * events give the time of every launch by itself.  GRDMA_ERR_INVALID for a job that is not on that schedule. */
+  GRDMA_RUN_INSTRUMENTED_SCHEDULE = 4
 };
 
 grdma_stream_job* grdma_stream_job_create(grdma_pair* tx, grdma_pair* rx,

@@ -198,6 +198,17 @@ inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
   return hipSuccess;
 }
 inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
+// hipLaunchKernel by function pointer (the instrumented schedule of a streaming job): same convention as a graph
+// node -- EMU_GRAPH_NODE_ARGS parameter slots of 8 bytes, a kernel with fewer ignores the rest
+inline hipError_t hipLaunchKernel(const void* func, dim3 grid, dim3 block, void** args, size_t, hipStream_t) {
+  std::lock_guard<std::recursive_mutex> lk(emu::launch_mutex());
+  typedef void (*fn_t)(uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t);
+  fn_t f = reinterpret_cast<fn_t>(const_cast<void*>(func));
+  uint64_t a[EMU_GRAPH_NODE_ARGS];
+  for (int i = 0; i < EMU_GRAPH_NODE_ARGS; i++) a[i] = *static_cast<uint64_t*>(args[i]);
+  emu::launch(grid, block, [=] { f(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]); });
+  return hipSuccess;
+}
 
 // A launch runs the whole grid under the emulator and returns when it is done.  One launch at a time: the
 // __shared__ objects of a kernel are statics.  The exception is a RESIDENT kernel (the latency engine k_engine,

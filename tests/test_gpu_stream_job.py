@@ -91,13 +91,16 @@ def _run_job(g, R, max_sge, slices, pipeline, flags=0, mode=None):
     # small ring the pipelined sender can also meet a round in which the credit of the
     # round before has not landed yet and nothing fits: leave room for those.
     job.set_rounds(2 * rounds + 4 if pipeline else rounds + 2)
-    for _ in range(PASSES - 1):
-        r = job.run(gs.RUN_GRAPH)
+    for i in range(PASSES - 1):
+        r = job.run(mode if (mode is not None and i == PASSES - 2) else gs.RUN_GRAPH)
         assert r.done and r.bytes_delivered == N and r.bytes_sent == N
+    last = r
     ds = job.delivered_slices(0)
     mem = dst.read(dst_cap)
     got = [mem[o:o + n] for o, n in ds]
-    out = {"slices": got, "rounds": rounds, "ring": rx.ring_mem(), "tx": tx.state(), "rx": rx.state()}
+    out = {"slices": got, "rounds": rounds, "ring": rx.ring_mem(), "tx": tx.state(), "rx": rx.state(),
+           "launches": [int(x) for x in last.launches_class], "ms": [float(x) for x in last.ms_class],
+           "rounds_set": 2 * rounds + 4 if pipeline else rounds + 2}
     job.close()
     tx.close()
     rx.close()
@@ -196,3 +199,36 @@ def test_steady_state_drains_through_the_fast_planner_match_the_oracle(gpu, case
         took, [a - b for a, b in zip(after[1:6], before[1:6])])
     # every Send of the three passes is priced from the index of the slice buffer (either wire, no empty slice)
     assert after[6] - before[6] >= PASSES * exp_rounds and after[7] == before[7], (after[6:], before[6:])
+
+
+@pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
+@pytest.mark.parametrize("case", FAST_CASES[:2], ids=["r16m_sge255", "r32m_sge511"])
+def test_the_instrumented_schedule_is_the_graphs_chain(gpu, case, flags):
+    """GRDMA_RUN_INSTRUMENTED_SCHEDULE (bench.py's roofline of the fused scatter + gather launch): the launches of
+    the paired schedule one by one with events between them -- the same slices, ring and state as the oracle's
+    rounds, one planner pair per round, one fused launch per round but the last."""
+    from grpc_rdma_amd import stream as gs
+    R, max_sge, n_msgs, msg_len = case
+    slices = _framed_slices(n_msgs, msg_len, seed=R % 89)
+    exp, exp_rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, slices)
+    got = _run_job(gpu, R, max_sge, slices, pipeline=True, flags=flags, mode=gs.RUN_INSTRUMENTED_SCHEDULE)
+    assert got["slices"] == exp
+    assert got["ring"] == ring == bytes(R)
+    for k in ("remote_tail", "remote_head", "partial_write"):
+        assert got["tx"][k] == st0[k], k
+    for k in ("head", "moving_head", "remain", "internal_read_size"):
+        assert got["rx"][k] == st1[k], k
+    n = got["rounds_set"]
+    la = dict(zip(gs.CLASS_NAMES, got["launches"]))
+    assert la["plan_pair"] == n and la["scatter_gather"] == n - 1 and la["rx_apply"] == 1, la
+    assert la["tx_plan"] == 1 and la["gather"] == 1 and la["wire"] == (0 if flags & 2 else n), la
+    assert la["rx_plan"] == 0
+    assert all(m >= 0 for m in got["ms"])
+
+
+def test_the_instrumented_schedule_refuses_a_job_on_another_schedule(gpu):
+    from grpc_rdma_amd import stream as gs
+    R, max_sge, n_msgs, msg_len = FAST_CASES[0]
+    slices = _framed_slices(n_msgs, msg_len, seed=3)
+    with pytest.raises(Exception, match="paired schedule"):
+        _run_job(gpu, R, max_sge, slices, pipeline=False, mode=gs.RUN_INSTRUMENTED_SCHEDULE)
