@@ -96,6 +96,7 @@ SIGNATURES = {
     "grdma_device_free": (None, [C.c_void_p]),
     "grdma_host_alloc_pinned": (C.c_void_p, [u64]),
     "grdma_host_pin_to_device_node": (C.c_int, []),
+    "grdma_host_pin_thread_to_core": (C.c_int, [C.c_int]),
     "grdma_endpoint_write_queue": (C.c_int, [C.c_void_p, C.c_void_p, u64]),
     "grdma_endpoint_write_adopt": (C.c_int, [C.c_void_p]),
     "grdma_endpoint_write_queue_stats": (C.c_int, [C.c_void_p, C.POINTER(u64)]),

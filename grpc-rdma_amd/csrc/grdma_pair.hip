@@ -6,6 +6,7 @@
 // Reference counterparts: src/core/lib/ibverbs/pair.{h,cc} (PairPollable),
 // src/core/lib/iomgr/rdma_bp_posix.cc (endpoint read/write loops).
 #include <hip/hip_runtime.h>
+#include <dirent.h>
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -2342,7 +2343,68 @@ int grdma_host_pin_to_device_node(void) {
   }
   fclose(f);
   if (n == 0 || sched_setaffinity(0, sizeof(set), &set) != 0) return -1;
+  // sched_setaffinity(0) moves the CALLING thread (threads it creates later inherit).  The threads that exist already
+  // -- the HIP runtime starts its signal / completion threads with the first HIP call, i.e. a few lines above -- stay
+  // where they were started, and a completion thread on the other socket is what a slow run of the vtable leg looked
+  // like (one in four or five): move every thread of the process.
+  if (DIR* d = opendir("/proc/self/task")) {
+    while (struct dirent* e = readdir(d)) {
+      const long tid = strtol(e->d_name, nullptr, 10);
+      if (tid > 0) sched_setaffinity((pid_t)tid, sizeof(set), &set);  // (a thread that has just exited: ignored)
+    }
+    closedir(d);
+  }
   return node;
+}
+// The calling thread alone onto the k-th PHYSICAL core of the device's NUMA node (a CPU that is the first of its
+// thread_siblings_list; k counts from the END of the node's list, away from where the kernel places new tasks first):
+// two busy-polling threads of one process -- the writer and the reader of a streaming endpoint pair -- otherwise share
+// a core's two hardware threads every few runs, and each then copies at ~0.7 of its speed.  Returns the CPU or -1.
+int grdma_host_pin_thread_to_core(int k) {
+  int dev = 0;
+  char bus[64] = {0};
+  if (k < 0 || hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, sizeof(bus), dev) != hipSuccess) return -1;
+  for (char* c = bus; *c; c++) *c = (char)tolower(*c);
+  char path[256];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  if (node < 0) return -1;
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  f = fopen(path, "r");
+  if (!f) return -1;
+  std::vector<int> cores;
+  int a = 0, b = 0;
+  while (fscanf(f, "%d", &a) == 1) {
+    b = a;
+    int ch = fgetc(f);
+    if (ch == '-') {
+      if (fscanf(f, "%d", &b) != 1) break;
+      ch = fgetc(f);
+    }
+    for (int c = a; c <= b && c < CPU_SETSIZE; c++) {
+      char sp[128];
+      snprintf(sp, sizeof(sp), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+      int first = c;
+      if (FILE* g = fopen(sp, "r")) {
+        if (fscanf(g, "%d", &first) != 1) first = c;
+        fclose(g);
+      }
+      if (first == c) cores.push_back(c);
+    }
+    if (ch != ',') break;
+  }
+  fclose(f);
+  if ((size_t)k >= cores.size()) return -1;
+  const int cpu = cores[cores.size() - 1 - (size_t)k];
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  CPU_SET(cpu, &set);
+  if (sched_setaffinity(0, sizeof(set), &set) != 0) return -1;
+  return cpu;
 }
 void* grdma_host_alloc_pinned(uint64_t bytes) {
   if (require_ctx()) return nullptr;

@@ -641,10 +641,14 @@ int64_t grdma_stats_time_print(char* buf, uint64_t cap);
 /* ---- device helpers for callers that keep payloads in HBM ---------------------- */
 void* grdma_device_alloc(uint64_t bytes);
 void grdma_device_free(void* p);
-/* Binds the calling thread (and the threads it starts) to the CPUs of the NUMA node the device hangs on, the way
- * `numactl --cpunodebind` would: pinned buffers allocated afterwards and the polling threads sit next to the device's
- * PCIe root.  Returns the node, or -1 when it is unknown (nothing changed then). */
+/* Binds every thread of the process (and the threads started later) to the CPUs of the NUMA node the device hangs on,
+ * the way `numactl --cpunodebind` would: pinned buffers allocated afterwards and the polling threads sit next to the
+ * device's PCIe root.  Returns the node, or -1 when it is unknown (nothing changed then). */
 int grdma_host_pin_to_device_node(void);
+/* Binds the CALLING thread alone to the k-th physical core of that node, counted from the end of the node's CPU list
+ * (`taskset -c`): busy-polling threads of one process then never share a core's two hardware threads.  Returns the CPU,
+ * or -1 (nothing changed). */
+int grdma_host_pin_thread_to_core(int k);
 void* grdma_host_alloc_pinned(uint64_t bytes);
 void grdma_host_free_pinned(void* p);
 int grdma_copy_to_device(void* dst, const void* src, uint64_t n);

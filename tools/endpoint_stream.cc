@@ -15,6 +15,7 @@
 // env:   GRPC_RDMA_RING_BUFFER_SIZE_KB, GRPC_RDMA_MAX_SGE ... as the reference reads them
 #include <emmintrin.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -180,12 +181,32 @@ int main(int argc, char** argv) {
         CHECK(std::chrono::steady_clock::now() - tl < std::chrono::seconds(100) && "endpoint made no progress");
     }
   };
-  const auto t0 = std::chrono::steady_clock::now();
+  // Writer and reader each on a physical core of their own, both under ONE L3 (neighbouring cores of the device's node;
+  // `taskset -c` per thread): measured on the 2 x 64-core box of the GPU pool, 26 runs of 26 at 14.5-15.3 GiB/s this way,
+  // against 15.4-15.6 in two runs of three and 11.5 in the third when the two threads float over the node, and the slow
+  // mode again (4 of 16) with the threads pinned to cores of different L3s -- the two threads share the library's state
+  // lines and locks.  GRDMA_PIN_CORES="w,r" = indices into the node's physical cores, counted from the end of its list;
+  // "none" lets the threads float.
+  int core_w = 1, core_r = 0;
+  if (const char* e = getenv("GRDMA_PIN_CORES")) {
+    if (sscanf(e, "%d,%d", &core_w, &core_r) != 2) core_w = core_r = -1;
+  }
+  const bool pin_cores = numa_node >= 0 && core_w >= 0 && core_r >= 0;
+  std::atomic<int> reader_ready{0};
+  std::atomic<bool> go{false};
+  auto t0 = std::chrono::steady_clock::now();
   if (threads >= 2) {
+    if (pin_cores) grdma_host_pin_thread_to_core(core_w);
     std::thread reader([&] {
+      if (pin_cores) grdma_host_pin_thread_to_core(core_r);
+      reader_ready.store(1, std::memory_order_release);  // (the sysfs walk of the pin stays outside the timed region)
+      while (!go.load(std::memory_order_acquire)) {}
       do_read(&st, GRPC_ERROR_NONE);
       loop(st.rx, nullptr, &st.read_done, nullptr);
     });
+    while (!reader_ready.load(std::memory_order_acquire)) {}
+    t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
     do_write(&st, GRPC_ERROR_NONE);
     // (a write completes when its bytes sit in the endpoint's send buffer: like a gRPC poller, this thread keeps
     // polling the sending endpoint until the stream has arrived, not just until the last write callback)
@@ -203,7 +224,8 @@ int main(int argc, char** argv) {
   grdma_endpoint_write_queue_stats(grdma_endpoint_pair(st.tx), wq);
   printf("{\"msgs\": %zu, \"payload\": %zu, \"slices_per_write\": %zu, \"endpoint_bytes\": %zu, \"seconds\": %.6f, "
          "\"GiBps\": %.4f, \"checked\": %s, \"latency_mode\": %s, \"threads\": %d, \"ring_kib\": %s, \"max_sge\": %s, "
-         "\"wire\": \"%s\", \"register_min\": %s, \"writes_queued\": [%llu, %llu, %llu], \"numa_pinned\": %s}\n",
+         "\"wire\": \"%s\", \"register_min\": %s, \"writes_queued\": [%llu, %llu, %llu], \"numa_pinned\": %s, "
+         "\"thread_cores\": [%d, %d]}\n",
          st.msgs_target, payload, st.frames.size(), st.bytes_target, sec,
          (double)(payload * st.msgs_target) / sec / (double)(1ull << 30), st.check ? "true" : "false",
          latency ? "true" : "false", threads >= 2 ? 2 : 1,
@@ -212,7 +234,7 @@ int main(int argc, char** argv) {
          getenv("GRPC_RDMA_HIP_WIRE") ? getenv("GRPC_RDMA_HIP_WIRE") : "direct",
          getenv("GRPC_RDMA_HIP_REGISTER_MIN") ? getenv("GRPC_RDMA_HIP_REGISTER_MIN") : "0",
          (unsigned long long)wq[0], (unsigned long long)wq[1], (unsigned long long)wq[2],
-         numa_node >= 0 ? "true" : "false");
+         numa_node >= 0 ? "true" : "false", pin_cores && threads >= 2 ? core_w : -1, pin_cores && threads >= 2 ? core_r : -1);
   if (latency) grdma_engine_stop();
   grpc_endpoint_shutdown(st.tx, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
   grpc_endpoint_shutdown(st.rx, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
