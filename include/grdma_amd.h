@@ -553,11 +553,14 @@ uint64_t grdma_h2_last_boundary_steps(void);
  * then device-clock ticks: waiting for staged windows, in bulk steps, in boundary steps, in the
  * byte-wise path, total}. */
 void grdma_h2_last_deframe_stats(uint64_t out[8]);
+/* The deframer over chunks (lists of >= 2048 slices, unless GRDMA_H2_NO_CHUNKS): out = {calls planned over chunks,
+ * calls whose chunks verified and were merged}; the difference went through the sequential deframer. */
+int grdma_h2_parser_chunk_stats(grdma_h2_parser* p, uint64_t out[2]);
+/* profiling aid: device-clock phase stamps of the last chunked call, 8 words per chunk + 8 of the merge */
+int grdma_h2_parser_chunk_dbg(grdma_h2_parser* p, uint64_t* out, uint64_t cap_words);
 /* grpc_chttp2_perform_read (parsing.cc:56-253) + grpc_deframe_unprocessed_incoming_frames
  * (frame_data.cc:92-276) over n delivered slices {offset, length} of d_arena.
  * Returns the number of events; *h2_error = connection error, if any. */
-int grdma_h2_parser_chunk_stats(grdma_h2_parser* p, uint64_t out[2]);
-int grdma_h2_parser_chunk_dbg(grdma_h2_parser* p, uint64_t* out, uint64_t cap_words);  /* profiling aid: phase stamps of the last chunked call */  /* calls planned / merged by the chunked deframer */
 int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_read_slice* slices,
                          uint64_t n, grdma_h2_event* events_out, uint64_t cap, int* h2_error);
 
