@@ -429,9 +429,12 @@ int grdma_stream_job_launch_streams(grdma_stream_job* j);
 int grdma_stream_job_sync(grdma_stream_job* j);
 int grdma_stream_job_slices(grdma_stream_job* j, grdma_read_slice* out, uint64_t cap);
 int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds);
-/* on != 0: run the rounds as a software pipeline (the send plan and gather of round t+1
- * and the scatter of round t overlap the wire and ring walk of neighbouring rounds, as
- * two hosts do over a NIC).  Same bytes delivered; affects GRDMA_RUN_GRAPH and _EAGER. */
+/* on != 0: neighbouring rounds share launches, the way two hosts and a NIC work on different rounds at once: the
+ * drain plan of round t with the send plan of round t + 1 (k_plan_pair_job), the scatter of round t with the
+ * gather of round t + 1 (k_rx_apply_gather), the wire in between -- three launches per round, two with a direct
+ * wire.  A drain walks exactly up to the tail its own Send reported; the sender may see a
+ * credit one round later than in the sequential schedule.  Same bytes delivered; affects GRDMA_RUN_GRAPH, _EAGER
+ * and _INSTRUMENTED_SCHEDULE. */
 int grdma_stream_job_set_pipeline(grdma_stream_job* j, int on);
 /* Sends per round (default 1).  burst > 1: a sender that runs ahead of its reader -- `burst`
  * rdma_flush steps back to back (rdma_bp_posix.cc:470-557, retried on every writable edge), each a
@@ -450,8 +453,8 @@ int grdma_pair_debug_hist(grdma_pair* p, uint32_t* hist_out /* 1024 entries */, 
                           uint32_t* period);
 int grdma_engine_debug(uint64_t out[5]);
 uint64_t grdma_express_drains(void);  /* drains served by the single-wave express path so far */
-int grdma_tx_fast_sends(uint64_t out[2]);  /* Sends of streaming jobs planned by k_tx_fast [0], left to the general planner [1] (csrc/grdma_tx_fast.hip) */
-int grdma_rx_fast_drains(uint64_t out[6]);  /* drains of streaming jobs taken by k_rx_fast [0], declined by reason [1..5] (csrc/grdma_rx_fast.hip) */
+int grdma_tx_fast_sends(uint64_t out[2]);  /* Sends of streaming jobs planned by k_tx_fast [0], left to the general planner [1] (csrc/grdma_tx_fast.h) */
+int grdma_rx_fast_drains(uint64_t out[6]);  /* drains of streaming jobs taken by k_rx_fast [0], declined by reason [1..5] (csrc/grdma_rx_fast.h) */
 int grdma_tx_small_ticks(uint64_t out[8]);  /* profiling aid: phase ticks of the latency engine's small Sends */
 /* Scalar ring arithmetic of the host layer (ring_buffer.h:101-143), exported so that the
  * CPU tests can pin it against the oracle without a device. */
