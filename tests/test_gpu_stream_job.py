@@ -7,7 +7,11 @@ Both schedules are covered: the sequential one (five kernels per round in stream
 and the pipelined one (neighbouring rounds overlap on side streams).  With rounds of
 at most ring/6 the pipelined schedule must reproduce the sequential slices exactly;
 with a small ring the credit may arrive a round later, the records may be cut at
-other places, and the delivered BYTE STREAM is what has to match.
+other places, and the delivered BYTE STREAM is what has to match -- for the stream-ordered
+pipeline, whose credit visibility depends on timing.  The PAIRED graph (the default schedule,
+what bench.py times) is a chain: its credit lag is exactly one round, the oracle can be driven
+the same way, and the last test of this file asserts bit-exact slices, ring and state at
+credit-limited rings too.
 """
 import random
 
@@ -232,3 +236,118 @@ def test_the_instrumented_schedule_refuses_a_job_on_another_schedule(gpu):
     slices = _framed_slices(n_msgs, msg_len, seed=3)
     with pytest.raises(Exception, match="paired schedule"):
         _run_job(gpu, R, max_sge, slices, pipeline=False, mode=gs.RUN_INSTRUMENTED_SCHEDULE)
+
+
+# ---- the paired schedule at a CREDIT-LIMITED ring: exact parity with the oracle, the credit one round late --------
+# The graph of a paired job is a chain: [P0] G0 W0 [X0 + P1] [A0 + G1] W1 [X1 + P2] ...  The credit of drain t is posted
+# by the last workgroup of its scatter (A_t), and the send plan of round k runs in the launch in front of A_{k-1}: Send k
+# sees the credits of the drains <= k - 2 of its pass (and everything of earlier passes).  That is deterministic, so the
+# oracle can be driven the same way -- the sender's view of the reader's head (status_recv.remote_head) held back by one
+# round -- and the job must then produce the oracle's records, slices, ring image and state EXACTLY, also where every
+# Send is cut by the credit.
+def _advance(slices, idx, byte, sent):
+    left = sent
+    while left > 0:  # the rdma_flush cursor, rdma_bp_posix.cc:480-493
+        room = len(slices[idx]) - byte
+        if left >= room:
+            left -= room
+            idx += 1
+            byte = 0
+        else:
+            byte += left
+            left = 0
+    return idx, byte
+
+
+def _oracle_sequential_then_paired(R, max_sge, slices, paired_rounds):
+    o = pyorc.OracleLink(R, max_sge)
+
+    def drain(out):
+        n = 0
+        while True:
+            s, _alloc = o.endpoint_read(1)
+            if not s:
+                return n
+            out.append(s)
+            n += 1
+
+    # pass 1: the sequential rounds (every Send sees every credit)
+    idx, byte, rounds = 0, 0, 0
+    first = []
+    while idx < len(slices):
+        idx, byte = _advance(slices, idx, byte, o.send(0, slices[idx:], byte))
+        rounds += 1
+        drain(first)
+        assert rounds < 100000
+    # pass 2: the paired chain
+    sender = o.p[0]
+    latest = sender.status_recv.remote_head  # what the reader has reported so far
+    views = []                               # views[t] = the report as it stands after drain t of this pass
+    start = latest
+    idx, byte = 0, 0
+    delivered = []
+    used = 0
+    for k in range(paired_rounds):
+        if idx >= len(slices):
+            break
+        lagged = start if k < 2 else views[k - 2]
+        sender.status_recv.remote_head = lagged
+        idx, byte = _advance(slices, idx, byte, o.send(0, slices[idx:], byte))
+        used = k + 1
+        drain(delivered)
+        if sender.status_recv.remote_head != lagged:  # this drain returned credit
+            latest = sender.status_recv.remote_head
+        views.append(latest)
+    assert idx == len(slices), "the rounds given to the paired pass do not carry the whole list"
+    sender.status_recv.remote_head = latest  # (what the sender sees once the pass is over)
+    st = (o.state(0), o.state(1))
+    ring = o.ring_mem(1)
+    o.close()
+    return first, rounds, delivered, used, st, ring
+
+
+@pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
+@pytest.mark.parametrize("case", [CASES[0], (1 << 18, 30, 120, 9000), (1 << 20, 64, 12, 200000)],
+                         ids=["r4m_1mib", "r256k_sge30_9k", "r1m_sge64_200k"])
+def test_paired_schedule_at_a_credit_limited_ring_equals_the_oracle_with_the_credit_one_round_late(gpu, case, flags):
+    from grpc_rdma_amd import stream as gs
+    R, max_sge, n_msgs, msg_len = case
+    slices = _framed_slices(n_msgs, msg_len, seed=R % 83)
+    g = gpu
+    rng = random.Random(5)
+    bufs = [g.DeviceBuffer(data=s, offset=rng.randrange(16)) for s in slices]
+    tx, rx = g.Pair(R, max_sge, flags), g.Pair(R, max_sge, flags)
+    g.connect_pairs(tx, rx)
+    N = sum(len(s) for s in slices)
+    dst_cap = N + 32 * (2 * len(slices) + 64) + 4096
+    dst = g.DeviceBuffer(nbytes=dst_cap)
+    sge = [(b.ptr, len(s)) for b, s in zip(bufs, slices)]
+    job = gs.MultiStreamJob([(tx, rx, sge, dst.ptr, dst_cap, 2 * len(slices) + 64)], 4096)
+    job.set_pipeline(False)
+    r = job.run(gs.RUN_EAGER)            # pass 1: sequential rounds
+    assert r.done and r.bytes_delivered == N
+    rounds1 = int(max(r.tx_rounds, r.rx_rounds))
+    paired_rounds = 2 * rounds1 + 6      # (a Send that finds the credit of the round before not yet there sends less)
+    exp1, exp_rounds1, exp2, used, (st0, st1), ring = _oracle_sequential_then_paired(R, max_sge, slices, paired_rounds)
+    assert rounds1 == exp_rounds1
+    mem = dst.read(dst_cap)
+    assert [mem[o:o + n] for o, n in job.delivered_slices(0)] == exp1
+    job.set_pipeline(True)
+    job.set_rounds(paired_rounds)
+    r = job.run(gs.RUN_GRAPH)            # pass 2: the paired chain
+    assert r.done and r.bytes_delivered == N and r.bytes_sent == N
+    print("rounds: sequential %d, paired %d of %d" % (rounds1, used, paired_rounds))
+    assert used > rounds1, "this case was meant to be credit-limited in the paired pass"
+    mem = dst.read(dst_cap)
+    got = [mem[o:o + n] for o, n in job.delivered_slices(0)]
+    assert [len(x) for x in got] == [len(x) for x in exp2]
+    assert got == exp2
+    assert rx.ring_mem() == ring == bytes(R)
+    txs, rxs = tx.state(), rx.state()
+    for k in ("remote_tail", "remote_head", "partial_write"):
+        assert txs[k] == st0[k], k
+    for k in ("head", "moving_head", "remain", "internal_read_size"):
+        assert rxs[k] == st1[k], k
+    job.close()
+    tx.close()
+    rx.close()
