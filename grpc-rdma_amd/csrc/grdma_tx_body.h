@@ -670,62 +670,42 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
   const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap);
   const uint64_t TB = 1ull << ts;
 
-  // The ops of the burst do not depend on what the Sends do: lane j fetches the pointers of Send (base + j) -- one
-  // memory round trip for up to 64 Sends instead of one per Send in front of every pricing step -- and the loop takes
-  // them from that lane.
-  grdma_plan* my_plan = nullptr;
-  grdma_plan* my_wplan = nullptr;
-  grdma_tx_result* my_res = nullptr;
-  uint8_t* my_stalt = nullptr;
-  uint64_t* my_tail_out = nullptr;
-  auto fetch_ops = [&](uint32_t base) {
-    const uint32_t q = base + (uint32_t)lane;
-    if (q < burst) {
-      const grdma_tx_op* o = ops + (size_t)q * stride;
-      my_plan = o->plan;
-      my_wplan = o->wire_plan;
-      my_res = o->result;
-      my_stalt = o->staging_alt;
-      my_tail_out = o->tail_out;
-    }
-  };
-  // what a Send that accepts nothing leaves behind: empty plans, nothing sent, state untouched
-  // (partial_write was set by the Send that came up empty, pair.cc:709)
-  auto write_dry = [&](grdma_plan* plan, grdma_plan* wplan, grdma_tx_result* r, uint64_t* tail_out, uint32_t partial_now,
-                       uint64_t tail_now, uint64_t idx_now, uint64_t bidx_now) {
-    plan->nsegs = 0;
-    plan->ntiles = 0;
-    plan->tile_bytes = (uint32_t)TB;
-    plan->tile_prefix[0] = 0;
-    plan->bytes = 0;
-    if (wplan != nullptr) {
-      wplan->nsegs = 0;
-      wplan->ntiles = 0;
-      wplan->tile_bytes = (uint32_t)TB;
-      wplan->tile_prefix[0] = 0;
-      wplan->bytes = 0;
-    }
-    r->wr_count = 0;
-    r->wr_off[0] = r->wr_off[1] = r->wr_len[0] = r->wr_len[1] = 0;
-    r->sent = 0;
-    r->records = 0;
-    r->staged = 0;
-    r->partial = partial_now;
-    r->new_remote_tail = tail_now;
-    if (tail_out != nullptr) *tail_out = tail_now;
-    r->slice_idx = idx_now;
-    r->byte_idx = bidx_now;
-    r->done = idx_now >= nslices ? 1 : 0;
-  };
-
+  bool dry = false;  // a Send accepted nothing: nothing changes until the peer reads, the rest accept nothing either
   for (uint32_t k = 0; k < burst; k++) {
-    if ((k & 63u) == 0) fetch_ops(k);
-    const int kl = (int)(k & 63u);
-    grdma_plan* const plan = reinterpret_cast<grdma_plan*>(__shfl((uint64_t)my_plan, kl, 64));
-    grdma_plan* const op_wire_plan = reinterpret_cast<grdma_plan*>(__shfl((uint64_t)my_wplan, kl, 64));
-    grdma_tx_result* const op_result = reinterpret_cast<grdma_tx_result*>(__shfl((uint64_t)my_res, kl, 64));
-    uint8_t* const op_staging_alt = reinterpret_cast<uint8_t*>(__shfl((uint64_t)my_stalt, kl, 64));
-    uint64_t* const op_tail_out = reinterpret_cast<uint64_t*>(__shfl((uint64_t)my_tail_out, kl, 64));
+    const grdma_tx_op op = ops[(size_t)k * stride];
+    grdma_plan* const plan = op.plan;
+    if (dry) {
+      // the same outcome as pricing it: empty plans, nothing sent, state untouched
+      // (partial_write was set by the Send that came up empty, pair.cc:709)
+      if (lane == 0) {
+        plan->nsegs = 0;
+        plan->ntiles = 0;
+        plan->tile_bytes = (uint32_t)TB;
+        plan->tile_prefix[0] = 0;
+        plan->bytes = 0;
+        if (op.wire_plan != nullptr) {
+          op.wire_plan->nsegs = 0;
+          op.wire_plan->ntiles = 0;
+          op.wire_plan->tile_bytes = (uint32_t)TB;
+          op.wire_plan->tile_prefix[0] = 0;
+          op.wire_plan->bytes = 0;
+        }
+        grdma_tx_result* r = op.result;
+        r->wr_count = 0;
+        r->wr_off[0] = r->wr_off[1] = r->wr_len[0] = r->wr_len[1] = 0;
+        r->sent = 0;
+        r->records = 0;
+        r->staged = 0;
+        r->partial = partial;
+        r->new_remote_tail = tail;
+        if (op.tail_out != nullptr) *op.tail_out = tail;
+        r->slice_idx = idx;
+        r->byte_idx = bidx;
+        r->done = idx >= nslices ? 1 : 0;
+      }
+      last_records = 0;
+      continue;
+    }
     const uint64_t avail = nslices - idx;
     uint64_t m = avail < max_sge ? avail : max_sge;
     if (!connected) m = 0;
@@ -763,7 +743,7 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
     for (int d = 32; d >= 1; d >>= 1) sent += __shfl_xor(sent, d, 64);
 
     // segments (see the block-wide plan: tags ride on the segments, GRDMA_SEG_TAG_*)
-    uint8_t* const staging = op_staging_alt ? op_staging_alt : conn_staging;
+    uint8_t* const staging = op.staging_alt ? op.staging_alt : conn_staging;
     uint8_t* const dbase = direct ? peer_ring : staging;
     const bool mine = (uint64_t)lane < nrec_total;
     const uint64_t hdr_off = direct ? ((tail + st) & mask) : st;
@@ -809,7 +789,7 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
       plan->tag_mask = direct ? mask : ~0ull;
       // the <= 2 RDMA WRITEs of GetWriteRequests(sg_list), ring_buffer.cc:261-330
       const uint64_t seg1 = staged < cap - tail ? staged : cap - tail;
-      grdma_tx_result* r = op_result;
+      grdma_tx_result* r = op.result;
       r->wr_count = 0;
       r->wr_off[0] = r->wr_off[1] = r->wr_len[0] = r->wr_len[1] = 0;
       if (staged > 0) {
@@ -822,7 +802,7 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
           r->wr_count = 2;
         }
       }
-      grdma_plan* wp = op_wire_plan;
+      grdma_plan* wp = op.wire_plan;
       if (wp != nullptr) {
         uint32_t ns = 0, nt = 0;
         if (!direct && staged > 0) {
@@ -848,7 +828,7 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
       r->staged = staged;
       r->partial = npartial;
       r->new_remote_tail = new_tail;
-      if (op_tail_out != nullptr) *op_tail_out = new_tail;
+      if (op.tail_out != nullptr) *op.tail_out = new_tail;
       r->slice_idx = nidx;
       r->byte_idx = nbidx;
       r->done = nidx >= nslices ? 1 : 0;
@@ -862,21 +842,8 @@ __device__ __forceinline__ void tx_burst_wave(const grdma_tx_op* ops, uint32_t s
     total_written += sent;
     records += nrec_total;
     last_records = (uint32_t)nrec_total;
-    if (nrec_total) {
-      rounds++;
-      continue;
-    }
-    // This Send accepted nothing: nothing changes until the peer reads, so the Sends behind it accept nothing either.
-    // Their empty plans and results are written side by side, lane j the one of Send (base + j), and the burst ends.
-    if (k + 1 < burst) {
-      last_records = 0;
-      for (uint32_t base = k & ~63u; base < burst; base += 64) {
-        if (base != (k & ~63u)) fetch_ops(base);
-        const uint32_t q = base + (uint32_t)lane;
-        if (q > k && q < burst) write_dry(my_plan, my_wplan, my_res, my_tail_out, partial, tail, idx, bidx);
-      }
-    }
-    break;
+    if (nrec_total) rounds++;
+    else dry = true;
   }
   if (lane == 0) {
     c->remote_tail = tail;
