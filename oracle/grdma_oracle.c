@@ -2,7 +2,10 @@
  *
  * Plain-C restatement of the reference's CPU algorithms on the RDMA_BP/BPEV
  * endpoint hot path.  Parity is pinned against the reference-built
- * oracle/_ref/libref_ring.so and the golden vectors under tests/golden/.
+ * oracle/_ref/libref_ring.so (its ring_buffer.cc), against oracle/_ref/ref_pair_trace
+ * (its pair.cc -- PairPollable::Send / Recv / SendZerocopy and the credit rule --
+ * compiled unmodified over the software verbs of oracle/fakeverbs) and the golden
+ * vectors under tests/golden/ (tests/test_oracle_vs_ref.py, tests/test_golden_*.py).
  */
 #define _POSIX_C_SOURCE 200809L
 #include "grdma_oracle.h"

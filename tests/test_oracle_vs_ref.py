@@ -188,3 +188,182 @@ def test_zerocopy_rules():
         assert L.send_zerocopy(0, [("zc", 0, 10)]) == 0
         assert L.zerocopy_state(0)["tail"] == 10
         L.close()
+
+
+# ---- the oracle against the reference's pair.cc ITSELF -------------------------------------------------------------
+# oracle/_ref/ref_pair_trace = the reference's unmodified pair.cc + ring_buffer.cc + device.cc + memory_region.cc +
+# buffer.cc + address.cc + config.cc over the software verbs of oracle/fakeverbs (oracle/Makefile): two PairPollable
+# objects connected to each other replay an operation list.  The same list goes through the plain-C oracle; every
+# return value, the credit-dependent writable size after every step, partial_write_, the bytes received, and at the end
+# remote_tail_, internal_read_size_, the head the sender has been told and the whole ring image must be the same.
+def _pat(seed, i, n):
+    import numpy as np
+    j = np.arange(n, dtype=np.uint64)
+    return ((seed * 131 + i * 17 + j * 7 + (j >> 8)) & 0xFF).astype(np.uint8).tobytes()
+
+
+def _fnv(b):
+    import zlib
+    return zlib.crc32(b) & 0xFFFFFFFF
+
+
+def _random_ops(rng, ring, max_sge, n_ops):
+    ops = []
+    for _ in range(n_ops):
+        side = rng.randrange(2)
+        r = rng.random()
+        if r < 0.5:
+            n = rng.choice([1, 1, 2, 3, max_sge - 1, max_sge, max_sge + 3, rng.randrange(1, 2 * max_sge)])
+            kind = rng.random()
+            if kind < 0.3:      # frame-like: small header slices between payload slices
+                lens = [rng.choice([9, 5, 14, rng.randrange(1, 300)]) if k % 2 == 0 else rng.randrange(1, ring // 6)
+                        for k in range(n)]
+            elif kind < 0.6:    # bulk
+                lens = [rng.randrange(1, ring // 3) for _ in range(n)]
+            else:
+                lens = [rng.randrange(1, 2000) for _ in range(n)]
+            byte_idx = rng.randrange(lens[0]) if rng.random() < 0.3 else 0
+            ops.append(("S", side, byte_idx, rng.randrange(1 << 16), lens))
+        else:
+            cap = rng.choice([1, 7, 255, 256, 257, 4096, rng.randrange(1, ring), 2 * ring])
+            ops.append(("R", side, cap))
+    # drain both sides completely at the end (the ring image then shows what the reader zeroed)
+    for side in (0, 1):
+        for _ in range(8):
+            ops.append(("R", side, 2 * ring))
+    return ops
+
+
+def _run_ref_pair_trace(ops, ring_kb, max_sge):
+    import os
+    import subprocess
+    text = []
+    for op in ops:
+        if op[0] == "S":
+            _, side, byte_idx, seed, lens = op
+            text.append("S %d %d %d %d %s" % (side, byte_idx, seed, len(lens), " ".join(map(str, lens))))
+        else:
+            text.append("R %d %d" % (op[1], op[2]))
+    text.append("Q")
+    env = dict(os.environ, GRPC_RDMA_RING_BUFFER_SIZE_KB=str(ring_kb), FAKEVERBS_MAX_SGE=str(max_sge))
+    p = subprocess.run([pyorc.REF_PAIR_TRACE], input="\n".join(text) + "\n", capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert p.returncode == 0, p.stderr[-400:]
+    return [ln.split() for ln in p.stdout.strip().splitlines()]
+
+
+@pytest.mark.parametrize("ring_kb,max_sge", [(64, 30), (256, 30), (64, 4), (1024, 64), (4096, 30)])
+@pytest.mark.parametrize("seed", range(10))
+def test_oracle_equals_the_reference_pairpollable_itself(seed, ring_kb, max_sge):
+    import os
+    if not os.path.exists(pyorc.REF_PAIR_TRACE):
+        pytest.skip("oracle/_ref/ref_pair_trace not built (no reference tree here)")
+    ring = ring_kb * 1024
+    rng = random.Random(1000 * seed + ring_kb + max_sge)
+    ops = _random_ops(rng, ring, max_sge, 160 if ring_kb <= 256 else 60)
+    ref = _run_ref_pair_trace(ops, ring_kb, max_sge)
+    o = pyorc.OracleLink(ring, max_sge)
+    try:
+        for k, (op, line) in enumerate(zip(ops, ref)):
+            if op[0] == "S":
+                _, side, byte_idx, sd, lens = op
+                sent = o.send(side, [_pat(sd, i, n) for i, n in enumerate(lens)], byte_idx)
+                got = ("S", sent, o.writable(side), int(o.p[side].partial_write))
+                want = ("S", int(line[1]), int(line[2]), int(line[3]))
+            else:
+                _, side, cap = op
+                b = o.recv(side, cap)
+                got = ("R", len(b), _fnv(b), o.readable(side), int(o.has_message(side)), o.writable(1 - side))
+                want = ("R", int(line[1]), int(line[2]), int(line[3]), int(line[4]), int(line[5]))
+            assert got == want, "op %d %r: oracle %r, pair.cc %r" % (k, op[:3], got, want)
+        q = ref[len(ops):]
+        assert len(q) == 2
+        for side in (0, 1):
+            st = o.state(side)
+            want = [int(x) for x in q[side][2:]]
+            got = [st["remote_tail"], st["internal_read_size"], st["remote_head"], st["moving_head"], _fnv(o.ring_mem(side))]
+            assert got == want, "side %d {remote_tail, internal_read_size, remote_head, get_head() = moving_head_, ring image}: %r vs %r" % (
+                side, got, want)
+    finally:
+        o.close()
+
+
+@pytest.mark.parametrize("ring_kb,max_sge", [(64, 30), (64, 5), (256, 8), (1024, 30)])
+@pytest.mark.parametrize("seed", range(10))
+def test_oracle_zerocopy_equals_the_reference_pairpollable_itself(seed, ring_kb, max_sge):
+    """PairPollable::AllocateSendBuffer / SendZerocopy of the reference's own pair.cc (pair.cc:305-323, 793-941; its
+    zero-copy buffer is as large as the ring: config.cc reads the ring-size variable for it) against the oracle:
+    allocator answers, accepted bytes, writable size, partial_write_, the buffer tail after every Send, received bytes,
+    final state and ring image.  Plain Sends and Recvs interleave."""
+    import os
+    if not os.path.exists(pyorc.REF_PAIR_TRACE):
+        pytest.skip("oracle/_ref/ref_pair_trace not built (no reference tree here)")
+    ring = ring_kb * 1024
+    Z = ring
+    rng = random.Random(7000 + 100 * seed + ring_kb + max_sge)
+    o = pyorc.OracleLink(ring, max_sge)
+    o.enable_zerocopy(0, Z)
+    o.enable_zerocopy(1, Z)
+    text, checks = [], []  # the op list for the reference; what the oracle said, in the same order
+    try:
+        for _ in range(120):
+            side = rng.randrange(2)
+            r = rng.random()
+            if r < 0.45:
+                sl, spec = [], []
+                sd = rng.randrange(1 << 16)
+                for i in range(rng.randint(1, 6)):
+                    n = rng.choice([1, 9, 100, 255, 256, 257, 4000, ring // 7, ring // 3])
+                    if rng.random() < 0.55:
+                        off = o.allocate_send_buffer(side, n)
+                        text.append("A %d %d" % (side, n))
+                        checks.append(("A", -1 if off is None else off))
+                        if off is None:
+                            if rng.random() < 0.5:   # any range of the buffer counts as "inside" for SendZerocopy
+                                off = rng.randrange(0, Z - n + 1)
+                            else:
+                                sl.append(_pat(sd, i, n))
+                                spec.append("%d -1" % n)
+                                continue
+                        wseed = rng.randrange(1 << 16)
+                        o.zerocopy_write(side, off, _pat(wseed, 0, n))
+                        text.append("W %d %d %d %d" % (side, off, wseed, n))
+                        sl.append(("zc", off, n))
+                        spec.append("%d %d" % (n, off))
+                    else:
+                        sl.append(_pat(sd, i, n))
+                        spec.append("%d -1" % n)
+                first = sl[0][2] if isinstance(sl[0], tuple) else len(sl[0])
+                bi = rng.randrange(first) if rng.random() < 0.3 else 0
+                sent = o.send_zerocopy(side, sl, bi)
+                text.append("Z %d %d %d %d %s" % (side, bi, sd, len(sl), " ".join(spec)))
+                checks.append(("Z", sent, o.writable(side), int(o.p[side].partial_write), o.zerocopy_state(side)["tail"]))
+            elif r < 0.6:
+                sd = rng.randrange(1 << 16)
+                lens = [rng.choice([5, 9, 300, 5000, ring // 5]) for _ in range(rng.randint(1, 4))]
+                sent = o.send(side, [_pat(sd, i, n) for i, n in enumerate(lens)], 0)
+                text.append("S %d 0 %d %d %s" % (side, sd, len(lens), " ".join(map(str, lens))))
+                checks.append(("S", sent, o.writable(side), int(o.p[side].partial_write)))
+            else:
+                cap = rng.choice([1, 8, 256, 4096, 2 * ring])
+                b = o.recv(side, cap)
+                text.append("R %d %d" % (side, cap))
+                checks.append(("R", len(b), _fnv(b), o.readable(side), int(o.has_message(side)), o.writable(1 - side)))
+        text.append("Q")
+        import subprocess
+        env = dict(os.environ, GRPC_RDMA_RING_BUFFER_SIZE_KB=str(ring_kb), FAKEVERBS_MAX_SGE=str(max_sge))
+        p = subprocess.run([pyorc.REF_PAIR_TRACE], input="\n".join(text) + "\n", capture_output=True, text=True,
+                           timeout=120, env=env)
+        assert p.returncode == 0, p.stderr[-400:]
+        lines = [ln.split() for ln in p.stdout.strip().splitlines()]
+        assert len(lines) == len(checks) + 2
+        for k, (want, line) in enumerate(zip(checks, lines)):
+            got = tuple([line[0]] + [int(x) for x in line[1:len(want)]])
+            assert got == want, "step %d: pair.cc %r, oracle %r" % (k, got, want)
+        for side in (0, 1):
+            st = o.state(side)
+            ref = [int(x) for x in lines[len(checks) + side][2:]]
+            mine = [st["remote_tail"], st["internal_read_size"], st["remote_head"], st["moving_head"], _fnv(o.ring_mem(side))]
+            assert mine == ref, "side %d: oracle %r, pair.cc %r" % (side, mine, ref)
+    finally:
+        o.close()
