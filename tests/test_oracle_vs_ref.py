@@ -367,3 +367,52 @@ def test_oracle_zerocopy_equals_the_reference_pairpollable_itself(seed, ring_kb,
             assert mine == ref, "side %d: oracle %r, pair.cc %r" % (side, mine, ref)
     finally:
         o.close()
+
+
+# ---- the oracle's DATA framing against the reference's grpc_chttp2_encode_data ITSELF -----------------------------------
+def _pat1(seed, n):
+    import numpy as np
+    j = np.arange(n, dtype=np.uint64)
+    return ((seed * 131 + j * 7 + (j >> 8)) & 0xFF).astype(np.uint8).tobytes()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_oracle_framing_equals_the_reference_encode_data_itself(seed):
+    """oracle/_ref/ref_h2_trace = the reference's unmodified frame_data.cc (grpc_chttp2_encode_data), slice.cc and
+    slice_buffer.cc (tiny_add, the inlined-slice merge rule of grpc_slice_buffer_add, the splits of
+    grpc_slice_buffer_move_first_no_ref) driven through the two call sites of chttp2_transport.cc:1502-1510 and
+    writing.cc:344-355.  Batches of messages queued on one outbuf -- empty, tiny, exactly a frame, many frames,
+    compressed flag, END_STREAM, several max_frame_size values -- must give the oracle's slice list (every length, in
+    order) and the oracle's bytes."""
+    import os
+    import subprocess
+    if not os.path.exists(pyorc.REF_H2_TRACE):
+        pytest.skip("oracle/_ref/ref_h2_trace not built (no reference tree here)")
+    rng = random.Random(4242 + seed)
+    text, want = [], []
+    for _ in range(25):
+        max_frame = rng.choice([16384, 16384, 16384, 32768, 20000, 1 << 20])
+        msgs, sids, flags = [], [], []
+        for _m in range(rng.randint(1, 6)):
+            n = rng.choice([0, 1, 7, 18, 19, 23, 100, max_frame - 5, max_frame - 4, max_frame, 3 * max_frame + 11,
+                            rng.randrange(0, 200000)])
+            sd = rng.randrange(1 << 16)
+            sid = 2 * rng.randrange(1, 1 << 20) + 1
+            compressed, end_stream = int(rng.random() < 0.2), int(rng.random() < 0.3)
+            msgs.append(_pat1(sd, n))
+            sids.append(sid)
+            flags.append(compressed | (end_stream << 1))
+            text.append("M %d %d %d %d %d %d" % (sid, compressed, end_stream, max_frame, n, sd))
+        text.append("F")
+        wire, lens = pyorc.h2_frame_batch(msgs, sids, flags, max_frame=max_frame)
+        want.append((len(lens), _fnv(wire), lens))
+    p = subprocess.run([pyorc.REF_H2_TRACE], input="\n".join(text) + "\n", capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-400:]
+    lines = [ln.split() for ln in p.stdout.strip().splitlines()]
+    assert len(lines) == len(want)
+    for k, (line, (n, crc, lens)) in enumerate(zip(lines, want)):
+        got_lens = [int(x) for x in line[5:]]
+        assert int(line[1]) == n and got_lens == lens, "batch %d: encode_data %r, oracle %r" % (k, got_lens, lens)
+        assert int(line[2]) == crc, "batch %d: the bytes differ" % k
+        # (grpc_transport_one_way_stats: 9 framing bytes per DATA frame, the rest is data)
+        assert int(line[3]) + int(line[4]) == sum(lens)
