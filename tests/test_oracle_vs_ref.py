@@ -416,3 +416,57 @@ def test_oracle_framing_equals_the_reference_encode_data_itself(seed):
         assert int(line[2]) == crc, "batch %d: the bytes differ" % k
         # (grpc_transport_one_way_stats: 9 framing bytes per DATA frame, the rest is data)
         assert int(line[3]) + int(line[4]) == sum(lens)
+
+
+# ---- the oracle's message deframer against the reference's grpc_deframe_unprocessed_incoming_frames ITSELF ----------
+@pytest.mark.parametrize("seed", range(40))
+def test_oracle_deframer_equals_the_reference_deframer_itself(seed):
+    """oracle/_ref/ref_h2_deframe_trace = the reference's unmodified frame_data.cc deframer (the FH_0 .. FH_4 / FRAME state
+    machine over a slice buffer) on its own slice layer.  A stream of framed gRPC messages -- empty, tiny, large,
+    compressed flag -- is cut into DATA frames and the wire into arbitrary chunks; the oracle's parser is fed the chunks,
+    the reference's deframer the payload pieces (what grpc_chttp2_data_parser_parse stores: the part of every chunk that
+    is DATA payload).  Message begin (flags, length), every payload piece handed on, message end: the same sequence."""
+    import os
+    import struct
+    import subprocess
+    if not os.path.exists(pyorc.REF_H2_DEFRAME_TRACE):
+        pytest.skip("oracle/_ref/ref_h2_deframe_trace not built (no reference tree here)")
+    rng = random.Random(9100 + seed)
+    msgs, flags = [], []
+    for _ in range(rng.randint(3, 30)):
+        n = rng.choice([0, 1, 4, 5, 6, 100, 1000, 16379, 16384, 40000, rng.randrange(0, 70000)])
+        msgs.append(_pat1(rng.randrange(1 << 16), n))
+        flags.append(int(rng.random() < 0.25))          # bit 0 = compressed; no END_STREAM: one stream carries them all
+    max_frame = rng.choice([16384, 16384, 1000, 70000])
+    wire, _lens = pyorc.h2_frame_batch(msgs, [1] * len(msgs), flags, max_frame=max_frame)
+    # arbitrary chunks: some tiny (a header byte at a time), some large
+    chunks, off = [], 0
+    while off < len(wire):
+        n = rng.choice([1, 1, 2, 3, 5, 9, 14, 100, 4096, 8192, 20000, rng.randrange(1, 50000)])
+        chunks.append(wire[off:off + n])
+        off += n
+    parser = pyorc.H2Parser(expect_client_prefix=False, max_frame_size=max_frame)
+    parser.open_stream(1)
+    want, pieces = [], []
+    for ch in chunks:
+        rc, evs = parser.feed(ch)
+        assert rc == 0
+        for kind, a, b, c, d in evs:
+            if kind == pyorc.EV_PAYLOAD:
+                pieces.append(ch[a:a + b])
+            elif kind == pyorc.EV_MSG_BEGIN:
+                want.append("B %d %d" % (0x80000000 if a else 0, b))   # GRPC_WRITE_INTERNAL_COMPRESS
+            elif kind == pyorc.EV_MSG_BYTES:
+                want.append("Y %d" % b)
+            elif kind == pyorc.EV_MSG_END:
+                want.append("E")
+    assert b"".join(pieces) == b"".join(bytes([f & 1]) + struct.pack(">I", len(m)) + m for m, f in zip(msgs, flags))
+    data = struct.pack("<I", len(pieces)) + b"".join(struct.pack("<I", len(p)) + p for p in pieces)
+    r = subprocess.run([pyorc.REF_H2_DEFRAME_TRACE], input=data, capture_output=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-300:]
+    got = r.stdout.decode().strip().splitlines()
+    assert got[-1].startswith("S ")
+    framing, data_bytes = [int(x) for x in got[-1].split()[1:]]
+    assert got[:-1] == want
+    assert framing == 5 * len(msgs) and data_bytes == sum(len(m) for m in msgs)
+    assert want.count("E") == len(msgs)
