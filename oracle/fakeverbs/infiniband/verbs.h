@@ -62,9 +62,14 @@ enum ibv_port_state { IBV_PORT_ACTIVE = 4 };
 struct ibv_port_attr {
   enum ibv_port_state state;
   uint16_t lid;
+  uint8_t link_layer;
+  int active_mtu;
 };
 
-enum ibv_access_flags { IBV_ACCESS_LOCAL_WRITE = 1, IBV_ACCESS_REMOTE_WRITE = 2 };
+enum ibv_access_flags { IBV_ACCESS_LOCAL_WRITE = 1, IBV_ACCESS_REMOTE_WRITE = 2, IBV_ACCESS_REMOTE_READ = 4 };
+/* (named by headers of the reference's other RDMA transport that rdma_bp_posix.cc includes; never used here) */
+struct ibv_comp_channel { int fd; };
+struct ibv_async_event { int event_type; };
 
 enum ibv_qp_type { IBV_QPT_RC = 2 };
 enum ibv_qp_state { IBV_QPS_RESET, IBV_QPS_INIT, IBV_QPS_RTR, IBV_QPS_RTS, IBV_QPS_SQD, IBV_QPS_SQE, IBV_QPS_ERR };

@@ -1,0 +1,243 @@
+// TEST INFRASTRUCTURE ONLY -- part of oracle/, never linked into the product.
+//
+// ref_endpoint_trace: the reference's OWN endpoint read path -- rdma_read / rdma_handle_read / rdma_continue_read /
+// rdma_do_read of src/core/lib/iomgr/rdma_bp_posix.cc (:180-376: the read sized max(256, readable), the slice kept
+// across a would-block, grpc_slice_buffer_trim_end into last_read_buffer and the swap on the next read) -- compiled
+// unmodified over the reference's own pair.cc / ring_buffer.cc (software verbs, oracle/fakeverbs) and its own slice
+// layer.  Two endpoints are created by grpc_rdma_bp_create itself, which exchanges the pair addresses over a socket
+// (here: the two ends of a socketpair, one thread per end, as two processes would).  What the file needs from iomgr is
+// stubbed below: an fd object that remembers the closure notify_on_read was given (the driver fires it: "the fd
+// became readable"), a slice allocator that allocates at once, errors as opaque handles.
+//
+//   ops:  S <side> <byte_idx> <seed> <n> <len_1> ... <len_n>    PairPollable::Send on the pair of endpoint <side>
+//         E <side>                                             one endpoint read on <side>: grpc_endpoint_read if none is
+//                                                              outstanding, then (if the endpoint asked for the readable
+//                                                              edge) the edge, once
+//   out:  S <sent>
+//         E <-1 | bytes delivered> <crc32> <slices> <readable after> <writable of the peer after>      (-1 = would block)
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sys/socket.h>
+#include <thread>
+#include <vector>
+
+#include <grpc/slice.h>
+#include <grpc/slice_buffer.h>
+#include <grpc/support/alloc.h>
+#include <grpc/support/log.h>
+
+#include "grpcpp/stats_time.h"
+#include "src/core/lib/address_utils/sockaddr_utils.h"
+#include "src/core/lib/channel/channel_args.h"
+#include "src/core/lib/debug/trace.h"
+#include "src/core/lib/gprpp/fork.h"
+#include "src/core/lib/ibverbs/pair.h"
+#include "src/core/lib/ibverbs/poller.h"
+#include "src/core/lib/iomgr/endpoint.h"
+#include "src/core/lib/iomgr/ev_posix.h"
+#include "src/core/lib/iomgr/exec_ctx.h"
+#include "src/core/lib/iomgr/rdma_bp_posix.h"
+#include "src/core/lib/iomgr/resource_quota.h"
+#include "src/core/lib/slice/slice_internal.h"
+
+// ---- gpr -----------------------------------------------------------------------------------------------------------
+extern "C" void gpr_log(const char*, int, gpr_log_severity, const char*, ...) {}
+extern "C" int gpr_should_log(gpr_log_severity) { return 0; }
+extern "C" void* gpr_malloc(size_t n) { return malloc(n ? n : 1); }
+extern "C" void* gpr_zalloc(size_t n) { return calloc(n ? n : 1, 1); }
+extern "C" void* gpr_realloc(void* p, size_t n) { return realloc(p, n ? n : 1); }
+extern "C" void gpr_free(void* p) { free(p); }
+char* gpr_getenv(const char* name) {
+  const char* v = getenv(name);
+  return v ? strdup(v) : nullptr;
+}
+// ---- errors: opaque handles ----------------------------------------------------------------------------------------
+static char g_error_object;
+grpc_error_handle grpc_error_create(const char*, int, const grpc_slice&, grpc_error_handle*, size_t) {
+  return reinterpret_cast<grpc_error_handle>(&g_error_object);
+}
+grpc_error_handle grpc_error_do_ref(grpc_error_handle e) { return e; }
+void grpc_error_do_unref(grpc_error_handle) {}
+grpc_error_handle grpc_error_set_int(grpc_error_handle e, grpc_error_ints, intptr_t) { return e; }
+grpc_error_handle grpc_error_set_str(grpc_error_handle e, grpc_error_strs, const grpc_slice&) { return e; }
+std::string grpc_error_std_string(grpc_error_handle) { return "error"; }
+// ---- the fd object of the event engine ----------------------------------------------------------------------------
+struct grpc_fd {
+  int fd;
+  void* arg;  // the PairPollable grpc_rdma_bp_create hands over (grpc_fd_set_arg)
+  grpc_closure* on_read;
+  grpc_closure* on_write;
+};
+int grpc_fd_wrapped_fd(grpc_fd* f) { return f->fd; }
+void grpc_fd_set_arg(grpc_fd* f, void* arg) { f->arg = arg; }
+void grpc_fd_notify_on_read(grpc_fd* f, grpc_closure* c) { f->on_read = c; }
+void grpc_fd_notify_on_write(grpc_fd* f, grpc_closure* c) { f->on_write = c; }
+void grpc_fd_shutdown(grpc_fd*, grpc_error_handle) {}
+void grpc_fd_orphan(grpc_fd*, grpc_closure*, int*, const char*) {}
+bool grpc_fd_is_shutdown(grpc_fd*) { return false; }
+void grpc_pollset_add_fd(grpc_pollset*, grpc_fd*) {}
+void grpc_pollset_set_add_fd(grpc_pollset_set*, grpc_fd*) {}
+void grpc_pollset_set_del_fd(grpc_pollset_set*, grpc_fd*) {}
+bool grpc_event_engine_can_track_errors() { return false; }
+std::string grpc_sockaddr_to_uri(const grpc_resolved_address*) { return ""; }
+char* grpc_channel_args_find_string(const grpc_channel_args*, const char*) { return nullptr; }
+// ---- resource quota: every allocation is granted at once ----------------------------------------------------------
+grpc_resource_quota* grpc_resource_quota_create(const char*) { return reinterpret_cast<grpc_resource_quota*>(uintptr_t{8}); }
+void grpc_resource_quota_unref_internal(grpc_resource_quota*) {}
+grpc_resource_user* grpc_resource_user_create(grpc_resource_quota*, const char*) {
+  return reinterpret_cast<grpc_resource_user*>(uintptr_t{8});
+}
+void grpc_resource_user_unref(grpc_resource_user*) {}
+void grpc_resource_user_shutdown(grpc_resource_user*) {}
+void grpc_resource_user_slice_allocator_init(grpc_resource_user_slice_allocator* a, grpc_resource_user* u, grpc_iomgr_cb_func,
+                                             void*) {
+  memset(a, 0, sizeof(*a));
+  a->resource_user = u;
+}
+bool grpc_resource_user_alloc_slices(grpc_resource_user_slice_allocator*, size_t length, size_t count,
+                                     grpc_slice_buffer* dest) {
+  for (size_t i = 0; i < count; i++) grpc_slice_buffer_add_indexed(dest, GRPC_SLICE_MALLOC(length));
+  return true;  // (resource_quota.cc:  true = the slices are there, the caller goes on)
+}
+// ---- the rest --------------------------------------------------------------------------------------------------------
+GRPCProfiler::GRPCProfiler(grpc_stats_time op) : op_(op) {}
+GRPCProfiler::~GRPCProfiler() {}
+grpc_error_handle grpc_wakeup_fd_init(grpc_wakeup_fd* fd) {
+  fd->read_fd = fd->write_fd = -1;
+  return GRPC_ERROR_NONE;
+}
+void grpc_wakeup_fd_destroy(grpc_wakeup_fd*) {}
+namespace grpc_core {
+TraceFlag::TraceFlag(bool, const char* name) : name_(name), value_(false) {}
+GPR_TLS_CLASS_DEF(ExecCtx::exec_ctx_);
+Atomic<bool> Fork::support_enabled_(false);
+void Fork::DoIncExecCtxCount() {}
+void Fork::DoDecExecCtxCount() {}
+bool ExecCtx::Flush() { return false; }
+namespace ibverbs {
+void Poller::AddPollable(PairPollable*) {}
+void Poller::RemovePollable(PairPollable*) {}
+void Poller::begin_polling(int) {}
+}  // namespace ibverbs
+}  // namespace grpc_core
+grpc_core::TraceFlag grpc_rdma_trace(false, "rdma");
+
+namespace {
+using grpc_core::ibverbs::PairPollable;
+uint32_t crc32_of(const uint8_t* p, uint64_t n, uint32_t c) {
+  static uint32_t table[256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t v = i;
+      for (int k = 0; k < 8; k++) v = (v & 1) ? 0xEDB88320u ^ (v >> 1) : v >> 1;
+      table[i] = v;
+    }
+    init = true;
+  }
+  for (uint64_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+  return c;
+}
+inline uint8_t pat(uint64_t seed, uint64_t i, uint64_t j) { return (uint8_t)(seed * 131 + i * 17 + j * 7 + (j >> 8)); }
+grpc_slice_refcount* const kFakeRefcount = reinterpret_cast<grpc_slice_refcount*>(uintptr_t{0x10});
+
+struct side_state {
+  grpc_fd fd;
+  grpc_endpoint* ep = nullptr;
+  grpc_slice_buffer incoming;
+  grpc_closure on_read_done;
+  bool outstanding = false, completed = false, failed = false;
+};
+side_state g_side[2];
+void read_done(void* arg, grpc_error_handle error) {
+  side_state* s = static_cast<side_state*>(arg);
+  s->completed = true;
+  s->failed = error != GRPC_ERROR_NONE;
+}
+}  // namespace
+
+int main() {
+  int sv[2];
+  if (socketpair(AF_UNIX, SOCK_STREAM, 0, sv) != 0) return 2;
+  for (int i = 0; i < 2; i++) {
+    memset(&g_side[i].fd, 0, sizeof(grpc_fd));
+    g_side[i].fd.fd = sv[i];
+    grpc_slice_buffer_init(&g_side[i].incoming);
+    GRPC_CLOSURE_INIT(&g_side[i].on_read_done, read_done, &g_side[i], grpc_schedule_on_exec_ctx);
+  }
+  {
+    std::thread t([&] { g_side[1].ep = grpc_rdma_bp_create(&g_side[1].fd, nullptr, "peer-of-1", false); });
+    g_side[0].ep = grpc_rdma_bp_create(&g_side[0].fd, nullptr, "peer-of-0", false);
+    t.join();
+  }
+  if (!g_side[0].ep || !g_side[1].ep) {
+    fprintf(stderr, "grpc_rdma_bp_create failed\n");
+    return 2;
+  }
+  PairPollable* pair[2] = {static_cast<PairPollable*>(g_side[0].fd.arg), static_cast<PairPollable*>(g_side[1].fd.arg)};
+  char op;
+  while (scanf(" %c", &op) == 1) {
+    if (op == 'S') {
+      int side;
+      unsigned long long byte_idx, seed, n;
+      if (scanf("%d %llu %llu %llu", &side, &byte_idx, &seed, &n) != 4) return 3;
+      std::vector<std::vector<uint8_t>> mem(n);
+      std::vector<grpc_slice> sl(n);
+      for (unsigned long long i = 0; i < n; i++) {
+        unsigned long long len;
+        if (scanf("%llu", &len) != 1) return 3;
+        mem[i].resize(len ? len : 1);
+        for (unsigned long long j = 0; j < len; j++) mem[i][j] = pat(seed, i, j);
+        memset(&sl[i], 0, sizeof(grpc_slice));
+        sl[i].refcount = kFakeRefcount;
+        sl[i].data.refcounted.length = len;
+        sl[i].data.refcounted.bytes = mem[i].data();
+      }
+      printf("S %llu\n", (unsigned long long)pair[side]->Send(sl.data(), n, byte_idx));
+    } else if (op == 'E') {
+      int side;
+      if (scanf("%d", &side) != 1) return 3;
+      side_state& s = g_side[side];
+      s.completed = false;
+      s.fd.on_read = nullptr;
+      if (!s.outstanding) {
+        s.outstanding = true;
+        s.ep->vtable->read(s.ep, &s.incoming, &s.on_read_done, /*urgent=*/false);
+      } else {
+        // a read is waiting for the readable edge: deliver it
+        grpc_closure* c = nullptr;
+        std::swap(c, s.fd.on_read);
+      }
+      if (!s.completed && s.fd.on_read == nullptr && s.outstanding) {
+        // (the read above was re-armed by an earlier would-block: its closure was consumed when it ran; ask again)
+      }
+      if (!s.completed) {
+        // the endpoint asked for the readable edge (first read, inq == 0, or a would-block): the fd is readable, once
+        static grpc_closure* pending[2] = {nullptr, nullptr};
+        if (s.fd.on_read != nullptr) pending[side] = s.fd.on_read;
+        grpc_closure* c = pending[side];
+        pending[side] = nullptr;
+        s.fd.on_read = nullptr;
+        if (c != nullptr) grpc_core::Closure::Run(DEBUG_LOCATION, c, GRPC_ERROR_NONE);
+        if (!s.completed && s.fd.on_read != nullptr) pending[side] = s.fd.on_read;  // would block: armed again
+      }
+      if (s.completed) {
+        s.outstanding = false;
+        uint32_t c = 0xFFFFFFFFu;
+        for (size_t i = 0; i < s.incoming.count; i++)
+          c = crc32_of(GRPC_SLICE_START_PTR(s.incoming.slices[i]), GRPC_SLICE_LENGTH(s.incoming.slices[i]), c);
+        printf("E %lld %u %zu %llu %llu\n", s.failed ? -2ll : (long long)s.incoming.length, c ^ 0xFFFFFFFFu, s.incoming.count,
+               (unsigned long long)pair[side]->GetReadableSize(), (unsigned long long)pair[1 - side]->GetWritableSize());
+      } else {
+        printf("E -1 0 0 %llu %llu\n", (unsigned long long)pair[side]->GetReadableSize(),
+               (unsigned long long)pair[1 - side]->GetWritableSize());
+      }
+    } else {
+      return 3;
+    }
+  }
+  fflush(stdout);
+  _exit(0);
+}

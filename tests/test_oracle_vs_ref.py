@@ -470,3 +470,55 @@ def test_oracle_deframer_equals_the_reference_deframer_itself(seed):
     assert got[:-1] == want
     assert framing == 5 * len(msgs) and data_bytes == sum(len(m) for m in msgs)
     assert want.count("E") == len(msgs)
+
+
+# ---- the oracle's endpoint-read loop against the reference's rdma_bp_posix.cc ITSELF -------------------------------------
+@pytest.mark.parametrize("ring_kb,max_sge", [(64, 30), (256, 30), (1024, 64), (64, 4)])
+@pytest.mark.parametrize("seed", range(8))
+def test_oracle_endpoint_read_equals_the_reference_endpoint_itself(seed, ring_kb, max_sge):
+    """oracle/_ref/ref_endpoint_trace = the reference's unmodified rdma_bp_posix.cc -- two endpoints made by
+    grpc_rdma_bp_create over a socketpair, reads through rdma_read / rdma_handle_read / rdma_continue_read / rdma_do_read --
+    on its own pair.cc and slice layer.  Sends of framed-looking and bulk slice lists, endpoint reads in between (also when
+    nothing has arrived: the read then keeps its 256-byte slice for the next edge).  Every read: would-block or the bytes
+    delivered, the readable size left, the peer's writable size (the credit the reads have returned)."""
+    import os
+    import subprocess
+    if not os.path.exists(pyorc.REF_ENDPOINT_TRACE):
+        pytest.skip("oracle/_ref/ref_endpoint_trace not built (no reference tree here)")
+    ring = ring_kb * 1024
+    rng = random.Random(31000 + 100 * seed + ring_kb + max_sge)
+    o = pyorc.OracleLink(ring, max_sge)
+    text, want = [], []
+    try:
+        for _ in range(150):
+            side = rng.randrange(2)
+            if rng.random() < 0.4:
+                n = rng.choice([1, 2, 3, max_sge, max_sge + 2, rng.randrange(1, 2 * max_sge)])
+                if rng.random() < 0.5:
+                    lens = [rng.choice([9, 5, 14, 100, 255, 256, 257]) if k % 2 == 0 else rng.randrange(1, ring // 5)
+                            for k in range(n)]
+                else:
+                    lens = [rng.choice([1, 9, 200, 256, 300, 511, 512, 5000]) for _ in range(n)]
+                sd = rng.randrange(1 << 16)
+                bi = rng.randrange(lens[0]) if rng.random() < 0.25 else 0
+                sent = o.send(side, [_pat(sd, i, m) for i, m in enumerate(lens)], bi)
+                text.append("S %d %d %d %d %s" % (side, bi, sd, len(lens), " ".join(map(str, lens))))
+                want.append(("S", sent))
+            else:
+                b, _alloc = o.endpoint_read(side)
+                text.append("E %d" % side)
+                want.append(("E", len(b) if b else -1, _fnv(b) if b else 0, o.readable(side), o.writable(1 - side)))
+        env = dict(os.environ, GRPC_RDMA_RING_BUFFER_SIZE_KB=str(ring_kb), FAKEVERBS_MAX_SGE=str(max_sge))
+        p = subprocess.run([pyorc.REF_ENDPOINT_TRACE], input="\n".join(text) + "\n", capture_output=True, text=True,
+                           timeout=120, env=env)
+        assert p.returncode == 0, p.stderr[-400:]
+        lines = [ln.split() for ln in p.stdout.strip().splitlines()]
+        assert len(lines) == len(want)
+        for k, (line, w) in enumerate(zip(lines, want)):
+            if w[0] == "S":
+                got = ("S", int(line[1]))
+            else:
+                got = ("E", int(line[1]), int(line[2]), int(line[4]), int(line[5]))
+            assert got == w, "step %d (%s): rdma_bp_posix.cc %r, oracle %r" % (k, text[k][:40], got, w)
+    finally:
+        o.close()
