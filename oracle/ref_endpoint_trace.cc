@@ -1,7 +1,9 @@
 // TEST INFRASTRUCTURE ONLY -- part of oracle/, never linked into the product.
 //
-// ref_endpoint_trace: the reference's OWN endpoint read path -- rdma_read / rdma_handle_read / rdma_continue_read /
-// rdma_do_read of src/core/lib/iomgr/rdma_bp_posix.cc (:180-376: the read sized max(256, readable), the slice kept
+// ref_endpoint_trace: the reference's OWN endpoint -- the write path rdma_write / rdma_flush / rdma_handle_write
+// (src/core/lib/iomgr/rdma_bp_posix.cc:470-586: one Send from the cursor per flush, the slices that went out whole dropped,
+// the rest waits for the writable edge) and the read path rdma_read / rdma_handle_read / rdma_continue_read /
+// rdma_do_read (:180-376: the read sized max(256, readable), the slice kept
 // across a would-block, grpc_slice_buffer_trim_end into last_read_buffer and the swap on the next read) -- compiled
 // unmodified over the reference's own pair.cc / ring_buffer.cc (software verbs, oracle/fakeverbs) and its own slice
 // layer.  Two endpoints are created by grpc_rdma_bp_create itself, which exchanges the pair addresses over a socket
@@ -13,7 +15,11 @@
 //         E <side>                                             one endpoint read on <side>: grpc_endpoint_read if none is
 //                                                              outstanding, then (if the endpoint asked for the readable
 //                                                              edge) the edge, once
+//         W <side> <seed> <n> <len_1> ... <len_n>               grpc_endpoint_write of a fresh slice buffer on <side>
+//         F <side>                                             the writable edge for the write of <side> that waits
 //   out:  S <sent>
+//         W | F <1 = the write completed, 0 = it waits for the writable edge> <readable size of the peer> <writable size>
+//               <HasPendingWrites>            ("F -" = nothing was waiting)
 //         E <-1 | bytes delivered> <crc32> <slices> <readable after> <writable of the peer after>      (-1 = would block)
 #include <cstdint>
 #include <cstdio>
@@ -149,12 +155,21 @@ struct side_state {
   grpc_slice_buffer incoming;
   grpc_closure on_read_done;
   bool outstanding = false, completed = false, failed = false;
+  // write side
+  grpc_slice_buffer outgoing;
+  grpc_closure on_write_done;
+  bool write_outstanding = false, write_completed = false, write_failed = false;
 };
 side_state g_side[2];
 void read_done(void* arg, grpc_error_handle error) {
   side_state* s = static_cast<side_state*>(arg);
   s->completed = true;
   s->failed = error != GRPC_ERROR_NONE;
+}
+void write_done(void* arg, grpc_error_handle error) {
+  side_state* s = static_cast<side_state*>(arg);
+  s->write_completed = true;
+  s->write_failed = error != GRPC_ERROR_NONE;
 }
 }  // namespace
 
@@ -166,6 +181,8 @@ int main() {
     g_side[i].fd.fd = sv[i];
     grpc_slice_buffer_init(&g_side[i].incoming);
     GRPC_CLOSURE_INIT(&g_side[i].on_read_done, read_done, &g_side[i], grpc_schedule_on_exec_ctx);
+    grpc_slice_buffer_init(&g_side[i].outgoing);
+    GRPC_CLOSURE_INIT(&g_side[i].on_write_done, write_done, &g_side[i], grpc_schedule_on_exec_ctx);
   }
   {
     std::thread t([&] { g_side[1].ep = grpc_rdma_bp_create(&g_side[1].fd, nullptr, "peer-of-1", false); });
@@ -196,6 +213,43 @@ int main() {
         sl[i].data.refcounted.bytes = mem[i].data();
       }
       printf("S %llu\n", (unsigned long long)pair[side]->Send(sl.data(), n, byte_idx));
+    } else if (op == 'W' || op == 'F') {
+      // W: grpc_endpoint_write of a fresh slice buffer (rdma_write -> rdma_flush: ONE Send from the cursor; what is left
+      //    waits for the writable edge).  F: the writable edge for a write that waits (rdma_handle_write -> rdma_flush).
+      int side;
+      if (scanf("%d", &side) != 1) return 3;
+      side_state& s = g_side[side];
+      if (op == 'W') {
+        unsigned long long seed, n;
+        if (scanf("%llu %llu", &seed, &n) != 2) return 3;
+        if (s.write_outstanding) return 4;  // (one write at a time: GPR_ASSERT(rdma->write_cb == nullptr))
+        grpc_slice_buffer_reset_and_unref(&s.outgoing);
+        for (unsigned long long i = 0; i < n; i++) {
+          unsigned long long len;
+          if (scanf("%llu", &len) != 1) return 3;
+          grpc_slice m = grpc_slice_malloc_large(len ? len : 1);
+          uint8_t* q = GRPC_SLICE_START_PTR(m);
+          for (unsigned long long j = 0; j < len; j++) q[j] = pat(seed, i, j);
+          if (len == 0) { grpc_slice_unref(m); m = grpc_empty_slice(); }
+          grpc_slice_buffer_add_indexed(&s.outgoing, m);
+        }
+        s.write_completed = false;
+        s.write_outstanding = true;
+        s.fd.on_write = nullptr;
+        s.ep->vtable->write(s.ep, &s.outgoing, &s.on_write_done, nullptr);
+      } else {
+        if (!s.write_outstanding || s.fd.on_write == nullptr) {
+          printf("F -\n");
+          continue;
+        }
+        grpc_closure* c = s.fd.on_write;
+        s.fd.on_write = nullptr;
+        grpc_core::Closure::Run(DEBUG_LOCATION, c, GRPC_ERROR_NONE);
+      }
+      if (s.write_completed) s.write_outstanding = false;
+      printf("%c %d %llu %llu %d\n", op, s.write_completed ? (s.write_failed ? -2 : 1) : 0,
+             (unsigned long long)pair[1 - side]->GetReadableSize(), (unsigned long long)pair[side]->GetWritableSize(),
+             pair[side]->HasPendingWrites() ? 1 : 0);
     } else if (op == 'E') {
       int side;
       if (scanf("%d", &side) != 1) return 3;

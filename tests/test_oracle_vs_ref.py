@@ -522,3 +522,71 @@ def test_oracle_endpoint_read_equals_the_reference_endpoint_itself(seed, ring_kb
             assert got == w, "step %d (%s): rdma_bp_posix.cc %r, oracle %r" % (k, text[k][:40], got, w)
     finally:
         o.close()
+
+
+@pytest.mark.parametrize("ring_kb,max_sge", [(64, 30), (256, 30), (64, 4), (1024, 64)])
+@pytest.mark.parametrize("seed", range(8))
+def test_oracle_write_loop_equals_the_reference_endpoint_itself(seed, ring_kb, max_sge):
+    """The reference's own write path -- rdma_write / rdma_flush / rdma_handle_write (rdma_bp_posix.cc:470-586) on its own
+    pair.cc: one Send from the cursor per flush, the slices that went out whole dropped from the buffer, the rest waits for
+    the writable edge -- against the oracle's Send driven by the same cursor walk.  Writes larger than the ring, writes
+    cut by max_sge, edges that find no credit, reads in between that return it: after every write / edge, whether the write
+    completed, what the peer can read, what the sender may still write, HasPendingWrites; every read as in the test above."""
+    import os
+    import subprocess
+    if not os.path.exists(pyorc.REF_ENDPOINT_TRACE):
+        pytest.skip("oracle/_ref/ref_endpoint_trace not built (no reference tree here)")
+    ring = ring_kb * 1024
+    rng = random.Random(52000 + 100 * seed + ring_kb + max_sge)
+    o = pyorc.OracleLink(ring, max_sge)
+    pending = [None, None]   # per side: [slices, idx, byte] of the write that waits
+    text, want = [], []
+
+    def flush(side):  # rdma_flush, rdma_bp_posix.cc:470-524
+        sl, idx, byte = pending[side]
+        left = o.send(side, sl[idx:], byte)
+        while left > 0:
+            room = len(sl[idx]) - byte
+            if left >= room:
+                left -= room
+                idx += 1
+                byte = 0
+            else:
+                byte += left
+                break
+        done = idx == len(sl) and byte == 0
+        pending[side] = None if done else [sl, idx, byte]
+        return ("w", 1 if done else 0, o.readable(1 - side), o.writable(side), int(o.p[side].partial_write))
+
+    try:
+        for _ in range(160):
+            side = rng.randrange(2)
+            r = rng.random()
+            if r < 0.3 and pending[side] is None:
+                n = rng.choice([1, 2, 5, max_sge, max_sge + 3, 3 * max_sge])
+                lens = [rng.choice([9, 14, 100, 256, 257, 4000, ring // 6, ring // 2, ring]) for _ in range(n)]
+                sd = rng.randrange(1 << 16)
+                pending[side] = [[_pat(sd, i, m) for i, m in enumerate(lens)], 0, 0]
+                text.append("W %d %d %d %s" % (side, sd, len(lens), " ".join(map(str, lens))))
+                want.append(flush(side))
+            elif r < 0.5:
+                text.append("F %d" % side)
+                want.append(flush(side) if pending[side] is not None else ("w", None))
+            else:
+                b, _alloc = o.endpoint_read(side)
+                text.append("E %d" % side)
+                want.append(("E", len(b) if b else -1, _fnv(b) if b else 0, o.readable(side), o.writable(1 - side)))
+        env = dict(os.environ, GRPC_RDMA_RING_BUFFER_SIZE_KB=str(ring_kb), FAKEVERBS_MAX_SGE=str(max_sge))
+        p = subprocess.run([pyorc.REF_ENDPOINT_TRACE], input="\n".join(text) + "\n", capture_output=True, text=True,
+                           timeout=120, env=env)
+        assert p.returncode == 0, p.stderr[-400:]
+        lines = [ln.split() for ln in p.stdout.strip().splitlines()]
+        assert len(lines) == len(want)
+        for k, (line, w) in enumerate(zip(lines, want)):
+            if w[0] == "w":
+                got = ("w", None) if line[1] == "-" else ("w", int(line[1]), int(line[2]), int(line[3]), int(line[4]))
+            else:
+                got = ("E", int(line[1]), int(line[2]), int(line[4]), int(line[5]))
+            assert got == w, "step %d (%s): rdma_bp_posix.cc %r, oracle %r" % (k, text[k][:40], got, w)
+    finally:
+        o.close()
