@@ -1,7 +1,15 @@
-"""CPU: the C restatement (oracle/grdma_oracle.c) against the REFERENCE's own ring
-codec (oracle/_ref/libref_ring.so, built from /root/reference/src/core/lib/ibverbs/
-ring_buffer.cc).  This is what pins the oracle; the reference tree itself ships no
-ring/pair unit tests (test/core/ibverbs/ is absent)."""
+"""CPU: the C restatement (oracle/grdma_oracle.c) against REFERENCE CODE built here from /root/reference, unmodified
+(oracle/Makefile).  This is what pins the oracle; the reference tree itself ships no ring / pair unit tests
+(test/core/ibverbs/ is absent).  Five builds, in the order of the tests below:
+  * oracle/_ref/libref_ring.so          ring_buffer.cc (+ a driver that transcribes pair.cc's call order around it)
+  * oracle/_ref/ref_pair_trace          pair.cc itself -- PairPollable::Send / Recv / credit / SendZerocopy -- with
+                                        ring_buffer.cc, device.cc, memory_region.cc, buffer.cc, address.cc, config.cc over
+                                        the software verbs of oracle/fakeverbs
+  * oracle/_ref/ref_h2_trace            frame_data.cc's grpc_chttp2_encode_data over slice.cc / slice_buffer.cc
+  * oracle/_ref/ref_h2_deframe_trace    frame_data.cc's grpc_deframe_unprocessed_incoming_frames over the same slice layer
+  * oracle/_ref/ref_endpoint_trace      rdma_bp_posix.cc itself -- grpc_rdma_bp_create, the endpoint's read and write
+                                        paths -- over pair.cc and the slice layer
+Every test feeds the same seeded operations to the oracle and to the reference build and compares step by step."""
 import random
 
 import pytest
