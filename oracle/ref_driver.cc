@@ -11,9 +11,11 @@
 //  * ref_pair_*  : a loop-back "pair" that drives those members in the order
 //                  PairPollable does (src/core/lib/ibverbs/pair.cc:645-734 Send,
 //                  :264-286 Recv, :294-301 GetWritableSize, :624-641
-//                  updateStatus).  pair.cc itself cannot be compiled here (needs
-//                  libibverbs, abseil, HdrHistogram), so ibv_post_send(RDMA_WRITE)
-//                  is replaced by executing the work requests that the
+//                  updateStatus).  This library was written when pair.cc itself
+//                  had not been built here yet (it needs libibverbs; since the end
+//                  of round 3 oracle/ref_pair_trace.cc builds it over the software
+//                  verbs of oracle/fakeverbs and the oracle is pinned to that too):
+//                  ibv_post_send(RDMA_WRITE) is replaced by executing the work requests that the
 //                  reference's GetWriteRequests() built: memcpy of every SGE to
 //                  remote_addr, in order -- the RC in-order placement contract.
 //
