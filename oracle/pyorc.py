@@ -17,6 +17,7 @@ REF_SO = os.path.join(HERE, "_ref", "libref_ring.so")
 REF_PAIR_TRACE = os.path.join(HERE, "_ref", "ref_pair_trace")
 REF_H2_TRACE = os.path.join(HERE, "_ref", "ref_h2_trace")
 REF_H2_DEFRAME_TRACE = os.path.join(HERE, "_ref", "ref_h2_deframe_trace")
+REF_H2_PERFORM_READ_TRACE = os.path.join(HERE, "_ref", "ref_h2_perform_read_trace")
 REF_ENDPOINT_TRACE = os.path.join(HERE, "_ref", "ref_endpoint_trace")
 
 u8p = C.POINTER(C.c_uint8)
@@ -34,6 +35,8 @@ def build(force=False):
             or os.path.getmtime(REF_H2_TRACE) < os.path.getmtime(os.path.join(HERE, "ref_h2_trace.cc"))
             or not os.path.exists(REF_ENDPOINT_TRACE)
             or os.path.getmtime(REF_ENDPOINT_TRACE) < os.path.getmtime(os.path.join(HERE, "ref_endpoint_trace.cc"))
+            or not os.path.exists(REF_H2_PERFORM_READ_TRACE)
+            or os.path.getmtime(REF_H2_PERFORM_READ_TRACE) < os.path.getmtime(os.path.join(HERE, "ref_h2_perform_read_trace.cc"))
             or not os.path.exists(REF_H2_DEFRAME_TRACE)
             or os.path.getmtime(REF_H2_DEFRAME_TRACE) < os.path.getmtime(os.path.join(HERE, "ref_h2_deframe_trace.cc"))
             or os.path.getmtime(REF_SO) < os.path.getmtime(os.path.join(HERE, "ref_driver.cc"))

@@ -7,6 +7,8 @@
                                         the software verbs of oracle/fakeverbs
   * oracle/_ref/ref_h2_trace            frame_data.cc's grpc_chttp2_encode_data over slice.cc / slice_buffer.cc
   * oracle/_ref/ref_h2_deframe_trace    frame_data.cc's grpc_deframe_unprocessed_incoming_frames over the same slice layer
+  * oracle/_ref/ref_h2_perform_read_trace  parsing.cc's grpc_chttp2_perform_read (frame headers, init_frame_parser, the stream-map
+                                        rules) over stream_map.cc, frame_data.cc, frame_rst_stream.cc and the slice layer
   * oracle/_ref/ref_endpoint_trace      rdma_bp_posix.cc itself -- grpc_rdma_bp_create, the endpoint's read and write
                                         paths -- over pair.cc and the slice layer
 Every test feeds the same seeded operations to the oracle and to the reference build and compares step by step."""
@@ -598,3 +600,205 @@ def test_oracle_write_loop_equals_the_reference_endpoint_itself(seed, ring_kb, m
             assert got == w, "step %d (%s): rdma_bp_posix.cc %r, oracle %r" % (k, text[k][:40], got, w)
     finally:
         o.close()
+
+
+# ---- the oracle's frame parser + stream map (K8) against the reference's grpc_chttp2_perform_read ITSELF ---------------
+_H2_ERRORS = [("Connect string mismatch", 1), ("Frame size", 2), ("Expected CONTINUATION frame, got", 5),
+              ("Expected CONTINUATION frame for", 6), ("Unexpected CONTINUATION", 7),
+              ("Expected SETTINGS frame as the first frame", 8), ("Max stream count exceeded", 9),
+              ("invalid rst_stream", 10)]
+_PREFACE = b"PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n"
+
+
+def _h2f(ftype, flags, sid, payload=b""):
+    import struct
+    return struct.pack(">I", len(payload))[1:] + bytes([ftype, flags]) + struct.pack(">I", sid) + payload
+
+
+def _perform_read_case(seed):
+    """A seeded connection: (is_server, first_frame, max_streams, ops) with ops = ('o', id) | ('w', id) | ('f', bytes)."""
+    import struct
+    rng = random.Random(52000 + seed)
+    server = rng.random() < 0.6
+    max_streams = rng.choice([0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 3, 6])
+    wire = bytearray()
+    pre_ops = []
+    if server:
+        wire += _PREFACE
+        if rng.random() < 0.92:
+            wire += _h2f(4, 0, 0, bytes(6 * rng.randint(0, 3)))     # SETTINGS first
+    known, hdr_blocks, pending, next_new = [], {}, {}, 1
+    if not server:
+        for _ in range(rng.randint(1, 6)):
+            pre_ops.append(("o", next_new))
+            known.append(next_new)
+            next_new += 2
+
+    def some_stream():
+        r = rng.random()
+        if known and r < 0.8:
+            return rng.choice(known)
+        if r < 0.9:
+            return rng.choice([2, 4, 1000001, next_new + 40])    # even / far away / unknown
+        return 0
+
+    def header_block(sid, allow_bad):
+        nonlocal wire
+        n_cont = rng.choice([0, 0, 0, 1, 2])
+        flags = (1 if rng.random() < 0.2 else 0) | (0x20 if rng.random() < 0.15 else 0)
+        if hdr_blocks.get(sid, 0) >= 2:
+            n_cont = 0       # (a third block without END_HEADERS on one stream: a documented corner, see the docstring)
+        hdr_blocks[sid] = hdr_blocks.get(sid, 0) + 1
+        wire += _h2f(1, flags | (4 if n_cont == 0 else 0), sid, bytes(rng.randrange(256) for _ in range(rng.randint(0, 30))))
+        for i in range(n_cont):
+            if allow_bad and rng.random() < 0.04:
+                wire += _h2f(rng.choice([0, 1, 6]), 0, sid, b"12345678")       # not a CONTINUATION
+                return
+            csid = sid if not (allow_bad and rng.random() < 0.04) else sid + 2
+            wire += _h2f(9, 4 if i == n_cont - 1 else 0, csid, bytes(rng.randint(0, 12)))
+
+    for _ in range(rng.randint(20, 120)):
+        r = rng.random()
+        if r < 0.18:                                            # HEADERS: a new stream, or one more block on a known one
+            if server and rng.random() < 0.6:
+                sid = next_new if rng.random() < 0.9 else max(1, next_new - 4)
+                if sid == next_new:
+                    next_new += rng.choice([2, 2, 4])
+                    known.append(sid)
+            else:
+                sid = some_stream() or 1
+            header_block(sid, True)
+        elif r < 0.68:                                          # DATA: the next bytes of that stream's message queue
+            sid = some_stream() or 3
+            q = pending.setdefault(sid, bytearray())
+            while len(q) < 3000:
+                n = rng.choice([0, 1, 5, 40, 700, 2500])
+                q += bytes([rng.randrange(2)]) + struct.pack(">I", n) + bytes((j * 7 + sid) & 255 for j in range(n))
+            k = rng.choice([0, 1, 2, 5, 9, 64, 1000, 2900])
+            flags = 1 if rng.random() < 0.08 else (8 if rng.random() < 0.03 else 0)
+            wire += _h2f(0, flags, sid, bytes(q[:k]))
+            del q[:k]
+        elif r < 0.74:
+            wire += _h2f(3, 0, some_stream() or 5, struct.pack(">I", rng.choice([0, 8, 2])) if rng.random() < 0.96 else b"123")
+        elif r < 0.80:
+            wire += _h2f(8, 0, rng.choice([0, some_stream()]), struct.pack(">I", 1000))     # WINDOW_UPDATE
+        elif r < 0.85:
+            wire += _h2f(6, rng.choice([0, 1]), 0, b"pingpong")
+        elif r < 0.89:
+            wire += _h2f(4, 1, 0, b"") if rng.random() < 0.5 else _h2f(4, 0, 0, bytes(6))
+        elif r < 0.92:
+            wire += _h2f(7, 0, 0, bytes(8) + b"bye")
+        elif r < 0.97:
+            wire += _h2f(rng.choice([0x0a, 0x0b, 0x42]), rng.randrange(256), some_stream(), bytes(rng.randint(0, 20)))
+        elif r < 0.985:
+            wire += _h2f(9, 4, some_stream() or 1, b"")          # CONTINUATION out of the blue
+        else:
+            wire += _h2f(0, 0, some_stream() or 1, b"")
+    ops, off = list(pre_ops), 0
+    while off < len(wire):
+        n = rng.choice([1, 1, 2, 3, 5, 9, 14, 33, 100, 400, 4096, rng.randrange(1, 3000)])
+        ops.append(("f", bytes(wire[off:off + n])))
+        off += n
+        if known and rng.random() < 0.05:
+            ops.append(("w", rng.choice(known)))
+    return server, max_streams, ops
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_oracle_frame_parser_equals_the_reference_perform_read_itself(seed):
+    """oracle/_ref/ref_h2_perform_read_trace = the reference's unmodified parsing.cc (grpc_chttp2_perform_read, init_frame_parser,
+    init_{data,header,rst_stream,settings,window_update,ping,goaway,skip}_frame_parser, parse_frame_slice) over its own
+    stream_map.cc, frame_data.cc, frame_rst_stream.cc and slice layer; the rest of the transport is stand-ins that keep what
+    the parser's control flow depends on (oracle/ref_h2_perform_read_trace.cc says which).  A seeded connection -- preface
+    and SETTINGS on a server, HEADERS / CONTINUATION blocks that open, continue and end streams, DATA carrying gRPC messages
+    on known, unknown, closed streams, with END_STREAM and with bad flags, RST_STREAM (also of a bad length), PING, SETTINGS,
+    WINDOW_UPDATE, GOAWAY, unknown types, stray CONTINUATIONs, a small MAX_CONCURRENT_STREAMS, the write side closing in
+    between -- is cut at arbitrary points; the same sequence of accepted streams, closed streams (and whether they left
+    the map), message begin / bytes / end per stream, the parser state behind every slice, the connection error and the
+    number of live streams at the end.
+
+    Left out of the generator, because oracle and kernel do not model them (malformed peers; control-plane errors): a
+    SETTINGS frame on a stream, wrong lengths of PING / WINDOW_UPDATE / GOAWAY / SETTINGS, a third header block on one
+    stream that lacks END_HEADERS (the reference answers each with a connection error), and frames larger than MAX_FRAME_SIZE (the check needs the reference's flow control)."""
+    import os
+    import struct
+    import subprocess
+    if not os.path.exists(pyorc.REF_H2_PERFORM_READ_TRACE):
+        pytest.skip("oracle/_ref/ref_h2_perform_read_trace not built (no reference tree here)")
+    server, max_streams, ops = _perform_read_case(seed)
+    parser = pyorc.H2Parser(flags=(pyorc.H2_SERVER | pyorc.H2_FIRST_FRAME) if server else 0, max_frame_size=1 << 24,
+                            max_concurrent_streams=max_streams)
+    data = struct.pack("<IIII", 0 if server else 1, 1 if server else 0, max_streams, 1001)
+    want, dead, rst = [], False, 0
+    for op in ops:
+        if op[0] == "f":
+            data += b"f" + struct.pack("<I", len(op[1])) + op[1]
+        else:
+            data += op[0].encode() + struct.pack("<I", op[1])
+        if dead:
+            continue
+        if op[0] == "o":
+            assert parser.open_stream(op[1]) == 0
+        elif op[0] == "w":
+            before = parser.live_streams()
+            if parser.close_writes(op[1]) == 0:
+                want.append("C %d %d" % (op[1], before - parser.live_streams()))
+        else:
+            rc, evs = parser.feed(op[1])
+            for kind, a, b, c, d in evs:
+                if kind == pyorc.EV_STREAM_OPEN:
+                    want.append("O %d" % c)
+                elif kind == pyorc.EV_STREAM_CLOSED:
+                    want.append("C %d %d" % (c, a))
+                elif kind == pyorc.EV_MSG_BEGIN:
+                    want.append("B %d %d %d" % (c, 0x80000000 if a else 0, b))
+                elif kind == pyorc.EV_MSG_BYTES:
+                    want.append("Y %d %d" % (c, b))
+                elif kind == pyorc.EV_MSG_END:
+                    want.append("E %d" % c)
+                elif kind == pyorc.EV_FRAME and a == 0xff:
+                    want.append("G %d" % c)     # a gRPC message flag byte > 1 (bytes of a skipped DATA frame are missing)
+                elif kind == pyorc.EV_FRAME and a == 0 and (b >> 8):
+                    rst += 1            # DATA with bad flags: RST_STREAM queued (parsing.cc:388-394)
+            if rc != 0:
+                want.append("X %d" % rc)
+                dead = True
+            else:
+                st = parser.p.state
+                want.append("P %d %d" % (st, parser.p.incoming_frame_size if st == 33 else 0))
+    want.append("S %d %d" % (rst, parser.live_streams()))
+    r = subprocess.run([pyorc.REF_H2_PERFORM_READ_TRACE], input=data, capture_output=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-300:]
+    got = []
+    for line in r.stdout.decode().strip().splitlines():
+        if line.startswith("X "):
+            codes = [c for pre, c in _H2_ERRORS if line[2:].startswith(pre)]
+            assert codes, line
+            line = "X %d" % codes[0]
+        got.append(line)
+
+
+    def split(lines):
+        """-> (stream / connection events in order, {stream: its B / Y / E sequence with adjacent payload pieces summed}):
+        when the surface pulls message bytes is not the parser's business (the driver pulls behind every slice)."""
+        control, per_stream = [], {}
+        for ln in lines:
+            f = ln.split()
+            if f[0] in "BYEG":
+                seq = per_stream.setdefault(int(f[1]), [])
+                if f[0] == "Y" and seq and seq[-1][0] == "Y":
+                    seq[-1] = ("Y", seq[-1][1] + int(f[2]))
+                elif f[0] == "Y":
+                    if int(f[2]):
+                        seq.append(("Y", int(f[2])))
+                else:
+                    seq.append(tuple(f[:1] + [int(x) for x in f[2:]]))
+            else:
+                control.append(ln)
+        return control, per_stream
+
+    got_c, got_m = split(got)
+    want_c, want_m = split(want)
+    assert got_c == want_c, next((i, g, w) for i, (g, w) in enumerate(zip(got_c + ["-"], want_c + ["-"])) if g != w)
+    assert got_m == want_m
+    assert any(got_m.values()) or any(ln[0] in "OCX" for ln in got_c)
