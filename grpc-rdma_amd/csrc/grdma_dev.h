@@ -237,7 +237,10 @@ struct grdma_plan {
   // that line made the early finishers' atomics fight the late starters' loads (2.4x the kernel time).
   uint32_t pad_line0[31];
   uint32_t blocks_done;
-  uint32_t pad_line1[31];
+  // arrival word of the multi-workgroup receive planner (grdma_rx_multi.h): workgroups arrived in the low half,
+  // workgroups that declined in the high half; zero between launches (the last workgroup to arrive clears it)
+  uint32_t mw_arrive;
+  uint32_t pad_line1[30];
 };
 
 // A kernel node another stage hangs into a streaming job's graph (grdma_job_set_hooks, csrc/grdma_pair.hip): the

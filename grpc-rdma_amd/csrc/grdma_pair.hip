@@ -68,6 +68,9 @@ hipError_t grdma_launch_tx_index(grdma_txf_ctl*, uint32_t, uint32_t, hipStream_t
 hipError_t grdma_launch_tx_plan_job(const grdma_tx_op*, const grdma_txf_ctl*, uint32_t, hipStream_t);
 const void* grdma_kernel_fn_plan_pair(void);
 const void* grdma_kernel_fn_plan_pair_job(void);
+const void* grdma_kernel_fn_plan_pair_mw(void);
+uint32_t grdma_rx_multi_groups(void);
+uint32_t grdma_tx_multi_groups(void);
 const void* grdma_kernel_fn_rxplan_gather_job(void);
 uint32_t grdma_kernel_threads(int which);
 uint32_t grdma_copy_resident_blocks(void);
@@ -2507,6 +2510,8 @@ struct grdma_stream_job {
                                       // (k_wire_txplan_job, k_rxplan_gather_job), three launches per round.  Measured: no
                                       // gain -- a planner's dependent loads run ~2.3 x slower beside a copy that saturates
                                       // the memory system (profiles/r03_fused_schedule_experiment.txt)
+  int rx_multi = 1;                   // paired schedule: the drain plan laid out by several workgroups (k_plan_pair_mw,
+                                      // csrc/grdma_rx_multi.h); GRDMA_RX_MULTI=0: the one-workgroup k_plan_pair_job
   int rx_fast = 1;                    // drains of one-Send rounds go through k_rx_fast first (grdma_rx_fast.hip), the
                                       // general planner behind it only does what that kernel declined
   int cumask_bits = 0;                // planner CUs (low bits of the mask); 0 = off
@@ -2536,7 +2541,7 @@ namespace {
 inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 : 2); }
 inline int job_fastkey(const grdma_stream_job* j) {
   return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0) | (j->pair_job ? 8 : 0) | (j->fuse ? 16 : 0) |
-         (j->fuse_ag ? 32 : 0);
+         (j->fuse_ag ? 32 : 0) | (j->rx_multi ? 64 : 0);
 }
 // copy workgroups (1024 threads: one per CU) next to a planner workgroup in a fused launch: every CU but the planner's
 inline uint32_t job_fused_copy_blocks() {
@@ -2659,13 +2664,15 @@ int job_enqueue_schedule_instrumented(grdma_stream_job* j, hipStream_t s) {
     if (cls >= 0) j->kev_cls.push_back(cls);
     return 0;
   };
-  auto launch = [&](const void* fn, dim3 grid, uint32_t threads, const void* a0, const void* a1, const void* a2) -> hipError_t {
+  auto launch = [&](const void* fn, dim3 grid, uint32_t threads, const void* a0, const void* a1, const void* a2,
+                    uint32_t a3 = 0) -> hipError_t {
     static uint64_t none = 0;
     void* args[GRDMA_JOB_HOOK_ARGS];
     for (uint32_t a = 0; a < GRDMA_JOB_HOOK_ARGS; a++) args[a] = &none;
     args[0] = const_cast<void*>(static_cast<const void*>(&a0));
     args[1] = const_cast<void*>(static_cast<const void*>(&a1));
     args[2] = const_cast<void*>(static_cast<const void*>(&a2));
+    args[3] = &a3;
     return hipLaunchKernel(fn, grid, dim3(threads), args, 0, s);
   };
   if (int rc = mark(-1)) return rc;
@@ -2688,6 +2695,10 @@ int job_enqueue_schedule_instrumented(grdma_stream_job* j, hipStream_t s) {
     }
     const bool more = t + 1 < R;
     const void* txop_next = j->d_txop + job_opset(t + 1) * n;
+    if (j->rx_multi)
+      HIP_TRY(launch(grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_rx_multi_groups() + (more ? grdma_tx_multi_groups() : 0)),
+                     grdma_kernel_threads(0), rxop, more ? txop_next : nullptr, j->d_txf, grdma_rx_multi_groups()));
+    else
     HIP_TRY(launch(grdma_kernel_fn_plan_pair_job(), dim3(n, more ? 2 : 1), grdma_rx_plan_job_threads(), rxop,
                    more ? txop_next : nullptr, j->d_txf));
     if (int rc = mark(5)) return rc;
@@ -2912,7 +2923,7 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
   const hipGraphNode_t pre_last = R > 0 ? add_hooks(j->pre_hooks, nullptr) : nullptr;
   // (every node hands over three pointer-sized parameters; a kernel with fewer ignores the rest)
   auto add3 = [&](hipGraphNode_t* node, const void* fn, dim3 grid, uint32_t threads, const void* arg, const void* arg2,
-                  const void* arg3, std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
+                  const void* arg3, std::initializer_list<hipGraphNode_t> deps, uint32_t arg4 = 0) -> hipError_t {
     std::vector<hipGraphNode_t> d;
     for (hipGraphNode_t x : deps)
       if (x && std::find(d.begin(), d.end(), x) == d.end()) d.push_back(x);  // (a node twice is an invalid argument)
@@ -2924,6 +2935,7 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
     args[0] = const_cast<void*>(static_cast<const void*>(&arg));
     args[1] = const_cast<void*>(static_cast<const void*>(&arg2));
     args[2] = const_cast<void*>(static_cast<const void*>(&arg3));
+    args[3] = &arg4;  // (a fourth, 4-byte parameter: k_plan_pair_mw's workgroup split)
     hipKernelNodeParams np;
     memset(&np, 0, sizeof(np));
     np.func = const_cast<void*>(fn);
@@ -3053,6 +3065,11 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
       const bool more = t + 1 < R;
       if (e == hipSuccess) {
         const void* txop_next = j->d_txop + job_opset(t + 1) * n;
+        if (j->rx_multi)
+          e = add3(&X[t], grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_rx_multi_groups() + (more ? grdma_tx_multi_groups() : 0)),
+                   grdma_kernel_threads(0), rxop, more ? txop_next : nullptr, j->d_txf, {j->direct ? G[t] : W[t], at(A, t, 1)},
+                   grdma_rx_multi_groups());
+        else
         e = add3(&X[t], grdma_kernel_fn_plan_pair_job(), dim3(n, more ? 2 : 1), grdma_rx_plan_job_threads(), rxop,
                  more ? txop_next : nullptr, j->d_txf, {j->direct ? G[t] : W[t], at(A, t, 1)});
         if (more) P[t + 1] = X[t];
@@ -3271,6 +3288,7 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
   if (const char* e = getenv("GRDMA_JOB_SCHEDULE")) j->deep = strcmp(e, "pair") == 0 ? 0 : 1;
   if (const char* e = getenv("GRDMA_JOB_CUMASK")) j->cumask_bits = atoi(e);
   if (const char* e = getenv("GRDMA_RX_FAST")) j->rx_fast = atoi(e) != 0;
+  if (const char* e = getenv("GRDMA_RX_MULTI")) j->rx_multi = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_PAIR_JOB")) j->pair_job = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_JOB_FUSE")) j->fuse = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_JOB_FUSE_AG")) j->fuse_ag = atoi(e) != 0;

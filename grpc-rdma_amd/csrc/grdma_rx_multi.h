@@ -1,0 +1,605 @@
+// rxm_body: the steady-state drain of a streaming connection (grdma_rx_fast.h) laid out by SEVERAL workgroups
+// at once, with no word exchanged between them (included by grdma_rx_plan.hip; k_plan_pair_mw / k_rx_plan_mw run it).
+//
+// Why: rxf_body is one workgroup, and what bounds it is not the dependent round trips (a chained load costs
+// ~0.2 us behind the launch before, tools/trip_probe.hip) but what ONE CU can push through its memory pipe and
+// issue: the probe of 4095 records 8 KB apart takes 6.9 us from one workgroup and 2.2 us from four, 393 KB of
+// segments 5.4 us against 1.3 us, and four records per thread are four times the instruction stream.  Same
+// contract as rxf_body -- GetReadableSize / Read (ring_buffer.cc:67-191), Recv with its credit rule
+// (pair.cc:264-286), the endpoint-read loop (rdma_bp_posix.cc:180-326) replayed for every record between the
+// reader's head and the tail its sender reported; identical slices, segments, ring state, credit reports and
+// history -- but workgroup b of G owns records [b * 256, (b + 1) * 256), ONE record per thread, and a workgroup is
+// FOUR wavefronts, one per SIMD: a SIMD issues one wave-instruction every four cycles, so the sixteen waves of a
+// 1024-thread planner on one CU take 16 x (instructions per thread) cycles whatever the memory system does (measured:
+// tools/trip_probe.hip, straight-line arithmetic at 64 / 256 / 1024 threads) -- a steady-state body of ~3000
+// instructions per thread is 20 us that way and 5 us as one wave per SIMD.
+//
+// What a record needs from the records in front of it -- how many slices, segments, tiles and arena bytes they
+// took -- is a block scan in rxf_body.  Here it is a closed form, so that no workgroup waits for another:
+//
+//   * The record sizes are periodic (period P, the precondition of the steady-state body).  The payload sizes of
+//     the pattern are the headers of the first min(P, V) records of this drain (every workgroup loads them in
+//     the same round trip as its own records' header and footer; every record's owner checks its header against
+//     the pattern, so a drain whose sizes are not periodic in the PAYLOAD size is declined as a whole).
+//   * The endpoint-read state in front of a record (space left in the open read) depends on the records back to
+//     the nearest one that resets it (n >= 512: whatever was open, such a record closes it and leaves nothing
+//     open).  Let F be the first such record of the drain (F <= RXF_LOOKBACK, else this body declines -- as
+//     rxf_body does for long runs of small records).  Records 0..F -- the PREFIX REGION -- depend on the read the
+//     last drain left open; every workgroup lays them out for itself (<= 193 records, a scan).  Behind F the
+//     state is a function of the position in the pattern alone, so "what records F+1 .. i-1 took" is
+//     cyc(i) - cyc(F + 1) with cyc(k) = (k / P) * (sum over one period) + (prefix inside the period): two table
+//     look-ups in LDS.  The tables are laid out for a ring without an end; the one record of a drain whose
+//     payload crosses the ring end is found by every workgroup from the same closed form (the record whose span
+//     contains offset `cap`), laid out both ways, and the difference added behind it.
+//
+// Every workgroup reaches the same verdict on everything that is not its own probe (same inputs, same
+// arithmetic); the probes are combined by the arrival counter: a workgroup adds 1 (and 65536 if it has to decline)
+// to plan->mw_arrive, the LAST one to arrive sees the sum, and either commits -- credit (pair.cc:276-284), state,
+// result, history: thread 0 and one thread per history entry -- or, if any workgroup declined, returns 2: its
+// caller then runs the general planner in the same launch (what the others wrote are plan / slice-table entries
+// beyond any count that was committed; the general planner rewrites them).  Nothing but that counter is shared.
+#ifndef GRDMA_RX_MULTI_H
+#define GRDMA_RX_MULTI_H
+#include "grdma_rx_fast.h"
+
+namespace {
+
+#define RXM_THREADS 256u               // one wave per SIMD
+#define RXM_WAVES (RXM_THREADS / 64u)
+#define RXM_G 16u                      // workgroups per drain (k_plan_pair_mw's grid): 16 x 256 records
+#define RXM_CHUNK RXM_THREADS          // records per workgroup = threads
+#define RXM_PFX (RXF_LOOKBACK + 1u)    // most records the prefix region may hold
+#define RXM_RESET (2u * RXF_MINRD)     // a record of this many bytes or more leaves no read open (rxf_space_after)
+#define RXM_NONE 0xFFFFFFFFu
+
+struct rx_lds_multi {
+  uint32_t hist[GRDMA_RX_HIST];
+  uint32_t pat[RXF_PMAX], pre[RXF_PMAX + 1];   // encoded sizes of the pattern and their exclusive prefix
+  uint32_t npat[RXF_PMAX];                      // payload sizes of the pattern (RXM_NONE: not part of this drain)
+  uint16_t sss[RXF_PMAX];                       // steady read state in front of pattern position j
+  uint32_t qpk[RXF_PMAX + 1], qtl[RXF_PMAX + 1], qby[RXF_PMAX + 1];  // exclusive prefix over the steady pattern of
+                                                // (slices | segments << 16), tiles, arena bytes; [P] = one period
+  uint32_t qn[RXF_PMAX + 1];                    // exclusive prefix of the payload sizes
+  uint16_t as[RXM_PFX + 1];                     // read state in front of prefix-region record t
+  uint32_t apk[RXM_PFX + 1], atl[RXM_PFX + 1], aby[RXM_PFX + 1];     // exclusive prefix over the prefix region
+};
+
+// exclusive block scans of four u32 values at once (RXM_THREADS threads); totals in tot[4]
+__device__ __forceinline__ void rxm_scan4(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t (*s_w)[RXM_WAVES],
+                                          uint32_t* x0, uint32_t* x1, uint32_t* x2, uint32_t* x3, uint32_t tot[4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t i0 = wave_incl_scan_u32(v0), i1 = wave_incl_scan_u32(v1), i2 = wave_incl_scan_u32(v2), i3 = wave_incl_scan_u32(v3);
+  if (lane == 63) {
+    s_w[0][wave] = i0;
+    s_w[1][wave] = i1;
+    s_w[2][wave] = i2;
+    s_w[3][wave] = i3;
+  }
+  __syncthreads();
+  uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+  for (int w = 0; w < (int)RXM_WAVES; w++) {
+    const uint32_t a = s_w[0][w], b = s_w[1][w], c = s_w[2][w], d = s_w[3][w];
+    if (w < wave) { b0 += a; b1 += b; b2 += c; b3 += d; }
+    t0 += a; t1 += b; t2 += c; t3 += d;
+  }
+  __syncthreads();
+  *x0 = b0 + i0 - v0;
+  *x1 = b1 + i1 - v1;
+  *x2 = b2 + i2 - v2;
+  *x3 = b3 + i3 - v3;
+  tot[0] = t0; tot[1] = t1; tot[2] = t2; tot[3] = t3;
+}
+
+// what the records [0, k) of an endless steady pattern took: k = q * P + r
+__device__ __forceinline__ void rxm_cyc(const rx_lds_multi& M, uint32_t P, uint32_t k, uint32_t* pk, uint32_t* tl, uint32_t* by) {
+  const uint32_t q = k / P, r = k - q * P;
+  *pk = q * M.qpk[P] + M.qpk[r];
+  *tl = q * M.qtl[P] + M.qtl[r];
+  *by = q * M.qby[P] + M.qby[r];
+}
+
+// Returns 0: not the last workgroup of this drain to arrive (nothing more to do); 1: the last one, the drain is
+// committed; 2: the last one, and a workgroup declined -- the caller runs the general planner (every thread of the
+// workgroup returns the same value).
+__device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg) {
+  static_assert(sizeof(rx_lds_multi) <= sizeof(rx_lds), "the multi-workgroup body's tables fit the receive planners' shared LDS");
+  rx_lds_multi& M = *reinterpret_cast<rx_lds_multi*>(rx_lds_get());
+  const grdma_rx_op op = op_in;
+  const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+  const uint32_t tid = threadIdx.x;
+  grdma_conn* c = op.conn;
+  grdma_plan* plan = op.plan;
+  grdma_rx_result* res = op.result;
+  __shared__ uint32_t s_w[4][RXM_WAVES];
+  __shared__ uint32_t s_bad, s_vj, s_first, s_F, s_last, s_any;
+
+  // ---- 0. state, preconditions (as rxf_body; nothing of the connection is stored before the last workgroup commits)
+  uint8_t* const ring = c->ring;
+  const uint64_t cap64 = c->cap;
+  const uint64_t head64 = c->head, mh0 = c->moving_head, remain0 = c->remain, leftover0 = c->leftover_cap;
+  const uint64_t irs0 = c->internal_read_size;
+  const uint64_t hc = c->rx_hist_count;
+  const uint32_t P = c->rx_period;
+  const uint32_t status = c->status;
+  const uint32_t* const gh = c->rx_hist;
+  const uint64_t lim = op.limit_ptr ? __hip_atomic_load(op.limit_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  const uint64_t slice_idx0 = op.append == 1 ? c->rx_slice_idx : 0;
+  const uint64_t a_off0 = op.append == 1 ? c->rx_arena_off : 0;
+  constexpr int NH = GRDMA_RX_HIST / RXM_THREADS;
+  uint32_t hv[NH];
+#pragma unroll
+  for (int r = 0; r < NH; r++) hv[r] = gh[tid + r * RXM_THREADS];
+
+  bool ok = status == GRDMA_PAIR_CONNECTED && op.raw_cap == 0 && op.append != 0 && !op.inline_apply &&
+            op.limit_ptr != nullptr && remain0 == 0 && leftover0 <= RXF_MINRD && P != 0 && P <= RXF_PMAX && hc >= P &&
+            cap64 <= (1ull << 31) && a_off0 < (1ull << 31);
+  uint64_t max_slices = GRDMA_MAX_SLICES;
+  {
+    const uint64_t room = op.slices_cap > slice_idx0 ? op.slices_cap - slice_idx0 : 0;
+    if (room < max_slices) max_slices = room;
+    if (op.max_reads < max_slices) max_slices = op.max_reads;
+  }
+  const uint32_t cap = (uint32_t)cap64, mask = cap - 1u, head = (uint32_t)head64;
+  const uint32_t Lr = ((uint32_t)lim - head) & mask;  // ring bytes between my head and the sender's tail
+  const bool idle = Lr == 0;
+  if (tid == 0) {
+    s_bad = 0;
+    s_vj = RXM_NONE;
+    s_first = RXM_NONE;
+    s_F = RXM_NONE;
+  }
+#pragma unroll
+  for (int r = 0; r < NH; r++) M.hist[tid + r * RXM_THREADS] = hv[r];
+  __syncthreads();
+  // `reason` (uniform over the workgroup once set): 0 = going on; the slots of g_rx_fast_drains otherwise
+  uint32_t reason = (!ok || idle) ? 1u : 0u;
+
+  // ---- 1. the pattern: the newest P encoded sizes, their prefix sums, where the limit falls in it (as rxf_body)
+  uint32_t SP = 0, V = 0;
+  if (!reason) {
+    const uint32_t j0 = 2 * tid, j1 = j0 + 1;
+    const uint32_t pv0 = j0 < P ? M.hist[(uint32_t)((hc - P + j0) % GRDMA_RX_HIST)] : 0;
+    const uint32_t pv1 = j1 < P ? M.hist[(uint32_t)((hc - P + j1) % GRDMA_RX_HIST)] : 0;
+    uint32_t px, d1, d2, d3, ptot[4];
+    rxm_scan4(pv0 + pv1, 0, 0, 0, s_w, &px, &d1, &d2, &d3, ptot);
+    SP = ptot[0];
+    if (j0 < P) {
+      M.pat[j0] = pv0;
+      M.pre[j0] = px;
+    }
+    if (j1 < P) {
+      M.pat[j1] = pv1;
+      M.pre[j1] = px + pv0;
+    }
+    if (tid == 0) M.pre[P] = SP;
+    const uint32_t q_full = SP ? Lr / SP : 0, rem = SP ? Lr - q_full * SP : 0;
+    if (SP != 0) {  // (pre[] is strictly increasing: at most one match)
+      if (j0 < P && px == rem) s_vj = j0;
+      if (j1 < P && px + pv0 == rem) s_vj = j1;
+    }
+    __syncthreads();
+    const uint32_t vj = s_vj;
+    const uint64_t V64 = (uint64_t)q_full * P + vj;
+    if (SP == 0 || vj == RXM_NONE || V64 == 0 || V64 > (uint64_t)nwg * RXM_CHUNK) reason = 2;
+    else V = (uint32_t)V64;
+  }
+  const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap64);
+  const uint64_t t_pattern = __builtin_amdgcn_s_memtime();
+
+  // ---- 2. one round trip: header and footer of my record, header of pattern record `tid`
+  const uint32_t i_mine = wg * RXM_CHUNK + tid;
+  const bool have = !reason && i_mine < V;
+  const uint32_t PV = reason ? 0u : (V < P ? V : P);  // pattern positions this drain holds a record for
+  uint32_t xe = 0, ee = 0, ri_mine = 0, n_mine = 0;
+  if (!reason) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const uint32_t ring_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)ring);
+    const uint32_t ring_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)ring >> 32));
+    const uint64_t ring_u = ((uint64_t)ring_hi << 32) | (uint64_t)ring_lo;
+    const uint32_t cap_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)cap);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ring_u, 0, cap_u, 0x00020000);
+    if (have) {
+      const uint32_t qi = i_mine / P;
+      ri_mine = i_mine - qi * P;
+      xe = qi * SP + M.pre[ri_mine];
+      ee = M.pat[ri_mine];
+    }
+    // (clamped, unconditional loads: every lane's four words are in flight together; pattern positions 2 tid, 2 tid + 1)
+    const uint32_t pj0 = 2 * tid, pj1 = pj0 + 1;
+    const uint32_t o_h = have ? ((head + xe) & mask & ~7u) : 0u;
+    const uint32_t o_f = have ? ((head + xe + ee - 8u) & mask & ~7u) : 0u;
+    const uint32_t o_p0 = pj0 < PV ? ((head + M.pre[pj0]) & mask & ~7u) : 0u;
+    const uint32_t o_p1 = pj1 < PV ? ((head + M.pre[pj1]) & mask & ~7u) : 0u;
+    const u32x2 hw = __builtin_amdgcn_raw_buffer_load_b64(rs, o_h, 0, 16 /* sc1 */);
+    const u32x2 fw = __builtin_amdgcn_raw_buffer_load_b64(rs, o_f, 0, 16);
+    const u32x2 pw0 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_p0, 0, 16);
+    const u32x2 pw1 = __builtin_amdgcn_raw_buffer_load_b64(rs, o_p1, 0, 16);
+    bool bad = false;
+    if (have) {
+      const uint64_t h = ((uint64_t)hw.y << 32) | hw.x, f = ((uint64_t)fw.y << 32) | fw.x;
+      bad |= !(h != 0 && h <= cap64 - GRDMA_RESERVED && 16u + (uint32_t)round_up8(h) == ee);
+      bad |= f != GRDMA_FOOTER;
+      n_mine = (uint32_t)h;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const uint32_t pj = r ? pj1 : pj0;
+      if (pj < P) {
+        uint32_t np = RXM_NONE;
+        if (pj < PV) {
+          const uint64_t h = r ? (((uint64_t)pw1.y << 32) | pw1.x) : (((uint64_t)pw0.y << 32) | pw0.x);
+          const uint32_t e = M.pat[pj];
+          // (a header that does not fit its slot makes the drain's owner of that record decline; keep the value harmless)
+          np = (h != 0 && h <= cap64 - GRDMA_RESERVED && 16u + (uint32_t)round_up8(h) == e) ? (uint32_t)h : e - 16u;
+          if (np != (uint32_t)h) bad = true;
+        }
+        M.npat[pj] = np;
+      }
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (have && n_mine != M.npat[ri_mine]) s_bad = 1;  // periodic in the encoded size but not in the payload size
+    // the first record that leaves no read open behind it (F), among the first RXM_PFX records
+    if (tid < RXM_PFX && tid < V && M.npat[tid % P] >= RXM_RESET) atomicMin(&s_F, tid);
+    __syncthreads();
+    if (s_bad) reason = 3;
+  }
+  const uint64_t t_probe = __builtin_amdgcn_s_memtime();
+
+  // ---- 3. the prefix region: records 0 .. NF - 1 from the read the last drain left open
+  const uint32_t s0 = (uint32_t)leftover0;
+  const bool odd_open = s0 != 0 && s0 != RXF_MINRD;  // the open read's capacity is not a fresh read's 256
+  uint32_t NF = 0, first_done = RXM_NONE;
+  uint32_t PS_pk = 0, PS_tl = 0, PS_by = 0;
+  if (!reason) {
+    const uint32_t F = s_F;
+    if (F != RXM_NONE) NF = F + 1;
+    else if (V <= RXM_PFX) NF = V;   // no such record in a short drain: all of it is prefix region
+    else reason = 4;                  // a long run of small records: not this body's case
+  }
+  if (!reason) {
+    uint32_t s_in = 0, n_t = 0;
+    const bool mine = tid < NF;
+    if (mine) {
+      uint32_t s = s0, rj = 0;
+      for (uint32_t j = 0; j < tid; j++) {
+        s = rxf_space_after(M.npat[rj], s);
+        if (++rj == P) rj = 0;
+      }
+      s_in = s;
+      n_t = M.npat[rj];
+      M.as[tid] = (uint16_t)s;
+      if (rxf_replay(n_t, s).sl_cnt != 0) atomicMin(&s_first, tid);
+    }
+    __syncthreads();
+    first_done = s_first;  // RXM_NONE: no slice completes in the prefix region (then it is the whole drain)
+    uint32_t my_pk = 0, my_tl = 0, my_by = 0;
+    if (mine) {
+      const uint32_t q = tid / P, r = tid - q * P;
+      const uint32_t x = q * SP + M.pre[r];
+      const bool in_first = odd_open && tid <= first_done;
+      const rxf_layout L = rxf_lay(n_t, s_in, (head + x + 8u) & mask, cap, in_first ? s0 : RXF_MINRD,
+                                   odd_open && tid == first_done, ts);
+      my_pk = L.sl_cnt | (L.nsg << 16);
+      my_tl = L.ntl;
+      my_by = L.bytes;
+    }
+    uint32_t x_pk, x_tl, x_by, x_d, tot[4];
+    rxm_scan4(my_pk, my_tl, my_by, 0, s_w, &x_pk, &x_tl, &x_by, &x_d, tot);
+    if (mine) {
+      M.apk[tid] = x_pk;
+      M.atl[tid] = x_tl;
+      M.aby[tid] = x_by;
+    }
+    PS_pk = tot[0];
+    PS_tl = tot[1];
+    PS_by = tot[2];
+  }
+
+  // ---- 4. the steady pattern: read state in front of every position, what every position takes, prefix sums
+  if (!reason) {
+    // (thread t: positions 2 t and 2 t + 1)
+    uint32_t v_pk[2] = {0, 0}, v_tl[2] = {0, 0}, v_by[2] = {0, 0}, v_n[2] = {0, 0};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const uint32_t pj = 2 * tid + r;
+      if (pj >= P) continue;
+      // back to the nearest position that resets the state (cyclic; positions this drain has no record for count
+      // as resets: they are only reached from positions whose values are never used)
+      uint32_t k = pj, steps = 0;
+      for (;;) {
+        const uint32_t kp = k == 0 ? P - 1 : k - 1;
+        if (M.npat[kp] >= RXM_RESET) break;
+        k = kp;
+        if (++steps > RXF_LOOKBACK) break;
+      }
+      if (steps > RXF_LOOKBACK && V > NF) s_bad = 1;  // (a drain that is all prefix region does not use these tables)
+      uint32_t s = 0;
+      for (uint32_t j = 0; j < steps && steps <= RXF_LOOKBACK; j++) {
+        s = rxf_space_after(M.npat[k], s);
+        if (++k == P) k = 0;
+      }
+      M.sss[pj] = (uint16_t)s;
+      const uint32_t n = M.npat[pj];
+      if (n != RXM_NONE) {
+        const rxf_layout L = rxf_lay(n, s, 0u, 0x80000000u, RXF_MINRD, false, ts);  // a ring without an end
+        v_pk[r] = L.sl_cnt | (L.nsg << 16);
+        v_tl[r] = L.ntl;
+        v_by[r] = L.bytes;
+        v_n[r] = n;
+      }
+    }
+    uint32_t x_pk, x_tl, x_by, x_n, tot[4];
+    rxm_scan4(v_pk[0] + v_pk[1], v_tl[0] + v_tl[1], v_by[0] + v_by[1], v_n[0] + v_n[1], s_w, &x_pk, &x_tl, &x_by, &x_n, tot);
+    if (2 * tid < P) {
+      M.qpk[2 * tid] = x_pk;
+      M.qtl[2 * tid] = x_tl;
+      M.qby[2 * tid] = x_by;
+      M.qn[2 * tid] = x_n;
+    }
+    if (2 * tid + 1 < P) {
+      M.qpk[2 * tid + 1] = x_pk + v_pk[0];
+      M.qtl[2 * tid + 1] = x_tl + v_tl[0];
+      M.qby[2 * tid + 1] = x_by + v_by[0];
+      M.qn[2 * tid + 1] = x_n + v_n[0];
+    }
+    if (tid == 0) {
+      M.qpk[P] = tot[0];
+      M.qtl[P] = tot[1];
+      M.qby[P] = tot[2];
+      M.qn[P] = tot[3];
+    }
+    __syncthreads();
+    if (s_bad) reason = 4;
+  }
+  const uint64_t t_state = __builtin_amdgcn_s_memtime();
+
+  // ---- 5. the record whose payload crosses the ring end (behind the prefix region), totals, room
+  // read state in front of record i, its payload size
+  auto state_of = [&](uint32_t i, uint32_t* n_out) -> uint32_t {
+    const uint32_t r = i % P;
+    *n_out = M.npat[r];
+    return i < NF ? (uint32_t)M.as[i] : (uint32_t)M.sss[r];
+  };
+  uint32_t w_rec = RXM_NONE, d_sg = 0, d_tl = 0;
+  // what records [0, i) took, NF <= i <= V
+  auto before = [&](uint32_t i, uint32_t* pk, uint32_t* tl, uint32_t* by) {
+    uint32_t a_pk, a_tl, a_by, b_pk, b_tl, b_by;
+    rxm_cyc(M, P, i, &a_pk, &a_tl, &a_by);
+    rxm_cyc(M, P, NF, &b_pk, &b_tl, &b_by);
+    const bool past = w_rec != RXM_NONE && i > w_rec;
+    *pk = PS_pk + (a_pk - b_pk) + (past ? d_sg << 16 : 0u);
+    *tl = PS_tl + (a_tl - b_tl) + (past ? d_tl : 0u);
+    *by = PS_by + (a_by - b_by);
+  };
+  uint32_t tot_pk = 0, tot_tl = 0, tot_by = 0, s_end = 0;
+  if (!reason) {
+    const uint32_t u = cap - head;  // ring bytes from my head to the ring end
+    if (u < Lr) {
+      const uint32_t q = u / SP, r = u - q * SP;
+      uint32_t lo = 0, hi = P;  // the last position whose prefix is <= r
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (M.pre[mid] <= r) lo = mid; else hi = mid;
+      }
+      const uint32_t w = q * P + lo;
+      if (w >= NF && w < V) {
+        const uint32_t n = M.npat[lo], s = M.sss[lo];
+        const rxf_layout La = rxf_lay(n, s, (head + q * SP + M.pre[lo] + 8u) & mask, cap, RXF_MINRD, false, ts);
+        const rxf_layout Lb = rxf_lay(n, s, 0u, 0x80000000u, RXF_MINRD, false, ts);
+        w_rec = w;
+        d_sg = La.nsg - Lb.nsg;
+        d_tl = La.ntl - Lb.ntl;
+      }
+    }
+    if (V > NF) before(V, &tot_pk, &tot_tl, &tot_by);
+    else { tot_pk = PS_pk; tot_tl = PS_tl; tot_by = PS_by; }
+    uint32_t n_last;
+    const uint32_t s_last_in = state_of(V - 1, &n_last);
+    s_end = rxf_space_after(n_last, s_last_in);
+  }
+  const uint32_t tot_sl = tot_pk & 0xFFFFu, tot_sg = tot_pk >> 16;
+  // the would-block at the end (rdma_do_read, rdma_bp_posix.cc:195-277), as rxf_body
+  const uint32_t cap_open_end = (odd_open && first_done == RXM_NONE) ? s0 : RXF_MINRD;
+  const uint32_t short_len = s_end ? cap_open_end - s_end : 0;
+  const uint32_t nsl_final = tot_sl + (short_len ? 1u : 0u);
+  const uint32_t leftover_final = s_end ? s_end : RXF_MINRD;
+  const uint64_t a_end = a_off0 + tot_by + rxf_al16(short_len);
+  if (!reason && !(nsl_final + 2 <= max_slices && tot_sg + 8 <= GRDMA_MAX_SEGS && a_end + leftover_final + 16 <= op.arena_cap &&
+                   a_end < (1ull << 32)))
+    reason = 5;
+  const uint64_t t_scan = __builtin_amdgcn_s_memtime();
+
+  // ---- 6. my record: segments, tile prefix, slices (entries beyond any committed count if the drain is declined)
+  grdma_slice_out* const out_slices = op.slices + slice_idx0;
+  if (!reason && have) {
+    uint32_t n, pk, tl, by;
+    const uint32_t s_in = state_of(i_mine, &n);
+    if (i_mine < NF) {
+      pk = M.apk[i_mine];
+      tl = M.atl[i_mine];
+      by = M.aby[i_mine];
+    } else {
+      before(i_mine, &pk, &tl, &by);
+    }
+    uint32_t sl = pk & 0xFFFFu, sg = pk >> 16;
+    const bool in_first = odd_open && i_mine <= first_done;
+    const rxf_layout L = rxf_lay(n, s_in, (head + xe + 8u) & mask, cap, in_first ? s0 : RXF_MINRD,
+                                 odd_open && i_mine == first_done, ts);
+    const uint64_t A = a_off0 + by;  // start of the open slice, or of the slice this record begins
+    int last_piece = 0;
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+      if (L.len[k]) last_piece = k;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (L.len[k] == 0) continue;
+      const uint64_t fl = GRDMA_SEG_ZERO_SRC | (k == 0 ? GRDMA_SEG_TAG_HDR : 0) | (k == last_piece ? GRDMA_SEG_TAG_FTR : 0);
+      plan->segs[sg] = {(uint64_t)op.arena + A + L.dst_rel[k], (uint64_t)(ring + L.off[k]), (uint64_t)L.len[k], fl};
+      plan->tile_prefix[sg] = tl;
+      sg++;
+      tl += rxf_tiles(L.len[k], ts);
+    }
+    uint64_t sof = A;
+    if (L.sl0) {
+      out_slices[sl].off = sof;
+      out_slices[sl].len = L.sl0;
+      sl++;
+      sof += rxf_al16(L.sl0);
+    }
+    if (L.sl1) {
+      out_slices[sl].off = sof;
+      out_slices[sl].len = L.sl1;
+    }
+  }
+  const uint64_t t_emit = __builtin_amdgcn_s_memtime();
+
+  // ---- 7. arrival: the last workgroup of the drain commits, or hands the drain to the general planner
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t prev = __hip_atomic_fetch_add(&plan->mw_arrive, 1u + (reason ? 0x10000u : 0u), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = (prev & 0xFFFFu) == nwg - 1;
+    s_last = last ? 1u : 0u;
+    s_any = (prev >> 16) + (reason ? 1u : 0u);
+    if (last) __hip_atomic_store(&plan->mw_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return 0;
+  if (s_any) {  // (uniform)
+    if (tid == 0) {
+      // (the slot of this workgroup's own reason if it has one, the probe's otherwise: another workgroup's records)
+      atomicAdd(&g_rx_fast_drains[reason ? reason : 3u], 1ull);
+      if (!idle) res->pad0++;  // (pad1 / pad0: drains of this result block taken / declined with data waiting)
+    }
+    return 2;
+  }
+
+  // history: the records of this drain become the newest entries (the pattern simply continues)
+#pragma unroll
+  for (int r = 0; r < NH; r++) {
+    const uint32_t back = tid + r * RXM_THREADS;  // the newest GRDMA_RX_HIST records
+    if (back < V) {
+      const uint32_t i = V - 1 - back;
+      c->rx_hist[(uint32_t)((hc + i) % GRDMA_RX_HIST)] = M.pat[i % P];
+    }
+  }
+  // ---- 8. credit (pair.cc:276-284), state, result: thread 0 (as rxf_body, per-record values from the tables)
+  if (tid == 0) {
+    // (what the commit adds to: one more round trip, ~0.2 us, in the one workgroup that commits)
+    const uint64_t o_total_read = c->total_read, o_credit_msgs = c->credit_msgs;
+    const uint64_t o_rx_records = c->rx_records, o_rx_rounds = c->rx_rounds;
+    const uint32_t o_h1 = c->rx_h1;
+    const uint64_t o_seq = res->seq;
+    grdma_hostline* const line = c->line;
+    const uint32_t tot_n = (V / P) * M.qn[P] + M.qn[V % P];  // payload bytes of the drain
+    auto enc_end = [&](uint32_t i) -> uint64_t {  // ring bytes consumed once record i is finished
+      const uint32_t qi = i / P, ri = i - qi * P;
+      return (uint64_t)qi * SP + M.pre[ri] + M.pat[ri];
+    };
+    const uint64_t T = cap64 / 2, Ctot = Lr;
+    uint64_t base = 0, thr = T - irs0, credit = 0, credit_head = 0;
+    bool crossed = false;
+    while (Ctot >= thr) {
+      uint32_t lo = 0, hi = V - 1;  // first record whose running consumption (after its last step) reaches thr
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (enc_end(mid) >= thr) hi = mid; else lo = mid + 1;
+      }
+      uint32_t n;
+      const uint32_t s_in = state_of(lo, &n);
+      const rxf_rec rp = rxf_replay(n, s_in);
+      const uint64_t C2 = enc_end(lo);
+      const uint64_t e = 16u + ((n + 7u) & ~7u);
+      const uint64_t cons2 = rp.c2 ? rp.c2 + (((n + 7u) & ~7u) - n + 8u) : 0;
+      const uint64_t C1 = C2 - cons2;
+      const uint64_t pos = (head64 + C2 - e) & (cap64 - 1);
+      if (rp.c2 && C1 >= thr) {  // crossed after the first step of a two-step record
+        credit_head = (pos + 8 + rp.c1) & (cap64 - 1);
+        base = C1;
+      } else {
+        credit_head = (pos + e) & (cap64 - 1);
+        base = C2;
+      }
+      credit++;
+      crossed = true;
+      thr = base + T;
+    }
+    const uint64_t irs = crossed ? Ctot - base : irs0 + Ctot;
+    const uint64_t nh = (head64 + Lr) & (cap64 - 1);
+    if (short_len) {
+      out_slices[tot_sl].off = a_off0 + tot_by;
+      out_slices[tot_sl].len = short_len;
+    }
+    plan->nsegs = tot_sg;
+    plan->ntiles = tot_tl;
+    plan->tile_bytes = 1u << ts;
+    plan->tile_prefix[tot_sg] = tot_tl;
+    plan->bytes = tot_n;
+    plan->tag_base = (uint64_t)ring;
+    plan->tag_mask = cap64 - 1;
+    plan->blocks_done = 0;
+    c->head = nh;
+    c->moving_head = nh;
+    c->remain = 0;
+    if (line != nullptr) {
+      line->rx_head = nh;
+      line->rx_remain = 0;
+    }
+    c->internal_read_size = irs;
+    c->leftover_cap = leftover_final;
+    c->total_read = o_total_read + tot_n;
+    c->credit_msgs = o_credit_msgs + credit;
+    c->rx_records = o_rx_records + V;
+    if (nsl_final) c->rx_rounds = o_rx_rounds + 1;
+    c->rx_arena_off = a_end;
+    c->rx_slice_idx = slice_idx0 + nsl_final;
+    c->rx_hist_count = hc + V;
+    {
+      const uint32_t rl = (V - 1) % P;
+      c->rx_h1 = M.pat[rl];
+      c->rx_h2 = V >= 2 ? M.pat[rl ? rl - 1 : P - 1] : o_h1;
+    }
+    if (credit) c->status_send.remote_head = credit_head;
+    res->credit_head = credit_head;
+    res->nslices = nsl_final;
+    res->bytes = tot_n;
+    res->consumed = Lr;
+    res->records = V;
+    res->would_block = 1;
+    res->credit_sent = credit;
+    res->head = nh;
+    res->moving_head = nh;
+    res->remain = 0;
+    res->arena_used = a_end;
+    res->zero_off[0] = res->zero_off[1] = res->zero_len[0] = res->zero_len[1] = 0;
+    if (nh > mh0) {
+      res->zero_off[0] = mh0;
+      res->zero_len[0] = nh - mh0;
+    } else {
+      res->zero_off[0] = mh0;
+      res->zero_len[0] = cap64 - mh0;
+      res->zero_off[1] = 0;
+      res->zero_len[1] = nh;
+    }
+    res->dbg[0] = t_begin;
+    res->dbg[2] = t_pattern - t_begin;
+    res->dbg[3] = t_probe - t_begin;
+    res->dbg[4] = t_state - t_begin;
+    res->dbg[5] = t_scan - t_begin;
+    res->dbg[6] = t_emit - t_begin;
+    res->dbg[7] = V;
+    res->dbg[8] = P;
+    res->dbg[9] = 0xFA57;  // this stamp set comes from a steady-state body
+    res->dbg[10] = nwg;
+    res->pad1++;
+    res->dbg[1] = __builtin_amdgcn_s_memtime();
+    atomicAdd(&g_rx_fast_drains[0], 1ull);
+    __hip_atomic_store(&res->seq, op.seq_next ? op.seq_next : o_seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  return 1;
+}
+
+}  // namespace
+#endif  // GRDMA_RX_MULTI_H

@@ -42,6 +42,8 @@
 #include "grdma_ops.h"
 #include "grdma_tx_body.h"
 #include "grdma_rx_fast.h"
+#include "grdma_rx_multi.h"
+#include "grdma_tx_multi.h"
 #include "grdma_tx_fast.h"
 
 namespace {
@@ -1492,6 +1494,30 @@ void k_plan_pair_job(const grdma_rx_op* rxops, const grdma_tx_op* txops, const g
 }
 
 // ----------------------------------------------------------------------------
+// k_plan_pair_mw: the planner pair of a streaming job's round as MANY small workgroups: the drain of round t laid out by
+// G workgroups of four wavefronts (grdma_rx_multi.h: one record per thread, nothing exchanged between the workgroups
+// but the arrival word), the Send of round t + 1 by H more (grdma_tx_multi.h).  gridDim.y = G + H; txops == nullptr:
+// the last round, no Send (H = 0).  A 1024-thread planner is sixteen waves on one CU: four per SIMD, which issues one
+// wave-instruction every four cycles -- 16 x (instructions per thread) cycles whatever the memory system does; here
+// every SIMD has one wave and the probe / the plan stores of a round go through sixteen CUs' memory pipes.  The last
+// workgroup to arrive commits, or -- if any of them declined -- runs the general planner right here (a 256-thread body
+// with the whole register file: no spills, unlike behind the 1024-thread job kernels).
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_plan_pair_mw(const grdma_rx_op* rxops, const grdma_tx_op* txops, const grdma_txf_ctl* ctls, uint32_t G) {
+  static_assert(RXM_THREADS == PLAN_THREADS && TXM_THREADS == PLAN_THREADS, "one workgroup shape for all planner bodies");
+  if (blockIdx.y < G) {
+    if (rxm_body(rxops[blockIdx.x], blockIdx.y, G) != 2) return;  // (uniform)
+    rx_plan_body(rxops[blockIdx.x]);
+    if (threadIdx.x == 0) rxops[blockIdx.x].result->dbg[9] = 0;
+  } else {
+    if (txm_body(txops[blockIdx.x], &ctls[blockIdx.x], blockIdx.y - G, gridDim.y - G) != 2) return;  // (uniform)
+    tx_plan_body(txops[blockIdx.x]);
+    if (threadIdx.x == 0) txops[blockIdx.x].result->dbg[9] = 0;
+  }
+}
+
+// ----------------------------------------------------------------------------
 // k_rxplan_gather_job: the drain plan of round t and the GATHER of round t + 1 in ONE launch (the other half of the
 // fused schedule, see k_wire_txplan_job in grdma_kernels.hip): the receive planner -- one workgroup, 28 us of dependent
 // memory round trips during which the rest of the chip used to idle -- needs the wire of round t; the gather of round
@@ -1696,6 +1722,9 @@ extern "C" int grdma_rx_fast_drains(uint64_t out[6]) {
 }
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rxplan_gather_job(void) { return reinterpret_cast<const void*>(&k_rxplan_gather_job); }
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_job(void) { return reinterpret_cast<const void*>(&k_plan_pair_job); }
+extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_mw(void) { return reinterpret_cast<const void*>(&k_plan_pair_mw); }
+extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_rx_multi_groups(void) { return RXM_G; }
+extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_groups(void) { return TXM_G; }
 // (this translation unit's copy of the index body's counters: the pair kernel's Sends)
 extern "C" __attribute__((visibility("hidden"))) int grdma_tx_fast_sends_pair(uint64_t out[2]) {
   unsigned long long v[2] = {0, 0};

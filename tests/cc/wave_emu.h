@@ -170,6 +170,13 @@ inline void trace_report(int nlanes) {
     }
   }
   fprintf(stderr, "wave_emu trace: the lanes agree on every entry they share\n");
+  // (one lane ran ahead of the others: the tails say how far each got)
+  for (int i = 0; i < nlanes && i < 2; i++) {
+    const auto& a = traces[i];
+    fprintf(stderr, "wave_emu trace: lane %d has %zu entries, the last ones:", i, a.size());
+    for (size_t k = a.size() > 6 ? a.size() - 6 : 0; k < a.size(); k++) fprintf(stderr, " %s=%llu", a[k].tag, (unsigned long long)a[k].v);
+    fprintf(stderr, "\n");
+  }
 }
 inline lane_ctx* cur_lane() { return &t_wave->lanes[t_wave->cur]; }
 inline void trace(const char* tag, uint64_t v) {

@@ -205,6 +205,52 @@ def test_steady_state_drains_through_the_fast_planner_match_the_oracle(gpu, case
     assert after[6] - before[6] >= PASSES * exp_rounds and after[7] == before[7], (after[6:], before[6:])
 
 
+# Drains of more than 1024 records: the multi-workgroup drain plan of the paired schedule (csrc/grdma_rx_multi.h:
+# workgroup b lays out records [1024 b, 1024 b + 1024) from closed forms over the pattern, nothing exchanged between
+# the workgroups).  An odd max_sge (every other drain starts with a read left open), rings of a few rounds (the ring
+# end and the credit threshold walk through the records of every workgroup), a six-record pattern with 16 KiB
+# payloads and a two-record pattern of small ones; the last case has no record that closes a read (all < 512
+# bytes): the body declines in every workgroup and the last one to arrive runs the general planner.
+MULTI_CASES = [
+    # (ring, max_sge, n_msgs, msg_len, taken by the steady-state body)
+    # (rounds of at most ring / 6: no Send of the paired schedule is credit-limited, the plain oracle rounds apply)
+    (1 << 23, 3001, 6000, 600, True),
+    (1 << 26, 2049, 1400, 20000, True),
+    (1 << 25, 4095, 8000, 1500, True),
+    (1 << 22, 1500, 3000, 100, False),
+]
+
+
+@pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
+@pytest.mark.parametrize("case", MULTI_CASES, ids=["r8m_sge3001", "r64m_sge2049", "r32m_sge4095", "r4m_sge1500_small"])
+def test_drains_of_several_workgroups_match_the_oracle(gpu, case, flags):
+    R, max_sge, n_msgs, msg_len, taken = case
+    rng = random.Random(R % 97)
+    body = bytes(rng.getrandbits(8) for _ in range(msg_len))
+    slices = []
+    for i in range(n_msgs):
+        wire, lens = pyorc.h2_frame_message(body, stream_id=2 * i + 1)
+        off = 0
+        for n in lens:
+            slices.append(wire[off:off + n])
+            off += n
+    exp, exp_rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, slices)
+    before = _fast_counts(gpu)
+    got = _run_job(gpu, R, max_sge, slices, pipeline=True, flags=flags)
+    after = _fast_counts(gpu)
+    assert [len(x) for x in got["slices"]] == [len(x) for x in exp]
+    assert got["slices"] == exp
+    assert got["ring"] == ring == bytes(R)
+    for k in ("remote_tail", "remote_head", "partial_write"):
+        assert got["tx"][k] == st0[k], k
+    for k in ("head", "moving_head", "remain", "internal_read_size"):
+        assert got["rx"][k] == st1[k], k
+    took = after[0] - before[0]
+    if taken:
+        assert took >= exp_rounds, "the steady-state bodies took %d drains (declined by reason: %s)" % (
+            took, [a - b for a, b in zip(after[1:6], before[1:6])])
+
+
 @pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
 @pytest.mark.parametrize("case", FAST_CASES[:2], ids=["r16m_sge255", "r32m_sge511"])
 def test_the_instrumented_schedule_is_the_graphs_chain(gpu, case, flags):
