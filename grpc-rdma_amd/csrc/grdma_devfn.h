@@ -357,16 +357,13 @@ __device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane)
 #ifndef GRDMA_PLAN_ST
 #define GRDMA_PLAN_ST 0
 #endif
-template <uint32_t TILE>
-__device__ __forceinline__ void plan_tile(const grdma_seg& sg, uint64_t off, uint64_t n, uint64_t tag_base, uint64_t tm, int lane) {
-  // (nontemporal loads: payload streams through once; plain stores: the next kernel of the
-  // round reads what this one wrote out of the Infinity Cache)
-  if (sg.src == 0) wave_zero_tile(reinterpret_cast<uint8_t*>(sg.dst + off), n, lane);
-  else if (sg.flags & GRDMA_SEG_ZERO_SRC) wave_move_tile<GRDMA_PLAN_LD, GRDMA_PLAN_ST, true, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
-  else wave_move_tile<GRDMA_PLAN_LD, GRDMA_PLAN_ST, false, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
+// the record tags a segment carries (header in front of its first tile, padding + footer behind its last one)
+__device__ __forceinline__ void plan_tags(const grdma_seg& sg_in, uint64_t off, uint64_t n, uint64_t tag_base, uint64_t tm, int lane) {
+  const grdma_seg sg = sg_in;  // (by value: a select between two fields of a referenced struct pins it to memory)
   if (sg.flags & (GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR)) {
     const bool wr = (sg.flags & GRDMA_SEG_TAG_WRITE) != 0;
-    const uint64_t side = wr ? sg.dst : sg.src;
+    const uint64_t v_dst = sg.dst, v_src = sg.src;
+    const uint64_t side = wr ? v_dst : v_src;
     uint8_t* const tb = reinterpret_cast<uint8_t*>(tag_base);
     if ((sg.flags & GRDMA_SEG_TAG_HDR) && off == 0 && lane == 0)
       *reinterpret_cast<uint64_t*>(tb + ((side - 8 - tag_base) & tm)) = wr ? (sg.flags >> GRDMA_SEG_TAG_LEN_SHIFT) : 0;
@@ -379,6 +376,33 @@ __device__ __forceinline__ void plan_tile(const grdma_seg& sg, uint64_t off, uin
   }
 }
 
+template <uint32_t TILE>
+__device__ __forceinline__ void plan_tile(const grdma_seg& sg, uint64_t off, uint64_t n, uint64_t tag_base, uint64_t tm, int lane) {
+  // (nontemporal loads: payload streams through once; plain stores: the next kernel of the
+  // round reads what this one wrote out of the Infinity Cache)
+  if (sg.src == 0) wave_zero_tile(reinterpret_cast<uint8_t*>(sg.dst + off), n, lane);
+  else if (sg.flags & GRDMA_SEG_ZERO_SRC) wave_move_tile<GRDMA_PLAN_LD, GRDMA_PLAN_ST, true, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
+  else wave_move_tile<GRDMA_PLAN_LD, GRDMA_PLAN_ST, false, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
+  plan_tags(sg, off, n, tag_base, tm, lane);
+}
+
+// A segment of at most 64 bytes -- the 9-byte frame-header slices and records of an HTTP/2 stream: HALF the segments
+// of a streaming round, each of which used to take a wave's whole pass (descriptor, load, store, tags: four dependent
+// steps for nine bytes) -- moved one byte per lane in two halves, so that it can ride along with the 16 KiB tile the
+// same wave moves next: its load is issued in front of that tile's loads, its stores behind that tile's stores.
+#define GRDMA_TINY_MAX 64u
+__device__ __forceinline__ uint8_t tiny_load(const grdma_seg& sg, int lane) {
+  const uint8_t* src = reinterpret_cast<const uint8_t*>(sg.src);
+  return (src != nullptr && (uint64_t)lane < sg.len) ? __builtin_nontemporal_load(src + lane) : (uint8_t)0;
+}
+__device__ __forceinline__ void tiny_store(const grdma_seg& sg, uint8_t v, uint64_t tag_base, uint64_t tm, int lane) {
+  if ((uint64_t)lane < sg.len) {
+    reinterpret_cast<uint8_t*>(sg.dst)[lane] = v;
+    if (sg.src != 0 && (sg.flags & GRDMA_SEG_ZERO_SRC)) reinterpret_cast<uint8_t*>(sg.src)[lane] = 0;
+  }
+  plan_tags(sg, 0, sg.len, tag_base, tm, lane);
+}
+
 template <uint32_t LDS_N, bool CONTIG, uint32_t TILE>
 __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t wave,
                                                uint32_t nwaves, int lane) {
@@ -389,11 +413,33 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
   // In flight together with the header: the segment of tile `wave`, should the plan turn out to
   // hold one tile per segment (the steady state of both the gather and the scatter: tile t then IS
   // segment t -- no prefix staging, no search, no barrier, one memory round trip less).
-  const grdma_seg spec = plan->segs[wave < GRDMA_MAX_SEGS ? wave : 0];
+  // (a wave takes segments 2 w and 2 w + 1, then 2 (w + nwaves), ...: a tiny segment rides along with its neighbour.
+  // The two 32-byte descriptors of a pass travel as ONE register: lane l holds dword l & 15 of the pair -- a single
+  // 64-byte load, in flight together with the plan header for the first pass and while the pass in front moves its
+  // bytes for the others -- and are read out into scalar registers when the pass begins.)
+  static_assert(sizeof(grdma_seg) == 32, "a pair of descriptors is sixteen dwords");
+  const uint32_t w2 = 2 * wave;
+  const uint32_t* const seg_words = reinterpret_cast<const uint32_t*>(plan->segs);
+  uint32_t pairw = seg_words[(size_t)(w2 + 1 < GRDMA_MAX_SEGS ? w2 : 0) * 8 + (lane & 15)];
   if (ntiles == nsegs) {  // (uniform over the workgroup; every segment has at least one tile)
-    for (uint32_t t = wave; t < ntiles; t += nwaves) {
-      const grdma_seg sg = t == wave ? spec : plan->segs[t];
-      plan_tile<TILE>(sg, 0, sg.len, tag_base, tm, lane);
+    for (uint32_t t = w2; t < ntiles; t += 2 * nwaves) {
+      auto word = [&](int k) -> uint64_t {  // 64-bit word k of the pair, wave-uniform
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)pairw, 2 * k + 1) << 32) |
+               (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)pairw, 2 * k);
+      };
+      const grdma_seg cur0 = {word(0), word(1), word(2), word(3)};
+      const grdma_seg cur1 = {word(4), word(5), word(6), word(7)};
+      const uint32_t tn = t + 2 * nwaves;
+      pairw = seg_words[(size_t)(tn + 1 < GRDMA_MAX_SEGS && tn < ntiles ? tn : t) * 8 + (lane & 15)];
+      const bool two = t + 1 < ntiles;
+      const bool tiny0 = cur0.len <= GRDMA_TINY_MAX, tiny1 = two && cur1.len <= GRDMA_TINY_MAX;
+      uint8_t b0 = 0, b1 = 0;
+      if (tiny0) b0 = tiny_load(cur0, lane);
+      if (tiny1) b1 = tiny_load(cur1, lane);
+      if (!tiny0) plan_tile<TILE>(cur0, 0, cur0.len, tag_base, tm, lane);
+      if (two && !tiny1) plan_tile<TILE>(cur1, 0, cur1.len, tag_base, tm, lane);
+      if (tiny0) tiny_store(cur0, b0, tag_base, tm, lane);
+      if (tiny1) tiny_store(cur1, b1, tag_base, tm, lane);
     }
     return;
   }

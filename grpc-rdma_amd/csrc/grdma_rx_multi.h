@@ -91,9 +91,14 @@ __device__ __forceinline__ void rxm_scan4(uint32_t v0, uint32_t v1, uint32_t v2,
   tot[0] = t0; tot[1] = t1; tot[2] = t2; tot[3] = t3;
 }
 
+// k / P for k * P < 2^32 from inv = ceil(2^32 / P) (one real division per launch instead of ~20: a u32 division is
+// ~40 instructions, and this body's time is its instruction count)
+// (P == 1: the reciprocal does not fit 32 bits; the quotient is k)
+__device__ __forceinline__ uint32_t rxm_div(uint32_t k, uint32_t P, uint32_t inv) { return P > 1 ? (uint32_t)(((uint64_t)k * inv) >> 32) : k; }
+
 // what the records [0, k) of an endless steady pattern took: k = q * P + r
-__device__ __forceinline__ void rxm_cyc(const rx_lds_multi& M, uint32_t P, uint32_t k, uint32_t* pk, uint32_t* tl, uint32_t* by) {
-  const uint32_t q = k / P, r = k - q * P;
+__device__ __forceinline__ void rxm_cyc(const rx_lds_multi& M, uint32_t P, uint32_t inv, uint32_t k, uint32_t* pk, uint32_t* tl, uint32_t* by) {
+  const uint32_t q = rxm_div(k, P, inv), r = k - q * P;
   *pk = q * M.qpk[P] + M.qpk[r];
   *tl = q * M.qtl[P] + M.qtl[r];
   *by = q * M.qby[P] + M.qby[r];
@@ -143,6 +148,9 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   const uint32_t cap = (uint32_t)cap64, mask = cap - 1u, head = (uint32_t)head64;
   const uint32_t Lr = ((uint32_t)lim - head) & mask;  // ring bytes between my head and the sender's tail
   const bool idle = Lr == 0;
+  // (k / P as a multiplication: exact for k * P < 2^32; k <= 4096 + RXM_PFX here, P <= 512)
+  const uint32_t invP = P > 1 ? (uint32_t)(0xFFFFFFFFu / P) + 1u : 0u;
+  auto divP = [&](uint32_t k) -> uint32_t { return rxm_div(k, P, invP); };
   if (tid == 0) {
     s_bad = 0;
     s_vj = RXM_NONE;
@@ -200,7 +208,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     const uint32_t cap_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)cap);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ring_u, 0, cap_u, 0x00020000);
     if (have) {
-      const uint32_t qi = i_mine / P;
+      const uint32_t qi = divP(i_mine);
       ri_mine = i_mine - qi * P;
       xe = qi * SP + M.pre[ri_mine];
       ee = M.pat[ri_mine];
@@ -241,7 +249,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     __syncthreads();
     if (have && n_mine != M.npat[ri_mine]) s_bad = 1;  // periodic in the encoded size but not in the payload size
     // the first record that leaves no read open behind it (F), among the first RXM_PFX records
-    if (tid < RXM_PFX && tid < V && M.npat[tid % P] >= RXM_RESET) atomicMin(&s_F, tid);
+    if (tid < RXM_PFX && tid < V && M.npat[tid - divP(tid) * P] >= RXM_RESET) atomicMin(&s_F, tid);
     __syncthreads();
     if (s_bad) reason = 3;
   }
@@ -276,7 +284,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     first_done = s_first;  // RXM_NONE: no slice completes in the prefix region (then it is the whole drain)
     uint32_t my_pk = 0, my_tl = 0, my_by = 0;
     if (mine) {
-      const uint32_t q = tid / P, r = tid - q * P;
+      const uint32_t q = divP(tid), r = tid - q * P;
       const uint32_t x = q * SP + M.pre[r];
       const bool in_first = odd_open && tid <= first_done;
       const rxf_layout L = rxf_lay(n_t, s_in, (head + x + 8u) & mask, cap, in_first ? s0 : RXF_MINRD,
@@ -358,7 +366,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   // ---- 5. the record whose payload crosses the ring end (behind the prefix region), totals, room
   // read state in front of record i, its payload size
   auto state_of = [&](uint32_t i, uint32_t* n_out) -> uint32_t {
-    const uint32_t r = i % P;
+    const uint32_t r = i - divP(i) * P;
     *n_out = M.npat[r];
     return i < NF ? (uint32_t)M.as[i] : (uint32_t)M.sss[r];
   };
@@ -366,8 +374,8 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   // what records [0, i) took, NF <= i <= V
   auto before = [&](uint32_t i, uint32_t* pk, uint32_t* tl, uint32_t* by) {
     uint32_t a_pk, a_tl, a_by, b_pk, b_tl, b_by;
-    rxm_cyc(M, P, i, &a_pk, &a_tl, &a_by);
-    rxm_cyc(M, P, NF, &b_pk, &b_tl, &b_by);
+    rxm_cyc(M, P, invP, i, &a_pk, &a_tl, &a_by);
+    rxm_cyc(M, P, invP, NF, &b_pk, &b_tl, &b_by);
     const bool past = w_rec != RXM_NONE && i > w_rec;
     *pk = PS_pk + (a_pk - b_pk) + (past ? d_sg << 16 : 0u);
     *tl = PS_tl + (a_tl - b_tl) + (past ? d_tl : 0u);
@@ -387,10 +395,10 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
       if (w >= NF && w < V) {
         const uint32_t n = M.npat[lo], s = M.sss[lo];
         const rxf_layout La = rxf_lay(n, s, (head + q * SP + M.pre[lo] + 8u) & mask, cap, RXF_MINRD, false, ts);
-        const rxf_layout Lb = rxf_lay(n, s, 0u, 0x80000000u, RXF_MINRD, false, ts);
+        // (what this position takes in a ring without an end: the difference of two table entries)
         w_rec = w;
-        d_sg = La.nsg - Lb.nsg;
-        d_tl = La.ntl - Lb.ntl;
+        d_sg = La.nsg - ((M.qpk[lo + 1] - M.qpk[lo]) >> 16);
+        d_tl = La.ntl - (M.qtl[lo + 1] - M.qtl[lo]);
       }
     }
     if (V > NF) before(V, &tot_pk, &tot_tl, &tot_by);
@@ -467,6 +475,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   }
   __syncthreads();
   if (!s_last) return 0;
+  const uint64_t t_arrived = __builtin_amdgcn_s_memtime();
   if (s_any) {  // (uniform)
     if (tid == 0) {
       // (the slot of this workgroup's own reason if it has one, the probe's otherwise: another workgroup's records)
@@ -482,7 +491,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     const uint32_t back = tid + r * RXM_THREADS;  // the newest GRDMA_RX_HIST records
     if (back < V) {
       const uint32_t i = V - 1 - back;
-      c->rx_hist[(uint32_t)((hc + i) % GRDMA_RX_HIST)] = M.pat[i % P];
+      c->rx_hist[(uint32_t)((hc + i) % GRDMA_RX_HIST)] = M.pat[i - divP(i) * P];
     }
   }
   // ---- 8. credit (pair.cc:276-284), state, result: thread 0 (as rxf_body, per-record values from the tables)
@@ -493,19 +502,32 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     const uint32_t o_h1 = c->rx_h1;
     const uint64_t o_seq = res->seq;
     grdma_hostline* const line = c->line;
-    const uint32_t tot_n = (V / P) * M.qn[P] + M.qn[V % P];  // payload bytes of the drain
+    const uint64_t t_loaded = __builtin_amdgcn_s_memtime() + (o_seq & 0);  // (behind the loads above)
+    const uint32_t tot_n = divP(V) * M.qn[P] + M.qn[V - divP(V) * P];  // payload bytes of the drain
     auto enc_end = [&](uint32_t i) -> uint64_t {  // ring bytes consumed once record i is finished
-      const uint32_t qi = i / P, ri = i - qi * P;
+      const uint32_t qi = divP(i), ri = i - qi * P;
       return (uint64_t)qi * SP + M.pre[ri] + M.pat[ri];
     };
     const uint64_t T = cap64 / 2, Ctot = Lr;
     uint64_t base = 0, thr = T - irs0, credit = 0, credit_head = 0;
     bool crossed = false;
     while (Ctot >= thr) {
-      uint32_t lo = 0, hi = V - 1;  // first record whose running consumption (after its last step) reaches thr
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (enc_end(mid) >= thr) hi = mid; else lo = mid + 1;
+      // first record whose running consumption (after its last step) reaches thr: enc_end(i) = E(i + 1) with
+      // E(k) = (k / P) SP + pre[k mod P] (pre[P] = SP), so the period comes from one division and the position from
+      // a search over the pattern's prefix in LDS
+      uint32_t lo;
+      {
+        const uint32_t t32 = (uint32_t)thr;  // (thr <= Ctot < 2^31 here)
+        const uint32_t qk = t32 / SP, r = t32 - qk * SP;
+        uint32_t a = 0, b = P;  // the smallest j in [1, P] with pre[j] >= r (r > 0), or j = 0 (r == 0)
+        if (r == 0) b = 0;
+        while (b - a > 1) {
+          const uint32_t mid = (a + b) >> 1;
+          if (M.pre[mid] >= r) b = mid; else a = mid;
+        }
+        const uint32_t k = qk * P + b;  // smallest k with E(k) >= thr
+        lo = k ? k - 1 : 0;
+        if (lo > V - 1) lo = V - 1;
       }
       uint32_t n;
       const uint32_t s_in = state_of(lo, &n);
@@ -526,6 +548,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
       crossed = true;
       thr = base + T;
     }
+    const uint64_t t_credit = __builtin_amdgcn_s_memtime();
     const uint64_t irs = crossed ? Ctot - base : irs0 + Ctot;
     const uint64_t nh = (head64 + Lr) & (cap64 - 1);
     if (short_len) {
@@ -557,7 +580,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     c->rx_slice_idx = slice_idx0 + nsl_final;
     c->rx_hist_count = hc + V;
     {
-      const uint32_t rl = (V - 1) % P;
+      const uint32_t rl = (V - 1) - divP(V - 1) * P;
       c->rx_h1 = M.pat[rl];
       c->rx_h2 = V >= 2 ? M.pat[rl ? rl - 1 : P - 1] : o_h1;
     }
@@ -593,6 +616,9 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     res->dbg[8] = P;
     res->dbg[9] = 0xFA57;  // this stamp set comes from a steady-state body
     res->dbg[10] = nwg;
+    res->dbg[11] = t_arrived - t_begin;
+    res->dbg[12] = t_loaded - t_begin;
+    res->dbg[13] = t_credit - t_begin;
     res->pad1++;
     res->dbg[1] = __builtin_amdgcn_s_memtime();
     atomicAdd(&g_rx_fast_drains[0], 1ull);

@@ -9,13 +9,19 @@ OUT=$R/oracle/_build
 mkdir -p $OUT/emu_obj
 FLAGS="-O1 -g -fno-omit-frame-pointer -std=c++17 -fPIC -pthread -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes -I$R/tests/cc -I$R/tests/cc/emu_include"
 objs=""
+pids=""
 for f in grdma_kernels.hip grdma_rx_plan.hip grdma_tx_fast.hip grdma_zc.hip grdma_h2.hip grdma_pair.hip grdma_host.cc grdma_endpoint.cc grdma_stats_time.cc; do
   o=$OUT/emu_obj/${f%.*}.o
+  rm -f $o
   $CXX $FLAGS -x c++ -c $R/grpc-rdma_amd/csrc/$f -o $o &
+  pids="$pids $!"
   objs="$objs $o"
 done
 $CXX $FLAGS -c $R/tests/cc/emu_link_stubs.cc -o $OUT/emu_obj/link_stubs.o &
+pids="$pids $!"
 $CXX $FLAGS -c $R/tests/cc/emu_segv.cc -o $OUT/emu_obj/segv.o &
-wait
+pids="$pids $!"
+# (a compile that fails must fail the build: a stale library would otherwise be tested in its place)
+for p in $pids; do wait $p || { echo "build_emu.sh: a source failed to compile" >&2; rm -f $OUT/libgrdma_emu.so; exit 1; }; done
 $CXX -shared -pthread -o $OUT/libgrdma_emu.so $objs $OUT/emu_obj/link_stubs.o $OUT/emu_obj/segv.o -rdynamic
 echo "built $OUT/libgrdma_emu.so"
