@@ -284,6 +284,14 @@ __global__ __launch_bounds__(64) void k_rx_commit1(grdma_conn* c, uint64_t seq) 
     __hip_atomic_store(&c->line->rx_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// k_rx_idle: an endpoint read that found nothing and never reached the device (the host saw "no message" in the pair's
+// state line).  rdma_continue_read had allocated its 256-byte slice by then, and that slice stays in the incoming buffer
+// for the next edge (rdma_bp_posix.cc:283-287, 306-326): the read state of the connection says so, exactly as a drain
+// that ended in a would-block leaves it.
+__global__ __launch_bounds__(64) void k_rx_idle(grdma_conn* c) {
+  if (threadIdx.x == 0 && c->remain == 0 && c->leftover_cap == 0) c->leftover_cap = GRDMA_MIN_READ_SLICE;
+}
+
 struct ring_probe {
   uint64_t n;      // header value at `pos`
   bool ready;      // header valid and footer tag present
@@ -379,6 +387,11 @@ __attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_commit(grdma_co
 
 __attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_commit1(grdma_conn* d_conn, uint64_t seq, hipStream_t s) {
   hipLaunchKernelGGL(k_tx_commit1, dim3(1), dim3(64), 0, s, d_conn, seq);
+  return hipGetLastError();
+}
+
+__attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_idle(grdma_conn* d_conn, hipStream_t s) {
+  hipLaunchKernelGGL(k_rx_idle, dim3(1), dim3(64), 0, s, d_conn);
   return hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ hipError_t grdma_launch_tx_plan_zc(const grdma_zc_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_tx_commit(grdma_conn* const*, const uint64_t*, uint32_t, hipStream_t);
 hipError_t grdma_launch_tx_commit1(grdma_conn*, uint64_t, hipStream_t);
 hipError_t grdma_launch_rx_commit1(grdma_conn*, uint64_t, hipStream_t);
+hipError_t grdma_launch_rx_idle(grdma_conn*, hipStream_t);
 hipError_t grdma_launch_copy(const grdma_plan* const*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_apply(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
@@ -233,6 +234,7 @@ struct grdma_pair {
   void* ipc_conn = nullptr;             // base of the peer's grdma_conn mapping
   grdma_status_report* remote_status = nullptr;  // peer's status_recv inside ipc_conn
   uint32_t serial = 0;                  // "queue pair number" of this pair in its process
+  bool ipc_export_failed = false;       // hipIpcGetMemHandle refused: only peers in this process can connect
   hipStream_t stream = nullptr;
   int wakeup_fd = -1;                // grpc_wakeup_fd of the pair (pair.h:187): an eventfd
   std::mutex fd_mu;                  // creation of wakeup_fd
@@ -748,6 +750,14 @@ void pool_free(void* ptr, size_t n, int kind) {
 }
 }  // namespace
 
+namespace {
+// pairs that have exported an address, by serial ("queue pair number"): a peer that turns out to live in THIS process
+// (client and server of one test binary: what gRPC's own end2end tests are) is looked up here instead of being
+// mapped through an IPC handle, which cannot be opened where it was made
+std::mutex g_exported_mu;
+std::unordered_map<uint32_t, grdma_pair*> g_exported;
+}  // namespace
+
 grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
   if (require_ctx()) return nullptr;
   // ring_buffer.cc:22-24
@@ -823,6 +833,11 @@ grdma_pair* grdma_pair_create(uint64_t ring_size, int max_sge, int flags) {
 
 void grdma_pair_destroy(grdma_pair* p) {
   if (!p) return;
+  if (p->serial != 0) {
+    std::lock_guard<std::mutex> lk(g_exported_mu);
+    auto it = g_exported.find(p->serial);
+    if (it != g_exported.end() && it->second == p) g_exported.erase(it);
+  }
   if (p->stream) hipStreamSynchronize(p->stream);
   // (a queued or skipped write chain, a drain in flight: nothing of this pair's may still run when its memory goes back)
   if (p->s_tx) hipStreamSynchronize(p->s_tx);
@@ -1006,6 +1021,10 @@ int grdma_pair_export_address(grdma_pair* p, grdma_bootstrap_blob* out) {
   if (!p || !out) return fail(GRDMA_ERR_INVALID, "null argument");
   memset(out, 0, sizeof(*out));
   if (p->serial == 0) p->serial = g_pair_serial.fetch_add(1);
+  {
+    std::lock_guard<std::mutex> lk(g_exported_mu);
+    g_exported[p->serial] = p;
+  }
   out->addr.lid = (uint32_t)g_ctx.device;          // "local id": the HIP device ordinal
   out->addr.qpn = p->serial;
   out->addr.psn = (uint32_t)(((uint64_t)getpid() * 2654435761u) ^ p->serial) & 0xffffffu;  // 24 bits, like lrand48() & 0xffffff
@@ -1026,11 +1045,17 @@ int grdma_pair_export_address(grdma_pair* p, grdma_bootstrap_blob* out) {
   if (!(p->flags & GRDMA_RING_FINE_GRAINED))
     return fail(GRDMA_ERR_INVALID, "a pair exported to a remote peer must be created with GRDMA_RING_FINE_GRAINED");
   static_assert(sizeof(hipIpcMemHandle_t) == sizeof(out->ring_handle), "HIP IPC handle size");
+  // (a peer in this process never opens them; a process whose runtime cannot export memory can still serve those)
   hipIpcMemHandle_t h;
-  HIP_TRY(hipIpcGetMemHandle(&h, p->d_ring));
-  memcpy(out->ring_handle, &h, sizeof(h));
-  HIP_TRY(hipIpcGetMemHandle(&h, p->d_conn));
-  memcpy(out->conn_handle, &h, sizeof(h));
+  if (hipIpcGetMemHandle(&h, p->d_ring) == hipSuccess) memcpy(out->ring_handle, &h, sizeof(h));
+  else p->ipc_export_failed = true;
+  if (hipIpcGetMemHandle(&h, p->d_conn) == hipSuccess) memcpy(out->conn_handle, &h, sizeof(h));
+  else p->ipc_export_failed = true;
+  if (p->ipc_export_failed) {
+    (void)hipGetLastError();
+    memset(out->ring_handle, 0, sizeof(out->ring_handle));
+    memset(out->conn_handle, 0, sizeof(out->conn_handle));
+  }
   return 0;
 }
 
@@ -1055,8 +1080,33 @@ int grdma_pair_connect_remote(grdma_pair* p, const grdma_bootstrap_blob* peer) {
                 (unsigned long long)peer->status_off, peer->wire_off);
   if (!(p->flags & GRDMA_RING_FINE_GRAINED))
     return fail(GRDMA_ERR_INVALID, "a pair connected to a remote peer must be created with GRDMA_RING_FINE_GRAINED");
-  if (peer->pid == (uint64_t)getpid())
-    return fail(GRDMA_ERR_INVALID, "peer lives in this process: use grdma_pair_connect (an IPC handle cannot be opened where it was made)");
+  if (peer->pid == (uint64_t)getpid()) {
+    // The peer lives in this process (an IPC handle cannot be opened where it was made): its half of
+    // grdma_pair_connect.  Both ends come through here, each for itself, possibly at the same time on two threads;
+    // the loop-back link's in-order queue is the stream of the end with the smaller serial on both sides.
+    grdma_pair* other = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(g_exported_mu);
+      auto it = g_exported.find(peer->addr.qpn);
+      if (it != g_exported.end()) other = it->second;
+    }
+    if (other == nullptr || other == p)
+      return fail(GRDMA_ERR_INVALID, "peer address names pair %u of this process, which does not exist", peer->addr.qpn);
+    c.peer_ring = other->d_ring;
+    c.peer_status = reinterpret_cast<grdma_status_report*>(reinterpret_cast<uint8_t*>(other->d_conn) + offsetof(grdma_conn, status_recv));
+    c.peer_wire = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(other->d_conn) + offsetof(grdma_conn, wire_recv) +
+                                              offsetof(grdma_wire_report, wire_tail));
+    c.peer_line = other->line;
+    c.line_remote = 0;
+    c.status = GRDMA_PAIR_CONNECTED;
+    HIP_TRY(hipMemcpy(p->d_conn, &c, sizeof(c), hipMemcpyHostToDevice));
+    p->peer = other;
+    if (other->serial != 0 && other->serial < p->serial) p->stream = other->stream;
+    p->status.store(GRDMA_PAIR_CONNECTED);
+    return 0;
+  }
+  if (peer->ring_handle[0] == 0 && memcmp(peer->ring_handle, peer->ring_handle + 1, sizeof(peer->ring_handle) - 1) == 0)
+    return fail(GRDMA_ERR_INVALID, "the peer could not export its ring (no IPC handle in its address)");
   hipIpcMemHandle_t h;
   void* ring = nullptr;
   void* conn = nullptr;
@@ -2239,6 +2289,19 @@ int grdma_endpoint_read_submit(grdma_pair* p, uint64_t max_reads) {
   return 0;
 }
 
+// An endpoint read that would block without a drain having been submitted for it (the host saw no message): the
+// connection's read state takes note, in stream order with the drains (k_rx_idle).  Latency-mode pairs, whose drains
+// go through the resident engine's mailbox, do not: their next read is sized afresh.
+int grdma_endpoint_read_idle(grdma_pair* p) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || !p->async) return fail(GRDMA_ERR_INVALID, "not an asynchronous endpoint (grdma_endpoint_set_async)");
+  if (p->latency) return 0;
+  std::lock_guard<std::mutex> lk(p->rx_mu);
+  if (p->rx_inflight.load(std::memory_order_acquire) >= 0) return 0;  // (a drain is in flight: it will find what there is)
+  HIP_TRY(grdma_launch_rx_idle(p->d_conn, p->s_rx));
+  return 0;
+}
+
 int64_t grdma_endpoint_read_test(grdma_pair* p, grdma_read_slice* slices, uint64_t slices_cap, int* would_block,
                                  grdma_window** window) {
   if (!p || !slices || !window) return fail(GRDMA_ERR_INVALID, "null argument");
@@ -2278,6 +2341,19 @@ int grdma_endpoint_drain_state(grdma_pair* p) {
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
   if (p->rx_inflight.load(std::memory_order_acquire) < 0) return 0;
   return drain_complete(p) ? 2 : 1;
+}
+
+// 1 while an asynchronous Send or drain of this pair is on the device and has not completed yet: what an event loop
+// that wants to run a connection to quiescence waits for (the edges themselves are grdma_endpoint_readable / _writable)
+int grdma_endpoint_busy(grdma_pair* p) {
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (p->rx_inflight.load(std::memory_order_acquire) >= 0 && !drain_complete(p)) return 1;
+  if (p->tx_inflight.load(std::memory_order_acquire)) {
+    const uint64_t seen = p->tx_by_engine ? __atomic_load_n(&p->h->txres.seq, __ATOMIC_ACQUIRE)
+                                          : __atomic_load_n(&p->line->tx_seq, __ATOMIC_ACQUIRE);
+    if (seen < p->tx_expect) return 1;
+  }
+  return 0;
 }
 
 int grdma_endpoint_free_windows(grdma_pair* p) {
@@ -2682,7 +2758,13 @@ int job_enqueue_schedule_instrumented(grdma_stream_job* j, hipStream_t s) {
     const void* gplans = j->d_plans;
     const void* wplans = j->d_plans + n * (1 + (t & 1));
     if (t == 0) {
-      HIP_TRY(job_launch_tx_plan(j, k, 0, n, s));  // k_tx_index + k_tx_plan_job
+      if (j->rx_multi) {  // k_tx_index + the Send priced by k_plan_pair_mw's small workgroups (as the graph does)
+        HIP_TRY(grdma_launch_tx_index(j->d_txf, n, job_index_blocks(j), s));
+        HIP_TRY(launch(grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_tx_multi_groups()), grdma_kernel_threads(0), nullptr,
+                       j->d_txop + k * n, j->d_txf, 0u));
+      } else {
+        HIP_TRY(job_launch_tx_plan(j, k, 0, n, s));  // k_tx_index + k_tx_plan_job
+      }
       if (int rc = mark(0)) return rc;
     }
     if (t == 0 || !j->fuse_ag) {
@@ -2971,6 +3053,10 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
     hipGraphNode_t pi = nullptr;
     hipError_t e2 = add(&pi, f_txi, dim3(job_index_blocks(j), n), grdma_tx_index_threads(), j->d_txf, deps);
     if (e2 != hipSuccess) return e2;
+    // (the first Send of a step priced by the small workgroups of the planner pair too: k_plan_pair_mw with no drain)
+    if (j->rx_multi && j->pipeline && j->pair_job && !j->fuse)
+      return add3(&P[t], grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_tx_multi_groups()), grdma_kernel_threads(0), nullptr, txop,
+                  j->d_txf, {pi}, 0u);
     return add2(&P[t], f_txj, dim3(n), grdma_tx_plan_job_threads(), txop, j->d_txf, {pi});
   };
   // X[t] = the receive plan of round t: k_rx_plan_job -- the steady-state body, the general planner behind it

@@ -310,8 +310,12 @@ int grdma_endpoint_write_quiesce(grdma_pair* p);  /* nothing of this pair's is l
 int grdma_endpoint_read_submit(grdma_pair* p, uint64_t max_reads);
 int64_t grdma_endpoint_read_test(grdma_pair* p, grdma_read_slice* slices, uint64_t slices_cap, int* would_block,
                                  grdma_window** window);
+int grdma_endpoint_read_idle(grdma_pair* p);      /* an endpoint read found nothing and submitted no drain: the 256-byte
+                                                     slice it allocated stays for the next edge (rdma_bp_posix.cc:283-287) */
 int grdma_endpoint_readable(grdma_pair* p);
 int grdma_endpoint_writable(grdma_pair* p);
+int grdma_endpoint_busy(grdma_pair* p);           /* 1: a Send or a drain of this pair is on the device and has not
+                                                     completed yet (an event loop running a connection to quiescence) */
 int grdma_endpoint_drain_state(grdma_pair* p);    /* 0: no drain in flight, 1: in flight, 2: completed, not collected
                                                      (a drain may have been posted by the in-process peer's sender
                                                      on behalf of an armed read) */

@@ -57,7 +57,7 @@
 
 namespace grdma_ep {
 
-constexpr uint64_t kReadAhead = 1024;    // endpoint reads performed per device pass
+constexpr uint64_t kReadAhead = 1024;    // endpoint reads performed per device pass (GRPC_RDMA_HIP_READ_AHEAD: fewer)
 constexpr size_t kWriteWindow = 4000;    // slices handed to one grdma_endpoint_write_begin (the ABI takes 4095)
 constexpr size_t kSendBufferMin = 8192;  // shorter writes go to the pair as they are (a unary-sized write rides inline
                                          // in the latency engine's command: nothing to gain from a copy in front of it)
@@ -108,7 +108,12 @@ struct core {
   size_t ahead_next = 0;
   grdma_window* ahead_win = nullptr;   // the receive window they lie in (this object's reference)
   bool ahead_copy = false;             // hand them out as copies (every other window is still held by the transport)
+  bool open_read_noted = false;        // the pair knows that a read is open (a drain ended in a would-block, or
+                                       // grdma_endpoint_read_idle told it): the next read fills that 256-byte slice first
   uint64_t arm_reads = 0;              // != 0: keep a read armed with the pair while waiting (latency mode)
+  uint64_t read_ahead = kReadAhead;    // endpoint reads per device pass: GRPC_RDMA_HIP_READ_AHEAD, 1 ... kReadAhead
+                                       // (1 = every read sized and filled at the moment the transport asks for it, as
+                                       // rdma_continue_read / rdma_do_read do: what the reference-trace test runs with)
 
   void init(host_t* host, grdma_pair* p) {
     h = host;
@@ -117,6 +122,10 @@ struct core {
     const char* e = getenv("GRPC_RDMA_HIP_SEND_BUFFER_KB");
     const long kb = e ? atol(e) : 4096;
     sbuf_cap = kb > 0 ? (size_t)kb * 1024 : 0;
+    if (const char* ra = getenv("GRPC_RDMA_HIP_READ_AHEAD")) {
+      const long v = atol(ra);
+      if (v >= 1 && (uint64_t)v <= kReadAhead) read_ahead = (uint64_t)v;
+    }
   }
   // rdma_free: nothing of the transport's may be referenced afterwards
   void release() {
@@ -199,20 +208,26 @@ struct core {
         }
         ahead.resize((size_t)n);
         ahead_next = 0;
+        open_read_noted = would_block != 0;  // (a drain that stopped at max_reads left no read open)
         if (n > 0) {
           ahead_win = win;
           ahead_copy = !any_window_free();
           // more has arrived meanwhile?  Then the next drain runs on the device while this one's slices are handed
           // to the transport (it needs a window of its own; none free = it waits until this one has been released)
-          if (!ahead_copy && grdma_pair_has_message(pair) > 0) grdma_endpoint_read_submit(pair, kReadAhead);
+          if (!ahead_copy && read_ahead > 1 && grdma_pair_has_message(pair) > 0) grdma_endpoint_read_submit(pair, read_ahead);
           continue;
         }
         grdma_window_unref(win);
         return read_would_block();  // the drain found no complete record
       }
       // nothing pending.  A record behind head_ (or a half-read one)?  That is a host load.
-      if (grdma_pair_has_message(pair) <= 0) return read_would_block();
-      const int rc = grdma_endpoint_read_submit(pair, kReadAhead);
+      if (grdma_pair_has_message(pair) <= 0) {
+        // rdma_continue_read has allocated its 256-byte slice by now and keeps it across the would-block (:283-287):
+        // the pair learns of it unless its last drain ended that way already
+        if (!open_read_noted && grdma_endpoint_read_idle(pair) == 0) open_read_noted = true;
+        return read_would_block();
+      }
+      const int rc = grdma_endpoint_read_submit(pair, read_ahead);
       if (rc < 0) return read_fail((std::string("Pair error, ") + grdma_last_error()).c_str());
       // (rc == 1: the transport holds slices of every window; the edge stays up and the next pass tries again)
       T::notify_on_read(h);

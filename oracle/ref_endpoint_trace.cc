@@ -11,21 +11,36 @@
 // stubbed below: an fd object that remembers the closure notify_on_read was given (the driver fires it: "the fd
 // became readable"), a slice allocator that allocates at once, errors as opaque handles.
 //
+// The SAME driver, compiled with -DGRDMA_HIP_ADAPTER over integration/rdma_hip_posix.cc + integration/ibverbs_facade
+// and linked against libgrdma_amd.so (oracle/_ref/hip_endpoint_trace; libgrdma_emu.so for the CPU suite:
+// hip_endpoint_trace_emu), replays the same operation lists on the file a maintainer SHIPS: the adapter's
+// grpc_rdma_bp_create makes both endpoints (the pair addresses exchanged over the same socketpair, both ends in this
+// process), and the driver stands in for the event engine the way the reference's engines poll the facade -- it fires
+// the readable / writable edge while a drain or a Send of the endpoint is on the device (grdma_endpoint_busy /
+// _readable / _writable), so that every operation is run to the quiescent point at which the reference's synchronous
+// endpoint stands when its call returns.  tests/test_adapter_trace.py compares the two outputs line by line.
+//
 //   ops:  S <side> <byte_idx> <seed> <n> <len_1> ... <len_n>    PairPollable::Send on the pair of endpoint <side>
 //         E <side>                                             one endpoint read on <side>: grpc_endpoint_read if none is
 //                                                              outstanding, then (if the endpoint asked for the readable
 //                                                              edge) the edge, once
 //         W <side> <seed> <n> <len_1> ... <len_n>               grpc_endpoint_write of a fresh slice buffer on <side>
 //         F <side>                                             the writable edge for the write of <side> that waits
+//         C <side>                                             grpc_endpoint_shutdown + grpc_endpoint_destroy of <side>
+//                                                              (rdma_free: Disconnect -- the peer becomes half closed)
 //   out:  S <sent>
 //         W | F <1 = the write completed, 0 = it waits for the writable edge> <readable size of the peer> <writable size>
 //               <HasPendingWrites>            ("F -" = nothing was waiting)
 //         E <-1 | bytes delivered> <crc32> <slices> <readable after> <writable of the peer after>      (-1 = would block)
+//         a read or write that FAILS prints -2 in place of the count and, behind the line, the error as the endpoint
+//         built it: "| <text> | fd <0 or 1: was GRPC_ERROR_INT_FD this endpoint's fd> | status <GRPC_ERROR_INT_GRPC_STATUS>
+//         | target <GRPC_ERROR_STR_TARGET_ADDRESS>" (rdma_annotate_error, rdma_bp_posix.cc:86-96)
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sys/socket.h>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -55,20 +70,43 @@ extern "C" void* gpr_malloc(size_t n) { return malloc(n ? n : 1); }
 extern "C" void* gpr_zalloc(size_t n) { return calloc(n ? n : 1, 1); }
 extern "C" void* gpr_realloc(void* p, size_t n) { return realloc(p, n ? n : 1); }
 extern "C" void gpr_free(void* p) { free(p); }
+#ifdef GRDMA_HIP_ADAPTER
+#include <pthread.h>
+#include <grpc/support/sync.h>
+void gpr_once_init(gpr_once* once, void (*init_function)(void)) { pthread_once(once, init_function); }  // (sync_posix.cc)
+#endif
 char* gpr_getenv(const char* name) {
   const char* v = getenv(name);
   return v ? strdup(v) : nullptr;
 }
-// ---- errors: opaque handles ----------------------------------------------------------------------------------------
-static char g_error_object;
-grpc_error_handle grpc_error_create(const char*, int, const grpc_slice&, grpc_error_handle*, size_t) {
-  return reinterpret_cast<grpc_error_handle>(&g_error_object);
+// ---- errors: what the endpoint put into them ---------------------------------------------------------------------
+struct trace_error {
+  std::string text, target;
+  intptr_t fd = -1, status = -1;
+};
+static std::string slice_text(const grpc_slice& s) {
+  return std::string(reinterpret_cast<const char*>(GRPC_SLICE_START_PTR(s)), GRPC_SLICE_LENGTH(s));
+}
+grpc_error_handle grpc_error_create(const char*, int, const grpc_slice& desc, grpc_error_handle*, size_t) {
+  trace_error* e = new trace_error();  // (never freed: a test driver)
+  e->text = slice_text(desc);
+  return reinterpret_cast<grpc_error_handle>(e);
 }
 grpc_error_handle grpc_error_do_ref(grpc_error_handle e) { return e; }
 void grpc_error_do_unref(grpc_error_handle) {}
-grpc_error_handle grpc_error_set_int(grpc_error_handle e, grpc_error_ints, intptr_t) { return e; }
-grpc_error_handle grpc_error_set_str(grpc_error_handle e, grpc_error_strs, const grpc_slice&) { return e; }
-std::string grpc_error_std_string(grpc_error_handle) { return "error"; }
+grpc_error_handle grpc_error_set_int(grpc_error_handle e, grpc_error_ints which, intptr_t v) {
+  trace_error* t = reinterpret_cast<trace_error*>(e);
+  if (which == GRPC_ERROR_INT_FD) t->fd = v;
+  if (which == GRPC_ERROR_INT_GRPC_STATUS) t->status = v;
+  return e;
+}
+grpc_error_handle grpc_error_set_str(grpc_error_handle e, grpc_error_strs which, const grpc_slice& str) {
+  if (which == GRPC_ERROR_STR_TARGET_ADDRESS) reinterpret_cast<trace_error*>(e)->target = slice_text(str);
+  return e;
+}
+std::string grpc_error_std_string(grpc_error_handle e) {
+  return e == GRPC_ERROR_NONE ? "OK" : reinterpret_cast<trace_error*>(e)->text;
+}
 // ---- the fd object of the event engine ----------------------------------------------------------------------------
 struct grpc_fd {
   int fd;
@@ -122,11 +160,13 @@ Atomic<bool> Fork::support_enabled_(false);
 void Fork::DoIncExecCtxCount() {}
 void Fork::DoDecExecCtxCount() {}
 bool ExecCtx::Flush() { return false; }
+#ifndef GRDMA_HIP_ADAPTER  // (the facade's Poller is a header over grdma_poller_*; this driver never enables it)
 namespace ibverbs {
 void Poller::AddPollable(PairPollable*) {}
 void Poller::RemovePollable(PairPollable*) {}
 void Poller::begin_polling(int) {}
 }  // namespace ibverbs
+#endif
 }  // namespace grpc_core
 grpc_core::TraceFlag grpc_rdma_trace(false, "rdma");
 
@@ -155,21 +195,84 @@ struct side_state {
   grpc_slice_buffer incoming;
   grpc_closure on_read_done;
   bool outstanding = false, completed = false, failed = false;
+  std::string read_error;
   // write side
   grpc_slice_buffer outgoing;
   grpc_closure on_write_done;
   bool write_outstanding = false, write_completed = false, write_failed = false;
+  std::string write_error;
 };
 side_state g_side[2];
+std::string error_line(side_state* s, grpc_error_handle error) {
+  const trace_error* e = reinterpret_cast<const trace_error*>(error);
+  return " | " + e->text + " | fd " + (e->fd == s->fd.fd ? "1" : "0") + " | status " + std::to_string((long long)e->status) +
+         " | target " + e->target;
+}
 void read_done(void* arg, grpc_error_handle error) {
   side_state* s = static_cast<side_state*>(arg);
   s->completed = true;
   s->failed = error != GRPC_ERROR_NONE;
+  s->read_error = s->failed ? error_line(s, error) : "";
 }
 void write_done(void* arg, grpc_error_handle error) {
   side_state* s = static_cast<side_state*>(arg);
   s->write_completed = true;
   s->write_failed = error != GRPC_ERROR_NONE;
+  s->write_error = s->write_failed ? error_line(s, error) : "";
+}
+
+// ---- what differs between the two builds: how the pair behind an endpoint is asked, and who plays the event engine
+#ifdef GRDMA_HIP_ADAPTER
+grdma_pair* hip(PairPollable* p) { return p->hip_pair(); }
+uint64_t pair_send(PairPollable* p, grpc_slice* sl, size_t n, size_t byte_idx) {
+  std::vector<grdma_slice> v(n);
+  for (size_t i = 0; i < n; i++) v[i] = grdma_slice{GRPC_SLICE_START_PTR(sl[i]), GRPC_SLICE_LENGTH(sl[i])};
+  const int64_t r = grdma_pair_send(hip(p), v.data(), n, byte_idx, GRDMA_MEM_HOST);
+  return r > 0 ? (uint64_t)r : 0;
+}
+bool pending_writes(PairPollable* p) { return grdma_pair_has_pending_writes(hip(p)) > 0; }  // partial_write_, pair.cc:303
+// The endpoint's Sends and drains are asynchronous: while one is on the device the endpoint has asked for the edge
+// that says "it has completed" -- what the event engines fire when HasMessage() / HasPendingWrites() of the facade
+// turn true.  Fired here until the operation has either completed or waits for the PEER (credit, data).
+void wait_not_busy(PairPollable* p) {
+  for (long spins = 0; grdma_endpoint_busy(hip(p)) > 0; spins++) {
+    if (spins > 200000000L) {
+      fprintf(stderr, "hip_endpoint_trace: an operation of the endpoint never completed\n");
+      _exit(5);
+    }
+  }
+}
+bool engine_sees_readable(PairPollable* p) { return grdma_endpoint_readable(hip(p)) > 0; }  // the facade's HasMessage()
+bool engine_sees_writable(PairPollable* p) { return grdma_endpoint_writable(hip(p)) > 0; }  // the facade's HasPendingWrites()
+#else
+uint64_t pair_send(PairPollable* p, grpc_slice* sl, size_t n, size_t byte_idx) { return p->Send(sl, n, byte_idx); }
+bool pending_writes(PairPollable* p) { return p->HasPendingWrites(); }
+void wait_not_busy(PairPollable*) {}  // (the reference's Sends and reads are synchronous)
+bool engine_sees_readable(PairPollable*) { return false; }  // (a read that found nothing would find nothing again)
+// what the engines' next pass acts on: HasPendingWrites() (ev_epollex_rdma_bpev_linux.cc:1116) -- with no room in the
+// peer's ring the flush it triggers sends nothing and waits again, so only a pair that can take bytes is worth firing
+bool engine_sees_writable(PairPollable* p) { return p->HasPendingWrites() && p->GetWritableSize() > 0; }
+#endif
+// Runs the operation to the quiescent point: the edge is fired as long as the event engine would see a reason to --
+// a drain or a Send that has completed on the device (the shipped endpoint), a partial write with room in the peer's
+// ring (both) -- and no longer (bounded: an edge that changes nothing is not fired for ever).
+void settle_read(side_state& s, PairPollable* p) {
+  for (int k = 0; k < 4096 && !s.completed && s.fd.on_read != nullptr; k++) {
+    wait_not_busy(p);
+    if (!engine_sees_readable(p)) break;
+    grpc_closure* c = s.fd.on_read;
+    s.fd.on_read = nullptr;
+    grpc_core::Closure::Run(DEBUG_LOCATION, c, GRPC_ERROR_NONE);
+  }
+}
+void settle_write(side_state& s, PairPollable* p) {
+  for (int k = 0; k < 4096 && !s.write_completed && s.fd.on_write != nullptr; k++) {
+    wait_not_busy(p);
+    if (!engine_sees_writable(p)) break;
+    grpc_closure* c = s.fd.on_write;
+    s.fd.on_write = nullptr;
+    grpc_core::Closure::Run(DEBUG_LOCATION, c, GRPC_ERROR_NONE);
+  }
 }
 }  // namespace
 
@@ -194,6 +297,7 @@ int main() {
     return 2;
   }
   PairPollable* pair[2] = {static_cast<PairPollable*>(g_side[0].fd.arg), static_cast<PairPollable*>(g_side[1].fd.arg)};
+  bool closed[2] = {false, false};
   char op;
   while (scanf(" %c", &op) == 1) {
     if (op == 'S') {
@@ -202,9 +306,11 @@ int main() {
       if (scanf("%d %llu %llu %llu", &side, &byte_idx, &seed, &n) != 4) return 3;
       std::vector<std::vector<uint8_t>> mem(n);
       std::vector<grpc_slice> sl(n);
+      const bool busy = g_side[side].write_outstanding || closed[side];  // (a raw Send would move a waiting write's cursor)
       for (unsigned long long i = 0; i < n; i++) {
         unsigned long long len;
         if (scanf("%llu", &len) != 1) return 3;
+        if (busy) continue;
         mem[i].resize(len ? len : 1);
         for (unsigned long long j = 0; j < len; j++) mem[i][j] = pat(seed, i, j);
         memset(&sl[i], 0, sizeof(grpc_slice));
@@ -212,17 +318,44 @@ int main() {
         sl[i].data.refcounted.length = len;
         sl[i].data.refcounted.bytes = mem[i].data();
       }
-      printf("S %llu\n", (unsigned long long)pair[side]->Send(sl.data(), n, byte_idx));
+      if (busy) {
+        printf("S busy\n");
+        continue;
+      }
+      printf("S %llu\n", (unsigned long long)pair_send(pair[side], sl.data(), n, byte_idx));
+    } else if (op == 'C') {
+      // grpc_endpoint_shutdown + grpc_endpoint_destroy (rdma_shutdown / rdma_destroy -> rdma_free, :106-164): the pair
+      // is disconnected (peer_exit in the peer's status buffer) and goes back to the pool
+      int side;
+      if (scanf("%d", &side) != 1) return 3;
+      side_state& s = g_side[side];
+      // (a read or write still outstanding would be failed by the fd's shutdown in a real engine; this driver's fd
+      // does nothing, so only an endpoint with nothing outstanding is closed)
+      if (closed[side] || s.outstanding || s.write_outstanding) {
+        printf("C busy\n");
+        continue;
+      }
+      grpc_error_handle why = GRPC_ERROR_CREATE_FROM_STATIC_STRING("endpoint closed by the driver");
+      s.ep->vtable->shutdown(s.ep, why);
+      s.ep->vtable->destroy(s.ep);
+      closed[side] = true;
+      printf("C %d\n", side);
     } else if (op == 'W' || op == 'F') {
       // W: grpc_endpoint_write of a fresh slice buffer (rdma_write -> rdma_flush: ONE Send from the cursor; what is left
       //    waits for the writable edge).  F: the writable edge for a write that waits (rdma_handle_write -> rdma_flush).
       int side;
       if (scanf("%d", &side) != 1) return 3;
       side_state& s = g_side[side];
+      if (closed[side]) return 4;
       if (op == 'W') {
         unsigned long long seed, n;
         if (scanf("%llu %llu", &seed, &n) != 2) return 3;
-        if (s.write_outstanding) return 4;  // (one write at a time: GPR_ASSERT(rdma->write_cb == nullptr))
+        if (s.write_outstanding) {  // (one write at a time, GPR_ASSERT(rdma->write_cb == nullptr): the list's author need not know)
+          for (unsigned long long i = 0, len; i < n; i++)
+            if (scanf("%llu", &len) != 1) return 3;
+          printf("W busy\n");
+          continue;
+        }
         grpc_slice_buffer_reset_and_unref(&s.outgoing);
         for (unsigned long long i = 0; i < n; i++) {
           unsigned long long len;
@@ -246,47 +379,52 @@ int main() {
         s.fd.on_write = nullptr;
         grpc_core::Closure::Run(DEBUG_LOCATION, c, GRPC_ERROR_NONE);
       }
+      settle_write(s, pair[side]);
       if (s.write_completed) s.write_outstanding = false;
-      printf("%c %d %llu %llu %d\n", op, s.write_completed ? (s.write_failed ? -2 : 1) : 0,
-             (unsigned long long)pair[1 - side]->GetReadableSize(), (unsigned long long)pair[side]->GetWritableSize(),
-             pair[side]->HasPendingWrites() ? 1 : 0);
+      if (s.write_completed && s.write_failed) {
+        printf("%c -2%s\n", op, s.write_error.c_str());
+        continue;
+      }
+      printf("%c %d %llu %llu %d\n", op, s.write_completed ? 1 : 0,
+             closed[1 - side] ? 0ull : (unsigned long long)pair[1 - side]->GetReadableSize(),
+             (unsigned long long)pair[side]->GetWritableSize(), pending_writes(pair[side]) ? 1 : 0);
     } else if (op == 'E') {
       int side;
       if (scanf("%d", &side) != 1) return 3;
       side_state& s = g_side[side];
+      if (closed[side]) return 4;
       s.completed = false;
       s.fd.on_read = nullptr;
+      static grpc_closure* pending[2] = {nullptr, nullptr};
       if (!s.outstanding) {
         s.outstanding = true;
         s.ep->vtable->read(s.ep, &s.incoming, &s.on_read_done, /*urgent=*/false);
-      } else {
-        // a read is waiting for the readable edge: deliver it
-        grpc_closure* c = nullptr;
-        std::swap(c, s.fd.on_read);
-      }
-      if (!s.completed && s.fd.on_read == nullptr && s.outstanding) {
-        // (the read above was re-armed by an earlier would-block: its closure was consumed when it ran; ask again)
       }
       if (!s.completed) {
         // the endpoint asked for the readable edge (first read, inq == 0, or a would-block): the fd is readable, once
-        static grpc_closure* pending[2] = {nullptr, nullptr};
         if (s.fd.on_read != nullptr) pending[side] = s.fd.on_read;
         grpc_closure* c = pending[side];
         pending[side] = nullptr;
         s.fd.on_read = nullptr;
         if (c != nullptr) grpc_core::Closure::Run(DEBUG_LOCATION, c, GRPC_ERROR_NONE);
+        settle_read(s, pair[side]);
         if (!s.completed && s.fd.on_read != nullptr) pending[side] = s.fd.on_read;  // would block: armed again
       }
       if (s.completed) {
         s.outstanding = false;
+        if (s.failed) {
+          printf("E -2%s\n", s.read_error.c_str());
+          continue;
+        }
         uint32_t c = 0xFFFFFFFFu;
         for (size_t i = 0; i < s.incoming.count; i++)
           c = crc32_of(GRPC_SLICE_START_PTR(s.incoming.slices[i]), GRPC_SLICE_LENGTH(s.incoming.slices[i]), c);
-        printf("E %lld %u %zu %llu %llu\n", s.failed ? -2ll : (long long)s.incoming.length, c ^ 0xFFFFFFFFu, s.incoming.count,
-               (unsigned long long)pair[side]->GetReadableSize(), (unsigned long long)pair[1 - side]->GetWritableSize());
+        printf("E %lld %u %zu %llu %llu\n", (long long)s.incoming.length, c ^ 0xFFFFFFFFu, s.incoming.count,
+               (unsigned long long)pair[side]->GetReadableSize(),
+               closed[1 - side] ? 0ull : (unsigned long long)pair[1 - side]->GetWritableSize());
       } else {
         printf("E -1 0 0 %llu %llu\n", (unsigned long long)pair[side]->GetReadableSize(),
-               (unsigned long long)pair[1 - side]->GetWritableSize());
+               closed[1 - side] ? 0ull : (unsigned long long)pair[1 - side]->GetWritableSize());
       }
     } else {
       return 3;
