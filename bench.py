@@ -261,6 +261,36 @@ def cpu_baseline(wl, ring, max_sge, target_s=12.0):
                 n_msgs, len(lens), what, ring >> 10, sec)}
 
 
+def sources_sha16():
+    """sha256 (16 hex digits) over the product's kernel and host sources: what ties a committed counter summary
+    (profiles/r0N_pmc_*.json, tools/pmc_summary.py) to the library a bench run is timing."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "grpc-rdma_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_summary_for(ring_kb):
+    """The newest committed counter summary for this ring size and whether it was collected from the sources this
+    run is timing: -> (path or None, summary dict or None, stale: str or None)."""
+    for rnd in ("r04", "r03", "r02"):
+        p = os.path.join(ROOT, "profiles", "%s_pmc_ring%dm_summary.json" % (rnd, ring_kb // 1024))
+        if os.path.exists(p):
+            try:
+                d = json.load(open(p))
+            except Exception:
+                return p, None, "unreadable"
+            have, want = d.get("sources_sha16"), sources_sha16()
+            if have != want:
+                return p, None, "collected from other sources (%s, this run %s): not used" % (have, want)
+            return p, d, None
+    return None, None, "no counter summary committed"
+
+
 def measure_rtt(g, iters=100000, warmup=2000):
     """Unary ping-pong, 64-byte payload both ways, 1 connection, 4 MiB rings in HBM, host
     in the loop where gRPC's consumer is (host slices in, host-visible slices out),
@@ -458,7 +488,8 @@ def main():
         # in its barrier.
         args.no_extra_legs = True
         args.no_small_ring = True
-        args.conns = 1
+        # (the BASELINE configs[3] leg stays: --conns connections per rank -- 32 x 8 GPUs = 256 -- of 64 KiB messages,
+        # every rank its own share, no data-path collective; every rank runs it, its barriers are the contract's)
 
     if args.armed_rtt_only or args.rtt_only:  # a child of rtt_subprocess: no torch, one leg, one JSON line
         import __graft_entry__ as ge
@@ -782,12 +813,11 @@ def main():
     achieved = per_launch / (classes[dom]["us_per_launch"] * 1e-6) / 1e9
     kname = "k_rx_apply" if dom == "rx_apply" else "k_copy"
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_ring%dm_summary.json" % (args.ring_kb // 1024))
-    if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_ring%dm_summary.json" % (args.ring_kb // 1024))
-    if os.path.exists(pmc) and args.msgs == 256 and args.wire == "staged":
+    pmc, pmc_d, pmc_stale = pmc_summary_for(args.ring_kb)
+    pmc_usable = pmc_d is not None and args.msgs == 256 and args.wire == "staged"
+    if pmc_usable:
         try:
-            k = json.load(open(pmc))["kernels"][kname]
+            k = pmc_d["kernels"][kname]
             # one FULL launch against the algorithmic bytes of one full launch (the plain mean also counts the
             # short last round of a step and the warm-ups)
             traffic = k.get("hbm_traffic_bytes_full_size_launch", k["hbm_traffic_bytes"])
@@ -797,7 +827,9 @@ def main():
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": (os.path.relpath(pmc, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                   "command, committed; NOT re-measured in this run)") if traffic is not None else None,
+                                   "command, committed, collected from these sources: sources_sha16 %s; NOT re-measured "
+                                   "in this run)" % sources_sha16()) if traffic is not None
+                else ("none: " + (pmc_stale or "not the profiled configuration")),
                 "bytes_per_launch": int(per_launch),
                 "us_per_launch": round(classes[dom]["us_per_launch"], 2)}
     # The default schedule runs the scatter of round t and the gather of round t + 1 as ONE launch (k_rx_apply_gather):
@@ -816,9 +848,9 @@ def main():
         per_launch_sg = fused_bytes / sg["launches"]
         ach = per_launch_sg / (sg["us_per_launch"] * 1e-6) / 1e9
         traffic_sg = None
-        if os.path.exists(pmc) and args.msgs == 256 and args.wire == "staged":
+        if pmc_usable:
             try:
-                k = json.load(open(pmc))["kernels"]["k_rx_apply_gather"]
+                k = pmc_d["kernels"]["k_rx_apply_gather"]
                 traffic_sg = k.get("hbm_traffic_bytes_full_size_launch")
             except Exception:
                 traffic_sg = None
@@ -832,8 +864,10 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic_sg,
                     "traffic_source": (os.path.relpath(pmc, ROOT) + " (hbm_traffic_bytes_full_size_launch: rocprofv3 --pmc "
                                        "FETCH_SIZE / WRITE_SIZE passes of this command, mean over the full-size launches "
-                                       "-- %d B algorithmic for one of those; committed, NOT re-measured in this run)"
-                                       % (5 * max(chunks))) if traffic_sg is not None else None,
+                                       "-- %d B algorithmic for one of those; committed, collected from these sources: "
+                                       "sources_sha16 %s; NOT re-measured in this run)"
+                                       % (5 * max(chunks), sources_sha16())) if traffic_sg is not None
+                    else ("none: " + (pmc_stale or "not the profiled configuration")),
                     "bytes_per_launch": int(per_launch_sg), "us_per_launch": round(sg["us_per_launch"], 2),
                     "launches_per_step": sg["launches"],
                     "measured": "HIP events around every launch of the timed schedule, enqueued in the graph's order on "
@@ -861,7 +895,7 @@ def main():
         top_s = max(sk, key=lambda k: sk[k]["share_of_kernel_time"])
         roofline["dominant_by_time_in_order_pass"] = roofline["dominant_by_time"]
         roofline["dominant_by_time"] = {
-            "kernel": top_s + {"plan_pair": " (k_plan_pair_job)", "scatter_gather": " (k_rx_apply_gather)"}.get(top_s, ""),
+            "kernel": top_s + {"plan_pair": " (k_plan_pair_mw)", "scatter_gather": " (k_rx_apply_gather)"}.get(top_s, ""),
             "us_per_launch": sk[top_s]["us_per_launch"], "share_of_kernel_time": sk[top_s]["share_of_kernel_time"],
             "planner_share_of_kernel_time": round(sum(sk[k]["share_of_kernel_time"] for k in ("tx_plan", "plan_pair", "rx_plan")
                                                       if k in sk), 3),
@@ -897,6 +931,13 @@ def main():
                                "(BASELINE.json configs[2])",
                    "msgs_per_step": args.msgs, "slices_per_msg": wl.slices_per_msg,
                    "ring_kib": args.ring_kb, "max_sge": args.max_sge, "wire": args.wire,
+                   "knobs_note": ("the ring size is the reference's own knob (GRPC_RDMA_RING_BUFFER_SIZE_KB; its bandwidth "
+                                  "plots sweep it); max_sge %d is the slices ONE Send's gather kernel takes -- no HCA offers "
+                                  "that many scatter-gather entries (30 on mlx5), so a NIC-backed wire would post more, "
+                                  "smaller Sends.  The same workload at the reference's DEFAULT knobs (4 MiB ring, "
+                                  "max_sge 30) is value_ring4096_sge30 -- an order of magnitude below `value` -- with the "
+                                  "reference's CPU codec at those knobs beside it (cpu_baseline_ring4096_sge30)"
+                                  % args.max_sge),
                    "schedule": schedule,
                    "rounds_per_step": rounds, "connections_per_gpu": 1,
                    "stages": "gather+encode, wire, ready-detect, decode+scatter+zero, credit"},

@@ -243,8 +243,8 @@ struct grpc_rdma {  // rdma_bp_posix.cc:45-88
   grpc_endpoint base;  // must be first (endpoint.h:112-114)
   int fd;
   std::atomic<int> refcount;
-  bool shutdown;
-  grpc_error_handle shutdown_error;
+  std::atomic<bool> shutdown;
+  grpc_error_handle shutdown_error;  // (written before `shutdown` is set, read after it has been seen set)
   grdma_pair* pair;
   bool enable_poller;
   grdma_ep::core<mirror_traits> core;
@@ -267,13 +267,17 @@ grpc_error_handle mirror_traits::annotate(grpc_rdma* rdma, const char* msg) {  /
     src->target_address = rdma->peer_string;
     return src;
   }
+// Any number of threads run grdma_pollset_work while another one may shut the endpoint down: the flag is armed FIRST
+// and the shutdown switch looked at afterwards, so that either rdma_shutdown's exchange finds the armed flag or this
+// thread finds the switch -- whoever takes the flag back runs the closure with the shutdown error, exactly once
+// (what grpc_fd's lock-free event does for notify_on vs. shutdown).
 void mirror_traits::notify_on_read(grpc_rdma* rdma) {
-    if (rdma->shutdown) rdma_handle_read(rdma, rdma->shutdown_error);
-    else rdma->read_armed = true;
+    rdma->read_armed.store(true, std::memory_order_seq_cst);
+    if (rdma->shutdown.load(std::memory_order_seq_cst) && rdma->read_armed.exchange(false)) rdma_handle_read(rdma, rdma->shutdown_error);
   }
 void mirror_traits::notify_on_write(grpc_rdma* rdma) {
-    if (rdma->shutdown) rdma_handle_write(rdma, rdma->shutdown_error);
-    else rdma->write_armed = true;
+    rdma->write_armed.store(true, std::memory_order_seq_cst);
+    if (rdma->shutdown.load(std::memory_order_seq_cst) && rdma->write_armed.exchange(false)) rdma_handle_write(rdma, rdma->shutdown_error);
   }
 bool mirror_traits::is_shutdown(grpc_rdma* rdma) { return rdma->shutdown; }
 void mirror_traits::ref(grpc_rdma* rdma) { rdma->refcount.fetch_add(1); }
@@ -291,9 +295,9 @@ void rdma_write(grpc_endpoint* ep, grpc_slice_buffer* buf, grpc_closure* cb, voi
 
 void rdma_shutdown(grpc_endpoint* ep, grpc_error_handle why) {  // :106-110
   grpc_rdma* rdma = reinterpret_cast<grpc_rdma*>(ep);
-  if (!rdma->shutdown) {
-    rdma->shutdown = true;
+  if (!rdma->shutdown.load()) {
     rdma->shutdown_error = why ? why : GRPC_ERROR_CREATE_FROM_STATIC_STRING("Endpoint shutdown");
+    rdma->shutdown.store(true, std::memory_order_seq_cst);
     // grpc_fd_shutdown: pending notify_on_* closures run with the error
     rdma->refcount.fetch_add(1);
     if (rdma->read_armed.exchange(false)) rdma_handle_read(rdma, rdma->shutdown_error);

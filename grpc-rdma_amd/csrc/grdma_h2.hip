@@ -78,21 +78,41 @@ static bool h2_chunks_prepare(grdma_h2_parser* p, uint64_t ev_cap, hipStream_t s
       return false;
     if (hipMemsetAsync(p->d_chunks, 0, sizeof(grdma_h2_chunks), st) != hipSuccess) return false;
   }
-  if (hipStreamSynchronize(st) != hipSuccess) return false;
+  // The larger segment first, then the old one goes -- behind every deframing call that may still read it (another
+  // pipe of this parser may run on another stream: the device is drained, this is a resize, not a hot path).  A
+  // failure leaves the parser WITHOUT chunk buffers (capacity 0, chunks off) rather than with a control block that
+  // points at freed memory.
+  grdma_h2_event* bigger = nullptr;
+  if (hipMalloc((void**)&bigger, sizeof(grdma_h2_event) * need) != hipSuccess) {
+    (void)hipGetLastError();
+    p->ev_tmp_cap = 0;
+    p->chunks_want = 0;
+    return false;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    hipFree(bigger);
+    p->ev_tmp_cap = 0;
+    p->chunks_want = 0;
+    return false;
+  }
   if (p->d_ev_tmp) hipFree(p->d_ev_tmp);
-  p->d_ev_tmp = nullptr;
-  if (hipMalloc((void**)&p->d_ev_tmp, sizeof(grdma_h2_event) * need) != hipSuccess) return false;
+  p->d_ev_tmp = bigger;
   p->ev_tmp_cap = need;
   // the host-owned words of the control block (the counters stay)
   struct { grdma_h2_stream_dev* tabs; grdma_h2_event* ev_tmp; uint64_t ev_total; uint32_t slots, pad; } tail =
       {p->d_tabs, p->d_ev_tmp, need, p->slots, 0};
   static_assert(offsetof(grdma_h2_chunks, pad) + sizeof(uint32_t) - offsetof(grdma_h2_chunks, tabs) == sizeof(tail), "layout");
   const uint32_t want = (uint32_t)p->chunks_want;
-  return hipMemcpyAsync(reinterpret_cast<uint8_t*>(p->d_chunks) + offsetof(grdma_h2_chunks, tabs), &tail, sizeof(tail),
-                        hipMemcpyHostToDevice, st) == hipSuccess &&
-         hipMemcpyAsync(reinterpret_cast<uint8_t*>(p->d_chunks) + offsetof(grdma_h2_chunks, want), &want, sizeof(want),
-                        hipMemcpyHostToDevice, st) == hipSuccess &&
-         hipStreamSynchronize(st) == hipSuccess;
+  const bool ok = hipMemcpyAsync(reinterpret_cast<uint8_t*>(p->d_chunks) + offsetof(grdma_h2_chunks, tabs), &tail, sizeof(tail),
+                                 hipMemcpyHostToDevice, st) == hipSuccess &&
+                  hipMemcpyAsync(reinterpret_cast<uint8_t*>(p->d_chunks) + offsetof(grdma_h2_chunks, want), &want, sizeof(want),
+                                 hipMemcpyHostToDevice, st) == hipSuccess &&
+                  hipStreamSynchronize(st) == hipSuccess;
+  if (!ok) {  // (the control block may not know the new segment: no chunked deframing with it)
+    p->ev_tmp_cap = 0;
+    p->chunks_want = 0;
+  }
+  return ok;
 }
 
 // The deframing of one list of delivered slices, enqueued on st: over chunks when the parser has the buffers (plan,

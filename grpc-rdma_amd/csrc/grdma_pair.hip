@@ -235,6 +235,7 @@ struct grdma_pair {
   grdma_status_report* remote_status = nullptr;  // peer's status_recv inside ipc_conn
   uint32_t serial = 0;                  // "queue pair number" of this pair in its process
   bool ipc_export_failed = false;       // hipIpcGetMemHandle refused: only peers in this process can connect
+  bool bounce_truncated = false;        // stage_slices copied less than the slices hold (the bounce buffer was full)
   hipStream_t stream = nullptr;
   int wakeup_fd = -1;                // grpc_wakeup_fd of the pair (pair.h:187): an eventfd
   std::mutex fd_mu;                  // creation of wakeup_fd
@@ -372,6 +373,7 @@ int stage_slices(grdma_pair* p, const grdma_slice* slices, uint64_t count, uint6
     return fail(GRDMA_ERR_CAPACITY, "slice list of %llu entries exceeds %d",
                 (unsigned long long)count, GRDMA_TX_MAX_RECORDS - 1);
   p->cmd_inline = false;
+  p->bounce_truncated = false;
   if ((flags & GRDMA_MEM_HOST) && p->latency && p->h_cmd && count <= GRDMA_CMD_MAX_SGES) {
     uint64_t total = 0;
     for (uint64_t i = 0; i < count; i++) total += slices[i].len;
@@ -409,7 +411,10 @@ int stage_slices(grdma_pair* p, const grdma_slice* slices, uint64_t count, uint6
       uint64_t sk = (i == 0) ? skip_first : 0;  // bytes before byte_idx are never read
       uint64_t room = cap > off ? cap - off : 0;
       uint64_t n = len > sk ? len - sk : 0;
-      if (n > room) n = room;
+      if (n > room) {
+        n = room;
+        p->bounce_truncated = true;  // (the Sends of this submit must not accept more than what was staged)
+      }
       if (n) memcpy(p->h_bounce + off, src + sk, n);
       p->h_sges[i].ptr = p->h_bounce + off - sk;  // so that ptr + byte_idx lands on the copy
       p->h_sges[i].len = len;
@@ -1816,6 +1821,13 @@ int64_t grdma_endpoint_write_begin(grdma_pair* p, const grdma_slice* slices, uin
 // buffer is unreffed there, so no view of it may survive in the pair).
 int grdma_endpoint_write_abort(grdma_pair* p) {
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  // A Send in flight may be gathering straight from the caller's pages (GRPC_RDMA_HIP_REGISTER_MIN: registered host
+  // slices are read where they lie) and the caller is about to unref them: the send stream is drained first.  The
+  // reference's Send is synchronous and has no such window.
+  if (p->async && p->tx_inflight.load(std::memory_order_acquire)) {
+    if (p->s_tx && register_min() != 0) (void)hipStreamSynchronize(p->s_tx);
+    p->tx_inflight.store(0, std::memory_order_release);
+  }
   p->w_active = false;
   p->w_slices.clear();
   p->w_idx = p->w_byte = 0;
@@ -1995,6 +2007,11 @@ int submit_send(grdma_pair* p, uint64_t count, uint64_t byte_idx) {
     // gathered by one.  Records go straight into the peer ring, so the Sends need no staging buffers of their own.
     constexpr uint32_t kBurstMax = 16;
     uint32_t B = (uint32_t)std::min<uint64_t>(kBurstMax, (count + p->max_sge - 1) / p->max_sge);
+    // The bounce buffer holds at most ring_size bytes of the slices.  The burst wave prices all Sends of a burst against
+    // ONE reading of the peer's head, so it accepts no more than the ring had room for; the fallback (max_sge > 64, or a
+    // ring above 1 GiB) runs the block-wide plan once per Send, each with a fresh reading, and with a reader draining
+    // meanwhile B Sends could take up to B * ring / 2 bytes -- past what was staged.  Two Sends cannot.
+    if (p->bounce_truncated && (p->max_sge > 64 || p->ring_size > (1ull << 30)) && B > 2) B = 2;
     // (a queued chain that was skipped may still sit in the stream and will read set 0's tables when it runs: it is
     // right behind the chain whose completion brought us here -- a few tens of microseconds, a rare path)
     while (__atomic_load_n(&p->line->tx_seq, __ATOMIC_ACQUIRE) < p->q_pending_seq) {
@@ -2255,7 +2272,9 @@ int grdma_endpoint_read_submit(grdma_pair* p, uint64_t max_reads) {
   if (max_reads == 0) return fail(GRDMA_ERR_INVALID, "max_reads is zero");
   if (max_reads > GRDMA_MAX_SLICES) max_reads = GRDMA_MAX_SLICES;
   std::lock_guard<std::mutex> lk(p->rx_mu);
-  if (p->rx_inflight.load(std::memory_order_acquire) >= 0) return fail(GRDMA_ERR_INVALID, "a drain is still in flight");
+  // A drain is in flight already: the in-process peer's sender may have posted this pair's ARMED drain between the
+  // caller's look at grdma_endpoint_drain_state and this call.  Not an error -- the readable edge comes when it is done.
+  if (p->rx_inflight.load(std::memory_order_acquire) >= 0) return 0;
   int w = -1;
   for (size_t i = 0; i < p->windows.size(); i++)
     if (p->windows[i]->refs.load(std::memory_order_acquire) == 1) { w = (int)i; break; }

@@ -64,7 +64,7 @@ def _ops(seed, ring_kb, max_sge, n_ops):
 def _run(binary, text, ring_kb, max_sge, extra=None):
     env = dict(os.environ, GRPC_RDMA_RING_BUFFER_SIZE_KB=str(ring_kb), FAKEVERBS_MAX_SGE=str(max_sge),
                GRPC_RDMA_MAX_SGE=str(max_sge), GRPC_RDMA_HIP_SEND_BUFFER_KB="0", GRPC_RDMA_HIP_READ_AHEAD="1",
-               GRPC_RDMA_HIP_PAIR_POOL_MB="0")
+               GRPC_RDMA_HIP_PAIR_POOL_MB="0", TRACE_ENGINE_SETTLE="1")
     env.update(extra or {})
     p = subprocess.run([binary], input="\n".join(text) + "\n", capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, "%s: rc %d, %s" % (os.path.basename(binary), p.returncode, p.stderr[-600:])

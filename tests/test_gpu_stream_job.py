@@ -397,3 +397,80 @@ def test_paired_schedule_at_a_credit_limited_ring_equals_the_oracle_with_the_cre
     job.close()
     tx.close()
     rx.close()
+
+
+# ---- both directions of ONE connection in flight (BASELINE configs[3] is bidirectional streaming; the reference's
+# pair is full duplex: Recv shares nothing with Send but the queue pair, pair.cc:264-286, pair.h:171-175) -----------
+@pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
+@pytest.mark.parametrize("pipeline", [False, True], ids=["sequential", "paired"])
+def test_bidirectional_job_both_directions_of_one_pair_in_the_same_launches(gpu, pipeline, flags):
+    """One pair of connected ends, TWO links of one job: a -> b and b -> a.  Every launch of the job carries both
+    directions (grid.y = 2: the Send of a and the Send of b priced side by side, both rings drained by one pass, the
+    credit of each direction returned through the other end's status word), so each end is sender and receiver at the
+    same time.  Each direction must deliver exactly what the oracle's rounds deliver for it, ring image and state
+    included -- the two directions share no protocol state."""
+    from grpc_rdma_amd import stream as gs
+    g = gpu
+    R, max_sge = 1 << 24, 255
+    fwd = _framed_slices(40, 1 << 17, seed=11)   # a -> b: 40 x 128 KiB
+    bwd = _framed_slices(70, 40000, seed=12)     # b -> a: 70 x 40 kB (another number of rounds, other record sizes)
+    # the oracle: one link object has both directions; a job's round = one Send per direction, then both drains
+    o = pyorc.OracleLink(R, max_sge)
+    exp = [[], []]
+    rounds = [0, 0]
+    for _ in range(PASSES):
+        cur = [[0, 0], [0, 0]]
+        delivered = [[], []]
+        lists = [fwd, bwd]
+        while cur[0][0] < len(fwd) or cur[1][0] < len(bwd):
+            for d in (0, 1):
+                idx, byte = cur[d]
+                if idx < len(lists[d]):
+                    sent = o.send(d, lists[d][idx:], byte)
+                    cur[d] = list(_advance(lists[d], idx, byte, sent))
+            for d in (0, 1):  # direction d is read by side 1 - d
+                while True:
+                    s, _alloc = o.endpoint_read(1 - d)
+                    if not s:
+                        break
+                    delivered[d].append(s)
+        exp = delivered
+    st = (o.state(0), o.state(1))
+    rings = (o.ring_mem(0), o.ring_mem(1))
+    o.close()
+
+    rng = random.Random(5)
+    a, b = g.Pair(R, max_sge, flags), g.Pair(R, max_sge, flags)
+    g.connect_pairs(a, b)
+    links, keep = [], []
+    for tx, rx, sl in ((a, b, fwd), (b, a, bwd)):
+        bufs = [g.DeviceBuffer(data=s, offset=rng.randrange(16)) for s in sl]
+        N = sum(len(s) for s in sl)
+        cap = N + 32 * (2 * len(sl) + 64) + 4096
+        dst = g.DeviceBuffer(nbytes=cap)
+        keep.append((bufs, dst, cap, N))
+        links.append((tx, rx, [(bf.ptr, len(s)) for bf, s in zip(bufs, sl)], dst.ptr, cap, 2 * len(sl) + 64))
+    job = gs.MultiStreamJob(links, 4096)
+    job.set_pipeline(pipeline)
+    r = job.run(gs.RUN_EAGER)
+    total = keep[0][3] + keep[1][3]
+    assert r.done and r.bytes_delivered == total and r.bytes_sent == total
+    nrounds = int(max(r.tx_rounds, r.rx_rounds))
+    job.set_rounds(2 * nrounds + 4 if pipeline else nrounds + 2)
+    for _ in range(PASSES - 1):
+        r = job.run(gs.RUN_GRAPH)
+        assert r.done and r.bytes_delivered == total
+    for d in (0, 1):
+        _bufs, dst, cap, _n = keep[d]
+        mem = dst.read(cap)
+        got = [mem[o_:o_ + n] for o_, n in job.delivered_slices(d)]
+        assert [len(x) for x in got] == [len(x) for x in exp[d]], "direction %d" % d
+        assert got == exp[d], "direction %d" % d
+    assert a.ring_mem() == rings[0] == bytes(R) and b.ring_mem() == rings[1] == bytes(R)
+    for pair_, s_ in ((a, st[0]), (b, st[1])):
+        ps = pair_.state()
+        for k in ("remote_tail", "remote_head", "partial_write", "head", "moving_head", "remain", "internal_read_size"):
+            assert ps[k] == s_[k], k
+    job.close()
+    a.close()
+    b.close()

@@ -11,6 +11,8 @@ import sys
 
 import pytest
 
+from oracle import pyorc
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -112,8 +114,8 @@ def test_echo_between_two_gpus(gpu):
 
 
 def test_connect_checks_of_the_reference(gpu):
-    """Connect() asserts equal tag and equal ring size (pair.cc:146-149); a handle cannot be
-    opened in the process that made it."""
+    """Connect() asserts equal tag and equal ring size (pair.cc:146-149); the offsets that come off the socket must be
+    this build's; a peer in this process must exist."""
     g = gpu
     coarse = g.Pair(1 << 20, 30)
     with pytest.raises(g.GrdmaError, match="FINE_GRAINED"):   # what another process writes must be fine-grained memory
@@ -126,8 +128,6 @@ def test_connect_checks_of_the_reference(gpu):
         a.connect_remote(bytes(blob))
     c = g.Pair(1 << 20, 30, flags=4)
     blob = bytearray(c.export_address())
-    with pytest.raises(g.GrdmaError, match="this process"):
-        a.connect_remote(bytes(blob))
     blob[32] = 0xA1
     with pytest.raises(g.GrdmaError, match="tag"):
         a.connect_remote(bytes(blob))
@@ -136,4 +136,36 @@ def test_connect_checks_of_the_reference(gpu):
     blob[64 + 8:64 + 16] = (os.getpid() + 1).to_bytes(8, "little")
     with pytest.raises(g.GrdmaError, match="layout"):
         a.connect_remote(bytes(blob))
+    # an address that names a pair of THIS process which does not exist (an IPC handle cannot be opened where it was
+    # made: a peer in this process is looked up by its serial, addr.qpn)
+    blob = bytearray(c.export_address())
+    blob[4:8] = (0x7FFFFFF0).to_bytes(4, "little")
+    with pytest.raises(g.GrdmaError, match="does not exist"):
+        a.connect_remote(bytes(blob))
     assert a.get_status() == 1  # still kInitialized
+
+
+def test_two_pairs_of_one_process_connect_through_the_bootstrap_path(gpu):
+    """Client and server in ONE process (what gRPC's own end2end tests are): both ends export their address and connect
+    to the other one's -- grdma_pair_bootstrap_fd's two halves -- and the peer, found to live in this process, is looked
+    up by its serial instead of being mapped through an IPC handle.  Then an echo in both directions."""
+    g = gpu
+    a, b = g.Pair(1 << 18, 30, flags=4), g.Pair(1 << 18, 30, flags=4)
+    ba, bb = a.export_address(), b.export_address()
+    a.connect_remote(bb)
+    b.connect_remote(ba)
+    assert a.get_status() == 2 and b.get_status() == 2  # kConnected
+    o = pyorc.OracleLink(1 << 18, 30)
+    for k, (src, dst, so, do) in enumerate([(a, b, 0, 1), (b, a, 1, 0)] * 2):
+        msg = [bytes((7 * i + k) % 251 for i in range(n)) for n in (9, 5000, 14, 70000)]
+        bufs = [g.DeviceBuffer(data=m) for m in msg]
+        assert src.Send(bufs) == o.send(so, msg)
+        got, _ = dst.endpoint_read(max_reads=64)
+        exp = []
+        while True:
+            s_, _a = o.endpoint_read(do)
+            if not s_:
+                break
+            exp.append(s_)
+        assert got == exp
+    o.close()

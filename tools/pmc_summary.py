@@ -11,6 +11,8 @@ import re
 import sys
 
 root, out_path, command = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (sources_sha16: which kernels these counters were collected from)
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
@@ -51,6 +53,7 @@ for name, ctrs in sorted(agg.items()):
             k[label] = round(ctrs[a][1] / ctrs[b][1], 4)
     kernels[name] = k
 json.dump({"command": command,
+           "sources_sha16": bench.sources_sha16(),
            "units": "FETCH_SIZE / WRITE_SIZE: KiB per dispatch; SQ_*: quad-cycles summed over waves; "
                     "averages per launch over the whole run; *_full_size_launch: over the launches within 10 % "
                     "of the kernel's largest (what one full drain / gather moves)",
