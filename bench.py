@@ -1079,7 +1079,7 @@ def main():
         # mixed message sizes (examples/cpp/test/common.h: uniform in [1, 4 MiB - 1 KiB]), 64 messages per step
         try:
             mw = MixedWorkload(g, 64)
-            mx = measure(args.ring_kb, half, 1, not args.no_verify, False, wls=[mw])
+            mx = measure(args.ring_kb, half, 1, not args.no_verify, False, pipeline=bool(args.pipeline), wls=[mw])
             out["value_mixed_sizes"] = round(mw.user_bytes * half * world / mx["elapsed"] / (1 << 30), 3)
             mx2 = measure(4096, half, 1, not args.no_verify, False, max_sge=30, wls=[mw], burst=16)
             out["value_mixed_sizes_ring4096_sge30"] = round(mw.user_bytes * half * world / mx2["elapsed"] / (1 << 30), 3)

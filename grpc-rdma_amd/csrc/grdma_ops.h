@@ -6,6 +6,17 @@
 
 #include "grdma_dev.h"
 
+// The payload sizes of the records one Send produced, handed by a streaming job from the Send of a round to the drain
+// of the same round (grdma_tx_op::sizes_out -> grdma_rx_op::sizes_in), the way the Send's tail is (tail_out ->
+// limit_ptr).  The drain uses it as a PREDICTION and checks every header and footer in the ring against it before it
+// consumes anything (csrc/grdma_rx_hint.h); a table that does not start at the reader's head is not used.
+struct grdma_size_hint {
+  uint64_t start_off;   // ring offset of the first record (the sender's remote_tail_ in front of the Send)
+  uint32_t count;       // records; 0 = no table for this Send
+  uint32_t pad;
+  uint32_t n[GRDMA_TX_MAX_RECORDS];
+};
+
 // One PairPollable::Send / rdma_flush step for one connection.
 struct grdma_tx_op {
   struct grdma_conn* conn;
@@ -27,6 +38,8 @@ struct grdma_tx_op {
                                    // would be a PCIe round trip in front of the release)
   uint64_t* tail_out;              // != NULL: remote_tail_ after this Send is also stored here (a streaming
                                    // job hands it to the drain of the same round: grdma_rx_op::limit_ptr)
+  struct grdma_size_hint* sizes_out;  // != NULL: the planners of grdma_tx_multi.h leave the record sizes of this Send
+                                   // here (count 0 when the Send was planned by another planner)
 };
 
 // Index of the slice buffer a streaming job writes (csrc/grdma_tx_fast.hip): prefix sums over ALL its slices, built
@@ -75,6 +88,7 @@ struct grdma_rx_op {
                                    // computed: the graph edge behind that Send's wire write says those bytes
                                    // have landed, and a later round may already be landing behind them);
                                    // NULL: conn->wire_recv.wire_tail when conn->wire_limit is set
+  const struct grdma_size_hint* sizes_in;  // != NULL: the sizes the Send of this round computed (see grdma_size_hint)
 };
 
 // Mailbox of the persistent latency engine (pinned host memory).

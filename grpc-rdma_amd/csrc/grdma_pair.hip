@@ -2573,6 +2573,8 @@ struct grdma_stream_job {
   grdma_tx_result* d_txres = nullptr; // [n]
   grdma_rx_result* d_rxres = nullptr; // [2 * n]
   const grdma_plan** d_plans = nullptr;  // [3 * n]: gather, wire (even), wire (odd)
+  grdma_size_hint* d_hints = nullptr; // [3 * n]: the record sizes the Send of a round computed, per op set: what the
+                                      // drain of the same round predicts the ring's records from (grdma_rx_op::sizes_in)
   uint64_t* d_limits = nullptr;       // [3 * n]: remote_tail_ after the Send(s) of a round, per op set: what the
                                       // drain of the same round may walk up to (grdma_rx_op::limit_ptr)
   grdma_conn** d_txconns = nullptr;   // [n]: the sending ends, for the arrival report behind the last round
@@ -3443,6 +3445,11 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
     off += l.count;
     ok = hipMemcpy(l.d_sges, tmp.data(), sizeof(grdma_sge) * l.count, hipMemcpyHostToDevice) == hipSuccess;
   }
+  // (the size tables of the rounds: GRDMA_JOB_SIZE_HINTS=0 leaves them out -- drains without a period then walk)
+  if (ok && !(getenv("GRDMA_JOB_SIZE_HINTS") && atoi(getenv("GRDMA_JOB_SIZE_HINTS")) == 0)) {
+    ok = hipMalloc((void**)&j->d_hints, sizeof(grdma_size_hint) * 3 * n) == hipSuccess &&
+         hipMemset(j->d_hints, 0, sizeof(grdma_size_hint) * 3 * n) == hipSuccess;
+  }
   const size_t sz_tx = sizeof(grdma_tx_op) * 3 * n, sz_rx = sizeof(grdma_rx_op) * 3 * n;
   const size_t sz_txr = sizeof(grdma_tx_result) * n, sz_rxr = sizeof(grdma_rx_result) * 2 * n;
   const size_t sz_pl = sizeof(grdma_plan*) * 3 * n;
@@ -3478,6 +3485,7 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
       t.result = &j->d_txres[i];
       t.use_cursor = k == 0 ? 2 : 1;
       t.tail_out = &j->d_limits[k * n + i];
+      t.sizes_out = j->d_hints ? &j->d_hints[k * n + i] : nullptr;
       grdma_rx_op& r = h_rx[k * n + i];
       r.conn = l.rx->d_conn;
       r.plan = odd ? l.d_rxplan2 : l.rx->d_rxplan;
@@ -3490,6 +3498,7 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
       r.append = k == 0 ? 2 : 1;
       r.slices_cap = l.slices_cap;
       r.limit_ptr = &j->d_limits[k * n + i];
+      r.sizes_in = t.sizes_out;
     }
   auto** h_cn = reinterpret_cast<grdma_conn**>(host.data() + sz_tx + sz_rx + sz_txr + sz_rxr + sz_pl + sz_lim);
   for (uint32_t i = 0; i < n; i++) h_cn[i] = j->links[i].tx->d_conn;
@@ -3544,6 +3553,7 @@ void grdma_stream_job_destroy(grdma_stream_job* j) {
       hipStreamDestroy(st);
     }
   if (j->d_txf) hipFree(j->d_txf);
+  if (j->d_hints) hipFree(j->d_hints);
   for (grdma_job_link& l : j->links) {
     if (l.d_encpre) hipFree(l.d_encpre);
     if (l.d_lenpre) hipFree(l.d_lenpre);

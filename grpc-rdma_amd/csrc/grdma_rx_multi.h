@@ -105,8 +105,9 @@ __device__ __forceinline__ void rxm_cyc(const rx_lds_multi& M, uint32_t P, uint3
 }
 
 // Returns 0: not the last workgroup of this drain to arrive (nothing more to do); 1: the last one, the drain is
-// committed; 2: the last one, and a workgroup declined -- the caller runs the general planner (every thread of the
-// workgroup returns the same value).
+// committed; 2: the last one, and a workgroup declined -- the caller runs the general planner; 3: every workgroup alike
+// found the connection without a usable period and the round carries a size table -- the caller runs rxh_body (every
+// thread of the workgroup returns the same value).
 __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg) {
   static_assert(sizeof(rx_lds_multi) <= sizeof(rx_lds), "the multi-workgroup body's tables fit the receive planners' shared LDS");
   rx_lds_multi& M = *reinterpret_cast<rx_lds_multi*>(rx_lds_get());
@@ -194,6 +195,10 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   }
   const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap64);
   const uint64_t t_pattern = __builtin_amdgcn_s_memtime();
+  // No period, or a pattern that does not end at the sender's tail: known to EVERY workgroup alike before the ring has
+  // been looked at and before anyone has arrived -- the caller may try the body that predicts from the Send's own size
+  // table instead (grdma_rx_hint.h); nothing has been written, nothing counted.
+  if (reason && !idle && op.sizes_in != nullptr) return 3;
 
   // ---- 2. one round trip: header and footer of my record, header of pattern record `tid`
   const uint32_t i_mine = wg * RXM_CHUNK + tid;

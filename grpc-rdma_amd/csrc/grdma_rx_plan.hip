@@ -43,6 +43,7 @@
 #include "grdma_tx_body.h"
 #include "grdma_rx_fast.h"
 #include "grdma_rx_multi.h"
+#include "grdma_rx_hint.h"
 #include "grdma_tx_multi.h"
 #include "grdma_tx_fast.h"
 
@@ -1507,7 +1508,15 @@ __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1,
 void k_plan_pair_mw(const grdma_rx_op* rxops, const grdma_tx_op* txops, const grdma_txf_ctl* ctls, uint32_t G) {
   static_assert(RXM_THREADS == PLAN_THREADS && TXM_THREADS == PLAN_THREADS, "one workgroup shape for all planner bodies");
   if (blockIdx.y < G) {
-    if (rxm_body(rxops[blockIdx.x], blockIdx.y, G) != 2) return;  // (uniform)
+    // a connection whose record sizes have a period: predicted from the pattern; none, but the round carries the sizes its
+    // own Send computed: predicted from those (grdma_rx_hint.h).  Either way every record is verified in the ring.
+    const grdma_rx_op& rop = rxops[blockIdx.x];
+    int r = rxm_body(rop, blockIdx.y, G);
+    if (r == 3) {  // (uniform over the whole grid: no workgroup has arrived yet)
+      __syncthreads();
+      r = rxh_body(rop, blockIdx.y, G);
+    }
+    if (r != 2) return;  // (uniform)
     rx_plan_body(rxops[blockIdx.x]);
     if (threadIdx.x == 0) rxops[blockIdx.x].result->dbg[9] = 0;
   } else {

@@ -160,6 +160,7 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     const uint64_t st_i = i == 0 ? 0 : e0 - base_e + D;
     const uint64_t p = i == nrec ? short_pay : (i == 0 ? sat_sub(g.len, byte_idx) : g.len);
     const uint64_t tagw = GRDMA_SEG_TAG_WRITE | (p << GRDMA_SEG_TAG_LEN_SHIFT);
+    if (op.sizes_out != nullptr) op.sizes_out->n[i] = (uint32_t)p;  // (for the drain of the same round: grdma_size_hint)
     const uint8_t* src = g.ptr + (i == 0 ? byte_idx : 0);
     const uint32_t t0 = i == 0 ? 0u : (uint32_t)(tp0 - base_t + Dt);
     if (!direct) {
@@ -197,6 +198,7 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     if (tid == 0) {
       atomicAdd(&g_tx_fast_sends[1], 1ull);
       op.result->dbg[11]++;  // (dbg[10] / dbg[11]: Sends of this result block priced from the index / declined)
+      if (op.sizes_out != nullptr) op.sizes_out->count = 0;  // (the general planner leaves no size table)
     }
     return 2;
   }
@@ -278,6 +280,10 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     r->partial = sent < offered ? 1 : 0;
     r->new_remote_tail = new_tail;
     if (op.tail_out != nullptr) *op.tail_out = new_tail;
+    if (op.sizes_out != nullptr) {
+      op.sizes_out->start_off = tail0;
+      op.sizes_out->count = (uint32_t)nrec_total;
+    }
     r->slice_idx = idx;
     r->byte_idx = bidx;
     r->done = (idx >= op.nslices) ? 1 : 0;

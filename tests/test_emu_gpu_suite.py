@@ -79,6 +79,15 @@ def test_steady_state_planner_and_pair_pool_gpu_tests_under_the_emulator(emu_lib
                             "-k", "(fast_planner and sge130) or pool or (credit_limited and r256k)"], 8)
 
 
+def test_planner_pair_of_many_workgroups_and_bidirectional_job_under_the_emulator(emu_lib):
+    """Round 4: k_plan_pair_mw (csrc/grdma_rx_multi.h, grdma_tx_multi.h: the drain plan and the send plan of a round laid
+    out by sixteen four-wave workgroups each from closed forms over the record pattern / a search over the slice index,
+    nothing exchanged but the arrival word) on drains of up to 3001 records that span workgroups, wrap the ring and
+    cross the credit threshold; the bidirectional job (both directions of one pair in every launch), paired schedule."""
+    run_gpu_tests(emu_lib, ["tests/test_gpu_stream_job.py", "-n", "4",
+                            "-k", "(several_workgroups and r8m_sge3001) or (bidirectional and paired)"], 4)
+
+
 def test_concurrent_writer_and_poller_gpu_tests_under_the_emulator(emu_lib):
     """Records landing header-first / footer-last from a second thread while the receiver polls and reads; the
     background poller thread (one k_poll launch per pass, eventfd wakeups)."""

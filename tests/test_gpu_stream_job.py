@@ -85,7 +85,10 @@ def _run_job(g, R, max_sge, slices, pipeline, flags=0, mode=None):
     dst_cap = N + 32 * (2 * len(slices) + 64) + 4096
     dst = g.DeviceBuffer(nbytes=dst_cap)
     sge = [(b.ptr, len(s)) for b, s in zip(bufs, slices)]
-    job = gs.MultiStreamJob([(tx, rx, sge, dst.ptr, dst_cap, 2 * len(slices) + 64)], 4096)
+    # (an eager run launches every round it was given, also the ones that find nothing to do: a bound from the sizes
+    # instead of 4096 -- rounds are cut by the staging budget, R / 2, or by max_sge, whichever comes first)
+    bound = min(4096, 6 * (N // (R // 2) + len(slices) // max_sge) + 24)
+    job = gs.MultiStreamJob([(tx, rx, sge, dst.ptr, dst_cap, 2 * len(slices) + 64)], bound)
     job.set_pipeline(pipeline)
     r = job.run(gs.RUN_EAGER)
     assert r.done and r.bytes_delivered == N and r.bytes_sent == N
@@ -450,7 +453,7 @@ def test_bidirectional_job_both_directions_of_one_pair_in_the_same_launches(gpu,
         dst = g.DeviceBuffer(nbytes=cap)
         keep.append((bufs, dst, cap, N))
         links.append((tx, rx, [(bf.ptr, len(s)) for bf, s in zip(bufs, sl)], dst.ptr, cap, 2 * len(sl) + 64))
-    job = gs.MultiStreamJob(links, 4096)
+    job = gs.MultiStreamJob(links, 6 * (keep[0][3] // (R // 2) + len(fwd) // max_sge + len(bwd) // max_sge) + 24)
     job.set_pipeline(pipeline)
     r = job.run(gs.RUN_EAGER)
     total = keep[0][3] + keep[1][3]
@@ -474,3 +477,38 @@ def test_bidirectional_job_both_directions_of_one_pair_in_the_same_launches(gpu,
     job.close()
     a.close()
     b.close()
+
+
+# ---- record sizes WITHOUT a period (the reference's own test distribution: message sizes uniform in [1, max],
+# examples/cpp/test/common.h:4-31): the drain of a round is predicted from the sizes its Send computed
+# (csrc/grdma_rx_hint.h), verified record by record in the ring, laid out by sixteen small workgroups ---------------
+@pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
+@pytest.mark.parametrize("case", [(1 << 25, 1023, 50, 300000, 7), (1 << 24, 640, 300, 9000, 8), (1 << 26, 4095, 40, 1 << 20, 9)],
+                         ids=["r32m_sge1023", "r16m_sge640_small", "r64m_sge4095"])
+def test_drains_without_a_period_are_predicted_from_the_sends_sizes(gpu, case, flags):
+    R, max_sge, n_msgs, max_len, seed = case
+    rng = random.Random(seed)
+    slices = []
+    for i in range(n_msgs):
+        n = rng.randrange(1, max_len + 1)
+        msg = bytes(rng.getrandbits(8) for _ in range(97)) * (n // 97) + bytes(n % 97)
+        wire, lens = pyorc.h2_frame_message(msg, stream_id=2 * i + 1)
+        off = 0
+        for ln in lens:
+            slices.append(wire[off:off + ln])
+            off += ln
+    exp, exp_rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, slices)
+    before = _fast_counts(gpu)
+    got = _run_job(gpu, R, max_sge, slices, pipeline=True, flags=flags)
+    after = _fast_counts(gpu)
+    assert [len(x) for x in got["slices"]] == [len(x) for x in exp]
+    assert got["slices"] == exp
+    assert got["ring"] == ring == bytes(R)
+    for k in ("remote_tail", "remote_head", "partial_write"):
+        assert got["tx"][k] == st0[k], k
+    for k in ("head", "moving_head", "remain", "internal_read_size"):
+        assert got["rx"][k] == st1[k], k
+    took = after[0] - before[0]
+    # (the eager first pass runs the sequential kernels, whose steady-state body needs a period: the graph passes count)
+    assert took >= (PASSES - 1) * exp_rounds - 2, "drains taken by a predicting body: %d (declined by reason: %s)" % (
+        took, [a - b for a, b in zip(after[1:6], before[1:6])])

@@ -59,7 +59,7 @@ for c in mine:
     dst = g.DeviceBuffer(nbytes=cap)
     links.append((tx, rx, [(b.ptr, len(s)) for b, s in zip(bufs, sl)], dst.ptr, cap, 2 * len(sl) + 64))
     keep.append((sl, bufs, dst, cap, nbytes, tx, rx))
-job = gs.MultiStreamJob(links, 4096)
+job = gs.MultiStreamJob(links, 12)
 grp.barrier()
 t0 = time.perf_counter()
 r = job.run(gs.RUN_EAGER)
@@ -85,7 +85,7 @@ if grp.rank == 0:
     nbytes = sum(len(s) for s in stream_sl)
     cap = nbytes + 32 * (2 * len(stream_sl) + 64) + 4096
     dst = g.DeviceBuffer(nbytes=cap)
-    j2 = gs.MultiStreamJob([(tx, rx, [(b.ptr, len(s)) for b, s in zip(bufs, stream_sl)], dst.ptr, cap, 2 * len(stream_sl) + 64)], 4096)
+    j2 = gs.MultiStreamJob([(tx, rx, [(b.ptr, len(s)) for b, s in zip(bufs, stream_sl)], dst.ptr, cap, 2 * len(stream_sl) + 64)], 12)
     r2 = j2.run(gs.RUN_EAGER)
     assert r2.done and r2.bytes_delivered == nbytes
     slices = j2.delivered_slices(0)
@@ -121,7 +121,8 @@ def test_two_ranks_run_their_share_of_the_connections_and_the_fanout(tmp_path, e
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), GRDMA_LIB_PATH=emu_lib, GRDMA_TEST_ALLOW_EMU="1")
+                   MASTER_PORT=str(port), GRDMA_LIB_PATH=emu_lib, GRDMA_TEST_ALLOW_EMU="1",
+                   GRDMA_COPY_BLOCKS="2")  # (grid size of the copy kernels: the emulator runs a workgroup at a time)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
