@@ -71,6 +71,7 @@ const void* grdma_kernel_fn_plan_pair(void);
 const void* grdma_kernel_fn_plan_pair_job(void);
 const void* grdma_kernel_fn_plan_pair_mw(void);
 uint32_t grdma_rx_multi_groups(void);
+hipError_t grdma_launch_rx_plan_mw(const grdma_rx_op*, uint32_t, hipStream_t);
 uint32_t grdma_tx_multi_groups(void);
 const void* grdma_kernel_fn_rxplan_gather_job(void);
 uint32_t grdma_kernel_threads(int which);
@@ -184,6 +185,10 @@ struct grdma_hostblk {
   // refresh pass of a pair whose peer lives in another process (k_poll over this one connection)
   grdma_conn* refresh_conn;
   uint64_t refresh_out[4];         // readable, ready mask, has-message mask, trigger mask
+  // how far the sender's completed writes reached when the drain in flight was submitted (the state line's wire_tail):
+  // ONE reading for all the workgroups that lay the drain out -- the sender goes on committing while they run, and two
+  // workgroups that read the connection's arrival report for themselves could see two different tails
+  uint64_t rx_limit;
 };
 
 // One receive window of an asynchronous endpoint: the slices of one drain, in pinned host memory the scatter kernel
@@ -672,6 +677,8 @@ void fill_rxop(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_r
   h->rxop.slices_cap = GRDMA_MAX_SLICES;
   h->rxop.inline_apply = p->latency ? 1 : 0;
   h->rxop.seq_next = p->latency ? h->rxres.seq + 1 : 0;
+  h->rxop.limit_ptr = nullptr;
+  h->rxop.sizes_in = nullptr;
 }
 
 }  // namespace
@@ -2298,7 +2305,17 @@ int grdma_endpoint_read_submit(grdma_pair* p, uint64_t max_reads) {
   p->rx_expect.store(++p->rx_seq, std::memory_order_relaxed);
   p->rx_by_engine.store(0, std::memory_order_relaxed);
   p->rx_inflight.store(w, std::memory_order_release);
-  hipError_t e = grdma_launch_rx_plan(&h->rxop, 1, p->s_rx);
+  // (GRDMA_ENDPOINT_RX_MULTI=1: the drain plan as many small workgroups -- a periodic stream's pass predicted and
+  // verified instead of walked.  Off by default: measured through the vtable with host slices it changes nothing,
+  // 14.8 / 11.3 against 15.1 GiB/s -- what bounds that path is the scatter into the pinned window and the PCIe
+  // round trips of the host loop, not the planner, profiles/r04_notes)
+  static const bool rx_mw = getenv("GRDMA_ENDPOINT_RX_MULTI") && atoi(getenv("GRDMA_ENDPOINT_RX_MULTI")) != 0;
+  const bool use_mw = rx_mw && !p->latency && !(p->flags & GRDMA_WIRE_ORDERED);
+  if (use_mw) {
+    h->rx_limit = __atomic_load_n(&p->line->wire_tail, __ATOMIC_ACQUIRE);
+    h->rxop.limit_ptr = &h->rx_limit;
+  }
+  hipError_t e = use_mw ? grdma_launch_rx_plan_mw(&h->rxop, 1, p->s_rx) : grdma_launch_rx_plan(&h->rxop, 1, p->s_rx);
   if (e == hipSuccess && !p->latency) e = grdma_launch_rx_apply(&h->rxop, 1, copy_blocks_for(p->ring_size), p->s_rx);
   if (e == hipSuccess) e = grdma_launch_rx_commit1(p->d_conn, p->rx_seq, p->s_rx);
   if (e != hipSuccess) {

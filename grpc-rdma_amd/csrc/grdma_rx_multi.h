@@ -129,7 +129,11 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   const uint32_t P = c->rx_period;
   const uint32_t status = c->status;
   const uint32_t* const gh = c->rx_hist;
-  const uint64_t lim = op.limit_ptr ? __hip_atomic_load(op.limit_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  // how far the sender's completed writes reach: the tail a streaming job's Send of the same round computed, or -- an
+  // endpoint's drain -- the connection's arrival report (grdma_wire_report), read once
+  const bool limited = op.limit_ptr != nullptr || c->wire_limit != 0;
+  const uint64_t lim = op.limit_ptr ? __hip_atomic_load(op.limit_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : __hip_atomic_load(&c->wire_recv.wire_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const uint64_t slice_idx0 = op.append == 1 ? c->rx_slice_idx : 0;
   const uint64_t a_off0 = op.append == 1 ? c->rx_arena_off : 0;
   constexpr int NH = GRDMA_RX_HIST / RXM_THREADS;
@@ -137,8 +141,8 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
 #pragma unroll
   for (int r = 0; r < NH; r++) hv[r] = gh[tid + r * RXM_THREADS];
 
-  bool ok = status == GRDMA_PAIR_CONNECTED && op.raw_cap == 0 && op.append != 0 && !op.inline_apply &&
-            op.limit_ptr != nullptr && remain0 == 0 && leftover0 <= RXF_MINRD && P != 0 && P <= RXF_PMAX && hc >= P &&
+  bool ok = status == GRDMA_PAIR_CONNECTED && op.raw_cap == 0 && !op.inline_apply &&
+            limited && remain0 == 0 && leftover0 <= RXF_MINRD && P != 0 && P <= RXF_PMAX && hc >= P &&
             cap64 <= (1ull << 31) && a_off0 < (1ull << 31);
   uint64_t max_slices = GRDMA_MAX_SLICES;
   {
@@ -581,8 +585,10 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     c->credit_msgs = o_credit_msgs + credit;
     c->rx_records = o_rx_records + V;
     if (nsl_final) c->rx_rounds = o_rx_rounds + 1;
-    c->rx_arena_off = a_end;
-    c->rx_slice_idx = slice_idx0 + nsl_final;
+    if (op.append) {  // (a streaming job's cursors)
+      c->rx_arena_off = a_end;
+      c->rx_slice_idx = slice_idx0 + nsl_final;
+    }
     c->rx_hist_count = hc + V;
     {
       const uint32_t rl = (V - 1) - divP(V - 1) * P;

@@ -1527,6 +1527,24 @@ void k_plan_pair_mw(const grdma_rx_op* rxops, const grdma_tx_op* txops, const gr
 }
 
 // ----------------------------------------------------------------------------
+// k_rx_plan_mw: the drain plan alone as many small workgroups (gridDim.y = G: grdma_rx_multi.h, the general planner in
+// the last workgroup to arrive for what that declines) -- an asynchronous endpoint's drains (grdma_endpoint_read_submit),
+// which walk up to the connection's arrival report: a 1 MiB message is 130 records with a period, and the general
+// planner's 30-50 us per pass was what bounded the receiving side of the endpoint vtable.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_rx_plan_mw(const grdma_rx_op* rxops) {
+  const grdma_rx_op& rop = rxops[blockIdx.x];
+  int r = rxm_body(rop, blockIdx.y, gridDim.y);
+  if (r == 3) {
+    __syncthreads();
+    r = rxh_body(rop, blockIdx.y, gridDim.y);
+  }
+  if (r != 2) return;  // (uniform)
+  rx_plan_body(rop);
+}
+
+// ----------------------------------------------------------------------------
 // k_rxplan_gather_job: the drain plan of round t and the GATHER of round t + 1 in ONE launch (the other half of the
 // fused schedule, see k_wire_txplan_job in grdma_kernels.hip): the receive planner -- one workgroup, 28 us of dependent
 // memory round trips during which the rest of the chip used to idle -- needs the wire of round t; the gather of round
@@ -1733,6 +1751,11 @@ extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rxp
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_job(void) { return reinterpret_cast<const void*>(&k_plan_pair_job); }
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_mw(void) { return reinterpret_cast<const void*>(&k_plan_pair_mw); }
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_rx_multi_groups(void) { return RXM_G; }
+extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan_mw(const grdma_rx_op* d_ops, uint32_t nops, hipStream_t s) {
+  if (nops == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_rx_plan_mw, dim3(nops, RXM_G), dim3(PLAN_THREADS), 0, s, d_ops);
+  return hipGetLastError();
+}
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_groups(void) { return TXM_G; }
 // (this translation unit's copy of the index body's counters: the pair kernel's Sends)
 extern "C" __attribute__((visibility("hidden"))) int grdma_tx_fast_sends_pair(uint64_t out[2]) {
