@@ -1,6 +1,8 @@
 """Background poller of the RDMA_BPEV platform (src/core/lib/ibverbs/poller.{h,cc}):
 registered pairs get their wakeup fd kicked when they have something for the event
-engine.  Thin wrapper over grdma_poller_* (one host thread, one k_poll launch per pass)."""
+engine.  Thin wrapper over grdma_poller_*: n_threads host threads (GRPC_RDMA_POLLER_THREAD_NUM) sharing one cursor over
+the slot table; a pass is host loads of the pairs' pinned state lines (no device call for a pair whose peer lives in
+this process; pairs with a remote peer keep one refresh pass of k_poll in flight)."""
 import ctypes as C
 
 from ._lib import GrdmaError, check, load
