@@ -339,6 +339,87 @@ __device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane)
   if ((uint64_t)lane < tail) p[(units << 4) + lane] = 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Words handed from one workgroup to another INSIDE one kernel (the planner workgroups of k_round_xag lay out the plan
+// its copy workgroups move): the workgroups of a launch sit on different XCDs, whose L2s do not see each other's lines
+// until a kernel ends.  The producer's stores are write-through (sc1: at the memory side once acknowledged), it waits
+// for their acknowledgement (GRDMA_WAIT_VMEM) before it publishes; the consumer's loads bypass its L2 (sc1).  The same
+// recipe as the link engine's tables (csrc/grdma_link.hip).  WT / SC1 = false: plain stores and loads (the consumer is
+// a later kernel).  The host emulation has one coherent memory: plain accesses there.
+// ---------------------------------------------------------------------------------------------
+template <bool WT>
+__device__ __forceinline__ void xwg_st32(uint32_t* p, uint32_t v) {
+  if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool WT>
+__device__ __forceinline__ void xwg_st64(uint64_t* p, uint64_t v) {
+  if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool SC1>
+__device__ __forceinline__ uint32_t xwg_ld32(const uint32_t* p) {
+  return SC1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool SC1>
+__device__ __forceinline__ uint64_t xwg_ld64(const uint64_t* p) {
+  return SC1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+// one 32-byte segment descriptor (two 16-byte write-through stores when WT: 8-byte sc1 stores cost 2.7 x per byte)
+template <bool WT>
+__device__ __forceinline__ void xwg_put_seg(grdma_seg* slot, uint64_t dst, uint64_t src, uint64_t len, uint64_t flags) {
+#ifndef GRDMA_WAVE_EMU
+  if (WT) {
+    typedef __attribute__((address_space(1))) u32x4 g_q;
+    g_q* q = (g_q*)(uint64_t)slot;
+    const u32x4 a = {(uint32_t)dst, (uint32_t)(dst >> 32), (uint32_t)src, (uint32_t)(src >> 32)};
+    const u32x4 b = {(uint32_t)len, (uint32_t)(len >> 32), (uint32_t)flags, (uint32_t)(flags >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(q), "v"(a) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(q + 1), "v"(b) : "memory");
+    return;
+  }
+#endif
+  *slot = grdma_seg{dst, src, len, flags};
+}
+// A copy workgroup waits until the plan it is about to move has been committed by the planner workgroups of the same
+// launch (grdma_plan::ready).  ONE wave polls, with ONE 64-byte L2-bypassing load of the plan's header line (lane l
+// reads dword l): the word that says "ready" arrives together with nsegs / ntiles / the tag window / the tile size, and
+// the workgroup's other waves take them from LDS -- a thousand workgroups each reading five header fields per wave past
+// the L2 are twelve thousand requests for one line of one memory channel, which is what the scatter then waits for
+// (measured: 85 us instead of 35 for the launch).  Bounded: a plan that never becomes ready -- a bug, not a state --
+// makes the workgroup leave without moving anything rather than hang the device (the job's verification then fails
+// loudly).  Returns nullptr in that case, else the header's sixteen dwords in LDS.
+struct plan_hdr {
+  uint32_t nsegs, ntiles;
+  uint64_t tag_base, tag_mask;
+  uint32_t tile_bytes;
+};
+__device__ __forceinline__ plan_hdr plan_hdr_of(const uint32_t* w) {
+  static_assert(offsetof(grdma_plan, nsegs) == 0 && offsetof(grdma_plan, ntiles) == 4 && offsetof(grdma_plan, tag_base) == 16 &&
+                    offsetof(grdma_plan, tag_mask) == 24 && offsetof(grdma_plan, tile_bytes) == 32 && offsetof(grdma_plan, ready) == 36,
+                "plan header layout");
+  return plan_hdr{w[0], w[1], (uint64_t)w[4] | ((uint64_t)w[5] << 32), (uint64_t)w[6] | ((uint64_t)w[7] << 32), w[8]};
+}
+__device__ __forceinline__ const uint32_t* plan_wait_ready(const grdma_plan* plan) {
+  __shared__ uint32_t s_hdr[16];
+  __shared__ uint32_t s_ready;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(plan);
+    uint32_t v = 0, ready = 0;
+    for (uint32_t spins = 0; spins < (1u << 16); spins++) {
+      v = __hip_atomic_load(&words[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ready = (uint32_t)__builtin_amdgcn_readlane((int)v, 9);
+      if (ready != 0) break;
+      __builtin_amdgcn_s_sleep(24);
+    }
+    if (lane < 16) s_hdr[lane] = v;
+    if (lane == 0) s_ready = ready;
+  }
+  __syncthreads();
+  return s_ready != 0 ? s_hdr : nullptr;
+}
+
 // Every workgroup stages the tile prefix in LDS (one coalesced load).  A wave takes a
 // CONTIGUOUS run of tiles: one LDS binary search finds the segment of its first tile, the
 // following tiles walk forward through the staged prefix (a 16 KiB record is four tiles
@@ -403,13 +484,22 @@ __device__ __forceinline__ void tiny_store(const grdma_seg& sg, uint8_t v, uint6
   plan_tags(sg, 0, sg.len, tag_base, tm, lane);
 }
 
-template <uint32_t LDS_N, bool CONTIG, uint32_t TILE>
+// a segment descriptor of the plan (SC1: laid out by another workgroup of this launch, see xwg_put_seg)
+template <bool SC1>
+__device__ __forceinline__ grdma_seg plan_seg(const grdma_plan* plan, uint32_t i) {
+  if (!SC1) return plan->segs[i];
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(&plan->segs[i]);
+  return grdma_seg{xwg_ld64<true>(w), xwg_ld64<true>(w + 1), xwg_ld64<true>(w + 2), xwg_ld64<true>(w + 3)};
+}
+
+template <uint32_t LDS_N, bool CONTIG, uint32_t TILE, bool SC1 = false>
 __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t wave,
-                                               uint32_t nwaves, int lane) {
+                                               uint32_t nwaves, int lane, const plan_hdr* hdr = nullptr) {
   __shared__ uint32_t s_prefix[LDS_N + 1];
-  const uint32_t nsegs = plan->nsegs;
-  const uint32_t ntiles = plan->ntiles;
-  const uint64_t tag_base = plan->tag_base, tm = plan->tag_mask;
+  // (hdr: the header as plan_wait_ready fetched it)
+  const uint32_t nsegs = hdr ? hdr->nsegs : xwg_ld32<SC1>(&plan->nsegs);
+  const uint32_t ntiles = hdr ? hdr->ntiles : xwg_ld32<SC1>(&plan->ntiles);
+  const uint64_t tag_base = hdr ? hdr->tag_base : xwg_ld64<SC1>(&plan->tag_base), tm = hdr ? hdr->tag_mask : xwg_ld64<SC1>(&plan->tag_mask);
   // In flight together with the header: the segment of tile `wave`, should the plan turn out to
   // hold one tile per segment (the steady state of both the gather and the scatter: tile t then IS
   // segment t -- no prefix staging, no search, no barrier, one memory round trip less).
@@ -420,7 +510,7 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
   static_assert(sizeof(grdma_seg) == 32, "a pair of descriptors is sixteen dwords");
   const uint32_t w2 = 2 * wave;
   const uint32_t* const seg_words = reinterpret_cast<const uint32_t*>(plan->segs);
-  uint32_t pairw = seg_words[(size_t)(w2 + 1 < GRDMA_MAX_SEGS ? w2 : 0) * 8 + (lane & 15)];
+  uint32_t pairw = xwg_ld32<SC1>(&seg_words[(size_t)(w2 + 1 < GRDMA_MAX_SEGS ? w2 : 0) * 8 + (lane & 15)]);
   if (ntiles == nsegs) {  // (uniform over the workgroup; every segment has at least one tile)
     for (uint32_t t = w2; t < ntiles; t += 2 * nwaves) {
       auto word = [&](int k) -> uint64_t {  // 64-bit word k of the pair, wave-uniform
@@ -430,7 +520,7 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
       const grdma_seg cur0 = {word(0), word(1), word(2), word(3)};
       const grdma_seg cur1 = {word(4), word(5), word(6), word(7)};
       const uint32_t tn = t + 2 * nwaves;
-      pairw = seg_words[(size_t)(tn + 1 < GRDMA_MAX_SEGS && tn < ntiles ? tn : t) * 8 + (lane & 15)];
+      pairw = xwg_ld32<SC1>(&seg_words[(size_t)(tn + 1 < GRDMA_MAX_SEGS && tn < ntiles ? tn : t) * 8 + (lane & 15)]);
       const bool two = t + 1 < ntiles;
       const bool tiny0 = cur0.len <= GRDMA_TINY_MAX, tiny1 = two && cur1.len <= GRDMA_TINY_MAX;
       uint8_t b0 = 0, b1 = 0;
@@ -446,7 +536,7 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
   uint32_t shift = 0;  // entry k of s_prefix is tile_prefix[k << shift]
   while (((nsegs >> shift) + 1) > LDS_N) shift++;
   const uint32_t nsamp = (nsegs >> shift) + 1;  // samples 0 .. nsegs >> shift
-  for (uint32_t i = threadIdx.x; i < nsamp; i += blockDim.x) s_prefix[i] = plan->tile_prefix[i << shift];
+  for (uint32_t i = threadIdx.x; i < nsamp; i += blockDim.x) s_prefix[i] = xwg_ld32<SC1>(&plan->tile_prefix[i << shift]);
   __syncthreads();
   // CONTIG: tiles [wave * per, (wave + 1) * per); otherwise wave, wave + nwaves, ... (each
   // located by its own search)
@@ -468,15 +558,15 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
       // entries seg .. seg + stride - 1 (those that exist): the last one that is <= t
       const uint32_t k = seg + (uint32_t)lane;
       const bool in = (uint32_t)lane < (1u << shift) && k < nsegs;
-      const uint32_t pk = in ? plan->tile_prefix[k] : 0xFFFFFFFFu;
+      const uint32_t pk = in ? xwg_ld32<SC1>(&plan->tile_prefix[k]) : 0xFFFFFFFFu;
       const uint64_t le = __ballot(in && pk <= t);
       const int last = 63 - __builtin_clzll(le);  // lane 0 always qualifies (pk == p0 <= t)
       seg += (uint32_t)last;
       p0 = __shfl(pk, last, 64);
     }
-    pnext = shift ? plan->tile_prefix[seg + 1] : s_prefix[seg + 1];
+    pnext = shift ? xwg_ld32<SC1>(&plan->tile_prefix[seg + 1]) : s_prefix[seg + 1];
   }
-  grdma_seg sg = plan->segs[seg];
+  grdma_seg sg = plan_seg<SC1>(plan, seg);
   for (;; ) {
     const uint64_t off = (uint64_t)(t - p0) * TILE;
     uint64_t n = sg.len - off;
@@ -494,19 +584,19 @@ __device__ __forceinline__ void run_plan_tiles(const grdma_plan* plan, uint32_t 
       do {
         seg++;
         p0 = pnext;
-        pnext = shift ? plan->tile_prefix[seg + 1] : s_prefix[seg + 1];
+        pnext = shift ? xwg_ld32<SC1>(&plan->tile_prefix[seg + 1]) : s_prefix[seg + 1];
       } while (t >= pnext);
-      sg = plan->segs[seg];
+      sg = plan_seg<SC1>(plan, seg);
     }
   }
 }
 
 
 // The plan says which tile size it was laid out for.
-template <uint32_t LDS_N, bool CONTIG = true>
-__device__ __forceinline__ void run_plan(const grdma_plan* plan, uint32_t wave, uint32_t nwaves, int lane) {
-  if (plan->tile_bytes == 16384u) run_plan_tiles<LDS_N, CONTIG, 16384u>(plan, wave, nwaves, lane);
-  else run_plan_tiles<LDS_N, CONTIG, 8192u>(plan, wave, nwaves, lane);
+template <uint32_t LDS_N, bool CONTIG = true, bool SC1 = false>
+__device__ __forceinline__ void run_plan(const grdma_plan* plan, uint32_t wave, uint32_t nwaves, int lane, const plan_hdr* hdr = nullptr) {
+  if ((hdr ? hdr->tile_bytes : xwg_ld32<SC1>(&plan->tile_bytes)) == 16384u) run_plan_tiles<LDS_N, CONTIG, 16384u, SC1>(plan, wave, nwaves, lane, hdr);
+  else run_plan_tiles<LDS_N, CONTIG, 8192u, SC1>(plan, wave, nwaves, lane, hdr);
 }
 
 #endif  // GRDMA_DEVFN_H

@@ -73,6 +73,9 @@ const void* grdma_kernel_fn_plan_pair_mw(void);
 uint32_t grdma_rx_multi_groups(void);
 hipError_t grdma_launch_rx_plan_mw(const grdma_rx_op*, uint32_t, hipStream_t);
 uint32_t grdma_tx_multi_groups(void);
+const void* grdma_kernel_fn_round_xag(void);
+uint64_t grdma_rx_scratch_bytes(void);
+uint32_t grdma_round_xag_resident_blocks(void);
 const void* grdma_kernel_fn_rxplan_gather_job(void);
 uint32_t grdma_kernel_threads(int which);
 uint32_t grdma_copy_resident_blocks(void);
@@ -2626,6 +2629,12 @@ struct grdma_stream_job {
                                       // the memory system (profiles/r03_fused_schedule_experiment.txt)
   int rx_multi = 1;                   // paired schedule: the drain plan laid out by several workgroups (k_plan_pair_mw,
                                       // csrc/grdma_rx_multi.h); GRDMA_RX_MULTI=0: the one-workgroup k_plan_pair_job
+  int fuse_round = 0;                 // GRDMA_JOB_FUSE_ROUND=1: the drain plan of round t, its scatter and the gather of round
+                                      // t + 1 in ONE launch (k_round_xag, grdma_rx_plan.hip), the Send of round t + 1 priced
+                                      // by a launch of its own in front of it
+  int fuse_round_after = -1;          // (tools/ experiment) GRDMA_JOB_FUSE_ROUND_AFTER=k: fuse_round from run k on
+  void** d_scratch = nullptr;         // [n] -> global scratch of the general planner inside k_round_xag
+  std::vector<void*> scratch_bufs;
   int rx_fast = 1;                    // drains of one-Send rounds go through k_rx_fast first (grdma_rx_fast.hip), the
                                       // general planner behind it only does what that kernel declined
   int cumask_bits = 0;                // planner CUs (low bits of the mask); 0 = off
@@ -2655,7 +2664,7 @@ namespace {
 inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 : 2); }
 inline int job_fastkey(const grdma_stream_job* j) {
   return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0) | (j->pair_job ? 8 : 0) | (j->fuse ? 16 : 0) |
-         (j->fuse_ag ? 32 : 0) | (j->rx_multi ? 64 : 0);
+         (j->fuse_ag ? 32 : 0) | (j->rx_multi ? 64 : 0) | (j->fuse_round ? 128 : 0);
 }
 // copy workgroups (1024 threads: one per CU) next to a planner workgroup in a fused launch: every CU but the planner's
 inline uint32_t job_fused_copy_blocks() {
@@ -2752,6 +2761,17 @@ int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
 // stream with an event between every two of them.  The graph's order is a chain already, so this is the same
 // work in the same order; what the events add is the time of each launch by itself (classes 5 = k_plan_pair_job,
 // 6 = k_rx_apply_gather beside the five of the in-order pass).
+// k_round_xag's grid: per link G planner, GB gather and SB scatter workgroups (shape = G | links << 8 | SB << 16)
+struct job_xag_shape { uint32_t grid, shape; };
+inline bool job_round_fused(const grdma_stream_job* j) { return j->fuse_round && j->rx_multi && j->fuse_ag && j->links.size() < 256; }
+job_xag_shape job_xag(const grdma_stream_job* j, uint32_t txb, uint32_t rxb, bool gather) {
+  const uint32_t n = (uint32_t)j->links.size(), G = grdma_rx_multi_groups();
+  static const uint32_t resident = grdma_round_xag_resident_blocks();
+  const uint32_t cap = std::max<uint32_t>(1, resident / n);
+  const uint32_t GB = gather ? std::max<uint32_t>(1, std::min(txb, cap)) : 0;
+  const uint32_t SB = std::max<uint32_t>(1, std::min<uint32_t>(std::min(rxb, cap), 0xFFFFu));
+  return {n * (G + GB + SB), G | (n << 8) | (SB << 16)};
+}
 bool job_is_paired(const grdma_stream_job* j) {
   return j->pipeline && j->burst == 1 && j->rx_fast && job_tx_fast(j) && j->pair_job && !j->fuse && j->rounds >= 1;
 }
@@ -2815,6 +2835,17 @@ int job_enqueue_schedule_instrumented(grdma_stream_job* j, hipStream_t s) {
     }
     const bool more = t + 1 < R;
     const void* txop_next = j->d_txop + job_opset(t + 1) * n;
+    if (job_round_fused(j)) {  // (class 5 = the Send's planners alone, class 6 = k_round_xag)
+      if (more) {
+        HIP_TRY(launch(grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_tx_multi_groups()), grdma_kernel_threads(0), nullptr, txop_next,
+                       j->d_txf, 0u));
+        if (int rc = mark(5)) return rc;
+      }
+      const job_xag_shape xs = job_xag(j, txb, rxb, more);
+      HIP_TRY(launch(grdma_kernel_fn_round_xag(), dim3(xs.grid), grdma_kernel_threads(0), rxop, gplans, j->d_scratch, xs.shape));
+      if (int rc = mark(6)) return rc;
+      continue;
+    }
     if (j->rx_multi)
       HIP_TRY(launch(grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_rx_multi_groups() + (more ? grdma_tx_multi_groups() : 0)),
                      grdma_kernel_threads(0), rxop, more ? txop_next : nullptr, j->d_txf, grdma_rx_multi_groups()));
@@ -3187,6 +3218,23 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
       W[t] = nullptr;
       if (e == hipSuccess && !j->direct) e = add(&W[t], f_cpy, dim3(txb, n), ct, wplans, {G[t]});
       const bool more = t + 1 < R;
+      if (e == hipSuccess && job_round_fused(j)) {
+        // (GRDMA_JOB_FUSE_ROUND) P_{t+1}: W_t        X_t + A_t + G_{t+1} (k_round_xag): P_{t+1}
+        const void* txop_next = j->d_txop + job_opset(t + 1) * n;
+        hipGraphNode_t last = j->direct ? G[t] : W[t];
+        if (more) {
+          e = add3(&P[t + 1], grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_tx_multi_groups()), grdma_kernel_threads(0), nullptr,
+                   txop_next, j->d_txf, {last, at(A, t, 1)}, 0u);
+          last = P[t + 1];
+        }
+        const job_xag_shape xs = job_xag(j, txb, rxb, more);
+        if (e == hipSuccess)
+          e = add3(&X[t], grdma_kernel_fn_round_xag(), dim3(xs.grid), grdma_kernel_threads(0), rxop, gplans, j->d_scratch,
+                   {last, at(A, t, 1)}, xs.shape);
+        A[t] = X[t];
+        if (more) G[t + 1] = X[t];
+        continue;
+      }
       if (e == hipSuccess) {
         const void* txop_next = j->d_txop + job_opset(t + 1) * n;
         if (j->rx_multi)
@@ -3416,6 +3464,8 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
   if (const char* e = getenv("GRDMA_PAIR_JOB")) j->pair_job = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_JOB_FUSE")) j->fuse = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_JOB_FUSE_AG")) j->fuse_ag = atoi(e) != 0;
+  if (const char* e = getenv("GRDMA_JOB_FUSE_ROUND")) j->fuse_round = atoi(e) != 0;
+  if (const char* e = getenv("GRDMA_JOB_FUSE_ROUND_AFTER")) j->fuse_round_after = atoi(e);
   if (const char* e = getenv("GRDMA_TX_FAST")) j->tx_fast = atoi(e) != 0;
   if (const char* e = getenv("GRDMA_SLIM_AFTER")) {  // experiment (tools/gpu_slim.sh): see grdma_stream_job_run
     j->slim_after = atoi(e);
@@ -3466,6 +3516,15 @@ grdma_stream_job* grdma_stream_job_create_multi(uint32_t n, grdma_pair* const* t
   if (ok && !(getenv("GRDMA_JOB_SIZE_HINTS") && atoi(getenv("GRDMA_JOB_SIZE_HINTS")) == 0)) {
     ok = hipMalloc((void**)&j->d_hints, sizeof(grdma_size_hint) * 3 * n) == hipSuccess &&
          hipMemset(j->d_hints, 0, sizeof(grdma_size_hint) * 3 * n) == hipSuccess;
+  }
+  if (ok && (j->fuse_round || j->fuse_round_after >= 0)) {
+    std::vector<void*> ptrs(n, nullptr);
+    for (uint32_t i = 0; i < n && ok; i++) {
+      ok = hipMalloc(&ptrs[i], grdma_rx_scratch_bytes()) == hipSuccess;
+      if (ok) j->scratch_bufs.push_back(ptrs[i]);
+    }
+    ok = ok && hipMalloc((void**)&j->d_scratch, sizeof(void*) * n) == hipSuccess &&
+         hipMemcpy(j->d_scratch, ptrs.data(), sizeof(void*) * n, hipMemcpyHostToDevice) == hipSuccess;
   }
   const size_t sz_tx = sizeof(grdma_tx_op) * 3 * n, sz_rx = sizeof(grdma_rx_op) * 3 * n;
   const size_t sz_txr = sizeof(grdma_tx_result) * n, sz_rxr = sizeof(grdma_rx_result) * 2 * n;
@@ -3571,6 +3630,8 @@ void grdma_stream_job_destroy(grdma_stream_job* j) {
     }
   if (j->d_txf) hipFree(j->d_txf);
   if (j->d_hints) hipFree(j->d_hints);
+  if (j->d_scratch) hipFree(j->d_scratch);
+  for (void* b : j->scratch_bufs) hipFree(b);
   for (grdma_job_link& l : j->links) {
     if (l.d_encpre) hipFree(l.d_encpre);
     if (l.d_lenpre) hipFree(l.d_lenpre);
@@ -3781,6 +3842,7 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
   // register budget) for what those decline.  A job whose last drains / Send keep being declined -- no period in
   // its record sizes, Sends cut by the staging budget, ... -- goes back to the plain planner kernels.
   j->runs++;
+  if (j->fuse_round_after >= 0 && j->runs >= j->fuse_round_after) j->fuse_round = 1;
   if (j->slim_after >= 0) {
     if (j->runs >= j->slim_after) j->rx_fast = j->tx_fast = 1;
     return 0;

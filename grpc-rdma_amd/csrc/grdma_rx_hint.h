@@ -37,9 +37,10 @@ struct rx_lds_hint {
   uint32_t x[RXH_MAX + 1];      // exclusive prefix of the encoded sizes
 };
 
+template <bool WT = false>  // (WT: see rxm_body)
 __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg) {
-  static_assert(sizeof(rx_lds_hint) <= sizeof(rx_lds), "the hinted body's tables fit the receive planners' shared LDS");
-  rx_lds_hint& H = *reinterpret_cast<rx_lds_hint*>(rx_lds_get());
+  static_assert(sizeof(rx_lds_hint) <= sizeof(rx_lds) && sizeof(rx_lds_hint) <= RXM_SMALL_LDS_BYTES, "the tables fit their LDS");
+  rx_lds_hint& H = *reinterpret_cast<rx_lds_hint*>(rx_tables<WT>());
   const grdma_rx_op op = op_in;
   const uint64_t t_begin = __builtin_amdgcn_s_memtime();
   const uint32_t tid = threadIdx.x;
@@ -250,8 +251,8 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
     for (int k = 0; k < 4; k++) {
       if (Lm.len[k] == 0) continue;
       const uint64_t fl = GRDMA_SEG_ZERO_SRC | (k == 0 ? GRDMA_SEG_TAG_HDR : 0) | (k == last_piece ? GRDMA_SEG_TAG_FTR : 0);
-      plan->segs[sg] = {(uint64_t)op.arena + A + Lm.dst_rel[k], (uint64_t)(ring + Lm.off[k]), (uint64_t)Lm.len[k], fl};
-      plan->tile_prefix[sg] = tl;
+      xwg_put_seg<WT>(&plan->segs[sg], (uint64_t)op.arena + A + Lm.dst_rel[k], (uint64_t)(ring + Lm.off[k]), (uint64_t)Lm.len[k], fl);
+      xwg_st32<WT>(&plan->tile_prefix[sg], tl);
       sg++;
       tl += rxf_tiles(Lm.len[k], ts);
     }
@@ -270,6 +271,7 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
   const uint64_t t_emit = __builtin_amdgcn_s_memtime();
 
   // ---- 6. arrival: the last workgroup of the drain commits, or hands the drain to the general planner
+  if (WT) GRDMA_WAIT_VMEM();  // (my plan entries are at the memory side before I count in)
   __syncthreads();
   if (tid == 0) {
     const uint32_t prev = __hip_atomic_fetch_add(&plan->mw_arrive, 1u + (reason ? 0x10000u : 0u), __ATOMIC_RELAXED,
@@ -342,14 +344,14 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
       out_slices[tot_sl].off = a_off0 + tot_by;
       out_slices[tot_sl].len = short_len;
     }
-    plan->nsegs = tot_sg;
-    plan->ntiles = tot_tl;
-    plan->tile_bytes = 1u << ts;
-    plan->tile_prefix[tot_sg] = tot_tl;
+    xwg_st32<WT>(&plan->nsegs, tot_sg);
+    xwg_st32<WT>(&plan->ntiles, tot_tl);
+    xwg_st32<WT>(&plan->tile_bytes, 1u << ts);
+    xwg_st32<WT>(&plan->tile_prefix[tot_sg], tot_tl);
     plan->bytes = tot_n;
-    plan->tag_base = (uint64_t)ring;
-    plan->tag_mask = cap64 - 1;
-    plan->blocks_done = 0;
+    xwg_st64<WT>(&plan->tag_base, (uint64_t)ring);
+    xwg_st64<WT>(&plan->tag_mask, cap64 - 1);
+    xwg_st32<WT>(&plan->blocks_done, 0u);
     c->head = nh;
     c->moving_head = nh;
     c->remain = 0;
@@ -369,13 +371,13 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
     c->rx_h1 = 16u + ((H.n[V - 1] + 7u) & ~7u);
     c->rx_h2 = V >= 2 ? 16u + ((H.n[V - 2] + 7u) & ~7u) : o_h1;
     if (credit) c->status_send.remote_head = credit_head;
-    res->credit_head = credit_head;
+    xwg_st64<WT>(&res->credit_head, credit_head);
     res->nslices = nsl_final;
     res->bytes = tot_n;
     res->consumed = Lr;
     res->records = V;
     res->would_block = 1;
-    res->credit_sent = credit;
+    xwg_st64<WT>(&res->credit_sent, credit);
     res->head = nh;
     res->moving_head = nh;
     res->remain = 0;

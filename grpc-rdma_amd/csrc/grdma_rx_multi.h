@@ -104,13 +104,29 @@ __device__ __forceinline__ void rxm_cyc(const rx_lds_multi& M, uint32_t P, uint3
   *by = q * M.qby[P] + M.qby[r];
 }
 
+// The tables of the multi-workgroup bodies: the receive planners' shared LDS (64 KB, the general planner's arrays), or --
+// WT, the bodies inside the copy launch, whose copy workgroups must keep their occupancy -- an allocation of their own
+// size (the general planner then works out of global scratch, k_round_xag).
+#define RXM_SMALL_LDS_BYTES 33024
+template <bool SMALL>
+__device__ __forceinline__ void* rx_tables() {
+  if (SMALL) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_small[RXM_SMALL_LDS_BYTES];
+    return s_small;
+  }
+  return rx_lds_get();
+}
+
 // Returns 0: not the last workgroup of this drain to arrive (nothing more to do); 1: the last one, the drain is
 // committed; 2: the last one, and a workgroup declined -- the caller runs the general planner; 3: every workgroup alike
 // found the connection without a usable period and the round carries a size table -- the caller runs rxh_body (every
 // thread of the workgroup returns the same value).
+// WT: the plan is moved by copy workgroups of the SAME launch (k_round_xag): plan and credit words are stored
+// write-through and acknowledged before a workgroup arrives (grdma_devfn.h: xwg_*); the caller publishes plan->ready.
+template <bool WT = false>
 __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg) {
-  static_assert(sizeof(rx_lds_multi) <= sizeof(rx_lds), "the multi-workgroup body's tables fit the receive planners' shared LDS");
-  rx_lds_multi& M = *reinterpret_cast<rx_lds_multi*>(rx_lds_get());
+  static_assert(sizeof(rx_lds_multi) <= sizeof(rx_lds) && sizeof(rx_lds_multi) <= RXM_SMALL_LDS_BYTES, "the tables fit their LDS");
+  rx_lds_multi& M = *reinterpret_cast<rx_lds_multi*>(rx_tables<WT>());
   const grdma_rx_op op = op_in;
   const uint64_t t_begin = __builtin_amdgcn_s_memtime();
   const uint32_t tid = threadIdx.x;
@@ -453,8 +469,8 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     for (int k = 0; k < 4; k++) {
       if (L.len[k] == 0) continue;
       const uint64_t fl = GRDMA_SEG_ZERO_SRC | (k == 0 ? GRDMA_SEG_TAG_HDR : 0) | (k == last_piece ? GRDMA_SEG_TAG_FTR : 0);
-      plan->segs[sg] = {(uint64_t)op.arena + A + L.dst_rel[k], (uint64_t)(ring + L.off[k]), (uint64_t)L.len[k], fl};
-      plan->tile_prefix[sg] = tl;
+      xwg_put_seg<WT>(&plan->segs[sg], (uint64_t)op.arena + A + L.dst_rel[k], (uint64_t)(ring + L.off[k]), (uint64_t)L.len[k], fl);
+      xwg_st32<WT>(&plan->tile_prefix[sg], tl);
       sg++;
       tl += rxf_tiles(L.len[k], ts);
     }
@@ -473,6 +489,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   const uint64_t t_emit = __builtin_amdgcn_s_memtime();
 
   // ---- 7. arrival: the last workgroup of the drain commits, or hands the drain to the general planner
+  if (WT) GRDMA_WAIT_VMEM();  // (my plan entries are at the memory side before I count in)
   __syncthreads();
   if (tid == 0) {
     const uint32_t prev = __hip_atomic_fetch_add(&plan->mw_arrive, 1u + (reason ? 0x10000u : 0u), __ATOMIC_RELAXED,
@@ -564,14 +581,14 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
       out_slices[tot_sl].off = a_off0 + tot_by;
       out_slices[tot_sl].len = short_len;
     }
-    plan->nsegs = tot_sg;
-    plan->ntiles = tot_tl;
-    plan->tile_bytes = 1u << ts;
-    plan->tile_prefix[tot_sg] = tot_tl;
+    xwg_st32<WT>(&plan->nsegs, tot_sg);
+    xwg_st32<WT>(&plan->ntiles, tot_tl);
+    xwg_st32<WT>(&plan->tile_bytes, 1u << ts);
+    xwg_st32<WT>(&plan->tile_prefix[tot_sg], tot_tl);
     plan->bytes = tot_n;
-    plan->tag_base = (uint64_t)ring;
-    plan->tag_mask = cap64 - 1;
-    plan->blocks_done = 0;
+    xwg_st64<WT>(&plan->tag_base, (uint64_t)ring);
+    xwg_st64<WT>(&plan->tag_mask, cap64 - 1);
+    xwg_st32<WT>(&plan->blocks_done, 0u);
     c->head = nh;
     c->moving_head = nh;
     c->remain = 0;
@@ -596,13 +613,13 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
       c->rx_h2 = V >= 2 ? M.pat[rl ? rl - 1 : P - 1] : o_h1;
     }
     if (credit) c->status_send.remote_head = credit_head;
-    res->credit_head = credit_head;
+    xwg_st64<WT>(&res->credit_head, credit_head);
     res->nslices = nsl_final;
     res->bytes = tot_n;
     res->consumed = Lr;
     res->records = V;
     res->would_block = 1;
-    res->credit_sent = credit;
+    xwg_st64<WT>(&res->credit_sent, credit);
     res->head = nh;
     res->moving_head = nh;
     res->remain = 0;

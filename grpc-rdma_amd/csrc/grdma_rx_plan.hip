@@ -246,7 +246,11 @@ struct rx_state {
   uint64_t hand_pos;
 };
 
-__device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
+// SCRATCH: the big arrays (rx_lds_general, 64 KB) live in global memory instead of LDS -- the general planner as the
+// rarely-taken fallback inside k_round_xag, whose copy workgroups could not keep their occupancy beside a 64 KB LDS
+// allocation per workgroup.  Same code, same results; slower.
+template <bool SCRATCH = false>
+__device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* scratch = nullptr) {
   // (a private copy: fields read through the reference would be re-fetched from memory
   // after every store the compiler cannot prove unrelated)
   const grdma_rx_op op = op_in;
@@ -273,7 +277,8 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in) {
   __shared__ rx_state S;
   __shared__ uint64_t s_chain[CHAIN_CAP];
   // (the big arrays share their allocation with the steady-state body, which has finished when this one runs)
-  rx_lds* const lds = rx_lds_get();
+  rx_lds* lds;
+  if constexpr (SCRATCH) lds = scratch; else lds = rx_lds_get();
   auto& s_hist = lds->g.hist;
   // padded like the send plan's arrays: contiguous 16-record runs per thread
 #define RXP(i) ((i) + ((i) >> 4))
@@ -1545,6 +1550,115 @@ void k_rx_plan_mw(const grdma_rx_op* rxops) {
 }
 
 // ----------------------------------------------------------------------------
+// k_round_xag: the drain PLAN of round t, its SCATTER and the gather of round t + 1 in ONE launch (x = "X", "A", "G"
+// of the job's schedule).  Per link G planner workgroups (rxm_body / rxh_body, write-through), GB gather workgroups
+// and SB scatter workgroups, all four waves.  The gather moves a plan the launch before laid out and starts at once; the
+// scatter workgroups wait (plan_wait_ready: a bounded spin of one wave on grdma_plan::ready) until the last planner
+// workgroup to arrive has committed the plan -- its entries stored write-through and acknowledged, the scatter's
+// reads of them L2-bypassing (grdma_devfn.h: xwg_*).  The gather hides the planners' latency, and a launch (3.5 us
+// between HIP events beyond its kernel) leaves every round.  A drain the predicting bodies decline is planned by the
+// general planner right here, out of global scratch (scratch[link]), published with an agent-scope release.  The
+// last copy workgroup of the launch to finish clears `ready` for the plan's next use.
+// ----------------------------------------------------------------------------
+#ifndef GRDMA_COPY_CONTIG
+#define GRDMA_COPY_CONTIG true  // (as grdma_kernels.hip)
+#endif
+#ifndef GRDMA_APPLY_CONTIG
+#define GRDMA_APPLY_CONTIG true
+#endif
+// (a 1-D grid, decoded here: the planners of every link first, then the gathers, then the scatters -- workgroups are
+// dispatched in index order, so every planner is on the chip before a scatter workgroup can wait for it, and a scatter
+// workgroup takes a slot only when the planners and gathers in front of it have theirs.  shape = G | links << 8 | SB << 16)
+#ifndef GRDMA_XAG_WAVES
+#define GRDMA_XAG_WAVES 3
+#endif
+__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(GRDMA_XAG_WAVES, GRDMA_XAG_WAVES)))
+void k_round_xag(const grdma_rx_op* rxops, const grdma_plan* const* gplans, rx_lds* const* scratch, uint32_t shape) {
+  static_assert(COPY_THREADS == PLAN_THREADS, "one workgroup shape for planners and copy workgroups");
+  static_assert(offsetof(grdma_plan, pad_line1) % 8 == 4, "the hand-over stamp is an aligned 64-bit word");
+  const uint32_t G = shape & 0xFFu, links = (shape >> 8) & 0xFFu, SB = shape >> 16;
+  const uint32_t GB = (gridDim.x - links * (G + SB)) / links;
+  const int lane = threadIdx.x & 63;
+  uint32_t idx = blockIdx.x;
+  if (idx < links * G) {  // ---- planner workgroups
+    const uint32_t link = idx / G, wg = idx - link * G;
+    const grdma_rx_op& rop = rxops[link];
+    int r = rxm_body<true>(rop, wg, G);
+    if (r == 3) {
+      __syncthreads();
+      r = rxh_body<true>(rop, wg, G);
+    }
+    if (r == 0) return;
+    if (r == 2) {  // (rare) the general planner, then everything it stored written back to memory
+#ifndef GRDMA_XAG_NO_FALLBACK  // (tools/ experiment: what the general planner's registers cost the copy workgroups)
+      rx_plan_body<true>(rop, scratch[link]);
+#endif
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    } else {
+      GRDMA_WAIT_VMEM();  // (the commit's write-through stores are acknowledged)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // (profiling aid: the plan is handed to the scatter -- in the planners' clock, and in the device-wide 100 MHz one)
+      rop.result->dbg[14] = __builtin_amdgcn_s_memtime();
+      xwg_st64<true>(reinterpret_cast<uint64_t*>(&rop.plan->pad_line1[1]), __builtin_amdgcn_s_memrealtime());
+      __hip_atomic_store(&rop.plan->ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  idx -= links * G;
+  grdma_plan* splan;
+  if (idx < links * GB) {  // ---- gather workgroups: the send plan of the launch before
+    const uint32_t link = idx / GB, b = idx - link * GB;
+    splan = rxops[link].plan;
+    const uint32_t wave = (b * COPY_THREADS + threadIdx.x) >> 6;
+    run_plan<256, GRDMA_COPY_CONTIG>(gplans[link], wave, (GB * COPY_THREADS) >> 6, lane);
+  } else {  // ---- scatter workgroups: k_rx_apply's body over the plan committed above
+    idx -= links * GB;
+    const uint32_t link = idx / SB, b = idx - link * SB;
+    const grdma_rx_op& rop = rxops[link];
+    splan = rop.plan;
+    if (const uint32_t* hw = plan_wait_ready(splan)) {
+      const plan_hdr hdr = plan_hdr_of(hw);
+      const uint32_t wave = (b * COPY_THREADS + threadIdx.x) >> 6;
+      run_plan<256, GRDMA_APPLY_CONTIG, true>(splan, wave, (SB * COPY_THREADS) >> 6, lane, &hdr);
+    }
+    // arrival of the scatter workgroups: the last one posts the credit (as rx_apply_body, grdma_kernels.hip)
+    __shared__ unsigned int s_last;
+    GRDMA_WAIT_VMEM();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int prev = __hip_atomic_fetch_add(&splan->blocks_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (prev == SB - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+      grdma_rx_result* res = rop.result;
+      const uint64_t credit_sent = xwg_ld64<true>(&res->credit_sent), credit_head = xwg_ld64<true>(&res->credit_head);
+      if (credit_sent) {
+        grdma_status_report* ps = rop.conn->peer_status;
+        if (ps != nullptr) __hip_atomic_store(&ps->remote_head, credit_head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        grdma_hostline* pl = rop.conn->peer_line;
+        if (pl != nullptr) __hip_atomic_store(&pl->remote_head, credit_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      // (profiling aid: the scatter is done, in 10 ns ticks since the plan was handed over)
+      res->dbg[15] = __builtin_amdgcn_s_memrealtime() - xwg_ld64<true>(reinterpret_cast<const uint64_t*>(&splan->pad_line1[1]));
+      __hip_atomic_store(&res->commit_seq, xwg_ld64<true>(&res->commit_seq) + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  // every copy workgroup of a link counts out; the last one of the launch clears the scatter plan's `ready` for its next use
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int prev = __hip_atomic_fetch_add(&splan->xag_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == SB + GB - 1) {
+      __hip_atomic_store(&splan->xag_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&splan->ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
 // k_rxplan_gather_job: the drain plan of round t and the GATHER of round t + 1 in ONE launch (the other half of the
 // fused schedule, see k_wire_txplan_job in grdma_kernels.hip): the receive planner -- one workgroup, 28 us of dependent
 // memory round trips during which the rest of the chip used to idle -- needs the wire of round t; the gather of round
@@ -1751,6 +1865,15 @@ extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rxp
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_job(void) { return reinterpret_cast<const void*>(&k_plan_pair_job); }
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_mw(void) { return reinterpret_cast<const void*>(&k_plan_pair_mw); }
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_rx_multi_groups(void) { return RXM_G; }
+extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_round_xag(void) { return reinterpret_cast<const void*>(&k_round_xag); }
+extern "C" __attribute__((visibility("hidden"))) uint64_t grdma_rx_scratch_bytes(void) { return sizeof(rx_lds); }
+extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_round_xag_resident_blocks(void) {
+  int dev = 0, cus = 0, a = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 768;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 768;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_round_xag, PLAN_THREADS, 0) != hipSuccess || a <= 0) a = GRDMA_XAG_WAVES;
+  return (uint32_t)(a * cus);
+}
 extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan_mw(const grdma_rx_op* d_ops, uint32_t nops, hipStream_t s) {
   if (nops == 0) return hipSuccess;
   hipLaunchKernelGGL(k_rx_plan_mw, dim3(nops, RXM_G), dim3(PLAN_THREADS), 0, s, d_ops);

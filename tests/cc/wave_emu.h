@@ -463,6 +463,7 @@ inline uint64_t __builtin_amdgcn_s_memtime() {
   static std::atomic<uint64_t> t{0};
   return t.fetch_add(1, std::memory_order_relaxed);
 }
+inline uint64_t __builtin_amdgcn_s_memrealtime() { return __builtin_amdgcn_s_memtime(); }
 inline void __builtin_amdgcn_s_sleep(int) {
   emu::yield_lane();
   sched_yield();

@@ -49,6 +49,8 @@ def main():
         tot = r_[1] - r_[0]
         print("parity %d drain plan: total %d ticks; pattern %d, probe %d, state %d, totals %d, emit %d, arrived %d, commit loads %d, credit %d; V %d P %d workgroups %d (stamp %x)"
               % (odd, tot, r_[2], r_[3], r_[4], r_[5], r_[6], r_[11], r_[12], r_[13], r_[7], r_[8], r_[10], r_[9]))
+        if r_[14]:
+            print("parity %d fused round: plan handed over %d ticks after the planners' start, scatter done %.1f us after that" % (odd, r_[14] - r_[0], r_[15] / 100.0))
         print("parity %d send plan: priced %d, end %d ticks; m %d (stamp %x)" % (odd, t_[1] - t_[0], t_[6] - t_[0], t_[7], t_[9]))
 
 
