@@ -450,9 +450,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--msgs", type=int, default=256, help="1 MiB messages per step")
     ap.add_argument("--ring-kb", type=int,
-                    default=int(os.environ.get("GRPC_RDMA_RING_BUFFER_SIZE_KB", 131072)),
+                    default=int(os.environ.get("GRPC_RDMA_RING_BUFFER_SIZE_KB", 262144)),
                     help="ring size (GRPC_RDMA_RING_BUFFER_SIZE_KB); the reference default is 4096")
     ap.add_argument("--max-sge", type=int, default=4095)
+    ap.add_argument("--sends", type=int, default=2,
+                    help="consecutive Sends per round of the pipelined single-connection legs (rdma_flush sends again while "
+                         "the ring has room; grdma_stream_job_set_sends); 1 = one Send per round")
     ap.add_argument("--launch", choices=["graph", "streams"], default="graph",
                     help="replay a step as one HIP graph, or issue its kernels on the job's streams")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -536,12 +539,14 @@ def main():
         torch.cuda.synchronize()
 
     def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB,
-                pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None, burst=1, reps=1):
+                pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None, burst=1, reps=1, sends=None):
         """n_links connections with rings of ring_kb KiB.  Graph schedule: calibrate the number of
         rounds, capture the graph, time `steps` replays.  Engine schedule: every step is ONE launch of
         the persistent link engine.  Then verify, optionally instrument."""
         ring = ring_kb * 1024
         max_sge = max_sge or args.max_sge
+        if sends is None:
+            sends = args.sends if (pipeline and burst == 1 and n_links == 1 and not engine) else 1
         wf = flags if wire_flags is None else wire_flags
         wls = wls or get_workloads(n_links, msgs_per_link or args.msgs, payload)
         links, keep = [], []
@@ -567,10 +572,13 @@ def main():
             job.set_pipeline(pipeline)
             if burst > 1:
                 job.set_burst(burst)                   # `burst` Sends per round, then one drain
+            if sends > 1:
+                job.set_sends(sends)                   # `sends` consecutive Sends in one plan per round, then one drain
             r = job.run(gs.RUN_EAGER)                  # calibration: how many rounds are needed
             assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
                 r.bytes_delivered, total_n)
-            rounds = int(max(r.tx_rounds, r.rx_rounds)) if burst == 1 else int(r.rx_rounds) + 1
+            # (tx_rounds counts Sends)
+            rounds = int(max(-(-int(r.tx_rounds) // sends), r.rx_rounds)) if burst == 1 else int(r.rx_rounds) + 1
             job.set_rounds(rounds)
             r = job.run(gs.RUN_GRAPH)                  # capture + first replay
             assert r.done and r.bytes_delivered == total_n
@@ -593,7 +601,7 @@ def main():
             all_elapsed.append(grp.max(e))
             barrier()
         elapsed = sorted(all_elapsed)[len(all_elapsed) // 2]
-        out = {"elapsed": elapsed, "all_elapsed": all_elapsed, "rounds": rounds, "verified": None, "classes": None,
+        out = {"elapsed": elapsed, "all_elapsed": all_elapsed, "rounds": rounds, "sends": sends, "verified": None, "classes": None,
                "user_bytes": sum(w.user_bytes for w in wls), "N": total_n,
                "E": sum(w.E for w in wls)}
         if verify:  # correctness of what the timed region produced (untimed)
@@ -670,8 +678,11 @@ def main():
                 r = job.run(gs.RUN_ENGINE)
             else:
                 job.set_pipeline(bool(args.pipeline))
+                h2_sends = args.sends if args.pipeline else 1
+                if h2_sends > 1:
+                    job.set_sends(h2_sends)
                 r = job.run(gs.RUN_EAGER)
-                job.set_rounds(int(max(r.tx_rounds, r.rx_rounds)))
+                job.set_rounds(int(max(-(-int(r.tx_rounds) // h2_sends), r.rx_rounds)))
                 r = job.run(gs.RUN_GRAPH)
             assert r.done and r.bytes_delivered == w.N
             delivered = len(job.delivered_slices(0))
@@ -838,7 +849,7 @@ def main():
     # rounds are the slice list in chunks of max_sge slices (no Send is cut by credit at this ring size).
     sched = head.get("schedule_classes") or {}
     if "scatter_gather" in sched and args.schedule != "engine":
-        sge = min(args.max_sge, 4095)
+        sge = min(args.max_sge, 4095) * head.get("sends", 1)  # (slices per round)
         chunks = [sum(wl.lens[i:i + sge]) for i in range(0, len(wl.lens), sge)]
         sg = sched["scatter_gather"]
         if len(chunks) == rounds and sg["launches"] == rounds - 1:
@@ -939,6 +950,12 @@ def main():
                                   "reference's CPU codec at those knobs beside it (cpu_baseline_ring4096_sge30)"
                                   % args.max_sge),
                    "schedule": schedule,
+                   "sends_per_round": head.get("sends", 1),
+                   "sends_per_round_note": "a round = rdma_flush's loop while the ring has room (rdma_bp_posix.cc:470-524): "
+                                           "that many Sends of <= max_sge slices back to back, then the peer's endpoint reads "
+                                           "until one would block.  Two Sends are 63 MiB: the ring (256 MiB) holds four such rounds, "
+                                           "as the 128 MiB ring of the earlier rounds held four rounds of one Send -- that "
+                                           "configuration is value_ring128m_one_send_per_round",
                    "rounds_per_step": rounds, "connections_per_gpu": 1,
                    "stages": "gather+encode, wire, ready-detect, decode+scatter+zero, credit"},
         "roofline": roofline,
@@ -974,6 +991,15 @@ def main():
             out["prng_payload_verified"] = pr["verified"]
         except Exception as e:
             out["prng_payload_error"] = str(e)[:200]
+    if not args.no_extra_legs and args.pipeline and args.schedule != "engine" and (args.sends > 1 or args.ring_kb != 131072):
+        # the configuration rounds 1 - 3 and the first half of round 4 reported as `value`: a 128 MiB ring, ONE Send per
+        # round (with two, a round is 63 MiB and that ring holds two of them: every other round waits for its credit)
+        try:
+            o1 = measure(131072, max(2, args.steps // 2), 1, not args.no_verify, False, pipeline=True, sends=1)
+            out["value_ring128m_one_send_per_round"] = round(wl.user_bytes * max(2, args.steps // 2) * world / o1["elapsed"] / (1 << 30), 3)
+            out["rounds_per_step_ring128m_one_send_per_round"] = o1["rounds"]
+        except Exception as e:
+            out["ring128m_one_send_per_round_error"] = str(e)[:200]
     if seq is not None:  # same workload and ring, five kernels per round strictly in order
         out["value_sequential"] = round(
             wl.user_bytes * max(2, args.steps // 2) * world / seq["elapsed"] / (1 << 30), 3)
@@ -1079,7 +1105,8 @@ def main():
         # mixed message sizes (examples/cpp/test/common.h: uniform in [1, 4 MiB - 1 KiB]), 64 messages per step
         try:
             mw = MixedWorkload(g, 64)
-            mx = measure(args.ring_kb, half, 1, not args.no_verify, False, pipeline=bool(args.pipeline), wls=[mw])
+            # (one Send per round: the size table a Send leaves for its drain holds 4096 records, csrc/grdma_rx_hint.h)
+            mx = measure(args.ring_kb, half, 1, not args.no_verify, False, pipeline=bool(args.pipeline), wls=[mw], sends=1)
             out["value_mixed_sizes"] = round(mw.user_bytes * half * world / mx["elapsed"] / (1 << 30), 3)
             mx2 = measure(4096, half, 1, not args.no_verify, False, max_sge=30, wls=[mw], burst=16)
             out["value_mixed_sizes_ring4096_sge30"] = round(mw.user_bytes * half * world / mx2["elapsed"] / (1 << 30), 3)

@@ -52,7 +52,8 @@ struct grdma_txf_ctl {
   uint32_t* tile_pre;              // [n + 1] sum of ceil(len_j / tile)
   uint32_t tile_shift;             // GRDMA_PLAN_TILE_SHIFT of the connection
   uint32_t valid;                  // k_tx_index: 1 = usable (no empty slice, lengths below 2 GiB)
-  uint32_t done;                   // (unused)
+  uint32_t sends;                  // > 1: a plan of the planners of grdma_tx_multi.h holds this many consecutive Sends
+                                   // (grdma_stream_job_set_sends; 0 / 1: one Send per plan)
   uint32_t pad;
 };
 

@@ -73,6 +73,7 @@ const void* grdma_kernel_fn_plan_pair_mw(void);
 uint32_t grdma_rx_multi_groups(void);
 hipError_t grdma_launch_rx_plan_mw(const grdma_rx_op*, uint32_t, hipStream_t);
 uint32_t grdma_tx_multi_groups(void);
+uint32_t grdma_tx_multi_max_sends(void);
 const void* grdma_kernel_fn_round_xag(void);
 uint64_t grdma_rx_scratch_bytes(void);
 uint32_t grdma_round_xag_resident_blocks(void);
@@ -2571,6 +2572,7 @@ struct grdma_job_link {
   grdma_plan* d_wireplan2 = nullptr;
   grdma_plan* d_rxplan2 = nullptr;
   uint8_t* d_staging2 = nullptr;
+  uint8_t* d_staging_n[2] = {nullptr, nullptr};  // grdma_stream_job_set_sends: both parities' staging for several Sends per plan
   // burst mode (several Sends per round): plans, staging buffers of Sends 1 .. burst-1
   std::vector<grdma_plan*> b_gplan, b_wplan;
   std::vector<uint8_t*> b_staging;
@@ -2629,6 +2631,8 @@ struct grdma_stream_job {
                                       // the memory system (profiles/r03_fused_schedule_experiment.txt)
   int rx_multi = 1;                   // paired schedule: the drain plan laid out by several workgroups (k_plan_pair_mw,
                                       // csrc/grdma_rx_multi.h); GRDMA_RX_MULTI=0: the one-workgroup k_plan_pair_job
+  uint32_t sends = 1;                 // grdma_stream_job_set_sends: consecutive Sends one round's plan holds (paired schedule,
+                                      // planners of grdma_tx_multi.h / grdma_rx_multi.h: 16 workgroups per Send's worth of records)
   int fuse_round = 0;                 // GRDMA_JOB_FUSE_ROUND=1: the drain plan of round t, its scatter and the gather of round
                                       // t + 1 in ONE launch (k_round_xag, grdma_rx_plan.hip), the Send of round t + 1 priced
                                       // by a launch of its own in front of it
@@ -2664,7 +2668,7 @@ namespace {
 inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 : 2); }
 inline int job_fastkey(const grdma_stream_job* j) {
   return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0) | (j->pair_job ? 8 : 0) | (j->fuse ? 16 : 0) |
-         (j->fuse_ag ? 32 : 0) | (j->rx_multi ? 64 : 0) | (j->fuse_round ? 128 : 0);
+         (j->fuse_ag ? 32 : 0) | (j->rx_multi ? 64 : 0) | (j->fuse_round ? 128 : 0) | ((int)j->sends << 8);
 }
 // copy workgroups (1024 threads: one per CU) next to a planner workgroup in a fused launch: every CU but the planner's
 inline uint32_t job_fused_copy_blocks() {
@@ -2687,6 +2691,19 @@ inline bool job_exec_stale(const grdma_stream_job* j) {
 // the send plan of round t: priced from the index of the slice buffer (built in front of the first round of a
 // step), the general planner in the same launch for what that declines
 inline bool job_tx_fast(const grdma_stream_job* j) { return j->tx_fast && j->burst == 1; }
+// planner workgroups of a round: sixteen per Send's worth of records
+inline uint32_t job_rx_groups(const grdma_stream_job* j) { return grdma_rx_multi_groups() * j->sends; }
+inline uint32_t job_tx_groups(const grdma_stream_job* j) { return grdma_tx_multi_groups() * j->sends; }
+inline bool job_mw(const grdma_stream_job* j) { return j->rx_multi && j->pipeline && j->pair_job && !j->fuse && j->rx_fast && j->burst == 1 && j->tx_fast; }
+hipError_t job_launch_pair_mw(const grdma_rx_op* rxops, const grdma_tx_op* txops, const grdma_txf_ctl* ctls, uint32_t n, uint32_t g_rx,
+                              uint32_t g_tx, hipStream_t s) {
+  // (an array of GRDMA_JOB_HOOK_ARGS entries, as for every kernel launched by address: the runtime reads as many as the kernel has)
+  static uint64_t none = 0;
+  void* args[GRDMA_JOB_HOOK_ARGS];
+  for (uint32_t a = 0; a < GRDMA_JOB_HOOK_ARGS; a++) args[a] = &none;
+  args[0] = (void*)&rxops; args[1] = (void*)&txops; args[2] = (void*)&ctls; args[3] = (void*)&g_rx;
+  return hipLaunchKernel(grdma_kernel_fn_plan_pair_mw(), dim3(n, g_rx + g_tx), dim3(grdma_kernel_threads(0)), args, 0, s);
+}
 inline uint32_t job_index_blocks(const grdma_stream_job* j) {  // k_tx_index: 1024 slices per workgroup
   uint64_t most = 1;
   for (const grdma_job_link& l : j->links) most = std::max<uint64_t>(most, l.count);
@@ -2696,12 +2713,15 @@ hipError_t job_launch_tx_plan(grdma_stream_job* j, int k, uint64_t t, uint32_t n
   if (!job_tx_fast(j)) return grdma_launch_tx_plan(j->d_txop + k * n, n, s);
   hipError_t e = hipSuccess;
   if (t == 0) e = grdma_launch_tx_index(j->d_txf, n, job_index_blocks(j), s);
-  if (e == hipSuccess) e = grdma_launch_tx_plan_job(j->d_txop + k * n, j->d_txf, n, s);
-  return e;
+  if (e != hipSuccess) return e;
+  // (several Sends per plan: only the planners of grdma_tx_multi.h price those -- also in the eager passes)
+  if (j->sends > 1 && job_mw(j)) return job_launch_pair_mw(nullptr, j->d_txop + k * n, j->d_txf, n, 0, job_tx_groups(j), s);
+  return grdma_launch_tx_plan_job(j->d_txop + k * n, j->d_txf, n, s);
 }
 
 // the receive plan of a round: k_rx_plan_job = the straight-line steady-state body, then the general planner for what it declines
 hipError_t job_launch_rx_plan(grdma_stream_job* j, const grdma_rx_op* ops, uint32_t n, hipStream_t s) {
+  if (j->sends > 1 && job_mw(j)) return job_launch_pair_mw(ops, nullptr, j->d_txf, n, job_rx_groups(j), 0, s);
   if (j->rx_fast && j->burst == 1) return grdma_launch_rx_plan_job(ops, n, s);
   return grdma_launch_rx_plan(ops, n, s);
 }
@@ -2765,7 +2785,7 @@ int job_enqueue(grdma_stream_job* j, hipStream_t s, bool instrument) {
 struct job_xag_shape { uint32_t grid, shape; };
 inline bool job_round_fused(const grdma_stream_job* j) { return j->fuse_round && j->rx_multi && j->fuse_ag && j->links.size() < 256; }
 job_xag_shape job_xag(const grdma_stream_job* j, uint32_t txb, uint32_t rxb, bool gather) {
-  const uint32_t n = (uint32_t)j->links.size(), G = grdma_rx_multi_groups();
+  const uint32_t n = (uint32_t)j->links.size(), G = job_rx_groups(j);
   static const uint32_t resident = grdma_round_xag_resident_blocks();
   const uint32_t cap = std::max<uint32_t>(1, resident / n);
   const uint32_t GB = gather ? std::max<uint32_t>(1, std::min(txb, cap)) : 0;
@@ -2818,7 +2838,7 @@ int job_enqueue_schedule_instrumented(grdma_stream_job* j, hipStream_t s) {
     if (t == 0) {
       if (j->rx_multi) {  // k_tx_index + the Send priced by k_plan_pair_mw's small workgroups (as the graph does)
         HIP_TRY(grdma_launch_tx_index(j->d_txf, n, job_index_blocks(j), s));
-        HIP_TRY(launch(grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_tx_multi_groups()), grdma_kernel_threads(0), nullptr,
+        HIP_TRY(launch(grdma_kernel_fn_plan_pair_mw(), dim3(n, job_tx_groups(j)), grdma_kernel_threads(0), nullptr,
                        j->d_txop + k * n, j->d_txf, 0u));
       } else {
         HIP_TRY(job_launch_tx_plan(j, k, 0, n, s));  // k_tx_index + k_tx_plan_job
@@ -2837,7 +2857,7 @@ int job_enqueue_schedule_instrumented(grdma_stream_job* j, hipStream_t s) {
     const void* txop_next = j->d_txop + job_opset(t + 1) * n;
     if (job_round_fused(j)) {  // (class 5 = the Send's planners alone, class 6 = k_round_xag)
       if (more) {
-        HIP_TRY(launch(grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_tx_multi_groups()), grdma_kernel_threads(0), nullptr, txop_next,
+        HIP_TRY(launch(grdma_kernel_fn_plan_pair_mw(), dim3(n, job_tx_groups(j)), grdma_kernel_threads(0), nullptr, txop_next,
                        j->d_txf, 0u));
         if (int rc = mark(5)) return rc;
       }
@@ -2847,8 +2867,8 @@ int job_enqueue_schedule_instrumented(grdma_stream_job* j, hipStream_t s) {
       continue;
     }
     if (j->rx_multi)
-      HIP_TRY(launch(grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_rx_multi_groups() + (more ? grdma_tx_multi_groups() : 0)),
-                     grdma_kernel_threads(0), rxop, more ? txop_next : nullptr, j->d_txf, grdma_rx_multi_groups()));
+      HIP_TRY(launch(grdma_kernel_fn_plan_pair_mw(), dim3(n, job_rx_groups(j) + (more ? job_tx_groups(j) : 0)),
+                     grdma_kernel_threads(0), rxop, more ? txop_next : nullptr, j->d_txf, job_rx_groups(j)));
     else
     HIP_TRY(launch(grdma_kernel_fn_plan_pair_job(), dim3(n, more ? 2 : 1), grdma_rx_plan_job_threads(), rxop,
                    more ? txop_next : nullptr, j->d_txf));
@@ -3124,7 +3144,7 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
     if (e2 != hipSuccess) return e2;
     // (the first Send of a step priced by the small workgroups of the planner pair too: k_plan_pair_mw with no drain)
     if (j->rx_multi && j->pipeline && j->pair_job && !j->fuse)
-      return add3(&P[t], grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_tx_multi_groups()), grdma_kernel_threads(0), nullptr, txop,
+      return add3(&P[t], grdma_kernel_fn_plan_pair_mw(), dim3(n, job_tx_groups(j)), grdma_kernel_threads(0), nullptr, txop,
                   j->d_txf, {pi}, 0u);
     return add2(&P[t], f_txj, dim3(n), grdma_tx_plan_job_threads(), txop, j->d_txf, {pi});
   };
@@ -3223,7 +3243,7 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
         const void* txop_next = j->d_txop + job_opset(t + 1) * n;
         hipGraphNode_t last = j->direct ? G[t] : W[t];
         if (more) {
-          e = add3(&P[t + 1], grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_tx_multi_groups()), grdma_kernel_threads(0), nullptr,
+          e = add3(&P[t + 1], grdma_kernel_fn_plan_pair_mw(), dim3(n, job_tx_groups(j)), grdma_kernel_threads(0), nullptr,
                    txop_next, j->d_txf, {last, at(A, t, 1)}, 0u);
           last = P[t + 1];
         }
@@ -3238,9 +3258,9 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
       if (e == hipSuccess) {
         const void* txop_next = j->d_txop + job_opset(t + 1) * n;
         if (j->rx_multi)
-          e = add3(&X[t], grdma_kernel_fn_plan_pair_mw(), dim3(n, grdma_rx_multi_groups() + (more ? grdma_tx_multi_groups() : 0)),
+          e = add3(&X[t], grdma_kernel_fn_plan_pair_mw(), dim3(n, job_rx_groups(j) + (more ? job_tx_groups(j) : 0)),
                    grdma_kernel_threads(0), rxop, more ? txop_next : nullptr, j->d_txf, {j->direct ? G[t] : W[t], at(A, t, 1)},
-                   grdma_rx_multi_groups());
+                   job_rx_groups(j));
         else
         e = add3(&X[t], grdma_kernel_fn_plan_pair_job(), dim3(n, more ? 2 : 1), grdma_rx_plan_job_threads(), rxop,
                  more ? txop_next : nullptr, j->d_txf, {j->direct ? G[t] : W[t], at(A, t, 1)});
@@ -3648,6 +3668,8 @@ void grdma_stream_job_destroy(grdma_stream_job* j) {
     hipFree(l.d_wireplan2);
     hipFree(l.d_rxplan2);
     hipFree(l.d_staging2);
+    for (uint8_t* b : l.d_staging_n)
+      if (b) hipFree(b);
     hipFree(l.d_lk);
     for (auto* t : l.d_tab) hipFree(t);
     for (auto* sb : l.d_staging_more) hipFree(sb);
@@ -3670,6 +3692,37 @@ int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds) {
 int grdma_stream_job_set_pipeline(grdma_stream_job* j, int on) {
   if (!j) return fail(GRDMA_ERR_INVALID, "null job");
   j->pipeline = on ? 1 : 0;
+  return 0;
+}
+
+// `sends` consecutive Sends per round in ONE plan (1 = the plain schedule): what rdma_flush does while the ring has
+// room -- Send, advance the cursor, Send again (rdma_bp_posix.cc:470-524) -- priced by the planners of
+// csrc/grdma_tx_multi.h from the index, Send k + 1 from the state Send k leaves; the peer drains once per round.  For
+// the paired schedule with the small planner workgroups (the default of a pipelined job); other schedules keep one
+// Send per round.  The staging buffers of both parities then hold `sends` x ring / 2 bytes.
+int grdma_stream_job_set_sends(grdma_stream_job* j, uint32_t sends) {
+  if (int rc = require_ctx()) return rc;
+  if (!j || sends == 0 || sends > grdma_tx_multi_max_sends()) return fail(GRDMA_ERR_INVALID, "sends must be 1..%u", grdma_tx_multi_max_sends());
+  if (sends == j->sends) return 0;
+  const uint32_t n = (uint32_t)j->links.size();
+  HIP_TRY(hipStreamSynchronize(j->stream));
+  for (uint32_t i = 0; i < n; i++) {
+    grdma_job_link& l = j->links[i];
+    if (!j->direct && sends > 1) {
+      const size_t bytes = (size_t)sends * (l.tx->ring_size / 2) + 64;
+      for (int q = 0; q < 2; q++) {
+        if (l.d_staging_n[q]) continue;
+        HIP_TRY(hipMalloc((void**)&l.d_staging_n[q], (size_t)grdma_tx_multi_max_sends() * (l.tx->ring_size / 2) + 64));
+        HIP_TRY(hipMemset(l.d_staging_n[q], 0, bytes));
+      }
+    }
+    for (int k = 0; k < 3; k++) {
+      uint8_t* alt = (sends > 1 && !j->direct) ? l.d_staging_n[k == 1 ? 1 : 0] : (k == 1 ? l.d_staging2 : nullptr);
+      HIP_TRY(hipMemcpy(&j->d_txop[k * n + i].staging_alt, &alt, sizeof(alt), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(&j->d_txf[i].sends, &sends, sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  j->sends = sends;
   return 0;
 }
 

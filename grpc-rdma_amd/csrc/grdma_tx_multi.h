@@ -25,6 +25,7 @@ namespace {
 #define TXM_THREADS 256u
 #define TXM_WAVES (TXM_THREADS / 64u)
 #define TXM_G 16u   // workgroups per Send: 16 x 256 records
+#define TXM_MAX_SENDS 2u  // consecutive Sends one plan may hold (grdma_txf_ctl::sends)
 static_assert(TXM_G * TXM_THREADS >= GRDMA_TX_MAX_RECORDS, "one pass covers a Send");
 
 // number of threads of the workgroup whose flag is set (every thread gets the count)
@@ -39,8 +40,27 @@ __device__ __forceinline__ uint32_t txm_count(bool flag, uint32_t* s_cnt) {
   return n;
 }
 
-// Returns 0: not the last workgroup of this Send to arrive; 1: the last one, the Send is planned; 2: the last one,
+// What one Send of the round was priced at (uniform over the workgroup, and the same in every workgroup).
+struct txm_send {
+  uint64_t tail0, start, byte_idx, offered;  // the state in front of it: remote_tail_, the rdma_flush cursor, what the write still holds
+  uint64_t m, nrec, short_pay, st_short;     // slices offered, records that go out whole, the short record behind them
+  uint64_t base_e, base_t, D, Dt;            // the index relative to the Send's first slice (the first one may be cut)
+  uint32_t wrap_rec, wrap_extra;             // direct wire: the record whose payload crosses the ring end
+  uint64_t nrec_total, sent, staged, ntiles, nsegs, new_tail, idx, bidx;
+  bool performed;
+};
+
+// Returns 0: not the last workgroup of this round to arrive; 1: the last one, the round is planned; 2: the last one,
 // and the body declined (in every workgroup alike: nothing written) -- the caller runs the general planner.
+//
+// ctl->sends > 1 (a streaming job's grdma_stream_job_set_sends): the plan holds that many CONSECUTIVE Sends -- what
+// rdma_flush does while the ring has room (rdma_bp_posix.cc:470-524: Send, advance the cursor, Send again) -- priced one
+// after the other from the same index: Send k + 1 starts at the tail, cursor and free space Send k leaves (no credit
+// arrives in between: this launch posts none), is skipped when Send k took the last slice, and its records follow
+// Send k's in the gather plan, in the staging buffer (which then holds `sends` x staging_cap bytes) and in the ring,
+// so the wire plan is still at most two pieces.  Every workgroup prices every Send (two round trips each); the
+// records of all of them are then spread over the threads of all workgroups.  State and counters advance Send by
+// Send (tx_rounds counts Sends); the result block is the LAST performed Send's.
 __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_txf_ctl* ctl, const uint32_t wg, const uint32_t nwg) {
   const grdma_tx_op op = op_in;
   const uint64_t t_begin = __builtin_amdgcn_s_memtime();
@@ -51,48 +71,53 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
   __shared__ uint32_t s_last;
 
   // ---- state; what this body takes (as txf_body)
-  const uint64_t cap = c->cap, mask = cap - 1, S = c->staging_cap, tail0 = c->remote_tail;
+  const uint64_t cap = c->cap, mask = cap - 1, S = c->staging_cap;
   const bool connected = c->status == GRDMA_PAIR_CONNECTED;
   const uint64_t n = ctl->n;
   const uint64_t* const enc_pre = ctl->enc_pre;
   const uint64_t* const len_pre = ctl->len_pre;
   const uint32_t* const tile_pre = ctl->tile_pre;
   const bool direct = c->wire_direct != 0;
+  const uint32_t NS = ctl->sends > 1 ? (ctl->sends < TXM_MAX_SENDS ? ctl->sends : TXM_MAX_SENDS) : 1u;
   const bool ok = ctl->valid != 0 && ctl->slices == op.slices && n == op.nslices && op.use_cursor != 0 && !op.inline_copy &&
                   connected && (direct || op.wire_plan != nullptr) && cap <= (1ull << 31) &&
-                  ctl->tile_shift == GRDMA_PLAN_TILE_SHIFT(cap) && nwg * TXM_THREADS >= GRDMA_TX_MAX_RECORDS - 1;
+                  ctl->tile_shift == GRDMA_PLAN_TILE_SHIFT(cap) &&
+                  (uint64_t)nwg * TXM_THREADS >= (uint64_t)NS * (GRDMA_TX_MAX_RECORDS - 1) &&
+                  (uint64_t)NS * GRDMA_TX_MAX_RECORDS + NS <= GRDMA_MAX_SEGS && (NS == 1 || direct || op.staging_alt != nullptr);
   // get_remote_head(), pair.h:229-233
   const uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  uint64_t start = op.use_cursor == 1 ? c->tx_slice_idx : 0;
-  const uint64_t byte_idx = op.use_cursor == 1 ? c->tx_byte_idx : 0;
-  const uint64_t remaining = c->tx_remaining;
-  uint32_t max_sge = c->max_sge;
-
-  uint64_t nrec = 0, short_pay = 0, st_short = 0, base_e = 0, base_t = 0, D = 0, Dt = 0, m = 0;
-  uint32_t wrap_rec = 0xFFFFFFFFu, wrap_extra = 0;
+  const uint32_t max_sge = c->max_sge;
   const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap);
   const uint64_t TB = 1ull << ts;
-  uint64_t free0 = 0, room0 = 0;
-  const grdma_sge* sl = op.slices;
   uint8_t* const staging = op.staging_alt ? op.staging_alt : c->staging;
-  if (ok) {  // (uniform)
+
+  // ---- one Send priced from the state in front of it (every thread gets the same answer)
+  auto price = [&](uint64_t tail0, uint64_t start, uint64_t byte_idx, uint64_t offered) -> txm_send {
+    txm_send q;
+    q.tail0 = tail0; q.byte_idx = byte_idx; q.offered = offered;
+    q.nrec = q.short_pay = q.st_short = q.base_e = q.base_t = q.D = q.Dt = q.m = 0;
+    q.wrap_rec = 0xFFFFFFFFu; q.wrap_extra = 0;
+    q.performed = true;
     if (start > n) start = n;
+    q.start = start;
     const uint64_t avail = n - start;
-    m = avail;
+    uint64_t m = avail;
     if (m > max_sge) m = max_sge;
     if (m > GRDMA_TX_MAX_RECORDS - 1) m = GRDMA_TX_MAX_RECORDS - 1;
-    sl = op.slices + start;
+    q.m = m;
+    const grdma_sge* sl = op.slices + start;
     const uint64_t occupied0 = (tail0 + cap - rhead) & mask;
-    free0 = cap - occupied0;
-    room0 = S < free0 ? S : free0;
+    const uint64_t free0 = cap - occupied0;
+    const uint64_t room0 = S < free0 ? S : free0;
     // the first slice may have been sent in part: its record is shorter than the index says
     if (m) {
       const uint64_t len0 = sl[0].len, l0 = sat_sub(len0, byte_idx);
-      base_e = enc_pre[start];
-      base_t = tile_pre[start];
-      D = enc_size(l0) - (enc_pre[start + 1] - base_e);              // (<= 0 as a signed number; modular arithmetic)
-      Dt = ((l0 + TB - 1) >> ts) - (tile_pre[start + 1] - base_t);
+      q.base_e = enc_pre[start];
+      q.base_t = tile_pre[start];
+      q.D = enc_size(l0) - (enc_pre[start + 1] - q.base_e);              // (<= 0 as a signed number; modular arithmetic)
+      q.Dt = ((l0 + TB - 1) >> ts) - (tile_pre[start + 1] - q.base_t);
     }
+    const uint64_t base_e = q.base_e, D = q.D;
     // st_i(k): staging offset of record k of this Send; st_n(k): where record k ends
     auto st_i_of = [&](uint64_t k, uint64_t e_k) -> uint64_t { return k == 0 ? 0 : e_k - base_e + D; };
     // ---- whole records (st_n + 8 <= room0) and records that start in front of the ring end (direct wire): two
@@ -109,7 +134,7 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
       c_whole = txm_count(whole, s_cnt);
       c_front = txm_count(front, s_cnt);
     }
-    uint64_t nfront;
+    uint64_t nrec, nfront;
     {
       const uint64_t lo_w = (uint64_t)c_whole * step, lo_f = (uint64_t)c_front * step;
       const uint64_t kw = lo_w + tid, kf = lo_f + tid;
@@ -121,57 +146,112 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
       nrec = lo_w + txm_count(whole, s_cnt);
       nfront = lo_f + txm_count(front, s_cnt);
     }
+    q.nrec = nrec;
     // ---- the short record behind the whole ones, the record that may cross the ring end: uniform loads, one round trip
     {
       const uint64_t wi = nfront ? nfront - 1 : 0;  // the last record that starts in front of the ring end
       const bool has_short = nrec < m;
       const uint64_t len_s = has_short ? sl[nrec].len : 0, e_s = m ? enc_pre[start + (nrec < m ? nrec : m)] : 0;
       const uint64_t len_w = (direct && nfront) ? sl[wi].len : 0, e_w = (direct && nfront) ? enc_pre[start + wi] : 0;
-      st_short = m ? st_i_of(nrec, e_s) : 0;  // st(nrec): where the short record starts, or st(m) = the end of the Send
+      q.st_short = m ? st_i_of(nrec, e_s) : 0;  // st(nrec): where the short record starts, or st(m) = the end of the Send
       if (has_short) {
         // (pay = min(len, W(S - st), W(free0 - st)): it did not fit whole)
         uint64_t p = nrec == 0 ? sat_sub(len_s, byte_idx) : len_s;
-        const uint64_t a = writable_of(sat_sub(S, st_short)), b = writable_of(sat_sub(free0, st_short));
+        const uint64_t a = writable_of(sat_sub(S, q.st_short)), b = writable_of(sat_sub(free0, q.st_short));
         if (a < p) p = a;
         if (b < p) p = b;
-        short_pay = p;
+        q.short_pay = p;
       }
-      const uint64_t nrec_total = nrec + (short_pay > 0 ? 1 : 0);
+      const uint64_t nrec_total = nrec + (q.short_pay > 0 ? 1 : 0);
       if (direct && nfront && wi < nrec_total) {
-        const uint64_t p = wi == nrec ? short_pay : (wi == 0 ? sat_sub(len_w, byte_idx) : len_w);
+        const uint64_t p = wi == nrec ? q.short_pay : (wi == 0 ? sat_sub(len_w, byte_idx) : len_w);
         const uint64_t pay_off = (tail0 + st_i_of(wi, e_w) + 8) & mask;
         if (pay_off + p > cap) {
           const uint64_t l1 = cap - pay_off;
-          wrap_rec = (uint32_t)wi;
-          wrap_extra = (uint32_t)(((l1 + TB - 1) >> ts) + ((p - l1 + TB - 1) >> ts) - ((p + TB - 1) >> ts));
+          q.wrap_rec = (uint32_t)wi;
+          q.wrap_extra = (uint32_t)(((l1 + TB - 1) >> ts) + ((p - l1 + TB - 1) >> ts) - ((p + TB - 1) >> ts));
         }
       }
     }
+    // ---- totals behind the whole records (two uniform loads), the rdma_flush cursor walk (rdma_bp_posix.cc:480-493)
+    q.nrec_total = nrec + (q.short_pay > 0 ? 1 : 0);
+    const uint64_t lp_start = m ? len_pre[start] : 0;
+    q.sent = q.short_pay;
+    q.ntiles = (q.short_pay + TB - 1) >> ts;
+    if (nrec) {
+      q.sent += len_pre[start + nrec] - lp_start - byte_idx;
+      q.ntiles += tile_pre[start + nrec] - q.base_t + q.Dt;
+    }
+    q.ntiles += q.wrap_extra;
+    q.staged = (nrec || q.short_pay) ? q.st_short + (q.short_pay > 0 ? enc_size(q.short_pay) : 0) : 0;
+    q.nsegs = q.nrec_total + (q.wrap_rec != 0xFFFFFFFFu ? 1 : 0);
+    q.new_tail = (tail0 + q.staged) & mask;
+    q.idx = start + nrec;
+    q.bidx = 0;
+    if (q.short_pay > 0) q.bidx = (nrec == 0 ? byte_idx : 0) + q.short_pay;
+    else if (nrec == 0) q.bidx = byte_idx;
+    return q;
+  };
+
+  txm_send Q[TXM_MAX_SENDS];
+  uint64_t rec0[TXM_MAX_SENDS + 1], seg0[TXM_MAX_SENDS + 1], tile0[TXM_MAX_SENDS + 1], stg0[TXM_MAX_SENDS + 1];
+  rec0[0] = seg0[0] = tile0[0] = stg0[0] = 0;
+  uint32_t performed = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < TXM_MAX_SENDS; k++) {
+    Q[k].performed = false;
+    Q[k].nrec_total = Q[k].nsegs = Q[k].ntiles = Q[k].staged = Q[k].m = 0;
+    if (ok && k < NS) {  // (uniform)
+      if (k == 0) {
+        const uint64_t remaining = c->tx_remaining;
+        Q[0] = price(c->remote_tail, op.use_cursor == 1 ? c->tx_slice_idx : 0, op.use_cursor == 1 ? c->tx_byte_idx : 0,
+                     op.use_cursor == 1 ? remaining : len_pre[n]);
+        performed = 1;
+      } else if (Q[k - 1].performed && Q[k - 1].idx < n) {  // the write still holds data: rdma_flush sends again
+        Q[k] = price(Q[k - 1].new_tail, Q[k - 1].idx, Q[k - 1].bidx, Q[k - 1].offered - Q[k - 1].sent);
+        performed = k + 1;
+      }
+    }
+    rec0[k + 1] = rec0[k] + Q[k].nrec_total;
+    seg0[k + 1] = seg0[k] + Q[k].nsegs;
+    tile0[k + 1] = tile0[k] + Q[k].ntiles;
+    stg0[k + 1] = stg0[k] + Q[k].staged;
   }
-  const uint64_t nrec_total = nrec + (short_pay > 0 ? 1 : 0);
+  const uint64_t nrec_all = rec0[TXM_MAX_SENDS];
+  const bool table = op.sizes_out != nullptr && nrec_all <= GRDMA_TX_MAX_RECORDS;  // (the size table holds one Send's worth)
   const uint64_t t_priced = __builtin_amdgcn_s_memtime();
 
   // ---- my record: its segment and tile-prefix entry (AppendHeader / AppendFooter ride on the segment), as txf_body
-  const uint64_t i = (uint64_t)wg * TXM_THREADS + tid;
-  if (ok && i < nrec_total) {
-    const grdma_sge g = sl[i];
-    const uint64_t e0 = enc_pre[start + i];
-    const uint32_t tp0 = tile_pre[start + i];
-    const uint64_t st_i = i == 0 ? 0 : e0 - base_e + D;
-    const uint64_t p = i == nrec ? short_pay : (i == 0 ? sat_sub(g.len, byte_idx) : g.len);
+  const uint64_t gi = (uint64_t)wg * TXM_THREADS + tid;
+  if (ok && gi < nrec_all) {
+    // (which Send the record belongs to: selected field by field, the Sends stay in registers)
+    txm_send q = Q[0];
+    uint64_t rec_k = 0, seg_k = 0, tile_k = 0, stg_k = 0;
+#pragma unroll
+    for (uint32_t kk = 1; kk < TXM_MAX_SENDS; kk++)
+      if (gi >= rec0[kk]) {
+        q = Q[kk];
+        rec_k = rec0[kk]; seg_k = seg0[kk]; tile_k = tile0[kk]; stg_k = stg0[kk];
+      }
+    const uint64_t i = gi - rec_k;
+    const grdma_sge g = op.slices[q.start + i];
+    const uint64_t e0 = enc_pre[q.start + i];
+    const uint32_t tp0 = tile_pre[q.start + i];
+    const uint64_t st_i = i == 0 ? 0 : e0 - q.base_e + q.D;
+    const uint64_t p = i == q.nrec ? q.short_pay : (i == 0 ? sat_sub(g.len, q.byte_idx) : g.len);
     const uint64_t tagw = GRDMA_SEG_TAG_WRITE | (p << GRDMA_SEG_TAG_LEN_SHIFT);
-    if (op.sizes_out != nullptr) op.sizes_out->n[i] = (uint32_t)p;  // (for the drain of the same round: grdma_size_hint)
-    const uint8_t* src = g.ptr + (i == 0 ? byte_idx : 0);
-    const uint32_t t0 = i == 0 ? 0u : (uint32_t)(tp0 - base_t + Dt);
+    if (table) op.sizes_out->n[gi] = (uint32_t)p;  // (for the drain of the same round: grdma_size_hint)
+    const uint8_t* src = g.ptr + (i == 0 ? q.byte_idx : 0);
+    const uint32_t t0 = (uint32_t)tile_k + (i == 0 ? 0u : (uint32_t)(tp0 - q.base_t + q.Dt));
     if (!direct) {
-      plan->segs[i] = {(uint64_t)(staging + st_i + 8), (uint64_t)src, p, tagw | GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR};
-      plan->tile_prefix[i] = t0;
+      plan->segs[seg_k + i] = {(uint64_t)(staging + stg_k + st_i + 8), (uint64_t)src, p, tagw | GRDMA_SEG_TAG_HDR | GRDMA_SEG_TAG_FTR};
+      plan->tile_prefix[seg_k + i] = t0;
     } else {
       uint8_t* const ring = c->peer_ring;
-      const uint64_t pay_off = (tail0 + st_i + 8) & mask;
-      const uint64_t seg = i + ((uint32_t)i > wrap_rec ? 1 : 0);
-      const uint32_t tx0 = t0 + ((uint32_t)i > wrap_rec ? wrap_extra : 0u);
-      if ((uint32_t)i == wrap_rec) {
+      const uint64_t pay_off = (q.tail0 + st_i + 8) & mask;
+      const uint64_t seg = seg_k + i + ((uint32_t)i > q.wrap_rec ? 1 : 0);
+      const uint32_t tx0 = t0 + ((uint32_t)i > q.wrap_rec ? q.wrap_extra : 0u);
+      if ((uint32_t)i == q.wrap_rec) {
         const uint64_t l1 = cap - pay_off;
         plan->segs[seg] = {(uint64_t)(ring + pay_off), (uint64_t)src, l1, tagw | GRDMA_SEG_TAG_HDR};
         plan->segs[seg + 1] = {(uint64_t)ring, (uint64_t)(src + l1), p - l1, tagw | GRDMA_SEG_TAG_FTR};
@@ -203,54 +283,56 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     return 2;
   }
   if (tid == 0) {
-    const uint64_t offered = op.use_cursor == 1 ? remaining : len_pre[n];
     const uint64_t o_written = c->total_written, o_records = c->tx_records, o_rounds = c->tx_rounds;
-    const uint64_t o_seq = op.result->seq, lp_start = m ? len_pre[start] : 0;
-    // totals behind the whole records
-    uint64_t sent = short_pay, ntiles = (short_pay + TB - 1) >> ts;
-    if (nrec) {
-      sent += len_pre[start + nrec] - lp_start - byte_idx;
-      ntiles += tile_pre[start + nrec] - base_t + Dt;
+    const uint64_t o_seq = op.result->seq;
+    txm_send L = Q[0];  // the last Send performed: the state it leaves, its result
+#pragma unroll
+    for (uint32_t kk = 1; kk < TXM_MAX_SENDS; kk++)
+      if (Q[kk].performed) L = Q[kk];
+    const uint64_t tail0 = Q[0].tail0;
+    const uint64_t nsegs = seg0[TXM_MAX_SENDS], ntiles = tile0[TXM_MAX_SENDS], staged_all = stg0[TXM_MAX_SENDS];
+    uint64_t sent_all = 0, rounds = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < TXM_MAX_SENDS; k++) {
+      sent_all += Q[k].performed ? Q[k].sent : 0;
+      rounds += (Q[k].performed && Q[k].nrec_total) ? 1 : 0;
     }
-    const uint64_t st_last = st_short;  // st(nrec)
-    const uint64_t staged = (nrec || short_pay) ? st_last + (short_pay > 0 ? enc_size(short_pay) : 0) : 0;
-    const uint64_t nsegs = nrec_total + (wrap_rec != 0xFFFFFFFFu ? 1 : 0);
-    ntiles += wrap_extra;
     plan->nsegs = (uint32_t)nsegs;
     plan->ntiles = (uint32_t)ntiles;
     plan->tile_bytes = (uint32_t)TB;
     plan->tile_prefix[nsegs] = (uint32_t)ntiles;
-    plan->bytes = sent;
+    plan->bytes = sent_all;
     plan->tag_base = direct ? (uint64_t)c->peer_ring : (uint64_t)staging;
     plan->tag_mask = direct ? mask : ~0ull;
-    const uint64_t new_tail = (tail0 + staged) & mask;
-    // the <= 2 RDMA WRITEs of GetWriteRequests(sg_list), ring_buffer.cc:261-330
-    const uint64_t seg1 = staged < cap - tail0 ? staged : cap - tail0;
+    // the <= 2 RDMA WRITEs of GetWriteRequests(sg_list), ring_buffer.cc:261-330 (of the last Send performed)
     grdma_tx_result* r = op.result;
     r->wr_count = 0;
     r->wr_off[0] = r->wr_off[1] = r->wr_len[0] = r->wr_len[1] = 0;
-    if (staged > 0) {
-      r->wr_off[0] = tail0;
-      r->wr_len[0] = seg1;
+    if (L.staged > 0) {
+      const uint64_t s1 = L.staged < cap - L.tail0 ? L.staged : cap - L.tail0;
+      r->wr_off[0] = L.tail0;
+      r->wr_len[0] = s1;
       r->wr_count = 1;
-      if (tail0 + staged >= cap) {  // a record reached (or crossed) the ring end
+      if (L.tail0 + L.staged >= cap) {  // a record reached (or crossed) the ring end
         r->wr_off[1] = 0;
-        r->wr_len[1] = staged - seg1;
+        r->wr_len[1] = L.staged - s1;
         r->wr_count = 2;
       }
     }
+    // the loop-back wire: the Sends are contiguous in the staging buffer and in the ring -- two pieces at most
     grdma_plan* wp = op.wire_plan;
     if (wp != nullptr) {
       uint32_t ns = 0, nt = 0;
-      if (staged > 0 && !direct) {
+      if (staged_all > 0 && !direct) {
+        const uint64_t seg1 = staged_all < cap - tail0 ? staged_all : cap - tail0;
         wp->segs[0] = {(uint64_t)(c->peer_ring + tail0), (uint64_t)staging, seg1, 0};
         wp->tile_prefix[0] = 0;
         nt = (uint32_t)((seg1 + TB - 1) >> ts);
         ns = 1;
-        if (staged > seg1) {
-          wp->segs[1] = {(uint64_t)c->peer_ring, (uint64_t)(staging + seg1), staged - seg1, 0};
+        if (staged_all > seg1) {
+          wp->segs[1] = {(uint64_t)c->peer_ring, (uint64_t)(staging + seg1), staged_all - seg1, 0};
           wp->tile_prefix[1] = nt;
-          nt += (uint32_t)((staged - seg1 + TB - 1) >> ts);
+          nt += (uint32_t)((staged_all - seg1 + TB - 1) >> ts);
           ns = 2;
         }
       }
@@ -258,42 +340,37 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
       wp->ntiles = nt;
       wp->tile_bytes = (uint32_t)TB;
       wp->tile_prefix[ns] = nt;
-      wp->bytes = direct ? 0 : staged;
+      wp->bytes = direct ? 0 : staged_all;
     }
-    // rdma_flush cursor walk, rdma_bp_posix.cc:480-493
-    const uint64_t idx = start + nrec;
-    uint64_t bidx = 0;
-    if (short_pay > 0) bidx = (nrec == 0 ? byte_idx : 0) + short_pay;
-    else if (nrec == 0) bidx = byte_idx;
-    c->remote_tail = new_tail;
-    c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709
-    c->total_written = o_written + sent;
-    c->tx_records = o_records + nrec_total;
-    c->tx_last_records = (uint32_t)nrec_total;
-    if (nrec_total) c->tx_rounds = o_rounds + 1;
-    c->tx_slice_idx = idx;
-    c->tx_byte_idx = bidx;
-    c->tx_remaining = offered - sent;
-    r->sent = sent;
-    r->records = nrec_total;
-    r->staged = staged;
-    r->partial = sent < offered ? 1 : 0;
-    r->new_remote_tail = new_tail;
-    if (op.tail_out != nullptr) *op.tail_out = new_tail;
+    c->remote_tail = L.new_tail;
+    c->partial_write = L.sent < L.offered ? 1 : 0;  // pair.cc:709
+    c->total_written = o_written + sent_all;
+    c->tx_records = o_records + nrec_all;
+    c->tx_last_records = (uint32_t)L.nrec_total;
+    if (rounds) c->tx_rounds = o_rounds + rounds;
+    c->tx_slice_idx = L.idx;
+    c->tx_byte_idx = L.bidx;
+    c->tx_remaining = L.offered - L.sent;
+    r->sent = L.sent;
+    r->records = L.nrec_total;
+    r->staged = L.staged;
+    r->partial = L.sent < L.offered ? 1 : 0;
+    r->new_remote_tail = L.new_tail;
+    if (op.tail_out != nullptr) *op.tail_out = L.new_tail;
     if (op.sizes_out != nullptr) {
       op.sizes_out->start_off = tail0;
-      op.sizes_out->count = (uint32_t)nrec_total;
+      op.sizes_out->count = table ? (uint32_t)nrec_all : 0u;
     }
-    r->slice_idx = idx;
-    r->byte_idx = bidx;
-    r->done = (idx >= op.nslices) ? 1 : 0;
+    r->slice_idx = L.idx;
+    r->byte_idx = L.bidx;
+    r->done = (L.idx >= op.nslices) ? 1 : 0;
     r->dbg[0] = t_begin;
     r->dbg[1] = t_priced;
     r->dbg[6] = __builtin_amdgcn_s_memtime();
-    r->dbg[7] = m;
+    r->dbg[7] = Q[0].m + (TXM_MAX_SENDS > 1 ? Q[TXM_MAX_SENDS - 1].m : 0);
     r->dbg[9] = 0xFA57;  // this Send was priced from the index
-    r->dbg[10]++;
-    atomicAdd(&g_tx_fast_sends[0], 1ull);
+    r->dbg[10] += performed;
+    atomicAdd(&g_tx_fast_sends[0], (unsigned long long)performed);
     const uint64_t nxt = op.seq_next ? op.seq_next : o_seq + 1;
     __hip_atomic_store(&r->seq, nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }

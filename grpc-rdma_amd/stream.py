@@ -63,6 +63,12 @@ class StreamJob:
     def set_rounds(self, n):
         check(self.lib.grdma_stream_job_set_rounds(self.h, n))
 
+    def set_sends(self, sends):
+        """`sends` consecutive Sends per round in one plan (grdma_stream_job_set_sends: rdma_flush's loop while the ring
+        has room), paired schedule of a pipelined job."""
+        self.lib.grdma_stream_job_set_sends.argtypes = [C.c_void_p, C.c_uint32]
+        check(self.lib.grdma_stream_job_set_sends(self.h, sends))
+
     def set_burst(self, burst):
         """`burst` Sends per round before the peer drains (grdma_stream_job_set_burst)."""
         self.lib.grdma_stream_job_set_burst.argtypes = [C.c_void_p, C.c_uint32]

@@ -39,7 +39,7 @@ def _framed_slices(n_msgs, msg_len, seed):
 PASSES = 3  # the job is run three times on the same connection (eager, graph, graph)
 
 
-def _oracle_rounds(R, max_sge, slices):
+def _oracle_rounds(R, max_sge, slices, sends=1):
     """The reference loop on the CPU: one Send from the rdma_flush cursor, then endpoint
     reads until one would block; repeat until the list is gone.  PASSES times over the
     same link; returns the slices of the last pass and the rounds of the first."""
@@ -49,18 +49,21 @@ def _oracle_rounds(R, max_sge, slices):
         idx, byte = 0, 0
         delivered, rounds = [], 0
         while idx < len(slices):
-            sent = o.send(0, slices[idx:], byte)
+            for _k in range(sends):  # (sends > 1: rdma_flush sends again while the write holds data, then the peer drains)
+                if idx >= len(slices):
+                    break
+                sent = o.send(0, slices[idx:], byte)
+                left = sent
+                while left > 0:  # advance the cursor like rdma_flush does
+                    room = len(slices[idx]) - byte
+                    if left >= room:
+                        left -= room
+                        idx += 1
+                        byte = 0
+                    else:
+                        byte += left
+                        left = 0
             rounds += 1
-            left = sent
-            while left > 0:  # advance the cursor like rdma_flush does
-                room = len(slices[idx]) - byte
-                if left >= room:
-                    left -= room
-                    idx += 1
-                    byte = 0
-                else:
-                    byte += left
-                    left = 0
             while True:
                 s, _alloc = o.endpoint_read(1)
                 if not s:
@@ -75,7 +78,7 @@ def _oracle_rounds(R, max_sge, slices):
     return delivered, first_rounds, st, ring
 
 
-def _run_job(g, R, max_sge, slices, pipeline, flags=0, mode=None):
+def _run_job(g, R, max_sge, slices, pipeline, flags=0, mode=None, sends=1):
     from grpc_rdma_amd import stream as gs
     rng = random.Random(5)
     bufs = [g.DeviceBuffer(data=s, offset=rng.randrange(16)) for s in slices]
@@ -90,9 +93,11 @@ def _run_job(g, R, max_sge, slices, pipeline, flags=0, mode=None):
     bound = min(4096, 6 * (N // (R // 2) + len(slices) // max_sge) + 24)
     job = gs.MultiStreamJob([(tx, rx, sge, dst.ptr, dst_cap, 2 * len(slices) + 64)], bound)
     job.set_pipeline(pipeline)
+    if sends > 1:
+        job.set_sends(sends)
     r = job.run(gs.RUN_EAGER)
     assert r.done and r.bytes_delivered == N and r.bytes_sent == N
-    rounds = int(max(r.tx_rounds, r.rx_rounds))
+    rounds = int(max(r.tx_rounds, r.rx_rounds))  # (tx_rounds counts Sends: an upper bound of the rounds)
     # replay as a captured graph; later passes start at another ring phase and may need a
     # round more or less than the first (surplus rounds find nothing to do).  With a
     # small ring the pipelined sender can also meet a round in which the credit of the
@@ -252,6 +257,53 @@ def test_drains_of_several_workgroups_match_the_oracle(gpu, case, flags):
     if taken:
         assert took >= exp_rounds, "the steady-state bodies took %d drains (declined by reason: %s)" % (
             took, [a - b for a, b in zip(after[1:6], before[1:6])])
+
+
+SENDS_CASES = [
+    # (exact cases: rounds of at most ring / 6, as MULTI_CASES)
+    (1 << 27, 1023, 90, 1 << 18, True),     # messages of 34 slices: rounds of two Sends of 1023 slices
+    (1 << 25, 4095, 8000, 1500, True),      # two Sends of 4095 records per round: 8190 records per drain
+    (1 << 24, 2500, 3000, 100, None),       # tiny messages: 9000 records, the second Send of a round ends the write
+                                            # (exact; the predicting drain bodies decline them, as in MULTI_CASES)
+    (1 << 22, 700, 40, 1 << 18, False),     # a ring the rounds fill: the second Send is cut by the free space
+]
+
+
+@pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
+@pytest.mark.parametrize("case", SENDS_CASES, ids=["r128m_sge1023", "r32m_sge4095", "r16m_small", "r4m_ring_limited"])
+def test_two_sends_per_round_in_one_plan_match_the_oracle(gpu, case, flags):
+    """grdma_stream_job_set_sends(2): a round's plan holds two consecutive Sends (rdma_flush's loop while the ring has
+    room), priced one after the other from the index by the small planner workgroups (csrc/grdma_tx_multi.h), their
+    records back to back in gather plan, staging buffer and ring; the drain of the round lays out both Sends' records
+    (32 workgroups).  Slices, ring image and state equal the oracle driven the same way: Send, Send, endpoint reads
+    until one would block.  (The ring-limited case: the paired schedule sees the credit a round late -- the byte
+    stream and the empty ring are checked, the oracle's rounds are not the job's.)"""
+    R, max_sge, n_msgs, msg_len, exact = case
+    rng = random.Random(R % 83)
+    body = bytes(rng.getrandbits(8) for _ in range(min(msg_len, 4096))) * (msg_len // min(msg_len, 4096) + 1)
+    slices = []
+    for i in range(n_msgs):
+        wire, lens = pyorc.h2_frame_message(body[:msg_len], stream_id=2 * i + 1)
+        off = 0
+        for ln in lens:
+            slices.append(wire[off:off + ln])
+            off += ln
+    before = _fast_counts(gpu)
+    got = _run_job(gpu, R, max_sge, slices, pipeline=True, flags=flags, sends=2)
+    after = _fast_counts(gpu)
+    assert b"".join(got["slices"]) == b"".join(slices)
+    assert got["ring"] == bytes(R)
+    if exact is not False:
+        exp, exp_rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, slices, sends=2)
+        assert [len(x) for x in got["slices"]] == [len(x) for x in exp]
+        assert got["slices"] == exp
+        for k in ("remote_tail", "remote_head", "partial_write"):
+            assert got["tx"][k] == st0[k], k
+        for k in ("head", "moving_head", "remain", "internal_read_size"):
+            assert got["rx"][k] == st1[k], k
+        if exact is True:
+            assert after[0] - before[0] >= exp_rounds, "drains taken by the predicting bodies: %d of %d rounds per pass" % (
+                after[0] - before[0], exp_rounds)
 
 
 @pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])

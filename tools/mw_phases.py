@@ -16,7 +16,8 @@ def main():
     import grpc_rdma_amd as g
     from grpc_rdma_amd import stream as gs
     g.init(0)
-    ring_kb = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+    ring_kb = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+    sends = int(os.environ.get("MW_SENDS", "2"))
     max_sge = int(sys.argv[2]) if len(sys.argv) > 2 else 4095
     w = bench.Workload(g, 256)
     ring = ring_kb * 1024
@@ -27,8 +28,10 @@ def main():
     dst = g.DeviceBuffer(nbytes=dst_cap)
     job = gs.MultiStreamJob([(tx, rx, w.sge, dst.ptr, dst_cap, scap)], max(8, 4 * (w.E // (ring // 2) + 2), 2 * (len(w.lens) // max_sge + 2)))
     job.set_pipeline(True)
+    if sends > 1:
+        job.set_sends(sends)
     r = job.run(gs.RUN_EAGER)
-    job.set_rounds(int(max(r.tx_rounds, r.rx_rounds)))
+    job.set_rounds(int(max(-(-int(r.tx_rounds) // sends), r.rx_rounds)))
     for _ in range(4):
         r = job.run(gs.RUN_GRAPH)
     print("graph step %.1f us" % (1e3 * r.ms_total))

@@ -11,7 +11,7 @@ stats() { tag=$1; shift
   f=$(find $out/stats_$tag -name '*kernel_stats.csv' | head -1)
   cp "$f" $out/${tag}_kernel_stats.csv; grep '^{"metric"' $out/stats_$tag.stdout | tail -1 > $out/${tag}_under_rocprof.json
   echo "== $tag"; head -8 "$f"; }
-stats ring128m --steps 10
+stats ring256m --steps 10
 stats ring4m --steps 6 --ring-kb 4096 --pipeline 0
 stats engine --steps 10 --schedule engine
 mkdir -p $out/pmc
@@ -19,6 +19,6 @@ for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
   d=$out/pmc/$(echo $ctr | cut -d' ' -f1)
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $d -o pmc -- $B --no-verify --steps 4 --warmup 1 > $d.stdout 2>&1
 done
-python $R/tools/pmc_summary.py $out/pmc $out/pmc_ring128m_summary.json "rocprofv3 --pmc <CTRS> --kernel-trace --output-format csv -- python bench.py --no-cpu-baseline --no-tcp-baseline --no-verify --no-small-ring --no-rtt --no-extra-legs --conns 1 --steps 4 --warmup 1 (one counter family per pass; tools/prof_all.sh)"
-rm -rf $out/stats_ring128m $out/stats_ring4m $out/stats_engine $out/pmc $out/*.stdout
+python $R/tools/pmc_summary.py $out/pmc $out/pmc_ring256m_summary.json "rocprofv3 --pmc <CTRS> --kernel-trace --output-format csv -- python bench.py --no-cpu-baseline --no-tcp-baseline --no-verify --no-small-ring --no-rtt --no-extra-legs --conns 1 --steps 4 --warmup 1 (one counter family per pass; tools/prof_all.sh)"
+rm -rf $out/stats_ring256m $out/stats_ring4m $out/stats_engine $out/pmc $out/*.stdout
 ls -la $out

@@ -15,4 +15,4 @@ echo "bench rc=$?"
 grep -o '"value": [0-9.]*\|"rx_plan": {[^}]*}\|"value_ring4096_sge30": [0-9.]*\|"value_mixed_sizes": [0-9.]*\|"rtt_p50_us": [0-9.]*' $out/bench.log | head -5
 timeout 30 python tools/plan_phases.py > $out/phases.log 2>&1 < /dev/null
 tail -1 $out/phases.log
-timeout 45 bash tools/prof_all.sh < /dev/null 2>&1 | grep -A3 "== ring128m"
+timeout 45 bash tools/prof_all.sh < /dev/null 2>&1 | grep -A3 "== ring256m"
