@@ -2631,6 +2631,10 @@ struct grdma_stream_job {
                                       // the memory system (profiles/r03_fused_schedule_experiment.txt)
   int rx_multi = 1;                   // paired schedule: the drain plan laid out by several workgroups (k_plan_pair_mw,
                                       // csrc/grdma_rx_multi.h); GRDMA_RX_MULTI=0: the one-workgroup k_plan_pair_job
+  // The index of the slice table (k_tx_index) is a function of the table alone, and the job owns the table: built by
+  // the first run, kept for the later ones -- unless something may rewrite the table between steps (kernel nodes hung
+  // in front of the job, or a caller that asked where the table lives: the HTTP/2 pipe does both).
+  bool index_valid = false, sges_exposed = false;
   uint32_t sends = 1;                 // grdma_stream_job_set_sends: consecutive Sends one round's plan holds (paired schedule,
                                       // planners of grdma_tx_multi.h / grdma_rx_multi.h: 16 workgroups per Send's worth of records)
   int fuse_round = 0;                 // GRDMA_JOB_FUSE_ROUND=1: the drain plan of round t, its scatter and the gather of round
@@ -2666,9 +2670,10 @@ struct grdma_stream_job {
 namespace {
 
 inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 : 2); }
+inline bool job_index_needed(const grdma_stream_job* j) { return !j->index_valid || !j->pre_hooks.empty() || j->sges_exposed; }
 inline int job_fastkey(const grdma_stream_job* j) {
   return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0) | (j->pair_job ? 8 : 0) | (j->fuse ? 16 : 0) |
-         (j->fuse_ag ? 32 : 0) | (j->rx_multi ? 64 : 0) | (j->fuse_round ? 128 : 0) | ((int)j->sends << 8);
+         (j->fuse_ag ? 32 : 0) | (j->rx_multi ? 64 : 0) | (j->fuse_round ? 128 : 0) | ((int)j->sends << 8) | (job_index_needed(j) ? (1 << 12) : 0);
 }
 // copy workgroups (1024 threads: one per CU) next to a planner workgroup in a fused launch: every CU but the planner's
 inline uint32_t job_fused_copy_blocks() {
@@ -2712,7 +2717,7 @@ inline uint32_t job_index_blocks(const grdma_stream_job* j) {  // k_tx_index: 10
 hipError_t job_launch_tx_plan(grdma_stream_job* j, int k, uint64_t t, uint32_t n, hipStream_t s) {
   if (!job_tx_fast(j)) return grdma_launch_tx_plan(j->d_txop + k * n, n, s);
   hipError_t e = hipSuccess;
-  if (t == 0) e = grdma_launch_tx_index(j->d_txf, n, job_index_blocks(j), s);
+  if (t == 0 && job_index_needed(j)) e = grdma_launch_tx_index(j->d_txf, n, job_index_blocks(j), s);
   if (e != hipSuccess) return e;
   // (several Sends per plan: only the planners of grdma_tx_multi.h price those -- also in the eager passes)
   if (j->sends > 1 && job_mw(j)) return job_launch_pair_mw(nullptr, j->d_txop + k * n, j->d_txf, n, 0, job_tx_groups(j), s);
@@ -2836,8 +2841,8 @@ int job_enqueue_schedule_instrumented(grdma_stream_job* j, hipStream_t s) {
     const void* gplans = j->d_plans;
     const void* wplans = j->d_plans + n * (1 + (t & 1));
     if (t == 0) {
-      if (j->rx_multi) {  // k_tx_index + the Send priced by k_plan_pair_mw's small workgroups (as the graph does)
-        HIP_TRY(grdma_launch_tx_index(j->d_txf, n, job_index_blocks(j), s));
+      if (j->rx_multi) {  // (k_tx_index +) the Send priced by k_plan_pair_mw's small workgroups (as the graph does)
+        if (job_index_needed(j)) HIP_TRY(grdma_launch_tx_index(j->d_txf, n, job_index_blocks(j), s));
         HIP_TRY(launch(grdma_kernel_fn_plan_pair_mw(), dim3(n, job_tx_groups(j)), grdma_kernel_threads(0), nullptr,
                        j->d_txop + k * n, j->d_txf, 0u));
       } else {
@@ -3140,13 +3145,18 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
     if (!tfast) return add(&P[t], f_txp, dim3(n), pt, txop, deps);
     if (t != 0) return add2(&P[t], f_txj, dim3(n), grdma_tx_plan_job_threads(), txop, j->d_txf, deps);
     hipGraphNode_t pi = nullptr;
-    hipError_t e2 = add(&pi, f_txi, dim3(job_index_blocks(j), n), grdma_tx_index_threads(), j->d_txf, deps);
-    if (e2 != hipSuccess) return e2;
+    if (job_index_needed(j)) {  // (the slice table's index: once per job unless the table may change between steps)
+      hipError_t e2 = add(&pi, f_txi, dim3(job_index_blocks(j), n), grdma_tx_index_threads(), j->d_txf, deps);
+      if (e2 != hipSuccess) return e2;
+    }
+    std::vector<hipGraphNode_t> dv(deps);
+    dv.resize(4, nullptr);  // (round 0's dependencies: at most four, all null today)
+    const hipGraphNode_t d0 = pi ? pi : dv[0], d1 = pi ? nullptr : dv[1], d2 = pi ? nullptr : dv[2], d3 = pi ? nullptr : dv[3];
     // (the first Send of a step priced by the small workgroups of the planner pair too: k_plan_pair_mw with no drain)
     if (j->rx_multi && j->pipeline && j->pair_job && !j->fuse)
       return add3(&P[t], grdma_kernel_fn_plan_pair_mw(), dim3(n, job_tx_groups(j)), grdma_kernel_threads(0), nullptr, txop,
-                  j->d_txf, {pi}, 0u);
-    return add2(&P[t], f_txj, dim3(n), grdma_tx_plan_job_threads(), txop, j->d_txf, {pi});
+                  j->d_txf, {d0, d1, d2, d3}, 0u);
+    return add2(&P[t], f_txj, dim3(n), grdma_tx_plan_job_threads(), txop, j->d_txf, {d0, d1, d2, d3});
   };
   // X[t] = the receive plan of round t: k_rx_plan_job -- the steady-state body, the general planner behind it
   auto add_rx = [&](uint64_t t, const void* rxop, std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
@@ -3895,6 +3905,7 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
   // register budget) for what those decline.  A job whose last drains / Send keep being declined -- no period in
   // its record sizes, Sends cut by the staging budget, ... -- goes back to the plain planner kernels.
   j->runs++;
+  if (mode != GRDMA_RUN_ENGINE && j->tx_fast && j->rounds >= 1) j->index_valid = true;  // (round 0 of this run built it)
   if (j->fuse_round_after >= 0 && j->runs >= j->fuse_round_after) j->fuse_round = 1;
   if (j->slim_after >= 0) {
     if (j->runs >= j->slim_after) j->rx_fast = j->tx_fast = 1;
@@ -3958,6 +3969,7 @@ extern "C" __attribute__((visibility("hidden"))) int grdma_job_link_view(grdma_s
                                                                          uint8_t** dst, hipStream_t* stream) {
   if (!j || link >= j->links.size()) return -1;
   grdma_job_link& l = j->links[link];
+  j->sges_exposed = true;  // (the caller may rewrite the table: its index is rebuilt at every step from now on)
   *d_sges = l.d_sges;
   *count = l.count;
   *d_slices = l.d_slices;
