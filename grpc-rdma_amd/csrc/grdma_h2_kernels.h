@@ -47,7 +47,7 @@ struct grdma_h2_parser_dev {
   uint32_t incoming_frame_flags;
   uint32_t incoming_stream_id;
   uint32_t max_frame_size;
-  int32_t cur_parser;   // 0 skip, 1 data, 2 header, 3 rst_stream
+  int32_t cur_parser;   // 0 skip, 1 data, 2 header, 3 rst_stream, 4 a third header block without END_HEADERS
   int32_t is_server;
   int32_t is_first_frame;
   uint32_t expect_continuation;
@@ -417,8 +417,9 @@ __global__ __launch_bounds__(H2_EMIT_THREADS) void k_h2_frame_one(const grdma_h2
 enum { EV_FRAME = 1, EV_PAYLOAD = 2, EV_MSG_BEGIN = 3, EV_MSG_BYTES = 4, EV_MSG_END = 5,
        EV_STREAM_OPEN = 6, EV_STREAM_CLOSED = 7 };
 enum { ST_FH0 = 24, ST_FRAME = 33 };
-enum { PARSER_SKIP = 0, PARSER_DATA = 1, PARSER_HEADER = 2, PARSER_RST = 3 };
-enum { FT_DATA = 0, FT_HEADERS = 1, FT_RST_STREAM = 3, FT_SETTINGS = 4, FT_CONTINUATION = 9 };
+enum { PARSER_SKIP = 0, PARSER_DATA = 1, PARSER_HEADER = 2, PARSER_RST = 3, PARSER_HEADER3 = 4 };
+enum { FT_DATA = 0, FT_HEADERS = 1, FT_RST_STREAM = 3, FT_SETTINGS = 4, FT_PING = 6, FT_GOAWAY = 7, FT_WINDOW_UPDATE = 8,
+       FT_CONTINUATION = 9 };
 
 // ---- stream map (single-lane code; callers broadcast the result) ----
 __device__ __forceinline__ uint32_t tab_home(uint32_t id, uint32_t mask) { return (id >> 1) & mask; }
@@ -753,6 +754,8 @@ __device__ __forceinline__ void h2_deframe_body(grdma_h2_parser_dev* gp, const u
         const uint32_t gone = h2_mark_closed(tab, mask, D, live, true, lane);                     \
         H2_PUSH(EV_STREAM_CLOSED, gone, 0, sid, 0, (uint32_t)(sl));                               \
       }                                                                                           \
+    } else if (cur_parser == PARSER_HEADER3) {                                                    \
+      err = 18; /* "Too many trailer frames", hpack_parser.cc:1756-1759 */                        \
     }                                                                                             \
   } while (0)
 
@@ -965,7 +968,25 @@ __device__ __forceinline__ void h2_deframe_body(grdma_h2_parser_dev* gp, const u
         } else if (ftype == FT_RST_STREAM) {
           if (fsz != 4) { err = 10; break; }                             // frame_rst_stream.cc:73-79
           if (h2_select_stream(tab, mask, D, sid, lane)) cur_parser = PARSER_RST;
-        }  // SETTINGS, WINDOW_UPDATE, PING, GOAWAY: control plane, payload skipped
+        } else if (ftype == FT_SETTINGS) {
+          // init_settings_frame_parser (:732-757) + grpc_chttp2_settings_parser_begin_frame (frame_settings.cc:88-111)
+          if (sid != 0) { err = 11; break; }
+          if (fflags == 1u) {
+            if (fsz != 0) { err = 12; break; }
+          } else if (fflags != 0) {
+            err = 13;
+            break;
+          } else if (fsz % 6 != 0) {
+            err = 14;
+            break;
+          }
+        } else if (ftype == FT_PING) {          // frame_ping.cc:58-64
+          if ((fflags & 0xfeu) || fsz != 8) { err = 15; break; }
+        } else if (ftype == FT_GOAWAY) {        // frame_goaway.cc:39-44
+          if (fsz < 8) { err = 17; break; }
+        } else if (ftype == FT_WINDOW_UPDATE) { // frame_window_update.cc:56-63 (before the stream is looked up)
+          if (fflags || fsz != 4) { err = 16; break; }
+        }  // the PAYLOADS of SETTINGS, WINDOW_UPDATE, PING, GOAWAY: control plane, skipped
         if (hdr_frame) {
           // init_header_frame_parser (parsing.cc:566-680): stream lookup / acceptance; the
           // HPACK bytes themselves are control plane and are skipped
@@ -984,6 +1005,9 @@ __device__ __forceinline__ void h2_deframe_body(grdma_h2_parser_dev* gp, const u
             have = h2_select_stream(tab, mask, D, sid, lane);
           }
           if (have && !D.read_closed && D.hdr_frames < 2) cur_parser = PARSER_HEADER;
+          // (a third header block: the header parser in skipping mode with is_boundary = "END_HEADERS is missing"
+          //  (parsing.cc:667-669, 318-327) -- the end of such a frame fails the connection, see H2_END_FRAME)
+          else if (have && !D.read_closed && !header_boundary) cur_parser = PARSER_HEADER3;
         }
         H2_PUSH(EV_FRAME, ftype, fflags | (status << 8), sid, fsz, (uint32_t)s);
         if (opened) H2_PUSH(EV_STREAM_OPEN, 0, 0, sid, 0, (uint32_t)s);

@@ -509,7 +509,16 @@ enum grdma_h2_error {
   GRDMA_H2_ERR_UNEXPECTED_CONTINUATION = 7,/* parsing.cc:287-289                            */
   GRDMA_H2_ERR_FIRST_FRAME = 8,            /* parsing.cc:256-263 first frame must be SETTINGS */
   GRDMA_H2_ERR_MAX_STREAMS = 9,            /* parsing.cc:623-627 (or the stream table is half full) */
-  GRDMA_H2_ERR_RST_LENGTH = 10             /* frame_rst_stream.cc:73-79                     */
+  GRDMA_H2_ERR_RST_LENGTH = 10,            /* frame_rst_stream.cc:73-79                     */
+  /* malformed control frames (the begin_frame checks of the control-frame parsers): connection errors */
+  GRDMA_H2_ERR_SETTINGS_STREAM = 11,       /* parsing.cc:735-739  SETTINGS on a stream      */
+  GRDMA_H2_ERR_SETTINGS_ACK_LENGTH = 12,   /* frame_settings.cc:95-101 non-empty ack        */
+  GRDMA_H2_ERR_SETTINGS_FLAGS = 13,        /* frame_settings.cc:102-104                     */
+  GRDMA_H2_ERR_SETTINGS_LENGTH = 14,       /* frame_settings.cc:105-107 not a multiple of 6 */
+  GRDMA_H2_ERR_PING = 15,                  /* frame_ping.cc:58-64 length != 8 or flags      */
+  GRDMA_H2_ERR_WINDOW_UPDATE = 16,         /* frame_window_update.cc:56-63                  */
+  GRDMA_H2_ERR_GOAWAY = 17,                /* frame_goaway.cc:39-44 shorter than 8 bytes    */
+  GRDMA_H2_ERR_TOO_MANY_TRAILERS = 18      /* hpack_parser.cc:1756-1759 third header block without END_HEADERS */
 };
 enum grdma_h2_parser_flags {
   GRDMA_H2_SERVER = 1,       /* expects the client preface; accepts streams from HEADERS frames

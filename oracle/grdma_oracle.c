@@ -569,8 +569,10 @@ int64_t orc_h2_frame_batch(const uint8_t* const* msgs, const uint64_t* msg_lens,
 
 static const char kClientPrefix[] = "PRI * HTTP/2.0\r\n\r\nSM\r\n\r\n"; /* internal.h:781 */
 enum { ST_FH0 = 24, ST_FH8 = 32, ST_FRAME = 33 };
-enum { PARSER_SKIP = 0, PARSER_DATA = 1, PARSER_HEADER = 2, PARSER_RST = 3 };
-enum { FT_DATA = 0, FT_HEADERS = 1, FT_RST_STREAM = 3, FT_SETTINGS = 4, FT_CONTINUATION = 9 };
+enum { PARSER_SKIP = 0, PARSER_DATA = 1, PARSER_HEADER = 2, PARSER_RST = 3, PARSER_HEADER3 = 4 };
+enum { FT_DATA = 0, FT_HEADERS = 1, FT_RST_STREAM = 3, FT_SETTINGS = 4, FT_PING = 6, FT_GOAWAY = 7, FT_WINDOW_UPDATE = 8,
+       FT_CONTINUATION = 9 };
+enum { FL_ACK = 1 };
 enum { FL_END_STREAM = 1, FL_END_HEADERS = 4 };
 
 void orc_h2_parser_init_ex(orc_h2_parser* p, int flags, uint32_t max_frame_size,
@@ -730,7 +732,14 @@ static int begin_header_frame(orc_h2_parser* p, int is_continuation, int* parser
     *opened = 1;
   }
   if (s->read_closed) return 0;                         /* :645-650 */
-  if (s->header_frames_received >= 2) return 0;         /* :673-675 too many header frames */
+  if (s->header_frames_received >= 2) {
+    /* :667-669 "too many header frames received": init_skip_frame_parser(t, 1) -- the header parser in skipping mode,
+     * with is_boundary = (expect_continuation_stream_id != 0) (:318-327), i.e. set when the frame LACKS END_HEADERS.
+     * The stream stays t->incoming_stream, so at the end of such a frame the parser finds header_frames_received == 2
+     * and fails the connection ("Too many trailer frames", hpack_parser.cc:1756-1759); with END_HEADERS it skips. */
+    if (!p->header_boundary) *parser_kind = PARSER_HEADER3;
+    return 0;
+  }
   *parser_kind = PARSER_HEADER;
   return 0;
 }
@@ -764,7 +773,27 @@ static int begin_frame(orc_h2_parser* p, orc_h2_event* ev, uint64_t cap, uint64_
   } else if (p->incoming_frame_type == FT_RST_STREAM) {
     if (p->incoming_frame_size != 4) return ORC_H2_ERR_RST_LENGTH;
     if (lookup_stream(p, id)) kind = PARSER_RST;
-  } /* SETTINGS, WINDOW_UPDATE, PING, GOAWAY: their payload parsers are control plane -> skipped */
+  } else if (p->incoming_frame_type == FT_SETTINGS) {
+    /* init_settings_frame_parser (:732-757) + grpc_chttp2_settings_parser_begin_frame (frame_settings.cc:88-111) */
+    if (id != 0) return ORC_H2_ERR_SETTINGS_STREAM;
+    if (p->incoming_frame_flags == FL_ACK) {
+      if (p->incoming_frame_size != 0) return ORC_H2_ERR_SETTINGS_ACK_LENGTH;
+    } else if (p->incoming_frame_flags != 0) {
+      return ORC_H2_ERR_SETTINGS_FLAGS;
+    } else if (p->incoming_frame_size % 6 != 0) {
+      return ORC_H2_ERR_SETTINGS_LENGTH;
+    }
+  } else if (p->incoming_frame_type == FT_PING) {
+    /* init_ping_parser (:705-712) + grpc_chttp2_ping_parser_begin_frame (frame_ping.cc:58-69) */
+    if ((p->incoming_frame_flags & 0xfe) || p->incoming_frame_size != 8) return ORC_H2_ERR_PING;
+  } else if (p->incoming_frame_type == FT_GOAWAY) {
+    /* init_goaway_parser (:723-730) + grpc_chttp2_goaway_parser_begin_frame (frame_goaway.cc:39-52) */
+    if (p->incoming_frame_size < 8) return ORC_H2_ERR_GOAWAY;
+  } else if (p->incoming_frame_type == FT_WINDOW_UPDATE) {
+    /* init_window_update_frame_parser (:686-703) + ..._begin_frame (frame_window_update.cc:56-67): checked before
+     * the stream is looked up */
+    if (p->incoming_frame_flags || p->incoming_frame_size != 4) return ORC_H2_ERR_WINDOW_UPDATE;
+  } /* the PAYLOADS of SETTINGS, WINDOW_UPDATE, PING, GOAWAY are control plane -> skipped */
   p->cur_parser = kind; /* must survive across feeds */
   if ((rc = push_ev(ev, cap, nev, ORC_EV_FRAME, p->incoming_frame_type,
                     p->incoming_frame_flags | (status << 8), id, p->incoming_frame_size)))
@@ -790,6 +819,8 @@ static int end_frame(orc_h2_parser* p, orc_h2_event* ev, uint64_t cap, uint64_t*
   } else if (p->cur_parser == PARSER_RST) {
     /* grpc_chttp2_rst_stream_parser_parse, frame_rst_stream.cc:99-119 */
     return mark_closed(p, id, 1, 1, ev, cap, nev);
+  } else if (p->cur_parser == PARSER_HEADER3) {
+    return ORC_H2_ERR_TOO_MANY_TRAILERS; /* hpack_parser.cc:1756-1759 (see begin_header_frame) */
   }
   return 0;
 }

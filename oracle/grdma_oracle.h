@@ -184,6 +184,16 @@ enum {
   ORC_H2_ERR_FIRST_FRAME = 8,   /* parsing.cc:256-263 */
   ORC_H2_ERR_MAX_STREAMS = 9,   /* parsing.cc:623-627 */
   ORC_H2_ERR_RST_LENGTH = 10,   /* frame_rst_stream.cc:73-79 */
+  /* malformed control frames: the begin_frame checks of the control-frame parsers, all connection errors */
+  ORC_H2_ERR_SETTINGS_STREAM = 11,      /* parsing.cc:735-739 "Settings frame received for grpc_chttp2_stream" */
+  ORC_H2_ERR_SETTINGS_ACK_LENGTH = 12,  /* frame_settings.cc:95-101 "non-empty settings ack frame received" */
+  ORC_H2_ERR_SETTINGS_FLAGS = 13,       /* frame_settings.cc:102-104 "invalid flags on settings frame" */
+  ORC_H2_ERR_SETTINGS_LENGTH = 14,      /* frame_settings.cc:105-107 "settings frames must be a multiple of six bytes" */
+  ORC_H2_ERR_PING = 15,                 /* frame_ping.cc:58-64 "invalid ping: length, flags" */
+  ORC_H2_ERR_WINDOW_UPDATE = 16,        /* frame_window_update.cc:56-63 "invalid window update: length, flags" */
+  ORC_H2_ERR_GOAWAY = 17,               /* frame_goaway.cc:39-44 "goaway frame too short" */
+  ORC_H2_ERR_TOO_MANY_TRAILERS = 18,    /* hpack_parser.cc:1756-1759: a third header block on one stream, met by the
+                                           skipping header parser with is_boundary set (parsing.cc:667-669, 318-327) */
   ORC_H2_ERR_EVENT_OVERFLOW = 100
 };
 enum { ORC_H2_SERVER = 1, ORC_H2_FIRST_FRAME = 2 };
@@ -212,7 +222,7 @@ typedef struct orc_h2_parser { /* internal.h grpc_chttp2_transport deframe field
   uint32_t incoming_stream_id;
   uint32_t max_frame_size;
   int check_frame_size;
-  int cur_parser;       /* which payload parser the frame in flight uses: 0 skip 1 data 2 header 3 rst */
+  int cur_parser;       /* which payload parser the frame in flight uses: 0 skip 1 data 2 header 3 rst 4 third header block */
   int is_server, is_first_frame;
   uint32_t expect_continuation_stream_id;
   int header_eof, header_boundary, received_last_frame;

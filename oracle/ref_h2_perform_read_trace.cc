@@ -182,16 +182,11 @@ SKIPPING_PARSER(ping)
 SKIPPING_PARSER(goaway)
 SKIPPING_PARSER(settings)
 SKIPPING_PARSER(window_update)
-grpc_error_handle grpc_chttp2_ping_parser_begin_frame(grpc_chttp2_ping_parser*, uint32_t, uint8_t) { return GRPC_ERROR_NONE; }
-grpc_error_handle grpc_chttp2_goaway_parser_begin_frame(grpc_chttp2_goaway_parser*, uint32_t, uint8_t) {
-  return GRPC_ERROR_NONE;
-}
-grpc_error_handle grpc_chttp2_settings_parser_begin_frame(grpc_chttp2_settings_parser*, uint32_t, uint8_t, uint32_t*) {
-  return GRPC_ERROR_NONE;
-}
-grpc_error_handle grpc_chttp2_window_update_parser_begin_frame(grpc_chttp2_window_update_parser*, uint32_t, uint8_t) {
-  return GRPC_ERROR_NONE;
-}
+// (the begin_frame functions of these four parsers -- the length / flag / stream-id checks of a control frame's header --
+//  are the REFERENCE's: frame_ping.cc, frame_goaway.cc, frame_settings.cc, frame_window_update.cc are compiled
+//  unmodified into this binary; the *_parser_parse stand-ins above take precedence over theirs at link time
+//  (oracle/Makefile: this file first, -Wl,--allow-multiple-definition; their own parse functions, which need the
+//  rest of the transport, are discarded unreferenced))
 void grpc_chttp2_act_on_flowctl_action(const grpc_core::chttp2::FlowControlAction&, grpc_chttp2_transport*,
                                        grpc_chttp2_stream*) {}
 void schedule_bdp_ping_locked(grpc_chttp2_transport*) {}
@@ -255,12 +250,28 @@ grpc_error_handle Chttp2IncomingByteStream::Finished(grpc_error_handle error, bo
 }
 }  // namespace grpc_core
 
+// parsing.cc:195-205 checks a frame's size against the acknowledged MAX_FRAME_SIZE only when flow control is enabled.
+// The reference's enabled class (flow_control.cc) cannot be built here; the check needs nothing of it but the answer
+// to flow_control_enabled(): everything else behaves like TransportFlowControlDisabled.
+namespace {
+class FlowControlSaysEnabled final : public grpc_core::chttp2::TransportFlowControlBase {
+ public:
+  bool flow_control_enabled() const override { return true; }
+  uint32_t MaybeSendUpdate(bool) override { return 0; }
+  grpc_core::chttp2::FlowControlAction MakeAction() override { return grpc_core::chttp2::FlowControlAction(); }
+  grpc_core::chttp2::FlowControlAction PeriodicUpdate() override { return grpc_core::chttp2::FlowControlAction(); }
+  void StreamSentData(int64_t) override {}
+  grpc_error_handle RecvData(int64_t) override { return GRPC_ERROR_NONE; }
+  void RecvUpdate(uint32_t) override {}
+};
+}  // namespace
+
 static bool rd32(uint32_t* v) { return fread(v, 4, 1, stdin) == 1; }
 
 int main() {
   setvbuf(stdout, nullptr, _IOLBF, 1 << 16);
-  uint32_t is_client = 0, first_frame = 0, max_streams = 0, next_stream_id = 0;
-  if (!rd32(&is_client) || !rd32(&first_frame) || !rd32(&max_streams) || !rd32(&next_stream_id)) return 3;
+  uint32_t is_client = 0, first_frame = 0, max_streams = 0, next_stream_id = 0, max_frame = 0;
+  if (!rd32(&is_client) || !rd32(&first_frame) || !rd32(&max_streams) || !rd32(&next_stream_id) || !rd32(&max_frame)) return 3;
   grpc_chttp2_transport* t = static_cast<grpc_chttp2_transport*>(calloc(1, sizeof(grpc_chttp2_transport)));
   t->is_client = is_client != 0;
   t->is_first_frame = first_frame != 0;
@@ -271,6 +282,13 @@ int main() {
   t->settings[GRPC_SENT_SETTINGS][GRPC_CHTTP2_SETTINGS_MAX_CONCURRENT_STREAMS] = max_streams;
   t->settings[GRPC_ACKED_SETTINGS][GRPC_CHTTP2_SETTINGS_MAX_CONCURRENT_STREAMS] = max_streams;
   t->flow_control.Init<grpc_core::chttp2::TransportFlowControlDisabled>(t);
+  if (max_frame != 0) {  // the frame-size check on: what this side announced and the peer acknowledged
+    static_assert(sizeof(FlowControlSaysEnabled) <= sizeof(grpc_core::chttp2::TransportFlowControlDisabled), "fits the member's storage");
+    t->flow_control->~TransportFlowControlBase();
+    new (t->flow_control.get()) FlowControlSaysEnabled();
+    for (int which : {GRPC_LOCAL_SETTINGS, GRPC_SENT_SETTINGS, GRPC_ACKED_SETTINGS})
+      t->settings[which][GRPC_CHTTP2_SETTINGS_MAX_FRAME_SIZE] = max_frame;
+  }
   grpc_chttp2_stream_map_init(&t->stream_map, 8);
   grpc_slice_buffer_init(&t->qbuf);
   bool dead = false;
