@@ -142,6 +142,15 @@ def test_endpoint_vtable_tools_under_the_emulator(emu_lib, tmp_path):
         queued, promoted, skipped = r["writes_queued"]
         assert r["checked"] and not r["latency_mode"] and queued >= 1 and promoted + skipped <= queued, r
         assert (promoted if want == "promoted" else skipped) >= 1, r
+    # the same, randomised (ENDPOINT_STREAM_SEED: writes of 2 .. 130 slices, a reader that stalls now and then)
+    for seed, ring_kb, always in ((1, "1024", "1"), (3, "4096", "0")):
+        p = subprocess.run([es, "24", str(1 << 20), "1", "0", "2"],
+                           env=dict(env, GRPC_RDMA_RING_BUFFER_SIZE_KB=ring_kb, GRDMA_WRITE_QUEUE_ALWAYS=always,
+                                    ENDPOINT_STREAM_SEED=str(seed)), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-500:]
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        queued, promoted, skipped = r["writes_queued"]
+        assert r["checked"] and queued >= 4 and promoted + skipped <= queued and promoted + skipped >= 4, r
 
 
 def test_endpoint_conformance_under_the_emulator(emu_lib, tmp_path):

@@ -79,3 +79,28 @@ def test_streamed_writes_queue_behind_the_sends_in_flight(gpu, ring_kb, always, 
         assert promoted >= 32 and skipped == 0, r
     elif want == "skipped":
         assert skipped >= 8 and promoted == 0, r
+
+
+@pytest.mark.parametrize("seed,ring_kb,always", [(1, "1024", "1"), (2, "256", "1"), (3, "4096", "0"), (4, "1024", "0"), (5, "2048", "1")])
+def test_randomised_writes_against_a_stalling_reader_skip_and_promote_queued_chains(gpu, seed, ring_kb, always):
+    """The skipped queued-chain path, randomised: every write takes a random number of the message's
+    DATA frames -- from two slices to all 130, i.e. writes below max_sge that are never queued next to chains of one to
+    five Sends --, the reader stalls for a random 50 - 1500 us after one read in four, so at a small ring a queued chain
+    finds the write in front short at random moments (skipped on the device: grdma_tx_op::use_cursor 3, results
+    done = 2; submitted again the ordinary way) and whole at others (promoted).  Bytes and byte sum of the delivered
+    stream equal what was written; over the five seeds both outcomes occur."""
+    import json
+    es = os.path.join(ROOT, "tools", "endpoint_stream")
+    env = dict(os.environ, GRPC_PLATFORM_TYPE="RDMA_BP", GRPC_RDMA_RING_BUFFER_SIZE_KB=ring_kb, GRDMA_WRITE_QUEUE_ALWAYS=always,
+               ENDPOINT_STREAM_SEED=str(seed))
+    p = subprocess.run([es, "160", str(1 << 20), "1", "0", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    queued, promoted, skipped = r["writes_queued"]
+    assert r["checked"] and promoted + skipped <= queued and queued >= 8, r
+    _RANDOMISED_OUTCOMES.append((promoted, skipped))
+    if len(_RANDOMISED_OUTCOMES) == 5:
+        assert sum(a for a, _ in _RANDOMISED_OUTCOMES) >= 8 and sum(b for _, b in _RANDOMISED_OUTCOMES) >= 8, _RANDOMISED_OUTCOMES
+
+
+_RANDOMISED_OUTCOMES = []

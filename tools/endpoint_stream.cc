@@ -13,6 +13,10 @@
 //        their own, the way a gRPC process has the two directions of a connection on different threads
 //        (pair.h:64-81: one writer, one reader per pair); 1: one loop polls both endpoints
 // env:   GRPC_RDMA_RING_BUFFER_SIZE_KB, GRPC_RDMA_MAX_SGE ... as the reference reads them
+//        ENDPOINT_STREAM_SEED=<s != 0>: randomised -- every write takes a random number of the message's DATA frames
+//        (2 .. all of its slices: writes below and above max_sge, queued chains of every length), and the reader stalls
+//        for a random 50 - 1500 us after one read in four, so the ring fills and drains at random moments (queued chains
+//        promoted AND skipped in one run); bytes and byte sum of what was delivered still equal what was written
 #include <emmintrin.h>
 
 #include <atomic>
@@ -67,11 +71,21 @@ struct state {
   bool check, failed;
   volatile bool write_done, read_done;
   uint64_t sum_read, sum_per_msg;
+  // randomised mode (ENDPOINT_STREAM_SEED): frame pairs of write k, xorshift state of the reading side
+  std::vector<uint32_t> pairs_of_write;
+  uint64_t sum_target = 0, rng_read = 0;
 };
+static inline uint64_t xorshift(uint64_t* s) {
+  uint64_t x = *s;
+  x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+  return *s = x;
+}
 
 static void do_write(void* p, grpc_error_handle) {
   auto* st = static_cast<state*>(p);
-  for (grpc_slice& s : st->frames) {
+  const size_t take = st->pairs_of_write.empty() ? st->frames.size() : 2 * (size_t)st->pairs_of_write[st->msgs_written];
+  for (size_t i = 0; i < take; i++) {
+    grpc_slice& s = st->frames[i];
     if (s.refcount) s.refcount->refs.fetch_add(1);
     grpc_slice_buffer_add_indexed(&st->outgoing, s);  // (indexed: no merging, like chttp2's frame slices)
   }
@@ -100,6 +114,8 @@ static void on_read(void* p, grpc_error_handle e) {
     st->bytes_read += n;
   }
   if (st->bytes_read >= st->bytes_target) { st->read_done = true; return; }
+  if (st->rng_read && (xorshift(&st->rng_read) & 3) == 0)  // (randomised: the application is slow to read now and then)
+    std::this_thread::sleep_for(std::chrono::microseconds(50 + xorshift(&st->rng_read) % 1450));
   g_queue.push_back(&st->next_read);
 }
 
@@ -157,6 +173,32 @@ int main(int argc, char** argv) {
     st.sum_per_msg += sum_bytes(GRPC_SLICE_START_PTR(s), GRPC_SLICE_LENGTH(s));
   }
   st.bytes_target = st.bytes_per_msg * st.msgs_target;
+  st.sum_target = st.sum_per_msg * st.msgs_target;
+  if (const char* e = getenv("ENDPOINT_STREAM_SEED")) {
+    uint64_t seed = strtoull(e, nullptr, 10);
+    if (seed) {
+      uint64_t rs = seed * 0x9E3779B97F4A7C15ull + 1;
+      st.rng_read = seed * 0xD1B54A32D192ED03ull + 7;
+      std::vector<uint64_t> pre_b(1, 0), pre_s(1, 0);  // bytes / byte sum of the first k frame pairs
+      for (size_t i = 0; i + 1 < st.frames.size(); i += 2) {
+        uint64_t b = 0, sm = 0;
+        for (size_t q = i; q < i + 2; q++) {
+          b += GRPC_SLICE_LENGTH(st.frames[q]);
+          sm += sum_bytes(GRPC_SLICE_START_PTR(st.frames[q]), GRPC_SLICE_LENGTH(st.frames[q]));
+        }
+        pre_b.push_back(pre_b.back() + b);
+        pre_s.push_back(pre_s.back() + sm);
+      }
+      const size_t npairs = st.frames.size() / 2;
+      st.bytes_target = st.sum_target = 0;
+      for (size_t k = 0; k < st.msgs_target; k++) {
+        const uint32_t pairs = 1 + (uint32_t)(xorshift(&rs) % npairs);
+        st.pairs_of_write.push_back(pairs);
+        st.bytes_target += pre_b[pairs];
+        st.sum_target += pre_s[pairs];
+      }
+    }
+  }
   grpc_slice_buffer_init(&st.outgoing);
   grpc_slice_buffer_init(&st.incoming);
   GRPC_CLOSURE_INIT(&st.done_write, on_write, &st, nullptr);
@@ -219,7 +261,7 @@ int main(int argc, char** argv) {
   }
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   CHECK(!st.failed && st.bytes_read == st.bytes_target);
-  if (st.check) CHECK(st.sum_read == st.sum_per_msg * st.msgs_target);
+  if (st.check) CHECK(st.sum_read == st.sum_target);
   uint64_t wq[3] = {0, 0, 0};  // writes queued behind the Send in flight / promoted / skipped on the device
   grdma_endpoint_write_queue_stats(grdma_endpoint_pair(st.tx), wq);
   printf("{\"msgs\": %zu, \"payload\": %zu, \"slices_per_write\": %zu, \"endpoint_bytes\": %zu, \"seconds\": %.6f, "
