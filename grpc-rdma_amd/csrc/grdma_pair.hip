@@ -74,6 +74,7 @@ uint32_t grdma_rx_multi_groups(void);
 hipError_t grdma_launch_rx_plan_mw(const grdma_rx_op*, uint32_t, hipStream_t);
 uint32_t grdma_tx_multi_groups(void);
 uint32_t grdma_tx_multi_max_sends(void);
+uint32_t grdma_tx_multi_seq_sends(void);
 const void* grdma_kernel_fn_round_xag(void);
 uint64_t grdma_rx_scratch_bytes(void);
 uint32_t grdma_round_xag_resident_blocks(void);
@@ -2673,7 +2674,7 @@ inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 
 inline bool job_index_needed(const grdma_stream_job* j) { return !j->index_valid || !j->pre_hooks.empty() || j->sges_exposed; }
 inline int job_fastkey(const grdma_stream_job* j) {
   return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0) | (j->pair_job ? 8 : 0) | (j->fuse ? 16 : 0) |
-         (j->fuse_ag ? 32 : 0) | (j->rx_multi ? 64 : 0) | (j->fuse_round ? 128 : 0) | ((int)j->sends << 8) | (job_index_needed(j) ? (1 << 12) : 0);
+         (j->fuse_ag ? 32 : 0) | (j->rx_multi ? 64 : 0) | (j->fuse_round ? 128 : 0) | ((int)(j->sends & 7) << 8) | (job_index_needed(j) ? (1 << 12) : 0) | ((int)j->sends << 16);
 }
 // copy workgroups (1024 threads: one per CU) next to a planner workgroup in a fused launch: every CU but the planner's
 inline uint32_t job_fused_copy_blocks() {
@@ -2697,9 +2698,21 @@ inline bool job_exec_stale(const grdma_stream_job* j) {
 // step), the general planner in the same launch for what that declines
 inline bool job_tx_fast(const grdma_stream_job* j) { return j->tx_fast && j->burst == 1; }
 // planner workgroups of a round: sixteen per Send's worth of records
-inline uint32_t job_rx_groups(const grdma_stream_job* j) { return grdma_rx_multi_groups() * j->sends; }
-inline uint32_t job_tx_groups(const grdma_stream_job* j) { return grdma_tx_multi_groups() * j->sends; }
+// (up to two Sends: priced one after the other, each may carry 4095 records.  More: folded into one cut of the index,
+//  a round carries at most sends x max_sge records -- 256 of them per workgroup)
+inline uint32_t job_groups(const grdma_stream_job* j, uint32_t per_send) {
+  if (j->sends <= grdma_tx_multi_seq_sends()) return per_send * j->sends;
+  uint64_t most = 1;
+  for (const grdma_job_link& l : j->links) most = std::max<uint64_t>(most, (uint64_t)j->sends * l.tx->max_sge);
+  return (uint32_t)std::min<uint64_t>(2 * per_send, (most + 255) / 256);
+}
+inline uint32_t job_rx_groups(const grdma_stream_job* j) { return job_groups(j, grdma_rx_multi_groups()); }
+inline uint32_t job_tx_groups(const grdma_stream_job* j) { return job_groups(j, grdma_tx_multi_groups()); }
 inline bool job_mw(const grdma_stream_job* j) { return j->rx_multi && j->pipeline && j->pair_job && !j->fuse && j->rx_fast && j->burst == 1 && j->tx_fast; }
+// the sequential schedule (five launches per round, strictly in order) with the small planner workgroups: what carries
+// several Sends per plan when the job is not pipelined -- a ring every round fills sees its credit at once here, a round
+// late on the paired schedule
+inline bool job_mw_seq(const grdma_stream_job* j) { return j->sends > 1 && j->rx_multi && !j->pipeline && j->rx_fast && j->burst == 1 && j->tx_fast; }
 hipError_t job_launch_pair_mw(const grdma_rx_op* rxops, const grdma_tx_op* txops, const grdma_txf_ctl* ctls, uint32_t n, uint32_t g_rx,
                               uint32_t g_tx, hipStream_t s) {
   // (an array of GRDMA_JOB_HOOK_ARGS entries, as for every kernel launched by address: the runtime reads as many as the kernel has)
@@ -2720,13 +2733,13 @@ hipError_t job_launch_tx_plan(grdma_stream_job* j, int k, uint64_t t, uint32_t n
   if (t == 0 && job_index_needed(j)) e = grdma_launch_tx_index(j->d_txf, n, job_index_blocks(j), s);
   if (e != hipSuccess) return e;
   // (several Sends per plan: only the planners of grdma_tx_multi.h price those -- also in the eager passes)
-  if (j->sends > 1 && job_mw(j)) return job_launch_pair_mw(nullptr, j->d_txop + k * n, j->d_txf, n, 0, job_tx_groups(j), s);
+  if (j->sends > 1 && (job_mw(j) || job_mw_seq(j))) return job_launch_pair_mw(nullptr, j->d_txop + k * n, j->d_txf, n, 0, job_tx_groups(j), s);
   return grdma_launch_tx_plan_job(j->d_txop + k * n, j->d_txf, n, s);
 }
 
 // the receive plan of a round: k_rx_plan_job = the straight-line steady-state body, then the general planner for what it declines
 hipError_t job_launch_rx_plan(grdma_stream_job* j, const grdma_rx_op* ops, uint32_t n, hipStream_t s) {
-  if (j->sends > 1 && job_mw(j)) return job_launch_pair_mw(ops, nullptr, j->d_txf, n, job_rx_groups(j), 0, s);
+  if (j->sends > 1 && (job_mw(j) || job_mw_seq(j))) return job_launch_pair_mw(ops, nullptr, j->d_txf, n, job_rx_groups(j), 0, s);
   if (j->rx_fast && j->burst == 1) return grdma_launch_rx_plan_job(ops, n, s);
   return grdma_launch_rx_plan(ops, n, s);
 }
@@ -3143,6 +3156,12 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
   // the Send priced from the index, the general planner behind it in the same launch for what that declines
   auto add_tx = [&](uint64_t t, const void* txop, std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
     if (!tfast) return add(&P[t], f_txp, dim3(n), pt, txop, deps);
+    if (t != 0 && job_mw_seq(j)) {  // (several Sends per plan, sequential schedule: the Send's planners alone)
+      std::vector<hipGraphNode_t> dq(deps);
+      dq.resize(4, nullptr);
+      return add3(&P[t], grdma_kernel_fn_plan_pair_mw(), dim3(n, job_tx_groups(j)), grdma_kernel_threads(0), nullptr, txop, j->d_txf,
+                  {dq[0], dq[1], dq[2], dq[3]}, 0u);
+    }
     if (t != 0) return add2(&P[t], f_txj, dim3(n), grdma_tx_plan_job_threads(), txop, j->d_txf, deps);
     hipGraphNode_t pi = nullptr;
     if (job_index_needed(j)) {  // (the slice table's index: once per job unless the table may change between steps)
@@ -3153,13 +3172,19 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
     dv.resize(4, nullptr);  // (round 0's dependencies: at most four, all null today)
     const hipGraphNode_t d0 = pi ? pi : dv[0], d1 = pi ? nullptr : dv[1], d2 = pi ? nullptr : dv[2], d3 = pi ? nullptr : dv[3];
     // (the first Send of a step priced by the small workgroups of the planner pair too: k_plan_pair_mw with no drain)
-    if (j->rx_multi && j->pipeline && j->pair_job && !j->fuse)
+    if ((j->rx_multi && j->pipeline && j->pair_job && !j->fuse) || job_mw_seq(j))
       return add3(&P[t], grdma_kernel_fn_plan_pair_mw(), dim3(n, job_tx_groups(j)), grdma_kernel_threads(0), nullptr, txop,
                   j->d_txf, {d0, d1, d2, d3}, 0u);
     return add2(&P[t], f_txj, dim3(n), grdma_tx_plan_job_threads(), txop, j->d_txf, {d0, d1, d2, d3});
   };
   // X[t] = the receive plan of round t: k_rx_plan_job -- the steady-state body, the general planner behind it
   auto add_rx = [&](uint64_t t, const void* rxop, std::initializer_list<hipGraphNode_t> deps) -> hipError_t {
+    if (job_mw_seq(j)) {  // (the drain's planners alone: rxm_body / rxh_body, the general planner behind them)
+      std::vector<hipGraphNode_t> dq(deps);
+      dq.resize(4, nullptr);
+      return add3(&X[t], grdma_kernel_fn_plan_pair_mw(), dim3(n, job_rx_groups(j)), grdma_kernel_threads(0), rxop, nullptr, j->d_txf,
+                  {dq[0], dq[1], dq[2], dq[3]}, job_rx_groups(j));
+    }
     return add(&X[t], fast ? f_rxj : f_rxp, dim3(n), fast ? grdma_rx_plan_job_threads() : pt, rxop, deps);
   };
   auto at = [](std::vector<hipGraphNode_t>& v, uint64_t t, uint64_t back) -> hipGraphNode_t {
@@ -3719,10 +3744,11 @@ int grdma_stream_job_set_sends(grdma_stream_job* j, uint32_t sends) {
   for (uint32_t i = 0; i < n; i++) {
     grdma_job_link& l = j->links[i];
     if (!j->direct && sends > 1) {
-      const size_t bytes = (size_t)sends * (l.tx->ring_size / 2) + 64;
+      // (the Sends of a round are limited by the free space of the ring: a ring's worth of staging is enough)
+      const size_t bytes = (size_t)l.tx->ring_size + 64;
       for (int q = 0; q < 2; q++) {
         if (l.d_staging_n[q]) continue;
-        HIP_TRY(hipMalloc((void**)&l.d_staging_n[q], (size_t)grdma_tx_multi_max_sends() * (l.tx->ring_size / 2) + 64));
+        HIP_TRY(hipMalloc((void**)&l.d_staging_n[q], bytes));
         HIP_TRY(hipMemset(l.d_staging_n[q], 0, bytes));
       }
     }
@@ -3911,7 +3937,9 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
     if (j->runs >= j->slim_after) j->rx_fast = j->tx_fast = 1;
     return 0;
   }
-  if (j->burst == 1 && mode != GRDMA_RUN_ENGINE && j->rounds >= 2 && (j->rx_fast || job_tx_fast(j))) {
+  // (not with several Sends per plan: only the small planner workgroups price those, and what they decline is planned
+  //  by the general planners inside the same launch, at their full register budget)
+  if (j->burst == 1 && j->sends == 1 && mode != GRDMA_RUN_ENGINE && j->rounds >= 2 && (j->rx_fast || job_tx_fast(j))) {
     uint64_t cnt[3][2];  // {taken, declined with work waiting} of link 0: drains of both parities, Sends
     uint32_t c32[2][2];  // {pad1 = taken, pad0 = declined}
     static_assert(offsetof(grdma_rx_result, pad0) == offsetof(grdma_rx_result, pad1) + 4, "layout");

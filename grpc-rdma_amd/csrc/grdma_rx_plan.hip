@@ -1880,7 +1880,8 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan
   return hipGetLastError();
 }
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_groups(void) { return TXM_G; }
-extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_max_sends(void) { return TXM_MAX_SENDS; }
+extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_max_sends(void) { return TXM_MAX_SENDS_FOLDED; }
+extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_seq_sends(void) { return TXM_MAX_SENDS; }
 // (this translation unit's copy of the index body's counters: the pair kernel's Sends)
 extern "C" __attribute__((visibility("hidden"))) int grdma_tx_fast_sends_pair(uint64_t out[2]) {
   unsigned long long v[2] = {0, 0};

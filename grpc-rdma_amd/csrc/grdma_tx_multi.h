@@ -25,7 +25,8 @@ namespace {
 #define TXM_THREADS 256u
 #define TXM_WAVES (TXM_THREADS / 64u)
 #define TXM_G 16u   // workgroups per Send: 16 x 256 records
-#define TXM_MAX_SENDS 2u  // consecutive Sends one plan may hold (grdma_txf_ctl::sends)
+#define TXM_MAX_SENDS 2u  // consecutive Sends priced ONE AFTER THE OTHER (grdma_txf_ctl::sends <= this)
+#define TXM_MAX_SENDS_FOLDED 64u  // more Sends per plan than that: priced as one cut of the index (see txm_body)
 static_assert(TXM_G * TXM_THREADS >= GRDMA_TX_MAX_RECORDS, "one pass covers a Send");
 
 // number of threads of the workgroup whose flag is set (every thread gets the count)
@@ -48,6 +49,10 @@ struct txm_send {
   uint32_t wrap_rec, wrap_extra;             // direct wire: the record whose payload crosses the ring end
   uint64_t nrec_total, sent, staged, ntiles, nsegs, new_tail, idx, bidx;
   bool performed;
+  // a unit that folds several Sends (price(..., ns > 1)): how many of them carried records, and the LAST Send performed
+  // -- its remote_tail_ in front, what it staged / sent / was offered, its records (an empty one when the ring was full)
+  uint64_t sends_nonempty, last_tail0, last_staged, last_sent, last_offered, last_records;
+  bool declined;
 };
 
 // Returns 0: not the last workgroup of this round to arrive; 1: the last one, the round is planned; 2: the last one,
@@ -78,12 +83,19 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
   const uint64_t* const len_pre = ctl->len_pre;
   const uint32_t* const tile_pre = ctl->tile_pre;
   const bool direct = c->wire_direct != 0;
-  const uint32_t NS = ctl->sends > 1 ? (ctl->sends < TXM_MAX_SENDS ? ctl->sends : TXM_MAX_SENDS) : 1u;
+  // sends <= TXM_MAX_SENDS: that many pricings in a row.  More (the reference's default knobs: max_sge 30, a round is
+  // dozens of Sends): ONE pricing that folds them -- every Send but the last takes exactly max_sge whole records and the
+  // staging budget of a single Send (staging_cap) binds nowhere (checked; declined otherwise), so "record i goes out
+  // whole" is the cumulative space rule st_n(i) + 8 <= free and the round is one cut of the index; what the Sends do
+  // one by one (tx_rounds, the last Send's result, partial_write_) follows from the cut in closed form.
+  const uint32_t sends_cfg = ctl->sends > 1 ? (ctl->sends < TXM_MAX_SENDS_FOLDED ? ctl->sends : TXM_MAX_SENDS_FOLDED) : 1u;
+  const uint32_t FOLD = sends_cfg > TXM_MAX_SENDS ? sends_cfg : 1u;
+  const uint32_t NS = FOLD > 1 ? 1u : sends_cfg;
   const bool ok = ctl->valid != 0 && ctl->slices == op.slices && n == op.nslices && op.use_cursor != 0 && !op.inline_copy &&
                   connected && (direct || op.wire_plan != nullptr) && cap <= (1ull << 31) &&
                   ctl->tile_shift == GRDMA_PLAN_TILE_SHIFT(cap) &&
-                  (uint64_t)nwg * TXM_THREADS >= (uint64_t)NS * (GRDMA_TX_MAX_RECORDS - 1) &&
-                  (uint64_t)NS * GRDMA_TX_MAX_RECORDS + NS <= GRDMA_MAX_SEGS && (NS == 1 || direct || op.staging_alt != nullptr);
+                  (uint64_t)NS * GRDMA_TX_MAX_RECORDS + NS <= GRDMA_MAX_SEGS && (sends_cfg == 1 || direct || op.staging_alt != nullptr);
+  // (that the workgroups cover the records offered is checked per pricing: m <= nwg x 256)
   // get_remote_head(), pair.h:229-233
   const uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const uint32_t max_sge = c->max_sge;
@@ -92,23 +104,28 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
   uint8_t* const staging = op.staging_alt ? op.staging_alt : c->staging;
 
   // ---- one Send priced from the state in front of it (every thread gets the same answer)
-  auto price = [&](uint64_t tail0, uint64_t start, uint64_t byte_idx, uint64_t offered) -> txm_send {
+  auto price = [&](uint64_t tail0, uint64_t start, uint64_t byte_idx, uint64_t offered, const uint32_t ns, const uint64_t m_cap) -> txm_send {
     txm_send q;
     q.tail0 = tail0; q.byte_idx = byte_idx; q.offered = offered;
+    q.declined = false;
     q.nrec = q.short_pay = q.st_short = q.base_e = q.base_t = q.D = q.Dt = q.m = 0;
     q.wrap_rec = 0xFFFFFFFFu; q.wrap_extra = 0;
     q.performed = true;
     if (start > n) start = n;
     q.start = start;
     const uint64_t avail = n - start;
+    uint64_t msge = max_sge;  // slices of one Send
+    if (msge > GRDMA_TX_MAX_RECORDS - 1) msge = GRDMA_TX_MAX_RECORDS - 1;
     uint64_t m = avail;
-    if (m > max_sge) m = max_sge;
-    if (m > GRDMA_TX_MAX_RECORDS - 1) m = GRDMA_TX_MAX_RECORDS - 1;
+    if (m > (uint64_t)ns * msge) m = (uint64_t)ns * msge;
+    if (m > m_cap) q.declined = true;  // (more records than the workgroups of this launch cover: uniform)
+    if (q.declined) m = 0;
     q.m = m;
     const grdma_sge* sl = op.slices + start;
     const uint64_t occupied0 = (tail0 + cap - rhead) & mask;
     const uint64_t free0 = cap - occupied0;
-    const uint64_t room0 = S < free0 ? S : free0;
+    // (several Sends folded: the free space is what binds; that no single Send exceeds staging_cap is checked below)
+    const uint64_t room0 = (ns == 1 && S < free0) ? S : free0;
     // the first slice may have been sent in part: its record is shorter than the index says
     if (m) {
       const uint64_t len0 = sl[0].len, l0 = sat_sub(len0, byte_idx);
@@ -147,6 +164,19 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
       nfront = lo_f + txm_count(front, s_cnt);
     }
     q.nrec = nrec;
+    // ---- (folded) no Send of the round may be bound by its own staging budget: Send t is the slices
+    //      [t msge, (t + 1) msge) -- thread t looks at its encoded size, one round trip
+    uint64_t st_send0 = 0;  // st of the first record of the Send the short record belongs to
+    if (ns > 1) {
+      const uint64_t a = (uint64_t)tid * msge, b = a + msge < m ? a + msge : m;
+      const bool in = a < m;
+      const uint64_t ea = in ? enc_pre[start + a] : 0, eb = in ? enc_pre[start + b] : 0;
+      const uint64_t sz = in ? (eb - ea + (a == 0 ? D : 0)) : 0;
+      const bool over = in && sz + 8 > S;
+      if (txm_count(over, s_cnt) != 0 || ns > TXM_THREADS) q.declined = true;
+      const uint64_t j0 = (nrec / msge) * msge;
+      st_send0 = (m && j0 < m) ? st_i_of(j0, enc_pre[start + j0]) : 0;
+    }
     // ---- the short record behind the whole ones, the record that may cross the ring end: uniform loads, one round trip
     {
       const uint64_t wi = nfront ? nfront - 1 : 0;  // the last record that starts in front of the ring end
@@ -157,7 +187,7 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
       if (has_short) {
         // (pay = min(len, W(S - st), W(free0 - st)): it did not fit whole)
         uint64_t p = nrec == 0 ? sat_sub(len_s, byte_idx) : len_s;
-        const uint64_t a = writable_of(sat_sub(S, q.st_short)), b = writable_of(sat_sub(free0, q.st_short));
+        const uint64_t a = writable_of(sat_sub(S, q.st_short - st_send0)), b = writable_of(sat_sub(free0, q.st_short));
         if (a < p) p = a;
         if (b < p) p = b;
         q.short_pay = p;
@@ -190,6 +220,21 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     q.bidx = 0;
     if (q.short_pay > 0) q.bidx = (nrec == 0 ? byte_idx : 0) + q.short_pay;
     else if (nrec == 0) q.bidx = byte_idx;
+    // ---- the Sends one by one: how many carried records, and the last one performed
+    q.sends_nonempty = q.nrec_total ? 1 : 0;
+    q.last_tail0 = tail0; q.last_staged = q.staged; q.last_sent = q.sent; q.last_offered = offered; q.last_records = q.nrec_total;
+    if (ns > 1 && q.nrec_total) {
+      const uint64_t s_last = (q.nrec_total - 1) / msge, j0 = s_last * msge;  // the last Send that carried records
+      q.sends_nonempty = s_last + 1;
+      const uint64_t st0 = j0 ? st_i_of(j0, enc_pre[start + j0]) : 0;
+      const uint64_t sent0 = j0 ? len_pre[start + j0] - lp_start - byte_idx : 0;
+      if (q.idx < n && q.sends_nonempty < ns) {  // data is left and so is a Send: it finds the ring full and sends nothing
+        q.last_tail0 = q.new_tail; q.last_staged = 0; q.last_sent = 0; q.last_offered = offered - q.sent; q.last_records = 0;
+      } else {
+        q.last_tail0 = (tail0 + st0) & mask; q.last_staged = q.staged - st0; q.last_sent = q.sent - sent0;
+        q.last_offered = offered - sent0; q.last_records = q.nrec_total - j0;
+      }
+    }
     return q;
   };
 
@@ -205,10 +250,10 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
       if (k == 0) {
         const uint64_t remaining = c->tx_remaining;
         Q[0] = price(c->remote_tail, op.use_cursor == 1 ? c->tx_slice_idx : 0, op.use_cursor == 1 ? c->tx_byte_idx : 0,
-                     op.use_cursor == 1 ? remaining : len_pre[n]);
+                     op.use_cursor == 1 ? remaining : len_pre[n], FOLD, (uint64_t)nwg * TXM_THREADS / NS);
         performed = 1;
       } else if (Q[k - 1].performed && Q[k - 1].idx < n) {  // the write still holds data: rdma_flush sends again
-        Q[k] = price(Q[k - 1].new_tail, Q[k - 1].idx, Q[k - 1].bidx, Q[k - 1].offered - Q[k - 1].sent);
+        Q[k] = price(Q[k - 1].new_tail, Q[k - 1].idx, Q[k - 1].bidx, Q[k - 1].offered - Q[k - 1].sent, 1u, (uint64_t)nwg * TXM_THREADS / NS);
         performed = k + 1;
       }
     }
@@ -217,7 +262,10 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     tile0[k + 1] = tile0[k] + Q[k].ntiles;
     stg0[k + 1] = stg0[k] + Q[k].staged;
   }
-  const uint64_t nrec_all = rec0[TXM_MAX_SENDS];
+  bool declined = false;  // (a pricing met what it does not take: in every workgroup alike)
+#pragma unroll
+  for (uint32_t k = 0; k < TXM_MAX_SENDS; k++) declined |= Q[k].performed && Q[k].declined;
+  const uint64_t nrec_all = declined ? 0 : rec0[TXM_MAX_SENDS];
   const bool table = op.sizes_out != nullptr && nrec_all <= GRDMA_TX_MAX_RECORDS;  // (the size table holds one Send's worth)
   const uint64_t t_priced = __builtin_amdgcn_s_memtime();
 
@@ -274,7 +322,7 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
   }
   __syncthreads();
   if (!s_last) return 0;
-  if (!ok) {  // (uniform, and the same in every workgroup)
+  if (!ok || declined) {  // (uniform, and the same in every workgroup)
     if (tid == 0) {
       atomicAdd(&g_tx_fast_sends[1], 1ull);
       op.result->dbg[11]++;  // (dbg[10] / dbg[11]: Sends of this result block priced from the index / declined)
@@ -295,7 +343,7 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
 #pragma unroll
     for (uint32_t k = 0; k < TXM_MAX_SENDS; k++) {
       sent_all += Q[k].performed ? Q[k].sent : 0;
-      rounds += (Q[k].performed && Q[k].nrec_total) ? 1 : 0;
+      rounds += Q[k].performed ? Q[k].sends_nonempty : 0;
     }
     plan->nsegs = (uint32_t)nsegs;
     plan->ntiles = (uint32_t)ntiles;
@@ -308,14 +356,14 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     grdma_tx_result* r = op.result;
     r->wr_count = 0;
     r->wr_off[0] = r->wr_off[1] = r->wr_len[0] = r->wr_len[1] = 0;
-    if (L.staged > 0) {
-      const uint64_t s1 = L.staged < cap - L.tail0 ? L.staged : cap - L.tail0;
-      r->wr_off[0] = L.tail0;
+    if (L.last_staged > 0) {
+      const uint64_t s1 = L.last_staged < cap - L.last_tail0 ? L.last_staged : cap - L.last_tail0;
+      r->wr_off[0] = L.last_tail0;
       r->wr_len[0] = s1;
       r->wr_count = 1;
-      if (L.tail0 + L.staged >= cap) {  // a record reached (or crossed) the ring end
+      if (L.last_tail0 + L.last_staged >= cap) {  // a record reached (or crossed) the ring end
         r->wr_off[1] = 0;
-        r->wr_len[1] = L.staged - s1;
+        r->wr_len[1] = L.last_staged - s1;
         r->wr_count = 2;
       }
     }
@@ -343,18 +391,18 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
       wp->bytes = direct ? 0 : staged_all;
     }
     c->remote_tail = L.new_tail;
-    c->partial_write = L.sent < L.offered ? 1 : 0;  // pair.cc:709
+    c->partial_write = L.last_sent < L.last_offered ? 1 : 0;  // pair.cc:709
     c->total_written = o_written + sent_all;
     c->tx_records = o_records + nrec_all;
-    c->tx_last_records = (uint32_t)L.nrec_total;
+    c->tx_last_records = (uint32_t)L.last_records;
     if (rounds) c->tx_rounds = o_rounds + rounds;
     c->tx_slice_idx = L.idx;
     c->tx_byte_idx = L.bidx;
     c->tx_remaining = L.offered - L.sent;
-    r->sent = L.sent;
-    r->records = L.nrec_total;
-    r->staged = L.staged;
-    r->partial = L.sent < L.offered ? 1 : 0;
+    r->sent = L.last_sent;
+    r->records = L.last_records;
+    r->staged = L.last_staged;
+    r->partial = L.last_sent < L.last_offered ? 1 : 0;
     r->new_remote_tail = L.new_tail;
     if (op.tail_out != nullptr) *op.tail_out = L.new_tail;
     if (op.sizes_out != nullptr) {
@@ -369,8 +417,8 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     r->dbg[6] = __builtin_amdgcn_s_memtime();
     r->dbg[7] = Q[0].m + (TXM_MAX_SENDS > 1 ? Q[TXM_MAX_SENDS - 1].m : 0);
     r->dbg[9] = 0xFA57;  // this Send was priced from the index
-    r->dbg[10] += performed;
-    atomicAdd(&g_tx_fast_sends[0], (unsigned long long)performed);
+    r->dbg[10] += FOLD > 1 ? (L.sends_nonempty ? L.sends_nonempty : 1) : performed;
+    atomicAdd(&g_tx_fast_sends[0], (unsigned long long)(FOLD > 1 ? (L.sends_nonempty ? L.sends_nonempty : 1) : performed));
     const uint64_t nxt = op.seq_next ? op.seq_next : o_seq + 1;
     __hip_atomic_store(&r->seq, nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }

@@ -447,9 +447,10 @@ int grdma_stream_job_set_pipeline(grdma_stream_job* j, int on);
  * Send carries ~242 KB) this is what keeps the chip busy: the Sends of a round are planned by one
  * launch, gathered by one, put on the wire by one.  Rounds run strictly in order. */
 int grdma_stream_job_set_burst(grdma_stream_job* j, uint32_t burst);
-/* `sends` (1..2) consecutive Sends per round in ONE plan -- rdma_flush's loop while the ring has room
+/* `sends` (1..64) consecutive Sends per round in ONE plan -- rdma_flush's loop while the ring has room
  * (rdma_bp_posix.cc:470-524): Send, advance the cursor, Send again -- before the peer drains; paired schedule of a
- * pipelined job only (other schedules keep one Send per round). */
+ * pipelined job only (other schedules keep one Send per round).  Up to two Sends are priced one after the other;
+ * more (small max_sge: the reference's default is 30) as one cut of the slice table's index. */
 int grdma_stream_job_set_sends(grdma_stream_job* j, uint32_t sends);
 
 /* ---- diagnostics (profiling aids used by tools/; not needed by an integration) ------------

@@ -269,6 +269,60 @@ SENDS_CASES = [
 ]
 
 
+FOLDED_CASES = [
+    # (ring, max_sge, sends, n_msgs, msg_len, exact): more than two Sends per round -- priced as ONE cut of the index
+    (1 << 25, 30, 8, 40, 1 << 18, True),      # the reference's max_sge: rounds of eight Sends of 30 slices
+    (1 << 26, 100, 6, 30, 1 << 20, True),     # 1 MiB messages, 600 slices per round
+    (1 << 24, 7, 64, 2000, 300, None),        # tiny messages, 64 Sends of 7 slices (the drain bodies decline them)
+    (1 << 22, 30, 64, 48, 1 << 20, False),    # the reference's default knobs: every round is cut by the free space
+    (1 << 18, 30, 16, 30, 50000, "declines"), # a 256 KiB ring: a Send of 30 slices exceeds the staging budget (ring / 2):
+                                              # the folded pricing declines, the general planner sends one Send per round
+]
+
+
+@pytest.mark.parametrize("pipeline", [True, False], ids=["paired", "sequential"])
+@pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
+@pytest.mark.parametrize("case", FOLDED_CASES, ids=["r32m_sge30x8", "r64m_sge100x6", "r16m_sge7x64", "r4m_sge30x64", "r256k_sge30x16"])
+def test_many_sends_per_round_priced_as_one_cut_of_the_index_match_the_oracle(gpu, case, flags, pipeline):
+    """grdma_stream_job_set_sends(n > 2): the Sends of a round folded into one pricing (csrc/grdma_tx_multi.h: every Send
+    but the last takes max_sge whole records, the staging budget of one Send binds nowhere, so the round is one cut of
+    the index against the free space; tx_rounds, the last Send's result and partial_write_ in closed form).  Slices,
+    ring image and state equal the oracle's rounds of n Sends and one drain; where every round is cut by the ring's
+    free space the paired schedule sees its credit a round late and the byte stream + the empty ring are checked --
+    the SEQUENTIAL schedule (five launches per round, the same planner workgroups) sees it at once and equals the
+    oracle's rounds there too (the reference's default knobs: 4 MiB ring, max_sge 30)."""
+    R, max_sge, sends, n_msgs, msg_len, exact = case
+    if not pipeline and exact is False:
+        exact = True
+    rng = random.Random(R % 79 + sends)
+    body = bytes(rng.getrandbits(8) for _ in range(min(msg_len, 4096))) * (msg_len // min(msg_len, 4096) + 1)
+    slices = []
+    for i in range(n_msgs):
+        wire, lens = pyorc.h2_frame_message(body[:msg_len], stream_id=2 * i + 1)
+        off = 0
+        for ln in lens:
+            slices.append(wire[off:off + ln])
+            off += ln
+    before = _fast_counts(gpu)
+    got = _run_job(gpu, R, max_sge, slices, pipeline=pipeline, flags=flags, sends=sends)
+    after = _fast_counts(gpu)
+    assert b"".join(got["slices"]) == b"".join(slices)
+    assert got["ring"] == bytes(R)
+    if exact != "declines":
+        assert after[6] - before[6] > 0 and after[7] == before[7], "Sends priced from the index / declined: %d / %d" % (
+            after[6] - before[6], after[7] - before[7])
+    else:
+        assert after[7] > before[7]
+    if exact in (True, None):
+        exp, exp_rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, slices, sends=sends)
+        assert [len(x) for x in got["slices"]] == [len(x) for x in exp]
+        assert got["slices"] == exp
+        for k in ("remote_tail", "remote_head", "partial_write"):
+            assert got["tx"][k] == st0[k], k
+        for k in ("head", "moving_head", "remain", "internal_read_size"):
+            assert got["rx"][k] == st1[k], k
+
+
 @pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
 @pytest.mark.parametrize("case", SENDS_CASES, ids=["r128m_sge1023", "r32m_sge4095", "r16m_small", "r4m_ring_limited"])
 def test_two_sends_per_round_in_one_plan_match_the_oracle(gpu, case, flags):
