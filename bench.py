@@ -539,7 +539,7 @@ def main():
         torch.cuda.synchronize()
 
     def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB,
-                pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None, burst=1, reps=1, sends=None):
+                pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None, burst=1, reps=1, sends=None, promise=False):
         """n_links connections with rings of ring_kb KiB.  Graph schedule: calibrate the number of
         rounds, capture the graph, time `steps` replays.  Engine schedule: every step is ONE launch of
         the persistent link engine.  Then verify, optionally instrument."""
@@ -574,12 +574,16 @@ def main():
                 job.set_burst(burst)                   # `burst` Sends per round, then one drain
             if sends > 1:
                 job.set_sends(sends)                   # `sends` consecutive Sends in one plan per round, then one drain
+            if promise:
+                job.set_promised_credit(True)          # the Send priced with the credit the drain in its launch will post
             r = job.run(gs.RUN_EAGER)                  # calibration: how many rounds are needed
             assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
                 r.bytes_delivered, total_n)
             # (tx_rounds counts Sends)
             rounds = int(max(-(-int(r.tx_rounds) // sends), r.rx_rounds)) if burst == 1 else int(r.rx_rounds) + 1
-            if sends > 2 and pipeline:
+            if sends > 2:
+                rounds += 2  # (a ring every round fills: later passes start at another ring phase and may need a round more)
+            if sends > 2 and pipeline and not promise:
                 # a credit-limited ring: the paired graph sees its credit a round late and needs more rounds than the
                 # in-order calibration pass -- replay with room, then keep what a pass really used
                 job.set_rounds(2 * rounds + 8)
@@ -1099,16 +1103,21 @@ def main():
         # as ONE cut of the slice table's index by the small planner workgroups, the drain predicted from the sizes they
         # leave; SEQUENTIAL schedule (five launches per round): every round fills the ring, and the paired schedule would
         # see its credit a round late.
-        for key, wf in (("value_ring4096_sge30", None), ("value_ring4096_sge30_wire_direct", 2)):
+        for key, wf, pl in (("value_ring4096_sge30", None, True), ("value_ring4096_sge30_sequential", None, False),
+                            ("value_ring4096_sge30_wire_direct", 2, False)):
             try:
-                rk = measure(4096, half, 1, not args.no_verify, False, max_sge=30, pipeline=False, sends=64, wire_flags=wf)
+                # staged wire: the PAIRED schedule (three launches per round) with the promised credit -- the Send of round
+                # t + 1 waits, inside the planner pair's launch, for the drain plan of round t and is priced with the credit
+                # it will post: every round fills the ring, as on the sequential schedule.  Direct wire: sequential (the
+                # gather of round t + 1 writes the ring, it cannot share a launch with the scatter of round t).
+                rk = measure(4096, half, 1, not args.no_verify, False, max_sge=30, pipeline=pl, sends=64, wire_flags=wf, promise=pl)
                 out[key] = round(wl.user_bytes * half * world / rk["elapsed"] / (1 << 30), 3)
                 out["rounds_per_step_" + key[6:]] = rk["rounds"]
-                if wf is None:
+                if key == "value_ring4096_sge30":
                     out["config"]["ring4096_sge30_leg"] = (
                         "4 MiB ring, max_sge 30 (the reference's defaults); a round = Sends of 30 slices until the ring is full "
-                        "(grdma_stream_job_set_sends), priced as one cut of the slice table's index; sequential schedule, %d rounds"
-                        % rk["rounds"])
+                        "(grdma_stream_job_set_sends), priced as one cut of the slice table's index; paired schedule with the "
+                        "promised credit (grdma_stream_job_set_promised_credit), %d rounds" % rk["rounds"])
             except Exception as e:
                 out[key[6:] + "_error"] = err_text(e)
         try:  # (rounds 2 - 4a: up to 16 Sends per round planned one by one by a single wave, general drain planner)

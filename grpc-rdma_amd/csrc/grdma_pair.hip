@@ -2636,6 +2636,10 @@ struct grdma_stream_job {
   // the first run, kept for the later ones -- unless something may rewrite the table between steps (kernel nodes hung
   // in front of the job, or a caller that asked where the table lives: the HTTP/2 pipe does both).
   bool index_valid = false, sges_exposed = false;
+  int promise = 0;                    // grdma_stream_job_set_promised_credit: the Send of round t + 1 waits, inside the planner
+                                      // pair's launch, for the drain plan of round t and is priced with the credit that
+                                      // drain's scatter will post (k_plan_pair_mw) -- the paired schedule without its round
+                                      // of credit lag
   uint32_t sends = 1;                 // grdma_stream_job_set_sends: consecutive Sends one round's plan holds (paired schedule,
                                       // planners of grdma_tx_multi.h / grdma_rx_multi.h: 16 workgroups per Send's worth of records)
   int fuse_round = 0;                 // GRDMA_JOB_FUSE_ROUND=1: the drain plan of round t, its scatter and the gather of round
@@ -2674,7 +2678,7 @@ inline int job_opset(uint64_t round) { return round == 0 ? 0 : ((round & 1) ? 1 
 inline bool job_index_needed(const grdma_stream_job* j) { return !j->index_valid || !j->pre_hooks.empty() || j->sges_exposed; }
 inline int job_fastkey(const grdma_stream_job* j) {
   return (j->rx_fast ? 1 : 0) | (j->tx_fast ? 2 : 0) | (j->deep ? 4 : 0) | (j->pair_job ? 8 : 0) | (j->fuse ? 16 : 0) |
-         (j->fuse_ag ? 32 : 0) | (j->rx_multi ? 64 : 0) | (j->fuse_round ? 128 : 0) | ((int)(j->sends & 7) << 8) | (job_index_needed(j) ? (1 << 12) : 0) | ((int)j->sends << 16);
+         (j->fuse_ag ? 32 : 0) | (j->rx_multi ? 64 : 0) | (j->fuse_round ? 128 : 0) | ((int)(j->sends & 7) << 8) | (job_index_needed(j) ? (1 << 12) : 0) | (j->promise ? (1 << 13) : 0) | ((int)j->sends << 16);
 }
 // copy workgroups (1024 threads: one per CU) next to a planner workgroup in a fused launch: every CU but the planner's
 inline uint32_t job_fused_copy_blocks() {
@@ -2707,6 +2711,9 @@ inline uint32_t job_groups(const grdma_stream_job* j, uint32_t per_send) {
   return (uint32_t)std::min<uint64_t>(2 * per_send, (most + 255) / 256);
 }
 inline uint32_t job_rx_groups(const grdma_stream_job* j) { return job_groups(j, grdma_rx_multi_groups()); }
+// (promised credit: every planner workgroup of the launch must be resident at once -- one per CU -- or a Send's
+//  workgroups could wait for a drain whose workgroups have no CU yet)
+inline bool job_promise(const grdma_stream_job* j);
 inline uint32_t job_tx_groups(const grdma_stream_job* j) { return job_groups(j, grdma_tx_multi_groups()); }
 inline bool job_mw(const grdma_stream_job* j) { return j->rx_multi && j->pipeline && j->pair_job && !j->fuse && j->rx_fast && j->burst == 1 && j->tx_fast; }
 // the sequential schedule (five launches per round, strictly in order) with the small planner workgroups: what carries
@@ -2722,6 +2729,21 @@ hipError_t job_launch_pair_mw(const grdma_rx_op* rxops, const grdma_tx_op* txops
   args[0] = (void*)&rxops; args[1] = (void*)&txops; args[2] = (void*)&ctls; args[3] = (void*)&g_rx;
   return hipLaunchKernel(grdma_kernel_fn_plan_pair_mw(), dim3(n, g_rx + g_tx), dim3(grdma_kernel_threads(0)), args, 0, s);
 }
+inline bool job_promise(const grdma_stream_job* j) {
+  // (staged wire only: with a direct wire the gather of round t + 1 writes the ring in the launch of round t's scatter)
+  if (!j->promise || !job_mw(j) || j->direct) return false;
+  static const int cus = [] {
+    int dev = 0, c = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 0;
+    return c;
+  }();
+#ifdef GRDMA_WAVE_EMU
+  return true;  // (the emulator runs the workgroups of a launch one after the other, in index order: the drain's first)
+#else
+  return (uint64_t)j->links.size() * (job_rx_groups(j) + job_tx_groups(j)) <= (uint64_t)cus;
+#endif
+}
+inline uint32_t job_pair_mode(const grdma_stream_job* j) { return job_rx_groups(j) | (job_promise(j) ? (1u << 16) : 0u); }
 inline uint32_t job_index_blocks(const grdma_stream_job* j) {  // k_tx_index: 1024 slices per workgroup
   uint64_t most = 1;
   for (const grdma_job_link& l : j->links) most = std::max<uint64_t>(most, l.count);
@@ -2886,7 +2908,7 @@ int job_enqueue_schedule_instrumented(grdma_stream_job* j, hipStream_t s) {
     }
     if (j->rx_multi)
       HIP_TRY(launch(grdma_kernel_fn_plan_pair_mw(), dim3(n, job_rx_groups(j) + (more ? job_tx_groups(j) : 0)),
-                     grdma_kernel_threads(0), rxop, more ? txop_next : nullptr, j->d_txf, job_rx_groups(j)));
+                     grdma_kernel_threads(0), rxop, more ? txop_next : nullptr, j->d_txf, job_pair_mode(j)));
     else
     HIP_TRY(launch(grdma_kernel_fn_plan_pair_job(), dim3(n, more ? 2 : 1), grdma_rx_plan_job_threads(), rxop,
                    more ? txop_next : nullptr, j->d_txf));
@@ -3295,7 +3317,7 @@ int job_build_graph(grdma_stream_job* j, hipGraph_t* out) {
         if (j->rx_multi)
           e = add3(&X[t], grdma_kernel_fn_plan_pair_mw(), dim3(n, job_rx_groups(j) + (more ? job_tx_groups(j) : 0)),
                    grdma_kernel_threads(0), rxop, more ? txop_next : nullptr, j->d_txf, {j->direct ? G[t] : W[t], at(A, t, 1)},
-                   job_rx_groups(j));
+                   job_pair_mode(j));
         else
         e = add3(&X[t], grdma_kernel_fn_plan_pair_job(), dim3(n, more ? 2 : 1), grdma_rx_plan_job_threads(), rxop,
                  more ? txop_next : nullptr, j->d_txf, {j->direct ? G[t] : W[t], at(A, t, 1)});
@@ -3730,6 +3752,17 @@ int grdma_stream_job_set_pipeline(grdma_stream_job* j, int on) {
   return 0;
 }
 
+// "Promised credit" for the paired schedule of a pipelined job on a staged wire (csrc/grdma_rx_plan.hip, k_plan_pair_mw): the
+// Send of round t + 1 is priced with the credit the drain of round t is going to post -- it waits for that drain's plan
+// inside the launch they share -- so a ring that every round fills (the reference's default: 4 MiB) carries a full round
+// every round, as on the sequential schedule, in three launches instead of five.
+int grdma_stream_job_set_promised_credit(grdma_stream_job* j, int on) {
+  if (int rc = require_ctx()) return rc;
+  if (!j) return fail(GRDMA_ERR_INVALID, "null job");
+  j->promise = on != 0;
+  return 0;
+}
+
 // `sends` consecutive Sends per round in ONE plan (1 = the plain schedule): what rdma_flush does while the ring has
 // room -- Send, advance the cursor, Send again (rdma_bp_posix.cc:470-524) -- priced by the planners of
 // csrc/grdma_tx_multi.h from the index, Send k + 1 from the state Send k leaves; the peer drains once per round.  For
@@ -3880,7 +3913,9 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
     HIP_TRY(hipEventRecord(j->ev0, s));
     if (mode == GRDMA_RUN_INSTRUMENTED_SCHEDULE) {
       if (int rc = job_enqueue_schedule_instrumented(j, s)) return rc;
-    } else if (j->pipeline && j->burst == 1 && mode == GRDMA_RUN_EAGER) {
+    } else if (j->pipeline && j->burst == 1 && mode == GRDMA_RUN_EAGER && !j->promise) {
+      // (a promised-credit job's eager pass runs in order instead: the stream pipeline sees its credit a round late,
+      //  the graph of such a job does not)
       if (int rc = (j->cumask_bits > 0 ? job_enqueue_masked(j, s) : job_enqueue_pipelined(j, s))) return rc;
     } else {
       if (int rc = job_enqueue(j, s, mode == GRDMA_RUN_INSTRUMENTED)) return rc;
@@ -3939,7 +3974,7 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
   }
   // (not with several Sends per plan: only the small planner workgroups price those, and what they decline is planned
   //  by the general planners inside the same launch, at their full register budget)
-  if (j->burst == 1 && j->sends == 1 && mode != GRDMA_RUN_ENGINE && j->rounds >= 2 && (j->rx_fast || job_tx_fast(j))) {
+  if (j->burst == 1 && j->sends == 1 && !j->promise && mode != GRDMA_RUN_ENGINE && j->rounds >= 2 && (j->rx_fast || job_tx_fast(j))) {
     uint64_t cnt[3][2];  // {taken, declined with work waiting} of link 0: drains of both parities, Sends
     uint32_t c32[2][2];  // {pad1 = taken, pad0 = declined}
     static_assert(offsetof(grdma_rx_result, pad0) == offsetof(grdma_rx_result, pad1) + 4, "layout");

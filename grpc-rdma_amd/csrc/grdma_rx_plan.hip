@@ -1510,8 +1510,15 @@ void k_plan_pair_job(const grdma_rx_op* rxops, const grdma_tx_op* txops, const g
 // with the whole register file: no spills, unlike behind the 1024-thread job kernels).
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_plan_pair_mw(const grdma_rx_op* rxops, const grdma_tx_op* txops, const grdma_txf_ctl* ctls, uint32_t G) {
+void k_plan_pair_mw(const grdma_rx_op* rxops, const grdma_tx_op* txops, const grdma_txf_ctl* ctls, uint32_t G_mode) {
   static_assert(RXM_THREADS == PLAN_THREADS && TXM_THREADS == PLAN_THREADS, "one workgroup shape for all planner bodies");
+  // G_mode = receive workgroups per link | "promised credit" << 16: the Send waits for the drain plan of this launch
+  // and is priced with the credit that drain's scatter will post (txm_body).  The hand-over: the workgroup that
+  // committed the drain writes its L2 back (one agent-scope release: the result block is at the memory side) and
+  // raises grdma_plan::ready; the Send's workgroups poll it (bounded), invalidate their L2's non-coherent lines (one
+  // agent-scope acquire) and read the credit words; the last of them to arrive clears the flag.  Receive workgroups are dispatched first (smaller blockIdx.y).
+  const uint32_t G = G_mode & 0xFFFFu;
+  const bool promise = (G_mode >> 16) != 0 && G != 0 && gridDim.y > G;
   if (blockIdx.y < G) {
     // a connection whose record sizes have a period: predicted from the pattern; none, but the round carries the sizes its
     // own Send computed: predicted from those (grdma_rx_hint.h).  Either way every record is verified in the ring.
@@ -1521,11 +1528,36 @@ void k_plan_pair_mw(const grdma_rx_op* rxops, const grdma_tx_op* txops, const gr
       __syncthreads();
       r = rxh_body(rop, blockIdx.y, G);
     }
-    if (r != 2) return;  // (uniform)
-    rx_plan_body(rxops[blockIdx.x]);
-    if (threadIdx.x == 0) rxops[blockIdx.x].result->dbg[9] = 0;
+    if (r == 0) return;  // (uniform: not the committing workgroup)
+    if (r == 2) {
+      rx_plan_body(rxops[blockIdx.x]);
+      if (threadIdx.x == 0) rxops[blockIdx.x].result->dbg[9] = 0;
+    }
+    if (promise) {
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&rop.plan->ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   } else {
-    if (txm_body(txops[blockIdx.x], &ctls[blockIdx.x], blockIdx.y - G, gridDim.y - G) != 2) return;  // (uniform)
+    const grdma_rx_result* promised = nullptr;
+    if (promise) {
+      if (plan_wait_ready(rxops[blockIdx.x].plan) != nullptr) {
+        // acquire: this XCD's L2 may hold the result block as a receive workgroup beside us read it when the launch
+        // began (an L2-bypassing load still hits a line that is there) -- drop what is not coherent before reading it
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        promised = rxops[blockIdx.x].result;
+      } else if (threadIdx.x == 0 && blockIdx.y == G) {
+        atomicAdd(&g_tx_promise[3], 1ull);
+      }
+      // (a wait that ran out -- a bug, not a state -- prices the Send with the credit posted so far: the paired schedule)
+    }
+    const int t = txm_body(txops[blockIdx.x], &ctls[blockIdx.x], blockIdx.y - G, gridDim.y - G, promised);
+    if (t == 0) return;  // (uniform)
+    if (promise && threadIdx.x == 0)  // every workgroup of the Send has passed its wait: the flag's next use is the next launch
+      __hip_atomic_store(&rxops[blockIdx.x].plan->ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t != 2) return;
     tx_plan_body(txops[blockIdx.x]);
     if (threadIdx.x == 0) txops[blockIdx.x].result->dbg[9] = 0;
   }
@@ -1882,6 +1914,12 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_groups(void) { return TXM_G; }
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_max_sends(void) { return TXM_MAX_SENDS_FOLDED; }
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_seq_sends(void) { return TXM_MAX_SENDS; }
+extern "C" int grdma_tx_promise_counts(uint64_t out[4]) {
+  unsigned long long v[4] = {0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_tx_promise), sizeof(v)) != hipSuccess) return -1;
+  for (int i = 0; i < 4; i++) out[i] = v[i];
+  return 0;
+}
 // (this translation unit's copy of the index body's counters: the pair kernel's Sends)
 extern "C" __attribute__((visibility("hidden"))) int grdma_tx_fast_sends_pair(uint64_t out[2]) {
   unsigned long long v[2] = {0, 0};

@@ -22,6 +22,10 @@
 
 namespace {
 
+// profiling aid (grdma_tx_promise_counts): Sends priced with a promised credit / with none in the drain's result /
+// with one that was not between the posted head and the tail (an older block); waits that ran out
+__device__ unsigned long long g_tx_promise[4] = {0, 0, 0, 0};
+
 #define TXM_THREADS 256u
 #define TXM_WAVES (TXM_THREADS / 64u)
 #define TXM_G 16u   // workgroups per Send: 16 x 256 records
@@ -66,7 +70,15 @@ struct txm_send {
 // so the wire plan is still at most two pieces.  Every workgroup prices every Send (two round trips each); the
 // records of all of them are then spread over the threads of all workgroups.  State and counters advance Send by
 // Send (tx_rounds counts Sends); the result block is the LAST performed Send's.
-__device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_txf_ctl* ctl, const uint32_t wg, const uint32_t nwg) {
+//
+// `promised` (a job's "promised credit" mode, k_plan_pair_mw): the result block of the drain planned by the receive
+// workgroups of the SAME launch, committed before this body starts (the caller waited).  The credit that drain's
+// scatter is going to post is then known -- credit_sent / credit_head are computed by the plan, the scatter only
+// publishes them once the bytes are free -- and the Send is priced with it: nothing of this Send touches the ring
+// before that scatter has run (the gather fills the staging buffer; the wire kernel is the launch behind the
+// scatter's), so the round sees the credit the sequential schedule would give it, a round earlier than the paired one.
+__device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_txf_ctl* ctl, const uint32_t wg, const uint32_t nwg,
+                                        const grdma_rx_result* promised = nullptr) {
   const grdma_tx_op op = op_in;
   const uint64_t t_begin = __builtin_amdgcn_s_memtime();
   const uint32_t tid = threadIdx.x;
@@ -97,7 +109,22 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
                   (uint64_t)NS * GRDMA_TX_MAX_RECORDS + NS <= GRDMA_MAX_SEGS && (sends_cfg == 1 || direct || op.staging_alt != nullptr);
   // (that the workgroups cover the records offered is checked per pricing: m <= nwg x 256)
   // get_remote_head(), pair.h:229-233
-  const uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (promised != nullptr) {
+    const bool first = wg == 0 && tid == 0;
+    if (xwg_ld64<true>(&promised->credit_sent) != 0) {
+      // (a head between the one posted so far and remote_tail_: a drain that found nothing leaves an older result block)
+      const uint64_t ph = xwg_ld64<true>(&promised->credit_head), tail_now = c->remote_tail;
+      if (((ph - rhead) & mask) <= ((tail_now - rhead) & mask)) {
+        rhead = ph;
+        if (first) atomicAdd(&g_tx_promise[0], 1ull);
+      } else if (first) {
+        atomicAdd(&g_tx_promise[2], 1ull);
+      }
+    } else if (first) {
+      atomicAdd(&g_tx_promise[1], 1ull);
+    }
+  }
   const uint32_t max_sge = c->max_sge;
   const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap);
   const uint64_t TB = 1ull << ts;

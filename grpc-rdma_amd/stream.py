@@ -69,6 +69,12 @@ class StreamJob:
         self.lib.grdma_stream_job_set_sends.argtypes = [C.c_void_p, C.c_uint32]
         check(self.lib.grdma_stream_job_set_sends(self.h, sends))
 
+    def set_promised_credit(self, on=True):
+        """Paired schedule, staged wire: the Send of round t + 1 priced with the credit the drain of round t will post
+        (grdma_stream_job_set_promised_credit)."""
+        self.lib.grdma_stream_job_set_promised_credit.argtypes = [C.c_void_p, C.c_int]
+        check(self.lib.grdma_stream_job_set_promised_credit(self.h, 1 if on else 0))
+
     def set_burst(self, burst):
         """`burst` Sends per round before the peer drains (grdma_stream_job_set_burst)."""
         self.lib.grdma_stream_job_set_burst.argtypes = [C.c_void_p, C.c_uint32]

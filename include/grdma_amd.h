@@ -452,6 +452,9 @@ int grdma_stream_job_set_burst(grdma_stream_job* j, uint32_t burst);
  * pipelined job only (other schedules keep one Send per round).  Up to two Sends are priced one after the other;
  * more (small max_sge: the reference's default is 30) as one cut of the slice table's index. */
 int grdma_stream_job_set_sends(grdma_stream_job* j, uint32_t sends);
+/* Paired schedule, staged wire: price the Send of round t + 1 with the credit the drain of round t will post (it waits
+ * for that drain's plan inside the launch they share) -- no round of credit lag at a ring every round fills. */
+int grdma_stream_job_set_promised_credit(grdma_stream_job* j, int on);
 
 /* ---- diagnostics (profiling aids used by tools/; not needed by an integration) ------------
  * s_memtime stamps / counters the plan kernels leave in their result blocks, the
@@ -464,6 +467,7 @@ int grdma_engine_debug(uint64_t out[5]);
 uint64_t grdma_express_drains(void);  /* drains served by the single-wave express path so far */
 int grdma_tx_fast_sends(uint64_t out[2]);  /* Sends of streaming jobs planned by k_tx_fast [0], left to the general planner [1] (csrc/grdma_tx_fast.h) */
 int grdma_rx_fast_drains(uint64_t out[6]);  /* drains of streaming jobs taken by k_rx_fast [0], declined by reason [1..5] (csrc/grdma_rx_fast.h) */
+int grdma_tx_promise_counts(uint64_t out[4]);  /* promised-credit Sends: priced with it [0], none in the drain [1], an older block [2]; waits that ran out [3] */
 int grdma_tx_small_ticks(uint64_t out[8]);  /* profiling aid: phase ticks of the latency engine's small Sends */
 /* Scalar ring arithmetic of the host layer (ring_buffer.h:101-143), exported so that the
  * CPU tests can pin it against the oracle without a device. */

@@ -78,7 +78,7 @@ def _oracle_rounds(R, max_sge, slices, sends=1):
     return delivered, first_rounds, st, ring
 
 
-def _run_job(g, R, max_sge, slices, pipeline, flags=0, mode=None, sends=1):
+def _run_job(g, R, max_sge, slices, pipeline, flags=0, mode=None, sends=1, promise=False):
     from grpc_rdma_amd import stream as gs
     rng = random.Random(5)
     bufs = [g.DeviceBuffer(data=s, offset=rng.randrange(16)) for s in slices]
@@ -95,6 +95,8 @@ def _run_job(g, R, max_sge, slices, pipeline, flags=0, mode=None, sends=1):
     job.set_pipeline(pipeline)
     if sends > 1:
         job.set_sends(sends)
+    if promise:
+        job.set_promised_credit(True)
     r = job.run(gs.RUN_EAGER)
     assert r.done and r.bytes_delivered == N and r.bytes_sent == N
     rounds = int(max(r.tx_rounds, r.rx_rounds))  # (tx_rounds counts Sends: an upper bound of the rounds)
@@ -267,6 +269,46 @@ SENDS_CASES = [
                                             # (exact; the predicting drain bodies decline them, as in MULTI_CASES)
     (1 << 22, 700, 40, 1 << 18, False),     # a ring the rounds fill: the second Send is cut by the free space
 ]
+
+
+@pytest.mark.parametrize("case", [(1 << 22, 30, 64, 48, 1 << 20), (1 << 18, 30, 1, 120, 9000), (1 << 20, 64, 2, 12, 200000),
+                                  (1 << 22, 700, 2, 40, 1 << 18), (1 << 23, 255, 1, 40, 1 << 17)],
+                         ids=["r4m_sge30x64", "r256k_sge30", "r1m_sge64x2", "r4m_sge700x2", "r8m_sge255"])
+def test_paired_schedule_with_promised_credit_equals_the_plain_oracle_rounds(gpu, case):
+    """grdma_stream_job_set_promised_credit: inside the planner pair's launch the Send of round t + 1 waits for the
+    drain plan of round t and is priced with the credit that drain's scatter will post.  The paired schedule then has
+    no round of credit lag: at rings every round fills -- the reference's 4 MiB default with max_sge 30, 256 KiB, 1 MiB
+    -- slices, ring image and state equal the oracle's PLAIN rounds (Send(s), endpoint reads until one would block),
+    which the paired schedule otherwise only matches with the credit a round late."""
+    R, max_sge, sends, n_msgs, msg_len = case
+    rng = random.Random(R % 73 + sends)
+    body = bytes(rng.getrandbits(8) for _ in range(min(msg_len, 4096))) * (msg_len // min(msg_len, 4096) + 1)
+    slices = []
+    for i in range(n_msgs):
+        wire, lens = pyorc.h2_frame_message(body[:msg_len], stream_id=2 * i + 1)
+        off = 0
+        for ln in lens:
+            slices.append(wire[off:off + ln])
+            off += ln
+    import ctypes as C
+    lib = gpu.load()
+    pc0 = (C.c_uint64 * 4)()
+    lib.grdma_tx_promise_counts(pc0)
+    got = _run_job(gpu, R, max_sge, slices, pipeline=True, flags=0, sends=sends, promise=True)
+    pc1 = (C.c_uint64 * 4)()
+    lib.grdma_tx_promise_counts(pc1)
+    counts = [int(b) - int(a) for a, b in zip(pc0, pc1)]
+    print("promised-credit Sends: priced with it %d, none in the drain %d, older block %d, waits that ran out %d" % tuple(counts))
+    assert counts[3] == 0 and counts[0] > 0, counts
+    exp, exp_rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, slices, sends=sends)
+    assert b"".join(got["slices"]) == b"".join(slices)
+    assert [len(x) for x in got["slices"]] == [len(x) for x in exp]
+    assert got["slices"] == exp
+    assert got["ring"] == ring == bytes(R)
+    for k in ("remote_tail", "remote_head", "partial_write"):
+        assert got["tx"][k] == st0[k], k
+    for k in ("head", "moving_head", "remain", "internal_read_size"):
+        assert got["rx"][k] == st1[k], k
 
 
 FOLDED_CASES = [

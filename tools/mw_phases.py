@@ -27,7 +27,10 @@ def main():
     dst_cap = w.N + 16 * scap + 4096
     dst = g.DeviceBuffer(nbytes=dst_cap)
     job = gs.MultiStreamJob([(tx, rx, w.sge, dst.ptr, dst_cap, scap)], max(8, 4 * (w.E // (ring // 2) + 2), 2 * (len(w.lens) // max_sge + 2)))
-    job.set_pipeline(True)
+    if os.environ.get("MW_WIRE") == "direct":
+        pass
+    pipeline = os.environ.get("MW_PIPELINE", "1") != "0"
+    job.set_pipeline(pipeline)
     if sends > 1:
         job.set_sends(sends)
     r = job.run(gs.RUN_EAGER)
@@ -35,7 +38,7 @@ def main():
     for _ in range(4):
         r = job.run(gs.RUN_GRAPH)
     print("graph step %.1f us" % (1e3 * r.ms_total))
-    inst = job.run(gs.RUN_INSTRUMENTED_SCHEDULE)
+    inst = job.run(gs.RUN_INSTRUMENTED_SCHEDULE if pipeline else gs.RUN_INSTRUMENTED)
     names = gs.CLASS_NAMES
     print("us per launch:", {names[i]: round(1e3 * inst.ms_class[i] / max(1, int(inst.launches_class[i])), 1) for i in range(len(names))})
     lib = g.load()

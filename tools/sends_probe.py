@@ -41,6 +41,8 @@ def main():
     job.set_pipeline(pipeline)
     if sends > 1:
         job.set_sends(sends)
+    if len(sys.argv) > 8 and int(sys.argv[8]):
+        job.set_promised_credit(True)
     c0 = counts(g)
     r = job.run(gs.RUN_EAGER)
     c1 = counts(g)
