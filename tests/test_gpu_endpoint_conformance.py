@@ -97,7 +97,9 @@ def test_randomised_writes_against_a_stalling_reader_skip_and_promote_queued_cha
     assert p.returncode == 0, p.stdout + p.stderr
     r = json.loads(p.stdout.strip().splitlines()[-1])
     queued, promoted, skipped = r["writes_queued"]
-    assert r["checked"] and promoted + skipped <= queued and queued >= 8, r
+    # (without GRDMA_WRITE_QUEUE_ALWAYS a write is only queued when the state line shows room for it behind the one in
+    #  flight: at a small ring that may be never)
+    assert r["checked"] and promoted + skipped <= queued and (queued >= 8 or always == "0"), r
     _RANDOMISED_OUTCOMES.append((promoted, skipped))
     if len(_RANDOMISED_OUTCOMES) == 5:
         assert sum(a for a, _ in _RANDOMISED_OUTCOMES) >= 8 and sum(b for _, b in _RANDOMISED_OUTCOMES) >= 8, _RANDOMISED_OUTCOMES
