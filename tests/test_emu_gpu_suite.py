@@ -88,6 +88,17 @@ def test_planner_pair_of_many_workgroups_and_bidirectional_job_under_the_emulato
                             "-k", "(several_workgroups and r8m_sge3001) or (bidirectional and paired)"], 4)
 
 
+def test_several_sends_per_plan_and_promised_credit_under_the_emulator(emu_lib):
+    """Round 4, second half: a round's plan holding two consecutive Sends priced one after the other, or the Sends of a
+    round folded into one cut of the slice table's index (csrc/grdma_tx_multi.h) -- on the paired and on the sequential
+    schedule, at the reference's max_sge of 30 --, and the paired schedule with the promised
+    credit (k_plan_pair_mw: the Send waits for the drain plan of its launch) against the oracle's plain rounds at rings
+    every round fills."""
+    run_gpu_tests(emu_lib, ["tests/test_gpu_stream_job.py", "-n", "4",
+                            "-k", "(two_sends and r16m_small and staged) or (many_sends and r32m_sge30x8 and staged) or "
+                                  "(promised and (r256k_sge30 or r1m_sge64x2))"], 5)
+
+
 def test_concurrent_writer_and_poller_gpu_tests_under_the_emulator(emu_lib):
     """Records landing header-first / footer-last from a second thread while the receiver polls and reads; the
     background poller thread (one k_poll launch per pass, eventfd wakeups)."""
