@@ -311,6 +311,60 @@ def test_paired_schedule_with_promised_credit_equals_the_plain_oracle_rounds(gpu
         assert got["rx"][k] == st1[k], k
 
 
+def test_three_links_of_one_job_with_two_sends_per_round_and_promised_credit(gpu):
+    """Three connections with different rings and max_sge in ONE job (one op per connection in every launch), two Sends
+    per round and the promised credit: every link's slices, ring image and state equal the oracle's plain rounds of that
+    link -- the planner workgroups of a launch are indexed by link, the hand-over of a link's drain plan to its Send is
+    per link."""
+    from grpc_rdma_amd import stream as gs
+    global PASSES
+    cfgs = [(1 << 20, 64, 12, 200000), (1 << 19, 30, 20, 70000), (1 << 21, 100, 9, 300000)]
+    links, keep, all_slices = [], [], []
+    for li, (R, max_sge, n_msgs, msg_len) in enumerate(cfgs):
+        rng = random.Random(100 + li)
+        body = bytes(rng.getrandbits(8) for _ in range(4096)) * (msg_len // 4096 + 1)
+        slices = []
+        for i in range(n_msgs):
+            wire, lens = pyorc.h2_frame_message(body[:msg_len], stream_id=2 * i + 1)
+            off = 0
+            for ln in lens:
+                slices.append(wire[off:off + ln])
+                off += ln
+        bufs = [gpu.DeviceBuffer(data=s, offset=rng.randrange(16)) for s in slices]
+        tx, rx = gpu.Pair(R, max_sge, 0), gpu.Pair(R, max_sge, 0)
+        gpu.connect_pairs(tx, rx)
+        N = sum(len(s) for s in slices)
+        dst_cap = N + 32 * (2 * len(slices) + 64) + 4096
+        dst = gpu.DeviceBuffer(nbytes=dst_cap)
+        links.append((tx, rx, [(b.ptr, len(s)) for b, s in zip(bufs, slices)], dst.ptr, dst_cap, 2 * len(slices) + 64))
+        keep.append((tx, rx, dst, dst_cap, bufs, R, max_sge, N))
+        all_slices.append(slices)
+    job = gs.MultiStreamJob(links, 60)
+    job.set_pipeline(True)
+    job.set_sends(2)
+    job.set_promised_credit(True)
+    total = sum(k[7] for k in keep)
+    for p in range(PASSES):
+        r = job.run(gs.RUN_EAGER if p == 0 else gs.RUN_GRAPH)
+        assert r.done and r.bytes_delivered == total
+        if p == 0:
+            job.set_rounds(30)
+    for li, (tx, rx, dst, dst_cap, _bufs, R, max_sge, _n) in enumerate(keep):
+        exp, _rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, all_slices[li], sends=2)
+        mem = dst.read(dst_cap)
+        got = [mem[o:o + n] for o, n in job.delivered_slices(li)]
+        assert got == exp, "link %d" % li
+        assert rx.ring_mem() == ring == bytes(R)
+        for k in ("remote_tail", "remote_head", "partial_write"):
+            assert tx.state()[k] == st0[k], (li, k)
+        for k in ("head", "moving_head", "remain", "internal_read_size"):
+            assert rx.state()[k] == st1[k], (li, k)
+    job.close()
+    for tx, rx, *_ in keep:
+        tx.close()
+        rx.close()
+
+
 FOLDED_CASES = [
     # (ring, max_sge, sends, n_msgs, msg_len, exact): more than two Sends per round -- priced as ONE cut of the index
     (1 << 25, 30, 8, 40, 1 << 18, True),      # the reference's max_sge: rounds of eight Sends of 30 slices
