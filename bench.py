@@ -1012,6 +1012,16 @@ def main():
             out["rounds_per_step_ring128m_one_send_per_round"] = o1["rounds"]
         except Exception as e:
             out["ring128m_one_send_per_round_error"] = str(e)[:200]
+        # ... and two Sends per round AT that 128 MiB ring, which holds two such rounds: with the promised credit
+        # (grdma_stream_job_set_promised_credit) the Send of round t + 1 is priced with the credit the drain of round t is
+        # about to post, so two rounds of ring are enough (the planner pair's launch then runs drain plan and send plan
+        # one after the other)
+        try:
+            o2 = measure(131072, max(2, args.steps // 2), 1, not args.no_verify, False, pipeline=True, sends=2, promise=True)
+            out["value_ring128m_promised_credit"] = round(wl.user_bytes * max(2, args.steps // 2) * world / o2["elapsed"] / (1 << 30), 3)
+            out["rounds_per_step_ring128m_promised_credit"] = o2["rounds"]
+        except Exception as e:
+            out["ring128m_promised_credit_error"] = str(e)[:200]
     if seq is not None:  # same workload and ring, five kernels per round strictly in order
         out["value_sequential"] = round(
             wl.user_bytes * max(2, args.steps // 2) * world / seq["elapsed"] / (1 << 30), 3)
