@@ -17,6 +17,21 @@ struct grdma_size_hint {
   uint32_t n[GRDMA_TX_MAX_RECORDS];
 };
 
+// The same hand-over inside ONE command of the latency engine (GRDMA_ENGINE_SEND_INLINE_DRAIN: a small send followed
+// by the armed drain of the local peer): the send wave leaves its record sizes in LDS, the drain takes them instead of
+// probing the ring.  cut_through: the engine found, before the first store, that the receiver's state admits the
+// express drain of exactly these records (ring empty, nothing half-read, the read fits) -- then the records never
+// touch the ring: the drain copies the payload from `src` (the command's inline data, the slices back to back) and
+// both connections advance as if the bytes had been written, read and cleared.  Prefix-compatible with
+// grdma_size_hint (the ops carry it in sizes_out / sizes_in).
+struct grdma_ct_hint {
+  uint64_t start_off;
+  uint32_t count;
+  uint32_t cut_through;
+  uint32_t n[8];
+  const uint8_t* src;
+};
+
 // One PairPollable::Send / rdma_flush step for one connection.
 struct grdma_tx_op {
   struct grdma_conn* conn;

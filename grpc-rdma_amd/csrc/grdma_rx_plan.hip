@@ -54,6 +54,10 @@ namespace {
 #define MINRD GRDMA_MIN_READ_SLICE
 
 __device__ unsigned long long g_express_drains = 0;  // diagnostics: drains served by the express path
+__device__ unsigned long long g_cut_through_drains = 0;
+// profiling aid (grdma_rx_express_ticks): ticks of an express drain's phases, summed -- {state loaded, records known,
+// payload loaded, stores issued, stores acknowledged, commit: counters loaded, commit: stores issued, released, count}
+__device__ unsigned long long g_rx_express_ticks[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... of which the records never touched the ring (grdma_ct_hint)
 
 struct chain_walker {
   const uint8_t* ring;
@@ -306,6 +310,19 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
   if (op.max_reads < max_slices) max_slices = op.max_reads;
   const uint64_t mh0 = c->moving_head;
   const uint64_t hist_count0 = c->rx_hist_count;
+  // Everything else of the connection block this body is going to need -- the pointers its commit stores go through,
+  // the counters it advances, the period bookkeeping -- loaded HERE, in the round trip of the loads above: a load
+  // behind the first store to the block waits for it (the block is reached through a generic pointer), and the
+  // latency path paid a round trip each for them (profiles/r04_rtt_probe.txt: 1.1 us "counters loaded" + the pointer
+  // loads between the commit's stores).  Nobody but this body writes these fields while it runs.
+  grdma_hostline* const pre_line = c->line;
+  grdma_status_report* const pre_ps = c->peer_status;
+  grdma_hostline* const pre_pl = c->peer_line;
+  uint32_t* const pre_hist = c->rx_hist;
+  const uint64_t pre_total_read = c->total_read, pre_credit_msgs = c->credit_msgs;
+  const uint64_t pre_rx_records = c->rx_records, pre_rx_rounds = c->rx_rounds;
+  const uint32_t pre_h1 = c->rx_h1, pre_h2 = c->rx_h2, pre_period = c->rx_period, pre_pad3 = c->pad3;
+  const uint64_t pre_retry_at = c->rx_period_retry_at;
 
   // ===================================================================== express drain
   // The unary small-message case (latency mode): nothing is half-read, at most EXPRESS_MAX
@@ -324,9 +341,24 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
   if (op.inline_apply && op.raw_cap == 0 && !op.append && connected && wave == 0 && c->remain == 0 &&
       max_slices >= 1) {
     const uint64_t head0 = c->head, leftover0 = c->leftover_cap, irs0 = c->internal_read_size;
-    chain_walker w = {ring, cap, head0, 0, c->rx_h2, c->rx_h1, false, room_at(head0)};
-    const uint32_t v = chain_round(&w, s_chain, lane);
-    const bool all_seen = w.dry && v <= EXPRESS_MAX;
+    const uint64_t te_a = __builtin_amdgcn_s_memtime() + (head0 & 0);  // (state loaded)
+    // (inline_apply bit 2, an engine command's armed drain: the records are the ones the send of the same command
+    //  produced -- their sizes in LDS, grdma_ct_hint -- and, cut through, they are not in the ring at all)
+    const grdma_ct_hint* cth = (op.inline_apply & 2u) ? reinterpret_cast<const grdma_ct_hint*>(op.sizes_in) : nullptr;
+    const bool hinted = cth != nullptr && cth->count >= 1 && cth->count <= EXPRESS_MAX && cth->start_off == head0;
+    const bool cut_through = hinted && cth->cut_through != 0;
+    uint32_t v;
+    bool all_seen;
+    if (hinted) {
+      v = cth->count;
+      if ((uint32_t)lane < v) s_chain[lane] = cth->n[lane];
+      all_seen = true;
+    } else {
+      chain_walker w = {ring, cap, head0, 0, pre_h2, pre_h1, false, room_at(head0)};
+      v = chain_round(&w, s_chain, lane);
+      all_seen = w.dry && v <= EXPRESS_MAX;
+    }
+    const uint64_t te_b = __builtin_amdgcn_s_memtime() + (v & 0);  // (records known)
     const uint32_t n = ((uint32_t)lane < v && all_seen) ? (uint32_t)s_chain[lane] : 0;
     const uint32_t enc = ((uint32_t)lane < v && all_seen) ? 16u + (uint32_t)round_up8(n) : 0;
     const uint32_t i_n = wave_incl_scan_u32(n), i_enc = wave_incl_scan_u32(enc);
@@ -356,11 +388,21 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
       // all byte loads first (global address space: no LDS counter involved), then the stores
       auto* gring = (const __attribute__((address_space(1))) uint8_t*)(uint64_t)ring;
       uint8_t bytes[8];
+      if (cut_through) {  // (the slices lie back to back in the command's inline data: output byte b is its byte b)
+        const uint8_t* src = cth->src;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t b = (uint32_t)lane * 8 + q;
+          bytes[q] = b < T ? src[b] : (uint8_t)0;
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         const uint32_t b = (uint32_t)lane * 8 + q;
         bytes[q] = b < T ? gring[(head0 + src_off[q]) & mask] : (uint8_t)0;
       }
+      }
+      const uint64_t te_c = __builtin_amdgcn_s_memtime() + (bytes[0] & 0);  // (payload loaded)
       // one 8-byte store per lane (the slice buffer is 16-byte aligned and `alloc` bytes long;
       // the bytes behind the slice end inside the last word are written as zero)
       if ((uint32_t)lane * 8 < T) {
@@ -370,10 +412,12 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
         *reinterpret_cast<uint64_t*>(dst + (uint32_t)lane * 8) = word;
       }
       // clear what was consumed: records are 8-byte granular, [head0, head0 + E) with wrap
+      // (cut through: nothing was written there)
+      if (!cut_through)
       for (uint32_t o = (uint32_t)lane * 8; o < E; o += 64 * 8)
         *reinterpret_cast<uint64_t*>(ring + ((head0 + o) & mask)) = 0;
       // history ring and the credit rule of Recv (pair.cc:276-284), record by record
-      uint32_t* gh = c->rx_hist;
+      uint32_t* gh = pre_hist;
       if ((uint32_t)lane < v) gh[(hist_count0 + lane) % GRDMA_RX_HIST] = enc;
       uint64_t irs = irs0, credit = 0, credit_head = 0;
       for (uint32_t r = 0; r < v; r++) {
@@ -386,7 +430,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
       }
       if (lane == 0) {
         const uint64_t nh = (head0 + E) & mask;
-        S.head = nh; S.mh = v ? nh : c->moving_head; S.remain = 0; S.irs = irs;
+        S.head = nh; S.mh = v ? nh : mh0; S.remain = 0; S.irs = irs;
         S.nsegs = S.ntiles = 0;
         S.consumed_total = E; S.records = v; S.bytes = T;
         S.credit = credit; S.credit_head = credit_head;
@@ -406,18 +450,30 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
         }
         S.stop = 1;
         S.bulk_tries = 0; S.bulk_blocked = 0; S.took = 0; S.hand_on = 0;
-        S.period = c->rx_period; S.period_searched = 0; S.period_retry_at = c->rx_period_retry_at;
-        S.period_strikes = c->pad3 & 0xFFFFu; S.period_backoff = c->pad3 >> 16; S.bulk_first = 1;
+        S.period = pre_period; S.period_searched = 0; S.period_retry_at = pre_retry_at;
+        S.period_strikes = pre_pad3 & 0xFFFFu; S.period_backoff = pre_pad3 >> 16; S.bulk_first = 1;
         for (int q = 0; q < 16; q++) s_dbg[q] = 0;
         s_dbg[0] = 1;
         // sizes of the two newest records, for the next call's probe round
         const uint32_t e_last = v >= 1 ? (uint32_t)s_chain[v - 1] : 0, e_prev = v >= 2 ? (uint32_t)s_chain[v - 2] : 0;
         if (v >= 2) { c->rx_h1 = 16u + (uint32_t)round_up8(e_last); c->rx_h2 = 16u + (uint32_t)round_up8(e_prev); }
-        else if (v == 1) { c->rx_h2 = c->rx_h1; c->rx_h1 = 16u + (uint32_t)round_up8(e_last); }
+        else if (v == 1) { c->rx_h2 = pre_h1; c->rx_h1 = 16u + (uint32_t)round_up8(e_last); }
         s_express = 1;
         atomicAdd(&g_express_drains, 1ull);
+        if (cut_through) atomicAdd(&g_cut_through_drains, 1ull);
       }
+      const uint64_t te_d = __builtin_amdgcn_s_memtime();  // (stores issued)
       GRDMA_WAIT_VMEM();
+      if (lane == 0) {
+        const uint64_t te_e = __builtin_amdgcn_s_memtime();
+        g_rx_express_ticks[0] += te_a - t_begin;
+        g_rx_express_ticks[1] += te_b - te_a;
+        g_rx_express_ticks[2] += te_c - te_b;
+        g_rx_express_ticks[3] += te_d - te_c;
+        g_rx_express_ticks[4] += te_e - te_d;
+        g_rx_express_ticks[8] += 1;
+        s_dbg[15] = te_e;
+      }
     }
   }
   __syncthreads();
@@ -1333,15 +1389,16 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
     plan->tag_mask = mask;
 
     // (counters: all loads before the first store to the connection, one round trip)
-    const uint64_t o_total_read = c->total_read, o_credit_msgs = c->credit_msgs;
-    const uint64_t o_rx_records = c->rx_records, o_rx_rounds = c->rx_rounds;
+    const uint64_t o_total_read = pre_total_read, o_credit_msgs = pre_credit_msgs;
+    const uint64_t o_rx_records = pre_rx_records, o_rx_rounds = pre_rx_rounds;
     const uint64_t o_slice_idx = op.append == 1 ? c->rx_slice_idx : 0;
+    const uint64_t te_f = __builtin_amdgcn_s_memtime() + ((o_total_read + o_rx_rounds) & 0);  // (counters loaded)
     c->head = head;
     c->moving_head = mh;
     c->remain = S.remain;
-    if (c->line != nullptr) {  // what HasMessage() on the host compares with the sender's arrival report
-      c->line->rx_head = head;
-      c->line->rx_remain = S.remain;
+    if (pre_line != nullptr) {  // what HasMessage() on the host compares with the sender's arrival report
+      pre_line->rx_head = head;
+      pre_line->rx_remain = S.remain;
     }
     c->internal_read_size = S.irs;
     c->leftover_cap = S.leftover;
@@ -1400,19 +1457,26 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
       // (relaxed stores: the single system-scope release on `seq` below publishes them;
       // every release is an L2 write-back, and this is the latency path)
       if (S.credit) {
-        grdma_status_report* ps = c->peer_status;
+        grdma_status_report* ps = pre_ps;
         if (ps != nullptr)
           __hip_atomic_store(&ps->remote_head, S.credit_head, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_SYSTEM);
-        if (c->peer_line != nullptr)
-          __hip_atomic_store(&c->peer_line->remote_head, S.credit_head, __ATOMIC_RELAXED,
+        if (pre_pl != nullptr)
+          __hip_atomic_store(&pre_pl->remote_head, S.credit_head, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_SYSTEM);
       }
       __hip_atomic_store(&res->commit_seq, op.seq_next ? op.seq_next : res->commit_seq + 1, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    const uint64_t te_g = __builtin_amdgcn_s_memtime();  // (commit stores issued)
     __hip_atomic_store(&res->seq, op.seq_next ? op.seq_next : res->seq + 1, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
+    if (express) {
+      const uint64_t te_h = __builtin_amdgcn_s_memtime();
+      g_rx_express_ticks[5] += te_f - s_dbg[15];
+      g_rx_express_ticks[6] += te_g - te_f;
+      g_rx_express_ticks[7] += te_h - te_g;
+    }
   }
 }
 
@@ -1714,6 +1778,44 @@ void k_rxplan_gather_job(const grdma_rx_op* rxops, const grdma_plan* const* gpla
   run_plan<256, true>(plan, wave, nwaves, lane);
 }
 
+// Will the express drain of `blk.rx` take exactly the records the small send of `blk.tx` is about to produce, all of
+// them whole?  (Every condition of tx_small_wave's pricing and of the express drain in rx_plan_body, evaluated on the
+// two connection blocks before either body runs; uniform over the workgroup.)
+__device__ __forceinline__ bool engine_cut_through_ok(const grdma_engine_cmd& blk) {
+  const grdma_tx_op& t = blk.tx;
+  const grdma_rx_op& r = blk.rx;
+  const grdma_conn* A = t.conn;
+  const grdma_conn* B = r.conn;
+  if (t.use_cursor != 0 || t.byte_idx != 0 || !t.inline_copy || !r.inline_apply || r.raw_cap != 0 || r.append != 0) return false;
+  const uint64_t nsl = t.nslices;
+  if (nsl < 1 || nsl > 8 || nsl > A->max_sge) return false;
+  if (A->status != GRDMA_PAIR_CONNECTED || B->status != GRDMA_PAIR_CONNECTED || A->peer_ring == nullptr || A->peer_ring != B->ring) return false;
+  const uint64_t cap = A->cap, mask = cap - 1;
+  if (cap != B->cap || cap > (1ull << 31)) return false;
+  const uint64_t tail0 = A->remote_tail, S = A->staging_cap;
+  const uint64_t rhead = __hip_atomic_load(&A->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const uint64_t free0 = cap - ((tail0 + cap - rhead) & mask);
+  // the send: every slice goes out whole (pay_i = len_i), at most 512 bytes in all
+  uint64_t st = 0, T = 0;
+  for (uint64_t i = 0; i < nsl; i++) {
+    const uint64_t len = blk.sges[i].len;
+    if (len == 0 || len > 256) return false;
+    if (writable_of(sat_sub(S, st)) < len || writable_of(sat_sub(free0, st)) < len) return false;
+    st += enc_size(len);
+    T += len;
+  }
+  if (T > 512) return false;
+  // the drain: nothing unread in front of these records, nothing half-read, the open (or a fresh) read takes them all
+  if (B->head != tail0 || B->moving_head != tail0 || B->remain != 0) return false;
+  uint64_t max_slices = GRDMA_MAX_SLICES;
+  if (r.max_reads < max_slices) max_slices = r.max_reads;
+  if (max_slices < 1) return false;
+  const uint64_t leftover0 = B->leftover_cap, n0 = blk.sges[0].len;
+  const uint64_t alloc = leftover0 ? leftover0 : (n0 > MINRD ? n0 : MINRD);
+  const uint64_t next_alloc = (alloc - (T <= alloc ? T : 0)) ? alloc - T : MINRD;
+  return T <= alloc && alloc <= r.arena_cap && ((T + 15) & ~15ull) + next_alloc <= r.arena_cap;
+}
+
 // ----------------------------------------------------------------------------
 // k_engine: persistent latency engine.  One workgroup stays resident and takes
 // Send / drain commands from a mailbox in pinned host memory, so a 64-byte RPC
@@ -1728,6 +1830,7 @@ void k_engine(grdma_engine_mbox* mb) {
   __shared__ uint64_t s_cmd[4];
   __shared__ uint64_t s_fast[GRDMA_FAST_WORDS];
   __shared__ __attribute__((aligned(16))) grdma_engine_cmd s_blk;
+  __shared__ grdma_ct_hint s_cth;
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // resume after the last command a previous incarnation completed
   uint64_t last = __hip_atomic_load(&mb->ack_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1830,17 +1933,45 @@ void k_engine(grdma_engine_mbox* mb) {
       }
       __syncthreads();
       te1 = __builtin_amdgcn_s_memtime();
+      bool chained = false;
       if (type != GRDMA_ENGINE_DRAIN_BLOCK) {
         if (threadIdx.x < GRDMA_CMD_MAX_SGES)
           s_blk.sges[threadIdx.x].ptr = s_blk.inline_data + (uint64_t)s_blk.sges[threadIdx.x].ptr;
         if (threadIdx.x == 0) s_blk.tx.slices = s_blk.sges;
         __syncthreads();
+        // A send with the armed drain behind it: the send wave leaves its record sizes in LDS for the drain (no probe
+        // of the ring), the two system-scope releases of the send wait for the drain's, and -- when both connections'
+        // state says the express drain will take exactly these records -- the records are CUT THROUGH: never written
+        // into staging or ring, never read back, never cleared (grdma_ct_hint, grdma_ops.h).  Decided here, by every
+        // thread alike, before the first store of the command.
+        if (type == GRDMA_ENGINE_SEND_INLINE_DRAIN && s_blk.tx.seq_next != 0 && s_blk.tx.nslices >= 1 && s_blk.tx.nslices <= 8 &&
+            s_blk.tx.sizes_out == nullptr && s_blk.rx.sizes_in == nullptr) {
+          chained = true;
+          const bool ct = engine_cut_through_ok(s_blk);
+          __syncthreads();
+          if (threadIdx.x == 0) {
+            s_cth.start_off = ~0ull;
+            s_cth.count = 0;
+            s_cth.cut_through = ct ? 1u : 0u;
+            s_cth.src = s_blk.sges[0].ptr;
+            s_blk.tx.inline_copy = 1u | (ct ? 2u : 0u) | 4u;
+            s_blk.tx.sizes_out = reinterpret_cast<grdma_size_hint*>(&s_cth);
+            s_blk.rx.sizes_in = reinterpret_cast<const grdma_size_hint*>(&s_cth);
+            s_blk.rx.inline_apply = 1u | 2u;
+          }
+          __syncthreads();
+        }
         tx_plan_call(&s_blk.tx);
         __syncthreads();
       }
       // (the armed drain of the local peer follows the send in the same command: what the host would
       // have asked for next, minus its doorbell round trip)
       if (type != GRDMA_ENGINE_SEND_INLINE) rx_plan_call(&s_blk.rx);
+      if (chained) {  // the send's sequence word, behind the drain's release (same thread): its result block is complete
+        __syncthreads();
+        if (threadIdx.x == 0)
+          __hip_atomic_store(&s_blk.tx.result->seq, s_blk.tx.seq_next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1872,6 +2003,17 @@ extern "C" int grdma_tx_small_ticks(uint64_t out[8]) {
   return 0;
 }
 
+extern "C" int grdma_rx_express_ticks(uint64_t out[9]) {
+  unsigned long long v[9];
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_rx_express_ticks), sizeof(v)) != hipSuccess) return -1;
+  for (int i = 0; i < 9; i++) out[i] = v[i];
+  return 0;
+}
+extern "C" uint64_t grdma_cut_through_drains(void) {
+  unsigned long long v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_cut_through_drains), sizeof(v)) != hipSuccess) return 0;
+  return (uint64_t)v;
+}
 extern "C" uint64_t grdma_express_drains(void) {
   unsigned long long v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_express_drains), sizeof(v)) != hipSuccess) return 0;

@@ -10,9 +10,14 @@ namespace {
 // The sender's side of grdma_wire_report / grdma_hostline: called by ONE thread once every byte of a Send
 // has landed in the peer ring (all waves of the caller have waited for their stores and met at a barrier,
 // or the wire kernel in front of k_tx_commit has completed).  tail = remote_tail_ after the Send.
-__device__ __forceinline__ void tx_publish(grdma_conn* c, uint64_t tail, uint64_t partial, uint64_t seq) {
+// (chained: the caller is the send of an engine command whose drain follows in the same workgroup and ends with a
+//  system-scope release by this very thread -- the arrival report needs none of its own)
+__device__ __forceinline__ void tx_publish(grdma_conn* c, uint64_t tail, uint64_t partial, uint64_t seq, bool chained = false) {
   uint64_t* pw = c->peer_wire;
-  if (pw != nullptr) __hip_atomic_store(pw, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (pw != nullptr) {
+    if (chained) __hip_atomic_store(pw, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(pw, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   grdma_hostline* pl = c->peer_line;
   if (pl != nullptr) __hip_atomic_store(&pl->wire_tail, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   grdma_hostline* ln = c->line;
@@ -46,6 +51,13 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
   const grdma_sge* sl = op.slices + start;
   const bool direct = c->wire_direct != 0;
   uint8_t* const dbase = direct ? c->peer_ring : c->staging;
+  // (what the commit below needs of the connection block, in the round trip of the loads above: behind the first
+  //  store to the block every load of it is a round trip of its own -- the arrival report's three pointers were)
+  uint64_t* const pre_pw = c->peer_wire;
+  grdma_hostline* const pre_pl = c->peer_line;
+  grdma_hostline* const pre_ln = c->line;
+  const uint64_t pre_written = c->total_written, pre_records = c->tx_records, pre_rounds = c->tx_rounds;
+  const uint64_t pre_partial = c->partial_write;
 
   uint64_t len = 0;
   const uint8_t* src = nullptr;
@@ -93,7 +105,19 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
   const uint64_t tk2 = __builtin_amdgcn_s_memtime() + (sent & 0);  // (after pricing)
   const uint64_t seg1 = staged < cap - tail0 ? staged : cap - tail0;
   uint8_t* const peer_ring = c->peer_ring;
-  if (nrec_total >= 1 && nrec_total <= 4 && __ballot(my_pay > 256) == 0 && peer_ring != nullptr) {
+  // (inline_copy bits of an engine command: 2 = cut-through, 4 = a drain follows in this command -- grdma_ct_hint)
+  const bool cut_through = (op.inline_copy & 2u) != 0, chained = (op.inline_copy & 4u) != 0;
+  if (chained && op.sizes_out != nullptr && nrec_total <= 8) {
+    grdma_ct_hint* h = reinterpret_cast<grdma_ct_hint*>(op.sizes_out);
+    if ((uint64_t)lane < nrec_total) h->n[lane] = (uint32_t)my_pay;
+    if (lane == 0) {
+      h->start_off = tail0;
+      h->count = (uint32_t)nrec_total;
+    }
+  }
+  if (cut_through) {
+    // the records are handed to the drain of this command in registers' reach: nothing is stored into staging or ring
+  } else if (nrec_total >= 1 && nrec_total <= 4 && __ballot(my_pay > 256) == 0 && peer_ring != nullptr) {
     // ---- unary-sized Sends: at most four records of at most 256 bytes ------------------------
     // Every payload byte is loaded BEFORE the first store (a load that is waited for behind a
     // store waits for the store: the memory counter is in order), from clamped addresses (no load
@@ -220,7 +244,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     if (short_pay > 0) bidx = (nrec == 0 ? byte_idx : 0) + short_pay;
     else if (nrec == 0) bidx = byte_idx;
     // (counters: loads before the first store to the connection, one round trip)
-    const uint64_t o_written = c->total_written, o_records = c->tx_records, o_rounds = c->tx_rounds;
+    const uint64_t o_written = pre_written, o_records = pre_records, o_rounds = pre_rounds;
     c->remote_tail = new_tail;
     if (connected) c->partial_write = sent < offered ? 1 : 0;  // pair.cc:709 (Send returns at :652-655 when not connected)
     c->total_written = o_written + sent;
@@ -235,7 +259,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     r->sent = sent;
     r->records = nrec_total;
     r->staged = staged;
-    r->partial = connected ? (sent < offered ? 1 : 0) : c->partial_write;
+    r->partial = connected ? (sent < offered ? 1 : 0) : pre_partial;
     r->new_remote_tail = new_tail;
     if (op.tail_out != nullptr) *op.tail_out = new_tail;
     r->slice_idx = idx;
@@ -243,11 +267,23 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     r->done = (idx >= op.nslices) ? 1 : 0;
     const uint64_t tk5 = __builtin_amdgcn_s_memtime();  // (bookkeeping stores issued)
     // (the wave has waited for every copy above: the arrival report may go out)
-    tx_publish(c, new_tail, connected ? (sent < offered ? 1 : 0) : c->partial_write, 0);
+    {  // tx_publish with the pointers loaded above
+      const uint64_t partial = connected ? (sent < offered ? 1 : 0) : pre_partial;
+      if (pre_pw != nullptr) {
+        if (chained) __hip_atomic_store(pre_pw, new_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else __hip_atomic_store(pre_pw, new_tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (pre_pl != nullptr) __hip_atomic_store(&pre_pl->wire_tail, new_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (pre_ln != nullptr) {
+        __hip_atomic_store(&pre_ln->remote_tail, new_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&pre_ln->partial_write, partial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     // the peer reads the ring in a later command / kernel; the host needs the result
     // block (pinned memory): a system-scope release on the sequence word covers it
-    __hip_atomic_store(&r->seq, op.seq_next ? op.seq_next : r->seq + 1, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
+    // (chained: the engine publishes the sequence word behind the drain of the same command -- k_engine)
+    if (!chained) __hip_atomic_store(&r->seq, op.seq_next ? op.seq_next : r->seq + 1, __ATOMIC_RELEASE,
+                                     __HIP_MEMORY_SCOPE_SYSTEM);
     const uint64_t tk6 = __builtin_amdgcn_s_memtime();
     g_tx_small_ticks[0] += tk1 - tk0;
     g_tx_small_ticks[1] += tk2 - tk1;

@@ -465,6 +465,8 @@ int grdma_pair_debug_hist(grdma_pair* p, uint32_t* hist_out /* 1024 entries */, 
                           uint32_t* period);
 int grdma_engine_debug(uint64_t out[5]);
 uint64_t grdma_express_drains(void);  /* drains served by the single-wave express path so far */
+int grdma_rx_express_ticks(uint64_t out[9]);  /* profiling aid: phase ticks of the express drain (latency engine) */
+uint64_t grdma_cut_through_drains(void);  /* ... of which the records of an armed send + drain command never touched the ring */
 int grdma_tx_fast_sends(uint64_t out[2]);  /* Sends of streaming jobs planned by k_tx_fast [0], left to the general planner [1] (csrc/grdma_tx_fast.h) */
 int grdma_rx_fast_drains(uint64_t out[6]);  /* drains of streaming jobs taken by k_rx_fast [0], declined by reason [1..5] (csrc/grdma_rx_fast.h) */
 int grdma_tx_promise_counts(uint64_t out[4]);  /* promised-credit Sends: priced with it [0], none in the drain [1], an older block [2]; waits that ran out [3] */

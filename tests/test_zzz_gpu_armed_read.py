@@ -24,10 +24,19 @@ def test_armed_reads_ride_in_the_send_command(gpu, sizes):
     a.arm_read(64)
     b.arm_read(64)
     g._lib.check(lib.grdma_engine_start())
+    import ctypes as C
+    lib.grdma_cut_through_drains.restype = C.c_uint64
+    ct0 = int(lib.grdma_cut_through_drains())
     try:
         g.pingpong(a, b, slices, slices, iters=20, warmup=5)
         inline = total <= 1024
         assert a.armed_hits() == (25 if inline else 0) and b.armed_hits() == (25 if inline else 0)
+        # (unary-sized commands are cut through: the records of an armed send + drain never touch the ring -- three
+        #  commands in four here: the read a drain leaves open takes 80 bytes three times, then 16 bytes are left of its
+        #  256 and the general tiers split the next message; a record of 600 bytes takes the ring, its sizes still
+        #  reach the drain through LDS)
+        ct = int(lib.grdma_cut_through_drains()) - ct0
+        assert (ct >= 30) if sizes == [14, 66] else (ct == 0), ct
         # an armed completion is handed out once, in order, with its bytes
         msg = [b"hello, ", b"armed read"]
         a.endpoint_write(msg)

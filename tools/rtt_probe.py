@@ -34,7 +34,11 @@ def main():
     t0 = (C.c_uint64 * 8)()
     lib.grdma_engine_debug(e0)
     lib.grdma_tx_small_ticks(t0)
+    x0 = (C.c_uint64 * 9)()
+    lib.grdma_rx_express_ticks(x0)
     rtt, ph = g.pingpong(a, b, slices, slices, iters=iters, warmup=0)
+    x1 = (C.c_uint64 * 9)()
+    lib.grdma_rx_express_ticks(x1)
     e1 = (C.c_uint64 * 5)()
     t1 = (C.c_uint64 * 8)()
     lib.grdma_engine_debug(e1)
@@ -48,6 +52,11 @@ def main():
     if n:
         names = ["slice loads", "pricing", "copies issued", "copies acked", "bookkeeping", "release"]
         print("small send wave, ticks per send (%d sends): " % n + ", ".join("%s %d" % (names[i], (int(t1[i]) - int(t0[i])) // n) for i in range(6)))
+    nx = int(x1[8]) - int(x0[8])
+    if nx:
+        names = ["state loaded", "records known", "payload loaded", "stores issued", "stores acknowledged", "commit: counters loaded",
+                 "commit: stores issued", "released"]
+        print("express drain, ticks per drain (%d drains): " % nx + ", ".join("%s %d" % (names[i], (int(x1[i]) - int(x0[i])) // nx) for i in range(8)))
 
 
 if __name__ == "__main__":
