@@ -526,6 +526,15 @@ int engine_wait_locked(uint64_t seq) {
   }
 }
 
+// GRDMA_ENGINE_CUT_THROUGH=0 (tests: the A/B of tests/test_zzz_gpu_armed_read.py): an armed send + drain command runs its
+// two bodies the way separate commands do -- records through the ring, a probe, three releases -- instead of handing
+// the sizes over in LDS and cutting unary-sized records through (k_engine).  The switch travels in the command: a
+// sizes_out of 1 is "do not chain" (the engine clears it).  Read per command: a test flips it inside one process.
+inline grdma_size_hint* engine_chain_marker() {
+  const char* e = getenv("GRDMA_ENGINE_CUT_THROUGH");
+  return (e && atoi(e) == 0) ? reinterpret_cast<grdma_size_hint*>(1) : nullptr;
+}
+
 // Hand one command to the resident engine WITHOUT waiting for it (the mailbox holds one command: the one posted
 // before must have been acknowledged, which this waits for).  The caller finds the completion in its result block.
 int engine_post(uint64_t type, const void* op) {
@@ -620,6 +629,7 @@ int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_curs
         // the send, in the same workgroup), and its completion waits in the peer's result block
         fill_rxop(q, q->h_arena, q->h_arena_cap, q->armed_reads, 0);
         p->h_cmd->rx = q->h->rxop;
+        p->h_cmd->tx.sizes_out = engine_chain_marker();
         if (int rc = engine_submit(GRDMA_ENGINE_SEND_INLINE_DRAIN, p->h_cmd)) return rc;
         q->armed_done = true;
         q->armed_hits++;
@@ -1998,6 +2008,7 @@ int submit_send(grdma_pair* p, uint64_t count, uint64_t byte_idx) {
           q->rx_expect.store(q->h->rxop.seq_next, std::memory_order_relaxed);
           q->rx_by_engine.store(1, std::memory_order_relaxed);
           q->rx_inflight.store(w, std::memory_order_release);
+          p->h_cmd->tx.sizes_out = engine_chain_marker();
           if (int rc = engine_post(GRDMA_ENGINE_SEND_INLINE_DRAIN, p->h_cmd)) {
             q->rx_inflight.store(-1);
             return rc;

@@ -1944,7 +1944,11 @@ void k_engine(grdma_engine_mbox* mb) {
         // state says the express drain will take exactly these records -- the records are CUT THROUGH: never written
         // into staging or ring, never read back, never cleared (grdma_ct_hint, grdma_ops.h).  Decided here, by every
         // thread alike, before the first store of the command.
-        if (type == GRDMA_ENGINE_SEND_INLINE_DRAIN && s_blk.tx.seq_next != 0 && s_blk.tx.nslices >= 1 && s_blk.tx.nslices <= 8 &&
+        if (s_blk.tx.sizes_out == reinterpret_cast<grdma_size_hint*>(1)) {  // (the host's "do not chain": GRDMA_ENGINE_CUT_THROUGH=0)
+          __syncthreads();
+          if (threadIdx.x == 0) s_blk.tx.sizes_out = nullptr;
+          __syncthreads();
+        } else if (type == GRDMA_ENGINE_SEND_INLINE_DRAIN && s_blk.tx.seq_next != 0 && s_blk.tx.nslices >= 1 && s_blk.tx.nslices <= 8 &&
             s_blk.tx.sizes_out == nullptr && s_blk.rx.sizes_in == nullptr) {
           chained = true;
           const bool ct = engine_cut_through_ok(s_blk);

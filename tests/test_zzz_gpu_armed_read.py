@@ -64,3 +64,65 @@ def test_armed_reads_ride_in_the_send_command(gpu, sizes):
         assert sa[k] == o.state(0)[k] and sb[k] == o.state(1)[k], k
     assert a.ring_mem() == o.ring_mem(0) and b.ring_mem() == o.ring_mem(1)
     a.close(); b.close(); o.close()
+
+
+def test_cut_through_commands_leave_the_state_the_two_bodies_leave(gpu, monkeypatch):
+    """The armed send + drain command with its round-4 hand-over (sizes through LDS, unary-sized records cut through, one
+    release) against the same command running its two bodies the way separate commands do (GRDMA_ENGINE_CUT_THROUGH=0):
+    after the same sequence of ping-pongs -- one to four slices of 1 .. 256 bytes, now and then a record that does not
+    fit the open read, one beyond 256 bytes -- every field of both connections' state, both record-size histories and
+    both rings are equal, and equal to the oracle's."""
+    import ctypes as C
+    import random
+    g = gpu
+    lib = g.load()
+    lib.grdma_cut_through_drains.restype = C.c_uint64
+    rng = random.Random(20260922)
+    rounds = []
+    for _ in range(14):
+        mk = lambda: [bytes(rng.getrandbits(8) for _ in range(rng.choice([1, 5, 9, 14, 66, 100, 200, 256])))
+                      for _ in range(rng.randint(1, 4))]
+        rounds.append((mk(), mk(), rng.randint(1, 6)))
+    rounds.insert(5, ([b"x" * 14, b"y" * 300], [b"z" * 9], 2))      # a record the unary branch does not take
+    outcomes = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GRDMA_ENGINE_CUT_THROUGH", mode)
+        a, b = mk_link(g, 1 << 20, 30)
+        a.set_latency_mode(True)
+        b.set_latency_mode(True)
+        a.arm_read(64)
+        b.arm_read(64)
+        g._lib.check(lib.grdma_engine_start())
+        ct0 = int(lib.grdma_cut_through_drains())
+        try:
+            for sa, sb, iters in rounds:
+                g.pingpong(a, b, sa, sb, iters=iters, warmup=0)
+        finally:
+            lib.grdma_engine_stop()
+        ct = int(lib.grdma_cut_through_drains()) - ct0
+        hist = []
+        for p in (a, b):
+            h = (C.c_uint32 * 4096)()
+            cnt, per = C.c_uint64(), C.c_uint32()
+            lib.grdma_pair_debug_hist.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+            assert lib.grdma_pair_debug_hist(p.h, h, C.byref(cnt), C.byref(per)) == 0
+            n = min(int(cnt.value), 64)
+            hist.append((int(cnt.value), int(per.value), [int(h[(int(cnt.value) - n + i) % 1024]) for i in range(n)]))
+        outcomes.append((ct, a.state(), b.state(), hist, a.ring_mem() == bytes(1 << 20), b.ring_mem() == bytes(1 << 20),
+                         a.armed_hits(), b.armed_hits()))
+        a.close(); b.close()
+    on, off = outcomes
+    assert on[0] > 0 and off[0] == 0, (on[0], off[0])
+    assert on[1] == off[1] and on[2] == off[2], "connection state differs between the two ways of running the command"
+    assert on[3] == off[3], "record-size history differs"
+    assert on[4:] == off[4:] and on[4] and on[5]
+    o = pyorc.OracleLink(1 << 20, 30)
+    for sa, sb, iters in rounds:
+        for _ in range(iters):
+            for src, dst, sl in ((0, 1, sa), (1, 0, sb)):
+                assert o.send(src, sl) == sum(len(x) for x in sl)
+                while o.endpoint_read(dst)[0]:
+                    pass
+    for k in STATE_KEYS:
+        assert on[1][k] == o.state(0)[k] and on[2][k] == o.state(1)[k], k
+    o.close()
