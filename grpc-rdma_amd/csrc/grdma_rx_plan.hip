@@ -59,6 +59,32 @@ __device__ unsigned long long g_cut_through_drains = 0;
 // payload loaded, stores issued, stores acknowledged, commit: counters loaded, commit: stores issued, released, count}
 __device__ unsigned long long g_rx_express_ticks[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... of which the records never touched the ring (grdma_ct_hint)
 
+// Does the express drain take a message of T payload bytes (first record n0) when the connection's open read has
+// leftover0 bytes of room (0 = none open)?  1: one read takes it all (the open read, or a fresh one of max(256, n0));
+// 2: the open read is smaller than the message -- it completes with leftover0 bytes, rdma_continue_read allocates
+// max(256, readable) -- readable = what is left of the record the first read stopped in (GetReadableSize is the length of
+// the message at the head, ring_buffer.cc; `rem1`, the caller's) -- and that read takes the rest (rdma_bp_posix.cc:306-326;
+// two slices; a rest beyond it would need a third read: not this path's case); 0: not the express path's case.
+// The arena must hold every read, the one that then finds nothing included.  Shared by the express drain and by the
+// latency engine's cut-through decision (engine_cut_through_ok), which must agree.
+__device__ __forceinline__ int express_fits(uint64_t leftover0, uint64_t n0, uint64_t T, uint64_t max_slices, uint64_t a_off0,
+                                            uint64_t arena_cap, uint64_t rem1, bool credit_due) {
+  if (T > 512 || max_slices < 1) return 0;
+  const uint64_t alloc = leftover0 ? leftover0 : (n0 > MINRD ? n0 : MINRD);
+  if (T <= alloc) {
+    const uint64_t next_alloc = (alloc - T) ? alloc - T : MINRD;
+    return (a_off0 + alloc <= arena_cap && ((a_off0 + T + 15) & ~15ull) + next_alloc <= arena_cap) ? 1 : 0;
+  }
+  // (credit_due: a status report falls into this drain -- Recv posts it read by read (pair.cc:276-284), and the first
+  //  read ends inside a record: left to the general tiers)
+  if (leftover0 == 0 || max_slices < 2 || credit_due) return 0;
+  const uint64_t L = leftover0, rest = T - L, alloc2 = rem1 > MINRD ? rem1 : MINRD;
+  if (rest > alloc2) return 0;
+  const uint64_t off1 = (a_off0 + L + 15) & ~15ull, off2 = (off1 + rest + 15) & ~15ull;
+  const uint64_t alloc3 = (alloc2 - rest) ? alloc2 - rest : MINRD;
+  return (off1 + alloc2 <= arena_cap && off2 + alloc3 <= arena_cap) ? 2 : 0;
+}
+
 struct chain_walker {
   const uint8_t* ring;
   uint64_t cap;
@@ -366,10 +392,21 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
     const uint32_t n0 = __shfl(n, 0, 64);
     // rdma_continue_read, rdma_bp_posix.cc:306-317: the open read, or a new one of max(256, readable)
     const uint64_t alloc = leftover0 ? leftover0 : (n0 > MINRD ? n0 : MINRD);
-    // (the arena must also hold the read that follows and finds nothing, like the loop below checks)
-    const uint64_t next_alloc = (alloc - (T <= alloc ? T : 0)) ? alloc - T : MINRD;
-    if (all_seen && T <= alloc && T <= EXPRESS_BYTES && a_off0 + alloc <= op.arena_cap &&
-        ((a_off0 + T + 15) & ~15ull) + next_alloc <= op.arena_cap) {
+    // (1: one read takes the message; 2: the open read completes and a fresh one takes the rest -- two slices)
+    // (rem1: what is left of the record in which the open read's last byte falls -- the next read is sized by it)
+    uint32_t rem1 = 0;
+    {
+      const uint32_t xn = i_n - n;
+      const bool mine = n != 0 && leftover0 >= xn && leftover0 < (uint64_t)xn + n;
+      const uint64_t who = __ballot(mine);
+      if (who) rem1 = __shfl(xn + n - (uint32_t)leftover0, __builtin_ctzll(who), 64);
+    }
+    const int fits = all_seen ? express_fits(leftover0, n0, T, max_slices, a_off0, op.arena_cap, rem1, irs0 + E >= cap / 2) : 0;
+    const bool split = fits == 2;
+    const uint32_t L0 = split ? (uint32_t)leftover0 : T;                                   // bytes of the first slice
+    const uint32_t off1 = split ? (uint32_t)(((a_off0 + L0 + 15) & ~15ull) - a_off0) : 0;  // the second slice, from dst
+    static_assert(EXPRESS_BYTES == 512, "express_fits knows the limit");
+    if (fits != 0) {
       // payload: output byte b of the slice lives in record r(b) at offset b - x_n(r)
       const uint32_t x_n = i_n - n, x_enc = i_enc - enc;
       uint8_t* dst = op.arena + a_off0;
@@ -405,7 +442,13 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
       const uint64_t te_c = __builtin_amdgcn_s_memtime() + (bytes[0] & 0);  // (payload loaded)
       // one 8-byte store per lane (the slice buffer is 16-byte aligned and `alloc` bytes long;
       // the bytes behind the slice end inside the last word are written as zero)
-      if ((uint32_t)lane * 8 < T) {
+      if (split) {  // (byte stores: the second slice starts at a 16-byte boundary of its own)
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t b = (uint32_t)lane * 8 + q;
+          if (b < T) dst[b < L0 ? b : off1 + (b - L0)] = bytes[q];
+        }
+      } else if ((uint32_t)lane * 8 < T) {
         uint64_t word = 0;
 #pragma unroll
         for (int q = 0; q < 8; q++) word |= (uint64_t)bytes[q] << (8 * q);
@@ -435,7 +478,18 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
         S.consumed_total = E; S.records = v; S.bytes = T;
         S.credit = credit; S.credit_head = credit_head;
         S.hist_count = hist_count0 + v;
-        if (v) {
+        if (v && split) {
+          // the open read completes with L0 bytes; a fresh read of max(256, readable) takes the rest; a third finds nothing
+          const uint64_t rest = T - L0, alloc2 = rem1 > MINRD ? rem1 : MINRD, rest2 = alloc2 - rest;
+          out_slices[0].off = a_off0;
+          out_slices[0].len = L0;
+          out_slices[1].off = a_off0 + off1;
+          out_slices[1].len = rest;
+          S.nslices = 2;
+          S.a_off = (a_off0 + off1 + rest + 15) & ~15ull;
+          S.would_block = max_slices >= 3 ? 1 : 0;
+          S.leftover = max_slices >= 3 ? (rest2 ? rest2 : MINRD) : rest2;
+        } else if (v) {
           // one completed read of T bytes; a second read finds nothing and keeps its buffer
           out_slices[0].off = a_off0;
           out_slices[0].len = T;
@@ -1810,10 +1864,13 @@ __device__ __forceinline__ bool engine_cut_through_ok(const grdma_engine_cmd& bl
   uint64_t max_slices = GRDMA_MAX_SLICES;
   if (r.max_reads < max_slices) max_slices = r.max_reads;
   if (max_slices < 1) return false;
-  const uint64_t leftover0 = B->leftover_cap, n0 = blk.sges[0].len;
-  const uint64_t alloc = leftover0 ? leftover0 : (n0 > MINRD ? n0 : MINRD);
-  const uint64_t next_alloc = (alloc - (T <= alloc ? T : 0)) ? alloc - T : MINRD;
-  return T <= alloc && alloc <= r.arena_cap && ((T + 15) & ~15ull) + next_alloc <= r.arena_cap;
+  uint64_t rem1 = 0, x = 0;  // what is left of the record in which the open read's last byte falls
+  for (uint64_t i = 0; i < nsl; i++) {
+    const uint64_t len = blk.sges[i].len;
+    if (B->leftover_cap >= x && B->leftover_cap < x + len) rem1 = x + len - B->leftover_cap;
+    x += len;
+  }
+  return express_fits(B->leftover_cap, blk.sges[0].len, T, max_slices, 0, r.arena_cap, rem1, B->internal_read_size + st >= cap / 2) != 0;
 }
 
 // ----------------------------------------------------------------------------

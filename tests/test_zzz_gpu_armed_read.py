@@ -117,12 +117,17 @@ def test_cut_through_commands_leave_the_state_the_two_bodies_leave(gpu, monkeypa
     assert on[3] == off[3], "record-size history differs"
     assert on[4:] == off[4:] and on[4] and on[5]
     o = pyorc.OracleLink(1 << 20, 30)
+    open_read = {0: None, 1: None}   # the read the endpoint keeps open behind a would-block: its size (leftover_cap)
     for sa, sb, iters in rounds:
         for _ in range(iters):
             for src, dst, sl in ((0, 1, sa), (1, 0, sb)):
                 assert o.send(src, sl) == sum(len(x) for x in sl)
-                while o.endpoint_read(dst)[0]:
-                    pass
+                while True:
+                    got, alloc = o.endpoint_read(dst)
+                    if not got:
+                        open_read[dst] = alloc
+                        break
     for k in STATE_KEYS:
         assert on[1][k] == o.state(0)[k] and on[2][k] == o.state(1)[k], k
+    assert on[1]["leftover_cap"] == open_read[0] and on[2]["leftover_cap"] == open_read[1]
     o.close()
