@@ -111,7 +111,11 @@ struct grdma_rx_op {
 enum { GRDMA_ENGINE_SEND = 1, GRDMA_ENGINE_DRAIN = 2, GRDMA_ENGINE_SEND_INLINE = 3, GRDMA_ENGINE_DRAIN_BLOCK = 4,
        // a small send followed, without a host hop, by the drain the LOCAL peer has armed (grdma_pair_arm_read):
        // the block carries both ops
-       GRDMA_ENGINE_SEND_INLINE_DRAIN = 5 };
+       GRDMA_ENGINE_SEND_INLINE_DRAIN = 5,
+       // arm / let go of a watch slot (grdma_watch_cmd): the standing read order of a connection, carried out by a
+       // resident watcher workgroup (k_watch) the moment the sender's arrival report -- or, on an ordered wire, a
+       // complete record -- shows up in the connection's own ring
+       GRDMA_ENGINE_WATCH = 6 };
 
 // Self-contained command block for small messages: the op, its slice table and the
 // payload bytes travel in ONE contiguous pinned block that the engine pulls into LDS
@@ -135,6 +139,38 @@ struct grdma_engine_cmd {
 // [the armed peer's grdma_rx_op, GRDMA_ENGINE_SEND_INLINE_DRAIN only].
 #define GRDMA_FAST_LINES 8
 #define GRDMA_FAST_WORDS (GRDMA_FAST_LINES * 7)  // payload words
+// ---- arrival-triggered reads (k_watch) -------------------------------------------------------------------------
+// What the reference's busy-polling thread is to an outstanding grpc_endpoint_read (HasMessage() on the connection's
+// OWN ring, ring_buffer.cc:56-65; ev_epollex_rdma_bpev_linux.cc:1105-1149, poller.cc:84), a resident watcher
+// workgroup is here: it polls the arrival report of every connection it has been handed (one load per connection
+// and pass, 64 connections per wave) and, when bytes have landed, runs the standing order -- one drain of up to
+// max_reads endpoint reads into the pinned arena -- and bumps the result block's sequence word in pinned host
+// memory.  grdma_endpoint_read is then a load from host memory.  It does not matter who wrote the ring: the
+// command workgroup of this engine, another process through an IPC mapping, a NIC.
+// One completion is outstanding per connection: the next drain waits until the host has taken the last one
+// (grdma_engine_mbox::consumed, mirrored into the slot by the command workgroup's doorbell poll).
+#define GRDMA_WATCH_SLOTS 64
+#define GRDMA_WATCH_MAX_GROUPS 8
+struct grdma_watch_slot {         // device memory; one writer per word
+  uint64_t gen;                   // command workgroup: != 0 armed (a fresh value per arming), 0 = let go
+  uint64_t ack_gen;               // watcher: the generation it has taken over (0: it has let go, nothing in flight)
+  uint64_t consumed;              // command workgroup: completions the host has taken since the arming
+  uint64_t done;                  // watcher: completions produced since the arming
+  struct grdma_rx_op op;          // the standing order; op.seq_next = sequence word of the first completion
+  uint64_t drains_dbg;            // watcher: drains run for this slot (all armings)
+  uint64_t pad[32 - 5 - sizeof(struct grdma_rx_op) / 8];
+};
+struct grdma_watch_ctl {          // device memory
+  uint64_t quit;                  // command workgroup: the engine incarnation that has been told to leave
+  uint64_t pad[31];
+  struct grdma_watch_slot slot[GRDMA_WATCH_SLOTS];
+};
+struct grdma_watch_cmd {          // pinned host memory: GRDMA_ENGINE_WATCH
+  uint64_t slot;
+  uint64_t gen;                   // 0 = let go
+  struct grdma_rx_op op;
+};
+
 struct grdma_engine_mbox {
   uint64_t cmd_seq;    // host: bumped last, after cmd_type/op are written
   uint64_t cmd_type;
@@ -145,6 +181,8 @@ struct grdma_engine_mbox {
   uint64_t exit_flag;  // host: ask the engine to leave
   uint64_t pad1[5];
   uint64_t fast[GRDMA_FAST_LINES * 8];
+  uint64_t consumed[GRDMA_WATCH_SLOTS];  // host: completions taken per watch slot (read by the doorbell poll, lane = slot)
+  uint64_t watch_alive[GRDMA_WATCH_MAX_GROUPS];  // watcher workgroup w: the engine incarnation it belongs to
 };
 
 #endif  // GRDMA_OPS_H

@@ -56,7 +56,8 @@ hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_apply(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*, uint64_t*, uint64_t*,
                              hipStream_t);
-hipError_t grdma_launch_engine(grdma_engine_mbox*, hipStream_t);
+hipError_t grdma_launch_engine(grdma_engine_mbox*, grdma_watch_ctl*, uint64_t epoch, hipStream_t);
+hipError_t grdma_launch_watch(grdma_engine_mbox*, grdma_watch_ctl*, uint64_t epoch, uint32_t groups, uint32_t flags, hipStream_t);
 const void* grdma_kernel_fn(int which);          // 0 tx_plan, 1 copy, 3 rx_apply, 4 tx_plan_seq
 const void* grdma_kernel_fn_rx_plan(void);
 const void* grdma_kernel_fn_rx_plan_job(void);
@@ -108,6 +109,16 @@ struct grdma_engine {
   bool wanted = false;   // grdma_engine_start() was called
   uint64_t seq = 0;
   uint64_t posted = 0;   // last command written into the mailbox (== seq while one may still be running)
+  // the read side (k_watch): watcher workgroups resident beside the command workgroup, and the slots they serve
+  hipStream_t wstream = nullptr;
+  grdma_watch_ctl* d_watch = nullptr;   // device memory
+  grdma_watch_cmd* h_wcmd = nullptr;    // pinned: the GRDMA_ENGINE_WATCH command in flight
+  uint32_t groups = 0;                  // watcher workgroups per incarnation
+  uint64_t epoch = 0;                   // engine incarnations launched
+  uint64_t gen = 0;                     // armings handed out
+  grdma_pair* slot_owner[GRDMA_WATCH_SLOTS] = {};
+  bool slot_posted[GRDMA_WATCH_SLOTS] = {};   // the device slot holds the owner's standing order
+  bool watch_dirty = false;             // some owner's order has yet to be posted
 };
 grdma_engine g_engine;
 
@@ -261,6 +272,14 @@ struct grdma_pair {
   std::atomic<bool> armed_done{false};  // a chained drain has completed and nobody has consumed it yet (set by the
                                      // sender's thread, consumed by the receiver's)
   uint64_t armed_hits = 0;
+  // ... or, by default, a watcher workgroup of the engine carries the standing order out when bytes land in this
+  // pair's ring, whoever wrote them (k_watch): the slot it was handed, the sequence word of the next completion,
+  // completions taken since the arming (what grdma_engine_mbox::consumed tells the device), completions taken in all
+  int watch_slot = -1;
+  uint64_t watch_expect = 0, watch_taken = 0, watch_hits = 0;
+  uint64_t armed_half = 0;           // which half of the arena the completion `armed_done` stands for lies in (a
+                                     // watcher's completion that was left behind when its order was taken back)
+  int watch_window = -1;             // asynchronous endpoint: the receive window the standing order writes into
   // asynchronous endpoint operations (grdma_endpoint_set_async): the send and the receive direction on streams of
   // their own, one Send and one drain in flight at most, completions in pinned host memory
   bool async = false;
@@ -439,20 +458,55 @@ int stage_slices(grdma_pair* p, const grdma_slice* slices, uint64_t count, uint6
   return 0;
 }
 
+// Watcher workgroups per engine incarnation (GRDMA_ENGINE_WATCHERS, 1 .. 8; slot s is served by workgroup s % n).
+uint32_t engine_watch_groups() {
+#ifdef GRDMA_WAVE_EMU
+  return 1;  // (the emulator runs the workgroups of a launch one after the other: a resident one never ends)
+#else
+  static const uint32_t n = [] {
+    const char* e = getenv("GRDMA_ENGINE_WATCHERS");
+    long v = e ? atol(e) : 4;
+    if (v < 1) v = 1;
+    if (v > GRDMA_WATCH_MAX_GROUPS) v = GRDMA_WATCH_MAX_GROUPS;
+    return (uint32_t)v;
+  }();
+  return n;
+#endif
+}
+
 int engine_launch() {
   grdma_engine& e = g_engine;
   if (!e.mb) {
     HIP_TRY(hipHostMalloc((void**)&e.mb, sizeof(grdma_engine_mbox), hipHostMallocCoherent | hipHostMallocMapped));
     memset(e.mb, 0, sizeof(*e.mb));
+    HIP_TRY(hipHostMalloc((void**)&e.h_wcmd, sizeof(grdma_watch_cmd), hipHostMallocCoherent | hipHostMallocMapped));
     HIP_TRY(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e.wstream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&e.d_watch, sizeof(grdma_watch_ctl)));
+    HIP_TRY(hipMemsetAsync(e.d_watch, 0, sizeof(grdma_watch_ctl), e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    e.groups = engine_watch_groups();
   }
   volatile uint64_t* alive = &e.mb->alive;
   if (*alive) return 0;
+  // the incarnation before has left (or is leaving: its watchers follow the command workgroup out)
+  HIP_TRY(hipStreamSynchronize(e.stream));
+  HIP_TRY(hipStreamSynchronize(e.wstream));
   e.mb->exit_flag = 0;
+  const uint64_t epoch = ++e.epoch;
   std::atomic_thread_fence(std::memory_order_seq_cst);
-  HIP_TRY(grdma_launch_engine(e.mb, e.stream));
+  HIP_TRY(grdma_launch_engine(e.mb, e.d_watch, epoch, e.stream));
+  // (GRDMA_WATCH_FAST=0: every drain of a watcher through the plan body -- the A/B of tests/test_zzz_gpu_watch_read.py)
+  const char* wf = getenv("GRDMA_WATCH_FAST");
+  HIP_TRY(grdma_launch_watch(e.mb, e.d_watch, epoch, e.groups, (wf && atoi(wf) == 0) ? 0u : 1u, e.wstream));
   const auto t0 = std::chrono::steady_clock::now();
-  while (!*alive) {
+  auto up = [&] {
+    if (!*alive) return false;
+    for (uint32_t w = 0; w < e.groups; w++)
+      if (*(volatile uint64_t*)&e.mb->watch_alive[w] != epoch) return false;
+    return true;
+  };
+  while (!up()) {
     if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5))
       return fail(GRDMA_ERR_HIP, "latency engine did not come up");
   }
@@ -535,12 +589,58 @@ inline grdma_size_hint* engine_chain_marker() {
   return (e && atoi(e) == 0) ? reinterpret_cast<grdma_size_hint*>(1) : nullptr;
 }
 
+// GRDMA_ENGINE_CHAIN=1 (the A/B of tests/test_zzz_gpu_armed_read.py): an armed read is carried by the in-process
+// peer's send command (GRDMA_ENGINE_SEND_INLINE_DRAIN, round 4) instead of by a watcher workgroup.  Read per call.
+inline bool engine_chain_mode() {
+  const char* e = getenv("GRDMA_ENGINE_CHAIN");
+  return e && atoi(e) != 0;
+}
+
+int engine_post_locked(uint64_t type, const void* op);
+void fill_rxop(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_reads, uint64_t raw_cap);
+
+// The standing order of `p` as its watcher runs it: grdma_endpoint_read(max_reads) into the pinned arena, the sequence
+// word continuing where the pair's result block stands.  engine.mu held; nothing of this pair's drains is in flight.
+void watch_fill_cmd(grdma_pair* p, uint32_t sidx, grdma_watch_cmd* cmd) {
+  fill_rxop(p, p->h_arena, p->h_arena_cap, p->armed_reads, 0);
+  cmd->slot = sidx;
+  cmd->gen = ++g_engine.gen;
+  cmd->op = p->h->rxop;
+  cmd->op.inline_apply = 1u | 8u;  // (8: a watcher's drain -- rx_plan_body reads the ring past the caches)
+  p->watch_expect = cmd->op.seq_next;
+  p->watch_taken = 0;
+  *(volatile uint64_t*)&g_engine.mb->consumed[sidx] = 0;
+}
+
+// Standing orders that have not reached their device slot yet (armed before the engine was started, or cleared
+// by grdma_engine_stop): one GRDMA_ENGINE_WATCH command each.  engine.mu held, engine resident.
+int watch_flush_locked() {
+  grdma_engine& e = g_engine;
+  if (!e.watch_dirty) return 0;
+  e.watch_dirty = false;
+  for (uint32_t sidx = 0; sidx < GRDMA_WATCH_SLOTS; sidx++) {
+    grdma_pair* p = e.slot_owner[sidx];
+    if (!p || e.slot_posted[sidx]) continue;
+    watch_fill_cmd(p, sidx, e.h_wcmd);
+    if (int rc = engine_post_locked(GRDMA_ENGINE_WATCH, e.h_wcmd)) return rc;
+    if (int rc = engine_wait_locked(e.posted)) return rc;
+    e.slot_posted[sidx] = true;
+  }
+  return 0;
+}
+
 // Hand one command to the resident engine WITHOUT waiting for it (the mailbox holds one command: the one posted
 // before must have been acknowledged, which this waits for).  The caller finds the completion in its result block.
 int engine_post(uint64_t type, const void* op) {
   grdma_engine& e = g_engine;
   std::lock_guard<std::mutex> lk(e.mu);
   if (int rc = engine_launch()) return rc;
+  if (int rc = watch_flush_locked()) return rc;
+  return engine_post_locked(type, op);
+}
+
+int engine_post_locked(uint64_t type, const void* op) {
+  grdma_engine& e = g_engine;
   if (e.posted != 0 && e.posted == e.seq) {
     if (int rc = engine_wait_locked(e.posted)) return rc;
   }
@@ -582,7 +682,58 @@ int engine_stop() {
   if (!e.mb) return 0;
   *(volatile uint64_t*)&e.mb->exit_flag = 1;
   HIP_TRY(hipStreamSynchronize(e.stream));
+  HIP_TRY(hipStreamSynchronize(e.wstream));
+  // Nothing is resident now: a pair whose read is armed drains through launches of its own until the engine is
+  // started again, so the device slots are emptied and the standing orders posted afresh (with the sequence
+  // numbers of that moment) by the first command of the next start.
+  bool any = false;
+  for (uint32_t sidx = 0; sidx < GRDMA_WATCH_SLOTS; sidx++) {
+    grdma_pair* p = e.slot_owner[sidx];
+    if (e.slot_posted[sidx]) {
+      any = true;
+      // a completion the watcher produced and nobody has taken stays for the next grdma_endpoint_read
+      if (p && p->watch_expect != 0 && __atomic_load_n(&p->h->rxres.seq, __ATOMIC_ACQUIRE) >= p->watch_expect) {
+        p->armed_half = p->watch_taken & 1;
+        p->armed_done = true;
+      }
+    }
+    if (p) p->watch_expect = 0;
+    e.slot_posted[sidx] = false;
+    if (p) e.watch_dirty = true;
+  }
+  if (any) {
+    HIP_TRY(hipMemsetAsync(e.d_watch, 0, sizeof(grdma_watch_ctl), e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+  }
   return 0;
+}
+
+// ---- arrival-triggered reads: the host side of k_watch (grdma_watch_slot, grdma_ops.h) ------------------------
+// (engine.mu held)
+int watch_slot_of(const grdma_pair* p) {
+  for (uint32_t sidx = 0; sidx < GRDMA_WATCH_SLOTS; sidx++)
+    if (g_engine.slot_owner[sidx] == p) return (int)sidx;
+  return -1;
+}
+
+// Take the standing order of `p` back from its watcher (slot freed).  engine.mu held.
+int watch_release_locked(grdma_pair* p) {
+  grdma_engine& e = g_engine;
+  const int sidx = watch_slot_of(p);
+  if (sidx < 0) return 0;
+  int rc = 0;
+  if (e.slot_posted[sidx]) {
+    // (a posted slot means an incarnation that has not been stopped: resident, or retired by itself -- the command
+    //  brings it back, and its command workgroup waits until the watcher has let the connection go)
+    e.h_wcmd->slot = (uint64_t)sidx;
+    e.h_wcmd->gen = 0;
+    rc = engine_launch();
+    if (!rc) rc = engine_post_locked(GRDMA_ENGINE_WATCH, e.h_wcmd);
+    if (!rc) rc = engine_wait_locked(e.posted);
+    e.slot_posted[sidx] = false;
+  }
+  e.slot_owner[sidx] = nullptr;
+  return rc;
 }
 
 // Wait for a plan kernel by watching its sequence word in pinned host memory
@@ -624,7 +775,7 @@ int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_curs
       // the slice table and payload were staged into the command block (stage_slices)
       p->h_cmd->tx = h->txop;
       grdma_pair* q = p->peer;
-      if (q && !p->remote && q->armed_reads && !q->armed_done && q->latency && q->h_arena) {
+      if (q && !p->remote && q->armed_reads && q->watch_slot < 0 && !q->armed_done && q->latency && q->h_arena) {
         // the peer has a read armed: its drain rides in this command (the engine runs it right after
         // the send, in the same workgroup), and its completion waits in the peer's result block
         fill_rxop(q, q->h_arena, q->h_arena_cap, q->armed_reads, 0);
@@ -659,6 +810,8 @@ int run_recv(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_rea
   // left the ring, their credit is out -- another drain now would overwrite the only record of them
   if (p->armed_done.load(std::memory_order_acquire))
     return fail(GRDMA_ERR_INVALID, "an armed read has completed: grdma_endpoint_read takes it before anything else drains");
+  if (p->watch_slot >= 0 && g_engine.wanted)
+    return fail(GRDMA_ERR_INVALID, "the read side of this pair belongs to its watcher (grdma_pair_arm_read): grdma_endpoint_read takes its completions");
   grdma_hostblk* h = p->h;
   fill_rxop(p, arena, arena_cap, max_reads, raw_cap);
   const uint32_t blocks = copy_blocks_for(p->ring_size);
@@ -864,6 +1017,11 @@ void grdma_pair_destroy(grdma_pair* p) {
     std::lock_guard<std::mutex> lk(g_exported_mu);
     auto it = g_exported.find(p->serial);
     if (it != g_exported.end() && it->second == p) g_exported.erase(it);
+  }
+  if (p->watch_slot >= 0) {  // (its watcher lets the connection go before the memory does)
+    std::lock_guard<std::mutex> lk(g_engine.mu);
+    watch_release_locked(p);
+    p->watch_slot = -1;
   }
   if (p->stream) hipStreamSynchronize(p->stream);
   // (a queued or skipped write chain, a drain in flight: nothing of this pair's may still run when its memory goes back)
@@ -1685,7 +1843,7 @@ int grdma_pair_arena_copy_out(grdma_pair* p, uint64_t off, void* host_dst, uint6
   if (int rc = require_ctx()) return rc;
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
   if (p->latency) {  // the arena is pinned host memory: the kernel already wrote it there
-    if (off + len > p->h_arena_cap) return fail(GRDMA_ERR_INVALID, "range outside the arena");
+    if (off + len > 2 * p->h_arena_cap) return fail(GRDMA_ERR_INVALID, "range outside the arena");
     memcpy(host_dst, p->h_arena + off, len);
     return 0;
   }
@@ -1730,9 +1888,14 @@ int grdma_pair_set_latency_mode(grdma_pair* p, int on) {
   if (on && !p->h_arena) {
     p->h_arena_cap = 2 * p->ring_size + 4096;
     if (p->h_arena_cap > (64ull << 20)) p->h_arena_cap = 64ull << 20;
-    HIP_TRY(hipHostMalloc((void**)&p->h_arena, p->h_arena_cap, hipHostMallocCoherent | hipHostMallocMapped));
+    // (twice what one drain may fill: a watcher's drains alternate between the halves, so the slices of a completion
+    //  stay where they are while the next drain -- which no longer waits for a call -- delivers; k_watch)
+    HIP_TRY(hipHostMalloc((void**)&p->h_arena, 2 * p->h_arena_cap, hipHostMallocCoherent | hipHostMallocMapped));
   }
   HIP_TRY(hipStreamSynchronize(p->stream));
+  if (!on && p->watch_slot >= 0) {
+    if (int rc = grdma_pair_arm_read(p, 0)) return rc;
+  }
   if (!on && p->armed_done) return fail(GRDMA_ERR_INVALID, "an armed read has completed and was not consumed");
   if (!on) p->armed_reads = 0;
   p->latency = on != 0;
@@ -1755,11 +1918,49 @@ int grdma_pair_arm_read(grdma_pair* p, uint64_t max_reads) {
     p->armed_async.store(max_reads, std::memory_order_release);
     return 0;
   }
+  if (engine_chain_mode() && p->watch_slot < 0) {  // (round 4's way: the in-process peer's send command carries the drain)
+    p->armed_reads = max_reads;
+    return 0;
+  }
+  grdma_engine& e = g_engine;
+  std::lock_guard<std::mutex> lk(e.mu);
+  if (p->watch_slot >= 0 && (max_reads == 0 || max_reads != p->armed_reads)) {
+    // back from the watcher; a completion it produced and nobody has taken stays for the next grdma_endpoint_read
+    // (watch_expect is non-zero exactly while the order sits in its device slot)
+    int rc = watch_release_locked(p);
+    if (p->watch_expect != 0 && __atomic_load_n(&p->h->rxres.seq, __ATOMIC_ACQUIRE) >= p->watch_expect) {
+      p->armed_half = p->watch_taken & 1;
+      p->armed_done = true;
+    }
+    p->watch_slot = -1;
+    p->watch_expect = 0;
+    if (rc) return rc;
+  }
   p->armed_reads = max_reads;
+  if (max_reads == 0 || p->watch_slot >= 0) return 0;
+  int sidx = -1;
+  for (uint32_t k = 0; k < GRDMA_WATCH_SLOTS; k++)
+    if (!e.slot_owner[k]) { sidx = (int)k; break; }
+  if (sidx < 0) return fail(GRDMA_ERR_CAPACITY, "all %d watch slots of the latency engine are taken", GRDMA_WATCH_SLOTS);
+  e.slot_owner[sidx] = p;
+  e.slot_posted[sidx] = false;
+  e.watch_dirty = true;
+  p->watch_slot = sidx;
+  p->watch_expect = 0;
+  if (e.wanted) {
+    if (int rc = engine_launch()) return rc;
+    if (int rc = watch_flush_locked()) return rc;
+  }
   return 0;
 }
 int64_t grdma_pair_armed_hits(const grdma_pair* p) { return p ? (int64_t)p->armed_hits : -1; }
-int grdma_pair_armed_ready(const grdma_pair* p) { return p && p->armed_done ? 1 : 0; }
+int64_t grdma_pair_watch_hits(const grdma_pair* p) { return p ? (int64_t)p->watch_hits : -1; }
+int grdma_engine_watchers(void) { return (int)engine_watch_groups(); }
+int grdma_pair_armed_ready(const grdma_pair* p) {
+  if (!p) return 0;
+  if (p->armed_done) return 1;
+  return p->watch_slot >= 0 && p->watch_expect != 0 && __atomic_load_n(&p->h->rxres.seq, __ATOMIC_ACQUIRE) >= p->watch_expect ? 1 : 0;
+}
 
 // Unary ping-pong over a connected loop-back link, host in the loop exactly
 // where gRPC's consumer is: a = client end, b = server end.  Per iteration:
@@ -1792,7 +1993,10 @@ int grdma_pingpong(grdma_pair* a, grdma_pair* b, const grdma_slice* req, uint64_
   auto read_all = [&](grdma_pair* p, uint64_t want) -> int {
     grdma_profiler profiler(GRDMA_STATS_TIME_TRANSPORT_READ);  // rdma_read, rdma_bp_posix.cc:345
     uint64_t got = 0;
-    for (int tries = 0; got < want && tries < 100000; tries++) {
+    // (a watched pair's read is a look at host memory: bounded by time, not by tries)
+    const bool watched = p->watch_slot >= 0;
+    const auto r0 = watched ? now() : std::chrono::steady_clock::time_point();
+    for (uint64_t tries = 0; got < want && (tries < 100000 || (watched && ns(r0, now()) < 5000000000ull)); tries++) {
       int wb = 0;
       int64_t n = grdma_endpoint_read(p, 64, sl, 64, &wb);
       if (n < 0) return (int)n;
@@ -1895,22 +2099,51 @@ int64_t grdma_endpoint_read(grdma_pair* p, uint64_t max_reads, grdma_read_slice*
   if (max_reads == 0) return 0;
   uint8_t* arena = p->latency ? p->h_arena : p->d_arena;
   const uint64_t acap = p->latency ? p->h_arena_cap : p->arena_cap;
+  bool watched = false;
   if (p->armed_done && p->latency) {
     // the drain already ran behind the peer's send (grdma_pair_arm_read)
     if (p->h->rxres.nslices > max_reads)   // (the completion stays: a call with room for it still gets it)
       return fail(GRDMA_ERR_INVALID, "the armed read delivered %llu slices, this call takes %llu",
                   (unsigned long long)p->h->rxres.nslices, (unsigned long long)max_reads);
     p->armed_done = false;
+  } else if (p->latency && p->watch_slot >= 0 && g_engine.wanted) {
+    // The standing order is with a watcher workgroup of the engine: it drains when bytes land, this call only looks
+    // at the result block in pinned host memory.  Nothing there: the read stays outstanding -- no device work, no
+    // change of state (what a pending grpc_endpoint_read is, rdma_bp_posix.cc:345-372).
+    grdma_engine& e = g_engine;
+    if (e.watch_dirty || !e.mb || !*(volatile uint64_t*)&e.mb->alive) {
+      std::lock_guard<std::mutex> lk(e.mu);
+      if (int rc = engine_launch()) return rc;   // (an engine that retired by itself comes back with its slots)
+      if (int rc = watch_flush_locked()) return rc;
+    }
+    if (p->watch_expect == 0 || __atomic_load_n(&p->h->rxres.seq, __ATOMIC_ACQUIRE) < p->watch_expect) {
+      if (would_block) *would_block = 1;
+      return 0;
+    }
+    if (p->h->rxres.nslices > max_reads)
+      return fail(GRDMA_ERR_INVALID, "the armed read delivered %llu slices, this call takes %llu",
+                  (unsigned long long)p->h->rxres.nslices, (unsigned long long)max_reads);
+    watched = true;
   } else if (int rc = run_recv(p, arena, acap, max_reads, 0)) {
     return rc;
   }
   const grdma_rx_result& r = p->h->rxres;
-  for (uint64_t i = 0; i < r.nslices; i++) {
-    slices[i].off = p->h_slices[i].off;
+  const uint64_t n = r.nslices;
+  // (a watcher's drains alternate between the two halves of the arena: completion k of an arming lies in half k & 1)
+  const uint64_t half_off = (watched ? (p->watch_taken & 1) : p->armed_half) * p->h_arena_cap;
+  p->armed_half = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    slices[i].off = p->h_slices[i].off + half_off;
     slices[i].len = p->h_slices[i].len;
   }
   if (would_block) *would_block = (int)r.would_block;
-  return (int64_t)r.nslices;
+  if (watched) {
+    // taken: the watcher may run the next drain (it overwrites result block, slice table and arena)
+    p->watch_expect++;
+    p->watch_hits++;
+    __atomic_store_n(&g_engine.mb->consumed[p->watch_slot], ++p->watch_taken, __ATOMIC_RELEASE);
+  }
+  return (int64_t)n;
 }
 
 // ---- asynchronous endpoint operations (see include/grdma_amd.h) ----------------------------------

@@ -432,6 +432,15 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
           const uint32_t b = (uint32_t)lane * 8 + q;
           bytes[q] = b < T ? src[b] : (uint8_t)0;
         }
+      } else if (op.inline_apply & 8u) {
+        // (a watcher's drain, csrc k_watch: the bytes were written by another workgroup, process or device since this
+        //  CU last looked at these lines, with no kernel boundary in between -- loads that go past the caches)
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t b = (uint32_t)lane * 8 + q;
+          const uint8_t x = __hip_atomic_load(&gring[(head0 + src_off[q]) & mask], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          bytes[q] = b < T ? x : (uint8_t)0;
+        }
       } else {
 #pragma unroll
       for (int q = 0; q < 8; q++) {
@@ -532,6 +541,12 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
   }
   __syncthreads();
   const bool express = s_express != 0;
+  if ((op.inline_apply & 8u) && !express) {
+    // a watcher's drain that the general tiers take: their loads of ring bytes are plain ones, and this CU has not
+    // seen a kernel boundary since it last read those lines
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+  }
 
   if (!express) {
     // (all loads first: `c->rx_hist` is a generic pointer, so a store to LDS between two
@@ -1447,28 +1462,34 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
     const uint64_t o_rx_records = pre_rx_records, o_rx_rounds = pre_rx_rounds;
     const uint64_t o_slice_idx = op.append == 1 ? c->rx_slice_idx : 0;
     const uint64_t te_f = __builtin_amdgcn_s_memtime() + ((o_total_read + o_rx_rounds) & 0);  // (counters loaded)
-    c->head = head;
-    c->moving_head = mh;
-    c->remain = S.remain;
+    // The connection block's own fields: nobody but the next drain of this connection -- this workgroup again, or a
+    // kernel behind a boundary -- reads them, so on the latency path (inline_apply) they are stored BEHIND the sequence
+    // word the host is waiting for; the launch-chain paths keep them in front of the result block.
+    auto commit_conn = [&] {
+      c->head = head;
+      c->moving_head = mh;
+      c->remain = S.remain;
+      c->internal_read_size = S.irs;
+      c->leftover_cap = S.leftover;
+      c->total_read = o_total_read + S.bytes;
+      c->credit_msgs = o_credit_msgs + S.credit;
+      c->rx_records = o_rx_records + S.records;
+      if (nslices) c->rx_rounds = o_rx_rounds + 1;
+      if (op.append) {
+        c->rx_arena_off = S.a_off;
+        c->rx_slice_idx = o_slice_idx + nslices;
+      }
+      op.plan->blocks_done = 0;
+      // updateStatus() (pair.cc:624-641) must not overtake the copy-out and the
+      // zero-fill of the bytes it grants: the 16-byte report is posted by the last
+      // workgroup of k_rx_apply.
+      if (S.credit) c->status_send.remote_head = S.credit_head;
+    };
+    if (!op.inline_apply) commit_conn();
     if (pre_line != nullptr) {  // what HasMessage() on the host compares with the sender's arrival report
       pre_line->rx_head = head;
       pre_line->rx_remain = S.remain;
     }
-    c->internal_read_size = S.irs;
-    c->leftover_cap = S.leftover;
-    c->total_read = o_total_read + S.bytes;
-    c->credit_msgs = o_credit_msgs + S.credit;
-    c->rx_records = o_rx_records + S.records;
-    if (nslices) c->rx_rounds = o_rx_rounds + 1;
-    if (op.append) {
-      c->rx_arena_off = S.a_off;
-      c->rx_slice_idx = o_slice_idx + nslices;
-    }
-    op.plan->blocks_done = 0;
-    // updateStatus() (pair.cc:624-641) must not overtake the copy-out and the
-    // zero-fill of the bytes it grants: the 16-byte report is posted by the last
-    // workgroup of k_rx_apply.
-    if (S.credit) c->status_send.remote_head = S.credit_head;
     res->credit_head = S.credit_head;
     res->nslices = nslices;
     res->bytes = S.bytes;
@@ -1511,6 +1532,9 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
       // (relaxed stores: the single system-scope release on `seq` below publishes them;
       // every release is an L2 write-back, and this is the latency path)
       if (S.credit) {
+        // (a watcher's drain: the sender runs on another CU, possibly behind another L2 -- the zero-fill of the bytes
+        //  this report grants must have left this L2 before the sender can overwrite them.  Once per ring / 2 bytes.)
+        if (op.inline_apply & 8u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         grdma_status_report* ps = pre_ps;
         if (ps != nullptr)
           __hip_atomic_store(&ps->remote_head, S.credit_head, __ATOMIC_RELAXED,
@@ -1525,6 +1549,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
     const uint64_t te_g = __builtin_amdgcn_s_memtime();  // (commit stores issued)
     __hip_atomic_store(&res->seq, op.seq_next ? op.seq_next : res->seq + 1, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
+    if (op.inline_apply) commit_conn();
     if (express) {
       const uint64_t te_h = __builtin_amdgcn_s_memtime();
       g_rx_express_ticks[5] += te_f - s_dbg[15];
@@ -1883,14 +1908,18 @@ __device__ __forceinline__ bool engine_cut_through_ok(const grdma_engine_cmd& bl
 // host sets exit_flag.
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_engine(grdma_engine_mbox* mb) {
+void k_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch) {
   __shared__ uint64_t s_cmd[4];
+  __shared__ uint64_t s_wcmd[sizeof(grdma_watch_cmd) / 8];
   __shared__ uint64_t s_fast[GRDMA_FAST_WORDS];
   __shared__ __attribute__((aligned(16))) grdma_engine_cmd s_blk;
   __shared__ grdma_ct_hint s_cth;
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // resume after the last command a previous incarnation completed
   uint64_t last = __hip_atomic_load(&mb->ack_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+  uint64_t my_consumed = ~0ull;  // (wave 0, lane = watch slot: what this incarnation has mirrored of mb->consumed)
+  uint64_t prof[4] = {mb->pad1[0], mb->pad1[1], mb->pad1[2], mb->pad1[3]};  // (thread 0's running totals, see the acknowledgement)
+  static_assert(GRDMA_WATCH_SLOTS == 64, "one lane of the doorbell wave per watch slot");
   if (threadIdx.x == 0) {
     __hip_atomic_store(&mb->alive, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -1902,10 +1931,15 @@ void k_engine(grdma_engine_mbox* mb) {
     if (wave == 0) {
       uint64_t seq, idle = 0, quit = 0, fast_words = 0, fast_type = 0;
       for (;;) {
-        // one poll = two loads in flight together: the eight fast-lane lines (lane l = word l)
-        // and the doorbell of the pointer path
+        // one poll = three loads in flight together: the eight fast-lane lines (lane l = word l), the completions the
+        // host has taken from the watch slots (lane l = slot l), and the doorbell of the pointer path
         const uint64_t fw = GRDMA_WAVE_LOAD_LINES(mb->fast, lane);
+        const uint64_t cw = __hip_atomic_load(&mb->consumed[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         seq = __hip_atomic_load(&mb->cmd_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (cw != my_consumed) {  // (into the slot, where the watcher of that connection polls it: device memory)
+          my_consumed = cw;
+          __hip_atomic_store(&wc->slot[lane].consumed, cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         seq = __shfl(seq, 0, 64);
         const uint64_t stamp0 = __shfl(fw, 7, 64);
         if (stamp0 == last + 1) {
@@ -1963,6 +1997,40 @@ void k_engine(grdma_engine_mbox* mb) {
       tx_plan_call(reinterpret_cast<const grdma_tx_op*>(opp));
     } else if (type == GRDMA_ENGINE_DRAIN) {
       rx_plan_call(reinterpret_cast<const grdma_rx_op*>(opp));
+    } else if (type == GRDMA_ENGINE_WATCH) {
+      // hand a connection's receive side to its watcher (gen != 0), or take it back (gen == 0)
+      if (threadIdx.x < sizeof(grdma_watch_cmd) / 8)
+        s_wcmd[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(opp) + threadIdx.x, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_SYSTEM);
+      __syncthreads();
+      const uint64_t slot = s_wcmd[0] % GRDMA_WATCH_SLOTS, gen = s_wcmd[1];
+      grdma_watch_slot* sl = &wc->slot[slot];
+      if (gen != 0) {
+        // (what this workgroup's own drains have left of the connection's state reaches memory before the watcher,
+        //  on another CU and possibly behind another L2, takes the connection over)
+        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (threadIdx.x < sizeof(grdma_rx_op) / 8)
+          __hip_atomic_store(reinterpret_cast<uint64_t*>(&sl->op) + threadIdx.x, s_wcmd[2 + threadIdx.x], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 64) __hip_atomic_store(&sl->consumed, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 65) __hip_atomic_store(&sl->done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        GRDMA_WAIT_VMEM();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&sl->gen, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        if (threadIdx.x == 0) __hip_atomic_store(&sl->gen, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (wave == 0) {  // (the whole wave spins, like the doorbell: a wave-uniform loop)
+          // the watcher lets go between two drains; a drain it is in the middle of completes first
+          for (uint64_t spins = 0; spins < (1ull << 24); spins++) {
+            uint64_t a = __hip_atomic_load(&sl->ack_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            a = __shfl(a, 0, 64);
+            if (a == 0) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+          if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+      }
+      if (wave == 0 && lane == slot) my_consumed = ~0ull;  // (mirrored afresh: the host counts from zero per arming)
     } else if (type == GRDMA_ENGINE_SEND_INLINE || type == GRDMA_ENGINE_DRAIN_BLOCK ||
                type == GRDMA_ENGINE_SEND_INLINE_DRAIN) {
       // one wide read of the whole command block into LDS, then everything the body
@@ -2036,22 +2104,489 @@ void k_engine(grdma_engine_mbox* mb) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      const uint64_t te2 = __builtin_amdgcn_s_memtime();
-      // profiling aid: cycles spent loading the command block / running the body, per type
-      mb->pad1[(type & 1) ? 0 : 2] += te1 - te0;
-      mb->pad1[(type & 1) ? 1 : 3] += te2 - te1;
+      // the acknowledgement first; then the profiling aid: cycles spent loading the command block / running the body,
+      // per type -- running totals kept in registers and STORED (a `+=` on the mailbox is a PCIe read in front of
+      // every acknowledgement: 1.5 us per command)
       __hip_atomic_store(&mb->ack_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      const uint64_t te2 = __builtin_amdgcn_s_memtime();
+      const int k = (type & 1) ? 0 : 2;
+      prof[k] += te1 - te0;
+      prof[k + 1] += te2 - te1;
+      __hip_atomic_store(&mb->pad1[k], prof[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&mb->pad1[k + 1], prof[k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0)
+  if (threadIdx.x == 0) {
+    // the watchers of this incarnation leave with it
+    __hip_atomic_store(&wc->quit, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&mb->alive, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ----------------------------------------------------------------------------
+// The watcher's own drain of a unary-sized message: rx_plan_body's express drain as ONE wavefront, straight line, no
+// barrier -- the other three waves of the watcher stay parked.  What makes it shorter than the express drain:
+//   * the connection's receive state lives in LDS between drains (rxw_state: only this workgroup changes it while the
+//     connection is handed to it), so nothing of the connection block is loaded;
+//   * the arrival report bounds the bytes ([head, wire_tail), at most 1 KiB for this path): ONE round trip loads them
+//     all -- tags and payload -- into LDS, and the record chain is walked there;
+//   * result block, slice table and payload leave as a handful of wide stores from many lanes, one wait, then the
+//     sequence word; the connection block is written back BEHIND it.
+// Same records, slices, state, history, credit and zero-fill as the express drain (tests/test_zzz_gpu_watch_read.py
+// runs both against the oracle, and against each other: GRDMA_WATCH_FAST=0).  Returns false -- nothing touched -- when
+// the message is not its case; the caller then runs the plan body.
+// ----------------------------------------------------------------------------
+struct rxw_state {
+  grdma_conn* conn;
+  uint8_t* ring;
+  uint64_t cap;
+  uint64_t head, mh, remain, leftover, irs, hist_count, total_read, credit_msgs, rx_records, rx_rounds;
+  uint32_t h1, h2, connected, limited;
+  grdma_hostline* line;
+  grdma_status_report* peer_status;
+  grdma_hostline* peer_line;
+  uint32_t* hist;
+};
+
+// (by the lane that owns the slot: the connection block as memory holds it -- loads past this CU's L1)
+__device__ __forceinline__ void rxw_load(rxw_state* st, grdma_conn* c) {
+  auto ld = [](const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto ld32 = [](const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  st->conn = c;
+  st->ring = c->ring;
+  st->cap = c->cap;
+  st->head = ld(&c->head);
+  st->mh = ld(&c->moving_head);
+  st->remain = ld(&c->remain);
+  st->leftover = ld(&c->leftover_cap);
+  st->irs = ld(&c->internal_read_size);
+  st->hist_count = ld(&c->rx_hist_count);
+  st->total_read = ld(&c->total_read);
+  st->credit_msgs = ld(&c->credit_msgs);
+  st->rx_records = ld(&c->rx_records);
+  st->rx_rounds = ld(&c->rx_rounds);
+  st->h1 = ld32(&c->rx_h1);
+  st->h2 = ld32(&c->rx_h2);
+  st->connected = ld32(&c->status) == GRDMA_PAIR_CONNECTED ? 1u : 0u;
+  st->limited = c->wire_limit != 0 ? 1u : 0u;
+  st->line = c->line;
+  st->peer_status = c->peer_status;
+  st->peer_line = c->peer_line;
+  st->hist = c->rx_hist;
+}
+
+__device__ unsigned long long g_watch_fast_drains = 0;
+
+#define RXW_EXT_WORDS 128   // the bytes one drain of this path looks at: 1 KiB
+__device__ __forceinline__ bool rxw_fast(rxw_state* st, const grdma_rx_op* opp, uint64_t done, uint64_t wt, int lane,
+                                         uint64_t* s_ext /* [RXW_EXT_WORDS + 8] */) {
+  const uint64_t cap = st->cap, mask = cap - 1, head0 = st->head;
+  const uint64_t E = (wt - head0) & mask;
+  if (!st->limited || !st->connected || st->remain != 0 || E == 0 || E > RXW_EXT_WORDS * 8 || (E & 7) != 0 || cap < 2048) return false;
+  const grdma_rx_op& op = *opp;
+  if (op.raw_cap != 0 || op.append != 0 || op.max_reads < 1) return false;
+  uint8_t* const ring = st->ring;
+  // ---- one round trip: every word of [head, head + E) ----------------------------------------------------------
+  const uint32_t nw = (uint32_t)(E >> 3);
+  uint64_t w0 = 0, w1 = 0;
+  if ((uint32_t)lane < nw)
+    w0 = __hip_atomic_load(reinterpret_cast<const uint64_t*>(ring + ((head0 + 8ull * lane) & mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((uint32_t)lane + 64u < nw)
+    w1 = __hip_atomic_load(reinterpret_cast<const uint64_t*>(ring + ((head0 + 8ull * (lane + 64)) & mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  s_ext[lane] = w0;
+  s_ext[lane + 64] = w1;
+  GRDMA_WAVE_CONVERGE();
+  // ---- the record chain, walked in LDS (every lane the same walk) ----------------------------------------------
+  constexpr uint32_t RMAX = 8;
+  uint32_t rn[RMAX], rxn[RMAX], rxe[RMAX];   // payload bytes, payload bytes in front, encoded bytes in front
+  uint32_t v = 0, pos = 0, T = 0;
+  bool ok = true;
+#pragma unroll
+  for (uint32_t r = 0; r < RMAX; r++) {
+    rn[r] = 0; rxn[r] = T; rxe[r] = pos;
+    if (ok && pos < (uint32_t)E) {
+      const uint64_t hdr = s_ext[pos >> 3];
+      const uint64_t encr = 16 + round_up8(hdr);
+      if (hdr == 0 || hdr > 512 || pos + encr > E) {
+        ok = false;
+      } else if (s_ext[(pos + 8 + (uint32_t)round_up8(hdr)) >> 3] != GRDMA_FOOTER) {
+        ok = false;
+      } else {
+        rn[r] = (uint32_t)hdr;
+        T += (uint32_t)hdr;
+        pos += (uint32_t)encr;
+        v = r + 1;
+      }
+    }
+  }
+  if (!ok || pos != (uint32_t)E || v == 0 || T > 512) return false;
+  const uint64_t leftover0 = st->leftover, irs0 = st->irs;
+  uint64_t max_slices = GRDMA_MAX_SLICES;
+  if (op.max_reads < max_slices) max_slices = op.max_reads;
+  const uint32_t n0 = rn[0];
+  uint32_t rem1 = 0;   // what is left of the record in which the open read's last byte falls
+#pragma unroll
+  for (uint32_t r = 0; r < RMAX; r++)
+    if (rn[r] != 0 && leftover0 >= rxn[r] && leftover0 < (uint64_t)rxn[r] + rn[r]) rem1 = rxn[r] + rn[r] - (uint32_t)leftover0;
+  const int fits = express_fits(leftover0, n0, T, max_slices, 0, op.arena_cap, rem1, irs0 + E >= cap / 2);
+  if (fits == 0) return false;
+  // ---- from here on the drain happens ----------------------------------------------------------------------------
+  const bool split = fits == 2;
+  const uint64_t alloc = leftover0 ? leftover0 : (n0 > MINRD ? n0 : MINRD);
+  const uint32_t L0 = split ? (uint32_t)leftover0 : T;
+  const uint32_t off1 = split ? (uint32_t)((L0 + 15u) & ~15u) : 0;
+  uint8_t* const dst = op.arena + (done & 1) * op.arena_cap;   // (the halves of the arena alternate: k_watch)
+  // payload: output byte b lives in record r(b) at offset b - rxn[r], i.e. at byte rxe[r] + 8 + (b - rxn[r]) of the extent
+  const uint8_t* ext8 = reinterpret_cast<const uint8_t*>(s_ext);
+  uint8_t bytes[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const uint32_t b = (uint32_t)lane * 8 + q;
+    uint32_t so = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < RMAX; r++)
+      if (b >= rxn[r] && b < rxn[r] + rn[r]) so = rxe[r] + 8 + (b - rxn[r]);
+    bytes[q] = b < T ? ext8[so] : (uint8_t)0;
+  }
+  if (split) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t b = (uint32_t)lane * 8 + q;
+      if (b < T) __hip_atomic_store(dst + (b < L0 ? b : off1 + (b - L0)), bytes[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  } else if ((uint32_t)lane * 8 < T) {
+    uint64_t word = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) word |= (uint64_t)bytes[q] << (8 * q);
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(dst + (uint32_t)lane * 8), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // what was consumed is cleared (records are 8-byte granular), past the caches: the sender overwrites it from another CU
+  if ((uint32_t)lane < nw)
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(ring + ((head0 + 8ull * lane) & mask)), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((uint32_t)lane + 64u < nw)
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(ring + ((head0 + 8ull * (lane + 64)) & mask)), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // history ring, the credit rule of Recv (pair.cc:276-284) record by record
+  const uint64_t hist_count0 = st->hist_count;
+  uint32_t my_enc = 0;
+#pragma unroll
+  for (uint32_t r = 0; r < RMAX; r++)
+    if ((uint32_t)lane == r) my_enc = rn[r] ? 16u + (uint32_t)round_up8(rn[r]) : 0u;
+  if ((uint32_t)lane < v) st->hist[(hist_count0 + lane) % GRDMA_RX_HIST] = my_enc;
+  uint64_t irs = irs0, credit = 0, credit_head = 0;
+#pragma unroll
+  for (uint32_t r = 0; r < RMAX; r++) {
+    if (r < v) {
+      const uint32_t encr = 16u + (uint32_t)round_up8(rn[r]);
+      irs += encr;
+      if (irs >= cap / 2) {
+        credit_head = (head0 + rxe[r] + encr) & mask;
+        credit++;
+        irs = 0;
+      }
+    }
+  }
+  const uint64_t nh = (head0 + E) & mask, mh0 = st->mh;
+  uint64_t nslices, a_off, would_block, leftover;
+  grdma_slice_out sl0 = {0, 0}, sl1 = {0, 0};
+  if (split) {
+    const uint64_t rest = T - L0, alloc2 = rem1 > MINRD ? rem1 : MINRD, rest2 = alloc2 - rest;
+    sl0.off = 0; sl0.len = L0;
+    sl1.off = off1; sl1.len = rest;
+    nslices = 2;
+    a_off = (off1 + rest + 15) & ~15ull;
+    would_block = max_slices >= 3 ? 1 : 0;
+    leftover = max_slices >= 3 ? (rest2 ? rest2 : MINRD) : rest2;
+  } else {
+    sl0.off = 0; sl0.len = T;
+    nslices = 1;
+    a_off = ((uint64_t)T + 15) & ~15ull;
+    const uint64_t rest = alloc - T;
+    would_block = max_slices >= 2 ? 1 : 0;
+    leftover = max_slices >= 2 ? (rest ? rest : MINRD) : rest;
+  }
+  // result block (pinned host memory): one word per lane
+  grdma_rx_result* res = op.result;
+  uint64_t zo0 = mh0, zl0, zo1 = 0, zl1 = 0;
+  if (nh > mh0) { zl0 = nh - mh0; } else { zl0 = cap - mh0; zl1 = nh; }
+  {
+    uint64_t val = 0;
+    switch (lane) {
+      case 0: val = nslices; break;
+      case 1: val = T; break;
+      case 2: val = E; break;
+      case 3: val = v; break;
+      case 4: val = would_block; break;
+      case 5: val = credit; break;
+      case 6: val = credit_head; break;
+      case 7: val = nh; break;
+      case 8: val = nh; break;
+      case 9: val = 0; break;
+      case 10: val = a_off; break;
+      case 11: val = zo0; break;
+      case 12: val = zo1; break;
+      case 13: val = zl0; break;
+      case 14: val = zl1; break;
+      default: break;
+    }
+    static_assert(offsetof(grdma_rx_result, zero_len) == 13 * 8 && offsetof(grdma_rx_result, seq) == 15 * 8 &&
+                  offsetof(grdma_rx_result, commit_seq) == 16 * 8, "rxw_fast writes the result block word by word");
+    if (lane < 15) __hip_atomic_store(reinterpret_cast<uint64_t*>(res) + lane, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 16) __hip_atomic_store(&res->commit_seq, op.seq_next + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // slice table
+    if (lane == 17) __hip_atomic_store(&op.slices[0].off, sl0.off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 18) __hip_atomic_store(&op.slices[0].len, sl0.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (split && lane == 19) __hip_atomic_store(&op.slices[1].off, sl1.off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (split && lane == 20) __hip_atomic_store(&op.slices[1].len, sl1.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // what HasMessage() on the host compares with the sender's arrival report
+    if (st->line != nullptr) {
+      if (lane == 21) __hip_atomic_store(&st->line->rx_head, nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (lane == 22) __hip_atomic_store(&st->line->rx_remain, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  // every store above is acknowledged -- the zero-fill has left this CU before the credit that grants it goes out
+  GRDMA_WAIT_VMEM();
+  GRDMA_WAVE_CONVERGE();  // (nothing on the GPU, where the lanes of a wave issue a store together)
+  if (credit) {
+    if (lane == 0 && st->peer_status != nullptr)
+      __hip_atomic_store(&st->peer_status->remote_head, credit_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 1 && st->peer_line != nullptr)
+      __hip_atomic_store(&st->peer_line->remote_head, credit_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    GRDMA_WAIT_VMEM();
+    GRDMA_WAVE_CONVERGE();
+  }
+  if (lane == 0) __hip_atomic_store(&res->seq, op.seq_next + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // ---- behind the sequence word: the state in LDS, and the connection block as the plan body would leave it ---------
+  const uint32_t e_last = 16u + (uint32_t)round_up8(rn[v - 1 < RMAX ? v - 1 : 0]);
+  uint32_t e_prev = 0;
+#pragma unroll
+  for (uint32_t r = 0; r + 1 < RMAX; r++)
+    if (r + 2 == v) e_prev = 16u + (uint32_t)round_up8(rn[r]);
+  uint32_t last_n = 0;
+#pragma unroll
+  for (uint32_t r = 0; r < RMAX; r++)
+    if (r + 1 == v) last_n = rn[r];
+  const uint32_t enc_last = 16u + (uint32_t)round_up8(last_n);
+  (void)e_last;
+  const uint32_t nh1 = enc_last, nh2 = v >= 2 ? e_prev : st->h1;
+  if (lane == 0) {
+    grdma_conn* c = st->conn;
+    c->rx_h1 = nh1;
+    c->rx_h2 = nh2;
+    c->rx_hist_count = hist_count0 + v;
+    c->head = nh;
+    c->moving_head = nh;
+    c->remain = 0;
+    c->internal_read_size = irs;
+    c->leftover_cap = leftover;
+    c->total_read = st->total_read + T;
+    c->credit_msgs = st->credit_msgs + credit;
+    c->rx_records = st->rx_records + v;
+    c->rx_rounds = st->rx_rounds + 1;
+    if (credit) c->status_send.remote_head = credit_head;
+    grdma_plan* plan = op.plan;
+    plan->nsegs = 0;
+    plan->ntiles = 0;
+    plan->tile_bytes = 1u << GRDMA_PLAN_TILE_SHIFT(cap);
+    plan->tile_prefix[0] = 0;
+    plan->bytes = T;
+    plan->tag_base = (uint64_t)ring;
+    plan->tag_mask = mask;
+    plan->blocks_done = 0;
+    st->h1 = nh1;
+    st->h2 = nh2;
+    st->hist_count = hist_count0 + v;
+    st->head = nh;
+    st->mh = nh;
+    st->irs = irs;
+    st->leftover = leftover;
+    st->total_read += T;
+    st->credit_msgs += credit;
+    st->rx_records += v;
+    st->rx_rounds += 1;
+    atomicAdd(&g_watch_fast_drains, 1ull);
+    atomicAdd(&g_express_drains, 1ull);
+  }
+  GRDMA_WAVE_CONVERGE();
+  return true;
+}
+
+// ----------------------------------------------------------------------------
+// k_watch: the read side of the latency engine (grdma_watch_slot, grdma_ops.h).  One workgroup per watcher; lane l of
+// its first wave owns slot blockIdx.x + l * gridDim.x and keeps that connection's head in a register.  A pass is one
+// round trip to device memory for all its connections at once: the slot's generation, the completions the host has
+// taken, and the connection's arrival report (ordered wire: the header at the head and the footer it points at,
+// GetReadableSize, ring_buffer.cc:67-97).  When a connection has bytes and its last completion has been taken, the
+// whole workgroup runs the standing order through the same plan body every other drain runs (bytes, state, credit:
+// those of grdma_endpoint_read called at that moment) and goes back to polling.  The drain is limited to what the
+// pass saw (grdma_rx_op::limit_ptr points at the word in LDS): what lands meanwhile is the next pass's.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_t flags) {
+  __shared__ __attribute__((aligned(16))) grdma_rx_op s_op;
+  __shared__ __attribute__((aligned(16))) grdma_rx_op s_ops[64];   // the standing orders of this workgroup's slots, by owning lane
+  __shared__ rxw_state s_st[64];                                    // ... and their connections' receive state
+  __shared__ __attribute__((aligned(16))) uint64_t s_ext[RXW_EXT_WORDS + 8];
+  __shared__ uint64_t s_limit, s_done, s_found;
+  __shared__ uint32_t s_fire, s_limited;
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned my_slot = blockIdx.x + lane * gridDim.x;
+  const bool have = my_slot < GRDMA_WATCH_SLOTS;
+  const bool fast_on = (flags & 1u) != 0;
+  grdma_watch_slot* const sl = &wc->slot[have ? my_slot : 0];
+  // (wave 0, per lane: the connection this lane watches)
+  uint64_t gen_seen = 0, head = 0, remain = 0, done = 0, mask = 0;
+  grdma_conn* conn = nullptr;
+  const uint8_t* ring = nullptr;
+  const uint64_t* wire_ptr = nullptr;
+  bool limited = true;
+  uint32_t rr = 0;
+  if (threadIdx.x == 0 && blockIdx.x < GRDMA_WATCH_MAX_GROUPS)
+    __hip_atomic_store(&mb->watch_alive[blockIdx.x], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  for (;;) {
+    if (wave == 0) {
+      uint32_t fire = 0;
+      for (;;) {
+        // one pass = one round trip: every load is issued before the first one is looked at
+        const bool armed = gen_seen != 0;
+        uint64_t q = __hip_atomic_load(&wc->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint64_t gen = have ? __hip_atomic_load(&sl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+        uint64_t consumed = 0, wt = 0;
+        if (armed) {
+          consumed = __hip_atomic_load(&sl->consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          // (ordered wire: the header at the head stands in for the arrival report)
+          wt = __hip_atomic_load(limited ? wire_ptr : reinterpret_cast<const uint64_t*>(ring + head), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        q = __shfl(q, 0, 64);
+        if (q == epoch) break;
+        bool fresh = false;
+        if (gen != gen_seen) {
+          if (gen != 0) {
+            // taken over: the connection block as its last owner left it (the command workgroup released it)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (unsigned k = 0; k < sizeof(grdma_rx_op) / 8; k++)
+              reinterpret_cast<uint64_t*>(&s_ops[lane])[k] =
+                  __hip_atomic_load(reinterpret_cast<const uint64_t*>(&sl->op) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            conn = s_ops[lane].conn;
+            rxw_load(&s_st[lane], conn);
+            ring = s_st[lane].ring;
+            mask = s_st[lane].cap - 1;
+            limited = s_st[lane].limited != 0;
+            wire_ptr = &conn->wire_recv.wire_tail;
+            head = s_st[lane].head;
+            remain = s_st[lane].remain;
+            done = __hip_atomic_load(&sl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          } else {
+            // let go: what this workgroup has written of the connection reaches memory before the acknowledgement
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          }
+          gen_seen = gen;
+          __hip_atomic_store(&sl->ack_gen, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          fresh = true;  // (the values of this pass belong to the slot's previous life: looked at in the next one)
+        }
+        bool ready = false;
+        if (armed && !fresh) {
+          bool arrived;
+          if (limited) {
+            arrived = wt != head;
+          } else {
+            arrived = false;  // GetReadableSize, ring_buffer.cc:67-97: a header, and the footer it points at
+            if (wt != 0 && wt <= mask + 1 - GRDMA_RESERVED) {
+              const uint64_t ftr = __hip_atomic_load(reinterpret_cast<const uint64_t*>(ring + ((head + 8 + round_up8(wt)) & mask)),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              arrived = ftr == GRDMA_FOOTER;
+            }
+          }
+          ready = (remain != 0 || arrived) && consumed >= done;
+        }
+        const uint64_t m = __ballot(ready);
+        if (m) {
+          // (round robin over the lanes: a connection that always has bytes does not starve its neighbours)
+          const uint64_t rot = rr ? ((m >> rr) | (m << (64 - rr))) : m;
+          const uint32_t pick = ((uint32_t)__builtin_ctzll(rot) + rr) & 63u;
+          rr = (pick + 1) & 63u;
+          const uint64_t t_found = __builtin_amdgcn_s_memrealtime();
+          const uint64_t wt_p = __shfl(wt, (int)pick, 64), done_p = __shfl(done, (int)pick, 64);
+          // a unary-sized message: this wave alone, straight line (rxw_fast); anything else: the plan body, all four waves
+          if (fast_on && rxw_fast(&s_st[pick], &s_ops[pick], done_p, wt_p, (int)lane, s_ext)) {
+            if (lane == pick) {
+              done += 1;
+              head = s_st[lane].head;
+              remain = 0;
+              __hip_atomic_store(&sl->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              // (profiling aid: 10 ns ticks)
+              const uint64_t t_done = __builtin_amdgcn_s_memrealtime();
+              const uint64_t t_pub = __hip_atomic_load(&g_watch_ticks[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              g_watch_ticks[1] += t_found - t_pub;
+              g_watch_ticks[2] += t_done - t_found;
+              g_watch_ticks[3] += 1;
+              sl->drains_dbg = sl->drains_dbg + 1;
+            }
+            continue;   // (uniform: every lane took the same way)
+          }
+          if (lane == pick) {
+            s_found = t_found;
+            s_limit = wt;
+            s_limited = limited ? 1u : 0u;
+            s_done = done;
+            s_fire = 1u + lane;
+          }
+          fire = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!fire && lane == 0) s_fire = 0;
+    }
+    __syncthreads();
+    const uint32_t f = s_fire;
+    if (f == 0) break;
+    if (threadIdx.x < sizeof(grdma_rx_op) / 8)
+      reinterpret_cast<uint64_t*>(&s_op)[threadIdx.x] = reinterpret_cast<const uint64_t*>(&s_ops[f - 1])[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint64_t k = s_done;
+      s_op.seq_next += k;
+      // (the slices of completion k - 1 may still be read by the host: the halves of the arena alternate)
+      s_op.arena += (k & 1) * s_op.arena_cap;
+      if (s_limited) s_op.limit_ptr = &s_limit;
+    }
+    __syncthreads();
+    const uint64_t t_body = __builtin_amdgcn_s_memrealtime();
+    rx_plan_call(&s_op);
+    __syncthreads();
+    if (wave == 0 && lane == f - 1) {
+      // (profiling aid: 10 ns ticks)
+      const uint64_t t_done = __builtin_amdgcn_s_memrealtime();
+      const uint64_t t_pub = __hip_atomic_load(&g_watch_ticks[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      g_watch_ticks[1] += s_found - t_pub;
+      g_watch_ticks[2] += t_done - s_found;
+      g_watch_ticks[3] += 1;
+      g_watch_ticks[4] += t_body - s_found;
+      done += 1;
+      __hip_atomic_store(&sl->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      sl->drains_dbg = sl->drains_dbg + 1;
+      rxw_load(&s_st[lane], conn);   // (the plan body changed the connection block: the state in LDS follows it)
+      head = s_st[lane].head;
+      remain = s_st[lane].remain;
+    }
+  }
+  if (threadIdx.x == 0 && blockIdx.x < GRDMA_WATCH_MAX_GROUPS)
+    __hip_atomic_store(&mb->watch_alive[blockIdx.x], 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
 
-extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_engine(grdma_engine_mbox* mb, hipStream_t s) {
-  hipLaunchKernelGGL(k_engine, dim3(1), dim3(PLAN_THREADS), 0, s, mb);
+extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch,
+                                                                                hipStream_t s) {
+  hipLaunchKernelGGL(k_engine, dim3(1), dim3(PLAN_THREADS), 0, s, mb, wc, epoch);
+  return hipGetLastError();
+}
+extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch,
+                                                                               uint32_t groups, uint32_t flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_watch, dim3(groups), dim3(PLAN_THREADS), 0, s, mb, wc, epoch, flags);
   return hipGetLastError();
 }
 
@@ -2064,6 +2599,14 @@ extern "C" int grdma_tx_small_ticks(uint64_t out[8]) {
   return 0;
 }
 
+// profiling aid: 10 ns ticks summed over the watchers' drains -- {-, arrival report published -> found by the watcher,
+// found -> drain done, drains, found -> plan body entered}
+extern "C" int grdma_watch_ticks(uint64_t out[8]) {
+  unsigned long long v[8];
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_watch_ticks), sizeof(v)) != hipSuccess) return -1;
+  for (int i = 0; i < 8; i++) out[i] = v[i];
+  return 0;
+}
 extern "C" int grdma_rx_express_ticks(uint64_t out[9]) {
   unsigned long long v[9];
   if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_rx_express_ticks), sizeof(v)) != hipSuccess) return -1;
@@ -2073,6 +2616,11 @@ extern "C" int grdma_rx_express_ticks(uint64_t out[9]) {
 extern "C" uint64_t grdma_cut_through_drains(void) {
   unsigned long long v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_cut_through_drains), sizeof(v)) != hipSuccess) return 0;
+  return (uint64_t)v;
+}
+extern "C" uint64_t grdma_watch_fast_drains(void) {   /* drains the watchers' single-wave path took (rxw_fast) */
+  unsigned long long v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_watch_fast_drains), sizeof(v)) != hipSuccess) return 0;
   return (uint64_t)v;
 }
 extern "C" uint64_t grdma_express_drains(void) {

@@ -39,6 +39,9 @@ __device__ __forceinline__ void tx_publish(grdma_conn* c, uint64_t tail, uint64_
 // profiling aid: ticks spent in the phases of tx_small_wave (per translation unit; the latency
 // engine's copy is read by grdma_tx_small_ticks)
 static __device__ unsigned long long g_tx_small_ticks[8];
+// profiling aid (grdma_watch_ticks): [0] the 100 MHz clock when the last small send published its arrival report;
+// the watcher that finds it adds [1] += found - published, [2] += drain done - found, [3] += 1, [4] += fire -> body entered
+static __device__ unsigned long long g_watch_ticks[8];
 
 __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t start,
                                               uint64_t byte_idx, uint64_t avail, int lane) {
@@ -213,6 +216,18 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
   GRDMA_WAIT_VMEM();
   const uint64_t tk4 = __builtin_amdgcn_s_memtime();  // (copies acknowledged)
   if (lane == 0) {
+    // The arrival report FIRST (the wave has waited for every copy above): the peer's watcher workgroup (k_watch) polls
+    // this word, and everything below -- plan headers, result block, counters -- is this end's own bookkeeping.  The
+    // release carries the ring bytes out of this L2 (the watcher may sit behind another one).
+    const uint64_t nt = (tail0 + staged) & mask;
+    __hip_atomic_store(&g_watch_ticks[0], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (pre_pw != nullptr) {
+      if (chained) __hip_atomic_store(pre_pw, nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      else __hip_atomic_store(pre_pw, nt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (pre_pl != nullptr) __hip_atomic_store(&pre_pl->wire_tail, nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (lane == 0) {
     grdma_plan* plan = op.plan;
     plan->nsegs = 0;
     plan->ntiles = 0;
@@ -267,13 +282,8 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     r->done = (idx >= op.nslices) ? 1 : 0;
     const uint64_t tk5 = __builtin_amdgcn_s_memtime();  // (bookkeeping stores issued)
     // (the wave has waited for every copy above: the arrival report may go out)
-    {  // tx_publish with the pointers loaded above
+    {  // the rest of tx_publish (the arrival report went out above), with the pointers loaded in front
       const uint64_t partial = connected ? (sent < offered ? 1 : 0) : pre_partial;
-      if (pre_pw != nullptr) {
-        if (chained) __hip_atomic_store(pre_pw, new_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        else __hip_atomic_store(pre_pw, new_tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      if (pre_pl != nullptr) __hip_atomic_store(&pre_pl->wire_tail, new_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (pre_ln != nullptr) {
         __hip_atomic_store(&pre_ln->remote_tail, new_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&pre_ln->partial_write, partial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -199,9 +199,20 @@ class Pair:
         check(self.lib.grdma_pair_set_latency_mode(self.h, int(on)))
 
     def arm_read(self, max_reads=64):
-        """grdma_pair_arm_read: the local peer's small sends carry this pair's drain (0 disarms)."""
+        """grdma_pair_arm_read: a standing read order, carried out by a watcher workgroup of the latency engine when
+        bytes land in this pair's ring (GRDMA_ENGINE_CHAIN=1: by the local peer's small sends); 0 disarms."""
         self.lib.grdma_pair_arm_read.argtypes = [C.c_void_p, C.c_uint64]
         check(self.lib.grdma_pair_arm_read(self.h, int(max_reads)))
+
+    def watch_hits(self):
+        """Completions a watcher workgroup of the engine produced (arrival-triggered drains) that a read has taken."""
+        self.lib.grdma_pair_watch_hits.argtypes = [C.c_void_p]
+        self.lib.grdma_pair_watch_hits.restype = C.c_int64
+        return int(self.lib.grdma_pair_watch_hits(self.h))
+
+    def armed_ready(self):
+        self.lib.grdma_pair_armed_ready.argtypes = [C.c_void_p]
+        return int(self.lib.grdma_pair_armed_ready(self.h))
 
     def armed_hits(self):
         self.lib.grdma_pair_armed_hits.argtypes = [C.c_void_p]

@@ -352,7 +352,9 @@ int grdma_pair_set_latency_mode(grdma_pair* p, int on);
  * completion without a command of its own.  Same bytes, order and state as the two separate calls.
  * max_reads = 0 disarms.  One thread per link. */
 int grdma_pair_arm_read(grdma_pair* p, uint64_t max_reads);
-int64_t grdma_pair_armed_hits(const grdma_pair* p);   /* sends that carried the peer's drain */
+int64_t grdma_pair_armed_hits(const grdma_pair* p);   /* sends that carried the peer's drain (GRDMA_ENGINE_CHAIN=1) */
+int64_t grdma_pair_watch_hits(const grdma_pair* p);   /* completions a watcher workgroup produced and a read took */
+int grdma_engine_watchers(void);                      /* watcher workgroups per engine incarnation (GRDMA_ENGINE_WATCHERS) */
 int grdma_pair_armed_ready(const grdma_pair* p);      /* 1: a completion is waiting (host memory only: no device work) */
 /* Persistent latency engine: one resident workgroup takes the fused Send / drain
  * commands of latency-mode pairs from a mailbox in pinned host memory (a PCIe
@@ -465,6 +467,8 @@ int grdma_pair_debug_hist(grdma_pair* p, uint32_t* hist_out /* 1024 entries */, 
                           uint32_t* period);
 int grdma_engine_debug(uint64_t out[5]);
 uint64_t grdma_express_drains(void);  /* drains served by the single-wave express path so far */
+uint64_t grdma_watch_fast_drains(void);      /* diagnostics: drains the watchers' single-wave path took */
+int grdma_watch_ticks(uint64_t out[8]);      /* profiling aid: 10 ns ticks of the watchers' drains (arrival found, drain done) */
 int grdma_rx_express_ticks(uint64_t out[9]);  /* profiling aid: phase ticks of the express drain (latency engine) */
 uint64_t grdma_cut_through_drains(void);  /* ... of which the records of an armed send + drain command never touched the ring */
 int grdma_tx_fast_sends(uint64_t out[2]);  /* Sends of streaming jobs planned by k_tx_fast [0], left to the general planner [1] (csrc/grdma_tx_fast.h) */

@@ -215,7 +215,7 @@ inline hipError_t hipLaunchKernel(const void* func, dim3 grid, dim3 block, void*
 // which serves a mailbox until the host tells it to leave): it runs in a thread of its own, outside the launch
 // lock, and hipStreamSynchronize on its stream waits for it.
 namespace emu {
-inline bool resident_kernel(const char* name) { return strcmp(name, "k_engine") == 0; }
+inline bool resident_kernel(const char* name) { return strcmp(name, "k_engine") == 0 || strcmp(name, "k_watch") == 0; }
 struct async_table {
   std::mutex mu;
   std::map<hipStream_t, std::thread> running;

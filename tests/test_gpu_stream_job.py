@@ -268,6 +268,10 @@ SENDS_CASES = [
     (1 << 24, 2500, 3000, 100, None),       # tiny messages: 9000 records, the second Send of a round ends the write
                                             # (exact; the predicting drain bodies decline them, as in MULTI_CASES)
     (1 << 22, 700, 40, 1 << 18, False),     # a ring the rounds fill: the second Send is cut by the free space
+    # bench.py's headline configuration itself (`value`): 256 x 1 MiB messages of 130 slices, 256 MiB ring, max_sge
+    # 4095, two Sends per round -- rounds of 63 / 63 / 63 / 63 / 4 messages; a Send is priced with the credits of the
+    # drains two rounds back and three rounds (189 MiB + tags) fit the ring, so the oracle's plain rounds apply
+    (1 << 28, 4095, 256, 1 << 20, True),
 ]
 
 
@@ -420,7 +424,7 @@ def test_many_sends_per_round_priced_as_one_cut_of_the_index_match_the_oracle(gp
 
 
 @pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
-@pytest.mark.parametrize("case", SENDS_CASES, ids=["r128m_sge1023", "r32m_sge4095", "r16m_small", "r4m_ring_limited"])
+@pytest.mark.parametrize("case", SENDS_CASES, ids=["r128m_sge1023", "r32m_sge4095", "r16m_small", "r4m_ring_limited", "r256m_headline"])
 def test_two_sends_per_round_in_one_plan_match_the_oracle(gpu, case, flags):
     """grdma_stream_job_set_sends(2): a round's plan holds two consecutive Sends (rdma_flush's loop while the ring has
     room), priced one after the other from the index by the small planner workgroups (csrc/grdma_tx_multi.h), their

@@ -11,11 +11,13 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180, method="thread")]
 
 
 @pytest.mark.parametrize("sizes", [[14, 66], [14, 600], [9, 2000, 5]], ids=["unary64", "two_records", "beyond_the_fast_lane"])
-def test_armed_reads_ride_in_the_send_command(gpu, sizes):
-    """grdma_pair_arm_read: the drain of the local peer runs behind the send in ONE engine command
+def test_armed_reads_ride_in_the_send_command(gpu, sizes, monkeypatch):
+    """grdma_pair_arm_read under GRDMA_ENGINE_CHAIN=1 (round 4's way; by default a watcher workgroup carries the order
+    out, tests/test_zzz_gpu_watch_read.py): the drain of the local peer runs behind the send in ONE engine command
     (GRDMA_ENGINE_SEND_INLINE_DRAIN); delivered bytes, state and rings are those of the separate commands."""
     g = gpu
     lib = g.load()
+    monkeypatch.setenv("GRDMA_ENGINE_CHAIN", "1")
     slices = [bytes((i * 11 + k) % 253 for i in range(n)) for k, n in enumerate(sizes)]
     total = sum(sizes)
     a, b = mk_link(g, 4 << 20, 30)
@@ -85,6 +87,7 @@ def test_cut_through_commands_leave_the_state_the_two_bodies_leave(gpu, monkeypa
         rounds.append((mk(), mk(), rng.randint(1, 6)))
     rounds.insert(5, ([b"x" * 14, b"y" * 300], [b"z" * 9], 2))      # a record the unary branch does not take
     outcomes = []
+    monkeypatch.setenv("GRDMA_ENGINE_CHAIN", "1")
     for mode in ("1", "0"):
         monkeypatch.setenv("GRDMA_ENGINE_CUT_THROUGH", mode)
         a, b = mk_link(g, 1 << 20, 30)

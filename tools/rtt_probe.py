@@ -16,7 +16,12 @@ def main():
     lib = g.load()
     g.init(0)
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-    armed = len(sys.argv) > 2 and sys.argv[2] == "armed"
+    # "watch": standing reads carried out by the engine's watcher workgroups (the default of grdma_pair_arm_read);
+    # "armed" / "chain": round 4's way, the in-process peer's send command carries the drain (GRDMA_ENGINE_CHAIN=1)
+    mode = sys.argv[2] if len(sys.argv) > 2 else ""
+    if mode in ("armed", "chain"):
+        os.environ["GRDMA_ENGINE_CHAIN"] = "1"
+    armed = mode in ("armed", "chain", "watch")
     msg = bytes([0x0A, 64]) + bytes(range(64))
     items = h2.frame_message(len(msg), 1)
     slices = [i[1] if i[0] == "inl" else msg[i[1][0]:i[1][0] + i[1][1]] for i in items]
@@ -36,7 +41,11 @@ def main():
     lib.grdma_tx_small_ticks(t0)
     x0 = (C.c_uint64 * 9)()
     lib.grdma_rx_express_ticks(x0)
+    w0 = (C.c_uint64 * 8)()
+    lib.grdma_watch_ticks(w0)
     rtt, ph = g.pingpong(a, b, slices, slices, iters=iters, warmup=0)
+    w1 = (C.c_uint64 * 8)()
+    lib.grdma_watch_ticks(w1)
     x1 = (C.c_uint64 * 9)()
     lib.grdma_rx_express_ticks(x1)
     e1 = (C.c_uint64 * 5)()
@@ -44,7 +53,11 @@ def main():
     lib.grdma_engine_debug(e1)
     lib.grdma_tx_small_ticks(t1)
     rtt.sort()
-    print("rtt p50 %.2f us  p95 %.2f  (%d round trips%s)" % (rtt[len(rtt) // 2] / 1e3, rtt[int(len(rtt) * .95)] / 1e3, iters, ", armed reads" if armed else ""))
+    print("rtt p50 %.2f us  p95 %.2f  (%d round trips%s)" % (rtt[len(rtt) // 2] / 1e3, rtt[int(len(rtt) * .95)] / 1e3, iters,
+                                                            ", reads: " + mode if armed else ""))
+    if armed:
+        print("watch hits %d / %d, armed hits %d / %d, watcher workgroups %d" % (a.watch_hits(), b.watch_hits(), a.armed_hits(), b.armed_hits(),
+                                                                             lib.grdma_engine_watchers()))
     print("host phases us: client write %.2f, server read %.2f, server write %.2f, client read %.2f" % tuple(p / 1e3 / iters for p in ph))
     de = [int(e1[i]) - int(e0[i]) for i in range(5)]
     print("engine ticks per round trip: odd-type commands load %d body %d; even-type commands load %d body %d" % tuple(x // iters for x in de[:4]))
@@ -57,6 +70,10 @@ def main():
         names = ["state loaded", "records known", "payload loaded", "stores issued", "stores acknowledged", "commit: counters loaded",
                  "commit: stores issued", "released"]
         print("express drain, ticks per drain (%d drains): " % nx + ", ".join("%s %d" % (names[i], (int(x1[i]) - int(x0[i])) // nx) for i in range(8)))
+    nw = int(w1[3]) - int(w0[3])
+    if nw:
+        print("watchers, us per drain (%d drains): arrival report published -> found %.2f, found -> plan body entered %.2f, found -> drain done %.2f" % (
+            nw, (int(w1[1]) - int(w0[1])) / nw / 100.0, (int(w1[4]) - int(w0[4])) / nw / 100.0, (int(w1[2]) - int(w0[2])) / nw / 100.0))
 
 
 if __name__ == "__main__":
