@@ -45,6 +45,10 @@ class Config(C.Structure):
 # test can walk it against include/grdma_amd.h.
 SIGNATURES = {
     "grdma_abi_version": (C.c_int, []),
+    "grdma_pair_watch_hits": (C.c_int64, [C.c_void_p]),
+    "grdma_engine_watchers": (C.c_int, []),
+    "grdma_watch_fast_drains": (u64, []),
+    "grdma_watch_ticks": (C.c_int, [C.POINTER(u64)]),
     "grdma_parse_platform": (C.c_int, [C.c_char_p]),
     "grdma_determine_platform": (C.c_int, []),
     "grdma_config_from_env": (C.c_int, [C.POINTER(Config)]),

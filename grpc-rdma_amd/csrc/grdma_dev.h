@@ -151,6 +151,10 @@ struct grdma_conn {
                                         // places bytes in order, footer last (a NIC)
   uint32_t line_remote;                 // 1: nobody pushes wire_tail / remote_head / peer_exit into my line
                                         // (the peer is another process): k_poll's refresh pass copies them
+  uint32_t peer_limited;                // 1: the peer's reader is known never to walk past my arrival report (its
+                                        // wire_limit is set: a peer in this process) -- the footer of a record I write
+                                        // needs no place of its own behind the record's bytes; 0: footers last
+  uint32_t pad4;
 };
 
 struct grdma_seg {

@@ -30,6 +30,14 @@
 #endif
 
 
+// Profiling stamps of the latency paths (bit 16 of grdma_tx_op::inline_copy / grdma_rx_op::inline_apply, bit 2 of the
+// resident kernels' flags; host: GRDMA_PROFILE_TICKS=1).  Off by default: the clocks are scalar-memory reads that
+// return out of order with LDS traffic -- a wait for an LDS word behind one waits for the clock too -- and a dozen of
+// them cost the 64-byte round trip two microseconds (profiles/r05_rtt_notes.txt).
+__device__ __forceinline__ uint64_t prof_time(bool on) { return on ? __builtin_amdgcn_s_memtime() : 0ull; }
+__device__ __forceinline__ uint64_t prof_realtime(bool on) { return on ? __builtin_amdgcn_s_memrealtime() : 0ull; }
+#define GRDMA_OP_PROFILE 16u
+
 __device__ __forceinline__ uint64_t round_up8(uint64_t v) { return (v + 7ull) & ~7ull; }
 __device__ __forceinline__ uint64_t round_down8(uint64_t v) { return v & ~7ull; }
 __device__ __forceinline__ uint64_t enc_size(uint64_t pay) { return 16ull + round_up8(pay); }

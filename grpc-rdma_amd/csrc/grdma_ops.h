@@ -151,14 +151,22 @@ struct grdma_engine_cmd {
 // (grdma_engine_mbox::consumed, mirrored into the slot by the command workgroup's doorbell poll).
 #define GRDMA_WATCH_SLOTS 64
 #define GRDMA_WATCH_MAX_GROUPS 8
+#define GRDMA_WATCH_WINDOWS 8
+// The word the host publishes per slot (grdma_engine_mbox::consumed, mirrored into grdma_watch_slot::consumed):
+// completions taken since the arming in the low 56 bits, and in the high byte the WINDOW the next drain delivers into
+// (grdma_watch_slot::win_base: the receive windows of an asynchronous endpoint, or the two halves of a blocking pair's
+// arena -- the slices of the completion just taken stay where they are while the next drain runs).
+#define GRDMA_WATCH_COUNT_MASK 0x00FFFFFFFFFFFFFFull
 struct grdma_watch_slot {         // device memory; one writer per word
   uint64_t gen;                   // command workgroup: != 0 armed (a fresh value per arming), 0 = let go
   uint64_t ack_gen;               // watcher: the generation it has taken over (0: it has let go, nothing in flight)
-  uint64_t consumed;              // command workgroup: completions the host has taken since the arming
+  uint64_t consumed;              // command workgroup: the host's word (above)
   uint64_t done;                  // watcher: completions produced since the arming
-  struct grdma_rx_op op;          // the standing order; op.seq_next = sequence word of the first completion
+  struct grdma_rx_op op;          // the standing order; op.seq_next = sequence word of the first completion,
+                                  // op.arena_cap = bytes of one window (op.arena is not used)
+  uint8_t* win_base[GRDMA_WATCH_WINDOWS];
   uint64_t drains_dbg;            // watcher: drains run for this slot (all armings)
-  uint64_t pad[32 - 5 - sizeof(struct grdma_rx_op) / 8];
+  uint64_t pad[32 - 5 - GRDMA_WATCH_WINDOWS - sizeof(struct grdma_rx_op) / 8];
 };
 struct grdma_watch_ctl {          // device memory
   uint64_t quit;                  // command workgroup: the engine incarnation that has been told to leave
@@ -168,7 +176,9 @@ struct grdma_watch_ctl {          // device memory
 struct grdma_watch_cmd {          // pinned host memory: GRDMA_ENGINE_WATCH
   uint64_t slot;
   uint64_t gen;                   // 0 = let go
+  uint64_t consumed0;             // the host's word at the arming: count 0, the first window
   struct grdma_rx_op op;
+  uint8_t* win_base[GRDMA_WATCH_WINDOWS];
 };
 
 struct grdma_engine_mbox {

@@ -56,7 +56,7 @@ hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_apply(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*, uint64_t*, uint64_t*,
                              hipStream_t);
-hipError_t grdma_launch_engine(grdma_engine_mbox*, grdma_watch_ctl*, uint64_t epoch, hipStream_t);
+hipError_t grdma_launch_engine(grdma_engine_mbox*, grdma_watch_ctl*, uint64_t epoch, uint32_t flags, hipStream_t);
 hipError_t grdma_launch_watch(grdma_engine_mbox*, grdma_watch_ctl*, uint64_t epoch, uint32_t groups, uint32_t flags, hipStream_t);
 const void* grdma_kernel_fn(int which);          // 0 tx_plan, 1 copy, 3 rx_apply, 4 tx_plan_seq
 const void* grdma_kernel_fn_rx_plan(void);
@@ -279,7 +279,8 @@ struct grdma_pair {
   uint64_t watch_expect = 0, watch_taken = 0, watch_hits = 0;
   uint64_t armed_half = 0;           // which half of the arena the completion `armed_done` stands for lies in (a
                                      // watcher's completion that was left behind when its order was taken back)
-  int watch_window = -1;             // asynchronous endpoint: the receive window the standing order writes into
+  bool watch_parked = false;         // asynchronous endpoint: the last completion was taken while the transport held
+                                     // every other window -- the watcher waits for the word that names the next one
   // asynchronous endpoint operations (grdma_endpoint_set_async): the send and the receive direction on streams of
   // their own, one Send and one drain in flight at most, completions in pinned host memory
   bool async = false;
@@ -458,6 +459,14 @@ int stage_slices(grdma_pair* p, const grdma_slice* slices, uint64_t count, uint6
   return 0;
 }
 
+// GRDMA_PROFILE_TICKS=1: the latency paths take their phase stamps (grdma_tx_small_ticks, grdma_rx_express_ticks,
+// grdma_watch_ticks, grdma_engine_debug); read once per process.
+inline bool profile_ticks() {
+  static const bool on = [] { const char* e = getenv("GRDMA_PROFILE_TICKS"); return e && atoi(e) != 0; }();
+  return on;
+}
+inline uint32_t latency_op_bits() { return 1u | (profile_ticks() ? 16u : 0u); }
+
 // Watcher workgroups per engine incarnation (GRDMA_ENGINE_WATCHERS, 1 .. 8; slot s is served by workgroup s % n).
 uint32_t engine_watch_groups() {
 #ifdef GRDMA_WAVE_EMU
@@ -495,10 +504,12 @@ int engine_launch() {
   e.mb->exit_flag = 0;
   const uint64_t epoch = ++e.epoch;
   std::atomic_thread_fence(std::memory_order_seq_cst);
-  HIP_TRY(grdma_launch_engine(e.mb, e.d_watch, epoch, e.stream));
-  // (GRDMA_WATCH_FAST=0: every drain of a watcher through the plan body -- the A/B of tests/test_zzz_gpu_watch_read.py)
+  // (GRDMA_WATCH_FAST=0: every drain of a watcher through the plan body -- the A/B of tests/test_zzz_gpu_watch_read.py;
+  //  GRDMA_PROFILE_TICKS=1: the phase stamps of the latency paths, off by default -- see prof_time in grdma_devfn.h)
   const char* wf = getenv("GRDMA_WATCH_FAST");
-  HIP_TRY(grdma_launch_watch(e.mb, e.d_watch, epoch, e.groups, (wf && atoi(wf) == 0) ? 0u : 1u, e.wstream));
+  const uint32_t kflags = ((wf && atoi(wf) == 0) ? 0u : 1u) | (profile_ticks() ? 2u : 0u);
+  HIP_TRY(grdma_launch_engine(e.mb, e.d_watch, epoch, kflags, e.stream));
+  HIP_TRY(grdma_launch_watch(e.mb, e.d_watch, epoch, e.groups, kflags, e.wstream));
   const auto t0 = std::chrono::steady_clock::now();
   auto up = [&] {
     if (!*alive) return false;
@@ -601,15 +612,61 @@ void fill_rxop(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_r
 
 // The standing order of `p` as its watcher runs it: grdma_endpoint_read(max_reads) into the pinned arena, the sequence
 // word continuing where the pair's result block stands.  engine.mu held; nothing of this pair's drains is in flight.
-void watch_fill_cmd(grdma_pair* p, uint32_t sidx, grdma_watch_cmd* cmd) {
-  fill_rxop(p, p->h_arena, p->h_arena_cap, p->armed_reads, 0);
+// Asynchronous endpoint, standing order posted, the last completion taken: name the window the next drain delivers
+// into -- the word the watcher is waiting for -- once the transport has let one go.  p->rx_mu held.
+void watch_unpark(grdma_pair* p) {
+  if (!p->watch_parked || p->watch_slot < 0 || p->watch_expect == 0) return;
+  int w = -1;
+  for (size_t i = 0; i < p->windows.size() && i < GRDMA_WATCH_WINDOWS; i++)
+    if (p->windows[i]->refs.load(std::memory_order_acquire) == 1) { w = (int)i; break; }
+  if (w < 0) return;
+  p->rx_expect.store(p->watch_expect, std::memory_order_relaxed);
+  p->rx_by_engine.store(1, std::memory_order_relaxed);
+  p->rx_inflight.store(w, std::memory_order_release);
+  p->watch_parked = false;
+  __atomic_store_n(&g_engine.mb->consumed[p->watch_slot], p->watch_taken | ((uint64_t)w << 56), __ATOMIC_RELEASE);
+}
+
+// false: not now (an asynchronous endpoint whose windows are all held by the transport, or with a drain of its own
+// still in flight) -- the order stays pending and is tried again with the next command / arming.
+bool watch_fill_cmd(grdma_pair* p, uint32_t sidx, grdma_watch_cmd* cmd) {
+  memset(cmd->win_base, 0, sizeof(cmd->win_base));
+  int w0 = 0;
+  std::unique_lock<std::mutex> rxl(p->rx_mu, std::defer_lock);
+  if (p->async) {
+    // the standing order is "a drain in flight" to the endpoint (grdma_endpoint_drain_state / _read_test): into the
+    // window named with it, completing by itself when bytes land
+    if (!rxl.try_lock()) return false;   // (the endpoint's reading thread is submitting or taking a drain right now)
+    if (p->rx_inflight.load(std::memory_order_acquire) >= 0) return false;
+    w0 = -1;
+    for (size_t i = 0; i < p->windows.size() && i < GRDMA_WATCH_WINDOWS; i++) {
+      cmd->win_base[i] = p->windows[i]->base;
+      if (w0 < 0 && p->windows[i]->refs.load(std::memory_order_acquire) == 1) w0 = (int)i;
+    }
+    if (w0 < 0) return false;
+    fill_rxop(p, p->windows[w0]->base, p->windows[w0]->bytes, p->armed_reads, 0);
+  } else {
+    // (a blocking pair: the two halves of its pinned arena take turns, so that the slices of the completion just
+    //  taken stay where they are while the next drain delivers)
+    cmd->win_base[0] = p->h_arena;
+    cmd->win_base[1] = p->h_arena + p->h_arena_cap;
+    fill_rxop(p, p->h_arena, p->h_arena_cap, p->armed_reads, 0);
+  }
   cmd->slot = sidx;
   cmd->gen = ++g_engine.gen;
   cmd->op = p->h->rxop;
-  cmd->op.inline_apply = 1u | 8u;  // (8: a watcher's drain -- rx_plan_body reads the ring past the caches)
+  cmd->op.inline_apply = latency_op_bits() | 8u;  // (8: a watcher's drain -- rx_plan_body reads the ring past the caches)
+  cmd->consumed0 = (uint64_t)w0 << 56;
   p->watch_expect = cmd->op.seq_next;
   p->watch_taken = 0;
-  *(volatile uint64_t*)&g_engine.mb->consumed[sidx] = 0;
+  p->watch_parked = false;
+  *(volatile uint64_t*)&g_engine.mb->consumed[sidx] = cmd->consumed0;
+  if (p->async) {
+    p->rx_expect.store(cmd->op.seq_next, std::memory_order_relaxed);
+    p->rx_by_engine.store(1, std::memory_order_relaxed);
+    p->rx_inflight.store(w0, std::memory_order_release);
+  }
+  return true;
 }
 
 // Standing orders that have not reached their device slot yet (armed before the engine was started, or cleared
@@ -621,7 +678,10 @@ int watch_flush_locked() {
   for (uint32_t sidx = 0; sidx < GRDMA_WATCH_SLOTS; sidx++) {
     grdma_pair* p = e.slot_owner[sidx];
     if (!p || e.slot_posted[sidx]) continue;
-    watch_fill_cmd(p, sidx, e.h_wcmd);
+    if (!watch_fill_cmd(p, sidx, e.h_wcmd)) {
+      e.watch_dirty = true;   // (not now: tried again with the next command)
+      continue;
+    }
     if (int rc = engine_post_locked(GRDMA_ENGINE_WATCH, e.h_wcmd)) return rc;
     if (int rc = engine_wait_locked(e.posted)) return rc;
     e.slot_posted[sidx] = true;
@@ -697,6 +757,10 @@ int engine_stop() {
         p->armed_done = true;
       }
     }
+    if (p && p->async && e.slot_posted[sidx] && p->rx_inflight.load() >= 0 &&
+        __atomic_load_n(&p->h->rxres.seq, __ATOMIC_ACQUIRE) < p->rx_expect.load())
+      p->rx_inflight.store(-1);   // (the standing order leaves with the engine; a completion that is there stays)
+    if (p && p->async) p->armed_done = false;
     if (p) p->watch_expect = 0;
     e.slot_posted[sidx] = false;
     if (p) e.watch_dirty = true;
@@ -767,7 +831,7 @@ int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_curs
   h->txop.wire_plan = p->d_wireplan;
   h->txop.result = &h->txres;
   h->txop.use_cursor = use_cursor;
-  h->txop.inline_copy = p->latency ? 1 : 0;
+  h->txop.inline_copy = p->latency ? latency_op_bits() : 0;
   h->txop.seq_next = p->latency ? h->txres.seq + 1 : 0;
   const uint32_t blocks = copy_blocks_for(p->ring_size / 2);
   if (p->latency) {
@@ -843,7 +907,7 @@ void fill_rxop(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_r
   h->rxop.raw_cap = raw_cap;
   h->rxop.append = 0;
   h->rxop.slices_cap = GRDMA_MAX_SLICES;
-  h->rxop.inline_apply = p->latency ? 1 : 0;
+  h->rxop.inline_apply = p->latency ? latency_op_bits() : 0;
   h->rxop.seq_next = p->latency ? h->rxres.seq + 1 : 0;
   h->rxop.limit_ptr = nullptr;
   h->rxop.sizes_in = nullptr;
@@ -1177,6 +1241,7 @@ int grdma_pair_connect(grdma_pair* a, grdma_pair* b) {
                                               offsetof(grdma_conn, wire_recv) + offsetof(grdma_wire_report, wire_tail));
     c.peer_line = other->line;  // both ends in this process: the kernels push into each other's state line
     c.line_remote = 0;
+    c.peer_limited = (other->flags & GRDMA_WIRE_ORDERED) ? 0 : 1;
     c.status = GRDMA_PAIR_CONNECTED;
     HIP_TRY(hipMemcpy(me->d_conn, &c, sizeof(c), hipMemcpyHostToDevice));
     me->status.store(GRDMA_PAIR_CONNECTED);
@@ -1283,6 +1348,7 @@ int grdma_pair_connect_remote(grdma_pair* p, const grdma_bootstrap_blob* peer) {
                                               offsetof(grdma_wire_report, wire_tail));
     c.peer_line = other->line;
     c.line_remote = 0;
+    c.peer_limited = (other->flags & GRDMA_WIRE_ORDERED) ? 0 : 1;
     c.status = GRDMA_PAIR_CONNECTED;
     HIP_TRY(hipMemcpy(p->d_conn, &c, sizeof(c), hipMemcpyHostToDevice));
     p->peer = other;
@@ -1312,6 +1378,7 @@ int grdma_pair_connect_remote(grdma_pair* p, const grdma_bootstrap_blob* peer) {
   c.peer_wire = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(conn) + peer->wire_off + offsetof(grdma_wire_report, wire_tail));
   c.peer_line = nullptr;  // pinned host memory of another process is out of reach:
   c.line_remote = 1;      // my line is refreshed from my own connection block (k_poll's refresh pass)
+  c.peer_limited = 0;     // (the address blob does not say how the peer reads: footers last)
   c.status = GRDMA_PAIR_CONNECTED;
   HIP_TRY(hipMemcpy(p->d_conn, &c, sizeof(c), hipMemcpyHostToDevice));
   p->peer_pid = peer->pid;
@@ -1914,24 +1981,36 @@ int grdma_pair_arm_read(grdma_pair* p, uint64_t max_reads) {
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
   if (max_reads && !p->latency) return fail(GRDMA_ERR_INVALID, "armed reads need latency mode");
   if (max_reads > GRDMA_MAX_SLICES) max_reads = GRDMA_MAX_SLICES;
-  if (p->async) {  // the standing order of an asynchronous endpoint (submit_send of the peer honours it)
-    p->armed_async.store(max_reads, std::memory_order_release);
-    return 0;
-  }
   if (engine_chain_mode() && p->watch_slot < 0) {  // (round 4's way: the in-process peer's send command carries the drain)
-    p->armed_reads = max_reads;
+    if (p->async) p->armed_async.store(max_reads, std::memory_order_release);
+    else p->armed_reads = max_reads;
     return 0;
   }
   grdma_engine& e = g_engine;
+  // (the endpoint arms before every wait: nothing to do when the order stands)
+  if (p->watch_slot >= 0 && max_reads == p->armed_reads && !e.watch_dirty && !p->watch_parked) return 0;
   std::lock_guard<std::mutex> lk(e.mu);
+  if (p->watch_slot >= 0 && max_reads == p->armed_reads) {
+    if (p->watch_parked) {
+      std::lock_guard<std::mutex> rl(p->rx_mu);
+      watch_unpark(p);
+    }
+    if (e.wanted && e.watch_dirty) {
+      if (int rc = engine_launch()) return rc;
+      if (int rc = watch_flush_locked()) return rc;
+    }
+    return 0;
+  }
   if (p->watch_slot >= 0 && (max_reads == 0 || max_reads != p->armed_reads)) {
     // back from the watcher; a completion it produced and nobody has taken stays for the next grdma_endpoint_read
     // (watch_expect is non-zero exactly while the order sits in its device slot)
     int rc = watch_release_locked(p);
-    if (p->watch_expect != 0 && __atomic_load_n(&p->h->rxres.seq, __ATOMIC_ACQUIRE) >= p->watch_expect) {
+    if (!p->async && p->watch_expect != 0 && __atomic_load_n(&p->h->rxres.seq, __ATOMIC_ACQUIRE) >= p->watch_expect) {
       p->armed_half = p->watch_taken & 1;
       p->armed_done = true;
     }
+    if (p->async && p->rx_inflight.load() >= 0 && __atomic_load_n(&p->h->rxres.seq, __ATOMIC_ACQUIRE) < p->rx_expect.load())
+      p->rx_inflight.store(-1);   // (the standing order is withdrawn; a completion that is there stays to be taken)
     p->watch_slot = -1;
     p->watch_expect = 0;
     if (rc) return rc;
@@ -2141,7 +2220,8 @@ int64_t grdma_endpoint_read(grdma_pair* p, uint64_t max_reads, grdma_read_slice*
     // taken: the watcher may run the next drain (it overwrites result block, slice table and arena)
     p->watch_expect++;
     p->watch_hits++;
-    __atomic_store_n(&g_engine.mb->consumed[p->watch_slot], ++p->watch_taken, __ATOMIC_RELEASE);
+    ++p->watch_taken;   // (the next drain delivers into the other half of the arena)
+    __atomic_store_n(&g_engine.mb->consumed[p->watch_slot], p->watch_taken | ((p->watch_taken & 1) << 56), __ATOMIC_RELEASE);
   }
   return (int64_t)n;
 }
@@ -2218,7 +2298,7 @@ int submit_send(grdma_pair* p, uint64_t count, uint64_t byte_idx) {
   h->txop.wire_plan = p->d_wireplan;
   h->txop.result = &h->txres;
   h->txop.use_cursor = 0;
-  h->txop.inline_copy = p->latency ? 1 : 0;
+  h->txop.inline_copy = p->latency ? latency_op_bits() : 0;
   h->txop.seq_next = p->latency ? h->txres.seq + 1 : 0;
   if (p->latency && g_engine.wanted) {
     p->tx_by_engine = true;
@@ -2531,6 +2611,11 @@ int grdma_endpoint_read_submit(grdma_pair* p, uint64_t max_reads) {
   // A drain is in flight already: the in-process peer's sender may have posted this pair's ARMED drain between the
   // caller's look at grdma_endpoint_drain_state and this call.  Not an error -- the readable edge comes when it is done.
   if (p->rx_inflight.load(std::memory_order_acquire) >= 0) return 0;
+  if (p->watch_slot >= 0 && p->watch_expect != 0 && g_engine.wanted) {
+    // the standing order is with a watcher and parked for want of a window: name one, or report that none is free
+    watch_unpark(p);
+    return p->watch_parked ? 1 : 0;
+  }
   int w = -1;
   for (size_t i = 0; i < p->windows.size(); i++)
     if (p->windows[i]->refs.load(std::memory_order_acquire) == 1) { w = (int)i; break; }
@@ -2611,6 +2696,18 @@ int64_t grdma_endpoint_read_test(grdma_pair* p, grdma_read_slice* slices, uint64
   win->refs.fetch_add(1, std::memory_order_relaxed);  // the caller's reference
   *window = win;
   const int64_t n = (int64_t)r.nslices;
+  if (p->watch_slot >= 0 && p->watch_expect != 0 && p->rx_by_engine.load() && p->rx_expect.load() == p->watch_expect) {
+    // a completion of the standing order (k_watch): the order goes on -- into the next free window, named to the
+    // watcher with the count of completions taken; none free: parked until the transport lets one go
+    std::lock_guard<std::mutex> rl(p->rx_mu);
+    p->watch_expect++;
+    p->watch_taken++;
+    p->watch_hits++;
+    p->rx_inflight.store(-1, std::memory_order_release);
+    p->watch_parked = true;
+    watch_unpark(p);
+    return n;
+  }
   p->rx_inflight.store(-1, std::memory_order_release);
   return n;
 }
@@ -2632,7 +2729,10 @@ int grdma_endpoint_drain_state(grdma_pair* p) {
 // that wants to run a connection to quiescence waits for (the edges themselves are grdma_endpoint_readable / _writable)
 int grdma_endpoint_busy(grdma_pair* p) {
   if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
-  if (p->rx_inflight.load(std::memory_order_acquire) >= 0 && !drain_complete(p)) return 1;
+  // (a standing order waiting for bytes is not work in progress)
+  const bool standing = p->watch_slot >= 0 && p->watch_expect != 0 && p->rx_expect.load() == p->watch_expect &&
+                        grdma_pair_has_message(p) <= 0;
+  if (p->rx_inflight.load(std::memory_order_acquire) >= 0 && !drain_complete(p) && !standing) return 1;
   if (p->tx_inflight.load(std::memory_order_acquire)) {
     const uint64_t seen = p->tx_by_engine ? __atomic_load_n(&p->h->txres.seq, __ATOMIC_ACQUIRE)
                                           : __atomic_load_n(&p->line->tx_seq, __ATOMIC_ACQUIRE);

@@ -284,7 +284,10 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
   // (a private copy: fields read through the reference would be re-fetched from memory
   // after every store the compiler cannot prove unrelated)
   const grdma_rx_op op = op_in;
-  const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+  // (the stamps of the launch-chain paths are always taken -- the result block's dbg words, hundreds of microseconds
+  //  of work behind them; the latency path's only when asked for: prof_time)
+  const bool prof = !op.inline_apply || (op.inline_apply & GRDMA_OP_PROFILE) != 0;
+  const uint64_t t_begin = prof_time(prof);
   const unsigned tid = threadIdx.x;
   const int lane = tid & 63;
   const unsigned wave = tid >> 6;
@@ -367,7 +370,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
   if (op.inline_apply && op.raw_cap == 0 && !op.append && connected && wave == 0 && c->remain == 0 &&
       max_slices >= 1) {
     const uint64_t head0 = c->head, leftover0 = c->leftover_cap, irs0 = c->internal_read_size;
-    const uint64_t te_a = __builtin_amdgcn_s_memtime() + (head0 & 0);  // (state loaded)
+    const uint64_t te_a = prof_time(prof) + (head0 & 0);  // (state loaded)
     // (inline_apply bit 2, an engine command's armed drain: the records are the ones the send of the same command
     //  produced -- their sizes in LDS, grdma_ct_hint -- and, cut through, they are not in the ring at all)
     const grdma_ct_hint* cth = (op.inline_apply & 2u) ? reinterpret_cast<const grdma_ct_hint*>(op.sizes_in) : nullptr;
@@ -384,7 +387,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
       v = chain_round(&w, s_chain, lane);
       all_seen = w.dry && v <= EXPRESS_MAX;
     }
-    const uint64_t te_b = __builtin_amdgcn_s_memtime() + (v & 0);  // (records known)
+    const uint64_t te_b = prof_time(prof) + (v & 0);  // (records known)
     const uint32_t n = ((uint32_t)lane < v && all_seen) ? (uint32_t)s_chain[lane] : 0;
     const uint32_t enc = ((uint32_t)lane < v && all_seen) ? 16u + (uint32_t)round_up8(n) : 0;
     const uint32_t i_n = wave_incl_scan_u32(n), i_enc = wave_incl_scan_u32(enc);
@@ -448,7 +451,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
         bytes[q] = b < T ? gring[(head0 + src_off[q]) & mask] : (uint8_t)0;
       }
       }
-      const uint64_t te_c = __builtin_amdgcn_s_memtime() + (bytes[0] & 0);  // (payload loaded)
+      const uint64_t te_c = prof_time(prof) + (bytes[0] & 0);  // (payload loaded)
       // one 8-byte store per lane (the slice buffer is 16-byte aligned and `alloc` bytes long;
       // the bytes behind the slice end inside the last word are written as zero)
       if (split) {  // (byte stores: the second slice starts at a 16-byte boundary of its own)
@@ -525,9 +528,9 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
         atomicAdd(&g_express_drains, 1ull);
         if (cut_through) atomicAdd(&g_cut_through_drains, 1ull);
       }
-      const uint64_t te_d = __builtin_amdgcn_s_memtime();  // (stores issued)
+      const uint64_t te_d = prof_time(prof);  // (stores issued)
       GRDMA_WAIT_VMEM();
-      if (lane == 0) {
+      if (lane == 0 && prof) {
         const uint64_t te_e = __builtin_amdgcn_s_memtime();
         g_rx_express_ticks[0] += te_a - t_begin;
         g_rx_express_ticks[1] += te_b - te_a;
@@ -1461,7 +1464,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
     const uint64_t o_total_read = pre_total_read, o_credit_msgs = pre_credit_msgs;
     const uint64_t o_rx_records = pre_rx_records, o_rx_rounds = pre_rx_rounds;
     const uint64_t o_slice_idx = op.append == 1 ? c->rx_slice_idx : 0;
-    const uint64_t te_f = __builtin_amdgcn_s_memtime() + ((o_total_read + o_rx_rounds) & 0);  // (counters loaded)
+    const uint64_t te_f = prof_time(prof) + ((o_total_read + o_rx_rounds) & 0);  // (counters loaded)
     // The connection block's own fields: nobody but the next drain of this connection -- this workgroup again, or a
     // kernel behind a boundary -- reads them, so on the latency path (inline_apply) they are stored BEHIND the sequence
     // word the host is waiting for; the launch-chain paths keep them in front of the result block.
@@ -1546,11 +1549,11 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
       __hip_atomic_store(&res->commit_seq, op.seq_next ? op.seq_next : res->commit_seq + 1, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    const uint64_t te_g = __builtin_amdgcn_s_memtime();  // (commit stores issued)
+    const uint64_t te_g = prof_time(prof);  // (commit stores issued)
     __hip_atomic_store(&res->seq, op.seq_next ? op.seq_next : res->seq + 1, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
     if (op.inline_apply) commit_conn();
-    if (express) {
+    if (express && prof) {
       const uint64_t te_h = __builtin_amdgcn_s_memtime();
       g_rx_express_ticks[5] += te_f - s_dbg[15];
       g_rx_express_ticks[6] += te_g - te_f;
@@ -1908,7 +1911,8 @@ __device__ __forceinline__ bool engine_cut_through_ok(const grdma_engine_cmd& bl
 // host sets exit_flag.
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch) {
+void k_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_t flags) {
+  const bool prof = (flags & 2u) != 0;
   __shared__ uint64_t s_cmd[4];
   __shared__ uint64_t s_wcmd[sizeof(grdma_watch_cmd) / 8];
   __shared__ uint64_t s_fast[GRDMA_FAST_WORDS];
@@ -1918,7 +1922,7 @@ void k_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch) {
   // resume after the last command a previous incarnation completed
   uint64_t last = __hip_atomic_load(&mb->ack_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
   uint64_t my_consumed = ~0ull;  // (wave 0, lane = watch slot: what this incarnation has mirrored of mb->consumed)
-  uint64_t prof[4] = {mb->pad1[0], mb->pad1[1], mb->pad1[2], mb->pad1[3]};  // (thread 0's running totals, see the acknowledgement)
+  uint64_t ptot[4] = {mb->pad1[0], mb->pad1[1], mb->pad1[2], mb->pad1[3]};  // (thread 0's running totals, see the acknowledgement)
   static_assert(GRDMA_WATCH_SLOTS == 64, "one lane of the doorbell wave per watch slot");
   if (threadIdx.x == 0) {
     __hip_atomic_store(&mb->alive, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1989,7 +1993,9 @@ void k_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch) {
     __syncthreads();
     if (quit) break;
     last = seq;
-    const uint64_t te0 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && prof)  // (profiling aid, grdma_watch_ticks)
+      __hip_atomic_store(&g_watch_ticks[8], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t te0 = prof_time(prof);
     uint64_t te1 = te0;
     if (opp == 0) {
       // malformed doorbell: acknowledge and keep serving
@@ -2009,10 +2015,13 @@ void k_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch) {
         // (what this workgroup's own drains have left of the connection's state reaches memory before the watcher,
         //  on another CU and possibly behind another L2, takes the connection over)
         if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (threadIdx.x < sizeof(grdma_rx_op) / 8)
-          __hip_atomic_store(reinterpret_cast<uint64_t*>(&sl->op) + threadIdx.x, s_wcmd[2 + threadIdx.x], __ATOMIC_RELAXED,
+        static_assert(offsetof(grdma_watch_cmd, op) == 24 && offsetof(grdma_watch_cmd, win_base) == 24 + sizeof(grdma_rx_op) &&
+                      offsetof(grdma_watch_slot, win_base) == offsetof(grdma_watch_slot, op) + sizeof(grdma_rx_op),
+                      "order and windows are copied as one run of words");
+        if (threadIdx.x < sizeof(grdma_rx_op) / 8 + GRDMA_WATCH_WINDOWS)
+          __hip_atomic_store(reinterpret_cast<uint64_t*>(&sl->op) + threadIdx.x, s_wcmd[3 + threadIdx.x], __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_SYSTEM);
-        if (threadIdx.x == 64) __hip_atomic_store(&sl->consumed, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 64) __hip_atomic_store(&sl->consumed, s_wcmd[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (threadIdx.x == 65) __hip_atomic_store(&sl->done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         GRDMA_WAIT_VMEM();
         __syncthreads();
@@ -2057,7 +2066,7 @@ void k_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch) {
           dst[i] = __builtin_nontemporal_load(src + i);
       }
       __syncthreads();
-      te1 = __builtin_amdgcn_s_memtime();
+      te1 = prof_time(prof);
       bool chained = false;
       if (type != GRDMA_ENGINE_DRAIN_BLOCK) {
         if (threadIdx.x < GRDMA_CMD_MAX_SGES)
@@ -2083,10 +2092,10 @@ void k_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch) {
             s_cth.count = 0;
             s_cth.cut_through = ct ? 1u : 0u;
             s_cth.src = s_blk.sges[0].ptr;
-            s_blk.tx.inline_copy = 1u | (ct ? 2u : 0u) | 4u;
+            s_blk.tx.inline_copy = (s_blk.tx.inline_copy & GRDMA_OP_PROFILE) | 1u | (ct ? 2u : 0u) | 4u;
             s_blk.tx.sizes_out = reinterpret_cast<grdma_size_hint*>(&s_cth);
             s_blk.rx.sizes_in = reinterpret_cast<const grdma_size_hint*>(&s_cth);
-            s_blk.rx.inline_apply = 1u | 2u;
+            s_blk.rx.inline_apply = (s_blk.rx.inline_apply & GRDMA_OP_PROFILE) | 1u | 2u;
           }
           __syncthreads();
         }
@@ -2108,12 +2117,14 @@ void k_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch) {
       // per type -- running totals kept in registers and STORED (a `+=` on the mailbox is a PCIe read in front of
       // every acknowledgement: 1.5 us per command)
       __hip_atomic_store(&mb->ack_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      const uint64_t te2 = __builtin_amdgcn_s_memtime();
-      const int k = (type & 1) ? 0 : 2;
-      prof[k] += te1 - te0;
-      prof[k + 1] += te2 - te1;
-      __hip_atomic_store(&mb->pad1[k], prof[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(&mb->pad1[k + 1], prof[k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (prof) {
+        const uint64_t te2 = __builtin_amdgcn_s_memtime();
+        const int k = (type & 1) ? 0 : 2;
+        ptot[k] += te1 - te0;
+        ptot[k + 1] += te2 - te1;
+        __hip_atomic_store(&mb->pad1[k], ptot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mb->pad1[k + 1], ptot[k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     __syncthreads();
   }
@@ -2179,56 +2190,77 @@ __device__ __forceinline__ void rxw_load(rxw_state* st, grdma_conn* c) {
 __device__ unsigned long long g_watch_fast_drains = 0;
 
 #define RXW_EXT_WORDS 128   // the bytes one drain of this path looks at: 1 KiB
-__device__ __forceinline__ bool rxw_fast(rxw_state* st, const grdma_rx_op* opp, uint64_t done, uint64_t wt, int lane,
-                                         uint64_t* s_ext /* [RXW_EXT_WORDS + 8] */) {
-  const uint64_t cap = st->cap, mask = cap - 1, head0 = st->head;
+__device__ __forceinline__ bool rxw_fast(rxw_state* __restrict__ st, const grdma_rx_op* __restrict__ opp, uint64_t done, uint64_t wt,
+                                         uint8_t* dst, int lane, uint64_t* __restrict__ s_ext /* [RXW_EXT_WORDS + 8 + 66] */, uint64_t t_found, bool prof) {
+  // Everything this drain needs of the state and the order, out of LDS in ONE batch of reads in front of the first LDS
+  // store (a read behind a store to LDS the compiler cannot tell apart from it waits for it: fifty waits in the first
+  // version of this function, profiles/r05_rtt_notes.txt).
+  const rxw_state S0 = *st;
+  const grdma_rx_op op = *opp;
+  auto rfl = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+  const uint64_t cap = S0.cap, mask = cap - 1, head0 = S0.head;
   const uint64_t E = (wt - head0) & mask;
-  if (!st->limited || !st->connected || st->remain != 0 || E == 0 || E > RXW_EXT_WORDS * 8 || (E & 7) != 0 || cap < 2048) return false;
-  const grdma_rx_op& op = *opp;
+  if (!S0.limited || !S0.connected || S0.remain != 0 || E == 0 || E > RXW_EXT_WORDS * 8 || (E & 7) != 0 || cap < 2048) return false;
   if (op.raw_cap != 0 || op.append != 0 || op.max_reads < 1) return false;
-  uint8_t* const ring = st->ring;
-  // ---- one round trip: every word of [head, head + E) ----------------------------------------------------------
-  const uint32_t nw = (uint32_t)(E >> 3);
+  uint8_t* const ring = S0.ring;
+  // ---- one round trip: every word of [head, head + E), lane l holds words l and l + 64 --------------------------
+  const uint32_t E32 = rfl((uint32_t)E), nw = E32 >> 3;
   uint64_t w0 = 0, w1 = 0;
   if ((uint32_t)lane < nw)
     w0 = __hip_atomic_load(reinterpret_cast<const uint64_t*>(ring + ((head0 + 8ull * lane) & mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if ((uint32_t)lane + 64u < nw)
+  if (nw > 64 && (uint32_t)lane + 64u < nw)
     w1 = __hip_atomic_load(reinterpret_cast<const uint64_t*>(ring + ((head0 + 8ull * (lane + 64)) & mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  s_ext[lane] = w0;
-  s_ext[lane + 64] = w1;
-  GRDMA_WAVE_CONVERGE();
-  // ---- the record chain, walked in LDS (every lane the same walk) ----------------------------------------------
+  const uint64_t t_loaded = prof_realtime(prof) + (w0 & 0);
+  // ---- the record chain, walked across the lanes' registers: the position is a scalar, a word of the extent is two
+  //      v_readlane -- no memory, no LDS ----------------------------------------------------------------------------
+  const uint32_t w0l = (uint32_t)w0, w0h = (uint32_t)(w0 >> 32), w1l = (uint32_t)w1, w1h = (uint32_t)(w1 >> 32);
+  auto word_lo = [&](uint32_t wi) -> uint32_t {   // (wi: scalar)
+    return wi < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)w0l, (int)wi) : (uint32_t)__builtin_amdgcn_readlane((int)w1l, (int)(wi - 64));
+  };
+  auto word_hi = [&](uint32_t wi) -> uint32_t {
+    return wi < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)w0h, (int)wi) : (uint32_t)__builtin_amdgcn_readlane((int)w1h, (int)(wi - 64));
+  };
   constexpr uint32_t RMAX = 8;
-  uint32_t rn[RMAX], rxn[RMAX], rxe[RMAX];   // payload bytes, payload bytes in front, encoded bytes in front
+  uint32_t rn[RMAX];   // payload bytes by record (scalars)
   uint32_t v = 0, pos = 0, T = 0;
   bool ok = true;
 #pragma unroll
   for (uint32_t r = 0; r < RMAX; r++) {
-    rn[r] = 0; rxn[r] = T; rxe[r] = pos;
-    if (ok && pos < (uint32_t)E) {
-      const uint64_t hdr = s_ext[pos >> 3];
-      const uint64_t encr = 16 + round_up8(hdr);
-      if (hdr == 0 || hdr > 512 || pos + encr > E) {
-        ok = false;
-      } else if (s_ext[(pos + 8 + (uint32_t)round_up8(hdr)) >> 3] != GRDMA_FOOTER) {
+    rn[r] = 0;
+    if (ok && pos < E32) {
+      const uint32_t wi = pos >> 3;
+      const uint32_t hlo = word_lo(wi), hhi = word_hi(wi);
+      const uint32_t encr = 16u + ((hlo + 7u) & ~7u);
+      if (hhi != 0 || hlo == 0 || hlo > 512 || pos + encr > E32) {
         ok = false;
       } else {
-        rn[r] = (uint32_t)hdr;
-        T += (uint32_t)hdr;
-        pos += (uint32_t)encr;
-        v = r + 1;
+        const uint32_t fi = (pos + encr - 8) >> 3;
+        if ((word_lo(fi) & word_hi(fi)) != 0xFFFFFFFFu) {
+          ok = false;
+        } else {
+          rn[r] = hlo;
+          T += hlo;
+          pos += encr;
+          v = r + 1;
+        }
       }
     }
   }
-  if (!ok || pos != (uint32_t)E || v == 0 || T > 512) return false;
-  const uint64_t leftover0 = st->leftover, irs0 = st->irs;
+  if (!ok || pos != E32 || v == 0 || T > 512) return false;
+  const uint64_t t_walk = prof_realtime(prof) + (T & 0);
+  const uint64_t leftover0 = S0.leftover, irs0 = S0.irs;
   uint64_t max_slices = GRDMA_MAX_SLICES;
   if (op.max_reads < max_slices) max_slices = op.max_reads;
   const uint32_t n0 = rn[0];
-  uint32_t rem1 = 0;   // what is left of the record in which the open read's last byte falls
+  uint32_t rem1 = 0;   // what is left of the record in which the open read's last byte falls (sizes the second read)
+  if (leftover0 != 0 && leftover0 < T) {
+    uint32_t x = 0;
 #pragma unroll
-  for (uint32_t r = 0; r < RMAX; r++)
-    if (rn[r] != 0 && leftover0 >= rxn[r] && leftover0 < (uint64_t)rxn[r] + rn[r]) rem1 = rxn[r] + rn[r] - (uint32_t)leftover0;
+    for (uint32_t r = 0; r < RMAX; r++) {
+      if (rn[r] != 0 && leftover0 >= x && leftover0 < (uint64_t)x + rn[r]) rem1 = x + rn[r] - (uint32_t)leftover0;
+      x += rn[r];
+    }
+  }
   const int fits = express_fits(leftover0, n0, T, max_slices, 0, op.arena_cap, rem1, irs0 + E >= cap / 2);
   if (fits == 0) return false;
   // ---- from here on the drain happens ----------------------------------------------------------------------------
@@ -2236,57 +2268,67 @@ __device__ __forceinline__ bool rxw_fast(rxw_state* st, const grdma_rx_op* opp, 
   const uint64_t alloc = leftover0 ? leftover0 : (n0 > MINRD ? n0 : MINRD);
   const uint32_t L0 = split ? (uint32_t)leftover0 : T;
   const uint32_t off1 = split ? (uint32_t)((L0 + 15u) & ~15u) : 0;
-  uint8_t* const dst = op.arena + (done & 1) * op.arena_cap;   // (the halves of the arena alternate: k_watch)
-  // payload: output byte b lives in record r(b) at offset b - rxn[r], i.e. at byte rxe[r] + 8 + (b - rxn[r]) of the extent
+  // payload: the extent into LDS, then record by record into s_out, back to back (the slice the reads deliver); the
+  // bytes behind the end inside the last word stay zero
+  uint32_t* const s_enc = reinterpret_cast<uint32_t*>(s_ext + RXW_EXT_WORDS);   // [RMAX] encoded sizes, by record
+  uint64_t* const s_out = s_ext + RXW_EXT_WORDS + 8;                            // [64 + 1] the delivered bytes
+  s_ext[lane] = w0;
+  if (nw > 64) s_ext[lane + 64] = w1;
+  s_out[lane] = 0;
+  GRDMA_WAVE_CONVERGE();
   const uint8_t* ext8 = reinterpret_cast<const uint8_t*>(s_ext);
-  uint8_t bytes[8];
+  uint8_t* out8 = reinterpret_cast<uint8_t*>(s_out);
+  {
+    uint32_t xn = 0, xe = 0;   // payload / encoded bytes in front of record r
 #pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const uint32_t b = (uint32_t)lane * 8 + q;
-    uint32_t so = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < RMAX; r++)
-      if (b >= rxn[r] && b < rxn[r] + rn[r]) so = rxe[r] + 8 + (b - rxn[r]);
-    bytes[q] = b < T ? ext8[so] : (uint8_t)0;
+    for (uint32_t r = 0; r < RMAX; r++) {
+      if (r < v) {
+        const uint32_t n = rn[r];
+        if (lane == 0) s_enc[r] = 16u + ((n + 7u) & ~7u);
+        for (uint32_t j = (uint32_t)lane; j < n; j += 64) out8[xn + j] = ext8[xe + 8 + j];
+        xn += n;
+        xe += 16u + ((n + 7u) & ~7u);
+      }
+    }
   }
+  GRDMA_WAVE_CONVERGE();
+  const uint64_t t_copy = prof_realtime(prof) + (s_out[0] & 0);
   if (split) {
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const uint32_t b = (uint32_t)lane * 8 + q;
-      if (b < T) __hip_atomic_store(dst + (b < L0 ? b : off1 + (b - L0)), bytes[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (b < T) __hip_atomic_store(dst + (b < L0 ? b : off1 + (b - L0)), out8[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   } else if ((uint32_t)lane * 8 < T) {
-    uint64_t word = 0;
-#pragma unroll
-    for (int q = 0; q < 8; q++) word |= (uint64_t)bytes[q] << (8 * q);
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(dst + (uint32_t)lane * 8), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(dst + (uint32_t)lane * 8), s_out[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // what was consumed is cleared (records are 8-byte granular), past the caches: the sender overwrites it from another CU
   if ((uint32_t)lane < nw)
     __hip_atomic_store(reinterpret_cast<uint64_t*>(ring + ((head0 + 8ull * lane) & mask)), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if ((uint32_t)lane + 64u < nw)
+  if (nw > 64 && (uint32_t)lane + 64u < nw)
     __hip_atomic_store(reinterpret_cast<uint64_t*>(ring + ((head0 + 8ull * (lane + 64)) & mask)), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // history ring, the credit rule of Recv (pair.cc:276-284) record by record
-  const uint64_t hist_count0 = st->hist_count;
-  uint32_t my_enc = 0;
+  const uint64_t hist_count0 = S0.hist_count;
+  if ((uint32_t)lane < v) S0.hist[(hist_count0 + lane) % GRDMA_RX_HIST] = s_enc[lane];
+  uint64_t irs = irs0 + E, credit = 0, credit_head = 0;
+  if (irs >= cap / 2) {   // (a status report falls into this drain: record by record)
+    irs = irs0;
+    uint32_t xe = 0;
 #pragma unroll
-  for (uint32_t r = 0; r < RMAX; r++)
-    if ((uint32_t)lane == r) my_enc = rn[r] ? 16u + (uint32_t)round_up8(rn[r]) : 0u;
-  if ((uint32_t)lane < v) st->hist[(hist_count0 + lane) % GRDMA_RX_HIST] = my_enc;
-  uint64_t irs = irs0, credit = 0, credit_head = 0;
-#pragma unroll
-  for (uint32_t r = 0; r < RMAX; r++) {
-    if (r < v) {
-      const uint32_t encr = 16u + (uint32_t)round_up8(rn[r]);
-      irs += encr;
-      if (irs >= cap / 2) {
-        credit_head = (head0 + rxe[r] + encr) & mask;
-        credit++;
-        irs = 0;
+    for (uint32_t r = 0; r < RMAX; r++) {
+      if (r < v) {
+        const uint32_t encr = 16u + ((rn[r] + 7u) & ~7u);
+        irs += encr;
+        xe += encr;
+        if (irs >= cap / 2) {
+          credit_head = (head0 + xe) & mask;
+          credit++;
+          irs = 0;
+        }
       }
     }
   }
-  const uint64_t nh = (head0 + E) & mask, mh0 = st->mh;
+  const uint64_t nh = (head0 + E) & mask, mh0 = S0.mh;
   uint64_t nslices, a_off, would_block, leftover;
   grdma_slice_out sl0 = {0, 0}, sl1 = {0, 0};
   if (split) {
@@ -2339,38 +2381,31 @@ __device__ __forceinline__ bool rxw_fast(rxw_state* st, const grdma_rx_op* opp, 
     if (split && lane == 19) __hip_atomic_store(&op.slices[1].off, sl1.off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (split && lane == 20) __hip_atomic_store(&op.slices[1].len, sl1.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // what HasMessage() on the host compares with the sender's arrival report
-    if (st->line != nullptr) {
-      if (lane == 21) __hip_atomic_store(&st->line->rx_head, nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (lane == 22) __hip_atomic_store(&st->line->rx_remain, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (S0.line != nullptr) {
+      if (lane == 21) __hip_atomic_store(&S0.line->rx_head, nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (lane == 22) __hip_atomic_store(&S0.line->rx_remain, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+  const uint64_t t_stores = prof_realtime(prof);
   // every store above is acknowledged -- the zero-fill has left this CU before the credit that grants it goes out
   GRDMA_WAIT_VMEM();
   GRDMA_WAVE_CONVERGE();  // (nothing on the GPU, where the lanes of a wave issue a store together)
   if (credit) {
-    if (lane == 0 && st->peer_status != nullptr)
-      __hip_atomic_store(&st->peer_status->remote_head, credit_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (lane == 1 && st->peer_line != nullptr)
-      __hip_atomic_store(&st->peer_line->remote_head, credit_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0 && S0.peer_status != nullptr)
+      __hip_atomic_store(&S0.peer_status->remote_head, credit_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 1 && S0.peer_line != nullptr)
+      __hip_atomic_store(&S0.peer_line->remote_head, credit_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     GRDMA_WAIT_VMEM();
     GRDMA_WAVE_CONVERGE();
   }
   if (lane == 0) __hip_atomic_store(&res->seq, op.seq_next + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const uint64_t t_seq = prof_realtime(prof);
   // ---- behind the sequence word: the state in LDS, and the connection block as the plan body would leave it ---------
-  const uint32_t e_last = 16u + (uint32_t)round_up8(rn[v - 1 < RMAX ? v - 1 : 0]);
-  uint32_t e_prev = 0;
-#pragma unroll
-  for (uint32_t r = 0; r + 1 < RMAX; r++)
-    if (r + 2 == v) e_prev = 16u + (uint32_t)round_up8(rn[r]);
-  uint32_t last_n = 0;
-#pragma unroll
-  for (uint32_t r = 0; r < RMAX; r++)
-    if (r + 1 == v) last_n = rn[r];
-  const uint32_t enc_last = 16u + (uint32_t)round_up8(last_n);
-  (void)e_last;
-  const uint32_t nh1 = enc_last, nh2 = v >= 2 ? e_prev : st->h1;
+  // sizes of the two newest records, for the plan body's probe round
+  const uint32_t enc_last = s_enc[v - 1], e_prev = v >= 2 ? s_enc[v - 2] : 0;
+  const uint32_t nh1 = enc_last, nh2 = v >= 2 ? e_prev : S0.h1;
   if (lane == 0) {
-    grdma_conn* c = st->conn;
+    grdma_conn* c = S0.conn;
     c->rx_h1 = nh1;
     c->rx_h2 = nh2;
     c->rx_hist_count = hist_count0 + v;
@@ -2379,10 +2414,10 @@ __device__ __forceinline__ bool rxw_fast(rxw_state* st, const grdma_rx_op* opp, 
     c->remain = 0;
     c->internal_read_size = irs;
     c->leftover_cap = leftover;
-    c->total_read = st->total_read + T;
-    c->credit_msgs = st->credit_msgs + credit;
-    c->rx_records = st->rx_records + v;
-    c->rx_rounds = st->rx_rounds + 1;
+    c->total_read = S0.total_read + T;
+    c->credit_msgs = S0.credit_msgs + credit;
+    c->rx_records = S0.rx_records + v;
+    c->rx_rounds = S0.rx_rounds + 1;
     if (credit) c->status_send.remote_head = credit_head;
     grdma_plan* plan = op.plan;
     plan->nsegs = 0;
@@ -2400,12 +2435,21 @@ __device__ __forceinline__ bool rxw_fast(rxw_state* st, const grdma_rx_op* opp, 
     st->mh = nh;
     st->irs = irs;
     st->leftover = leftover;
-    st->total_read += T;
-    st->credit_msgs += credit;
-    st->rx_records += v;
-    st->rx_rounds += 1;
+    st->total_read = S0.total_read + T;
+    st->credit_msgs = S0.credit_msgs + credit;
+    st->rx_records = S0.rx_records + v;
+    st->rx_rounds = S0.rx_rounds + 1;
     atomicAdd(&g_watch_fast_drains, 1ull);
     atomicAdd(&g_express_drains, 1ull);
+    // (profiling aid, grdma_watch_ticks: 10 ns ticks since the watcher found the arrival report)
+    if (prof) {
+    g_watch_ticks[5] += t_loaded - t_found;
+    g_watch_ticks[6] += t_stores - t_found;
+    g_watch_ticks[7] += t_seq - t_found;
+    g_watch_ticks[10] += t_walk - t_found;
+    g_watch_ticks[11] += t_copy - t_found;
+    g_watch_ticks[9] += t_found - __hip_atomic_load(&g_watch_ticks[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   GRDMA_WAVE_CONVERGE();
   return true;
@@ -2426,13 +2470,15 @@ void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_
   __shared__ __attribute__((aligned(16))) grdma_rx_op s_op;
   __shared__ __attribute__((aligned(16))) grdma_rx_op s_ops[64];   // the standing orders of this workgroup's slots, by owning lane
   __shared__ rxw_state s_st[64];                                    // ... and their connections' receive state
-  __shared__ __attribute__((aligned(16))) uint64_t s_ext[RXW_EXT_WORDS + 8];
+  __shared__ uint8_t* s_win[64][GRDMA_WATCH_WINDOWS];               // ... and the windows their drains deliver into
+  __shared__ __attribute__((aligned(16))) uint64_t s_ext[RXW_EXT_WORDS + 8 + 66];   // extent, record table, delivered bytes (rxw_fast)
   __shared__ uint64_t s_limit, s_done, s_found;
+  __shared__ uint8_t* s_arena;
   __shared__ uint32_t s_fire, s_limited;
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned my_slot = blockIdx.x + lane * gridDim.x;
   const bool have = my_slot < GRDMA_WATCH_SLOTS;
-  const bool fast_on = (flags & 1u) != 0;
+  const bool fast_on = (flags & 1u) != 0, prof = (flags & 2u) != 0;
   grdma_watch_slot* const sl = &wc->slot[have ? my_slot : 0];
   // (wave 0, per lane: the connection this lane watches)
   uint64_t gen_seen = 0, head = 0, remain = 0, done = 0, mask = 0;
@@ -2469,6 +2515,9 @@ void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_
             for (unsigned k = 0; k < sizeof(grdma_rx_op) / 8; k++)
               reinterpret_cast<uint64_t*>(&s_ops[lane])[k] =
                   __hip_atomic_load(reinterpret_cast<const uint64_t*>(&sl->op) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (unsigned k = 0; k < GRDMA_WATCH_WINDOWS; k++)
+              s_win[lane][k] = reinterpret_cast<uint8_t*>(
+                  __hip_atomic_load(reinterpret_cast<const uint64_t*>(&sl->win_base[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
             conn = s_ops[lane].conn;
             rxw_load(&s_st[lane], conn);
             ring = s_st[lane].ring;
@@ -2499,7 +2548,7 @@ void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_
               arrived = ftr == GRDMA_FOOTER;
             }
           }
-          ready = (remain != 0 || arrived) && consumed >= done;
+          ready = (remain != 0 || arrived) && (consumed & GRDMA_WATCH_COUNT_MASK) >= done;
         }
         const uint64_t m = __ballot(ready);
         if (m) {
@@ -2507,22 +2556,24 @@ void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_
           const uint64_t rot = rr ? ((m >> rr) | (m << (64 - rr))) : m;
           const uint32_t pick = ((uint32_t)__builtin_ctzll(rot) + rr) & 63u;
           rr = (pick + 1) & 63u;
-          const uint64_t t_found = __builtin_amdgcn_s_memrealtime();
+          const uint64_t t_found = prof_realtime(prof);
           const uint64_t wt_p = __shfl(wt, (int)pick, 64), done_p = __shfl(done, (int)pick, 64);
+          // (the window this drain delivers into: the host names it with the count of completions it has taken)
+          uint8_t* const win_p = s_win[pick][(__shfl(consumed, (int)pick, 64) >> 56) % GRDMA_WATCH_WINDOWS];
           // a unary-sized message: this wave alone, straight line (rxw_fast); anything else: the plan body, all four waves
-          if (fast_on && rxw_fast(&s_st[pick], &s_ops[pick], done_p, wt_p, (int)lane, s_ext)) {
+          if (fast_on && rxw_fast(&s_st[pick], &s_ops[pick], done_p, wt_p, win_p, (int)lane, s_ext, t_found, prof)) {
             if (lane == pick) {
               done += 1;
               head = s_st[lane].head;
               remain = 0;
               __hip_atomic_store(&sl->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-              // (profiling aid: 10 ns ticks)
-              const uint64_t t_done = __builtin_amdgcn_s_memrealtime();
-              const uint64_t t_pub = __hip_atomic_load(&g_watch_ticks[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-              g_watch_ticks[1] += t_found - t_pub;
-              g_watch_ticks[2] += t_done - t_found;
-              g_watch_ticks[3] += 1;
-              sl->drains_dbg = sl->drains_dbg + 1;
+              if (prof) {  // (profiling aid: 10 ns ticks)
+                const uint64_t t_done = __builtin_amdgcn_s_memrealtime();
+                const uint64_t t_pub = __hip_atomic_load(&g_watch_ticks[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                g_watch_ticks[1] += t_found - t_pub;
+                g_watch_ticks[2] += t_done - t_found;
+                g_watch_ticks[3] += 1;
+              }
             }
             continue;   // (uniform: every lane took the same way)
           }
@@ -2531,6 +2582,7 @@ void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_
             s_limit = wt;
             s_limited = limited ? 1u : 0u;
             s_done = done;
+            s_arena = win_p;
             s_fire = 1u + lane;
           }
           fire = 1;
@@ -2549,25 +2601,24 @@ void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_
     if (threadIdx.x == 0) {
       const uint64_t k = s_done;
       s_op.seq_next += k;
-      // (the slices of completion k - 1 may still be read by the host: the halves of the arena alternate)
-      s_op.arena += (k & 1) * s_op.arena_cap;
+      s_op.arena = s_arena;
       if (s_limited) s_op.limit_ptr = &s_limit;
     }
     __syncthreads();
-    const uint64_t t_body = __builtin_amdgcn_s_memrealtime();
+    const uint64_t t_body = prof_realtime(prof);
     rx_plan_call(&s_op);
     __syncthreads();
     if (wave == 0 && lane == f - 1) {
-      // (profiling aid: 10 ns ticks)
-      const uint64_t t_done = __builtin_amdgcn_s_memrealtime();
-      const uint64_t t_pub = __hip_atomic_load(&g_watch_ticks[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      g_watch_ticks[1] += s_found - t_pub;
-      g_watch_ticks[2] += t_done - s_found;
-      g_watch_ticks[3] += 1;
-      g_watch_ticks[4] += t_body - s_found;
+      if (prof) {  // (profiling aid: 10 ns ticks)
+        const uint64_t t_done = __builtin_amdgcn_s_memrealtime();
+        const uint64_t t_pub = __hip_atomic_load(&g_watch_ticks[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        g_watch_ticks[1] += s_found - t_pub;
+        g_watch_ticks[2] += t_done - s_found;
+        g_watch_ticks[3] += 1;
+        g_watch_ticks[4] += t_body - s_found;
+      }
       done += 1;
       __hip_atomic_store(&sl->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      sl->drains_dbg = sl->drains_dbg + 1;
       rxw_load(&s_st[lane], conn);   // (the plan body changed the connection block: the state in LDS follows it)
       head = s_st[lane].head;
       remain = s_st[lane].remain;
@@ -2580,8 +2631,8 @@ void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_
 }  // namespace
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch,
-                                                                                hipStream_t s) {
-  hipLaunchKernelGGL(k_engine, dim3(1), dim3(PLAN_THREADS), 0, s, mb, wc, epoch);
+                                                                                uint32_t flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_engine, dim3(1), dim3(PLAN_THREADS), 0, s, mb, wc, epoch, flags);
   return hipGetLastError();
 }
 extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch,
@@ -2600,11 +2651,12 @@ extern "C" int grdma_tx_small_ticks(uint64_t out[8]) {
 }
 
 // profiling aid: 10 ns ticks summed over the watchers' drains -- {-, arrival report published -> found by the watcher,
-// found -> drain done, drains, found -> plan body entered}
-extern "C" int grdma_watch_ticks(uint64_t out[8]) {
-  unsigned long long v[8];
+// found -> drain done, drains, found -> plan body entered, found -> bytes loaded, found -> stores issued, found -> sequence
+// word stored (the last three: the single-wave path), -, command taken off the mailbox -> found}
+extern "C" int grdma_watch_ticks(uint64_t out[12]) {
+  unsigned long long v[12];
   if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_watch_ticks), sizeof(v)) != hipSuccess) return -1;
-  for (int i = 0; i < 8; i++) out[i] = v[i];
+  for (int i = 0; i < 12; i++) out[i] = v[i];
   return 0;
 }
 extern "C" int grdma_rx_express_ticks(uint64_t out[9]) {

@@ -40,12 +40,15 @@ __device__ __forceinline__ void tx_publish(grdma_conn* c, uint64_t tail, uint64_
 // engine's copy is read by grdma_tx_small_ticks)
 static __device__ unsigned long long g_tx_small_ticks[8];
 // profiling aid (grdma_watch_ticks): [0] the 100 MHz clock when the last small send published its arrival report;
-// the watcher that finds it adds [1] += found - published, [2] += drain done - found, [3] += 1, [4] += fire -> body entered
-static __device__ unsigned long long g_watch_ticks[8];
+// the watcher that finds it adds [1] += found - published, [2] += drain done - found, [3] += 1, [4] += fire -> body entered,
+// [5] += bytes loaded - found, [6] += stores issued - found, [7] += sequence word stored - found; [8] the clock when the
+// command workgroup took the last command off the mailbox, [9] += found - that
+static __device__ unsigned long long g_watch_ticks[12];
 
 __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t start,
-                                              uint64_t byte_idx, uint64_t avail, int lane) {
-  const uint64_t tk0 = __builtin_amdgcn_s_memtime();
+                                              uint64_t byte_idx, uint64_t avail, int lane, uint64_t* lds = nullptr /* [160] */) {
+  const bool prof = (op.inline_copy & GRDMA_OP_PROFILE) != 0;
+  const uint64_t tk0 = prof_time(prof);
   grdma_conn* c = op.conn;
   const uint64_t cap = c->cap, mask = cap - 1, S = c->staging_cap, tail0 = c->remote_tail;
   const uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED,
@@ -61,6 +64,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
   grdma_hostline* const pre_ln = c->line;
   const uint64_t pre_written = c->total_written, pre_records = c->tx_records, pre_rounds = c->tx_rounds;
   const uint64_t pre_partial = c->partial_write;
+  const bool peer_limited = c->peer_limited != 0 && pre_pw != nullptr;
 
   uint64_t len = 0;
   const uint8_t* src = nullptr;
@@ -72,7 +76,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
       src += byte_idx;
     }
   }
-  const uint64_t tk1 = __builtin_amdgcn_s_memtime() + (len & 0);  // (after the slice loads)
+  const uint64_t tk1 = prof_time(prof) + (len & 0);  // (after the slice loads)
   // total offered (pair.cc:660-663)
   uint64_t offered = len;
 #pragma unroll
@@ -105,11 +109,12 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) sent += __shfl_xor(sent, d, 64);
 
-  const uint64_t tk2 = __builtin_amdgcn_s_memtime() + (sent & 0);  // (after pricing)
+  const uint64_t tk2 = prof_time(prof) + (sent & 0);  // (after pricing)
   const uint64_t seg1 = staged < cap - tail0 ? staged : cap - tail0;
   uint8_t* const peer_ring = c->peer_ring;
   // (inline_copy bits of an engine command: 2 = cut-through, 4 = a drain follows in this command -- grdma_ct_hint)
   const bool cut_through = (op.inline_copy & 2u) != 0, chained = (op.inline_copy & 4u) != 0;
+  bool sys_stores = false;   // every byte of this Send went into the peer ring past the caches
   if (chained && op.sizes_out != nullptr && nrec_total <= 8) {
     grdma_ct_hint* h = reinterpret_cast<grdma_ct_hint*>(op.sizes_out);
     if ((uint64_t)lane < nrec_total) h->n[lane] = (uint32_t)my_pay;
@@ -120,52 +125,50 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
   }
   if (cut_through) {
     // the records are handed to the drain of this command in registers' reach: nothing is stored into staging or ring
-  } else if (nrec_total >= 1 && nrec_total <= 4 && __ballot(my_pay > 256) == 0 && peer_ring != nullptr) {
+  } else if (nrec_total >= 1 && nrec_total <= 4 && __ballot(my_pay > 256) == 0 && peer_ring != nullptr && lds != nullptr) {
     // ---- unary-sized Sends: at most four records of at most 256 bytes ------------------------
-    // Every payload byte is loaded BEFORE the first store (a load that is waited for behind a
-    // store waits for the store: the memory counter is in order), from clamped addresses (no load
-    // under a branch); then the records go to staging AND to the peer ring from registers -- the
-    // <= 2 RDMA WRITEs of GetWriteRequests (ring_buffer.cc:261-330) without reading staging back.
-    // The ring's footers are stored last, once everything in front of them is acknowledged
-    // (a record becomes visible to the peer with its footer, ring_buffer.cc:67-97).
-    uint8_t b[4][4];
-    uint32_t rp[4], rst[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int rr = (uint64_t)r < nrec_total ? r : 0;
-      rp[r] = (uint32_t)__shfl(my_pay, rr, 64);
-      rst[r] = (uint32_t)__shfl((uint32_t)st, rr, 64);
-      const uint8_t* sp = reinterpret_cast<const uint8_t*>(__shfl((uint64_t)src, rr, 64));
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t o = (uint32_t)lane + 64u * k;
-        b[r][k] = sp[o < rp[r] ? o : rp[r] - 1];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      if ((uint64_t)r >= nrec_total) break;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t o = (uint32_t)lane + 64u * k;
-        if (o < rp[r]) {
-          if (!direct) c->staging[rst[r] + 8 + o] = b[r][k];
-          peer_ring[(tail0 + rst[r] + 8 + o) & mask] = b[r][k];
-        }
-      }
-    }
+    // The encoded bytes of the Send -- [length][payload, zero padded][footer] per record, back to back: what the <= 2
+    // RDMA WRITEs of GetWriteRequests carry (ring_buffer.cc:261-330) -- are put together in LDS and leave as 8-byte
+    // words, lane l the words l, l + 64, l + 128: into staging, and into the peer ring PAST the caches (the peer's
+    // watcher workgroup reads them from another CU, possibly behind another L2 -- and then the arrival report needs
+    // no write-back of this L2 in front of it).  A handful of wide stores instead of the thirty byte stores per record
+    // this branch began with (2.5 us of a single wave's issue, profiles/r05_rtt_notes.txt).  For a reader that finds
+    // records by their tags, the footers go out behind everything else (ring_buffer.cc:67-97).
+    const uint32_t nwords = (uint32_t)(staged >> 3);   // <= 4 * (16 + 256) / 8 = 136
+    uint8_t* const s8 = reinterpret_cast<uint8_t*>(lds);
+    for (uint32_t w = (uint32_t)lane; w < nwords; w += 64) lds[w] = 0;
+    GRDMA_WAVE_CONVERGE();
     if (my_pay > 0) {  // lane i owns the tags of record i
-      const uint64_t pad_end = round_up8(my_pay);
-      if (!direct) {
-        *reinterpret_cast<uint64_t*>(c->staging + st) = my_pay;
-        *reinterpret_cast<uint64_t*>(c->staging + st + 8 + pad_end) = GRDMA_FOOTER;
-        for (uint64_t q = my_pay; q < pad_end; q++) c->staging[st + 8 + q] = 0;
-      }
-      *reinterpret_cast<uint64_t*>(peer_ring + ((tail0 + st) & mask)) = my_pay;
-      for (uint64_t q = my_pay; q < pad_end; q++) peer_ring[(tail0 + st + 8 + q) & mask] = 0;
-      GRDMA_WAIT_VMEM();
-      *reinterpret_cast<uint64_t*>(peer_ring + ((tail0 + st + 8 + pad_end) & mask)) = GRDMA_FOOTER;
+      lds[st >> 3] = my_pay;
+      lds[(st + 8 + round_up8(my_pay)) >> 3] = GRDMA_FOOTER;
     }
+    uint32_t fw[4];   // the footers' words
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      fw[r] = 0xFFFFFFFFu;
+      if ((uint64_t)r < nrec_total) {
+        const uint32_t p = (uint32_t)__shfl(my_pay, r, 64), so = (uint32_t)__shfl((uint32_t)st, r, 64);
+        const uint8_t* sp = reinterpret_cast<const uint8_t*>(__shfl((uint64_t)src, r, 64));
+        fw[r] = (so + 8 + ((p + 7u) & ~7u)) >> 3;
+        for (uint32_t j = (uint32_t)lane; j < p; j += 64) s8[so + 8 + j] = sp[j];
+      }
+    }
+    GRDMA_WAVE_CONVERGE();
+    for (uint32_t w = (uint32_t)lane; w < nwords; w += 64) {
+      const uint64_t val = lds[w];
+      const bool is_f = w == fw[0] || w == fw[1] || w == fw[2] || w == fw[3];
+      if (!direct) *reinterpret_cast<uint64_t*>(c->staging + 8ull * w) = val;
+      if (peer_limited || !is_f)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(peer_ring + ((tail0 + 8ull * w) & mask)), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (!peer_limited) {
+      GRDMA_WAIT_VMEM();
+      GRDMA_WAVE_CONVERGE();
+      if (my_pay > 0)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(peer_ring + ((tail0 + st + 8 + round_up8(my_pay)) & mask)), GRDMA_FOOTER, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    sys_stores = true;
   } else {
   // tags (AppendHeader / AppendFooter, ring_buffer.h:84-99) and zero padding
   uint64_t pay_off = 0;
@@ -212,17 +215,18 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     }
   }
   }
-  const uint64_t tk3 = __builtin_amdgcn_s_memtime();  // (copies issued)
+  const uint64_t tk3 = prof_time(prof);  // (copies issued)
   GRDMA_WAIT_VMEM();
-  const uint64_t tk4 = __builtin_amdgcn_s_memtime();  // (copies acknowledged)
+  const uint64_t tk4 = prof_time(prof);  // (copies acknowledged)
   if (lane == 0) {
     // The arrival report FIRST (the wave has waited for every copy above): the peer's watcher workgroup (k_watch) polls
     // this word, and everything below -- plan headers, result block, counters -- is this end's own bookkeeping.  The
     // release carries the ring bytes out of this L2 (the watcher may sit behind another one).
     const uint64_t nt = (tail0 + staged) & mask;
-    __hip_atomic_store(&g_watch_ticks[0], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (prof) __hip_atomic_store(&g_watch_ticks[0], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (pre_pw != nullptr) {
-      if (chained) __hip_atomic_store(pre_pw, nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // (bytes stored past the caches and acknowledged are in memory: no write-back of this L2 in front of the report)
+      if (chained || sys_stores) __hip_atomic_store(pre_pw, nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       else __hip_atomic_store(pre_pw, nt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (pre_pl != nullptr) __hip_atomic_store(&pre_pl->wire_tail, nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -280,7 +284,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     r->slice_idx = idx;
     r->byte_idx = bidx;
     r->done = (idx >= op.nslices) ? 1 : 0;
-    const uint64_t tk5 = __builtin_amdgcn_s_memtime();  // (bookkeeping stores issued)
+    const uint64_t tk5 = prof_time(prof);  // (bookkeeping stores issued)
     // (the wave has waited for every copy above: the arrival report may go out)
     {  // the rest of tx_publish (the arrival report went out above), with the pointers loaded in front
       const uint64_t partial = connected ? (sent < offered ? 1 : 0) : pre_partial;
@@ -294,14 +298,16 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     // (chained: the engine publishes the sequence word behind the drain of the same command -- k_engine)
     if (!chained) __hip_atomic_store(&r->seq, op.seq_next ? op.seq_next : r->seq + 1, __ATOMIC_RELEASE,
                                      __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint64_t tk6 = __builtin_amdgcn_s_memtime();
-    g_tx_small_ticks[0] += tk1 - tk0;
-    g_tx_small_ticks[1] += tk2 - tk1;
-    g_tx_small_ticks[2] += tk3 - tk2;
-    g_tx_small_ticks[3] += tk4 - tk3;
-    g_tx_small_ticks[4] += tk5 - tk4;
-    g_tx_small_ticks[5] += tk6 - tk5;
-    g_tx_small_ticks[6] += 1;
+    if (prof) {
+      const uint64_t tk6 = __builtin_amdgcn_s_memtime();
+      g_tx_small_ticks[0] += tk1 - tk0;
+      g_tx_small_ticks[1] += tk2 - tk1;
+      g_tx_small_ticks[2] += tk3 - tk2;
+      g_tx_small_ticks[3] += tk4 - tk3;
+      g_tx_small_ticks[4] += tk5 - tk4;
+      g_tx_small_ticks[5] += tk6 - tk5;
+      g_tx_small_ticks[6] += 1;
+    }
   }
 }
 
@@ -358,7 +364,7 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
     }
     __syncthreads();
     if (s_small_total <= (64ull << 10)) {
-      if (tid < 64) tx_small_wave(op, start, byte_idx, avail, (int)tid);
+      if (tid < 64) tx_small_wave(op, start, byte_idx, avail, (int)tid, s_len);
       return;
     }
   }

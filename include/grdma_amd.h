@@ -468,7 +468,7 @@ int grdma_pair_debug_hist(grdma_pair* p, uint32_t* hist_out /* 1024 entries */, 
 int grdma_engine_debug(uint64_t out[5]);
 uint64_t grdma_express_drains(void);  /* drains served by the single-wave express path so far */
 uint64_t grdma_watch_fast_drains(void);      /* diagnostics: drains the watchers' single-wave path took */
-int grdma_watch_ticks(uint64_t out[8]);      /* profiling aid: 10 ns ticks of the watchers' drains (arrival found, drain done) */
+int grdma_watch_ticks(uint64_t out[12]);      /* profiling aid: 10 ns ticks of the watchers' drains (arrival found, drain done) */
 int grdma_rx_express_ticks(uint64_t out[9]);  /* profiling aid: phase ticks of the express drain (latency engine) */
 uint64_t grdma_cut_through_drains(void);  /* ... of which the records of an armed send + drain command never touched the ring */
 int grdma_tx_fast_sends(uint64_t out[2]);  /* Sends of streaming jobs planned by k_tx_fast [0], left to the general planner [1] (csrc/grdma_tx_fast.h) */

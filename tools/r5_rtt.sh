@@ -11,4 +11,6 @@ fi
 for w in ${WATCHERS:-4}; do
   echo "== rtt, watched reads, $w watcher workgroup(s)"
   GRDMA_ENGINE_WATCHERS=$w timeout 120 python tools/rtt_probe.py ${ITERS:-20000} watch 2>&1 | grep -v amdgpu.ids | tee $out/rtt_watch_w$w.txt
+  echo "== the same with the phase stamps"
+  GRDMA_ENGINE_WATCHERS=$w timeout 120 python tools/rtt_probe.py ${ITERS:-20000} watch prof 2>&1 | grep -v amdgpu.ids | tee $out/rtt_watch_w${w}_prof.txt
 done

@@ -19,6 +19,8 @@ def main():
     # "watch": standing reads carried out by the engine's watcher workgroups (the default of grdma_pair_arm_read);
     # "armed" / "chain": round 4's way, the in-process peer's send command carries the drain (GRDMA_ENGINE_CHAIN=1)
     mode = sys.argv[2] if len(sys.argv) > 2 else ""
+    if "prof" in sys.argv[3:]:   # the phase stamps cost about two microseconds per round trip: off unless asked for
+        os.environ["GRDMA_PROFILE_TICKS"] = "1"
     if mode in ("armed", "chain"):
         os.environ["GRDMA_ENGINE_CHAIN"] = "1"
     armed = mode in ("armed", "chain", "watch")
@@ -41,10 +43,10 @@ def main():
     lib.grdma_tx_small_ticks(t0)
     x0 = (C.c_uint64 * 9)()
     lib.grdma_rx_express_ticks(x0)
-    w0 = (C.c_uint64 * 8)()
+    w0 = (C.c_uint64 * 12)()
     lib.grdma_watch_ticks(w0)
     rtt, ph = g.pingpong(a, b, slices, slices, iters=iters, warmup=0)
-    w1 = (C.c_uint64 * 8)()
+    w1 = (C.c_uint64 * 12)()
     lib.grdma_watch_ticks(w1)
     x1 = (C.c_uint64 * 9)()
     lib.grdma_rx_express_ticks(x1)
@@ -74,6 +76,9 @@ def main():
     if nw:
         print("watchers, us per drain (%d drains): arrival report published -> found %.2f, found -> plan body entered %.2f, found -> drain done %.2f" % (
             nw, (int(w1[1]) - int(w0[1])) / nw / 100.0, (int(w1[4]) - int(w0[4])) / nw / 100.0, (int(w1[2]) - int(w0[2])) / nw / 100.0))
+        d = lambda i: (int(w1[i]) - int(w0[i])) / nw / 100.0
+        print("  single-wave drains, us since found: bytes loaded %.2f, chain walked %.2f, payload in LDS %.2f, stores issued %.2f, sequence word stored %.2f; command off the mailbox -> found %.2f" % (
+            d(5), d(10), d(11), d(6), d(7), d(9)))
 
 
 if __name__ == "__main__":
