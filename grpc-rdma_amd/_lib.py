@@ -46,6 +46,7 @@ class Config(C.Structure):
 SIGNATURES = {
     "grdma_abi_version": (C.c_int, []),
     "grdma_pair_watch_hits": (C.c_int64, [C.c_void_p]),
+    "grdma_pingpong_end": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Slice), u64, u64, C.c_int, u64, u64, C.POINTER(u64), C.POINTER(u64)]),
     "grdma_engine_watchers": (C.c_int, []),
     "grdma_watch_fast_drains": (u64, []),
     "grdma_watch_ticks": (C.c_int, [C.POINTER(u64)]),

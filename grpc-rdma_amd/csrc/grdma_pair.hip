@@ -56,8 +56,7 @@ hipError_t grdma_launch_rx_plan(const grdma_rx_op*, uint32_t, hipStream_t);
 hipError_t grdma_launch_rx_apply(const grdma_rx_op*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_poll(grdma_conn* const*, uint32_t, uint64_t*, uint64_t*, uint64_t*, uint64_t*,
                              hipStream_t);
-hipError_t grdma_launch_engine(grdma_engine_mbox*, grdma_watch_ctl*, uint64_t epoch, uint32_t flags, hipStream_t);
-hipError_t grdma_launch_watch(grdma_engine_mbox*, grdma_watch_ctl*, uint64_t epoch, uint32_t groups, uint32_t flags, hipStream_t);
+hipError_t grdma_launch_engine(grdma_engine_mbox*, grdma_watch_ctl*, uint64_t epoch, uint32_t groups, uint32_t flags, hipStream_t, hipStream_t);
 const void* grdma_kernel_fn(int which);          // 0 tx_plan, 1 copy, 3 rx_apply, 4 tx_plan_seq
 const void* grdma_kernel_fn_rx_plan(void);
 const void* grdma_kernel_fn_rx_plan_job(void);
@@ -508,8 +507,7 @@ int engine_launch() {
   //  GRDMA_PROFILE_TICKS=1: the phase stamps of the latency paths, off by default -- see prof_time in grdma_devfn.h)
   const char* wf = getenv("GRDMA_WATCH_FAST");
   const uint32_t kflags = ((wf && atoi(wf) == 0) ? 0u : 1u) | (profile_ticks() ? 2u : 0u);
-  HIP_TRY(grdma_launch_engine(e.mb, e.d_watch, epoch, kflags, e.stream));
-  HIP_TRY(grdma_launch_watch(e.mb, e.d_watch, epoch, e.groups, kflags, e.wstream));
+  HIP_TRY(grdma_launch_engine(e.mb, e.d_watch, epoch, e.groups, kflags, e.stream, e.wstream));
   const auto t0 = std::chrono::steady_clock::now();
   auto up = [&] {
     if (!*alive) return false;
@@ -519,7 +517,9 @@ int engine_launch() {
   };
   while (!up()) {
     if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5))
-      return fail(GRDMA_ERR_HIP, "latency engine did not come up");
+      return fail(GRDMA_ERR_HIP, "latency engine did not come up (command workgroup %s, watchers %llu %llu %llu %llu of incarnation %llu)",
+                  *alive ? "resident" : "not resident", (unsigned long long)e.mb->watch_alive[0], (unsigned long long)e.mb->watch_alive[1],
+                  (unsigned long long)e.mb->watch_alive[2], (unsigned long long)e.mb->watch_alive[3], (unsigned long long)epoch);
   }
   return 0;
 }
@@ -2102,6 +2102,67 @@ int grdma_pingpong(grdma_pair* a, grdma_pair* b, const grdma_slice* req, uint64_
       }
     }
   }
+  return 0;
+}
+
+// ONE end of a unary ping-pong whose other end lives elsewhere -- another process, through the IPC mapping of the
+// rings -- the client's loop of examples/cpp/micro-bench/mb_client.cc or the server's echo side: client = write `out`,
+// then read until in_bytes have arrived; server = the other way round.  The read side is whatever the pair is set up
+// for: with a standing order (grdma_pair_arm_read) the watcher workgroup of THIS process's engine finds what the other
+// process wrote into this pair's ring and the loop only looks at host memory.  rtt_ns (client: per iteration, first
+// write to last byte read; server: read to read), byte_sum = sum of every byte received (both ends check it).
+int grdma_pingpong_end(grdma_pair* p, int is_client, const grdma_slice* out, uint64_t nout, uint64_t in_bytes, int mem_flags,
+                       uint64_t iters, uint64_t warmup, uint64_t* rtt_ns, uint64_t* byte_sum) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || !out || !rtt_ns) return fail(GRDMA_ERR_INVALID, "bad argument");
+  grdma_read_slice sl[64];
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ns = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(y - x).count();
+  };
+  uint64_t sum = 0;
+  const uint8_t* arena = static_cast<const uint8_t*>(grdma_pair_arena_device_ptr(p));
+  auto write_all = [&]() -> int {
+    if (int64_t rc = grdma_endpoint_write_begin(p, out, nout, mem_flags); rc < 0) return (int)rc;
+    int done = 0;
+    for (int tries = 0; !done && tries < 100000; tries++) {
+      int64_t rc = grdma_endpoint_write_step(p, &done);
+      if (rc < 0) return (int)rc;
+    }
+    return done ? 0 : fail(GRDMA_ERR_HIP, "write did not complete");
+  };
+  auto read_all = [&]() -> int {
+    uint64_t got = 0;
+    const auto r0 = now();
+    while (got < in_bytes) {
+      int wb = 0;
+      int64_t n = grdma_endpoint_read(p, 64, sl, 64, &wb);
+      if (n < 0) return (int)n;
+      for (int64_t i = 0; i < n; i++) {
+        got += sl[i].len;
+        if (p->latency && arena)
+          for (uint64_t k = 0; k < sl[i].len; k++) sum += arena[sl[i].off + k];
+      }
+      if (n == 0 && ns(r0, now()) > 20000000000ull) return fail(GRDMA_ERR_HIP, "no message within 20 s");
+    }
+    return got == in_bytes ? 0 : fail(GRDMA_ERR_HIP, "a message of %llu bytes instead of %llu", (unsigned long long)got,
+                                      (unsigned long long)in_bytes);
+  };
+  auto t_prev = now();
+  for (uint64_t it = 0; it < warmup + iters; it++) {
+    const auto t0 = now();
+    if (is_client) {
+      if (int rc = write_all()) return rc;
+      if (int rc = read_all()) return rc;
+    } else {
+      if (int rc = read_all()) return rc;
+      if (int rc = write_all()) return rc;
+    }
+    const auto t1 = now();
+    if (it >= warmup) rtt_ns[it - warmup] = is_client ? ns(t0, t1) : ns(t_prev, t1);
+    t_prev = t1;
+  }
+  if (byte_sum) *byte_sum = sum;
   return 0;
 }
 

@@ -1910,8 +1910,7 @@ __device__ __forceinline__ bool engine_cut_through_ok(const grdma_engine_cmd& bl
 // the batched path.  The engine leaves by itself when idle for ~1 s or when the
 // host sets exit_flag.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_t flags) {
+__device__ __attribute__((noinline)) void engine_body(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_t flags) {
   const bool prof = (flags & 2u) != 0;
   __shared__ uint64_t s_cmd[4];
   __shared__ uint64_t s_wcmd[sizeof(grdma_watch_cmd) / 8];
@@ -2465,18 +2464,29 @@ __device__ __forceinline__ bool rxw_fast(rxw_state* __restrict__ st, const grdma
 // those of grdma_endpoint_read called at that moment) and goes back to polling.  The drain is limited to what the
 // pass saw (grdma_rx_op::limit_ptr points at the word in LDS): what lands meanwhile is the next pass's.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_t flags) {
+__device__ __attribute__((noinline)) void watch_body(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_t flags,
+                                                     const unsigned wg, const unsigned nwg) {
   __shared__ __attribute__((aligned(16))) grdma_rx_op s_op;
-  __shared__ __attribute__((aligned(16))) grdma_rx_op s_ops[64];   // the standing orders of this workgroup's slots, by owning lane
-  __shared__ rxw_state s_st[64];                                    // ... and their connections' receive state
-  __shared__ uint8_t* s_win[64][GRDMA_WATCH_WINDOWS];               // ... and the windows their drains deliver into
+  // the standing orders of this workgroup's slots, by owning lane; their connections' receive state; the windows their
+  // drains deliver into
+#ifdef GRDMA_WAVE_EMU
+  // (the emulator's __shared__ objects are process-wide statics and the command workgroup runs beside this one there)
+  __shared__ __attribute__((aligned(16))) grdma_rx_op s_ops[64];
+  __shared__ rxw_state s_st[64];
+  __shared__ uint8_t* s_win[64][GRDMA_WATCH_WINDOWS];
+#else
+  // (in the send plan's first array: a watcher never plans a Send -- see g_txs_len)
+  static_assert(64 * (sizeof(grdma_rx_op) + sizeof(rxw_state) + 8 * GRDMA_WATCH_WINDOWS) <= sizeof(g_txs_len), "the watcher's tables fit");
+  grdma_rx_op* const s_ops = reinterpret_cast<grdma_rx_op*>(g_txs_len);
+  rxw_state* const s_st = reinterpret_cast<rxw_state*>(s_ops + 64);
+  uint8_t* (*const s_win)[GRDMA_WATCH_WINDOWS] = reinterpret_cast<uint8_t* (*)[GRDMA_WATCH_WINDOWS]>(s_st + 64);
+#endif
   __shared__ __attribute__((aligned(16))) uint64_t s_ext[RXW_EXT_WORDS + 8 + 66];   // extent, record table, delivered bytes (rxw_fast)
   __shared__ uint64_t s_limit, s_done, s_found;
   __shared__ uint8_t* s_arena;
   __shared__ uint32_t s_fire, s_limited;
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const unsigned my_slot = blockIdx.x + lane * gridDim.x;
+  const unsigned my_slot = wg + lane * nwg;
   const bool have = my_slot < GRDMA_WATCH_SLOTS;
   const bool fast_on = (flags & 1u) != 0, prof = (flags & 2u) != 0;
   grdma_watch_slot* const sl = &wc->slot[have ? my_slot : 0];
@@ -2487,8 +2497,8 @@ void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_
   const uint64_t* wire_ptr = nullptr;
   bool limited = true;
   uint32_t rr = 0;
-  if (threadIdx.x == 0 && blockIdx.x < GRDMA_WATCH_MAX_GROUPS)
-    __hip_atomic_store(&mb->watch_alive[blockIdx.x], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0 && wg < GRDMA_WATCH_MAX_GROUPS)
+    __hip_atomic_store(&mb->watch_alive[wg], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();
   for (;;) {
     if (wave == 0) {
@@ -2624,20 +2634,38 @@ void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_
       remain = s_st[lane].remain;
     }
   }
-  if (threadIdx.x == 0 && blockIdx.x < GRDMA_WATCH_MAX_GROUPS)
-    __hip_atomic_store(&mb->watch_alive[blockIdx.x], 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0 && wg < GRDMA_WATCH_MAX_GROUPS)
+    __hip_atomic_store(&mb->watch_alive[wg], 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The resident kernels.  On the device ONE launch holds the command workgroup (block 0) and the watchers (blocks 1 ..):
+// two launches on two streams are two hardware queues, and a process that shares the GPU with another one is not
+// promised a second queue while the first never drains -- the watchers of the second process of
+// tests/test_gpu_two_process.py never started.  (The host emulation runs the blocks of a launch one after the other, so
+// there the two bodies stay launches -- threads -- of their own.)
+__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_t flags) {
+  if (blockIdx.x == 0) engine_body(mb, wc, epoch, flags);
+  else watch_body(mb, wc, epoch, flags, blockIdx.x - 1, gridDim.x - 1);
+}
+__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_t flags) {
+  watch_body(mb, wc, epoch, flags, blockIdx.x, gridDim.x);
 }
 
 }  // namespace
 
+// groups watcher workgroups beside the command workgroup: one launch on the device (s), two under the emulator (s, ws)
 extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch,
-                                                                                uint32_t flags, hipStream_t s) {
+                                                                                uint32_t groups, uint32_t flags, hipStream_t s, hipStream_t ws) {
+#ifdef GRDMA_WAVE_EMU
   hipLaunchKernelGGL(k_engine, dim3(1), dim3(PLAN_THREADS), 0, s, mb, wc, epoch, flags);
-  return hipGetLastError();
-}
-extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch,
-                                                                               uint32_t groups, uint32_t flags, hipStream_t s) {
-  hipLaunchKernelGGL(k_watch, dim3(groups), dim3(PLAN_THREADS), 0, s, mb, wc, epoch, flags);
+  hipLaunchKernelGGL(k_watch, dim3(groups), dim3(PLAN_THREADS), 0, ws, mb, wc, epoch, flags);
+#else
+  (void)ws;
+  (void)&k_watch;
+  hipLaunchKernelGGL(k_engine, dim3(1 + groups), dim3(PLAN_THREADS), 0, s, mb, wc, epoch, flags);
+#endif
   return hipGetLastError();
 }
 

@@ -311,6 +311,12 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
   }
 }
 
+// LDS index padding of the send plan's arrays (see tx_plan_body).  The first of them is declared here, outside the
+// function: a workgroup that never plans a Send -- a watcher of the latency engine, k_watch -- keeps its own tables in
+// these 34 KB (one kernel holds both bodies, and the compiler adds their LDS up).
+#define TXP(i) ((i) + ((i) >> 4))
+static __shared__ uint64_t g_txs_len[TXP(GRDMA_TX_MAX_RECORDS) + 1];
+
 // ----------------------------------------------------------------------------
 // k_tx_plan: PairPollable::Send arithmetic + rdma_flush cursor, one block per op
 // ----------------------------------------------------------------------------
@@ -328,8 +334,7 @@ __device__ __forceinline__ void tx_plan_body(const grdma_tx_op& op_in) {
   __shared__ uint64_t s_wave[PLAN_THREADS / 64];
   // LDS index padding: threads walk contiguous runs of up to 16 records, a 128-byte
   // stride that would put all 64 lanes on the same banks; one extra slot per 16 breaks it
-#define TXP(i) ((i) + ((i) >> 4))
-  __shared__ uint64_t s_len[TXP(GRDMA_TX_MAX_RECORDS) + 1];       // len_i, later pay_i
+  auto& s_len = g_txs_len;                                         // len_i, later pay_i
   __shared__ uint64_t s_excl[TXP(GRDMA_TX_MAX_RECORDS + 1) + 1];  // st_i
   __shared__ unsigned int s_first_short;
   __shared__ unsigned int s_wrap_rec;

@@ -368,6 +368,13 @@ int grdma_pingpong(grdma_pair* a, grdma_pair* b, const grdma_slice* req, uint64_
                    const grdma_slice* resp, uint64_t nresp, int mem_flags, uint64_t iters,
                    uint64_t warmup, uint64_t* rtt_ns, uint64_t phase_ns[4]);
 
+/* One END of a unary ping-pong whose other end lives in another process (the rings mapped through IPC handles,
+ * grdma_pair_bootstrap_fd): is_client = write `out`, then read until in_bytes have arrived; server = the other way
+ * round.  With a standing read order (grdma_pair_arm_read) the bytes the OTHER process wrote into this pair's ring are
+ * found by a watcher workgroup of this process's engine.  byte_sum = sum of every byte received. */
+int grdma_pingpong_end(grdma_pair* p, int is_client, const grdma_slice* out, uint64_t nout, uint64_t in_bytes, int mem_flags,
+                       uint64_t iters, uint64_t warmup, uint64_t* rtt_ns, uint64_t* byte_sum);
+
 /* ---- K3 batched message-ready detection ------------------------------------------- */
 /* HasMessage()/GetReadableSize() for n pairs in one launch (the busy-poll scan
  * of ev_epollex_rdma_bpev_linux.cc:1105-1149 / poller.cc:84).  readable[i] = bytes,

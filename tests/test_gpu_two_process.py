@@ -75,6 +75,38 @@ def test_credit_return_across_processes_for_ten_seconds(gpu):
     assert "ok server" in outs[0][1] and "ok client" in outs[1][1]
 
 
+def test_unary_pingpong_between_two_processes_on_the_arrival_triggered_path(gpu):
+    """BASELINE configs[1] across a process boundary: client process and server process, each with its own latency
+    engine; every read is a standing order carried out by a watcher workgroup of the READING process's engine when
+    the bytes the other process wrote land in its ring (k_watch) -- the path a NIC-fed ring takes too: the reader
+    learns of a message from its own ring, as ring_buffer.cc:56-97 / ev_epollex_rdma_bpev_linux.cc:1105-1149 do.
+    5000 round trips of [14 B][66 B]; byte sums, hit counts (no send carried a drain) and zero rings checked in
+    both processes (tests/two_proc_peer.py: unary_pingpong)."""
+    a, b = socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM)
+    env = dict(os.environ, GRDMA_TEST_PAIR_FLAGS="4")
+    env.pop("GRDMA_ENGINE_CHAIN", None)
+    procs = []
+    for role, sock in (("pp_server", a), ("pp_client", b)):
+        os.set_inheritable(sock.fileno(), True)
+        procs.append(subprocess.Popen([sys.executable, PEER, role, str(sock.fileno()), "0", "1024", "5000", "0", "0"],
+                                      pass_fds=[sock.fileno()], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    a.close()
+    b.close()
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        assert rc == 0, "peer failed:\n" + o + e[-3000:]
+    assert "ok server 5000 round trips" in outs[0][1] and "ok client 5000 round trips" in outs[1][1]
+    print(outs[1][1].strip())
+
+
 def test_killed_peer_turns_the_pair_half_closed(gpu):
     """kill -9 of the peer process: no Disconnect(), no peer_exit word.  The reference notices through
     ibv_query_qp every 500 ms (pair.cc:358-372 => kHalfClosed) and the TCP fd's hang-up; here get_status()

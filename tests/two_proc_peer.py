@@ -91,6 +91,46 @@ def on_the_clock(role, pair, w, seconds, ring_kib, write_size, slice_size):
     pair.close()
 
 
+def unary_pingpong(role, pair, iters, ring_kib):
+    """Unary 64-byte ping-pong ACROSS the process boundary on the arrival-triggered path: each process runs its own
+    latency engine; a read is a standing order (grdma_pair_arm_read) that a watcher workgroup of the READER's engine
+    carries out when the bytes the OTHER process wrote land in its ring (k_watch) -- no command of the reading process,
+    nothing both ends would have to share but the rings.  [14 B][66 B] each way, sizes and byte sums checked per end,
+    the rings all zero afterwards; the client prints its round-trip percentiles."""
+    lib = pair.lib
+    lib.grdma_cut_through_drains.restype = C.c_uint64
+    pair.set_latency_mode(True)
+    pair.arm_read(64)
+    check(lib.grdma_engine_start())
+    is_client = role == "pp_client"
+    msg = [bytes((i * 7 + (3 if is_client else 5)) % 251 for i in range(14)), bytes((i * 11 + (1 if is_client else 2)) % 253 for i in range(66))]
+    peer = [bytes((i * 7 + (5 if is_client else 3)) % 251 for i in range(14)), bytes((i * 11 + (2 if is_client else 1)) % 253 for i in range(66))]
+    arr, keep, _ = g.Pair._slices(msg)
+    warmup = max(10, iters // 10)
+    rtt = (C.c_uint64 * iters)()
+    bsum = C.c_uint64(0)
+    try:
+        check(lib.grdma_pingpong_end(pair.h, 1 if is_client else 0, arr, 2, 80, 1, iters, warmup, rtt, C.byref(bsum)))
+        hits, armed, ct = pair.watch_hits(), pair.armed_hits(), int(lib.grdma_cut_through_drains())
+        if is_client:
+            pair.Disconnect()
+        else:
+            for _ in range(4000):
+                if pair.get_status() == 3:
+                    break
+                time.sleep(0.005)
+    finally:
+        lib.grdma_engine_stop()
+    expect = sum(sum(x) for x in peer) * (iters + warmup)
+    assert bsum.value == expect, "byte sum of what arrived: %d, expected %d" % (bsum.value, expect)
+    assert hits == iters + warmup and armed == 0 and ct == 0, (hits, armed, ct)
+    assert pair.ring_mem() == bytes(ring_kib * 1024), "ring not zero after the ping-pong"
+    r = sorted(rtt)
+    print("ok %s %d round trips, watch hits %d, rtt p50 %.2f us p95 %.2f us p99 %.2f us" % (
+        "client" if is_client else "server", iters, hits, r[iters // 2] / 1e3, r[int(iters * .95)] / 1e3, r[int(iters * .99)] / 1e3))
+    pair.close()
+
+
 def main():
     role, fd, dev, ring_kib, num_bytes, write_size, slice_size = sys.argv[1], *map(int, sys.argv[2:8])
     g.init(dev)
@@ -111,6 +151,8 @@ def main():
         print("ok watcher: half closed %.3f s after the connection came up" % (time.time() - t0), flush=True)
         pair.close()
         return
+    if role in ("pp_client", "pp_server"):
+        return unary_pingpong(role, pair, num_bytes, ring_kib)
     w = Writer(pair)
     seconds = float(os.environ.get("GRDMA_TEST_SECONDS", "0"))
     if seconds > 0:
