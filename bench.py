@@ -569,7 +569,8 @@ def main():
         torch.cuda.synchronize()
 
     def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB,
-                pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None, burst=1, reps=1, sends=None, promise=False):
+                pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None, burst=1, reps=1, sends=None, promise=False,
+                reindex=False, bidi=False):
         """n_links connections with rings of ring_kb KiB.  Graph schedule: calibrate the number of
         rounds, capture the graph, time `steps` replays.  Engine schedule: every step is ONE launch of
         the persistent link engine.  Then verify, optionally instrument."""
@@ -580,9 +581,16 @@ def main():
         wf = flags if wire_flags is None else wire_flags
         wls = wls or get_workloads(n_links, msgs_per_link or args.msgs, payload)
         links, keep = [], []
-        for w in wls:
-            tx, rx = g.Pair(ring, max_sge, wf), g.Pair(ring, max_sge, wf)
-            g.connect_pairs(tx, rx)
+        prev = None
+        for k, w in enumerate(wls):
+            if bidi and k % 2 == 1:
+                # BASELINE configs[3] is BIDIRECTIONAL streaming: the second link of a pair runs the other way over the
+                # same two ends -- each end sender and receiver at once (pair.cc:264-286), both directions in every launch
+                rx, tx = prev
+            else:
+                tx, rx = g.Pair(ring, max_sge, wf), g.Pair(ring, max_sge, wf)
+                g.connect_pairs(tx, rx)
+                prev = (tx, rx)
             scap = len(w.lens) * 2 + 64 + w.N // 256
             dst_cap = w.N + 16 * scap + 4096
             dst = g.DeviceBuffer(nbytes=dst_cap)
@@ -606,6 +614,8 @@ def main():
                 job.set_sends(sends)                   # `sends` consecutive Sends in one plan per round, then one drain
             if promise:
                 job.set_promised_credit(True)          # the Send priced with the credit the drain in its launch will post
+            if reindex:
+                job.set_rebuild_index(True)            # the slice table counts as rewritten: k_tx_index in every step
             r = job.run(gs.RUN_EAGER)                  # calibration: how many rounds are needed
             assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
                 r.bytes_delivered, total_n)
@@ -998,6 +1008,10 @@ def main():
                                            "until one would block.  Two Sends are 63 MiB: the ring (256 MiB) holds four such rounds, "
                                            "as the 128 MiB ring of the earlier rounds held four rounds of one Send -- that "
                                            "configuration is value_ring128m_one_send_per_round",
+                   "slice_index": "`value` replays ONE slice table: the index its Sends are priced from (k_tx_index, prefix sums over "
+                                  "the table) is built in the job's first step only.  A real stream brings a new slice buffer with "
+                                  "every grpc_endpoint_write (rdma_bp_posix.cc:559-586): value_index_rebuilt_every_step is the same "
+                                  "step with the index rebuilt in EVERY step",
                    "rounds_per_step": rounds, "connections_per_gpu": 1,
                    "stages": "gather+encode, wire, ready-detect, decode+scatter+zero, credit"},
         "roofline": roofline,
@@ -1025,6 +1039,14 @@ def main():
             out["conn_setup_us"] = conn_setup_us(g)
         except Exception as e:
             out["conn_setup_error"] = str(e)[:200]
+    if not args.no_extra_legs and args.schedule != "engine":
+        # the headline step with the slice table counted as rewritten between steps: k_tx_index inside every timed step
+        try:
+            ri = measure(args.ring_kb, max(2, args.steps // 2), 1, not args.no_verify, False, pipeline=bool(args.pipeline), reindex=True)
+            out["value_index_rebuilt_every_step"] = round(wl.user_bytes * max(2, args.steps // 2) * world / ri["elapsed"] / (1 << 30), 3)
+            out["index_rebuilt_every_step_verified"] = ri["verified"]
+        except Exception as e:
+            out["index_rebuilt_every_step_error"] = str(e)[:200]
     if not args.no_extra_legs:
         # the same headline step with PRNG payload bytes (seed 1234): the reference's second payload kind
         try:
@@ -1232,6 +1254,19 @@ def main():
             mc["user_bytes"] * max(2, args.steps // 2) * world / mc["elapsed"] / (1 << 30), 3)
         out["config"]["multi_connection_leg"] = "%d connections x %d x 64 KiB messages per step, 4 MiB rings, %d rounds" % (
             args.conns, per, mc["rounds"])
+        # ... and as BASELINE.json states it -- BIDIRECTIONAL streaming: the same %d pairs with a link in each direction,
+        # every end sender and receiver at once, both directions of every pair in every launch, paired schedule
+        try:
+            bd_steps = max(2, args.steps // 2)
+            mb = measure(4096, bd_steps, 1, not args.no_verify, False, n_links=2 * args.conns, msgs_per_link=per,
+                         payload=64 * 1024, pipeline=True, sends=1, bidi=True)
+            out["value_conns%d_64KiB_bidi" % args.conns] = round(mb["user_bytes"] * bd_steps * world / mb["elapsed"] / (1 << 30), 3)
+            out["conns%d_64KiB_bidi_verified" % args.conns] = mb["verified"]
+            out["config"]["multi_connection_bidi_leg"] = (
+                "%d pairs x 2 directions x %d x 64 KiB messages per step (both directions counted), 4 MiB rings, paired "
+                "schedule, %d rounds" % (args.conns, per, mb["rounds"]))
+        except Exception as e:
+            out["conns%d_64KiB_bidi_error" % args.conns] = str(e)[:200]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, ring, min(args.max_sge, 4095))
         if not args.no_extra_legs:

@@ -45,6 +45,7 @@ class Config(C.Structure):
 # test can walk it against include/grdma_amd.h.
 SIGNATURES = {
     "grdma_abi_version": (C.c_int, []),
+    "grdma_stream_job_set_rebuild_index": (C.c_int, [C.c_void_p, C.c_int]),
     "grdma_pair_watch_hits": (C.c_int64, [C.c_void_p]),
     "grdma_pingpong_end": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Slice), u64, u64, C.c_int, u64, u64, C.POINTER(u64), C.POINTER(u64)]),
     "grdma_engine_watchers": (C.c_int, []),

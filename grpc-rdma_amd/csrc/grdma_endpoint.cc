@@ -244,6 +244,7 @@ struct grpc_rdma {  // rdma_bp_posix.cc:45-88
   int fd;
   std::atomic<int> refcount;
   std::atomic<bool> shutdown;
+  std::atomic<bool> shutdown_claimed{false};  // the one rdma_shutdown that sets shutdown_error and publishes `shutdown`
   grpc_error_handle shutdown_error;  // (written before `shutdown` is set, read after it has been seen set)
   grdma_pair* pair;
   bool enable_poller;
@@ -295,7 +296,9 @@ void rdma_write(grpc_endpoint* ep, grpc_slice_buffer* buf, grpc_closure* cb, voi
 
 void rdma_shutdown(grpc_endpoint* ep, grpc_error_handle why) {  // :106-110
   grpc_rdma* rdma = reinterpret_cast<grpc_rdma*>(ep);
-  if (!rdma->shutdown.load()) {
+  // (one winner: two concurrent shutdowns must not both assign shutdown_error and both run the armed closures --
+  //  grpc_fd_shutdown resolves the same race atomically)
+  if (!rdma->shutdown_claimed.exchange(true, std::memory_order_acq_rel)) {
     rdma->shutdown_error = why ? why : GRPC_ERROR_CREATE_FROM_STATIC_STRING("Endpoint shutdown");
     rdma->shutdown.store(true, std::memory_order_seq_cst);
     // grpc_fd_shutdown: pending notify_on_* closures run with the error

@@ -2191,7 +2191,21 @@ int grdma_endpoint_write_abort(grdma_pair* p) {
   // slices are read where they lie) and the caller is about to unref them: the send stream is drained first.  The
   // reference's Send is synchronous and has no such window.
   if (p->async && p->tx_inflight.load(std::memory_order_acquire)) {
-    if (p->s_tx && register_min() != 0) (void)hipStreamSynchronize(p->s_tx);
+    // the Send in flight reads the pinned tables (h_sges, the bounce buffer, the command block) -- and, with
+    // registered host slices, the caller's pages -- until it has completed: wait for ITS completion word (an engine
+    // command publishes txres.seq, a launch chain line->tx_seq) before the flag comes down and the next submit may
+    // overwrite them.  Bounded: a wedged device must not turn an error exit into a hang.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const uint64_t seen = p->tx_by_engine ? __atomic_load_n(&p->h->txres.seq, __ATOMIC_ACQUIRE)
+                                            : __atomic_load_n(&p->line->tx_seq, __ATOMIC_ACQUIRE);
+      if (seen >= p->tx_expect) break;
+      if (!p->tx_by_engine && p->s_tx) {
+        (void)hipStreamSynchronize(p->s_tx);
+        break;
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+    }
     p->tx_inflight.store(0, std::memory_order_release);
   }
   p->w_active = false;
@@ -4168,6 +4182,18 @@ int grdma_stream_job_set_promised_credit(grdma_stream_job* j, int on) {
   return 0;
 }
 
+int grdma_stream_job_set_rebuild_index(grdma_stream_job* j, int on) {
+  if (int rc = require_ctx()) return rc;
+  if (!j) return fail(GRDMA_ERR_INVALID, "null job");
+  if (j->sges_exposed == (on != 0)) return 0;
+  HIP_TRY(hipStreamSynchronize(j->stream));
+  j->sges_exposed = on != 0;      // (job_index_needed: the graph is captured with k_tx_index in front of round 0)
+  j->index_valid = false;
+  if (j->exec) hipGraphExecDestroy(j->exec);
+  j->exec = nullptr;
+  return 0;
+}
+
 // `sends` consecutive Sends per round in ONE plan (1 = the plain schedule): what rdma_flush does while the ring has
 // room -- Send, advance the cursor, Send again (rdma_bp_posix.cc:470-524) -- priced by the planners of
 // csrc/grdma_tx_multi.h from the index, Send k + 1 from the state Send k leaves; the peer drains once per round.  For
@@ -4197,6 +4223,7 @@ int grdma_stream_job_set_sends(grdma_stream_job* j, uint32_t sends) {
     HIP_TRY(hipMemcpy(&j->d_txf[i].sends, &sends, sizeof(uint32_t), hipMemcpyHostToDevice));
   }
   j->sends = sends;
+  j->index_valid = false;  // (built again by the next run's first round)
   return 0;
 }
 
@@ -4269,6 +4296,7 @@ int grdma_stream_job_set_burst(grdma_stream_job* j, uint32_t burst) {
     }
   HIP_TRY(hipMemcpy(j->d_bctl, host.data(), host.size(), hipMemcpyHostToDevice));
   j->burst = burst;
+  j->index_valid = false;  // (a burst schedule does not keep the slice index up to date)
   return 0;
 }
 
@@ -4371,7 +4399,9 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
   // register budget) for what those decline.  A job whose last drains / Send keep being declined -- no period in
   // its record sizes, Sends cut by the staging budget, ... -- goes back to the plain planner kernels.
   j->runs++;
-  if (mode != GRDMA_RUN_ENGINE && j->tx_fast && j->rounds >= 1) j->index_valid = true;  // (round 0 of this run built it)
+  // (round 0 of this run built the index -- only a schedule that prices its Sends from it launches k_tx_index: a run
+  //  with a burst, or on the link engine, leaves the index as it was)
+  if (mode != GRDMA_RUN_ENGINE && job_tx_fast(j) && j->rounds >= 1) j->index_valid = true;
   if (j->fuse_round_after >= 0 && j->runs >= j->fuse_round_after) j->fuse_round = 1;
   if (j->slim_after >= 0) {
     if (j->runs >= j->slim_after) j->rx_fast = j->tx_fast = 1;

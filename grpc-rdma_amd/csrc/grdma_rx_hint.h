@@ -37,7 +37,7 @@ struct rx_lds_hint {
   uint32_t x[RXH_MAX + 1];      // exclusive prefix of the encoded sizes
 };
 
-template <bool WT = false>  // (WT: see rxm_body)
+template <bool WT = false, bool EWT = WT>  // (WT, EWT: see rxm_body)
 __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg) {
   static_assert(sizeof(rx_lds_hint) <= sizeof(rx_lds) && sizeof(rx_lds_hint) <= RXM_SMALL_LDS_BYTES, "the tables fit their LDS");
   rx_lds_hint& H = *reinterpret_cast<rx_lds_hint*>(rx_tables<WT>());
@@ -251,27 +251,27 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
     for (int k = 0; k < 4; k++) {
       if (Lm.len[k] == 0) continue;
       const uint64_t fl = GRDMA_SEG_ZERO_SRC | (k == 0 ? GRDMA_SEG_TAG_HDR : 0) | (k == last_piece ? GRDMA_SEG_TAG_FTR : 0);
-      xwg_put_seg<WT>(&plan->segs[sg], (uint64_t)op.arena + A + Lm.dst_rel[k], (uint64_t)(ring + Lm.off[k]), (uint64_t)Lm.len[k], fl);
-      xwg_st32<WT>(&plan->tile_prefix[sg], tl);
+      xwg_put_seg<EWT>(&plan->segs[sg], (uint64_t)op.arena + A + Lm.dst_rel[k], (uint64_t)(ring + Lm.off[k]), (uint64_t)Lm.len[k], fl);
+      xwg_st32<EWT>(&plan->tile_prefix[sg], tl);
       sg++;
       tl += rxf_tiles(Lm.len[k], ts);
     }
     uint64_t sof = A;
     if (Lm.sl0) {
-      out_slices[sl].off = sof;
-      out_slices[sl].len = Lm.sl0;
+      xwg_st64<EWT>(&out_slices[sl].off, sof);
+      xwg_st64<EWT>(&out_slices[sl].len, (uint64_t)Lm.sl0);
       sl++;
       sof += rxf_al16(Lm.sl0);
     }
     if (Lm.sl1) {
-      out_slices[sl].off = sof;
-      out_slices[sl].len = Lm.sl1;
+      xwg_st64<EWT>(&out_slices[sl].off, sof);
+      xwg_st64<EWT>(&out_slices[sl].len, (uint64_t)Lm.sl1);
     }
   }
   const uint64_t t_emit = __builtin_amdgcn_s_memtime();
 
   // ---- 6. arrival: the last workgroup of the drain commits, or hands the drain to the general planner
-  if (WT) GRDMA_WAIT_VMEM();  // (my plan entries are at the memory side before I count in)
+  if (EWT) GRDMA_WAIT_VMEM();  // (my plan entries are at the memory side before I count in)
   __syncthreads();
   if (tid == 0) {
     const uint32_t prev = __hip_atomic_fetch_add(&plan->mw_arrive, 1u + (reason ? 0x10000u : 0u), __ATOMIC_RELAXED,

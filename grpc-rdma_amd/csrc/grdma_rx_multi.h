@@ -123,7 +123,12 @@ __device__ __forceinline__ void* rx_tables() {
 // thread of the workgroup returns the same value).
 // WT: the plan is moved by copy workgroups of the SAME launch (k_round_xag): plan and credit words are stored
 // write-through and acknowledged before a workgroup arrives (grdma_devfn.h: xwg_*); the caller publishes plan->ready.
-template <bool WT = false>
+// EWT: the entries a workgroup emits for its own records (segments, tile prefix, slices) are stored write-through
+// and acknowledged before it arrives, whatever WT says about the rest.  The kernels whose last workgroup runs the general
+// planner IN THE SAME LAUNCH when some workgroup declined (k_plan_pair_mw, k_rx_plan_mw) need it: that planner rewrites
+// the same slots from index 0, and entries left dirty in another XCD's L2 by a workgroup whose own probe passed would
+// be written back over them, or not, in no defined order when the kernel ends.
+template <bool WT = false, bool EWT = WT>
 __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg) {
   static_assert(sizeof(rx_lds_multi) <= sizeof(rx_lds) && sizeof(rx_lds_multi) <= RXM_SMALL_LDS_BYTES, "the tables fit their LDS");
   rx_lds_multi& M = *reinterpret_cast<rx_lds_multi*>(rx_tables<WT>());
@@ -469,27 +474,27 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     for (int k = 0; k < 4; k++) {
       if (L.len[k] == 0) continue;
       const uint64_t fl = GRDMA_SEG_ZERO_SRC | (k == 0 ? GRDMA_SEG_TAG_HDR : 0) | (k == last_piece ? GRDMA_SEG_TAG_FTR : 0);
-      xwg_put_seg<WT>(&plan->segs[sg], (uint64_t)op.arena + A + L.dst_rel[k], (uint64_t)(ring + L.off[k]), (uint64_t)L.len[k], fl);
-      xwg_st32<WT>(&plan->tile_prefix[sg], tl);
+      xwg_put_seg<EWT>(&plan->segs[sg], (uint64_t)op.arena + A + L.dst_rel[k], (uint64_t)(ring + L.off[k]), (uint64_t)L.len[k], fl);
+      xwg_st32<EWT>(&plan->tile_prefix[sg], tl);
       sg++;
       tl += rxf_tiles(L.len[k], ts);
     }
     uint64_t sof = A;
     if (L.sl0) {
-      out_slices[sl].off = sof;
-      out_slices[sl].len = L.sl0;
+      xwg_st64<EWT>(&out_slices[sl].off, sof);
+      xwg_st64<EWT>(&out_slices[sl].len, (uint64_t)L.sl0);
       sl++;
       sof += rxf_al16(L.sl0);
     }
     if (L.sl1) {
-      out_slices[sl].off = sof;
-      out_slices[sl].len = L.sl1;
+      xwg_st64<EWT>(&out_slices[sl].off, sof);
+      xwg_st64<EWT>(&out_slices[sl].len, (uint64_t)L.sl1);
     }
   }
   const uint64_t t_emit = __builtin_amdgcn_s_memtime();
 
   // ---- 7. arrival: the last workgroup of the drain commits, or hands the drain to the general planner
-  if (WT) GRDMA_WAIT_VMEM();  // (my plan entries are at the memory side before I count in)
+  if (EWT) GRDMA_WAIT_VMEM();  // (my plan entries are at the memory side before I count in)
   __syncthreads();
   if (tid == 0) {
     const uint32_t prev = __hip_atomic_fetch_add(&plan->mw_arrive, 1u + (reason ? 0x10000u : 0u), __ATOMIC_RELAXED,

@@ -1669,10 +1669,11 @@ void k_plan_pair_mw(const grdma_rx_op* rxops, const grdma_tx_op* txops, const gr
     // a connection whose record sizes have a period: predicted from the pattern; none, but the round carries the sizes its
     // own Send computed: predicted from those (grdma_rx_hint.h).  Either way every record is verified in the ring.
     const grdma_rx_op& rop = rxops[blockIdx.x];
-    int r = rxm_body(rop, blockIdx.y, G);
+    // (<false, true>: every workgroup's own entries write-through -- the general planner may rewrite them below)
+    int r = rxm_body<false, true>(rop, blockIdx.y, G);
     if (r == 3) {  // (uniform over the whole grid: no workgroup has arrived yet)
       __syncthreads();
-      r = rxh_body(rop, blockIdx.y, G);
+      r = rxh_body<false, true>(rop, blockIdx.y, G);
     }
     if (r == 0) return;  // (uniform: not the committing workgroup)
     if (r == 2) {
@@ -1718,10 +1719,10 @@ void k_plan_pair_mw(const grdma_rx_op* rxops, const grdma_tx_op* txops, const gr
 __global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_rx_plan_mw(const grdma_rx_op* rxops) {
   const grdma_rx_op& rop = rxops[blockIdx.x];
-  int r = rxm_body(rop, blockIdx.y, gridDim.y);
+  int r = rxm_body<false, true>(rop, blockIdx.y, gridDim.y);
   if (r == 3) {
     __syncthreads();
-    r = rxh_body(rop, blockIdx.y, gridDim.y);
+    r = rxh_body<false, true>(rop, blockIdx.y, gridDim.y);
   }
   if (r != 2) return;  // (uniform)
   rx_plan_body(rop);

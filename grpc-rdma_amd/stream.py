@@ -75,6 +75,12 @@ class StreamJob:
         self.lib.grdma_stream_job_set_promised_credit.argtypes = [C.c_void_p, C.c_int]
         check(self.lib.grdma_stream_job_set_promised_credit(self.h, 1 if on else 0))
 
+    def set_rebuild_index(self, on=True):
+        """The slice tables are rewritten between steps: the index the Sends are priced from is rebuilt in every step
+        (grdma_stream_job_set_rebuild_index)."""
+        self.lib.grdma_stream_job_set_rebuild_index.argtypes = [C.c_void_p, C.c_int]
+        check(self.lib.grdma_stream_job_set_rebuild_index(self.h, 1 if on else 0))
+
     def set_burst(self, burst):
         """`burst` Sends per round before the peer drains (grdma_stream_job_set_burst)."""
         self.lib.grdma_stream_job_set_burst.argtypes = [C.c_void_p, C.c_uint32]

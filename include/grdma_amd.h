@@ -464,6 +464,10 @@ int grdma_stream_job_set_sends(grdma_stream_job* j, uint32_t sends);
 /* Paired schedule, staged wire: price the Send of round t + 1 with the credit the drain of round t will post (it waits
  * for that drain's plan inside the launch they share) -- no round of credit lag at a ring every round fills. */
 int grdma_stream_job_set_promised_credit(grdma_stream_job* j, int on);
+/* The job's slice tables are rewritten between steps (every grpc_endpoint_write brings a new slice buffer,
+ * rdma_bp_posix.cc:559-586): the index its Sends are priced from (k_tx_index: prefix sums over the table) is rebuilt
+ * in EVERY step's first round instead of once per job.  bench.py times both. */
+int grdma_stream_job_set_rebuild_index(grdma_stream_job* j, int on);
 
 /* ---- diagnostics (profiling aids used by tools/; not needed by an integration) ------------
  * s_memtime stamps / counters the plan kernels leave in their result blocks, the

@@ -111,6 +111,14 @@ def test_latency_engine_gpu_tests_under_the_emulator(emu_lib):
     run_gpu_tests(emu_lib, ["tests/test_zz_gpu_latency_engine.py", "tests/test_zzz_gpu_armed_read.py"], 6)
 
 
+def test_arrival_triggered_reads_under_the_emulator(emu_lib):
+    """Round 5: k_watch -- the watcher workgroup that carries out a pair's standing read order when bytes land in its
+    ring (a second resident thread here), its single-wave drain (rxw_fast) and the plan body behind it, on unary
+    ping-pongs, random sequences over staged / direct / fine-grained / wrapping rings, an ordered wire, an engine that
+    is stopped and started: bytes, state, histories and rings against the oracle (tests/test_zzz_gpu_watch_read.py)."""
+    run_gpu_tests(emu_lib, ["tests/test_zzz_gpu_watch_read.py", "-n", "4"], 13)
+
+
 def test_pair_protocol_gpu_tests_under_the_emulator(emu_lib):
     """All of tests/test_gpu_pair_parity.py: random operation sequences in the four wire / memory modes, the golden
     traces, batched polling, the multi-record drains of k_rx_plan (chain walker, one-lane-per-record replay, bulk tier
