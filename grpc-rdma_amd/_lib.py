@@ -46,6 +46,11 @@ class Config(C.Structure):
 SIGNATURES = {
     "grdma_abi_version": (C.c_int, []),
     "grdma_stream_job_set_rebuild_index": (C.c_int, [C.c_void_p, C.c_int]),
+    "grdma_verbs_supported": (C.c_int, []),
+    "grdma_pair_verbs_open": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "grdma_pair_verbs_address": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "grdma_pair_verbs_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "grdma_pair_verbs_counts": (C.c_int, [C.c_void_p, C.POINTER(u64)]),
     "grdma_pair_watch_hits": (C.c_int64, [C.c_void_p]),
     "grdma_pingpong_end": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Slice), u64, u64, C.c_int, u64, u64, C.POINTER(u64), C.POINTER(u64)]),
     "grdma_engine_watchers": (C.c_int, []),

@@ -39,6 +39,7 @@
 #include "grdma_dev.h"
 #include "grdma_host.h"
 #include "grdma_ops.h"
+#include "grdma_wire_verbs.h"
 #include "grdma_link.h"
 
 extern "C" {
@@ -274,6 +275,7 @@ struct grdma_pair {
   // ... or, by default, a watcher workgroup of the engine carries the standing order out when bytes land in this
   // pair's ring, whoever wrote them (k_watch): the slot it was handed, the sequence word of the next completion,
   // completions taken since the arming (what grdma_engine_mbox::consumed tells the device), completions taken in all
+  grdma_verbs_wire* verbs = nullptr; // != NULL: a NIC writes the peer's ring and mine (csrc/grdma_wire_verbs.cc)
   int watch_slot = -1;
   uint64_t watch_expect = 0, watch_taken = 0, watch_hits = 0;
   uint64_t armed_half = 0;           // which half of the arena the completion `armed_done` stands for lies in (a
@@ -859,8 +861,16 @@ int run_send(grdma_pair* p, uint64_t count, uint64_t byte_idx, uint32_t use_curs
   }
   HIP_TRY(grdma_launch_tx_plan(&h->txop, 1, p->stream));
   HIP_TRY(grdma_launch_copy(&h->plan_ptrs[0], 1, blocks, p->stream));
-  if (!(p->flags & GRDMA_WIRE_DIRECT))
+  if (p->verbs) {
+    // the wire is a NIC: the records lie encoded in the staging buffer, the planner has left the Send's <= 2 write
+    // requests in the result block (K2) -- posted as chained RDMA WRITEs and reaped (pair.cc:709-734, waitDataWrites)
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    std::string err;
+    if (grdma_verbs_post_data(p->verbs, h->txres.wr_off, h->txres.wr_len, h->txres.wr_count, &err) != 0)
+      return fail(GRDMA_ERR_HIP, "NIC wire: %s", err.c_str());
+  } else if (!(p->flags & GRDMA_WIRE_DIRECT)) {
     HIP_TRY(grdma_launch_copy(&h->plan_ptrs[1], 1, blocks, p->stream));
+  }
   // behind the wire write, as a kernel of its own: the arrival report (and the state lines)
   HIP_TRY(grdma_launch_tx_commit1(p->d_conn, ++p->tx_seq, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -892,6 +902,12 @@ int run_recv(grdma_pair* p, uint8_t* arena, uint64_t arena_cap, uint64_t max_rea
   HIP_TRY(grdma_launch_rx_plan(&h->rxop, 1, p->stream));
   HIP_TRY(grdma_launch_rx_apply(&h->rxop, 1, blocks, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->verbs && h->rxres.credit_sent) {
+    // updateStatus() (pair.cc:624-641): the drain's planner has left remote_head in status_send; the copy-out and the
+    // zero-fill of the bytes it grants are done (the synchronize above) -- the 16-byte report goes out as an RDMA WRITE
+    std::string err;
+    if (grdma_verbs_post_status(p->verbs, &err) != 0) return fail(GRDMA_ERR_HIP, "NIC wire: %s", err.c_str());
+  }
   return 0;
 }
 
@@ -1081,6 +1097,10 @@ void grdma_pair_destroy(grdma_pair* p) {
     std::lock_guard<std::mutex> lk(g_exported_mu);
     auto it = g_exported.find(p->serial);
     if (it != g_exported.end() && it->second == p) g_exported.erase(it);
+  }
+  if (p->verbs) {
+    grdma_verbs_close(p->verbs);
+    p->verbs = nullptr;
   }
   if (p->watch_slot >= 0) {  // (its watcher lets the connection go before the memory does)
     std::lock_guard<std::mutex> lk(g_engine.mu);
@@ -1439,6 +1459,14 @@ int grdma_pair_disconnect(grdma_pair* p) {
     HIP_TRY(hipMemcpy(dst + offsetof(grdma_status_report, peer_exit), &one, sizeof(one), hipMemcpyHostToDevice));
     if (p->peer && p->peer->line)  // an in-process peer sees it in its state line at once
       __atomic_store_n(&p->peer->line->peer_exit, 1, __ATOMIC_RELEASE);
+  }
+  if (st0 == GRDMA_PAIR_CONNECTED && p->verbs) {
+    // Disconnect() over a NIC wire (pair.cc:332-336): peer_exit = 1 in my status_send, and the report goes out
+    int32_t one = 1;
+    HIP_TRY(hipMemcpy(reinterpret_cast<uint8_t*>(p->d_conn) + offsetof(grdma_conn, status_send) + offsetof(grdma_status_report, peer_exit),
+                      &one, sizeof(one), hipMemcpyHostToDevice));
+    std::string err;
+    (void)grdma_verbs_post_status(p->verbs, &err);  // (a peer that is gone already: nothing to tell)
   }
   uint32_t st = GRDMA_PAIR_DISCONNECTED;
   HIP_TRY(hipMemcpy(reinterpret_cast<uint8_t*>(p->d_conn) + offsetof(grdma_conn, status), &st,
@@ -1966,6 +1994,63 @@ int grdma_pair_set_latency_mode(grdma_pair* p, int on) {
   if (!on && p->armed_done) return fail(GRDMA_ERR_INVALID, "an armed read has completed and was not consumed");
   if (!on) p->armed_reads = 0;
   p->latency = on != 0;
+  return 0;
+}
+
+// ---- NIC wire (ibverbs): see include/grdma_amd.h and csrc/grdma_wire_verbs.cc -------------------------------------
+int grdma_verbs_supported(void) { return grdma_verbs_available() ? 1 : 0; }
+
+int grdma_pair_verbs_open(grdma_pair* p, const char* device, int port, int gid_index) {
+  if (int rc = require_ctx()) return rc;
+  if (!p) return fail(GRDMA_ERR_INVALID, "null pair");
+  if (p->verbs) return fail(GRDMA_ERR_INVALID, "the pair has a NIC wire already");
+  if (!(p->flags & GRDMA_WIRE_ORDERED) || (p->flags & GRDMA_WIRE_DIRECT))
+    return fail(GRDMA_ERR_INVALID, "a NIC-written ring needs GRDMA_WIRE_ORDERED and a staged wire (no GRDMA_WIRE_DIRECT)");
+  if (p->status.load() == GRDMA_PAIR_CONNECTED) return fail(GRDMA_ERR_INVALID, "the pair is connected already");
+  // the ring's dma-buf, where the runtime exports one (what ibv_reg_dmabuf_mr takes): -1 = register by address
+  int fd = grdma_pair_export_ring_dmabuf(p);
+  if (fd < 0) fd = -1;
+  uint8_t* conn = reinterpret_cast<uint8_t*>(p->d_conn);
+  std::string err;
+  p->verbs = grdma_verbs_open(device, port, gid_index, p->d_ring, p->ring_size, fd, p->d_staging, p->ring_size / 2 + 64,
+                              conn + offsetof(grdma_conn, status_send), conn + offsetof(grdma_conn, status_recv),
+                              sizeof(grdma_status_report), &err);
+  if (fd >= 0) close(fd);  // (the registration holds its own reference)
+  if (!p->verbs) return fail(GRDMA_ERR_HIP, "NIC wire: %s", err.c_str());
+  return 0;
+}
+
+int grdma_pair_verbs_address(grdma_pair* p, grdma_verbs_address* out) {
+  if (!p || !out || !p->verbs) return fail(GRDMA_ERR_INVALID, "no NIC wire on this pair");
+  return grdma_verbs_address_of(p->verbs, out) == 0 ? 0 : fail(GRDMA_ERR_HIP, "NIC wire: no address");
+}
+
+int grdma_pair_verbs_connect(grdma_pair* p, const grdma_verbs_address* peer) {
+  if (int rc = require_ctx()) return rc;
+  if (!p || !peer || !p->verbs) return fail(GRDMA_ERR_INVALID, "no NIC wire on this pair");
+  if (peer->ring_size != p->ring_size)  // pair.cc:149
+    return fail(GRDMA_ERR_INVALID, "ring sizes differ (%llu vs %llu)", (unsigned long long)p->ring_size, (unsigned long long)peer->ring_size);
+  std::string err;
+  if (grdma_verbs_connect(p->verbs, peer, &err) != 0) return fail(GRDMA_ERR_HIP, "NIC wire: %s", err.c_str());
+  grdma_conn c;
+  if (int rc = fetch_conn(p, &c)) return rc;
+  c.peer_ring = nullptr;      // what this end writes leaves through the queue pair, never through a pointer
+  c.peer_status = nullptr;
+  c.peer_wire = nullptr;      // (a NIC places bytes in order: the peer reads by the records' tags, no arrival report)
+  c.peer_line = nullptr;
+  c.line_remote = 1;          // credit lands in status_recv by DMA: the state line is refreshed from the connection block
+  c.peer_limited = 0;
+  c.wire_limit = 0;
+  c.status = GRDMA_PAIR_CONNECTED;
+  HIP_TRY(hipMemcpy(p->d_conn, &c, sizeof(c), hipMemcpyHostToDevice));
+  p->remote = true;           // (host-side queries take the paths of a peer that is not in this process)
+  p->status.store(GRDMA_PAIR_CONNECTED);
+  return 0;
+}
+
+int grdma_pair_verbs_counts(grdma_pair* p, uint64_t out[3]) {
+  if (!p || !out) return fail(GRDMA_ERR_INVALID, "null argument");
+  grdma_verbs_counts(p->verbs, out);
   return 0;
 }
 

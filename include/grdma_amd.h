@@ -335,6 +335,34 @@ int grdma_forget_host_range(const void* ptr, uint64_t len);
  * RDMA NIC -- the place of ibv_reg_mr() in the reference (rdma_utils.h:108-160, pair.cc:107-119).
  * Returns the fd (owned by the caller: close() it) or < 0. */
 int grdma_pair_export_ring_dmabuf(grdma_pair* p);
+/* ---- NIC wire (ibverbs): what PairPollable's verbs calls are in the reference --------------------------------
+ * grdma_pair_verbs_open     Init(): device, protection domain, completion queue, queue pair; ring and status block
+ *                           registered remote-writable -- the ring through its dma-buf where the verbs library has
+ *                           ibv_reg_dmabuf_mr -- staging buffer and status_send as local regions (pair.cc:107-119,
+ *                           rdma_utils.h:108-160).  The pair must have been created with GRDMA_WIRE_ORDERED (a NIC places
+ *                           the bytes of a write in order, footer last) and without GRDMA_WIRE_DIRECT.
+ * grdma_pair_verbs_address  what the reference's Address carries for this end (pair.h:53-98): queue pair number, lid,
+ *                           gid, ring and status addresses with their rkeys.
+ * grdma_pair_verbs_connect  Connect(peer): RESET -> INIT -> RTR -> RTS (pair.cc:143-262); the pair is kConnected and
+ *                           from then on a Send's <= 2 chained IBV_WR_RDMA_WRITEs (pair.cc:709-734: what the send planner
+ *                           left in grdma_pair_last_wrs) and a drain's 16-byte status write (updateStatus, :624-641) are
+ *                           posted through the queue pair and reaped (csrc/grdma_wire_verbs.cc).
+ * Libraries built without <infiniband/verbs.h> (grdma_verbs_supported() == 0) report an error from _open. */
+typedef struct grdma_verbs_address {
+  uint32_t qpn, psn;
+  uint16_t lid;
+  uint16_t pad0;
+  uint32_t ring_rkey;
+  uint8_t gid[16];
+  uint64_t ring_addr, ring_size;
+  uint64_t status_addr;
+  uint32_t status_rkey, status_size;
+} grdma_verbs_address;
+int grdma_verbs_supported(void);
+int grdma_pair_verbs_open(grdma_pair* p, const char* device, int port, int gid_index);
+int grdma_pair_verbs_address(grdma_pair* p, grdma_verbs_address* out);
+int grdma_pair_verbs_connect(grdma_pair* p, const grdma_verbs_address* peer);
+int grdma_pair_verbs_counts(grdma_pair* p, uint64_t out[3]);  /* data writes posted, status writes posted, completions reaped */
 void* grdma_pair_arena_device_ptr(grdma_pair* p);
 uint64_t grdma_pair_arena_size(grdma_pair* p);
 int grdma_pair_arena_copy_out(grdma_pair* p, uint64_t off, void* host_dst, uint64_t len);

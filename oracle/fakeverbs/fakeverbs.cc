@@ -121,6 +121,9 @@ ibv_mr* ibv_reg_mr(ibv_pd* pd, void* addr, size_t length, int) {
   F().mrs[mr->lkey] = mr;
   return mr;
 }
+ibv_mr* ibv_reg_dmabuf_mr(ibv_pd* pd, uint64_t offset, size_t length, uint64_t iova, int, int access) {
+  return ibv_reg_mr(pd, reinterpret_cast<void*>(iova + offset), length, access);
+}
 int ibv_dereg_mr(ibv_mr* mr) {
   std::lock_guard<std::mutex> lk(F().mu);
   F().mrs.erase(mr->lkey);

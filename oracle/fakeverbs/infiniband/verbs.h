@@ -181,6 +181,9 @@ int ibv_query_gid(struct ibv_context* context, uint8_t port_num, int index, unio
 struct ibv_pd* ibv_alloc_pd(struct ibv_context* context);
 int ibv_dealloc_pd(struct ibv_pd* pd);
 struct ibv_mr* ibv_reg_mr(struct ibv_pd* pd, void* addr, size_t length, int access);
+/* (rdma-core >= 34: a memory region over a dma-buf -- how device memory is registered for GPUDirect RDMA.  Here the
+ *  "device" is process memory: iova is the address, the descriptor is not looked at.) */
+struct ibv_mr* ibv_reg_dmabuf_mr(struct ibv_pd* pd, uint64_t offset, size_t length, uint64_t iova, int fd, int access);
 int ibv_dereg_mr(struct ibv_mr* mr);
 struct ibv_cq* ibv_create_cq(struct ibv_context* context, int cqe, void* cq_context, void* channel, int comp_vector);
 int ibv_destroy_cq(struct ibv_cq* cq);

@@ -119,6 +119,15 @@ def test_arrival_triggered_reads_under_the_emulator(emu_lib):
     run_gpu_tests(emu_lib, ["tests/test_zzz_gpu_watch_read.py", "-n", "4"], 13)
 
 
+def test_nic_wire_back_end_over_the_verbs_stand_in(emu_lib):
+    """Round 5: csrc/grdma_wire_verbs.cc -- memory registration (the ring through the dma-buf call), queue-pair bring-up,
+    the <= 2 chained RDMA WRITEs of a Send, the 16-byte status write, completion reaping -- compiled against
+    oracle/fakeverbs and driven by the reference-made endpoint traces: results step by step, write requests and ring
+    image after every Send against the oracle (tests/test_zz_gpu_wire_verbs.py; skipped on the GPU box, whose library
+    is built without <infiniband/verbs.h>)."""
+    run_gpu_tests(emu_lib, ["tests/test_zz_gpu_wire_verbs.py", "-n", "4"], 5)
+
+
 def test_pair_protocol_gpu_tests_under_the_emulator(emu_lib):
     """All of tests/test_gpu_pair_parity.py: random operation sequences in the four wire / memory modes, the golden
     traces, batched polling, the multi-record drains of k_rx_plan (chain walker, one-lane-per-record replay, bulk tier
