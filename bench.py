@@ -498,9 +498,9 @@ def main():
     ap.add_argument("--no-fanout", action="store_true", help="skip the RCCL fan-out leg (N>1 only)")
     ap.add_argument("--conns", type=int, default=32,
                     help="connections per GPU in the multi-connection leg (BASELINE configs[3]: 32); 1 = skip")
-    ap.add_argument("--schedule", choices=["graph", "engine"], default="graph",
-                    help="how the timed step is launched: the round-by-round kernels of a HIP graph, or ONE launch of "
-                         "the persistent link engine (k_link); the other one is reported as a comparison leg")
+    ap.add_argument("--schedule", choices=["graph"], default="graph",
+                    help="how the timed step is launched: the round-by-round kernels of a HIP graph (the persistent link "
+                         "engine, k_link -- a third of this rate in rounds 2 - 4 -- was retired in round 5)")
     ap.add_argument("--no-tcp-baseline", action="store_true", help="skip the loop-back TCP baselines")
     ap.add_argument("--reps", type=int, default=3,
                     help="timed regions of --steps steps each; the median is reported (reference protocol: 3 repetitions)")
@@ -571,9 +571,8 @@ def main():
     def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB,
                 pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None, burst=1, reps=1, sends=None, promise=False,
                 reindex=False, bidi=False):
-        """n_links connections with rings of ring_kb KiB.  Graph schedule: calibrate the number of
-        rounds, capture the graph, time `steps` replays.  Engine schedule: every step is ONE launch of
-        the persistent link engine.  Then verify, optionally instrument."""
+        """n_links connections with rings of ring_kb KiB: calibrate the number of rounds, capture the graph, time
+        `steps` replays.  Then verify, optionally instrument."""
         ring = ring_kb * 1024
         max_sge = max_sge or args.max_sge
         if sends is None:
@@ -600,13 +599,7 @@ def main():
         est_rounds = max(8, 4 * (w0.E // (ring // 2) + 2), 2 * (len(w0.lens) // min(max_sge, 4095) + 2))
         job = gs.MultiStreamJob(links, est_rounds)
         total_n = sum(w.N for w in wls)
-        if engine:
-            r = job.run(gs.RUN_ENGINE)
-            assert r.done and r.bytes_delivered == total_n, "engine pass did not deliver everything (%d/%d bytes)" % (
-                r.bytes_delivered, total_n)
-            rounds = int(max(r.tx_rounds, r.rx_rounds))
-            launch = job.launch_engine
-        else:
+        if True:
             job.set_pipeline(pipeline)
             if burst > 1:
                 job.set_burst(burst)                   # `burst` Sends per round, then one drain
@@ -657,7 +650,7 @@ def main():
                "user_bytes": sum(w.user_bytes for w in wls), "N": total_n,
                "E": sum(w.E for w in wls)}
         if verify:  # correctness of what the timed region produced (untimed)
-            r = job.run(gs.RUN_ENGINE if engine else gs.RUN_GRAPH)
+            r = job.run(gs.RUN_GRAPH)
             assert r.done and r.bytes_delivered == total_n and r.bytes_sent == total_n
             for li, (tx, rx, dst, dst_cap, w) in enumerate(keep):
                 if li not in (0, len(keep) - 1):
@@ -669,9 +662,7 @@ def main():
                 assert stream == exp, "delivered byte stream differs from the framed messages"
                 assert rx.ring_mem() == bytes(ring), "ring not zero after the drain"
             out["verified"] = True
-        if engine:
-            out["engine"] = job.engine_stats(0)
-        if instrument and not engine:  # per-kernel time, HIP events on the launch stream
+        if instrument:  # per-kernel time, HIP events on the launch stream
             inst = None
             for _ in range(3):
                 inst = job.run(gs.RUN_INSTRUMENTED)
@@ -726,16 +717,13 @@ def main():
             dst = g.DeviceBuffer(nbytes=dst_cap)
             est = max(8, 4 * (w.E // (ring // 2) + 2), 2 * (len(w.lens) // min(args.max_sge, 4095) + 2))
             job = gs.MultiStreamJob([(tx, rx, w.sge, dst.ptr, dst_cap, scap)], est)
-            if engine:
-                r = job.run(gs.RUN_ENGINE)
-            else:
-                job.set_pipeline(bool(args.pipeline))
-                h2_sends = args.sends if args.pipeline else 1
-                if h2_sends > 1:
-                    job.set_sends(h2_sends)
-                r = job.run(gs.RUN_EAGER)
-                job.set_rounds(int(max(-(-int(r.tx_rounds) // h2_sends), r.rx_rounds)))
-                r = job.run(gs.RUN_GRAPH)
+            job.set_pipeline(bool(args.pipeline))
+            h2_sends = args.sends if args.pipeline else 1
+            if h2_sends > 1:
+                job.set_sends(h2_sends)
+            r = job.run(gs.RUN_EAGER)
+            job.set_rounds(int(max(-(-int(r.tx_rounds) // h2_sends), r.rx_rounds)))
+            r = job.run(gs.RUN_GRAPH)
             assert r.done and r.bytes_delivered == w.N
             delivered = len(job.delivered_slices(0))
             pipes.append(h2dev.Pipe(job, msgs, parser, delivered, 4 * len(w.lens) + 1024))
@@ -747,13 +735,13 @@ def main():
             else:
                 os.environ["GRDMA_H2_PIPE_FUSED"] = env_fused
         for i in range(max(2, warmup)):
-            pipes[i % n_pipes].enqueue(engine)
+            pipes[i % n_pipes].enqueue(False)
         for p_ in pipes:
             p_.sync()
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            pipes[i % n_pipes].enqueue(engine)
+            pipes[i % n_pipes].enqueue(False)
         for p_ in pipes:
             p_.sync()
         torch.cuda.synchronize()
@@ -818,7 +806,7 @@ def main():
                             ("value_with_h2_sequential_deframer", False, False)):
             if tag != "value_with_h2" and os.environ.get("BENCH_H2_DEFAULT_LEG_ONLY"):
                 continue
-            h2_ = measure_with_h2(args.ring_kb, args.steps, max(2, args.warmup), engine=(args.schedule == "engine"), chunks=ch,
+            h2_ = measure_with_h2(args.ring_kb, args.steps, max(2, args.warmup), chunks=ch,
                                   fused=fu)
             o_[tag] = round(wl.user_bytes * args.steps * world / h2_["elapsed"] / (1 << 30), 3)
             o_[tag + "_verified"] = h2_["verified"]
@@ -828,7 +816,7 @@ def main():
 
     if args.h2_bulk_pairs_only:  # the child of the value_with_h2_bulk_pairs leg: one leg, one JSON line
         few = max(2, args.steps // 4)
-        h2_ = measure_with_h2(args.ring_kb, few, 2, engine=(args.schedule == "engine"), bulk_pairs=False)
+        h2_ = measure_with_h2(args.ring_kb, few, 2, bulk_pairs=False)
         print(json.dumps({"value_with_h2_bulk32": round(wl.user_bytes * few * world / h2_["elapsed"] / (1 << 30), 3),
                           "with_h2_bulk32_deframe_us": h2_["stages"]["deframe_us"],
                           "with_h2_bulk32_verified": h2_["verified"]}))
@@ -849,18 +837,6 @@ def main():
     if head is None:
         head, seq = seq, None
     graph_head = head
-    eng = None
-    if args.schedule == "engine" or not args.no_extra_legs:
-        try:
-            eng = measure(args.ring_kb, args.steps if args.schedule == "engine" else max(2, args.steps // 2),
-                          args.warmup if args.schedule == "engine" else 1, not args.no_verify, False, engine=True)
-        except Exception as e:
-            eng = None
-            if args.schedule == "engine":
-                schedule += " (engine run failed: %s)" % str(e)[:120]
-    if args.schedule == "engine" and eng is not None:
-        head = dict(eng, classes=graph_head["classes"])
-        schedule = "engine (one k_link launch per step)"
     elapsed, rounds, classes, verified = head["elapsed"], head["rounds"], head["classes"], head["verified"]
     ring = args.ring_kb * 1024
     small = None
@@ -966,13 +942,6 @@ def main():
     roofline["step_level"] = {"bytes": int(step_bytes), "achieved": round(step_bytes / step_s / 1e9, 1), "unit": "GB/s",
                               "frac": round(step_bytes / step_s / 1e9 / HBM_PEAK_GBPS, 4),
                               "frac_with_wire": round((step_bytes + 2 * wl.E) / step_s / 1e9 / HBM_PEAK_GBPS, 4)}
-    if args.schedule == "engine" and eng is not None:
-        # one kernel does the whole step: N read + N written (gather), E + E (wire), N + N + N (scatter + clear)
-        per_launch = 5 * wl.N + 2 * wl.E
-        us = 1e6 * elapsed / args.steps
-        roofline = {"bound": "hbm", "kernel": "k_link (whole step)", "achieved": round(per_launch / us / 1e3, 1),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(per_launch / us / 1e3 / HBM_PEAK_GBPS, 4),
-                    "traffic": None, "bytes_per_launch": int(per_launch), "us_per_launch": round(us, 2)}
     try:
         roofline["measured_ceiling"] = measured_copy_ceiling(torch, torch.device("cuda", local_rank))
     except Exception as e:
@@ -1092,20 +1061,10 @@ def main():
         except Exception as e:
             out["wire_direct_error"] = str(e)[:200]
     half = max(2, args.steps // 2)
-    if args.schedule == "engine":
-        out["value_graph"] = round(wl.user_bytes * args.steps * world / graph_head["elapsed"] / (1 << 30), 3)
-    elif eng is not None:
-        out["value_engine"] = round(wl.user_bytes * half * world / eng["elapsed"] / (1 << 30), 3)
-    if eng is not None:
-        st = eng["engine"]
-        out["engine"] = {"launches_per_step": 1, "sends": st["sends"], "receive_chunks": st["chunks"],
-                         "table_entries": [st["gather_entries"], st["wire_entries"], st["scatter_entries"]],
-                         "worker_waves": [st["gather_waves"], st["wire_waves"], st["scatter_waves"]],
-                         "workgroups": st["team"], "staging_buffers": st["staging_buffers"], "verified": eng["verified"]}
     if not args.no_extra_legs or os.environ.get("BENCH_H2"):
         # frame -> endpoint -> deframe, all three inside the timed device pipeline
         try:
-            hh = measure_with_h2(args.ring_kb, args.steps, max(2, args.warmup), engine=(args.schedule == "engine"))
+            hh = measure_with_h2(args.ring_kb, args.steps, max(2, args.warmup))
             out["value_with_h2"] = round(wl.user_bytes * args.steps * world / hh["elapsed"] / (1 << 30), 3)
             out["with_h2_verified"] = hh["verified"]
             out["with_h2_stages"] = hh["stages"]
@@ -1119,10 +1078,9 @@ def main():
                                             "value_with_h2_bulk32: 32 frames per bulk step (GRDMA_H2_BULK_PAIRS=0)")
         except Exception as e:
             out["with_h2_error"] = err_text(e)
-        eng_ = (args.schedule == "engine")
         few = max(2, args.steps // 4)
         try:  # per-stage times: the stages enqueued around the job's graph, each between two events
-            hs = measure_with_h2(args.ring_kb, few, 2, engine=eng_, fused=False)
+            hs = measure_with_h2(args.ring_kb, few, 2, fused=False)
             out["value_with_h2_stages_around_the_graph"] = round(wl.user_bytes * few * world / hs["elapsed"] / (1 << 30), 3)
             for k_ in ("frame_us", "deframe_us"):
                 out["with_h2_stages"][k_] = hs["stages"][k_]
@@ -1131,19 +1089,19 @@ def main():
         except Exception as e:
             out["with_h2_unfused_error"] = err_text(e)
         try:  # the phase ticks of the deframing kernel (a short run with the clock samples on)
-            ht = measure_with_h2(args.ring_kb, 2, 2, engine=eng_, ticks=True, fused=False)
+            ht = measure_with_h2(args.ring_kb, 2, 2, ticks=True, fused=False)
             out["with_h2_stages"]["deframe_ticks"] = ht["stages"]["deframe_ticks"]
             out["with_h2_stages"]["deframe_us_with_clock_samples"] = ht["stages"]["deframe_us"]
         except Exception as e:
             out["with_h2_ticks_error"] = err_text(e)
         try:  # the same leg with message starts left to the byte-wise automaton
-            h0 = measure_with_h2(args.ring_kb, few, 2, engine=eng_, boundary_step=False)
+            h0 = measure_with_h2(args.ring_kb, few, 2, boundary_step=False)
             out["value_with_h2_no_boundary_step"] = round(wl.user_bytes * few * world / h0["elapsed"] / (1 << 30), 3)
             out["with_h2_no_boundary_step_deframe_us"] = h0["stages"]["deframe_us"]
         except Exception as e:
             out["with_h2_no_boundary_step_error"] = err_text(e)
         try:  # the same leg with the one-wave sequential deframer (no chunks: the default until the end of round 3)
-            h1 = measure_with_h2(args.ring_kb, few, 2, engine=eng_, chunks=False, fused=False)
+            h1 = measure_with_h2(args.ring_kb, few, 2, chunks=False, fused=False)
             out["value_with_h2_sequential_deframer"] = round(wl.user_bytes * few * world / h1["elapsed"] / (1 << 30), 3)
             out["with_h2_sequential_deframer_deframe_us"] = h1["stages"]["deframe_us"]
         except Exception as e:

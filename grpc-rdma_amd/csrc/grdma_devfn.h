@@ -352,7 +352,7 @@ __device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane)
 // its copy workgroups move): the workgroups of a launch sit on different XCDs, whose L2s do not see each other's lines
 // until a kernel ends.  The producer's stores are write-through (sc1: at the memory side once acknowledged), it waits
 // for their acknowledgement (GRDMA_WAIT_VMEM) before it publishes; the consumer's loads bypass its L2 (sc1).  The same
-// recipe as the link engine's tables (csrc/grdma_link.hip).  WT / SC1 = false: plain stores and loads (the consumer is
+// recipe as the tables of the link engine of rounds 2 - 4 were.  WT / SC1 = false: plain stores and loads (the consumer is
 // a later kernel).  The host emulation has one coherent memory: plain accesses there.
 // ---------------------------------------------------------------------------------------------
 template <bool WT>

@@ -419,7 +419,6 @@ struct grdma_stream_job;
 int grdma_job_link_view(grdma_stream_job* j, uint32_t link, grdma_sge** d_sges, uint64_t* count,
                         grdma_slice_out** d_slices, uint8_t** dst, hipStream_t* stream);
 int grdma_stream_job_launch(grdma_stream_job* j);
-int grdma_stream_job_launch_engine(grdma_stream_job* j);
 extern "C" int grdma_job_set_hooks(grdma_stream_job* j, const grdma_job_hook* pre, uint32_t n_pre, const grdma_job_hook* post,
                                    uint32_t n_post);
 
@@ -574,10 +573,10 @@ void grdma_h2_pipe_destroy(grdma_h2_pipe* p) {
   delete p;
 }
 
-// One step: schedule 0 = the job's captured graph, 1 = the persistent link engine.
+// One step on the job's captured graph (schedule 0: the only schedule since the link engine was retired).
 int grdma_h2_pipe_enqueue(grdma_h2_pipe* p, int schedule) {
   if (grdma_device_count() <= 0) return -GRDMA_ERR_NO_DEVICE;
-  if (!p) return -GRDMA_ERR_INVALID;
+  if (!p || schedule != 0) return -GRDMA_ERR_INVALID;
   if (p->fused && schedule == 0) {
     // one graph launch: [k_h2_frame_index, k_h2_frame_emit] -> the job's rounds -> [the deframer]; steps and pipes
     // of one connection are ordered by the job's stream (a parser last used on another stream: by its event)
@@ -593,9 +592,6 @@ int grdma_h2_pipe_enqueue(grdma_h2_pipe* p, int schedule) {
     p->timed = false;
     return 0;
   }
-  if (p->fused) {  // (the engine schedule runs the stages around k_link: the graph's hooks are not in that path)
-    if (hipStreamWaitEvent(p->frame_stream, p->deframed, 0) != hipSuccess) return -GRDMA_ERR_HIP;
-  }
   p->timed = true;
   // framing overwrites the slice table the job's previous step read
   if (p->launched && hipStreamWaitEvent(p->frame_stream, p->job_done, 0) != hipSuccess) return -GRDMA_ERR_HIP;
@@ -609,7 +605,7 @@ int grdma_h2_pipe_enqueue(grdma_h2_pipe* p, int schedule) {
   if (hipStreamWaitEvent(p->job_stream, p->framed, 0) != hipSuccess) return -GRDMA_ERR_HIP;
   if (p->launched && p->deframe_stream != p->job_stream && hipStreamWaitEvent(p->job_stream, p->deframed, 0) != hipSuccess)
     return -GRDMA_ERR_HIP;
-  const int rc = schedule == 1 ? grdma_stream_job_launch_engine(p->job) : grdma_stream_job_launch(p->job);
+  const int rc = grdma_stream_job_launch(p->job);
   if (rc < 0) return rc;
   if (hipEventRecord(p->job_done, p->job_stream) != hipSuccess) return -GRDMA_ERR_HIP;
   if (p->deframe_stream != p->job_stream && hipStreamWaitEvent(p->deframe_stream, p->job_done, 0) != hipSuccess)

@@ -158,8 +158,8 @@ class Pipe:
         if not self.h:
             raise GrdmaError("h2 pipe allocation failed")
 
-    def enqueue(self, engine=False):
-        check(self.lib.grdma_h2_pipe_enqueue(self.h, 1 if engine else 0))
+    def enqueue(self, _unused=False):
+        check(self.lib.grdma_h2_pipe_enqueue(self.h, 0))
 
     def sync(self, want_events=False):
         """-> dict(framed, frame_overflow, events, deframe_overflow, parsed, h2_error[, event list])"""

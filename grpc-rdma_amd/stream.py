@@ -14,7 +14,7 @@ class StreamResult(C.Structure):
                 ("launches_class", u64 * 8)]
 
 
-RUN_EAGER, RUN_GRAPH, RUN_INSTRUMENTED, RUN_ENGINE, RUN_INSTRUMENTED_SCHEDULE = 0, 1, 2, 3, 4
+RUN_EAGER, RUN_GRAPH, RUN_INSTRUMENTED, RUN_INSTRUMENTED_SCHEDULE = 0, 1, 2, 4
 # classes 5 and 6 exist in RUN_INSTRUMENTED_SCHEDULE only: the launches two stages of neighbouring rounds share
 CLASS_NAMES = ["tx_plan", "gather", "wire", "rx_plan", "rx_apply", "plan_pair", "scatter_gather"]
 
@@ -41,8 +41,6 @@ def _bind():
                                                       C.POINTER(u64), C.POINTER(u64), u64]
         lib.grdma_stream_job_slices_of.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(ReadSlice), u64]
         lib.grdma_stream_job_sync.argtypes = [C.c_void_p]
-        lib.grdma_stream_job_launch_engine.argtypes = [C.c_void_p]
-        lib.grdma_stream_job_engine_stats.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(u64)]
         _bound = True
     return lib
 
@@ -103,43 +101,10 @@ class StreamJob:
     def sync(self):
         check(self.lib.grdma_stream_job_sync(self.h))
 
-    def launch_engine(self):
-        check(self.lib.grdma_stream_job_launch_engine(self.h))
-
-    def engine_stats(self, link=0):
-        out = (u64 * 16)()
-        check(self.lib.grdma_stream_job_engine_stats(self.h, link, out))
-        names = ["sends", "chunks", "gather_entries", "wire_entries", "scatter_entries", "tx_wait_slots",
-                 "tx_wait_credit", "rx_wait_data", "rx_wait_scatter", "abort", "team", "gather_waves",
-                 "wire_waves", "scatter_waves", "staging_buffers"]
-        d = {k: int(out[i]) for i, k in enumerate(names)}
-        pr = (u64 * 12)()
-        self.lib.grdma_stream_job_engine_prof.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(u64)]
-        check(self.lib.grdma_stream_job_engine_prof(self.h, link, pr))
-        for i, k in enumerate(["tx_price", "tx_publish", "tx_total", "rx_walk", "rx_fast", "rx_scalar", "rx_total",
-                               "rx_emit", "tx_ph_load", "tx_ph_price", "tx_ph_count", "tx_ph_emit"]):
-            d[k] = int(pr[i])
-        return d
-
     def delivered_slices(self, link=0):
         arr = (ReadSlice * self.slices_cap)()
         n = check(self.lib.grdma_stream_job_slices_of(self.h, link, arr, self.slices_cap))
         return [(int(arr[i].off), int(arr[i].len)) for i in range(n)]
-
-    def engine_trace(self, link=0):
-        """-> sorted [(us since the first event, who, tag, arg)] of the last engine pass."""
-        out = ((u64 * 193) * 5)()
-        self.lib.grdma_stream_job_engine_trace.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
-        check(self.lib.grdma_stream_job_engine_trace(self.h, link, out))
-        ev = []
-        for who in range(5):
-            for i in range(int(out[who][0])):
-                v = int(out[who][1 + i])
-                ev.append((v & 0xFFFFFFFFFF, who, v >> 56, (v >> 40) & 0xFFFF))
-        if not ev:
-            return []
-        t0 = min(e[0] for e in ev)
-        return sorted(((t - t0) / 100.0, who, tag, arg) for t, who, tag, arg in ev)
 
     def close(self):
         if self.h:

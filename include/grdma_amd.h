@@ -431,10 +431,8 @@ typedef struct grdma_stream_result {
 } grdma_stream_result;
 enum grdma_stream_mode {
   GRDMA_RUN_EAGER = 0, GRDMA_RUN_GRAPH = 1, GRDMA_RUN_INSTRUMENTED = 2,
-  /* ONE launch of the persistent link engine (k_link): sender, wire and receiver of every link
-   * run concurrently as resident workgroups that hand work to each other through memory, like
-   * two hosts and a NIC; deterministic, equal to the sequential rounds (see csrc/grdma_link.h) */
-  GRDMA_RUN_ENGINE = 3,
+  /* (3 was the persistent link engine, k_link: one resident launch per step -- a third of the graph schedule's rate in
+   *  rounds 2 - 4, retired in round 5; profiles/r04_bench_engine_*) */
   /* The launches of the default (pipelined, paired) schedule one after the other on one stream with a HIP event
    * between every two: the graph's order is a chain already, so the work and its order are the graph's; the
    * events give the time of every launch by itself.  GRDMA_ERR_INVALID for a job that is not on that schedule. */
@@ -460,11 +458,6 @@ int grdma_stream_job_run(grdma_stream_job* j, int mode, grdma_stream_result* out
 /* Asynchronous form for timed loops: enqueue one pass (the captured graph) on
  * the link's stream without reading any state back; _sync() waits for it. */
 int grdma_stream_job_launch(grdma_stream_job* j);
-/* Same work as one GRDMA_RUN_ENGINE pass, enqueued without waiting (timed loops). */
-int grdma_stream_job_launch_engine(grdma_stream_job* j);
-int grdma_stream_job_engine_stats(grdma_stream_job* j, uint32_t link, uint64_t out[16]);
-int grdma_stream_job_engine_prof(grdma_stream_job* j, uint32_t link, uint64_t out[12]);
-int grdma_stream_job_engine_trace(grdma_stream_job* j, uint32_t link, uint64_t out[5][193]);
 /* Same work as _launch, issued kernel by kernel on the job's streams (no graph). */
 int grdma_stream_job_launch_streams(grdma_stream_job* j);
 int grdma_stream_job_sync(grdma_stream_job* j);
@@ -641,7 +634,7 @@ int64_t grdma_h2_deframe(grdma_h2_parser* p, const void* d_arena, const grdma_re
  * streams ordered by events, nothing returns to the host in between.  The job must have been run
  * once (graph captured / engine prepared); delivered_slices is what that run delivered.  Two pipes
  * over two jobs of one connection may alternate: framing and deframing then run beside the other
- * job's step.  schedule: 0 = the job's graph, 1 = the link engine. */
+ * job's step.  schedule: 0 = the job's graph (the only one). */
 typedef struct grdma_h2_pipe grdma_h2_pipe;
 grdma_h2_pipe* grdma_h2_pipe_create(grdma_stream_job* job, uint32_t link, const grdma_h2_msg* msgs, uint64_t nmsgs,
                                     uint32_t max_frame, grdma_h2_parser* parser, uint64_t delivered_slices,

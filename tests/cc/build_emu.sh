@@ -25,11 +25,9 @@ pids="$pids $!"
 $CXX $FLAGS -I$R/oracle/fakeverbs -c $R/oracle/fakeverbs/fakeverbs.cc -o $OUT/emu_obj/fakeverbs.o &
 pids="$pids $!"
 objs="$objs $OUT/emu_obj/grdma_wire_verbs.o $OUT/emu_obj/fakeverbs.o"
-$CXX $FLAGS -c $R/tests/cc/emu_link_stubs.cc -o $OUT/emu_obj/link_stubs.o &
-pids="$pids $!"
 $CXX $FLAGS -c $R/tests/cc/emu_segv.cc -o $OUT/emu_obj/segv.o &
 pids="$pids $!"
 # (a compile that fails must fail the build: a stale library would otherwise be tested in its place)
 for p in $pids; do wait $p || { echo "build_emu.sh: a source failed to compile" >&2; rm -f $OUT/libgrdma_emu.so; exit 1; }; done
-$CXX -shared -pthread -o $OUT/libgrdma_emu.so $objs $OUT/emu_obj/link_stubs.o $OUT/emu_obj/segv.o -rdynamic
+$CXX -shared -pthread -o $OUT/libgrdma_emu.so $objs $OUT/emu_obj/segv.o -rdynamic
 echo "built $OUT/libgrdma_emu.so"

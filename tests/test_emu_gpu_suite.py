@@ -6,7 +6,7 @@ What runs here: the deframer (all of tests/test_gpu_h2.py but the link-engine pi
 per bulk step, frame -> job -> deframe as a HIP graph), the zero-copy send (tests/test_zz_gpu_zerocopy.py: k_tx_plan_zc + k_copy + the host API), and the
 pair protocol on random operation sequences and the reference-generated golden traces (k_tx_plan, k_copy, k_rx_plan,
 k_rx_apply, k_poll), and the receive planner's multi-record drains.  What the emulator cannot run is deselected:
-resident kernels that wait for the host (latency engine, link engine).  The streaming jobs (HIP graphs of kernel
+resident kernels of more than one workgroup per launch.  The streaming jobs (HIP graphs of kernel
 nodes, run node by node) work too but take minutes: GRDMA_LIB_PATH=oracle/_build/libgrdma_emu.so python -m pytest
 tests/test_gpu_stream_job.py -m gpu -k r256k.
 
@@ -28,7 +28,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROC
 def emu_lib(built):
     srcs = []
     for d in (os.path.join(ROOT, "grpc-rdma_amd", "csrc"), os.path.join(ROOT, "tests", "cc"), os.path.join(ROOT, "include")):
-        srcs += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".cc", ".h", ".hpp", ".sh"))]
+        srcs += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".cc", ".h", ".hpp", ".sh", ".inc"))]
     if not os.path.exists(EMU_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in srcs):
         subprocess.check_call(["bash", os.path.join(ROOT, "tests", "cc", "build_emu.sh")], stdout=subprocess.DEVNULL,
                               stderr=subprocess.DEVNULL)
@@ -51,7 +51,7 @@ def run_gpu_tests(emu_lib, args, min_passed):
 
 
 def test_deframer_gpu_tests_under_the_emulator(emu_lib):
-    run_gpu_tests(emu_lib, ["tests/test_gpu_h2.py", "tests/test_zz_gpu_h2_boundary.py", "-k", "not engine"], 32)
+    run_gpu_tests(emu_lib, ["tests/test_gpu_h2.py", "tests/test_zz_gpu_h2_boundary.py"], 32)
 
 
 def test_chunked_deframer_gpu_tests_under_the_emulator(emu_lib):
@@ -66,8 +66,8 @@ def test_zero_copy_gpu_tests_under_the_emulator(emu_lib):
 
 def test_burst_round_gpu_tests_under_the_emulator(emu_lib):
     """Streaming jobs with several Sends per round (k_tx_plan_seq: the single-wave burst planner), eager and as a HIP
-    graph, three links in one launch: the small configurations of tests/test_gpu_link_engine.py."""
-    run_gpu_tests(emu_lib, ["tests/test_gpu_link_engine.py", "-n", "4", "-k", "burst and (r64k or r256k or three_links)"], 7)
+    graph, three links in one launch: the small configurations of tests/test_gpu_bench_configs.py."""
+    run_gpu_tests(emu_lib, ["tests/test_gpu_bench_configs.py", "-n", "4", "-k", "burst and (r64k or r256k or three_links)"], 7)
 
 
 def test_steady_state_planner_and_pair_pool_gpu_tests_under_the_emulator(emu_lib):

@@ -1,13 +1,11 @@
-"""GPU parity of the persistent link engine (k_link, GRDMA_RUN_ENGINE) and of the graph schedules
-at the EXACT configurations bench.py times.
+"""GPU parity of the graph schedules at the EXACT configurations bench.py times, and of the burst rounds.
 
-The engine runs sender, wire and receiver concurrently inside one launch, but is built to be
-deterministic: it must reproduce the sequential execution of the reference's loops -- one Send
-from the rdma_flush cursor (rdma_bp_posix.cc:470-524), then endpoint reads until one would block
-(:180-291) -- slice for slice: same delivered slices, same number of Sends, same final protocol
-state, ring all zero; also when the ring is so small that every Send is cut by the peer's credit.
-The oracle side is oracle/grdma_oracle.c:orc_stream_rounds (checked against the Python-driven
-OracleLink loop below)."""
+The job must reproduce the sequential execution of the reference's loops -- one Send from the rdma_flush cursor
+(rdma_bp_posix.cc:470-524), then endpoint reads until one would block (:180-291) -- slice for slice: same delivered
+slices, same number of Sends, same final protocol state, ring all zero.  The oracle side is
+oracle/grdma_oracle.c:orc_stream_rounds (checked against the Python-driven OracleLink loop below).
+(Until round 4 this file also held the tests of the persistent link engine, k_link -- one resident launch per step, a
+third of the graph schedule's rate -- which round 5 retired.)"""
 import random
 
 import pytest
@@ -98,19 +96,6 @@ class Link:
         self.dst.free()
 
 
-def run_engine(g, links, passes=PASSES):
-    from grpc_rdma_amd import stream as gs
-    job = gs.MultiStreamJob([l.spec() for l in links], 8)
-    first = None
-    for _ in range(passes):
-        r = job.run(gs.RUN_ENGINE)
-        assert r.done, "engine pass did not deliver everything"
-        assert r.bytes_delivered == sum(l.N for l in links) == r.bytes_sent
-        if first is None:
-            first = r
-    return job, first
-
-
 CASES = [
     # (ring, max_sge, n_msgs, msg_len)
     (1 << 22, 4095, 6, 1 << 20),      # reference default ring, 1 MiB messages: every Send is cut by the staging budget
@@ -156,83 +141,17 @@ def test_c_rounds_oracle_equals_the_python_driven_loop():
     link.close()
 
 
-@pytest.mark.parametrize("case", CASES, ids=IDS)
-def test_engine_equals_the_sequential_rounds(gpu, case):
-    R, max_sge, n_msgs, msg_len = case
-    wire, lens = framed(n_msgs, msg_len, seed=R % 97)
-    exp = pyorc.stream_rounds(R, max_sge, wire, lens, passes=PASSES)
-    assert exp["stream_ok"] and exp["ring_zero"]
-    link = Link(gpu, R, max_sge, wire, lens)
-    job, first = run_engine(gpu, [link])
-    assert int(first.tx_rounds) == exp["rounds"]
-    link.check(job, 0, exp, exact=True)
-    job.close()
-    link.close()
-
-
-@pytest.mark.parametrize("case", CASES[:5], ids=IDS[:5])
-def test_engine_direct_wire_equals_the_sequential_rounds(gpu, case):
-    """GRDMA_WIRE_DIRECT: records are built in the peer ring itself (no staging, no wire stage);
-    the records -- hence slices and state -- are the same."""
-    R, max_sge, n_msgs, msg_len = case
-    wire, lens = framed(n_msgs, msg_len, seed=R % 89)
-    exp = pyorc.stream_rounds(R, max_sge, wire, lens, passes=PASSES)
-    link = Link(gpu, R, max_sge, wire, lens, flags=2)
-    job, first = run_engine(gpu, [link])
-    assert int(first.tx_rounds) == exp["rounds"]
-    link.check(job, 0, exp, exact=True)
-    job.close()
-    link.close()
-
-
-def test_engine_mixed_message_sizes(gpu):
-    """Sizes like the reference's echo test (1 B ... 4 MiB - 1 KiB), 4 MiB ring, max_sge 30."""
-    wire, lens = mixed(24, seed=0)
-    exp = pyorc.stream_rounds(4 << 20, 30, wire, lens, passes=2)
-    link = Link(gpu, 4 << 20, 30, wire, lens)
-    job, first = run_engine(gpu, [link], passes=2)
-    assert int(first.tx_rounds) == exp["rounds"]
-    link.check(job, 0, exp, exact=True)
-    job.close()
-    link.close()
-
-
-def test_engine_odd_slices(gpu):
-    """Not h2-shaped: slice lengths 1 .. 70000 at random, including runs of tiny ones (shared
-    256-byte reads), records longer than a table entry, and a ring that wraps many times."""
-    rng = random.Random(77)
-    lens = [rng.choice([1, 2, 7, 8, 9, 23, 255, 256, 257, 511, 512, 4096, 16384, 16385, 40000, 70000])
-            for _ in range(700)]
-    wire = bytes(rng.getrandbits(8) for _ in range(4093)) * (sum(lens) // 4093 + 1)
-    wire = wire[:sum(lens)]
-    for R, max_sge in ((1 << 20, 30), (1 << 18, 4095), (1 << 22, 64)):
-        exp = pyorc.stream_rounds(R, max_sge, wire, lens, passes=2)
-        link = Link(gpu, R, max_sge, wire, lens)
-        job, first = run_engine(gpu, [link], passes=2)
-        assert int(first.tx_rounds) == exp["rounds"]
-        link.check(job, 0, exp, exact=True)
-        job.close()
-        link.close()
-
-
 # ---- the exact configurations of bench.py ------------------------------------------------------
 def test_bench_config_256x1mib_ring128m(gpu):
-    """256 x 1 MiB messages, 128 MiB ring, max_sge 4095 (bench.py defaults): engine AND the
-    pipelined / sequential graph schedules against the sequential-rounds oracle."""
+    """256 x 1 MiB messages, 128 MiB ring, max_sge 4095 (bench.py's value_ring128m_one_send_per_round): the pipelined and
+    the sequential graph schedule against the sequential-rounds oracle."""
     from grpc_rdma_amd import stream as gs
     R, max_sge = 128 << 20, 4095
     wire, lens = framed(256, 1048580, seed=11)
     exp = pyorc.stream_rounds(R, max_sge, wire, lens, passes=1)
     assert exp["stream_ok"] and exp["ring_zero"]
-    # engine
-    link = Link(gpu, R, max_sge, wire, lens)
-    job, first = run_engine(gpu, [link], passes=1)
-    assert int(first.tx_rounds) == exp["rounds"]
-    link.check(job, 0, exp, exact=True)
-    job.close()
-    link.close()
-    # graph schedules: at this ring no Send is limited by the credit, so the pipelined schedule
-    # makes the same records (hence slices and state) as the sequential one
+    # at this ring no Send is limited by the credit, so the pipelined schedule makes the same records (hence slices
+    # and state) as the sequential one
     for pipeline in (False, True):
         link = Link(gpu, R, max_sge, wire, lens)
         job = gs.MultiStreamJob([link.spec()], 64)
@@ -246,19 +165,12 @@ def test_bench_config_256x1mib_ring128m(gpu):
 
 
 def test_bench_config_32_links_64kib(gpu):
-    """32 connections x 64 x 64 KiB messages, 4 MiB rings (BASELINE configs[3] shape): every link
-    against its own oracle, engine and lock-step graph job."""
+    """32 connections x 64 x 64 KiB messages, 4 MiB rings (BASELINE configs[3] shape): every link against its own
+    oracle, the lock-step graph job."""
     from grpc_rdma_amd import stream as gs
     R, max_sge, n = 4 << 20, 4095, 32
     data = [framed(64, 65536 + 3, seed=100 + i) for i in range(n)]
     exps = [pyorc.stream_rounds(R, max_sge, w, l, passes=1) for w, l in data]
-    links = [Link(gpu, R, max_sge, w, l, seed=i) for i, (w, l) in enumerate(data)]
-    job, first = run_engine(gpu, links, passes=1)
-    for i, (l, e) in enumerate(zip(links, exps)):
-        l.check(job, i, e, exact=True)
-    job.close()
-    for l in links:
-        l.close()
     links = [Link(gpu, R, max_sge, w, l, seed=i) for i, (w, l) in enumerate(data)]
     job = gs.MultiStreamJob([l.spec() for l in links], 64)
     r = job.run(gs.RUN_EAGER)
@@ -268,20 +180,6 @@ def test_bench_config_32_links_64kib(gpu):
     job.close()
     for l in links:
         l.close()
-
-
-def test_engine_reports_a_stuck_job_instead_of_hanging(gpu):
-    """A destination buffer that is too small: the engine aborts with an error, no hang."""
-    from grpc_rdma_amd import stream as gs
-    g = gpu
-    wire, lens = framed(4, 100000, 1)
-    link = Link(g, 1 << 20, 30, wire, lens)
-    link.dst_cap = 50000
-    job = gs.MultiStreamJob([link.spec()], 8)
-    with pytest.raises(g.GrdmaError, match="destination buffer too small"):
-        job.run(gs.RUN_ENGINE)
-    job.close()
-    link.close()
 
 
 BURST_CASES = [

@@ -387,8 +387,7 @@ def test_deframe_streaming_shape_bulk_step(gpu, gaps):
     assert rc_o == 0 and rc_g == 0 and ev_g == ev_o
 
 
-@pytest.mark.parametrize("engine", [False, True], ids=["graph", "engine"])
-def test_h2_pipe_frame_job_deframe_matches_the_oracle(gpu, engine):
+def test_h2_pipe_frame_job_deframe_matches_the_oracle(gpu):
     """frame -> connection -> deframe as ONE enqueued device pipeline (grdma_h2_pipe): the framing
     kernel writes the job's slice list, the job delivers it through a 256 KiB ring, the deframing
     kernel parses the delivered slices.  Three steps back to back; the events of the last one equal
@@ -412,12 +411,9 @@ def test_h2_pipe_frame_job_deframe_matches_the_oracle(gpu, engine):
     dst_cap = N + 16 * scap + 4096
     dst = g.DeviceBuffer(nbytes=dst_cap)
     job = gs.StreamJob(tx, rx, sge, dst.ptr, dst_cap, scap, 64)
-    if engine:
-        r = job.run(gs.RUN_ENGINE)
-    else:
-        r = job.run(gs.RUN_EAGER)
-        job.set_rounds(int(max(r.tx_rounds, r.rx_rounds)))
-        r = job.run(gs.RUN_GRAPH)
+    r = job.run(gs.RUN_EAGER)
+    job.set_rounds(int(max(r.tx_rounds, r.rx_rounds)))
+    r = job.run(gs.RUN_GRAPH)
     assert r.done and r.bytes_delivered == N
     delivered = job.delivered_slices(0)
     parser = h2dev.Parser(False)
@@ -426,7 +422,7 @@ def test_h2_pipe_frame_job_deframe_matches_the_oracle(gpu, engine):
     po = pyorc.H2Parser(expect_client_prefix=False)
     assert po.open_stream(1) == 0
     for step in range(3):
-        pipe.enqueue(engine)
+        pipe.enqueue()
         res = pipe.sync(want_events=True)
         assert res["h2_error"] == 0 and res["framed"] == len(lens) and res["parsed"] == len(delivered)
         ds = job.delivered_slices(0)
