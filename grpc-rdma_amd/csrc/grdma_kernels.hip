@@ -59,50 +59,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tx_plan(const grdma_tx_op* ops
 // (launched in the index body's shape, 1024 threads; the general planner is a 256-thread body: waves 4-15 leave)
 __global__ __launch_bounds__(TXB_THREADS) TXB_KERNEL_ATTR void k_tx_plan_job(const grdma_tx_op* ops, const grdma_txf_ctl* ctls) {
   if (txf_body(ops[blockIdx.x], &ctls[blockIdx.x])) return;  // (uniform)
-#ifdef GRDMA_SLIM_PLANNERS
-  // experiment (tools/gpu_slim.sh): no general planner in this kernel -- a declined Send accepts nothing
-  if (threadIdx.x == 0) {
-    const grdma_tx_op op = ops[blockIdx.x];
-    for (grdma_plan* pl : {op.plan, op.wire_plan}) {
-      if (pl == nullptr) continue;
-      pl->nsegs = 0;
-      pl->ntiles = 0;
-      pl->tile_prefix[0] = 0;
-      pl->bytes = 0;
-    }
-    op.result->sent = 0;
-    op.result->records = 0;
-    op.result->staged = 0;
-    if (op.tail_out != nullptr) *op.tail_out = op.conn->remote_tail;
-    op.result->dbg[9] = 0;
-  }
-#else
   if (threadIdx.x >= PLAN_THREADS) return;
   tx_plan_body(ops[blockIdx.x]);
   if (threadIdx.x == 0) ops[blockIdx.x].result->dbg[9] = 0;  // (not priced from the index)
-#endif
-}
-
-// k_wire_txplan_job: the wire of round t and the send plan of round t + 1 in ONE launch.  A send plan is a one-workgroup,
-// latency-bound kernel; it needs the credit of round t - 1 and the sender's state after round t's plan -- not the wire of
-// round t -- and kernels of different graph branches do not run side by side on this stack, so the planner rides in the
-// copy kernel's grid: workgroup x = 0 of every link prices the next Send (k_tx_plan_job's body), workgroups x >= 1 move
-// the wire plan's tiles, sixteen waves each.  The wire plan is the one the planner of the launch before wrote; this
-// planner writes the other parity's (and the gather plan, whose reader -- the gather of round t -- has completed).
-__global__ __launch_bounds__(TXB_THREADS) void k_wire_txplan_job(const grdma_plan* const* wplans, const grdma_tx_op* txops,
-                                                                 const grdma_txf_ctl* ctls) {
-  if (blockIdx.x == 0) {
-    if (txf_body(txops[blockIdx.y], &ctls[blockIdx.y])) return;  // (uniform)
-    if (threadIdx.x >= PLAN_THREADS) return;
-    tx_plan_body(txops[blockIdx.y]);
-    if (threadIdx.x == 0) txops[blockIdx.y].result->dbg[9] = 0;
-    return;
-  }
-  const grdma_plan* plan = wplans[blockIdx.y];
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = ((blockIdx.x - 1) * TXB_THREADS + threadIdx.x) >> 6;
-  const uint32_t nwaves = ((gridDim.x - 1) * TXB_THREADS) >> 6;
-  run_plan<256, GRDMA_COPY_CONTIG>(plan, wave, nwaves, lane);
 }
 
 // k_tx_plan_seq: gridDim.y Sends of the SAME connection back to back in one launch (a sender that
@@ -449,7 +408,6 @@ __attribute__((visibility("hidden"))) const void* grdma_kernel_fn(int which) {
     case 4: return reinterpret_cast<const void*>(&k_tx_plan_seq);
     case 5: return reinterpret_cast<const void*>(&k_tx_commit);
     case 6: return reinterpret_cast<const void*>(&k_tx_plan_job);
-    case 7: return reinterpret_cast<const void*>(&k_wire_txplan_job);
     case 8: return reinterpret_cast<const void*>(&k_rx_apply_gather);
     default: return nullptr;
   }

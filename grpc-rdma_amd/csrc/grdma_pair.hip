@@ -73,10 +73,6 @@ hipError_t grdma_launch_rx_plan_mw(const grdma_rx_op*, uint32_t, hipStream_t);
 uint32_t grdma_tx_multi_groups(void);
 uint32_t grdma_tx_multi_max_sends(void);
 uint32_t grdma_tx_multi_seq_sends(void);
-const void* grdma_kernel_fn_round_xag(void);
-uint64_t grdma_rx_scratch_bytes(void);
-uint32_t grdma_round_xag_resident_blocks(void);
-const void* grdma_kernel_fn_rxplan_gather_job(void);
 uint32_t grdma_kernel_threads(int which);
 uint32_t grdma_copy_resident_blocks(void);
 }

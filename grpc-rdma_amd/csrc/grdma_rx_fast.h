@@ -37,15 +37,9 @@
 
 namespace {
 
-#ifdef GRDMA_SLIM_PLANNERS  // experiment: a planner workgroup small enough to sit beside the copy kernels' workgroups
-#define RXF_THREADS 256
-#define RXF_PER 16
-#define RXF_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
-#else
 #define RXF_THREADS 1024
 #define RXF_PER 4
 #define RXF_KERNEL_ATTR
-#endif
 #define RXF_MAX (RXF_THREADS * RXF_PER)
 #define RXF_WAVES (RXF_THREADS / 64)
 #define RXF_MINRD 256u

@@ -1577,28 +1577,9 @@ void k_rx_plan(const grdma_rx_op* ops) {
 __global__ __launch_bounds__(RXF_THREADS) RXF_KERNEL_ATTR
 void k_rx_plan_job(const grdma_rx_op* ops) {
   if (rxf_body(ops[blockIdx.x])) return;  // (uniform)
-#ifdef GRDMA_SLIM_PLANNERS
-  // experiment (tools/gpu_slim.sh): no general planner in this kernel -- a declined drain simply does not happen
-  // in this round (empty scatter plan, nothing consumed, no credit); the data stays in the ring
-  if (threadIdx.x == 0) {
-    const grdma_rx_op op = ops[blockIdx.x];
-    op.plan->nsegs = 0;
-    op.plan->ntiles = 0;
-    op.plan->tile_prefix[0] = 0;
-    op.plan->bytes = 0;
-    op.plan->blocks_done = 0;
-    op.result->nslices = 0;
-    op.result->bytes = 0;
-    op.result->consumed = 0;
-    op.result->records = 0;
-    op.result->credit_sent = 0;
-    op.result->dbg[9] = 0;
-  }
-#else
   if (threadIdx.x >= PLAN_THREADS) return;
   rx_plan_body(ops[blockIdx.x]);
   if (threadIdx.x == 0) ops[blockIdx.x].result->dbg[9] = 0;  // (not rxf_body's stamps)
-#endif
 }
 
 // Out-of-line copies for the resident engine: with both bodies inlined into its
@@ -1726,139 +1707,6 @@ void k_rx_plan_mw(const grdma_rx_op* rxops) {
   }
   if (r != 2) return;  // (uniform)
   rx_plan_body(rop);
-}
-
-// ----------------------------------------------------------------------------
-// k_round_xag: the drain PLAN of round t, its SCATTER and the gather of round t + 1 in ONE launch (x = "X", "A", "G"
-// of the job's schedule).  Per link G planner workgroups (rxm_body / rxh_body, write-through), GB gather workgroups
-// and SB scatter workgroups, all four waves.  The gather moves a plan the launch before laid out and starts at once; the
-// scatter workgroups wait (plan_wait_ready: a bounded spin of one wave on grdma_plan::ready) until the last planner
-// workgroup to arrive has committed the plan -- its entries stored write-through and acknowledged, the scatter's
-// reads of them L2-bypassing (grdma_devfn.h: xwg_*).  The gather hides the planners' latency, and a launch (3.5 us
-// between HIP events beyond its kernel) leaves every round.  A drain the predicting bodies decline is planned by the
-// general planner right here, out of global scratch (scratch[link]), published with an agent-scope release.  The
-// last copy workgroup of the launch to finish clears `ready` for the plan's next use.
-// ----------------------------------------------------------------------------
-#ifndef GRDMA_COPY_CONTIG
-#define GRDMA_COPY_CONTIG true  // (as grdma_kernels.hip)
-#endif
-#ifndef GRDMA_APPLY_CONTIG
-#define GRDMA_APPLY_CONTIG true
-#endif
-// (a 1-D grid, decoded here: the planners of every link first, then the gathers, then the scatters -- workgroups are
-// dispatched in index order, so every planner is on the chip before a scatter workgroup can wait for it, and a scatter
-// workgroup takes a slot only when the planners and gathers in front of it have theirs.  shape = G | links << 8 | SB << 16)
-#ifndef GRDMA_XAG_WAVES
-#define GRDMA_XAG_WAVES 3
-#endif
-__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(GRDMA_XAG_WAVES, GRDMA_XAG_WAVES)))
-void k_round_xag(const grdma_rx_op* rxops, const grdma_plan* const* gplans, rx_lds* const* scratch, uint32_t shape) {
-  static_assert(COPY_THREADS == PLAN_THREADS, "one workgroup shape for planners and copy workgroups");
-  static_assert(offsetof(grdma_plan, pad_line1) % 8 == 4, "the hand-over stamp is an aligned 64-bit word");
-  const uint32_t G = shape & 0xFFu, links = (shape >> 8) & 0xFFu, SB = shape >> 16;
-  const uint32_t GB = (gridDim.x - links * (G + SB)) / links;
-  const int lane = threadIdx.x & 63;
-  uint32_t idx = blockIdx.x;
-  if (idx < links * G) {  // ---- planner workgroups
-    const uint32_t link = idx / G, wg = idx - link * G;
-    const grdma_rx_op& rop = rxops[link];
-    int r = rxm_body<true>(rop, wg, G);
-    if (r == 3) {
-      __syncthreads();
-      r = rxh_body<true>(rop, wg, G);
-    }
-    if (r == 0) return;
-    if (r == 2) {  // (rare) the general planner, then everything it stored written back to memory
-#ifndef GRDMA_XAG_NO_FALLBACK  // (tools/ experiment: what the general planner's registers cost the copy workgroups)
-      rx_plan_body<true>(rop, scratch[link]);
-#endif
-      __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    } else {
-      GRDMA_WAIT_VMEM();  // (the commit's write-through stores are acknowledged)
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      // (profiling aid: the plan is handed to the scatter -- in the planners' clock, and in the device-wide 100 MHz one)
-      rop.result->dbg[14] = __builtin_amdgcn_s_memtime();
-      xwg_st64<true>(reinterpret_cast<uint64_t*>(&rop.plan->pad_line1[1]), __builtin_amdgcn_s_memrealtime());
-      __hip_atomic_store(&rop.plan->ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
-  }
-  idx -= links * G;
-  grdma_plan* splan;
-  if (idx < links * GB) {  // ---- gather workgroups: the send plan of the launch before
-    const uint32_t link = idx / GB, b = idx - link * GB;
-    splan = rxops[link].plan;
-    const uint32_t wave = (b * COPY_THREADS + threadIdx.x) >> 6;
-    run_plan<256, GRDMA_COPY_CONTIG>(gplans[link], wave, (GB * COPY_THREADS) >> 6, lane);
-  } else {  // ---- scatter workgroups: k_rx_apply's body over the plan committed above
-    idx -= links * GB;
-    const uint32_t link = idx / SB, b = idx - link * SB;
-    const grdma_rx_op& rop = rxops[link];
-    splan = rop.plan;
-    if (const uint32_t* hw = plan_wait_ready(splan)) {
-      const plan_hdr hdr = plan_hdr_of(hw);
-      const uint32_t wave = (b * COPY_THREADS + threadIdx.x) >> 6;
-      run_plan<256, GRDMA_APPLY_CONTIG, true>(splan, wave, (SB * COPY_THREADS) >> 6, lane, &hdr);
-    }
-    // arrival of the scatter workgroups: the last one posts the credit (as rx_apply_body, grdma_kernels.hip)
-    __shared__ unsigned int s_last;
-    GRDMA_WAIT_VMEM();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned int prev = __hip_atomic_fetch_add(&splan->blocks_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (prev == SB - 1) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (s_last && threadIdx.x == 0) {
-      grdma_rx_result* res = rop.result;
-      const uint64_t credit_sent = xwg_ld64<true>(&res->credit_sent), credit_head = xwg_ld64<true>(&res->credit_head);
-      if (credit_sent) {
-        grdma_status_report* ps = rop.conn->peer_status;
-        if (ps != nullptr) __hip_atomic_store(&ps->remote_head, credit_head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        grdma_hostline* pl = rop.conn->peer_line;
-        if (pl != nullptr) __hip_atomic_store(&pl->remote_head, credit_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      // (profiling aid: the scatter is done, in 10 ns ticks since the plan was handed over)
-      res->dbg[15] = __builtin_amdgcn_s_memrealtime() - xwg_ld64<true>(reinterpret_cast<const uint64_t*>(&splan->pad_line1[1]));
-      __hip_atomic_store(&res->commit_seq, xwg_ld64<true>(&res->commit_seq) + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  // every copy workgroup of a link counts out; the last one of the launch clears the scatter plan's `ready` for its next use
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned int prev = __hip_atomic_fetch_add(&splan->xag_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == SB + GB - 1) {
-      __hip_atomic_store(&splan->xag_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&splan->ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-// ----------------------------------------------------------------------------
-// k_rxplan_gather_job: the drain plan of round t and the GATHER of round t + 1 in ONE launch (the other half of the
-// fused schedule, see k_wire_txplan_job in grdma_kernels.hip): the receive planner -- one workgroup, 28 us of dependent
-// memory round trips during which the rest of the chip used to idle -- needs the wire of round t; the gather of round
-// t + 1 needs the send plan the launch before produced and a staging buffer the wire of round t - 1 has left.  Neither
-// needs the other: workgroup x = 0 of every link plans the drain (k_rx_plan_job's body), workgroups x >= 1 move the
-// gather plan's tiles.
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(RXF_THREADS)
-void k_rxplan_gather_job(const grdma_rx_op* rxops, const grdma_plan* const* gplans) {
-  if (blockIdx.x == 0) {
-    if (rxf_body(rxops[blockIdx.y])) return;  // (uniform)
-    if (threadIdx.x >= PLAN_THREADS) return;
-    rx_plan_body(rxops[blockIdx.y]);
-    if (threadIdx.x == 0) rxops[blockIdx.y].result->dbg[9] = 0;
-    return;
-  }
-  const grdma_plan* plan = gplans[blockIdx.y];
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = ((blockIdx.x - 1) * RXF_THREADS + threadIdx.x) >> 6;
-  const uint32_t nwaves = ((gridDim.x - 1) * RXF_THREADS) >> 6;
-  run_plan<256, true>(plan, wave, nwaves, lane);
 }
 
 // Will the express drain of `blk.rx` take exactly the records the small send of `blk.tx` is about to produce, all of
@@ -2725,19 +2573,9 @@ extern "C" int grdma_rx_fast_drains(uint64_t out[6]) {
   for (int i = 0; i < 6; i++) out[i] = v[i];
   return 0;
 }
-extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_rxplan_gather_job(void) { return reinterpret_cast<const void*>(&k_rxplan_gather_job); }
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_job(void) { return reinterpret_cast<const void*>(&k_plan_pair_job); }
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_mw(void) { return reinterpret_cast<const void*>(&k_plan_pair_mw); }
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_rx_multi_groups(void) { return RXM_G; }
-extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_round_xag(void) { return reinterpret_cast<const void*>(&k_round_xag); }
-extern "C" __attribute__((visibility("hidden"))) uint64_t grdma_rx_scratch_bytes(void) { return sizeof(rx_lds); }
-extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_round_xag_resident_blocks(void) {
-  int dev = 0, cus = 0, a = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 768;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 768;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_round_xag, PLAN_THREADS, 0) != hipSuccess || a <= 0) a = GRDMA_XAG_WAVES;
-  return (uint32_t)(a * cus);
-}
 extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan_mw(const grdma_rx_op* d_ops, uint32_t nops, hipStream_t s) {
   if (nops == 0) return hipSuccess;
   hipLaunchKernelGGL(k_rx_plan_mw, dim3(nops, RXM_G), dim3(PLAN_THREADS), 0, s, d_ops);

@@ -9,15 +9,9 @@
 
 namespace {
 
-#ifdef GRDMA_SLIM_PLANNERS  // (see grdma_rx_fast.h)
-#define TXB_THREADS 256
-#define TXB_PER 16
-#define TXB_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
-#else
 #define TXB_THREADS 1024
 #define TXB_PER 4
 #define TXB_KERNEL_ATTR
-#endif
 #define TXB_WAVES (TXB_THREADS / 64)
 static_assert(TXB_THREADS * TXB_PER >= GRDMA_TX_MAX_RECORDS, "one pass covers a Send");
 

@@ -76,7 +76,7 @@ def test_steady_state_planner_and_pair_pool_gpu_tests_under_the_emulator(emu_lib
     pipelined graphs against the oracle's rounds; the paired graph at a credit-limited ring against the oracle driven with
     the credit one round late; the PairPool on recycled memory."""
     run_gpu_tests(emu_lib, ["tests/test_gpu_stream_job.py", "tests/test_gpu_pair_pool.py", "-n", "4",
-                            "-k", "(fast_planner and sge130) or pool or (credit_limited and r256k) or (fused_round and r256k)"], 10)
+                            "-k", "(fast_planner and sge130) or pool or (credit_limited and r256k)"], 9)
 
 
 def test_planner_pair_of_many_workgroups_and_bidirectional_job_under_the_emulator(emu_lib):

@@ -461,41 +461,6 @@ def test_two_sends_per_round_in_one_plan_match_the_oracle(gpu, case, flags):
 
 
 @pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
-@pytest.mark.parametrize("case", [MULTI_CASES[0][:4] + (True,), MULTI_CASES[2][:4] + (True,), (1 << 24, 640, 300, 9000, True),
-                                  (1 << 18, 30, 120, 9000, False)],
-                         ids=["r8m_sge3001", "r32m_sge4095", "r16m_no_period", "r256k_credit_limited"])
-def test_fused_round_launch_matches_the_oracle(gpu, case, flags, monkeypatch):
-    """GRDMA_JOB_FUSE_ROUND=1 (an experiment kept behind its switch): the drain plan of round t,
-    its scatter and the gather of round t + 1 in ONE launch (k_round_xag) -- planner workgroups that store the plan
-    write-through, scatter workgroups of the same launch that wait for it (bounded) and read it past their L2, the
-    general planner out of global scratch for what the predicting bodies decline.  Same slices, ring and state as the
-    oracle's rounds (the credit-limited case: with the credit one round late, as the paired schedule)."""
-    monkeypatch.setenv("GRDMA_JOB_FUSE_ROUND", "1")
-    R, max_sge, n_msgs, msg_len, exact = case
-    rng = random.Random(R % 89)
-    slices = []
-    for i in range(n_msgs):
-        n = msg_len if R != (1 << 24) else rng.randrange(msg_len // 2, 2 * msg_len)
-        wire, lens = pyorc.h2_frame_message(bytes(rng.getrandbits(8) for _ in range(64)) * (n // 64 + 1), stream_id=2 * i + 1)
-        off = 0
-        for ln in lens:
-            slices.append(wire[off:off + ln])
-            off += ln
-    got = _run_job(gpu, R, max_sge, slices, pipeline=True, flags=flags)
-    assert b"".join(got["slices"]) == b"".join(slices)
-    if exact:
-        exp, _, (st0, st1), ring = _oracle_rounds(R, max_sge, slices)
-        assert got["slices"] == exp
-        assert got["ring"] == ring == bytes(R)
-        for k in ("remote_tail", "remote_head", "partial_write"):
-            assert got["tx"][k] == st0[k], k
-        for k in ("head", "moving_head", "remain", "internal_read_size"):
-            assert got["rx"][k] == st1[k], k
-    else:
-        assert got["ring"] == bytes(R)
-
-
-@pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
 @pytest.mark.parametrize("case", FAST_CASES[:2], ids=["r16m_sge255", "r32m_sge511"])
 def test_the_instrumented_schedule_is_the_graphs_chain(gpu, case, flags):
     """GRDMA_RUN_INSTRUMENTED_SCHEDULE (bench.py's roofline of the fused scatter + gather launch): the launches of
