@@ -569,14 +569,14 @@ def main():
         torch.cuda.synchronize()
 
     def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB,
-                pipeline=False, max_sge=None, wire_flags=None, engine=False, wls=None, burst=1, reps=1, sends=None, promise=False,
+                pipeline=False, max_sge=None, wire_flags=None, wls=None, reps=1, sends=None, promise=False,
                 reindex=False, bidi=False):
         """n_links connections with rings of ring_kb KiB: calibrate the number of rounds, capture the graph, time
         `steps` replays.  Then verify, optionally instrument."""
         ring = ring_kb * 1024
         max_sge = max_sge or args.max_sge
         if sends is None:
-            sends = args.sends if (pipeline and burst == 1 and n_links == 1 and not engine) else 1
+            sends = args.sends if (pipeline and n_links == 1) else 1
         wf = flags if wire_flags is None else wire_flags
         wls = wls or get_workloads(n_links, msgs_per_link or args.msgs, payload)
         links, keep = [], []
@@ -601,8 +601,6 @@ def main():
         total_n = sum(w.N for w in wls)
         if True:
             job.set_pipeline(pipeline)
-            if burst > 1:
-                job.set_burst(burst)                   # `burst` Sends per round, then one drain
             if sends > 1:
                 job.set_sends(sends)                   # `sends` consecutive Sends in one plan per round, then one drain
             if promise:
@@ -613,7 +611,7 @@ def main():
             assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
                 r.bytes_delivered, total_n)
             # (tx_rounds counts Sends)
-            rounds = int(max(-(-int(r.tx_rounds) // sends), r.rx_rounds)) if burst == 1 else int(r.rx_rounds) + 1
+            rounds = int(max(-(-int(r.tx_rounds) // sends), r.rx_rounds))
             if sends > 2:
                 rounds += 2  # (a ring every round fills: later passes start at another ring phase and may need a round more)
             if sends > 2 and pipeline and not promise:
@@ -692,7 +690,7 @@ def main():
             tx.close(); rx.close(); dst.free()
         return out
 
-    def measure_with_h2(ring_kb, steps, warmup, engine=False, boundary_step=None, bulk_pairs=None, ticks=False, chunks=None,
+    def measure_with_h2(ring_kb, steps, warmup, boundary_step=None, bulk_pairs=None, ticks=False, chunks=None,
                         fused=None):
         """The same step with the HTTP/2 stages INSIDE the timed device pipeline: k_h2_frame_index + k_h2_frame_emit rebuild
         the slice list from the message table, the job carries it through the connection, k_h2_deframe
@@ -1141,13 +1139,11 @@ def main():
                         "promised credit (grdma_stream_job_set_promised_credit), %d rounds" % rk["rounds"])
             except Exception as e:
                 out[key[6:] + "_error"] = err_text(e)
-        try:  # (rounds 2 - 4a: up to 16 Sends per round planned one by one by a single wave, general drain planner)
-            rk = measure(4096, half, 1, not args.no_verify, False, max_sge=30, burst=16)
-            out["value_ring4096_sge30_burst_schedule"] = round(wl.user_bytes * half * world / rk["elapsed"] / (1 << 30), 3)
+        try:  # (one Send of 30 slices per round, drained at once: what the reference's loop is without rdma_flush's retries)
             rk1 = measure(4096, 2, 1, False, False, max_sge=30)
             out["value_ring4096_sge30_one_send_per_round"] = round(wl.user_bytes * 2 * world / rk1["elapsed"] / (1 << 30), 3)
         except Exception as e:
-            out["ring4096_sge30_burst_schedule_error"] = err_text(e)
+            out["ring4096_sge30_one_send_per_round_error"] = err_text(e)
         # mixed message sizes (examples/cpp/test/common.h: uniform in [1, 4 MiB - 1 KiB]), 64 messages per step
         try:
             mw = MixedWorkload(g, 64)

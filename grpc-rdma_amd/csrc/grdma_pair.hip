@@ -66,7 +66,6 @@ uint32_t grdma_tx_index_threads(void);
 hipError_t grdma_launch_tx_index(grdma_txf_ctl*, uint32_t, uint32_t, hipStream_t);
 hipError_t grdma_launch_tx_plan_job(const grdma_tx_op*, const grdma_txf_ctl*, uint32_t, hipStream_t);
 const void* grdma_kernel_fn_plan_pair(void);
-const void* grdma_kernel_fn_plan_pair_job(void);
 const void* grdma_kernel_fn_plan_pair_mw(void);
 uint32_t grdma_rx_multi_groups(void);
 hipError_t grdma_launch_rx_plan_mw(const grdma_rx_op*, uint32_t, hipStream_t);

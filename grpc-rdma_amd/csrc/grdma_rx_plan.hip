@@ -1588,919 +1588,8 @@ void k_rx_plan_job(const grdma_rx_op* ops) {
 __device__ __attribute__((noinline)) void tx_plan_call(const grdma_tx_op* op) { tx_plan_body(*op); }
 __device__ __attribute__((noinline)) void rx_plan_call(const grdma_rx_op* op) { rx_plan_body(*op); }
 
-// ----------------------------------------------------------------------------
-// k_plan_pair: the two planners of a pipelined round in ONE launch.  The send plan of round t + 1
-// depends on the gather of round t and on the credit of round t - 1, not on the receive plan of
-// round t; both are single-workgroup, latency-bound kernels, and a queue runs kernels one after
-// the other -- so they share a launch: workgroup (link, 0) walks and plans the drain of round t,
-// workgroup (link, 1) prices the Send of round t + 1 on another CU at the same time.  They touch
-// different connection blocks (the receiving and the sending end).  gridDim.y == 1: the receive
-// plan alone (last round).
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_plan_pair(const grdma_rx_op* rxops, const grdma_tx_op* txops) {
-  // (both bodies inline: the out-of-line copies used by the resident engine spill)
-  if (blockIdx.y == 0) rx_plan_body(rxops[blockIdx.x]);
-  else tx_plan_body(txops[blockIdx.x]);
-}
-
-// ----------------------------------------------------------------------------
-// k_plan_pair_job: k_plan_pair for a streaming job -- the drain of round t (workgroup y = 0: steady-state body, the
-// general planner if that declines) and the Send of round t + 1 (y = 1: priced from the index, the general planner
-// if that declines) in ONE launch of 1024-thread workgroups.  One kernel boundary and the send plan's whole duration
-// leave the round's chain: gather, wire, THIS, scatter.
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(RXF_THREADS)
-void k_plan_pair_job(const grdma_rx_op* rxops, const grdma_tx_op* txops, const grdma_txf_ctl* ctls) {
-  static_assert(RXF_THREADS == TXB_THREADS, "one workgroup shape for both planners");
-  if (blockIdx.y == 0) {
-    if (rxf_body(rxops[blockIdx.x])) return;  // (uniform)
-    if (threadIdx.x >= PLAN_THREADS) return;
-    rx_plan_body(rxops[blockIdx.x]);
-    if (threadIdx.x == 0) rxops[blockIdx.x].result->dbg[9] = 0;
-  } else {
-    if (txf_body(txops[blockIdx.x], &ctls[blockIdx.x])) return;  // (uniform)
-    if (threadIdx.x >= PLAN_THREADS) return;
-    tx_plan_body(txops[blockIdx.x]);
-    if (threadIdx.x == 0) txops[blockIdx.x].result->dbg[9] = 0;
-  }
-}
-
-// ----------------------------------------------------------------------------
-// k_plan_pair_mw: the planner pair of a streaming job's round as MANY small workgroups: the drain of round t laid out by
-// G workgroups of four wavefronts (grdma_rx_multi.h: one record per thread, nothing exchanged between the workgroups
-// but the arrival word), the Send of round t + 1 by H more (grdma_tx_multi.h).  gridDim.y = G + H; txops == nullptr:
-// the last round, no Send (H = 0).  A 1024-thread planner is sixteen waves on one CU: four per SIMD, which issues one
-// wave-instruction every four cycles -- 16 x (instructions per thread) cycles whatever the memory system does; here
-// every SIMD has one wave and the probe / the plan stores of a round go through sixteen CUs' memory pipes.  The last
-// workgroup to arrive commits, or -- if any of them declined -- runs the general planner right here (a 256-thread body
-// with the whole register file: no spills, unlike behind the 1024-thread job kernels).
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_plan_pair_mw(const grdma_rx_op* rxops, const grdma_tx_op* txops, const grdma_txf_ctl* ctls, uint32_t G_mode) {
-  static_assert(RXM_THREADS == PLAN_THREADS && TXM_THREADS == PLAN_THREADS, "one workgroup shape for all planner bodies");
-  // G_mode = receive workgroups per link | "promised credit" << 16: the Send waits for the drain plan of this launch
-  // and is priced with the credit that drain's scatter will post (txm_body).  The hand-over: the workgroup that
-  // committed the drain writes its L2 back (one agent-scope release: the result block is at the memory side) and
-  // raises grdma_plan::ready; the Send's workgroups poll it (bounded), invalidate their L2's non-coherent lines (one
-  // agent-scope acquire) and read the credit words; the last of them to arrive clears the flag.  Receive workgroups are dispatched first (smaller blockIdx.y).
-  const uint32_t G = G_mode & 0xFFFFu;
-  const bool promise = (G_mode >> 16) != 0 && G != 0 && gridDim.y > G;
-  if (blockIdx.y < G) {
-    // a connection whose record sizes have a period: predicted from the pattern; none, but the round carries the sizes its
-    // own Send computed: predicted from those (grdma_rx_hint.h).  Either way every record is verified in the ring.
-    const grdma_rx_op& rop = rxops[blockIdx.x];
-    // (<false, true>: every workgroup's own entries write-through -- the general planner may rewrite them below)
-    int r = rxm_body<false, true>(rop, blockIdx.y, G);
-    if (r == 3) {  // (uniform over the whole grid: no workgroup has arrived yet)
-      __syncthreads();
-      r = rxh_body<false, true>(rop, blockIdx.y, G);
-    }
-    if (r == 0) return;  // (uniform: not the committing workgroup)
-    if (r == 2) {
-      rx_plan_body(rxops[blockIdx.x]);
-      if (threadIdx.x == 0) rxops[blockIdx.x].result->dbg[9] = 0;
-    }
-    if (promise) {
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_store(&rop.plan->ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  } else {
-    const grdma_rx_result* promised = nullptr;
-    if (promise) {
-      if (plan_wait_ready(rxops[blockIdx.x].plan) != nullptr) {
-        // acquire: this XCD's L2 may hold the result block as a receive workgroup beside us read it when the launch
-        // began (an L2-bypassing load still hits a line that is there) -- drop what is not coherent before reading it
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        promised = rxops[blockIdx.x].result;
-      } else if (threadIdx.x == 0 && blockIdx.y == G) {
-        atomicAdd(&g_tx_promise[3], 1ull);
-      }
-      // (a wait that ran out -- a bug, not a state -- prices the Send with the credit posted so far: the paired schedule)
-    }
-    const int t = txm_body(txops[blockIdx.x], &ctls[blockIdx.x], blockIdx.y - G, gridDim.y - G, promised);
-    if (t == 0) return;  // (uniform)
-    if (promise && threadIdx.x == 0)  // every workgroup of the Send has passed its wait: the flag's next use is the next launch
-      __hip_atomic_store(&rxops[blockIdx.x].plan->ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t != 2) return;
-    tx_plan_body(txops[blockIdx.x]);
-    if (threadIdx.x == 0) txops[blockIdx.x].result->dbg[9] = 0;
-  }
-}
-
-// ----------------------------------------------------------------------------
-// k_rx_plan_mw: the drain plan alone as many small workgroups (gridDim.y = G: grdma_rx_multi.h, the general planner in
-// the last workgroup to arrive for what that declines) -- an asynchronous endpoint's drains (grdma_endpoint_read_submit),
-// which walk up to the connection's arrival report: a 1 MiB message is 130 records with a period, and the general
-// planner's 30-50 us per pass was what bounded the receiving side of the endpoint vtable.
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_rx_plan_mw(const grdma_rx_op* rxops) {
-  const grdma_rx_op& rop = rxops[blockIdx.x];
-  int r = rxm_body<false, true>(rop, blockIdx.y, gridDim.y);
-  if (r == 3) {
-    __syncthreads();
-    r = rxh_body<false, true>(rop, blockIdx.y, gridDim.y);
-  }
-  if (r != 2) return;  // (uniform)
-  rx_plan_body(rop);
-}
-
-// Will the express drain of `blk.rx` take exactly the records the small send of `blk.tx` is about to produce, all of
-// them whole?  (Every condition of tx_small_wave's pricing and of the express drain in rx_plan_body, evaluated on the
-// two connection blocks before either body runs; uniform over the workgroup.)
-__device__ __forceinline__ bool engine_cut_through_ok(const grdma_engine_cmd& blk) {
-  const grdma_tx_op& t = blk.tx;
-  const grdma_rx_op& r = blk.rx;
-  const grdma_conn* A = t.conn;
-  const grdma_conn* B = r.conn;
-  if (t.use_cursor != 0 || t.byte_idx != 0 || !t.inline_copy || !r.inline_apply || r.raw_cap != 0 || r.append != 0) return false;
-  const uint64_t nsl = t.nslices;
-  if (nsl < 1 || nsl > 8 || nsl > A->max_sge) return false;
-  if (A->status != GRDMA_PAIR_CONNECTED || B->status != GRDMA_PAIR_CONNECTED || A->peer_ring == nullptr || A->peer_ring != B->ring) return false;
-  const uint64_t cap = A->cap, mask = cap - 1;
-  if (cap != B->cap || cap > (1ull << 31)) return false;
-  const uint64_t tail0 = A->remote_tail, S = A->staging_cap;
-  const uint64_t rhead = __hip_atomic_load(&A->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const uint64_t free0 = cap - ((tail0 + cap - rhead) & mask);
-  // the send: every slice goes out whole (pay_i = len_i), at most 512 bytes in all
-  uint64_t st = 0, T = 0;
-  for (uint64_t i = 0; i < nsl; i++) {
-    const uint64_t len = blk.sges[i].len;
-    if (len == 0 || len > 256) return false;
-    if (writable_of(sat_sub(S, st)) < len || writable_of(sat_sub(free0, st)) < len) return false;
-    st += enc_size(len);
-    T += len;
-  }
-  if (T > 512) return false;
-  // the drain: nothing unread in front of these records, nothing half-read, the open (or a fresh) read takes them all
-  if (B->head != tail0 || B->moving_head != tail0 || B->remain != 0) return false;
-  uint64_t max_slices = GRDMA_MAX_SLICES;
-  if (r.max_reads < max_slices) max_slices = r.max_reads;
-  if (max_slices < 1) return false;
-  uint64_t rem1 = 0, x = 0;  // what is left of the record in which the open read's last byte falls
-  for (uint64_t i = 0; i < nsl; i++) {
-    const uint64_t len = blk.sges[i].len;
-    if (B->leftover_cap >= x && B->leftover_cap < x + len) rem1 = x + len - B->leftover_cap;
-    x += len;
-  }
-  return express_fits(B->leftover_cap, blk.sges[0].len, T, max_slices, 0, r.arena_cap, rem1, B->internal_read_size + st >= cap / 2) != 0;
-}
-
-// ----------------------------------------------------------------------------
-// k_engine: persistent latency engine.  One workgroup stays resident and takes
-// Send / drain commands from a mailbox in pinned host memory, so a 64-byte RPC
-// pays a PCIe doorbell read instead of a kernel launch.  The command bodies are
-// exactly the plan kernels above with the byte movement inlined
-// (op.inline_copy / op.inline_apply), so ring bytes and state are identical to
-// the batched path.  The engine leaves by itself when idle for ~1 s or when the
-// host sets exit_flag.
-// ----------------------------------------------------------------------------
-__device__ __attribute__((noinline)) void engine_body(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_t flags) {
-  const bool prof = (flags & 2u) != 0;
-  __shared__ uint64_t s_cmd[4];
-  __shared__ uint64_t s_wcmd[sizeof(grdma_watch_cmd) / 8];
-  __shared__ uint64_t s_fast[GRDMA_FAST_WORDS];
-  __shared__ __attribute__((aligned(16))) grdma_engine_cmd s_blk;
-  __shared__ grdma_ct_hint s_cth;
-  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // resume after the last command a previous incarnation completed
-  uint64_t last = __hip_atomic_load(&mb->ack_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-  uint64_t my_consumed = ~0ull;  // (wave 0, lane = watch slot: what this incarnation has mirrored of mb->consumed)
-  uint64_t ptot[4] = {mb->pad1[0], mb->pad1[1], mb->pad1[2], mb->pad1[3]};  // (thread 0's running totals, see the acknowledgement)
-  static_assert(GRDMA_WATCH_SLOTS == 64, "one lane of the doorbell wave per watch slot");
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(&mb->alive, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  __syncthreads();
-  for (;;) {
-    // Doorbell.  The whole of wave 0 spins (a wave-uniform branch, all lanes load the
-    // same word): a single-lane spin loop would be a divergent loop around the
-    // barriers below, which the compiler may legally serialise into a deadlock.
-    if (wave == 0) {
-      uint64_t seq, idle = 0, quit = 0, fast_words = 0, fast_type = 0;
-      for (;;) {
-        // one poll = three loads in flight together: the eight fast-lane lines (lane l = word l), the completions the
-        // host has taken from the watch slots (lane l = slot l), and the doorbell of the pointer path
-        const uint64_t fw = GRDMA_WAVE_LOAD_LINES(mb->fast, lane);
-        const uint64_t cw = __hip_atomic_load(&mb->consumed[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        seq = __hip_atomic_load(&mb->cmd_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (cw != my_consumed) {  // (into the slot, where the watcher of that connection polls it: device memory)
-          my_consumed = cw;
-          __hip_atomic_store(&wc->slot[lane].consumed, cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        seq = __shfl(seq, 0, 64);
-        const uint64_t stamp0 = __shfl(fw, 7, 64);
-        if (stamp0 == last + 1) {
-          // a fast command: every line it spans must carry its stamp
-          const uint64_t hdr = __shfl(fw, 0, 64);
-          const uint64_t ftype = hdr & 0xFF, nsg = (hdr >> 8) & 0xFF, db = (hdr >> 16) & 0xFFFF;
-          const uint64_t nw = 1 + (ftype == GRDMA_ENGINE_DRAIN_BLOCK ? 0 : sizeof(grdma_tx_op) / 8) +
-                              (ftype == GRDMA_ENGINE_SEND_INLINE ? 0 : sizeof(grdma_rx_op) / 8) + 2 * nsg + (db + 7) / 8;
-          const uint64_t lines = (nw + 6) / 7;
-          const bool mine_ok = (lane & 7) != 7 || (uint64_t)(lane >> 3) >= lines || fw == stamp0;
-          if (nw <= GRDMA_FAST_WORDS && __all(mine_ok)) {
-            if ((lane & 7) != 7) s_fast[(lane >> 3) * 7 + (lane & 7)] = fw;
-            seq = stamp0;
-            fast_words = nw;
-            fast_type = ftype;
-            break;
-          }
-          // (a line is still on its way: poll again)
-        } else if (seq == last + 1) {
-          break;
-        }
-        if ((idle & 63) == 63) {
-          quit = __hip_atomic_load(&mb->exit_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          quit = __shfl(quit, 0, 64);
-          if (quit || idle > (1ull << 19)) { quit = 1; break; }   // ~1 s of polling
-        }
-        idle++;
-        __builtin_amdgcn_s_sleep(8);
-      }
-      uint64_t type, opp;
-      if (fast_words) {
-        type = fast_type;
-        opp = 1;  // "the command came through the fast lane": the block is rebuilt from s_fast below
-      } else {
-        type = quit ? 0 : mb->cmd_type;
-        opp = quit ? 0 : (uint64_t)mb->op;
-      }
-      if (lane == 0) {
-        s_cmd[0] = seq;
-        s_cmd[1] = type;
-        s_cmd[2] = opp;
-        s_cmd[3] = quit;
-      }
-    }
-    __syncthreads();
-    const uint64_t seq = s_cmd[0], type = s_cmd[1], opp = s_cmd[2], quit = s_cmd[3];
-    __syncthreads();
-    if (quit) break;
-    last = seq;
-    if (threadIdx.x == 0 && prof)  // (profiling aid, grdma_watch_ticks)
-      __hip_atomic_store(&g_watch_ticks[8], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint64_t te0 = prof_time(prof);
-    uint64_t te1 = te0;
-    if (opp == 0) {
-      // malformed doorbell: acknowledge and keep serving
-    } else if (type == GRDMA_ENGINE_SEND) {
-      tx_plan_call(reinterpret_cast<const grdma_tx_op*>(opp));
-    } else if (type == GRDMA_ENGINE_DRAIN) {
-      rx_plan_call(reinterpret_cast<const grdma_rx_op*>(opp));
-    } else if (type == GRDMA_ENGINE_WATCH) {
-      // hand a connection's receive side to its watcher (gen != 0), or take it back (gen == 0)
-      if (threadIdx.x < sizeof(grdma_watch_cmd) / 8)
-        s_wcmd[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(opp) + threadIdx.x, __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_SYSTEM);
-      __syncthreads();
-      const uint64_t slot = s_wcmd[0] % GRDMA_WATCH_SLOTS, gen = s_wcmd[1];
-      grdma_watch_slot* sl = &wc->slot[slot];
-      if (gen != 0) {
-        // (what this workgroup's own drains have left of the connection's state reaches memory before the watcher,
-        //  on another CU and possibly behind another L2, takes the connection over)
-        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        static_assert(offsetof(grdma_watch_cmd, op) == 24 && offsetof(grdma_watch_cmd, win_base) == 24 + sizeof(grdma_rx_op) &&
-                      offsetof(grdma_watch_slot, win_base) == offsetof(grdma_watch_slot, op) + sizeof(grdma_rx_op),
-                      "order and windows are copied as one run of words");
-        if (threadIdx.x < sizeof(grdma_rx_op) / 8 + GRDMA_WATCH_WINDOWS)
-          __hip_atomic_store(reinterpret_cast<uint64_t*>(&sl->op) + threadIdx.x, s_wcmd[3 + threadIdx.x], __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_SYSTEM);
-        if (threadIdx.x == 64) __hip_atomic_store(&sl->consumed, s_wcmd[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (threadIdx.x == 65) __hip_atomic_store(&sl->done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        GRDMA_WAIT_VMEM();
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(&sl->gen, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      } else {
-        if (threadIdx.x == 0) __hip_atomic_store(&sl->gen, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (wave == 0) {  // (the whole wave spins, like the doorbell: a wave-uniform loop)
-          // the watcher lets go between two drains; a drain it is in the middle of completes first
-          for (uint64_t spins = 0; spins < (1ull << 24); spins++) {
-            uint64_t a = __hip_atomic_load(&sl->ack_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            a = __shfl(a, 0, 64);
-            if (a == 0) break;
-            __builtin_amdgcn_s_sleep(2);
-          }
-          if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-      }
-      if (wave == 0 && lane == slot) my_consumed = ~0ull;  // (mirrored afresh: the host counts from zero per arming)
-    } else if (type == GRDMA_ENGINE_SEND_INLINE || type == GRDMA_ENGINE_DRAIN_BLOCK ||
-               type == GRDMA_ENGINE_SEND_INLINE_DRAIN) {
-      // one wide read of the whole command block into LDS, then everything the body
-      // touches (op, slice table, payload) is local
-      if (opp == 1) {
-        // fast lane: the words are in LDS already (the barrier after the doorbell published them)
-        const uint64_t hdr = s_fast[0];
-        const unsigned nsg = (unsigned)((hdr >> 8) & 0xFF), dw = (unsigned)((((hdr >> 16) & 0xFFFF) + 7) / 8);
-        const bool is_tx = type != GRDMA_ENGINE_DRAIN_BLOCK;
-        const unsigned opw = is_tx ? sizeof(grdma_tx_op) / 8 : sizeof(grdma_rx_op) / 8;
-        uint64_t* dop = is_tx ? reinterpret_cast<uint64_t*>(&s_blk.tx) : reinterpret_cast<uint64_t*>(&s_blk.rx);
-        if (threadIdx.x < opw) dop[threadIdx.x] = s_fast[1 + threadIdx.x];
-        if (is_tx) {
-          if (threadIdx.x < 2 * nsg) reinterpret_cast<uint64_t*>(s_blk.sges)[threadIdx.x] = s_fast[1 + opw + threadIdx.x];
-          if (threadIdx.x < dw)
-            reinterpret_cast<uint64_t*>(s_blk.inline_data)[threadIdx.x] = s_fast[1 + opw + 2 * nsg + threadIdx.x];
-          if (type == GRDMA_ENGINE_SEND_INLINE_DRAIN && threadIdx.x < sizeof(grdma_rx_op) / 8)
-            reinterpret_cast<uint64_t*>(&s_blk.rx)[threadIdx.x] = s_fast[1 + opw + 2 * nsg + dw + threadIdx.x];
-        }
-      } else {
-        const u32x4* src = reinterpret_cast<const u32x4*>(opp);
-        u32x4* dst = reinterpret_cast<u32x4*>(&s_blk);
-        for (unsigned i = threadIdx.x; i < sizeof(grdma_engine_cmd) / 16; i += PLAN_THREADS)
-          dst[i] = __builtin_nontemporal_load(src + i);
-      }
-      __syncthreads();
-      te1 = prof_time(prof);
-      bool chained = false;
-      if (type != GRDMA_ENGINE_DRAIN_BLOCK) {
-        if (threadIdx.x < GRDMA_CMD_MAX_SGES)
-          s_blk.sges[threadIdx.x].ptr = s_blk.inline_data + (uint64_t)s_blk.sges[threadIdx.x].ptr;
-        if (threadIdx.x == 0) s_blk.tx.slices = s_blk.sges;
-        __syncthreads();
-        // A send with the armed drain behind it: the send wave leaves its record sizes in LDS for the drain (no probe
-        // of the ring), the two system-scope releases of the send wait for the drain's, and -- when both connections'
-        // state says the express drain will take exactly these records -- the records are CUT THROUGH: never written
-        // into staging or ring, never read back, never cleared (grdma_ct_hint, grdma_ops.h).  Decided here, by every
-        // thread alike, before the first store of the command.
-        if (s_blk.tx.sizes_out == reinterpret_cast<grdma_size_hint*>(1)) {  // (the host's "do not chain": GRDMA_ENGINE_CUT_THROUGH=0)
-          __syncthreads();
-          if (threadIdx.x == 0) s_blk.tx.sizes_out = nullptr;
-          __syncthreads();
-        } else if (type == GRDMA_ENGINE_SEND_INLINE_DRAIN && s_blk.tx.seq_next != 0 && s_blk.tx.nslices >= 1 && s_blk.tx.nslices <= 8 &&
-            s_blk.tx.sizes_out == nullptr && s_blk.rx.sizes_in == nullptr) {
-          chained = true;
-          const bool ct = engine_cut_through_ok(s_blk);
-          __syncthreads();
-          if (threadIdx.x == 0) {
-            s_cth.start_off = ~0ull;
-            s_cth.count = 0;
-            s_cth.cut_through = ct ? 1u : 0u;
-            s_cth.src = s_blk.sges[0].ptr;
-            s_blk.tx.inline_copy = (s_blk.tx.inline_copy & GRDMA_OP_PROFILE) | 1u | (ct ? 2u : 0u) | 4u;
-            s_blk.tx.sizes_out = reinterpret_cast<grdma_size_hint*>(&s_cth);
-            s_blk.rx.sizes_in = reinterpret_cast<const grdma_size_hint*>(&s_cth);
-            s_blk.rx.inline_apply = (s_blk.rx.inline_apply & GRDMA_OP_PROFILE) | 1u | 2u;
-          }
-          __syncthreads();
-        }
-        tx_plan_call(&s_blk.tx);
-        __syncthreads();
-      }
-      // (the armed drain of the local peer follows the send in the same command: what the host would
-      // have asked for next, minus its doorbell round trip)
-      if (type != GRDMA_ENGINE_SEND_INLINE) rx_plan_call(&s_blk.rx);
-      if (chained) {  // the send's sequence word, behind the drain's release (same thread): its result block is complete
-        __syncthreads();
-        if (threadIdx.x == 0)
-          __hip_atomic_store(&s_blk.tx.result->seq, s_blk.tx.seq_next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      // the acknowledgement first; then the profiling aid: cycles spent loading the command block / running the body,
-      // per type -- running totals kept in registers and STORED (a `+=` on the mailbox is a PCIe read in front of
-      // every acknowledgement: 1.5 us per command)
-      __hip_atomic_store(&mb->ack_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (prof) {
-        const uint64_t te2 = __builtin_amdgcn_s_memtime();
-        const int k = (type & 1) ? 0 : 2;
-        ptot[k] += te1 - te0;
-        ptot[k + 1] += te2 - te1;
-        __hip_atomic_store(&mb->pad1[k], ptot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mb->pad1[k + 1], ptot[k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    // the watchers of this incarnation leave with it
-    __hip_atomic_store(&wc->quit, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&mb->alive, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
-// ----------------------------------------------------------------------------
-// The watcher's own drain of a unary-sized message: rx_plan_body's express drain as ONE wavefront, straight line, no
-// barrier -- the other three waves of the watcher stay parked.  What makes it shorter than the express drain:
-//   * the connection's receive state lives in LDS between drains (rxw_state: only this workgroup changes it while the
-//     connection is handed to it), so nothing of the connection block is loaded;
-//   * the arrival report bounds the bytes ([head, wire_tail), at most 1 KiB for this path): ONE round trip loads them
-//     all -- tags and payload -- into LDS, and the record chain is walked there;
-//   * result block, slice table and payload leave as a handful of wide stores from many lanes, one wait, then the
-//     sequence word; the connection block is written back BEHIND it.
-// Same records, slices, state, history, credit and zero-fill as the express drain (tests/test_zzz_gpu_watch_read.py
-// runs both against the oracle, and against each other: GRDMA_WATCH_FAST=0).  Returns false -- nothing touched -- when
-// the message is not its case; the caller then runs the plan body.
-// ----------------------------------------------------------------------------
-struct rxw_state {
-  grdma_conn* conn;
-  uint8_t* ring;
-  uint64_t cap;
-  uint64_t head, mh, remain, leftover, irs, hist_count, total_read, credit_msgs, rx_records, rx_rounds;
-  uint32_t h1, h2, connected, limited;
-  grdma_hostline* line;
-  grdma_status_report* peer_status;
-  grdma_hostline* peer_line;
-  uint32_t* hist;
-};
-
-// (by the lane that owns the slot: the connection block as memory holds it -- loads past this CU's L1)
-__device__ __forceinline__ void rxw_load(rxw_state* st, grdma_conn* c) {
-  auto ld = [](const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  auto ld32 = [](const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  st->conn = c;
-  st->ring = c->ring;
-  st->cap = c->cap;
-  st->head = ld(&c->head);
-  st->mh = ld(&c->moving_head);
-  st->remain = ld(&c->remain);
-  st->leftover = ld(&c->leftover_cap);
-  st->irs = ld(&c->internal_read_size);
-  st->hist_count = ld(&c->rx_hist_count);
-  st->total_read = ld(&c->total_read);
-  st->credit_msgs = ld(&c->credit_msgs);
-  st->rx_records = ld(&c->rx_records);
-  st->rx_rounds = ld(&c->rx_rounds);
-  st->h1 = ld32(&c->rx_h1);
-  st->h2 = ld32(&c->rx_h2);
-  st->connected = ld32(&c->status) == GRDMA_PAIR_CONNECTED ? 1u : 0u;
-  st->limited = c->wire_limit != 0 ? 1u : 0u;
-  st->line = c->line;
-  st->peer_status = c->peer_status;
-  st->peer_line = c->peer_line;
-  st->hist = c->rx_hist;
-}
-
-__device__ unsigned long long g_watch_fast_drains = 0;
-
-#define RXW_EXT_WORDS 128   // the bytes one drain of this path looks at: 1 KiB
-__device__ __forceinline__ bool rxw_fast(rxw_state* __restrict__ st, const grdma_rx_op* __restrict__ opp, uint64_t done, uint64_t wt,
-                                         uint8_t* dst, int lane, uint64_t* __restrict__ s_ext /* [RXW_EXT_WORDS + 8 + 66] */, uint64_t t_found, bool prof) {
-  // Everything this drain needs of the state and the order, out of LDS in ONE batch of reads in front of the first LDS
-  // store (a read behind a store to LDS the compiler cannot tell apart from it waits for it: fifty waits in the first
-  // version of this function, profiles/r05_rtt_notes.txt).
-  const rxw_state S0 = *st;
-  const grdma_rx_op op = *opp;
-  auto rfl = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
-  const uint64_t cap = S0.cap, mask = cap - 1, head0 = S0.head;
-  const uint64_t E = (wt - head0) & mask;
-  if (!S0.limited || !S0.connected || S0.remain != 0 || E == 0 || E > RXW_EXT_WORDS * 8 || (E & 7) != 0 || cap < 2048) return false;
-  if (op.raw_cap != 0 || op.append != 0 || op.max_reads < 1) return false;
-  uint8_t* const ring = S0.ring;
-  // ---- one round trip: every word of [head, head + E), lane l holds words l and l + 64 --------------------------
-  const uint32_t E32 = rfl((uint32_t)E), nw = E32 >> 3;
-  uint64_t w0 = 0, w1 = 0;
-  if ((uint32_t)lane < nw)
-    w0 = __hip_atomic_load(reinterpret_cast<const uint64_t*>(ring + ((head0 + 8ull * lane) & mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (nw > 64 && (uint32_t)lane + 64u < nw)
-    w1 = __hip_atomic_load(reinterpret_cast<const uint64_t*>(ring + ((head0 + 8ull * (lane + 64)) & mask)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const uint64_t t_loaded = prof_realtime(prof) + (w0 & 0);
-  // ---- the record chain, walked across the lanes' registers: the position is a scalar, a word of the extent is two
-  //      v_readlane -- no memory, no LDS ----------------------------------------------------------------------------
-  const uint32_t w0l = (uint32_t)w0, w0h = (uint32_t)(w0 >> 32), w1l = (uint32_t)w1, w1h = (uint32_t)(w1 >> 32);
-  auto word_lo = [&](uint32_t wi) -> uint32_t {   // (wi: scalar)
-    return wi < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)w0l, (int)wi) : (uint32_t)__builtin_amdgcn_readlane((int)w1l, (int)(wi - 64));
-  };
-  auto word_hi = [&](uint32_t wi) -> uint32_t {
-    return wi < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)w0h, (int)wi) : (uint32_t)__builtin_amdgcn_readlane((int)w1h, (int)(wi - 64));
-  };
-  constexpr uint32_t RMAX = 8;
-  uint32_t rn[RMAX];   // payload bytes by record (scalars)
-  uint32_t v = 0, pos = 0, T = 0;
-  bool ok = true;
-#pragma unroll
-  for (uint32_t r = 0; r < RMAX; r++) {
-    rn[r] = 0;
-    if (ok && pos < E32) {
-      const uint32_t wi = pos >> 3;
-      const uint32_t hlo = word_lo(wi), hhi = word_hi(wi);
-      const uint32_t encr = 16u + ((hlo + 7u) & ~7u);
-      if (hhi != 0 || hlo == 0 || hlo > 512 || pos + encr > E32) {
-        ok = false;
-      } else {
-        const uint32_t fi = (pos + encr - 8) >> 3;
-        if ((word_lo(fi) & word_hi(fi)) != 0xFFFFFFFFu) {
-          ok = false;
-        } else {
-          rn[r] = hlo;
-          T += hlo;
-          pos += encr;
-          v = r + 1;
-        }
-      }
-    }
-  }
-  if (!ok || pos != E32 || v == 0 || T > 512) return false;
-  const uint64_t t_walk = prof_realtime(prof) + (T & 0);
-  const uint64_t leftover0 = S0.leftover, irs0 = S0.irs;
-  uint64_t max_slices = GRDMA_MAX_SLICES;
-  if (op.max_reads < max_slices) max_slices = op.max_reads;
-  const uint32_t n0 = rn[0];
-  uint32_t rem1 = 0;   // what is left of the record in which the open read's last byte falls (sizes the second read)
-  if (leftover0 != 0 && leftover0 < T) {
-    uint32_t x = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < RMAX; r++) {
-      if (rn[r] != 0 && leftover0 >= x && leftover0 < (uint64_t)x + rn[r]) rem1 = x + rn[r] - (uint32_t)leftover0;
-      x += rn[r];
-    }
-  }
-  const int fits = express_fits(leftover0, n0, T, max_slices, 0, op.arena_cap, rem1, irs0 + E >= cap / 2);
-  if (fits == 0) return false;
-  // ---- from here on the drain happens ----------------------------------------------------------------------------
-  const bool split = fits == 2;
-  const uint64_t alloc = leftover0 ? leftover0 : (n0 > MINRD ? n0 : MINRD);
-  const uint32_t L0 = split ? (uint32_t)leftover0 : T;
-  const uint32_t off1 = split ? (uint32_t)((L0 + 15u) & ~15u) : 0;
-  // payload: the extent into LDS, then record by record into s_out, back to back (the slice the reads deliver); the
-  // bytes behind the end inside the last word stay zero
-  uint32_t* const s_enc = reinterpret_cast<uint32_t*>(s_ext + RXW_EXT_WORDS);   // [RMAX] encoded sizes, by record
-  uint64_t* const s_out = s_ext + RXW_EXT_WORDS + 8;                            // [64 + 1] the delivered bytes
-  s_ext[lane] = w0;
-  if (nw > 64) s_ext[lane + 64] = w1;
-  s_out[lane] = 0;
-  GRDMA_WAVE_CONVERGE();
-  const uint8_t* ext8 = reinterpret_cast<const uint8_t*>(s_ext);
-  uint8_t* out8 = reinterpret_cast<uint8_t*>(s_out);
-  {
-    uint32_t xn = 0, xe = 0;   // payload / encoded bytes in front of record r
-#pragma unroll
-    for (uint32_t r = 0; r < RMAX; r++) {
-      if (r < v) {
-        const uint32_t n = rn[r];
-        if (lane == 0) s_enc[r] = 16u + ((n + 7u) & ~7u);
-        for (uint32_t j = (uint32_t)lane; j < n; j += 64) out8[xn + j] = ext8[xe + 8 + j];
-        xn += n;
-        xe += 16u + ((n + 7u) & ~7u);
-      }
-    }
-  }
-  GRDMA_WAVE_CONVERGE();
-  const uint64_t t_copy = prof_realtime(prof) + (s_out[0] & 0);
-  if (split) {
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const uint32_t b = (uint32_t)lane * 8 + q;
-      if (b < T) __hip_atomic_store(dst + (b < L0 ? b : off1 + (b - L0)), out8[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  } else if ((uint32_t)lane * 8 < T) {
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(dst + (uint32_t)lane * 8), s_out[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  // what was consumed is cleared (records are 8-byte granular), past the caches: the sender overwrites it from another CU
-  if ((uint32_t)lane < nw)
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(ring + ((head0 + 8ull * lane) & mask)), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (nw > 64 && (uint32_t)lane + 64u < nw)
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(ring + ((head0 + 8ull * (lane + 64)) & mask)), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  // history ring, the credit rule of Recv (pair.cc:276-284) record by record
-  const uint64_t hist_count0 = S0.hist_count;
-  if ((uint32_t)lane < v) S0.hist[(hist_count0 + lane) % GRDMA_RX_HIST] = s_enc[lane];
-  uint64_t irs = irs0 + E, credit = 0, credit_head = 0;
-  if (irs >= cap / 2) {   // (a status report falls into this drain: record by record)
-    irs = irs0;
-    uint32_t xe = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < RMAX; r++) {
-      if (r < v) {
-        const uint32_t encr = 16u + ((rn[r] + 7u) & ~7u);
-        irs += encr;
-        xe += encr;
-        if (irs >= cap / 2) {
-          credit_head = (head0 + xe) & mask;
-          credit++;
-          irs = 0;
-        }
-      }
-    }
-  }
-  const uint64_t nh = (head0 + E) & mask, mh0 = S0.mh;
-  uint64_t nslices, a_off, would_block, leftover;
-  grdma_slice_out sl0 = {0, 0}, sl1 = {0, 0};
-  if (split) {
-    const uint64_t rest = T - L0, alloc2 = rem1 > MINRD ? rem1 : MINRD, rest2 = alloc2 - rest;
-    sl0.off = 0; sl0.len = L0;
-    sl1.off = off1; sl1.len = rest;
-    nslices = 2;
-    a_off = (off1 + rest + 15) & ~15ull;
-    would_block = max_slices >= 3 ? 1 : 0;
-    leftover = max_slices >= 3 ? (rest2 ? rest2 : MINRD) : rest2;
-  } else {
-    sl0.off = 0; sl0.len = T;
-    nslices = 1;
-    a_off = ((uint64_t)T + 15) & ~15ull;
-    const uint64_t rest = alloc - T;
-    would_block = max_slices >= 2 ? 1 : 0;
-    leftover = max_slices >= 2 ? (rest ? rest : MINRD) : rest;
-  }
-  // result block (pinned host memory): one word per lane
-  grdma_rx_result* res = op.result;
-  uint64_t zo0 = mh0, zl0, zo1 = 0, zl1 = 0;
-  if (nh > mh0) { zl0 = nh - mh0; } else { zl0 = cap - mh0; zl1 = nh; }
-  {
-    uint64_t val = 0;
-    switch (lane) {
-      case 0: val = nslices; break;
-      case 1: val = T; break;
-      case 2: val = E; break;
-      case 3: val = v; break;
-      case 4: val = would_block; break;
-      case 5: val = credit; break;
-      case 6: val = credit_head; break;
-      case 7: val = nh; break;
-      case 8: val = nh; break;
-      case 9: val = 0; break;
-      case 10: val = a_off; break;
-      case 11: val = zo0; break;
-      case 12: val = zo1; break;
-      case 13: val = zl0; break;
-      case 14: val = zl1; break;
-      default: break;
-    }
-    static_assert(offsetof(grdma_rx_result, zero_len) == 13 * 8 && offsetof(grdma_rx_result, seq) == 15 * 8 &&
-                  offsetof(grdma_rx_result, commit_seq) == 16 * 8, "rxw_fast writes the result block word by word");
-    if (lane < 15) __hip_atomic_store(reinterpret_cast<uint64_t*>(res) + lane, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (lane == 16) __hip_atomic_store(&res->commit_seq, op.seq_next + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // slice table
-    if (lane == 17) __hip_atomic_store(&op.slices[0].off, sl0.off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (lane == 18) __hip_atomic_store(&op.slices[0].len, sl0.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (split && lane == 19) __hip_atomic_store(&op.slices[1].off, sl1.off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (split && lane == 20) __hip_atomic_store(&op.slices[1].len, sl1.len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // what HasMessage() on the host compares with the sender's arrival report
-    if (S0.line != nullptr) {
-      if (lane == 21) __hip_atomic_store(&S0.line->rx_head, nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (lane == 22) __hip_atomic_store(&S0.line->rx_remain, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  const uint64_t t_stores = prof_realtime(prof);
-  // every store above is acknowledged -- the zero-fill has left this CU before the credit that grants it goes out
-  GRDMA_WAIT_VMEM();
-  GRDMA_WAVE_CONVERGE();  // (nothing on the GPU, where the lanes of a wave issue a store together)
-  if (credit) {
-    if (lane == 0 && S0.peer_status != nullptr)
-      __hip_atomic_store(&S0.peer_status->remote_head, credit_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (lane == 1 && S0.peer_line != nullptr)
-      __hip_atomic_store(&S0.peer_line->remote_head, credit_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    GRDMA_WAIT_VMEM();
-    GRDMA_WAVE_CONVERGE();
-  }
-  if (lane == 0) __hip_atomic_store(&res->seq, op.seq_next + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const uint64_t t_seq = prof_realtime(prof);
-  // ---- behind the sequence word: the state in LDS, and the connection block as the plan body would leave it ---------
-  // sizes of the two newest records, for the plan body's probe round
-  const uint32_t enc_last = s_enc[v - 1], e_prev = v >= 2 ? s_enc[v - 2] : 0;
-  const uint32_t nh1 = enc_last, nh2 = v >= 2 ? e_prev : S0.h1;
-  if (lane == 0) {
-    grdma_conn* c = S0.conn;
-    c->rx_h1 = nh1;
-    c->rx_h2 = nh2;
-    c->rx_hist_count = hist_count0 + v;
-    c->head = nh;
-    c->moving_head = nh;
-    c->remain = 0;
-    c->internal_read_size = irs;
-    c->leftover_cap = leftover;
-    c->total_read = S0.total_read + T;
-    c->credit_msgs = S0.credit_msgs + credit;
-    c->rx_records = S0.rx_records + v;
-    c->rx_rounds = S0.rx_rounds + 1;
-    if (credit) c->status_send.remote_head = credit_head;
-    grdma_plan* plan = op.plan;
-    plan->nsegs = 0;
-    plan->ntiles = 0;
-    plan->tile_bytes = 1u << GRDMA_PLAN_TILE_SHIFT(cap);
-    plan->tile_prefix[0] = 0;
-    plan->bytes = T;
-    plan->tag_base = (uint64_t)ring;
-    plan->tag_mask = mask;
-    plan->blocks_done = 0;
-    st->h1 = nh1;
-    st->h2 = nh2;
-    st->hist_count = hist_count0 + v;
-    st->head = nh;
-    st->mh = nh;
-    st->irs = irs;
-    st->leftover = leftover;
-    st->total_read = S0.total_read + T;
-    st->credit_msgs = S0.credit_msgs + credit;
-    st->rx_records = S0.rx_records + v;
-    st->rx_rounds = S0.rx_rounds + 1;
-    atomicAdd(&g_watch_fast_drains, 1ull);
-    atomicAdd(&g_express_drains, 1ull);
-    // (profiling aid, grdma_watch_ticks: 10 ns ticks since the watcher found the arrival report)
-    if (prof) {
-    g_watch_ticks[5] += t_loaded - t_found;
-    g_watch_ticks[6] += t_stores - t_found;
-    g_watch_ticks[7] += t_seq - t_found;
-    g_watch_ticks[10] += t_walk - t_found;
-    g_watch_ticks[11] += t_copy - t_found;
-    g_watch_ticks[9] += t_found - __hip_atomic_load(&g_watch_ticks[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  GRDMA_WAVE_CONVERGE();
-  return true;
-}
-
-// ----------------------------------------------------------------------------
-// k_watch: the read side of the latency engine (grdma_watch_slot, grdma_ops.h).  One workgroup per watcher; lane l of
-// its first wave owns slot blockIdx.x + l * gridDim.x and keeps that connection's head in a register.  A pass is one
-// round trip to device memory for all its connections at once: the slot's generation, the completions the host has
-// taken, and the connection's arrival report (ordered wire: the header at the head and the footer it points at,
-// GetReadableSize, ring_buffer.cc:67-97).  When a connection has bytes and its last completion has been taken, the
-// whole workgroup runs the standing order through the same plan body every other drain runs (bytes, state, credit:
-// those of grdma_endpoint_read called at that moment) and goes back to polling.  The drain is limited to what the
-// pass saw (grdma_rx_op::limit_ptr points at the word in LDS): what lands meanwhile is the next pass's.
-// ----------------------------------------------------------------------------
-__device__ __attribute__((noinline)) void watch_body(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_t flags,
-                                                     const unsigned wg, const unsigned nwg) {
-  __shared__ __attribute__((aligned(16))) grdma_rx_op s_op;
-  // the standing orders of this workgroup's slots, by owning lane; their connections' receive state; the windows their
-  // drains deliver into
-#ifdef GRDMA_WAVE_EMU
-  // (the emulator's __shared__ objects are process-wide statics and the command workgroup runs beside this one there)
-  __shared__ __attribute__((aligned(16))) grdma_rx_op s_ops[64];
-  __shared__ rxw_state s_st[64];
-  __shared__ uint8_t* s_win[64][GRDMA_WATCH_WINDOWS];
-#else
-  // (in the send plan's first array: a watcher never plans a Send -- see g_txs_len)
-  static_assert(64 * (sizeof(grdma_rx_op) + sizeof(rxw_state) + 8 * GRDMA_WATCH_WINDOWS) <= sizeof(g_txs_len), "the watcher's tables fit");
-  grdma_rx_op* const s_ops = reinterpret_cast<grdma_rx_op*>(g_txs_len);
-  rxw_state* const s_st = reinterpret_cast<rxw_state*>(s_ops + 64);
-  uint8_t* (*const s_win)[GRDMA_WATCH_WINDOWS] = reinterpret_cast<uint8_t* (*)[GRDMA_WATCH_WINDOWS]>(s_st + 64);
-#endif
-  __shared__ __attribute__((aligned(16))) uint64_t s_ext[RXW_EXT_WORDS + 8 + 66];   // extent, record table, delivered bytes (rxw_fast)
-  __shared__ uint64_t s_limit, s_done, s_found;
-  __shared__ uint8_t* s_arena;
-  __shared__ uint32_t s_fire, s_limited;
-  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const unsigned my_slot = wg + lane * nwg;
-  const bool have = my_slot < GRDMA_WATCH_SLOTS;
-  const bool fast_on = (flags & 1u) != 0, prof = (flags & 2u) != 0;
-  grdma_watch_slot* const sl = &wc->slot[have ? my_slot : 0];
-  // (wave 0, per lane: the connection this lane watches)
-  uint64_t gen_seen = 0, head = 0, remain = 0, done = 0, mask = 0;
-  grdma_conn* conn = nullptr;
-  const uint8_t* ring = nullptr;
-  const uint64_t* wire_ptr = nullptr;
-  bool limited = true;
-  uint32_t rr = 0;
-  if (threadIdx.x == 0 && wg < GRDMA_WATCH_MAX_GROUPS)
-    __hip_atomic_store(&mb->watch_alive[wg], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  __syncthreads();
-  for (;;) {
-    if (wave == 0) {
-      uint32_t fire = 0;
-      for (;;) {
-        // one pass = one round trip: every load is issued before the first one is looked at
-        const bool armed = gen_seen != 0;
-        uint64_t q = __hip_atomic_load(&wc->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const uint64_t gen = have ? __hip_atomic_load(&sl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
-        uint64_t consumed = 0, wt = 0;
-        if (armed) {
-          consumed = __hip_atomic_load(&sl->consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          // (ordered wire: the header at the head stands in for the arrival report)
-          wt = __hip_atomic_load(limited ? wire_ptr : reinterpret_cast<const uint64_t*>(ring + head), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        q = __shfl(q, 0, 64);
-        if (q == epoch) break;
-        bool fresh = false;
-        if (gen != gen_seen) {
-          if (gen != 0) {
-            // taken over: the connection block as its last owner left it (the command workgroup released it)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            for (unsigned k = 0; k < sizeof(grdma_rx_op) / 8; k++)
-              reinterpret_cast<uint64_t*>(&s_ops[lane])[k] =
-                  __hip_atomic_load(reinterpret_cast<const uint64_t*>(&sl->op) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            for (unsigned k = 0; k < GRDMA_WATCH_WINDOWS; k++)
-              s_win[lane][k] = reinterpret_cast<uint8_t*>(
-                  __hip_atomic_load(reinterpret_cast<const uint64_t*>(&sl->win_base[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-            conn = s_ops[lane].conn;
-            rxw_load(&s_st[lane], conn);
-            ring = s_st[lane].ring;
-            mask = s_st[lane].cap - 1;
-            limited = s_st[lane].limited != 0;
-            wire_ptr = &conn->wire_recv.wire_tail;
-            head = s_st[lane].head;
-            remain = s_st[lane].remain;
-            done = __hip_atomic_load(&sl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          } else {
-            // let go: what this workgroup has written of the connection reaches memory before the acknowledgement
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          }
-          gen_seen = gen;
-          __hip_atomic_store(&sl->ack_gen, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          fresh = true;  // (the values of this pass belong to the slot's previous life: looked at in the next one)
-        }
-        bool ready = false;
-        if (armed && !fresh) {
-          bool arrived;
-          if (limited) {
-            arrived = wt != head;
-          } else {
-            arrived = false;  // GetReadableSize, ring_buffer.cc:67-97: a header, and the footer it points at
-            if (wt != 0 && wt <= mask + 1 - GRDMA_RESERVED) {
-              const uint64_t ftr = __hip_atomic_load(reinterpret_cast<const uint64_t*>(ring + ((head + 8 + round_up8(wt)) & mask)),
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-              arrived = ftr == GRDMA_FOOTER;
-            }
-          }
-          ready = (remain != 0 || arrived) && (consumed & GRDMA_WATCH_COUNT_MASK) >= done;
-        }
-        const uint64_t m = __ballot(ready);
-        if (m) {
-          // (round robin over the lanes: a connection that always has bytes does not starve its neighbours)
-          const uint64_t rot = rr ? ((m >> rr) | (m << (64 - rr))) : m;
-          const uint32_t pick = ((uint32_t)__builtin_ctzll(rot) + rr) & 63u;
-          rr = (pick + 1) & 63u;
-          const uint64_t t_found = prof_realtime(prof);
-          const uint64_t wt_p = __shfl(wt, (int)pick, 64), done_p = __shfl(done, (int)pick, 64);
-          // (the window this drain delivers into: the host names it with the count of completions it has taken)
-          uint8_t* const win_p = s_win[pick][(__shfl(consumed, (int)pick, 64) >> 56) % GRDMA_WATCH_WINDOWS];
-          // a unary-sized message: this wave alone, straight line (rxw_fast); anything else: the plan body, all four waves
-          if (fast_on && rxw_fast(&s_st[pick], &s_ops[pick], done_p, wt_p, win_p, (int)lane, s_ext, t_found, prof)) {
-            if (lane == pick) {
-              done += 1;
-              head = s_st[lane].head;
-              remain = 0;
-              __hip_atomic_store(&sl->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-              if (prof) {  // (profiling aid: 10 ns ticks)
-                const uint64_t t_done = __builtin_amdgcn_s_memrealtime();
-                const uint64_t t_pub = __hip_atomic_load(&g_watch_ticks[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                g_watch_ticks[1] += t_found - t_pub;
-                g_watch_ticks[2] += t_done - t_found;
-                g_watch_ticks[3] += 1;
-              }
-            }
-            continue;   // (uniform: every lane took the same way)
-          }
-          if (lane == pick) {
-            s_found = t_found;
-            s_limit = wt;
-            s_limited = limited ? 1u : 0u;
-            s_done = done;
-            s_arena = win_p;
-            s_fire = 1u + lane;
-          }
-          fire = 1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (!fire && lane == 0) s_fire = 0;
-    }
-    __syncthreads();
-    const uint32_t f = s_fire;
-    if (f == 0) break;
-    if (threadIdx.x < sizeof(grdma_rx_op) / 8)
-      reinterpret_cast<uint64_t*>(&s_op)[threadIdx.x] = reinterpret_cast<const uint64_t*>(&s_ops[f - 1])[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint64_t k = s_done;
-      s_op.seq_next += k;
-      s_op.arena = s_arena;
-      if (s_limited) s_op.limit_ptr = &s_limit;
-    }
-    __syncthreads();
-    const uint64_t t_body = prof_realtime(prof);
-    rx_plan_call(&s_op);
-    __syncthreads();
-    if (wave == 0 && lane == f - 1) {
-      if (prof) {  // (profiling aid: 10 ns ticks)
-        const uint64_t t_done = __builtin_amdgcn_s_memrealtime();
-        const uint64_t t_pub = __hip_atomic_load(&g_watch_ticks[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        g_watch_ticks[1] += s_found - t_pub;
-        g_watch_ticks[2] += t_done - s_found;
-        g_watch_ticks[3] += 1;
-        g_watch_ticks[4] += t_body - s_found;
-      }
-      done += 1;
-      __hip_atomic_store(&sl->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      rxw_load(&s_st[lane], conn);   // (the plan body changed the connection block: the state in LDS follows it)
-      head = s_st[lane].head;
-      remain = s_st[lane].remain;
-    }
-  }
-  if (threadIdx.x == 0 && wg < GRDMA_WATCH_MAX_GROUPS)
-    __hip_atomic_store(&mb->watch_alive[wg], 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// The resident kernels.  On the device ONE launch holds the command workgroup (block 0) and the watchers (blocks 1 ..):
-// two launches on two streams are two hardware queues, and a process that shares the GPU with another one is not
-// promised a second queue while the first never drains -- the watchers of the second process of
-// tests/test_gpu_two_process.py never started.  (The host emulation runs the blocks of a launch one after the other, so
-// there the two bodies stay launches -- threads -- of their own.)
-__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_engine(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_t flags) {
-  if (blockIdx.x == 0) engine_body(mb, wc, epoch, flags);
-  else watch_body(mb, wc, epoch, flags, blockIdx.x - 1, gridDim.x - 1);
-}
-__global__ __launch_bounds__(PLAN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_watch(grdma_engine_mbox* mb, grdma_watch_ctl* wc, uint64_t epoch, uint32_t flags) {
-  watch_body(mb, wc, epoch, flags, blockIdx.x, gridDim.x);
-}
+#include "grdma_job_kernels.inc"
+#include "grdma_engine_kernels.inc"
 
 }  // namespace
 
@@ -2573,7 +1662,6 @@ extern "C" int grdma_rx_fast_drains(uint64_t out[6]) {
   for (int i = 0; i < 6; i++) out[i] = v[i];
   return 0;
 }
-extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_job(void) { return reinterpret_cast<const void*>(&k_plan_pair_job); }
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_mw(void) { return reinterpret_cast<const void*>(&k_plan_pair_mw); }
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_rx_multi_groups(void) { return RXM_G; }
 extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan_mw(const grdma_rx_op* d_ops, uint32_t nops, hipStream_t s) {

@@ -79,11 +79,6 @@ class StreamJob:
         self.lib.grdma_stream_job_set_rebuild_index.argtypes = [C.c_void_p, C.c_int]
         check(self.lib.grdma_stream_job_set_rebuild_index(self.h, 1 if on else 0))
 
-    def set_burst(self, burst):
-        """`burst` Sends per round before the peer drains (grdma_stream_job_set_burst)."""
-        self.lib.grdma_stream_job_set_burst.argtypes = [C.c_void_p, C.c_uint32]
-        check(self.lib.grdma_stream_job_set_burst(self.h, burst))
-
     def set_pipeline(self, on):
         check(self.lib.grdma_stream_job_set_pipeline(self.h, 1 if on else 0))
 

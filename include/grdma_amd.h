@@ -470,13 +470,6 @@ int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds);
  * credit one round later than in the sequential schedule.  Same bytes delivered; affects GRDMA_RUN_GRAPH, _EAGER
  * and _INSTRUMENTED_SCHEDULE. */
 int grdma_stream_job_set_pipeline(grdma_stream_job* j, int on);
-/* Sends per round (default 1).  burst > 1: a sender that runs ahead of its reader -- `burst`
- * rdma_flush steps back to back (rdma_bp_posix.cc:470-557, retried on every writable edge), each a
- * Send from the cursor with its own staging buffer and <= 2 wire requests, then ONE drain of the
- * peer until a read would block.  With the reference's default knobs (4 MiB ring, max_sge 30: a
- * Send carries ~242 KB) this is what keeps the chip busy: the Sends of a round are planned by one
- * launch, gathered by one, put on the wire by one.  Rounds run strictly in order. */
-int grdma_stream_job_set_burst(grdma_stream_job* j, uint32_t burst);
 /* `sends` (1..64) consecutive Sends per round in ONE plan -- rdma_flush's loop while the ring has room
  * (rdma_bp_posix.cc:470-524): Send, advance the cursor, Send again -- before the peer drains; paired schedule of a
  * pipelined job only (other schedules keep one Send per round).  Up to two Sends are priced one after the other;

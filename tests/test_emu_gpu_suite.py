@@ -64,12 +64,6 @@ def test_zero_copy_gpu_tests_under_the_emulator(emu_lib):
     run_gpu_tests(emu_lib, ["tests/test_zz_gpu_zerocopy.py"], 10)
 
 
-def test_burst_round_gpu_tests_under_the_emulator(emu_lib):
-    """Streaming jobs with several Sends per round (k_tx_plan_seq: the single-wave burst planner), eager and as a HIP
-    graph, three links in one launch: the small configurations of tests/test_gpu_bench_configs.py."""
-    run_gpu_tests(emu_lib, ["tests/test_gpu_bench_configs.py", "-n", "4", "-k", "burst and (r64k or r256k or three_links)"], 7)
-
-
 def test_steady_state_planner_and_pair_pool_gpu_tests_under_the_emulator(emu_lib):
     """Round 3: the job kernels (k_rx_plan_job / k_tx_plan_job / k_plan_pair_job: steady-state bodies with the general
     planners behind them, csrc/grdma_rx_fast.h, grdma_tx_fast.h) on periodic streams cut by max_sge, sequential and

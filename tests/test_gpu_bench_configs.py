@@ -1,4 +1,4 @@
-"""GPU parity of the graph schedules at the EXACT configurations bench.py times, and of the burst rounds.
+"""GPU parity of the graph schedules at the EXACT configurations bench.py times.
 
 The job must reproduce the sequential execution of the reference's loops -- one Send from the rdma_flush cursor
 (rdma_bp_posix.cc:470-524), then endpoint reads until one would block (:180-291) -- slice for slice: same delivered
@@ -177,91 +177,6 @@ def test_bench_config_32_links_64kib(gpu):
     assert r.done
     for i, (l, e) in enumerate(zip(links, exps)):
         l.check(job, i, e, exact=True)
-    job.close()
-    for l in links:
-        l.close()
-
-
-BURST_CASES = [
-    # (ring, max_sge, n_msgs, msg_len, burst)
-    (1 << 22, 30, 8, 1 << 20, 16),     # the reference's default knobs, 16 Sends per round (what bench.py times)
-    (1 << 22, 30, 8, 1 << 20, 4),
-    (1 << 18, 30, 24, 3000, 8),        # small ring: later Sends of a round find no credit and accept nothing
-    (1 << 16, 30, 40, 20000, 3),       # 64 KiB ring: every round is cut by the peer's credit
-    (1 << 24, 512, 40, 70000, 2),
-]
-
-
-@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
-@pytest.mark.parametrize("case", BURST_CASES, ids=["r4m_sge30_b16", "r4m_sge30_b4", "r256k_b8", "r64k_b3", "r16m_b2"])
-def test_burst_rounds_equal_the_oracle(gpu, case, graph):
-    """grdma_stream_job_set_burst: `burst` Sends back to back (one k_tx_plan_seq launch, one gather
-    launch over burst plans, one wire launch), then ONE drain.  Delivered slices, number of Sends,
-    final protocol state and the zero ring equal oracle/grdma_oracle.c:orc_stream_rounds_burst
-    driving the same schedule, pass after pass."""
-    from grpc_rdma_amd import stream as gs
-    R, sge, n_msgs, msg_len, burst = case
-    wire, lens = framed(n_msgs, msg_len, seed=R ^ burst)
-    exp = pyorc.stream_rounds(R, sge, wire, lens, passes=PASSES, burst=burst)
-    assert exp["stream_ok"] and exp["ring_zero"]
-    link = Link(gpu, R, sge, wire, lens)
-    job = gs.MultiStreamJob([link.spec()], 4 * (exp["rounds"] + 8))
-    job.set_burst(burst)
-    first = None
-    for p in range(PASSES):
-        r = job.run(gs.RUN_EAGER)
-        assert r.done and r.bytes_delivered == link.N == r.bytes_sent
-        if first is None:
-            first = r
-        if graph and p == 0:
-            job.set_rounds(int(r.rx_rounds) + 1)
-            r = job.run(gs.RUN_GRAPH)
-            assert r.done and r.bytes_delivered == link.N
-            break
-    assert int(first.tx_rounds) == exp["rounds"], "number of Sends that accepted bytes"
-    if graph:
-        exp = pyorc.stream_rounds(R, sge, wire, lens, passes=2, burst=burst)
-    link.check(job, 0, exp, exact=True)
-    job.close()
-    link.close()
-
-
-@pytest.mark.parametrize("case", [(1 << 22, 30, 8, 1 << 20, 16), (1 << 16, 30, 40, 20000, 3), (1 << 18, 64, 30, 9000, 5)],
-                         ids=["r4m_sge30_b16", "r64k_b3", "r256k_sge64_b5"])
-def test_burst_rounds_direct_wire(gpu, case):
-    """Burst rounds with GRDMA_WIRE_DIRECT: the Sends of a round build their records in the peer
-    ring itself (no staging, no wire launch); a record that crosses the ring end is two segments."""
-    from grpc_rdma_amd import stream as gs
-    R, sge, n_msgs, msg_len, burst = case
-    wire, lens = framed(n_msgs, msg_len, seed=R + burst)
-    exp = pyorc.stream_rounds(R, sge, wire, lens, passes=PASSES, burst=burst)
-    link = Link(gpu, R, sge, wire, lens, flags=2)
-    job = gs.MultiStreamJob([link.spec()], 4 * (exp["rounds"] + 8))
-    job.set_burst(burst)
-    for _ in range(PASSES):
-        r = job.run(gs.RUN_EAGER)
-        assert r.done and r.bytes_delivered == link.N == r.bytes_sent
-    link.check(job, 0, exp, exact=True)
-    job.close()
-    link.close()
-
-
-def test_burst_rounds_three_links(gpu):
-    """Three connections of different shapes advance in lock step, 6 Sends per round each."""
-    from grpc_rdma_amd import stream as gs
-    shapes = [(1 << 20, 30, 12, 50000), (1 << 18, 30, 20, 7000), (1 << 22, 30, 3, 1 << 20)]
-    links, exps = [], []
-    for i, (R, sge, n_msgs, msg_len) in enumerate(shapes):
-        wire, lens = framed(n_msgs, msg_len, seed=70 + i)
-        exps.append(pyorc.stream_rounds(R, sge, wire, lens, passes=2, burst=6))
-        links.append(Link(gpu, R, sge, wire, lens, seed=i))
-    job = gs.MultiStreamJob([l.spec() for l in links], 4 * (max(e["rounds"] for e in exps) + 8))
-    job.set_burst(6)
-    for _ in range(2):
-        r = job.run(gs.RUN_EAGER)
-        assert r.done and r.bytes_delivered == sum(l.N for l in links)
-    for i, l in enumerate(links):
-        l.check(job, i, exps[i], exact=True)
     job.close()
     for l in links:
         l.close()

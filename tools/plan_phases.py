@@ -18,7 +18,6 @@ def main():
     g.init(0)
     ring_kb = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
     max_sge = int(sys.argv[2]) if len(sys.argv) > 2 else 4095
-    burst = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     w = bench.Workload(g, 256)
     ring = ring_kb * 1024
     tx, rx = g.Pair(ring, max_sge), g.Pair(ring, max_sge)
@@ -27,10 +26,8 @@ def main():
     dst_cap = w.N + 16 * scap + 4096
     dst = g.DeviceBuffer(nbytes=dst_cap)
     job = gs.MultiStreamJob([(tx, rx, w.sge, dst.ptr, dst_cap, scap)], max(8, 4 * (w.E // (ring // 2) + 2), 2 * (len(w.lens) // max_sge + 2)))
-    if burst > 1:
-        job.set_burst(burst)
     r = job.run(gs.RUN_EAGER)
-    job.set_rounds(int(max(r.tx_rounds, r.rx_rounds)) if burst == 1 else int(r.rx_rounds) + 1)
+    job.set_rounds(int(max(r.tx_rounds, r.rx_rounds)))
     job.run(gs.RUN_GRAPH)
     for _ in range(3):
         inst = job.run(gs.RUN_INSTRUMENTED)
