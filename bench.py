@@ -302,7 +302,6 @@ def measure_rtt(g, iters=100000, warmup=2000, reads="standing"):
     from grpc_rdma_amd import h2
     import ctypes as C
     lib = g.load()
-    os.environ.pop("GRDMA_ENGINE_CHAIN", None)
     msg = bytes([0x0A, 64]) + bytes(range(64))           # SimpleRequest{bytes message = 64 B}
     items = h2.frame_message(len(msg), 1)
     slices = [i[1] if i[0] == "inl" else msg[i[1][0]:i[1][0] + i[1][1]] for i in items]
@@ -314,16 +313,14 @@ def measure_rtt(g, iters=100000, warmup=2000, reads="standing"):
         a.arm_read(64)
         b.arm_read(64)
     g._lib.check(lib.grdma_engine_start())
-    lib.grdma_cut_through_drains.restype = C.c_uint64
     lib.grdma_watch_fast_drains.restype = C.c_uint64
-    ct0, fd0 = int(lib.grdma_cut_through_drains()), int(lib.grdma_watch_fast_drains())
+    fd0 = int(lib.grdma_watch_fast_drains())
     prof = {}
     try:
         t0 = time.perf_counter()
         rtt, ph = g.pingpong(a, b, slices, slices, iters=iters, warmup=warmup)
         wall = time.perf_counter() - t0
-        counts = {"watch_hits": a.watch_hits() + b.watch_hits(), "armed_hits": a.armed_hits() + b.armed_hits(),
-                  "cut_through_drains": int(lib.grdma_cut_through_drains()) - ct0,
+        counts = {"watch_hits": a.watch_hits() + b.watch_hits(),
                   "single_wave_drains": int(lib.grdma_watch_fast_drains()) - fd0,
                   "watcher_workgroups": int(lib.grdma_engine_watchers())}
         # a second, short pass with the GRPCProfiler mirror on (slot 0): the same round trips under the
@@ -367,49 +364,14 @@ def measure_rtt(g, iters=100000, warmup=2000, reads="standing"):
             "rtt_config": "unary ping-pong 64 B, 1 connection, 4 MiB ring in HBM, slices [14 B][66 B] each way; a write = "
                           "one command to the resident latency engine, a read = a standing order carried out by a watcher "
                           "workgroup when the bytes land in the pair's own ring (arrival-triggered, k_watch) -- every record "
-                          "goes through the ring, no send carries a drain; host slices in / pinned slices out",
+                          "goes through the ring; host slices in / pinned slices out",
             "rtt_counts": counts,
             "rtt_breakdown_us": {k: round(v / iters / 1e3, 2) for k, v in zip(
                 ["client_write", "server_read", "server_write", "client_read"], ph)},
             "rtt_profile_us": prof}
 
 
-def measure_rtt_armed(g, iters=20000, warmup=200):
-    """Round 4's armed read, kept as a comparison (GRDMA_ENGINE_CHAIN=1): the drain rides in the in-process peer's send
-    command (GRDMA_ENGINE_SEND_INLINE_DRAIN), unary-sized records cut through -- a path that only exists when both ends
-    sit in one engine command; NOT the latency figure (that is rtt_p50_us).  Runs in a process of its own."""
-    from grpc_rdma_amd import h2
-    lib = g.load()
-    os.environ["GRDMA_ENGINE_CHAIN"] = "1"
-    msg = bytes([0x0A, 64]) + bytes(range(64))
-    items = h2.frame_message(len(msg), 1)
-    slices = [i[1] if i[0] == "inl" else msg[i[1][0]:i[1][0] + i[1][1]] for i in items]
-    a, b = g.Pair(4 << 20, 30), g.Pair(4 << 20, 30)
-    g.connect_pairs(a, b)
-    a.set_latency_mode(True)
-    b.set_latency_mode(True)
-    a.arm_read(64)
-    b.arm_read(64)
-    g._lib.check(lib.grdma_engine_start())
-    try:
-        r2, ph2 = g.pingpong(a, b, slices, slices, iters=iters, warmup=warmup)
-        hits = a.armed_hits() + b.armed_hits()
-        a.arm_read(0)
-        b.arm_read(0)
-    finally:
-        lib.grdma_engine_stop()
-    a.close()
-    b.close()
-    r2.sort()
-    return {"rtt_chained_read_p50_us": round(r2[iters // 2] / 1e3, 2),
-            "rtt_chained_read_p95_us": round(r2[int(iters * .95)] / 1e3, 2),
-            "rtt_chained_read_iters": iters, "rtt_chained_read_hits": hits,
-            "rtt_chained_read_note": "round 4's in-process cut-through (GRDMA_ENGINE_CHAIN=1): comparison only",
-            "rtt_chained_read_breakdown_us": {k: round(v / iters / 1e3, 2) for k, v in zip(
-                ["client_write+server_drain", "server_read", "server_write+client_drain", "client_read"], ph2)}}
-
-
-def rtt_subprocess(flag, iters, timeout_s=150, key="rtt_armed_read_error"):
+def rtt_subprocess(flag, iters, timeout_s=150, key="rtt_error"):
     """The ping-pong legs run a RESIDENT kernel (k_engine).  One that wedged would hang every later synchronize of
     this process and take the whole line with it, so each leg runs in a child that can be killed."""
     import subprocess
@@ -507,7 +469,6 @@ def main():
     ap.add_argument("--rtt-iters", type=int, default=200000,
                     help="64 B round trips (>= 10 s of them on this part; the reference runs >= 10 s or 1 M RPCs behind "
                          "10 000 warm-up calls, examples/cpp/micro-bench/mb_client.cc:41-44)")
-    ap.add_argument("--armed-rtt-only", action="store_true", help="(internal) run only the chained-read ping-pong (round 4's way)")
     ap.add_argument("--rtt-commands-only", action="store_true", help="(internal) run only the ping-pong whose reads are commands")
     ap.add_argument("--rtt-only", action="store_true", help="(internal) run only the 64 B ping-pong leg")
     ap.add_argument("--h2-only", action="store_true", help="(internal) run only the with-h2 legs")
@@ -522,7 +483,7 @@ def main():
         # (the BASELINE configs[3] leg stays: --conns connections per rank -- 32 x 8 GPUs = 256 -- of 64 KiB messages,
         # every rank its own share, no data-path collective; every rank runs it, its barriers are the contract's)
 
-    if args.armed_rtt_only or args.rtt_only or args.rtt_commands_only:  # a child of rtt_subprocess: no torch, one leg, one JSON line
+    if args.rtt_only or args.rtt_commands_only:  # a child of rtt_subprocess: no torch, one leg, one JSON line
         import __graft_entry__ as ge
         import grpc_rdma_amd as g
         g.init(int(os.environ.get("LOCAL_RANK", "0")))
@@ -530,10 +491,8 @@ def main():
             g.load().grdma_host_pin_to_device_node()
         if args.rtt_only:
             print(json.dumps(measure_rtt(g, iters=args.rtt_iters, warmup=min(10000, max(10, args.rtt_iters // 10)))))
-        elif args.rtt_commands_only:
-            print(json.dumps(measure_rtt(g, iters=args.rtt_iters, warmup=min(1000, max(10, args.rtt_iters // 10)), reads="command")))
         else:
-            print(json.dumps(measure_rtt_armed(g, iters=args.rtt_iters, warmup=min(200, max(10, args.rtt_iters // 10)))))
+            print(json.dumps(measure_rtt(g, iters=args.rtt_iters, warmup=min(1000, max(10, args.rtt_iters // 10)), reads="command")))
         return
 
     import torch
@@ -1000,7 +959,6 @@ def main():
             out.update(rtt_subprocess("--rtt-only", args.rtt_iters, 240, key="rtt_error"))
             if world == 1:
                 out.update(rtt_subprocess("--rtt-commands-only", max(1000, args.rtt_iters // 10), key="rtt_read_commands_error"))
-                out.update(rtt_subprocess("--armed-rtt-only", max(1000, args.rtt_iters // 10), key="rtt_chained_read_error"))
     if not args.no_extra_legs and rank == 0:
         try:
             out["conn_setup_us"] = conn_setup_us(g)
@@ -1188,11 +1146,10 @@ def main():
         vt = {}
         # (engine_standing_read: a read stays outstanding on each endpoint, as chttp2 keeps it, and a watcher workgroup of
         #  the engine completes it when the bytes land -- THE vtable latency figure; engine: every read a command, round
-        #  4's configuration; engine_chained_read: round 4's in-process cut-through, comparison only)
-        for mode, name, n, extra in ((0, "launch_chain", 2000, {}), (1, "engine", 20000, {}), (2, "engine_standing_read", 50000, {}),
-                                     (2, "engine_chained_read", 20000, {"GRDMA_ENGINE_CHAIN": "1"})):
-            r = run_json([pp, str(n), "64", str(mode)], 90, dict(env, **extra))
-            vt[name] = {k: r.get(k) for k in ("p50_us", "p95_us", "p99_us", "iters", "armed_hits", "watch_hits")} if "p50_us" in r else r
+        #  4's configuration)
+        for mode, name, n in ((0, "launch_chain", 2000), (1, "engine", 20000), (2, "engine_standing_read", 50000)):
+            r = run_json([pp, str(n), "64", str(mode)], 90, env)
+            vt[name] = {k: r.get(k) for k in ("p50_us", "p95_us", "p99_us", "iters", "watch_hits")} if "p50_us" in r else r
         out["rtt_endpoint_vtable_us"] = vt
     if small is not None:
         sm_steps = max(2, args.steps // 2)

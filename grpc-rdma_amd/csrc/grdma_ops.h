@@ -17,21 +17,6 @@ struct grdma_size_hint {
   uint32_t n[GRDMA_TX_MAX_RECORDS];
 };
 
-// The same hand-over inside ONE command of the latency engine (GRDMA_ENGINE_SEND_INLINE_DRAIN: a small send followed
-// by the armed drain of the local peer): the send wave leaves its record sizes in LDS, the drain takes them instead of
-// probing the ring.  cut_through: the engine found, before the first store, that the receiver's state admits the
-// express drain of exactly these records (ring empty, nothing half-read, the read fits) -- then the records never
-// touch the ring: the drain copies the payload from `src` (the command's inline data, the slices back to back) and
-// both connections advance as if the bytes had been written, read and cleared.  Prefix-compatible with
-// grdma_size_hint (the ops carry it in sizes_out / sizes_in).
-struct grdma_ct_hint {
-  uint64_t start_off;
-  uint32_t count;
-  uint32_t cut_through;
-  uint32_t n[8];
-  const uint8_t* src;
-};
-
 // One PairPollable::Send / rdma_flush step for one connection.
 struct grdma_tx_op {
   struct grdma_conn* conn;
@@ -109,9 +94,8 @@ struct grdma_rx_op {
 
 // Mailbox of the persistent latency engine (pinned host memory).
 enum { GRDMA_ENGINE_SEND = 1, GRDMA_ENGINE_DRAIN = 2, GRDMA_ENGINE_SEND_INLINE = 3, GRDMA_ENGINE_DRAIN_BLOCK = 4,
-       // a small send followed, without a host hop, by the drain the LOCAL peer has armed (grdma_pair_arm_read):
-       // the block carries both ops
-       GRDMA_ENGINE_SEND_INLINE_DRAIN = 5,
+       // (5 was round 4's send + chained drain of the in-process peer, with its cut-through of unary-sized records:
+       //  a path only two ends inside one engine command could take -- retired for the watcher workgroups below)
        // arm / let go of a watch slot (grdma_watch_cmd): the standing read order of a connection, carried out by a
        // resident watcher workgroup (k_watch) the moment the sender's arrival report -- or, on an ordered wire, a
        // complete record -- shows up in the connection's own ring
@@ -135,8 +119,7 @@ struct grdma_engine_cmd {
 // command's words.  Wave 0 of the engine reads all eight lines with ONE load per poll (lane l =
 // word l), so a 64-byte RPC costs one PCIe round trip from doorbell to payload-in-LDS instead of
 // three dependent ones (doorbell -> type/op -> command block).
-// Payload: [type | nsges << 8 | data bytes << 16] [the op struct] [nsges x {offset, len}] [data]
-// [the armed peer's grdma_rx_op, GRDMA_ENGINE_SEND_INLINE_DRAIN only].
+// Payload: [type | nsges << 8 | data bytes << 16] [the op struct] [nsges x {offset, len}] [data].
 #define GRDMA_FAST_LINES 8
 #define GRDMA_FAST_WORDS (GRDMA_FAST_LINES * 7)  // payload words
 // ---- arrival-triggered reads (k_watch) -------------------------------------------------------------------------

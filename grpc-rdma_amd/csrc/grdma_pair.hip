@@ -258,15 +258,13 @@ struct grdma_pair {
   uint32_t zc_tail = 0;              // zerocopy_buffer_tail_ (std::atomic_uint32_t)
   uint64_t zc_bytes = 0, zc_copy_bytes = 0, zc_last_sges = 0;
   std::mutex zc_mu;
-  // armed read (grdma_pair_arm_read): the LOCAL peer's small sends carry this pair's drain in the same
-  // engine command; the next grdma_endpoint_read picks the completion up instead of asking for one
-  uint64_t armed_reads = 0;          // max_reads of the armed drain, 0 = not armed
-  std::atomic<bool> armed_done{false};  // a chained drain has completed and nobody has consumed it yet (set by the
-                                     // sender's thread, consumed by the receiver's)
-  uint64_t armed_hits = 0;
-  // ... or, by default, a watcher workgroup of the engine carries the standing order out when bytes land in this
-  // pair's ring, whoever wrote them (k_watch): the slot it was handed, the sequence word of the next completion,
-  // completions taken since the arming (what grdma_engine_mbox::consumed tells the device), completions taken in all
+  // standing read order (grdma_pair_arm_read): a watcher workgroup of the engine carries it out when bytes land in this
+  // pair's ring, whoever wrote them (k_watch).  armed_reads: max_reads of the order, 0 = none; armed_done: a completion
+  // the watcher produced waits in the result block although the order has been taken back (engine stopped, disarmed);
+  // then: the slot the order was handed, the sequence word of the next completion, completions taken since the arming
+  // (what grdma_engine_mbox::consumed tells the device), completions taken in all
+  uint64_t armed_reads = 0;
+  std::atomic<bool> armed_done{false};
   grdma_verbs_wire* verbs = nullptr; // != NULL: a NIC writes the peer's ring and mine (csrc/grdma_wire_verbs.cc)
   int watch_slot = -1;
   uint64_t watch_expect = 0, watch_taken = 0, watch_hits = 0;
@@ -288,7 +286,6 @@ struct grdma_pair {
   uint64_t tx_expect = 0;               // line->tx_seq (launch chain) or txres.seq (engine command) of the Send in flight
   bool tx_by_engine = false;
   std::mutex rx_mu;                     // receive-side submission state: the armed read lets the PEER's sender post my drain
-  std::atomic<uint64_t> armed_async{0}; // standing order of an asynchronous endpoint: max_reads, 0 = none
   uint64_t test_calls = 0, test_calls_rx = 0;
   // several Sends per submit (a write of more slices than max_sge, wire direct): rdma_flush retried back to back on
   // the device from the cursor, every Send with a gather plan of its own, ONE planning launch and ONE gather launch

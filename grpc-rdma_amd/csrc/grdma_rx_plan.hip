@@ -54,7 +54,6 @@ namespace {
 #define MINRD GRDMA_MIN_READ_SLICE
 
 __device__ unsigned long long g_express_drains = 0;  // diagnostics: drains served by the express path
-__device__ unsigned long long g_cut_through_drains = 0;
 // profiling aid (grdma_rx_express_ticks): ticks of an express drain's phases, summed -- {state loaded, records known,
 // payload loaded, stores issued, stores acknowledged, commit: counters loaded, commit: stores issued, released, count}
 __device__ unsigned long long g_rx_express_ticks[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... of which the records never touched the ring (grdma_ct_hint)
@@ -66,7 +65,7 @@ __device__ unsigned long long g_rx_express_ticks[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0
 // the message at the head, ring_buffer.cc; `rem1`, the caller's) -- and that read takes the rest (rdma_bp_posix.cc:306-326;
 // two slices; a rest beyond it would need a third read: not this path's case); 0: not the express path's case.
 // The arena must hold every read, the one that then finds nothing included.  Shared by the express drain and by the
-// latency engine's cut-through decision (engine_cut_through_ok), which must agree.
+// watcher's single-wave drain (rxw_fast), which must agree.
 __device__ __forceinline__ int express_fits(uint64_t leftover0, uint64_t n0, uint64_t T, uint64_t max_slices, uint64_t a_off0,
                                             uint64_t arena_cap, uint64_t rem1, bool credit_due) {
   if (T > 512 || max_slices < 1) return 0;
@@ -371,22 +370,9 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
       max_slices >= 1) {
     const uint64_t head0 = c->head, leftover0 = c->leftover_cap, irs0 = c->internal_read_size;
     const uint64_t te_a = prof_time(prof) + (head0 & 0);  // (state loaded)
-    // (inline_apply bit 2, an engine command's armed drain: the records are the ones the send of the same command
-    //  produced -- their sizes in LDS, grdma_ct_hint -- and, cut through, they are not in the ring at all)
-    const grdma_ct_hint* cth = (op.inline_apply & 2u) ? reinterpret_cast<const grdma_ct_hint*>(op.sizes_in) : nullptr;
-    const bool hinted = cth != nullptr && cth->count >= 1 && cth->count <= EXPRESS_MAX && cth->start_off == head0;
-    const bool cut_through = hinted && cth->cut_through != 0;
-    uint32_t v;
-    bool all_seen;
-    if (hinted) {
-      v = cth->count;
-      if ((uint32_t)lane < v) s_chain[lane] = cth->n[lane];
-      all_seen = true;
-    } else {
-      chain_walker w = {ring, cap, head0, 0, pre_h2, pre_h1, false, room_at(head0)};
-      v = chain_round(&w, s_chain, lane);
-      all_seen = w.dry && v <= EXPRESS_MAX;
-    }
+    chain_walker w = {ring, cap, head0, 0, pre_h2, pre_h1, false, room_at(head0)};
+    const uint32_t v = chain_round(&w, s_chain, lane);
+    const bool all_seen = w.dry && v <= EXPRESS_MAX;
     const uint64_t te_b = prof_time(prof) + (v & 0);  // (records known)
     const uint32_t n = ((uint32_t)lane < v && all_seen) ? (uint32_t)s_chain[lane] : 0;
     const uint32_t enc = ((uint32_t)lane < v && all_seen) ? 16u + (uint32_t)round_up8(n) : 0;
@@ -428,14 +414,7 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
       // all byte loads first (global address space: no LDS counter involved), then the stores
       auto* gring = (const __attribute__((address_space(1))) uint8_t*)(uint64_t)ring;
       uint8_t bytes[8];
-      if (cut_through) {  // (the slices lie back to back in the command's inline data: output byte b is its byte b)
-        const uint8_t* src = cth->src;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint32_t b = (uint32_t)lane * 8 + q;
-          bytes[q] = b < T ? src[b] : (uint8_t)0;
-        }
-      } else if (op.inline_apply & 8u) {
+      if (op.inline_apply & 8u) {
         // (a watcher's drain, csrc k_watch: the bytes were written by another workgroup, process or device since this
         //  CU last looked at these lines, with no kernel boundary in between -- loads that go past the caches)
 #pragma unroll
@@ -467,8 +446,6 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
         *reinterpret_cast<uint64_t*>(dst + (uint32_t)lane * 8) = word;
       }
       // clear what was consumed: records are 8-byte granular, [head0, head0 + E) with wrap
-      // (cut through: nothing was written there)
-      if (!cut_through)
       for (uint32_t o = (uint32_t)lane * 8; o < E; o += 64 * 8)
         *reinterpret_cast<uint64_t*>(ring + ((head0 + o) & mask)) = 0;
       // history ring and the credit rule of Recv (pair.cc:276-284), record by record
@@ -526,7 +503,6 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
         else if (v == 1) { c->rx_h2 = pre_h1; c->rx_h1 = 16u + (uint32_t)round_up8(e_last); }
         s_express = 1;
         atomicAdd(&g_express_drains, 1ull);
-        if (cut_through) atomicAdd(&g_cut_through_drains, 1ull);
       }
       const uint64_t te_d = prof_time(prof);  // (stores issued)
       GRDMA_WAIT_VMEM();
@@ -1630,11 +1606,6 @@ extern "C" int grdma_rx_express_ticks(uint64_t out[9]) {
   if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_rx_express_ticks), sizeof(v)) != hipSuccess) return -1;
   for (int i = 0; i < 9; i++) out[i] = v[i];
   return 0;
-}
-extern "C" uint64_t grdma_cut_through_drains(void) {
-  unsigned long long v = 0;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_cut_through_drains), sizeof(v)) != hipSuccess) return 0;
-  return (uint64_t)v;
 }
 extern "C" uint64_t grdma_watch_fast_drains(void) {   /* drains the watchers' single-wave path took (rxw_fast) */
   unsigned long long v = 0;

@@ -10,14 +10,9 @@ namespace {
 // The sender's side of grdma_wire_report / grdma_hostline: called by ONE thread once every byte of a Send
 // has landed in the peer ring (all waves of the caller have waited for their stores and met at a barrier,
 // or the wire kernel in front of k_tx_commit has completed).  tail = remote_tail_ after the Send.
-// (chained: the caller is the send of an engine command whose drain follows in the same workgroup and ends with a
-//  system-scope release by this very thread -- the arrival report needs none of its own)
-__device__ __forceinline__ void tx_publish(grdma_conn* c, uint64_t tail, uint64_t partial, uint64_t seq, bool chained = false) {
+__device__ __forceinline__ void tx_publish(grdma_conn* c, uint64_t tail, uint64_t partial, uint64_t seq) {
   uint64_t* pw = c->peer_wire;
-  if (pw != nullptr) {
-    if (chained) __hip_atomic_store(pw, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    else __hip_atomic_store(pw, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  if (pw != nullptr) __hip_atomic_store(pw, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   grdma_hostline* pl = c->peer_line;
   if (pl != nullptr) __hip_atomic_store(&pl->wire_tail, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   grdma_hostline* ln = c->line;
@@ -112,20 +107,8 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
   const uint64_t tk2 = prof_time(prof) + (sent & 0);  // (after pricing)
   const uint64_t seg1 = staged < cap - tail0 ? staged : cap - tail0;
   uint8_t* const peer_ring = c->peer_ring;
-  // (inline_copy bits of an engine command: 2 = cut-through, 4 = a drain follows in this command -- grdma_ct_hint)
-  const bool cut_through = (op.inline_copy & 2u) != 0, chained = (op.inline_copy & 4u) != 0;
   bool sys_stores = false;   // every byte of this Send went into the peer ring past the caches
-  if (chained && op.sizes_out != nullptr && nrec_total <= 8) {
-    grdma_ct_hint* h = reinterpret_cast<grdma_ct_hint*>(op.sizes_out);
-    if ((uint64_t)lane < nrec_total) h->n[lane] = (uint32_t)my_pay;
-    if (lane == 0) {
-      h->start_off = tail0;
-      h->count = (uint32_t)nrec_total;
-    }
-  }
-  if (cut_through) {
-    // the records are handed to the drain of this command in registers' reach: nothing is stored into staging or ring
-  } else if (nrec_total >= 1 && nrec_total <= 4 && __ballot(my_pay > 256) == 0 && peer_ring != nullptr && lds != nullptr) {
+  if (nrec_total >= 1 && nrec_total <= 4 && __ballot(my_pay > 256) == 0 && peer_ring != nullptr && lds != nullptr) {
     // ---- unary-sized Sends: at most four records of at most 256 bytes ------------------------
     // The encoded bytes of the Send -- [length][payload, zero padded][footer] per record, back to back: what the <= 2
     // RDMA WRITEs of GetWriteRequests carry (ring_buffer.cc:261-330) -- are put together in LDS and leave as 8-byte
@@ -226,7 +209,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     if (prof) __hip_atomic_store(&g_watch_ticks[0], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (pre_pw != nullptr) {
       // (bytes stored past the caches and acknowledged are in memory: no write-back of this L2 in front of the report)
-      if (chained || sys_stores) __hip_atomic_store(pre_pw, nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (sys_stores) __hip_atomic_store(pre_pw, nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       else __hip_atomic_store(pre_pw, nt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (pre_pl != nullptr) __hip_atomic_store(&pre_pl->wire_tail, nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -295,9 +278,7 @@ __device__ __forceinline__ void tx_small_wave(const grdma_tx_op& op, uint64_t st
     }
     // the peer reads the ring in a later command / kernel; the host needs the result
     // block (pinned memory): a system-scope release on the sequence word covers it
-    // (chained: the engine publishes the sequence word behind the drain of the same command -- k_engine)
-    if (!chained) __hip_atomic_store(&r->seq, op.seq_next ? op.seq_next : r->seq + 1, __ATOMIC_RELEASE,
-                                     __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&r->seq, op.seq_next ? op.seq_next : r->seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (prof) {
       const uint64_t tk6 = __builtin_amdgcn_s_memtime();
       g_tx_small_ticks[0] += tk1 - tk0;

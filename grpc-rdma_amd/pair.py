@@ -200,7 +200,7 @@ class Pair:
 
     def arm_read(self, max_reads=64):
         """grdma_pair_arm_read: a standing read order, carried out by a watcher workgroup of the latency engine when
-        bytes land in this pair's ring (GRDMA_ENGINE_CHAIN=1: by the local peer's small sends); 0 disarms."""
+        bytes land in this pair's ring; 0 disarms."""
         self.lib.grdma_pair_arm_read.argtypes = [C.c_void_p, C.c_uint64]
         check(self.lib.grdma_pair_arm_read(self.h, int(max_reads)))
 
@@ -213,11 +213,6 @@ class Pair:
     def armed_ready(self):
         self.lib.grdma_pair_armed_ready.argtypes = [C.c_void_p]
         return int(self.lib.grdma_pair_armed_ready(self.h))
-
-    def armed_hits(self):
-        self.lib.grdma_pair_armed_hits.argtypes = [C.c_void_p]
-        self.lib.grdma_pair_armed_hits.restype = C.c_int64
-        return int(self.lib.grdma_pair_armed_hits(self.h))
 
     # -- observability -------------------------------------------------------------
     def state(self):

@@ -380,7 +380,6 @@ int grdma_pair_set_latency_mode(grdma_pair* p, int on);
  * completion without a command of its own.  Same bytes, order and state as the two separate calls.
  * max_reads = 0 disarms.  One thread per link. */
 int grdma_pair_arm_read(grdma_pair* p, uint64_t max_reads);
-int64_t grdma_pair_armed_hits(const grdma_pair* p);   /* sends that carried the peer's drain (GRDMA_ENGINE_CHAIN=1) */
 int64_t grdma_pair_watch_hits(const grdma_pair* p);   /* completions a watcher workgroup produced and a read took */
 int grdma_engine_watchers(void);                      /* watcher workgroups per engine incarnation (GRDMA_ENGINE_WATCHERS) */
 int grdma_pair_armed_ready(const grdma_pair* p);      /* 1: a completion is waiting (host memory only: no device work) */
@@ -495,7 +494,6 @@ uint64_t grdma_express_drains(void);  /* drains served by the single-wave expres
 uint64_t grdma_watch_fast_drains(void);      /* diagnostics: drains the watchers' single-wave path took */
 int grdma_watch_ticks(uint64_t out[12]);      /* profiling aid: 10 ns ticks of the watchers' drains (arrival found, drain done) */
 int grdma_rx_express_ticks(uint64_t out[9]);  /* profiling aid: phase ticks of the express drain (latency engine) */
-uint64_t grdma_cut_through_drains(void);  /* ... of which the records of an armed send + drain command never touched the ring */
 int grdma_tx_fast_sends(uint64_t out[2]);  /* Sends of streaming jobs planned by k_tx_fast [0], left to the general planner [1] (csrc/grdma_tx_fast.h) */
 int grdma_rx_fast_drains(uint64_t out[6]);  /* drains of streaming jobs taken by k_rx_fast [0], declined by reason [1..5] (csrc/grdma_rx_fast.h) */
 int grdma_tx_promise_counts(uint64_t out[4]);  /* promised-credit Sends: priced with it [0], none in the drain [1], an older block [2]; waits that ran out [3] */

@@ -348,8 +348,8 @@ static void check_zerocopy() {
 }
 
 // ---- armed read through the latency engine against the oracle ---------------------------------------
-// unary ping-pong, [14 B][66 B] each way; armed = the drain rides in the peer's send command
-// (GRDMA_ENGINE_SEND_INLINE_DRAIN).  State and rings must equal the oracle's after the same traffic, and
+// unary ping-pong, [14 B][66 B] each way; armed = a standing read order carried out by a watcher workgroup (k_watch)
+// State and rings must equal the oracle's after the same traffic, and
 // equal the un-armed run's; prints both p50s.
 static bool pingpong_run(bool armed, uint64_t iters, uint64_t* p50_ns, grdma_pair_state st[2], bytes rings[2],
                          int64_t* hits) {
@@ -369,7 +369,7 @@ static bool pingpong_run(bool armed, uint64_t iters, uint64_t* p50_ns, grdma_pai
   bool ok = grdma_engine_start() == 0 &&
             grdma_pingpong(a, b, sl, 2, sl, 2, GRDMA_MEM_HOST, iters, 20, rtt.data(), ph) == 0;
   if (ok && armed) {
-    *hits = grdma_pair_armed_hits(a) + grdma_pair_armed_hits(b);
+    *hits = grdma_pair_watch_hits(a) + grdma_pair_watch_hits(b);
     ok = grdma_pair_arm_read(a, 0) == 0 && grdma_pair_arm_read(b, 0) == 0;
   }
   grdma_engine_stop();
@@ -427,7 +427,7 @@ static void check_armed_read() {
         SAY("armed read FAIL: state, armed %d side %d\n", armed, k);
       }
     }
-  if (ok && hits != (int64_t)(2 * (iters + 20))) { ok = false; SAY("armed read FAIL: %lld chained sends\n", (long long)hits); }
+  if (ok && hits != (int64_t)(2 * (iters + 20))) { ok = false; SAY("armed read FAIL: %lld watcher completions\n", (long long)hits); }
   orc_pair_destroy(&o[0]);
   orc_pair_destroy(&o[1]);
   if (!ok) g_fail++;

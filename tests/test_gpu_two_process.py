@@ -80,11 +80,9 @@ def test_unary_pingpong_between_two_processes_on_the_arrival_triggered_path(gpu)
     engine; every read is a standing order carried out by a watcher workgroup of the READING process's engine when
     the bytes the other process wrote land in its ring (k_watch) -- the path a NIC-fed ring takes too: the reader
     learns of a message from its own ring, as ring_buffer.cc:56-97 / ev_epollex_rdma_bpev_linux.cc:1105-1149 do.
-    5000 round trips of [14 B][66 B]; byte sums, hit counts (no send carried a drain) and zero rings checked in
-    both processes (tests/two_proc_peer.py: unary_pingpong)."""
+    5000 round trips of [14 B][66 B]; byte sums, hit counts and zero rings checked in both processes (tests/two_proc_peer.py: unary_pingpong)."""
     a, b = socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM)
     env = dict(os.environ, GRDMA_TEST_PAIR_FLAGS="4")
-    env.pop("GRDMA_ENGINE_CHAIN", None)
     procs = []
     for role, sock in (("pp_server", a), ("pp_client", b)):
         os.set_inheritable(sock.fileno(), True)

@@ -98,7 +98,6 @@ def unary_pingpong(role, pair, iters, ring_kib):
     nothing both ends would have to share but the rings.  [14 B][66 B] each way, sizes and byte sums checked per end,
     the rings all zero afterwards; the client prints its round-trip percentiles."""
     lib = pair.lib
-    lib.grdma_cut_through_drains.restype = C.c_uint64
     pair.set_latency_mode(True)
     pair.arm_read(64)
     check(lib.grdma_engine_start())
@@ -111,7 +110,7 @@ def unary_pingpong(role, pair, iters, ring_kib):
     bsum = C.c_uint64(0)
     try:
         check(lib.grdma_pingpong_end(pair.h, 1 if is_client else 0, arr, 2, 80, 1, iters, warmup, rtt, C.byref(bsum)))
-        hits, armed, ct = pair.watch_hits(), pair.armed_hits(), int(lib.grdma_cut_through_drains())
+        hits = pair.watch_hits()
         if is_client:
             pair.Disconnect()
         else:
@@ -123,7 +122,7 @@ def unary_pingpong(role, pair, iters, ring_kib):
         lib.grdma_engine_stop()
     expect = sum(sum(x) for x in peer) * (iters + warmup)
     assert bsum.value == expect, "byte sum of what arrived: %d, expected %d" % (bsum.value, expect)
-    assert hits == iters + warmup and armed == 0 and ct == 0, (hits, armed, ct)
+    assert hits == iters + warmup, hits
     assert pair.ring_mem() == bytes(ring_kib * 1024), "ring not zero after the ping-pong"
     r = sorted(rtt)
     print("ok %s %d round trips, watch hits %d, rtt p50 %.2f us p95 %.2f us p99 %.2f us" % (

@@ -9,9 +9,8 @@
 // usage: endpoint_pingpong <iters> <payload_bytes> <mode>      prints one JSON line
 //   mode 0: launch chains (one Send / one drain enqueued per write / read, completion seen in pinned memory)
 //   mode 1: both pairs in latency mode: every write / read is one command posted to the resident engine
-//   mode 2: mode 1 + armed reads (grdma_pair_arm_read): a watcher workgroup of the engine drains when the bytes land
-//           (GRDMA_ENGINE_CHAIN=1: the drain rides in the peer's send command) and the poll sees the completion in
-//           host memory, no command between the arrival and the read callback
+//   mode 2: mode 1 + standing reads (grdma_pair_arm_read): a watcher workgroup of the engine drains when the bytes land
+//           and the poll sees the completion in host memory, no command between the arrival and the read callback
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -172,14 +171,12 @@ int main(int argc, char** argv) {
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - T0).count();
   CHECK(cl.sum == sum_per_msg * (warmup + iters) && sv.sum == sum_per_msg * (warmup + iters));
   std::sort(rtt.begin(), rtt.end());
-  const int64_t hits = mode >= 2 ? grdma_pair_armed_hits(grdma_endpoint_pair(cl.ep)) + grdma_pair_armed_hits(grdma_endpoint_pair(sv.ep)) : 0;
-  // (completions the engine's watcher workgroups produced -- arrival-triggered drains, k_watch: the default of mode 2;
-  //  armed_hits counts round 4's way, GRDMA_ENGINE_CHAIN=1: drains carried by the peer's send command)
+  // (completions the engine's watcher workgroups produced -- arrival-triggered drains, k_watch)
   const int64_t whits = mode >= 2 ? grdma_pair_watch_hits(grdma_endpoint_pair(cl.ep)) + grdma_pair_watch_hits(grdma_endpoint_pair(sv.ep)) : 0;
   printf("{\"iters\": %zu, \"payload\": %zu, \"mode\": %d, \"p50_us\": %.2f, \"p95_us\": %.2f, \"p99_us\": %.2f, "
-         "\"seconds\": %.3f, \"armed_hits\": %lld, \"watch_hits\": %lld, \"checked\": true}\n",
+         "\"seconds\": %.3f, \"watch_hits\": %lld, \"checked\": true}\n",
          iters, payload, mode, rtt[iters / 2] / 1e3, rtt[(size_t)(iters * 0.95)] / 1e3, rtt[(size_t)(iters * 0.99)] / 1e3,
-         sec, (long long)hits, (long long)whits);
+         sec, (long long)whits);
   if (mode >= 1) grdma_engine_stop();
   grpc_endpoint_shutdown(cl.ep, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
   grpc_endpoint_shutdown(sv.ep, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));

@@ -16,14 +16,12 @@ def main():
     lib = g.load()
     g.init(0)
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-    # "watch": standing reads carried out by the engine's watcher workgroups (the default of grdma_pair_arm_read);
-    # "armed" / "chain": round 4's way, the in-process peer's send command carries the drain (GRDMA_ENGINE_CHAIN=1)
+    # "watch": standing reads carried out by the engine's watcher workgroups (grdma_pair_arm_read); without it every
+    # read is a command of its own (round 4's configuration)
     mode = sys.argv[2] if len(sys.argv) > 2 else ""
-    if "prof" in sys.argv[3:]:   # the phase stamps cost about two microseconds per round trip: off unless asked for
+    if "prof" in sys.argv[3:]:   # the phase stamps of the latency paths: off unless asked for
         os.environ["GRDMA_PROFILE_TICKS"] = "1"
-    if mode in ("armed", "chain"):
-        os.environ["GRDMA_ENGINE_CHAIN"] = "1"
-    armed = mode in ("armed", "chain", "watch")
+    armed = mode == "watch"
     msg = bytes([0x0A, 64]) + bytes(range(64))
     items = h2.frame_message(len(msg), 1)
     slices = [i[1] if i[0] == "inl" else msg[i[1][0]:i[1][0] + i[1][1]] for i in items]
@@ -58,8 +56,7 @@ def main():
     print("rtt p50 %.2f us  p95 %.2f  (%d round trips%s)" % (rtt[len(rtt) // 2] / 1e3, rtt[int(len(rtt) * .95)] / 1e3, iters,
                                                             ", reads: " + mode if armed else ""))
     if armed:
-        print("watch hits %d / %d, armed hits %d / %d, watcher workgroups %d" % (a.watch_hits(), b.watch_hits(), a.armed_hits(), b.armed_hits(),
-                                                                             lib.grdma_engine_watchers()))
+        print("watch hits %d / %d, watcher workgroups %d" % (a.watch_hits(), b.watch_hits(), lib.grdma_engine_watchers()))
     print("host phases us: client write %.2f, server read %.2f, server write %.2f, client read %.2f" % tuple(p / 1e3 / iters for p in ph))
     de = [int(e1[i]) - int(e0[i]) for i in range(5)]
     print("engine ticks per round trip: odd-type commands load %d body %d; even-type commands load %d body %d" % tuple(x // iters for x in de[:4]))
