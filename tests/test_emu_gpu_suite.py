@@ -65,12 +65,12 @@ def test_zero_copy_gpu_tests_under_the_emulator(emu_lib):
 
 
 def test_steady_state_planner_and_pair_pool_gpu_tests_under_the_emulator(emu_lib):
-    """Round 3: the job kernels (k_rx_plan_job / k_tx_plan_job / k_plan_pair_job: steady-state bodies with the general
+    """Round 3: the job kernels (k_rx_plan_job / k_tx_plan_job: steady-state bodies with the general
     planners behind them, csrc/grdma_rx_fast.h, grdma_tx_fast.h) on periodic streams cut by max_sge, sequential and
     pipelined graphs against the oracle's rounds; the paired graph at a credit-limited ring against the oracle driven with
     the credit one round late; the PairPool on recycled memory."""
     run_gpu_tests(emu_lib, ["tests/test_gpu_stream_job.py", "tests/test_gpu_pair_pool.py", "-n", "4",
-                            "-k", "(fast_planner and sge130) or pool or (credit_limited and r256k)"], 9)
+                            "-k", "(fast_planner and sge130) or pool or (credit_limited and r256k)"], 8)
 
 
 def test_planner_pair_of_many_workgroups_and_bidirectional_job_under_the_emulator(emu_lib):

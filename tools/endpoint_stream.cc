@@ -208,15 +208,31 @@ int main(int argc, char** argv) {
 
   const int threads = argc > 5 ? atoi(argv[5]) : 2;
   // the pollset_work loop of one thread: polls `ep` (and `ep2`, if any) until *flag (and *flag2)
-  auto loop = [&](grpc_endpoint* ep, grpc_endpoint* ep2, volatile bool* flag, volatile bool* flag2) {
+  // ENDPOINT_STREAM_PROFILE=1: where each polling thread's time goes -- inside the closures it runs (the writer's:
+  // grpc_endpoint_write with its copy into the send buffer; the reader's: the byte sum and grpc_endpoint_read), inside
+  // polls that made progress, inside polls that found nothing (waiting for the device)
+  const bool profile = getenv("ENDPOINT_STREAM_PROFILE") && atoi(getenv("ENDPOINT_STREAM_PROFILE")) != 0;
+  struct prof_t { double closures = 0, poll_busy = 0, poll_idle = 0; uint64_t n_closures = 0, n_busy = 0, n_idle = 0; };
+  static prof_t prof[2];
+  auto loop = [&](grpc_endpoint* ep, grpc_endpoint* ep2, volatile bool* flag, volatile bool* flag2, int who = 0) {
     const auto tl = std::chrono::steady_clock::now();
     uint64_t spins = 0;
+    prof_t& pr = prof[who];
     while (!*flag || (flag2 && !*flag2)) {
+      std::chrono::steady_clock::time_point a, b;
+      if (profile) a = std::chrono::steady_clock::now();
       int ran = grdma_endpoint_poll(ep) + (ep2 ? grdma_endpoint_poll(ep2) : 0);
+      if (profile) {
+        b = std::chrono::steady_clock::now();
+        const double d = std::chrono::duration<double>(b - a).count();
+        if (ran) { pr.poll_busy += d; pr.n_busy++; } else { pr.poll_idle += d; pr.n_idle++; }
+      }
       while (!g_queue.empty()) {
         grpc_closure* c = g_queue.front();
         g_queue.pop_front();
+        if (profile) a = std::chrono::steady_clock::now();
         c->cb(c->cb_arg, GRPC_ERROR_NONE);
+        if (profile) { pr.closures += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); pr.n_closures++; }
         ran++;
       }
       if (!ran && (++spins & 0xFFFFF) == 0)
@@ -244,7 +260,7 @@ int main(int argc, char** argv) {
       reader_ready.store(1, std::memory_order_release);  // (the sysfs walk of the pin stays outside the timed region)
       while (!go.load(std::memory_order_acquire)) {}
       do_read(&st, GRPC_ERROR_NONE);
-      loop(st.rx, nullptr, &st.read_done, nullptr);
+      loop(st.rx, nullptr, &st.read_done, nullptr, 1);
     });
     while (!reader_ready.load(std::memory_order_acquire)) {}
     t0 = std::chrono::steady_clock::now();
@@ -277,6 +293,11 @@ int main(int argc, char** argv) {
          getenv("GRPC_RDMA_HIP_REGISTER_MIN") ? getenv("GRPC_RDMA_HIP_REGISTER_MIN") : "0",
          (unsigned long long)wq[0], (unsigned long long)wq[1], (unsigned long long)wq[2],
          numa_node >= 0 ? "true" : "false", pin_cores && threads >= 2 ? core_w : -1, pin_cores && threads >= 2 ? core_r : -1);
+  if (profile)
+    for (int w = 0; w < 2; w++)
+      fprintf(stderr, "profile %s: closures %.1f ms (%llu), polls that ran something %.1f ms (%llu), idle polls %.1f ms (%llu) of %.1f ms\n",
+              w == 0 ? "writer" : "reader", prof[w].closures * 1e3, (unsigned long long)prof[w].n_closures, prof[w].poll_busy * 1e3,
+              (unsigned long long)prof[w].n_busy, prof[w].poll_idle * 1e3, (unsigned long long)prof[w].n_idle, sec * 1e3);
   if (latency) grdma_engine_stop();
   grpc_endpoint_shutdown(st.tx, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
   grpc_endpoint_shutdown(st.rx, GRPC_ERROR_CREATE_FROM_STATIC_STRING("done"));
