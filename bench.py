@@ -1121,6 +1121,16 @@ def main():
         ev = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "1024", str(MIB), "1", "0", "2"], 120, env)
         out["value_endpoint_vtable"] = ev.get("GiBps")
         out["endpoint_vtable"] = ev
+        # what the link gives a copy engine in both directions at once (tools/pcie_probe.py): the ceiling of a stream that
+        # crosses it once each way
+        pc = run_json([sys.executable, os.path.join(ROOT, "tools", "pcie_probe.py"), "256"], 120, env)
+        out["pcie_ceiling"] = pc
+        if pc.get("both_each_GiBps") and ev.get("GiBps"):
+            out["value_endpoint_vtable_frac_of_pcie_ceiling"] = round(ev["GiBps"] / pc["both_each_GiBps"], 3)
+        # ... every write a chain of its own (round 4's behaviour: no coalescing in the send buffer that waits)
+        evc = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "1024", str(MIB), "1", "0", "2"], 120,
+                       dict(env, GRPC_RDMA_HIP_COALESCE="0"))
+        out["value_endpoint_vtable_no_coalescing"] = evc.get("GiBps")
         # the same at the reference's default ring (GRPC_RDMA_RING_BUFFER_SIZE_KB 4096, config.cc): ring and receive
         # windows stay cache- and IOMMU-resident
         ev4 = run_json([os.path.join(ROOT, "tools", "endpoint_stream"), "1024", str(MIB), "1", "0", "2"], 120,

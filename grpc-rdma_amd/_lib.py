@@ -111,6 +111,7 @@ SIGNATURES = {
     "grdma_endpoint_write_queue": (C.c_int, [C.c_void_p, C.c_void_p, u64]),
     "grdma_endpoint_write_adopt": (C.c_int, [C.c_void_p]),
     "grdma_endpoint_write_queue_stats": (C.c_int, [C.c_void_p, C.POINTER(u64)]),
+    "grdma_endpoint_write_queue_limits": (C.c_int, [C.c_void_p, C.POINTER(u64)]),
     "grdma_endpoint_write_quiesce": (C.c_int, [C.c_void_p]),
     "grdma_host_free_pinned": (None, [C.c_void_p]),
     "grdma_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, u64]),

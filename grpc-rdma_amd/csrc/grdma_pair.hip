@@ -167,6 +167,8 @@ void line_free(grdma_hostline* l) {
   g_lines.free_list.push_back(l);
 }
 
+#define GRDMA_HOST_RX_BLOCKS_DEFAULT 64u
+#define GRDMA_HOST_TX_BLOCKS_DEFAULT 16u
 uint32_t copy_blocks_for(uint64_t bytes) {
   uint64_t tiles = (bytes + GRDMA_TILE_BYTES - 1) / GRDMA_TILE_BYTES;
   uint64_t blocks = (tiles + 3) / 4;  // 4 waves per block, one tile per wave pass
@@ -178,6 +180,20 @@ uint32_t copy_blocks_for(uint64_t bytes) {
   }();
   if (blocks > cap_blocks) blocks = cap_blocks;
   return (uint32_t)blocks;
+}
+
+// Workgroups of a copy launch whose bytes cross PCIe (an asynchronous endpoint: the gather reads the endpoint's pinned send
+// buffers, the scatter writes the pinned receive window).  A link of ~57 GB/s is kept full by a few dozen waves; the
+// grid an HBM copy wants (768 resident workgroups, 48 MiB of stores in flight) queues tens of microseconds of posted
+// writes in front of the other direction's read requests: the gather of a Send ran at a quarter of its speed whenever a
+// scatter was in flight (profiles/r05_vtable_timeline_before_throttle.txt, tools/pcie_duplex_probe).  dir 0: towards the host (scatter), 1: from
+// the host (gather).  GRDMA_HOST_RX_BLOCKS / GRDMA_HOST_TX_BLOCKS: tuning knobs (0 = the HBM grid).
+uint32_t host_copy_blocks(int dir, uint32_t hbm_blocks) {
+  static const uint32_t cfg[2] = {
+      [] { const char* e = getenv("GRDMA_HOST_RX_BLOCKS"); return e ? (uint32_t)atol(e) : GRDMA_HOST_RX_BLOCKS_DEFAULT; }(),
+      [] { const char* e = getenv("GRDMA_HOST_TX_BLOCKS"); return e ? (uint32_t)atol(e) : GRDMA_HOST_TX_BLOCKS_DEFAULT; }()};
+  const uint32_t v = cfg[dir];
+  return v == 0 || v > hbm_blocks ? hbm_blocks : v;
 }
 
 }  // namespace

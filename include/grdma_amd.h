@@ -306,6 +306,7 @@ int grdma_endpoint_write_test(grdma_pair* p, int* done, int64_t* sent);
 int grdma_endpoint_write_queue(grdma_pair* p, const grdma_slice* slices, uint64_t count);
 int grdma_endpoint_write_adopt(grdma_pair* p);
 int grdma_endpoint_write_queue_stats(grdma_pair* p, uint64_t out[3]);  /* queued, promoted, skipped */
+int grdma_endpoint_write_queue_limits(grdma_pair* p, uint64_t out[2]); /* slices, bytes one queued write may hold */
 int grdma_endpoint_write_quiesce(grdma_pair* p);  /* nothing of this pair's is left in its send stream when it returns */
 int grdma_endpoint_read_submit(grdma_pair* p, uint64_t max_reads);
 int64_t grdma_endpoint_read_test(grdma_pair* p, grdma_read_slice* slices, uint64_t slices_cap, int* would_block,

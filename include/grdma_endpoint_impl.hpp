@@ -21,7 +21,12 @@
 //     caller's slices are free, the bytes are the endpoint's to deliver.  The device chain of write k then runs while
 //     the transport prepares and copies write k + 1; an error of a write that has already completed is reported by the
 //     next write (like a socket's).  Writes that do not fit, or that arrive while both buffers are taken, go the
-//     way described above, behind the buffered ones;
+//     way described above, behind the buffered ones.  While a Send is in flight the buffer that waits behind it
+//     COALESCES: further writes are appended to it (slice boundaries kept) until another write of that size would
+//     not fit -- the buffer, the sixteen Sends of a burst, a quarter of the ring -- and only then does its chain go
+//     into the send stream.  A chain's planner, commit and launch gaps cost the same for one message as for three,
+//     and so does the host's work to submit it (what a socket's send buffer does with the bytes written while the
+//     NIC is busy; GRPC_RDMA_HIP_COALESCE=0: every write a chain of its own);
 //   * a read that finds a message enqueues one drain -- up to kReadAhead endpoint reads in ONE device pass, each the
 //     slice rdma_continue_read would have sized (max(256, readable)) and rdma_do_read would have filled -- and
 //     returns; the completions are handed to the transport one read callback each, as slices that point into the
@@ -57,7 +62,8 @@
 
 namespace grdma_ep {
 
-constexpr uint64_t kReadAhead = 1024;    // endpoint reads performed per device pass (GRPC_RDMA_HIP_READ_AHEAD: fewer)
+constexpr uint64_t kReadAheadMax = 4096; // most endpoint reads one device pass may perform (GRPC_RDMA_HIP_READ_AHEAD)
+constexpr uint64_t kReadAhead = 1024;    // ... and the default
 constexpr size_t kWriteWindow = 4000;    // slices handed to one grdma_endpoint_write_begin (the ABI takes 4095)
 constexpr size_t kSendBufferMin = 8192;  // shorter writes go to the pair as they are (a unary-sized write rides inline
                                          // in the latency engine's command: nothing to gain from a copy in front of it)
@@ -89,9 +95,11 @@ struct core {
   struct send_buffer {
     uint8_t* mem = nullptr;
     std::vector<grdma_slice> views;
+    size_t used = 0;                   // bytes of mem that views cover
   };
   send_buffer sbuf[2];
   size_t sbuf_cap = 0;                 // bytes per buffer, 0 = off
+  size_t co_bytes = 0, co_slices = 0;  // what the waiting buffer may grow to by coalescing (0 = off): init()
   int bg_running = -1, bg_waiting = -1;
   bool bg_queued = false;              // the waiting buffer's chain is already in the pair's send stream
                                        // (grdma_endpoint_write_queue): adopted, not submitted, when its turn comes
@@ -111,20 +119,26 @@ struct core {
   bool open_read_noted = false;        // the pair knows that a read is open (a drain ended in a would-block, or
                                        // grdma_endpoint_read_idle told it): the next read fills that 256-byte slice first
   uint64_t arm_reads = 0;              // != 0: keep a read armed with the pair while waiting (latency mode)
-  uint64_t read_ahead = kReadAhead;    // endpoint reads per device pass: GRPC_RDMA_HIP_READ_AHEAD, 1 ... kReadAhead
+  uint64_t read_ahead = kReadAhead;    // endpoint reads per device pass: GRPC_RDMA_HIP_READ_AHEAD, 1 ... kReadAheadMax
                                        // (1 = every read sized and filled at the moment the transport asks for it, as
                                        // rdma_continue_read / rdma_do_read do: what the reference-trace test runs with)
 
   void init(host_t* host, grdma_pair* p) {
     h = host;
     pair = p;
-    ahead.reserve(kReadAhead);
+    ahead.reserve(kReadAheadMax);
     const char* e = getenv("GRPC_RDMA_HIP_SEND_BUFFER_KB");
     const long kb = e ? atol(e) : 4096;
     sbuf_cap = kb > 0 ? (size_t)kb * 1024 : 0;
+    const char* co = getenv("GRPC_RDMA_HIP_COALESCE");
+    uint64_t lim[2] = {0, 0};
+    if (sbuf_cap != 0 && !(co && atoi(co) == 0) && grdma_endpoint_write_queue_limits(p, lim) == 0) {
+      co_slices = (size_t)lim[0] < kWriteWindow ? (size_t)lim[0] : kWriteWindow;
+      co_bytes = (size_t)lim[1] < sbuf_cap ? (size_t)lim[1] : sbuf_cap;
+    }
     if (const char* ra = getenv("GRPC_RDMA_HIP_READ_AHEAD")) {
       const long v = atol(ra);
-      if (v >= 1 && (uint64_t)v <= kReadAhead) read_ahead = (uint64_t)v;
+      if (v >= 1 && (uint64_t)v <= kReadAheadMax) read_ahead = (uint64_t)v;
     }
   }
   // rdma_free: nothing of the transport's may be referenced afterwards
@@ -195,8 +209,8 @@ struct core {
       if (grdma_endpoint_drain_state(pair) != 0) {  // (submitted below, or by the peer's sender for an armed read)
         int would_block = 0;
         grdma_window* win = nullptr;
-        ahead.resize(kReadAhead);
-        const int64_t n = grdma_endpoint_read_test(pair, ahead.data(), kReadAhead, &would_block, &win);
+        ahead.resize(kReadAheadMax);
+        const int64_t n = grdma_endpoint_read_test(pair, ahead.data(), kReadAheadMax, &would_block, &win);
         if (n == -(int64_t)GRDMA_ERR_AGAIN) {  // still on the device: the readable edge comes when it is done
           ahead.clear();
           T::notify_on_read(h);
@@ -357,21 +371,36 @@ struct core {
     }
     return flush(error);
   }
-  // copies buf's slices into send buffer s (boundaries kept: one ring record each); false = no pinned memory
-  bool fill_send_buffer(int s, sb_t* buf) {
+  // copies buf's slices into send buffer s (boundaries kept: one ring record each), behind what it holds when
+  // `append`; false = no pinned memory
+  bool fill_send_buffer(int s, sb_t* buf, bool append = false) {
     send_buffer& b = sbuf[s];
     if (b.mem == nullptr) b.mem = static_cast<uint8_t*>(grdma_host_alloc_pinned(sbuf_cap));
     if (b.mem == nullptr) return false;
     const size_t n = T::count(buf);
-    b.views.resize(n);
-    size_t off = 0;
+    const size_t v0 = append ? b.views.size() : 0;
+    b.views.resize(v0 + n);
+    size_t off = append ? b.used : 0;
     for (size_t i = 0; i < n; i++) {
       const size_t l = T::slice_len(buf, i);
       if (l) memcpy(b.mem + off, T::slice_ptr(buf, i), l);
-      b.views[i] = grdma_slice{b.mem + off, (uint64_t)l};
+      b.views[v0 + i] = grdma_slice{b.mem + off, (uint64_t)l};
       off += l;
     }
+    b.used = off;
     return true;
+  }
+  // would the buffer that waits take `len` more bytes in `count` more slices?  (Only while its chain has not gone
+  // into the send stream; a buffer is never grown past what ONE queued write may hold.)
+  bool waiting_takes(size_t len, size_t count) const {
+    if (co_bytes == 0 || bg_waiting < 0 || bg_queued) return false;
+    const send_buffer& b = sbuf[bg_waiting];
+    return b.used + len <= co_bytes && b.views.size() + count <= co_slices;
+  }
+  // The buffer that waits has just taken a write of `len` bytes in `count` slices: its chain goes into the send stream
+  // now unless another write like this one would still fit (coalescing); without coalescing, at once.
+  void queue_waiting_if_full(size_t len, size_t count) {
+    if (!waiting_takes(len, count)) try_queue_waiting();
   }
   bool fits_send_buffer(sb_t* buf) {
     const size_t len = T::length(buf);
@@ -382,6 +411,7 @@ struct core {
   void buffer_the_deferred_write() {
     if (!deferred || bg_failed || bg_running < 0 || bg_waiting >= 0 || !fits_send_buffer(deferred_buf)) return;
     const int s = free_send_buffer();
+    const size_t dlen = T::length(deferred_buf), dcount = T::count(deferred_buf);
     if (s < 0 || !fill_send_buffer(s, deferred_buf)) return;
     T::reset_and_unref(deferred_buf);
     deferred_buf = nullptr;
@@ -389,7 +419,7 @@ struct core {
     closure_t* cb = write_cb;
     write_cb = nullptr;
     bg_waiting = s;
-    try_queue_waiting();
+    queue_waiting_if_full(dlen, dcount);
     T::run(h, cb, T::none());
     T::unref(h);  // (the reference the deferred write took in write())
   }
@@ -532,13 +562,21 @@ struct core {
       T::run(h, cb, T::annotate(h, bg_error.c_str()));
       return;
     }
+    const size_t wlen = T::length(buf), wcount = T::count(buf);
+    if (!deferred && !T::is_shutdown(h) && waiting_takes(wlen, wcount) && fill_send_buffer(bg_waiting, buf, true)) {
+      // behind the bytes that wait for the Send in flight to finish: one chain for all of them
+      T::reset_and_unref(buf);
+      queue_waiting_if_full(wlen, wcount);
+      T::run(h, cb, T::none());
+      return;
+    }
     const int s = free_send_buffer();
     if (fits_send_buffer(buf) && s >= 0 && !deferred && !T::is_shutdown(h) && fill_send_buffer(s, buf)) {
       // the slices keep their boundaries, their bytes are the endpoint's now
       T::reset_and_unref(buf);
       if (bg_running >= 0) {
         bg_waiting = s;  // behind the buffer that is on its way; handle_write starts it
-        try_queue_waiting();
+        queue_waiting_if_full(wlen, wcount);
       } else {
         error_t err;
         if (!start_buffered(s, &err)) T::notify_on_write(h);

@@ -58,25 +58,35 @@ def test_pollset_with_64_connections(gpu, bpev):
 
 
 
-@pytest.mark.parametrize("ring_kb,always,want", [("16384", "0", "promoted"), ("256", "1", "skipped"), ("4096", "0", None)],
-                         ids=["r16m_promoted", "r256k_skipped", "r4m_mixed"])
+@pytest.mark.parametrize("ring_kb,always,want", [("16384", "0", "promoted"), ("256", "1", "skipped"), ("4096", "0", None),
+                                                 ("262144", "0", "coalesced"), ("262144", "0", "one_chain_per_write")],
+                         ids=["r16m_promoted", "r256k_skipped", "r4m_mixed", "r256m_coalesced", "r256m_coalescing_off"])
 def test_streamed_writes_queue_behind_the_sends_in_flight(gpu, ring_kb, always, want):
     """tools/endpoint_stream: 1 MiB writes of 130 slices through grpc_endpoint_write / _read, byte-checked on the reading
     side.  The endpoint's send buffers complete a write once it is copied, and the buffer that waits is queued into the
     pair's send stream behind the Sends in flight (grdma_endpoint_write_queue): promoted when the write in front went out
     whole -- decided on the device --, skipped and submitted again the ordinary way when it did not (a 256 KiB ring,
     GRDMA_WRITE_QUEUE_ALWAYS: every queued chain finds the write in front short).  The delivered bytes are the written
-    bytes either way."""
+    bytes either way.  Round 5: the buffer that waits COALESCES -- writes that arrive while a Send is in flight are
+    appended to it until another one would not fit (the buffer, sixteen Sends, a quarter of the ring), so at a 256 MiB
+    ring a chain carries up to three 1 MiB messages and there are fewer chains than writes; GRPC_RDMA_HIP_COALESCE=0
+    gives every write a chain of its own again."""
     import json
     es = os.path.join(ROOT, "tools", "endpoint_stream")
     env = dict(os.environ, GRPC_PLATFORM_TYPE="RDMA_BP", GRPC_RDMA_RING_BUFFER_SIZE_KB=ring_kb, GRDMA_WRITE_QUEUE_ALWAYS=always)
+    if want == "one_chain_per_write":
+        env["GRPC_RDMA_HIP_COALESCE"] = "0"
     p = subprocess.run([es, "96", str(1 << 20), "1", "0", "2"], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
     r = json.loads(p.stdout.strip().splitlines()[-1])
     queued, promoted, skipped = r["writes_queued"]
     assert r["checked"] and r["endpoint_bytes"] > 96 << 20 and promoted + skipped <= queued, r
     if want == "promoted":
-        assert promoted >= 32 and skipped == 0, r
+        assert promoted >= 6 and promoted >= 2 * skipped, r   # (chains of up to 4 MiB at a 16 MiB ring: a few find the write in front short)
+    elif want == "coalesced":
+        assert queued <= 64 and skipped == 0, r          # (96 writes; three to a chain when the writer keeps ahead)
+    elif want == "one_chain_per_write":
+        assert queued >= 80 and skipped == 0, r
     elif want == "skipped":
         assert skipped >= 8 and promoted == 0, r
 

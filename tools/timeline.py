@@ -1,4 +1,4 @@
-"""Print the kernel timeline of the last step in a rocprofv3 kernel-trace csv
+"""Print the kernel timeline of the last step (or, with a third argument, of n launches that many before the end) in a rocprofv3 kernel-trace csv
 (start/end relative to the step start, per kernel, gap to the previous kernel's end) to see what overlaps
 and what a kernel boundary costs."""
 import csv
@@ -15,7 +15,8 @@ with open(sys.argv[1]) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1)))
 rows.sort()
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-tail = rows[-n:]
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # that many launches from the end are left out (the run's tail)
+tail = rows[-(n + skip):-skip] if skip else rows[-n:]
 t0 = tail[0][0]
 prev_end = None
 for s, e, k in tail:
