@@ -277,7 +277,7 @@ def sources_sha16():
 def pmc_summary_for(ring_kb):
     """The newest committed counter summary for this ring size and whether it was collected from the sources this
     run is timing: -> (path or None, summary dict or None, stale: str or None)."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", "%s_pmc_ring%dm_summary.json" % (rnd, ring_kb // 1024))
         if os.path.exists(p):
             try:
@@ -445,6 +445,9 @@ def main():
     ap.add_argument("--sends", type=int, default=2,
                     help="consecutive Sends per round of the pipelined single-connection legs (rdma_flush sends again while "
                          "the ring has room; grdma_stream_job_set_sends); 1 = one Send per round")
+    ap.add_argument("--promise", action="store_true",
+                    help="the headline leg with the promised credit (grdma_stream_job_set_promised_credit): what the "
+                         "value_ring4096_sge30 leg runs with --ring-kb 4096 --max-sge 30 --sends 64 (profiling)")
     ap.add_argument("--launch", choices=["graph", "streams"], default="graph",
                     help="replay a step as one HIP graph, or issue its kernels on the job's streams")
     ap.add_argument("--pipeline", type=int, default=1,
@@ -783,7 +786,8 @@ def main():
     head = None
     if args.pipeline:
         try:
-            head = measure(args.ring_kb, args.steps, args.warmup, not args.no_verify, True, pipeline=True, reps=args.reps)
+            head = measure(args.ring_kb, args.steps, args.warmup, not args.no_verify, True, pipeline=True, reps=args.reps,
+                           promise=args.promise)
         except Exception as e:  # keep the line: fall back to the plain schedule and say so
             schedule = "sequential (pipelined run failed: %s)" % str(e)[:120]
     seq = None
@@ -972,6 +976,18 @@ def main():
             out["index_rebuilt_every_step_verified"] = ri["verified"]
         except Exception as e:
             out["index_rebuilt_every_step_error"] = str(e)[:200]
+    if not args.no_extra_legs and args.msgs == 256 and args.sends == 2 and args.max_sge == 4095:
+        # A step of 256 messages is four rounds of 63 (two Sends of <= 4095 slices: 31 + 32 messages of 130) and a FIFTH of
+        # four messages -- wire, planner pair and scatter launched once more for 1.5 % of the bytes.  A continuous stream has
+        # no such round; the same step with 252 messages (four full rounds) shows what it costs `value`.
+        try:
+            fw = Workload(g, 252)
+            fr = measure(args.ring_kb, max(2, args.steps // 2), 1, not args.no_verify, False, pipeline=bool(args.pipeline), wls=[fw])
+            out["value_msgs252_full_rounds_only"] = round(fw.user_bytes * max(2, args.steps // 2) * world / fr["elapsed"] / (1 << 30), 3)
+            out["rounds_per_step_msgs252"] = fr["rounds"]
+            out["msgs252_verified"] = fr["verified"]
+        except Exception as e:
+            out["msgs252_error"] = str(e)[:200]
     if not args.no_extra_legs:
         # the same headline step with PRNG payload bytes (seed 1234): the reference's second payload kind
         try:

@@ -155,10 +155,11 @@ __global__ __launch_bounds__(COPY_THREADS) void k_copy(const grdma_plan* const* 
 // k_rx_apply: K4 in one launch -- copy the payload out, clear it behind, and let
 // the last workgroup post the credit (status report) once every byte is free.
 // ----------------------------------------------------------------------------
-__device__ __forceinline__ void rx_apply_body(const grdma_rx_op op) {
+// (bx of gx: this workgroup's place among the workgroups that move the plan -- the launch's own x by default)
+__device__ __forceinline__ void rx_apply_body(const grdma_rx_op op, const uint32_t bx = blockIdx.x, const uint32_t gx = gridDim.x) {
   const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * COPY_THREADS + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * COPY_THREADS) >> 6;
+  const uint32_t wave = (bx * COPY_THREADS + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gx * COPY_THREADS) >> 6;
   run_plan<256, GRDMA_APPLY_CONTIG>(op.plan, wave, nwaves, lane);
   // arrival: my stores have been issued and acknowledged (vmcnt(0)); count in,
   // the last workgroup publishes.  Consumers on this device run in later
@@ -177,7 +178,7 @@ __device__ __forceinline__ void rx_apply_body(const grdma_rx_op op) {
     // at memory), and every workgroup waited for its acknowledgements (vmcnt(0)) before arriving.
     unsigned int prev = __hip_atomic_fetch_add(&op.plan->blocks_done, 1u, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (prev == gridDim.x - 1) ? 1u : 0u;
+    s_last = (prev == gx - 1) ? 1u : 0u;
   }
   __syncthreads();
   if (s_last && threadIdx.x == 0) {
@@ -204,17 +205,36 @@ __global__ __launch_bounds__(COPY_THREADS) void k_rx_apply(const grdma_rx_op* op
 // has run -- the drain plan for the scatter, the next send plan for the gather, whose staging buffer the wire of round
 // t - 1 has left -- and neither touches what the other does; two copy kernels back to back pay a kernel boundary and a
 // ramp each, and the tail of the first leaves most of the chip idle.  One launch less per round.
+//
+// Which workgroup does what (round 5).  The grid is (gx, 2 x links) and workgroups are dispatched x first: taken as
+// "y < links scatters" the whole scatter (1 byte read, 2 written per payload byte) was resident before the first
+// gather workgroup (1 read, 1 written) started, and a launch was a write-heavy phase followed by a balanced one.  Now
+// the 2 gx workgroups of a link alternate between the two plans in GROUPS OF EIGHT in dispatch order -- eight consecutive
+// workgroups are one per XCD, so every XCD, every L2 and every moment of the launch sees both mixes: 60.2 -> 57.7 us per
+// launch on one box, 59.3 -> 56.9 on another (profiles/r05_copy_launch_interleave.txt; alternating one by one, which
+// gives the even XCDs the scatter and the odd ones the gather, gains a third of that; a 3 : 2 split by bytes nothing).
+// Each plan's workgroups know their own index and count (rx_apply_body's arrival counter, run_plan's grid stride).
 __global__ __launch_bounds__(COPY_THREADS) void k_rx_apply_gather(const grdma_rx_op* ops, const grdma_plan* const* gplans) {
-  const uint32_t links = gridDim.y >> 1;
-  if (blockIdx.y < links) {
-    rx_apply_body(ops[blockIdx.y]);
+  const uint32_t gx = gridDim.x, per = 2 * gx;
+  const uint32_t F = blockIdx.y * gx + blockIdx.x, link = F / per, f = F - link * per;
+  uint32_t role, idx, cnt;
+  if (gx >= 8) {
+    const uint32_t g = f >> 3;
+    const uint32_t D = per >> 4, rem = per & 15u;  // whole double groups; what is left of the last one
+    role = g & 1u;
+    idx = ((g >> 1) << 3) + (f & 7u);
+    cnt = role == 0 ? D * 8 + (rem < 8 ? rem : 8u) : D * 8 + (rem > 8 ? rem - 8 : 0u);
+  } else {  // (a launch of a few workgroups: one by one, so that each plan has at least one)
+    role = f & 1u;
+    idx = f >> 1;
+    cnt = gx;
+  }
+  if (role == 0) {
+    rx_apply_body(ops[link], idx, cnt);
     return;
   }
-  const grdma_plan* plan = gplans[blockIdx.y - links];
   const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * COPY_THREADS + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * COPY_THREADS) >> 6;
-  run_plan<256, GRDMA_COPY_CONTIG>(plan, wave, nwaves, lane);
+  run_plan<256, GRDMA_COPY_CONTIG>(gplans[link], (idx * COPY_THREADS + threadIdx.x) >> 6, (cnt * COPY_THREADS) >> 6, lane);
 }
 
 // ----------------------------------------------------------------------------

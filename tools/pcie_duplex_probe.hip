@@ -40,6 +40,31 @@ __global__ __launch_bounds__(256) void k_move(u32x4* dst, const u32x4* src, size
   }
 }
 
+// the same towards the host with other store shapes: U 16-byte units per lane in flight, then wait for the acknowledgements
+// (U = 16 is k_move); NT: non-temporal stores
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_store_paced(u32x4* dst, const u32x4* src, size_t units) {
+  const size_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * 256) >> 6;
+  const int lane = threadIdx.x & 63;
+  for (size_t t = wave * 64 * U; t < units; t += nwaves * 64 * U) {
+    u32x4 a[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      const size_t u = t + lane + 64 * k;
+      a[k] = u < units ? __builtin_nontemporal_load(src + u) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      const size_t u = t + lane + 64 * k;
+      if (u < units) {
+        if (NT) __builtin_nontemporal_store(a[k], dst + u);
+        else dst[u] = a[k];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // every store of the tile acknowledged before the next tile's
+  }
+}
+
 int main() {
   const size_t H2D = 3u << 20, D2H = 64u << 20;
   uint8_t *h_src, *h_dst, *d_a, *d_b;
@@ -55,7 +80,14 @@ int main() {
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
   // D2H load kinds: 0 none, > 0 kernel with that many workgroups, -1 hipMemcpyAsync
   auto start_load = [&](int kind) {
-    if (kind > 0) hipLaunchKernelGGL(k_move, dim3(kind), dim3(256), 0, s_down, (u32x4*)h_dst, (const u32x4*)d_b, D2H / 16);
+    if (kind >= 100000) {  // paced variants: 100000 + variant * 10000 + workgroups
+      const int v = (kind - 100000) / 10000, wg = kind % 10000;
+      u32x4* d = (u32x4*)h_dst; const u32x4* sr = (const u32x4*)d_b; const size_t n = D2H / 16;
+      if (v == 0) hipLaunchKernelGGL((k_store_paced<1, false>), dim3(wg), dim3(256), 0, s_down, d, sr, n);
+      else if (v == 1) hipLaunchKernelGGL((k_store_paced<4, false>), dim3(wg), dim3(256), 0, s_down, d, sr, n);
+      else if (v == 2) hipLaunchKernelGGL((k_store_paced<16, true>), dim3(wg), dim3(256), 0, s_down, d, sr, n);
+      else hipLaunchKernelGGL((k_store_paced<1, true>), dim3(wg), dim3(256), 0, s_down, d, sr, n);
+    } else if (kind > 0) hipLaunchKernelGGL(k_move, dim3(kind), dim3(256), 0, s_down, (u32x4*)h_dst, (const u32x4*)d_b, D2H / 16);
     else if (kind < 0) CK(hipMemcpyAsync(h_dst, d_b, D2H, hipMemcpyDeviceToHost, s_down));
   };
   auto h2d = [&](int how, int blocks) {
@@ -97,6 +129,14 @@ int main() {
                load == 0 ? "none " : load < 0 ? "copy engine " : "kernel, workgroups ", load < 0 ? 0 : load);
       measure(name, how, blocks, load);
     }
+  }
+  {
+    const char* vn[4] = {"1 unit/lane, acked", "4 units/lane, acked", "16 units nt, acked", "1 unit nt, acked"};
+    for (int v = 0; v < 4; v++)
+      for (int wg : {2, 4, 8, 32}) {
+        snprintf(name, sizeof(name), "H2D kernel; D2H %s, %d wg", vn[v], wg);
+        measure(name, 0, 64, 100000 + v * 10000 + wg);
+      }
   }
   for (int blocks : {4, 16, 256, 768}) {
     snprintf(name, sizeof(name), "H2D by kernel (%d wg), no load", blocks);
