@@ -446,6 +446,22 @@ __device__ __forceinline__ const uint32_t* plan_wait_ready(const grdma_plan* pla
 #ifndef GRDMA_PLAN_ST
 #define GRDMA_PLAN_ST 0
 #endif
+// ... and of the tiles of a SCATTER (segments that clear their source): what they store -- the delivered slices and the
+// zeros behind them -- is not read again by any kernel of the round (the arena belongs to the transport, the ring's next
+// writer overwrites whole records), unlike what the gather and the wire store: non-temporal, so that 126 MiB of
+// scatter output per round do not push the staging buffer and the ring window (what the wire and the next scatter read)
+// out of the Infinity Cache.  value 540 -> 565 GiB/s, eight alternations on one box (profiles/r05_scatter_store_policy.txt;
+// the plan-free probe: tools/copy_probe, 46.5 -> 42.7 us).  Round 3 had tried nt for ALL plan stores: slower.
+#ifndef GRDMA_PLAN_ST_ZERO
+#define GRDMA_PLAN_ST_ZERO 2
+#endif
+// ... and what a scatter LOADS is the ring window the wire has just written: it is in the Infinity Cache now that the
+// scatter's own output no longer pushes it out, and a default-policy load takes it from there where a streaming one
+// did not (copy launch 56.7 -> 51.0 us, value 576 -> 601, five alternations: profiles/r05_scatter_store_policy.txt;
+// default loads for the gather and the wire as well: +3 % instead of +4.5 %, the wire itself 21.5 -> 23 us)
+#ifndef GRDMA_PLAN_LD_ZERO
+#define GRDMA_PLAN_LD_ZERO 0
+#endif
 // the record tags a segment carries (header in front of its first tile, padding + footer behind its last one)
 __device__ __forceinline__ void plan_tags(const grdma_seg& sg_in, uint64_t off, uint64_t n, uint64_t tag_base, uint64_t tm, int lane) {
   const grdma_seg sg = sg_in;  // (by value: a select between two fields of a referenced struct pins it to memory)
@@ -470,7 +486,7 @@ __device__ __forceinline__ void plan_tile(const grdma_seg& sg, uint64_t off, uin
   // (nontemporal loads: payload streams through once; plain stores: the next kernel of the
   // round reads what this one wrote out of the Infinity Cache)
   if (sg.src == 0) wave_zero_tile(reinterpret_cast<uint8_t*>(sg.dst + off), n, lane);
-  else if (sg.flags & GRDMA_SEG_ZERO_SRC) wave_move_tile<GRDMA_PLAN_LD, GRDMA_PLAN_ST, true, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
+  else if (sg.flags & GRDMA_SEG_ZERO_SRC) wave_move_tile<GRDMA_PLAN_LD_ZERO, GRDMA_PLAN_ST_ZERO, true, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
   else wave_move_tile<GRDMA_PLAN_LD, GRDMA_PLAN_ST, false, (int)(TILE / 1024)>(sg.dst + off, sg.src + off, (uint32_t)n, lane);
   plan_tags(sg, off, n, tag_base, tm, lane);
 }

@@ -169,11 +169,22 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&arena, R));
   CK(hipMalloc((void**)&d_plan, sizeof(grdma_plan)));
   CK(hipMemset(ring, 1, R));
+  // W windows of ring and arena, one per launch in turn: 3 x (79 + 79 MB) does not fit the 256 MiB Infinity Cache, so the
+  // launches are fed from HBM as in the pipeline (COPY_PROBE_WINDOWS=1: one window, cache-resident after the first launch)
+  const int W = getenv("COPY_PROBE_WINDOWS") ? atoi(getenv("COPY_PROBE_WINDOWS")) : 3;
+  const uint64_t stride = 85ull << 20;
+  grdma_plan* d_plans[3];
+  d_plans[0] = d_plan;
+  for (int k = 1; k < W; k++) CK(hipMalloc((void**)&d_plans[k], sizeof(grdma_plan)));
   std::vector<uint8_t> hp(sizeof(grdma_plan));
   grdma_plan* P = reinterpret_cast<grdma_plan*>(hp.data());
-  memset(P, 0, sizeof(grdma_plan));
-  uint64_t x = 4096, o = 0, total = 0;
+  uint64_t total = 0;
   uint32_t ns = 0;
+  for (int win = 0; win < W; win++) {
+  memset(P, 0, sizeof(grdma_plan));
+  uint64_t x = 4096 + win * stride, o = win * stride;
+  total = 0;
+  ns = 0;
   auto seg = [&](uint64_t d, uint64_t s, uint64_t len) {
     P->segs[ns].dst = (uint64_t)arena + d;
     P->segs[ns].src = (uint64_t)ring + s;
@@ -201,17 +212,18 @@ int main(int argc, char** argv) {
   P->tile_bytes = 16384;
   P->tag_base = (uint64_t)ring;
   P->tag_mask = ~0ull;
-  CK(hipMemcpy(d_plan, P, sizeof(grdma_plan), hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_plans[win], P, sizeof(grdma_plan), hipMemcpyHostToDevice));
+  }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const double alg = 3.0 * (double)total;  // read + write + clear
   printf("frames %d segments %u payload %.2f MB algorithmic %.2f MB (read + write + clear)\n", frames, ns, total / 1e6, alg / 1e6);
   auto timeit = [&](const char* name, int blocks, auto&& launch) {
-    for (int i = 0; i < 10; i++) launch();
+    for (int i = 0; i < 10; i++) launch(i % W);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; i++) launch();
+    for (int i = 0; i < reps; i++) launch(i % W);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -220,18 +232,29 @@ int main(int argc, char** argv) {
     printf("%-12s blocks %5d  %7.2f us per launch  %6.2f TB/s\n", name, blocks, us, alg / us / 1e6);
   };
   for (int blocks : {512, 768, 1024, 1280, 1366, 1536, 2048, 2730, 4096})
-    timeit("v0", blocks, [&] { hipLaunchKernelGGL(k_v0, dim3(blocks), dim3(COPY_THREADS), 0, 0, (const grdma_plan*)d_plan); });
+    timeit("v0", blocks, [&](int w) { hipLaunchKernelGGL(k_v0, dim3(blocks), dim3(COPY_THREADS), 0, 0, (const grdma_plan*)d_plans[w]); });
   for (int blocks : {256, 455, 512, 768, 1024, 1366})
-    timeit("v1", blocks, [&] { hipLaunchKernelGGL(k_v1, dim3(blocks), dim3(COPY_THREADS), 0, 0, (const grdma_plan*)d_plan); });
+    timeit("v1", blocks, [&](int w) { hipLaunchKernelGGL(k_v1, dim3(blocks), dim3(COPY_THREADS), 0, 0, (const grdma_plan*)d_plans[w]); });
   for (int blocks : {256, 455, 512, 768, 1024, 2048})
-    timeit("ideal", blocks, [&] { hipLaunchKernelGGL(k_ideal, dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena, (uint64_t)ring, total); });
+    timeit("ideal", blocks, [&](int w) { hipLaunchKernelGGL(k_ideal, dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride, (uint64_t)ring + w * stride, total); });
+  // where the tiles' edges fall in the destination: +8 -- a record's payload behind its 8-byte header: every 16 KiB tile
+  // starts and ends inside a line and moves its first and last 8 bytes as byte stores; +64 / +16: 16-byte units only, but
+  // the 128-byte lines at the tile edges are shared by two waves; src + 8: the realigning path (DPP) on aligned stores
+  for (int blocks : {768, 1024}) {
+    timeit("ideal dst+8", blocks, [&](int w) { hipLaunchKernelGGL(k_ideal, dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride + 8, (uint64_t)ring + w * stride, total); });
+    timeit("ideal dst+16", blocks, [&](int w) { hipLaunchKernelGGL(k_ideal, dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride + 16, (uint64_t)ring + w * stride, total); });
+    timeit("ideal dst+64", blocks, [&](int w) { hipLaunchKernelGGL(k_ideal, dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride + 64, (uint64_t)ring + w * stride, total); });
+    timeit("ideal src+8", blocks, [&](int w) { hipLaunchKernelGGL(k_ideal, dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride, (uint64_t)ring + w * stride + 8, total); });
+    timeit("ideal both+8", blocks, [&](int w) { hipLaunchKernelGGL(k_ideal, dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride + 8, (uint64_t)ring + w * stride + 8, total); });
+    timeit("ideal aligned", blocks, [&](int w) { hipLaunchKernelGGL(k_ideal, dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride, (uint64_t)ring + w * stride, total); });
+  }
   for (int blocks : {512, 1024, 2048}) {
-    timeit("ideal st=nt", blocks, [&] { hipLaunchKernelGGL((k_ideal_v<2, 2, 16>), dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena, (uint64_t)ring, total); });
-    timeit("ideal ld=0", blocks, [&] { hipLaunchKernelGGL((k_ideal_v<0, 0, 16>), dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena, (uint64_t)ring, total); });
-    timeit("ideal sc1", blocks, [&] { hipLaunchKernelGGL((k_ideal_v<2, 16, 16>), dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena, (uint64_t)ring, total); });
-    timeit("ideal 8K", blocks, [&] { hipLaunchKernelGGL((k_ideal_v<2, 0, 8>), dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena, (uint64_t)ring, total); });
-    timeit("ideal 4K", blocks, [&] { hipLaunchKernelGGL((k_ideal_v<2, 0, 4>), dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena, (uint64_t)ring, total); });
-    timeit("ideal 8Knt", blocks, [&] { hipLaunchKernelGGL((k_ideal_v<2, 2, 8>), dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena, (uint64_t)ring, total); });
+    timeit("ideal st=nt", blocks, [&](int w) { hipLaunchKernelGGL((k_ideal_v<2, 2, 16>), dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride, (uint64_t)ring + w * stride, total); });
+    timeit("ideal ld=0", blocks, [&](int w) { hipLaunchKernelGGL((k_ideal_v<0, 0, 16>), dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride, (uint64_t)ring + w * stride, total); });
+    timeit("ideal sc1", blocks, [&](int w) { hipLaunchKernelGGL((k_ideal_v<2, 16, 16>), dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride, (uint64_t)ring + w * stride, total); });
+    timeit("ideal 8K", blocks, [&](int w) { hipLaunchKernelGGL((k_ideal_v<2, 0, 8>), dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride, (uint64_t)ring + w * stride, total); });
+    timeit("ideal 4K", blocks, [&](int w) { hipLaunchKernelGGL((k_ideal_v<2, 0, 4>), dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride, (uint64_t)ring + w * stride, total); });
+    timeit("ideal 8Knt", blocks, [&](int w) { hipLaunchKernelGGL((k_ideal_v<2, 2, 8>), dim3(blocks), dim3(COPY_THREADS), 0, 0, (uint64_t)arena + w * stride, (uint64_t)ring + w * stride, total); });
   }
   {
     for (int i = 0; i < 5; i++) CK(hipMemcpyAsync(arena, ring, total, hipMemcpyDeviceToDevice, 0));
