@@ -13,6 +13,6 @@ for l in sys.stdin:
         print('%-14s value %.1f  ms/step %.4f  frac %.4f  copy launch %.2f us  wire %.2f  pair %.2f  verified %s' % ('${lib:-base}', d['value'], d['ms_per_step'], r['frac'], r['us_per_launch'], sk['wire']['us_per_launch'], sk['plan_pair']['us_per_launch'], d['verified']))
 "
 }
-for rep in 1 2 3 4 5; do
-  run ""; run lib_ldz0.so; run lib_ld0z2.so; run lib_ld0.so
+for rep in 1 2 3 4 5 6; do
+  run ""; run lib_wld0.so
 done 2>&1 | tee $out/variants.txt
