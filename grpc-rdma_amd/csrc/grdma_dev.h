@@ -21,6 +21,14 @@
 #define GRDMA_MAX_SLICES 8192       // delivered slices per receive plan
 #define GRDMA_TX_MAX_RECORDS 4096   // records priced by one send plan
 #define GRDMA_RX_HIST 1024          // record sizes remembered per connection
+// Behind the history (same allocation): the read-state tables rxm_body derives from a connection's record pattern, kept
+// across drains (grdma_rx_multi.h, "table cache").  GRDMA_RX_TAB_SLOTS slots of [hdr 4][key][sss][qpk][qtl][qby][qn],
+// each array GRDMA_RX_TAB_STRIDE words (512 pattern positions + the period's total at index 512).
+#define GRDMA_RX_TAB_SLOTS 8u
+#define GRDMA_RX_TAB_STRIDE 516u
+#define GRDMA_RX_TAB_WORDS (4u + 6u * GRDMA_RX_TAB_STRIDE)
+#define GRDMA_RX_TAB_MAGIC 0x7AB1E5u
+#define GRDMA_RX_HIST_ALLOC_WORDS (GRDMA_RX_HIST + GRDMA_RX_TAB_SLOTS * GRDMA_RX_TAB_WORDS)
 #define GRDMA_TILE_BYTES 8192ull    // chunk of the single-wave inline copies (latency paths)
 // Bytes one wave copies per tile of a plan: 16 KiB (64 lanes x 16 B x 16 loads in flight) for
 // connections with rings of 32 MiB and more -- a 16 KiB payload is then ONE tile and most plans
