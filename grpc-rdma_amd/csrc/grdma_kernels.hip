@@ -156,8 +156,23 @@ __global__ __launch_bounds__(COPY_THREADS) void k_copy(const grdma_plan* const* 
 // the last workgroup post the credit (status report) once every byte is free.
 // ----------------------------------------------------------------------------
 // (bx of gx: this workgroup's place among the workgroups that move the plan -- the launch's own x by default)
-__device__ __forceinline__ void rx_apply_body(const grdma_rx_op op, const uint32_t bx = blockIdx.x, const uint32_t gx = gridDim.x) {
+__device__ __forceinline__ void rx_apply_body(const grdma_rx_op op, const uint32_t bx = blockIdx.x, const uint32_t gx_in = gridDim.x) {
   const int lane = threadIdx.x & 63;
+  // A plan with one tile per segment is moved by waves that take segment PAIRS (run_plan): the workgroups beyond the
+  // last pair have nothing to move -- the fifth round of a step is 520 segments under a grid sized for 8190, a round at
+  // the reference's default knobs 260 -- and they do not count in either: hundreds of arrivals at one counter were
+  // ~6 us of the launch that moves the fifth round's 12 MB (value +1.4 %, six alternations:
+  // profiles/r05_copy_launch_interleave.txt, "active").
+  uint32_t gx = gx_in;
+  {
+    const uint32_t nsegs = op.plan->nsegs, ntiles = op.plan->ntiles;
+    if (ntiles == nsegs) {
+      const uint32_t need = (((ntiles + 1) >> 1) + (COPY_THREADS / 64) - 1) / (COPY_THREADS / 64);  // workgroups with a pair
+      const uint32_t active = need < 1 ? 1u : (need < gx ? need : gx);  // (an empty plan: one workgroup posts the commit)
+      if (bx >= active) return;
+      gx = active;
+    }
+  }
   const uint32_t wave = (bx * COPY_THREADS + threadIdx.x) >> 6;
   const uint32_t nwaves = (gx * COPY_THREADS) >> 6;
   run_plan<256, GRDMA_APPLY_CONTIG>(op.plan, wave, nwaves, lane);

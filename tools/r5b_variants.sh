@@ -14,5 +14,5 @@ for l in sys.stdin:
 "
 }
 for rep in 1 2 3 4 5 6; do
-  run ""; run lib_wld0.so
+  run ""; run lib_active.so
 done 2>&1 | tee $out/variants.txt
