@@ -124,6 +124,7 @@ SIGNATURES = {
     "grdma_pair_pool_stats": (C.c_int, [u64p]),
     "grdma_pair_pool_trim": (None, []),
     "grdma_rx_fast_drains": (C.c_int, [u64p]),
+    "grdma_rx_table_cache_stats": (C.c_int, [u64p]),
     "grdma_tx_fast_sends": (C.c_int, [u64p]),
     "grdma_tx_promise_counts": (C.c_int, [u64p]),
 }

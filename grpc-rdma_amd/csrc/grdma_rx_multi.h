@@ -52,6 +52,10 @@ namespace {
 #define RXM_RESET (2u * RXF_MINRD)     // a record of this many bytes or more leaves no read open (rxf_space_after)
 #define RXM_NONE 0xFFFFFFFFu
 
+// diagnostics: committed drains whose read-state tables came out of the connection's table cache [0] / were computed and
+// written back [1] (grdma_rx_table_cache_stats)
+__device__ unsigned long long g_rx_tab_stats[2] = {0, 0};
+
 struct rx_lds_multi {
   uint32_t hist[GRDMA_RX_HIST];
   uint32_t pat[RXF_PMAX], pre[RXF_PMAX + 1];   // encoded sizes of the pattern and their exclusive prefix
@@ -187,15 +191,15 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   }
   // ---- table cache, part 1: the tables of step 4 are a function of the pattern's payload sizes, the period and the tile
   // size alone -- what every workgroup of every drain of a periodic stream recomputed (3.9 us of a drain plan's 13-15,
-  // profiles/r05_plan_phases.txt).  They are kept behind the connection's history, one slot per rotation of the pattern
-  // (a drain begins wherever the last one ended: hc mod P), each slot with the payload sizes it was derived from as
+  // profiles/r05_plan_phases.txt).  They are kept behind the connection's history, eight slots chosen by a hash of the
+  // pattern as the drain sees it (a drain begins wherever the last one ended), each slot with the payload sizes it was derived from as
   // its key.  The slot's words are requested here, in flight under steps 1-3; step 4 compares the key with the sizes
   // the probe has just read from the ring and takes the tables, or computes them as before.  The LAST workgroup of a
   // drain to arrive writes the slot (every other one has long read it; the next reader is the next launch).
   // ---- table cache, part 1: the tables of step 4 are a function of the pattern's payload sizes, the period and the tile
   // size alone -- what every workgroup of every drain of a periodic stream recomputed (3.9 us of a drain plan's 13-15,
-  // profiles/r05_plan_phases.txt).  They are kept behind the connection's history, one slot per rotation of the pattern
-  // (a drain begins wherever the last one ended: hc mod P), each slot with the payload sizes it was derived from as
+  // profiles/r05_plan_phases.txt).  They are kept behind the connection's history, eight slots chosen by a hash of the
+  // pattern as the drain sees it (a drain begins wherever the last one ended), each slot with the payload sizes it was derived from as
   // its key.  The slot's words are requested in step 2; step 4 compares the key with the sizes the probe has read from
   // the ring and takes the tables, or computes them as before.  The LAST workgroup of a drain to arrive writes the slot
   // (every other one has long read it; the next reader is the next launch).
@@ -275,8 +279,14 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     // (table cache: the slot's words, requested BEHIND the probe's loads -- loads return in order, the probe does not
     //  wait for them -- and in flight under the probe's round trip and step 3)
     {
-      const uint32_t c_rot = (uint32_t)hc % P;  // (32 bits: a slot choice, not a value)
-      c_tab = const_cast<uint32_t*>(gh) + GRDMA_RX_HIST + ((c_rot * 0x9E3779B1u) >> 29) * GRDMA_RX_TAB_WORDS;
+      // which slot: a hash of eight samples of the pattern AS THIS DRAIN SEES IT (its encoded sizes, rotated to where the
+      // drain begins).  Two drains with the same key have the same samples -- a stream of identical messages has as many
+      // distinct rotations as its true period allows, however large the detected period P is (a multiple of it) --, and
+      // drains whose keys differ but share the samples only cost each other a recomputation.
+      uint32_t c_h = P;
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) c_h = c_h * 0x9E3779B1u + M.pat[(k * P) >> 3];
+      c_tab = const_cast<uint32_t*>(gh) + GRDMA_RX_HIST + ((c_h * 0x85EBCA6Bu) >> 29) * GRDMA_RX_TAB_WORDS;
       static_assert(GRDMA_RX_TAB_SLOTS == 8 && GRDMA_RX_TAB_STRIDE >= RXF_PMAX + 1 && 2 * RXM_THREADS >= RXF_PMAX, "slot index and layout");
       const uint32_t* const a = c_tab + 4;
 #pragma unroll
@@ -622,6 +632,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     return 2;
   }
 
+  if (tid == 0) atomicAdd(&g_rx_tab_stats[c_hit ? 0 : 1], 1ull);
   // history: the records of this drain become the newest entries (the pattern simply continues)
 #pragma unroll
   for (int r = 0; r < NH; r++) {

@@ -1633,6 +1633,13 @@ extern "C" int grdma_rx_fast_drains(uint64_t out[6]) {
   for (int i = 0; i < 6; i++) out[i] = v[i];
   return 0;
 }
+extern "C" int grdma_rx_table_cache_stats(uint64_t out[2]) {
+  unsigned long long v[2] = {0, 0};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_rx_tab_stats), sizeof(v)) != hipSuccess) return -1;
+  out[0] = v[0];
+  out[1] = v[1];
+  return 0;
+}
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_mw(void) { return reinterpret_cast<const void*>(&k_plan_pair_mw); }
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_rx_multi_groups(void) { return RXM_G; }
 extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan_mw(const grdma_rx_op* d_ops, uint32_t nops, hipStream_t s) {
