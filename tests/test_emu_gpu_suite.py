@@ -165,6 +165,19 @@ def test_endpoint_vtable_tools_under_the_emulator(emu_lib, tmp_path):
         queued, promoted, skipped = r["writes_queued"]
         assert r["checked"] and not r["latency_mode"] and queued >= 1 and promoted + skipped <= queued, r
         assert (promoted if want == "promoted" else skipped) >= 1, r
+    # round 5: the send buffer that waits COALESCES -- writes that arrive while a Send is in flight share it (up to the
+    # buffer, sixteen Sends, a quarter of the ring: three 1 MiB messages at a 64 MiB ring) and go out as one chain;
+    # GRPC_RDMA_HIP_COALESCE=0 gives every write a chain of its own.  Same bytes either way.
+    chains = {}
+    for co in ("1", "0"):
+        p = subprocess.run([es, "24", str(1 << 20), "1", "0", "2"],
+                           env=dict(env, GRPC_RDMA_RING_BUFFER_SIZE_KB="65536", GRPC_RDMA_HIP_COALESCE=co),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-500:]
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        assert r["checked"] and r["endpoint_bytes"] > 24 << 20, r
+        chains[co] = r["writes_queued"][0]
+    assert 1 <= chains["1"] <= 12 and chains["0"] >= chains["1"] + 4, chains
     # the same, randomised (ENDPOINT_STREAM_SEED: writes of 2 .. 130 slices, a reader that stalls now and then)
     for seed, ring_kb, always in ((1, "1024", "1"), (3, "4096", "0")):
         p = subprocess.run([es, "24", str(1 << 20), "1", "0", "2"],
