@@ -116,3 +116,20 @@ def test_randomised_writes_against_a_stalling_reader_skip_and_promote_queued_cha
 
 
 _RANDOMISED_OUTCOMES = []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ring_kb,max_sge,slices,nbytes", [(4096, 30, 480, 1 << 20), (262144, 30, 480, 64 << 20),
+                                                           (1024, 4095, 4095, 256 << 10)])
+def test_write_queue_limits_are_sixteen_sends_and_a_quarter_of_the_ring(gpu, ring_kb, max_sge, slices, nbytes):
+    """grdma_endpoint_write_queue_limits: what ONE queued write may hold -- the sixteen Sends of a burst (capped by the
+    records a send plan prices) and a quarter of the ring -- i.e. how far the endpoint's waiting send buffer coalesces
+    (include/grdma_endpoint_impl.hpp clamps both once more to its buffer size and its write window)."""
+    import ctypes as C
+    p = gpu.Pair(ring_kb * 1024, max_sge, 2)
+    lib = gpu.load()
+    out = (C.c_uint64 * 2)()
+    lib.grdma_endpoint_write_queue_limits.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    assert lib.grdma_endpoint_write_queue_limits(p.h, out) == 0
+    assert (int(out[0]), int(out[1])) == (slices, nbytes)
+    p.close()
