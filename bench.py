@@ -925,13 +925,20 @@ def main():
                    "msgs_per_step": args.msgs, "slices_per_msg": wl.slices_per_msg,
                    "ring_kib": args.ring_kb, "max_sge": args.max_sge, "wire": args.wire,
                    "knobs_note": ("the ring size is the reference's own knob (GRPC_RDMA_RING_BUFFER_SIZE_KB; its bandwidth "
-                                  "plots sweep it); max_sge %d is the slices ONE Send's gather kernel takes -- no HCA offers "
-                                  "that many scatter-gather entries (30 on mlx5), so a NIC-backed wire would post more, "
-                                  "smaller Sends.  The same workload at the reference's DEFAULT knobs (4 MiB ring, "
+                                  "plots sweep it); max_sge %d is how many slices (ring records) ONE Send takes.  In the "
+                                  "reference that count is the HCA's scatter-gather limit (30 on mlx5: its work request "
+                                  "gathers the records, pair.cc:53-60, 676-734); here the device has gathered them into the "
+                                  "contiguous staging buffer and the NIC wire posts num_sge = 1 per work request "
+                                  "(csrc/grdma_wire_verbs.cc: <= 2 requests per Send whatever max_sge is), so max_sge only "
+                                  "places the cut between Sends and no HCA limit stands against this value -- it is a "
+                                  "legal setting of GRPC_RDMA_MAX_SGE, not the reference's default.  The same workload at "
+                                  "the reference's DEFAULT knobs (4 MiB ring, "
                                   "max_sge 30) is value_ring4096_sge30 -- an order of magnitude below `value` -- with the "
                                   "reference's CPU codec at those knobs beside it (cpu_baseline_ring4096_sge30)"
                                   % args.max_sge),
                    "schedule": schedule,
+                   # (the spread of the timed regions, where the driver's parser keeps it: `value` is their median)
+                   "repetitions_ms_per_step": [round(1e3 * e / args.steps, 4) for e in head.get("all_elapsed", [elapsed])],
                    "sends_per_round": head.get("sends", 1),
                    "sends_per_round_note": "a round = rdma_flush's loop while the ring has room (rdma_bp_posix.cc:470-524): "
                                            "that many Sends of <= max_sge slices back to back, then the peer's endpoint reads "

@@ -348,8 +348,8 @@ __device__ __forceinline__ void wave_zero_tile(uint8_t* p, uint64_t n, int lane)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Words handed from one workgroup to another INSIDE one kernel (the planner workgroups of k_round_xag lay out the plan
-// its copy workgroups move): the workgroups of a launch sit on different XCDs, whose L2s do not see each other's lines
+// Words handed from one workgroup to another INSIDE one kernel (the drain workgroups of k_plan_pair_mw hand the promised
+// credit to its Send workgroups; the entries a declining drain's general planner rewrites): the workgroups of a launch sit on different XCDs, whose L2s do not see each other's lines
 // until a kernel ends.  The producer's stores are write-through (sc1: at the memory side once acknowledged), it waits
 // for their acknowledgement (GRDMA_WAIT_VMEM) before it publishes; the consumer's loads bypass its L2 (sc1).  The same
 // recipe as the tables of the link engine of rounds 2 - 4 were.  WT / SC1 = false: plain stores and loads (the consumer is

@@ -415,7 +415,7 @@ __attribute__((visibility("hidden"))) hipError_t grdma_launch_tx_plan_job(const 
   return hipGetLastError();
 }
 // diagnostics: Sends of streaming jobs planned by txf_body [0], left to the general planner [1]
-int grdma_tx_fast_sends_pair(uint64_t out[2]);  // (grdma_rx_plan.hip: the Sends planned inside k_plan_pair_job)
+int grdma_tx_fast_sends_pair(uint64_t out[2]);  // (grdma_rx_plan.hip: the Sends planned inside the planner-pair launches)
 int grdma_tx_fast_sends(uint64_t out[2]) {
   unsigned long long v[2] = {0, 0};
   uint64_t w[2] = {0, 0};

@@ -52,7 +52,7 @@ namespace {
 __device__ unsigned long long g_rx_fast_drains[6] = {0, 0, 0, 0, 0, 0};
 
 // LDS of the receive planners.  The steady-state body runs first and the general planner (grdma_rx_plan.hip) only
-// after it has declined, so their big arrays share one allocation: that is what lets k_plan_pair_job hold both
+// after it has declined, so their big arrays share one allocation: that is what lets one planner launch (k_plan_pair, k_plan_pair_mw) hold both
 // receive bodies AND both send bodies within the CU's 160 KB.
 #define RXG_BULK 4096                       // BULK_MAX of the general planner
 #define RXG_PAD(i) ((i) + ((i) >> 4))       // its index padding (RXP)

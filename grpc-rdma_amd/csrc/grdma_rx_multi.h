@@ -108,9 +108,9 @@ __device__ __forceinline__ void rxm_cyc(const rx_lds_multi& M, uint32_t P, uint3
   *by = q * M.qby[P] + M.qby[r];
 }
 
-// The tables of the multi-workgroup bodies: the receive planners' shared LDS (64 KB, the general planner's arrays), or --
-// WT, the bodies inside the copy launch, whose copy workgroups must keep their occupancy -- an allocation of their own
-// size (the general planner then works out of global scratch, k_round_xag).
+// The tables of the multi-workgroup bodies: the receive planners' shared LDS (64 KB, the general planner's arrays).
+// (SMALL: an allocation of their own size, for a body that shares its launch with copy workgroups which must keep
+//  their occupancy -- round 4's fused round, retired; no kernel instantiates it now.)
 #define RXM_SMALL_LDS_BYTES 33024
 template <bool SMALL>
 __device__ __forceinline__ void* rx_tables() {
@@ -125,8 +125,9 @@ __device__ __forceinline__ void* rx_tables() {
 // committed; 2: the last one, and a workgroup declined -- the caller runs the general planner; 3: every workgroup alike
 // found the connection without a usable period and the round carries a size table -- the caller runs rxh_body (every
 // thread of the workgroup returns the same value).
-// WT: the plan is moved by copy workgroups of the SAME launch (k_round_xag): plan and credit words are stored
-// write-through and acknowledged before a workgroup arrives (grdma_devfn.h: xwg_*); the caller publishes plan->ready.
+// WT: every plan and credit word is stored write-through and acknowledged before a workgroup arrives (grdma_devfn.h:
+// xwg_*), for a plan consumed inside the SAME launch; unused since round 4's fused round was retired -- every kernel
+// passes false, the plan's consumers are later launches.
 // EWT: the entries a workgroup emits for its own records (segments, tile prefix, slices) are stored write-through
 // and acknowledged before it arrives, whatever WT says about the rest.  The kernels whose last workgroup runs the general
 // planner IN THE SAME LAUNCH when some workgroup declined (k_plan_pair_mw, k_rx_plan_mw) need it: that planner rewrites
@@ -189,13 +190,6 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     s_miss = 0;
     s_lb = 0;
   }
-  // ---- table cache, part 1: the tables of step 4 are a function of the pattern's payload sizes, the period and the tile
-  // size alone -- what every workgroup of every drain of a periodic stream recomputed (3.9 us of a drain plan's 13-15,
-  // profiles/r05_plan_phases.txt).  They are kept behind the connection's history, eight slots chosen by a hash of the
-  // pattern as the drain sees it (a drain begins wherever the last one ended), each slot with the payload sizes it was derived from as
-  // its key.  The slot's words are requested here, in flight under steps 1-3; step 4 compares the key with the sizes
-  // the probe has just read from the ring and takes the tables, or computes them as before.  The LAST workgroup of a
-  // drain to arrive writes the slot (every other one has long read it; the next reader is the next launch).
   // ---- table cache, part 1: the tables of step 4 are a function of the pattern's payload sizes, the period and the tile
   // size alone -- what every workgroup of every drain of a periodic stream recomputed (3.9 us of a drain plan's 13-15,
   // profiles/r05_plan_phases.txt).  They are kept behind the connection's history, eight slots chosen by a hash of the

@@ -276,8 +276,8 @@ struct rx_state {
 };
 
 // SCRATCH: the big arrays (rx_lds_general, 64 KB) live in global memory instead of LDS -- the general planner as the
-// rarely-taken fallback inside k_round_xag, whose copy workgroups could not keep their occupancy beside a 64 KB LDS
-// allocation per workgroup.  Same code, same results; slower.
+// rarely-taken fallback inside a launch whose other workgroups cannot keep their occupancy beside a 64 KB LDS
+// allocation per workgroup (round 4's fused round, retired: no kernel instantiates SCRATCH = true now).  Same code, same results; slower.
 template <bool SCRATCH = false>
 __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* scratch = nullptr) {
   // (a private copy: fields read through the reference would be re-fetched from memory

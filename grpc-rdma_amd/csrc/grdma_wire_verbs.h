@@ -9,7 +9,9 @@
 
 #include "../../include/grdma_amd.h"
 
-enum { GRDMA_VERBS_ERR_UNSUPPORTED = 7, GRDMA_VERBS_ERR_DEVICE = 2, GRDMA_VERBS_ERR_SETUP = 3, GRDMA_VERBS_ERR_WIRE = 3 };
+// UNSUPPORTED: built without verbs; DEVICE: no (such) RDMA device; SETUP: registration / queue-pair bring-up failed, the
+// pair is unusable but nothing was sent; WIRE: a posted write failed or never completed -- the queue pair is dead
+enum { GRDMA_VERBS_ERR_UNSUPPORTED = 7, GRDMA_VERBS_ERR_DEVICE = 2, GRDMA_VERBS_ERR_SETUP = 3, GRDMA_VERBS_ERR_WIRE = 4 };
 
 struct grdma_verbs_wire;
 bool grdma_verbs_available();

@@ -291,8 +291,9 @@ int64_t grdma_endpoint_read(grdma_pair* p, uint64_t max_reads, grdma_read_slice*
  * grdma_endpoint_read_test(p, slices, cap, &would_block, &window)   >= 0: completions, slices[i].off relative to
  *                                   grdma_window_base(window); the caller owns one reference of the window
  *                                   (grdma_window_unref when the last slice is gone); -GRDMA_ERR_AGAIN: in flight.
- * grdma_pair_arm_read(p, n) on an asynchronous pair in latency mode: the in-process peer's small sends carry this
- *                                   pair's drain in the same engine command (it then shows up as a drain in flight). */
+ * grdma_pair_arm_read(p, n) on an asynchronous pair in latency mode: a standing read order with a watcher workgroup of
+ *                                   the resident engine, carried out when bytes land in the pair's ring (whoever wrote
+ *                                   them); to the endpoint it is a drain in flight that completes by itself. */
 typedef struct grdma_window grdma_window;
 int grdma_endpoint_set_async(grdma_pair* p, int windows, uint64_t window_bytes);
 int grdma_endpoint_write_submit(grdma_pair* p);
@@ -374,12 +375,14 @@ int grdma_pair_arena_copy_out(grdma_pair* p, uint64_t off, void* host_dst, uint6
  * memory instead of a stream synchronize, and delivered slices are written
  * straight into a pinned host arena. */
 int grdma_pair_set_latency_mode(grdma_pair* p, int on);
-/* Armed read: what an outstanding grpc_endpoint_read is to the reference's busy-polling thread
- * (rdma_bp_posix.cc:345-372 arms it, the poller completes it when a record lands).  With both ends of
- * a link in this process and on the latency engine, the peer's small sends carry this pair's drain in
- * the same engine command; the next grdma_endpoint_read (max_reads >= the armed value) returns that
- * completion without a command of its own.  Same bytes, order and state as the two separate calls.
- * max_reads = 0 disarms.  One thread per link. */
+/* Standing read order: what an outstanding grpc_endpoint_read is to the reference's busy-polling thread
+ * (rdma_bp_posix.cc:345-372 arms it, the poller completes it when a record lands, ring_buffer.cc:56-97).
+ * "grdma_endpoint_read(max_reads) into the next free window, whenever there is something": the order sits in one
+ * of the resident engine's 64 watch slots; a watcher workgroup polls the arrival report of THIS pair's ring and
+ * drains when it moves -- whoever wrote the bytes (the in-process peer, another process over IPC, a NIC) --, and the
+ * next grdma_endpoint_read (max_reads >= the armed value) finds the completion in pinned memory without a command
+ * of its own.  Same bytes, order and state as a read issued at that moment.  Latency mode only; not on a NIC-wire
+ * pair.  max_reads = 0 takes the order back.  One reading thread per pair. */
 int grdma_pair_arm_read(grdma_pair* p, uint64_t max_reads);
 int64_t grdma_pair_watch_hits(const grdma_pair* p);   /* completions a watcher workgroup produced and a read took */
 int grdma_engine_watchers(void);                      /* watcher workgroups per engine incarnation (GRDMA_ENGINE_WATCHERS) */
@@ -464,7 +467,7 @@ int grdma_stream_job_sync(grdma_stream_job* j);
 int grdma_stream_job_slices(grdma_stream_job* j, grdma_read_slice* out, uint64_t cap);
 int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds);
 /* on != 0: neighbouring rounds share launches, the way two hosts and a NIC work on different rounds at once: the
- * drain plan of round t with the send plan of round t + 1 (k_plan_pair_job), the scatter of round t with the
+ * drain plan of round t with the send plan of round t + 1 (k_plan_pair_mw), the scatter of round t with the
  * gather of round t + 1 (k_rx_apply_gather), the wire in between -- three launches per round, two with a direct
  * wire.  A drain walks exactly up to the tail its own Send reported; the sender may see a
  * credit one round later than in the sequential schedule.  Same bytes delivered; affects GRDMA_RUN_GRAPH, _EAGER

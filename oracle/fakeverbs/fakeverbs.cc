@@ -5,7 +5,18 @@
 // pairs connect to each other), throughput does not matter.  Checks that a real HCA would make and the reference's code
 // relies on are kept: a work request must name a registered region (lkey / rkey) that covers it, a queue pair must be
 // ready to send, a SEND needs a posted receive; violations complete with an error status, as on hardware.
+//
+// -DFAKEVERBS_HIP (tests/cc/build_fakeverbs_hip.sh, the MI355X box): the registered regions are DEVICE memory -- an HBM
+// ring, the staging buffer, the status words in the connection block -- and the fabric's "HCA" moves the bytes of a work
+// request with the copy engine (hipMemcpyAsync on a stream of its own, never the null stream: a resident kernel of the
+// library may be running): an RDMA WRITE lands in increasing address order, its last eight bytes -- the footer of the
+// last record, ring_buffer.h:84-104 -- in a second copy behind everything else, and has completed (the stream is
+// waited for) before its completion is queued, as on hardware.
 #include <infiniband/verbs.h>
+
+#ifdef FAKEVERBS_HIP
+#include <hip/hip_runtime.h>
+#endif
 
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +45,7 @@ struct fabric {
   std::map<uint32_t, ibv_mr*> mrs;             // by lkey (== rkey)
   std::map<uint32_t, qp_state> qps;            // by qp_num
   std::map<ibv_cq*, std::deque<ibv_wc>> cqs;
+  int fail_writes = 0;
   fabric() {
     memset(&dev, 0, sizeof(dev));
     snprintf(dev.name, sizeof(dev.name), "fakeverbs0");
@@ -50,6 +62,30 @@ bool covers(uint32_t key, uint64_t addr, uint64_t len) {
   const uint64_t base = (uint64_t)it->second->addr;
   return addr >= base && addr + len <= base + it->second->length;
 }
+#ifdef FAKEVERBS_HIP
+hipStream_t fabric_stream() {
+  static hipStream_t s = nullptr;
+  if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+  return s;
+}
+// one scatter-gather entry of a write: in address order, and -- `last` -- its final eight bytes behind the rest
+bool fabric_copy(uint8_t* dst, const void* src, size_t n, bool last) {
+  hipStream_t s = fabric_stream();
+  if (!s) return false;
+  const size_t tail = (last && n > 8) ? 8 : 0;
+  if (n - tail && hipMemcpyAsync(dst, src, n - tail, hipMemcpyDefault, s) != hipSuccess) return false;
+  if (tail && hipMemcpyAsync(dst + n - tail, static_cast<const uint8_t*>(src) + n - tail, tail, hipMemcpyDefault, s) != hipSuccess)
+    return false;
+  return true;
+}
+bool fabric_flush() { return hipStreamSynchronize(fabric_stream()) == hipSuccess; }
+#else
+bool fabric_copy(uint8_t* dst, const void* src, size_t n, bool) {
+  memcpy(dst, src, n);
+  return true;
+}
+bool fabric_flush() { return true; }
+#endif
 void complete(ibv_cq* cq, uint64_t wr_id, ibv_wc_status st, ibv_wc_opcode op, uint32_t bytes, uint32_t imm, uint32_t qpn) {
   ibv_wc wc;
   memset(&wc, 0, sizeof(wc));
@@ -218,12 +254,19 @@ int ibv_post_send(ibv_qp* qp, ibv_send_wr* wr, ibv_send_wr** bad) {
       ibv_wc_status st = IBV_WC_SUCCESS;
       if (!local_ok) st = IBV_WC_LOC_PROT_ERR;
       else if (peer == F().qps.end() || !covers(wr->wr.rdma.rkey, wr->wr.rdma.remote_addr, total)) st = IBV_WC_REM_ACCESS_ERR;
+      else if (F().fail_writes > 0) {   // (fakeverbs_fail_next_writes: what a peer that deregistered its ring looks like)
+        F().fail_writes--;
+        st = IBV_WC_REM_ACCESS_ERR;
+        qp->state = IBV_QPS_ERR;
+      }
       if (st == IBV_WC_SUCCESS) {
         uint8_t* dst = reinterpret_cast<uint8_t*>(wr->wr.rdma.remote_addr);
+        bool ok = true;
         for (int i = 0; i < wr->num_sge; i++) {
-          memcpy(dst, reinterpret_cast<const void*>(wr->sg_list[i].addr), wr->sg_list[i].length);
+          ok = ok && fabric_copy(dst, reinterpret_cast<const void*>(wr->sg_list[i].addr), wr->sg_list[i].length, i + 1 == wr->num_sge);
           dst += wr->sg_list[i].length;
         }
+        if (!ok || !fabric_flush()) st = IBV_WC_GENERAL_ERR;
       }
       if (signaled || st != IBV_WC_SUCCESS) complete(qp->send_cq, wr->wr_id, st, IBV_WC_RDMA_WRITE, (uint32_t)total, 0, qp->qp_num);
     } else if (wr->opcode == IBV_WR_SEND_WITH_IMM || wr->opcode == IBV_WR_SEND) {
@@ -252,6 +295,11 @@ int ibv_post_send(ibv_qp* qp, ibv_send_wr* wr, ibv_send_wr** bad) {
     }
   }
   return 0;
+}
+// test hook: the next n RDMA WRITEs complete with a remote access error and leave their queue pair in the error state
+void fakeverbs_fail_next_writes(int n) {
+  std::lock_guard<std::mutex> lk(F().mu);
+  F().fail_writes = n;
 }
 int ibv_poll_cq(ibv_cq* cq, int n, ibv_wc* wc) {
   std::lock_guard<std::mutex> lk(F().mu);

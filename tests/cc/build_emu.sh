@@ -20,7 +20,7 @@ done
 # the NIC wire back end (csrc/grdma_wire_verbs.cc) against the verbs stand-in of oracle/fakeverbs: the build and GPU
 # images have no <infiniband/verbs.h>, so this is where that file's logic is compiled for real and run
 rm -f $OUT/emu_obj/grdma_wire_verbs.o $OUT/emu_obj/fakeverbs.o
-$CXX $FLAGS -I$R/oracle/fakeverbs -DGRDMA_VERBS_HAVE_DMABUF -c $R/grpc-rdma_amd/csrc/grdma_wire_verbs.cc -o $OUT/emu_obj/grdma_wire_verbs.o &
+$CXX $FLAGS -I$R/oracle/fakeverbs -DGRDMA_WITH_VERBS -DGRDMA_VERBS_HAVE_DMABUF -c $R/grpc-rdma_amd/csrc/grdma_wire_verbs.cc -o $OUT/emu_obj/grdma_wire_verbs.o &
 pids="$pids $!"
 $CXX $FLAGS -I$R/oracle/fakeverbs -c $R/oracle/fakeverbs/fakeverbs.cc -o $OUT/emu_obj/fakeverbs.o &
 pids="$pids $!"

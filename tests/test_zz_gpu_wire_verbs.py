@@ -10,8 +10,12 @@ Replayed through it: the endpoint traces the REFERENCE produced (tests/golden/re
 pair.cc, unmodified) -- accepted bytes, delivered bytes (CRC), readable size and returned credit step by step --, and
 after every Send the receiver's ring image equals the oracle's (pinned to the reference-built pair.cc).
 
-Runs where the library was built with <infiniband/verbs.h>: the emulated library of the CPU suite
-(tests/test_emu_gpu_suite.py) -- the build and GPU images have neither the header nor an HCA, there it skips."""
+Runs where the library carries the NIC wire: the emulated library of the CPU suite (tests/test_emu_gpu_suite.py), and
+ON THE MI355X the product sources built for gfx950 with the same back end over the stand-in's fabric in its HIP form
+(tests/cc/build_fakeverbs_hip.sh -> oracle/_build/libgrdma_amd_fakeverbs.so: an RDMA WRITE is a copy-engine copy into the
+registered HBM ring in address order, the last eight bytes last) -- the product library itself is built without verbs
+(no header, no HCA in these images), so each test re-runs itself in a child pytest against that variant: real k_tx_plan /
+k_copy / k_rx_plan / k_rx_apply on both sides of the queue pair, the ring registered through its real dma-buf fd."""
 import ctypes as C
 import glob
 import json
@@ -34,6 +38,27 @@ class VerbsAddress(C.Structure):
     _fields_ = [("qpn", C.c_uint32), ("psn", C.c_uint32), ("lid", C.c_uint16), ("pad0", C.c_uint16), ("ring_rkey", C.c_uint32),
                 ("gid", C.c_uint8 * 16), ("ring_addr", C.c_uint64), ("ring_size", C.c_uint64), ("status_addr", C.c_uint64),
                 ("status_rkey", C.c_uint32), ("status_size", C.c_uint32)]
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANT = os.path.join(ROOT, "oracle", "_build", "libgrdma_amd_fakeverbs.so")
+
+
+def wire_here_or_in_the_variant(lib, request):
+    """True: this process's library has the NIC wire, go on.  False: the test has just passed in a child pytest that
+    loaded the gfx950 build with the wire over the HIP fabric.  Skips only where neither exists."""
+    lib.grdma_verbs_supported.restype = C.c_int
+    if lib.grdma_verbs_supported():
+        return True
+    if os.environ.get("GRDMA_LIB_PATH") or not os.path.exists(VARIANT):
+        pytest.skip("this library was built without the NIC wire and oracle/_build/libgrdma_amd_fakeverbs.so is absent")
+    import subprocess
+    import sys
+    env = dict(os.environ, GRDMA_LIB_PATH=VARIANT, GRDMA_TEST_ALLOW_EMU="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", request.node.nodeid],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert p.returncode == 0 and " 1 passed" in (" " + p.stdout), (p.stdout + p.stderr)[-3000:]
+    return False
 
 
 def pattern(seed, i, n):
@@ -65,12 +90,11 @@ def writable(R, st):   # GetWritableSize(), pair.cc:294-301, from the connection
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[len("ref_endpoint_"):-5] for f in FILES])
-def test_reference_made_endpoint_trace_over_the_verbs_wire(gpu, path):
+def test_reference_made_endpoint_trace_over_the_verbs_wire(gpu, path, request):
     g = gpu
     lib = g.load()
-    lib.grdma_verbs_supported.restype = C.c_int
-    if not lib.grdma_verbs_supported():
-        pytest.skip("this library was built without <infiniband/verbs.h> (the CPU suite runs this test on the emulated one)")
+    if not wire_here_or_in_the_variant(lib, request):
+        return
     doc = json.load(open(path))
     R = doc["ring_kib"] * 1024
     a, b = verbs_link(g, lib, R, doc["max_sge"])
@@ -116,14 +140,13 @@ def test_reference_made_endpoint_trace_over_the_verbs_wire(gpu, path):
         o.close()
 
 
-def test_verbs_wire_checks(gpu):
+def test_verbs_wire_checks(gpu, request):
     """What Init() / Connect() refuse: a ring that is not marked NIC-written, a peer with another ring size; and
     Disconnect() tells the peer through the status write (pair.cc:332-336 => kHalfClosed, :349-356)."""
     g = gpu
     lib = g.load()
-    lib.grdma_verbs_supported.restype = C.c_int
-    if not lib.grdma_verbs_supported():
-        pytest.skip("this library was built without <infiniband/verbs.h>")
+    if not wire_here_or_in_the_variant(lib, request):
+        return
     lib.grdma_pair_verbs_open.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
     plain = g.Pair(1 << 16, 30, 0)
     assert lib.grdma_pair_verbs_open(plain.h, None, 1, 0) < 0 and b"GRDMA_WIRE_ORDERED" in lib.grdma_last_error()
@@ -139,6 +162,19 @@ def test_verbs_wire_checks(gpu):
     assert a.Send(bufs) == 313
     got, _ = b.endpoint_read(4)
     assert b"".join(got) == b"".join(msg)
+    # what has no way to reach the queue pair is refused, not silently accounted (the engine's commands, asynchronous
+    # launch chains and device-resident jobs write through a peer-ring pointer this wire does not have)
+    lib.grdma_pair_set_latency_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.grdma_endpoint_set_async.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+    lib.grdma_pair_arm_read.argtypes = [C.c_void_p, C.c_uint64]
+    assert lib.grdma_pair_set_latency_mode(a.h, 1) < 0 and b"NIC wire" in lib.grdma_last_error()
+    assert lib.grdma_endpoint_set_async(a.h, 0, 0) < 0 and b"NIC wire" in lib.grdma_last_error()
+    assert lib.grdma_pair_arm_read(b.h, 4) < 0 and b"NIC wire" in lib.grdma_last_error()
+    from importlib import import_module
+    stream = import_module(g.Pair.__module__.rsplit(".", 1)[0] + ".stream")
+    dst = g.DeviceBuffer(1 << 16)
+    with pytest.raises(Exception, match="NIC wire"):
+        stream.StreamJob(a, b, [(x.ptr, x.nbytes) for x in bufs], dst.ptr, 1 << 16, 64, 4)
     a.Disconnect()
     import time
     t0 = time.time()
@@ -146,3 +182,29 @@ def test_verbs_wire_checks(gpu):
         assert time.time() - t0 < 10, "the peer never saw the disconnect"
         time.sleep(0.01)
     a.close(); b.close(); c.close()
+
+
+def test_a_failed_write_gives_the_wire_up_at_once(gpu, request):
+    """A work completion in error (here: the fabric refuses the write, as a peer that has gone does): the Send reports it
+    without waiting ten seconds for completions that will never come, nothing stays counted as pending, and the next
+    Send is refused immediately -- the queue pair is in the error state (pair.cc:500-558 turns this into kError)."""
+    g = gpu
+    lib = g.load()
+    if not wire_here_or_in_the_variant(lib, request):
+        return
+    import time
+    a, b = verbs_link(g, lib, 1 << 16, 30)
+    bufs = [g.DeviceBuffer(data=b"x" * 100)]
+    assert a.Send(bufs) == 100
+    lib.fakeverbs_fail_next_writes.argtypes = [C.c_int]
+    lib.fakeverbs_fail_next_writes(1)
+    t0 = time.time()
+    with pytest.raises(Exception, match="work completion"):
+        a.Send(bufs)
+    with pytest.raises(Exception, match="error state"):
+        a.Send(bufs)
+    assert time.time() - t0 < 5
+    cnt = (C.c_uint64 * 3)()
+    lib.grdma_pair_verbs_counts(a.h, cnt)
+    assert cnt[0] == 2 and cnt[2] == 1, list(cnt)     # two posted, the good one reaped; the failed one is not waited for
+    a.close(); b.close()

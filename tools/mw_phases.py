@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of the drain plan inside the PAIRED schedule (k_plan_pair_mw / k_plan_pair_job): runs the bench
+"""Phase stamps of the drain plan inside the PAIRED schedule (k_plan_pair_mw): runs the bench
 workload's job as its graph, then reads the result blocks of both parities (s_memtime ticks of the committing
 workgroup: pattern, probe, read state, totals, emission, end) next to the launch's duration between HIP events."""
 import ctypes as C
