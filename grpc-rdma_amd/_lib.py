@@ -125,6 +125,8 @@ SIGNATURES = {
     "grdma_pair_pool_trim": (None, []),
     "grdma_rx_fast_drains": (C.c_int, [u64p]),
     "grdma_rx_table_cache_stats": (C.c_int, [u64p]),
+    "grdma_rx_verdict_counts": (C.c_int, [u64p]),
+    "grdma_debug_set_promise_wait": (C.c_int, [C.c_uint32]),
     "grdma_tx_fast_sends": (C.c_int, [u64p]),
     "grdma_tx_promise_counts": (C.c_int, [u64p]),
 }

@@ -239,9 +239,9 @@ struct grdma_plan {
   uint64_t tag_base;   // window for the record tags of GRDMA_SEG_TAG_* segments
   uint64_t tag_mask;
   uint32_t tile_bytes; // 8192 or 16384: what tile_prefix counts in (GRDMA_PLAN_TILE_SHIFT)
-  // promised credit (k_plan_pair_mw): 1 once the drain workgroups of the launch have committed this
-  // plan's result block for the Send workgroups of the SAME launch (plan_wait_ready: the poll fetches the whole header
-  // line); cleared by the last Send workgroup to leave.  Other kernels neither read nor write it.
+  // promised credit (k_plan_pair_mw): the hand-over word between the drain's committing workgroup and
+  // the Send workgroups of the SAME launch -- 0 nothing yet, 1 kept, 2 given up (csrc/grdma_devfn.h: promise_keep /
+  // promise_wait); zero between launches.  Other kernels neither read nor write it.
   uint32_t ready;
   struct grdma_seg segs[GRDMA_MAX_SEGS];
   uint32_t tile_prefix[GRDMA_MAX_SEGS + 1];
@@ -255,7 +255,8 @@ struct grdma_plan {
   // arrival word of the multi-workgroup receive planner (grdma_rx_multi.h): workgroups arrived in the low half,
   // workgroups that declined in the high half; zero between launches (the last workgroup to arrive clears it)
   uint32_t mw_arrive;
-  uint32_t pad_line1[30];
+  uint32_t promise_done;  // participants of the promised-credit hand-over that are through with `ready` (promise_leave)
+  uint32_t pad_line1[29];
 };
 
 // A kernel node another stage hangs into a streaming job's graph (grdma_job_set_hooks, csrc/grdma_pair.hip): the

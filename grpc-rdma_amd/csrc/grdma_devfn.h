@@ -389,14 +389,7 @@ __device__ __forceinline__ void xwg_put_seg(grdma_seg* slot, uint64_t dst, uint6
 #endif
   *slot = grdma_seg{dst, src, len, flags};
 }
-// A copy workgroup waits until the plan it is about to move has been committed by the planner workgroups of the same
-// launch (grdma_plan::ready).  ONE wave polls, with ONE 64-byte L2-bypassing load of the plan's header line (lane l
-// reads dword l): the word that says "ready" arrives together with nsegs / ntiles / the tag window / the tile size, and
-// the workgroup's other waves take them from LDS -- a thousand workgroups each reading five header fields per wave past
-// the L2 are twelve thousand requests for one line of one memory channel, which is what the scatter then waits for
-// (measured: 85 us instead of 35 for the launch).  Bounded: a plan that never becomes ready -- a bug, not a state --
-// makes the workgroup leave without moving anything rather than hang the device (the job's verification then fails
-// loudly).  Returns nullptr in that case, else the header's sixteen dwords in LDS.
+// the header words of a plan as one 64-byte line (the copy kernels' waves take them from LDS)
 struct plan_hdr {
   uint32_t nsegs, ntiles;
   uint64_t tag_base, tag_mask;
@@ -408,24 +401,54 @@ __device__ __forceinline__ plan_hdr plan_hdr_of(const uint32_t* w) {
                 "plan header layout");
   return plan_hdr{w[0], w[1], (uint64_t)w[4] | ((uint64_t)w[5] << 32), (uint64_t)w[6] | ((uint64_t)w[7] << 32), w[8]};
 }
-__device__ __forceinline__ const uint32_t* plan_wait_ready(const grdma_plan* plan) {
-  __shared__ uint32_t s_hdr[16];
-  __shared__ uint32_t s_ready;
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(plan);
-    uint32_t v = 0, ready = 0;
-    for (uint32_t spins = 0; spins < (1u << 16); spins++) {
-      v = __hip_atomic_load(&words[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ready = (uint32_t)__builtin_amdgcn_readlane((int)v, 9);
-      if (ready != 0) break;
+// Promised credit (k_plan_pair_mw): grdma_plan::ready is the hand-over word between the workgroup that
+// commits the drain of a launch and the Send workgroups of the SAME launch.  0: nothing yet; 1: the drain's result block
+// is committed and at the memory side -- the promise is KEPT; 2: a Send workgroup's bounded wait ran out first -- the
+// promise is GIVEN UP for this launch.  Both transitions start from 0 and are compare-and-swaps, so the word takes
+// exactly one of the two values per launch and every Send workgroup, whenever it looks, comes away with the same
+// answer: a wait that runs out in one workgroup can no longer split the Send between workgroups that price with the
+// promise and workgroups that price without it (ADVICE r4 / VERDICT r5).  Every participant -- the committer and each
+// Send workgroup -- counts itself out in grdma_plan::promise_done once it is through with the word; the last of the
+// H + 1 to do so zeroes both for the next launch (nobody touches them after it: a committer that comes late, behind
+// Send workgroups that all gave up, finds 2, leaves it, and is the one that clears).
+__device__ __forceinline__ void promise_leave(grdma_plan* plan, uint32_t participants) {
+  const uint32_t prev = __hip_atomic_fetch_add(&plan->promise_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (prev + 1 == participants) {
+    __hip_atomic_store(&plan->promise_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&plan->ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// the committing drain workgroup, thread 0, its result block written: 1 = the Send will be priced with it
+__device__ __forceinline__ uint32_t promise_keep(grdma_plan* plan, uint32_t participants) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the result block is at the memory side before the word says so)
+  uint32_t seen = 0;
+  const bool kept = __hip_atomic_compare_exchange_strong(&plan->ready, &seen, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+  promise_leave(plan, participants);
+  return kept ? 1u : 0u;
+}
+// a Send workgroup (all threads call it): polls at most `bound` times; 1 = kept, 0 = given up (by this workgroup or by
+// another one -- uniformly for the launch)
+__device__ __forceinline__ uint32_t promise_wait(grdma_plan* plan, uint32_t bound, uint32_t participants) {
+  __shared__ uint32_t s_word;
+  if (threadIdx.x == 0) {
+    uint32_t v = 0;
+    for (uint32_t spins = 0; spins < bound; spins++) {
+      v = __hip_atomic_load(&plan->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v != 0) break;
       __builtin_amdgcn_s_sleep(24);
     }
-    if (lane < 16) s_hdr[lane] = v;
-    if (lane == 0) s_ready = ready;
+    if (v == 0) {  // the wait ran out -- a bug or a stalled drain, not a state: give the promise up for everybody
+      uint32_t seen = 0;
+      v = __hip_atomic_compare_exchange_strong(&plan->ready, &seen, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+              ? 0x80000002u   // (bit 31: this workgroup is the one whose wait ran out)
+              : seen;
+    }
+    promise_leave(plan, participants);
+    s_word = v;
   }
   __syncthreads();
-  return s_ready != 0 ? s_hdr : nullptr;
+  return s_word;
 }
 
 // Every workgroup stages the tile prefix in LDS (one coalesced load).  A wave takes a

@@ -286,6 +286,7 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
   if (s_any) {  // (uniform)
     if (tid == 0) {
       atomicAdd(&g_rx_fast_drains[reason ? reason : 3u], 1ull);
+      atomicAdd(&g_rx_verdicts[s_any < nwg ? 0 : 1], 1ull);
       if (!idle) res->pad0++;
     }
     return 2;

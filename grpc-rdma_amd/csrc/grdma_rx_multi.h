@@ -55,6 +55,10 @@ namespace {
 // diagnostics: committed drains whose read-state tables came out of the connection's table cache [0] / were computed and
 // written back [1] (grdma_rx_table_cache_stats)
 __device__ unsigned long long g_rx_tab_stats[2] = {0, 0};
+// diagnostics: drains of the multi-workgroup bodies that went to the general planner with a MIXED verdict -- some
+// workgroups' probes passed (their plan entries were written, and are rewritten by that planner in the same launch),
+// some declined -- [0], and with every workgroup declining [1] (grdma_rx_verdict_counts)
+__device__ unsigned long long g_rx_verdicts[2] = {0, 0};
 
 struct rx_lds_multi {
   uint32_t hist[GRDMA_RX_HIST];
@@ -621,6 +625,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     if (tid == 0) {
       // (the slot of this workgroup's own reason if it has one, the probe's otherwise: another workgroup's records)
       atomicAdd(&g_rx_fast_drains[reason ? reason : 3u], 1ull);
+      atomicAdd(&g_rx_verdicts[s_any < nwg ? 0 : 1], 1ull);
       if (!idle) res->pad0++;  // (pad1 / pad0: drains of this result block taken / declined with data waiting)
     }
     return 2;

@@ -1640,6 +1640,13 @@ extern "C" int grdma_rx_table_cache_stats(uint64_t out[2]) {
   out[1] = v[1];
   return 0;
 }
+extern "C" int grdma_rx_verdict_counts(uint64_t out[2]) {
+  unsigned long long v[2] = {0, 0};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_rx_verdicts), sizeof(v)) != hipSuccess) return -1;
+  out[0] = v[0];
+  out[1] = v[1];
+  return 0;
+}
 extern "C" __attribute__((visibility("hidden"))) const void* grdma_kernel_fn_plan_pair_mw(void) { return reinterpret_cast<const void*>(&k_plan_pair_mw); }
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_rx_multi_groups(void) { return RXM_G; }
 extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan_mw(const grdma_rx_op* d_ops, uint32_t nops, hipStream_t s) {
@@ -1650,6 +1657,9 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t grdma_launch_rx_plan
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_groups(void) { return TXM_G; }
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_max_sends(void) { return TXM_MAX_SENDS_FOLDED; }
 extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_seq_sends(void) { return TXM_MAX_SENDS; }
+extern "C" int grdma_debug_set_promise_wait(uint32_t v) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_promise_wait_dbg), &v, sizeof(v)) == hipSuccess ? 0 : -1;
+}
 extern "C" int grdma_tx_promise_counts(uint64_t out[4]) {
   unsigned long long v[4] = {0, 0, 0, 0};
   if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_tx_promise), sizeof(v)) != hipSuccess) return -1;

@@ -25,6 +25,9 @@ namespace {
 // profiling aid (grdma_tx_promise_counts): Sends priced with a promised credit / with none in the drain's result /
 // with one that was not between the posted head and the tail (an older block); waits that ran out
 __device__ unsigned long long g_tx_promise[4] = {0, 0, 0, 0};
+// test knob (grdma_debug_set_promise_wait): 0 = every Send workgroup polls up to 2^16 times; v > 0 = the Send workgroups
+// with an odd index poll v - 1 times only (v = 1: their wait runs out before the first look)
+__device__ uint32_t g_promise_wait_dbg = 0;
 
 #define TXM_THREADS 256u
 #define TXM_WAVES (TXM_THREADS / 64u)

@@ -37,14 +37,28 @@ def byte_range(part):
     return (part[0][0], part[-1][0] + part[-1][1])
 
 
-def scatter_arena(group, arena, slices, src=0):
+def stream_checksum(t, slices, start=0):
+    """Checksum of the bytes `slices` [(offset, length)] of the uint8 tensor t hold, taken as bytes start, start + 1, ...
+    of one stream: (sum of the bytes, sum of byte i x (i mod 65521 + 1)) -- the second one moves when bytes swap places
+    or a share lands at another position.  Sums over disjoint shares of a stream add up to the whole stream's, so the
+    ranks of a fan-out can each check their share and one all-reduce checks the concatenation.  Computed where t
+    lives (one gather, two reductions); exact in int64 up to 2^38 bytes."""
+    if not slices:
+        return (0, 0)
+    flat = torch.cat([t[o:o + n] for o, n in slices]).to(torch.int64)
+    w = (torch.arange(start, start + flat.numel(), dtype=torch.int64, device=flat.device) % 65521) + 1
+    return (int(flat.sum().item()), int((flat * w).sum().item()))
+
+
+def scatter_arena(group, arena, slices, src=0, return_start=False):
     """arena: uint8 tensor on the ingest rank (the stream job's destination buffer),
     slices: delivered slices [(offset, length)] (only needed on `src`).
-    Returns (my_tensor, my_slices) where my_slices are rebased to my_tensor."""
+    Returns (my_tensor, my_slices) where my_slices are rebased to my_tensor; with return_start also the position of my
+    share's first byte in the delivered stream (what stream_checksum takes)."""
     dist = group.dist
     world, rank = group.world, group.rank
     if dist is None or world == 1:
-        return arena, list(slices)
+        return (arena, list(slices), 0) if return_start else (arena, list(slices))
     device = arena.device
     if rank == src:
         parts = partition_slices(slices, world)
@@ -83,4 +97,7 @@ def scatter_arena(group, arena, slices, src=0):
         table = torch.zeros((world, max(1, nmax), 2), dtype=torch.int64, device=device)
     dist.broadcast(table, src=src)
     my_slices = [(int(o), int(n)) for o, n in table[rank, :int(counts[rank].item())].tolist()]
+    if return_start:
+        start = int(sum(int(table[r, :int(counts[r].item()), 1].sum().item()) for r in range(rank)))
+        return mine, my_slices, start
     return mine, my_slices

@@ -64,6 +64,17 @@ class RankGroup:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def sum_int(self, value):
+        """Exact sum of one integer per rank (< 2^62 each): all-gathered as int64, added as Python ints."""
+        if self.dist is None:
+            return int(value)
+        import torch
+        dev = self.device if self.device is not None else "cpu"
+        mine = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+        every = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        self.dist.all_gather(every, mine)
+        return sum(int(t.item()) for t in every)
+
     def close(self):
         if self.dist is not None and self.dist.is_initialized():
             self.dist.destroy_process_group()

@@ -501,6 +501,8 @@ int grdma_rx_express_ticks(uint64_t out[9]);  /* profiling aid: phase ticks of t
 int grdma_tx_fast_sends(uint64_t out[2]);  /* Sends of streaming jobs planned by k_tx_fast [0], left to the general planner [1] (csrc/grdma_tx_fast.h) */
 int grdma_rx_fast_drains(uint64_t out[6]);  /* drains of streaming jobs taken by k_rx_fast [0], declined by reason [1..5] (csrc/grdma_rx_fast.h) */
 int grdma_rx_table_cache_stats(uint64_t out[2]);  /* committed drains of the multi-workgroup planner whose read-state tables came out of the connection's table cache [0] / were computed and written back [1] (csrc/grdma_rx_multi.h) */
+int grdma_rx_verdict_counts(uint64_t out[2]);  /* drains of the multi-workgroup planner handed to the general planner with a mixed verdict (some workgroups' probes passed, some declined) [0] / with every workgroup declining [1] */
+int grdma_debug_set_promise_wait(uint32_t v);  /* test knob: v > 0 makes the promised-credit wait of every other Send workgroup run out after v - 1 polls (0 = the default bound for all) */
 int grdma_tx_promise_counts(uint64_t out[4]);  /* promised-credit Sends: priced with it [0], none in the drain [1], an older block [2]; waits that ran out [3] */
 int grdma_tx_small_ticks(uint64_t out[8]);  /* profiling aid: phase ticks of the latency engine's small Sends */
 /* Scalar ring arithmetic of the host layer (ring_buffer.h:101-143), exported so that the

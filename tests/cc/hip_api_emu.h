@@ -127,6 +127,11 @@ inline hipError_t hipMemcpyFromSymbol(void* d, const T& sym, size_t n, size_t of
   memcpy(d, reinterpret_cast<const char*>(&sym) + off, n);
   return hipSuccess;
 }
+template <typename T>
+inline hipError_t hipMemcpyToSymbol(T& sym, const void* s, size_t n, size_t off = 0, hipMemcpyKind = hipMemcpyHostToDevice) {
+  memcpy(reinterpret_cast<char*>(&sym) + off, s, n);
+  return hipSuccess;
+}
 #define HIP_SYMBOL(x) x
 
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = reinterpret_cast<hipStream_t>(malloc(8)); return hipSuccess; }

@@ -473,6 +473,7 @@ inline void __builtin_amdgcn_s_setprio(int) {}
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), (order))
+#define __hip_atomic_compare_exchange_strong(p, expected, desired, so, fo, scope) __atomic_compare_exchange_n((p), (expected), (desired), false, (so), (fo))
 template <typename T>
 inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 template <typename T>
