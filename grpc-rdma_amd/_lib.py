@@ -80,6 +80,8 @@ SIGNATURES = {
     "grdma_pair_send": (C.c_int64, [C.c_void_p, C.POINTER(Slice), u64, u64, C.c_int]),
     "grdma_pair_recv": (C.c_int64, [C.c_void_p, C.c_void_p, u64, C.c_int]),
     "grdma_pair_enable_zerocopy": (C.c_int, [C.c_void_p, u64]),
+    "grdma_pair_enable_zerocopy_ex": (C.c_int, [C.c_void_p, u64, C.c_int]),
+    "grdma_pair_zerocopy_mem": (C.c_int, [C.c_void_p]),
     "grdma_pair_allocate_send_buffer": (C.c_void_p, [C.c_void_p, u64]),
     "grdma_pair_send_zerocopy": (C.c_int64, [C.c_void_p, C.POINTER(Slice), u64, u64, C.c_int]),
     "grdma_pair_zerocopy_state": (C.c_int, [C.c_void_p, u64p]),

@@ -269,8 +269,9 @@ struct grdma_pair {
   int wakeup_fd = -1;                // grpc_wakeup_fd of the pair (pair.h:187): an eventfd
   std::mutex fd_mu;                  // creation of wakeup_fd
   // zero-copy send buffer (send_buffers_[kZeroCopyBuffer], pair.h:96,178,195)
-  uint8_t* d_zc = nullptr;
+  uint8_t* d_zc = nullptr;          // host-writable AND device-readable unless zc_mem == GRDMA_ZC_MEM_DEVICE
   uint64_t zc_cap = 0;
+  int zc_mem = GRDMA_ZC_MEM_HOST;
   uint32_t zc_tail = 0;              // zerocopy_buffer_tail_ (std::atomic_uint32_t)
   uint64_t zc_bytes = 0, zc_copy_bytes = 0, zc_last_sges = 0;
   std::mutex zc_mu;

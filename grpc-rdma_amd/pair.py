@@ -48,6 +48,9 @@ class DeviceBuffer:
             pass
 
 
+ZC_MEM_HOST, ZC_MEM_BAR, ZC_MEM_DEVICE = 0, 1, 2
+
+
 class Pair:
     def __init__(self, ring_size=4 << 20, max_sge=30, flags=WIRE_STAGED, handle=None):
         self.lib = load()
@@ -97,19 +100,30 @@ class Pair:
         return check(self.lib.grdma_pair_send(self.h, arr, len(slices), byte_idx, flags))
 
     # -- zero-copy send buffer (pair.cc:305-323, 793-941) ----------------------------
-    def enable_zerocopy(self, nbytes=0):
-        check(self.lib.grdma_pair_enable_zerocopy(self.h, nbytes))
+    def enable_zerocopy(self, nbytes=0, mem=None):
+        """mem: None = GRPC_RDMA_HIP_ZEROCOPY_MEM (default "host"), or ZC_MEM_HOST / ZC_MEM_BAR / ZC_MEM_DEVICE."""
+        if mem is None:
+            check(self.lib.grdma_pair_enable_zerocopy(self.h, nbytes))
+        else:
+            check(self.lib.grdma_pair_enable_zerocopy_ex(self.h, nbytes, mem))
+
+    def zerocopy_mem(self):
+        return self.lib.grdma_pair_zerocopy_mem(self.h)
 
     def AllocateSendBuffer(self, size):
-        """-> device pointer into the pair's zero-copy buffer, or None (as the reference's nullptr)."""
+        """-> pointer into the pair's zero-copy buffer (host-writable unless the buffer is ZC_MEM_DEVICE), or None
+        (as the reference's nullptr)."""
         return self.lib.grdma_pair_allocate_send_buffer(self.h, size) or None
 
     def SendZerocopy(self, slices, byte_idx=0):
-        """slices: DeviceBuffer or (device ptr, len) -- ranges of the zero-copy buffer among them."""
+        """slices: DeviceBuffer or (ptr, len) -- ranges of the zero-copy buffer among them -- or, with a host-writable
+        zero-copy buffer, bytes (host memory: what grpc_endpoint_write holds beside the serialised message); a list
+        with host slices is sent with GRDMA_MEM_HOST, so everything in it that is not a range of the zero-copy buffer
+        must be host memory."""
         arr, keep, host = self._slices(slices)
-        if host:
-            raise GrdmaError("SendZerocopy takes device-accessible slices")
-        return check(self.lib.grdma_pair_send_zerocopy(self.h, arr, len(slices), byte_idx, MEM_DEVICE))
+        if host and any(isinstance(s, DeviceBuffer) for s in slices):
+            raise GrdmaError("SendZerocopy: host slices and device buffers cannot be mixed in one call")
+        return check(self.lib.grdma_pair_send_zerocopy(self.h, arr, len(slices), byte_idx, MEM_HOST if host else MEM_DEVICE))
 
     def zerocopy_state(self):
         out = (C.c_uint64 * 4)()

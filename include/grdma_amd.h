@@ -191,25 +191,39 @@ int64_t grdma_pair_readable_size(grdma_pair* p);   /* GetReadableSize(), ring_bu
 int64_t grdma_pair_writable_size(grdma_pair* p);   /* GetWritableSize(), pair.cc:294-301   */
 
 /* Zero-copy send buffer (pair.h:96,127,140; pair.cc:103-120, 305-323, 793-941).
- * grdma_pair_enable_zerocopy   initSendBuffer(kZeroCopyBuffer): `bytes` of device memory owned by the
- *                              pair (0 = GRPC_RDMA_ZEROCOPY_BUFFER_SIZE_KB as the reference's Config
- *                              reads it); allocate_send_buffer enables it on first use.
- * grdma_pair_allocate_send_buffer  AllocateSendBuffer(size): a device pointer into that buffer, or NULL
+ * grdma_pair_enable_zerocopy   initSendBuffer(kZeroCopyBuffer): `bytes` owned by the pair (0 =
+ *                              GRPC_RDMA_ZEROCOPY_BUFFER_SIZE_KB as the reference's Config reads it);
+ *                              allocate_send_buffer enables it on first use.  HOST-WRITABLE and device-readable:
+ *                              the reference's caller serialises into it with the CPU (GenericSerialize ->
+ *                              SerializeWithCachedSizesToArray, include/grpcpp/impl/codegen/proto_utils.h:68-95, through
+ *                              CoreCodegen::grpc_call_allocate_send_buffer, src/cpp/common/core_codegen.cc:122-146).
+ *                              _ex names the memory: GRDMA_ZC_MEM_HOST (pinned mapped host memory, the default: the
+ *                              gather pulls the payload over PCIe into the peer ring), GRDMA_ZC_MEM_BAR (fine-grained
+ *                              device memory the CPU writes through the PCIe BAR), GRDMA_ZC_MEM_DEVICE (device memory
+ *                              for serialisers that run on the device; not host-writable).  Environment:
+ *                              GRPC_RDMA_HIP_ZEROCOPY_MEM = host | bar | device.
+ * grdma_pair_allocate_send_buffer  AllocateSendBuffer(size): a pointer into that buffer, or NULL
  *                              when size == 0, the buffer is not empty (the reference serves one
  *                              allocation at a time: tail != 0 -> nullptr) or the size does not fit.
- *                              The caller serialises its message there (device-side).
+ *                              The caller serialises its message there (plain CPU stores for HOST / BAR).
  * grdma_pair_send_zerocopy     SendZerocopy(slices, count, byte_idx): a slice that lies inside the
  *                              zero-copy buffer becomes a record whose payload is read where it lies
  *                              (limited by the receiver's credit only; the reference stages 16 +
  *                              padding tag bytes and uses 4 of its max_sge entries for it), any other
- *                              slice is priced as Send prices it.  Device-accessible slices only.
+ *                              slice is priced as Send prices it.  GRDMA_MEM_DEVICE: every slice is device-
+ *                              accessible; GRDMA_MEM_HOST: the slices are the host's (what grpc_endpoint_write hands
+ *                              over) -- ranges of the zero-copy buffer are still read in place, the others are
+ *                              copied through the pinned bounce buffer as grdma_pair_send does.
  *                              Returns the payload bytes accepted; partial_write, remote_tail and the
  *                              <= 2 work requests (grdma_pair_last_wrs) as the reference leaves them.
  *                              On this wire every record of the call goes straight from its source into
  *                              the peer ring (one gather launch); nothing is written to the staging buffer.
  * grdma_pair_zerocopy_state    out = {zerocopy_buffer_tail_, zerocopy_bytes_, copy_bytes_, scatter-gather
  *                              entries the reference's list would hold after the last call}. */
+enum grdma_zc_mem { GRDMA_ZC_MEM_HOST = 0, GRDMA_ZC_MEM_BAR = 1, GRDMA_ZC_MEM_DEVICE = 2 };
 int grdma_pair_enable_zerocopy(grdma_pair* p, uint64_t bytes);
+int grdma_pair_enable_zerocopy_ex(grdma_pair* p, uint64_t bytes, int mem);
+int grdma_pair_zerocopy_mem(grdma_pair* p);   /* the kind of the buffer in use, or -1 */
 void* grdma_pair_allocate_send_buffer(grdma_pair* p, uint64_t size);
 int64_t grdma_pair_send_zerocopy(grdma_pair* p, const grdma_slice* slices, uint64_t count,
                                  uint64_t byte_idx, int flags);

@@ -7,6 +7,11 @@
 #   2. $REF/src/core/lib/iomgr/ev_epollex_rdma_bpev_linux.cc      -- the reference's event engines, UNMODIFIED: they cast the
 #   3. $REF/src/core/lib/iomgr/ev_epollex_rdma_bp_linux.cc           fd's arg to PairPollable* and call HasMessage() /
 #                                                                    HasPendingWrites() / get_status() / get_wakeup_fd() on it
+#   4. $REF/src/cpp/common/core_codegen.cc WITH ITS ZERO-COPY HOOK SWITCHED ON -- CoreCodegen::grpc_call_allocate_send_buffer
+#      (:122-146) is `#if 0`-ed out in the reference; the check compiles the file with that one `#if 0` / `#endif` pair
+#      removed (a temporary copy made on the fly, nothing kept), so that Config::Get().get_zerocopy_threshold_kb(),
+#      PairPool::Get().Get(peer), PairPollable::get_status() == PairStatus::kConnected and AllocateSendBuffer(size) bind to
+#      the facade: the hook surface of SURVEY.md 8(f-3) is there for a maintainer who lifts the `#if 0`.
 # Nothing is linked and nothing of the reference is copied; exit status 0 = the adapter, the facade and the
 # reference's endpoint / event-engine / slice interfaces still fit together.
 REF=${REF:-/root/reference}
@@ -23,4 +28,9 @@ for f in "$HERE/rdma_hip_posix.cc" "$REF/src/core/lib/iomgr/ev_epollex_rdma_bpev
          "$REF/src/core/lib/iomgr/ev_epollex_rdma_bp_linux.cc"; do
   if $CXX $FLAGS "$f"; then echo "ok: $f"; else echo "FAILED: $f" >&2; rc=1; fi
 done
+tmp=$(mktemp /tmp/core_codegen_zc.XXXXXX.cc)
+awk 'BEGIN{s=0} /^#if 0$/ && s==0 {s=1; next} /^#endif$/ && s==1 {s=2; next} {print}' "$REF/src/cpp/common/core_codegen.cc" > "$tmp"
+if grep -q "AllocateSendBuffer" "$tmp" && $CXX $FLAGS "$tmp"; then echo "ok: $REF/src/cpp/common/core_codegen.cc with the zero-copy hook (:122-146) switched on"
+else echo "FAILED: core_codegen.cc with the zero-copy hook switched on" >&2; rc=1; fi
+rm -f "$tmp"
 exit $rc

@@ -12,8 +12,15 @@
 #ifndef GRPC_SRC_CORE_LIB_IBVERBS_PAIR_H
 #define GRPC_SRC_CORE_LIB_IBVERBS_PAIR_H
 #ifdef GRPC_USE_IBVERBS
-#include <string>
+#include <grpc/slice.h>
 
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "src/core/lib/ibverbs/config.h"
 #include "src/core/lib/iomgr/wakeup_fd_posix.h"
 
 #include "grdma_amd.h"
@@ -63,10 +70,91 @@ class PairPollable {
   void Disconnect() { grdma_pair_disconnect(pair_); }
   grdma_pair* hip_pair() const { return pair_; }
 
+  // ---- zero-copy send buffer (pair.h:127,140; pair.cc:305-323, 793-941) -------------------------------------------
+  // AllocateSendBuffer: the pointer CoreCodegen::grpc_call_allocate_send_buffer hands to GenericSerialize
+  // (src/cpp/common/core_codegen.cc:122-146, include/grpcpp/impl/codegen/proto_utils.h:68-95), which lets protobuf
+  // serialise into it with the CPU: pinned host memory the gather kernel reads in place (GRDMA_ZC_MEM_HOST).  One
+  // allocation at a time, nullptr otherwise -- the reference's rule.
+  uint8_t* AllocateSendBuffer(size_t size) {
+    return static_cast<uint8_t*>(grdma_pair_allocate_send_buffer(pair_, static_cast<uint64_t>(size)));
+  }
+  // SendZerocopy(slices, count, byte_idx): the slices as grpc_endpoint_write holds them; the one that lies in the
+  // zero-copy buffer leaves from where it is, the rest (frame and message headers) as Send sends them
+  uint64_t SendZerocopy(grpc_slice* slices, size_t slice_count, size_t byte_idx) {
+    std::vector<grdma_slice> v(slice_count);
+    for (size_t i = 0; i < slice_count; i++) {
+      v[i].ptr = GRPC_SLICE_START_PTR(slices[i]);
+      v[i].len = GRPC_SLICE_LENGTH(slices[i]);
+    }
+    const int64_t n = grdma_pair_send_zerocopy(pair_, v.data(), slice_count, byte_idx, GRDMA_MEM_HOST);
+    return n > 0 ? static_cast<uint64_t>(n) : 0;
+  }
+
  private:
   grdma_pair* pair_;
   grpc_wakeup_fd wakeup_fd_;
   mutable std::string error_;
+};
+
+// PairPool (pair.h:273-333): Take(id) / Get(id) / Putback over the library's pool of pair MEMORY
+// (grdma_pair_pool_take / _putback), keeping the id -> PairPollable* table the zero-copy hook looks a call's pair up in
+// (core_codegen.cc:130-139: PairPool::Get().Get(peer) with the string grpc_call_get_peer_id returns, surface/call.cc:663-672).
+// Take() shapes the pair from Config, as the reference's PairPollable() does; the endpoint (integration/
+// rdma_hip_posix.cc) takes its pair here and puts it back in rdma_free.
+class PairPool {
+  PairPool() {}
+
+ public:
+  PairPool(const PairPool&) = delete;
+  PairPool& operator=(const PairPool&) = delete;
+
+  static PairPool& Get() {
+    static PairPool pool;
+    return pool;
+  }
+
+  PairPollable* Take(const std::string& id) {
+    grdma_config cfg;
+    if (grdma_config_from_env(&cfg) < 0 || grdma_init(cfg.hip_device) < 0) return nullptr;
+    static const int pool_on = grdma_pair_pool_reserve(0, 0, 0, 0, static_cast<uint64_t>(cfg.hip_pair_pool_mb) << 20);
+    (void)pool_on;
+    // (fine-grained: the peer -- another process -- writes this pair's ring and status block through an IPC mapping)
+    grdma_pair* pair = grdma_pair_pool_take(id.c_str(), static_cast<uint64_t>(cfg.ring_buffer_size_kb) * 1024, cfg.max_sge,
+                                            (cfg.hip_wire_direct ? GRDMA_WIRE_DIRECT : GRDMA_WIRE_STAGED) | GRDMA_RING_FINE_GRAINED);
+    if (pair == nullptr) return nullptr;
+    PairPollable* pollable = new PairPollable(pair);
+    std::unique_lock<std::shared_timed_mutex> lock(mu_);
+    id_pair_[id] = pollable;
+    pair_id_[pollable] = id;  // (the reference never fills this table, so its Putback never erases: SURVEY.md A.10)
+    return pollable;
+  }
+
+  void Putback(PairPollable* pollable) {
+    if (pollable == nullptr) return;
+    {
+      std::unique_lock<std::shared_timed_mutex> lock(mu_);
+      auto it = pair_id_.find(pollable);
+      if (it != pair_id_.end()) {
+        auto by_id = id_pair_.find(it->second);
+        if (by_id != id_pair_.end() && by_id->second == pollable) id_pair_.erase(by_id);
+        pair_id_.erase(it);
+      }
+    }
+    grdma_pair* pair = pollable->hip_pair();
+    delete pollable;
+    grdma_pair_pool_putback(pair);
+  }
+
+  PairPollable* Get(const std::string& id) {
+    std::shared_lock<std::shared_timed_mutex> lock(mu_);
+    auto it = id_pair_.find(id);
+    return it != id_pair_.end() ? it->second : nullptr;
+  }
+
+ private:
+  std::shared_timed_mutex mu_;
+  std::unordered_map<std::string, PairPollable*> id_pair_;
+  std::unordered_map<PairPollable*, std::string> pair_id_;
 };
 
 }  // namespace ibverbs

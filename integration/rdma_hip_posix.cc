@@ -151,8 +151,8 @@ void hip_free(grpc_rdma_hip* rdma) {  // rdma_free, :112-131
   if (rdma->pair != nullptr) {
     if (rdma->enable_poller) grpc_core::ibverbs::Poller::Get().RemovePollable(rdma->pollable);
     grdma_pair_disconnect(rdma->pair);
-    delete rdma->pollable;
-    grdma_pair_pool_putback(rdma->pair);  // PairPool::Putback (:128)
+    grpc_core::ibverbs::PairPool::Get().Putback(rdma->pollable);  // :128 (deletes the facade object, returns the memory)
+    rdma->pollable = nullptr;
     rdma->pair = nullptr;
   }
   delete rdma;
@@ -272,10 +272,10 @@ grpc_endpoint* grpc_rdma_bp_create(grpc_fd* em_fd, const grpc_channel_args* chan
     const size_t pos = uri.find_last_of('/');  // get rid of prefix "dns:///"
     if (pos != std::string::npos) pair_id = uri.substr(pos + 1);
   }
-  static const int pool_on = grdma_pair_pool_reserve(0, 0, 0, 0, static_cast<uint64_t>(g_cfg.hip_pair_pool_mb) << 20);
-  (void)pool_on;
-  grdma_pair* pair = grdma_pair_pool_take(pair_id.c_str(), static_cast<uint64_t>(g_cfg.ring_buffer_size_kb) * 1024, g_cfg.max_sge,
-                                          (g_cfg.hip_wire_direct ? GRDMA_WIRE_DIRECT : GRDMA_WIRE_STAGED) | GRDMA_RING_FINE_GRAINED);
+  // (the facade's PairPool keeps the id -> PairPollable* table the zero-copy hook looks the call's pair up in,
+  //  core_codegen.cc:130-139; the pair itself comes out of the library's pool of pair memory)
+  grpc_core::ibverbs::PairPollable* pollable = grpc_core::ibverbs::PairPool::Get().Take(pair_id);
+  grdma_pair* pair = pollable != nullptr ? pollable->hip_pair() : nullptr;
   // exchange_data + PairPollable::Connect (:640-692, :767-771; pair.cc:143-168): both ends write
   // their 48-byte Address (plus the memory handles of ring and status block) to the bootstrap
   // socket and read the peer's, full duplex, then map the peer's ring
@@ -283,14 +283,14 @@ grpc_endpoint* grpc_rdma_bp_create(grpc_fd* em_fd, const grpc_channel_args* chan
     gpr_log(GPR_ERROR, "Connection failed: %s", grdma_last_error());
     if (pair != nullptr) {
       grdma_pair_disconnect(pair);
-      grdma_pair_pool_putback(pair);  // :780
+      grpc_core::ibverbs::PairPool::Get().Putback(pollable);  // :780
     }
     grpc_resource_user_unref(rdma->resource_user);
     delete rdma;
     return nullptr;
   }
   rdma->pair = pair;
-  rdma->pollable = new grpc_core::ibverbs::PairPollable(pair);
+  rdma->pollable = pollable;
   rdma->enable_poller = enable_poller;
   rdma->core.init(rdma, pair);
   // :788 -- the event engines keep this pointer as a PairPollable* and poll HasMessage() / HasPendingWrites() /

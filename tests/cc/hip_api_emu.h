@@ -47,7 +47,7 @@ struct hipKernelNodeParams {
   unsigned int sharedMemBytes;
 };
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocCoherent = 0x40000000, hipHostMallocMapped = 2,
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocCoherent = 0x40000000, hipHostMallocMapped = 2, hipHostMallocNonCoherent = 0x80000000u,
        hipDeviceMallocFinegrained = 1, hipIpcMemLazyEnablePeerAccess = 1, hipMemRangeHandleTypeDmaBufFd = 1 };
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1, hipDeviceAttributeWallClockRate = 2 };
 
