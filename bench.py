@@ -388,12 +388,20 @@ def rtt_subprocess(flag, iters, timeout_s=150, key="rtt_error"):
         return {key: err_text(e)}
 
 
+EMULATED = False  # (set by main: GRDMA_BENCH_EMULATED=1, the dry run of the CPU suite)
+
+
+def dev_sync(torch):
+    if not EMULATED:
+        torch.cuda.synchronize()
+
+
 def fanout_leg(g, gs, grp, torch, args, flags, n_msgs=128):
     """One 128 MiB stream (128 x 1 MiB messages) ingested on rank 0, decoded into a torch
     tensor, then rebalanced to all ranks with one grouped RCCL send/recv step over views of the arena
     (grpc_rdma_amd.fanout: no padded copies on the source)."""
     from grpc_rdma_amd import fanout
-    dev = torch.device("cuda", grp.local_rank)
+    dev = torch.device("cpu") if EMULATED else torch.device("cuda", grp.local_rank)
     ring = args.ring_kb * 1024
     arena, slices = torch.zeros(16, dtype=torch.uint8, device=dev), []
     t_ingest = 0.0
@@ -409,17 +417,17 @@ def fanout_leg(g, gs, grp, torch, args, flags, n_msgs=128):
         assert r.done
         job.set_rounds(int(max(r.tx_rounds, r.rx_rounds)))
         job.run(gs.RUN_GRAPH)
-        torch.cuda.synchronize()
+        dev_sync(torch)
         t0 = time.perf_counter()
         job.launch()
         job.sync()
         t_ingest = time.perf_counter() - t0
         slices = job.delivered_slices()
-    torch.cuda.synchronize()
+    dev_sync(torch)
     grp.barrier()
     t0 = time.perf_counter()
     mine, my_slices, start = fanout.scatter_arena(grp, arena, slices, src=0, return_start=True)
-    torch.cuda.synchronize()
+    dev_sync(torch)
     t_scatter = grp.max(time.perf_counter() - t0)
     got = grp.sum(sum(n for _, n in my_slices))
     # what the ranks hold afterwards, concatenated in rank order, must BE the framed stream: every rank checksums its
@@ -488,6 +496,11 @@ def main():
     ap.add_argument("--rtt-iters", type=int, default=200000,
                     help="64 B round trips (>= 10 s of them on this part; the reference runs >= 10 s or 1 M RPCs behind "
                          "10 000 warm-up calls, examples/cpp/micro-bench/mb_client.cc:41-44)")
+    ap.add_argument("--payload", type=int, default=MIB,
+                    help="payload bytes of a message of the headline leg (the metric is quoted at 1 MiB; smaller values are "
+                         "for the emulated dry run of the CPU suite, tests/test_bench_emulated.py)")
+    ap.add_argument("--conn-msgs", type=int, default=0, help="messages per connection in the multi-connection legs (0 = max(8, 2048 / conns))")
+    ap.add_argument("--fanout-msgs", type=int, default=128, help="1 MiB messages of the single-stream fan-out leg")
     ap.add_argument("--rtt-commands-only", action="store_true", help="(internal) run only the ping-pong whose reads are commands")
     ap.add_argument("--rtt-only", action="store_true", help="(internal) run only the 64 B ping-pong leg")
     ap.add_argument("--h2-only", action="store_true", help="(internal) run only the with-h2 legs")
@@ -518,20 +531,35 @@ def main():
     from_env = (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
                 int(os.environ.get("WORLD_SIZE", "1")))
     rank, local_rank, world = from_env
-    torch.cuda.set_device(local_rank)
+    # GRDMA_BENCH_EMULATED=1 (tests/test_bench_emulated.py, the CPU suite): a DRY RUN of this script, rank for rank as the
+    # driver launches it, with the product sources compiled over the wave emulator as the library (GRDMA_LIB_PATH must
+    # name it), CPU tensors and gloo in place of HBM tensors and RCCL.  It checks that the N > 1 path executes -- sharded
+    # connections, barriers, the max over ranks, the fan-out with its checksum -- not how fast anything is: the line it
+    # prints says "emulated" in `data` and its `value` is not a measurement.  Never set on a GPU box.
+    global EMULATED
+    EMULATED = os.environ.get("GRDMA_BENCH_EMULATED") == "1"
+    if EMULATED and "emu" not in os.path.basename(os.environ.get("GRDMA_LIB_PATH", "")):
+        raise SystemExit("GRDMA_BENCH_EMULATED=1 needs GRDMA_LIB_PATH=<the emulated library>: refusing to dry-run the product library")
     import __graft_entry__ as ge
-    if not os.path.exists(ge.LIB):
-        ge.build()
+    if EMULATED:
+        device = torch.device("cpu")
+        local_rank_dev = 0
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        local_rank_dev = local_rank
+        if not os.path.exists(ge.LIB):
+            ge.build()
     import grpc_rdma_amd as g
     from grpc_rdma_amd import stream as gs
-    g.init(local_rank)
+    g.init(local_rank_dev)
     from grpc_rdma_amd import shard
-    grp = shard.RankGroup(backend="nccl", device=torch.device("cuda", local_rank))
+    grp = shard.RankGroup(backend="gloo" if EMULATED else "nccl", device=None if EMULATED else device)
     dist = grp.dist
 
     flags = 2 if args.wire == "direct" else 0
-    wl = Workload(g, args.msgs)
-    workloads = {(args.msgs, MIB): [wl]}
+    wl = Workload(g, args.msgs, args.payload)
+    workloads = {(args.msgs, args.payload): [wl]}
 
     def get_workloads(n_links, msgs_per_link, payload):
         key = (msgs_per_link, payload)
@@ -541,12 +569,12 @@ def main():
         return lst[:n_links]
 
     def barrier():
-        torch.cuda.synchronize()
+        dev_sync(torch)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync(torch)
 
-    def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=MIB,
+    def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=None,
                 pipeline=False, max_sge=None, wire_flags=None, wls=None, reps=1, sends=None, promise=False,
                 reindex=False, bidi=False):
         """n_links connections with rings of ring_kb KiB: calibrate the number of rounds, capture the graph, time
@@ -556,7 +584,7 @@ def main():
         if sends is None:
             sends = args.sends if (pipeline and n_links == 1) else 1
         wf = flags if wire_flags is None else wire_flags
-        wls = wls or get_workloads(n_links, msgs_per_link or args.msgs, payload)
+        wls = wls or get_workloads(n_links, msgs_per_link or args.msgs, payload or args.payload)
         links, keep = [], []
         prev = None
         for k, w in enumerate(wls):
@@ -617,7 +645,7 @@ def main():
             for _ in range(steps):
                 launch()
             job.sync()
-            torch.cuda.synchronize()
+            dev_sync(torch)
             e = time.perf_counter() - t0
             all_elapsed.append(grp.max(e))
             barrier()
@@ -920,7 +948,7 @@ def main():
                               "frac": round(step_bytes / step_s / 1e9 / HBM_PEAK_GBPS, 4),
                               "frac_with_wire": round((step_bytes + 2 * wl.E) / step_s / 1e9 / HBM_PEAK_GBPS, 4)}
     try:
-        roofline["measured_ceiling"] = measured_copy_ceiling(torch, torch.device("cuda", local_rank))
+        roofline["measured_ceiling"] = None if EMULATED else measured_copy_ceiling(torch, device)
     except Exception as e:
         roofline["measured_ceiling"] = {"error": str(e)[:120]}
 
@@ -933,7 +961,8 @@ def main():
         "repetitions": {"n": len(head.get("all_elapsed", [elapsed])), "reported": "median",
                         "ms_per_step": [round(1e3 * e / args.steps, 4) for e in head.get("all_elapsed", [elapsed])]},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
-        "data": "synthetic",
+        "data": "synthetic" if not EMULATED else "synthetic; EMULATED DEVICE (GRDMA_BENCH_EMULATED=1: the product sources on the "
+                                                 "wave emulator, CPU tensors, gloo) -- a dry run of the script, `value` is NOT a measurement",
         "value_is": "device-resident: slices in HBM before the timed region, delivered slices left in HBM "
                     "(host-slice rate through the endpoint vtable: value_endpoint_vtable)",
         "config": {"workload": "client-streaming 1 MiB payloads, 1 connection on 1xMI355X "
@@ -977,7 +1006,7 @@ def main():
     #  128 MiB stream and checksums the delivered arena against the framed messages: the checker runs on hardware)
     if not args.no_fanout and (world > 1 or not args.no_extra_legs):
         try:
-            fo = fanout_leg(g, gs, grp, torch, args, flags)
+            fo = fanout_leg(g, gs, grp, torch, args, flags, n_msgs=args.fanout_msgs)
             if rank == 0:
                 out.update(fo)
         except Exception as e:
@@ -1209,7 +1238,7 @@ def main():
     if args.conns > 1:
         # BASELINE.json configs[3] shape: many connections per GPU, 64 KiB messages, reference-default
         # 4 MiB rings; one op per connection in every launch
-        per = max(8, 2048 // args.conns)
+        per = args.conn_msgs or max(8, 2048 // args.conns)
         mc = measure(4096, max(2, args.steps // 2), 1, not args.no_verify, False, n_links=args.conns,
                      msgs_per_link=per, payload=64 * 1024)
         out["value_conns%d_64KiB_ring4096" % args.conns] = round(

@@ -28,9 +28,20 @@
 //         F <side>                                             the writable edge for the write of <side> that waits
 //         C <side>                                             grpc_endpoint_shutdown + grpc_endpoint_destroy of <side>
 //                                                              (rdma_free: Disconnect -- the peer becomes half closed)
+//         Z <side> <seed> <hdr_len> <msg_len>                  the zero-copy hook as the reference's caller would run it:
+//                                                              the body of CoreCodegen::grpc_call_allocate_send_buffer
+//                                                              (src/cpp/common/core_codegen.cc:126-142: Config's threshold,
+//                                                              PairPool::Get().Get(peer id), get_status() == kConnected,
+//                                                              AllocateSendBuffer), the HOST writes the message through
+//                                                              the pointer (GenericSerialize, proto_utils.h:78-84), then
+//                                                              SendZerocopy([header: host memory][the message: a static
+//                                                              slice over the buffer]) from the cursor until nothing more
+//                                                              goes out
 //   out:  S <sent>
 //         W | F <1 = the write completed, 0 = it waits for the writable edge> <readable size of the peer> <writable size>
 //               <HasPendingWrites>            ("F -" = nothing was waiting)
+//         Z <1 = the pool knew the id> <1 = a buffer was handed out> <bytes of every SendZerocopy ...> | <readable size of
+//               the peer> <writable size> <HasPendingWrites>
 //         E <-1 | bytes delivered> <crc32> <slices> <readable after> <writable of the peer after>      (-1 = would block)
 //         a read or write that FAILS prints -2 in place of the count and, behind the line, the error as the endpoint
 //         built it: "| <text> | fd <0 or 1: was GRPC_ERROR_INT_FD this endpoint's fd> | status <GRPC_ERROR_INT_GRPC_STATUS>
@@ -54,6 +65,7 @@
 #include "src/core/lib/channel/channel_args.h"
 #include "src/core/lib/debug/trace.h"
 #include "src/core/lib/gprpp/fork.h"
+#include "src/core/lib/ibverbs/config.h"
 #include "src/core/lib/ibverbs/pair.h"
 #include "src/core/lib/ibverbs/poller.h"
 #include "src/core/lib/iomgr/endpoint.h"
@@ -328,6 +340,57 @@ int main() {
         continue;
       }
       printf("S %llu\n", (unsigned long long)pair_send(pair[side], sl.data(), n, byte_idx));
+    } else if (op == 'Z') {
+      int side;
+      unsigned long long seed, hdr_len, msg_len;
+      if (scanf("%d %llu %llu %llu", &side, &seed, &hdr_len, &msg_len) != 4) return 3;
+      if (g_side[side].write_outstanding || closed[side]) {  // (as S: a raw Send would move a waiting write's cursor)
+        printf("Z busy\n");
+        continue;
+      }
+      // ---- core_codegen.cc:126-142, as it stands there (the `call` is replaced by the id its peer lookup returns:
+      //      grpc_call_get_peer_id = the peer string the endpoint registered its pair under, surface/call.cc:663-672)
+      void* buffer = nullptr;
+      bool known = false;
+      {
+        auto& config = grpc_core::ibverbs::Config::Get();
+        if (msg_len / 1024 >= config.get_zerocopy_threshold_kb()) {
+          auto& pair_pool = grpc_core::ibverbs::PairPool::Get();
+          const std::string peer = std::string("peer-of-") + (side ? "1" : "0");
+          auto* found = pair_pool.Get(peer);
+          known = found == pair[side];
+          if (found != nullptr && found->get_status() == grpc_core::ibverbs::PairStatus::kConnected) {
+            buffer = found->AllocateSendBuffer(msg_len);
+          }
+        }
+      }
+      printf("Z %d %d", known ? 1 : 0, buffer != nullptr ? 1 : 0);
+      if (buffer != nullptr) {
+        uint8_t* q = static_cast<uint8_t*>(buffer);
+        for (unsigned long long j = 0; j < msg_len; j++) q[j] = pat(seed, 1, j);  // <- the host serialises into the buffer
+        std::vector<uint8_t> hdr(hdr_len ? hdr_len : 1);
+        for (unsigned long long j = 0; j < hdr_len; j++) hdr[j] = pat(seed, 0, j);
+        grpc_slice sl[2];
+        memset(sl, 0, sizeof(sl));
+        sl[0].refcount = sl[1].refcount = kFakeRefcount;
+        sl[0].data.refcounted.length = hdr_len;
+        sl[0].data.refcounted.bytes = hdr.data();
+        sl[1].data.refcounted.length = msg_len;
+        sl[1].data.refcounted.bytes = q;
+        size_t idx = hdr_len ? 0 : 1, byte = 0;
+        for (int k = 0; k < 64 && idx < 2; k++) {
+          uint64_t sent = pair[side]->SendZerocopy(sl + idx, 2 - idx, byte);
+          printf(" %llu", (unsigned long long)sent);
+          if (sent == 0) break;
+          while (sent > 0) {  // the cursor walk of rdma_flush (rdma_bp_posix.cc:480-493)
+            const uint64_t room = GRPC_SLICE_LENGTH(sl[idx]) - byte;
+            if (sent >= room) { sent -= room; idx++; byte = 0; }
+            else { byte += sent; sent = 0; }
+          }
+        }
+      }
+      printf(" | %llu %llu %d\n", closed[1 - side] ? 0ull : (unsigned long long)pair[1 - side]->GetReadableSize(),
+             (unsigned long long)pair[side]->GetWritableSize(), pending_writes(pair[side]) ? 1 : 0);
     } else if (op == 'C') {
       // grpc_endpoint_shutdown + grpc_endpoint_destroy (rdma_shutdown / rdma_destroy -> rdma_free, :106-164): the pair
       // is disconnected (peer_exit in the peer's status buffer) and goes back to the pool

@@ -10,7 +10,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <stdio.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include <functional>
 #include <map>
@@ -82,11 +85,49 @@ inline void* dev_alloc(size_t n) {
   memset(p, 0xA5, n);  // device memory does not come zeroed
   return p;
 }
+// Fine-grained device memory (hipExtMallocWithFlags: the rings and connection blocks another PROCESS may map through a
+// HIP IPC handle) lives in an anonymous shared-memory file (memfd): the handle names {pid, fd, length}, the peer process
+// opens /proc/<pid>/fd/<fd> and maps the same pages -- two emulated processes then share a ring the way two processes
+// on one GPU do (tests/test_two_process_emu.py).  Nothing is left behind in /dev/shm; the pages go with the processes.
+struct shared_block { int fd; size_t len; };
+inline std::map<void*, shared_block>& shared_blocks() {
+  static std::map<void*, shared_block> m;
+  return m;
+}
+inline std::mutex& shared_mu() {
+  static std::mutex m;
+  return m;
+}
+inline void* dev_alloc_shared(size_t n) {
+  const size_t len = ((n ? n : 1) + 4095) & ~(size_t)4095;
+  const int fd = memfd_create("grdma_emu_finegrained", 0);
+  if (fd < 0 || ftruncate(fd, (off_t)len) != 0) return nullptr;
+  void* p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  if (p == MAP_FAILED) {
+    close(fd);
+    return nullptr;
+  }
+  memset(p, 0xA5, len);
+  std::lock_guard<std::mutex> lk(shared_mu());
+  shared_blocks()[p] = shared_block{fd, len};
+  return p;
+}
 inline void dev_free(void* p) {
   if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(shared_mu());
+    auto it = shared_blocks().find(p);
+    if (it != shared_blocks().end()) {
+      munmap(p, it->second.len);
+      close(it->second.fd);
+      shared_blocks().erase(it);
+      return;
+    }
+  }
   if (guard_alloc()) return;  // (kept mapped: see above)
   free(p);
 }
+struct ipc_handle { uint32_t magic; int32_t pid, fd; uint32_t pad; uint64_t len; };
 }  // namespace emu
 
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "emulated HIP error"; }
@@ -109,7 +150,10 @@ inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, s
 template <typename T>
 inline hipError_t hipMalloc(T** p, size_t n) { *p = static_cast<T*>(emu::dev_alloc(n)); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T>
-inline hipError_t hipExtMallocWithFlags(T** p, size_t n, unsigned) { return hipMalloc(p, n); }
+inline hipError_t hipExtMallocWithFlags(T** p, size_t n, unsigned) {
+  *p = static_cast<T*>(emu::dev_alloc_shared(n));
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 template <typename T>
 inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 enum { hipHostRegisterMapped = 2 };
@@ -148,9 +192,45 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hip
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
 
-inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return hipErrorNotSupported; }
-inline hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned) { return hipErrorNotSupported; }
-inline hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
+inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {
+  std::lock_guard<std::mutex> lk(emu::shared_mu());
+  auto it = emu::shared_blocks().find(p);
+  if (it == emu::shared_blocks().end()) return hipErrorNotSupported;  // (only fine-grained allocations are exportable here)
+  emu::ipc_handle v{0x454d5549u, (int32_t)getpid(), it->second.fd, 0, it->second.len};
+  static_assert(sizeof(v) <= sizeof(h->reserved), "handle fits");
+  memset(h, 0, sizeof(*h));
+  memcpy(h->reserved, &v, sizeof(v));
+  return hipSuccess;
+}
+inline std::map<void*, size_t>& emu_ipc_mappings() {
+  static std::map<void*, size_t> m;
+  return m;
+}
+inline hipError_t hipIpcOpenMemHandle(void** out, hipIpcMemHandle_t h, unsigned) {
+  emu::ipc_handle v;
+  memcpy(&v, h.reserved, sizeof(v));
+  if (v.magic != 0x454d5549u || v.pid == (int32_t)getpid()) return hipErrorNotSupported;  // (as on hardware: not where it was made)
+  char path[64];
+  snprintf(path, sizeof(path), "/proc/%d/fd/%d", v.pid, v.fd);
+  const int fd = open(path, O_RDWR);
+  if (fd < 0) return hipErrorNotSupported;
+  void* p = mmap(nullptr, v.len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return hipErrorOutOfMemory;
+  std::lock_guard<std::mutex> lk(emu::shared_mu());
+  emu_ipc_mappings()[p] = v.len;
+  *out = p;
+  return hipSuccess;
+}
+inline hipError_t hipIpcCloseMemHandle(void* p) {
+  std::lock_guard<std::mutex> lk(emu::shared_mu());
+  auto it = emu_ipc_mappings().find(p);
+  if (it != emu_ipc_mappings().end()) {
+    munmap(p, it->second);
+    emu_ipc_mappings().erase(it);
+  }
+  return hipSuccess;
+}
 inline hipError_t hipMemGetHandleForAddressRange(void*, hipDeviceptr_t, size_t, int, unsigned long long) { return hipErrorNotSupported; }
 
 // HIP graphs of kernel nodes (what csrc/grdma_pair.hip builds for a streaming job: every node carries two

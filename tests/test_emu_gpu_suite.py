@@ -122,6 +122,17 @@ def test_nic_wire_back_end_over_the_verbs_stand_in(emu_lib):
     run_gpu_tests(emu_lib, ["tests/test_zz_gpu_wire_verbs.py", "-n", "4"], 5)
 
 
+def test_two_process_gpu_tests_under_the_emulator(emu_lib):
+    """Round 6: tests/test_gpu_two_process.py with BOTH processes emulated -- the emulator keeps fine-grained device
+    memory in anonymous shared-memory files and its HIP IPC handles name them (tests/cc/hip_api_emu.h), so the server
+    process and the client process map each other's ring and connection block as two processes on one GPU do.  The
+    bootstrap over the inherited socket (48-byte Address + memory handles, rdma_bp_posix.cc:640-692, 763-784), the
+    endpoint conformance grid echoed across the process boundary on a staged wire, and GRDMA_WIRE_DIRECT encoding
+    straight into the mapped peer ring (the cross-GPU pair's code path): the world-2 stand-in of the CPU suite."""
+    run_gpu_tests(emu_lib, ["tests/test_gpu_two_process.py", "-n", "4", "-k",
+                            "(echo_between_two_processes and not gpus) or connect_checks or bootstrap_path"], 8)
+
+
 def test_pair_protocol_gpu_tests_under_the_emulator(emu_lib):
     """All of tests/test_gpu_pair_parity.py: random operation sequences in the four wire / memory modes, the golden
     traces, batched polling, the multi-record drains of k_rx_plan (chain walker, one-lane-per-record replay, bulk tier

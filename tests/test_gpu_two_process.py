@@ -66,6 +66,17 @@ def test_echo_between_two_processes_fine_grained_rings(gpu):
     assert "ok server" in outs[0][1] and "ok client" in outs[1][1]
 
 
+@pytest.mark.parametrize("ring_kib,num_bytes,write_size,slice_size", [(4096, 2000000, 100000, 8192), (64, 500000, 100000, 8192)])
+def test_echo_between_two_processes_direct_wire_into_the_mapped_peer_ring(gpu, ring_kib, num_bytes, write_size, slice_size):
+    """GRDMA_WIRE_DIRECT across a process boundary: the gather kernel of one process encodes its records STRAIGHT into
+    the other process's ring through the IPC mapping (no staging buffer, no wire step), the credit report comes back into
+    this process's connection block the same way.  This is the code path of a pair whose ends sit on two GPUs of a node
+    (the peer ring mapped over xGMI instead of over the same GPU's memory: test_echo_between_two_gpus, which needs a second
+    GPU and has never had one) -- the stand-in one GPU allows.  The small ring parks every write on credit several times."""
+    outs = run_pair(ring_kib, num_bytes, write_size, slice_size, pair_flags=4 | 2)
+    assert "ok server" in outs[0][1] and "ok client" in outs[1][1]
+
+
 def test_credit_return_across_processes_for_ten_seconds(gpu):
     """64 KiB rings: every ~32 KiB consumed the reader zero-fills what it read and posts a credit report into
     the OTHER process's connection block, and the writer reuses that space at once.  Ten seconds of echo
