@@ -93,6 +93,16 @@ def test_several_sends_per_plan_and_promised_credit_under_the_emulator(emu_lib):
                                   "(promised and (r256k_sge30 or r1m_sge64x2))"], 5)
 
 
+def test_round6_parity_cases_under_the_emulator(emu_lib):
+    """Round 6: one workgroup of the multi-workgroup drain plan declining while its neighbours accept (a record that
+    changes payload inside its encoded size: the general planner rewrites the plan in the same launch, the verdict
+    counter shows the mix); the promised-credit hand-over (here the drain's workgroups run first, so the promise is
+    always kept -- the wait that runs out is provoked on the MI355X); BASELINE configs[3] bidirectional on a ring every
+    round fills, every link against the oracle driven with the credit a round late."""
+    run_gpu_tests(emu_lib, ["tests/test_gpu_stream_job.py", "-n", "4",
+                            "-k", "(one_drain_workgroup and r8m and staged) or (runs_out and r256k) or (config3 and pairs2)"], 3)
+
+
 def test_concurrent_writer_and_poller_gpu_tests_under_the_emulator(emu_lib):
     """Records landing header-first / footer-last from a second thread while the receiver polls and reads; the
     background poller thread (one k_poll launch per pass, eventfd wakeups)."""

@@ -941,7 +941,7 @@ def test_a_promised_credit_wait_that_runs_out_gives_the_promise_up_for_the_whole
         rx.close()
 
 
-@pytest.mark.parametrize("case", [(2, 1 << 18, 30, 8, 65539), (32, 4 << 20, 4095, 64, 65539)], ids=["pairs2_r256k", "pairs32_r4m_bench"])
+@pytest.mark.parametrize("case", [(2, 1 << 18, 30, 5, 65539), (32, 4 << 20, 4095, 64, 65539)], ids=["pairs2_r256k", "pairs32_r4m_bench"])
 def test_config3_bidirectional_job_on_every_link_matches_the_oracle(gpu, case):
     """BASELINE configs[3] as bench.py times it (value_conns32_64KiB_bidi): 32 pairs, 4 MiB rings, 64 x 64 KiB messages
     in EACH direction of every pair, all 64 links in every launch of one job on the paired graph -- a ring every round
