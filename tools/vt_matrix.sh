@@ -7,15 +7,15 @@ run() {  # label, env...
   local label=$1; shift
   for k in 1 2; do
     r=$(env GRPC_PLATFORM_TYPE=RDMA_BP "$@" $R/tools/endpoint_stream 1024 1048576 1 0 2 2>/dev/null | tail -1)
-    echo "$label | $(echo "$r" | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("%6.2f GiB/s  mirror %s queued %s checked %s" % (d["GiBps"], d.get("tx_mirror"), d["writes_queued"], d["checked"]))' 2>/dev/null || echo "FAILED: $r")" >> $out
+    echo "$label | $(echo "$r" | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("%6.2f GiB/s  queued %s checked %s" % (d["GiBps"], d["writes_queued"], d["checked"]))' 2>/dev/null || echo "FAILED: $r")" >> $out
   done
 }
 for ring in 262144 4096; do
   echo "== ring $ring KiB" >> $out
-  run "mirror off rx64 (round 5)          " GRPC_RDMA_RING_BUFFER_SIZE_KB=$ring GRDMA_TX_MIRROR=0
-  for rx in 32 64 128 256; do
-    run "mirror on  rx$rx                   " GRPC_RDMA_RING_BUFFER_SIZE_KB=$ring GRDMA_HOST_RX_BLOCKS=$rx
+  run "rx64 tx16 (round 5)        " GRPC_RDMA_RING_BUFFER_SIZE_KB=$ring
+  for rx in 2 4 8 16 32 64; do
+    run "rx$rx acked                 " GRPC_RDMA_RING_BUFFER_SIZE_KB=$ring GRDMA_HOST_RX_BLOCKS=$rx GRDMA_HOST_RX_ACKED=1
   done
-  run "mirror on  rx128 rxmulti ahead4096 " GRPC_RDMA_RING_BUFFER_SIZE_KB=$ring GRDMA_HOST_RX_BLOCKS=128 GRDMA_ENDPOINT_RX_MULTI=1 GRPC_RDMA_HIP_READ_AHEAD=4096
-  run "mirror on  rx128 8M send buffers   " GRPC_RDMA_RING_BUFFER_SIZE_KB=$ring GRDMA_HOST_RX_BLOCKS=128 GRPC_RDMA_HIP_SEND_BUFFER_KB=8192
+  run "rx8 acked tx32              " GRPC_RDMA_RING_BUFFER_SIZE_KB=$ring GRDMA_HOST_RX_BLOCKS=8 GRDMA_HOST_RX_ACKED=1 GRDMA_HOST_TX_BLOCKS=32
+  run "rx8 acked tx8               " GRPC_RDMA_RING_BUFFER_SIZE_KB=$ring GRDMA_HOST_RX_BLOCKS=8 GRDMA_HOST_RX_ACKED=1 GRDMA_HOST_TX_BLOCKS=8
 done
