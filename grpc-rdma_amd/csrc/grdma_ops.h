@@ -151,9 +151,17 @@ struct grdma_watch_slot {         // device memory; one writer per word
   uint64_t drains_dbg;            // watcher: drains run for this slot (all armings)
   uint64_t pad[32 - 5 - GRDMA_WATCH_WINDOWS - sizeof(struct grdma_rx_op) / 8];
 };
+struct grdma_engine_mbox;
 struct grdma_watch_ctl {          // device memory
   uint64_t quit;                  // command workgroup: the engine incarnation that has been told to leave
-  uint64_t pad[31];
+  // Where the HOST's words of the mailbox live (cmd_seq / cmd_type / op, exit_flag, the fast lane, consumed[]): NULL = in
+  // the mailbox itself (pinned host memory: every poll of the doorbell is a PCIe read, 1.3-2 us there and back);
+  // otherwise a second grdma_engine_mbox in fine-grained DEVICE memory that the host writes through the PCIe BAR
+  // (write-combined stores + sfence: a posted write, ~0.6 us one way) and the doorbell wave polls locally.  What the
+  // engine writes (ack_seq, alive, the profiling totals, watch_alive) stays in pinned host memory, where the host
+  // polls it with plain loads.  (round 6: the unary round trip's two mailbox hops)
+  struct grdma_engine_mbox* inbox;
+  uint64_t pad[30];
   struct grdma_watch_slot slot[GRDMA_WATCH_SLOTS];
 };
 struct grdma_watch_cmd {          // pinned host memory: GRDMA_ENGINE_WATCH

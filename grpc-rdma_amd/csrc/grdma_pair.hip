@@ -97,6 +97,8 @@ thread_local std::string g_err;
 struct grdma_engine {
   std::mutex mu;         // one command in the mailbox at a time: callers on different threads queue here
   grdma_engine_mbox* mb = nullptr;
+  grdma_engine_mbox* mbi = nullptr;   // where the host writes its words: == mb, or a copy in device memory written through
+                                      // the PCIe BAR (grdma_watch_ctl::inbox; GRDMA_MBOX_BAR=0: always mb)
   hipStream_t stream = nullptr;
   bool wanted = false;   // grdma_engine_start() was called
   uint64_t seq = 0;

@@ -52,7 +52,7 @@ struct hipKernelNodeParams {
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocCoherent = 0x40000000, hipHostMallocMapped = 2, hipHostMallocNonCoherent = 0x80000000u,
        hipDeviceMallocFinegrained = 1, hipIpcMemLazyEnablePeerAccess = 1, hipMemRangeHandleTypeDmaBufFd = 1 };
-enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1, hipDeviceAttributeWallClockRate = 2 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1, hipDeviceAttributeWallClockRate = 2, hipDeviceAttributeIsLargeBar = 3 };
 
 namespace emu {
 inline std::recursive_mutex& launch_mutex() {
@@ -137,7 +137,7 @@ inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
-  *v = a == hipDeviceAttributeMultiprocessorCount ? 2 : 100000;
+  *v = a == hipDeviceAttributeMultiprocessorCount ? 2 : a == hipDeviceAttributeIsLargeBar ? 1 : 100000;  // (device memory IS host memory here)
   return hipSuccess;
 }
 inline hipError_t hipDeviceGetPCIBusId(char* s, int n, int) {
