@@ -461,7 +461,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--msgs", type=int, default=256, help="1 MiB messages per step")
+    ap.add_argument("--msgs", type=int, default=1008,
+                    help="1 MiB messages per step of the headline leg: 1008 = sixteen FULL rounds of two Sends of <= 4095 slices "
+                         "(63 messages each) -- a continuous stream has no short last round and no per-step first gather / last "
+                         "scatter; rounds 1-5 timed steps of 256 messages (four rounds of 63 and one of 4), which stays in "
+                         "the line as value_msgs256_per_step")
+    ap.add_argument("--leg-msgs", type=int, default=256, help="1 MiB messages per step of the comparison legs")
     ap.add_argument("--ring-kb", type=int,
                     default=int(os.environ.get("GRPC_RDMA_RING_BUFFER_SIZE_KB", 262144)),
                     help="ring size (GRPC_RDMA_RING_BUFFER_SIZE_KB); the reference default is 4096")
@@ -558,8 +563,9 @@ def main():
     dist = grp.dist
 
     flags = 2 if args.wire == "direct" else 0
-    wl = Workload(g, args.msgs, args.payload)
-    workloads = {(args.msgs, args.payload): [wl]}
+    wl = Workload(g, args.msgs, args.payload)                     # the headline leg's step
+    wl_leg = wl if args.leg_msgs == args.msgs else Workload(g, args.leg_msgs, args.payload)   # the comparison legs' step
+    workloads = {(args.msgs, args.payload): [wl], (args.leg_msgs, args.payload): [wl_leg]}
 
     def get_workloads(n_links, msgs_per_link, payload):
         key = (msgs_per_link, payload)
@@ -584,7 +590,7 @@ def main():
         if sends is None:
             sends = args.sends if (pipeline and n_links == 1) else 1
         wf = flags if wire_flags is None else wire_flags
-        wls = wls or get_workloads(n_links, msgs_per_link or args.msgs, payload or args.payload)
+        wls = wls or get_workloads(n_links, msgs_per_link or args.leg_msgs, payload or args.payload)
         links, keep = [], []
         prev = None
         for k, w in enumerate(wls):
@@ -704,7 +710,7 @@ def main():
         the one connection alternate, so framing / deframing of neighbouring steps run beside a job."""
         from grpc_rdma_amd import h2dev
         ring = ring_kb * 1024
-        w = wl
+        w = wl_leg
         tx, rx = g.Pair(ring, args.max_sge, flags), g.Pair(ring, args.max_sge, flags)
         g.connect_pairs(tx, rx)
         scap = len(w.lens) * 2 + 64 + w.N // 256
@@ -831,14 +837,14 @@ def main():
     if args.pipeline:
         try:
             head = measure(args.ring_kb, args.steps, args.warmup, not args.no_verify, True, pipeline=True, reps=args.reps,
-                           promise=args.promise)
+                           promise=args.promise, wls=[wl])
         except Exception as e:  # keep the line: fall back to the plain schedule and say so
             schedule = "sequential (pipelined run failed: %s)" % str(e)[:120]
     seq = None
     if head is None or not args.no_extra_legs:
         seq = measure(args.ring_kb, args.steps if head is None else max(2, args.steps // 2),
                       args.warmup if head is None else 1, not args.no_verify, head is None, pipeline=False,
-                      reps=args.reps if head is None else 1)
+                      reps=args.reps if head is None else 1, wls=[wl] if head is None else None)
     if head is None:
         head, seq = seq, None
     graph_head = head
@@ -858,7 +864,9 @@ def main():
     kname = "k_rx_apply" if dom == "rx_apply" else "k_copy"
     traffic = None
     pmc, pmc_d, pmc_stale = pmc_summary_for(args.ring_kb)
-    pmc_usable = pmc_d is not None and args.msgs == 256 and args.wire == "staged"
+    # (the summary's figure is per FULL-SIZE launch -- two Sends of 4095 slices scattered, two gathered: the same launch
+    #  whatever the number of messages per step)
+    pmc_usable = pmc_d is not None and args.wire == "staged" and args.max_sge == 4095 and args.sends == 2 and args.payload == MIB
     if pmc_usable:
         try:
             k = pmc_d["kernels"][kname]
@@ -1025,12 +1033,22 @@ def main():
     if not args.no_extra_legs and args.schedule != "engine":
         # the headline step with the slice table counted as rewritten between steps: k_tx_index inside every timed step
         try:
-            ri = measure(args.ring_kb, max(2, args.steps // 2), 1, not args.no_verify, False, pipeline=bool(args.pipeline), reindex=True)
+            ri = measure(args.ring_kb, max(2, args.steps // 2), 1, not args.no_verify, False, pipeline=bool(args.pipeline), reindex=True, wls=[wl])
             out["value_index_rebuilt_every_step"] = round(wl.user_bytes * max(2, args.steps // 2) * world / ri["elapsed"] / (1 << 30), 3)
             out["index_rebuilt_every_step_verified"] = ri["verified"]
         except Exception as e:
             out["index_rebuilt_every_step_error"] = str(e)[:200]
-    if not args.no_extra_legs and args.msgs == 256 and args.sends == 2 and args.max_sge == 4095:
+    if not args.no_extra_legs and args.leg_msgs != args.msgs:
+        # the step of rounds 1 - 5: 256 messages = four rounds of 63 and a fifth of four, with its own first gather and last
+        # scatter -- what `value` was quoted on until round 5 (same kernels, same schedule, same ring)
+        try:
+            o256 = measure(args.ring_kb, args.steps, 2, not args.no_verify, False, pipeline=bool(args.pipeline), wls=[wl_leg])
+            out["value_msgs%d_per_step" % args.leg_msgs] = round(wl_leg.user_bytes * args.steps * world / o256["elapsed"] / (1 << 30), 3)
+            out["rounds_per_step_msgs%d" % args.leg_msgs] = o256["rounds"]
+            out["msgs%d_per_step_verified" % args.leg_msgs] = o256["verified"]
+        except Exception as e:
+            out["msgs%d_per_step_error" % args.leg_msgs] = str(e)[:200]
+    if not args.no_extra_legs and args.leg_msgs == 256 and args.sends == 2 and args.max_sge == 4095:
         # A step of 256 messages is four rounds of 63 (two Sends of <= 4095 slices: 31 + 32 messages of 130) and a FIFTH of
         # four messages -- wire, planner pair and scatter launched once more for 1.5 % of the bytes.  A continuous stream has
         # no such round; the same step with 252 messages (four full rounds) shows what it costs `value`.
@@ -1056,7 +1074,7 @@ def main():
         # round (with two, a round is 63 MiB and that ring holds two of them: every other round waits for its credit)
         try:
             o1 = measure(131072, max(2, args.steps // 2), 1, not args.no_verify, False, pipeline=True, sends=1)
-            out["value_ring128m_one_send_per_round"] = round(wl.user_bytes * max(2, args.steps // 2) * world / o1["elapsed"] / (1 << 30), 3)
+            out["value_ring128m_one_send_per_round"] = round(wl_leg.user_bytes * max(2, args.steps // 2) * world / o1["elapsed"] / (1 << 30), 3)
             out["rounds_per_step_ring128m_one_send_per_round"] = o1["rounds"]
         except Exception as e:
             out["ring128m_one_send_per_round_error"] = str(e)[:200]
@@ -1066,20 +1084,20 @@ def main():
         # one after the other)
         try:
             o2 = measure(131072, max(2, args.steps // 2), 1, not args.no_verify, False, pipeline=True, sends=2, promise=True)
-            out["value_ring128m_promised_credit"] = round(wl.user_bytes * max(2, args.steps // 2) * world / o2["elapsed"] / (1 << 30), 3)
+            out["value_ring128m_promised_credit"] = round(wl_leg.user_bytes * max(2, args.steps // 2) * world / o2["elapsed"] / (1 << 30), 3)
             out["rounds_per_step_ring128m_promised_credit"] = o2["rounds"]
         except Exception as e:
             out["ring128m_promised_credit_error"] = str(e)[:200]
     if seq is not None:  # same workload and ring, five kernels per round strictly in order
         out["value_sequential"] = round(
-            wl.user_bytes * max(2, args.steps // 2) * world / seq["elapsed"] / (1 << 30), 3)
+            wl_leg.user_bytes * max(2, args.steps // 2) * world / seq["elapsed"] / (1 << 30), 3)
     if not args.no_extra_legs and args.wire == "staged":
         # GRDMA_WIRE_DIRECT: the gather writes the records straight into the peer ring
         # (HBM / xGMI peer memory), no staging copy and no wire kernel
         try:
             dr = measure(args.ring_kb, args.steps, max(2, args.warmup), not args.no_verify, False,
                          pipeline=bool(args.pipeline), wire_flags=2)
-            out["value_wire_direct"] = round(wl.user_bytes * args.steps * world / dr["elapsed"] / (1 << 30), 3)
+            out["value_wire_direct"] = round(wl_leg.user_bytes * args.steps * world / dr["elapsed"] / (1 << 30), 3)
             out["wire_direct_verified"] = dr.get("verified")
             out["config"]["wire_direct_leg"] = ("the same step with GRDMA_WIRE_DIRECT pairs: the gather writes the records straight into the peer "
                                                 "ring (HBM / xGMI peer memory), no staging copy, no wire kernel -- two launches per round "
@@ -1091,7 +1109,7 @@ def main():
         # frame -> endpoint -> deframe, all three inside the timed device pipeline
         try:
             hh = measure_with_h2(args.ring_kb, args.steps, max(2, args.warmup))
-            out["value_with_h2"] = round(wl.user_bytes * args.steps * world / hh["elapsed"] / (1 << 30), 3)
+            out["value_with_h2"] = round(wl_leg.user_bytes * args.steps * world / hh["elapsed"] / (1 << 30), 3)
             out["with_h2_verified"] = hh["verified"]
             out["with_h2_stages"] = hh["stages"]
             out["config"]["with_h2_leg"] = ("k_h2_frame_index + k_h2_frame_emit -> the job -> k_h2_deframe inside the timed pipeline, library defaults "
@@ -1107,7 +1125,7 @@ def main():
         few = max(2, args.steps // 4)
         try:  # per-stage times: the stages enqueued around the job's graph, each between two events
             hs = measure_with_h2(args.ring_kb, few, 2, fused=False)
-            out["value_with_h2_stages_around_the_graph"] = round(wl.user_bytes * few * world / hs["elapsed"] / (1 << 30), 3)
+            out["value_with_h2_stages_around_the_graph"] = round(wl_leg.user_bytes * few * world / hs["elapsed"] / (1 << 30), 3)
             for k_ in ("frame_us", "deframe_us"):
                 out["with_h2_stages"][k_] = hs["stages"][k_]
             out["with_h2_stages"]["stage_times_from"] = ("a run with GRDMA_H2_PIPE_FUSED=0 (stages enqueued around the job's "
@@ -1122,20 +1140,21 @@ def main():
             out["with_h2_ticks_error"] = err_text(e)
         try:  # the same leg with message starts left to the byte-wise automaton
             h0 = measure_with_h2(args.ring_kb, few, 2, boundary_step=False)
-            out["value_with_h2_no_boundary_step"] = round(wl.user_bytes * few * world / h0["elapsed"] / (1 << 30), 3)
+            out["value_with_h2_no_boundary_step"] = round(wl_leg.user_bytes * few * world / h0["elapsed"] / (1 << 30), 3)
             out["with_h2_no_boundary_step_deframe_us"] = h0["stages"]["deframe_us"]
         except Exception as e:
             out["with_h2_no_boundary_step_error"] = err_text(e)
         try:  # the same leg with the one-wave sequential deframer (no chunks: the default until the end of round 3)
             h1 = measure_with_h2(args.ring_kb, few, 2, chunks=False, fused=False)
-            out["value_with_h2_sequential_deframer"] = round(wl.user_bytes * few * world / h1["elapsed"] / (1 << 30), 3)
+            out["value_with_h2_sequential_deframer"] = round(wl_leg.user_bytes * few * world / h1["elapsed"] / (1 << 30), 3)
             out["with_h2_sequential_deframer_deframe_us"] = h1["stages"]["deframe_us"]
         except Exception as e:
             out["with_h2_sequential_deframer_error"] = err_text(e)
         try:  # ... and with 32 frames per bulk step (the default until round 3), in a helper process, N=1 only
             if rank == 0 and world == 1:
                 cmd = [sys.executable, os.path.abspath(__file__), "--h2-bulk-pairs-only", "--steps", str(args.steps),
-                       "--ring-kb", str(args.ring_kb), "--msgs", str(args.msgs), "--schedule", args.schedule]
+                       "--ring-kb", str(args.ring_kb), "--msgs", str(args.leg_msgs), "--leg-msgs", str(args.leg_msgs),
+                       "--schedule", args.schedule]
                 r_ = run_json(cmd, 150)
                 if "value_with_h2_bulk32" in r_:
                     out.update(r_)
@@ -1158,7 +1177,7 @@ def main():
                 # it will post: every round fills the ring, as on the sequential schedule.  Direct wire: sequential (the
                 # gather of round t + 1 writes the ring, it cannot share a launch with the scatter of round t).
                 rk = measure(4096, half, 1, not args.no_verify, False, max_sge=30, pipeline=pl, sends=64, wire_flags=wf, promise=pl)
-                out[key] = round(wl.user_bytes * half * world / rk["elapsed"] / (1 << 30), 3)
+                out[key] = round(wl_leg.user_bytes * half * world / rk["elapsed"] / (1 << 30), 3)
                 out["rounds_per_step_" + key[6:]] = rk["rounds"]
                 if key == "value_ring4096_sge30":
                     out["config"]["ring4096_sge30_leg"] = (
@@ -1169,7 +1188,7 @@ def main():
                 out[key[6:] + "_error"] = err_text(e)
         try:  # (one Send of 30 slices per round, drained at once: what the reference's loop is without rdma_flush's retries)
             rk1 = measure(4096, 2, 1, False, False, max_sge=30)
-            out["value_ring4096_sge30_one_send_per_round"] = round(wl.user_bytes * 2 * world / rk1["elapsed"] / (1 << 30), 3)
+            out["value_ring4096_sge30_one_send_per_round"] = round(wl_leg.user_bytes * 2 * world / rk1["elapsed"] / (1 << 30), 3)
         except Exception as e:
             out["ring4096_sge30_one_send_per_round_error"] = err_text(e)
         # mixed message sizes (examples/cpp/test/common.h: uniform in [1, 4 MiB - 1 KiB]), 64 messages per step
@@ -1233,7 +1252,7 @@ def main():
         out["rtt_endpoint_vtable_us"] = vt
     if small is not None:
         sm_steps = max(2, args.steps // 2)
-        out["value_ring4096"] = round(wl.user_bytes * sm_steps * world / small["elapsed"] / (1 << 30), 3)
+        out["value_ring4096"] = round(wl_leg.user_bytes * sm_steps * world / small["elapsed"] / (1 << 30), 3)
         out["rounds_per_step_ring4096"] = small["rounds"]
     if args.conns > 1:
         # BASELINE.json configs[3] shape: many connections per GPU, 64 KiB messages, reference-default
