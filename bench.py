@@ -238,10 +238,12 @@ def measured_copy_ceiling(torch, dev, nbytes=256 * MIB, reps=20):
     return out
 
 
-def cpu_baseline(wl, ring, max_sge, target_s=12.0):
+def cpu_baseline(wl, ring, max_sge, target_s=12.0, threads=1):
     """The CPU port (oracle/) timed on host cores: same slices, same ring size, full
     pair protocol + endpoint read loop, single thread (the reference is
-    single-reader/single-writer per pair)."""
+    single-reader/single-writer per pair).  threads > 1: that many connections, each on a thread of its own (the C
+    loop runs outside the interpreter lock), messages counted over the wall time of all of them -- how the reference's
+    codec scales over the host's cores when the connections are independent."""
     from oracle import pyorc
     wire = wl.expected_wire(0)
     lens = wl.lens[:wl.slices_per_msg]
@@ -254,6 +256,23 @@ def cpu_baseline(wl, ring, max_sge, target_s=12.0):
     n, sec = run(ring, max_sge, wire, lens, 16)
     per_msg = sec / 16
     n_msgs = max(16, min(400000, int(target_s / per_msg)))
+    if threads > 1:
+        import threading
+        secs = [0.0] * threads
+
+        def one(k):
+            secs[k] = run(ring, max_sge, wire, lens, n_msgs)[1]
+        ts = [threading.Thread(target=one, args=(k,)) for k in range(threads)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        sec = time.perf_counter() - t0
+        gib = (threads * n_msgs * (wl.user_bytes // wl.n_msgs)) / sec / (1 << 30)
+        return {"value": round(gib, 3), "unit": "GiB/s", "cores": threads, "kind": kind,
+                "sample": "%d connections x %d x 1 MiB messages (%d slices each) through %s, %d KiB rings, one thread per "
+                          "connection, %.1f s wall (slowest thread %.1f s)" % (threads, n_msgs, len(lens), what, ring >> 10, sec, max(secs))}
     n, sec = run(ring, max_sge, wire, lens, n_msgs)
     gib = (n_msgs * (wl.user_bytes // wl.n_msgs)) / sec / (1 << 30)
     return {"value": round(gib, 3), "unit": "GiB/s", "cores": 1, "kind": kind,
@@ -1281,6 +1300,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(wl, ring, min(args.max_sge, 4095))
         if not args.no_extra_legs:
             out["cpu_baseline_ring4096_sge30"] = cpu_baseline(wl, 4096 * 1024, 30, target_s=6.0)
+            # ... and the same codec on min(nproc, 8) cores, one connection per core: a CPU's answer to more connections is
+            # more cores, and the comparison with one GPU should say what eight of them do
+            nthr = max(1, min(os.cpu_count() or 1, 8))
+            out["cpu_baseline_ring4096_sge30_%dcores" % nthr] = cpu_baseline(wl, 4096 * 1024, 30, target_s=5.0, threads=nthr)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0 and world == 1 and not args.no_tcp_baseline:
