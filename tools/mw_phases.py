@@ -33,6 +33,8 @@ def main():
     job.set_pipeline(pipeline)
     if sends > 1:
         job.set_sends(sends)
+    if os.environ.get("MW_PROMISE") == "1":
+        job.set_promised_credit(True)
     r = job.run(gs.RUN_EAGER)
     job.set_rounds(int(max(-(-int(r.tx_rounds) // sends), r.rx_rounds)))
     for _ in range(4):
