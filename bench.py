@@ -296,7 +296,7 @@ def sources_sha16():
 def pmc_summary_for(ring_kb):
     """The newest committed counter summary for this ring size and whether it was collected from the sources this
     run is timing: -> (path or None, summary dict or None, stale: str or None)."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", "%s_pmc_ring%dm_summary.json" % (rnd, ring_kb // 1024))
         if os.path.exists(p):
             try:
