@@ -293,6 +293,14 @@ struct grdma_pair {
                                      // every other window -- the watcher waits for the word that names the next one
   // asynchronous endpoint operations (grdma_endpoint_set_async): the send and the receive direction on streams of
   // their own, one Send and one drain in flight at most, completions in pinned host memory
+  // What a peer IN THIS PROCESS that went away first has left in my care: its ring, its connection block and its state
+  // line -- my device-side connection block still names them (peer_ring, peer_status / peer_wire, peer_line), and a Send
+  // of mine that was under way, or that my owner starts before it has asked get_status(), writes there.  The reference's
+  // Send to a peer that has exited fails in the HCA (pair.cc:500-558: a work completion in error); here the memory simply
+  // outlives the peer until I go too (grdma_pair_destroy), so that write is harmless instead of a write into freed --
+  // or, with the PairPool, into somebody else's -- memory.
+  struct orphan { void* ptr; size_t bytes; int kind; };   // kind: pool_free's, 3 = a state line
+  std::vector<orphan> orphans;
   bool async = false;
   hipStream_t s_tx = nullptr, s_rx = nullptr;
   std::vector<grdma_window*> windows;   // receive windows (pinned host memory), one drain each
