@@ -433,16 +433,27 @@ __device__ __forceinline__ void rx_plan_body(const grdma_rx_op& op_in, rx_lds* s
       const uint64_t te_c = prof_time(prof) + (bytes[0] & 0);  // (payload loaded)
       // one 8-byte store per lane (the slice buffer is 16-byte aligned and `alloc` bytes long;
       // the bytes behind the slice end inside the last word are written as zero)
-      if (split) {  // (byte stores: the second slice starts at a 16-byte boundary of its own)
+      uint64_t word = 0;   // output bytes 8 * lane .. 8 * lane + 7 (zero behind T)
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint32_t b = (uint32_t)lane * 8 + q;
-          if (b < T) dst[b < L0 ? b : off1 + (b - L0)] = bytes[q];
+      for (int q = 0; q < 8; q++) word |= (uint64_t)bytes[q] << (8 * q);
+      if (split) {
+        // The second slice starts at a 16-byte boundary of its own (off1): its word k is output bytes L0 + 8 k ..., which
+        // lie in the registers of lanes (L0 >> 3) + k and the one behind it.  Both slices leave as 8-byte words, the
+        // bytes behind a slice's end inside its last word as zeros (arena padding) -- byte stores were eighty posted
+        // writes over PCIe when the arena is pinned host memory (profiles/r06_rtt_notes.txt; rxw_fast does the same).
+        const uint32_t nw0 = (L0 + 7u) >> 3, nw1 = (T - L0 + 7u) >> 3, j0 = L0 >> 3, sh = 8u * (L0 & 7u);
+        const uint32_t ja = (j0 + (uint32_t)lane) & 63u, jb = (j0 + (uint32_t)lane + 1u) & 63u;
+        const uint64_t lo = __shfl(word, (int)ja, 64);
+        uint64_t hi = __shfl(word, (int)jb, 64);
+        if (j0 + (uint32_t)lane + 1u > 63u) hi = 0;
+        const uint64_t w1 = (j0 + (uint32_t)lane > 63u) ? 0ull : (sh ? ((lo >> sh) | (hi << (64u - sh))) : lo);
+        if ((uint32_t)lane < nw0) {
+          uint64_t w0 = word;
+          if ((uint32_t)lane == nw0 - 1 && (L0 & 7u) != 0) w0 &= (1ull << sh) - 1ull;
+          *reinterpret_cast<uint64_t*>(dst + (uint32_t)lane * 8) = w0;
         }
+        if ((uint32_t)lane < nw1) *reinterpret_cast<uint64_t*>(dst + off1 + (uint32_t)lane * 8) = w1;
       } else if ((uint32_t)lane * 8 < T) {
-        uint64_t word = 0;
-#pragma unroll
-        for (int q = 0; q < 8; q++) word |= (uint64_t)bytes[q] << (8 * q);
         *reinterpret_cast<uint64_t*>(dst + (uint32_t)lane * 8) = word;
       }
       // clear what was consumed: records are 8-byte granular, [head0, head0 + E) with wrap
