@@ -10,6 +10,7 @@
 #ifndef GRDMA_DEV_H
 #define GRDMA_DEV_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #define GRDMA_ALIGN 8ull            // ring_buffer.h:49
@@ -239,10 +240,7 @@ struct grdma_plan {
   uint64_t tag_base;   // window for the record tags of GRDMA_SEG_TAG_* segments
   uint64_t tag_mask;
   uint32_t tile_bytes; // 8192 or 16384: what tile_prefix counts in (GRDMA_PLAN_TILE_SHIFT)
-  // promised credit (k_plan_pair_mw, DESIGN.md 2.9): the hand-over word between the drain's committing workgroup and
-  // the Send workgroups of the SAME launch -- 0 nothing yet, 1 kept, 2 given up (csrc/grdma_devfn.h: promise_keep /
-  // promise_wait); zero between launches.  Other kernels neither read nor write it.
-  uint32_t ready;
+  uint32_t ready;      // (unused since round 6: the hand-over word of the promised credit is `promise` below)
   struct grdma_seg segs[GRDMA_MAX_SEGS];
   uint32_t tile_prefix[GRDMA_MAX_SEGS + 1];
   // k_rx_apply arrival counter (the last workgroup commits).  It lives in the plan -- always
@@ -255,9 +253,16 @@ struct grdma_plan {
   // arrival word of the multi-workgroup receive planner (grdma_rx_multi.h): workgroups arrived in the low half,
   // workgroups that declined in the high half; zero between launches (the last workgroup to arrive clears it)
   uint32_t mw_arrive;
-  uint32_t promise_done;  // participants of the promised-credit hand-over that are through with `ready` (promise_leave)
-  uint32_t pad_line1[29];
+  uint32_t promise_done;  // participants of the promised-credit hand-over that are through with `promise` (promise_leave)
+  uint32_t pad_p;
+  // promised credit (k_plan_pair_mw, DESIGN.md 2.9): the hand-over word between the drain's committing workgroup and
+  // the Send workgroups of the SAME launch, touched by atomics only -- 0 nothing yet; bits 0-1 = 1: KEPT, and the word
+  // carries the promise itself (bit 2: the drain posts a credit, bits 3..: its head -- a ring offset, < 2^31); = 2: GIVEN
+  // UP (csrc/grdma_devfn.h: promise_keep / promise_wait); zero between launches.  Other kernels neither read nor write it.
+  uint64_t promise;
+  uint32_t pad_line1[26];
 };
+static_assert(offsetof(grdma_plan, promise) % 8 == 0, "the hand-over word is a 64-bit atomic");
 
 // A kernel node another stage hangs into a streaming job's graph (grdma_job_set_hooks, csrc/grdma_pair.hip): the
 // kernel, its launch shape and its parameters (each at most 8 bytes, one slot per parameter).

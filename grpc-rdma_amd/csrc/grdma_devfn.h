@@ -401,47 +401,56 @@ __device__ __forceinline__ plan_hdr plan_hdr_of(const uint32_t* w) {
                 "plan header layout");
   return plan_hdr{w[0], w[1], (uint64_t)w[4] | ((uint64_t)w[5] << 32), (uint64_t)w[6] | ((uint64_t)w[7] << 32), w[8]};
 }
-// Promised credit (k_plan_pair_mw): grdma_plan::ready is the hand-over word between the workgroup that
-// commits the drain of a launch and the Send workgroups of the SAME launch.  0: nothing yet; 1: the drain's result block
-// is committed and at the memory side -- the promise is KEPT; 2: a Send workgroup's bounded wait ran out first -- the
-// promise is GIVEN UP for this launch.  Both transitions start from 0 and are compare-and-swaps, so the word takes
-// exactly one of the two values per launch and every Send workgroup, whenever it looks, comes away with the same
-// answer: a wait that runs out in one workgroup can no longer split the Send between workgroups that price with the
-// promise and workgroups that price without it (ADVICE r4 / VERDICT r5).  Every participant -- the committer and each
-// Send workgroup -- counts itself out in grdma_plan::promise_done once it is through with the word; the last of the
-// H + 1 to do so zeroes both for the next launch (nobody touches them after it: a committer that comes late, behind
-// Send workgroups that all gave up, finds 2, leaves it, and is the one that clears).
+// Promised credit (k_plan_pair_mw): grdma_plan::promise is the hand-over word between the workgroup that
+// commits the drain of a launch and the Send workgroups of the SAME launch.  0: nothing yet; state 1: the drain is
+// committed -- the promise is KEPT, and the word carries it (whether the drain posts a credit, and its head); state 2: a
+// Send workgroup's bounded wait ran out first -- the promise is GIVEN UP for this launch.  Both transitions start from 0
+// and are compare-and-swaps, so the word takes exactly one value per launch and every Send workgroup, whenever it
+// looks, comes away with the same answer: a wait that runs out in one workgroup cannot split the Send between
+// workgroups that price with the promise and workgroups that price without it (ADVICE r4 / VERDICT r5).
+// (round 6) The word IS the message.  Through round 5 it was a flag over the drain's result block: the committer wrote
+// its L2 back before raising it (an agent-scope release), a Send workgroup invalidated its own L2 after seeing it (an
+// acquire) and then fetched two words of the block -- 6.6 us between the drain's last stamp and the Send's "priced"
+// stamp at the reference's default knobs (profiles/r06_plan_phases.txt), most of it those two cache operations.  A
+// device-scope atomic is carried out at the memory side whichever XCD issues it: no fence, no second round trip.
+// Every participant -- the committer and each Send workgroup -- counts itself out in grdma_plan::promise_done once it is
+// through with the word; the last of the H + 1 to do so zeroes both for the next launch (nobody touches them after it:
+// a committer that comes late, behind Send workgroups that all gave up, finds 2, leaves it, and is the one that clears).
+#define GRDMA_PROMISE_KEPT 1ull
+#define GRDMA_PROMISE_GIVEN_UP 2ull
+#define GRDMA_PROMISE_RAN_OUT (1ull << 63)  // (in promise_wait's return value only: this workgroup's wait is the one that ran out)
 __device__ __forceinline__ void promise_leave(grdma_plan* plan, uint32_t participants) {
   const uint32_t prev = __hip_atomic_fetch_add(&plan->promise_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (prev + 1 == participants) {
     __hip_atomic_store(&plan->promise_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&plan->ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&plan->promise, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-// the committing drain workgroup, thread 0, its result block written: 1 = the Send will be priced with it
-__device__ __forceinline__ uint32_t promise_keep(grdma_plan* plan, uint32_t participants) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the result block is at the memory side before the word says so)
-  uint32_t seen = 0;
-  const bool kept = __hip_atomic_compare_exchange_strong(&plan->ready, &seen, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT);
+// the committing drain workgroup, thread 0, with what the drain's scatter is going to post
+__device__ __forceinline__ uint32_t promise_keep(grdma_plan* plan, uint32_t participants, uint64_t credit_sent, uint64_t credit_head) {
+  unsigned long long seen = 0;
+  const unsigned long long word = GRDMA_PROMISE_KEPT | (credit_sent ? 4ull : 0ull) | (credit_head << 3);
+  const bool kept = __hip_atomic_compare_exchange_strong((unsigned long long*)&plan->promise, &seen, word, __ATOMIC_RELAXED,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   promise_leave(plan, participants);
   return kept ? 1u : 0u;
 }
-// a Send workgroup (all threads call it): polls at most `bound` times; 1 = kept, 0 = given up (by this workgroup or by
-// another one -- uniformly for the launch)
-__device__ __forceinline__ uint32_t promise_wait(grdma_plan* plan, uint32_t bound, uint32_t participants) {
-  __shared__ uint32_t s_word;
+// a Send workgroup (all threads call it): polls at most `bound` times; returns the word -- state 1 = kept, 2 = given up
+// (by this workgroup or by another one: uniformly for the launch)
+__device__ __forceinline__ uint64_t promise_wait(grdma_plan* plan, uint32_t bound, uint32_t participants) {
+  __shared__ uint64_t s_word;
   if (threadIdx.x == 0) {
-    uint32_t v = 0;
+    unsigned long long v = 0;
     for (uint32_t spins = 0; spins < bound; spins++) {
-      v = __hip_atomic_load(&plan->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = __hip_atomic_load((unsigned long long*)&plan->promise, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (v != 0) break;
-      __builtin_amdgcn_s_sleep(24);
+      __builtin_amdgcn_s_sleep(2);
     }
     if (v == 0) {  // the wait ran out -- a bug or a stalled drain, not a state: give the promise up for everybody
-      uint32_t seen = 0;
-      v = __hip_atomic_compare_exchange_strong(&plan->ready, &seen, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-              ? 0x80000002u   // (bit 31: this workgroup is the one whose wait ran out)
+      unsigned long long seen = 0;
+      v = __hip_atomic_compare_exchange_strong((unsigned long long*)&plan->promise, &seen, (unsigned long long)GRDMA_PROMISE_GIVEN_UP,
+                                               __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+              ? (GRDMA_PROMISE_GIVEN_UP | GRDMA_PROMISE_RAN_OUT)
               : seen;
     }
     promise_leave(plan, participants);

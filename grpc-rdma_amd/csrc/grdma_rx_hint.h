@@ -37,8 +37,34 @@ struct rx_lds_hint {
   uint32_t x[RXH_MAX + 1];      // exclusive prefix of the encoded sizes
 };
 
+// (round 6) The table's header and this thread's sixteen sizes, REQUESTED when the launch begins -- beside the connection
+// state the periodic body (rxm_body) asks for, before that body has found out that the connection has no period: the
+// table's address is in the op, its words do not depend on anything the drain reads first.  What used to be two more
+// dependent round trips behind rxm_body's (the header, then the sizes clamped by its count: 4.7 us of this body's 14,
+// profiles/r06_plan_phases.txt) is in flight with the first.  The sizes are read unclamped -- the table has
+// GRDMA_TX_MAX_RECORDS entries whatever its count says -- and the entries behind the count are zeroed below as before.
+struct rxh_pre {
+  uint32_t nv[RXH_MAX / RXM_THREADS];
+  uint32_t V;
+  uint64_t h_start;
+};
+__device__ __forceinline__ void rxh_preload(const grdma_rx_op& op, rxh_pre& p) {
+  constexpr uint32_t PER = RXH_MAX / RXM_THREADS;
+  const grdma_size_hint* const hint = op.sizes_in;
+  p.V = 0;
+  p.h_start = ~0ull;
+#pragma unroll
+  for (uint32_t r = 0; r < PER; r++) p.nv[r] = 0;
+  if (hint != nullptr) {  // (uniform)
+    p.h_start = hint->start_off;
+    p.V = hint->count;
+#pragma unroll
+    for (uint32_t r = 0; r < PER; r++) p.nv[r] = hint->n[threadIdx.x * PER + r];
+  }
+}
+
 template <bool WT = false, bool EWT = WT>  // (WT, EWT: see rxm_body)
-__device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg) {
+__device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg, const rxh_pre* pre = nullptr) {
   static_assert(sizeof(rx_lds_hint) <= sizeof(rx_lds) && sizeof(rx_lds_hint) <= RXM_SMALL_LDS_BYTES, "the tables fit their LDS");
   rx_lds_hint& H = *reinterpret_cast<rx_lds_hint*>(rx_tables<WT>());
   const grdma_rx_op op = op_in;
@@ -61,8 +87,8 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
   const uint64_t slice_idx0 = op.append == 1 ? c->rx_slice_idx : 0;
   const uint64_t a_off0 = op.append == 1 ? c->rx_arena_off : 0;
   const grdma_size_hint* const hint = op.sizes_in;
-  const uint64_t h_start = hint ? hint->start_off : ~0ull;
-  const uint32_t V = hint ? hint->count : 0;
+  const uint64_t h_start = pre ? pre->h_start : (hint ? hint->start_off : ~0ull);
+  const uint32_t V = pre ? pre->V : (hint ? hint->count : 0);
 
   bool ok = status == GRDMA_PAIR_CONNECTED && op.raw_cap == 0 && op.append != 0 && !op.inline_apply &&
             op.limit_ptr != nullptr && remain0 == 0 && leftover0 <= RXF_MINRD && cap64 <= (1ull << 31) &&
@@ -91,7 +117,7 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
     uint32_t nv[PER];
     const uint32_t i0 = tid * PER;
 #pragma unroll
-    for (uint32_t r = 0; r < PER; r++) nv[r] = hint->n[i0 + r < V ? i0 + r : 0];  // (clamped: all loads in flight)
+    for (uint32_t r = 0; r < PER; r++) nv[r] = pre ? pre->nv[r] : hint->n[i0 + r < V ? i0 + r : 0];  // (clamped: all loads in flight)
     uint32_t sum = 0;
     bool bad = false;
 #pragma unroll

@@ -48,6 +48,23 @@ __device__ __forceinline__ uint32_t txm_count(bool flag, uint32_t* s_cnt) {
   return n;
 }
 
+// (round 6) The index window: entries [start, start + m] of the slice table's three prefix arrays, copied into LDS by one
+// round of loads before a pricing looks at the credit.  A pricing used to be a chain of dependent round trips to the
+// index -- the first search level, the second, the short record, the totals, the last Send of a folded round: 4-5 of
+// them, 6-7 us behind the promised credit at the reference's default knobs -- and every one of them is a look-up in
+// these 40 KB now.  m >= TXM_WIN (a job with more records per Send than that): the look-ups go to memory as before.
+#define TXM_WIN 2048u
+struct txm_win {
+  uint64_t enc[TXM_WIN], len[TXM_WIN];
+  uint32_t tile[TXM_WIN];
+};
+
+// What a launch's drain promises its Send (the hand-over word of the plan, csrc/grdma_devfn.h)
+struct txm_promise {
+  bool kept;
+  uint64_t credit_sent, credit_head;
+};
+
 // What one Send of the round was priced at (uniform over the workgroup, and the same in every workgroup).
 struct txm_send {
   uint64_t tail0, start, byte_idx, offered;  // the state in front of it: remote_tail_, the rdma_flush cursor, what the write still holds
@@ -80,8 +97,17 @@ struct txm_send {
 // publishes them once the bytes are free -- and the Send is priced with it: nothing of this Send touches the ring
 // before that scatter has run (the gather fills the staging buffer; the wire kernel is the launch behind the
 // scatter's), so the round sees the credit the sequential schedule would give it, a round earlier than the paired one.
+// (round 6) The promise is fetched through `wait_promise` -- a callable that returns what the drain of this launch is
+// going to post once it is committed, or kept = false (no promise in this launch, or given up) -- and it is CALLED from inside the first pricing, behind
+// everything that pricing loads without knowing the credit: the connection's state, the index entry of the cursor, the
+// 256 samples of the first search level, the encoded sizes of the folded Sends, the payload prefix of the cursor.  Those
+// round trips used to begin when the wait was over (the planner launch at the reference's default knobs: 24.5 us of
+// kernel time, the drain plan's 14.7 followed by the Send's 6.6, profiles/r06_plan_phases.txt); now they are in flight
+// while the Send's workgroups wait, and what is left behind the wait is the second search level, the short record and
+// the totals.
+template <class WaitFn>
 __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_txf_ctl* ctl, const uint32_t wg, const uint32_t nwg,
-                                        const grdma_rx_result* promised = nullptr) {
+                                        WaitFn wait_promise, txm_win* const W = nullptr) {
   const grdma_tx_op op = op_in;
   const uint64_t t_begin = __builtin_amdgcn_s_memtime();
   const uint32_t tid = threadIdx.x;
@@ -113,12 +139,18 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
   // (that the workgroups cover the records offered is checked per pricing: m <= nwg x 256)
   // get_remote_head(), pair.h:229-233
   uint64_t rhead = __hip_atomic_load(&c->status_recv.remote_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (promised != nullptr) {
+  const uint64_t tail_at_start = c->remote_tail;
+  bool promise_pending = true;
+  auto take_promise = [&]() {  // (uniform: every thread of every workgroup of the Send comes away with the same head)
+    if (!promise_pending) return;
+    promise_pending = false;
+    const txm_promise promised = wait_promise();
+    if (!promised.kept) return;
     const bool first = wg == 0 && tid == 0;
-    if (xwg_ld64<true>(&promised->credit_sent) != 0) {
+    if (promised.credit_sent != 0) {
       // (a head between the one posted so far and remote_tail_: a drain that found nothing leaves an older result block)
-      const uint64_t ph = xwg_ld64<true>(&promised->credit_head), tail_now = c->remote_tail;
-      if (((ph - rhead) & mask) <= ((tail_now - rhead) & mask)) {
+      const uint64_t ph = promised.credit_head;
+      if (((ph - rhead) & mask) <= ((tail_at_start - rhead) & mask)) {
         rhead = ph;
         if (first) atomicAdd(&g_tx_promise[0], 1ull);
       } else if (first) {
@@ -127,8 +159,22 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     } else if (first) {
       atomicAdd(&g_tx_promise[1], 1ull);
     }
-  }
+  };
   const uint32_t max_sge = c->max_sge;
+  // (what the committing workgroup adds to, and the entries of "my" record if it belongs to the first Send: requested now)
+  const uint64_t o_written = c->total_written, o_records = c->tx_records, o_rounds = c->tx_rounds;
+  const uint64_t o_seq = op.result->seq;
+  const uint64_t start0 = op.use_cursor == 1 ? c->tx_slice_idx : 0, bidx0 = op.use_cursor == 1 ? c->tx_byte_idx : 0;
+  const uint64_t gi = (uint64_t)wg * TXM_THREADS + tid;
+  const bool pre_mine = ok && start0 + gi < n;
+  grdma_sge g_pre = {};
+  uint64_t e_pre = 0;
+  uint32_t tp_pre = 0;
+  if (pre_mine) {
+    g_pre = op.slices[start0 + gi];
+    e_pre = enc_pre[start0 + gi];
+    tp_pre = tile_pre[start0 + gi];
+  }
   const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap);
   const uint64_t TB = 1ull << ts;
   uint8_t* const staging = op.staging_alt ? op.staging_alt : c->staging;
@@ -151,68 +197,106 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     if (m > m_cap) q.declined = true;  // (more records than the workgroups of this launch cover: uniform)
     if (q.declined) m = 0;
     q.m = m;
-    const grdma_sge* sl = op.slices + start;
-    const uint64_t occupied0 = (tail0 + cap - rhead) & mask;
-    const uint64_t free0 = cap - occupied0;
-    // (several Sends folded: the free space is what binds; that no single Send exceeds staging_cap is checked below)
-    const uint64_t room0 = (ns == 1 && S < free0) ? S : free0;
+    // ---- the index window (or, m >= TXM_WIN, loads): everything this pricing reads of the index WITHOUT knowing the
+    //      credit is requested here -- for the first pricing of a launch with a promise, while the drain's workgroups
+    //      are still at work
+    const bool win = W != nullptr && m != 0 && m < TXM_WIN;  // (uniform)
+    if (W != nullptr) __syncthreads();  // (the pricing in front of this one has read the window)
+    if (win) {
+      constexpr uint32_t NR = TXM_WIN / TXM_THREADS;
+      uint64_t ve[NR], vl[NR];
+      uint32_t vt[NR];
+#pragma unroll
+      for (uint32_t r = 0; r < NR; r++) {
+        const uint64_t k = tid + r * TXM_THREADS, kk = k <= m ? k : m;
+        ve[r] = enc_pre[start + kk];
+        vl[r] = len_pre[start + kk];
+        vt[r] = tile_pre[start + kk];
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < NR; r++) {
+        const uint64_t k = tid + r * TXM_THREADS;
+        if (k <= m) {
+          W->enc[k] = ve[r];
+          W->len[k] = vl[r];
+          W->tile[k] = vt[r];
+        }
+      }
+      __syncthreads();
+    }
+    auto E = [&](uint64_t k) -> uint64_t { return win ? W->enc[k] : enc_pre[start + k]; };
+    auto Lp = [&](uint64_t k) -> uint64_t { return win ? W->len[k] : len_pre[start + k]; };
+    auto Tp = [&](uint64_t k) -> uint32_t { return win ? W->tile[k] : tile_pre[start + k]; };
+    const uint64_t step = (m + TXM_THREADS - 1) / TXM_THREADS;  // <= 16
+    const uint64_t k_s = ((uint64_t)tid + 1) * step - 1;
+    const bool in_s = m != 0 && k_s < m;
+    const uint64_t kk_s = in_s ? k_s : 0;
+    const uint64_t e0_s = m ? E(kk_s) : 0, e1_s = m ? E(kk_s + 1) : 0;
+    const uint64_t a_f = (uint64_t)tid * msge, b_f = a_f + msge < m ? a_f + msge : m;
+    const bool in_f0 = ns > 1 && a_f < m;
+    const uint64_t ea_f = in_f0 ? E(a_f) : 0, eb_f = in_f0 ? E(b_f) : 0;
+    const uint64_t lp_start = m ? Lp(0) : 0;
     // the first slice may have been sent in part: its record is shorter than the index says
     if (m) {
-      const uint64_t len0 = sl[0].len, l0 = sat_sub(len0, byte_idx);
-      q.base_e = enc_pre[start];
-      q.base_t = tile_pre[start];
-      q.D = enc_size(l0) - (enc_pre[start + 1] - q.base_e);              // (<= 0 as a signed number; modular arithmetic)
-      q.Dt = ((l0 + TB - 1) >> ts) - (tile_pre[start + 1] - q.base_t);
+      const uint64_t len0 = Lp(1) - lp_start, l0 = sat_sub(len0, byte_idx);
+      q.base_e = E(0);
+      q.base_t = Tp(0);
+      q.D = enc_size(l0) - (E(1) - q.base_e);              // (<= 0 as a signed number; modular arithmetic)
+      q.Dt = ((l0 + TB - 1) >> ts) - (Tp(1) - q.base_t);
     }
     const uint64_t base_e = q.base_e, D = q.D;
     // st_i(k): staging offset of record k of this Send; st_n(k): where record k ends
     auto st_i_of = [&](uint64_t k, uint64_t e_k) -> uint64_t { return k == 0 ? 0 : e_k - base_e + D; };
-    // ---- whole records (st_n + 8 <= room0) and records that start in front of the ring end (direct wire): two
-    //      monotone predicates, one two-level search over the index
-    const uint64_t step = (m + TXM_THREADS - 1) / TXM_THREADS;  // <= 16
-    uint32_t c_whole, c_front;
+    // ---- records that start in front of the ring end (direct wire): a monotone predicate the credit has no part in --
+    //      both levels of its search
+    uint64_t nfront;
     {
-      const uint64_t k = ((uint64_t)tid + 1) * step - 1;
-      const bool in = m != 0 && k < m;
-      const uint64_t kk = in ? k : 0;
-      const uint64_t e0 = m ? enc_pre[start + kk] : 0, e1 = m ? enc_pre[start + kk + 1] : 0;
-      const bool whole = in && (e1 - base_e + D) + 8 <= room0;
-      const bool front = in && tail0 + st_i_of(kk, e0) + 8 < cap;
-      c_whole = txm_count(whole, s_cnt);
-      c_front = txm_count(front, s_cnt);
+      const bool front = in_s && tail0 + st_i_of(kk_s, e0_s) + 8 < cap;
+      const uint64_t lo_f = (uint64_t)txm_count(front, s_cnt) * step;
+      const uint64_t kf = lo_f + tid;
+      const bool in_f = tid < step && kf < m;
+      const uint64_t e0f = in_f ? E(kf) : 0;
+      const bool front2 = in_f && tail0 + st_i_of(kf, e0f) + 8 < cap;
+      nfront = lo_f + txm_count(front2, s_cnt);
     }
-    uint64_t nrec, nfront;
+    // ---- the credit: the head posted so far, or -- first pricing of a launch with a promise -- the head the drain of
+    //      this launch is going to post (the wait is here)
+    take_promise();
+    const uint64_t occupied0 = (tail0 + cap - rhead) & mask;
+    const uint64_t free0 = cap - occupied0;
+    // (several Sends folded: the free space is what binds; that no single Send exceeds staging_cap is checked below)
+    const uint64_t room0 = (ns == 1 && S < free0) ? S : free0;
+    // ---- whole records (st_n + 8 <= room0): a monotone predicate, a two-level search over the index
+    uint64_t nrec;
     {
-      const uint64_t lo_w = (uint64_t)c_whole * step, lo_f = (uint64_t)c_front * step;
-      const uint64_t kw = lo_w + tid, kf = lo_f + tid;
-      const bool in_w = tid < step && kw < m, in_f = tid < step && kf < m;
-      const uint64_t e1w = in_w ? enc_pre[start + kw + 1] : 0;
-      const uint64_t e0f = in_f ? enc_pre[start + kf] : 0;
-      const bool whole = in_w && (e1w - base_e + D) + 8 <= room0;
-      const bool front = in_f && tail0 + st_i_of(kf, e0f) + 8 < cap;
-      nrec = lo_w + txm_count(whole, s_cnt);
-      nfront = lo_f + txm_count(front, s_cnt);
+      const bool whole = in_s && (e1_s - base_e + D) + 8 <= room0;
+      const uint64_t lo_w = (uint64_t)txm_count(whole, s_cnt) * step;
+      const uint64_t kw = lo_w + tid;
+      const bool in_w = tid < step && kw < m;
+      const uint64_t e1w = in_w ? E(kw + 1) : 0;
+      const bool whole2 = in_w && (e1w - base_e + D) + 8 <= room0;
+      nrec = lo_w + txm_count(whole2, s_cnt);
     }
     q.nrec = nrec;
     // ---- (folded) no Send of the round may be bound by its own staging budget: Send t is the slices
     //      [t msge, (t + 1) msge) -- thread t looks at its encoded size, one round trip
     uint64_t st_send0 = 0;  // st of the first record of the Send the short record belongs to
     if (ns > 1) {
-      const uint64_t a = (uint64_t)tid * msge, b = a + msge < m ? a + msge : m;
-      const bool in = a < m;
-      const uint64_t ea = in ? enc_pre[start + a] : 0, eb = in ? enc_pre[start + b] : 0;
+      const uint64_t a = a_f;
+      const bool in = in_f0;
+      const uint64_t ea = ea_f, eb = eb_f;
       const uint64_t sz = in ? (eb - ea + (a == 0 ? D : 0)) : 0;
       const bool over = in && sz + 8 > S;
       if (txm_count(over, s_cnt) != 0 || ns > TXM_THREADS) q.declined = true;
       const uint64_t j0 = (nrec / msge) * msge;
-      st_send0 = (m && j0 < m) ? st_i_of(j0, enc_pre[start + j0]) : 0;
+      st_send0 = (m && j0 < m) ? st_i_of(j0, E(j0)) : 0;
     }
     // ---- the short record behind the whole ones, the record that may cross the ring end: uniform loads, one round trip
     {
       const uint64_t wi = nfront ? nfront - 1 : 0;  // the last record that starts in front of the ring end
       const bool has_short = nrec < m;
-      const uint64_t len_s = has_short ? sl[nrec].len : 0, e_s = m ? enc_pre[start + (nrec < m ? nrec : m)] : 0;
-      const uint64_t len_w = (direct && nfront) ? sl[wi].len : 0, e_w = (direct && nfront) ? enc_pre[start + wi] : 0;
+      const uint64_t len_s = has_short ? Lp(nrec + 1) - Lp(nrec) : 0, e_s = m ? E(nrec < m ? nrec : m) : 0;
+      const uint64_t len_w = (direct && nfront) ? Lp(wi + 1) - Lp(wi) : 0, e_w = (direct && nfront) ? E(wi) : 0;
       q.st_short = m ? st_i_of(nrec, e_s) : 0;  // st(nrec): where the short record starts, or st(m) = the end of the Send
       if (has_short) {
         // (pay = min(len, W(S - st), W(free0 - st)): it did not fit whole)
@@ -235,12 +319,11 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     }
     // ---- totals behind the whole records (two uniform loads), the rdma_flush cursor walk (rdma_bp_posix.cc:480-493)
     q.nrec_total = nrec + (q.short_pay > 0 ? 1 : 0);
-    const uint64_t lp_start = m ? len_pre[start] : 0;
     q.sent = q.short_pay;
     q.ntiles = (q.short_pay + TB - 1) >> ts;
     if (nrec) {
-      q.sent += len_pre[start + nrec] - lp_start - byte_idx;
-      q.ntiles += tile_pre[start + nrec] - q.base_t + q.Dt;
+      q.sent += Lp(nrec) - lp_start - byte_idx;
+      q.ntiles += Tp(nrec) - q.base_t + q.Dt;
     }
     q.ntiles += q.wrap_extra;
     q.staged = (nrec || q.short_pay) ? q.st_short + (q.short_pay > 0 ? enc_size(q.short_pay) : 0) : 0;
@@ -256,8 +339,8 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     if (ns > 1 && q.nrec_total) {
       const uint64_t s_last = (q.nrec_total - 1) / msge, j0 = s_last * msge;  // the last Send that carried records
       q.sends_nonempty = s_last + 1;
-      const uint64_t st0 = j0 ? st_i_of(j0, enc_pre[start + j0]) : 0;
-      const uint64_t sent0 = j0 ? len_pre[start + j0] - lp_start - byte_idx : 0;
+      const uint64_t st0 = j0 ? st_i_of(j0, E(j0)) : 0;
+      const uint64_t sent0 = j0 ? Lp(j0) - lp_start - byte_idx : 0;
       if (q.idx < n && q.sends_nonempty < ns) {  // data is left and so is a Send: it finds the ring full and sends nothing
         q.last_tail0 = q.new_tail; q.last_staged = 0; q.last_sent = 0; q.last_offered = offered - q.sent; q.last_records = 0;
       } else {
@@ -279,7 +362,7 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     if (ok && k < NS) {  // (uniform)
       if (k == 0) {
         const uint64_t remaining = c->tx_remaining;
-        Q[0] = price(c->remote_tail, op.use_cursor == 1 ? c->tx_slice_idx : 0, op.use_cursor == 1 ? c->tx_byte_idx : 0,
+        Q[0] = price(tail_at_start, start0, bidx0,
                      op.use_cursor == 1 ? remaining : len_pre[n], FOLD, (uint64_t)nwg * TXM_THREADS / NS);
         performed = 1;
       } else if (Q[k - 1].performed && Q[k - 1].idx < n) {  // the write still holds data: rdma_flush sends again
@@ -292,6 +375,7 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     tile0[k + 1] = tile0[k] + Q[k].ntiles;
     stg0[k + 1] = stg0[k] + Q[k].staged;
   }
+  take_promise();  // (a body that priced nothing -- not ok -- still counts itself out of the hand-over: uniform)
   bool declined = false;  // (a pricing met what it does not take: in every workgroup alike)
 #pragma unroll
   for (uint32_t k = 0; k < TXM_MAX_SENDS; k++) declined |= Q[k].performed && Q[k].declined;
@@ -300,7 +384,6 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
   const uint64_t t_priced = __builtin_amdgcn_s_memtime();
 
   // ---- my record: its segment and tile-prefix entry (AppendHeader / AppendFooter ride on the segment), as txf_body
-  const uint64_t gi = (uint64_t)wg * TXM_THREADS + tid;
   if (ok && gi < nrec_all) {
     // (which Send the record belongs to: selected field by field, the Sends stay in registers)
     txm_send q = Q[0];
@@ -312,9 +395,10 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
         rec_k = rec0[kk]; seg_k = seg0[kk]; tile_k = tile0[kk]; stg_k = stg0[kk];
       }
     const uint64_t i = gi - rec_k;
-    const grdma_sge g = op.slices[q.start + i];
-    const uint64_t e0 = enc_pre[q.start + i];
-    const uint32_t tp0 = tile_pre[q.start + i];
+    const bool mine_pre = pre_mine && q.start + i == start0 + gi;  // (a record of the first Send)
+    const grdma_sge g = mine_pre ? g_pre : op.slices[q.start + i];
+    const uint64_t e0 = mine_pre ? e_pre : enc_pre[q.start + i];
+    const uint32_t tp0 = mine_pre ? tp_pre : tile_pre[q.start + i];
     const uint64_t st_i = i == 0 ? 0 : e0 - q.base_e + q.D;
     const uint64_t p = i == q.nrec ? q.short_pay : (i == 0 ? sat_sub(g.len, q.byte_idx) : g.len);
     const uint64_t tagw = GRDMA_SEG_TAG_WRITE | (p << GRDMA_SEG_TAG_LEN_SHIFT);
@@ -361,8 +445,6 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     return 2;
   }
   if (tid == 0) {
-    const uint64_t o_written = c->total_written, o_records = c->tx_records, o_rounds = c->tx_rounds;
-    const uint64_t o_seq = op.result->seq;
     txm_send L = Q[0];  // the last Send performed: the state it leaves, its result
 #pragma unroll
     for (uint32_t kk = 1; kk < TXM_MAX_SENDS; kk++)
@@ -453,6 +535,15 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     __hip_atomic_store(&r->seq, nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   return 1;
+}
+
+// (no promise in this launch / the caller has the drain's result block already)
+__device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_txf_ctl* ctl, const uint32_t wg, const uint32_t nwg,
+                                        const grdma_rx_result* promised = nullptr) {
+  return txm_body(op_in, ctl, wg, nwg, [promised]() -> txm_promise {
+    if (promised == nullptr) return txm_promise{false, 0, 0};
+    return txm_promise{true, xwg_ld64<true>(&promised->credit_sent), xwg_ld64<true>(&promised->credit_head)};
+  }, (txm_win*)nullptr);
 }
 
 }  // namespace
