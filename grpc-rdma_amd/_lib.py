@@ -131,6 +131,9 @@ SIGNATURES = {
     "grdma_debug_set_promise_wait": (C.c_int, [C.c_uint32]),
     "grdma_tx_fast_sends": (C.c_int, [u64p]),
     "grdma_tx_promise_counts": (C.c_int, [u64p]),
+    "grdma_wire_wait_runouts": (u64, []),
+    "grdma_stream_job_set_fused_wire": (C.c_int, [C.c_void_p, C.c_int]),
+    "grdma_stream_job_wire_groups": (C.c_uint32, [C.c_void_p]),
 }
 
 _lib = None

@@ -15,6 +15,10 @@
 #ifndef GRDMA_WAIT_VMEM
 #define GRDMA_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
+// ... and every LOAD of the wave has returned as well, scalar ones included
+#ifndef GRDMA_WAIT_LOADS
+#define GRDMA_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#endif
 // A point every lane of the wave reaches before any lane goes on.  Nothing on the GPU, where a wave's
 // lanes execute an instruction together; the host emulation (one coroutine per lane) meets here, so that a
 // value one lane stores behind this point is not seen by a lane that has yet to load it in front of it.

@@ -63,8 +63,9 @@ __device__ __forceinline__ void rxh_preload(const grdma_rx_op& op, rxh_pre& p) {
   }
 }
 
-template <bool WT = false, bool EWT = WT>  // (WT, EWT: see rxm_body)
-__device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg, const rxh_pre* pre = nullptr) {
+template <bool WT = false, bool EWT = WT, class RingWait = ring_ready_now, class Publish = credit_unpublished>  // (see rxm_body)
+__device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg, const rxh_pre* pre = nullptr,
+                                        RingWait* ring_wait = nullptr, Publish* publish = nullptr) {
   static_assert(sizeof(rx_lds_hint) <= sizeof(rx_lds) && sizeof(rx_lds_hint) <= RXM_SMALL_LDS_BYTES, "the tables fit their LDS");
   rx_lds_hint& H = *reinterpret_cast<rx_lds_hint*>(rx_tables<WT>());
   const grdma_rx_op op = op_in;
@@ -140,6 +141,7 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
     if (s_bad || H.x[V] != Lr) reason = 2;  // the table does not end where the sender's tail is
   }
   const uint64_t t_pattern = __builtin_amdgcn_s_memtime();
+  if (ring_wait != nullptr) (*ring_wait)();
 
   // ---- 2. one round trip: header and footer of my record
   const uint32_t i_mine = wg * RXM_CHUNK + tid;
@@ -365,6 +367,7 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
       crossed = true;
       thr = base + T;
     }
+    if (publish != nullptr) (*publish)(credit, credit_head);
     const uint64_t irs = crossed ? Ctot - base : irs0 + Ctot;
     const uint64_t nh = (head64 + Lr) & (cap64 - 1);
     if (short_len) {

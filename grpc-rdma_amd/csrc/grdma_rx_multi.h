@@ -125,6 +125,61 @@ __device__ __forceinline__ void* rx_tables() {
   return rx_lds_get();
 }
 
+// Wire inside the planner pair's launch (k_plan_pair_mw; a job of few links with small rings): the wire's
+// workgroups -- the lowest blockIdx.y, dispatched first -- move the round into the peer ring, write their L2 back and
+// count in at the WIRE plan's arrival word; the drain's workgroups do everything that does not look at the ring, then
+// wait here for all of them.  Every drain workgroup of the launch calls this exactly once (all threads); the last one
+// through zeroes the words for the next launch.  A wait that runs out is counted (g_wire_wait_runout: a test reads it)
+// and the drain goes on -- it delivers what the ring holds, as it always does.
+__device__ unsigned long long g_wire_wait_runout = 0;
+__device__ __forceinline__ void wire_arrive(grdma_plan* wp) {  // (thread 0 of a wire workgroup, behind a barrier)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __hip_atomic_fetch_add(&wp->mw_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wire_wait(grdma_plan* wp, uint32_t wire_groups, uint32_t participants) {
+  if (threadIdx.x == 0) {
+    bool seen = false;
+    for (uint32_t spins = 0; spins < (1u << 22) && !seen; spins++) {
+      seen = __hip_atomic_load(&wp->mw_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wire_groups;
+      if (!seen) __builtin_amdgcn_s_sleep(2);
+    }
+    if (!seen) atomicAdd(&g_wire_wait_runout, 1ull);
+    const uint32_t prev = __hip_atomic_fetch_add(&wp->promise_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1 == participants) {
+      __hip_atomic_store(&wp->promise_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&wp->mw_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+}
+// (what a drain body calls before it looks at the ring for the first time)
+struct ring_ready_now {
+  __device__ __forceinline__ void operator()() {}
+};
+struct ring_behind_wire {
+  grdma_plan* wp;
+  uint32_t wire_groups, participants;
+  bool done;
+  __device__ __forceinline__ void operator()() {
+    if (wp != nullptr && !done) wire_wait(wp, wire_groups, participants);  // (uniform)
+    done = true;
+  }
+};
+// (what the committing thread of a drain body calls with the credit the drain posts, as soon as it is known -- before
+//  the body's bookkeeping: the promised credit of a launch, csrc/grdma_devfn.h promise_keep)
+struct credit_unpublished {
+  __device__ __forceinline__ void operator()(uint64_t, uint64_t) {}
+};
+struct credit_promised {
+  grdma_plan* plan;
+  uint32_t participants;
+  bool done;
+  __device__ __forceinline__ void operator()(uint64_t credit_sent, uint64_t credit_head) {
+    if (plan != nullptr && !done) (void)promise_keep(plan, participants, credit_sent, credit_head);
+    done = true;
+  }
+};
+
 // Returns 0: not the last workgroup of this drain to arrive (nothing more to do); 1: the last one, the drain is
 // committed; 2: the last one, and a workgroup declined -- the caller runs the general planner; 3: every workgroup alike
 // found the connection without a usable period and the round carries a size table -- the caller runs rxh_body (every
@@ -137,8 +192,12 @@ __device__ __forceinline__ void* rx_tables() {
 // planner IN THE SAME LAUNCH when some workgroup declined (k_plan_pair_mw, k_rx_plan_mw) need it: that planner rewrites
 // the same slots from index 0, and entries left dirty in another XCD's L2 by a workgroup whose own probe passed would
 // be written back over them, or not, in no defined order when the kernel ends.
-template <bool WT = false, bool EWT = WT>
-__device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg) {
+// ring_wait (may be null): called once by every thread, before the body looks at the ring for the first time -- the
+// wire of the round may share the launch (ring_behind_wire); a body that returns 3 has not called it.
+// publish (may be null): called by the committing thread with the credit of the drain (credit_promised).
+template <bool WT = false, bool EWT = WT, class RingWait = ring_ready_now, class Publish = credit_unpublished>
+__device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg, RingWait* ring_wait = nullptr,
+                                        Publish* publish = nullptr) {
   static_assert(sizeof(rx_lds_multi) <= sizeof(rx_lds) && sizeof(rx_lds_multi) <= RXM_SMALL_LDS_BYTES, "the tables fit their LDS");
   rx_lds_multi& M = *reinterpret_cast<rx_lds_multi*>(rx_tables<WT>());
   const grdma_rx_op op = op_in;
@@ -245,6 +304,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   // been looked at and before anyone has arrived -- the caller may try the body that predicts from the Send's own size
   // table instead (grdma_rx_hint.h); nothing has been written, nothing counted.
   if (reason && !idle && op.sizes_in != nullptr) return 3;
+  if (ring_wait != nullptr) (*ring_wait)();
 
   // ---- 2. one round trip: header and footer of my record, header of pattern record `tid`
   const uint32_t i_mine = wg * RXM_CHUNK + tid;
@@ -695,6 +755,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
       crossed = true;
       thr = base + T;
     }
+    if (publish != nullptr) (*publish)(credit, credit_head);
     const uint64_t t_credit = __builtin_amdgcn_s_memtime();
     const uint64_t irs = crossed ? Ctot - base : irs0 + Ctot;
     const uint64_t nh = (head64 + Lr) & (cap64 - 1);

@@ -1675,6 +1675,11 @@ extern "C" __attribute__((visibility("hidden"))) uint32_t grdma_tx_multi_seq_sen
 extern "C" int grdma_debug_set_promise_wait(uint32_t v) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_promise_wait_dbg), &v, sizeof(v)) == hipSuccess ? 0 : -1;
 }
+extern "C" uint64_t grdma_wire_wait_runouts(void) {
+  unsigned long long v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_wire_wait_runout), sizeof(v)) != hipSuccess) return ~0ull;
+  return v;
+}
 extern "C" int grdma_tx_promise_counts(uint64_t out[4]) {
   unsigned long long v[4] = {0, 0, 0, 0};
   if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_tx_promise), sizeof(v)) != hipSuccess) return -1;

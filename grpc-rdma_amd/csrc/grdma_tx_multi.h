@@ -114,7 +114,6 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
   grdma_conn* c = op.conn;
   grdma_plan* plan = op.plan;
   __shared__ uint32_t s_cnt[TXM_WAVES];
-  __shared__ uint32_t s_last;
 
   // ---- state; what this body takes (as txf_body)
   const uint64_t cap = c->cap, mask = cap - 1, S = c->staging_cap;
@@ -144,6 +143,11 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
   auto take_promise = [&]() {  // (uniform: every thread of every workgroup of the Send comes away with the same head)
     if (!promise_pending) return;
     promise_pending = false;
+    // (once per body, here: every load of the connection's state this workgroup makes has been requested -- they have
+    //  returned, in every wave, before it counts itself in; the committing workgroup waits for all counts, see below)
+    GRDMA_WAIT_LOADS();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(&plan->mw_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const txm_promise promised = wait_promise();
     if (!promised.kept) return;
     const bool first = wg == 0 && tid == 0;
@@ -426,16 +430,24 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
     }
   }
 
-  // ---- arrival: the last workgroup writes totals, wire plan, state, result -- or hands the Send to the general planner
-  __syncthreads();
+  // ---- the LAST workgroup of the Send writes totals, wire plan, state and result -- or hands the Send to the general
+  //      planner; the verdict is the same in every workgroup.  What it writes does not depend on the others' entries
+  //      (everything is at the memory side when the launch ends), but the connection's state must not change under a
+  //      workgroup that has yet to read it: every workgroup has counted itself in once its state loads had returned
+  //      (take_promise), and the last one -- dispatched behind the others -- waits for all the counts.  (Round 6.
+  //      Through round 5 the workgroups counted in HERE, behind their entries: a device-scope round trip at the tail of
+  //      every planner launch; the count now travels while the Send waits for its promise and is priced.)
+  if (wg != nwg - 1) return 0;
   if (tid == 0) {
-    const uint32_t prev = __hip_atomic_fetch_add(&plan->mw_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = prev == nwg - 1;
-    s_last = last ? 1u : 0u;
-    if (last) __hip_atomic_store(&plan->mw_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool all = false;
+    for (uint32_t spins = 0; spins < (1u << 22) && !all; spins++) {
+      all = __hip_atomic_load(&plan->mw_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nwg;
+      if (!all) __builtin_amdgcn_s_sleep(1);
+    }
+    if (!all) atomicAdd(&g_tx_promise[3], 1ull);  // (a wait that runs out: counted with the promise's, a test asserts zero)
+    __hip_atomic_store(&plan->mw_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (!s_last) return 0;
   if (!ok || declined) {  // (uniform, and the same in every workgroup)
     if (tid == 0) {
       atomicAdd(&g_tx_fast_sends[1], 1ull);

@@ -73,6 +73,14 @@ class StreamJob:
         self.lib.grdma_stream_job_set_promised_credit.argtypes = [C.c_void_p, C.c_int]
         check(self.lib.grdma_stream_job_set_promised_credit(self.h, 1 if on else 0))
 
+    def set_fused_wire(self, on=True):
+        """Few links, small rings: the wire of a round inside the planner pair's launch (grdma_stream_job_set_fused_wire)."""
+        check(self.lib.grdma_stream_job_set_fused_wire(self.h, 1 if on else 0))
+
+    def wire_groups(self):
+        """Wire workgroups per link in the planner pair's launch; 0 = the wire is a launch of its own."""
+        return int(self.lib.grdma_stream_job_wire_groups(self.h))
+
     def set_rebuild_index(self, on=True):
         """The slice tables are rewritten between steps: the index the Sends are priced from is rebuilt in every step
         (grdma_stream_job_set_rebuild_index)."""

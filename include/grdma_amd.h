@@ -495,6 +495,13 @@ int grdma_stream_job_set_sends(grdma_stream_job* j, uint32_t sends);
 /* Paired schedule, staged wire: price the Send of round t + 1 with the credit the drain of round t will post (it waits
  * for that drain's plan inside the launch they share) -- no round of credit lag at a ring every round fills. */
 int grdma_stream_job_set_promised_credit(grdma_stream_job* j, int on);
+/* Paired schedule, staged wire, a job of few links with rings of at most 16 MiB: the wire of a round rides in the launch
+ * of the planner pair (wire workgroups of k_plan_pair_mw; the drain's workgroups wait for them before they look at the
+ * ring) instead of a k_copy launch of its own -- two launches per round.  On by default where every workgroup of that
+ * launch has a CU at once (GRDMA_JOB_FUSE_WIRE=0 in the environment: off); the getter says how many wire workgroups per
+ * link the job's graph carries (0: the wire is a launch of its own). */
+int grdma_stream_job_set_fused_wire(grdma_stream_job* j, int on);
+uint32_t grdma_stream_job_wire_groups(grdma_stream_job* j);
 /* The job's slice tables are rewritten between steps (every grpc_endpoint_write brings a new slice buffer,
  * rdma_bp_posix.cc:559-586): the index its Sends are priced from (k_tx_index: prefix sums over the table) is rebuilt
  * in EVERY step's first round instead of once per job.  bench.py times both. */
@@ -517,6 +524,7 @@ int grdma_rx_fast_drains(uint64_t out[6]);  /* drains of streaming jobs taken by
 int grdma_rx_table_cache_stats(uint64_t out[2]);  /* committed drains of the multi-workgroup planner whose read-state tables came out of the connection's table cache [0] / were computed and written back [1] (csrc/grdma_rx_multi.h) */
 int grdma_rx_verdict_counts(uint64_t out[2]);  /* drains of the multi-workgroup planner handed to the general planner with a mixed verdict (some workgroups' probes passed, some declined) [0] / with every workgroup declining [1] */
 int grdma_debug_set_promise_wait(uint32_t v);  /* test knob: v > 0 makes the promised-credit wait of every other Send workgroup run out after v - 1 polls (0 = the default bound for all) */
+uint64_t grdma_wire_wait_runouts(void);  /* fused wire: drain workgroups whose wait for the wire workgroups of their launch ran out (must stay 0) */
 int grdma_tx_promise_counts(uint64_t out[4]);  /* promised-credit Sends: priced with it [0], none in the drain [1], an older block [2]; waits that ran out [3] */
 int grdma_tx_small_ticks(uint64_t out[8]);  /* profiling aid: phase ticks of the latency engine's small Sends */
 /* Scalar ring arithmetic of the host layer (ring_buffer.h:101-143), exported so that the

@@ -48,6 +48,7 @@
 #define amdgpu_waves_per_eu(...)
 // "every vector-memory operation of this wave is acknowledged": host stores are already there
 #define GRDMA_WAIT_VMEM() asm volatile("" ::: "memory")
+#define GRDMA_WAIT_LOADS() asm volatile("" ::: "memory")
 #define GRDMA_WAVE_CONVERGE() emu::exchange(0)
 #define GRDMA_WAVE_LOAD_LINES(base, lane) emu::wave_load_lines(reinterpret_cast<const uint64_t*>(base))
 

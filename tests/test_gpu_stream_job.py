@@ -78,7 +78,7 @@ def _oracle_rounds(R, max_sge, slices, sends=1):
     return delivered, first_rounds, st, ring
 
 
-def _run_job(g, R, max_sge, slices, pipeline, flags=0, mode=None, sends=1, promise=False):
+def _run_job(g, R, max_sge, slices, pipeline, flags=0, mode=None, sends=1, promise=False, fused_wire=None):
     from grpc_rdma_amd import stream as gs
     rng = random.Random(5)
     bufs = [g.DeviceBuffer(data=s, offset=rng.randrange(16)) for s in slices]
@@ -97,6 +97,8 @@ def _run_job(g, R, max_sge, slices, pipeline, flags=0, mode=None, sends=1, promi
         job.set_sends(sends)
     if promise:
         job.set_promised_credit(True)
+    if fused_wire is not None:
+        job.set_fused_wire(fused_wire)
     r = job.run(gs.RUN_EAGER)
     assert r.done and r.bytes_delivered == N and r.bytes_sent == N
     rounds = int(max(r.tx_rounds, r.rx_rounds))  # (tx_rounds counts Sends: an upper bound of the rounds)
@@ -112,7 +114,7 @@ def _run_job(g, R, max_sge, slices, pipeline, flags=0, mode=None, sends=1, promi
     ds = job.delivered_slices(0)
     mem = dst.read(dst_cap)
     got = [mem[o:o + n] for o, n in ds]
-    out = {"slices": got, "rounds": rounds, "ring": rx.ring_mem(), "tx": tx.state(), "rx": rx.state(),
+    out = {"slices": got, "rounds": rounds, "ring": rx.ring_mem(), "tx": tx.state(), "rx": rx.state(), "wire_groups": job.wire_groups(),
            "launches": [int(x) for x in last.launches_class], "ms": [float(x) for x in last.ms_class],
            "rounds_set": 2 * rounds + 4 if pipeline else rounds + 2}
     job.close()
@@ -328,6 +330,41 @@ def test_paired_schedule_with_promised_credit_equals_the_plain_oracle_rounds(gpu
         assert got["tx"][k] == st0[k], k
     for k in ("head", "moving_head", "remain", "internal_read_size"):
         assert got["rx"][k] == st1[k], k
+
+
+@pytest.mark.parametrize("promise", [True, False], ids=["promised", "credit_a_round_late"])
+@pytest.mark.parametrize("case", [(1 << 22, 30, 64, 24, 1 << 20), (1 << 18, 30, 1, 120, 9000), (1 << 24, 4095, 1, 40, 70000)],
+                         ids=["r4m_sge30x64", "r256k_sge30", "r16m_sge4095"])
+def test_the_wire_inside_the_planner_pairs_launch_delivers_what_a_wire_launch_of_its_own_delivers(gpu, case, promise):
+    """Round 6: a paired job of few links with small rings carries the wire of a round in the launch of the planner pair
+    -- wire workgroups in front of the drain's, which wait for them before they look at the ring -- instead of a k_copy
+    launch of its own (grdma_stream_job_set_fused_wire; two launches per round).  Same job with the fused wire and
+    without: the graph has no wire launches in the first case and one per round in the second, no drain's wait ran out,
+    and slices, ring image and state of both are the oracle's (plain rounds with the promised credit; without it the
+    two runs must agree with each other and deliver the stream)."""
+    R, max_sge, sends, n_msgs, msg_len = case
+    slices = _framed_slices(n_msgs, msg_len, seed=R % 89 + sends)
+    lib = gpu.load()
+    ran_out0 = int(lib.grdma_wire_wait_runouts())
+    runs = {}
+    for fw in (True, False):
+        runs[fw] = _run_job(gpu, R, max_sge, slices, pipeline=True, flags=0, sends=sends, promise=promise, fused_wire=fw)
+    assert int(lib.grdma_wire_wait_runouts()) == ran_out0
+    on, off = runs[True], runs[False]
+    assert on["wire_groups"] >= 8 and off["wire_groups"] == 0, (on["wire_groups"], off["wire_groups"])
+    # (launches by class in the last, instrumented-or-graph pass: class 2 is the wire)
+    print("launches by class: fused %s, separate %s" % (on["launches"], off["launches"]))
+    assert b"".join(on["slices"]) == b"".join(slices)
+    for k in ("slices", "ring", "tx", "rx"):
+        assert on[k] == off[k], k
+    if promise:
+        exp, _rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, slices, sends=sends)
+        assert on["slices"] == exp
+        assert on["ring"] == ring == bytes(R)
+        for k in ("remote_tail", "remote_head", "partial_write"):
+            assert on["tx"][k] == st0[k], k
+        for k in ("head", "moving_head", "remain", "internal_read_size"):
+            assert on["rx"][k] == st1[k], k
 
 
 def test_three_links_of_one_job_with_two_sends_per_round_and_promised_credit(gpu):
