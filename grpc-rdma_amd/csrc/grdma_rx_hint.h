@@ -296,51 +296,21 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
       xwg_st64<EWT>(&out_slices[sl].len, (uint64_t)Lm.sl1);
     }
   }
-  const uint64_t t_emit = __builtin_amdgcn_s_memtime();
-
-  // ---- 6. arrival: the last workgroup of the drain commits, or hands the drain to the general planner
-  if (EWT) GRDMA_WAIT_VMEM();  // (my plan entries are at the memory side before I count in)
-  __syncthreads();
-  if (tid == 0) {
-    const uint32_t prev = __hip_atomic_fetch_add(&plan->mw_arrive, 1u + (reason ? 0x10000u : 0u), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = (prev & 0xFFFFu) == nwg - 1;
-    s_last = last ? 1u : 0u;
-    s_any = (prev >> 16) + (reason ? 1u : 0u);
-    if (last) __hip_atomic_store(&plan->mw_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!s_last) return 0;
-  if (s_any) {  // (uniform)
-    if (tid == 0) {
-      atomicAdd(&g_rx_fast_drains[reason ? reason : 3u], 1ull);
-      atomicAdd(&g_rx_verdicts[s_any < nwg ? 0 : 1], 1ull);
-      if (!idle) res->pad0++;
-    }
-    return 2;
-  }
-
-  // history: the encoded sizes of this drain's records become the newest entries (what the period detector of the
-  // general planner looks at when the traffic changes)
-  constexpr int NH = GRDMA_RX_HIST / RXM_THREADS;
-#pragma unroll
-  for (int r = 0; r < NH; r++) {
-    const uint32_t back = tid + r * RXM_THREADS;
-    if (back < V) {
-      const uint32_t i = V - 1 - back;
-      c->rx_hist[(uint32_t)((hc + i) % GRDMA_RX_HIST)] = 16u + ((H.n[i] + 7u) & ~7u);
-    }
-  }
-  // ---- 7. credit (pair.cc:276-284), state, result: thread 0
-  if (tid == 0) {
-    const uint64_t o_total_read = c->total_read, o_credit_msgs = c->credit_msgs;
-    const uint64_t o_rx_records = c->rx_records, o_rx_rounds = c->rx_rounds;
-    const uint32_t o_h1 = c->rx_h1;
-    const uint64_t o_seq = res->seq;
-    grdma_hostline* const line = c->line;
+  // ---- (round 6) the counters the commit adds to and the credit of the drain, by thread 0 of EVERY workgroup while its
+  //      entries are on their way to the memory side (see rxm_body)
+  uint64_t o_total_read = 0, o_credit_msgs = 0, o_rx_records = 0, o_rx_rounds = 0, o_seq = 0;
+  uint32_t o_h1 = 0;
+  grdma_hostline* line = nullptr;
+  uint64_t base = 0, credit = 0, credit_head = 0;
+  bool crossed = false;
+  if (tid == 0 && !reason) {
+    o_total_read = c->total_read; o_credit_msgs = c->credit_msgs;
+    o_rx_records = c->rx_records; o_rx_rounds = c->rx_rounds;
+    o_h1 = c->rx_h1;
+    o_seq = res->seq;
+    line = c->line;
     const uint64_t T = cap64 / 2, Ctot = Lr;
-    uint64_t base = 0, thr = T - irs0, credit = 0, credit_head = 0;
-    bool crossed = false;
+    uint64_t thr = T - irs0;
     while (Ctot >= thr) {
       uint32_t lo = 0, hi = V - 1;  // first record whose running consumption (after its last step) reaches thr
       const uint32_t t32 = (uint32_t)thr;
@@ -367,7 +337,47 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
       crossed = true;
       thr = base + T;
     }
-    if (publish != nullptr) (*publish)(credit, credit_head);
+  }
+  const uint64_t t_emit = __builtin_amdgcn_s_memtime();
+
+  // ---- 6. arrival: the last workgroup of the drain commits, or hands the drain to the general planner
+  if (EWT) GRDMA_WAIT_VMEM();  // (my plan entries are at the memory side before I count in)
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t prev = __hip_atomic_fetch_add(&plan->mw_arrive, 1u + (reason ? 0x10000u : 0u), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = (prev & 0xFFFFu) == nwg - 1;
+    s_last = last ? 1u : 0u;
+    s_any = (prev >> 16) + (reason ? 1u : 0u);
+    if (last) __hip_atomic_store(&plan->mw_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return 0;
+  if (s_any) {  // (uniform)
+    if (tid == 0) {
+      atomicAdd(&g_rx_fast_drains[reason ? reason : 3u], 1ull);
+      atomicAdd(&g_rx_verdicts[s_any < nwg ? 0 : 1], 1ull);
+      if (!idle) res->pad0++;
+    }
+    return 2;
+  }
+  // (the drain is committed as far as its Send is concerned: the promise leaves before the bookkeeping)
+  if (tid == 0 && publish != nullptr) (*publish)(credit, credit_head);
+
+  // history: the encoded sizes of this drain's records become the newest entries (what the period detector of the
+  // general planner looks at when the traffic changes)
+  constexpr int NH = GRDMA_RX_HIST / RXM_THREADS;
+#pragma unroll
+  for (int r = 0; r < NH; r++) {
+    const uint32_t back = tid + r * RXM_THREADS;
+    if (back < V) {
+      const uint32_t i = V - 1 - back;
+      c->rx_hist[(uint32_t)((hc + i) % GRDMA_RX_HIST)] = 16u + ((H.n[i] + 7u) & ~7u);
+    }
+  }
+  // ---- 7. credit (pair.cc:276-284), state, result: thread 0
+  if (tid == 0) {
+    const uint64_t Ctot = Lr;
     const uint64_t irs = crossed ? Ctot - base : irs0 + Ctot;
     const uint64_t nh = (head64 + Lr) & (cap64 - 1);
     if (short_len) {

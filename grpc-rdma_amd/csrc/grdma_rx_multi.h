@@ -639,6 +639,67 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
       xwg_st64<EWT>(&out_slices[sl].len, (uint64_t)L.sl1);
     }
   }
+  // ---- (round 6) what the commit needs and no probe has a part in -- the counters it adds to, and the credit of the
+  //      drain (pair.cc:276-284: a function of the pattern, the read-state tables and internal_read_size) -- by thread 0
+  //      of EVERY workgroup, here, while its entries are on their way to the memory side: through round 5 the one
+  //      workgroup that commits fetched the counters and walked the credit loop behind the arrival, 2 us at the tail of
+  //      every planner launch (profiles/r06_plan_phases.txt: "commit loads", "credit").  Nothing of this is written
+  //      before the last workgroup commits; the counters only ever change there.
+  uint64_t o_total_read = 0, o_credit_msgs = 0, o_rx_records = 0, o_rx_rounds = 0, o_seq = 0;
+  uint32_t o_h1 = 0;
+  grdma_hostline* line = nullptr;
+  uint64_t base = 0, credit = 0, credit_head = 0;
+  bool crossed = false;
+  if (tid == 0 && !reason) {
+    o_total_read = c->total_read; o_credit_msgs = c->credit_msgs;
+    o_rx_records = c->rx_records; o_rx_rounds = c->rx_rounds;
+    o_h1 = c->rx_h1;
+    o_seq = res->seq;
+    line = c->line;
+    auto enc_end = [&](uint32_t i) -> uint64_t {  // ring bytes consumed once record i is finished
+      const uint32_t qi = divP(i), ri = i - qi * P;
+      return (uint64_t)qi * SP + M.pre[ri] + M.pat[ri];
+    };
+    const uint64_t T = cap64 / 2, Ctot = Lr;
+    uint64_t thr = T - irs0;
+    while (Ctot >= thr) {
+      // first record whose running consumption (after its last step) reaches thr: enc_end(i) = E(i + 1) with
+      // E(k) = (k / P) SP + pre[k mod P] (pre[P] = SP), so the period comes from one division and the position from
+      // a search over the pattern's prefix in LDS
+      uint32_t lo;
+      {
+        const uint32_t t32 = (uint32_t)thr;  // (thr <= Ctot < 2^31 here)
+        const uint32_t qk = t32 / SP, r = t32 - qk * SP;
+        uint32_t a = 0, b = P;  // the smallest j in [1, P] with pre[j] >= r (r > 0), or j = 0 (r == 0)
+        if (r == 0) b = 0;
+        while (b - a > 1) {
+          const uint32_t mid = (a + b) >> 1;
+          if (M.pre[mid] >= r) b = mid; else a = mid;
+        }
+        const uint32_t k = qk * P + b;  // smallest k with E(k) >= thr
+        lo = k ? k - 1 : 0;
+        if (lo > V - 1) lo = V - 1;
+      }
+      uint32_t n;
+      const uint32_t s_in = state_of(lo, &n);
+      const rxf_rec rp = rxf_replay(n, s_in);
+      const uint64_t C2 = enc_end(lo);
+      const uint64_t e = 16u + ((n + 7u) & ~7u);
+      const uint64_t cons2 = rp.c2 ? rp.c2 + (((n + 7u) & ~7u) - n + 8u) : 0;
+      const uint64_t C1 = C2 - cons2;
+      const uint64_t pos = (head64 + C2 - e) & (cap64 - 1);
+      if (rp.c2 && C1 >= thr) {  // crossed after the first step of a two-step record
+        credit_head = (pos + 8 + rp.c1) & (cap64 - 1);
+        base = C1;
+      } else {
+        credit_head = (pos + e) & (cap64 - 1);
+        base = C2;
+      }
+      credit++;
+      crossed = true;
+      thr = base + T;
+    }
+  }
   const uint64_t t_emit = __builtin_amdgcn_s_memtime();
 
   // ---- 7. arrival: the last workgroup of the drain commits, or hands the drain to the general planner
@@ -690,6 +751,8 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     }
     return 2;
   }
+  // (the drain is committed as far as its Send is concerned: the promise leaves before the bookkeeping)
+  if (tid == 0 && publish != nullptr) (*publish)(credit, credit_head);
 
   if (tid == 0) atomicAdd(&g_rx_tab_stats[c_hit ? 0 : 1], 1ull);
   // history: the records of this drain become the newest entries (the pattern simply continues)
@@ -703,59 +766,9 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   }
   // ---- 8. credit (pair.cc:276-284), state, result: thread 0 (as rxf_body, per-record values from the tables)
   if (tid == 0) {
-    // (what the commit adds to: one more round trip, ~0.2 us, in the one workgroup that commits)
-    const uint64_t o_total_read = c->total_read, o_credit_msgs = c->credit_msgs;
-    const uint64_t o_rx_records = c->rx_records, o_rx_rounds = c->rx_rounds;
-    const uint32_t o_h1 = c->rx_h1;
-    const uint64_t o_seq = res->seq;
-    grdma_hostline* const line = c->line;
-    const uint64_t t_loaded = __builtin_amdgcn_s_memtime() + (o_seq & 0);  // (behind the loads above)
+    const uint64_t t_loaded = __builtin_amdgcn_s_memtime() + (o_seq & 0);
     const uint32_t tot_n = divP(V) * M.qn[P] + M.qn[V - divP(V) * P];  // payload bytes of the drain
-    auto enc_end = [&](uint32_t i) -> uint64_t {  // ring bytes consumed once record i is finished
-      const uint32_t qi = divP(i), ri = i - qi * P;
-      return (uint64_t)qi * SP + M.pre[ri] + M.pat[ri];
-    };
-    const uint64_t T = cap64 / 2, Ctot = Lr;
-    uint64_t base = 0, thr = T - irs0, credit = 0, credit_head = 0;
-    bool crossed = false;
-    while (Ctot >= thr) {
-      // first record whose running consumption (after its last step) reaches thr: enc_end(i) = E(i + 1) with
-      // E(k) = (k / P) SP + pre[k mod P] (pre[P] = SP), so the period comes from one division and the position from
-      // a search over the pattern's prefix in LDS
-      uint32_t lo;
-      {
-        const uint32_t t32 = (uint32_t)thr;  // (thr <= Ctot < 2^31 here)
-        const uint32_t qk = t32 / SP, r = t32 - qk * SP;
-        uint32_t a = 0, b = P;  // the smallest j in [1, P] with pre[j] >= r (r > 0), or j = 0 (r == 0)
-        if (r == 0) b = 0;
-        while (b - a > 1) {
-          const uint32_t mid = (a + b) >> 1;
-          if (M.pre[mid] >= r) b = mid; else a = mid;
-        }
-        const uint32_t k = qk * P + b;  // smallest k with E(k) >= thr
-        lo = k ? k - 1 : 0;
-        if (lo > V - 1) lo = V - 1;
-      }
-      uint32_t n;
-      const uint32_t s_in = state_of(lo, &n);
-      const rxf_rec rp = rxf_replay(n, s_in);
-      const uint64_t C2 = enc_end(lo);
-      const uint64_t e = 16u + ((n + 7u) & ~7u);
-      const uint64_t cons2 = rp.c2 ? rp.c2 + (((n + 7u) & ~7u) - n + 8u) : 0;
-      const uint64_t C1 = C2 - cons2;
-      const uint64_t pos = (head64 + C2 - e) & (cap64 - 1);
-      if (rp.c2 && C1 >= thr) {  // crossed after the first step of a two-step record
-        credit_head = (pos + 8 + rp.c1) & (cap64 - 1);
-        base = C1;
-      } else {
-        credit_head = (pos + e) & (cap64 - 1);
-        base = C2;
-      }
-      credit++;
-      crossed = true;
-      thr = base + T;
-    }
-    if (publish != nullptr) (*publish)(credit, credit_head);
+    const uint64_t Ctot = Lr;
     const uint64_t t_credit = __builtin_amdgcn_s_memtime();
     const uint64_t irs = crossed ? Ctot - base : irs0 + Ctot;
     const uint64_t nh = (head64 + Lr) & (cap64 - 1);
