@@ -601,7 +601,7 @@ def main():
 
     def measure(ring_kb, steps, warmup, verify, instrument, n_links=1, msgs_per_link=None, payload=None,
                 pipeline=False, max_sge=None, wire_flags=None, wls=None, reps=1, sends=None, promise=False,
-                reindex=False, bidi=False):
+                reindex=False, bidi=False, fused_wire=None):
         """n_links connections with rings of ring_kb KiB: calibrate the number of rounds, capture the graph, time
         `steps` replays.  Then verify, optionally instrument."""
         ring = ring_kb * 1024
@@ -638,6 +638,8 @@ def main():
                 job.set_promised_credit(True)          # the Send priced with the credit the drain in its launch will post
             if reindex:
                 job.set_rebuild_index(True)            # the slice table counts as rewritten: k_tx_index in every step
+            if fused_wire is not None:
+                job.set_fused_wire(fused_wire)         # few links, small rings: the wire inside the planner pair's launch
             r = job.run(gs.RUN_EAGER)                  # calibration: how many rounds are needed
             assert r.done, "calibration pass did not deliver everything (%d/%d bytes)" % (
                 r.bytes_delivered, total_n)
@@ -656,6 +658,7 @@ def main():
             job.set_rounds(rounds)
             r = job.run(gs.RUN_GRAPH)                  # capture + first replay
             assert r.done and r.bytes_delivered == total_n
+            wire_groups = job.wire_groups()
             use_streams = args.launch == "streams"
             launch = lambda: job.launch(use_streams)  # noqa: E731
         for _ in range(warmup):
@@ -676,6 +679,7 @@ def main():
             barrier()
         elapsed = sorted(all_elapsed)[len(all_elapsed) // 2]
         out = {"elapsed": elapsed, "all_elapsed": all_elapsed, "rounds": rounds, "sends": sends, "verified": None, "classes": None,
+               "wire_groups": wire_groups,
                "user_bytes": sum(w.user_bytes for w in wls), "N": total_n,
                "E": sum(w.E for w in wls)}
         if verify:  # correctness of what the timed region produced (untimed)
@@ -1188,21 +1192,28 @@ def main():
         # as ONE cut of the slice table's index by the small planner workgroups, the drain predicted from the sizes they
         # leave; SEQUENTIAL schedule (five launches per round): every round fills the ring, and the paired schedule would
         # see its credit a round late.
-        for key, wf, pl in (("value_ring4096_sge30", None, True), ("value_ring4096_sge30_sequential", None, False),
-                            ("value_ring4096_sge30_wire_direct", 2, False)):
+        for key, wf, pl, fw in (("value_ring4096_sge30", None, True, None), ("value_ring4096_sge30_wire_in_its_own_launch", None, True, False),
+                                ("value_ring4096_sge30_sequential", None, False, None), ("value_ring4096_sge30_wire_direct", 2, False, None)):
             try:
-                # staged wire: the PAIRED schedule (three launches per round) with the promised credit -- the Send of round
-                # t + 1 waits, inside the planner pair's launch, for the drain plan of round t and is priced with the credit
-                # it will post: every round fills the ring, as on the sequential schedule.  Direct wire: sequential (the
-                # gather of round t + 1 writes the ring, it cannot share a launch with the scatter of round t).
-                rk = measure(4096, half, 1, not args.no_verify, False, max_sge=30, pipeline=pl, sends=64, wire_flags=wf, promise=pl)
+                # staged wire: the PAIRED schedule with the promised credit -- the Send of round t + 1 waits, inside the
+                # planner pair's launch, for the drain plan of round t and is priced with the credit it will post: every
+                # round fills the ring, as on the sequential schedule -- and (round 6) with the WIRE of round t in that same
+                # launch: wire workgroups in front of the drain's, which wait for them before they look at the ring; two
+                # launches per round (planner pair + wire; scatter + next gather).  "_wire_in_its_own_launch": the same
+                # with the wire as a k_copy launch (three launches per round, what every job with more links or bigger
+                # rings runs).  Direct wire: sequential (the gather of round t + 1 writes the ring, it cannot share a
+                # launch with the scatter of round t).
+                rk = measure(4096, half, 1, not args.no_verify, False, max_sge=30, pipeline=pl, sends=64, wire_flags=wf, promise=pl,
+                             fused_wire=fw)
                 out[key] = round(wl_leg.user_bytes * half * world / rk["elapsed"] / (1 << 30), 3)
                 out["rounds_per_step_" + key[6:]] = rk["rounds"]
                 if key == "value_ring4096_sge30":
                     out["config"]["ring4096_sge30_leg"] = (
                         "4 MiB ring, max_sge 30 (the reference's defaults); a round = Sends of 30 slices until the ring is full "
                         "(grdma_stream_job_set_sends), priced as one cut of the slice table's index; paired schedule with the "
-                        "promised credit (grdma_stream_job_set_promised_credit), %d rounds" % rk["rounds"])
+                        "promised credit (grdma_stream_job_set_promised_credit), the wire of a round inside the planner pair's "
+                        "launch (%d wire workgroups, grdma_stream_job_wire_groups): two launches per round, %d rounds" % (
+                            rk["wire_groups"], rk["rounds"]))
             except Exception as e:
                 out[key[6:] + "_error"] = err_text(e)
         try:  # (one Send of 30 slices per round, drained at once: what the reference's loop is without rdma_flush's retries)

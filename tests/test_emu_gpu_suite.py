@@ -90,17 +90,19 @@ def test_several_sends_per_plan_and_promised_credit_under_the_emulator(emu_lib):
     every round fills."""
     run_gpu_tests(emu_lib, ["tests/test_gpu_stream_job.py", "-n", "4",
                             "-k", "(two_sends and r16m_small and staged) or (many_sends and r32m_sge30x8 and staged) or "
-                                  "(promised and (r256k_sge30 or r1m_sge64x2))"], 5)
+                                  "(paired_schedule_with_promised and (r256k_sge30 or r1m_sge64x2))"], 5)
 
 
 def test_round6_parity_cases_under_the_emulator(emu_lib):
     """Round 6: one workgroup of the multi-workgroup drain plan declining while its neighbours accept (a record that
     changes payload inside its encoded size: the general planner rewrites the plan in the same launch, the verdict
-    counter shows the mix); the promised-credit hand-over (here the drain's workgroups run first, so the promise is
-    always kept -- the wait that runs out is provoked on the MI355X); BASELINE configs[3] bidirectional on a ring every
-    round fills, every link against the oracle driven with the credit a round late."""
+    counter shows the mix); the promised-credit hand-over through the plan's 64-bit word (here the drain's workgroups run
+    first, so the promise is always kept -- the wait that runs out is provoked by the test's knob); the wire of a round
+    inside the planner pair's launch against the same job with a wire launch of its own, both against the oracle.
+    (BASELINE configs[3] bidirectional, every link against the oracle, takes two minutes here: MI355X only --
+    GRDMA_LIB_PATH=oracle/_build/libgrdma_emu.so python -m pytest tests/test_gpu_stream_job.py -m gpu -k "config3 and pairs2".)"""
     run_gpu_tests(emu_lib, ["tests/test_gpu_stream_job.py", "-n", "4",
-                            "-k", "(one_drain_workgroup and r8m and staged) or (runs_out and r256k) or (config3 and pairs2)"], 3)
+                            "-k", "(one_drain_workgroup and r8m and staged) or (runs_out and r256k) or (wire_inside and r256k)"], 4)
 
 
 def test_concurrent_writer_and_poller_gpu_tests_under_the_emulator(emu_lib):
