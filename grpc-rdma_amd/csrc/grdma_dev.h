@@ -260,7 +260,10 @@ struct grdma_plan {
   // carries the promise itself (bit 2: the drain posts a credit, bits 3..: its head -- a ring offset, < 2^31); = 2: GIVEN
   // UP (csrc/grdma_devfn.h: promise_keep / promise_wait); zero between launches.  Other kernels neither read nor write it.
   uint64_t promise;
-  uint32_t pad_line1[26];
+  // workgroups of the multi-workgroup receive planner, but the committing one, whose entries are at the memory side
+  // (they count out here when they leave; the committer waits for them before it clears the words: drain_close)
+  uint32_t mw_done;
+  uint32_t pad_line1[25];
 };
 static_assert(offsetof(grdma_plan, promise) % 8 == 0, "the hand-over word is a 64-bit atomic");
 

@@ -75,7 +75,7 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
   grdma_plan* plan = op.plan;
   grdma_rx_result* res = op.result;
   __shared__ uint32_t s_w[4][RXM_WAVES];
-  __shared__ uint32_t s_bad, s_first, s_F, s_last, s_any;
+  __shared__ uint32_t s_bad, s_first, s_F;
 
   // ---- 0. state, the table's header, preconditions
   uint8_t* const ring = c->ring;
@@ -264,6 +264,11 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
                    a_end < (1ull << 32)))
     reason = 5;
   const uint64_t t_scan = __builtin_amdgcn_s_memtime();
+  // ---- my verdict is final: counted in (grdma_rx_multi.h: drain_count_in), behind the loads of everything the commit overwrites
+  const bool committer = wg == nwg - 1;
+  GRDMA_WAIT_LOADS();
+  __syncthreads();
+  if (tid == 0) drain_count_in(plan, reason);
 
   // ---- 5. my record: segments, tile prefix, slices (entries beyond any committed count if the drain is declined)
   grdma_slice_out* const out_slices = op.slices + slice_idx0;
@@ -303,7 +308,7 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
   grdma_hostline* line = nullptr;
   uint64_t base = 0, credit = 0, credit_head = 0;
   bool crossed = false;
-  if (tid == 0 && !reason) {
+  if (tid == 0 && !reason && committer) {
     o_total_read = c->total_read; o_credit_msgs = c->credit_msgs;
     o_rx_records = c->rx_records; o_rx_rounds = c->rx_rounds;
     o_h1 = c->rx_h1;
@@ -340,25 +345,24 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
   }
   const uint64_t t_emit = __builtin_amdgcn_s_memtime();
 
-  // ---- 6. arrival: the last workgroup of the drain commits, or hands the drain to the general planner
-  if (EWT) GRDMA_WAIT_VMEM();  // (my plan entries are at the memory side before I count in)
-  __syncthreads();
-  if (tid == 0) {
-    const uint32_t prev = __hip_atomic_fetch_add(&plan->mw_arrive, 1u + (reason ? 0x10000u : 0u), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = (prev & 0xFFFFu) == nwg - 1;
-    s_last = last ? 1u : 0u;
-    s_any = (prev >> 16) + (reason ? 1u : 0u);
-    if (last) __hip_atomic_store(&plan->mw_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- 6. the committer goes on once every verdict is in; the others leave behind their entries' acknowledgement
+  if (!committer) {
+    if (EWT) GRDMA_WAIT_VMEM();
+    __syncthreads();
+    if (tid == 0) drain_leave(plan);
+    return 0;
   }
-  __syncthreads();
-  if (!s_last) return 0;
+  const uint32_t s_any = drain_verdicts(plan, nwg);
   if (s_any) {  // (uniform)
     if (tid == 0) {
       atomicAdd(&g_rx_fast_drains[reason ? reason : 3u], 1ull);
       atomicAdd(&g_rx_verdicts[s_any < nwg ? 0 : 1], 1ull);
       if (!idle) res->pad0++;
     }
+    // (the general planner rewrites entries: everybody's are at the memory side first, mine included)
+    if (EWT) GRDMA_WAIT_VMEM();
+    if (tid == 0) drain_close(plan, nwg);
+    __syncthreads();
     return 2;
   }
   // (the drain is committed as far as its Send is concerned: the promise leaves before the bookkeeping)
@@ -447,6 +451,7 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
     res->dbg[1] = __builtin_amdgcn_s_memtime();
     atomicAdd(&g_rx_fast_drains[0], 1ull);
     __hip_atomic_store(&res->seq, op.seq_next ? op.seq_next : o_seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    drain_close(plan, nwg);
   }
   return 1;
 }

@@ -180,6 +180,48 @@ struct credit_promised {
   }
 };
 
+// ---- (round 6) Who commits a drain, and when.  Through the first half of the round every workgroup counted in behind its
+// entries -- write-through stores acknowledged first, because the general planner may rewrite them in this launch -- and the
+// LAST TO ARRIVE committed: an acknowledgement round trip and a device-scope round trip at the tail of every drain plan.
+// What the count carries is the verdict, and that is final before a workgroup emits anything: it counts in THERE (its
+// loads of the connection block and of the table slot have returned by then -- what the commit will overwrite), and the
+// workgroup dispatched LAST commits once all verdicts are in, which they usually are when it has emitted its own
+// entries.  The acknowledgement moved off the path: a workgroup that is not the committer counts OUT behind it
+// (grdma_plan::mw_done); the committer waits for those counts before it lets the general planner rewrite entries (a
+// declined drain), or else at the very end, before it clears both words for the next launch.  (Under the emulator, which
+// runs the workgroups of a launch in index order, the others are through when the last one starts.)
+__device__ __forceinline__ void drain_count_in(grdma_plan* plan, uint32_t reason) {  // (thread 0, behind a barrier)
+  __hip_atomic_fetch_add(&plan->mw_arrive, 1u + (reason ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void drain_leave(grdma_plan* plan) {  // (thread 0 of a workgroup that does not commit)
+  __hip_atomic_fetch_add(&plan->mw_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the committer, all threads: every verdict is in; returns how many workgroups declined
+__device__ __forceinline__ uint32_t drain_verdicts(grdma_plan* plan, uint32_t nwg) {
+  __shared__ uint32_t s_declined;
+  if (threadIdx.x == 0) {
+    uint32_t v = 0;
+    for (uint32_t spins = 0; spins < (1u << 22); spins++) {
+      v = __hip_atomic_load(&plan->mw_arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((v & 0xFFFFu) >= nwg) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    // (a wait that runs out -- never seen -- declines the drain: the general planner walks what the ring holds)
+    s_declined = (v & 0xFFFFu) >= nwg ? (v >> 16) : nwg;
+  }
+  __syncthreads();
+  return s_declined;
+}
+// the committer, thread 0: the other workgroups' entries are at the memory side; the words are clear for the next launch
+__device__ __forceinline__ void drain_close(grdma_plan* plan, uint32_t nwg) {
+  for (uint32_t spins = 0; spins < (1u << 22); spins++) {
+    if (__hip_atomic_load(&plan->mw_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nwg - 1) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __hip_atomic_store(&plan->mw_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&plan->mw_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Returns 0: not the last workgroup of this drain to arrive (nothing more to do); 1: the last one, the drain is
 // committed; 2: the last one, and a workgroup declined -- the caller runs the general planner; 3: every workgroup alike
 // found the connection without a usable period and the round carries a size table -- the caller runs rxh_body (every
@@ -207,7 +249,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   grdma_plan* plan = op.plan;
   grdma_rx_result* res = op.result;
   __shared__ uint32_t s_w[4][RXM_WAVES];
-  __shared__ uint32_t s_bad, s_vj, s_first, s_F, s_last, s_any, s_miss, s_lb;
+  __shared__ uint32_t s_bad, s_vj, s_first, s_F, s_miss, s_lb;
 
   // ---- 0. state, preconditions (as rxf_body; nothing of the connection is stored before the last workgroup commits)
   uint8_t* const ring = c->ring;
@@ -596,6 +638,11 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
                    a_end < (1ull << 32)))
     reason = 5;
   const uint64_t t_scan = __builtin_amdgcn_s_memtime();
+  // ---- my verdict is final: counted in (drain_count_in, above), behind the loads of everything the commit overwrites
+  const bool committer = wg == nwg - 1;
+  GRDMA_WAIT_LOADS();
+  __syncthreads();
+  if (tid == 0) drain_count_in(plan, reason);
 
   // ---- 6. my record: segments, tile prefix, slices (entries beyond any committed count if the drain is declined)
   grdma_slice_out* const out_slices = op.slices + slice_idx0;
@@ -650,7 +697,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   grdma_hostline* line = nullptr;
   uint64_t base = 0, credit = 0, credit_head = 0;
   bool crossed = false;
-  if (tid == 0 && !reason) {
+  if (tid == 0 && !reason && committer) {
     o_total_read = c->total_read; o_credit_msgs = c->credit_msgs;
     o_rx_records = c->rx_records; o_rx_rounds = c->rx_rounds;
     o_h1 = c->rx_h1;
@@ -702,20 +749,15 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
   }
   const uint64_t t_emit = __builtin_amdgcn_s_memtime();
 
-  // ---- 7. arrival: the last workgroup of the drain commits, or hands the drain to the general planner
-  if (EWT) GRDMA_WAIT_VMEM();  // (my plan entries are at the memory side before I count in)
-  __syncthreads();
-  if (tid == 0) {
-    const uint32_t prev = __hip_atomic_fetch_add(&plan->mw_arrive, 1u + (reason ? 0x10000u : 0u), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = (prev & 0xFFFFu) == nwg - 1;
-    s_last = last ? 1u : 0u;
-    s_any = (prev >> 16) + (reason ? 1u : 0u);
-    if (last) __hip_atomic_store(&plan->mw_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- 7. the committer goes on once every verdict is in; the others leave behind their entries' acknowledgement
+  if (!committer) {
+    if (EWT) GRDMA_WAIT_VMEM();
+    __syncthreads();
+    if (tid == 0) drain_leave(plan);
+    return 0;
   }
-  __syncthreads();
-  if (!s_last) return 0;
-  // (table cache, part 3: the slot is written by the last workgroup to arrive, from the tables it computed itself)
+  const uint32_t s_any = drain_verdicts(plan, nwg);
+  // (table cache, part 3: the slot is written by the committing workgroup, from the tables it computed itself)
   if (c_fresh) {
     uint32_t* const a = c_tab + 4;
 #pragma unroll
@@ -749,6 +791,10 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
       atomicAdd(&g_rx_verdicts[s_any < nwg ? 0 : 1], 1ull);
       if (!idle) res->pad0++;  // (pad1 / pad0: drains of this result block taken / declined with data waiting)
     }
+    // (the general planner rewrites entries: everybody's are at the memory side first, mine included)
+    if (EWT) GRDMA_WAIT_VMEM();
+    if (tid == 0) drain_close(plan, nwg);
+    __syncthreads();
     return 2;
   }
   // (the drain is committed as far as its Send is concerned: the promise leaves before the bookkeeping)
@@ -846,6 +892,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
     res->dbg[1] = __builtin_amdgcn_s_memtime();
     atomicAdd(&g_rx_fast_drains[0], 1ull);
     __hip_atomic_store(&res->seq, op.seq_next ? op.seq_next : o_seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    drain_close(plan, nwg);
   }
   return 1;
 }
