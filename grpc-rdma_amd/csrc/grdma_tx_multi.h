@@ -212,10 +212,14 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
       uint32_t vt[NR];
 #pragma unroll
       for (uint32_t r = 0; r < NR; r++) {
-        const uint64_t k = tid + r * TXM_THREADS, kk = k <= m ? k : m;
-        ve[r] = enc_pre[start + kk];
-        vl[r] = len_pre[start + kk];
-        vt[r] = tile_pre[start + kk];
+        ve[r] = vl[r] = 0;
+        vt[r] = 0;
+        if ((uint64_t)r * TXM_THREADS <= m) {  // (uniform: a short table is one or two rounds of loads, not eight)
+          const uint64_t k = tid + r * TXM_THREADS, kk = k <= m ? k : m;
+          ve[r] = enc_pre[start + kk];
+          vl[r] = len_pre[start + kk];
+          vt[r] = tile_pre[start + kk];
+        }
       }
 #pragma unroll
       for (uint32_t r = 0; r < NR; r++) {
