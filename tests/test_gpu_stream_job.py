@@ -367,6 +367,37 @@ def test_the_wire_inside_the_planner_pairs_launch_delivers_what_a_wire_launch_of
             assert on["rx"][k] == st1[k], k
 
 
+@pytest.mark.parametrize("case", [(1 << 20, 30, 64, 40, 200000), (1 << 22, 30, 64, 14, 1 << 20)], ids=["r1m_sge30x64", "r4m_sge30x64"])
+def test_promised_credit_with_mixed_message_sizes_equals_the_plain_oracle_rounds(gpu, case):
+    """The reference's own test distribution -- message sizes uniform in [1, max] (examples/cpp/test/common.h:4-31) -- at
+    its default max_sge of 30, rounds of up to 64 Sends, paired schedule with the promised credit and (on one link with
+    a small ring) the wire inside the planner pair's launch: what bench.py times as value_mixed_sizes_ring4096_sge30.
+    No period in the record sizes: the drains are predicted from the sizes their own Sends computed (rxh_body) and
+    verified in the ring.  Slices, ring image and state equal the oracle's plain rounds."""
+    R, max_sge, sends, n_msgs, max_len = case
+    rng = random.Random(R % 71 + n_msgs)
+    slices = []
+    for i in range(n_msgs):
+        ln = rng.randrange(1, max_len)
+        body = bytes(rng.getrandbits(8) for _ in range(min(ln, 2048))) * (ln // min(ln, 2048) + 1)
+        wire, lens = pyorc.h2_frame_message(body[:ln], stream_id=2 * i + 1)
+        off = 0
+        for l in lens:
+            slices.append(wire[off:off + l])
+            off += l
+    got = _run_job(gpu, R, max_sge, slices, pipeline=True, flags=0, sends=sends, promise=True)
+    assert got["wire_groups"] > 0
+    exp, _rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, slices, sends=sends)
+    assert b"".join(got["slices"]) == b"".join(slices)
+    assert [len(x) for x in got["slices"]] == [len(x) for x in exp]
+    assert got["slices"] == exp
+    assert got["ring"] == ring == bytes(R)
+    for k in ("remote_tail", "remote_head", "partial_write"):
+        assert got["tx"][k] == st0[k], k
+    for k in ("head", "moving_head", "remain", "internal_read_size"):
+        assert got["rx"][k] == st1[k], k
+
+
 def test_three_links_of_one_job_with_two_sends_per_round_and_promised_credit(gpu):
     """Three connections with different rings and max_sge in ONE job (one op per connection in every launch), two Sends
     per round and the promised credit: every link's slices, ring image and state equal the oracle's plain rounds of that
