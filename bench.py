@@ -875,7 +875,10 @@ def main():
     ring = args.ring_kb * 1024
     small = None
     if args.ring_kb != 4096 and not args.no_small_ring:
-        small = measure(4096, max(2, args.steps // 2), 1, not args.no_verify, False)
+        # (round 6: the paired schedule with the promised credit, and -- one link, a small ring -- the wire in the planner
+        #  pair's launch; the sequential schedule, what this leg ran through round 5, beside it)
+        small = measure(4096, max(2, args.steps // 2), 1, not args.no_verify, False, pipeline=True, sends=1, promise=True)
+        small_seq = measure(4096, max(2, args.steps // 2), 1, False, False)
 
     # algorithmic bytes per step per kernel class:
     alg = {"gather": 2 * wl.N,          # K1: N read + N written (tags E-N by tx_plan)
@@ -1289,6 +1292,11 @@ def main():
         sm_steps = max(2, args.steps // 2)
         out["value_ring4096"] = round(wl_leg.user_bytes * sm_steps * world / small["elapsed"] / (1 << 30), 3)
         out["rounds_per_step_ring4096"] = small["rounds"]
+        out["value_ring4096_sequential"] = round(wl_leg.user_bytes * sm_steps * world / small_seq["elapsed"] / (1 << 30), 3)
+        out["config"]["ring4096_leg"] = ("the headline's connection with a 4 MiB ring (max_sge %d, one Send per round = a ring's worth): paired "
+                                         "schedule with the promised credit, the wire inside the planner pair's launch (%d wire workgroups), "
+                                         "%d rounds; _sequential: five launches per round, what this leg ran through round 5" % (
+                                             args.max_sge, small["wire_groups"], small["rounds"]))
     if args.conns > 1:
         # BASELINE.json configs[3] shape: many connections per GPU, 64 KiB messages, reference-default
         # 4 MiB rings; one op per connection in every launch
@@ -1299,6 +1307,13 @@ def main():
             mc["user_bytes"] * max(2, args.steps // 2) * world / mc["elapsed"] / (1 << 30), 3)
         out["config"]["multi_connection_leg"] = "%d connections x %d x 64 KiB messages per step, 4 MiB rings, %d rounds" % (
             args.conns, per, mc["rounds"])
+        try:  # (the same on the paired schedule: three launches per round instead of five, the credit a round late)
+            mp = measure(4096, max(2, args.steps // 2), 1, not args.no_verify, False, n_links=args.conns,
+                         msgs_per_link=per, payload=64 * 1024, pipeline=True, sends=1)
+            out["value_conns%d_64KiB_ring4096_paired" % args.conns] = round(
+                mp["user_bytes"] * max(2, args.steps // 2) * world / mp["elapsed"] / (1 << 30), 3)
+        except Exception as e:
+            out["conns%d_64KiB_paired_error" % args.conns] = str(e)[:200]
         # ... and as BASELINE.json states it -- BIDIRECTIONAL streaming: the same %d pairs with a link in each direction,
         # every end sender and receiver at once, both directions of every pair in every launch, paired schedule
         try:
