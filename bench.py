@@ -1327,6 +1327,23 @@ def main():
                 "schedule, %d rounds" % (args.conns, per, mb["rounds"]))
         except Exception as e:
             out["conns%d_64KiB_bidi_error" % args.conns] = str(e)[:200]
+        # ... and in the STEADY STATE: the legs above are a ring's worth per link and step -- three rounds that begin at an
+        # empty ring.  512 messages per link (32 MiB through a 4 MiB ring) is what a stream looks like: every round is cut
+        # by the credit; the paired schedule sees it a round late, or -- promised credit (round 6: 64 links x (3 + 3)
+        # planner workgroups no longer have to be resident at once) -- in the launch that plans the drain.
+        try:
+            st_steps = max(2, args.steps // 4)
+            for key, pr in (("steady", True), ("steady_credit_a_round_late", False)):
+                ms_ = measure(4096, st_steps, 1, not args.no_verify, False, n_links=2 * args.conns, msgs_per_link=8 * per,
+                              payload=64 * 1024, pipeline=True, sends=1, bidi=True, promise=pr)
+                out["value_conns%d_64KiB_bidi_%s" % (args.conns, key)] = round(
+                    ms_["user_bytes"] * st_steps * world / ms_["elapsed"] / (1 << 30), 3)
+                out["rounds_per_step_conns%d_64KiB_bidi_%s" % (args.conns, key)] = ms_["rounds"]
+            out["config"]["multi_connection_bidi_steady_leg"] = (
+                "%d pairs x 2 directions x %d x 64 KiB messages per step (both directions counted), 4 MiB rings, paired schedule "
+                "with the promised credit / with the credit a round late" % (args.conns, 8 * per))
+        except Exception as e:
+            out["conns%d_64KiB_bidi_steady_error" % args.conns] = str(e)[:200]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, ring, min(args.max_sge, 4095))
         if not args.no_extra_legs:
