@@ -250,8 +250,9 @@ struct grdma_plan {
   // that line made the early finishers' atomics fight the late starters' loads (2.4x the kernel time).
   uint32_t pad_line0[31];
   uint32_t blocks_done;
-  // arrival word of the multi-workgroup receive planner (grdma_rx_multi.h): workgroups arrived in the low half,
-  // workgroups that declined in the high half; zero between launches (the last workgroup to arrive clears it)
+  // count-in word of the multi-workgroup planners (grdma_rx_multi.h, grdma_tx_multi.h): workgroups counted in in the low
+  // half, workgroups that declined in the high half (drain plan); zero between launches (the committing workgroup --
+  // the one dispatched last -- clears it).  On a WIRE plan: wire workgroups of the planner pair's launch that are done.
   uint32_t mw_arrive;
   uint32_t promise_done;  // participants of the promised-credit hand-over that are through with `promise` (promise_leave)
   uint32_t pad_p;

@@ -222,11 +222,11 @@ __device__ __forceinline__ void drain_close(grdma_plan* plan, uint32_t nwg) {
   __hip_atomic_store(&plan->mw_arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Returns 0: not the last workgroup of this drain to arrive (nothing more to do); 1: the last one, the drain is
-// committed; 2: the last one, and a workgroup declined -- the caller runs the general planner; 3: every workgroup alike
+// Returns 0: not the committing workgroup of this drain (nothing more to do); 1: the committing one, the drain is
+// committed; 2: the committing one, and a workgroup declined -- the caller runs the general planner; 3: every workgroup alike
 // found the connection without a usable period and the round carries a size table -- the caller runs rxh_body (every
 // thread of the workgroup returns the same value).
-// WT: every plan and credit word is stored write-through and acknowledged before a workgroup arrives (grdma_devfn.h:
+// WT: every plan and credit word is stored write-through and acknowledged before a workgroup leaves (grdma_devfn.h:
 // xwg_*), for a plan consumed inside the SAME launch; unused since round 4's fused round was retired -- every kernel
 // passes false, the plan's consumers are later launches.
 // EWT: the entries a workgroup emits for its own records (segments, tile prefix, slices) are stored write-through
@@ -490,7 +490,7 @@ __device__ __forceinline__ int rxm_body(const grdma_rx_op& op_in, const uint32_t
 
   // ---- 4. the steady pattern: read state in front of every position, what every position takes, prefix sums
   // (table cache, part 2: taken from the slot when its key is this drain's pattern)
-  bool c_fresh = false;  // this workgroup computed the tables itself (it writes the slot if it is the last to arrive)
+  bool c_fresh = false;  // this workgroup computed the tables itself (it writes the slot if it is the committing one)
   bool c_hit = false;
   if (!reason) {
     bool mine_ok = c_hdr[3] == GRDMA_RX_TAB_MAGIC && c_hdr[0] == P && c_hdr[1] == ts;

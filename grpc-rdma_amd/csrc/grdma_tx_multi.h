@@ -11,7 +11,7 @@
 // is a search -- 256 samples of the encoded prefix in one round trip, then the <= 16 entries between two samples in a
 // second one.  The record of a direct-wire Send whose payload crosses the ring end comes out of the same two round
 // trips ("starts in front of the ring end" is monotone too).  Then every thread writes the segment of its own record,
-// and the last workgroup to arrive (plan->mw_arrive) writes totals, wire plan, state and result.
+// and the workgroup dispatched last, once all have counted in (plan->mw_arrive), writes totals, wire plan, state and result.
 //
 // Every workgroup reads the credit word (status_recv.remote_head) for itself: inside a job's chain nothing posts a
 // credit while the planner pair runs (the scatter that does is the launch before or the launch behind), which is the
