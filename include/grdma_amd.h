@@ -482,8 +482,9 @@ int grdma_stream_job_slices(grdma_stream_job* j, grdma_read_slice* out, uint64_t
 int grdma_stream_job_set_rounds(grdma_stream_job* j, uint64_t rounds);
 /* on != 0: neighbouring rounds share launches, the way two hosts and a NIC work on different rounds at once: the
  * drain plan of round t with the send plan of round t + 1 (k_plan_pair_mw), the scatter of round t with the
- * gather of round t + 1 (k_rx_apply_gather), the wire in between -- three launches per round, two with a direct
- * wire.  A drain walks exactly up to the tail its own Send reported; the sender may see a
+ * gather of round t + 1 (k_rx_apply_gather), the wire in between -- three launches per round; two with a direct
+ * wire, or with the wire inside the planner pair's launch (grdma_stream_job_set_fused_wire: few links, rings of at
+ * most 16 MiB) (DESIGN.md sections 2.5, 2.9).  A drain walks exactly up to the tail its own Send reported; the sender may see a
  * credit one round later than in the sequential schedule.  Same bytes delivered; affects GRDMA_RUN_GRAPH, _EAGER
  * and _INSTRUMENTED_SCHEDULE. */
 int grdma_stream_job_set_pipeline(grdma_stream_job* j, int on);
