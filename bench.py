@@ -1227,8 +1227,11 @@ def main():
         # mixed message sizes (examples/cpp/test/common.h: uniform in [1, 4 MiB - 1 KiB]), 64 messages per step
         try:
             mw = MixedWorkload(g, 64)
-            # (one Send per round: the size table a Send leaves for its drain holds 4096 records, csrc/grdma_rx_hint.h)
-            mx = measure(args.ring_kb, half, 1, not args.no_verify, False, pipeline=bool(args.pipeline), wls=[mw], sends=1)
+            # (the headline's two Sends per round: the size table a round leaves for its drain holds two Sends' worth, 8192
+            #  records, since round 6 -- csrc/grdma_rx_hint.h; one Send per round, what rounds 4-5 ran, beside it)
+            mx = measure(args.ring_kb, half, 1, not args.no_verify, False, pipeline=bool(args.pipeline), wls=[mw], sends=args.sends)
+            mx1 = measure(args.ring_kb, half, 1, False, False, pipeline=bool(args.pipeline), wls=[mw], sends=1)
+            out["value_mixed_sizes_one_send_per_round"] = round(mw.user_bytes * half * world / mx1["elapsed"] / (1 << 30), 3)
             out["value_mixed_sizes"] = round(mw.user_bytes * half * world / mx["elapsed"] / (1 << 30), 3)
             # at the reference's default knobs: the paired schedule with the promised credit and the wire in the planner
             # pair's launch, as the 1 MiB leg runs (round 6; the sequential schedule, what rounds 4-5 reported, beside it)

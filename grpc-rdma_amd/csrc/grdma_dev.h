@@ -21,6 +21,7 @@
                                     // bulk pass, plus wrap splits)
 #define GRDMA_MAX_SLICES 8192       // delivered slices per receive plan
 #define GRDMA_TX_MAX_RECORDS 4096   // records priced by one send plan
+#define GRDMA_HINT_MAX_RECORDS 8192 // records of a round whose sizes its Sends leave for the drain (grdma_size_hint): two Sends' worth
 #define GRDMA_RX_HIST 1024          // record sizes remembered per connection
 // Behind the history (same allocation): the read-state tables rxm_body derives from a connection's record pattern, kept
 // across drains (grdma_rx_multi.h, "table cache").  GRDMA_RX_TAB_SLOTS slots of [hdr 4][key][sss][qpk][qtl][qby][qn],

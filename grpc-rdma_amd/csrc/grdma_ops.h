@@ -14,7 +14,7 @@ struct grdma_size_hint {
   uint64_t start_off;   // ring offset of the first record (the sender's remote_tail_ in front of the Send)
   uint32_t count;       // records; 0 = no table for this Send
   uint32_t pad;
-  uint32_t n[GRDMA_TX_MAX_RECORDS];
+  uint32_t n[GRDMA_HINT_MAX_RECORDS];
 };
 
 // One PairPollable::Send / rdma_flush step for one connection.

@@ -72,6 +72,7 @@ struct rx_lds_fast {
 union rx_lds {
   rx_lds_general g;
   rx_lds_fast f;
+  uint32_t hint_room[2 * GRDMA_HINT_MAX_RECORDS + 2];  // (rx_lds_hint, grdma_rx_hint.h: the sizes of a round and their prefix)
 };
 __device__ __forceinline__ rx_lds* rx_lds_get() {
   __shared__ rx_lds L;

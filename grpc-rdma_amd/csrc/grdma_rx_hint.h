@@ -25,12 +25,14 @@
 // before it), so that again nothing is exchanged between the workgroups but the arrival word.
 #ifndef GRDMA_RX_HINT_H
 #define GRDMA_RX_HINT_H
+#include <type_traits>
 #include "grdma_rx_multi.h"
 
 namespace {
 
-#define RXH_MAX (RXM_G * RXM_THREADS)  // records per drain
-static_assert(RXH_MAX <= GRDMA_TX_MAX_RECORDS, "the size table of a Send covers a drain");
+#define RXH_HALF (RXM_G * RXM_THREADS)  // records of one Send's worth: the half of the table every drain loads at once
+#define RXH_MAX (2 * RXH_HALF)          // records per drain (round 6: a round of two Sends -- 8190 records of mixed sizes)
+static_assert(RXH_MAX <= GRDMA_HINT_MAX_RECORDS, "the size table of a round covers a drain");
 
 struct rx_lds_hint {
   uint32_t n[RXH_MAX];          // payload sizes
@@ -44,12 +46,12 @@ struct rx_lds_hint {
 // profiles/r06_plan_phases.txt) is in flight with the first.  The sizes are read unclamped -- the table has
 // GRDMA_TX_MAX_RECORDS entries whatever its count says -- and the entries behind the count are zeroed below as before.
 struct rxh_pre {
-  uint32_t nv[RXH_MAX / RXM_THREADS];
+  uint32_t nv[RXH_HALF / RXM_THREADS];
   uint32_t V;
   uint64_t h_start;
 };
 __device__ __forceinline__ void rxh_preload(const grdma_rx_op& op, rxh_pre& p) {
-  constexpr uint32_t PER = RXH_MAX / RXM_THREADS;
+  constexpr uint32_t PER = RXH_HALF / RXM_THREADS;
   const grdma_size_hint* const hint = op.sizes_in;
   p.V = 0;
   p.h_start = ~0ull;
@@ -66,7 +68,7 @@ __device__ __forceinline__ void rxh_preload(const grdma_rx_op& op, rxh_pre& p) {
 template <bool WT = false, bool EWT = WT, class RingWait = ring_ready_now, class Publish = credit_unpublished>  // (see rxm_body)
 __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t wg, const uint32_t nwg, const rxh_pre* pre = nullptr,
                                         RingWait* ring_wait = nullptr, Publish* publish = nullptr) {
-  static_assert(sizeof(rx_lds_hint) <= sizeof(rx_lds) && sizeof(rx_lds_hint) <= RXM_SMALL_LDS_BYTES, "the tables fit their LDS");
+  static_assert(sizeof(rx_lds_hint) <= sizeof(rx_lds) && !WT, "the tables fit the planners' LDS (not the small one of a write-through body)");
   rx_lds_hint& H = *reinterpret_cast<rx_lds_hint*>(rx_tables<WT>());
   const grdma_rx_op op = op_in;
   const uint64_t t_begin = __builtin_amdgcn_s_memtime();
@@ -91,7 +93,14 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
   const uint64_t h_start = pre ? pre->h_start : (hint ? hint->start_off : ~0ull);
   const uint32_t V = pre ? pre->V : (hint ? hint->count : 0);
 
-  bool ok = status == GRDMA_PAIR_CONNECTED && op.raw_cap == 0 && op.append != 0 && !op.inline_apply &&
+  // A round of more than one Send's worth of records (round 6: the table holds two) is what a PERIODIC stream's rounds look
+  // like too -- bench.py's headline: 8190 records, period 390 -- and those belong to rxm_body, which lays them out in a
+  // third of the time; but a connection's period is found by the general planner's search over the record-size history,
+  // and a drain this body takes never gets there.  So: no period yet and a search due (the planner's own back-off,
+  // rx_period_retry_at) -> this body declines a big round, the general planner walks it and searches.  A stream without
+  // a period costs a handful of walked drains, ever rarer; one with a period is rxm_body's from its second drain on.
+  const bool search_due = V > RXH_HALF && c->rx_period == 0 && hc >= c->rx_period_retry_at;
+  bool ok = !search_due && status == GRDMA_PAIR_CONNECTED && op.raw_cap == 0 && op.append != 0 && !op.inline_apply &&
             op.limit_ptr != nullptr && remain0 == 0 && leftover0 <= RXF_MINRD && cap64 <= (1ull << 31) &&
             a_off0 < (1ull << 31) && hint != nullptr && h_start == head64 && V != 0 && V <= nwg * RXM_CHUNK && V <= RXH_MAX;
   uint64_t max_slices = GRDMA_MAX_SLICES;
@@ -112,30 +121,43 @@ __device__ __forceinline__ int rxh_body(const grdma_rx_op& op_in, const uint32_t
   uint32_t reason = (!ok || idle) ? 1u : 0u;
   const uint32_t ts = GRDMA_PLAN_TILE_SHIFT(cap64);
 
-  // ---- 1. the sizes into LDS, their encoded prefix: thread t holds records 16 t .. 16 t + 15
-  constexpr uint32_t PER = RXH_MAX / RXM_THREADS;
+  // ---- 1. the sizes into LDS, their encoded prefix: thread t holds records 16 t .. 16 t + 15 of the table's first half
+  //      (one Send's worth: what every drain loads, requested when the launch began) and, for a round of more than 4096
+  //      records, 4096 + 16 t .. of the second (a second round of loads and a second scan, for those rounds only)
+  constexpr uint32_t PER = RXH_HALF / RXM_THREADS;
   if (!reason) {
-    uint32_t nv[PER];
-    const uint32_t i0 = tid * PER;
-#pragma unroll
-    for (uint32_t r = 0; r < PER; r++) nv[r] = pre ? pre->nv[r] : hint->n[i0 + r < V ? i0 + r : 0];  // (clamped: all loads in flight)
-    uint32_t sum = 0;
     bool bad = false;
+    uint32_t base_x = 0;
+    // (the half as a compile-time constant: the preloaded sizes stay in registers -- indexed through a loop variable
+    //  they went to scratch memory, and a planner kernel with a scratch segment costs every launch 1-2 us)
+    auto load_half = [&](auto HALF) {
+      constexpr uint32_t half = decltype(HALF)::value;
+      uint32_t nv[PER];
+      const uint32_t i0 = half * RXH_HALF + tid * PER;
 #pragma unroll
-    for (uint32_t r = 0; r < PER; r++) {
-      if (i0 + r >= V) nv[r] = 0;
-      else bad |= nv[r] == 0 || nv[r] > cap - (uint32_t)GRDMA_RESERVED;
-      sum += i0 + r < V ? 16u + ((nv[r] + 7u) & ~7u) : 0u;
-    }
-    uint32_t px, d1, d2, d3, tot[4];
-    rxm_scan4(sum, 0, 0, 0, s_w, &px, &d1, &d2, &d3, tot);
+      for (uint32_t r = 0; r < PER; r++)
+        nv[r] = (half == 0 && pre) ? pre->nv[r] : hint->n[i0 + r < V ? i0 + r : 0];  // (clamped: all loads in flight)
+      uint32_t sum = 0;
 #pragma unroll
-    for (uint32_t r = 0; r < PER; r++) {
-      H.n[i0 + r] = nv[r];
-      H.x[i0 + r] = px;
-      px += i0 + r < V ? 16u + ((nv[r] + 7u) & ~7u) : 0u;
-    }
-    if (tid == RXM_THREADS - 1) H.x[RXH_MAX] = px;
+      for (uint32_t r = 0; r < PER; r++) {
+        if (i0 + r >= V) nv[r] = 0;
+        else bad |= nv[r] == 0 || nv[r] > cap - (uint32_t)GRDMA_RESERVED;
+        sum += i0 + r < V ? 16u + ((nv[r] + 7u) & ~7u) : 0u;
+      }
+      uint32_t px, d1, d2, d3, tot[4];
+      rxm_scan4(sum, 0, 0, 0, s_w, &px, &d1, &d2, &d3, tot);
+      px += base_x;
+#pragma unroll
+      for (uint32_t r = 0; r < PER; r++) {
+        H.n[i0 + r] = nv[r];
+        H.x[i0 + r] = px;
+        px += i0 + r < V ? 16u + ((nv[r] + 7u) & ~7u) : 0u;
+      }
+      if (tid == RXM_THREADS - 1) H.x[(half + 1) * RXH_HALF] = px;  // (the end of this half: x[4096], x[8192])
+      base_x += tot[0];
+    };
+    load_half(std::integral_constant<uint32_t, 0>{});
+    if (V > RXH_HALF) load_half(std::integral_constant<uint32_t, 1>{});  // (uniform)
     if (bad) s_bad = 1;
     __syncthreads();
     if (s_bad || H.x[V] != Lr) reason = 2;  // the table does not end where the sender's tail is

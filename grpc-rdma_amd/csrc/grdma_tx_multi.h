@@ -388,7 +388,7 @@ __device__ __forceinline__ int txm_body(const grdma_tx_op& op_in, const grdma_tx
 #pragma unroll
   for (uint32_t k = 0; k < TXM_MAX_SENDS; k++) declined |= Q[k].performed && Q[k].declined;
   const uint64_t nrec_all = declined ? 0 : rec0[TXM_MAX_SENDS];
-  const bool table = op.sizes_out != nullptr && nrec_all <= GRDMA_TX_MAX_RECORDS;  // (the size table holds one Send's worth)
+  const bool table = op.sizes_out != nullptr && nrec_all <= GRDMA_HINT_MAX_RECORDS;  // (the size table holds two Sends' worth)
   const uint64_t t_priced = __builtin_amdgcn_s_memtime();
 
   // ---- my record: its segment and tile-prefix entry (AppendHeader / AppendFooter ride on the segment), as txf_body

@@ -775,10 +775,13 @@ def test_bidirectional_job_both_directions_of_one_pair_in_the_same_launches(gpu,
 # examples/cpp/test/common.h:4-31): the drain of a round is predicted from the sizes its Send computed
 # (csrc/grdma_rx_hint.h), verified record by record in the ring, laid out by sixteen small workgroups ---------------
 @pytest.mark.parametrize("flags", [0, 2], ids=["staged", "direct"])
-@pytest.mark.parametrize("case", [(1 << 25, 1023, 50, 300000, 7), (1 << 24, 640, 300, 9000, 8), (1 << 26, 4095, 40, 1 << 20, 9)],
-                         ids=["r32m_sge1023", "r16m_sge640_small", "r64m_sge4095"])
+@pytest.mark.parametrize("case", [(1 << 25, 1023, 50, 300000, 7, 1), (1 << 24, 640, 300, 9000, 8, 1), (1 << 26, 4095, 40, 1 << 20, 9, 1),
+                                  (1 << 28, 4095, 64, 2 << 20, 10, 2), (1 << 26, 2500, 6000, 900, 11, 2)],
+                         ids=["r32m_sge1023", "r16m_sge640_small", "r64m_sge4095", "r256m_sge4095x2", "r64m_sge2500x2_small"])
 def test_drains_without_a_period_are_predicted_from_the_sends_sizes(gpu, case, flags):
-    R, max_sge, n_msgs, max_len, seed = case
+    """(x2, round 6: rounds of TWO Sends -- up to 8190 records -- the size table holds two Sends' worth and the drain loads
+    its second half when the round has more than 4096 records: what bench.py's value_mixed_sizes runs)"""
+    R, max_sge, n_msgs, max_len, seed, sends = case
     rng = random.Random(seed)
     slices = []
     for i in range(n_msgs):
@@ -789,9 +792,9 @@ def test_drains_without_a_period_are_predicted_from_the_sends_sizes(gpu, case, f
         for ln in lens:
             slices.append(wire[off:off + ln])
             off += ln
-    exp, exp_rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, slices)
+    exp, exp_rounds, (st0, st1), ring = _oracle_rounds(R, max_sge, slices, sends=sends)
     before = _fast_counts(gpu)
-    got = _run_job(gpu, R, max_sge, slices, pipeline=True, flags=flags)
+    got = _run_job(gpu, R, max_sge, slices, pipeline=True, flags=flags, sends=sends)
     after = _fast_counts(gpu)
     assert [len(x) for x in got["slices"]] == [len(x) for x in exp]
     assert got["slices"] == exp
@@ -801,8 +804,12 @@ def test_drains_without_a_period_are_predicted_from_the_sends_sizes(gpu, case, f
     for k in ("head", "moving_head", "remain", "internal_read_size"):
         assert got["rx"][k] == st1[k], k
     took = after[0] - before[0]
+    print("rounds %d, drains taken by a predicting body %d, declined by reason %s" % (exp_rounds, took, [a - b for a, b in zip(after[1:6], before[1:6])]))
     # (the eager first pass runs the sequential kernels, whose steady-state body needs a period: the graph passes count)
-    assert took >= (PASSES - 1) * exp_rounds - 2, "drains taken by a predicting body: %d (declined by reason: %s)" % (
+    # (a round of more than 4096 records on a connection without a period is left to the general planner whenever its
+    #  period search is due -- five times in a row at first, then ever more rarely: csrc/grdma_rx_hint.h, search_due)
+    searches = 5 if sends > 1 else 0
+    assert took >= max(1, (PASSES - 1) * exp_rounds - 2 - searches), "drains taken by a predicting body: %d (declined by reason: %s)" % (
         took, [a - b for a, b in zip(after[1:6], before[1:6])])
 
 
