@@ -99,12 +99,13 @@ def test_round6_parity_cases_under_the_emulator(emu_lib):
     counter shows the mix); the promised-credit hand-over through the plan's 64-bit word (here the drain's workgroups run
     first, so the promise is always kept -- the wait that runs out is provoked by the test's knob); the wire of a round
     inside the planner pair's launch against the same job with a wire launch of its own, both against the oracle; the
-    reference's mixed message sizes at max_sge 30 on that schedule against the oracle's plain rounds.
+    reference's mixed message sizes at max_sge 30 on that schedule against the oracle's plain rounds; rounds of more than
+    4096 records without a period (the second half of the size table, the period search that is due).
     (BASELINE configs[3] bidirectional, every link against the oracle, takes two minutes here: MI355X only --
     GRDMA_LIB_PATH=oracle/_build/libgrdma_emu.so python -m pytest tests/test_gpu_stream_job.py -m gpu -k "config3 and pairs2".)"""
     run_gpu_tests(emu_lib, ["tests/test_gpu_stream_job.py", "-n", "4",
                             "-k", "(one_drain_workgroup and r8m and staged) or (runs_out and r256k) or (wire_inside and r256k) or "
-                                  "mixed_message_sizes"], 6)
+                                  "mixed_message_sizes or (without_a_period and x2_small and staged)"], 7)
 
 
 def test_concurrent_writer_and_poller_gpu_tests_under_the_emulator(emu_lib):
